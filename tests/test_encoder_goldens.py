@@ -1,0 +1,78 @@
+"""Encoder parity: the reference's own encoded graphs reproduced bit-for-bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from blackwater.data.circuit import Circuit, circuit_to_qasm, eval_angle
+from blackwater.data.utils import circuit_to_graph_data_json
+from helpers import G1_GATES_ORDER, g1_graph, infer_gates_order
+
+
+def test_json_goldens_bit_exact(golden_dir, lima_props):
+    entries = json.load(open(os.path.join(golden_dir, "encoder_goldens.json")))
+    assert len(entries) == 30
+    for e in entries:
+        circ = Circuit.from_qasm_str(e["circuit"])
+        want = e["circuit_graph"]
+        props = dict(lima_props)
+        props["gates_set"] = infer_gates_order(circ, want["nodes"]["DAGOpNode"], lima_props["gates_set"])
+        got = circuit_to_graph_data_json(circ, props, use_gate_features=True, use_qubit_features=True)
+        assert got["edges"] == want["edges"]  # indices, order and edge_attr, all four buckets
+        assert got["nodes"]["DAGInNode"] == want["nodes"]["DAGInNode"]
+        assert got["nodes"]["DAGOutNode"] == want["nodes"]["DAGOutNode"]
+        a, b = np.array(got["nodes"]["DAGOpNode"]), np.array(want["nodes"]["DAGOpNode"])
+        assert a.shape == b.shape
+        assert np.array_equal(a[:, 3:], b[:, 3:])
+        # the stored QASM prints angles near k*pi/n symbolically ("pi/20"), losing the last bits
+        assert np.abs(a[:, :3] - b[:, :3]).max() < 1e-9
+        assert circ.depth() == e["circuit_depth"]
+
+
+def test_g1_circuits_bit_exact(g1, lima_props):
+    props = dict(lima_props)
+    props["gates_set"] = G1_GATES_ORDER
+    for i, text in enumerate(g1["qasm"]):
+        x, ei, ea = g1_graph(g1, i)
+        got = circuit_to_graph_data_json(text, props, use_gate_features=True, use_qubit_features=True)
+        wires = got["edges"]["DAGOpNode_wire_DAGOpNode"]
+        assert np.array_equal(np.array(got["nodes"]["DAGOpNode"]), x)
+        assert np.array_equal(np.array(wires["edge_index"]), ei)
+        assert np.array_equal(np.array(wires["edge_attr"]), ea)
+        assert Circuit.from_qasm_str(text).depth() == g1["depth"][i]
+
+
+def test_feature_width_options(lima_props):
+    text = 'OPENQASM 2.0;\ninclude "qelib1.inc";\nqreg q[2];\ncreg c[2];\nx q[1];\ncx q[0],q[1];\nmeasure q -> c;\n'
+    base = circuit_to_graph_data_json(text, lima_props)
+    assert len(base["nodes"]["DAGOpNode"][0]) == 3 + 8
+    full = circuit_to_graph_data_json(text, lima_props, use_gate_features=True, use_qubit_features=True)
+    assert len(full["nodes"]["DAGOpNode"][0]) == 22
+    assert len(full["nodes"]["DAGOpNode"]) == 4  # x, cx, 2 broadcast measures
+    assert full["nodes"]["DAGOpNode"][1][-2:] == [lima_props["gate_props"]["cx_0_1"]["gate_error"],
+                                                  lima_props["gate_props"]["cx_0_1"]["gate_length"]]
+
+
+def test_more_than_three_qubits_rejected(lima_props):
+    text = 'OPENQASM 2.0;\nqreg q[5];\nfoo q[0],q[1],q[2],q[3];\n'
+    props = dict(lima_props, gates_set=lima_props["gates_set"] + ["foo"])
+    with pytest.raises(Exception, match="more than 3 qubits"):
+        circuit_to_graph_data_json(text, props)
+    with pytest.raises(KeyError):  # gate outside the backend vocabulary
+        circuit_to_graph_data_json('OPENQASM 2.0;\nqreg q[1];\nh q[0];\n', lima_props)
+
+
+def test_qasm_reader_roundtrip_and_expressions():
+    assert eval_angle("pi/2") == np.pi / 2
+    assert eval_angle("-3*pi/4") == -3 * np.pi / 4
+    assert eval_angle("2*(pi-1.5)") == 2 * (np.pi - 1.5)
+    text = ('OPENQASM 2.0;\ninclude "qelib1.inc";\ngate ecr q0,q1 { rzx(pi/4) q0,q1; x q0; rzx(-pi/4) q0,q1; }\n'
+            'qreg q[3];\ncreg meas[3];\nrz(0.25) q[0];\necr q[0],q[1]; // comment\nbarrier q;\nmeasure q -> meas;\n')
+    c = Circuit.from_qasm_str(text)
+    assert [o.name for o in c.ops] == ["rz", "ecr", "barrier", "measure", "measure", "measure"]
+    assert c.ops[2].qubits == (0, 1, 2) and c.ops[4].clbits == (1,)
+    again = Circuit.from_qasm_str(circuit_to_qasm(c))
+    assert [(o.name, o.qubits, o.clbits, o.params) for o in again.ops] == \
+           [(o.name, o.qubits, o.clbits, o.params) for o in c.ops]
+    assert c.count_ops() == {"rz": 1, "ecr": 1, "barrier": 1, "measure": 3}
