@@ -1,0 +1,123 @@
+/*
+ * mlqem_hip.h -- C ABI of libmlqem_hip.so, the MI355X (gfx950) implementation of the ml-qem
+ * expectation-value-regressor hot path.
+ *
+ * The reference (qiskit-community/ml-qem) has no FFI of its own: its per-batch arithmetic is delegated to
+ * torch_geometric / torch-sparse (requirements.txt:1-2).  Each entry point below therefore cites the
+ * reference call site whose third-party op it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name starts with h_ (host) ; the caller owns all buffers
+ *   - fp32 data, int32 indices (int64 only where the reference hands over torch.long edge_index)
+ *   - row-major matrices with an explicit leading dimension (elements, not bytes)
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no allocation, no host sync, no global state
+ *   - returns 0 on success, a negative MLQEM_ERR_* code otherwise (bad shape, unsupported width, launch error)
+ *   - re-entrant across streams and threads
+ *
+ * Graph layout.  A batch of graphs is the disjoint union of its members: N nodes, graph g owns the node range
+ * [graph_ptr[g], graph_ptr[g+1]).  Connectivity is held as TWO CSR structures over the edges that are not
+ * self-loops: `in_ptr/in_src` groups edges by destination (forward aggregation), `out_ptr/out_dst` by source
+ * (the transpose, used by the backward pass).  Self-loops are not stored as edges: `loops[i]` is the number of
+ * (i,i) entries the caller's edge list had, and each layer adds the self term it needs analytically.
+ */
+#ifndef MLQEM_HIP_H
+#define MLQEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLQEM_OK 0
+#define MLQEM_ERR_BAD_ARG (-1)
+#define MLQEM_ERR_UNSUPPORTED (-2)
+#define MLQEM_ERR_LAUNCH (-3)
+#define MLQEM_ERR_WORKSPACE (-4)
+
+typedef void* mlqem_stream_t; /* hipStream_t */
+
+int mlqem_abi_version(void);
+const char* mlqem_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Graph structure.  Replaces what PyG derives inside every conv from `edge_index`
+ * (docs/tutorials/gnn.py:104-113 passes the raw [2,E] tensor to TransformerConv / ASAPooling;
+ *  blackwater/data/loaders/exp_val.py:33 AddSelfLoops; PyG gcn_norm / get_laplacian / degree).
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch mlqem_csr_build needs for a graph with N nodes and E edge-list entries. */
+size_t mlqem_csr_build_workspace_bytes(int64_t N, int64_t E);
+
+/* edge_index: [2,E] int64 row-major (row 0 = source, row 1 = destination), self-loops allowed.
+ * Outputs: in_ptr[N+1], in_src[E] (only the first in_ptr[N] entries are meaningful), out_ptr[N+1], out_dst[E],
+ * loops[N].  Inside a row the original edge order is kept (stable).  */
+int mlqem_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* in_ptr, int32_t* in_src,
+                    int32_t* out_ptr, int32_t* out_dst, int32_t* loops, void* workspace, size_t workspace_bytes,
+                    mlqem_stream_t stream);
+
+/* Per-node normalisation scalars of the three Family-A convolutions (docs/tutorials/01_ngem.ipynb cell [9]):
+ *   gcn_dinv[i]  = (indeg[i] + 1)^-1/2                     GCNConv, add_remaining_self_loops, degree by destination
+ *   sage_rinv[i] = 1 / max(indeg[i] + loops[i], 1)         SAGEConv mean over the raw in-edges (self-loops count)
+ *   cheb_dinv[i] = outdeg[i]^-1/2, 0 when outdeg[i] == 0   ChebConv sym normalisation, self-loops removed, degree by source
+ * Any output pointer may be NULL. */
+int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* loops, int64_t N,
+                      float* gcn_dinv, float* sage_rinv, float* cheb_dinv, mlqem_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * CSR aggregation ("scatter-add") -- the roofline kernel.  Replaces the gather x[edge_index[0]] + scatter(...,
+ * reduce='sum'|'mean') inside GCNConv / SAGEConv / ChebConv / LEConv propagate (01_ngem.ipynb cell [9];
+ * docs/tutorials/gnn.py:85,92 via ASAPooling) and, on the transposed CSR, their backward.
+ *
+ *   agg[i,:] = rscale[i] * sum_{e in [ptr[i],ptr[i+1])} cscale[idx[e]] * x[idx[e],:]  +  dself[i] * x[i,:]
+ *   out[i,:] = act( alpha * agg[i,:] + beta * z[i,:] + bias[:] )
+ *
+ * cscale / rscale / dself / z / bias may be NULL (meaning 1 / 1 / 0 / absent / absent).
+ * act: bit 0 = ReLU; drop_p > 0 applies inverted dropout after the ReLU with a counter-based generator keyed by
+ * (seed, element index).  Algorithmic bytes per call: 4(N+1) + 4E + 4N + 4C(E+N)  (SURVEY.md section 8d).
+ * ---------------------------------------------------------------------------------------------------- */
+int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
+                            const float* cscale, const float* rscale, const float* dself, float alpha, float beta,
+                            const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
+                            float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
+
+/* Segment max with the node itself included: out[i,:] = max(x[i,:], max_e x[idx[e],:])
+ * (ASAPooling's scatter(..., reduce='max') after add_remaining_self_loops; docs/tutorials/gnn.py:85,92). */
+int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, float* out,
+                              int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
+
+/* gx = (y > 0) ? g * scale : 0  -- backward of ReLU followed by inverted dropout, recovered from the output y. */
+int mlqem_relu_dropout_bwd_f32(const float* g, const float* y, float scale, float* gx, int64_t n,
+                               mlqem_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Dense layers.  Replace torch.nn.Linear / torch_geometric.nn.Linear (docs/tutorials/gnn.py:94-98 body_seq,
+ * docs/tutorials/mlp.py:18-108 MLP1/2/3, the per-node projections inside every conv).
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* y[n,:] = act( x[n,:] @ W^T + b ),  W: [O,I] row-major as torch stores it (transposed = 0),
+ * or y = x @ W with W: [I,O] (transposed = 1; this is the data-gradient form gx = gy @ W).
+ * accumulate != 0 adds into y instead of overwriting.  act bit 0 = ReLU. */
+int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, float* y,
+                     int64_t ldy, int64_t N, int I, int O, int act, int accumulate, mlqem_stream_t stream);
+
+size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
+
+/* gw[o,i] (+)= sum_n gy[n,o] * x[n,i] ;  gb[o] (+)= sum_n gy[n,o]  (gb may be NULL).  Two-stage, deterministic. */
+int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
+                           int64_t N, int I, int O, int accumulate, void* workspace, size_t workspace_bytes,
+                           mlqem_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Pooling over graphs.  Replaces global_mean_pool (docs/tutorials/gnn.py:114; 01_ngem.ipynb cell [9]).
+ * ---------------------------------------------------------------------------------------------------- */
+int mlqem_segment_mean_f32(const float* x, int64_t ldx, const int32_t* graph_ptr, float* out, int64_t ldo,
+                           int64_t B, int C, mlqem_stream_t stream);
+int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph_ptr, float* gx, int64_t ldgx,
+                               int64_t B, int C, mlqem_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLQEM_HIP_H */

@@ -1,0 +1,69 @@
+"""Loads ``libmlqem_hip.so`` (the C ABI of include/mlqem_hip.h) through ctypes.
+
+There is deliberately no fallback: if the library is missing or a call returns an error code this raises.
+PyTorch appears only as the owner of device memory and streams -- every argument that crosses the boundary is
+a raw device pointer, a size or a stream handle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmlqem_hip.so"))
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_P, _I, _L, _F, _S, _U = c_void_p, c_int, c_int64, c_float, c_size_t, c_uint64
+
+# name -> (restype, argtypes); kept in the order of include/mlqem_hip.h
+SIGNATURES = {
+    "mlqem_abi_version": (_I, []),
+    "mlqem_error_string": (c_char_p, [_I]),
+    "mlqem_csr_build_workspace_bytes": (_S, [_L, _L]),
+    "mlqem_csr_build": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "mlqem_graph_norms": (_I, [_P, _P, _P, _L, _P, _P, _P, _P]),
+    "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
+                                  _P, _L, _P, _P, _P, _P, _P, _P, _P]),
+    "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _L, _L, _I, _P]),
+    "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _P]),
+    "mlqem_relu_dropout_bwd_f32": (_I, [_P, _P, _F, _P, _L, _P]),
+    "mlqem_linear_f32": (_I, [_P, _L, _P, _I, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
+    "mlqem_linear_wgrad_workspace_bytes": (_S, [_I, _I]),
+    "mlqem_linear_wgrad_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P]),
+    "mlqem_segment_mean_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P]),
+    "mlqem_segment_mean_bwd_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Returns the loaded library, loading it on first use."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype, fn.argtypes = restype, argtypes
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().mlqem_error_string(code).decode()
+        raise NativeLibraryError(f"{what} failed with code {code}: {msg}")

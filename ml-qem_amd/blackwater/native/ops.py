@@ -1,0 +1,176 @@
+"""Thin typed wrappers over the C ABI (no autograd here): tensors in, raw pointers out.
+
+Every function asserts what the kernel assumes (device, dtype, row-major with unit column stride, sizes
+matching the CSR arrays) BEFORE launching -- a kernel that reads out of bounds can take the whole node down.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    """Checks a 2-D row-major device matrix and returns its leading dimension."""
+    if not t.is_cuda:
+        raise _lib.NativeLibraryError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype or t.dim() != 2:
+        raise ValueError(f"{name}: want 2-D {dtype}, got {t.dim()}-D {t.dtype}")
+    if t.shape[0] > 1 and t.shape[1] > 0 and t.stride(1) != 1:
+        raise ValueError(f"{name}: columns must be contiguous (stride {t.stride()})")
+    return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
+
+
+def _vec(t: Optional[torch.Tensor], name: str, n: int, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or t.dim() != 1 or t.shape[0] < n or (t.numel() > 1 and t.stride(0) != 1):
+        raise ValueError(f"{name}: want contiguous 1-D {dtype} cuda tensor with >= {n} entries, got "
+                         f"{tuple(t.shape)} {t.dtype} {t.device}")
+
+
+def csr_aggregate(x, ptr, idx, *, cscale=None, rscale=None, dself=None, alpha=1.0, z=None, beta=0.0, bias=None,
+                  relu=False, drop_p=0.0, seed=0, out=None):
+    """out = act(alpha * (rscale * sum_e cscale[idx[e]] x[idx[e]] + dself * x) + beta * z + bias)."""
+    n, c = x.shape
+    ldx = _mat(x, "x")
+    _vec(ptr, "ptr", n + 1, torch.int32)
+    _vec(idx, "idx", 0, torch.int32)
+    for nm, v in (("cscale", cscale), ("rscale", rscale), ("dself", dself)):
+        _vec(v, nm, n)
+    _vec(bias, "bias", c)
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    ldo = _mat(out, "out")
+    ldz = 0
+    if z is not None:
+        if z.shape != x.shape:
+            raise ValueError("z must have the shape of x")
+        ldz = _mat(z, "z")
+    code = _lib.load().mlqem_csr_aggregate_f32(
+        _p(x), ldx, _p(ptr), _p(idx), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
+        _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), ldo, n, c, _stream())
+    _lib.check(code, "mlqem_csr_aggregate_f32")
+    return out
+
+
+def csr_segment_max(x, ptr, idx, out=None):
+    n, c = x.shape
+    ldx = _mat(x, "x")
+    _vec(ptr, "ptr", n + 1, torch.int32)
+    _vec(idx, "idx", 0, torch.int32)
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    code = _lib.load().mlqem_csr_segment_max_f32(_p(x), ldx, _p(ptr), _p(idx), _p(out), _mat(out, "out"), n, c, _stream())
+    _lib.check(code, "mlqem_csr_segment_max_f32")
+    return out
+
+
+def relu_dropout_bwd(g, y, scale=1.0):
+    g = g.contiguous()
+    if g.shape != y.shape or not y.is_contiguous() or not g.is_cuda or g.dtype != torch.float32:
+        raise ValueError("relu_dropout_bwd: g and y must be contiguous fp32 cuda tensors of one shape")
+    gx = torch.empty_like(g)
+    code = _lib.load().mlqem_relu_dropout_bwd_f32(_p(g), _p(y), float(scale), _p(gx), g.numel(), _stream())
+    _lib.check(code, "mlqem_relu_dropout_bwd_f32")
+    return gx
+
+
+def linear(x, w, b=None, *, transposed=False, relu=False, out=None, accumulate=False):
+    """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O])."""
+    n, i = x.shape
+    ldx = _mat(x, "x")
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
+        raise ValueError("w must be a contiguous 2-D fp32 cuda tensor")
+    o = w.shape[1] if transposed else w.shape[0]
+    if (w.shape[0] if transposed else w.shape[1]) != i:
+        raise ValueError(f"linear: x has {i} columns, w is {tuple(w.shape)} (transposed={transposed})")
+    _vec(b, "b", o)
+    if out is None:
+        out = torch.empty((n, o), dtype=torch.float32, device=x.device)
+    elif out.shape != (n, o):
+        raise ValueError("linear: bad out shape")
+    code = _lib.load().mlqem_linear_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(out), _mat(out, "out"),
+                                        n, i, o, 1 if relu else 0, 1 if accumulate else 0, _stream())
+    _lib.check(code, "mlqem_linear_f32")
+    return out
+
+
+_wgrad_ws = {}
+
+
+def linear_wgrad(gy, x, gw, gb=None, accumulate=False):
+    """gw (+)= gy.T @ x ; gb (+)= gy.sum(0)."""
+    n, o = gy.shape
+    i = x.shape[1]
+    if x.shape[0] != n or gw.shape != (o, i) or not gw.is_contiguous() or gw.dtype != torch.float32:
+        raise ValueError("linear_wgrad: shape mismatch")
+    _vec(gb, "gb", o)
+    lib = _lib.load()
+    need = lib.mlqem_linear_wgrad_workspace_bytes(i, o)
+    key = (gy.device, need)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=gy.device)
+    code = lib.mlqem_linear_wgrad_f32(_p(gy), _mat(gy, "gy"), _p(x), _mat(x, "x"), _p(gw), _p(gb), n, i, o,
+                                      1 if accumulate else 0, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_linear_wgrad_f32")
+
+
+def segment_mean(x, graph_ptr, num_graphs):
+    c = x.shape[1]
+    _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
+    out = torch.empty((num_graphs, c), dtype=torch.float32, device=x.device)
+    code = _lib.load().mlqem_segment_mean_f32(_p(x), _mat(x, "x"), _p(graph_ptr), _p(out), _mat(out, "out"),
+                                              num_graphs, c, _stream())
+    _lib.check(code, "mlqem_segment_mean_f32")
+    return out
+
+
+def segment_mean_bwd(g, graph_ptr, num_nodes):
+    b, c = g.shape
+    _vec(graph_ptr, "graph_ptr", b + 1, torch.int32)
+    gx = torch.empty((num_nodes, c), dtype=torch.float32, device=g.device)
+    code = _lib.load().mlqem_segment_mean_bwd_f32(_p(g), _mat(g, "g"), _p(graph_ptr), _p(gx), _mat(gx, "gx"), b, c,
+                                                  _stream())
+    _lib.check(code, "mlqem_segment_mean_bwd_f32")
+    return gx
+
+
+def csr_build(edge_index: torch.Tensor, num_nodes: int):
+    """[2,E] int64 cuda edge list -> (in_ptr, in_src, out_ptr, out_dst, loops), all int32."""
+    if not edge_index.is_cuda or edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index must be a [2,E] int64 cuda tensor")
+    edge_index = edge_index.contiguous()
+    e = int(edge_index.shape[1])
+    dev = edge_index.device
+    lib = _lib.load()
+    mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    in_ptr, out_ptr, loops = mk(num_nodes + 1), mk(num_nodes + 1), mk(num_nodes)
+    in_src, out_dst = mk(e), mk(e)
+    need = lib.mlqem_csr_build_workspace_bytes(num_nodes, e)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    code = lib.mlqem_csr_build(_p(edge_index), e, num_nodes, _p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst),
+                               _p(loops), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_csr_build")
+    return in_ptr, in_src, out_ptr, out_dst, loops
+
+
+def graph_norms(in_ptr, out_ptr, loops, num_nodes):
+    dev = in_ptr.device
+    mk = lambda: torch.empty(max(num_nodes, 1), dtype=torch.float32, device=dev)
+    gcn, sage, cheb = mk(), mk(), mk()
+    code = _lib.load().mlqem_graph_norms(_p(in_ptr), _p(out_ptr), _p(loops), num_nodes, _p(gcn), _p(sage), _p(cheb),
+                                         _stream())
+    _lib.check(code, "mlqem_graph_norms")
+    return gcn, sage, cheb

@@ -1,0 +1,77 @@
+"""Device-resident connectivity of one batch of graphs, in the layout the kernels consume.
+
+``GraphStructure`` is what a conv needs instead of PyG's raw ``edge_index``: CSR by destination (forward),
+CSR by source (backward), self-loop counts, graph boundaries, and the per-node normalisation scalars.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class GraphStructure:
+    def __init__(self, num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs, num_edges=None,
+                 norms=None):
+        self.num_nodes = int(num_nodes)
+        self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops = in_ptr, in_src, out_ptr, out_dst, loops
+        self.graph_ptr, self.num_graphs = graph_ptr, int(num_graphs)
+        self.num_edges = num_edges  # non-self-loop edges, host int when known without a sync
+        self._norms = norms
+        self._derived = {}
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def from_edge_index(edge_index: torch.Tensor, num_nodes: int, batch: Optional[torch.Tensor] = None,
+                        num_graphs: Optional[int] = None, graph_ptr: Optional[torch.Tensor] = None) -> "GraphStructure":
+        """Builds the structure on the device from a [2,E] int64 edge list (the reference's model protocol)."""
+        in_ptr, in_src, out_ptr, out_dst, loops = ops.csr_build(edge_index, num_nodes)
+        dev = edge_index.device
+        if graph_ptr is None:
+            if batch is None:
+                graph_ptr = torch.tensor([0, num_nodes], dtype=torch.int32, device=dev)
+                num_graphs = 1
+            else:
+                if num_graphs is None:
+                    raise ValueError("num_graphs is required with `batch` (avoids a device sync)")
+                counts = torch.bincount(batch, minlength=num_graphs)
+                graph_ptr = torch.zeros(num_graphs + 1, dtype=torch.int32, device=dev)
+                graph_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        else:
+            graph_ptr = graph_ptr.to(device=dev, dtype=torch.int32)
+            num_graphs = graph_ptr.numel() - 1
+        return GraphStructure(num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs)
+
+    # ------------------------------------------------------------------------------------------------
+    def _base_norms(self):
+        if self._norms is None:
+            self._norms = ops.graph_norms(self.in_ptr, self.out_ptr, self.loops, self.num_nodes)
+        return self._norms
+
+    @property
+    def gcn_dinv(self):
+        return self._base_norms()[0]
+
+    @property
+    def sage_rinv(self):
+        return self._base_norms()[1]
+
+    @property
+    def cheb_dinv(self):
+        return self._base_norms()[2]
+
+    def derived(self, key):
+        """Per-node scalars derived from the base norms, cached per structure (tiny elementwise torch ops)."""
+        if key not in self._derived:
+            if key == "gcn_dself":      # weight of the (i,i) term of D^-1/2 (A+I) D^-1/2
+                v = self.gcn_dinv * self.gcn_dinv
+            elif key == "sage_dself":   # self-loops of the raw edge list take part in the mean
+                v = self.loops.to(torch.float32) * self.sage_rinv
+            elif key == "cheb_neg":     # row factor of L^ = -D^-1/2 A D^-1/2
+                v = -self.cheb_dinv
+            else:
+                raise KeyError(key)
+            self._derived[key] = v
+        return self._derived[key]

@@ -1,0 +1,80 @@
+"""The reference's model families as modules over the native kernels.
+
+All models keep the reference's six-positional-argument protocol
+``model(exp_value, observable, circuit_depth, nodes, edge_index, batch)`` (pinned by
+tests/library/ngem/test_estimator.py:24 in the reference).  ``edge_index`` may be the reference's [2,E] int64
+tensor (the structure is then built on the device on the fly) or a prebuilt :class:`GraphStructure`
+(what the device-resident dataset hands out, so nothing is rebuilt per step).
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import torch
+from torch import nn
+
+from ..native import functional as F
+from ..native.structure import GraphStructure
+from .conv import ChebConv, GCNConv, SAGEConv, _kaiming_linear, _WeightOnly
+
+
+def as_structure(edge_index: Union[torch.Tensor, GraphStructure], num_nodes: int, batch: Optional[torch.Tensor],
+                 num_graphs: int) -> GraphStructure:
+    if isinstance(edge_index, GraphStructure):
+        return edge_index
+    return GraphStructure.from_edge_index(edge_index, num_nodes, batch=batch, num_graphs=num_graphs)
+
+
+class _Seq(nn.Module):
+    """Two Linear layers at indices 0 and 2 (index 1 is the reference's Dropout), PyG/torch key names."""
+
+    def __init__(self, sizes, dropout=None, second_index=2):
+        super().__init__()
+        w, b = _kaiming_linear(sizes[1], sizes[0])
+        self.add_module("0", _WeightOnly(w, b))
+        w, b = _kaiming_linear(sizes[2], sizes[1])
+        self.add_module(str(second_index), _WeightOnly(w, b))
+        self._second, self.p = str(second_index), dropout
+
+    def forward(self, x):
+        first, second = getattr(self, "0"), getattr(self, self._second)
+        h = F.linear(x, first.weight, first.bias)
+        if self.p and self.training:
+            h = nn.functional.dropout(h, self.p, True)
+        return F.linear(h, second.weight, second.bias)
+
+
+class ExpValCircuitGraphModelA(nn.Module):
+    """Family A: GCNx3 || Chebx2 || SAGEx2 -> mean pools; observable MLP; 6-wide body
+    (reference: docs/tutorials/01_ngem.ipynb cell [9], constructed with n_qubits=5, 22 features, hidden 10)."""
+
+    def __init__(self, n_qubits: int, num_node_features: int, hidden_channels: int):
+        super().__init__()
+        hc = hidden_channels
+        self.conv1, self.conv2, self.conv3 = GCNConv(num_node_features, hc), GCNConv(hc, hc), GCNConv(hc, 1)
+        self.cheb_conv1, self.cheb_conv2 = ChebConv(num_node_features, hc, K=3), ChebConv(hc, 1, K=2)
+        self.sage_conv1, self.sage_conv2 = SAGEConv(num_node_features, hc), SAGEConv(hc, 1)
+        self.obs_seq = _Seq([n_qubits * 4 + 1, hc, 1], dropout=0.2)
+        self.body_seq = _Seq([6, hc, 1], second_index=1)
+        self._step = 0
+
+    def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
+        b = exp_value.shape[0]
+        s = as_structure(edge_index, nodes.shape[0], batch, b)
+        train = self.training
+        self._step += 1
+        seed = self._step * 7919
+        g = self.conv1(nodes, s, relu=True, drop_p=0.1 if train else 0.0, seed=seed + 1)
+        g = self.conv2(g, s, relu=True, drop_p=0.1 if train else 0.0, seed=seed + 2)
+        g = F.segment_mean(self.conv3(g, s), s)
+        c = torch.relu(self.cheb_conv1(nodes, s))
+        if train:
+            c = nn.functional.dropout(c, 0.2, True)
+        c = F.segment_mean(self.cheb_conv2(c, s), s)
+        sg = torch.relu(self.sage_conv1(nodes, s))
+        if train:
+            sg = nn.functional.dropout(sg, 0.2, True)
+        sg = F.segment_mean(self.sage_conv2(sg, s), s)
+        obs = torch.mean(self.obs_seq(observable), dim=1)
+        merged = torch.cat((g, c, sg, obs, circuit_depth, exp_value), dim=1)
+        return self.body_seq(merged)

@@ -1,0 +1,71 @@
+// Shared device/host helpers for libmlqem_hip.so (gfx950 only: 64-lane wavefronts, 8 XCDs, 256 CUs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/mlqem_hip.h"
+
+namespace mlqem {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;   // 4 waves: one per SIMD of a CU
+constexpr int kXcds = 8;
+
+inline hipStream_t as_stream(mlqem_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? MLQEM_OK : MLQEM_ERR_LAUNCH;
+}
+
+__host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Kernels that walk a
+// row range want each XCD to own one CONTIGUOUS slice of it, so that the window of source rows a tile
+// gathers from is already in that XCD's L2.  This is the bijective remap for any grid size.
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned nb) {
+  const unsigned q = nb / kXcds, r = nb % kXcds;
+  const unsigned xcd = b % kXcds, k = b / kXcds;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+// Counter-based uniform in [0,1): one splitmix64 round over (seed, element index).
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+template <int V> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int V> __device__ __forceinline__ void vload(const float* p, float (&r)[V]) {
+  if constexpr (V == 1) {
+    r[0] = *p;
+  } else if constexpr (V == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    r[0] = t.x; r[1] = t.y;
+  } else {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  }
+}
+template <int V> __device__ __forceinline__ void vstore(float* p, const float (&r)[V]) {
+  if constexpr (V == 1) {
+    *p = r[0];
+  } else if constexpr (V == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]);
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace mlqem

@@ -1,0 +1,219 @@
+// Graph-structure preparation: COO edge list -> the two CSR structures + self-loop counts, the per-node
+// normalisation scalars of the convolutions, and on-device batch assembly from a resident dataset arena.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+
+namespace mlqem {
+
+__global__ __launch_bounds__(kBlock) void split_edges_kernel(const int64_t* __restrict__ ei, int64_t E, int32_t N,
+                                                             int32_t* __restrict__ key_d, int32_t* __restrict__ val_s,
+                                                             int32_t* __restrict__ key_s, int32_t* __restrict__ val_d,
+                                                             int32_t* __restrict__ loops) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const int32_t s = (int32_t)ei[e], d = (int32_t)ei[E + e];
+  const bool loop = s == d;
+  if (loop) atomicAdd(&loops[s], 1);
+  // self-loops sort behind every real row (key N) and fall outside ptr[N]
+  key_d[e] = loop ? N : d;
+  key_s[e] = loop ? N : s;
+  val_s[e] = s;
+  val_d[e] = d;
+}
+
+// ptr[i] = first position whose sorted key is >= i  (i = 0..N)
+__global__ __launch_bounds__(kBlock) void lower_bound_kernel(const int32_t* __restrict__ sorted, int64_t E, int64_t N,
+                                                             int32_t* __restrict__ ptr) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i > N) return;
+  int64_t lo = 0, hi = E;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted[mid] < (int32_t)i) lo = mid + 1; else hi = mid;
+  }
+  ptr[i] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(kBlock) void graph_norms_kernel(const int32_t* __restrict__ in_ptr,
+                                                             const int32_t* __restrict__ out_ptr,
+                                                             const int32_t* __restrict__ loops, int64_t N,
+                                                             float* __restrict__ gcn_dinv, float* __restrict__ sage_rinv,
+                                                             float* __restrict__ cheb_dinv) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const int indeg = in_ptr[i + 1] - in_ptr[i];
+  if (gcn_dinv) gcn_dinv[i] = 1.0f / sqrtf((float)(indeg + 1));
+  if (sage_rinv) {
+    const int cnt = indeg + (loops ? loops[i] : 0);
+    sage_rinv[i] = 1.0f / (float)(cnt > 0 ? cnt : 1);
+  }
+  if (cheb_dinv) {
+    const int outdeg = out_ptr[i + 1] - out_ptr[i];
+    cheb_dinv[i] = outdeg > 0 ? 1.0f / sqrtf((float)outdeg) : 0.f;
+  }
+}
+
+struct SortPlan {
+  size_t keys_bytes, temp_bytes;
+  int end_bit;
+};
+
+static SortPlan plan_sort(int64_t N, int64_t E) {
+  SortPlan p{};
+  p.keys_bytes = ((size_t)E * sizeof(int32_t) + 255) / 256 * 256;
+  int bits = 1;
+  while ((1ll << bits) <= N) ++bits;  // keys are in [0, N]
+  p.end_bit = bits;
+  size_t temp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, temp, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                  (int32_t*)nullptr, (size_t)E, 0, (unsigned)bits, (hipStream_t)0);
+  p.temp_bytes = (temp + 255) / 256 * 256;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------- batch assembly
+struct AssembleArgs {
+  const float* x; int64_t ldx; int F;
+  const float* nscal; int K;
+  const int32_t* a_gptr; const int32_t* a_in_ptr; const int32_t* a_in_src;
+  const int32_t* a_out_ptr; const int32_t* a_out_dst; const int32_t* a_loops;
+  const int32_t* sel; const int32_t* b_nptr; const int32_t* b_eptr;
+  int B; int64_t Nb; int64_t Eb;
+  float* xb; int64_t ldxb; float* nscal_b;
+  int32_t* in_ptr_b; int32_t* in_src_b; int32_t* out_ptr_b; int32_t* out_dst_b; int32_t* loops_b;
+};
+
+__device__ __forceinline__ int find_segment(const int32_t* __restrict__ ptr, int n_seg, int32_t v) {
+  int lo = 0, hi = n_seg;  // largest b with ptr[b] <= v
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// rows of x (and of the packed per-node scalars): flattened (node, column) so loads and stores stay coalesced
+__global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArgs a) {
+  const int W = a.F + a.K;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.Nb * W) return;
+  const int32_t i = (int32_t)(t / W);
+  const int c = (int)(t - (int64_t)i * W);
+  const int b = find_segment(a.b_nptr, a.B, i);
+  const int64_t gn = (int64_t)a.a_gptr[a.sel[b]] + (i - a.b_nptr[b]);
+  if (c < a.F) a.xb[(int64_t)i * a.ldxb + c] = a.x[gn * a.ldx + c];
+  else a.nscal_b[(int64_t)i * a.K + (c - a.F)] = a.nscal[gn * a.K + (c - a.F)];
+}
+
+__global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i > a.Nb) return;
+  if (i == a.Nb) {
+    a.in_ptr_b[i] = (int32_t)a.Eb;
+    a.out_ptr_b[i] = (int32_t)a.Eb;
+    return;
+  }
+  const int b = find_segment(a.b_nptr, a.B, (int32_t)i);
+  const int32_t g0 = a.a_gptr[a.sel[b]];
+  const int64_t gn = (int64_t)g0 + (i - a.b_nptr[b]);
+  a.in_ptr_b[i] = a.a_in_ptr[gn] - a.a_in_ptr[g0] + a.b_eptr[b];
+  a.out_ptr_b[i] = a.a_out_ptr[gn] - a.a_out_ptr[g0] + a.b_eptr[b];
+  if (a.loops_b) a.loops_b[i] = a.a_loops[gn];
+}
+
+__global__ __launch_bounds__(kBlock) void assemble_edges_kernel(const AssembleArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= a.Eb) return;
+  const int b = find_segment(a.b_eptr, a.B, (int32_t)e);
+  const int32_t g0 = a.a_gptr[a.sel[b]];
+  const int32_t shift = a.b_nptr[b] - g0;
+  const int64_t le = e - a.b_eptr[b];
+  a.in_src_b[e] = a.a_in_src[a.a_in_ptr[g0] + le] + shift;
+  a.out_dst_b[e] = a.a_out_dst[a.a_out_ptr[g0] + le] + shift;
+}
+
+}  // namespace mlqem
+
+using namespace mlqem;
+
+extern "C" size_t mlqem_csr_build_workspace_bytes(int64_t N, int64_t E) {
+  if (N < 0 || E < 0) return 0;
+  const SortPlan p = plan_sort(N, E > 0 ? E : 1);
+  return 5 * p.keys_bytes + p.temp_bytes;
+}
+
+extern "C" int mlqem_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* in_ptr, int32_t* in_src,
+                               int32_t* out_ptr, int32_t* out_dst, int32_t* loops, void* workspace,
+                               size_t workspace_bytes, mlqem_stream_t stream_) {
+  hipStream_t stream = as_stream(stream_);
+  if (N < 0 || E < 0 || N >= 0x7fffffffLL || E >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if (!in_ptr || !out_ptr || !loops) return MLQEM_ERR_BAD_ARG;
+  if (hipMemsetAsync(loops, 0, sizeof(int32_t) * (size_t)N, stream) != hipSuccess && N > 0) return MLQEM_ERR_LAUNCH;
+  if (E == 0) {
+    (void)hipMemsetAsync(in_ptr, 0, sizeof(int32_t) * (size_t)(N + 1), stream);
+    (void)hipMemsetAsync(out_ptr, 0, sizeof(int32_t) * (size_t)(N + 1), stream);
+    return launch_status();
+  }
+  if (!edge_index || !in_src || !out_dst) return MLQEM_ERR_BAD_ARG;
+  const SortPlan p = plan_sort(N, E);
+  if (!workspace || workspace_bytes < 5 * p.keys_bytes + p.temp_bytes) return MLQEM_ERR_WORKSPACE;
+  char* ws = static_cast<char*>(workspace);
+  int32_t* key_d = reinterpret_cast<int32_t*>(ws);
+  int32_t* val_s = reinterpret_cast<int32_t*>(ws + p.keys_bytes);
+  int32_t* key_s = reinterpret_cast<int32_t*>(ws + 2 * p.keys_bytes);
+  int32_t* val_d = reinterpret_cast<int32_t*>(ws + 3 * p.keys_bytes);
+  int32_t* sorted = reinterpret_cast<int32_t*>(ws + 4 * p.keys_bytes);
+  void* temp = ws + 5 * p.keys_bytes;
+  size_t temp_bytes = p.temp_bytes;
+
+  const unsigned eb = (unsigned)ceil_div(E, kBlock), nb = (unsigned)ceil_div(N + 1, kBlock);
+  hipLaunchKernelGGL(split_edges_kernel, dim3(eb), dim3(kBlock), 0, stream, edge_index, E, (int32_t)N, key_d, val_s,
+                     key_s, val_d, loops);
+  // LSD radix sort is stable: inside a row the caller's edge order survives
+  if (rocprim::radix_sort_pairs(temp, temp_bytes, key_d, sorted, val_s, in_src, (size_t)E, 0, (unsigned)p.end_bit,
+                                stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(lower_bound_kernel, dim3(nb), dim3(kBlock), 0, stream, sorted, E, N, in_ptr);
+  if (rocprim::radix_sort_pairs(temp, temp_bytes, key_s, sorted, val_d, out_dst, (size_t)E, 0, (unsigned)p.end_bit,
+                                stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(lower_bound_kernel, dim3(nb), dim3(kBlock), 0, stream, sorted, E, N, out_ptr);
+  return launch_status();
+}
+
+extern "C" int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* loops, int64_t N,
+                                 float* gcn_dinv, float* sage_rinv, float* cheb_dinv, mlqem_stream_t stream) {
+  if (N < 0 || (N > 0 && (!in_ptr || (cheb_dinv && !out_ptr)))) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  hipLaunchKernelGGL(graph_norms_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream),
+                     in_ptr, out_ptr, loops, N, gcn_dinv, sage_rinv, cheb_dinv);
+  return launch_status();
+}
+
+extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K,
+                                    const int32_t* a_gptr, const int32_t* a_in_ptr, const int32_t* a_in_src,
+                                    const int32_t* a_out_ptr, const int32_t* a_out_dst, const int32_t* a_loops,
+                                    const int32_t* sel, const int32_t* b_nptr, const int32_t* b_eptr, int64_t B,
+                                    int64_t Nb, int64_t Eb, float* xb, int64_t ldxb, float* nscal_b,
+                                    int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
+                                    int32_t* loops_b, mlqem_stream_t stream_) {
+  hipStream_t stream = as_stream(stream_);
+  if (B <= 0 || Nb < 0 || Eb < 0 || F <= 0 || K < 0 || ldx < F || ldxb < F) return MLQEM_ERR_BAD_ARG;
+  if (B > 0x7fffffff || Nb >= 0x7fffffffLL || Eb >= 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
+  if (!x || !a_gptr || !a_in_ptr || !a_out_ptr || !sel || !b_nptr || !b_eptr || !xb || !in_ptr_b || !out_ptr_b)
+    return MLQEM_ERR_BAD_ARG;
+  if (K > 0 && (!nscal || !nscal_b)) return MLQEM_ERR_BAD_ARG;
+  if (Eb > 0 && (!a_in_src || !a_out_dst || !in_src_b || !out_dst_b)) return MLQEM_ERR_BAD_ARG;
+  if (loops_b && !a_loops) return MLQEM_ERR_BAD_ARG;
+  AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_loops, sel, b_nptr, b_eptr,
+                 (int)B, Nb, Eb, xb, ldxb, nscal_b, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, loops_b};
+  if (Nb > 0)
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)ceil_div(Nb * (F + K), kBlock)), dim3(kBlock), 0, stream, a);
+  hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
+  if (Eb > 0)
+    hipLaunchKernelGGL(assemble_edges_kernel, dim3((unsigned)ceil_div(Eb, kBlock)), dim3(kBlock), 0, stream, a);
+  return launch_status();
+}

@@ -1,0 +1,66 @@
+"""Family A (GCN || Cheb || SAGE) on the GPU vs the CPU oracle: forward within 1e-5, gradients of every
+parameter, on batches collated the way the reference's training path collates them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import g1_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ARGS = ("noisy", "observable", "depth", "x", "edge_index", "batch")
+
+
+def _models(seed=0):
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from oracle.models import FamilyA
+
+    torch.manual_seed(seed)
+    model = ExpValCircuitGraphModelA(5, 22, 10)
+    # GCN/Cheb biases start at zero; give them values so their gradients/paths are exercised
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bias"):
+                p.uniform_(-0.5, 0.5)
+    ref = FamilyA(5, 22, 10).double()
+    ref.load_state_dict(model.state_dict(), strict=True)
+    return model.to(DEV), ref
+
+
+@pytest.mark.parametrize("self_loops", [True, False])
+@pytest.mark.parametrize("count", [1, 32, 300])
+def test_forward_matches_oracle(g1, self_loops, count):
+    model, ref = _models()
+    batch = g1_batch(g1, range(count), self_loops=self_loops)
+    out = model.eval()(*[batch[k].to(DEV) for k in ARGS])
+    want = ref.eval()(*[batch[k].double() if batch[k].is_floating_point() else batch[k] for k in ARGS])
+    assert out.shape == (count, 1)
+    assert (out.detach().cpu().double() - want.detach()).abs().max().item() < 1e-5  # north_star tolerance
+
+
+def test_gradients_match_oracle(g1):
+    model, ref = _models(seed=1)
+    batch = g1_batch(g1, range(40, 104))
+    model.eval(), ref.eval()  # dropout off; gradients still flow
+    out = model(*[batch[k].to(DEV) for k in ARGS])
+    torch.nn.functional.mse_loss(out, batch["y"].to(DEV)).backward()
+    want = ref(*[batch[k].double() if batch[k].is_floating_point() else batch[k] for k in ARGS])
+    torch.nn.functional.mse_loss(want, batch["y"].double()).backward()
+    ref_grads = dict(ref.named_parameters())
+    for name, p in model.named_parameters():
+        g_ref = ref_grads[name].grad
+        scale = g_ref.abs().max().item() + 1e-9
+        err = (p.grad.cpu().double() - g_ref).abs().max().item() / scale
+        assert err < 1e-4, f"{name}: relative grad error {err}"
+
+
+def test_train_mode_dropout_runs_and_is_seeded(g1):
+    model, _ = _models()
+    batch = g1_batch(g1, range(32))
+    args = [batch[k].to(DEV) for k in ARGS]
+    model.train()
+    out = model(*args)
+    torch.nn.functional.mse_loss(out, batch["y"].to(DEV)).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
