@@ -52,6 +52,11 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(LIB_PATH)}` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    # torch ships its own libamdhip64 (soname libamdhip64.so.7).  It must be in the process BEFORE this library is
+    # mapped so that both resolve to ONE HIP runtime; loaded the other way round, /opt/rocm's copy comes in as a
+    # second runtime and every launch on torch-owned memory fails.
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:

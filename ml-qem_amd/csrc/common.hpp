@@ -15,6 +15,10 @@ constexpr int kXcds = 8;
 
 inline hipStream_t as_stream(mlqem_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipGetLastError() reports the last error of ANY runtime call on this thread, including benign ones the caller
+// made (hipErrorNotReady from an event query of torch's allocator).  Entry points therefore clear the slot
+// first (begin_launches) and read it after their own launches (launch_status).
+inline void begin_launches() { (void)hipGetLastError(); }
 inline int launch_status() {
   return hipGetLastError() == hipSuccess ? MLQEM_OK : MLQEM_ERR_LAUNCH;
 }

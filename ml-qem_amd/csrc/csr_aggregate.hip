@@ -138,6 +138,7 @@ extern "C" int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_
                                        float beta, const float* z, int64_t ldz, const float* bias, int act,
                                        float drop_p, uint64_t seed, float* out, int64_t ldo, int64_t N, int C,
                                        mlqem_stream_t stream) {
+  begin_launches();
   if (drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
   AggArgs a{x, ldx, ptr, idx, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, out, ldo, N, C, 0};
   return launch_aggregate<false>(a, as_stream(stream));
@@ -145,12 +146,14 @@ extern "C" int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_
 
 extern "C" int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
                                          float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream) {
+  begin_launches();
   AggArgs a{x, ldx, ptr, idx, nullptr, nullptr, nullptr, 1.f, 0.f, nullptr, 0, nullptr, 0, 0.f, 0, out, ldo, N, C, 0};
   return launch_aggregate<true>(a, as_stream(stream));
 }
 
 extern "C" int mlqem_relu_dropout_bwd_f32(const float* g, const float* y, float scale, float* gx, int64_t n,
                                           mlqem_stream_t stream) {
+  begin_launches();
   if (n < 0 || (n > 0 && (!g || !y || !gx))) return MLQEM_ERR_BAD_ARG;
   if (n == 0) return MLQEM_OK;
   hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, as_stream(stream),

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_partial_kernel(const float* __re
   float* x_t = tile + kWgradTile * O;
   const int I1 = I + 1;
   const int pairs = O * I1;
+  const int pair0 = blockIdx.y * kBlock * kWgradMaxPairsPerThread;  // this block's slice of the (o,i) pairs
   float acc[kWgradMaxPairsPerThread];
 #pragma unroll
   for (int q = 0; q < kWgradMaxPairsPerThread; ++q) acc[q] = 0.f;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_partial_kernel(const float* __re
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kWgradMaxPairsPerThread; ++q) {
-      const int p = threadIdx.x + q * kBlock;
+      const int p = pair0 + threadIdx.x + q * kBlock;
       if (p < pairs) {
         const int o = p / I1, k = p % I1;
         float s = acc[q];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_partial_kernel(const float* __re
   }
 #pragma unroll
   for (int q = 0; q < kWgradMaxPairsPerThread; ++q) {
-    const int p = threadIdx.x + q * kBlock;
+    const int p = pair0 + threadIdx.x + q * kBlock;
     if (p < pairs) partial[(int64_t)blockIdx.x * pairs + p] = acc[q];
   }
 }
@@ -112,6 +113,7 @@ using namespace mlqem;
 
 extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, float* y,
                                 int64_t ldy, int64_t N, int I, int O, int act, int accumulate, mlqem_stream_t stream) {
+  begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!x || !w || !y) return MLQEM_ERR_BAD_ARG;
@@ -134,16 +136,17 @@ extern "C" size_t mlqem_linear_wgrad_workspace_bytes(int I, int O) {
 extern "C" int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
                                       int64_t N, int I, int O, int accumulate, void* workspace, size_t workspace_bytes,
                                       mlqem_stream_t stream) {
+  begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || !gw || ldgy < O || ldx < I) return MLQEM_ERR_BAD_ARG;
-  if (O * (I + 1) > kBlock * kWgradMaxPairsPerThread) return MLQEM_ERR_UNSUPPORTED;
   const size_t lds = (size_t)kWgradTile * (O + I + 1) * sizeof(float);
   if (lds > 64 * 1024) return MLQEM_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, O)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && (!gy || !x)) return MLQEM_ERR_BAD_ARG;
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(N, kWgradTile)));
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(G), dim3(kBlock), lds, as_stream(stream), gy, ldgy, x, ldx, partial, N,
-                     I, O);
+  const int slices = (int)ceil_div(O * (I + 1), kBlock * kWgradMaxPairsPerThread);
+  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(G, slices), dim3(kBlock), lds, as_stream(stream), gy, ldgy, x, ldx,
+                     partial, N, I, O);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), kBlock)), dim3(kBlock), 0,
                      as_stream(stream), partial, G, I, O, gw, gb, accumulate);
   return launch_status();

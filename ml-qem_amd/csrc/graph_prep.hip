@@ -148,6 +148,7 @@ extern "C" size_t mlqem_csr_build_workspace_bytes(int64_t N, int64_t E) {
 extern "C" int mlqem_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* in_ptr, int32_t* in_src,
                                int32_t* out_ptr, int32_t* out_dst, int32_t* loops, void* workspace,
                                size_t workspace_bytes, mlqem_stream_t stream_) {
+  begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (N < 0 || E < 0 || N >= 0x7fffffffLL || E >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
   if (!in_ptr || !out_ptr || !loops) return MLQEM_ERR_BAD_ARG;
@@ -186,6 +187,7 @@ extern "C" int mlqem_csr_build(const int64_t* edge_index, int64_t E, int64_t N, 
 
 extern "C" int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* loops, int64_t N,
                                  float* gcn_dinv, float* sage_rinv, float* cheb_dinv, mlqem_stream_t stream) {
+  begin_launches();
   if (N < 0 || (N > 0 && (!in_ptr || (cheb_dinv && !out_ptr)))) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   hipLaunchKernelGGL(graph_norms_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream),
@@ -200,6 +202,7 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
                                     int64_t Nb, int64_t Eb, float* xb, int64_t ldxb, float* nscal_b,
                                     int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
                                     int32_t* loops_b, mlqem_stream_t stream_) {
+  begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (B <= 0 || Nb < 0 || Eb < 0 || F <= 0 || K < 0 || ldx < F || ldxb < F) return MLQEM_ERR_BAD_ARG;
   if (B > 0x7fffffff || Nb >= 0x7fffffffLL || Eb >= 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;

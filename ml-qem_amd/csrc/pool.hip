@@ -53,6 +53,7 @@ using namespace mlqem;
 
 extern "C" int mlqem_segment_mean_f32(const float* x, int64_t ldx, const int32_t* graph_ptr, float* out, int64_t ldo,
                                       int64_t B, int C, mlqem_stream_t stream) {
+  begin_launches();
   if (B < 0 || C <= 0 || ldx < C || ldo < C) return MLQEM_ERR_BAD_ARG;
   if (B == 0) return MLQEM_OK;
   if (!x || !graph_ptr || !out) return MLQEM_ERR_BAD_ARG;
@@ -63,6 +64,7 @@ extern "C" int mlqem_segment_mean_f32(const float* x, int64_t ldx, const int32_t
 
 extern "C" int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph_ptr, float* gx,
                                           int64_t ldgx, int64_t B, int C, mlqem_stream_t stream) {
+  begin_launches();
   if (B < 0 || C <= 0 || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
   if (B == 0) return MLQEM_OK;
   if (!g || !graph_ptr || !gx) return MLQEM_ERR_BAD_ARG;
