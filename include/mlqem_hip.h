@@ -96,15 +96,18 @@ int mlqem_relu_dropout_bwd_f32(const float* g, const float* y, float scale, floa
  * docs/tutorials/mlp.py:18-108 MLP1/2/3, the per-node projections inside every conv).
  * ---------------------------------------------------------------------------------------------------- */
 
-/* y[n,:] = act( x[n,:] @ W^T + b ),  W: [O,I] row-major as torch stores it (transposed = 0),
- * or y = x @ W with W: [I,O] (transposed = 1; this is the data-gradient form gx = gy @ W).
- * accumulate != 0 adds into y instead of overwriting.  act bit 0 = ReLU. */
-int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, float* y,
-                     int64_t ldy, int64_t N, int I, int O, int act, int accumulate, mlqem_stream_t stream);
+/* y[n,:] = act( (x[n,:] @ W^T + b) * rowscale[n] ),  W: [O,I] row-major as torch stores it (transposed = 0),
+ * or the same with y = x @ W, W: [I,O] (transposed = 1; this is the data-gradient form gx = gy @ W).
+ * b and rowscale may be NULL.  accumulate != 0 adds into y instead of overwriting.  act bit 0 = ReLU.
+ * Runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32) for I <= 128, N >= 16. */
+int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
+                     const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act, int accumulate,
+                     mlqem_stream_t stream);
 
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 
-/* gw[o,i] (+)= sum_n gy[n,o] * x[n,i] ;  gb[o] (+)= sum_n gy[n,o]  (gb may be NULL).  Two-stage, deterministic. */
+/* gw[o,i] (+)= sum_n gy[n,o] * x[n,i] ;  gb[o] (+)= sum_n gy[n,o]  (gb may be NULL).  Matrix-core partial sums per
+ * workgroup, then a fixed-order reduction: deterministic. */
 int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
                            int64_t N, int I, int O, int accumulate, void* workspace, size_t workspace_bytes,
                            mlqem_stream_t stream);
@@ -116,6 +119,24 @@ int mlqem_segment_mean_f32(const float* x, int64_t ldx, const int32_t* graph_ptr
                            int64_t B, int C, mlqem_stream_t stream);
 int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph_ptr, float* gx, int64_t ldgx,
                                int64_t B, int C, mlqem_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Batch assembly from a device-resident dataset.  Replaces torch_geometric.loader.DataLoader's collate
+ * (Batch.from_data_list; call sites docs/tutorials/gnn.py:293-307, docs/tutorials/__ml_models.py:105-119), which
+ * concatenates ~9 attributes of B Data objects on the host every step.
+ *
+ * Arena (whole dataset, G graphs): x[Ntot,F], nscal[Ntot,K] (per-node scalars, e.g. the three norms), a_gptr[G+1],
+ * and the CSR arrays of mlqem_csr_build run over the whole arena (global node ids).
+ * Selection: sel[B] graph ids (repeats allowed); b_nptr[B+1] / b_eptr[B+1] = prefix sums of the selected graphs'
+ * node / edge counts (host knows them without a sync); Nb = b_nptr[B], Eb = b_eptr[B].
+ * Outputs: the batch's x, nscal, both CSR structures (node ids rebased to the batch) and loops.
+ * ---------------------------------------------------------------------------------------------------- */
+int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K, const int32_t* a_gptr,
+                         const int32_t* a_in_ptr, const int32_t* a_in_src, const int32_t* a_out_ptr,
+                         const int32_t* a_out_dst, const int32_t* a_loops, const int32_t* sel, const int32_t* b_nptr,
+                         const int32_t* b_eptr, int64_t B, int64_t Nb, int64_t Eb, float* xb, int64_t ldxb,
+                         float* nscal_b, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
+                         int32_t* loops_b, mlqem_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,113 @@
+"""Device-resident circuit-graph dataset ("arena") and on-device batch assembly.
+
+The reference collates a batch on the host every step: PyG's ``DataLoader`` concatenates ~9 attributes of 32
+``Data`` objects and offsets ``edge_index`` (docs/tutorials/__ml_models.py:105-119,148).  Here the whole encoded
+dataset is uploaded once: node features, both CSR structures, self-loop counts and the per-node normalisation
+scalars live in HBM (a 1M-circuit corpus is a few tens of GB of the 288 GB), and a batch is gathered by one
+native call from a list of graph ids -- no host-side tensor work beyond two prefix sums over B integers.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..native import _lib, ops
+from ..native.structure import GraphStructure
+
+
+class DeviceBatch:
+    """One assembled batch: node features, structure and the per-graph tensors of the model protocol."""
+
+    def __init__(self, x, structure, y, noisy, depth, observable, graph_ids):
+        self.x, self.structure = x, structure
+        self.y, self.noisy_0, self.circuit_depth, self.observable = y, noisy, depth, observable
+        self.graph_ids = graph_ids
+        self.num_graphs = structure.num_graphs
+
+    def model_args(self):
+        """The six positional arguments of the reference's model protocol."""
+        return self.noisy_0, self.observable, self.circuit_depth, self.x, self.structure, None
+
+
+class GraphArena:
+    def __init__(self, x, node_counts, structure_arrays, nscal, y, noisy, depth, observable, edge_counts):
+        self.x = x
+        self.node_counts = np.asarray(node_counts, dtype=np.int64)
+        self.edge_counts = np.asarray(edge_counts, dtype=np.int64)
+        self.gptr, self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops = structure_arrays
+        self.nscal = nscal  # [N,3]: gcn_dinv, sage_rinv, cheb_dinv
+        self.y, self.noisy, self.depth, self.observable = y, noisy, depth, observable
+        self.device = x.device
+
+    def __len__(self):
+        return len(self.node_counts)
+
+    @property
+    def num_nodes(self):
+        return int(self.node_counts.sum())
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def from_arrays(xs: Sequence[np.ndarray], edge_indices: Sequence[np.ndarray], y, noisy, depth, observable,
+                    device="cuda") -> "GraphArena":
+        """xs[g]: [n_g,F] float; edge_indices[g]: [2,e_g] graph-local int (self-loops allowed, e.g. after
+        ``AddSelfLoops``); y/noisy/depth/observable: per-graph arrays with leading dimension G."""
+        node_counts = np.array([a.shape[0] for a in xs], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(node_counts)])
+        x = torch.from_numpy(np.ascontiguousarray(np.concatenate(xs, axis=0), dtype=np.float32)).to(device)
+        ei = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(edge_indices, offs[:-1])], axis=1)
+        n_total = int(offs[-1])
+        ei_dev = torch.from_numpy(np.ascontiguousarray(ei)).to(device)
+        in_ptr, in_src, out_ptr, out_dst, loops = ops.csr_build(ei_dev, n_total)
+        gcn, sage, cheb = ops.graph_norms(in_ptr, out_ptr, loops, n_total)
+        nscal = torch.stack([gcn, sage, cheb], dim=1).contiguous()
+        gptr = torch.from_numpy(offs.astype(np.int32)).to(device)
+        # edges per graph (self-loops excluded): one read-back at build time
+        edge_counts = np.diff(in_ptr.cpu().numpy()[offs]).astype(np.int64)
+        t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
+        return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops), nscal, t(y), t(noisy),
+                          t(depth), t(observable), edge_counts)
+
+    @staticmethod
+    def from_data_list(graphs, device="cuda") -> "GraphArena":
+        """From the host dataset's ``Data`` entries (CircuitGraphExpValMitigationDataset)."""
+        xs = [g.x.numpy() for g in graphs]
+        eis = [g.edge_index.numpy() for g in graphs]
+        y = np.stack([g.y.numpy().reshape(-1) for g in graphs])
+        noisy = np.stack([g.noisy_0.numpy().reshape(-1) for g in graphs])
+        depth = np.stack([g.circuit_depth.numpy().reshape(-1) for g in graphs])
+        obs = np.stack([g.observable.numpy()[0] for g in graphs])
+        return GraphArena.from_arrays(xs, eis, y, noisy, depth, obs, device=device)
+
+    # ------------------------------------------------------------------------------------------------
+    def batch(self, graph_ids) -> DeviceBatch:
+        """Gathers the graphs ``graph_ids`` (host ints, any order, repeats allowed) into one batch on the device."""
+        sel = np.asarray(graph_ids, dtype=np.int64)
+        b = int(sel.shape[0])
+        if b == 0:
+            raise ValueError("empty batch")
+        nptr = np.zeros(b + 1, dtype=np.int64)
+        eptr = np.zeros(b + 1, dtype=np.int64)
+        np.cumsum(self.node_counts[sel], out=nptr[1:])
+        np.cumsum(self.edge_counts[sel], out=eptr[1:])
+        nb, eb = int(nptr[-1]), int(eptr[-1])
+        packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.device, non_blocking=True)
+        sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:]
+        dev, f = self.device, self.x.shape[1]
+        xb = torch.empty((nb, f), dtype=torch.float32, device=dev)
+        nscal_b = torch.empty((nb, 3), dtype=torch.float32, device=dev)
+        mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        in_ptr, out_ptr, loops = mk(nb + 1), mk(nb + 1), mk(nb)
+        in_src, out_dst = mk(eb), mk(eb)
+        p = ops._p
+        code = _lib.load().mlqem_batch_assemble(
+            p(self.x), self.x.stride(0), f, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
+            p(self.out_ptr), p(self.out_dst), p(self.loops), p(sel_d), p(nptr_d), p(eptr_d), b, nb, eb,
+            p(xb), f, p(nscal_b), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(loops), ops._stream())
+        _lib.check(code, "mlqem_batch_assemble")
+        norms = (nscal_b[:, 0].contiguous(), nscal_b[:, 1].contiguous(), nscal_b[:, 2].contiguous())
+        s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms)
+        idx = sel_d.to(torch.int64)
+        return DeviceBatch(xb, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)

@@ -86,7 +86,7 @@ def relu_dropout_bwd(g, y, scale=1.0):
     return gx
 
 
-def linear(x, w, b=None, *, transposed=False, relu=False, out=None, accumulate=False):
+def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=None, accumulate=False):
     """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O])."""
     n, i = x.shape
     ldx = _mat(x, "x")
@@ -96,11 +96,12 @@ def linear(x, w, b=None, *, transposed=False, relu=False, out=None, accumulate=F
     if (w.shape[0] if transposed else w.shape[1]) != i:
         raise ValueError(f"linear: x has {i} columns, w is {tuple(w.shape)} (transposed={transposed})")
     _vec(b, "b", o)
+    _vec(rowscale, "rowscale", n)
     if out is None:
         out = torch.empty((n, o), dtype=torch.float32, device=x.device)
     elif out.shape != (n, o):
         raise ValueError("linear: bad out shape")
-    code = _lib.load().mlqem_linear_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(out), _mat(out, "out"),
+    code = _lib.load().mlqem_linear_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(rowscale), _p(out), _mat(out, "out"),
                                         n, i, o, 1 if relu else 0, 1 if accumulate else 0, _stream())
     _lib.check(code, "mlqem_linear_f32")
     return out

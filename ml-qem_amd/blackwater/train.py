@@ -1,0 +1,135 @@
+"""Training loop of the path: same semantics as the reference's ``train_gnn``
+(docs/tutorials/__ml_models.py:100-187 == docs/tutorials/gnn.py:282-378): MSE loss on ``squeeze(y, 1)``,
+Adam(lr=1e-3), ReduceLROnPlateau('min', factor 0.1, patience 15, min_lr 1e-5) stepped on the SUMMED validation
+loss, batch 32 by default -- with three MI355X-side changes that do not alter the maths:
+
+* the dataset is device-resident (:class:`GraphArena`) and batches are assembled on the GPU,
+* the loss is accumulated on the device (the reference calls ``loss.item()`` every step: a host sync),
+* under ``torch.distributed`` each rank trains on its shard and gradients are averaged with ONE all-reduce
+  over a flat fp32 buffer (RCCL over xGMI on MI355X, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Iterable, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def flatten_parameters(model: nn.Module):
+    """Re-homes every parameter as a view into one contiguous fp32 buffer and gives each a ``.grad`` view into a
+    second one.  The optimizer then steps a single tensor and data-parallel training reduces a single buffer
+    (13,645 ... 103,465 floats for the reference's models)."""
+    params = [p for p in model.parameters()]
+    total = sum(p.numel() for p in params)
+    dev = params[0].device
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = flat_grad[off:off + n].view(p.shape)
+            off += n
+    flat_param = nn.Parameter(flat)
+    flat_param.grad = flat_grad
+    return flat_param, flat_grad
+
+
+class DataParallelShard:
+    """Contiguous, node-count-balanced shard of the graph ids for one rank (graphs on this path vary 13x in size)."""
+
+    @staticmethod
+    def split(node_counts: np.ndarray, world_size: int) -> List[np.ndarray]:
+        order = np.argsort(-node_counts, kind="stable")
+        loads = np.zeros(world_size)
+        buckets: List[List[int]] = [[] for _ in range(world_size)]
+        for g in order:  # longest-processing-time greedy, then keep every shard the same length
+            r = int(np.argmin(loads))
+            buckets[r].append(int(g))
+            loads[r] += node_counts[g]
+        n = min(len(b) for b in buckets)
+        return [np.sort(np.asarray(b[:n], dtype=np.int64)) for b in buckets]
+
+
+class Trainer:
+    def __init__(self, model: nn.Module, lr: float = 1e-3, distributed: bool = False, flat: bool = True):
+        self.model = model
+        self.distributed = distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world = torch.distributed.get_world_size() if self.distributed else 1
+        if flat:
+            self.flat_param, self.flat_grad = flatten_parameters(model)
+            opt_params = [self.flat_param]
+        else:
+            self.flat_param = self.flat_grad = None
+            opt_params = list(model.parameters())
+        fused = opt_params[0].is_cuda
+        self.optimizer = torch.optim.Adam(opt_params, lr=lr, fused=fused) if fused else torch.optim.Adam(opt_params, lr=lr)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", factor=0.1, patience=15,
+                                                                    min_lr=1e-5)
+        self.criterion = nn.MSELoss()
+
+    # -- one optimisation step on an assembled batch -------------------------------------------------------
+    def step(self, batch) -> torch.Tensor:
+        """forward -> MSE -> backward -> (all-reduce) -> Adam.  Returns the loss as a device tensor (no sync)."""
+        self.model.train()
+        if self.flat_grad is not None:
+            self.flat_grad.zero_()
+        else:
+            self.optimizer.zero_grad(set_to_none=False)
+        out = self.model(*batch.model_args())
+        target = batch.y if batch.y.dim() == 2 else torch.squeeze(batch.y, 1)
+        loss = self.criterion(out, target)
+        loss.backward()
+        if self.distributed:
+            self.all_reduce_gradients()
+        self.optimizer.step()
+        return loss.detach()
+
+    def all_reduce_gradients(self):
+        if self.flat_grad is not None:
+            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM)
+            self.flat_grad.div_(self.world)
+        else:
+            for p in self.model.parameters():
+                torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
+                p.grad.div_(self.world)
+
+    @torch.no_grad()
+    def evaluate(self, batches: Iterable) -> torch.Tensor:
+        """Sum of per-batch MSE losses over ``batches`` (what the reference feeds the LR scheduler)."""
+        self.model.eval()
+        total = None
+        for batch in batches:
+            out = self.model(*batch.model_args())
+            target = batch.y if batch.y.dim() == 2 else torch.squeeze(batch.y, 1)
+            l = self.criterion(out, target)
+            total = l if total is None else total + l
+        return total
+
+    def fit(self, arena, train_ids, val_ids, epochs: int, batch_size: int = 32, seed: int = 0, log: Callable = None):
+        """Epoch loop with per-epoch shuffling (seed + epoch) and the reference's LR schedule."""
+        history = {"train_losses": [], "val_losses": []}
+        for epoch in range(epochs):
+            rng = np.random.RandomState(seed + epoch)
+            order = rng.permutation(np.asarray(train_ids))
+            running, n_batches = None, 0
+            for i in range(0, len(order), batch_size):
+                loss = self.step(arena.batch(order[i:i + batch_size]))
+                running = loss if running is None else running + loss
+                n_batches += 1
+            val_batches = [arena.batch(val_ids[i:i + batch_size]) for i in range(0, len(val_ids), batch_size)]
+            val_total = self.evaluate(val_batches)
+            if self.distributed:
+                torch.distributed.all_reduce(val_total, op=torch.distributed.ReduceOp.SUM)
+            self.scheduler.step(val_total.item())  # one sync per epoch
+            if epoch >= 1:  # the reference drops epoch 0 from its curves (__ml_models.py:182)
+                history["train_losses"].append(running.item() / n_batches)
+                history["val_losses"].append(val_total.item() / max(len(val_batches), 1) / self.world)
+            if log:
+                log(epoch, history)
+        return history

@@ -1,14 +1,23 @@
 // CSR aggregation kernels: the "scatter-add" of the GNN layers, written as a gather over destination rows
 // so that no atomics are needed and every output row is written exactly once (deterministic).
 //
-// Work decomposition.  The (row, channel-vector) space is flattened: thread t handles row = t / CV and the
-// VEC-wide channel slice (t % CV) * VEC, CV = C / VEC.  Consecutive lanes therefore cover consecutive
-// addresses of out[] (fully coalesced 4/8/16-B stores), the lanes of one row read one contiguous source row
-// per edge, and no lane is idle whatever C is (C = 1 ... 125 on this path).  The CSR arrays are read with the
-// same address by all lanes of a row (one request per row after coalescing).  Blocks are remapped so that
-// every XCD walks one contiguous slice of the rows: op nodes are numbered in program order and an edge joins
-// an op to the next op on the same wire, so the source rows of a tile lie within a few hundred rows of it and
-// are served from that XCD's L2 after the first touch.
+// Work decomposition (csr_aggregate_kernel).  A 256-thread workgroup owns R consecutive destination rows and
+// R*CV "items", an item being one row x one VEC-wide channel slice (CV = C / VEC; R = 1024 / CV, so every
+// thread has 4 items whatever C is -- C runs from 1 to 125 on this path).  Items are numbered row-major, so
+// consecutive lanes write consecutive addresses of out[] and the lanes of one row read one contiguous source
+// row per edge.
+//   phase 1  the block's slice of rowptr / rscale / dself goes to LDS with coalesced loads
+//   phase 2  the block's slice of col[] (contiguous, because rows are) goes to LDS coalesced, together with the
+//            per-edge source scalar cscale[col[e]]
+//   phase 3  every thread issues, for ALL of its items at once, the loads of the self row and of the first two
+//            source rows (op nodes have in-degree <= 2 except barriers), so 12 independent vector loads per
+//            thread are in flight instead of a ptr -> col -> row dependent chain per row
+//   phase 4  rows with more in-edges finish in a per-item loop; rows above kHeavyDegree (barrier nodes: one
+//            in-edge per qubit) are left to phase 5
+//   phase 5  the whole workgroup splits each heavy row's edges and reduces through LDS
+// Blocks are remapped so that every XCD walks one contiguous slice of the rows: op nodes are numbered in
+// program order and an edge joins an op to the next op on the same wire, so the source rows of a tile lie within
+// a few hundred rows of it and are served from that XCD's L2 after the first touch.
 #include "common.hpp"
 
 namespace mlqem {
@@ -22,60 +31,23 @@ struct AggArgs {
   const float* bias;
   int act; float drop_p; uint64_t seed;
   float* out; int64_t ldo;
-  int64_t N; int C; int CV;
+  int64_t N; int C; int CV; int R;
 };
 
+constexpr int kItemsPerThread = 4;
+constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rscale / dself)
+constexpr int kEdgeCap = 2048;       // staged col[] entries per block; a denser tile reads col[] from global
+constexpr int kHeavyDegree = 32;     // rows above this are reduced by the whole block
+constexpr int kHeavyCap = 64;
+
 template <int VEC, bool IS_MAX>
-__global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) {
-  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const int64_t t = (int64_t)blk * kBlock + threadIdx.x;
-  const int64_t row = t / a.CV;
-  if (row >= a.N) return;
-  const int ch = (int)(t - row * a.CV) * VEC;
-
-  const int beg = a.ptr[row], end = a.ptr[row + 1];
-  const float* __restrict__ xc = a.x + ch;
-  float acc[VEC];
-  float self[VEC];
-  const bool need_self = IS_MAX || a.dself != nullptr;  // Cheb-style calls have no self term: skip the row read
-  if (need_self) vload<VEC>(xc + row * a.ldx, self);
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) { if (!need_self) self[v] = 0.f; acc[v] = IS_MAX ? self[v] : 0.f; }
-
-  int e = beg;
-  // two edges per trip: both index loads, then both row loads, are in flight together
-  for (; e + 1 < end; e += 2) {
-    const int j0 = a.idx[e], j1 = a.idx[e + 1];
-    float s0 = 1.f, s1 = 1.f;
-    if (!IS_MAX && a.cscale) { s0 = a.cscale[j0]; s1 = a.cscale[j1]; }
-    float r0[VEC], r1[VEC];
-    vload<VEC>(xc + (int64_t)j0 * a.ldx, r0);
-    vload<VEC>(xc + (int64_t)j1 * a.ldx, r1);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      if (IS_MAX) acc[v] = fmaxf(acc[v], fmaxf(r0[v], r1[v]));
-      else { acc[v] = fmaf(s0, r0[v], acc[v]); acc[v] = fmaf(s1, r1[v], acc[v]); }
-    }
-  }
-  if (e < end) {
-    const int j0 = a.idx[e];
-    const float s0 = (!IS_MAX && a.cscale) ? a.cscale[j0] : 1.f;
-    float r0[VEC];
-    vload<VEC>(xc + (int64_t)j0 * a.ldx, r0);
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      if (IS_MAX) acc[v] = fmaxf(acc[v], r0[v]);
-      else acc[v] = fmaf(s0, r0[v], acc[v]);
-    }
-  }
-
+__device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
+                                           const float (&self)[VEC], float rs, float ds) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) res[v] = acc[v];
   } else {
-    const float rs = a.rscale ? a.rscale[row] : 1.f;
-    const float ds = a.dself ? a.dself[row] : 0.f;
     float zz[VEC];
     if (a.z) vload<VEC>(a.z + row * a.ldz + ch, zz);
 #pragma unroll
@@ -94,6 +66,162 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
   vstore<VEC>(a.out + row * a.ldo + ch, res);
 }
 
+template <int VEC, bool IS_MAX>
+__global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) {
+  __shared__ int s_ptr[kRowsMax + 1];
+  __shared__ float s_rs[kRowsMax];
+  __shared__ float s_ds[kRowsMax];
+  __shared__ int s_idx[kEdgeCap];
+  __shared__ float s_w[kEdgeCap];
+  __shared__ int s_heavy[kHeavyCap];
+  __shared__ int s_nheavy;
+  __shared__ float s_red[kBlock * VEC];
+
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int64_t r0 = (int64_t)blk * a.R;
+  const int nrows = (int)min((int64_t)a.R, a.N - r0);
+  const int tid = threadIdx.x;
+  const bool use_self = IS_MAX || a.dself != nullptr;
+
+  // ---- phase 1
+  for (int i = tid; i <= nrows; i += kBlock) s_ptr[i] = a.ptr[r0 + i];
+  for (int i = tid; i < nrows; i += kBlock) {
+    s_rs[i] = a.rscale ? a.rscale[r0 + i] : 1.f;
+    s_ds[i] = a.dself ? a.dself[r0 + i] : 0.f;
+  }
+  if (tid == 0) s_nheavy = 0;
+  __syncthreads();
+  const int e0 = s_ptr[0];
+  const int ecount = s_ptr[nrows] - e0;
+  const bool staged = ecount <= kEdgeCap;
+  // ---- phase 2
+  if (staged) {
+    for (int i = tid; i < ecount; i += kBlock) {
+      const int j = a.idx[e0 + i];
+      s_idx[i] = j;
+      s_w[i] = (!IS_MAX && a.cscale) ? a.cscale[j] : 1.f;
+    }
+  }
+  __syncthreads();
+  auto edge_src = [&](int le) { return staged ? s_idx[le] : a.idx[e0 + le]; };
+  auto edge_w = [&](int le, int j) {
+    if (IS_MAX || !a.cscale) return 1.f;
+    return staged ? s_w[le] : a.cscale[j];
+  };
+
+  // ---- phase 3: first two edges + self row of every item, all loads issued together
+  const int n_items = nrows * a.CV;
+  int rl[kItemsPerThread], ch[kItemsPerThread], beg[kItemsPerThread], deg[kItemsPerThread];
+  float acc[kItemsPerThread][VEC], self[kItemsPerThread][VEC];
+  float v0[kItemsPerThread][VEC], v1[kItemsPerThread][VEC], w0[kItemsPerThread], w1[kItemsPerThread];
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+    const int t = k * kBlock + tid;
+    const bool live = t < n_items;
+    rl[k] = live ? t / a.CV : 0;
+    ch[k] = live ? (t - rl[k] * a.CV) * VEC : 0;
+    beg[k] = s_ptr[rl[k]] - e0;
+    deg[k] = live ? s_ptr[rl[k] + 1] - e0 - beg[k] : -1;
+    const int64_t row = r0 + rl[k];
+    const float* __restrict__ xc = a.x + ch[k];
+    // a missing edge reads the row itself (a valid address) with weight 0 / as a no-op for max
+    const bool fast = deg[k] <= kHeavyDegree;
+    const int j0 = (fast && deg[k] > 0) ? edge_src(beg[k]) : (int)row;
+    const int j1 = (fast && deg[k] > 1) ? edge_src(beg[k] + 1) : (int)row;
+    w0[k] = (fast && deg[k] > 0) ? edge_w(beg[k], j0) : 0.f;
+    w1[k] = (fast && deg[k] > 1) ? edge_w(beg[k] + 1, j1) : 0.f;
+    vload<VEC>(xc + (int64_t)j0 * a.ldx, v0[k]);
+    vload<VEC>(xc + (int64_t)j1 * a.ldx, v1[k]);
+    if (use_self) vload<VEC>(xc + row * a.ldx, self[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (!use_self) self[k][v] = 0.f;
+      if (IS_MAX) {
+        float m = self[k][v];
+        if (deg[k] > 0) m = fmaxf(m, v0[k][v]);
+        if (deg[k] > 1) m = fmaxf(m, v1[k][v]);
+        acc[k][v] = m;
+      } else {
+        acc[k][v] = fmaf(w1[k], v1[k][v], w0[k] * v0[k][v]);
+      }
+    }
+  }
+  // ---- phase 4: remaining edges of medium rows, then the epilogue
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+    if (deg[k] < 0) continue;
+    const int64_t row = r0 + rl[k];
+    if (deg[k] > kHeavyDegree) {
+      if (ch[k] == 0) {
+        const int slot = atomicAdd(&s_nheavy, 1);
+        if (slot < kHeavyCap) s_heavy[slot] = rl[k];
+      }
+      continue;
+    }
+    const float* __restrict__ xc = a.x + ch[k];
+    for (int e = beg[k] + 2; e < beg[k] + deg[k]; ++e) {
+      const int j = edge_src(e);
+      const float w = edge_w(e, j);
+      float r[VEC];
+      vload<VEC>(xc + (int64_t)j * a.ldx, r);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
+    }
+    finish_row<VEC, IS_MAX>(a, row, ch[k], acc[k], self[k], s_rs[rl[k]], s_ds[rl[k]]);
+  }
+  // ---- phase 5: heavy rows, one at a time, edges split over kBlock / CV slots
+  __syncthreads();
+  const int n_heavy = s_nheavy;
+  if (n_heavy == 0) return;
+  const int slots = kBlock / a.CV;  // >= 1 because CV <= kBlock is checked on the host
+  const int slot = tid / a.CV, hch = (tid - slot * a.CV) * VEC;
+  auto reduce_heavy_row = [&](int r) {
+    __syncthreads();  // s_red is reused from the previous heavy row
+    float part[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? -INFINITY : 0.f;
+    if (slot < slots) {
+      for (int e = s_ptr[r] - e0 + slot; e < s_ptr[r + 1] - e0; e += slots) {
+        const int j = edge_src(e);
+        const float w = edge_w(e, j);
+        float q[VEC];
+        vload<VEC>(a.x + hch + (int64_t)j * a.ldx, q);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? fmaxf(part[v], q[v]) : fmaf(w, q[v], part[v]);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) s_red[tid * VEC + v] = part[v];
+    }
+    __syncthreads();
+    if (slot == 0) {  // the first CV threads own one channel slice each and add the slots in a fixed order
+      float tot[VEC], sf[VEC];
+      const int64_t row = r0 + r;
+      if (use_self) vload<VEC>(a.x + hch + row * a.ldx, sf);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (!use_self) sf[v] = 0.f;
+        tot[v] = IS_MAX ? sf[v] : 0.f;
+      }
+      for (int sl = 0; sl < slots; ++sl)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float q = s_red[(sl * a.CV + tid) * VEC + v];
+          tot[v] = IS_MAX ? fmaxf(tot[v], q) : tot[v] + q;
+        }
+      finish_row<VEC, IS_MAX>(a, row, hch, tot, sf, s_rs[r], s_ds[r]);
+    }
+  };
+  if (n_heavy <= kHeavyCap) {
+    for (int h = 0; h < n_heavy; ++h) reduce_heavy_row(s_heavy[h]);
+  } else {  // more heavy rows than the list holds: find them again by scanning the block's rows
+    for (int r = 0; r < nrows; ++r)
+      if (s_ptr[r + 1] - s_ptr[r] > kHeavyDegree) reduce_heavy_row(r);
+  }
+}
+
 template <bool IS_MAX>
 static int launch_aggregate(AggArgs a, hipStream_t stream) {
   if (a.N < 0 || a.C <= 0 || !a.x || !a.ptr || !a.out || a.ldx < a.C || a.ldo < a.C) return MLQEM_ERR_BAD_ARG;
@@ -110,8 +238,9 @@ static int launch_aggregate(AggArgs a, hipStream_t stream) {
   };
   if (ok(4)) vec = 4; else if (ok(2)) vec = 2;
   a.CV = a.C / vec;
-  const int64_t threads = a.N * a.CV;
-  const int64_t blocks = ceil_div(threads, kBlock);
+  if (a.CV > kBlock) return MLQEM_ERR_UNSUPPORTED;
+  a.R = std::min(kRowsMax, kBlock * kItemsPerThread / a.CV);
+  const int64_t blocks = ceil_div(a.N, a.R);
   if (blocks > 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
   dim3 grid((unsigned)blocks), block(kBlock);
   switch (vec) {
@@ -140,14 +269,14 @@ extern "C" int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_
                                        mlqem_stream_t stream) {
   begin_launches();
   if (drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
-  AggArgs a{x, ldx, ptr, idx, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, out, ldo, N, C, 0};
+  AggArgs a{x, ldx, ptr, idx, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, out, ldo, N, C, 0, 0};
   return launch_aggregate<false>(a, as_stream(stream));
 }
 
 extern "C" int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
                                          float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream) {
   begin_launches();
-  AggArgs a{x, ldx, ptr, idx, nullptr, nullptr, nullptr, 1.f, 0.f, nullptr, 0, nullptr, 0, 0.f, 0, out, ldo, N, C, 0};
+  AggArgs a{x, ldx, ptr, idx, nullptr, nullptr, nullptr, 1.f, 0.f, nullptr, 0, nullptr, 0, 0.f, 0, out, ldo, N, C, 0, 0};
   return launch_aggregate<true>(a, as_stream(stream));
 }
 

@@ -1,131 +1,281 @@
-// Dense layers of the path (per-node projections inside the convs, the MLP heads).  All shapes here are
-// "tall and skinny": N rows (nodes or graphs) by I, O <= a few hundred, so the kernels are bandwidth-bound
-// on the N x (I + O) activations and the weights live in LDS.
+// Dense layers of the path (per-node projections inside the convs, the MLP heads) and their weight gradients.
+// All shapes here are "tall and skinny": N rows (nodes or graphs) by I, O <= a few hundred.
+//
+// Both GEMM forms run on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fmaf chain):
+//   forward      Y[N,O] = X[N,I] W^T     M = 16 rows per tile, N = outputs, K = I; W fragments stay in registers
+//   weight grad  gW[O,I] = gY^T X        M = outputs, N = inputs (+1 column of ones for the bias), K = the N rows,
+//                                        4 rows per MFMA, operands loaded straight from HBM (each byte is used once)
+// Operand lane maps (guide section 3): A: lane l holds A[l & 15][l >> 4]; B: lane l holds B[l >> 4][l & 15];
+// C/D: lane l, register r holds D[(l >> 4) * 4 + r][l & 15].
 #include "common.hpp"
 
 namespace mlqem {
 
-// y[n,o] = act(sum_k x[n,k] * W(o,k) + b[o]).  Thread t of the flattened (row, output) space; the x row is
-// broadcast to the lanes that share it, W is read from LDS.  TRANSPOSED selects W stored [I,O] (gx = gy @ W).
-template <bool TRANSPOSED>
-__global__ __launch_bounds__(kBlock) void linear_kernel(const float* __restrict__ x, int64_t ldx,
-                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                        float* __restrict__ y, int64_t ldy, int64_t N, int I, int O,
-                                                        int act, int accumulate) {
-  extern __shared__ float w_lds[];  // [O][I+pad], pad makes the row stride odd -> conflict-free across o
-  const int stride = I | 1;
-  for (int p = threadIdx.x; p < O * I; p += kBlock) {
-    const int o = TRANSPOSED ? p % O : p / I;
-    const int k = TRANSPOSED ? p / O : p % I;
-    w_lds[o * stride + k] = w[p];
-  }
-  __syncthreads();
-  const int64_t total = N * O;
-  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
-    const int64_t row = t / O;
-    const int o = (int)(t - row * O);
-    const float* __restrict__ xr = x + row * ldx;
-    const float* wr = w_lds + o * stride;
-    float acc0 = b ? b[o] : 0.f, acc1 = 0.f;
-    int k = 0;
-    for (; k + 1 < I; k += 2) {
-      acc0 = fmaf(xr[k], wr[k], acc0);
-      acc1 = fmaf(xr[k + 1], wr[k + 1], acc1);
-    }
-    if (k < I) acc0 = fmaf(xr[k], wr[k], acc0);
-    float r = acc0 + acc1;
-    if (act & 1) r = fmaxf(r, 0.f);
-    float* dst = y + row * ldy + o;
-    *dst = accumulate ? *dst + r : r;
-  }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// Stage 1 of the weight gradient: block b owns the row tiles b, b+G, ... and keeps one running sum per (o,i)
-// pair (and per o for the bias) in registers; tiles of gy and x are staged through LDS with coalesced loads.
-constexpr int kWgradTile = 64;      // rows per LDS tile
-constexpr int kWgradMaxPairsPerThread = 16;
+struct LinArgs {
+  const float* x; int64_t ldx;
+  const float* w; const float* b; const float* rowscale;
+  float* y; int64_t ldy;
+  int64_t N; int I; int O; int act; int accumulate;
+};
 
-__global__ __launch_bounds__(kBlock) void wgrad_partial_kernel(const float* __restrict__ gy, int64_t ldgy,
-                                                               const float* __restrict__ x, int64_t ldx,
-                                                               float* __restrict__ partial, int64_t N, int I, int O) {
-  extern __shared__ float tile[];  // gy tile [T][O] then x tile [T][I+1] (last column = 1 for the bias)
-  float* gy_t = tile;
-  float* x_t = tile + kWgradTile * O;
-  const int I1 = I + 1;
-  const int pairs = O * I1;
-  const int pair0 = blockIdx.y * kBlock * kWgradMaxPairsPerThread;  // this block's slice of the (o,i) pairs
-  float acc[kWgradMaxPairsPerThread];
+// ---------------------------------------------------------------------------------------------- forward
+// One wave owns row tiles t, t + W, ... (W = waves in the grid) and OBT blocks of 16 outputs.
+// KS = ceil(I / 4) k-steps; the W fragments of all k-steps are loaded once per wave.
+template <int OBT, int KS, bool TRANSPOSED>
+__global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kBlock) >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ob0 = blockIdx.y * OBT;
+
+  float wf[OBT][KS];
 #pragma unroll
-  for (int q = 0; q < kWgradMaxPairsPerThread; ++q) acc[q] = 0.f;
-
-  const int64_t n_tiles = ceil_div(N, kWgradTile);
-  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
-    const int64_t r0 = tl * kWgradTile;
-    const int rows = (int)min((int64_t)kWgradTile, N - r0);
-    __syncthreads();
-    for (int p = threadIdx.x; p < rows * O; p += kBlock) gy_t[p] = gy[(r0 + p / O) * ldgy + p % O];
-    for (int p = threadIdx.x; p < rows * I1; p += kBlock) {
-      const int r = p / I1, k = p % I1;
-      x_t[p] = k < I ? x[(r0 + r) * ldx + k] : 1.f;
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o = (ob0 + ob) * 16 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = ks * 4 + lq;
+      float v = 0.f;
+      if (o < a.O && k < a.I) v = TRANSPOSED ? a.w[(int64_t)k * a.O + o] : a.w[(int64_t)o * a.I + k];
+      wf[ob][ks] = v;
     }
-    __syncthreads();
+  }
+  float bias[OBT];
 #pragma unroll
-    for (int q = 0; q < kWgradMaxPairsPerThread; ++q) {
-      const int p = pair0 + threadIdx.x + q * kBlock;
-      if (p < pairs) {
-        const int o = p / I1, k = p % I1;
-        float s = acc[q];
-        for (int r = 0; r < rows; ++r) s = fmaf(gy_t[r * O + o], x_t[r * I1 + k], s);
-        acc[q] = s;
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o = (ob0 + ob) * 16 + lr;
+    bias[ob] = (a.b && o < a.O) ? a.b[o] : 0.f;
+  }
+
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    const int64_t n0 = t * 16;
+    const int64_t arow = n0 + lr;
+    const bool row_ok = arow < a.N;
+    const float* __restrict__ xr = a.x + arow * a.ldx + lq;
+    float af[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[ks] = (row_ok && ks * 4 + lq < a.I) ? xr[ks * 4] : 0.f;
+    f32x4 acc[OBT];
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob) acc[ob] = mfma16x16x4(af[ks], wf[ob][ks], acc[ob]);
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) {
+      const int o = (ob0 + ob) * 16 + lr;
+      if (o >= a.O) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = n0 + lq * 4 + r;
+        if (row >= a.N) continue;
+        float v = acc[ob][r] + bias[ob];
+        if (a.rowscale) v *= a.rowscale[row];
+        if (a.act & 1) v = fmaxf(v, 0.f);
+        float* dst = a.y + row * a.ldy + o;
+        *dst = a.accumulate ? *dst + v : v;
       }
     }
   }
-#pragma unroll
-  for (int q = 0; q < kWgradMaxPairsPerThread; ++q) {
-    const int p = pair0 + threadIdx.x + q * kBlock;
-    if (p < pairs) partial[(int64_t)blockIdx.x * pairs + p] = acc[q];
+}
+
+// Generic fallback (any I, O that fits LDS): thread per (row, output), W in LDS.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a) {
+  extern __shared__ float w_lds[];  // [O][I|1]: odd row stride -> conflict-free across o
+  const int stride = a.I | 1;
+  for (int p = threadIdx.x; p < a.O * a.I; p += kBlock) {
+    const int o = TRANSPOSED ? p % a.O : p / a.I;
+    const int k = TRANSPOSED ? p / a.O : p % a.I;
+    w_lds[o * stride + k] = a.w[p];
+  }
+  __syncthreads();
+  const int64_t total = a.N * a.O;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = t / a.O;
+    const int o = (int)(t - row * a.O);
+    const float* __restrict__ xr = a.x + row * a.ldx;
+    const float* wr = w_lds + o * stride;
+    float acc = 0.f;  // one k-ordered chain, the same summation order as the MFMA path
+    for (int k = 0; k < a.I; ++k) acc = fmaf(xr[k], wr[k], acc);
+    float r = acc + (a.b ? a.b[o] : 0.f);
+    if (a.rowscale) r *= a.rowscale[row];
+    if (a.act & 1) r = fmaxf(r, 0.f);
+    float* dst = a.y + row * a.ldy + o;
+    *dst = a.accumulate ? *dst + r : r;
   }
 }
 
-// Stage 2: fixed-order sum over the G partials (deterministic), scattered to gw / gb.
+// ------------------------------------------------------------------------------------------ weight gradient
+struct WgradArgs {
+  const float* gy; int64_t ldgy;
+  const float* x; int64_t ldx;
+  float* partial;          // [gridDim.x][O * (I + 1)]
+  int64_t N; int I; int O;
+};
+
+constexpr int kWgradUnroll = 4;  // MFMA k-steps (of 4 rows) whose loads are issued together
+
+template <int OBT, int IBT>
+__global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
+  __shared__ f32x4 s_acc[4][OBT * IBT][kWave];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wid;
+  const int n_waves = gridDim.x * 4;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int I1 = a.I + 1;
+  const int n_ib = (int)ceil_div(ceil_div(I1, 16), IBT);
+  const int ob0 = (blockIdx.y / n_ib) * OBT, ib0 = (blockIdx.y % n_ib) * IBT;
+
+  f32x4 acc[OBT][IBT];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t rows_per_iter = 4 * kWgradUnroll;
+  const int64_t n_iters = ceil_div(a.N, rows_per_iter);
+  for (int64_t it = wave; it < n_iters; it += n_waves) {
+    float af[kWgradUnroll][OBT], bf[kWgradUnroll][IBT];
+#pragma unroll
+    for (int u = 0; u < kWgradUnroll; ++u) {
+      const int64_t n = it * rows_per_iter + u * 4 + lq;
+      const bool ok = n < a.N;
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob) {
+        const int o = (ob0 + ob) * 16 + lr;
+        af[u][ob] = (ok && o < a.O) ? a.gy[n * a.ldgy + o] : 0.f;
+      }
+#pragma unroll
+      for (int ib = 0; ib < IBT; ++ib) {
+        const int i = (ib0 + ib) * 16 + lr;
+        float v = 0.f;
+        if (ok) v = i < a.I ? a.x[n * a.ldx + i] : (i == a.I ? 1.f : 0.f);  // column I: ones -> bias gradient
+        bf[u][ib] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kWgradUnroll; ++u)
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+        for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = mfma16x16x4(af[u][ob], bf[u][ib], acc[ob][ib]);
+  }
+  // the four waves of the block add up through LDS in a fixed order
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IBT; ++ib) s_acc[wid][ob * IBT + ib][lane] = acc[ob][ib];
+  __syncthreads();
+  if (wid == 0) {
+    float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * a.O * I1;
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < IBT; ++ib) {
+        f32x4 t = s_acc[0][ob * IBT + ib][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t += s_acc[w][ob * IBT + ib][lane];
+        const int i = (ib0 + ib) * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (ob0 + ob) * 16 + lq * 4 + r;
+          if (o < a.O && i < I1) dst[o * I1 + i] = t[r];
+        }
+      }
+  }
+}
+
+// Stage 2: fixed-order sum over the G partials.  Block = 32 (o,i) pairs x 8 slices of the G range.
 __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ partial, int G, int I, int O,
                                                               float* __restrict__ gw, float* __restrict__ gb,
                                                               int accumulate) {
-  const int I1 = I + 1;
-  const int p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= O * I1) return;
-  float s = 0.f;
-  for (int g = 0; g < G; ++g) s += partial[(int64_t)g * O * I1 + p];
-  const int o = p / I1, k = p % I1;
-  if (k < I) {
-    float* d = gw + o * I + k;
-    *d = accumulate ? *d + s : s;
-  } else if (gb) {
-    gb[o] = accumulate ? gb[o] + s : s;
+  __shared__ float s[8][32];
+  const int I1 = I + 1, pairs = O * I1;
+  const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int p = blockIdx.x * 32 + pl;
+  float t = 0.f;
+  if (p < pairs) {
+    const int per = (G + 7) / 8;
+    const int g1 = min(G, (sl + 1) * per);
+    for (int g = sl * per; g < g1; ++g) t += partial[(int64_t)g * pairs + p];
+  }
+  s[sl][pl] = t;
+  __syncthreads();
+  if (sl == 0 && p < pairs) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += s[k][pl];
+    const int o = p / I1, k = p % I1;
+    if (k < I) {
+      float* d = gw + o * I + k;
+      *d = accumulate ? *d + tot : tot;
+    } else if (gb) {
+      gb[o] = accumulate ? gb[o] + tot : tot;
+    }
   }
 }
 
 constexpr int kWgradBlocks = 512;
 
+template <int OBT, bool TRANSPOSED>
+static void launch_linear_mfma(const LinArgs& a, int ks, dim3 grid, hipStream_t s) {
+  switch (ks) {
+#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_mfma_kernel<OBT, K, TRANSPOSED>), grid, dim3(kBlock), 0, s, a); break;
+    MLQEM_CASE(1) MLQEM_CASE(2) MLQEM_CASE(3) MLQEM_CASE(4) MLQEM_CASE(6) MLQEM_CASE(8) MLQEM_CASE(12) MLQEM_CASE(16)
+    MLQEM_CASE(20) MLQEM_CASE(24) MLQEM_CASE(32)
+#undef MLQEM_CASE
+  }
+}
+
+static int round_ks(int ks) {
+  const int opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 32};
+  for (int o : opts) if (ks <= o) return o;
+  return -1;
+}
+
 }  // namespace mlqem
 
 using namespace mlqem;
 
-extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, float* y,
-                                int64_t ldy, int64_t N, int I, int O, int act, int accumulate, mlqem_stream_t stream) {
+extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
+                                const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act,
+                                int accumulate, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!x || !w || !y) return MLQEM_ERR_BAD_ARG;
+  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate};
+  hipStream_t s = as_stream(stream);
+  const int ks = round_ks((I + 3) / 4);
+  if (ks > 0 && N >= 16) {
+    const int ob = (O + 15) / 16;
+    const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : 4);
+    const int64_t tiles = ceil_div(N, 16);
+    const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8);  // 4 waves per block
+    dim3 grid(gx, (unsigned)ceil_div(ob, obt));
+    if (obt == 1) transposed ? launch_linear_mfma<1, true>(a, ks, grid, s) : launch_linear_mfma<1, false>(a, ks, grid, s);
+    else if (obt == 2) transposed ? launch_linear_mfma<2, true>(a, ks, grid, s) : launch_linear_mfma<2, false>(a, ks, grid, s);
+    else transposed ? launch_linear_mfma<4, true>(a, ks, grid, s) : launch_linear_mfma<4, false>(a, ks, grid, s);
+    return launch_status();
+  }
   const size_t lds = (size_t)O * (I | 1) * sizeof(float);
   if (lds > 64 * 1024) return MLQEM_ERR_UNSUPPORTED;
   const int64_t blocks = std::min<int64_t>(ceil_div(N * O, kBlock), 256 * 16);
   if (transposed)
-    hipLaunchKernelGGL(linear_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, as_stream(stream), x, ldx, w, b,
-                       y, ldy, N, I, O, act, accumulate);
+    hipLaunchKernelGGL(linear_scalar_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, s, a);
   else
-    hipLaunchKernelGGL(linear_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, as_stream(stream), x, ldx, w, b,
-                       y, ldy, N, I, O, act, accumulate);
+    hipLaunchKernelGGL(linear_scalar_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, s, a);
   return launch_status();
 }
 
@@ -138,16 +288,23 @@ extern "C" int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float
                                       mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || !gw || ldgy < O || ldx < I) return MLQEM_ERR_BAD_ARG;
-  const size_t lds = (size_t)kWgradTile * (O + I + 1) * sizeof(float);
-  if (lds > 64 * 1024) return MLQEM_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, O)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && (!gy || !x)) return MLQEM_ERR_BAD_ARG;
-  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(N, kWgradTile)));
+  const int64_t iters = ceil_div(std::max<int64_t>(N, 1), 4 * kWgradUnroll);
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
   float* partial = static_cast<float*>(workspace);
-  const int slices = (int)ceil_div(O * (I + 1), kBlock * kWgradMaxPairsPerThread);
-  hipLaunchKernelGGL(wgrad_partial_kernel, dim3(G, slices), dim3(kBlock), lds, as_stream(stream), gy, ldgy, x, ldx,
-                     partial, N, I, O);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), partial, G, I, O, gw, gb, accumulate);
+  WgradArgs a{gy, ldgy, x, ldx, partial, N, I, O};
+  const int ob = (O + 15) / 16, ib = (I + 1 + 15) / 16;
+  hipStream_t s = as_stream(stream);
+  if (ob == 1 && ib <= 2) {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+  } else if (ob == 1) {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<2, 4>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4))), dim3(kBlock),
+                       0, s, a);
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), 32)), dim3(kBlock), 0, s, partial, G, I,
+                     O, gw, gb, accumulate);
   return launch_status();
 }
