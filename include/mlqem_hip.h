@@ -74,18 +74,25 @@ int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, const int32
  *   out[i,:] = act( alpha * agg[i,:] + beta * z[i,:] + bias[:] )
  *
  * cscale / rscale / dself / z / bias may be NULL (meaning 1 / 1 / 0 / absent / absent).
+ * ell (optional, [N,2] int32 from mlqem_ell_from_csr for the SAME ptr/idx): the first two col[] entries of every
+ * row, (-1 = no such edge, bit 31 of the first = row continues in col[]).  With it the row pointer -> col -> source
+ * row dependent chain of the CSR walk shortens to ell -> source row for the 99.8 % of circuit-graph rows that have
+ * at most two in-edges; rows with more fall back to ptr/idx, so the result is identical with or without it.
  * act: bit 0 = ReLU; drop_p > 0 applies inverted dropout after the ReLU with a counter-based generator keyed by
  * (seed, element index).  Algorithmic bytes per call: 4(N+1) + 4E + 4N + 4C(E+N)  (SURVEY.md section 8d).
  * ---------------------------------------------------------------------------------------------------- */
-int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
+int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
                             const float* cscale, const float* rscale, const float* dself, float alpha, float beta,
                             const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
                             float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
 
 /* Segment max with the node itself included: out[i,:] = max(x[i,:], max_e x[idx[e],:])
  * (ASAPooling's scatter(..., reduce='max') after add_remaining_self_loops; docs/tutorials/gnn.py:85,92). */
-int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, float* out,
-                              int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
+int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
+                              float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
+
+/* ell[i] = (col[ptr[i]], col[ptr[i]+1]) with the conventions above; ell: [N,2] int32, 8-byte aligned. */
+int mlqem_ell_from_csr(const int32_t* ptr, const int32_t* idx, int64_t N, int32_t* ell, mlqem_stream_t stream);
 
 /* gx = (y > 0) ? g * scale : 0  -- backward of ReLU followed by inverted dropout, recovered from the output y. */
 int mlqem_relu_dropout_bwd_f32(const float* g, const float* y, float scale, float* gx, int64_t n,
@@ -129,13 +136,14 @@ int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph
  * and the CSR arrays of mlqem_csr_build run over the whole arena (global node ids).
  * Selection: sel[B] graph ids (repeats allowed); b_nptr[B+1] / b_eptr[B+1] = prefix sums of the selected graphs'
  * node / edge counts (host knows them without a sync); Nb = b_nptr[B], Eb = b_eptr[B].
- * Outputs: the batch's x, nscal, both CSR structures (node ids rebased to the batch) and loops.
+ * Outputs: the batch's x, nscal, src_node[Nb] (arena row of every batch node), both CSR structures (node ids
+ * rebased to the batch) and loops.
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K, const int32_t* a_gptr,
                          const int32_t* a_in_ptr, const int32_t* a_in_src, const int32_t* a_out_ptr,
                          const int32_t* a_out_dst, const int32_t* a_loops, const int32_t* sel, const int32_t* b_nptr,
                          const int32_t* b_eptr, int64_t B, int64_t Nb, int64_t Eb, float* xb, int64_t ldxb,
-                         float* nscal_b, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
+                         float* nscal_b, int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
                          int32_t* loops_b, mlqem_stream_t stream);
 
 #ifdef __cplusplus

@@ -99,13 +99,13 @@ class GraphArena:
         xb = torch.empty((nb, f), dtype=torch.float32, device=dev)
         nscal_b = torch.empty((nb, 3), dtype=torch.float32, device=dev)
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        in_ptr, out_ptr, loops = mk(nb + 1), mk(nb + 1), mk(nb)
+        in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
         in_src, out_dst = mk(eb), mk(eb)
         p = ops._p
         code = _lib.load().mlqem_batch_assemble(
             p(self.x), self.x.stride(0), f, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
             p(self.out_ptr), p(self.out_dst), p(self.loops), p(sel_d), p(nptr_d), p(eptr_d), b, nb, eb,
-            p(xb), f, p(nscal_b), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(loops), ops._stream())
+            p(xb), f, p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(loops), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[:, 0].contiguous(), nscal_b[:, 1].contiguous(), nscal_b[:, 2].contiguous())
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms)

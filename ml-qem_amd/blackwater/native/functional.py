@@ -14,7 +14,7 @@ class _CsrAggregate(Function):
     @staticmethod
     def forward(ctx, x, z, bias, struct: GraphStructure, cscale, rscale, dself, alpha, beta, relu, drop_p, seed):
         x = x.contiguous()
-        y = ops.csr_aggregate(x, struct.in_ptr, struct.in_src, cscale=cscale, rscale=rscale, dself=dself, alpha=alpha,
+        y = ops.csr_aggregate(x, struct.in_ptr, struct.in_src, ell=struct.in_ell, cscale=cscale, rscale=rscale, dself=dself, alpha=alpha,
                               z=z, beta=beta, bias=bias, relu=relu, drop_p=drop_p, seed=seed)
         ctx.struct, ctx.scales = struct, (cscale, rscale, dself)
         ctx.alpha, ctx.beta, ctx.relu, ctx.drop_p = alpha, beta, relu, drop_p
@@ -32,7 +32,7 @@ class _CsrAggregate(Function):
         s = ctx.struct
         gx = gz = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.csr_aggregate(g, s.out_ptr, s.out_dst, cscale=rscale, rscale=cscale, dself=dself, alpha=ctx.alpha)
+            gx = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=rscale, rscale=cscale, dself=dself, alpha=ctx.alpha)
         if ctx.has_z and ctx.needs_input_grad[1]:
             gz = g * ctx.beta
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -75,6 +75,46 @@ def linear(x, w, b=None, relu=False):
     lead = x.shape[:-1]
     y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b, relu)
     return y.reshape(*lead, w.shape[0])
+
+
+class _GCNLayer(Function):
+    """y = act(D^-1/2 (A+I) D^-1/2 (x W^T) + b) as ONE autograd node.
+
+    Forward: the projection writes h' = dinv * (x W^T) (row scale fused in the GEMM epilogue), so the aggregation
+    needs no per-edge scalar: y = act(dinv * (sum_e h'[src_e] + h'[i]) + b).  Backward: ReLU/dropout mask from y,
+    then the same symmetric-normalised aggregation on the transposed CSR, then the two GEMM gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed):
+        x = x.contiguous()
+        dinv = struct.gcn_dinv
+        h = ops.linear(x, w.contiguous(), rowscale=dinv)
+        y = ops.csr_aggregate(h, struct.in_ptr, struct.in_src, ell=struct.in_ell, rscale=dinv, dself=dinv, bias=bias, relu=relu,
+                              drop_p=drop_p, seed=seed)
+        ctx.struct, ctx.relu, ctx.drop_p = struct, relu, drop_p
+        ctx.save_for_backward(x, w, y if (relu or drop_p > 0) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        s = ctx.struct
+        g = g.contiguous()
+        if y is not None:
+            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        gb = g.sum(0) if ctx.needs_input_grad[2] else None
+        gh = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.gcn_dinv, rscale=s.gcn_dinv,
+                               dself=s.derived("gcn_dself"))
+        gx = ops.linear(gh, w.contiguous(), transposed=True) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w, memory_format=torch.contiguous_format)
+            ops.linear_wgrad(gh, x, gw, None)
+        return gx, gw, gb, None, None, None, None
+
+
+def gcn_layer(x, w, bias, struct, relu=False, drop_p=0.0, seed=0):
+    return _GCNLayer.apply(x, w, bias, struct, relu, drop_p, seed)
 
 
 class _SegmentMean(Function):

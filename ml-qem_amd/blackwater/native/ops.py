@@ -39,13 +39,14 @@ def _vec(t: Optional[torch.Tensor], name: str, n: int, dtype=torch.float32):
                          f"{tuple(t.shape)} {t.dtype} {t.device}")
 
 
-def csr_aggregate(x, ptr, idx, *, cscale=None, rscale=None, dself=None, alpha=1.0, z=None, beta=0.0, bias=None,
+def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None, alpha=1.0, z=None, beta=0.0, bias=None,
                   relu=False, drop_p=0.0, seed=0, out=None):
     """out = act(alpha * (rscale * sum_e cscale[idx[e]] x[idx[e]] + dself * x) + beta * z + bias)."""
     n, c = x.shape
     ldx = _mat(x, "x")
     _vec(ptr, "ptr", n + 1, torch.int32)
     _vec(idx, "idx", 0, torch.int32)
+    _ell(ell, n)
     for nm, v in (("cscale", cscale), ("rscale", rscale), ("dself", dself)):
         _vec(v, nm, n)
     _vec(bias, "bias", c)
@@ -58,20 +59,37 @@ def csr_aggregate(x, ptr, idx, *, cscale=None, rscale=None, dself=None, alpha=1.
             raise ValueError("z must have the shape of x")
         ldz = _mat(z, "z")
     code = _lib.load().mlqem_csr_aggregate_f32(
-        _p(x), ldx, _p(ptr), _p(idx), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
+        _p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
         _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), ldo, n, c, _stream())
     _lib.check(code, "mlqem_csr_aggregate_f32")
     return out
 
 
-def csr_segment_max(x, ptr, idx, out=None):
+def _ell(ell, n):
+    if ell is None:
+        return
+    if (not ell.is_cuda or ell.dtype != torch.int32 or ell.dim() != 2 or ell.shape[1] != 2 or ell.shape[0] < n
+            or not ell.is_contiguous()):
+        raise ValueError("ell must be a contiguous [N,2] int32 cuda tensor")
+
+
+def ell_from_csr(ptr, idx, num_nodes):
+    ell = torch.empty((max(num_nodes, 1), 2), dtype=torch.int32, device=ptr.device)
+    code = _lib.load().mlqem_ell_from_csr(_p(ptr), _p(idx), num_nodes, _p(ell), _stream())
+    _lib.check(code, "mlqem_ell_from_csr")
+    return ell
+
+
+def csr_segment_max(x, ptr, idx, ell=None, out=None):
     n, c = x.shape
     ldx = _mat(x, "x")
     _vec(ptr, "ptr", n + 1, torch.int32)
     _vec(idx, "idx", 0, torch.int32)
+    _ell(ell, n)
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    code = _lib.load().mlqem_csr_segment_max_f32(_p(x), ldx, _p(ptr), _p(idx), _p(out), _mat(out, "out"), n, c, _stream())
+    code = _lib.load().mlqem_csr_segment_max_f32(_p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(out), _mat(out, "out"), n, c,
+                                                 _stream())
     _lib.check(code, "mlqem_csr_segment_max_f32")
     return out
 

@@ -21,6 +21,7 @@ class GraphStructure:
         self.num_edges = num_edges  # non-self-loop edges, host int when known without a sync
         self._norms = norms
         self._derived = {}
+        self._ell = {}
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -61,6 +62,20 @@ class GraphStructure:
     @property
     def cheb_dinv(self):
         return self._base_norms()[2]
+
+    @property
+    def in_ell(self):
+        """First two sources of every destination row (fast path of the forward aggregation)."""
+        if "in" not in self._ell:
+            self._ell["in"] = ops.ell_from_csr(self.in_ptr, self.in_src, self.num_nodes)
+        return self._ell["in"]
+
+    @property
+    def out_ell(self):
+        """First two destinations of every source row (fast path of the backward aggregation)."""
+        if "out" not in self._ell:
+            self._ell["out"] = ops.ell_from_csr(self.out_ptr, self.out_dst, self.num_nodes)
+        return self._ell["out"]
 
     def derived(self, key):
         """Per-node scalars derived from the base norms, cached per structure (tiny elementwise torch ops)."""

@@ -52,9 +52,7 @@ class GCNConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
     def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
-        h = F.linear(x, self.lin.weight)
-        return F.csr_aggregate(h, struct, cscale=struct.gcn_dinv, rscale=struct.gcn_dinv,
-                               dself=struct.derived("gcn_dself"), bias=self.bias, relu=relu, drop_p=drop_p, seed=seed)
+        return F.gcn_layer(x, self.lin.weight, self.bias, struct, relu=relu, drop_p=drop_p, seed=seed)
 
 
 class SAGEConv(nn.Module):

@@ -7,17 +7,18 @@
 // consecutive lanes write consecutive addresses of out[] and the lanes of one row read one contiguous source
 // row per edge.
 //   phase 1  the block's slice of rowptr / rscale / dself goes to LDS with coalesced loads
-//   phase 2  the block's slice of col[] (contiguous, because rows are) goes to LDS coalesced, together with the
-//            per-edge source scalar cscale[col[e]]
-//   phase 3  every thread issues, for ALL of its items at once, the loads of the self row and of the first two
-//            source rows (op nodes have in-degree <= 2 except barriers), so 12 independent vector loads per
-//            thread are in flight instead of a ptr -> col -> row dependent chain per row
-//   phase 4  rows with more in-edges finish in a per-item loop; rows above kHeavyDegree (barrier nodes: one
-//            in-edge per qubit) are left to phase 5
-//   phase 5  the whole workgroup splits each heavy row's edges and reduces through LDS
+//   phase 2  every thread reads, for ALL of its items at once, the first two col[] entries of the row (op nodes
+//            have in-degree <= 2 except barriers; consecutive rows own consecutive col[] entries, so a wave reads
+//            one or two cache lines), then issues the loads of the self row and of those two source rows together:
+//            12 independent vector loads per thread are in flight instead of a ptr -> col -> row chain per row
+//   phase 3  rows with more in-edges finish in a per-item loop; rows above kHeavyDegree (barrier nodes: one
+//            in-edge per qubit) are left to phase 4
+//   phase 4  the whole workgroup splits each heavy row's edges and reduces through LDS
 // Blocks are remapped so that every XCD walks one contiguous slice of the rows: op nodes are numbered in
 // program order and an edge joins an op to the next op on the same wire, so the source rows of a tile lie within
 // a few hundred rows of it and are served from that XCD's L2 after the first touch.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mlqem {
@@ -25,6 +26,7 @@ namespace mlqem {
 struct AggArgs {
   const float* x; int64_t ldx;
   const int32_t* ptr; const int32_t* idx;
+  const int32_t* ell;   // optional [N,2]: the first two col[] entries of every row (see csr_aggregate_ell_kernel)
   const float* cscale; const float* rscale; const float* dself;
   float alpha, beta;
   const float* z; int64_t ldz;
@@ -34,9 +36,7 @@ struct AggArgs {
   int64_t N; int C; int CV; int R;
 };
 
-constexpr int kItemsPerThread = 4;
 constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rscale / dself)
-constexpr int kEdgeCap = 2048;       // staged col[] entries per block; a denser tile reads col[] from global
 constexpr int kHeavyDegree = 32;     // rows above this are reduced by the whole block
 constexpr int kHeavyCap = 64;
 
@@ -66,13 +66,11 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
   vstore<VEC>(a.out + row * a.ldo + ch, res);
 }
 
-template <int VEC, bool IS_MAX>
+template <int VEC, bool IS_MAX, int kItemsPerThread>
 __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) {
   __shared__ int s_ptr[kRowsMax + 1];
   __shared__ float s_rs[kRowsMax];
   __shared__ float s_ds[kRowsMax];
-  __shared__ int s_idx[kEdgeCap];
-  __shared__ float s_w[kEdgeCap];
   __shared__ int s_heavy[kHeavyCap];
   __shared__ int s_nheavy;
   __shared__ float s_red[kBlock * VEC];
@@ -91,48 +89,39 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
   }
   if (tid == 0) s_nheavy = 0;
   __syncthreads();
-  const int e0 = s_ptr[0];
-  const int ecount = s_ptr[nrows] - e0;
-  const bool staged = ecount <= kEdgeCap;
-  // ---- phase 2
-  if (staged) {
-    for (int i = tid; i < ecount; i += kBlock) {
-      const int j = a.idx[e0 + i];
-      s_idx[i] = j;
-      s_w[i] = (!IS_MAX && a.cscale) ? a.cscale[j] : 1.f;
-    }
-  }
-  __syncthreads();
-  auto edge_src = [&](int le) { return staged ? s_idx[le] : a.idx[e0 + le]; };
-  auto edge_w = [&](int le, int j) {
-    if (IS_MAX || !a.cscale) return 1.f;
-    return staged ? s_w[le] : a.cscale[j];
-  };
+  const int e0 = 0;  // s_ptr holds absolute positions in col[]
+  auto edge_src = [&](int e) { return a.idx[e]; };
+  auto edge_w = [&](int, int j) { return (IS_MAX || !a.cscale) ? 1.f : a.cscale[j]; };
 
-  // ---- phase 3: first two edges + self row of every item, all loads issued together
+  // ---- phase 2: first two edges + self row of every item, all loads issued together
   const int n_items = nrows * a.CV;
   int rl[kItemsPerThread], ch[kItemsPerThread], beg[kItemsPerThread], deg[kItemsPerThread];
   float acc[kItemsPerThread][VEC], self[kItemsPerThread][VEC];
   float v0[kItemsPerThread][VEC], v1[kItemsPerThread][VEC], w0[kItemsPerThread], w1[kItemsPerThread];
+  int j0[kItemsPerThread], j1[kItemsPerThread];
 #pragma unroll
   for (int k = 0; k < kItemsPerThread; ++k) {
     const int t = k * kBlock + tid;
     const bool live = t < n_items;
     rl[k] = live ? t / a.CV : 0;
     ch[k] = live ? (t - rl[k] * a.CV) * VEC : 0;
-    beg[k] = s_ptr[rl[k]] - e0;
-    deg[k] = live ? s_ptr[rl[k] + 1] - e0 - beg[k] : -1;
-    const int64_t row = r0 + rl[k];
-    const float* __restrict__ xc = a.x + ch[k];
+    beg[k] = s_ptr[rl[k]];
+    deg[k] = live ? s_ptr[rl[k] + 1] - beg[k] : -1;
     // a missing edge reads the row itself (a valid address) with weight 0 / as a no-op for max
     const bool fast = deg[k] <= kHeavyDegree;
-    const int j0 = (fast && deg[k] > 0) ? edge_src(beg[k]) : (int)row;
-    const int j1 = (fast && deg[k] > 1) ? edge_src(beg[k] + 1) : (int)row;
-    w0[k] = (fast && deg[k] > 0) ? edge_w(beg[k], j0) : 0.f;
-    w1[k] = (fast && deg[k] > 1) ? edge_w(beg[k] + 1, j1) : 0.f;
-    vload<VEC>(xc + (int64_t)j0 * a.ldx, v0[k]);
-    vload<VEC>(xc + (int64_t)j1 * a.ldx, v1[k]);
-    if (use_self) vload<VEC>(xc + row * a.ldx, self[k]);
+    const int row = (int)(r0 + rl[k]);
+    j0[k] = (fast && deg[k] > 0) ? a.idx[beg[k]] : row;
+    j1[k] = (fast && deg[k] > 1) ? a.idx[beg[k] + 1] : row;
+  }
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+    const bool fast = deg[k] <= kHeavyDegree;
+    const float* __restrict__ xc = a.x + ch[k];
+    w0[k] = (fast && deg[k] > 0) ? edge_w(0, j0[k]) : 0.f;
+    w1[k] = (fast && deg[k] > 1) ? edge_w(0, j1[k]) : 0.f;
+    vload<VEC>(xc + (int64_t)j0[k] * a.ldx, v0[k]);
+    vload<VEC>(xc + (int64_t)j1[k] * a.ldx, v1[k]);
+    if (use_self) vload<VEC>(xc + (r0 + rl[k]) * a.ldx, self[k]);
   }
 #pragma unroll
   for (int k = 0; k < kItemsPerThread; ++k) {
@@ -149,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
       }
     }
   }
-  // ---- phase 4: remaining edges of medium rows, then the epilogue
+  // ---- phase 3: remaining edges of medium rows, then the epilogue
 #pragma unroll
   for (int k = 0; k < kItemsPerThread; ++k) {
     if (deg[k] < 0) continue;
@@ -172,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
     }
     finish_row<VEC, IS_MAX>(a, row, ch[k], acc[k], self[k], s_rs[rl[k]], s_ds[rl[k]]);
   }
-  // ---- phase 5: heavy rows, one at a time, edges split over kBlock / CV slots
+  // ---- phase 4: heavy rows, one at a time, edges split over kBlock / CV slots
   __syncthreads();
   const int n_heavy = s_nheavy;
   if (n_heavy == 0) return;
@@ -222,6 +211,153 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
   }
 }
 
+// ELL-assisted variant.  `ell[row] = (s0, s1)` repeats the first two col[] entries of the row (-1 = no such
+// edge; bit 31 of s0 set = the row has more than two edges, finish it from the CSR arrays).  On circuit graphs
+// 99.8 % of the rows are complete after (s0, s1), so the row pointer -> col -> source row chain of the CSR walk
+// becomes ell -> source row: one dependent round trip less, no LDS staging and no barrier on the fast path.
+// Items are (row, channel-slice) pairs numbered row-major exactly as above; a workgroup owns kBlock * IPT items.
+constexpr int kEllMore = (int)0x80000000;
+
+template <int VEC, bool IS_MAX, int kItemsPerThread>
+__global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs a) {
+  __shared__ int s_heavy[kHeavyCap];
+  __shared__ int s_nheavy;
+  __shared__ float s_red[kBlock * VEC];
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int64_t t0 = (int64_t)blk * (kBlock * kItemsPerThread);
+  const int64_t n_items = a.N * a.CV;
+  const int tid = threadIdx.x;
+  const bool use_self = IS_MAX || a.dself != nullptr;
+  if (tid == 0) s_nheavy = 0;
+
+  int row[kItemsPerThread], ch[kItemsPerThread];
+  int2 e2[kItemsPerThread];
+  float rs[kItemsPerThread], ds[kItemsPerThread];
+  bool live[kItemsPerThread];
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+    const int64_t t = t0 + k * kBlock + tid;
+    live[k] = t < n_items;
+    const int64_t tt = live[k] ? t : 0;
+    row[k] = (int)(tt / a.CV);
+    ch[k] = (int)(tt - (int64_t)row[k] * a.CV) * VEC;
+    e2[k] = reinterpret_cast<const int2*>(a.ell)[row[k]];
+    rs[k] = a.rscale ? a.rscale[row[k]] : 1.f;
+    ds[k] = a.dself ? a.dself[row[k]] : 0.f;
+  }
+  float acc[kItemsPerThread][VEC], self[kItemsPerThread][VEC];
+  float v0[kItemsPerThread][VEC], v1[kItemsPerThread][VEC], w0[kItemsPerThread], w1[kItemsPerThread];
+  bool more[kItemsPerThread];
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+    more[k] = (e2[k].x & kEllMore) != 0 && e2[k].x != -1;
+    const int s0 = e2[k].x == -1 ? -1 : (e2[k].x & ~kEllMore), s1 = e2[k].y;
+    const int j0 = s0 >= 0 ? s0 : row[k];  // a missing edge reads the row itself with weight 0 / as a no-op for max
+    const int j1 = s1 >= 0 ? s1 : row[k];
+    const float* __restrict__ xc = a.x + ch[k];
+    w0[k] = s0 >= 0 ? ((IS_MAX || !a.cscale) ? 1.f : a.cscale[j0]) : 0.f;
+    w1[k] = s1 >= 0 ? ((IS_MAX || !a.cscale) ? 1.f : a.cscale[j1]) : 0.f;
+    vload<VEC>(xc + (int64_t)j0 * a.ldx, v0[k]);
+    vload<VEC>(xc + (int64_t)j1 * a.ldx, v1[k]);
+    if (use_self) vload<VEC>(xc + (int64_t)row[k] * a.ldx, self[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (!use_self) self[k][v] = 0.f;
+      if (IS_MAX) {
+        float m = self[k][v];
+        if (w0[k] != 0.f) m = fmaxf(m, v0[k][v]);
+        if (w1[k] != 0.f) m = fmaxf(m, v1[k][v]);
+        acc[k][v] = m;
+      } else {
+        acc[k][v] = fmaf(w1[k], v1[k][v], w0[k] * v0[k][v]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) {
+    if (!live[k]) continue;
+    if (more[k]) {  // rare: rows with more than two in-edges walk the CSR arrays from the third edge on
+      const int beg = a.ptr[row[k]], end = a.ptr[row[k] + 1];
+      if (end - beg > kHeavyDegree) {
+        if (ch[k] == 0) {
+          const int slot = atomicAdd(&s_nheavy, 1);
+          if (slot < kHeavyCap) s_heavy[slot] = row[k];
+        }
+        continue;
+      }
+      const float* __restrict__ xc = a.x + ch[k];
+      for (int e = beg + 2; e < end; ++e) {
+        const int j = a.idx[e];
+        const float w = (IS_MAX || !a.cscale) ? 1.f : a.cscale[j];
+        float r[VEC];
+        vload<VEC>(xc + (int64_t)j * a.ldx, r);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
+      }
+    }
+    finish_row<VEC, IS_MAX>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k]);
+  }
+  // heavy rows (barrier nodes): the whole workgroup splits the row's edges and reduces through LDS
+  __syncthreads();
+  const int n_heavy = min(s_nheavy, kHeavyCap);
+  if (n_heavy == 0) return;
+  const int slots = kBlock / a.CV;
+  const int slot = tid / a.CV, hch = (tid - slot * a.CV) * VEC;
+  for (int h = 0; h < n_heavy; ++h) {
+    const int r = s_heavy[h];
+    const int beg = a.ptr[r], end = a.ptr[r + 1];
+    __syncthreads();
+    float part[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? -INFINITY : 0.f;
+    if (slot < slots) {
+      for (int e = beg + slot; e < end; e += slots) {
+        const int j = a.idx[e];
+        const float w = (IS_MAX || !a.cscale) ? 1.f : a.cscale[j];
+        float q[VEC];
+        vload<VEC>(a.x + hch + (int64_t)j * a.ldx, q);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? fmaxf(part[v], q[v]) : fmaf(w, q[v], part[v]);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) s_red[tid * VEC + v] = part[v];
+    }
+    __syncthreads();
+    if (slot == 0) {
+      float tot[VEC], sf[VEC];
+      if (use_self) vload<VEC>(a.x + hch + (int64_t)r * a.ldx, sf);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (!use_self) sf[v] = 0.f;
+        tot[v] = IS_MAX ? sf[v] : 0.f;
+      }
+      for (int sl = 0; sl < slots; ++sl)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float q = s_red[(sl * a.CV + tid) * VEC + v];
+          tot[v] = IS_MAX ? fmaxf(tot[v], q) : tot[v] + q;
+        }
+      finish_row<VEC, IS_MAX>(a, r, hch, tot, sf, a.rscale ? a.rscale[r] : 1.f, a.dself ? a.dself[r] : 0.f);
+    }
+  }
+}
+
+// ell[row] from the CSR arrays (used by mlqem_csr_build and after batch assembly)
+__global__ __launch_bounds__(kBlock) void ell_from_csr_kernel(const int32_t* __restrict__ ptr,
+                                                              const int32_t* __restrict__ idx, int64_t N,
+                                                              int32_t* __restrict__ ell) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const int beg = ptr[i], deg = ptr[i + 1] - beg;
+  int s0 = deg > 0 ? idx[beg] : -1;
+  const int s1 = deg > 1 ? idx[beg + 1] : -1;
+  if (deg > 2) s0 |= kEllMore;
+  reinterpret_cast<int2*>(ell)[i] = make_int2(s0, s1);
+}
+
 template <bool IS_MAX>
 static int launch_aggregate(AggArgs a, hipStream_t stream) {
   if (a.N < 0 || a.C <= 0 || !a.x || !a.ptr || !a.out || a.ldx < a.C || a.ldo < a.C) return MLQEM_ERR_BAD_ARG;
@@ -239,15 +375,32 @@ static int launch_aggregate(AggArgs a, hipStream_t stream) {
   if (ok(4)) vec = 4; else if (ok(2)) vec = 2;
   a.CV = a.C / vec;
   if (a.CV > kBlock) return MLQEM_ERR_UNSUPPORTED;
-  a.R = std::min(kRowsMax, kBlock * kItemsPerThread / a.CV);
+  // items per thread: measured best on MI355X (C = 10 and 22, 2.8M-node batch): 4 for the CSR walk (more loads in
+  // flight per thread outweigh 6 waves/SIMD), 2 for the ELL-assisted kernel (8 waves/SIMD).  MLQEM_AGG_IPT overrides.
+  static const int ipt_env = getenv("MLQEM_AGG_IPT") ? atoi(getenv("MLQEM_AGG_IPT")) : 0;
+  const int ipt = ipt_env > 0 ? ipt_env : (a.ell ? 2 : 4);
+  a.R = std::min(kRowsMax, kBlock * ipt / a.CV);
   const int64_t blocks = ceil_div(a.N, a.R);
   if (blocks > 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
   dim3 grid((unsigned)blocks), block(kBlock);
-  switch (vec) {
-    case 4: hipLaunchKernelGGL((csr_aggregate_kernel<4, IS_MAX>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((csr_aggregate_kernel<2, IS_MAX>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((csr_aggregate_kernel<1, IS_MAX>), grid, block, 0, stream, a); break;
+  if (a.ell) {  // kernel partitions the item space, not the row space
+    const int64_t eblocks = ceil_div(a.N * a.CV, (int64_t)kBlock * ipt);
+    if (eblocks > 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
+    grid = dim3((unsigned)eblocks);
   }
+#define MLQEM_LAUNCH(V, P)                                                                                  \
+  do {                                                                                                      \
+    if (a.ell) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P>), grid, block, 0, stream, a);      \
+    else hipLaunchKernelGGL((csr_aggregate_kernel<V, IS_MAX, P>), grid, block, 0, stream, a);               \
+  } while (0)
+#define MLQEM_BY_IPT(V) do { if (ipt == 1) MLQEM_LAUNCH(V, 1); else if (ipt == 2) MLQEM_LAUNCH(V, 2); else if (ipt == 8) MLQEM_LAUNCH(V, 8); else MLQEM_LAUNCH(V, 4); } while (0)
+  switch (vec) {
+    case 4: MLQEM_BY_IPT(4); break;
+    case 2: MLQEM_BY_IPT(2); break;
+    default: MLQEM_BY_IPT(1); break;
+  }
+#undef MLQEM_BY_IPT
+#undef MLQEM_LAUNCH
   return launch_status();
 }
 
@@ -263,20 +416,20 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* _
 using namespace mlqem;
 
 extern "C" int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
-                                       const float* cscale, const float* rscale, const float* dself, float alpha,
+                                       const int32_t* ell, const float* cscale, const float* rscale, const float* dself, float alpha,
                                        float beta, const float* z, int64_t ldz, const float* bias, int act,
                                        float drop_p, uint64_t seed, float* out, int64_t ldo, int64_t N, int C,
                                        mlqem_stream_t stream) {
   begin_launches();
   if (drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
-  AggArgs a{x, ldx, ptr, idx, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, out, ldo, N, C, 0, 0};
+  AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, out, ldo, N, C, 0, 0};
   return launch_aggregate<false>(a, as_stream(stream));
 }
 
 extern "C" int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
-                                         float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream) {
+                                         const int32_t* ell, float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream) {
   begin_launches();
-  AggArgs a{x, ldx, ptr, idx, nullptr, nullptr, nullptr, 1.f, 0.f, nullptr, 0, nullptr, 0, 0.f, 0, out, ldo, N, C, 0, 0};
+  AggArgs a{x, ldx, ptr, idx, ell, nullptr, nullptr, nullptr, 1.f, 0.f, nullptr, 0, nullptr, 0, 0.f, 0, out, ldo, N, C, 0, 0};
   return launch_aggregate<true>(a, as_stream(stream));
 }
 
@@ -287,5 +440,15 @@ extern "C" int mlqem_relu_dropout_bwd_f32(const float* g, const float* y, float 
   if (n == 0) return MLQEM_OK;
   hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, as_stream(stream),
                      g, y, scale, gx, n);
+  return launch_status();
+}
+
+extern "C" int mlqem_ell_from_csr(const int32_t* ptr, const int32_t* idx, int64_t N, int32_t* ell,
+                                  mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || (N > 0 && (!ptr || !ell))) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  hipLaunchKernelGGL(ell_from_csr_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream), ptr,
+                     idx, N, ell);
   return launch_status();
 }

@@ -83,6 +83,7 @@ struct AssembleArgs {
   const int32_t* sel; const int32_t* b_nptr; const int32_t* b_eptr;
   int B; int64_t Nb; int64_t Eb;
   float* xb; int64_t ldxb; float* nscal_b;
+  int32_t* src_node;   // [Nb] arena row of every batch node (written by the nodes kernel, read by the rows kernel)
   int32_t* in_ptr_b; int32_t* in_src_b; int32_t* out_ptr_b; int32_t* out_dst_b; int32_t* loops_b;
 };
 
@@ -102,8 +103,7 @@ __global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArg
   if (t >= a.Nb * W) return;
   const int32_t i = (int32_t)(t / W);
   const int c = (int)(t - (int64_t)i * W);
-  const int b = find_segment(a.b_nptr, a.B, i);
-  const int64_t gn = (int64_t)a.a_gptr[a.sel[b]] + (i - a.b_nptr[b]);
+  const int64_t gn = a.src_node[i];
   if (c < a.F) a.xb[(int64_t)i * a.ldxb + c] = a.x[gn * a.ldx + c];
   else a.nscal_b[(int64_t)i * a.K + (c - a.F)] = a.nscal[gn * a.K + (c - a.F)];
 }
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleAr
   const int b = find_segment(a.b_nptr, a.B, (int32_t)i);
   const int32_t g0 = a.a_gptr[a.sel[b]];
   const int64_t gn = (int64_t)g0 + (i - a.b_nptr[b]);
+  a.src_node[i] = (int32_t)gn;
   a.in_ptr_b[i] = a.a_in_ptr[gn] - a.a_in_ptr[g0] + a.b_eptr[b];
   a.out_ptr_b[i] = a.a_out_ptr[gn] - a.a_out_ptr[g0] + a.b_eptr[b];
   if (a.loops_b) a.loops_b[i] = a.a_loops[gn];
@@ -200,22 +201,22 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
                                     const int32_t* a_out_ptr, const int32_t* a_out_dst, const int32_t* a_loops,
                                     const int32_t* sel, const int32_t* b_nptr, const int32_t* b_eptr, int64_t B,
                                     int64_t Nb, int64_t Eb, float* xb, int64_t ldxb, float* nscal_b,
-                                    int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
+                                    int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
                                     int32_t* loops_b, mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (B <= 0 || Nb < 0 || Eb < 0 || F <= 0 || K < 0 || ldx < F || ldxb < F) return MLQEM_ERR_BAD_ARG;
   if (B > 0x7fffffff || Nb >= 0x7fffffffLL || Eb >= 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
-  if (!x || !a_gptr || !a_in_ptr || !a_out_ptr || !sel || !b_nptr || !b_eptr || !xb || !in_ptr_b || !out_ptr_b)
+  if (!x || !a_gptr || !a_in_ptr || !a_out_ptr || !sel || !b_nptr || !b_eptr || !xb || !src_node || !in_ptr_b || !out_ptr_b)
     return MLQEM_ERR_BAD_ARG;
   if (K > 0 && (!nscal || !nscal_b)) return MLQEM_ERR_BAD_ARG;
   if (Eb > 0 && (!a_in_src || !a_out_dst || !in_src_b || !out_dst_b)) return MLQEM_ERR_BAD_ARG;
   if (loops_b && !a_loops) return MLQEM_ERR_BAD_ARG;
   AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_loops, sel, b_nptr, b_eptr,
-                 (int)B, Nb, Eb, xb, ldxb, nscal_b, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, loops_b};
+                 (int)B, Nb, Eb, xb, ldxb, nscal_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, loops_b};
+  hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
   if (Nb > 0)
     hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)ceil_div(Nb * (F + K), kBlock)), dim3(kBlock), 0, stream, a);
-  hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
   if (Eb > 0)
     hipLaunchKernelGGL(assemble_edges_kernel, dim3((unsigned)ceil_div(Eb, kBlock)), dim3(kBlock), 0, stream, a);
   return launch_status();

@@ -1,0 +1,83 @@
+"""Device-resident dataset: on-device batch assembly equals the host collate, and a few optimisation steps on the
+GPU follow the CPU oracle's loss trajectory."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import g1_batch, g1_graph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _arena(g1, count, with_host=False):
+    from blackwater.data.arena import GraphArena
+
+    xs, eis = [], []
+    for i in range(count):
+        x, ei, _ = g1_graph(g1, i)
+        n = x.shape[0]
+        loops = np.arange(n)
+        xs.append(x.astype(np.float32))
+        eis.append(np.concatenate([ei, np.stack([loops, loops])], axis=1))  # AddSelfLoops, as the training path
+    host = g1_batch(g1, range(count))
+    arena = GraphArena.from_arrays(xs, eis, host["y"].numpy(), host["noisy"].numpy(), host["depth"].numpy(),
+                                   host["observable"].numpy(), device=DEV)
+    return (arena, host) if with_host else arena
+
+
+def test_batch_assembly_matches_host_collate(g1):
+    from blackwater.native import ops
+
+    arena, all_host = _arena(g1, 120, with_host=True)
+    sel = [5, 119, 0, 5, 64, 33]  # arbitrary order, one repeat
+    b = arena.batch(sel)
+    host = g1_batch(g1, sel)
+    assert torch.equal(b.x.cpu(), host["x"])
+    assert torch.equal(b.noisy_0.cpu(), host["noisy"]) and torch.equal(b.y.cpu(), host["y"])
+    assert torch.equal(b.circuit_depth.cpu(), host["depth"])
+    assert torch.equal(b.observable.cpu(), all_host["observable"][sel])
+    ref = ops.csr_build(host["edge_index"].to(DEV), host["x"].shape[0])
+    s = b.structure
+    m = int(ref[0][-1].item())
+    assert s.num_edges == m
+    for got, want, k in ((s.in_ptr, ref[0], None), (s.in_src, ref[1], m), (s.out_ptr, ref[2], None),
+                         (s.out_dst, ref[3], m), (s.loops, ref[4], None)):
+        assert torch.equal(got[:k] if k else got[: want.numel()], want[:k] if k else want)
+    gcn, sage, cheb = ops.graph_norms(ref[0], ref[2], ref[4], host["x"].shape[0])
+    assert torch.equal(s.gcn_dinv, gcn) and torch.equal(s.sage_rinv, sage) and torch.equal(s.cheb_dinv, cheb)
+    assert s.graph_ptr.cpu().tolist() == np.concatenate([[0], np.cumsum(arena.node_counts[sel])]).tolist()
+
+
+def test_training_steps_follow_the_oracle(g1):
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import Trainer
+    from oracle.models import FamilyA
+
+    arena = _arena(g1, 96)
+    torch.manual_seed(3)
+    model = ExpValCircuitGraphModelA(5, 22, 10)
+    ref = FamilyA(5, 22, 10)
+    ref.load_state_dict(model.state_dict())
+    # dropout off on both sides so that the two trajectories are comparable step by step
+    ref.p_gcn = ref.p_other = 0.0
+    ref.obs_seq[1].p = 0.0
+    model = model.to(DEV)
+    trainer = Trainer(model, lr=1e-3)
+    model.eval()
+    model.train = lambda *a, **k: model  # keep eval() through Trainer.step: the product applies dropout in train mode
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    args = ("noisy", "observable", "depth", "x", "edge_index", "batch")
+    for step in range(5):
+        sel = list(range(step * 16, step * 16 + 32))
+        batch = arena.batch(sel)
+        loss = trainer.step(batch).item()
+        host = g1_batch(g1, sel)
+        host["observable"] = batch.observable.cpu()  # the arena holds the observables drawn for the full list
+        opt.zero_grad()
+        ref_loss = torch.nn.functional.mse_loss(ref(*[host[k] for k in args]), host["y"])
+        ref_loss.backward()
+        opt.step()
+        assert abs(loss - ref_loss.item()) < 2e-4 * max(1.0, abs(ref_loss.item())), (step, loss, ref_loss.item())
+    for (name, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p.detach().cpu(), q.detach(), rtol=2e-3, atol=2e-4), name

@@ -72,6 +72,11 @@ def test_csr_aggregate_matches_dense(c):
     assert torch.allclose(got_relu.cpu().double(), want.clamp(min=0), rtol=1e-5, atol=1e-5)
     plain = ops.csr_aggregate(x.to(DEV), in_ptr, in_src)
     assert torch.allclose(plain.cpu().double(), a @ xd, rtol=1e-5, atol=1e-5)
+    # the ELL-assisted kernel (first two sources per row in a side table) gives the same rows
+    ell = ops.ell_from_csr(in_ptr, in_src, n)
+    fast = ops.csr_aggregate(x.to(DEV), in_ptr, in_src, ell=ell, cscale=cs.to(DEV), rscale=rs.to(DEV),
+                             dself=ds.to(DEV), alpha=1.5, z=z.to(DEV), beta=-0.5, bias=bias.to(DEV))
+    assert torch.allclose(fast.cpu().double(), want, rtol=1e-5, atol=1e-5)
     # strided input (a column slice of a wider matrix) goes through the leading-dimension path
     wide = torch.randn(n, c + 3, generator=g).to(DEV)
     sl = ops.csr_aggregate(wide[:, 1:1 + c], in_ptr, in_src)
@@ -111,6 +116,39 @@ def test_segment_max_includes_self():
             want[d] = torch.maximum(want[d], x[s])
     got = ops.csr_segment_max(x.to(DEV), in_ptr, in_src)
     assert torch.equal(got.cpu(), want)
+    got = ops.csr_segment_max(x.to(DEV), in_ptr, in_src, ell=ops.ell_from_csr(in_ptr, in_src, n))
+    assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("c", [1, 10, 22])
+def test_heavy_rows_barrier_like(c):
+    """Rows with hundreds of in-edges (barrier nodes) take the block-cooperative path; mixed with light rows."""
+    from blackwater.native import ops
+
+    n = 2500
+    g = torch.Generator().manual_seed(11 + c)
+    src, dst = [], []
+    for hub in (7, 300, 301, 1999):  # hub rows with 100..700 in-edges
+        k = 100 + hub % 601
+        src.append(torch.randint(0, n, (k,), generator=g)); dst.append(torch.full((k,), hub))
+    src.append(torch.arange(0, n - 1)); dst.append(torch.arange(1, n))  # a chain: in-degree 1 elsewhere
+    src.append(torch.randint(0, n, (40,), generator=g)); dst.append(torch.full((40,), 55))  # just above 32
+    ei = torch.stack([torch.cat(src), torch.cat(dst)])
+    in_ptr, in_src, *_ = ops.csr_build(ei.to(DEV), n)
+    x = torch.randn(n, c, generator=g)
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((ei[1], ei[0]), torch.ones(ei.shape[1], dtype=torch.float64), accumulate=True)
+    a.fill_diagonal_(0)
+    want = a @ x.double()
+    for ell in (None, ops.ell_from_csr(in_ptr, in_src, n)):
+        got = ops.csr_aggregate(x.to(DEV), in_ptr, in_src, ell=ell)
+        assert torch.allclose(got.cpu().double(), want, rtol=1e-5, atol=1e-4)
+        mx = ops.csr_segment_max(x.to(DEV), in_ptr, in_src, ell=ell)
+        ref = x.clone()
+        for s_, d_ in ei.t().tolist():
+            if s_ != d_:
+                ref[d_] = torch.maximum(ref[d_], x[s_])
+        assert torch.equal(mx.cpu(), ref)
 
 
 @pytest.mark.parametrize("n,i,o", [(1, 22, 10), (1000, 22, 45), (777, 45, 30), (64, 35, 15), (5000, 10, 1), (333, 125, 125)])
