@@ -146,6 +146,57 @@ int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal,
                          float* nscal_b, int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
                          int32_t* loops_b, mlqem_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Family B (docs/tutorials/gnn.py:70-276): TransformerConv attention and ASAPooling.  Forward kernels.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* TransformerConv(heads=H, concat=True, beta=False, edge_dim=None, root_weight=True) message + aggregate + skip
+ * (gnn.py:80-91,104,109).  qkvs[N, 4*H*C] = [query | key | value | skip] from ONE fused projection.
+ * out[i, h*C:(h+1)*C] = sum_e softmax_e( q_i.k_src / sqrt(C) ) v_src + skip_i ; softmax over the CSR in-edges of i
+ * followed by loops[i] copies of the self-loop (loops may be NULL); denominator + 1e-16 as in PyG.  C <= 32. */
+int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
+                                    const int32_t* loops, int64_t N, int H, int C, float* out, int64_t ldo,
+                                    mlqem_stream_t stream);
+
+/* ASAPooling steps 3-4 (gnn.py:85,92): out[i,:] = sum_e softmax_e(LeakyReLU(a_dst[i] + c_src[src_e])) x[src_e,:]
+ * over the CSR in-edges of i plus its own self-loop (add_remaining_self_loops). */
+int mlqem_csr_softmax_aggregate_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src,
+                                    const float* a_dst, const float* c_src, float negative_slope, int64_t N, int C,
+                                    float* out, int64_t ldo, mlqem_stream_t stream);
+
+/* ASAPooling step 5, LEConv(D->1) + sigmoid on per-node scalars pqr[N,3] = (lin1 x', lin2 x', lin3 x'):
+ * fitness[i] = sigmoid( sum_{e in in(i) + self} (p[src_e] - q[i]) + r[i] ). */
+int mlqem_leconv_fitness_f32(const float* pqr, const int32_t* in_ptr, const int32_t* in_src, int64_t N,
+                             float* fitness, mlqem_stream_t stream);
+
+/* out[p,:] = x[perm[p],:] * scale[perm[p]]  (x_out = x'[perm] * fitness[perm]; scale may be NULL). */
+int mlqem_gather_scale_rows_f32(const float* x, int64_t ldx, const int32_t* perm, const float* scale, int64_t K, int C,
+                                float* out, int64_t ldo, mlqem_stream_t stream);
+
+/* ASAPooling step 6 (PyG topk(fitness, ratio, batch)): for graph g keep its new_graph_ptr[g+1]-new_graph_ptr[g]
+ * nodes of largest fitness, listed by descending fitness (ties: lower index first), graphs in order. */
+size_t mlqem_segment_topk_workspace_bytes(int64_t N, int64_t B);
+int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr, const int32_t* new_graph_ptr, int64_t N,
+                       int64_t B, int64_t K, int32_t* perm, void* workspace, size_t workspace_bytes,
+                       mlqem_stream_t stream);
+
+/* ASAPooling step 7 (torch-sparse S^T A S, remove_diag, coo): only the PATTERN is consumed by the models.
+ * count: slot[N] (cluster id of each kept node, -1 elsewhere), offsets[K+1] (exclusive scan of candidate pairs per
+ * cluster; offsets[K] = total T, read back by the caller).  fill: keys[T] = p << 32 | q, duplicates included.
+ * sort_unique: ascending distinct keys + their number (device int64).  keys_to_edge_index: [2,E] int64 (src=p, dst=q),
+ * i.e. row-major (p,q) order as SparseTensor.coo() returns it; feed it to mlqem_csr_build. */
+size_t mlqem_asap_coarsen_workspace_bytes(int64_t K);
+int mlqem_asap_coarsen_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                             const int32_t* out_dst, const int32_t* perm, int64_t N, int64_t K, int32_t* slot,
+                             int64_t* offsets, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_asap_coarsen_fill(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                            const int32_t* out_dst, const int32_t* perm, const int32_t* slot, const int64_t* offsets,
+                            int64_t K, uint64_t* keys, mlqem_stream_t stream);
+size_t mlqem_sort_unique_u64_workspace_bytes(int64_t T);
+int mlqem_sort_unique_u64(const uint64_t* keys, int64_t T, uint64_t* out_keys, int64_t* out_count, void* workspace,
+                          size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t* edge_index, mlqem_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

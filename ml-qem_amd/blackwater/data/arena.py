@@ -108,6 +108,7 @@ class GraphArena:
             p(xb), f, p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(loops), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[:, 0].contiguous(), nscal_b[:, 1].contiguous(), nscal_b[:, 2].contiguous())
-        s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms)
+        s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,
+                           graph_sizes=self.node_counts[sel])
         idx = sel_d.to(torch.int64)
         return DeviceBatch(xb, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)

@@ -38,6 +38,18 @@ SIGNATURES = {
     "mlqem_linear_wgrad_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P]),
     "mlqem_segment_mean_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P]),
     "mlqem_segment_mean_bwd_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P]),
+    "mlqem_transformer_attention_f32": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
+    "mlqem_csr_softmax_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _F, _L, _I, _P, _L, _P]),
+    "mlqem_leconv_fitness_f32": (_I, [_P, _P, _P, _L, _P, _P]),
+    "mlqem_gather_scale_rows_f32": (_I, [_P, _L, _P, _P, _L, _I, _P, _L, _P]),
+    "mlqem_segment_topk_workspace_bytes": (_S, [_L, _L]),
+    "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _S, _P]),
+    "mlqem_asap_coarsen_workspace_bytes": (_S, [_L]),
+    "mlqem_asap_coarsen_count": (_I, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _S, _P]),
+    "mlqem_asap_coarsen_fill": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "mlqem_sort_unique_u64_workspace_bytes": (_S, [_L]),
+    "mlqem_sort_unique_u64": (_I, [_P, _L, _P, _P, _P, _S, _P]),
+    "mlqem_keys_to_edge_index": (_I, [_P, _L, _P, _P]),
 }
 
 _lib = None

@@ -131,3 +131,23 @@ class _SegmentMean(Function):
 
 def segment_mean(x, struct):
     return _SegmentMean.apply(x, struct)
+
+
+class _ForwardOnly(Function):
+    """Wraps a forward-only native op so that asking for its gradient fails loudly instead of silently
+    cutting the graph (Family B's backward kernels are the next milestone)."""
+
+    @staticmethod
+    def forward(ctx, fn, name, *tensors):
+        ctx.name = name
+        return fn(*[t.detach() if torch.is_tensor(t) else t for t in tensors])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError(f"{ctx.name}: backward kernel not implemented yet (forward/inference only)")
+
+
+def forward_only(fn, name, *tensors):
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        return _ForwardOnly.apply(fn, name, *tensors)
+    return fn(*tensors)

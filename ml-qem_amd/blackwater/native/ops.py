@@ -193,3 +193,102 @@ def graph_norms(in_ptr, out_ptr, loops, num_nodes):
                                          _stream())
     _lib.check(code, "mlqem_graph_norms")
     return gcn, sage, cheb
+
+
+# ------------------------------------------------------------------------------------------------- Family B
+def transformer_attention(qkvs, in_ptr, in_src, loops, heads, channels):
+    n = qkvs.shape[0]
+    hc = heads * channels
+    if qkvs.shape[1] != 4 * hc:
+        raise ValueError(f"qkvs must be [N, {4 * hc}] (query|key|value|skip), got {tuple(qkvs.shape)}")
+    ld = _mat(qkvs, "qkvs")
+    _vec(in_ptr, "in_ptr", n + 1, torch.int32)
+    _vec(loops, "loops", n, torch.int32)
+    out = torch.empty((n, hc), dtype=torch.float32, device=qkvs.device)
+    code = _lib.load().mlqem_transformer_attention_f32(_p(qkvs), ld, _p(in_ptr), _p(in_src), _p(loops), n, heads,
+                                                       channels, _p(out), _mat(out, "out"), _stream())
+    _lib.check(code, "mlqem_transformer_attention_f32")
+    return out
+
+
+def csr_softmax_aggregate(x, in_ptr, in_src, a_dst, c_src, negative_slope):
+    n, c = x.shape
+    ldx = _mat(x, "x")
+    _vec(in_ptr, "in_ptr", n + 1, torch.int32)
+    _vec(a_dst, "a_dst", n)
+    _vec(c_src, "c_src", n)
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    code = _lib.load().mlqem_csr_softmax_aggregate_f32(_p(x), ldx, _p(in_ptr), _p(in_src), _p(a_dst), _p(c_src),
+                                                       float(negative_slope), n, c, _p(out), _mat(out, "out"),
+                                                       _stream())
+    _lib.check(code, "mlqem_csr_softmax_aggregate_f32")
+    return out
+
+
+def leconv_fitness(pqr, in_ptr, in_src):
+    n = pqr.shape[0]
+    if pqr.shape[1] != 3 or not pqr.is_contiguous() or pqr.dtype != torch.float32 or not pqr.is_cuda:
+        raise ValueError("pqr must be a contiguous [N,3] fp32 cuda tensor")
+    _vec(in_ptr, "in_ptr", n + 1, torch.int32)
+    f = torch.empty(max(n, 1), dtype=torch.float32, device=pqr.device)[:n]
+    code = _lib.load().mlqem_leconv_fitness_f32(_p(pqr), _p(in_ptr), _p(in_src), n, _p(f), _stream())
+    _lib.check(code, "mlqem_leconv_fitness_f32")
+    return f
+
+
+def gather_scale_rows(x, perm, scale=None):
+    k, c = perm.shape[0], x.shape[1]
+    _vec(perm, "perm", k, torch.int32)
+    _vec(scale, "scale", x.shape[0])
+    out = torch.empty((k, c), dtype=torch.float32, device=x.device)
+    code = _lib.load().mlqem_gather_scale_rows_f32(_p(x), _mat(x, "x"), _p(perm), _p(scale), k, c, _p(out),
+                                                   _mat(out, "out"), _stream())
+    _lib.check(code, "mlqem_gather_scale_rows_f32")
+    return out
+
+
+def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_total):
+    _vec(fitness, "fitness", num_nodes)
+    _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
+    _vec(new_graph_ptr, "new_graph_ptr", num_graphs + 1, torch.int32)
+    lib = _lib.load()
+    need = lib.mlqem_segment_topk_workspace_bytes(num_nodes, num_graphs)
+    ws = torch.empty(need, dtype=torch.uint8, device=fitness.device)
+    perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=fitness.device)[:k_total]
+    code = lib.mlqem_segment_topk(_p(fitness), _p(graph_ptr), _p(new_graph_ptr), num_nodes, num_graphs, k_total,
+                                  _p(perm), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_segment_topk")
+    return perm
+
+
+def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes):
+    """Edge list [2,E] int64 (cluster ids, row-major (src,dst) order, no diagonal) of the pooled graph.
+    Two small device->host reads (candidate total, distinct total) size the buffers."""
+    dev = perm.device
+    k = int(perm.shape[0])
+    lib = _lib.load()
+    slot = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=dev)
+    offsets = torch.empty(k + 1, dtype=torch.int64, device=dev)
+    need = lib.mlqem_asap_coarsen_workspace_bytes(k)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    code = lib.mlqem_asap_coarsen_count(_p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst), _p(perm), num_nodes, k,
+                                        _p(slot), _p(offsets), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_asap_coarsen_count")
+    total = int(offsets[k].item())
+    if total == 0:
+        return torch.zeros((2, 0), dtype=torch.int64, device=dev)
+    keys = torch.empty(total, dtype=torch.int64, device=dev)
+    code = lib.mlqem_asap_coarsen_fill(_p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst), _p(perm), _p(slot),
+                                       _p(offsets), k, _p(keys), _stream())
+    _lib.check(code, "mlqem_asap_coarsen_fill")
+    uniq = torch.empty(total, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    need = lib.mlqem_sort_unique_u64_workspace_bytes(total)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    code = lib.mlqem_sort_unique_u64(_p(keys), total, _p(uniq), _p(count), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_sort_unique_u64")
+    e = int(count.item())
+    ei = torch.empty((2, e), dtype=torch.int64, device=dev)
+    code = lib.mlqem_keys_to_edge_index(_p(uniq), e, _p(ei), _stream())
+    _lib.check(code, "mlqem_keys_to_edge_index")
+    return ei

@@ -14,7 +14,7 @@ from . import ops
 
 class GraphStructure:
     def __init__(self, num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs, num_edges=None,
-                 norms=None):
+                 norms=None, graph_sizes=None):
         self.num_nodes = int(num_nodes)
         self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops = in_ptr, in_src, out_ptr, out_dst, loops
         self.graph_ptr, self.num_graphs = graph_ptr, int(num_graphs)
@@ -22,6 +22,7 @@ class GraphStructure:
         self._norms = norms
         self._derived = {}
         self._ell = {}
+        self._graph_sizes = None if graph_sizes is None else [int(v) for v in graph_sizes]
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -34,6 +35,8 @@ class GraphStructure:
             if batch is None:
                 graph_ptr = torch.tensor([0, num_nodes], dtype=torch.int32, device=dev)
                 num_graphs = 1
+                return GraphStructure(num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, 1,
+                                      graph_sizes=[num_nodes])
             else:
                 if num_graphs is None:
                     raise ValueError("num_graphs is required with `batch` (avoids a device sync)")
@@ -44,6 +47,15 @@ class GraphStructure:
             graph_ptr = graph_ptr.to(device=dev, dtype=torch.int32)
             num_graphs = graph_ptr.numel() - 1
         return GraphStructure(num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs)
+
+    @property
+    def graph_sizes(self):
+        """Host-side node count of every graph (pooling needs it to size its output); read back once if the
+        structure was built from a device-side ``batch`` vector."""
+        if self._graph_sizes is None:
+            ptr = self.graph_ptr.cpu().tolist()
+            self._graph_sizes = [b - a for a, b in zip(ptr[:-1], ptr[1:])]
+        return self._graph_sizes
 
     # ------------------------------------------------------------------------------------------------
     def _base_norms(self):

@@ -1,0 +1,183 @@
+// Edge-softmax kernels of Family B (docs/tutorials/gnn.py:70-276): TransformerConv's multi-head attention and
+// ASAPooling's attention-weighted cluster sum.  Both are "softmax over the in-edges of a row, then a weighted sum
+// of source rows"; the softmax statistics of a row are recomputed by each thread that needs them (rows have a
+// handful of in-edges), which keeps the kernels free of cross-lane traffic and of any [E]-sized intermediate.
+#include "common.hpp"
+
+namespace mlqem {
+
+constexpr int kAttnMaxC = 32;  // channels per head held in registers (reference models: 15 and 25)
+
+// TransformerConv (heads=H, concat, root_weight, no edge features).
+// qkvs: [N, 4*H*C] = [query | key | value | skip] as produced by one fused projection.
+// Thread = (row, head).  Edge order: the row's CSR entries, then its self-loop(s) -- the order PyG's scatter sees.
+__global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const float* __restrict__ qkvs, int64_t ld,
+                                                                  const int32_t* __restrict__ ptr,
+                                                                  const int32_t* __restrict__ idx,
+                                                                  const int32_t* __restrict__ loops, int64_t N, int H,
+                                                                  int C, float* __restrict__ out, int64_t ldo) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * H) return;
+  const int64_t row = t / H;
+  const int h = (int)(t - row * H);
+  const int HC = H * C;
+  const float scale = 1.0f / sqrtf((float)C);
+  const float* __restrict__ qi = qkvs + row * ld + h * C;
+  float q[kAttnMaxC];
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c) q[c] = c < C ? qi[c] : 0.f;
+
+  const int beg = ptr[row], end = ptr[row + 1];
+  const int n_self = loops ? loops[row] : 0;
+  auto score = [&](int64_t j) {
+    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kAttnMaxC; ++c)
+      if (c < C) s = fmaf(q[c], kj[c], s);
+    return s * scale;
+  };
+  // pass 1: segment max
+  float m = -INFINITY;
+  for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
+  if (n_self > 0) m = fmaxf(m, score(row));
+  // pass 2: exp, sum, weighted value sum
+  float acc[kAttnMaxC];
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c) acc[c] = 0.f;
+  float denom = 0.f;
+  auto add = [&](int64_t j, float mult) {
+    const float p = expf(score(j) - m) * mult;
+    denom += p;
+    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
+#pragma unroll
+    for (int c = 0; c < kAttnMaxC; ++c)
+      if (c < C) acc[c] = fmaf(p, vj[c], acc[c]);
+  };
+  for (int e = beg; e < end; ++e) add(idx[e], 1.f);
+  if (n_self > 0) add(row, (float)n_self);
+  const float inv = 1.0f / (denom + 1e-16f);
+  const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
+  float* __restrict__ o = out + row * ldo + h * C;
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c)
+    if (c < C) o[c] = acc[c] * inv + skip[c];
+}
+
+// ASAPooling steps 3-4: score_e = LeakyReLU(a[dst] + c[src]), softmax over the in-edges of
+// dst PLUS its own self-loop (add_remaining_self_loops), out[dst] = sum_e score_e * x[src_e].
+// a[i] = att_w[:D] . lin(xq)[i] + att_b and c[j] = att_w[D:] . x[j] are per-node scalars made by the dense kernel.
+// Thread = (row, channel) flattened.
+__global__ __launch_bounds__(kBlock) void softmax_aggregate_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                   const int32_t* __restrict__ ptr,
+                                                                   const int32_t* __restrict__ idx,
+                                                                   const float* __restrict__ a_dst,
+                                                                   const float* __restrict__ c_src, float slope,
+                                                                   int64_t N, int C, float* __restrict__ out,
+                                                                   int64_t ldo) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * C) return;
+  const int64_t row = t / C;
+  const int ch = (int)(t - row * C);
+  const int beg = ptr[row], end = ptr[row + 1];
+  const float ai = a_dst[row];
+  auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  float m = leaky(ai + c_src[row]);  // the self-loop is always there
+  for (int e = beg; e < end; ++e) m = fmaxf(m, leaky(ai + c_src[idx[e]]));
+  float denom = 0.f, acc = 0.f;
+  for (int e = beg; e < end; ++e) {
+    const int j = idx[e];
+    const float p = expf(leaky(ai + c_src[j]) - m);
+    denom += p;
+    acc = fmaf(p, x[(int64_t)j * ldx + ch], acc);
+  }
+  {
+    const float p = expf(leaky(ai + c_src[row]) - m);  // self-loop last, as appended by add_remaining_self_loops
+    denom += p;
+    acc = fmaf(p, x[row * ldx + ch], acc);
+  }
+  // PyG normalises every edge score first (p / (denom + 1e-16)) and then sums the messages
+  out[row * ldo + ch] = acc / (denom + 1e-16f);
+}
+
+// LEConv(D -> 1) fitness of ASAPooling step 5 on per-node scalars pqr[N,3] = (lin1(x') , lin2(x'), lin3(x')):
+// f[i] = sigmoid( sum_{e in in(i)} p[src_e] + p[i] - (deg_i + 1) * q[i] + r[i] ), edges incl. the added self-loop.
+__global__ __launch_bounds__(kBlock) void leconv_fitness_kernel(const float* __restrict__ pqr,
+                                                                const int32_t* __restrict__ ptr,
+                                                                const int32_t* __restrict__ idx, int64_t N,
+                                                                float* __restrict__ fitness) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const int beg = ptr[i], end = ptr[i + 1];
+  const float qi = pqr[i * 3 + 1];
+  float s = 0.f;
+  for (int e = beg; e < end; ++e) s += pqr[(int64_t)idx[e] * 3] - qi;  // message a_j - b_i, summed in edge order
+  s += pqr[i * 3] - qi;                                                 // the self-loop
+  s += pqr[i * 3 + 2];
+  fitness[i] = 1.0f / (1.0f + expf(-s));
+}
+
+// x_out[p,:] = x[perm[p],:] * scale[perm[p]]
+__global__ __launch_bounds__(kBlock) void gather_scale_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                   const int32_t* __restrict__ perm,
+                                                                   const float* __restrict__ scale, int64_t K, int C,
+                                                                   float* __restrict__ out, int64_t ldo) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= K * C) return;
+  const int64_t p = t / C;
+  const int c = (int)(t - p * C);
+  const int64_t j = perm[p];
+  out[p * ldo + c] = x[j * ldx + c] * (scale ? scale[j] : 1.f);
+}
+
+}  // namespace mlqem
+
+using namespace mlqem;
+
+extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
+                                               const int32_t* in_src, const int32_t* loops, int64_t N, int H, int C,
+                                               float* out, int64_t ldo, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldo < H * C) return MLQEM_ERR_BAD_ARG;
+  if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
+  if (N == 0) return MLQEM_OK;
+  if (!qkvs || !in_ptr || !out) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(transformer_attn_kernel, dim3((unsigned)ceil_div(N * H, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), qkvs, ld, in_ptr, in_src, loops, N, H, C, out, ldo);
+  return launch_status();
+}
+
+extern "C" int mlqem_csr_softmax_aggregate_f32(const float* x, int64_t ldx, const int32_t* in_ptr,
+                                               const int32_t* in_src, const float* a_dst, const float* c_src,
+                                               float negative_slope, int64_t N, int C, float* out, int64_t ldo,
+                                               mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C <= 0 || ldx < C || ldo < C) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !in_ptr || !a_dst || !c_src || !out) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(softmax_aggregate_kernel, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), x, ldx, in_ptr, in_src, a_dst, c_src, negative_slope, N, C, out, ldo);
+  return launch_status();
+}
+
+extern "C" int mlqem_leconv_fitness_f32(const float* pqr, const int32_t* in_ptr, const int32_t* in_src, int64_t N,
+                                        float* fitness, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!pqr || !in_ptr || !fitness) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(leconv_fitness_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream),
+                     pqr, in_ptr, in_src, N, fitness);
+  return launch_status();
+}
+
+extern "C" int mlqem_gather_scale_rows_f32(const float* x, int64_t ldx, const int32_t* perm, const float* scale,
+                                           int64_t K, int C, float* out, int64_t ldo, mlqem_stream_t stream) {
+  begin_launches();
+  if (K < 0 || C <= 0 || ldx < C || ldo < C) return MLQEM_ERR_BAD_ARG;
+  if (K == 0) return MLQEM_OK;
+  if (!x || !perm || !out) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gather_scale_rows_kernel, dim3((unsigned)ceil_div(K * C, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), x, ldx, perm, scale, K, C, out, ldo);
+  return launch_status();
+}

@@ -88,23 +88,25 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
   }
 }
 
-// Generic fallback (any I, O that fits LDS): thread per (row, output), W in LDS.
+// Generic fallback (any I; used for I > 128): thread per (row, output); a block stages one chunk of `oc` outputs' weights
+// in LDS (blockIdx.y selects the chunk).
 template <bool TRANSPOSED>
-__global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a) {
-  extern __shared__ float w_lds[];  // [O][I|1]: odd row stride -> conflict-free across o
+__global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a, int oc) {
+  extern __shared__ float w_lds[];  // [oc][I|1]: odd row stride -> conflict-free across o
   const int stride = a.I | 1;
-  for (int p = threadIdx.x; p < a.O * a.I; p += kBlock) {
-    const int o = TRANSPOSED ? p % a.O : p / a.I;
-    const int k = TRANSPOSED ? p / a.O : p % a.I;
-    w_lds[o * stride + k] = a.w[p];
+  const int o0 = blockIdx.y * oc;
+  const int no = min(oc, a.O - o0);
+  for (int p = threadIdx.x; p < no * a.I; p += kBlock) {
+    const int o = p / a.I, k = p % a.I;
+    w_lds[o * stride + k] = TRANSPOSED ? a.w[(int64_t)k * a.O + o0 + o] : a.w[(int64_t)(o0 + o) * a.I + k];
   }
   __syncthreads();
-  const int64_t total = a.N * a.O;
+  const int64_t total = a.N * no;
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
-    const int64_t row = t / a.O;
-    const int o = (int)(t - row * a.O);
+    const int64_t row = t / no;
+    const int ol = (int)(t - row * no), o = o0 + ol;
     const float* __restrict__ xr = a.x + row * a.ldx;
-    const float* wr = w_lds + o * stride;
+    const float* wr = w_lds + ol * stride;
     float acc = 0.f;  // one k-ordered chain, the same summation order as the MFMA path
     for (int k = 0; k < a.I; ++k) acc = fmaf(xr[k], wr[k], acc);
     float r = acc + (a.b ? a.b[o] : 0.f);
@@ -258,7 +260,7 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
   LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate};
   hipStream_t s = as_stream(stream);
   const int ks = round_ks((I + 3) / 4);
-  if (ks > 0 && N >= 16) {
+  if (ks > 0) {
     const int ob = (O + 15) / 16;
     const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : 4);
     const int64_t tiles = ceil_div(N, 16);
@@ -269,13 +271,15 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
     else transposed ? launch_linear_mfma<4, true>(a, ks, grid, s) : launch_linear_mfma<4, false>(a, ks, grid, s);
     return launch_status();
   }
-  const size_t lds = (size_t)O * (I | 1) * sizeof(float);
-  if (lds > 64 * 1024) return MLQEM_ERR_UNSUPPORTED;
-  const int64_t blocks = std::min<int64_t>(ceil_div(N * O, kBlock), 256 * 16);
+  const int oc = (int)std::min<int64_t>(O, (48 * 1024) / ((I | 1) * sizeof(float)));
+  if (oc < 1) return MLQEM_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)oc * (I | 1) * sizeof(float);
+  const int64_t blocks = std::min<int64_t>(ceil_div(N * oc, kBlock), 256 * 16);
+  dim3 grid((unsigned)blocks, (unsigned)ceil_div(O, oc));
   if (transposed)
-    hipLaunchKernelGGL(linear_scalar_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL(linear_scalar_kernel<true>, grid, dim3(kBlock), lds, s, a, oc);
   else
-    hipLaunchKernelGGL(linear_scalar_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL(linear_scalar_kernel<false>, grid, dim3(kBlock), lds, s, a, oc);
   return launch_status();
 }
 

@@ -1,0 +1,214 @@
+"""Family B and the MLP path on the GPU against the reference's goldens and the CPU oracle:
+G1 through the product model AND through the ``ngem`` decorator from QASM text, G2 through the product MLP1 and
+through ``TorchLearningModelProcessor``; kernel-level checks of the attention / pooling pieces."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import G1_GATES_ORDER, g1_batch, g1_graph, mean_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ckpt(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, "ckpt", name), weights_only=True)
+
+
+def _oracle_outputs(sd, g1, idx, dtype=torch.float64):
+    from oracle.models import family_b_from_state_dict
+
+    model = family_b_from_state_dict(sd).to(dtype).eval()
+    outs = []
+    with torch.no_grad():
+        for i in idx:
+            x, ei, _ = g1_graph(g1, i)
+            out = model(torch.tensor(g1["noisy"][i], dtype=torch.float32).to(dtype).view(1, 1, -1), None,
+                        torch.tensor([[float(g1["depth"][i])]], dtype=dtype),
+                        torch.tensor(x, dtype=torch.float32).to(dtype), torch.tensor(ei, dtype=torch.long), None)
+            outs.append(out.numpy().ravel())
+    return np.stack(outs)
+
+
+def _gpu_outputs(model, g1, idx):
+    outs = []
+    with torch.no_grad():
+        for i in idx:
+            x, ei, _ = g1_graph(g1, i)
+            out = model(torch.tensor(g1["noisy"][i], dtype=torch.float32, device=DEV).view(1, 1, -1), None,
+                        torch.tensor([[float(g1["depth"][i])]], device=DEV),
+                        torch.tensor(x, dtype=torch.float32, device=DEV),
+                        torch.tensor(ei, dtype=torch.long, device=DEV), None)
+            outs.append(out.cpu().numpy().ravel())
+    return np.stack(outs)
+
+
+def test_g1_golden_on_gpu(golden_dir, g1):
+    from blackwater.nn import family_b_from_state_dict
+
+    sd = _ckpt(golden_dir, "gnn1.pth")
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    idx = range(300)
+    got = _gpu_outputs(model, g1, idx)
+    assert round(mean_l2(g1["ideal"], got), 6) == 0.117838  # docs/tutorials/h17_compare_over_steps.ipynb:513
+    want = _oracle_outputs(sd, g1, idx)
+    assert np.abs(got - want).max() < 1e-5  # north_star tolerance, per circuit, vs the fp64 oracle
+
+
+@pytest.mark.parametrize("name", ["gnn3_ising.pth", "train_fakelima.pth"])
+def test_other_reference_architectures(golden_dir, g1, name):
+    """Heads 5/3 with the MLP3 head (hidden 25, 103 465 parameters) and the single-output variant."""
+    from blackwater.nn import family_b_from_state_dict
+
+    sd = _ckpt(golden_dir, name)
+    out_size = sd["body_seq.fc4.weight"].shape[0] if "body_seq.fc4.weight" in sd else sd["body_seq.2.weight"].shape[0]
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    sub = dict(g1)
+    sub["noisy"] = g1["noisy"][:, :out_size]
+    idx = range(0, 300, 7)
+    got, want = _gpu_outputs(model, sub, idx), _oracle_outputs(sd, sub, idx)
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_batched_with_self_loops_matches_oracle(golden_dir, g1):
+    """The training-time convention: AddSelfLoops + collate (the attention then includes the self-loop)."""
+    from blackwater.nn import family_b_from_state_dict
+    from oracle.models import family_b_from_state_dict as oracle_from_sd
+
+    sd = _ckpt(golden_dir, "gnn1.pth")
+    batch = g1_batch(g1, range(100, 148), self_loops=True, first_only=False)
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    with torch.no_grad():
+        got = model(batch["noisy"].to(DEV), None, batch["depth"].to(DEV), batch["x"].to(DEV),
+                    batch["edge_index"].to(DEV), batch["batch"].to(DEV))
+        want = oracle_from_sd(sd).double().eval()(batch["noisy"].double(), None, batch["depth"].double(),
+                                                  batch["x"].double(), batch["edge_index"], batch["batch"])
+    assert got.shape == (48, 4)
+    assert (got.cpu().double() - want).abs().max().item() < 1e-5
+
+
+def test_pooling_pieces_match_oracle(golden_dir, g1):
+    """perm (top-k order) and the coarsened edge list are integer outputs: exact match with the oracle."""
+    from blackwater.native.structure import GraphStructure
+    from blackwater.nn import family_b_from_state_dict
+    from oracle.models import family_b_from_state_dict as oracle_from_sd
+
+    sd = _ckpt(golden_dir, "gnn1.pth")
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    ref = oracle_from_sd(sd).eval()
+    batch = g1_batch(g1, [3, 250, 77], self_loops=False, first_only=False)
+    x, ei, bvec = batch["x"], batch["edge_index"], batch["batch"]
+    with torch.no_grad():
+        s = GraphStructure.from_edge_index(ei.to(DEV), x.shape[0], batch=bvec.to(DEV), num_graphs=3)
+        g = model.transformer1(x.to(DEV), s)
+        g_ref = ref.transformer1(x, ei)
+        assert (g.cpu() - g_ref).abs().max().item() < 1e-4
+        xo, s2, perm = model.pooling1(g, s)
+        xo_ref, ei_ref, _, b_ref, perm_ref = ref.pooling1(g_ref, ei, batch=bvec)
+    assert perm.cpu().tolist() == perm_ref.tolist()
+    assert (xo.cpu() - xo_ref).abs().max().item() < 1e-4
+    # pooled structure: CSR by source of the GPU result lists exactly the oracle's sorted (src, dst) pairs
+    k = perm.numel()
+    out_ptr, out_dst = s2.out_ptr.cpu().numpy(), s2.out_dst.cpu().numpy()
+    pairs = [(p, int(q)) for p in range(k) for q in out_dst[out_ptr[p]:out_ptr[p + 1]]]
+    assert pairs == [tuple(e) for e in ei_ref.t().tolist()]
+    assert s2.graph_ptr.cpu().tolist() == np.concatenate([[0], np.cumsum(np.bincount(b_ref.numpy(), minlength=3))]).tolist()
+
+
+def test_g2_golden_mlp_on_gpu(golden_dir, g1, lima_props):
+    from blackwater.data.circuit import Circuit
+    from blackwater.library.learning.mlp import MLP1, encode_data
+
+    sd = _ckpt(golden_dir, "mlp1_smaller_2.pth")
+    model = MLP1(58, 64, 4)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    X, _ = encode_data([Circuit.from_qasm_str(t) for t in g1["qasm"]], lima_props, g1["ideal"].tolist(),
+                       g1["noisy"].tolist(), 4)
+    with torch.no_grad():
+        out = model(X.to(DEV)).cpu().numpy()
+    assert round(mean_l2(g1["ideal"], out), 6) == 0.032910  # h17 cell [14], L2_mlp step 0
+
+
+@pytest.mark.parametrize("name,cls", [("mlp2_mbd.pth", "MLP2"), ("mlp3_ising.pth", "MLP3")])
+def test_mlp2_mlp3_match_oracle(golden_dir, name, cls):
+    import blackwater.nn as bnn
+    import oracle.models as om
+
+    sd = _ckpt(golden_dir, name)
+    i, h = sd["fc1.weight"].shape[1], sd["fc1.weight"].shape[0]
+    o = sd["fc4.weight"].shape[0] if "fc4.weight" in sd else sd["fc3.weight"].shape[0]
+    gpu, ref = getattr(bnn, cls)(i, h, o), getattr(om, cls)(i, h, o).double()
+    gpu.load_state_dict(sd, strict=True)
+    ref.load_state_dict(sd, strict=True)
+    x = torch.randn(257, i, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        got = gpu.to(DEV).eval()(x.to(DEV)).cpu().double()
+        want = ref.eval()(x.double())
+    assert (got - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+
+
+def test_ngem_decorator_end_to_end_from_qasm(g1, lima_backend):
+    """QASM text -> encoder -> graph -> GPU model through the estimator wrapper, with the model family the reference
+    uses the decorator with (docs/tutorials/01_ngem.ipynb / 04_ngem_vqe.ipynb: scalar exp_value, an observable)."""
+    from blackwater.data.backends import PauliObservable
+    from blackwater.data.utils import encode_pauli_sum_op
+    from blackwater.library.ngem.estimator import ngem
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from oracle.models import FamilyA
+    from test_estimators import FakeEstimator, _Job
+    import blackwater.library.ngem.estimator as mod
+
+    torch.manual_seed(4)
+    model = ExpValCircuitGraphModelA(5, 22, 10)
+    ref = FamilyA(5, 22, 10).double().eval()
+    ref.load_state_dict(model.state_dict())
+    model = model.to(DEV).eval()
+    idx = [0, 17, 150, 299]
+    obs = PauliObservable([("IIZIZ", 0.75)])
+
+    class Est(FakeEstimator):
+        def _run(self, circuits, observables, parameter_values, **opts):
+            return _Job([g1["noisy"][i][0] for i in idx])
+
+    orig = mod.get_backend_properties_v1  # the fixture graphs use the reference's (hash-random) gate column order
+    mod.get_backend_properties_v1 = lambda b: orig(b, gates_order=G1_GATES_ORDER)
+    try:
+        res = ngem(Est, model, lima_backend)().run([g1["qasm"][i] for i in idx], [obs] * len(idx)).result()
+    finally:
+        mod.get_backend_properties_v1 = orig
+    want = []
+    for i in idx:
+        x, ei, _ = g1_graph(g1, i)  # == what the encoder yields for this QASM (tests/test_encoder_goldens.py)
+        out = ref(torch.tensor([[g1["noisy"][i][0]]], dtype=torch.float64),
+                  torch.tensor([encode_pauli_sum_op(obs)], dtype=torch.float64),
+                  torch.zeros(1, 1, dtype=torch.float64),  # NgemJob builds the entry without a depth (reference :68-73)
+                  torch.tensor(x, dtype=torch.float32).double(), torch.tensor(ei, dtype=torch.long), None)
+        want.append(out.item())
+    assert np.abs(res.values - np.array(want)).max() < 1e-5
+
+
+def test_learning_decorator_end_to_end(golden_dir, g1, lima_backend):
+    from blackwater.data.backends import PauliObservable
+    from blackwater.library.learning.estimator import TorchLearningModelProcessor, learning
+    from blackwater.library.learning.mlp import MLP1
+    from test_estimators import FakeEstimator
+
+    torch.manual_seed(0)
+    model = MLP1(8 + 6 + 40 + 1 + 21, 64, 1).to(DEV).eval()
+    est = learning(FakeEstimator, TorchLearningModelProcessor(model, lima_backend), skip_transpile=True)()
+    res = est.run([g1["qasm"][0], g1["qasm"][1]], [PauliObservable("IIIIZ"), PauliObservable([("IIIZI", 0.5)])]).result()
+    assert res.values.shape == (2,) and np.isfinite(res.values).all()
+    assert res.metadata[1]["original_value"] == pytest.approx(0.6)
+    # same rows through the CPU oracle MLP
+    from oracle.models import MLP1 as OracleMLP1
+    from blackwater.library.learning.features import encode_data
+    from blackwater.data.utils import encode_pauli_sum_op, get_backend_properties_v1
+
+    ref = OracleMLP1(76, 64, 1)
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    props = get_backend_properties_v1(lima_backend)
+    X, _ = encode_data([g1["qasm"][1]], props, [[0.0]], [[0.6]], 1, meas_bases=encode_pauli_sum_op("IIIZI"))
+    assert res.values[1] == pytest.approx(0.5 * ref(X).item(), abs=1e-6)
