@@ -49,8 +49,8 @@ def roofline_leg(batch, reps=20):
     # one norm scalar per node.  Four input/output buffer pairs are rotated so that no launch finds its operands
     # in the 256 MiB Infinity Cache left there by the previous one.
     nbuf = 4
-    hs = [torch.randn(n, c, device=batch.x.device) for _ in range(nbuf)]
-    outs = [torch.empty_like(hs[0]) for _ in range(nbuf)]
+    hs = [ops.padded_empty(n, c, batch.x.device).normal_() for _ in range(nbuf)]   # the layout the model uses
+    outs = [ops.padded_empty(n, c, batch.x.device) for _ in range(nbuf)]
     dinv = s.gcn_dinv
     run = lambda k: ops.csr_aggregate(hs[k % nbuf], s.in_ptr, s.in_src, ell=s.in_ell, rscale=dinv, dself=dinv, out=outs[k % nbuf])
     for k in range(nbuf):

@@ -78,8 +78,10 @@ int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, const int32
  * row, (-1 = no such edge, bit 31 of the first = row continues in col[]).  With it the row pointer -> col -> source
  * row dependent chain of the CSR walk shortens to ell -> source row for the 99.8 % of circuit-graph rows that have
  * at most two in-edges; rows with more fall back to ptr/idx, so the result is identical with or without it.
- * act: bit 0 = ReLU; drop_p > 0 applies inverted dropout after the ReLU with a counter-based generator keyed by
- * (seed, element index).  Algorithmic bytes per call: 4(N+1) + 4E + 4N + 4C(E+N)  (SURVEY.md section 8d).
+ * Vector width: when x, out (and z) own round_up(C,4) columns per row (leading dimensions multiples of 4, bases
+ * 16-byte aligned) the kernel moves 16 bytes per lane and processes the pad columns along; columns never mix, so
+ * the pads may hold anything.  16-byte accesses run ~1.4x the rate of 8-byte ones here: C = 12 takes less time
+ * than C = 10, so the host lays every activation out with a padded leading dimension.
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
                             const float* cscale, const float* rscale, const float* dself, float alpha, float beta,
@@ -94,22 +96,24 @@ int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, c
 /* ell[i] = (col[ptr[i]], col[ptr[i]+1]) with the conventions above; ell: [N,2] int32, 8-byte aligned. */
 int mlqem_ell_from_csr(const int32_t* ptr, const int32_t* idx, int64_t N, int32_t* ell, mlqem_stream_t stream);
 
-/* gx = (y > 0) ? g * scale : 0  -- backward of ReLU followed by inverted dropout, recovered from the output y. */
-int mlqem_relu_dropout_bwd_f32(const float* g, const float* y, float scale, float* gx, int64_t n,
-                               mlqem_stream_t stream);
+/* gx[n,c] = (y[n,c] > 0) ? g[n,c] * scale : 0  -- backward of ReLU followed by inverted dropout, recovered from the
+ * output y (an element that was clamped OR dropped has y == 0 and no gradient either way). */
+int mlqem_relu_dropout_bwd_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, float scale, float* gx,
+                               int64_t ldgx, int64_t N, int C, mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Dense layers.  Replace torch.nn.Linear / torch_geometric.nn.Linear (docs/tutorials/gnn.py:94-98 body_seq,
  * docs/tutorials/mlp.py:18-108 MLP1/2/3, the per-node projections inside every conv).
  * ---------------------------------------------------------------------------------------------------- */
 
-/* y[n,:] = act( (x[n,:] @ W^T + b) * rowscale[n] ),  W: [O,I] row-major as torch stores it (transposed = 0),
- * or the same with y = x @ W, W: [I,O] (transposed = 1; this is the data-gradient form gx = gy @ W).
- * b and rowscale may be NULL.  accumulate != 0 adds into y instead of overwriting.  act bit 0 = ReLU.
- * Runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32) for I <= 128, N >= 16. */
+/* y[n,:] = drop( act( (x[n,:] @ W^T + b [+ y[n,:] if accumulate]) * rowscale[n] ) ),  W: [O,I] row-major as torch
+ * stores it (transposed = 0), or the same with x @ W, W: [I,O] (transposed = 1: the data-gradient form gx = gy @ W).
+ * b and rowscale may be NULL.  accumulate chains several calls into one sum of products (ChebConv's sum_k lins[k](T_k),
+ * SAGEConv's lin_l(mean) + lin_r(x)); the activation belongs on the last call.  act bit 0 = ReLU; drop_p > 0 applies
+ * inverted dropout keyed by (seed, n*O + o).  Runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32) for I <= 128. */
 int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                      const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act, int accumulate,
-                     mlqem_stream_t stream);
+                     float drop_p, uint64_t seed, mlqem_stream_t stream);
 
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 

@@ -56,7 +56,10 @@ class GraphArena:
         ``AddSelfLoops``); y/noisy/depth/observable: per-graph arrays with leading dimension G."""
         node_counts = np.array([a.shape[0] for a in xs], dtype=np.int64)
         offs = np.concatenate([[0], np.cumsum(node_counts)])
-        x = torch.from_numpy(np.ascontiguousarray(np.concatenate(xs, axis=0), dtype=np.float32)).to(device)
+        x_host = np.ascontiguousarray(np.concatenate(xs, axis=0), dtype=np.float32)
+        f = x_host.shape[1]
+        x = ops.padded_empty(x_host.shape[0], f, torch.device(device))  # rows padded to a multiple of 4 floats
+        x.copy_(torch.from_numpy(x_host))
         ei = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(edge_indices, offs[:-1])], axis=1)
         n_total = int(offs[-1])
         ei_dev = torch.from_numpy(np.ascontiguousarray(ei)).to(device)
@@ -96,7 +99,7 @@ class GraphArena:
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.device, non_blocking=True)
         sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:]
         dev, f = self.device, self.x.shape[1]
-        xb = torch.empty((nb, f), dtype=torch.float32, device=dev)
+        xb = ops.padded_empty(nb, f, dev)
         nscal_b = torch.empty((nb, 3), dtype=torch.float32, device=dev)
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
@@ -105,7 +108,7 @@ class GraphArena:
         code = _lib.load().mlqem_batch_assemble(
             p(self.x), self.x.stride(0), f, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
             p(self.out_ptr), p(self.out_dst), p(self.loops), p(sel_d), p(nptr_d), p(eptr_d), b, nb, eb,
-            p(xb), f, p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(loops), ops._stream())
+            p(xb), xb.stride(0), p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(loops), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[:, 0].contiguous(), nscal_b[:, 1].contiguous(), nscal_b[:, 2].contiguous())
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,

@@ -13,7 +13,7 @@ class _CsrAggregate(Function):
 
     @staticmethod
     def forward(ctx, x, z, bias, struct: GraphStructure, cscale, rscale, dself, alpha, beta, relu, drop_p, seed):
-        x = x.contiguous()
+        x = ops.rowmajor(x)
         y = ops.csr_aggregate(x, struct.in_ptr, struct.in_src, ell=struct.in_ell, cscale=cscale, rscale=rscale, dself=dself, alpha=alpha,
                               z=z, beta=beta, bias=bias, relu=relu, drop_p=drop_p, seed=seed)
         ctx.struct, ctx.scales = struct, (cscale, rscale, dself)
@@ -25,7 +25,7 @@ class _CsrAggregate(Function):
     @staticmethod
     def backward(ctx, g):
         (y,) = ctx.saved_tensors
-        g = g.contiguous()
+        g = ops.rowmajor(g)
         if y is not None:
             g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
         cscale, rscale, dself = ctx.scales
@@ -48,7 +48,7 @@ def csr_aggregate(x, struct, *, cscale=None, rscale=None, dself=None, alpha=1.0,
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, relu):
-        x = x.contiguous()
+        x = ops.rowmajor(x)
         y = ops.linear(x, w.contiguous(), b, relu=relu)
         ctx.relu = relu
         ctx.save_for_backward(x, w, y if relu else None)
@@ -58,7 +58,7 @@ class _Linear(Function):
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
-        g = g.contiguous()
+        g = ops.rowmajor(g)
         if ctx.relu:
             g = ops.relu_dropout_bwd(g, y, 1.0)
         gx = gw = gb = None
@@ -77,6 +77,52 @@ def linear(x, w, b=None, relu=False):
     return y.reshape(*lead, w.shape[0])
 
 
+class _MultiLinear(Function):
+    """y = drop(act(sum_k x_k W_k^T + b)) -- ChebConv's sum over Chebyshev terms, SAGEConv's lin_l(mean) + lin_r(x) --
+    as chained accumulating GEMM launches and ONE autograd node (no elementwise adds / relu / dropout passes)."""
+
+    @staticmethod
+    def forward(ctx, bias, relu, drop_p, seed, k, *xs_ws):
+        xs = [ops.rowmajor(t) for t in xs_ws[:k]]
+        ws = [t.contiguous() for t in xs_ws[k:]]
+        y = None
+        for i, (x, w) in enumerate(zip(xs, ws)):
+            last = i == k - 1
+            y = ops.linear(x, w, bias if i == 0 else None, out=y, accumulate=i > 0, relu=relu and last,
+                           drop_p=drop_p if last else 0.0, seed=seed)
+        ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias = k, relu, drop_p, bias is not None
+        ctx.save_for_backward(*xs, *ws, y if (relu or drop_p > 0) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        k = ctx.k
+        saved = ctx.saved_tensors
+        xs, ws, y = saved[:k], saved[k:2 * k], saved[2 * k]
+        g = ops.rowmajor(g)
+        if y is not None:
+            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        gb = None
+        gxs, gws = [], []
+        for i in range(k):
+            gxs.append(ops.linear(g, ws[i], transposed=True) if ctx.needs_input_grad[5 + i] else None)
+            gw = None
+            if ctx.needs_input_grad[5 + k + i] or (i == 0 and ctx.has_bias and ctx.needs_input_grad[0]):
+                gw = torch.empty_like(ws[i])
+                want_b = i == 0 and ctx.has_bias
+                if want_b:
+                    gb = torch.empty(ws[i].shape[0], dtype=g.dtype, device=g.device)
+                ops.linear_wgrad(g, xs[i], gw, gb if want_b else None)
+            gws.append(gw)
+        if ctx.has_bias and gb is None and ctx.needs_input_grad[0]:
+            gb = g.sum(0)
+        return (gb, None, None, None, None, *gxs, *gws)
+
+
+def multi_linear(xs, ws, bias=None, relu=False, drop_p=0.0, seed=0):
+    return _MultiLinear.apply(bias, relu, drop_p, seed, len(xs), *xs, *ws)
+
+
 class _GCNLayer(Function):
     """y = act(D^-1/2 (A+I) D^-1/2 (x W^T) + b) as ONE autograd node.
 
@@ -86,7 +132,7 @@ class _GCNLayer(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed):
-        x = x.contiguous()
+        x = ops.rowmajor(x)
         dinv = struct.gcn_dinv
         h = ops.linear(x, w.contiguous(), rowscale=dinv)
         y = ops.csr_aggregate(h, struct.in_ptr, struct.in_src, ell=struct.in_ell, rscale=dinv, dself=dinv, bias=bias, relu=relu,
@@ -99,7 +145,7 @@ class _GCNLayer(Function):
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
         s = ctx.struct
-        g = g.contiguous()
+        g = ops.rowmajor(g)
         if y is not None:
             g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
         gb = g.sum(0) if ctx.needs_input_grad[2] else None
@@ -122,11 +168,11 @@ class _SegmentMean(Function):
     def forward(ctx, x, struct: GraphStructure):
         ctx.struct = struct
         ctx.n = x.shape[0]
-        return ops.segment_mean(x.contiguous(), struct.graph_ptr, struct.num_graphs)
+        return ops.segment_mean(ops.rowmajor(x), struct.graph_ptr, struct.num_graphs)
 
     @staticmethod
     def backward(ctx, g):
-        return ops.segment_mean_bwd(g.contiguous(), ctx.struct.graph_ptr, ctx.n), None
+        return ops.segment_mean_bwd(ops.rowmajor(g), ctx.struct.graph_ptr, ctx.n), None
 
 
 def segment_mean(x, struct):

@@ -56,7 +56,7 @@ class GCNConv(nn.Module):
 
 
 class SAGEConv(nn.Module):
-    """out = lin_l(mean_{j->i} x_j) + lin_r(x_i)."""
+    """out = act(lin_l(mean_{j->i} x_j) + lin_r(x_i)), optional fused ReLU + dropout epilogue."""
 
     def __init__(self, in_channels: int, out_channels: int):
         super().__init__()
@@ -65,28 +65,25 @@ class SAGEConv(nn.Module):
         w, _ = _kaiming_linear(out_channels, in_channels, bias=False)
         self.lin_r = _WeightOnly(w)
 
-    def forward(self, x, struct: GraphStructure):
+    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
         mean = F.csr_aggregate(x, struct, rscale=struct.sage_rinv, dself=struct.derived("sage_dself"))
-        return F.linear(mean, self.lin_l.weight, self.lin_l.bias) + F.linear(x, self.lin_r.weight)
+        return F.multi_linear([mean, x], [self.lin_l.weight, self.lin_r.weight], self.lin_l.bias, relu=relu,
+                              drop_p=drop_p, seed=seed)
 
 
 class ChebConv(nn.Module):
-    """out = sum_k lins[k](T_k) + b with T_0 = x, T_1 = L^x, T_k = 2 L^ T_{k-1} - T_{k-2}, L^ = -D^-1/2 A D^-1/2."""
+    """out = act(sum_k lins[k](T_k) + b) with T_0 = x, T_1 = L^x, T_k = 2 L^ T_{k-1} - T_{k-2}, L^ = -D^-1/2 A D^-1/2."""
 
     def __init__(self, in_channels: int, out_channels: int, K: int):
         super().__init__()
         self.lins = nn.ModuleList([_WeightOnly(_glorot(out_channels, in_channels)) for _ in range(K)])
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
-    def forward(self, x, struct: GraphStructure):
+    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
         lap = dict(cscale=struct.cheb_dinv, rscale=struct.derived("cheb_neg"))
-        tx0 = x
-        out = F.linear(tx0, self.lins[0].weight, self.bias)
+        terms = [x]
         if len(self.lins) > 1:
-            tx1 = F.csr_aggregate(x, struct, **lap)
-            out = out + F.linear(tx1, self.lins[1].weight)
-            for lin in self.lins[2:]:
-                tx2 = F.csr_aggregate(tx1, struct, alpha=2.0, z=tx0, beta=-1.0, **lap)
-                out = out + F.linear(tx2, lin.weight)
-                tx0, tx1 = tx1, tx2
-        return out
+            terms.append(F.csr_aggregate(x, struct, **lap))
+            for _ in self.lins[2:]:
+                terms.append(F.csr_aggregate(terms[-1], struct, alpha=2.0, z=terms[-2], beta=-1.0, **lap))
+        return F.multi_linear(terms, [lin.weight for lin in self.lins], self.bias, relu=relu, drop_p=drop_p, seed=seed)

@@ -73,13 +73,13 @@ class ASAPooling(nn.Module):
         def pool(x):
             xq = ops.linear(ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell), self.lin.weight, self.lin.bias)
             att_w = self.att.weight
-            a_dst = ops.linear(xq, att_w[:, :d].contiguous(), self.att.bias).view(-1)
-            c_src = ops.linear(x, att_w[:, d:].contiguous()).view(-1)
+            a_dst = ops.linear(xq, att_w[:, :d].contiguous(), self.att.bias)[:, 0].contiguous()
+            c_src = ops.linear(x, att_w[:, d:].contiguous())[:, 0].contiguous()
             x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, self.negative_slope)
             g = self.gnn_score
             w3 = torch.cat([g.lin1.weight, g.lin2.weight, g.lin3.weight], 0)
             b3 = torch.cat([g.lin1.bias, torch.zeros_like(g.lin1.bias), g.lin3.bias], 0)
-            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3), s.in_ptr, s.in_src)
+            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
             # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk
             keep = [int(math.ceil(float(torch.tensor(self.ratio * float(m), dtype=torch.float32)))) for m in s.graph_sizes]
             new_ptr_host = [0]
@@ -97,7 +97,7 @@ class ASAPooling(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("ASAPooling: backward kernels not implemented yet (forward/inference only); "
                                       "call under torch.no_grad()")
-        return pool(x.contiguous())
+        return pool(ops.rowmajor(x))
 
 
 class _FamilyB(nn.Module):

@@ -67,13 +67,9 @@ class ExpValCircuitGraphModelA(nn.Module):
         g = self.conv1(nodes, s, relu=True, drop_p=0.1 if train else 0.0, seed=seed + 1)
         g = self.conv2(g, s, relu=True, drop_p=0.1 if train else 0.0, seed=seed + 2)
         g = F.segment_mean(self.conv3(g, s), s)
-        c = torch.relu(self.cheb_conv1(nodes, s))
-        if train:
-            c = nn.functional.dropout(c, 0.2, True)
+        c = self.cheb_conv1(nodes, s, relu=True, drop_p=0.2 if train else 0.0, seed=seed + 3)
         c = F.segment_mean(self.cheb_conv2(c, s), s)
-        sg = torch.relu(self.sage_conv1(nodes, s))
-        if train:
-            sg = nn.functional.dropout(sg, 0.2, True)
+        sg = self.sage_conv1(nodes, s, relu=True, drop_p=0.2 if train else 0.0, seed=seed + 4)
         sg = F.segment_mean(self.sage_conv2(sg, s), s)
         obs = torch.mean(self.obs_seq(observable), dim=1)
         merged = torch.cat((g, c, sg, obs, circuit_depth, exp_value), dim=1)

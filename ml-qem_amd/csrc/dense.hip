@@ -22,6 +22,7 @@ struct LinArgs {
   const float* w; const float* b; const float* rowscale;
   float* y; int64_t ldy;
   int64_t N; int I; int O; int act; int accumulate;
+  float drop_p; uint64_t seed;
 };
 
 // ---------------------------------------------------------------------------------------------- forward
@@ -78,11 +79,14 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int64_t row = n0 + lq * 4 + r;
         if (row >= a.N) continue;
+        float* dst = a.y + row * a.ldy + o;
         float v = acc[ob][r] + bias[ob];
+        if (a.accumulate) v += *dst;
         if (a.rowscale) v *= a.rowscale[row];
         if (a.act & 1) v = fmaxf(v, 0.f);
-        float* dst = a.y + row * a.ldy + o;
-        *dst = a.accumulate ? *dst + v : v;
+        if (a.drop_p > 0.f)
+          v = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : v * (1.f / (1.f - a.drop_p));
+        *dst = v;
       }
     }
   }
@@ -109,11 +113,14 @@ __global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a, 
     const float* wr = w_lds + ol * stride;
     float acc = 0.f;  // one k-ordered chain, the same summation order as the MFMA path
     for (int k = 0; k < a.I; ++k) acc = fmaf(xr[k], wr[k], acc);
+    float* dst = a.y + row * a.ldy + o;
     float r = acc + (a.b ? a.b[o] : 0.f);
+    if (a.accumulate) r += *dst;
     if (a.rowscale) r *= a.rowscale[row];
     if (a.act & 1) r = fmaxf(r, 0.f);
-    float* dst = a.y + row * a.ldy + o;
-    *dst = a.accumulate ? *dst + r : r;
+    if (a.drop_p > 0.f)
+      r = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : r * (1.f / (1.f - a.drop_p));
+    *dst = r;
   }
 }
 
@@ -252,12 +259,12 @@ using namespace mlqem;
 
 extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                                 const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act,
-                                int accumulate, mlqem_stream_t stream) {
+                                int accumulate, float drop_p, uint64_t seed, mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return MLQEM_ERR_BAD_ARG;
+  if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!x || !w || !y) return MLQEM_ERR_BAD_ARG;
-  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate};
+  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate, drop_p, seed};
   hipStream_t s = as_stream(stream);
   const int ks = round_ks((I + 3) / 4);
   if (ks > 0) {

@@ -1,0 +1,52 @@
+"""Ablation of the ELL aggregation kernel on the benchmark batch: where does the time go?"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
+import numpy as np, torch
+from bench import build_corpus
+from blackwater.data.arena import GraphArena
+from blackwater.native import ops
+c = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+corpus = build_corpus(50)
+arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
+                               corpus["observable"], device="cuda:0")
+n_graphs = len(corpus["x"])
+b = arena.batch(np.arange(256) * n_graphs // 256)
+s = b.structure
+n = s.num_nodes
+hs = [torch.randn(n, c, device="cuda:0") for _ in range(4)]
+outs = [torch.empty_like(hs[0]) for _ in range(4)]
+real = s.in_ell
+rows = torch.arange(n, device="cuda:0", dtype=torch.int32)
+none = torch.full((n, 2), -1, dtype=torch.int32, device="cuda:0")
+selfs = torch.stack([rows, rows], 1).contiguous()
+prev = torch.stack([(rows - 1).clamp(min=0), (rows - 2).clamp(min=0)], 1).contiguous()
+perm = torch.randperm(n, device="cuda:0").to(torch.int32)
+rand = torch.stack([perm, perm.roll(1)], 1).contiguous()
+one = torch.stack([real[:, 0] & 0x7FFFFFFF, torch.full((n,), -1, dtype=torch.int32, device="cuda:0")], 1)
+one[real[:, 0] == -1, 0] = -1
+one = one.contiguous()
+def run(name, ell, rscale=True, dself=True, reps=30):
+    kw = dict(rscale=s.gcn_dinv if rscale else None, dself=s.gcn_dinv if dself else None)
+    for k in range(4):
+        ops.csr_aggregate(hs[k % 4], s.in_ptr, s.in_src, ell=ell, out=outs[k % 4], **kw)
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    beg.record()
+    for k in range(reps):
+        ops.csr_aggregate(hs[k % 4], s.in_ptr, s.in_src, ell=ell, out=outs[k % 4], **kw)
+    end.record(); torch.cuda.synchronize()
+    print(f"{name:34s} {beg.elapsed_time(end) * 1e3 / reps:8.1f} us")
+# copy baseline
+beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for k in range(4): outs[k].copy_(hs[k])
+beg.record()
+for k in range(30): outs[k % 4].copy_(hs[k % 4])
+end.record(); torch.cuda.synchronize()
+print(f"{'torch copy [N,C] (r+w %d MB)' % (2*n*c*4/1e6):34s} {beg.elapsed_time(end) * 1e3 / 30:8.1f} us")
+run("real ell", real)
+run("no edges (self+scalars+store)", none)
+run("no edges, no self/rs/ds", none, False, False)
+run("edges = (row,row)", selfs)
+run("edges = (row-1,row-2)", prev)
+run("first real edge only", one)
+run("random edges", rand)

@@ -15,8 +15,10 @@ n_graphs = len(corpus["x"])
 b = arena.batch(np.arange(256) * n_graphs // 256)
 s = b.structure
 n = s.num_nodes
-hs = [torch.randn(n, c, device="cuda:0") for _ in range(4)]
-outs = [torch.empty_like(hs[0]) for _ in range(4)]
+PAD = os.environ.get("MLQEM_PAD", "1") == "1"
+mk = (lambda: ops.padded_empty(n, c, torch.device("cuda:0"))) if PAD else (lambda: torch.empty(n, c, device="cuda:0"))
+hs = [mk().normal_() for _ in range(4)]
+outs = [mk() for _ in range(4)]
 ELL = s.in_ell if os.environ.get('MLQEM_USE_ELL', '1') == '1' else None
 torch.cuda.synchronize()
 beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,5 +32,5 @@ torch.cuda.synchronize()
 us = beg.elapsed_time(end) * 1e3 / reps
 e = s.num_edges + n
 alg = 4 * (n + 1) + 4 * e + 4 * n + 4 * c * (e + n)
-print("nodes", n, "edges", s.num_edges, "C", c, "IPT", os.environ.get("MLQEM_AGG_IPT"), "ell", ELL is not None, "us/launch %.1f" % us,
+print("nodes", n, "edges", s.num_edges, "C", c, "IPT", os.environ.get("MLQEM_AGG_IPT"), "ell", ELL is not None, "padded", PAD,  "us/launch %.1f" % us,
       "alg GB/s %.0f" % (alg / us / 1e3))

@@ -98,7 +98,7 @@ def test_csr_aggregate_empty_rows_and_dropout():
     assert torch.allclose(y[y > 0], torch.tensor(1 / 0.75, device=DEV))
     y2 = ops.csr_aggregate(x, in_ptr, in_src, dself=ones, drop_p=0.25, seed=7)
     assert torch.equal(y, y2)  # counter-based generator: same seed, same mask
-    g = torch.full_like(y, 2.0)
+    g = torch.full((n, c), 2.0, device=DEV)
     gx = ops.relu_dropout_bwd(g, y, 1 / 0.75)
     assert torch.equal(gx > 0, y > 0)
 
