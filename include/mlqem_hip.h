@@ -52,10 +52,11 @@ size_t mlqem_csr_build_workspace_bytes(int64_t N, int64_t E);
 
 /* edge_index: [2,E] int64 row-major (row 0 = source, row 1 = destination), self-loops allowed.
  * Outputs: in_ptr[N+1], in_src[E] (only the first in_ptr[N] entries are meaningful), out_ptr[N+1], out_dst[E],
- * loops[N].  Inside a row the original edge order is kept (stable).  */
+ * out_eid[E] (optional: position in in_src[] of the edge each out_dst[] entry stands for; the backward kernels of the
+ * edge-softmax ops read per-edge buffers through it), loops[N].  Inside a row the original edge order is kept. */
 int mlqem_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* in_ptr, int32_t* in_src,
-                    int32_t* out_ptr, int32_t* out_dst, int32_t* loops, void* workspace, size_t workspace_bytes,
-                    mlqem_stream_t stream);
+                    int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, int32_t* loops, void* workspace,
+                    size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Per-node normalisation scalars of the three Family-A convolutions (docs/tutorials/01_ngem.ipynb cell [9]):
  *   gcn_dinv[i]  = (indeg[i] + 1)^-1/2                     GCNConv, add_remaining_self_loops, degree by destination
@@ -145,10 +146,11 @@ int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K, const int32_t* a_gptr,
                          const int32_t* a_in_ptr, const int32_t* a_in_src, const int32_t* a_out_ptr,
-                         const int32_t* a_out_dst, const int32_t* a_loops, const int32_t* sel, const int32_t* b_nptr,
+                         const int32_t* a_out_dst, const int32_t* a_out_eid, const int32_t* a_loops, const int32_t* sel,
+                         const int32_t* b_nptr,
                          const int32_t* b_eptr, int64_t B, int64_t Nb, int64_t Eb, float* xb, int64_t ldxb,
-                         float* nscal_b, int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
-                         int32_t* loops_b, mlqem_stream_t stream);
+                         float* nscal_b, int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b,
+                         int32_t* out_dst_b, int32_t* out_eid_b, int32_t* loops_b, mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Family B (docs/tutorials/gnn.py:70-276): TransformerConv attention and ASAPooling.  Forward kernels.
@@ -200,6 +202,53 @@ size_t mlqem_sort_unique_u64_workspace_bytes(int64_t T);
 int mlqem_sort_unique_u64(const uint64_t* keys, int64_t T, uint64_t* out_keys, int64_t* out_count, void* workspace,
                           size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t* edge_index, mlqem_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Family B backward.  Edge-softmax gradients are split into a destination-side pass that writes per-edge buffers in
+ * in-CSR order (E entries, then one self-loop entry per node at E + row) and a source-side pass that reads them
+ * through out_eid.  No atomics; every gradient row is written once.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Training forward of mlqem_transformer_attention_f32: same result, plus attn_out (the sum before the skip term) and
+ * the softmax statistics stat_m / stat_den [N,H]; drop_p > 0 drops attention weights (TransformerConv(dropout=0.1),
+ * gnn.py:83,90) with a mask keyed by (seed, in-CSR position, head). */
+int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
+                                          const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p,
+                                          uint64_t seed, float* out, int64_t ldo, float* attn_out, int64_t lda,
+                                          float* stat_m, float* stat_den, mlqem_stream_t stream);
+
+/* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  edge_al / edge_gs: scratch [(E+N)*H]. */
+int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg,
+                                        const float* attn_out, int64_t lda, const float* stat_m, const float* stat_den,
+                                        const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                        const int32_t* out_dst, const int32_t* out_eid, const int32_t* loops, int64_t N,
+                                        int64_t E, int H, int C, float drop_p, uint64_t seed, float* gqkvs, int64_t ldq,
+                                        float* edge_al, float* edge_gs, mlqem_stream_t stream);
+
+/* Backward of mlqem_csr_softmax_aggregate_f32: gx (+)= d/dx, g_a[N] = d/d a_dst, g_c[N] = d/d c_src.
+ * xnew = the forward output, gnew its gradient; edge_al / edge_gp: scratch [E+N]. */
+int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn, const float* gnew,
+                                        int64_t ldg, const int32_t* in_ptr, const int32_t* in_src,
+                                        const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                                        const float* a_dst, const float* c_src, float negative_slope, int64_t N,
+                                        int64_t E, int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
+                                        float* g_c, float* edge_al, float* edge_gp, mlqem_stream_t stream);
+
+/* Backward of mlqem_csr_segment_max_f32, ACCUMULATING into gx: the gradient of a row's maximum goes to the source (or
+ * the row itself) whose value equals it. */
+int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const float* gmax,
+                                  int64_t ldg, const int32_t* out_ptr, const int32_t* out_dst, int64_t N, int C,
+                                  float* gx, int64_t ldgx, mlqem_stream_t stream);
+
+/* Backward of x_out = x'[perm] * fitness[perm] over all N rows (slot[i] = cluster id or -1 from
+ * mlqem_asap_coarsen_count): gxnew[i,:] = gout[slot[i],:] * fitness[i] (0 for dropped rows), gfit[i] = gout[slot[i]].x'[i]. */
+int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, const float* xnew, int64_t ldn,
+                                    const float* fitness, const int32_t* slot, int64_t N, int C, float* gxnew,
+                                    int64_t ldgn, float* gfit, mlqem_stream_t stream);
+
+/* Backward of mlqem_leconv_fitness_f32 onto pqr[N,3]. */
+int mlqem_leconv_fitness_bwd_f32(const float* gfit, const float* fitness, const int32_t* in_ptr, const int32_t* out_ptr,
+                                 const int32_t* out_dst, int64_t N, float* gpqr, mlqem_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ class GraphArena:
         self.x = x
         self.node_counts = np.asarray(node_counts, dtype=np.int64)
         self.edge_counts = np.asarray(edge_counts, dtype=np.int64)
-        self.gptr, self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops = structure_arrays
+        self.gptr, self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops, self.out_eid = structure_arrays
         self.nscal = nscal  # [N,3]: gcn_dinv, sage_rinv, cheb_dinv
         self.y, self.noisy, self.depth, self.observable = y, noisy, depth, observable
         self.device = x.device
@@ -63,14 +63,15 @@ class GraphArena:
         ei = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(edge_indices, offs[:-1])], axis=1)
         n_total = int(offs[-1])
         ei_dev = torch.from_numpy(np.ascontiguousarray(ei)).to(device)
-        in_ptr, in_src, out_ptr, out_dst, loops = ops.csr_build(ei_dev, n_total)
+        csr = ops.csr_build(ei_dev, n_total)
+        in_ptr, in_src, out_ptr, out_dst, loops = csr
         gcn, sage, cheb = ops.graph_norms(in_ptr, out_ptr, loops, n_total)
         nscal = torch.stack([gcn, sage, cheb], dim=1).contiguous()
         gptr = torch.from_numpy(offs.astype(np.int32)).to(device)
         # edges per graph (self-loops excluded): one read-back at build time
         edge_counts = np.diff(in_ptr.cpu().numpy()[offs]).astype(np.int64)
         t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
-        return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops), nscal, t(y), t(noisy),
+        return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops, csr.out_eid), nscal, t(y), t(noisy),
                           t(depth), t(observable), edge_counts)
 
     @staticmethod
@@ -103,15 +104,15 @@ class GraphArena:
         nscal_b = torch.empty((nb, 3), dtype=torch.float32, device=dev)
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
-        in_src, out_dst = mk(eb), mk(eb)
+        in_src, out_dst, out_eid = mk(eb), mk(eb), mk(eb)
         p = ops._p
         code = _lib.load().mlqem_batch_assemble(
             p(self.x), self.x.stride(0), f, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
-            p(self.out_ptr), p(self.out_dst), p(self.loops), p(sel_d), p(nptr_d), p(eptr_d), b, nb, eb,
-            p(xb), xb.stride(0), p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(loops), ops._stream())
+            p(self.out_ptr), p(self.out_dst), p(self.out_eid), p(self.loops), p(sel_d), p(nptr_d), p(eptr_d), b, nb, eb,
+            p(xb), xb.stride(0), p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(out_eid), p(loops), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[:, 0].contiguous(), nscal_b[:, 1].contiguous(), nscal_b[:, 2].contiguous())
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,
-                           graph_sizes=self.node_counts[sel])
+                           graph_sizes=self.node_counts[sel], out_eid=out_eid)
         idx = sel_d.to(torch.int64)
         return DeviceBatch(xb, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)

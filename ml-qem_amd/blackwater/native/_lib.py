@@ -25,10 +25,10 @@ SIGNATURES = {
     "mlqem_abi_version": (_I, []),
     "mlqem_error_string": (c_char_p, [_I]),
     "mlqem_csr_build_workspace_bytes": (_S, [_L, _L]),
-    "mlqem_csr_build": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "mlqem_csr_build": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "mlqem_graph_norms": (_I, [_P, _P, _P, _L, _P, _P, _P, _P]),
-    "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
-                                  _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
+                                  _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _L, _L, _I, _P]),
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
@@ -50,6 +50,14 @@ SIGNATURES = {
     "mlqem_sort_unique_u64_workspace_bytes": (_S, [_L]),
     "mlqem_sort_unique_u64": (_I, [_P, _L, _P, _P, _P, _S, _P]),
     "mlqem_keys_to_edge_index": (_I, [_P, _L, _P, _P]),
+    "mlqem_transformer_attention_train_f32": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _F, _U, _P, _L, _P, _L, _P, _P, _P]),
+    "mlqem_transformer_attention_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I,
+                                                 _F, _U, _P, _L, _P, _P, _P]),
+    "mlqem_csr_softmax_aggregate_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _L, _L, _I, _I,
+                                                 _P, _L, _P, _P, _P, _P, _P]),
+    "mlqem_csr_segment_max_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _P, _L, _P]),
+    "mlqem_gather_scale_rows_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _P, _L, _P, _P]),
+    "mlqem_leconv_fitness_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
 }
 
 _lib = None

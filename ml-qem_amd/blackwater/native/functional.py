@@ -179,6 +179,124 @@ def segment_mean(x, struct):
     return _SegmentMean.apply(x, struct)
 
 
+class _TransformerConv(Function):
+    """out = attention(x W_qkvs^T + b) + skip as ONE autograd node: fused projection (one read of x), edge softmax
+    with optional dropout on the attention weights, and on the way back the destination/source-side attention
+    gradient kernels followed by the projection's data and weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, struct: GraphStructure, heads, channels, drop_p, seed):
+        x = ops.rowmajor(x)
+        w = w.contiguous()
+        qkvs = ops.linear(x, w, b)
+        e = struct.edge_count()
+        if not any(ctx.needs_input_grad) and drop_p == 0.0:  # inference: no statistics kept
+            return ops.transformer_attention(qkvs, struct.in_ptr, struct.in_src, struct.loops, heads, channels)
+        out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
+                                                           channels, drop_p, seed)
+        ctx.struct, ctx.cfg = struct, (e, heads, channels, drop_p, seed)
+        ctx.save_for_backward(x, w, qkvs, attn, m, den)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, qkvs, attn, m, den = ctx.saved_tensors
+        e, heads, channels, drop_p, seed = ctx.cfg
+        gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed)
+        gx = ops.linear(gqkvs, w, transposed=True) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
+        ops.linear_wgrad(gqkvs, x, gw, gb)
+        return gx, gw, gb, None, None, None, None, None
+
+
+def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
+    return _TransformerConv.apply(x, w, b, struct, heads, channels, drop_p, seed)
+
+
+class _ASAPool(Function):
+    """ASAPooling as ONE autograd node.  Differentiable output: x_out = x'[perm] * fitness[perm]; the pooled structure
+    and ``perm`` are data-dependent side results handed back through ``holder``."""
+
+    @staticmethod
+    def forward(ctx, x, lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w, l3_b, struct: GraphStructure, ratio, slope,
+                holder):
+        import math
+
+        s = struct
+        x = ops.rowmajor(x)
+        d, n = x.shape[1], s.num_nodes
+        xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
+        xq = ops.linear(xq_raw, lin_w.contiguous(), lin_b)
+        att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
+        a_dst = ops.linear(xq, att_q, att_b)[:, 0].contiguous()
+        c_src = ops.linear(x, att_x)[:, 0].contiguous()
+        x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
+        w3 = torch.cat([l1_w, l2_w, l3_w], 0).contiguous()
+        b3 = torch.cat([l1_b, torch.zeros_like(l1_b), l3_b], 0)
+        fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
+        # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk
+        keep = [int(math.ceil(float(torch.tensor(ratio * float(m), dtype=torch.float32)))) for m in s.graph_sizes]
+        new_ptr_host = [0]
+        for k in keep:
+            new_ptr_host.append(new_ptr_host[-1] + k)
+        k_total = new_ptr_host[-1]
+        new_ptr = torch.tensor(new_ptr_host, dtype=torch.int32, device=x.device)
+        perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total)
+        x_out = ops.gather_scale_rows(x_new, perm, fitness)
+        ei, slot = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n, return_slot=True)
+        csr = ops.csr_build(ei, k_total)
+        holder["structure"] = GraphStructure(k_total, csr[0], csr[1], csr[2], csr[3], csr[4], new_ptr, s.num_graphs,
+                                             num_edges=int(ei.shape[1]), graph_sizes=keep, out_eid=csr.out_eid)
+        holder["perm"] = perm
+        ctx.struct, ctx.slope, ctx.d = s, slope, d
+        ctx.save_for_backward(x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3)
+        return x_out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3 = ctx.saved_tensors
+        s, d = ctx.struct, ctx.d
+        e = s.edge_count()
+        dev = x.device
+        # x_out = x'[perm] * f[perm]
+        gxnew, gfit = ops.gather_scale_rows_bwd(g_out, x_new, fitness, slot)
+        # f = sigmoid(LEConv(x')) on scalars pqr = x' W3^T + b3
+        gpqr = ops.leconv_fitness_bwd(gfit, fitness, s.in_ptr, s.out_ptr, s.out_dst)
+        ops.linear(gpqr, w3, transposed=True, out=gxnew, accumulate=True)
+        gw3 = torch.empty_like(w3)
+        gb3 = torch.empty(3, dtype=torch.float32, device=dev)
+        ops.linear_wgrad(gpqr, x_new, gw3, gb3)
+        # x' = sum_e softmax(LeakyReLU(a_i + c_j)) x_j
+        gx, g_a, g_c = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope)
+        att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
+        g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
+        ops.linear(g_c2, att_x, transposed=True, out=gx, accumulate=True)           # c = x att_x^T
+        g_att_x = torch.empty_like(att_x)
+        ops.linear_wgrad(g_c2, x, g_att_x, None)
+        g_xq = ops.linear(g_a2, att_q, transposed=True)                              # a = xq att_q^T + b
+        g_att_q = torch.empty_like(att_q)
+        g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.linear_wgrad(g_a2, xq, g_att_q, g_att_b)
+        g_xq_raw = ops.linear(g_xq, lin_w.contiguous(), transposed=True)             # xq = xq_raw W^T + b
+        g_lin_w = torch.empty_like(lin_w)
+        g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
+        ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
+        ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s.out_ptr, s.out_dst)      # xq_raw = segment max of x
+        g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
+        return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],
+                None, None, None, None)
+
+
+def asap_pool(x, mod, struct):
+    """Runs ASAPooling with the parameters of ``mod``; returns (x_out, pooled structure, perm)."""
+    holder = {}
+    g = mod.gnn_score
+    x_out = _ASAPool.apply(x, mod.lin.weight, mod.lin.bias, mod.att.weight, mod.att.bias, g.lin1.weight, g.lin1.bias,
+                           g.lin2.weight, g.lin3.weight, g.lin3.bias, struct, mod.ratio, mod.negative_slope, holder)
+    return x_out, holder["structure"], holder["perm"]
+
+
 class _ForwardOnly(Function):
     """Wraps a forward-only native op so that asking for its gradient fails loudly instead of silently
     cutting the graph (Family B's backward kernels are the next milestone)."""

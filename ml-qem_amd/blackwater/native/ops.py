@@ -187,8 +187,17 @@ def segment_mean_bwd(g, graph_ptr, num_nodes):
     return gx
 
 
+class CsrArrays(tuple):
+    """(in_ptr, in_src, out_ptr, out_dst, loops) -- unpacks like the 5-tuple it always was -- plus ``.out_eid``."""
+
+    def __new__(cls, in_ptr, in_src, out_ptr, out_dst, loops, out_eid):
+        self = super().__new__(cls, (in_ptr, in_src, out_ptr, out_dst, loops))
+        self.out_eid = out_eid
+        return self
+
+
 def csr_build(edge_index: torch.Tensor, num_nodes: int):
-    """[2,E] int64 cuda edge list -> (in_ptr, in_src, out_ptr, out_dst, loops), all int32."""
+    """[2,E] int64 cuda edge list -> (in_ptr, in_src, out_ptr, out_dst, loops) int32, with ``.out_eid``."""
     if not edge_index.is_cuda or edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError("edge_index must be a [2,E] int64 cuda tensor")
     edge_index = edge_index.contiguous()
@@ -197,13 +206,13 @@ def csr_build(edge_index: torch.Tensor, num_nodes: int):
     lib = _lib.load()
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     in_ptr, out_ptr, loops = mk(num_nodes + 1), mk(num_nodes + 1), mk(num_nodes)
-    in_src, out_dst = mk(e), mk(e)
+    in_src, out_dst, out_eid = mk(e), mk(e), mk(e)
     need = lib.mlqem_csr_build_workspace_bytes(num_nodes, e)
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     code = lib.mlqem_csr_build(_p(edge_index), e, num_nodes, _p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst),
-                               _p(loops), _p(ws), need, _stream())
+                               _p(out_eid), _p(loops), _p(ws), need, _stream())
     _lib.check(code, "mlqem_csr_build")
-    return in_ptr, in_src, out_ptr, out_dst, loops
+    return CsrArrays(in_ptr, in_src, out_ptr, out_dst, loops, out_eid)
 
 
 def graph_norms(in_ptr, out_ptr, loops, num_nodes):
@@ -282,7 +291,7 @@ def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_tot
     return perm
 
 
-def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes):
+def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes, return_slot=False):
     """Edge list [2,E] int64 (cluster ids, row-major (src,dst) order, no diagonal) of the pooled graph.
     Two small device->host reads (candidate total, distinct total) size the buffers."""
     dev = perm.device
@@ -297,7 +306,8 @@ def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes):
     _lib.check(code, "mlqem_asap_coarsen_count")
     total = int(offsets[k].item())
     if total == 0:
-        return torch.zeros((2, 0), dtype=torch.int64, device=dev)
+        ei = torch.zeros((2, 0), dtype=torch.int64, device=dev)
+        return (ei, slot) if return_slot else ei
     keys = torch.empty(total, dtype=torch.int64, device=dev)
     code = lib.mlqem_asap_coarsen_fill(_p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst), _p(perm), _p(slot),
                                        _p(offsets), k, _p(keys), _stream())
@@ -312,4 +322,83 @@ def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes):
     ei = torch.empty((2, e), dtype=torch.int64, device=dev)
     code = lib.mlqem_keys_to_edge_index(_p(uniq), e, _p(ei), _stream())
     _lib.check(code, "mlqem_keys_to_edge_index")
-    return ei
+    return (ei, slot) if return_slot else ei
+
+
+# ------------------------------------------------------------------------------------------ Family B backward
+def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0):
+    n, hc = qkvs.shape[0], heads * channels
+    if qkvs.shape[1] != 4 * hc:
+        raise ValueError("qkvs must be [N, 4*H*C]")
+    _vec(in_ptr, "in_ptr", n + 1, torch.int32)
+    _vec(loops, "loops", n, torch.int32)
+    dev = qkvs.device
+    out, attn = padded_empty(n, hc, dev), padded_empty(n, hc, dev)
+    m = torch.empty((max(n, 1), heads), dtype=torch.float32, device=dev)
+    den = torch.empty_like(m)
+    code = _lib.load().mlqem_transformer_attention_train_f32(
+        _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
+        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _mat(out, "out"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
+    _lib.check(code, "mlqem_transformer_attention_train_f32")
+    return out, attn, m, den
+
+
+def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, drop_p=0.0, seed=0):
+    n, hc = qkvs.shape[0], heads * channels
+    g = rowmajor(g)
+    dev = qkvs.device
+    gqkvs = padded_empty(n, 4 * hc, dev)
+    scratch = torch.empty((2, (num_edges + n) * heads + 1), dtype=torch.float32, device=dev)
+    code = _lib.load().mlqem_transformer_attention_bwd_f32(
+        _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr),
+        _p(s.in_src), _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(s.loops), n, num_edges, heads, channels,
+        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(gqkvs), _mat(gqkvs, "gqkvs"), _p(scratch[0]), _p(scratch[1]),
+        _stream())
+    _lib.check(code, "mlqem_transformer_attention_bwd_f32")
+    return gqkvs
+
+
+def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope):
+    n, c = x.shape
+    dev = x.device
+    gx = padded_empty(n, c, dev)
+    g_a = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
+    g_c = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
+    scratch = torch.empty((2, num_edges + n + 1), dtype=torch.float32, device=dev)
+    code = _lib.load().mlqem_csr_softmax_aggregate_bwd_f32(
+        _p(x), _mat(x, "x"), _p(xnew), _mat(xnew, "xnew"), _p(gnew), _mat(gnew, "gnew"), _p(s.in_ptr), _p(s.in_src),
+        _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(a_dst), _p(c_src), float(negative_slope), n, num_edges, c, 0,
+        _p(gx), _mat(gx, "gx"), _p(g_a), _p(g_c), _p(scratch[0]), _p(scratch[1]), _stream())
+    _lib.check(code, "mlqem_csr_softmax_aggregate_bwd_f32")
+    return gx, g_a, g_c
+
+
+def csr_segment_max_bwd_(gx, x, xmax, gmax, out_ptr, out_dst):
+    """gx += backward of the segment max (in place)."""
+    n, c = x.shape
+    code = _lib.load().mlqem_csr_segment_max_bwd_f32(_p(x), _mat(x, "x"), _p(xmax), _mat(xmax, "xmax"), _p(gmax),
+                                                     _mat(gmax, "gmax"), _p(out_ptr), _p(out_dst), n, c, _p(gx),
+                                                     _mat(gx, "gx"), _stream())
+    _lib.check(code, "mlqem_csr_segment_max_bwd_f32")
+    return gx
+
+
+def gather_scale_rows_bwd(gout, xnew, fitness, slot):
+    n, c = xnew.shape
+    gout = rowmajor(gout)
+    gxnew = padded_empty(n, c, xnew.device)
+    gfit = torch.empty(max(n, 1), dtype=torch.float32, device=xnew.device)[:n]
+    code = _lib.load().mlqem_gather_scale_rows_bwd_f32(_p(gout), _mat(gout, "gout") if gout.shape[0] else c, _p(xnew),
+                                                       _mat(xnew, "xnew"), _p(fitness), _p(slot), n, c, _p(gxnew),
+                                                       _mat(gxnew, "gxnew"), _p(gfit), _stream())
+    _lib.check(code, "mlqem_gather_scale_rows_bwd_f32")
+    return gxnew, gfit
+
+
+def leconv_fitness_bwd(gfit, fitness, in_ptr, out_ptr, out_dst):
+    n = fitness.shape[0]
+    gpqr = torch.empty((max(n, 1), 3), dtype=torch.float32, device=fitness.device)[:n]
+    code = _lib.load().mlqem_leconv_fitness_bwd_f32(_p(gfit), _p(fitness), _p(in_ptr), _p(out_ptr), _p(out_dst), n,
+                                                    _p(gpqr), _stream())
+    _lib.check(code, "mlqem_leconv_fitness_bwd_f32")
+    return gpqr

@@ -14,11 +14,12 @@ from . import ops
 
 class GraphStructure:
     def __init__(self, num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs, num_edges=None,
-                 norms=None, graph_sizes=None):
+                 norms=None, graph_sizes=None, out_eid=None):
         self.num_nodes = int(num_nodes)
         self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops = in_ptr, in_src, out_ptr, out_dst, loops
         self.graph_ptr, self.num_graphs = graph_ptr, int(num_graphs)
         self.num_edges = num_edges  # non-self-loop edges, host int when known without a sync
+        self.out_eid = out_eid      # in-CSR position of every out-CSR entry (edge-softmax backward)
         self._norms = norms
         self._derived = {}
         self._ell = {}
@@ -29,14 +30,16 @@ class GraphStructure:
     def from_edge_index(edge_index: torch.Tensor, num_nodes: int, batch: Optional[torch.Tensor] = None,
                         num_graphs: Optional[int] = None, graph_ptr: Optional[torch.Tensor] = None) -> "GraphStructure":
         """Builds the structure on the device from a [2,E] int64 edge list (the reference's model protocol)."""
-        in_ptr, in_src, out_ptr, out_dst, loops = ops.csr_build(edge_index, num_nodes)
+        csr = ops.csr_build(edge_index, num_nodes)
+        in_ptr, in_src, out_ptr, out_dst, loops = csr
+        out_eid = csr.out_eid
         dev = edge_index.device
         if graph_ptr is None:
             if batch is None:
                 graph_ptr = torch.tensor([0, num_nodes], dtype=torch.int32, device=dev)
                 num_graphs = 1
                 return GraphStructure(num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, 1,
-                                      graph_sizes=[num_nodes])
+                                      graph_sizes=[num_nodes], out_eid=out_eid)
             else:
                 if num_graphs is None:
                     raise ValueError("num_graphs is required with `batch` (avoids a device sync)")
@@ -46,7 +49,7 @@ class GraphStructure:
         else:
             graph_ptr = graph_ptr.to(device=dev, dtype=torch.int32)
             num_graphs = graph_ptr.numel() - 1
-        return GraphStructure(num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs)
+        return GraphStructure(num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs, out_eid=out_eid)
 
     @property
     def graph_sizes(self):
@@ -74,6 +77,12 @@ class GraphStructure:
     @property
     def cheb_dinv(self):
         return self._base_norms()[2]
+
+    def edge_count(self) -> int:
+        """Number of stored (non-self-loop) edges; one device read if the structure was built without it."""
+        if self.num_edges is None:
+            self.num_edges = int(self.in_ptr[self.num_nodes].item())
+        return self.num_edges
 
     @property
     def in_ell(self):

@@ -2,8 +2,8 @@
 checkpoint the reference ships (docs/tutorials/gnn.py:70-276; census in SURVEY.md section 2.3).
 
 State-dict keys equal the reference's (``transformer1.lin_key.weight`` ... ``pooling1.gnn_score.lin2.weight`` ...
-``body_seq.0.weight``).  Forward runs on the native kernels; the backward kernels of the attention / pooling ops are
-not written yet, so these modules are inference-only for now and raise if a gradient is requested through them.
+``body_seq.0.weight``).  Forward and backward run on the native kernels (attention with dropout on the weights in train mode; ASAPooling's
+top-k and coarsened connectivity are structural and carry no gradient, as in PyG).
 """
 from __future__ import annotations
 
@@ -41,12 +41,10 @@ class TransformerConv(nn.Module):
         # one projection for query | key | value | skip: x is read once
         w = torch.cat([self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight], 0)
         b = torch.cat([self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias], 0)
-        qkvs = F.linear(x, w, b)
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("TransformerConv: train-mode attention dropout needs the backward kernels (next)")
-        fn = lambda t: ops.transformer_attention(t, struct.in_ptr, struct.in_src, struct.loops, self.heads,
-                                                 self.out_channels)
-        return F.forward_only(fn, "transformer_attention", qkvs)
+        self._calls = getattr(self, "_calls", 0) + 1
+        drop = self.dropout if self.training else 0.0
+        return F.transformer_conv(x, w, b, struct, self.heads, self.out_channels, drop_p=drop,
+                                  seed=self._calls * 104729 + id(self) % 9973)
 
 
 class _LEConv(nn.Module):
@@ -67,37 +65,7 @@ class ASAPooling(nn.Module):
         self.gnn_score = _LEConv(in_channels)
 
     def forward(self, x, struct: GraphStructure):
-        d, n = self.in_channels, struct.num_nodes
-        s = struct
-
-        def pool(x):
-            xq = ops.linear(ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell), self.lin.weight, self.lin.bias)
-            att_w = self.att.weight
-            a_dst = ops.linear(xq, att_w[:, :d].contiguous(), self.att.bias)[:, 0].contiguous()
-            c_src = ops.linear(x, att_w[:, d:].contiguous())[:, 0].contiguous()
-            x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, self.negative_slope)
-            g = self.gnn_score
-            w3 = torch.cat([g.lin1.weight, g.lin2.weight, g.lin3.weight], 0)
-            b3 = torch.cat([g.lin1.bias, torch.zeros_like(g.lin1.bias), g.lin3.bias], 0)
-            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
-            # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk
-            keep = [int(math.ceil(float(torch.tensor(self.ratio * float(m), dtype=torch.float32)))) for m in s.graph_sizes]
-            new_ptr_host = [0]
-            for k in keep:
-                new_ptr_host.append(new_ptr_host[-1] + k)
-            new_ptr = torch.tensor(new_ptr_host, dtype=torch.int32, device=x.device)
-            perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, new_ptr_host[-1])
-            x_out = ops.gather_scale_rows(x_new, perm, fitness)
-            ei = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n)
-            in_ptr, in_src, out_ptr, out_dst, loops = ops.csr_build(ei, new_ptr_host[-1])
-            pooled = GraphStructure(new_ptr_host[-1], in_ptr, in_src, out_ptr, out_dst, loops, new_ptr, s.num_graphs,
-                                    num_edges=int(ei.shape[1]), graph_sizes=keep)
-            return x_out, pooled, perm
-
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("ASAPooling: backward kernels not implemented yet (forward/inference only); "
-                                      "call under torch.no_grad()")
-        return pool(ops.rowmajor(x))
+        return F.asap_pool(x, self, struct)
 
 
 class _FamilyB(nn.Module):

@@ -415,15 +415,21 @@ static int launch_aggregate(AggArgs a, hipStream_t stream) {
   return launch_status();
 }
 
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* __restrict__ g, int64_t ldg,
                                                                   const float* __restrict__ y, int64_t ldy, float scale,
                                                                   float* __restrict__ gx, int64_t ldgx, int64_t N,
-                                                                  int C) {
+                                                                  int CV) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= N * C) return;
-  const int64_t r = t / C;
-  const int c = (int)(t - r * C);
-  gx[r * ldgx + c] = y[r * ldy + c] > 0.f ? g[r * ldg + c] * scale : 0.f;
+  if (t >= N * CV) return;
+  const int64_t r = t / CV;
+  const int c = (int)(t - r * CV) * VEC;
+  float gv[VEC], yv[VEC], o[VEC];
+  vload<VEC>(g + r * ldg + c, gv);
+  vload<VEC>(y + r * ldy + c, yv);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) o[v] = yv[v] > 0.f ? gv[v] * scale : 0.f;
+  vstore<VEC>(gx + r * ldgx + c, o);
 }
 
 }  // namespace mlqem
@@ -454,8 +460,16 @@ extern "C" int mlqem_relu_dropout_bwd_f32(const float* g, int64_t ldg, const flo
   if (N < 0 || C <= 0 || ldg < C || ldy < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!g || !y || !gx) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), g, ldg, y, ldy, scale, gx, ldgx, N, C);
+  // padded rows (see mlqem_csr_aggregate_f32): 16 bytes per lane, pad columns processed along
+  const int c4 = (C + 3) / 4 * 4;
+  const bool wide = ldg >= c4 && ldy >= c4 && ldgx >= c4 && ldg % 4 == 0 && ldy % 4 == 0 && ldgx % 4 == 0 &&
+                    aligned_to(g, 16) && aligned_to(y, 16) && aligned_to(gx, 16);
+  if (wide)
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel<4>, dim3((unsigned)ceil_div(N * (c4 / 4), kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), g, ldg, y, ldy, scale, gx, ldgx, N, c4 / 4);
+  else
+    hipLaunchKernelGGL(relu_dropout_bwd_kernel<1>, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), g, ldg, y, ldy, scale, gx, ldgx, N, C);
   return launch_status();
 }
 

@@ -1,0 +1,381 @@
+// Backward kernels of Family B (TransformerConv attention, ASAPooling).  Each edge-softmax backward is split
+// into a destination-side pass (per-edge softmax weight alpha_e and score gradient g_e, written once to [E]-sized
+// buffers in in-CSR order, plus the gradients that are sums over a destination's in-edges) and a source-side pass
+// (gradients that are sums over a source's out-edges, read through `out_eid`, the in-CSR position of each
+// out-CSR entry).  No atomics: every gradient row is written once, in a fixed order.
+#include "common.hpp"
+
+namespace mlqem {
+
+constexpr int kAttnMaxC = 32;
+
+// ---------------------------------------------------------------------------------------- TransformerConv
+// Forward with statistics: identical arithmetic to transformer_attn_kernel (attn.hip) plus m[N,H] (segment max) and
+// den[N,H] (sum of exp + 1e-16) for the backward, and optional dropout on the attention weights
+// (mask keyed by (seed, in-CSR position, head); self-loop entries use position E + row).
+__global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(
+    const float* __restrict__ qkvs, int64_t ld, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
+    float* __restrict__ out, int64_t ldo, float* __restrict__ attn_out, int64_t lda, float* __restrict__ stat_m,
+    float* __restrict__ stat_den) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * H) return;
+  const int64_t row = t / H;
+  const int h = (int)(t - row * H);
+  const int HC = H * C;
+  const float scale = 1.0f / sqrtf((float)C);
+  const float keep = 1.f / (1.f - drop_p);
+  const float* __restrict__ qi = qkvs + row * ld + h * C;
+  float q[kAttnMaxC];
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c) q[c] = c < C ? qi[c] : 0.f;
+  const int beg = ptr[row], end = ptr[row + 1];
+  const int n_self = loops ? loops[row] : 0;
+  auto score = [&](int64_t j) {
+    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kAttnMaxC; ++c)
+      if (c < C) s = fmaf(q[c], kj[c], s);
+    return s * scale;
+  };
+  float m = -INFINITY;
+  for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
+  if (n_self > 0) m = fmaxf(m, score(row));
+  float denom = 0.f;
+  for (int e = beg; e < end; ++e) denom += expf(score(idx[e]) - m);
+  if (n_self > 0) denom += expf(score(row) - m) * (float)n_self;
+  denom += 1e-16f;
+  float acc[kAttnMaxC];
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c) acc[c] = 0.f;
+  auto add = [&](int64_t j, float mult, int64_t pos) {
+    float a = expf(score(j) - m) / denom * mult;
+    if (drop_p > 0.f) a = uniform01(seed, (uint64_t)(pos * H + h)) < drop_p ? 0.f : a * keep;
+    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
+#pragma unroll
+    for (int c = 0; c < kAttnMaxC; ++c)
+      if (c < C) acc[c] = fmaf(a, vj[c], acc[c]);
+  };
+  for (int e = beg; e < end; ++e) add(idx[e], 1.f, e);
+  if (n_self > 0) add(row, (float)n_self, E + row);
+  const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c)
+    if (c < C) {
+      attn_out[row * lda + h * C + c] = acc[c];
+      out[row * ldo + h * C + c] = acc[c] + skip[c];
+    }
+  stat_m[row * H + h] = m;
+  stat_den[row * H + h] = denom;
+}
+
+// Destination side: g_q, g_skip, and per edge (in-CSR order; self entries at E + row): al = effective attention weight
+// (after dropout), gs = d loss / d score * (1/sqrt(C)).
+__global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(
+    const float* __restrict__ qkvs, int64_t ld, const float* __restrict__ g, int64_t ldg,
+    const float* __restrict__ attn_out, int64_t lda, const float* __restrict__ stat_m,
+    const float* __restrict__ stat_den, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
+    float* __restrict__ gqkvs, int64_t ldq, float* __restrict__ edge_al, float* __restrict__ edge_gs) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * H) return;
+  const int64_t row = t / H;
+  const int h = (int)(t - row * H);
+  const int HC = H * C;
+  const float scale = 1.0f / sqrtf((float)C);
+  const float keep = 1.f / (1.f - drop_p);
+  float q[kAttnMaxC], gi[kAttnMaxC], gq[kAttnMaxC];
+  float delta = 0.f;
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c) {
+    q[c] = c < C ? qkvs[row * ld + h * C + c] : 0.f;
+    gi[c] = c < C ? g[row * ldg + h * C + c] : 0.f;
+    gq[c] = 0.f;
+    if (c < C) delta = fmaf(gi[c], attn_out[row * lda + h * C + c], delta);
+  }
+  const float m = stat_m[row * H + h], den = stat_den[row * H + h];
+  const int beg = ptr[row], end = ptr[row + 1];
+  const int n_self = loops ? loops[row] : 0;
+  auto visit = [&](int64_t j, float mult, int64_t pos) {
+    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
+    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
+    float s = 0.f, gv = 0.f;
+#pragma unroll
+    for (int c = 0; c < kAttnMaxC; ++c)
+      if (c < C) {
+        s = fmaf(q[c], kj[c], s);
+        gv = fmaf(gi[c], vj[c], gv);
+      }
+    const float alpha = expf(s * scale - m) / den * mult;  // softmax weight (all copies of a repeated self-loop)
+    float dmask = 1.f;
+    if (drop_p > 0.f) dmask = uniform01(seed, (uint64_t)(pos * H + h)) < drop_p ? 0.f : keep;
+    const float gs = alpha * (gv * dmask - delta) * scale;
+    edge_al[pos * H + h] = alpha * dmask;
+    edge_gs[pos * H + h] = gs;
+#pragma unroll
+    for (int c = 0; c < kAttnMaxC; ++c)
+      if (c < C) gq[c] = fmaf(gs, kj[c], gq[c]);
+  };
+  for (int e = beg; e < end; ++e) visit(idx[e], 1.f, e);
+  if (n_self > 0) visit(row, (float)n_self, E + row);
+  else { edge_al[(E + row) * H + h] = 0.f; edge_gs[(E + row) * H + h] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c)
+    if (c < C) {
+      gqkvs[row * ldq + h * C + c] = gq[c];
+      gqkvs[row * ldq + 3 * HC + h * C + c] = gi[c];
+    }
+}
+
+// Source side: g_k[j] = sum_{e: j->i} gs_e q_i ; g_v[j] = sum_e al_e g_i  (self entry included).
+__global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_kernel(
+    const float* __restrict__ qkvs, int64_t ld, const float* __restrict__ g, int64_t ldg,
+    const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, const int32_t* __restrict__ oeid, int64_t N,
+    int64_t E, int H, int C, const float* __restrict__ edge_al, const float* __restrict__ edge_gs,
+    float* __restrict__ gqkvs, int64_t ldq) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * H) return;
+  const int64_t row = t / H;
+  const int h = (int)(t - row * H);
+  const int HC = H * C;
+  float gk[kAttnMaxC], gv[kAttnMaxC];
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c) gk[c] = gv[c] = 0.f;
+  auto visit = [&](int64_t i, int64_t pos) {
+    const float gs = edge_gs[pos * H + h], al = edge_al[pos * H + h];
+    const float* __restrict__ qi = qkvs + i * ld + h * C;
+    const float* __restrict__ gi = g + i * ldg + h * C;
+#pragma unroll
+    for (int c = 0; c < kAttnMaxC; ++c)
+      if (c < C) {
+        gk[c] = fmaf(gs, qi[c], gk[c]);
+        gv[c] = fmaf(al, gi[c], gv[c]);
+      }
+  };
+  for (int e = optr[row]; e < optr[row + 1]; ++e) visit(odst[e], oeid[e]);
+  visit(row, E + row);
+#pragma unroll
+  for (int c = 0; c < kAttnMaxC; ++c)
+    if (c < C) {
+      gqkvs[row * ldq + HC + h * C + c] = gk[c];
+      gqkvs[row * ldq + 2 * HC + h * C + c] = gv[c];
+    }
+}
+
+// --------------------------------------------------------------------------------------------- ASAPooling
+// Destination side of x'[i] = sum_e softmax_e(LeakyReLU(a_i + c_src)) x[src] (in-edges + own self-loop):
+// per edge al_e (softmax weight) and gp_e (gradient at the pre-activation a_i + c_src); g_a[i] = sum_e gp_e.
+__global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ xnew, int64_t ldn,
+    const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+    const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
+    float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a) {
+  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (row >= N) return;
+  const int beg = ptr[row], end = ptr[row + 1];
+  const float ai = a_dst[row];
+  auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  float m = leaky(ai + c_src[row]);
+  for (int e = beg; e < end; ++e) m = fmaxf(m, leaky(ai + c_src[idx[e]]));
+  float den = expf(leaky(ai + c_src[row]) - m);
+  for (int e = beg; e < end; ++e) den += expf(leaky(ai + c_src[idx[e]]) - m);
+  den += 1e-16f;
+  const float* __restrict__ gi = gnew + row * ldg;
+  float delta = 0.f;
+  for (int c = 0; c < C; ++c) delta = fmaf(gi[c], xnew[row * ldn + c], delta);
+  float ga = 0.f;
+  auto visit = [&](int64_t j, int64_t pos) {
+    const float pre = ai + c_src[j];
+    const float al = expf(leaky(pre) - m) / den;
+    const float* __restrict__ xj = x + j * ldx;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot = fmaf(gi[c], xj[c], dot);
+    const float gp = al * (dot - delta) * (pre > 0.f ? 1.f : slope);
+    edge_al[pos] = al;
+    edge_gp[pos] = gp;
+    ga += gp;
+  };
+  for (int e = beg; e < end; ++e) visit(idx[e], e);
+  visit(row, E + row);
+  g_a[row] = ga;
+}
+
+// Source side: g_x[j,:] (+)= sum_{e: j->i} al_e gnew[i,:] (self included); g_c[j] = sum_e gp_e.
+__global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
+    const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
+    const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
+    int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * C) return;
+  const int64_t row = t / C;
+  const int ch = (int)(t - row * C);
+  float acc = edge_al[E + row] * gnew[row * ldg + ch];
+  float gc = edge_gp[E + row];
+  for (int e = optr[row]; e < optr[row + 1]; ++e) {
+    const int pos = oeid[e];
+    acc = fmaf(edge_al[pos], gnew[(int64_t)odst[e] * ldg + ch], acc);
+    gc += edge_gp[pos];
+  }
+  float* d = gx + row * ldgx + ch;
+  *d = accumulate ? *d + acc : acc;
+  if (ch == 0) g_c[row] = gc;
+}
+
+// Segment-max backward, source side: g_x[j,c] += sum over destinations i of j (and j itself) whose max came from j.
+// The winner of a row is found by value equality with the stored maximum (exact ties share the gradient; they do not
+// occur with real-valued features).
+__global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
+    const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
+    int64_t N, int C, float* __restrict__ gx, int64_t ldgx) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * C) return;
+  const int64_t row = t / C;
+  const int ch = (int)(t - row * C);
+  const float v = x[row * ldx + ch];
+  float acc = (v == xmax[row * ldm + ch]) ? gmax[row * ldg + ch] : 0.f;
+  for (int e = optr[row]; e < optr[row + 1]; ++e) {
+    const int64_t i = odst[e];
+    if (v == xmax[i * ldm + ch]) acc += gmax[i * ldg + ch];
+  }
+  gx[row * ldgx + ch] += acc;
+}
+
+// x_out[p] = x'[perm[p]] * f[perm[p]]:  g_x'[perm[p],:] = g_out[p,:] * f ; g_f[perm[p]] = g_out[p,:] . x'[perm[p],:].
+// Rows that were not kept get zero (buffers are zero-filled by the caller's memset: here by the kernel over N first).
+__global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_kernel(
+    const float* __restrict__ gout, int64_t ldgo, const float* __restrict__ xnew, int64_t ldn,
+    const float* __restrict__ fitness, const int32_t* __restrict__ slot, int64_t N, int C, float* __restrict__ gxnew,
+    int64_t ldgn, float* __restrict__ gfit) {
+  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (row >= N) return;
+  const int p = slot[row];
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float gv = 0.f;
+    if (p >= 0) {
+      const float go = gout[(int64_t)p * ldgo + c];
+      gv = go * fitness[row];
+      dot = fmaf(go, xnew[row * ldn + c], dot);
+    }
+    gxnew[row * ldgn + c] = gv;
+  }
+  gfit[row] = dot;
+}
+
+// LEConv + sigmoid backward on scalars: from g_f and f build the gradient of pqr[N,3] = (p, q, r):
+//   g_raw = g_f f (1 - f);  g_p[j] = g_raw[j] + sum_{e: j->i} g_raw[i];  g_q[i] = -(indeg_i + 1) g_raw[i];  g_r = g_raw.
+__global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
+    const float* __restrict__ gfit, const float* __restrict__ fitness, const int32_t* __restrict__ iptr,
+    const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, int64_t N, float* __restrict__ gpqr) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= N) return;
+  auto graw = [&](int64_t i) { const float f = fitness[i]; return gfit[i] * f * (1.f - f); };
+  const float gj = graw(j);
+  float gp = gj;
+  for (int e = optr[j]; e < optr[j + 1]; ++e) gp += graw(odst[e]);
+  gpqr[j * 3] = gp;
+  gpqr[j * 3 + 1] = -(float)(iptr[j + 1] - iptr[j] + 1) * gj;
+  gpqr[j * 3 + 2] = gj;
+}
+
+}  // namespace mlqem
+
+using namespace mlqem;
+
+#define MLQEM_GRID(n) dim3((unsigned)ceil_div((n), kBlock)), dim3(kBlock), 0, as_stream(stream)
+
+extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
+                                                     const int32_t* in_src, const int32_t* loops, int64_t N, int64_t E,
+                                                     int H, int C, float drop_p, uint64_t seed, float* out, int64_t ldo,
+                                                     float* attn_out, int64_t lda, float* stat_m, float* stat_den,
+                                                     mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
+    return MLQEM_ERR_BAD_ARG;
+  if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
+  if (N == 0) return MLQEM_OK;
+  if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(transformer_attn_train_kernel, MLQEM_GRID(N * H), qkvs, ld, in_ptr, in_src, loops, N, E, H, C,
+                     drop_p, seed, out, ldo, attn_out, lda, stat_m, stat_den);
+  return launch_status();
+}
+
+extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg,
+                                                   const float* attn_out, int64_t lda, const float* stat_m,
+                                                   const float* stat_den, const int32_t* in_ptr, const int32_t* in_src,
+                                                   const int32_t* out_ptr, const int32_t* out_dst,
+                                                   const int32_t* out_eid, const int32_t* loops, int64_t N, int64_t E,
+                                                   int H, int C, float drop_p, uint64_t seed, float* gqkvs, int64_t ldq,
+                                                   float* edge_al, float* edge_gs, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldq < 4 * H * C || ldg < H * C || lda < H * C)
+    return MLQEM_ERR_BAD_ARG;
+  if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
+  if (N == 0) return MLQEM_OK;
+  if (!qkvs || !g || !attn_out || !stat_m || !stat_den || !in_ptr || !out_ptr || !gqkvs || !edge_al || !edge_gs)
+    return MLQEM_ERR_BAD_ARG;
+  if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel, MLQEM_GRID(N * H), qkvs, ld, g, ldg, attn_out, lda, stat_m,
+                     stat_den, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, gqkvs, ldq, edge_al, edge_gs);
+  hipLaunchKernelGGL(transformer_attn_bwd_src_kernel, MLQEM_GRID(N * H), qkvs, ld, g, ldg, out_ptr, out_dst, out_eid,
+                     N, E, H, C, edge_al, edge_gs, gqkvs, ldq);
+  return launch_status();
+}
+
+extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn,
+                                                   const float* gnew, int64_t ldg, const int32_t* in_ptr,
+                                                   const int32_t* in_src, const int32_t* out_ptr,
+                                                   const int32_t* out_dst, const int32_t* out_eid, const float* a_dst,
+                                                   const float* c_src, float negative_slope, int64_t N, int64_t E,
+                                                   int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
+                                                   float* g_c, float* edge_al, float* edge_gp, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || E < 0 || C <= 0 || ldx < C || ldn < C || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !xnew || !gnew || !in_ptr || !out_ptr || !a_dst || !c_src || !gx || !g_a || !g_c || !edge_al || !edge_gp)
+    return MLQEM_ERR_BAD_ARG;
+  if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(softmax_aggregate_bwd_dst_kernel, MLQEM_GRID(N), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,
+                     a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a);
+  hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel, MLQEM_GRID(N * C), gnew, ldg, out_ptr, out_dst, out_eid,
+                     edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c);
+  return launch_status();
+}
+
+extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm,
+                                             const float* gmax, int64_t ldg, const int32_t* out_ptr,
+                                             const int32_t* out_dst, int64_t N, int C, float* gx, int64_t ldgx,
+                                             mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C <= 0 || ldx < C || ldm < C || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !xmax || !gmax || !out_ptr || !gx) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(segment_max_bwd_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gmax, ldg, out_ptr, out_dst, N, C,
+                     gx, ldgx);
+  return launch_status();
+}
+
+extern "C" int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, const float* xnew, int64_t ldn,
+                                               const float* fitness, const int32_t* slot, int64_t N, int C,
+                                               float* gxnew, int64_t ldgn, float* gfit, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C <= 0 || ldgo < C || ldn < C || ldgn < C) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!xnew || !fitness || !slot || !gxnew || !gfit) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gather_scale_rows_bwd_kernel, MLQEM_GRID(N), gout, ldgo, xnew, ldn, fitness, slot, N, C, gxnew,
+                     ldgn, gfit);
+  return launch_status();
+}
+
+extern "C" int mlqem_leconv_fitness_bwd_f32(const float* gfit, const float* fitness, const int32_t* in_ptr,
+                                            const int32_t* out_ptr, const int32_t* out_dst, int64_t N, float* gpqr,
+                                            mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!gfit || !fitness || !in_ptr || !out_ptr || !gpqr) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(leconv_fitness_bwd_kernel, MLQEM_GRID(N), gfit, fitness, in_ptr, out_ptr, out_dst, N, gpqr);
+  return launch_status();
+}

@@ -9,9 +9,8 @@
 namespace mlqem {
 
 __global__ __launch_bounds__(kBlock) void split_edges_kernel(const int64_t* __restrict__ ei, int64_t E, int32_t N,
-                                                             int32_t* __restrict__ key_d, int32_t* __restrict__ val_s,
-                                                             int32_t* __restrict__ key_s, int32_t* __restrict__ val_d,
-                                                             int32_t* __restrict__ loops) {
+                                                             int32_t* __restrict__ key_d, int32_t* __restrict__ key_s,
+                                                             int32_t* __restrict__ eid, int32_t* __restrict__ loops) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (e >= E) return;
   const int32_t s = (int32_t)ei[e], d = (int32_t)ei[E + e];
@@ -20,8 +19,30 @@ __global__ __launch_bounds__(kBlock) void split_edges_kernel(const int64_t* __re
   // self-loops sort behind every real row (key N) and fall outside ptr[N]
   key_d[e] = loop ? N : d;
   key_s[e] = loop ? N : s;
-  val_s[e] = s;
-  val_d[e] = d;
+  eid[e] = (int32_t)e;
+}
+
+// After the stable sort by destination: in_src[p] = src[eid_in[p]] and pos_in[eid_in[p]] = p.
+__global__ __launch_bounds__(kBlock) void gather_in_kernel(const int64_t* __restrict__ ei, int64_t E,
+                                                           const int32_t* __restrict__ eid_in,
+                                                           int32_t* __restrict__ in_src, int32_t* __restrict__ pos_in) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= E) return;
+  const int32_t e = eid_in[p];
+  in_src[p] = (int32_t)ei[e];
+  pos_in[e] = (int32_t)p;
+}
+
+// After the stable sort by source: out_dst[p] = dst[eid_out[p]], out_eid[p] = position of that edge in the in-CSR.
+__global__ __launch_bounds__(kBlock) void gather_out_kernel(const int64_t* __restrict__ ei, int64_t E,
+                                                            const int32_t* __restrict__ eid_out,
+                                                            const int32_t* __restrict__ pos_in,
+                                                            int32_t* __restrict__ out_dst, int32_t* __restrict__ out_eid) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= E) return;
+  const int32_t e = eid_out[p];
+  out_dst[p] = (int32_t)ei[E + e];
+  if (out_eid) out_eid[p] = pos_in[e];
 }
 
 // ptr[i] = first position whose sorted key is >= i  (i = 0..N)
@@ -79,12 +100,12 @@ struct AssembleArgs {
   const float* x; int64_t ldx; int F;
   const float* nscal; int K;
   const int32_t* a_gptr; const int32_t* a_in_ptr; const int32_t* a_in_src;
-  const int32_t* a_out_ptr; const int32_t* a_out_dst; const int32_t* a_loops;
+  const int32_t* a_out_ptr; const int32_t* a_out_dst; const int32_t* a_out_eid; const int32_t* a_loops;
   const int32_t* sel; const int32_t* b_nptr; const int32_t* b_eptr;
   int B; int64_t Nb; int64_t Eb;
   float* xb; int64_t ldxb; float* nscal_b;
   int32_t* src_node;   // [Nb] arena row of every batch node (written by the nodes kernel, read by the rows kernel)
-  int32_t* in_ptr_b; int32_t* in_src_b; int32_t* out_ptr_b; int32_t* out_dst_b; int32_t* loops_b;
+  int32_t* in_ptr_b; int32_t* in_src_b; int32_t* out_ptr_b; int32_t* out_dst_b; int32_t* out_eid_b; int32_t* loops_b;
 };
 
 __device__ __forceinline__ int find_segment(const int32_t* __restrict__ ptr, int n_seg, int32_t v) {
@@ -134,6 +155,8 @@ __global__ __launch_bounds__(kBlock) void assemble_edges_kernel(const AssembleAr
   const int64_t le = e - a.b_eptr[b];
   a.in_src_b[e] = a.a_in_src[a.a_in_ptr[g0] + le] + shift;
   a.out_dst_b[e] = a.a_out_dst[a.a_out_ptr[g0] + le] + shift;
+  // in-CSR position of the same edge: rebased from the graph's slice of the arena to its slice of the batch
+  if (a.out_eid_b) a.out_eid_b[e] = a.a_out_eid[a.a_out_ptr[g0] + le] - a.a_in_ptr[g0] + a.b_eptr[b];
 }
 
 }  // namespace mlqem
@@ -143,11 +166,11 @@ using namespace mlqem;
 extern "C" size_t mlqem_csr_build_workspace_bytes(int64_t N, int64_t E) {
   if (N < 0 || E < 0) return 0;
   const SortPlan p = plan_sort(N, E > 0 ? E : 1);
-  return 5 * p.keys_bytes + p.temp_bytes;
+  return 6 * p.keys_bytes + p.temp_bytes;
 }
 
 extern "C" int mlqem_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* in_ptr, int32_t* in_src,
-                               int32_t* out_ptr, int32_t* out_dst, int32_t* loops, void* workspace,
+                               int32_t* out_ptr, int32_t* out_dst, int32_t* out_eid, int32_t* loops, void* workspace,
                                size_t workspace_bytes, mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
@@ -161,27 +184,31 @@ extern "C" int mlqem_csr_build(const int64_t* edge_index, int64_t E, int64_t N, 
   }
   if (!edge_index || !in_src || !out_dst) return MLQEM_ERR_BAD_ARG;
   const SortPlan p = plan_sort(N, E);
-  if (!workspace || workspace_bytes < 5 * p.keys_bytes + p.temp_bytes) return MLQEM_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < 6 * p.keys_bytes + p.temp_bytes) return MLQEM_ERR_WORKSPACE;
   char* ws = static_cast<char*>(workspace);
   int32_t* key_d = reinterpret_cast<int32_t*>(ws);
-  int32_t* val_s = reinterpret_cast<int32_t*>(ws + p.keys_bytes);
-  int32_t* key_s = reinterpret_cast<int32_t*>(ws + 2 * p.keys_bytes);
-  int32_t* val_d = reinterpret_cast<int32_t*>(ws + 3 * p.keys_bytes);
+  int32_t* key_s = reinterpret_cast<int32_t*>(ws + p.keys_bytes);
+  int32_t* eid = reinterpret_cast<int32_t*>(ws + 2 * p.keys_bytes);
+  int32_t* eid_sorted = reinterpret_cast<int32_t*>(ws + 3 * p.keys_bytes);
   int32_t* sorted = reinterpret_cast<int32_t*>(ws + 4 * p.keys_bytes);
-  void* temp = ws + 5 * p.keys_bytes;
+  int32_t* pos_in = reinterpret_cast<int32_t*>(ws + 5 * p.keys_bytes);
+  void* temp = ws + 6 * p.keys_bytes;
   size_t temp_bytes = p.temp_bytes;
 
   const unsigned eb = (unsigned)ceil_div(E, kBlock), nb = (unsigned)ceil_div(N + 1, kBlock);
-  hipLaunchKernelGGL(split_edges_kernel, dim3(eb), dim3(kBlock), 0, stream, edge_index, E, (int32_t)N, key_d, val_s,
-                     key_s, val_d, loops);
+  hipLaunchKernelGGL(split_edges_kernel, dim3(eb), dim3(kBlock), 0, stream, edge_index, E, (int32_t)N, key_d, key_s,
+                     eid, loops);
   // LSD radix sort is stable: inside a row the caller's edge order survives
-  if (rocprim::radix_sort_pairs(temp, temp_bytes, key_d, sorted, val_s, in_src, (size_t)E, 0, (unsigned)p.end_bit,
+  if (rocprim::radix_sort_pairs(temp, temp_bytes, key_d, sorted, eid, eid_sorted, (size_t)E, 0, (unsigned)p.end_bit,
                                 stream) != hipSuccess)
     return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gather_in_kernel, dim3(eb), dim3(kBlock), 0, stream, edge_index, E, eid_sorted, in_src, pos_in);
   hipLaunchKernelGGL(lower_bound_kernel, dim3(nb), dim3(kBlock), 0, stream, sorted, E, N, in_ptr);
-  if (rocprim::radix_sort_pairs(temp, temp_bytes, key_s, sorted, val_d, out_dst, (size_t)E, 0, (unsigned)p.end_bit,
+  if (rocprim::radix_sort_pairs(temp, temp_bytes, key_s, sorted, eid, eid_sorted, (size_t)E, 0, (unsigned)p.end_bit,
                                 stream) != hipSuccess)
     return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(gather_out_kernel, dim3(eb), dim3(kBlock), 0, stream, edge_index, E, eid_sorted, pos_in, out_dst,
+                     out_eid);
   hipLaunchKernelGGL(lower_bound_kernel, dim3(nb), dim3(kBlock), 0, stream, sorted, E, N, out_ptr);
   return launch_status();
 }
@@ -198,11 +225,12 @@ extern "C" int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, 
 
 extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K,
                                     const int32_t* a_gptr, const int32_t* a_in_ptr, const int32_t* a_in_src,
-                                    const int32_t* a_out_ptr, const int32_t* a_out_dst, const int32_t* a_loops,
+                                    const int32_t* a_out_ptr, const int32_t* a_out_dst, const int32_t* a_out_eid,
+                                    const int32_t* a_loops,
                                     const int32_t* sel, const int32_t* b_nptr, const int32_t* b_eptr, int64_t B,
                                     int64_t Nb, int64_t Eb, float* xb, int64_t ldxb, float* nscal_b,
                                     int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
-                                    int32_t* loops_b, mlqem_stream_t stream_) {
+                                    int32_t* out_eid_b, int32_t* loops_b, mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (B <= 0 || Nb < 0 || Eb < 0 || F <= 0 || K < 0 || ldx < F || ldxb < F) return MLQEM_ERR_BAD_ARG;
@@ -212,8 +240,9 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
   if (K > 0 && (!nscal || !nscal_b)) return MLQEM_ERR_BAD_ARG;
   if (Eb > 0 && (!a_in_src || !a_out_dst || !in_src_b || !out_dst_b)) return MLQEM_ERR_BAD_ARG;
   if (loops_b && !a_loops) return MLQEM_ERR_BAD_ARG;
-  AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_loops, sel, b_nptr, b_eptr,
-                 (int)B, Nb, Eb, xb, ldxb, nscal_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, loops_b};
+  if (out_eid_b && !a_out_eid) return MLQEM_ERR_BAD_ARG;
+  AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_out_eid, a_loops, sel, b_nptr, b_eptr,
+                 (int)B, Nb, Eb, xb, ldxb, nscal_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, out_eid_b, loops_b};
   hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
   if (Nb > 0)
     hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)ceil_div(Nb * (F + K), kBlock)), dim3(kBlock), 0, stream, a);
