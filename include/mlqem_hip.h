@@ -111,10 +111,13 @@ int mlqem_relu_dropout_bwd_f32(const float* g, int64_t ldg, const float* y, int6
  * stores it (transposed = 0), or the same with x @ W, W: [I,O] (transposed = 1: the data-gradient form gx = gy @ W).
  * b and rowscale may be NULL.  accumulate chains several calls into one sum of products (ChebConv's sum_k lins[k](T_k),
  * SAGEConv's lin_l(mean) + lin_r(x)); the activation belongs on the last call.  act bit 0 = ReLU; drop_p > 0 applies
- * inverted dropout keyed by (seed, n*O + o).  Runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32) for I <= 128. */
+ * inverted dropout keyed by (seed, n*O + o).  Column ranges: rowscale applies to outputs o < rs_cols and ReLU/dropout to
+ * outputs o >= act_from (-1, -1 = every column), so that one launch can serve several layers that read the same input
+ * rows (the three first-layer projections of GCN | Cheb | SAGE).  Runs on the f32-input matrix cores
+ * (v_mfma_f32_16x16x4_f32) for I <= 128. */
 int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                      const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act, int accumulate,
-                     float drop_p, uint64_t seed, mlqem_stream_t stream);
+                     float drop_p, uint64_t seed, int rs_cols, int act_from, mlqem_stream_t stream);
 
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 

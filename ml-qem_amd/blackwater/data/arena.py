@@ -58,7 +58,8 @@ class GraphArena:
         offs = np.concatenate([[0], np.cumsum(node_counts)])
         x_host = np.ascontiguousarray(np.concatenate(xs, axis=0), dtype=np.float32)
         f = x_host.shape[1]
-        x = ops.padded_empty(x_host.shape[0], f, torch.device(device))  # rows padded to a multiple of 4 floats
+        f4 = (f + 3) // 4 * 4                                    # rows padded to a multiple of 4 floats, pads zero
+        x = torch.zeros((x_host.shape[0], f4), dtype=torch.float32, device=torch.device(device))[:, :f]
         x.copy_(torch.from_numpy(x_host))
         ei = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(edge_indices, offs[:-1])], axis=1)
         n_total = int(offs[-1])
@@ -100,14 +101,17 @@ class GraphArena:
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.device, non_blocking=True)
         sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:]
         dev, f = self.device, self.x.shape[1]
-        xb = ops.padded_empty(nb, f, dev)
+        # the batch's features are the first column slice of a 4x-wide row: the fused Family-A node writes its
+        # three propagated copies of x (L^x, 2L^L^x - x, mean x) into the other slices without moving x
+        f4 = (f + 3) // 4 * 4
+        xb = torch.empty((max(nb, 1), 4 * f4), dtype=torch.float32, device=dev)[:nb, :f]
         nscal_b = torch.empty((nb, 3), dtype=torch.float32, device=dev)
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
         in_src, out_dst, out_eid = mk(eb), mk(eb), mk(eb)
         p = ops._p
         code = _lib.load().mlqem_batch_assemble(
-            p(self.x), self.x.stride(0), f, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
+            p(self.x), self.x.stride(0), f4, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
             p(self.out_ptr), p(self.out_dst), p(self.out_eid), p(self.loops), p(sel_d), p(nptr_d), p(eptr_d), b, nb, eb,
             p(xb), xb.stride(0), p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(out_eid), p(loops), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")

@@ -108,13 +108,15 @@ def csr_segment_max(x, ptr, idx, ell=None, out=None):
     return out
 
 
-def relu_dropout_bwd(g, y, scale=1.0):
-    """gx = (y > 0) ? g * scale : 0 on [N, C] matrices (any leading dimensions)."""
+def relu_dropout_bwd(g, y, scale=1.0, out=None):
+    """gx = (y > 0) ? g * scale : 0 on [N, C] matrices (any leading dimensions; ``out`` may alias ``g``)."""
     if g.shape != y.shape or g.dim() != 2:
         raise ValueError("relu_dropout_bwd: g and y must be 2-D of one shape")
     g, y = rowmajor(g), rowmajor(y)
     n, c = g.shape
-    gx = padded_empty(n, c, g.device)
+    gx = padded_empty(n, c, g.device) if out is None else out
+    if gx.shape != g.shape:
+        raise ValueError("relu_dropout_bwd: bad out shape")
     code = _lib.load().mlqem_relu_dropout_bwd_f32(_p(g), _mat(g, "g"), _p(y), _mat(y, "y"), float(scale), _p(gx),
                                                   _mat(gx, "gx"), n, c, _stream())
     _lib.check(code, "mlqem_relu_dropout_bwd_f32")
@@ -122,7 +124,7 @@ def relu_dropout_bwd(g, y, scale=1.0):
 
 
 def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=None, accumulate=False, drop_p=0.0,
-           seed=0):
+           seed=0, rs_cols=-1, act_from=-1):
     """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O])."""
     n, i = x.shape
     ldx = _mat(x, "x")
@@ -141,7 +143,7 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
         raise ValueError("linear: bad out shape")
     code = _lib.load().mlqem_linear_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(rowscale), _p(out), _mat(out, "out"),
                                         n, i, o, 1 if relu else 0, 1 if accumulate else 0, float(drop_p),
-                                        int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(rs_cols), int(act_from), _stream())
     _lib.check(code, "mlqem_linear_f32")
     return out
 
@@ -168,6 +170,7 @@ def linear_wgrad(gy, x, gw, gb=None, accumulate=False):
 
 
 def segment_mean(x, graph_ptr, num_graphs):
+    x = rowmajor(x)
     c = x.shape[1]
     _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
     out = torch.empty((num_graphs, c), dtype=torch.float32, device=x.device)
@@ -177,10 +180,13 @@ def segment_mean(x, graph_ptr, num_graphs):
     return out
 
 
-def segment_mean_bwd(g, graph_ptr, num_nodes):
+def segment_mean_bwd(g, graph_ptr, num_nodes, out=None):
     b, c = g.shape
+    g = rowmajor(g)
     _vec(graph_ptr, "graph_ptr", b + 1, torch.int32)
-    gx = padded_empty(num_nodes, c, g.device)
+    gx = padded_empty(num_nodes, c, g.device) if out is None else out
+    if gx.shape != (num_nodes, c):
+        raise ValueError("segment_mean_bwd: bad out shape")
     code = _lib.load().mlqem_segment_mean_bwd_f32(_p(g), _mat(g, "g"), _p(graph_ptr), _p(gx), _mat(gx, "gx"), b, c,
                                                   _stream())
     _lib.check(code, "mlqem_segment_mean_bwd_f32")

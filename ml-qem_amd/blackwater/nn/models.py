@@ -59,6 +59,20 @@ class ExpValCircuitGraphModelA(nn.Module):
         self._step = 0
 
     def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
+        """Graph branches as one fused autograd node (nn/family_a_fused.py); set ``self.fused = False`` for the
+        layer-by-layer path (same maths, one kernel pair per layer)."""
+        if not getattr(self, "fused", True):
+            return self.forward_layers(exp_value, observable, circuit_depth, nodes, edge_index, batch)
+        from .family_a_fused import family_a_graph_part
+
+        b = exp_value.shape[0]
+        s = as_structure(edge_index, nodes.shape[0], batch, b)
+        self._step += 1
+        pooled = family_a_graph_part(self, nodes, s, self.training, self._step * 7919)
+        obs = torch.mean(self.obs_seq(observable), dim=1)
+        return self.body_seq(torch.cat((pooled, obs, circuit_depth, exp_value), dim=1))
+
+    def forward_layers(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         train = self.training

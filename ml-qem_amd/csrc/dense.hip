@@ -23,6 +23,8 @@ struct LinArgs {
   float* y; int64_t ldy;
   int64_t N; int I; int O; int act; int accumulate;
   float drop_p; uint64_t seed;
+  int rs_cols;    // rowscale applies to outputs o < rs_cols
+  int act_from;   // ReLU / dropout apply to outputs o >= act_from
 };
 
 // ---------------------------------------------------------------------------------------------- forward
@@ -82,10 +84,12 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
         float* dst = a.y + row * a.ldy + o;
         float v = acc[ob][r] + bias[ob];
         if (a.accumulate) v += *dst;
-        if (a.rowscale) v *= a.rowscale[row];
-        if (a.act & 1) v = fmaxf(v, 0.f);
-        if (a.drop_p > 0.f)
-          v = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : v * (1.f / (1.f - a.drop_p));
+        if (a.rowscale && o < a.rs_cols) v *= a.rowscale[row];
+        if (o >= a.act_from) {
+          if (a.act & 1) v = fmaxf(v, 0.f);
+          if (a.drop_p > 0.f)
+            v = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : v * (1.f / (1.f - a.drop_p));
+        }
         *dst = v;
       }
     }
@@ -116,10 +120,12 @@ __global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a, 
     float* dst = a.y + row * a.ldy + o;
     float r = acc + (a.b ? a.b[o] : 0.f);
     if (a.accumulate) r += *dst;
-    if (a.rowscale) r *= a.rowscale[row];
-    if (a.act & 1) r = fmaxf(r, 0.f);
-    if (a.drop_p > 0.f)
-      r = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : r * (1.f / (1.f - a.drop_p));
+    if (a.rowscale && o < a.rs_cols) r *= a.rowscale[row];
+    if (o >= a.act_from) {
+      if (a.act & 1) r = fmaxf(r, 0.f);
+      if (a.drop_p > 0.f)
+        r = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : r * (1.f / (1.f - a.drop_p));
+    }
     *dst = r;
   }
 }
@@ -259,12 +265,15 @@ using namespace mlqem;
 
 extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                                 const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act,
-                                int accumulate, float drop_p, uint64_t seed, mlqem_stream_t stream) {
+                                int accumulate, float drop_p, uint64_t seed, int rs_cols, int act_from,
+                                mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
+  if (rs_cols < 0) rs_cols = O;
+  if (act_from < 0) act_from = 0;
   if (N == 0) return MLQEM_OK;
   if (!x || !w || !y) return MLQEM_ERR_BAD_ARG;
-  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate, drop_p, seed};
+  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate, drop_p, seed, rs_cols, act_from};
   hipStream_t s = as_stream(stream);
   const int ks = round_ks((I + 3) / 4);
   if (ks > 0) {

@@ -1,0 +1,28 @@
+"""Side benchmark (not the driver's bench line): Family B (the reference's own GNN, docs/tutorials/gnn.py:70-122) train
+step on cfg2-like synthetic 4-qubit TFIM graphs."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
+import numpy as np, torch
+from blackwater.data.arena import GraphArena
+from blackwater.data.synthetic import tfim_corpus
+from blackwater.nn import ExpValCircuitGraphModel
+from blackwater.train import Trainer
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+corpus = tfim_corpus(4, list(range(0, 15)), 40, two_q="cx", exp_value_size=4)
+arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"][:, None, :], corpus["noisy"][:, None, :],
+                               corpus["depth"], corpus["observable"], device="cuda:0")
+torch.manual_seed(0)
+model = ExpValCircuitGraphModel(22, 15).to("cuda:0")
+tr = Trainer(model, lr=1e-3)
+rng = np.random.RandomState(0)
+draw = lambda: rng.randint(0, len(arena), size=batch)
+for _ in range(3):
+    tr.step(arena.batch(draw()))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps):
+    loss = tr.step(arena.batch(draw()))
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"family B train step: batch {batch} graphs ({arena.num_nodes / len(arena):.0f} nodes/graph), "
+      f"{dt / steps * 1e3:.2f} ms/step, {batch * steps / dt:.0f} circuits/s, loss {loss.item():.4f}")
