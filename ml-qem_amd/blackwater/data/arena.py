@@ -101,10 +101,8 @@ class GraphArena:
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.device, non_blocking=True)
         sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:]
         dev, f = self.device, self.x.shape[1]
-        # the batch's features are the first column slice of a 4x-wide row: the fused Family-A node writes its
-        # three propagated copies of x (L^x, 2L^L^x - x, mean x) into the other slices without moving x
         f4 = (f + 3) // 4 * 4
-        xb = torch.empty((max(nb, 1), 4 * f4), dtype=torch.float32, device=dev)[:nb, :f]
+        xb = torch.empty((max(nb, 1), f4), dtype=torch.float32, device=dev)[:nb, :f]   # 16-byte rows, pads zero
         nscal_b = torch.empty((nb, 3), dtype=torch.float32, device=dev)
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)

@@ -59,9 +59,10 @@ class ExpValCircuitGraphModelA(nn.Module):
         self._step = 0
 
     def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
-        """Graph branches as one fused autograd node (nn/family_a_fused.py); set ``self.fused = False`` for the
-        layer-by-layer path (same maths, one kernel pair per layer)."""
-        if not getattr(self, "fused", True):
+        """Layer-by-layer path by default.  ``self.fused = True`` selects the single-node schedule of
+        nn/family_a_fused.py (same maths; measured SLOWER on MI355X because column slices of wide rows waste cache-line
+        sectors in the aggregation gathers -- kept as a tested alternative schedule)."""
+        if not getattr(self, "fused", False):
             return self.forward_layers(exp_value, observable, circuit_depth, nodes, edge_index, batch)
         from .family_a_fused import family_a_graph_part
 
