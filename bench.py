@@ -66,9 +66,20 @@ def roofline_leg(batch, reps=20):
     b = agg_bytes(n, e_loops, c)
     peak = 8000.0  # GB/s, MI355X HBM3E (guide: MI355X_MICROARCH.md chip table)
     ach = b / sec / 1e9
-    return {"bound": "hbm", "kernel": "csr_aggregate_kernel<2,false> (C=10, GCN norm)", "achieved": round(ach, 1),
-            "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4), "traffic": None,
-            "bytes_per_launch": int(b), "us_per_launch": round(sec * 1e6, 2), "nodes": n, "edges_with_loops": e_loops}
+    # HBM traffic per launch comes from rocprofv3 PMC passes (they cannot run inside this process); the committed
+    # summary applies only if it was taken on exactly this batch.
+    traffic, src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_aggregate_pmc.json")) as fh:
+            pmc = json.load(fh)
+        if pmc["nodes"] == n and pmc["edges_with_loops"] == e_loops and pmc["C"] == c:
+            traffic, src = pmc["traffic_bytes_per_launch"], "profiles/r01_aggregate_pmc.json (FETCH_SIZE x2 + WRITE_SIZE)"
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "hbm", "kernel": "csr_aggregate_ell_kernel<4,false,2> (GCN forward aggregation, C=10)",
+            "achieved": round(ach, 1), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_source": src, "bytes_per_launch": int(b), "us_per_launch": round(sec * 1e6, 2), "nodes": n,
+            "edges_with_loops": e_loops}
 
 
 def cpu_baseline_leg(corpus, ids, n_qubits, budget_s=20.0):
