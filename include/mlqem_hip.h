@@ -253,6 +253,34 @@ int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, const float
 int mlqem_leconv_fitness_bwd_f32(const float* gfit, const float* fitness, const int32_t* in_ptr, const int32_t* out_ptr,
                                  const int32_t* out_dst, int64_t N, float* gpqr, mlqem_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Host-side native encoder (no GPU needed).  Replaces the Python loops of circuit_to_graph_data_json
+ * (blackwater/data/utils.py:198-389) for the part ExpValueEntry.to_pyg_data consumes
+ * (blackwater/data/generators/exp_val.py:63-70): the op-node feature matrix and the op->op qubit-wire edges, in the
+ * reference's node and edge order, as float64 (the reference holds Python floats).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct mlqem_backend_props {
+  int num_qubits;                    /* length of t1 / t2 / readout */
+  const double* t1;                  /* seconds, as get_backend_properties_v1 stores them */
+  const double* t2;
+  const double* readout;
+  int num_gate_types;                /* len(properties["gates_set"]); "barrier" and "measure" are appended internally */
+  const char* const* gate_names;     /* one-hot column order */
+  int num_gate_props;                /* entries of properties["gate_props"] */
+  const char* const* gate_keys;      /* "cx_0_1", "sx_3", ... */
+  const double* gate_error;
+  const double* gate_length;
+} mlqem_backend_props;
+
+/* Two-call pattern.  Size query: x == NULL -> *num_nodes, *num_edges, *num_features, *depth are filled.  Fill: pass
+ * buffers x[N*F], edge_src[E], edge_dst[E], edge_attr[E*3] (edge_attr may be NULL) with *num_nodes / *num_edges set to
+ * their capacities.  Errors (MLQEM_ERR_UNSUPPORTED): a gate outside gates_set, a non-barrier gate on more than 3
+ * qubits, more than 3 parameters, malformed QASM -- mlqem_encode_last_error() has the message (per thread). */
+int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* props, int use_qubit_features, int use_gate_features,
+                      int64_t* num_nodes, int64_t* num_edges, int* num_features, int* depth, double* x,
+                      int32_t* edge_src, int32_t* edge_dst, double* edge_attr);
+const char* mlqem_encode_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif
