@@ -105,3 +105,29 @@ def test_torch_processor_feature_row_and_coefficients(lima_backend):
     assert out == pytest.approx((0.25 + 1.0) * 2.0 + (0.25 + 1.0) * -1.0)
     assert probe.row[0, 55:].tolist() == [1.0] + [1, 0, 0, 0] + [0, 0, 0, 1] + [1, 0, 0, 0] * 3  # IXIII, coeff 1
     assert probe.row[0, 8 + 0].item() == pytest.approx(0.01)  # one cx
+
+
+def test_batched_postprocessing_equals_serial(lima_backend):
+    """``ngem(..., batched=True)`` and ``TorchLearningModelProcessor.process_batch`` give the per-circuit results."""
+
+    class MeanModel(torch.nn.Module):  # uses every argument incl. ``batch``
+        def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
+            b = exp_value.shape[0]
+            idx = torch.zeros(nodes.shape[0], dtype=torch.long) if batch is None else batch
+            pooled = torch.zeros(b, nodes.shape[1]).index_add_(0, idx, nodes)
+            counts = torch.zeros(b).index_add_(0, idx, torch.ones(nodes.shape[0]))
+            return exp_value + (pooled / counts[:, None]).sum(1, keepdim=True) + observable.sum((1, 2)).unsqueeze(1)
+
+    q2 = QASM.replace("rz(0.3) q[0];", "rz(0.3) q[0];\nx q[1];\nsx q[1];")
+    circuits, obs = [QASM, q2, QASM], [PauliObservable("ZIIII"), PauliObservable("IZIII"), PauliObservable("IIZII")]
+    serial = ngem(FakeEstimator, MeanModel(), lima_backend)().run(circuits, obs).result().values
+    batched = ngem(FakeEstimator, MeanModel(), lima_backend, batched=True)().run(circuits, obs).result().values
+    assert np.allclose(serial, batched, rtol=1e-6)
+
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(76, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+    proc = TorchLearningModelProcessor(mlp, lima_backend)
+    two_terms = PauliObservable([("ZIIII", 0.5), ("IXIII", -2.0)])
+    want = [proc.process(0.5, QASM, two_terms, ()), proc.process(0.6, q2, PauliObservable("IIIIZ"), ())]
+    got = learning(FakeEstimator, proc, skip_transpile=True)().run([QASM, q2], [two_terms, PauliObservable("IIIIZ")]).result()
+    assert np.allclose(got.values, want, rtol=1e-6) and got.metadata[1]["original_value"] == pytest.approx(0.6)
