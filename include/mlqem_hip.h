@@ -237,11 +237,13 @@ int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float
                                         int64_t E, int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
                                         float* g_c, float* edge_al, float* edge_gp, mlqem_stream_t stream);
 
-/* Backward of mlqem_csr_segment_max_f32, ACCUMULATING into gx: the gradient of a row's maximum goes to the source (or
- * the row itself) whose value equals it. */
+/* Backward of mlqem_csr_segment_max_f32, ACCUMULATING into gx: the gradient of a row's maximum goes to the entries
+ * (sources or the row itself) whose value equals it, split evenly among ties (torch scatter_reduce(amax) rule).
+ * gshare: scratch [N, lds >= C]. */
 int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const float* gmax,
-                                  int64_t ldg, const int32_t* out_ptr, const int32_t* out_dst, int64_t N, int C,
-                                  float* gx, int64_t ldgx, mlqem_stream_t stream);
+                                  int64_t ldg, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                  const int32_t* out_dst, int64_t N, int C, float* gx, int64_t ldgx, float* gshare,
+                                  int64_t lds, mlqem_stream_t stream);
 
 /* Backward of x_out = x'[perm] * fitness[perm] over all N rows (slot[i] = cluster id or -1 from
  * mlqem_asap_coarsen_count): gxnew[i,:] = gout[slot[i],:] * fitness[i] (0 for dropped rows), gfit[i] = gout[slot[i]].x'[i]. */

@@ -60,6 +60,92 @@ def tfim_circuit(nq: int, steps: int, J: float, h: float = 0.66 * math.pi, dt: f
     return Circuit(nq, nq, ops)
 
 
+def random_circuit(nq: int, depth: int, seed: int, two_q: str = "cx", measure: bool = True) -> Circuit:
+    """Layers of random disjoint one- and two-qubit gates, like the reference's use of
+    ``qiskit.circuit.random.random_circuit`` (blackwater/data/generators/exp_val.py:116-120), already in the backend
+    basis {rz, sx, x, two_q}; two-qubit gates act on neighbours of a line so that calibration entries exist."""
+    rng = np.random.default_rng(seed)
+    ops: List[CircuitOp] = []
+    for _ in range(depth):
+        q = 0
+        while q < nq:
+            if q + 1 < nq and rng.random() < 0.35:
+                a, b = (q, q + 1) if rng.random() < 0.5 else (q + 1, q)
+                ops.append(CircuitOp(two_q, (a, b)))
+                q += 2
+                continue
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                ops.append(CircuitOp("rz", (q,), (), (float(rng.uniform(-math.pi, math.pi)),)))
+            elif kind == 1:
+                ops.append(CircuitOp("sx", (q,)))
+            elif kind == 2:
+                ops.append(CircuitOp("x", (q,)))
+            q += 1  # kind 3: idle wire in this layer
+    if measure:
+        ops.append(CircuitOp("barrier", tuple(range(nq))))
+        ops.extend(CircuitOp("measure", (q,), (q,)) for q in range(nq))
+    return Circuit(nq, nq if measure else 0, ops)
+
+
+def pauli_twirl(circ: Circuit, seed: int, two_q=("cx", "ecr")) -> Circuit:
+    """Random single-qubit Paulis (x, or rz(pi) for Z, or both for Y) before and after every two-qubit gate -- the
+    structural effect of Pauli twirling on the circuit graph (cfg5 of BASELINE.json)."""
+    rng = np.random.default_rng(seed)
+
+    def pauli(q):
+        k = rng.integers(0, 4)
+        out = []
+        if k in (1, 2):
+            out.append(CircuitOp("x", (q,)))
+        if k in (2, 3):
+            out.append(CircuitOp("rz", (q,), (), (math.pi,)))
+        return out
+
+    ops: List[CircuitOp] = []
+    for op in circ.ops:
+        if op.name in two_q:
+            for q in op.qubits:
+                ops += pauli(q)
+            ops.append(op)
+            for q in op.qubits:
+                ops += pauli(q)
+        else:
+            ops.append(op)
+    return Circuit(circ.num_qubits, circ.num_clbits, ops)
+
+
+def encode_corpus(circuits, nq: int, two_q: str = "cx", seed: int = 7, exp_value_size: int = 1,
+                  add_self_loops: bool = True) -> Dict[str, list]:
+    """Arena-ready arrays (same keys as :func:`tfim_corpus`) for arbitrary circuits, encoded by the native encoder."""
+    from .circuit import circuit_to_qasm
+    from .native_encoder import NativeEncoder
+
+    props = get_backend_properties_v1(synthetic_backend(nq, two_q))
+    enc = NativeEncoder(props)
+    rng = np.random.default_rng(seed)
+    xs, eis, ys, noisy, depth, obs = [], [], [], [], [], []
+    for circ in circuits:
+        x, ei, _, d = enc.encode(circuit_to_qasm(circ))
+        if add_self_loops:
+            loops = np.arange(x.shape[0], dtype=np.int64)
+            ei = np.concatenate([ei, np.stack([loops, loops])], axis=1)
+        ideal = rng.uniform(-1, 1, size=exp_value_size)
+        n2q = sum(1 for op in circ.ops if op.name == two_q)
+        xs.append(x.astype(np.float32))
+        eis.append(ei)
+        ys.append(ideal)
+        noisy.append(ideal * math.exp(-5e-3 * n2q) + rng.normal(0, 0.01, size=exp_value_size))
+        depth.append([float(d)])
+        o = np.zeros((1, 4 * nq + 1), dtype=np.float32)
+        o[0, 0], o[0, 1::4] = 1.0, 1.0
+        qz = int(rng.integers(0, nq))
+        o[0, 1 + 4 * qz], o[0, 2 + 4 * qz] = 0.0, 1.0
+        obs.append(o)
+    return {"x": xs, "edge_index": eis, "y": np.asarray(ys, np.float32), "noisy": np.asarray(noisy, np.float32),
+            "depth": np.asarray(depth, np.float32), "observable": np.asarray(obs, np.float32)}
+
+
 def synthetic_backend(nq: int, two_q: str = "ecr", seed: int = 0) -> StaticBackend:
     """FakeLima-like calibration table stretched to ``nq`` qubits on a line (seeded)."""
     rng = np.random.default_rng(seed)

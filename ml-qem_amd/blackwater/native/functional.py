@@ -282,7 +282,7 @@ class _ASAPool(Function):
         g_lin_w = torch.empty_like(lin_w)
         g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
         ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
-        ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s.out_ptr, s.out_dst)      # xq_raw = segment max of x
+        ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s)      # xq_raw = segment max of x
         g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],
                 None, None, None, None)

@@ -379,12 +379,14 @@ def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negativ
     return gx, g_a, g_c
 
 
-def csr_segment_max_bwd_(gx, x, xmax, gmax, out_ptr, out_dst):
-    """gx += backward of the segment max (in place)."""
+def csr_segment_max_bwd_(gx, x, xmax, gmax, s):
+    """gx += backward of the segment max over structure ``s`` (in place)."""
     n, c = x.shape
+    share = padded_empty(n, c, x.device)
     code = _lib.load().mlqem_csr_segment_max_bwd_f32(_p(x), _mat(x, "x"), _p(xmax), _mat(xmax, "xmax"), _p(gmax),
-                                                     _mat(gmax, "gmax"), _p(out_ptr), _p(out_dst), n, c, _p(gx),
-                                                     _mat(gx, "gx"), _stream())
+                                                     _mat(gmax, "gmax"), _p(s.in_ptr), _p(s.in_src), _p(s.out_ptr),
+                                                     _p(s.out_dst), n, c, _p(gx), _mat(gx, "gx"), _p(share),
+                                                     _mat(share, "share"), _stream())
     _lib.check(code, "mlqem_csr_segment_max_bwd_f32")
     return gx
 

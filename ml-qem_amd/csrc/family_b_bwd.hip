@@ -222,9 +222,25 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
   if (ch == 0) g_c[row] = gc;
 }
 
-// Segment-max backward, source side: g_x[j,c] += sum over destinations i of j (and j itself) whose max came from j.
-// The winner of a row is found by value equality with the stored maximum (exact ties share the gradient; they do not
-// occur with real-valued features).
+// Segment-max backward.  Ties: the gradient of a row's maximum is split EVENLY among the entries that attain it
+// (torch's scatter_reduce(amax) rule, which PyG >= 2.3 uses without torch_scatter): circuit graphs do contain exact
+// ties, because identical gates on one qubit have identical feature rows.
+// Pass 1 (destination side): gshare[i,c] = gmax[i,c] / #{entries of row i (sources and i itself) equal to xmax[i,c]}.
+__global__ __launch_bounds__(kBlock) void segment_max_share_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
+    const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ iptr, const int32_t* __restrict__ isrc,
+    int64_t N, int C, float* __restrict__ gshare, int64_t lds) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * C) return;
+  const int64_t row = t / C;
+  const int ch = (int)(t - row * C);
+  const float m = xmax[row * ldm + ch];
+  int cnt = x[row * ldx + ch] == m ? 1 : 0;
+  for (int e = iptr[row]; e < iptr[row + 1]; ++e) cnt += x[(int64_t)isrc[e] * ldx + ch] == m ? 1 : 0;
+  gshare[row * lds + ch] = gmax[row * ldg + ch] / (float)(cnt > 0 ? cnt : 1);
+}
+
+// Pass 2 (source side): g_x[j,c] += sum over destinations i of j (and j itself) whose maximum equals x[j,c].
 __global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
@@ -345,14 +361,17 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
 }
 
 extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm,
-                                             const float* gmax, int64_t ldg, const int32_t* out_ptr,
-                                             const int32_t* out_dst, int64_t N, int C, float* gx, int64_t ldgx,
+                                             const float* gmax, int64_t ldg, const int32_t* in_ptr,
+                                             const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                             int64_t N, int C, float* gx, int64_t ldgx, float* gshare, int64_t lds,
                                              mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || C <= 0 || ldx < C || ldm < C || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
+  if (N < 0 || C <= 0 || ldx < C || ldm < C || ldg < C || ldgx < C || lds < C) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
-  if (!x || !xmax || !gmax || !out_ptr || !gx) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(segment_max_bwd_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gmax, ldg, out_ptr, out_dst, N, C,
+  if (!x || !xmax || !gmax || !in_ptr || !out_ptr || !gx || !gshare) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(segment_max_share_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, N, C,
+                     gshare, lds);
+  hipLaunchKernelGGL(segment_max_bwd_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gshare, lds, out_ptr, out_dst, N, C,
                      gx, ldgx);
   return launch_status();
 }

