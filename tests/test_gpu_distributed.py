@@ -1,0 +1,52 @@
+"""The RCCL leg of the data-parallel path, as far as one GPU can exercise it: a world-size-1 ``nccl`` process group
+carries the flat-gradient all-reduce of ``Trainer`` (the multi-rank logic is covered on CPU with gloo in
+tests/test_distributed_cpu.py; the driver runs 2/4/8 ranks)."""
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import g1_graph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_trainer_step_over_rccl_world1(g1):
+    from blackwater.data.arena import GraphArena
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import Trainer
+    from helpers import g1_batch
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                         device_id=torch.device(DEV))
+    try:
+        xs, eis = [], []
+        for i in range(64):
+            x, ei, _ = g1_graph(g1, i)
+            loops = np.arange(x.shape[0])
+            xs.append(x.astype(np.float32))
+            eis.append(np.concatenate([ei, np.stack([loops, loops])], axis=1))
+        host = g1_batch(g1, range(64))
+        arena = GraphArena.from_arrays(xs, eis, host["y"].numpy(), host["noisy"].numpy(), host["depth"].numpy(),
+                                       host["observable"].numpy(), device=DEV)
+        results = []
+        for distributed in (True, False):
+            torch.manual_seed(0)
+            model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV)
+            model.eval()
+            model.train = lambda *a, **k: model  # dropout off: the two runs must agree bit for bit
+            tr = Trainer(model, lr=1e-3, distributed=distributed)
+            assert tr.distributed == distributed
+            for step in range(3):
+                loss = tr.step(arena.batch(list(range(step * 8, step * 8 + 32))))
+            results.append((loss.item(), tr.flat_param.detach().clone()))
+        assert results[0][0] == results[1][0]
+        assert torch.equal(results[0][1], results[1][1])
+    finally:
+        torch.distributed.destroy_process_group()
