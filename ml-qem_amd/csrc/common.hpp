@@ -71,5 +71,6 @@ template <int V> __device__ __forceinline__ void vstore(float* p, const float (&
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+__device__ __forceinline__ bool aligned_to_dev(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace mlqem

@@ -7,6 +7,8 @@
 //                                        4 rows per MFMA, operands loaded straight from HBM (each byte is used once)
 // Operand lane maps (guide section 3): A: lane l holds A[l & 15][l >> 4]; B: lane l holds B[l >> 4][l & 15];
 // C/D: lane l, register r holds D[(l >> 4) * 4 + r][l & 15].
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mlqem {
@@ -92,6 +94,113 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
         }
         *dst = v;
       }
+    }
+  }
+}
+
+// 16-byte operand loads.  The MFMA consumes K in any order as long as A and B agree, so lane (row r = l & 15,
+// group q = l >> 4) loads the contiguous float4 X[r][16g + 4q .. +3] ONCE per 16-column group g and feeds its four
+// components to four consecutive k-steps (step s of group g multiplies k = 16g + 4q + s); the W fragment of that step
+// holds W[o][16g + 4q + s].  One load instruction then covers 64 bytes of each of 16 rows instead of 16 bytes:
+// 2 loads instead of 6 for I = 22.  Needs 16-byte aligned rows (the padded activation layout).
+template <int OBT, int G, bool TRANSPOSED>
+__global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kBlock) >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ob0 = blockIdx.y * OBT;
+
+  // W is the MFMA's A operand (M = outputs) and the X tile its B operand (N = rows): the result tile is Y^T, so a lane
+  // ends up with FOUR CONSECUTIVE OUTPUTS of ONE row (D[o = 4*(l>>4) + r][n = l & 15]) and stores them as one float4.
+  float wf[OBT][G][4];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o = (ob0 + ob) * 16 + lr;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 16 * g + 4 * lq + s4;
+        float v = 0.f;
+        if (o < a.O && k < a.I) v = TRANSPOSED ? a.w[(int64_t)k * a.O + o] : a.w[(int64_t)o * a.I + k];
+        wf[ob][g][s4] = v;
+      }
+  }
+  float bias[OBT][4];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = (ob0 + ob) * 16 + lq * 4 + r;
+      bias[ob][r] = (a.b && o < a.O) ? a.b[o] : 0.f;
+    }
+  const bool vec_store = a.ldy % 4 == 0 && aligned_to_dev(a.y, 16);
+
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    const int64_t row = t * 16 + lr;          // the row this lane loads AND stores
+    const bool row_ok = row < a.N;
+    const float* __restrict__ xr = a.x + row * a.ldx + 4 * lq;
+    float4 av[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 16 * g + 4 * lq;
+      av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // the whole float4 lies inside the row's allocation when k0 + 4 <= ldx; columns >= I are zeroed below
+      if (row_ok && k0 < a.I && k0 + 4 <= a.ldx) av[g] = *reinterpret_cast<const float4*>(xr + 16 * g);
+      else if (row_ok && k0 < a.I) {
+        av[g].x = xr[16 * g];
+        if (k0 + 1 < a.I) av[g].y = xr[16 * g + 1];
+        if (k0 + 2 < a.I) av[g].z = xr[16 * g + 2];
+      }
+      if (k0 + 1 >= a.I) av[g].y = 0.f;
+      if (k0 + 2 >= a.I) av[g].z = 0.f;
+      if (k0 + 3 >= a.I) av[g].w = 0.f;
+    }
+    f32x4 acc[OBT];
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float comp[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int ob = 0; ob < OBT; ++ob) acc[ob] = mfma16x16x4(wf[ob][g][s4], comp[s4], acc[ob]);
+    }
+    if (!row_ok) continue;
+    const float rscale = a.rowscale ? a.rowscale[row] : 1.f;
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) {
+      const int o0 = (ob0 + ob) * 16 + lq * 4;
+      if (o0 >= a.O) continue;
+      float* dst = a.y + row * a.ldy + o0;
+      const bool full = vec_store && o0 + 4 <= a.O;
+      float prev[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.accumulate) {
+        if (full) { const float4 p = *reinterpret_cast<const float4*>(dst); prev[0] = p.x; prev[1] = p.y; prev[2] = p.z; prev[3] = p.w; }
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (o0 + r < a.O) prev[r] = dst[r];
+      }
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + r;
+        float u = acc[ob][r] + bias[ob][r] + prev[r];
+        if (a.rowscale && o < a.rs_cols) u *= rscale;
+        if (o >= a.act_from) {
+          if (a.act & 1) u = fmaxf(u, 0.f);
+          if (a.drop_p > 0.f)
+            u = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : u * (1.f / (1.f - a.drop_p));
+        }
+        v[r] = u;
+      }
+      if (full) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o0 + r < a.O) dst[r] = v[r];
     }
   }
 }
@@ -253,6 +362,15 @@ static void launch_linear_mfma(const LinArgs& a, int ks, dim3 grid, hipStream_t 
   }
 }
 
+template <int OBT, bool TRANSPOSED>
+static void launch_linear_v4(const LinArgs& a, int g, dim3 grid, hipStream_t s) {
+  switch (g) {
+#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_mfma_v4_kernel<OBT, K, TRANSPOSED>), grid, dim3(kBlock), 0, s, a); break;
+    MLQEM_CASE(1) MLQEM_CASE(2) MLQEM_CASE(3) MLQEM_CASE(4) MLQEM_CASE(5) MLQEM_CASE(6) MLQEM_CASE(7) MLQEM_CASE(8)
+#undef MLQEM_CASE
+  }
+}
+
 static int round_ks(int ks) {
   const int opts[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 32};
   for (int o : opts) if (ks <= o) return o;
@@ -282,6 +400,14 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
     const int64_t tiles = ceil_div(N, 16);
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8);  // 4 waves per block
     dim3 grid(gx, (unsigned)ceil_div(ob, obt));
+    static const int v4_env = getenv("MLQEM_LINEAR_V4") ? atoi(getenv("MLQEM_LINEAR_V4")) : 1;
+    if (v4_env && ldx % 4 == 0 && aligned_to(x, 16)) {  // padded activation rows: 16-byte A-operand loads
+      const int g = (I + 15) / 16;
+      if (obt == 1) transposed ? launch_linear_v4<1, true>(a, g, grid, s) : launch_linear_v4<1, false>(a, g, grid, s);
+      else if (obt == 2) transposed ? launch_linear_v4<2, true>(a, g, grid, s) : launch_linear_v4<2, false>(a, g, grid, s);
+      else transposed ? launch_linear_v4<4, true>(a, g, grid, s) : launch_linear_v4<4, false>(a, g, grid, s);
+      return launch_status();
+    }
     if (obt == 1) transposed ? launch_linear_mfma<1, true>(a, ks, grid, s) : launch_linear_mfma<1, false>(a, ks, grid, s);
     else if (obt == 2) transposed ? launch_linear_mfma<2, true>(a, ks, grid, s) : launch_linear_mfma<2, false>(a, ks, grid, s);
     else transposed ? launch_linear_mfma<4, true>(a, ks, grid, s) : launch_linear_mfma<4, false>(a, ks, grid, s);

@@ -1,0 +1,24 @@
+"""Micro-benchmark of the dense forward kernel on the benchmark batch's shapes (A/B of operand-load variants is done
+by running this under MLQEM_LINEAR_V4=0 / 1)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
+import torch
+from blackwater.native import ops
+n = 2817008
+dev = torch.device("cuda:0")
+for (i, o, tr) in [(22, 10, False), (10, 10, False), (10, 1, False), (10, 22, True), (1, 10, True), (45, 180, False)]:
+    xs = [ops.padded_empty(n if i * o < 2000 else n // 8, i, dev).normal_() for _ in range(3)]
+    w = torch.randn((i, o) if tr else (o, i), device=dev)
+    ys = [ops.padded_empty(xs[0].shape[0], o, dev) for _ in range(3)]
+    want = (xs[0][:1000] @ (w if tr else w.t()))
+    got = ops.linear(xs[0], w, transposed=tr, out=ys[0])[:1000]
+    err = (got - want).abs().max().item()
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for k in range(3): ops.linear(xs[k], w, transposed=tr, out=ys[k])
+    beg.record()
+    for k in range(12): ops.linear(xs[k % 3], w, transposed=tr, out=ys[k % 3])
+    end.record(); torch.cuda.synchronize()
+    us = beg.elapsed_time(end) * 1e3 / 12
+    nb = xs[0].shape[0] * (xs[0].stride(0) + ys[0].stride(0)) * 4
+    print(f"I={i:3d} O={o:3d} transposed={tr!s:5s} rows={xs[0].shape[0]:8d}  {us:7.1f} us  {nb / us / 1e3:6.0f} GB/s (padded bytes)  maxerr {err:.2e}")
