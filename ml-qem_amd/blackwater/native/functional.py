@@ -123,6 +123,106 @@ def multi_linear(xs, ws, bias=None, relu=False, drop_p=0.0, seed=0):
     return _MultiLinear.apply(bias, relu, drop_p, seed, len(xs), *xs, *ws)
 
 
+class _ChebLayer(Function):
+    """ChebConv as ONE autograd node: T_0 = x, T_1 = L^x, T_k = 2 L^T_{k-1} - T_{k-2}; y = act(sum_k T_k W_k^T + b).
+    Backward runs the recurrence in reverse with the transposed aggregation, folding every "+=" into the aggregation
+    kernel's z/beta epilogue, so no gradient is ever summed by a separate elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, *ws):
+        s = struct
+        x = ops.rowmajor(x)
+        k = len(ws)
+        ws = [w.contiguous() for w in ws]
+        lap = dict(cscale=s.cheb_dinv, rscale=s.derived("cheb_neg"))
+        terms = [x]
+        if k > 1:
+            terms.append(ops.csr_aggregate(x, s.in_ptr, s.in_src, ell=s.in_ell, **lap))
+        for _ in range(2, k):
+            terms.append(ops.csr_aggregate(terms[-1], s.in_ptr, s.in_src, ell=s.in_ell, alpha=2.0, z=terms[-2],
+                                           beta=-1.0, **lap))
+        y = None
+        for i in range(k):
+            last = i == k - 1
+            y = ops.linear(terms[i], ws[i], bias if i == 0 else None, out=y, accumulate=i > 0, relu=relu and last,
+                           drop_p=drop_p if last else 0.0, seed=seed)
+        ctx.struct, ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias = s, k, relu, drop_p, bias is not None
+        ctx.save_for_backward(*terms, *ws, y if (relu or drop_p > 0) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        k, s = ctx.k, ctx.struct
+        saved = ctx.saved_tensors
+        terms, ws, y = saved[:k], saved[k:2 * k], saved[2 * k]
+        g = ops.rowmajor(g)
+        if y is not None:
+            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        gws, gb = [], None
+        for i in range(k):
+            gw = torch.empty_like(ws[i])
+            want_b = i == 0 and ctx.has_bias
+            if want_b:
+                gb = torch.empty(ws[i].shape[0], dtype=g.dtype, device=g.device)
+            ops.linear_wgrad(g, terms[i], gw, gb if want_b else None)
+            gws.append(gw)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # adjoint of the recurrence: a_k = g W_k; for k = K-1 .. 2: a_{k-1} += 2 L^T a_k, a_{k-2} -= a_k; gx = a_0 + L^T a_1
+            lap_t = dict(cscale=s.derived("cheb_neg"), rscale=s.cheb_dinv)
+            a = [ops.linear(g, ws[i], transposed=True) for i in range(k)]
+            for i in range(k - 1, 1, -1):
+                ops.csr_aggregate(a[i], s.out_ptr, s.out_dst, ell=s.out_ell, alpha=2.0, z=a[i - 1], beta=1.0,
+                                  out=a[i - 1], **lap_t)
+                a[i - 2] = a[i - 2] - a[i]
+            gx = a[0] if k == 1 else ops.csr_aggregate(a[1], s.out_ptr, s.out_dst, ell=s.out_ell, z=a[0], beta=1.0,
+                                                       out=a[0], **lap_t)
+        return (gx, gb, None, None, None, None, *gws)
+
+
+def cheb_layer(x, ws, bias, struct, relu=False, drop_p=0.0, seed=0):
+    return _ChebLayer.apply(x, bias, struct, relu, drop_p, seed, *ws)
+
+
+class _SAGELayer(Function):
+    """SAGEConv as ONE autograd node: y = act(mean_in(x) W_l^T + b + x W_r^T); gx = g W_r + mean_in^T(g W_l)."""
+
+    @staticmethod
+    def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed):
+        s = struct
+        x = ops.rowmajor(x)
+        wl, wr = wl.contiguous(), wr.contiguous()
+        mean = ops.csr_aggregate(x, s.in_ptr, s.in_src, ell=s.in_ell, rscale=s.sage_rinv, dself=s.derived("sage_dself"))
+        y = ops.linear(mean, wl, bl)
+        ops.linear(x, wr, out=y, accumulate=True, relu=relu, drop_p=drop_p, seed=seed)
+        ctx.struct, ctx.relu, ctx.drop_p = s, relu, drop_p
+        ctx.save_for_backward(x, mean, wl, wr, y if (relu or drop_p > 0) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, wl, wr, y = ctx.saved_tensors
+        s = ctx.struct
+        g = ops.rowmajor(g)
+        if y is not None:
+            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        gwl, gwr = torch.empty_like(wl), torch.empty_like(wr)
+        gbl = torch.empty(wl.shape[0], dtype=g.dtype, device=g.device)
+        ops.linear_wgrad(g, mean, gwl, gbl)
+        ops.linear_wgrad(g, x, gwr, None)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear(g, wr, transposed=True)
+            gm = ops.linear(g, wl, transposed=True)
+            ops.csr_aggregate(gm, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.sage_rinv,
+                              dself=s.derived("sage_dself"), z=gx, beta=1.0, out=gx)
+        return gx, gwl, gbl, gwr, None, None, None, None
+
+
+def sage_layer(x, wl, bl, wr, struct, relu=False, drop_p=0.0, seed=0):
+    return _SAGELayer.apply(x, wl, bl, wr, struct, relu, drop_p, seed)
+
+
 class _GCNLayer(Function):
     """y = act(D^-1/2 (A+I) D^-1/2 (x W^T) + b) as ONE autograd node.
 

@@ -66,9 +66,8 @@ class SAGEConv(nn.Module):
         self.lin_r = _WeightOnly(w)
 
     def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
-        mean = F.csr_aggregate(x, struct, rscale=struct.sage_rinv, dself=struct.derived("sage_dself"))
-        return F.multi_linear([mean, x], [self.lin_l.weight, self.lin_r.weight], self.lin_l.bias, relu=relu,
-                              drop_p=drop_p, seed=seed)
+        return F.sage_layer(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, struct, relu=relu, drop_p=drop_p,
+                            seed=seed)
 
 
 class ChebConv(nn.Module):
@@ -80,10 +79,4 @@ class ChebConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
     def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
-        lap = dict(cscale=struct.cheb_dinv, rscale=struct.derived("cheb_neg"))
-        terms = [x]
-        if len(self.lins) > 1:
-            terms.append(F.csr_aggregate(x, struct, **lap))
-            for _ in self.lins[2:]:
-                terms.append(F.csr_aggregate(terms[-1], struct, alpha=2.0, z=terms[-2], beta=-1.0, **lap))
-        return F.multi_linear(terms, [lin.weight for lin in self.lins], self.bias, relu=relu, drop_p=drop_p, seed=seed)
+        return F.cheb_layer(x, [lin.weight for lin in self.lins], self.bias, struct, relu=relu, drop_p=drop_p, seed=seed)

@@ -117,16 +117,25 @@ __device__ __forceinline__ int find_segment(const int32_t* __restrict__ ptr, int
   return lo;
 }
 
-// rows of x (and of the packed per-node scalars): flattened (node, column) so loads and stores stay coalesced
+// rows of x (and of the packed per-node scalars): flattened (node, 16-byte chunk) so loads and stores stay coalesced.
+// VEC4: both the arena's and the batch's feature rows are 16-byte aligned with F a multiple of 4 (the padded layout).
+template <bool VEC4>
 __global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArgs a) {
-  const int W = a.F + a.K;
+  const int FC = VEC4 ? a.F / 4 : a.F;         // feature chunks per row
+  const int W = FC + a.K;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= a.Nb * W) return;
   const int32_t i = (int32_t)(t / W);
   const int c = (int)(t - (int64_t)i * W);
   const int64_t gn = a.src_node[i];
-  if (c < a.F) a.xb[(int64_t)i * a.ldxb + c] = a.x[gn * a.ldx + c];
-  else a.nscal_b[(int64_t)i * a.K + (c - a.F)] = a.nscal[gn * a.K + (c - a.F)];
+  if (c < FC) {
+    if (VEC4)
+      reinterpret_cast<float4*>(a.xb + (int64_t)i * a.ldxb)[c] = reinterpret_cast<const float4*>(a.x + gn * a.ldx)[c];
+    else
+      a.xb[(int64_t)i * a.ldxb + c] = a.x[gn * a.ldx + c];
+  } else {
+    a.nscal_b[(int64_t)i * a.K + (c - FC)] = a.nscal[gn * a.K + (c - FC)];
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleArgs a) {
@@ -244,8 +253,15 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
   AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_out_eid, a_loops, sel, b_nptr, b_eptr,
                  (int)B, Nb, Eb, xb, ldxb, nscal_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, out_eid_b, loops_b};
   hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
-  if (Nb > 0)
-    hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)ceil_div(Nb * (F + K), kBlock)), dim3(kBlock), 0, stream, a);
+  if (Nb > 0) {
+    const bool vec4 = F % 4 == 0 && ldx % 4 == 0 && ldxb % 4 == 0 && aligned_to(x, 16) && aligned_to(xb, 16);
+    if (vec4)
+      hipLaunchKernelGGL(assemble_rows_kernel<true>, dim3((unsigned)ceil_div(Nb * (F / 4 + K), kBlock)), dim3(kBlock), 0,
+                         stream, a);
+    else
+      hipLaunchKernelGGL(assemble_rows_kernel<false>, dim3((unsigned)ceil_div(Nb * (F + K), kBlock)), dim3(kBlock), 0,
+                         stream, a);
+  }
   if (Eb > 0)
     hipLaunchKernelGGL(assemble_edges_kernel, dim3((unsigned)ceil_div(Eb, kBlock)), dim3(kBlock), 0, stream, a);
   return launch_status();
