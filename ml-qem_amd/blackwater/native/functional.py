@@ -77,52 +77,6 @@ def linear(x, w, b=None, relu=False):
     return y.reshape(*lead, w.shape[0])
 
 
-class _MultiLinear(Function):
-    """y = drop(act(sum_k x_k W_k^T + b)) -- ChebConv's sum over Chebyshev terms, SAGEConv's lin_l(mean) + lin_r(x) --
-    as chained accumulating GEMM launches and ONE autograd node (no elementwise adds / relu / dropout passes)."""
-
-    @staticmethod
-    def forward(ctx, bias, relu, drop_p, seed, k, *xs_ws):
-        xs = [ops.rowmajor(t) for t in xs_ws[:k]]
-        ws = [t.contiguous() for t in xs_ws[k:]]
-        y = None
-        for i, (x, w) in enumerate(zip(xs, ws)):
-            last = i == k - 1
-            y = ops.linear(x, w, bias if i == 0 else None, out=y, accumulate=i > 0, relu=relu and last,
-                           drop_p=drop_p if last else 0.0, seed=seed)
-        ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias = k, relu, drop_p, bias is not None
-        ctx.save_for_backward(*xs, *ws, y if (relu or drop_p > 0) else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        k = ctx.k
-        saved = ctx.saved_tensors
-        xs, ws, y = saved[:k], saved[k:2 * k], saved[2 * k]
-        g = ops.rowmajor(g)
-        if y is not None:
-            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
-        gb = None
-        gxs, gws = [], []
-        for i in range(k):
-            gxs.append(ops.linear(g, ws[i], transposed=True) if ctx.needs_input_grad[5 + i] else None)
-            gw = None
-            if ctx.needs_input_grad[5 + k + i] or (i == 0 and ctx.has_bias and ctx.needs_input_grad[0]):
-                gw = torch.empty_like(ws[i])
-                want_b = i == 0 and ctx.has_bias
-                if want_b:
-                    gb = torch.empty(ws[i].shape[0], dtype=g.dtype, device=g.device)
-                ops.linear_wgrad(g, xs[i], gw, gb if want_b else None)
-            gws.append(gw)
-        if ctx.has_bias and gb is None and ctx.needs_input_grad[0]:
-            gb = g.sum(0)
-        return (gb, None, None, None, None, *gxs, *gws)
-
-
-def multi_linear(xs, ws, bias=None, relu=False, drop_p=0.0, seed=0):
-    return _MultiLinear.apply(bias, relu, drop_p, seed, len(xs), *xs, *ws)
-
-
 class _ChebLayer(Function):
     """ChebConv as ONE autograd node: T_0 = x, T_1 = L^x, T_k = 2 L^T_{k-1} - T_{k-2}; y = act(sum_k T_k W_k^T + b).
     Backward runs the recurrence in reverse with the transposed aggregation, folding every "+=" into the aggregation
