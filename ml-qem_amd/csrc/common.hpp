@@ -70,6 +70,22 @@ template <int V> __device__ __forceinline__ void vstore(float* p, const float (&
   }
 }
 
+// Streaming (non-temporal) stores: the aggregation output is written once and read by a LATER kernel, so it should not
+// displace the source rows in L2 (measured -5...-9 % on the aggregation kernel).
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+template <int V> __device__ __forceinline__ void vstore_nt(float* p, const float (&r)[V]) {
+  if constexpr (V == 1) {
+    __builtin_nontemporal_store(r[0], p);
+  } else if constexpr (V == 2) {
+    nt_f2 t = {r[0], r[1]};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f2*>(p));
+  } else {
+    nt_f4 t = {r[0], r[1], r[2], r[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+  }
+}
+
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 __device__ __forceinline__ bool aligned_to_dev(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 

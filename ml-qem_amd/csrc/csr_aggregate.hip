@@ -33,7 +33,7 @@ struct AggArgs {
   const float* bias;
   int act; float drop_p; uint64_t seed;
   float* out; int64_t ldo;
-  int64_t N; int C; int CV; int R;
+  int64_t N; int C; int CV; int R; int nt;
 };
 
 constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rscale / dself)
@@ -63,7 +63,8 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
       res[v] = r;
     }
   }
-  vstore<VEC>(a.out + row * a.ldo + ch, res);
+  if (a.nt) vstore_nt<VEC>(a.out + row * a.ldo + ch, res);
+  else vstore<VEC>(a.out + row * a.ldo + ch, res);
 }
 
 template <int VEC, bool IS_MAX, int kItemsPerThread>
@@ -247,9 +248,11 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs
     const int lrow = (int)(((unsigned)lj * magic) >> 20);
     row[k] = (int)r0 + lrow;
     ch[k] = (lj - lrow * a.CV) * VEC;
-    e2[k] = reinterpret_cast<const int2*>(a.ell)[row[k]];
-    rs[k] = a.rscale ? a.rscale[row[k]] : 1.f;
-    ds[k] = a.dself ? a.dself[row[k]] : 0.f;
+    {
+      e2[k] = reinterpret_cast<const int2*>(a.ell)[row[k]];
+      rs[k] = a.rscale ? a.rscale[row[k]] : 1.f;
+      ds[k] = a.dself ? a.dself[row[k]] : 0.f;
+    }
   }
   float acc[kItemsPerThread][VEC], self[kItemsPerThread][VEC];
   float v0[kItemsPerThread][VEC], v1[kItemsPerThread][VEC], w0[kItemsPerThread], w1[kItemsPerThread];
@@ -387,6 +390,8 @@ static int launch_aggregate(AggArgs a, hipStream_t stream) {
   if (a.CV > kBlock) return MLQEM_ERR_UNSUPPORTED;
   // items per thread: measured best on MI355X (C = 10 and 22, 2.8M-node batch): 4 for the CSR walk (more loads in
   // flight per thread outweigh 6 waves/SIMD), 2 for the ELL-assisted kernel (8 waves/SIMD).  MLQEM_AGG_IPT overrides.
+  static const int nt_env = getenv("MLQEM_AGG_NT") ? atoi(getenv("MLQEM_AGG_NT")) : 1;  // streaming stores (-8 % measured)
+  a.nt = nt_env;
   static const int ipt_env = getenv("MLQEM_AGG_IPT") ? atoi(getenv("MLQEM_AGG_IPT")) : 0;
   const int ipt = ipt_env > 0 ? ipt_env : (a.ell ? 2 : 4);
   a.R = std::min(kRowsMax, kBlock * ipt / a.CV);
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* _
   vload<VEC>(y + r * ldy + c, yv);
 #pragma unroll
   for (int v = 0; v < VEC; ++v) o[v] = yv[v] > 0.f ? gv[v] * scale : 0.f;
-  vstore<VEC>(gx + r * ldgx + c, o);
+  vstore_nt<VEC>(gx + r * ldgx + c, o);
 }
 
 }  // namespace mlqem

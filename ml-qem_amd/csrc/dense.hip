@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
         }
         v[r] = u;
       }
-      if (full) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      if (full) vstore_nt<4>(dst, v);
       else
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (o0 + r < a.O) dst[r] = v[r];

@@ -130,7 +130,11 @@ __global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArg
   const int64_t gn = a.src_node[i];
   if (c < FC) {
     if (VEC4)
-      reinterpret_cast<float4*>(a.xb + (int64_t)i * a.ldxb)[c] = reinterpret_cast<const float4*>(a.x + gn * a.ldx)[c];
+    {
+      const float4 v = reinterpret_cast<const float4*>(a.x + gn * a.ldx)[c];
+      const float r[4] = {v.x, v.y, v.z, v.w};
+      vstore_nt<4>(a.xb + (int64_t)i * a.ldxb + 4 * c, r);
+    }
     else
       a.xb[(int64_t)i * a.ldxb + c] = a.x[gn * a.ldx + c];
   } else {
