@@ -47,11 +47,26 @@ class NgemJob(job_base()):  # type: ignore[misc]
         device = model_device(self._model)
         mitigated = []
         entries = []
+        native = None
+        if self._batched:  # the fast mode also encodes with the C++ encoder (bit-identical arrays, ~10x faster)
+            from ...data.circuit import Circuit, circuit_to_qasm
+            from ...data.graph import Data
+            from ...data.native_encoder import NativeEncoder
+
+            native = NativeEncoder(properties)
         for value, circuit, obs, params in zip(result.values, self._circuits, self._observables,
                                                self._parameter_values):
             if not is_pauli_observable(obs):
                 raise BlackwaterException("Only `PauliSumOp` observables are supported by NGEM.")
             bound = transpile_and_bind(circuit, self._backend, params, _options_dict(self._options))
+            if native is not None:
+                text = bound if isinstance(bound, str) else circuit_to_qasm(Circuit.from_any(bound))
+                x, ei, ea, _ = native.encode(text)
+                entries.append(Data(x=torch.from_numpy(x).float(), edge_index=torch.from_numpy(ei),
+                                    edge_attr=torch.from_numpy(ea).float(), y=torch.zeros(1, 1),
+                                    observable=torch.tensor([encode_pauli_sum_op(obs)], dtype=torch.float),
+                                    circuit_depth=torch.zeros(1, 1), noisy_0=torch.tensor([[value]], dtype=torch.float)))
+                continue
             graph = circuit_to_graph_data_json(circuit=bound, properties=properties, use_qubit_features=True,
                                                use_gate_features=True)
             data = ExpValueEntry(circuit_graph=graph, observable=encode_pauli_sum_op(obs), ideal_exp_value=0.0,
