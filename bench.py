@@ -150,12 +150,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # MLQEM_BENCH_BACKEND=gloo lets two ranks share one GPU to rehearse the multi-rank control flow on a 1-GPU box;
+    # the driver's runs use the default: one GPU per rank, RCCL ("nccl") over xGMI.
+    backend = os.environ.get("MLQEM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from blackwater.data.arena import GraphArena
     from blackwater.nn import ExpValCircuitGraphModelA
@@ -208,8 +216,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(corpus, np.arange(n_graphs), 100)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if distributed:
+        torch.distributed.barrier()  # rank 0 is still in its roofline leg: leave together
         torch.distributed.destroy_process_group()
 
 
