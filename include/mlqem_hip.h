@@ -190,17 +190,24 @@ int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr, const int
                        mlqem_stream_t stream);
 
 /* ASAPooling step 7 (torch-sparse S^T A S, remove_diag, coo): only the PATTERN is consumed by the models.
- * count: slot[N] (cluster id of each kept node, -1 elsewhere), offsets[K+1] (exclusive scan of candidate pairs per
- * cluster; offsets[K] = total T, read back by the caller).  fill: keys[T] = p << 32 | q, duplicates included.
- * sort_unique: ascending distinct keys + their number (device int64).  keys_to_edge_index: [2,E] int64 (src=p, dst=q),
- * i.e. row-major (p,q) order as SparseTensor.coo() returns it; feed it to mlqem_csr_build. */
-size_t mlqem_asap_coarsen_workspace_bytes(int64_t K);
-int mlqem_asap_coarsen_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
-                             const int32_t* out_dst, const int32_t* perm, int64_t N, int64_t K, int32_t* slot,
-                             int64_t* offsets, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
-int mlqem_asap_coarsen_fill(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
-                            const int32_t* out_dst, const int32_t* perm, const int32_t* slot, const int64_t* offsets,
-                            int64_t K, uint64_t* keys, mlqem_stream_t stream);
+ * Two hops with a sort-unique in between (counting every 3-step path explodes around 100-wire barriers):
+ *   hop1_count: slot[N] (cluster id of each kept node, -1 elsewhere), offsets[K+1] = exclusive scan of the (cluster p,
+ *               node v) candidates, v reachable in one step from a member of p; offsets[K] = total, read back by the caller
+ *   hop1_fill:  keys = p << 32 | v                 -> mlqem_sort_unique_u64 -> M distinct pairs
+ *   hop2_count / hop2_fill over those pairs: keys = p << 32 | q for every kept w in N+[v], q = slot[w] != p
+ *               -> mlqem_sort_unique_u64 -> the pooled edges in row-major (p, q) order, as SparseTensor.coo() lists them
+ *   mlqem_keys_to_edge_index: [2,E] int64 (src = p, dst = q); feed it to mlqem_csr_build. */
+size_t mlqem_asap_coarsen_workspace_bytes(int64_t K);   /* for a count call over K items (hop1: clusters, hop2: pairs) */
+int mlqem_asap_hop1_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                          const int32_t* perm, int64_t N, int64_t K, int32_t* slot, int64_t* offsets, void* workspace,
+                          size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_asap_hop1_fill(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                         const int32_t* perm, const int64_t* offsets, int64_t K, uint64_t* keys, mlqem_stream_t stream);
+int mlqem_asap_hop2_count(const uint64_t* pairs, int64_t M, const int32_t* out_ptr, const int32_t* out_dst,
+                          const int32_t* slot, int64_t* offsets, void* workspace, size_t workspace_bytes,
+                          mlqem_stream_t stream);
+int mlqem_asap_hop2_fill(const uint64_t* pairs, int64_t M, const int32_t* out_ptr, const int32_t* out_dst,
+                         const int32_t* slot, const int64_t* offsets, uint64_t* keys, mlqem_stream_t stream);
 size_t mlqem_sort_unique_u64_workspace_bytes(int64_t T);
 int mlqem_sort_unique_u64(const uint64_t* keys, int64_t T, uint64_t* out_keys, int64_t* out_count, void* workspace,
                           size_t workspace_bytes, mlqem_stream_t stream);

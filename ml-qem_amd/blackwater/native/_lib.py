@@ -45,8 +45,10 @@ SIGNATURES = {
     "mlqem_segment_topk_workspace_bytes": (_S, [_L, _L]),
     "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_workspace_bytes": (_S, [_L]),
-    "mlqem_asap_coarsen_count": (_I, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _S, _P]),
-    "mlqem_asap_coarsen_fill": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "mlqem_asap_hop1_count": (_I, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _S, _P]),
+    "mlqem_asap_hop1_fill": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "mlqem_asap_hop2_count": (_I, [_P, _L, _P, _P, _P, _P, _P, _S, _P]),
+    "mlqem_asap_hop2_fill": (_I, [_P, _L, _P, _P, _P, _P, _P, _P]),
     "mlqem_sort_unique_u64_workspace_bytes": (_S, [_L]),
     "mlqem_sort_unique_u64": (_I, [_P, _L, _P, _P, _P, _S, _P]),
     "mlqem_keys_to_edge_index": (_I, [_P, _L, _P, _P]),

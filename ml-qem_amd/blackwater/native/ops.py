@@ -297,34 +297,58 @@ def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_tot
     return perm
 
 
-def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes, return_slot=False):
-    """Edge list [2,E] int64 (cluster ids, row-major (src,dst) order, no diagonal) of the pooled graph.
-    Two small device->host reads (candidate total, distinct total) size the buffers."""
-    dev = perm.device
-    k = int(perm.shape[0])
+def _sort_unique(keys, total):
+    dev = keys.device
     lib = _lib.load()
-    slot = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=dev)
-    offsets = torch.empty(k + 1, dtype=torch.int64, device=dev)
-    need = lib.mlqem_asap_coarsen_workspace_bytes(k)
-    ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    code = lib.mlqem_asap_coarsen_count(_p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst), _p(perm), num_nodes, k,
-                                        _p(slot), _p(offsets), _p(ws), need, _stream())
-    _lib.check(code, "mlqem_asap_coarsen_count")
-    total = int(offsets[k].item())
-    if total == 0:
-        ei = torch.zeros((2, 0), dtype=torch.int64, device=dev)
-        return (ei, slot) if return_slot else ei
-    keys = torch.empty(total, dtype=torch.int64, device=dev)
-    code = lib.mlqem_asap_coarsen_fill(_p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst), _p(perm), _p(slot),
-                                       _p(offsets), k, _p(keys), _stream())
-    _lib.check(code, "mlqem_asap_coarsen_fill")
     uniq = torch.empty(total, dtype=torch.int64, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
     need = lib.mlqem_sort_unique_u64_workspace_bytes(total)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     code = lib.mlqem_sort_unique_u64(_p(keys), total, _p(uniq), _p(count), _p(ws), need, _stream())
     _lib.check(code, "mlqem_sort_unique_u64")
-    e = int(count.item())
+    return uniq, int(count.item())
+
+
+def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes, return_slot=False):
+    """Edge list [2,E] int64 (cluster ids, row-major (src,dst) order, no diagonal) of the pooled graph.
+    Two hops, each count -> fill -> sort-unique; four small device->host reads size the buffers."""
+    dev = perm.device
+    k = int(perm.shape[0])
+    lib = _lib.load()
+    slot = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=dev)
+    empty = torch.zeros((2, 0), dtype=torch.int64, device=dev)
+
+    def scan_ws(n):
+        need = lib.mlqem_asap_coarsen_workspace_bytes(n)
+        return torch.empty(need, dtype=torch.uint8, device=dev), need
+
+    offsets = torch.empty(k + 1, dtype=torch.int64, device=dev)
+    ws, need = scan_ws(k)
+    code = lib.mlqem_asap_hop1_count(_p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst), _p(perm), num_nodes, k, _p(slot),
+                                     _p(offsets), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_asap_hop1_count")
+    total = int(offsets[k].item())
+    if total == 0:
+        return (empty, slot) if return_slot else empty
+    keys = torch.empty(total, dtype=torch.int64, device=dev)
+    code = lib.mlqem_asap_hop1_fill(_p(in_ptr), _p(in_src), _p(out_ptr), _p(out_dst), _p(perm), _p(offsets), k, _p(keys),
+                                    _stream())
+    _lib.check(code, "mlqem_asap_hop1_fill")
+    pairs, m = _sort_unique(keys, total)
+    del keys
+    offsets2 = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    ws, need = scan_ws(m)
+    code = lib.mlqem_asap_hop2_count(_p(pairs), m, _p(out_ptr), _p(out_dst), _p(slot), _p(offsets2), _p(ws), need,
+                                     _stream())
+    _lib.check(code, "mlqem_asap_hop2_count")
+    total2 = int(offsets2[m].item())
+    if total2 == 0:
+        return (empty, slot) if return_slot else empty
+    keys2 = torch.empty(total2, dtype=torch.int64, device=dev)
+    code = lib.mlqem_asap_hop2_fill(_p(pairs), m, _p(out_ptr), _p(out_dst), _p(slot), _p(offsets2), _p(keys2), _stream())
+    _lib.check(code, "mlqem_asap_hop2_fill")
+    uniq, e = _sort_unique(keys2, total2)
+    del keys2
     ei = torch.empty((2, e), dtype=torch.int64, device=dev)
     code = lib.mlqem_keys_to_edge_index(_p(uniq), e, _p(ei), _stream())
     _lib.check(code, "mlqem_keys_to_edge_index")
