@@ -349,23 +349,3 @@ def asap_pool(x, mod, struct):
     x_out = _ASAPool.apply(x, mod.lin.weight, mod.lin.bias, mod.att.weight, mod.att.bias, g.lin1.weight, g.lin1.bias,
                            g.lin2.weight, g.lin3.weight, g.lin3.bias, struct, mod.ratio, mod.negative_slope, holder)
     return x_out, holder["structure"], holder["perm"]
-
-
-class _ForwardOnly(Function):
-    """Wraps a forward-only native op so that asking for its gradient fails loudly instead of silently
-    cutting the graph (Family B's backward kernels are the next milestone)."""
-
-    @staticmethod
-    def forward(ctx, fn, name, *tensors):
-        ctx.name = name
-        return fn(*[t.detach() if torch.is_tensor(t) else t for t in tensors])
-
-    @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError(f"{ctx.name}: backward kernel not implemented yet (forward/inference only)")
-
-
-def forward_only(fn, name, *tensors):
-    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
-        return _ForwardOnly.apply(fn, name, *tensors)
-    return fn(*tensors)

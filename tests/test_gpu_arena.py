@@ -81,3 +81,25 @@ def test_training_steps_follow_the_oracle(g1):
         assert abs(loss - ref_loss.item()) < 2e-4 * max(1.0, abs(ref_loss.item())), (step, loss, ref_loss.item())
     for (name, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         assert torch.allclose(p.detach().cpu(), q.detach(), rtol=2e-3, atol=2e-4), name
+
+
+def test_fit_epoch_loop_and_scheduler(g1):
+    """Trainer.fit: the reference's epoch loop (docs/tutorials/__ml_models.py:145-187): per-epoch shuffling, summed
+    validation loss into ReduceLROnPlateau, history without epoch 0; the loss goes down on the golden graphs."""
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import Trainer
+
+    arena = _arena(g1, 160)
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV)
+    trainer = Trainer(model, lr=1e-3)
+    seen = []
+    hist = trainer.fit(arena, train_ids=np.arange(0, 128), val_ids=np.arange(128, 160), epochs=6, batch_size=32,
+                       log=lambda epoch, h: seen.append(epoch))
+    assert seen == list(range(6))
+    assert len(hist["train_losses"]) == 5 and len(hist["val_losses"]) == 5  # epoch 0 is dropped, as in the reference
+    assert hist["train_losses"][-1] < hist["train_losses"][0]
+    assert trainer.optimizer.param_groups[0]["lr"] == 1e-3  # no plateau yet (patience 15)
+    sd = model.state_dict()  # parameters are views of the flat buffer but save/load like any module
+    clone = ExpValCircuitGraphModelA(5, 22, 10)
+    clone.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
