@@ -253,7 +253,7 @@ int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax
                                   int64_t lds, mlqem_stream_t stream);
 
 /* Backward of x_out = x'[perm] * fitness[perm] over all N rows (slot[i] = cluster id or -1 from
- * mlqem_asap_coarsen_count): gxnew[i,:] = gout[slot[i],:] * fitness[i] (0 for dropped rows), gfit[i] = gout[slot[i]].x'[i]. */
+ * mlqem_asap_hop1_count): gxnew[i,:] = gout[slot[i],:] * fitness[i] (0 for dropped rows), gfit[i] = gout[slot[i]].x'[i]. */
 int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, const float* xnew, int64_t ldn,
                                     const float* fitness, const int32_t* slot, int64_t N, int C, float* gxnew,
                                     int64_t ldgn, float* gfit, mlqem_stream_t stream);
