@@ -12,7 +12,13 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """The HIP stream torch currently launches on, as the integer handle the C ABI takes."""
+    if _raw_stream is not None:  # same handle as below without building a torch.cuda.Stream object per launch
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
