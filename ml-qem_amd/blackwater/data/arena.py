@@ -31,6 +31,16 @@ class DeviceBatch:
         return self.noisy_0, self.observable, self.circuit_depth, self.x, self.structure, None
 
 
+def _ranges(starts, lengths):
+    """Concatenation of arange(starts[i], starts[i] + lengths[i]) without a Python loop."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    total = int(lengths.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    first = np.cumsum(lengths) - lengths
+    return np.repeat(np.asarray(starts, dtype=np.int64) - first, lengths) + np.arange(total, dtype=np.int64)
+
+
 class GraphArena:
     def __init__(self, x, node_counts, structure_arrays, nscal, y, noisy, depth, observable, edge_counts):
         self.x = x
@@ -57,11 +67,53 @@ class GraphArena:
         node_counts = np.array([a.shape[0] for a in xs], dtype=np.int64)
         offs = np.concatenate([[0], np.cumsum(node_counts)])
         x_host = np.ascontiguousarray(np.concatenate(xs, axis=0), dtype=np.float32)
+        ei = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(edge_indices, offs[:-1])], axis=1)
+        return GraphArena._from_flat(x_host, node_counts, ei, y, noisy, depth, observable, device)
+
+    @staticmethod
+    def from_shards(shards, device="cuda", rank: int = 0, world: int = 1) -> "GraphArena":
+        """From binary shards (``data/shards.py``: paths or ``GraphShard`` objects).  With ``world > 1`` rank ``r``
+        keeps the graphs ``r, r + world, ...`` of the concatenated corpus (the data-parallel split by circuit)."""
+        from .shards import GraphShard, read_shard
+
+        parts = [s if isinstance(s, GraphShard) else read_shard(s) for s in shards]
+        if not parts:
+            raise ValueError("from_shards: no shards given")
+        xs, eis, counts, labels = [], [], [], {k: [] for k in ("y", "noisy", "depth", "observable")}
+        first = 0
+        for sh in parts:
+            keep = np.arange(len(sh))
+            keep = keep[(first + keep) % world == rank] if world > 1 else keep
+            first += len(sh)
+            n_of = np.diff(sh.node_ptr)[keep]
+            e_of = np.diff(sh.edge_ptr)[keep]
+            if world > 1:   # gather the kept graphs' rows / edges
+                rows = _ranges(np.asarray(sh.node_ptr)[keep], n_of)
+                cols = _ranges(np.asarray(sh.edge_ptr)[keep], e_of)
+                xs.append(np.asarray(sh.x)[rows])
+                eis.append(np.asarray(sh.edge_index)[:, cols].astype(np.int64))
+            else:
+                xs.append(np.asarray(sh.x))
+                eis.append(np.asarray(sh.edge_index).astype(np.int64))
+            counts.append((n_of, e_of))
+            for k in labels:
+                labels[k].append(np.asarray(sh.arrays[k])[keep])
+        node_counts = np.concatenate([c[0] for c in counts]).astype(np.int64)
+        edge_counts = np.concatenate([c[1] for c in counts]).astype(np.int64)
+        offs = np.concatenate([[0], np.cumsum(node_counts)])[:-1]
+        ei = np.concatenate(eis, axis=1) + np.repeat(offs, edge_counts)[None, :]   # graph-local -> arena-global ids
+        lab = {k: np.concatenate(v, axis=0) for k, v in labels.items()}
+        return GraphArena._from_flat(np.ascontiguousarray(np.concatenate(xs, axis=0), dtype=np.float32), node_counts,
+                                     ei, lab["y"], lab["noisy"], lab["depth"], lab["observable"], device)
+
+    @staticmethod
+    def _from_flat(x_host, node_counts, ei, y, noisy, depth, observable, device) -> "GraphArena":
+        """x_host [N,F] f32 (graphs back to back), ei [2,E] int64 with arena-global node ids."""
+        offs = np.concatenate([[0], np.cumsum(node_counts)])
         f = x_host.shape[1]
         f4 = (f + 3) // 4 * 4                                    # rows padded to a multiple of 4 floats, pads zero
         x = torch.zeros((x_host.shape[0], f4), dtype=torch.float32, device=torch.device(device))[:, :f]
         x.copy_(torch.from_numpy(x_host))
-        ei = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(edge_indices, offs[:-1])], axis=1)
         n_total = int(offs[-1])
         ei_dev = torch.from_numpy(np.ascontiguousarray(ei)).to(device)
         csr = ops.csr_build(ei_dev, n_total)

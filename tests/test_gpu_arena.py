@@ -103,3 +103,42 @@ def test_fit_epoch_loop_and_scheduler(g1):
     sd = model.state_dict()  # parameters are views of the flat buffer but save/load like any module
     clone = ExpValCircuitGraphModelA(5, 22, 10)
     clone.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
+
+
+def test_arena_from_shards_equals_arena_from_arrays(g1, tmp_path):
+    """Binary shards (data/shards.py) -> device arena: same batches as the per-graph-list path, for one rank and for
+    the round-robin split over two ranks."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.shards import pack_graphs, write_shard
+
+    count = 90
+    xs, eis = [], []
+    for i in range(count):
+        x, ei, _ = g1_graph(g1, i)
+        loops = np.arange(x.shape[0])
+        xs.append(x.astype(np.float32))
+        eis.append(np.concatenate([ei, np.stack([loops, loops])], axis=1))
+    host = g1_batch(g1, range(count))
+    lab = [host[k].numpy() for k in ("y", "noisy", "depth", "observable")]
+    want = GraphArena.from_arrays(xs, eis, *lab, device=DEV)
+    paths = []
+    for k, (lo, hi) in enumerate(((0, 50), (50, 90))):   # two shards of different sizes
+        paths.append(str(tmp_path / f"part{k}.mlqs"))
+        write_shard(paths[-1], pack_graphs(xs[lo:hi], eis[lo:hi], *[a[lo:hi] for a in lab]))
+    got = GraphArena.from_shards(paths, device=DEV)
+    assert np.array_equal(got.node_counts, want.node_counts) and np.array_equal(got.edge_counts, want.edge_counts)
+    for name in ("x", "gptr", "in_ptr", "in_src", "out_ptr", "out_dst", "loops", "out_eid", "nscal", "y", "noisy",
+                 "depth", "observable"):
+        assert torch.equal(getattr(got, name), getattr(want, name)), name
+    sel = [3, 77, 51, 49, 50]
+    a, b = got.batch(sel), want.batch(sel)
+    assert torch.equal(a.x, b.x) and torch.equal(a.structure.in_src, b.structure.in_src)
+    # rank r of 2 keeps graphs r, r+2, ...
+    for rank in (0, 1):
+        part = GraphArena.from_shards(paths, device=DEV, rank=rank, world=2)
+        ids = np.arange(rank, count, 2)
+        assert np.array_equal(part.node_counts, want.node_counts[ids])
+        pb, wb = part.batch(np.arange(len(ids))), want.batch(ids)
+        assert torch.equal(pb.x, wb.x) and torch.equal(pb.y, wb.y)
+        assert torch.equal(pb.structure.in_ptr, wb.structure.in_ptr) and torch.equal(pb.structure.in_src, wb.structure.in_src)
+        assert torch.equal(pb.structure.out_dst, wb.structure.out_dst)
