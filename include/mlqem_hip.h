@@ -290,6 +290,16 @@ int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* props, int us
                       int32_t* edge_src, int32_t* edge_dst, double* edge_attr);
 const char* mlqem_encode_last_error(void);
 
+/* Circuit-level features of the MLP regressors -- the per-circuit part of encode_data / encode_data_v2_ecr
+ * (docs/tutorials/mlp.py:111-145 count_gates_by_rotation_angle, :148-252; == blackwater/library/learning/mlp.py) from
+ * the same op scan as the graph encoder (host CPU):
+ *   gate_counts[i] = number of ops named gate_names[i]                  (QuantumCircuit.count_ops lookups)
+ *   angle_hist[b]  = number of one-qubit rx/ry/rz ops whose angle lies in bin b of bin_edges[num_edges]
+ *                    (numpy.histogram rule: [e_b, e_b+1), last bin closed; values outside are dropped).
+ * The caller passes the edges (numpy.arange(-2pi, 2pi + bin, bin) in the reference) so both sides bin identically. */
+int mlqem_circuit_features_qasm(const char* qasm, const char* const* gate_names, int num_gates, const double* bin_edges,
+                                int num_edges, int64_t* gate_counts, int64_t* angle_hist);
+
 #ifdef __cplusplus
 }
 #endif

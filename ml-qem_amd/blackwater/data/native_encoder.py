@@ -63,3 +63,19 @@ class NativeEncoder:
         if "not in the backend's gates_set" in msg:
             raise KeyError(msg)
         raise Exception(msg or f"mlqem_encode_qasm failed with code {code}")
+
+
+def circuit_features(qasm: str, gate_names, bin_edges) -> Tuple[np.ndarray, np.ndarray]:
+    """(gate counts [len(gate_names)], rotation-angle histogram [len(bin_edges) - 1]) of one OpenQASM-2 circuit through
+    ``mlqem_circuit_features_qasm`` -- the per-circuit part of ``encode_data`` / ``encode_data_v2_ecr``."""
+    lib = _lib.load()
+    names = [g.encode() for g in gate_names]
+    c_names = (ctypes.c_char_p * max(len(names), 1))(*names)
+    edges = np.ascontiguousarray(bin_edges, dtype=np.float64)
+    counts = np.zeros(len(names), dtype=np.int64)
+    hist = np.zeros(max(len(edges) - 1, 0), dtype=np.int64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    code = lib.mlqem_circuit_features_qasm(qasm.encode(), c_names, len(names), vp(edges), len(edges), vp(counts), vp(hist))
+    if code != 0:
+        raise Exception(lib.mlqem_encode_last_error().decode() or f"mlqem_circuit_features_qasm failed with code {code}")
+    return counts, hist

@@ -1,9 +1,10 @@
 """Learning-based estimator: wraps any qiskit-style Estimator class so that ``job.result()`` returns values
 post-processed by a pluggable processor (reference: blackwater/library/learning/estimator.py:22-30,151-328).
 
-In scope: the decorator, the job wrapper, the processor protocol, ``TorchLearningModelProcessor`` and
-``EmptyProcessor``.  ``ScikitLearningModelProcessor`` / ``ZNEProcessor`` (random-forest and ZNE baselines, no tensor
-math) are out of scope.
+In scope: the decorator, the job wrapper, the processor protocol, ``TorchLearningModelProcessor``,
+``EmptyProcessor`` and ``ScikitLearningModelProcessor`` (the random-forest / OLS baselines: same feature rows, the
+model stays on the host CPU by design).  ``ZNEProcessor`` (runs extra noisy circuits
+through a ZNE estimator; no model) is out of scope.
 """
 from __future__ import annotations
 
@@ -76,6 +77,28 @@ class TorchLearningModelProcessor(LearningMethodEstimatorProcessor):
         for k, o, c in zip(owners, out, coeffs):
             totals[k] = totals[k] + o * c
         return totals
+
+
+class ScikitLearningModelProcessor(LearningMethodEstimatorProcessor):
+    """The same per-term ``encode_data`` rows into anything with scikit-learn's ``predict`` (reference :90-148; the
+    demos fit ``RandomForestRegressor`` / OLS on these rows).  Host CPU only: there is no tensor work to move."""
+
+    def __init__(self, model, backend):
+        if not hasattr(model, "predict"):
+            raise BlackwaterException("ScikitLearningModelProcessor needs a fitted estimator with .predict(X)")
+        self._model = model
+        self._backend = backend
+        self._properties = get_backend_properties_v1(backend)
+
+    def process(self, expectation_value, circuits, observables, parameter_values):
+        total = 0.0
+        for term in observables:
+            row, _ = encode_data(circuits=[circuits], properties=self._properties, ideal_exp_vals=[[0.0]],
+                                 noisy_exp_vals=[[expectation_value]], num_qubits=1,
+                                 meas_bases=encode_pauli_sum_op([(str(term.paulis[0]), 1.0)]))
+            output = float(np.ravel(self._model.predict(row.numpy()))[0])
+            total = total + output * float(np.real(term.coeffs[0]))
+        return total
 
 
 class EmptyProcessor(LearningMethodEstimatorProcessor):

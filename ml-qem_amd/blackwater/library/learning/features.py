@@ -58,16 +58,27 @@ def _unwrap_single(noisy_exp_vals):
     return noisy_exp_vals
 
 
-def _fill_rows(X, circuits, gates_set, offset, bin_size, n_bins, n_vals, noisy_exp_vals, meas_bases):
+def _fill_rows(X, circuits, gates_set, offset, bin_size, n_bins, n_vals, noisy_exp_vals, meas_bases, native=False):
     c0, c1 = offset, offset + len(gates_set)
     a1 = c1 + n_bins
     v1 = a1 + n_vals
+    edges = np.arange(-2 * np.pi, 2 * np.pi + bin_size, bin_size)
     for i, circuit in enumerate(circuits):
-        circ = Circuit.from_any(circuit)
-        tally = circ.count_ops()
+        if native:
+            # the C++ op scan shared with the graph encoder (mlqem_circuit_features_qasm): same integers, no Python parse
+            if not isinstance(circuit, str):
+                raise TypeError("native=True takes OpenQASM-2 text (the 'circuit' field of the reference's datasets)")
+            from ...data.native_encoder import circuit_features
+
+            counts, hist = circuit_features(circuit, gates_set, edges)
+            counts, hist = counts.tolist(), hist.tolist()
+        else:
+            circ = Circuit.from_any(circuit)
+            tally = circ.count_ops()
+            counts, hist = [tally.get(g, 0) for g in gates_set], count_gates_by_rotation_angle(circ, bin_size)
         # integer tensors times a python float promote to float32, as in the reference
-        X[i, c0:c1] = torch.tensor([tally.get(g, 0) for g in gates_set]) * 0.01
-        X[i, c1:a1] = torch.tensor(count_gates_by_rotation_angle(circ, bin_size)) * 0.01
+        X[i, c0:c1] = torch.tensor(counts) * 0.01
+        X[i, c1:a1] = torch.tensor(hist) * 0.01
         if n_vals > 1:
             assert len(noisy_exp_vals[i]) == n_vals
         elif n_vals == 1:
@@ -79,7 +90,7 @@ def _fill_rows(X, circuits, gates_set, offset, bin_size, n_bins, n_vals, noisy_e
             X[i, v1:] = torch.tensor(basis)
 
 
-def encode_data(circuits, properties, ideal_exp_vals, noisy_exp_vals, num_qubits, meas_bases=None):
+def encode_data(circuits, properties, ideal_exp_vals, noisy_exp_vals, num_qubits, meas_bases=None, native=False):
     """Rows ``[8 | len(gates_set) | 40 | num_qubits | len(basis)]`` (58 wide for FakeLima, 4 observables)."""
     noisy_exp_vals = _unwrap_single(noisy_exp_vals)
     gates_set = sorted(properties["gates_set"])
@@ -90,11 +101,12 @@ def encode_data(circuits, properties, ideal_exp_vals, noisy_exp_vals, num_qubits
     n_bins = int(np.ceil(4 * np.pi / bin_size))
     X = torch.zeros([len(circuits), len(vec) + len(gates_set) + n_bins + num_qubits + len(meas_bases[0])])
     X[:, : len(vec)] = vec[None, :]
-    _fill_rows(X, circuits, gates_set, len(vec), bin_size, n_bins, num_qubits, noisy_exp_vals, meas_bases)
+    _fill_rows(X, circuits, gates_set, len(vec), bin_size, n_bins, num_qubits, noisy_exp_vals, meas_bases, native)
     return X, torch.tensor(ideal_exp_vals, dtype=torch.float32)
 
 
-def encode_data_v2_ecr(circuits, ideal_exp_vals, noisy_exp_vals, obs_size, meas_bases=None, two_q_gate="ecr"):
+def encode_data_v2_ecr(circuits, ideal_exp_vals, noisy_exp_vals, obs_size, meas_bases=None, two_q_gate="ecr",
+                       native=False):
     """Rows ``[5 gate counts | 160 angle bins | obs_size | len(basis)]`` (the demo feature set)."""
     noisy_exp_vals = _unwrap_single(noisy_exp_vals)
     if meas_bases is None:
@@ -103,5 +115,5 @@ def encode_data_v2_ecr(circuits, ideal_exp_vals, noisy_exp_vals, obs_size, meas_
     bin_size = 0.025 * np.pi
     n_bins = int(np.ceil(4 * np.pi / bin_size))
     X = torch.zeros([len(circuits), len(gates_set) + n_bins + obs_size + len(meas_bases[0])])
-    _fill_rows(X, circuits, gates_set, 0, bin_size, n_bins, obs_size, noisy_exp_vals, meas_bases)
+    _fill_rows(X, circuits, gates_set, 0, bin_size, n_bins, obs_size, noisy_exp_vals, meas_bases, native)
     return X, torch.tensor(ideal_exp_vals, dtype=torch.float32)

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mlqem_leconv_fitness_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
     "mlqem_encode_qasm": (_I, [c_char_p, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mlqem_encode_last_error": (c_char_p, []),
+    "mlqem_circuit_features_qasm": (_I, [c_char_p, _P, _I, _P, _I, _P, _P]),
 }
 
 _lib = None

@@ -4,6 +4,7 @@
 // same feature layout, same edge order (for each source op, its out-edges most recently inserted first), same doubles.
 // No DAG library: a DAG built by appending ops has one chain per wire, so the edge list follows from "the previous op
 // on each wire".  Pure C++17, no HIP calls: it can run on a box without a GPU.
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdlib>
@@ -301,5 +302,38 @@ extern "C" int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* pr
   } catch (const std::exception& err) {
     g_last_error = err.what();
     return MLQEM_ERR_BAD_ARG;
+  }
+}
+
+// Circuit-level features of the MLP regressors (docs/tutorials/mlp.py:111-145, 148-252): by-products of the same op scan.
+extern "C" int mlqem_circuit_features_qasm(const char* qasm, const char* const* gate_names, int num_gates,
+                                           const double* bin_edges, int num_edges, int64_t* gate_counts,
+                                           int64_t* angle_hist) {
+  if (!qasm || num_gates < 0 || num_edges < 0 || (num_gates && (!gate_names || !gate_counts)) ||
+      (num_edges && (!bin_edges || !angle_hist)))
+    return MLQEM_ERR_BAD_ARG;
+  try {
+    const Circuit c = parse_qasm(qasm);
+    for (int i = 0; i < num_gates; ++i) gate_counts[i] = 0;
+    const int bins = num_edges > 1 ? num_edges - 1 : 0;
+    for (int i = 0; i < bins; ++i) angle_hist[i] = 0;
+    for (const Op& op : c.ops) {
+      for (int i = 0; i < num_gates; ++i) if (op.name == gate_names[i]) ++gate_counts[i];
+      const bool rot = op.name == "rx" || op.name == "ry" || op.name == "rz";
+      if (!rot || op.qubits.size() != 1 || op.params.empty() || bins == 0) continue;
+      const double a = op.params[0];
+      if (!(a >= bin_edges[0]) || a > bin_edges[bins]) continue;          // outside, or NaN
+      // numpy.histogram with explicit edges: [e_i, e_{i+1}) and a closed last bin
+      int b = (int)(std::upper_bound(bin_edges, bin_edges + num_edges, a) - bin_edges) - 1;
+      if (b >= bins) b = bins - 1;
+      ++angle_hist[b];
+    }
+    return MLQEM_OK;
+  } catch (const ParseError& e) {
+    g_last_error = e.what;
+    return MLQEM_ERR_UNSUPPORTED;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return MLQEM_ERR_UNSUPPORTED;
   }
 }

@@ -7,7 +7,7 @@ import torch
 from blackwater.data.backends import PauliObservable
 from blackwater.exception import BlackwaterException
 from blackwater.library.learning.estimator import (EmptyProcessor, LearningMethodEstimatorProcessor, PostProcessedJob,
-                                                   TorchLearningModelProcessor, learning)
+                                                   ScikitLearningModelProcessor, TorchLearningModelProcessor, learning)
 from blackwater.library.ngem.estimator import NgemJob, ngem
 
 QASM = ('OPENQASM 2.0;\ninclude "qelib1.inc";\nqreg q[5];\ncreg meas[2];\nrz(0.3) q[0];\nsx q[0];\ncx q[0],q[1];\n'
@@ -131,3 +131,24 @@ def test_batched_postprocessing_equals_serial(lima_backend):
     want = [proc.process(0.5, QASM, two_terms, ()), proc.process(0.6, q2, PauliObservable("IIIIZ"), ())]
     got = learning(FakeEstimator, proc, skip_transpile=True)().run([QASM, q2], [two_terms, PauliObservable("IIIIZ")]).result()
     assert np.allclose(got.values, want, rtol=1e-6) and got.metadata[1]["original_value"] == pytest.approx(0.6)
+
+
+def test_scikit_processor_matches_torch_processor_on_a_linear_model(lima_backend):
+    """The RF / OLS baseline path (reference learning/estimator.py:90-148): the same 76-wide rows go to ``predict``; an
+    OLS fit and a torch Linear carrying its coefficients must agree through the decorator."""
+    from sklearn.linear_model import LinearRegression
+
+    rng = np.random.default_rng(0)
+    ols = LinearRegression().fit(rng.normal(size=(200, 76)), rng.normal(size=200))
+    lin = torch.nn.Linear(76, 1)
+    with torch.no_grad():
+        lin.weight.copy_(torch.tensor(ols.coef_, dtype=torch.float32)[None])
+        lin.bias.fill_(float(ols.intercept_))
+    obs = [PauliObservable([("ZIIII", 0.5), ("IXIII", -2.0)]), PauliObservable("IIIIZ")]
+    sk = learning(FakeEstimator, ScikitLearningModelProcessor(ols, lima_backend), skip_transpile=True)
+    th = learning(FakeEstimator, TorchLearningModelProcessor(lin, lima_backend), skip_transpile=True)
+    a = sk().run([QASM, QASM], obs).result().values
+    b = th().run([QASM, QASM], obs).result().values
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-4)
+    with pytest.raises(BlackwaterException):
+        ScikitLearningModelProcessor(object(), lima_backend)

@@ -53,3 +53,33 @@ def test_100_qubit_circuit_and_errors():
     x, ei, _, _ = enc.encode('OPENQASM 2.0;\ninclude "qelib1.inc";\nqreg q[3];\ncreg c[3];\nrz(-3*pi/4) q; // all\n'
                              'barrier q;\nmeasure q -> c;\n')
     assert x.shape[0] == 7 and x[0, 0] == -3 * np.pi / 4 and ei.shape[1] == 6
+
+
+def test_circuit_features_match_python_feature_rows(g1, golden_dir, lima_props):
+    """mlqem_circuit_features_qasm: gate counts and the rotation-angle histogram of the MLP
+    feature rows from the C++ op scan equal the Python path, bit for bit, on the reference's circuits."""
+    import torch
+
+    from blackwater.data.native_encoder import circuit_features
+    from blackwater.library.learning.features import count_gates_by_rotation_angle, encode_data, encode_data_v2_ecr
+
+    qasms = list(g1["qasm"][:40]) + [e["circuit"] for e in json.load(open(os.path.join(golden_dir, "encoder_goldens.json")))]
+    noisy = [[0.1 * (k % 7)] for k in range(len(qasms))]
+    ideal = [[0.0]] * len(qasms)
+    a, _ = encode_data(qasms, lima_props, ideal, noisy, num_qubits=1)
+    b, _ = encode_data(qasms, lima_props, ideal, noisy, num_qubits=1, native=True)
+    assert torch.equal(a, b) and a[:, 8:54].abs().sum() > 0
+    a, _ = encode_data_v2_ecr(qasms, ideal, noisy, obs_size=1, two_q_gate="cx")
+    b, _ = encode_data_v2_ecr(qasms, ideal, noisy, obs_size=1, two_q_gate="cx", native=True)
+    assert torch.equal(a, b) and a.shape[1] == 5 + 160 + 1
+    # bin edges: left-closed bins, closed last bin, outside values dropped, two-qubit rotations ignored
+    text = ('OPENQASM 2.0;\ninclude "qelib1.inc";\nqreg q[2];\nrz(0) q[0];\nrx(-2*pi) q[0];\nry(2*pi) q[1];\n'
+            'rz(7) q[0];\nrzz(0.3) q[0],q[1];\nrz(0.5) q;\nbarrier q;\n')
+    edges = np.array([-2 * np.pi, -1.0, 0.0, 0.5, 2 * np.pi])
+    counts, hist = circuit_features(text, ["rz", "barrier", "h", "rz"], edges)
+    assert counts.tolist() == [4, 1, 0, 4] and hist.tolist() == [1, 0, 1, 3]
+    bins = count_gates_by_rotation_angle(text, 0.1 * np.pi)
+    _, hist = circuit_features(text, [], np.arange(-2 * np.pi, 2 * np.pi + 0.1 * np.pi, 0.1 * np.pi))
+    assert hist.tolist() == bins
+    with pytest.raises(TypeError):
+        encode_data([Circuit.from_qasm_str(text)], lima_props, [[0.0]], [[0.1]], num_qubits=1, native=True)
