@@ -119,6 +119,26 @@ int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed
                      const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act, int accumulate,
                      float drop_p, uint64_t seed, int rs_cols, int act_from, mlqem_stream_t stream);
 
+/* A matrix given as up to four COLUMN BLOCKS in separate buffers: block p is ptr[p][N, cols] (row stride ld[p]) and
+ * stands at columns [p*width, p*width + cols) of the concatenation; columns cols..width-1 of a block are padding (read
+ * as 0, written as scratch).  For mlqem_linear_parts_f32 width and every ld must be multiples of 4 and every ptr 16-byte
+ * aligned (the padded activation layout). */
+typedef struct mlqem_col_parts {
+  int32_t count, width, cols, reserved;
+  void* ptr[4];
+  int64_t ld[4];
+} mlqem_col_parts;
+
+/* Y = X W^T + b over column-partitioned X and Y: W is [O, I] row-major (transposed = 0) or [I, O] (transposed = 1) with
+ * I = x->count * x->width, O = y->count * y->width, i.e. indexed in the concatenated column spaces, padding included
+ * (padding columns of X never reach the product).  b: [O] or NULL.  One launch replaces
+ *   - the per-term projections of ChebConv / SAGEConv that read the same input rows (fan-out: lins[k](x), lin_l(x),
+ *     lin_r(x); 01_ngem.ipynb cell [9]) and
+ *   - the sum of per-term data gradients (fan-in: gx = sum_k g_k W_k)
+ * without building the concatenation, whose wide rows would slow the aggregation gathers.  I <= 64. */
+int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* w, int transposed, const float* b,
+                           const mlqem_col_parts* y, int64_t N, mlqem_stream_t stream);
+
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 
 /* gw[o,i] (+)= sum_n gy[n,o] * x[n,i] ;  gb[o] (+)= sum_n gy[n,o]  (gb may be NULL).  Matrix-core partial sums per
@@ -126,6 +146,11 @@ size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
                            int64_t N, int I, int O, int accumulate, void* workspace, size_t workspace_bytes,
                            mlqem_stream_t stream);
+
+/* The same with gy given as column blocks (O = gy->count * gy->width rows of gw / entries of gb, padding rows are 0):
+ * the weight gradients of all terms that share the input x in one pass over x. */
+int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int64_t ldx, float* gw, float* gb, int64_t N,
+                                 int I, int accumulate, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Pooling over graphs.  Replaces global_mean_pool (docs/tutorials/gnn.py:114; 01_ngem.ipynb cell [9]).

@@ -154,7 +154,76 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
     return out
 
 
+def _col_parts(blocks, name: str, vector_rows: bool) -> "_lib.ColParts":
+    """The C view of a list of [N, c] blocks (one shape, padded rows when ``vector_rows``)."""
+    if not 1 <= len(blocks) <= 4:
+        raise ValueError(f"{name}: 1..4 column blocks, got {len(blocks)}")
+    n, c = blocks[0].shape
+    width = (c + 3) // 4 * 4
+    cp = _lib.ColParts()
+    cp.count, cp.width, cp.cols, cp.reserved = len(blocks), width, c, 0
+    for k, t in enumerate(blocks):
+        if tuple(t.shape) != (n, c):
+            raise ValueError(f"{name}: blocks must share one shape, got {tuple(t.shape)} vs {(n, c)}")
+        _mat(t, f"{name}[{k}]")
+        ld = int(t.stride(0)) if n >= 1 else width          # a one-row block still has to own its padding
+        if vector_rows and (ld < width or ld % 4 or t.data_ptr() % 16):
+            raise ValueError(f"{name}[{k}]: needs the padded row layout (ops.padded_empty), got stride {ld}")
+        cp.ptr[k], cp.ld[k] = t.data_ptr(), ld
+    return cp
+
+
+def pad_weight_blocks(ws, in_cols: int):
+    """[W_0; W_1; ...] for ``linear_parts`` with the blocks on the OUTPUT side: each [O, I] weight becomes a
+    [round_up(O, 4), round_up(I, 4)] zero-padded block, stacked along dim 0."""
+    o = ws[0].shape[0]
+    pad = torch.nn.functional.pad(torch.stack(list(ws)), (0, (in_cols + 3) // 4 * 4 - in_cols, 0, (o + 3) // 4 * 4 - o))
+    return pad.reshape(-1, pad.shape[-1])
+
+
+def linear_parts(xs, w, b, ys, transposed=False):
+    """[ys[0] | ys[1] | ...] = [xs[0] | xs[1] | ...] @ w.T + b over column blocks in separate (padded) buffers;
+    ``w`` is indexed in the padded concatenated spaces: [len(ys)*round_up(O,4), len(xs)*round_up(I,4)] (or its
+    transpose's layout with ``transposed=True``)."""
+    n = xs[0].shape[0]
+    xp, yp = _col_parts(xs, "xs", True), _col_parts(ys, "ys", True)
+    if ys[0].shape[0] != n:
+        raise ValueError("linear_parts: xs and ys differ in rows")
+    i_tot, o_tot = xp.count * xp.width, yp.count * yp.width
+    want = (i_tot, o_tot) if transposed else (o_tot, i_tot)
+    if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != want or not w.is_contiguous():
+        raise ValueError(f"linear_parts: w must be a contiguous fp32 cuda tensor of shape {want}, got {tuple(w.shape)}")
+    _vec(b, "b", o_tot)
+    import ctypes as _ct
+
+    code = _lib.load().mlqem_linear_parts_f32(_ct.addressof(xp), _p(w), 1 if transposed else 0, _p(b), _ct.addressof(yp),
+                                              n, _stream())
+    _lib.check(code, "mlqem_linear_parts_f32")
+    return ys
+
+
 _wgrad_ws = {}
+
+
+def linear_wgrad_parts(gys, x, gw, gb=None, accumulate=False):
+    """gw[k*W + o, i] (+)= sum_n gys[k][n, o] x[n, i]; gb likewise (W = round_up(O, 4); padding rows come out 0)."""
+    n, i = x.shape
+    gp = _col_parts(gys, "gys", False)
+    o_tot = gp.count * gp.width
+    if gys[0].shape[0] != n or tuple(gw.shape) != (o_tot, i) or not gw.is_contiguous() or gw.dtype != torch.float32:
+        raise ValueError(f"linear_wgrad_parts: gw must be contiguous fp32 [{o_tot}, {i}]")
+    _vec(gb, "gb", o_tot)
+    lib = _lib.load()
+    need = lib.mlqem_linear_wgrad_workspace_bytes(i, o_tot)
+    key = (x.device, need)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    import ctypes as _ct
+
+    code = lib.mlqem_linear_wgrad_parts_f32(_ct.addressof(gp), _p(x), _mat(x, "x"), _p(gw), _p(gb), n, i,
+                                            1 if accumulate else 0, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_linear_wgrad_parts_f32")
 
 
 def linear_wgrad(gy, x, gw, gb=None, accumulate=False):

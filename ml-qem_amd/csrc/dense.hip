@@ -205,6 +205,103 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
   }
 }
 
+// ------------------------------------------------------------------------- column-partitioned operands
+// Y = X W^T (+ b) where X and/or Y are CONCATENATIONS OF COLUMN BLOCKS THAT LIVE IN SEPARATE BUFFERS: block p of X is
+// xp[p][N, xc] and occupies columns [p*xw, p*xw + xc) of the concatenated matrix (xw = multiple of 4; the columns
+// between xc and xw are padding: read as 0, written as scratch).  One read of a shared input serves several
+// projections (fan-out: y_p = x W_p^T) and one write serves a sum of projections (fan-in: y = sum_p x_p W_p^T)
+// without ever materialising the concatenation -- whose rows would be too wide for the aggregation gathers.
+// Same lane maps and summation order as linear_mfma_v4_kernel; every row access is one aligned float4.
+struct PartsArgs {
+  const float* xp[4]; int64_t ldx[4]; int xn, xw, xc;
+  float* yp[4]; int64_t ldy[4]; int yn, yw, yc;
+  const float* w; const float* b;
+  int64_t N; int I, O;   // I = xn * xw, O = yn * yw: the shape of W ([O, I], or [I, O] when TRANSPOSED)
+};
+
+template <int OBT, int G, bool TRANSPOSED>
+__global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kBlock) >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ob0 = blockIdx.y * OBT;
+
+  // this lane's input column groups: k0 = 16g + 4*lq .. +3 lie inside ONE block (xw is a multiple of 4)
+  const float* xcol[G]; int64_t xld[G]; int xlive[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int k0 = 16 * g + 4 * lq;
+    const int part = k0 / a.xw, lc = k0 - part * a.xw;
+    const bool ok = k0 < a.I && part < a.xn && lc < a.xc;
+    xcol[g] = ok ? a.xp[part] + lc : nullptr;
+    xld[g] = ok ? a.ldx[part] : 0;
+    xlive[g] = ok ? min(4, a.xc - lc) : 0;
+  }
+  float wf[OBT][G][4];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o = (ob0 + ob) * 16 + lr;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 16 * g + 4 * lq + s4;
+        float v = 0.f;
+        if (o < a.O && k < a.I && s4 < xlive[g]) v = TRANSPOSED ? a.w[(int64_t)k * a.O + o] : a.w[(int64_t)o * a.I + k];
+        wf[ob][g][s4] = v;
+      }
+  }
+  float bias[OBT][4];
+  float* ycol[OBT]; int64_t yld[OBT];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o0 = (ob0 + ob) * 16 + lq * 4;
+    const int part = o0 / a.yw, lc = o0 - part * a.yw;
+    const bool ok = o0 < a.O && part < a.yn;
+    ycol[ob] = ok ? a.yp[part] + lc : nullptr;
+    yld[ob] = ok ? a.ldy[part] : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[ob][r] = (a.b && ok && lc + r < a.yc) ? a.b[o0 + r] : 0.f;
+  }
+
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    const int64_t row = t * 16 + lr;
+    const bool row_ok = row < a.N;
+    float4 av[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row_ok && xcol[g]) av[g] = *reinterpret_cast<const float4*>(xcol[g] + row * xld[g]);
+      if (xlive[g] < 2) av[g].y = 0.f;     // padding may hold anything (NaN included): it must not reach the MFMA
+      if (xlive[g] < 3) av[g].z = 0.f;
+      if (xlive[g] < 4) av[g].w = 0.f;
+      if (xlive[g] < 1) av[g].x = 0.f;
+    }
+    f32x4 acc[OBT];
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float comp[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int ob = 0; ob < OBT; ++ob) acc[ob] = mfma16x16x4(wf[ob][g][s4], comp[s4], acc[ob]);
+    }
+    if (!row_ok) continue;
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) {
+      if (!ycol[ob]) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[ob][r] + bias[ob][r];
+      vstore_nt<4>(ycol[ob] + row * yld[ob], v);
+    }
+  }
+}
+
 // Generic fallback (any I; used for I > 128): thread per (row, output); a block stages one chunk of `oc` outputs' weights
 // in LDS (blockIdx.y selects the chunk).
 template <bool TRANSPOSED>
@@ -241,7 +338,8 @@ __global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a, 
 
 // ------------------------------------------------------------------------------------------ weight gradient
 struct WgradArgs {
-  const float* gy; int64_t ldgy;
+  const float* gyp[4]; int64_t ldgy[4];   // gy = column blocks in separate buffers (see PartsArgs); one block: gn = 1
+  int gn, gw, gc;                          // blocks, columns per block in the concatenation, meaningful columns per block
   const float* x; int64_t ldx;
   float* partial;          // [gridDim.x][O * (I + 1)]
   int64_t N; int I; int O;
@@ -267,6 +365,17 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
 #pragma unroll
     for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // this lane's gradient columns o = 16*ob + lr: which block they live in is fixed for the whole kernel
+  const float* gcol[OBT]; int64_t gld[OBT];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o = (ob0 + ob) * 16 + lr;
+    const int part = o / a.gw, lc = o - part * a.gw;
+    const bool ok = o < a.O && part < a.gn && lc < a.gc;
+    gcol[ob] = ok ? a.gyp[part] + lc : nullptr;
+    gld[ob] = ok ? a.ldgy[part] : 0;
+  }
+
   const int64_t rows_per_iter = 4 * kWgradUnroll;
   const int64_t n_iters = ceil_div(a.N, rows_per_iter);
   for (int64_t it = wave; it < n_iters; it += n_waves) {
@@ -276,10 +385,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
       const int64_t n = it * rows_per_iter + u * 4 + lq;
       const bool ok = n < a.N;
 #pragma unroll
-      for (int ob = 0; ob < OBT; ++ob) {
-        const int o = (ob0 + ob) * 16 + lr;
-        af[u][ob] = (ok && o < a.O) ? a.gy[n * a.ldgy + o] : 0.f;
-      }
+      for (int ob = 0; ob < OBT; ++ob) af[u][ob] = (ok && gcol[ob]) ? gcol[ob][n * gld[ob]] : 0.f;
 #pragma unroll
       for (int ib = 0; ib < IBT; ++ib) {
         const int i = (ib0 + ib) * 16 + lr;
@@ -425,8 +531,67 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
   return launch_status();
 }
 
+template <bool TRANSPOSED>
+static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, hipStream_t s) {
+#define MLQEM_PARTS(OB, K) hipLaunchKernelGGL((linear_parts_kernel<OB, K, TRANSPOSED>), grid, dim3(kBlock), 0, s, a); return true;
+#define MLQEM_PARTS_G(OB) switch (g) { case 1: MLQEM_PARTS(OB, 1) case 2: MLQEM_PARTS(OB, 2) case 3: MLQEM_PARTS(OB, 3) case 4: MLQEM_PARTS(OB, 4) default: return false; }
+  if (obt == 1) MLQEM_PARTS_G(1)
+  if (obt == 2) MLQEM_PARTS_G(2)
+  MLQEM_PARTS_G(4)
+#undef MLQEM_PARTS_G
+#undef MLQEM_PARTS
+}
+
+static bool parts_ok(const mlqem_col_parts* p, bool vector_rows) {
+  if (!p || p->count < 1 || p->count > 4 || p->width < 1 || p->cols < 1 || p->cols > p->width) return false;
+  if (vector_rows && p->width % 4) return false;
+  for (int i = 0; i < p->count; ++i) {
+    if (!p->ptr[i] || p->ld[i] < (vector_rows ? p->width : p->cols)) return false;
+    if (vector_rows && (p->ld[i] % 4 || !aligned_to(p->ptr[i], 16))) return false;
+  }
+  return true;
+}
+
+extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* w, int transposed, const float* b,
+                                      const mlqem_col_parts* y, int64_t N, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || !w || !parts_ok(x, true) || !parts_ok(y, true)) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  PartsArgs a{};
+  for (int i = 0; i < x->count; ++i) { a.xp[i] = static_cast<const float*>(x->ptr[i]); a.ldx[i] = x->ld[i]; }
+  for (int i = 0; i < y->count; ++i) { a.yp[i] = static_cast<float*>(y->ptr[i]); a.ldy[i] = y->ld[i]; }
+  a.xn = x->count; a.xw = x->width; a.xc = x->cols;
+  a.yn = y->count; a.yw = y->width; a.yc = y->cols;
+  a.w = w; a.b = b; a.N = N; a.I = x->count * x->width; a.O = y->count * y->width;
+  const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
+  if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
+  const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : 4);
+  const int64_t tiles = ceil_div(N, 16);
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
+  const bool ok = transposed ? launch_linear_parts<true>(a, g, obt, grid, as_stream(stream))
+                             : launch_linear_parts<false>(a, g, obt, grid, as_stream(stream));
+  return ok ? launch_status() : MLQEM_ERR_UNSUPPORTED;
+}
+
 extern "C" size_t mlqem_linear_wgrad_workspace_bytes(int I, int O) {
   return (size_t)kWgradBlocks * O * (I + 1) * sizeof(float);
+}
+
+static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipStream_t s) {
+  const int64_t iters = ceil_div(std::max<int64_t>(a.N, 1), 4 * kWgradUnroll);
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
+  const int ob = (a.O + 15) / 16, ib = (a.I + 1 + 15) / 16;
+  if (ob == 1 && ib <= 2) {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+  } else if (ob == 1) {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<2, 4>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4))), dim3(kBlock),
+                       0, s, a);
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), 32)), dim3(kBlock), 0, s, a.partial,
+                     G, a.I, a.O, gw, gb, accumulate);
+  return launch_status();
 }
 
 extern "C" int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
@@ -436,21 +601,23 @@ extern "C" int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float
   if (N < 0 || I <= 0 || O <= 0 || !gw || ldgy < O || ldx < I) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, O)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && (!gy || !x)) return MLQEM_ERR_BAD_ARG;
-  const int64_t iters = ceil_div(std::max<int64_t>(N, 1), 4 * kWgradUnroll);
-  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
-  float* partial = static_cast<float*>(workspace);
-  WgradArgs a{gy, ldgy, x, ldx, partial, N, I, O};
-  const int ob = (O + 15) / 16, ib = (I + 1 + 15) / 16;
-  hipStream_t s = as_stream(stream);
-  if (ob == 1 && ib <= 2) {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
-  } else if (ob == 1) {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<2, 4>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4))), dim3(kBlock),
-                       0, s, a);
-  }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), 32)), dim3(kBlock), 0, s, partial, G, I,
-                     O, gw, gb, accumulate);
-  return launch_status();
+  WgradArgs a{};
+  a.gyp[0] = gy; a.ldgy[0] = ldgy; a.gn = 1; a.gw = O; a.gc = O;
+  a.x = x; a.ldx = ldx; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
+  return launch_wgrad(a, gw, gb, accumulate, as_stream(stream));
+}
+
+extern "C" int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int64_t ldx, float* gw, float* gb,
+                                            int64_t N, int I, int accumulate, void* workspace, size_t workspace_bytes,
+                                            mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || I <= 0 || !gw || ldx < I || !parts_ok(gy, false)) return MLQEM_ERR_BAD_ARG;
+  const int O = gy->count * gy->width;
+  if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, O)) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && !x) return MLQEM_ERR_BAD_ARG;
+  WgradArgs a{};
+  for (int i = 0; i < gy->count; ++i) { a.gyp[i] = static_cast<const float*>(gy->ptr[i]); a.ldgy[i] = gy->ld[i]; }
+  a.gn = gy->count; a.gw = gy->width; a.gc = gy->cols;
+  a.x = x; a.ldx = ldx; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
+  return launch_wgrad(a, gw, gb, accumulate, as_stream(stream));
 }

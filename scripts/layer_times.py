@@ -1,0 +1,64 @@
+"""Per-layer device time of the Family A train step on the benchmark batch (HIP events, forward and backward apart)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
+import numpy as np, torch
+import bench
+from blackwater.data.arena import GraphArena
+from blackwater.native import functional as F, ops
+from blackwater.nn.conv import ChebConv, GCNConv, SAGEConv
+
+dev = torch.device("cuda", 0)
+corpus = bench.build_corpus(50)
+arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
+                               corpus["observable"], device=dev)
+n_graphs = len(corpus["x"])
+b = arena.batch(np.arange(256) * n_graphs // 256)
+s, x = b.structure, b.x
+n = x.shape[0]
+print(f"N = {n}, E = {s.num_edges}")
+torch.manual_seed(0)
+
+
+def timed(fn, reps=10):
+    for _ in range(2):
+        fn()
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    beg.record()
+    for _ in range(reps):
+        fn()
+    end.record(); end.synchronize()
+    return beg.elapsed_time(end) * 1e3 / reps
+
+
+def layer(name, mod, inp, needs_gx, **kw):
+    mod = mod.to(dev)
+    inp = inp.detach().requires_grad_(needs_gx)
+    fwd = timed(lambda: mod(inp, s, **kw))
+    y = mod(inp, s, **kw)
+    g = ops.padded_empty(n, y.shape[1], dev).normal_()
+    def bwd():
+        torch.autograd.backward(y, g, retain_graph=True)
+    t_b = timed(bwd)
+    print(f"{name:28s} fwd {fwd:7.1f} us   bwd {t_b:7.1f} us")
+    return fwd + t_b
+
+
+h10 = ops.padded_empty(n, 10, dev).normal_()
+tot = 0.0
+tot += layer("conv1 GCN 22->10 relu drop", GCNConv(22, 10), x, False, relu=True, drop_p=0.1, seed=1)
+tot += layer("conv2 GCN 10->10 relu drop", GCNConv(10, 10), h10, True, relu=True, drop_p=0.1, seed=2)
+tot += layer("conv3 GCN 10->1", GCNConv(10, 1), h10, True)
+tot += layer("cheb1 22->10 K3 relu drop", ChebConv(22, 10, K=3), x, False, relu=True, drop_p=0.2, seed=3)
+tot += layer("cheb2 10->1 K2", ChebConv(10, 1, K=2), h10, True)
+tot += layer("sage1 22->10 relu drop", SAGEConv(22, 10), x, False, relu=True, drop_p=0.2, seed=4)
+tot += layer("sage2 10->1", SAGEConv(10, 1), h10, True)
+h1 = ops.padded_empty(n, 1, dev).normal_().requires_grad_(True)
+f = timed(lambda: F.segment_mean(h1, s))
+y = F.segment_mean(h1, s); g = torch.randn_like(y)
+bw = timed(lambda: torch.autograd.backward(y, g, retain_graph=True))
+print(f"{'segment_mean [N,1] (x3)':28s} fwd {f:7.1f} us   bwd {bw:7.1f} us")
+tot += 3 * (f + bw)
+t_asm = timed(lambda: arena.batch(np.arange(256) * n_graphs // 256))
+print(f"{'batch assemble':28s}     {t_asm:7.1f} us")
+print(f"sum of layers + 3 pools + assemble: {tot + t_asm:.1f} us")

@@ -195,3 +195,72 @@ def test_segment_mean_forward_backward():
         want.backward(go.double())
         got.backward(go.to(DEV))
         assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-7)
+
+
+def _padded(t, poison=True):
+    """A device copy of ``t`` in the padded row layout, the pad columns holding NaN (they are scratch by contract)."""
+    from blackwater.native import ops
+
+    n, c = t.shape
+    out = ops.padded_empty(n, c, DEV)
+    if poison and out.stride(0) > c and n > 0:
+        torch.as_strided(out, (n, out.stride(0)), (out.stride(0), 1)).fill_(float("nan"))
+    out.copy_(t.to(DEV))
+    return out
+
+
+@pytest.mark.parametrize("n,i,o,k", [(1, 22, 10, 3), (1000, 22, 10, 3), (777, 10, 1, 2), (4099, 10, 10, 2), (50, 5, 3, 4),
+                                     (333, 45, 13, 1)])
+def test_linear_over_column_blocks(n, i, o, k):
+    """mlqem_linear_parts_f32 / mlqem_linear_wgrad_parts_f32: fan-out (one input, k outputs), fan-in (k inputs summed
+    into one output, the data-gradient form) and the k weight gradients in one pass, against fp64 algebra; the pad
+    columns of every operand hold NaN and must not leak."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(n * 31 + i * 7 + o + k)
+    x = torch.randn(n, i, generator=g)
+    ws = [torch.randn(o, i, generator=g) / i ** 0.5 for _ in range(k)]
+    bs = [torch.randn(o, generator=g) for _ in range(k)]
+    ow = (o + 3) // 4 * 4
+    w_cat = ops.pad_weight_blocks([w.to(DEV) for w in ws], i).contiguous()
+    assert tuple(w_cat.shape) == (k * ow, (i + 3) // 4 * 4)
+    b_cat = torch.zeros(k * ow, device=DEV)
+    for j in range(k):
+        b_cat[j * ow: j * ow + o] = bs[j].to(DEV)
+    # fan-out
+    xd = _padded(x)
+    ys = [_padded(torch.zeros(n, o)) for _ in range(k)]
+    ops.linear_parts([xd], w_cat, b_cat, ys)
+    for j in range(k):
+        want = x.double() @ ws[j].double().t() + bs[j].double()
+        assert torch.allclose(ys[j].cpu().double(), want, rtol=1e-5, atol=1e-5), j
+    # fan-in, transposed: gx = sum_j g_j @ W_j
+    gs = [torch.randn(n, o, generator=g) for _ in range(k)]
+    gd = [_padded(t) for t in gs]
+    gx = _padded(torch.zeros(n, i))
+    ops.linear_parts(gd, w_cat, None, [gx], transposed=True)
+    want = sum(gs[j].double() @ ws[j].double() for j in range(k))
+    assert torch.allclose(gx.cpu().double(), want, rtol=1e-5, atol=1e-5)
+    # weight gradients of all blocks in one pass over x
+    gw = torch.empty(k * ow, i, device=DEV)
+    gb = torch.empty(k * ow, device=DEV)
+    ops.linear_wgrad_parts(gd, xd, gw, gb)
+    gw3, gb2 = gw.cpu().double().reshape(k, ow, i), gb.cpu().double().reshape(k, ow)
+    for j in range(k):
+        want_w, want_b = gs[j].double().t() @ x.double(), gs[j].double().sum(0)
+        scale = want_w.abs().max().item() + 1e-12
+        assert (gw3[j, :o] - want_w).abs().max().item() / scale < 2e-5
+        assert (gb2[j, :o] - want_b).abs().max().item() / (want_b.abs().max().item() + 1e-12) < 2e-5
+        assert not gw3[j, o:].any() and not gb2[j, o:].any()          # padding rows: exactly zero, never NaN
+
+
+def test_linear_over_column_blocks_rejects_unpadded_operands():
+    from blackwater.native import ops
+
+    x = torch.randn(64, 22, device=DEV)                                # compact rows: stride 22, not a multiple of 4
+    y = ops.padded_empty(64, 10, DEV)
+    w = torch.zeros(12, 24, device=DEV)
+    with pytest.raises(ValueError, match="padded row layout"):
+        ops.linear_parts([x], w, None, [y])
+    with pytest.raises(ValueError, match="shape"):
+        ops.linear_parts([ops.padded_empty(64, 22, DEV)], torch.zeros(12, 22, device=DEV), None, [y])
