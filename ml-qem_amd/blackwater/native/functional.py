@@ -77,10 +77,108 @@ def linear(x, w, b=None, relu=False):
     return y.reshape(*lead, w.shape[0])
 
 
+def _mask_grad(g, y, drop_p):
+    """Gradient through the fused ReLU / dropout epilogue (the mask is read back from the saved output)."""
+    g = ops.rowmajor(g)
+    if y is None:
+        return g
+    return ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0)
+
+
+_PARTS_MAX_COLS = 64   # mlqem_linear_parts_f32 keeps the weight fragments of I <= 64 concatenated columns in registers
+
+
+def _padded_rows(t):
+    return t if (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1) else ops.padded_copy(t)
+
+
+def _fan_out(x, blocks, b_cat, o):
+    """[x W_0^T | x W_1^T | ...] (+ b_cat) into separate padded buffers: one launch, x read once."""
+    n, i = x.shape
+    outs = [ops.padded_empty(n, o, x.device) for _ in blocks]
+    w_cat = ops.pad_weight_blocks(blocks, i)
+    if i <= _PARTS_MAX_COLS:
+        ops.linear_parts([x], w_cat, b_cat, outs)
+    else:   # wide inputs: one launch per block
+        ow = (o + 3) // 4 * 4
+        for j, w in enumerate(blocks):
+            ops.linear(x, w.contiguous(), None if b_cat is None else b_cat[j * ow: j * ow + o], out=outs[j])
+    return outs, w_cat
+
+
+def _fan_in_t(gs, w_cat, o, i):
+    """gx = sum_j gs[j] W_j (W_j = block j of the padded ``w_cat``): one launch, gx written once."""
+    n = gs[0].shape[0]
+    ow = (o + 3) // 4 * 4
+    gx = ops.padded_empty(n, i, gs[0].device)
+    if len(gs) * ow <= _PARTS_MAX_COLS:
+        ops.linear_parts(gs, w_cat, None, [gx], transposed=True)
+    else:
+        for j, g in enumerate(gs):
+            ops.linear(g, w_cat[j * ow: j * ow + o, :i].contiguous(), transposed=True, out=gx, accumulate=j > 0)
+    return gx
+
+
 class _ChebLayer(Function):
-    """ChebConv as ONE autograd node: T_0 = x, T_1 = L^x, T_k = 2 L^T_{k-1} - T_{k-2}; y = act(sum_k T_k W_k^T + b).
+    """ChebConv (K = 2, 3) as ONE autograd node, evaluated PROJECT-FIRST (Clenshaw form).
+
+    PyG computes T_0 = x, T_1 = L^x, T_2 = 2 L^T_1 - x and then sum_k T_k W_k^T (ChebConv.forward): every aggregation
+    runs at the INPUT width and three [N, I] tensors are kept for the backward.  The same polynomial, re-associated:
+
+        c_k = x W_k^T                      one GEMM over column blocks, x read once
+        b_1 = c_1 + 2 L^ c_2               aggregation at the OUTPUT width, "+ c_1" in its epilogue
+        y   = act((c_0 - c_2) + L^ b_1 + b)     c_0 - c_2 = x (W_0 - W_2)^T: folded into the weights
+
+    so the aggregations move O instead of I columns (10 vs 22 in the first layer, 1 vs 10 in the second), and the
+    backward needs only x: g_b1 = L^T g, g_c2 = 2 L^T g_b1, then ONE weight-gradient pass x^T [g | g_b1 | g_c2] and ONE
+    GEMM gx = g (W_0 - W_2) + g_b1 W_1 + g_c2 W_2.  Same algebra as the reference, different fp32 rounding order
+    (covered by the 1e-5 parity tests)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, *ws):
+        s, k = struct, len(ws)
+        x = _padded_rows(ops.rowmajor(x))
+        o = ws[0].shape[0]
+        ow = (o + 3) // 4 * 4
+        blocks = [ws[0] - ws[2], ws[1], ws[2]] if k == 3 else list(ws)
+        b_cat = torch.nn.functional.pad(bias, (0, k * ow - o)) if bias is not None else None
+        c, w_cat = _fan_out(x, blocks, b_cat, o)
+        lap = dict(ell=s.in_ell, cscale=s.cheb_dinv, rscale=s.derived("cheb_neg"))
+        act = dict(relu=relu, drop_p=drop_p, seed=seed)
+        if k == 2:
+            y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], **lap, **act)
+        else:
+            ops.csr_aggregate(c[2], s.in_ptr, s.in_src, alpha=2.0, z=c[1], beta=1.0, out=c[1], **lap)
+            y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], **lap, **act)
+        ctx.struct, ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, k, relu, drop_p, bias is not None, (o, ow)
+        ctx.save_for_backward(x, w_cat, y if (relu or drop_p > 0) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        k, s, (o, ow) = ctx.k, ctx.struct, ctx.dims
+        x, w_cat, y = ctx.saved_tensors
+        n, i = x.shape
+        g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
+        lap_t = dict(ell=s.out_ell, cscale=s.derived("cheb_neg"), rscale=s.cheb_dinv)
+        gs = [g]
+        if k >= 2:
+            gs.append(ops.csr_aggregate(g, s.out_ptr, s.out_dst, **lap_t))
+        if k == 3:
+            gs.append(ops.csr_aggregate(gs[1], s.out_ptr, s.out_dst, alpha=2.0, **lap_t))
+        gw = torch.empty((k * ow, i), dtype=torch.float32, device=x.device)
+        gb = torch.empty(k * ow, dtype=torch.float32, device=x.device)
+        ops.linear_wgrad_parts(gs, x, gw, gb)
+        gw = gw.reshape(k, ow, i)[:, :o]
+        gws = [gw[0], gw[1], gw[2] - gw[0]] if k == 3 else [gw[j] for j in range(k)]
+        gx = _fan_in_t(gs, w_cat, o, i) if ctx.needs_input_grad[0] else None
+        return (gx, gb[:o] if ctx.has_bias else None, None, None, None, None, *gws)
+
+
+class _ChebLayerRecurrence(Function):
+    """ChebConv for any K (used for K = 1 and K > 3), in PyG's own order: T_0 = x, T_1 = L^x, T_k = 2 L^T_{k-1} - T_{k-2}; y = act(sum_k T_k W_k^T + b).
     Backward runs the recurrence in reverse with the transposed aggregation, folding every "+=" into the aggregation
-    kernel's z/beta epilogue, so no gradient is ever summed by a separate elementwise pass."""
+    kernel's z/beta epilogue."""
 
     @staticmethod
     def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, *ws):
@@ -109,9 +207,7 @@ class _ChebLayer(Function):
         k, s = ctx.k, ctx.struct
         saved = ctx.saved_tensors
         terms, ws, y = saved[:k], saved[k:2 * k], saved[2 * k]
-        g = ops.rowmajor(g)
-        if y is not None:
-            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        g = _mask_grad(g, y, ctx.drop_p)
         gws, gb = [], None
         for i in range(k):
             gw = torch.empty_like(ws[i])
@@ -135,42 +231,42 @@ class _ChebLayer(Function):
 
 
 def cheb_layer(x, ws, bias, struct, relu=False, drop_p=0.0, seed=0):
-    return _ChebLayer.apply(x, bias, struct, relu, drop_p, seed, *ws)
+    node = _ChebLayer if 2 <= len(ws) <= 3 else _ChebLayerRecurrence
+    return node.apply(x, bias, struct, relu, drop_p, seed, *ws)
 
 
 class _SAGELayer(Function):
-    """SAGEConv as ONE autograd node: y = act(mean_in(x) W_l^T + b + x W_r^T); gx = g W_r + mean_in^T(g W_l)."""
+    """SAGEConv as ONE autograd node, PROJECT-FIRST: y = act(mean_in(x W_l^T) + x W_r^T + b) -- one GEMM produces both
+    projections from one read of x, the mean runs at the output width with "+ x W_r^T + b" in its epilogue (PyG
+    aggregates at the input width and projects afterwards: same algebra, different fp32 rounding order).
+    Backward: g_p = mean_in^T(g); one weight-gradient pass x^T [g_p | g]; gx = g_p W_l + g W_r in one GEMM."""
 
     @staticmethod
     def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed):
         s = struct
-        x = ops.rowmajor(x)
-        wl, wr = wl.contiguous(), wr.contiguous()
-        mean = ops.csr_aggregate(x, s.in_ptr, s.in_src, ell=s.in_ell, rscale=s.sage_rinv, dself=s.derived("sage_dself"))
-        y = ops.linear(mean, wl, bl)
-        ops.linear(x, wr, out=y, accumulate=True, relu=relu, drop_p=drop_p, seed=seed)
-        ctx.struct, ctx.relu, ctx.drop_p = s, relu, drop_p
-        ctx.save_for_backward(x, mean, wl, wr, y if (relu or drop_p > 0) else None)
+        x = _padded_rows(ops.rowmajor(x))
+        o = wl.shape[0]
+        ow = (o + 3) // 4 * 4
+        b_cat = torch.nn.functional.pad(bl, (ow, ow - o)) if bl is not None else None     # the bias rides on the root term
+        (p, r), w_cat = _fan_out(x, [wl, wr], b_cat, o)
+        y = ops.csr_aggregate(p, s.in_ptr, s.in_src, ell=s.in_ell, rscale=s.sage_rinv, dself=s.derived("sage_dself"),
+                              z=r, beta=1.0, relu=relu, drop_p=drop_p, seed=seed, out=r)
+        ctx.struct, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, relu, drop_p, bl is not None, (o, ow)
+        ctx.save_for_backward(x, w_cat, y if (relu or drop_p > 0) else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, mean, wl, wr, y = ctx.saved_tensors
-        s = ctx.struct
-        g = ops.rowmajor(g)
-        if y is not None:
-            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
-        gwl, gwr = torch.empty_like(wl), torch.empty_like(wr)
-        gbl = torch.empty(wl.shape[0], dtype=g.dtype, device=g.device)
-        ops.linear_wgrad(g, mean, gwl, gbl)
-        ops.linear_wgrad(g, x, gwr, None)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = ops.linear(g, wr, transposed=True)
-            gm = ops.linear(g, wl, transposed=True)
-            ops.csr_aggregate(gm, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.sage_rinv,
-                              dself=s.derived("sage_dself"), z=gx, beta=1.0, out=gx)
-        return gx, gwl, gbl, gwr, None, None, None, None
+        x, w_cat, y = ctx.saved_tensors
+        s, (o, ow) = ctx.struct, ctx.dims
+        n, i = x.shape
+        g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
+        gp = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.sage_rinv, dself=s.derived("sage_dself"))
+        gw = torch.empty((2 * ow, i), dtype=torch.float32, device=x.device)
+        gb = torch.empty(2 * ow, dtype=torch.float32, device=x.device)
+        ops.linear_wgrad_parts([gp, g], x, gw, gb)
+        gx = _fan_in_t([gp, g], w_cat, o, i) if ctx.needs_input_grad[0] else None
+        return gx, gw[:o], gb[ow:ow + o] if ctx.has_bias else None, gw[ow:ow + o], None, None, None, None
 
 
 def sage_layer(x, wl, bl, wr, struct, relu=False, drop_p=0.0, seed=0):
@@ -199,15 +295,21 @@ class _GCNLayer(Function):
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
         s = ctx.struct
-        g = ops.rowmajor(g)
-        if y is not None:
-            g = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
-        gb = g.sum(0) if ctx.needs_input_grad[2] else None
+        g = _mask_grad(g, y, ctx.drop_p)
         gh = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.gcn_dinv, rscale=s.gcn_dinv,
                                dself=s.derived("gcn_dself"))
         gx = ops.linear(gh, w.contiguous(), transposed=True) if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
+        gw = gb = None
+        if ctx.needs_input_grad[2]:
+            # the bias gradient sum_n g[n,:] is the ones-column of a weight-gradient pass: give that pass a second
+            # column block [gh | g] instead of sweeping g with a separate reduction
+            o, i = w.shape
+            ow = (o + 3) // 4 * 4
+            gw2 = torch.empty((2 * ow, i), dtype=torch.float32, device=x.device)
+            gb2 = torch.empty(2 * ow, dtype=torch.float32, device=x.device)
+            ops.linear_wgrad_parts([gh, g], x, gw2, gb2)
+            gw, gb = gw2[:o], gb2[ow:ow + o]
+        elif ctx.needs_input_grad[1]:
             gw = torch.empty_like(w, memory_format=torch.contiguous_format)
             ops.linear_wgrad(gh, x, gw, None)
         return gx, gw, gb, None, None, None, None

@@ -44,6 +44,13 @@ def padded_empty(n: int, c: int, device) -> torch.Tensor:
     return torch.empty((max(n, 1), c4), dtype=torch.float32, device=device)[:n, :c]
 
 
+def padded_copy(t: torch.Tensor) -> torch.Tensor:
+    """``t`` copied into the padded row layout."""
+    out = padded_empty(t.shape[0], t.shape[1], t.device)
+    out.copy_(t)
+    return out
+
+
 def rowmajor(t: torch.Tensor) -> torch.Tensor:
     """``t`` itself when its columns are unit-stride (padded views stay padded), else a compact copy."""
     if t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1]):
