@@ -583,6 +583,10 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
   const int ob = (a.O + 15) / 16, ib = (a.I + 1 + 15) / 16;
   if (ob == 1 && ib <= 2) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+  } else if (ob == 2 && ib <= 2) {   // two or three column blocks of gy against a narrow x: still ONE pass over x
+    hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+  } else if (ob == 3 && ib <= 2) {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<3, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob == 1) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
   } else {
