@@ -113,11 +113,14 @@ int mlqem_relu_dropout_bwd_f32(const float* g, int64_t ldg, const float* y, int6
  * SAGEConv's lin_l(mean) + lin_r(x)); the activation belongs on the last call.  act bit 0 = ReLU; drop_p > 0 applies
  * inverted dropout keyed by (seed, n*O + o).  Column ranges: rowscale applies to outputs o < rs_cols and ReLU/dropout to
  * outputs o >= act_from (-1, -1 = every column), so that one launch can serve several layers that read the same input
- * rows (the three first-layer projections of GCN | Cheb | SAGE).  Runs on the f32-input matrix cores
- * (v_mfma_f32_16x16x4_f32) for I <= 128. */
+ * rows (the three first-layer projections of GCN | Cheb | SAGE).  gate (may be NULL), applied last:
+ * y[n,o] = gate[n,o] > 0 ? y[n,o] * gate_scale : 0 -- the backward of a ReLU/dropout epilogue whose output `gate` is this
+ * layer's input, folded into the data-gradient GEMM that produces the incoming gradient (no separate masking pass).
+ * Runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32) for I <= 128. */
 int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                      const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act, int accumulate,
-                     float drop_p, uint64_t seed, int rs_cols, int act_from, mlqem_stream_t stream);
+                     float drop_p, uint64_t seed, int rs_cols, int act_from, const float* gate, int64_t ldgate,
+                     float gate_scale, mlqem_stream_t stream);
 
 /* A matrix given as up to four COLUMN BLOCKS in separate buffers: block p is ptr[p][N, cols] (row stride ld[p]) and
  * stands at columns [p*width, p*width + cols) of the concatenation; columns cols..width-1 of a block are padding (read
@@ -135,9 +138,11 @@ typedef struct mlqem_col_parts {
  *   - the per-term projections of ChebConv / SAGEConv that read the same input rows (fan-out: lins[k](x), lin_l(x),
  *     lin_r(x); 01_ngem.ipynb cell [9]) and
  *   - the sum of per-term data gradients (fan-in: gx = sum_k g_k W_k)
- * without building the concatenation, whose wide rows would slow the aggregation gathers.  I <= 64. */
+ * without building the concatenation, whose wide rows would slow the aggregation gathers.  I <= 64.
+ * gate / gate_scale as in mlqem_linear_f32 (single-block Y only; gate rows padded like Y's). */
 int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* w, int transposed, const float* b,
-                           const mlqem_col_parts* y, int64_t N, mlqem_stream_t stream);
+                           const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate, float gate_scale,
+                           mlqem_stream_t stream);
 
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 

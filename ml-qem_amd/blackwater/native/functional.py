@@ -77,6 +77,13 @@ def linear(x, w, b=None, relu=False):
     return y.reshape(*lead, w.shape[0])
 
 
+# Mask hand-over between consecutive layers of one branch (a private contract of the model code, see nn/models.py):
+# a layer called with ``defer_mask=True`` does not apply its own ReLU/dropout mask in backward and does not keep its
+# output for it -- the NEXT layer, whose input x IS that output, is called with ``x_gate_scale = 1/(1-p)`` and returns
+# gx already multiplied by (x > 0) * scale from the epilogue of its data-gradient GEMM.  One [N, C] read-modify-write
+# pass per hidden layer disappears.  Only valid when the deferred layer's output feeds exactly that one consumer.
+
+
 def _mask_grad(g, y, drop_p):
     """Gradient through the fused ReLU / dropout epilogue (the mask is read back from the saved output)."""
     g = ops.rowmajor(g)
@@ -106,16 +113,18 @@ def _fan_out(x, blocks, b_cat, o):
     return outs, w_cat
 
 
-def _fan_in_t(gs, w_cat, o, i):
-    """gx = sum_j gs[j] W_j (W_j = block j of the padded ``w_cat``): one launch, gx written once."""
+def _fan_in_t(gs, w_cat, o, i, gate=None, gate_scale=1.0):
+    """gx = sum_j gs[j] W_j (W_j = block j of the padded ``w_cat``): one launch, gx written once; optional gate."""
     n = gs[0].shape[0]
     ow = (o + 3) // 4 * 4
     gx = ops.padded_empty(n, i, gs[0].device)
     if len(gs) * ow <= _PARTS_MAX_COLS:
-        ops.linear_parts(gs, w_cat, None, [gx], transposed=True)
+        ops.linear_parts(gs, w_cat, None, [gx], transposed=True, gate=gate, gate_scale=gate_scale)
     else:
         for j, g in enumerate(gs):
-            ops.linear(g, w_cat[j * ow: j * ow + o, :i].contiguous(), transposed=True, out=gx, accumulate=j > 0)
+            last = j == len(gs) - 1
+            ops.linear(g, w_cat[j * ow: j * ow + o, :i].contiguous(), transposed=True, out=gx, accumulate=j > 0,
+                       gate=gate if last else None, gate_scale=gate_scale)
     return gx
 
 
@@ -135,7 +144,7 @@ class _ChebLayer(Function):
     (covered by the 1e-5 parity tests)."""
 
     @staticmethod
-    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, *ws):
+    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, *ws):
         s, k = struct, len(ws)
         x = _padded_rows(ops.rowmajor(x))
         o = ws[0].shape[0]
@@ -151,7 +160,8 @@ class _ChebLayer(Function):
             ops.csr_aggregate(c[2], s.in_ptr, s.in_src, alpha=2.0, z=c[1], beta=1.0, out=c[1], **lap)
             y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], **lap, **act)
         ctx.struct, ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, k, relu, drop_p, bias is not None, (o, ow)
-        ctx.save_for_backward(x, w_cat, y if (relu or drop_p > 0) else None)
+        ctx.x_gate_scale = x_gate_scale
+        ctx.save_for_backward(x, w_cat, y if ((relu or drop_p > 0) and not defer_mask) else None)
         return y
 
     @staticmethod
@@ -171,8 +181,11 @@ class _ChebLayer(Function):
         ops.linear_wgrad_parts(gs, x, gw, gb)
         gw = gw.reshape(k, ow, i)[:, :o]
         gws = [gw[0], gw[1], gw[2] - gw[0]] if k == 3 else [gw[j] for j in range(k)]
-        gx = _fan_in_t(gs, w_cat, o, i) if ctx.needs_input_grad[0] else None
-        return (gx, gb[:o] if ctx.has_bias else None, None, None, None, None, *gws)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gated = ctx.x_gate_scale is not None
+            gx = _fan_in_t(gs, w_cat, o, i, gate=x if gated else None, gate_scale=ctx.x_gate_scale if gated else 1.0)
+        return (gx, gb[:o] if ctx.has_bias else None, None, None, None, None, None, None, *gws)
 
 
 class _ChebLayerRecurrence(Function):
@@ -181,7 +194,7 @@ class _ChebLayerRecurrence(Function):
     kernel's z/beta epilogue."""
 
     @staticmethod
-    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, *ws):
+    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, *ws):
         s = struct
         x = ops.rowmajor(x)
         k = len(ws)
@@ -199,7 +212,8 @@ class _ChebLayerRecurrence(Function):
             y = ops.linear(terms[i], ws[i], bias if i == 0 else None, out=y, accumulate=i > 0, relu=relu and last,
                            drop_p=drop_p if last else 0.0, seed=seed)
         ctx.struct, ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias = s, k, relu, drop_p, bias is not None
-        ctx.save_for_backward(*terms, *ws, y if (relu or drop_p > 0) else None)
+        ctx.x_gate_scale = x_gate_scale
+        ctx.save_for_backward(*terms, *ws, y if ((relu or drop_p > 0) and not defer_mask) else None)
         return y
 
     @staticmethod
@@ -227,12 +241,14 @@ class _ChebLayerRecurrence(Function):
                 a[i - 2] = a[i - 2] - a[i]
             gx = a[0] if k == 1 else ops.csr_aggregate(a[1], s.out_ptr, s.out_dst, ell=s.out_ell, z=a[0], beta=1.0,
                                                        out=a[0], **lap_t)
-        return (gx, gb, None, None, None, None, *gws)
+            if ctx.x_gate_scale is not None:
+                gx = ops.relu_dropout_bwd(gx, terms[0], ctx.x_gate_scale)
+        return (gx, gb, None, None, None, None, None, None, *gws)
 
 
-def cheb_layer(x, ws, bias, struct, relu=False, drop_p=0.0, seed=0):
+def cheb_layer(x, ws, bias, struct, relu=False, drop_p=0.0, seed=0, defer_mask=False, x_gate_scale=None):
     node = _ChebLayer if 2 <= len(ws) <= 3 else _ChebLayerRecurrence
-    return node.apply(x, bias, struct, relu, drop_p, seed, *ws)
+    return node.apply(x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
 
 
 class _SAGELayer(Function):
@@ -242,7 +258,7 @@ class _SAGELayer(Function):
     Backward: g_p = mean_in^T(g); one weight-gradient pass x^T [g_p | g]; gx = g_p W_l + g W_r in one GEMM."""
 
     @staticmethod
-    def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed):
+    def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale):
         s = struct
         x = _padded_rows(ops.rowmajor(x))
         o = wl.shape[0]
@@ -252,7 +268,8 @@ class _SAGELayer(Function):
         y = ops.csr_aggregate(p, s.in_ptr, s.in_src, ell=s.in_ell, rscale=s.sage_rinv, dself=s.derived("sage_dself"),
                               z=r, beta=1.0, relu=relu, drop_p=drop_p, seed=seed, out=r)
         ctx.struct, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, relu, drop_p, bl is not None, (o, ow)
-        ctx.save_for_backward(x, w_cat, y if (relu or drop_p > 0) else None)
+        ctx.x_gate_scale = x_gate_scale
+        ctx.save_for_backward(x, w_cat, y if ((relu or drop_p > 0) and not defer_mask) else None)
         return y
 
     @staticmethod
@@ -265,12 +282,15 @@ class _SAGELayer(Function):
         gw = torch.empty((2 * ow, i), dtype=torch.float32, device=x.device)
         gb = torch.empty(2 * ow, dtype=torch.float32, device=x.device)
         ops.linear_wgrad_parts([gp, g], x, gw, gb)
-        gx = _fan_in_t([gp, g], w_cat, o, i) if ctx.needs_input_grad[0] else None
-        return gx, gw[:o], gb[ow:ow + o] if ctx.has_bias else None, gw[ow:ow + o], None, None, None, None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gated = ctx.x_gate_scale is not None
+            gx = _fan_in_t([gp, g], w_cat, o, i, gate=x if gated else None, gate_scale=ctx.x_gate_scale if gated else 1.0)
+        return gx, gw[:o], gb[ow:ow + o] if ctx.has_bias else None, gw[ow:ow + o], None, None, None, None, None, None
 
 
-def sage_layer(x, wl, bl, wr, struct, relu=False, drop_p=0.0, seed=0):
-    return _SAGELayer.apply(x, wl, bl, wr, struct, relu, drop_p, seed)
+def sage_layer(x, wl, bl, wr, struct, relu=False, drop_p=0.0, seed=0, defer_mask=False, x_gate_scale=None):
+    return _SAGELayer.apply(x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
 
 
 class _GCNLayer(Function):
@@ -281,14 +301,14 @@ class _GCNLayer(Function):
     then the same symmetric-normalised aggregation on the transposed CSR, then the two GEMM gradients."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed):
+    def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale):
         x = ops.rowmajor(x)
         dinv = struct.gcn_dinv
         h = ops.linear(x, w.contiguous(), rowscale=dinv)
         y = ops.csr_aggregate(h, struct.in_ptr, struct.in_src, ell=struct.in_ell, rscale=dinv, dself=dinv, bias=bias, relu=relu,
                               drop_p=drop_p, seed=seed)
-        ctx.struct, ctx.relu, ctx.drop_p = struct, relu, drop_p
-        ctx.save_for_backward(x, w, y if (relu or drop_p > 0) else None)
+        ctx.struct, ctx.relu, ctx.drop_p, ctx.x_gate_scale = struct, relu, drop_p, x_gate_scale
+        ctx.save_for_backward(x, w, y if ((relu or drop_p > 0) and not defer_mask) else None)
         return y
 
     @staticmethod
@@ -298,7 +318,11 @@ class _GCNLayer(Function):
         g = _mask_grad(g, y, ctx.drop_p)
         gh = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.gcn_dinv, rscale=s.gcn_dinv,
                                dself=s.derived("gcn_dself"))
-        gx = ops.linear(gh, w.contiguous(), transposed=True) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gated = ctx.x_gate_scale is not None
+            gx = ops.linear(gh, w.contiguous(), transposed=True, gate=x if gated else None,
+                            gate_scale=ctx.x_gate_scale if gated else 1.0)
         gw = gb = None
         if ctx.needs_input_grad[2]:
             # the bias gradient sum_n g[n,:] is the ones-column of a weight-gradient pass: give that pass a second
@@ -312,11 +336,11 @@ class _GCNLayer(Function):
         elif ctx.needs_input_grad[1]:
             gw = torch.empty_like(w, memory_format=torch.contiguous_format)
             ops.linear_wgrad(gh, x, gw, None)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def gcn_layer(x, w, bias, struct, relu=False, drop_p=0.0, seed=0):
-    return _GCNLayer.apply(x, w, bias, struct, relu, drop_p, seed)
+def gcn_layer(x, w, bias, struct, relu=False, drop_p=0.0, seed=0, defer_mask=False, x_gate_scale=None):
+    return _GCNLayer.apply(x, w, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
 
 
 class _SegmentMean(Function):

@@ -136,9 +136,24 @@ def relu_dropout_bwd(g, y, scale=1.0, out=None):
     return gx
 
 
+def _gate(gate, n, o, padded: bool):
+    """(pointer, leading dimension) of an optional [n, o] gate matrix (see mlqem_linear_f32)."""
+    if gate is None:
+        return None, 0
+    if tuple(gate.shape) != (n, o):
+        raise ValueError(f"gate must be [{n}, {o}], got {tuple(gate.shape)}")
+    ld = _mat(gate, "gate")
+    if n == 1:
+        ld = int(gate.stride(0))
+    if padded and (ld % 4 or ld < (o + 3) // 4 * 4 or gate.data_ptr() % 16):
+        raise ValueError("gate: needs the padded row layout here")
+    return gate.data_ptr(), ld
+
+
 def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=None, accumulate=False, drop_p=0.0,
-           seed=0, rs_cols=-1, act_from=-1):
-    """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O])."""
+           seed=0, rs_cols=-1, act_from=-1, gate=None, gate_scale=1.0):
+    """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O]);
+    ``gate``: y = gate > 0 ? y * gate_scale : 0 as the last step."""
     n, i = x.shape
     ldx = _mat(x, "x")
     if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
@@ -156,7 +171,8 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
         raise ValueError("linear: bad out shape")
     code = _lib.load().mlqem_linear_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(rowscale), _p(out), _mat(out, "out"),
                                         n, i, o, 1 if relu else 0, 1 if accumulate else 0, float(drop_p),
-                                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(rs_cols), int(act_from), _stream())
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(rs_cols), int(act_from),
+                                        *_gate(gate, n, o, False), float(gate_scale), _stream())
     _lib.check(code, "mlqem_linear_f32")
     return out
 
@@ -188,7 +204,7 @@ def pad_weight_blocks(ws, in_cols: int):
     return pad.reshape(-1, pad.shape[-1])
 
 
-def linear_parts(xs, w, b, ys, transposed=False):
+def linear_parts(xs, w, b, ys, transposed=False, gate=None, gate_scale=1.0):
     """[ys[0] | ys[1] | ...] = [xs[0] | xs[1] | ...] @ w.T + b over column blocks in separate (padded) buffers;
     ``w`` is indexed in the padded concatenated spaces: [len(ys)*round_up(O,4), len(xs)*round_up(I,4)] (or its
     transpose's layout with ``transposed=True``)."""
@@ -203,8 +219,10 @@ def linear_parts(xs, w, b, ys, transposed=False):
     _vec(b, "b", o_tot)
     import ctypes as _ct
 
+    if gate is not None and len(ys) != 1:
+        raise ValueError("linear_parts: a gate needs a single output block")
     code = _lib.load().mlqem_linear_parts_f32(_ct.addressof(xp), _p(w), 1 if transposed else 0, _p(b), _ct.addressof(yp),
-                                              n, _stream())
+                                              n, *_gate(gate, n, ys[0].shape[1], True), float(gate_scale), _stream())
     _lib.check(code, "mlqem_linear_parts_f32")
     return ys
 

@@ -51,8 +51,9 @@ class GCNConv(nn.Module):
         self.lin = _WeightOnly(_glorot(out_channels, in_channels))
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
-    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
-        return F.gcn_layer(x, self.lin.weight, self.bias, struct, relu=relu, drop_p=drop_p, seed=seed)
+    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0, **handover):
+        """``handover``: ``defer_mask`` / ``x_gate_scale`` (native/functional.py, "Mask hand-over")."""
+        return F.gcn_layer(x, self.lin.weight, self.bias, struct, relu=relu, drop_p=drop_p, seed=seed, **handover)
 
 
 class SAGEConv(nn.Module):
@@ -65,9 +66,9 @@ class SAGEConv(nn.Module):
         w, _ = _kaiming_linear(out_channels, in_channels, bias=False)
         self.lin_r = _WeightOnly(w)
 
-    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
+    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0, **handover):
         return F.sage_layer(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, struct, relu=relu, drop_p=drop_p,
-                            seed=seed)
+                            seed=seed, **handover)
 
 
 class ChebConv(nn.Module):
@@ -78,5 +79,6 @@ class ChebConv(nn.Module):
         self.lins = nn.ModuleList([_WeightOnly(_glorot(out_channels, in_channels)) for _ in range(K)])
         self.bias = nn.Parameter(torch.zeros(out_channels))
 
-    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0):
-        return F.cheb_layer(x, [lin.weight for lin in self.lins], self.bias, struct, relu=relu, drop_p=drop_p, seed=seed)
+    def forward(self, x, struct: GraphStructure, relu=False, drop_p=0.0, seed=0, **handover):
+        return F.cheb_layer(x, [lin.weight for lin in self.lins], self.bias, struct, relu=relu, drop_p=drop_p, seed=seed,
+                            **handover)

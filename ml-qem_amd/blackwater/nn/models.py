@@ -79,13 +79,17 @@ class ExpValCircuitGraphModelA(nn.Module):
         train = self.training
         self._step += 1
         seed = self._step * 7919
-        g = self.conv1(nodes, s, relu=True, drop_p=0.1 if train else 0.0, seed=seed + 1)
-        g = self.conv2(g, s, relu=True, drop_p=0.1 if train else 0.0, seed=seed + 2)
-        g = F.segment_mean(self.conv3(g, s), s)
-        c = self.cheb_conv1(nodes, s, relu=True, drop_p=0.2 if train else 0.0, seed=seed + 3)
-        c = F.segment_mean(self.cheb_conv2(c, s), s)
-        sg = self.sage_conv1(nodes, s, relu=True, drop_p=0.2 if train else 0.0, seed=seed + 4)
-        sg = F.segment_mean(self.sage_conv2(sg, s), s)
+        # Each hidden activation has exactly one consumer -- the next layer of its branch -- so the ReLU/dropout mask of
+        # its backward is applied by that consumer's data-gradient GEMM (native/functional.py, "Mask hand-over").
+        p1, p2 = (0.1, 0.2) if train else (0.0, 0.0)
+        k1, k2 = 1.0 / (1.0 - p1), 1.0 / (1.0 - p2)
+        g = self.conv1(nodes, s, relu=True, drop_p=p1, seed=seed + 1, defer_mask=True)
+        g = self.conv2(g, s, relu=True, drop_p=p1, seed=seed + 2, defer_mask=True, x_gate_scale=k1)
+        g = F.segment_mean(self.conv3(g, s, x_gate_scale=k1), s)
+        c = self.cheb_conv1(nodes, s, relu=True, drop_p=p2, seed=seed + 3, defer_mask=True)
+        c = F.segment_mean(self.cheb_conv2(c, s, x_gate_scale=k2), s)
+        sg = self.sage_conv1(nodes, s, relu=True, drop_p=p2, seed=seed + 4, defer_mask=True)
+        sg = F.segment_mean(self.sage_conv2(sg, s, x_gate_scale=k2), s)
         obs = torch.mean(self.obs_seq(observable), dim=1)
         merged = torch.cat((g, c, sg, obs, circuit_depth, exp_value), dim=1)
         return self.body_seq(merged)

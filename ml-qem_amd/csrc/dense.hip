@@ -27,6 +27,7 @@ struct LinArgs {
   float drop_p; uint64_t seed;
   int rs_cols;    // rowscale applies to outputs o < rs_cols
   int act_from;   // ReLU / dropout apply to outputs o >= act_from
+  const float* gate; int64_t ldgate; float gate_scale;   // last: y = gate[n,o] > 0 ? y * gate_scale : 0
 };
 
 // ---------------------------------------------------------------------------------------------- forward
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
           if (a.drop_p > 0.f)
             v = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : v * (1.f / (1.f - a.drop_p));
         }
+        if (a.gate) v = a.gate[row * a.ldgate + o] > 0.f ? v * a.gate_scale : 0.f;
         *dst = v;
       }
     }
@@ -197,6 +199,17 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
         }
         v[r] = u;
       }
+      if (a.gate) {
+        const float* gp = a.gate + row * a.ldgate + o0;
+        if (full && a.ldgate % 4 == 0 && aligned_to_dev(a.gate, 16)) {
+          const float4 m = *reinterpret_cast<const float4*>(gp);
+          v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
+          v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (o0 + r < a.O) v[r] = gp[r] > 0.f ? v[r] * a.gate_scale : 0.f;
+        }
+      }
       if (full) vstore_nt<4>(dst, v);
       else
 #pragma unroll
@@ -217,6 +230,7 @@ struct PartsArgs {
   float* yp[4]; int64_t ldy[4]; int yn, yw, yc;
   const float* w; const float* b;
   int64_t N; int I, O;   // I = xn * xw, O = yn * yw: the shape of W ([O, I], or [I, O] when TRANSPOSED)
+  const float* gate; int64_t ldgate; float gate_scale;   // single-block Y only: y = gate[n,o] > 0 ? y * gate_scale : 0
 };
 
 template <int OBT, int G, bool TRANSPOSED>
@@ -297,6 +311,11 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[ob][r] + bias[ob][r];
+      if (a.gate) {   // host checked: one output block, gate rows padded like it
+        const float4 m = *reinterpret_cast<const float4*>(a.gate + row * a.ldgate + (ob0 + ob) * 16 + lq * 4);
+        v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
+        v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
+      }
       vstore_nt<4>(ycol[ob] + row * yld[ob], v);
     }
   }
@@ -332,6 +351,7 @@ __global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a, 
       if (a.drop_p > 0.f)
         r = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : r * (1.f / (1.f - a.drop_p));
     }
+    if (a.gate) r = a.gate[row * a.ldgate + o] > 0.f ? r * a.gate_scale : 0.f;
     *dst = r;
   }
 }
@@ -490,14 +510,16 @@ using namespace mlqem;
 extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                                 const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act,
                                 int accumulate, float drop_p, uint64_t seed, int rs_cols, int act_from,
-                                mlqem_stream_t stream) {
+                                const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
+  if (gate && ldgate < O) return MLQEM_ERR_BAD_ARG;
   if (rs_cols < 0) rs_cols = O;
   if (act_from < 0) act_from = 0;
   if (N == 0) return MLQEM_OK;
   if (!x || !w || !y) return MLQEM_ERR_BAD_ARG;
-  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate, drop_p, seed, rs_cols, act_from};
+  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate, drop_p, seed, rs_cols, act_from, gate, ldgate,
+            gate_scale};
   hipStream_t s = as_stream(stream);
   const int ks = round_ks((I + 3) / 4);
   if (ks > 0) {
@@ -553,9 +575,11 @@ static bool parts_ok(const mlqem_col_parts* p, bool vector_rows) {
 }
 
 extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* w, int transposed, const float* b,
-                                      const mlqem_col_parts* y, int64_t N, mlqem_stream_t stream) {
+                                      const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate,
+                                      float gate_scale, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || !w || !parts_ok(x, true) || !parts_ok(y, true)) return MLQEM_ERR_BAD_ARG;
+  if (gate && (y->count != 1 || ldgate < y->width || ldgate % 4 || !aligned_to(gate, 16))) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   PartsArgs a{};
   for (int i = 0; i < x->count; ++i) { a.xp[i] = static_cast<const float*>(x->ptr[i]); a.ldx[i] = x->ld[i]; }
@@ -563,6 +587,7 @@ extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* w, 
   a.xn = x->count; a.xw = x->width; a.xc = x->cols;
   a.yn = y->count; a.yw = y->width; a.yc = y->cols;
   a.w = w; a.b = b; a.N = N; a.I = x->count * x->width; a.O = y->count * y->width;
+  a.gate = gate; a.ldgate = ldgate; a.gate_scale = gate_scale;
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
   const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : 4);

@@ -264,3 +264,34 @@ def test_linear_over_column_blocks_rejects_unpadded_operands():
         ops.linear_parts([x], w, None, [y])
     with pytest.raises(ValueError, match="shape"):
         ops.linear_parts([ops.padded_empty(64, 22, DEV)], torch.zeros(12, 22, device=DEV), None, [y])
+
+
+def test_mask_handover_between_layers_equals_separate_masking():
+    """defer_mask / x_gate_scale (native/functional.py): a two-layer chain of every conv kind gives the same parameter
+    gradients whether the hidden ReLU/dropout mask is applied by the producer's backward or by the consumer's
+    data-gradient GEMM."""
+    from blackwater.nn.conv import ChebConv, GCNConv, SAGEConv
+    from blackwater.native.structure import GraphStructure
+
+    g = torch.Generator().manual_seed(5)
+    n, e = 3000, 7000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    s = GraphStructure.from_edge_index(ei.to(DEV), n)
+    x = torch.randn(n, 22, generator=g).to(DEV)
+    go = torch.randn(n, 3, generator=g).to(DEV)
+    for make in (lambda: (GCNConv(22, 10), GCNConv(10, 3)), lambda: (ChebConv(22, 10, K=3), ChebConv(10, 3, K=2)),
+                 lambda: (SAGEConv(22, 10), SAGEConv(10, 3)), lambda: (ChebConv(22, 10, K=4), ChebConv(10, 3, K=1))):
+        torch.manual_seed(1)
+        a, b = (m.to(DEV) for m in make())
+        grads = []
+        for fused in (False, True):
+            for m in (a, b):
+                m.zero_grad()
+            kw1 = dict(defer_mask=True) if fused else {}
+            kw2 = dict(x_gate_scale=1.0 / 0.8) if fused else {}
+            h = a(x, s, relu=True, drop_p=0.2, seed=11, **kw1)
+            y = b(h, s, **kw2)
+            y.backward(go)
+            grads.append([p.grad.clone() for m in (a, b) for p in m.parameters()])
+        for u, v in zip(*grads):
+            assert torch.allclose(u, v, rtol=1e-5, atol=1e-6 * (1 + v.abs().max().item()))
