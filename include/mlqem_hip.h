@@ -174,16 +174,19 @@ int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph
  * and the CSR arrays of mlqem_csr_build run over the whole arena (global node ids).
  * Selection: sel[B] graph ids (repeats allowed); b_nptr[B+1] / b_eptr[B+1] = prefix sums of the selected graphs'
  * node / edge counts (host knows them without a sync); Nb = b_nptr[B], Eb = b_eptr[B].
- * Outputs: the batch's x, nscal, src_node[Nb] (arena row of every batch node), both CSR structures (node ids
- * rebased to the batch) and loops.
+ * Outputs: the batch's x, nscal_b -- PLANAR [K, Nb], scalar k of all nodes contiguous, so each is usable as a vector
+ * without a strided copy --, src_node[Nb] (arena row of every batch node), both CSR structures (node ids rebased to
+ * the batch), loops and, when the arena's ELL side tables a_in_ell / a_out_ell (mlqem_ell_from_csr over the arena)
+ * are given, the batch's side tables in_ell_b / out_ell_b [Nb,2] rebased the same way (NULL = not wanted).
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K, const int32_t* a_gptr,
                          const int32_t* a_in_ptr, const int32_t* a_in_src, const int32_t* a_out_ptr,
-                         const int32_t* a_out_dst, const int32_t* a_out_eid, const int32_t* a_loops, const int32_t* sel,
-                         const int32_t* b_nptr,
+                         const int32_t* a_out_dst, const int32_t* a_out_eid, const int32_t* a_loops,
+                         const int32_t* a_in_ell, const int32_t* a_out_ell, const int32_t* sel, const int32_t* b_nptr,
                          const int32_t* b_eptr, int64_t B, int64_t Nb, int64_t Eb, float* xb, int64_t ldxb,
                          float* nscal_b, int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b,
-                         int32_t* out_dst_b, int32_t* out_eid_b, int32_t* loops_b, mlqem_stream_t stream);
+                         int32_t* out_dst_b, int32_t* out_eid_b, int32_t* loops_b, int32_t* in_ell_b, int32_t* out_ell_b,
+                         mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Family B (docs/tutorials/gnn.py:70-276): TransformerConv attention and ASAPooling.  Forward kernels.

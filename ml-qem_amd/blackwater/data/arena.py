@@ -47,6 +47,10 @@ class GraphArena:
         self.node_counts = np.asarray(node_counts, dtype=np.int64)
         self.edge_counts = np.asarray(edge_counts, dtype=np.int64)
         self.gptr, self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops, self.out_eid = structure_arrays
+        n_total = int(self.node_counts.sum())
+        # ELL side tables of the whole arena: a batch's tables are these rows, rebased (no per-batch CSR walk)
+        self.in_ell = ops.ell_from_csr(self.in_ptr, self.in_src, n_total)
+        self.out_ell = ops.ell_from_csr(self.out_ptr, self.out_dst, n_total)
         self.nscal = nscal  # [N,3]: gcn_dinv, sage_rinv, cheb_dinv
         self.y, self.noisy, self.depth, self.observable = y, noisy, depth, observable
         self.device = x.device
@@ -155,18 +159,21 @@ class GraphArena:
         dev, f = self.device, self.x.shape[1]
         f4 = (f + 3) // 4 * 4
         xb = torch.empty((max(nb, 1), f4), dtype=torch.float32, device=dev)[:nb, :f]   # 16-byte rows, pads zero
-        nscal_b = torch.empty((nb, 3), dtype=torch.float32, device=dev)
+        nscal_b = torch.empty((3, max(nb, 1)), dtype=torch.float32, device=dev)   # planar: one contiguous vector per norm
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
         in_src, out_dst, out_eid = mk(eb), mk(eb), mk(eb)
+        in_ell = torch.empty((max(nb, 1), 2), dtype=torch.int32, device=dev)
+        out_ell = torch.empty((max(nb, 1), 2), dtype=torch.int32, device=dev)
         p = ops._p
         code = _lib.load().mlqem_batch_assemble(
             p(self.x), self.x.stride(0), f4, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
-            p(self.out_ptr), p(self.out_dst), p(self.out_eid), p(self.loops), p(sel_d), p(nptr_d), p(eptr_d), b, nb, eb,
-            p(xb), xb.stride(0), p(nscal_b), p(src_node), p(in_ptr), p(in_src), p(out_ptr), p(out_dst), p(out_eid), p(loops), ops._stream())
+            p(self.out_ptr), p(self.out_dst), p(self.out_eid), p(self.loops), p(self.in_ell), p(self.out_ell), p(sel_d),
+            p(nptr_d), p(eptr_d), b, nb, eb, p(xb), xb.stride(0), p(nscal_b), p(src_node), p(in_ptr), p(in_src),
+            p(out_ptr), p(out_dst), p(out_eid), p(loops), p(in_ell), p(out_ell), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
-        norms = (nscal_b[:, 0].contiguous(), nscal_b[:, 1].contiguous(), nscal_b[:, 2].contiguous())
+        norms = (nscal_b[0, :nb], nscal_b[1, :nb], nscal_b[2, :nb])
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,
-                           graph_sizes=self.node_counts[sel], out_eid=out_eid)
+                           graph_sizes=self.node_counts[sel], out_eid=out_eid, ell=(in_ell, out_ell))
         idx = sel_d.to(torch.int64)
         return DeviceBatch(xb, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)

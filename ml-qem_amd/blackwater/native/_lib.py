@@ -35,8 +35,8 @@ SIGNATURES = {
     "mlqem_csr_build_workspace_bytes": (_S, [_L, _L]),
     "mlqem_csr_build": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "mlqem_graph_norms": (_I, [_P, _P, _P, _L, _P, _P, _P, _P]),
-    "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
-                                  _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
+                                  _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _L, _L, _I, _P]),
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),

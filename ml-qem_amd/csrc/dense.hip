@@ -446,17 +446,19 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
   }
 }
 
-// Stage 2: fixed-order sum over the G partials.  Block = 32 (o,i) pairs x 8 slices of the G range.
+// Stage 2: fixed-order sum over the G partials.  Block = 8 (o,i) pairs x 32 slices of the G range: a thread adds
+// G/32 partials, then the 32 slice sums of a pair are added in slice order.
+constexpr int kReducePairs = 8, kReduceSlices = kBlock / kReducePairs;
 __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ partial, int G, int I, int O,
                                                               float* __restrict__ gw, float* __restrict__ gb,
                                                               int accumulate) {
-  __shared__ float s[8][32];
+  __shared__ float s[kReduceSlices][kReducePairs + 1];
   const int I1 = I + 1, pairs = O * I1;
-  const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int p = blockIdx.x * 32 + pl;
+  const int pl = threadIdx.x % kReducePairs, sl = threadIdx.x / kReducePairs;
+  const int p = blockIdx.x * kReducePairs + pl;
   float t = 0.f;
   if (p < pairs) {
-    const int per = (G + 7) / 8;
+    const int per = (G + kReduceSlices - 1) / kReduceSlices;
     const int g1 = min(G, (sl + 1) * per);
     for (int g = sl * per; g < g1; ++g) t += partial[(int64_t)g * pairs + p];
   }
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __res
   if (sl == 0 && p < pairs) {
     float tot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += s[k][pl];
+    for (int k = 0; k < kReduceSlices; ++k) tot += s[k][pl];
     const int o = p / I1, k = p % I1;
     if (k < I) {
       float* d = gw + o * I + k;
@@ -618,7 +620,7 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     hipLaunchKernelGGL((wgrad_mfma_kernel<2, 4>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4))), dim3(kBlock),
                        0, s, a);
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), 32)), dim3(kBlock), 0, s, a.partial,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial,
                      G, a.I, a.O, gw, gb, accumulate);
   return launch_status();
 }

@@ -106,6 +106,8 @@ struct AssembleArgs {
   float* xb; int64_t ldxb; float* nscal_b;
   int32_t* src_node;   // [Nb] arena row of every batch node (written by the nodes kernel, read by the rows kernel)
   int32_t* in_ptr_b; int32_t* in_src_b; int32_t* out_ptr_b; int32_t* out_dst_b; int32_t* out_eid_b; int32_t* loops_b;
+  const int32_t* a_in_ell; const int32_t* a_out_ell;   // optional [N,2] side tables of the arena (global ids)
+  int32_t* in_ell_b; int32_t* out_ell_b;
 };
 
 __device__ __forceinline__ int find_segment(const int32_t* __restrict__ ptr, int n_seg, int32_t v) {
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArg
     else
       a.xb[(int64_t)i * a.ldxb + c] = a.x[gn * a.ldx + c];
   } else {
-    a.nscal_b[(int64_t)i * a.K + (c - FC)] = a.nscal[gn * a.K + (c - FC)];
+    a.nscal_b[(int64_t)(c - FC) * a.Nb + i] = a.nscal[gn * a.K + (c - FC)];   // planar [K, Nb]: each scalar contiguous
   }
 }
 
@@ -157,6 +159,15 @@ __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleAr
   a.in_ptr_b[i] = a.a_in_ptr[gn] - a.a_in_ptr[g0] + a.b_eptr[b];
   a.out_ptr_b[i] = a.a_out_ptr[gn] - a.a_out_ptr[g0] + a.b_eptr[b];
   if (a.loops_b) a.loops_b[i] = a.a_loops[gn];
+  // ELL side tables: the arena's entries rebased to batch ids (-1 = no edge, bit 31 of .x = more than two edges)
+  const int32_t shift = a.b_nptr[b] - g0;
+  auto rebase = [&](int2 e) {
+    if (e.x != -1) e.x = (((e.x & 0x7fffffff) + shift) | (e.x & (int32_t)0x80000000));
+    if (e.y != -1) e.y += shift;
+    return e;
+  };
+  if (a.in_ell_b) reinterpret_cast<int2*>(a.in_ell_b)[i] = rebase(reinterpret_cast<const int2*>(a.a_in_ell)[gn]);
+  if (a.out_ell_b) reinterpret_cast<int2*>(a.out_ell_b)[i] = rebase(reinterpret_cast<const int2*>(a.a_out_ell)[gn]);
 }
 
 __global__ __launch_bounds__(kBlock) void assemble_edges_kernel(const AssembleArgs a) {
@@ -239,11 +250,12 @@ extern "C" int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, 
 extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K,
                                     const int32_t* a_gptr, const int32_t* a_in_ptr, const int32_t* a_in_src,
                                     const int32_t* a_out_ptr, const int32_t* a_out_dst, const int32_t* a_out_eid,
-                                    const int32_t* a_loops,
+                                    const int32_t* a_loops, const int32_t* a_in_ell, const int32_t* a_out_ell,
                                     const int32_t* sel, const int32_t* b_nptr, const int32_t* b_eptr, int64_t B,
                                     int64_t Nb, int64_t Eb, float* xb, int64_t ldxb, float* nscal_b,
                                     int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
-                                    int32_t* out_eid_b, int32_t* loops_b, mlqem_stream_t stream_) {
+                                    int32_t* out_eid_b, int32_t* loops_b, int32_t* in_ell_b, int32_t* out_ell_b,
+                                    mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (B <= 0 || Nb < 0 || Eb < 0 || F <= 0 || K < 0 || ldx < F || ldxb < F) return MLQEM_ERR_BAD_ARG;
@@ -254,8 +266,10 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
   if (Eb > 0 && (!a_in_src || !a_out_dst || !in_src_b || !out_dst_b)) return MLQEM_ERR_BAD_ARG;
   if (loops_b && !a_loops) return MLQEM_ERR_BAD_ARG;
   if (out_eid_b && !a_out_eid) return MLQEM_ERR_BAD_ARG;
+  if ((in_ell_b && !a_in_ell) || (out_ell_b && !a_out_ell)) return MLQEM_ERR_BAD_ARG;
   AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_out_eid, a_loops, sel, b_nptr, b_eptr,
-                 (int)B, Nb, Eb, xb, ldxb, nscal_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, out_eid_b, loops_b};
+                 (int)B, Nb, Eb, xb, ldxb, nscal_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, out_eid_b, loops_b,
+                 a_in_ell, a_out_ell, in_ell_b, out_ell_b};
   hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
   if (Nb > 0) {
     const bool vec4 = F % 4 == 0 && ldx % 4 == 0 && ldxb % 4 == 0 && aligned_to(x, 16) && aligned_to(xb, 16);

@@ -44,6 +44,9 @@ def test_batch_assembly_matches_host_collate(g1):
     for got, want, k in ((s.in_ptr, ref[0], None), (s.in_src, ref[1], m), (s.out_ptr, ref[2], None),
                          (s.out_dst, ref[3], m), (s.loops, ref[4], None)):
         assert torch.equal(got[:k] if k else got[: want.numel()], want[:k] if k else want)
+    n_b = host["x"].shape[0]
+    assert torch.equal(s.in_ell[:n_b], ops.ell_from_csr(ref[0], ref[1], n_b))      # rebased from the arena's side tables
+    assert torch.equal(s.out_ell[:n_b], ops.ell_from_csr(ref[2], ref[3], n_b))
     gcn, sage, cheb = ops.graph_norms(ref[0], ref[2], ref[4], host["x"].shape[0])
     assert torch.equal(s.gcn_dinv, gcn) and torch.equal(s.sage_rinv, sage) and torch.equal(s.cheb_dinv, cheb)
     assert s.graph_ptr.cpu().tolist() == np.concatenate([[0], np.cumsum(arena.node_counts[sel])]).tolist()
