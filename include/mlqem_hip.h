@@ -132,17 +132,20 @@ typedef struct mlqem_col_parts {
   int64_t ld[4];
 } mlqem_col_parts;
 
-/* Y = X W^T + b over column-partitioned X and Y: W is [O, I] row-major (transposed = 0) or [I, O] (transposed = 1) with
- * I = x->count * x->width, O = y->count * y->width, i.e. indexed in the concatenated column spaces, padding included
- * (padding columns of X never reach the product).  b: [O] or NULL.  One launch replaces
- *   - the per-term projections of ChebConv / SAGEConv that read the same input rows (fan-out: lins[k](x), lin_l(x),
- *     lin_r(x); 01_ngem.ipynb cell [9]) and
- *   - the sum of per-term data gradients (fan-in: gx = sum_k g_k W_k)
- * without building the concatenation, whose wide rows would slow the aggregation gathers.  I <= 64.
- * gate / gate_scale as in mlqem_linear_f32 (single-block Y only; gate rows padded like Y's). */
-int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* w, int transposed, const float* b,
-                           const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate, float gate_scale,
-                           mlqem_stream_t stream);
+/* Projections over column blocks, the blocks on ONE side:
+ *   transposed = 0, fan-out (x->count == 1):  Y_k = X W_k^T + b_k        W_k = w_blocks[k]: [y->cols, x->cols]
+ *   transposed = 1, fan-in  (y->count == 1):  Y   = sum_k X_k W_k        W_k = w_blocks[k]: [x->cols, y->cols]
+ * Weight blocks are row-major and unpadded, exactly as the layers store them; w_minus_blocks[k] (array or entries may
+ * be NULL) is subtracted element-wise from W_k (the Clenshaw form of ChebConv multiplies by W_0 - W_2);
+ * bias_blocks[k] (fan-out only, may be NULL): [y->cols].  One launch replaces
+ *   - the per-term projections of ChebConv / SAGEConv that read the same input rows (lins[k](x), lin_l(x), lin_r(x);
+ *     01_ngem.ipynb cell [9]) and
+ *   - the sum of per-term data gradients (gx = sum_k g_k W_k)
+ * without building the concatenation, whose wide rows would slow the aggregation gathers.  Concatenated width of the
+ * input side <= 64 columns.  gate / gate_scale as in mlqem_linear_f32 (fan-in; gate rows padded like Y's). */
+int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* const* w_blocks, const float* const* w_minus_blocks,
+                           int transposed, const float* const* bias_blocks, const mlqem_col_parts* y, int64_t N,
+                           const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream);
 
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 

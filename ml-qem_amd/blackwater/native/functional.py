@@ -99,32 +99,32 @@ def _padded_rows(t):
     return t if (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1) else ops.padded_copy(t)
 
 
-def _fan_out(x, blocks, b_cat, o):
-    """[x W_0^T | x W_1^T | ...] (+ b_cat) into separate padded buffers: one launch, x read once."""
+def _fan_out(x, ws, biases, w_minus=None):
+    """[x (W_0 - M_0)^T + b_0 | x W_1^T | ...] into separate padded buffers: one launch, x read once."""
     n, i = x.shape
-    outs = [ops.padded_empty(n, o, x.device) for _ in blocks]
-    w_cat = ops.pad_weight_blocks(blocks, i)
+    o = ws[0].shape[0]
+    outs = [ops.padded_empty(n, o, x.device) for _ in ws]
     if i <= _PARTS_MAX_COLS:
-        ops.linear_parts([x], w_cat, b_cat, outs)
+        ops.linear_parts([x], ws, outs, w_minus=w_minus, biases=biases)
     else:   # wide inputs: one launch per block
-        ow = (o + 3) // 4 * 4
-        for j, w in enumerate(blocks):
-            ops.linear(x, w.contiguous(), None if b_cat is None else b_cat[j * ow: j * ow + o], out=outs[j])
-    return outs, w_cat
+        for j, w in enumerate(ws):
+            wj = w if (w_minus is None or w_minus[j] is None) else w - w_minus[j]
+            ops.linear(x, wj.contiguous(), None if biases is None else biases[j], out=outs[j])
+    return outs
 
 
-def _fan_in_t(gs, w_cat, o, i, gate=None, gate_scale=1.0):
-    """gx = sum_j gs[j] W_j (W_j = block j of the padded ``w_cat``): one launch, gx written once; optional gate."""
-    n = gs[0].shape[0]
-    ow = (o + 3) // 4 * 4
+def _fan_in_t(gs, ws, i, w_minus=None, gate=None, gate_scale=1.0):
+    """gx = sum_j gs[j] (W_j - M_j): one launch, gx written once; optional gate on the result."""
+    n, o = gs[0].shape
     gx = ops.padded_empty(n, i, gs[0].device)
-    if len(gs) * ow <= _PARTS_MAX_COLS:
-        ops.linear_parts(gs, w_cat, None, [gx], transposed=True, gate=gate, gate_scale=gate_scale)
+    if len(gs) * ((o + 3) // 4 * 4) <= _PARTS_MAX_COLS:
+        ops.linear_parts(gs, ws, [gx], w_minus=w_minus, transposed=True, gate=gate, gate_scale=gate_scale)
     else:
         for j, g in enumerate(gs):
             last = j == len(gs) - 1
-            ops.linear(g, w_cat[j * ow: j * ow + o, :i].contiguous(), transposed=True, out=gx, accumulate=j > 0,
-                       gate=gate if last else None, gate_scale=gate_scale)
+            wj = ws[j] if (w_minus is None or w_minus[j] is None) else ws[j] - w_minus[j]
+            ops.linear(g, wj.contiguous(), transposed=True, out=gx, accumulate=j > 0, gate=gate if last else None,
+                       gate_scale=gate_scale)
     return gx
 
 
@@ -149,9 +149,9 @@ class _ChebLayer(Function):
         x = _padded_rows(ops.rowmajor(x))
         o = ws[0].shape[0]
         ow = (o + 3) // 4 * 4
-        blocks = [ws[0] - ws[2], ws[1], ws[2]] if k == 3 else list(ws)
-        b_cat = torch.nn.functional.pad(bias, (0, k * ow - o)) if bias is not None else None
-        c, w_cat = _fan_out(x, blocks, b_cat, o)
+        ws = [w.contiguous() for w in ws]
+        w_minus = [ws[2], None, None] if k == 3 else None          # block 0 multiplies by W_0 - W_2
+        c = _fan_out(x, ws, [bias] + [None] * (k - 1), w_minus)
         lap = dict(ell=s.in_ell, cscale=s.cheb_dinv, rscale=s.derived("cheb_neg"))
         act = dict(relu=relu, drop_p=drop_p, seed=seed)
         if k == 2:
@@ -161,13 +161,13 @@ class _ChebLayer(Function):
             y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], **lap, **act)
         ctx.struct, ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, k, relu, drop_p, bias is not None, (o, ow)
         ctx.x_gate_scale = x_gate_scale
-        ctx.save_for_backward(x, w_cat, y if ((relu or drop_p > 0) and not defer_mask) else None)
+        ctx.save_for_backward(x, y if ((relu or drop_p > 0) and not defer_mask) else None, *ws)
         return y
 
     @staticmethod
     def backward(ctx, g):
         k, s, (o, ow) = ctx.k, ctx.struct, ctx.dims
-        x, w_cat, y = ctx.saved_tensors
+        x, y, *ws = ctx.saved_tensors
         n, i = x.shape
         g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
         lap_t = dict(ell=s.out_ell, cscale=s.derived("cheb_neg"), rscale=s.cheb_dinv)
@@ -184,7 +184,8 @@ class _ChebLayer(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gated = ctx.x_gate_scale is not None
-            gx = _fan_in_t(gs, w_cat, o, i, gate=x if gated else None, gate_scale=ctx.x_gate_scale if gated else 1.0)
+            gx = _fan_in_t(gs, ws, i, w_minus=[ws[2], None, None] if k == 3 else None, gate=x if gated else None,
+                           gate_scale=ctx.x_gate_scale if gated else 1.0)
         return (gx, gb[:o] if ctx.has_bias else None, None, None, None, None, None, None, *gws)
 
 
@@ -263,18 +264,18 @@ class _SAGELayer(Function):
         x = _padded_rows(ops.rowmajor(x))
         o = wl.shape[0]
         ow = (o + 3) // 4 * 4
-        b_cat = torch.nn.functional.pad(bl, (ow, ow - o)) if bl is not None else None     # the bias rides on the root term
-        (p, r), w_cat = _fan_out(x, [wl, wr], b_cat, o)
+        wl, wr = wl.contiguous(), wr.contiguous()
+        p, r = _fan_out(x, [wl, wr], [None, bl])                      # the bias rides on the root term
         y = ops.csr_aggregate(p, s.in_ptr, s.in_src, ell=s.in_ell, rscale=s.sage_rinv, dself=s.derived("sage_dself"),
                               z=r, beta=1.0, relu=relu, drop_p=drop_p, seed=seed, out=r)
         ctx.struct, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, relu, drop_p, bl is not None, (o, ow)
         ctx.x_gate_scale = x_gate_scale
-        ctx.save_for_backward(x, w_cat, y if ((relu or drop_p > 0) and not defer_mask) else None)
+        ctx.save_for_backward(x, wl, wr, y if ((relu or drop_p > 0) and not defer_mask) else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w_cat, y = ctx.saved_tensors
+        x, wl, wr, y = ctx.saved_tensors
         s, (o, ow) = ctx.struct, ctx.dims
         n, i = x.shape
         g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
@@ -285,7 +286,7 @@ class _SAGELayer(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gated = ctx.x_gate_scale is not None
-            gx = _fan_in_t([gp, g], w_cat, o, i, gate=x if gated else None, gate_scale=ctx.x_gate_scale if gated else 1.0)
+            gx = _fan_in_t([gp, g], [wl, wr], i, gate=x if gated else None, gate_scale=ctx.x_gate_scale if gated else 1.0)
         return gx, gw[:o], gb[ow:ow + o] if ctx.has_bias else None, gw[ow:ow + o], None, None, None, None, None, None
 
 

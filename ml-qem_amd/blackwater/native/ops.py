@@ -196,33 +196,51 @@ def _col_parts(blocks, name: str, vector_rows: bool) -> "_lib.ColParts":
     return cp
 
 
-def pad_weight_blocks(ws, in_cols: int):
-    """[W_0; W_1; ...] for ``linear_parts`` with the blocks on the OUTPUT side: each [O, I] weight becomes a
-    [round_up(O, 4), round_up(I, 4)] zero-padded block, stacked along dim 0."""
-    o = ws[0].shape[0]
-    pad = torch.nn.functional.pad(torch.stack(list(ws)), (0, (in_cols + 3) // 4 * 4 - in_cols, 0, (o + 3) // 4 * 4 - o))
-    return pad.reshape(-1, pad.shape[-1])
+def _ptr_array(tensors, count):
+    import ctypes as _ct
+
+    arr = (_ct.c_void_p * 4)()
+    for k in range(count):
+        t = tensors[k] if tensors is not None else None
+        arr[k] = None if t is None else t.data_ptr()
+    return arr
 
 
-def linear_parts(xs, w, b, ys, transposed=False, gate=None, gate_scale=1.0):
-    """[ys[0] | ys[1] | ...] = [xs[0] | xs[1] | ...] @ w.T + b over column blocks in separate (padded) buffers;
-    ``w`` is indexed in the padded concatenated spaces: [len(ys)*round_up(O,4), len(xs)*round_up(I,4)] (or its
-    transpose's layout with ``transposed=True``)."""
+def linear_parts(xs, ws, ys, *, w_minus=None, biases=None, transposed=False, gate=None, gate_scale=1.0):
+    """Projections over column blocks in separate (padded) buffers, the blocks on one side:
+    fan-out (one x, ``transposed=False``): ys[k] = xs[0] @ (ws[k] - w_minus[k]).T + biases[k], ws[k]: [O, I];
+    fan-in (one y, ``transposed=True``): ys[0] = sum_k xs[k] @ (ws[k] - w_minus[k]), ws[k]: [cols(xs[k]), cols(ys[0])].
+    Weight blocks are the layers' own contiguous tensors -- nothing is concatenated or padded on the host."""
+    import ctypes as _ct
+
     n = xs[0].shape[0]
     xp, yp = _col_parts(xs, "xs", True), _col_parts(ys, "ys", True)
     if ys[0].shape[0] != n:
         raise ValueError("linear_parts: xs and ys differ in rows")
-    i_tot, o_tot = xp.count * xp.width, yp.count * yp.width
-    want = (i_tot, o_tot) if transposed else (o_tot, i_tot)
-    if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != want or not w.is_contiguous():
-        raise ValueError(f"linear_parts: w must be a contiguous fp32 cuda tensor of shape {want}, got {tuple(w.shape)}")
-    _vec(b, "b", o_tot)
-    import ctypes as _ct
-
+    if (len(ys) if transposed else len(xs)) != 1:
+        raise ValueError("linear_parts: the column blocks sit on one side (fan-out: one x; fan-in: one y)")
+    nblk = len(xs) if transposed else len(ys)
+    want = (xs[0].shape[1], ys[0].shape[1]) if transposed else (ys[0].shape[1], xs[0].shape[1])
+    for name, group in (("ws", ws), ("w_minus", w_minus)):
+        if group is None:
+            continue
+        if len(group) != nblk:
+            raise ValueError(f"linear_parts: {name} needs {nblk} blocks")
+        for w in group:
+            if w is not None and (not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != want or not w.is_contiguous()):
+                raise ValueError(f"linear_parts: every {name} block must be a contiguous fp32 cuda tensor of shape {want}")
+    if any(w is None for w in ws):
+        raise ValueError("linear_parts: ws blocks cannot be None")
+    if biases is not None:
+        if transposed or len(biases) != nblk:
+            raise ValueError("linear_parts: biases go with the fan-out form, one (or None) per block")
+        for bvec in biases:
+            _vec(bvec, "bias", want[0])
     if gate is not None and len(ys) != 1:
         raise ValueError("linear_parts: a gate needs a single output block")
-    code = _lib.load().mlqem_linear_parts_f32(_ct.addressof(xp), _p(w), 1 if transposed else 0, _p(b), _ct.addressof(yp),
-                                              n, *_gate(gate, n, ys[0].shape[1], True), float(gate_scale), _stream())
+    code = _lib.load().mlqem_linear_parts_f32(_ct.addressof(xp), _ptr_array(ws, nblk), _ptr_array(w_minus, nblk),
+                                              1 if transposed else 0, _ptr_array(biases, nblk), _ct.addressof(yp), n,
+                                              *_gate(gate, n, ys[0].shape[1], True), float(gate_scale), _stream())
     _lib.check(code, "mlqem_linear_parts_f32")
     return ys
 

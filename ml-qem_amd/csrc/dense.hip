@@ -228,8 +228,12 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
 struct PartsArgs {
   const float* xp[4]; int64_t ldx[4]; int xn, xw, xc;
   float* yp[4]; int64_t ldy[4]; int yn, yw, yc;
-  const float* w; const float* b;
-  int64_t N; int I, O;   // I = xn * xw, O = yn * yw: the shape of W ([O, I], or [I, O] when TRANSPOSED)
+  // Weights by block, unpadded, as the layers store them: block k is wk[k][rows, cols] row-major and belongs to output
+  // block k (fan-out: rows = yc outputs, cols = xc inputs; needs xn == 1) or, TRANSPOSED, to input block k (fan-in:
+  // rows = xc, cols = yc outputs, used as its transpose; needs yn == 1).  wm[k] (optional) is subtracted element-wise:
+  // the Clenshaw form of ChebConv needs W_0 - W_2.  bk[k] (optional): bias of output block k.
+  const float* wk[4]; const float* wm[4]; const float* bk[4];
+  int64_t N; int I, O;   // I = xn * xw, O = yn * yw: the concatenated (padded) column spaces
   const float* gate; int64_t ldgate; float gate_scale;   // single-block Y only: y = gate[n,o] > 0 ? y * gate_scale : 0
 };
 
@@ -262,7 +266,16 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
       for (int s4 = 0; s4 < 4; ++s4) {
         const int k = 16 * g + 4 * lq + s4;
         float v = 0.f;
-        if (o < a.O && k < a.I && s4 < xlive[g]) v = TRANSPOSED ? a.w[(int64_t)k * a.O + o] : a.w[(int64_t)o * a.I + k];
+        if (o < a.O && k < a.I && s4 < xlive[g]) {
+          const int xpart = k / a.xw, xl = k - xpart * a.xw;      // input block / column inside it
+          const int ypart = o / a.yw, yl = o - ypart * a.yw;      // output block / column inside it
+          if (yl < a.yc && ypart < a.yn) {
+            const int blk = TRANSPOSED ? xpart : ypart;
+            const int64_t at = TRANSPOSED ? (int64_t)xl * a.yc + yl : (int64_t)yl * a.xc + xl;
+            v = a.wk[blk][at];
+            if (a.wm[blk]) v -= a.wm[blk][at];
+          }
+        }
         wf[ob][g][s4] = v;
       }
   }
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
     ycol[ob] = ok ? a.yp[part] + lc : nullptr;
     yld[ob] = ok ? a.ldy[part] : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[ob][r] = (a.b && ok && lc + r < a.yc) ? a.b[o0 + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bias[ob][r] = (ok && a.bk[part] && lc + r < a.yc) ? a.bk[part][lc + r] : 0.f;
   }
 
   const int64_t n_tiles = ceil_div(a.N, 16);
@@ -576,19 +589,28 @@ static bool parts_ok(const mlqem_col_parts* p, bool vector_rows) {
   return true;
 }
 
-extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* w, int transposed, const float* b,
-                                      const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate,
-                                      float gate_scale, mlqem_stream_t stream) {
+extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* const* w_blocks,
+                                      const float* const* w_minus_blocks, int transposed,
+                                      const float* const* bias_blocks, const mlqem_col_parts* y, int64_t N,
+                                      const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || !w || !parts_ok(x, true) || !parts_ok(y, true)) return MLQEM_ERR_BAD_ARG;
+  if (N < 0 || !w_blocks || !parts_ok(x, true) || !parts_ok(y, true)) return MLQEM_ERR_BAD_ARG;
+  if (transposed ? y->count != 1 : x->count != 1) return MLQEM_ERR_BAD_ARG;   // the blocks sit on ONE side
   if (gate && (y->count != 1 || ldgate < y->width || ldgate % 4 || !aligned_to(gate, 16))) return MLQEM_ERR_BAD_ARG;
+  const int nblk = transposed ? x->count : y->count;
+  for (int i = 0; i < nblk; ++i) if (!w_blocks[i]) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   PartsArgs a{};
   for (int i = 0; i < x->count; ++i) { a.xp[i] = static_cast<const float*>(x->ptr[i]); a.ldx[i] = x->ld[i]; }
   for (int i = 0; i < y->count; ++i) { a.yp[i] = static_cast<float*>(y->ptr[i]); a.ldy[i] = y->ld[i]; }
+  for (int i = 0; i < nblk; ++i) {
+    a.wk[i] = w_blocks[i];
+    a.wm[i] = w_minus_blocks ? w_minus_blocks[i] : nullptr;
+    a.bk[i] = (bias_blocks && !transposed) ? bias_blocks[i] : nullptr;
+  }
   a.xn = x->count; a.xw = x->width; a.xc = x->cols;
   a.yn = y->count; a.yw = y->width; a.yc = y->cols;
-  a.w = w; a.b = b; a.N = N; a.I = x->count * x->width; a.O = y->count * y->width;
+  a.N = N; a.I = x->count * x->width; a.O = y->count * y->width;
   a.gate = gate; a.ldgate = ldgate; a.gate_scale = gate_scale;
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;

@@ -222,25 +222,26 @@ def test_linear_over_column_blocks(n, i, o, k):
     ws = [torch.randn(o, i, generator=g) / i ** 0.5 for _ in range(k)]
     bs = [torch.randn(o, generator=g) for _ in range(k)]
     ow = (o + 3) // 4 * 4
-    w_cat = ops.pad_weight_blocks([w.to(DEV) for w in ws], i).contiguous()
-    assert tuple(w_cat.shape) == (k * ow, (i + 3) // 4 * 4)
-    b_cat = torch.zeros(k * ow, device=DEV)
-    for j in range(k):
-        b_cat[j * ow: j * ow + o] = bs[j].to(DEV)
-    # fan-out
+    wd, bd = [w.to(DEV) for w in ws], [t.to(DEV) for t in bs]
+    # fan-out (block 0 with a subtracted weight, as the Clenshaw form of ChebConv uses it; one block without bias)
     xd = _padded(x)
     ys = [_padded(torch.zeros(n, o)) for _ in range(k)]
-    ops.linear_parts([xd], w_cat, b_cat, ys)
+    minus = [wd[-1]] + [None] * (k - 1)
+    ops.linear_parts([xd], wd, ys, w_minus=minus, biases=bd[:-1] + [None])
     for j in range(k):
-        want = x.double() @ ws[j].double().t() + bs[j].double()
+        wj = ws[j].double() - (ws[-1].double() if j == 0 else 0.0)
+        want = x.double() @ wj.t() + (bs[j].double() if j < k - 1 else 0.0)
         assert torch.allclose(ys[j].cpu().double(), want, rtol=1e-5, atol=1e-5), j
-    # fan-in, transposed: gx = sum_j g_j @ W_j
+    # fan-in, transposed: gx = sum_j g_j @ W_j, gated by a mask matrix
     gs = [torch.randn(n, o, generator=g) for _ in range(k)]
     gd = [_padded(t) for t in gs]
     gx = _padded(torch.zeros(n, i))
-    ops.linear_parts(gd, w_cat, None, [gx], transposed=True)
-    want = sum(gs[j].double() @ ws[j].double() for j in range(k))
+    ops.linear_parts(gd, wd, [gx], w_minus=minus, transposed=True)
+    want = sum(gs[j].double() @ (ws[j].double() - (ws[-1].double() if j == 0 else 0.0)) for j in range(k))
     assert torch.allclose(gx.cpu().double(), want, rtol=1e-5, atol=1e-5)
+    gate = _padded((torch.rand(n, i, generator=g) - 0.4).clamp_min(0.0), poison=False)
+    ops.linear_parts(gd, wd, [gx], w_minus=minus, transposed=True, gate=gate, gate_scale=1.25)
+    assert torch.allclose(gx.cpu().double(), torch.where(gate.cpu() > 0, want * 1.25, torch.zeros_like(want)), rtol=1e-5, atol=1e-5)
     # weight gradients of all blocks in one pass over x
     gw = torch.empty(k * ow, i, device=DEV)
     gb = torch.empty(k * ow, device=DEV)
@@ -259,11 +260,13 @@ def test_linear_over_column_blocks_rejects_unpadded_operands():
 
     x = torch.randn(64, 22, device=DEV)                                # compact rows: stride 22, not a multiple of 4
     y = ops.padded_empty(64, 10, DEV)
-    w = torch.zeros(12, 24, device=DEV)
+    w = torch.zeros(10, 22, device=DEV)
     with pytest.raises(ValueError, match="padded row layout"):
-        ops.linear_parts([x], w, None, [y])
+        ops.linear_parts([x], [w], [y])
     with pytest.raises(ValueError, match="shape"):
-        ops.linear_parts([ops.padded_empty(64, 22, DEV)], torch.zeros(12, 22, device=DEV), None, [y])
+        ops.linear_parts([ops.padded_empty(64, 22, DEV)], [torch.zeros(12, 24, device=DEV)], [y])
+    with pytest.raises(ValueError, match="one side"):
+        ops.linear_parts([ops.padded_empty(64, 22, DEV)] * 2, [w, w], [y, y])
 
 
 def test_mask_handover_between_layers_equals_separate_masking():
