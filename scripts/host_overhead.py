@@ -43,3 +43,39 @@ for _ in range(10):
     trainer.step(arena.batch(draw()))
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+
+# ---- where the host time goes: wall time inside each native wrapper (both the forward and the autograd thread)
+import collections, time as _t
+from blackwater.native import ops as _ops, functional as _F
+acc, cnt = collections.Counter(), collections.Counter()
+def _wrap(mod, name):
+    fn = getattr(mod, name)
+    def inner(*a, **k):
+        t0 = _t.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            acc[name] += _t.perf_counter() - t0; cnt[name] += 1
+    setattr(mod, name, inner)
+for nm in ("csr_aggregate", "linear", "linear_parts", "linear_wgrad", "linear_wgrad_parts", "relu_dropout_bwd",
+           "segment_mean", "segment_mean_bwd", "padded_empty"):
+    _wrap(_ops, nm)
+orig_batch = arena.batch
+K2 = 20
+t_batch = t_fwd = t_bwd = t_opt = 0.0
+for _ in range(K2):
+    # a sync before every phase: the queue is empty, so the times are pure enqueue cost (no back-pressure)
+    sync = torch.cuda.synchronize
+    sync(); t0 = _t.perf_counter(); b = orig_batch(draw()); t1 = _t.perf_counter()
+    trainer.optimizer.zero_grad(set_to_none=False)
+    sync(); t1b = _t.perf_counter()
+    out = model(*b.model_args()); loss = torch.nn.functional.mse_loss(out, b.y); t2 = _t.perf_counter()
+    sync(); t2b = _t.perf_counter()
+    loss.backward(); t3 = _t.perf_counter()
+    sync(); t3b = _t.perf_counter()
+    trainer.optimizer.step(); t4 = _t.perf_counter()
+    t_batch += t1 - t0; t_fwd += t2 - t1b; t_bwd += t3 - t2b; t_opt += t4 - t3b
+torch.cuda.synchronize()
+print(f"host ms/step: batch {1e3*t_batch/K2:.3f}  forward+loss {1e3*t_fwd/K2:.3f}  backward {1e3*t_bwd/K2:.3f}  optimizer {1e3*t_opt/K2:.3f}")
+for nm, v in acc.most_common():
+    print(f"  {nm:22s} {cnt[nm]/K2:5.1f} calls/step  {1e6*v/cnt[nm]:6.1f} us/call  {1e3*v/K2:.3f} ms/step")
