@@ -138,6 +138,9 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
       bias[ob][r] = (a.b && o < a.O) ? a.b[o] : 0.f;
     }
   const bool vec_store = a.ldy % 4 == 0 && aligned_to_dev(a.y, 16);
+  // gate rows read as float4 when they are padded like the output (whole float4s inside the row's allocation)
+  const bool gate_vec = a.gate && a.ldgate % 4 == 0 && aligned_to_dev(a.gate, 16);
+  const int gate_cols = gate_vec ? (int)min((int64_t)((a.O + 3) / 4 * 4), a.ldgate) : 0;
 
   const int64_t n_tiles = ceil_div(a.N, 16);
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
@@ -159,6 +162,16 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
       if (k0 + 1 >= a.I) av[g].y = 0.f;
       if (k0 + 2 >= a.I) av[g].z = 0.f;
       if (k0 + 3 >= a.I) av[g].w = 0.f;
+    }
+    // the gate rows are independent of the product: fetch them with the operands, not after the MFMAs
+    float4 gv[OBT];
+    if (gate_vec) {
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob) {
+        const int o0 = (ob0 + ob) * 16 + lq * 4;
+        gv[ob] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (row_ok && o0 + 4 <= gate_cols) gv[ob] = *reinterpret_cast<const float4*>(a.gate + row * a.ldgate + o0);
+      }
     }
     f32x4 acc[OBT];
 #pragma unroll
@@ -200,12 +213,12 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
         v[r] = u;
       }
       if (a.gate) {
-        const float* gp = a.gate + row * a.ldgate + o0;
-        if (full && a.ldgate % 4 == 0 && aligned_to_dev(a.gate, 16)) {
-          const float4 m = *reinterpret_cast<const float4*>(gp);
+        if (gate_vec && o0 + 4 <= gate_cols) {
+          const float4 m = gv[ob];
           v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
           v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
         } else {
+          const float* gp = a.gate + row * a.ldgate + o0;
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (o0 + r < a.O) v[r] = gp[r] > 0.f ? v[r] * a.gate_scale : 0.f;
         }
@@ -306,6 +319,14 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
       if (xlive[g] < 4) av[g].w = 0.f;
       if (xlive[g] < 1) av[g].x = 0.f;
     }
+    float4 gv[OBT];
+    if (a.gate) {   // host checked: one output block, gate rows padded like it; fetched with the operands
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob) {
+        gv[ob] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (row_ok && ycol[ob]) gv[ob] = *reinterpret_cast<const float4*>(a.gate + row * a.ldgate + (ob0 + ob) * 16 + lq * 4);
+      }
+    }
     f32x4 acc[OBT];
 #pragma unroll
     for (int ob = 0; ob < OBT; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -324,8 +345,8 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[ob][r] + bias[ob][r];
-      if (a.gate) {   // host checked: one output block, gate rows padded like it
-        const float4 m = *reinterpret_cast<const float4*>(a.gate + row * a.ldgate + (ob0 + ob) * 16 + lq * 4);
+      if (a.gate) {
+        const float4 m = gv[ob];
         v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
         v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
       }
