@@ -1,7 +1,7 @@
 // Edge-softmax kernels of Family B (docs/tutorials/gnn.py:70-276): TransformerConv's multi-head attention and
 // ASAPooling's attention-weighted cluster sum.  Both are "softmax over the in-edges of a row, then a weighted sum
 // of source rows"; the softmax statistics of a row are recomputed by each thread that needs them (rows have a
-// handful of in-edges), which keeps the kernels free of cross-lane traffic and of any [E]-sized intermediate.
+// handful of in-edges), which keeps the kernels free of any [E]-sized intermediate.
 #include "common.hpp"
 
 namespace mlqem {
@@ -10,58 +10,53 @@ constexpr int kAttnMaxC = 32;  // channels per head held in registers (reference
 
 // TransformerConv (heads=H, concat, root_weight, no edge features).
 // qkvs: [N, 4*H*C] = [query | key | value | skip] as produced by one fused projection.
-// Thread = (row, head).  Edge order: the row's CSR entries, then its self-loop(s) -- the order PyG's scatter sees.
+// One 16-lane group = (row, head); lane l holds channels l and l + 16 (C <= 32), so a key/value row segment is one
+// coalesced 64-byte read and q.k is a cross-lane sum.  Edge order: the row's CSR entries, then its self-loop(s) -- the
+// order PyG's scatter sees.
 __global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const float* __restrict__ qkvs, int64_t ld,
                                                                   const int32_t* __restrict__ ptr,
                                                                   const int32_t* __restrict__ idx,
                                                                   const int32_t* __restrict__ loops, int64_t N, int H,
                                                                   int C, float* __restrict__ out, int64_t ldo) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= N * H) return;
+  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (t >= N * H) return;                       // a whole group leaves together
   const int64_t row = t / H;
   const int h = (int)(t - row * H);
   const int HC = H * C;
   const float scale = 1.0f / sqrtf((float)C);
+  const bool c0 = l < C, c1 = l + kGroup < C;
   const float* __restrict__ qi = qkvs + row * ld + h * C;
-  float q[kAttnMaxC];
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c) q[c] = c < C ? qi[c] : 0.f;
+  const float q0 = c0 ? qi[l] : 0.f, q1 = c1 ? qi[l + kGroup] : 0.f;
 
   const int beg = ptr[row], end = ptr[row + 1];
   const int n_self = loops ? loops[row] : 0;
   auto score = [&](int64_t j) {
     const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < kAttnMaxC; ++c)
-      if (c < C) s = fmaf(q[c], kj[c], s);
-    return s * scale;
+    float s = q0 * (c0 ? kj[l] : 0.f);
+    if (c1) s = fmaf(q1, kj[l + kGroup], s);
+    return group16_sum(s) * scale;
   };
   // pass 1: segment max
   float m = -INFINITY;
   for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
   if (n_self > 0) m = fmaxf(m, score(row));
   // pass 2: exp, sum, weighted value sum
-  float acc[kAttnMaxC];
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c) acc[c] = 0.f;
-  float denom = 0.f;
+  float a0 = 0.f, a1 = 0.f, denom = 0.f;
   auto add = [&](int64_t j, float mult) {
     const float p = expf(score(j) - m) * mult;
     denom += p;
     const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
-#pragma unroll
-    for (int c = 0; c < kAttnMaxC; ++c)
-      if (c < C) acc[c] = fmaf(p, vj[c], acc[c]);
+    if (c0) a0 = fmaf(p, vj[l], a0);
+    if (c1) a1 = fmaf(p, vj[l + kGroup], a1);
   };
   for (int e = beg; e < end; ++e) add(idx[e], 1.f);
   if (n_self > 0) add(row, (float)n_self);
   const float inv = 1.0f / (denom + 1e-16f);
   const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
   float* __restrict__ o = out + row * ldo + h * C;
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c)
-    if (c < C) o[c] = acc[c] * inv + skip[c];
+  if (c0) o[l] = a0 * inv + skip[l];
+  if (c1) o[l + kGroup] = a1 * inv + skip[l + kGroup];
 }
 
 // ASAPooling steps 3-4: score_e = LeakyReLU(a[dst] + c[src]), softmax over the in-edges of
@@ -142,7 +137,7 @@ extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, co
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(transformer_attn_kernel, dim3((unsigned)ceil_div(N * H, kBlock)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(transformer_attn_kernel, dim3((unsigned)ceil_div(N * H * kGroup, kBlock)), dim3(kBlock), 0,
                      as_stream(stream), qkvs, ld, in_ptr, in_src, loops, N, H, C, out, ldo);
   return launch_status();
 }

@@ -87,6 +87,18 @@ template <int V> __device__ __forceinline__ void vstore_nt(float* p, const float
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+// Sum over the 16 lanes of an aligned lane group (all 16 must be active); every lane gets the total.  The attention
+// and pooling kernels give one group to a (row, head) or a row: lane l holds channels l, l + 16, ... so that a source row
+// is read with 64-byte coalesced loads and a dot product over the channels is four cross-lane adds in a fixed order.
+constexpr int kGroup = 16;
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 8, kGroup);
+  v += __shfl_xor(v, 4, kGroup);
+  v += __shfl_xor(v, 2, kGroup);
+  v += __shfl_xor(v, 1, kGroup);
+  return v;
+}
+
 __device__ __forceinline__ bool aligned_to_dev(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace mlqem

@@ -10,6 +10,9 @@ namespace mlqem {
 constexpr int kAttnMaxC = 32;
 
 // ---------------------------------------------------------------------------------------- TransformerConv
+// All three kernels give one 16-lane group to a (row, head): lane l holds channels l and l + 16 (C <= 32); row segments
+// are read with coalesced 64-byte loads and dot products over the channels are cross-lane sums (common.hpp).
+//
 // Forward with statistics: identical arithmetic to transformer_attn_kernel (attn.hip) plus m[N,H] (segment max) and
 // den[N,H] (sum of exp + 1e-16) for the backward, and optional dropout on the attention weights
 // (mask keyed by (seed, in-CSR position, head); self-loop entries use position E + row).
@@ -18,26 +21,24 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(
     const int32_t* __restrict__ loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
     float* __restrict__ out, int64_t ldo, float* __restrict__ attn_out, int64_t lda, float* __restrict__ stat_m,
     float* __restrict__ stat_den) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
   if (t >= N * H) return;
   const int64_t row = t / H;
   const int h = (int)(t - row * H);
   const int HC = H * C;
   const float scale = 1.0f / sqrtf((float)C);
   const float keep = 1.f / (1.f - drop_p);
+  const bool c0 = l < C, c1 = l + kGroup < C;
   const float* __restrict__ qi = qkvs + row * ld + h * C;
-  float q[kAttnMaxC];
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c) q[c] = c < C ? qi[c] : 0.f;
+  const float q0 = c0 ? qi[l] : 0.f, q1 = c1 ? qi[l + kGroup] : 0.f;
   const int beg = ptr[row], end = ptr[row + 1];
   const int n_self = loops ? loops[row] : 0;
   auto score = [&](int64_t j) {
     const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < kAttnMaxC; ++c)
-      if (c < C) s = fmaf(q[c], kj[c], s);
-    return s * scale;
+    float s = q0 * (c0 ? kj[l] : 0.f);
+    if (c1) s = fmaf(q1, kj[l + kGroup], s);
+    return group16_sum(s) * scale;
   };
   float m = -INFINITY;
   for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
@@ -46,28 +47,23 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(
   for (int e = beg; e < end; ++e) denom += expf(score(idx[e]) - m);
   if (n_self > 0) denom += expf(score(row) - m) * (float)n_self;
   denom += 1e-16f;
-  float acc[kAttnMaxC];
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c) acc[c] = 0.f;
+  float a0 = 0.f, a1 = 0.f;
   auto add = [&](int64_t j, float mult, int64_t pos) {
     float a = expf(score(j) - m) / denom * mult;
     if (drop_p > 0.f) a = uniform01(seed, (uint64_t)(pos * H + h)) < drop_p ? 0.f : a * keep;
     const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
-#pragma unroll
-    for (int c = 0; c < kAttnMaxC; ++c)
-      if (c < C) acc[c] = fmaf(a, vj[c], acc[c]);
+    if (c0) a0 = fmaf(a, vj[l], a0);
+    if (c1) a1 = fmaf(a, vj[l + kGroup], a1);
   };
   for (int e = beg; e < end; ++e) add(idx[e], 1.f, e);
   if (n_self > 0) add(row, (float)n_self, E + row);
   const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c)
-    if (c < C) {
-      attn_out[row * lda + h * C + c] = acc[c];
-      out[row * ldo + h * C + c] = acc[c] + skip[c];
-    }
-  stat_m[row * H + h] = m;
-  stat_den[row * H + h] = denom;
+  if (c0) { attn_out[row * lda + h * C + l] = a0; out[row * ldo + h * C + l] = a0 + skip[l]; }
+  if (c1) { attn_out[row * lda + h * C + l + kGroup] = a1; out[row * ldo + h * C + l + kGroup] = a1 + skip[l + kGroup]; }
+  if (l == 0) {
+    stat_m[row * H + h] = m;
+    stat_den[row * H + h] = denom;
+  }
 }
 
 // Destination side: g_q, g_skip, and per edge (in-CSR order; self entries at E + row): al = effective attention weight
@@ -78,54 +74,49 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(
     const float* __restrict__ stat_den, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const int32_t* __restrict__ loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
     float* __restrict__ gqkvs, int64_t ldq, float* __restrict__ edge_al, float* __restrict__ edge_gs) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
   if (t >= N * H) return;
   const int64_t row = t / H;
   const int h = (int)(t - row * H);
   const int HC = H * C;
   const float scale = 1.0f / sqrtf((float)C);
   const float keep = 1.f / (1.f - drop_p);
-  float q[kAttnMaxC], gi[kAttnMaxC], gq[kAttnMaxC];
-  float delta = 0.f;
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c) {
-    q[c] = c < C ? qkvs[row * ld + h * C + c] : 0.f;
-    gi[c] = c < C ? g[row * ldg + h * C + c] : 0.f;
-    gq[c] = 0.f;
-    if (c < C) delta = fmaf(gi[c], attn_out[row * lda + h * C + c], delta);
-  }
+  const bool c0 = l < C, c1 = l + kGroup < C;
+  const int o0 = h * C + l, o1 = o0 + kGroup;
+  const float q0 = c0 ? qkvs[row * ld + o0] : 0.f, q1 = c1 ? qkvs[row * ld + o1] : 0.f;
+  const float gi0 = c0 ? g[row * ldg + o0] : 0.f, gi1 = c1 ? g[row * ldg + o1] : 0.f;
+  float d = gi0 * (c0 ? attn_out[row * lda + o0] : 0.f);
+  if (c1) d = fmaf(gi1, attn_out[row * lda + o1], d);
+  const float delta = group16_sum(d);
+  float gq0 = 0.f, gq1 = 0.f;
   const float m = stat_m[row * H + h], den = stat_den[row * H + h];
   const int beg = ptr[row], end = ptr[row + 1];
   const int n_self = loops ? loops[row] : 0;
   auto visit = [&](int64_t j, float mult, int64_t pos) {
     const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
     const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
-    float s = 0.f, gv = 0.f;
-#pragma unroll
-    for (int c = 0; c < kAttnMaxC; ++c)
-      if (c < C) {
-        s = fmaf(q[c], kj[c], s);
-        gv = fmaf(gi[c], vj[c], gv);
-      }
+    const float k0 = c0 ? kj[l] : 0.f, k1 = c1 ? kj[l + kGroup] : 0.f;
+    float s = q0 * k0, gv = gi0 * (c0 ? vj[l] : 0.f);
+    if (c1) { s = fmaf(q1, k1, s); gv = fmaf(gi1, vj[l + kGroup], gv); }
+    s = group16_sum(s);
+    gv = group16_sum(gv);
     const float alpha = expf(s * scale - m) / den * mult;  // softmax weight (all copies of a repeated self-loop)
     float dmask = 1.f;
     if (drop_p > 0.f) dmask = uniform01(seed, (uint64_t)(pos * H + h)) < drop_p ? 0.f : keep;
     const float gs = alpha * (gv * dmask - delta) * scale;
-    edge_al[pos * H + h] = alpha * dmask;
-    edge_gs[pos * H + h] = gs;
-#pragma unroll
-    for (int c = 0; c < kAttnMaxC; ++c)
-      if (c < C) gq[c] = fmaf(gs, kj[c], gq[c]);
+    if (l == 0) {
+      edge_al[pos * H + h] = alpha * dmask;
+      edge_gs[pos * H + h] = gs;
+    }
+    gq0 = fmaf(gs, k0, gq0);
+    gq1 = fmaf(gs, k1, gq1);
   };
   for (int e = beg; e < end; ++e) visit(idx[e], 1.f, e);
   if (n_self > 0) visit(row, (float)n_self, E + row);
-  else { edge_al[(E + row) * H + h] = 0.f; edge_gs[(E + row) * H + h] = 0.f; }
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c)
-    if (c < C) {
-      gqkvs[row * ldq + h * C + c] = gq[c];
-      gqkvs[row * ldq + 3 * HC + h * C + c] = gi[c];
-    }
+  else if (l == 0) { edge_al[(E + row) * H + h] = 0.f; edge_gs[(E + row) * H + h] = 0.f; }
+  if (c0) { gqkvs[row * ldq + o0] = gq0; gqkvs[row * ldq + 3 * HC + o0] = gi0; }
+  if (c1) { gqkvs[row * ldq + o1] = gq1; gqkvs[row * ldq + 3 * HC + o1] = gi1; }
 }
 
 // Source side: g_k[j] = sum_{e: j->i} gs_e q_i ; g_v[j] = sum_e al_e g_i  (self entry included).
@@ -134,44 +125,37 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_kernel(
     const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, const int32_t* __restrict__ oeid, int64_t N,
     int64_t E, int H, int C, const float* __restrict__ edge_al, const float* __restrict__ edge_gs,
     float* __restrict__ gqkvs, int64_t ldq) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
   if (t >= N * H) return;
   const int64_t row = t / H;
   const int h = (int)(t - row * H);
   const int HC = H * C;
-  float gk[kAttnMaxC], gv[kAttnMaxC];
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c) gk[c] = gv[c] = 0.f;
+  const bool c0 = l < C, c1 = l + kGroup < C;
+  const int o0 = h * C + l, o1 = o0 + kGroup;
+  float gk0 = 0.f, gk1 = 0.f, gv0 = 0.f, gv1 = 0.f;
   auto visit = [&](int64_t i, int64_t pos) {
     const float gs = edge_gs[pos * H + h], al = edge_al[pos * H + h];
-    const float* __restrict__ qi = qkvs + i * ld + h * C;
-    const float* __restrict__ gi = g + i * ldg + h * C;
-#pragma unroll
-    for (int c = 0; c < kAttnMaxC; ++c)
-      if (c < C) {
-        gk[c] = fmaf(gs, qi[c], gk[c]);
-        gv[c] = fmaf(al, gi[c], gv[c]);
-      }
+    if (c0) { gk0 = fmaf(gs, qkvs[i * ld + o0], gk0); gv0 = fmaf(al, g[i * ldg + o0], gv0); }
+    if (c1) { gk1 = fmaf(gs, qkvs[i * ld + o1], gk1); gv1 = fmaf(al, g[i * ldg + o1], gv1); }
   };
   for (int e = optr[row]; e < optr[row + 1]; ++e) visit(odst[e], oeid[e]);
   visit(row, E + row);
-#pragma unroll
-  for (int c = 0; c < kAttnMaxC; ++c)
-    if (c < C) {
-      gqkvs[row * ldq + HC + h * C + c] = gk[c];
-      gqkvs[row * ldq + 2 * HC + h * C + c] = gv[c];
-    }
+  if (c0) { gqkvs[row * ldq + HC + o0] = gk0; gqkvs[row * ldq + 2 * HC + o0] = gv0; }
+  if (c1) { gqkvs[row * ldq + HC + o1] = gk1; gqkvs[row * ldq + 2 * HC + o1] = gv1; }
 }
 
 // --------------------------------------------------------------------------------------------- ASAPooling
 // Destination side of x'[i] = sum_e softmax_e(LeakyReLU(a_i + c_src)) x[src] (in-edges + own self-loop):
 // per edge al_e (softmax weight) and gp_e (gradient at the pre-activation a_i + c_src); g_a[i] = sum_e gp_e.
+// One 16-lane group per destination row; lane l holds channels l, l + 16, ...
 __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xnew, int64_t ldn,
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
     float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a) {
-  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   const int beg = ptr[row], end = ptr[row + 1];
   const float ai = a_dst[row];
@@ -182,23 +166,27 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
   for (int e = beg; e < end; ++e) den += expf(leaky(ai + c_src[idx[e]]) - m);
   den += 1e-16f;
   const float* __restrict__ gi = gnew + row * ldg;
-  float delta = 0.f;
-  for (int c = 0; c < C; ++c) delta = fmaf(gi[c], xnew[row * ldn + c], delta);
+  float d = 0.f;
+  for (int c = l; c < C; c += kGroup) d = fmaf(gi[c], xnew[row * ldn + c], d);
+  const float delta = group16_sum(d);
   float ga = 0.f;
   auto visit = [&](int64_t j, int64_t pos) {
     const float pre = ai + c_src[j];
     const float al = expf(leaky(pre) - m) / den;
     const float* __restrict__ xj = x + j * ldx;
     float dot = 0.f;
-    for (int c = 0; c < C; ++c) dot = fmaf(gi[c], xj[c], dot);
+    for (int c = l; c < C; c += kGroup) dot = fmaf(gi[c], xj[c], dot);
+    dot = group16_sum(dot);
     const float gp = al * (dot - delta) * (pre > 0.f ? 1.f : slope);
-    edge_al[pos] = al;
-    edge_gp[pos] = gp;
+    if (l == 0) {
+      edge_al[pos] = al;
+      edge_gp[pos] = gp;
+    }
     ga += gp;
   };
   for (int e = beg; e < end; ++e) visit(idx[e], e);
   visit(row, E + row);
-  g_a[row] = ga;
+  if (l == 0) g_a[row] = ga;
 }
 
 // Source side: g_x[j,:] (+)= sum_{e: j->i} al_e gnew[i,:] (self included); g_c[j] = sum_e gp_e.
@@ -264,20 +252,23 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_kernel(
     const float* __restrict__ gout, int64_t ldgo, const float* __restrict__ xnew, int64_t ldn,
     const float* __restrict__ fitness, const int32_t* __restrict__ slot, int64_t N, int C, float* __restrict__ gxnew,
     int64_t ldgn, float* __restrict__ gfit) {
-  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;   // one 16-lane group per row
+  const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   const int p = slot[row];
+  const float f = fitness[row];
   float dot = 0.f;
-  for (int c = 0; c < C; ++c) {
+  for (int c = l; c < C; c += kGroup) {
     float gv = 0.f;
     if (p >= 0) {
       const float go = gout[(int64_t)p * ldgo + c];
-      gv = go * fitness[row];
+      gv = go * f;
       dot = fmaf(go, xnew[row * ldn + c], dot);
     }
     gxnew[row * ldgn + c] = gv;
   }
-  gfit[row] = dot;
+  dot = group16_sum(dot);
+  if (l == 0) gfit[row] = dot;
 }
 
 // LEConv + sigmoid backward on scalars: from g_f and f build the gradient of pqr[N,3] = (p, q, r):
@@ -313,7 +304,7 @@ extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t 
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(transformer_attn_train_kernel, MLQEM_GRID(N * H), qkvs, ld, in_ptr, in_src, loops, N, E, H, C,
+  hipLaunchKernelGGL(transformer_attn_train_kernel, MLQEM_GRID(N * H * kGroup), qkvs, ld, in_ptr, in_src, loops, N, E, H, C,
                      drop_p, seed, out, ldo, attn_out, lda, stat_m, stat_den);
   return launch_status();
 }
@@ -333,9 +324,9 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if (!qkvs || !g || !attn_out || !stat_m || !stat_den || !in_ptr || !out_ptr || !gqkvs || !edge_al || !edge_gs)
     return MLQEM_ERR_BAD_ARG;
   if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel, MLQEM_GRID(N * H), qkvs, ld, g, ldg, attn_out, lda, stat_m,
+  hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel, MLQEM_GRID(N * H * kGroup), qkvs, ld, g, ldg, attn_out, lda, stat_m,
                      stat_den, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, gqkvs, ldq, edge_al, edge_gs);
-  hipLaunchKernelGGL(transformer_attn_bwd_src_kernel, MLQEM_GRID(N * H), qkvs, ld, g, ldg, out_ptr, out_dst, out_eid,
+  hipLaunchKernelGGL(transformer_attn_bwd_src_kernel, MLQEM_GRID(N * H * kGroup), qkvs, ld, g, ldg, out_ptr, out_dst, out_eid,
                      N, E, H, C, edge_al, edge_gs, gqkvs, ldq);
   return launch_status();
 }
@@ -353,7 +344,7 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
   if (!x || !xnew || !gnew || !in_ptr || !out_ptr || !a_dst || !c_src || !gx || !g_a || !g_c || !edge_al || !edge_gp)
     return MLQEM_ERR_BAD_ARG;
   if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(softmax_aggregate_bwd_dst_kernel, MLQEM_GRID(N), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,
+  hipLaunchKernelGGL(softmax_aggregate_bwd_dst_kernel, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,
                      a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a);
   hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel, MLQEM_GRID(N * C), gnew, ldg, out_ptr, out_dst, out_eid,
                      edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c);
@@ -383,7 +374,7 @@ extern "C" int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, 
   if (N < 0 || C <= 0 || ldgo < C || ldn < C || ldgn < C) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!xnew || !fitness || !slot || !gxnew || !gfit) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gather_scale_rows_bwd_kernel, MLQEM_GRID(N), gout, ldgo, xnew, ldn, fitness, slot, N, C, gxnew,
+  hipLaunchKernelGGL(gather_scale_rows_bwd_kernel, MLQEM_GRID(N * kGroup), gout, ldgo, xnew, ldn, fitness, slot, N, C, gxnew,
                      ldgn, gfit);
   return launch_status();
 }
