@@ -14,8 +14,8 @@ n_graphs = len(corpus["x"])
 b = arena.batch(np.arange(256) * n_graphs // 256)
 s = b.structure
 n = s.num_nodes
-hs = [torch.randn(n, c, device="cuda:0") for _ in range(4)]
-outs = [torch.empty_like(hs[0]) for _ in range(4)]
+hs = [ops.padded_empty(n, c, "cuda:0").normal_() for _ in range(4)]
+outs = [ops.padded_empty(n, c, "cuda:0") for _ in range(4)]
 real = s.in_ell
 rows = torch.arange(n, device="cuda:0", dtype=torch.int32)
 none = torch.full((n, 2), -1, dtype=torch.int32, device="cuda:0")
