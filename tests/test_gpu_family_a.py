@@ -13,18 +13,18 @@ DEV = "cuda:0"
 ARGS = ("noisy", "observable", "depth", "x", "edge_index", "batch")
 
 
-def _models(seed=0):
+def _models(seed=0, hidden=10):
     from blackwater.nn import ExpValCircuitGraphModelA
     from oracle.models import FamilyA
 
     torch.manual_seed(seed)
-    model = ExpValCircuitGraphModelA(5, 22, 10)
+    model = ExpValCircuitGraphModelA(5, 22, hidden)
     # GCN/Cheb biases start at zero; give them values so their gradients/paths are exercised
     with torch.no_grad():
         for name, p in model.named_parameters():
             if name.endswith("bias"):
                 p.uniform_(-0.5, 0.5)
-    ref = FamilyA(5, 22, 10).double()
+    ref = FamilyA(5, 22, hidden).double()
     ref.load_state_dict(model.state_dict(), strict=True)
     return model.to(DEV), ref
 
@@ -54,6 +54,25 @@ def test_gradients_match_oracle(g1):
         scale = g_ref.abs().max().item() + 1e-9
         err = (p.grad.cpu().double() - g_ref).abs().max().item() / scale
         assert err < 1e-4, f"{name}: relative grad error {err}"
+
+
+@pytest.mark.parametrize("hidden", [3, 40, 80])
+def test_other_hidden_widths(g1, hidden):
+    """Hidden widths around the limits of the column-block GEMM (64 concatenated input columns; 16-column output tiles):
+    3 (one partial tile), 40 (three blocks = 120 output columns), 80 (per-block fallback launches)."""
+    model, ref = _models(seed=2, hidden=hidden)
+    batch = g1_batch(g1, range(100, 148))
+    model.eval(), ref.eval()
+    out = model(*[batch[k].to(DEV) for k in ARGS])
+    want = ref(*[batch[k].double() if batch[k].is_floating_point() else batch[k] for k in ARGS])
+    assert (out.detach().cpu().double() - want.detach()).abs().max().item() < 1e-5
+    torch.nn.functional.mse_loss(out, batch["y"].to(DEV)).backward()
+    torch.nn.functional.mse_loss(want, batch["y"].double()).backward()
+    ref_grads = dict(ref.named_parameters())
+    for name, p in model.named_parameters():
+        g_ref = ref_grads[name].grad
+        scale = g_ref.abs().max().item() + 1e-9
+        assert (p.grad.cpu().double() - g_ref).abs().max().item() / scale < 1e-4, name
 
 
 def test_train_mode_dropout_runs_and_is_seeded(g1):
