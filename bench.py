@@ -64,6 +64,18 @@ def roofline_leg(batch, reps=20):
     end.synchronize()
     sec = beg.elapsed_time(end) * 1e-3 / reps
     b = agg_bytes(n, e_loops, c)
+    # the box's own stream-copy rate, for context (SURVEY section 8d asks for the measured peak next to the vendor one)
+    src_buf = torch.empty(256 << 20, dtype=torch.float32, device=batch.x.device).normal_()
+    dst_bufs = [torch.empty_like(src_buf) for _ in range(2)]
+    for k in range(2):
+        dst_bufs[k].copy_(src_buf)
+    beg.record(stream)
+    for k in range(6):
+        dst_bufs[k % 2].copy_(src_buf)
+    end.record(stream)
+    end.synchronize()
+    copy_gbps = 6 * 2 * src_buf.numel() * 4 / (beg.elapsed_time(end) * 1e-3) / 1e9
+    del src_buf, dst_bufs
     peak = 8000.0  # GB/s, MI355X HBM3E (guide: MI355X_MICROARCH.md chip table)
     ach = b / sec / 1e9
     # HBM traffic per launch comes from rocprofv3 PMC passes (they cannot run inside this process); the committed
@@ -79,7 +91,7 @@ def roofline_leg(batch, reps=20):
     return {"bound": "hbm", "kernel": "csr_aggregate_ell_kernel<4,false,2> (GCN forward aggregation, C=10)",
             "achieved": round(ach, 1), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_source": src, "bytes_per_launch": int(b), "us_per_launch": round(sec * 1e6, 2), "nodes": n,
-            "edges_with_loops": e_loops}
+            "edges_with_loops": e_loops, "measured_copy_GBps": round(copy_gbps, 1)}
 
 
 def parity_leg(model, arena, corpus, n_qubits, n_check=10):

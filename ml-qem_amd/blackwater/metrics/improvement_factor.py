@@ -59,3 +59,28 @@ def error_summary(ideal: Sequence, predicted: Sequence) -> dict:
     d = a - b
     return {"rmse": float(np.sqrt(np.mean(d ** 2))), "mean_l2": float(np.mean(np.linalg.norm(d, axis=1))),
             "mae": float(np.mean(np.abs(d)))}
+
+
+def mitigation_report(ideal: Sequence, noisy: Sequence, mitigated: Sequence) -> dict:
+    """The numbers the reference's evaluation cell prints after training (docs/tutorials/__ml_models.py:207-253):
+    ``RMSE_noisy_q`` / ``RMSE_mitigated_q`` for every measured qubit q, their all-qubit counterparts
+    (sqrt of the mean of the per-qubit mean squared distances), plus mean-L2 and MAE before/after for comparison with
+    BASELINE.md's tables.  Inputs: [num_circuits, k] arrays (a trailing singleton axis of the dataset's [.,1,k] is fine)."""
+    def as2d(v):
+        v = np.asarray(v, dtype=np.float64)
+        return v.reshape(v.shape[0], -1)
+
+    a, n, m = as2d(ideal), as2d(noisy), as2d(mitigated)
+    if not (a.shape == n.shape == m.shape):
+        raise ValueError(f"shape mismatch: ideal {a.shape}, noisy {n.shape}, mitigated {m.shape}")
+    sq_n, sq_m = (a - n) ** 2, (a - m) ** 2
+    out = {}
+    for q in range(a.shape[1]):
+        out[f"RMSE_noisy_{q}"] = float(np.sqrt(sq_n[:, q].mean()))
+        out[f"RMSE_mitigated_{q}"] = float(np.sqrt(sq_m[:, q].mean()))
+    out["RMSE_noisy"] = float(np.sqrt(np.mean(sq_n.mean(axis=0))))
+    out["RMSE_mitigated"] = float(np.sqrt(np.mean(sq_m.mean(axis=0))))
+    before, after = error_summary(a, n), error_summary(a, m)
+    out.update({"L2_noisy": before["mean_l2"], "L2_mitigated": after["mean_l2"], "MAE_noisy": before["mae"],
+                "MAE_mitigated": after["mae"]})
+    return out

@@ -111,6 +111,18 @@ class Trainer:
             total = l if total is None else total + l
         return total
 
+    def predict(self, arena, ids, batch_size: int = 256) -> torch.Tensor:
+        """Model outputs (eval mode, no gradients) for the graphs ``ids`` of ``arena``, in that order -- the input of
+        ``metrics.mitigation_report`` (the reference's post-training evaluation loop, __ml_models.py:207-230)."""
+        was_training = self.model.training
+        self.model.eval()
+        outs = []
+        with torch.no_grad():
+            for i in range(0, len(ids), batch_size):
+                outs.append(self.model(*arena.batch(ids[i:i + batch_size]).model_args()))
+        self.model.train(was_training)
+        return torch.cat(outs, dim=0)
+
     def fit(self, arena, train_ids, val_ids, epochs: int, batch_size: int = 32, seed: int = 0, log: Callable = None):
         """Epoch loop with per-epoch shuffling (seed + epoch) and the reference's LR schedule."""
         history = {"train_losses": [], "val_losses": []}
