@@ -22,3 +22,30 @@ for (i, o, tr) in [(22, 10, False), (10, 10, False), (10, 1, False), (10, 22, Tr
     us = beg.elapsed_time(end) * 1e3 / 12
     nb = xs[0].shape[0] * (xs[0].stride(0) + ys[0].stride(0)) * 4
     print(f"I={i:3d} O={o:3d} transposed={tr!s:5s} rows={xs[0].shape[0]:8d}  {us:7.1f} us  {nb / us / 1e3:6.0f} GB/s (padded bytes)  maxerr {err:.2e}")
+
+# column-block GEMMs and weight gradients of the first layers
+def timed(fn, reps=12):
+    for _ in range(3): fn()
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    beg.record()
+    for _ in range(reps): fn()
+    end.record(); torch.cuda.synchronize()
+    return beg.elapsed_time(end) * 1e3 / reps
+x = ops.padded_empty(n, 22, dev).normal_()
+for k in (2, 3):
+    ws = [torch.randn(10, 22, device=dev) for _ in range(k)]
+    ys = [ops.padded_empty(n, 10, dev) for _ in range(k)]
+    us = timed(lambda: ops.linear_parts([x], ws, ys))
+    print(f"fan-out 22 -> {k} x 10: {us:7.1f} us  {n * (24 + 12 * k) * 4 / us / 1e3:6.0f} GB/s")
+    gs = [ops.padded_empty(n, 10, dev).normal_() for _ in range(k)]
+    gw = torch.empty(12 * k, 22, device=dev); gb = torch.empty(12 * k, device=dev)
+    us = timed(lambda: ops.linear_wgrad_parts(gs, x, gw, gb))
+    print(f"wgrad x[22]^T [{k} x 10]: {us:7.1f} us  {n * (24 + 12 * k) * 4 / us / 1e3:6.0f} GB/s")
+g1 = ops.padded_empty(n, 10, dev).normal_()
+gw = torch.empty(10, 22, device=dev); gb = torch.empty(10, device=dev)
+us = timed(lambda: ops.linear_wgrad(g1, x, gw, gb))
+print(f"wgrad x[22]^T [10]: {us:7.1f} us  {n * 36 * 4 / us / 1e3:6.0f} GB/s")
+h = ops.padded_empty(n, 10, dev).normal_()
+gw = torch.empty(10, 10, device=dev)
+us = timed(lambda: ops.linear_wgrad(g1, h, gw, gb))
+print(f"wgrad x[10]^T [10]: {us:7.1f} us  {n * 24 * 4 / us / 1e3:6.0f} GB/s")
