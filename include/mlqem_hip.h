@@ -122,14 +122,16 @@ int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed
                      float drop_p, uint64_t seed, int rs_cols, int act_from, const float* gate, int64_t ldgate,
                      float gate_scale, mlqem_stream_t stream);
 
-/* A matrix given as up to four COLUMN BLOCKS in separate buffers: block p is ptr[p][N, cols] (row stride ld[p]) and
+#define MLQEM_MAX_COL_PARTS 8
+
+/* A matrix given as up to MLQEM_MAX_COL_PARTS COLUMN BLOCKS in separate buffers: block p is ptr[p][N, cols] (row stride ld[p]) and
  * stands at columns [p*width, p*width + cols) of the concatenation; columns cols..width-1 of a block are padding (read
  * as 0, written as scratch).  For mlqem_linear_parts_f32 width and every ld must be multiples of 4 and every ptr 16-byte
  * aligned (the padded activation layout). */
 typedef struct mlqem_col_parts {
   int32_t count, width, cols, reserved;
-  void* ptr[4];
-  int64_t ld[4];
+  void* ptr[MLQEM_MAX_COL_PARTS];
+  int64_t ld[MLQEM_MAX_COL_PARTS];
 } mlqem_col_parts;
 
 /* Projections over column blocks, the blocks on ONE side:
@@ -137,15 +139,17 @@ typedef struct mlqem_col_parts {
  *   transposed = 1, fan-in  (y->count == 1):  Y   = sum_k X_k W_k        W_k = w_blocks[k]: [x->cols, y->cols]
  * Weight blocks are row-major and unpadded, exactly as the layers store them; w_minus_blocks[k] (array or entries may
  * be NULL) is subtracted element-wise from W_k (the Clenshaw form of ChebConv multiplies by W_0 - W_2);
- * bias_blocks[k] (fan-out only, may be NULL): [y->cols].  One launch replaces
+ * bias_blocks[k] (fan-out only, may be NULL): [y->cols]; rowscale_blocks[k] (fan-out only, may be NULL): [N], block k's
+ * rows are multiplied by it after the bias (GCNConv's D^-1/2 pre-scaling).  One launch replaces
  *   - the per-term projections of ChebConv / SAGEConv that read the same input rows (lins[k](x), lin_l(x), lin_r(x);
  *     01_ngem.ipynb cell [9]) and
  *   - the sum of per-term data gradients (gx = sum_k g_k W_k)
  * without building the concatenation, whose wide rows would slow the aggregation gathers.  Concatenated width of the
  * input side <= 64 columns.  gate / gate_scale as in mlqem_linear_f32 (fan-in; gate rows padded like Y's). */
 int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* const* w_blocks, const float* const* w_minus_blocks,
-                           int transposed, const float* const* bias_blocks, const mlqem_col_parts* y, int64_t N,
-                           const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream);
+                           int transposed, const float* const* bias_blocks, const float* const* rowscale_blocks,
+                           const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate, float gate_scale,
+                           mlqem_stream_t stream);
 
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 

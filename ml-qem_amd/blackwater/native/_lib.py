@@ -21,11 +21,14 @@ class NativeLibraryError(RuntimeError):
 _P, _I, _L, _F, _S, _U = c_void_p, c_int, c_int64, c_float, c_size_t, c_uint64
 
 
+MAX_COL_PARTS = 8   # MLQEM_MAX_COL_PARTS
+
+
 class ColParts(ctypes.Structure):
     """``mlqem_col_parts``: a matrix given as up to four column blocks in separate buffers."""
 
     _fields_ = [("count", ctypes.c_int32), ("width", ctypes.c_int32), ("cols", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("ptr", c_void_p * 4), ("ld", c_int64 * 4)]
+                ("reserved", ctypes.c_int32), ("ptr", c_void_p * MAX_COL_PARTS), ("ld", c_int64 * MAX_COL_PARTS)]
 
 
 # name -> (restype, argtypes); kept in the order of include/mlqem_hip.h
@@ -42,7 +45,7 @@ SIGNATURES = {
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
     "mlqem_relu_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _F, _P, _L, _L, _I, _P]),
     "mlqem_linear_f32": (_I, [_P, _L, _P, _I, _P, _P, _P, _L, _L, _I, _I, _I, _I, _F, _U, _I, _I, _P, _L, _F, _P]),
-    "mlqem_linear_parts_f32": (_I, [_P, _P, _P, _I, _P, _P, _L, _P, _L, _F, _P]),
+    "mlqem_linear_parts_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _L, _P, _L, _F, _P]),
     "mlqem_linear_wgrad_workspace_bytes": (_S, [_I, _I]),
     "mlqem_linear_wgrad_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P]),
     "mlqem_linear_wgrad_parts_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P]),

@@ -179,8 +179,8 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
 
 def _col_parts(blocks, name: str, vector_rows: bool) -> "_lib.ColParts":
     """The C view of a list of [N, c] blocks (one shape, padded rows when ``vector_rows``)."""
-    if not 1 <= len(blocks) <= 4:
-        raise ValueError(f"{name}: 1..4 column blocks, got {len(blocks)}")
+    if not 1 <= len(blocks) <= _lib.MAX_COL_PARTS:
+        raise ValueError(f"{name}: 1..{_lib.MAX_COL_PARTS} column blocks, got {len(blocks)}")
     n, c = blocks[0].shape
     width = (c + 3) // 4 * 4
     cp = _lib.ColParts()
@@ -199,14 +199,14 @@ def _col_parts(blocks, name: str, vector_rows: bool) -> "_lib.ColParts":
 def _ptr_array(tensors, count):
     import ctypes as _ct
 
-    arr = (_ct.c_void_p * 4)()
+    arr = (_ct.c_void_p * _lib.MAX_COL_PARTS)()
     for k in range(count):
         t = tensors[k] if tensors is not None else None
         arr[k] = None if t is None else t.data_ptr()
     return arr
 
 
-def linear_parts(xs, ws, ys, *, w_minus=None, biases=None, transposed=False, gate=None, gate_scale=1.0):
+def linear_parts(xs, ws, ys, *, w_minus=None, biases=None, rowscales=None, transposed=False, gate=None, gate_scale=1.0):
     """Projections over column blocks in separate (padded) buffers, the blocks on one side:
     fan-out (one x, ``transposed=False``): ys[k] = xs[0] @ (ws[k] - w_minus[k]).T + biases[k], ws[k]: [O, I];
     fan-in (one y, ``transposed=True``): ys[0] = sum_k xs[k] @ (ws[k] - w_minus[k]), ws[k]: [cols(xs[k]), cols(ys[0])].
@@ -236,10 +236,16 @@ def linear_parts(xs, ws, ys, *, w_minus=None, biases=None, transposed=False, gat
             raise ValueError("linear_parts: biases go with the fan-out form, one (or None) per block")
         for bvec in biases:
             _vec(bvec, "bias", want[0])
+    if rowscales is not None:
+        if transposed or len(rowscales) != nblk:
+            raise ValueError("linear_parts: rowscales go with the fan-out form, one (or None) per block")
+        for rvec in rowscales:
+            _vec(rvec, "rowscale", n)
     if gate is not None and len(ys) != 1:
         raise ValueError("linear_parts: a gate needs a single output block")
     code = _lib.load().mlqem_linear_parts_f32(_ct.addressof(xp), _ptr_array(ws, nblk), _ptr_array(w_minus, nblk),
-                                              1 if transposed else 0, _ptr_array(biases, nblk), _ct.addressof(yp), n,
+                                              1 if transposed else 0, _ptr_array(biases, nblk),
+                                              _ptr_array(rowscales, nblk), _ct.addressof(yp), n,
                                               *_gate(gate, n, ys[0].shape[1], True), float(gate_scale), _stream())
     _lib.check(code, "mlqem_linear_parts_f32")
     return ys

@@ -238,14 +238,17 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
 // projections (fan-out: y_p = x W_p^T) and one write serves a sum of projections (fan-in: y = sum_p x_p W_p^T)
 // without ever materialising the concatenation -- whose rows would be too wide for the aggregation gathers.
 // Same lane maps and summation order as linear_mfma_v4_kernel; every row access is one aligned float4.
+constexpr int kMaxParts = MLQEM_MAX_COL_PARTS;
+
 struct PartsArgs {
-  const float* xp[4]; int64_t ldx[4]; int xn, xw, xc;
-  float* yp[4]; int64_t ldy[4]; int yn, yw, yc;
+  const float* xp[kMaxParts]; int64_t ldx[kMaxParts]; int xn, xw, xc;
+  float* yp[kMaxParts]; int64_t ldy[kMaxParts]; int yn, yw, yc;
   // Weights by block, unpadded, as the layers store them: block k is wk[k][rows, cols] row-major and belongs to output
   // block k (fan-out: rows = yc outputs, cols = xc inputs; needs xn == 1) or, TRANSPOSED, to input block k (fan-in:
   // rows = xc, cols = yc outputs, used as its transpose; needs yn == 1).  wm[k] (optional) is subtracted element-wise:
   // the Clenshaw form of ChebConv needs W_0 - W_2.  bk[k] (optional): bias of output block k.
-  const float* wk[4]; const float* wm[4]; const float* bk[4];
+  const float* wk[kMaxParts]; const float* wm[kMaxParts]; const float* bk[kMaxParts];
+  const float* rsk[kMaxParts];   // optional per-output-block row scale (fan-out): Y_k[n,:] *= rsk[k][n]  (GCN's D^-1/2)
   int64_t N; int I, O;   // I = xn * xw, O = yn * yw: the concatenated (padded) column spaces
   const float* gate; int64_t ldgate; float gate_scale;   // single-block Y only: y = gate[n,o] > 0 ? y * gate_scale : 0
 };
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
       }
   }
   float bias[OBT][4];
-  float* ycol[OBT]; int64_t yld[OBT];
+  float* ycol[OBT]; int64_t yld[OBT]; const float* yrs[OBT];
 #pragma unroll
   for (int ob = 0; ob < OBT; ++ob) {
     const int o0 = (ob0 + ob) * 16 + lq * 4;
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
     const bool ok = o0 < a.O && part < a.yn;
     ycol[ob] = ok ? a.yp[part] + lc : nullptr;
     yld[ob] = ok ? a.ldy[part] : 0;
+    yrs[ob] = ok ? a.rsk[part] : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[ob][r] = (ok && a.bk[part] && lc + r < a.yc) ? a.bk[part][lc + r] : 0.f;
   }
@@ -345,6 +349,11 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[ob][r] + bias[ob][r];
+      if (yrs[ob]) {
+        const float rs = yrs[ob][row];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rs;
+      }
       if (a.gate) {
         const float4 m = gv[ob];
         v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void linear_scalar_kernel(const LinArgs a, 
 
 // ------------------------------------------------------------------------------------------ weight gradient
 struct WgradArgs {
-  const float* gyp[4]; int64_t ldgy[4];   // gy = column blocks in separate buffers (see PartsArgs); one block: gn = 1
+  const float* gyp[MLQEM_MAX_COL_PARTS]; int64_t ldgy[MLQEM_MAX_COL_PARTS];   // gy = column blocks in separate buffers (see PartsArgs); one block: gn = 1
   int gn, gw, gc;                          // blocks, columns per block in the concatenation, meaningful columns per block
   const float* x; int64_t ldx;
   float* partial;          // [gridDim.x][O * (I + 1)]
@@ -597,13 +606,16 @@ static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, h
 #define MLQEM_PARTS_G(OB) switch (g) { case 1: MLQEM_PARTS(OB, 1) case 2: MLQEM_PARTS(OB, 2) case 3: MLQEM_PARTS(OB, 3) case 4: MLQEM_PARTS(OB, 4) default: return false; }
   if (obt == 1) MLQEM_PARTS_G(1)
   if (obt == 2) MLQEM_PARTS_G(2)
+  if (obt == 6) {   // up to 96 output columns from ONE read of a narrow x (the first layers of all three branches)
+    switch (g) { case 1: MLQEM_PARTS(6, 1) case 2: MLQEM_PARTS(6, 2) default: return false; }
+  }
   MLQEM_PARTS_G(4)
 #undef MLQEM_PARTS_G
 #undef MLQEM_PARTS
 }
 
 static bool parts_ok(const mlqem_col_parts* p, bool vector_rows) {
-  if (!p || p->count < 1 || p->count > 4 || p->width < 1 || p->cols < 1 || p->cols > p->width) return false;
+  if (!p || p->count < 1 || p->count > MLQEM_MAX_COL_PARTS || p->width < 1 || p->cols < 1 || p->cols > p->width) return false;
   if (vector_rows && p->width % 4) return false;
   for (int i = 0; i < p->count; ++i) {
     if (!p->ptr[i] || p->ld[i] < (vector_rows ? p->width : p->cols)) return false;
@@ -614,8 +626,8 @@ static bool parts_ok(const mlqem_col_parts* p, bool vector_rows) {
 
 extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* const* w_blocks,
                                       const float* const* w_minus_blocks, int transposed,
-                                      const float* const* bias_blocks, const mlqem_col_parts* y, int64_t N,
-                                      const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream) {
+                                      const float* const* bias_blocks, const float* const* rowscale_blocks,
+                                      const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || !w_blocks || !parts_ok(x, true) || !parts_ok(y, true)) return MLQEM_ERR_BAD_ARG;
   if (transposed ? y->count != 1 : x->count != 1) return MLQEM_ERR_BAD_ARG;   // the blocks sit on ONE side
@@ -630,6 +642,7 @@ extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* con
     a.wk[i] = w_blocks[i];
     a.wm[i] = w_minus_blocks ? w_minus_blocks[i] : nullptr;
     a.bk[i] = (bias_blocks && !transposed) ? bias_blocks[i] : nullptr;
+    a.rsk[i] = (rowscale_blocks && !transposed) ? rowscale_blocks[i] : nullptr;
   }
   a.xn = x->count; a.xw = x->width; a.xc = x->cols;
   a.yn = y->count; a.yw = y->width; a.yc = y->cols;
@@ -637,7 +650,7 @@ extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* con
   a.gate = gate; a.ldgate = ldgate; a.gate_scale = gate_scale;
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
-  const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : 4);
+  const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : ((ob == 5 || ob == 6) && g <= 2 ? 6 : 4));
   const int64_t tiles = ceil_div(N, 16);
   dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
   const bool ok = transposed ? launch_linear_parts<true>(a, g, obt, grid, as_stream(stream))
@@ -659,6 +672,10 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob == 3 && ib <= 2) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<3, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+  } else if (ob == 4 && ib <= 2) {   // up to eight blocks (the three first layers of Family A share x): one pass
+    hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+  } else if (ob <= 6 && ib <= 2) {
+    hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob == 1) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
   } else {

@@ -49,3 +49,18 @@ h = ops.padded_empty(n, 10, dev).normal_()
 gw = torch.empty(10, 10, device=dev)
 us = timed(lambda: ops.linear_wgrad(g1, h, gw, gb))
 print(f"wgrad x[10]^T [10]: {us:7.1f} us  {n * 24 * 4 / us / 1e3:6.0f} GB/s")
+
+# all first-layer projections / weight gradients of Family A from ONE pass over x
+rs = torch.rand(n, device=dev)
+ws6 = [torch.randn(10, 22, device=dev) for _ in range(6)]
+ys6 = [ops.padded_empty(n, 10, dev) for _ in range(6)]
+us = timed(lambda: ops.linear_parts([x], ws6, ys6, rowscales=[rs] + [None] * 5))
+print(f"fan-out 22 -> 6 x 10 (one row-scaled): {us:7.1f} us  {n * (24 + 72) * 4 / us / 1e3:6.0f} GB/s")
+gs7 = [ops.padded_empty(n, 10, dev).normal_() for _ in range(7)]
+gw = torch.empty(84, 22, device=dev); gb = torch.empty(84, device=dev)
+us = timed(lambda: ops.linear_wgrad_parts(gs7, x, gw, gb))
+print(f"wgrad x[22]^T [7 x 10]: {us:7.1f} us  {n * (24 + 84) * 4 / us / 1e3:6.0f} GB/s")
+want = torch.cat([g[:200000].t() @ x[:200000] for g in gs7], 0)
+ops.linear_wgrad_parts([g[:200000] for g in gs7], x[:200000], gw, gb)
+got = gw.reshape(7, 12, 22)[:, :10].reshape(70, 22)
+print("wgrad 7-block max rel err", ((got - want).abs().max() / want.abs().max()).item())

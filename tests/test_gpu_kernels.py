@@ -255,6 +255,35 @@ def test_linear_over_column_blocks(n, i, o, k):
         assert not gw3[j, o:].any() and not gb2[j, o:].any()          # padding rows: exactly zero, never NaN
 
 
+def test_linear_over_many_column_blocks_with_row_scale():
+    """Six output blocks (96 output columns from one read of x) with a per-block row scale, and the weight gradients of
+    seven blocks in one pass -- the widest shapes the column-block kernels are instantiated for."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(9)
+    n, i, o = 2500, 22, 10
+    x = torch.randn(n, i, generator=g)
+    ws = [torch.randn(o, i, generator=g) / i ** 0.5 for _ in range(6)]
+    rs = torch.rand(n, generator=g) + 0.5
+    xd = _padded(x)
+    ys = [_padded(torch.zeros(n, o)) for _ in range(6)]
+    ops.linear_parts([xd], [w.to(DEV) for w in ws], ys, rowscales=[None, rs.to(DEV)] + [None] * 4)
+    for j in range(6):
+        want = x.double() @ ws[j].double().t()
+        if j == 1:
+            want = want * rs.double()[:, None]
+        assert torch.allclose(ys[j].cpu().double(), want, rtol=1e-5, atol=1e-5), j
+    gs = [torch.randn(n, o, generator=g) for _ in range(7)]
+    gw = torch.empty(7 * 12, i, device=DEV)
+    gb = torch.empty(7 * 12, device=DEV)
+    ops.linear_wgrad_parts([_padded(t) for t in gs], xd, gw, gb)
+    gw3 = gw.cpu().double().reshape(7, 12, i)
+    for j in range(7):
+        want = gs[j].double().t() @ x.double()
+        assert (gw3[j, :o] - want).abs().max().item() / want.abs().max().item() < 2e-5
+        assert torch.allclose(gb.cpu().double().reshape(7, 12)[j, :o], gs[j].double().sum(0), rtol=1e-4, atol=1e-4)
+
+
 def test_linear_over_column_blocks_rejects_unpadded_operands():
     from blackwater.native import ops
 
