@@ -122,6 +122,13 @@ int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed
                      float drop_p, uint64_t seed, int rs_cols, int act_from, const float* gate, int64_t ldgate,
                      float gate_scale, mlqem_stream_t stream);
 
+/* y = act(x @ W^T + b) with both operands rounded to bf16 (nearest-even) in registers and fp32 accumulation on
+ * v_mfma_f32_16x16x32_bf16: the "bf16 MFMA MLP head" option of the MLP regressors (docs/tutorials/mlp.py:18-108) for
+ * BASELINE.json's mixed-corpus configuration.  x, W, y are fp32 in memory; W: [O, I] row-major; b may be NULL;
+ * act bit 0 = ReLU; I <= 256.  Forward only: gradients use the fp32 entry points. */
+int mlqem_linear_bf16_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t N,
+                          int I, int O, int act, mlqem_stream_t stream);
+
 #define MLQEM_MAX_COL_PARTS 8
 
 /* A matrix given as up to MLQEM_MAX_COL_PARTS COLUMN BLOCKS in separate buffers: block p is ptr[p][N, cols] (row stride ld[p]) and

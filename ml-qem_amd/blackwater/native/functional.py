@@ -47,9 +47,14 @@ def csr_aggregate(x, struct, *, cscale=None, rscale=None, dself=None, alpha=1.0,
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, mfma):
         x = ops.rowmajor(x)
-        y = ops.linear(x, w.contiguous(), b, relu=relu)
+        if mfma == "bf16":   # operands rounded to bf16 on the matrix cores; the backward below stays fp32
+            y = ops.linear_bf16(x, w.contiguous(), b, relu=relu)
+        elif mfma == "f32":
+            y = ops.linear(x, w.contiguous(), b, relu=relu)
+        else:
+            raise ValueError(f"mfma must be 'f32' or 'bf16', got {mfma!r}")
         ctx.relu = relu
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = b is not None
@@ -68,12 +73,12 @@ class _Linear(Function):
             gw = torch.empty_like(w, memory_format=torch.contiguous_format)
             gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device) if ctx.has_bias else None
             ops.linear_wgrad(g, x, gw, gb)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
-def linear(x, w, b=None, relu=False):
+def linear(x, w, b=None, relu=False, mfma="f32"):
     lead = x.shape[:-1]
-    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b, relu)
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b, relu, mfma)
     return y.reshape(*lead, w.shape[0])
 
 

@@ -177,6 +177,25 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
     return out
 
 
+def linear_bf16(x, w, b=None, *, relu=False, out=None):
+    """y = act(x @ w.T + b) on the bf16 matrix cores: operands rounded to bf16 in registers, fp32 accumulation, fp32 in
+    and out (mlqem_linear_bf16_f32).  Forward only."""
+    n, i = x.shape
+    ldx = _mat(x, "x")
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous() or w.shape[1] != i:
+        raise ValueError(f"linear_bf16: w must be a contiguous fp32 cuda tensor [O, {i}], got {tuple(w.shape)}")
+    o = w.shape[0]
+    _vec(b, "b", o)
+    if out is None:
+        out = padded_empty(n, o, x.device)
+    elif out.shape != (n, o):
+        raise ValueError("linear_bf16: bad out shape")
+    code = _lib.load().mlqem_linear_bf16_f32(_p(x), ldx, _p(w), _p(b), _p(out), _mat(out, "out"), n, i, o,
+                                             1 if relu else 0, _stream())
+    _lib.check(code, "mlqem_linear_bf16_f32")
+    return out
+
+
 def _col_parts(blocks, name: str, vector_rows: bool) -> "_lib.ColParts":
     """The C view of a list of [N, c] blocks (one shape, padded rows when ``vector_rows``)."""
     if not 1 <= len(blocks) <= _lib.MAX_COL_PARTS:
@@ -251,7 +270,15 @@ def linear_parts(xs, ws, ys, *, w_minus=None, biases=None, rowscales=None, trans
     return ys
 
 
-_wgrad_ws = {}
+_wgrad_ws = {}   # (device, stream, bytes) -> partial-sum workspace: per stream, so concurrent streams never share one
+
+
+def _wgrad_workspace(device, need: int):
+    key = (device, _stream(), need)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
 
 
 def linear_wgrad_parts(gys, x, gw, gb=None, accumulate=False):
@@ -264,10 +291,7 @@ def linear_wgrad_parts(gys, x, gw, gb=None, accumulate=False):
     _vec(gb, "gb", o_tot)
     lib = _lib.load()
     need = lib.mlqem_linear_wgrad_workspace_bytes(i, o_tot)
-    key = (x.device, need)
-    ws = _wgrad_ws.get(key)
-    if ws is None:
-        ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ws = _wgrad_workspace(x.device, need)
     import ctypes as _ct
 
     code = lib.mlqem_linear_wgrad_parts_f32(_ct.addressof(gp), _p(x), _mat(x, "x"), _p(gw), _p(gb), n, i,
@@ -284,10 +308,7 @@ def linear_wgrad(gy, x, gw, gb=None, accumulate=False):
     _vec(gb, "gb", o)
     lib = _lib.load()
     need = lib.mlqem_linear_wgrad_workspace_bytes(i, o)
-    key = (gy.device, need)
-    ws = _wgrad_ws.get(key)
-    if ws is None:
-        ws = _wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=gy.device)
+    ws = _wgrad_workspace(gy.device, need)
     code = lib.mlqem_linear_wgrad_f32(_p(gy), _mat(gy, "gy"), _p(x), _mat(x, "x"), _p(gw), _p(gb), n, i, o,
                                       1 if accumulate else 0, _p(ws), need, _stream())
     _lib.check(code, "mlqem_linear_wgrad_f32")

@@ -3,6 +3,10 @@
 Same constructor signatures and state-dict keys (``fc1.weight`` ... ``bn1.running_mean`` ...), so the reference's
 21 MLP checkpoints load with ``strict=True``.  The GEMMs (+bias, +ReLU where nothing sits in between) run on the
 f32-MFMA dense kernel; BatchNorm/dropout/residual act on [batch, hidden] tensors and stay elementwise torch ops.
+
+``model.mfma = "bf16"`` (default ``"f32"``) sends the forward GEMMs to the bf16 matrix cores -- operands rounded to bf16
+in registers, fp32 accumulation, fp32 tensors in memory: the "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus
+configuration.  Outputs then differ from the fp32 path at the 1e-2 level, so it is an opt-in; gradients stay fp32.
 """
 from __future__ import annotations
 
@@ -22,10 +26,11 @@ class MLP1(nn.Module):
     def __init__(self, input_size, hidden_size, output_size):
         super().__init__()
         self.fc1, self.fc2 = _fc(input_size, hidden_size), _fc(hidden_size, output_size)
+        self.mfma = "f32"
 
     def forward(self, x):
-        h = F.linear(x, self.fc1.weight, self.fc1.bias, relu=True)
-        return F.linear(h, self.fc2.weight, self.fc2.bias)
+        h = F.linear(x, self.fc1.weight, self.fc1.bias, relu=True, mfma=self.mfma)
+        return F.linear(h, self.fc2.weight, self.fc2.bias, mfma=self.mfma)
 
 
 class MLP2(nn.Module):
@@ -35,17 +40,18 @@ class MLP2(nn.Module):
         self.fc2, self.bn2 = _fc(hidden_size, hidden_size), nn.BatchNorm1d(hidden_size)
         self.fc3 = _fc(hidden_size, output_size)
         self.p = dropout_rate
+        self.mfma = "f32"
 
     def _drop(self, t):
         return nn.functional.dropout(t, self.p, True) if (self.training and self.p > 0) else t
 
     def trunk(self, x):
-        x1 = self._drop(torch.relu(self.bn1(F.linear(x, self.fc1.weight, self.fc1.bias))))
-        x2 = self._drop(torch.relu(self.bn2(F.linear(x1, self.fc2.weight, self.fc2.bias))))
+        x1 = self._drop(torch.relu(self.bn1(F.linear(x, self.fc1.weight, self.fc1.bias, mfma=self.mfma))))
+        x2 = self._drop(torch.relu(self.bn2(F.linear(x1, self.fc2.weight, self.fc2.bias, mfma=self.mfma))))
         return x1 + x2
 
     def forward(self, x):
-        return F.linear(self.trunk(x), self.fc3.weight, self.fc3.bias)
+        return F.linear(self.trunk(x), self.fc3.weight, self.fc3.bias, mfma=self.mfma)
 
 
 class MLP3(MLP2):
@@ -55,5 +61,5 @@ class MLP3(MLP2):
         self.fc4 = _fc(hidden_size // 3, output_size)
 
     def forward(self, x):
-        h = F.linear(self.trunk(x), self.fc3.weight, self.fc3.bias, relu=True)
-        return F.linear(self._drop(h), self.fc4.weight, self.fc4.bias)
+        h = F.linear(self.trunk(x), self.fc3.weight, self.fc3.bias, relu=True, mfma=self.mfma)
+        return F.linear(self._drop(h), self.fc4.weight, self.fc4.bias, mfma=self.mfma)

@@ -231,6 +231,105 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------- bf16 matrix cores
+// Y = act(X W^T + b) with the operands ROUNDED TO BF16 IN REGISTERS (round-to-nearest-even) and fp32 accumulation on
+// v_mfma_f32_16x16x32_bf16 -- the "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus configuration.  X, W, Y stay
+// fp32 in memory (these layers are bound by reading X, not by the matrix cores), so this is an arithmetic option, not a
+// bandwidth one: results differ from the fp32 path at the 1e-2 level and equal "round both operands to bf16, multiply
+// exactly, add in fp32".  Lane maps (guide section 3): A: lane l holds A[l & 15][8 (l >> 4) + j], j = 0..7; B likewise;
+// C/D as for the f32 MFMA, so the transposed formulation of linear_mfma_v4_kernel carries over: W is the A operand,
+// the X tile the B operand, a lane ends with four consecutive outputs of one row.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ short to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (short)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (short)(u >> 16);
+}
+
+template <int OBT, int G>
+__global__ __launch_bounds__(kBlock) void linear_bf16_kernel(const LinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kBlock) >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ob0 = blockIdx.y * OBT;
+
+  bf16x8 wf[OBT][G];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o = (ob0 + ob) * 16 + lr;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * g + 8 * lq + j;
+        wf[ob][g][j] = (o < a.O && k < a.I) ? to_bf16(a.w[(int64_t)o * a.I + k]) : (short)0;
+      }
+  }
+  float bias[OBT][4];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = (ob0 + ob) * 16 + lq * 4 + r;
+      bias[ob][r] = (a.b && o < a.O) ? a.b[o] : 0.f;
+    }
+  const bool vec_load = a.ldx % 4 == 0 && aligned_to_dev(a.x, 16);
+  const bool vec_store = a.ldy % 4 == 0 && aligned_to_dev(a.y, 16);
+
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    const int64_t row = t * 16 + lr;
+    const bool row_ok = row < a.N;
+    const float* __restrict__ xr = a.x + row * a.ldx;
+    bf16x8 xf[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 32 * g + 8 * lq;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (row_ok && vec_load && k0 + 8 <= a.ldx) {       // both float4s inside the row's allocation
+        const float4 p = *reinterpret_cast<const float4*>(xr + k0), q = *reinterpret_cast<const float4*>(xr + k0 + 4);
+        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+      } else if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + j < a.I) v[j] = xr[k0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[g][j] = (k0 + j < a.I) ? to_bf16(v[j]) : (short)0;
+    }
+    f32x4 acc[OBT];
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob)
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ob][g], xf[g], acc[ob], 0, 0, 0);
+    if (!row_ok) continue;
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) {
+      const int o0 = (ob0 + ob) * 16 + lq * 4;
+      if (o0 >= a.O) continue;
+      float* dst = a.y + row * a.ldy + o0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u = acc[ob][r] + bias[ob][r];
+        if (a.act & 1) u = fmaxf(u, 0.f);
+        v[r] = u;
+      }
+      if (vec_store && o0 + 4 <= a.O) vstore<4>(dst, v);
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (o0 + r < a.O) dst[r] = v[r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------- column-partitioned operands
 // Y = X W^T (+ b) where X and/or Y are CONCATENATIONS OF COLUMN BLOCKS THAT LIVE IN SEPARATE BUFFERS: block p of X is
 // xp[p][N, xc] and occupies columns [p*xw, p*xw + xc) of the concatenated matrix (xw = multiple of 4; the columns
@@ -655,6 +754,34 @@ extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* con
   dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
   const bool ok = transposed ? launch_linear_parts<true>(a, g, obt, grid, as_stream(stream))
                              : launch_linear_parts<false>(a, g, obt, grid, as_stream(stream));
+  return ok ? launch_status() : MLQEM_ERR_UNSUPPORTED;
+}
+
+template <int OBT>
+static bool launch_linear_bf16(const LinArgs& a, int g, dim3 grid, hipStream_t s) {
+  switch (g) {
+#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_bf16_kernel<OBT, K>), grid, dim3(kBlock), 0, s, a); return true;
+    MLQEM_CASE(1) MLQEM_CASE(2) MLQEM_CASE(3) MLQEM_CASE(4) MLQEM_CASE(5) MLQEM_CASE(6) MLQEM_CASE(7) MLQEM_CASE(8)
+#undef MLQEM_CASE
+  }
+  return false;
+}
+
+extern "C" int mlqem_linear_bf16_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
+                                     int64_t N, int I, int O, int act, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return MLQEM_ERR_BAD_ARG;
+  if (I > 256) return MLQEM_ERR_UNSUPPORTED;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !w || !y) return MLQEM_ERR_BAD_ARG;
+  LinArgs a{x, ldx, w, b, nullptr, y, ldy, N, I, O, act, 0, 0.f, 0, O, 0, nullptr, 0, 1.f};
+  const int g = (I + 31) / 32, ob = (O + 15) / 16;
+  const int obt = (ob == 1) ? 1 : ((ob == 2 || g > 4) ? 2 : 4);    // keep OBT * G weight fragments <= 16 (64 VGPRs)
+  const int64_t tiles = ceil_div(N, 16);
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
+  const bool ok = obt == 1 ? launch_linear_bf16<1>(a, g, grid, as_stream(stream))
+                : obt == 2 ? launch_linear_bf16<2>(a, g, grid, as_stream(stream))
+                           : launch_linear_bf16<4>(a, g, grid, as_stream(stream));
   return ok ? launch_status() : MLQEM_ERR_UNSUPPORTED;
 }
 

@@ -139,3 +139,40 @@ def test_cfg1_mlp_on_v2_features():
         for (name, p), (_, q) in zip(gpu.named_parameters(), ref.named_parameters()):
             scale = max(q.grad.abs().max().item(), 1e-9)
             assert (p.grad.cpu().double() - q.grad).abs().max().item() / scale < 2e-4, (cls, name)
+
+
+def test_cfg5_bf16_mfma_mlp_head():
+    """The "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus configuration: MLP3 on 169-d rows with
+    ``model.mfma = "bf16"``.  Stated tolerances: (1) the kernel equals "round both operands to bf16, multiply exactly,
+    accumulate in fp32" to 1e-5 of the output scale on every layer shape of MLP1/MLP3; (2) the whole MLP3 differs from
+    its fp32 path by < 3e-2 of the output scale; (3) gradients flow through the fp32 backward."""
+    import blackwater.nn as bnn
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(0)
+    for n, i, o, relu in ((1, 169, 64, True), (1000, 169, 128, False), (777, 128, 42, True), (4099, 58, 4, False),
+                          (300, 256, 20, False), (50, 42, 4, False)):
+        x = torch.randn(n, i, generator=g)
+        w = torch.randn(o, i, generator=g) / i ** 0.5
+        b = torch.randn(o, generator=g)
+        got = ops.linear_bf16(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu).cpu().double()
+        want = x.bfloat16().double() @ w.bfloat16().double().t() + b.double()
+        want = want.relu() if relu else want
+        assert (got - want).abs().max().item() < 1e-5 * max(want.abs().max().item(), 1.0), (n, i, o)
+        full = x.double() @ w.double().t() + b.double()
+        full = full.relu() if relu else full
+        assert (got - full).abs().max().item() < 3e-2 * max(full.abs().max().item(), 1.0)
+    with pytest.raises(Exception):
+        ops.linear_bf16(torch.randn(4, 300, device=DEV), torch.randn(8, 300, device=DEV))      # I > 256: unsupported
+
+    torch.manual_seed(3)
+    model = bnn.MLP3(169, 128, 4).to(DEV).eval()
+    x = torch.randn(512, 169, device=DEV)
+    ref = model(x)
+    model.mfma = "bf16"
+    out = model(x)
+    scale = ref.abs().max().item()
+    err = (out - ref).abs().max().item()
+    assert 0 < err < 3e-2 * scale                      # a different arithmetic, within the stated tolerance
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
