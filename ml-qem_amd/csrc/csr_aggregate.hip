@@ -235,6 +235,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs
   const int tid = threadIdx.x;
   const bool use_self = IS_MAX || a.dself != nullptr;
   if (tid == 0) s_nheavy = 0;
+  __syncthreads();   // before any wave can list a heavy row (the waves have only just started: this costs nothing measurable)
 
   int row[kItemsPerThread], ch[kItemsPerThread];
   int2 e2[kItemsPerThread];
@@ -311,13 +312,17 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs
   }
   // heavy rows (barrier nodes): the whole workgroup splits the row's edges and reduces through LDS
   __syncthreads();
-  const int n_heavy = min(s_nheavy, kHeavyCap);
-  if (n_heavy == 0) return;
+  const int listed = s_nheavy;
+  if (listed == 0) return;
   const int slots = kBlock / a.CV;
   const int slot = tid / a.CV, hch = (tid - slot * a.CV) * VEC;
-  for (int h = 0; h < n_heavy; ++h) {
-    const int r = s_heavy[h];
+  // more heavy rows than the list holds (a tile full of hub rows): find them again by scanning the workgroup's rows
+  const bool overflow = listed > kHeavyCap;
+  const int total = overflow ? nrows : listed;
+  for (int h = 0; h < total; ++h) {
+    const int r = overflow ? (int)r0 + h : s_heavy[h];
     const int beg = a.ptr[r], end = a.ptr[r + 1];
+    if (overflow && end - beg <= kHeavyDegree) continue;   // uniform across the workgroup
     __syncthreads();
     float part[VEC];
 #pragma unroll

@@ -327,3 +327,34 @@ def test_mask_handover_between_layers_equals_separate_masking():
             grads.append([p.grad.clone() for m in (a, b) for p in m.parameters()])
         for u, v in zip(*grads):
             assert torch.allclose(u, v, rtol=1e-5, atol=1e-6 * (1 + v.abs().max().item()))
+
+
+@pytest.mark.parametrize("c", [1, 10, 22])
+def test_tiles_full_of_hub_rows(c):
+    """More rows above the cooperative-reduction threshold (32 in-edges) in one workgroup tile than its lists hold: a
+    complete directed graph on 300 nodes (every row has 299 sources) next to ordinary rows.  Sum and max, with and
+    without the ELL side table, against index_add / scatter-max references; two runs must agree bit for bit."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(c)
+    hub, n = 300, 1500
+    src = torch.arange(hub).repeat_interleave(hub)
+    dst = torch.arange(hub).repeat(hub)
+    keep = src != dst
+    chain = torch.stack([torch.arange(hub, n - 1), torch.arange(hub + 1, n)])
+    ei = torch.cat([torch.stack([src[keep], dst[keep]]), chain], dim=1)
+    ei = ei[:, torch.randperm(ei.shape[1], generator=g)].to(DEV)
+    csr = ops.csr_build(ei, n)
+    in_ptr, in_src = csr[0], csr[1]
+    ell = ops.ell_from_csr(in_ptr, in_src, n)
+    x = ops.padded_empty(n, c, DEV).normal_(generator=torch.Generator(device=DEV).manual_seed(1))
+    want_sum = torch.zeros(n, c, device=DEV, dtype=torch.float64).index_add_(0, ei[1], x.double()[ei[0]])
+    want_max = x.clone()
+    want_max = want_max.scatter_reduce(0, ei[1][:, None].expand(-1, c), x[ei[0]], reduce="amax", include_self=True)
+    for side in (ell, None):
+        got = ops.csr_aggregate(x, in_ptr, in_src, ell=side)
+        again = ops.csr_aggregate(x, in_ptr, in_src, ell=side)
+        assert torch.equal(got, again)
+        assert torch.allclose(got.double(), want_sum, rtol=1e-5, atol=1e-4)
+        mx = ops.csr_segment_max(x, in_ptr, in_src, ell=side)
+        assert torch.equal(mx, want_max)
