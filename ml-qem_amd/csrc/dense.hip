@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
           for (int r = 0; r < 4; ++r) if (o0 + r < a.O) v[r] = gp[r] > 0.f ? v[r] * a.gate_scale : 0.f;
         }
       }
-      if (full) vstore_nt<4>(dst, v);
+      if (full) { if (a.act & 256) vstore<4>(dst, v); else vstore_nt<4>(dst, v); }
       else
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (o0 + r < a.O) dst[r] = v[r];
@@ -350,6 +350,7 @@ struct PartsArgs {
   const float* rsk[kMaxParts];   // optional per-output-block row scale (fan-out): Y_k[n,:] *= rsk[k][n]  (GCN's D^-1/2)
   int64_t N; int I, O;   // I = xn * xw, O = yn * yw: the concatenated (padded) column spaces
   const float* gate; int64_t ldgate; float gate_scale;   // single-block Y only: y = gate[n,o] > 0 ? y * gate_scale : 0
+  int plain_stores;   // a block's rows are wider than one store instruction (16 columns): see mlqem_linear_f32
 };
 
 template <int OBT, int G, bool TRANSPOSED>
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
         v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
         v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
       }
-      vstore_nt<4>(ycol[ob] + row * yld[ob], v);
+      if (a.plain_stores) vstore<4>(ycol[ob] + row * yld[ob], v); else vstore_nt<4>(ycol[ob] + row * yld[ob], v);
     }
   }
 }
@@ -664,8 +665,12 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
   if (act_from < 0) act_from = 0;
   if (N == 0) return MLQEM_OK;
   if (!x || !w || !y) return MLQEM_ERR_BAD_ARG;
-  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act, accumulate, drop_p, seed, rs_cols, act_from, gate, ldgate,
-            gate_scale};
+  // Streaming (non-temporal) stores only when one store instruction writes a row's whole output (O <= 16): with wider
+  // rows each instruction writes a 64-byte piece of the row and the pieces must meet in L2 to leave as full lines
+  // (measured: O = 22: 279 -> 175 us, O = 180: 266 -> 174 us with plain stores; O <= 16 unchanged).  act bit 8 = plain.
+  const bool plain = O > 16;
+  LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act | (plain ? 256 : 0), accumulate, drop_p, seed, rs_cols, act_from,
+            gate, ldgate, gate_scale};
   hipStream_t s = as_stream(stream);
   const int ks = round_ks((I + 3) / 4);
   if (ks > 0) {
@@ -747,6 +752,7 @@ extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* con
   a.yn = y->count; a.yw = y->width; a.yc = y->cols;
   a.N = N; a.I = x->count * x->width; a.O = y->count * y->width;
   a.gate = gate; a.ldgate = ldgate; a.gate_scale = gate_scale;
+  a.plain_stores = y->cols > 16;
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
   const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : ((ob == 5 || ob == 6) && g <= 2 ? 6 : 4));
