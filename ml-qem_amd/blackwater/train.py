@@ -41,7 +41,9 @@ def flatten_parameters(model: nn.Module):
 
 
 class DataParallelShard:
-    """Contiguous, node-count-balanced shard of the graph ids for one rank (graphs on this path vary 13x in size)."""
+    """Node-count-balanced shards of the graph ids, one per rank and all of one length, so that every rank runs the same
+    number of steps per epoch (graphs on this path vary 13x in size; a rank with more nodes per step would stall the
+    gradient all-reduce of all the others)."""
 
     @staticmethod
     def split(node_counts: np.ndarray, world_size: int) -> List[np.ndarray]:
