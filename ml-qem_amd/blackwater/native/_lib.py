@@ -80,6 +80,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:
@@ -104,6 +105,9 @@ def load() -> ctypes.CDLL:
         except AttributeError as exc:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from exc
         fn.restype, fn.argtypes = restype, argtypes
+    found = lib.mlqem_abi_version()
+    if found != ABI_VERSION:   # a stale build would be called with the wrong argument lists
+        raise NativeLibraryError(f"{LIB_PATH} has ABI version {found}, this binding expects {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

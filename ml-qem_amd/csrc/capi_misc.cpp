@@ -1,7 +1,7 @@
 // Version / error-string entry points of the C ABI.
 #include "../../include/mlqem_hip.h"
 
-extern "C" int mlqem_abi_version(void) { return 1; }
+extern "C" int mlqem_abi_version(void) { return MLQEM_ABI_VERSION; }
 
 extern "C" const char* mlqem_error_string(int code) {
   switch (code) {

@@ -22,7 +22,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} is declared in include/mlqem_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
-    assert lib.mlqem_abi_version() == 1
+    assert lib.mlqem_abi_version() == _lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "mlqem_hip.h")).read()
+    assert f"#define MLQEM_ABI_VERSION {_lib.ABI_VERSION} " in header
     assert lib.mlqem_error_string(-4).decode().startswith("workspace")
 
 
