@@ -21,7 +21,7 @@ from torch import nn
 def flatten_parameters(model: nn.Module):
     """Re-homes every parameter as a view into one contiguous fp32 buffer and gives each a ``.grad`` view into a
     second one.  The optimizer then steps a single tensor and data-parallel training reduces a single buffer
-    (13,645 ... 103,465 floats for the reference's models)."""
+    (13,645 ... 103,465 floats for the reference's models).  Returns (flat parameter, flat gradient buffer)."""
     params = [p for p in model.parameters()]
     total = sum(p.numel() for p in params)
     dev = params[0].device
@@ -66,6 +66,12 @@ class Trainer:
         if flat:
             self.flat_param, self.flat_grad = flatten_parameters(model)
             opt_params = [self.flat_param]
+            # gradient slots of the flat buffer, one view per parameter, in parameter order (see step())
+            self._params = [p for p in model.parameters()]
+            self._grad_slots, off = [], 0
+            for p in self._params:
+                self._grad_slots.append(self.flat_grad[off:off + p.numel()].view(p.shape))
+                off += p.numel()
         else:
             self.flat_param = self.flat_grad = None
             opt_params = list(model.parameters())
@@ -80,13 +86,28 @@ class Trainer:
         """forward -> MSE -> backward -> (all-reduce) -> Adam.  Returns the loss as a device tensor (no sync)."""
         self.model.train()
         if self.flat_grad is not None:
-            self.flat_grad.zero_()
+            # With .grad pointing into the flat buffer autograd would ADD every parameter's gradient into its slot: one
+            # tiny kernel per parameter (~30 per step here).  Cleared .grad fields make it hand the gradient tensors
+            # over as they are; one multi-tensor copy then files them into the flat buffer.
+            for p in self._params:
+                p.grad = None
         else:
             self.optimizer.zero_grad(set_to_none=False)
         out = self.model(*batch.model_args())
         target = batch.y if batch.y.dim() == 2 else torch.squeeze(batch.y, 1)
         loss = self.criterion(out, target)
         loss.backward()
+        if self.flat_grad is not None:
+            grads = [p.grad for p in self._params]
+            if any(g is None for g in grads):   # a parameter the loss does not reach: its slot must read zero
+                self.flat_grad.zero_()
+                pairs = [(d, g) for d, g in zip(self._grad_slots, grads) if g is not None]
+                if pairs:
+                    torch._foreach_copy_([d for d, _ in pairs], [g for _, g in pairs])
+            else:
+                torch._foreach_copy_(self._grad_slots, grads)
+            for p, slot in zip(self._params, self._grad_slots):
+                p.grad = slot                   # what callers (and the reference's loop shape) expect to find
         if self.distributed:
             self.all_reduce_gradients()
         self.optimizer.step()
