@@ -221,10 +221,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
 constexpr int kEllMore = (int)0x80000000;
 
 template <int VEC, bool IS_MAX, int kItemsPerThread>
-__global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs a) {
-  __shared__ int s_heavy[kHeavyCap];
-  __shared__ int s_nheavy;
-  __shared__ float s_red[kBlock * VEC];
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {
   // A block owns a.R = (kBlock * IPT) / CV whole rows; the local item index li < kBlock * IPT <= 2048 is split into
   // (row, slice) with a multiply-shift (exact for li * CV < 2^20) instead of a division.
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -234,8 +231,6 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs
   const unsigned magic = ((1u << 20) + a.CV - 1) / a.CV;
   const int tid = threadIdx.x;
   const bool use_self = IS_MAX || a.dself != nullptr;
-  if (tid == 0) s_nheavy = 0;
-  __syncthreads();   // before any wave can list a heavy row (the waves have only just started: this costs nothing measurable)
 
   int row[kItemsPerThread], ch[kItemsPerThread];
   int2 e2[kItemsPerThread];
@@ -286,16 +281,16 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs
       }
     }
   }
+  bool heavy[kItemsPerThread];
+#pragma unroll
+  for (int k = 0; k < kItemsPerThread; ++k) heavy[k] = false;
 #pragma unroll
   for (int k = 0; k < kItemsPerThread; ++k) {
     if (!live[k]) continue;
     if (more[k]) {  // rare: rows with more than two in-edges walk the CSR arrays from the third edge on
       const int beg = a.ptr[row[k]], end = a.ptr[row[k] + 1];
-      if (end - beg > kHeavyDegree) {
-        if (ch[k] == 0) {
-          const int slot = atomicAdd(&s_nheavy, 1);
-          if (slot < kHeavyCap) s_heavy[slot] = row[k];
-        }
+      if (end - beg > kHeavyDegree) {   // a hub row (barrier node): left to the wave-cooperative pass below
+        heavy[k] = ch[k] == 0;          // its slice-0 item speaks for the whole row; the other slices just skip it
         continue;
       }
       const float* __restrict__ xc = a.x + ch[k];
@@ -310,51 +305,74 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_ell_kernel(const AggArgs
     }
     finish_row<VEC, IS_MAX>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k]);
   }
-  // heavy rows (barrier nodes): the whole workgroup splits the row's edges and reduces through LDS
-  __syncthreads();
-  const int listed = s_nheavy;
-  if (listed == 0) return;
-  const int slots = kBlock / a.CV;
-  const int slot = tid / a.CV, hch = (tid - slot * a.CV) * VEC;
-  // more heavy rows than the list holds (a tile full of hub rows): find them again by scanning the workgroup's rows
-  const bool overflow = listed > kHeavyCap;
-  const int total = overflow ? nrows : listed;
-  for (int h = 0; h < total; ++h) {
-    const int r = overflow ? (int)r0 + h : s_heavy[h];
-    const int beg = a.ptr[r], end = a.ptr[r + 1];
-    if (overflow && end - beg <= kHeavyDegree) continue;   // uniform across the workgroup
-    __syncthreads();
-    float part[VEC];
+  // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
+  // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
+  // tree in a fixed order.  No LDS, no workgroup barrier: the other waves of the workgroup are not held up, and nothing
+  // is shared that would need initialising (47 % of the benchmark's workgroups contain such a row).
+  const int lane = tid & (kWave - 1);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? -INFINITY : 0.f;
-    if (slot < slots) {
-      for (int e = beg + slot; e < end; e += slots) {
-        const int j = a.idx[e];
-        const float w = (IS_MAX || !a.cscale) ? 1.f : a.cscale[j];
-        float q[VEC];
-        vload<VEC>(a.x + hch + (int64_t)j * a.ldx, q);
+  for (int k = 0; k < kItemsPerThread; ++k) {
+    unsigned long long todo = __ballot(heavy[k]);
+    while (todo) {
+      const int owner = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int r = __shfl(row[k], owner);
+      const float rs_r = __shfl(rs[k], owner), ds_r = __shfl(ds[k], owner);
+      const int beg = a.ptr[r], end = a.ptr[r + 1];
+      if (a.CV <= kWave) {
+        const int nslots = kWave / a.CV;
+        const int slot = lane / a.CV, hch = (lane - slot * a.CV) * VEC;
+        const bool worker = slot < nslots;
+        float part[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? fmaxf(part[v], q[v]) : fmaf(w, q[v], part[v]);
-      }
+        for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? -INFINITY : 0.f;
+        if (worker)
+          for (int e = beg + slot; e < end; e += nslots) {
+            const int j = a.idx[e];
+            const float w = (IS_MAX || !a.cscale) ? 1.f : a.cscale[j];
+            float q[VEC];
+            vload<VEC>(a.x + hch + (int64_t)j * a.ldx, q);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) s_red[tid * VEC + v] = part[v];
-    }
-    __syncthreads();
-    if (slot == 0) {
-      float tot[VEC], sf[VEC];
-      if (use_self) vload<VEC>(a.x + hch + (int64_t)r * a.ldx, sf);
+            for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? fmaxf(part[v], q[v]) : fmaf(w, q[v], part[v]);
+          }
+        for (int off = 32; off >= 1; off >>= 1) {      // slot s takes slot s + off: same tree for every row
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        if (!use_self) sf[v] = 0.f;
-        tot[v] = IS_MAX ? sf[v] : 0.f;
-      }
-      for (int sl = 0; sl < slots; ++sl)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const float q = s_red[(sl * a.CV + tid) * VEC + v];
-          tot[v] = IS_MAX ? fmaxf(tot[v], q) : tot[v] + q;
+          for (int v = 0; v < VEC; ++v) {
+            const float other = __shfl_down(part[v], off * a.CV);
+            if (worker && slot + off < nslots) part[v] = IS_MAX ? fmaxf(part[v], other) : part[v] + other;
+          }
         }
-      finish_row<VEC, IS_MAX>(a, r, hch, tot, sf, a.rscale ? a.rscale[r] : 1.f, a.dself ? a.dself[r] : 0.f);
+        if (worker && slot == 0) {
+          float sf[VEC];
+          if (use_self) vload<VEC>(a.x + hch + (int64_t)r * a.ldx, sf);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            if (!use_self) sf[v] = 0.f;
+            if (IS_MAX) part[v] = fmaxf(part[v], sf[v]);
+          }
+          finish_row<VEC, IS_MAX>(a, r, hch, part, sf, rs_r, ds_r);
+        }
+      } else {   // more slices than lanes: every lane walks all edges for its slices
+        for (int sl = lane; sl < a.CV; sl += kWave) {
+          const int hch = sl * VEC;
+          float tot[VEC], sf[VEC];
+          if (use_self) vload<VEC>(a.x + hch + (int64_t)r * a.ldx, sf);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            if (!use_self) sf[v] = 0.f;
+            tot[v] = IS_MAX ? sf[v] : 0.f;
+          }
+          for (int e = beg; e < end; ++e) {
+            const int j = a.idx[e];
+            const float w = (IS_MAX || !a.cscale) ? 1.f : a.cscale[j];
+            float q[VEC];
+            vload<VEC>(a.x + hch + (int64_t)j * a.ldx, q);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) tot[v] = IS_MAX ? fmaxf(tot[v], q[v]) : fmaf(w, q[v], tot[v]);
+          }
+          finish_row<VEC, IS_MAX>(a, r, hch, tot, sf, rs_r, ds_r);
+        }
+      }
     }
   }
 }

@@ -50,3 +50,14 @@ run("edges = (row,row)", selfs)
 run("edges = (row-1,row-2)", prev)
 run("first real edge only", one)
 run("random edges", rand)
+# how does the cost of the second source depend on how far back it lies?
+has2 = real[:, 1] >= 0
+for dist in (2, 8, 32, 64, 128, 256, 512, 2048):
+    e = real.clone()
+    e[has2, 1] = (rows[has2] - dist).clamp(min=0)
+    run(f"second source = row-{dist}", e.contiguous())
+d_real = (rows[has2] - real[has2, 1]).float()
+print("real second-source distance: median %.0f  mean %.0f  p90 %.0f  max %.0f  (rows with one: %d)" % (
+    d_real.median().item(), d_real.mean().item(), d_real.quantile(0.9).item(), d_real.max().item(), int(has2.sum())))
+d0 = (rows - (real[:, 0] & 0x7FFFFFFF)).float()[real[:, 0] != -1]
+print("real first-source distance:  median %.0f  mean %.0f  p90 %.0f  max %.0f" % (d0.median().item(), d0.mean().item(), d0.quantile(0.9).item(), d0.max().item()))
