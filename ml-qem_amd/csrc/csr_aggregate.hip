@@ -326,15 +326,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         float part[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? -INFINITY : 0.f;
-        if (worker)
-          for (int e = beg + slot; e < end; e += nslots) {
-            const int j = a.idx[e];
-            const float w = (IS_MAX || !a.cscale) ? 1.f : a.cscale[j];
-            float q[VEC];
-            vload<VEC>(a.x + hch + (int64_t)j * a.ldx, q);
+        // 64 edges at a time: one coalesced read of their source ids, handed to the (slot, slice) lanes by shuffle (the
+        // loops are wave-uniform: every lane takes part in every shuffle), so a round costs one memory round trip
+        for (int base = beg; base < end; base += kWave) {
+          const int my_src = base + lane < end ? a.idx[base + lane] : 0;
+          const int in_chunk = min(kWave, end - base);
+          const int rounds = (in_chunk + nslots - 1) / nslots;
+          for (int rd = 0; rd < rounds; ++rd) {
+            const int el = slot + rd * nslots;
+            const int j = __shfl(my_src, el < kWave ? el : 0);
+            if (worker && el < in_chunk) {
+              const float w = (IS_MAX || !a.cscale) ? 1.f : a.cscale[j];
+              float q[VEC];
+              vload<VEC>(a.x + hch + (int64_t)j * a.ldx, q);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? fmaxf(part[v], q[v]) : fmaf(w, q[v], part[v]);
+              for (int v = 0; v < VEC; ++v) part[v] = IS_MAX ? fmaxf(part[v], q[v]) : fmaf(w, q[v], part[v]);
+            }
           }
+        }
         for (int off = 32; off >= 1; off >>= 1) {      // slot s takes slot s + off: same tree for every row
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {

@@ -61,3 +61,13 @@ print("real second-source distance: median %.0f  mean %.0f  p90 %.0f  max %.0f  
     d_real.median().item(), d_real.mean().item(), d_real.quantile(0.9).item(), d_real.max().item(), int(has2.sum())))
 d0 = (rows - (real[:, 0] & 0x7FFFFFFF)).float()[real[:, 0] != -1]
 print("real first-source distance:  median %.0f  mean %.0f  p90 %.0f  max %.0f" % (d0.median().item(), d0.mean().item(), d0.quantile(0.9).item(), d0.max().item()))
+# the remaining gap: hub rows ("more" flag) vs the rows with a second source
+more_bit = real[:, 0] & ~0x7FFFFFFF
+hub_only = torch.stack([real[:, 0], torch.full((n,), -1, dtype=torch.int32, device="cuda:0")], 1)
+hub_only[(real[:, 0] == -1), 0] = -1
+run("first source + hub rows (no 2nd src)", hub_only.contiguous())
+no_hub = real.clone(); no_hub[:, 0] = torch.where(real[:, 0] == -1, real[:, 0], real[:, 0] & 0x7FFFFFFF)
+run("two sources, hub rows cut to 2 edges", no_hub.contiguous())
+deg = (s.in_ptr[1:n + 1] - s.in_ptr[:n])
+print("rows with > 2 in-edges: %d (of which > 32: %d), their edges: %d of %d" % (
+    int((deg > 2).sum()), int((deg > 32).sum()), int(deg[deg > 2].sum()), int(deg.sum())))
