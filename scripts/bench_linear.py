@@ -64,3 +64,14 @@ want = torch.cat([g[:200000].t() @ x[:200000] for g in gs7], 0)
 ops.linear_wgrad_parts([g[:200000] for g in gs7], x[:200000], gw, gb)
 got = gw.reshape(7, 12, 22)[:, :10].reshape(70, 22)
 print("wgrad 7-block max rel err", ((got - want).abs().max() / want.abs().max()).item())
+
+# the column-block kernel with ONE block on each side vs the general dense kernel on the same shapes
+for (i, o) in [(22, 10), (10, 10), (10, 1)]:
+    xx = ops.padded_empty(n, i, dev).normal_()
+    w = torch.randn(o, i, device=dev)
+    y1, y2 = ops.padded_empty(n, o, dev), ops.padded_empty(n, o, dev)
+    t_parts = timed(lambda: ops.linear_parts([xx], [w], [y1]))
+    t_lin = timed(lambda: ops.linear(xx, w, out=y2))
+    nb = n * (xx.stride(0) + y1.stride(0)) * 4
+    print(f"{i}->{o}: parts kernel {t_parts:6.1f} us ({nb / t_parts / 1e3:5.0f} GB/s)   dense kernel {t_lin:6.1f} us ({nb / t_lin / 1e3:5.0f} GB/s)  "
+          f"max diff {(y1 - y2).abs().max().item():.1e}")
