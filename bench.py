@@ -229,7 +229,7 @@ def main():
     # Batches differ in node count (circuits vary 13x), so torch's caching allocator keeps growing -- each growth is a
     # hipMalloc that drains the queue -- until it has seen the largest batch.  Show it that batch once, untimed.
     sizes = np.asarray([x.shape[0] for x in corpus["x"]])
-    trainer.step(arena.batch(np.argsort(sizes)[::-1][np.arange(args.batch) % min(args.batch // 4, n_graphs)]))
+    trainer.step(arena.batch(np.argsort(sizes)[::-1][np.arange(args.batch) % max(1, min(args.batch // 4, n_graphs))]))
     for _ in range(args.warmup):
         trainer.step(arena.batch(draw()))
     if distributed:
