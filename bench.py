@@ -94,6 +94,23 @@ def roofline_leg(batch, reps=20):
             "edges_with_loops": e_loops, "measured_copy_GBps": round(copy_gbps, 1)}
 
 
+def mae_leg(model, batch):
+    """Mean absolute error of the model after the benchmark's few dozen steps from random initialisation, and of the
+    unmitigated noisy values, against the SYNTHETIC ideal values on the fixed 256-circuit batch.  It only shows that the
+    loss plumbing is live (600 steps bring the MSE from ~8 to 0.09, scripts/soak.py); the expectation-value accuracy claim
+    of this build -- the "exp-val MAE" half of BASELINE.json's metric -- is the `parity` object: device predictions vs the
+    CPU reference arithmetic on identical inputs and weights."""
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        pred = model(*batch.model_args())
+    model.train(was_training)
+    y = batch.y.reshape(pred.shape)
+    noisy = batch.noisy_0.reshape(pred.shape)
+    return {"mitigated": round(float((pred - y).abs().mean()), 6), "noisy": round(float((noisy - y).abs().mean()), 6),
+            "circuits": int(y.shape[0]), "labels": "synthetic"}
+
+
 def parity_leg(model, arena, corpus, n_qubits, n_check=10):
     """Predictions of the trained device model vs the CPU oracle carrying the same weights, on one circuit per
     Trotter step count (eval mode, fp32 oracle = the reference's CPU arithmetic, fp64 oracle = the exact value)."""
@@ -261,6 +278,7 @@ def main():
                        "circuits_per_step_per_gpu": args.batch, "corpus_circuits": n_graphs,
                        "mean_nodes_per_circuit": round(arena.num_nodes / n_graphs, 1), "parallelism": f"dp{world}"},
             "final_loss": round(float(loss.item()), 6),
+            "train_mae_synthetic": dict(mae_leg(model, fixed), after_steps=args.warmup + args.steps + 1),
             "roofline": roofline_leg(fixed),
         }
         if world == 1 and not args.no_cpu_baseline:
