@@ -137,10 +137,8 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
       const int o = (ob0 + ob) * 16 + lq * 4 + r;
       bias[ob][r] = (a.b && o < a.O) ? a.b[o] : 0.f;
     }
-  const bool vec_store = a.ldy % 4 == 0 && aligned_to_dev(a.y, 16);
-  // gate rows read as float4 when they are padded like the output (whole float4s inside the row's allocation)
-  const bool gate_vec = a.gate && a.ldgate % 4 == 0 && aligned_to_dev(a.gate, 16);
-  const int gate_cols = gate_vec ? (int)min((int64_t)((a.O + 3) / 4 * 4), a.ldgate) : 0;
+  const bool gate_vec = a.gate != nullptr;   // padded like the output (host checked)
+  const int gate_cols = (a.O + 3) / 4 * 4;
 
   const int64_t n_tiles = ceil_div(a.N, 16);
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
@@ -152,13 +150,9 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
     for (int g = 0; g < G; ++g) {
       const int k0 = 16 * g + 4 * lq;
       av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      // the whole float4 lies inside the row's allocation when k0 + 4 <= ldx; columns >= I are zeroed below
-      if (row_ok && k0 < a.I && k0 + 4 <= a.ldx) av[g] = *reinterpret_cast<const float4*>(xr + 16 * g);
-      else if (row_ok && k0 < a.I) {
-        av[g].x = xr[16 * g];
-        if (k0 + 1 < a.I) av[g].y = xr[16 * g + 1];
-        if (k0 + 2 < a.I) av[g].z = xr[16 * g + 2];
-      }
+      // one access path only (the host launches this kernel for padded rows: ldx >= round_up(I, 4), so the whole
+      // float4 lies inside the row's allocation); columns >= I are zeroed below
+      if (row_ok && k0 < a.I) av[g] = *reinterpret_cast<const float4*>(xr + 16 * g);
       if (k0 + 1 >= a.I) av[g].y = 0.f;
       if (k0 + 2 >= a.I) av[g].z = 0.f;
       if (k0 + 3 >= a.I) av[g].w = 0.f;
@@ -190,14 +184,11 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
     for (int ob = 0; ob < OBT; ++ob) {
       const int o0 = (ob0 + ob) * 16 + lq * 4;
       if (o0 >= a.O) continue;
-      float* dst = a.y + row * a.ldy + o0;
-      const bool full = vec_store && o0 + 4 <= a.O;
+      float* dst = a.y + row * a.ldy + o0;   // padded output rows (host checked): always one float4, pads are scratch
       float prev[4] = {0.f, 0.f, 0.f, 0.f};
       if (a.accumulate) {
-        if (full) { const float4 p = *reinterpret_cast<const float4*>(dst); prev[0] = p.x; prev[1] = p.y; prev[2] = p.z; prev[3] = p.w; }
-        else
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (o0 + r < a.O) prev[r] = dst[r];
+        const float4 p = *reinterpret_cast<const float4*>(dst);
+        prev[0] = p.x; prev[1] = p.y; prev[2] = p.z; prev[3] = p.w;
       }
       float v[4];
 #pragma unroll
@@ -212,21 +203,12 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
         }
         v[r] = u;
       }
-      if (a.gate) {
-        if (gate_vec && o0 + 4 <= gate_cols) {
-          const float4 m = gv[ob];
-          v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
-          v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
-        } else {
-          const float* gp = a.gate + row * a.ldgate + o0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (o0 + r < a.O) v[r] = gp[r] > 0.f ? v[r] * a.gate_scale : 0.f;
-        }
+      if (a.gate) {   // padded like the output (host checked)
+        const float4 m = gv[ob];
+        v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
+        v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
       }
-      if (full) { if (a.act & 256) vstore<4>(dst, v); else vstore_nt<4>(dst, v); }
-      else
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (o0 + r < a.O) dst[r] = v[r];
+      if (a.act & 256) vstore<4>(dst, v); else vstore_nt<4>(dst, v);
     }
   }
 }
@@ -716,7 +698,9 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8);  // 4 waves per block
     dim3 grid(gx, (unsigned)ceil_div(ob, obt));
     static const int v4_env = getenv("MLQEM_LINEAR_V4") ? atoi(getenv("MLQEM_LINEAR_V4")) : 1;
-    if (v4_env && ldx % 4 == 0 && aligned_to(x, 16)) {  // padded activation rows: 16-byte A-operand loads
+    const bool padded = ldx % 4 == 0 && ldx >= c4i && aligned_to(x, 16) && ldy % 4 == 0 && ldy >= c4o && aligned_to(y, 16) &&
+                        (!gate || (ldgate % 4 == 0 && ldgate >= c4o && aligned_to(gate, 16)));
+    if (v4_env && padded) {  // padded activation rows on every operand: one 16-byte access path, no scalar tails
       const int g = (I + 15) / 16;
       if (obt == 1) transposed ? launch_linear_v4<1, true>(a, g, grid, s) : launch_linear_v4<1, false>(a, g, grid, s);
       else if (obt == 2) transposed ? launch_linear_v4<2, true>(a, g, grid, s) : launch_linear_v4<2, false>(a, g, grid, s);
