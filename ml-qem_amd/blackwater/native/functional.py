@@ -1,4 +1,8 @@
-"""torch.autograd wrappers: each forward/backward is one or two native kernel launches."""
+"""torch.autograd nodes over the native kernels.
+
+One node per conv layer (``_GCNLayer``, ``_ChebLayer``, ``_SAGELayer``, ``_TransformerConv``, ``_ASAPool``): its forward
+and backward are short, fixed sequences of launches with the element-wise work folded into kernel epilogues; plus the
+generic differentiable building blocks ``csr_aggregate``, ``linear`` and ``segment_mean``."""
 from __future__ import annotations
 
 import torch

@@ -358,3 +358,34 @@ def test_tiles_full_of_hub_rows(c):
         assert torch.allclose(got.double(), want_sum, rtol=1e-5, atol=1e-4)
         mx = ops.csr_segment_max(x, in_ptr, in_src, ell=side)
         assert torch.equal(mx, want_max)
+
+
+def test_differentiable_aggregation_building_block():
+    """functional.csr_aggregate (the generic autograd node: y = act(alpha (R A C x + D x) + beta z + bias)) against the
+    same expression written with dense torch ops, forward and the gradients of x, z and bias."""
+    from blackwater.native import functional as F
+    from blackwater.native.structure import GraphStructure
+
+    g = torch.Generator().manual_seed(11)
+    n, e, c = 700, 1600, 7
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei = ei[:, ei[0] != ei[1]]
+    s = GraphStructure.from_edge_index(ei.to(DEV), n)
+    adj = torch.zeros(n, n, dtype=torch.float64).index_put_((ei[1], ei[0]), torch.ones(ei.shape[1], dtype=torch.float64),
+                                                            accumulate=True)
+    x, z = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+    bias = torch.randn(c, generator=g)
+    cs, rs, ds = (torch.rand(n, generator=g) + 0.5 for _ in range(3))
+    ref = [t.clone().double().requires_grad_(True) for t in (x, z, bias)]
+    want = (1.5 * (rs.double()[:, None] * (adj @ (cs.double()[:, None] * ref[0])) + ds.double()[:, None] * ref[0])
+            - 0.5 * ref[1] + ref[2]).relu()
+    dev = [t.clone().to(DEV).requires_grad_(True) for t in (x, z, bias)]
+    got = F.csr_aggregate(dev[0], s, cscale=cs.to(DEV), rscale=rs.to(DEV), dself=ds.to(DEV), alpha=1.5, z=dev[1], beta=-0.5,
+                          bias=dev[2], relu=True)
+    assert torch.allclose(got.detach().cpu().double(), want.detach(), rtol=1e-5, atol=1e-5)
+    go = torch.randn(n, c, generator=g)
+    want.backward(go.double())
+    got.backward(go.to(DEV))
+    for a_, b_ in zip(dev, ref):
+        scale = b_.grad.abs().max().item() + 1e-12
+        assert (a_.grad.cpu().double() - b_.grad).abs().max().item() / scale < 2e-5
