@@ -145,3 +145,24 @@ def test_arena_from_shards_equals_arena_from_arrays(g1, tmp_path):
         assert torch.equal(pb.x, wb.x) and torch.equal(pb.y, wb.y)
         assert torch.equal(pb.structure.in_ptr, wb.structure.in_ptr) and torch.equal(pb.structure.in_src, wb.structure.in_src)
         assert torch.equal(pb.structure.out_dst, wb.structure.out_dst)
+
+
+def test_end_to_end_example_runs(tmp_path):
+    """examples/train_family_a.py: shards -> arena -> Trainer.fit -> mitigation_report, as a user would run it."""
+    import importlib.util
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("example_train_family_a", os.path.join(root, "examples", "train_family_a.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ["train_family_a.py", "--qubits", "6", "--steps", "3", "--n-j", "12", "--epochs", "3", "--batch", "8",
+                "--shard-dir", str(tmp_path)]
+    try:
+        hist, rep = mod.main()
+    finally:
+        sys.argv = argv
+    assert len(hist["train_losses"]) == 2 and np.isfinite(hist["val_losses"]).all()
+    assert set(("RMSE_noisy", "RMSE_mitigated", "MAE_noisy", "MAE_mitigated")) <= set(rep)
