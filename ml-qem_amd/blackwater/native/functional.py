@@ -485,3 +485,74 @@ def asap_pool(x, mod, struct):
     x_out = _ASAPool.apply(x, mod.lin.weight, mod.lin.bias, mod.att.weight, mod.att.bias, g.lin1.weight, g.lin1.bias,
                            g.lin2.weight, g.lin3.weight, g.lin3.bias, struct, mod.ratio, mod.negative_slope, holder)
     return x_out, holder["structure"], holder["perm"]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Family A's graph part as ONE autograd node.  torch.autograd.Function.apply costs ~30 us of host time per node and
+# direction; the model has 7 conv layers + 3 pools, which made the host enqueue a train step in 2.0 ms (a batch of 32
+# small graphs is host-bound).  This node runs the very same layer code -- each layer's forward/backward static methods
+# are called with a private context object -- so the arithmetic and the launch sequence do not change.
+class _LayerCtx:
+    """The part of a torch.autograd.Function context the layer nodes use."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _FamilyAGraph(Function):
+    """pooled [B, 3] = [GCN x3 | Cheb x2 | SAGE x2 branch, each mean-pooled] of the node features (01_ngem.ipynb cell [9]).
+
+    Parameters, in order: conv1.W, conv1.b, conv2.W, conv2.b, conv3.W, conv3.b, cheb1.W0..W2, cheb1.b, cheb2.W0, cheb2.W1,
+    cheb2.b, sage1.Wl, sage1.bl, sage1.Wr, sage2.Wl, sage2.bl, sage2.Wr (19 tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, struct: GraphStructure, p1, p2, seed, *prm):
+        (g1w, g1b, g2w, g2b, g3w, g3b, c1w0, c1w1, c1w2, c1b, c2w0, c2w1, c2b, s1l, s1b, s1r, s2l, s2b, s2r) = prm
+        k1, k2 = 1.0 / (1.0 - p1), 1.0 / (1.0 - p2)
+        T, Fa = True, False
+        mk = lambda n_in, x_grad: _LayerCtx((x_grad,) + (T,) * (n_in - 1))
+        L = ctx.layers = {}
+        # GCN branch: args (x, w, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
+        L["g1"] = mk(9, Fa); h = _GCNLayer.forward(L["g1"], x, g1w, g1b, struct, T, p1, seed + 1, T, None)
+        L["g2"] = mk(9, T); h = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1)
+        L["g3"] = mk(9, T); h = _GCNLayer.forward(L["g3"], h, g3w, g3b, struct, Fa, 0.0, 0, Fa, k1)
+        L["gp"] = mk(2, T); pg = _SegmentMean.forward(L["gp"], h, struct)
+        # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
+        L["c1"] = mk(11, Fa); h = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2)
+        L["c2"] = mk(10, T); h = _ChebLayer.forward(L["c2"], h, c2b, struct, Fa, 0.0, 0, Fa, k2, c2w0, c2w1)
+        L["cp"] = mk(2, T); pc = _SegmentMean.forward(L["cp"], h, struct)
+        # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
+        L["s1"] = mk(10, Fa); h = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None)
+        L["s2"] = mk(10, T); h = _SAGELayer.forward(L["s2"], h, s2l, s2b, s2r, struct, Fa, 0.0, 0, Fa, k2)
+        L["sp"] = mk(2, T); ps = _SegmentMean.forward(L["sp"], h, struct)
+        return torch.cat((pg, pc, ps), dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = ctx.layers
+        g = g.contiguous()
+        gg, gc, gs = g[:, 0:1].contiguous(), g[:, 1:2].contiguous(), g[:, 2:3].contiguous()
+        # GCN branch, last layer first
+        t = _SegmentMean.backward(L["gp"], gg)[0]
+        t, g3w, g3b = _GCNLayer.backward(L["g3"], t)[:3]
+        t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
+        _, g1w, g1b = _GCNLayer.backward(L["g1"], t)[:3]
+        t = _SegmentMean.backward(L["cp"], gc)[0]
+        r = _ChebLayer.backward(L["c2"], t)
+        t, c2b, c2w0, c2w1 = r[0], r[1], r[8], r[9]
+        r = _ChebLayer.backward(L["c1"], t)
+        c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
+        t = _SegmentMean.backward(L["sp"], gs)[0]
+        t, s2l, s2b, s2r = _SAGELayer.backward(L["s2"], t)[:4]
+        _, s1l, s1b, s1r = _SAGELayer.backward(L["s1"], t)[:4]
+        return (None, None, None, None, None, g1w, g1b, g2w, g2b, g3w, g3b, c1w0, c1w1, c1w2, c1b, c2w0, c2w1, c2b,
+                s1l, s1b, s1r, s2l, s2b, s2r)
+
+
+def family_a_graph(x, struct, p1, p2, seed, params):
+    """One-node form of Family A's three conv branches + pools; ``params`` as listed in ``_FamilyAGraph``."""
+    return _FamilyAGraph.apply(x, struct, p1, p2, seed, *params)

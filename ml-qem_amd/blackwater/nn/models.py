@@ -73,6 +73,18 @@ class ExpValCircuitGraphModelA(nn.Module):
         obs = torch.mean(self.obs_seq(observable), dim=1)
         return self.body_seq(torch.cat((pooled, obs, circuit_depth, exp_value), dim=1))
 
+    def _graph_params(self):
+        c1, c2, s1, s2 = self.cheb_conv1, self.cheb_conv2, self.sage_conv1, self.sage_conv2
+        return (self.conv1.lin.weight, self.conv1.bias, self.conv2.lin.weight, self.conv2.bias, self.conv3.lin.weight,
+                self.conv3.bias, c1.lins[0].weight, c1.lins[1].weight, c1.lins[2].weight, c1.bias, c2.lins[0].weight,
+                c2.lins[1].weight, c2.bias, s1.lin_l.weight, s1.lin_l.bias, s1.lin_r.weight, s2.lin_l.weight,
+                s2.lin_l.bias, s2.lin_r.weight)
+
+    def _single_node_ok(self, nodes):
+        """The one-node form covers the reference's configuration (K = 3 / 2, node features that need no gradient)."""
+        return (getattr(self, "single_node", True) and not nodes.requires_grad and len(self.cheb_conv1.lins) == 3
+                and len(self.cheb_conv2.lins) == 2)
+
     def forward_layers(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
@@ -83,6 +95,11 @@ class ExpValCircuitGraphModelA(nn.Module):
         # its backward is applied by that consumer's data-gradient GEMM (native/functional.py, "Mask hand-over").
         p1, p2 = (0.1, 0.2) if train else (0.0, 0.0)
         k1, k2 = 1.0 / (1.0 - p1), 1.0 / (1.0 - p2)
+        if self._single_node_ok(nodes):
+            # the same seven layers and three pools as below, as ONE autograd node (saves ~0.7 ms of host time per step)
+            pooled = F.family_a_graph(nodes, s, p1, p2, seed, self._graph_params())
+            obs = torch.mean(self.obs_seq(observable), dim=1)
+            return self.body_seq(torch.cat((pooled, obs, circuit_depth, exp_value), dim=1))
         g = self.conv1(nodes, s, relu=True, drop_p=p1, seed=seed + 1, defer_mask=True)
         g = self.conv2(g, s, relu=True, drop_p=p1, seed=seed + 2, defer_mask=True, x_gate_scale=k1)
         g = F.segment_mean(self.conv3(g, s, x_gate_scale=k1), s)

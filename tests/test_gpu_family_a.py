@@ -75,6 +75,27 @@ def test_other_hidden_widths(g1, hidden):
         assert (p.grad.cpu().double() - g_ref).abs().max().item() / scale < 1e-4, name
 
 
+def test_single_node_and_per_layer_paths_are_the_same_arithmetic(g1):
+    """The graph part as one autograd node (default) and as one node per layer launch the same kernels with the same
+    seeds: outputs and every gradient agree bit for bit, in train mode (dropout on) too."""
+    model, _ = _models(seed=4)
+    batch = g1_batch(g1, range(20, 84))
+    args = [batch[k].to(DEV) for k in ARGS]
+    results = []
+    for single in (True, False):
+        model.single_node = single
+        model.train()
+        model._step = 0                      # same dropout seeds in both runs (the conv layers' counter-based masks ...
+        torch.manual_seed(123)               # ... and torch's generator for the observable MLP's nn.Dropout)
+        model.zero_grad()
+        out = model(*args)
+        out.square().mean().backward()
+        results.append((out.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(results[0][0], results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
+
+
 def test_train_mode_dropout_runs_and_is_seeded(g1):
     model, _ = _models()
     batch = g1_batch(g1, range(32))
