@@ -80,3 +80,41 @@ def test_node_balanced_sharding():
     assert len(set(flat.tolist())) == len(flat)  # disjoint
     loads = np.array([counts[s].sum() for s in shards], dtype=float)
     assert loads.max() / loads.mean() < 1.15
+
+
+def test_trainer_step_equals_plain_adam_and_handles_unused_parameters():
+    """Trainer.step files autograd's gradients into the flat buffer with one multi-tensor copy: same updates as a plain
+    per-parameter Adam loop; a parameter the loss does not reach keeps a zero gradient slot; flat=False agrees too."""
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(6, 5), torch.nn.Linear(5, 2)
+            self.unused = torch.nn.Parameter(torch.ones(3))
+
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x)))
+
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(16, 6, generator=g), torch.randn(16, 2, generator=g)
+    finals = []
+    for mode in ("flat", "per-parameter", "reference"):
+        torch.manual_seed(1)
+        net = Net()
+        if mode == "reference":
+            opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+            for _ in range(4):
+                opt.zero_grad()
+                torch.nn.functional.mse_loss(net(X), Y).backward()
+                opt.step()
+        else:
+            trainer = Trainer(net, lr=1e-2, flat=mode == "flat")
+            for _ in range(4):
+                trainer.step(_ToyBatch(X, Y))
+            if mode == "flat":
+                assert net.unused.grad is not None and not net.unused.grad.any()
+                for prm, slot in zip(trainer._params, trainer._grad_slots):            # .grad fields: views of the flat buffer
+                    assert prm.grad.data_ptr() == slot.data_ptr()
+        finals.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
+    assert torch.allclose(finals[0], finals[2], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(finals[1], finals[2], rtol=1e-6, atol=1e-7)
+    assert torch.equal(finals[0][:3], torch.ones(3))         # the unused parameter (first in parameters()) never moved
