@@ -24,6 +24,18 @@ import numpy as np
 import torch
 
 
+# Circuits per step per GPU.  Sized for 288 GB of HBM rather than for the reference's host-collated batches of 32: one step
+# then moves 11 M graph nodes (~20 GB of activations), launches are long enough for their tails not to matter
+# (aggregation kernel: 72 % of the HBM peak at 256 circuits, 78 % at 1024) and the host has 11 ms to enqueue 2 ms of work.
+# Measured on one MI355X: 256 -> 78 k, 512 -> 85 k, 1024 -> 89 k, 2048 -> 92 k circuits/s.
+DEFAULT_BATCH = 1024
+
+
+def fixed_ids(n_graphs, batch=DEFAULT_BATCH):
+    """The representative batch the roofline leg (and the profiling scripts) use: every step count, evenly."""
+    return np.arange(batch) * n_graphs // batch
+
+
 def build_corpus(n_j, seed=42):
     from blackwater.data.synthetic import tfim_corpus
 
@@ -96,7 +108,7 @@ def roofline_leg(batch, reps=20):
 
 def mae_leg(model, batch):
     """Mean absolute error of the model after the benchmark's few dozen steps from random initialisation, and of the
-    unmitigated noisy values, against the SYNTHETIC ideal values on the fixed 256-circuit batch.  It only shows that the
+    unmitigated noisy values, against the SYNTHETIC ideal values on the fixed representative batch.  It only shows that the
     loss plumbing is live (600 steps bring the MSE from ~8 to 0.09, scripts/soak.py); the expectation-value accuracy claim
     of this build -- the "exp-val MAE" half of BASELINE.json's metric -- is the `parity` object: device predictions vs the
     CPU reference arithmetic on identical inputs and weights."""
@@ -202,7 +214,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="circuits per step per GPU")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="circuits per step per GPU")
     ap.add_argument("--n-j", type=int, default=50, help="J values per Trotter step count (corpus = 10 x n_j circuits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -267,7 +279,7 @@ def main():
 
     if rank == 0:
         total = args.batch * world * args.steps
-        fixed = arena.batch(np.arange(args.batch) * n_graphs // args.batch)  # every step count, evenly
+        fixed = arena.batch(fixed_ids(n_graphs, args.batch))
         line = {
             "metric": "circuits/sec (GNN train step), 100q TFIM Trotter",
             "value": round(total / elapsed, 2), "unit": "circuits/s", "n_gpus": world, "steps": args.steps,

@@ -4,14 +4,14 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
 import numpy as np, torch
-from bench import build_corpus
+from bench import build_corpus, fixed_ids as bench_fixed_ids
 from blackwater.data.arena import GraphArena
 from blackwater.native import ops
 corpus = build_corpus(50)
 arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
                                corpus["observable"], device="cuda:0")
 n_graphs = len(corpus["x"])
-s = arena.batch(np.arange(256) * n_graphs // 256).structure
+s = arena.batch(bench_fixed_ids(n_graphs)).structure
 n, dev = s.num_nodes, torch.device("cuda:0")
 tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MLQEM_AGG"))
 dst = torch.repeat_interleave(torch.arange(n, device=dev), (s.in_ptr[1:n + 1] - s.in_ptr[:n]).long())

@@ -9,7 +9,7 @@ from blackwater.data.arena import GraphArena
 from blackwater.nn import ExpValCircuitGraphModelA
 from blackwater.train import Trainer
 
-batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else bench.DEFAULT_BATCH
 dev = torch.device("cuda", 0)
 corpus = bench.build_corpus(50)
 arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],

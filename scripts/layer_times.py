@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
 import numpy as np, torch
 import bench
+bench_fixed_ids = bench.fixed_ids
 from blackwater.data.arena import GraphArena
 from blackwater.native import functional as F, ops
 from blackwater.nn.conv import ChebConv, GCNConv, SAGEConv
@@ -13,7 +14,7 @@ corpus = bench.build_corpus(50)
 arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
                                corpus["observable"], device=dev)
 n_graphs = len(corpus["x"])
-b = arena.batch(np.arange(256) * n_graphs // 256)
+b = arena.batch(bench_fixed_ids(n_graphs))
 s, x = b.structure, b.x
 n = x.shape[0]
 print(f"N = {n}, E = {s.num_edges}")
@@ -59,6 +60,6 @@ y = F.segment_mean(h1, s); g = torch.randn_like(y)
 bw = timed(lambda: torch.autograd.backward(y, g, retain_graph=True))
 print(f"{'segment_mean [N,1] (x3)':28s} fwd {f:7.1f} us   bwd {bw:7.1f} us")
 tot += 3 * (f + bw)
-t_asm = timed(lambda: arena.batch(np.arange(256) * n_graphs // 256))
+t_asm = timed(lambda: arena.batch(bench_fixed_ids(n_graphs)))
 print(f"{'batch assemble':28s}     {t_asm:7.1f} us")
 print(f"sum of layers + 3 pools + assemble: {tot + t_asm:.1f} us")

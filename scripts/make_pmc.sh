@@ -42,7 +42,7 @@ wr = vals["WRITE_SIZE"] * 1024
 rec = {
     "what": "rocprofv3 --pmc passes (one counter group per pass, no tracing) over `scripts/profile_agg.py 8 10`: the GCN "
             "forward aggregation (C = 10 in 12-float rows, ELL-assisted kernel, streaming stores) on the benchmark's "
-            "representative 256-circuit batch; plus one --kernel-trace pass of the same command for the duration; "
+            "representative batch (bench.fixed_ids); plus one --kernel-trace pass of the same command for the duration; "
             "regenerate with scripts/make_pmc.sh",
     "kernel": "void mlqem::csr_aggregate_ell_kernel<4, false, 2>(mlqem::AggArgs)",
     "nodes": n, "edges_with_loops": e, "C": c, "launches_averaged": reps,

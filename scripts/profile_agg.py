@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
 import numpy as np, torch
-from bench import build_corpus
+from bench import build_corpus, fixed_ids as bench_fixed_ids
 from blackwater.data.arena import GraphArena
 from blackwater.native import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -12,7 +12,7 @@ corpus = build_corpus(50)
 arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
                                corpus["observable"], device="cuda:0")
 n_graphs = len(corpus["x"])
-b = arena.batch(np.arange(256) * n_graphs // 256)
+b = arena.batch(bench_fixed_ids(n_graphs))
 s = b.structure
 n = s.num_nodes
 PAD = os.environ.get("MLQEM_PAD", "1") == "1"
