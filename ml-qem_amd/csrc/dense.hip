@@ -336,7 +336,7 @@ struct PartsArgs {
   int act; float drop_p; uint64_t seed;   // ACT kernels only: ReLU (bit 0) and inverted dropout keyed by (seed, n*yc + o)
 };
 
-template <int OBT, int G, bool TRANSPOSED, bool ACT>
+template <int OBT, int G, bool TRANSPOSED, bool ACT, bool GATE>
 __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -406,12 +406,12 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
       if (xlive[g] < 4) av[g].w = 0.f;
       if (xlive[g] < 1) av[g].x = 0.f;
     }
-    float4 gv[OBT];
-    if (a.gate) {   // host checked: one output block, gate rows padded like it; fetched with the operands
+    float4 gv[GATE ? OBT : 1];
+    if (GATE) {   // host checked: one output block, gate rows padded like it; fetched with the operands
 #pragma unroll
       for (int ob = 0; ob < OBT; ++ob) {
-        gv[ob] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (row_ok && ycol[ob]) gv[ob] = *reinterpret_cast<const float4*>(a.gate + row * a.ldgate + (ob0 + ob) * 16 + lq * 4);
+        gv[GATE ? ob : 0] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (row_ok && ycol[ob]) gv[GATE ? ob : 0] = *reinterpret_cast<const float4*>(a.gate + row * a.ldgate + (ob0 + ob) * 16 + lq * 4);
       }
     }
     f32x4 acc[OBT];
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
             v[r] = uniform01(a.seed, (uint64_t)(row * a.yc + o0 + r)) < a.drop_p ? 0.f : v[r] * (1.f / (1.f - a.drop_p));
         }
       }
-      if (a.gate) {
-        const float4 m = gv[ob];
+      if (GATE) {
+        const float4 m = gv[GATE ? ob : 0];
         v[0] = m.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = m.y > 0.f ? v[1] * a.gate_scale : 0.f;
         v[2] = m.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = m.w > 0.f ? v[3] * a.gate_scale : 0.f;
       }
@@ -724,14 +724,14 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
   return launch_status();
 }
 
-template <bool TRANSPOSED, bool ACT>
+template <bool TRANSPOSED, bool ACT, bool GATE>
 static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, hipStream_t s) {
-#define MLQEM_PARTS(OB, K) hipLaunchKernelGGL((linear_parts_kernel<OB, K, TRANSPOSED, ACT>), grid, dim3(kBlock), 0, s, a); return true;
+#define MLQEM_PARTS(OB, K) hipLaunchKernelGGL((linear_parts_kernel<OB, K, TRANSPOSED, ACT, GATE>), grid, dim3(kBlock), 0, s, a); return true;
 #define MLQEM_PARTS_G(OB) switch (g) { case 1: MLQEM_PARTS(OB, 1) case 2: MLQEM_PARTS(OB, 2) case 3: MLQEM_PARTS(OB, 3) case 4: MLQEM_PARTS(OB, 4) default: return false; }
   if (obt == 1) MLQEM_PARTS_G(1)
   if (obt == 2) MLQEM_PARTS_G(2)
   if (obt == 6) {   // up to 96 output columns from ONE read of a narrow x (the first layers of all three branches)
-    if (ACT) return false;
+    if (ACT || GATE) return false;
     switch (g) { case 1: MLQEM_PARTS(6, 1) case 2: MLQEM_PARTS(6, 2) default: return false; }
   }
   MLQEM_PARTS_G(4)
@@ -744,13 +744,16 @@ static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, h
 static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
-  const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : ((ob == 5 || ob == 6) && g <= 2 && !a.act && a.drop_p == 0.f ? 6 : 4));
+  const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : ((ob == 5 || ob == 6) && g <= 2 && !a.act && a.drop_p == 0.f && !a.gate ? 6 : 4));
   const int64_t tiles = ceil_div(a.N, 16);
   dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
   const bool act = a.act != 0 || a.drop_p > 0.f;
+  const bool gate = a.gate != nullptr;
   bool ok;
-  if (transposed) ok = act ? false : launch_linear_parts<true, false>(a, g, obt, grid, s);
-  else ok = act ? launch_linear_parts<false, true>(a, g, obt, grid, s) : launch_linear_parts<false, false>(a, g, obt, grid, s);
+  if (transposed) ok = act ? false : (gate ? launch_linear_parts<true, false, true>(a, g, obt, grid, s)
+                                           : launch_linear_parts<true, false, false>(a, g, obt, grid, s));
+  else if (act) ok = gate ? false : launch_linear_parts<false, true, false>(a, g, obt, grid, s);
+  else ok = gate ? launch_linear_parts<false, false, true>(a, g, obt, grid, s) : launch_linear_parts<false, false, false>(a, g, obt, grid, s);
   return ok ? launch_status() : MLQEM_ERR_UNSUPPORTED;
 }
 
