@@ -730,6 +730,7 @@ static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, h
 #define MLQEM_PARTS_G(OB) switch (g) { case 1: MLQEM_PARTS(OB, 1) case 2: MLQEM_PARTS(OB, 2) case 3: MLQEM_PARTS(OB, 3) case 4: MLQEM_PARTS(OB, 4) default: return false; }
   if (obt == 1) MLQEM_PARTS_G(1)
   if (obt == 2) MLQEM_PARTS_G(2)
+  if (obt == 3) MLQEM_PARTS_G(3)
   if (obt == 6) {   // up to 96 output columns from ONE read of a narrow x (the first layers of all three branches)
     if (ACT || GATE) return false;
     switch (g) { case 1: MLQEM_PARTS(6, 1) case 2: MLQEM_PARTS(6, 2) default: return false; }
@@ -744,7 +745,7 @@ static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, h
 static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
-  const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : ((ob == 5 || ob == 6) && g <= 2 && !a.act && a.drop_p == 0.f && !a.gate ? 6 : 4));
+  const int obt = ob <= 3 ? ob : ((ob == 5 || ob == 6) && g <= 2 && !a.act && a.drop_p == 0.f && !a.gate ? 6 : 4);
   const int64_t tiles = ceil_div(a.N, 16);
   dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
   const bool act = a.act != 0 || a.drop_p > 0.f;
