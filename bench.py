@@ -61,8 +61,8 @@ def roofline_leg(batch, reps=20):
     # one norm scalar per node.  Four input/output buffer pairs are rotated so that no launch finds its operands
     # in the 256 MiB Infinity Cache left there by the previous one.
     nbuf = 4
-    hs = [ops.padded_empty(n, c, batch.x.device).normal_() for _ in range(nbuf)]   # the layout the model uses
-    outs = [ops.padded_empty(n, c, batch.x.device) for _ in range(nbuf)]
+    hs = [ops.padded_empty(n, c, batch.structure.in_ptr.device).normal_() for _ in range(nbuf)]   # the layout the model uses
+    outs = [ops.padded_empty(n, c, batch.structure.in_ptr.device) for _ in range(nbuf)]
     dinv = s.gcn_dinv
     run = lambda k: ops.csr_aggregate(hs[k % nbuf], s.in_ptr, s.in_src, ell=s.in_ell, rscale=dinv, dself=dinv, out=outs[k % nbuf])
     for k in range(nbuf):
@@ -77,7 +77,7 @@ def roofline_leg(batch, reps=20):
     sec = beg.elapsed_time(end) * 1e-3 / reps
     b = agg_bytes(n, e_loops, c)
     # the box's own stream-copy rate, for context (SURVEY section 8d asks for the measured peak next to the vendor one)
-    src_buf = torch.empty(256 << 20, dtype=torch.float32, device=batch.x.device).normal_()
+    src_buf = torch.empty(256 << 20, dtype=torch.float32, device=batch.structure.in_ptr.device).normal_()
     dst_bufs = [torch.empty_like(src_buf) for _ in range(2)]
     for k in range(2):
         dst_bufs[k].copy_(src_buf)

@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 2 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 3 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -117,11 +117,15 @@ int mlqem_relu_dropout_bwd_f32(const float* g, int64_t ldg, const float* y, int6
  * rows (the three first-layer projections of GCN | Cheb | SAGE).  gate (may be NULL), applied last:
  * y[n,o] = gate[n,o] > 0 ? y[n,o] * gate_scale : 0 -- the backward of a ReLU/dropout epilogue whose output `gate` is this
  * layer's input, folded into the data-gradient GEMM that produces the incoming gradient (no separate masking pass).
+ * x_rows (may be NULL): row n of x is row x_rows[n] of the buffer -- the first layers read their input rows straight
+ * from the device-resident dataset through the batch's row map (src_node of mlqem_batch_assemble) instead of from a
+ * gathered copy; only for calls the lean kernel can express (padded operands, I, O <= 64, no accumulate), else
+ * MLQEM_ERR_UNSUPPORTED.
  * Runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32) for I <= 128. */
 int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                      const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act, int accumulate,
                      float drop_p, uint64_t seed, int rs_cols, int act_from, const float* gate, int64_t ldgate,
-                     float gate_scale, mlqem_stream_t stream);
+                     float gate_scale, const int32_t* x_rows, mlqem_stream_t stream);
 
 /* y = act(x @ W^T + b) with both operands rounded to bf16 (nearest-even) in registers and fp32 accumulation on
  * v_mfma_f32_16x16x32_bf16: the "bf16 MFMA MLP head" option of the MLP regressors (docs/tutorials/mlp.py:18-108) for
@@ -157,20 +161,21 @@ typedef struct mlqem_col_parts {
 int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* const* w_blocks, const float* const* w_minus_blocks,
                            int transposed, const float* const* bias_blocks, const float* const* rowscale_blocks,
                            const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate, float gate_scale,
-                           mlqem_stream_t stream);
+                           const int32_t* x_rows, mlqem_stream_t stream);
 
 size_t mlqem_linear_wgrad_workspace_bytes(int I, int O);
 
 /* gw[o,i] (+)= sum_n gy[n,o] * x[n,i] ;  gb[o] (+)= sum_n gy[n,o]  (gb may be NULL).  Matrix-core partial sums per
- * workgroup, then a fixed-order reduction: deterministic. */
+ * workgroup, then a fixed-order reduction: deterministic.  x_rows (may be NULL): row map for x as in mlqem_linear_f32. */
 int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
                            int64_t N, int I, int O, int accumulate, void* workspace, size_t workspace_bytes,
-                           mlqem_stream_t stream);
+                           const int32_t* x_rows, mlqem_stream_t stream);
 
 /* The same with gy given as column blocks (O = gy->count * gy->width rows of gw / entries of gb, padding rows are 0):
  * the weight gradients of all terms that share the input x in one pass over x. */
 int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int64_t ldx, float* gw, float* gb, int64_t N,
-                                 int I, int accumulate, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+                                 int I, int accumulate, void* workspace, size_t workspace_bytes, const int32_t* x_rows,
+                                 mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Pooling over graphs.  Replaces global_mean_pool (docs/tutorials/gnn.py:114; 01_ngem.ipynb cell [9]).
@@ -189,7 +194,8 @@ int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph
  * and the CSR arrays of mlqem_csr_build run over the whole arena (global node ids).
  * Selection: sel[B] graph ids (repeats allowed); b_nptr[B+1] / b_eptr[B+1] = prefix sums of the selected graphs'
  * node / edge counts (host knows them without a sync); Nb = b_nptr[B], Eb = b_eptr[B].
- * Outputs: the batch's x, nscal_b -- PLANAR [K, Nb], scalar k of all nodes contiguous, so each is usable as a vector
+ * Outputs: the batch's x (xb may be NULL: no copy of the feature rows is made and the caller's first layers read them
+ * from the arena through src_node, the x_rows argument of the dense entry points), nscal_b -- PLANAR [K, Nb], scalar k of all nodes contiguous, so each is usable as a vector
  * without a strided copy --, src_node[Nb] (arena row of every batch node), both CSR structures (node ids rebased to
  * the batch), loops and, when the arena's ELL side tables a_in_ell / a_out_ell (mlqem_ell_from_csr over the arena)
  * are given, the batch's side tables in_ell_b / out_ell_b [Nb,2] rebased the same way (NULL = not wanted).

@@ -18,17 +18,29 @@ from ..native.structure import GraphStructure
 
 
 class DeviceBatch:
-    """One assembled batch: node features, structure and the per-graph tensors of the model protocol."""
+    """One assembled batch: node features, structure and the per-graph tensors of the model protocol.
 
-    def __init__(self, x, structure, y, noisy, depth, observable, graph_ids):
-        self.x, self.structure = x, structure
+    The node features are NOT copied when the batch is assembled: ``nodes`` is ``ops.RowsOf(arena.x, src_node)`` -- the
+    batch's rows of the arena -- which the first layers of the models read through the row map.  ``x`` materialises (and
+    caches) the gathered [N, F] matrix for anything that wants a plain tensor."""
+
+    def __init__(self, nodes, structure, y, noisy, depth, observable, graph_ids):
+        self.nodes, self.structure = nodes, structure
         self.y, self.noisy_0, self.circuit_depth, self.observable = y, noisy, depth, observable
         self.graph_ids = graph_ids
         self.num_graphs = structure.num_graphs
+        self._x = nodes if isinstance(nodes, torch.Tensor) else None
+
+    @property
+    def x(self) -> torch.Tensor:
+        if self._x is None:
+            self._x = self.nodes.materialize()
+        return self._x
 
     def model_args(self):
-        """The six positional arguments of the reference's model protocol."""
-        return self.noisy_0, self.observable, self.circuit_depth, self.x, self.structure, None
+        """The six positional arguments of the reference's model protocol (``nodes`` may be a ``RowsOf``)."""
+        nodes = self._x if self._x is not None else self.nodes
+        return self.noisy_0, self.observable, self.circuit_depth, nodes, self.structure, None
 
 
 def _ranges(starts, lengths):
@@ -158,7 +170,6 @@ class GraphArena:
         sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:]
         dev, f = self.device, self.x.shape[1]
         f4 = (f + 3) // 4 * 4
-        xb = torch.empty((max(nb, 1), f4), dtype=torch.float32, device=dev)[:nb, :f]   # 16-byte rows, pads zero
         nscal_b = torch.empty((3, max(nb, 1)), dtype=torch.float32, device=dev)   # planar: one contiguous vector per norm
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
@@ -169,11 +180,12 @@ class GraphArena:
         code = _lib.load().mlqem_batch_assemble(
             p(self.x), self.x.stride(0), f4, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
             p(self.out_ptr), p(self.out_dst), p(self.out_eid), p(self.loops), p(self.in_ell), p(self.out_ell), p(sel_d),
-            p(nptr_d), p(eptr_d), b, nb, eb, p(xb), xb.stride(0), p(nscal_b), p(src_node), p(in_ptr), p(in_src),
+            p(nptr_d), p(eptr_d), b, nb, eb, None, 0, p(nscal_b), p(src_node), p(in_ptr), p(in_src),
             p(out_ptr), p(out_dst), p(out_eid), p(loops), p(in_ell), p(out_ell), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[0, :nb], nscal_b[1, :nb], nscal_b[2, :nb])
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,
                            graph_sizes=self.node_counts[sel], out_eid=out_eid, ell=(in_ell, out_ell))
         idx = sel_d.to(torch.int64)
-        return DeviceBatch(xb, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)
+        nodes = ops.RowsOf(self.x, src_node[:nb])     # the feature rows stay in the arena
+        return DeviceBatch(nodes, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)

@@ -105,6 +105,8 @@ _PARTS_MAX_COLS = 64   # mlqem_linear_parts_f32 keeps the weight fragments of I 
 
 
 def _padded_rows(t):
+    if isinstance(t, ops.RowsOf):     # rows of the (padded) arena, read through the batch's row map
+        return t
     return t if (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1) else ops.padded_copy(t)
 
 

@@ -37,6 +37,40 @@ def _mat(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     return int(t.stride(0)) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
 
 
+class RowsOf:
+    """Rows ``rows`` (int32 [n], device) of the padded matrix ``base`` [M, c]: a gathered matrix that is never
+    materialised.  The dense entry points take it as their ``x`` operand (``x_rows`` of the C ABI), so the first layers
+    of a model read their input rows straight from the device-resident dataset instead of from a per-batch copy."""
+
+    requires_grad = False
+    is_cuda = True
+
+    def __init__(self, base: torch.Tensor, rows: torch.Tensor):
+        if (not rows.is_cuda or rows.dtype != torch.int32 or rows.dim() != 1 or (rows.numel() > 1 and rows.stride(0) != 1)):
+            raise ValueError("RowsOf: rows must be a contiguous 1-D int32 cuda tensor")
+        _mat(base, "base")
+        self.base, self.rows = base, rows
+        self.shape = (int(rows.shape[0]), int(base.shape[1]))
+        self.device, self.dtype = base.device, base.dtype
+
+    def dim(self):
+        return 2
+
+    def materialize(self) -> torch.Tensor:
+        """The gathered matrix in the padded row layout (one torch gather over whole padded rows)."""
+        n, c = self.shape
+        ld = int(self.base.stride(0)) if self.base.shape[0] > 1 else (c + 3) // 4 * 4
+        whole = torch.as_strided(self.base, (self.base.shape[0], ld), (ld, 1))
+        return whole.index_select(0, self.rows.long())[:, :c]
+
+
+def _x_operand(x, name="x"):
+    """(tensor to address, leading dimension, rows of the operand, row-map pointer or None) for a dense-kernel input."""
+    if isinstance(x, RowsOf):
+        return x.base, _mat(x.base, name), x.shape[0], x.rows.data_ptr()
+    return x, _mat(x, name), x.shape[0], None
+
+
 def padded_empty(n: int, c: int, device) -> torch.Tensor:
     """An [n, c] fp32 view of a buffer whose rows hold round_up(c, 4) floats (16-byte aligned rows): the kernels
     then move 16 bytes per lane, ~1.4x the rate of 8-byte accesses.  The pad columns are scratch."""
@@ -53,6 +87,8 @@ def padded_copy(t: torch.Tensor) -> torch.Tensor:
 
 def rowmajor(t: torch.Tensor) -> torch.Tensor:
     """``t`` itself when its columns are unit-stride (padded views stay padded), else a compact copy."""
+    if isinstance(t, RowsOf):
+        return t
     if t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1]):
         return t
     return t.contiguous()
@@ -154,8 +190,8 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
            seed=0, rs_cols=-1, act_from=-1, gate=None, gate_scale=1.0):
     """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O]);
     ``gate``: y = gate > 0 ? y * gate_scale : 0 as the last step."""
-    n, i = x.shape
-    ldx = _mat(x, "x")
+    i = x.shape[1]
+    xt, ldx, n, x_rows = _x_operand(x)
     if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
         raise ValueError("w must be a contiguous 2-D fp32 cuda tensor")
     o = w.shape[1] if transposed else w.shape[0]
@@ -167,12 +203,12 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
         if accumulate:
             raise ValueError("linear: accumulate needs an existing out")
         out = padded_empty(n, o, x.device)
-    elif out.shape != (n, o):
+    elif tuple(out.shape) != (n, o):
         raise ValueError("linear: bad out shape")
-    code = _lib.load().mlqem_linear_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(rowscale), _p(out), _mat(out, "out"),
+    code = _lib.load().mlqem_linear_f32(_p(xt), ldx, _p(w), 1 if transposed else 0, _p(b), _p(rowscale), _p(out), _mat(out, "out"),
                                         n, i, o, 1 if relu else 0, 1 if accumulate else 0, float(drop_p),
                                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(rs_cols), int(act_from),
-                                        *_gate(gate, n, o, False), float(gate_scale), _stream())
+                                        *_gate(gate, n, o, False), float(gate_scale), x_rows, _stream())
     _lib.check(code, "mlqem_linear_f32")
     return out
 
@@ -232,7 +268,14 @@ def linear_parts(xs, ws, ys, *, w_minus=None, biases=None, rowscales=None, trans
     Weight blocks are the layers' own contiguous tensors -- nothing is concatenated or padded on the host."""
     import ctypes as _ct
 
-    n = xs[0].shape[0]
+    x_rows = None
+    if isinstance(xs[0], RowsOf):       # the (single) input block read through a row map
+        if len(xs) != 1:
+            raise ValueError("linear_parts: a RowsOf input must be the only input block")
+        x_rows, n = xs[0].rows.data_ptr(), xs[0].shape[0]
+        xs = [xs[0].base]
+    else:
+        n = xs[0].shape[0]
     xp, yp = _col_parts(xs, "xs", True), _col_parts(ys, "ys", True)
     if ys[0].shape[0] != n:
         raise ValueError("linear_parts: xs and ys differ in rows")
@@ -265,7 +308,7 @@ def linear_parts(xs, ws, ys, *, w_minus=None, biases=None, rowscales=None, trans
     code = _lib.load().mlqem_linear_parts_f32(_ct.addressof(xp), _ptr_array(ws, nblk), _ptr_array(w_minus, nblk),
                                               1 if transposed else 0, _ptr_array(biases, nblk),
                                               _ptr_array(rowscales, nblk), _ct.addressof(yp), n,
-                                              *_gate(gate, n, ys[0].shape[1], True), float(gate_scale), _stream())
+                                              *_gate(gate, n, ys[0].shape[1], True), float(gate_scale), x_rows, _stream())
     _lib.check(code, "mlqem_linear_parts_f32")
     return ys
 
@@ -283,7 +326,8 @@ def _wgrad_workspace(device, need: int):
 
 def linear_wgrad_parts(gys, x, gw, gb=None, accumulate=False):
     """gw[k*W + o, i] (+)= sum_n gys[k][n, o] x[n, i]; gb likewise (W = round_up(O, 4); padding rows come out 0)."""
-    n, i = x.shape
+    i = x.shape[1]
+    xt, ldx, n, x_rows = _x_operand(x)
     gp = _col_parts(gys, "gys", False)
     o_tot = gp.count * gp.width
     if gys[0].shape[0] != n or tuple(gw.shape) != (o_tot, i) or not gw.is_contiguous() or gw.dtype != torch.float32:
@@ -294,8 +338,8 @@ def linear_wgrad_parts(gys, x, gw, gb=None, accumulate=False):
     ws = _wgrad_workspace(x.device, need)
     import ctypes as _ct
 
-    code = lib.mlqem_linear_wgrad_parts_f32(_ct.addressof(gp), _p(x), _mat(x, "x"), _p(gw), _p(gb), n, i,
-                                            1 if accumulate else 0, _p(ws), need, _stream())
+    code = lib.mlqem_linear_wgrad_parts_f32(_ct.addressof(gp), _p(xt), ldx, _p(gw), _p(gb), n, i,
+                                            1 if accumulate else 0, _p(ws), need, x_rows, _stream())
     _lib.check(code, "mlqem_linear_wgrad_parts_f32")
 
 
@@ -303,14 +347,15 @@ def linear_wgrad(gy, x, gw, gb=None, accumulate=False):
     """gw (+)= gy.T @ x ; gb (+)= gy.sum(0)."""
     n, o = gy.shape
     i = x.shape[1]
-    if x.shape[0] != n or gw.shape != (o, i) or not gw.is_contiguous() or gw.dtype != torch.float32:
+    xt, ldx, xn, x_rows = _x_operand(x)
+    if xn != n or gw.shape != (o, i) or not gw.is_contiguous() or gw.dtype != torch.float32:
         raise ValueError("linear_wgrad: shape mismatch")
     _vec(gb, "gb", o)
     lib = _lib.load()
     need = lib.mlqem_linear_wgrad_workspace_bytes(i, o)
     ws = _wgrad_workspace(gy.device, need)
-    code = lib.mlqem_linear_wgrad_f32(_p(gy), _mat(gy, "gy"), _p(x), _mat(x, "x"), _p(gw), _p(gb), n, i, o,
-                                      1 if accumulate else 0, _p(ws), need, _stream())
+    code = lib.mlqem_linear_wgrad_f32(_p(gy), _mat(gy, "gy"), _p(xt), ldx, _p(gw), _p(gb), n, i, o,
+                                      1 if accumulate else 0, _p(ws), need, x_rows, _stream())
     _lib.check(code, "mlqem_linear_wgrad_f32")
 
 

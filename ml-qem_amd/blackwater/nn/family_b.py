@@ -80,6 +80,8 @@ class _FamilyB(nn.Module):
         return hidden_channels * h2
 
     def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
+        if hasattr(nodes, "materialize"):     # a device batch hands over rows-of-the-arena; this family wants the tensor
+            nodes = nodes.materialize()
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         g = self.transformer1(nodes, s)

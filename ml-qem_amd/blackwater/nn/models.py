@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from ..native import functional as F
+from ..native import ops
 from ..native.structure import GraphStructure
 from .conv import ChebConv, GCNConv, SAGEConv, _kaiming_linear, _WeightOnly
 
@@ -66,6 +67,8 @@ class ExpValCircuitGraphModelA(nn.Module):
             return self.forward_layers(exp_value, observable, circuit_depth, nodes, edge_index, batch)
         from .family_a_fused import family_a_graph_part
 
+        if isinstance(nodes, ops.RowsOf):
+            nodes = nodes.materialize()
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         self._step += 1
@@ -86,6 +89,8 @@ class ExpValCircuitGraphModelA(nn.Module):
                 and len(self.cheb_conv2.lins) == 2)
 
     def forward_layers(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
+        if isinstance(nodes, ops.RowsOf) and not self._single_node_ok(nodes):
+            nodes = nodes.materialize()      # the per-layer autograd nodes save plain tensors
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         train = self.training

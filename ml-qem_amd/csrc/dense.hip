@@ -334,6 +334,7 @@ struct PartsArgs {
   const float* gate; int64_t ldgate; float gate_scale;   // single-block Y only: y = gate[n,o] > 0 ? y * gate_scale : 0
   int plain_stores;   // a block's rows are wider than one store instruction (16 columns): see mlqem_linear_f32
   int act; float drop_p; uint64_t seed;   // ACT kernels only: ReLU (bit 0) and inverted dropout keyed by (seed, n*yc + o)
+  const int32_t* xrows;   // optional row map: row n of X is row xrows[n] of the buffers (X read straight from the arena)
 };
 
 template <int OBT, int G, bool TRANSPOSED, bool ACT, bool GATE>
@@ -396,11 +397,12 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
     const int64_t row = t * 16 + lr;
     const bool row_ok = row < a.N;
+    const int64_t xrow = (a.xrows && row_ok) ? (int64_t)a.xrows[row] : row;
     float4 av[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_ok && xcol[g]) av[g] = *reinterpret_cast<const float4*>(xcol[g] + row * xld[g]);
+      if (row_ok && xcol[g]) av[g] = *reinterpret_cast<const float4*>(xcol[g] + xrow * xld[g]);
       if (xlive[g] < 2) av[g].y = 0.f;     // padding may hold anything (NaN included): it must not reach the MFMA
       if (xlive[g] < 3) av[g].z = 0.f;
       if (xlive[g] < 4) av[g].w = 0.f;
@@ -496,6 +498,7 @@ struct WgradArgs {
   const float* gyp[MLQEM_MAX_COL_PARTS]; int64_t ldgy[MLQEM_MAX_COL_PARTS];   // gy = column blocks in separate buffers (see PartsArgs); one block: gn = 1
   int gn, gw, gc;                          // blocks, columns per block in the concatenation, meaningful columns per block
   const float* x; int64_t ldx;
+  const int32_t* xrows;    // optional row map for x (see PartsArgs)
   float* partial;          // [gridDim.x][O * (I + 1)]
   int64_t N; int I; int O;
 };
@@ -533,19 +536,35 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
 
   const int64_t rows_per_iter = 4 * kWgradUnroll;
   const int64_t n_iters = ceil_div(a.N, rows_per_iter);
+  // with a row map the x row numbers of the NEXT iteration are fetched during the current one, so the map lookup
+  // never sits in front of the operand loads (a dependent lookup per iteration cost 40 % on this kernel)
+  int xmap[kWgradUnroll];
+  auto fetch_map = [&](int64_t it) {
+#pragma unroll
+    for (int u = 0; u < kWgradUnroll; ++u) {
+      const int64_t n = it * rows_per_iter + u * 4 + lq;
+      xmap[u] = (a.xrows && it < n_iters && n < a.N) ? a.xrows[n] : 0;
+    }
+  };
+  fetch_map(wave);
   for (int64_t it = wave; it < n_iters; it += n_waves) {
     float af[kWgradUnroll][OBT], bf[kWgradUnroll][IBT];
+    int xcur[kWgradUnroll];
+#pragma unroll
+    for (int u = 0; u < kWgradUnroll; ++u) xcur[u] = xmap[u];
+    if (a.xrows) fetch_map(it + n_waves);
 #pragma unroll
     for (int u = 0; u < kWgradUnroll; ++u) {
       const int64_t n = it * rows_per_iter + u * 4 + lq;
       const bool ok = n < a.N;
+      const int64_t xn = a.xrows ? (int64_t)xcur[u] : n;
 #pragma unroll
       for (int ob = 0; ob < OBT; ++ob) af[u][ob] = (ok && gcol[ob]) ? gcol[ob][n * gld[ob]] : 0.f;
 #pragma unroll
       for (int ib = 0; ib < IBT; ++ib) {
         const int i = (ib0 + ib) * 16 + lr;
         float v = 0.f;
-        if (ok) v = i < a.I ? a.x[n * a.ldx + i] : (i == a.I ? 1.f : 0.f);  // column I: ones -> bias gradient
+        if (ok) v = i < a.I ? a.x[xn * a.ldx + i] : (i == a.I ? 1.f : 0.f);  // column I: ones -> bias gradient
         bf[u][ib] = v;
       }
     }
@@ -651,7 +670,8 @@ static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s);   // d
 extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b,
                                 const float* rowscale, float* y, int64_t ldy, int64_t N, int I, int O, int act,
                                 int accumulate, float drop_p, uint64_t seed, int rs_cols, int act_from,
-                                const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream) {
+                                const float* gate, int64_t ldgate, float gate_scale, const int32_t* x_rows,
+                                mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
   if (gate && ldgate < O) return MLQEM_ERR_BAD_ARG;
@@ -685,11 +705,13 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
     p.gate = gate; p.ldgate = ldgate; p.gate_scale = gate_scale;
     p.plain_stores = O > 16;
     p.act = act & 1; p.drop_p = drop_p; p.seed = seed;
+    p.xrows = x_rows;
     if (!(transposed && b)) {   // a bias on the data-gradient form is not something the lean kernel carries
       const int rc = run_linear_parts(p, transposed, s);
       if (rc != MLQEM_ERR_UNSUPPORTED) return rc;
     }
   }
+  if (x_rows) return MLQEM_ERR_UNSUPPORTED;   // the row map is carried by the lean kernel only
   const int ks = round_ks((I + 3) / 4);
   if (ks > 0) {
     const int ob = (O + 15) / 16;
@@ -771,7 +793,8 @@ static bool parts_ok(const mlqem_col_parts* p, bool vector_rows) {
 extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* const* w_blocks,
                                       const float* const* w_minus_blocks, int transposed,
                                       const float* const* bias_blocks, const float* const* rowscale_blocks,
-                                      const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate, float gate_scale, mlqem_stream_t stream) {
+                                      const mlqem_col_parts* y, int64_t N, const float* gate, int64_t ldgate,
+                                      float gate_scale, const int32_t* x_rows, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || !w_blocks || !parts_ok(x, true) || !parts_ok(y, true)) return MLQEM_ERR_BAD_ARG;
   if (transposed ? y->count != 1 : x->count != 1) return MLQEM_ERR_BAD_ARG;   // the blocks sit on ONE side
@@ -792,6 +815,7 @@ extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* con
   a.yn = y->count; a.yw = y->width; a.yc = y->cols;
   a.N = N; a.I = x->count * x->width; a.O = y->count * y->width;
   a.gate = gate; a.ldgate = ldgate; a.gate_scale = gate_scale;
+  a.xrows = x_rows;
   a.plain_stores = y->cols > 16;
   return run_linear_parts(a, transposed, as_stream(stream));
 }
@@ -855,20 +879,20 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
 
 extern "C" int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
                                       int64_t N, int I, int O, int accumulate, void* workspace, size_t workspace_bytes,
-                                      mlqem_stream_t stream) {
+                                      const int32_t* x_rows, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || !gw || ldgy < O || ldx < I) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, O)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && (!gy || !x)) return MLQEM_ERR_BAD_ARG;
   WgradArgs a{};
   a.gyp[0] = gy; a.ldgy[0] = ldgy; a.gn = 1; a.gw = O; a.gc = O;
-  a.x = x; a.ldx = ldx; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
+  a.x = x; a.ldx = ldx; a.xrows = x_rows; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
   return launch_wgrad(a, gw, gb, accumulate, as_stream(stream));
 }
 
 extern "C" int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int64_t ldx, float* gw, float* gb,
                                             int64_t N, int I, int accumulate, void* workspace, size_t workspace_bytes,
-                                            mlqem_stream_t stream) {
+                                            const int32_t* x_rows, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || !gw || ldx < I || !parts_ok(gy, false)) return MLQEM_ERR_BAD_ARG;
   const int O = gy->count * gy->width;
@@ -877,6 +901,6 @@ extern "C" int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const flo
   WgradArgs a{};
   for (int i = 0; i < gy->count; ++i) { a.gyp[i] = static_cast<const float*>(gy->ptr[i]); a.ldgy[i] = gy->ld[i]; }
   a.gn = gy->count; a.gw = gy->width; a.gc = gy->cols;
-  a.x = x; a.ldx = ldx; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
+  a.x = x; a.ldx = ldx; a.xrows = x_rows; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
   return launch_wgrad(a, gw, gb, accumulate, as_stream(stream));
 }

@@ -123,7 +123,7 @@ __device__ __forceinline__ int find_segment(const int32_t* __restrict__ ptr, int
 // VEC4: both the arena's and the batch's feature rows are 16-byte aligned with F a multiple of 4 (the padded layout).
 template <bool VEC4>
 __global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArgs a) {
-  const int FC = VEC4 ? a.F / 4 : a.F;         // feature chunks per row
+  const int FC = a.xb ? (VEC4 ? a.F / 4 : a.F) : 0;   // feature chunks per row (none: the caller reads x through src_node)
   const int W = FC + a.K;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= a.Nb * W) return;
@@ -258,9 +258,9 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
                                     mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
-  if (B <= 0 || Nb < 0 || Eb < 0 || F <= 0 || K < 0 || ldx < F || ldxb < F) return MLQEM_ERR_BAD_ARG;
+  if (B <= 0 || Nb < 0 || Eb < 0 || F <= 0 || K < 0 || ldx < F || (xb && ldxb < F)) return MLQEM_ERR_BAD_ARG;
   if (B > 0x7fffffff || Nb >= 0x7fffffffLL || Eb >= 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
-  if (!x || !a_gptr || !a_in_ptr || !a_out_ptr || !sel || !b_nptr || !b_eptr || !xb || !src_node || !in_ptr_b || !out_ptr_b)
+  if (!x || !a_gptr || !a_in_ptr || !a_out_ptr || !sel || !b_nptr || !b_eptr || !src_node || !in_ptr_b || !out_ptr_b)
     return MLQEM_ERR_BAD_ARG;
   if (K > 0 && (!nscal || !nscal_b)) return MLQEM_ERR_BAD_ARG;
   if (Eb > 0 && (!a_in_src || !a_out_dst || !in_src_b || !out_dst_b)) return MLQEM_ERR_BAD_ARG;
@@ -272,13 +272,17 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
                  a_in_ell, a_out_ell, in_ell_b, out_ell_b};
   hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
   if (Nb > 0) {
-    const bool vec4 = F % 4 == 0 && ldx % 4 == 0 && ldxb % 4 == 0 && aligned_to(x, 16) && aligned_to(xb, 16);
-    if (vec4)
-      hipLaunchKernelGGL(assemble_rows_kernel<true>, dim3((unsigned)ceil_div(Nb * (F / 4 + K), kBlock)), dim3(kBlock), 0,
-                         stream, a);
-    else
-      hipLaunchKernelGGL(assemble_rows_kernel<false>, dim3((unsigned)ceil_div(Nb * (F + K), kBlock)), dim3(kBlock), 0,
-                         stream, a);
+    // xb == NULL: only the per-node scalars are gathered; the caller's first layers read x through src_node
+    const bool vec4 = xb && F % 4 == 0 && ldx % 4 == 0 && ldxb % 4 == 0 && aligned_to(x, 16) && aligned_to(xb, 16);
+    const int64_t per_row = (xb ? (vec4 ? F / 4 : F) : 0) + K;
+    if (per_row > 0) {
+      if (vec4)
+        hipLaunchKernelGGL(assemble_rows_kernel<true>, dim3((unsigned)ceil_div(Nb * per_row, kBlock)), dim3(kBlock), 0,
+                           stream, a);
+      else
+        hipLaunchKernelGGL(assemble_rows_kernel<false>, dim3((unsigned)ceil_div(Nb * per_row, kBlock)), dim3(kBlock), 0,
+                           stream, a);
+    }
   }
   if (Eb > 0)
     hipLaunchKernelGGL(assemble_edges_kernel, dim3((unsigned)ceil_div(Eb, kBlock)), dim3(kBlock), 0, stream, a);

@@ -75,3 +75,20 @@ for (i, o) in [(22, 10), (10, 10), (10, 1)]:
     nb = n * (xx.stride(0) + y1.stride(0)) * 4
     print(f"{i}->{o}: parts kernel {t_parts:6.1f} us ({nb / t_parts / 1e3:5.0f} GB/s)   dense kernel {t_lin:6.1f} us ({nb / t_lin / 1e3:5.0f} GB/s)  "
           f"max diff {(y1 - y2).abs().max().item():.1e}")
+
+# the same first-layer shapes with x read through a row map (RowsOf): identity map and a map with the batch's structure
+rows_id = torch.arange(n, device=dev, dtype=torch.int32)
+blocks = torch.randint(0, 400, (n // 11000 + 1,), device=dev)             # ~11k-row graphs drawn from a 400-graph arena
+starts = (blocks * 11000).repeat_interleave(11000)[:n].to(torch.int32)
+rows_real = starts + (torch.arange(n, device=dev, dtype=torch.int32) % 11000)
+base = ops.padded_empty(int(rows_real.max().item()) + 1, 22, dev).normal_()
+for name, xx in (("plain tensor", x), ("RowsOf identity", ops.RowsOf(x, rows_id)), ("RowsOf per-graph runs", ops.RowsOf(base, rows_real))):
+    ws3 = [torch.randn(10, 22, device=dev) for _ in range(3)]
+    ys3 = [ops.padded_empty(n, 10, dev) for _ in range(3)]
+    t_f = timed(lambda: ops.linear_parts([xx], ws3, ys3))
+    y1 = ops.padded_empty(n, 10, dev)
+    t_l = timed(lambda: ops.linear(xx, ws3[0], out=y1))
+    gs3 = [ops.padded_empty(n, 10, dev).normal_() for _ in range(3)]
+    gw = torch.empty(36, 22, device=dev); gb = torch.empty(36, device=dev)
+    t_w = timed(lambda: ops.linear_wgrad_parts(gs3, xx, gw, gb))
+    print(f"{name:24s} fan-out 22->3x10 {t_f:6.1f} us   linear 22->10 {t_l:6.1f} us   wgrad [3x10] {t_w:6.1f} us")
