@@ -159,6 +159,8 @@ __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleAr
   a.in_ptr_b[i] = a.a_in_ptr[gn] - a.a_in_ptr[g0] + a.b_eptr[b];
   a.out_ptr_b[i] = a.a_out_ptr[gn] - a.a_out_ptr[g0] + a.b_eptr[b];
   if (a.loops_b) a.loops_b[i] = a.a_loops[gn];
+  if (!a.xb)   // no feature rows to move: the per-node scalars ride along here instead of in a pass of their own
+    for (int k = 0; k < a.K; ++k) a.nscal_b[(int64_t)k * a.Nb + i] = a.nscal[gn * a.K + k];   // planar [K, Nb]
   // ELL side tables: the arena's entries rebased to batch ids (-1 = no edge, bit 31 of .x = more than two edges)
   const int32_t shift = a.b_nptr[b] - g0;
   auto rebase = [&](int2 e) {
@@ -274,7 +276,7 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
   if (Nb > 0) {
     // xb == NULL: only the per-node scalars are gathered; the caller's first layers read x through src_node
     const bool vec4 = xb && F % 4 == 0 && ldx % 4 == 0 && ldxb % 4 == 0 && aligned_to(x, 16) && aligned_to(xb, 16);
-    const int64_t per_row = (xb ? (vec4 ? F / 4 : F) : 0) + K;
+    const int64_t per_row = xb ? (vec4 ? F / 4 : F) + K : 0;   // without xb the nodes kernel has moved the scalars
     if (per_row > 0) {
       if (vec4)
         hipLaunchKernelGGL(assemble_rows_kernel<true>, dim3((unsigned)ceil_div(Nb * per_row, kBlock)), dim3(kBlock), 0,
