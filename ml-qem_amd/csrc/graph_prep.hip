@@ -144,15 +144,28 @@ __global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArg
   }
 }
 
+// Segment (graph) of element `mine`, for a workgroup whose elements are consecutive: ONE binary search per workgroup (by
+// thread 0, for the workgroup's first element), then every thread steps forward from there -- graphs hold thousands of
+// elements, so that is zero or one step instead of log2(B) dependent loads per element.  Call from all threads.
+__device__ __forceinline__ int segment_from_block_start(const int32_t* __restrict__ ptr, int n_seg, int64_t block_first,
+                                                        int64_t n_total, int64_t mine) {
+  __shared__ int s_first;
+  if (threadIdx.x == 0) s_first = find_segment(ptr, n_seg, (int32_t)min(block_first, max(n_total - 1, (int64_t)0)));
+  __syncthreads();
+  int b = s_first;
+  while (b + 1 < n_seg && mine >= ptr[b + 1]) ++b;
+  return b;
+}
+
 __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleArgs a) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int b = segment_from_block_start(a.b_nptr, a.B, (int64_t)blockIdx.x * kBlock, a.Nb, min(i, max(a.Nb - 1, (int64_t)0)));
   if (i > a.Nb) return;
   if (i == a.Nb) {
     a.in_ptr_b[i] = (int32_t)a.Eb;
     a.out_ptr_b[i] = (int32_t)a.Eb;
     return;
   }
-  const int b = find_segment(a.b_nptr, a.B, (int32_t)i);
   const int32_t g0 = a.a_gptr[a.sel[b]];
   const int64_t gn = (int64_t)g0 + (i - a.b_nptr[b]);
   a.src_node[i] = (int32_t)gn;
@@ -174,8 +187,8 @@ __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleAr
 
 __global__ __launch_bounds__(kBlock) void assemble_edges_kernel(const AssembleArgs a) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int b = segment_from_block_start(a.b_eptr, a.B, (int64_t)blockIdx.x * kBlock, a.Eb, min(e, max(a.Eb - 1, (int64_t)0)));
   if (e >= a.Eb) return;
-  const int b = find_segment(a.b_eptr, a.B, (int32_t)e);
   const int32_t g0 = a.a_gptr[a.sel[b]];
   const int32_t shift = a.b_nptr[b] - g0;
   const int64_t le = e - a.b_eptr[b];
