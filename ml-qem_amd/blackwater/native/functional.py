@@ -494,6 +494,17 @@ def asap_pool(x, mod, struct):
 # direction; the model has 7 conv layers + 3 pools, which made the host enqueue a train step in 2.0 ms (a batch of 32
 # small graphs is host-bound).  This node runs the very same layer code -- each layer's forward/backward static methods
 # are called with a private context object -- so the arithmetic and the launch sequence do not change.
+_side_streams = {}
+
+
+def _branch_streams(device):
+    """Two side streams per device for the Cheb and SAGE branches (created once)."""
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _side_streams[key]
+
+
 class _LayerCtx:
     """The part of a torch.autograd.Function context the layer nodes use."""
 
@@ -518,19 +529,34 @@ class _FamilyAGraph(Function):
         T, Fa = True, False
         mk = lambda n_in, x_grad: _LayerCtx((x_grad,) + (T,) * (n_in - 1))
         L = ctx.layers = {}
+        # The three branches are independent until the concatenation: each runs on its own HIP stream, so the tail of one
+        # branch's kernels (hub-row waves keep a launch's last workgroups alive) is filled by the others' workgroups.
+        main = torch.cuda.current_stream(x.device)
+        side = ctx.side = _branch_streams(x.device)
+        # everything the branches share must exist before they fork: the structure builds its side tables and derived
+        # scalars on first use, and a table built by one branch's stream would be read by another's without an edge
+        _ = (struct.in_ell, struct.out_ell, struct.gcn_dinv, struct.derived("gcn_dself"), struct.derived("sage_dself"),
+             struct.derived("cheb_neg"))
+        for st in side:
+            st.wait_stream(main)
         # GCN branch: args (x, w, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
         L["g1"] = mk(9, Fa); h = _GCNLayer.forward(L["g1"], x, g1w, g1b, struct, T, p1, seed + 1, T, None)
         L["g2"] = mk(9, T); h = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1)
         L["g3"] = mk(9, T); h = _GCNLayer.forward(L["g3"], h, g3w, g3b, struct, Fa, 0.0, 0, Fa, k1)
         L["gp"] = mk(2, T); pg = _SegmentMean.forward(L["gp"], h, struct)
-        # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
-        L["c1"] = mk(11, Fa); h = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2)
-        L["c2"] = mk(10, T); h = _ChebLayer.forward(L["c2"], h, c2b, struct, Fa, 0.0, 0, Fa, k2, c2w0, c2w1)
-        L["cp"] = mk(2, T); pc = _SegmentMean.forward(L["cp"], h, struct)
-        # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
-        L["s1"] = mk(10, Fa); h = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None)
-        L["s2"] = mk(10, T); h = _SAGELayer.forward(L["s2"], h, s2l, s2b, s2r, struct, Fa, 0.0, 0, Fa, k2)
-        L["sp"] = mk(2, T); ps = _SegmentMean.forward(L["sp"], h, struct)
+        with torch.cuda.stream(side[0]):
+            # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
+            L["c1"] = mk(11, Fa); h = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2)
+            L["c2"] = mk(10, T); h = _ChebLayer.forward(L["c2"], h, c2b, struct, Fa, 0.0, 0, Fa, k2, c2w0, c2w1)
+            L["cp"] = mk(2, T); pc = _SegmentMean.forward(L["cp"], h, struct)
+        with torch.cuda.stream(side[1]):
+            # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
+            L["s1"] = mk(10, Fa); h = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None)
+            L["s2"] = mk(10, T); h = _SAGELayer.forward(L["s2"], h, s2l, s2b, s2r, struct, Fa, 0.0, 0, Fa, k2)
+            L["sp"] = mk(2, T); ps = _SegmentMean.forward(L["sp"], h, struct)
+        for st, t in zip(side, (pc, ps)):
+            main.wait_stream(st)
+            t.record_stream(main)
         return torch.cat((pg, pc, ps), dim=1)
 
     @staticmethod
@@ -538,19 +564,29 @@ class _FamilyAGraph(Function):
         L = ctx.layers
         g = g.contiguous()
         gg, gc, gs = g[:, 0:1].contiguous(), g[:, 1:2].contiguous(), g[:, 2:3].contiguous()
+        main = torch.cuda.current_stream(g.device)
+        side = ctx.side
+        for st in side:
+            st.wait_stream(main)
         # GCN branch, last layer first
         t = _SegmentMean.backward(L["gp"], gg)[0]
         t, g3w, g3b = _GCNLayer.backward(L["g3"], t)[:3]
         t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
         _, g1w, g1b = _GCNLayer.backward(L["g1"], t)[:3]
-        t = _SegmentMean.backward(L["cp"], gc)[0]
-        r = _ChebLayer.backward(L["c2"], t)
-        t, c2b, c2w0, c2w1 = r[0], r[1], r[8], r[9]
-        r = _ChebLayer.backward(L["c1"], t)
-        c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
-        t = _SegmentMean.backward(L["sp"], gs)[0]
-        t, s2l, s2b, s2r = _SAGELayer.backward(L["s2"], t)[:4]
-        _, s1l, s1b, s1r = _SAGELayer.backward(L["s1"], t)[:4]
+        with torch.cuda.stream(side[0]):
+            t = _SegmentMean.backward(L["cp"], gc)[0]
+            r = _ChebLayer.backward(L["c2"], t)
+            t, c2b, c2w0, c2w1 = r[0], r[1], r[8], r[9]
+            r = _ChebLayer.backward(L["c1"], t)
+            c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
+        with torch.cuda.stream(side[1]):
+            t = _SegmentMean.backward(L["sp"], gs)[0]
+            t, s2l, s2b, s2r = _SAGELayer.backward(L["s2"], t)[:4]
+            _, s1l, s1b, s1r = _SAGELayer.backward(L["s1"], t)[:4]
+        for st in side:
+            main.wait_stream(st)
+        for t in (c2b, c2w0, c2w1, c1b, c1w0, c1w1, c1w2, s2l, s2b, s2r, s1l, s1b, s1r):
+            t.record_stream(main)
         return (None, None, None, None, None, g1w, g1b, g2w, g2b, g3w, g3b, c1w0, c1w1, c1w2, c1b, c2w0, c2w1, c2b,
                 s1l, s1b, s1r, s2l, s2b, s2r)
 
