@@ -27,7 +27,7 @@ import torch
 # Circuits per step per GPU.  Sized for 288 GB of HBM rather than for the reference's host-collated batches of 32: one step
 # then moves 11 M graph nodes (~20 GB of activations), launches are long enough for their tails not to matter
 # (aggregation kernel: 72 % of the HBM peak at 256 circuits, 78 % at 1024) and the host has 11 ms to enqueue 2 ms of work.
-# Measured on one MI355X: 256 -> 78 k, 512 -> 85 k, 1024 -> 89 k, 2048 -> 92 k circuits/s.
+# Measured on one MI355X: 256 -> 88 k, 1024 -> 99-101 k, 2048 -> 101 k circuits/s.
 DEFAULT_BATCH = 1024
 
 
