@@ -84,6 +84,9 @@ int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, const int32
  * 16-byte aligned) the kernel moves 16 bytes per lane and processes the pad columns along; columns never mix, so
  * the pads may hold anything.  16-byte accesses run ~1.4x the rate of 8-byte ones here: C = 12 takes less time
  * than C = 10, so the host lays every activation out with a padded leading dimension.
+ * CONTRACT: with 16-byte-aligned rows the columns C .. round_up(C,4)-1 of `out` ARE WRITTEN (scratch values).  A
+ * caller whose `out` is a column slice of a wider matrix must pass an unaligned base / a leading dimension that is
+ * not a multiple of 4, or use a padded buffer; the Python binding refuses such slices (ops._owns_pad_columns).
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
                             const float* cscale, const float* rscale, const float* dself, float alpha, float beta,

@@ -125,20 +125,31 @@ class GraphArena:
     @staticmethod
     def _from_flat(x_host, node_counts, ei, y, noisy, depth, observable, device) -> "GraphArena":
         """x_host [N,F] f32 (graphs back to back), ei [2,E] int64 with arena-global node ids."""
-        offs = np.concatenate([[0], np.cumsum(node_counts)])
         f = x_host.shape[1]
         f4 = (f + 3) // 4 * 4                                    # rows padded to a multiple of 4 floats, pads zero
         x = torch.zeros((x_host.shape[0], f4), dtype=torch.float32, device=torch.device(device))[:, :f]
         x.copy_(torch.from_numpy(x_host))
-        n_total = int(offs[-1])
         ei_dev = torch.from_numpy(np.ascontiguousarray(ei)).to(device)
+        return GraphArena.from_device(x, node_counts, ei_dev, y, noisy, depth, observable)
+
+    @staticmethod
+    def from_device(x: torch.Tensor, node_counts, ei_dev: torch.Tensor, y, noisy, depth, observable) -> "GraphArena":
+        """From tensors already on the device: ``x`` [N,F] fp32 in the padded row layout (row stride a multiple of 4
+        floats, pad columns zero), graphs back to back; ``ei_dev`` [2,E] int64 with arena-global node ids; labels as
+        host arrays with leading dimension G."""
+        device = x.device
+        node_counts = np.asarray(node_counts, dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(node_counts)])
+        n_total = int(offs[-1])
+        if x.shape[0] != n_total or x.dtype != torch.float32 or (n_total > 1 and (x.stride(0) % 4 or x.stride(1) != 1)):
+            raise ValueError("GraphArena.from_device: x must be [sum(node_counts), F] fp32 with rows padded to 4 floats")
         csr = ops.csr_build(ei_dev, n_total)
         in_ptr, in_src, out_ptr, out_dst, loops = csr
         gcn, sage, cheb = ops.graph_norms(in_ptr, out_ptr, loops, n_total)
         nscal = torch.stack([gcn, sage, cheb], dim=1).contiguous()
         gptr = torch.from_numpy(offs.astype(np.int32)).to(device)
         # edges per graph (self-loops excluded): one read-back at build time
-        edge_counts = np.diff(in_ptr.cpu().numpy()[offs]).astype(np.int64)
+        edge_counts = np.diff(in_ptr[gptr.long()].cpu().numpy()).astype(np.int64)
         t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
         return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops, csr.out_eid), nscal, t(y), t(noisy),
                           t(depth), t(observable), edge_counts)

@@ -168,45 +168,115 @@ def synthetic_backend(nq: int, two_q: str = "ecr", seed: int = 0) -> StaticBacke
     return StaticBackend(f"synthetic_{nq}q", {"backend_name": f"synthetic_{nq}q", "qubits": qubits, "gates": gates})
 
 
+class TfimCorpus:
+    """The (steps x J) grid of encoded TFIM-Trotter graphs, WITHOUT holding one feature matrix per circuit.
+
+    The graph of a TFIM circuit depends on J only through the rz angle of the bond rotations (feature column 0), so each
+    step count is encoded once with the real encoder ("template") and a circuit is (template, J).  Graph ids run
+    step-major: ``g = steps_index * n_J + j``; J ~ U(0, 0.66 pi) from ``np.random.RandomState(seed)`` as in the reference's
+    ``get_Js`` (h24 notebook cell [7]).  ``host_graphs(ids)`` materialises plain numpy graphs (what the CPU oracle and
+    the host-side loaders consume); ``arena(device, ids)`` replicates the templates ON THE DEVICE straight into a
+    :class:`GraphArena` -- an 8 200-circuit / 90 M-node corpus costs ten template uploads instead of 9 GB of host
+    arrays."""
+
+    def __init__(self, nq: int, steps_list, n_J: int, seed: int = 42, two_q: str = "ecr", exp_value_size: int = 1,
+                 add_self_loops: bool = True):
+        props = get_backend_properties_v1(synthetic_backend(nq, two_q))
+        self.nq, self.n_J, self.steps_list = nq, int(n_J), list(steps_list)
+        rs = np.random.RandomState(seed)
+        self.Js = rs.uniform(0, 0.66 * math.pi, size=n_J)
+        label_rng = np.random.default_rng(seed + 1)
+        self.templates = []
+        ys, noisy, depth, obs_z = [], [], [], []
+        for steps in self.steps_list:
+            circ = tfim_circuit(nq, steps, J=1.0, two_q=two_q)  # phi = -2*J*dt = -1.0: marks the J-dependent nodes
+            graph = circuit_to_graph_data_json(circ, props, use_gate_features=True, use_qubit_features=True)
+            x0 = np.asarray(graph["nodes"]["DAGOpNode"], dtype=np.float32)
+            ei = np.asarray(graph["edges"]["DAGOpNode_wire_DAGOpNode"]["edge_index"], dtype=np.int64)
+            if add_self_loops:  # the training path's dataset transform (loaders/exp_val.py:33)
+                loops = np.arange(x0.shape[0], dtype=np.int64)
+                ei = np.concatenate([ei, np.stack([loops, loops])], axis=1)
+            bond_nodes = np.array([k for k, op in enumerate(circ.ops) if op.name == "rz" and op.params[0] == -1.0],
+                                  dtype=np.int64)
+            n2q = sum(1 for op in circ.ops if op.name == two_q)
+            d = circ.depth()
+            self.templates.append({"x": x0, "edge_index": ei, "bond_nodes": bond_nodes, "depth": float(d)})
+            for _ in range(self.n_J):   # same draw order as ever: ideal, noise, observable qubit -- per circuit
+                ideal = label_rng.uniform(-1, 1, size=exp_value_size)
+                ys.append(ideal)
+                noisy.append(ideal * math.exp(-2e-4 * n2q) + label_rng.normal(0, 0.01, size=exp_value_size))
+                depth.append([float(d)])
+                obs_z.append(int(label_rng.integers(0, nq)))
+        self.y, self.noisy = np.asarray(ys, np.float32), np.asarray(noisy, np.float32)
+        self.depth, self.obs_z = np.asarray(depth, np.float32), np.asarray(obs_z, np.int64)
+        self.node_counts = np.repeat([t["x"].shape[0] for t in self.templates], self.n_J).astype(np.int64)
+
+    def __len__(self):
+        return len(self.templates) * self.n_J
+
+    def observables(self, ids) -> np.ndarray:
+        """[len(ids), 1, 4 nq + 1]: coefficient 1, identity everywhere except one Z."""
+        ids = np.asarray(ids, dtype=np.int64)
+        o = np.zeros((len(ids), 1, 4 * self.nq + 1), dtype=np.float32)
+        o[:, 0, 0] = 1.0
+        o[:, 0, 1::4] = 1.0
+        rows = np.arange(len(ids))
+        o[rows, 0, 1 + 4 * self.obs_z[ids]] = 0.0
+        o[rows, 0, 2 + 4 * self.obs_z[ids]] = 1.0
+        return o
+
+    def graph_x(self, g: int) -> np.ndarray:
+        t = self.templates[g // self.n_J]
+        x = t["x"].copy()
+        x[t["bond_nodes"], 0] = np.float32(-2 * self.Js[g % self.n_J] * 0.5)
+        return x
+
+    def host_graphs(self, ids=None) -> Dict[str, list]:
+        ids = np.arange(len(self)) if ids is None else np.asarray(ids, dtype=np.int64)
+        return {"x": [self.graph_x(int(g)) for g in ids],
+                "edge_index": [self.templates[int(g) // self.n_J]["edge_index"] for g in ids],
+                "y": self.y[ids], "noisy": self.noisy[ids], "depth": self.depth[ids], "observable": self.observables(ids)}
+
+    def arena(self, device, ids=None):
+        """The graphs ``ids`` (ascending global ids; default all) as a device-resident arena, built by replicating the
+        templates on the device.  Under data parallelism every rank passes its own shard of ids."""
+        import torch
+
+        from .arena import GraphArena
+
+        ids = np.arange(len(self)) if ids is None else np.asarray(ids, dtype=np.int64)
+        if len(ids) > 1 and (np.diff(ids) <= 0).any():
+            raise ValueError("TfimCorpus.arena: ids must be strictly ascending")
+        dev = torch.device(device)
+        f = self.templates[0]["x"].shape[1]
+        f4 = (f + 3) // 4 * 4
+        tmpl_of = ids // self.n_J
+        n_total = int(self.node_counts[ids].sum())
+        x = torch.zeros((max(n_total, 1), f4), dtype=torch.float32, device=dev)
+        ei_parts, base = [], 0
+        for t_idx, t in enumerate(self.templates):
+            mine = ids[tmpl_of == t_idx]
+            c = len(mine)
+            if c == 0:
+                continue
+            n_t = t["x"].shape[0]
+            x0 = torch.from_numpy(t["x"]).to(dev)
+            block = x[base:base + c * n_t].view(c, n_t, f4)
+            block[:, :, :f] = x0.unsqueeze(0)
+            bond = torch.from_numpy(t["bond_nodes"]).to(dev)
+            jv = torch.from_numpy((-2 * self.Js[mine % self.n_J] * 0.5).astype(np.float32)).to(dev)
+            block[:, bond, 0] = jv.unsqueeze(1)
+            ei_t = torch.from_numpy(t["edge_index"]).to(dev)
+            offs = base + torch.arange(c, device=dev, dtype=torch.int64) * n_t
+            ei_parts.append((ei_t.unsqueeze(1) + offs.view(1, c, 1)).reshape(2, -1))
+            base += c * n_t
+        ei = torch.cat(ei_parts, dim=1) if ei_parts else torch.zeros((2, 0), dtype=torch.int64, device=dev)
+        return GraphArena.from_device(x[:n_total, :f], self.node_counts[ids], ei, self.y[ids], self.noisy[ids],
+                                      self.depth[ids], self.observables(ids))
+
+
 def tfim_corpus(nq: int, steps_list, n_J: int, seed: int = 42, two_q: str = "ecr", exp_value_size: int = 1,
                 add_self_loops: bool = True) -> Dict[str, list]:
-    """Encoded graphs for every (steps, J) pair: ``steps_list`` x ``n_J`` circuits, J ~ U(0, 0.66 pi) with
-    ``np.random.seed(seed)`` as in the reference's ``get_Js`` (h24 notebook cell [7]).
-
-    The graph of a TFIM circuit depends on J only through the rz angles of the bond rotations (feature
-    column 0), so each step count is encoded once with the real encoder and the J-dependent column is rewritten.
-    """
-    props = get_backend_properties_v1(synthetic_backend(nq, two_q))
-    rs = np.random.RandomState(seed)
-    Js = rs.uniform(0, 0.66 * math.pi, size=n_J)
-    label_rng = np.random.default_rng(seed + 1)
-    xs, eis, ys, noisy, depth, obs = [], [], [], [], [], []
-    for steps in steps_list:
-        circ = tfim_circuit(nq, steps, J=1.0, two_q=two_q)  # phi = -2*J*dt = -1.0: marks the J-dependent nodes
-        graph = circuit_to_graph_data_json(circ, props, use_gate_features=True, use_qubit_features=True)
-        x0 = np.asarray(graph["nodes"]["DAGOpNode"], dtype=np.float32)
-        ei = np.asarray(graph["edges"]["DAGOpNode_wire_DAGOpNode"]["edge_index"], dtype=np.int64)
-        if add_self_loops:  # the training path's dataset transform (loaders/exp_val.py:33)
-            loops = np.arange(x0.shape[0], dtype=np.int64)
-            ei = np.concatenate([ei, np.stack([loops, loops])], axis=1)
-        bond_nodes = np.array([k for k, op in enumerate(circ.ops) if op.name == "rz" and op.params[0] == -1.0],
-                              dtype=np.int64)
-        n2q = sum(1 for op in circ.ops if op.name == two_q)
-        d = circ.depth()
-        for J in Js:
-            x = x0.copy()
-            x[bond_nodes, 0] = np.float32(-2 * J * 0.5)
-            ideal = label_rng.uniform(-1, 1, size=exp_value_size)
-            xs.append(x)
-            eis.append(ei)
-            ys.append(ideal)
-            noisy.append(ideal * math.exp(-2e-4 * n2q) + label_rng.normal(0, 0.01, size=exp_value_size))
-            depth.append([float(d)])
-            o = np.zeros((1, 4 * nq + 1), dtype=np.float32)
-            o[0, 0] = 1.0
-            o[0, 1::4] = 1.0                                   # identity everywhere ...
-            qz = int(label_rng.integers(0, nq))
-            o[0, 1 + 4 * qz], o[0, 2 + 4 * qz] = 0.0, 1.0      # ... except one Z
-            obs.append(o)
-    return {"x": xs, "edge_index": eis, "y": np.asarray(ys, np.float32), "noisy": np.asarray(noisy, np.float32),
-            "depth": np.asarray(depth, np.float32), "observable": np.asarray(obs, np.float32)}
+    """Encoded graphs for every (steps, J) pair as plain host arrays: ``steps_list`` x ``n_J`` circuits
+    (see :class:`TfimCorpus`)."""
+    return TfimCorpus(nq, steps_list, n_J, seed, two_q, exp_value_size, add_self_loops).host_graphs()

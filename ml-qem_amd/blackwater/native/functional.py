@@ -498,7 +498,14 @@ _side_streams = {}
 
 
 def _branch_streams(device):
-    """Two side streams per device for the Cheb and SAGE branches (created once)."""
+    """Two side streams per device for the Cheb and SAGE branches (created once).  ``MLQEM_SINGLE_STREAM=1`` keeps all
+    three branches on the caller's stream: kernels then run one after the other, which is what a per-kernel profile
+    needs (durations of overlapping kernels stretch each other; scripts/make_profiles.sh uses it for attribution)."""
+    import os
+
+    if os.environ.get("MLQEM_SINGLE_STREAM", "0") == "1":
+        cur = torch.cuda.current_stream(device)
+        return (cur, cur)
     key = torch.device(device).index
     if key not in _side_streams:
         _side_streams[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))

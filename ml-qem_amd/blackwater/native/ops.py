@@ -102,6 +102,17 @@ def _vec(t: Optional[torch.Tensor], name: str, n: int, dtype=torch.float32):
                          f"{tuple(t.shape)} {t.dtype} {t.device}")
 
 
+def _owns_pad_columns(t, name):
+    """The aggregation kernels move 16 bytes per lane whenever the operands' rows are 16-byte aligned, and then WRITE
+    the columns between C and round_up(C, 4) of the output along with the rest.  In the padded row layout
+    (``padded_empty``) those columns are scratch; in a column slice of a wider matrix they are a neighbour's data."""
+    c = t.shape[1]
+    c4 = (c + 3) // 4 * 4
+    if c % 4 and t.shape[0] > 1 and t.stride(0) != c4 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        raise ValueError(f"{name}: [N, {c}] view with row stride {t.stride(0)}: the kernel would overwrite columns {c}..{c4 - 1} "
+                         f"of every row; write into a padded_empty(N, {c}) buffer instead")
+
+
 def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None, alpha=1.0, z=None, beta=0.0, bias=None,
                   relu=False, drop_p=0.0, seed=0, out=None):
     """out = act(alpha * (rscale * sum_e cscale[idx[e]] x[idx[e]] + dself * x) + beta * z + bias)."""
@@ -115,6 +126,8 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
     _vec(bias, "bias", c)
     if out is None:
         out = padded_empty(n, c, x.device)
+    else:
+        _owns_pad_columns(out, "out")
     ldo = _mat(out, "out")
     ldz = 0
     if z is not None:
@@ -151,6 +164,8 @@ def csr_segment_max(x, ptr, idx, ell=None, out=None):
     _ell(ell, n)
     if out is None:
         out = padded_empty(n, c, x.device)
+    else:
+        _owns_pad_columns(out, "out")
     code = _lib.load().mlqem_csr_segment_max_f32(_p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(out), _mat(out, "out"), n, c,
                                                  _stream())
     _lib.check(code, "mlqem_csr_segment_max_f32")

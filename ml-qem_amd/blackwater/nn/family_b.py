@@ -18,7 +18,7 @@ from ..native import ops
 from ..native.structure import GraphStructure
 from .conv import _kaiming_linear, _WeightOnly
 from .mlp import MLP2, MLP3
-from .models import _Seq, as_structure
+from .models import _Seq, as_structure, dropout_key
 
 
 def _lin(in_f, out_f, bias=True):
@@ -44,7 +44,7 @@ class TransformerConv(nn.Module):
         self._calls = getattr(self, "_calls", 0) + 1
         drop = self.dropout if self.training else 0.0
         return F.transformer_conv(x, w, b, struct, self.heads, self.out_channels, drop_p=drop,
-                                  seed=self._calls * 104729 + id(self) % 9973)
+                                  seed=dropout_key(self._calls, salt=self.heads * 1000003 + self.out_channels))
 
 
 class _LEConv(nn.Module):

@@ -26,6 +26,17 @@ def as_structure(edge_index: Union[torch.Tensor, GraphStructure], num_nodes: int
     return GraphStructure.from_edge_index(edge_index, num_nodes, batch=batch, num_graphs=num_graphs)
 
 
+def dropout_key(call: int, salt: int = 0) -> int:
+    """Key of the counter-based dropout masks of one forward call: a function of torch's seed (so runs are reproducible
+    under ``torch.manual_seed`` and differ between seeds, like the reference's ``nn.Dropout``), of the data-parallel
+    rank (replicas draw different masks) and of the module's call counter."""
+    rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+    z = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (rank + 1) + 0xBF58476D1CE4E5B9 * (call + 1) + salt) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
+
+
 class _Seq(nn.Module):
     """Two Linear layers at indices 0 and 2 (index 1 is the reference's Dropout), PyG/torch key names."""
 
@@ -60,21 +71,7 @@ class ExpValCircuitGraphModelA(nn.Module):
         self._step = 0
 
     def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
-        """Layer-by-layer path by default.  ``self.fused = True`` selects the single-node schedule of
-        nn/family_a_fused.py (same maths; measured SLOWER on MI355X because column slices of wide rows waste cache-line
-        sectors in the aggregation gathers -- kept as a tested alternative schedule)."""
-        if not getattr(self, "fused", False):
-            return self.forward_layers(exp_value, observable, circuit_depth, nodes, edge_index, batch)
-        from .family_a_fused import family_a_graph_part
-
-        if isinstance(nodes, ops.RowsOf):
-            nodes = nodes.materialize()
-        b = exp_value.shape[0]
-        s = as_structure(edge_index, nodes.shape[0], batch, b)
-        self._step += 1
-        pooled = family_a_graph_part(self, nodes, s, self.training, self._step * 7919)
-        obs = torch.mean(self.obs_seq(observable), dim=1)
-        return self.body_seq(torch.cat((pooled, obs, circuit_depth, exp_value), dim=1))
+        return self.forward_layers(exp_value, observable, circuit_depth, nodes, edge_index, batch)
 
     def _graph_params(self):
         c1, c2, s1, s2 = self.cheb_conv1, self.cheb_conv2, self.sage_conv1, self.sage_conv2
@@ -95,7 +92,7 @@ class ExpValCircuitGraphModelA(nn.Module):
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         train = self.training
         self._step += 1
-        seed = self._step * 7919
+        seed = dropout_key(self._step)
         # Each hidden activation has exactly one consumer -- the next layer of its branch -- so the ReLU/dropout mask of
         # its backward is applied by that consumer's data-gradient GEMM (native/functional.py, "Mask hand-over").
         p1, p2 = (0.1, 0.2) if train else (0.0, 0.0)

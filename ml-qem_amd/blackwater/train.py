@@ -80,6 +80,30 @@ class Trainer:
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", factor=0.1, patience=15,
                                                                     min_lr=1e-5)
         self.criterion = nn.MSELoss()
+        if self.distributed:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self, src: int = 0):
+        """Every replica starts from rank ``src``'s parameters and buffers (what DistributedDataParallel does at
+        construction): a rank seeded differently, or restored from another checkpoint, cannot silently average gradients
+        over diverging replicas."""
+        with torch.no_grad():
+            if self.flat_param is not None:
+                torch.distributed.broadcast(self.flat_param.data, src=src)
+            else:
+                for p in self.model.parameters():
+                    torch.distributed.broadcast(p.data, src=src)
+            for b in self.model.buffers():
+                torch.distributed.broadcast(b.data, src=src)
+
+    def _agreed_min(self, n: int) -> int:
+        """min over ranks of a host integer (1 collective); ``n`` itself outside torch.distributed."""
+        if not self.distributed:
+            return int(n)
+        dev = self.flat_param.device if self.flat_param is not None else next(self.model.parameters()).device
+        t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        return int(t.item())
 
     # -- one optimisation step on an assembled batch -------------------------------------------------------
     def step(self, batch) -> torch.Tensor:
@@ -147,13 +171,20 @@ class Trainer:
         return torch.cat(outs, dim=0)
 
     def fit(self, arena, train_ids, val_ids, epochs: int, batch_size: int = 32, seed: int = 0, log: Callable = None):
-        """Epoch loop with per-epoch shuffling (seed + epoch) and the reference's LR schedule."""
+        """Epoch loop with per-epoch shuffling (seed + epoch) and the reference's LR schedule.
+
+        Under data parallelism every step ends in a gradient all-reduce, so all ranks must run the SAME number of steps:
+        the per-epoch step count is agreed once (min over ranks of this rank's batch count); a rank whose shard holds a
+        few graphs more -- round-robin shards differ by one -- leaves its surplus out of that epoch (a different surplus
+        each epoch, the permutation is reseeded)."""
         history = {"train_losses": [], "val_losses": []}
+        train_ids = np.asarray(train_ids)
+        steps_per_epoch = self._agreed_min(-(-len(train_ids) // batch_size))
         for epoch in range(epochs):
             rng = np.random.RandomState(seed + epoch)
-            order = rng.permutation(np.asarray(train_ids))
+            order = rng.permutation(train_ids)
             running, n_batches = None, 0
-            for i in range(0, len(order), batch_size):
+            for i in range(0, steps_per_epoch * batch_size, batch_size):
                 loss = self.step(arena.batch(order[i:i + batch_size]))
                 running = loss if running is None else running + loss
                 n_batches += 1

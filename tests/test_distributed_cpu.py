@@ -118,3 +118,51 @@ def test_trainer_step_equals_plain_adam_and_handles_unused_parameters():
     assert torch.allclose(finals[0], finals[2], rtol=1e-6, atol=1e-7)
     assert torch.allclose(finals[1], finals[2], rtol=1e-6, atol=1e-7)
     assert torch.equal(finals[0][:3], torch.ones(3))         # the unused parameter (first in parameters()) never moved
+
+
+class _ToyArena:
+    """arena.batch(ids) over in-memory rows (the Trainer.fit protocol)."""
+
+    def __init__(self, X, Y):
+        self.X, self.Y = X, Y
+
+    def batch(self, ids):
+        ids = torch.as_tensor(np.asarray(ids), dtype=torch.long)
+        return _ToyBatch(self.X[ids], self.Y[ids])
+
+
+def _fit_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(rank)          # DIFFERENT seeds: the Trainer must bring every replica to rank 0's parameters
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    trainer = Trainer(model, lr=1e-2, distributed=True)
+    torch.save(trainer.flat_param.detach().clone(), os.path.join(out_dir, f"init{rank}.pt"))
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(80, 6, generator=g), torch.randn(80, 2, generator=g)
+    # round-robin shards of an ODD corpus: 33 vs 32 training graphs at batch 32 -> 2 vs 1 batches per epoch
+    mine = np.arange(rank, 65, world)
+    steps = []
+    orig_step = trainer.step
+    trainer.step = lambda b: (steps.append(1), orig_step(b))[1]
+    hist = trainer.fit(_ToyArena(X, Y), mine, np.arange(70 + rank, 80, world), epochs=3, batch_size=32)
+    torch.save({"steps": len(steps), "param": trainer.flat_param.detach().clone(), "hist": hist},
+               os.path.join(out_dir, f"fit{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_fit_agrees_on_step_count_and_initial_parameters(tmp_path):
+    """An odd corpus gives the two ranks different batch counts; every step ends in an all-reduce, so an unmatched
+    step would hang the job (round-1 advisor finding).  Also: replicas built from different seeds start from rank 0's
+    parameters."""
+    port = _free_port()
+    mp.spawn(_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    i0, i1 = (torch.load(tmp_path / f"init{r}.pt") for r in (0, 1))
+    assert torch.equal(i0, i1)
+    torch.manual_seed(0)
+    want = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    assert torch.equal(i0, torch.cat([p.detach().reshape(-1) for p in want.parameters()]))
+    f0, f1 = (torch.load(tmp_path / f"fit{r}.pt", weights_only=False) for r in (0, 1))
+    assert f0["steps"] == f1["steps"] == 3                    # min(2, 1) batches x 3 epochs on BOTH ranks
+    assert torch.equal(f0["param"], f1["param"])
+    assert f0["hist"]["val_losses"] == f1["hist"]["val_losses"]

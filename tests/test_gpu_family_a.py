@@ -97,30 +97,18 @@ def test_single_node_and_per_layer_paths_are_the_same_arithmetic(g1):
 
 
 def test_train_mode_dropout_runs_and_is_seeded(g1):
-    model, _ = _models()
+    """Dropout masks are keyed by torch's seed (nn/models.py dropout_key): the same seed reproduces a run bit for bit,
+    another seed draws other masks -- the behaviour of the reference's nn.Dropout under torch.manual_seed."""
     batch = g1_batch(g1, range(32))
-    args = [batch[k].to(DEV) for k in ARGS]
-    model.train()
-    out = model(*args)
-    torch.nn.functional.mse_loss(out, batch["y"].to(DEV)).backward()
-    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
-
-
-def test_fused_and_layerwise_paths_agree(g1):
-    """The fused graph node and the layer-by-layer modules are two schedules of one computation."""
-    model, _ = _models(seed=2)
-    batch = g1_batch(g1, range(10, 58))
-    args = [batch[k].to(DEV) for k in ARGS]
-    model.eval()
-    outs, grads = [], []
-    for fused in (True, False):
-        model.fused = fused
-        model.zero_grad()
+    outs = []
+    for seed in (11, 11, 12):
+        model, _ = _models()
+        args = [batch[k].to(DEV) for k in ARGS]
+        torch.manual_seed(seed)
+        model.train()
         out = model(*args)
         torch.nn.functional.mse_loss(out, batch["y"].to(DEV)).backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
         outs.append(out.detach().clone())
-        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
-    assert (outs[0] - outs[1]).abs().max().item() < 2e-6
-    for k in grads[0]:
-        scale = grads[1][k].abs().max().item() + 1e-9
-        assert (grads[0][k] - grads[1][k]).abs().max().item() / scale < 1e-4, k
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2])
