@@ -8,9 +8,8 @@ from bench import build_corpus, fixed_ids as bench_fixed_ids
 from blackwater.data.arena import GraphArena
 from blackwater.native import ops
 corpus = build_corpus(50)
-arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
-                               corpus["observable"], device="cuda:0")
-n_graphs = len(corpus["x"])
+arena = corpus.arena("cuda:0")
+n_graphs = len(corpus)
 s = arena.batch(bench_fixed_ids(n_graphs)).structure
 n, dev = s.num_nodes, torch.device("cuda:0")
 tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MLQEM_AGG"))

@@ -12,13 +12,12 @@ from blackwater.train import Trainer
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else bench.DEFAULT_BATCH
 dev = torch.device("cuda", 0)
 corpus = bench.build_corpus(50)
-arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
-                               corpus["observable"], device=dev)
+arena = corpus.arena(dev)
 torch.manual_seed(0)
 model = ExpValCircuitGraphModelA(100, 22, 10).to(dev)
 trainer = Trainer(model, lr=1e-3)
 rng = np.random.RandomState(1000)
-draw = lambda: rng.randint(0, len(corpus["x"]), size=batch)
+draw = lambda: rng.randint(0, len(corpus), size=batch)
 for _ in range(5):
     trainer.step(arena.batch(draw()))
 torch.cuda.synchronize()

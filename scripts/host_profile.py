@@ -10,7 +10,7 @@ from blackwater.nn import ExpValCircuitGraphModelA
 from blackwater.native import functional as F
 dev = torch.device("cuda", 0)
 corpus = bench.build_corpus(4)
-arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"], corpus["observable"], device=dev)
+arena = corpus.arena(dev)
 torch.manual_seed(0)
 model = ExpValCircuitGraphModelA(100, 22, 10).to(dev).train()
 rng = np.random.RandomState(0)

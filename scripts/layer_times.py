@@ -11,9 +11,8 @@ from blackwater.nn.conv import ChebConv, GCNConv, SAGEConv
 
 dev = torch.device("cuda", 0)
 corpus = bench.build_corpus(50)
-arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
-                               corpus["observable"], device=dev)
-n_graphs = len(corpus["x"])
+arena = corpus.arena(dev)
+n_graphs = len(corpus)
 b = arena.batch(bench_fixed_ids(n_graphs))
 s, x = b.structure, b.x
 n = x.shape[0]

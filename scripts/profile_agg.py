@@ -9,9 +9,8 @@ from blackwater.native import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 c = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 corpus = build_corpus(50)
-arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
-                               corpus["observable"], device="cuda:0")
-n_graphs = len(corpus["x"])
+arena = corpus.arena("cuda:0")
+n_graphs = len(corpus)
 b = arena.batch(bench_fixed_ids(n_graphs))
 s = b.structure
 n = s.num_nodes

@@ -7,7 +7,7 @@ from blackwater.nn import ExpValCircuitGraphModelA
 from blackwater.train import Trainer
 dev = torch.device("cuda", 0)
 corpus = bench.build_corpus(50)
-arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"], corpus["observable"], device=dev)
+arena = corpus.arena(dev)
 torch.manual_seed(0)
 model = ExpValCircuitGraphModelA(100, 22, 10).to(dev)
 tr = Trainer(model, lr=1e-3)

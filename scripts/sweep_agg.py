@@ -7,9 +7,8 @@ from bench import build_corpus
 from blackwater.data.arena import GraphArena
 from blackwater.native import ops
 corpus = build_corpus(50)
-arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
-                               corpus["observable"], device="cuda:0")
-n_graphs = len(corpus["x"])
+arena = corpus.arena("cuda:0")
+n_graphs = len(corpus)
 s = arena.batch(np.arange(256) * n_graphs // 256).structure
 n = s.num_nodes
 dev = torch.device("cuda:0")

@@ -121,8 +121,8 @@ def test_family_b_100q_predictions_within_1e5_of_fp64_oracle():
     """Family B (TransformerConv / ASAPooling x2 / mean pool / head) on the same three circuits, exp_value_size 4.
     The pooling's top-k is a discrete choice: the test first checks that the device and the fp64 oracle keep the same
     clusters at both poolings (a near-tie at the k-th place may legitimately resolve differently in fp32), then the
-    1e-5 tolerance on the predictions -- relative to the prediction scale, which is ~20 here because the raw circuit
-    depth (up to 331) enters the head un-normalised (gnn.py:118-120)."""
+    1e-5 tolerance on the predictions (absolute, although the predictions are ~20 in magnitude here because the raw
+    circuit depth, up to 331, enters the head un-normalised, gnn.py:118-120)."""
     from blackwater.native.structure import GraphStructure
     from blackwater.nn import ExpValCircuitGraphModel
     from oracle.models import FamilyB
@@ -167,4 +167,4 @@ def test_family_b_100q_predictions_within_1e5_of_fp64_oracle():
     rec["relative_gpu_vs_f64"] = rec["gpu_vs_f64"] / max(1.0, rec["prediction_scale"])
     _record("family_b_seed0", rec)
     assert all(same_clusters), rec
-    assert rec["relative_gpu_vs_f64"] < TOL, rec
+    assert rec["gpu_vs_f64"] < TOL, rec

@@ -53,9 +53,10 @@ def test_trainer_step_over_rccl_world1(g1):
 
 
 def test_bench_two_ranks_on_one_gpu_rehearsal():
-    """bench.py's multi-rank control flow (rendezvous, per-rank draws, barrier-bracketed timing, MAX over ranks, rank-0
-    JSON line, joint shutdown) with two ranks sharing this box's single GPU over gloo -- the driver's real runs use one
-    GPU per rank over RCCL, which one GPU cannot host."""
+    """Plain ``python bench.py --gpus 2`` (the shape of the driver's command): bench.py starts the two ranks itself before
+    touching the GPU, each rank builds ITS shard of the corpus, and rank 0 prints the one line.  The two ranks share this
+    box's single GPU over gloo (MLQEM_BENCH_BACKEND) -- the driver's real runs use one GPU per rank over RCCL, which one
+    GPU cannot host."""
     import json
     import os
     import subprocess
@@ -63,17 +64,16 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MLQEM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "32", "--n-j", "4"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1                                    # rank 0 only
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
-    assert rec["config"]["parallelism"] == "dp2" and "cpu_baseline" not in rec and rec["roofline"]["frac"] > 0
+    cfg = rec["config"]
+    assert cfg["parallelism"] == "dp2" and cfg["ranks_joined"] == 2 and "cpu_baseline" not in rec and rec["roofline"]["frac"] > 0
+    # corpus = 8 x batch x ranks circuits (rounded up to whole J grids), each rank holds half of it
+    assert cfg["corpus_circuits"] >= 8 * 32 * 2 and cfg["corpus_circuits_per_gpu"] == cfg["corpus_circuits"] // 2

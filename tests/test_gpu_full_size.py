@@ -18,12 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def full_batch():
     sys.path.insert(0, ROOT)
     import bench
-    from blackwater.data.arena import GraphArena
 
-    corpus = bench.build_corpus(50)
-    arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"], corpus["noisy"], corpus["depth"],
-                                   corpus["observable"], device=DEV)
-    ids = bench.fixed_ids(len(corpus["x"]))
+    corpus = bench.build_corpus(103)          # 1 030 circuits, replicated from the ten templates on the device
+    arena = corpus.arena(DEV)
+    ids = bench.fixed_ids(len(corpus))
     return arena, ids, arena.batch(ids)
 
 
