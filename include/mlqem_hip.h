@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 3 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 4 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -183,10 +183,26 @@ int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int6
 /* ------------------------------------------------------------------------------------------------------
  * Pooling over graphs.  Replaces global_mean_pool (docs/tutorials/gnn.py:114; 01_ngem.ipynb cell [9]).
  * ---------------------------------------------------------------------------------------------------- */
-int mlqem_segment_mean_f32(const float* x, int64_t ldx, const int32_t* graph_ptr, float* out, int64_t ldo,
-                           int64_t B, int C, mlqem_stream_t stream);
-int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph_ptr, float* gx, int64_t ldgx,
-                               int64_t B, int C, mlqem_stream_t stream);
+/* out_mean[g,:] = (1/n_g) sum_{r in graph g} x[r,:] and/or out_wmean[g,:] = (1/n_g) sum_r weights[r] * x[r,:] over the
+ * contiguous row range [graph_ptr[g], graph_ptr[g+1]) of every graph (either output may be NULL, not both; weights may be
+ * NULL = 1; an empty graph gives 0).  The weighted form is the last conv layer of a Family A branch folded into its
+ * pool: mean_pool(P (h W^T)) = wmean(h) W^T with weights = P^T 1, the column sums of the layer's propagation matrix
+ * (01_ngem.ipynb cell [9] puts no non-linearity between conv3 / cheb_conv2 / sage_conv2 and global_mean_pool).
+ * Rows are tiled over workgroups (1024 rows each, whatever graph they belong to), per-(tile, graph) partial sums are
+ * added in tile order by a second kernel: balanced for graphs of 7 ... 20 000 nodes, deterministic, no atomics.
+ * workspace: mlqem_segment_pool_workspace_bytes(N, B, C) bytes. */
+size_t mlqem_segment_pool_workspace_bytes(int64_t N, int64_t B, int C);
+int mlqem_segment_pool_f32(const float* x, int64_t ldx, const float* weights, const int32_t* graph_ptr, int64_t N, int64_t B,
+                           int C, float* out_mean, int64_t ld_mean, float* out_wmean, int64_t ld_wmean, void* workspace,
+                           size_t workspace_bytes, mlqem_stream_t stream);
+/* Backward: gx[r,:] = (g_mean[g,:] + weights[r] * g_wmean[g,:]) / n_g for every row r of graph g (either gradient may be
+ * NULL); gate (may be NULL), applied last: gx = gate[r,:] > 0 ? gx * gate_scale : 0 -- the ReLU/dropout mask of the
+ * pooled activation, see mlqem_linear_f32.  16-byte accesses when gx, gate AND the [B,C] gradients own round_up(C,4)
+ * columns per row. */
+int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const float* g_wmean, int64_t ld_gwmean,
+                               const float* weights, const int32_t* graph_ptr, int64_t N, int64_t B, int C,
+                               const float* gate, int64_t ldgate, float gate_scale, float* gx, int64_t ldgx,
+                               mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Batch assembly from a device-resident dataset.  Replaces torch_geometric.loader.DataLoader's collate

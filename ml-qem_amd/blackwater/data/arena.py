@@ -54,16 +54,17 @@ def _ranges(starts, lengths):
 
 
 class GraphArena:
-    def __init__(self, x, node_counts, structure_arrays, nscal, y, noisy, depth, observable, edge_counts):
+    def __init__(self, x, node_counts, structure_arrays, nscal, y, noisy, depth, observable, edge_counts, ell=None):
         self.x = x
         self.node_counts = np.asarray(node_counts, dtype=np.int64)
         self.edge_counts = np.asarray(edge_counts, dtype=np.int64)
         self.gptr, self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops, self.out_eid = structure_arrays
         n_total = int(self.node_counts.sum())
         # ELL side tables of the whole arena: a batch's tables are these rows, rebased (no per-batch CSR walk)
-        self.in_ell = ops.ell_from_csr(self.in_ptr, self.in_src, n_total)
-        self.out_ell = ops.ell_from_csr(self.out_ptr, self.out_dst, n_total)
-        self.nscal = nscal  # [N,3]: gcn_dinv, sage_rinv, cheb_dinv
+        if ell is None:
+            ell = (ops.ell_from_csr(self.in_ptr, self.in_src, n_total), ops.ell_from_csr(self.out_ptr, self.out_dst, n_total))
+        self.in_ell, self.out_ell = ell
+        self.nscal = nscal  # [N,6]: gcn_dinv, sage_rinv, cheb_dinv, then the column sums P^T 1 of the three convs (structure.colsum)
         self.y, self.noisy, self.depth, self.observable = y, noisy, depth, observable
         self.device = x.device
 
@@ -146,13 +147,18 @@ class GraphArena:
         csr = ops.csr_build(ei_dev, n_total)
         in_ptr, in_src, out_ptr, out_dst, loops = csr
         gcn, sage, cheb = ops.graph_norms(in_ptr, out_ptr, loops, n_total)
-        nscal = torch.stack([gcn, sage, cheb], dim=1).contiguous()
         gptr = torch.from_numpy(offs.astype(np.int32)).to(device)
+        # column sums of the three propagation matrices: structural, so computed once for the whole arena
+        ell = (ops.ell_from_csr(in_ptr, in_src, n_total), ops.ell_from_csr(out_ptr, out_dst, n_total))
+        whole = GraphStructure(n_total, in_ptr, in_src, out_ptr, out_dst, loops, gptr, len(node_counts), norms=(gcn, sage, cheb),
+                               ell=ell)
+        nscal = torch.stack([gcn, sage, cheb, whole.colsum("gcn"), whole.colsum("sage"), whole.colsum("cheb")], dim=1).contiguous()
+        del whole
         # edges per graph (self-loops excluded): one read-back at build time
         edge_counts = np.diff(in_ptr[gptr.long()].cpu().numpy()).astype(np.int64)
         t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
         return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops, csr.out_eid), nscal, t(y), t(noisy),
-                          t(depth), t(observable), edge_counts)
+                          t(depth), t(observable), edge_counts, ell=ell)
 
     @staticmethod
     def from_data_list(graphs, device="cuda") -> "GraphArena":
@@ -181,7 +187,8 @@ class GraphArena:
         sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:]
         dev, f = self.device, self.x.shape[1]
         f4 = (f + 3) // 4 * 4
-        nscal_b = torch.empty((3, max(nb, 1)), dtype=torch.float32, device=dev)   # planar: one contiguous vector per norm
+        k = int(self.nscal.shape[1])
+        nscal_b = torch.empty((k, max(nb, 1)), dtype=torch.float32, device=dev)   # planar: one contiguous vector per scalar
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
         in_src, out_dst, out_eid = mk(eb), mk(eb), mk(eb)
@@ -189,14 +196,15 @@ class GraphArena:
         out_ell = torch.empty((max(nb, 1), 2), dtype=torch.int32, device=dev)
         p = ops._p
         code = _lib.load().mlqem_batch_assemble(
-            p(self.x), self.x.stride(0), f4, p(self.nscal), 3, p(self.gptr), p(self.in_ptr), p(self.in_src),
+            p(self.x), self.x.stride(0), f4, p(self.nscal), k, p(self.gptr), p(self.in_ptr), p(self.in_src),
             p(self.out_ptr), p(self.out_dst), p(self.out_eid), p(self.loops), p(self.in_ell), p(self.out_ell), p(sel_d),
             p(nptr_d), p(eptr_d), b, nb, eb, None, 0, p(nscal_b), p(src_node), p(in_ptr), p(in_src),
             p(out_ptr), p(out_dst), p(out_eid), p(loops), p(in_ell), p(out_ell), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[0, :nb], nscal_b[1, :nb], nscal_b[2, :nb])
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,
-                           graph_sizes=self.node_counts[sel], out_eid=out_eid, ell=(in_ell, out_ell))
+                           graph_sizes=self.node_counts[sel], out_eid=out_eid, ell=(in_ell, out_ell),
+                           colsums=(nscal_b[3, :nb], nscal_b[4, :nb], nscal_b[5, :nb]))
         idx = sel_d.to(torch.int64)
         nodes = ops.RowsOf(self.x, src_node[:nb])     # the feature rows stay in the arena
         return DeviceBatch(nodes, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)

@@ -50,8 +50,9 @@ SIGNATURES = {
     "mlqem_linear_wgrad_workspace_bytes": (_S, [_I, _I]),
     "mlqem_linear_wgrad_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P, _P]),
     "mlqem_linear_wgrad_parts_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P, _P]),
-    "mlqem_segment_mean_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P]),
-    "mlqem_segment_mean_bwd_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P]),
+    "mlqem_segment_pool_workspace_bytes": (_S, [_L, _L, _I]),
+    "mlqem_segment_pool_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P, _L, _P, _L, _P, _S, _P]),
+    "mlqem_segment_pool_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _L, _F, _P, _L, _P]),
     "mlqem_transformer_attention_f32": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
     "mlqem_csr_softmax_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _F, _L, _I, _P, _L, _P]),
     "mlqem_leconv_fitness_f32": (_I, [_P, _P, _P, _L, _P, _P]),
@@ -80,7 +81,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 4   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

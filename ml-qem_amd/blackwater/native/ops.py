@@ -374,28 +374,72 @@ def linear_wgrad(gy, x, gw, gb=None, accumulate=False):
     _lib.check(code, "mlqem_linear_wgrad_f32")
 
 
-def segment_mean(x, graph_ptr, num_graphs):
+_pool_ws = {}   # (device, stream, bytes) -> partial-sum workspace of the pooling kernels (per stream, like _wgrad_ws)
+
+
+def segment_pool(x, graph_ptr, num_graphs, weights=None, mean=True, wmean=False):
+    """(mean, wmean): mean[g] = (1/n_g) sum_{r in g} x[r], wmean[g] = (1/n_g) sum_r weights[r] x[r]; either may be skipped
+    (None is returned in its place).  Outputs are [B, C] in the padded row layout."""
     x = rowmajor(x)
-    c = x.shape[1]
+    n, c = x.shape
+    if not (mean or wmean):
+        raise ValueError("segment_pool: nothing to compute")
     _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
-    out = torch.empty((num_graphs, c), dtype=torch.float32, device=x.device)
-    code = _lib.load().mlqem_segment_mean_f32(_p(x), _mat(x, "x"), _p(graph_ptr), _p(out), _mat(out, "out"),
-                                              num_graphs, c, _stream())
-    _lib.check(code, "mlqem_segment_mean_f32")
-    return out
+    if wmean:
+        _vec(weights, "weights", n)
+    lib = _lib.load()
+    need = lib.mlqem_segment_pool_workspace_bytes(n, num_graphs, c)
+    key = (x.device, _stream(), need)
+    ws = _pool_ws.get(key)
+    if ws is None:
+        ws = _pool_ws[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
+    o0 = padded_empty(num_graphs, c, x.device) if mean else None
+    o1 = padded_empty(num_graphs, c, x.device) if wmean else None
+    ld = lambda t: 0 if t is None else (int(t.stride(0)) if num_graphs > 1 else (c + 3) // 4 * 4)
+    code = lib.mlqem_segment_pool_f32(_p(x), _mat(x, "x"), _p(weights) if wmean else None, _p(graph_ptr), n, num_graphs, c,
+                                      _p(o0), ld(o0), _p(o1), ld(o1), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_segment_pool_f32")
+    return o0, o1
+
+
+def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=None, gate_scale=1.0, out=None):
+    """gx[r] = (g_mean[g] + weights[r] g_wmean[g]) / n_g (either gradient may be None), optionally gated by gate > 0."""
+    ref = g_mean if g_mean is not None else g_wmean
+    if ref is None:
+        raise ValueError("segment_pool_bwd: no gradient given")
+    b, c = ref.shape
+
+    def padded(t):   # the [B, C] gradients are tiny: give them 16-byte rows so the kernel keeps one vector width
+        if t is None:
+            return None
+        if tuple(t.shape) != (b, c):
+            raise ValueError("segment_pool_bwd: gradients must share one shape")
+        ok = t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and \
+            t.stride(0) >= (c + 3) // 4 * 4 and t.data_ptr() % 16 == 0
+        return t if ok else padded_copy(t)
+
+    g_mean, g_wmean = padded(g_mean), padded(g_wmean)
+    _vec(graph_ptr, "graph_ptr", b + 1, torch.int32)
+    if g_wmean is not None:
+        _vec(weights, "weights", num_nodes)
+    gx = padded_empty(num_nodes, c, ref.device) if out is None else out
+    if tuple(gx.shape) != (num_nodes, c):
+        raise ValueError("segment_pool_bwd: bad out shape")
+    gp, gld = _gate(gate, num_nodes, c, False)
+    ld = lambda t: 0 if t is None else (int(t.stride(0)) if b > 1 else (c + 3) // 4 * 4)
+    code = _lib.load().mlqem_segment_pool_bwd_f32(_p(g_mean), ld(g_mean), _p(g_wmean), ld(g_wmean),
+                                                  _p(weights) if g_wmean is not None else None, _p(graph_ptr), num_nodes, b, c,
+                                                  gp, gld, float(gate_scale), _p(gx), _mat(gx, "gx"), _stream())
+    _lib.check(code, "mlqem_segment_pool_bwd_f32")
+    return gx
+
+
+def segment_mean(x, graph_ptr, num_graphs):
+    return segment_pool(x, graph_ptr, num_graphs)[0]
 
 
 def segment_mean_bwd(g, graph_ptr, num_nodes, out=None):
-    b, c = g.shape
-    g = rowmajor(g)
-    _vec(graph_ptr, "graph_ptr", b + 1, torch.int32)
-    gx = padded_empty(num_nodes, c, g.device) if out is None else out
-    if gx.shape != (num_nodes, c):
-        raise ValueError("segment_mean_bwd: bad out shape")
-    code = _lib.load().mlqem_segment_mean_bwd_f32(_p(g), _mat(g, "g"), _p(graph_ptr), _p(gx), _mat(gx, "gx"), b, c,
-                                                  _stream())
-    _lib.check(code, "mlqem_segment_mean_bwd_f32")
-    return gx
+    return segment_pool_bwd(rowmajor(g), None, graph_ptr, num_nodes, out=out)
 
 
 class CsrArrays(tuple):

@@ -14,7 +14,7 @@ from . import ops
 
 class GraphStructure:
     def __init__(self, num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs, num_edges=None,
-                 norms=None, graph_sizes=None, out_eid=None, ell=None):
+                 norms=None, graph_sizes=None, out_eid=None, ell=None, colsums=None):
         self.num_nodes = int(num_nodes)
         self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops = in_ptr, in_src, out_ptr, out_dst, loops
         self.graph_ptr, self.num_graphs = graph_ptr, int(num_graphs)
@@ -22,6 +22,7 @@ class GraphStructure:
         self.out_eid = out_eid      # in-CSR position of every out-CSR entry (edge-softmax backward)
         self._norms = norms
         self._derived = {}
+        self._colsum = {} if colsums is None else dict(zip(("gcn", "sage", "cheb"), colsums))
         self._ell = {} if ell is None else {"in": ell[0], "out": ell[1]}   # side tables, built on demand otherwise
         self._graph_sizes = None if graph_sizes is None else [int(v) for v in graph_sizes]
 
@@ -97,6 +98,27 @@ class GraphStructure:
         if "out" not in self._ell:
             self._ell["out"] = ops.ell_from_csr(self.out_ptr, self.out_dst, self.num_nodes)
         return self._ell["out"]
+
+    def colsum(self, kind):
+        """t = P^T 1, the column sums of a conv's propagation matrix P (``gcn``: D^-1/2 (A+I) D^-1/2, ``sage``: the in-edge
+        mean incl. listed self-loops, ``cheb``: L^ = -D^-1/2 A D^-1/2) -- one structural scalar per node.  A conv that
+        feeds a mean pool directly collapses onto it: mean_pool(P (h W^T)) = wmean_t(h) W^T (csrc/pool.hip).  Batches of
+        a :class:`GraphArena` carry these from the arena (graphs are disjoint, so a node's column sum does not depend
+        on the batch it is in); otherwise they are one transposed aggregation of the ones vector, cached."""
+        if kind not in self._colsum:
+            ones = torch.ones((max(self.num_nodes, 1), 1), dtype=torch.float32, device=self.in_ptr.device)[:self.num_nodes]
+            if kind == "gcn":
+                kw = dict(cscale=self.gcn_dinv, rscale=self.gcn_dinv, dself=self.derived("gcn_dself"))
+            elif kind == "sage":
+                kw = dict(cscale=self.sage_rinv, dself=self.derived("sage_dself"))
+            elif kind == "cheb":
+                kw = dict(cscale=self.derived("cheb_neg"), rscale=self.cheb_dinv)
+            else:
+                raise KeyError(kind)
+            out = torch.empty_like(ones)
+            ops.csr_aggregate(ones, self.out_ptr, self.out_dst, ell=self.out_ell, out=out, **kw)
+            self._colsum[kind] = out[:, 0]
+        return self._colsum[kind]
 
     def derived(self, key):
         """Per-node scalars derived from the base norms, cached per structure (tiny elementwise torch ops)."""

@@ -1,53 +1,187 @@
-// Mean pooling over the contiguous node range of each graph (global_mean_pool) and its backward.
+// Pooling over the contiguous node range of each graph (global_mean_pool, docs/tutorials/gnn.py:114; 01_ngem.ipynb
+// cell [9]) and its backward -- with an optional per-node weight, which is what the last conv layer of a Family A
+// branch collapses to:  mean_pool(P (h W^T)) = (1/n_g) sum_j t_j (h_j W^T)  with  t = P^T 1  (column sums of the
+// propagation matrix P: a structural per-node scalar), because nothing non-linear sits between that conv and the pool.
+//
+// Work decomposition.  Graphs on this path have 7 ... 20,711 nodes, so a workgroup per graph is either starved or
+// alone with 20k rows (round 1: 5 % of the HBM peak).  Here the ROWS are tiled: a 256-thread workgroup owns kPoolRows
+// consecutive rows whatever graphs they belong to, walks the (tile, graph) segments inside its tile -- one or two for
+// 100-qubit graphs, a handful for 4-qubit graphs -- and reduces each with 16-byte row loads, several rows in flight per
+// thread, then an LDS tree in a fixed order.  A segment's partial sum goes to slot (tile + graph): both indices are
+// monotone along the row axis, so the slot is unique and < tiles + graphs.  A second tiny kernel adds a graph's slots in
+// tile order and divides by the node count: deterministic, no atomics.
 #include "common.hpp"
 
 namespace mlqem {
 
-// One block per graph: threads stride over the graph's rows, then the per-thread sums are added in a fixed order.
-// Graphs on this path have 7 ... 20,711 nodes and C <= 125 channels; a batch has a few hundred graphs, so the block is
-// made as large as the hardware allows (1024 threads = 16 waves) -- with 256 threads the 256-graph benchmark batch kept
-// one wave per SIMD busy and took 32 us per call for 45 MB.
-constexpr int kPoolBlock = 1024;
-__global__ __launch_bounds__(kPoolBlock) void segment_mean_kernel(const float* __restrict__ x, int64_t ldx,
-                                                                  const int32_t* __restrict__ gptr,
-                                                                  float* __restrict__ out, int64_t ldo, int C) {
-  constexpr int kBlock = kPoolBlock;   // shadows the library-wide block size inside this kernel
-  __shared__ float red[kBlock];
-  const int g = blockIdx.x;
-  const int beg = gptr[g], end = gptr[g + 1];
-  // lane layout: cl consecutive threads cover the channels of one row, kBlock/cl rows in flight
-  const int cl = C >= kBlock ? kBlock : C;
-  const int rows_par = kBlock / cl;
-  const int c_lane = threadIdx.x % cl, r_lane = threadIdx.x / cl;
-  for (int c0 = 0; c0 < C; c0 += cl) {
-    const int c = c0 + c_lane;
-    float s = 0.f;
-    if (r_lane < rows_par && c < C)
-      for (int r = beg + r_lane; r < end; r += rows_par) s += x[(int64_t)r * ldx + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (r_lane == 0 && c < C) {
-      float tot = 0.f;
-      for (int k = 0; k < rows_par; ++k) tot += red[k * cl + c_lane];
-      const int n = end - beg;
-      out[(int64_t)g * ldo + c] = n > 0 ? tot / (float)n : 0.f;
+constexpr int kPoolRows = 1024;   // rows per workgroup
+constexpr int kPoolUnroll = 4;    // rows a thread has in flight
+
+struct PoolArgs {
+  const float* x; int64_t ldx;
+  const float* wts;          // optional [N]
+  const int32_t* gptr;       // [B+1]
+  int64_t N; int B; int C; int CV;   // CV = ceil(C / VEC) channel slices per row
+  float* partial;            // [(tiles + B)][2][CV * VEC]
+};
+
+// largest g in [0, B) with gptr[g] <= r (gptr[0] = 0 <= r): the graph of row r, or of the empty graphs just before it
+__device__ __forceinline__ int graph_at(const int32_t* __restrict__ gptr, int B, int64_t r) {
+  int lo = 0, hi = B;   // invariant: gptr[lo] <= r < gptr[hi] (gptr[B] = N > r)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)gptr[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void pool_partial_kernel(const PoolArgs a) {
+  __shared__ float s_red[kBlock][2 * VEC];
+  const int tid = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  const int64_t r0 = tile * kPoolRows, r1 = min(a.N, r0 + kPoolRows);
+  const int lanes_r = kBlock / a.CV;            // row lanes (>= 1: CV <= kBlock checked on the host)
+  const int cs = tid % a.CV, rl = tid / a.CV;
+  const bool worker = rl < lanes_r;
+  const int ch = cs * VEC;
+  const int q_lanes = min(16, lanes_r);         // second-level width of the LDS tree
+  const int slot_w = a.CV * VEC;
+  for (int g = graph_at(a.gptr, a.B, r0); g < a.B && (int64_t)a.gptr[g] < r1; ++g) {   // workgroup-uniform loop
+    const int64_t s0 = max(r0, (int64_t)a.gptr[g]), s1 = min(r1, (int64_t)a.gptr[g + 1]);
+    if (s1 <= s0) continue;                     // an empty graph
+    float acc0[VEC], acc1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc0[v] = acc1[v] = 0.f;
+    if (worker) {
+      for (int64_t r = s0 + rl; r < s1; r += (int64_t)lanes_r * kPoolUnroll) {
+        float xv[kPoolUnroll][VEC], w[kPoolUnroll];
+#pragma unroll
+        for (int u = 0; u < kPoolUnroll; ++u) {
+          const int64_t ru = r + (int64_t)u * lanes_r;
+          const bool ok = ru < s1;
+          const int64_t rr = ok ? ru : s0;      // a valid address; its contribution is zeroed below
+          vload<VEC>(a.x + rr * a.ldx + ch, xv[u]);
+          w[u] = a.wts ? a.wts[rr] : 1.f;
+          if (!ok) {
+            w[u] = 0.f;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xv[u][v] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kPoolUnroll; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            acc0[v] += xv[u][v];
+            acc1[v] = fmaf(w[u], xv[u][v], acc1[v]);
+          }
+      }
     }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s_red[tid][v] = acc0[v]; s_red[tid][VEC + v] = acc1[v]; }
     __syncthreads();
+    // second level: row lane q < Q adds lanes q, q + Q, q + 2Q, ... in that order, then lane 0 adds the Q sums
+    const bool second = worker && rl < q_lanes;
+    float t2[2 * VEC];
+#pragma unroll
+    for (int v = 0; v < 2 * VEC; ++v) t2[v] = 0.f;
+    if (second)
+      for (int k = rl; k < lanes_r; k += q_lanes)
+#pragma unroll
+        for (int v = 0; v < 2 * VEC; ++v) t2[v] += s_red[k * a.CV + cs][v];
+    __syncthreads();                            // every read of the first level is done
+    if (second)
+#pragma unroll
+      for (int v = 0; v < 2 * VEC; ++v) s_red[tid][v] = t2[v];
+    __syncthreads();
+    if (rl == 0) {
+      float t[2 * VEC];
+#pragma unroll
+      for (int v = 0; v < 2 * VEC; ++v) t[v] = 0.f;
+      for (int k = 0; k < q_lanes; ++k)
+#pragma unroll
+        for (int v = 0; v < 2 * VEC; ++v) t[v] += s_red[k * a.CV + cs][v];
+      float* dst = a.partial + ((tile + g) * 2) * slot_w + ch;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { dst[v] = t[v]; dst[slot_w + v] = t[VEC + v]; }
+    }
+    __syncthreads();                            // s_red is reused by the next segment
   }
 }
 
-__global__ __launch_bounds__(kBlock) void segment_mean_bwd_kernel(const float* __restrict__ g, int64_t ldg,
-                                                                  const int32_t* __restrict__ gptr,
-                                                                  float* __restrict__ gx, int64_t ldgx, int C) {
-  const int gi = blockIdx.x;
-  const int beg = gptr[gi], end = gptr[gi + 1];
-  const int n = end - beg;
-  if (n <= 0) return;
-  const float inv = 1.f / (float)n;
-  const int64_t total = (int64_t)n * C;
-  for (int64_t t = (int64_t)blockIdx.y * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.y * kBlock) {
-    const int r = (int)(t / C), c = (int)(t % C);
-    gx[(int64_t)(beg + r) * ldgx + c] = g[(int64_t)gi * ldg + c] * inv;
+__global__ __launch_bounds__(kBlock) void pool_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ gptr,
+                                                             int B, int C, int slot_w, float* __restrict__ out_mean, int64_t ld0,
+                                                             float* __restrict__ out_wmean, int64_t ld1) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= (int64_t)B * C) return;
+  const int g = (int)(t / C), c = (int)(t - (int64_t)g * C);
+  const int beg = gptr[g], end = gptr[g + 1];
+  float s0 = 0.f, s1 = 0.f;
+  if (end > beg) {
+    const int64_t t_first = beg / kPoolRows, t_last = (end - 1) / kPoolRows;
+    for (int64_t tile = t_first; tile <= t_last; ++tile) {
+      const float* p = partial + ((tile + g) * 2) * slot_w + c;
+      s0 += p[0];
+      s1 += p[slot_w];
+    }
+    const float inv = 1.f / (float)(end - beg);
+    s0 *= inv; s1 *= inv;
+  }
+  if (out_mean) out_mean[(int64_t)g * ld0 + c] = s0;
+  if (out_wmean) out_wmean[(int64_t)g * ld1 + c] = s1;
+}
+
+// Backward: gx[r,:] = (g_mean[g,:] + wts[r] * g_wmean[g,:]) / n_g, g = graph of row r, optionally gated by the ReLU/dropout
+// mask of the activation that was pooled (gx = gate[r,:] > 0 ? gx * gate_scale : 0 -- the mask hand-over of the layer
+// nodes).  Items = (row, 16-byte channel slice) numbered row-major, kPoolBwdItems per thread; the workgroup finds the
+// graph of its first row once, keeps the next graph boundaries in LDS and every item walks forward from there.
+constexpr int kPoolBwdItems = 4;
+constexpr int kPoolPtrCache = 64;
+
+template <int VEC, bool GATE>
+__global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restrict__ g0, int64_t ldg0, const float* __restrict__ g1,
+                                                          int64_t ldg1, const float* __restrict__ wts,
+                                                          const int32_t* __restrict__ gptr, int64_t N, int B, int CV,
+                                                          const float* __restrict__ gate, int64_t ldgate, float gate_scale,
+                                                          float* __restrict__ gx, int64_t ldgx) {
+  __shared__ int s_ptr[kPoolPtrCache + 1];
+  __shared__ int s_g0;
+  const int tid = threadIdx.x;
+  const int64_t item0 = (int64_t)blockIdx.x * kBlock * kPoolBwdItems;
+  const int64_t n_items = N * CV;
+  const int64_t row_first = item0 / CV;
+  if (tid == 0) s_g0 = graph_at(gptr, B, row_first);
+  __syncthreads();
+  const int gbase = s_g0;
+  if (tid <= kPoolPtrCache) s_ptr[tid] = gptr[min(gbase + tid, B)];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPoolBwdItems; ++k) {
+    const int64_t it = item0 + (int64_t)k * kBlock + tid;
+    if (it >= n_items) continue;
+    const int64_t r = it / CV;
+    const int ch = (int)(it - r * CV) * VEC;
+    int j = 0;                                   // graph = gbase + j: s_ptr[j] <= r < s_ptr[j + 1]
+    while (j < kPoolPtrCache && (int64_t)s_ptr[j + 1] <= r) ++j;
+    int g = gbase + j, beg, end;
+    if (j < kPoolPtrCache) { beg = s_ptr[j]; end = s_ptr[j + 1]; }
+    else { g = graph_at(gptr, B, r); beg = gptr[g]; end = gptr[g + 1]; }     // more than 64 graphs inside one workgroup
+    const float inv = 1.f / (float)(end - beg);
+    float a0[VEC], a1[VEC], gv[VEC], o[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a0[v] = a1[v] = 0.f;
+    if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
+    if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
+    const float w = (g1 && wts) ? wts[r] : 1.f;
+    if (GATE) vload<VEC>(gate + r * ldgate + ch, gv);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float u = fmaf(w, a1[v], a0[v]) * inv;
+      if (GATE) u = gv[v] > 0.f ? u * gate_scale : 0.f;
+      o[v] = u;
+    }
+    vstore_nt<VEC>(gx + r * ldgx + ch, o);
   }
 }
 
@@ -55,24 +189,59 @@ __global__ __launch_bounds__(kBlock) void segment_mean_bwd_kernel(const float* _
 
 using namespace mlqem;
 
-extern "C" int mlqem_segment_mean_f32(const float* x, int64_t ldx, const int32_t* graph_ptr, float* out, int64_t ldo,
-                                      int64_t B, int C, mlqem_stream_t stream) {
+extern "C" size_t mlqem_segment_pool_workspace_bytes(int64_t N, int64_t B, int C) {
+  if (N < 0 || B < 0 || C <= 0) return 0;
+  const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), kPoolRows);
+  return (size_t)(tiles + B) * 2 * ((C + 3) / 4 * 4) * sizeof(float);
+}
+
+extern "C" int mlqem_segment_pool_f32(const float* x, int64_t ldx, const float* weights, const int32_t* graph_ptr, int64_t N,
+                                      int64_t B, int C, float* out_mean, int64_t ld_mean, float* out_wmean, int64_t ld_wmean,
+                                      void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
   begin_launches();
-  if (B < 0 || C <= 0 || ldx < C || ldo < C) return MLQEM_ERR_BAD_ARG;
+  if (N < 0 || B < 0 || C <= 0 || ldx < C || B > 0x7fffffffLL || N > 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if ((!out_mean && !out_wmean) || (out_mean && ld_mean < C) || (out_wmean && ld_wmean < C)) return MLQEM_ERR_BAD_ARG;
   if (B == 0) return MLQEM_OK;
-  if (!x || !graph_ptr || !out) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(segment_mean_kernel, dim3((unsigned)B), dim3(kPoolBlock), 0, as_stream(stream), x, ldx, graph_ptr,
-                     out, ldo, C);
+  if (!graph_ptr || (N > 0 && !x)) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_segment_pool_workspace_bytes(N, B, C)) return MLQEM_ERR_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  const int c4 = (C + 3) / 4 * 4;
+  // 16-byte row accesses when the rows own round_up(C, 4) columns (the padded activation layout): the pad columns are
+  // summed along and never read back
+  const bool wide = ldx >= c4 && ldx % 4 == 0 && aligned_to(x, 16);
+  PoolArgs a{x, ldx, weights, graph_ptr, N, (int)B, C, wide ? c4 / 4 : C, static_cast<float*>(workspace)};
+  if (a.CV > kBlock) return MLQEM_ERR_UNSUPPORTED;
+  if (N > 0) {
+    const unsigned tiles = (unsigned)ceil_div(N, kPoolRows);
+    if (wide) hipLaunchKernelGGL(pool_partial_kernel<4>, dim3(tiles), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL(pool_partial_kernel<1>, dim3(tiles), dim3(kBlock), 0, s, a);
+  }
+  hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)ceil_div(B * C, kBlock)), dim3(kBlock), 0, s, a.partial, graph_ptr, (int)B,
+                     C, wide ? c4 : C, out_mean, ld_mean, out_wmean, ld_wmean);
   return launch_status();
 }
 
-extern "C" int mlqem_segment_mean_bwd_f32(const float* g, int64_t ldg, const int32_t* graph_ptr, float* gx,
-                                          int64_t ldgx, int64_t B, int C, mlqem_stream_t stream) {
+extern "C" int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const float* g_wmean, int64_t ld_gwmean,
+                                          const float* weights, const int32_t* graph_ptr, int64_t N, int64_t B, int C,
+                                          const float* gate, int64_t ldgate, float gate_scale, float* gx, int64_t ldgx,
+                                          mlqem_stream_t stream) {
   begin_launches();
-  if (B < 0 || C <= 0 || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
-  if (B == 0) return MLQEM_OK;
-  if (!g || !graph_ptr || !gx) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3((unsigned)B, 8), dim3(kBlock), 0, as_stream(stream), g, ldg,
-                     graph_ptr, gx, ldgx, C);
+  if (N < 0 || B < 0 || C <= 0 || ldgx < C || B > 0x7fffffffLL || N > 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if ((!g_mean && !g_wmean) || (g_mean && ld_gmean < C) || (g_wmean && ld_gwmean < C) || (gate && ldgate < C)) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!graph_ptr || !gx || B == 0) return MLQEM_ERR_BAD_ARG;
+  const int c4 = (C + 3) / 4 * 4;
+  auto rows_ok = [&](const float* p, int64_t ld) { return !p || (ld >= c4 && ld % 4 == 0 && aligned_to(p, 16)); };
+  // the [B, C] gradient rows are read with the same vector width as the [N, C] rows: they must own their padding too
+  const bool wide = rows_ok(gx, ldgx) && rows_ok(gate, ldgate) && rows_ok(g_mean, ld_gmean) && rows_ok(g_wmean, ld_gwmean);
+  const int cv = wide ? c4 / 4 : C;
+  const int64_t blocks = ceil_div(N * cv, (int64_t)kBlock * kPoolBwdItems);
+  if (blocks > 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+#define MLQEM_POOL_BWD(V, G) hipLaunchKernelGGL((pool_bwd_kernel<V, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, g_mean, ld_gmean, \
+                                                g_wmean, ld_gwmean, weights, graph_ptr, N, (int)B, cv, gate, ldgate, gate_scale, gx, ldgx)
+  if (wide) { if (gate) MLQEM_POOL_BWD(4, true); else MLQEM_POOL_BWD(4, false); }
+  else { if (gate) MLQEM_POOL_BWD(1, true); else MLQEM_POOL_BWD(1, false); }
+#undef MLQEM_POOL_BWD
   return launch_status();
 }

@@ -2,7 +2,9 @@
 
 Records every native call (``blackwater.native.ops``) of ONE real train step on the benchmark's representative batch,
 single stream, then replays each recorded call in isolation: per-launch HIP events on the launch stream, the 256 MiB
-Infinity Cache flushed between launches (an untimed 1 GiB fill), median of ``--reps`` launches.  Algorithmic bytes per
+Infinity Cache flushed between launches (an untimed READ of a 1 GiB buffer: the caches are left full of clean lines of
+foreign data, so the timed launch neither finds its operands cached nor pays for someone else's write-backs), median of
+``--reps`` launches.  Algorithmic bytes per
 call follow DESIGN.md section 3 / SURVEY.md section 8d (no cache credit); fraction = bytes / time / 8 TB/s.
 Rows are aggregated by call signature (op, shapes, flags); ``share`` = the signature's part of the summed native time.
 
@@ -147,7 +149,7 @@ def main():
         trainer.step(batch)
     torch.cuda.synchronize()
     struct = batch.structure
-    flush = torch.empty(256 << 20, dtype=torch.float32, device=dev)   # 1 GiB
+    flush = torch.zeros(256 << 20, dtype=torch.float32, device=dev)   # 1 GiB
     stream = torch.cuda.current_stream()
     beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     rows = {}
@@ -155,7 +157,7 @@ def main():
         sig, by = describe(name, a, k, struct)
         times = []
         for _ in range(args.reps):
-            flush.fill_(1.0)
+            flush.sum()
             beg.record(stream)
             fn(*a, **k)
             end.record(stream)
@@ -168,7 +170,7 @@ def main():
     # batch assembly (called by arena.batch, outside ops)
     times = []
     for _ in range(args.reps):
-        flush.fill_(1.0)
+        flush.sum()
         beg.record(stream)
         arena.batch(ids)
         end.record(stream)

@@ -75,9 +75,11 @@ def test_other_hidden_widths(g1, hidden):
         assert (p.grad.cpu().double() - g_ref).abs().max().item() / scale < 1e-4, name
 
 
-def test_single_node_and_per_layer_paths_are_the_same_arithmetic(g1):
-    """The graph part as one autograd node (default) and as one node per layer launch the same kernels with the same
-    seeds: outputs and every gradient agree bit for bit, in train mode (dropout on) too."""
+def test_single_node_and_per_layer_paths_agree(g1):
+    """The graph part as ONE autograd node (default; the last conv of every branch folded into its pool as a weighted
+    mean, native/functional.py _FamilyAGraph) and as one node per layer (conv3 / cheb_conv2 / sage_conv2 run as layers,
+    then a plain mean pool) compute the same function with the same dropout masks: outputs and every gradient agree to
+    fp32 rounding, in train mode (dropout on) too."""
     model, _ = _models(seed=4)
     batch = g1_batch(g1, range(20, 84))
     args = [batch[k].to(DEV) for k in ARGS]
@@ -91,9 +93,9 @@ def test_single_node_and_per_layer_paths_are_the_same_arithmetic(g1):
         out = model(*args)
         out.square().mean().backward()
         results.append((out.detach().clone(), [p.grad.clone() for p in model.parameters()]))
-    assert torch.equal(results[0][0], results[1][0])
-    for a, b in zip(results[0][1], results[1][1]):
-        assert torch.equal(a, b)
+    assert (results[0][0] - results[1][0]).abs().max().item() < 2e-6 * max(1.0, results[1][0].abs().max().item())
+    for (name, _), a, b in zip(model.named_parameters(), results[0][1], results[1][1]):
+        assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-9), name
 
 
 def test_train_mode_dropout_runs_and_is_seeded(g1):

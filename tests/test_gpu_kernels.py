@@ -197,6 +197,84 @@ def test_segment_mean_forward_backward():
         assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("c,padded", [(1, True), (1, False), (10, True), (10, False), (30, True), (125, True)])
+def test_segment_pool_weighted_mean_and_backward(c, padded):
+    """mlqem_segment_pool_f32 / _bwd: plain and weighted means over row tiles against fp64 loops -- graphs that span
+    several 1024-row tiles, several graphs inside one tile, empty graphs (also first and last), one-node graphs; padded
+    (16-byte, NaN-poisoned pads) and unpadded rows; the gated backward."""
+    from blackwater.native import ops
+
+    sizes = [0, 1, 7, 3000, 0, 0, 2, 5000, 31, 1024, 1, 0]
+    n, b = sum(sizes), len(sizes)
+    ptr_h = np.concatenate([[0], np.cumsum(sizes)])
+    ptr = torch.tensor(ptr_h, dtype=torch.int32, device=DEV)
+    gen = torch.Generator().manual_seed(c)
+    x, w = torch.randn(n, c, generator=gen), torch.rand(n, generator=gen) * 3 - 1
+    xd = _padded(x) if padded else x.to(DEV)
+    mean, wmean = ops.segment_pool(xd, ptr, b, weights=w.to(DEV), mean=True, wmean=True)
+    only_w = ops.segment_pool(xd, ptr, b, weights=w.to(DEV), mean=False, wmean=True)
+    assert only_w[0] is None and torch.equal(only_w[1], wmean)
+    x64, w64 = x.double(), w.double()
+    for g in range(b):
+        seg = slice(ptr_h[g], ptr_h[g + 1])
+        want0 = x64[seg].mean(0) if sizes[g] else torch.zeros(c, dtype=torch.float64)
+        want1 = (x64[seg] * w64[seg, None]).sum(0) / sizes[g] if sizes[g] else torch.zeros(c, dtype=torch.float64)
+        assert torch.allclose(mean[g].cpu().double(), want0, rtol=1e-5, atol=2e-6), g
+        assert torch.allclose(wmean[g].cpu().double(), want1, rtol=1e-5, atol=2e-6), g
+    # two launches on the same input: bit-identical (fixed summation order, no atomics)
+    again = ops.segment_pool(xd, ptr, b, weights=w.to(DEV), mean=True, wmean=True)
+    assert torch.equal(again[0], mean) and torch.equal(again[1], wmean)
+    # backward, with and without the gate
+    g0, g1 = torch.randn(b, c, generator=gen), torch.randn(b, c, generator=gen)
+    gate = torch.randn(n, c, generator=gen)
+    graph_of = np.repeat(np.arange(b), sizes)
+    inv = torch.tensor([1.0 / s if s else 0.0 for s in sizes], dtype=torch.float64)[graph_of]
+    base = (g0.double()[graph_of] + w64[:, None] * g1.double()[graph_of]) * inv[:, None]
+    gd = _padded(gate) if padded else gate.to(DEV)
+    got = ops.segment_pool_bwd(g0.to(DEV), g1.to(DEV), ptr, n, weights=w.to(DEV))
+    assert torch.allclose(got.cpu().double(), base, rtol=1e-5, atol=1e-7)
+    got = ops.segment_pool_bwd(g0.to(DEV), g1.to(DEV), ptr, n, weights=w.to(DEV), gate=gd, gate_scale=1.25)
+    assert torch.allclose(got.cpu().double(), torch.where(gate.double() > 0, base * 1.25, torch.zeros_like(base)), rtol=1e-5, atol=1e-7)
+    got = ops.segment_pool_bwd(None, g1.to(DEV), ptr, n, weights=w.to(DEV))
+    assert torch.allclose(got.cpu().double(), w64[:, None] * g1.double()[graph_of] * inv[:, None], rtol=1e-5, atol=1e-7)
+
+
+def test_colsum_scalars_are_the_transposed_propagation_of_ones(g1):
+    """GraphStructure.colsum(kind) = P^T 1 against dense algebra, and the arena's copies (gathered by batch assembly)
+    equal the ones computed on the batch itself."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.native.structure import GraphStructure
+    from helpers import g1_batch, g1_graph
+
+    batch = g1_batch(g1, [5, 17], self_loops=True)
+    n = batch["x"].shape[0]
+    ei = batch["edge_index"]
+    s = GraphStructure.from_edge_index(ei.to(DEV), n, batch=batch["batch"].to(DEV), num_graphs=2)
+    a = torch.zeros(n, n, dtype=torch.float64)
+    for src, dst in ei.t().tolist():
+        a[dst, src] += 1.0
+    off = a - torch.diag(torch.diag(a))
+    isq = lambda d: torch.where(d > 0, d.clamp(min=1e-30) ** -0.5, torch.zeros_like(d))
+    a_hat = off + torch.eye(n, dtype=torch.float64)
+    dm = torch.diag(isq(a_hat.sum(1)))
+    want = {"gcn": (dm @ a_hat @ dm).sum(0), "sage": (a / a.sum(1).clamp(min=1)[:, None]).sum(0),
+            "cheb": (-torch.diag(isq(off.sum(0))) @ off @ torch.diag(isq(off.sum(0)))).sum(0)}
+    for kind, w in want.items():
+        assert torch.allclose(s.colsum(kind).cpu().double(), w, rtol=1e-5, atol=1e-6), kind
+    xs, eis = [], []
+    for i in (5, 17):
+        x, e, _ = g1_graph(g1, i)
+        loops = np.arange(x.shape[0])
+        xs.append(x.astype(np.float32))
+        eis.append(np.concatenate([e, np.stack([loops, loops])], axis=1))
+    arena = GraphArena.from_arrays(xs, eis, batch["y"].numpy(), batch["noisy"].numpy(), batch["depth"].numpy(),
+                                   batch["observable"].numpy(), device=DEV)
+    sb = arena.batch([1, 0, 1]).structure
+    ref = GraphStructure(sb.num_nodes, sb.in_ptr, sb.in_src, sb.out_ptr, sb.out_dst, sb.loops, sb.graph_ptr, 3)
+    for kind in want:
+        assert torch.equal(sb.colsum(kind), ref.colsum(kind)), kind
+
+
 def _padded(t, poison=True):
     """A device copy of ``t`` in the padded row layout, the pad columns holding NaN (they are scratch by contract)."""
     from blackwater.native import ops
