@@ -44,6 +44,20 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// Keep/drop decisions for V consecutive elements from ONE splitmix64 round keyed by the index of their first element:
+// element v is dropped when the v-th 16-bit field of the hash is < floor(p * 65536) (|P(drop) - p| < 1.6e-5).  The
+// aggregation epilogue draws a whole 16-byte slice at once: a quarter of the 64-bit multiplies of one hash per element.
+template <int V> __device__ __forceinline__ void dropout_keep(uint64_t seed, uint64_t first_idx, float p, bool (&keep)[V]) {
+  static_assert(V <= 4, "one 64-bit hash carries four 16-bit uniforms");
+  uint64_t z = seed + (first_idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const unsigned thr = (unsigned)(p * 65536.f);
+#pragma unroll
+  for (int v = 0; v < V; ++v) keep[v] = (unsigned)((z >> (16 * v)) & 0xFFFFu) >= thr;
+}
+
 template <int V> struct VecT;
 template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = float2; };

@@ -40,9 +40,20 @@ constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rsca
 constexpr int kHeavyDegree = 32;     // rows above this are reduced by the whole block
 constexpr int kHeavyCap = 64;
 
+// The bias vector is staged in LDS once per workgroup (zero beyond C): read from global memory inside finish_row it was
+// one more dependent memory round trip at the very end of every item (+110 us on the 11 M-row GCN layers), and held in
+// registers per item it pushed the 64-VGPR kernels into scratch.
+constexpr int kBiasLds = kBlock * 4;   // CV <= kBlock slices of up to 4 channels
+
+__device__ __forceinline__ void stage_bias(const AggArgs& a, float* s_bias, int cols) {
+  if (!a.bias) return;                  // workgroup-uniform
+  for (int i = threadIdx.x; i < cols; i += kBlock) s_bias[i] = i < a.C ? a.bias[i] : 0.f;
+  __syncthreads();
+}
+
 template <int VEC, bool IS_MAX>
 __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
-                                           const float (&self)[VEC], float rs, float ds) {
+                                           const float (&self)[VEC], float rs, float ds, const float* s_bias) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
@@ -50,16 +61,15 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
   } else {
     float zz[VEC];
     if (a.z) vload<VEC>(a.z + row * a.ldz + ch, zz);
+    bool keep[VEC];
+    if (a.drop_p > 0.f) dropout_keep<VEC>(a.seed, (uint64_t)(row * a.C + ch), a.drop_p, keep);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float r = a.alpha * fmaf(ds, self[v], rs * acc[v]);
       if (a.z) r = fmaf(a.beta, zz[v], r);
-      if (a.bias && ch + v < a.C) r += a.bias[ch + v];
+      if (a.bias) r += s_bias[ch + v];
       if (a.act & 1) r = fmaxf(r, 0.f);
-      if (a.drop_p > 0.f) {
-        const float u = uniform01(a.seed, (uint64_t)(row * a.C + ch + v));
-        r = u < a.drop_p ? 0.f : r * (1.f / (1.f - a.drop_p));
-      }
+      if (a.drop_p > 0.f) r = keep[v] ? r * (1.f / (1.f - a.drop_p)) : 0.f;
       res[v] = r;
     }
   }
@@ -75,6 +85,8 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
   __shared__ int s_heavy[kHeavyCap];
   __shared__ int s_nheavy;
   __shared__ float s_red[kBlock * VEC];
+  __shared__ float s_bias[kBiasLds];
+  stage_bias(a, s_bias, a.CV * VEC);
 
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int64_t r0 = (int64_t)blk * a.R;
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
     }
-    finish_row<VEC, IS_MAX>(a, row, ch[k], acc[k], self[k], s_rs[rl[k]], s_ds[rl[k]]);
+    finish_row<VEC, IS_MAX>(a, row, ch[k], acc[k], self[k], s_rs[rl[k]], s_ds[rl[k]], s_bias);
   }
   // ---- phase 4: heavy rows, one at a time, edges split over kBlock / CV slots
   __syncthreads();
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
           const float q = s_red[(sl * a.CV + tid) * VEC + v];
           tot[v] = IS_MAX ? fmaxf(tot[v], q) : tot[v] + q;
         }
-      finish_row<VEC, IS_MAX>(a, row, hch, tot, sf, s_rs[r], s_ds[r]);
+      finish_row<VEC, IS_MAX>(a, row, hch, tot, sf, s_rs[r], s_ds[r], s_bias);
     }
   };
   if (n_heavy <= kHeavyCap) {
@@ -224,6 +236,8 @@ template <int VEC, bool IS_MAX, int kItemsPerThread>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {
   // A block owns a.R = (kBlock * IPT) / CV whole rows; the local item index li < kBlock * IPT <= 2048 is split into
   // (row, slice) with a multiply-shift (exact for li * CV < 2^20) instead of a division.
+  __shared__ float s_bias[kBiasLds];
+  stage_bias(a, s_bias, a.CV * VEC);
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int64_t r0 = (int64_t)blk * a.R;
   const int nrows = (int)min((int64_t)a.R, a.N - r0);
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
       }
     }
-    finish_row<VEC, IS_MAX>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k]);
+    finish_row<VEC, IS_MAX>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias);
   }
   // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
   // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (!use_self) sf[v] = 0.f;
             if (IS_MAX) part[v] = fmaxf(part[v], sf[v]);
           }
-          finish_row<VEC, IS_MAX>(a, r, hch, part, sf, rs_r, ds_r);
+          finish_row<VEC, IS_MAX>(a, r, hch, part, sf, rs_r, ds_r, s_bias);
         }
       } else {   // more slices than lanes: every lane walks all edges for its slices
         for (int sl = lane; sl < a.CV; sl += kWave) {
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #pragma unroll
             for (int v = 0; v < VEC; ++v) tot[v] = IS_MAX ? fmaxf(tot[v], q[v]) : fmaf(w, q[v], tot[v]);
           }
-          finish_row<VEC, IS_MAX>(a, r, hch, tot, sf, rs_r, ds_r);
+          finish_row<VEC, IS_MAX>(a, r, hch, tot, sf, rs_r, ds_r, s_bias);
         }
       }
     }

@@ -42,7 +42,7 @@ class Recorder:
     """Wraps the ops entry points the Family A step uses; keeps (name, args, kwargs) so the call can be replayed."""
 
     NAMES = ("csr_aggregate", "linear", "linear_parts", "linear_wgrad", "linear_wgrad_parts", "segment_mean",
-             "segment_mean_bwd", "relu_dropout_bwd", "pooled_aggregate", "pooled_aggregate_bwd")
+             "segment_mean_bwd", "relu_dropout_bwd", "segment_pool", "segment_pool_bwd")
 
     def __init__(self):
         self.calls, self.orig = [], {}
@@ -80,10 +80,19 @@ def describe(name, a, k, struct):
                                      "self" if k.get("dself") is not None else "",
                                      "T" if a[1].data_ptr() == struct.out_ptr.data_ptr() else "") if f)
         return f"csr_aggregate N={n} C={c} [{flags}]", by
-    if name in ("pooled_aggregate", "pooled_aggregate_bwd"):
+    if name == "segment_pool":
         x = a[0]
-        n, c = (x.shape if name == "pooled_aggregate" else (n_nodes, 1))
-        return f"{name} N={n_nodes} C={c}", k.get("_bytes", 0)
+        n, c = x.shape
+        b = a[2]
+        outs = int(bool(k.get("mean", True))) + int(bool(k.get("wmean", False)))
+        return f"segment_pool N={n} C={c} outs={outs}", 4 * c * (n + b * outs) + 4 * (b + 1) + (4 * n if k.get("wmean") else 0)
+    if name == "segment_pool_bwd":
+        ref = a[0] if a[0] is not None else a[1]
+        b, c = ref.shape
+        n = a[3]
+        gated = k.get("gate") is not None
+        return (f"segment_pool_bwd N={n} C={c}{' gate' if gated else ''}",
+                4 * c * n * (2 if gated else 1) + 4 * n + 4 * c * b * 2 + 4 * (b + 1))
     if name == "linear":
         x, w = a[0], a[1]
         n, i = x.shape
