@@ -230,6 +230,31 @@ def cpu_baseline_leg(corpus, ids, n_qubits, large_batch=256):
                             "sample": f"the first {len(big)} circuits of the same representative batch as ONE step, median of 2 after 1 warm-up"}}
 
 
+def accuracy_leg(dev):
+    """The "exp-val MAE" half of the metric: Family B and MLP1 trained with the reference's loop and settings on the
+    reference's own circuits (tests/golden/ising_trainval.npz; blackwater/metrics/accuracy.py states the split), validation
+    MSE next to the curve the reference recorded, and the evaluation cell's MAE / RMSE / mean-L2 before and after
+    mitigation.  tests/test_gpu_accuracy.py asserts the band."""
+    from blackwater.data.backends import StaticBackend
+    from blackwater.data.utils import get_backend_properties_v1
+    from blackwater.metrics.accuracy import load_trainval, train_family_b, train_mlp1
+
+    golden = os.path.join(ROOT, "tests", "golden")
+    z = load_trainval(golden)
+    props = get_backend_properties_v1(StaticBackend.from_json(os.path.join(golden, "fake_lima_backend_props.json")))
+    out = {"data": "reference circuits: docs/tutorials/data/ising_init_from_qasm_no_readout/{train/step_0,val/step_0..2}.pk, "
+                   "pooled split (510 train / 90 validation), batch 32, Adam 1e-3, 100 epochs, seed 0"}
+    for key, rec in (("family_b", train_family_b(z, dev)), ("mlp1", train_mlp1(z, props, dev))):
+        rep = rec["report"]
+        out[key] = {"model": rec["model"], "val_mse": round(rec["val_mse_final"], 6),
+                    "reference_recorded_val_mse": round(rec["reference_val_mse_final"], 6),
+                    "train_mse": round(rec["train_mse_final"], 6),
+                    "exp_val_mae_noisy": round(rep["MAE_noisy"], 5), "exp_val_mae_mitigated": round(rep["MAE_mitigated"], 5),
+                    "rmse_noisy": round(rep["RMSE_noisy"], 5), "rmse_mitigated": round(rep["RMSE_mitigated"], 5),
+                    "mean_l2_noisy": round(rep["L2_noisy"], 5), "mean_l2_mitigated": round(rep["L2_mitigated"], 5)}
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run.  Nothing in
     this process has touched the GPU (torch.cuda.device_count() does not initialise it on this image); the parent only
@@ -355,6 +380,9 @@ def main():
             rep = local_ids[fixed_ids(n_local, args.batch)]
             line["cpu_baseline"] = cpu_baseline_leg(corpus, rep, 100)
             line["parity"] = parity_leg(model, arena, corpus, local_ids, 100)   # the oracle as the checker, outside the timed region
+            del trainer, model, arena, fixed
+            torch.cuda.empty_cache()
+            line["accuracy"] = accuracy_leg(dev)
         print(json.dumps(line), flush=True)
     if distributed:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: leave together

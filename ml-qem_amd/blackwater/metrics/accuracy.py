@@ -1,0 +1,123 @@
+"""Training-to-accuracy harness on the reference's own circuits (the "exp-val MAE" half of the headline metric).
+
+Reference procedure: docs/tutorials/__ml_models.py:100-253 (``train_gnn`` then the evaluation cell) and
+docs/tutorials/h10_mlp.ipynb cells [10]-[13] for the MLP: batch 32, Adam(lr 1e-3), MSE on ``squeeze(y, 1)``,
+ReduceLROnPlateau('min', 0.1, patience 15, min_lr 1e-5) on the summed validation loss, 100 epochs.
+Data: the snapshot of docs/tutorials/data/ising_init_from_qasm_no_readout/ holds ``train/step_0.pk`` (300 circuits, Trotter
+step 0 only) and ``val/step_{0,1,2}.pk`` (100 each).  The reference trained on every Trotter step (files that are not
+in the snapshot); a model that has only seen step 0 cannot extrapolate the depth feature, so the split used here pools
+what exists: train = train/step_0 + 70 % of each val file, validation = the remaining 30 % (seeded).  The recorded curves
+next to the reference's checkpoints (gnn1.pk: val MSE 0.0808 -> 0.00687, mlp1_smaller_2.pk: 0.00640 -> 0.00122) are the
+convergence band, loose by design.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .improvement_factor import mitigation_report
+
+
+def load_trainval(golden_dir: str) -> Dict[str, np.ndarray]:
+    z = dict(np.load(os.path.join(golden_dir, "ising_trainval.npz")))
+    with open(os.path.join(golden_dir, "ising_trainval_circuits.json")) as fh:
+        z["qasm"] = json.load(fh)
+    with open(os.path.join(golden_dir, "ref_loss_curves.json")) as fh:
+        z["ref_curves"] = json.load(fh)
+    return z
+
+
+def pooled_split(split: np.ndarray, seed: int = 0, train_frac: float = 0.7):
+    """(train ids, val ids): the train file whole, each val file cut ``train_frac`` / rest by a seeded permutation."""
+    rng = np.random.RandomState(seed)
+    train, val = [np.flatnonzero(split == 0)], []
+    for k in sorted(set(split.tolist()) - {0}):
+        ids = rng.permutation(np.flatnonzero(split == k))
+        cut = int(round(train_frac * len(ids)))
+        train.append(ids[:cut])
+        val.append(ids[cut:])
+    return np.sort(np.concatenate(train)), np.sort(np.concatenate(val))
+
+
+def train_family_b(z, device, epochs: int = 100, seed: int = 0, batch_size: int = 32):
+    """Family B (gnn.py:70-122; hidden 15, 4 outputs: the architecture of gnn1.pth) through ``Trainer.fit``."""
+    from ..data.arena import GraphArena
+    from ..nn import ExpValCircuitGraphModel
+    from ..train import Trainer
+
+    g = len(z["depth"])
+    xs, eis = [], []
+    for i in range(g):
+        s, e = z["node_ptr"][i], z["node_ptr"][i + 1]
+        es, ee = z["edge_ptr"][i], z["edge_ptr"][i + 1]
+        n = int(e - s)
+        loops = np.arange(n, dtype=np.int64)
+        xs.append(z["x"][s:e].astype(np.float32))
+        # the training path's dataset transform: AddSelfLoops (blackwater/data/loaders/exp_val.py:33)
+        eis.append(np.concatenate([z["edge_index"][:, es:ee].astype(np.int64), np.stack([loops, loops])], axis=1))
+    y = z["ideal"].astype(np.float32)[:, None, :]
+    noisy = z["noisy"].astype(np.float32)[:, None, :]
+    depth = z["depth"].astype(np.float32)[:, None]
+    obs = np.zeros((g, 1, 1), dtype=np.float32)          # this dataset carries no observable (the model ignores it)
+    arena = GraphArena.from_arrays(xs, eis, y, noisy, depth, obs, device=device)
+    train_ids, val_ids = pooled_split(z["split"], seed)
+    torch.manual_seed(seed)
+    model = ExpValCircuitGraphModel(xs[0].shape[1], 15, 4).to(device)
+    trainer = Trainer(model, lr=1e-3)
+    hist = trainer.fit(arena, train_ids, val_ids, epochs=epochs, batch_size=batch_size, seed=seed)
+    pred = trainer.predict(arena, val_ids).cpu().numpy()
+    rep = mitigation_report(z["ideal"][val_ids], z["noisy"][val_ids], pred)
+    return {"model": "family_b(22, 15, 4)", "train_circuits": int(len(train_ids)), "val_circuits": int(len(val_ids)),
+            "epochs": epochs, "train_mse_first": hist["train_losses"][0], "train_mse_final": hist["train_losses"][-1],
+            "val_mse_first": hist["val_losses"][0], "val_mse_final": hist["val_losses"][-1],
+            "reference_val_mse_final": z["ref_curves"]["gnn1"]["val_losses"][-1],
+            "reference_train_mse_final": z["ref_curves"]["gnn1"]["train_losses"][-1], "report": rep}
+
+
+def train_mlp1(z, props, device, epochs: int = 100, seed: int = 0, batch_size: int = 32):
+    """MLP1(58 -> 64 -> 4) on ``encode_data`` rows (mlp.py:198-252; the architecture of mlp1_smaller_2.pth) with the same
+    loop: shuffled batches of 32, Adam(1e-3), MSE, ReduceLROnPlateau on the summed validation loss."""
+    from ..library.learning.features import encode_data
+    from ..nn.mlp import MLP1
+
+    X, y = encode_data(z["qasm"], props, z["ideal"].tolist(), z["noisy"].tolist(), 4, native=True)
+    X, y = X.to(device), y.to(device)
+    train_ids, val_ids = pooled_split(z["split"], seed)
+    torch.manual_seed(seed)
+    model = MLP1(X.shape[1], 64, 4).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", factor=0.1, patience=15, min_lr=1e-5)
+    crit = torch.nn.MSELoss()
+    tv = torch.as_tensor(val_ids, device=device)
+    hist = {"train": [], "val": []}
+    for epoch in range(epochs):
+        order = torch.as_tensor(np.random.RandomState(seed + epoch).permutation(train_ids), device=device)
+        model.train()
+        running, nb = None, 0
+        for i in range(0, len(order), batch_size):
+            sel = order[i:i + batch_size]
+            opt.zero_grad()
+            loss = crit(model(X[sel]), y[sel])
+            loss.backward()
+            opt.step()
+            running = loss.detach() if running is None else running + loss.detach()
+            nb += 1
+        model.eval()
+        with torch.no_grad():
+            vb = [crit(model(X[tv[i:i + batch_size]]), y[tv[i:i + batch_size]]) for i in range(0, len(tv), batch_size)]
+            vsum = torch.stack(vb).sum()
+        sched.step(vsum.item())
+        hist["train"].append(running.item() / nb)
+        hist["val"].append(vsum.item() / len(vb))
+    with torch.no_grad():
+        pred = model(X[tv]).cpu().numpy()
+    rep = mitigation_report(z["ideal"][val_ids], z["noisy"][val_ids], pred)
+    return {"model": "mlp1(58, 64, 4)", "train_circuits": int(len(train_ids)), "val_circuits": int(len(val_ids)),
+            "epochs": epochs, "train_mse_first": hist["train"][0], "train_mse_final": hist["train"][-1],
+            "val_mse_first": hist["val"][0], "val_mse_final": hist["val"][-1],
+            "reference_val_mse_final": z["ref_curves"]["mlp1_smaller_2"]["val_losses"][-1],
+            "reference_train_mse_final": z["ref_curves"]["mlp1_smaller_2"]["train_losses"][-1], "report": rep}

@@ -12,6 +12,12 @@ Outputs (all data, no source):
   g1_circuits.json               the same 300 circuits as OpenQASM-2 text (rebuilt from the pickled op lists)
   encoder_goldens.json           dataset-format entries (QASM + reference-encoded circuit_graph) sampled from
                                  docs/tutorials/data/mbd_datasets2/theta_0.05pi/{train,val}/*.json
+  ising_trainval.npz             the graphs + labels of docs/tutorials/data/ising_init_from_qasm_no_readout/
+                                 {train/step_0 (300), val/step_0, val/step_1, val/step_2 (100 each)}.pk, in that order
+                                 (``split`` = 0 for the train file, 1..3 for the val files) -- the training-to-accuracy set
+  ising_trainval_circuits.json   the same 600 circuits as OpenQASM-2 text (input of the MLP feature encoder)
+  ref_loss_curves.json           the loss curves the reference recorded next to its checkpoints
+                                 (docs/tutorials/model/ising_init_from_qasm_no_readout/{gnn1,mlp1_smaller_2}.pk)
   ckpt/*.pth                     reference state-dicts (one per architecture used by the parity tests)
   ckpt_manifest.json             key -> shape for all 63 reference checkpoints (strict-load test)
 """
@@ -149,6 +155,40 @@ def make_g1():
     print("g1:", len(entries), "graphs", nptr[-1], "nodes", eptr[-1], "edges")
 
 
+def make_trainval():
+    base = os.path.join(TUT, "data/ising_init_from_qasm_no_readout")
+    xs, eis, nptr, eptr, noisy, ideal, depth, split, qasm = [], [], [0], [0], [], [], [], [], []
+    for k, rel in enumerate(["train/step_0.pk", "val/step_0.pk", "val/step_1.pk", "val/step_2.pk"]):
+        for e in load_pk(os.path.join(base, rel)):
+            g = e["circuit_graph"]
+            x = np.asarray(g["nodes"]["DAGOpNode"], dtype=np.float64)
+            ei = np.asarray(g["edges"]["DAGOpNode_wire_DAGOpNode"]["edge_index"], dtype=np.int32)
+            xs.append(x)
+            eis.append(ei)
+            nptr.append(nptr[-1] + x.shape[0])
+            eptr.append(eptr[-1] + ei.shape[1])
+            assert len(e["noisy_exp_values"]) == 1 and e["observable"] == []
+            noisy.append(e["noisy_exp_values"][0])
+            ideal.append(e["ideal_exp_value"])
+            depth.append(e["circuit_depth"])
+            split.append(k)
+            qasm.append(circuit_to_qasm(e["circuit"], angle_from_graph=x[:, :3]))
+    np.savez_compressed(os.path.join(OUT, "ising_trainval.npz"), x=np.concatenate(xs).astype(np.float32),
+                        edge_index=np.concatenate(eis, axis=1), node_ptr=np.asarray(nptr, np.int64),
+                        edge_ptr=np.asarray(eptr, np.int64), noisy=np.asarray(noisy, np.float64),
+                        ideal=np.asarray(ideal, np.float64), depth=np.asarray(depth, np.int64),
+                        split=np.asarray(split, np.int8))
+    with open(os.path.join(OUT, "ising_trainval_circuits.json"), "w") as fh:
+        json.dump(qasm, fh)
+    curves = {}
+    for name in ("gnn1", "mlp1_smaller_2"):
+        d = load_pk(os.path.join(TUT, "model/ising_init_from_qasm_no_readout", name + ".pk"))
+        curves[name] = {k: [float(v) for v in d[k]] for k in ("train_losses", "val_losses")}
+    with open(os.path.join(OUT, "ref_loss_curves.json"), "w") as fh:
+        json.dump(curves, fh)
+    print("trainval:", len(split), "graphs", nptr[-1], "nodes")
+
+
 def make_encoder_goldens():
     base = os.path.join(TUT, "data/mbd_datasets2/theta_0.05pi")
     picks = [("train/step_0.json", 6), ("val/step_0.json", 6), ("val/step_1.json", 10), ("val/step_2.json", 8)]
@@ -191,5 +231,6 @@ if __name__ == "__main__":
         sys.exit("needs the reference checkout at /root/reference")
     make_backend_props()
     make_g1()
+    make_trainval()
     make_encoder_goldens()
     make_ckpts()
