@@ -1,0 +1,121 @@
+"""SURVEY.md section 8 row f1 on the device: every circuit of one ``run()`` post-processed by ONE model call.
+
+* ``ngem(..., batched=True)`` (native C++ encoder -> ``Batch.from_data_list`` -> one call) with Family A, 12 QASM
+  circuits, against the per-circuit fp64 oracle (the reference's serial loop, blackwater/library/ngem/estimator.py:49-84);
+* the same collate with Family B (gnn1.pth), inference convention (raw graphs, no self-loops), against the per-circuit
+  oracle.  Family B does not go through the ``ngem`` wrapper itself in the reference either: the wrapper hands the model
+  ``noisy_0`` of shape [1, 1] (estimator.py:68-73) and gnn.py:117 squeezes dim 1 of a [B, 1, k] tensor;
+* ``TorchLearningModelProcessor.process_batch`` through ``learning`` with MLP1, 10 circuits x multi-term observables,
+  against the per-circuit oracle MLP.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import G1_GATES_ORDER, g1_graph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+IDX = [0, 3, 17, 42, 77, 101, 150, 200, 222, 250, 280, 299]
+
+
+def test_ngem_batched_family_a_equals_per_circuit_oracle(g1, lima_backend):
+    from blackwater.data.backends import PauliObservable
+    from blackwater.data.utils import encode_pauli_sum_op
+    from blackwater.library.ngem.estimator import ngem
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from oracle.models import FamilyA
+    from test_estimators import FakeEstimator, _Job
+    import blackwater.library.ngem.estimator as mod
+
+    torch.manual_seed(4)
+    model = ExpValCircuitGraphModelA(5, 22, 10)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bias"):
+                p.uniform_(-0.5, 0.5)
+    ref = FamilyA(5, 22, 10).double().eval()
+    ref.load_state_dict(model.state_dict())
+    model = model.to(DEV).eval()
+    obs = PauliObservable([("IIZIZ", 0.75)])
+
+    class Est(FakeEstimator):
+        def _run(self, circuits, observables, parameter_values, **opts):
+            return _Job([g1["noisy"][i][0] for i in IDX])
+
+    orig = mod.get_backend_properties_v1  # the fixture graphs use the reference's (hash-random) gate column order
+    mod.get_backend_properties_v1 = lambda b: orig(b, gates_order=G1_GATES_ORDER)
+    try:
+        circuits = [g1["qasm"][i] for i in IDX]
+        batched = ngem(Est, model, lima_backend, batched=True)().run(circuits, [obs] * len(IDX)).result()
+        serial = ngem(Est, model, lima_backend)().run(circuits, [obs] * len(IDX)).result()
+    finally:
+        mod.get_backend_properties_v1 = orig
+    want = []
+    for i in IDX:
+        x, ei, _ = g1_graph(g1, i)
+        out = ref(torch.tensor([[g1["noisy"][i][0]]], dtype=torch.float64),
+                  torch.tensor([encode_pauli_sum_op(obs)], dtype=torch.float64), torch.zeros(1, 1, dtype=torch.float64),
+                  torch.tensor(x, dtype=torch.float32).double(), torch.tensor(ei, dtype=torch.long), None)
+        want.append(out.item())
+    assert batched.values.shape == (len(IDX),)
+    assert np.abs(batched.values - np.array(want)).max() < 1e-5      # north_star tolerance, per circuit
+    assert np.abs(batched.values - serial.values).max() < 1e-5
+
+
+def test_batched_collate_family_b_equals_per_circuit_oracle(golden_dir, g1):
+    from blackwater.data.graph import Batch, Data
+    from blackwater.nn import family_b_from_state_dict
+    from oracle.models import family_b_from_state_dict as oracle_from_sd
+
+    sd = torch.load(os.path.join(golden_dir, "ckpt", "gnn1.pth"), weights_only=True)
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    ref = oracle_from_sd(sd).double().eval()
+    entries, want = [], []
+    with torch.no_grad():
+        for i in IDX:
+            x, ei, ea = g1_graph(g1, i)
+            noisy = torch.tensor(g1["noisy"][i], dtype=torch.float32).view(1, 1, -1)
+            depth = torch.tensor([[float(g1["depth"][i])]])
+            entries.append(Data(x=torch.tensor(x, dtype=torch.float32), edge_index=torch.tensor(ei, dtype=torch.long),
+                                edge_attr=torch.tensor(ea, dtype=torch.float32), y=torch.zeros(1, 1),
+                                observable=torch.zeros(1, 0), circuit_depth=depth, noisy_0=noisy))
+            want.append(ref(noisy.double(), None, depth.double(), torch.tensor(x, dtype=torch.float32).double(),
+                            torch.tensor(ei, dtype=torch.long), None).numpy().ravel())
+        batch = Batch.from_data_list(entries).to(DEV)
+        got = model(batch.noisy_0, batch.observable, batch.circuit_depth, batch.x, batch.edge_index, batch.batch)
+    assert got.shape == (len(IDX), 4)
+    assert np.abs(got.cpu().numpy() - np.stack(want)).max() < 1e-5
+
+
+def test_learning_process_batch_equals_per_circuit_oracle(g1, lima_backend):
+    from blackwater.data.backends import PauliObservable
+    from blackwater.data.utils import encode_pauli_sum_op, get_backend_properties_v1
+    from blackwater.library.learning.estimator import TorchLearningModelProcessor, learning
+    from blackwater.library.learning.features import encode_data
+    from blackwater.library.learning.mlp import MLP1
+    from oracle.models import MLP1 as OracleMLP1
+    from test_estimators import FakeEstimator
+
+    torch.manual_seed(0)
+    model = MLP1(8 + 6 + 40 + 1 + 21, 64, 1).to(DEV).eval()
+    proc = TorchLearningModelProcessor(model, lima_backend)
+    assert hasattr(proc, "process_batch")
+    est = learning(FakeEstimator, proc, skip_transpile=True)()
+    idx = IDX[:10]
+    terms = [[("IIIIZ", 1.0)], [("IIIZI", 0.5), ("ZIIII", -0.25)], [("IZIZI", 2.0)]]
+    observables = [PauliObservable(terms[k % 3]) for k in range(len(idx))]
+    res = est.run([g1["qasm"][i] for i in idx], observables).result()
+    ref = OracleMLP1(76, 64, 1).double()
+    ref.load_state_dict({k: v.cpu().double() for k, v in model.state_dict().items()})
+    props = get_backend_properties_v1(lima_backend)
+    for k, i in enumerate(idx):
+        value = 0.5 + 0.1 * k                                   # FakeEstimator's noisy values
+        total = 0.0
+        for label, coeff in terms[k % 3]:
+            X, _ = encode_data([g1["qasm"][i]], props, [[0.0]], [[value]], 1, meas_bases=encode_pauli_sum_op(label))
+            total += coeff * ref(X.double()).item()
+        assert res.values[k] == pytest.approx(total, abs=1e-5)
+        assert res.metadata[k]["original_value"] == pytest.approx(value)
