@@ -286,6 +286,22 @@ int mlqem_sort_unique_u64(const uint64_t* keys, int64_t T, uint64_t* out_keys, i
                           size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t* edge_index, mlqem_stream_t stream);
 
+/* Coarsened connectivity WITHOUT host read-backs, for batches whose graphs all pool to at most
+ * mlqem_asap_coarsen_dense_max_k() clusters (512): the pooled adjacency of every graph is built as a k_g x k_g bit
+ * matrix in LDS by one workgroup per graph (idempotent atomicOr: order-independent), device scans of the row / column
+ * popcounts give new_in_ptr / new_out_ptr directly, and a second kernel lists rows and columns in ascending order --
+ * the same arrays mlqem_csr_build yields from the two-hop path's sorted edge list.  graph_ptr / new_graph_ptr: node
+ * ranges of the graphs before / after pooling; perm: the kept centres, graph by graph (mlqem_segment_topk); kmax >= the
+ * largest k_g (host knows it: k_g = ceil(ratio * n_g)).  new_in_src / new_out_dst / new_out_eid must hold
+ * sum_g k_g (k_g - 1) entries; only the first new_in_ptr[K] are written.  new_loops[K] = 0 (no diagonal). */
+int mlqem_asap_coarsen_dense_max_k(void);
+size_t mlqem_asap_coarsen_dense_workspace_bytes(int64_t B, int64_t K, int kmax);
+int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                             const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N, int64_t K,
+                             int64_t B, int kmax, int32_t* slot, int32_t* new_in_ptr, int32_t* new_in_src,
+                             int32_t* new_out_ptr, int32_t* new_out_dst, int32_t* new_out_eid, int32_t* new_loops,
+                             void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Family B backward.  Edge-softmax gradients are split into a destination-side pass that writes per-edge buffers in
  * in-CSR order (E entries, then one self-loop entry per node at E + row) and a source-side pass that reads them

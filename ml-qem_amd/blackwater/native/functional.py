@@ -5,6 +5,9 @@ and backward are short, fixed sequences of launches with the element-wise work f
 generic differentiable building blocks ``csr_aggregate``, ``linear`` and ``segment_mean``."""
 from __future__ import annotations
 
+import os
+
+import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -406,6 +409,11 @@ def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
     return _TransformerConv.apply(x, w, b, struct, heads, channels, drop_p, seed)
 
 
+# MLQEM_ASAP_DENSE=0 forces the general two-hop coarsening (four device->host size reads per pooling) for every batch; the
+# default uses the sync-free dense form whenever every graph of the batch pools to <= 512 clusters.
+_ASAP_DENSE = os.environ.get("MLQEM_ASAP_DENSE", "1") != "0"
+
+
 class _ASAPool(Function):
     """ASAPooling as ONE autograd node.  Differentiable output: x_out = x'[perm] * fitness[perm]; the pooled structure
     and ``perm`` are data-dependent side results handed back through ``holder``."""
@@ -413,8 +421,6 @@ class _ASAPool(Function):
     @staticmethod
     def forward(ctx, x, lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w, l3_b, struct: GraphStructure, ratio, slope,
                 holder):
-        import math
-
         s = struct
         x = ops.rowmajor(x)
         d, n = x.shape[1], s.num_nodes
@@ -427,19 +433,26 @@ class _ASAPool(Function):
         w3 = torch.cat([l1_w, l2_w, l3_w], 0).contiguous()
         b3 = torch.cat([l1_b, torch.zeros_like(l1_b), l3_b], 0)
         fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
-        # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk
-        keep = [int(math.ceil(float(torch.tensor(ratio * float(m), dtype=torch.float32)))) for m in s.graph_sizes]
-        new_ptr_host = [0]
-        for k in keep:
-            new_ptr_host.append(new_ptr_host[-1] + k)
-        k_total = new_ptr_host[-1]
-        new_ptr = torch.tensor(new_ptr_host, dtype=torch.int32, device=x.device)
+        # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk (float32 tensor times a python scalar)
+        sizes = np.asarray(s.graph_sizes, dtype=np.int64)
+        keep = np.ceil(sizes.astype(np.float32) * np.float32(ratio)).astype(np.int64)
+        new_ptr_host = np.zeros(len(keep) + 1, dtype=np.int64)
+        np.cumsum(keep, out=new_ptr_host[1:])
+        k_total = int(new_ptr_host[-1])
+        new_ptr = torch.from_numpy(new_ptr_host.astype(np.int32)).to(x.device, non_blocking=True)
         perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total)
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
-        ei, slot = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n, return_slot=True)
-        csr = ops.csr_build(ei, k_total)
+        dense_ok = _ASAP_DENSE and len(keep) > 0 and int(keep.max()) <= ops.asap_dense_max_k()
+        if dense_ok:
+            # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
+            csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
+            num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
+        else:
+            ei, slot = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n, return_slot=True)
+            csr = ops.csr_build(ei, k_total)
+            num_edges = int(ei.shape[1])
         holder["structure"] = GraphStructure(k_total, csr[0], csr[1], csr[2], csr[3], csr[4], new_ptr, s.num_graphs,
-                                             num_edges=int(ei.shape[1]), graph_sizes=keep, out_eid=csr.out_eid)
+                                             num_edges=num_edges, graph_sizes=keep, out_eid=csr.out_eid)
         holder["perm"] = perm
         ctx.struct, ctx.slope, ctx.d = s, slope, d
         ctx.save_for_backward(x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3)

@@ -604,6 +604,33 @@ def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes, return_slot=
     return (ei, slot) if return_slot else ei
 
 
+def asap_coarsen_dense(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, keep_sizes):
+    """Pooled structure arrays (in_ptr, in_src, out_ptr, out_dst, out_eid, loops, slot) and the capacity of the edge
+    arrays, with NO device->host copy (mlqem_asap_coarsen_dense).  ``keep_sizes``: host array of k_g per graph."""
+    import numpy as np
+
+    keep = np.asarray(keep_sizes, dtype=np.int64)
+    b, k = int(keep.shape[0]), int(keep.sum())
+    kmax = int(keep.max()) if b else 0
+    cap = int((keep * (keep - 1)).sum())
+    dev = perm.device
+    lib = _lib.load()
+    mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    slot, in_ptr, out_ptr, loops = mk(num_nodes), mk(k + 1), mk(k + 1), mk(k)
+    in_src, out_dst, out_eid = mk(cap), mk(cap), mk(cap)
+    need = lib.mlqem_asap_coarsen_dense_workspace_bytes(b, k, kmax)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    code = lib.mlqem_asap_coarsen_dense(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(graph_ptr), _p(new_graph_ptr),
+                                        _p(perm), num_nodes, k, b, kmax, _p(slot), _p(in_ptr), _p(in_src), _p(out_ptr),
+                                        _p(out_dst), _p(out_eid), _p(loops), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_asap_coarsen_dense")
+    return CsrArrays(in_ptr, in_src, out_ptr, out_dst, loops, out_eid), slot, cap
+
+
+def asap_dense_max_k() -> int:
+    return int(_lib.load().mlqem_asap_coarsen_dense_max_k())
+
+
 # ------------------------------------------------------------------------------------------ Family B backward
 def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0):
     n, hc = qkvs.shape[0], heads * channels

@@ -126,6 +126,114 @@ __global__ __launch_bounds__(kBlock) void keys_to_edge_index_kernel(const uint64
   ei[E + e] = (int64_t)(keys[e] & 0xFFFFFFFFull);
 }
 
+// ------------------------------------------------------------- coarsened connectivity, small graphs, no host sync
+// The two-hop path above sizes its buffers from totals the host reads back (four 8-byte device->host copies per
+// pooling: each one drains the queue).  For graphs whose pooled size k_g is at most kDenseMaxK -- every dataset the
+// reference ships (<= 97 nodes per circuit) and the 4- and 20-qubit synthetic corpora -- the pooled adjacency of a graph
+// fits in LDS as a k_g x k_g BIT matrix, and nothing data-dependent has to be known on the host:
+//   kernel 1 (one workgroup per graph): for every node u, every pair (p, q), p in cl(u), q in cl(v), v in N+[u]
+//            (cl(x) = kept centres among N+[x]; N+ includes the node) sets bit (p, q), p != q -- an idempotent LDS
+//            atomicOr, so the result does not depend on the order; row / column popcounts give both degree vectors;
+//   device scans turn the degrees into in_ptr / out_ptr (clusters are numbered graph by graph, so the global prefix
+//            sums ARE the CSR pointers);
+//   kernel 2 scans rows (out_dst, ascending q) and columns (in_src, ascending p: the order of the reference's coalesced
+//            COO list) and links the two (out_eid).
+// The host only provides a capacity: sum_g k_g (k_g - 1) entries, never touched beyond the true edge count.
+constexpr int kDenseMaxK = 512;
+
+struct DenseArgs {
+  const int32_t* in_ptr; const int32_t* in_src; const int32_t* out_ptr; const int32_t* out_dst;
+  const int32_t* gptr; const int32_t* new_gptr; const int32_t* slot;
+  int W;                         // 32-bit words per bitmap row (uniform over the batch)
+  uint32_t* bitmaps;             // [B][kmax][W]
+  int kmax;
+  int32_t* outdeg; int32_t* indeg;   // [K + 1]
+};
+
+__global__ __launch_bounds__(kBlock) void coarsen_dense_bitmap_kernel(const DenseArgs a) {
+  extern __shared__ uint32_t s_bm[];   // [kg][W]
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int n0 = a.gptr[g], n1 = a.gptr[g + 1];
+  const int k0 = a.new_gptr[g], kg = a.new_gptr[g + 1] - k0;
+  const int W = a.W;
+  for (int i = tid; i < kg * W; i += kBlock) s_bm[i] = 0u;
+  __syncthreads();
+  for (int u = n0 + tid; u < n1; u += kBlock) {
+    const int ub = a.out_ptr[u], ue = a.out_ptr[u + 1];
+    for (int ci = ub - 1; ci < ue; ++ci) {                 // c over {u} + out(u)
+      const int c = ci < ub ? u : a.out_dst[ci];
+      const int p = a.slot[c];
+      if (p < 0) continue;
+      uint32_t* row = s_bm + (p - k0) * W;
+      for (int vi = ub - 1; vi < ue; ++vi) {               // v over {u} + out(u)
+        const int v = vi < ub ? u : a.out_dst[vi];
+        const int vb = a.out_ptr[v], ve = a.out_ptr[v + 1];
+        for (int di = vb - 1; di < ve; ++di) {             // d over {v} + out(v)
+          const int d = di < vb ? v : a.out_dst[di];
+          const int q = a.slot[d];
+          if (q >= 0 && q != p) atomicOr(row + ((q - k0) >> 5), 1u << ((q - k0) & 31));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t* gb = a.bitmaps + (int64_t)g * a.kmax * W;
+  for (int i = tid; i < kg * W; i += kBlock) gb[i] = s_bm[i];
+  for (int r = tid; r < kg; r += kBlock) {
+    int od = 0, id = 0;
+    for (int w = 0; w < W; ++w) od += __popc(s_bm[r * W + w]);
+    const int wq = r >> 5;
+    const uint32_t mq = 1u << (r & 31);
+    for (int rr = 0; rr < kg; ++rr) id += (s_bm[rr * W + wq] & mq) ? 1 : 0;   // column r
+    a.outdeg[k0 + r] = od;
+    a.indeg[k0 + r] = id;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_dense_fill_kernel(const DenseArgs a, const int32_t* __restrict__ in_ptr_new,
+                                                                    const int32_t* __restrict__ out_ptr_new,
+                                                                    int32_t* __restrict__ in_src_new,
+                                                                    int32_t* __restrict__ out_dst_new,
+                                                                    int32_t* __restrict__ out_eid_new) {
+  extern __shared__ uint32_t s_bm[];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int k0 = a.new_gptr[g], kg = a.new_gptr[g + 1] - k0;
+  const int W = a.W;
+  const uint32_t* gb = a.bitmaps + (int64_t)g * a.kmax * W;
+  for (int i = tid; i < kg * W; i += kBlock) s_bm[i] = gb[i];
+  __syncthreads();
+  for (int r = tid; r < kg; r += kBlock) {
+    int pos = out_ptr_new[k0 + r];                         // row r: destinations in ascending order
+    for (int w = 0; w < W; ++w) {
+      uint32_t bits = s_bm[r * W + w];
+      while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        out_dst_new[pos++] = k0 + w * 32 + b;
+      }
+    }
+    int ipos = in_ptr_new[k0 + r];                         // column r: sources in ascending order
+    const int wq = r >> 5;
+    const uint32_t mq = 1u << (r & 31), below = mq - 1u;
+    for (int rr = 0; rr < kg; ++rr) {
+      const uint32_t* row = s_bm + rr * W;
+      if (!(row[wq] & mq)) continue;
+      in_src_new[ipos] = k0 + rr;
+      int rank = __popc(row[wq] & below);                  // position of (rr -> r) inside row rr of the out-CSR
+      for (int w = 0; w < wq; ++w) rank += __popc(row[w]);
+      out_eid_new[out_ptr_new[k0 + rr] + rank] = ipos;
+      ++ipos;
+    }
+  }
+}
+
+static size_t dense_scan_bytes(int64_t K) {
+  size_t temp = 0;
+  (void)rocprim::exclusive_scan(nullptr, temp, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(K + 1),
+                                rocprim::plus<int32_t>(), (hipStream_t)0);
+  return (temp + 255) / 256 * 256;
+}
+
 }  // namespace mlqem
 
 using namespace mlqem;
@@ -290,5 +398,60 @@ extern "C" int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t
   if (!keys || !edge_index) return MLQEM_ERR_BAD_ARG;
   hipLaunchKernelGGL(keys_to_edge_index_kernel, dim3((unsigned)ceil_div(E, kBlock)), dim3(kBlock), 0,
                      as_stream(stream), keys, E, edge_index);
+  return launch_status();
+}
+
+extern "C" int mlqem_asap_coarsen_dense_max_k(void) { return kDenseMaxK; }
+
+extern "C" size_t mlqem_asap_coarsen_dense_workspace_bytes(int64_t B, int64_t K, int kmax) {
+  if (B < 0 || K < 0 || kmax < 0) return 0;
+  const size_t W = (size_t)(kmax + 31) / 32;
+  const size_t bm = ((size_t)B * kmax * W * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
+  return bm + 2 * deg + dense_scan_bytes(K);
+}
+
+extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                        const int32_t* out_dst, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
+                                        const int32_t* perm, int64_t N, int64_t K, int64_t B, int kmax, int32_t* slot,
+                                        int32_t* new_in_ptr, int32_t* new_in_src, int32_t* new_out_ptr, int32_t* new_out_dst,
+                                        int32_t* new_out_eid, int32_t* new_loops, void* workspace, size_t workspace_bytes,
+                                        mlqem_stream_t stream_) {
+  begin_launches();
+  hipStream_t stream = as_stream(stream_);
+  if (N < 0 || K < 0 || K > N || B < 0 || kmax < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if (kmax > kDenseMaxK) return MLQEM_ERR_UNSUPPORTED;
+  if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_asap_coarsen_dense_workspace_bytes(B, K, kmax)) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  if (K == 0 || B == 0) {
+    (void)hipMemsetAsync(new_in_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
+    (void)hipMemsetAsync(new_out_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
+    return launch_status();
+  }
+  if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm || !new_in_src || !new_out_dst || !new_loops)
+    return MLQEM_ERR_BAD_ARG;
+  const int W = (kmax + 31) / 32;
+  const size_t bm = ((size_t)B * kmax * W * sizeof(uint32_t) + 255) / 256 * 256;
+  const size_t deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
+  char* ws = static_cast<char*>(workspace);
+  DenseArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, slot, W, reinterpret_cast<uint32_t*>(ws), kmax,
+              reinterpret_cast<int32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + bm + deg)};
+  void* temp = ws + bm + 2 * deg;
+  size_t temp_bytes = dense_scan_bytes(K);
+  if (hipMemsetAsync(a.outdeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  if (hipMemsetAsync(a.indeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  if (hipMemsetAsync(new_loops, 0, sizeof(int32_t) * (size_t)K, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
+  const size_t lds = (size_t)kmax * W * sizeof(uint32_t);
+  hipLaunchKernelGGL(coarsen_dense_bitmap_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, a);
+  if (rocprim::exclusive_scan(temp, temp_bytes, a.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
+                              stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  if (rocprim::exclusive_scan(temp, temp_bytes, a.indeg, new_in_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
+                              stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(coarsen_dense_fill_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, a, new_in_ptr, new_out_ptr,
+                     new_in_src, new_out_dst, new_out_eid);
   return launch_status();
 }

@@ -295,3 +295,72 @@ def test_family_b_trains_through_the_reference_loop(golden_dir, g1):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < 0.5 * losses[0]
+
+
+def test_dense_sync_free_coarsening_equals_the_two_hop_path(golden_dir, g1):
+    """ASAPooling's coarsened connectivity built as per-graph bit matrices in LDS (no device->host copy; the default for
+    graphs that pool to <= 512 clusters) against the general two-hop path (count -> read back -> fill -> sort-unique):
+    identical CSR arrays at both pooling levels, hence bit-identical model outputs."""
+    from blackwater.native import functional as F
+    from blackwater.native.structure import GraphStructure
+    from blackwater.nn import family_b_from_state_dict
+
+    sd = _ckpt(golden_dir, "gnn1.pth")
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    for self_loops in (True, False):
+        batch = g1_batch(g1, list(range(60, 100)) + [299, 0, 150], self_loops=self_loops, first_only=False)
+        n, b = batch["x"].shape[0], batch["noisy"].shape[0]
+        results = {}
+        for dense in (True, False):
+            F._ASAP_DENSE = dense
+            try:
+                with torch.no_grad():
+                    s = GraphStructure.from_edge_index(batch["edge_index"].to(DEV), n, batch=batch["batch"].to(DEV), num_graphs=b)
+                    h = model.transformer1(batch["x"].to(DEV), s)
+                    h1, s1, perm1 = model.pooling1(h, s)
+                    h2, s2, perm2 = model.pooling2(model.transformer2(h1, s1), s1)
+                    out = model(batch["noisy"].to(DEV), None, batch["depth"].to(DEV), batch["x"].to(DEV),
+                                batch["edge_index"].to(DEV), batch["batch"].to(DEV))
+            finally:
+                F._ASAP_DENSE = True
+            results[dense] = (s1, s2, perm1, perm2, out)
+        for lvl in (0, 1):
+            a, c = results[True][lvl], results[False][lvl]
+            e = int(c.in_ptr[c.num_nodes].item())
+            assert e == c.num_edges and a.num_edges >= e            # the dense path only knows a capacity on the host
+            assert torch.equal(a.in_ptr[:a.num_nodes + 1], c.in_ptr[:c.num_nodes + 1])
+            assert torch.equal(a.out_ptr[:a.num_nodes + 1], c.out_ptr[:c.num_nodes + 1])
+            assert torch.equal(a.in_src[:e], c.in_src[:e]) and torch.equal(a.out_dst[:e], c.out_dst[:e])
+            assert torch.equal(a.out_eid[:e], c.out_eid[:e])
+            assert not a.loops[:a.num_nodes].any()
+        assert torch.equal(results[True][2], results[False][2]) and torch.equal(results[True][3], results[False][3])
+        assert torch.equal(results[True][4], results[False][4])
+
+
+def test_family_b_train_step_makes_no_device_to_host_copy(golden_dir, g1):
+    """A Family B train step on an arena batch of small graphs enqueues without a single device->host read: checked by
+    making every synchronising call an error (torch.cuda.set_sync_debug_mode) around the step."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.nn import ExpValCircuitGraphModel
+    from blackwater.train import Trainer
+
+    xs, eis = [], []
+    for i in range(64):
+        x, ei, _ = g1_graph(g1, i)
+        loops = np.arange(x.shape[0])
+        xs.append(x.astype(np.float32))
+        eis.append(np.concatenate([ei, np.stack([loops, loops])], axis=1))
+    arena = GraphArena.from_arrays(xs, eis, g1["ideal"][:64, None, :].astype(np.float32),
+                                   g1["noisy"][:64, None, :].astype(np.float32),
+                                   g1["depth"][:64, None].astype(np.float32), np.zeros((64, 1, 1), np.float32), device=DEV)
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel(22, 15, 4).to(DEV)
+    trainer = Trainer(model, lr=1e-3)
+    trainer.step(arena.batch(np.arange(32)))          # warm-up: allocator growth, lazily built tables
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss = trainer.step(arena.batch(np.arange(32, 64)))
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(loss).item()
