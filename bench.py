@@ -255,6 +255,109 @@ def accuracy_leg(dev):
     return out
 
 
+def family_b_leg(dev, steps=30):
+    """The reference's own model family (docs/tutorials/gnn.py:70-122: TransformerConv / ASAPooling x2, hidden 15, 4 outputs)
+    as a measured workload: full train steps on cfg2 (synthetic 4-qubit TFIM-Trotter circuits, steps 0-14) at 1024
+    circuits per step and at the reference's 32, plus the roofline of its dominant graph kernel, the attention forward
+    (4(N+1) + 4E' + 4HC(N [q] + E' [k] + E' [v] + N [out]), E' counts the self-loop entry)."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import TfimCorpus
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModel
+    from blackwater.train import Trainer
+
+    corpus = TfimCorpus(4, list(range(15)), 70, seed=42, two_q="cx", exp_value_size=4)
+    h = corpus.host_graphs()
+    arena = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"],
+                                   device=dev)
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel(22, 15, 4).to(dev)
+    trainer = Trainer(model, lr=1e-3)
+    rng = np.random.RandomState(7)
+    out = {"model": "family B: TransformerConv(22,15,h3) ASAP TransformerConv(45,15,h2) ASAP mean-pool head, 13 645 parameters",
+           "workload": "cfg2: 4-qubit TFIM Trotter steps 0-14 x 70 J values (1 050 circuits, %.0f nodes per circuit)"
+                       % (arena.num_nodes / len(arena))}
+    for batch, n_steps in ((1024, steps), (32, 4 * steps)):
+        draw = lambda: rng.randint(0, len(arena), size=batch)
+        for _ in range(5):
+            trainer.step(arena.batch(draw()))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            trainer.step(arena.batch(draw()))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"batch{batch}"] = {"circuits_per_s": round(batch * n_steps / dt, 1), "ms_per_step": round(dt / n_steps * 1e3, 3),
+                                "steps": n_steps}
+    b = arena.batch(np.arange(1024) * len(arena) // 1024)
+    s = b.structure
+    n, e, heads, ch = s.num_nodes, s.num_edges, 3, 15
+    hc = heads * ch
+    qk = [ops.padded_empty(n, 4 * hc, dev).normal_() for _ in range(4)]
+    run = lambda k: ops.transformer_attention_train(qk[k % 4], s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 1234 + k)
+    for k in range(4):
+        run(k)
+    stream = torch.cuda.current_stream()
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    beg.record(stream)
+    for k in range(20):
+        run(k)
+    end.record(stream)
+    end.synchronize()
+    sec = beg.elapsed_time(end) * 1e-3 / 20
+    e1 = e + n
+    by = 4 * (n + 1) + 4 * e1 + 4 * hc * (n + e1 + e1 + n)
+    out["roofline"] = {"bound": "hbm", "kernel": "transformer_attn_train_kernel (H=3, C=15, attention dropout 0.1)",
+                       "achieved": round(by / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / sec / 1e9 / 8000.0, 4),
+                       "traffic": None, "bytes_per_launch": int(by), "us_per_launch": round(sec * 1e6, 2), "nodes": n,
+                       "edges_with_loops": e1,
+                       "note": "a 1024-circuit batch of 4-qubit graphs is 0.23 M nodes: the launch is %.0f us long and the step is "
+                               "bound by launch count, not by this kernel" % (sec * 1e6)}
+    return out
+
+
+def small_batch_leg(dev, steps=300):
+    """The reference's batch size (32, docs/tutorials/__ml_models.py:105) on cfg2 (4-qubit TFIM circuits, Family A): the
+    step is ~8 k graph nodes, i.e. launch-bound.  ``eager`` = the ordinary Trainer (one Python-enqueued launch sequence per
+    step); ``hipgraph`` = BucketedTrainer: the whole step captured per size bucket and replayed with one launch."""
+    from blackwater.data.synthetic import TfimCorpus
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import BucketedTrainer, Trainer
+
+    corpus = TfimCorpus(4, list(range(15)), 70, seed=42, two_q="cx", exp_value_size=1)
+    arena = corpus.arena(dev, filler_nodes=4096)
+    rng = np.random.RandomState(11)
+    plans = [rng.choice(len(arena), size=32, replace=False) for _ in range(steps + 200)]
+    out = {"workload": "cfg2: 4-qubit TFIM Trotter steps 0-14 x 70 J values, family A, 32 circuits per step "
+                       "(%.0f nodes per circuit)" % (arena.num_nodes / len(arena))}
+    for mode in ("eager", "hipgraph"):
+        torch.manual_seed(0)
+        model = ExpValCircuitGraphModelA(4, 22, 10).to(dev)
+        if mode == "eager":
+            ops.set_seed_counter(None)
+            tr = Trainer(model, lr=1e-3)
+            run = lambda ids: tr.step(arena.batch(ids))
+        else:
+            tr = BucketedTrainer(model, arena, lr=1e-3, graphs=True, node_quantum=1024, edge_quantum=4096)
+            run = tr.step_ids
+        for ids in plans[:200]:          # allocator growth / every bucket captured
+            run(ids)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ids in plans[200:]:
+            loss = run(ids)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[mode] = {"circuits_per_s": round(32 * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+                     "final_loss": round(float(loss.item()), 6)}
+        if mode == "hipgraph":
+            out[mode]["buckets_captured"] = len(tr._entries)
+    ops.set_seed_counter(None)
+    out["speedup"] = round(out["hipgraph"]["circuits_per_s"] / out["eager"]["circuits_per_s"], 2)
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run.  Nothing in
     this process has touched the GPU (torch.cuda.device_count() does not initialise it on this image); the parent only
@@ -383,6 +486,8 @@ def main():
             del trainer, model, arena, fixed
             torch.cuda.empty_cache()
             line["accuracy"] = accuracy_leg(dev)
+            line["family_b"] = family_b_leg(dev)
+            line["small_batch"] = small_batch_leg(dev)
         print(json.dumps(line), flush=True)
     if distributed:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: leave together

@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 4 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 5 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -87,11 +87,13 @@ int mlqem_graph_norms(const int32_t* in_ptr, const int32_t* out_ptr, const int32
  * CONTRACT: with 16-byte-aligned rows the columns C .. round_up(C,4)-1 of `out` ARE WRITTEN (scratch values).  A
  * caller whose `out` is a column slice of a wider matrix must pass an unaligned base / a leading dimension that is
  * not a multiple of 4, or use a padded buffer; the Python binding refuses such slices (ops._owns_pad_columns).
+ * seed_counter (may be NULL): a device-resident uint64 added (times an odd constant) to `seed` when the dropout mask is
+ * drawn -- a launch captured in a hipGraph then draws a fresh mask on every replay as the caller bumps the counter.
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
                             const float* cscale, const float* rscale, const float* dself, float alpha, float beta,
                             const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
-                            float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
+                            const uint64_t* seed_counter, float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
 
 /* Segment max with the node itself included: out[i,:] = max(x[i,:], max_e x[idx[e],:])
  * (ASAPooling's scatter(..., reduce='max') after add_remaining_self_loops; docs/tutorials/gnn.py:85,92). */
@@ -218,6 +220,9 @@ int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const floa
  * without a strided copy --, src_node[Nb] (arena row of every batch node), both CSR structures (node ids rebased to
  * the batch), loops and, when the arena's ELL side tables a_in_ell / a_out_ell (mlqem_ell_from_csr over the arena)
  * are given, the batch's side tables in_ell_b / out_ell_b [Nb,2] rebased the same way (NULL = not wanted).
+ * Fixed-shape launches (hipGraph replay over size buckets): Nb must equal b_nptr[B], but Eb may be a CAPACITY >= b_eptr[B];
+ * the kernels take the real edge total from b_eptr[B] on the device, so one captured launch serves every selection whose
+ * totals fit the bucket (the caller pads the node count with a slice of an edgeless filler graph of the arena).
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal, int K, const int32_t* a_gptr,
                          const int32_t* a_in_ptr, const int32_t* a_in_src, const int32_t* a_out_ptr,

@@ -24,11 +24,13 @@ class DeviceBatch:
     batch's rows of the arena -- which the first layers of the models read through the row map.  ``x`` materialises (and
     caches) the gathered [N, F] matrix for anything that wants a plain tensor."""
 
-    def __init__(self, nodes, structure, y, noisy, depth, observable, graph_ids):
+    def __init__(self, nodes, structure, y, noisy, depth, observable, graph_ids, num_real=None):
         self.nodes, self.structure = nodes, structure
         self.y, self.noisy_0, self.circuit_depth, self.observable = y, noisy, depth, observable
         self.graph_ids = graph_ids
         self.num_graphs = structure.num_graphs
+        # a batch padded to a size bucket ends in a slice of the arena's edgeless filler graph: its output row is not a circuit
+        self.num_real = self.num_graphs if num_real is None else int(num_real)
         self._x = nodes if isinstance(nodes, torch.Tensor) else None
 
     @property
@@ -54,8 +56,12 @@ def _ranges(starts, lengths):
 
 
 class GraphArena:
-    def __init__(self, x, node_counts, structure_arrays, nscal, y, noisy, depth, observable, edge_counts, ell=None):
+    def __init__(self, x, node_counts, structure_arrays, nscal, y, noisy, depth, observable, edge_counts, ell=None,
+                 filler_nodes=0):
         self.x = x
+        # the LAST graph is an edgeless, all-zero filler of `filler_nodes` nodes when filler_nodes > 0: batches padded to a
+        # size bucket (batch(..., bucket=)) end in a slice of it; it is not part of len(arena)
+        self.filler_nodes = int(filler_nodes)
         self.node_counts = np.asarray(node_counts, dtype=np.int64)
         self.edge_counts = np.asarray(edge_counts, dtype=np.int64)
         self.gptr, self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops, self.out_eid = structure_arrays
@@ -69,23 +75,23 @@ class GraphArena:
         self.device = x.device
 
     def __len__(self):
-        return len(self.node_counts)
+        return len(self.node_counts) - (1 if self.filler_nodes else 0)
 
     @property
     def num_nodes(self):
-        return int(self.node_counts.sum())
+        return int(self.node_counts.sum()) - self.filler_nodes
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
     def from_arrays(xs: Sequence[np.ndarray], edge_indices: Sequence[np.ndarray], y, noisy, depth, observable,
-                    device="cuda") -> "GraphArena":
+                    device="cuda", filler_nodes: int = 0) -> "GraphArena":
         """xs[g]: [n_g,F] float; edge_indices[g]: [2,e_g] graph-local int (self-loops allowed, e.g. after
         ``AddSelfLoops``); y/noisy/depth/observable: per-graph arrays with leading dimension G."""
         node_counts = np.array([a.shape[0] for a in xs], dtype=np.int64)
         offs = np.concatenate([[0], np.cumsum(node_counts)])
         x_host = np.ascontiguousarray(np.concatenate(xs, axis=0), dtype=np.float32)
         ei = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(edge_indices, offs[:-1])], axis=1)
-        return GraphArena._from_flat(x_host, node_counts, ei, y, noisy, depth, observable, device)
+        return GraphArena._from_flat(x_host, node_counts, ei, y, noisy, depth, observable, device, filler_nodes)
 
     @staticmethod
     def from_shards(shards, device="cuda", rank: int = 0, world: int = 1) -> "GraphArena":
@@ -124,22 +130,33 @@ class GraphArena:
                                      ei, lab["y"], lab["noisy"], lab["depth"], lab["observable"], device)
 
     @staticmethod
-    def _from_flat(x_host, node_counts, ei, y, noisy, depth, observable, device) -> "GraphArena":
+    def _from_flat(x_host, node_counts, ei, y, noisy, depth, observable, device, filler_nodes=0) -> "GraphArena":
         """x_host [N,F] f32 (graphs back to back), ei [2,E] int64 with arena-global node ids."""
         f = x_host.shape[1]
         f4 = (f + 3) // 4 * 4                                    # rows padded to a multiple of 4 floats, pads zero
         x = torch.zeros((x_host.shape[0], f4), dtype=torch.float32, device=torch.device(device))[:, :f]
         x.copy_(torch.from_numpy(x_host))
         ei_dev = torch.from_numpy(np.ascontiguousarray(ei)).to(device)
-        return GraphArena.from_device(x, node_counts, ei_dev, y, noisy, depth, observable)
+        return GraphArena.from_device(x, node_counts, ei_dev, y, noisy, depth, observable, filler_nodes)
 
     @staticmethod
-    def from_device(x: torch.Tensor, node_counts, ei_dev: torch.Tensor, y, noisy, depth, observable) -> "GraphArena":
+    def from_device(x: torch.Tensor, node_counts, ei_dev: torch.Tensor, y, noisy, depth, observable,
+                    filler_nodes: int = 0) -> "GraphArena":
         """From tensors already on the device: ``x`` [N,F] fp32 in the padded row layout (row stride a multiple of 4
         floats, pad columns zero), graphs back to back; ``ei_dev`` [2,E] int64 with arena-global node ids; labels as
-        host arrays with leading dimension G."""
+        host arrays with leading dimension G.  ``filler_nodes`` > 0 appends the edgeless all-zero filler graph that
+        bucket-padded batches draw from."""
         device = x.device
         node_counts = np.asarray(node_counts, dtype=np.int64)
+        if filler_nodes > 0:
+            f = x.shape[1]
+            f4 = (f + 3) // 4 * 4
+            grown = torch.zeros((x.shape[0] + filler_nodes, f4), dtype=torch.float32, device=device)[:, :f]
+            grown[:x.shape[0]].copy_(x)
+            x = grown
+            node_counts = np.concatenate([node_counts, [filler_nodes]])
+            zrow = lambda a: np.concatenate([np.asarray(a), np.zeros((1,) + np.asarray(a).shape[1:], dtype=np.asarray(a).dtype)])
+            y, noisy, depth, observable = zrow(y), zrow(noisy), zrow(depth), zrow(observable)
         offs = np.concatenate([[0], np.cumsum(node_counts)])
         n_total = int(offs[-1])
         if x.shape[0] != n_total or x.dtype != torch.float32 or (n_total > 1 and (x.stride(0) % 4 or x.stride(1) != 1)):
@@ -158,7 +175,7 @@ class GraphArena:
         edge_counts = np.diff(in_ptr[gptr.long()].cpu().numpy()).astype(np.int64)
         t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
         return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops, csr.out_eid), nscal, t(y), t(noisy),
-                          t(depth), t(observable), edge_counts, ell=ell)
+                          t(depth), t(observable), edge_counts, ell=ell, filler_nodes=filler_nodes)
 
     @staticmethod
     def from_data_list(graphs, device="cuda") -> "GraphArena":
@@ -172,19 +189,48 @@ class GraphArena:
         return GraphArena.from_arrays(xs, eis, y, noisy, depth, obs, device=device)
 
     # ------------------------------------------------------------------------------------------------
-    def batch(self, graph_ids) -> DeviceBatch:
-        """Gathers the graphs ``graph_ids`` (host ints, any order, repeats allowed) into one batch on the device."""
+    def selection(self, graph_ids, bucket=None):
+        """Host side of a batch: (sel, nptr, eptr, Nb, Eb, number of real graphs).  With ``bucket = (n_pad, e_pad)`` the
+        batch is padded to exactly n_pad nodes by a slice of the filler graph (appended as one more, edgeless, graph) and
+        Eb = e_pad is a capacity: every kernel of a step then launches with the same shapes for all selections that fit the
+        bucket -- what a captured hipGraph needs."""
         sel = np.asarray(graph_ids, dtype=np.int64)
         b = int(sel.shape[0])
         if b == 0:
             raise ValueError("empty batch")
-        nptr = np.zeros(b + 1, dtype=np.int64)
-        eptr = np.zeros(b + 1, dtype=np.int64)
-        np.cumsum(self.node_counts[sel], out=nptr[1:])
-        np.cumsum(self.edge_counts[sel], out=eptr[1:])
+        if sel.min() < 0 or sel.max() >= len(self):
+            raise IndexError("graph id out of range")
+        n_of, e_of = self.node_counts[sel], self.edge_counts[sel]
+        if bucket is not None:
+            n_pad, e_pad = int(bucket[0]), int(bucket[1])
+            nb, eb = int(n_of.sum()), int(e_of.sum())
+            if not self.filler_nodes:
+                raise ValueError("bucketed batches need an arena built with filler_nodes > 0")
+            if nb > n_pad or eb > e_pad or n_pad - nb > self.filler_nodes:
+                raise ValueError(f"selection ({nb} nodes, {eb} edges) does not fit bucket {bucket} (filler {self.filler_nodes})")
+            sel = np.concatenate([sel, [len(self)]])
+            n_of, e_of = np.concatenate([n_of, [n_pad - nb]]), np.concatenate([e_of, [0]])
+        nptr = np.zeros(len(sel) + 1, dtype=np.int64)
+        eptr = np.zeros(len(sel) + 1, dtype=np.int64)
+        np.cumsum(n_of, out=nptr[1:])
+        np.cumsum(e_of, out=eptr[1:])
         nb, eb = int(nptr[-1]), int(eptr[-1])
+        if bucket is not None:
+            eb = int(bucket[1])
+        return sel, nptr, eptr, nb, eb, b
+
+    def batch(self, graph_ids, bucket=None) -> DeviceBatch:
+        """Gathers the graphs ``graph_ids`` (host ints, any order, repeats allowed) into one batch on the device."""
+        sel, nptr, eptr, nb, eb, b_real = self.selection(graph_ids, bucket)
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.device, non_blocking=True)
-        sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:]
+        return self.assemble(packed, len(sel), nb, eb, self.node_counts[sel] if bucket is None else nptr[1:] - nptr[:-1],
+                             sel, b_real)
+
+    def assemble(self, packed: torch.Tensor, b: int, nb: int, eb: int, graph_sizes, sel_host=None, num_real=None) -> DeviceBatch:
+        """Device side of a batch: ``packed`` = [sel (b) | nptr (b + 1) | eptr (b + 1)] int32 on the device.  Nothing
+        here reads a host value other than the shapes, so with a persistent ``packed`` buffer the whole call can sit
+        inside a captured hipGraph and be replayed for another selection of the same bucket."""
+        sel_d, nptr_d, eptr_d = packed[:b], packed[b:2 * b + 1], packed[2 * b + 1:3 * b + 2]
         dev, f = self.device, self.x.shape[1]
         f4 = (f + 3) // 4 * 4
         k = int(self.nscal.shape[1])
@@ -203,8 +249,8 @@ class GraphArena:
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[0, :nb], nscal_b[1, :nb], nscal_b[2, :nb])
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,
-                           graph_sizes=self.node_counts[sel], out_eid=out_eid, ell=(in_ell, out_ell),
+                           graph_sizes=graph_sizes, out_eid=out_eid, ell=(in_ell, out_ell),
                            colsums=(nscal_b[3, :nb], nscal_b[4, :nb], nscal_b[5, :nb]))
         idx = sel_d.to(torch.int64)
         nodes = ops.RowsOf(self.x, src_node[:nb])     # the feature rows stay in the arena
-        return DeviceBatch(nodes, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel)
+        return DeviceBatch(nodes, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel_host, num_real)

@@ -237,7 +237,7 @@ class TfimCorpus:
                 "edge_index": [self.templates[int(g) // self.n_J]["edge_index"] for g in ids],
                 "y": self.y[ids], "noisy": self.noisy[ids], "depth": self.depth[ids], "observable": self.observables(ids)}
 
-    def arena(self, device, ids=None):
+    def arena(self, device, ids=None, filler_nodes: int = 0):
         """The graphs ``ids`` (ascending global ids; default all) as a device-resident arena, built by replicating the
         templates on the device.  Under data parallelism every rank passes its own shard of ids."""
         import torch
@@ -272,7 +272,7 @@ class TfimCorpus:
             base += c * n_t
         ei = torch.cat(ei_parts, dim=1) if ei_parts else torch.zeros((2, 0), dtype=torch.int64, device=dev)
         return GraphArena.from_device(x[:n_total, :f], self.node_counts[ids], ei, self.y[ids], self.noisy[ids],
-                                      self.depth[ids], self.observables(ids))
+                                      self.depth[ids], self.observables(ids), filler_nodes=filler_nodes)
 
 
 def tfim_corpus(nq: int, steps_list, n_J: int, seed: int = 42, two_q: str = "ecr", exp_value_size: int = 1,

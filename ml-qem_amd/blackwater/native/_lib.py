@@ -40,7 +40,7 @@ SIGNATURES = {
     "mlqem_graph_norms": (_I, [_P, _P, _P, _L, _P, _P, _P, _P]),
     "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
                                   _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _L, _L, _I, _P]),
+    "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _P, _L, _L, _I, _P]),
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
     "mlqem_relu_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _F, _P, _L, _L, _I, _P]),
@@ -84,7 +84,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 5   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -113,6 +113,18 @@ def _owns_pad_columns(t, name):
                          f"of every row; write into a padded_empty(N, {c}) buffer instead")
 
 
+_seed_counter = None   # optional device uint64 (an int64 tensor of one element) the dropout epilogues add to their seed
+
+
+def set_seed_counter(t):
+    """Installs (or, with None, removes) the device-resident step counter added to every dropout seed: launches captured
+    in a hipGraph draw a fresh mask per replay as the owner bumps the counter (train.BucketedTrainer)."""
+    global _seed_counter
+    if t is not None and (not t.is_cuda or t.dtype != torch.int64 or t.numel() != 1):
+        raise ValueError("seed counter: one int64 element on the device")
+    _seed_counter = t
+
+
 def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None, alpha=1.0, z=None, beta=0.0, bias=None,
                   relu=False, drop_p=0.0, seed=0, out=None):
     """out = act(alpha * (rscale * sum_e cscale[idx[e]] x[idx[e]] + dself * x) + beta * z + bias)."""
@@ -136,7 +148,8 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
         ldz = _mat(z, "z")
     code = _lib.load().mlqem_csr_aggregate_f32(
         _p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
-        _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), ldo, n, c, _stream())
+        _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+        _p(_seed_counter) if drop_p > 0 else None, _p(out), ldo, n, c, _stream())
     _lib.check(code, "mlqem_csr_aggregate_f32")
     return out
 

@@ -92,7 +92,8 @@ class ExpValCircuitGraphModelA(nn.Module):
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         train = self.training
         self._step += 1
-        seed = dropout_key(self._step)
+        # static_dropout_key: a device-resident step counter varies the masks instead (train.BucketedTrainer, hipGraph replay)
+        seed = dropout_key(0 if getattr(self, "static_dropout_key", False) else self._step)
         # Each hidden activation has exactly one consumer -- the next layer of its branch -- so the ReLU/dropout mask of
         # its backward is applied by that consumer's data-gradient GEMM (native/functional.py, "Mask hand-over").
         p1, p2 = (0.1, 0.2) if train else (0.0, 0.0)

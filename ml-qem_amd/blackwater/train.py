@@ -59,7 +59,8 @@ class DataParallelShard:
 
 
 class Trainer:
-    def __init__(self, model: nn.Module, lr: float = 1e-3, distributed: bool = False, flat: bool = True):
+    def __init__(self, model: nn.Module, lr: float = 1e-3, distributed: bool = False, flat: bool = True,
+                 capturable: bool = False):
         self.model = model
         self.distributed = distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world = torch.distributed.get_world_size() if self.distributed else 1
@@ -76,7 +77,11 @@ class Trainer:
             self.flat_param = self.flat_grad = None
             opt_params = list(model.parameters())
         fused = opt_params[0].is_cuda
-        self.optimizer = torch.optim.Adam(opt_params, lr=lr, fused=fused) if fused else torch.optim.Adam(opt_params, lr=lr)
+        if capturable:   # step count and learning rate live on the device: the update can sit inside a captured hipGraph
+            self.optimizer = torch.optim.Adam(opt_params, lr=torch.tensor(lr, dtype=torch.float32, device=opt_params[0].device),
+                                              fused=True, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(opt_params, lr=lr, fused=fused) if fused else torch.optim.Adam(opt_params, lr=lr)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", factor=0.1, patience=15,
                                                                     min_lr=1e-5)
         self.criterion = nn.MSELoss()
@@ -119,6 +124,9 @@ class Trainer:
             self.optimizer.zero_grad(set_to_none=False)
         out = self.model(*batch.model_args())
         target = batch.y if batch.y.dim() == 2 else torch.squeeze(batch.y, 1)
+        real = getattr(batch, "num_real", None)
+        if real is not None and real < out.shape[0]:   # a bucket-padded batch: the last row is the filler graph's
+            out, target = out[:real], target[:real]
         loss = self.criterion(out, target)
         loss.backward()
         if self.flat_grad is not None:
@@ -199,3 +207,118 @@ class Trainer:
             if log:
                 log(epoch, history)
         return history
+
+
+class BucketedTrainer(Trainer):
+    """The small-batch path (the reference's regime: batches of 32, docs/tutorials/__ml_models.py:105,148).
+
+    At 32 four-qubit circuits a train step is ~8 k graph nodes: every kernel runs for microseconds and the step costs what
+    the host needs to enqueue it (~2 ms of Python for ~100 launches).  Here the WHOLE step -- device batch assembly,
+    forward, loss, backward, gradient filing, Adam -- is captured once per SIZE BUCKET in a hipGraph (torch.cuda.CUDAGraph)
+    and replayed with one launch:
+
+    * a batch is padded to its bucket's node count with a slice of the arena's edgeless filler graph (its output row is
+      cut off before the loss) and the edge arrays are sized to the bucket's capacity, so every launch of the step has the
+      same shapes for every selection of the bucket (``GraphArena.selection(ids, bucket)``);
+    * what changes between replays lives in device memory: the packed selection (one small host->device copy per step) and
+      the dropout step counter (``ops.set_seed_counter``; bumped inside the graph);
+    * Adam runs with device-resident step / learning rate (``capturable=True``).
+
+    ``graphs=False`` runs the very same bucketed step eagerly: the two modes launch identical kernels with identical
+    arguments, so their loss trajectories agree bit for bit (tests/test_gpu_small_batch.py)."""
+
+    def __init__(self, model: nn.Module, arena, lr: float = 1e-3, graphs: bool = True, node_quantum: int = 1024,
+                 edge_quantum: int = 2048):
+        super().__init__(model, lr=lr, distributed=False, flat=True, capturable=True)
+        if not arena.filler_nodes:
+            raise ValueError("BucketedTrainer needs an arena built with filler_nodes > 0")
+        if node_quantum > arena.filler_nodes:
+            raise ValueError("node_quantum must not exceed the arena's filler_nodes")
+        from .native import ops
+
+        self.arena, self.graphs, self.nq, self.eq = arena, graphs, int(node_quantum), int(edge_quantum)
+        dev = self.flat_param.device
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.set_seed_counter(self.counter)
+        model.static_dropout_key = True          # seeds = key(seed, rank) + device counter instead of a host call counter
+        self._entries = {}
+        self._pool = None
+        self._warm = False
+
+    def bucket_of(self, graph_ids):
+        sel = np.asarray(graph_ids, dtype=np.int64)
+        nb, eb = int(self.arena.node_counts[sel].sum()), int(self.arena.edge_counts[sel].sum())
+        return (-(-nb // self.nq) * self.nq, -(-max(eb, 1) // self.eq) * self.eq, len(sel))
+
+    def _step_on(self, packed, b, n_pad, e_pad, sizes, num_real):
+        self.counter.add_(1)
+        batch = self.arena.assemble(packed, b, n_pad, e_pad, sizes, None, num_real)
+        return Trainer.step(self, batch)
+
+    def _warm_up(self, ids, bucket):
+        """torch asks for a few eager iterations on a side stream before the first capture (lazy initialisation of
+        libraries, the autograd engine's threads).  They must not count as training: parameters, Adam state and the
+        dropout counter are restored afterwards."""
+        dev = self.flat_param.device
+        keep = (self.flat_param.detach().clone(), self.counter.clone(), torch.cuda.get_rng_state(dev))
+        sel, nptr, eptr, nb, eb, real = self.arena.selection(ids, bucket[:2])
+        packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.flat_param.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._step_on(packed, len(sel), nb, eb, nptr[1:] - nptr[:-1], real)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            self.flat_param.copy_(keep[0])
+            self.counter.copy_(keep[1])
+            for st in self.optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.cuda.synchronize()
+        torch.cuda.set_rng_state(keep[2], dev)
+        self._warm = True
+
+    def step_ids(self, graph_ids) -> torch.Tensor:
+        """One optimisation step on the graphs ``graph_ids`` of the arena; returns the loss (a device tensor that the
+        NEXT step of the same bucket overwrites in graph mode: read or clone it before stepping again)."""
+        bucket = self.bucket_of(graph_ids)
+        sel, nptr, eptr, nb, eb, real = self.arena.selection(graph_ids, bucket[:2])
+        host = np.concatenate([sel, nptr, eptr]).astype(np.int32)
+        sizes = nptr[1:] - nptr[:-1]
+        if not self.graphs:
+            packed = torch.from_numpy(host).to(self.flat_param.device, non_blocking=True)
+            return self._step_on(packed, len(sel), nb, eb, sizes, real)
+        entry = self._entries.get(bucket)
+        if entry is None:
+            if not self._warm:
+                self._warm_up(graph_ids, bucket)
+            # the selection travels through a small ring of pinned buffers: the host may run several steps ahead of the
+            # device, so a buffer is rewritten only after the copy that read it has completed (its event)
+            entry = {"ring": [[torch.empty(len(host), dtype=torch.int32).pin_memory(), None] for _ in range(4)], "turn": 0,
+                     "packed": torch.empty(len(host), dtype=torch.int32, device=self.flat_param.device),
+                     "graph": torch.cuda.CUDAGraph()}
+            self._send(entry, host)
+            torch.cuda.synchronize()
+            kw = {} if self._pool is None else {"pool": self._pool}
+            with torch.cuda.graph(entry["graph"], **kw):
+                entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real)
+            if self._pool is None:
+                self._pool = entry["graph"].pool()
+            self._entries[bucket] = entry
+        else:
+            self._send(entry, host)
+        entry["graph"].replay()
+        return entry["loss"]
+
+    @staticmethod
+    def _send(entry, host: np.ndarray):
+        slot = entry["ring"][entry["turn"] % len(entry["ring"])]
+        entry["turn"] += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].copy_(torch.from_numpy(host))
+        entry["packed"].copy_(slot[0], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()

@@ -31,7 +31,7 @@ struct AggArgs {
   float alpha, beta;
   const float* z; int64_t ldz;
   const float* bias;
-  int act; float drop_p; uint64_t seed;
+  int act; float drop_p; uint64_t seed; const uint64_t* seed_counter;
   float* out; int64_t ldo;
   int64_t N; int C; int CV; int R; int nt;
 };
@@ -62,7 +62,9 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
     float zz[VEC];
     if (a.z) vload<VEC>(a.z + row * a.ldz + ch, zz);
     bool keep[VEC];
-    if (a.drop_p > 0.f) dropout_keep<VEC>(a.seed, (uint64_t)(row * a.C + ch), a.drop_p, keep);
+    if (a.drop_p > 0.f)
+      dropout_keep<VEC>(a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull), (uint64_t)(row * a.C + ch),
+                        a.drop_p, keep);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float r = a.alpha * fmaf(ds, self[v], rs * acc[v]);
@@ -490,18 +492,18 @@ using namespace mlqem;
 extern "C" int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
                                        const int32_t* ell, const float* cscale, const float* rscale, const float* dself, float alpha,
                                        float beta, const float* z, int64_t ldz, const float* bias, int act,
-                                       float drop_p, uint64_t seed, float* out, int64_t ldo, int64_t N, int C,
-                                       mlqem_stream_t stream) {
+                                       float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out, int64_t ldo,
+                                       int64_t N, int C, mlqem_stream_t stream) {
   begin_launches();
   if (drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
-  AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, out, ldo, N, C, 0, 0};
+  AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, seed_counter, out, ldo, N, C, 0, 0};
   return launch_aggregate<false>(a, as_stream(stream));
 }
 
 extern "C" int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx,
                                          const int32_t* ell, float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream) {
   begin_launches();
-  AggArgs a{x, ldx, ptr, idx, ell, nullptr, nullptr, nullptr, 1.f, 0.f, nullptr, 0, nullptr, 0, 0.f, 0, out, ldo, N, C, 0, 0};
+  AggArgs a{x, ldx, ptr, idx, ell, nullptr, nullptr, nullptr, 1.f, 0.f, nullptr, 0, nullptr, 0, 0.f, 0, nullptr, out, ldo, N, C, 0, 0};
   return launch_aggregate<true>(a, as_stream(stream));
 }
 

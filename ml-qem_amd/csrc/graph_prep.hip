@@ -161,9 +161,9 @@ __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleAr
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int b = segment_from_block_start(a.b_nptr, a.B, (int64_t)blockIdx.x * kBlock, a.Nb, min(i, max(a.Nb - 1, (int64_t)0)));
   if (i > a.Nb) return;
-  if (i == a.Nb) {
-    a.in_ptr_b[i] = (int32_t)a.Eb;
-    a.out_ptr_b[i] = (int32_t)a.Eb;
+  if (i == a.Nb) {   // the selection's own edge total (== Eb unless the caller over-provisioned Eb, see the header)
+    a.in_ptr_b[i] = a.b_eptr[a.B];
+    a.out_ptr_b[i] = a.b_eptr[a.B];
     return;
   }
   const int32_t g0 = a.a_gptr[a.sel[b]];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleAr
 __global__ __launch_bounds__(kBlock) void assemble_edges_kernel(const AssembleArgs a) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int b = segment_from_block_start(a.b_eptr, a.B, (int64_t)blockIdx.x * kBlock, a.Eb, min(e, max(a.Eb - 1, (int64_t)0)));
-  if (e >= a.Eb) return;
+  if (e >= a.Eb || e >= a.b_eptr[a.B]) return;   // Eb may be a capacity (fixed-shape launches): the real total is on the device
   const int32_t g0 = a.a_gptr[a.sel[b]];
   const int32_t shift = a.b_nptr[b] - g0;
   const int64_t le = e - a.b_eptr[b];

@@ -28,8 +28,8 @@ t("_mat(x)", lambda: ops._mat(x, "x"))
 t("_vec(dinv)", lambda: ops._vec(dinv, "d", n))
 t("x.data_ptr()", x.data_ptr)
 args = (x.data_ptr(), 12, s.in_ptr.data_ptr(), s.in_src.data_ptr(), ell.data_ptr(), None, dinv.data_ptr(), dinv.data_ptr(), 1.0, 0.0,
-        None, 0, None, 0, 0.0, 0, out.data_ptr(), 12, n, 10, ops._stream())
-t("raw ctypes mlqem_csr_aggregate_f32 (21 args)", lambda: lib.mlqem_csr_aggregate_f32(*args))
+        None, 0, None, 0, 0.0, 0, None, out.data_ptr(), 12, n, 10, ops._stream())
+t("raw ctypes mlqem_csr_aggregate_f32 (22 args)", lambda: lib.mlqem_csr_aggregate_f32(*args))
 t("ops.csr_aggregate(out=...)", lambda: ops.csr_aggregate(x, s.in_ptr, s.in_src, ell=ell, rscale=dinv, dself=dinv, out=out))
 t("ops.csr_aggregate()  (allocating)", lambda: ops.csr_aggregate(x, s.in_ptr, s.in_src, ell=ell, rscale=dinv, dself=dinv))
 t("ops.linear(out=...)", lambda: ops.linear(x, w, out=out))

@@ -35,7 +35,7 @@ def test_host_only_entry_points_validate_arguments():
     lib = _lib.load()
     assert lib.mlqem_linear_f32(None, 4, None, 0, None, None, None, 4, -1, 4, 4, 0, 0, 0.0, 0, -1, -1, None, 0, 1.0, None, None) == -1  # N < 0
     assert lib.mlqem_csr_aggregate_f32(None, 4, None, None, None, None, None, None, 1.0, 0.0, None, 0, None, 0, 1.5, 0,
-                                       None, 4, 10, 4, None) == -1  # drop_p out of range
+                                       None, None, 4, 10, 4, None) == -1  # drop_p out of range
     assert lib.mlqem_segment_pool_f32(None, 1, None, None, 0, 0, 1, None, 1, None, 1, None, 0, None) == -1  # no output wanted
     assert lib.mlqem_segment_pool_workspace_bytes(2048, 3, 10) == (2 + 3) * 2 * 12 * 4
 
