@@ -158,14 +158,15 @@ class _ChebLayer(Function):
     (covered by the 1e-5 parity tests)."""
 
     @staticmethod
-    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, *ws):
+    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, *ws, pre=None):
         s, k = struct, len(ws)
         x = _padded_rows(ops.rowmajor(x))
         o = ws[0].shape[0]
         ow = (o + 3) // 4 * 4
         ws = [w.contiguous() for w in ws]
         w_minus = [ws[2], None, None] if k == 3 else None          # block 0 multiplies by W_0 - W_2
-        c = _fan_out(x, ws, [bias] + [None] * (k - 1), w_minus)
+        # pre: the projections c_k, already produced by a GEMM shared with other layers that read the same x
+        c = list(pre) if pre is not None else _fan_out(x, ws, [bias] + [None] * (k - 1), w_minus)
         lap = dict(ell=s.in_ell, cscale=s.cheb_dinv, rscale=s.derived("cheb_neg"))
         act = dict(relu=relu, drop_p=drop_p, seed=seed)
         if k == 2:
@@ -179,7 +180,7 @@ class _ChebLayer(Function):
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, blocks_only=False):
         k, s, (o, ow) = ctx.k, ctx.struct, ctx.dims
         x, y, *ws = ctx.saved_tensors
         n, i = x.shape
@@ -190,6 +191,8 @@ class _ChebLayer(Function):
             gs.append(ops.csr_aggregate(g, s.out_ptr, s.out_dst, **lap_t))
         if k == 3:
             gs.append(ops.csr_aggregate(gs[1], s.out_ptr, s.out_dst, alpha=2.0, **lap_t))
+        if blocks_only:     # the caller runs ONE weight-gradient pass over x for several layers (see cheb_grads_from_blocks)
+            return gs
         gw = torch.empty((k * ow, i), dtype=torch.float32, device=x.device)
         gb = torch.empty(k * ow, dtype=torch.float32, device=x.device)
         ops.linear_wgrad_parts(gs, x, gw, gb)
@@ -273,13 +276,13 @@ class _SAGELayer(Function):
     Backward: g_p = mean_in^T(g); one weight-gradient pass x^T [g_p | g]; gx = g_p W_l + g W_r in one GEMM."""
 
     @staticmethod
-    def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale):
+    def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, pre=None):
         s = struct
         x = _padded_rows(ops.rowmajor(x))
         o = wl.shape[0]
         ow = (o + 3) // 4 * 4
         wl, wr = wl.contiguous(), wr.contiguous()
-        p, r = _fan_out(x, [wl, wr], [None, bl])                      # the bias rides on the root term
+        p, r = pre if pre is not None else _fan_out(x, [wl, wr], [None, bl])   # the bias rides on the root term
         y = ops.csr_aggregate(p, s.in_ptr, s.in_src, ell=s.in_ell, rscale=s.sage_rinv, dself=s.derived("sage_dself"),
                               z=r, beta=1.0, relu=relu, drop_p=drop_p, seed=seed, out=r)
         ctx.struct, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, relu, drop_p, bl is not None, (o, ow)
@@ -288,12 +291,14 @@ class _SAGELayer(Function):
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, blocks_only=False):
         x, wl, wr, y = ctx.saved_tensors
         s, (o, ow) = ctx.struct, ctx.dims
         n, i = x.shape
         g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
         gp = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.sage_rinv, dself=s.derived("sage_dself"))
+        if blocks_only:
+            return [gp, g]
         gw = torch.empty((2 * ow, i), dtype=torch.float32, device=x.device)
         gb = torch.empty(2 * ow, dtype=torch.float32, device=x.device)
         ops.linear_wgrad_parts([gp, g], x, gw, gb)
@@ -316,10 +321,10 @@ class _GCNLayer(Function):
     then the same symmetric-normalised aggregation on the transposed CSR, then the two GEMM gradients."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale):
+    def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, pre=None):
         x = ops.rowmajor(x)
         dinv = struct.gcn_dinv
-        h = ops.linear(x, w.contiguous(), rowscale=dinv)
+        h = pre if pre is not None else ops.linear(x, w.contiguous(), rowscale=dinv)
         y = ops.csr_aggregate(h, struct.in_ptr, struct.in_src, ell=struct.in_ell, rscale=dinv, dself=dinv, bias=bias, relu=relu,
                               drop_p=drop_p, seed=seed)
         ctx.struct, ctx.relu, ctx.drop_p, ctx.x_gate_scale = struct, relu, drop_p, x_gate_scale
@@ -327,12 +332,14 @@ class _GCNLayer(Function):
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, blocks_only=False):
         x, w, y = ctx.saved_tensors
         s = ctx.struct
         g = _mask_grad(g, y, ctx.drop_p)
         gh = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.gcn_dinv, rscale=s.gcn_dinv,
                                dself=s.derived("gcn_dself"))
+        if blocks_only:
+            return [gh, _padded_rows(g)]
         gx = None
         if ctx.needs_input_grad[0]:
             gated = ctx.x_gate_scale is not None
@@ -508,6 +515,9 @@ def asap_pool(x, mod, struct):
 # small graphs is host-bound).  This node runs the very same layer code -- each layer's forward/backward static methods
 # are called with a private context object -- so the arithmetic and the launch sequence do not change.
 _side_streams = {}
+# MLQEM_FUSE_FIRST=0: every branch projects x with its own GEMM and runs its own weight-gradient pass (three reads of the
+# feature rows per direction instead of one); kept for measurements.
+_FUSE_FIRST = os.environ.get("MLQEM_FUSE_FIRST", "1") != "0"
 
 
 def _branch_streams(device):
@@ -573,26 +583,44 @@ class _FamilyAGraph(Function):
         _ = (struct.in_ell, struct.out_ell, struct.gcn_dinv, struct.derived("gcn_dself"), struct.derived("sage_dself"),
              struct.derived("cheb_neg"))
         tg, tc, ts = struct.colsum("gcn"), struct.colsum("cheb"), struct.colsum("sage")
+        # The first layer of every branch projects the SAME x: one GEMM over six output blocks reads x once instead of
+        # three times (GCN: dinv * x W^T | Cheb: x (W_0 - W_2)^T + b, x W_1^T, x W_2^T | SAGE: x W_l^T, x W_r^T + b), and in the
+        # backward ONE weight-gradient pass over x serves all seven gradient blocks (see backward).
+        fuse = ctx.fuse = _FUSE_FIRST and x.shape[1] <= _PARTS_MAX_COLS and 6 * ((g1w.shape[0] + 3) // 4 * 4) <= 96
+        pre_g = pre_c = pre_s = None
+        if fuse:
+            xr = _padded_rows(ops.rowmajor(x))
+            o = g1w.shape[0]
+            blocks = [ops.padded_empty(xr.shape[0], o, x.device) for _ in range(6)]
+            ws6 = [w.contiguous() for w in (g1w, c1w0, c1w1, c1w2, s1l, s1r)]
+            ops.linear_parts([xr], ws6, blocks, w_minus=[None, ws6[3], None, None, None, None],
+                             biases=[None, c1b, None, None, None, s1b],
+                             rowscales=[struct.gcn_dinv, None, None, None, None, None])
+            pre_g, pre_c, pre_s = blocks[0], blocks[1:4], blocks[4:6]
         for st in side:
             st.wait_stream(main)
         # GCN branch: args (x, w, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
-        L["g1"] = mk(9, Fa); h = _GCNLayer.forward(L["g1"], x, g1w, g1b, struct, T, p1, seed + 1, T, None)
+        L["g1"] = mk(9, Fa); h = _GCNLayer.forward(L["g1"], x, g1w, g1b, struct, T, p1, seed + 1, T, None, pre=pre_g)
         L["g2"] = mk(9, T); hg = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1)
         _, wg = ops.segment_pool(hg, gptr, nb, weights=tg, mean=False, wmean=True)
         pg = torch.addmm(g3b, wg, g3w.t())
         with torch.cuda.stream(side[0]):
             # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
-            L["c1"] = mk(11, Fa); hc = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2)
+            L["c1"] = mk(11, Fa); hc = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2,
+                                                          pre=pre_c)
             mc, wc = ops.segment_pool(hc, gptr, nb, weights=tc, mean=True, wmean=True)
             pc = torch.addmm(c2b, mc, c2w0.t()).addmm_(wc, c2w1.t())
         with torch.cuda.stream(side[1]):
             # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
-            L["s1"] = mk(10, Fa); hs = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None)
+            L["s1"] = mk(10, Fa); hs = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None, pre=pre_s)
             ms, ws = ops.segment_pool(hs, gptr, nb, weights=ts, mean=True, wmean=True)
             ps = torch.addmm(s2b, ws, s2l.t()).addmm_(ms, s2r.t())
         for st, t in zip(side, (pc, ps)):
             main.wait_stream(st)
             t.record_stream(main)
+        if fuse:
+            for t in blocks[1:]:          # made on the compute stream, consumed by the side streams
+                t.record_stream(side[0] if t is not blocks[4] and t is not blocks[5] else side[1])
         ctx.tail = (struct, k1, k2, (hg, wg, g3w), (hc, mc, wc, c2w0, c2w1), (hs, ms, ws, s2l, s2r))
         return torch.cat((pg, pc, ps), dim=1)
 
@@ -611,19 +639,44 @@ class _FamilyAGraph(Function):
         g3wg, g3bg = gg.t().mm(wg), gg.sum(0)
         t = ops.segment_pool_bwd(None, gg.mm(g3w), gptr, n, weights=struct.colsum("gcn"), gate=hg, gate_scale=k1)
         t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
-        _, g1w, g1b = _GCNLayer.backward(L["g1"], t)[:3]
+        fuse = ctx.fuse
+        if fuse:
+            bg = _GCNLayer.backward(L["g1"], t, blocks_only=True)            # [gh, g]
+        else:
+            _, g1w, g1b = _GCNLayer.backward(L["g1"], t)[:3]
         with torch.cuda.stream(side[0]):
             c2w0g, c2w1g, c2bg = gc.t().mm(mc), gc.t().mm(wc), gc.sum(0)
             t = ops.segment_pool_bwd(gc.mm(c2w0), gc.mm(c2w1), gptr, n, weights=struct.colsum("cheb"), gate=hc, gate_scale=k2)
-            r = _ChebLayer.backward(L["c1"], t)
-            c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
+            if fuse:
+                bc = _ChebLayer.backward(L["c1"], t, blocks_only=True)       # [g, g_b1, g_c2]
+            else:
+                r = _ChebLayer.backward(L["c1"], t)
+                c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
         with torch.cuda.stream(side[1]):
             s2lg, s2bg, s2rg = gs.t().mm(ws), gs.sum(0), gs.t().mm(ms)
             t = ops.segment_pool_bwd(gs.mm(s2r), gs.mm(s2l), gptr, n, weights=struct.colsum("sage"), gate=hs, gate_scale=k2)
-            _, s1l, s1b, s1r = _SAGELayer.backward(L["s1"], t)[:4]
+            if fuse:
+                bs = _SAGELayer.backward(L["s1"], t, blocks_only=True)       # [g_p, g]
+            else:
+                _, s1l, s1b, s1r = _SAGELayer.backward(L["s1"], t)[:4]
         for st in side:
             main.wait_stream(st)
-        for t in (c2bg, c2w0g, c2w1g, c1b, c1w0, c1w1, c1w2, s2lg, s2bg, s2rg, s1l, s1b, s1r):
+        if fuse:
+            # ONE pass over x for the weight gradients of all three first layers: x^T [gh | g || g | g_b1 | g_c2 || g_p | g];
+            # the ones column of the pass yields the three bias gradients
+            x0 = L["g1"].saved_tensors[0]
+            o, i = L["g1"].saved_tensors[1].shape
+            ow = (o + 3) // 4 * 4
+            for blk in bc + bs:
+                blk.record_stream(main)
+            gw7 = torch.empty((7 * ow, i), dtype=torch.float32, device=g.device)
+            gb7 = torch.empty(7 * ow, dtype=torch.float32, device=g.device)
+            ops.linear_wgrad_parts(bg + bc + bs, x0, gw7, gb7)
+            gw7 = gw7.reshape(7, ow, i)[:, :o]
+            g1w, g1b = gw7[0], gb7[ow:ow + o]
+            c1w0, c1w1, c1w2, c1b = gw7[2], gw7[3], gw7[4] - gw7[2], gb7[2 * ow:2 * ow + o]
+            s1l, s1r, s1b = gw7[5], gw7[6], gb7[6 * ow:6 * ow + o]
+        for t in (c2bg, c2w0g, c2w1g, s2lg, s2bg, s2rg) + (() if fuse else (c1b, c1w0, c1w1, c1w2, s1l, s1b, s1r)):
             t.record_stream(main)
         return (None, None, None, None, None, g1w, g1b, g2w, g2b, g3wg, g3bg, c1w0, c1w1, c1w2, c1b, c2w0g, c2w1g, c2bg,
                 s1l, s1b, s1r, s2lg, s2bg, s2rg)
