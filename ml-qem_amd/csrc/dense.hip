@@ -458,6 +458,90 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
   }
 }
 
+// Fan-out with every output block narrower than one MFMA tile (<= 16 columns: the hidden widths of this path): block k
+// IS output tile k.  The weight fragments of ALL blocks live in LDS (yn * G KB), not in registers -- the register-resident
+// form above needs ~170 VGPRs for six blocks and runs two waves per SIMD at 3 TB/s; here a wave holds one X fragment and
+// one accumulator tile at a time (~48 VGPRs, eight waves per SIMD), reads a tile's fragments with one ds_read_b128 per
+// 16 input columns, and a tile's store is 16 rows x (block width) contiguous bytes of ONE buffer.  Same MFMA step order
+// per output as linear_parts_kernel: bit-identical results.
+template <int G>
+__global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsArgs a) {
+  __shared__ float4 s_w[kMaxParts][G][kWave];
+  __shared__ float s_b[kMaxParts][16];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < a.yn * G * kWave; idx += kBlock) {
+    const int blk = idx / (G * kWave), g = (idx / kWave) % G, l = idx % kWave;
+    const int o = l & 15, lq = l >> 4;
+    float v[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int k = 16 * g + 4 * lq + s4;
+      float w = 0.f;
+      if (o < a.yc && k < a.xc) {
+        w = a.wk[blk][(int64_t)o * a.xc + k];
+        if (a.wm[blk]) w -= a.wm[blk][(int64_t)o * a.xc + k];
+      }
+      v[s4] = w;
+    }
+    s_w[blk][g][l] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  for (int idx = tid; idx < a.yn * 16; idx += kBlock) {
+    const int blk = idx >> 4, o = idx & 15;
+    s_b[blk][o] = (a.bk[blk] && o < a.yc) ? a.bk[blk][o] : 0.f;
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = (blockIdx.x * kBlock + tid) >> 6;
+  const int n_waves = (gridDim.x * kBlock) >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const float* xcol[G]; int xlive[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int k0 = 16 * g + 4 * lq;
+    xlive[g] = k0 < a.xc ? min(4, a.xc - k0) : 0;
+    xcol[g] = xlive[g] ? a.xp[0] + k0 : nullptr;
+  }
+  const bool store_lane = 4 * lq < a.yw;       // the block's padded width: lanes beyond it own no output columns
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    const int64_t row = t * 16 + lr;
+    const bool row_ok = row < a.N;
+    const int64_t xrow = (a.xrows && row_ok) ? (int64_t)a.xrows[row] : row;
+    float4 av[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row_ok && xcol[g]) av[g] = *reinterpret_cast<const float4*>(xcol[g] + xrow * a.ldx[0]);
+      if (xlive[g] < 2) av[g].y = 0.f;     // padding may hold anything (NaN included): it must not reach the MFMA
+      if (xlive[g] < 3) av[g].z = 0.f;
+      if (xlive[g] < 4) av[g].w = 0.f;
+      if (xlive[g] < 1) av[g].x = 0.f;
+    }
+#pragma unroll
+    for (int blk = 0; blk < kMaxParts; ++blk) {
+      if (blk >= a.yn) break;
+      const float rs = (a.rsk[blk] && row_ok) ? a.rsk[blk][row] : 1.f;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 w4 = s_w[blk][g][lane];
+        acc = mfma16x16x4(w4.x, av[g].x, acc);
+        acc = mfma16x16x4(w4.y, av[g].y, acc);
+        acc = mfma16x16x4(w4.z, av[g].z, acc);
+        acc = mfma16x16x4(w4.w, av[g].w, acc);
+      }
+      if (!row_ok || !store_lane) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[r] + s_b[blk][4 * lq + r];
+        if (a.rsk[blk]) v[r] *= rs;
+      }
+      vstore_nt<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
+    }
+  }
+}
+
 // Generic fallback (any I; used for I > 128): thread per (row, output); a block stages one chunk of `oc` outputs' weights
 // in LDS (blockIdx.y selects the chunk).
 template <bool TRANSPOSED>
@@ -767,6 +851,19 @@ static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, h
 static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
+  static const int lds_env = getenv("MLQEM_FANOUT_LDS") ? atoi(getenv("MLQEM_FANOUT_LDS")) : 1;
+  if (lds_env && !transposed && a.xn == 1 && a.yn >= 2 && a.yw <= 16 && !a.act && a.drop_p == 0.f && !a.gate) {
+    // several narrow output blocks from one read of x: weight fragments in LDS, one MFMA tile per block
+    const int64_t tiles = ceil_div(a.N, 16);
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8));
+    switch (g) {
+      case 1: hipLaunchKernelGGL(linear_fanout_lds_kernel<1>, grid, dim3(kBlock), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(linear_fanout_lds_kernel<2>, grid, dim3(kBlock), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(linear_fanout_lds_kernel<3>, grid, dim3(kBlock), 0, s, a); break;
+      default: hipLaunchKernelGGL(linear_fanout_lds_kernel<4>, grid, dim3(kBlock), 0, s, a); break;
+    }
+    return launch_status();
+  }
   const int obt = ob <= 3 ? ob : ((ob == 5 || ob == 6) && g <= 2 && !a.act && a.drop_p == 0.f && !a.gate ? 6 : 4);
   const int64_t tiles = ceil_div(a.N, 16);
   dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
