@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 5 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 6 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -132,12 +132,18 @@ int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int transposed
                      float drop_p, uint64_t seed, int rs_cols, int act_from, const float* gate, int64_t ldgate,
                      float gate_scale, const int32_t* x_rows, mlqem_stream_t stream);
 
-/* y = act(x @ W^T + b) with both operands rounded to bf16 (nearest-even) in registers and fp32 accumulation on
- * v_mfma_f32_16x16x32_bf16: the "bf16 MFMA MLP head" option of the MLP regressors (docs/tutorials/mlp.py:18-108) for
- * BASELINE.json's mixed-corpus configuration.  x, W, y are fp32 in memory; W: [O, I] row-major; b may be NULL;
- * act bit 0 = ReLU; I <= 256.  Forward only: gradients use the fp32 entry points. */
-int mlqem_linear_bf16_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int64_t N,
-                          int I, int O, int act, mlqem_stream_t stream);
+/* y = act(x @ W^T + b) (transposed = 0, W: [O, I]) or y = x @ W (transposed = 1, W: [I, O]: the data-gradient form) with
+ * both operands rounded to bf16 (nearest-even) in registers and fp32 accumulation on v_mfma_f32_16x16x32_bf16: the "bf16
+ * MFMA MLP head" option of the MLP regressors (docs/tutorials/mlp.py:18-108) for BASELINE.json's mixed-corpus
+ * configuration.  x, W, y are fp32 in memory; b may be NULL; act bit 0 = ReLU; I <= 256. */
+int mlqem_linear_bf16_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, float* y, int64_t ldy,
+                          int64_t N, int I, int O, int act, mlqem_stream_t stream);
+
+/* gw[o,i] (+)= sum_n bf16(gy[n,o]) * bf16(x[n,i]);  gb[o] (+)= sum_n bf16(gy[n,o])  on the same matrix cores (32 rows per
+ * MFMA, fp32 accumulation, deterministic two-stage reduction): with the two entry points above the bf16 head trains
+ * end to end on v_mfma_f32_16x16x32_bf16.  workspace: mlqem_linear_wgrad_workspace_bytes(I, O). */
+int mlqem_linear_wgrad_bf16_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb, int64_t N,
+                                int I, int O, int accumulate, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 #define MLQEM_MAX_COL_PARTS 8
 

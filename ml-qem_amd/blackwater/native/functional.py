@@ -56,13 +56,13 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, relu, mfma):
         x = ops.rowmajor(x)
-        if mfma == "bf16":   # operands rounded to bf16 on the matrix cores; the backward below stays fp32
+        if mfma == "bf16":   # operands rounded to bf16 on the matrix cores, forward and both gradients
             y = ops.linear_bf16(x, w.contiguous(), b, relu=relu)
         elif mfma == "f32":
             y = ops.linear(x, w.contiguous(), b, relu=relu)
         else:
             raise ValueError(f"mfma must be 'f32' or 'bf16', got {mfma!r}")
-        ctx.relu = relu
+        ctx.relu, ctx.mfma = relu, mfma
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = b is not None
         return y
@@ -74,12 +74,13 @@ class _Linear(Function):
         if ctx.relu:
             g = ops.relu_dropout_bwd(g, y, 1.0)
         gx = gw = gb = None
+        bf16 = ctx.mfma == "bf16" and w.shape[0] <= 256
         if ctx.needs_input_grad[0]:
-            gx = ops.linear(g, w.contiguous(), transposed=True)
+            gx = ops.linear_bf16(g, w.contiguous(), transposed=True) if bf16 else ops.linear(g, w.contiguous(), transposed=True)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty_like(w, memory_format=torch.contiguous_format)
             gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device) if ctx.has_bias else None
-            ops.linear_wgrad(g, x, gw, gb)
+            (ops.linear_wgrad_bf16 if ctx.mfma == "bf16" else ops.linear_wgrad)(g, x, gw, gb)
         return gx, gw, gb, None, None
 
 

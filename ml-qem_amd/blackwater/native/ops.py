@@ -241,23 +241,38 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
     return out
 
 
-def linear_bf16(x, w, b=None, *, relu=False, out=None):
-    """y = act(x @ w.T + b) on the bf16 matrix cores: operands rounded to bf16 in registers, fp32 accumulation, fp32 in
-    and out (mlqem_linear_bf16_f32).  Forward only."""
+def linear_bf16(x, w, b=None, *, relu=False, transposed=False, out=None):
+    """y = act(x @ w.T + b) (w: [O, I]) or, ``transposed``, y = x @ w (w: [I, O]) on the bf16 matrix cores: operands rounded
+    to bf16 in registers, fp32 accumulation, fp32 in and out (mlqem_linear_bf16_f32)."""
     n, i = x.shape
     ldx = _mat(x, "x")
-    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous() or w.shape[1] != i:
-        raise ValueError(f"linear_bf16: w must be a contiguous fp32 cuda tensor [O, {i}], got {tuple(w.shape)}")
-    o = w.shape[0]
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous() or w.shape[0 if transposed else 1] != i:
+        raise ValueError(f"linear_bf16: w must be a contiguous fp32 cuda tensor matching {i} input columns, got {tuple(w.shape)}")
+    o = w.shape[1] if transposed else w.shape[0]
     _vec(b, "b", o)
     if out is None:
         out = padded_empty(n, o, x.device)
     elif out.shape != (n, o):
         raise ValueError("linear_bf16: bad out shape")
-    code = _lib.load().mlqem_linear_bf16_f32(_p(x), ldx, _p(w), _p(b), _p(out), _mat(out, "out"), n, i, o,
+    code = _lib.load().mlqem_linear_bf16_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(out), _mat(out, "out"), n, i, o,
                                              1 if relu else 0, _stream())
     _lib.check(code, "mlqem_linear_bf16_f32")
     return out
+
+
+def linear_wgrad_bf16(gy, x, gw, gb=None, accumulate=False):
+    """gw (+)= bf16(gy).T @ bf16(x); gb (+)= bf16(gy).sum(0) with fp32 accumulation (mlqem_linear_wgrad_bf16_f32)."""
+    n, o = gy.shape
+    i = x.shape[1]
+    if x.shape[0] != n or gw.shape != (o, i) or not gw.is_contiguous() or gw.dtype != torch.float32:
+        raise ValueError("linear_wgrad_bf16: shape mismatch")
+    _vec(gb, "gb", o)
+    lib = _lib.load()
+    need = lib.mlqem_linear_wgrad_workspace_bytes(i, o)
+    ws = _wgrad_workspace(gy.device, need)
+    code = lib.mlqem_linear_wgrad_bf16_f32(_p(gy), _mat(gy, "gy"), _p(x), _mat(x, "x"), _p(gw), _p(gb), n, i, o,
+                                           1 if accumulate else 0, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_linear_wgrad_bf16_f32")
 
 
 def _col_parts(blocks, name: str, vector_rows: bool) -> "_lib.ColParts":

@@ -230,7 +230,7 @@ __device__ __forceinline__ short to_bf16(float f) {
   return (short)(u >> 16);
 }
 
-template <int OBT, int G>
+template <int OBT, int G, bool TRANSPOSED>
 __global__ __launch_bounds__(kBlock) void linear_bf16_kernel(const LinArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void linear_bf16_kernel(const LinArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = 32 * g + 8 * lq + j;
-        wf[ob][g][j] = (o < a.O && k < a.I) ? to_bf16(a.w[(int64_t)o * a.I + k]) : (short)0;
+        wf[ob][g][j] = (o < a.O && k < a.I) ? to_bf16(TRANSPOSED ? a.w[(int64_t)k * a.O + o] : a.w[(int64_t)o * a.I + k]) : (short)0;
       }
   }
   float bias[OBT][4];
@@ -684,6 +684,76 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
   }
 }
 
+// bf16 matrix-core weight gradient (the "bf16 MFMA MLP head" trains on v_mfma_f32_16x16x32_bf16 too): gW = gY^T X with both
+// operands rounded to bf16 in registers, fp32 accumulation, fp32 tensors in memory.  M = outputs, N = inputs (+ the ones
+// column for the bias), K = 32 rows per MFMA: lane l holds rows 8 (l >> 4) .. + 7 of column (l & 15) of each operand tile.
+// Same partial-sum layout and second stage as wgrad_mfma_kernel.
+template <int OBT, int IBT>
+__global__ __launch_bounds__(kBlock) void wgrad_bf16_kernel(const WgradArgs a) {
+  __shared__ f32x4 s_acc[4][OBT * IBT][kWave];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wid;
+  const int n_waves = gridDim.x * 4;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int I1 = a.I + 1;
+  const int n_ib = (int)ceil_div(ceil_div(I1, 16), IBT);
+  const int ob0 = (blockIdx.y / n_ib) * OBT, ib0 = (blockIdx.y % n_ib) * IBT;
+  f32x4 acc[OBT][IBT];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t n_iters = ceil_div(a.N, 32);
+  for (int64_t it = wave; it < n_iters; it += n_waves) {
+    bf16x8 af[OBT], bf[IBT];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t n = it * 32 + 8 * lq + j;
+      const bool ok = n < a.N;
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob) {
+        const int o = (ob0 + ob) * 16 + lr;
+        af[ob][j] = (ok && o < a.O) ? to_bf16(a.gyp[0][n * a.ldgy[0] + o]) : (short)0;
+      }
+#pragma unroll
+      for (int ib = 0; ib < IBT; ++ib) {
+        const int i = (ib0 + ib) * 16 + lr;
+        float v = 0.f;
+        if (ok) v = i < a.I ? a.x[n * a.ldx + i] : (i == a.I ? 1.f : 0.f);
+        bf[ib][j] = to_bf16(v);
+      }
+    }
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < IBT; ++ib)
+        acc[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ob], bf[ib], acc[ob][ib], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IBT; ++ib) s_acc[wid][ob * IBT + ib][lane] = acc[ob][ib];
+  __syncthreads();
+  if (wid == 0) {
+    float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * a.O * I1;
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < IBT; ++ib) {
+        f32x4 t = s_acc[0][ob * IBT + ib][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t += s_acc[w][ob * IBT + ib][lane];
+        const int i = (ib0 + ib) * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (ob0 + ob) * 16 + lq * 4 + r;
+          if (o < a.O && i < I1) dst[o * I1 + i] = t[r];
+        }
+      }
+  }
+}
+
 // Stage 2: fixed-order sum over the G partials.  Block = 8 (o,i) pairs x 32 slices of the G range: a thread adds
 // G/32 partials, then the 32 slice sums of a pair are added in slice order.
 constexpr int kReducePairs = 8, kReduceSlices = kBlock / kReducePairs;
@@ -917,18 +987,18 @@ extern "C" int mlqem_linear_parts_f32(const mlqem_col_parts* x, const float* con
   return run_linear_parts(a, transposed, as_stream(stream));
 }
 
-template <int OBT>
+template <int OBT, bool TRANSPOSED>
 static bool launch_linear_bf16(const LinArgs& a, int g, dim3 grid, hipStream_t s) {
   switch (g) {
-#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_bf16_kernel<OBT, K>), grid, dim3(kBlock), 0, s, a); return true;
+#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_bf16_kernel<OBT, K, TRANSPOSED>), grid, dim3(kBlock), 0, s, a); return true;
     MLQEM_CASE(1) MLQEM_CASE(2) MLQEM_CASE(3) MLQEM_CASE(4) MLQEM_CASE(5) MLQEM_CASE(6) MLQEM_CASE(7) MLQEM_CASE(8)
 #undef MLQEM_CASE
   }
   return false;
 }
 
-extern "C" int mlqem_linear_bf16_f32(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy,
-                                     int64_t N, int I, int O, int act, mlqem_stream_t stream) {
+extern "C" int mlqem_linear_bf16_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, float* y,
+                                     int64_t ldy, int64_t N, int I, int O, int act, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || ldx < I || ldy < O) return MLQEM_ERR_BAD_ARG;
   if (I > 256) return MLQEM_ERR_UNSUPPORTED;
@@ -939,9 +1009,14 @@ extern "C" int mlqem_linear_bf16_f32(const float* x, int64_t ldx, const float* w
   const int obt = (ob == 1) ? 1 : ((ob == 2 || g > 4) ? 2 : 4);    // keep OBT * G weight fragments <= 16 (64 VGPRs)
   const int64_t tiles = ceil_div(N, 16);
   dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8), (unsigned)ceil_div(ob, obt));
-  const bool ok = obt == 1 ? launch_linear_bf16<1>(a, g, grid, as_stream(stream))
-                : obt == 2 ? launch_linear_bf16<2>(a, g, grid, as_stream(stream))
-                           : launch_linear_bf16<4>(a, g, grid, as_stream(stream));
+  hipStream_t s = as_stream(stream);
+  bool ok;
+  if (transposed)
+    ok = obt == 1 ? launch_linear_bf16<1, true>(a, g, grid, s) : obt == 2 ? launch_linear_bf16<2, true>(a, g, grid, s)
+                                                                          : launch_linear_bf16<4, true>(a, g, grid, s);
+  else
+    ok = obt == 1 ? launch_linear_bf16<1, false>(a, g, grid, s) : obt == 2 ? launch_linear_bf16<2, false>(a, g, grid, s)
+                                                                           : launch_linear_bf16<4, false>(a, g, grid, s);
   return ok ? launch_status() : MLQEM_ERR_UNSUPPORTED;
 }
 
@@ -1000,4 +1075,24 @@ extern "C" int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const flo
   a.gn = gy->count; a.gw = gy->width; a.gc = gy->cols;
   a.x = x; a.ldx = ldx; a.xrows = x_rows; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
   return launch_wgrad(a, gw, gb, accumulate, as_stream(stream));
+}
+
+extern "C" int mlqem_linear_wgrad_bf16_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, float* gw, float* gb,
+                                           int64_t N, int I, int O, int accumulate, void* workspace, size_t workspace_bytes,
+                                           mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || I <= 0 || O <= 0 || !gw || ldgy < O || ldx < I) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, O)) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && (!gy || !x)) return MLQEM_ERR_BAD_ARG;
+  WgradArgs a{};
+  a.gyp[0] = gy; a.ldgy[0] = ldgy; a.gn = 1; a.gw = O; a.gc = O;
+  a.x = x; a.ldx = ldx; a.xrows = nullptr; a.partial = static_cast<float*>(workspace); a.N = N; a.I = I; a.O = O;
+  hipStream_t s = as_stream(stream);
+  const int64_t iters = ceil_div(std::max<int64_t>(N, 1), 32);
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
+  const int ob = (O + 15) / 16, ib = (I + 1 + 15) / 16;
+  hipLaunchKernelGGL((wgrad_bf16_kernel<2, 2>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 2))), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial, G, I, O,
+                     gw, gb, accumulate);
+  return launch_status();
 }

@@ -145,7 +145,9 @@ def test_cfg5_bf16_mfma_mlp_head():
     """The "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus configuration: MLP3 on 169-d rows with
     ``model.mfma = "bf16"``.  Stated tolerances: (1) the kernel equals "round both operands to bf16, multiply exactly,
     accumulate in fp32" to 1e-5 of the output scale on every layer shape of MLP1/MLP3; (2) the whole MLP3 differs from
-    its fp32 path by < 3e-2 of the output scale; (3) gradients flow through the fp32 backward."""
+    its fp32 path by < 3e-2 of the output scale; (3) the backward runs on the same matrix cores: data gradient and weight
+    gradient equal the bf16-rounded-operand products to 1e-5 of their scale, and the MLP3's parameter gradients stay within
+    10 % (Frobenius norm) of the fp32 path's."""
     import blackwater.nn as bnn
     from blackwater.native import ops
 
@@ -176,3 +178,26 @@ def test_cfg5_bf16_mfma_mlp_head():
     assert 0 < err < 3e-2 * scale                      # a different arithmetic, within the stated tolerance
     out.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    bf16_grads = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    model.mfma = "f32"
+    model(x).square().mean().backward()
+    for (name, p), gb in zip(model.named_parameters(), bf16_grads):
+        # ReLU masks can flip for pre-activations within bf16 rounding of zero: compare in the Frobenius norm
+        assert (gb - p.grad).norm().item() < 0.1 * (p.grad.norm().item() + 1e-12), name
+
+    # the two backward kernels against "round both operands to bf16, multiply exactly"
+    for n, i, o in ((1, 169, 64), (1000, 169, 128), (777, 128, 42), (4099, 58, 4), (33, 20, 256)):
+        gy = torch.randn(n, o, generator=g)
+        xx = torch.randn(n, i, generator=g)
+        w = torch.randn(o, i, generator=g) / i ** 0.5
+        gx = ops.linear_bf16(gy.to(DEV), w.to(DEV), transposed=True).cpu().double()
+        want = gy.bfloat16().double() @ w.bfloat16().double()
+        assert (gx - want).abs().max().item() < 1e-5 * max(want.abs().max().item(), 1.0), (n, i, o)
+        gw = torch.empty(o, i, device=DEV)
+        gbias = torch.empty(o, device=DEV)
+        ops.linear_wgrad_bf16(gy.to(DEV), xx.to(DEV), gw, gbias)
+        want_w = gy.bfloat16().double().t() @ xx.bfloat16().double()
+        assert (gw.cpu().double() - want_w).abs().max().item() < 2e-5 * max(want_w.abs().max().item(), 1.0), (n, i, o)
+        want_b = gy.bfloat16().double().sum(0)
+        assert (gbias.cpu().double() - want_b).abs().max().item() < 2e-5 * max(want_b.abs().max().item(), 1.0)
