@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 6 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 7 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -107,6 +107,14 @@ int mlqem_ell_from_csr(const int32_t* ptr, const int32_t* idx, int64_t N, int32_
  * output y (an element that was clamped OR dropped has y == 0 and no gradient either way). */
 int mlqem_relu_dropout_bwd_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, float scale, float* gx,
                                int64_t ldgx, int64_t N, int C, mlqem_stream_t stream);
+
+/* y = dropout(relu(x)) (inverted dropout, mask keyed by (seed [+ seed_counter], n*C + c)) and, when residual is given,
+ * sum = y + residual in the same pass -- the element-wise tail of an MLP2 / MLP3 trunk layer (docs/tutorials/mlp.py:60-66:
+ * x1 = drop(relu(bn1(fc1 x))), x2 = drop(relu(bn2(fc2 x1))), x1 + x2) as ONE launch.  y is what the backward needs
+ * (mlqem_relu_dropout_bwd_f32 recovers the mask from it); sum may be NULL; seed_counter as in mlqem_csr_aggregate_f32. */
+int mlqem_relu_dropout_f32(const float* x, int64_t ldx, float drop_p, uint64_t seed, const uint64_t* seed_counter,
+                           const float* residual, int64_t ldr, float* y, int64_t ldy, float* sum, int64_t lds, int64_t N, int C,
+                           mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Dense layers.  Replace torch.nn.Linear / torch_geometric.nn.Linear (docs/tutorials/gnn.py:94-98 body_seq,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
     "mlqem_relu_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _F, _P, _L, _L, _I, _P]),
+    "mlqem_relu_dropout_f32": (_I, [_P, _L, _F, _U, _P, _P, _L, _P, _L, _P, _L, _L, _I, _P]),
     "mlqem_linear_f32": (_I, [_P, _L, _P, _I, _P, _P, _P, _L, _L, _I, _I, _I, _I, _F, _U, _I, _I, _P, _L, _F, _P, _P]),
     "mlqem_linear_bf16_f32": (_I, [_P, _L, _P, _I, _P, _P, _L, _L, _I, _I, _I, _P]),
     "mlqem_linear_wgrad_bf16_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P]),
@@ -85,7 +86,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 7   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -90,6 +90,29 @@ def linear(x, w, b=None, relu=False, mfma="f32"):
     return y.reshape(*lead, w.shape[0])
 
 
+class _ReluDropoutAdd(Function):
+    """s = dropout(relu(u)) (+ residual) as one launch; the backward recovers the mask from the saved activation."""
+
+    @staticmethod
+    def forward(ctx, u, residual, drop_p, seed):
+        y, s = ops.relu_dropout(u, drop_p, seed, residual)
+        ctx.drop_p, ctx.has_res = drop_p, residual is not None
+        ctx.save_for_backward(y)
+        return y if s is None else s
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = ops.rowmajor(g)
+        gu = ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - ctx.drop_p) if ctx.drop_p > 0 else 1.0)
+        return gu, (g if ctx.has_res else None), None, None
+
+
+def relu_dropout_add(u, residual=None, drop_p=0.0, seed=0):
+    """dropout(relu(u)) + residual (the tail of an MLP2 / MLP3 trunk layer, docs/tutorials/mlp.py:60-66)."""
+    return _ReluDropoutAdd.apply(u, residual, drop_p, seed)
+
+
 # Mask hand-over between consecutive layers of one branch (a private contract of the model code, see nn/models.py):
 # a layer called with ``defer_mask=True`` does not apply its own ReLU/dropout mask in backward and does not keep its
 # output for it -- the NEXT layer, whose input x IS that output, is called with ``x_gate_scale = 1/(1-p)`` and returns

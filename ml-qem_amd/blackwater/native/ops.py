@@ -200,6 +200,25 @@ def relu_dropout_bwd(g, y, scale=1.0, out=None):
     return gx
 
 
+def relu_dropout(x, drop_p=0.0, seed=0, residual=None):
+    """(y, s): y = dropout(relu(x)); s = y + residual (None without a residual) -- one launch (mlqem_relu_dropout_f32)."""
+    x = rowmajor(x)
+    n, c = x.shape
+    y = padded_empty(n, c, x.device)
+    s = None
+    if residual is not None:
+        residual = rowmajor(residual)
+        if residual.shape != x.shape:
+            raise ValueError("relu_dropout: residual must have the shape of x")
+        s = padded_empty(n, c, x.device)
+    code = _lib.load().mlqem_relu_dropout_f32(_p(x), _mat(x, "x"), float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              _p(_seed_counter) if drop_p > 0 else None, _p(residual),
+                                              _mat(residual, "residual") if residual is not None else 0, _p(y), _mat(y, "y"),
+                                              _p(s), _mat(s, "s") if s is not None else 0, n, c, _stream())
+    _lib.check(code, "mlqem_relu_dropout_f32")
+    return y, s
+
+
 def _gate(gate, n, o, padded: bool):
     """(pointer, leading dimension) of an optional [n, o] gate matrix (see mlqem_linear_f32)."""
     if gate is None:

@@ -1,12 +1,21 @@
 """MLP regressors / heads (reference: docs/tutorials/mlp.py:18-108 == blackwater/library/learning/mlp.py:18-108).
 
 Same constructor signatures and state-dict keys (``fc1.weight`` ... ``bn1.running_mean`` ...), so the reference's
-21 MLP checkpoints load with ``strict=True``.  The GEMMs (+bias, +ReLU where nothing sits in between) run on the
-f32-MFMA dense kernel; BatchNorm/dropout/residual act on [batch, hidden] tensors and stay elementwise torch ops.
+21 MLP checkpoints load with ``strict=True``.  The GEMMs run on the MFMA dense kernels with the element-wise work in
+their epilogues wherever the maths allows:
 
-``model.mfma = "bf16"`` (default ``"f32"``) sends the forward GEMMs to the bf16 matrix cores -- operands rounded to bf16
-in registers, fp32 accumulation, fp32 tensors in memory: the "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus
-configuration.  Outputs then differ from the fp32 path at the 1e-2 level, so it is an opt-in; gradients stay fp32.
+* eval mode: BatchNorm is an affine map of the GEMM output, so ``relu(bn(fc(x)))`` is ONE GEMM with bias + ReLU epilogue
+  over weights scaled by ``gamma / sqrt(running_var + eps)`` (folded on the fly from the live parameters: four [H]-sized
+  ops instead of three [batch, H] passes);
+* train mode: BatchNorm needs the batch statistics of the GEMM output (torch's kernel, per-rank statistics under data
+  parallelism exactly like ``DistributedDataParallel`` without ``SyncBatchNorm``; running statistics are broadcast from
+  rank 0 once by ``Trainer``); ReLU, dropout and the residual add of the trunk are one fused launch
+  (``F.relu_dropout_add``), its mask keyed by torch's seed like every dropout of this build.
+
+``model.mfma = "bf16"`` (default ``"f32"``) sends the GEMMs -- forward, data gradient and weight gradient -- to the bf16
+matrix cores (v_mfma_f32_16x16x32_bf16): operands rounded to bf16 in registers, fp32 accumulation, fp32 tensors in
+memory: the "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus configuration.  Results then differ from the fp32 path
+at the 1e-2 level, so it is an opt-in.
 """
 from __future__ import annotations
 
@@ -45,10 +54,26 @@ class MLP2(nn.Module):
     def _drop(self, t):
         return nn.functional.dropout(t, self.p, True) if (self.training and self.p > 0) else t
 
+    @staticmethod
+    def _folded(fc, bn):
+        """(W', b') with relu(bn(fc(x))) == relu(x W'^T + b') in eval mode."""
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        return fc.weight * scale[:, None], (fc.bias - bn.running_mean) * scale + bn.bias
+
+    def _layer(self, x, fc, bn, residual=None):
+        if not self.training:
+            w, b = self._folded(fc, bn)
+            y = F.linear(x, w, b, relu=True, mfma=self.mfma)
+            return y if residual is None else y + residual
+        self._calls = getattr(self, "_calls", 0) + 1
+        from .models import dropout_key
+
+        u = bn(F.linear(x, fc.weight, fc.bias, mfma=self.mfma))
+        return F.relu_dropout_add(u, residual, self.p, dropout_key(self._calls, salt=0x4D4C50))
+
     def trunk(self, x):
-        x1 = self._drop(torch.relu(self.bn1(F.linear(x, self.fc1.weight, self.fc1.bias, mfma=self.mfma))))
-        x2 = self._drop(torch.relu(self.bn2(F.linear(x1, self.fc2.weight, self.fc2.bias, mfma=self.mfma))))
-        return x1 + x2
+        x1 = self._layer(x, self.fc1, self.bn1)
+        return self._layer(x1, self.fc2, self.bn2, residual=x1)
 
     def forward(self, x):
         return F.linear(self.trunk(x), self.fc3.weight, self.fc3.bias, mfma=self.mfma)

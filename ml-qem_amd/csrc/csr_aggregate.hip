@@ -485,6 +485,36 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(const float* _
   vstore_nt<VEC>(gx + r * ldgx + c, o);
 }
 
+// y = dropout(relu(x)) and, with a residual, sum = y + residual in the same pass (the trunk of MLP2 / MLP3:
+// x1 + drop(relu(bn2(...))), docs/tutorials/mlp.py:60-66): one launch instead of three element-wise ones.  Masks: one hash
+// per 4 consecutive elements of a row (dropout_keep), keyed by (seed + counter, row * C + col).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void relu_dropout_kernel(const float* __restrict__ x, int64_t ldx, float p, uint64_t seed,
+                                                              const uint64_t* __restrict__ seed_counter,
+                                                              const float* __restrict__ residual, int64_t ldr,
+                                                              float* __restrict__ y, int64_t ldy, float* __restrict__ sum,
+                                                              int64_t lds, int64_t N, int C, int CV) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * CV) return;
+  const int64_t r = t / CV;
+  const int c = (int)(t - r * CV) * VEC;
+  float xv[VEC], rv[VEC], o[VEC], sv[VEC];
+  vload<VEC>(x + r * ldx + c, xv);
+  if (residual) vload<VEC>(residual + r * ldr + c, rv);
+  bool keep[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) keep[v] = true;
+  if (p > 0.f) dropout_keep<VEC>(seed + (seed_counter ? *seed_counter * 0xD1B54A32D192ED03ull : 0ull), (uint64_t)(r * C + c), p, keep);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const float u = fmaxf(xv[v], 0.f);
+    o[v] = keep[v] ? u * (1.f / (1.f - p)) : 0.f;
+    sv[v] = residual ? o[v] + rv[v] : o[v];
+  }
+  vstore<VEC>(y + r * ldy + c, o);
+  if (sum) vstore<VEC>(sum + r * lds + c, sv);
+}
+
 }  // namespace mlqem
 
 using namespace mlqem;
@@ -533,5 +563,25 @@ extern "C" int mlqem_ell_from_csr(const int32_t* ptr, const int32_t* idx, int64_
   if (N == 0) return MLQEM_OK;
   hipLaunchKernelGGL(ell_from_csr_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream), ptr,
                      idx, N, ell);
+  return launch_status();
+}
+
+extern "C" int mlqem_relu_dropout_f32(const float* x, int64_t ldx, float drop_p, uint64_t seed, const uint64_t* seed_counter,
+                                      const float* residual, int64_t ldr, float* y, int64_t ldy, float* sum, int64_t lds,
+                                      int64_t N, int C, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C <= 0 || ldx < C || ldy < C || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
+  if ((residual && ldr < C) || (sum && lds < C) || (sum && !residual)) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !y) return MLQEM_ERR_BAD_ARG;
+  const int c4 = (C + 3) / 4 * 4;
+  auto rows_ok = [&](const float* q, int64_t ld) { return !q || (ld >= c4 && ld % 4 == 0 && aligned_to(q, 16)); };
+  const bool wide = rows_ok(x, ldx) && rows_ok(y, ldy) && rows_ok(residual, ldr) && rows_ok(sum, lds);
+  if (wide)
+    hipLaunchKernelGGL(relu_dropout_kernel<4>, dim3((unsigned)ceil_div(N * (c4 / 4), kBlock)), dim3(kBlock), 0, as_stream(stream), x,
+                       ldx, drop_p, seed, seed_counter, residual, ldr, y, ldy, sum, lds, N, C, c4 / 4);
+  else
+    hipLaunchKernelGGL(relu_dropout_kernel<1>, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0, as_stream(stream), x, ldx,
+                       drop_p, seed, seed_counter, residual, ldr, y, ldy, sum, lds, N, C, C);
   return launch_status();
 }

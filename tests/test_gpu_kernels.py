@@ -467,3 +467,35 @@ def test_differentiable_aggregation_building_block():
     for a_, b_ in zip(dev, ref):
         scale = b_.grad.abs().max().item() + 1e-12
         assert (a_.grad.cpu().double() - b_.grad).abs().max().item() / scale < 2e-5
+
+
+def test_relu_dropout_add_forward_backward():
+    """mlqem_relu_dropout_f32: y = dropout(relu(x)), sum = y + residual in one launch; keep rate, scaling, mask reuse in
+    the backward, and the seed contract (same seed -> same mask, other seed -> other mask)."""
+    from blackwater.native import functional as F
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(0)
+    for n, c, p in ((1, 1, 0.0), (777, 64, 0.5), (1000, 125, 0.3), (33, 10, 0.2)):
+        x = torch.randn(n, c, generator=g)
+        r = torch.randn(n, c, generator=g)
+        xd, rd = x.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+        s = F.relu_dropout_add(xd, rd, p, 99)
+        y = (s - rd).detach()
+        kept = ops.relu_dropout(x.to(DEV), p, 99)[0] != 0
+        relu = x.clamp(min=0).to(DEV)
+        scale = 1.0 / (1.0 - p)
+        assert torch.allclose(y[kept], relu[kept] * scale, rtol=1e-6, atol=1e-6)          # kept entries: relu(x) / (1 - p)
+        if p > 0 and n * c > 10000:
+            frac = (kept & (relu > 0)).sum().item() / (relu > 0).sum().item()
+            assert abs(frac - (1 - p)) < 0.02
+        go = torch.randn(n, c, generator=g).to(DEV)
+        s.backward(go)
+        assert torch.equal(rd.grad, go)
+        assert torch.allclose(xd.grad, torch.where(kept, go * scale, torch.zeros_like(go)), rtol=1e-6, atol=1e-7)
+        again, _ = ops.relu_dropout(x.to(DEV), p, 99)
+        other, _ = ops.relu_dropout(x.to(DEV), p, 100)
+        assert torch.allclose(again, y, rtol=1e-5, atol=1e-6) and torch.equal(again != 0, kept | (again != 0))
+        assert torch.equal(again, ops.relu_dropout(x.to(DEV), p, 99)[0])          # same seed: the same mask, bit for bit
+        if p > 0 and n * c > 100:
+            assert not torch.equal(other, again)
