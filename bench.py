@@ -108,7 +108,7 @@ def roofline_leg(batch, reps=20):
             traffic, src = pmc["traffic_bytes_per_launch"], os.path.relpath(PMC_SUMMARY, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE)"
     except (OSError, KeyError, ValueError):
         pass
-    out = {"bound": "hbm", "kernel": "csr_aggregate_ell_kernel<4,false,2> (GCN forward aggregation, C=10)",
+    out = {"bound": "hbm", "kernel": "csr_aggregate_ell_kernel<4,false,2,false> (GCN forward aggregation, C=10)",
            "achieved": round(ach, 1), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
            "traffic_source": src, "bytes_per_launch": int(b), "us_per_launch": round(sec * 1e6, 2), "nodes": n,
            "edges_with_loops": e_loops, "measured_copy_GBps": round(copy_gbps, 1),

@@ -51,13 +51,20 @@ __device__ __forceinline__ void stage_bias(const AggArgs& a, float* s_bias, int 
   __syncthreads();
 }
 
-template <int VEC, bool IS_MAX>
+// EPI = false: the plain form out = alpha * (rs * acc + ds * self) -- every backward aggregation and the roofline launch.
+// Compiled apart from the full epilogue (z, bias, ReLU, dropout) because the kernels are pinned at 64 VGPRs for eight waves
+// per SIMD and the epilogue's operands (about a dozen more SGPRs, 64-bit hash temporaries) tipped the hot path into
+// scratch: +20 % write traffic and +15 % time on the plain launches, measured with the PMC passes of round 2.
+template <int VEC, bool IS_MAX, bool EPI = true>
 __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
                                            const float (&self)[VEC], float rs, float ds, const float* s_bias) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) res[v] = acc[v];
+  } else if (!EPI) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) res[v] = a.alpha * fmaf(ds, self[v], rs * acc[v]);
   } else {
     float zz[VEC];
     if (a.z) vload<VEC>(a.z + row * a.ldz + ch, zz);
@@ -234,12 +241,12 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
 // Items are (row, channel-slice) pairs numbered row-major exactly as above; a workgroup owns kBlock * IPT items.
 constexpr int kEllMore = (int)0x80000000;
 
-template <int VEC, bool IS_MAX, int kItemsPerThread>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {
+template <int VEC, bool IS_MAX, int kItemsPerThread, bool EPI>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(EPI ? 6 : 8, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {
   // A block owns a.R = (kBlock * IPT) / CV whole rows; the local item index li < kBlock * IPT <= 2048 is split into
   // (row, slice) with a multiply-shift (exact for li * CV < 2^20) instead of a division.
-  __shared__ float s_bias[kBiasLds];
-  stage_bias(a, s_bias, a.CV * VEC);
+  __shared__ float s_bias[EPI ? kBiasLds : 1];
+  if (EPI) stage_bias(a, s_bias, a.CV * VEC);
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int64_t r0 = (int64_t)blk * a.R;
   const int nrows = (int)min((int64_t)a.R, a.N - r0);
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
       }
     }
-    finish_row<VEC, IS_MAX>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias);
+    finish_row<VEC, IS_MAX, EPI>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias);
   }
   // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
   // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (!use_self) sf[v] = 0.f;
             if (IS_MAX) part[v] = fmaxf(part[v], sf[v]);
           }
-          finish_row<VEC, IS_MAX>(a, r, hch, part, sf, rs_r, ds_r, s_bias);
+          finish_row<VEC, IS_MAX, EPI>(a, r, hch, part, sf, rs_r, ds_r, s_bias);
         }
       } else {   // more slices than lanes: every lane walks all edges for its slices
         for (int sl = lane; sl < a.CV; sl += kWave) {
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 #pragma unroll
             for (int v = 0; v < VEC; ++v) tot[v] = IS_MAX ? fmaxf(tot[v], q[v]) : fmaf(w, q[v], tot[v]);
           }
-          finish_row<VEC, IS_MAX>(a, r, hch, tot, sf, rs_r, ds_r, s_bias);
+          finish_row<VEC, IS_MAX, EPI>(a, r, hch, tot, sf, rs_r, ds_r, s_bias);
         }
       }
     }
@@ -452,9 +459,11 @@ static int launch_aggregate(AggArgs a, hipStream_t stream) {
     if (eblocks > 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
     grid = dim3((unsigned)eblocks);
   }
+  const bool epi = !IS_MAX && (a.z || a.bias || a.act || a.drop_p > 0.f);
 #define MLQEM_LAUNCH(V, P)                                                                                  \
   do {                                                                                                      \
-    if (a.ell) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P>), grid, block, 0, stream, a);      \
+    if (a.ell && epi) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true>), grid, block, 0, stream, a);   \
+    else if (a.ell) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, false>), grid, block, 0, stream, a);    \
     else hipLaunchKernelGGL((csr_aggregate_kernel<V, IS_MAX, P>), grid, block, 0, stream, a);               \
   } while (0)
 #define MLQEM_BY_IPT(V) do { if (ipt == 1) MLQEM_LAUNCH(V, 1); else if (ipt == 2) MLQEM_LAUNCH(V, 2); else if (ipt == 8) MLQEM_LAUNCH(V, 8); else MLQEM_LAUNCH(V, 4); } while (0)
