@@ -241,8 +241,8 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
 // Items are (row, channel-slice) pairs numbered row-major exactly as above; a workgroup owns kBlock * IPT items.
 constexpr int kEllMore = (int)0x80000000;
 
-template <int VEC, bool IS_MAX, int kItemsPerThread, bool EPI>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(EPI ? 6 : 8, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {
+template <int VEC, bool IS_MAX, int kItemsPerThread, bool EPI, int kMinWaves = 8>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWaves, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {
   // A block owns a.R = (kBlock * IPT) / CV whole rows; the local item index li < kBlock * IPT <= 2048 is split into
   // (row, slice) with a multiply-shift (exact for li * CV < 2^20) instead of a division.
   __shared__ float s_bias[EPI ? kBiasLds : 1];
@@ -460,9 +460,12 @@ static int launch_aggregate(AggArgs a, hipStream_t stream) {
     grid = dim3((unsigned)eblocks);
   }
   const bool epi = !IS_MAX && (a.z || a.bias || a.act || a.drop_p > 0.f);
+  static const int epi_waves = getenv("MLQEM_AGG_EPI_WAVES") ? atoi(getenv("MLQEM_AGG_EPI_WAVES")) : 7;   // measured: 7 -> 304/351 us, 6 -> 341/385, 8 (spilling) -> 356/385 (GCN / Cheb forward)
 #define MLQEM_LAUNCH(V, P)                                                                                  \
   do {                                                                                                      \
-    if (a.ell && epi) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true>), grid, block, 0, stream, a);   \
+    if (a.ell && epi && epi_waves == 8) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 8>), grid, block, 0, stream, a);   \
+    else if (a.ell && epi && epi_waves == 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 7>), grid, block, 0, stream, a);   \
+    else if (a.ell && epi) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 6>), grid, block, 0, stream, a);   \
     else if (a.ell) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, false>), grid, block, 0, stream, a);    \
     else hipLaunchKernelGGL((csr_aggregate_kernel<V, IS_MAX, P>), grid, block, 0, stream, a);               \
   } while (0)
