@@ -13,6 +13,8 @@ Parity status: PINNED by the reference's committed artefacts (SURVEY.md section 
   G2  MLP1 + encode_data with .../mlp1_smaller_2.pth on the same circuits -> 0.032910 (same cell)
   G3  L2 of the raw noisy values -> 0.027510
 Family A (GCN/Cheb/SAGE, docs/tutorials/01_ngem.ipynb cell [9]) has no checkpoint or printed output in the
-reference: for those three layers the oracle is "parity unpinned" against the reference and is instead
-cross-checked against dense-matrix formulas on small graphs (tests/test_oracle_family_a.py).
+reference -- nothing of the reference's can pin those three layers.  They are pinned instead by checks that share no
+code with this package (tests/test_oracle_family_a.py): hand-computed answers on 3-node graphs and an independent
+dense-matrix formulation in numpy fp64 covering duplicate edges, pre-existing self-loops, isolated nodes and
+zero-out-degree sources, following PyG's published definitions.
 """
