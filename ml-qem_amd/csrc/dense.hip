@@ -587,11 +587,14 @@ struct WgradArgs {
   int64_t N; int I; int O;
 };
 
-constexpr int kWgradUnroll = 4;  // MFMA k-steps (of 4 rows) whose loads are issued together
+constexpr int kWgradUnroll = 4;  // MFMA k-steps (of 4 rows) whose loads are issued together (default)
 
-template <int OBT, int IBT>
+// kU: k-steps per iteration.  The wide tile shapes (six output tiles: the seven first-layer gradient blocks in one pass)
+// can take kU = 2 (136 instead of 180 VGPRs: three waves per SIMD instead of two) -- measured SLOWER (1680 vs 1201 us on the
+// seven-block pass): the kernel lives on loads in flight per wave, so four stays the default (MLQEM_WGRAD_WIDE_U).
+template <int OBT, int IBT, int kU = kWgradUnroll>
 __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
-  __shared__ f32x4 s_acc[4][OBT * IBT][kWave];
+  __shared__ f32x4 s_acc[4][kWave];   // the four waves' copies of ONE accumulator tile at a time (see the end)
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wid;
@@ -618,27 +621,27 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
     gld[ob] = ok ? a.ldgy[part] : 0;
   }
 
-  const int64_t rows_per_iter = 4 * kWgradUnroll;
+  const int64_t rows_per_iter = 4 * kU;
   const int64_t n_iters = ceil_div(a.N, rows_per_iter);
   // with a row map the x row numbers of the NEXT iteration are fetched during the current one, so the map lookup
   // never sits in front of the operand loads (a dependent lookup per iteration cost 40 % on this kernel)
-  int xmap[kWgradUnroll];
+  int xmap[kU];
   auto fetch_map = [&](int64_t it) {
 #pragma unroll
-    for (int u = 0; u < kWgradUnroll; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const int64_t n = it * rows_per_iter + u * 4 + lq;
       xmap[u] = (a.xrows && it < n_iters && n < a.N) ? a.xrows[n] : 0;
     }
   };
   fetch_map(wave);
   for (int64_t it = wave; it < n_iters; it += n_waves) {
-    float af[kWgradUnroll][OBT], bf[kWgradUnroll][IBT];
-    int xcur[kWgradUnroll];
+    float af[kU][OBT], bf[kU][IBT];
+    int xcur[kU];
 #pragma unroll
-    for (int u = 0; u < kWgradUnroll; ++u) xcur[u] = xmap[u];
+    for (int u = 0; u < kU; ++u) xcur[u] = xmap[u];
     if (a.xrows) fetch_map(it + n_waves);
 #pragma unroll
-    for (int u = 0; u < kWgradUnroll; ++u) {
+    for (int u = 0; u < kU; ++u) {
       const int64_t n = it * rows_per_iter + u * 4 + lq;
       const bool ok = n < a.N;
       const int64_t xn = a.xrows ? (int64_t)xcur[u] : n;
@@ -653,27 +656,25 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < kWgradUnroll; ++u)
+    for (int u = 0; u < kU; ++u)
 #pragma unroll
       for (int ob = 0; ob < OBT; ++ob)
 #pragma unroll
         for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = mfma16x16x4(af[u][ob], bf[u][ib], acc[ob][ib]);
   }
-  // the four waves of the block add up through LDS in a fixed order
+  // the four waves of the block add up through LDS in a fixed order, one accumulator tile at a time (4 KB of LDS instead
+  // of 4 KB per tile: twelve tiles would cap the kernel at three workgroups per CU)
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * a.O * I1;
 #pragma unroll
   for (int ob = 0; ob < OBT; ++ob)
 #pragma unroll
-    for (int ib = 0; ib < IBT; ++ib) s_acc[wid][ob * IBT + ib][lane] = acc[ob][ib];
-  __syncthreads();
-  if (wid == 0) {
-    float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * a.O * I1;
+    for (int ib = 0; ib < IBT; ++ib) {
+      s_acc[wid][lane] = acc[ob][ib];
+      __syncthreads();
+      if (wid == 0) {
+        f32x4 t = s_acc[0][lane];
 #pragma unroll
-    for (int ob = 0; ob < OBT; ++ob)
-#pragma unroll
-      for (int ib = 0; ib < IBT; ++ib) {
-        f32x4 t = s_acc[0][ob * IBT + ib][lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) t += s_acc[w][ob * IBT + ib][lane];
+        for (int w = 1; w < 4; ++w) t += s_acc[w][lane];
         const int i = (ib0 + ib) * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -681,7 +682,8 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
           if (o < a.O && i < I1) dst[o * I1 + i] = t[r];
         }
       }
-  }
+      __syncthreads();
+    }
 }
 
 // bf16 matrix-core weight gradient (the "bf16 MFMA MLP head" trains on v_mfma_f32_16x16x32_bf16 too): gW = gY^T X with both
@@ -1025,7 +1027,10 @@ extern "C" size_t mlqem_linear_wgrad_workspace_bytes(int I, int O) {
 }
 
 static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipStream_t s) {
-  const int64_t iters = ceil_div(std::max<int64_t>(a.N, 1), 4 * kWgradUnroll);
+  static const int wide_u = getenv("MLQEM_WGRAD_WIDE_U") ? atoi(getenv("MLQEM_WGRAD_WIDE_U")) : 4;   // measured on the 7-block pass: 4 -> 1201 us (180 VGPRs, 2 waves/SIMD), 2 -> 1680 us (136 VGPRs, 3 waves): loads in flight per wave matter more than occupancy
+  const int ob_ = (a.O + 15) / 16, ib_ = (a.I + 1 + 15) / 16;
+  const bool wide = ob_ >= 4 && ob_ <= 6 && ib_ <= 2;
+  const int64_t iters = ceil_div(std::max<int64_t>(a.N, 1), 4 * (wide && wide_u == 2 ? 2 : kWgradUnroll));
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
   const int ob = (a.O + 15) / 16, ib = (a.I + 1 + 15) / 16;
   if (ob == 1 && ib <= 2) {
@@ -1035,9 +1040,11 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
   } else if (ob == 3 && ib <= 2) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<3, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob == 4 && ib <= 2) {   // up to eight blocks (the three first layers of Family A share x): one pass
-    hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob <= 6 && ib <= 2) {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob == 1) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
   } else {
