@@ -311,8 +311,9 @@ def family_b_leg(dev, steps=30):
                        "achieved": round(by / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / sec / 1e9 / 8000.0, 4),
                        "traffic": None, "bytes_per_launch": int(by), "us_per_launch": round(sec * 1e6, 2), "nodes": n,
                        "edges_with_loops": e1,
-                       "note": "a 1024-circuit batch of 4-qubit graphs is 0.23 M nodes: the launch is %.0f us long and the step is "
-                               "bound by launch count, not by this kernel" % (sec * 1e6)}
+                       "note": "latency-bound, not bandwidth-bound: 16 lanes per (row, head) fetch 60-byte key/value segments at odd "
+                               "float offsets (C = 15), three dependent round trips per row; a 1024-circuit batch of 4-qubit "
+                               "graphs is only 0.23 M nodes and the step spreads over ~100 such small launches"}
     return out
 
 

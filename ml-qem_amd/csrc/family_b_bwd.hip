@@ -16,6 +16,8 @@ constexpr int kAttnMaxC = 32;
 // Forward with statistics: identical arithmetic to transformer_attn_kernel (attn.hip) plus m[N,H] (segment max) and
 // den[N,H] (sum of exp + 1e-16) for the backward, and optional dropout on the attention weights
 // (mask keyed by (seed, in-CSR position, head); self-loop entries use position E + row).
+constexpr int kAttnShort = 6;   // in-edges (+ self) of a row handled from registers
+
 __global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(
     const float* __restrict__ qkvs, int64_t ld, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const int32_t* __restrict__ loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
@@ -40,23 +42,47 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(
     if (c1) s = fmaf(q1, kj[l + kGroup], s);
     return group16_sum(s) * scale;
   };
-  float m = -INFINITY;
-  for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
-  if (n_self > 0) m = fmaxf(m, score(row));
-  float denom = 0.f;
-  for (int e = beg; e < end; ++e) denom += expf(score(idx[e]) - m);
-  if (n_self > 0) denom += expf(score(row) - m) * (float)n_self;
-  denom += 1e-16f;
+  float m = -INFINITY, denom = 0.f;
   float a0 = 0.f, a1 = 0.f;
-  auto add = [&](int64_t j, float mult, int64_t pos) {
-    float a = expf(score(j) - m) / denom * mult;
+  auto add_p = [&](int64_t j, float a, int64_t pos) {          // a = softmax weight (times its multiplicity)
     if (drop_p > 0.f) a = uniform01(seed, (uint64_t)(pos * H + h)) < drop_p ? 0.f : a * keep;
     const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
     if (c0) a0 = fmaf(a, vj[l], a0);
     if (c1) a1 = fmaf(a, vj[l + kGroup], a1);
   };
-  for (int e = beg; e < end; ++e) add(idx[e], 1.f, e);
-  if (n_self > 0) add(row, (float)n_self, E + row);
+  const int deg = end - beg;
+  const int cnt = deg + (n_self > 0 ? 1 : 0);
+  if (cnt <= kAttnShort) {
+    // Short rows (all but the barrier nodes of a circuit graph): the source ids, then ALL key rows, then ALL value rows are
+    // fetched together and every score is computed ONCE and kept in registers -- three dependent round trips per row
+    // instead of three per in-edge.  Same expressions in the same order as the general path below: bit-identical.
+    int64_t jj[kAttnShort];
+    float sc[kAttnShort];
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) jj[e] = e < deg ? (int64_t)idx[beg + e] : row;
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) sc[e] = e < cnt ? score(jj[e]) : -INFINITY;     // group-uniform predicate
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) if (e < cnt) m = fmaxf(m, sc[e]);
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) if (e < deg) denom += expf(sc[e] - m);
+    float p_self = 0.f;
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) if (e == deg && n_self > 0) p_self = expf(sc[e] - m);
+    if (n_self > 0) denom += p_self * (float)n_self;
+    denom += 1e-16f;
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) if (e < deg) add_p(jj[e], expf(sc[e] - m) / denom * 1.f, beg + e);
+    if (n_self > 0) add_p(row, p_self / denom * (float)n_self, E + row);
+  } else {
+    for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
+    if (n_self > 0) m = fmaxf(m, score(row));
+    for (int e = beg; e < end; ++e) denom += expf(score(idx[e]) - m);
+    if (n_self > 0) denom += expf(score(row) - m) * (float)n_self;
+    denom += 1e-16f;
+    for (int e = beg; e < end; ++e) add_p(idx[e], expf(score(idx[e]) - m) / denom * 1.f, e);
+    if (n_self > 0) add_p(row, expf(score(row) - m) / denom * (float)n_self, E + row);
+  }
   const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
   if (c0) { attn_out[row * lda + h * C + l] = a0; out[row * ldo + h * C + l] = a0 + skip[l]; }
   if (c1) { attn_out[row * lda + h * C + l + kGroup] = a1; out[row * ldo + h * C + l + kGroup] = a1 + skip[l + kGroup]; }
