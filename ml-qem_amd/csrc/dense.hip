@@ -592,7 +592,7 @@ constexpr int kWgradUnroll = 4;  // MFMA k-steps (of 4 rows) whose loads are iss
 // kU: k-steps per iteration.  The wide tile shapes (six output tiles: the seven first-layer gradient blocks in one pass)
 // can take kU = 2 (136 instead of 180 VGPRs: three waves per SIMD instead of two) -- measured SLOWER (1680 vs 1201 us on the
 // seven-block pass): the kernel lives on loads in flight per wave, so four stays the default (MLQEM_WGRAD_WIDE_U).
-template <int OBT, int IBT, int kU = kWgradUnroll>
+template <int OBT, int IBT, int kU = kWgradUnroll, bool PF = false>
 __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
   __shared__ f32x4 s_acc[4][kWave];   // the four waves' copies of ONE accumulator tile at a time (see the end)
   const int lane = threadIdx.x & 63;
@@ -633,34 +633,66 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
       xmap[u] = (a.xrows && it < n_iters && n < a.N) ? a.xrows[n] : 0;
     }
   };
-  fetch_map(wave);
-  for (int64_t it = wave; it < n_iters; it += n_waves) {
-    float af[kU][OBT], bf[kU][IBT];
-    int xcur[kU];
-#pragma unroll
-    for (int u = 0; u < kU; ++u) xcur[u] = xmap[u];
-    if (a.xrows) fetch_map(it + n_waves);
+  auto issue = [&](int64_t it, const int (&xr)[kU], float (&A)[kU][OBT], float (&B)[kU][IBT]) {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int64_t n = it * rows_per_iter + u * 4 + lq;
       const bool ok = n < a.N;
-      const int64_t xn = a.xrows ? (int64_t)xcur[u] : n;
+      const int64_t xn = a.xrows ? (int64_t)xr[u] : n;
 #pragma unroll
-      for (int ob = 0; ob < OBT; ++ob) af[u][ob] = (ok && gcol[ob]) ? gcol[ob][n * gld[ob]] : 0.f;
+      for (int ob = 0; ob < OBT; ++ob) A[u][ob] = (ok && gcol[ob]) ? gcol[ob][n * gld[ob]] : 0.f;
 #pragma unroll
       for (int ib = 0; ib < IBT; ++ib) {
         const int i = (ib0 + ib) * 16 + lr;
         float v = 0.f;
         if (ok) v = i < a.I ? a.x[xn * a.ldx + i] : (i == a.I ? 1.f : 0.f);  // column I: ones -> bias gradient
-        bf[u][ib] = v;
+        B[u][ib] = v;
       }
     }
+  };
+  auto multiply = [&](const float (&A)[kU][OBT], const float (&B)[kU][IBT]) {
 #pragma unroll
     for (int u = 0; u < kU; ++u)
 #pragma unroll
       for (int ob = 0; ob < OBT; ++ob)
 #pragma unroll
-        for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = mfma16x16x4(af[u][ob], bf[u][ib], acc[ob][ib]);
+        for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = mfma16x16x4(A[u][ob], B[u][ib], acc[ob][ib]);
+  };
+  fetch_map(wave);
+  if constexpr (PF) {
+    // Software pipeline for the wide tile shapes (two waves per SIMD: too few for the hardware to overlap one wave's loads
+    // with another's 48 MFMAs): the operands of iteration t + 1 are in flight while iteration t multiplies.
+    float af[kU][OBT], bf[kU][IBT];
+    int xcur[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) xcur[u] = xmap[u];
+    if (a.xrows) fetch_map(wave + n_waves);
+    issue(wave, xcur, af, bf);
+    for (int64_t it = wave; it < n_iters; it += n_waves) {
+      float afn[kU][OBT], bfn[kU][IBT];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) xcur[u] = xmap[u];
+      if (a.xrows) fetch_map(it + 2 * n_waves);
+      issue(it + n_waves, xcur, afn, bfn);          // rows beyond N load nothing and contribute zeros
+      multiply(af, bf);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+#pragma unroll
+        for (int ob = 0; ob < OBT; ++ob) af[u][ob] = afn[u][ob];
+#pragma unroll
+        for (int ib = 0; ib < IBT; ++ib) bf[u][ib] = bfn[u][ib];
+      }
+    }
+  } else {
+    for (int64_t it = wave; it < n_iters; it += n_waves) {
+      float af[kU][OBT], bf[kU][IBT];
+      int xcur[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) xcur[u] = xmap[u];
+      if (a.xrows) fetch_map(it + n_waves);
+      issue(it, xcur, af, bf);
+      multiply(af, bf);
+    }
   }
   // the four waves of the block add up through LDS in a fixed order, one accumulator tile at a time (4 KB of LDS instead
   // of 4 KB per tile: twelve tiles would cap the kernel at three workgroups per CU)
@@ -1028,6 +1060,7 @@ extern "C" size_t mlqem_linear_wgrad_workspace_bytes(int I, int O) {
 
 static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipStream_t s) {
   static const int wide_u = getenv("MLQEM_WGRAD_WIDE_U") ? atoi(getenv("MLQEM_WGRAD_WIDE_U")) : 4;   // measured on the 7-block pass: 4 -> 1201 us (180 VGPRs, 2 waves/SIMD), 2 -> 1680 us (136 VGPRs, 3 waves): loads in flight per wave matter more than occupancy
+  static const int wide_pf = getenv("MLQEM_WGRAD_PF") ? atoi(getenv("MLQEM_WGRAD_PF")) : 1;
   const int ob_ = (a.O + 15) / 16, ib_ = (a.I + 1 + 15) / 16;
   const bool wide = ob_ >= 4 && ob_ <= 6 && ib_ <= 2;
   const int64_t iters = ceil_div(std::max<int64_t>(a.N, 1), 4 * (wide && wide_u == 2 ? 2 : kWgradUnroll));
@@ -1044,6 +1077,7 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     else hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob <= 6 && ib <= 2) {
     if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    else if (wide_pf) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, kWgradUnroll, true>), dim3(G, 1), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob == 1) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
