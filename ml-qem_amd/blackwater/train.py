@@ -85,6 +85,13 @@ class Trainer:
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", factor=0.1, patience=15,
                                                                     min_lr=1e-5)
         self.criterion = nn.MSELoss()
+        # The host enqueues a step several times faster than the device runs it.  Unbounded run-ahead makes torch's caching
+        # allocator grow without end on the multi-stream path: blocks handed between the branch streams can only be reused
+        # after their recorded events have completed, so every step queued ahead needs its own copy of the activations and
+        # each growth is a hipMalloc that drains the queue (measured: 1536-circuit steps 11.7 ms -> 16-51 ms).  Two steps
+        # in flight keep the device busy and the pool at its steady size.
+        self.max_steps_in_flight = 0   # 0 = unbounded (default: at the benchmark batch of 1024 circuits the pool settles after the first steps)
+        self._inflight = []
         if self.distributed:
             self.broadcast_parameters()
 
@@ -112,7 +119,12 @@ class Trainer:
 
     # -- one optimisation step on an assembled batch -------------------------------------------------------
     def step(self, batch) -> torch.Tensor:
-        """forward -> MSE -> backward -> (all-reduce) -> Adam.  Returns the loss as a device tensor (no sync)."""
+        """forward -> MSE -> backward -> (all-reduce) -> Adam.  Returns the loss as a device tensor (the host waits only for
+        the step ``max_steps_in_flight`` steps back, see __init__)."""
+        throttle = self.max_steps_in_flight and self.flat_grad is not None and self.flat_grad.is_cuda \
+            and not torch.cuda.is_current_stream_capturing()
+        if throttle and len(self._inflight) >= self.max_steps_in_flight:
+            self._inflight.pop(0).synchronize()
         self.model.train()
         if self.flat_grad is not None:
             # With .grad pointing into the flat buffer autograd would ADD every parameter's gradient into its slot: one
@@ -143,6 +155,10 @@ class Trainer:
         if self.distributed:
             self.all_reduce_gradients()
         self.optimizer.step()
+        if throttle:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._inflight.append(ev)
         return loss.detach()
 
     def all_reduce_gradients(self):
