@@ -289,6 +289,31 @@ def family_b_leg(dev, steps=30):
         dt = time.perf_counter() - t0
         out[f"batch{batch}"] = {"circuits_per_s": round(batch * n_steps / dt, 1), "ms_per_step": round(dt / n_steps * 1e3, 3),
                                 "steps": n_steps}
+    # the CPU oracle doing the same step at the reference's batch size (bounded: 6 steps, the first one untimed)
+    from oracle.models import FamilyB
+
+    torch.manual_seed(0)
+    ref = FamilyB(22, 15, 4).train()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    times = []
+    for k in range(6):
+        sel = rng.randint(0, len(arena), size=32)
+        t0 = time.perf_counter()
+        xs, eis, bs, off = [], [], [], 0
+        for bi, g in enumerate(sel):
+            x = torch.from_numpy(h["x"][g])
+            xs.append(x)
+            eis.append(torch.from_numpy(h["edge_index"][g]) + off)
+            bs.append(torch.full((x.shape[0],), bi, dtype=torch.long))
+            off += x.shape[0]
+        opt.zero_grad()
+        pred = ref(torch.from_numpy(h["noisy"][sel][:, None, :]), None, torch.from_numpy(h["depth"][sel]), torch.cat(xs),
+                   torch.cat(eis, 1), torch.cat(bs))
+        torch.nn.functional.mse_loss(pred, torch.from_numpy(h["y"][sel])).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    out["cpu_oracle_batch32"] = {"circuits_per_s": round(32 / float(np.median(times[1:])), 1),
+                                 "sample": "oracle/models.py FamilyB, full train step, median of 5 steps of 32 circuits, torch default threads"}
     b = arena.batch(np.arange(1024) * len(arena) // 1024)
     s = b.structure
     n, e, heads, ch = s.num_nodes, s.num_edges, 3, 15
