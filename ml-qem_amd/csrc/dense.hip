@@ -503,10 +503,18 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
   }
   const bool store_lane = 4 * lq < a.yw;       // the block's padded width: lanes beyond it own no output columns
   const int64_t n_tiles = ceil_div(a.N, 16);
+  // the row-map entry of the NEXT tile is fetched while this tile is processed: a dependent lookup in front of every
+  // tile's operand loads is a whole extra memory round trip (the weight-gradient kernel does the same)
+  auto map_of = [&](int64_t t) {
+    const int64_t r = t * 16 + lr;
+    return (a.xrows && t < n_tiles && r < a.N) ? a.xrows[r] : 0;
+  };
+  int xnext = map_of(wave);
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
     const int64_t row = t * 16 + lr;
     const bool row_ok = row < a.N;
-    const int64_t xrow = (a.xrows && row_ok) ? (int64_t)a.xrows[row] : row;
+    const int64_t xrow = a.xrows ? (int64_t)xnext : row;
+    xnext = map_of(t + n_waves);
     float4 av[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -537,7 +545,8 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
         v[r] = acc[r] + s_b[blk][4 * lq + r];
         if (a.rsk[blk]) v[r] *= rs;
       }
-      vstore_nt<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
+      if (a.plain_stores) vstore<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
+      else vstore_nt<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
     }
   }
 }
@@ -959,7 +968,10 @@ static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
   if (lds_env && !transposed && a.xn == 1 && a.yn >= 2 && a.yw <= 16 && !a.act && a.drop_p == 0.f && !a.gate) {
     // several narrow output blocks from one read of x: weight fragments in LDS, one MFMA tile per block
     const int64_t tiles = ceil_div(a.N, 16);
-    dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8));
+    static const int plain_env = getenv("MLQEM_FANOUT_PLAIN") ? atoi(getenv("MLQEM_FANOUT_PLAIN")) : 0;
+    static const int grid_env = getenv("MLQEM_FANOUT_GRID") ? atoi(getenv("MLQEM_FANOUT_GRID")) : 16;   // workgroups per CU x 256: measured 4 -> 1358, 8 -> 1268, 16 -> 1197, 64 -> 1249 us
+    a.plain_stores = plain_env;
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * grid_env));
     switch (g) {
       case 1: hipLaunchKernelGGL(linear_fanout_lds_kernel<1>, grid, dim3(kBlock), 0, s, a); break;
       case 2: hipLaunchKernelGGL(linear_fanout_lds_kernel<2>, grid, dim3(kBlock), 0, s, a); break;
