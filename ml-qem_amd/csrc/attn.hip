@@ -7,6 +7,7 @@
 namespace mlqem {
 
 constexpr int kAttnMaxC = 32;  // channels per head held in registers (reference models: 15 and 25)
+constexpr int kAttnShortRow = 6;   // in-edges (+ self) of a row whose scores are kept in registers
 
 // TransformerConv (heads=H, concat, root_weight, no edge features).
 // qkvs: [N, 4*H*C] = [query | key | value | skip] as produced by one fused projection.
@@ -37,21 +38,39 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const float* _
     if (c1) s = fmaf(q1, kj[l + kGroup], s);
     return group16_sum(s) * scale;
   };
-  // pass 1: segment max
   float m = -INFINITY;
-  for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
-  if (n_self > 0) m = fmaxf(m, score(row));
-  // pass 2: exp, sum, weighted value sum
   float a0 = 0.f, a1 = 0.f, denom = 0.f;
-  auto add = [&](int64_t j, float mult) {
-    const float p = expf(score(j) - m) * mult;
+  auto add_p = [&](int64_t j, float p) {
     denom += p;
     const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
     if (c0) a0 = fmaf(p, vj[l], a0);
     if (c1) a1 = fmaf(p, vj[l + kGroup], a1);
   };
-  for (int e = beg; e < end; ++e) add(idx[e], 1.f);
-  if (n_self > 0) add(row, (float)n_self);
+  const int deg = end - beg;
+  const int cnt = deg + (n_self > 0 ? 1 : 0);
+  if (cnt <= kAttnShortRow) {
+    // short rows: source ids, then all key rows, then all value rows fetched together; every score computed once and
+    // kept in registers (same expressions, same order as the general path: bit-identical)
+    int64_t jj[kAttnShortRow];
+    float sc[kAttnShortRow];
+#pragma unroll
+    for (int e = 0; e < kAttnShortRow; ++e) jj[e] = e < deg ? (int64_t)idx[beg + e] : row;
+#pragma unroll
+    for (int e = 0; e < kAttnShortRow; ++e) sc[e] = e < cnt ? score(jj[e]) : -INFINITY;
+#pragma unroll
+    for (int e = 0; e < kAttnShortRow; ++e) if (e < cnt) m = fmaxf(m, sc[e]);
+#pragma unroll
+    for (int e = 0; e < kAttnShortRow; ++e) if (e < deg) add_p(jj[e], expf(sc[e] - m) * 1.f);
+#pragma unroll
+    for (int e = 0; e < kAttnShortRow; ++e) if (e == deg && n_self > 0) add_p(row, expf(sc[e] - m) * (float)n_self);
+  } else {
+    // pass 1: segment max
+    for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
+    if (n_self > 0) m = fmaxf(m, score(row));
+    // pass 2: exp, sum, weighted value sum
+    for (int e = beg; e < end; ++e) add_p(idx[e], expf(score(idx[e]) - m) * 1.f);
+    if (n_self > 0) add_p(row, expf(score(row) - m) * (float)n_self);
+  }
   const float inv = 1.0f / (denom + 1e-16f);
   const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
   float* __restrict__ o = out + row * ldo + h * C;
