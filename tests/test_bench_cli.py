@@ -47,3 +47,28 @@ def test_corpus_is_sharded_in_equal_node_balanced_parts():
         assert (np.diff(s) > 0).all()          # ascending ids: what TfimCorpus.arena takes
     h = corpus.host_graphs(shards[1][:3])
     assert len(h["x"]) == 3 and h["observable"].shape == (3, 1, 25) and h["y"].shape == (3, 1)
+
+
+def test_accuracy_fixture_and_pooled_split(golden_dir):
+    """The training-to-accuracy set (tests/golden/ising_trainval.npz): 300 + 3 x 100 circuits of the reference's
+    ising_init_from_qasm_no_readout folders, the recorded loss curves, and the seeded pooled split."""
+    import numpy as np
+
+    from blackwater.metrics.accuracy import load_trainval, pooled_split
+
+    z = load_trainval(golden_dir)
+    assert len(z["qasm"]) == 600 and z["split"].tolist().count(0) == 300
+    assert [int((z["split"] == k).sum()) for k in (1, 2, 3)] == [100, 100, 100]
+    assert z["x"].shape[1] == 22 and z["node_ptr"][-1] == z["x"].shape[0] == 25837
+    assert len(z["ref_curves"]["gnn1"]["val_losses"]) == 99            # epochs 1-99, as the reference records them
+    assert round(z["ref_curves"]["gnn1"]["val_losses"][0], 4) == 0.0808 and round(z["ref_curves"]["gnn1"]["val_losses"][-1], 5) == 0.00687
+    tr, va = pooled_split(z["split"], seed=0)
+    assert len(tr) == 510 and len(va) == 90 and not set(tr.tolist()) & set(va.tolist())
+    assert set(np.flatnonzero(z["split"] == 0).tolist()) <= set(tr.tolist())
+    tr2, va2 = pooled_split(z["split"], seed=0)
+    assert np.array_equal(tr, tr2) and np.array_equal(va, va2)
+    # every circuit text parses and has as many ops as its graph has nodes
+    from blackwater.data.circuit import Circuit
+
+    for i in (0, 299, 300, 450, 599):
+        assert len(Circuit.from_qasm_str(z["qasm"][i]).ops) == z["node_ptr"][i + 1] - z["node_ptr"][i]
