@@ -670,26 +670,32 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
   fetch_map(wave);
   if constexpr (PF) {
     // Software pipeline for the wide tile shapes (two waves per SIMD: too few for the hardware to overlap one wave's loads
-    // with another's 48 MFMAs): the operands of iteration t + 1 are in flight while iteration t multiplies.
-    float af[kU][OBT], bf[kU][IBT];
-    int xcur[kU];
+    // with another's 48 MFMAs).  The kernel is bound by bytes in flight (Little's law: one 6.9 KB slab per wave in flight
+    // at ~3 us of loaded latency is ~4.5 TB/s chip-wide), so the operands of iterations t + 1 AND t + 2 are in flight
+    // while iteration t multiplies: three register sets, 252 VGPRs, still two waves per SIMD.
+    float a0[kU][OBT], b0[kU][IBT], a1[kU][OBT], b1[kU][IBT];
+    int xr0[kU], xr1[kU], xr2[kU];
 #pragma unroll
-    for (int u = 0; u < kU; ++u) xcur[u] = xmap[u];
+    for (int u = 0; u < kU; ++u) xr0[u] = xmap[u];
     if (a.xrows) fetch_map(wave + n_waves);
-    issue(wave, xcur, af, bf);
-    for (int64_t it = wave; it < n_iters; it += n_waves) {
-      float afn[kU][OBT], bfn[kU][IBT];
 #pragma unroll
-      for (int u = 0; u < kU; ++u) xcur[u] = xmap[u];
-      if (a.xrows) fetch_map(it + 2 * n_waves);
-      issue(it + n_waves, xcur, afn, bfn);          // rows beyond N load nothing and contribute zeros
-      multiply(af, bf);
+    for (int u = 0; u < kU; ++u) xr1[u] = xmap[u];
+    if (a.xrows) fetch_map(wave + 2 * n_waves);
+    issue(wave, xr0, a0, b0);
+    issue(wave + n_waves, xr1, a1, b1);
+    for (int64_t it = wave; it < n_iters; it += n_waves) {
+      float a2[kU][OBT], b2[kU][IBT];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) xr2[u] = xmap[u];
+      if (a.xrows) fetch_map(it + 3 * n_waves);
+      issue(it + 2 * n_waves, xr2, a2, b2);           // rows beyond N load nothing and contribute zeros
+      multiply(a0, b0);
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
 #pragma unroll
-        for (int ob = 0; ob < OBT; ++ob) af[u][ob] = afn[u][ob];
+        for (int ob = 0; ob < OBT; ++ob) { a0[u][ob] = a1[u][ob]; a1[u][ob] = a2[u][ob]; }
 #pragma unroll
-        for (int ib = 0; ib < IBT; ++ib) bf[u][ib] = bfn[u][ib];
+        for (int ib = 0; ib < IBT; ++ib) { b0[u][ib] = b1[u][ib]; b1[u][ib] = b2[u][ib]; }
       }
     }
   } else {
