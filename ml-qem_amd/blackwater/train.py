@@ -11,6 +11,7 @@ loss, batch 32 by default -- with three MI355X-side changes that do not alter th
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Iterable, List, Optional
 
 import numpy as np
@@ -88,9 +89,9 @@ class Trainer:
         # The host enqueues a step several times faster than the device runs it.  Unbounded run-ahead makes torch's caching
         # allocator grow without end on the multi-stream path: blocks handed between the branch streams can only be reused
         # after their recorded events have completed, so every step queued ahead needs its own copy of the activations and
-        # each growth is a hipMalloc that drains the queue (measured: 1536-circuit steps 11.7 ms -> 16-51 ms).  Two steps
+        # each growth is a hipMalloc that drains the queue (seen as 1536-circuit steps of 16-51 ms instead of 11.7).  A few steps
         # in flight keep the device busy and the pool at its steady size.
-        self.max_steps_in_flight = 0   # 0 = unbounded (default: at the benchmark batch of 1024 circuits the pool settles after the first steps)
+        self.max_steps_in_flight = int(os.environ.get("MLQEM_MAX_STEPS_IN_FLIGHT", "4"))   # 0 = unbounded; 4 measured as fast as unbounded (129-131 k circuits/s either way)
         self._inflight = []
         if self.distributed:
             self.broadcast_parameters()
