@@ -504,6 +504,17 @@ def main():
         torch.distributed.all_reduce(ones, op=torch.distributed.ReduceOp.SUM)
         elapsed, joined = t[0].item(), int(round(ones.item()))
 
+    # how long the HOST needs to enqueue one step (the step is device-bound only while this stays below ms_per_step): a few
+    # extra steps with unbounded run-ahead, timed up to the return of the last enqueue
+    keep_bound, trainer.max_steps_in_flight = trainer.max_steps_in_flight, 0
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(4):
+        trainer.step(arena.batch(draw()))
+    host_ms = (time.perf_counter() - t1) / 4 * 1e3
+    torch.cuda.synchronize()
+    trainer.max_steps_in_flight = keep_bound
+
     if rank == 0:
         total = args.batch * joined * args.steps
         fixed = arena.batch(fixed_ids(n_local, args.batch))
@@ -519,7 +530,7 @@ def main():
                        "mean_nodes_per_circuit": round(arena.num_nodes / n_local, 1), "parallelism": f"dp{joined}",
                        "backend": backend, "ranks_joined": joined,
                        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None},
-            "final_loss": round(float(loss.item()), 6),
+            "final_loss": round(float(loss.item()), 6), "host_enqueue_ms_per_step": round(host_ms, 3),
             "roofline": roofline_leg(fixed),
         }
         if world == 1 and not args.no_cpu_baseline:
