@@ -52,6 +52,7 @@ SIGNATURES = {
     "mlqem_linear_wgrad_workspace_bytes": (_S, [_I, _I]),
     "mlqem_linear_wgrad_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P, _P]),
     "mlqem_linear_wgrad_parts_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P, _P]),
+    "mlqem_linear_bwd_fused_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _F, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_segment_pool_workspace_bytes": (_S, [_L, _L, _I]),
     "mlqem_segment_pool_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P, _L, _P, _L, _P, _S, _P]),
     "mlqem_segment_pool_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _L, _F, _P, _L, _P]),
@@ -86,7 +87,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 8   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

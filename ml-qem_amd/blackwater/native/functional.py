@@ -364,6 +364,11 @@ class _GCNLayer(Function):
                                dself=s.derived("gcn_dself"))
         if blocks_only:
             return [gh, _padded_rows(g)]
+        if (_FUSE_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.x_gate_scale is not None
+                and max(w.shape) <= 12 and ops._fused_bwd_ok(gh, g, x)):
+            # hidden layer of width <= 12 (conv2): gated data gradient, weight and bias gradient from ONE pass over gh, x, g
+            gx, gw, gb = ops.linear_bwd_fused(gh, x, w.contiguous(), gb_src=g, gate_scale=ctx.x_gate_scale)
+            return gx, gw, gb, None, None, None, None, None, None
         gx = None
         if ctx.needs_input_grad[0]:
             gated = ctx.x_gate_scale is not None
@@ -542,6 +547,9 @@ _side_streams = {}
 # MLQEM_FUSE_FIRST=0: every branch projects x with its own GEMM and runs its own weight-gradient pass (three reads of the
 # feature rows per direction instead of one); kept for measurements.
 _FUSE_FIRST = os.environ.get("MLQEM_FUSE_FIRST", "1") != "0"
+# MLQEM_FUSE_NARROW_BWD=0: data gradient and weight gradient of GCN layer 2 as two kernels (each reading gh and x) instead of
+# the one-pass mlqem_linear_bwd_fused_f32
+_FUSE_NARROW_BWD = os.environ.get("MLQEM_FUSE_NARROW_BWD", "1") != "0"
 
 
 def _branch_streams(device):

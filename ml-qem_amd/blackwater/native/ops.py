@@ -424,6 +424,34 @@ def linear_wgrad(gy, x, gw, gb=None, accumulate=False):
 _pool_ws = {}   # (device, stream, bytes) -> partial-sum workspace of the pooling kernels (per stream, like _wgrad_ws)
 
 
+def linear_bwd_fused(gy, x, w, gb_src=None, gate_scale=None):
+    """(gx, gw, gb) of a narrow hidden layer in one pass (mlqem_linear_bwd_fused_f32): gx = gate(x) * (gy @ w),
+    gw = gy.T @ x, gb = gb_src.sum(0) (gb_src defaults to gy).  All row operands in the padded layout, I, O <= 12."""
+    n, o = gy.shape
+    i = x.shape[1]
+    if tuple(w.shape) != (o, i) or not w.is_contiguous() or x.shape[0] != n or (gb_src is not None and gb_src.shape != gy.shape):
+        raise ValueError("linear_bwd_fused: shape mismatch")
+    gx = padded_empty(n, i, gy.device)
+    gw2 = torch.empty((24, i), dtype=torch.float32, device=gy.device)
+    gb2 = torch.empty(24, dtype=torch.float32, device=gy.device)
+    lib = _lib.load()
+    need = lib.mlqem_linear_wgrad_workspace_bytes(i, 24)
+    ws = _wgrad_workspace(gy.device, need)
+    if not _fused_bwd_ok(gy, x, *([gb_src] if gb_src is not None else [])):
+        raise ValueError("linear_bwd_fused: operands must be 2-D fp32 matrices of <= 12 columns in the padded row layout")
+    ld = lambda t: int(t.stride(0))          # padded rows: the stride is meaningful (and a multiple of 4) for one row too
+    code = lib.mlqem_linear_bwd_fused_f32(_p(gy), ld(gy), _p(gb_src), ld(gb_src) if gb_src is not None else 0, _p(x), ld(x), _p(w),
+                                          0 if gate_scale is None else 1, float(gate_scale or 1.0), _p(gx), ld(gx), _p(gw2),
+                                          _p(gb2), n, i, o, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_linear_bwd_fused_f32")
+    return gx, gw2[:o], gb2[12:12 + o]
+
+
+def _fused_bwd_ok(*mats):
+    return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] <= 12 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+               and t.stride(0) >= (t.shape[1] + 3) // 4 * 4 and t.data_ptr() % 16 == 0 for t in mats)
+
+
 def segment_pool(x, graph_ptr, num_graphs, weights=None, mean=True, wmean=False):
     """(mean, wmean): mean[g] = (1/n_g) sum_{r in g} x[r], wmean[g] = (1/n_g) sum_r weights[r] x[r]; either may be skipped
     (None is returned in its place).  Outputs are [B, C] in the padded row layout."""

@@ -733,6 +733,116 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------- fused backward of a narrow layer
+// One pass for what the backward of a hidden layer of width <= 12 needs from its GEMM: the gated data gradient
+//     gx = (x > 0 ? gate_scale : 0) * (gy W)                      (mask hand-over: x is the previous activation)
+// and the weight / bias gradients
+//     gW = gy^T x,      gb = sum_n gb_src[n, :]                   (gb_src = gy unless the bias sits behind another op)
+// gy, x and gb_src are read ONCE (the separate data-gradient and weight-gradient kernels read gy and x twice: 288 instead
+// of 192 bytes per row on GCN layer 2).  A wave takes 16-row tiles: three contiguous 768-byte loads, parked in its own LDS
+// region; the data gradient is one MFMA tile (W^T as the A operand, as in linear_mfma_v4_kernel), the two gradient tiles
+// ([gy | gb_src]^T against [x | 1]) accumulate over the wave's tiles with K = the rows, as in wgrad_mfma_kernel; partials
+// per workgroup, fixed-order second stage (wgrad_reduce_kernel): deterministic.
+struct BwdFusedArgs {
+  const float* gy; int64_t ldgy; const float* gbs; int64_t ldgbs; const float* x; int64_t ldx; const float* w;
+  float gate_scale; int gate;
+  float* gx; int64_t ldgx; float* partial;
+  int64_t N; int I; int O;
+};
+
+__global__ __launch_bounds__(kBlock) void linear_bwd_fused_kernel(const BwdFusedArgs a) {
+  __shared__ float s_t[4][3][16][12];     // per wave: gy, x, gb_src tiles
+  __shared__ f32x4 s_acc[4][kWave];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int I1 = a.I + 1;
+  float wf[4];                              // A operand of the data gradient: A[m = i][k = o] = W[o][i], o = 4 lq + s
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int o = 4 * lq + s4;
+    wf[s4] = (lr < a.I && o < a.O) ? a.w[(int64_t)o * a.I + lr] : 0.f;
+  }
+  f32x4 acc_w = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tr = lane / 3, tc = (lane - tr * 3) * 4;      // this lane's float4 of a 16 x 12 tile (lanes 0..47)
+  const bool loader = lane < 48;
+  float (*t_gy)[12] = s_t[wid][0];
+  float (*t_x)[12] = s_t[wid][1];
+  float (*t_gb)[12] = s_t[wid][2];
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    const int64_t r0 = t * 16;
+    if (loader) {
+      const int64_t r = r0 + tr;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0;
+      if (r < a.N) {   // 4-column chunks beyond a row's padded width do not exist in memory
+        if (tc < (a.O + 3) / 4 * 4) {
+          v0 = *reinterpret_cast<const float4*>(a.gy + r * a.ldgy + tc);
+          v2 = *reinterpret_cast<const float4*>(a.gbs + r * a.ldgbs + tc);
+        }
+        if (tc < (a.I + 3) / 4 * 4) v1 = *reinterpret_cast<const float4*>(a.x + r * a.ldx + tc);
+      }
+      *reinterpret_cast<float4*>(&t_gy[tr][tc]) = v0;
+      *reinterpret_cast<float4*>(&t_x[tr][tc]) = v1;
+      *reinterpret_cast<float4*>(&t_gb[tr][tc]) = v2;
+    }
+    // data gradient: lane (row lr, quarter lq) feeds gy[lr][4 lq .. + 3] to four k-steps and ends with gx[lr][4 lq .. + 3]
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f), xv = b;
+    if (lq < 3) {
+      b = *reinterpret_cast<const float4*>(&t_gy[lr][4 * lq]);
+      xv = *reinterpret_cast<const float4*>(&t_x[lr][4 * lq]);
+      // pad columns may hold anything: they must not reach the MFMA
+      if (4 * lq + 1 >= a.O) b.y = 0.f;
+      if (4 * lq + 2 >= a.O) b.z = 0.f;
+      if (4 * lq + 3 >= a.O) b.w = 0.f;
+      if (4 * lq >= a.O) b.x = 0.f;
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = mfma16x16x4(wf[0], b.x, acc);
+    acc = mfma16x16x4(wf[1], b.y, acc);
+    acc = mfma16x16x4(wf[2], b.z, acc);
+    acc = mfma16x16x4(wf[3], b.w, acc);
+    if (lq < 3 && 4 * lq < a.I && r0 + lr < a.N) {
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+      if (a.gate) {
+        v[0] = xv.x > 0.f ? v[0] * a.gate_scale : 0.f; v[1] = xv.y > 0.f ? v[1] * a.gate_scale : 0.f;
+        v[2] = xv.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = xv.w > 0.f ? v[3] * a.gate_scale : 0.f;
+      }
+      vstore_nt<4>(a.gx + (r0 + lr) * a.ldgx + 4 * lq, v);
+    }
+    // weight / bias gradients: A[m = o][k = row], B[k = row][n = i]; column I of B is the ones column
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = 4 * u + lq;
+      const bool live = r0 + row < a.N;
+      const float a1 = (lr < a.O) ? t_gy[row][lr < 12 ? lr : 0] : 0.f;
+      const float a2 = (lr < a.O) ? t_gb[row][lr < 12 ? lr : 0] : 0.f;
+      const float bc = lr < a.I ? t_x[row][lr < 12 ? lr : 0] : ((lr == a.I && live) ? 1.f : 0.f);
+      acc_w = mfma16x16x4(a1, bc, acc_w);
+      acc_b = mfma16x16x4(a2, bc, acc_b);
+    }
+  }
+  // partials: [workgroup][(block * 12 + o) * (I + 1) + i], block 0 = gy rows, block 1 = gb_src rows (the layout of
+  // mlqem_linear_wgrad_parts_f32 with two 12-wide blocks)
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * 24 * I1;
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile) {
+    s_acc[wid][lane] = tile == 0 ? acc_w : acc_b;
+    __syncthreads();
+    if (wid == 0) {
+      f32x4 tt = s_acc[0][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) tt += s_acc[w][lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = lq * 4 + r;
+        if (o < 12 && lr < I1) dst[(tile * 12 + o) * I1 + lr] = tt[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // bf16 matrix-core weight gradient (the "bf16 MFMA MLP head" trains on v_mfma_f32_16x16x32_bf16 too): gW = gY^T X with both
 // operands rounded to bf16 in registers, fp32 accumulation, fp32 tensors in memory.  M = outputs, N = inputs (+ the ones
 // column for the bias), K = 32 rows per MFMA: lane l holds rows 8 (l >> 4) .. + 7 of column (l & 15) of each operand tile.
@@ -1153,5 +1263,29 @@ extern "C" int mlqem_linear_wgrad_bf16_f32(const float* gy, int64_t ldgy, const 
   hipLaunchKernelGGL((wgrad_bf16_kernel<2, 2>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 2))), dim3(kBlock), 0, s, a);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial, G, I, O,
                      gw, gb, accumulate);
+  return launch_status();
+}
+
+extern "C" int mlqem_linear_bwd_fused_f32(const float* gy, int64_t ldgy, const float* gb_src, int64_t ldgbs, const float* x,
+                                          int64_t ldx, const float* w, int gate, float gate_scale, float* gx, int64_t ldgx,
+                                          float* gw2, float* gb2, int64_t N, int I, int O, void* workspace,
+                                          size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || I <= 0 || O <= 0 || !gw2 || !gb2) return MLQEM_ERR_BAD_ARG;
+  if (I > 12 || O > 12) return MLQEM_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, 24)) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && (!gy || !x || !w || !gx)) return MLQEM_ERR_BAD_ARG;
+  if (!gb_src) { gb_src = gy; ldgbs = ldgy; }
+  auto rows_ok = [](const float* p, int64_t ld, int cols) { return ld >= (cols + 3) / 4 * 4 && ld % 4 == 0 && aligned_to(p, 16); };
+  if (!rows_ok(gy, ldgy, O) || !rows_ok(gb_src, ldgbs, O) || !rows_ok(x, ldx, I) || !rows_ok(gx, ldgx, I)) return MLQEM_ERR_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), 16);
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks * 2, ceil_div(tiles, 4)));
+  BwdFusedArgs a{gy, ldgy, gb_src, ldgbs, x, ldx, w, gate_scale, gate, gx, ldgx, static_cast<float*>(workspace), N, I, O};
+  // the partial buffer is sized for kWgradBlocks workgroups of 24 x (I + 1) floats: cap the grid accordingly
+  const int Gc = std::min(G, kWgradBlocks);
+  hipLaunchKernelGGL(linear_bwd_fused_kernel, dim3(Gc), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(24 * (I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial, Gc, I, 24,
+                     gw2, gb2, 0);
   return launch_status();
 }

@@ -499,3 +499,32 @@ def test_relu_dropout_add_forward_backward():
         assert torch.equal(again, ops.relu_dropout(x.to(DEV), p, 99)[0])          # same seed: the same mask, bit for bit
         if p > 0 and n * c > 100:
             assert not torch.equal(other, again)
+
+
+@pytest.mark.parametrize("n,i,o", [(1, 10, 10), (15, 10, 10), (16, 12, 12), (1000, 10, 10), (4099, 7, 10), (70000, 10, 3)])
+def test_linear_bwd_fused_equals_separate_kernels(n, i, o):
+    """mlqem_linear_bwd_fused_f32 (gated data gradient + weight gradient + bias gradient in one pass) against fp64 algebra
+    and against the two-kernel path it replaces; padded operands with NaN-poisoned pads."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(n + i)
+    gy, gbs, x = torch.randn(n, o, generator=g), torch.randn(n, o, generator=g), torch.randn(n, i, generator=g)
+    w = torch.randn(o, i, generator=g)
+    gyd, gbd, xd, wd = _padded(gy), _padded(gbs), _padded(x), w.to(DEV)
+    gx, gw, gb = ops.linear_bwd_fused(gyd, xd, wd, gb_src=gbd, gate_scale=1.25)
+    want_gx = torch.where(x.double() > 0, (gy.double() @ w.double()) * 1.25, torch.zeros(n, i, dtype=torch.float64))
+    assert torch.allclose(gx.cpu().double(), want_gx, rtol=1e-5, atol=1e-5)
+    want_gw = gy.double().t() @ x.double()
+    assert (gw.cpu().double() - want_gw).abs().max().item() < 2e-5 * max(want_gw.abs().max().item(), 1.0)
+    want_gb = gbs.double().sum(0)
+    assert (gb.cpu().double() - want_gb).abs().max().item() < 2e-5 * max(want_gb.abs().max().item(), 1.0)
+    # without a gate and with gb_src = gy
+    gx2, _, gb2 = ops.linear_bwd_fused(gyd, xd, wd)
+    assert torch.allclose(gx2.cpu().double(), gy.double() @ w.double(), rtol=1e-5, atol=1e-5)
+    assert (gb2.cpu().double() - gy.double().sum(0)).abs().max().item() < 2e-5 * max(gy.double().sum(0).abs().max().item(), 1.0)
+    # the two-kernel path it replaces gives the same data gradient to fp32 rounding
+    ref_gx = ops.linear(gyd, wd, transposed=True, gate=xd, gate_scale=1.25)
+    assert torch.allclose(ref_gx, gx, rtol=1e-5, atol=1e-6)
+    # deterministic
+    again = ops.linear_bwd_fused(gyd, xd, wd, gb_src=gbd, gate_scale=1.25)
+    assert torch.equal(again[0], gx) and torch.equal(again[1], gw) and torch.equal(again[2], gb)
