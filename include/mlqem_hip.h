@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 8 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 9 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -232,6 +232,24 @@ int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const floa
                                const float* gate, int64_t ldgate, float gate_scale, float* gx, int64_t ldgx,
                                mlqem_stream_t stream);
 
+/* What remains of a branch's last conv once it is folded into its pool: out[b, col[t]] (+)= P_t[b, :] . W_t (+ bias[col]),
+ * t < n_terms (Family A: GCN one term, Cheb and SAGE two each -> three columns), and its backward:
+ * gP_t[b, :] = gout[b, col[t]] * W_t;  gW[t, :] = sum_b gout[b, col[t]] * P_t[b, :];  gb[k] = sum_b gout[b, k].
+ * P_t: [B, C] device matrices (row stride ldp[t]); W_t: [C]; bias[k]: one float on the device or NULL.
+ * gP, ldgp: HOST arrays of n_terms device pointers / row strides. */
+#define MLQEM_HEAD_MAX_TERMS 8
+typedef struct mlqem_head_desc {
+  int32_t n_terms, n_cols;
+  const void* P[MLQEM_HEAD_MAX_TERMS];
+  int64_t ldp[MLQEM_HEAD_MAX_TERMS];
+  const void* W[MLQEM_HEAD_MAX_TERMS];
+  int32_t col[MLQEM_HEAD_MAX_TERMS];
+  const void* bias[MLQEM_HEAD_MAX_TERMS];
+} mlqem_head_desc;
+int mlqem_pooled_head_f32(const mlqem_head_desc* desc, int64_t B, int C, float* out, int64_t ldo, mlqem_stream_t stream);
+int mlqem_pooled_head_bwd_f32(const mlqem_head_desc* desc, const float* gout, int64_t ldg, int64_t B, int C, float* const* gP,
+                              const int64_t* ldgp, float* gW, float* gb, mlqem_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Batch assembly from a device-resident dataset.  Replaces torch_geometric.loader.DataLoader's collate
  * (Batch.from_data_list; call sites docs/tutorials/gnn.py:293-307, docs/tutorials/__ml_models.py:105-119), which
@@ -246,6 +264,9 @@ int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const floa
  * without a strided copy --, src_node[Nb] (arena row of every batch node), both CSR structures (node ids rebased to
  * the batch), loops and, when the arena's ELL side tables a_in_ell / a_out_ell (mlqem_ell_from_csr over the arena)
  * are given, the batch's side tables in_ell_b / out_ell_b [Nb,2] rebased the same way (NULL = not wanted).
+ * derived_b (may be NULL; needs K >= 3 with nscal = [gcn_dinv, sage_rinv, cheb_dinv, ...] and a_loops): planar [3, Nb] =
+ * gcn_dinv^2 (the (i,i) weight of the GCN operator), loops * sage_rinv (the self share of SAGE's mean), -cheb_dinv -- the
+ * per-node scalars the layers derive, written in the same pass instead of by three element-wise kernels per batch.
  * Fixed-shape launches (hipGraph replay over size buckets): Nb must equal b_nptr[B], but Eb may be a CAPACITY >= b_eptr[B];
  * the kernels take the real edge total from b_eptr[B] on the device, so one captured launch serves every selection whose
  * totals fit the bucket (the caller pads the node count with a slice of an edgeless filler graph of the arena).
@@ -255,7 +276,7 @@ int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal,
                          const int32_t* a_out_dst, const int32_t* a_out_eid, const int32_t* a_loops,
                          const int32_t* a_in_ell, const int32_t* a_out_ell, const int32_t* sel, const int32_t* b_nptr,
                          const int32_t* b_eptr, int64_t B, int64_t Nb, int64_t Eb, float* xb, int64_t ldxb,
-                         float* nscal_b, int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b,
+                         float* nscal_b, float* derived_b, int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b,
                          int32_t* out_dst_b, int32_t* out_eid_b, int32_t* loops_b, int32_t* in_ell_b, int32_t* out_ell_b,
                          mlqem_stream_t stream);
 

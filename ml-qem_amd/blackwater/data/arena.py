@@ -235,6 +235,7 @@ class GraphArena:
         f4 = (f + 3) // 4 * 4
         k = int(self.nscal.shape[1])
         nscal_b = torch.empty((k, max(nb, 1)), dtype=torch.float32, device=dev)   # planar: one contiguous vector per scalar
+        derived_b = torch.empty((3, max(nb, 1)), dtype=torch.float32, device=dev)
         mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         in_ptr, out_ptr, loops, src_node = mk(nb + 1), mk(nb + 1), mk(nb), mk(nb)
         in_src, out_dst, out_eid = mk(eb), mk(eb), mk(eb)
@@ -244,13 +245,14 @@ class GraphArena:
         code = _lib.load().mlqem_batch_assemble(
             p(self.x), self.x.stride(0), f4, p(self.nscal), k, p(self.gptr), p(self.in_ptr), p(self.in_src),
             p(self.out_ptr), p(self.out_dst), p(self.out_eid), p(self.loops), p(self.in_ell), p(self.out_ell), p(sel_d),
-            p(nptr_d), p(eptr_d), b, nb, eb, None, 0, p(nscal_b), p(src_node), p(in_ptr), p(in_src),
+            p(nptr_d), p(eptr_d), b, nb, eb, None, 0, p(nscal_b), p(derived_b), p(src_node), p(in_ptr), p(in_src),
             p(out_ptr), p(out_dst), p(out_eid), p(loops), p(in_ell), p(out_ell), ops._stream())
         _lib.check(code, "mlqem_batch_assemble")
         norms = (nscal_b[0, :nb], nscal_b[1, :nb], nscal_b[2, :nb])
         s = GraphStructure(nb, in_ptr, in_src, out_ptr, out_dst, loops, nptr_d, b, num_edges=eb, norms=norms,
                            graph_sizes=graph_sizes, out_eid=out_eid, ell=(in_ell, out_ell),
-                           colsums=(nscal_b[3, :nb], nscal_b[4, :nb], nscal_b[5, :nb]))
+                           colsums=(nscal_b[3, :nb], nscal_b[4, :nb], nscal_b[5, :nb]),
+                           derived={"gcn_dself": derived_b[0, :nb], "sage_dself": derived_b[1, :nb], "cheb_neg": derived_b[2, :nb]})
         idx = sel_d.to(torch.int64)
         nodes = ops.RowsOf(self.x, src_node[:nb])     # the feature rows stay in the arena
         return DeviceBatch(nodes, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel_host, num_real)

@@ -24,6 +24,17 @@ _P, _I, _L, _F, _S, _U = c_void_p, c_int, c_int64, c_float, c_size_t, c_uint64
 MAX_COL_PARTS = 8   # MLQEM_MAX_COL_PARTS
 
 
+MAX_HEAD_TERMS = 8   # MLQEM_HEAD_MAX_TERMS
+
+
+class HeadDesc(ctypes.Structure):
+    """``mlqem_head_desc``: the terms P_t . W_t of a pooled head and the output column each adds to."""
+
+    _fields_ = [("n_terms", ctypes.c_int32), ("n_cols", ctypes.c_int32), ("P", c_void_p * MAX_HEAD_TERMS),
+                ("ldp", c_int64 * MAX_HEAD_TERMS), ("W", c_void_p * MAX_HEAD_TERMS), ("col", ctypes.c_int32 * MAX_HEAD_TERMS),
+                ("bias", c_void_p * MAX_HEAD_TERMS)]
+
+
 class ColParts(ctypes.Structure):
     """``mlqem_col_parts``: a matrix given as up to four column blocks in separate buffers."""
 
@@ -39,7 +50,7 @@ SIGNATURES = {
     "mlqem_csr_build": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "mlqem_graph_norms": (_I, [_P, _P, _P, _L, _P, _P, _P, _P]),
     "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
-                                  _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                  _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _P, _L, _L, _I, _P]),
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
@@ -53,6 +64,8 @@ SIGNATURES = {
     "mlqem_linear_wgrad_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P, _P]),
     "mlqem_linear_wgrad_parts_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P, _P]),
     "mlqem_linear_bwd_fused_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _F, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
+    "mlqem_pooled_head_f32": (_I, [_P, _L, _I, _P, _L, _P]),
+    "mlqem_pooled_head_bwd_f32": (_I, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _P]),
     "mlqem_segment_pool_workspace_bytes": (_S, [_L, _L, _I]),
     "mlqem_segment_pool_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P, _L, _P, _L, _P, _S, _P]),
     "mlqem_segment_pool_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _L, _F, _P, _L, _P]),
@@ -87,7 +100,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 9   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

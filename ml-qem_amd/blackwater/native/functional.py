@@ -635,41 +635,43 @@ class _FamilyAGraph(Function):
         L["g1"] = mk(9, Fa); h = _GCNLayer.forward(L["g1"], x, g1w, g1b, struct, T, p1, seed + 1, T, None, pre=pre_g)
         L["g2"] = mk(9, T); hg = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1)
         _, wg = ops.segment_pool(hg, gptr, nb, weights=tg, mean=False, wmean=True)
-        pg = torch.addmm(g3b, wg, g3w.t())
         with torch.cuda.stream(side[0]):
             # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
             L["c1"] = mk(11, Fa); hc = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2,
                                                           pre=pre_c)
             mc, wc = ops.segment_pool(hc, gptr, nb, weights=tc, mean=True, wmean=True)
-            pc = torch.addmm(c2b, mc, c2w0.t()).addmm_(wc, c2w1.t())
         with torch.cuda.stream(side[1]):
             # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
             L["s1"] = mk(10, Fa); hs = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None, pre=pre_s)
             ms, ws = ops.segment_pool(hs, gptr, nb, weights=ts, mean=True, wmean=True)
-            ps = torch.addmm(s2b, ws, s2l.t()).addmm_(ms, s2r.t())
-        for st, t in zip(side, (pc, ps)):
+        for st, ts_ in zip(side, ((mc, wc), (ms, ws))):
             main.wait_stream(st)
-            t.record_stream(main)
+            for t in ts_:
+                t.record_stream(main)
         if fuse:
             for t in blocks[1:]:          # made on the compute stream, consumed by the side streams
                 t.record_stream(side[0] if t is not blocks[4] and t is not blocks[5] else side[1])
-        ctx.tail = (struct, k1, k2, (hg, wg, g3w), (hc, mc, wc, c2w0, c2w1), (hs, ms, ws, s2l, s2r))
-        return torch.cat((pg, pc, ps), dim=1)
+        # the three folded last convs: [wmean_g . W3 + b3 | mean_c . W0 + wmean_c . W1 + b | wmean_s . Wl + bl + mean_s . Wr]
+        ctx.head = ([(wg, g3w, 0), (mc, c2w0, 1), (wc, c2w1, 1), (ws, s2l, 2), (ms, s2r, 2)], [g3b, c2b, s2b])
+        out = ops.pooled_head(*ctx.head)
+        ctx.tail = (struct, k1, k2, hg, hc, hs)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         L = ctx.layers
-        struct, k1, k2, (hg, wg, g3w), (hc, mc, wc, c2w0, c2w1), (hs, ms, ws, s2l, s2r) = ctx.tail
+        struct, k1, k2, hg, hc, hs = ctx.tail
         gptr, n = struct.graph_ptr, struct.num_nodes
-        g = g.contiguous()
-        gg, gc, gs = g[:, 0:1], g[:, 1:2], g[:, 2:3]
         main = torch.cuda.current_stream(g.device)
         side = ctx.side
+        # the folded last convs first, on the compute stream: gradients of the five pooled matrices, five weight rows, three biases
+        (ggw, gcm, gcw, gsw, gsm), gw5, gb3 = ops.pooled_head_bwd(ctx.head[0], ctx.head[1], g)
+        g3wg, c2w0g, c2w1g, s2lg, s2rg = gw5[0:1], gw5[1:2], gw5[2:3], gw5[3:4], gw5[4:5]
+        g3bg, c2bg, s2bg = gb3[0:1], gb3[1:2], gb3[2:3]
         for st in side:
             st.wait_stream(main)
         # GCN branch, last layer first: pooled = wmean(h) W^T + b
-        g3wg, g3bg = gg.t().mm(wg), gg.sum(0)
-        t = ops.segment_pool_bwd(None, gg.mm(g3w), gptr, n, weights=struct.colsum("gcn"), gate=hg, gate_scale=k1)
+        t = ops.segment_pool_bwd(None, ggw, gptr, n, weights=struct.colsum("gcn"), gate=hg, gate_scale=k1)
         t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
         fuse = ctx.fuse
         if fuse:
@@ -677,16 +679,14 @@ class _FamilyAGraph(Function):
         else:
             _, g1w, g1b = _GCNLayer.backward(L["g1"], t)[:3]
         with torch.cuda.stream(side[0]):
-            c2w0g, c2w1g, c2bg = gc.t().mm(mc), gc.t().mm(wc), gc.sum(0)
-            t = ops.segment_pool_bwd(gc.mm(c2w0), gc.mm(c2w1), gptr, n, weights=struct.colsum("cheb"), gate=hc, gate_scale=k2)
+            t = ops.segment_pool_bwd(gcm, gcw, gptr, n, weights=struct.colsum("cheb"), gate=hc, gate_scale=k2)
             if fuse:
                 bc = _ChebLayer.backward(L["c1"], t, blocks_only=True)       # [g, g_b1, g_c2]
             else:
                 r = _ChebLayer.backward(L["c1"], t)
                 c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
         with torch.cuda.stream(side[1]):
-            s2lg, s2bg, s2rg = gs.t().mm(ws), gs.sum(0), gs.t().mm(ms)
-            t = ops.segment_pool_bwd(gs.mm(s2r), gs.mm(s2l), gptr, n, weights=struct.colsum("sage"), gate=hs, gate_scale=k2)
+            t = ops.segment_pool_bwd(gsm, gsw, gptr, n, weights=struct.colsum("sage"), gate=hs, gate_scale=k2)
             if fuse:
                 bs = _SAGELayer.backward(L["s1"], t, blocks_only=True)       # [g_p, g]
             else:
@@ -708,7 +708,9 @@ class _FamilyAGraph(Function):
             g1w, g1b = gw7[0], gb7[ow:ow + o]
             c1w0, c1w1, c1w2, c1b = gw7[2], gw7[3], gw7[4] - gw7[2], gb7[2 * ow:2 * ow + o]
             s1l, s1r, s1b = gw7[5], gw7[6], gb7[6 * ow:6 * ow + o]
-        for t in (c2bg, c2w0g, c2w1g, s2lg, s2bg, s2rg) + (() if fuse else (c1b, c1w0, c1w1, c1w2, s1l, s1b, s1r)):
+        for t in (gcm, gcw, gsm, gsw):        # made on the compute stream, consumed by the side streams
+            t.record_stream(side[0] if t is gcm or t is gcw else side[1])
+        for t in (() if fuse else (c1b, c1w0, c1w1, c1w2, s1l, s1b, s1r)):
             t.record_stream(main)
         return (None, None, None, None, None, g1w, g1b, g2w, g2b, g3wg, g3bg, c1w0, c1w1, c1w2, c1b, c2w0g, c2w1g, c2bg,
                 s1l, s1b, s1r, s2lg, s2bg, s2rg)

@@ -452,6 +452,56 @@ def _fused_bwd_ok(*mats):
                and t.stride(0) >= (t.shape[1] + 3) // 4 * 4 and t.data_ptr() % 16 == 0 for t in mats)
 
 
+def _head_desc(terms, biases):
+    """terms: [(P [B, C], w [C] or [1, C], column)], biases: per output column a 1-element tensor or None."""
+    import ctypes as _ct
+
+    d = _lib.HeadDesc()
+    d.n_terms, d.n_cols = len(terms), len(biases)
+    if not 1 <= d.n_terms <= _lib.MAX_HEAD_TERMS or not 1 <= d.n_cols <= _lib.MAX_HEAD_TERMS:
+        raise ValueError("pooled head: 1..8 terms and columns")
+    b, c = terms[0][0].shape
+    for t, (pm, w, col) in enumerate(terms):
+        if tuple(pm.shape) != (b, c) or w.numel() != c or not w.is_contiguous() or not w.is_cuda or w.dtype != torch.float32:
+            raise ValueError("pooled head: every term needs P [B, C] and a contiguous fp32 cuda W of C entries")
+        _mat(pm, f"P[{t}]")
+        d.P[t], d.ldp[t], d.W[t], d.col[t] = pm.data_ptr(), (int(pm.stride(0)) if b > 1 else max(c, 1)), w.data_ptr(), int(col)
+    for k, bias in enumerate(biases):
+        d.bias[k] = None if bias is None else bias.data_ptr()
+    return d, b, c
+
+
+def pooled_head(terms, biases):
+    """out[b, col] = bias[col] + sum over the terms of that column of P_t[b, :] . w_t  -> [B, n_cols] (one launch)."""
+    import ctypes as _ct
+
+    d, b, c = _head_desc(terms, biases)
+    out = torch.empty((b, d.n_cols), dtype=torch.float32, device=terms[0][0].device)
+    code = _lib.load().mlqem_pooled_head_f32(_ct.addressof(d), b, c, _p(out), d.n_cols, _stream())
+    _lib.check(code, "mlqem_pooled_head_f32")
+    return out
+
+
+def pooled_head_bwd(terms, biases, gout):
+    """([gP_t [B, C] padded], gW [n_terms, C], gb [n_cols]) for ``pooled_head`` (two launches)."""
+    import ctypes as _ct
+
+    d, b, c = _head_desc(terms, biases)
+    gout = rowmajor(gout)
+    if tuple(gout.shape) != (b, d.n_cols):
+        raise ValueError("pooled_head_bwd: gout must be [B, n_cols]")
+    dev = gout.device
+    gps = [padded_empty(b, c, dev) for _ in terms]
+    gw = torch.empty((len(terms), c), dtype=torch.float32, device=dev)
+    gb = torch.empty(d.n_cols, dtype=torch.float32, device=dev)
+    ptrs = (_ct.c_void_p * _lib.MAX_HEAD_TERMS)(*[g.data_ptr() for g in gps])
+    lds = (_ct.c_int64 * _lib.MAX_HEAD_TERMS)(*[(int(g.stride(0)) if b > 1 else (c + 3) // 4 * 4) for g in gps])
+    code = _lib.load().mlqem_pooled_head_bwd_f32(_ct.addressof(d), _p(gout), _mat(gout, "gout"), b, c, ptrs, lds, _p(gw), _p(gb),
+                                                 _stream())
+    _lib.check(code, "mlqem_pooled_head_bwd_f32")
+    return gps, gw, gb
+
+
 def segment_pool(x, graph_ptr, num_graphs, weights=None, mean=True, wmean=False):
     """(mean, wmean): mean[g] = (1/n_g) sum_{r in g} x[r], wmean[g] = (1/n_g) sum_r weights[r] x[r]; either may be skipped
     (None is returned in its place).  Outputs are [B, C] in the padded row layout."""

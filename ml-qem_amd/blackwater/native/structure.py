@@ -14,14 +14,14 @@ from . import ops
 
 class GraphStructure:
     def __init__(self, num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs, num_edges=None,
-                 norms=None, graph_sizes=None, out_eid=None, ell=None, colsums=None):
+                 norms=None, graph_sizes=None, out_eid=None, ell=None, colsums=None, derived=None):
         self.num_nodes = int(num_nodes)
         self.in_ptr, self.in_src, self.out_ptr, self.out_dst, self.loops = in_ptr, in_src, out_ptr, out_dst, loops
         self.graph_ptr, self.num_graphs = graph_ptr, int(num_graphs)
         self.num_edges = num_edges  # non-self-loop edges, host int when known without a sync
         self.out_eid = out_eid      # in-CSR position of every out-CSR entry (edge-softmax backward)
         self._norms = norms
-        self._derived = {}
+        self._derived = {} if derived is None else dict(derived)
         self._colsum = {} if colsums is None else dict(zip(("gcn", "sage", "cheb"), colsums))
         self._ell = {} if ell is None else {"in": ell[0], "out": ell[1]}   # side tables, built on demand otherwise
         self._graph_sizes = None if graph_sizes is None else [int(v) for v in graph_sizes]

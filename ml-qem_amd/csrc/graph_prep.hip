@@ -104,6 +104,7 @@ struct AssembleArgs {
   const int32_t* sel; const int32_t* b_nptr; const int32_t* b_eptr;
   int B; int64_t Nb; int64_t Eb;
   float* xb; int64_t ldxb; float* nscal_b;
+  float* derived_b;   // optional planar [3, Nb]: gcn_dinv^2, loops * sage_rinv, -cheb_dinv (needs K >= 3 and loops)
   int32_t* src_node;   // [Nb] arena row of every batch node (written by the nodes kernel, read by the rows kernel)
   int32_t* in_ptr_b; int32_t* in_src_b; int32_t* out_ptr_b; int32_t* out_dst_b; int32_t* out_eid_b; int32_t* loops_b;
   const int32_t* a_in_ell; const int32_t* a_out_ell;   // optional [N,2] side tables of the arena (global ids)
@@ -174,6 +175,12 @@ __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleAr
   if (a.loops_b) a.loops_b[i] = a.a_loops[gn];
   if (!a.xb)   // no feature rows to move: the per-node scalars ride along here instead of in a pass of their own
     for (int k = 0; k < a.K; ++k) a.nscal_b[(int64_t)k * a.Nb + i] = a.nscal[gn * a.K + k];   // planar [K, Nb]
+  if (a.derived_b) {   // the layers' derived per-node scalars, made here instead of by three element-wise passes per batch
+    const float s0 = a.nscal[gn * a.K], s1 = a.nscal[gn * a.K + 1], s2 = a.nscal[gn * a.K + 2];
+    a.derived_b[i] = s0 * s0;
+    a.derived_b[a.Nb + i] = (float)a.a_loops[gn] * s1;
+    a.derived_b[2 * a.Nb + i] = -s2;
+  }
   // ELL side tables: the arena's entries rebased to batch ids (-1 = no edge, bit 31 of .x = more than two edges)
   const int32_t shift = a.b_nptr[b] - g0;
   auto rebase = [&](int2 e) {
@@ -267,7 +274,7 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
                                     const int32_t* a_out_ptr, const int32_t* a_out_dst, const int32_t* a_out_eid,
                                     const int32_t* a_loops, const int32_t* a_in_ell, const int32_t* a_out_ell,
                                     const int32_t* sel, const int32_t* b_nptr, const int32_t* b_eptr, int64_t B,
-                                    int64_t Nb, int64_t Eb, float* xb, int64_t ldxb, float* nscal_b,
+                                    int64_t Nb, int64_t Eb, float* xb, int64_t ldxb, float* nscal_b, float* derived_b,
                                     int32_t* src_node, int32_t* in_ptr_b, int32_t* in_src_b, int32_t* out_ptr_b, int32_t* out_dst_b,
                                     int32_t* out_eid_b, int32_t* loops_b, int32_t* in_ell_b, int32_t* out_ell_b,
                                     mlqem_stream_t stream_) {
@@ -278,12 +285,13 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
   if (!x || !a_gptr || !a_in_ptr || !a_out_ptr || !sel || !b_nptr || !b_eptr || !src_node || !in_ptr_b || !out_ptr_b)
     return MLQEM_ERR_BAD_ARG;
   if (K > 0 && (!nscal || !nscal_b)) return MLQEM_ERR_BAD_ARG;
+  if (derived_b && (K < 3 || !a_loops)) return MLQEM_ERR_BAD_ARG;
   if (Eb > 0 && (!a_in_src || !a_out_dst || !in_src_b || !out_dst_b)) return MLQEM_ERR_BAD_ARG;
   if (loops_b && !a_loops) return MLQEM_ERR_BAD_ARG;
   if (out_eid_b && !a_out_eid) return MLQEM_ERR_BAD_ARG;
   if ((in_ell_b && !a_in_ell) || (out_ell_b && !a_out_ell)) return MLQEM_ERR_BAD_ARG;
   AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_out_eid, a_loops, sel, b_nptr, b_eptr,
-                 (int)B, Nb, Eb, xb, ldxb, nscal_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, out_eid_b, loops_b,
+                 (int)B, Nb, Eb, xb, ldxb, nscal_b, derived_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, out_eid_b, loops_b,
                  a_in_ell, a_out_ell, in_ell_b, out_ell_b};
   hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
   if (Nb > 0) {

@@ -185,6 +185,75 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------- pooled head
+// out[b, col(t)] += P_t[b, :] . w_t  (+ bias_col): the [B, C] x [C] products that remain of a branch's last conv once it
+// has been folded into its pool (three branches, five terms in Family A).  As torch ops these are fifteen tiny launches
+// per step (rocBLAS picks a 28 us kernel for a [1, B] x [B, 10] product); here the forward is one launch and the
+// backward two: gP_t[b, :] = gout[b, col(t)] w_t, then gw_t = sum_b gout[b, col(t)] P_t[b, :] and gb_k = sum_b gout[b, k]
+// by one workgroup per term / column with a fixed-order tree.
+struct HeadArgs {
+  int n_terms, n_cols, C;
+  const float* P[MLQEM_HEAD_MAX_TERMS]; int64_t ldp[MLQEM_HEAD_MAX_TERMS];
+  const float* W[MLQEM_HEAD_MAX_TERMS]; int col[MLQEM_HEAD_MAX_TERMS];
+  const float* bias[MLQEM_HEAD_MAX_TERMS];   // per output column (may be NULL)
+  int64_t B;
+};
+
+__global__ __launch_bounds__(kBlock) void pooled_head_kernel(const HeadArgs a, float* __restrict__ out, int64_t ldo) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.B * a.n_cols) return;
+  const int64_t b = t / a.n_cols;
+  const int k = (int)(t - b * a.n_cols);
+  float acc = a.bias[k] ? a.bias[k][0] : 0.f;
+  for (int term = 0; term < a.n_terms; ++term) {
+    if (a.col[term] != k) continue;
+    const float* __restrict__ p = a.P[term] + b * a.ldp[term];
+    float s = 0.f;
+    for (int c = 0; c < a.C; ++c) s = fmaf(p[c], a.W[term][c], s);
+    acc += s;
+  }
+  out[b * ldo + k] = acc;
+}
+
+struct HeadGradRows { float* gP[MLQEM_HEAD_MAX_TERMS]; int64_t ld[MLQEM_HEAD_MAX_TERMS]; };
+
+__global__ __launch_bounds__(kBlock) void pooled_head_bwd_rows_kernel(const HeadArgs a, const float* __restrict__ gout, int64_t ldg,
+                                                                      const HeadGradRows o) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t per = a.B * a.C;
+  if (t >= per * a.n_terms) return;
+  const int term = (int)(t / per);
+  const int64_t r = t - (int64_t)term * per;
+  const int64_t b = r / a.C;
+  const int c = (int)(r - b * a.C);
+  o.gP[term][b * o.ld[term] + c] = gout[b * ldg + a.col[term]] * a.W[term][c];
+}
+
+// blockIdx.x < n_terms: gw of that term; otherwise gb of column blockIdx.x - n_terms
+__global__ __launch_bounds__(kBlock) void pooled_head_bwd_sums_kernel(const HeadArgs a, const float* __restrict__ gout, int64_t ldg,
+                                                                      float* __restrict__ gW, float* __restrict__ gb) {
+  __shared__ float s_red[kBlock];
+  const int tid = threadIdx.x;
+  const bool is_w = (int)blockIdx.x < a.n_terms;
+  const int term = is_w ? blockIdx.x : 0, k = is_w ? a.col[term] : (int)blockIdx.x - a.n_terms;
+  const int n_out = is_w ? a.C : 1;
+  for (int c = 0; c < n_out; ++c) {
+    float s = 0.f;
+    for (int64_t b = tid; b < a.B; b += kBlock) {
+      const float g = gout[b * ldg + k];
+      s += is_w ? g * a.P[term][b * a.ldp[term] + c] : g;
+    }
+    s_red[tid] = s;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {       // fixed tree: deterministic
+      if (tid < off) s_red[tid] += s_red[tid + off];
+      __syncthreads();
+    }
+    if (tid == 0) { if (is_w) gW[term * a.C + c] = s_red[0]; else gb[k] = s_red[0]; }
+    __syncthreads();
+  }
+}
+
 }  // namespace mlqem
 
 using namespace mlqem;
@@ -243,5 +312,48 @@ extern "C" int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean,
   if (wide) { if (gate) MLQEM_POOL_BWD(4, true); else MLQEM_POOL_BWD(4, false); }
   else { if (gate) MLQEM_POOL_BWD(1, true); else MLQEM_POOL_BWD(1, false); }
 #undef MLQEM_POOL_BWD
+  return launch_status();
+}
+
+static int head_args(const mlqem_head_desc* d, int64_t B, int C, HeadArgs& a) {
+  if (!d || B < 0 || C <= 0 || d->n_terms < 1 || d->n_terms > MLQEM_HEAD_MAX_TERMS || d->n_cols < 1 || d->n_cols > MLQEM_HEAD_MAX_TERMS)
+    return MLQEM_ERR_BAD_ARG;
+  a.n_terms = d->n_terms; a.n_cols = d->n_cols; a.C = C; a.B = B;
+  for (int t = 0; t < d->n_terms; ++t) {
+    if (!d->P[t] || !d->W[t] || d->ldp[t] < C || d->col[t] < 0 || d->col[t] >= d->n_cols) return MLQEM_ERR_BAD_ARG;
+    a.P[t] = static_cast<const float*>(d->P[t]); a.ldp[t] = d->ldp[t]; a.W[t] = static_cast<const float*>(d->W[t]); a.col[t] = d->col[t];
+  }
+  for (int k = 0; k < MLQEM_HEAD_MAX_TERMS; ++k) a.bias[k] = k < d->n_cols ? static_cast<const float*>(d->bias[k]) : nullptr;
+  return MLQEM_OK;
+}
+
+extern "C" int mlqem_pooled_head_f32(const mlqem_head_desc* desc, int64_t B, int C, float* out, int64_t ldo, mlqem_stream_t stream) {
+  begin_launches();
+  HeadArgs a{};
+  const int rc = head_args(desc, B, C, a);
+  if (rc != MLQEM_OK) return rc;
+  if (B == 0) return MLQEM_OK;
+  if (!out || ldo < a.n_cols) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pooled_head_kernel, dim3((unsigned)ceil_div(B * a.n_cols, kBlock)), dim3(kBlock), 0, as_stream(stream), a, out, ldo);
+  return launch_status();
+}
+
+extern "C" int mlqem_pooled_head_bwd_f32(const mlqem_head_desc* desc, const float* gout, int64_t ldg, int64_t B, int C,
+                                         float* const* gP, const int64_t* ldgp, float* gW, float* gb, mlqem_stream_t stream) {
+  begin_launches();
+  HeadArgs a{};
+  const int rc = head_args(desc, B, C, a);
+  if (rc != MLQEM_OK) return rc;
+  if (!gout || ldg < a.n_cols || !gP || !ldgp || !gW || !gb) return MLQEM_ERR_BAD_ARG;
+  HeadGradRows o{};
+  for (int t = 0; t < a.n_terms; ++t) {
+    if (!gP[t] || ldgp[t] < C) return MLQEM_ERR_BAD_ARG;
+    o.gP[t] = gP[t]; o.ld[t] = ldgp[t];
+  }
+  hipStream_t s = as_stream(stream);
+  if (B > 0)
+    hipLaunchKernelGGL(pooled_head_bwd_rows_kernel, dim3((unsigned)ceil_div(B * C * a.n_terms, kBlock)), dim3(kBlock), 0, s, a, gout, ldg,
+                       o);
+  hipLaunchKernelGGL(pooled_head_bwd_sums_kernel, dim3((unsigned)(a.n_terms + a.n_cols)), dim3(kBlock), 0, s, a, gout, ldg, gW, gb);
   return launch_status();
 }

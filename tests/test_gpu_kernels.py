@@ -528,3 +528,34 @@ def test_linear_bwd_fused_equals_separate_kernels(n, i, o):
     # deterministic
     again = ops.linear_bwd_fused(gyd, xd, wd, gb_src=gbd, gate_scale=1.25)
     assert torch.equal(again[0], gx) and torch.equal(again[1], gw) and torch.equal(again[2], gb)
+
+
+def test_pooled_head_forward_backward():
+    """mlqem_pooled_head_f32 / _bwd: the [B, C] x [C] products left of the folded last convs, against torch autograd."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(5)
+    for b, c in ((1, 10), (37, 10), (1024, 10), (300, 3)):
+        ps = [torch.randn(b, c, generator=g) for _ in range(5)]
+        ws = [torch.randn(1, c, generator=g) for _ in range(5)]
+        bias = [torch.randn(1, generator=g) for _ in range(3)]
+        cols = [0, 1, 1, 2, 2]
+        pd = [_padded(p) for p in ps]
+        wd = [w.to(DEV) for w in ws]
+        bd = [x.to(DEV) for x in bias]
+        out = ops.pooled_head([(p, w, k) for p, w, k in zip(pd, wd, cols)], bd)
+        pr = [p.double().requires_grad_(True) for p in ps]
+        wr = [w.double().requires_grad_(True) for w in ws]
+        br = [x.double().requires_grad_(True) for x in bias]
+        want = torch.stack([sum((pr[t] @ wr[t].t())[:, 0] for t in range(5) if cols[t] == k) + br[k] for k in range(3)], dim=1)
+        assert out.shape == (b, 3) and torch.allclose(out.cpu().double(), want.detach(), rtol=1e-5, atol=1e-5)
+        go = torch.randn(b, 3, generator=g)
+        want.backward(go.double())
+        gps, gw, gb = ops.pooled_head_bwd([(p, w, k) for p, w, k in zip(pd, wd, cols)], bd, go.to(DEV))
+        for t in range(5):
+            assert torch.allclose(gps[t].cpu().double(), pr[t].grad, rtol=1e-5, atol=1e-6)
+            assert (gw[t].cpu().double() - wr[t].grad[0]).abs().max().item() < 2e-5 * max(wr[t].grad.abs().max().item(), 1.0)
+        for k in range(3):
+            assert abs(gb[k].item() - br[k].grad.item()) < 2e-5 * max(abs(br[k].grad.item()), 1.0)
+        again = ops.pooled_head_bwd([(p, w, k) for p, w, k in zip(pd, wd, cols)], bd, go.to(DEV))
+        assert torch.equal(again[1], gw) and torch.equal(again[2], gb)
