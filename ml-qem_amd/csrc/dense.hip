@@ -525,10 +525,16 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
       if (xlive[g] < 4) av[g].w = 0.f;
       if (xlive[g] < 1) av[g].x = 0.f;
     }
+    // every global LOAD of the tile is issued here, before its first store: vmcnt counts loads and stores in one in-order
+    // queue on gfx9, so a load behind a store can only be waited for by draining that store -- a row-scale load inside the
+    // block loop cost one write round trip per block (1307 vs 846 us on the six-block first layer)
+    float rsv[kMaxParts];
+#pragma unroll
+    for (int blk = 0; blk < kMaxParts; ++blk) rsv[blk] = (blk < a.yn && a.rsk[blk] && row_ok) ? a.rsk[blk][row] : 1.f;
 #pragma unroll
     for (int blk = 0; blk < kMaxParts; ++blk) {
       if (blk >= a.yn) break;
-      const float rs = (a.rsk[blk] && row_ok) ? a.rsk[blk][row] : 1.f;
+      const float rs = rsv[blk];
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[r] + s_b[blk][4 * lq + r];
-        if (a.rsk[blk]) v[r] *= rs;
+        v[r] *= rs;                        // 1.0f where the block has no row scale: exact
       }
       if (a.plain_stores) vstore<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
       else vstore_nt<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
@@ -726,6 +732,121 @@ __global__ __launch_bounds__(kBlock) void wgrad_mfma_kernel(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = (ob0 + ob) * 16 + lq * 4 + r;
+          if (o < a.O && i < I1) dst[o * I1 + i] = t[r];
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// The same product for the WIDE tile shapes (the seven first-layer gradient blocks against x in one pass), rebuilt around
+// what bounds it.  48 fp32 MFMAs per 16 rows are 0.44 ms of matrix-pipe time against 0.83 ms of memory time for this
+// launch (scripts/micro/mix_roofline.hip: the same loads without arithmetic), so the two have to overlap; with 250
+// registers the kernel above runs two waves per SIMD and they do not (1.19 ms).  Here:
+//   * KU k-steps per iteration, the loads of DEPTH later iterations in flight while one multiplies -- register sets are
+//     [KU][OBT + IBT] floats, all blocks share one leading dimension (a scalar), 32-bit row offsets;
+//   * vmcnt is ONE in-order counter for loads and stores on gfx9: waiting for a load waits for everything issued before
+//     it.  A row-map entry fetched after iteration j's operand loads and needed at the top of iteration j + 1 would drain
+//     those loads and flatten the pipeline, so the map entries of iteration j + 2*DEPTH - 1 are fetched at the top of
+//     iteration j, in front of its operand loads;
+//   * three to four waves per SIMD (about 160 registers).
+template <int OBT, int IBT, int KU, int DEPTH>
+__global__ __launch_bounds__(kBlock) void wgrad_pipe_kernel(const WgradArgs a) {
+  __shared__ f32x4 s_acc[4][kWave];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int I1 = a.I + 1;
+  const int64_t n_waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + wid;
+  constexpr int kRows = 4 * KU;
+  const int64_t n_iters = ceil_div(a.N, (int64_t)kRows);
+  const int64_t ldg = a.ldgy[0];
+
+  f32x4 acc[OBT][IBT];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* gcol[OBT];
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob) {
+    const int o = ob * 16 + lr;
+    const int part = o / a.gw, lc = o - part * a.gw;
+    gcol[ob] = (o < a.O && part < a.gn && lc < a.gc) ? a.gyp[part] + lc : nullptr;
+  }
+  const float* xcol[IBT]; float xfill[IBT];
+#pragma unroll
+  for (int ib = 0; ib < IBT; ++ib) {
+    const int i = ib * 16 + lr;
+    xcol[ib] = i < a.I ? a.x + i : nullptr;
+    xfill[ib] = i == a.I ? 1.f : 0.f;            // column I: ones -> the bias gradient
+  }
+
+  constexpr int kMapSets = 2 * DEPTH;            // map entries of iterations it .. it + 2*DEPTH - 1, oldest first
+  int xm[kMapSets][KU];
+  auto fetch_map = [&](int64_t it, int (&m)[KU]) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int64_t n = it * kRows + u * 4 + lq;
+      m[u] = (a.xrows && n < a.N) ? a.xrows[n] : 0;
+    }
+  };
+  float A[DEPTH + 1][KU][OBT], B[DEPTH + 1][KU][IBT];
+  auto issue = [&](int64_t it, const int (&m)[KU], float (&ga)[KU][OBT], float (&xb)[KU][IBT]) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int64_t n = it * kRows + u * 4 + lq;
+      const bool ok = n < a.N;
+      const int64_t xn = a.xrows ? (int64_t)m[u] : n;
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob) ga[u][ob] = (ok && gcol[ob]) ? gcol[ob][n * ldg] : 0.f;
+#pragma unroll
+      for (int ib = 0; ib < IBT; ++ib) xb[u][ib] = ok ? (xcol[ib] ? xcol[ib][xn * a.ldx] : xfill[ib]) : 0.f;
+    }
+  };
+  // prologue: map entries of the first 2*DEPTH - 1 iterations, then the operands of the first DEPTH
+#pragma unroll
+  for (int d = 0; d < kMapSets - 1; ++d) fetch_map(wave + d * n_waves, xm[d]);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(wave + d * n_waves, xm[d], A[d], B[d]);
+  for (int64_t it = wave; it < n_iters; it += n_waves) {
+    fetch_map(it + (kMapSets - 1) * n_waves, xm[kMapSets - 1]);
+    issue(it + DEPTH * n_waves, xm[DEPTH], A[DEPTH], B[DEPTH]);      // rows beyond N load nothing and contribute zeros
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+        for (int ib = 0; ib < IBT; ++ib) acc[ob][ib] = mfma16x16x4(A[0][u][ob], B[0][u][ib], acc[ob][ib]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+#pragma unroll
+        for (int ob = 0; ob < OBT; ++ob) A[d][u][ob] = A[d + 1][u][ob];
+#pragma unroll
+        for (int ib = 0; ib < IBT; ++ib) B[d][u][ib] = B[d + 1][u][ib];
+      }
+#pragma unroll
+    for (int d = 0; d < kMapSets - 1; ++d)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) xm[d][u] = xm[d + 1][u];
+  }
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * a.O * I1;
+#pragma unroll
+  for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+    for (int ib = 0; ib < IBT; ++ib) {
+      s_acc[wid][lane] = acc[ob][ib];
+      __syncthreads();
+      if (wid == 0) {
+        f32x4 t = s_acc[0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t += s_acc[w][lane];
+        const int i = ib * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = ob * 16 + lq * 4 + r;
           if (o < a.O && i < I1) dst[o * I1 + i] = t[r];
         }
       }
@@ -1076,6 +1197,21 @@ static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, h
   return true;
 }
 
+// Workgroups of `kernel` that are resident at once on the whole device (occupancy x compute units).  The persistent
+// kernels below split their rows statically over the grid (deterministic partial sums), so a grid that is not a whole
+// number of resident rounds ends with a thin last round that runs at a fraction of the occupancy the kernel needs:
+// measured on the seven-block weight gradient, 3 workgroups per CU (= its occupancy) 1.01 ms, 4 per CU 1.47 ms.
+template <typename K>
+static int resident_workgroups(K kernel) {
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return per_cu * cus;
+}
+
 // Picks the tile shape and launches; `a` is complete except for the grid-related choices.
 static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
@@ -1085,9 +1221,17 @@ static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
     // several narrow output blocks from one read of x: weight fragments in LDS, one MFMA tile per block
     const int64_t tiles = ceil_div(a.N, 16);
     static const int plain_env = getenv("MLQEM_FANOUT_PLAIN") ? atoi(getenv("MLQEM_FANOUT_PLAIN")) : 0;
-    static const int grid_env = getenv("MLQEM_FANOUT_GRID") ? atoi(getenv("MLQEM_FANOUT_GRID")) : 16;   // workgroups per CU x 256: measured 4 -> 1358, 8 -> 1268, 16 -> 1197, 64 -> 1249 us
+    static const int grid_env = getenv("MLQEM_FANOUT_GRID") ? atoi(getenv("MLQEM_FANOUT_GRID")) : 0;    // workgroups per CU; 0 = whole resident rounds
+    static const int rounds_env = getenv("MLQEM_FANOUT_ROUNDS") ? atoi(getenv("MLQEM_FANOUT_ROUNDS")) : 1;
     a.plain_stores = plain_env;
-    dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * grid_env));
+    int res = 0;
+    switch (g) {
+      case 1: { static const int r = resident_workgroups(linear_fanout_lds_kernel<1>); res = r; break; }
+      case 2: { static const int r = resident_workgroups(linear_fanout_lds_kernel<2>); res = r; break; }
+      case 3: { static const int r = resident_workgroups(linear_fanout_lds_kernel<3>); res = r; break; }
+      default: { static const int r = resident_workgroups(linear_fanout_lds_kernel<4>); res = r; break; }
+    }
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), grid_env > 0 ? 256 * grid_env : res * rounds_env));
     switch (g) {
       case 1: hipLaunchKernelGGL(linear_fanout_lds_kernel<1>, grid, dim3(kBlock), 0, s, a); break;
       case 2: hipLaunchKernelGGL(linear_fanout_lds_kernel<2>, grid, dim3(kBlock), 0, s, a); break;
@@ -1191,6 +1335,10 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
   static const int wide_pf = getenv("MLQEM_WGRAD_PF") ? atoi(getenv("MLQEM_WGRAD_PF")) : 1;
   const int ob_ = (a.O + 15) / 16, ib_ = (a.I + 1 + 15) / 16;
   const bool wide = ob_ >= 4 && ob_ <= 6 && ib_ <= 2;
+  static const int pipe_env = getenv("MLQEM_WGRAD_PIPE") ? atoi(getenv("MLQEM_WGRAD_PIPE")) : 2;    // 0: wgrad_mfma_kernel, 1: KU = 4 (two waves per SIMD), 2: KU = 2 (three)
+  static const int pipe_grid = getenv("MLQEM_WGRAD_GRID") ? atoi(getenv("MLQEM_WGRAD_GRID")) : 0;  // workgroups per CU; 0 = the resident count
+  bool uniform_ld = true;
+  for (int k = 1; k < a.gn; ++k) uniform_ld = uniform_ld && a.ldgy[k] == a.ldgy[0];
   const int64_t iters = ceil_div(std::max<int64_t>(a.N, 1), 4 * (wide && wide_u == 2 ? 2 : kWgradUnroll));
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
   const int ob = (a.O + 15) / 16, ib = (a.I + 1 + 15) / 16;
@@ -1203,6 +1351,16 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
   } else if (ob == 4 && ib <= 2) {   // up to eight blocks (the three first layers of Family A share x): one pass
     if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+  } else if (ob <= 6 && ib <= 2 && pipe_env && uniform_ld) {
+    // the seven first-layer blocks: software-pipelined form (see wgrad_pipe_kernel)
+    static const int res2 = resident_workgroups(wgrad_pipe_kernel<6, 2, 2, 2>), res4 = resident_workgroups(wgrad_pipe_kernel<6, 2, 4, 2>);
+    const int want = pipe_grid > 0 ? 256 * pipe_grid : (pipe_env == 2 ? res2 : res4);      // one resident round exactly
+    const int Gp = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kWgradBlocks, want), ceil_div(ceil_div(a.N, 16), 4)));
+    if (pipe_env == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<6, 2, 2, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_pipe_kernel<6, 2, 4, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial,
+                       Gp, a.I, a.O, gw, gb, accumulate);
+    return launch_status();
   } else if (ob <= 6 && ib <= 2) {
     if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
     else if (wide_pf) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, kWgradUnroll, true>), dim3(G, 1), dim3(kBlock), 0, s, a);
