@@ -145,64 +145,178 @@ __global__ __launch_bounds__(kBlock) void assemble_rows_kernel(const AssembleArg
   }
 }
 
-// Segment (graph) of element `mine`, for a workgroup whose elements are consecutive: ONE binary search per workgroup (by
-// thread 0, for the workgroup's first element), then every thread steps forward from there -- graphs hold thousands of
-// elements, so that is zero or one step instead of log2(B) dependent loads per element.  Call from all threads.
-__device__ __forceinline__ int segment_from_block_start(const int32_t* __restrict__ ptr, int n_seg, int64_t block_first,
-                                                        int64_t n_total, int64_t mine) {
-  __shared__ int s_first;
-  if (threadIdx.x == 0) s_first = find_segment(ptr, n_seg, (int32_t)min(block_first, max(n_total - 1, (int64_t)0)));
+// ---- nodes and edges of the batch: a workgroup takes kChunk consecutive elements.
+// Who owns an element (which selected graph) and where that graph sits in the arena is found ONCE per workgroup: two
+// binary searches (first and last element), then the facts of the few graphs the chunk spans go to LDS.  Every thread
+// then issues ALL loads of its kAsmPer elements before its first store: a thread of the one-element-per-thread form went
+// through six dependent round trips (segment -> sel -> graph start -> pointers -> data -> store, and a load behind a
+// store waits for that store on gfx9's single in-order vmcnt), which left the kernels latency-bound at 2.3 / 4.7 TB/s.
+constexpr int kAsmPer = 4;
+constexpr int kChunk = kAsmPer * kBlock;
+constexpr int kSpanMax = 256;     // graphs per chunk held in LDS; chunks spanning more (tiny or empty graphs) use the slow path
+
+struct ChunkGraphs {
+  int b0, span;                   // first graph of the chunk, number of graphs it touches (0: slow path)
+};
+
+// start[j] = ptr[b0 + j] (j = 0..span), g0[j] = arena node id of graph b0 + j's first node, nb[j] = b_nptr, eb[j] = b_eptr
+__device__ __forceinline__ ChunkGraphs chunk_graphs(const AssembleArgs& a, const int32_t* __restrict__ ptr, int64_t first,
+                                                    int64_t total, int32_t* s_start, int32_t* s_g0, int32_t* s_nb,
+                                                    int32_t* s_eb) {
+  __shared__ int s_b0, s_b1;
+  const int64_t last = min(first + kChunk, total) - 1;
+  if (threadIdx.x == 0) s_b0 = find_segment(ptr, a.B, (int32_t)first);
+  if (threadIdx.x == 64) s_b1 = find_segment(ptr, a.B, (int32_t)last);
   __syncthreads();
-  int b = s_first;
-  while (b + 1 < n_seg && mine >= ptr[b + 1]) ++b;
-  return b;
+  ChunkGraphs c{s_b0, s_b1 - s_b0 + 1};
+  if (c.span > kSpanMax) { c.span = 0; return c; }
+  for (int j = threadIdx.x; j <= c.span; j += kBlock) {
+    const int b = c.b0 + j;
+    s_start[j] = ptr[b];                      // b <= B: ptr has B + 1 entries
+    if (j < c.span) {
+      s_g0[j] = a.a_gptr[a.sel[b]];
+      s_nb[j] = a.b_nptr[b];
+      s_eb[j] = a.b_eptr[b];
+    }
+  }
+  __syncthreads();
+  return c;
 }
 
+template <int KS>    // KS = 6: the six per-node scalars of the arena move through registers (no xb); -1: any K, one at a time
 __global__ __launch_bounds__(kBlock) void assemble_nodes_kernel(const AssembleArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int b = segment_from_block_start(a.b_nptr, a.B, (int64_t)blockIdx.x * kBlock, a.Nb, min(i, max(a.Nb - 1, (int64_t)0)));
-  if (i > a.Nb) return;
-  if (i == a.Nb) {   // the selection's own edge total (== Eb unless the caller over-provisioned Eb, see the header)
-    a.in_ptr_b[i] = a.b_eptr[a.B];
-    a.out_ptr_b[i] = a.b_eptr[a.B];
+  __shared__ int32_t s_start[kSpanMax + 1], s_g0[kSpanMax], s_nb[kSpanMax], s_eb[kSpanMax];
+  const int64_t first = (int64_t)blockIdx.x * kChunk;
+  if (first >= a.Nb) {            // the one workgroup past the nodes: the selection's own edge total closes both pointers
+    if (first == ceil_div(a.Nb, (int64_t)kChunk) * kChunk && threadIdx.x == 0) {
+      a.in_ptr_b[a.Nb] = a.b_eptr[a.B];
+      a.out_ptr_b[a.Nb] = a.b_eptr[a.B];
+    }
     return;
   }
-  const int32_t g0 = a.a_gptr[a.sel[b]];
-  const int64_t gn = (int64_t)g0 + (i - a.b_nptr[b]);
-  a.src_node[i] = (int32_t)gn;
-  a.in_ptr_b[i] = a.a_in_ptr[gn] - a.a_in_ptr[g0] + a.b_eptr[b];
-  a.out_ptr_b[i] = a.a_out_ptr[gn] - a.a_out_ptr[g0] + a.b_eptr[b];
-  if (a.loops_b) a.loops_b[i] = a.a_loops[gn];
-  if (!a.xb)   // no feature rows to move: the per-node scalars ride along here instead of in a pass of their own
-    for (int k = 0; k < a.K; ++k) a.nscal_b[(int64_t)k * a.Nb + i] = a.nscal[gn * a.K + k];   // planar [K, Nb]
-  if (a.derived_b) {   // the layers' derived per-node scalars, made here instead of by three element-wise passes per batch
-    const float s0 = a.nscal[gn * a.K], s1 = a.nscal[gn * a.K + 1], s2 = a.nscal[gn * a.K + 2];
-    a.derived_b[i] = s0 * s0;
-    a.derived_b[a.Nb + i] = (float)a.a_loops[gn] * s1;
-    a.derived_b[2 * a.Nb + i] = -s2;
+  const ChunkGraphs c = chunk_graphs(a, a.b_nptr, first, a.Nb, s_start, s_g0, s_nb, s_eb);
+  int64_t gn[kAsmPer]; int32_t g0[kAsmPer], eb[kAsmPer], shift[kAsmPer]; bool ok[kAsmPer];
+  int lb = 0;
+#pragma unroll
+  for (int j = 0; j < kAsmPer; ++j) {
+    const int64_t i = first + j * kBlock + threadIdx.x;
+    ok[j] = i < a.Nb;
+    const int32_t ii = (int32_t)min(i, a.Nb - 1);
+    int32_t nb;
+    if (c.span) {
+      while (lb + 1 < c.span && ii >= s_start[lb + 1]) ++lb;
+      g0[j] = s_g0[lb]; nb = s_nb[lb]; eb[j] = s_eb[lb];
+    } else {
+      const int b = find_segment(a.b_nptr, a.B, ii);
+      g0[j] = a.a_gptr[a.sel[b]]; nb = a.b_nptr[b]; eb[j] = a.b_eptr[b];
+    }
+    gn[j] = (int64_t)g0[j] + (ii - nb);
+    shift[j] = nb - g0[j];
   }
-  // ELL side tables: the arena's entries rebased to batch ids (-1 = no edge, bit 31 of .x = more than two edges)
-  const int32_t shift = a.b_nptr[b] - g0;
-  auto rebase = [&](int2 e) {
-    if (e.x != -1) e.x = (((e.x & 0x7fffffff) + shift) | (e.x & (int32_t)0x80000000));
-    if (e.y != -1) e.y += shift;
-    return e;
-  };
-  if (a.in_ell_b) reinterpret_cast<int2*>(a.in_ell_b)[i] = rebase(reinterpret_cast<const int2*>(a.a_in_ell)[gn]);
-  if (a.out_ell_b) reinterpret_cast<int2*>(a.out_ell_b)[i] = rebase(reinterpret_cast<const int2*>(a.a_out_ell)[gn]);
+  // ---- loads
+  int32_t ip[kAsmPer], ip0[kAsmPer], op[kAsmPer], op0[kAsmPer], lp[kAsmPer];
+  int2 ie[kAsmPer], oe[kAsmPer];
+  float sc[kAsmPer][KS > 0 ? KS : 1];
+  const bool want_loops = a.loops_b || a.derived_b;
+#pragma unroll
+  for (int j = 0; j < kAsmPer; ++j) {
+    ip[j] = a.a_in_ptr[gn[j]]; ip0[j] = a.a_in_ptr[g0[j]];
+    op[j] = a.a_out_ptr[gn[j]]; op0[j] = a.a_out_ptr[g0[j]];
+    lp[j] = want_loops ? a.a_loops[gn[j]] : 0;
+    if (a.in_ell_b) ie[j] = reinterpret_cast<const int2*>(a.a_in_ell)[gn[j]];
+    if (a.out_ell_b) oe[j] = reinterpret_cast<const int2*>(a.a_out_ell)[gn[j]];
+    if (KS > 0) {
+#pragma unroll
+      for (int k = 0; k < KS; k += 2) {      // KS even, rows of KS floats: 8-byte aligned pairs
+        const float2 v = *reinterpret_cast<const float2*>(a.nscal + gn[j] * KS + k);
+        sc[j][k] = v.x; sc[j][k + 1] = v.y;
+      }
+    }
+  }
+  // ---- stores
+#pragma unroll
+  for (int j = 0; j < kAsmPer; ++j) {
+    if (!ok[j]) continue;
+    const int64_t i = first + j * kBlock + threadIdx.x;
+    a.src_node[i] = (int32_t)gn[j];
+    a.in_ptr_b[i] = ip[j] - ip0[j] + eb[j];
+    a.out_ptr_b[i] = op[j] - op0[j] + eb[j];
+    if (a.loops_b) a.loops_b[i] = lp[j];
+    if (KS > 0) {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) a.nscal_b[(int64_t)k * a.Nb + i] = sc[j][k];      // planar [K, Nb]
+      if (a.derived_b) {    // the layers' derived per-node scalars, made here instead of by three element-wise passes per batch
+        a.derived_b[i] = sc[j][0] * sc[j][0];
+        a.derived_b[a.Nb + i] = (float)lp[j] * sc[j][1];
+        a.derived_b[2 * a.Nb + i] = -sc[j][2];
+      }
+    } else if (KS < 0) {
+      if (!a.xb)   // no feature rows to move: the per-node scalars ride along here instead of in a pass of their own
+        for (int k = 0; k < a.K; ++k) a.nscal_b[(int64_t)k * a.Nb + i] = a.nscal[gn[j] * a.K + k];
+      if (a.derived_b) {
+        const float s0 = a.nscal[gn[j] * a.K], s1 = a.nscal[gn[j] * a.K + 1], s2 = a.nscal[gn[j] * a.K + 2];
+        a.derived_b[i] = s0 * s0;
+        a.derived_b[a.Nb + i] = (float)lp[j] * s1;
+        a.derived_b[2 * a.Nb + i] = -s2;
+      }
+    }
+    // ELL side tables: the arena's entries rebased to batch ids (-1 = no edge, bit 31 of .x = more than two edges)
+    auto rebase = [&](int2 e) {
+      if (e.x != -1) e.x = (((e.x & 0x7fffffff) + shift[j]) | (e.x & (int32_t)0x80000000));
+      if (e.y != -1) e.y += shift[j];
+      return e;
+    };
+    if (a.in_ell_b) reinterpret_cast<int2*>(a.in_ell_b)[i] = rebase(ie[j]);
+    if (a.out_ell_b) reinterpret_cast<int2*>(a.out_ell_b)[i] = rebase(oe[j]);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void assemble_edges_kernel(const AssembleArgs a) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int b = segment_from_block_start(a.b_eptr, a.B, (int64_t)blockIdx.x * kBlock, a.Eb, min(e, max(a.Eb - 1, (int64_t)0)));
-  if (e >= a.Eb || e >= a.b_eptr[a.B]) return;   // Eb may be a capacity (fixed-shape launches): the real total is on the device
-  const int32_t g0 = a.a_gptr[a.sel[b]];
-  const int32_t shift = a.b_nptr[b] - g0;
-  const int64_t le = e - a.b_eptr[b];
-  a.in_src_b[e] = a.a_in_src[a.a_in_ptr[g0] + le] + shift;
-  a.out_dst_b[e] = a.a_out_dst[a.a_out_ptr[g0] + le] + shift;
-  // in-CSR position of the same edge: rebased from the graph's slice of the arena to its slice of the batch
-  if (a.out_eid_b) a.out_eid_b[e] = a.a_out_eid[a.a_out_ptr[g0] + le] - a.a_in_ptr[g0] + a.b_eptr[b];
+  __shared__ int32_t s_start[kSpanMax + 1], s_g0[kSpanMax], s_nb[kSpanMax], s_eb[kSpanMax];
+  __shared__ int32_t s_in0[kSpanMax], s_out0[kSpanMax];
+  const int64_t total = min(a.Eb, (int64_t)a.b_eptr[a.B]);   // Eb may be a capacity (fixed-shape launches): the real total is on the device
+  const int64_t first = (int64_t)blockIdx.x * kChunk;
+  if (first >= total) return;
+  const ChunkGraphs c = chunk_graphs(a, a.b_eptr, first, total, s_start, s_g0, s_nb, s_eb);
+  if (c.span) {
+    for (int j = threadIdx.x; j < c.span; j += kBlock) { s_in0[j] = a.a_in_ptr[s_g0[j]]; s_out0[j] = a.a_out_ptr[s_g0[j]]; }
+    __syncthreads();
+  }
+  int32_t shift[kAsmPer], eoff[kAsmPer]; int64_t in_at[kAsmPer], out_at[kAsmPer]; bool ok[kAsmPer];
+  int lb = 0;
+#pragma unroll
+  for (int j = 0; j < kAsmPer; ++j) {
+    const int64_t e = first + j * kBlock + threadIdx.x;
+    ok[j] = e < total;
+    const int32_t ee = (int32_t)min(e, total - 1);
+    int32_t g0, nb, eb, in0, out0;
+    if (c.span) {
+      while (lb + 1 < c.span && ee >= s_start[lb + 1]) ++lb;       // empty graphs in between are stepped over
+      g0 = s_g0[lb]; nb = s_nb[lb]; eb = s_eb[lb]; in0 = s_in0[lb]; out0 = s_out0[lb];
+    } else {
+      const int b = find_segment(a.b_eptr, a.B, ee);
+      g0 = a.a_gptr[a.sel[b]]; nb = a.b_nptr[b]; eb = a.b_eptr[b]; in0 = a.a_in_ptr[g0]; out0 = a.a_out_ptr[g0];
+    }
+    shift[j] = nb - g0;
+    in_at[j] = (int64_t)in0 + (ee - eb);
+    out_at[j] = (int64_t)out0 + (ee - eb);
+    eoff[j] = eb - in0;       // in-CSR position of an edge: rebased from the graph's slice of the arena to its slice of the batch
+  }
+  int32_t src[kAsmPer], dst[kAsmPer], eid[kAsmPer];
+#pragma unroll
+  for (int j = 0; j < kAsmPer; ++j) {
+    src[j] = a.a_in_src[in_at[j]];
+    dst[j] = a.a_out_dst[out_at[j]];
+    eid[j] = a.out_eid_b ? a.a_out_eid[out_at[j]] : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < kAsmPer; ++j) {
+    if (!ok[j]) continue;
+    const int64_t e = first + j * kBlock + threadIdx.x;
+    a.in_src_b[e] = src[j] + shift[j];
+    a.out_dst_b[e] = dst[j] + shift[j];
+    if (a.out_eid_b) a.out_eid_b[e] = eid[j] + eoff[j];
+  }
 }
 
 }  // namespace mlqem
@@ -293,7 +407,10 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
   AssembleArgs a{x, ldx, F, nscal, K, a_gptr, a_in_ptr, a_in_src, a_out_ptr, a_out_dst, a_out_eid, a_loops, sel, b_nptr, b_eptr,
                  (int)B, Nb, Eb, xb, ldxb, nscal_b, derived_b, src_node, in_ptr_b, in_src_b, out_ptr_b, out_dst_b, out_eid_b, loops_b,
                  a_in_ell, a_out_ell, in_ell_b, out_ell_b};
-  hipLaunchKernelGGL(assemble_nodes_kernel, dim3((unsigned)ceil_div(Nb + 1, kBlock)), dim3(kBlock), 0, stream, a);
+  // one workgroup past the last node chunk writes the closing pointer entries
+  const dim3 ngrid((unsigned)(ceil_div(Nb, (int64_t)kChunk) + 1));
+  if (!xb && K == 6 && aligned_to(nscal, 8)) hipLaunchKernelGGL(assemble_nodes_kernel<6>, ngrid, dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL(assemble_nodes_kernel<-1>, ngrid, dim3(kBlock), 0, stream, a);
   if (Nb > 0) {
     // xb == NULL: only the per-node scalars are gathered; the caller's first layers read x through src_node
     const bool vec4 = xb && F % 4 == 0 && ldx % 4 == 0 && ldxb % 4 == 0 && aligned_to(x, 16) && aligned_to(xb, 16);
@@ -308,6 +425,6 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
     }
   }
   if (Eb > 0)
-    hipLaunchKernelGGL(assemble_edges_kernel, dim3((unsigned)ceil_div(Eb, kBlock)), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(assemble_edges_kernel, dim3((unsigned)ceil_div(Eb, (int64_t)kChunk)), dim3(kBlock), 0, stream, a);
   return launch_status();
 }
