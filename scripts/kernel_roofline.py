@@ -42,7 +42,8 @@ class Recorder:
     """Wraps the ops entry points the Family A step uses; keeps (name, args, kwargs) so the call can be replayed."""
 
     NAMES = ("csr_aggregate", "linear", "linear_parts", "linear_wgrad", "linear_wgrad_parts", "segment_mean",
-             "segment_mean_bwd", "relu_dropout_bwd", "segment_pool", "segment_pool_bwd")
+             "segment_mean_bwd", "relu_dropout_bwd", "segment_pool", "segment_pool_bwd", "linear_bwd_fused", "pooled_head",
+             "pooled_head_bwd")
 
     def __init__(self):
         self.calls, self.orig = [], {}
@@ -131,6 +132,16 @@ def describe(name, a, k, struct):
         b, c = g.shape
         n = a[2]
         return f"segment_mean_bwd N={n} C={c}", 4 * c * (n + b) + 4 * (b + 1)
+    if name == "linear_bwd_fused":
+        gy, x, w = a[0], a[1], a[2]
+        n, o = gy.shape
+        i = x.shape[1]
+        extra = 4 * n * o if (len(a) > 3 and a[3] is not None) or k.get("gb_src") is not None else 0
+        return f"linear_bwd_fused N={n} gy[{o}] x[{i}] (gx + gW + gb, one pass)", 4 * n * (o + 2 * i) + extra
+    if name in ("pooled_head", "pooled_head_bwd"):
+        terms = a[0]
+        b, c = terms[0][0].shape
+        return f"{name} B={b} C={c} terms={len(terms)}", 4 * b * c * len(terms) * (2 if name.endswith("bwd") else 1)
     if name == "relu_dropout_bwd":
         n, c = a[0].shape
         return f"relu_dropout_bwd N={n} C={c}", 12 * n * c
