@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 9 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 10 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -337,6 +337,27 @@ size_t mlqem_sort_unique_u64_workspace_bytes(int64_t T);
 int mlqem_sort_unique_u64(const uint64_t* keys, int64_t T, uint64_t* out_keys, int64_t* out_count, void* workspace,
                           size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t* edge_index, mlqem_stream_t stream);
+
+/* Coarsened connectivity of LARGE graphs (100-qubit circuits pool to thousands of clusters; their second pooling runs on
+ * graphs with hub clusters of hundreds of neighbours, where the two-hop path above sorts ~50 candidate keys per distinct
+ * edge).  One wave per cluster p builds the row's reach as bitsets in LDS -- nodes v in N+[N-[c_p]], then clusters
+ * q = slot[w], w in N+[v] -- so duplicates collapse without a sort and rows come out in ascending order; the rows and
+ * their transpose are kept as bit matrices [K][ceil(kmax / 32)] in the workspace.  Two calls, ONE host read between them:
+ *   rows_count: slot[N], new_in_ptr[K + 1], new_out_ptr[K + 1]; the caller reads new_out_ptr[K] (the edge total E);
+ *   rows_fill:  new_in_src[E], new_out_dst[E], new_out_eid[E] -- the arrays mlqem_csr_build yields from the two-hop path's
+ *               edge list -- from the SAME workspace, untouched in between.
+ * nmax / kmax: largest graph / largest pooled graph of the batch; nmax + kmax + 64 <= mlqem_asap_coarsen_rows_max_bits()
+ * (131 072: 64 KB of LDS for the four waves of a workgroup), else MLQEM_ERR_UNSUPPORTED.  Replaces the same
+ * ASAPooling.forward lines as the entry points above (gnn.py:105-107,110-112). */
+size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax);
+int mlqem_asap_coarsen_rows_max_bits(void);
+int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                  const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N,
+                                  int64_t K, int64_t B, int nmax, int kmax, int32_t* slot, int32_t* new_in_ptr,
+                                  int32_t* new_out_ptr, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_asap_coarsen_rows_fill(const int32_t* new_graph_ptr, int64_t K, int64_t B, int kmax, const int32_t* new_in_ptr,
+                                 const int32_t* new_out_ptr, int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid,
+                                 const void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Coarsened connectivity WITHOUT host read-backs, for batches whose graphs all pool to at most
  * mlqem_asap_coarsen_dense_max_k() clusters (512): the pooled adjacency of every graph is built as a k_g x k_g bit

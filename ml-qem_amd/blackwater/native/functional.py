@@ -448,6 +448,8 @@ def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
 # MLQEM_ASAP_DENSE=0 forces the general two-hop coarsening (four device->host size reads per pooling) for every batch; the
 # default uses the sync-free dense form whenever every graph of the batch pools to <= 512 clusters.
 _ASAP_DENSE = os.environ.get("MLQEM_ASAP_DENSE", "1") != "0"
+# MLQEM_ASAP_ROWS=0 keeps the two-hop path for graphs too large for the dense form (default: the wave-per-cluster form)
+_ASAP_ROWS = os.environ.get("MLQEM_ASAP_ROWS", "1") != "0"
 
 
 class _ASAPool(Function):
@@ -483,6 +485,11 @@ class _ASAPool(Function):
             # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
             csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
             num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
+        elif (_ASAP_ROWS and len(keep) > 0
+              and int(sizes.max()) + int(keep.max()) + 64 <= ops.asap_rows_max_bits()):
+            # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)
+            csr, slot, num_edges = ops.asap_coarsen_rows(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n,
+                                                         sizes, keep)
         else:
             ei, slot = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n, return_slot=True)
             csr = ops.csr_build(ei, k_total)

@@ -5,6 +5,8 @@ matching the CSR arrays) BEFORE launching -- a kernel that reads out of bounds c
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -723,6 +725,8 @@ def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes, return_slot=
     _lib.check(code, "mlqem_asap_hop2_fill")
     uniq, e = _sort_unique(keys2, total2)
     del keys2
+    if os.environ.get("MLQEM_ASAP_DEBUG"):
+        print(f"asap_coarsen: N={num_nodes} k={k} hop1 candidates={total} distinct (p,v)={m} hop2 candidates={total2} edges={e}", flush=True)
     ei = torch.empty((2, e), dtype=torch.int64, device=dev)
     code = lib.mlqem_keys_to_edge_index(_p(uniq), e, _p(ei), _stream())
     _lib.check(code, "mlqem_keys_to_edge_index")
@@ -750,6 +754,40 @@ def asap_coarsen_dense(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
                                         _p(out_dst), _p(out_eid), _p(loops), _p(ws), need, _stream())
     _lib.check(code, "mlqem_asap_coarsen_dense")
     return CsrArrays(in_ptr, in_src, out_ptr, out_dst, loops, out_eid), slot, cap
+
+
+def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, graph_sizes, keep_sizes):
+    """The same pooled structure arrays for LARGE graphs (mlqem_asap_coarsen_rows_count / _fill: one wave per cluster, bitsets
+    in LDS, no sort): ONE 4-byte device->host read (the edge total) instead of the two-hop path's four reads and two
+    64-bit sorts.  Returns (CsrArrays, slot, number of edges)."""
+    import numpy as np
+
+    keep = np.asarray(keep_sizes, dtype=np.int64)
+    b, k = int(keep.shape[0]), int(keep.sum())
+    kmax = int(keep.max()) if b else 0
+    nmax = int(np.asarray(graph_sizes).max()) if b else 0
+    dev = perm.device
+    lib = _lib.load()
+    mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    slot, in_ptr, out_ptr = mk(num_nodes), mk(k + 1), mk(k + 1)
+    need = lib.mlqem_asap_coarsen_rows_workspace_bytes(k, kmax)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    code = lib.mlqem_asap_coarsen_rows_count(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(graph_ptr),
+                                             _p(new_graph_ptr), _p(perm), num_nodes, k, b, nmax, kmax, _p(slot), _p(in_ptr),
+                                             _p(out_ptr), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_asap_coarsen_rows_count")
+    e = int(out_ptr[k].item()) if k > 0 else 0
+    in_src, out_dst, out_eid = mk(e), mk(e), mk(e)
+    loops = torch.zeros(max(k, 1), dtype=torch.int32, device=dev)
+    if e > 0:
+        code = lib.mlqem_asap_coarsen_rows_fill(_p(new_graph_ptr), k, b, kmax, _p(in_ptr), _p(out_ptr), _p(in_src), _p(out_dst),
+                                                _p(out_eid), _p(ws), need, _stream())
+        _lib.check(code, "mlqem_asap_coarsen_rows_fill")
+    return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], out_eid[:e]), slot, e
+
+
+def asap_rows_max_bits() -> int:
+    return int(_lib.load().mlqem_asap_coarsen_rows_max_bits())
 
 
 def asap_dense_max_k() -> int:

@@ -227,6 +227,166 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_fill_kernel(const DenseA
   }
 }
 
+// ------------------------------------------------------ coarsened connectivity, large graphs: one WAVE per cluster
+// 100-qubit circuits pool to thousands of clusters per graph and their second pooling runs on graphs whose hub clusters
+// have hundreds of neighbours: the two-hop path above then enumerates ~50 candidates per distinct pair (147 M hop-1 and
+// 234 M hop-2 keys for eight circuits), sorts them as 64-bit keys (65 GB of buffers at 64 circuits) and reads four sizes
+// back.  Here a wave owns cluster p and keeps two BITSETS in LDS: X (the graph's nodes, n_g bits: v in N+[N-[c_p]]) and
+// Y (the graph's clusters, k_g bits: q = slot[w], w in N+[v], v in X).  Duplicates collapse in the LDS atomicOr, nothing
+// is sorted, and a bitset is enumerated in ascending order -- which is the order the CSR arrays want.  Row p of the
+// pooled adjacency goes to a global bit matrix [K][Wk]; its transpose is filled with one global atomicOr per DISTINCT
+// edge.  Popcounts -> device scans -> the CSR pointers; the host reads ONE number (the edge total) to size the edge
+// arrays; a second kernel lists rows / columns and links them (out_eid).  Graphs up to ~87 k nodes (64 KB of LDS per
+// workgroup of four waves).
+struct RowsArgs {
+  const int32_t* in_ptr; const int32_t* in_src; const int32_t* out_ptr; const int32_t* out_dst;
+  const int32_t* gptr; const int32_t* new_gptr; const int32_t* perm; const int32_t* slot;
+  int B; int64_t K;
+  int Wn, Wk;                    // words of the node / cluster bitsets (batch maxima)
+  uint32_t* bm; uint32_t* bmT;   // [K][Wk]: row p = clusters q (local index) with p -> q; bmT row q = sources p
+  int32_t* outdeg; int32_t* indeg;   // [K + 1]
+};
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) {
+  extern __shared__ uint32_t s_bits[];              // per wave: X [Wn] then Y [Wk]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t* X = s_bits + (size_t)wid * (a.Wn + a.Wk);
+  uint32_t* Y = X + a.Wn;
+  const int64_t p = (int64_t)blockIdx.x * 4 + wid;
+  const bool live = p < a.K;
+  for (int i = lane; i < a.Wn + a.Wk; i += 64) X[i] = 0u;
+  __syncthreads();
+  int c = 0, n0 = 0, k0 = 0, kg = 0;
+  if (live) {
+    c = a.perm[p];
+    int lo = 0, hi = a.B;                            // graph of cluster p: largest g with new_gptr[g] <= p
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)a.new_gptr[mid] <= p) lo = mid; else hi = mid; }
+    n0 = a.gptr[lo]; k0 = a.new_gptr[lo]; kg = a.new_gptr[lo + 1] - k0;
+    // X = N+[N-[c]]: lanes split the in-neighbours (and c itself, index -1)
+    const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
+    for (int i = ib - 1 + lane; i < ie; i += 64) {
+      const int u = i < ib ? c : a.in_src[i];
+      atomicOr(&X[(u - n0) >> 5], 1u << ((u - n0) & 31));
+      for (int e = a.out_ptr[u]; e < a.out_ptr[u + 1]; ++e) {
+        const int v = a.out_dst[e] - n0;
+        atomicOr(&X[v >> 5], 1u << (v & 31));
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    // Y = kept centres among N+[X], as local cluster indices, without p itself
+    for (int wi = lane; wi < a.Wn; wi += 64) {
+      uint32_t bits = X[wi];
+      while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const int v = n0 + wi * 32 + b;
+        for (int e = a.out_ptr[v] - 1; e < a.out_ptr[v + 1]; ++e) {
+          const int w = e < a.out_ptr[v] ? v : a.out_dst[e];
+          const int q = a.slot[w];
+          if (q >= 0 && q != (int)p) atomicOr(&Y[(q - k0) >> 5], 1u << ((q - k0) & 31));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    int cnt = 0;
+    const int pl = (int)(p - k0);
+    for (int wi = lane; wi < a.Wk; wi += 64) {
+      uint32_t bits = Y[wi];
+      a.bm[p * a.Wk + wi] = bits;
+      cnt += __popc(bits);
+      while (bits) {                                  // one global atomicOr per distinct edge p -> q
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        atomicOr(&a.bmT[(int64_t)(k0 + wi * 32 + b) * a.Wk + (pl >> 5)], 1u << (pl & 31));
+      }
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) a.outdeg[p] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_rows_indeg_kernel(const RowsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= a.K) return;
+  int cnt = 0;
+  for (int wi = lane; wi < a.Wk; wi += 64) cnt += __popc(a.bmT[q * a.Wk + wi]);
+  cnt = wave_sum(cnt);
+  if (lane == 0) a.indeg[q] = cnt;
+}
+
+// exclusive prefix over the wave of a per-lane count
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {
+  int s = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(s, o);
+    if (lane >= o) s += t;
+  }
+  return s - v;
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArgs a, const int32_t* __restrict__ in_ptr_new,
+                                                                   const int32_t* __restrict__ out_ptr_new,
+                                                                   int32_t* __restrict__ in_src_new,
+                                                                   int32_t* __restrict__ out_dst_new,
+                                                                   int32_t* __restrict__ out_eid_new) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.K) return;
+  int lo = 0, hi = a.B;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)a.new_gptr[mid] <= r) lo = mid; else hi = mid; }
+  const int k0 = a.new_gptr[lo];
+  const int rl = (int)(r - k0);
+  // row r of the out-CSR: destinations ascending
+  int base = out_ptr_new[r];
+  for (int w0 = 0; w0 < a.Wk; w0 += 64) {
+    const int wi = w0 + lane;
+    uint32_t bits = wi < a.Wk ? a.bm[r * a.Wk + wi] : 0u;
+    const int n = __popc(bits);
+    int pos = base + wave_excl_scan(n, lane);
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      out_dst_new[pos++] = k0 + wi * 32 + b;
+    }
+    base += __shfl(wave_excl_scan(n, lane) + n, 63);
+  }
+  // row r of the in-CSR: sources ascending; each entry also tells its out-CSR twin where it lives
+  base = in_ptr_new[r];
+  const int wq = rl >> 5;
+  const uint32_t below = (1u << (rl & 31)) - 1u;
+  for (int w0 = 0; w0 < a.Wk; w0 += 64) {
+    const int wi = w0 + lane;
+    uint32_t bits = wi < a.Wk ? a.bmT[r * a.Wk + wi] : 0u;
+    const int n = __popc(bits);
+    const int ex = wave_excl_scan(n, lane);
+    int pos = base + ex;
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      const int64_t src = (int64_t)k0 + wi * 32 + b;
+      in_src_new[pos] = (int32_t)src;
+      const uint32_t* row = a.bm + src * a.Wk;       // rank of r inside row src of the out-CSR
+      int rank = __popc(row[wq] & below);
+      for (int w = 0; w < wq; ++w) rank += __popc(row[w]);
+      out_eid_new[out_ptr_new[src] + rank] = pos;
+      ++pos;
+    }
+    base += __shfl(ex + n, 63);
+  }
+}
+
 static size_t dense_scan_bytes(int64_t K) {
   size_t temp = 0;
   (void)rocprim::exclusive_scan(nullptr, temp, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(K + 1),
@@ -398,6 +558,95 @@ extern "C" int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t
   if (!keys || !edge_index) return MLQEM_ERR_BAD_ARG;
   hipLaunchKernelGGL(keys_to_edge_index_kernel, dim3((unsigned)ceil_div(E, kBlock)), dim3(kBlock), 0,
                      as_stream(stream), keys, E, edge_index);
+  return launch_status();
+}
+
+static void rows_layout(int64_t K, int kmax, size_t& bm, size_t& deg) {
+  const size_t Wk = (size_t)(kmax + 31) / 32;
+  bm = ((size_t)K * Wk * sizeof(uint32_t) + 255) / 256 * 256;
+  deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
+}
+
+extern "C" size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax) {
+  if (K < 0 || kmax < 0) return 0;
+  size_t bm, deg;
+  rows_layout(K, kmax, bm, deg);
+  return 2 * bm + 2 * deg + dense_scan_bytes(K);
+}
+
+extern "C" int mlqem_asap_coarsen_rows_max_bits(void) { return 64 * 1024 * 8 / 4; }   // (n_g + k_g) bits per wave: 64 KB of LDS, four waves
+
+static bool rows_args(RowsArgs& a, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                      const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, const int32_t* slot,
+                      int64_t K, int64_t B, int nmax, int kmax, void* workspace) {
+  size_t bm, deg;
+  rows_layout(K, kmax, bm, deg);
+  char* ws = static_cast<char*>(workspace);
+  a = RowsArgs{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, K, (nmax + 31) / 32, (kmax + 31) / 32,
+               reinterpret_cast<uint32_t*>(ws), reinterpret_cast<uint32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + 2 * bm),
+               reinterpret_cast<int32_t*>(ws + 2 * bm + deg)};
+  return true;
+}
+
+// Pass 1: slot[], the two bit matrices (kept in the workspace for pass 2) and both CSR pointer arrays; new_out_ptr[K] is the
+// edge total the caller reads to size the edge arrays.  nmax / kmax: largest graph / largest pooled graph of the batch.
+extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                             const int32_t* out_dst, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
+                                             const int32_t* perm, int64_t N, int64_t K, int64_t B, int nmax, int kmax,
+                                             int32_t* slot, int32_t* new_in_ptr, int32_t* new_out_ptr, void* workspace,
+                                             size_t workspace_bytes, mlqem_stream_t stream_) {
+  begin_launches();
+  hipStream_t stream = as_stream(stream_);
+  if (N < 0 || K < 0 || K > N || B < 0 || kmax < 0 || nmax < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if (nmax + kmax + 64 > mlqem_asap_coarsen_rows_max_bits()) return MLQEM_ERR_UNSUPPORTED;
+  if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_asap_coarsen_rows_workspace_bytes(K, kmax)) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  if (K == 0 || B == 0) {
+    (void)hipMemsetAsync(new_in_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
+    (void)hipMemsetAsync(new_out_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
+    return launch_status();
+  }
+  if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm) return MLQEM_ERR_BAD_ARG;
+  RowsArgs a;
+  rows_args(a, in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, K, B, nmax, kmax, workspace);
+  size_t bm, deg;
+  rows_layout(K, kmax, bm, deg);
+  if (hipMemsetAsync(a.bmT, 0, bm, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  if (hipMemsetAsync(a.outdeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  if (hipMemsetAsync(a.indeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
+  const size_t lds = (size_t)4 * (a.Wn + a.Wk) * sizeof(uint32_t);
+  const unsigned grid = (unsigned)ceil_div(K, (int64_t)4);
+  hipLaunchKernelGGL(coarsen_rows_kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+  hipLaunchKernelGGL(coarsen_rows_indeg_kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+  void* temp = static_cast<char*>(workspace) + 2 * bm + 2 * deg;
+  size_t temp_bytes = dense_scan_bytes(K);
+  if (rocprim::exclusive_scan(temp, temp_bytes, a.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
+                              stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  if (rocprim::exclusive_scan(temp, temp_bytes, a.indeg, new_in_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
+                              stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  return launch_status();
+}
+
+// Pass 2 (same workspace, untouched in between): the edge arrays, each sized new_out_ptr[K].
+extern "C" int mlqem_asap_coarsen_rows_fill(const int32_t* new_graph_ptr, int64_t K, int64_t B, int kmax, const int32_t* new_in_ptr,
+                                            const int32_t* new_out_ptr, int32_t* new_in_src, int32_t* new_out_dst,
+                                            int32_t* new_out_eid, const void* workspace, size_t workspace_bytes,
+                                            mlqem_stream_t stream_) {
+  begin_launches();
+  hipStream_t stream = as_stream(stream_);
+  if (K < 0 || B < 0 || kmax < 0) return MLQEM_ERR_BAD_ARG;
+  if (K == 0 || B == 0) return MLQEM_OK;
+  if (!new_graph_ptr || !new_in_ptr || !new_out_ptr || !new_in_src || !new_out_dst || !new_out_eid) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_asap_coarsen_rows_workspace_bytes(K, kmax)) return MLQEM_ERR_WORKSPACE;
+  RowsArgs a;
+  rows_args(a, nullptr, nullptr, nullptr, nullptr, nullptr, new_graph_ptr, nullptr, nullptr, K, B, 0, kmax,
+            const_cast<void*>(workspace));
+  hipLaunchKernelGGL(coarsen_rows_fill_kernel, dim3((unsigned)ceil_div(K, (int64_t)4)), dim3(kBlock), 0, stream, a, new_in_ptr,
+                     new_out_ptr, new_in_src, new_out_dst, new_out_eid);
   return launch_status();
 }
 

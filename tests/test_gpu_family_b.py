@@ -337,6 +337,60 @@ def test_dense_sync_free_coarsening_equals_the_two_hop_path(golden_dir, g1):
         assert torch.equal(results[True][4], results[False][4])
 
 
+def _pooled_levels(model, x, ei, batch_vec, b):
+    from blackwater.native.structure import GraphStructure
+
+    with torch.no_grad():
+        s = GraphStructure.from_edge_index(ei, x.shape[0], batch=batch_vec, num_graphs=b)
+        h = model.transformer1(x, s)
+        h1, s1, perm1 = model.pooling1(h, s)
+        h2, s2, perm2 = model.pooling2(model.transformer2(h1, s1), s1)
+    return s1, s2, perm1, perm2, h2
+
+
+def test_wave_per_cluster_coarsening_equals_the_two_hop_path(golden_dir, g1):
+    """The large-graph form of ASAPooling's coarsening (one wave per cluster, LDS bitsets, one host read) against the
+    two-hop path (four reads, two 64-bit sorts): identical CSR arrays and out_eid at both pooling levels -- on the
+    reference's small graphs (dense form switched off) and on 100-qubit circuits whose second pooling has hub clusters
+    with hundreds of neighbours."""
+    from blackwater.data.synthetic import TfimCorpus
+    from blackwater.native import functional as F
+    from blackwater.nn import ExpValCircuitGraphModel, family_b_from_state_dict
+
+    cases = []
+    small = g1_batch(g1, list(range(60, 90)) + [299, 0, 150], self_loops=True, first_only=False)
+    cases.append((family_b_from_state_dict(_ckpt(golden_dir, "gnn1.pth")).to(DEV).eval(), small["x"].to(DEV),
+                  small["edge_index"].to(DEV), small["batch"].to(DEV), small["noisy"].shape[0]))
+    corpus = TfimCorpus(100, [1, 4, 7], 1, seed=3, exp_value_size=4)
+    hg = corpus.host_graphs()
+    counts = np.asarray([g.shape[0] for g in hg["x"]])
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    xs = np.concatenate(hg["x"], 0).astype(np.float32)
+    eis = np.concatenate([np.asarray(e, dtype=np.int64) + o for e, o in zip(hg["edge_index"], offs)], 1)
+    torch.manual_seed(1)
+    cases.append((ExpValCircuitGraphModel(22, 15).to(DEV).eval(), torch.from_numpy(xs).to(DEV), torch.from_numpy(eis).to(DEV),
+                  torch.from_numpy(np.repeat(np.arange(len(counts)), counts)).to(DEV), len(counts)))
+    for model, x, ei, bv, b in cases:
+        res = {}
+        for rows in (True, False):
+            F._ASAP_DENSE, F._ASAP_ROWS = False, rows
+            try:
+                res[rows] = _pooled_levels(model, x, ei, bv, b)
+            finally:
+                F._ASAP_DENSE, F._ASAP_ROWS = True, True
+        for lvl in (0, 1):
+            a, c = res[True][lvl], res[False][lvl]
+            e = int(c.in_ptr[c.num_nodes].item())
+            assert e == c.num_edges == a.num_edges and e > 0
+            assert torch.equal(a.in_ptr[:a.num_nodes + 1], c.in_ptr[:c.num_nodes + 1])
+            assert torch.equal(a.out_ptr[:a.num_nodes + 1], c.out_ptr[:c.num_nodes + 1])
+            assert torch.equal(a.in_src[:e], c.in_src[:e]) and torch.equal(a.out_dst[:e], c.out_dst[:e])
+            assert torch.equal(a.out_eid[:e], c.out_eid[:e])
+            assert not a.loops[:a.num_nodes].any()
+        assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+        assert torch.equal(res[True][4], res[False][4])
+
+
 def test_family_b_train_step_makes_no_device_to_host_copy(golden_dir, g1):
     """A Family B train step on an arena batch of small graphs enqueues without a single device->host read: checked by
     making every synchronising call an error (torch.cuda.set_sync_debug_mode) around the step."""
