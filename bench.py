@@ -306,6 +306,30 @@ def family_b_leg(dev, steps=30):
         dt = time.perf_counter() - t0
         out[f"batch{batch}"] = {"circuits_per_s": round(batch * n_steps / dt, 1), "ms_per_step": round(dt / n_steps * 1e3, 3),
                                 "steps": n_steps}
+    # the same model on the headline workload's graphs (100-qubit circuits, 2-20 k nodes each): ASAPooling's coarsening takes the
+    # wave-per-cluster form there (mlqem_asap_coarsen_rows_*: no sort, one host read per pooling)
+    torch.cuda.reset_peak_memory_stats()
+    mem_before = torch.cuda.memory_allocated()
+    hb = TfimCorpus(100, list(range(1, 11)), 7, seed=42, exp_value_size=4).host_graphs()
+    big_arena = GraphArena.from_arrays(hb["x"], hb["edge_index"], hb["y"][:, None, :], hb["noisy"][:, None, :], hb["depth"],
+                                       hb["observable"], device=dev)
+    del hb
+    torch.manual_seed(0)
+    big_trainer = Trainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), lr=1e-3)
+    big_batch, big_steps = 64, max(4, steps // 3)
+    draw_big = lambda: rng.randint(0, len(big_arena), size=big_batch)
+    for _ in range(3):
+        big_trainer.step(big_arena.batch(draw_big()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(big_steps):
+        big_trainer.step(big_arena.batch(draw_big()))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["cfg4_100q_batch64"] = {"circuits_per_s": round(big_batch * big_steps / dt, 1), "ms_per_step": round(dt / big_steps * 1e3, 2),
+                                "steps": big_steps, "nodes_per_circuit": round(big_arena.num_nodes / len(big_arena)),
+                                "peak_mem_GB_above_the_rest_of_the_bench": round((torch.cuda.max_memory_allocated() - mem_before) / 1e9, 2)}
+    del big_trainer, big_arena
     # the CPU oracle doing the same step at the reference's batch size (bounded: 6 steps, the first one untimed)
     from oracle.models import FamilyB
 

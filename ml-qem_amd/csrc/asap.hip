@@ -245,84 +245,13 @@ struct RowsArgs {
   int Wn, Wk;                    // words of the node / cluster bitsets (batch maxima)
   uint32_t* bm; uint32_t* bmT;   // [K][Wk]: row p = clusters q (local index) with p -> q; bmT row q = sources p
   int32_t* outdeg; int32_t* indeg;   // [K + 1]
+  int Wb; int32_t* pref;         // [K][Wb]: set bits of row p in words < 32 j (rank lookups of the fill pass)
 };
 
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
-}
-
-__global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) {
-  extern __shared__ uint32_t s_bits[];              // per wave: X [Wn] then Y [Wk]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  uint32_t* X = s_bits + (size_t)wid * (a.Wn + a.Wk);
-  uint32_t* Y = X + a.Wn;
-  const int64_t p = (int64_t)blockIdx.x * 4 + wid;
-  const bool live = p < a.K;
-  for (int i = lane; i < a.Wn + a.Wk; i += 64) X[i] = 0u;
-  __syncthreads();
-  int c = 0, n0 = 0, k0 = 0, kg = 0;
-  if (live) {
-    c = a.perm[p];
-    int lo = 0, hi = a.B;                            // graph of cluster p: largest g with new_gptr[g] <= p
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)a.new_gptr[mid] <= p) lo = mid; else hi = mid; }
-    n0 = a.gptr[lo]; k0 = a.new_gptr[lo]; kg = a.new_gptr[lo + 1] - k0;
-    // X = N+[N-[c]]: lanes split the in-neighbours (and c itself, index -1)
-    const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
-    for (int i = ib - 1 + lane; i < ie; i += 64) {
-      const int u = i < ib ? c : a.in_src[i];
-      atomicOr(&X[(u - n0) >> 5], 1u << ((u - n0) & 31));
-      for (int e = a.out_ptr[u]; e < a.out_ptr[u + 1]; ++e) {
-        const int v = a.out_dst[e] - n0;
-        atomicOr(&X[v >> 5], 1u << (v & 31));
-      }
-    }
-  }
-  __syncthreads();
-  if (live) {
-    // Y = kept centres among N+[X], as local cluster indices, without p itself
-    for (int wi = lane; wi < a.Wn; wi += 64) {
-      uint32_t bits = X[wi];
-      while (bits) {
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        const int v = n0 + wi * 32 + b;
-        for (int e = a.out_ptr[v] - 1; e < a.out_ptr[v + 1]; ++e) {
-          const int w = e < a.out_ptr[v] ? v : a.out_dst[e];
-          const int q = a.slot[w];
-          if (q >= 0 && q != (int)p) atomicOr(&Y[(q - k0) >> 5], 1u << ((q - k0) & 31));
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (live) {
-    int cnt = 0;
-    const int pl = (int)(p - k0);
-    for (int wi = lane; wi < a.Wk; wi += 64) {
-      uint32_t bits = Y[wi];
-      a.bm[p * a.Wk + wi] = bits;
-      cnt += __popc(bits);
-      while (bits) {                                  // one global atomicOr per distinct edge p -> q
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        atomicOr(&a.bmT[(int64_t)(k0 + wi * 32 + b) * a.Wk + (pl >> 5)], 1u << (pl & 31));
-      }
-    }
-    cnt = wave_sum(cnt);
-    if (lane == 0) a.outdeg[p] = cnt;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void coarsen_rows_indeg_kernel(const RowsArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= a.K) return;
-  int cnt = 0;
-  for (int wi = lane; wi < a.Wk; wi += 64) cnt += __popc(a.bmT[q * a.Wk + wi]);
-  cnt = wave_sum(cnt);
-  if (lane == 0) a.indeg[q] = cnt;
 }
 
 // exclusive prefix over the wave of a per-lane count
@@ -334,6 +263,108 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
     if (lane >= o) s += t;
   }
   return s - v;
+}
+
+// LDS traffic of ONE wave on its own region: the LDS pipeline serves a wave's instructions in order, so a fence that keeps the
+// compiler from moving accesses across it (and waits for the returns) is all the synchronisation the phases below need --
+// no workgroup barrier, the four waves of a workgroup never wait for each other's clusters.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kRowsLight = 16;   // out-degree up to which a lane walks a node's edges alone
+
+// Every lane brings one node (or none); f(w) is called for the node itself and for every w in its out-neighbourhood.
+// Nodes with few edges are walked by their lane; the others one after the other by the whole wave (coalesced reads of
+// their adjacency) -- a hub cluster's reach is a few nodes with hundreds of edges each, which one lane would walk for
+// hundreds of dependent round trips while 63 wait.
+template <typename F>
+__device__ __forceinline__ void visit_closed_out(const RowsArgs& a, bool has, int node, int lane, F f) {
+  int eb = 0, ee = 0;
+  if (has) { eb = a.out_ptr[node]; ee = a.out_ptr[node + 1]; f(node); }
+  const bool heavy = has && ee - eb > kRowsLight;
+  if (has && !heavy)
+    for (int e = eb; e < ee; ++e) f(a.out_dst[e]);
+  unsigned long long todo = __ballot(heavy);
+  while (todo) {
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int b = __shfl(eb, owner), e = __shfl(ee, owner);
+    for (int i = b + lane; i < e; i += 64) f(a.out_dst[i]);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) {
+  extern __shared__ uint32_t s_bits[];              // per wave: X [Wn] then Y [Wk]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t* X = s_bits + (size_t)wid * (a.Wn + a.Wk);
+  uint32_t* Y = X + a.Wn;
+  const int64_t p = (int64_t)blockIdx.x * 4 + wid;
+  if (p >= a.K) return;                              // wave-uniform
+  for (int i = lane; i < a.Wn + a.Wk; i += 64) X[i] = 0u;
+  wave_lds_sync();
+  const int c = a.perm[p];
+  int lo = 0, hi = a.B;                              // graph of cluster p: largest g with new_gptr[g] <= p
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)a.new_gptr[mid] <= p) lo = mid; else hi = mid; }
+  const int n0 = a.gptr[lo], k0 = a.new_gptr[lo];
+  // X = N+[N-[c]] (node bits, local to the graph)
+  const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
+  for (int i0 = ib - 1; i0 < ie; i0 += 64) {         // index ib - 1 stands for c itself
+    const int i = i0 + lane;
+    const bool has = i < ie;
+    const int u = has ? (i < ib ? c : a.in_src[i]) : 0;
+    visit_closed_out(a, has, u, lane, [&](int v) { atomicOr(&X[(v - n0) >> 5], 1u << ((v - n0) & 31)); });
+  }
+  wave_lds_sync();
+  // Y = kept centres among N+[X] (cluster bits, local to the graph), without p itself
+  for (int w0 = 0; w0 < a.Wn; w0 += 64) {
+    const int wi = w0 + lane;
+    uint32_t bits = wi < a.Wn ? X[wi] : 0u;
+    while (__ballot(bits != 0u)) {                   // every lane offers its next node, if it has one left
+      const bool has = bits != 0u;
+      int v = 0;
+      if (has) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; v = n0 + wi * 32 + b; }
+      visit_closed_out(a, has, v, lane, [&](int w) {
+        const int q = a.slot[w];
+        if (q >= 0 && q != (int)p) atomicOr(&Y[(q - k0) >> 5], 1u << ((q - k0) & 31));
+      });
+    }
+  }
+  wave_lds_sync();
+  int cnt = 0;
+  const int pl = (int)(p - k0);
+  for (int wi = lane; wi < a.Wk; wi += 64) {
+    uint32_t bits = Y[wi];
+    a.bm[p * a.Wk + wi] = bits;
+    cnt += __popc(bits);
+    while (bits) {                                    // one global atomicOr per distinct edge p -> q
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      atomicOr(&a.bmT[(int64_t)(k0 + wi * 32 + b) * a.Wk + (pl >> 5)], 1u << (pl & 31));
+    }
+  }
+  cnt = wave_sum(cnt);
+  if (lane == 0) a.outdeg[p] = cnt;
+  for (int j0 = 0, run = 0; j0 < a.Wb; j0 += 64) {   // block prefix counts (blocks of 32 words) for the fill pass
+    const int j = j0 + lane;
+    int blk = 0;
+    if (j < a.Wb)
+      for (int w = 32 * j; w < min(32 * j + 32, a.Wk); ++w) blk += __popc(Y[w]);
+    const int ex = wave_excl_scan(blk, lane);
+    if (j < a.Wb) a.pref[p * a.Wb + j] = run + ex;
+    run += __shfl(ex + blk, 63);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_rows_indeg_kernel(const RowsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= a.K) return;
+  int cnt = 0;
+  for (int wi = lane; wi < a.Wk; wi += 64) cnt += __popc(a.bmT[q * a.Wk + wi]);
+  cnt = wave_sum(cnt);
+  if (lane == 0) a.indeg[q] = cnt;
 }
 
 __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArgs a, const int32_t* __restrict__ in_ptr_new,
@@ -378,8 +409,8 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArg
       const int64_t src = (int64_t)k0 + wi * 32 + b;
       in_src_new[pos] = (int32_t)src;
       const uint32_t* row = a.bm + src * a.Wk;       // rank of r inside row src of the out-CSR
-      int rank = __popc(row[wq] & below);
-      for (int w = 0; w < wq; ++w) rank += __popc(row[w]);
+      int rank = a.pref[src * a.Wb + (wq >> 5)] + __popc(row[wq] & below);
+      for (int w = wq & ~31; w < wq; ++w) rank += __popc(row[w]);
       out_eid_new[out_ptr_new[src] + rank] = pos;
       ++pos;
     }
@@ -561,17 +592,18 @@ extern "C" int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t
   return launch_status();
 }
 
-static void rows_layout(int64_t K, int kmax, size_t& bm, size_t& deg) {
-  const size_t Wk = (size_t)(kmax + 31) / 32;
+static void rows_layout(int64_t K, int kmax, size_t& bm, size_t& deg, size_t& pref) {
+  const size_t Wk = (size_t)(kmax + 31) / 32, Wb = (Wk + 31) / 32;
   bm = ((size_t)K * Wk * sizeof(uint32_t) + 255) / 256 * 256;
   deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
+  pref = ((size_t)K * Wb * sizeof(int32_t) + 255) / 256 * 256;
 }
 
 extern "C" size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax) {
   if (K < 0 || kmax < 0) return 0;
-  size_t bm, deg;
-  rows_layout(K, kmax, bm, deg);
-  return 2 * bm + 2 * deg + dense_scan_bytes(K);
+  size_t bm, deg, pref;
+  rows_layout(K, kmax, bm, deg, pref);
+  return 2 * bm + 2 * deg + pref + dense_scan_bytes(K);
 }
 
 extern "C" int mlqem_asap_coarsen_rows_max_bits(void) { return 64 * 1024 * 8 / 4; }   // (n_g + k_g) bits per wave: 64 KB of LDS, four waves
@@ -579,12 +611,13 @@ extern "C" int mlqem_asap_coarsen_rows_max_bits(void) { return 64 * 1024 * 8 / 4
 static bool rows_args(RowsArgs& a, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                       const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, const int32_t* slot,
                       int64_t K, int64_t B, int nmax, int kmax, void* workspace) {
-  size_t bm, deg;
-  rows_layout(K, kmax, bm, deg);
+  size_t bm, deg, pref;
+  rows_layout(K, kmax, bm, deg, pref);
   char* ws = static_cast<char*>(workspace);
-  a = RowsArgs{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, K, (nmax + 31) / 32, (kmax + 31) / 32,
+  const int Wk = (kmax + 31) / 32;
+  a = RowsArgs{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, K, (nmax + 31) / 32, Wk,
                reinterpret_cast<uint32_t*>(ws), reinterpret_cast<uint32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + 2 * bm),
-               reinterpret_cast<int32_t*>(ws + 2 * bm + deg)};
+               reinterpret_cast<int32_t*>(ws + 2 * bm + deg), (Wk + 31) / 32, reinterpret_cast<int32_t*>(ws + 2 * bm + 2 * deg)};
   return true;
 }
 
@@ -610,8 +643,8 @@ extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_
   if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm) return MLQEM_ERR_BAD_ARG;
   RowsArgs a;
   rows_args(a, in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, K, B, nmax, kmax, workspace);
-  size_t bm, deg;
-  rows_layout(K, kmax, bm, deg);
+  size_t bm, deg, pref;
+  rows_layout(K, kmax, bm, deg, pref);
   if (hipMemsetAsync(a.bmT, 0, bm, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
   if (hipMemsetAsync(a.outdeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
   if (hipMemsetAsync(a.indeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
@@ -620,7 +653,7 @@ extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_
   const unsigned grid = (unsigned)ceil_div(K, (int64_t)4);
   hipLaunchKernelGGL(coarsen_rows_kernel, dim3(grid), dim3(kBlock), lds, stream, a);
   hipLaunchKernelGGL(coarsen_rows_indeg_kernel, dim3(grid), dim3(kBlock), 0, stream, a);
-  void* temp = static_cast<char*>(workspace) + 2 * bm + 2 * deg;
+  void* temp = static_cast<char*>(workspace) + 2 * bm + 2 * deg + pref;
   size_t temp_bytes = dense_scan_bytes(K);
   if (rocprim::exclusive_scan(temp, temp_bytes, a.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
                               stream) != hipSuccess)
