@@ -76,6 +76,21 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int ob = 0; ob < OBT; ++ob) acc[ob] = mfma16x16x4(af[ks], wf[ob][ks], acc[ob]);
+    // every load of the epilogue before its first store (vmcnt is one in-order counter for loads and stores on gfx9: a
+    // load behind a store is waited for by draining that store)
+    float prev[OBT][4], gt[OBT][4], rs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = n0 + lq * 4 + r;
+      rs[r] = (a.rowscale && row < a.N) ? a.rowscale[row] : 1.f;
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob) {
+        const int o = (ob0 + ob) * 16 + lr;
+        const bool ok = o < a.O && row < a.N;
+        prev[ob][r] = (a.accumulate && ok) ? a.y[row * a.ldy + o] : 0.f;
+        gt[ob][r] = (a.gate && ok) ? a.gate[row * a.ldgate + o] : 1.f;
+      }
+    }
 #pragma unroll
     for (int ob = 0; ob < OBT; ++ob) {
       const int o = (ob0 + ob) * 16 + lr;
@@ -86,14 +101,14 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(const LinArgs a) {
         if (row >= a.N) continue;
         float* dst = a.y + row * a.ldy + o;
         float v = acc[ob][r] + bias[ob];
-        if (a.accumulate) v += *dst;
-        if (a.rowscale && o < a.rs_cols) v *= a.rowscale[row];
+        if (a.accumulate) v += prev[ob][r];
+        if (a.rowscale && o < a.rs_cols) v *= rs[r];
         if (o >= a.act_from) {
           if (a.act & 1) v = fmaxf(v, 0.f);
           if (a.drop_p > 0.f)
             v = uniform01(a.seed, (uint64_t)(row * a.O + o)) < a.drop_p ? 0.f : v * (1.f / (1.f - a.drop_p));
         }
-        if (a.gate) v = a.gate[row * a.ldgate + o] > 0.f ? v * a.gate_scale : 0.f;
+        if (a.gate) v = gt[ob][r] > 0.f ? v * a.gate_scale : 0.f;
         *dst = v;
       }
     }
@@ -180,16 +195,20 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
     }
     if (!row_ok) continue;
     const float rscale = a.rowscale ? a.rowscale[row] : 1.f;
+    // the accumulate operands of ALL tiles before the first store (a load behind a store drains it: one in-order vmcnt)
+    float4 pv[OBT];
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob) {
+      const int o0 = (ob0 + ob) * 16 + lq * 4;
+      pv[ob] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.accumulate && o0 < a.O) pv[ob] = *reinterpret_cast<const float4*>(a.y + row * a.ldy + o0);
+    }
 #pragma unroll
     for (int ob = 0; ob < OBT; ++ob) {
       const int o0 = (ob0 + ob) * 16 + lq * 4;
       if (o0 >= a.O) continue;
       float* dst = a.y + row * a.ldy + o0;   // padded output rows (host checked): always one float4, pads are scratch
-      float prev[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.accumulate) {
-        const float4 p = *reinterpret_cast<const float4*>(dst);
-        prev[0] = p.x; prev[1] = p.y; prev[2] = p.z; prev[3] = p.w;
-      }
+      const float prev[4] = {pv[ob].x, pv[ob].y, pv[ob].z, pv[ob].w};
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
