@@ -1,4 +1,5 @@
-"""Family B train steps on cfg2 (4-qubit TFIM graphs) for rocprofv3: `python scripts/profile_family_b.py [batch] [steps]`."""
+"""Family B train steps for rocprofv3: `python scripts/profile_family_b.py [batch] [steps] [qubits]` -- cfg2 (4-qubit TFIM graphs) by
+default, qubits = 100 for the headline graphs (cfg4: 100-qubit circuits, Trotter steps 1-10)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
@@ -9,7 +10,9 @@ from blackwater.nn import ExpValCircuitGraphModel
 from blackwater.train import Trainer
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-corpus = TfimCorpus(4, list(range(15)), 70, seed=42, two_q="cx", exp_value_size=4)
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+corpus = (TfimCorpus(4, list(range(15)), 70, seed=42, two_q="cx", exp_value_size=4) if nq == 4
+          else TfimCorpus(nq, list(range(1, 11)), 7, seed=42, exp_value_size=4))
 h = corpus.host_graphs()
 arena = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"], device="cuda:0")
 torch.manual_seed(0)
