@@ -450,6 +450,8 @@ def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
 _ASAP_DENSE = os.environ.get("MLQEM_ASAP_DENSE", "1") != "0"
 # MLQEM_ASAP_ROWS=0 keeps the two-hop path for graphs too large for the dense form (default: the wave-per-cluster form)
 _ASAP_ROWS = os.environ.get("MLQEM_ASAP_ROWS", "1") != "0"
+# MLQEM_ASAP_LAZY=0 computes the coarsened connectivity inside ASAPooling's forward even when no later layer reads it
+_ASAP_LAZY = os.environ.get("MLQEM_ASAP_LAZY", "1") != "0"
 
 
 class _ASAPool(Function):
@@ -480,22 +482,35 @@ class _ASAPool(Function):
         new_ptr = torch.from_numpy(new_ptr_host.astype(np.int32)).to(x.device, non_blocking=True)
         perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total)
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
-        dense_ok = _ASAP_DENSE and len(keep) > 0 and int(keep.max()) <= ops.asap_dense_max_k()
-        if dense_ok:
-            # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
-            csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
-            num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
-        elif (_ASAP_ROWS and len(keep) > 0
-              and int(sizes.max()) + int(keep.max()) + 64 <= ops.asap_rows_max_bits()):
-            # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)
-            csr, slot, num_edges = ops.asap_coarsen_rows(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n,
-                                                         sizes, keep)
+        use_dense, use_rows = _ASAP_DENSE, _ASAP_ROWS       # the switches as they stand now: build() may run later
+
+        def build():
+            dense_ok = use_dense and len(keep) > 0 and int(keep.max()) <= ops.asap_dense_max_k()
+            if dense_ok:
+                # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
+                csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
+                num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
+            elif (use_rows and len(keep) > 0
+                  and int(sizes.max()) + int(keep.max()) + 64 <= ops.asap_rows_max_bits()):
+                # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)
+                csr, slot, num_edges = ops.asap_coarsen_rows(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm,
+                                                             n, sizes, keep)
+            else:
+                ei, slot = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n, return_slot=True)
+                csr = ops.csr_build(ei, k_total)
+                num_edges = int(ei.shape[1])
+            return (csr[0], csr[1], csr[2], csr[3], csr[4], num_edges, csr.out_eid), slot
+
+        if _ASAP_LAZY:
+            # the coarsened connectivity S^T A S waits until a layer reads it (GraphStructure.deferred); the backward's
+            # slot[] (cluster id of every kept centre, -1 elsewhere) does not depend on it
+            slot = torch.full((max(n, 1),), -1, dtype=torch.int32, device=x.device)
+            slot[perm.long()] = torch.arange(k_total, dtype=torch.int32, device=x.device)
+            holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=keep)
         else:
-            ei, slot = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n, return_slot=True)
-            csr = ops.csr_build(ei, k_total)
-            num_edges = int(ei.shape[1])
-        holder["structure"] = GraphStructure(k_total, csr[0], csr[1], csr[2], csr[3], csr[4], new_ptr, s.num_graphs,
-                                             num_edges=num_edges, graph_sizes=keep, out_eid=csr.out_eid)
+            csr7, slot = build()
+            holder["structure"] = GraphStructure(k_total, csr7[0], csr7[1], csr7[2], csr7[3], csr7[4], new_ptr, s.num_graphs,
+                                                 num_edges=csr7[5], graph_sizes=keep, out_eid=csr7[6])
         holder["perm"] = perm
         ctx.struct, ctx.slope, ctx.d = s, slope, d
         ctx.save_for_backward(x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3)

@@ -12,6 +12,9 @@ import torch
 from . import ops
 
 
+_CSR_FIELDS = ("in_ptr", "in_src", "out_ptr", "out_dst", "loops", "num_edges", "out_eid")
+
+
 class GraphStructure:
     def __init__(self, num_nodes, in_ptr, in_src, out_ptr, out_dst, loops, graph_ptr, num_graphs, num_edges=None,
                  norms=None, graph_sizes=None, out_eid=None, ell=None, colsums=None, derived=None):
@@ -20,6 +23,36 @@ class GraphStructure:
         self.graph_ptr, self.num_graphs = graph_ptr, int(num_graphs)
         self.num_edges = num_edges  # non-self-loop edges, host int when known without a sync
         self.out_eid = out_eid      # in-CSR position of every out-CSR entry (edge-softmax backward)
+        self._init_rest(norms, graph_sizes, ell, colsums, derived)
+
+    @classmethod
+    def deferred(cls, num_nodes, graph_ptr, num_graphs, build, graph_sizes=None) -> "GraphStructure":
+        """A structure whose CONNECTIVITY is built on first use: ``build()`` returns (in_ptr, in_src, out_ptr, out_dst, loops,
+        num_edges, out_eid) and runs when one of those attributes is first read.  Graph boundaries and sizes are there at
+        once.  ASAPooling hands its coarsened graph back this way: every model of the reference follows its second pooling
+        with ``global_mean_pool`` (docs/tutorials/gnn.py:112-114), which reads the boundaries only, so the second coarsening
+        -- the most expensive kernel of a step on 100-qubit circuits -- is never computed unless someone looks at it."""
+        self = cls.__new__(cls)
+        self.num_nodes = int(num_nodes)
+        self.graph_ptr, self.num_graphs = graph_ptr, int(num_graphs)
+        self._build = build
+        self._init_rest(None, graph_sizes, None, None, None)
+        return self
+
+    def __getattr__(self, name):
+        # only reached for attributes that are not set: the connectivity of a deferred structure
+        if name in _CSR_FIELDS and "_build" in self.__dict__:
+            build = self.__dict__.pop("_build")
+            for key, val in zip(_CSR_FIELDS, build()):
+                self.__dict__[key] = val
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    @property
+    def connectivity_built(self) -> bool:
+        return "_build" not in self.__dict__
+
+    def _init_rest(self, norms, graph_sizes, ell, colsums, derived):
         self._norms = norms
         self._derived = {} if derived is None else dict(derived)
         self._colsum = {} if colsums is None else dict(zip(("gcn", "sage", "cheb"), colsums))

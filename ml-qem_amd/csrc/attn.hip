@@ -64,11 +64,54 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const float* _
 #pragma unroll
     for (int e = 0; e < kAttnShortRow; ++e) if (e == deg && n_self > 0) add_p(row, expf(sc[e] - m) * (float)n_self);
   } else {
+    // long rows in chunks (for_edge_chunks, common.hpp): same expressions in the same order as one edge at a time
     // pass 1: segment max
-    for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
+    for_edge_chunks(beg, end, [&](int e, auto kc) {
+      constexpr int K = decltype(kc)::value;
+      int64_t jj[K];
+      float k0[K], k1[K];
+#pragma unroll
+      for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
+        k0[u] = c0 ? kj[l] : 0.f;
+        k1[u] = c1 ? kj[l + kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        float s = q0 * k0[u];
+        if (c1) s = fmaf(q1, k1[u], s);
+        m = fmaxf(m, group16_sum(s) * scale);
+      }
+    });
     if (n_self > 0) m = fmaxf(m, score(row));
     // pass 2: exp, sum, weighted value sum
-    for (int e = beg; e < end; ++e) add_p(idx[e], expf(score(idx[e]) - m) * 1.f);
+    for_edge_chunks(beg, end, [&](int e, auto kc) {
+      constexpr int K = decltype(kc)::value;
+      int64_t jj[K];
+      float k0[K], k1[K], v0[K], v1[K];
+#pragma unroll
+      for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
+        const float* __restrict__ vj = qkvs + jj[u] * ld + 2 * HC + h * C;
+        k0[u] = c0 ? kj[l] : 0.f;
+        k1[u] = c1 ? kj[l + kGroup] : 0.f;
+        v0[u] = c0 ? vj[l] : 0.f;
+        v1[u] = c1 ? vj[l + kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        float s = q0 * k0[u];
+        if (c1) s = fmaf(q1, k1[u], s);
+        const float p = expf(group16_sum(s) * scale - m) * 1.f;
+        denom += p;
+        if (c0) a0 = fmaf(p, v0[u], a0);
+        if (c1) a1 = fmaf(p, v1[u], a1);
+      }
+    });
     if (n_self > 0) add_p(row, expf(score(row) - m) * (float)n_self);
   }
   const float inv = 1.0f / (denom + 1e-16f);
@@ -97,14 +140,36 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_kernel(const float* 
   const float ai = a_dst[row];
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
   float m = leaky(ai + c_src[row]);  // the self-loop is always there
-  for (int e = beg; e < end; ++e) m = fmaxf(m, leaky(ai + c_src[idx[e]]));
+  for_edge_chunks(beg, end, [&](int e, auto kc) {        // chunks of edges fetched together, used in edge order (common.hpp)
+    constexpr int K = decltype(kc)::value;
+    int jj[K];
+    float cj[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+    for (int u = 0; u < K; ++u) cj[u] = c_src[jj[u]];
+#pragma unroll
+    for (int u = 0; u < K; ++u) m = fmaxf(m, leaky(ai + cj[u]));
+  });
   float denom = 0.f, acc = 0.f;
-  for (int e = beg; e < end; ++e) {
-    const int j = idx[e];
-    const float p = expf(leaky(ai + c_src[j]) - m);
-    denom += p;
-    acc = fmaf(p, x[(int64_t)j * ldx + ch], acc);
-  }
+  for_edge_chunks(beg, end, [&](int e, auto kc) {
+    constexpr int K = decltype(kc)::value;
+    int jj[K];
+    float cj[K], xj[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      cj[u] = c_src[jj[u]];
+      xj[u] = x[(int64_t)jj[u] * ldx + ch];
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const float p = expf(leaky(ai + cj[u]) - m);
+      denom += p;
+      acc = fmaf(p, xj[u], acc);
+    }
+  });
   {
     const float p = expf(leaky(ai + c_src[row]) - m);  // self-loop last, as appended by add_remaining_self_loops
     denom += p;
@@ -125,7 +190,14 @@ __global__ __launch_bounds__(kBlock) void leconv_fitness_kernel(const float* __r
   const int beg = ptr[i], end = ptr[i + 1];
   const float qi = pqr[i * 3 + 1];
   float s = 0.f;
-  for (int e = beg; e < end; ++e) s += pqr[(int64_t)idx[e] * 3] - qi;  // message a_j - b_i, summed in edge order
+  for_edge_chunks(beg, end, [&](int e, auto kc) {                        // message a_j - b_i, summed in edge order
+    constexpr int K = decltype(kc)::value;
+    float pj[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) pj[u] = pqr[(int64_t)idx[e + u] * 3];
+#pragma unroll
+    for (int u = 0; u < K; ++u) s += pj[u] - qi;
+  });
   s += pqr[i * 3] - qi;                                                 // the self-loop
   s += pqr[i * 3 + 2];
   fitness[i] = 1.0f / (1.0f + expf(-s));

@@ -113,6 +113,20 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// Rows are walked in chunks of 8 / 4 / 2 / 1 edges: a chunk's index entries, then all of its source rows, are fetched
+// before the first one is used, so a row of the coarsened graph of a 100-qubit circuit (100-500 edges) costs deg / 8
+// dependent round trips instead of deg, and a two-edge row of a circuit DAG one instead of two.  The callback gets the
+// first edge of the chunk and its size as a type (EdgeChunk<K>); it must consume the fetched values in edge order, so that
+// every sum is the sum a one-edge-at-a-time loop forms, bit for bit.
+template <int K> struct EdgeChunk { static constexpr int value = K; };
+template <class F> __device__ __forceinline__ void for_edge_chunks(int beg, int end, F&& f) {
+  int e = beg;
+  for (; e + 8 <= end; e += 8) f(e, EdgeChunk<8>{});
+  if (e + 4 <= end) { f(e, EdgeChunk<4>{}); e += 4; }
+  if (e + 2 <= end) { f(e, EdgeChunk<2>{}); e += 2; }
+  if (e < end) f(e, EdgeChunk<1>{});
+}
+
 __device__ __forceinline__ bool aligned_to_dev(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace mlqem

@@ -3,6 +3,8 @@
 // buffers in in-CSR order, plus the gradients that are sums over a destination's in-edges) and a source-side pass
 // (gradients that are sums over a source's out-edges, read through `out_eid`, the in-CSR position of each
 // out-CSR entry).  No atomics: every gradient row is written once, in a fixed order.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mlqem {
@@ -75,12 +77,46 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(
     for (int e = 0; e < kAttnShort; ++e) if (e < deg) add_p(jj[e], expf(sc[e] - m) / denom * 1.f, beg + e);
     if (n_self > 0) add_p(row, p_self / denom * (float)n_self, E + row);
   } else {
-    for (int e = beg; e < end; ++e) m = fmaxf(m, score(idx[e]));
+    // long rows in chunks (for_edge_chunks, common.hpp): same expressions in the same order as one edge at a time.
+    // `use(edge, score, v0, v1)` sees the chunk's scores in edge order; `with_values` also fetches the value rows.
+    auto walk = [&](auto with_values, auto&& use) {
+      for_edge_chunks(beg, end, [&](int e, auto kc) {
+        constexpr int K = decltype(kc)::value;
+        constexpr bool kValues = decltype(with_values)::value;
+        int64_t jj[K];
+        float k0[K], k1[K], v0[kValues ? K : 1], v1[kValues ? K : 1];
+#pragma unroll
+        for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
+          k0[u] = c0 ? kj[l] : 0.f;
+          k1[u] = c1 ? kj[l + kGroup] : 0.f;
+          if constexpr (kValues) {
+            const float* __restrict__ vj = qkvs + jj[u] * ld + 2 * HC + h * C;
+            v0[u] = c0 ? vj[l] : 0.f;
+            v1[u] = c1 ? vj[l + kGroup] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          float s = q0 * k0[u];
+          if (c1) s = fmaf(q1, k1[u], s);
+          use(e + u, group16_sum(s) * scale, kValues ? v0[u] : 0.f, kValues ? v1[u] : 0.f);
+        }
+      });
+    };
+    walk(std::false_type{}, [&](int, float sc, float, float) { m = fmaxf(m, sc); });
     if (n_self > 0) m = fmaxf(m, score(row));
-    for (int e = beg; e < end; ++e) denom += expf(score(idx[e]) - m);
+    walk(std::false_type{}, [&](int, float sc, float, float) { denom += expf(sc - m); });
     if (n_self > 0) denom += expf(score(row) - m) * (float)n_self;
     denom += 1e-16f;
-    for (int e = beg; e < end; ++e) add_p(idx[e], expf(score(idx[e]) - m) / denom * 1.f, e);
+    walk(std::true_type{}, [&](int e, float sc, float v0, float v1) {
+      float a = expf(sc - m) / denom * 1.f;
+      if (drop_p > 0.f) a = uniform01(seed, (uint64_t)((int64_t)e * H + h)) < drop_p ? 0.f : a * keep;
+      if (c0) a0 = fmaf(a, v0, a0);
+      if (c1) a1 = fmaf(a, v1, a1);
+    });
     if (n_self > 0) add_p(row, expf(score(row) - m) / denom * (float)n_self, E + row);
   }
   const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
@@ -119,12 +155,9 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(
   const float m = stat_m[row * H + h], den = stat_den[row * H + h];
   const int beg = ptr[row], end = ptr[row + 1];
   const int n_self = loops ? loops[row] : 0;
-  auto visit = [&](int64_t j, float mult, int64_t pos) {
-    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
-    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
-    const float k0 = c0 ? kj[l] : 0.f, k1 = c1 ? kj[l + kGroup] : 0.f;
-    float s = q0 * k0, gv = gi0 * (c0 ? vj[l] : 0.f);
-    if (c1) { s = fmaf(q1, k1, s); gv = fmaf(gi1, vj[l + kGroup], gv); }
+  auto use = [&](float k0, float k1, float v0, float v1, float mult, int64_t pos) {
+    float s = q0 * k0, gv = gi0 * v0;
+    if (c1) { s = fmaf(q1, k1, s); gv = fmaf(gi1, v1, gv); }
     s = group16_sum(s);
     gv = group16_sum(gv);
     const float alpha = expf(s * scale - m) / den * mult;  // softmax weight (all copies of a repeated self-loop)
@@ -138,7 +171,29 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(
     gq0 = fmaf(gs, k0, gq0);
     gq1 = fmaf(gs, k1, gq1);
   };
-  for (int e = beg; e < end; ++e) visit(idx[e], 1.f, e);
+  auto visit = [&](int64_t j, float mult, int64_t pos) {
+    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
+    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
+    use(c0 ? kj[l] : 0.f, c1 ? kj[l + kGroup] : 0.f, c0 ? vj[l] : 0.f, c1 ? vj[l + kGroup] : 0.f, mult, pos);
+  };
+  for_edge_chunks(beg, end, [&](int e, auto kc) {      // chunks of edges fetched together, used in edge order (common.hpp)
+    constexpr int K = decltype(kc)::value;
+    int64_t jj[K];
+    float k0[K], k1[K], v0[K], v1[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
+      const float* __restrict__ vj = qkvs + jj[u] * ld + 2 * HC + h * C;
+      k0[u] = c0 ? kj[l] : 0.f;
+      k1[u] = c1 ? kj[l + kGroup] : 0.f;
+      v0[u] = c0 ? vj[l] : 0.f;
+      v1[u] = c1 ? vj[l + kGroup] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) use(k0[u], k1[u], v0[u], v1[u], 1.f, e + u);
+  });
   if (n_self > 0) visit(row, (float)n_self, E + row);
   else if (l == 0) { edge_al[(E + row) * H + h] = 0.f; edge_gs[(E + row) * H + h] = 0.f; }
   if (c0) { gqkvs[row * ldq + o0] = gq0; gqkvs[row * ldq + 3 * HC + o0] = gi0; }
@@ -165,7 +220,30 @@ __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_kernel(
     if (c0) { gk0 = fmaf(gs, qkvs[i * ld + o0], gk0); gv0 = fmaf(al, g[i * ldg + o0], gv0); }
     if (c1) { gk1 = fmaf(gs, qkvs[i * ld + o1], gk1); gv1 = fmaf(al, g[i * ldg + o1], gv1); }
   };
-  for (int e = optr[row]; e < optr[row + 1]; ++e) visit(odst[e], oeid[e]);
+  for_edge_chunks(optr[row], optr[row + 1], [&](int e, auto kc) {     // chunks fetched together, used in edge order
+    constexpr int K = decltype(kc)::value;
+    int64_t ii[K], pp[K];
+    float gs[K], al[K], qa[K], qb[K], ga[K], gb[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      ii[u] = odst[e + u];
+      pp[u] = oeid[e + u];
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      gs[u] = edge_gs[pp[u] * H + h];
+      al[u] = edge_al[pp[u] * H + h];
+      qa[u] = c0 ? qkvs[ii[u] * ld + o0] : 0.f;
+      qb[u] = c1 ? qkvs[ii[u] * ld + o1] : 0.f;
+      ga[u] = c0 ? g[ii[u] * ldg + o0] : 0.f;
+      gb[u] = c1 ? g[ii[u] * ldg + o1] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      if (c0) { gk0 = fmaf(gs[u], qa[u], gk0); gv0 = fmaf(al[u], ga[u], gv0); }
+      if (c1) { gk1 = fmaf(gs[u], qb[u], gk1); gv1 = fmaf(al[u], gb[u], gv1); }
+    }
+  });
   visit(row, E + row);
   if (c0) { gqkvs[row * ldq + HC + o0] = gk0; gqkvs[row * ldq + 2 * HC + o0] = gv0; }
   if (c1) { gqkvs[row * ldq + HC + o1] = gk1; gqkvs[row * ldq + 2 * HC + o1] = gv1; }
@@ -186,22 +264,33 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
   const int beg = ptr[row], end = ptr[row + 1];
   const float ai = a_dst[row];
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  // rows are walked in chunks of edges fetched together (for_edge_chunks, common.hpp); every sum runs in edge order
+  auto walk_c = [&](auto&& use) {
+    for_edge_chunks(beg, end, [&](int e, auto kc) {
+      constexpr int K = decltype(kc)::value;
+      int jj[K];
+      float cj[K];
+#pragma unroll
+      for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+      for (int u = 0; u < K; ++u) cj[u] = c_src[jj[u]];
+#pragma unroll
+      for (int u = 0; u < K; ++u) use(cj[u]);
+    });
+  };
   float m = leaky(ai + c_src[row]);
-  for (int e = beg; e < end; ++e) m = fmaxf(m, leaky(ai + c_src[idx[e]]));
+  walk_c([&](float cj) { m = fmaxf(m, leaky(ai + cj)); });
   float den = expf(leaky(ai + c_src[row]) - m);
-  for (int e = beg; e < end; ++e) den += expf(leaky(ai + c_src[idx[e]]) - m);
+  walk_c([&](float cj) { den += expf(leaky(ai + cj) - m); });
   den += 1e-16f;
   const float* __restrict__ gi = gnew + row * ldg;
   float d = 0.f;
   for (int c = l; c < C; c += kGroup) d = fmaf(gi[c], xnew[row * ldn + c], d);
   const float delta = group16_sum(d);
   float ga = 0.f;
-  auto visit = [&](int64_t j, int64_t pos) {
-    const float pre = ai + c_src[j];
+  auto use = [&](float cjv, float dot, int64_t pos) {
+    const float pre = ai + cjv;
     const float al = expf(leaky(pre) - m) / den;
-    const float* __restrict__ xj = x + j * ldx;
-    float dot = 0.f;
-    for (int c = l; c < C; c += kGroup) dot = fmaf(gi[c], xj[c], dot);
     dot = group16_sum(dot);
     const float gp = al * (dot - delta) * (pre > 0.f ? 1.f : slope);
     if (l == 0) {
@@ -210,7 +299,39 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
     }
     ga += gp;
   };
-  for (int e = beg; e < end; ++e) visit(idx[e], e);
+  auto visit = [&](int64_t j, int64_t pos) {
+    const float* __restrict__ xj = x + j * ldx;
+    float dot = 0.f;
+    for (int c = l; c < C; c += kGroup) dot = fmaf(gi[c], xj[c], dot);
+    use(c_src[j], dot, pos);
+  };
+  if (C <= 2 * kGroup) {
+    const bool c0 = l < C, c1 = l + kGroup < C;
+    const float g0 = c0 ? gi[l] : 0.f, g1 = c1 ? gi[l + kGroup] : 0.f;
+    for_edge_chunks(beg, end, [&](int e, auto kc) {
+      constexpr int K = decltype(kc)::value;
+      int64_t jj[K];
+      float cj[K], x0[K], x1[K];
+#pragma unroll
+      for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        const float* __restrict__ xj = x + jj[u] * ldx;
+        cj[u] = c_src[jj[u]];
+        x0[u] = c0 ? xj[l] : 0.f;
+        x1[u] = c1 ? xj[l + kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        float dot = 0.f;                 // the same fmaf chain as visit(): channels l, l + 16
+        if (c0) dot = fmaf(g0, x0[u], dot);
+        if (c1) dot = fmaf(g1, x1[u], dot);
+        use(cj[u], dot, e + u);
+      }
+    });
+  } else {
+    for (int e = beg; e < end; ++e) visit(idx[e], e);
+  }
   visit(row, E + row);
   if (l == 0) g_a[row] = ga;
 }
@@ -226,11 +347,28 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
   const int ch = (int)(t - row * C);
   float acc = edge_al[E + row] * gnew[row * ldg + ch];
   float gc = edge_gp[E + row];
-  for (int e = optr[row]; e < optr[row + 1]; ++e) {
-    const int pos = oeid[e];
-    acc = fmaf(edge_al[pos], gnew[(int64_t)odst[e] * ldg + ch], acc);
-    gc += edge_gp[pos];
-  }
+  for_edge_chunks(optr[row], optr[row + 1], [&](int e, auto kc) {     // chunks fetched together, used in edge order
+    constexpr int K = decltype(kc)::value;
+    int pos[K];
+    int64_t ii[K];
+    float al[K], gp[K], gn[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      pos[u] = oeid[e + u];
+      ii[u] = odst[e + u];
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      al[u] = edge_al[pos[u]];
+      gp[u] = edge_gp[pos[u]];
+      gn[u] = gnew[ii[u] * ldg + ch];
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      acc = fmaf(al[u], gn[u], acc);
+      gc += gp[u];
+    }
+  });
   float* d = gx + row * ldgx + ch;
   *d = accumulate ? *d + acc : acc;
   if (ch == 0) g_c[row] = gc;
@@ -250,7 +388,14 @@ __global__ __launch_bounds__(kBlock) void segment_max_share_kernel(
   const int ch = (int)(t - row * C);
   const float m = xmax[row * ldm + ch];
   int cnt = x[row * ldx + ch] == m ? 1 : 0;
-  for (int e = iptr[row]; e < iptr[row + 1]; ++e) cnt += x[(int64_t)isrc[e] * ldx + ch] == m ? 1 : 0;
+  for_edge_chunks(iptr[row], iptr[row + 1], [&](int e, auto kc) {     // chunks of edges fetched together (common.hpp)
+    constexpr int K = decltype(kc)::value;
+    float xs[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) xs[u] = x[(int64_t)isrc[e + u] * ldx + ch];
+#pragma unroll
+    for (int u = 0; u < K; ++u) cnt += xs[u] == m ? 1 : 0;
+  });
   gshare[row * lds + ch] = gmax[row * ldg + ch] / (float)(cnt > 0 ? cnt : 1);
 }
 
@@ -265,10 +410,18 @@ __global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
   const int ch = (int)(t - row * C);
   const float v = x[row * ldx + ch];
   float acc = (v == xmax[row * ldm + ch]) ? gmax[row * ldg + ch] : 0.f;
-  for (int e = optr[row]; e < optr[row + 1]; ++e) {
-    const int64_t i = odst[e];
-    if (v == xmax[i * ldm + ch]) acc += gmax[i * ldg + ch];
-  }
+  for_edge_chunks(optr[row], optr[row + 1], [&](int e, auto kc) {     // chunks fetched together, used in edge order
+    constexpr int K = decltype(kc)::value;
+    float xm[K], gm[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const int64_t i = odst[e + u];
+      xm[u] = xmax[i * ldm + ch];
+      gm[u] = gmax[i * ldg + ch];
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) if (v == xm[u]) acc += gm[u];
+  });
   gx[row * ldgx + ch] += acc;
 }
 
@@ -307,7 +460,14 @@ __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
   auto graw = [&](int64_t i) { const float f = fitness[i]; return gfit[i] * f * (1.f - f); };
   const float gj = graw(j);
   float gp = gj;
-  for (int e = optr[j]; e < optr[j + 1]; ++e) gp += graw(odst[e]);
+  for_edge_chunks(optr[j], optr[j + 1], [&](int e, auto kc) {         // chunks fetched together, used in edge order
+    constexpr int K = decltype(kc)::value;
+    float gr[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) gr[u] = graw(odst[e + u]);
+#pragma unroll
+    for (int u = 0; u < K; ++u) gp += gr[u];
+  });
   gpqr[j * 3] = gp;
   gpqr[j * 3 + 1] = -(float)(iptr[j + 1] - iptr[j] + 1) * gj;
   gpqr[j * 3 + 2] = gj;
