@@ -2,123 +2,15 @@
 // ASAPooling's attention-weighted cluster sum.  Both are "softmax over the in-edges of a row, then a weighted sum
 // of source rows"; the softmax statistics of a row are recomputed by each thread that needs them (rows have a
 // handful of in-edges), which keeps the kernels free of any [E]-sized intermediate.
+#include "attn_fwd.hpp"
 #include "common.hpp"
 
 namespace mlqem {
 
-constexpr int kAttnMaxC = 32;  // channels per head held in registers (reference models: 15 and 25)
-constexpr int kAttnShortRow = 6;   // in-edges (+ self) of a row whose scores are kept in registers
-
-// TransformerConv (heads=H, concat, root_weight, no edge features).
-// qkvs: [N, 4*H*C] = [query | key | value | skip] as produced by one fused projection.
-// One 16-lane group = (row, head); lane l holds channels l and l + 16 (C <= 32), so a key/value row segment is one
-// coalesced 64-byte read and q.k is a cross-lane sum.  Edge order: the row's CSR entries, then its self-loop(s) -- the
-// order PyG's scatter sees.
-__global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const float* __restrict__ qkvs, int64_t ld,
-                                                                  const int32_t* __restrict__ ptr,
-                                                                  const int32_t* __restrict__ idx,
-                                                                  const int32_t* __restrict__ loops, int64_t N, int H,
-                                                                  int C, float* __restrict__ out, int64_t ldo) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
-  const int l = threadIdx.x % kGroup;
-  if (t >= N * H) return;                       // a whole group leaves together
-  const int64_t row = t / H;
-  const int h = (int)(t - row * H);
-  const int HC = H * C;
-  const float scale = 1.0f / sqrtf((float)C);
-  const bool c0 = l < C, c1 = l + kGroup < C;
-  const float* __restrict__ qi = qkvs + row * ld + h * C;
-  const float q0 = c0 ? qi[l] : 0.f, q1 = c1 ? qi[l + kGroup] : 0.f;
-
-  const int beg = ptr[row], end = ptr[row + 1];
-  const int n_self = loops ? loops[row] : 0;
-  auto score = [&](int64_t j) {
-    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
-    float s = q0 * (c0 ? kj[l] : 0.f);
-    if (c1) s = fmaf(q1, kj[l + kGroup], s);
-    return group16_sum(s) * scale;
-  };
-  float m = -INFINITY;
-  float a0 = 0.f, a1 = 0.f, denom = 0.f;
-  auto add_p = [&](int64_t j, float p) {
-    denom += p;
-    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
-    if (c0) a0 = fmaf(p, vj[l], a0);
-    if (c1) a1 = fmaf(p, vj[l + kGroup], a1);
-  };
-  const int deg = end - beg;
-  const int cnt = deg + (n_self > 0 ? 1 : 0);
-  if (cnt <= kAttnShortRow) {
-    // short rows: source ids, then all key rows, then all value rows fetched together; every score computed once and
-    // kept in registers (same expressions, same order as the general path: bit-identical)
-    int64_t jj[kAttnShortRow];
-    float sc[kAttnShortRow];
-#pragma unroll
-    for (int e = 0; e < kAttnShortRow; ++e) jj[e] = e < deg ? (int64_t)idx[beg + e] : row;
-#pragma unroll
-    for (int e = 0; e < kAttnShortRow; ++e) sc[e] = e < cnt ? score(jj[e]) : -INFINITY;
-#pragma unroll
-    for (int e = 0; e < kAttnShortRow; ++e) if (e < cnt) m = fmaxf(m, sc[e]);
-#pragma unroll
-    for (int e = 0; e < kAttnShortRow; ++e) if (e < deg) add_p(jj[e], expf(sc[e] - m) * 1.f);
-#pragma unroll
-    for (int e = 0; e < kAttnShortRow; ++e) if (e == deg && n_self > 0) add_p(row, expf(sc[e] - m) * (float)n_self);
-  } else {
-    // long rows in chunks (for_edge_chunks, common.hpp): same expressions in the same order as one edge at a time
-    // pass 1: segment max
-    for_edge_chunks(beg, end, [&](int e, auto kc) {
-      constexpr int K = decltype(kc)::value;
-      int64_t jj[K];
-      float k0[K], k1[K];
-#pragma unroll
-      for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
-#pragma unroll
-      for (int u = 0; u < K; ++u) {
-        const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
-        k0[u] = c0 ? kj[l] : 0.f;
-        k1[u] = c1 ? kj[l + kGroup] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < K; ++u) {
-        float s = q0 * k0[u];
-        if (c1) s = fmaf(q1, k1[u], s);
-        m = fmaxf(m, group16_sum(s) * scale);
-      }
-    });
-    if (n_self > 0) m = fmaxf(m, score(row));
-    // pass 2: exp, sum, weighted value sum
-    for_edge_chunks(beg, end, [&](int e, auto kc) {
-      constexpr int K = decltype(kc)::value;
-      int64_t jj[K];
-      float k0[K], k1[K], v0[K], v1[K];
-#pragma unroll
-      for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
-#pragma unroll
-      for (int u = 0; u < K; ++u) {
-        const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
-        const float* __restrict__ vj = qkvs + jj[u] * ld + 2 * HC + h * C;
-        k0[u] = c0 ? kj[l] : 0.f;
-        k1[u] = c1 ? kj[l + kGroup] : 0.f;
-        v0[u] = c0 ? vj[l] : 0.f;
-        v1[u] = c1 ? vj[l + kGroup] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < K; ++u) {
-        float s = q0 * k0[u];
-        if (c1) s = fmaf(q1, k1[u], s);
-        const float p = expf(group16_sum(s) * scale - m) * 1.f;
-        denom += p;
-        if (c0) a0 = fmaf(p, v0[u], a0);
-        if (c1) a1 = fmaf(p, v1[u], a1);
-      }
-    });
-    if (n_self > 0) add_p(row, expf(score(row) - m) * (float)n_self);
-  }
-  const float inv = 1.0f / (denom + 1e-16f);
-  const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
-  float* __restrict__ o = out + row * ldo + h * C;
-  if (c0) o[l] = a0 * inv + skip[l];
-  if (c1) o[l + kGroup] = a1 * inv + skip[l + kGroup];
+// TransformerConv (heads=H, concat, root_weight, no edge features), inference form: no dropout, no
+// statistics.  The schedule (short rows from registers, longer ones in one chunked pass) is in attn_fwd.hpp.
+template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const AttnFwdArgs a) {
+  attn_forward<false, WIDE>(a);
 }
 
 // ASAPooling steps 3-4: score_e = LeakyReLU(a[dst] + c[src]), softmax over the in-edges of
@@ -228,8 +120,11 @@ extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, co
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(transformer_attn_kernel, dim3((unsigned)ceil_div(N * H * kGroup, kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), qkvs, ld, in_ptr, in_src, loops, N, H, C, out, ldo);
+  if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
+  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, 0, H, C, 0.f, 0, out, ldo, nullptr, 0, nullptr, nullptr};
+  const dim3 grid((unsigned)ceil_div(N * H * kGroup, kBlock));
+  if (C > kGroup) hipLaunchKernelGGL(transformer_attn_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(transformer_attn_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), a);
   return launch_status();
 }
 

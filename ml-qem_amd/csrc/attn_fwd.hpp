@@ -1,0 +1,193 @@
+// TransformerConv's edge softmax, forward (docs/tutorials/gnn.py:80-91; PyG semantics in SURVEY appendix B.1), shared by
+// the inference kernel (attn.hip) and the training kernel (family_b_bwd.hip).
+//
+//   out[i, h] = sum_e alpha_e v[src_e, h] + skip[i, h],  alpha = dropout(softmax_e(q[i,h] . k[src_e,h] / sqrt(C)))
+//
+// over the CSR in-edges of row i followed by its self-loop entry (multiplicity loops[i]); denominator + 1e-16 as in PyG.
+//
+// One 16-lane group owns a (row, head): lane l holds channel l (and l + 16 in the WIDE instantiation, C > 16), a key /
+// value row segment is one coalesced 64-byte read, q.k is a cross-lane sum.  Two row shapes:
+//
+//  * SHORT rows (<= kAttnShort entries: every node of a circuit DAG except its barriers): all key AND value rows are
+//    fetched together, scores stay in registers.
+//  * LONGER rows (barrier nodes; the coarsened graphs ASAPooling makes of 100-qubit circuits, whose rows have 100-500
+//    in-edges and hold 95 % of a batch's edges): the group walks the row eight edges at a time -- index entries, then eight
+//    key and eight value rows in flight together -- in ONE pass: a running maximum that grows rescales what was summed
+//    before it (the three-pass form gathered every key row three times).
+//
+// The un-normalised weights exp(s - m) are summed and the sum divided once (PyG normalises every weight first: the same
+// value in another rounding).  The dropout mask is keyed by (seed, in-CSR position, head) as in the backward kernels and
+// drawn by a 32-bit hash (common.hpp: uniform01_edge).
+//
+// Measured and dropped (scripts/attn_micro.py; cfg2 level 0 / 100-qubit level 1, forward): the four groups of a wave
+// walking one long row together, one row after the other (209 / 921 us against 145 / 696 us for this form: rows of a wave
+// then run serially, and keeping the wave together to the end costs the short rows their early exit); source ids from the
+// ELL side table (no gain: the kernel does not wait on that round trip); value rows fetched after the scores (244 us).
+#pragma once
+
+#include "common.hpp"
+
+namespace mlqem {
+
+constexpr int kAttnMaxC = 32;   // channels per head held in registers (reference models: 15 and 25)
+constexpr int kAttnShort = 6;   // entries (in-edges + self) of a row handled from registers
+
+struct AttnFwdArgs {
+  const float* qkvs; int64_t ld;            // [N, 4*H*C] = [query | key | value | skip]
+  const int32_t* ptr; const int32_t* idx;   // CSR by destination
+  const int32_t* loops;                     // optional [N]: multiplicity of the self-loop entry
+  int64_t N, E; int H, C; float drop_p; uint64_t seed;
+  float* out; int64_t ldo;
+  float* attn_out; int64_t lda; float* stat_m; float* stat_den;   // training only
+};
+
+template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(const AttnFwdArgs& a) {
+  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  const int H = a.H, C = a.C, HC = H * C;
+  if (t >= a.N * H) return;                             // a whole group leaves together
+  const int row = (int)(t / H);
+  const int h = (int)(t - (int64_t)row * H);
+  const float scale = 1.0f / sqrtf((float)C);
+  const float keep = 1.f / (1.f - a.drop_p);
+  const bool c0 = l < C, c1 = WIDE && l + kGroup < C;
+  const int l1 = c1 ? l + kGroup : l;                   // a valid channel for the second load of the narrow case (unused)
+  const float* __restrict__ qkvs = a.qkvs;
+  const int64_t ld = a.ld;
+  const int32_t* __restrict__ idx = a.idx;
+
+  // everything that depends on the row number only, fetched together
+  const float* __restrict__ qi = qkvs + (int64_t)row * ld + h * C;
+  const float q0 = c0 ? qi[l] : 0.f, q1 = c1 ? qi[l1] : 0.f;
+  const int beg = a.ptr[row];
+  const int end = a.ptr[row + 1];
+  const int n_self = a.loops ? a.loops[row] : 0;
+  const int deg = end - beg;
+  const int cnt = deg + (n_self > 0 ? 1 : 0);
+
+  float m = -INFINITY, denom = 0.f, a0 = 0.f, a1 = 0.f;
+  auto dot = [&](float qa, float qb, float k0, float k1) {
+    float s = qa * k0;
+    if (WIDE) s = fmaf(qb, k1, s);
+    return group16_sum(s) * scale;
+  };
+  auto weight = [&](float p, int64_t pos, int hh) {     // the weight a value row gets: dropout on the attention weight
+    if (TRAIN && a.drop_p > 0.f) return uniform01_edge(a.seed, (uint64_t)(pos * H + hh)) < a.drop_p ? 0.f : p * keep;
+    return p;
+  };
+  // one chunk of up to eight edges e .. e + k - 1 of a row of head hh, absorbed into a running (max, denominator, sums)
+  auto absorb8 = [&](int e, int k, int hh, float qa, float qb, float& ms, float& ds, float& x0, float& x1) {
+    int jj[8];
+    float k0[8], k1[WIDE ? 8 : 1], v0[8], v1[WIDE ? 8 : 1], sc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) jj[u] = idx[e + min(u, k - 1)];       // past the end: the last edge again (not used)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* __restrict__ kj = qkvs + (int64_t)jj[u] * ld + HC + hh * C;
+      k0[u] = c0 ? kj[l] : 0.f;
+      v0[u] = c0 ? kj[HC + l] : 0.f;
+      if (WIDE) {
+        k1[u] = c1 ? kj[l1] : 0.f;
+        v1[u] = c1 ? kj[HC + l1] : 0.f;
+      }
+    }
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float s = dot(qa, qb, k0[u], WIDE ? k1[u] : 0.f);         // every lane of the group takes part in the sum
+      sc[u] = u < k ? s : -INFINITY;
+      cm = fmaxf(cm, sc[u]);
+    }
+    if (cm > ms) {                                       // the running maximum grows: rescale what was summed under the old one
+      const float r = expf(ms - cm);                     // exp(-inf) = 0 the first time
+      ds *= r; x0 *= r; x1 *= r;
+      ms = cm;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < k) {
+        const float p = expf(sc[u] - ms);
+        ds += p;
+        const float w = weight(p, (int64_t)e + u, hh);
+        x0 = fmaf(w, v0[u], x0);
+        if (WIDE) x1 = fmaf(w, v1[u], x1);
+      }
+    }
+  };
+  // the self-loop entry of the group's own row, absorbed last (PyG appends it after the edges)
+  auto absorb_self = [&]() {
+    const float* __restrict__ kj = qkvs + (int64_t)row * ld + HC + h * C;
+    const float ks0 = c0 ? kj[l] : 0.f, vs0 = c0 ? kj[HC + l] : 0.f;
+    const float ks1 = c1 ? kj[l1] : 0.f, vs1 = c1 ? kj[HC + l1] : 0.f;
+    const float s = dot(q0, q1, ks0, ks1);
+    if (s > m) {
+      const float rr = expf(m - s);
+      denom *= rr; a0 *= rr; a1 *= rr;
+      m = s;
+    }
+    const float p = expf(s - m) * (float)n_self;
+    denom += p;
+    const float w = weight(p, a.E + row, h);
+    a0 = fmaf(w, vs0, a0);
+    if (WIDE) a1 = fmaf(w, vs1, a1);
+  };
+
+  if (cnt <= kAttnShort) {
+    int jj[kAttnShort];
+    float k0[kAttnShort], k1[WIDE ? kAttnShort : 1], v0[kAttnShort], v1[WIDE ? kAttnShort : 1], sc[kAttnShort];
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) {
+      int j = row;                                       // entry `deg` is the self-loop; entries past cnt are not used
+      if (e < deg) j = idx[beg + e];
+      jj[e] = j;
+    }
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) {
+      if (e < cnt) {                                     // group-uniform
+        const float* __restrict__ kj = qkvs + (int64_t)jj[e] * ld + HC + h * C;
+        k0[e] = c0 ? kj[l] : 0.f;
+        if (WIDE) k1[e] = c1 ? kj[l1] : 0.f;
+        v0[e] = c0 ? kj[HC + l] : 0.f;
+        if (WIDE) v1[e] = c1 ? kj[HC + l1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) sc[e] = e < cnt ? dot(q0, q1, k0[e], WIDE ? k1[e] : 0.f) : -INFINITY;
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) m = fmaxf(m, sc[e]);
+#pragma unroll
+    for (int e = 0; e < kAttnShort; ++e) {
+      if (e < cnt) {
+        const bool self = e == deg;
+        const float p = expf(sc[e] - m) * (self ? (float)n_self : 1.f);
+        denom += p;
+        const float w = weight(p, self ? a.E + row : (int64_t)beg + e, h);
+        a0 = fmaf(w, v0[e], a0);
+        if (WIDE) a1 = fmaf(w, v1[e], a1);
+      }
+    }
+  } else {
+    for (int e = beg; e < end; e += 8) absorb8(e, min(8, end - e), h, q0, q1, m, denom, a0, a1);
+    if (n_self > 0) absorb_self();
+  }
+
+  denom += 1e-16f;
+  const float inv = 1.0f / denom;
+  a0 *= inv;
+  a1 *= inv;
+  const float* __restrict__ skip = qkvs + (int64_t)row * ld + 3 * HC + h * C;
+  float* __restrict__ o = a.out + (int64_t)row * a.ldo + h * C;
+  if (c0) o[l] = a0 + skip[l];
+  if (c1) o[l1] = a1 + skip[l1];
+  if (TRAIN) {
+    float* __restrict__ ao = a.attn_out + (int64_t)row * a.lda + h * C;
+    if (c0) ao[l] = a0;
+    if (c1) ao[l1] = a1;
+    if (l == 0) {
+      a.stat_m[(int64_t)row * H + h] = m;
+      a.stat_den[(int64_t)row * H + h] = denom;
+    }
+  }
+}
+
+}  // namespace mlqem

@@ -44,6 +44,21 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// The same for the per-edge kernels (attention dropout draws one number per (edge, head) in EVERY lane of a 16-lane group,
+// forward and backward): two rounds of a 32-bit avalanche hash, 4 integer multiplies instead of the ~14 of splitmix64's
+// 64-bit products (32-bit integer multiplies run at quarter rate on CDNA).
+__device__ __forceinline__ uint32_t avalanche32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float uniform01_edge(uint64_t seed, uint64_t idx) {
+  uint32_t x = avalanche32((uint32_t)idx ^ (uint32_t)seed);
+  x = avalanche32(x ^ (uint32_t)(seed >> 32) ^ ((uint32_t)(idx >> 32) * 0x9E3779B1u));
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
 // Keep/drop decisions for V consecutive elements from ONE splitmix64 round keyed by the index of their first element:
 // element v is dropped when the v-th 16-bit field of the hash is < floor(p * 65536) (|P(drop) - p| < 1.6e-5).  The
 // aggregation epilogue draws a whole 16-byte slice at once: a quarter of the 64-bit multiplies of one hash per element.
@@ -112,6 +127,10 @@ __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 1, kGroup);
   return v;
 }
+
+// ELL side table of a CSR structure (mlqem_ell_from_csr): ell[row] = (s0, s1), the first two col[] entries of the row, -1 for
+// a missing one; the sign bit of s0 says that the row has more than two entries.
+constexpr int kEllMore = (int)0x80000000;
 
 // Rows are walked in chunks of 8 / 4 / 2 / 1 edges: a chunk's index entries, then all of its source rows, are fetched
 // before the first one is used, so a row of the coarsened graph of a 100-qubit circuit (100-500 edges) costs deg / 8

@@ -239,7 +239,6 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
 // 99.8 % of the rows are complete after (s0, s1), so the row pointer -> col -> source row chain of the CSR walk
 // becomes ell -> source row: one dependent round trip less, no LDS staging and no barrier on the fast path.
 // Items are (row, channel-slice) pairs numbered row-major exactly as above; a workgroup owns kBlock * IPT items.
-constexpr int kEllMore = (int)0x80000000;
 
 template <int VEC, bool IS_MAX, int kItemsPerThread, bool EPI, int kMinWaves = 8>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWaves, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {

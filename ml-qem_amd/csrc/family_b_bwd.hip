@@ -5,248 +5,158 @@
 // out-CSR entry).  No atomics: every gradient row is written once, in a fixed order.
 #include <type_traits>
 
+#include "attn_fwd.hpp"
 #include "common.hpp"
 
 namespace mlqem {
 
-constexpr int kAttnMaxC = 32;
 
 // ---------------------------------------------------------------------------------------- TransformerConv
 // All three kernels give one 16-lane group to a (row, head): lane l holds channels l and l + 16 (C <= 32); row segments
 // are read with coalesced 64-byte loads and dot products over the channels are cross-lane sums (common.hpp).
 //
-// Forward with statistics: identical arithmetic to transformer_attn_kernel (attn.hip) plus m[N,H] (segment max) and
-// den[N,H] (sum of exp + 1e-16) for the backward, and optional dropout on the attention weights
+// Forward with statistics (attn_fwd.hpp): the inference kernel's schedule plus m[N,H] (segment max) and den[N,H] (sum of
+// exp + 1e-16) for the backward, attn_out (the sum before the skip term) and optional dropout on the attention weights
 // (mask keyed by (seed, in-CSR position, head); self-loop entries use position E + row).
-constexpr int kAttnShort = 6;   // in-edges (+ self) of a row handled from registers
-
-__global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(
-    const float* __restrict__ qkvs, int64_t ld, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-    const int32_t* __restrict__ loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
-    float* __restrict__ out, int64_t ldo, float* __restrict__ attn_out, int64_t lda, float* __restrict__ stat_m,
-    float* __restrict__ stat_den) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
-  const int l = threadIdx.x % kGroup;
-  if (t >= N * H) return;
-  const int64_t row = t / H;
-  const int h = (int)(t - row * H);
-  const int HC = H * C;
-  const float scale = 1.0f / sqrtf((float)C);
-  const float keep = 1.f / (1.f - drop_p);
-  const bool c0 = l < C, c1 = l + kGroup < C;
-  const float* __restrict__ qi = qkvs + row * ld + h * C;
-  const float q0 = c0 ? qi[l] : 0.f, q1 = c1 ? qi[l + kGroup] : 0.f;
-  const int beg = ptr[row], end = ptr[row + 1];
-  const int n_self = loops ? loops[row] : 0;
-  auto score = [&](int64_t j) {
-    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
-    float s = q0 * (c0 ? kj[l] : 0.f);
-    if (c1) s = fmaf(q1, kj[l + kGroup], s);
-    return group16_sum(s) * scale;
-  };
-  float m = -INFINITY, denom = 0.f;
-  float a0 = 0.f, a1 = 0.f;
-  auto add_p = [&](int64_t j, float a, int64_t pos) {          // a = softmax weight (times its multiplicity)
-    if (drop_p > 0.f) a = uniform01(seed, (uint64_t)(pos * H + h)) < drop_p ? 0.f : a * keep;
-    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
-    if (c0) a0 = fmaf(a, vj[l], a0);
-    if (c1) a1 = fmaf(a, vj[l + kGroup], a1);
-  };
-  const int deg = end - beg;
-  const int cnt = deg + (n_self > 0 ? 1 : 0);
-  if (cnt <= kAttnShort) {
-    // Short rows (all but the barrier nodes of a circuit graph): the source ids, then ALL key rows, then ALL value rows are
-    // fetched together and every score is computed ONCE and kept in registers -- three dependent round trips per row
-    // instead of three per in-edge.  Same expressions in the same order as the general path below: bit-identical.
-    int64_t jj[kAttnShort];
-    float sc[kAttnShort];
-#pragma unroll
-    for (int e = 0; e < kAttnShort; ++e) jj[e] = e < deg ? (int64_t)idx[beg + e] : row;
-#pragma unroll
-    for (int e = 0; e < kAttnShort; ++e) sc[e] = e < cnt ? score(jj[e]) : -INFINITY;     // group-uniform predicate
-#pragma unroll
-    for (int e = 0; e < kAttnShort; ++e) if (e < cnt) m = fmaxf(m, sc[e]);
-#pragma unroll
-    for (int e = 0; e < kAttnShort; ++e) if (e < deg) denom += expf(sc[e] - m);
-    float p_self = 0.f;
-#pragma unroll
-    for (int e = 0; e < kAttnShort; ++e) if (e == deg && n_self > 0) p_self = expf(sc[e] - m);
-    if (n_self > 0) denom += p_self * (float)n_self;
-    denom += 1e-16f;
-#pragma unroll
-    for (int e = 0; e < kAttnShort; ++e) if (e < deg) add_p(jj[e], expf(sc[e] - m) / denom * 1.f, beg + e);
-    if (n_self > 0) add_p(row, p_self / denom * (float)n_self, E + row);
-  } else {
-    // long rows in chunks (for_edge_chunks, common.hpp): same expressions in the same order as one edge at a time.
-    // `use(edge, score, v0, v1)` sees the chunk's scores in edge order; `with_values` also fetches the value rows.
-    auto walk = [&](auto with_values, auto&& use) {
-      for_edge_chunks(beg, end, [&](int e, auto kc) {
-        constexpr int K = decltype(kc)::value;
-        constexpr bool kValues = decltype(with_values)::value;
-        int64_t jj[K];
-        float k0[K], k1[K], v0[kValues ? K : 1], v1[kValues ? K : 1];
-#pragma unroll
-        for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
-#pragma unroll
-        for (int u = 0; u < K; ++u) {
-          const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
-          k0[u] = c0 ? kj[l] : 0.f;
-          k1[u] = c1 ? kj[l + kGroup] : 0.f;
-          if constexpr (kValues) {
-            const float* __restrict__ vj = qkvs + jj[u] * ld + 2 * HC + h * C;
-            v0[u] = c0 ? vj[l] : 0.f;
-            v1[u] = c1 ? vj[l + kGroup] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < K; ++u) {
-          float s = q0 * k0[u];
-          if (c1) s = fmaf(q1, k1[u], s);
-          use(e + u, group16_sum(s) * scale, kValues ? v0[u] : 0.f, kValues ? v1[u] : 0.f);
-        }
-      });
-    };
-    walk(std::false_type{}, [&](int, float sc, float, float) { m = fmaxf(m, sc); });
-    if (n_self > 0) m = fmaxf(m, score(row));
-    walk(std::false_type{}, [&](int, float sc, float, float) { denom += expf(sc - m); });
-    if (n_self > 0) denom += expf(score(row) - m) * (float)n_self;
-    denom += 1e-16f;
-    walk(std::true_type{}, [&](int e, float sc, float v0, float v1) {
-      float a = expf(sc - m) / denom * 1.f;
-      if (drop_p > 0.f) a = uniform01(seed, (uint64_t)((int64_t)e * H + h)) < drop_p ? 0.f : a * keep;
-      if (c0) a0 = fmaf(a, v0, a0);
-      if (c1) a1 = fmaf(a, v1, a1);
-    });
-    if (n_self > 0) add_p(row, expf(score(row) - m) / denom * (float)n_self, E + row);
-  }
-  const float* __restrict__ skip = qkvs + row * ld + 3 * HC + h * C;
-  if (c0) { attn_out[row * lda + h * C + l] = a0; out[row * ldo + h * C + l] = a0 + skip[l]; }
-  if (c1) { attn_out[row * lda + h * C + l + kGroup] = a1; out[row * ldo + h * C + l + kGroup] = a1 + skip[l + kGroup]; }
-  if (l == 0) {
-    stat_m[row * H + h] = m;
-    stat_den[row * H + h] = denom;
-  }
+template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_train_kernel(const AttnFwdArgs a) {
+  attn_forward<true, WIDE>(a);
 }
 
 // Destination side: g_q, g_skip, and per edge (in-CSR order; self entries at E + row): al = effective attention weight
-// (after dropout), gs = d loss / d score * (1/sqrt(C)).
-__global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(
-    const float* __restrict__ qkvs, int64_t ld, const float* __restrict__ g, int64_t ldg,
-    const float* __restrict__ attn_out, int64_t lda, const float* __restrict__ stat_m,
-    const float* __restrict__ stat_den, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-    const int32_t* __restrict__ loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
-    float* __restrict__ gqkvs, int64_t ldq, float* __restrict__ edge_al, float* __restrict__ edge_gs) {
+// (after dropout), gs = d loss / d score * (1/sqrt(C)).  WIDE = channels 16..31 present (C > 16); rows are walked in
+// chunks of edges whose key and value rows are fetched together (for_edge_chunks, common.hpp).
+struct AttnBwdArgs {
+  const float* qkvs; int64_t ld; const float* g; int64_t ldg; const float* attn_out; int64_t lda;
+  const float* stat_m; const float* stat_den;
+  const int32_t* ptr; const int32_t* idx; const int32_t* optr; const int32_t* odst; const int32_t* oeid; const int32_t* loops;
+  int64_t N, E; int H, C; float drop_p; uint64_t seed;
+  float* gqkvs; int64_t ldq; float* edge_al; float* edge_gs;
+};
+
+template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(const AttnBwdArgs a) {
   const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
-  if (t >= N * H) return;
-  const int64_t row = t / H;
-  const int h = (int)(t - row * H);
-  const int HC = H * C;
+  const int H = a.H, C = a.C, HC = H * C;
+  if (t >= a.N * H) return;
+  const int row = (int)(t / H);
+  const int h = (int)(t - (int64_t)row * H);
   const float scale = 1.0f / sqrtf((float)C);
-  const float keep = 1.f / (1.f - drop_p);
-  const bool c0 = l < C, c1 = l + kGroup < C;
-  const int o0 = h * C + l, o1 = o0 + kGroup;
-  const float q0 = c0 ? qkvs[row * ld + o0] : 0.f, q1 = c1 ? qkvs[row * ld + o1] : 0.f;
-  const float gi0 = c0 ? g[row * ldg + o0] : 0.f, gi1 = c1 ? g[row * ldg + o1] : 0.f;
-  float d = gi0 * (c0 ? attn_out[row * lda + o0] : 0.f);
-  if (c1) d = fmaf(gi1, attn_out[row * lda + o1], d);
+  const float keep = 1.f / (1.f - a.drop_p);
+  const bool c0 = l < C, c1 = WIDE && l + kGroup < C;
+  const int o0 = h * C + l, o1 = c1 ? o0 + kGroup : o0;
+  const float* __restrict__ qkvs = a.qkvs;
+  const int64_t ld = a.ld;
+  const int32_t* __restrict__ idx = a.idx;
+  float* __restrict__ edge_al = a.edge_al;
+  float* __restrict__ edge_gs = a.edge_gs;
+  const float q0 = c0 ? qkvs[(int64_t)row * ld + o0] : 0.f, q1 = c1 ? qkvs[(int64_t)row * ld + o1] : 0.f;
+  const float gi0 = c0 ? a.g[(int64_t)row * a.ldg + o0] : 0.f, gi1 = c1 ? a.g[(int64_t)row * a.ldg + o1] : 0.f;
+  float d = gi0 * (c0 ? a.attn_out[(int64_t)row * a.lda + o0] : 0.f);
+  if (WIDE) d = fmaf(gi1, c1 ? a.attn_out[(int64_t)row * a.lda + o1] : 0.f, d);
   const float delta = group16_sum(d);
   float gq0 = 0.f, gq1 = 0.f;
-  const float m = stat_m[row * H + h], den = stat_den[row * H + h];
-  const int beg = ptr[row], end = ptr[row + 1];
-  const int n_self = loops ? loops[row] : 0;
+  const float m = a.stat_m[(int64_t)row * H + h];
+  const float inv_den = 1.0f / a.stat_den[(int64_t)row * H + h];     // one division per row, as in the forward
+  const int beg = a.ptr[row], end = a.ptr[row + 1];
+  const int n_self = a.loops ? a.loops[row] : 0;
   auto use = [&](float k0, float k1, float v0, float v1, float mult, int64_t pos) {
     float s = q0 * k0, gv = gi0 * v0;
-    if (c1) { s = fmaf(q1, k1, s); gv = fmaf(gi1, v1, gv); }
+    if (WIDE) { s = fmaf(q1, k1, s); gv = fmaf(gi1, v1, gv); }
     s = group16_sum(s);
     gv = group16_sum(gv);
-    const float alpha = expf(s * scale - m) / den * mult;  // softmax weight (all copies of a repeated self-loop)
+    const float alpha = expf(s * scale - m) * inv_den * mult;  // softmax weight (all copies of a repeated self-loop)
     float dmask = 1.f;
-    if (drop_p > 0.f) dmask = uniform01(seed, (uint64_t)(pos * H + h)) < drop_p ? 0.f : keep;
+    if (a.drop_p > 0.f) dmask = uniform01_edge(a.seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
     const float gs = alpha * (gv * dmask - delta) * scale;
     if (l == 0) {
       edge_al[pos * H + h] = alpha * dmask;
       edge_gs[pos * H + h] = gs;
     }
     gq0 = fmaf(gs, k0, gq0);
-    gq1 = fmaf(gs, k1, gq1);
+    if (WIDE) gq1 = fmaf(gs, k1, gq1);
   };
-  auto visit = [&](int64_t j, float mult, int64_t pos) {
-    const float* __restrict__ kj = qkvs + j * ld + HC + h * C;
-    const float* __restrict__ vj = qkvs + j * ld + 2 * HC + h * C;
-    use(c0 ? kj[l] : 0.f, c1 ? kj[l + kGroup] : 0.f, c0 ? vj[l] : 0.f, c1 ? vj[l + kGroup] : 0.f, mult, pos);
-  };
-  for_edge_chunks(beg, end, [&](int e, auto kc) {      // chunks of edges fetched together, used in edge order (common.hpp)
+  for_edge_chunks(beg, end, [&](int e, auto kc) {
     constexpr int K = decltype(kc)::value;
-    int64_t jj[K];
-    float k0[K], k1[K], v0[K], v1[K];
+    int jj[K];
+    float k0[K], k1[WIDE ? K : 1], v0[K], v1[WIDE ? K : 1];
 #pragma unroll
     for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-      const float* __restrict__ kj = qkvs + jj[u] * ld + HC + h * C;
-      const float* __restrict__ vj = qkvs + jj[u] * ld + 2 * HC + h * C;
-      k0[u] = c0 ? kj[l] : 0.f;
-      k1[u] = c1 ? kj[l + kGroup] : 0.f;
-      v0[u] = c0 ? vj[l] : 0.f;
-      v1[u] = c1 ? vj[l + kGroup] : 0.f;
+      const float* __restrict__ kj = qkvs + (int64_t)jj[u] * ld + HC;
+      k0[u] = c0 ? kj[o0] : 0.f;
+      v0[u] = c0 ? kj[HC + o0] : 0.f;
+      if (WIDE) {
+        k1[u] = c1 ? kj[o1] : 0.f;
+        v1[u] = c1 ? kj[HC + o1] : 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < K; ++u) use(k0[u], k1[u], v0[u], v1[u], 1.f, e + u);
+    for (int u = 0; u < K; ++u) use(k0[u], WIDE ? k1[u] : 0.f, v0[u], WIDE ? v1[u] : 0.f, 1.f, e + u);
   });
-  if (n_self > 0) visit(row, (float)n_self, E + row);
-  else if (l == 0) { edge_al[(E + row) * H + h] = 0.f; edge_gs[(E + row) * H + h] = 0.f; }
-  if (c0) { gqkvs[row * ldq + o0] = gq0; gqkvs[row * ldq + 3 * HC + o0] = gi0; }
-  if (c1) { gqkvs[row * ldq + o1] = gq1; gqkvs[row * ldq + 3 * HC + o1] = gi1; }
+  if (n_self > 0) {
+    const float* __restrict__ kj = qkvs + (int64_t)row * ld + HC;
+    use(c0 ? kj[o0] : 0.f, c1 ? kj[o1] : 0.f, c0 ? kj[HC + o0] : 0.f, c1 ? kj[HC + o1] : 0.f, (float)n_self, a.E + row);
+  } else if (l == 0) {
+    edge_al[(a.E + row) * H + h] = 0.f;
+    edge_gs[(a.E + row) * H + h] = 0.f;
+  }
+  float* __restrict__ gq = a.gqkvs + (int64_t)row * a.ldq;
+  if (c0) { gq[o0] = gq0; gq[3 * HC + o0] = gi0; }
+  if (c1) { gq[o1] = gq1; gq[3 * HC + o1] = gi1; }
 }
 
 // Source side: g_k[j] = sum_{e: j->i} gs_e q_i ; g_v[j] = sum_e al_e g_i  (self entry included).
-__global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_kernel(
-    const float* __restrict__ qkvs, int64_t ld, const float* __restrict__ g, int64_t ldg,
-    const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, const int32_t* __restrict__ oeid, int64_t N,
-    int64_t E, int H, int C, const float* __restrict__ edge_al, const float* __restrict__ edge_gs,
-    float* __restrict__ gqkvs, int64_t ldq) {
+template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_kernel(const AttnBwdArgs a) {
   const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
-  if (t >= N * H) return;
-  const int64_t row = t / H;
-  const int h = (int)(t - row * H);
-  const int HC = H * C;
-  const bool c0 = l < C, c1 = l + kGroup < C;
-  const int o0 = h * C + l, o1 = o0 + kGroup;
+  const int H = a.H, C = a.C, HC = H * C;
+  if (t >= a.N * H) return;
+  const int row = (int)(t / H);
+  const int h = (int)(t - (int64_t)row * H);
+  const bool c0 = l < C, c1 = WIDE && l + kGroup < C;
+  const int o0 = h * C + l, o1 = c1 ? o0 + kGroup : o0;
+  const float* __restrict__ qkvs = a.qkvs;
+  const float* __restrict__ g = a.g;
+  const float* __restrict__ edge_al = a.edge_al;
+  const float* __restrict__ edge_gs = a.edge_gs;
+  const int64_t ld = a.ld, ldg = a.ldg;
   float gk0 = 0.f, gk1 = 0.f, gv0 = 0.f, gv1 = 0.f;
-  auto visit = [&](int64_t i, int64_t pos) {
-    const float gs = edge_gs[pos * H + h], al = edge_al[pos * H + h];
-    if (c0) { gk0 = fmaf(gs, qkvs[i * ld + o0], gk0); gv0 = fmaf(al, g[i * ldg + o0], gv0); }
-    if (c1) { gk1 = fmaf(gs, qkvs[i * ld + o1], gk1); gv1 = fmaf(al, g[i * ldg + o1], gv1); }
-  };
-  for_edge_chunks(optr[row], optr[row + 1], [&](int e, auto kc) {     // chunks fetched together, used in edge order
+  for_edge_chunks(a.optr[row], a.optr[row + 1], [&](int e, auto kc) {     // chunks fetched together, used in edge order
     constexpr int K = decltype(kc)::value;
-    int64_t ii[K], pp[K];
-    float gs[K], al[K], qa[K], qb[K], ga[K], gb[K];
+    int ii[K], pp[K];
+    float gs[K], al[K], qa[K], qb[WIDE ? K : 1], ga[K], gb[WIDE ? K : 1];
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-      ii[u] = odst[e + u];
-      pp[u] = oeid[e + u];
+      ii[u] = a.odst[e + u];
+      pp[u] = a.oeid[e + u];
     }
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-      gs[u] = edge_gs[pp[u] * H + h];
-      al[u] = edge_al[pp[u] * H + h];
-      qa[u] = c0 ? qkvs[ii[u] * ld + o0] : 0.f;
-      qb[u] = c1 ? qkvs[ii[u] * ld + o1] : 0.f;
-      ga[u] = c0 ? g[ii[u] * ldg + o0] : 0.f;
-      gb[u] = c1 ? g[ii[u] * ldg + o1] : 0.f;
+      gs[u] = edge_gs[(int64_t)pp[u] * H + h];
+      al[u] = edge_al[(int64_t)pp[u] * H + h];
+      qa[u] = c0 ? qkvs[(int64_t)ii[u] * ld + o0] : 0.f;
+      ga[u] = c0 ? g[(int64_t)ii[u] * ldg + o0] : 0.f;
+      if (WIDE) {
+        qb[u] = c1 ? qkvs[(int64_t)ii[u] * ld + o1] : 0.f;
+        gb[u] = c1 ? g[(int64_t)ii[u] * ldg + o1] : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-      if (c0) { gk0 = fmaf(gs[u], qa[u], gk0); gv0 = fmaf(al[u], ga[u], gv0); }
-      if (c1) { gk1 = fmaf(gs[u], qb[u], gk1); gv1 = fmaf(al[u], gb[u], gv1); }
+      gk0 = fmaf(gs[u], qa[u], gk0);
+      gv0 = fmaf(al[u], ga[u], gv0);
+      if (WIDE) { gk1 = fmaf(gs[u], qb[u], gk1); gv1 = fmaf(al[u], gb[u], gv1); }
     }
   });
-  visit(row, E + row);
-  if (c0) { gqkvs[row * ldq + HC + o0] = gk0; gqkvs[row * ldq + 2 * HC + o0] = gv0; }
-  if (c1) { gqkvs[row * ldq + HC + o1] = gk1; gqkvs[row * ldq + 2 * HC + o1] = gv1; }
+  {   // the self entry, last
+    const float gs = edge_gs[(a.E + row) * H + h], al = edge_al[(a.E + row) * H + h];
+    if (c0) { gk0 = fmaf(gs, qkvs[(int64_t)row * ld + o0], gk0); gv0 = fmaf(al, g[(int64_t)row * ldg + o0], gv0); }
+    if (c1) { gk1 = fmaf(gs, qkvs[(int64_t)row * ld + o1], gk1); gv1 = fmaf(al, g[(int64_t)row * ldg + o1], gv1); }
+  }
+  float* __restrict__ gq = a.gqkvs + (int64_t)row * a.ldq;
+  if (c0) { gq[HC + o0] = gk0; gq[2 * HC + o0] = gv0; }
+  if (c1) { gq[HC + o1] = gk1; gq[2 * HC + o1] = gv1; }
 }
 
 // --------------------------------------------------------------------------------------------- ASAPooling
@@ -481,17 +391,19 @@ using namespace mlqem;
 
 extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
                                                      const int32_t* in_src, const int32_t* loops, int64_t N, int64_t E,
-                                                     int H, int C, float drop_p, uint64_t seed, float* out, int64_t ldo,
-                                                     float* attn_out, int64_t lda, float* stat_m, float* stat_den,
-                                                     mlqem_stream_t stream) {
+                                                     int H, int C, float drop_p, uint64_t seed,
+                                                     float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m,
+                                                     float* stat_den, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
     return MLQEM_ERR_BAD_ARG;
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(transformer_attn_train_kernel, MLQEM_GRID(N * H * kGroup), qkvs, ld, in_ptr, in_src, loops, N, E, H, C,
-                     drop_p, seed, out, ldo, attn_out, lda, stat_m, stat_den);
+  if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
+  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, out, ldo, attn_out, lda, stat_m, stat_den};
+  if (C > kGroup) hipLaunchKernelGGL(transformer_attn_train_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
+  else hipLaunchKernelGGL(transformer_attn_train_kernel<false>, MLQEM_GRID(N * H * kGroup), a);
   return launch_status();
 }
 
@@ -510,10 +422,16 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if (!qkvs || !g || !attn_out || !stat_m || !stat_den || !in_ptr || !out_ptr || !gqkvs || !edge_al || !edge_gs)
     return MLQEM_ERR_BAD_ARG;
   if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel, MLQEM_GRID(N * H * kGroup), qkvs, ld, g, ldg, attn_out, lda, stat_m,
-                     stat_den, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, gqkvs, ldq, edge_al, edge_gs);
-  hipLaunchKernelGGL(transformer_attn_bwd_src_kernel, MLQEM_GRID(N * H * kGroup), qkvs, ld, g, ldg, out_ptr, out_dst, out_eid,
-                     N, E, H, C, edge_al, edge_gs, gqkvs, ldq);
+  if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
+  const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
+                      N, E, H, C, drop_p, seed, gqkvs, ldq, edge_al, edge_gs};
+  if (C > kGroup) {
+    hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
+    hipLaunchKernelGGL(transformer_attn_bwd_src_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
+  } else {
+    hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel<false>, MLQEM_GRID(N * H * kGroup), a);
+    hipLaunchKernelGGL(transformer_attn_bwd_src_kernel<false>, MLQEM_GRID(N * H * kGroup), a);
+  }
   return launch_status();
 }
 
