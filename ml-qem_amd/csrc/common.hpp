@@ -120,11 +120,17 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 // and pooling kernels give one group to a (row, head) or a row: lane l holds channels l, l + 16, ... so that a source row
 // is read with 64-byte coalesced loads and a dot product over the channels is four cross-lane adds in a fixed order.
 constexpr int kGroup = 16;
+// The four steps are DPP row operations (a DPP row IS 16 lanes): lane i adds lane i^1, i^2, then its mirror in the half
+// row and in the row -- four v_add_f32_dpp, no LDS crossbar (ds_bpermute) and nothing to wait for.  Every lane ends with
+// the same value (each step adds the same two partial sums in both partners).
+template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 8, kGroup);
-  v += __shfl_xor(v, 4, kGroup);
-  v += __shfl_xor(v, 2, kGroup);
-  v += __shfl_xor(v, 1, kGroup);
+  v += dpp_row<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_row<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_row<0x141>(v);   // row_half_mirror
+  v += dpp_row<0x140>(v);   // row_mirror
   return v;
 }
 
