@@ -245,7 +245,7 @@ struct RowsArgs {
   int Wn, Wk;                    // words of the node / cluster bitsets (batch maxima)
   uint32_t* bm; uint32_t* bmT;   // [K][Wk]: row p = clusters q (local index) with p -> q; bmT row q = sources p
   int32_t* outdeg; int32_t* indeg;   // [K + 1]
-  int Wb; int32_t* pref;         // [K][Wb]: set bits of row p in words < 32 j (rank lookups of the fill pass)
+  uint16_t* prefw;               // [K][Wk]: set bits of row p in the words before word j (rank lookups of the fill pass)
 };
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -332,29 +332,25 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) 
     }
   }
   wave_lds_sync();
-  int cnt = 0;
   const int pl = (int)(p - k0);
-  for (int wi = lane; wi < a.Wk; wi += 64) {
-    uint32_t bits = Y[wi];
-    a.bm[p * a.Wk + wi] = bits;
-    cnt += __popc(bits);
+  int run = 0;                                        // set bits of Y in the words before the current 64
+  for (int w0 = 0; w0 < a.Wk; w0 += 64) {
+    const int wi = w0 + lane;
+    uint32_t bits = wi < a.Wk ? Y[wi] : 0u;
+    const int c = __popc(bits);
+    const int ex = wave_excl_scan(c, lane);
+    if (wi < a.Wk) {
+      a.bm[p * a.Wk + wi] = bits;
+      a.prefw[p * a.Wk + wi] = (uint16_t)(run + ex);  // rank of the word's first bit inside row p (< k_g <= 65536)
+    }
+    run += __shfl(ex + c, 63);
     while (bits) {                                    // one global atomicOr per distinct edge p -> q
       const int b = __ffs((int)bits) - 1;
       bits &= bits - 1;
       atomicOr(&a.bmT[(int64_t)(k0 + wi * 32 + b) * a.Wk + (pl >> 5)], 1u << (pl & 31));
     }
   }
-  cnt = wave_sum(cnt);
-  if (lane == 0) a.outdeg[p] = cnt;
-  for (int j0 = 0, run = 0; j0 < a.Wb; j0 += 64) {   // block prefix counts (blocks of 32 words) for the fill pass
-    const int j = j0 + lane;
-    int blk = 0;
-    if (j < a.Wb)
-      for (int w = 32 * j; w < min(32 * j + 32, a.Wk); ++w) blk += __popc(Y[w]);
-    const int ex = wave_excl_scan(blk, lane);
-    if (j < a.Wb) a.pref[p * a.Wb + j] = run + ex;
-    run += __shfl(ex + blk, 63);
-  }
+  if (lane == 0) a.outdeg[p] = run;
 }
 
 __global__ __launch_bounds__(kBlock) void coarsen_rows_indeg_kernel(const RowsArgs a) {
@@ -408,9 +404,8 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArg
       bits &= bits - 1;
       const int64_t src = (int64_t)k0 + wi * 32 + b;
       in_src_new[pos] = (int32_t)src;
-      const uint32_t* row = a.bm + src * a.Wk;       // rank of r inside row src of the out-CSR
-      int rank = a.pref[src * a.Wb + (wq >> 5)] + __popc(row[wq] & below);
-      for (int w = wq & ~31; w < wq; ++w) rank += __popc(row[w]);
+      // rank of r inside row src of the out-CSR: bits before word wq (count pass) + bits below r in that word
+      const int rank = (int)a.prefw[src * a.Wk + wq] + __popc(a.bm[src * a.Wk + wq] & below);
       out_eid_new[out_ptr_new[src] + rank] = pos;
       ++pos;
     }
@@ -593,10 +588,10 @@ extern "C" int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t
 }
 
 static void rows_layout(int64_t K, int kmax, size_t& bm, size_t& deg, size_t& pref) {
-  const size_t Wk = (size_t)(kmax + 31) / 32, Wb = (Wk + 31) / 32;
+  const size_t Wk = (size_t)(kmax + 31) / 32;
   bm = ((size_t)K * Wk * sizeof(uint32_t) + 255) / 256 * 256;
   deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
-  pref = ((size_t)K * Wb * sizeof(int32_t) + 255) / 256 * 256;
+  pref = ((size_t)K * Wk * sizeof(uint16_t) + 255) / 256 * 256;
 }
 
 extern "C" size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax) {
@@ -617,7 +612,7 @@ static bool rows_args(RowsArgs& a, const int32_t* in_ptr, const int32_t* in_src,
   const int Wk = (kmax + 31) / 32;
   a = RowsArgs{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, K, (nmax + 31) / 32, Wk,
                reinterpret_cast<uint32_t*>(ws), reinterpret_cast<uint32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + 2 * bm),
-               reinterpret_cast<int32_t*>(ws + 2 * bm + deg), (Wk + 31) / 32, reinterpret_cast<int32_t*>(ws + 2 * bm + 2 * deg)};
+               reinterpret_cast<int32_t*>(ws + 2 * bm + deg), reinterpret_cast<uint16_t*>(ws + 2 * bm + 2 * deg)};
   return true;
 }
 
@@ -631,7 +626,7 @@ extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (N < 0 || K < 0 || K > N || B < 0 || kmax < 0 || nmax < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
-  if (nmax + kmax + 64 > mlqem_asap_coarsen_rows_max_bits()) return MLQEM_ERR_UNSUPPORTED;
+  if (nmax + kmax + 64 > mlqem_asap_coarsen_rows_max_bits() || kmax > 65536) return MLQEM_ERR_UNSUPPORTED;   // ranks are 16-bit
   if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_asap_coarsen_rows_workspace_bytes(K, kmax)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
