@@ -16,8 +16,86 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
 // ASAPooling steps 3-4: score_e = LeakyReLU(a[dst] + c[src]), softmax over the in-edges of
 // dst PLUS its own self-loop (add_remaining_self_loops), out[dst] = sum_e score_e * x[src_e].
 // a[i] = att_w[:D] . lin(xq)[i] + att_b and c[j] = att_w[D:] . x[j] are per-node scalars made by the dense kernel.
-// Thread = (row, channel) flattened.
-__global__ __launch_bounds__(kBlock) void softmax_aggregate_kernel(const float* __restrict__ x, int64_t ldx,
+//
+// One 16-lane group per row; lane l holds channels l, l + 16, ... (NV per lane).  The scalar work of an edge -- its
+// source id, c[src], LeakyReLU, exp -- is done by ONE lane: a chunk is 16 edges, lane u owns edge u, and the weight and
+// the source id reach the other lanes by a DPP row broadcast when the rows are accumulated.  (The thread-per-(row,
+// channel) form repeated that scalar work in every one of a row's 30-45 threads, twice: it spent its time on exp.)
+// One pass: a running maximum that grows rescales what was summed under the old one.
+template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_kernel(
+    const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+    const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int C,
+    float* __restrict__ out, int64_t ldo) {
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;                              // a whole group leaves together
+  const int beg = ptr[row], end = ptr[row + 1];
+  const float ai = a_dst[row];
+  auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  bool has[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) has[v] = l + v * kGroup < C;
+  float m = -INFINITY, den = 0.f, acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+  auto grow = [&](float cm) {
+    if (cm > m) {
+      const float r = expf(m - cm);                  // exp(-inf) = 0 the first time
+      den *= r;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] *= r;
+      m = cm;
+    }
+  };
+  for (int e0 = beg; e0 < end; e0 += kGroup) {
+    const int k = min(kGroup, end - e0);              // group-uniform
+    const int j = idx[e0 + min(l, k - 1)];            // lane u: edge e0 + u (lanes past k repeat the last edge, weight 0)
+    const float s = l < k ? leaky(ai + c_src[j]) : -INFINITY;
+    grow(group16_max(s));
+    const float p = l < k ? expf(s - m) : 0.f;
+    den += group16_sum(p);
+    auto rows = [&](auto first) {                     // eight source rows in flight, then eight multiply-adds in edge order
+      constexpr int U0 = decltype(first)::value;
+      int ju[8];
+      float pu[8], xv[8][NV];
+      ju[0] = group16_bcast<U0 + 0>(j); ju[1] = group16_bcast<U0 + 1>(j); ju[2] = group16_bcast<U0 + 2>(j);
+      ju[3] = group16_bcast<U0 + 3>(j); ju[4] = group16_bcast<U0 + 4>(j); ju[5] = group16_bcast<U0 + 5>(j);
+      ju[6] = group16_bcast<U0 + 6>(j); ju[7] = group16_bcast<U0 + 7>(j);
+      pu[0] = group16_bcast<U0 + 0>(p); pu[1] = group16_bcast<U0 + 1>(p); pu[2] = group16_bcast<U0 + 2>(p);
+      pu[3] = group16_bcast<U0 + 3>(p); pu[4] = group16_bcast<U0 + 4>(p); pu[5] = group16_bcast<U0 + 5>(p);
+      pu[6] = group16_bcast<U0 + 6>(p); pu[7] = group16_bcast<U0 + 7>(p);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xv[u][v] = has[v] ? xj[v * kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = fmaf(pu[u], xv[u][v], acc[v]);
+    };
+    rows(EdgeChunk<0>{});
+    if (k > 8) rows(EdgeChunk<8>{});
+  }
+  {  // the self-loop last, as appended by add_remaining_self_loops
+    const float s = leaky(ai + c_src[row]);
+    grow(s);
+    const float p = expf(s - m);
+    den += p;
+    const float* __restrict__ xr = x + row * ldx + l;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = fmaf(p, has[v] ? xr[v * kGroup] : 0.f, acc[v]);
+  }
+  // PyG normalises every edge score first (p / (denom + 1e-16)) and then sums the messages: the same value, one division
+  const float inv = 1.0f / (den + 1e-16f);
+  float* __restrict__ o = out + row * ldo + l;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) if (has[v]) o[v * kGroup] = acc[v] * inv;
+}
+
+// Rows wider than 128 channels (no reference model has them): thread = (row, channel) flattened, every thread walks its row.
+__global__ __launch_bounds__(kBlock) void softmax_aggregate_any_width_kernel(const float* __restrict__ x, int64_t ldx,
                                                                    const int32_t* __restrict__ ptr,
                                                                    const int32_t* __restrict__ idx,
                                                                    const float* __restrict__ a_dst,
@@ -136,8 +214,18 @@ extern "C" int mlqem_csr_softmax_aggregate_f32(const float* x, int64_t ldx, cons
   if (N < 0 || C <= 0 || ldx < C || ldo < C) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!x || !in_ptr || !a_dst || !c_src || !out) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(softmax_aggregate_kernel, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), x, ldx, in_ptr, in_src, a_dst, c_src, negative_slope, N, C, out, ldo);
+  const dim3 grid((unsigned)ceil_div(N * kGroup, kBlock));
+#define MLQEM_SA(NV) hipLaunchKernelGGL(softmax_aggregate_kernel<NV>, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, in_ptr, \
+                                        in_src, a_dst, c_src, negative_slope, N, C, out, ldo)
+  if (C <= 16) MLQEM_SA(1);
+  else if (C <= 32) MLQEM_SA(2);
+  else if (C <= 48) MLQEM_SA(3);
+  else if (C <= 64) MLQEM_SA(4);
+  else if (C <= 128) MLQEM_SA(8);
+  else
+    hipLaunchKernelGGL(softmax_aggregate_any_width_kernel, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), x, ldx, in_ptr, in_src, a_dst, c_src, negative_slope, N, C, out, ldo);
+#undef MLQEM_SA
   return launch_status();
 }
 

@@ -126,6 +126,20 @@ constexpr int kGroup = 16;
 template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// value of lane U of the 16-lane group, in every lane of the group (row_newbcast: one v_mov_b32_dpp)
+template <int U> __device__ __forceinline__ float group16_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + U, 0xF, 0xF, true));
+}
+template <int U> __device__ __forceinline__ int group16_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float group16_max(float v) {
+  v = fmaxf(v, dpp_row<0xB1>(v));
+  v = fmaxf(v, dpp_row<0x4E>(v));
+  v = fmaxf(v, dpp_row<0x141>(v));
+  v = fmaxf(v, dpp_row<0x140>(v));
+  return v;
+}
 __device__ __forceinline__ float group16_sum(float v) {
   v += dpp_row<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_row<0x4E>(v);    // quad_perm [2,3,0,1]

@@ -162,8 +162,106 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
 // --------------------------------------------------------------------------------------------- ASAPooling
 // Destination side of x'[i] = sum_e softmax_e(LeakyReLU(a_i + c_src)) x[src] (in-edges + own self-loop):
 // per edge al_e (softmax weight) and gp_e (gradient at the pre-activation a_i + c_src); g_a[i] = sum_e gp_e.
+// One 16-lane group per destination row; lane l holds channels l, l + 16, ... (NV per lane).  As in the forward
+// (attn.hip) the scalar work of an edge is done by ONE lane: a chunk is 16 edges, lane u owns edge u -- its c[src], its
+// softmax weight, its gp -- and writes al / gp for it, so a chunk's results leave as two coalesced 64-byte stores; only the
+// dot product gnew[i] . x[src] of an edge involves the whole group.  Statistics (max, denominator) are recomputed first
+// by the same lane-per-edge walk.
+template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ xnew, int64_t ldn,
+    const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+    const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
+    float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a) {
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  const int beg = ptr[row], end = ptr[row + 1];
+  const float ai = a_dst[row];
+  auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  bool has[NV];
+  float gi[NV];
+  float d = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    has[v] = l + v * kGroup < C;
+    gi[v] = has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f;
+    d = fmaf(gi[v], has[v] ? xnew[row * ldn + l + v * kGroup] : 0.f, d);
+  }
+  const float delta = group16_sum(d);
+  // statistics: running maximum and denominator over the edges, then the self-loop
+  const float s_self = leaky(ai + c_src[row]);
+  float m = -INFINITY, den = 0.f;
+  for (int e0 = beg; e0 < end; e0 += kGroup) {
+    const int k = min(kGroup, end - e0);
+    const float s = l < k ? leaky(ai + c_src[idx[e0 + min(l, k - 1)]]) : -INFINITY;
+    const float cm = group16_max(s);
+    if (cm > m) { den *= expf(m - cm); m = cm; }
+    den += group16_sum(l < k ? expf(s - m) : 0.f);
+  }
+  if (s_self > m) { den *= expf(m - s_self); m = s_self; }
+  den += expf(s_self - m);
+  const float inv = 1.0f / (den + 1e-16f);
+  float ga = 0.f;                                      // lane u: the sum of its edges' gp
+  for (int e0 = beg; e0 < end; e0 += kGroup) {
+    const int k = min(kGroup, end - e0);
+    const int j = idx[e0 + min(l, k - 1)];
+    const float pre = ai + c_src[j];
+    float mydot = 0.f;
+    auto dots = [&](auto first) {                      // eight source rows in flight; lane u keeps the dot product of edge u
+      constexpr int U0 = decltype(first)::value;
+      int ju[8];
+      float xv[8][NV];
+      ju[0] = group16_bcast<U0 + 0>(j); ju[1] = group16_bcast<U0 + 1>(j); ju[2] = group16_bcast<U0 + 2>(j);
+      ju[3] = group16_bcast<U0 + 3>(j); ju[4] = group16_bcast<U0 + 4>(j); ju[5] = group16_bcast<U0 + 5>(j);
+      ju[6] = group16_bcast<U0 + 6>(j); ju[7] = group16_bcast<U0 + 7>(j);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xv[u][v] = has[v] ? xj[v * kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float dd = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dd = fmaf(gi[v], xv[u][v], dd);
+        dd = group16_sum(dd);
+        if (l == U0 + u) mydot = dd;
+      }
+    };
+    dots(EdgeChunk<0>{});
+    if (k > 8) dots(EdgeChunk<8>{});
+    if (l < k) {
+      const float al = expf(leaky(pre) - m) * inv;
+      const float gp = al * (mydot - delta) * (pre > 0.f ? 1.f : slope);
+      edge_al[e0 + l] = al;
+      edge_gp[e0 + l] = gp;
+      ga += gp;
+    }
+  }
+  ga = group16_sum(ga);
+  {  // the self-loop entry (position E + row)
+    const float pre = ai + c_src[row];
+    const float al = expf(leaky(pre) - m) * inv;
+    float dd = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) dd = fmaf(gi[v], has[v] ? x[row * ldx + l + v * kGroup] : 0.f, dd);
+    dd = group16_sum(dd);
+    const float gp = al * (dd - delta) * (pre > 0.f ? 1.f : slope);
+    ga += gp;
+    if (l == 0) {
+      edge_al[E + row] = al;
+      edge_gp[E + row] = gp;
+      g_a[row] = ga;
+    }
+  }
+}
+
+// The same for rows wider than 128 channels (no reference model has them): every lane repeats the per-edge scalars.
+// Destination side of x'[i] = sum_e softmax_e(LeakyReLU(a_i + c_src)) x[src] (in-edges + own self-loop):
+// per edge al_e (softmax weight) and gp_e (gradient at the pre-activation a_i + c_src); g_a[i] = sum_e gp_e.
 // One 16-lane group per destination row; lane l holds channels l, l + 16, ...
-__global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
+__global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_any_width_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xnew, int64_t ldn,
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
@@ -448,8 +546,17 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
   if (!x || !xnew || !gnew || !in_ptr || !out_ptr || !a_dst || !c_src || !gx || !g_a || !g_c || !edge_al || !edge_gp)
     return MLQEM_ERR_BAD_ARG;
   if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(softmax_aggregate_bwd_dst_kernel, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,
-                     a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a);
+#define MLQEM_SAB(NV) hipLaunchKernelGGL(softmax_aggregate_bwd_dst_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, \
+                                         in_ptr, in_src, a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a)
+  if (C <= 16) MLQEM_SAB(1);
+  else if (C <= 32) MLQEM_SAB(2);
+  else if (C <= 48) MLQEM_SAB(3);
+  else if (C <= 64) MLQEM_SAB(4);
+  else if (C <= 128) MLQEM_SAB(8);
+  else
+    hipLaunchKernelGGL(softmax_aggregate_bwd_dst_any_width_kernel, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr,
+                       in_src, a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a);
+#undef MLQEM_SAB
   hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel, MLQEM_GRID(N * C), gnew, ldg, out_ptr, out_dst, out_eid,
                      edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c);
   return launch_status();
