@@ -13,7 +13,8 @@
 //  * LONGER rows (barrier nodes; the coarsened graphs ASAPooling makes of 100-qubit circuits, whose rows have 100-500
 //    in-edges and hold 95 % of a batch's edges): the group walks the row eight edges at a time -- index entries, then eight
 //    key and eight value rows in flight together -- in ONE pass: a running maximum that grows rescales what was summed
-//    before it (the three-pass form gathered every key row three times).
+//    before it (the three-pass form gathered every key row three times).  The kernel is bound by the vector ALU, not by
+//    memory, so the scalar work of an edge (exp, dropout draw) is done by one lane per edge and broadcast (absorb8).
 //
 // The un-normalised weights exp(s - m) are summed and the sum divided once (PyG normalises every weight first: the same
 // value in another rounding).  The dropout mask is keyed by (seed, in-CSR position, head) as in the backward kernels and
@@ -75,15 +76,20 @@ template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(co
     if (TRAIN && a.drop_p > 0.f) return uniform01_edge(a.seed, (uint64_t)(pos * H + hh)) < a.drop_p ? 0.f : p * keep;
     return p;
   };
-  // one chunk of up to eight edges e .. e + k - 1 of a row of head hh, absorbed into a running (max, denominator, sums)
-  auto absorb8 = [&](int e, int k, int hh, float qa, float qb, float& ms, float& ds, float& x0, float& x1) {
-    int jj[8];
-    float k0[8], k1[WIDE ? 8 : 1], v0[8], v1[WIDE ? 8 : 1], sc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) jj[u] = idx[e + min(u, k - 1)];       // past the end: the last edge again (not used)
+  // One chunk of up to eight edges e .. e + k - 1 of the row, absorbed into the running (max, denominator, sums).  The
+  // scalar work of an edge -- its source id, exp, dropout draw -- is done by ONE lane (lanes u and u + 8 own edge u); the
+  // ids and the weights reach the other lanes by DPP row broadcasts when the rows are fetched / accumulated, and only the
+  // dot product q.k of an edge involves the whole group.
+  auto absorb8 = [&](int e, int k) {
+    const int lu = l & 7;
+    const int j = idx[e + min(lu, k - 1)];              // past the end: the last edge again (weight 0)
+    int ju[8];
+    float k0[8], k1[WIDE ? 8 : 1], v0[8], v1[WIDE ? 8 : 1];
+    ju[0] = group16_bcast<0>(j); ju[1] = group16_bcast<1>(j); ju[2] = group16_bcast<2>(j); ju[3] = group16_bcast<3>(j);
+    ju[4] = group16_bcast<4>(j); ju[5] = group16_bcast<5>(j); ju[6] = group16_bcast<6>(j); ju[7] = group16_bcast<7>(j);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const float* __restrict__ kj = qkvs + (int64_t)jj[u] * ld + HC + hh * C;
+      const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HC + h * C;
       k0[u] = c0 ? kj[l] : 0.f;
       v0[u] = c0 ? kj[HC + l] : 0.f;
       if (WIDE) {
@@ -91,27 +97,29 @@ template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(co
         v1[u] = c1 ? kj[HC + l1] : 0.f;
       }
     }
-    float cm = -INFINITY;
+    float mys = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const float s = dot(qa, qb, k0[u], WIDE ? k1[u] : 0.f);         // every lane of the group takes part in the sum
-      sc[u] = u < k ? s : -INFINITY;
-      cm = fmaxf(cm, sc[u]);
+      const float s = dot(q0, q1, k0[u], WIDE ? k1[u] : 0.f);
+      if (lu == u) mys = s;
     }
-    if (cm > ms) {                                       // the running maximum grows: rescale what was summed under the old one
-      const float r = expf(ms - cm);                     // exp(-inf) = 0 the first time
-      ds *= r; x0 *= r; x1 *= r;
-      ms = cm;
+    if (lu >= k) mys = -INFINITY;
+    const float cm = group16_max(mys);
+    if (cm > m) {                                        // the running maximum grows: rescale what was summed under the old one
+      const float r = expf(m - cm);                      // exp(-inf) = 0 the first time
+      denom *= r; a0 *= r; a1 *= r;
+      m = cm;
     }
+    const float p = lu < k ? expf(mys - m) : 0.f;
+    denom += group16_sum(l < 8 ? p : 0.f);
+    const float w = weight(p, (int64_t)e + lu, h);
+    float wu[8];
+    wu[0] = group16_bcast<0>(w); wu[1] = group16_bcast<1>(w); wu[2] = group16_bcast<2>(w); wu[3] = group16_bcast<3>(w);
+    wu[4] = group16_bcast<4>(w); wu[5] = group16_bcast<5>(w); wu[6] = group16_bcast<6>(w); wu[7] = group16_bcast<7>(w);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (u < k) {
-        const float p = expf(sc[u] - ms);
-        ds += p;
-        const float w = weight(p, (int64_t)e + u, hh);
-        x0 = fmaf(w, v0[u], x0);
-        if (WIDE) x1 = fmaf(w, v1[u], x1);
-      }
+      a0 = fmaf(wu[u], v0[u], a0);
+      if (WIDE) a1 = fmaf(wu[u], v1[u], a1);
     }
   };
   // the self-loop entry of the group's own row, absorbed last (PyG appends it after the edges)
@@ -167,7 +175,7 @@ template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(co
       }
     }
   } else {
-    for (int e = beg; e < end; e += 8) absorb8(e, min(8, end - e), h, q0, q1, m, denom, a0, a1);
+    for (int e = beg; e < end; e += 8) absorb8(e, min(8, end - e));
     if (n_self > 0) absorb_self();
   }
 

@@ -75,15 +75,19 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
     gq0 = fmaf(gs, k0, gq0);
     if (WIDE) gq1 = fmaf(gs, k1, gq1);
   };
-  for_edge_chunks(beg, end, [&](int e, auto kc) {
-    constexpr int K = decltype(kc)::value;
-    int jj[K];
-    float k0[K], k1[WIDE ? K : 1], v0[K], v1[WIDE ? K : 1];
+  // Rows of eight or more in-edges, eight at a time: the scalar work of an edge -- softmax weight, dropout draw, score
+  // gradient -- is done by ONE lane (lanes u and u + 8 own edge u) and lanes 0..7 store the chunk's al / gs entries
+  // together; only the two dot products of an edge involve the whole group, and gs reaches the lanes by DPP broadcast.
+  auto chunk8 = [&](int e, int k) {
+    const int lu = l & 7;
+    const int j = idx[e + min(lu, k - 1)];              // past the end: the last edge again (gs 0, nothing stored)
+    int ju[8];
+    float k0[8], k1[WIDE ? 8 : 1], v0[8], v1[WIDE ? 8 : 1];
+    ju[0] = group16_bcast<0>(j); ju[1] = group16_bcast<1>(j); ju[2] = group16_bcast<2>(j); ju[3] = group16_bcast<3>(j);
+    ju[4] = group16_bcast<4>(j); ju[5] = group16_bcast<5>(j); ju[6] = group16_bcast<6>(j); ju[7] = group16_bcast<7>(j);
 #pragma unroll
-    for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
-#pragma unroll
-    for (int u = 0; u < K; ++u) {
-      const float* __restrict__ kj = qkvs + (int64_t)jj[u] * ld + HC;
+    for (int u = 0; u < 8; ++u) {
+      const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HC;
       k0[u] = c0 ? kj[o0] : 0.f;
       v0[u] = c0 ? kj[HC + o0] : 0.f;
       if (WIDE) {
@@ -91,9 +95,57 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
         v1[u] = c1 ? kj[HC + o1] : 0.f;
       }
     }
+    float mys = 0.f, mygv = 0.f;
 #pragma unroll
-    for (int u = 0; u < K; ++u) use(k0[u], WIDE ? k1[u] : 0.f, v0[u], WIDE ? v1[u] : 0.f, 1.f, e + u);
-  });
+    for (int u = 0; u < 8; ++u) {
+      float sd = q0 * k0[u], gd = gi0 * v0[u];
+      if (WIDE) { sd = fmaf(q1, k1[u], sd); gd = fmaf(gi1, v1[u], gd); }
+      sd = group16_sum(sd);
+      gd = group16_sum(gd);
+      if (lu == u) { mys = sd; mygv = gd; }
+    }
+    const int64_t pos = (int64_t)e + lu;
+    const float alpha = expf(mys * scale - m) * inv_den;
+    float dmask = 1.f;
+    if (a.drop_p > 0.f) dmask = uniform01_edge(a.seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
+    float gs = alpha * (mygv * dmask - delta) * scale;
+    if (lu >= k) gs = 0.f;
+    if (l < 8 && lu < k) {
+      edge_al[pos * H + h] = alpha * dmask;
+      edge_gs[pos * H + h] = gs;
+    }
+    float gu[8];
+    gu[0] = group16_bcast<0>(gs); gu[1] = group16_bcast<1>(gs); gu[2] = group16_bcast<2>(gs); gu[3] = group16_bcast<3>(gs);
+    gu[4] = group16_bcast<4>(gs); gu[5] = group16_bcast<5>(gs); gu[6] = group16_bcast<6>(gs); gu[7] = group16_bcast<7>(gs);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      gq0 = fmaf(gu[u], k0[u], gq0);
+      if (WIDE) gq1 = fmaf(gu[u], k1[u], gq1);
+    }
+  };
+  if (end - beg >= 8) {
+    for (int e = beg; e < end; e += 8) chunk8(e, min(8, end - e));
+  } else {
+    for_edge_chunks(beg, end, [&](int e, auto kc) {
+      constexpr int K = decltype(kc)::value;
+      int jj[K];
+      float k0[K], k1[WIDE ? K : 1], v0[K], v1[WIDE ? K : 1];
+#pragma unroll
+      for (int u = 0; u < K; ++u) jj[u] = idx[e + u];
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        const float* __restrict__ kj = qkvs + (int64_t)jj[u] * ld + HC;
+        k0[u] = c0 ? kj[o0] : 0.f;
+        v0[u] = c0 ? kj[HC + o0] : 0.f;
+        if (WIDE) {
+          k1[u] = c1 ? kj[o1] : 0.f;
+          v1[u] = c1 ? kj[HC + o1] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) use(k0[u], WIDE ? k1[u] : 0.f, v0[u], WIDE ? v1[u] : 0.f, 1.f, e + u);
+    });
+  }
   if (n_self > 0) {
     const float* __restrict__ kj = qkvs + (int64_t)row * ld + HC;
     use(c0 ? kj[o0] : 0.f, c1 ? kj[o1] : 0.f, c0 ? kj[HC + o0] : 0.f, c1 ? kj[HC + o1] : 0.f, (float)n_self, a.E + row);
