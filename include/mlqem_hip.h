@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 10 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 11 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -350,6 +350,12 @@ int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t* edge_inde
  * (131 072: 64 KB of LDS for the four waves of a workgroup), else MLQEM_ERR_UNSUPPORTED.  Replaces the same
  * ASAPooling.forward lines as the entry points above (gnn.py:105-107,110-112). */
 size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax);
+
+/* slot[N] alone: slot[perm[p]] = p for the K kept centres, -1 elsewhere (every coarsening entry point writes it too).
+ * ASAPooling's backward needs it (x_out = x'[perm] * fitness[perm], gnn.py:105-107,110-112) even when nobody reads the
+ * coarsened connectivity -- the second pooling of every reference model is followed by global_mean_pool (gnn.py:112-114)
+ * -- so the host can skip the coarsening and call only this. */
+int mlqem_asap_slot_map(const int32_t* perm, int64_t N, int64_t K, int32_t* slot, mlqem_stream_t stream);
 int mlqem_asap_coarsen_rows_max_bits(void);
 int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                   const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N,

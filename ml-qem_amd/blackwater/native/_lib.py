@@ -85,6 +85,7 @@ SIGNATURES = {
     "mlqem_keys_to_edge_index": (_I, [_P, _L, _P, _P]),
     "mlqem_asap_coarsen_rows_workspace_bytes": (_S, [_L, _I]),
     "mlqem_asap_coarsen_rows_max_bits": (_I, []),
+    "mlqem_asap_slot_map": (_I, [_P, _L, _L, _P, _P]),
     "mlqem_asap_coarsen_rows_count": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_rows_fill": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_dense_max_k": (_I, []),
@@ -104,7 +105,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 10   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 11   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

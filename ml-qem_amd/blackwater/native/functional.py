@@ -504,8 +504,7 @@ class _ASAPool(Function):
         if _ASAP_LAZY:
             # the coarsened connectivity S^T A S waits until a layer reads it (GraphStructure.deferred); the backward's
             # slot[] (cluster id of every kept centre, -1 elsewhere) does not depend on it
-            slot = torch.full((max(n, 1),), -1, dtype=torch.int32, device=x.device)
-            slot[perm.long()] = torch.arange(k_total, dtype=torch.int32, device=x.device)
+            slot = ops.asap_slot_map(perm, n)
             holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=keep)
         else:
             csr7, slot = build()

@@ -786,6 +786,15 @@ def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_g
     return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], out_eid[:e]), slot, e
 
 
+def asap_slot_map(perm, num_nodes):
+    """slot[N]: cluster id of every kept centre (slot[perm[p]] = p), -1 elsewhere."""
+    k = int(perm.shape[0])
+    slot = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=perm.device)
+    code = _lib.load().mlqem_asap_slot_map(_p(perm), num_nodes, k, _p(slot), _stream())
+    _lib.check(code, "mlqem_asap_slot_map")
+    return slot
+
+
 def asap_rows_max_bits() -> int:
     return int(_lib.load().mlqem_asap_coarsen_rows_max_bits())
 

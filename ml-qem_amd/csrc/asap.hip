@@ -601,6 +601,17 @@ extern "C" size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax) {
   return 2 * bm + 2 * deg + pref + dense_scan_bytes(K);
 }
 
+extern "C" int mlqem_asap_slot_map(const int32_t* perm, int64_t N, int64_t K, int32_t* slot, mlqem_stream_t stream_) {
+  begin_launches();
+  hipStream_t stream = as_stream(stream_);
+  if (N < 0 || K < 0 || K > N) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!slot || (K > 0 && !perm)) return MLQEM_ERR_BAD_ARG;
+  if (hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  if (K > 0) hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
+  return launch_status();
+}
+
 extern "C" int mlqem_asap_coarsen_rows_max_bits(void) { return 64 * 1024 * 8 / 4; }   // (n_g + k_g) bits per wave: 64 KB of LDS, four waves
 
 static bool rows_args(RowsArgs& a, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
