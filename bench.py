@@ -307,7 +307,9 @@ def family_b_leg(dev, steps=30):
         out[f"batch{batch}"] = {"circuits_per_s": round(batch * n_steps / dt, 1), "ms_per_step": round(dt / n_steps * 1e3, 3),
                                 "steps": n_steps}
     # the same model on the headline workload's graphs (100-qubit circuits, 2-20 k nodes each): ASAPooling's coarsening takes the
-    # wave-per-cluster form there (mlqem_asap_coarsen_rows_*: no sort, one host read per pooling)
+    # wave-per-cluster form there (mlqem_asap_coarsen_rows_*: no sort, one host read per pooling) and is computed for the first
+    # pooling only (nothing reads the second one's: GraphStructure.deferred); the coarsened graph has 27 edges per node in
+    # rows of 100-500, which the attention / ASAPooling kernels walk in chunks with one lane per edge for the scalar work
     torch.cuda.reset_peak_memory_stats()
     mem_before = torch.cuda.memory_allocated()
     hb = TfimCorpus(100, list(range(1, 11)), 7, seed=42, exp_value_size=4).host_graphs()
@@ -377,9 +379,11 @@ def family_b_leg(dev, steps=30):
                        "achieved": round(by / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / sec / 1e9 / 8000.0, 4),
                        "traffic": None, "bytes_per_launch": int(by), "us_per_launch": round(sec * 1e6, 2), "nodes": n,
                        "edges_with_loops": e1,
-                       "note": "latency-bound, not bandwidth-bound: 16 lanes per (row, head) fetch 60-byte key/value segments at odd "
-                               "float offsets (C = 15), three dependent round trips per row; a 1024-circuit batch of 4-qubit "
-                               "graphs is only 0.23 M nodes and the step spreads over ~100 such small launches"}
+                       "note": "bound by the vector ALU, not by bandwidth: a 16-lane group per (row, head) repeats the per-edge scalar "
+                               "work (exp, dropout draw, addresses) in every lane and 15 of its 16 lanes hold a channel (C = 15); "
+                               "measured by elimination in scripts/attn_micro.py (fetching values with the keys, a 32-bit hash, "
+                               "DPP reductions and one pass instead of three each paid; the ELL side table did not). A 1024-circuit "
+                               "batch of 4-qubit graphs is only 0.23 M nodes and the step spreads over ~100 such small launches"}
     return out
 
 
