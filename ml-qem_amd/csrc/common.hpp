@@ -133,6 +133,12 @@ template <int U> __device__ __forceinline__ float group16_bcast(float v) {
 template <int U> __device__ __forceinline__ int group16_bcast(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, true);
 }
+// lanes U0 .. U0 + 7 of the group, each broadcast to all sixteen
+template <int U0, class T> __device__ __forceinline__ void group16_bcast8(T v, T (&out)[8]) {
+  out[0] = group16_bcast<U0 + 0>(v); out[1] = group16_bcast<U0 + 1>(v); out[2] = group16_bcast<U0 + 2>(v);
+  out[3] = group16_bcast<U0 + 3>(v); out[4] = group16_bcast<U0 + 4>(v); out[5] = group16_bcast<U0 + 5>(v);
+  out[6] = group16_bcast<U0 + 6>(v); out[7] = group16_bcast<U0 + 7>(v);
+}
 __device__ __forceinline__ float group16_max(float v) {
   v = fmaxf(v, dpp_row<0xB1>(v));
   v = fmaxf(v, dpp_row<0x4E>(v));

@@ -396,8 +396,161 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_any_width_ke
   if (l == 0) g_a[row] = ga;
 }
 
+// The three source-/destination-side passes below give a 16-lane group to a row; lane l holds channels l, l + 16, ... (NV
+// per lane).  A chunk is 16 edges: lane u fetches the index entries (and per-edge scalars) of edge u, the others get them by
+// DPP broadcast when the rows are fetched, eight rows in flight.  (A thread per (row, channel) repeats the index loads and
+// the address arithmetic in each of a row's 30-45 threads: these kernels are bound by instruction issue, see attn_fwd.hpp.)
+// The *_any_width kernels after them are the thread-per-(row, channel) forms, kept for rows wider than 128 channels.
+
 // Source side: g_x[j,:] (+)= sum_{e: j->i} al_e gnew[i,:] (self included); g_c[j] = sum_e gp_e.
-__global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
+template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
+    const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
+    const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
+    int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  bool has[NV];
+  float acc[NV];
+  const float al_self = edge_al[E + row];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    has[v] = l + v * kGroup < C;
+    acc[v] = al_self * (has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f);
+  }
+  float gc = 0.f;                                      // lane u: the gp of its edges
+  const int beg = optr[row], end = optr[row + 1];
+  for (int e0 = beg; e0 < end; e0 += kGroup) {
+    const int k = min(kGroup, end - e0);
+    const int ee = e0 + min(l, k - 1);
+    const int i = odst[ee], pos = oeid[ee];
+    const float al = l < k ? edge_al[pos] : 0.f;        // lanes past the end: the last edge again with weight 0
+    if (l < k) gc += edge_gp[pos];
+    auto rows = [&](auto first) {
+      constexpr int U0 = decltype(first)::value;
+      int iu[8];
+      float au[8], gn[8][NV];
+      group16_bcast8<U0>(i, iu);
+      group16_bcast8<U0>(al, au);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg + l;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) gn[u][v] = has[v] ? gi[v * kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = fmaf(au[u], gn[u][v], acc[v]);
+    };
+    rows(EdgeChunk<0>{});
+    if (k > 8) rows(EdgeChunk<8>{});
+  }
+  gc = group16_sum(gc) + edge_gp[E + row];
+  float* __restrict__ d = gx + row * ldgx + l;
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    if (has[v]) d[v * kGroup] = accumulate ? d[v * kGroup] + acc[v] : acc[v];
+  if (l == 0) g_c[row] = gc;
+}
+
+// Segment-max backward.  Ties: the gradient of a row's maximum is split EVENLY among the entries that attain it
+// (torch's scatter_reduce(amax) rule, which PyG >= 2.3 uses without torch_scatter): circuit graphs do contain exact
+// ties, because identical gates on one qubit have identical feature rows.
+// Pass 1 (destination side): gshare[i,c] = gmax[i,c] / #{entries of row i (sources and i itself) equal to xmax[i,c]}.
+template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_share_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
+    const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ iptr, const int32_t* __restrict__ isrc,
+    int64_t N, int C, float* __restrict__ gshare, int64_t lds) {
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  bool has[NV];
+  float m[NV];
+  int cnt[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    has[v] = l + v * kGroup < C;
+    m[v] = has[v] ? xmax[row * ldm + l + v * kGroup] : 0.f;
+    cnt[v] = (has[v] && x[row * ldx + l + v * kGroup] == m[v]) ? 1 : 0;
+  }
+  const int beg = iptr[row], end = iptr[row + 1];
+  for (int e0 = beg; e0 < end; e0 += kGroup) {
+    const int k = min(kGroup, end - e0);
+    const int j = isrc[e0 + min(l, k - 1)];
+    auto rows = [&](auto first, int kk) {               // kk: edges of this half that exist
+      constexpr int U0 = decltype(first)::value;
+      int ju[8];
+      float xs[8][NV];
+      group16_bcast8<U0>(j, ju);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xs[u][v] = has[v] ? xj[v * kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cnt[v] += (u < kk && xs[u][v] == m[v]) ? 1 : 0;
+    };
+    rows(EdgeChunk<0>{}, k);
+    if (k > 8) rows(EdgeChunk<8>{}, k - 8);
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    if (has[v]) gshare[row * lds + l + v * kGroup] = gmax[row * ldg + l + v * kGroup] / (float)(cnt[v] > 0 ? cnt[v] : 1);
+}
+
+// Pass 2 (source side): g_x[j,c] += sum over destinations i of j (and j itself) whose maximum equals x[j,c].
+template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
+    const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
+    int64_t N, int C, float* __restrict__ gx, int64_t ldgx) {
+  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  bool has[NV];
+  float xv[NV], acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    has[v] = l + v * kGroup < C;
+    xv[v] = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
+    acc[v] = (has[v] && xv[v] == xmax[row * ldm + l + v * kGroup]) ? gmax[row * ldg + l + v * kGroup] : 0.f;
+  }
+  const int beg = optr[row], end = optr[row + 1];
+  for (int e0 = beg; e0 < end; e0 += kGroup) {
+    const int k = min(kGroup, end - e0);
+    const int i = odst[e0 + min(l, k - 1)];
+    auto rows = [&](auto first, int kk) {
+      constexpr int U0 = decltype(first)::value;
+      int iu[8];
+      float xm[8][NV], gm[8][NV];
+      group16_bcast8<U0>(i, iu);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* __restrict__ xi = xmax + (int64_t)iu[u] * ldm + l;
+        const float* __restrict__ gi = gmax + (int64_t)iu[u] * ldg + l;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          xm[u][v] = has[v] ? xi[v * kGroup] : 0.f;
+          gm[u][v] = has[v] ? gi[v * kGroup] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) if (u < kk && has[v] && xv[v] == xm[u][v]) acc[v] += gm[u][v];
+    };
+    rows(EdgeChunk<0>{}, k);
+    if (k > 8) rows(EdgeChunk<8>{}, k - 8);
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) if (has[v]) gx[row * ldgx + l + v * kGroup] += acc[v];
+}
+
+// Source side: g_x[j,:] (+)= sum_{e: j->i} al_e gnew[i,:] (self included); g_c[j] = sum_e gp_e.
+__global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_any_width_kernel(
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
     int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
@@ -438,7 +591,7 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
 // (torch's scatter_reduce(amax) rule, which PyG >= 2.3 uses without torch_scatter): circuit graphs do contain exact
 // ties, because identical gates on one qubit have identical feature rows.
 // Pass 1 (destination side): gshare[i,c] = gmax[i,c] / #{entries of row i (sources and i itself) equal to xmax[i,c]}.
-__global__ __launch_bounds__(kBlock) void segment_max_share_kernel(
+__global__ __launch_bounds__(kBlock) void segment_max_share_any_width_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ iptr, const int32_t* __restrict__ isrc,
     int64_t N, int C, float* __restrict__ gshare, int64_t lds) {
@@ -460,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void segment_max_share_kernel(
 }
 
 // Pass 2 (source side): g_x[j,c] += sum over destinations i of j (and j itself) whose maximum equals x[j,c].
-__global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
+__global__ __launch_bounds__(kBlock) void segment_max_bwd_any_width_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     int64_t N, int C, float* __restrict__ gx, int64_t ldgx) {
@@ -609,8 +762,17 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
     hipLaunchKernelGGL(softmax_aggregate_bwd_dst_any_width_kernel, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr,
                        in_src, a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a);
 #undef MLQEM_SAB
-  hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel, MLQEM_GRID(N * C), gnew, ldg, out_ptr, out_dst, out_eid,
-                     edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c);
+#define MLQEM_SAS(NV) hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel<NV>, MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, \
+                                         out_eid, edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c)
+  if (C <= 16) MLQEM_SAS(1);
+  else if (C <= 32) MLQEM_SAS(2);
+  else if (C <= 48) MLQEM_SAS(3);
+  else if (C <= 64) MLQEM_SAS(4);
+  else if (C <= 128) MLQEM_SAS(8);
+  else
+    hipLaunchKernelGGL(softmax_aggregate_bwd_src_any_width_kernel, MLQEM_GRID(N * C), gnew, ldg, out_ptr, out_dst, out_eid,
+                       edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c);
+#undef MLQEM_SAS
   return launch_status();
 }
 
@@ -623,10 +785,25 @@ extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const 
   if (N < 0 || C <= 0 || ldx < C || ldm < C || ldg < C || ldgx < C || lds < C) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!x || !xmax || !gmax || !in_ptr || !out_ptr || !gx || !gshare) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(segment_max_share_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, N, C,
-                     gshare, lds);
-  hipLaunchKernelGGL(segment_max_bwd_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gshare, lds, out_ptr, out_dst, N, C,
-                     gx, ldgx);
+#define MLQEM_SMB(NV)                                                                                                        \
+  do {                                                                                                                       \
+    hipLaunchKernelGGL(segment_max_share_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, N, \
+                       C, gshare, lds);                                                                                      \
+    hipLaunchKernelGGL(segment_max_bwd_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xmax, ldm, gshare, lds, out_ptr, out_dst,  \
+                       N, C, gx, ldgx);                                                                                      \
+  } while (0)
+  if (C <= 16) MLQEM_SMB(1);
+  else if (C <= 32) MLQEM_SMB(2);
+  else if (C <= 48) MLQEM_SMB(3);
+  else if (C <= 64) MLQEM_SMB(4);
+  else if (C <= 128) MLQEM_SMB(8);
+  else {
+    hipLaunchKernelGGL(segment_max_share_any_width_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, N,
+                       C, gshare, lds);
+    hipLaunchKernelGGL(segment_max_bwd_any_width_kernel, MLQEM_GRID(N * C), x, ldx, xmax, ldm, gshare, lds, out_ptr, out_dst,
+                       N, C, gx, ldgx);
+  }
+#undef MLQEM_SMB
   return launch_status();
 }
 
