@@ -10,12 +10,12 @@
 namespace mlqem {
 
 // ------------------------------------------------------------------------------------------ per-graph top-k
-// key = (order-preserving bits of fitness) << 32 | (0xFFFFFFFF - local index): a DESCENDING sort of these unique
-// keys lists a graph's nodes by descending fitness with ties broken by the lower index, whatever algorithm the
-// segmented sort picks for the segment size.
+// key = (order-preserving bits of fitness) << b | (2^b - 1 - local index), b = bits of the largest local index: a
+// DESCENDING sort of these unique keys lists a graph's nodes by descending fitness with ties broken by the lower index,
+// whatever algorithm the segmented sort picks for the segment size, and the radix sort walks 32 + b bits instead of 64.
 __global__ __launch_bounds__(kBlock) void topk_keys_kernel(const float* __restrict__ fitness,
                                                            const int32_t* __restrict__ gptr, int B, int64_t N,
-                                                           uint64_t* __restrict__ keys) {
+                                                           int idx_bits, uint64_t* __restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
   int lo = 0, hi = B;  // graph of node i: largest g with gptr[g] <= i
@@ -26,13 +26,13 @@ __global__ __launch_bounds__(kBlock) void topk_keys_kernel(const float* __restri
   const uint32_t bits = __float_as_uint(fitness[i]);
   const uint32_t ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
   const uint32_t local = (uint32_t)(i - gptr[lo]);
-  keys[i] = ((uint64_t)ord << 32) | (uint64_t)(0xFFFFFFFFu - local);
+  keys[i] = ((uint64_t)ord << idx_bits) | (uint64_t)(((1u << idx_bits) - 1u) - local);
 }
 
 __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __restrict__ sorted,
                                                              const int32_t* __restrict__ gptr,
                                                              const int32_t* __restrict__ new_gptr, int B,
-                                                             int64_t K, int32_t* __restrict__ perm) {
+                                                             int64_t K, int idx_bits, int32_t* __restrict__ perm) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= K) return;
   int lo = 0, hi = B;
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __r
   }
   const int64_t r = p - new_gptr[lo];
   const uint64_t key = sorted[gptr[lo] + r];
-  perm[p] = gptr[lo] + (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+  const uint32_t mask = (1u << idx_bits) - 1u;
+  perm[p] = gptr[lo] + (int32_t)(mask - ((uint32_t)key & mask));
 }
 
 static size_t topk_temp_bytes(int64_t N, int64_t B) {
@@ -445,13 +446,15 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
   uint64_t* sorted = reinterpret_cast<uint64_t*>(ws + kb);
   void* temp = ws + 2 * kb;
   size_t temp_bytes = topk_temp_bytes(N, B);
+  int idx_bits = 1;                                    // a graph has at most N nodes: local indices fit idx_bits bits (N < 2^31)
+  while (idx_bits < 31 && ((int64_t)1 << idx_bits) < N) ++idx_bits;
   hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, fitness,
-                     graph_ptr, (int)B, N, keys);
+                     graph_ptr, (int)B, N, idx_bits, keys);
   if (rocprim::segmented_radix_sort_keys_desc(temp, temp_bytes, keys, sorted, (unsigned)N, (unsigned)B, graph_ptr,
-                                              graph_ptr + 1, 0, 64, stream) != hipSuccess)
+                                              graph_ptr + 1, 0, 32 + idx_bits, stream) != hipSuccess)
     return MLQEM_ERR_LAUNCH;
   hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, sorted,
-                     graph_ptr, new_graph_ptr, (int)B, K, perm);
+                     graph_ptr, new_graph_ptr, (int)B, K, idx_bits, perm);
   return launch_status();
 }
 

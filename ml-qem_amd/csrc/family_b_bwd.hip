@@ -174,33 +174,68 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
   const float* __restrict__ edge_gs = a.edge_gs;
   const int64_t ld = a.ld, ldg = a.ldg;
   float gk0 = 0.f, gk1 = 0.f, gv0 = 0.f, gv1 = 0.f;
-  for_edge_chunks(a.optr[row], a.optr[row + 1], [&](int e, auto kc) {     // chunks fetched together, used in edge order
-    constexpr int K = decltype(kc)::value;
-    int ii[K], pp[K];
-    float gs[K], al[K], qa[K], qb[WIDE ? K : 1], ga[K], gb[WIDE ? K : 1];
+  const int obeg = a.optr[row], oend = a.optr[row + 1];
+  if (oend - obeg >= 8) {
+    // long rows, eight edges at a time: lane u (and u + 8) fetches the index entries and the two per-edge scalars of edge u,
+    // the others get them by DPP broadcast when the rows are fetched
+    for (int e = obeg; e < oend; e += 8) {
+      const int k = min(8, oend - e);
+      const int lu = l & 7;
+      const int ee = e + min(lu, k - 1);
+      const int i = a.odst[ee];
+      const int64_t pos = a.oeid[ee];
+      const float gs = lu < k ? edge_gs[pos * H + h] : 0.f;    // past the end: the last edge again with weight 0
+      const float al = lu < k ? edge_al[pos * H + h] : 0.f;
+      int iu[8];
+      float gsu[8], alu[8], qa[8], qb[WIDE ? 8 : 1], ga[8], gb[WIDE ? 8 : 1];
+      group16_bcast8<0>(i, iu);
+      group16_bcast8<0>(gs, gsu);
+      group16_bcast8<0>(al, alu);
 #pragma unroll
-    for (int u = 0; u < K; ++u) {
-      ii[u] = a.odst[e + u];
-      pp[u] = a.oeid[e + u];
-    }
+      for (int u = 0; u < 8; ++u) {
+        qa[u] = c0 ? qkvs[(int64_t)iu[u] * ld + o0] : 0.f;
+        ga[u] = c0 ? g[(int64_t)iu[u] * ldg + o0] : 0.f;
+        if (WIDE) {
+          qb[u] = c1 ? qkvs[(int64_t)iu[u] * ld + o1] : 0.f;
+          gb[u] = c1 ? g[(int64_t)iu[u] * ldg + o1] : 0.f;
+        }
+      }
 #pragma unroll
-    for (int u = 0; u < K; ++u) {
-      gs[u] = edge_gs[(int64_t)pp[u] * H + h];
-      al[u] = edge_al[(int64_t)pp[u] * H + h];
-      qa[u] = c0 ? qkvs[(int64_t)ii[u] * ld + o0] : 0.f;
-      ga[u] = c0 ? g[(int64_t)ii[u] * ldg + o0] : 0.f;
-      if (WIDE) {
-        qb[u] = c1 ? qkvs[(int64_t)ii[u] * ld + o1] : 0.f;
-        gb[u] = c1 ? g[(int64_t)ii[u] * ldg + o1] : 0.f;
+      for (int u = 0; u < 8; ++u) {
+        gk0 = fmaf(gsu[u], qa[u], gk0);
+        gv0 = fmaf(alu[u], ga[u], gv0);
+        if (WIDE) { gk1 = fmaf(gsu[u], qb[u], gk1); gv1 = fmaf(alu[u], gb[u], gv1); }
       }
     }
+  } else {
+    for_edge_chunks(obeg, oend, [&](int e, auto kc) {                 // chunks fetched together, used in edge order
+      constexpr int K = decltype(kc)::value;
+      int ii[K], pp[K];
+      float gs[K], al[K], qa[K], qb[WIDE ? K : 1], ga[K], gb[WIDE ? K : 1];
 #pragma unroll
-    for (int u = 0; u < K; ++u) {
-      gk0 = fmaf(gs[u], qa[u], gk0);
-      gv0 = fmaf(al[u], ga[u], gv0);
-      if (WIDE) { gk1 = fmaf(gs[u], qb[u], gk1); gv1 = fmaf(al[u], gb[u], gv1); }
-    }
-  });
+      for (int u = 0; u < K; ++u) {
+        ii[u] = a.odst[e + u];
+        pp[u] = a.oeid[e + u];
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        gs[u] = edge_gs[(int64_t)pp[u] * H + h];
+        al[u] = edge_al[(int64_t)pp[u] * H + h];
+        qa[u] = c0 ? qkvs[(int64_t)ii[u] * ld + o0] : 0.f;
+        ga[u] = c0 ? g[(int64_t)ii[u] * ldg + o0] : 0.f;
+        if (WIDE) {
+          qb[u] = c1 ? qkvs[(int64_t)ii[u] * ld + o1] : 0.f;
+          gb[u] = c1 ? g[(int64_t)ii[u] * ldg + o1] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < K; ++u) {
+        gk0 = fmaf(gs[u], qa[u], gk0);
+        gv0 = fmaf(al[u], ga[u], gv0);
+        if (WIDE) { gk1 = fmaf(gs[u], qb[u], gk1); gv1 = fmaf(al[u], gb[u], gv1); }
+      }
+    });
+  }
   {   // the self entry, last
     const float gs = edge_gs[(a.E + row) * H + h], al = edge_al[(a.E + row) * H + h];
     if (c0) { gk0 = fmaf(gs, qkvs[(int64_t)row * ld + o0], gk0); gv0 = fmaf(al, g[(int64_t)row * ldg + o0], gv0); }
