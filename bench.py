@@ -482,48 +482,56 @@ def main():
             torch.distributed.init_process_group(backend)
 
     from blackwater.nn import ExpValCircuitGraphModelA
-    from blackwater.train import DataParallelShard, Trainer
+    from blackwater.train import BucketedTrainer, DataParallelShard, StratifiedBatches
 
     n_j = args.n_j if args.n_j > 0 else -(-CORPUS_BATCHES * args.batch * world // len(STEPS_LIST))
     corpus = build_corpus(n_j)
     # the data-parallel split by circuit: balanced by node count, every shard the same length
     local_ids = DataParallelShard.split(corpus.node_counts, world)[rank]
-    arena = corpus.arena(dev, local_ids)
+    node_quantum = 1024
+    arena = corpus.arena(dev, local_ids, filler_nodes=node_quantum)
     n_local = len(arena)
     torch.manual_seed(0)
     model = ExpValCircuitGraphModelA(100, 22, 10).to(dev)
-    trainer = Trainer(model, lr=1e-3, distributed=distributed)
 
-    # every rank walks its own shard in seeded epoch permutations, `batch` circuits per step
-    rng = np.random.RandomState(1000 + rank)
-    state = {"perm": rng.permutation(n_local), "pos": 0}
+    # Every rank walks its own shard in size-stratified batches (StratifiedBatches: the same number of circuits of every
+    # Trotter step count in every batch, each class in its own seeded epoch permutation), `batch` circuits per step.  All
+    # batches then have the same node and edge totals, so the whole step -- device batch assembly, forward, loss, backward,
+    # (eager gradient all-reduce,) Adam -- is captured ONCE in a hipGraph and replayed: the host uploads 1024 graph ids and
+    # launches the graph.  MLQEM_BENCH_GRAPHS=0 enqueues the same bucketed step kernel by kernel (~70 launches, 2 ms of host
+    # time on a quiet box, 6 ms on a loaded one -- the step takes 6.8 ms on the device).
+    sampler = StratifiedBatches(arena.node_counts[:n_local], arena.edge_counts[:n_local], args.batch, seed=1000 + rank)
+    use_graphs = os.environ.get("MLQEM_BENCH_GRAPHS", "1") != "0"
+    trainer = BucketedTrainer(model, arena, lr=1e-3, graphs=use_graphs, node_quantum=node_quantum, distributed=distributed)
+    step_mode = "hipgraph replay (one capture: size-stratified batches share one bucket)" if use_graphs else "eager (bucketed)"
 
-    def draw():
-        if args.batch >= n_local:
-            return rng.randint(0, n_local, size=args.batch)
-        if state["pos"] + args.batch > n_local:
-            state["perm"], state["pos"] = rng.permutation(n_local), 0
-        sel = state["perm"][state["pos"]:state["pos"] + args.batch]
-        state["pos"] += args.batch
-        return sel
+    def step():
+        return trainer.step_ids(sampler.draw())
 
-    # Batches differ in node count (circuits vary 10x), so torch's caching allocator keeps growing -- each growth is a
-    # hipMalloc that drains the queue -- until it has seen the largest batch.  Show it that batch once, untimed.
-    sizes = arena.node_counts
-    trainer.step(arena.batch(np.argsort(sizes)[::-1][np.arange(args.batch) % max(1, min(args.batch // 4, n_local))]))
+    try:
+        step()                      # the capture (or, eagerly, the allocator's first sight of the batch), untimed
+    except Exception as exc:        # a box where the capture fails still gets a measured, correct, eager number
+        if distributed:
+            raise
+        print(f"bench.py: hipGraph capture failed ({type(exc).__name__}: {exc}); enqueueing the bucketed step eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        trainer.graphs = False
+        step_mode = "eager (bucketed; capture failed: %s)" % type(exc).__name__
+        step()
     for _ in range(args.warmup):
-        trainer.step(arena.batch(draw()))
+        step()
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = None
     for _ in range(args.steps):
-        loss = trainer.step(arena.batch(draw()))
+        loss = step()
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    loss = loss.clone()
     joined = 1
     if distributed:
         t = torch.tensor([elapsed, 0.0], device=dev, dtype=torch.float64)
@@ -533,15 +541,13 @@ def main():
         elapsed, joined = t[0].item(), int(round(ones.item()))
 
     # how long the HOST needs to enqueue one step (the step is device-bound only while this stays below ms_per_step): a few
-    # extra steps with unbounded run-ahead, timed up to the return of the last enqueue
-    keep_bound, trainer.max_steps_in_flight = trainer.max_steps_in_flight, 0
+    # extra steps, timed up to the return of the last enqueue
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(4):
-        trainer.step(arena.batch(draw()))
+        step()
     host_ms = (time.perf_counter() - t1) / 4 * 1e3
     torch.cuda.synchronize()
-    trainer.max_steps_in_flight = keep_bound
 
     if rank == 0:
         total = args.batch * joined * args.steps
@@ -556,6 +562,8 @@ def main():
                        "circuits_per_step_per_gpu": args.batch, "corpus_circuits": len(corpus),
                        "corpus_circuits_per_gpu": n_local, "arena_nodes_per_gpu": int(arena.num_nodes),
                        "mean_nodes_per_circuit": round(arena.num_nodes / n_local, 1), "parallelism": f"dp{joined}",
+                       "nodes_per_step_per_gpu": sampler.nodes_per_batch, "step_mode": step_mode,
+                       "sampling": "size-stratified: %s circuits of the 10 Trotter step counts per batch" % "/".join(map(str, sampler.quota)),
                        "backend": backend, "ranks_joined": joined,
                        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None},
             "final_loss": round(float(loss.item()), 6), "host_enqueue_ms_per_step": round(host_ms, 3),
@@ -566,6 +574,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline_leg(corpus, rep, 100)
             line["parity"] = parity_leg(model, arena, corpus, local_ids, 100)   # the oracle as the checker, outside the timed region
             del trainer, model, arena, fixed
+            from blackwater.native import ops as _ops
+            _ops.set_seed_counter(None)       # the bucketed trainer's device-resident dropout counter
             torch.cuda.empty_cache()
             line["accuracy"] = accuracy_leg(dev)
             line["family_b"] = family_b_leg(dev)

@@ -126,6 +126,18 @@ class Trainer:
             and not torch.cuda.is_current_stream_capturing()
         if throttle and len(self._inflight) >= self.max_steps_in_flight:
             self._inflight.pop(0).synchronize()
+        loss = self._forward_backward(batch)
+        if self.distributed:
+            self.all_reduce_gradients()
+        self.optimizer.step()
+        if throttle:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._inflight.append(ev)
+        return loss
+
+    def _forward_backward(self, batch) -> torch.Tensor:
+        """The local half of a step: forward, loss, backward, gradients filed into the flat buffer.  Returns the loss."""
         self.model.train()
         if self.flat_grad is not None:
             # With .grad pointing into the flat buffer autograd would ADD every parameter's gradient into its slot: one
@@ -153,13 +165,6 @@ class Trainer:
                 torch._foreach_copy_(self._grad_slots, grads)
             for p, slot in zip(self._params, self._grad_slots):
                 p.grad = slot                   # what callers (and the reference's loop shape) expect to find
-        if self.distributed:
-            self.all_reduce_gradients()
-        self.optimizer.step()
-        if throttle:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._inflight.append(ev)
         return loss.detach()
 
     def all_reduce_gradients(self):
@@ -226,6 +231,51 @@ class Trainer:
         return history
 
 
+class StratifiedBatches:
+    """Batches that all hold the same number of graphs of every SIZE (node count, edge count): a size-stratified sampler.
+
+    The graphs of a circuit corpus come in a few sizes (a Trotter circuit's graph depends on its step count, not on its
+    couplings), and a batch drawn uniformly has a different node total every time -- different launch shapes, a different
+    allocation pattern, nothing to capture.  Here every batch takes ``quota[c]`` graphs of size class c -- the quotas are
+    the classes' shares of ``batch``, remainders handed to the classes nearest the mean size so that the batch total stays
+    near batch x mean -- walking each class in its own seeded epoch permutation.  All batches then have identical node and
+    edge totals: one bucket for :class:`BucketedTrainer`, no padding."""
+
+    def __init__(self, node_counts, edge_counts, batch: int, seed: int = 0):
+        nodes, edges = np.asarray(node_counts, dtype=np.int64), np.asarray(edge_counts, dtype=np.int64)
+        keys = nodes * (int(edges.max()) + 1 if len(edges) else 1) + edges
+        uniq, inverse = np.unique(keys, return_inverse=True)
+        self.classes = [np.flatnonzero(inverse == c) for c in range(len(uniq))]
+        sizes = np.array([len(c) for c in self.classes], dtype=np.float64)
+        share = sizes / sizes.sum() * batch
+        quota = np.floor(share).astype(np.int64)
+        class_nodes = np.array([nodes[c[0]] for c in self.classes], dtype=np.float64)
+        mean = float((class_nodes * sizes).sum() / sizes.sum())
+        spare = int(batch - quota.sum())
+        # the remainder goes to classes with the largest fractional share, ties to the sizes nearest the mean
+        order = sorted(range(len(uniq)), key=lambda c: (-(share[c] - quota[c]), abs(class_nodes[c] - mean)))
+        for c in order[:spare]:
+            quota[c] += 1
+        if (quota > sizes).any():
+            raise ValueError("StratifiedBatches: a size class holds fewer graphs than its share of one batch")
+        self.quota, self.batch = quota, int(batch)
+        self.rng = np.random.RandomState(seed)
+        self._perm = [self.rng.permutation(c) for c in self.classes]
+        self._pos = [0] * len(self.classes)
+        self.nodes_per_batch = int((quota * class_nodes).sum())
+
+    def draw(self) -> np.ndarray:
+        out = []
+        for c, q in enumerate(self.quota):
+            if q == 0:
+                continue
+            if self._pos[c] + q > len(self._perm[c]):
+                self._perm[c], self._pos[c] = self.rng.permutation(self.classes[c]), 0
+            out.append(self._perm[c][self._pos[c]:self._pos[c] + q])
+            self._pos[c] += q
+        return np.concatenate(out)
+
+
 class BucketedTrainer(Trainer):
     """The small-batch path (the reference's regime: batches of 32, docs/tutorials/__ml_models.py:105,148).
 
@@ -242,11 +292,20 @@ class BucketedTrainer(Trainer):
     * Adam runs with device-resident step / learning rate (``capturable=True``).
 
     ``graphs=False`` runs the very same bucketed step eagerly: the two modes launch identical kernels with identical
-    arguments, so their loss trajectories agree bit for bit (tests/test_gpu_small_batch.py)."""
+    arguments, so their loss trajectories agree bit for bit (tests/test_gpu_small_batch.py).
+
+    The same trainer drives LARGE batches when their sizes repeat: with :class:`StratifiedBatches` every batch of the
+    headline workload holds the same number of circuits of every size, so all of them fall into ONE bucket, nothing is
+    padded (beyond the node quantum) and the step costs the host one selection upload and one replay -- it no longer
+    matters whether the box's host enqueues a 70-launch step in 2 ms or in 6."""
 
     def __init__(self, model: nn.Module, arena, lr: float = 1e-3, graphs: bool = True, node_quantum: int = 1024,
-                 edge_quantum: int = 2048):
-        super().__init__(model, lr=lr, distributed=False, flat=True, capturable=True)
+                 edge_quantum: int = 2048, distributed: bool = False, split_update: bool = False):
+        super().__init__(model, lr=lr, distributed=distributed, flat=True, capturable=True)
+        # Under data parallelism the gradient all-reduce sits between two captured halves -- (assembly, forward, backward)
+        # and (Adam) -- and is enqueued eagerly: one collective call per step on the host instead of ~70 launches.
+        # ``split_update`` forces the two-graph form without a process group (tests).
+        self.split = bool(split_update) or self.distributed
         if not arena.filler_nodes:
             raise ValueError("BucketedTrainer needs an arena built with filler_nodes > 0")
         if node_quantum > arena.filler_nodes:
@@ -260,6 +319,7 @@ class BucketedTrainer(Trainer):
         model.static_dropout_key = True          # seeds = key(seed, rank) + device counter instead of a host call counter
         self._entries = {}
         self._pool = None
+        self._update_graph = None
         self._warm = False
 
     def bucket_of(self, graph_ids):
@@ -268,9 +328,16 @@ class BucketedTrainer(Trainer):
         return (-(-nb // self.nq) * self.nq, -(-max(eb, 1) // self.eq) * self.eq, len(sel))
 
     def _step_on(self, packed, b, n_pad, e_pad, sizes, num_real):
+        loss = self._local_half(packed, b, n_pad, e_pad, sizes, num_real)
+        if self.distributed:
+            self.all_reduce_gradients()
+        self.optimizer.step()
+        return loss
+
+    def _local_half(self, packed, b, n_pad, e_pad, sizes, num_real):
         self.counter.add_(1)
         batch = self.arena.assemble(packed, b, n_pad, e_pad, sizes, None, num_real)
-        return Trainer.step(self, batch)
+        return self._forward_backward(batch)
 
     def _warm_up(self, ids, bucket):
         """torch asks for a few eager iterations on a side stream before the first capture (lazy initialisation of
@@ -319,14 +386,28 @@ class BucketedTrainer(Trainer):
             self._send(entry, host)
             torch.cuda.synchronize()
             kw = {} if self._pool is None else {"pool": self._pool}
-            with torch.cuda.graph(entry["graph"], **kw):
-                entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real)
+            if not self.split:
+                with torch.cuda.graph(entry["graph"], **kw):
+                    entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real)
+            else:
+                with torch.cuda.graph(entry["graph"], **kw):
+                    entry["loss"] = self._local_half(entry["packed"], len(sel), nb, eb, sizes, real)
             if self._pool is None:
                 self._pool = entry["graph"].pool()
+            if self.split and self._update_graph is None:
+                # Adam touches the flat buffers only: one graph serves all buckets (its own memory pool: it is replayed after
+                # whichever bucket's graph ran, not in capture order)
+                self._update_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._update_graph):
+                    self.optimizer.step()
             self._entries[bucket] = entry
         else:
             self._send(entry, host)
         entry["graph"].replay()
+        if self.split:
+            if self.distributed:
+                self.all_reduce_gradients()
+            self._update_graph.replay()
         return entry["loss"]
 
     @staticmethod

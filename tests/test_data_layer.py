@@ -95,3 +95,27 @@ def test_feature_encoders_match_oracle_and_shapes(g1, lima_props):
     X2, _ = encode_data_v2_ecr(circs[:3], [[0.0] * 4] * 3, g1["noisy"][:3].tolist(), 4, two_q_gate="cx")
     assert X2.shape == (3, 5 + 160 + 4)  # 169-d demo2 feature set
     assert X2[0, 0].item() == pytest.approx(0.01 * circs[0].count_ops().get("cx", 0))
+
+
+def test_stratified_batches_quotas_and_epochs():
+    """train.StratifiedBatches (host logic): quotas are the classes' shares of the batch, remainders go to the sizes nearest
+    the mean, every batch has the same node total, and a class is walked through completely before any of it repeats."""
+    import numpy as np
+
+    from blackwater.train import StratifiedBatches
+
+    nodes = np.repeat(np.arange(1, 11) * 2000 + 89, 820)
+    edges = nodes * 5 // 4
+    sb = StratifiedBatches(nodes, edges, 1024, seed=1)
+    assert sb.quota.sum() == 1024 and sorted(set(sb.quota.tolist())) == [102, 103]
+    assert sb.quota[3:7].tolist() == [103, 103, 103, 103]            # the four spare places: the sizes nearest the mean
+    assert sb.nodes_per_batch == int(1024 * nodes.mean())
+    seen = []
+    for _ in range(8):                                               # 8 x 102 = 816 <= 820: no class wraps yet
+        ids = sb.draw()
+        assert len(ids) == 1024 and nodes[ids].sum() == sb.nodes_per_batch
+        seen.append(ids)
+    first_class = np.concatenate([ids[nodes[ids] == nodes[0]] for ids in seen])
+    assert len(set(first_class.tolist())) == len(first_class)        # no repeats inside an epoch of the class
+    with np.testing.assert_raises(ValueError):
+        StratifiedBatches(nodes[:50], edges[:50], 1024)

@@ -75,5 +75,7 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
     cfg = rec["config"]
     assert cfg["parallelism"] == "dp2" and cfg["ranks_joined"] == 2 and "cpu_baseline" not in rec and rec["roofline"]["frac"] > 0
+    # the step is replayed from two captured graphs with the gradient all-reduce enqueued between them
+    assert cfg["step_mode"].startswith("hipgraph replay")
     # corpus = 8 x batch x ranks circuits (rounded up to whole J grids), each rank holds half of it
     assert cfg["corpus_circuits"] >= 8 * 32 * 2 and cfg["corpus_circuits_per_gpu"] == cfg["corpus_circuits"] // 2

@@ -75,6 +75,52 @@ def test_graph_replay_equals_eager_bucketed_steps_bit_for_bit(g1):
     assert finals[0][0][-1] < finals[0][0][0]    # and it trains
 
 
+def test_two_graph_form_equals_the_single_graph_bit_for_bit(g1):
+    """Under data parallelism the step is captured as two graphs -- (assembly, forward, backward) and (Adam) -- with the
+    gradient all-reduce enqueued between them.  ``split_update=True`` forces that form without a process group: same
+    losses, same final parameters as the single captured graph."""
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import BucketedTrainer
+
+    arena = _arena(g1)
+    rng = np.random.RandomState(5)
+    plans = [rng.choice(160, size=32, replace=False) for _ in range(20)]
+    finals = []
+    for split in (False, True):
+        torch.manual_seed(0)
+        model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV)
+        tr = BucketedTrainer(model, arena, lr=1e-3, graphs=True, node_quantum=256, edge_quantum=512, split_update=split)
+        torch.manual_seed(77)
+        losses = [tr.step_ids(ids).item() for ids in plans]
+        finals.append((losses, tr.flat_param.detach().clone()))
+    assert finals[0][0] == finals[1][0]
+    assert torch.equal(finals[0][1], finals[1][1])
+
+
+def test_size_stratified_batches_share_one_bucket(g1):
+    """StratifiedBatches: every batch holds the same number of graphs of every size, so all of them land in one bucket of
+    the BucketedTrainer (one capture) and an epoch still visits every graph of a class before repeating one."""
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import BucketedTrainer, StratifiedBatches
+
+    arena = _arena(g1)
+    n = len(arena)
+    sampler = StratifiedBatches(arena.node_counts[:n], arena.edge_counts[:n], 32, seed=4)
+    assert int(sampler.quota.sum()) == 32
+    torch.manual_seed(0)
+    tr = BucketedTrainer(ExpValCircuitGraphModelA(5, 22, 10).to(DEV), arena, lr=1e-3, graphs=True, node_quantum=256,
+                         edge_quantum=512)
+    buckets, first, last = set(), None, None
+    for k in range(12):
+        ids = sampler.draw()
+        assert len(ids) == 32 and int(arena.node_counts[ids].sum()) == sampler.nodes_per_batch
+        buckets.add(tr.bucket_of(ids))
+        last = tr.step_ids(ids).item()
+        first = last if first is None else first
+    assert len(buckets) == 1 and len(tr._entries) == 1
+    assert np.isfinite(last)
+
+
 def test_bucketed_trainer_follows_the_plain_trainer(g1):
     """Against the ordinary Trainer (no padding, host-counted dropout keys): dropout off so that the masks cannot differ,
     losses agree to fp32 rounding over 20 steps."""
