@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 11 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 12 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -389,19 +389,22 @@ int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const
 
 /* Training forward of mlqem_transformer_attention_f32: same result, plus attn_out (the sum before the skip term) and
  * the softmax statistics stat_m / stat_den [N,H]; drop_p > 0 drops attention weights (TransformerConv(dropout=0.1),
- * gnn.py:83,90) with a mask keyed by (seed, in-CSR position, head). */
+ * gnn.py:83,90) with a mask keyed by (seed, in-CSR position, head); seed_counter (may be NULL): a device-resident step
+ * counter mixed into the seed, so that a launch captured in a hipGraph draws a fresh mask per replay (the backward entry
+ * point must be given the same pair). */
 int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
                                           const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p,
-                                          uint64_t seed, float* out, int64_t ldo, float* attn_out, int64_t lda,
-                                          float* stat_m, float* stat_den, mlqem_stream_t stream);
+                                          uint64_t seed, const uint64_t* seed_counter, float* out, int64_t ldo,
+                                          float* attn_out, int64_t lda, float* stat_m, float* stat_den,
+                                          mlqem_stream_t stream);
 
 /* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  edge_al / edge_gs: scratch [(E+N)*H]. */
 int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg,
                                         const float* attn_out, int64_t lda, const float* stat_m, const float* stat_den,
                                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                         const int32_t* out_dst, const int32_t* out_eid, const int32_t* loops, int64_t N,
-                                        int64_t E, int H, int C, float drop_p, uint64_t seed, float* gqkvs, int64_t ldq,
-                                        float* edge_al, float* edge_gs, mlqem_stream_t stream);
+                                        int64_t E, int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
+                                        float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs, mlqem_stream_t stream);
 
 /* Backward of mlqem_csr_softmax_aggregate_f32: gx (+)= d/dx, g_a[N] = d/d a_dst, g_c[N] = d/d c_src.
  * xnew = the forward output, gnew its gradient; edge_al / edge_gp: scratch [E+N]. */

@@ -454,6 +454,22 @@ _ASAP_ROWS = os.environ.get("MLQEM_ASAP_ROWS", "1") != "0"
 _ASAP_LAZY = os.environ.get("MLQEM_ASAP_LAZY", "1") != "0"
 
 
+# Graph boundaries of pooled batches on the device, by content.  Batches of a training run repeat their size patterns (the
+# size-stratified batches of train.StratifiedBatches always do), and inside a hipGraph capture a host->device copy from
+# pageable memory is not allowed: the warm-up iterations that precede a capture leave the array here.
+_ptr_cache = {}
+
+
+def _device_ptr(host_i32, device):
+    key = (host_i32.tobytes(), str(device))
+    t = _ptr_cache.get(key)
+    if t is None:
+        if len(_ptr_cache) >= 256:
+            _ptr_cache.clear()
+        t = _ptr_cache[key] = torch.from_numpy(host_i32).to(device, non_blocking=not torch.cuda.is_current_stream_capturing())
+    return t
+
+
 class _ASAPool(Function):
     """ASAPooling as ONE autograd node.  Differentiable output: x_out = x'[perm] * fitness[perm]; the pooled structure
     and ``perm`` are data-dependent side results handed back through ``holder``."""
@@ -479,7 +495,7 @@ class _ASAPool(Function):
         new_ptr_host = np.zeros(len(keep) + 1, dtype=np.int64)
         np.cumsum(keep, out=new_ptr_host[1:])
         k_total = int(new_ptr_host[-1])
-        new_ptr = torch.from_numpy(new_ptr_host.astype(np.int32)).to(x.device, non_blocking=True)
+        new_ptr = _device_ptr(new_ptr_host.astype(np.int32), x.device)
         perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total)
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
         use_dense, use_rows = _ASAP_DENSE, _ASAP_ROWS       # the switches as they stand now: build() may run later

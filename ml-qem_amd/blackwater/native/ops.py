@@ -816,7 +816,8 @@ def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, c
     den = torch.empty_like(m)
     code = _lib.load().mlqem_transformer_attention_train_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
-        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _mat(out, "out"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
+        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, _p(out), _mat(out, "out"), _p(attn),
+        _mat(attn, "attn"), _p(m), _p(den), _stream())
     _lib.check(code, "mlqem_transformer_attention_train_f32")
     return out, attn, m, den
 
@@ -830,7 +831,8 @@ def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channe
     code = _lib.load().mlqem_transformer_attention_bwd_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr),
         _p(s.in_src), _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(s.loops), n, num_edges, heads, channels,
-        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(gqkvs), _mat(gqkvs, "gqkvs"), _p(scratch[0]), _p(scratch[1]),
+        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, _p(gqkvs),
+        _mat(gqkvs, "gqkvs"), _p(scratch[0]), _p(scratch[1]),
         _stream())
     _lib.check(code, "mlqem_transformer_attention_bwd_f32")
     return gqkvs

@@ -43,8 +43,10 @@ class TransformerConv(nn.Module):
         b = torch.cat([self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias], 0)
         self._calls = getattr(self, "_calls", 0) + 1
         drop = self.dropout if self.training else 0.0
+        # static_dropout_key: a device-resident step counter varies the masks instead (train.BucketedTrainer, hipGraph replay)
+        call = 0 if getattr(self, "static_dropout_key", False) else self._calls
         return F.transformer_conv(x, w, b, struct, self.heads, self.out_channels, drop_p=drop,
-                                  seed=dropout_key(self._calls, salt=self.heads * 1000003 + self.out_channels))
+                                  seed=dropout_key(call, salt=self.heads * 1000003 + self.out_channels))
 
 
 class _LEConv(nn.Module):
@@ -70,6 +72,9 @@ class ASAPooling(nn.Module):
 
 class _FamilyB(nn.Module):
     heads = (3, 2)
+    # ASAPooling sizes its outputs from the per-graph node counts (k_g = ceil(n_g / 2), the capacity of the coarsened edge
+    # list): a captured step (train.BucketedTrainer) is only valid for batches with the SAME sequence of graph sizes
+    needs_size_pattern = True
 
     def _build(self, num_node_features, hidden_channels):
         h1, h2 = self.heads
@@ -84,6 +89,7 @@ class _FamilyB(nn.Module):
             nodes = nodes.materialize()
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
+        self.transformer1.static_dropout_key = self.transformer2.static_dropout_key = getattr(self, "static_dropout_key", False)
         g = self.transformer1(nodes, s)
         g, s, _ = self.pooling1(g, s)
         g = self.transformer2(g, s)

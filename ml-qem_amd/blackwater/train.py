@@ -325,7 +325,12 @@ class BucketedTrainer(Trainer):
     def bucket_of(self, graph_ids):
         sel = np.asarray(graph_ids, dtype=np.int64)
         nb, eb = int(self.arena.node_counts[sel].sum()), int(self.arena.edge_counts[sel].sum())
-        return (-(-nb // self.nq) * self.nq, -(-max(eb, 1) // self.eq) * self.eq, len(sel))
+        key = (-(-nb // self.nq) * self.nq, -(-max(eb, 1) // self.eq) * self.eq, len(sel))
+        if getattr(self.model, "needs_size_pattern", False):
+            # models whose launch shapes depend on every graph's size (Family B: ASAPooling keeps ceil(n_g / 2) clusters per
+            # graph) replay a capture only for the same SEQUENCE of sizes -- what StratifiedBatches produces batch after batch
+            key += (self.arena.node_counts[sel].tobytes(),)
+        return key
 
     def _step_on(self, packed, b, n_pad, e_pad, sizes, num_real):
         loss = self._local_half(packed, b, n_pad, e_pad, sizes, num_real)

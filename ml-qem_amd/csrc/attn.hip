@@ -199,7 +199,7 @@ extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, co
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
-  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, 0, H, C, 0.f, 0, out, ldo, nullptr, 0, nullptr, nullptr};
+  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, 0, H, C, 0.f, 0, nullptr, out, ldo, nullptr, 0, nullptr, nullptr};
   const dim3 grid((unsigned)ceil_div(N * H * kGroup, kBlock));
   if (C > kGroup) hipLaunchKernelGGL(transformer_attn_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), a);
   else hipLaunchKernelGGL(transformer_attn_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), a);

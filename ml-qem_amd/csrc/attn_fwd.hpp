@@ -38,6 +38,7 @@ struct AttnFwdArgs {
   const int32_t* ptr; const int32_t* idx;   // CSR by destination
   const int32_t* loops;                     // optional [N]: multiplicity of the self-loop entry
   int64_t N, E; int H, C; float drop_p; uint64_t seed;
+  const uint64_t* seed_counter;             // optional device-resident step counter mixed into the seed (hipGraph replay)
   float* out; int64_t ldo;
   float* attn_out; int64_t lda; float* stat_m; float* stat_den;   // training only
 };
@@ -51,6 +52,7 @@ template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(co
   const int h = (int)(t - (int64_t)row * H);
   const float scale = 1.0f / sqrtf((float)C);
   const float keep = 1.f / (1.f - a.drop_p);
+  const uint64_t seed = a.seed + ((TRAIN && a.seed_counter) ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
   const bool c0 = l < C, c1 = WIDE && l + kGroup < C;
   const int l1 = c1 ? l + kGroup : l;                   // a valid channel for the second load of the narrow case (unused)
   const float* __restrict__ qkvs = a.qkvs;
@@ -73,7 +75,7 @@ template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(co
     return group16_sum(s) * scale;
   };
   auto weight = [&](float p, int64_t pos, int hh) {     // the weight a value row gets: dropout on the attention weight
-    if (TRAIN && a.drop_p > 0.f) return uniform01_edge(a.seed, (uint64_t)(pos * H + hh)) < a.drop_p ? 0.f : p * keep;
+    if (TRAIN && a.drop_p > 0.f) return uniform01_edge(seed, (uint64_t)(pos * H + hh)) < a.drop_p ? 0.f : p * keep;
     return p;
   };
   // One chunk of up to eight edges e .. e + k - 1 of the row, absorbed into the running (max, denominator, sums).  The

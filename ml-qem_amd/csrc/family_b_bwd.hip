@@ -29,7 +29,7 @@ struct AttnBwdArgs {
   const float* qkvs; int64_t ld; const float* g; int64_t ldg; const float* attn_out; int64_t lda;
   const float* stat_m; const float* stat_den;
   const int32_t* ptr; const int32_t* idx; const int32_t* optr; const int32_t* odst; const int32_t* oeid; const int32_t* loops;
-  int64_t N, E; int H, C; float drop_p; uint64_t seed;
+  int64_t N, E; int H, C; float drop_p; uint64_t seed; const uint64_t* seed_counter;
   float* gqkvs; int64_t ldq; float* edge_al; float* edge_gs;
 };
 
@@ -42,6 +42,7 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
   const int h = (int)(t - (int64_t)row * H);
   const float scale = 1.0f / sqrtf((float)C);
   const float keep = 1.f / (1.f - a.drop_p);
+  const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);   // as the forward
   const bool c0 = l < C, c1 = WIDE && l + kGroup < C;
   const int o0 = h * C + l, o1 = c1 ? o0 + kGroup : o0;
   const float* __restrict__ qkvs = a.qkvs;
@@ -66,7 +67,7 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
     gv = group16_sum(gv);
     const float alpha = expf(s * scale - m) * inv_den * mult;  // softmax weight (all copies of a repeated self-loop)
     float dmask = 1.f;
-    if (a.drop_p > 0.f) dmask = uniform01_edge(a.seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
+    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
     const float gs = alpha * (gv * dmask - delta) * scale;
     if (l == 0) {
       edge_al[pos * H + h] = alpha * dmask;
@@ -107,7 +108,7 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
     const int64_t pos = (int64_t)e + lu;
     const float alpha = expf(mys * scale - m) * inv_den;
     float dmask = 1.f;
-    if (a.drop_p > 0.f) dmask = uniform01_edge(a.seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
+    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
     float gs = alpha * (mygv * dmask - delta) * scale;
     if (lu >= k) gs = 0.f;
     if (l < 8 && lu < k) {
@@ -730,7 +731,7 @@ using namespace mlqem;
 extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
                                                      const int32_t* in_src, const int32_t* loops, int64_t N, int64_t E,
                                                      int H, int C, float drop_p, uint64_t seed,
-                                                     float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m,
+                                                     const uint64_t* seed_counter, float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m,
                                                      float* stat_den, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
@@ -739,7 +740,7 @@ extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t 
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
-  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, out, ldo, attn_out, lda, stat_m, stat_den};
+  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den};
   if (C > kGroup) hipLaunchKernelGGL(transformer_attn_train_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
   else hipLaunchKernelGGL(transformer_attn_train_kernel<false>, MLQEM_GRID(N * H * kGroup), a);
   return launch_status();
@@ -750,8 +751,9 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
                                                    const float* stat_den, const int32_t* in_ptr, const int32_t* in_src,
                                                    const int32_t* out_ptr, const int32_t* out_dst,
                                                    const int32_t* out_eid, const int32_t* loops, int64_t N, int64_t E,
-                                                   int H, int C, float drop_p, uint64_t seed, float* gqkvs, int64_t ldq,
-                                                   float* edge_al, float* edge_gs, mlqem_stream_t stream) {
+                                                   int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
+                                                   float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
+                                                   mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldq < 4 * H * C || ldg < H * C || lda < H * C)
     return MLQEM_ERR_BAD_ARG;
@@ -762,7 +764,7 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
   const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
-                      N, E, H, C, drop_p, seed, gqkvs, ldq, edge_al, edge_gs};
+                      N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs};
   if (C > kGroup) {
     hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
     hipLaunchKernelGGL(transformer_attn_bwd_src_kernel<true>, MLQEM_GRID(N * H * kGroup), a);

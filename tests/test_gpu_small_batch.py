@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _arena(g1, n=160, filler=2048):
+def _arena(g1, n=160, filler=2048, family_b=False):
     from blackwater.data.arena import GraphArena
 
     xs, eis = [], []
@@ -21,8 +21,11 @@ def _arena(g1, n=160, filler=2048):
         xs.append(x.astype(np.float32))
         eis.append(np.concatenate([ei, np.stack([loops, loops])], axis=1))
     host = g1_batch(g1, range(n))
-    return GraphArena.from_arrays(xs, eis, host["y"].numpy(), host["noisy"].numpy(), host["depth"].numpy(),
-                                  host["observable"].numpy(), device=DEV, filler_nodes=filler)
+    y, noisy = host["y"].numpy(), host["noisy"].numpy()
+    if family_b:       # the reference's Family B takes exp values as [B, 1, k] (gnn.py:116)
+        y, noisy = y.reshape(n, 1, -1), noisy.reshape(n, 1, -1)
+    return GraphArena.from_arrays(xs, eis, y, noisy, host["depth"].numpy(), host["observable"].numpy(), device=DEV,
+                                  filler_nodes=filler)
 
 
 def test_padded_batch_equals_plain_batch(g1):
@@ -119,6 +122,32 @@ def test_size_stratified_batches_share_one_bucket(g1):
         first = last if first is None else first
     assert len(buckets) == 1 and len(tr._entries) == 1
     assert np.isfinite(last)
+
+
+def test_family_b_step_replayed_from_a_graph_equals_the_eager_step(g1):
+    """The reference's own model (TransformerConv / ASAPooling x2) through the captured step: ASAPooling's output sizes follow
+    the per-graph node counts, so a capture is keyed by the batch's size pattern, which size-stratified batches repeat.
+    graphs=True and graphs=False: same losses bit for bit (attention dropout on: its mask follows the device-resident step
+    counter), one capture, and the loss moves."""
+    from blackwater.nn import ExpValCircuitGraphModel
+    from blackwater.train import BucketedTrainer, StratifiedBatches
+
+    arena = _arena(g1, family_b=True)
+    n = len(arena)
+    k = int(arena.y.shape[-1])
+    finals = []
+    for graphs in (True, False):
+        sampler = StratifiedBatches(arena.node_counts[:n], arena.edge_counts[:n], 32, seed=9)
+        torch.manual_seed(0)
+        model = ExpValCircuitGraphModel(22, 15, k).to(DEV)
+        tr = BucketedTrainer(model, arena, lr=1e-3, graphs=graphs, node_quantum=256, edge_quantum=512)
+        torch.manual_seed(78)
+        losses = [tr.step_ids(sampler.draw()).item() for _ in range(14)]
+        finals.append((losses, tr.flat_param.detach().clone(), len(tr._entries)))
+    assert finals[0][2] == 1
+    assert finals[0][0] == finals[1][0]
+    assert torch.equal(finals[0][1], finals[1][1])
+    assert len(set(finals[0][0])) > 10           # fresh batches and fresh dropout masks every replay
 
 
 def test_bucketed_trainer_follows_the_plain_trainer(g1):
