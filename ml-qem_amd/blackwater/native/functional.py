@@ -487,7 +487,7 @@ class _ASAPool(Function):
         c_src = ops.linear(x, att_x)[:, 0].contiguous()
         x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
         w3 = torch.cat([l1_w, l2_w, l3_w], 0).contiguous()
-        b3 = torch.cat([l1_b, torch.zeros_like(l1_b), l3_b], 0)
+        b3 = torch.cat([l1_b, l1_b * 0.0, l3_b], 0)      # lin2 has no bias (a multiply, not a memset: the step may be captured)
         fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
         # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk (float32 tensor times a python scalar)
         sizes = np.asarray(s.graph_sizes, dtype=np.int64)

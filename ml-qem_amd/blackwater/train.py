@@ -157,7 +157,7 @@ class Trainer:
         if self.flat_grad is not None:
             grads = [p.grad for p in self._params]
             if any(g is None for g in grads):   # a parameter the loss does not reach: its slot must read zero
-                self.flat_grad.zero_()
+                self.flat_grad.fill_(0.0)     # a fill kernel, not a memset node: the step may be replayed from a hipGraph (csrc/asap.hip)
                 pairs = [(d, g) for d, g in zip(self._grad_slots, grads) if g is not None]
                 if pairs:
                     torch._foreach_copy_([d for d, _ in pairs], [g for _, g in pairs])

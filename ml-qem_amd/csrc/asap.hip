@@ -113,6 +113,17 @@ __global__ __launch_bounds__(kBlock) void coarsen_hop2_kernel(const uint64_t* __
   if (!FILL) counts[t] = n;
 }
 
+// Fills of device arrays are KERNELS here, not hipMemsetAsync: these entry points run inside captured hipGraphs
+// (train.BucketedTrainer), and a replayed memset node was seen to run out of order with the kernels around it -- the second
+// replay of a Family B step faulted with slot[] entries wiped after slot_map_kernel had written them.
+__global__ __launch_bounds__(kBlock) void fill_i32_kernel(int32_t* __restrict__ p, int32_t v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+static inline void fill_i32(int32_t* p, int32_t v, int64_t n, hipStream_t stream) {
+  if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(n, (int64_t)kBlock)), dim3(kBlock), 0, stream, p, v, n);
+}
+
 __global__ __launch_bounds__(kBlock) void slot_map_kernel(const int32_t* __restrict__ perm, int64_t K,
                                                           int32_t* __restrict__ slot) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -485,7 +496,7 @@ extern "C" int mlqem_asap_hop1_count(const int32_t* in_ptr, const int32_t* in_sr
   if (N < 0 || K < 0 || K > N) return MLQEM_ERR_BAD_ARG;
   if (!slot || !offsets) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < scan_bytes(K)) return MLQEM_ERR_WORKSPACE;
-  if (N > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  fill_i32(slot, -1, N, stream);
   const size_t cb = ((size_t)(K + 1) * sizeof(int64_t) + 255) / 256 * 256;
   int64_t* counts = static_cast<int64_t*>(workspace);
   if (hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(K + 1), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
@@ -610,7 +621,7 @@ extern "C" int mlqem_asap_slot_map(const int32_t* perm, int64_t N, int64_t K, in
   if (N < 0 || K < 0 || K > N) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!slot || (K > 0 && !perm)) return MLQEM_ERR_BAD_ARG;
-  if (hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  fill_i32(slot, -1, N, stream);
   if (K > 0) hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
   return launch_status();
 }
@@ -643,10 +654,10 @@ extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_
   if (nmax + kmax + 64 > mlqem_asap_coarsen_rows_max_bits() || kmax > 65536) return MLQEM_ERR_UNSUPPORTED;   // ranks are 16-bit
   if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_asap_coarsen_rows_workspace_bytes(K, kmax)) return MLQEM_ERR_WORKSPACE;
-  if (N > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  fill_i32(slot, -1, N, stream);
   if (K == 0 || B == 0) {
-    (void)hipMemsetAsync(new_in_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
-    (void)hipMemsetAsync(new_out_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
+    fill_i32(new_in_ptr, 0, K + 1, stream);
+    fill_i32(new_out_ptr, 0, K + 1, stream);
     return launch_status();
   }
   if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm) return MLQEM_ERR_BAD_ARG;
@@ -654,9 +665,9 @@ extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_
   rows_args(a, in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, K, B, nmax, kmax, workspace);
   size_t bm, deg, pref;
   rows_layout(K, kmax, bm, deg, pref);
-  if (hipMemsetAsync(a.bmT, 0, bm, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
-  if (hipMemsetAsync(a.outdeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
-  if (hipMemsetAsync(a.indeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  fill_i32(reinterpret_cast<int32_t*>(a.bmT), 0, (int64_t)(bm / sizeof(int32_t)), stream);
+  fill_i32(a.outdeg + K, 0, 1, stream);
+  fill_i32(a.indeg + K, 0, 1, stream);
   hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
   const size_t lds = (size_t)4 * (a.Wn + a.Wk) * sizeof(uint32_t);
   const unsigned grid = (unsigned)ceil_div(K, (int64_t)4);
@@ -714,10 +725,10 @@ extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in
   if (kmax > kDenseMaxK) return MLQEM_ERR_UNSUPPORTED;
   if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_asap_coarsen_dense_workspace_bytes(B, K, kmax)) return MLQEM_ERR_WORKSPACE;
-  if (N > 0 && hipMemsetAsync(slot, 0xFF, sizeof(int32_t) * (size_t)N, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  fill_i32(slot, -1, N, stream);
   if (K == 0 || B == 0) {
-    (void)hipMemsetAsync(new_in_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
-    (void)hipMemsetAsync(new_out_ptr, 0, sizeof(int32_t) * (size_t)(K + 1), stream);
+    fill_i32(new_in_ptr, 0, K + 1, stream);
+    fill_i32(new_out_ptr, 0, K + 1, stream);
     return launch_status();
   }
   if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm || !new_in_src || !new_out_dst || !new_loops)
@@ -730,9 +741,9 @@ extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in
               reinterpret_cast<int32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + bm + deg)};
   void* temp = ws + bm + 2 * deg;
   size_t temp_bytes = dense_scan_bytes(K);
-  if (hipMemsetAsync(a.outdeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
-  if (hipMemsetAsync(a.indeg + K, 0, sizeof(int32_t), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
-  if (hipMemsetAsync(new_loops, 0, sizeof(int32_t) * (size_t)K, stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  fill_i32(a.outdeg + K, 0, 1, stream);
+  fill_i32(a.indeg + K, 0, 1, stream);
+  fill_i32(new_loops, 0, K, stream);
   hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
   const size_t lds = (size_t)kmax * W * sizeof(uint32_t);
   hipLaunchKernelGGL(coarsen_dense_bitmap_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, a);
