@@ -114,8 +114,9 @@ __global__ __launch_bounds__(kBlock) void coarsen_hop2_kernel(const uint64_t* __
 }
 
 // Fills of device arrays are KERNELS here, not hipMemsetAsync: these entry points run inside captured hipGraphs
-// (train.BucketedTrainer), and a replayed memset node was seen to run out of order with the kernels around it -- the second
-// replay of a Family B step faulted with slot[] entries wiped after slot_map_kernel had written them.
+// (train.BucketedTrainer): with hipMemsetAsync here the second replay of a captured Family B step ended in a GPU memory
+// fault (the first was bit-identical to the eager step); with kernels it does not -- consistent with a replayed memset
+// node running out of order with its neighbours (slot[] wiped after slot_map_kernel had written it, then used as an index).
 __global__ __launch_bounds__(kBlock) void fill_i32_kernel(int32_t* __restrict__ p, int32_t v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
