@@ -314,24 +314,25 @@ def family_b_leg(dev, steps=30):
     arena_f = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"],
                                      device=dev, filler_nodes=1024)
     n_f = len(arena_f)
-    sampler = StratifiedBatches(arena_f.node_counts[:n_f], arena_f.edge_counts[:n_f], 32, seed=11)
-    for graphs in (False, True):
-        torch.manual_seed(0)
-        bt = BucketedTrainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), arena_f, lr=1e-3, graphs=graphs, node_quantum=256,
-                             edge_quantum=512)
-        for _ in range(5):
-            bt.step_ids(sampler.draw())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(4 * steps):
-            last = bt.step_ids(sampler.draw())
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["batch32_stratified_" + ("hipgraph" if graphs else "eager")] = {
-            "circuits_per_s": round(32 * 4 * steps / dt, 1), "ms_per_step": round(dt / (4 * steps) * 1e3, 3), "steps": 4 * steps,
-            "final_loss": round(float(last.item()), 6), "captures": len(bt._entries)}
-        _ops.set_seed_counter(None)
-        del bt
+    for bsz, variants, n_steps in ((32, (False, True), 4 * steps), (1024, (True,), steps)):
+        sampler = StratifiedBatches(arena_f.node_counts[:n_f], arena_f.edge_counts[:n_f], bsz, seed=11)
+        for graphs in variants:
+            torch.manual_seed(0)
+            bt = BucketedTrainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), arena_f, lr=1e-3, graphs=graphs, node_quantum=256,
+                                 edge_quantum=512)
+            for _ in range(5):
+                bt.step_ids(sampler.draw())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                last = bt.step_ids(sampler.draw())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["batch%d_stratified_%s" % (bsz, "hipgraph" if graphs else "eager")] = {
+                "circuits_per_s": round(bsz * n_steps / dt, 1), "ms_per_step": round(dt / n_steps * 1e3, 3), "steps": n_steps,
+                "final_loss": round(float(last.item()), 6), "captures": len(bt._entries)}
+            _ops.set_seed_counter(None)
+            del bt
     del arena_f
     # the same model on the headline workload's graphs (100-qubit circuits, 2-20 k nodes each): ASAPooling's coarsening takes the
     # wave-per-cluster form there (mlqem_asap_coarsen_rows_*: no sort, one host read per pooling) and is computed for the first

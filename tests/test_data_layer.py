@@ -119,3 +119,29 @@ def test_stratified_batches_quotas_and_epochs():
     assert len(set(first_class.tolist())) == len(first_class)        # no repeats inside an epoch of the class
     with np.testing.assert_raises(ValueError):
         StratifiedBatches(nodes[:50], edges[:50], 1024)
+
+
+def test_deferred_structure_builds_its_connectivity_on_first_use():
+    """native.structure.GraphStructure.deferred: graph boundaries are there at once, the CSR arrays appear when a layer first
+    reads one of them (ASAPooling's second coarsening is never read by the reference's models: gnn.py:112-114)."""
+    import torch
+
+    from blackwater.native.structure import GraphStructure
+
+    calls = []
+
+    def build():
+        calls.append(1)
+        z = torch.zeros(4, dtype=torch.int32)
+        return (z, z[:0], z, z[:0], z[:3], 0, z[:0])
+
+    s = GraphStructure.deferred(3, torch.tensor([0, 3], dtype=torch.int32), 1, build, graph_sizes=[3])
+    assert s.num_nodes == 3 and s.num_graphs == 1 and s.graph_sizes == [3] and not s.connectivity_built and not calls
+    assert s.in_ptr.shape[0] == 4 and calls == [1] and s.connectivity_built
+    assert s.edge_count() == 0 and s.out_eid.numel() == 0 and calls == [1]      # built once
+    try:
+        s.no_such_attribute
+    except AttributeError:
+        pass
+    else:
+        raise AssertionError("unknown attributes must raise")
