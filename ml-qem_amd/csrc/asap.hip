@@ -315,12 +315,16 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) 
   uint32_t* Y = X + a.Wn;
   const int64_t p = (int64_t)blockIdx.x * 4 + wid;
   if (p >= a.K) return;                              // wave-uniform
-  for (int i = lane; i < a.Wn + a.Wk; i += 64) X[i] = 0u;
-  wave_lds_sync();
   const int c = a.perm[p];
   int lo = 0, hi = a.B;                              // graph of cluster p: largest g with new_gptr[g] <= p
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)a.new_gptr[mid] <= p) lo = mid; else hi = mid; }
   const int n0 = a.gptr[lo], k0 = a.new_gptr[lo];
+  // words of THIS graph's bitsets (the LDS regions and the rows of the bit matrices are laid out for the batch's largest
+  // graph; a batch mixes 2 k- and 20 k-node circuits, and every loop below runs over words, set or not)
+  const int Wn = (a.gptr[lo + 1] - n0 + 31) >> 5, Wk = (a.new_gptr[lo + 1] - k0 + 31) >> 5;
+  for (int i = lane; i < Wn; i += 64) X[i] = 0u;
+  for (int i = lane; i < Wk; i += 64) Y[i] = 0u;
+  wave_lds_sync();
   // X = N+[N-[c]] (node bits, local to the graph)
   const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
   for (int i0 = ib - 1; i0 < ie; i0 += 64) {         // index ib - 1 stands for c itself
@@ -331,9 +335,9 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) 
   }
   wave_lds_sync();
   // Y = kept centres among N+[X] (cluster bits, local to the graph), without p itself
-  for (int w0 = 0; w0 < a.Wn; w0 += 64) {
+  for (int w0 = 0; w0 < Wn; w0 += 64) {
     const int wi = w0 + lane;
-    uint32_t bits = wi < a.Wn ? X[wi] : 0u;
+    uint32_t bits = wi < Wn ? X[wi] : 0u;
     while (__ballot(bits != 0u)) {                   // every lane offers its next node, if it has one left
       const bool has = bits != 0u;
       int v = 0;
@@ -347,12 +351,12 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) 
   wave_lds_sync();
   const int pl = (int)(p - k0);
   int run = 0;                                        // set bits of Y in the words before the current 64
-  for (int w0 = 0; w0 < a.Wk; w0 += 64) {
+  for (int w0 = 0; w0 < Wk; w0 += 64) {                // words past Wk of row p of bm / prefw stay unwritten: nobody reads them
     const int wi = w0 + lane;
-    uint32_t bits = wi < a.Wk ? Y[wi] : 0u;
+    uint32_t bits = wi < Wk ? Y[wi] : 0u;
     const int c = __popc(bits);
     const int ex = wave_excl_scan(c, lane);
-    if (wi < a.Wk) {
+    if (wi < Wk) {
       a.bm[p * a.Wk + wi] = bits;
       a.prefw[p * a.Wk + wi] = (uint16_t)(run + ex);  // rank of the word's first bit inside row p (< k_g <= 65536)
     }
@@ -388,11 +392,12 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArg
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)a.new_gptr[mid] <= r) lo = mid; else hi = mid; }
   const int k0 = a.new_gptr[lo];
   const int rl = (int)(r - k0);
+  const int Wk = (a.new_gptr[lo + 1] - k0 + 31) >> 5;   // words of this graph's rows (the count pass wrote no more)
   // row r of the out-CSR: destinations ascending
   int base = out_ptr_new[r];
-  for (int w0 = 0; w0 < a.Wk; w0 += 64) {
+  for (int w0 = 0; w0 < Wk; w0 += 64) {
     const int wi = w0 + lane;
-    uint32_t bits = wi < a.Wk ? a.bm[r * a.Wk + wi] : 0u;
+    uint32_t bits = wi < Wk ? a.bm[r * a.Wk + wi] : 0u;
     const int n = __popc(bits);
     int pos = base + wave_excl_scan(n, lane);
     while (bits) {
@@ -406,9 +411,9 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArg
   base = in_ptr_new[r];
   const int wq = rl >> 5;
   const uint32_t below = (1u << (rl & 31)) - 1u;
-  for (int w0 = 0; w0 < a.Wk; w0 += 64) {
+  for (int w0 = 0; w0 < Wk; w0 += 64) {
     const int wi = w0 + lane;
-    uint32_t bits = wi < a.Wk ? a.bmT[r * a.Wk + wi] : 0u;
+    uint32_t bits = wi < Wk ? a.bmT[r * a.Wk + wi] : 0u;
     const int n = __popc(bits);
     const int ex = wave_excl_scan(n, lane);
     int pos = base + ex;
