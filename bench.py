@@ -415,6 +415,56 @@ def family_b_leg(dev, steps=30):
     return out
 
 
+def mlp_head_leg(dev, rows=262144, steps=20):
+    """The MLP path of BASELINE.json's configs[0] / configs[4] (docs/tutorials/mlp.py:18-108; demo2's 169/170-wide
+    `encode_data_v2_ecr` rows): MLP1(170, 128, 1) and MLP3(170, 125, 1) train steps (forward, MSE, backward, Adam) on `rows`
+    synthetic feature rows, GEMMs on the fp32 matrix cores and -- `mfma = "bf16"`, the "bf16 MFMA MLP head" of cfg5 -- on
+    v_mfma_f32_16x16x32_bf16.  Each model's GEMMs move 4 (rows (in + out) + in out) bytes and do 2 rows in out flops per
+    layer, three times per step (forward, data gradient, weight gradient): both rates are reported against their peaks --
+    at these widths (<= 170) the layers are bound by HBM, three orders of magnitude below the matrix cores' rate."""
+    from blackwater.nn.mlp import MLP1, MLP3
+    from blackwater.train import Trainer
+
+    class _Rows:        # the batch protocol of Trainer.step for a plain feature matrix
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+        def model_args(self):
+            return (self.x,)
+
+    torch.manual_seed(0)
+    x = torch.randn(rows, 170, device=dev)
+    y = torch.randn(rows, 1, device=dev)
+    out = {"rows_per_step": rows, "features": 170,
+           "peaks": {"hbm_GBps": 8000.0, "mfma_f32_TFLOPs": 157.0, "mfma_bf16_TFLOPs": 2500.0}}
+    for name, make, widths in (("mlp1_170_128_1", lambda: MLP1(170, 128, 1), [(170, 128), (128, 1)]),
+                               ("mlp3_170_125_1", lambda: MLP3(170, 125, 1), [(170, 125), (125, 125), (125, 41), (41, 1)])):
+        gemm_bytes = 3 * sum(4 * (rows * (i + o) + i * o) for i, o in widths)
+        gemm_flops = 3 * sum(2 * rows * i * o for i, o in widths)
+        for mode in ("f32", "bf16"):
+            torch.manual_seed(1)
+            model = make().to(dev)
+            model.mfma = mode
+            tr = Trainer(model, lr=1e-3)
+            batch = _Rows(x, y)
+            for _ in range(3):
+                tr.step(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = tr.step(batch)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[f"{name}_{mode}"] = {"rows_per_s": round(rows / dt, 0), "ms_per_step": round(dt * 1e3, 3),
+                                     "gemm_GBps_algorithmic": round(gemm_bytes / dt / 1e9, 1),
+                                     "gemm_TFLOPs": round(gemm_flops / dt / 1e12, 3),
+                                     "frac_of_hbm_peak": round(gemm_bytes / dt / 1e9 / 8000.0, 4),
+                                     "frac_of_mfma_peak": round(gemm_flops / dt / 1e12 / (157.0 if mode == "f32" else 2500.0), 5),
+                                     "final_loss": round(float(loss.item()), 6)}
+            del tr, model
+    return out
+
+
 def small_batch_leg(dev, steps=300):
     """The reference's batch size (32, docs/tutorials/__ml_models.py:105) on cfg2 (4-qubit TFIM circuits, Family A): the
     step is ~8 k graph nodes, i.e. launch-bound.  ``eager`` = the ordinary Trainer (one Python-enqueued launch sequence per
@@ -608,6 +658,7 @@ def main():
             line["accuracy"] = accuracy_leg(dev)
             line["family_b"] = family_b_leg(dev)
             line["small_batch"] = small_batch_leg(dev)
+            line["mlp_head"] = mlp_head_leg(dev)
         print(json.dumps(line), flush=True)
     if distributed:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: leave together

@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 12 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 13 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -102,6 +102,21 @@ int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, c
 
 /* ell[i] = (col[ptr[i]], col[ptr[i]+1]) with the conventions above; ell: [N,2] int32, 8-byte aligned. */
 int mlqem_ell_from_csr(const int32_t* ptr, const int32_t* idx, int64_t N, int32_t* ell, mlqem_stream_t stream);
+
+/* BatchNorm1d in training mode over [N, C] rows: the bn1 / bn2 of MLP2 / MLP3 (docs/tutorials/mlp.py:45-66,87-108) and its
+ * autograd; replaces torch.nn.BatchNorm1d's forward / backward kernels for that call site (C <= 256).
+ *   forward:  mean[C], var[C] (biased), invstd[C] = rsqrt(var + eps), y = (x - mean) * invstd * gamma + beta
+ *   backward: dbeta = sum dy, dgamma = sum dy * xhat, dx = gamma * invstd * (dy - dbeta / N - xhat * dgamma / N)
+ * gamma / beta may be NULL (no affine).  Deterministic (per-workgroup partials summed in a fixed order, in double).  The
+ * running statistics (momentum, unbiased variance) are the caller's: they are [C]-sized host-side bookkeeping. */
+size_t mlqem_batch_norm_workspace_bytes(int64_t N, int C);
+int mlqem_batch_norm_train_f32(const float* x, int64_t ldx, int64_t N, int C, const float* gamma, const float* beta, float eps,
+                               float* y, int64_t ldy, float* mean, float* var, float* invstd, void* workspace,
+                               size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_batch_norm_train_bwd_f32(const float* dy, int64_t ldg, const float* x, int64_t ldx, int64_t N, int C,
+                                   const float* gamma, const float* mean, const float* invstd, float* dx, int64_t lddx,
+                                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                   mlqem_stream_t stream);
 
 /* gx[n,c] = (y[n,c] > 0) ? g[n,c] * scale : 0  -- backward of ReLU followed by inverted dropout, recovered from the
  * output y (an element that was clamped OR dropped has y == 0 and no gradient either way). */

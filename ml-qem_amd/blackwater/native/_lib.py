@@ -86,6 +86,9 @@ SIGNATURES = {
     "mlqem_asap_coarsen_rows_workspace_bytes": (_S, [_L, _I]),
     "mlqem_asap_coarsen_rows_max_bits": (_I, []),
     "mlqem_asap_slot_map": (_I, [_P, _L, _L, _P, _P]),
+    "mlqem_batch_norm_workspace_bytes": (_S, [_L, _I]),
+    "mlqem_batch_norm_train_f32": (_I, [_P, _L, _L, _I, _P, _P, _F, _P, _L, _P, _P, _P, _P, _S, _P]),
+    "mlqem_batch_norm_train_bwd_f32": (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _L, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_rows_count": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_rows_fill": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_dense_max_k": (_I, []),
@@ -105,7 +108,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 12   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 13   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -108,6 +108,42 @@ class _ReluDropoutAdd(Function):
         return gu, (g if ctx.has_res else None), None, None
 
 
+class _BatchNormTrain(Function):
+    """BatchNorm1d in training mode on the native kernels (csrc/bn.hip): y, and the batch statistics for the running buffers."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = ops.rowmajor(x)
+        y, mean, var, invstd = ops.batch_norm_train(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, mean, invstd)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.batch_norm_train_bwd(ops.rowmajor(gy), x, gamma, mean, invstd)
+        return dx, dgamma, dbeta, None
+
+
+def batch_norm_train(x, bn):
+    """``bn(x)`` for a ``torch.nn.BatchNorm1d`` in training mode over [N, C] rows, running statistics updated as torch does
+    (momentum, unbiased variance, num_batches_tracked).  Falls back to the module itself for what the kernels do not cover
+    (no affine parameters, cumulative-average momentum, C > 256, a single row)."""
+    n, c = x.shape
+    if bn.weight is None or bn.momentum is None or c > 256 or n < 2 or not x.is_cuda:
+        return bn(x)
+    y, mean, var = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            m = bn.momentum
+            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(var, alpha=m * n / (n - 1))
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+    return y
+
+
 def relu_dropout_add(u, residual=None, drop_p=0.0, seed=0):
     """dropout(relu(u)) + residual (the tail of an MLP2 / MLP3 trunk layer, docs/tutorials/mlp.py:60-66)."""
     return _ReluDropoutAdd.apply(u, residual, drop_p, seed)

@@ -786,6 +786,37 @@ def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_g
     return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], out_eid[:e]), slot, e
 
 
+def batch_norm_train(x, gamma, beta, eps):
+    """y, mean, biased var, invstd of BatchNorm1d in training mode over the rows of x [N, C] (mlqem_batch_norm_train_f32)."""
+    n, c = x.shape
+    ldx = _mat(x, "x")
+    dev = x.device
+    y = padded_empty(n, c, dev)
+    mean, var, invstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
+    lib = _lib.load()
+    need = lib.mlqem_batch_norm_workspace_bytes(n, c)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    code = lib.mlqem_batch_norm_train_f32(_p(x), ldx, n, c, _p(gamma), _p(beta), float(eps), _p(y), _mat(y, "y"), _p(mean), _p(var),
+                                          _p(invstd), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_batch_norm_train_f32")
+    return y, mean, var, invstd
+
+
+def batch_norm_train_bwd(dy, x, gamma, mean, invstd):
+    """dx, dgamma, dbeta (mlqem_batch_norm_train_bwd_f32)."""
+    n, c = x.shape
+    dev = x.device
+    dx = padded_empty(n, c, dev)
+    dgamma, dbeta = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(2))
+    lib = _lib.load()
+    need = lib.mlqem_batch_norm_workspace_bytes(n, c)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    code = lib.mlqem_batch_norm_train_bwd_f32(_p(dy), _mat(dy, "dy"), _p(x), _mat(x, "x"), n, c, _p(gamma), _p(mean), _p(invstd),
+                                              _p(dx), _mat(dx, "dx"), _p(dgamma), _p(dbeta), _p(ws), need, _stream())
+    _lib.check(code, "mlqem_batch_norm_train_bwd_f32")
+    return dx, dgamma, dbeta
+
+
 def asap_slot_map(perm, num_nodes):
     """slot[N]: cluster id of every kept centre (slot[perm[p]] = p), -1 elsewhere."""
     k = int(perm.shape[0])

@@ -7,9 +7,10 @@ their epilogues wherever the maths allows:
 * eval mode: BatchNorm is an affine map of the GEMM output, so ``relu(bn(fc(x)))`` is ONE GEMM with bias + ReLU epilogue
   over weights scaled by ``gamma / sqrt(running_var + eps)`` (folded on the fly from the live parameters: four [H]-sized
   ops instead of three [batch, H] passes);
-* train mode: BatchNorm needs the batch statistics of the GEMM output (torch's kernel, per-rank statistics under data
-  parallelism exactly like ``DistributedDataParallel`` without ``SyncBatchNorm``; running statistics are broadcast from
-  rank 0 once by ``Trainer``); ReLU, dropout and the residual add of the trunk are one fused launch
+* train mode: BatchNorm needs the batch statistics of the GEMM output (``F.batch_norm_train``: the column reductions and
+  element-wise passes of csrc/bn.hip -- torch's kernels take 27 ms per layer and direction at 262 k rows; per-rank statistics
+  under data parallelism exactly like ``DistributedDataParallel`` without ``SyncBatchNorm``; running statistics are
+  broadcast from rank 0 once by ``Trainer``); ReLU, dropout and the residual add of the trunk are one fused launch
   (``F.relu_dropout_add``), its mask keyed by torch's seed like every dropout of this build.
 
 ``model.mfma = "bf16"`` (default ``"f32"``) sends the GEMMs -- forward, data gradient and weight gradient -- to the bf16
@@ -68,7 +69,7 @@ class MLP2(nn.Module):
         self._calls = getattr(self, "_calls", 0) + 1
         from .models import dropout_key
 
-        u = bn(F.linear(x, fc.weight, fc.bias, mfma=self.mfma))
+        u = F.batch_norm_train(F.linear(x, fc.weight, fc.bias, mfma=self.mfma), bn)
         return F.relu_dropout_add(u, residual, self.p, dropout_key(self._calls, salt=0x4D4C50))
 
     def trunk(self, x):

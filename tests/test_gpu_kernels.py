@@ -559,3 +559,32 @@ def test_pooled_head_forward_backward():
             assert abs(gb[k].item() - br[k].grad.item()) < 2e-5 * max(abs(br[k].grad.item()), 1.0)
         again = ops.pooled_head_bwd([(p, w, k) for p, w, k in zip(pd, wd, cols)], bd, go.to(DEV))
         assert torch.equal(again[1], gw) and torch.equal(again[2], gb)
+
+
+@pytest.mark.parametrize("n,c", [(1000, 125), (37, 5), (5000, 256), (262144 // 8, 64)])
+def test_batch_norm_train_matches_torch_in_fp64(n, c):
+    """native BatchNorm1d training forward / backward (csrc/bn.hip; the bn1 / bn2 of MLP2 / MLP3, docs/tutorials/mlp.py:45-66)
+    against torch.nn.BatchNorm1d evaluated in float64 on the CPU: output, running statistics, all three gradients."""
+    from blackwater.native import functional as F
+
+    torch.manual_seed(n + c)
+    x = (torch.randn(n, c) * 3.0 + 1.5)
+    gy = torch.randn(n, c)
+    ref = torch.nn.BatchNorm1d(c).double().train()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-1.0, 1.0)
+    bn = torch.nn.BatchNorm1d(c).to(DEV).train()
+    bn.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    yd = F.batch_norm_train(xd, bn)
+    yd.backward(gy.to(DEV))
+    rel = lambda a, b: (a.double().cpu() - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+    assert rel(yd.detach(), yr.detach()) < 2e-6
+    assert rel(xd.grad, xr.grad) < 1e-5
+    assert rel(bn.weight.grad, ref.weight.grad) < 1e-5 and rel(bn.bias.grad, ref.bias.grad) < 1e-5
+    assert rel(bn.running_mean, ref.running_mean) < 1e-6 and rel(bn.running_var, ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
