@@ -433,7 +433,9 @@ def mlp_head_leg(dev, rows=262144, steps=20):
             return (self.x,)
 
     torch.manual_seed(0)
-    x = torch.randn(rows, 170, device=dev)
+    from blackwater.native import ops as _ops
+
+    x = _ops.padded_copy(torch.randn(rows, 170, device=dev))      # rows in the padded layout (16-byte aligned), as the arena's
     y = torch.randn(rows, 1, device=dev)
     out = {"rows_per_step": rows, "features": 170,
            "peaks": {"hbm_GBps": 8000.0, "mfma_f32_TFLOPs": 157.0, "mfma_bf16_TFLOPs": 2500.0}}

@@ -235,11 +235,31 @@ def _gate(gate, n, o, padded: bool):
     return gate.data_ptr(), ld
 
 
+_MFMA_MAX_IN = 128    # input columns the matrix-core GEMM kernels take in one call (csrc/dense.hip: round_ks)
+
+
 def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=None, accumulate=False, drop_p=0.0,
            seed=0, rs_cols=-1, act_from=-1, gate=None, gate_scale=1.0):
     """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O]);
     ``gate``: y = gate > 0 ? y * gate_scale : 0 as the last step."""
     i = x.shape[1]
+    if i > _MFMA_MAX_IN and not transposed and torch.is_tensor(x) and w.dim() == 2 and w.shape[1] == i:
+        # The matrix-core kernels hold a row's inputs in registers (<= 128 columns); wider inputs (MLP rows of 169-170
+        # encode_data_v2_ecr features, docs/tutorials/mlp.py:148-194) used to fall to a scalar kernel (1.3 ms for 262 k x 170 -> 125
+        # against 0.15 ms here).  Split the k range: y = x[:, :128] W[:, :128]^T + b, then y += x[:, 128:] W[:, 128:]^T with the
+        # epilogue (row scale, ReLU, dropout, gate) on the last piece.
+        if out is None:
+            if accumulate:
+                raise ValueError("linear: accumulate needs an existing out")
+            out = padded_empty(x.shape[0], w.shape[0], x.device)
+        for k0 in range(0, i, _MFMA_MAX_IN):
+            k1 = min(k0 + _MFMA_MAX_IN, i)
+            first, last = k0 == 0, k1 == i
+            linear(x[:, k0:k1], w[:, k0:k1].contiguous(), b if first else None, relu=relu and last,
+                   rowscale=rowscale if last else None, out=out, accumulate=accumulate or not first,
+                   drop_p=drop_p if last else 0.0, seed=seed, rs_cols=rs_cols if last else -1, act_from=act_from if last else -1,
+                   gate=gate if last else None, gate_scale=gate_scale)
+        return out
     xt, ldx, n, x_rows = _x_operand(x)
     if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
         raise ValueError("w must be a contiguous 2-D fp32 cuda tensor")

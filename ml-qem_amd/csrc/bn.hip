@@ -6,7 +6,7 @@
 //
 // Two passes per direction: a column reduction (every workgroup takes a contiguous range of rows, lanes along the
 // columns so that a wave reads whole rows, eight row lanes per workgroup added in a fixed order; one partial per workgroup,
-// summed in workgroup order in double precision by a one-workgroup finish kernel: deterministic, no atomics) and an
+// summed in a fixed order in double precision by a finish kernel, one wave per column: deterministic, no atomics) and an
 // element-wise pass.  torch's kernels for this shape (N = 262 144, C = 125) take 7 ms (Welford reduction) and 20 ms (backward)
 // on an MI355X -- 94 % of an MLP3 train step; these take 0.1-0.2 ms each, the time of their 2-3 passes over the matrix.
 #include "common.hpp"
@@ -66,36 +66,44 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void bn_column_sums_ker
   }
 }
 
+// One 64-lane workgroup per column: lane j adds the partials of workgroups j, j + 64, ... in double, lane 0 adds the 64 lane
+// sums in lane order (a fixed order: deterministic).  (One thread per column walking all 2048 partials took 0.5 ms.)
 // MODE 0: mean, biased variance, invstd, and the affine map of the forward (scale = gamma * invstd, shift = beta - mean * scale).
 // MODE 1: dbeta = s1, dgamma = s2, and the per-column constants of the backward's element-wise pass.
-template <int MODE> __global__ __launch_bounds__(kBlock) void bn_finish_kernel(
+template <int MODE> __global__ __launch_bounds__(kWave) void bn_finish_kernel(
     const float* __restrict__ partial, int nblocks, int64_t N, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ invstd_in, float eps, float* __restrict__ o1,
     float* __restrict__ o2, float* __restrict__ o3, float* __restrict__ o4, float* __restrict__ o5) {
-  for (int c = threadIdx.x; c < C; c += kBlock) {
-    double t1 = 0.0, t2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-      t1 += (double)partial[((int64_t)b * 2 + 0) * C + c];
-      t2 += (double)partial[((int64_t)b * 2 + 1) * C + c];
-    }
-    if (MODE == 0) {
-      const double m = t1 / (double)N;
-      double var = t2 / (double)N - m * m;
-      if (var < 0.0) var = 0.0;
-      const float is = (float)(1.0 / sqrt(var + (double)eps));
-      const float sc = (gamma ? gamma[c] : 1.f) * is;
-      o1[c] = (float)m;                         // mean
-      o2[c] = (float)var;                       // biased variance
-      o3[c] = is;                               // invstd
-      o4[c] = sc;                               // scale
-      o5[c] = (beta ? beta[c] : 0.f) - (float)m * sc;   // shift
-    } else {
-      o1[c] = (float)t1;                        // dbeta
-      o2[c] = (float)t2;                        // dgamma
-      o3[c] = (gamma ? gamma[c] : 1.f) * invstd_in[c];  // gamma * invstd
-      o4[c] = (float)(t1 / (double)N);          // dbeta / N
-      o5[c] = (float)(t2 / (double)N);          // dgamma / N
-    }
+  __shared__ double s_t[2][kWave];
+  const int c = blockIdx.x, j = threadIdx.x;
+  double t1 = 0.0, t2 = 0.0;
+  for (int b = j; b < nblocks; b += kWave) {
+    t1 += (double)partial[((int64_t)b * 2 + 0) * C + c];
+    t2 += (double)partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  s_t[0][j] = t1;
+  s_t[1][j] = t2;
+  __syncthreads();
+  if (j != 0) return;
+  t1 = t2 = 0.0;
+  for (int k = 0; k < kWave; ++k) { t1 += s_t[0][k]; t2 += s_t[1][k]; }
+  if (MODE == 0) {
+    const double m = t1 / (double)N;
+    double var = t2 / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    o1[c] = (float)m;                         // mean
+    o2[c] = (float)var;                       // biased variance
+    o3[c] = is;                               // invstd
+    o4[c] = sc;                               // scale
+    o5[c] = (beta ? beta[c] : 0.f) - (float)m * sc;   // shift
+  } else {
+    o1[c] = (float)t1;                        // dbeta
+    o2[c] = (float)t2;                        // dgamma
+    o3[c] = (gamma ? gamma[c] : 1.f) * invstd_in[c];  // gamma * invstd
+    o4[c] = (float)(t1 / (double)N);          // dbeta / N
+    o5[c] = (float)(t2 / (double)N);          // dgamma / N
   }
 }
 
@@ -157,7 +165,7 @@ extern "C" int mlqem_batch_norm_train_f32(const float* x, int64_t ldx, int64_t N
   float* shift = scale + C;
   hipLaunchKernelGGL(bn_column_sums_kernel<0>, dim3((unsigned)nb), dim3(kBlock), 0, stream, x, ldx, (const float*)nullptr,
                      (int64_t)0, (const float*)nullptr, (const float*)nullptr, N, C, ceil_div(N, (int64_t)nb), partial);
-  hipLaunchKernelGGL(bn_finish_kernel<0>, dim3(1), dim3(kBlock), 0, stream, partial, nb, N, C, gamma, beta,
+  hipLaunchKernelGGL(bn_finish_kernel<0>, dim3((unsigned)C), dim3(kWave), 0, stream, partial, nb, N, C, gamma, beta,
                      (const float*)nullptr, eps, mean, var, invstd, scale, shift);
   hipLaunchKernelGGL(bn_affine_kernel, dim3((unsigned)ceil_div(N * C, (int64_t)kBlock)), dim3(kBlock), 0, stream, x, ldx,
                      scale, shift, N, C, y, ldy);
@@ -181,7 +189,7 @@ extern "C" int mlqem_batch_norm_train_bwd_f32(const float* dy, int64_t ldg, cons
   float* k2 = k1 + C;
   hipLaunchKernelGGL(bn_column_sums_kernel<1>, dim3((unsigned)nb), dim3(kBlock), 0, stream, dy, ldg, x, ldx, mean, invstd, N,
                      C, ceil_div(N, (int64_t)nb), partial);
-  hipLaunchKernelGGL(bn_finish_kernel<1>, dim3(1), dim3(kBlock), 0, stream, partial, nb, N, C, gamma, (const float*)nullptr,
+  hipLaunchKernelGGL(bn_finish_kernel<1>, dim3((unsigned)C), dim3(kWave), 0, stream, partial, nb, N, C, gamma, (const float*)nullptr,
                      invstd, 0.f, dbeta, dgamma, gs, k1, k2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(N * C, (int64_t)kBlock)), dim3(kBlock), 0, stream, dy, ldg,
                      x, ldx, mean, invstd, gs, k1, k2, N, C, dx, lddx);

@@ -588,3 +588,22 @@ def test_batch_norm_train_matches_torch_in_fp64(n, c):
     assert rel(bn.weight.grad, ref.weight.grad) < 1e-5 and rel(bn.bias.grad, ref.bias.grad) < 1e-5
     assert rel(bn.running_mean, ref.running_mean) < 1e-6 and rel(bn.running_var, ref.running_var) < 1e-5
     assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("padded", [True, False])
+def test_linear_with_more_than_128_inputs_runs_on_the_matrix_cores_in_two_pieces(padded):
+    """ops.linear splits inputs wider than 128 columns (the 169/170-wide encode_data_v2_ecr rows of the MLP path) into
+    k-pieces for the MFMA kernels, bias on the first, ReLU on the last; against float64."""
+    from blackwater.native import ops
+
+    torch.manual_seed(5)
+    n, i, o = 3000, 170, 125
+    x = torch.randn(n, i, device=DEV)
+    if padded:
+        x = ops.padded_copy(x)
+    w, b = torch.randn(o, i, device=DEV) * 0.1, torch.randn(o, device=DEV)
+    want = torch.relu(x.double() @ w.double().t() + b.double())
+    got = ops.linear(x, w, b, relu=True)
+    assert (got.double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
+    got2 = ops.linear(x, w, None, out=got.clone(), accumulate=True)          # accumulate onto an existing matrix
+    assert (got2.double() - (want + x.double() @ w.double().t())).abs().max().item() < 1e-4 * want.abs().max().item() * 2
