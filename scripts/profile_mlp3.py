@@ -11,7 +11,7 @@ class Rows:
     def model_args(s): return (s.x,)
 torch.manual_seed(0)
 x, y = torch.randn(rows, 170, device=dev), torch.randn(rows, 1, device=dev)
-m = MLP3(170, 125, 1).to(dev); tr = Trainer(m, lr=1e-3); b = Rows(x, y)
+m = MLP3(170, 125, 1).to(dev); m.mfma = sys.argv[2] if len(sys.argv) > 2 else "f32"; tr = Trainer(m, lr=1e-3); b = Rows(x, y)
 for _ in range(3): tr.step(b)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): tr.step(b)
