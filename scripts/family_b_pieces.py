@@ -39,11 +39,12 @@ else:
     sampler = StratifiedBatches(arena.node_counts[:n], arena.edge_counts[:n], 32, seed=11)
     print("quota", sampler.quota.tolist(), "nodes per batch", sampler.nodes_per_batch, flush=True)
     bt = BucketedTrainer(model, arena, lr=1e-3, graphs=what == "strat_graph", node_quantum=256, edge_quantum=512)
-    for k in range(12):
+    for k in range(int(os.environ.get('PIECE_STEPS', '12'))):
         ids = sampler.draw()
         if k == 0:
             print("bucket", bt.bucket_of(ids)[:3], flush=True)
         loss = bt.step_ids(ids)
-        torch.cuda.synchronize()
-        print(what, "step", k, float(loss), flush=True)
+        if k < 12:
+            torch.cuda.synchronize()
+            print(what, "step", k, float(loss), flush=True)
 print("done", what, flush=True)
