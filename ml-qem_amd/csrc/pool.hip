@@ -14,7 +14,10 @@
 
 namespace mlqem {
 
-constexpr int kPoolRows = 1024;   // rows per workgroup
+constexpr int kPoolRows = 1024;   // rows per workgroup (graphs of hundreds to thousands of rows)
+constexpr int kPoolRowsSmall = 64;   // ... when the batch's graphs average fewer than 128 rows: a tile then holds a graph or two
+                                     // instead of dozens, which one workgroup would walk one after the other (three barriers each:
+                                     // 40 us for the 33 pooled graphs of a 32-circuit Family B batch, whatever their size)
 constexpr int kPoolUnroll = 4;    // rows a thread has in flight
 
 struct PoolArgs {
@@ -23,6 +26,7 @@ struct PoolArgs {
   const int32_t* gptr;       // [B+1]
   int64_t N; int B; int C; int CV;   // CV = ceil(C / VEC) channel slices per row
   float* partial;            // [(tiles + B)][2][CV * VEC]
+  int rows;                  // rows per tile: kPoolRows or kPoolRowsSmall
 };
 
 // largest g in [0, B) with gptr[g] <= r (gptr[0] = 0 <= r): the graph of row r, or of the empty graphs just before it
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(kBlock) void pool_partial_kernel(const PoolArgs a) 
   __shared__ float s_red[kBlock][2 * VEC];
   const int tid = threadIdx.x;
   const int64_t tile = blockIdx.x;
-  const int64_t r0 = tile * kPoolRows, r1 = min(a.N, r0 + kPoolRows);
+  const int64_t r0 = tile * a.rows, r1 = min(a.N, r0 + a.rows);
   const int lanes_r = kBlock / a.CV;            // row lanes (>= 1: CV <= kBlock checked on the host)
   const int cs = tid % a.CV, rl = tid / a.CV;
   const bool worker = rl < lanes_r;
@@ -111,15 +115,15 @@ __global__ __launch_bounds__(kBlock) void pool_partial_kernel(const PoolArgs a) 
 }
 
 __global__ __launch_bounds__(kBlock) void pool_finish_kernel(const float* __restrict__ partial, const int32_t* __restrict__ gptr,
-                                                             int B, int C, int slot_w, float* __restrict__ out_mean, int64_t ld0,
-                                                             float* __restrict__ out_wmean, int64_t ld1) {
+                                                             int B, int C, int slot_w, int rows, float* __restrict__ out_mean,
+                                                             int64_t ld0, float* __restrict__ out_wmean, int64_t ld1) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= (int64_t)B * C) return;
   const int g = (int)(t / C), c = (int)(t - (int64_t)g * C);
   const int beg = gptr[g], end = gptr[g + 1];
   float s0 = 0.f, s1 = 0.f;
   if (end > beg) {
-    const int64_t t_first = beg / kPoolRows, t_last = (end - 1) / kPoolRows;
+    const int64_t t_first = beg / rows, t_last = (end - 1) / rows;
     for (int64_t tile = t_first; tile <= t_last; ++tile) {
       const float* p = partial + ((tile + g) * 2) * slot_w + c;
       s0 += p[0];
@@ -254,13 +258,15 @@ __global__ __launch_bounds__(kBlock) void pooled_head_bwd_sums_kernel(const Head
   }
 }
 
+static int pool_rows(int64_t N, int64_t B) { return (B > 0 && N / B < 128) ? kPoolRowsSmall : kPoolRows; }
+
 }  // namespace mlqem
 
 using namespace mlqem;
 
 extern "C" size_t mlqem_segment_pool_workspace_bytes(int64_t N, int64_t B, int C) {
   if (N < 0 || B < 0 || C <= 0) return 0;
-  const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), kPoolRows);
+  const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), pool_rows(N, B));
   return (size_t)(tiles + B) * 2 * ((C + 3) / 4 * 4) * sizeof(float);
 }
 
@@ -278,15 +284,15 @@ extern "C" int mlqem_segment_pool_f32(const float* x, int64_t ldx, const float* 
   // 16-byte row accesses when the rows own round_up(C, 4) columns (the padded activation layout): the pad columns are
   // summed along and never read back
   const bool wide = ldx >= c4 && ldx % 4 == 0 && aligned_to(x, 16);
-  PoolArgs a{x, ldx, weights, graph_ptr, N, (int)B, C, wide ? c4 / 4 : C, static_cast<float*>(workspace)};
+  PoolArgs a{x, ldx, weights, graph_ptr, N, (int)B, C, wide ? c4 / 4 : C, static_cast<float*>(workspace), pool_rows(N, B)};
   if (a.CV > kBlock) return MLQEM_ERR_UNSUPPORTED;
   if (N > 0) {
-    const unsigned tiles = (unsigned)ceil_div(N, kPoolRows);
+    const unsigned tiles = (unsigned)ceil_div(N, (int64_t)a.rows);
     if (wide) hipLaunchKernelGGL(pool_partial_kernel<4>, dim3(tiles), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL(pool_partial_kernel<1>, dim3(tiles), dim3(kBlock), 0, s, a);
   }
   hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)ceil_div(B * C, kBlock)), dim3(kBlock), 0, s, a.partial, graph_ptr, (int)B,
-                     C, wide ? c4 : C, out_mean, ld_mean, out_wmean, ld_wmean);
+                     C, wide ? c4 : C, a.rows, out_mean, ld_mean, out_wmean, ld_wmean);
   return launch_status();
 }
 
