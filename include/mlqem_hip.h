@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 13 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 14 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -210,6 +210,29 @@ int mlqem_linear_wgrad_f32(const float* gy, int64_t ldgy, const float* x, int64_
 int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int64_t ldx, float* gw, float* gb, int64_t N,
                                  int I, int accumulate, void* workspace, size_t workspace_bytes, const int32_t* x_rows,
                                  mlqem_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * The MLP regressor as one forward and one backward launch.  Replaces MLP1.forward and its autograd
+ * (docs/tutorials/mlp.py:18-30 == blackwater/library/learning/mlp.py: fc2(relu(fc1(x))); trained by h10_mlp.ipynb cells
+ * [10]-[13] on a plain feature matrix, so x needs no gradient).  I <= MLQEM_MLP1_MAX_IN inputs, H <= 128 hidden units,
+ * O2 <= MLQEM_MLP1_MAX_OUT outputs; x rows padded to a multiple of 4 floats and 16-byte aligned (ldx % 4 == 0).
+ *   forward : h = relu(x W1^T + b1) ; out = h W2^T + b2.  h_stash (optional, [N, MLQEM_MLP1_HIDDEN_PAD], 16-byte aligned)
+ *             receives h for the backward: fp32 when bf16 == 0, bf16 (2 bytes per element) when bf16 != 0.
+ *   backward: gW1 = gh^T x, gb1 = sum gh, gW2 = gout^T h, gb2 = sum gout with gh = (gout W2) o (h > 0), from ONE pass
+ *             over x and the stash; per-workgroup partial sums, fixed-order second stage (deterministic).
+ * bf16 == 0: exact fp32 on v_mfma_f32_16x16x4_f32.  bf16 != 0: every GEMM operand rounded to bf16 (nearest-even), fp32
+ * accumulation on v_mfma_f32_16x16x32_bf16, the stash kept in bf16 (the "bf16 MFMA MLP head" of the mixed-corpus
+ * configuration); gb2 is summed from the unrounded gout.  workspace: mlqem_mlp1_workspace_bytes(I, O2). */
+#define MLQEM_MLP1_HIDDEN_PAD 128
+#define MLQEM_MLP1_MAX_OUT 4
+#define MLQEM_MLP1_MAX_IN 175
+size_t mlqem_mlp1_workspace_bytes(int I, int O2);
+int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,
+                       void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2, int bf16,
+                       mlqem_stream_t stream);
+int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t ldx, const void* h_stash, const float* w2,
+                        float* gw1, float* gb1, float* gw2, float* gb2, int64_t N, int I, int H, int O2, int bf16,
+                        void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Backward of a narrow hidden layer (I, O <= 12) in ONE pass over its operands:
  *   gx[n,:] = (x[n,:] > 0 ? gate_scale : 0) * (gy[n,:] @ W)   (gate != 0; plain gy @ W otherwise)      W: [O, I]
@@ -469,8 +492,13 @@ typedef struct mlqem_backend_props {
 
 /* Two-call pattern.  Size query: x == NULL -> *num_nodes, *num_edges, *num_features, *depth are filled.  Fill: pass
  * buffers x[N*F], edge_src[E], edge_dst[E], edge_attr[E*3] (edge_attr may be NULL) with *num_nodes / *num_edges set to
- * their capacities.  Errors (MLQEM_ERR_UNSUPPORTED): a gate outside gates_set, a non-barrier gate on more than 3
- * qubits, more than 3 parameters, malformed QASM -- mlqem_encode_last_error() has the message (per thread). */
+ * their capacities.  Errors: MLQEM_ERR_UNSUPPORTED for a well-formed circuit the encoding does not cover (a gate
+ * outside gates_set, a non-barrier gate on more than 3 qubits, more than 3 parameters, a qubit beyond the calibration
+ * table: where the reference raises); MLQEM_ERR_BAD_ARG for text that is not OpenQASM 2 (unbalanced or too deeply nested
+ * parentheses -- angle expressions nest at most 64 levels --, bad or out-of-range indices, mismatched register sizes,
+ * more than 2^20 register bits, truncated statements).  mlqem_encode_last_error() has the message (per thread).  The
+ * parser is bounded: no input makes it recurse or allocate beyond these limits (csrc `make asan` runs it under
+ * AddressSanitizer / UBSan over a malformed corpus, tests/test_encoder_fuzz.py). */
 int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* props, int use_qubit_features, int use_gate_features,
                       int64_t* num_nodes, int64_t* num_edges, int* num_features, int* depth, double* x,
                       int32_t* edge_src, int32_t* edge_dst, double* edge_attr);

@@ -90,6 +90,37 @@ def linear(x, w, b=None, relu=False, mfma="f32"):
     return y.reshape(*lead, w.shape[0])
 
 
+class _MLP1(Function):
+    """fc2(relu(fc1(x))) as one forward and one backward launch (csrc/mlp_head.hip); x gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, bf16):
+        train = any(ctx.needs_input_grad[1:5])
+        out, hs, xp = ops.mlp1_forward(x, w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous(), bf16=bf16, stash=train)
+        ctx.bf16 = bf16
+        ctx.save_for_backward(xp, hs, w2)
+        ctx.dims = (w1.shape[1], w1.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, hs, w2 = ctx.saved_tensors
+        gw1, gb1, gw2, gb2 = ops.mlp1_backward(g, xp, hs, w2.contiguous(), ctx.dims[0], ctx.dims[1], bf16=ctx.bf16)
+        return None, gw1, gb1, gw2, gb2, None
+
+
+def mlp1_fused_ok(x, w1, w2) -> bool:
+    """Whether ``mlp1`` can take this call: a GPU feature matrix that needs no gradient, widths inside the kernel's limits."""
+    return (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not x.requires_grad
+            and ops.mlp1_fits(w1.shape[1], w1.shape[0], w2.shape[0]) and os.environ.get("MLQEM_MLP1_FUSED", "1") != "0")
+
+
+def mlp1(x, w1, b1, w2, b2, mfma="f32"):
+    if mfma not in ("f32", "bf16"):
+        raise ValueError(f"mfma must be 'f32' or 'bf16', got {mfma!r}")
+    return _MLP1.apply(x, w1, b1, w2, b2, mfma == "bf16")
+
+
 class _ReluDropoutAdd(Function):
     """s = dropout(relu(u)) (+ residual) as one launch; the backward recovers the mask from the saved activation."""
 

@@ -443,6 +443,67 @@ def linear_wgrad(gy, x, gw, gb=None, accumulate=False):
     _lib.check(code, "mlqem_linear_wgrad_f32")
 
 
+MLP1_MAX_IN, MLP1_MAX_HIDDEN, MLP1_MAX_OUT = 175, 128, 4   # MLQEM_MLP1_MAX_IN / _HIDDEN_PAD / _MAX_OUT
+
+
+def mlp1_fits(i: int, h: int, o2: int) -> bool:
+    """Shapes the one-launch MLP head takes (csrc/mlp_head.hip); wider layers go through the per-layer GEMMs."""
+    return 1 <= i <= MLP1_MAX_IN and 1 <= h <= MLP1_MAX_HIDDEN and 1 <= o2 <= MLP1_MAX_OUT
+
+
+def _mlp1_x(x):
+    """x in the padded row layout the head kernels read (16-byte aligned rows of round_up(I, 4) floats)."""
+    if not x.is_cuda:
+        raise _lib.NativeLibraryError(f"x must live on the GPU (got {x.device}); there is no CPU path")
+    x = rowmajor(x)
+    if x.shape[0] > 1 and (x.stride(0) % 4 or x.stride(0) < (x.shape[1] + 3) // 4 * 4 or x.data_ptr() % 16):
+        x = padded_copy(x)
+    elif x.shape[0] <= 1 and (x.data_ptr() % 16 or x.shape[1] % 4):
+        x = padded_copy(x)
+    return x
+
+
+def mlp1_forward(x, w1, b1, w2, b2, bf16=False, stash=True):
+    """(out [N, O2], stash): out = relu(x w1^T + b1) w2^T + b2 in one launch (mlqem_mlp1_forward); ``stash`` = the hidden
+    activation [N, 128] the backward reads, fp32 or -- ``bf16`` -- bfloat16 (None when ``stash`` is False)."""
+    x = _mlp1_x(x)
+    n, i = x.shape
+    h, o2 = w1.shape[0], w2.shape[0]
+    for name, t, shape in (("w1", w1, (h, i)), ("b1", b1, (h,)), ("w2", w2, (o2, h)), ("b2", b2, (o2,))):
+        if not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous():
+            raise ValueError(f"mlp1_forward: {name} must be a contiguous fp32 cuda tensor of shape {shape}, got {tuple(t.shape)}")
+    out = torch.empty((n, o2), dtype=torch.float32, device=x.device)
+    hs = torch.empty((max(n, 1), MLP1_MAX_HIDDEN), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device) if stash else None
+    ldx = _mat(x, "x") if n > 1 else (i + 3) // 4 * 4
+    code = _lib.load().mlqem_mlp1_forward(_p(x), ldx, _p(w1), _p(b1), _p(w2), _p(b2), _p(hs), _p(out), o2, n, i, h, o2,
+                                          1 if bf16 else 0, _stream())
+    _lib.check(code, "mlqem_mlp1_forward")
+    return out, hs, x
+
+
+def mlp1_backward(gout, x, hs, w2, i, h, bf16=False):
+    """(gw1 [H, I], gb1, gw2 [O2, H], gb2) from one pass over x and the stash (mlqem_mlp1_backward); ``x`` as returned by
+    :func:`mlp1_forward` (padded rows)."""
+    n, o2 = gout.shape
+    gout = rowmajor(gout)
+    if gout.dtype != torch.float32 or hs.shape != (max(n, 1), MLP1_MAX_HIDDEN) or hs.dtype != (torch.bfloat16 if bf16 else torch.float32):
+        raise ValueError("mlp1_backward: gout / stash do not match the forward call")
+    if tuple(x.shape) != (n, i) or tuple(w2.shape) != (o2, h) or not w2.is_contiguous():
+        raise ValueError("mlp1_backward: shape mismatch")
+    dev = x.device
+    gw1, gb1 = torch.empty((h, i), dtype=torch.float32, device=dev), torch.empty(h, dtype=torch.float32, device=dev)
+    gw2, gb2 = torch.empty((o2, h), dtype=torch.float32, device=dev), torch.empty(o2, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    need = lib.mlqem_mlp1_workspace_bytes(i, o2)
+    ws = _wgrad_workspace(dev, need)
+    ldx = _mat(x, "x") if n > 1 else (i + 3) // 4 * 4
+    ldg = int(gout.stride(0)) if n > 1 else o2
+    code = lib.mlqem_mlp1_backward(_p(gout), ldg, _p(x), ldx, _p(hs), _p(w2), _p(gw1), _p(gb1), _p(gw2), _p(gb2), n, i, h, o2,
+                                   1 if bf16 else 0, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_mlp1_backward")
+    return gw1, gb1, gw2, gb2
+
+
 _pool_ws = {}   # (device, stream, bytes) -> partial-sum workspace of the pooling kernels (per stream, like _wgrad_ws)
 
 

@@ -25,11 +25,37 @@ struct Op {
 
 struct Reg { int base, size; };
 
-struct ParseError { std::string what; };
+// Two kinds of failure: text that is not OpenQASM 2 (MLQEM_ERR_BAD_ARG) and a well-formed circuit the encoding does not
+// cover (a gate outside gates_set, more than 3 qubits / parameters: MLQEM_ERR_UNSUPPORTED, where the reference raises too).
+struct ParseError { std::string what; bool unsupported = false; };
+
+// Limits that keep hostile text from turning into unbounded recursion or allocation: the text arrives through a public
+// entry point (the decorators hand over whatever the caller's circuits serialise to).
+constexpr int kMaxExprDepth = 64;           // nested parentheses / function calls / unary signs in one angle expression
+constexpr long kMaxRegisterBits = 1 << 20;  // qubits + clbits of a circuit (the largest devices have ~1e3)
+
+// decimal integer followed by ']' at s (after optional spaces); -1 when it is anything else or does not fit
+long bracket_index(const char* s) {
+  while (*s && std::isspace((unsigned char)*s)) ++s;
+  if (!std::isdigit((unsigned char)*s)) return -1;
+  long v = 0;
+  for (; std::isdigit((unsigned char)*s); ++s) {
+    v = v * 10 + (*s - '0');
+    if (v > kMaxRegisterBits) return -1;
+  }
+  while (*s && std::isspace((unsigned char)*s)) ++s;
+  return *s == ']' ? v : -1;
+}
 
 // ---- angle expressions: numbers, pi, + - * / ^, unary sign, parentheses, sin cos tan exp ln sqrt asin acos atan
 struct Expr {
   const char* p;
+  int depth = 0;
+  struct Nest {   // one level of recursion (a parenthesis, a function argument, a unary sign, an exponent)
+    int& d;
+    explicit Nest(int& depth) : d(depth) { if (++d > kMaxExprDepth) throw ParseError{"angle expression nested too deeply"}; }
+    ~Nest() { --d; }
+  };
   explicit Expr(const char* s) : p(s) {}
   void ws() { while (*p && std::isspace((unsigned char)*p)) ++p; }
   double parse() { double v = sum(); ws(); if (*p) throw ParseError{"trailing characters in angle expression"}; return v; }
@@ -52,20 +78,20 @@ struct Expr {
     }
   }
   double unary() {
-    ws();
-    if (*p == '-') { ++p; return -unary(); }
-    if (*p == '+') { ++p; return unary(); }
-    return power();
+    bool neg = false;                       // a run of signs is a loop, not a recursion
+    for (ws(); *p == '-' || *p == '+'; ws()) { if (*p == '-') neg = !neg; ++p; }
+    const double v = power();
+    return neg ? -v : v;
   }
   double power() {
     double b = atom();
     ws();
-    if (*p == '^') { ++p; return std::pow(b, unary()); }
+    if (*p == '^') { ++p; Nest n(depth); return std::pow(b, unary()); }
     return b;
   }
   double atom() {
     ws();
-    if (*p == '(') { ++p; double v = sum(); ws(); if (*p != ')') throw ParseError{"missing ) in angle expression"}; ++p; return v; }
+    if (*p == '(') { Nest n(depth); ++p; double v = sum(); ws(); if (*p != ')') throw ParseError{"missing ) in angle expression"}; ++p; return v; }
     if (std::isdigit((unsigned char)*p) || *p == '.') { char* end; double v = std::strtod(p, &end); p = end; return v; }
     if (std::isalpha((unsigned char)*p)) {
       std::string id;
@@ -73,6 +99,7 @@ struct Expr {
       if (id == "pi") return M_PI;
       ws();
       if (*p != '(') throw ParseError{"unknown identifier '" + id + "' in angle expression"};
+      Nest n(depth);
       ++p; double a = sum(); ws(); if (*p != ')') throw ParseError{"missing ) after function"}; ++p;
       if (id == "sin") return std::sin(a); if (id == "cos") return std::cos(a); if (id == "tan") return std::tan(a);
       if (id == "exp") return std::exp(a); if (id == "ln") return std::log(a); if (id == "sqrt") return std::sqrt(a);
@@ -116,9 +143,9 @@ std::vector<int> bits_of(const std::string& arg, const std::unordered_map<std::s
   if (it == regs.end()) throw ParseError{"unknown register in '" + a + "'"};
   std::vector<int> out;
   if (br == std::string::npos) { for (int i = 0; i < it->second.size; ++i) out.push_back(it->second.base + i); return out; }
-  int idx = std::atoi(a.c_str() + br + 1);
-  if (idx < 0 || idx >= it->second.size) throw ParseError{"index out of range in '" + a + "'"};
-  out.push_back(it->second.base + idx);
+  const long idx = bracket_index(a.c_str() + br + 1);
+  if (idx < 0 || idx >= it->second.size) throw ParseError{"bad or out-of-range index in '" + a + "'"};
+  out.push_back(it->second.base + (int)idx);
   return out;
 }
 
@@ -162,7 +189,10 @@ Circuit parse_qasm(const char* text) {
       size_t br = rest.find('[');
       if (br == std::string::npos) throw ParseError{"bad register declaration '" + st + "'"};
       std::string name = trim(rest.substr(0, br));
-      int size = std::atoi(rest.c_str() + br + 1);
+      const long size_l = bracket_index(rest.c_str() + br + 1);
+      if (name.empty() || size_l < 0 || c.nq + c.nc + size_l > kMaxRegisterBits) throw ParseError{"bad register declaration '" + st + "'"};
+      if (qregs.count(name) || cregs.count(name)) throw ParseError{"register '" + name + "' declared twice"};
+      const int size = (int)size_l;
       if (q) { qregs[name] = Reg{c.nq, size}; c.nq += size; for (int i = 0; i < size; ++i) c.reg_index.push_back(i); }
       else { cregs[name] = Reg{c.nc, size}; c.nc += size; }
       continue;
@@ -172,7 +202,7 @@ Circuit parse_qasm(const char* text) {
       if (arrow == std::string::npos) throw ParseError{"bad measure '" + st + "'"};
       auto qs = bits_of(st.substr(7, arrow - 7), qregs);
       auto cs = bits_of(st.substr(arrow + 2), cregs);
-      if (qs.size() != cs.size()) throw ParseError{"measure size mismatch"};
+      if (qs.size() != cs.size() || qs.empty()) throw ParseError{"measure size mismatch"};
       for (size_t i = 0; i < qs.size(); ++i) c.ops.push_back(Op{"measure", {qs[i]}, {cs[i]}, {}});
       continue;
     }
@@ -189,19 +219,22 @@ Circuit parse_qasm(const char* text) {
     // name [ (params) ] args
     size_t i = 0;
     while (i < st.size() && (std::isalnum((unsigned char)st[i]) || st[i] == '_')) ++i;
-    if (i == 0) throw ParseError{"cannot parse statement '" + st + "'"};
+    if (i == 0) throw ParseError{"cannot parse statement '" + st.substr(0, 64) + "'"};
     Op op; op.name = st.substr(0, i);
     std::string rest = trim(st.substr(i));
     if (!rest.empty() && rest[0] == '(') {
       int depth = 0; size_t j = 0;
       for (; j < rest.size(); ++j) { if (rest[j] == '(') ++depth; else if (rest[j] == ')' && --depth == 0) break; }
-      if (j >= rest.size()) throw ParseError{"unbalanced parameter list in '" + st + "'"};
+      if (j >= rest.size()) throw ParseError{"unbalanced parameter list in '" + st.substr(0, 64) + "'"};
       for (auto& e : split_top(rest.substr(1, j - 1))) op.params.push_back(Expr(e.c_str()).parse());
       rest = trim(rest.substr(j + 1));
     }
     std::vector<std::vector<int>> args;
     size_t width = 1;
     for (auto& a : split_top(rest)) { args.push_back(bits_of(a, qregs)); width = std::max(width, args.back().size()); }
+    if (args.empty()) throw ParseError{"statement without qubit arguments '" + st.substr(0, 64) + "'"};
+    for (auto& a : args)   // whole-register arguments must agree in size (OpenQASM 2, section 4.2); an empty register has no bit to act on
+      if (a.empty() || (a.size() > 1 && a.size() != width)) throw ParseError{"register size mismatch in '" + st.substr(0, 64) + "'"};
     for (size_t k = 0; k < width; ++k) {  // whole-register arguments broadcast
       Op o = op;
       for (auto& a : args) o.qubits.push_back(a.size() > 1 ? a[k] : a[0]);
@@ -239,8 +272,8 @@ extern "C" int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* pr
     std::vector<int> level(c.nq + c.nc, 0);
     for (int64_t k = 0; k < N; ++k) {
       const Op& op = c.ops[k];
-      if (op.name != "barrier" && op.qubits.size() > 3) throw ParseError{"Non barrier gate that has more than 3 qubits."};
-      if (op.params.size() > 3) throw ParseError{"more than 3 gate parameters"};
+      if (op.name != "barrier" && op.qubits.size() > 3) throw ParseError{"Non barrier gate that has more than 3 qubits.", true};
+      if (op.params.size() > 3) throw ParseError{"more than 3 gate parameters", true};
       int lvl = 0;
       for (int q : op.qubits) { if (last[q] >= 0) out[last[q]].push_back({(int)k, q}); last[q] = (int)k; lvl = std::max(lvl, level[q]); }
       for (int cb : op.clbits) { int w = c.nq + cb; if (last[w] >= 0) out[last[w]].push_back({(int)k, w}); last[w] = (int)k; lvl = std::max(lvl, level[w]); }
@@ -264,14 +297,14 @@ extern "C" int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* pr
       for (int i = 0; i < F; ++i) row[i] = 0.0;
       for (size_t i = 0; i < op.params.size(); ++i) row[i] = op.params[i];
       auto it = type_slot.find(op.name);
-      if (it == type_slot.end()) throw ParseError{"gate '" + op.name + "' is not in the backend's gates_set"};
+      if (it == type_slot.end()) throw ParseError{"gate '" + op.name + "' is not in the backend's gates_set", true};
       row[3 + it->second] = 1.0;
       int col = 3 + n_types;
       if (use_qubit_features) {
         if (op.name != "barrier")
           for (size_t s = 0; s < op.qubits.size(); ++s) {
             const int qi = c.reg_index[op.qubits[s]];
-            if (qi >= props->num_qubits) throw ParseError{"qubit index beyond the calibration table"};
+            if (qi >= props->num_qubits) throw ParseError{"qubit index beyond the calibration table", true};
             row[col + s] = props->t1[qi]; row[col + 3 + s] = props->t2[qi]; row[col + 6 + s] = props->readout[qi];
           }
         col += 9;
@@ -290,7 +323,7 @@ extern "C" int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* pr
         edge_src[e] = (int32_t)k; edge_dst[e] = it->first;
         if (edge_attr) {
           const int qi = c.reg_index[it->second];
-          if (qi >= props->num_qubits) throw ParseError{"qubit index beyond the calibration table"};
+          if (qi >= props->num_qubits) throw ParseError{"qubit index beyond the calibration table", true};
           edge_attr[e * 3] = props->t1[qi]; edge_attr[e * 3 + 1] = props->t2[qi]; edge_attr[e * 3 + 2] = props->readout[qi];
         }
         ++e;
@@ -298,8 +331,8 @@ extern "C" int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* pr
     return MLQEM_OK;
   } catch (const ParseError& err) {
     g_last_error = err.what;
-    return MLQEM_ERR_UNSUPPORTED;
-  } catch (const std::exception& err) {
+    return err.unsupported ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
+  } catch (const std::exception& err) {   // bad_alloc, length_error: the text asked for more than the host has
     g_last_error = err.what();
     return MLQEM_ERR_BAD_ARG;
   }
@@ -331,9 +364,9 @@ extern "C" int mlqem_circuit_features_qasm(const char* qasm, const char* const* 
     return MLQEM_OK;
   } catch (const ParseError& e) {
     g_last_error = e.what;
-    return MLQEM_ERR_UNSUPPORTED;
+    return e.unsupported ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
   } catch (const std::exception& e) {
     g_last_error = e.what();
-    return MLQEM_ERR_UNSUPPORTED;
+    return MLQEM_ERR_BAD_ARG;
   }
 }

@@ -1,0 +1,711 @@
+// The MLP regressor head as ONE forward and ONE backward launch (reference: docs/tutorials/mlp.py:18-30, MLP1 =
+// fc2(relu(fc1 x)); the demo feature sets are 58 / 169 / 170 columns wide, hidden 64 / 128, 1 or 4 outputs).
+//
+// Shapes: N rows (circuits, 1e5..1e6 at the mixed-corpus scale), I <= 175 inputs, H <= 128 hidden, O2 <= 4 outputs.
+// What bounds it: 170 x 128 is 43.5 kFLOP per 688-byte row = 63 FLOP/B, three times the ridge of the fp32 matrix cores
+// (157 TFLOP/s / 8 TB/s = 20 FLOP/B): in fp32 the head is MFMA-bound (2 x 11.4 GFLOP at 262 144 rows = 146 us at peak), on
+// the bf16 matrix cores (16x the rate) it is HBM-bound.  So
+//   * forward: fc1 on the matrix cores with the whole W1 in LDS as ready-made A fragments, bias + ReLU + fc2 (a dot product
+//     per output) in the epilogue -- the hidden activation never goes to memory as an operand, only as the STASH the
+//     backward needs: fp32 [N,128] in fp32 mode (exact), bf16 [N,128] in bf16 mode (half the bytes);
+//   * backward: one pass over x and the stash gives gW1, gb1, gW2, gb2 -- the hidden gradient gh = (gout w2) o (h > 0) is
+//     formed in registers (the input needs no gradient: docs/tutorials/mlp.py trains on a plain feature matrix).
+// fp32 mode is exact fp32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain); bf16 mode rounds every GEMM operand to bf16
+// (round-to-nearest-even), accumulates in fp32 on v_mfma_f32_16x16x32_bf16 and keeps h as bf16.
+//
+// Lane maps (guide section 3).  f32 16x16x4: A: lane l holds A[l & 15][l >> 4]; B: lane l holds B[l >> 4][l & 15].
+// bf16 16x16x32: A: lane l holds A[l & 15][8 (l >> 4) + j], j = 0..7; B: B[8 (l >> 4) + j][l & 15].  C/D (both): lane l,
+// register r holds D[4 (l >> 4) + r][l & 15].  The MFMA sums over k in any order as long as A and B agree, and the m / n
+// indices of a tile may stand for any 16 rows / columns -- both freedoms are used to make every global access 16 bytes wide.
+#include "common.hpp"
+
+namespace mlqem {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHeadH = MLQEM_MLP1_HIDDEN_PAD;   // columns of the stash (hidden width padded to 128)
+constexpr int kHeadMaxOut = MLQEM_MLP1_MAX_OUT;
+constexpr int kFwdThreads = 256;                // the waves of a workgroup share one W1 image in LDS
+constexpr int kBwdThreads = 256;
+
+struct Mlp1Args {
+  const float* x; int64_t ldx; int64_t N; int I, H, O2;
+  const float* w1; const float* b1; const float* w2; const float* b2;   // [H,I], [H], [O2,H], [O2]
+  void* h;                      // stash [N,128]: float (fp32 mode) or bf16 (bf16 mode); forward may pass nullptr (inference)
+  float* out; int64_t ldo;      // forward: [N,O2]
+  const float* gout; int64_t ldg;   // backward: d loss / d out, [N,O2]
+  float* partial;               // backward: per-workgroup partial sums, see mlp1_partial_floats
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};             // one v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16_round(float f) { return (float)(__bf16)f; }
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+
+// Output tile ob (0..7), tile row m (0..15) <-> hidden unit: lane group q = m >> 2 ends up with EIGHT consecutive units of
+// every tile pair (32 (ob >> 1) + 8 q + 0..7), i.e. one 16-byte (bf16) or two 16-byte (fp32) stores per pair.
+__device__ __forceinline__ int head_unit(int ob, int m) { return 32 * (ob >> 1) + 8 * (m >> 2) + 4 * (ob & 1) + (m & 3); }
+
+// ------------------------------------------------------------------------------------------------ forward
+// LDS: the W1 image (8 output tiles x G k-groups x 64 lanes x 16 bytes), then b1[128], w2[4][128].
+template <bool BF16, int G>
+__device__ __forceinline__ void head_fill_lds(const Mlp1Args& a, u32x4* s_w, float* s_b1, float* s_w2) {
+  for (int idx = threadIdx.x; idx < 8 * G * kWave; idx += kFwdThreads) {
+    const int l = idx & 63, g = (idx >> 6) % G, ob = idx / (64 * G);
+    const int o = head_unit(ob, l & 15), lq = l >> 4;
+    const float* wr = a.w1 + (int64_t)o * a.I;
+    u32x4 v;
+    if constexpr (BF16) {
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * g + 8 * lq + j;
+        w[j] = (o < a.H && k < a.I) ? wr[k] : 0.f;
+      }
+      v = u32x4{pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3]), pack_bf16(w[4], w[5]), pack_bf16(w[6], w[7])};
+    } else {
+      float w[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 16 * g + 4 * lq + s4;
+        w[s4] = (o < a.H && k < a.I) ? wr[k] : 0.f;
+      }
+      v = u32x4{__builtin_bit_cast(unsigned, w[0]), __builtin_bit_cast(unsigned, w[1]), __builtin_bit_cast(unsigned, w[2]),
+                __builtin_bit_cast(unsigned, w[3])};
+    }
+    s_w[idx] = v;
+  }
+  for (int o = threadIdx.x; o < kHeadH; o += kFwdThreads) s_b1[o] = o < a.H ? a.b1[o] : 0.f;
+  for (int idx = threadIdx.x; idx < kHeadMaxOut * kHeadH; idx += kFwdThreads) {
+    const int q = idx / kHeadH, o = idx % kHeadH;
+    float w = (q < a.O2 && o < a.H) ? a.w2[(int64_t)q * a.H + o] : 0.f;
+    if (BF16) w = bf16_round(w);
+    s_w2[idx] = w;
+  }
+}
+
+// bias + ReLU, the stash, fc2: the lane holds 32 hidden units of row `row` (hv[p][e] = unit 32 p + 8 lq + e).
+template <bool BF16>
+__device__ __forceinline__ void head_epilogue(const Mlp1Args& a, const f32x4 (&acc)[8], const float* s_b1, const float* s_w2,
+                                              const float (&b2r)[kHeadMaxOut], int64_t row, int lq) {
+  float hv[4][8];
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = ob >> 1, e = 4 * (ob & 1) + r;
+      float v = fmaxf(acc[ob][r] + s_b1[32 * p + 8 * lq + e], 0.f);
+      if (BF16) v = bf16_round(v);           // fc2 and the backward see the stashed value
+      hv[p][e] = v;
+    }
+  const bool row_ok = row < a.N;
+  if (a.h && row_ok) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if constexpr (BF16) {
+        u32x4 v = {pack_bf16(hv[p][0], hv[p][1]), pack_bf16(hv[p][2], hv[p][3]), pack_bf16(hv[p][4], hv[p][5]),
+                   pack_bf16(hv[p][6], hv[p][7])};
+        *reinterpret_cast<u32x4*>(static_cast<unsigned short*>(a.h) + row * kHeadH + 32 * p + 8 * lq) = v;
+      } else {
+        float* dst = static_cast<float*>(a.h) + row * kHeadH + 32 * p + 8 * lq;
+        *reinterpret_cast<float4*>(dst) = make_float4(hv[p][0], hv[p][1], hv[p][2], hv[p][3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(hv[p][4], hv[p][5], hv[p][6], hv[p][7]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kHeadMaxOut; ++q) {
+    if (q >= a.O2) break;
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(hv[p][e], s_w2[q * kHeadH + 32 * p + 8 * lq + e], s);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (lq == 0 && row_ok) a.out[row * a.ldo + q] = s + b2r[q];
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_f32_kernel(const Mlp1Args a) {
+  extern __shared__ u32x4 s_raw[];
+  u32x4* s_w = s_raw;
+  float* s_b1 = reinterpret_cast<float*>(s_raw + 8 * G * kWave);
+  float* s_w2 = s_b1 + kHeadH;
+  head_fill_lds<false, G>(a, s_w, s_b1, s_w2);
+  __syncthreads();
+  float b2r[kHeadMaxOut];       // a global load in the epilogue would sit behind the stash stores (one in-order vmcnt)
+#pragma unroll
+  for (int q = 0; q < kHeadMaxOut; ++q) b2r[q] = q < a.O2 ? a.b2[q] : 0.f;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  const int64_t n_waves = (int64_t)gridDim.x * (kFwdThreads / kWave), wave = (int64_t)blockIdx.x * (kFwdThreads / kWave) + wid;
+  const int ipad = (a.I + 3) / 4 * 4;          // the row's allocated width: ldx >= ipad (host checked)
+  // lane (row lr, quarter lq) loads the float4 x[row][16 g + 4 lq .. + 3] once per 16-column group and feeds its four
+  // components to four consecutive k-steps (the W image is built in the same k order).  Loads are UNCONDITIONAL (row and
+  // column clamped into the matrix) and whatever must be zero is zeroed where the value is consumed: a fix-up at the load
+  // makes the compiler wait for the load right there (one memory round trip per load instead of one per tile), and a fix-up
+  // that ends up behind the epilogue's stores waits for those too (vmcnt is one in-order counter).
+  auto load_tile = [&](int64_t t, float4 (&xv)[G]) {
+    const int64_t row = min(t * 16 + lr, a.N - 1);
+    const float* xr = a.x + row * a.ldx;
+#pragma unroll
+    for (int g = 0; g < G; ++g) xv[g] = *reinterpret_cast<const float4*>(xr + min(16 * g + 4 * lq, ipad - 4));
+  };
+  auto fix_tile = [&](float4 (&xv)[G]) {      // pad columns may hold anything: they must not reach the MFMA
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (16 * g + 16 <= a.I) continue;        // uniform: only the boundary groups pay
+      const int k0 = 16 * g + 4 * lq;
+      if (k0 + 0 >= a.I) xv[g].x = 0.f;
+      if (k0 + 1 >= a.I) xv[g].y = 0.f;
+      if (k0 + 2 >= a.I) xv[g].z = 0.f;
+      if (k0 + 3 >= a.I) xv[g].w = 0.f;
+    }
+  };
+  float4 xc[G], xn[G];
+  load_tile(wave, xc);
+  fix_tile(xc);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    load_tile(t + n_waves, xn);                // the next tile's operands are in flight while this one multiplies
+    __builtin_amdgcn_sched_barrier(0);         // ... which they are only if the loads are ISSUED here: left alone, the compiler
+                                               // loads xn into xc's registers after xc's last use (the copy below coalesces)
+    f32x4 acc[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      f32x4 wf[8];
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) wf[ob] = __builtin_bit_cast(f32x4, s_w[(ob * G + g) * kWave + lane]);
+      const float comp[4] = {xc[g].x, xc[g].y, xc[g].z, xc[g].w};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ob][s4], comp[s4], acc[ob], 0, 0, 0);
+      // keep the fragment reads of later groups behind this group's MFMAs: hoisted to the top, the 88 ds_read_b128 of a tile
+      // need 352 registers and spill
+      if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // the next tile's values are taken over BEFORE this tile's stores are issued (see load_tile), but behind the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) xc[g] = xn[g];
+    fix_tile(xc);
+    __builtin_amdgcn_sched_barrier(0);
+    head_epilogue<false>(a, acc, s_b1, s_w2, b2r, t * 16 + lr, lq);
+  }
+}
+
+// bf16 matrix cores: G2 = 32-column groups; lane (row lr, quarter lq) loads x[row][32 g + 8 lq .. + 7] (two float4) and
+// rounds the eight values to one B fragment.
+template <int G2>
+__global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_bf16_kernel(const Mlp1Args a) {
+  extern __shared__ u32x4 s_raw[];
+  u32x4* s_w = s_raw;
+  float* s_b1 = reinterpret_cast<float*>(s_raw + 8 * G2 * kWave);
+  float* s_w2 = s_b1 + kHeadH;
+  head_fill_lds<true, G2>(a, s_w, s_b1, s_w2);
+  __syncthreads();
+  float b2r[kHeadMaxOut];       // a global load in the epilogue would sit behind the stash stores (one in-order vmcnt)
+#pragma unroll
+  for (int q = 0; q < kHeadMaxOut; ++q) b2r[q] = q < a.O2 ? a.b2[q] : 0.f;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  const int64_t n_waves = (int64_t)gridDim.x * (kFwdThreads / kWave), wave = (int64_t)blockIdx.x * (kFwdThreads / kWave) + wid;
+  const int ipad = (a.I + 3) / 4 * 4;
+  auto load_tile = [&](int64_t t, float4 (&xv)[2 * G2]) {      // unconditional, clamped: see mlp1_fwd_f32_kernel
+    const int64_t row = min(t * 16 + lr, a.N - 1);
+    const float* xr = a.x + row * a.ldx;
+#pragma unroll
+    for (int c = 0; c < 2 * G2; ++c) xv[c] = *reinterpret_cast<const float4*>(xr + min(32 * (c >> 1) + 8 * lq + 4 * (c & 1), ipad - 4));
+  };
+  auto to_frag = [&](const float4 (&xv)[2 * G2], int g) {
+    float4 p = xv[2 * g], q = xv[2 * g + 1];
+    const int k0 = 32 * g + 8 * lq;
+    if (32 * g + 32 > a.I) {                   // uniform: the boundary group; pad columns must not reach the MFMA
+      if (k0 + 0 >= a.I) p.x = 0.f;
+      if (k0 + 1 >= a.I) p.y = 0.f;
+      if (k0 + 2 >= a.I) p.z = 0.f;
+      if (k0 + 3 >= a.I) p.w = 0.f;
+      if (k0 + 4 >= a.I) q.x = 0.f;
+      if (k0 + 5 >= a.I) q.y = 0.f;
+      if (k0 + 6 >= a.I) q.z = 0.f;
+      if (k0 + 7 >= a.I) q.w = 0.f;
+    }
+    const u32x4 v = {pack_bf16(p.x, p.y), pack_bf16(p.z, p.w), pack_bf16(q.x, q.y), pack_bf16(q.z, q.w)};
+    return v;
+  };
+  float4 xr0[2 * G2];
+  u32x4 xc[G2];                                // the current tile as ready B fragments (half the registers of the fp32 values)
+  load_tile(wave, xr0);
+#pragma unroll
+  for (int g = 0; g < G2; ++g) xc[g] = to_frag(xr0, g);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    float4 xn[2 * G2];
+    load_tile(t + n_waves, xn);
+    __builtin_amdgcn_sched_barrier(0);         // issue the prefetch HERE (see mlp1_fwd_f32_kernel)
+    f32x4 acc[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, xc[g]);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s_w[(ob * G2 + g) * kWave + lane]), xf, acc[ob], 0, 0, 0);
+      if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // take the next tile over (wait for its loads, round) BEFORE this tile's stores are issued, but behind the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G2; ++g) xc[g] = to_frag(xn, g);
+    __builtin_amdgcn_sched_barrier(0);
+    head_epilogue<true>(a, acc, s_b1, s_w2, b2r, t * 16 + lr, lq);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// gW1[128, I + 1] = gh^T [x | 1] (column I = gb1) and gW2[O2, 128 + 1] = gout^T [h | 1] summed over the rows: K = the rows.
+// The 128 x 176 fp32 result does not fit one wave's registers, so the four waves of a workgroup split the x COLUMNS: wave w
+// owns the float4 chunks [cpw w, cpw (w + 1)) of a row (cpw = chunks per wave, <= 11: 44 columns) and all 128 hidden units
+// (32 accumulator tiles); every wave reads the whole stash row (it is the smaller operand and comes from L1 / L2 after the
+// first wave), its own slice of x, and forms gh in registers.  Tile column n of B fragment s stands for x column
+// 4 (cpw w + n) + s, tile row m of A fragment t for hidden unit 8 m + t (bf16) / 64 p + 4 m + s (fp32): all global loads
+// are 16 bytes per lane.  Workgroups take row slabs round-robin; per-workgroup partial sums, fixed-order second stage.
+//
+// Partial layout per workgroup: [128][ci] (gW1 | gb1, ci = I + 1) then [O2][129] (gW2 | gb2).
+__host__ __device__ inline int64_t mlp1_partial_floats(int I, int O2) { return (int64_t)kHeadH * (I + 1) + (int64_t)O2 * (kHeadH + 1); }
+
+template <int O2T>   // 1, or 4 (covers 2..4: absent outputs carry zeros)
+__global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_bf16_kernel(const Mlp1Args a, int cpw) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ipad = (a.I + 3) / 4 * 4;
+  const int col0 = 4 * (cpw * wid + lr);                 // this lane's x columns col0 .. col0 + 3
+  const bool xlane = lr < cpw && col0 <= a.I;            // column I is the ones column (bias gradient)
+  float w2r[O2T][8];                                     // fc2 weights of this lane's hidden units 8 lr + t, rounded to bf16
+#pragma unroll
+  for (int q = 0; q < O2T; ++q)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int o = 8 * lr + t;
+      w2r[q][t] = (q < a.O2 && o < a.H) ? bf16_round(a.w2[(int64_t)q * a.H + o]) : 0.f;
+    }
+  f32x4 acc[8][4], acc2[2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[t][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gb2 = 0.f;
+
+  struct Slab { float4 xv[8]; u32x4 hv[8]; float gv[8][O2T]; };
+  const int64_t n_slabs = ceil_div(a.N, 32);
+  const unsigned short* hb = static_cast<const unsigned short*>(a.h);
+  const int colc = min(col0, ipad - 4);                  // lanes without columns of their own re-read the last chunk (dropped below)
+  // this lane's x components: a column < I is the loaded value, column I is the ones column, anything else is zero
+  const bool x_raw[4] = {col0 + 0 < a.I, col0 + 1 < a.I, col0 + 2 < a.I, col0 + 3 < a.I};
+  const float x_fill[4] = {xlane && col0 + 0 == a.I ? 1.f : 0.f, xlane && col0 + 1 == a.I ? 1.f : 0.f,
+                           xlane && col0 + 2 == a.I ? 1.f : 0.f, xlane && col0 + 3 == a.I ? 1.f : 0.f};
+  // Loads are UNCONDITIONAL (rows clamped into the matrix) and fixed up where they are consumed: a fix-up at the load (the
+  // ones column, zeros for rows beyond N) makes the compiler wait for that load on the spot -- one memory round trip per
+  // load instead of one per slab.  A clamped row contributes nothing: its gout is taken as zero below.
+  auto load_slab = [&](int64_t s, Slab& d) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t row = min(s * 32 + 8 * lq + j, a.N - 1);
+      d.xv[j] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + colc);
+      d.hv[j] = *reinterpret_cast<const u32x4*>(hb + row * kHeadH + 8 * lr);
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) d.gv[j][q] = a.gout[row * a.ldg + min(q, a.O2 - 1)];
+    }
+  };
+  Slab cur, nxt;
+  load_slab(blockIdx.x, cur);
+  for (int64_t s = blockIdx.x; s < n_slabs; s += gridDim.x) {
+    load_slab(s + gridDim.x, nxt);
+    __builtin_amdgcn_sched_barrier(0);         // the prefetch is issued HERE: left alone, the compiler folds nxt into cur's registers
+                                               // (the copy at the end coalesces) and loads each value just before its use
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = s * 32 + 8 * lq + j < a.N;
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) cur.gv[j][q] = (ok && q < a.O2) ? cur.gv[j][q] : 0.f;
+      cur.xv[j].x = x_raw[0] ? cur.xv[j].x : x_fill[0];
+      cur.xv[j].y = x_raw[1] ? cur.xv[j].y : x_fill[1];
+      cur.xv[j].z = x_raw[2] ? cur.xv[j].z : x_fill[2];
+      cur.xv[j].w = x_raw[3] ? cur.xv[j].w : x_fill[3];
+    }
+    // B fragments: x, four tile-column sets (s4): element j = row 8 lq + j
+    bf16x8 bx[4];
+    {
+      u32x4 v0, v1, v2, v3;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        v0[d] = pack_bf16(cur.xv[2 * d].x, cur.xv[2 * d + 1].x);
+        v1[d] = pack_bf16(cur.xv[2 * d].y, cur.xv[2 * d + 1].y);
+        v2[d] = pack_bf16(cur.xv[2 * d].z, cur.xv[2 * d + 1].z);
+        v3[d] = pack_bf16(cur.xv[2 * d].w, cur.xv[2 * d + 1].w);
+      }
+      bx[0] = __builtin_bit_cast(bf16x8, v0); bx[1] = __builtin_bit_cast(bf16x8, v1);
+      bx[2] = __builtin_bit_cast(bf16x8, v2); bx[3] = __builtin_bit_cast(bf16x8, v3);
+    }
+    // per-row scalars: bf16-rounded gout (the data-gradient GEMM's operand)
+    float gr[8][O2T];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) gr[j][q] = bf16_round(cur.gv[j][q]);
+    // gW2 / gb2: this wave's two A fragments of the un-gated stash (t = 2 wid, 2 wid + 1) against gout as B ([row][q = lr])
+    {
+      float gq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < O2T; ++q) v = lr == q ? cur.gv[j][q] : v;
+        gq[j] = v;
+        if (wid == 0) gb2 += v;
+      }
+      const u32x4 gb = {pack_bf16(gq[0], gq[1]), pack_bf16(gq[2], gq[3]), pack_bf16(gq[4], gq[5]), pack_bf16(gq[6], gq[7])};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int t = 2 * wid + k, c = t >> 1;
+        u32x4 av;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          av[d] = (t & 1) ? __builtin_amdgcn_perm(cur.hv[2 * d + 1][c], cur.hv[2 * d][c], 0x07060302u)
+                          : __builtin_amdgcn_perm(cur.hv[2 * d + 1][c], cur.hv[2 * d][c], 0x05040100u);
+        acc2[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, gb), acc2[k], 0, 0, 0);
+      }
+    }
+    // gW1 | gb1: A fragment t = the gated hidden gradient of units 8 lr + t, element j = row 8 lq + j
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = t >> 1;
+      u32x4 av;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float g2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int j = 2 * d + k;
+          const unsigned hw = cur.hv[j][c];
+          const float hval = (t & 1) ? bf16_hi(hw) : bf16_lo(hw);
+          float gs = 0.f;
+#pragma unroll
+          for (int q = 0; q < O2T; ++q) gs = fmaf(gr[j][q], w2r[q][t], gs);
+          g2[k] = hval > 0.f ? gs : 0.f;
+        }
+        av[d] = pack_bf16(g2[0], g2[1]);
+      }
+      const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[t][s4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bx[s4], acc[t][s4], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);         // ... and taken over HERE, not where cur's registers first fall free
+    cur = nxt;
+  }
+  // partial sums of this workgroup: D[m = 4 lq + r][n = lr] of (t, s4) is gW1[8 m + t][4 (cpw wid + lr) + s4]
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * mlp1_partial_floats(a.I, a.O2);
+  const int ci = a.I + 1;
+  if (lr < cpw) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int col = col0 + s4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 8 * (4 * lq + r) + t;
+          if (col < ci) dst[(int64_t)o * ci + col] = acc[t][s4][r];
+        }
+      }
+  }
+  float* __restrict__ dst2 = dst + (int64_t)kHeadH * ci;
+  if (lr < a.O2) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst2[lr * (kHeadH + 1) + 8 * (4 * lq + r) + 2 * wid + k] = acc2[k][r];
+  }
+  if (wid == 0) {
+    gb2 += __shfl_xor(gb2, 16);
+    gb2 += __shfl_xor(gb2, 32);
+    if (lq == 0 && lr < a.O2) dst2[lr * (kHeadH + 1) + kHeadH] = gb2;
+  }
+}
+
+// fp32: K-steps of 4 rows (row = step base + lq), KU steps per iteration with the next iteration's operands in flight.
+// A fragment (p, s): tile row m <-> hidden unit 64 p + 4 m + s (float4 loads of the stash); B fragment s: tile column n <->
+// x column 4 (cpw wid + n) + s.
+template <int O2T, int KU>
+__global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_f32_kernel(const Mlp1Args a, int cpw) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ipad = (a.I + 3) / 4 * 4;
+  const int col0 = 4 * (cpw * wid + lr);
+  const bool xlane = lr < cpw && col0 <= a.I;
+  float w2r[O2T][2][4];
+#pragma unroll
+  for (int q = 0; q < O2T; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int o = 64 * p + 4 * lr + s;
+        w2r[q][p][s] = (q < a.O2 && o < a.H) ? a.w2[(int64_t)q * a.H + o] : 0.f;
+      }
+  f32x4 acc[2][4][4], acc2[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[p][s][s4] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gb2 = 0.f;
+
+  struct Step { float4 xv, h0, h1; float gv[O2T]; };
+  const float* hf = static_cast<const float*>(a.h);
+  constexpr int kRows = 4 * KU;
+  const int64_t n_iters = ceil_div(a.N, (int64_t)kRows);
+  const int colc = min(col0, ipad - 4);
+  const bool x_raw[4] = {col0 + 0 < a.I, col0 + 1 < a.I, col0 + 2 < a.I, col0 + 3 < a.I};
+  const float x_fill[4] = {xlane && col0 + 0 == a.I ? 1.f : 0.f, xlane && col0 + 1 == a.I ? 1.f : 0.f,
+                           xlane && col0 + 2 == a.I ? 1.f : 0.f, xlane && col0 + 3 == a.I ? 1.f : 0.f};
+  auto load_iter = [&](int64_t it, Step (&d)[KU]) {     // unconditional, rows clamped: see mlp1_bwd_bf16_kernel
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int64_t row = min(it * kRows + 4 * u + lq, a.N - 1);
+      d[u].xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + colc);
+      d[u].h0 = *reinterpret_cast<const float4*>(hf + row * kHeadH + 4 * lr);
+      d[u].h1 = *reinterpret_cast<const float4*>(hf + row * kHeadH + 64 + 4 * lr);
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) d[u].gv[q] = a.gout[row * a.ldg + min(q, a.O2 - 1)];
+    }
+  };
+  Step cur[KU], nxt[KU];
+  load_iter(blockIdx.x, cur);
+  for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+    load_iter(it + gridDim.x, nxt);
+    __builtin_amdgcn_sched_barrier(0);         // issue the prefetch HERE (see mlp1_bwd_bf16_kernel)
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const bool ok = it * kRows + 4 * u + lq < a.N;
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) cur[u].gv[q] = (ok && q < a.O2) ? cur[u].gv[q] : 0.f;
+      const float xb[4] = {x_raw[0] ? cur[u].xv.x : x_fill[0], x_raw[1] ? cur[u].xv.y : x_fill[1],
+                           x_raw[2] ? cur[u].xv.z : x_fill[2], x_raw[3] ? cur[u].xv.w : x_fill[3]};
+      const float hv[2][4] = {{cur[u].h0.x, cur[u].h0.y, cur[u].h0.z, cur[u].h0.w}, {cur[u].h1.x, cur[u].h1.y, cur[u].h1.z, cur[u].h1.w}};
+      // gW2 / gb2: this wave's two un-gated stash fragments against gout ([row = lq][q = lr])
+      float gq = 0.f;
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) gq = lr == q ? cur[u].gv[q] : gq;
+      if (wid == 0) gb2 += gq;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int f = 2 * wid + k;               // fragment (p, s) = (f >> 2, f & 3)
+        float hsel = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) hsel = (4 * p + s == f) ? hv[p][s] : hsel;
+        acc2[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(hsel, gq, acc2[k], 0, 0, 0);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float gs = 0.f;
+#pragma unroll
+          for (int q = 0; q < O2T; ++q) gs = fmaf(cur[u].gv[q], w2r[q][p][s], gs);
+          const float gh = hv[p][s] > 0.f ? gs : 0.f;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc[p][s][s4] = __builtin_amdgcn_mfma_f32_16x16x4f32(gh, xb[s4], acc[p][s][s4], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);         // take the prefetch over HERE, not where cur's registers first fall free
+#pragma unroll
+    for (int u = 0; u < KU; ++u) cur[u] = nxt[u];
+  }
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * mlp1_partial_floats(a.I, a.O2);
+  const int ci = a.I + 1;
+  if (lr < cpw) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int col = col0 + s4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = 64 * p + 4 * (4 * lq + r) + s;
+            if (col < ci) dst[(int64_t)o * ci + col] = acc[p][s][s4][r];
+          }
+        }
+  }
+  float* __restrict__ dst2 = dst + (int64_t)kHeadH * ci;
+  if (lr < a.O2) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int f = 2 * wid + k;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst2[lr * (kHeadH + 1) + 64 * (f >> 2) + 4 * (4 * lq + r) + (f & 3)] = acc2[k][r];
+    }
+  }
+  if (wid == 0) {
+    gb2 += __shfl_xor(gb2, 16);
+    gb2 += __shfl_xor(gb2, 32);
+    if (lq == 0 && lr < a.O2) dst2[lr * (kHeadH + 1) + kHeadH] = gb2;
+  }
+}
+
+// Second stage: element e of the partial layout summed over the G workgroups in a fixed order (32 slices of the G range per
+// element, slice sums added in slice order), then filed into gW1 [H,I] / gb1 [H] / gW2 [O2,H] / gb2 [O2].
+constexpr int kHeadReducePairs = 8, kHeadReduceSlices = 256 / kHeadReducePairs;
+__global__ __launch_bounds__(256) void mlp1_bwd_reduce_kernel(const float* __restrict__ partial, int G, int I, int H, int O2,
+                                                              float* __restrict__ gw1, float* __restrict__ gb1,
+                                                              float* __restrict__ gw2, float* __restrict__ gb2) {
+  __shared__ float s[kHeadReduceSlices][kHeadReducePairs + 1];
+  const int64_t total = mlp1_partial_floats(I, O2);
+  const int pl = threadIdx.x % kHeadReducePairs, sl = threadIdx.x / kHeadReducePairs;
+  const int64_t e = (int64_t)blockIdx.x * kHeadReducePairs + pl;
+  float t = 0.f;
+  if (e < total) {
+    const int per = (G + kHeadReduceSlices - 1) / kHeadReduceSlices;
+    const int g1 = min(G, (sl + 1) * per);
+    for (int g = sl * per; g < g1; ++g) t += partial[(int64_t)g * total + e];
+  }
+  s[sl][pl] = t;
+  __syncthreads();
+  if (sl != 0 || e >= total) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < kHeadReduceSlices; ++k) tot += s[k][pl];
+  const int ci = I + 1;
+  const int64_t n1 = (int64_t)kHeadH * ci;
+  if (e < n1) {
+    const int o = (int)(e / ci), c = (int)(e % ci);
+    if (o < H) {
+      if (c < I) gw1[(int64_t)o * I + c] = tot;
+      else gb1[o] = tot;
+    }
+  } else {
+    const int64_t f = e - n1;
+    const int q = (int)(f / (kHeadH + 1)), o = (int)(f % (kHeadH + 1));
+    if (o < H) gw2[(int64_t)q * H + o] = tot;
+    else if (o == kHeadH) gb2[q] = tot;
+  }
+}
+
+template <typename K>
+static int head_resident_workgroups(K kernel, int threads, size_t lds) {
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return per_cu * cus;
+}
+
+constexpr int kHeadMaxBwdBlocks = 512;    // partial-sum slots of the backward workspace
+
+template <bool BF16, int G>
+static int launch_head_fwd(const Mlp1Args& a, hipStream_t s) {
+  const size_t lds = (size_t)8 * G * kWave * sizeof(u32x4) + (kHeadH + kHeadMaxOut * kHeadH) * sizeof(float);
+  void (*kernel)(Mlp1Args);
+  if constexpr (BF16) kernel = mlp1_fwd_bf16_kernel<G>; else kernel = mlp1_fwd_f32_kernel<G>;
+  static const int once = [&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
+  }();
+  if (!once) return MLQEM_ERR_LAUNCH;
+  static const int res = head_resident_workgroups(kernel, kFwdThreads, lds);
+  const int64_t tiles = ceil_div(a.N, 16);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(res, ceil_div(tiles, kFwdThreads / kWave)));
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kFwdThreads), lds, s, a);
+  return launch_status();
+}
+
+}  // namespace mlqem
+
+using namespace mlqem;
+
+static bool head_shapes_ok(int64_t N, int I, int H, int O2) {
+  return N >= 0 && I >= 1 && I <= MLQEM_MLP1_MAX_IN && H >= 1 && H <= kHeadH && O2 >= 1 && O2 <= kHeadMaxOut;
+}
+
+extern "C" size_t mlqem_mlp1_workspace_bytes(int I, int O2) {
+  if (I < 1 || O2 < 1 || O2 > kHeadMaxOut) return 0;
+  return (size_t)kHeadMaxBwdBlocks * (size_t)mlp1_partial_floats(I, O2) * sizeof(float);
+}
+
+extern "C" int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2,
+                                  const float* b2, void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2,
+                                  int bf16, mlqem_stream_t stream) {
+  begin_launches();
+  if (!head_shapes_ok(N, I, H, O2)) return (I > MLQEM_MLP1_MAX_IN || H > kHeadH || O2 > kHeadMaxOut) ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
+  if (ldx < (I + 3) / 4 * 4 || ldx % 4 || ldo < O2) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !w1 || !b1 || !w2 || !b2 || !out || !aligned_to(x, 16) || (h_stash && !aligned_to(h_stash, 16))) return MLQEM_ERR_BAD_ARG;
+  Mlp1Args a{x, ldx, N, I, H, O2, w1, b1, w2, b2, h_stash, out, ldo, nullptr, 0, nullptr};
+  hipStream_t s = as_stream(stream);
+  if (bf16) {
+    const int g2 = (I + 31) / 32;
+    if (g2 <= 2) return launch_head_fwd<true, 2>(a, s);
+    if (g2 <= 4) return launch_head_fwd<true, 4>(a, s);
+    return launch_head_fwd<true, 6>(a, s);
+  }
+  const int g = (I + 15) / 16;
+  if (g <= 4) return launch_head_fwd<false, 4>(a, s);
+  if (g <= 8) return launch_head_fwd<false, 8>(a, s);
+  return launch_head_fwd<false, 11>(a, s);
+}
+
+extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t ldx, const void* h_stash,
+                                   const float* w2, float* gw1, float* gb1, float* gw2, float* gb2, int64_t N, int I, int H,
+                                   int O2, int bf16, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (!head_shapes_ok(N, I, H, O2)) return (I > MLQEM_MLP1_MAX_IN || H > kHeadH || O2 > kHeadMaxOut) ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
+  if (ldx < (I + 3) / 4 * 4 || ldx % 4 || ldg < O2 || !gw1 || !gb1 || !gw2 || !gb2) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_mlp1_workspace_bytes(I, O2)) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && (!gout || !x || !h_stash || !w2 || !aligned_to(x, 16) || !aligned_to(h_stash, 16))) return MLQEM_ERR_BAD_ARG;
+  Mlp1Args a{x, ldx, N, I, H, O2, nullptr, nullptr, w2, nullptr, const_cast<void*>(h_stash), nullptr, 0, gout, ldg,
+             static_cast<float*>(workspace)};
+  hipStream_t s = as_stream(stream);
+  const int chunks = (I + 1 + 3) / 4;             // float4 chunks of [x | 1]
+  const int cpw = (chunks + 3) / 4;               // per wave: <= 11 for I <= 175
+  int G;
+  if (N == 0) {
+    G = 0;                                        // nothing to sum: the second stage writes zeros
+  } else if (bf16) {
+    static const int res1 = head_resident_workgroups(mlp1_bwd_bf16_kernel<1>, kBwdThreads, 0);
+    static const int res4 = head_resident_workgroups(mlp1_bwd_bf16_kernel<4>, kBwdThreads, 0);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(O2 == 1 ? res1 : res4, kHeadMaxBwdBlocks), ceil_div(std::max<int64_t>(N, 1), 32)));
+    if (O2 == 1) hipLaunchKernelGGL(mlp1_bwd_bf16_kernel<1>, dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
+    else hipLaunchKernelGGL(mlp1_bwd_bf16_kernel<4>, dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
+  } else {
+    constexpr int KU = 4;
+    static const int res1 = head_resident_workgroups(mlp1_bwd_f32_kernel<1, KU>, kBwdThreads, 0);
+    static const int res4 = head_resident_workgroups(mlp1_bwd_f32_kernel<4, KU>, kBwdThreads, 0);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(O2 == 1 ? res1 : res4, kHeadMaxBwdBlocks), ceil_div(std::max<int64_t>(N, 1), 4 * KU)));
+    if (O2 == 1) hipLaunchKernelGGL((mlp1_bwd_f32_kernel<1, KU>), dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
+    else hipLaunchKernelGGL((mlp1_bwd_f32_kernel<4, KU>), dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
+  }
+  const int64_t total = mlp1_partial_floats(I, O2);
+  hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(total, kHeadReducePairs)), dim3(256), 0, s, a.partial, G, I, H, O2,
+                     gw1, gb1, gw2, gb2);
+  return launch_status();
+}
