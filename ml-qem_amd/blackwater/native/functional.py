@@ -523,17 +523,36 @@ _ASAP_LAZY = os.environ.get("MLQEM_ASAP_LAZY", "1") != "0"
 
 # Graph boundaries of pooled batches on the device, by content.  Batches of a training run repeat their size patterns (the
 # size-stratified batches of train.StratifiedBatches always do), and inside a hipGraph capture a host->device copy from
-# pageable memory is not allowed: the warm-up iterations that precede a capture leave the array here.
-_ptr_cache = {}
+# pageable memory is not allowed: the eager pass that precedes a capture (train.BucketedTrainer runs a pattern eagerly the
+# first time it sees it) leaves the array here.  Two tiers: an LRU of what eager calls made, and the arrays a CAPTURED graph
+# reads -- their addresses are baked into the graph, so they are owned here for good and never evicted (evicting them handed
+# their memory back to the allocator while replays still read it as graph boundaries).
+from collections import OrderedDict
+
+_ptr_cache = OrderedDict()
+_ptr_pinned = {}
+_PTR_CACHE_MAX = 256
 
 
 def _device_ptr(host_i32, device):
     key = (host_i32.tobytes(), str(device))
+    t = _ptr_pinned.get(key)
+    if t is not None:
+        return t
+    capturing = torch.cuda.is_current_stream_capturing()
     t = _ptr_cache.get(key)
+    if capturing:
+        if t is None:
+            raise RuntimeError("pooled graph boundaries of this size pattern are not on the device yet: run the batch eagerly once "
+                               "before capturing it (a host->device copy cannot be part of a hipGraph capture)")
+        _ptr_pinned[key] = _ptr_cache.pop(key)
+        return t
     if t is None:
-        if len(_ptr_cache) >= 256:
-            _ptr_cache.clear()
-        t = _ptr_cache[key] = torch.from_numpy(host_i32).to(device, non_blocking=not torch.cuda.is_current_stream_capturing())
+        while len(_ptr_cache) >= _PTR_CACHE_MAX:
+            _ptr_cache.popitem(last=False)
+        t = _ptr_cache[key] = torch.from_numpy(host_i32).to(device, non_blocking=True)
+    else:
+        _ptr_cache.move_to_end(key)
     return t
 
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import math
 import os
+import pickle
 from typing import Callable, Iterable, List, Optional
 
 import numpy as np
@@ -93,6 +94,8 @@ class Trainer:
         # in flight keep the device busy and the pool at its steady size.
         self.max_steps_in_flight = int(os.environ.get("MLQEM_MAX_STEPS_IN_FLIGHT", "4"))   # 0 = unbounded; 4 measured as fast as unbounded (129-131 k circuits/s either way)
         self._inflight = []
+        self._prescaled = False
+        self.history = {"train_losses": [], "val_losses": []}
         if self.distributed:
             self.broadcast_parameters()
 
@@ -163,18 +166,28 @@ class Trainer:
                     torch._foreach_copy_([d for d, _ in pairs], [g for _, g in pairs])
             else:
                 torch._foreach_copy_(self._grad_slots, grads)
+            if self.world > 1:
+                # the data-parallel mean: scale BEFORE the all-reduce, one kernel over the flat buffer that is part of the
+                # captured half of a replayed step (a div_ behind the collective was one more eager launch per step)
+                self.flat_grad.mul_(1.0 / self.world)
+                self._prescaled = True
             for p, slot in zip(self._params, self._grad_slots):
                 p.grad = slot                   # what callers (and the reference's loop shape) expect to find
         return loss.detach()
 
     def all_reduce_gradients(self):
+        """Averages the gradients over the ranks: ONE collective over the flat buffer.  The 1/world factor is applied where
+        the gradients are filed into the flat buffer (``_forward_backward``: inside the captured half of a replayed step), so
+        the collective is a plain SUM and nothing runs behind it but Adam."""
         if self.flat_grad is not None:
+            if not self._prescaled:       # gradients that did not come through _forward_backward (a caller's own backward)
+                self.flat_grad.mul_(1.0 / self.world)
             torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM)
-            self.flat_grad.div_(self.world)
+            self._prescaled = False
         else:
             for p in self.model.parameters():
+                p.grad.mul_(1.0 / self.world)
                 torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
-                p.grad.div_(self.world)
 
     @torch.no_grad()
     def evaluate(self, batches: Iterable) -> torch.Tensor:
@@ -200,6 +213,36 @@ class Trainer:
         self.model.train(was_training)
         return torch.cat(outs, dim=0)
 
+    def save(self, path: str, history: Optional[dict] = None) -> str:
+        """Writes what the reference's training cell writes (docs/tutorials/__ml_models.py:196-205): ``<path>.pth`` =
+        ``torch.save(model.state_dict())`` -- plain CPU tensors under the reference's parameter names, loadable with
+        ``strict=True`` by the reference's (and the oracle's) modules -- and ``<path>.pk`` = the pickled
+        ``{'train_losses': [...], 'val_losses': [...]}`` of the last ``fit`` (or ``history``).  ``path`` may end in ``.pth``.
+        Under data parallelism every rank holds the same parameters; rank 0 writes."""
+        stem = path[:-4] if path.endswith(".pth") else path
+        if self.distributed and torch.distributed.get_rank() != 0:
+            return stem + ".pth"
+        state = {k: v.detach().to("cpu", copy=True).contiguous() for k, v in self.model.state_dict().items()}
+        os.makedirs(os.path.dirname(os.path.abspath(stem)), exist_ok=True)
+        torch.save(state, stem + ".pth")
+        hist = history if history is not None else self.history
+        to_save = {"train_losses": [float(v) for v in hist["train_losses"]], "val_losses": [float(v) for v in hist["val_losses"]]}
+        with open(stem + ".pk", "wb") as handle:
+            pickle.dump(to_save, handle, protocol=pickle.HIGHEST_PROTOCOL)
+        return stem + ".pth"
+
+    def load(self, path: str) -> dict:
+        """Restores ``save``'s files: parameters and buffers ``strict=True`` (into the flat buffer the optimizer steps), and
+        returns the loss curves (empty lists when there is no ``.pk`` next to the checkpoint)."""
+        stem = path[:-4] if path.endswith(".pth") else path
+        state = torch.load(stem + ".pth", map_location="cpu", weights_only=True)
+        missing = self.model.load_state_dict(state, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        if os.path.exists(stem + ".pk"):
+            with open(stem + ".pk", "rb") as handle:
+                self.history = pickle.load(handle)
+        return self.history
+
     def fit(self, arena, train_ids, val_ids, epochs: int, batch_size: int = 32, seed: int = 0, log: Callable = None):
         """Epoch loop with per-epoch shuffling (seed + epoch) and the reference's LR schedule.
 
@@ -207,7 +250,7 @@ class Trainer:
         the per-epoch step count is agreed once (min over ranks of this rank's batch count); a rank whose shard holds a
         few graphs more -- round-robin shards differ by one -- leaves its surplus out of that epoch (a different surplus
         each epoch, the permutation is reseeded)."""
-        history = {"train_losses": [], "val_losses": []}
+        history = self.history = {"train_losses": [], "val_losses": []}
         train_ids = np.asarray(train_ids)
         steps_per_epoch = self._agreed_min(-(-len(train_ids) // batch_size))
         for epoch in range(epochs):
@@ -321,6 +364,14 @@ class BucketedTrainer(Trainer):
         self._pool = None
         self._update_graph = None
         self._warm = False
+        # Models whose launch shapes follow every graph's size (Family B) replay a capture only for the same SEQUENCE of sizes.
+        # With a size-stable sampler (StratifiedBatches) that is one pattern; with uniformly shuffled batches almost every
+        # batch is a new one.  So such a pattern is run EAGERLY the first time it is seen (which also leaves its pooled graph
+        # boundaries on the device: native/functional._device_ptr) and captured only when it comes back, and at most
+        # ``max_pattern_captures`` patterns are ever captured (each holds a graph and a pinned ring): the rest stay eager.
+        self._pattern_model = bool(getattr(model, "needs_size_pattern", False))
+        self.max_pattern_captures = int(os.environ.get("MLQEM_MAX_PATTERN_CAPTURES", "64"))
+        self._seen = {}
 
     def bucket_of(self, graph_ids):
         sel = np.asarray(graph_ids, dtype=np.int64)
@@ -350,6 +401,10 @@ class BucketedTrainer(Trainer):
         dropout counter are restored afterwards."""
         dev = self.flat_param.device
         keep = (self.flat_param.detach().clone(), self.counter.clone(), torch.cuda.get_rng_state(dev))
+        # optimizer state (a checkpoint's, or what eager steps before the first capture left) and module buffers (BatchNorm
+        # running statistics of an MLP2/3 head) are saved and put back: the three warm-up steps must leave no trace
+        opt_keep = {id(st): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for st in self.optimizer.state.values()}
+        buf_keep = [b.detach().clone() for b in self.model.buffers()]
         sel, nptr, eptr, nb, eb, real = self.arena.selection(ids, bucket[:2])
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.flat_param.device)
         side = torch.cuda.Stream()
@@ -362,9 +417,15 @@ class BucketedTrainer(Trainer):
             self.flat_param.copy_(keep[0])
             self.counter.copy_(keep[1])
             for st in self.optimizer.state.values():
-                for v in st.values():
+                saved = opt_keep.get(id(st))
+                for k, v in st.items():
                     if torch.is_tensor(v):
-                        v.zero_()
+                        if saved is not None and torch.is_tensor(saved.get(k)):
+                            v.copy_(saved[k])
+                        else:
+                            v.zero_()           # state the warm-up created: Adam's zero initial state
+            for b, kept in zip(self.model.buffers(), buf_keep):
+                b.copy_(kept)
         torch.cuda.synchronize()
         torch.cuda.set_rng_state(keep[2], dev)
         self._warm = True
@@ -376,10 +437,17 @@ class BucketedTrainer(Trainer):
         sel, nptr, eptr, nb, eb, real = self.arena.selection(graph_ids, bucket[:2])
         host = np.concatenate([sel, nptr, eptr]).astype(np.int32)
         sizes = nptr[1:] - nptr[:-1]
-        if not self.graphs:
+        entry = self._entries.get(bucket) if self.graphs else None
+        eager = not self.graphs
+        if self.graphs and entry is None and self._pattern_model:
+            first_sight = bucket not in self._seen
+            if first_sight and len(self._seen) >= 4096:
+                self._seen.pop(next(iter(self._seen)))       # forget the oldest pattern: it gets its eager pass again
+            self._seen[bucket] = True
+            eager = first_sight or len(self._entries) >= self.max_pattern_captures
+        if eager:
             packed = torch.from_numpy(host).to(self.flat_param.device, non_blocking=True)
             return self._step_on(packed, len(sel), nb, eb, sizes, real)
-        entry = self._entries.get(bucket)
         if entry is None:
             if not self._warm:
                 self._warm_up(graph_ids, bucket)
@@ -411,6 +479,7 @@ class BucketedTrainer(Trainer):
         entry["graph"].replay()
         if self.split:
             if self.distributed:
+                self._prescaled = True      # the replayed half scaled the flat buffer by 1/world (its capture ran _forward_backward)
                 self.all_reduce_gradients()
             self._update_graph.replay()
         return entry["loss"]

@@ -1,7 +1,9 @@
 // BatchNorm1d in training mode over [N, C] activations (the bn1 / bn2 of MLP2 / MLP3, docs/tutorials/mlp.py:45-66,
 // 87-108), forward and backward.
 //
-//   forward:   mean_c = E[x_c], var_c = E[x_c^2] - mean_c^2 (biased), y = (x - mean) * rsqrt(var + eps) * gamma + beta
+//   forward:   mean_c = E[x_c], var_c = E[(x_c - s_c)^2] - (mean_c - s_c)^2 (biased; s_c = x[0, c], a shift that keeps the two
+//              terms at the size of the variance: E[x^2] - mean^2 on raw values cancels catastrophically for columns with
+//              |mean| >> std, where torch's Welford reduction does not), y = (x - mean) * rsqrt(var + eps) * gamma + beta
 //   backward:  dbeta = sum dy, dgamma = sum dy * xhat, dx = gamma * invstd * (dy - dbeta / N - xhat * dgamma / N)
 //
 // Two passes per direction: a column reduction (every workgroup takes a contiguous range of rows, lanes along the
@@ -18,7 +20,8 @@ constexpr int kBnRowLanes = kBlock / kBnLanes;    // 8 row lanes
 constexpr int kBnMaxChunks = 8;                   // C <= 256
 constexpr int kBnMaxBlocks = 2048;
 
-// MODE 0: s1 = sum x, s2 = sum x^2.   MODE 1: s1 = sum dy, s2 = sum dy * xhat, xhat = (x - mean) * invstd.
+// MODE 0: s1 = sum (x - s), s2 = sum (x - s)^2 with the per-column shift s = x[0, :].
+// MODE 1: s1 = sum dy, s2 = sum dy * xhat, xhat = (x - mean) * invstd.
 template <int MODE> __global__ __launch_bounds__(kBlock) void bn_column_sums_kernel(
     const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
     const float* __restrict__ invstd, int64_t N, int C, int64_t rows_per_block, float* __restrict__ partial) {
@@ -32,7 +35,7 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void bn_column_sums_ker
   for (int k = 0; k < kBnMaxChunks; ++k) {
     s1[k] = s2[k] = 0.f;
     const int c = k * kBnLanes + tx;
-    mu[k] = (MODE == 1 && k < chunks && c < C) ? mean[c] : 0.f;
+    mu[k] = (k < chunks && c < C) ? (MODE == 1 ? mean[c] : a[c]) : 0.f;     // MODE 0: the shift (row 0 of the matrix)
     is[k] = (MODE == 1 && k < chunks && c < C) ? invstd[c] : 0.f;
   }
   for (int64_t r = r0 + ty; r < r1; r += kBnRowLanes) {
@@ -42,8 +45,9 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void bn_column_sums_ker
       if (k < chunks && c < C) {
         const float v = a[r * lda + c];
         if (MODE == 0) {
-          s1[k] += v;
-          s2[k] = fmaf(v, v, s2[k]);
+          const float d = v - mu[k];
+          s1[k] += d;
+          s2[k] = fmaf(d, d, s2[k]);
         } else {
           s1[k] += v;
           s2[k] = fmaf(v, (x[r * ldx + c] - mu[k]) * is[k], s2[k]);
@@ -72,7 +76,7 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void bn_column_sums_ker
 // MODE 1: dbeta = s1, dgamma = s2, and the per-column constants of the backward's element-wise pass.
 template <int MODE> __global__ __launch_bounds__(kWave) void bn_finish_kernel(
     const float* __restrict__ partial, int nblocks, int64_t N, int C, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ invstd_in, float eps, float* __restrict__ o1,
+    const float* __restrict__ beta, const float* __restrict__ invstd_in /* MODE 0: the shift, row 0 of x */, float eps, float* __restrict__ o1,
     float* __restrict__ o2, float* __restrict__ o3, float* __restrict__ o4, float* __restrict__ o5) {
   __shared__ double s_t[2][kWave];
   const int c = blockIdx.x, j = threadIdx.x;
@@ -88,9 +92,10 @@ template <int MODE> __global__ __launch_bounds__(kWave) void bn_finish_kernel(
   t1 = t2 = 0.0;
   for (int k = 0; k < kWave; ++k) { t1 += s_t[0][k]; t2 += s_t[1][k]; }
   if (MODE == 0) {
-    const double m = t1 / (double)N;
-    double var = t2 / (double)N - m * m;
+    const double ms = t1 / (double)N;                   // mean of the shifted values
+    double var = t2 / (double)N - ms * ms;
     if (var < 0.0) var = 0.0;
+    const double m = (double)invstd_in[c] + ms;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = (gamma ? gamma[c] : 1.f) * is;
     o1[c] = (float)m;                         // mean
@@ -166,7 +171,7 @@ extern "C" int mlqem_batch_norm_train_f32(const float* x, int64_t ldx, int64_t N
   hipLaunchKernelGGL(bn_column_sums_kernel<0>, dim3((unsigned)nb), dim3(kBlock), 0, stream, x, ldx, (const float*)nullptr,
                      (int64_t)0, (const float*)nullptr, (const float*)nullptr, N, C, ceil_div(N, (int64_t)nb), partial);
   hipLaunchKernelGGL(bn_finish_kernel<0>, dim3((unsigned)C), dim3(kWave), 0, stream, partial, nb, N, C, gamma, beta,
-                     (const float*)nullptr, eps, mean, var, invstd, scale, shift);
+                     x /* the shift: row 0 */, eps, mean, var, invstd, scale, shift);
   hipLaunchKernelGGL(bn_affine_kernel, dim3((unsigned)ceil_div(N * C, (int64_t)kBlock)), dim3(kBlock), 0, stream, x, ldx,
                      scale, shift, N, C, y, ldy);
   return launch_status();

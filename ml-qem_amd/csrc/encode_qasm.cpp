@@ -123,7 +123,7 @@ std::vector<std::string> split_top(const std::string& s) {  // commas outside pa
     if (c == '(') ++depth; else if (c == ')') --depth;
     if (c == ',' && depth == 0) { out.push_back(trim(cur)); cur.clear(); } else cur.push_back(c);
   }
-  if (!trim(cur).empty()) out.push_back(trim(cur));
+  if (!trim(cur).empty() || !out.empty()) out.push_back(trim(cur));   // "a," has an (empty) second element: the callers reject it
   return out;
 }
 
@@ -274,6 +274,11 @@ extern "C" int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* pr
       const Op& op = c.ops[k];
       if (op.name != "barrier" && op.qubits.size() > 3) throw ParseError{"Non barrier gate that has more than 3 qubits.", true};
       if (op.params.size() > 3) throw ParseError{"more than 3 gate parameters", true};
+      // what the fill pass would refuse is refused by the size query too (a caller sizes its buffers, then fills them)
+      if (!type_slot.count(op.name)) throw ParseError{"gate '" + op.name + "' is not in the backend's gates_set", true};
+      if (use_qubit_features && op.name != "barrier")
+        for (int q : op.qubits)
+          if (c.reg_index[q] >= props->num_qubits) throw ParseError{"qubit index beyond the calibration table", true};
       int lvl = 0;
       for (int q : op.qubits) { if (last[q] >= 0) out[last[q]].push_back({(int)k, q}); last[q] = (int)k; lvl = std::max(lvl, level[q]); }
       for (int cb : op.clbits) { int w = c.nq + cb; if (last[w] >= 0) out[last[w]].push_back({(int)k, w}); last[w] = (int)k; lvl = std::max(lvl, level[w]); }

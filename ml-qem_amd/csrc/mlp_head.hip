@@ -29,6 +29,9 @@ constexpr int kHeadH = MLQEM_MLP1_HIDDEN_PAD;   // columns of the stash (hidden 
 constexpr int kHeadMaxOut = MLQEM_MLP1_MAX_OUT;
 constexpr int kFwdThreads = 256;                // the waves of a workgroup share one W1 image in LDS
 constexpr int kBwdThreads = 256;
+#ifndef MLQEM_HEAD_BWD_KU
+#define MLQEM_HEAD_BWD_KU 8    // k-steps (of 4 rows) per iteration of the fp32 backward: one iteration = the prefetch distance
+#endif
 
 struct Mlp1Args {
   const float* x; int64_t ldx; int64_t N; int I, H, O2;
@@ -283,8 +286,12 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_bf16_kernel(const Mlp1Ar
 // 4 (cpw w + n) + s, tile row m of A fragment t for hidden unit 8 m + t (bf16) / 64 p + 4 m + s (fp32): all global loads
 // are 16 bytes per lane.  Workgroups take row slabs round-robin; per-workgroup partial sums, fixed-order second stage.
 //
-// Partial layout per workgroup: [128][ci] (gW1 | gb1, ci = I + 1) then [O2][129] (gW2 | gb2).
-__host__ __device__ inline int64_t mlp1_partial_floats(int I, int O2) { return (int64_t)kHeadH * (I + 1) + (int64_t)O2 * (kHeadH + 1); }
+// Partial sums per workgroup in the LANES' OWN order -- [wave][tile][register][lane] for the 32 gW1 tiles of a wave, then
+// [wave][k][register][lane] for its two gW2 tiles, then gb2[4] -- so that every store instruction of the main kernel and
+// every load instruction of the second stage moves 256 contiguous bytes (an (o, column)-ordered layout is 64 scattered
+// dwords per instruction: 22 MB of 4-byte writes).  The second stage decodes an element's (o, column) from its position.
+constexpr int kHeadW1Floats = 4 * 32 * 4 * kWave, kHeadW2Floats = 4 * 2 * 4 * kWave;
+constexpr int kHeadPartialFloats = kHeadW1Floats + kHeadW2Floats + kHeadMaxOut;
 
 template <int O2T>   // 1, or 4 (covers 2..4: absent outputs carry zeros)
 __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_bf16_kernel(const Mlp1Args a, int cpw) {
@@ -416,33 +423,23 @@ __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_bf16_kernel(const Mlp1Ar
     __builtin_amdgcn_sched_barrier(0);         // ... and taken over HERE, not where cur's registers first fall free
     cur = nxt;
   }
-  // partial sums of this workgroup: D[m = 4 lq + r][n = lr] of (t, s4) is gW1[8 m + t][4 (cpw wid + lr) + s4]
-  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * mlp1_partial_floats(a.I, a.O2);
-  const int ci = a.I + 1;
-  if (lr < cpw) {
+  // partial sums of this workgroup (lane order): register r of tile (t, s4) is gW1[8 (4 lq + r) + t][4 (cpw wid + lr) + s4]
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + (wid * 32 * 4) * kWave + lane;
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+  for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int col = col0 + s4;
+    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = 8 * (4 * lq + r) + t;
-          if (col < ci) dst[(int64_t)o * ci + col] = acc[t][s4][r];
-        }
-      }
-  }
-  float* __restrict__ dst2 = dst + (int64_t)kHeadH * ci;
-  if (lr < a.O2) {
+      for (int r = 0; r < 4; ++r) dst[((t * 4 + s4) * 4 + r) * kWave] = acc[t][s4][r];
+  float* __restrict__ dst2 = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + kHeadW1Floats;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst2[lr * (kHeadH + 1) + 8 * (4 * lq + r) + 2 * wid + k] = acc2[k][r];
-  }
+    for (int r = 0; r < 4; ++r) dst2[((wid * 2 + k) * 4 + r) * kWave + lane] = acc2[k][r];   // gW2[q = lr][8 (4 lq + r) + 2 wid + k]
   if (wid == 0) {
     gb2 += __shfl_xor(gb2, 16);
     gb2 += __shfl_xor(gb2, 32);
-    if (lq == 0 && lr < a.O2) dst2[lr * (kHeadH + 1) + kHeadH] = gb2;
+    if (lq == 0 && lr < kHeadMaxOut) dst2[kHeadW2Floats + lr] = gb2;
   }
 }
 
@@ -539,75 +536,73 @@ __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_f32_kernel(const Mlp1Arg
 #pragma unroll
     for (int u = 0; u < KU; ++u) cur[u] = nxt[u];
   }
-  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * mlp1_partial_floats(a.I, a.O2);
-  const int ci = a.I + 1;
-  if (lr < cpw) {
+  // partial sums (lane order): register r of tile (p, s, s4) is gW1[64 p + 4 (4 lq + r) + s][4 (cpw wid + lr) + s4]
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + (wid * 32 * 4) * kWave + lane;
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int col = col0 + s4;
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int o = 64 * p + 4 * (4 * lq + r) + s;
-            if (col < ci) dst[(int64_t)o * ci + col] = acc[p][s][s4][r];
-          }
-        }
-  }
-  float* __restrict__ dst2 = dst + (int64_t)kHeadH * ci;
-  if (lr < a.O2) {
+        for (int r = 0; r < 4; ++r) dst[((((p * 4 + s) * 4) + s4) * 4 + r) * kWave] = acc[p][s][s4][r];
+  float* __restrict__ dst2 = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + kHeadW1Floats;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int f = 2 * wid + k;
+  for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst2[lr * (kHeadH + 1) + 64 * (f >> 2) + 4 * (4 * lq + r) + (f & 3)] = acc2[k][r];
-    }
-  }
+    for (int r = 0; r < 4; ++r) dst2[((wid * 2 + k) * 4 + r) * kWave + lane] = acc2[k][r];   // fragment f = 2 wid + k: gW2[q = lr][64 (f >> 2) + 4 (4 lq + r) + (f & 3)]
   if (wid == 0) {
     gb2 += __shfl_xor(gb2, 16);
     gb2 += __shfl_xor(gb2, 32);
-    if (lq == 0 && lr < a.O2) dst2[lr * (kHeadH + 1) + kHeadH] = gb2;
+    if (lq == 0 && lr < kHeadMaxOut) dst2[kHeadW2Floats + lr] = gb2;
   }
 }
 
-// Second stage: element e of the partial layout summed over the G workgroups in a fixed order (32 slices of the G range per
-// element, slice sums added in slice order), then filed into gW1 [H,I] / gb1 [H] / gW2 [O2,H] / gb2 [O2].
-constexpr int kHeadReducePairs = 8, kHeadReduceSlices = 256 / kHeadReducePairs;
+// Second stage: element e of the lane-ordered layout summed over the G workgroups in a fixed order (4 slices of the G range
+// per element, slice sums added in slice order), decoded to its (o, column) and filed into gW1 [H,I] / gb1 [H] / gW2 [O2,H] /
+// gb2 [O2].  64 consecutive elements per workgroup: every load instruction reads 256 contiguous bytes of one partial.
+constexpr int kHeadReduceSlices = 4;
 __global__ __launch_bounds__(256) void mlp1_bwd_reduce_kernel(const float* __restrict__ partial, int G, int I, int H, int O2,
-                                                              float* __restrict__ gw1, float* __restrict__ gb1,
+                                                              int cpw, int bf16, float* __restrict__ gw1, float* __restrict__ gb1,
                                                               float* __restrict__ gw2, float* __restrict__ gb2) {
-  __shared__ float s[kHeadReduceSlices][kHeadReducePairs + 1];
-  const int64_t total = mlp1_partial_floats(I, O2);
-  const int pl = threadIdx.x % kHeadReducePairs, sl = threadIdx.x / kHeadReducePairs;
-  const int64_t e = (int64_t)blockIdx.x * kHeadReducePairs + pl;
+  __shared__ float s[kHeadReduceSlices][kWave];
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * kWave + el;
+  // where the element goes (-1: a lane / row / column that stands for nothing)
+  int kind = -1, o = 0, c = 0;
+  if (e < kHeadW1Floats) {
+    const int lane = e & 63, r = (e >> 6) & 3, tile = (e >> 8) & 31, wid = e >> 13;
+    const int lr = lane & 15, lq = lane >> 4, s4 = tile & 3, ft = tile >> 2;     // ft: bf16 t, fp32 4 p + s
+    o = bf16 ? 8 * (4 * lq + r) + ft : 64 * (ft >> 2) + 4 * (4 * lq + r) + (ft & 3);
+    c = 4 * (cpw * wid + lr) + s4;
+    if (lr < cpw && c <= I && o < H) kind = c < I ? 0 : 1;
+  } else if (e < kHeadW1Floats + kHeadW2Floats) {
+    const int f = e - kHeadW1Floats;
+    const int lane = f & 63, r = (f >> 6) & 3, k = (f >> 8) & 1, wid = f >> 9;
+    const int lr = lane & 15, lq = lane >> 4, fr = 2 * wid + k;
+    o = bf16 ? 8 * (4 * lq + r) + fr : 64 * (fr >> 2) + 4 * (4 * lq + r) + (fr & 3);
+    c = lr;
+    if (c < O2 && o < H) kind = 2;
+  } else if (e < kHeadPartialFloats) {
+    c = e - kHeadW1Floats - kHeadW2Floats;
+    if (c < O2) kind = 3;
+  }
   float t = 0.f;
-  if (e < total) {
+  if (kind >= 0) {
     const int per = (G + kHeadReduceSlices - 1) / kHeadReduceSlices;
     const int g1 = min(G, (sl + 1) * per);
-    for (int g = sl * per; g < g1; ++g) t += partial[(int64_t)g * total + e];
+    for (int g = sl * per; g < g1; ++g) t += partial[(int64_t)g * kHeadPartialFloats + e];
   }
-  s[sl][pl] = t;
+  s[sl][el] = t;
   __syncthreads();
-  if (sl != 0 || e >= total) return;
+  if (sl != 0 || kind < 0) return;
   float tot = 0.f;
 #pragma unroll
-  for (int k = 0; k < kHeadReduceSlices; ++k) tot += s[k][pl];
-  const int ci = I + 1;
-  const int64_t n1 = (int64_t)kHeadH * ci;
-  if (e < n1) {
-    const int o = (int)(e / ci), c = (int)(e % ci);
-    if (o < H) {
-      if (c < I) gw1[(int64_t)o * I + c] = tot;
-      else gb1[o] = tot;
-    }
-  } else {
-    const int64_t f = e - n1;
-    const int q = (int)(f / (kHeadH + 1)), o = (int)(f % (kHeadH + 1));
-    if (o < H) gw2[(int64_t)q * H + o] = tot;
-    else if (o == kHeadH) gb2[q] = tot;
-  }
+  for (int k = 0; k < kHeadReduceSlices; ++k) tot += s[k][el];
+  if (kind == 0) gw1[(int64_t)o * I + c] = tot;
+  else if (kind == 1) gb1[o] = tot;
+  else if (kind == 2) gw2[(int64_t)c * H + o] = tot;
+  else gb2[c] = tot;
 }
 
 template <typename K>
@@ -649,7 +644,7 @@ static bool head_shapes_ok(int64_t N, int I, int H, int O2) {
 
 extern "C" size_t mlqem_mlp1_workspace_bytes(int I, int O2) {
   if (I < 1 || O2 < 1 || O2 > kHeadMaxOut) return 0;
-  return (size_t)kHeadMaxBwdBlocks * (size_t)mlp1_partial_floats(I, O2) * sizeof(float);
+  return (size_t)kHeadMaxBwdBlocks * (size_t)kHeadPartialFloats * sizeof(float);
 }
 
 extern "C" int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2,
@@ -697,15 +692,14 @@ extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* 
     if (O2 == 1) hipLaunchKernelGGL(mlp1_bwd_bf16_kernel<1>, dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
     else hipLaunchKernelGGL(mlp1_bwd_bf16_kernel<4>, dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
   } else {
-    constexpr int KU = 4;
+    constexpr int KU = MLQEM_HEAD_BWD_KU;
     static const int res1 = head_resident_workgroups(mlp1_bwd_f32_kernel<1, KU>, kBwdThreads, 0);
     static const int res4 = head_resident_workgroups(mlp1_bwd_f32_kernel<4, KU>, kBwdThreads, 0);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(O2 == 1 ? res1 : res4, kHeadMaxBwdBlocks), ceil_div(std::max<int64_t>(N, 1), 4 * KU)));
     if (O2 == 1) hipLaunchKernelGGL((mlp1_bwd_f32_kernel<1, KU>), dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
     else hipLaunchKernelGGL((mlp1_bwd_f32_kernel<4, KU>), dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
   }
-  const int64_t total = mlp1_partial_floats(I, O2);
-  hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(total, kHeadReducePairs)), dim3(256), 0, s, a.partial, G, I, H, O2,
-                     gw1, gb1, gw2, gb2);
+  hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(kHeadPartialFloats, kWave)), dim3(256), 0, s, a.partial, G, I, H, O2, cpw,
+                     bf16 ? 1 : 0, gw1, gb1, gw2, gb2);
   return launch_status();
 }

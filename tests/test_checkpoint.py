@@ -1,0 +1,44 @@
+"""``Trainer.save`` writes the reference's artefacts (docs/tutorials/__ml_models.py:196-205): ``model.pth`` = the state dict,
+``model.pk`` = ``{'train_losses', 'val_losses'}`` pickled -- the form of the 63 checkpoints and loss curves the reference ships
+(SURVEY.md section 2.3 / Appendix D).  CPU part: file format and round trip through a plain torch module."""
+import pickle
+
+import torch
+
+from blackwater.train import Trainer
+from oracle.models import MLP1
+
+
+class _Rows:
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+    def model_args(self):
+        return (self.x,)
+
+
+def test_save_writes_state_dict_and_loss_curves_in_the_reference_form(tmp_path):
+    torch.manual_seed(0)
+    model = MLP1(58, 64, 4)
+    tr = Trainer(model, lr=1e-3)
+    x, y = torch.randn(64, 58), torch.randn(64, 4)
+    losses = [float(tr.step(_Rows(x, y))) for _ in range(5)]
+    assert losses[-1] < losses[0]
+    tr.history = {"train_losses": losses, "val_losses": [l * 2 for l in losses]}
+    path = tr.save(str(tmp_path / "run" / "mlp1_smaller_2.pth"))
+    assert path.endswith("mlp1_smaller_2.pth")
+    state = torch.load(path, map_location="cpu", weights_only=True)          # plain tensors: loads with weights_only
+    assert list(state) == ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]   # the reference's key names, in order
+    assert all(v.is_contiguous() and v.storage_offset() == 0 for v in state.values())   # not views into the flat buffer
+    with open(str(tmp_path / "run" / "mlp1_smaller_2.pk"), "rb") as fh:
+        curves = pickle.load(fh)
+    assert set(curves) == {"train_losses", "val_losses"} and curves["train_losses"] == losses
+    fresh = MLP1(58, 64, 4)
+    fresh.load_state_dict(state, strict=True)
+    assert torch.equal(fresh(x), model(x))
+    # and back into a trainer: parameters land in the flat buffer the optimizer steps
+    other = Trainer(MLP1(58, 64, 4), lr=1e-3)
+    hist = other.load(path)
+    assert hist["val_losses"] == curves["val_losses"]
+    assert torch.equal(other.model(x), model(x))
+    assert torch.equal(other.flat_param.detach()[:58 * 64].view(64, 58), model.fc1.weight.detach())

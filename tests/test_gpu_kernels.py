@@ -590,6 +590,29 @@ def test_batch_norm_train_matches_torch_in_fp64(n, c):
     assert int(bn.num_batches_tracked) == 1
 
 
+def test_batch_norm_statistics_of_columns_far_from_zero():
+    """Columns with |mean| >> std (un-normalised features: a raw circuit depth of ~300 with a spread of ~1): E[x^2] - mean^2 on
+    raw fp32 values loses the variance to cancellation (relative error ~1e-7 (mean/std)^2); the kernels shift every column by
+    its first row before squaring, as stable as torch's Welford reduction.  Against float64."""
+    from blackwater.native import functional as F
+
+    torch.manual_seed(0)
+    n, c = 20000, 16
+    mean = torch.tensor([0.0, 1.0, 30.0, 300.0, 3000.0, -3000.0, 1e4, -1e4] * 2)
+    std = torch.tensor([1.0] * 8 + [0.01] * 8)
+    x = torch.randn(n, c) * std + mean
+    ref = torch.nn.BatchNorm1d(c).double().train()
+    bn = torch.nn.BatchNorm1d(c).to(DEV).train()
+    yr = ref(x.double())
+    yd = F.batch_norm_train(x.to(DEV), bn)
+    want_var = x.double().var(0, unbiased=True)
+    got_var = (bn.running_var.cpu().double() - 0.9) / 0.1
+    assert ((got_var - want_var).abs() / want_var).max().item() < 1e-4          # the naive form is off by 1e-1 ... 1e+3 here
+    assert (yd.cpu().double() - yr).abs().max().item() < 5e-3                      # |x| = 1e4 carries 1e-3 of fp32 rounding in x - mean alone
+    small = mean.abs() <= 30
+    assert (yd.cpu().double() - yr)[:, small].abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("padded", [True, False])
 def test_linear_with_more_than_128_inputs_runs_on_the_matrix_cores_in_two_pieces(padded):
     """ops.linear splits inputs wider than 128 columns (the 169/170-wide encode_data_v2_ecr rows of the MLP path) into
