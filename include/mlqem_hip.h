@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 14 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 15 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -222,14 +222,16 @@ int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int6
  *             over x and the stash; per-workgroup partial sums, fixed-order second stage (deterministic).
  * bf16 == 0: exact fp32 on v_mfma_f32_16x16x4_f32.  bf16 != 0: every GEMM operand rounded to bf16 (nearest-even), fp32
  * accumulation on v_mfma_f32_16x16x32_bf16, the stash kept in bf16 (the "bf16 MFMA MLP head" of the mixed-corpus
- * configuration); gb2 is summed from the unrounded gout.  workspace: mlqem_mlp1_workspace_bytes(I, O2). */
+ * configuration); gb2 is summed from the unrounded gout.  workspace (both calls; 16-byte aligned): mlqem_mlp1_workspace_bytes(I, O2) -- the
+ * forward keeps the W1 fragment image its workgroups copy into LDS there, the backward its partial sums; a forward and a
+ * backward on one stream may share it. */
 #define MLQEM_MLP1_HIDDEN_PAD 128
 #define MLQEM_MLP1_MAX_OUT 4
 #define MLQEM_MLP1_MAX_IN 175
 size_t mlqem_mlp1_workspace_bytes(int I, int O2);
 int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,
-                       void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2, int bf16,
-                       mlqem_stream_t stream);
+                       void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2, int bf16, void* workspace,
+                       size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t ldx, const void* h_stash, const float* w2,
                         float* gw1, float* gb1, float* gw2, float* gb2, int64_t N, int I, int H, int O2, int bf16,
                         void* workspace, size_t workspace_bytes, mlqem_stream_t stream);

@@ -64,7 +64,7 @@ SIGNATURES = {
     "mlqem_linear_wgrad_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _S, _P, _P]),
     "mlqem_linear_wgrad_parts_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P, _P]),
     "mlqem_mlp1_workspace_bytes": (_S, [_I, _I]),
-    "mlqem_mlp1_forward": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _P]),
+    "mlqem_mlp1_forward": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _P, _S, _P]),
     "mlqem_mlp1_backward": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _S, _P]),
     "mlqem_linear_bwd_fused_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _F, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_pooled_head_f32": (_I, [_P, _L, _I, _P, _L, _P]),
@@ -111,7 +111,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 14   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 15   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -475,8 +475,11 @@ def mlp1_forward(x, w1, b1, w2, b2, bf16=False, stash=True):
     out = torch.empty((n, o2), dtype=torch.float32, device=x.device)
     hs = torch.empty((max(n, 1), MLP1_MAX_HIDDEN), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device) if stash else None
     ldx = _mat(x, "x") if n > 1 else (i + 3) // 4 * 4
-    code = _lib.load().mlqem_mlp1_forward(_p(x), ldx, _p(w1), _p(b1), _p(w2), _p(b2), _p(hs), _p(out), o2, n, i, h, o2,
-                                          1 if bf16 else 0, _stream())
+    lib = _lib.load()
+    need = lib.mlqem_mlp1_workspace_bytes(i, o2)
+    ws = _wgrad_workspace(x.device, need)
+    code = lib.mlqem_mlp1_forward(_p(x), ldx, _p(w1), _p(b1), _p(w2), _p(b2), _p(hs), _p(out), o2, n, i, h, o2,
+                                  1 if bf16 else 0, _p(ws), need, _stream())
     _lib.check(code, "mlqem_mlp1_forward")
     return out, hs, x
 

@@ -30,7 +30,7 @@ constexpr int kHeadMaxOut = MLQEM_MLP1_MAX_OUT;
 constexpr int kFwdThreads = 256;                // the waves of a workgroup share one W1 image in LDS
 constexpr int kBwdThreads = 256;
 #ifndef MLQEM_HEAD_BWD_KU
-#define MLQEM_HEAD_BWD_KU 8    // k-steps (of 4 rows) per iteration of the fp32 backward: one iteration = the prefetch distance
+#define MLQEM_HEAD_BWD_KU 8    // k-steps (of 4 rows) per iteration of the fp32 backward: one iteration = the prefetch distance; 8 spills (two register sets)
 #endif
 
 struct Mlp1Args {
@@ -39,7 +39,8 @@ struct Mlp1Args {
   void* h;                      // stash [N,128]: float (fp32 mode) or bf16 (bf16 mode); forward may pass nullptr (inference)
   float* out; int64_t ldo;      // forward: [N,O2]
   const float* gout; int64_t ldg;   // backward: d loss / d out, [N,O2]
-  float* partial;               // backward: per-workgroup partial sums, see mlp1_partial_floats
+  float* partial;               // backward: per-workgroup partial sums (kHeadPartialFloats each)
+  const void* image;            // forward: the LDS image built by mlp1_image_kernel
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
@@ -56,10 +57,17 @@ __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast
 __device__ __forceinline__ int head_unit(int ob, int m) { return 32 * (ob >> 1) + 8 * (m >> 2) + 4 * (ob & 1) + (m & 3); }
 
 // ------------------------------------------------------------------------------------------------ forward
-// LDS: the W1 image (8 output tiles x G k-groups x 64 lanes x 16 bytes), then b1[128], w2[4][128].
-template <bool BF16, int G>
-__device__ __forceinline__ void head_fill_lds(const Mlp1Args& a, u32x4* s_w, float* s_b1, float* s_w2) {
-  for (int idx = threadIdx.x; idx < 8 * G * kWave; idx += kFwdThreads) {
+// The LDS image of a forward workgroup: W1 as ready-made A fragments (8 output tiles x G k-groups x 64 lanes x 16 bytes),
+// then b1[128], w2[4][128].  It is built ONCE per call by a small kernel into the workspace and copied into LDS by every
+// workgroup with coalesced 16-byte loads: building it in each of the 256 workgroups from the row-major weights (scalar
+// loads of an unaligned 170-float row, 88 per thread) took 30 us of a 140 us launch.
+__host__ __device__ inline int head_image_u32x4(int G) { return 8 * G * kWave + (kHeadH + kHeadMaxOut * kHeadH) / 4; }
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void mlp1_image_kernel(const Mlp1Args a, int G, u32x4* __restrict__ image) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int n_frag = 8 * G * kWave;
+  if (idx < n_frag) {
     const int l = idx & 63, g = (idx >> 6) % G, ob = idx / (64 * G);
     const int o = head_unit(ob, l & 15), lq = l >> 4;
     const float* wr = a.w1 + (int64_t)o * a.I;
@@ -82,15 +90,24 @@ __device__ __forceinline__ void head_fill_lds(const Mlp1Args& a, u32x4* s_w, flo
       v = u32x4{__builtin_bit_cast(unsigned, w[0]), __builtin_bit_cast(unsigned, w[1]), __builtin_bit_cast(unsigned, w[2]),
                 __builtin_bit_cast(unsigned, w[3])};
     }
-    s_w[idx] = v;
+    image[idx] = v;
+    return;
   }
-  for (int o = threadIdx.x; o < kHeadH; o += kFwdThreads) s_b1[o] = o < a.H ? a.b1[o] : 0.f;
-  for (int idx = threadIdx.x; idx < kHeadMaxOut * kHeadH; idx += kFwdThreads) {
-    const int q = idx / kHeadH, o = idx % kHeadH;
+  float* tail = reinterpret_cast<float*>(image + n_frag);
+  const int t = idx - n_frag;
+  if (t < kHeadH) {
+    tail[t] = t < a.H ? a.b1[t] : 0.f;
+  } else if (t < kHeadH + kHeadMaxOut * kHeadH) {
+    const int q = (t - kHeadH) / kHeadH, o = (t - kHeadH) % kHeadH;
     float w = (q < a.O2 && o < a.H) ? a.w2[(int64_t)q * a.H + o] : 0.f;
     if (BF16) w = bf16_round(w);
-    s_w2[idx] = w;
+    tail[t] = w;
   }
+}
+
+template <int G>
+__device__ __forceinline__ void head_fill_lds(const u32x4* __restrict__ image, u32x4* s_raw) {
+  for (int idx = threadIdx.x; idx < head_image_u32x4(G); idx += kFwdThreads) s_raw[idx] = image[idx];
 }
 
 // bias + ReLU, the stash, fc2: the lane holds 32 hidden units of row `row` (hv[p][e] = unit 32 p + 8 lq + e).
@@ -142,7 +159,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_f32_kernel(const Mlp1Arg
   u32x4* s_w = s_raw;
   float* s_b1 = reinterpret_cast<float*>(s_raw + 8 * G * kWave);
   float* s_w2 = s_b1 + kHeadH;
-  head_fill_lds<false, G>(a, s_w, s_b1, s_w2);
+  head_fill_lds<G>(static_cast<const u32x4*>(a.image), s_raw);
   __syncthreads();
   float b2r[kHeadMaxOut];       // a global load in the epilogue would sit behind the stash stores (one in-order vmcnt)
 #pragma unroll
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_bf16_kernel(const Mlp1Ar
   u32x4* s_w = s_raw;
   float* s_b1 = reinterpret_cast<float*>(s_raw + 8 * G2 * kWave);
   float* s_w2 = s_b1 + kHeadH;
-  head_fill_lds<true, G2>(a, s_w, s_b1, s_w2);
+  head_fill_lds<G2>(static_cast<const u32x4*>(a.image), s_raw);
   __syncthreads();
   float b2r[kHeadMaxOut];       // a global load in the epilogue would sit behind the stash stores (one in-order vmcnt)
 #pragma unroll
@@ -290,6 +307,7 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_bf16_kernel(const Mlp1Ar
 // [wave][k][register][lane] for its two gW2 tiles, then gb2[4] -- so that every store instruction of the main kernel and
 // every load instruction of the second stage moves 256 contiguous bytes (an (o, column)-ordered layout is 64 scattered
 // dwords per instruction: 22 MB of 4-byte writes).  The second stage decodes an element's (o, column) from its position.
+constexpr int kHeadF32Tiles = 2 * 11;                 // per wave in the fp32 backward: 2 hidden fragments x at most 11 column fragments
 constexpr int kHeadW1Floats = 4 * 32 * 4 * kWave, kHeadW2Floats = 4 * 2 * 4 * kWave;
 constexpr int kHeadPartialFloats = kHeadW1Floats + kHeadW2Floats + kHeadMaxOut;
 
@@ -317,35 +335,30 @@ __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_bf16_kernel(const Mlp1Ar
   float gb2 = 0.f;
 
   struct Slab { float4 xv[8]; u32x4 hv[8]; float gv[8][O2T]; };
-  const int64_t n_slabs = ceil_div(a.N, 32);
+  const int64_t n_slabs = a.N / 32;                        // full slabs; the ragged tail (N % 32 rows) is taken after the loop
   const unsigned short* hb = static_cast<const unsigned short*>(a.h);
   const int colc = min(col0, ipad - 4);                  // lanes without columns of their own re-read the last chunk (dropped below)
   // this lane's x components: a column < I is the loaded value, column I is the ones column, anything else is zero
   const bool x_raw[4] = {col0 + 0 < a.I, col0 + 1 < a.I, col0 + 2 < a.I, col0 + 3 < a.I};
   const float x_fill[4] = {xlane && col0 + 0 == a.I ? 1.f : 0.f, xlane && col0 + 1 == a.I ? 1.f : 0.f,
                            xlane && col0 + 2 == a.I ? 1.f : 0.f, xlane && col0 + 3 == a.I ? 1.f : 0.f};
-  // Loads are UNCONDITIONAL (rows clamped into the matrix) and fixed up where they are consumed: a fix-up at the load (the
-  // ones column, zeros for rows beyond N) makes the compiler wait for that load on the spot -- one memory round trip per
-  // load instead of one per slab.  A clamped row contributes nothing: its gout is taken as zero below.
-  auto load_slab = [&](int64_t s, Slab& d) {
+  // Row j of a slab: a SCALAR base (row 32 s + j) plus 32-bit lane offsets that never change; loads are unconditional and there
+  // is no control flow around them (a slab index beyond the end re-reads the last full slab and is never consumed): a fix-up at
+  // the load, or a branch around it, makes the compiler wait for memory on the spot (see mlp1_bwd_f32_kernel).
+  const unsigned xo = (unsigned)(8 * lq * a.ldx + colc), ho = (unsigned)(8 * lq * kHeadH + 8 * lr), go = (unsigned)(8 * lq * a.ldg);
+  auto issue_row = [&](Slab& d, int64_t s, int j) {
+    const int64_t r0 = 32 * min(s, n_slabs - 1) + j;      // uniform
+    d.xv[j] = *reinterpret_cast<const float4*>(a.x + r0 * a.ldx + xo);
+    d.hv[j] = *reinterpret_cast<const u32x4*>(hb + r0 * kHeadH + ho);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int64_t row = min(s * 32 + 8 * lq + j, a.N - 1);
-      d.xv[j] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + colc);
-      d.hv[j] = *reinterpret_cast<const u32x4*>(hb + row * kHeadH + 8 * lr);
-#pragma unroll
-      for (int q = 0; q < O2T; ++q) d.gv[j][q] = a.gout[row * a.ldg + min(q, a.O2 - 1)];
-    }
+    for (int q = 0; q < O2T; ++q) d.gv[j][q] = a.gout[r0 * a.ldg + go + min(q, a.O2 - 1)];
   };
-  Slab cur, nxt;
-  load_slab(blockIdx.x, cur);
-  for (int64_t s = blockIdx.x; s < n_slabs; s += gridDim.x) {
-    load_slab(s + gridDim.x, nxt);
-    __builtin_amdgcn_sched_barrier(0);         // the prefetch is issued HERE: left alone, the compiler folds nxt into cur's registers
-                                               // (the copy at the end coalesces) and loads each value just before its use
+  // One slab: B fragments of x and the per-row scalars first, then the eight A fragments of the gated hidden gradient, four
+  // MFMAs each; `after(t)` runs behind fragment t's MFMAs (the main loop issues row t of a later slab there).
+  auto consume = [&](Slab& cur, int64_t first_row, auto&& after) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool ok = s * 32 + 8 * lq + j < a.N;
+      const bool ok = first_row + 8 * lq + j < a.N;
 #pragma unroll
       for (int q = 0; q < O2T; ++q) cur.gv[j][q] = (ok && q < a.O2) ? cur.gv[j][q] : 0.f;
       cur.xv[j].x = x_raw[0] ? cur.xv[j].x : x_fill[0];
@@ -419,9 +432,36 @@ __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_bf16_kernel(const Mlp1Ar
       const bf16x8 af = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc[t][s4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bx[s4], acc[t][s4], 0, 0, 0);
+      after(t);
     }
-    __builtin_amdgcn_sched_barrier(0);         // ... and taken over HERE, not where cur's registers first fall free
-    cur = nxt;
+  };
+  // Two register sets: the next slab is requested in one block in front of this slab's work and taken over behind it; the two
+  // scheduling barriers pin that order (see mlp1_bwd_f32_kernel).
+  Slab cur, nxt;
+  const int64_t G = gridDim.x;
+  if (n_slabs > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_row(cur, blockIdx.x, j);
+    for (int64_t sl = blockIdx.x; sl < n_slabs; sl += G) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) issue_row(nxt, sl + G, j);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(cur, 32 * sl, [](int) {});
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+  }
+  if (blockIdx.x == 0 && (a.N & 31)) {                     // the ragged tail: rows 32 n_slabs .. N - 1, lane rows clamped
+    Slab t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t row = min(32 * n_slabs + 8 * lq + j, a.N - 1);
+      t.xv[j] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + colc);
+      t.hv[j] = *reinterpret_cast<const u32x4*>(hb + row * kHeadH + 8 * lr);
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) t.gv[j][q] = a.gout[row * a.ldg + min(q, a.O2 - 1)];
+    }
+    consume(t, 32 * n_slabs, [](int) {});
   }
   // partial sums of this workgroup (lane order): register r of tile (t, s4) is gW1[8 (4 lq + r) + t][4 (cpw wid + lr) + s4]
   float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + (wid * 32 * 4) * kWave + lane;
@@ -444,113 +484,160 @@ __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_bf16_kernel(const Mlp1Ar
 }
 
 // fp32: K-steps of 4 rows (row = step base + lq), KU steps per iteration with the next iteration's operands in flight.
-// A fragment (p, s): tile row m <-> hidden unit 64 p + 4 m + s (float4 loads of the stash); B fragment s: tile column n <->
-// x column 4 (cpw wid + n) + s.
-template <int O2T, int KU>
-__global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_f32_kernel(const Mlp1Args a, int cpw) {
+// Here the waves split the HIDDEN UNITS (wave w owns units 32 w .. 32 w + 31: two A fragments, float2 loads of the stash,
+// fragment s: tile row m <-> unit 32 w + 2 m + s) and every wave multiplies them with ALL columns of [x | 1]: NG groups of 64
+// columns as float4 loads (fragment (g, s4): tile column n <-> column 64 g + 4 n + s4) and NS fragments of 16 columns as
+// scalar loads (fragment f: tile column n <-> column 64 NG + 16 f + n).  170 inputs: 2 x (8 + 3) + 2 = 24 MFMAs per k-step and
+// wave against 34 with the columns split four ways (44 columns fill 11 of a float4 fragment set's 16 lanes) -- this kernel is
+// bound by the fp32 matrix cores, so fewer MFMAs is the lever; x comes from L1 / L2 for three of the four waves.
+// Partial sums (lane order): [wave][tile s (4 NG + NS) + b][register][lane], then [wave][s][register][lane] for gW2, then gb2.
+template <int O2T, int KU, int NG, int NS>
+__global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_f32_kernel(const Mlp1Args a) {
+  constexpr int NB = 4 * NG + NS;                            // B fragments
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int ipad = (a.I + 3) / 4 * 4;
-  const int col0 = 4 * (cpw * wid + lr);
-  const bool xlane = lr < cpw && col0 <= a.I;
-  float w2r[O2T][2][4];
+  float w2r[O2T][2];
 #pragma unroll
   for (int q = 0; q < O2T; ++q)
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int s = 0; s < 2; ++s) {
+      const int o = 32 * wid + 2 * lr + s;
+      w2r[q][s] = (q < a.O2 && o < a.H) ? a.w2[(int64_t)q * a.H + o] : 0.f;
+    }
+  f32x4 acc[2][NB], acc2[2];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int o = 64 * p + 4 * lr + s;
-        w2r[q][p][s] = (q < a.O2 && o < a.H) ? a.w2[(int64_t)q * a.H + o] : 0.f;
-      }
-  f32x4 acc[2][4][4], acc2[2];
+  for (int s = 0; s < 2; ++s)
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc[p][s][s4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b) acc[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   float gb2 = 0.f;
 
-  struct Step { float4 xv, h0, h1; float gv[O2T]; };
+  struct Step { float4 xg[NG]; float xs[NS > 0 ? NS : 1]; float2 hv; float gv[O2T]; };
   const float* hf = static_cast<const float*>(a.h);
-  constexpr int kRows = 4 * KU;
-  const int64_t n_iters = ceil_div(a.N, (int64_t)kRows);
-  const int colc = min(col0, ipad - 4);
-  const bool x_raw[4] = {col0 + 0 < a.I, col0 + 1 < a.I, col0 + 2 < a.I, col0 + 3 < a.I};
-  const float x_fill[4] = {xlane && col0 + 0 == a.I ? 1.f : 0.f, xlane && col0 + 1 == a.I ? 1.f : 0.f,
-                           xlane && col0 + 2 == a.I ? 1.f : 0.f, xlane && col0 + 3 == a.I ? 1.f : 0.f};
-  auto load_iter = [&](int64_t it, Step (&d)[KU]) {     // unconditional, rows clamped: see mlp1_bwd_bf16_kernel
+  const int64_t n_steps = a.N / 4;                          // full k-steps; the ragged tail (N % 4 rows) is taken after the loop
+  const int64_t n_iters = ceil_div(n_steps, (int64_t)KU);
+  // this lane's columns: a column < I is the loaded value, column I is the ones column (bias gradient), anything else is zero;
+  // loads are clamped into the row (pads may hold anything, a clamped column is overridden below)
+  int gcol[NG], scol[NS > 0 ? NS : 1];
+  bool g_raw[NG][4], s_raw[NS > 0 ? NS : 1];
+  float g_fill[NG][4], s_fill[NS > 0 ? NS : 1];
 #pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const int64_t row = min(it * kRows + 4 * u + lq, a.N - 1);
-      d[u].xv = *reinterpret_cast<const float4*>(a.x + row * a.ldx + colc);
-      d[u].h0 = *reinterpret_cast<const float4*>(hf + row * kHeadH + 4 * lr);
-      d[u].h1 = *reinterpret_cast<const float4*>(hf + row * kHeadH + 64 + 4 * lr);
+  for (int g = 0; g < NG; ++g) {
+    const int c0 = 64 * g + 4 * lr;
+    gcol[g] = min(c0, ipad - 4);
 #pragma unroll
-      for (int q = 0; q < O2T; ++q) d[u].gv[q] = a.gout[row * a.ldg + min(q, a.O2 - 1)];
-    }
-  };
-  Step cur[KU], nxt[KU];
-  load_iter(blockIdx.x, cur);
-  for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
-    load_iter(it + gridDim.x, nxt);
-    __builtin_amdgcn_sched_barrier(0);         // issue the prefetch HERE (see mlp1_bwd_bf16_kernel)
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const bool ok = it * kRows + 4 * u + lq < a.N;
-#pragma unroll
-      for (int q = 0; q < O2T; ++q) cur[u].gv[q] = (ok && q < a.O2) ? cur[u].gv[q] : 0.f;
-      const float xb[4] = {x_raw[0] ? cur[u].xv.x : x_fill[0], x_raw[1] ? cur[u].xv.y : x_fill[1],
-                           x_raw[2] ? cur[u].xv.z : x_fill[2], x_raw[3] ? cur[u].xv.w : x_fill[3]};
-      const float hv[2][4] = {{cur[u].h0.x, cur[u].h0.y, cur[u].h0.z, cur[u].h0.w}, {cur[u].h1.x, cur[u].h1.y, cur[u].h1.z, cur[u].h1.w}};
-      // gW2 / gb2: this wave's two un-gated stash fragments against gout ([row = lq][q = lr])
-      float gq = 0.f;
-#pragma unroll
-      for (int q = 0; q < O2T; ++q) gq = lr == q ? cur[u].gv[q] : gq;
-      if (wid == 0) gb2 += gq;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int f = 2 * wid + k;               // fragment (p, s) = (f >> 2, f & 3)
-        float hsel = 0.f;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) hsel = (4 * p + s == f) ? hv[p][s] : hsel;
-        acc2[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(hsel, gq, acc2[k], 0, 0, 0);
-      }
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          float gs = 0.f;
-#pragma unroll
-          for (int q = 0; q < O2T; ++q) gs = fmaf(cur[u].gv[q], w2r[q][p][s], gs);
-          const float gh = hv[p][s] > 0.f ? gs : 0.f;
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) acc[p][s][s4] = __builtin_amdgcn_mfma_f32_16x16x4f32(gh, xb[s4], acc[p][s][s4], 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);         // take the prefetch over HERE, not where cur's registers first fall free
-#pragma unroll
-    for (int u = 0; u < KU; ++u) cur[u] = nxt[u];
+    for (int c = 0; c < 4; ++c) { g_raw[g][c] = c0 + c < a.I; g_fill[g][c] = c0 + c == a.I ? 1.f : 0.f; }
   }
-  // partial sums (lane order): register r of tile (p, s, s4) is gW1[64 p + 4 (4 lq + r) + s][4 (cpw wid + lr) + s4]
-  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + (wid * 32 * 4) * kWave + lane;
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int f = 0; f < NS; ++f) {
+    const int c = 64 * NG + 16 * f + lr;
+    scol[f] = min(c, ipad - 1);
+    s_raw[f] = c < a.I; s_fill[f] = c == a.I ? 1.f : 0.f;
+  }
+  // Loads: a SCALAR base per k-step plus 32-bit lane offsets that never change, unconditional, no control flow (a step
+  // beyond the end re-reads the last full step; its gout is taken as zero where it is consumed).  A fix-up at the load or a
+  // branch around it makes the compiler wait for memory on the spot (vmcnt is one in-order counter, and at a join the
+  // compiler no longer knows how many loads are in flight).
+  unsigned xo[NG], so[NS > 0 ? NS : 1];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+  for (int g = 0; g < NG; ++g) xo[g] = (unsigned)(lq * a.ldx + gcol[g]);
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
+  for (int f = 0; f < NS; ++f) so[f] = (unsigned)(lq * a.ldx + scol[f]);
+  const unsigned ho = (unsigned)(lq * kHeadH + 32 * wid + 2 * lr), go = (unsigned)(lq * a.ldg);
+  auto issue = [&](Step& d, int64_t it, int u) {
+    const int64_t r0 = 4 * min(it * KU + u, n_steps - 1);   // uniform
+    const float* xb = a.x + r0 * a.ldx; const float* hb = hf + r0 * kHeadH; const float* gb = a.gout + r0 * a.ldg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[((((p * 4 + s) * 4) + s4) * 4 + r) * kWave] = acc[p][s][s4][r];
+    for (int g = 0; g < NG; ++g) d.xg[g] = *reinterpret_cast<const float4*>(xb + xo[g]);
+#pragma unroll
+    for (int f = 0; f < NS; ++f) d.xs[f] = xb[so[f]];
+    d.hv = *reinterpret_cast<const float2*>(hb + ho);
+#pragma unroll
+    for (int q = 0; q < O2T; ++q) d.gv[q] = gb[go + min(q, a.O2 - 1)];
+  };
+  auto consume = [&](const Step& c, bool ok) {
+    float gv[O2T];
+#pragma unroll
+    for (int q = 0; q < O2T; ++q) gv[q] = (ok && q < a.O2) ? c.gv[q] : 0.f;
+    float xb[NB];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      xb[4 * g + 0] = g_raw[g][0] ? c.xg[g].x : g_fill[g][0];
+      xb[4 * g + 1] = g_raw[g][1] ? c.xg[g].y : g_fill[g][1];
+      xb[4 * g + 2] = g_raw[g][2] ? c.xg[g].z : g_fill[g][2];
+      xb[4 * g + 3] = g_raw[g][3] ? c.xg[g].w : g_fill[g][3];
+    }
+#pragma unroll
+    for (int f = 0; f < NS; ++f) xb[4 * NG + f] = s_raw[f] ? c.xs[f] : s_fill[f];
+    const float hv[2] = {c.hv.x, c.hv.y};
+    // gW2 / gb2: the un-gated stash fragments against gout ([row = lq][q = lr])
+    float gq = 0.f;
+#pragma unroll
+    for (int q = 0; q < O2T; ++q) gq = lr == q ? gv[q] : gq;
+    if (wid == 0) gb2 += gq;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc2[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[s], gq, acc2[s], 0, 0, 0);
+    float gh[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float gs = 0.f;
+#pragma unroll
+      for (int q = 0; q < O2T; ++q) gs = fmaf(gv[q], w2r[q][s], gs);
+      gh[s] = hv[s] > 0.f ? gs : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc[s][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gh[s], xb[b], acc[s][b], 0, 0, 0);
+  };
+  // Two register sets: the whole next iteration is requested in one block in front of this iteration's MFMAs and taken over
+  // behind them.  The two scheduling barriers pin that order: left alone, the compiler folds the second set into the first
+  // (the copy coalesces) and loads every value just before its use.  Tried and measured slower or no faster (the loads and
+  // their address arithmetic interleaved with the MFMAs instead of a block in front of them): two sets with the loop
+  // unrolled twice -- at the loop head the compiler's wait-count analysis gives up and waits for every load in flight,
+  // vmcnt(0), one k-step after the last one was issued (254 vs 228 us on the column-split form); one set used as a ring --
+  // the register allocator rotates the ring through AGPRs with copies that wait for the newest loads.
+  Step cur[KU], nxt[KU];
+  if (n_steps > 0) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) issue(cur[u], blockIdx.x, u);
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) issue(nxt[u], it + gridDim.x, u);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < KU; ++u) consume(cur[u], it * KU + u < n_steps);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < KU; ++u) cur[u] = nxt[u];
+    }
+  }
+  if (blockIdx.x == 0 && (a.N & 3)) {                       // the ragged tail: rows 4 n_steps .. N - 1, lane rows clamped
+    const int64_t row = min(4 * n_steps + lq, a.N - 1);
+    Step t;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t.xg[g] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + gcol[g]);
+#pragma unroll
+    for (int f = 0; f < NS; ++f) t.xs[f] = a.x[row * a.ldx + scol[f]];
+    t.hv = *reinterpret_cast<const float2*>(hf + row * kHeadH + 32 * wid + 2 * lr);
+#pragma unroll
+    for (int q = 0; q < O2T; ++q) t.gv[q] = a.gout[row * a.ldg + min(q, a.O2 - 1)];
+    consume(t, 4 * n_steps + lq < a.N);
+  }
+  // partial sums (lane order): register r of tile (s, b) is gW1[32 wid + 2 (4 lq + r) + s][column of fragment b, lane lr]
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + (wid * kHeadF32Tiles * 4) * kWave + lane;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[((s * NB + b) * 4 + r) * kWave] = acc[s][b][r];
   float* __restrict__ dst2 = a.partial + (int64_t)blockIdx.x * kHeadPartialFloats + kHeadW1Floats;
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst2[((wid * 2 + k) * 4 + r) * kWave + lane] = acc2[k][r];   // fragment f = 2 wid + k: gW2[q = lr][64 (f >> 2) + 4 (4 lq + r) + (f & 3)]
+    for (int r = 0; r < 4; ++r) dst2[((wid * 2 + s) * 4 + r) * kWave + lane] = acc2[s][r];   // gW2[q = lr][32 wid + 2 (4 lq + r) + s]
   if (wid == 0) {
     gb2 += __shfl_xor(gb2, 16);
     gb2 += __shfl_xor(gb2, 32);
@@ -571,16 +658,27 @@ __global__ __launch_bounds__(256) void mlp1_bwd_reduce_kernel(const float* __res
   // where the element goes (-1: a lane / row / column that stands for nothing)
   int kind = -1, o = 0, c = 0;
   if (e < kHeadW1Floats) {
-    const int lane = e & 63, r = (e >> 6) & 3, tile = (e >> 8) & 31, wid = e >> 13;
-    const int lr = lane & 15, lq = lane >> 4, s4 = tile & 3, ft = tile >> 2;     // ft: bf16 t, fp32 4 p + s
-    o = bf16 ? 8 * (4 * lq + r) + ft : 64 * (ft >> 2) + 4 * (4 * lq + r) + (ft & 3);
-    c = 4 * (cpw * wid + lr) + s4;
-    if (lr < cpw && c <= I && o < H) kind = c < I ? 0 : 1;
+    const int lane = e & 63, r = (e >> 6) & 3, lr = lane & 15, lq = lane >> 4;
+    if (bf16) {                                   // columns split over the waves: [wave][tile t 4 + s4][r][lane]
+      const int tile = (e >> 8) & 31, wid = e >> 13, s4 = tile & 3, t = tile >> 2;
+      o = 8 * (4 * lq + r) + t;
+      c = 4 * (cpw * wid + lr) + s4;
+      if (lr < cpw && c <= I && o < H) kind = c < I ? 0 : 1;
+    } else {                                      // hidden units split over the waves: [wave][tile s NB + b][r][lane]
+      const int ng = cpw >> 8, nb = 4 * ng + (cpw & 255);           // cpw carries (NG << 8) | NS for this layout
+      const int tile = (e >> 8) % kHeadF32Tiles, wid = (e >> 8) / kHeadF32Tiles;
+      if (wid < 4 && tile < 2 * nb) {
+        const int sfr = tile / nb, b = tile % nb;
+        o = 32 * wid + 2 * (4 * lq + r) + sfr;
+        c = b < 4 * ng ? 64 * (b >> 2) + 4 * lr + (b & 3) : 64 * ng + 16 * (b - 4 * ng) + lr;
+        if (c <= I && o < H) kind = c < I ? 0 : 1;
+      }
+    }
   } else if (e < kHeadW1Floats + kHeadW2Floats) {
     const int f = e - kHeadW1Floats;
     const int lane = f & 63, r = (f >> 6) & 3, k = (f >> 8) & 1, wid = f >> 9;
-    const int lr = lane & 15, lq = lane >> 4, fr = 2 * wid + k;
-    o = bf16 ? 8 * (4 * lq + r) + fr : 64 * (fr >> 2) + 4 * (4 * lq + r) + (fr & 3);
+    const int lr = lane & 15, lq = lane >> 4;
+    o = bf16 ? 8 * (4 * lq + r) + 2 * wid + k : 32 * wid + 2 * (4 * lq + r) + k;
     c = lr;
     if (c < O2 && o < H) kind = 2;
   } else if (e < kHeadPartialFloats) {
@@ -619,8 +717,8 @@ static int head_resident_workgroups(K kernel, int threads, size_t lds) {
 constexpr int kHeadMaxBwdBlocks = 512;    // partial-sum slots of the backward workspace
 
 template <bool BF16, int G>
-static int launch_head_fwd(const Mlp1Args& a, hipStream_t s) {
-  const size_t lds = (size_t)8 * G * kWave * sizeof(u32x4) + (kHeadH + kHeadMaxOut * kHeadH) * sizeof(float);
+static int launch_head_fwd(Mlp1Args a, void* workspace, hipStream_t s) {
+  const size_t lds = (size_t)head_image_u32x4(G) * sizeof(u32x4);
   void (*kernel)(Mlp1Args);
   if constexpr (BF16) kernel = mlp1_fwd_bf16_kernel<G>; else kernel = mlp1_fwd_f32_kernel<G>;
   static const int once = [&] {
@@ -628,6 +726,9 @@ static int launch_head_fwd(const Mlp1Args& a, hipStream_t s) {
   }();
   if (!once) return MLQEM_ERR_LAUNCH;
   static const int res = head_resident_workgroups(kernel, kFwdThreads, lds);
+  a.image = workspace;
+  hipLaunchKernelGGL(mlp1_image_kernel<BF16>, dim3((unsigned)ceil_div(head_image_u32x4(G) * 4, 256)), dim3(256), 0, s, a, G,
+                     static_cast<u32x4*>(workspace));
   const int64_t tiles = ceil_div(a.N, 16);
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(res, ceil_div(tiles, kFwdThreads / kWave)));
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(kFwdThreads), lds, s, a);
@@ -644,29 +745,32 @@ static bool head_shapes_ok(int64_t N, int I, int H, int O2) {
 
 extern "C" size_t mlqem_mlp1_workspace_bytes(int I, int O2) {
   if (I < 1 || O2 < 1 || O2 > kHeadMaxOut) return 0;
-  return (size_t)kHeadMaxBwdBlocks * (size_t)kHeadPartialFloats * sizeof(float);
+  const size_t bwd = (size_t)kHeadMaxBwdBlocks * (size_t)kHeadPartialFloats * sizeof(float);
+  const size_t fwd = (size_t)head_image_u32x4(11) * sizeof(u32x4);      // the widest forward image
+  return bwd > fwd ? bwd : fwd;
 }
 
 extern "C" int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2,
                                   const float* b2, void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2,
-                                  int bf16, mlqem_stream_t stream) {
+                                  int bf16, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
   begin_launches();
   if (!head_shapes_ok(N, I, H, O2)) return (I > MLQEM_MLP1_MAX_IN || H > kHeadH || O2 > kHeadMaxOut) ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
   if (ldx < (I + 3) / 4 * 4 || ldx % 4 || ldo < O2) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_mlp1_workspace_bytes(I, O2) || !aligned_to(workspace, 16)) return MLQEM_ERR_WORKSPACE;
   if (N == 0) return MLQEM_OK;
   if (!x || !w1 || !b1 || !w2 || !b2 || !out || !aligned_to(x, 16) || (h_stash && !aligned_to(h_stash, 16))) return MLQEM_ERR_BAD_ARG;
-  Mlp1Args a{x, ldx, N, I, H, O2, w1, b1, w2, b2, h_stash, out, ldo, nullptr, 0, nullptr};
+  Mlp1Args a{x, ldx, N, I, H, O2, w1, b1, w2, b2, h_stash, out, ldo, nullptr, 0, nullptr, nullptr};
   hipStream_t s = as_stream(stream);
   if (bf16) {
     const int g2 = (I + 31) / 32;
-    if (g2 <= 2) return launch_head_fwd<true, 2>(a, s);
-    if (g2 <= 4) return launch_head_fwd<true, 4>(a, s);
-    return launch_head_fwd<true, 6>(a, s);
+    if (g2 <= 2) return launch_head_fwd<true, 2>(a, workspace, s);
+    if (g2 <= 4) return launch_head_fwd<true, 4>(a, workspace, s);
+    return launch_head_fwd<true, 6>(a, workspace, s);
   }
   const int g = (I + 15) / 16;
-  if (g <= 4) return launch_head_fwd<false, 4>(a, s);
-  if (g <= 8) return launch_head_fwd<false, 8>(a, s);
-  return launch_head_fwd<false, 11>(a, s);
+  if (g <= 4) return launch_head_fwd<false, 4>(a, workspace, s);
+  if (g <= 8) return launch_head_fwd<false, 8>(a, workspace, s);
+  return launch_head_fwd<false, 11>(a, workspace, s);
 }
 
 extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t ldx, const void* h_stash,
@@ -678,28 +782,43 @@ extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* 
   if (!workspace || workspace_bytes < mlqem_mlp1_workspace_bytes(I, O2)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && (!gout || !x || !h_stash || !w2 || !aligned_to(x, 16) || !aligned_to(h_stash, 16))) return MLQEM_ERR_BAD_ARG;
   Mlp1Args a{x, ldx, N, I, H, O2, nullptr, nullptr, w2, nullptr, const_cast<void*>(h_stash), nullptr, 0, gout, ldg,
-             static_cast<float*>(workspace)};
+             static_cast<float*>(workspace), nullptr};
   hipStream_t s = as_stream(stream);
   const int chunks = (I + 1 + 3) / 4;             // float4 chunks of [x | 1]
   const int cpw = (chunks + 3) / 4;               // per wave: <= 11 for I <= 175
-  int G;
+  int G, reduce_layout = cpw;
   if (N == 0) {
     G = 0;                                        // nothing to sum: the second stage writes zeros
   } else if (bf16) {
     static const int res1 = head_resident_workgroups(mlp1_bwd_bf16_kernel<1>, kBwdThreads, 0);
     static const int res4 = head_resident_workgroups(mlp1_bwd_bf16_kernel<4>, kBwdThreads, 0);
-    G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(O2 == 1 ? res1 : res4, kHeadMaxBwdBlocks), ceil_div(std::max<int64_t>(N, 1), 32)));
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(O2 == 1 ? res1 : res4, kHeadMaxBwdBlocks), std::max<int64_t>(N / 32, 1)));
     if (O2 == 1) hipLaunchKernelGGL(mlp1_bwd_bf16_kernel<1>, dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
     else hipLaunchKernelGGL(mlp1_bwd_bf16_kernel<4>, dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
   } else {
     constexpr int KU = MLQEM_HEAD_BWD_KU;
-    static const int res1 = head_resident_workgroups(mlp1_bwd_f32_kernel<1, KU>, kBwdThreads, 0);
-    static const int res4 = head_resident_workgroups(mlp1_bwd_f32_kernel<4, KU>, kBwdThreads, 0);
-    G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(O2 == 1 ? res1 : res4, kHeadMaxBwdBlocks), ceil_div(std::max<int64_t>(N, 1), 4 * KU)));
-    if (O2 == 1) hipLaunchKernelGGL((mlp1_bwd_f32_kernel<1, KU>), dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
-    else hipLaunchKernelGGL((mlp1_bwd_f32_kernel<4, KU>), dim3(G), dim3(kBwdThreads), 0, s, a, cpw);
+    // columns of [x | 1] as NG float4 groups of 64 and NS scalar fragments of 16
+    const int ci = I + 1;
+    const int ng = ci <= 112 ? 1 : 2, ns = ci <= 64 * ng ? 0 : 3;
+    reduce_layout = (ng << 8) | ns;
+    auto launch = [&](auto kernel) {
+      static const int res = head_resident_workgroups(kernel, kBwdThreads, 0);
+      G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(res, kHeadMaxBwdBlocks), ceil_div(std::max<int64_t>(N / 4, 1), KU)));
+      hipLaunchKernelGGL(kernel, dim3(G), dim3(kBwdThreads), 0, s, a);
+    };
+    if (O2 == 1) {
+      if (ng == 1 && ns == 0) launch(mlp1_bwd_f32_kernel<1, KU, 1, 0>);
+      else if (ng == 1) launch(mlp1_bwd_f32_kernel<1, KU, 1, 3>);
+      else if (ns == 0) launch(mlp1_bwd_f32_kernel<1, KU, 2, 0>);
+      else launch(mlp1_bwd_f32_kernel<1, KU, 2, 3>);
+    } else {
+      if (ng == 1 && ns == 0) launch(mlp1_bwd_f32_kernel<4, KU, 1, 0>);
+      else if (ng == 1) launch(mlp1_bwd_f32_kernel<4, KU, 1, 3>);
+      else if (ns == 0) launch(mlp1_bwd_f32_kernel<4, KU, 2, 0>);
+      else launch(mlp1_bwd_f32_kernel<4, KU, 2, 3>);
+    }
   }
-  hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(kHeadPartialFloats, kWave)), dim3(256), 0, s, a.partial, G, I, H, O2, cpw,
-                     bf16 ? 1 : 0, gw1, gb1, gw2, gb2);
+  hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(kHeadPartialFloats, kWave)), dim3(256), 0, s, a.partial, G, I, H, O2,
+                     reduce_layout, bf16 ? 1 : 0, gw1, gb1, gw2, gb2);
   return launch_status();
 }

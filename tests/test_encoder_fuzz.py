@@ -45,12 +45,15 @@ def _code(encoder, text):
                                           ctypes.byref(f), ctypes.byref(d), None, None, None, None)
 
 
-@pytest.mark.parametrize("body", [
+MALFORMED = [
     "rz(((((1) q[0];", "rz(1)) q[0];", "rz(" + "(" * 100000 + "1" + ")" * 100000 + ") q[0];",
     "rz(1) q[99999999999999999999];", "rz(1) q[-1];", "rz(1) q[5];", "rz(1) q[x];", "rz(1) q[1", "rz(1", "cx q[0],",
     "measure q[0] ->", "rz(foo) q[0];", "if(c==1) x q[0];", "gate foo a { x a;", "qreg r[4000000000];", "qreg r[-2];",
     "qreg q[2];", "qreg r[0]; x r;", "qreg r[2]; cx q,r;",
-])
+]
+
+
+@pytest.mark.parametrize("body", MALFORMED, ids=[f"case{k}" for k in range(len(MALFORMED))])
 def test_malformed_text_is_a_bad_argument(encoder, body):
     assert _code(encoder, HEAD + body) == -1
     assert encoder._lib.mlqem_encode_last_error()     # and says why
