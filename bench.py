@@ -56,23 +56,9 @@ def agg_bytes(n, e_with_loops, c):
     return 4 * (n + 1) + 4 * e_with_loops + 4 * n + 4 * c * (e_with_loops + n)
 
 
-def roofline_leg(batch, reps=20):
-    """Times the dominant kernel -- the GCN-normalised CSR aggregation at C = 10 (the hidden width of the model) --
-    on the benchmark batch with HIP events on the launch stream."""
-    from blackwater.native import ops
-
-    s = batch.structure
-    n = s.num_nodes
-    e_loops = s.num_edges + n  # the self-loop of every node is one more source row (SURVEY section 8: E')
-    c = 10
-    # the GCN layer's forward aggregation exactly as the model launches it: input pre-scaled by the projection,
-    # one norm scalar per node.  Four input/output buffer pairs are rotated so that no launch finds its operands
-    # in the 256 MiB Infinity Cache left there by the previous one.
-    nbuf = 4
-    hs = [ops.padded_empty(n, c, batch.structure.in_ptr.device).normal_() for _ in range(nbuf)]   # the layout the model uses
-    outs = [ops.padded_empty(n, c, batch.structure.in_ptr.device) for _ in range(nbuf)]
-    dinv = s.gcn_dinv
-    run = lambda k: ops.csr_aggregate(hs[k % nbuf], s.in_ptr, s.in_src, ell=s.in_ell, rscale=dinv, dself=dinv, out=outs[k % nbuf])
+def _timed_launches(run, reps, nbuf):
+    """Average seconds per launch of ``run(k)`` with HIP events on the launch stream (torch's current stream IS the stream
+    the C ABI is handed, native/ops._stream); ``nbuf`` rotated operand sets are touched first."""
     for k in range(nbuf):
         run(k)
     stream = torch.cuda.current_stream()
@@ -82,10 +68,122 @@ def roofline_leg(batch, reps=20):
         run(k)
     end.record(stream)
     end.synchronize()
-    sec = beg.elapsed_time(end) * 1e-3 / reps
-    b = agg_bytes(n, e_loops, c)
+    return beg.elapsed_time(end) * 1e-3 / reps
+
+
+def in_step_aggregation_times(arena, ids, n_qubits, steps=3):
+    """Every CSR aggregation launch of a real train step timed IN the step: an eager, single-stream step of a fresh Family A
+    model on the representative batch with ``ops.csr_aggregate`` wrapped in HIP events.  Returns {variant: [us, bytes, count]}
+    (variant = what the launch carries: epilogue / z operand / self term / which CSR)."""
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import Trainer
+
+    prev = os.environ.get("MLQEM_SINGLE_STREAM")
+    os.environ["MLQEM_SINGLE_STREAM"] = "1"
+    keep_counter = ops._seed_counter
+    ops.set_seed_counter(None)
+    records = []
+    orig = ops.csr_aggregate
+    batch = arena.batch(ids)
+    st = batch.structure
+    in_ptr = st.in_ptr.data_ptr()
+    e_real = st.num_edges
+
+    def wrapped(x, ptr, idx, **kw):
+        epi = kw.get("bias") is not None or kw.get("relu") or kw.get("drop_p", 0.0) > 0
+        name = ("epilogue (bias+ReLU+dropout)" if epi else "plain") + (" +z" if kw.get("z") is not None else "") + \
+               (" +self" if kw.get("dself") is not None else "") + (" forward CSR" if ptr.data_ptr() == in_ptr else " transposed CSR")
+        n, c = x.shape
+        by = agg_bytes(n, e_real + (n if kw.get("dself") is not None else 0), c) + (4 * n * c if kw.get("z") is not None else 0)
+        b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b.record()
+        out = orig(x, ptr, idx, **kw)
+        e.record()
+        records.append((name, c, by, b, e))
+        return out
+
+    try:
+        torch.manual_seed(0)
+        tr = Trainer(ExpValCircuitGraphModelA(n_qubits, 22, 10).to(st.in_ptr.device), lr=1e-3)
+        tr.step(batch)                              # allocator warm-up, untimed
+        torch.cuda.synchronize()
+        ops.csr_aggregate = wrapped
+        for _ in range(steps):
+            tr.step(batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.csr_aggregate = orig
+        ops.set_seed_counter(keep_counter)
+        if prev is None:
+            os.environ.pop("MLQEM_SINGLE_STREAM", None)
+        else:
+            os.environ["MLQEM_SINGLE_STREAM"] = prev
+    agg = {}
+    for name, c, by, b, e in records:
+        key = f"C={c} {name}"
+        t = agg.setdefault(key, [0.0, by, 0])
+        t[0] += b.elapsed_time(e) * 1e3
+        t[2] += 1
+    del tr
+    return {k: [v[0] / v[2], v[1], v[2] // steps] for k, v in agg.items()}
+
+
+def roofline_leg(batch, arena=None, ids=None, n_qubits=100, reps=20):
+    """Times the dominant kernel -- the CSR aggregation at C = 10 (the hidden width of the model) -- on the benchmark batch with
+    HIP events on the launch stream, in each instantiation the model launches: the plain form (no epilogue; every backward
+    aggregation) and the full-epilogue form of the GCN forward (bias + ReLU + dropout: a separate instantiation built for
+    seven waves per SIMD), alone with rotated buffers and, when ``arena`` is given, inside a real single-stream train step."""
+    from blackwater.native import ops
+
+    s = batch.structure
+    n = s.num_nodes
+    e_loops = s.num_edges + n  # the self-loop of every node is one more source row (SURVEY section 8: E')
+    c = 10
+    dev = s.in_ptr.device
+    # Four input/output buffer pairs are rotated so that no launch finds its operands in the 256 MiB Infinity Cache left
+    # there by the previous one.  Operands in the padded row layout the model uses.
+    nbuf = 4
+    hs = [ops.padded_empty(n, c, dev).normal_() for _ in range(nbuf)]
+    zs = [ops.padded_empty(n, c, dev).normal_() for _ in range(nbuf)]
+    outs = [ops.padded_empty(n, c, dev) for _ in range(nbuf)]
+    bias = torch.randn(c, device=dev)
+    dinv = s.gcn_dinv
+    forms = [
+        ("csr_aggregate_ell_kernel<4,false,2,false,8> plain: GCN-normalised forward aggregation without epilogue", e_loops, 0,
+         lambda k: ops.csr_aggregate(hs[k % nbuf], s.in_ptr, s.in_src, ell=s.in_ell, rscale=dinv, dself=dinv, out=outs[k % nbuf])),
+        ("csr_aggregate_ell_kernel<4,false,2,true,7> epilogue: the GCN layer's forward launch (bias + ReLU + dropout 0.1)", e_loops, 0,
+         lambda k: ops.csr_aggregate(hs[k % nbuf], s.in_ptr, s.in_src, ell=s.in_ell, rscale=dinv, dself=dinv, bias=bias, relu=True,
+                                     drop_p=0.1, seed=1234 + k, out=outs[k % nbuf])),
+        ("plain, transposed CSR + self term: the GCN layer's backward launch", e_loops, 0,
+         lambda k: ops.csr_aggregate(hs[k % nbuf], s.out_ptr, s.out_dst, ell=s.out_ell, cscale=dinv, rscale=dinv, dself=s.derived("gcn_dself"),
+                                     out=outs[k % nbuf])),
+        ("plain, transposed CSR, no self term: the Cheb / SAGE backward launches", s.num_edges, 0,
+         lambda k: ops.csr_aggregate(hs[k % nbuf], s.out_ptr, s.out_dst, ell=s.out_ell, out=outs[k % nbuf])),
+        ("epilogue with a z operand (alpha A x + beta z): the Cheb recurrence / SAGE forward launches", s.num_edges, 4 * n * c,
+         lambda k: ops.csr_aggregate(hs[k % nbuf], s.in_ptr, s.in_src, ell=s.in_ell, z=zs[k % nbuf], alpha=2.0, beta=-1.0, out=outs[k % nbuf])),
+    ]
+    peak = 8000.0  # GB/s, MI355X HBM3E (guide: MI355X_MICROARCH.md chip table)
+    variants = []
+    for name, e_eff, extra, run in forms:
+        sec = _timed_launches(run, reps, nbuf)
+        b = agg_bytes(n, e_eff, c) + extra
+        variants.append({"launch": name, "bytes_per_launch": int(b), "us_isolated": round(sec * 1e6, 2),
+                         "GBps_isolated": round(b / sec / 1e9, 1), "frac_isolated": round(b / sec / 1e9 / peak, 4)})
+    sec = variants[0]["us_isolated"] * 1e-6
+    b = variants[0]["bytes_per_launch"]
+    in_step = None
+    if arena is not None:
+        rec = in_step_aggregation_times(arena, ids, n_qubits)
+        in_step = [{"launch": k, "launches_per_step": v[2], "bytes_per_launch": int(v[1]), "us_in_step": round(v[0], 2),
+                    "frac_in_step": round(v[1] / (v[0] * 1e-6) / 1e9 / peak, 4)} for k, v in sorted(rec.items())]
+        tot_b = sum(v[1] * v[2] for v in rec.values())
+        tot_t = sum(v[0] * v[2] for v in rec.values()) * 1e-6
+    del hs, zs, outs
     # the box's own stream-copy rate, for context (SURVEY section 8d asks for the measured peak next to the vendor one)
-    src_buf = torch.empty(256 << 20, dtype=torch.float32, device=batch.structure.in_ptr.device).normal_()
+    stream = torch.cuda.current_stream()
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    src_buf = torch.empty(256 << 20, dtype=torch.float32, device=dev).normal_()
     dst_bufs = [torch.empty_like(src_buf) for _ in range(2)]
     for k in range(2):
         dst_bufs[k].copy_(src_buf)
@@ -112,7 +210,6 @@ def roofline_leg(batch, reps=20):
     end.synchronize()
     fill_gbps = 6 * src_buf.numel() * 4 / (beg.elapsed_time(end) * 1e-3) / 1e9
     del src_buf, dst_bufs
-    peak = 8000.0  # GB/s, MI355X HBM3E (guide: MI355X_MICROARCH.md chip table)
     ach = b / sec / 1e9
     # HBM traffic per launch comes from rocprofv3 PMC passes (they cannot run inside this process); the committed
     # summary applies only if it was taken on exactly this batch.
@@ -124,14 +221,20 @@ def roofline_leg(batch, reps=20):
             traffic, src = pmc["traffic_bytes_per_launch"], os.path.relpath(PMC_SUMMARY, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE)"
     except (OSError, KeyError, ValueError):
         pass
-    out = {"bound": "hbm", "kernel": "csr_aggregate_ell_kernel<4,false,2,false,8> (GCN forward aggregation, C=10; the plain variant)",
+    out = {"bound": "hbm", "kernel": "csr_aggregate_ell_kernel<4,false,2,false,8> (the plain instantiation, timed alone; `variants` has "
+                                     "every instantiation the model launches, alone and inside a train step)",
            "achieved": round(ach, 1), "peak": peak, "unit": "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
            "traffic_source": src, "bytes_per_launch": int(b), "us_per_launch": round(sec * 1e6, 2), "nodes": n,
-           "edges_with_loops": e_loops, "measured_copy_GBps": round(copy_gbps, 1),
+           "edges_with_loops": e_loops, "variants": variants, "measured_copy_GBps": round(copy_gbps, 1),
            "measured_add_GBps": round(add_gbps, 1), "measured_fill_GBps": round(fill_gbps, 1),
            "note": "achieved/frac use ALGORITHMIC bytes (one source row per edge, no cache credit); hbm_GBps/hbm_frac "
                    "use the PMC-counted HBM traffic, i.e. what the memory system really moved (L2-served re-reads "
-                   "excluded)"}
+                   "excluded); frac_isolated = launches alone with rotated buffers, frac_in_step = the same launches inside an "
+                   "eager single-stream train step (HIP events around each call)"}
+    if in_step is not None:
+        out["in_step"] = in_step
+        out["in_step_all_aggregations"] = {"bytes_per_step": int(tot_b), "us_per_step": round(tot_t * 1e6, 1),
+                                           "frac": round(tot_b / tot_t / 1e9 / peak, 4)}
     if traffic:
         out["hbm_GBps"] = round(traffic / sec / 1e9, 1)
         out["hbm_frac"] = round(traffic / sec / 1e9 / peak, 4)
@@ -231,6 +334,18 @@ def cpu_baseline_leg(corpus, ids, n_qubits, large_batch=256):
         dt = one_step(probe)
         if best_t is None or dt < best_t:
             best_t, best_n = dt, nt
+    # SURVEY section 8d's setting, torch.set_num_threads(os.cpu_count()), printed rather than asserted: ONE bounded step on two
+    # circuits (after a one-circuit warm-up) at all cores, and the same two circuits at the best setting beside it
+    all_cores = None
+    if ncpu > best_n:
+        torch.set_num_threads(ncpu)
+        one_step(ids[:1])
+        t_all = one_step(ids[:2])
+        torch.set_num_threads(best_n)
+        one_step(ids[:2])
+        t_best = one_step(ids[:2])
+        all_cores = {"threads": ncpu, "circuits": 2, "ms_per_step": round(t_all * 1e3, 1), "circuits_per_s": round(2 / t_all, 2),
+                     "same_step_at_best_threads_ms": round(t_best * 1e3, 1), "best_threads": best_n}
     torch.set_num_threads(best_n)
     rng = np.random.RandomState(0)
     small = [one_step(rng.choice(ids, size=32, replace=False)) for _ in range(25)][5:]
@@ -242,7 +357,7 @@ def cpu_baseline_leg(corpus, ids, n_qubits, large_batch=256):
             "sample": f"batch 32 (the reference's setting): median of 20 steps after 5 warm-ups, batches drawn from the "
                       f"bench's representative batch; oracle/models.py FamilyA, fp32, full train step (collate + forward "
                       f"+ MSE + backward + Adam), torch {best_n} threads = fastest of 1/8/16/32 on this {ncpu}-core host",
-            "batch32_ms_per_step": round(med32 * 1e3, 1),
+            "batch32_ms_per_step": round(med32 * 1e3, 1), "all_cores": all_cores,
             "large_batch": {"circuits": int(len(big)), "value": round(len(big) / big_t, 2), "ms_per_step": round(big_t * 1e3, 1),
                             "sample": f"the first {len(big)} circuits of the same representative batch as ONE step, median of 2 after 1 warm-up"}}
 
@@ -259,12 +374,15 @@ def accuracy_leg(dev):
     golden = os.path.join(ROOT, "tests", "golden")
     z = load_trainval(golden)
     props = get_backend_properties_v1(StaticBackend.from_json(os.path.join(golden, "fake_lima_backend_props.json")))
+    from blackwater.metrics.accuracy import SPLIT_NOTE
+
     out = {"data": "reference circuits: docs/tutorials/data/ising_init_from_qasm_no_readout/{train/step_0,val/step_0..2}.pk, "
-                   "pooled split (510 train / 90 validation), batch 32, Adam 1e-3, 100 epochs, seed 0"}
+                   "pooled split (510 train / 90 validation), batch 32, Adam 1e-3, 100 epochs, seed 0",
+           "split": SPLIT_NOTE}
     for key, rec in (("family_b", train_family_b(z, dev)), ("mlp1", train_mlp1(z, props, dev))):
         rep = rec["report"]
         out[key] = {"model": rec["model"], "val_mse": round(rec["val_mse_final"], 6),
-                    "reference_recorded_val_mse": round(rec["reference_val_mse_final"], 6),
+                    "reference_recorded_val_mse_on_its_own_split": round(rec["reference_val_mse_final"], 6),
                     "train_mse": round(rec["train_mse_final"], 6),
                     "exp_val_mae_noisy": round(rep["MAE_noisy"], 5), "exp_val_mae_mitigated": round(rep["MAE_mitigated"], 5),
                     "rmse_noisy": round(rep["RMSE_noisy"], 5), "rmse_mitigated": round(rep["RMSE_mitigated"], 5),
@@ -340,26 +458,39 @@ def family_b_leg(dev, steps=30):
     # rows of 100-500, which the attention / ASAPooling kernels walk in chunks with one lane per edge for the scalar work
     torch.cuda.reset_peak_memory_stats()
     mem_before = torch.cuda.memory_allocated()
-    hb = TfimCorpus(100, list(range(1, 11)), 7, seed=42, exp_value_size=4).host_graphs()
+    hb = TfimCorpus(100, list(range(1, 11)), 13, seed=42, exp_value_size=4).host_graphs()
     big_arena = GraphArena.from_arrays(hb["x"], hb["edge_index"], hb["y"][:, None, :], hb["noisy"][:, None, :], hb["depth"],
-                                       hb["observable"], device=dev)
+                                       hb["observable"], device=dev, filler_nodes=1024)
     del hb
-    torch.manual_seed(0)
-    big_trainer = Trainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), lr=1e-3)
-    big_batch, big_steps = 64, max(4, steps // 3)
-    draw_big = lambda: rng.randint(0, len(big_arena), size=big_batch)
-    for _ in range(3):
-        big_trainer.step(big_arena.batch(draw_big()))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(big_steps):
-        big_trainer.step(big_arena.batch(draw_big()))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out["cfg4_100q_batch64"] = {"circuits_per_s": round(big_batch * big_steps / dt, 1), "ms_per_step": round(dt / big_steps * 1e3, 2),
-                                "steps": big_steps, "nodes_per_circuit": round(big_arena.num_nodes / len(big_arena)),
-                                "peak_mem_GB_above_the_rest_of_the_bench": round((torch.cuda.max_memory_allocated() - mem_before) / 1e9, 2)}
-    del big_trainer, big_arena
+    nb_graphs = len(big_arena)
+    big_batch, big_steps = 64, max(6, steps // 2)
+    cfg4 = {"nodes_per_circuit": round(big_arena.num_nodes / nb_graphs), "circuits_per_step": big_batch,
+            "coarsened_edge_capacity_per_node": round(float(big_arena.coarse_caps[:nb_graphs].sum()) / big_arena.num_nodes, 1)}
+    # size-stratified batches (6-7 circuits of each Trotter step count) through the bucketed trainer: eager, then captured.  The
+    # coarsened edge arrays are sized by a structural bound (GraphArena.coarse_caps), so the step reads nothing from the device
+    # and the whole of it -- assembly, two TransformerConv + ASAPooling levels, head, backward, Adam -- replays from ONE graph.
+    for graphs in (False, True):
+        torch.manual_seed(0)
+        sampler = StratifiedBatches(big_arena.node_counts[:nb_graphs], big_arena.edge_counts[:nb_graphs], big_batch, seed=13)
+        bt = BucketedTrainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), big_arena, lr=1e-3, graphs=graphs, node_quantum=1024,
+                             edge_quantum=4096)
+        for _ in range(4):
+            bt.step_ids(sampler.draw())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(big_steps):
+            last = bt.step_ids(sampler.draw())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cfg4["hipgraph" if graphs else "eager"] = {"circuits_per_s": round(big_batch * big_steps / dt, 1), "ms_per_step": round(dt / big_steps * 1e3, 2),
+                                                   "steps": big_steps, "final_loss": round(float(last.item()), 6)}
+        _ops.set_seed_counter(None)
+        del bt
+    cfg4["circuits_per_s"] = cfg4["hipgraph"]["circuits_per_s"]
+    cfg4["ms_per_step"] = cfg4["hipgraph"]["ms_per_step"]
+    cfg4["peak_mem_GB_above_the_rest_of_the_bench"] = round((torch.cuda.max_memory_allocated() - mem_before) / 1e9, 2)
+    out["cfg4_100q_batch64"] = cfg4
+    del big_arena
     # the CPU oracle doing the same step at the reference's batch size (bounded: 6 steps, the first one untimed)
     from oracle.models import FamilyB
 
@@ -415,55 +546,216 @@ def family_b_leg(dev, steps=30):
     return out
 
 
-def mlp_head_leg(dev, rows=262144, steps=20):
+def mlp_head_leg(dev, rows=262144, steps=50):
     """The MLP path of BASELINE.json's configs[0] / configs[4] (docs/tutorials/mlp.py:18-108; demo2's 169/170-wide
     `encode_data_v2_ecr` rows): MLP1(170, 128, 1) and MLP3(170, 125, 1) train steps (forward, MSE, backward, Adam) on `rows`
-    synthetic feature rows, GEMMs on the fp32 matrix cores and -- `mfma = "bf16"`, the "bf16 MFMA MLP head" of cfg5 -- on
-    v_mfma_f32_16x16x32_bf16.  Each model's GEMMs move 4 (rows (in + out) + in out) bytes and do 2 rows in out flops per
-    layer, three times per step (forward, data gradient, weight gradient): both rates are reported against their peaks --
-    at these widths (<= 170) the layers are bound by HBM, three orders of magnitude below the matrix cores' rate."""
+    synthetic feature rows, in fp32 (exact, v_mfma_f32_16x16x4_f32) and with `mfma = "bf16"` -- the "bf16 MFMA MLP head" of
+    cfg5: v_mfma_f32_16x16x32_bf16, hidden activations kept as a bf16 stash.  The step is replayed from a hipGraph
+    (train.RowsTrainer; `eager_ms_per_step` = the same step enqueued launch by launch).  GEMM model: a layer moves
+    4 (rows (in + out) + in out) bytes and does 2 rows in out flops per pass; passes = forward + weight gradient + data
+    gradient, except that the FIRST layer has no data gradient (the feature matrix needs none).  `kernels` times the two
+    launches of the one-launch MLP1 head alone (HIP events on the launch stream) against their own bytes and flops."""
+    from blackwater.native import ops as _ops
     from blackwater.nn.mlp import MLP1, MLP3
-    from blackwater.train import Trainer
-
-    class _Rows:        # the batch protocol of Trainer.step for a plain feature matrix
-        def __init__(self, x, y):
-            self.x, self.y = x, y
-
-        def model_args(self):
-            return (self.x,)
+    from blackwater.train import RowsTrainer
 
     torch.manual_seed(0)
-    from blackwater.native import ops as _ops
-
     x = _ops.padded_copy(torch.randn(rows, 170, device=dev))      # rows in the padded layout (16-byte aligned), as the arena's
     y = torch.randn(rows, 1, device=dev)
     out = {"rows_per_step": rows, "features": 170,
            "peaks": {"hbm_GBps": 8000.0, "mfma_f32_TFLOPs": 157.0, "mfma_bf16_TFLOPs": 2500.0}}
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        st = torch.cuda.current_stream()
+        beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        beg.record(st)
+        for _ in range(reps):
+            fn()
+        end.record(st)
+        end.synchronize()
+        return beg.elapsed_time(end) * 1e-3 / reps
+
+    # the two launches of the fused MLP1 head, alone
+    w1, b1 = torch.randn(128, 170, device=dev) / 13.0, torch.randn(128, device=dev)
+    w2, b2 = torch.randn(1, 128, device=dev) / 11.0, torch.randn(1, device=dev)
+    gout = torch.randn(rows, 1, device=dev)
+    kern = {}
+    for mode in ("f32", "bf16"):
+        bf = mode == "bf16"
+        _, hs, xp = _ops.mlp1_forward(x, w1, b1, w2, b2, bf16=bf)
+        tf = timed(lambda: _ops.mlp1_forward(x, w1, b1, w2, b2, bf16=bf))
+        tb = timed(lambda: _ops.mlp1_backward(gout, xp, hs, w2, 170, 128, bf16=bf))
+        by = rows * (4 * 172 + (2 if bf else 4) * 128 + 4)        # x row + stash row + output / gout, per direction
+        fl = 2 * rows * 170 * 128
+        peak = 2500.0 if bf else 157.0
+        kern[mode] = {"forward_us": round(tf * 1e6, 1), "backward_us": round(tb * 1e6, 1), "bytes_per_launch": by,
+                      "forward_frac_hbm": round(by / tf / 8e12, 3), "backward_frac_hbm": round(by / tb / 8e12, 3),
+                      "forward_frac_mfma": round(fl / tf / 1e12 / peak, 3), "backward_frac_mfma": round(fl / tb / 1e12 / peak, 3)}
+        del hs, xp
+    out["mlp1_head_kernels"] = kern
     for name, make, widths in (("mlp1_170_128_1", lambda: MLP1(170, 128, 1), [(170, 128), (128, 1)]),
                                ("mlp3_170_125_1", lambda: MLP3(170, 125, 1), [(170, 125), (125, 125), (125, 41), (41, 1)])):
-        gemm_bytes = 3 * sum(4 * (rows * (i + o) + i * o) for i, o in widths)
-        gemm_flops = 3 * sum(2 * rows * i * o for i, o in widths)
+        passes = [2] + [3] * (len(widths) - 1)       # no data gradient for the first layer
+        gemm_bytes = sum(p * 4 * (rows * (i + o) + i * o) for p, (i, o) in zip(passes, widths))
+        gemm_flops = sum(p * 2 * rows * i * o for p, (i, o) in zip(passes, widths))
         for mode in ("f32", "bf16"):
-            torch.manual_seed(1)
-            model = make().to(dev)
-            model.mfma = mode
-            tr = Trainer(model, lr=1e-3)
-            batch = _Rows(x, y)
-            for _ in range(3):
-                tr.step(batch)
-            torch.cuda.synchronize()
+            rec = {}
+            for graphs in (True, False):
+                torch.manual_seed(1)
+                model = make().to(dev)
+                model.mfma = mode
+                tr = RowsTrainer(model, lr=1e-3, graphs=graphs)
+                for _ in range(3):
+                    tr.step_rows(x, y)
+                # the rows are resident in HBM when the timed region starts: in graph mode, in the graph's own input buffers
+                xs, ys = tr.input_buffers(x.shape, y.shape) if graphs else (x, y)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    loss = tr.step_rows(xs, ys)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                if graphs:
+                    rec = {"rows_per_s": round(rows / dt, 0), "ms_per_step": round(dt * 1e3, 3), "step_mode": "hipgraph replay",
+                           "gemm_GBps_algorithmic": round(gemm_bytes / dt / 1e9, 1), "gemm_TFLOPs": round(gemm_flops / dt / 1e12, 3),
+                           "frac_of_hbm_peak": round(gemm_bytes / dt / 1e9 / 8000.0, 4),
+                           "frac_of_mfma_peak": round(gemm_flops / dt / 1e12 / (157.0 if mode == "f32" else 2500.0), 5),
+                           "final_loss": round(float(loss.item()), 6)}
+                else:
+                    rec["eager_ms_per_step"] = round(dt * 1e3, 3)
+                    rec["eager_final_loss"] = round(float(loss.item()), 6)
+                _ops.set_seed_counter(None)
+                del tr, model
+            out[f"{name}_{mode}"] = rec
+    return out
+
+
+def inference_leg(dev):
+    """The "inference" half of the path: the estimator decorators' post-processing (the reference's VQE inner loop calls it
+    once per energy evaluation: blackwater/library/ngem/estimator.py:49-84, learning/estimator.py:220-245), from OpenQASM text
+    to mitigated values.  `batched` = native C++ encoder + ONE collate + ONE device call per run() (SURVEY section 8 f1/f2);
+    `serial` = the reference's shape, one Python encode and one model call per circuit; `cpu_oracle` = the CPU restatement's
+    per-circuit loop on the same circuits (bounded samples, sizes stated).  Synthetic TFIM-Trotter circuits, 4 and 100 qubits."""
+    from blackwater.data.backends import PauliObservable
+    from blackwater.data.circuit import circuit_to_qasm
+    from blackwater.data.synthetic import synthetic_backend, tfim_circuit
+    from blackwater.data.utils import get_backend_properties_v1
+    from blackwater.library.learning.estimator import TorchLearningModelProcessor, learning
+    from blackwater.library.ngem.estimator import ngem
+    from blackwater.nn import ExpValCircuitGraphModel, ExpValCircuitGraphModelA
+    from blackwater.nn.mlp import MLP1
+    from oracle.models import FamilyA, FamilyB
+
+    class _Result:
+        def __init__(self, values):
+            self.values, self.metadata = np.asarray(values, dtype=float), [{} for _ in values]
+
+    class _Job:
+        def __init__(self, values):
+            self._values = values
+
+        def result(self):
+            return _Result(self._values)
+
+        def job_id(self):
+            return "bench"
+
+        def status(self):
+            return "DONE"
+
+    class Est:       # stand-in for a qiskit BaseEstimator (no simulator in the loop: the post-processing is what is timed)
+        def run(self, circuits, observables, parameter_values=None, **opts):
+            return self._run(circuits, observables, parameter_values or [()] * len(circuits), **opts)
+
+        def _run(self, circuits, observables, parameter_values, **opts):
+            return _Job([0.1 + 0.001 * (k % 97) for k in range(len(circuits))])
+
+    class ScalarNoisy(torch.nn.Module):
+        """The decorator hands a model ``exp_value`` as [B, 1] (ngem/estimator.py:68-82); Family B squeezes a [B, 1, k] tensor
+        (gnn.py:116): the one-output variant takes the decorator's value with one more axis."""
+
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
+            return self.inner(exp_value.unsqueeze(-1), observable, circuit_depth, nodes, edge_index, batch)
+
+    def wall(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    out = {"note": "circuits/s from OpenQASM text to mitigated values; one run() per measurement after one warm-up run"}
+    rng = np.random.RandomState(3)
+    for nq, two_q, steps_list, n_distinct in ((4, "cx", list(range(15)), 60), (100, "ecr", list(range(1, 11)), 20)):
+        backend = synthetic_backend(nq, two_q)
+        texts = [circuit_to_qasm(tfim_circuit(nq, steps_list[k % len(steps_list)], float(rng.uniform(0, 2.0)), two_q=two_q))
+                 for k in range(n_distinct)]
+        obs1 = PauliObservable("I" * (nq - 1) + "Z")
+        torch.manual_seed(0)
+        fam_a = ExpValCircuitGraphModelA(nq, 22, 10).to(dev).eval()
+        fam_b = ScalarNoisy(ExpValCircuitGraphModel(22, 15, 1)).to(dev).eval()
+        rec = {"distinct_circuits": n_distinct, "mean_ops_per_circuit": round(float(np.mean([t.count(";") for t in texts])), 0)}
+        for name, model in (("family_a", fam_a), ("family_b", fam_b)):
+            r = {}
+            est_b = ngem(Est, model, backend, batched=True)()
+            for count in (64, 1024):
+                qs = [texts[k % n_distinct] for k in range(count)]
+                ob = [obs1] * count
+                est_b.run(qs[:8], ob[:8]).result()
+                dt, vals = wall(lambda: est_b.run(qs, ob).result().values)
+                r[f"batched_{count}"] = {"circuits_per_s": round(count / dt, 1), "ms_per_run": round(dt * 1e3, 2)}
+            n_serial = 32 if nq == 4 else 4
+            est_s = ngem(Est, model, backend)()
+            qs, ob = [texts[k % n_distinct] for k in range(n_serial)], [obs1] * n_serial
+            est_s.run(qs[:2], ob[:2]).result()
+            dt, vals_s = wall(lambda: est_s.run(qs, ob).result().values)
+            r["serial"] = {"circuits": n_serial, "circuits_per_s": round(n_serial / dt, 1), "ms_per_circuit": round(dt / n_serial * 1e3, 2)}
+            vals_b = est_b.run(qs, ob).result().values
+            r["max_abs_batched_minus_serial"] = float(np.abs(np.asarray(vals_b) - np.asarray(vals_s)).max())
+            # the CPU oracle's per-circuit loop (the reference's arithmetic on the host), same circuits, bounded
+            state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            ref = (FamilyA(nq, 22, 10) if name == "family_a" else ScalarNoisy(FamilyB(22, 15, 1))).eval()
+            ref.load_state_dict(state)
+            est_c = ngem(Est, ref, backend)()
+            n_cpu = 8 if nq == 4 else 2
+            qs, ob = qs[:n_cpu], ob[:n_cpu]
             t0 = time.perf_counter()
-            for _ in range(steps):
-                loss = tr.step(batch)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-            out[f"{name}_{mode}"] = {"rows_per_s": round(rows / dt, 0), "ms_per_step": round(dt * 1e3, 3),
-                                     "gemm_GBps_algorithmic": round(gemm_bytes / dt / 1e9, 1),
-                                     "gemm_TFLOPs": round(gemm_flops / dt / 1e12, 3),
-                                     "frac_of_hbm_peak": round(gemm_bytes / dt / 1e9 / 8000.0, 4),
-                                     "frac_of_mfma_peak": round(gemm_flops / dt / 1e12 / (157.0 if mode == "f32" else 2500.0), 5),
-                                     "final_loss": round(float(loss.item()), 6)}
-            del tr, model
+            vals_c = est_c.run(qs, ob).result().values
+            dt = time.perf_counter() - t0
+            r["cpu_oracle_serial"] = {"circuits": n_cpu, "circuits_per_s": round(n_cpu / dt, 2), "ms_per_circuit": round(dt / n_cpu * 1e3, 1)}
+            r["max_abs_device_minus_cpu_oracle_f32"] = float(np.abs(np.asarray(vals_s[:n_cpu]) - np.asarray(vals_c)).max())
+            rec[name] = r
+            del est_b, est_s, est_c
+        # the MLP path: TorchLearningModelProcessor.process_batch (one feature matrix, one device call) vs process per circuit
+        props = get_backend_properties_v1(backend)
+        n_gates = len(props["gates_set"])
+        torch.manual_seed(0)
+        mlp = MLP1(8 + n_gates + 40 + 1 + (4 * nq + 1), 64, 1).to(dev).eval()
+        proc = TorchLearningModelProcessor(mlp, backend)
+        est_l = learning(Est, proc, skip_transpile=True)()
+        r = {}
+        for count in (64, 1024):
+            qs, ob = [texts[k % n_distinct] for k in range(count)], [obs1] * count
+            est_l.run(qs[:8], ob[:8]).result()
+            dt, _ = wall(lambda: est_l.run(qs, ob).result().values)
+            r[f"process_batch_{count}"] = {"circuits_per_s": round(count / dt, 1), "ms_per_run": round(dt * 1e3, 2)}
+        n_serial = 32 if nq == 4 else 8
+        qs = [texts[k % n_distinct] for k in range(n_serial)]
+        t0 = time.perf_counter()
+        for k, q in enumerate(qs):
+            proc.process(0.1, q, obs1, ())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        r["process_serial"] = {"circuits": n_serial, "circuits_per_s": round(n_serial / dt, 1), "ms_per_circuit": round(dt / n_serial * 1e3, 2)}
+        rec["learning_mlp1"] = r
+        out[f"tfim_{nq}q"] = rec
+        del fam_a, fam_b, mlp
     return out
 
 
@@ -530,7 +822,7 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="circuits per step per GPU")
     ap.add_argument("--n-j", type=int, default=0, help="J values per Trotter step count; 0 = 8 x batch x gpus / 10")
@@ -603,17 +895,28 @@ def main():
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step device times (HIP events on the step's stream)
     t0 = time.perf_counter()
     loss = None
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         loss = step()
+        marks[k + 1].record()
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_step = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)])
     loss = loss.clone()
     joined = 1
+    dp_host_ms = None
     if distributed:
+        # per-rank host time of the eager RCCL all-reduce call between the two graph replays of a step (the only eager launch of
+        # a data-parallel step), so that a multi-GPU number explains itself
+        mine = torch.tensor([trainer.host_between_replays_s / max(trainer.host_between_replays_n, 1) * 1e3], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        dp_host_ms = [round(float(v.item()), 4) for v in every]
         t = torch.tensor([elapsed, 0.0], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t[:1], op=torch.distributed.ReduceOp.MAX)
         ones = torch.ones(1, device=dev, dtype=torch.float64)
@@ -644,10 +947,14 @@ def main():
                        "mean_nodes_per_circuit": round(arena.num_nodes / n_local, 1), "parallelism": f"dp{joined}",
                        "nodes_per_step_per_gpu": sampler.nodes_per_batch, "step_mode": step_mode,
                        "sampling": "size-stratified: %s circuits of the 10 Trotter step counts per batch" % "/".join(map(str, sampler.quota)),
-                       "backend": backend, "ranks_joined": joined,
+                       "backend": backend, "ranks_joined": joined, "host_ms_between_graph_replays_per_rank": dp_host_ms,
+                       "gradient_floats_all_reduced": int(trainer.flat_grad.numel()),
                        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None},
+            "ms_per_step_percentiles": {"p10": round(float(np.percentile(per_step, 10)), 3), "p50": round(float(np.percentile(per_step, 50)), 3),
+                                        "p90": round(float(np.percentile(per_step, 90)), 3), "min": round(float(per_step.min()), 3),
+                                        "max": round(float(per_step.max()), 3), "note": "HIP events between consecutive steps on rank 0"},
             "final_loss": round(float(loss.item()), 6), "host_enqueue_ms_per_step": round(host_ms, 3),
-            "roofline": roofline_leg(fixed),
+            "roofline": roofline_leg(fixed, arena if world == 1 else None, fixed_ids(n_local, args.batch), 100),
         }
         if world == 1 and not args.no_cpu_baseline:
             rep = local_ids[fixed_ids(n_local, args.batch)]
@@ -661,6 +968,7 @@ def main():
             line["family_b"] = family_b_leg(dev)
             line["small_batch"] = small_batch_leg(dev)
             line["mlp_head"] = mlp_head_leg(dev)
+            line["inference"] = inference_leg(dev)
         print(json.dumps(line), flush=True)
     if distributed:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: leave together

@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 15 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 16 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -235,6 +235,42 @@ int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float
 int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t ldx, const void* h_stash, const float* w2,
                         float* gw1, float* gb1, float* gw2, float* gb2, int64_t N, int I, int H, int O2, int bf16,
                         void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * MLP2 / MLP3 with bf16 STORAGE (docs/tutorials/mlp.py:33-108 == blackwater/library/learning/mlp.py: fc -> BatchNorm1d -> ReLU ->
+ * Dropout blocks with a residual; `mfma = "bf16"`, the "bf16 MFMA MLP head" of the mixed-corpus configuration).  Every
+ * activation matrix -- layer outputs and what the backward re-reads -- is [N, MLQEM_MLP1_HIDDEN_PAD] bf16 (256-byte rows,
+ * 16-byte aligned, columns beyond the layer's width zero); weights, BatchNorm statistics, parameter gradients and all sums are
+ * fp32; GEMM operands are rounded to bf16 (nearest-even) and accumulated in fp32 on v_mfma_f32_16x16x32_bf16.  Dropout masks
+ * are counter-based, keyed by (seed + *seed_counter, row * 128 + column), and recomputed in the backward.  All entry points
+ * take workspace = mlqem_layer_workspace_bytes() (16-byte aligned); partial sums per workgroup, fixed-order second stages.
+ *   gemm      : Y = X W^T + b (transposed = 0, W [U,K]) or Y = X W (+ add) (transposed = 1, W [K,U]: the data gradient);
+ *               X fp32 [N,K <= 192] (ldx floats, ldx % 4 == 0) or bf16 [N,128] (K <= 128); Y bf16 [N,128] or fp32 [N,ldy].
+ *   colstats 0: batch statistics of y -> mean, biased var, invstd, scale = gamma invstd, shift = beta - mean scale.
+ *   colstats 1: with gu = g o (y scale + shift > 0) o keep / (1 - p): dbeta = sum gu, dgamma = sum gu xhat, gs = gamma invstd,
+ *               k1 = dbeta / N, k2 = dgamma / N  (g: bf16 [N,128], or fp32 [N,ldg32] when g32 != NULL).
+ *   pointwise 0: out = dropout(relu?(y scale + shift)) (+ res);   1: out = gs (gu - k1 - xhat k2)   (BatchNorm backward).
+ *   wgrad     : gw [U,K] = dY^T X, gb [U] = sum dY  (X fp32 [N,K <= 175] or bf16 [N,128], K <= 128).
+ *   rowdot    : the final O <= 4 outputs, out = h w^T + b; rowdot_bwd: gh = g w (bf16), gw = g^T h, gb = sum g. */
+size_t mlqem_layer_workspace_bytes(void);
+int mlqem_layer_gemm_bf16(const void* x, int x_is_bf16, int64_t ldx, const float* w, int transposed, const float* b,
+                          const void* add_bf16, void* y, int y_is_f32, int64_t ldy, int64_t N, int K, int U, void* workspace,
+                          size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale,
+                              const float* shift, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              float eps, int relu, float drop_p, uint64_t seed, const uint64_t* seed_counter, int64_t N, int C,
+                              float* o1, float* o2, float* o3, float* o4, float* o5, void* workspace, size_t workspace_bytes,
+                              mlqem_stream_t stream);
+int mlqem_layer_pointwise_bf16(int op, const void* y, const void* g, const float* g32, int64_t ldg32, const void* res,
+                               const float* scale, const float* shift, const float* mean, const float* invstd, const float* gs,
+                               const float* k1, const float* k2, int relu, float drop_p, uint64_t seed,
+                               const uint64_t* seed_counter, void* out, int64_t N, int C, mlqem_stream_t stream);
+int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf16, int64_t ldx, float* gw, float* gb, int64_t N, int K, int U,
+                           void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_layer_rowdot_bf16(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O,
+                            mlqem_stream_t stream);
+int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float* gw, float* gb,
+                                int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Backward of a narrow hidden layer (I, O <= 12) in ONE pass over its operands:
  *   gx[n,:] = (x[n,:] > 0 ? gate_scale : 0) * (gy[n,:] @ W)   (gate != 0; plain gy @ W otherwise)      W: [O, I]

@@ -55,10 +55,41 @@ def _ranges(starts, lengths):
     return np.repeat(np.asarray(starts, dtype=np.int64) - first, lengths) + np.arange(total, dtype=np.int64)
 
 
+def _coarse_capacities(out_ptr, out_dst, gptr, n_total) -> np.ndarray:
+    """Per graph, an upper bound on the edges of the graph ASAPooling coarsens it to, from the structure alone (computed once
+    per arena, on the device).  Cluster p is its centre and the centre's in-neighbours; (p, q) is a coarsened edge iff some
+    member u of p has u -> v or u = v for a member v of q.  A node w belongs to at most
+    1 + outdeg(w) clusters (itself, if kept, and its kept out-neighbours), so whatever top-k keeps,
+
+        #edges  <=  sum_u (1 + outdeg u) * sum_{v in N+[u] or v = u} (1 + outdeg v).
+
+    On 100-qubit TFIM circuits this is ~100 per node against ~27 real coarsened edges per node (barrier nodes have 100
+    out-edges): memory, not time -- the kernels walk the real rows.  What it buys: the coarsened edge arrays are sized on the
+    host, so the one device->host read of the wave-per-cluster coarsening (the edge total) disappears and a Family B step on
+    the headline graphs can be captured in a hipGraph."""
+    if n_total == 0:
+        return np.zeros(max(int(gptr.numel()) - 1, 0), dtype=np.int64)
+    optr = out_ptr[: n_total + 1].to(torch.int64)
+    outdeg = optr[1:] - optr[:-1]
+    od1 = outdeg + 1
+    e = int(optr[-1].item())
+    s_u = od1.clone()
+    if e > 0:
+        src = torch.repeat_interleave(torch.arange(n_total, device=optr.device), outdeg)
+        s_u.index_add_(0, src, od1[out_dst[:e].long()])
+    c = torch.zeros(n_total + 1, dtype=torch.int64, device=optr.device)
+    torch.cumsum(od1 * s_u, 0, out=c[1:])
+    g = gptr.long()
+    return (c[g[1:]] - c[g[:-1]]).cpu().numpy()
+
+
 class GraphArena:
     def __init__(self, x, node_counts, structure_arrays, nscal, y, noisy, depth, observable, edge_counts, ell=None,
-                 filler_nodes=0):
+                 filler_nodes=0, coarse_caps=None):
         self.x = x
+        # per graph: a structural upper bound on the number of edges ASAPooling's coarsened graph can have (see
+        # _coarse_capacities): lets a batch size its pooled edge arrays without reading the count back from the device
+        self.coarse_caps = None if coarse_caps is None else np.asarray(coarse_caps, dtype=np.int64)
         # the LAST graph is an edgeless, all-zero filler of `filler_nodes` nodes when filler_nodes > 0: batches padded to a
         # size bucket (batch(..., bucket=)) end in a slice of it; it is not part of len(arena)
         self.filler_nodes = int(filler_nodes)
@@ -175,7 +206,8 @@ class GraphArena:
         edge_counts = np.diff(in_ptr[gptr.long()].cpu().numpy()).astype(np.int64)
         t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
         return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops, csr.out_eid), nscal, t(y), t(noisy),
-                          t(depth), t(observable), edge_counts, ell=ell, filler_nodes=filler_nodes)
+                          t(depth), t(observable), edge_counts, ell=ell, filler_nodes=filler_nodes,
+                          coarse_caps=_coarse_capacities(out_ptr, out_dst, gptr, n_total))
 
     @staticmethod
     def from_data_list(graphs, device="cuda") -> "GraphArena":
@@ -219,14 +251,22 @@ class GraphArena:
             eb = int(bucket[1])
         return sel, nptr, eptr, nb, eb, b
 
+    def coarse_capacity(self, sel) -> Optional[int]:
+        """Upper bound on the coarsened edges of a batch of the graphs ``sel`` (None when unknown or beyond int32 indexing)."""
+        if self.coarse_caps is None:
+            return None
+        cap = int(self.coarse_caps[np.asarray(sel, dtype=np.int64)].sum())
+        return cap if cap < (1 << 30) else None
+
     def batch(self, graph_ids, bucket=None) -> DeviceBatch:
         """Gathers the graphs ``graph_ids`` (host ints, any order, repeats allowed) into one batch on the device."""
         sel, nptr, eptr, nb, eb, b_real = self.selection(graph_ids, bucket)
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.device, non_blocking=True)
         return self.assemble(packed, len(sel), nb, eb, self.node_counts[sel] if bucket is None else nptr[1:] - nptr[:-1],
-                             sel, b_real)
+                             sel, b_real, coarse_capacity=self.coarse_capacity(sel))
 
-    def assemble(self, packed: torch.Tensor, b: int, nb: int, eb: int, graph_sizes, sel_host=None, num_real=None) -> DeviceBatch:
+    def assemble(self, packed: torch.Tensor, b: int, nb: int, eb: int, graph_sizes, sel_host=None, num_real=None,
+                 coarse_capacity=None) -> DeviceBatch:
         """Device side of a batch: ``packed`` = [sel (b) | nptr (b + 1) | eptr (b + 1)] int32 on the device.  Nothing
         here reads a host value other than the shapes, so with a persistent ``packed`` buffer the whole call can sit
         inside a captured hipGraph and be replayed for another selection of the same bucket."""
@@ -253,6 +293,7 @@ class GraphArena:
                            graph_sizes=graph_sizes, out_eid=out_eid, ell=(in_ell, out_ell),
                            colsums=(nscal_b[3, :nb], nscal_b[4, :nb], nscal_b[5, :nb]),
                            derived={"gcn_dself": derived_b[0, :nb], "sage_dself": derived_b[1, :nb], "cheb_neg": derived_b[2, :nb]})
+        s.coarse_capacity = coarse_capacity
         idx = sel_d.to(torch.int64)
         nodes = ops.RowsOf(self.x, src_node[:nb])     # the feature rows stay in the arena
         return DeviceBatch(nodes, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel_host, num_real)

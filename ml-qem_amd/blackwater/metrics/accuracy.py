@@ -22,6 +22,11 @@ import torch
 from .improvement_factor import mitigation_report
 
 
+SPLIT_NOTE = ("pooled split: train = train/step_0 + 70 % of each val file, validation = the remaining 30 % (seeded). NOT the reference's "
+              "split: its recorded curves were computed on the full val files by a model trained on every Trotter step (files that are not "
+              "in the snapshot), so `reference_val_mse_final` is a convergence band, not a like-for-like comparison")
+
+
 def load_trainval(golden_dir: str) -> Dict[str, np.ndarray]:
     z = dict(np.load(os.path.join(golden_dir, "ising_trainval.npz")))
     with open(os.path.join(golden_dir, "ising_trainval_circuits.json")) as fh:
@@ -71,7 +76,7 @@ def train_family_b(z, device, epochs: int = 100, seed: int = 0, batch_size: int 
     hist = trainer.fit(arena, train_ids, val_ids, epochs=epochs, batch_size=batch_size, seed=seed)
     pred = trainer.predict(arena, val_ids).cpu().numpy()
     rep = mitigation_report(z["ideal"][val_ids], z["noisy"][val_ids], pred)
-    return {"model": "family_b(22, 15, 4)", "train_circuits": int(len(train_ids)), "val_circuits": int(len(val_ids)),
+    return {"model": "family_b(22, 15, 4)", "split": SPLIT_NOTE, "train_circuits": int(len(train_ids)), "val_circuits": int(len(val_ids)),
             "epochs": epochs, "train_mse_first": hist["train_losses"][0], "train_mse_final": hist["train_losses"][-1],
             "val_mse_first": hist["val_losses"][0], "val_mse_final": hist["val_losses"][-1],
             "reference_val_mse_final": z["ref_curves"]["gnn1"]["val_losses"][-1],
@@ -116,7 +121,7 @@ def train_mlp1(z, props, device, epochs: int = 100, seed: int = 0, batch_size: i
     with torch.no_grad():
         pred = model(X[tv]).cpu().numpy()
     rep = mitigation_report(z["ideal"][val_ids], z["noisy"][val_ids], pred)
-    return {"model": "mlp1(58, 64, 4)", "train_circuits": int(len(train_ids)), "val_circuits": int(len(val_ids)),
+    return {"model": "mlp1(58, 64, 4)", "split": SPLIT_NOTE, "train_circuits": int(len(train_ids)), "val_circuits": int(len(val_ids)),
             "epochs": epochs, "train_mse_first": hist["train"][0], "train_mse_final": hist["train"][-1],
             "val_mse_first": hist["val"][0], "val_mse_final": hist["val"][-1],
             "reference_val_mse_final": z["ref_curves"]["mlp1_smaller_2"]["val_losses"][-1],

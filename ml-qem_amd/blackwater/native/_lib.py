@@ -66,6 +66,14 @@ SIGNATURES = {
     "mlqem_mlp1_workspace_bytes": (_S, [_I, _I]),
     "mlqem_mlp1_forward": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _P, _S, _P]),
     "mlqem_mlp1_backward": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _S, _P]),
+    "mlqem_layer_workspace_bytes": (_S, []),
+    "mlqem_layer_gemm_bf16": (_I, [_P, _I, _L, _P, _I, _P, _P, _P, _I, _L, _L, _I, _I, _P, _S, _P]),
+    "mlqem_layer_colstats_bf16": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _F, _I, _F, _U, _P, _L, _I, _P, _P, _P, _P, _P,
+                                       _P, _S, _P]),
+    "mlqem_layer_pointwise_bf16": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U, _P, _P, _L, _I, _P]),
+    "mlqem_layer_wgrad_bf16": (_I, [_P, _P, _I, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
+    "mlqem_layer_rowdot_bf16": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P]),
+    "mlqem_layer_rowdot_bwd_bf16": (_I, [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_linear_bwd_fused_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _F, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_pooled_head_f32": (_I, [_P, _L, _I, _P, _L, _P]),
     "mlqem_pooled_head_bwd_f32": (_I, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _P]),
@@ -111,7 +119,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 15   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 16   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -121,6 +121,102 @@ def mlp1(x, w1, b1, w2, b2, mfma="f32"):
     return _MLP1.apply(x, w1, b1, w2, b2, mfma == "bf16")
 
 
+class _MLPTrunkBf16(Function):
+    """MLP2 / MLP3 in training mode with bf16 storage (csrc/mlp_layers.hip): fc1 -> bn1 -> relu -> drop -> fc2 -> bn2 -> relu -> drop
+    (+ residual) -> [fc3 -> relu -> drop -> fc4 | fc3], one autograd node.  Every activation it writes or saves is a [N, 128]
+    bfloat16 matrix; the dropout masks are recomputed from their counters in the backward.  Returns (out, mean1, var1, mean2,
+    var2) -- the batch statistics feed the running buffers."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, w4, b4):
+        eps1, eps2, p_trunk, p_tail, seeds = cfg
+        n, i = x.shape
+        h = w1.shape[0]
+        xin = x if x.dtype == torch.bfloat16 else ops._mlp1_x(x)
+        y1 = ops.layer_gemm_bf16(xin, w1.contiguous(), b1)
+        m1, v1, is1, sc1, sh1 = ops.layer_colstats_fwd(y1, g1, be1, eps1, n, h)
+        x1 = ops.layer_act_bf16(y1, sc1, sh1, n, h, True, p_trunk, seeds[0])
+        y2 = ops.layer_gemm_bf16(x1, w2.contiguous(), b2)
+        m2, v2, is2, sc2, sh2 = ops.layer_colstats_fwd(y2, g2, be2, eps2, n, h)
+        s = ops.layer_act_bf16(y2, sc2, sh2, n, h, True, p_trunk, seeds[1], res=x1)
+        if w4 is None:                      # MLP2: out = fc3(s)
+            out = ops.layer_rowdot_bf16(s, w3.contiguous(), b3, n)
+            y3 = h3 = None
+        else:                               # MLP3: out = fc4(drop(relu(fc3(s))))
+            h3w = w3.shape[0]
+            y3 = ops.layer_gemm_bf16(s, w3.contiguous(), b3)
+            ctx.one, ctx.zero = torch.ones(ops.LAYER_W, device=x.device), torch.full((ops.LAYER_W,), 0.0, device=x.device)
+            h3 = ops.layer_act_bf16(y3, ctx.one, ctx.zero, n, h3w, True, p_tail, seeds[2])
+            out = ops.layer_rowdot_bf16(h3, w4.contiguous(), b4, n)
+        ctx.cfg, ctx.dims = cfg, (n, i, h)
+        ctx.x_needs_grad = ctx.needs_input_grad[0]
+        ctx.save_for_backward(xin, y1, x1, y2, s, y3, h3, w1, w2, w3, w4, g1, g2, m1, is1, sc1, sh1, m2, is2, sc2, sh2)
+        ctx.mark_non_differentiable(m1, v1, m2, v2)
+        return out, m1[:h], v1[:h], m2[:h], v2[:h]
+
+    @staticmethod
+    def backward(ctx, gout, *_):
+        xin, y1, x1, y2, s, y3, h3, w1, w2, w3, w4, g1, g2, m1, is1, sc1, sh1, m2, is2, sc2, sh2 = ctx.saved_tensors
+        eps1, eps2, p_trunk, p_tail, seeds = ctx.cfg
+        n, i, h = ctx.dims
+        gout = ops.rowmajor(gout)
+        if w4 is None:
+            gs, gw3, gb3 = ops.layer_rowdot_bwd_bf16(gout, s, w3.contiguous(), n)
+            gw4 = gb4 = None
+        else:
+            h3w = w3.shape[0]
+            gh3, gw4, gb4 = ops.layer_rowdot_bwd_bf16(gout, h3, w4.contiguous(), n)
+            dy3 = ops.layer_bwd_apply_bf16(gh3, y3, ctx.one, ctx.zero, ctx.zero, ctx.one, ctx.one, ctx.zero, ctx.zero, n, h3w, True,
+                                           p_tail, seeds[2])
+            gw3, gb3 = ops.layer_wgrad_bf16(dy3, s, h3w, h)
+            gs = ops.layer_gemm_bf16(dy3, w3.contiguous(), transposed=True)
+        # block 2: s = x1 + drop(relu(bn2(fc2 x1)))
+        db2, dg2, gs2, k1, k2 = ops.layer_colstats_bwd(gs, y2, sc2, sh2, m2, is2, g2, True, p_trunk, seeds[1], n, h)
+        dy2 = ops.layer_bwd_apply_bf16(gs, y2, sc2, sh2, m2, is2, gs2, k1, k2, n, h, True, p_trunk, seeds[1])
+        gw2, gb2 = ops.layer_wgrad_bf16(dy2, x1, h, h)
+        gx1 = ops.layer_gemm_bf16(dy2, w2.contiguous(), transposed=True, add=gs)       # + the residual path
+        # block 1: x1 = drop(relu(bn1(fc1 x)))
+        db1, dg1, gs1, k1, k2 = ops.layer_colstats_bwd(gx1, y1, sc1, sh1, m1, is1, g1, True, p_trunk, seeds[0], n, h)
+        dy1 = ops.layer_bwd_apply_bf16(gx1, y1, sc1, sh1, m1, is1, gs1, k1, k2, n, h, True, p_trunk, seeds[0])
+        gw1, gb1 = ops.layer_wgrad_bf16(dy1, xin, h, i)
+        gx = ops.layer_gemm_bf16(dy1, w1.contiguous(), transposed=True, out_f32=True) if ctx.x_needs_grad else None
+        return (gx, None, gw1, gb1, dg1[:h], db1[:h], gw2, gb2, dg2[:h], db2[:h], gw3, gb3, gw4, gb4)
+
+
+def mlp_trunk_bf16_ok(x, fc1, fc2, fc3, fc4, bn1, bn2) -> bool:
+    """Whether the bf16-storage pipeline takes this call: widths inside the kernels' limits, affine BatchNorm with a momentum."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 2):
+        return False
+    i, h = fc1.weight.shape[1], fc1.weight.shape[0]
+    last = fc3 if fc4 is None else fc4
+    if h > 128 or last.weight.shape[0] > ops.MLP1_MAX_OUT or i > (128 if x.requires_grad else ops.MLP1_MAX_IN):
+        return False
+    if fc4 is not None and fc3.weight.shape[0] > 128:
+        return False
+    for bn in (bn1, bn2):
+        if bn.weight is None or bn.momentum is None:
+            return False
+    return os.environ.get("MLQEM_MLP_BF16_STORAGE", "1") != "0"
+
+
+def mlp_trunk_bf16(x, fc1, bn1, fc2, bn2, fc3, fc4, p_trunk, p_tail, seeds):
+    """Runs the block and updates the BatchNorm running statistics like torch (momentum, unbiased variance, batch counter)."""
+    cfg = (float(bn1.eps), float(bn2.eps), float(p_trunk), float(p_tail), tuple(int(v) for v in seeds))
+    w4, b4 = (None, None) if fc4 is None else (fc4.weight, fc4.bias)
+    out, m1, v1, m2, v2 = _MLPTrunkBf16.apply(x, cfg, fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight,
+                                              bn2.bias, fc3.weight, fc3.bias, w4, b4)
+    n = x.shape[0]
+    with torch.no_grad():
+        for bn, mean, var in ((bn1, m1, v1), (bn2, m2, v2)):
+            if bn.track_running_stats and bn.running_mean is not None:
+                mo = bn.momentum
+                bn.running_mean.mul_(1.0 - mo).add_(mean, alpha=mo)
+                bn.running_var.mul_(1.0 - mo).add_(var, alpha=mo * n / (n - 1))
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+    return out
+
+
 class _ReluDropoutAdd(Function):
     """s = dropout(relu(u)) (+ residual) as one launch; the backward recovers the mask from the saved activation."""
 
@@ -596,7 +692,7 @@ class _ASAPool(Function):
                   and int(sizes.max()) + int(keep.max()) + 64 <= ops.asap_rows_max_bits()):
                 # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)
                 csr, slot, num_edges = ops.asap_coarsen_rows(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm,
-                                                             n, sizes, keep)
+                                                             n, sizes, keep, capacity=getattr(s, "coarse_capacity", None))
             else:
                 ei, slot = ops.asap_coarsen(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, perm, n, return_slot=True)
                 csr = ops.csr_build(ei, k_total)

@@ -507,6 +507,126 @@ def mlp1_backward(gout, x, hs, w2, i, h, bf16=False):
     return gw1, gb1, gw2, gb2
 
 
+# ---- bf16-storage layers of MLP2 / MLP3 (csrc/mlp_layers.hip): every activation is a [N, 128] bfloat16 matrix
+LAYER_W = 128
+
+
+def _layer_ws(device):
+    need = _lib.load().mlqem_layer_workspace_bytes()
+    return _wgrad_workspace(device, need), need
+
+
+def _act(n, device):
+    return torch.empty((max(n, 1), LAYER_W), dtype=torch.bfloat16, device=device)
+
+
+def _seed_args(drop_p, seed):
+    return float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, (_p(_seed_counter) if drop_p > 0 else None)
+
+
+def layer_gemm_bf16(x, w, b=None, *, transposed=False, add=None, out_f32=False):
+    """Y = X W^T + b (W [U, K]) or, ``transposed``, Y = X W (+ add) (W [K, U]: the data gradient).  X: fp32 [N, K] (padded rows)
+    or a bf16 activation [N, 128]; returns a bf16 activation [N, 128] or, ``out_f32``, fp32 [N, U]."""
+    x_bf16 = x.dtype == torch.bfloat16
+    n = x.shape[0]
+    k, u = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    if x_bf16:
+        if tuple(x.shape[1:]) != (LAYER_W,) or not x.is_contiguous():
+            raise ValueError("layer_gemm_bf16: a bf16 input must be a contiguous [N, 128] activation")
+        ldx = LAYER_W
+    else:
+        x = _mlp1_x(x)
+        if x.shape[1] != k:
+            raise ValueError(f"layer_gemm_bf16: x has {x.shape[1]} columns, w wants {k}")
+        ldx = _mat(x, "x") if n > 1 else (k + 3) // 4 * 4
+    if not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
+        raise ValueError("layer_gemm_bf16: w must be a contiguous fp32 cuda tensor")
+    y = torch.empty((n, u), dtype=torch.float32, device=w.device) if out_f32 else _act(n, w.device)
+    ws, need = _layer_ws(w.device)
+    code = _lib.load().mlqem_layer_gemm_bf16(_p(x), 1 if x_bf16 else 0, ldx, _p(w), 1 if transposed else 0, _p(b), _p(add), _p(y),
+                                             1 if out_f32 else 0, u, n, k, u, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_layer_gemm_bf16")
+    return y
+
+
+def layer_colstats_fwd(y, gamma, beta, eps, n, c):
+    """(mean, var, invstd, scale, shift) of the first ``c`` columns of the bf16 activation ``y`` over ``n`` rows."""
+    dev = y.device
+    o = [torch.zeros(LAYER_W, dtype=torch.float32, device=dev) for _ in range(5)]
+    ws, need = _layer_ws(dev)
+    code = _lib.load().mlqem_layer_colstats_bf16(0, _p(y), None, None, 0, None, None, None, None, _p(gamma), _p(beta), float(eps), 0, 0.0, 0,
+                                                 None, n, c, *[_p(t) for t in o], _p(ws), need, _stream())
+    _lib.check(code, "mlqem_layer_colstats_bf16")
+    return o
+
+
+def layer_colstats_bwd(g, y, scale, shift, mean, invstd, gamma, relu, drop_p, seed, n, c):
+    """(dbeta, dgamma, gs, k1, k2) of a BatchNorm block from the incoming gradient ``g`` (bf16 activation or fp32 [N, c]) and ``y``."""
+    dev = y.device
+    o = [torch.zeros(LAYER_W, dtype=torch.float32, device=dev) for _ in range(5)]
+    ws, need = _layer_ws(dev)
+    g16, g32, ld = (g, None, 0) if g.dtype == torch.bfloat16 else (None, g, _mat(g, "g") if n > 1 else c)
+    code = _lib.load().mlqem_layer_colstats_bf16(1, _p(y), _p(g16), _p(g32), ld, _p(scale), _p(shift), _p(mean), _p(invstd), _p(gamma), None,
+                                                 0.0, 1 if relu else 0, *_seed_args(drop_p, seed), n, c, *[_p(t) for t in o], _p(ws),
+                                                 need, _stream())
+    _lib.check(code, "mlqem_layer_colstats_bf16")
+    return o
+
+
+def layer_act_bf16(y, scale, shift, n, c, relu=True, drop_p=0.0, seed=0, res=None):
+    """drop(relu(y scale + shift)) (+ res) as a new bf16 activation."""
+    out = _act(n, y.device)
+    code = _lib.load().mlqem_layer_pointwise_bf16(0, _p(y), None, None, 0, _p(res), _p(scale), _p(shift), None, None, None, None, None,
+                                                  1 if relu else 0, *_seed_args(drop_p, seed), _p(out), n, c, _stream())
+    _lib.check(code, "mlqem_layer_pointwise_bf16")
+    return out
+
+
+def layer_bwd_apply_bf16(g, y, scale, shift, mean, invstd, gs, k1, k2, n, c, relu=True, drop_p=0.0, seed=0):
+    """dy = gs (gu - k1 - xhat k2) as a bf16 activation (gs = 1, k1 = k2 = 0: dy = gu, a block without BatchNorm)."""
+    out = _act(n, y.device)
+    g16, g32, ld = (g, None, 0) if g.dtype == torch.bfloat16 else (None, g, _mat(g, "g") if n > 1 else c)
+    code = _lib.load().mlqem_layer_pointwise_bf16(1, _p(y), _p(g16), _p(g32), ld, None, _p(scale), _p(shift), _p(mean), _p(invstd), _p(gs),
+                                                  _p(k1), _p(k2), 1 if relu else 0, *_seed_args(drop_p, seed), _p(out), n, c, _stream())
+    _lib.check(code, "mlqem_layer_pointwise_bf16")
+    return out
+
+
+def layer_wgrad_bf16(dy, x, u, k):
+    """(gw [u, k], gb [u]) = (dy^T x, sum dy) with dy a bf16 activation and x fp32 [N, k] (padded rows) or a bf16 activation."""
+    n = dy.shape[0] if x.dtype == torch.bfloat16 else x.shape[0]
+    x_bf16 = x.dtype == torch.bfloat16
+    ldx = LAYER_W if x_bf16 else (_mat(x, "x") if n > 1 else (k + 3) // 4 * 4)
+    gw = torch.empty((u, k), dtype=torch.float32, device=dy.device)
+    gb = torch.empty(u, dtype=torch.float32, device=dy.device)
+    ws, need = _layer_ws(dy.device)
+    code = _lib.load().mlqem_layer_wgrad_bf16(_p(dy), _p(x), 1 if x_bf16 else 0, ldx, _p(gw), _p(gb), n, k, u, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_layer_wgrad_bf16")
+    return gw, gb
+
+
+def layer_rowdot_bf16(h, w, b, n):
+    o, c = w.shape
+    out = torch.empty((n, o), dtype=torch.float32, device=h.device)
+    code = _lib.load().mlqem_layer_rowdot_bf16(_p(h), _p(w), _p(b), _p(out), o, n, c, o, _stream())
+    _lib.check(code, "mlqem_layer_rowdot_bf16")
+    return out
+
+
+def layer_rowdot_bwd_bf16(g, h, w, n):
+    """(gh bf16 activation, gw [O, C], gb [O]) of out = h w^T + b."""
+    o, c = w.shape
+    g = rowmajor(g)
+    gh = _act(n, h.device)
+    gw = torch.empty((o, c), dtype=torch.float32, device=h.device)
+    gb = torch.empty(o, dtype=torch.float32, device=h.device)
+    ws, need = _layer_ws(h.device)
+    code = _lib.load().mlqem_layer_rowdot_bwd_bf16(_p(g), int(g.stride(0)) if n > 1 else o, _p(h), _p(w), _p(gh), _p(gw), _p(gb), n, c, o,
+                                                   _p(ws), need, _stream())
+    _lib.check(code, "mlqem_layer_rowdot_bwd_bf16")
+    return gh, gw, gb
+
+
 _pool_ws = {}   # (device, stream, bytes) -> partial-sum workspace of the pooling kernels (per stream, like _wgrad_ws)
 
 
@@ -840,10 +960,13 @@ def asap_coarsen_dense(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
     return CsrArrays(in_ptr, in_src, out_ptr, out_dst, loops, out_eid), slot, cap
 
 
-def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, graph_sizes, keep_sizes):
+def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, graph_sizes, keep_sizes,
+                      capacity=None):
     """The same pooled structure arrays for LARGE graphs (mlqem_asap_coarsen_rows_count / _fill: one wave per cluster, bitsets
     in LDS, no sort): ONE 4-byte device->host read (the edge total) instead of the two-hop path's four reads and two
-    64-bit sorts.  Returns (CsrArrays, slot, number of edges)."""
+    64-bit sorts -- and NONE when the caller knows an upper bound ``capacity`` on the edge total (GraphArena.coarse_capacity):
+    the edge arrays are then sized to it and the true total stays on the device (in_ptr[k]).  Returns (CsrArrays, slot,
+    number of edges or the capacity)."""
     import numpy as np
 
     keep = np.asarray(keep_sizes, dtype=np.int64)
@@ -860,9 +983,12 @@ def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_g
                                              _p(new_graph_ptr), _p(perm), num_nodes, k, b, nmax, kmax, _p(slot), _p(in_ptr),
                                              _p(out_ptr), _p(ws), need, _stream())
     _lib.check(code, "mlqem_asap_coarsen_rows_count")
-    e = int(out_ptr[k].item()) if k > 0 else 0
+    if capacity is None:
+        e = int(out_ptr[k].item()) if k > 0 else 0
+    else:
+        e = int(capacity) if k > 0 else 0
     in_src, out_dst, out_eid = mk(e), mk(e), mk(e)
-    loops = torch.zeros(max(k, 1), dtype=torch.int32, device=dev)
+    loops = torch.full((max(k, 1),), 0, dtype=torch.int32, device=dev)      # a fill kernel, not a memset node (the call may be captured)
     if e > 0:
         code = lib.mlqem_asap_coarsen_rows_fill(_p(new_graph_ptr), k, b, kmax, _p(in_ptr), _p(out_ptr), _p(in_src), _p(out_dst),
                                                 _p(out_eid), _p(ws), need, _stream())

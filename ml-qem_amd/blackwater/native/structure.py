@@ -53,6 +53,7 @@ class GraphStructure:
         return "_build" not in self.__dict__
 
     def _init_rest(self, norms, graph_sizes, ell, colsums, derived):
+        self.coarse_capacity = None   # host-side upper bound on the edges of this structure's ASAPooling coarsening (data/arena.py)
         self._norms = norms
         self._derived = {} if derived is None else dict(derived)
         self._colsum = {} if colsums is None else dict(zip(("gcn", "sage", "cheb"), colsums))

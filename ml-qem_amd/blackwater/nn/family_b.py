@@ -90,6 +90,7 @@ class _FamilyB(nn.Module):
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         self.transformer1.static_dropout_key = self.transformer2.static_dropout_key = getattr(self, "static_dropout_key", False)
+        self.body_seq.static_dropout_key = getattr(self, "static_dropout_key", False)      # an MLP2 / MLP3 head draws masks too
         g = self.transformer1(nodes, s)
         g, s, _ = self.pooling1(g, s)
         g = self.transformer2(g, s)

@@ -14,9 +14,11 @@ their epilogues wherever the maths allows:
   (``F.relu_dropout_add``), its mask keyed by torch's seed like every dropout of this build.
 
 ``model.mfma = "bf16"`` (default ``"f32"``) sends the GEMMs -- forward, data gradient and weight gradient -- to the bf16
-matrix cores (v_mfma_f32_16x16x32_bf16): operands rounded to bf16 in registers, fp32 accumulation, fp32 tensors in
-memory: the "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus configuration.  Results then differ from the fp32 path
-at the 1e-2 level, so it is an opt-in.
+matrix cores (v_mfma_f32_16x16x32_bf16): operands rounded to bf16, fp32 accumulation, fp32 master weights -- the "bf16 MFMA MLP
+head" of BASELINE.json's mixed-corpus configuration.  In training mode the hidden activations are STORED as bf16 too (MLP1: the
+one-launch head's stash, csrc/mlp_head.hip; MLP2 / MLP3: the bf16-storage pipeline of csrc/mlp_layers.hip with BatchNorm, ReLU,
+dropout and the residual in one pass per block): these layers are bound by HBM, so half the bytes is what makes the mode
+faster than fp32.  Results differ from the fp32 path at the 1e-2 level, so it is an opt-in.
 """
 from __future__ import annotations
 
@@ -75,14 +77,35 @@ class MLP2(nn.Module):
         self._calls = getattr(self, "_calls", 0) + 1
         from .models import dropout_key
 
+        # static_dropout_key: the step counter lives on the device (train.RowsTrainer replays the step from a hipGraph, where a
+        # host counter would freeze the masks); the layer's position keeps the two masks of one step apart
+        call = (1 if residual is None else 2) if getattr(self, "static_dropout_key", False) else self._calls
         u = F.batch_norm_train(F.linear(x, fc.weight, fc.bias, mfma=self.mfma), bn)
-        return F.relu_dropout_add(u, residual, self.p, dropout_key(self._calls, salt=0x4D4C50))
+        return F.relu_dropout_add(u, residual, self.p, dropout_key(call, salt=0x4D4C50))
 
     def trunk(self, x):
         x1 = self._layer(x, self.fc1, self.bn1)
         return self._layer(x1, self.fc2, self.bn2, residual=x1)
 
+    def _bf16_storage(self, x, fc4=None, p_tail=0.0):
+        """``mfma == "bf16"`` in training mode: the whole block on the bf16-storage kernels (csrc/mlp_layers.hip) -- layer outputs
+        and everything kept for the backward as bfloat16, half the bytes of every pass.  None when the shapes are not theirs."""
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        if not (self.training and self.mfma == "bf16" and F.mlp_trunk_bf16_ok(x2, self.fc1, self.fc2, self.fc3, fc4, self.bn1, self.bn2)):
+            return None
+        from .models import dropout_key
+
+        self._calls = getattr(self, "_calls", 0) + 1
+        static = getattr(self, "static_dropout_key", False)
+        seeds = [dropout_key((k + 1) if static else 3 * self._calls + k, salt=0x4D4C50) for k in range(3)]
+        out = F.mlp_trunk_bf16(x2, self.fc1, self.bn1, self.fc2, self.bn2, self.fc3, fc4, self.p, p_tail, seeds)
+        return out.reshape(*lead, out.shape[-1])
+
     def forward(self, x):
+        out = self._bf16_storage(x)
+        if out is not None:
+            return out
         return F.linear(self.trunk(x), self.fc3.weight, self.fc3.bias, mfma=self.mfma)
 
 
@@ -93,5 +116,19 @@ class MLP3(MLP2):
         self.fc4 = _fc(hidden_size // 3, output_size)
 
     def forward(self, x):
-        h = F.linear(self.trunk(x), self.fc3.weight, self.fc3.bias, relu=True, mfma=self.mfma)
-        return F.linear(self._drop(h), self.fc4.weight, self.fc4.bias, mfma=self.mfma)
+        out = self._bf16_storage(x, self.fc4, self.p)
+        if out is not None:
+            return out
+        t = self.trunk(x)
+        if self.training and self.p > 0:
+            # dropout(relu(fc3 t)) with the counter-based masks of this build (one launch, keyed like the trunk's: a captured
+            # step replays with fresh masks, which torch's generator-driven nn.functional.dropout does not give bit for bit)
+            from .models import dropout_key
+
+            self._calls = getattr(self, "_calls", 0) + 1
+            call = 3 if getattr(self, "static_dropout_key", False) else self._calls
+            u = F.linear(t, self.fc3.weight, self.fc3.bias, mfma=self.mfma)
+            h = F.relu_dropout_add(u, None, self.p, dropout_key(call, salt=0x4D4C50))
+        else:
+            h = F.linear(t, self.fc3.weight, self.fc3.bias, relu=True, mfma=self.mfma)
+        return F.linear(h, self.fc4.weight, self.fc4.bias, mfma=self.mfma)

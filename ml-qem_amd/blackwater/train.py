@@ -13,6 +13,7 @@ from __future__ import annotations
 import math
 import os
 import pickle
+import time
 from typing import Callable, Iterable, List, Optional
 
 import numpy as np
@@ -274,6 +275,104 @@ class Trainer:
         return history
 
 
+class RowsTrainer(Trainer):
+    """Training of a feature-matrix model (MLP1 / MLP2 / MLP3: docs/tutorials/mlp.py, trained in h10_mlp.ipynb cells [10]-[13]
+    on fixed-size batches of ``encode_data`` rows) with the WHOLE step -- forward, MSE, backward, gradient filing, Adam --
+    captured once per batch shape in a hipGraph and replayed: the host copies the batch into the graph's input buffers and
+    launches one graph.  An MLP1 step on 262 144 rows is ~0.15-0.35 ms of device work in 6 kernels, and ~0.3 ms of Python when
+    enqueued launch by launch.  Same mechanics as :class:`BucketedTrainer`: Adam with device-resident step count and learning
+    rate, dropout masks keyed by a device-resident counter bumped inside the graph, three eager warm-up iterations that leave
+    no trace.  ``graphs=False`` runs the identical step eagerly (bit-identical losses)."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-3, graphs: bool = True, distributed: bool = False):
+        super().__init__(model, lr=lr, distributed=distributed, flat=True, capturable=True)
+        from .native import ops
+
+        self.graphs = graphs
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.flat_param.device)
+        ops.set_seed_counter(self.counter)
+        model.static_dropout_key = True
+        self._entries = {}
+        self._warm = False
+
+    class _Rows:
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+        def model_args(self):
+            return (self.x,)
+
+    def _step_on(self, batch):
+        self.counter.add_(1)
+        loss = self._forward_backward(batch)
+        if self.distributed:
+            self.all_reduce_gradients()
+        self.optimizer.step()
+        return loss
+
+    def step_rows(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on the rows ``x`` [N, F] with targets ``y``; returns the loss (in graph mode a device
+        tensor the next step of the same shape overwrites: read or clone it before stepping again)."""
+        from .native import ops
+
+        if not self.graphs or self.distributed:      # under data parallelism the collective sits inside the step: eager
+            # the rows in the padded layout the captured step reads them in: the same kernels, the same sums, the same bits
+            return self._step_on(self._Rows(ops._mlp1_x(x) if x.dtype == torch.float32 else x, y))
+
+        key = (tuple(x.shape), tuple(y.shape))
+        entry = self._entries.get(key)
+        if entry is None:
+            xs = ops.padded_empty(x.shape[0], x.shape[1], x.device)
+            ys = torch.empty_like(y)
+            xs.copy_(x)
+            ys.copy_(y)
+            batch = self._Rows(xs, ys)
+            if not self._warm:
+                dev = self.flat_param.device
+                keep = (self.flat_param.detach().clone(), self.counter.clone(), torch.cuda.get_rng_state(dev))
+                opt_keep = {id(st): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for st in self.optimizer.state.values()}
+                buf_keep = [b.detach().clone() for b in self.model.buffers()]
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        self._step_on(batch)
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.no_grad():
+                    self.flat_param.copy_(keep[0])
+                    self.counter.copy_(keep[1])
+                    for st in self.optimizer.state.values():
+                        saved = opt_keep.get(id(st))
+                        for k, v in st.items():
+                            if torch.is_tensor(v):
+                                if saved is not None and torch.is_tensor(saved.get(k)):
+                                    v.copy_(saved[k])
+                                else:
+                                    v.zero_()
+                    for b, kept in zip(self.model.buffers(), buf_keep):
+                        b.copy_(kept)
+                torch.cuda.synchronize()
+                torch.cuda.set_rng_state(keep[2], dev)
+                self._warm = True
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self._step_on(batch)
+            entry = self._entries[key] = {"graph": graph, "x": xs, "y": ys, "loss": loss}
+        else:
+            if x.data_ptr() != entry["x"].data_ptr():
+                entry["x"].copy_(x)
+            if y.data_ptr() != entry["y"].data_ptr():
+                entry["y"].copy_(y)
+        entry["graph"].replay()
+        return entry["loss"]
+
+    def input_buffers(self, x_shape, y_shape):
+        """The graph's own input buffers for a batch shape (after its first step): a caller that assembles its batch directly
+        in them (an index-select with ``out=``) saves the copy."""
+        e = self._entries.get((tuple(x_shape), tuple(y_shape)))
+        return (e["x"], e["y"]) if e else None
+
+
 class StratifiedBatches:
     """Batches that all hold the same number of graphs of every SIZE (node count, edge count): a size-stratified sampler.
 
@@ -369,6 +468,7 @@ class BucketedTrainer(Trainer):
         # batch is a new one.  So such a pattern is run EAGERLY the first time it is seen (which also leaves its pooled graph
         # boundaries on the device: native/functional._device_ptr) and captured only when it comes back, and at most
         # ``max_pattern_captures`` patterns are ever captured (each holds a graph and a pinned ring): the rest stay eager.
+        self.host_between_replays_s, self.host_between_replays_n = 0.0, 0
         self._pattern_model = bool(getattr(model, "needs_size_pattern", False))
         self.max_pattern_captures = int(os.environ.get("MLQEM_MAX_PATTERN_CAPTURES", "64"))
         self._seen = {}
@@ -379,20 +479,21 @@ class BucketedTrainer(Trainer):
         key = (-(-nb // self.nq) * self.nq, -(-max(eb, 1) // self.eq) * self.eq, len(sel))
         if getattr(self.model, "needs_size_pattern", False):
             # models whose launch shapes depend on every graph's size (Family B: ASAPooling keeps ceil(n_g / 2) clusters per
-            # graph) replay a capture only for the same SEQUENCE of sizes -- what StratifiedBatches produces batch after batch
-            key += (self.arena.node_counts[sel].tobytes(),)
+            # graph) replay a capture only for the same SEQUENCE of sizes -- what StratifiedBatches produces batch after batch --
+            # and the same capacity of the coarsened edge arrays (a structural bound per graph: GraphArena.coarse_capacity)
+            key += (self.arena.node_counts[sel].tobytes(), self.arena.coarse_capacity(sel))
         return key
 
-    def _step_on(self, packed, b, n_pad, e_pad, sizes, num_real):
-        loss = self._local_half(packed, b, n_pad, e_pad, sizes, num_real)
+    def _step_on(self, packed, b, n_pad, e_pad, sizes, num_real, cap=None):
+        loss = self._local_half(packed, b, n_pad, e_pad, sizes, num_real, cap)
         if self.distributed:
             self.all_reduce_gradients()
         self.optimizer.step()
         return loss
 
-    def _local_half(self, packed, b, n_pad, e_pad, sizes, num_real):
+    def _local_half(self, packed, b, n_pad, e_pad, sizes, num_real, cap=None):
         self.counter.add_(1)
-        batch = self.arena.assemble(packed, b, n_pad, e_pad, sizes, None, num_real)
+        batch = self.arena.assemble(packed, b, n_pad, e_pad, sizes, None, num_real, coarse_capacity=cap)
         return self._forward_backward(batch)
 
     def _warm_up(self, ids, bucket):
@@ -411,7 +512,7 @@ class BucketedTrainer(Trainer):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                self._step_on(packed, len(sel), nb, eb, nptr[1:] - nptr[:-1], real)
+                self._step_on(packed, len(sel), nb, eb, nptr[1:] - nptr[:-1], real, bucket[4] if len(bucket) > 4 else None)
         torch.cuda.current_stream().wait_stream(side)
         with torch.no_grad():
             self.flat_param.copy_(keep[0])
@@ -437,6 +538,7 @@ class BucketedTrainer(Trainer):
         sel, nptr, eptr, nb, eb, real = self.arena.selection(graph_ids, bucket[:2])
         host = np.concatenate([sel, nptr, eptr]).astype(np.int32)
         sizes = nptr[1:] - nptr[:-1]
+        cap = bucket[4] if len(bucket) > 4 else None
         entry = self._entries.get(bucket) if self.graphs else None
         eager = not self.graphs
         if self.graphs and entry is None and self._pattern_model:
@@ -447,7 +549,7 @@ class BucketedTrainer(Trainer):
             eager = first_sight or len(self._entries) >= self.max_pattern_captures
         if eager:
             packed = torch.from_numpy(host).to(self.flat_param.device, non_blocking=True)
-            return self._step_on(packed, len(sel), nb, eb, sizes, real)
+            return self._step_on(packed, len(sel), nb, eb, sizes, real, cap)
         if entry is None:
             if not self._warm:
                 self._warm_up(graph_ids, bucket)
@@ -461,10 +563,10 @@ class BucketedTrainer(Trainer):
             kw = {} if self._pool is None else {"pool": self._pool}
             if not self.split:
                 with torch.cuda.graph(entry["graph"], **kw):
-                    entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real)
+                    entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap)
             else:
                 with torch.cuda.graph(entry["graph"], **kw):
-                    entry["loss"] = self._local_half(entry["packed"], len(sel), nb, eb, sizes, real)
+                    entry["loss"] = self._local_half(entry["packed"], len(sel), nb, eb, sizes, real, cap)
             if self._pool is None:
                 self._pool = entry["graph"].pool()
             if self.split and self._update_graph is None:
@@ -480,7 +582,10 @@ class BucketedTrainer(Trainer):
         if self.split:
             if self.distributed:
                 self._prescaled = True      # the replayed half scaled the flat buffer by 1/world (its capture ran _forward_backward)
+                t0 = time.perf_counter()
                 self.all_reduce_gradients()
+                self.host_between_replays_s += time.perf_counter() - t0      # host time of the eager collective between the two replays
+                self.host_between_replays_n += 1
             self._update_graph.replay()
         return entry["loss"]
 

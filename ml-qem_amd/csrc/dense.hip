@@ -520,34 +520,44 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
   }
   const bool store_lane = 4 * lq < a.yw;       // the block's padded width: lanes beyond it own no output columns
   const int64_t n_tiles = ceil_div(a.N, 16);
-  // the row-map entry of the NEXT tile is fetched while this tile is processed: a dependent lookup in front of every
-  // tile's operand loads is a whole extra memory round trip (the weight-gradient kernel does the same)
-  auto map_of = [&](int64_t t) {
-    const int64_t r = t * 16 + lr;
-    return (a.xrows && t < n_tiles && r < a.N) ? a.xrows[r] : 0;
+  // The x rows of the NEXT tile are requested before this tile's stores are issued (and its row-map entry one tile earlier
+  // still): a load issued behind a store can only be waited for by draining that store (one in-order vmcnt), so a tile whose
+  // operand loads sit behind the previous tile's six stores starts with a write round trip.  Loads are unconditional (rows
+  // clamped into the matrix); pad columns are zeroed where the values are consumed.
+  auto load_x = [&](int64_t t, int xmap, float4 (&v)[G]) {
+    const int64_t r = min(t * 16 + lr, a.N - 1);
+    const int64_t xr = a.xrows ? (int64_t)xmap : r;
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = xcol[g] ? *reinterpret_cast<const float4*>(xcol[g] + xr * a.ldx[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  int xnext = map_of(wave);
+  auto map_at = [&](int64_t t) {
+    const int64_t r = min(t * 16 + lr, a.N - 1);
+    return (a.xrows && t < n_tiles) ? a.xrows[r] : 0;
+  };
+  float4 av[G], an[G];
+  int xnext = map_at(wave + n_waves);
+  load_x(wave, map_at(wave), av);
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
     const int64_t row = t * 16 + lr;
     const bool row_ok = row < a.N;
-    const int64_t xrow = a.xrows ? (int64_t)xnext : row;
-    xnext = map_of(t + n_waves);
-    float4 av[G];
+    // every global LOAD of the tile is issued here, before its first store: vmcnt counts loads and stores in one in-order
+    // queue on gfx9, so a load behind a store can only be waited for by draining that store -- a row-scale load inside the
+    // block loop cost one write round trip per block (1307 vs 846 us on the six-block first layer).  The row scales (needed
+    // by this tile) go first, the next tile's map entry and x rows behind them: waiting for the scales then leaves the
+    // prefetch in flight.
+    float rsv[kMaxParts];
+#pragma unroll
+    for (int blk = 0; blk < kMaxParts; ++blk) rsv[blk] = (blk < a.yn && a.rsk[blk] && row_ok) ? a.rsk[blk][row] : 1.f;
+    const int xmap2 = map_at(t + 2 * n_waves);
+    load_x(t + n_waves, xnext, an);        // a tile beyond the end re-reads row N - 1 and is never used
+    xnext = xmap2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_ok && xcol[g]) av[g] = *reinterpret_cast<const float4*>(xcol[g] + xrow * a.ldx[0]);
       if (xlive[g] < 2) av[g].y = 0.f;     // padding may hold anything (NaN included): it must not reach the MFMA
       if (xlive[g] < 3) av[g].z = 0.f;
       if (xlive[g] < 4) av[g].w = 0.f;
       if (xlive[g] < 1) av[g].x = 0.f;
     }
-    // every global LOAD of the tile is issued here, before its first store: vmcnt counts loads and stores in one in-order
-    // queue on gfx9, so a load behind a store can only be waited for by draining that store -- a row-scale load inside the
-    // block loop cost one write round trip per block (1307 vs 846 us on the six-block first layer)
-    float rsv[kMaxParts];
-#pragma unroll
-    for (int blk = 0; blk < kMaxParts; ++blk) rsv[blk] = (blk < a.yn && a.rsk[blk] && row_ok) ? a.rsk[blk][row] : 1.f;
 #pragma unroll
     for (int blk = 0; blk < kMaxParts; ++blk) {
       if (blk >= a.yn) break;
@@ -571,6 +581,8 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
       if (a.plain_stores) vstore<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
       else vstore_nt<4>(a.yp[blk] + row * a.ldy[blk] + 4 * lq, v);
     }
+#pragma unroll
+    for (int g = 0; g < G; ++g) av[g] = an[g];
   }
 }
 

@@ -1,0 +1,745 @@
+// MLP2 / MLP3 with `mfma = "bf16"` as a bf16-STORAGE pipeline (reference: docs/tutorials/mlp.py:33-108 -- fc -> BatchNorm1d ->
+// ReLU -> Dropout blocks with a residual; the "bf16 MFMA MLP head" of the mixed-corpus configuration).  Layer outputs and
+// everything saved for the backward are [N, 128] bf16 matrices (256-byte rows, columns beyond the layer's width zero); master
+// weights, BatchNorm statistics, gradients of the parameters and every accumulation are fp32.  These layers are bound by HBM
+// at widths <= 170 (the bf16 matrix cores are three orders of magnitude faster than the rows arrive), so halving the bytes of
+// every activation pass is what the mode is for -- with fp32 tensors in memory the bf16 GEMMs were SLOWER than the fp32 ones.
+//
+// Building blocks (all deterministic: per-workgroup partial sums, fixed-order second stages):
+//   layer_fwd     Y = X W^T + b                 X fp32 [N, I <= 192] or bf16 [N,128]; Y bf16 [N,128] or fp32 [N,O]; W1-style
+//                                                fragment image in LDS (mlp_head.hip's forward); also the data gradient
+//                                                gX = dY W (+ add) with the image built from W^T
+//   colsum<0>     sum y, sum y^2                 BatchNorm batch statistics
+//   act           z = drop(relu(y s + t)) (+ r)  BatchNorm affine + ReLU + dropout + residual, bf16 -> bf16, one pass
+//   colsum<1>     sum gu, sum gu xhat            gu = g o mask(y): the two sums of the BatchNorm backward
+//   bwd_apply     dy = gs (gu - k1 - xhat k2)    gradient at the layer's GEMM output, bf16
+//   layer_wgrad   gW = dY^T X, gb = sum dY       mlp_head.hip's backward with dY loaded instead of formed from a gate
+//   rowdot        out = h w^T + b ; gh = g w ; gw = g^T h ; gb = sum g     the final O <= 4 outputs
+// Dropout masks are counter-based (common.hpp dropout_keep keyed by (seed + counter, row * 128 + column)): the backward
+// recomputes them, nothing is stored.
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace mlqem {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLW = MLQEM_MLP1_HIDDEN_PAD;      // columns of every bf16 activation matrix
+constexpr int kLayerThreads = 256;
+
+__device__ __forceinline__ unsigned lpack(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float blo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bhi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+  f[0] = blo(v.x); f[1] = bhi(v.x); f[2] = blo(v.y); f[3] = bhi(v.y);
+  f[4] = blo(v.z); f[5] = bhi(v.z); f[6] = blo(v.w); f[7] = bhi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return u32x4{lpack(f[0], f[1]), lpack(f[2], f[3]), lpack(f[4], f[5]), lpack(f[6], f[7])};
+}
+// component c of a 4-vector, for c a constant after unrolling
+__device__ __forceinline__ unsigned vget(const u32x4 v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+__device__ __forceinline__ int layer_unit(int ob, int m) { return 32 * (ob >> 1) + 8 * (m >> 2) + 4 * (ob & 1) + (m & 3); }
+
+// ------------------------------------------------------------------------------------------------ GEMM
+struct LayerArgs {
+  const void* x; int64_t ldx; int x_bf16;       // input rows: fp32 (ldx floats, padded to 4) or bf16 [N,128]
+  const float* w; const float* b; int transposed;   // W [O,I] (Y = X W^T + b) or, transposed, W [K,U] used as its transpose (gX = dY W)
+  const unsigned short* add;                    // optional bf16 [N,128] added to the result
+  void* y; int y_f32; int64_t ldy;              // output: bf16 [N,128], or fp32 [N, ldy] (the first U columns)
+  int64_t N; int K, U;                          // K input columns, U output units (<= 128)
+  const void* image;
+};
+
+__host__ __device__ inline int layer_image_u32x4(int G2) { return 8 * G2 * kWave + kLW / 4; }
+
+// fragment image: A[m = unit][k], 8 bf16 per lane and 32-column group, then the bias
+__global__ __launch_bounds__(256) void layer_image_kernel(const LayerArgs a, int G2, u32x4* __restrict__ image) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int n_frag = 8 * G2 * kWave;
+  if (idx < n_frag) {
+    const int l = idx & 63, g = (idx >> 6) % G2, ob = idx / (64 * G2);
+    const int u = layer_unit(ob, l & 15), lq = l >> 4;
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * g + 8 * lq + j;
+      float v = 0.f;
+      if (u < a.U && k < a.K) v = a.transposed ? a.w[(int64_t)k * a.U + u] : a.w[(int64_t)u * a.K + k];
+      w[j] = v;
+    }
+    image[idx] = u32x4{lpack(w[0], w[1]), lpack(w[2], w[3]), lpack(w[4], w[5]), lpack(w[6], w[7])};
+    return;
+  }
+  const int t = idx - n_frag;
+  if (t < kLW) reinterpret_cast<float*>(image + n_frag)[t] = (a.b && t < a.U) ? a.b[t] : 0.f;
+}
+
+template <int G2, bool IN_BF16>
+__global__ __launch_bounds__(kLayerThreads) void layer_fwd_kernel(const LayerArgs a) {
+  extern __shared__ u32x4 s_raw[];
+  for (int idx = threadIdx.x; idx < layer_image_u32x4(G2); idx += kLayerThreads) s_raw[idx] = static_cast<const u32x4*>(a.image)[idx];
+  __syncthreads();
+  const u32x4* s_w = s_raw;
+  const float* s_b = reinterpret_cast<const float*>(s_raw + 8 * G2 * kWave);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  const int64_t n_waves = (int64_t)gridDim.x * (kLayerThreads / kWave), wave = (int64_t)blockIdx.x * (kLayerThreads / kWave) + wid;
+  const int kpad = (a.K + 3) / 4 * 4;
+  // unconditional, clamped loads; fix-ups where the values are consumed (see mlp_head.hip)
+  // fp32 rows are loaded as float4 (HIP's struct of floats), bf16 rows as 4 dwords: a 16-byte load of float memory through an
+  // unsigned-int vector type came out of the compiler as ONE global_load_dword with the other three components undefined
+  constexpr int NL = IN_BF16 ? G2 : 2 * G2;
+  using XT = std::conditional_t<IN_BF16, u32x4, float4>;
+  struct Raw { XT v[NL]; };
+  auto load_tile = [&](int64_t t, Raw& r) {
+    const int64_t row = min(t * 16 + lr, a.N - 1);
+    if constexpr (IN_BF16) {
+      const unsigned short* xr = static_cast<const unsigned short*>(a.x) + row * kLW + 8 * lq;
+#pragma unroll
+      for (int g = 0; g < G2; ++g) r.v[g] = *reinterpret_cast<const u32x4*>(xr + 32 * g);       // 32 g + 8 lq < 128: inside the row
+    } else {
+      const float* xr = static_cast<const float*>(a.x) + row * a.ldx;
+#pragma unroll
+      for (int c = 0; c < 2 * G2; ++c)
+        r.v[c] = *reinterpret_cast<const float4*>(xr + min(32 * (c >> 1) + 8 * lq + 4 * (c & 1), kpad - 4));
+    }
+  };
+  auto to_frag = [&](const Raw& r, int g) {
+    if constexpr (IN_BF16) {
+      return r.v[g];                              // the loaded bytes ARE the fragment; pad columns of an activation matrix are zero
+    } else {
+      const float4 lo = r.v[2 * g], hi = r.v[2 * g + 1];
+      float p[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const int k0 = 32 * g + 8 * lq;
+      if (32 * g + 32 > a.K) {                    // uniform: the boundary group; pad columns must not reach the MFMA
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + j >= a.K) p[j] = 0.f;
+      }
+      return pack8(p);
+    }
+  };
+  Raw r0;
+  u32x4 xc[G2];
+  load_tile(wave, r0);
+#pragma unroll
+  for (int g = 0; g < G2; ++g) xc[g] = to_frag(r0, g);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    Raw rn;
+    load_tile(t + n_waves, rn);
+    __builtin_amdgcn_sched_barrier(0);            // the prefetch is issued HERE
+    f32x4 acc[8];
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, xc[g]);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s_w[(ob * G2 + g) * kWave + lane]), xf, acc[ob], 0, 0, 0);
+      if (g % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    const int64_t row = t * 16 + lr;
+    // the epilogue's own load (the add operand) and the take-over of the next tile BEFORE the stores
+    u32x4 addv[4];
+    if (a.add) {
+      const int64_t rc = min(row, a.N - 1);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) addv[p] = *reinterpret_cast<const u32x4*>(a.add + rc * kLW + 32 * p + 8 * lq);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G2; ++g) xc[g] = to_frag(rn, g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (row < a.N) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[2 * p + (e >> 2)][e & 3] + s_b[32 * p + 8 * lq + e];
+        if (a.add) {
+          float r[8];
+          unpack8(addv[p], r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (a.y_f32) {
+          float* dst = static_cast<float*>(a.y) + row * a.ldy;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (32 * p + 8 * lq + e < a.U) dst[32 * p + 8 * lq + e] = v[e];
+        } else {
+          *reinterpret_cast<u32x4*>(static_cast<unsigned short*>(a.y) + row * kLW + 32 * p + 8 * lq) = pack8(v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise and column sums
+// A thread owns the 8 columns c0 = 8 (tid & 15) of rows (tid >> 4) + 16 k: one 16-byte access per matrix and row.
+struct ActArgs {
+  const unsigned short* y; const unsigned short* g; const unsigned short* res;   // [N,128] bf16
+  const float* g32; int64_t ldg32;                                                  // the incoming gradient as fp32 [N, ldg32] instead of g
+  const float* scale; const float* shift; const float* mean; const float* invstd;  // per column [128]
+  const float* gs; const float* k1; const float* k2;                                // backward apply
+  unsigned short* out;
+  float* partial;                                                                   // column sums: [blocks][2][128]
+  int64_t N; int C; int relu;
+  float drop_p; uint64_t seed; const uint64_t* seed_counter;
+  int64_t rows_per_block;
+};
+
+// the 8 per-column constants of this thread: two 16-byte loads (every per-column vector of this file is [128] floats with zeros
+// beyond the layer's width).  Eight predicated scalar loads per vector cost more than the rows the thread then processes.
+__device__ __forceinline__ void col8(const float* __restrict__ v, int c0, float (&f)[8]) {
+  const float4 lo = *reinterpret_cast<const float4*>(v + c0), hi = *reinterpret_cast<const float4*>(v + c0 + 4);
+  f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+}
+
+// keep / drop decisions of the 8 columns c0 .. c0 + 7 of a row as a bit mask: two splitmix64 rounds, four 16-bit uniforms each
+// (the scheme of common.hpp's dropout_keep; a mask in a register -- bool arrays handed through references went to scratch
+// memory, byte by byte, and made every element-wise kernel of this file six times slower than its bytes)
+__device__ __forceinline__ unsigned keep_mask8(const ActArgs& a, uint64_t seed, int64_t row, int c0) {
+  if (!(a.drop_p > 0.f)) return 0xFFu;
+  const unsigned thr = (unsigned)(a.drop_p * 65536.f);
+  unsigned m = 0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    uint64_t z = seed + ((uint64_t)(row * kLW + c0 + 4 * half) + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) m |= ((unsigned)((z >> (16 * v)) & 0xFFFFu) >= thr ? 1u : 0u) << (4 * half + v);
+  }
+  return m;
+}
+
+// z = drop(relu(y s + t)) (+ res); columns >= C stay zero
+__global__ __launch_bounds__(256) void layer_act_kernel(const ActArgs a) {
+  const int c0 = 8 * (threadIdx.x & 15);
+  float sc[8], sh[8];
+  col8(a.scale, c0, sc);
+  col8(a.shift, c0, sh);
+  const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
+  const float inv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < a.N; row += (int64_t)gridDim.x * 16) {
+    float y[8], r[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.y + row * kLW + c0), y);
+    if (a.res) unpack8(*reinterpret_cast<const u32x4*>(a.res + row * kLW + c0), r);
+    const unsigned keep = keep_mask8(a, seed, row, c0);
+    float z[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float u = fmaf(y[e], sc[e], sh[e]);
+      if (a.relu) u = fmaxf(u, 0.f);
+      u = ((keep >> e) & 1u) ? u * inv : 0.f;
+      if (a.res) u = (float)(__bf16)u + r[e];        // the residual adds to the STORED activation (what the next layer and the backward see)
+      z[e] = (c0 + e < a.C) ? u : 0.f;
+    }
+    *reinterpret_cast<u32x4*>(a.out + row * kLW + c0) = pack8(z);
+  }
+}
+
+// The gradient at a block's pre-activation u = y s + t: gu = g o (u > 0) o keep / (1 - p), from g (bf16 or fp32) and y.
+__device__ __forceinline__ void load_gu(const ActArgs& a, uint64_t seed, float inv, const float (&sc)[8], const float (&sh)[8], int64_t row,
+                                        int c0, float (&gu)[8], float (&y)[8]) {
+  float g[8];
+  unpack8(*reinterpret_cast<const u32x4*>(a.y + row * kLW + c0), y);
+  if (a.g32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = (c0 + e < a.C) ? a.g32[row * a.ldg32 + c0 + e] : 0.f;
+  } else {
+    unpack8(*reinterpret_cast<const u32x4*>(a.g + row * kLW + c0), g);
+  }
+  const unsigned keep = keep_mask8(a, seed, row, c0);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float u = fmaf(y[e], sc[e], sh[e]);
+    const bool on = (!a.relu || u > 0.f) && ((keep >> e) & 1u) && c0 + e < a.C;
+    gu[e] = on ? g[e] * inv : 0.f;
+  }
+}
+
+// MODE 0: s1 = sum y, s2 = sum y^2.  MODE 1: s1 = sum gu, s2 = sum gu xhat, xhat = (y - mean) invstd.
+template <int MODE>
+__global__ __launch_bounds__(256) void layer_colsum_kernel(const ActArgs a) {
+  __shared__ float s_red[2][16][kLW];
+  const int c0 = 8 * (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[e] = sh[e] = mu[e] = is[e] = s1[e] = s2[e] = 0.f;
+  if (MODE == 1) { col8(a.scale, c0, sc); col8(a.shift, c0, sh); col8(a.mean, c0, mu); col8(a.invstd, c0, is); }
+  const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
+  const float inv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block, r1 = min(r0 + a.rows_per_block, a.N);
+  for (int64_t row = r0 + rl; row < r1; row += 16) {
+    if (MODE == 0) {
+      float y[8];
+      unpack8(*reinterpret_cast<const u32x4*>(a.y + row * kLW + c0), y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += y[e]; s2[e] = fmaf(y[e], y[e], s2[e]); }
+    } else {
+      float gu[8], y[8];
+      load_gu(a, seed, inv, sc, sh, row, c0, gu, y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += gu[e]; s2[e] = fmaf(gu[e], (y[e] - mu[e]) * is[e], s2[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s_red[0][rl][c0 + e] = s1[e]; s_red[1][rl][c0 + e] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < kLW) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { t1 += s_red[0][j][threadIdx.x]; t2 += s_red[1][j][threadIdx.x]; }
+    a.partial[((int64_t)blockIdx.x * 2 + 0) * kLW + threadIdx.x] = t1;
+    a.partial[((int64_t)blockIdx.x * 2 + 1) * kLW + threadIdx.x] = t2;
+  }
+}
+
+// One 64-lane workgroup per column: partials added in a fixed order in double.
+// MODE 0 -> mean, biased var, invstd, scale = gamma invstd, shift = beta - mean scale.
+// MODE 1 -> dbeta (s1), dgamma (s2), gs = gamma invstd, k1 = s1 / N, k2 = s2 / N.
+template <int MODE>
+__global__ __launch_bounds__(kWave) void layer_finish_kernel(const float* __restrict__ partial, int nblocks, int64_t N, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ invstd_in, float eps,
+                                                             float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3,
+                                                             float* __restrict__ o4, float* __restrict__ o5) {
+  __shared__ double s_t[2][kWave];
+  const int c = blockIdx.x, j = threadIdx.x;
+  double t1 = 0.0, t2 = 0.0;
+  for (int b = j; b < nblocks; b += kWave) {
+    t1 += (double)partial[((int64_t)b * 2 + 0) * kLW + c];
+    t2 += (double)partial[((int64_t)b * 2 + 1) * kLW + c];
+  }
+  s_t[0][j] = t1; s_t[1][j] = t2;
+  __syncthreads();
+  if (j != 0) return;
+  t1 = t2 = 0.0;
+  for (int k = 0; k < kWave; ++k) { t1 += s_t[0][k]; t2 += s_t[1][k]; }
+  if (MODE == 0) {
+    const double m = t1 / (double)N;
+    double var = t2 / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * is;
+    o1[c] = (float)m; o2[c] = (float)var; o3[c] = is; o4[c] = sc; o5[c] = beta[c] - (float)m * sc;
+  } else {
+    o1[c] = (float)t1; o2[c] = (float)t2; o3[c] = gamma[c] * invstd_in[c];
+    o4[c] = (float)(t1 / (double)N); o5[c] = (float)(t2 / (double)N);
+  }
+}
+
+// dy = gs (gu - k1 - xhat k2) in bf16; with gs = 1, k1 = k2 = 0 (a block without BatchNorm) dy = gu
+__global__ __launch_bounds__(256) void layer_bwd_apply_kernel(const ActArgs a) {
+  const int c0 = 8 * (threadIdx.x & 15);
+  float sc[8], sh[8], mu[8], is[8], gs[8], k1[8], k2[8];
+  col8(a.scale, c0, sc); col8(a.shift, c0, sh); col8(a.mean, c0, mu); col8(a.invstd, c0, is);
+  col8(a.gs, c0, gs); col8(a.k1, c0, k1); col8(a.k2, c0, k2);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) if (c0 + e >= a.C) gs[e] = 0.f;          // dy of the pad columns is zero whatever the vectors hold there
+  const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
+  const float inv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < a.N; row += (int64_t)gridDim.x * 16) {
+    float gu[8], y[8], d[8];
+    load_gu(a, seed, inv, sc, sh, row, c0, gu, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = gs[e] * (gu[e] - k1[e] - (y[e] - mu[e]) * is[e] * k2[e]);
+    *reinterpret_cast<u32x4*>(a.out + row * kLW + c0) = pack8(d);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// gW[128, K + 1] = dY^T [X | 1]: mlp_head.hip's column-split backward with the A fragments loaded (dY is in memory).
+// Partial layout per workgroup: [wave][tile t 4 + s4][register][lane] (lane order, 256-byte stores).
+constexpr int kLayerW1Floats = 4 * 32 * 4 * kWave;
+constexpr int kLayerMaxBlocks = 512;
+
+struct WgradLayerArgs {
+  const unsigned short* dy; const void* x; int64_t ldx; int x_bf16;
+  int64_t N; int K; float* partial;
+};
+
+template <bool IN_BF16>
+__global__ __launch_bounds__(kLayerThreads) void layer_wgrad_kernel(const WgradLayerArgs a, int cpw) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int kpad = IN_BF16 ? kLW : (a.K + 3) / 4 * 4;
+  const int col0 = 4 * (cpw * wid + lr);
+  const bool xlane = lr < cpw && col0 <= a.K;
+  const int colc = min(col0, kpad - 4);
+  const bool x_raw[4] = {col0 + 0 < a.K, col0 + 1 < a.K, col0 + 2 < a.K, col0 + 3 < a.K};
+  const float x_fill[4] = {xlane && col0 + 0 == a.K ? 1.f : 0.f, xlane && col0 + 1 == a.K ? 1.f : 0.f,
+                           xlane && col0 + 2 == a.K ? 1.f : 0.f, xlane && col0 + 3 == a.K ? 1.f : 0.f};
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[t][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  using XT = std::conditional_t<IN_BF16, uint2, float4>;     // per row: four bf16 or four fp32 columns (loaded through their own types)
+  struct Slab { XT xv[8]; u32x4 dv[8]; };
+  const int64_t n_slabs = a.N / 32;
+  const unsigned xo = (unsigned)(8 * lq * (IN_BF16 ? kLW : a.ldx) + colc), dof = (unsigned)(8 * lq * kLW + 8 * lr);
+  auto issue_row = [&](Slab& d, int64_t s, int j) {
+    const int64_t r0 = 32 * min(s, n_slabs - 1) + j;
+    if constexpr (IN_BF16) d.xv[j] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.x) + r0 * kLW + xo);
+    else d.xv[j] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + r0 * a.ldx + xo);
+    d.dv[j] = *reinterpret_cast<const u32x4*>(a.dy + r0 * kLW + dof);
+  };
+  auto consume = [&](Slab& cur, int64_t first_row) {
+    float xf[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = first_row + 8 * lq + j < a.N;
+      const XT xq = cur.xv[j];
+      float v[4];
+      if constexpr (IN_BF16) { v[0] = blo(xq.x); v[1] = bhi(xq.x); v[2] = blo(xq.y); v[3] = bhi(xq.y); }
+      else { v[0] = xq.x; v[1] = xq.y; v[2] = xq.z; v[3] = xq.w; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xf[j][c] = x_raw[c] ? v[c] : x_fill[c];
+      if (!ok) cur.dv[j] = u32x4{0u, 0u, 0u, 0u};            // a clamped row of the ragged tail contributes nothing
+    }
+    bf16x8 bx[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 v = {lpack(xf[0][c], xf[1][c]), lpack(xf[2][c], xf[3][c]), lpack(xf[4][c], xf[5][c]), lpack(xf[6][c], xf[7][c])};
+      bx[c] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = t >> 1;
+      unsigned ad[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        ad[d] = (t & 1) ? __builtin_amdgcn_perm(vget(cur.dv[2 * d + 1], c), vget(cur.dv[2 * d], c), 0x07060302u)
+                        : __builtin_amdgcn_perm(vget(cur.dv[2 * d + 1], c), vget(cur.dv[2 * d], c), 0x05040100u);
+      const u32x4 av = {ad[0], ad[1], ad[2], ad[3]};
+      const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[t][s4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bx[s4], acc[t][s4], 0, 0, 0);
+    }
+  };
+  Slab cur, nxt;
+  const int64_t G = gridDim.x;
+  if (n_slabs > 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_row(cur, blockIdx.x, j);
+    for (int64_t sl = blockIdx.x; sl < n_slabs; sl += G) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) issue_row(nxt, sl + G, j);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(cur, 32 * sl);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+  }
+  if (blockIdx.x == 0 && (a.N & 31)) {
+    Slab t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t row = min(32 * n_slabs + 8 * lq + j, a.N - 1);
+      if constexpr (IN_BF16) t.xv[j] = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(a.x) + row * kLW + colc);
+      else t.xv[j] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + row * a.ldx + colc);
+      t.dv[j] = *reinterpret_cast<const u32x4*>(a.dy + row * kLW + 8 * lr);
+    }
+    consume(t, 32 * n_slabs);
+  }
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kLayerW1Floats + (wid * 32 * 4) * kWave + lane;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[((t * 4 + s4) * 4 + r) * kWave] = acc[t][s4][r];
+}
+
+__global__ __launch_bounds__(256) void layer_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int K, int U, int cpw,
+                                                                 float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float s[4][kWave];
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * kWave + el;
+  const int lane = e & 63, r = (e >> 6) & 3, tile = (e >> 8) & 31, wid = e >> 13;
+  const int lr = lane & 15, lq = lane >> 4, s4 = tile & 3, t = tile >> 2;
+  const int o = 8 * (4 * lq + r) + t, c = 4 * (cpw * wid + lr) + s4;
+  const bool live = e < kLayerW1Floats && lr < cpw && c <= K && o < U;
+  float v = 0.f;
+  if (live) {
+    const int per = (G + 3) / 4;
+    const int g1 = min(G, (sl + 1) * per);
+    for (int g = sl * per; g < g1; ++g) v += partial[(int64_t)g * kLayerW1Floats + e];
+  }
+  s[sl][el] = v;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+  const float tot = s[0][el] + s[1][el] + s[2][el] + s[3][el];
+  if (c < K) gw[(int64_t)o * K + c] = tot;
+  else if (gb) gb[o] = tot;
+}
+
+// ------------------------------------------------------------------------------------------------ the final O <= 4 outputs
+// forward: out[n,q] = sum_c h[n,c] w[q,c] + b[q] (operands rounded to bf16 like every GEMM of the mode); 16 lanes per row.
+struct DotArgs {
+  const unsigned short* h; const float* w; const float* b; float* out; int64_t ldo;     // forward
+  const float* g; int64_t ldg; unsigned short* gh; float* partial;                         // backward
+  int64_t N; int C; int O; int64_t rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void layer_rowdot_fwd_kernel(const DotArgs a) {
+  const int c0 = 8 * (threadIdx.x & 15);
+  float w[MLQEM_MLP1_MAX_OUT][8];
+#pragma unroll
+  for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[q][e] = (q < a.O && c0 + e < a.C) ? (float)(__bf16)a.w[(int64_t)q * a.C + c0 + e] : 0.f;
+  const int64_t n_iter = ceil_div(a.N, (int64_t)gridDim.x * 16);
+  for (int64_t it = 0; it < n_iter; ++it) {                    // every lane of a 16-lane group stays in the loop (DPP sums)
+    const int64_t row = it * gridDim.x * 16 + (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = row < a.N;
+    float h[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.h + min(row, a.N - 1) * kLW + c0), h);
+#pragma unroll
+    for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
+      if (q >= a.O) break;
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(h[e], w[q][e], s);
+      s = group16_sum(s);
+      if (ok && (threadIdx.x & 15) == 0) a.out[row * a.ldo + q] = s + a.b[q];
+    }
+  }
+}
+
+// backward: gh[n,c] = sum_q g[n,q] w[q,c] (bf16), and per-workgroup partials of gw[q,c] = sum_n g[n,q] h[n,c], gb[q] = sum_n g[n,q]:
+// partial[block][q][c] for c < 128, partial[block][q][128] = gb.
+__global__ __launch_bounds__(256) void layer_rowdot_bwd_kernel(const DotArgs a) {
+  __shared__ float s_red[16][MLQEM_MLP1_MAX_OUT][kLW + 1];
+  const int c0 = 8 * (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  float w[MLQEM_MLP1_MAX_OUT][8], gw[MLQEM_MLP1_MAX_OUT][8], gb[MLQEM_MLP1_MAX_OUT];
+#pragma unroll
+  for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
+    gb[q] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { w[q][e] = (q < a.O && c0 + e < a.C) ? (float)(__bf16)a.w[(int64_t)q * a.C + c0 + e] : 0.f; gw[q][e] = 0.f; }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block, r1 = min(r0 + a.rows_per_block, a.N);
+  for (int64_t row = r0 + rl; row < r1; row += 16) {
+    float h[8], gh[8];
+    unpack8(*reinterpret_cast<const u32x4*>(a.h + row * kLW + c0), h);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gh[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
+      if (q >= a.O) break;
+      const float g = a.g[row * a.ldg + q], gr = (float)(__bf16)g;
+      if (c0 == 0) gb[q] += g;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gh[e] = fmaf(gr, w[q][e], gh[e]); gw[q][e] = fmaf(gr, h[e], gw[q][e]); }
+    }
+    *reinterpret_cast<u32x4*>(a.gh + row * kLW + c0) = pack8(gh);
+  }
+#pragma unroll
+  for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_red[rl][q][c0 + e] = gw[q][e];
+    if (c0 == 0) s_red[rl][q][kLW] = gb[q];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < MLQEM_MLP1_MAX_OUT * (kLW + 1); idx += 256) {
+    const int q = idx / (kLW + 1), c = idx % (kLW + 1);
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += s_red[j][q][c];
+    a.partial[((int64_t)blockIdx.x * MLQEM_MLP1_MAX_OUT + q) * (kLW + 1) + c] = t;
+  }
+}
+
+__global__ __launch_bounds__(kWave) void layer_rowdot_finish_kernel(const float* __restrict__ partial, int nblocks, int C, int O,
+                                                                    float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ double s_t[kWave];
+  const int q = blockIdx.x / (kLW + 1), c = blockIdx.x % (kLW + 1), j = threadIdx.x;
+  double t = 0.0;
+  for (int b = j; b < nblocks; b += kWave) t += (double)partial[((int64_t)b * MLQEM_MLP1_MAX_OUT + q) * (kLW + 1) + c];
+  s_t[j] = t;
+  __syncthreads();
+  if (j != 0 || q >= O) return;
+  t = 0.0;
+  for (int k = 0; k < kWave; ++k) t += s_t[k];
+  if (c < C) gw[(int64_t)q * C + c] = (float)t;
+  else if (c == kLW) gb[q] = (float)t;
+}
+
+template <typename K>
+static int layer_resident(K kernel, int threads, size_t lds) {
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return per_cu * cus;
+}
+
+template <int G2, bool IN_BF16>
+static int launch_layer_fwd(LayerArgs a, void* workspace, hipStream_t s) {
+  const size_t lds = (size_t)layer_image_u32x4(G2) * sizeof(u32x4);
+  auto kernel = layer_fwd_kernel<G2, IN_BF16>;
+  static const int once = [&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
+  }();
+  if (!once) return MLQEM_ERR_LAUNCH;
+  static const int res = layer_resident(kernel, kLayerThreads, lds);
+  a.image = workspace;
+  hipLaunchKernelGGL(layer_image_kernel, dim3((unsigned)ceil_div(layer_image_u32x4(G2) * 4, 256)), dim3(256), 0, s, a, G2, static_cast<u32x4*>(workspace));
+  const int64_t tiles = ceil_div(a.N, 16);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(res, ceil_div(tiles, kLayerThreads / kWave)));
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kLayerThreads), lds, s, a);
+  return launch_status();
+}
+
+constexpr int kColsumMaxBlocks = 2048;
+static int colsum_blocks(int64_t N) {
+  const int64_t want = ceil_div(N, (int64_t)64);
+  return (int)(want < 1 ? 1 : (want > kColsumMaxBlocks ? kColsumMaxBlocks : want));
+}
+
+}  // namespace mlqem
+
+using namespace mlqem;
+
+extern "C" size_t mlqem_layer_workspace_bytes(void) {
+  const size_t image = (size_t)layer_image_u32x4(6) * sizeof(u32x4);
+  const size_t wgrad = (size_t)kLayerMaxBlocks * kLayerW1Floats * sizeof(float);
+  const size_t colsum = (size_t)kColsumMaxBlocks * 2 * kLW * sizeof(float);
+  const size_t dot = (size_t)kColsumMaxBlocks * MLQEM_MLP1_MAX_OUT * (kLW + 1) * sizeof(float);
+  return std::max(std::max(image, wgrad), std::max(colsum, dot));
+}
+
+extern "C" int mlqem_layer_gemm_bf16(const void* x, int x_is_bf16, int64_t ldx, const float* w, int transposed, const float* b,
+                                     const void* add_bf16, void* y, int y_is_f32, int64_t ldy, int64_t N, int K, int U,
+                                     void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || K < 1 || U < 1 || !w) return MLQEM_ERR_BAD_ARG;
+  if (U > kLW || K > (x_is_bf16 ? kLW : 192)) return MLQEM_ERR_UNSUPPORTED;
+  if (!x_is_bf16 && (ldx < (K + 3) / 4 * 4 || ldx % 4)) return MLQEM_ERR_BAD_ARG;
+  if (y_is_f32 && ldy < U) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes() || !aligned_to(workspace, 16)) return MLQEM_ERR_WORKSPACE;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !y || !aligned_to(x, 16) || (!y_is_f32 && !aligned_to(y, 16)) || (add_bf16 && !aligned_to(add_bf16, 16))) return MLQEM_ERR_BAD_ARG;
+  LayerArgs a{x, ldx, x_is_bf16, w, b, transposed, static_cast<const unsigned short*>(add_bf16), y, y_is_f32, ldy, N, K, U, nullptr};
+  hipStream_t s = as_stream(stream);
+  const int g2 = (K + 31) / 32;
+  if (x_is_bf16) {
+    if (g2 <= 2) return launch_layer_fwd<2, true>(a, workspace, s);
+    return launch_layer_fwd<4, true>(a, workspace, s);
+  }
+  if (g2 <= 2) return launch_layer_fwd<2, false>(a, workspace, s);
+  if (g2 <= 4) return launch_layer_fwd<4, false>(a, workspace, s);
+  return launch_layer_fwd<6, false>(a, workspace, s);
+}
+
+// mode 0: batch statistics of y -> mean, var, invstd, scale, shift (each [128]; gamma / beta [C]).
+// mode 1: backward sums from (g, y) -> dbeta, dgamma, gs, k1, k2.  g: bf16 [N,128], or fp32 [N, ldg32] when g32 != NULL.
+extern "C" int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale,
+                                         const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                         const float* beta, float eps, int relu, float drop_p, uint64_t seed,
+                                         const uint64_t* seed_counter, int64_t N, int C, float* o1, float* o2, float* o3, float* o4,
+                                         float* o5, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N <= 0 || C < 1 || C > kLW || !y || !gamma || !o1 || !o2 || !o3 || !o4 || !o5 || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
+  if (mode == 0 ? !beta : (!scale || !shift || !mean || !invstd || (!g && !g32))) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes()) return MLQEM_ERR_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  const int nb = colsum_blocks(N);
+  ActArgs a{};
+  a.y = static_cast<const unsigned short*>(y); a.g = static_cast<const unsigned short*>(g); a.g32 = g32; a.ldg32 = ldg32;
+  a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.partial = static_cast<float*>(workspace);
+  a.N = N; a.C = C; a.relu = relu; a.drop_p = drop_p; a.seed = seed; a.seed_counter = seed_counter;
+  a.rows_per_block = ceil_div(N, (int64_t)nb);
+  if (mode == 0) {
+    hipLaunchKernelGGL(layer_colsum_kernel<0>, dim3(nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(layer_finish_kernel<0>, dim3(C), dim3(kWave), 0, s, a.partial, nb, N, gamma, beta, (const float*)nullptr, eps, o1, o2, o3, o4, o5);
+  } else {
+    hipLaunchKernelGGL(layer_colsum_kernel<1>, dim3(nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(layer_finish_kernel<1>, dim3(C), dim3(kWave), 0, s, a.partial, nb, N, gamma, (const float*)nullptr, invstd, 0.f, o1, o2, o3, o4, o5);
+  }
+  return launch_status();
+}
+
+// op 0: out = drop(relu?(y scale + shift)) (+ res).   op 1: out = gs (gu - k1 - xhat k2), gu from (g | g32, y).
+extern "C" int mlqem_layer_pointwise_bf16(int op, const void* y, const void* g, const float* g32, int64_t ldg32, const void* res,
+                                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                                          const float* gs, const float* k1, const float* k2, int relu, float drop_p, uint64_t seed,
+                                          const uint64_t* seed_counter, void* out, int64_t N, int C, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C < 1 || C > kLW || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!y || !out || !scale || !shift) return MLQEM_ERR_BAD_ARG;
+  if (op == 1 && (!mean || !invstd || !gs || !k1 || !k2 || (!g && !g32))) return MLQEM_ERR_BAD_ARG;
+  ActArgs a{};
+  a.y = static_cast<const unsigned short*>(y); a.g = static_cast<const unsigned short*>(g); a.g32 = g32; a.ldg32 = ldg32;
+  a.res = static_cast<const unsigned short*>(res); a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+  a.gs = gs; a.k1 = k1; a.k2 = k2; a.out = static_cast<unsigned short*>(out);
+  a.N = N; a.C = C; a.relu = relu; a.drop_p = drop_p; a.seed = seed; a.seed_counter = seed_counter;
+  const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(N, 16), 256 * 8);
+  if (op == 0) hipLaunchKernelGGL(layer_act_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(layer_bwd_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  return launch_status();
+}
+
+extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf16, int64_t ldx, float* gw, float* gb, int64_t N,
+                                      int K, int U, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || K < 1 || U < 1 || !gw) return MLQEM_ERR_BAD_ARG;
+  if (U > kLW || K > (x_is_bf16 ? kLW : MLQEM_MLP1_MAX_IN)) return MLQEM_ERR_UNSUPPORTED;
+  if (!x_is_bf16 && (ldx < (K + 3) / 4 * 4 || ldx % 4)) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes()) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && (!dy || !x || !aligned_to(dy, 16) || !aligned_to(x, 8))) return MLQEM_ERR_BAD_ARG;
+  hipStream_t s = as_stream(stream);
+  WgradLayerArgs a{static_cast<const unsigned short*>(dy), x, ldx, x_is_bf16, N, K, static_cast<float*>(workspace)};
+  const int chunks = (K + 1 + 3) / 4, cpw = (chunks + 3) / 4;
+  int G = 0;
+  if (N > 0) {
+    static const int r0 = layer_resident(layer_wgrad_kernel<false>, kLayerThreads, 0), r1 = layer_resident(layer_wgrad_kernel<true>, kLayerThreads, 0);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(x_is_bf16 ? r1 : r0, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
+    if (x_is_bf16) hipLaunchKernelGGL(layer_wgrad_kernel<true>, dim3(G), dim3(kLayerThreads), 0, s, a, cpw);
+    else hipLaunchKernelGGL(layer_wgrad_kernel<false>, dim3(G), dim3(kLayerThreads), 0, s, a, cpw);
+  }
+  hipLaunchKernelGGL(layer_wgrad_reduce_kernel, dim3((unsigned)ceil_div(kLayerW1Floats, kWave)), dim3(256), 0, s, a.partial, G, K, U, cpw, gw, gb);
+  return launch_status();
+}
+
+extern "C" int mlqem_layer_rowdot_bf16(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O,
+                                       mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C < 1 || C > kLW || O < 1 || O > MLQEM_MLP1_MAX_OUT || ldo < O) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!h || !w || !b || !out) return MLQEM_ERR_BAD_ARG;
+  DotArgs a{};
+  a.h = static_cast<const unsigned short*>(h); a.w = w; a.b = b; a.out = out; a.ldo = ldo; a.N = N; a.C = C; a.O = O;
+  hipLaunchKernelGGL(layer_rowdot_fwd_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(N, 16), 256 * 16)), dim3(256), 0, as_stream(stream), a);
+  return launch_status();
+}
+
+extern "C" int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float* gw, float* gb,
+                                           int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N <= 0 || C < 1 || C > kLW || O < 1 || O > MLQEM_MLP1_MAX_OUT || ldg < O || !g || !h || !w || !gh || !gw || !gb) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes()) return MLQEM_ERR_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  const int nb = colsum_blocks(N);
+  DotArgs a{};
+  a.h = static_cast<const unsigned short*>(h); a.w = w; a.g = g; a.ldg = ldg; a.gh = static_cast<unsigned short*>(gh);
+  a.partial = static_cast<float*>(workspace); a.N = N; a.C = C; a.O = O; a.rows_per_block = ceil_div(N, (int64_t)nb);
+  hipLaunchKernelGGL(layer_rowdot_bwd_kernel, dim3(nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(layer_rowdot_finish_kernel, dim3(MLQEM_MLP1_MAX_OUT * (kLW + 1)), dim3(kWave), 0, s, a.partial, nb, C, O, gw, gb);
+  return launch_status();
+}

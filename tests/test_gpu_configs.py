@@ -1,12 +1,30 @@
 """BASELINE.json's other configurations as parity cases (small instances): cfg1 MLP on circuit-level features,
 cfg2 4-qubit TFIM GNN, cfg3 random 20-qubit depth-40 circuits, cfg5 mixed corpus with Pauli-twirled members.
 Each: GPU forward vs the fp64 oracle within 1e-5 and, for the GNNs, one backward pass vs oracle autograd."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(key, value):
+    """Realised gaps go to gpurun_out/parity_configs.json (copied to profiles/ by the builder), as tests/test_gpu_cfg4_parity.py
+    does for cfg4: a loosened bound is only honest next to the number it was loosened for."""
+    path = os.path.join(ROOT, "gpurun_out", "parity_configs.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        with open(path) as fh:
+            data = json.load(fh)
+    data[key] = value
+    with open(path, "w") as fh:
+        json.dump(data, fh, indent=1, sort_keys=True)
 
 
 def _host_batch(corpus, sel, exp_3d=False):
@@ -48,7 +66,7 @@ def _check_family_a(corpus, nq, sel):
         assert (p.grad.cpu().double() - grads[name]).abs().max().item() / scale < 2e-4, name
 
 
-def _check_family_b(corpus, sel, out_size):
+def _check_family_b(corpus, sel, out_size, tag=None):
     """With the reference's trained weights (gnn1.pth).  Random-init weights saturate the pooling fitness sigmoid to
     exactly 1.0 in fp32 for activations in (17, 37) where fp64 still separates them, so the discrete top-k choice --
     and with it every downstream gradient -- would legitimately differ between an fp32 and an fp64 implementation."""
@@ -72,8 +90,13 @@ def _check_family_b(corpus, sel, out_size):
         want32 = oracle_from_sd(sd).eval()(hb["noisy"], None, hb["depth"], hb["x"], hb["edge_index"], hb["batch"])
     fp32_gap = (want32.double() - want.detach()).abs().max().item()
     err = (out.detach().cpu().double() - want.detach()).abs().max().item()
+    err32 = (out.detach().cpu() - want32).abs().max().item()
+    if tag:
+        _record(tag, {"max_abs_gpu_minus_fp64_oracle": err, "max_abs_fp32_cpu_minus_fp64_oracle": fp32_gap,
+                      "max_abs_gpu_minus_fp32_cpu": err32, "bound_asserted": max(1e-5, 2 * fp32_gap), "north_star": 1e-5,
+                      "prediction_scale": float(want.detach().abs().max()), "nodes": int(hb["x"].shape[0]), "graphs": int(len(sel))})
     assert err < max(1e-5, 2 * fp32_gap), (err, fp32_gap)
-    assert (out.detach().cpu() - want32).abs().max().item() < max(1e-5, 2 * fp32_gap)
+    assert err32 < max(1e-5, 2 * fp32_gap)
     torch.nn.functional.mse_loss(out, hb["y"].to(DEV)).backward()
     torch.nn.functional.mse_loss(want, hb["y"].double()).backward()
     grads = {k: p.grad for k, p in ref.named_parameters()}
@@ -90,7 +113,7 @@ def test_cfg2_tfim_4q_gnn_batch32():
     sel = np.arange(0, 45)[:32]
     _check_family_a(corpus, 4, sel)
     corpus4 = tfim_corpus(4, list(range(0, 15)), 3, two_q="cx", exp_value_size=4)
-    _check_family_b(corpus4, sel, 4)
+    _check_family_b(corpus4, sel, 4, tag="cfg2_family_b_gnn1")
 
 
 def test_cfg3_random_20q_depth40():
@@ -101,7 +124,7 @@ def test_cfg3_random_20q_depth40():
     assert 400 < corpus["x"][0].shape[0] < 900
     _check_family_a(corpus, 20, np.arange(12))
     corpus4 = encode_corpus(circs, 20, exp_value_size=4)
-    _check_family_b(corpus4, np.arange(12), 4)
+    _check_family_b(corpus4, np.arange(12), 4, tag="cfg3_family_b_gnn1")
 
 
 def test_cfg5_mixed_corpus_with_pauli_twirl():
@@ -201,3 +224,83 @@ def test_cfg5_bf16_mfma_mlp_head():
         assert (gw.cpu().double() - want_w).abs().max().item() < 2e-5 * max(want_w.abs().max().item(), 1.0), (n, i, o)
         want_b = gy.bfloat16().double().sum(0)
         assert (gbias.cpu().double() - want_b).abs().max().item() < 2e-5 * max(want_b.abs().max().item(), 1.0)
+
+
+def test_cfg5_family_b_with_bf16_mlp3_head_on_a_mixed_corpus(golden_dir):
+    """cfg5 as ONE composition: the reference's GNN with an MLP3 head (ExpValCircuitGraphModel_3, docs/tutorials/gnn.py:178-224;
+    weights: the reference's gnn3_ising.pth, 103 465 parameters) whose head runs ``mfma = "bf16"``, on a mixed mini-corpus --
+    TFIM, random and Pauli-twirled circuits of 4, 12, 20 and 100 qubits in one batch.  Stated tolerances:
+    * the graph part (what enters the head: pooled features | noisy values | depth) within 1e-5 of the fp64 oracle's, relative to
+      its scale (depth is a raw ~1e2 count) -- or twice the fp32 CPU oracle's own gap where that is larger, recorded;
+    * the whole fp32 model within the same bound of the fp64 oracle at the output;
+    * the bf16 head equals "round both operands of every GEMM to bf16 (the eval-mode BatchNorm folded into the weights first),
+      multiply exactly, add in fp32" to 1e-4 of the output scale GIVEN the device's own head input, and stays within 5e-2 of
+      the fp32 head (a different arithmetic)."""
+    from blackwater.data.synthetic import encode_corpus, pauli_twirl, random_circuit, tfim_circuit
+    from blackwater.nn import family_b_from_state_dict
+    from blackwater.nn.family_b import ExpValCircuitGraphModel_3
+    from oracle.models import family_b_from_state_dict as oracle_from_sd
+
+    parts = [
+        encode_corpus([tfim_circuit(4, s, J=0.2 * s, two_q="cx") for s in (1, 4, 9)], 4, two_q="cx", exp_value_size=4),
+        encode_corpus([random_circuit(20, 40, seed=s) for s in (1, 2)], 20, two_q="cx", exp_value_size=4),
+        encode_corpus([pauli_twirl(tfim_circuit(12, s, J=0.7, two_q="cx"), seed=s) for s in (2, 4)], 12, two_q="cx", exp_value_size=4),
+        encode_corpus([pauli_twirl(tfim_circuit(100, 1, J=0.4, two_q="ecr"), seed=9)], 100, two_q="ecr", exp_value_size=4),
+    ]
+    corpus = {"x": sum((p["x"] for p in parts), []), "edge_index": sum((p["edge_index"] for p in parts), [])}
+    for k in ("y", "noisy", "depth"):
+        corpus[k] = np.concatenate([p[k] for p in parts])
+    corpus["observable"] = np.zeros((len(corpus["x"]), 1, 1), np.float32)     # Family B ignores it (gnn.py:100-122)
+    sel = np.arange(len(corpus["x"]))
+    assert corpus["x"][-1].shape[0] > 2000 and len(sel) == 8                   # the 100-qubit twirled member is in the batch
+    sd = torch.load(os.path.join(golden_dir, "ckpt", "gnn3_ising.pth"), weights_only=True)
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    assert isinstance(model, ExpValCircuitGraphModel_3) and sum(p.numel() for p in model.parameters()) == 103465
+    ref64, ref32 = oracle_from_sd(sd).double().eval(), oracle_from_sd(sd).eval()
+    hb = _host_batch(corpus, sel, exp_3d=True)
+    seen = {}
+    model.body_seq.register_forward_pre_hook(lambda m, a: seen.__setitem__("gpu", a[0].detach().cpu().double()))
+    ref64.body_seq.register_forward_pre_hook(lambda m, a: seen.__setitem__("f64", a[0].detach()))
+    ref32.body_seq.register_forward_pre_hook(lambda m, a: seen.__setitem__("f32", a[0].detach().double()))
+    args_dev = (hb["noisy"].to(DEV), None, hb["depth"].to(DEV), hb["x"].to(DEV), hb["edge_index"].to(DEV), hb["batch"].to(DEV))
+    with torch.no_grad():
+        out32 = model(*args_dev).cpu().double()
+        want = ref64(hb["noisy"].double(), None, hb["depth"].double(), hb["x"].double(), hb["edge_index"], hb["batch"])
+        want32 = ref32(hb["noisy"], None, hb["depth"], hb["x"], hb["edge_index"], hb["batch"]).double()
+        head_in = seen["gpu"]
+        model.body_seq.mfma = "bf16"
+        out16 = model(*args_dev).cpu().double()
+    scale_in = seen["f64"].abs().max().item()
+    gap_in, cpu_gap_in = (head_in - seen["f64"]).abs().max().item(), (seen["f32"] - seen["f64"]).abs().max().item()
+    scale = want.abs().max().item()
+    gap_out, cpu_gap_out = (out32 - want).abs().max().item(), (want32 - want).abs().max().item()
+
+    # the bf16 head, emulated exactly on the device's own head input
+    bf = lambda t: t.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+    m = model.body_seq
+
+    def folded(fc, bn):
+        sc = bn.weight.detach().cpu().double() * torch.rsqrt(bn.running_var.cpu().double() + bn.eps)
+        return (fc.weight.detach().cpu().double() * sc[:, None]).float(), \
+               ((fc.bias.detach().cpu().double() - bn.running_mean.cpu().double()) * sc + bn.bias.detach().cpu().double()).float()
+
+    def lin(x, w, b, relu):
+        y = bf(x) @ bf(w).T + b.double()
+        return y.relu().float().double() if relu else y.float().double()      # layer outputs are fp32 tensors on the device
+
+    w1, b1 = folded(m.fc1, m.bn1)
+    w2, b2 = folded(m.fc2, m.bn2)
+    x1 = lin(head_in, w1, b1, True)
+    x2 = lin(x1, w2, b2, True) + x1
+    h3 = lin(x2.float().double(), m.fc3.weight.detach().cpu(), m.fc3.bias.detach().cpu(), True)
+    emu = lin(h3, m.fc4.weight.detach().cpu(), m.fc4.bias.detach().cpu(), False)
+    gap_bf16 = (out16 - emu).abs().max().item()
+    _record("cfg5_family_b3_bf16_head", {
+        "graphs": 8, "nodes": int(hb["x"].shape[0]), "head_input_scale": scale_in, "head_input_gap_gpu_vs_fp64": gap_in,
+        "head_input_gap_fp32_cpu_vs_fp64": cpu_gap_in, "output_scale": scale, "output_gap_gpu_fp32_vs_fp64": gap_out,
+        "output_gap_fp32_cpu_vs_fp64": cpu_gap_out, "bf16_head_vs_rounded_operand_emulation": gap_bf16,
+        "bf16_head_vs_fp32_head": (out16 - out32).abs().max().item()})
+    assert gap_in <= max(1e-5 * scale_in, 2 * cpu_gap_in), (gap_in, cpu_gap_in, scale_in)
+    assert gap_out <= max(1e-5 * max(scale, 1.0), 2 * cpu_gap_out), (gap_out, cpu_gap_out)
+    assert gap_bf16 <= 1e-4 * max(scale, 1.0), gap_bf16
+    assert 0 < (out16 - out32).abs().max().item() <= 5e-2 * max(scale, 1.0)

@@ -418,3 +418,94 @@ def test_family_b_train_step_makes_no_device_to_host_copy(golden_dir, g1):
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.isfinite(loss).item()
+
+
+def _big_arena(steps, n_j, filler=0, seed=3):
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import TfimCorpus
+
+    hb = TfimCorpus(100, steps, n_j, seed=seed, exp_value_size=4).host_graphs()
+    return GraphArena.from_arrays(hb["x"], hb["edge_index"], hb["y"][:, None, :], hb["noisy"][:, None, :], hb["depth"],
+                                  hb["observable"], device=DEV, filler_nodes=filler)
+
+
+def test_coarsened_edge_capacity_bounds_the_real_count_on_100_qubit_graphs():
+    """GraphArena.coarse_caps: the structural bound sum_u (1 + outdeg u) sum_{v in N+[u]} (1 + outdeg v) really is an upper
+    bound on ASAPooling's coarsened edge count (whatever the top-k keeps), per graph, and the capacity-sized sync-free form of
+    the wave-per-cluster coarsening gives the same arrays as the form that reads the count back."""
+    from blackwater.native import functional as F
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    arena = _big_arena([1, 3, 6, 10], 2)
+    assert arena.coarse_caps is not None and len(arena.coarse_caps) == len(arena.node_counts)
+    torch.manual_seed(1)
+    model = ExpValCircuitGraphModel(22, 15, 4).to(DEV).eval()
+    sel = np.arange(len(arena))
+    res = {}
+    for use_cap in (True, False):
+        b = arena.batch(sel)
+        s = b.structure
+        assert s.coarse_capacity == int(arena.coarse_caps[sel].sum())
+        if not use_cap:
+            s.coarse_capacity = None
+        with torch.no_grad():
+            g = model.transformer1(b.x, s)
+            if use_cap:
+                torch.cuda.synchronize()
+                torch.cuda.set_sync_debug_mode("error")      # no device->host read in the pooling + coarsening
+            try:
+                g, s1, perm = model.pooling1(g, s)
+                _ = s1.in_ptr                                  # builds the (deferred) coarsened connectivity
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+        res[use_cap] = (s1, perm)
+    a, c = res[True][0], res[False][0]
+    e = int(c.in_ptr[c.num_nodes].item())
+    assert c.num_edges == e and a.num_edges == int(arena.coarse_caps[sel].sum()) >= e > 0
+    assert torch.equal(a.in_ptr[:a.num_nodes + 1], c.in_ptr[:c.num_nodes + 1])
+    assert torch.equal(a.out_ptr[:a.num_nodes + 1], c.out_ptr[:c.num_nodes + 1])
+    assert torch.equal(a.in_src[:e], c.in_src[:e]) and torch.equal(a.out_dst[:e], c.out_dst[:e]) and torch.equal(a.out_eid[:e], c.out_eid[:e])
+    assert torch.equal(res[True][1], res[False][1])
+    # per graph: real coarsened edges <= the graph's own bound
+    gp = a.graph_ptr.cpu().numpy()
+    per_graph = np.diff(c.out_ptr.cpu().numpy()[gp])
+    assert (per_graph <= arena.coarse_caps[sel]).all() and per_graph.sum() == e
+
+
+def test_family_b_step_on_100_qubit_graphs_is_captured_and_replays_bit_for_bit():
+    """The reference's GNN on the headline graphs as a captured step: with the coarsened edge arrays sized by the structural
+    bound nothing in the step reads the device, so train.BucketedTrainer captures it (size-stratified batches repeat their
+    size pattern) -- replayed losses equal the eagerly enqueued bucketed step's, bit for bit, and an eager step passes under
+    torch's sync-debug mode."""
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModel
+    from blackwater.train import BucketedTrainer, StratifiedBatches
+
+    arena = _big_arena([1, 2, 5], 6, filler=1024)
+    n = len(arena)
+    runs = {}
+    for graphs in (False, True):
+        torch.manual_seed(0)
+        sampler = StratifiedBatches(arena.node_counts[:n], arena.edge_counts[:n], 6, seed=5)
+        bt = BucketedTrainer(ExpValCircuitGraphModel(22, 15, 4).to(DEV), arena, lr=1e-3, graphs=graphs, node_quantum=1024,
+                             edge_quantum=2048)
+        losses = []
+        for k in range(6):
+            ids = sampler.draw()
+            if not graphs and k == 3:
+                torch.cuda.synchronize()
+                torch.cuda.set_sync_debug_mode("error")
+                try:
+                    loss = bt.step_ids(ids)
+                finally:
+                    torch.cuda.set_sync_debug_mode("default")
+            else:
+                loss = bt.step_ids(ids)
+            losses.append(float(loss))
+        runs[graphs] = (losses, bt.flat_param.detach().clone(), len(bt._entries))
+        ops.set_seed_counter(None)
+        del bt
+    assert runs[True][2] == 1                      # one pattern, seen eagerly once, then captured
+    assert runs[False][0] == runs[True][0]
+    assert torch.equal(runs[False][1], runs[True][1])
+    assert all(np.isfinite(runs[True][0]))

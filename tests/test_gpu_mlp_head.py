@@ -136,3 +136,34 @@ def test_inference_call_writes_no_stash_and_empty_input_is_fine():
     with pytest.raises(Exception):
         ops.mlp1_forward(torch.randn(4, 300, device=DEV), torch.randn(8, 300, device=DEV), torch.randn(8, device=DEV),
                          torch.randn(1, 8, device=DEV), torch.randn(1, device=DEV))      # I > 175: not this kernel's shape
+
+
+@pytest.mark.parametrize("kind", ["mlp1", "mlp3"])
+def test_rows_trainer_replays_the_step_from_a_graph_bit_for_bit(kind):
+    """train.RowsTrainer: the whole MLP step (forward, MSE, backward, Adam) captured in a hipGraph equals the same step
+    enqueued eagerly, loss by loss -- with BatchNorm statistics and dropout masks (MLP3) advancing per replay."""
+    from blackwater.native import ops
+    from blackwater.nn.mlp import MLP1, MLP3
+    from blackwater.train import RowsTrainer
+
+    torch.manual_seed(0)
+    x, y = torch.randn(4096, 170, device=DEV), torch.randn(4096, 1, device=DEV)
+    x2 = torch.randn(4096, 170, device=DEV)
+    runs = {}
+    for graphs in (False, True):
+        torch.manual_seed(1)
+        model = (MLP1(170, 128, 1) if kind == "mlp1" else MLP3(170, 125, 1)).to(DEV)
+        tr = RowsTrainer(model, lr=1e-3, graphs=graphs)
+        losses = []
+        for k in range(12):
+            losses.append(float(tr.step_rows(x if k % 2 == 0 else x2, y)))
+        runs[graphs] = (losses, [p.detach().clone() for p in model.parameters()], [b.detach().clone() for b in model.buffers()])
+        ops.set_seed_counter(None)
+    assert runs[False][0] == runs[True][0]
+    assert runs[False][0][-1] < runs[False][0][0]
+    for a, b in zip(runs[False][1], runs[True][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(runs[False][2], runs[True][2]):
+        assert torch.equal(a, b)
+    if kind == "mlp3":      # the masks move with the device counter: two consecutive steps on the same rows differ in their dropout
+        assert len(set(runs[True][0])) == len(runs[True][0])
