@@ -39,6 +39,14 @@ STEPS_LIST = list(range(1, 11))
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_aggregate_pmc.json")
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """One line on stderr per leg (stdout carries the ONE JSON line): a run that prints nothing for minutes looks hung."""
+    print(f"[bench {time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def fixed_ids(n_graphs, batch=DEFAULT_BATCH):
     """The representative batch the roofline leg (and the profiling scripts) use: every step count, evenly."""
     return np.arange(batch) * n_graphs // batch
@@ -857,6 +865,7 @@ def main():
     from blackwater.train import BucketedTrainer, DataParallelShard, StratifiedBatches
 
     n_j = args.n_j if args.n_j > 0 else -(-CORPUS_BATCHES * args.batch * world // len(STEPS_LIST))
+    progress("building the corpus")
     corpus = build_corpus(n_j)
     # the data-parallel split by circuit: balanced by node count, every shard the same length
     local_ids = DataParallelShard.split(corpus.node_counts, world)[rank]
@@ -935,6 +944,7 @@ def main():
     if rank == 0:
         total = args.batch * joined * args.steps
         fixed = arena.batch(fixed_ids(n_local, args.batch))
+        progress(f"timed region done: {total / elapsed:.0f} circuits/s; roofline leg")
         line = {
             "metric": "circuits/sec (GNN train step), 100q TFIM Trotter",
             "value": round(total / elapsed, 2), "unit": "circuits/s", "n_gpus": joined, "steps": args.steps,
@@ -958,17 +968,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             rep = local_ids[fixed_ids(n_local, args.batch)]
+            progress("cpu_baseline leg")
             line["cpu_baseline"] = cpu_baseline_leg(corpus, rep, 100)
+            progress("parity leg")
             line["parity"] = parity_leg(model, arena, corpus, local_ids, 100)   # the oracle as the checker, outside the timed region
             del trainer, model, arena, fixed
             from blackwater.native import ops as _ops
             _ops.set_seed_counter(None)       # the bucketed trainer's device-resident dropout counter
             torch.cuda.empty_cache()
-            line["accuracy"] = accuracy_leg(dev)
-            line["family_b"] = family_b_leg(dev)
-            line["small_batch"] = small_batch_leg(dev)
-            line["mlp_head"] = mlp_head_leg(dev)
-            line["inference"] = inference_leg(dev)
+            for key, leg in (("accuracy", accuracy_leg), ("family_b", family_b_leg), ("small_batch", small_batch_leg),
+                             ("mlp_head", mlp_head_leg), ("inference", inference_leg)):
+                progress(f"{key} leg")
+                line[key] = leg(dev)
+            progress("done")
         print(json.dumps(line), flush=True)
     if distributed:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: leave together
