@@ -713,6 +713,7 @@ def inference_leg(dev):
             r = {}
             est_b = ngem(Est, model, backend, batched=True)()
             for count in (64, 1024):
+                progress(f"  inference {nq}q {name}: batched run of {count}")
                 qs = [texts[k % n_distinct] for k in range(count)]
                 ob = [obs1] * count
                 est_b.run(qs[:8], ob[:8]).result()
@@ -720,6 +721,7 @@ def inference_leg(dev):
                 r[f"batched_{count}"] = {"circuits_per_s": round(count / dt, 1), "ms_per_run": round(dt * 1e3, 2)}
             n_serial = 32 if nq == 4 else 4
             est_s = ngem(Est, model, backend)()
+            progress(f"  inference {nq}q {name}: serial run of {n_serial}")
             qs, ob = [texts[k % n_distinct] for k in range(n_serial)], [obs1] * n_serial
             est_s.run(qs[:2], ob[:2]).result()
             dt, vals_s = wall(lambda: est_s.run(qs, ob).result().values)
@@ -732,6 +734,7 @@ def inference_leg(dev):
             ref.load_state_dict(state)
             est_c = ngem(Est, ref, backend)()
             n_cpu = 8 if nq == 4 else 2
+            progress(f"  inference {nq}q {name}: CPU oracle on {n_cpu}")
             qs, ob = qs[:n_cpu], ob[:n_cpu]
             t0 = time.perf_counter()
             vals_c = est_c.run(qs, ob).result().values
@@ -749,6 +752,7 @@ def inference_leg(dev):
         est_l = learning(Est, proc, skip_transpile=True)()
         r = {}
         for count in (64, 1024):
+            progress(f"  inference {nq}q learning: process_batch of {count}")
             qs, ob = [texts[k % n_distinct] for k in range(count)], [obs1] * count
             est_l.run(qs[:8], ob[:8]).result()
             dt, _ = wall(lambda: est_l.run(qs, ob).result().values)
@@ -976,8 +980,11 @@ def main():
             from blackwater.native import ops as _ops
             _ops.set_seed_counter(None)       # the bucketed trainer's device-resident dropout counter
             torch.cuda.empty_cache()
+            only = [k for k in os.environ.get("MLQEM_BENCH_LEGS", "").split(",") if k]     # diagnostics: a subset of the legs
             for key, leg in (("accuracy", accuracy_leg), ("family_b", family_b_leg), ("small_batch", small_batch_leg),
                              ("mlp_head", mlp_head_leg), ("inference", inference_leg)):
+                if only and key not in only:
+                    continue
                 progress(f"{key} leg")
                 line[key] = leg(dev)
             progress("done")

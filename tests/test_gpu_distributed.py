@@ -79,3 +79,50 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert cfg["step_mode"].startswith("hipgraph replay")
     # corpus = 8 x batch x ranks circuits (rounded up to whole J grids), each rank holds half of it
     assert cfg["corpus_circuits"] >= 8 * 32 * 2 and cfg["corpus_circuits_per_gpu"] == cfg["corpus_circuits"] // 2
+
+
+def test_family_b_two_ranks_on_one_gpu_equal_one_process_on_the_whole_batch(tmp_path):
+    """The reference's model (Family B, hidden 48: a flat gradient buffer of 105 418 floats) trained by two ranks that share
+    this box's GPU over gloo, each on its half of every batch, against ONE process on the whole batch: replicas start from
+    rank 0's parameters (they are built from different seeds), stay in lock-step, and all-reduce to the single process's
+    gradient up to fp32 rounding (pre-scaled by 1/world before a SUM all-reduce).  Parameters are compared through the
+    gradient and the losses, not element by element: Adam turns a gradient that is zero in exact arithmetic (the key bias of
+    an attention layer: softmax is shift-invariant) into +-lr steps whose sign is rounding noise.  tests/dp_family_b_worker.py
+    is one rank."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "dp_family_b_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    outs = [str(tmp_path / f"rank{r}.pt") for r in (0, 1)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), outs[r]], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=600)[0])
+    finally:
+        for p in procs:          # exactly the two children this test started
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(log[-1500:] for log in logs)
+    single = str(tmp_path / "single.pt")
+    one = subprocess.run([sys.executable, worker, "0", "1", "0", single], env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-1500:]
+    r0, r1, ref = (torch.load(p, weights_only=False) for p in (outs[0], outs[1], single))
+    assert r0["floats"] == 105418
+    assert torch.equal(r0["param"], r1["param"])                          # lock-step, bit for bit
+    assert r0["losses"] != r1["losses"]                                   # ... on different halves
+    assert torch.equal(r0["grad0"], r1["grad0"])
+    gap = (ref["grad0"] - r0["grad0"]).norm().item() / ref["grad0"].norm().item()
+    assert gap <= 1e-5, gap                                               # mean of the two half-batch gradients = the batch's
+    assert ((ref["param"] - r0["param"]).abs() > 1e-5).float().mean().item() < 0.01
+    mean = [(a + b) / 2 for a, b in zip(r0["losses"], r1["losses"])]     # equal halves: the whole batch's MSE is their mean
+    assert np.allclose(mean, ref["losses"], rtol=1e-4, atol=1e-7)
+    assert ref["losses"][-1] < ref["losses"][0]
