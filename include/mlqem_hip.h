@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 16 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 17 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -541,6 +541,24 @@ int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* props, int us
                       int64_t* num_nodes, int64_t* num_edges, int* num_features, int* depth, double* x,
                       int32_t* edge_src, int32_t* edge_dst, double* edge_attr);
 const char* mlqem_encode_last_error(void);
+
+/* The same encoding for ALL circuits of one estimator run() (NgemJob.result loops over them one by one:
+ * blackwater/library/ngem/estimator.py:49-84), as the COLLATED batch the models consume (what PyG's Batch.from_data_list makes
+ * of the per-circuit Data objects, docs/tutorials/__ml_models.py:105-119), on `threads` host threads (0 = one per core, at
+ * most 16).  Two calls, so that the caller owns every output buffer at its exact size:
+ *   parse: scans and checks every text; node_ptr[count+1] / edge_ptr[count+1] are the prefix sums of the circuits' node and
+ *          edge counts, depths[count] (optional) their depths, *num_features the row width; *handle keeps the parsed circuits.
+ *          On an error nothing is kept, *failed (optional) is the index of the first bad circuit and the message names it.
+ *   fill:  x[node_ptr[count], F] as float32 (the rounding the reference's torch.tensor(..., dtype=float) applies),
+ *          edge_src / edge_dst[edge_ptr[count]] as int64 with each circuit's node offset added (the two rows of edge_index),
+ *          batch[node_ptr[count]] (optional) = the circuit index of every node.  May be called more than once.
+ *   free:  releases the handle (NULL is fine).
+ * Same error codes as mlqem_encode_qasm; same arrays, circuit by circuit (tests/test_native_encoder.py). */
+int mlqem_qasm_batch_parse(const char* const* qasm, int64_t count, const mlqem_backend_props* props, int use_qubit_features,
+                           int use_gate_features, int threads, void** handle, int64_t* node_ptr, int64_t* edge_ptr,
+                           int* depths, int* num_features, int64_t* failed);
+int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_t* edge_src, int64_t* edge_dst, int64_t* batch);
+void mlqem_qasm_batch_free(void* handle);
 
 /* Circuit-level features of the MLP regressors -- the per-circuit part of encode_data / encode_data_v2_ecr
  * (docs/tutorials/mlp.py:111-145 count_gates_by_rotation_angle, :148-252; == blackwater/library/learning/mlp.py) from

@@ -39,24 +39,76 @@ class NativeEncoder:
                              self._keys, dp(self._ge), dp(self._gl))
         self._lib = _lib.load()
 
-    def encode(self, qasm: str, use_gate_features: bool = True, use_qubit_features: bool = True):
-        """-> (x [N,F] f64, edge_index [2,E] int64, edge_attr [E,3] f64, depth)."""
+    def encode(self, qasm: str, use_gate_features: bool = True, use_qubit_features: bool = True, edge_attr: bool = True):
+        """-> (x [N,F] f64, edge_index [2,E] int64, edge_attr [E,3] f64 (None with ``edge_attr=False``), depth)."""
         lib, text = self._lib, qasm.encode()
-        n, e = ctypes.c_int64(0), ctypes.c_int64(0)
         f, d = ctypes.c_int(0), ctypes.c_int(0)
-        args = (text, ctypes.byref(self._props), int(use_qubit_features), int(use_gate_features), ctypes.byref(n),
-                ctypes.byref(e), ctypes.byref(f), ctypes.byref(d))
-        code = lib.mlqem_encode_qasm(*args, None, None, None, None)
-        if code != 0:
-            self._raise(code)
-        x = np.empty((n.value, f.value), dtype=np.float64)
-        src, dst = np.empty(e.value, dtype=np.int32), np.empty(e.value, dtype=np.int32)
-        attr = np.empty((e.value, 3), dtype=np.float64)
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        code = lib.mlqem_encode_qasm(*args, vp(x), vp(src), vp(dst), vp(attr))
+        n_feat = 3 + self._props.num_gate_types + 2 + (9 if use_qubit_features else 0) + (2 if use_gate_features else 0)
+        # ONE parse: buffers sized from the text (a statement per ';', a qubit argument per '['); only a circuit that
+        # broadcasts over whole registers can need more, and then the call reports the sizes it wants
+        cap_n, cap_e = text.count(b";"), text.count(b"[")
+        for _ in range(2):
+            n, e = ctypes.c_int64(cap_n), ctypes.c_int64(cap_e)
+            x = np.empty((cap_n, n_feat), dtype=np.float64)
+            src, dst = np.empty(cap_e, dtype=np.int32), np.empty(cap_e, dtype=np.int32)
+            attr = np.empty((cap_e, 3), dtype=np.float64) if edge_attr else None
+            code = lib.mlqem_encode_qasm(text, ctypes.byref(self._props), int(use_qubit_features), int(use_gate_features),
+                                         ctypes.byref(n), ctypes.byref(e), ctypes.byref(f), ctypes.byref(d), vp(x), vp(src), vp(dst),
+                                         vp(attr) if edge_attr else None)
+            if code != _lib.ERR_WORKSPACE:
+                break
+            cap_n, cap_e = max(n.value, cap_n), max(e.value, cap_e)
         if code != 0:
             self._raise(code)
-        return x, np.stack([src, dst]).astype(np.int64), attr, d.value
+        assert f.value == n_feat
+        x, src, dst = x[:n.value], src[:e.value], dst[:e.value]
+        return x, np.stack([src, dst]).astype(np.int64), (attr[:e.value] if edge_attr else None), d.value
+
+    def encode_many(self, texts, threads: int = 0, **kwargs):
+        """``encode`` of every text, on a pool of host threads (the C call releases the GIL; results in input order)."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        threads = threads or min(16, os.cpu_count() or 1, max(len(texts), 1))
+        if threads <= 1 or len(texts) <= 1:
+            return [self.encode(t, **kwargs) for t in texts]
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            return list(pool.map(lambda t: self.encode(t, **kwargs), texts))
+
+    def encode_batch(self, texts, threads: int = 0, pin: bool = False, use_gate_features: bool = True,
+                     use_qubit_features: bool = True):
+        """The collated batch the models consume, straight from the texts of one ``run()`` (``mlqem_qasm_batch_parse`` /
+        ``_fill``: every circuit scanned on a pool of host threads, rows written once, as float32, at their place in the
+        batch): ``x`` [sum N, F] float32, ``edge_index`` [2, sum E] int64 with node offsets applied, ``batch`` [sum N] int64,
+        per-circuit node counts and depths.  Equal to ``Batch.from_data_list`` of the per-circuit encodings (no self-loops:
+        blackwater/library/ngem/estimator.py:61-66 encodes at inference without the training transform).  ``pin``: page-locked
+        outputs (one DMA to the GPU)."""
+        import torch
+
+        lib, count = self._lib, len(texts)
+        raw = [t.encode() for t in texts]
+        arr = (ctypes.c_char_p * max(count, 1))(*raw)
+        node_ptr, edge_ptr = np.zeros(count + 1, dtype=np.int64), np.zeros(count + 1, dtype=np.int64)
+        depths = np.zeros(max(count, 1), dtype=np.int32)
+        handle, f, failed = ctypes.c_void_p(None), ctypes.c_int(0), ctypes.c_int64(-1)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        code = lib.mlqem_qasm_batch_parse(arr, count, ctypes.byref(self._props), int(use_qubit_features), int(use_gate_features),
+                                          int(threads), ctypes.byref(handle), vp(node_ptr), vp(edge_ptr), vp(depths), ctypes.byref(f),
+                                          ctypes.byref(failed))
+        if code != 0:
+            self._raise(code)
+        try:
+            n, e = int(node_ptr[-1]), int(edge_ptr[-1])
+            x = torch.empty((n, f.value), dtype=torch.float32, pin_memory=pin)
+            ei = torch.empty((2, e), dtype=torch.int64, pin_memory=pin)
+            batch = torch.empty(n, dtype=torch.int64, pin_memory=pin)
+            code = lib.mlqem_qasm_batch_fill(handle, int(threads), x.data_ptr(), ei[0].data_ptr(), ei[1].data_ptr(), batch.data_ptr())
+            if code != 0:
+                self._raise(code)
+        finally:
+            lib.mlqem_qasm_batch_free(handle)
+        return x, ei, batch, np.diff(node_ptr), depths[:count].tolist()
 
     def _raise(self, code):
         msg = self._lib.mlqem_encode_last_error().decode()

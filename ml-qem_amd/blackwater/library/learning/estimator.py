@@ -35,6 +35,8 @@ class TorchLearningModelProcessor(LearningMethodEstimatorProcessor):
     As in the reference (:170-187) the WHOLE-observable expectation value is the noisy input of every term, so this is
     meant for single-Pauli observables (``separate_observables=True`` in the VQE drivers)."""
 
+    accepts_qasm_text = True     # process_batch scans OpenQASM text natively: PostProcessedJob hands text over unparsed
+
     def __init__(self, model: torch.nn.Module, backend):
         self._model = model
         self._backend = backend
@@ -58,16 +60,20 @@ class TorchLearningModelProcessor(LearningMethodEstimatorProcessor):
     def process_batch(self, expectation_values, circuits, observables, parameter_values):
         """All (circuit, Pauli term) rows of one ``run()`` through ONE model call (an addition: ``PostProcessedJob``
         uses it when the processor has it; results equal ``process`` applied circuit by circuit)."""
-        rows, owners, coeffs = [], [], []
+        rows, owners, coeffs, values, bases = [], [], [], [], []
         for k, (value, circuit, obs) in enumerate(zip(expectation_values, circuits, observables)):
             for term in obs:
-                x, _ = encode_data(circuits=[circuit], properties=self._properties, ideal_exp_vals=[[0.0]],
-                                   noisy_exp_vals=[[value]], num_qubits=1,
-                                   meas_bases=encode_pauli_sum_op([(str(term.paulis[0]), 1.0)]))
-                rows.append(x)
+                rows.append(circuit)
                 owners.append(k)
                 coeffs.append(term.coeffs[0])
-        model_input = torch.cat(rows, dim=0)
+                values.append([float(value)])
+                bases.append(encode_pauli_sum_op([(str(term.paulis[0]), 1.0)])[0])
+        if not rows:
+            return [0.0] * len(circuits)
+        # one feature matrix for the whole run(); OpenQASM text goes through the C++ op scan (mlqem_circuit_features_qasm)
+        native = all(isinstance(c, str) for c in rows)
+        model_input, _ = encode_data(circuits=rows, properties=self._properties, ideal_exp_vals=[[0.0]] * len(rows),
+                                     noisy_exp_vals=values, num_qubits=1, meas_bases=bases, native=native)
         device = model_device(self._model)
         if device is not None:
             model_input = model_input.to(device)
@@ -138,8 +144,8 @@ class PostProcessedJob(job_base()):  # type: ignore[misc]
             if not is_pauli_observable(obs):
                 raise BlackwaterException("Only `PauliSumOp` observables are supported by learning primitive.")
             opts = dict(optimization_level=3, **_options_dict(self._options))
-            bound = transpile_and_bind(circuit, self._wrapped_backend, params, opts,
-                                       do_transpile=not self._skip_transpile)
+            bound = transpile_and_bind(circuit, self._wrapped_backend, params, opts, do_transpile=not self._skip_transpile,
+                                       keep_text=batch_fn is not None and getattr(self._processor, "accepts_qasm_text", False))
             metadata.append({**meta, "original_value": value})
             if batch_fn is not None:
                 bound_all.append(bound)

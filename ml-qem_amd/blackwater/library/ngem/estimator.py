@@ -46,51 +46,51 @@ class NgemJob(job_base()):  # type: ignore[misc]
         properties = get_backend_properties_v1(self._backend)  # recomputed per call, like the reference (:46)
         device = model_device(self._model)
         mitigated = []
-        entries = []
-        native = None
-        if self._batched:  # the fast mode also encodes with the C++ encoder (bit-identical arrays, ~10x faster)
-            from ...data.circuit import Circuit, circuit_to_qasm
-            from ...data.graph import Data
-            from ...data.native_encoder import NativeEncoder
-
-            native = NativeEncoder(properties)
+        if self._batched:
+            return make_estimator_result(np.array(self._result_batched_native(result, properties, device)), result.metadata)
         for value, circuit, obs, params in zip(result.values, self._circuits, self._observables,
                                                self._parameter_values):
             if not is_pauli_observable(obs):
                 raise BlackwaterException("Only `PauliSumOp` observables are supported by NGEM.")
             bound = transpile_and_bind(circuit, self._backend, params, _options_dict(self._options))
-            if native is not None:
-                text = bound if isinstance(bound, str) else circuit_to_qasm(Circuit.from_any(bound))
-                x, ei, ea, _ = native.encode(text)
-                entries.append(Data(x=torch.from_numpy(x).float(), edge_index=torch.from_numpy(ei),
-                                    edge_attr=torch.from_numpy(ea).float(), y=torch.zeros(1, 1),
-                                    observable=torch.tensor([encode_pauli_sum_op(obs)], dtype=torch.float),
-                                    circuit_depth=torch.zeros(1, 1), noisy_0=torch.tensor([[value]], dtype=torch.float)))
-                continue
             graph = circuit_to_graph_data_json(circuit=bound, properties=properties, use_qubit_features=True,
                                                use_gate_features=True)
             data = ExpValueEntry(circuit_graph=graph, observable=encode_pauli_sum_op(obs), ideal_exp_value=0.0,
                                  noisy_exp_values=[value]).to_pyg_data()
-            if self._batched:
-                entries.append(data)
-                continue
             if device is not None:
                 data = data.to(device)
             with torch.no_grad():
                 out = self._model(data.noisy_0, data.observable, data.circuit_depth, data.x, data.edge_index,
                                   data.batch)
             mitigated.append(out.item())
-        if self._batched and entries:
-            # one collate + ONE model call for every circuit of this run() (the reference loops circuit by circuit,
-            # :49-84); needs observables of one shape, which a run() over one operator family has
-            batch = Batch.from_data_list(entries)
-            if device is not None:
-                batch = batch.to(device)
-            with torch.no_grad():
-                out = self._model(batch.noisy_0, batch.observable, batch.circuit_depth, batch.x, batch.edge_index,
-                                  batch.batch)
-            mitigated = out.reshape(len(entries), -1)[:, 0].tolist()
         return make_estimator_result(np.array(mitigated), result.metadata)
+
+    def _result_batched_native(self, result, properties, device):
+        """``batched=True``: every circuit of this run() encoded by the C++ encoder on a pool of host threads straight into ONE
+        collated batch (pinned when the model is on the GPU), ONE upload, ONE model call.  The reference's loop
+        (:49-84) encodes in Python and calls the model per circuit; the arrays are bit-identical (tests/test_gpu_family_b.py)."""
+        from ...data.circuit import Circuit, circuit_to_qasm
+        from ...data.native_encoder import NativeEncoder
+
+        texts, values, observables = [], [], []
+        for value, circuit, obs, params in zip(result.values, self._circuits, self._observables, self._parameter_values):
+            if not is_pauli_observable(obs):
+                raise BlackwaterException("Only `PauliSumOp` observables are supported by NGEM.")
+            bound = transpile_and_bind(circuit, self._backend, params, _options_dict(self._options), keep_text=True)
+            texts.append(bound if isinstance(bound, str) else circuit_to_qasm(Circuit.from_any(bound)))
+            values.append([float(value)])
+            observables.append(encode_pauli_sum_op(obs))   # needs observables of one shape, which a run() over one operator family has
+        on_gpu = device is not None and torch.device(device).type == "cuda"
+        x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch(texts, pin=on_gpu)
+        noisy = torch.tensor(values, dtype=torch.float)
+        observable = torch.tensor(observables, dtype=torch.float)
+        depth = torch.zeros(len(texts), 1)
+        args = [noisy, observable, depth, x, edge_index, batch]
+        if device is not None:
+            args = [a.to(device, non_blocking=on_gpu) for a in args]
+        with torch.no_grad():
+            out = self._model(*args)
+        return out.reshape(len(texts), -1)[:, 0].tolist()
 
     def submit(self):
         return self._base_job.submit()

@@ -115,11 +115,15 @@ SIGNATURES = {
     "mlqem_leconv_fitness_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
     "mlqem_encode_qasm": (_I, [c_char_p, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mlqem_encode_last_error": (c_char_p, []),
+    "mlqem_qasm_batch_parse": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "mlqem_qasm_batch_fill": (_I, [_P, _I, _P, _P, _P, _P]),
+    "mlqem_qasm_batch_free": (None, [_P]),
     "mlqem_circuit_features_qasm": (_I, [c_char_p, _P, _I, _P, _I, _P, _P]),
 }
 
 _lib = None
-ABI_VERSION = 16   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
+ABI_VERSION = 17   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

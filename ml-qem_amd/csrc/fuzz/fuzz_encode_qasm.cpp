@@ -42,6 +42,40 @@ static int run(const std::string& text, bool fill, int* code_out) {
   return 0;
 }
 
+// The batch entry points on the same texts, two worker threads: the batch is accepted exactly when every member is, a
+// rejected batch leaves no handle and names its first bad member, an accepted one fills buffers of the sizes it announced.
+static int run_batch(const std::vector<std::string>& texts, const std::vector<int>& single_codes) {
+  mlqem_backend_props p;
+  std::memset(&p, 0, sizeof(p));
+  p.num_qubits = 5; p.t1 = g_t1; p.t2 = g_t2; p.readout = g_ro;
+  p.num_gate_types = 6; p.gate_names = kGates; p.num_gate_props = 0;
+  std::vector<const char*> ptr;
+  for (auto& t : texts) ptr.push_back(t.c_str());
+  const int64_t count = (int64_t)texts.size();
+  std::vector<int64_t> node_ptr(count + 1), edge_ptr(count + 1);
+  std::vector<int> depths(count + 1);
+  void* handle = nullptr; int f = 0; int64_t failed = -1;
+  const int code = mlqem_qasm_batch_parse(ptr.data(), count, &p, 1, 1, 2, &handle, node_ptr.data(), edge_ptr.data(), depths.data(), &f, &failed);
+  int64_t first_bad = -1;
+  for (int64_t i = 0; i < count; ++i) if (single_codes[i] != MLQEM_OK) { first_bad = i; break; }
+  if ((code == MLQEM_OK) != (first_bad < 0)) { std::fprintf(stderr, "batch code %d, first bad member %ld\n", code, (long)first_bad); return 1; }
+  if (code != MLQEM_OK) {
+    if (handle != nullptr) { std::fprintf(stderr, "a rejected batch left a handle\n"); return 1; }
+    if (failed < 0 || failed >= count || single_codes[failed] == MLQEM_OK) { std::fprintf(stderr, "batch blames member %ld\n", (long)failed); return 1; }
+    return 0;
+  }
+  const int64_t n = node_ptr[count], e = edge_ptr[count];
+  std::vector<float> x((size_t)n * f + 1);
+  std::vector<int64_t> src((size_t)e + 1), dst((size_t)e + 1), batch((size_t)n + 1);
+  int rc = mlqem_qasm_batch_fill(handle, 2, x.data(), src.data(), dst.data(), batch.data());
+  mlqem_qasm_batch_free(handle);
+  if (rc != MLQEM_OK) { std::fprintf(stderr, "batch fill failed: %d\n", rc); return 1; }
+  for (int64_t i = 0; i < count; ++i)
+    for (int64_t k = edge_ptr[i]; k < edge_ptr[i + 1]; ++k)
+      if (src[k] < node_ptr[i] || src[k] >= node_ptr[i + 1] || dst[k] < node_ptr[i] || dst[k] >= node_ptr[i + 1]) { std::fprintf(stderr, "batch edge out of its circuit\n"); return 1; }
+  return 0;
+}
+
 int main() {
   const std::string head = "OPENQASM 2.0;\ninclude \"qelib1.inc\";\nqreg q[5];\ncreg c[5];\n";
   const std::string valid = head + "rz(pi/2) q[0];\nsx q[0];\ncx q[0],q[1];\nbarrier q;\nrz(-3*pi/4 + 0.5) q[2];\nx q;\nmeasure q -> c;\n";
@@ -118,6 +152,28 @@ int main() {
     bad |= run(t, (it & 3) == 0, nullptr);
   }
   std::printf("mutations: %d rounds\n", rounds);
+
+  // batches of mutated texts through mlqem_qasm_batch_parse / _fill (worker threads, pooled scratch)
+  int batches = 0;
+  for (int it = 0; it < rounds / 40 + 4; ++it, ++batches) {
+    std::vector<std::string> texts;
+    std::vector<int> codes;
+    const int members = (int)(rng() % 7);           // including the empty batch
+    for (int m = 0; m < members; ++m) {
+      std::string t = valid;
+      if (rng() % 3 == 0) {                         // one in three members is damaged
+        const size_t pos = rng() % t.size();
+        if (rng() % 2) t.erase(pos, 1 + rng() % 4); else t[pos] = alphabet[rng() % (sizeof(alphabet) - 1)];
+      }
+      int c = 0;
+      bad |= run(t, false, &c);
+      texts.push_back(t);
+      codes.push_back(c);
+    }
+    bad |= run_batch(texts, codes);
+  }
+  mlqem_qasm_batch_free(nullptr);
+  std::printf("batches: %d\n", batches);
   if (bad) return 1;
   std::printf("fuzz ok\n");
   return 0;

@@ -83,3 +83,45 @@ def test_circuit_features_match_python_feature_rows(g1, golden_dir, lima_props):
     assert hist.tolist() == bins
     with pytest.raises(TypeError):
         encode_data([Circuit.from_qasm_str(text)], lima_props, [[0.0]], [[0.1]], num_qubits=1, native=True)
+
+
+def test_batch_encoder_equals_the_collate_of_per_circuit_encodings(g1, lima_props):
+    """mlqem_qasm_batch_parse / _fill (every circuit of one estimator run() at once): the
+    collated batch equals ``Batch.from_data_list`` of the per-circuit encodings -- the reference's path
+    (blackwater/library/ngem/estimator.py:61-66, then PyG's collate) -- bit for bit, whatever the number of worker threads;
+    includes a circuit that broadcasts over whole registers, comments and a gate definition."""
+    import torch
+
+    from blackwater.data.graph import Batch, Data
+
+    props = dict(lima_props, gates_set=G1_GATES_ORDER)
+    enc = NativeEncoder(props)
+    extra = ('OPENQASM 2.0;\ninclude "qelib1.inc";\ngate foo a { x a; }\nqreg q[3];\ncreg c[3];\nrz(-3*pi/4) q; // all three\n'
+             'barrier q;\nx q[1];\nmeasure q -> c;\n')
+    texts = list(g1["qasm"][:40]) + [extra] + list(g1["qasm"][40:60])
+    entries = []
+    for t in texts:
+        x, ei, _, depth = enc.encode(t)
+        entries.append(Data(x=torch.from_numpy(x).float(), edge_index=torch.from_numpy(ei), y=torch.zeros(1, 1)))
+    want = Batch.from_data_list(entries)
+    for threads in (1, 3, 0):
+        x, ei, batch, counts, depths = enc.encode_batch(texts, threads=threads)
+        assert x.dtype == torch.float32 and torch.equal(x, want.x)
+        assert ei.dtype == torch.int64 and torch.equal(ei, want.edge_index)
+        assert torch.equal(batch, want.batch)
+        assert counts.tolist() == [e.x.shape[0] for e in entries]
+        assert depths[:40] == [int(d) for d in g1["depth"][:40]]
+    # the empty run()
+    x, ei, batch, counts, depths = enc.encode_batch([])
+    assert x.shape[0] == 0 and ei.shape == (2, 0) and batch.numel() == 0 and len(counts) == 0 and depths == []
+
+
+def test_batch_encoder_names_the_first_bad_circuit(lima_props):
+    enc = NativeEncoder(lima_props)
+    good = 'OPENQASM 2.0;\nqreg q[2];\nx q[0];\n'
+    with pytest.raises(Exception, match="circuit 2: "):
+        enc.encode_batch([good, good, 'OPENQASM 2.0;\nqreg q[2];\nrz(1 q[0];\n', good, 'OPENQASM 2.0;\nqreg q[2];\nrz((1) q[0];\n'], threads=1)
+    with pytest.raises(KeyError):           # a gate outside gates_set stays a KeyError, as in encode()
+        enc.encode_batch([good, 'OPENQASM 2.0;\nqreg q[2];\nh q[0];\n'])
+    x, _, _, _, _ = enc.encode_batch([good])        # the encoder is usable after a rejected batch
+    assert x.shape[0] == 1
