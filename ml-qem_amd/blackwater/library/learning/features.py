@@ -63,19 +63,30 @@ def _fill_rows(X, circuits, gates_set, offset, bin_size, n_bins, n_vals, noisy_e
     a1 = c1 + n_bins
     v1 = a1 + n_vals
     edges = np.arange(-2 * np.pi, 2 * np.pi + bin_size, bin_size)
-    for i, circuit in enumerate(circuits):
-        if native:
-            # the C++ op scan shared with the graph encoder (mlqem_circuit_features_qasm): same integers, no Python parse
+    if native:
+        # the C++ op scan shared with the graph encoder (mlqem_circuit_features_qasm): same integers, no Python parse; the rows
+        # of a whole run() are filled by three array assignments instead of three tensor constructions per circuit
+        from ...data.native_encoder import circuit_features
+
+        counts = np.zeros((len(circuits), len(gates_set)), dtype=np.int64)
+        hists = np.zeros((len(circuits), n_bins), dtype=np.int64)
+        for i, circuit in enumerate(circuits):
             if not isinstance(circuit, str):
                 raise TypeError("native=True takes OpenQASM-2 text (the 'circuit' field of the reference's datasets)")
-            from ...data.native_encoder import circuit_features
-
-            counts, hist = circuit_features(circuit, gates_set, edges)
-            counts, hist = counts.tolist(), hist.tolist()
-        else:
-            circ = Circuit.from_any(circuit)
-            tally = circ.count_ops()
-            counts, hist = [tally.get(g, 0) for g in gates_set], count_gates_by_rotation_angle(circ, bin_size)
+            counts[i], hists[i] = circuit_features(circuit, gates_set, edges)
+            if n_vals > 1:
+                assert len(noisy_exp_vals[i]) == n_vals
+            elif n_vals == 1:
+                assert isinstance(noisy_exp_vals[i], float)
+        if len(circuits):
+            # integer tensors times a python float promote to float32, as in the reference
+            X[:, c0:c1] = torch.from_numpy(counts) * 0.01
+            X[:, c1:a1] = torch.from_numpy(hists) * 0.01
+            X[:, a1:v1] = torch.tensor(noisy_exp_vals).reshape(len(circuits), -1)
+    for i, circuit in enumerate(circuits if not native else []):
+        circ = Circuit.from_any(circuit)
+        tally = circ.count_ops()
+        counts, hist = [tally.get(g, 0) for g in gates_set], count_gates_by_rotation_angle(circ, bin_size)
         # integer tensors times a python float promote to float32, as in the reference
         X[i, c0:c1] = torch.tensor(counts) * 0.01
         X[i, c1:a1] = torch.tensor(hist) * 0.01
@@ -86,8 +97,8 @@ def _fill_rows(X, circuits, gates_set, offset, bin_size, n_bins, n_vals, noisy_e
         X[i, a1:v1] = torch.tensor(noisy_exp_vals[i])
     if meas_bases != [[]]:
         assert len(meas_bases) == len(circuits)
-        for i, basis in enumerate(meas_bases):
-            X[i, v1:] = torch.tensor(basis)
+        if len(circuits):
+            X[:, v1:] = torch.tensor(meas_bases, dtype=X.dtype)
 
 
 def encode_data(circuits, properties, ideal_exp_vals, noisy_exp_vals, num_qubits, meas_bases=None, native=False):

@@ -187,6 +187,50 @@ def csr_segment_max(x, ptr, idx, ell=None, out=None):
     return out
 
 
+_tickets = {}   # (device, stream) -> zero-initialised unsigned the "last workgroup done" kernels count on (they leave it at zero)
+
+
+def _ticket(device):
+    key = (device, _stream())
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def mse_loss_grad(out, target, want_grad=True):
+    """(loss, g): loss = mean((out - target)^2) as a 0-dim device tensor and g = 2 (out - target) / numel -- what
+    ``MSELoss()(out, target).backward()`` hands to ``out`` -- from ONE launch (mlqem_mse_loss_grad_f32).  2-D fp32 operands
+    with contiguous columns (row-strided views are fine)."""
+    if out.shape != target.shape or out.dim() != 2 or out.numel() == 0:
+        raise ValueError("mse_loss_grad: out and target must be non-empty 2-D tensors of one shape")
+    n, c = out.shape
+    ldo, ldy = _mat(out, "out"), _mat(target, "target")
+    g = torch.empty((n, c), dtype=torch.float32, device=out.device) if want_grad else None
+    loss = torch.empty((), dtype=torch.float32, device=out.device)
+    lib = _lib.load()
+    need = lib.mlqem_mse_loss_workspace_bytes()
+    ws = _wgrad_workspace(out.device, need)
+    code = lib.mlqem_mse_loss_grad_f32(_p(out), ldo, _p(target), ldy, _p(g), c, n, c, _p(loss), _p(ws), need, _p(_ticket(out.device)), _stream())
+    _lib.check(code, "mlqem_mse_loss_grad_f32")
+    return loss, g
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):
+    """One Adam update of the flat fp32 buffer ``param`` in place (mlqem_adam_step_f32); ``step`` (0-dim fp32) and ``lr`` (0-dim
+    fp32) live on the device: ``step`` is incremented by the launch."""
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if not t.is_cuda:
+            raise _lib.NativeLibraryError(f"adam_step: {name} must live on the GPU; there is no CPU path")
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != param.numel():
+            raise ValueError(f"adam_step: {name} must be contiguous fp32 of the parameters' size")
+    if step.dtype != torch.float32 or lr.dtype != torch.float32 or step.numel() != 1 or lr.numel() != 1 or not (step.is_cuda and lr.is_cuda):
+        raise ValueError("adam_step: step and lr must be one-element fp32 device tensors")
+    code = _lib.load().mlqem_adam_step_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(lr), _p(step), float(beta1),
+                                           float(beta2), float(eps), _p(_ticket(param.device)), _stream())
+    _lib.check(code, "mlqem_adam_step_f32")
+
+
 def relu_dropout_bwd(g, y, scale=1.0, out=None):
     """gx = (y > 0) ? g * scale : 0 on [N, C] matrices (any leading dimensions; ``out`` may alias ``g``)."""
     if g.shape != y.shape or g.dim() != 2:

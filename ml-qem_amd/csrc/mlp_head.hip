@@ -645,11 +645,13 @@ __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_f32_kernel(const Mlp1Arg
   }
 }
 
-// Second stage: element e of the lane-ordered layout summed over the G workgroups in a fixed order (4 slices of the G range
+// Second stage: element e of the lane-ordered layout summed over the G workgroups in a fixed order (16 slices of the G range
 // per element, slice sums added in slice order), decoded to its (o, column) and filed into gW1 [H,I] / gb1 [H] / gW2 [O2,H] /
-// gb2 [O2].  64 consecutive elements per workgroup: every load instruction reads 256 contiguous bytes of one partial.
-constexpr int kHeadReduceSlices = 4;
-__global__ __launch_bounds__(256) void mlp1_bwd_reduce_kernel(const float* __restrict__ partial, int G, int I, int H, int O2,
+// gb2 [O2].  64 consecutive elements per workgroup: every load instruction reads 256 contiguous bytes of one partial.  The
+// pass reads G x 90 KB (46 MB at 512 workgroups): with 4 slices every thread walked 128 partials one dependent add after the
+// other and the launch took 22 us; 16 slices keep four times as many loads in flight.
+constexpr int kHeadReduceSlices = 16;
+__global__ __launch_bounds__(kHeadReduceSlices * kWave) void mlp1_bwd_reduce_kernel(const float* __restrict__ partial, int G, int I, int H, int O2,
                                                               int cpw, int bf16, float* __restrict__ gw1, float* __restrict__ gb1,
                                                               float* __restrict__ gw2, float* __restrict__ gb2) {
   __shared__ float s[kHeadReduceSlices][kWave];
@@ -689,7 +691,16 @@ __global__ __launch_bounds__(256) void mlp1_bwd_reduce_kernel(const float* __res
   if (kind >= 0) {
     const int per = (G + kHeadReduceSlices - 1) / kHeadReduceSlices;
     const int g1 = min(G, (sl + 1) * per);
-    for (int g = sl * per; g < g1; ++g) t += partial[(int64_t)g * kHeadPartialFloats + e];
+    int g = sl * per;
+    float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (; g + 3 < g1; g += 4) {              // four independent chains, joined in a fixed order below
+      t += partial[(int64_t)g * kHeadPartialFloats + e];
+      t1 += partial[(int64_t)(g + 1) * kHeadPartialFloats + e];
+      t2 += partial[(int64_t)(g + 2) * kHeadPartialFloats + e];
+      t3 += partial[(int64_t)(g + 3) * kHeadPartialFloats + e];
+    }
+    for (; g < g1; ++g) t += partial[(int64_t)g * kHeadPartialFloats + e];
+    t = (t + t1) + (t2 + t3);
   }
   s[sl][el] = t;
   __syncthreads();
@@ -818,7 +829,7 @@ extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* 
       else launch(mlp1_bwd_f32_kernel<4, KU, 2, 3>);
     }
   }
-  hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(kHeadPartialFloats, kWave)), dim3(256), 0, s, a.partial, G, I, H, O2,
+  hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(kHeadPartialFloats, kWave)), dim3(kHeadReduceSlices * kWave), 0, s, a.partial, G, I, H, O2,
                      reduce_layout, bf16 ? 1 : 0, gw1, gb1, gw2, gb2);
   return launch_status();
 }
