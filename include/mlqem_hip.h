@@ -267,7 +267,10 @@ int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t 
  * take workspace = mlqem_layer_workspace_bytes() (16-byte aligned); partial sums per workgroup, fixed-order second stages.
  *   gemm      : Y = X W^T + b (transposed = 0, W [U,K]) or Y = X W (+ add) (transposed = 1, W [K,U]: the data gradient);
  *               X fp32 [N,K <= 192] (ldx floats, ldx % 4 == 0) or bf16 [N,128] (K <= 128); Y bf16 [N,128] or fp32 [N,ldy].
- *   colstats 0: batch statistics of y -> mean, biased var, invstd, scale = gamma invstd, shift = beta - mean scale.
+ *   colstats 0: batch statistics of y -> mean, biased var, invstd, scale = gamma invstd, shift = beta - mean scale (outputs
+ *               are [128]; columns >= C come out 0), and, when running_mean / running_var [C] are given, BatchNorm1d's
+ *               update of them in the same launch (running = (1 - momentum) running + momentum batch, variance unbiased,
+ *               *num_batches_tracked += 1 when given; N >= 2).
  *   colstats 1: with gu = g o (y scale + shift > 0) o keep / (1 - p): dbeta = sum gu, dgamma = sum gu xhat, gs = gamma invstd,
  *               k1 = dbeta / N, k2 = dgamma / N  (g: bf16 [N,128], or fp32 [N,ldg32] when g32 != NULL).
  *   pointwise 0: out = dropout(relu?(y scale + shift)) (+ res);   1: out = gs (gu - k1 - xhat k2)   (BatchNorm backward).
@@ -280,7 +283,8 @@ int mlqem_layer_gemm_bf16(const void* x, int x_is_bf16, int64_t ldx, const float
 int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale,
                               const float* shift, const float* mean, const float* invstd, const float* gamma, const float* beta,
                               float eps, int relu, float drop_p, uint64_t seed, const uint64_t* seed_counter, int64_t N, int C,
-                              float* o1, float* o2, float* o3, float* o4, float* o5, void* workspace, size_t workspace_bytes,
+                              float* o1, float* o2, float* o3, float* o4, float* o5, float* running_mean, float* running_var,
+                              float momentum, int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
                               mlqem_stream_t stream);
 int mlqem_layer_pointwise_bf16(int op, const void* y, const void* g, const float* g32, int64_t ldg32, const void* res,
                                const float* scale, const float* shift, const float* mean, const float* invstd, const float* gs,

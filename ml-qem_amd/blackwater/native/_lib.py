@@ -72,7 +72,7 @@ SIGNATURES = {
     "mlqem_layer_workspace_bytes": (_S, []),
     "mlqem_layer_gemm_bf16": (_I, [_P, _I, _L, _P, _I, _P, _P, _P, _I, _L, _L, _I, _I, _P, _S, _P]),
     "mlqem_layer_colstats_bf16": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _F, _I, _F, _U, _P, _L, _I, _P, _P, _P, _P, _P,
-                                       _P, _S, _P]),
+                                       _P, _P, _F, _P, _P, _S, _P]),
     "mlqem_layer_pointwise_bf16": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U, _P, _P, _L, _I, _P]),
     "mlqem_layer_wgrad_bf16": (_I, [_P, _P, _I, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_layer_rowdot_bf16": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P]),

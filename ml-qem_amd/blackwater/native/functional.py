@@ -128,16 +128,16 @@ class _MLPTrunkBf16(Function):
     var2) -- the batch statistics feed the running buffers."""
 
     @staticmethod
-    def forward(ctx, x, cfg, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, w4, b4):
+    def forward(ctx, x, cfg, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, w4, b4, run1=None, run2=None):
         eps1, eps2, p_trunk, p_tail, seeds = cfg
         n, i = x.shape
         h = w1.shape[0]
         xin = x if x.dtype == torch.bfloat16 else ops._mlp1_x(x)
         y1 = ops.layer_gemm_bf16(xin, w1.contiguous(), b1)
-        m1, v1, is1, sc1, sh1 = ops.layer_colstats_fwd(y1, g1, be1, eps1, n, h)
+        m1, v1, is1, sc1, sh1 = ops.layer_colstats_fwd(y1, g1, be1, eps1, n, h, running=run1)
         x1 = ops.layer_act_bf16(y1, sc1, sh1, n, h, True, p_trunk, seeds[0])
         y2 = ops.layer_gemm_bf16(x1, w2.contiguous(), b2)
-        m2, v2, is2, sc2, sh2 = ops.layer_colstats_fwd(y2, g2, be2, eps2, n, h)
+        m2, v2, is2, sc2, sh2 = ops.layer_colstats_fwd(y2, g2, be2, eps2, n, h, running=run2)
         s = ops.layer_act_bf16(y2, sc2, sh2, n, h, True, p_trunk, seeds[1], res=x1)
         if w4 is None:                      # MLP2: out = fc3(s)
             out = ops.layer_rowdot_bf16(s, w3.contiguous(), b3, n)
@@ -145,7 +145,7 @@ class _MLPTrunkBf16(Function):
         else:                               # MLP3: out = fc4(drop(relu(fc3(s))))
             h3w = w3.shape[0]
             y3 = ops.layer_gemm_bf16(s, w3.contiguous(), b3)
-            ctx.one, ctx.zero = torch.ones(ops.LAYER_W, device=x.device), torch.full((ops.LAYER_W,), 0.0, device=x.device)
+            ctx.one, ctx.zero = ops.layer_identity_vectors(x.device)
             h3 = ops.layer_act_bf16(y3, ctx.one, ctx.zero, n, h3w, True, p_tail, seeds[2])
             out = ops.layer_rowdot_bf16(h3, w4.contiguous(), b4, n)
         ctx.cfg, ctx.dims = cfg, (n, i, h)
@@ -180,7 +180,7 @@ class _MLPTrunkBf16(Function):
         dy1 = ops.layer_bwd_apply_bf16(gx1, y1, sc1, sh1, m1, is1, gs1, k1, k2, n, h, True, p_trunk, seeds[0])
         gw1, gb1 = ops.layer_wgrad_bf16(dy1, xin, h, i)
         gx = ops.layer_gemm_bf16(dy1, w1.contiguous(), transposed=True, out_f32=True) if ctx.x_needs_grad else None
-        return (gx, None, gw1, gb1, dg1[:h], db1[:h], gw2, gb2, dg2[:h], db2[:h], gw3, gb3, gw4, gb4)
+        return (gx, None, gw1, gb1, dg1[:h], db1[:h], gw2, gb2, dg2[:h], db2[:h], gw3, gb3, gw4, gb4, None, None)
 
 
 def mlp_trunk_bf16_ok(x, fc1, fc2, fc3, fc4, bn1, bn2) -> bool:
@@ -203,17 +203,11 @@ def mlp_trunk_bf16(x, fc1, bn1, fc2, bn2, fc3, fc4, p_trunk, p_tail, seeds):
     """Runs the block and updates the BatchNorm running statistics like torch (momentum, unbiased variance, batch counter)."""
     cfg = (float(bn1.eps), float(bn2.eps), float(p_trunk), float(p_tail), tuple(int(v) for v in seeds))
     w4, b4 = (None, None) if fc4 is None else (fc4.weight, fc4.bias)
-    out, m1, v1, m2, v2 = _MLPTrunkBf16.apply(x, cfg, fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight,
-                                              bn2.bias, fc3.weight, fc3.bias, w4, b4)
-    n = x.shape[0]
-    with torch.no_grad():
-        for bn, mean, var in ((bn1, m1, v1), (bn2, m2, v2)):
-            if bn.track_running_stats and bn.running_mean is not None:
-                mo = bn.momentum
-                bn.running_mean.mul_(1.0 - mo).add_(mean, alpha=mo)
-                bn.running_var.mul_(1.0 - mo).add_(var, alpha=mo * n / (n - 1))
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
+    # BatchNorm1d's buffer update rides in the statistics launches (running mean / unbiased variance / batch counter)
+    runs = [((bn.running_mean, bn.running_var, float(bn.momentum), bn.num_batches_tracked)
+             if bn.track_running_stats and bn.running_mean is not None else None) for bn in (bn1, bn2)]
+    out, _m1, _v1, _m2, _v2 = _MLPTrunkBf16.apply(x, cfg, fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight,
+                                                  bn2.bias, fc3.weight, fc3.bias, w4, b4, runs[0], runs[1])
     return out
 
 

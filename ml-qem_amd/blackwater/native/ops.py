@@ -560,6 +560,16 @@ def _layer_ws(device):
     return _wgrad_workspace(device, need), need
 
 
+_layer_consts = {}   # device -> (ones [128], zeros [128]): the scale / shift of a block without BatchNorm
+
+
+def layer_identity_vectors(device):
+    c = _layer_consts.get(device)
+    if c is None:
+        c = _layer_consts[device] = (torch.ones(LAYER_W, dtype=torch.float32, device=device), torch.zeros(LAYER_W, dtype=torch.float32, device=device))
+    return c
+
+
 def _act(n, device):
     return torch.empty((max(n, 1), LAYER_W), dtype=torch.bfloat16, device=device)
 
@@ -593,13 +603,19 @@ def layer_gemm_bf16(x, w, b=None, *, transposed=False, add=None, out_f32=False):
     return y
 
 
-def layer_colstats_fwd(y, gamma, beta, eps, n, c):
-    """(mean, var, invstd, scale, shift) of the first ``c`` columns of the bf16 activation ``y`` over ``n`` rows."""
+def layer_colstats_fwd(y, gamma, beta, eps, n, c, running=None):
+    """(mean, var, invstd, scale, shift) of the first ``c`` columns of the bf16 activation ``y`` over ``n`` rows (each [128], zeros
+    beyond ``c``).  ``running`` = (running_mean, running_var, momentum, num_batches_tracked | None): BatchNorm1d's buffer update,
+    applied by the same launch."""
     dev = y.device
-    o = [torch.zeros(LAYER_W, dtype=torch.float32, device=dev) for _ in range(5)]
+    o = list(torch.empty((5, LAYER_W), dtype=torch.float32, device=dev).unbind(0))      # the launch writes every entry
     ws, need = _layer_ws(dev)
+    rm, rv, mo, nbt = running if running is not None else (None, None, 0.0, None)
+    if rm is not None and not (rm.is_cuda and rv.is_cuda and rm.dtype == rv.dtype == torch.float32 and rm.numel() == rv.numel() == c
+                               and rm.is_contiguous() and rv.is_contiguous() and (nbt is None or (nbt.is_cuda and nbt.dtype == torch.int64))):
+        raise ValueError("layer_colstats_fwd: running statistics must be contiguous fp32 [c] device tensors (counter: int64)")
     code = _lib.load().mlqem_layer_colstats_bf16(0, _p(y), None, None, 0, None, None, None, None, _p(gamma), _p(beta), float(eps), 0, 0.0, 0,
-                                                 None, n, c, *[_p(t) for t in o], _p(ws), need, _stream())
+                                                 None, n, c, *[_p(t) for t in o], _p(rm), _p(rv), float(mo), _p(nbt), _p(ws), need, _stream())
     _lib.check(code, "mlqem_layer_colstats_bf16")
     return o
 
@@ -607,12 +623,12 @@ def layer_colstats_fwd(y, gamma, beta, eps, n, c):
 def layer_colstats_bwd(g, y, scale, shift, mean, invstd, gamma, relu, drop_p, seed, n, c):
     """(dbeta, dgamma, gs, k1, k2) of a BatchNorm block from the incoming gradient ``g`` (bf16 activation or fp32 [N, c]) and ``y``."""
     dev = y.device
-    o = [torch.zeros(LAYER_W, dtype=torch.float32, device=dev) for _ in range(5)]
+    o = list(torch.empty((5, LAYER_W), dtype=torch.float32, device=dev).unbind(0))      # the launch writes every entry
     ws, need = _layer_ws(dev)
     g16, g32, ld = (g, None, 0) if g.dtype == torch.bfloat16 else (None, g, _mat(g, "g") if n > 1 else c)
     code = _lib.load().mlqem_layer_colstats_bf16(1, _p(y), _p(g16), _p(g32), ld, _p(scale), _p(shift), _p(mean), _p(invstd), _p(gamma), None,
-                                                 0.0, 1 if relu else 0, *_seed_args(drop_p, seed), n, c, *[_p(t) for t in o], _p(ws),
-                                                 need, _stream())
+                                                 0.0, 1 if relu else 0, *_seed_args(drop_p, seed), n, c, *[_p(t) for t in o], None, None, 0.0,
+                                                 None, _p(ws), need, _stream())
     _lib.check(code, "mlqem_layer_colstats_bf16")
     return o
 

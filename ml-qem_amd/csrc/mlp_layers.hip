@@ -309,15 +309,28 @@ __global__ __launch_bounds__(256) void layer_colsum_kernel(const ActArgs a) {
 // One 64-lane workgroup per column: partials added in a fixed order in double.
 // MODE 0 -> mean, biased var, invstd, scale = gamma invstd, shift = beta - mean scale.
 // MODE 1 -> dbeta (s1), dgamma (s2), gs = gamma invstd, k1 = s1 / N, k2 = s2 / N.
+// One workgroup per column of the 128-wide layout (columns >= C get zeros: the element-wise kernels load the vectors eight
+// columns at a time).  256 threads walk the partials (with 64 a thread summed 32 partials one load after the other: 15 us a
+// launch, four launches a step); the 256 thread sums are added in thread order, in double.  MODE 0 also applies the
+// BatchNorm running-statistics update (torch: running = (1 - momentum) running + momentum batch, the variance unbiased;
+// num_batches_tracked += 1) when the buffers are given -- five element-wise launches of the host side otherwise.
+constexpr int kFinishThreads = 256;
 template <int MODE>
-__global__ __launch_bounds__(kWave) void layer_finish_kernel(const float* __restrict__ partial, int nblocks, int64_t N, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ invstd_in, float eps,
-                                                             float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3,
-                                                             float* __restrict__ o4, float* __restrict__ o5) {
-  __shared__ double s_t[2][kWave];
+__global__ __launch_bounds__(kFinishThreads) void layer_finish_kernel(const float* __restrict__ partial, int nblocks, int64_t N, int C,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      const float* __restrict__ invstd_in, float eps, float* __restrict__ o1,
+                                                                      float* __restrict__ o2, float* __restrict__ o3, float* __restrict__ o4,
+                                                                      float* __restrict__ o5, float* __restrict__ run_mean,
+                                                                      float* __restrict__ run_var, float momentum,
+                                                                      long long* __restrict__ batches) {
+  __shared__ double s_t[2][kFinishThreads];
   const int c = blockIdx.x, j = threadIdx.x;
+  if (c >= C) {
+    if (j == 0) { o1[c] = 0.f; o2[c] = 0.f; o3[c] = 0.f; o4[c] = 0.f; o5[c] = 0.f; }
+    return;
+  }
   double t1 = 0.0, t2 = 0.0;
-  for (int b = j; b < nblocks; b += kWave) {
+  for (int b = j; b < nblocks; b += kFinishThreads) {
     t1 += (double)partial[((int64_t)b * 2 + 0) * kLW + c];
     t2 += (double)partial[((int64_t)b * 2 + 1) * kLW + c];
   }
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(kWave) void layer_finish_kernel(const float* __rest
   __syncthreads();
   if (j != 0) return;
   t1 = t2 = 0.0;
-  for (int k = 0; k < kWave; ++k) { t1 += s_t[0][k]; t2 += s_t[1][k]; }
+  for (int k = 0; k < kFinishThreads; ++k) { t1 += s_t[0][k]; t2 += s_t[1][k]; }
   if (MODE == 0) {
     const double m = t1 / (double)N;
     double var = t2 / (double)N - m * m;
@@ -333,6 +346,11 @@ __global__ __launch_bounds__(kWave) void layer_finish_kernel(const float* __rest
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * is;
     o1[c] = (float)m; o2[c] = (float)var; o3[c] = is; o4[c] = sc; o5[c] = beta[c] - (float)m * sc;
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * ((float)var * ((float)N / (float)(N - 1)));
+    }
+    if (batches && c == 0) *batches += 1;
   } else {
     o1[c] = (float)t1; o2[c] = (float)t2; o3[c] = gamma[c] * invstd_in[c];
     o4[c] = (float)(t1 / (double)N); o5[c] = (float)(t2 / (double)N);
@@ -462,9 +480,10 @@ __global__ __launch_bounds__(kLayerThreads) void layer_wgrad_kernel(const WgradL
       for (int r = 0; r < 4; ++r) dst[((t * 4 + s4) * 4 + r) * kWave] = acc[t][s4][r];
 }
 
-__global__ __launch_bounds__(256) void layer_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int K, int U, int cpw,
+constexpr int kLayerReduceSlices = 16;      // as mlp_head.hip's second stage: 16 slices of the G range per element
+__global__ __launch_bounds__(kLayerReduceSlices * kWave) void layer_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int K, int U, int cpw,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
-  __shared__ float s[4][kWave];
+  __shared__ float s[kLayerReduceSlices][kWave];
   const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int e = blockIdx.x * kWave + el;
   const int lane = e & 63, r = (e >> 6) & 3, tile = (e >> 8) & 31, wid = e >> 13;
@@ -473,14 +492,25 @@ __global__ __launch_bounds__(256) void layer_wgrad_reduce_kernel(const float* __
   const bool live = e < kLayerW1Floats && lr < cpw && c <= K && o < U;
   float v = 0.f;
   if (live) {
-    const int per = (G + 3) / 4;
+    const int per = (G + kLayerReduceSlices - 1) / kLayerReduceSlices;
     const int g1 = min(G, (sl + 1) * per);
-    for (int g = sl * per; g < g1; ++g) v += partial[(int64_t)g * kLayerW1Floats + e];
+    int g = sl * per;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    for (; g + 3 < g1; g += 4) {
+      v += partial[(int64_t)g * kLayerW1Floats + e];
+      v1 += partial[(int64_t)(g + 1) * kLayerW1Floats + e];
+      v2 += partial[(int64_t)(g + 2) * kLayerW1Floats + e];
+      v3 += partial[(int64_t)(g + 3) * kLayerW1Floats + e];
+    }
+    for (; g < g1; ++g) v += partial[(int64_t)g * kLayerW1Floats + e];
+    v = (v + v1) + (v2 + v3);
   }
   s[sl][el] = v;
   __syncthreads();
   if (sl != 0 || !live) return;
-  const float tot = s[0][el] + s[1][el] + s[2][el] + s[3][el];
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < kLayerReduceSlices; ++k) tot += s[k][el];
   if (c < K) gw[(int64_t)o * K + c] = tot;
   else if (gb) gb[o] = tot;
 }
@@ -562,17 +592,18 @@ __global__ __launch_bounds__(256) void layer_rowdot_bwd_kernel(const DotArgs a) 
   }
 }
 
-__global__ __launch_bounds__(kWave) void layer_rowdot_finish_kernel(const float* __restrict__ partial, int nblocks, int C, int O,
+__global__ __launch_bounds__(kFinishThreads) void layer_rowdot_finish_kernel(const float* __restrict__ partial, int nblocks, int C, int O,
                                                                     float* __restrict__ gw, float* __restrict__ gb) {
-  __shared__ double s_t[kWave];
+  __shared__ double s_t[kFinishThreads];
   const int q = blockIdx.x / (kLW + 1), c = blockIdx.x % (kLW + 1), j = threadIdx.x;
+  if (q >= O || (c >= C && c != kLW)) return;       // nothing is filed from these sums
   double t = 0.0;
-  for (int b = j; b < nblocks; b += kWave) t += (double)partial[((int64_t)b * MLQEM_MLP1_MAX_OUT + q) * (kLW + 1) + c];
+  for (int b = j; b < nblocks; b += kFinishThreads) t += (double)partial[((int64_t)b * MLQEM_MLP1_MAX_OUT + q) * (kLW + 1) + c];
   s_t[j] = t;
   __syncthreads();
-  if (j != 0 || q >= O) return;
+  if (j != 0) return;
   t = 0.0;
-  for (int k = 0; k < kWave; ++k) t += s_t[k];
+  for (int k = 0; k < kFinishThreads; ++k) t += s_t[k];
   if (c < C) gw[(int64_t)q * C + c] = (float)t;
   else if (c == kLW) gb[q] = (float)t;
 }
@@ -652,7 +683,8 @@ extern "C" int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g,
                                          const float* shift, const float* mean, const float* invstd, const float* gamma,
                                          const float* beta, float eps, int relu, float drop_p, uint64_t seed,
                                          const uint64_t* seed_counter, int64_t N, int C, float* o1, float* o2, float* o3, float* o4,
-                                         float* o5, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+                                         float* o5, float* running_mean, float* running_var, float momentum,
+                                         int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
   begin_launches();
   if (N <= 0 || C < 1 || C > kLW || !y || !gamma || !o1 || !o2 || !o3 || !o4 || !o5 || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
   if (mode == 0 ? !beta : (!scale || !shift || !mean || !invstd || (!g && !g32))) return MLQEM_ERR_BAD_ARG;
@@ -666,10 +698,13 @@ extern "C" int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g,
   a.rows_per_block = ceil_div(N, (int64_t)nb);
   if (mode == 0) {
     hipLaunchKernelGGL(layer_colsum_kernel<0>, dim3(nb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(layer_finish_kernel<0>, dim3(C), dim3(kWave), 0, s, a.partial, nb, N, gamma, beta, (const float*)nullptr, eps, o1, o2, o3, o4, o5);
+    if ((running_mean == nullptr) != (running_var == nullptr) || (running_mean && N < 2)) return MLQEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(layer_finish_kernel<0>, dim3(kLW), dim3(kFinishThreads), 0, s, a.partial, nb, N, C, gamma, beta, (const float*)nullptr, eps,
+                       o1, o2, o3, o4, o5, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   } else {
     hipLaunchKernelGGL(layer_colsum_kernel<1>, dim3(nb), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(layer_finish_kernel<1>, dim3(C), dim3(kWave), 0, s, a.partial, nb, N, gamma, (const float*)nullptr, invstd, 0.f, o1, o2, o3, o4, o5);
+    hipLaunchKernelGGL(layer_finish_kernel<1>, dim3(kLW), dim3(kFinishThreads), 0, s, a.partial, nb, N, C, gamma, (const float*)nullptr, invstd, 0.f,
+                       o1, o2, o3, o4, o5, (float*)nullptr, (float*)nullptr, 0.f, (long long*)nullptr);
   }
   return launch_status();
 }
@@ -713,7 +748,7 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
     if (x_is_bf16) hipLaunchKernelGGL(layer_wgrad_kernel<true>, dim3(G), dim3(kLayerThreads), 0, s, a, cpw);
     else hipLaunchKernelGGL(layer_wgrad_kernel<false>, dim3(G), dim3(kLayerThreads), 0, s, a, cpw);
   }
-  hipLaunchKernelGGL(layer_wgrad_reduce_kernel, dim3((unsigned)ceil_div(kLayerW1Floats, kWave)), dim3(256), 0, s, a.partial, G, K, U, cpw, gw, gb);
+  hipLaunchKernelGGL(layer_wgrad_reduce_kernel, dim3((unsigned)ceil_div(kLayerW1Floats, kWave)), dim3(kLayerReduceSlices * kWave), 0, s, a.partial, G, K, U, cpw, gw, gb);
   return launch_status();
 }
 
@@ -740,6 +775,6 @@ extern "C" int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const vo
   a.h = static_cast<const unsigned short*>(h); a.w = w; a.g = g; a.ldg = ldg; a.gh = static_cast<unsigned short*>(gh);
   a.partial = static_cast<float*>(workspace); a.N = N; a.C = C; a.O = O; a.rows_per_block = ceil_div(N, (int64_t)nb);
   hipLaunchKernelGGL(layer_rowdot_bwd_kernel, dim3(nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(layer_rowdot_finish_kernel, dim3(MLQEM_MLP1_MAX_OUT * (kLW + 1)), dim3(kWave), 0, s, a.partial, nb, C, O, gw, gb);
+  hipLaunchKernelGGL(layer_rowdot_finish_kernel, dim3(MLQEM_MLP1_MAX_OUT * (kLW + 1)), dim3(kFinishThreads), 0, s, a.partial, nb, C, O, gw, gb);
   return launch_status();
 }
