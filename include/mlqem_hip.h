@@ -128,7 +128,8 @@ int mlqem_batch_norm_train_bwd_f32(const float* dy, int64_t ldg, const float* x,
  *   workspace: mlqem_mse_loss_workspace_bytes(); ticket: one zero-initialised unsigned the call leaves at zero.
  * mlqem_adam_step_f32: torch.optim.Adam(betas, eps; amsgrad = False, weight_decay = 0, maximize = False) on ONE flat
  *   buffer of n floats: step <- step + 1; m <- lerp(m, g, 1 - beta1); v <- beta2 v + (1 - beta2) g^2;
- *   p <- p - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).  `lr` and `step` (a float, as torch keeps
+ *   p <- p - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)  (betas arrive as doubles: 1 - beta and the bias
+ *   corrections are formed in double, as torch forms them, the update itself in fp32).  `lr` and `step` (a float, as torch keeps
  *   it) live on the device, so the launch can sit in a captured hipGraph and a scheduler can change the rate between
  *   replays; ticket as above.  Replaces torch's multi-tensor kernel, which runs a buffer of this path's size (1.8 k-180 k
  *   floats) on one workgroup.
@@ -137,7 +138,7 @@ size_t mlqem_mse_loss_workspace_bytes(void);
 int mlqem_mse_loss_grad_f32(const float* out, int64_t ldo, const float* y, int64_t ldy, float* g, int64_t ldg, int64_t N, int C,
                             float* loss, void* workspace, size_t workspace_bytes, unsigned* ticket, mlqem_stream_t stream);
 int mlqem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
-                        float* step, float beta1, float beta2, float eps, unsigned* ticket, mlqem_stream_t stream);
+                        float* step, double beta1, double beta2, double eps, unsigned* ticket, mlqem_stream_t stream);
 
 /* gx[n,c] = (y[n,c] > 0) ? g[n,c] * scale : 0  -- backward of ReLU followed by inverted dropout, recovered from the
  * output y (an element that was clamped OR dropped has y == 0 and no gradient either way). */

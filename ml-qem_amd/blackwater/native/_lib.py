@@ -18,7 +18,7 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
-_P, _I, _L, _F, _S, _U = c_void_p, c_int, c_int64, c_float, c_size_t, c_uint64
+_P, _I, _L, _F, _S, _U, _D = c_void_p, c_int, c_int64, c_float, c_size_t, c_uint64, ctypes.c_double
 
 
 MAX_COL_PARTS = 8   # MLQEM_MAX_COL_PARTS
@@ -56,7 +56,7 @@ SIGNATURES = {
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
     "mlqem_mse_loss_workspace_bytes": (_S, []),
     "mlqem_mse_loss_grad_f32": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P, _P, _S, _P, _P]),
-    "mlqem_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _P, _P]),
+    "mlqem_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _P, _P]),
     "mlqem_relu_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _F, _P, _L, _L, _I, _P]),
     "mlqem_relu_dropout_f32": (_I, [_P, _L, _F, _U, _P, _P, _L, _P, _L, _P, _L, _L, _I, _P]),
     "mlqem_linear_f32": (_I, [_P, _L, _P, _I, _P, _P, _P, _L, _L, _I, _I, _I, _I, _F, _U, _I, _I, _P, _L, _F, _P, _P]),

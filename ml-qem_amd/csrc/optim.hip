@@ -66,19 +66,21 @@ __global__ __launch_bounds__(kBlock) void mse_loss_grad_kernel(const float* __re
 // One thread per four parameters.  s = step + 1 is what every thread computes with; the last workgroup writes it back.
 __global__ __launch_bounds__(kBlock) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, int64_t n, const float* __restrict__ lr_ptr,
-                                                           float* __restrict__ step_ptr, float beta1, float beta2, float eps,
+                                                           float* __restrict__ step_ptr, double beta1_d, double beta2_d, float eps,
                                                            unsigned* __restrict__ ticket) {
   const float s = *step_ptr + 1.0f;
   const float lr = *lr_ptr;
   // torch.optim.Adam: bias corrections in double from the double betas (fused_adam_utils.cuh), the update in fp32
-  const double bc1 = 1.0 - pow((double)beta1, (double)s);
-  const double bc2 = 1.0 - pow((double)beta2, (double)s);
+  const double bc1 = 1.0 - pow(beta1_d, (double)s);
+  const double bc2 = 1.0 - pow(beta2_d, (double)s);
+  // the weights as torch forms them: 1 - beta in DOUBLE, then rounded (1.0f - 0.999f is off by 1.3e-5 of itself)
+  const float beta2 = (float)beta2_d, w1 = (float)(1.0 - beta1_d), w2 = (float)(1.0 - beta2_d);
   const float step_size = (float)((double)lr / bc1);
   const float bc2_sqrt = (float)sqrt(bc2);
   const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
   auto update = [&](float& pi, float gi, float& mi, float& vi) {
-    mi = mi + (gi - mi) * (1.0f - beta1);                        // exp_avg.lerp_(grad, 1 - beta1)
-    vi = beta2 * vi + (1.0f - beta2) * gi * gi;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    mi = mi + (gi - mi) * w1;                                    // exp_avg.lerp_(grad, 1 - beta1)
+    vi = beta2 * vi + w2 * gi * gi;                              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     pi = pi - step_size * (mi / denom);
   };
@@ -117,12 +119,12 @@ extern "C" int mlqem_mse_loss_grad_f32(const float* out, int64_t ldo, const floa
 }
 
 extern "C" int mlqem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
-                                   float* step, float beta1, float beta2, float eps, unsigned* ticket, mlqem_stream_t stream) {
+                                   float* step, double beta1, double beta2, double eps, unsigned* ticket, mlqem_stream_t stream) {
   begin_launches();
   if (n < 0 || !lr || !step || !ticket || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return MLQEM_ERR_BAD_ARG;
   if (!aligned_to(param, 16) || !aligned_to(grad, 16) || !aligned_to(exp_avg, 16) || !aligned_to(exp_avg_sq, 16)) return MLQEM_ERR_BAD_ARG;
   const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(n, 4 * kBlock));
   hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, lr, step,
-                     beta1, beta2, eps, ticket);
+                     beta1, beta2, (float)eps, ticket);
   return launch_status();
 }
