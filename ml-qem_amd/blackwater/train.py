@@ -122,6 +122,7 @@ class Trainer:
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", factor=0.1, patience=15,
                                                                     min_lr=1e-5)
         self.criterion = nn.MSELoss()
+        self._fused_loss = os.environ.get("MLQEM_TORCH_MSE", "0") != "1"      # A/B switch: torch's MSELoss kernels instead of optim.hip's
         # The host enqueues a step several times faster than the device runs it.  Unbounded run-ahead makes torch's caching
         # allocator grow without end on the multi-stream path: blocks handed between the branch streams can only be reused
         # after their recorded events have completed, so every step queued ahead needs its own copy of the activations and
@@ -190,7 +191,7 @@ class Trainer:
         real = getattr(batch, "num_real", None)
         if real is not None and real < out.shape[0]:   # a bucket-padded batch: the last row is the filler graph's
             out, target = out[:real], target[:real]
-        if (type(self.criterion) is nn.MSELoss and self.criterion.reduction == "mean" and out.is_cuda and out.dtype == torch.float32
+        if (self._fused_loss and type(self.criterion) is nn.MSELoss and self.criterion.reduction == "mean" and out.is_cuda and out.dtype == torch.float32
                 and out.dim() == 2 and target.shape == out.shape and target.dtype == torch.float32 and out.numel() > 0
                 and out.stride(1) == 1 and target.stride(1) == 1):
             # loss and d loss / d out from one launch; the backward starts from that gradient (no ones fill, no mse kernels)

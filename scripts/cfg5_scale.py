@@ -53,7 +53,7 @@ rec = {"what": "one rank's shard (1/8) of BASELINE.json's cfg5 corpus, device-re
        "arena_build_s": round(build_s, 1), "hbm_after_build_GB": round(torch.cuda.memory_allocated() / 1e9, 2)}
 rs = np.random.RandomState(0)
 for name, make, batch, steps in (("family_a", lambda: ExpValCircuitGraphModelA(100, f, 10), 1024, 10),
-                                 ("family_b_mlp3_head_bf16", lambda: ExpValCircuitGraphModel_3(f, 15, 4), 64, 5)):
+                                 ("family_b_mlp3_head_bf16", lambda: ExpValCircuitGraphModel_3(f, 15, 4), 64, 20)):
     torch.manual_seed(0)
     model = make().to(dev)
     if name.startswith("family_b"):
