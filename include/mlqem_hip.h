@@ -595,6 +595,12 @@ void mlqem_qasm_batch_free(void* handle);
  * The caller passes the edges (numpy.arange(-2pi, 2pi + bin, bin) in the reference) so both sides bin identically. */
 int mlqem_circuit_features_qasm(const char* qasm, const char* const* gate_names, int num_gates, const double* bin_edges,
                                 int num_edges, int64_t* gate_counts, int64_t* angle_hist);
+/* The same for every circuit of one run() (PostProcessedJob.result loops over them: blackwater/library/learning/estimator.py:
+ * 220-245) on `threads` host threads (0 = one per core, at most 16): gate_counts[count, num_gates], angle_hist[count,
+ * num_edges - 1].  On an error *failed (optional) is the index of the first bad circuit and the message names it. */
+int mlqem_circuit_features_qasm_batch(const char* const* qasm, int64_t count, const char* const* gate_names, int num_gates,
+                                      const double* bin_edges, int num_edges, int threads, int64_t* gate_counts,
+                                      int64_t* angle_hist, int64_t* failed);
 
 #ifdef __cplusplus
 }

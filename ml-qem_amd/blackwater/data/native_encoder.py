@@ -131,3 +131,24 @@ def circuit_features(qasm: str, gate_names, bin_edges) -> Tuple[np.ndarray, np.n
     if code != 0:
         raise Exception(lib.mlqem_encode_last_error().decode() or f"mlqem_circuit_features_qasm failed with code {code}")
     return counts, hist
+
+
+def circuit_features_batch(texts, gate_names, bin_edges, threads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """``circuit_features`` of every text of one ``run()`` on a pool of host threads (``mlqem_circuit_features_qasm_batch``):
+    (gate counts [n, len(gate_names)], angle histograms [n, len(bin_edges) - 1])."""
+    lib = _lib.load()
+    n = len(texts)
+    names = [g.encode() for g in gate_names]
+    c_names = (ctypes.c_char_p * max(len(names), 1))(*names)
+    raw = [t.encode() for t in texts]
+    arr = (ctypes.c_char_p * max(n, 1))(*raw)
+    edges = np.ascontiguousarray(bin_edges, dtype=np.float64)
+    counts = np.zeros((n, len(names)), dtype=np.int64)
+    hist = np.zeros((n, max(len(edges) - 1, 0)), dtype=np.int64)
+    failed = ctypes.c_int64(-1)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    code = lib.mlqem_circuit_features_qasm_batch(arr, n, c_names, len(names), vp(edges), len(edges), int(threads), vp(counts), vp(hist),
+                                                 ctypes.byref(failed))
+    if code != 0:
+        raise Exception(lib.mlqem_encode_last_error().decode() or f"mlqem_circuit_features_qasm_batch failed with code {code}")
+    return counts, hist

@@ -66,14 +66,13 @@ def _fill_rows(X, circuits, gates_set, offset, bin_size, n_bins, n_vals, noisy_e
     if native:
         # the C++ op scan shared with the graph encoder (mlqem_circuit_features_qasm): same integers, no Python parse; the rows
         # of a whole run() are filled by three array assignments instead of three tensor constructions per circuit
-        from ...data.native_encoder import circuit_features
+        from ...data.native_encoder import circuit_features_batch
 
-        counts = np.zeros((len(circuits), len(gates_set)), dtype=np.int64)
-        hists = np.zeros((len(circuits), n_bins), dtype=np.int64)
-        for i, circuit in enumerate(circuits):
+        for circuit in circuits:
             if not isinstance(circuit, str):
                 raise TypeError("native=True takes OpenQASM-2 text (the 'circuit' field of the reference's datasets)")
-            counts[i], hists[i] = circuit_features(circuit, gates_set, edges)
+        counts, hists = circuit_features_batch(list(circuits), gates_set, edges)      # host threads over the circuits
+        for i in range(len(circuits)):
             if n_vals > 1:
                 assert len(noisy_exp_vals[i]) == n_vals
             elif n_vals == 1:

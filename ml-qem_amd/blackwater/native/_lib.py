@@ -122,6 +122,7 @@ SIGNATURES = {
     "mlqem_qasm_batch_fill": (_I, [_P, _I, _P, _P, _P, _P]),
     "mlqem_qasm_batch_free": (None, [_P]),
     "mlqem_circuit_features_qasm": (_I, [c_char_p, _P, _I, _P, _I, _P, _P]),
+    "mlqem_circuit_features_qasm_batch": (_I, [_P, _L, _P, _I, _P, _I, _I, _P, _P, _P]),
 }
 
 _lib = None

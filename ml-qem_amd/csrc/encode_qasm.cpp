@@ -672,36 +672,67 @@ extern "C" int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_
 extern "C" void mlqem_qasm_batch_free(void* handle) { delete static_cast<Batch*>(handle); }
 
 // Circuit-level features of the MLP regressors (docs/tutorials/mlp.py:111-145, 148-252): by-products of the same op scan.
+namespace {
+
+void circuit_features(const Circuit& c, const char* const* gate_names, int num_gates, const double* bin_edges, int num_edges,
+                      int64_t* gate_counts, int64_t* angle_hist) {
+  for (int i = 0; i < num_gates; ++i) gate_counts[i] = 0;
+  const int bins = num_edges > 1 ? num_edges - 1 : 0;
+  for (int i = 0; i < bins; ++i) angle_hist[i] = 0;
+  std::vector<int64_t> per_type(c.names.size(), 0);
+  std::vector<char> rot(c.names.size(), 0);
+  for (size_t t = 0; t < c.names.size(); ++t) rot[t] = c.names[t] == "rx" || c.names[t] == "ry" || c.names[t] == "rz";
+  for (const Op& op : c.ops) {
+    ++per_type[op.type];
+    if (!rot[op.type] || op.q_cnt != 1 || op.p_cnt == 0 || bins == 0) continue;
+    const double a = c.params[op.p_off];
+    if (!(a >= bin_edges[0]) || a > bin_edges[bins]) continue;          // outside, or NaN
+    // numpy.histogram with explicit edges: [e_i, e_{i+1}) and a closed last bin
+    int b = (int)(std::upper_bound(bin_edges, bin_edges + num_edges, a) - bin_edges) - 1;
+    if (b >= bins) b = bins - 1;
+    ++angle_hist[b];
+  }
+  for (int i = 0; i < num_gates; ++i)          // a name listed twice is counted under both entries
+    for (size_t t = 0; t < c.names.size(); ++t) if (c.names[t] == gate_names[i]) gate_counts[i] += per_type[t];
+}
+
+bool features_args_ok(int num_gates, int num_edges, const char* const* gate_names, const double* bin_edges, const int64_t* gate_counts,
+                      const int64_t* angle_hist) {
+  return num_gates >= 0 && num_edges >= 0 && !(num_gates && (!gate_names || !gate_counts)) && !(num_edges > 1 && (!bin_edges || !angle_hist));
+}
+
+}  // namespace
+
 extern "C" int mlqem_circuit_features_qasm(const char* qasm, const char* const* gate_names, int num_gates,
                                            const double* bin_edges, int num_edges, int64_t* gate_counts,
                                            int64_t* angle_hist) {
-  if (!qasm || num_gates < 0 || num_edges < 0 || (num_gates && (!gate_names || !gate_counts)) ||
-      (num_edges && (!bin_edges || !angle_hist)))
+  if (!qasm || !features_args_ok(num_gates, num_edges, gate_names, bin_edges, gate_counts, angle_hist) || (num_edges && (!bin_edges || !angle_hist)))
     return MLQEM_ERR_BAD_ARG;
   try {
     const Circuit c = parse_qasm(qasm);
-    for (int i = 0; i < num_gates; ++i) gate_counts[i] = 0;
-    const int bins = num_edges > 1 ? num_edges - 1 : 0;
-    for (int i = 0; i < bins; ++i) angle_hist[i] = 0;
-    std::vector<int64_t> per_type(c.names.size(), 0);
-    std::vector<char> rot(c.names.size(), 0);
-    for (size_t t = 0; t < c.names.size(); ++t) rot[t] = c.names[t] == "rx" || c.names[t] == "ry" || c.names[t] == "rz";
-    for (const Op& op : c.ops) {
-      ++per_type[op.type];
-      if (!rot[op.type] || op.q_cnt != 1 || op.p_cnt == 0 || bins == 0) continue;
-      const double a = c.params[op.p_off];
-      if (!(a >= bin_edges[0]) || a > bin_edges[bins]) continue;          // outside, or NaN
-      // numpy.histogram with explicit edges: [e_i, e_{i+1}) and a closed last bin
-      int b = (int)(std::upper_bound(bin_edges, bin_edges + num_edges, a) - bin_edges) - 1;
-      if (b >= bins) b = bins - 1;
-      ++angle_hist[b];
-    }
-    for (int i = 0; i < num_gates; ++i)          // a name listed twice is counted under both entries, as before
-      for (size_t t = 0; t < c.names.size(); ++t) if (c.names[t] == gate_names[i]) gate_counts[i] += per_type[t];
+    circuit_features(c, gate_names, num_gates, bin_edges, num_edges, gate_counts, angle_hist);
     return MLQEM_OK;
   } catch (const ParseError& e) {
-    g_last_error = e.what;
-    return e.unsupported ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
+    return report(e);
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return MLQEM_ERR_BAD_ARG;
+  }
+}
+
+extern "C" int mlqem_circuit_features_qasm_batch(const char* const* qasm, int64_t count, const char* const* gate_names, int num_gates,
+                                                 const double* bin_edges, int num_edges, int threads, int64_t* gate_counts,
+                                                 int64_t* angle_hist, int64_t* failed) {
+  if (count < 0 || (count > 0 && !qasm) || !features_args_ok(num_gates, num_edges, gate_names, bin_edges, gate_counts, angle_hist) ||
+      (num_edges && (!bin_edges || !angle_hist)))
+    return MLQEM_ERR_BAD_ARG;
+  for (int64_t i = 0; i < count; ++i) if (!qasm[i]) return MLQEM_ERR_BAD_ARG;
+  const int bins = num_edges > 1 ? num_edges - 1 : 0;
+  try {
+    return for_each_parallel(count, threads, failed, [&](int64_t i, WorkerScratch& w) {
+      parse_qasm(qasm[i], w.circuit, w.text_a, w.text_b);
+      circuit_features(w.circuit, gate_names, num_gates, bin_edges, num_edges, gate_counts + i * num_gates, angle_hist + i * bins);
+    });
   } catch (const std::exception& e) {
     g_last_error = e.what();
     return MLQEM_ERR_BAD_ARG;

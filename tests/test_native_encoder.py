@@ -125,3 +125,29 @@ def test_batch_encoder_names_the_first_bad_circuit(lima_props):
         enc.encode_batch([good, 'OPENQASM 2.0;\nqreg q[2];\nh q[0];\n'])
     x, _, _, _, _ = enc.encode_batch([good])        # the encoder is usable after a rejected batch
     assert x.shape[0] == 1
+
+
+def test_batch_feature_scan_equals_the_per_circuit_scan(g1, lima_props):
+    """mlqem_circuit_features_qasm_batch (the op scan of every circuit of a run() on host threads) against the per-circuit entry
+    point, and ``encode_data(native=True)`` rows against the Python path on the reference's circuits."""
+    import torch
+
+    from blackwater.data.native_encoder import circuit_features, circuit_features_batch
+    from blackwater.library.learning.features import encode_data
+
+    texts = list(g1["qasm"][:50])
+    gates = sorted(lima_props["gates_set"])
+    edges = np.arange(-2 * np.pi, 2 * np.pi + 0.1 * np.pi, 0.1 * np.pi)
+    for threads in (1, 4, 0):
+        counts, hist = circuit_features_batch(texts, gates, edges, threads=threads)
+        for i, t in enumerate(texts):
+            c, h = circuit_features(t, gates, edges)
+            assert np.array_equal(counts[i], c) and np.array_equal(hist[i], h)
+    assert circuit_features_batch([], gates, edges)[0].shape == (0, len(gates))
+    with pytest.raises(Exception, match="circuit 1: "):
+        circuit_features_batch([texts[0], "OPENQASM 2.0;\nqreg q[2];\nrz(1 q[0];\n"], gates, edges)
+    noisy = [[0.1 * k] for k in range(len(texts))]
+    bases = [[1.0, 0, 1, 0, 0] for _ in texts]
+    a, _ = encode_data(texts, lima_props, [[0.0]] * len(texts), noisy, 1, meas_bases=bases, native=True)
+    b, _ = encode_data(texts, lima_props, [[0.0]] * len(texts), noisy, 1, meas_bases=bases, native=False)
+    assert torch.equal(a, b)
