@@ -123,7 +123,8 @@ int mlqem_batch_norm_train_bwd_f32(const float* dy, int64_t ldg, const float* x,
  * `loss = criterion(out, y); loss.backward(); optimizer.step()` with torch.nn.MSELoss and torch.optim.Adam).
  *
  * mlqem_mse_loss_grad_f32: *loss = mean over the N x C elements of (out - y)^2 and, when g is given,
- *   g = 2 (out - y) / (N C) -- the gradient `loss.backward()` hands to the model's output -- from one pass, one launch;
+ *   g = 2 (out - y) / (N C) -- the gradient `loss.backward()` hands to the model's output -- from one pass, one launch; g has
+ *   g_rows >= N rows, the rows beyond N (filler rows of a padded batch, which the loss does not see) come out zero;
  *   per-workgroup partial sums added in index order by the workgroup that finishes last (deterministic).
  *   workspace: mlqem_mse_loss_workspace_bytes(); ticket: one zero-initialised unsigned the call leaves at zero.
  * mlqem_adam_step_f32: torch.optim.Adam(betas, eps; amsgrad = False, weight_decay = 0, maximize = False) on ONE flat
@@ -136,7 +137,7 @@ int mlqem_batch_norm_train_bwd_f32(const float* dy, int64_t ldg, const float* x,
  * ---------------------------------------------------------------------------------------------------- */
 size_t mlqem_mse_loss_workspace_bytes(void);
 int mlqem_mse_loss_grad_f32(const float* out, int64_t ldo, const float* y, int64_t ldy, float* g, int64_t ldg, int64_t N, int C,
-                            float* loss, void* workspace, size_t workspace_bytes, unsigned* ticket, mlqem_stream_t stream);
+                            int64_t g_rows, float* loss, void* workspace, size_t workspace_bytes, unsigned* ticket, mlqem_stream_t stream);
 int mlqem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
                         float* step, double beta1, double beta2, double eps, unsigned* ticket, mlqem_stream_t stream);
 

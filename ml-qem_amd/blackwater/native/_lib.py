@@ -55,7 +55,7 @@ SIGNATURES = {
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
     "mlqem_mse_loss_workspace_bytes": (_S, []),
-    "mlqem_mse_loss_grad_f32": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P, _P, _S, _P, _P]),
+    "mlqem_mse_loss_grad_f32": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _L, _P, _P, _S, _P, _P]),
     "mlqem_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _P, _P]),
     "mlqem_relu_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _F, _P, _L, _L, _I, _P]),
     "mlqem_relu_dropout_f32": (_I, [_P, _L, _F, _U, _P, _P, _L, _P, _L, _P, _L, _L, _I, _P]),

@@ -198,20 +198,26 @@ def _ticket(device):
     return t
 
 
-def mse_loss_grad(out, target, want_grad=True):
+def mse_loss_grad(out, target, want_grad=True, rows=None):
     """(loss, g): loss = mean((out - target)^2) as a 0-dim device tensor and g = 2 (out - target) / numel -- what
     ``MSELoss()(out, target).backward()`` hands to ``out`` -- from ONE launch (mlqem_mse_loss_grad_f32).  2-D fp32 operands
-    with contiguous columns (row-strided views are fine)."""
-    if out.shape != target.shape or out.dim() != 2 or out.numel() == 0:
-        raise ValueError("mse_loss_grad: out and target must be non-empty 2-D tensors of one shape")
-    n, c = out.shape
+    with contiguous columns (row-strided views are fine).  ``rows``: only the first ``rows`` rows enter the loss (the rest are
+    a padded batch's filler rows); g still has ``out``'s shape, zero beyond them -- what slicing the output and letting
+    autograd pad the gradient back produces with a fill and a copy."""
+    if out.dim() != 2 or target.dim() != 2 or out.shape[1] != target.shape[1] or out.numel() == 0:
+        raise ValueError("mse_loss_grad: out and target must be non-empty 2-D tensors of one width")
+    g_rows, c = out.shape
+    n = g_rows if rows is None else int(rows)
+    if not (1 <= n <= g_rows) or target.shape[0] < n:
+        raise ValueError("mse_loss_grad: rows must lie in [1, out.shape[0]] and target must hold them")
     ldo, ldy = _mat(out, "out"), _mat(target, "target")
-    g = torch.empty((n, c), dtype=torch.float32, device=out.device) if want_grad else None
+    g = torch.empty((g_rows, c), dtype=torch.float32, device=out.device) if want_grad else None
     loss = torch.empty((), dtype=torch.float32, device=out.device)
     lib = _lib.load()
     need = lib.mlqem_mse_loss_workspace_bytes()
     ws = _wgrad_workspace(out.device, need)
-    code = lib.mlqem_mse_loss_grad_f32(_p(out), ldo, _p(target), ldy, _p(g), c, n, c, _p(loss), _p(ws), need, _p(_ticket(out.device)), _stream())
+    code = lib.mlqem_mse_loss_grad_f32(_p(out), ldo, _p(target), ldy, _p(g), c, n, c, g_rows, _p(loss), _p(ws), need, _p(_ticket(out.device)),
+                                       _stream())
     _lib.check(code, "mlqem_mse_loss_grad_f32")
     return loss, g
 

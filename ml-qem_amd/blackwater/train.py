@@ -189,17 +189,20 @@ class Trainer:
         out = self.model(*batch.model_args())
         target = batch.y if batch.y.dim() == 2 else torch.squeeze(batch.y, 1)
         real = getattr(batch, "num_real", None)
-        if real is not None and real < out.shape[0]:   # a bucket-padded batch: the last row is the filler graph's
-            out, target = out[:real], target[:real]
+        padded = real is not None and real < out.shape[0]   # a bucket-padded batch: the last row is the filler graph's
+        rows = real if padded else out.shape[0]
         if (self._fused_loss and type(self.criterion) is nn.MSELoss and self.criterion.reduction == "mean" and out.is_cuda and out.dtype == torch.float32
-                and out.dim() == 2 and target.shape == out.shape and target.dtype == torch.float32 and out.numel() > 0
-                and out.stride(1) == 1 and target.stride(1) == 1):
-            # loss and d loss / d out from one launch; the backward starts from that gradient (no ones fill, no mse kernels)
+                and out.dim() == 2 and target.dim() == 2 and target.shape[1] == out.shape[1] and target.shape[0] >= rows
+                and target.dtype == torch.float32 and rows > 0 and out.stride(1) == 1 and target.stride(1) == 1):
+            # loss and d loss / d out from one launch; the backward starts from that gradient (no ones fill, no mse kernels, and
+            # for a padded batch no slice: the filler rows' gradient is written as zero by the same launch)
             from .native import ops
 
-            loss, g_out = ops.mse_loss_grad(out.detach(), target)
+            loss, g_out = ops.mse_loss_grad(out.detach(), target, rows=rows)
             out.backward(g_out)
         else:
+            if padded:
+                out, target = out[:real], target[:real]
             loss = self.criterion(out, target)
             loss.backward()
         if self.flat_grad is not None:

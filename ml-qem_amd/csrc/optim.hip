@@ -20,7 +20,7 @@ constexpr int kLossMaxBlocks = 256;
 
 __global__ __launch_bounds__(kBlock) void mse_loss_grad_kernel(const float* __restrict__ out, int64_t ldo, const float* __restrict__ y,
                                                                int64_t ldy, float* __restrict__ g, int64_t ldg, int64_t N, int C,
-                                                               float grad_scale, float* __restrict__ loss,
+                                                               int64_t g_rows, float grad_scale, float* __restrict__ loss,
                                                                float* __restrict__ partial, unsigned* __restrict__ ticket) {
   __shared__ float s_red[kBlock / kWave];
   __shared__ bool s_last;
@@ -28,6 +28,14 @@ __global__ __launch_bounds__(kBlock) void mse_loss_grad_kernel(const float* __re
   const int64_t per = ceil_div(total, (int64_t)gridDim.x);
   const int64_t e0 = (int64_t)blockIdx.x * per, e1 = e0 + per < total ? e0 + per : total;
   float acc = 0.f;
+  if (g && g_rows > N) {       // rows of the output that are not part of the loss (a padded batch's filler rows) get a zero gradient
+    const int64_t extra = (g_rows - N) * C;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < extra; e += (int64_t)gridDim.x * kBlock) {
+      const int64_t r = N + (C == 1 ? e : e / C);
+      const int c = C == 1 ? 0 : (int)(e % C);
+      g[r * ldg + c] = 0.f;
+    }
+  }
   for (int64_t e = e0 + threadIdx.x; e < e1; e += kBlock) {
     const int64_t r = C == 1 ? e : e / C;
     const int c = C == 1 ? 0 : (int)(e - r * C);
@@ -111,14 +119,14 @@ using namespace mlqem;
 extern "C" size_t mlqem_mse_loss_workspace_bytes(void) { return (size_t)kLossMaxBlocks * sizeof(float); }
 
 extern "C" int mlqem_mse_loss_grad_f32(const float* out, int64_t ldo, const float* y, int64_t ldy, float* g, int64_t ldg, int64_t N,
-                                       int C, float* loss, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                                       int C, int64_t g_rows, float* loss, void* workspace, size_t workspace_bytes, unsigned* ticket,
                                        mlqem_stream_t stream) {
   begin_launches();
-  if (N < 1 || C < 1 || !out || !y || !loss || !ticket || ldo < C || ldy < C || (g && ldg < C)) return MLQEM_ERR_BAD_ARG;
+  if (N < 1 || C < 1 || !out || !y || !loss || !ticket || ldo < C || ldy < C || (g && (ldg < C || g_rows < N))) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_mse_loss_workspace_bytes()) return MLQEM_ERR_WORKSPACE;
   const int64_t total = N * C;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(kLossMaxBlocks, ceil_div(total, 4 * kBlock)));
-  hipLaunchKernelGGL(mse_loss_grad_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), out, ldo, y, ldy, g, ldg, N, C,
+  hipLaunchKernelGGL(mse_loss_grad_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), out, ldo, y, ldy, g, ldg, N, C, g_rows,
                      2.0f / (float)total, loss, static_cast<float*>(workspace), ticket);
   return launch_status();
 }

@@ -75,3 +75,21 @@ def test_reduce_lr_on_plateau_drives_the_device_resident_rate():
     p.grad = torch.ones_like(p)
     opt.step()
     assert torch.allclose(p, torch.full_like(p, -1e-4), rtol=1e-5)   # the first Adam step moves every weight by lr
+
+
+def test_fused_mse_on_a_padded_batch_equals_slicing_the_output():
+    """A bucket-padded batch: the loss sees the first ``rows`` rows, the gradient has the output's shape with zero rows behind
+    them -- what ``mse_loss(out[:rows], y[:rows]).backward()`` leaves in ``out.grad``."""
+    from blackwater.native import ops
+
+    torch.manual_seed(5)
+    for n_pad, rows, c in ((33, 32, 1), (1025, 1024, 4), (40, 7, 3)):
+        out = torch.randn(n_pad, c, device=DEV)
+        y = torch.randn(n_pad, c, device=DEV)
+        loss, g = ops.mse_loss_grad(out, y, rows=rows)
+        ref = out.clone().requires_grad_(True)
+        want = torch.nn.functional.mse_loss(ref[:rows], y[:rows])
+        want.backward()
+        assert abs(loss.item() - want.item()) <= 1e-6 * abs(want.item())
+        assert tuple(g.shape) == (n_pad, c) and (g[rows:] == 0).all()
+        assert (g - ref.grad).abs().max().item() <= 1e-6 * ref.grad.abs().max().item()
