@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 17 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 18 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -411,11 +411,14 @@ int mlqem_gather_scale_rows_f32(const float* x, int64_t ldx, const int32_t* perm
                                 float* out, int64_t ldo, mlqem_stream_t stream);
 
 /* ASAPooling step 6 (PyG topk(fitness, ratio, batch)): for graph g keep its new_graph_ptr[g+1]-new_graph_ptr[g]
- * nodes of largest fitness, listed by descending fitness (ties: lower index first), graphs in order. */
+ * nodes of largest fitness, listed by descending fitness (ties: lower index first), graphs in order.
+ * max_graph_nodes: an upper bound on a graph's node count when the caller has one (0: none, N is used) -- it sizes the
+ * index field of the sort key, and lets batches of large graphs (>= 1024 nodes on average) go through ONE device-wide radix
+ * sort with the graph index in the key's top bits instead of a segmented sort that gives each graph to one workgroup. */
 size_t mlqem_segment_topk_workspace_bytes(int64_t N, int64_t B);
 int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr, const int32_t* new_graph_ptr, int64_t N,
-                       int64_t B, int64_t K, int32_t* perm, void* workspace, size_t workspace_bytes,
-                       mlqem_stream_t stream);
+                       int64_t B, int64_t K, int64_t max_graph_nodes, int32_t* perm, void* workspace,
+                       size_t workspace_bytes, mlqem_stream_t stream);
 
 /* ASAPooling step 7 (torch-sparse S^T A S, remove_diag, coo): only the PATTERN is consumed by the models.
  * Two hops with a sort-unique in between (counting every 3-step path explodes around 100-wire barriers):

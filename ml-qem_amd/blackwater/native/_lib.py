@@ -88,7 +88,7 @@ SIGNATURES = {
     "mlqem_leconv_fitness_f32": (_I, [_P, _P, _P, _L, _P, _P]),
     "mlqem_gather_scale_rows_f32": (_I, [_P, _L, _P, _P, _L, _I, _P, _L, _P]),
     "mlqem_segment_topk_workspace_bytes": (_S, [_L, _L]),
-    "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _P, _P, _S, _P]),
+    "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_workspace_bytes": (_S, [_L]),
     "mlqem_asap_hop1_count": (_I, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _S, _P]),
     "mlqem_asap_hop1_fill": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P]),
@@ -127,7 +127,7 @@ SIGNATURES = {
 
 _lib = None
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 17   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 18   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -672,7 +672,7 @@ class _ASAPool(Function):
         np.cumsum(keep, out=new_ptr_host[1:])
         k_total = int(new_ptr_host[-1])
         new_ptr = _device_ptr(new_ptr_host.astype(np.int32), x.device)
-        perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total)
+        perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=int(sizes.max()) if len(sizes) else 0)
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
         use_dense, use_rows = _ASAP_DENSE, _ASAP_ROWS       # the switches as they stand now: build() may run later
 

@@ -929,7 +929,7 @@ def gather_scale_rows(x, perm, scale=None):
     return out
 
 
-def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_total):
+def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_total, max_graph_nodes=0):
     _vec(fitness, "fitness", num_nodes)
     _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
     _vec(new_graph_ptr, "new_graph_ptr", num_graphs + 1, torch.int32)
@@ -937,7 +937,7 @@ def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_tot
     need = lib.mlqem_segment_topk_workspace_bytes(num_nodes, num_graphs)
     ws = torch.empty(need, dtype=torch.uint8, device=fitness.device)
     perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=fitness.device)[:k_total]
-    code = lib.mlqem_segment_topk(_p(fitness), _p(graph_ptr), _p(new_graph_ptr), num_nodes, num_graphs, k_total,
+    code = lib.mlqem_segment_topk(_p(fitness), _p(graph_ptr), _p(new_graph_ptr), num_nodes, num_graphs, k_total, int(max_graph_nodes),
                                   _p(perm), _p(ws), need, _stream())
     _lib.check(code, "mlqem_segment_topk")
     return perm

@@ -13,9 +13,11 @@ namespace mlqem {
 // key = (order-preserving bits of fitness) << b | (2^b - 1 - local index), b = bits of the largest local index: a
 // DESCENDING sort of these unique keys lists a graph's nodes by descending fitness with ties broken by the lower index,
 // whatever algorithm the segmented sort picks for the segment size, and the radix sort walks 32 + b bits instead of 64.
+// graph_bits > 0: the key also carries (B - 1 - graph) above the fitness bits, so that ONE device-wide descending sort lists the
+// graphs in ascending order, each by descending fitness (batches of large graphs: see mlqem_segment_topk).
 __global__ __launch_bounds__(kBlock) void topk_keys_kernel(const float* __restrict__ fitness,
                                                            const int32_t* __restrict__ gptr, int B, int64_t N,
-                                                           int idx_bits, uint64_t* __restrict__ keys) {
+                                                           int idx_bits, int graph_bits, uint64_t* __restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
   int lo = 0, hi = B;  // graph of node i: largest g with gptr[g] <= i
@@ -26,7 +28,9 @@ __global__ __launch_bounds__(kBlock) void topk_keys_kernel(const float* __restri
   const uint32_t bits = __float_as_uint(fitness[i]);
   const uint32_t ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
   const uint32_t local = (uint32_t)(i - gptr[lo]);
-  keys[i] = ((uint64_t)ord << idx_bits) | (uint64_t)(((1u << idx_bits) - 1u) - local);
+  uint64_t key = ((uint64_t)ord << idx_bits) | (uint64_t)(((1u << idx_bits) - 1u) - local);
+  if (graph_bits > 0) key |= (uint64_t)(B - 1 - lo) << (32 + idx_bits);
+  keys[i] = key;
 }
 
 __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __restrict__ sorted,
@@ -46,12 +50,19 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __r
   perm[p] = gptr[lo] + (int32_t)(mask - ((uint32_t)key & mask));
 }
 
-static size_t topk_temp_bytes(int64_t N, int64_t B) {
-  size_t temp = 0;
-  (void)rocprim::segmented_radix_sort_keys_desc(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)N,
+static size_t topk_temp_bytes(int64_t N, int64_t B) {     // enough for either sort
+  size_t seg = 0, whole = 0;
+  (void)rocprim::segmented_radix_sort_keys_desc(nullptr, seg, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)N,
                                                 (unsigned)B, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 64,
                                                 (hipStream_t)0);
-  return (temp + 255) / 256 * 256;
+  (void)rocprim::radix_sort_keys_desc(nullptr, whole, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)N, 0, 64, (hipStream_t)0);
+  return (std::max(seg, whole) + 255) / 256 * 256;
+}
+
+static int bits_for(int64_t values) {     // bits that hold 0 .. values - 1
+  int b = 1;
+  while (b < 31 && ((int64_t)1 << b) < values) ++b;
+  return b;
 }
 
 // ------------------------------------------------------------------------------- coarsened connectivity
@@ -449,7 +460,7 @@ extern "C" size_t mlqem_segment_topk_workspace_bytes(int64_t N, int64_t B) {
 }
 
 extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
-                                  int64_t N, int64_t B, int64_t K, int32_t* perm, void* workspace,
+                                  int64_t N, int64_t B, int64_t K, int64_t max_graph_nodes, int32_t* perm, void* workspace,
                                   size_t workspace_bytes, mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
@@ -463,12 +474,21 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
   uint64_t* sorted = reinterpret_cast<uint64_t*>(ws + kb);
   void* temp = ws + 2 * kb;
   size_t temp_bytes = topk_temp_bytes(N, B);
-  int idx_bits = 1;                                    // a graph has at most N nodes: local indices fit idx_bits bits (N < 2^31)
-  while (idx_bits < 31 && ((int64_t)1 << idx_bits) < N) ++idx_bits;
+  // a graph has at most max_graph_nodes (the caller's bound; N when it has none) nodes: local indices fit idx_bits bits
+  if (max_graph_nodes < 0 || max_graph_nodes > N) return MLQEM_ERR_BAD_ARG;
+  const int idx_bits = bits_for(max_graph_nodes > 0 ? max_graph_nodes : N);
+  // Graphs of thousands of nodes: the segmented sort gives a segment to ONE workgroup (64 workgroups on 256 CUs for a batch of
+  // 64 100-qubit circuits: 0.40 ms for 0.7 M keys); with the graph index in the key's top bits one device-wide radix sort
+  // does the same job with every CU.  Same keys below the graph bits, so the same permutation.
+  const int graph_bits = bits_for(B);
+  const bool whole = N / B >= 1024 && graph_bits + 32 + idx_bits <= 64;
   hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, fitness,
-                     graph_ptr, (int)B, N, idx_bits, keys);
-  if (rocprim::segmented_radix_sort_keys_desc(temp, temp_bytes, keys, sorted, (unsigned)N, (unsigned)B, graph_ptr,
-                                              graph_ptr + 1, 0, 32 + idx_bits, stream) != hipSuccess)
+                     graph_ptr, (int)B, N, idx_bits, whole ? graph_bits : 0, keys);
+  if (whole) {
+    if (rocprim::radix_sort_keys_desc(temp, temp_bytes, keys, sorted, (size_t)N, 0, (unsigned)(graph_bits + 32 + idx_bits), stream) != hipSuccess)
+      return MLQEM_ERR_LAUNCH;
+  } else if (rocprim::segmented_radix_sort_keys_desc(temp, temp_bytes, keys, sorted, (unsigned)N, (unsigned)B, graph_ptr,
+                                                     graph_ptr + 1, 0, 32 + idx_bits, stream) != hipSuccess)
     return MLQEM_ERR_LAUNCH;
   hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, sorted,
                      graph_ptr, new_graph_ptr, (int)B, K, idx_bits, perm);

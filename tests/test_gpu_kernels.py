@@ -634,3 +634,34 @@ def test_linear_with_more_than_128_inputs_runs_on_the_matrix_cores_in_two_pieces
     assert (got.double() - want).abs().max().item() < 1e-4 * want.abs().max().item()
     got2 = ops.linear(x, w, None, out=got.clone(), accumulate=True)          # accumulate onto an existing matrix
     assert (got2.double() - (want + x.double() @ w.double().t())).abs().max().item() < 1e-4 * want.abs().max().item() * 2
+
+
+@pytest.mark.parametrize("sizes", [[5, 1, 0, 17, 300], [3000, 9000, 1500, 4096, 2048, 7777], [20000] * 3 + [2089] * 5])
+def test_segment_topk_lists_each_graph_by_descending_fitness_ties_to_the_lower_index(sizes):
+    """mlqem_segment_topk (PyG ``topk(fitness, ratio, batch)`` of ASAPooling): small graphs go through the segmented sort,
+    batches of large graphs through ONE device-wide sort with the graph index in the key -- both must list, for every graph,
+    its ceil(n/2) nodes of largest fitness in descending order with ties broken by the lower index; with and without the
+    caller's bound on the graph size.  Fitness values are quantised so that ties are frequent; integers: exact."""
+    import numpy as np
+
+    from blackwater.native import ops
+
+    rng = np.random.RandomState(len(sizes))
+    sizes = np.asarray(sizes, dtype=np.int64)
+    n = int(sizes.sum())
+    fit = (rng.randint(0, 50, size=n) / 50.0).astype(np.float32)
+    fit[rng.rand(n) < 0.05] *= -1.0
+    keep = (sizes + 1) // 2
+    gptr = np.zeros(len(sizes) + 1, dtype=np.int32); gptr[1:] = np.cumsum(sizes)
+    nptr = np.zeros(len(sizes) + 1, dtype=np.int32); nptr[1:] = np.cumsum(keep)
+    want = []
+    for g in range(len(sizes)):
+        seg = fit[gptr[g]:gptr[g + 1]]
+        order = np.lexsort((np.arange(len(seg)), -seg.astype(np.float64)))      # by descending fitness, then ascending index
+        want.append(gptr[g] + order[:keep[g]])
+    want = np.concatenate(want) if want else np.zeros(0, dtype=np.int64)
+    f = torch.from_numpy(fit).to(DEV)
+    gp, np_ = torch.from_numpy(gptr).to(DEV), torch.from_numpy(nptr).to(DEV)
+    for bound in (int(sizes.max()), 0):
+        perm = ops.segment_topk(f, gp, np_, n, len(sizes), int(keep.sum()), max_graph_nodes=bound)
+        assert np.array_equal(perm.cpu().numpy().astype(np.int64), want), bound
