@@ -1063,13 +1063,15 @@ __global__ __launch_bounds__(kBlock) void wgrad_bf16_kernel(const WgradArgs a) {
   }
 }
 
-// Stage 2: fixed-order sum over the G partials.  Block = 8 (o,i) pairs x 32 slices of the G range: a thread adds
-// G/32 partials, then the 32 slice sums of a pair are added in slice order.
-constexpr int kReducePairs = 8, kReduceSlices = kBlock / kReducePairs;
-__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ partial, int G, int I, int O,
-                                                              float* __restrict__ gw, float* __restrict__ gb,
-                                                              int accumulate) {
-  __shared__ float s[kReduceSlices][kReducePairs + 1];
+// Stage 2: fixed-order sum over the G partials.  Block = 64 consecutive (o,i) pairs x 16 slices of the G range: every load
+// instruction of a wave reads 256 contiguous bytes of one partial (8 pairs x 32 slices read eight 32-byte pieces per
+// instruction: 32 us for the 34 MB of a 180 x 46 gradient, twelve launches per Family B step); a thread adds its G/16
+// partials on four independent chains, then the 16 slice sums of a pair are added in slice order.
+constexpr int kReducePairs = 64, kReduceSlices = 16;
+__global__ __launch_bounds__(kReducePairs * kReduceSlices) void wgrad_reduce_kernel(const float* __restrict__ partial, int G, int I, int O,
+                                                                                   float* __restrict__ gw, float* __restrict__ gb,
+                                                                                   int accumulate) {
+  __shared__ float s[kReduceSlices][kReducePairs];
   const int I1 = I + 1, pairs = O * I1;
   const int pl = threadIdx.x % kReducePairs, sl = threadIdx.x / kReducePairs;
   const int p = blockIdx.x * kReducePairs + pl;
@@ -1077,7 +1079,16 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __res
   if (p < pairs) {
     const int per = (G + kReduceSlices - 1) / kReduceSlices;
     const int g1 = min(G, (sl + 1) * per);
-    for (int g = sl * per; g < g1; ++g) t += partial[(int64_t)g * pairs + p];
+    int g = sl * per;
+    float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (; g + 3 < g1; g += 4) {
+      t += partial[(int64_t)g * pairs + p];
+      t1 += partial[(int64_t)(g + 1) * pairs + p];
+      t2 += partial[(int64_t)(g + 2) * pairs + p];
+      t3 += partial[(int64_t)(g + 3) * pairs + p];
+    }
+    for (; g < g1; ++g) t += partial[(int64_t)g * pairs + p];
+    t = (t + t1) + (t2 + t3);
   }
   s[sl][pl] = t;
   __syncthreads();
@@ -1387,7 +1398,7 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     const int Gp = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kWgradBlocks, want), ceil_div(ceil_div(a.N, 16), 4)));
     if (pipe_env == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<6, 2, 2, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((wgrad_pipe_kernel<6, 2, 4, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial,
                        Gp, a.I, a.O, gw, gb, accumulate);
     return launch_status();
   } else if (ob <= 6 && ib <= 2) {
@@ -1400,7 +1411,7 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     hipLaunchKernelGGL((wgrad_mfma_kernel<2, 4>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4))), dim3(kBlock),
                        0, s, a);
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial,
                      G, a.I, a.O, gw, gb, accumulate);
   return launch_status();
 }
@@ -1448,7 +1459,7 @@ extern "C" int mlqem_linear_wgrad_bf16_f32(const float* gy, int64_t ldgy, const 
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
   const int ob = (O + 15) / 16, ib = (I + 1 + 15) / 16;
   hipLaunchKernelGGL((wgrad_bf16_kernel<2, 2>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 2))), dim3(kBlock), 0, s, a);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial, G, I, O,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial, G, I, O,
                      gw, gb, accumulate);
   return launch_status();
 }
@@ -1472,7 +1483,7 @@ extern "C" int mlqem_linear_bwd_fused_f32(const float* gy, int64_t ldgy, const f
   // the partial buffer is sized for kWgradBlocks workgroups of 24 x (I + 1) floats: cap the grid accordingly
   const int Gc = std::min(G, kWgradBlocks);
   hipLaunchKernelGGL(linear_bwd_fused_kernel, dim3(Gc), dim3(kBlock), 0, s, a);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(24 * (I + 1), kReducePairs)), dim3(kBlock), 0, s, a.partial, Gc, I, 24,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(24 * (I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial, Gc, I, 24,
                      gw2, gb2, 0);
   return launch_status();
 }
