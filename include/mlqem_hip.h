@@ -95,6 +95,22 @@ int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, con
                             const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
                             const uint64_t* seed_counter, float* out, int64_t ldo, int64_t N, int C, mlqem_stream_t stream);
 
+/* mlqem_csr_aggregate_f32 AND the pooled means of its output (mlqem_segment_pool_f32 of `out` with `pool_weights`) from ONE
+ * pass: the aggregation's workgroups keep their rows of the output in LDS and leave per-(tile, graph) partial sums, added in
+ * tile order by the pool's finish kernel (deterministic).  Replaces the last hidden layer of a Family A branch followed by
+ * global_mean_pool (01_ngem.ipynb cell [9]; DESIGN section 3: the last conv is folded into the pool) without reading the
+ * [N, C] activation a second time.  out_mean / out_wmean: [B, C] (either may be NULL).  Needs the ELL side table and rows of
+ * round_up(C, 4) floats (MLQEM_ERR_UNSUPPORTED otherwise: call the two entry points).  workspace:
+ * mlqem_csr_aggregate_pool_workspace_bytes(N, B, C). */
+size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C);
+int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
+                                 const float* cscale, const float* rscale, const float* dself, float alpha, float beta,
+                                 const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
+                                 const uint64_t* seed_counter, float* out, int64_t ldo, int64_t N, int C,
+                                 const float* pool_weights, const int32_t* graph_ptr, int64_t B, float* out_mean,
+                                 int64_t ld_mean, float* out_wmean, int64_t ld_wmean, void* workspace, size_t workspace_bytes,
+                                 mlqem_stream_t stream);
+
 /* Segment max with the node itself included: out[i,:] = max(x[i,:], max_e x[idx[e],:])
  * (ASAPooling's scatter(..., reduce='max') after add_remaining_self_loops; docs/tutorials/gnn.py:85,92). */
 int mlqem_csr_segment_max_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,

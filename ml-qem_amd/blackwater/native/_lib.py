@@ -52,6 +52,9 @@ SIGNATURES = {
     "mlqem_batch_assemble": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L,
                                   _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _P, _L, _L, _I, _P]),
+    "mlqem_csr_aggregate_pool_workspace_bytes": (_S, [_L, _L, _I]),
+    "mlqem_csr_aggregate_pool_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _P, _L, _L, _I,
+                                          _P, _P, _L, _P, _L, _P, _L, _P, _S, _P]),
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
     "mlqem_mse_loss_workspace_bytes": (_S, []),
@@ -126,6 +129,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
 ABI_VERSION = 18   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 

@@ -128,8 +128,12 @@ def set_seed_counter(t):
 
 
 def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None, alpha=1.0, z=None, beta=0.0, bias=None,
-                  relu=False, drop_p=0.0, seed=0, out=None):
-    """out = act(alpha * (rscale * sum_e cscale[idx[e]] x[idx[e]] + dself * x) + beta * z + bias)."""
+                  relu=False, drop_p=0.0, seed=0, out=None, pool=None):
+    """out = act(alpha * (rscale * sum_e cscale[idx[e]] x[idx[e]] + dself * x) + beta * z + bias).
+
+    ``pool`` = a dict with ``graph_ptr``, ``num_graphs``, optional ``weights`` and the flags ``mean`` / ``wmean``: the pooled
+    means of ``out`` come from the same launch (mlqem_csr_aggregate_pool_f32) and are left in ``pool["mean"]`` /
+    ``pool["wmean"]`` ([B, c] tensors); shapes the fused kernel does not serve fall back to ``segment_pool`` on ``out``."""
     n, c = x.shape
     ldx = _mat(x, "x")
     _vec(ptr, "ptr", n + 1, torch.int32)
@@ -148,12 +152,38 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
         if z.shape != x.shape:
             raise ValueError("z must have the shape of x")
         ldz = _mat(z, "z")
-    code = _lib.load().mlqem_csr_aggregate_f32(
-        _p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
-        _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
-        _p(_seed_counter) if drop_p > 0 else None, _p(out), ldo, n, c, _stream())
+    common = (_p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
+              _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+              _p(_seed_counter) if drop_p > 0 else None, _p(out), ldo, n, c)
+    lib = _lib.load()
+    if pool is not None:
+        gptr, nb, wts = pool["graph_ptr"], int(pool["num_graphs"]), pool.get("weights")
+        want_mean, want_wmean = bool(pool.get("mean", True)), bool(pool.get("wmean", True))
+        fused = ell is not None and _POOL_FUSED and n > 0 and nb > 0
+        if fused:
+            _vec(gptr, "graph_ptr", nb + 1, torch.int32)
+            _vec(wts, "weights", n)
+            mean = padded_empty(nb, c, x.device) if want_mean else None
+            wmean = padded_empty(nb, c, x.device) if want_wmean else None
+            need = lib.mlqem_csr_aggregate_pool_workspace_bytes(n, nb, c)
+            ws = _wgrad_workspace(x.device, need)
+            code = lib.mlqem_csr_aggregate_pool_f32(*common, _p(wts), _p(gptr), nb, _p(mean), _mat(mean, "mean") if want_mean else 0,
+                                                    _p(wmean), _mat(wmean, "wmean") if want_wmean else 0, _p(ws), need, _stream())
+            if code == _lib.ERR_UNSUPPORTED:
+                fused = False
+            else:
+                _lib.check(code, "mlqem_csr_aggregate_pool_f32")
+                pool["mean"], pool["wmean"] = mean, wmean
+                return out
+    code = lib.mlqem_csr_aggregate_f32(*common, _stream())
     _lib.check(code, "mlqem_csr_aggregate_f32")
+    if pool is not None:
+        pool["mean"], pool["wmean"] = segment_pool(out, pool["graph_ptr"], int(pool["num_graphs"]), weights=pool.get("weights"),
+                                                   mean=bool(pool.get("mean", True)), wmean=bool(pool.get("wmean", True)))
     return out
+
+
+_POOL_FUSED = __import__("os").environ.get("MLQEM_POOL_FUSED", "1") != "0"    # 0: aggregation and pool as two launches (A/B)
 
 
 def _ell(ell, n):

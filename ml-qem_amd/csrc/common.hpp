@@ -174,4 +174,14 @@ template <class F> __device__ __forceinline__ void for_edge_chunks(int beg, int 
 
 __device__ __forceinline__ bool aligned_to_dev(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// largest g in [0, B) with gptr[g] <= r (gptr[0] = 0 <= r): the graph of row r, or of the empty graphs just before it
+__device__ __forceinline__ int graph_at(const int32_t* __restrict__ gptr, int B, int64_t r) {
+  int lo = 0, hi = B;   // invariant: gptr[lo] <= r < gptr[hi] (gptr[B] = N > r)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)gptr[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 }  // namespace mlqem

@@ -36,6 +36,15 @@ struct AggArgs {
   int64_t N; int C; int CV; int R; int nt;
 };
 
+// The pooled means of the activation a launch produces, from the same launch (mlqem_csr_aggregate_pool_f32): per-(tile, graph)
+// partial sums of out and of wts * out in pool.hip's layout, tile = the workgroup's whole rows.
+struct PoolFuse {
+  const float* wts;        // optional [N]
+  const int32_t* gptr;     // [B+1]
+  int B;
+  float* partial;          // [(tiles + B)][2][CV * VEC]
+};
+
 constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rscale / dself)
 constexpr int kHeavyDegree = 32;     // rows above this are reduced by the whole block
 constexpr int kHeavyCap = 64;
@@ -55,9 +64,10 @@ __device__ __forceinline__ void stage_bias(const AggArgs& a, float* s_bias, int 
 // Compiled apart from the full epilogue (z, bias, ReLU, dropout) because the kernels are pinned at 64 VGPRs for eight waves
 // per SIMD and the epilogue's operands (about a dozen more SGPRs, 64-bit hash temporaries) tipped the hot path into
 // scratch: +20 % write traffic and +15 % time on the plain launches, measured with the PMC passes of round 2.
-template <int VEC, bool IS_MAX, bool EPI = true>
+template <int VEC, bool IS_MAX, bool EPI = true, bool POOL = false>
 __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
-                                           const float (&self)[VEC], float rs, float ds, const float* s_bias) {
+                                           const float (&self)[VEC], float rs, float ds, const float* s_bias,
+                                           float* s_tile = nullptr, int64_t r0 = 0) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
@@ -84,6 +94,11 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
   }
   if (a.nt) vstore_nt<VEC>(a.out + row * a.ldo + ch, res);
   else vstore<VEC>(a.out + row * a.ldo + ch, res);
+  if (POOL) {               // the workgroup's tile of the output, row-major, for the pooled partial sums at the end of the kernel
+    float* t = s_tile + (int)(row - r0) * (a.CV * VEC) + ch;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) t[v] = res[v];
+  }
 }
 
 template <int VEC, bool IS_MAX, int kItemsPerThread>
@@ -240,11 +255,13 @@ __global__ __launch_bounds__(kBlock) void csr_aggregate_kernel(const AggArgs a) 
 // becomes ell -> source row: one dependent round trip less, no LDS staging and no barrier on the fast path.
 // Items are (row, channel-slice) pairs numbered row-major exactly as above; a workgroup owns kBlock * IPT items.
 
-template <int VEC, bool IS_MAX, int kItemsPerThread, bool EPI, int kMinWaves = 8>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWaves, 8))) void csr_aggregate_ell_kernel(const AggArgs a) {
+template <int VEC, bool IS_MAX, int kItemsPerThread, bool EPI, int kMinWaves = 8, bool POOL = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWaves, 8))) void csr_aggregate_ell_kernel(const AggArgs a, const PoolFuse pf) {
   // A block owns a.R = (kBlock * IPT) / CV whole rows; the local item index li < kBlock * IPT <= 2048 is split into
   // (row, slice) with a multiply-shift (exact for li * CV < 2^20) instead of a division.
   __shared__ float s_bias[EPI ? kBiasLds : 1];
+  __shared__ float s_tile[POOL ? kBlock * kItemsPerThread * VEC : 1];       // POOL: this workgroup's rows of the output
+  __shared__ float s_pred[POOL ? kBlock : 1][2 * VEC];
   if (EPI) stage_bias(a, s_bias, a.CV * VEC);
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int64_t r0 = (int64_t)blk * a.R;
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
         for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
       }
     }
-    finish_row<VEC, IS_MAX, EPI>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias);
+    finish_row<VEC, IS_MAX, EPI, POOL>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias, s_tile, r0);
   }
   // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
   // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
@@ -381,7 +398,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
             if (!use_self) sf[v] = 0.f;
             if (IS_MAX) part[v] = fmaxf(part[v], sf[v]);
           }
-          finish_row<VEC, IS_MAX, EPI>(a, r, hch, part, sf, rs_r, ds_r, s_bias);
+          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, part, sf, rs_r, ds_r, s_bias, s_tile, r0);
         }
       } else {   // more slices than lanes: every lane walks all edges for its slices
         for (int sl = lane; sl < a.CV; sl += kWave) {
@@ -401,9 +418,66 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
 #pragma unroll
             for (int v = 0; v < VEC; ++v) tot[v] = IS_MAX ? fmaxf(tot[v], q[v]) : fmaf(w, q[v], tot[v]);
           }
-          finish_row<VEC, IS_MAX, EPI>(a, r, hch, tot, sf, rs_r, ds_r, s_bias);
+          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, tot, sf, rs_r, ds_r, s_bias, s_tile, r0);
         }
       }
+    }
+  }
+  if constexpr (POOL) {
+    // Pooled partial sums of the tile (pool.hip's pool_partial_kernel on rows that are still in LDS): for every graph with
+    // rows in this tile, sum over its rows of out and of wts * out per channel slice.  Row lanes add their rows in a fixed
+    // order, a two-level tree in LDS adds the lanes in a fixed order; one partial per (tile, graph) at index tile + graph.
+    __syncthreads();                              // every row of the tile is in s_tile
+    const int cvv = a.CV * VEC;
+    const int lanes_r = kBlock / a.CV;            // >= 1: CV <= kBlock is checked on the host
+    const int cs = tid % a.CV, rl = tid / a.CV;
+    const bool worker = rl < lanes_r;
+    const int chp = cs * VEC;
+    const int q_lanes = min(16, lanes_r);
+    for (int g = graph_at(pf.gptr, pf.B, r0); g < pf.B && (int64_t)pf.gptr[g] < r0 + nrows; ++g) {   // workgroup-uniform loop
+      const int s0 = (int)(max(r0, (int64_t)pf.gptr[g]) - r0), s1 = (int)(min(r0 + nrows, (int64_t)pf.gptr[g + 1]) - r0);
+      if (s1 <= s0) continue;                     // an empty graph
+      float acc0[VEC], acc1[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc0[v] = acc1[v] = 0.f;
+      if (worker)
+        for (int r = s0 + rl; r < s1; r += lanes_r) {
+          const float w = pf.wts ? pf.wts[r0 + r] : 1.f;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float xv = s_tile[r * cvv + chp + v];
+            acc0[v] += xv;
+            acc1[v] = fmaf(w, xv, acc1[v]);
+          }
+        }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { s_pred[tid][v] = acc0[v]; s_pred[tid][VEC + v] = acc1[v]; }
+      __syncthreads();
+      const bool second = worker && rl < q_lanes;
+      float t2[2 * VEC];
+#pragma unroll
+      for (int v = 0; v < 2 * VEC; ++v) t2[v] = 0.f;
+      if (second)
+        for (int k = rl; k < lanes_r; k += q_lanes)
+#pragma unroll
+          for (int v = 0; v < 2 * VEC; ++v) t2[v] += s_pred[k * a.CV + cs][v];
+      __syncthreads();                            // every read of the first level is done
+      if (second)
+#pragma unroll
+        for (int v = 0; v < 2 * VEC; ++v) s_pred[tid][v] = t2[v];
+      __syncthreads();
+      if (rl == 0) {
+        float t[2 * VEC];
+#pragma unroll
+        for (int v = 0; v < 2 * VEC; ++v) t[v] = 0.f;
+        for (int k = 0; k < q_lanes; ++k)
+#pragma unroll
+          for (int v = 0; v < 2 * VEC; ++v) t[v] += s_pred[k * a.CV + cs][v];
+        float* dst = pf.partial + (((int64_t)blk + g) * 2) * cvv + chp;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { dst[v] = t[v]; dst[cvv + v] = t[VEC + v]; }
+      }
+      __syncthreads();                            // s_pred is reused by the next graph of the tile
     }
   }
 }
@@ -422,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void ell_from_csr_kernel(const int32_t* __r
 }
 
 template <bool IS_MAX>
-static int launch_aggregate(AggArgs a, hipStream_t stream) {
+static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool = nullptr, int* rows_per_tile = nullptr) {
   if (a.N < 0 || a.C <= 0 || !a.x || !a.ptr || !a.out || a.ldx < a.C || a.ldo < a.C) return MLQEM_ERR_BAD_ARG;
   if (a.z && a.ldz < a.C) return MLQEM_ERR_BAD_ARG;
   if (a.N == 0) return MLQEM_OK;
@@ -459,13 +533,24 @@ static int launch_aggregate(AggArgs a, hipStream_t stream) {
     grid = dim3((unsigned)eblocks);
   }
   const bool epi = !IS_MAX && (a.z || a.bias || a.act || a.drop_p > 0.f);
+  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr};
+  if (pool) {     // the pooled form exists for the shape the models launch it with: ELL side table, 16-byte rows, an epilogue
+    if (IS_MAX || !a.ell || vec != 4 || ipt != 2) return MLQEM_ERR_UNSUPPORTED;
+    if (rows_per_tile) *rows_per_tile = a.R;
+    if constexpr (!IS_MAX) {
+      static const int pool_waves = getenv("MLQEM_AGG_POOL_WAVES") ? atoi(getenv("MLQEM_AGG_POOL_WAVES")) : 7;
+      if (pool_waves >= 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<4, false, 2, true, 7, true>), grid, block, 0, stream, a, *pool);
+      else hipLaunchKernelGGL((csr_aggregate_ell_kernel<4, false, 2, true, 6, true>), grid, block, 0, stream, a, *pool);
+    }
+    return launch_status();
+  }
   static const int epi_waves = getenv("MLQEM_AGG_EPI_WAVES") ? atoi(getenv("MLQEM_AGG_EPI_WAVES")) : 7;   // measured: 7 -> 304/351 us, 6 -> 341/385, 8 (spilling) -> 356/385 (GCN / Cheb forward)
 #define MLQEM_LAUNCH(V, P)                                                                                  \
   do {                                                                                                      \
-    if (a.ell && epi && epi_waves == 8) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 8>), grid, block, 0, stream, a);   \
-    else if (a.ell && epi && epi_waves == 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 7>), grid, block, 0, stream, a);   \
-    else if (a.ell && epi) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 6>), grid, block, 0, stream, a);   \
-    else if (a.ell) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, false>), grid, block, 0, stream, a);    \
+    if (a.ell && epi && epi_waves == 8) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 8>), grid, block, 0, stream, a, no_pool);   \
+    else if (a.ell && epi && epi_waves == 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 7>), grid, block, 0, stream, a, no_pool);   \
+    else if (a.ell && epi) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 6>), grid, block, 0, stream, a, no_pool);   \
+    else if (a.ell) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, false>), grid, block, 0, stream, a, no_pool);    \
     else hipLaunchKernelGGL((csr_aggregate_kernel<V, IS_MAX, P>), grid, block, 0, stream, a);               \
   } while (0)
 #define MLQEM_BY_IPT(V) do { if (ipt == 1) MLQEM_LAUNCH(V, 1); else if (ipt == 2) MLQEM_LAUNCH(V, 2); else if (ipt == 8) MLQEM_LAUNCH(V, 8); else MLQEM_LAUNCH(V, 4); } while (0)
@@ -525,6 +610,21 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_kernel(const float* __res
   vstore<VEC>(y + r * ldy + c, o);
   if (sum) vstore<VEC>(sum + r * lds + c, sv);
 }
+
+// The aggregation launch of mlqem_csr_aggregate_pool_f32 (pool.hip owns the entry point and the finish kernel): the epilogue
+// form writing per-(tile, graph) pooled partial sums; *rows_per_tile = the rows a workgroup owns.
+int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell, const float* cscale,
+                               const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
+                               const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
+                               int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
+                               float* partial, int* rows_per_tile, hipStream_t stream) {
+  AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, seed_counter, out, ldo, N, C, 0, 0};
+  const PoolFuse pf{pool_weights, graph_ptr, B, partial};
+  return launch_aggregate<false>(a, stream, &pf, rows_per_tile);
+}
+
+// rows a workgroup of the pooled form owns for C channels (what sizes the partial-sum workspace)
+int aggregate_pool_rows_per_tile(int C) { return std::max(1, kBlock * 2 / ((C + 3) / 4)); }
 
 }  // namespace mlqem
 

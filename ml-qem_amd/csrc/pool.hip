@@ -29,16 +29,6 @@ struct PoolArgs {
   int rows;                  // rows per tile: kPoolRows or kPoolRowsSmall
 };
 
-// largest g in [0, B) with gptr[g] <= r (gptr[0] = 0 <= r): the graph of row r, or of the empty graphs just before it
-__device__ __forceinline__ int graph_at(const int32_t* __restrict__ gptr, int B, int64_t r) {
-  int lo = 0, hi = B;   // invariant: gptr[lo] <= r < gptr[hi] (gptr[B] = N > r)
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if ((int64_t)gptr[mid] <= r) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void pool_partial_kernel(const PoolArgs a) {
   __shared__ float s_red[kBlock][2 * VEC];
@@ -293,6 +283,54 @@ extern "C" int mlqem_segment_pool_f32(const float* x, int64_t ldx, const float* 
   }
   hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)ceil_div(B * C, kBlock)), dim3(kBlock), 0, s, a.partial, graph_ptr, (int)B,
                      C, wide ? c4 : C, a.rows, out_mean, ld_mean, out_wmean, ld_wmean);
+  return launch_status();
+}
+
+namespace mlqem {
+int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell, const float* cscale,
+                               const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
+                               const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
+                               int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
+                               float* partial, int* rows_per_tile, hipStream_t stream);
+int aggregate_pool_rows_per_tile(int C);
+}  // namespace mlqem
+
+extern "C" size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C) {
+  if (N < 0 || B < 0 || C <= 0) return 0;
+  const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), aggregate_pool_rows_per_tile(C));
+  return (size_t)(tiles + B) * 2 * ((C + 3) / 4 * 4) * sizeof(float);
+}
+
+// mlqem_csr_aggregate_f32 and mlqem_segment_pool_f32 of its output in one pass over the rows: the aggregation's workgroups
+// keep their tile of the output in LDS and leave per-(tile, graph) partial sums, the finish kernel is the pool's own.
+extern "C" int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
+                                            const float* cscale, const float* rscale, const float* dself, float alpha, float beta,
+                                            const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
+                                            const uint64_t* seed_counter, float* out, int64_t ldo, int64_t N, int C,
+                                            const float* pool_weights, const int32_t* graph_ptr, int64_t B, float* out_mean,
+                                            int64_t ld_mean, float* out_wmean, int64_t ld_wmean, void* workspace,
+                                            size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || B < 0 || C <= 0 || drop_p < 0.f || drop_p >= 1.f || B > 0x7fffffffLL || N > 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if ((!out_mean && !out_wmean) || (out_mean && ld_mean < C) || (out_wmean && ld_wmean < C)) return MLQEM_ERR_BAD_ARG;
+  if (!ell) return MLQEM_ERR_UNSUPPORTED;
+  if (B == 0) return MLQEM_OK;
+  if (!graph_ptr) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_csr_aggregate_pool_workspace_bytes(N, B, C)) return MLQEM_ERR_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  int rows = 0;
+  if (N > 0) {
+    const int rc = launch_aggregate_with_pool(x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed,
+                                              seed_counter, out, ldo, N, C, pool_weights, graph_ptr, (int)B, static_cast<float*>(workspace),
+                                              &rows, s);
+    if (rc != MLQEM_OK) return rc;
+    if (rows != aggregate_pool_rows_per_tile(C)) return MLQEM_ERR_LAUNCH;      // the workspace was sized for another tiling
+  } else {
+    rows = aggregate_pool_rows_per_tile(C);
+  }
+  const int c4 = (C + 3) / 4 * 4;
+  hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)ceil_div(B * C, kBlock)), dim3(kBlock), 0, s, static_cast<const float*>(workspace),
+                     graph_ptr, (int)B, C, c4, rows, out_mean, ld_mean, out_wmean, ld_wmean);
   return launch_status();
 }
 
