@@ -339,7 +339,7 @@ class _ChebLayer(Function):
     (covered by the 1e-5 parity tests)."""
 
     @staticmethod
-    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, *ws, pre=None):
+    def forward(ctx, x, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, *ws, pre=None, pool=None):
         s, k = struct, len(ws)
         x = _padded_rows(ops.rowmajor(x))
         o = ws[0].shape[0]
@@ -350,11 +350,12 @@ class _ChebLayer(Function):
         c = list(pre) if pre is not None else _fan_out(x, ws, [bias] + [None] * (k - 1), w_minus)
         lap = dict(ell=s.in_ell, cscale=s.cheb_dinv, rscale=s.derived("cheb_neg"))
         act = dict(relu=relu, drop_p=drop_p, seed=seed)
+        # pool: the pooled means of y from the launch that writes y (ops.csr_aggregate)
         if k == 2:
-            y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], **lap, **act)
+            y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], pool=pool, **lap, **act)
         else:
             ops.csr_aggregate(c[2], s.in_ptr, s.in_src, alpha=2.0, z=c[1], beta=1.0, out=c[1], **lap)
-            y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], **lap, **act)
+            y = ops.csr_aggregate(c[1], s.in_ptr, s.in_src, z=c[0], beta=1.0, out=c[0], pool=pool, **lap, **act)
         ctx.struct, ctx.k, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, k, relu, drop_p, bias is not None, (o, ow)
         ctx.x_gate_scale = x_gate_scale
         ctx.save_for_backward(x, y if ((relu or drop_p > 0) and not defer_mask) else None, *ws)
@@ -457,7 +458,7 @@ class _SAGELayer(Function):
     Backward: g_p = mean_in^T(g); one weight-gradient pass x^T [g_p | g]; gx = g_p W_l + g W_r in one GEMM."""
 
     @staticmethod
-    def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, pre=None):
+    def forward(ctx, x, wl, bl, wr, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, pre=None, pool=None):
         s = struct
         x = _padded_rows(ops.rowmajor(x))
         o = wl.shape[0]
@@ -465,7 +466,7 @@ class _SAGELayer(Function):
         wl, wr = wl.contiguous(), wr.contiguous()
         p, r = pre if pre is not None else _fan_out(x, [wl, wr], [None, bl])   # the bias rides on the root term
         y = ops.csr_aggregate(p, s.in_ptr, s.in_src, ell=s.in_ell, rscale=s.sage_rinv, dself=s.derived("sage_dself"),
-                              z=r, beta=1.0, relu=relu, drop_p=drop_p, seed=seed, out=r)
+                              z=r, beta=1.0, relu=relu, drop_p=drop_p, seed=seed, out=r, pool=pool)
         ctx.struct, ctx.relu, ctx.drop_p, ctx.has_bias, ctx.dims = s, relu, drop_p, bl is not None, (o, ow)
         ctx.x_gate_scale = x_gate_scale
         ctx.save_for_backward(x, wl, wr, y if ((relu or drop_p > 0) and not defer_mask) else None)
@@ -502,12 +503,12 @@ class _GCNLayer(Function):
     then the same symmetric-normalised aggregation on the transposed CSR, then the two GEMM gradients."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, pre=None):
+    def forward(ctx, x, w, bias, struct: GraphStructure, relu, drop_p, seed, defer_mask, x_gate_scale, pre=None, pool=None):
         x = ops.rowmajor(x)
         dinv = struct.gcn_dinv
         h = pre if pre is not None else ops.linear(x, w.contiguous(), rowscale=dinv)
         y = ops.csr_aggregate(h, struct.in_ptr, struct.in_src, ell=struct.in_ell, rscale=dinv, dself=dinv, bias=bias, relu=relu,
-                              drop_p=drop_p, seed=seed)
+                              drop_p=drop_p, seed=seed, pool=pool)
         ctx.struct, ctx.relu, ctx.drop_p, ctx.x_gate_scale = struct, relu, drop_p, x_gate_scale
         ctx.save_for_backward(x, w, y if ((relu or drop_p > 0) and not defer_mask) else None)
         return y
@@ -846,17 +847,22 @@ class _FamilyAGraph(Function):
             st.wait_stream(main)
         # GCN branch: args (x, w, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
         L["g1"] = mk(9, Fa); h = _GCNLayer.forward(L["g1"], x, g1w, g1b, struct, T, p1, seed + 1, T, None, pre=pre_g)
-        L["g2"] = mk(9, T); hg = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1)
-        _, wg = ops.segment_pool(hg, gptr, nb, weights=tg, mean=False, wmean=True)
+        # the pooled means of each branch's last hidden activation come out of the aggregation launch that writes it
+        # (mlqem_csr_aggregate_pool_f32: the activation is not read a second time)
+        pg = dict(graph_ptr=gptr, num_graphs=nb, weights=tg, mean=False, wmean=True)
+        L["g2"] = mk(9, T); hg = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1, pool=pg)
+        wg = pg["out_wmean"]
         with torch.cuda.stream(side[0]):
             # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
+            pc = dict(graph_ptr=gptr, num_graphs=nb, weights=tc, mean=True, wmean=True)
             L["c1"] = mk(11, Fa); hc = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2,
-                                                          pre=pre_c)
-            mc, wc = ops.segment_pool(hc, gptr, nb, weights=tc, mean=True, wmean=True)
+                                                          pre=pre_c, pool=pc)
+            mc, wc = pc["out_mean"], pc["out_wmean"]
         with torch.cuda.stream(side[1]):
             # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
-            L["s1"] = mk(10, Fa); hs = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None, pre=pre_s)
-            ms, ws = ops.segment_pool(hs, gptr, nb, weights=ts, mean=True, wmean=True)
+            ps = dict(graph_ptr=gptr, num_graphs=nb, weights=ts, mean=True, wmean=True)
+            L["s1"] = mk(10, Fa); hs = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None, pre=pre_s, pool=ps)
+            ms, ws = ps["out_mean"], ps["out_wmean"]
         for st, ts_ in zip(side, ((mc, wc), (ms, ws))):
             main.wait_stream(st)
             for t in ts_:

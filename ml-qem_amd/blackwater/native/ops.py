@@ -132,8 +132,8 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
     """out = act(alpha * (rscale * sum_e cscale[idx[e]] x[idx[e]] + dself * x) + beta * z + bias).
 
     ``pool`` = a dict with ``graph_ptr``, ``num_graphs``, optional ``weights`` and the flags ``mean`` / ``wmean``: the pooled
-    means of ``out`` come from the same launch (mlqem_csr_aggregate_pool_f32) and are left in ``pool["mean"]`` /
-    ``pool["wmean"]`` ([B, c] tensors); shapes the fused kernel does not serve fall back to ``segment_pool`` on ``out``."""
+    means of ``out`` come from the same launch (mlqem_csr_aggregate_pool_f32) and are left in ``pool["out_mean"]`` /
+    ``pool["out_wmean"]`` ([B, c] tensors, None for a mean that was not asked for); shapes the fused kernel does not serve fall back to ``segment_pool`` on ``out``."""
     n, c = x.shape
     ldx = _mat(x, "x")
     _vec(ptr, "ptr", n + 1, torch.int32)
@@ -173,17 +173,21 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
                 fused = False
             else:
                 _lib.check(code, "mlqem_csr_aggregate_pool_f32")
-                pool["mean"], pool["wmean"] = mean, wmean
+                pool["out_mean"], pool["out_wmean"] = mean, wmean
                 return out
     code = lib.mlqem_csr_aggregate_f32(*common, _stream())
     _lib.check(code, "mlqem_csr_aggregate_f32")
     if pool is not None:
-        pool["mean"], pool["wmean"] = segment_pool(out, pool["graph_ptr"], int(pool["num_graphs"]), weights=pool.get("weights"),
+        pool["out_mean"], pool["out_wmean"] = segment_pool(out, pool["graph_ptr"], int(pool["num_graphs"]), weights=pool.get("weights"),
                                                    mean=bool(pool.get("mean", True)), wmean=bool(pool.get("wmean", True)))
     return out
 
 
-_POOL_FUSED = __import__("os").environ.get("MLQEM_POOL_FUSED", "1") != "0"    # 0: aggregation and pool as two launches (A/B)
+# MLQEM_POOL_FUSED=1: the pooled means from the aggregation launch itself (mlqem_csr_aggregate_pool_f32).  Off by default: measured
+# on the bench's step it LOSES to the two-launch form (7.54-7.66 vs 7.33-7.34 ms per step on one box) -- the tile reduction
+# needs workgroup barriers at the end of a kernel whose waves otherwise never wait for each other, so a wave that is still
+# walking a hub row holds the workgroup's four wave slots and 20 KB of LDS; see DESIGN.md section 9.
+_POOL_FUSED = __import__("os").environ.get("MLQEM_POOL_FUSED", "0") == "1"
 
 
 def _ell(ell, n):

@@ -270,6 +270,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   const unsigned magic = ((1u << 20) + a.CV - 1) / a.CV;
   const int tid = threadIdx.x;
   const bool use_self = IS_MAX || a.dself != nullptr;
+  // POOL: the graph of the tile's first row, searched for now (ten dependent scalar loads) so that the latency hides behind
+  // the gathers instead of standing at the end of the kernel
+  int g_first = 0;
+  if constexpr (POOL) g_first = graph_at(pf.gptr, pf.B, r0);
 
   int row[kItemsPerThread], ch[kItemsPerThread];
   int2 e2[kItemsPerThread];
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     const bool worker = rl < lanes_r;
     const int chp = cs * VEC;
     const int q_lanes = min(16, lanes_r);
-    for (int g = graph_at(pf.gptr, pf.B, r0); g < pf.B && (int64_t)pf.gptr[g] < r0 + nrows; ++g) {   // workgroup-uniform loop
+    for (int g = g_first; g < pf.B && (int64_t)pf.gptr[g] < r0 + nrows; ++g) {   // workgroup-uniform loop
       const int s0 = (int)(max(r0, (int64_t)pf.gptr[g]) - r0), s1 = (int)(min(r0 + nrows, (int64_t)pf.gptr[g + 1]) - r0);
       if (s1 <= s0) continue;                     // an empty graph
       float acc0[VEC], acc1[VEC];
