@@ -183,10 +183,10 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
     return out
 
 
-# MLQEM_POOL_FUSED=1: the pooled means from the aggregation launch itself (mlqem_csr_aggregate_pool_f32).  Off by default: measured
-# on the bench's step it LOSES to the two-launch form (7.54-7.66 vs 7.33-7.34 ms per step on one box) -- the tile reduction
-# needs workgroup barriers at the end of a kernel whose waves otherwise never wait for each other, so a wave that is still
-# walking a hub row holds the workgroup's four wave slots and 20 KB of LDS; see DESIGN.md section 9.
+# MLQEM_POOL_FUSED=1: the pooled means from the aggregation launch itself (mlqem_csr_aggregate_pool_f32).  Off by default: on the
+# bench's step it is a wash against the two-launch form (6.91-6.97 vs 6.94-6.98 ms per step on one box; a first version with
+# workgroup barriers at the end of the kernel LOST 0.2-0.6 ms) -- what the pool kernels' second read of the activation costs,
+# the aggregation kernel pays in LDS footprint and in a tail that one wave per workgroup runs alone; see DESIGN.md section 9.
 _POOL_FUSED = __import__("os").environ.get("MLQEM_POOL_FUSED", "0") == "1"
 
 

@@ -43,7 +43,16 @@ struct PoolFuse {
   const int32_t* gptr;     // [B+1]
   int B;
   float* partial;          // [(tiles + B)][2][CV * VEC]
+  const int32_t* tile_graph;   // [tiles]: the graph of each tile's first row (tile_graph_kernel)
 };
+
+// graph of the first row of every tile of `rows` rows: one binary search per tile, outside the kernel that needs it (inside,
+// its ten dependent scalar loads sat in front of every later scalar or LDS wait of the workgroup)
+__global__ __launch_bounds__(kBlock) void tile_graph_kernel(const int32_t* __restrict__ gptr, int B, int rows, int64_t tiles,
+                                                            int32_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < tiles) out[t] = graph_at(gptr, B, t * rows);
+}
 
 constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rscale / dself)
 constexpr int kHeavyDegree = 32;     // rows above this are reduced by the whole block
@@ -261,7 +270,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   // (row, slice) with a multiply-shift (exact for li * CV < 2^20) instead of a division.
   __shared__ float s_bias[EPI ? kBiasLds : 1];
   __shared__ float s_tile[POOL ? kBlock * kItemsPerThread * VEC : 1];       // POOL: this workgroup's rows of the output
-  __shared__ float s_pred[POOL ? kBlock : 1][2 * VEC];
+  __shared__ float s_wts[POOL ? kBlock * kItemsPerThread : 1];               // ... the rows' pooling weights
+  __shared__ int s_done;                                                     // ... tickets of the waves that are done
   if (EPI) stage_bias(a, s_bias, a.CV * VEC);
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int64_t r0 = (int64_t)blk * a.R;
@@ -272,8 +282,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   const bool use_self = IS_MAX || a.dself != nullptr;
   // POOL: the graph of the tile's first row, searched for now (ten dependent scalar loads) so that the latency hides behind
   // the gathers instead of standing at the end of the kernel
-  int g_first = 0;
-  if constexpr (POOL) g_first = graph_at(pf.gptr, pf.B, r0);
+  // POOL: the ticket counter starts at zero (the one barrier, at the start where every wave is anyway and nothing is in
+  // flight); the rows' pooling weights are fetched now and parked in LDS just before the ticket is taken
+  float wreg[kItemsPerThread];
+  if constexpr (POOL) {
+    if (tid == 0) s_done = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kItemsPerThread; ++k) {
+      const int r = k * kBlock + tid;
+      wreg[k] = (pf.wts && r < nrows) ? pf.wts[r0 + r] : 1.f;
+    }
+  }
 
   int row[kItemsPerThread], ch[kItemsPerThread];
   int2 e2[kItemsPerThread];
@@ -428,60 +448,57 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     }
   }
   if constexpr (POOL) {
-    // Pooled partial sums of the tile (pool.hip's pool_partial_kernel on rows that are still in LDS): for every graph with
-    // rows in this tile, sum over its rows of out and of wts * out per channel slice.  Row lanes add their rows in a fixed
-    // order, a two-level tree in LDS adds the lanes in a fixed order; one partial per (tile, graph) at index tile + graph.
-    __syncthreads();                              // every row of the tile is in s_tile
+    // Pooled partial sums of the tile: for every graph with rows in it, the sums over its rows of out and of wts * out per
+    // column.  No workgroup barrier: the waves of this kernel never wait for each other (a wave walking a hub row would hold
+    // the other three), so every wave publishes its rows in LDS and takes a ticket, and the wave that draws the LAST ticket
+    // reduces the whole tile alone while the others have already left: 64 / (CV VEC) row groups x (CV VEC) columns, a
+    // group's rows added in order, the groups added in order (deterministic).  One partial per (tile, graph) at index
+    // tile + graph, pool.hip's layout, summed over the tiles by its finish kernel.
+#pragma unroll
+    for (int k = 0; k < kItemsPerThread; ++k) {
+      const int r = k * kBlock + tid;
+      if (r < nrows) s_wts[r] = wreg[k];
+    }
+    __threadfence_block();                        // this wave's rows of s_tile and s_wts are visible before its ticket is
+    int last = 0;
+    if (lane == 0) last = atomicAdd(&s_done, 1) == kBlock / kWave - 1;
+    last = __shfl(last, 0);
+    if (!last) return;
+    __threadfence_block();
+    // lane = slice * groups + group: a lane adds every groups-th row of its 16-byte channel slice, then the groups of a slice
+    // (consecutive lanes) are added by a fixed shuffle tree
     const int cvv = a.CV * VEC;
-    const int lanes_r = kBlock / a.CV;            // >= 1: CV <= kBlock is checked on the host
-    const int cs = tid % a.CV, rl = tid / a.CV;
-    const bool worker = rl < lanes_r;
-    const int chp = cs * VEC;
-    const int q_lanes = min(16, lanes_r);
-    for (int g = g_first; g < pf.B && (int64_t)pf.gptr[g] < r0 + nrows; ++g) {   // workgroup-uniform loop
+    const int groups = kWave / a.CV;              // CV <= 64: checked on the host
+    const int sl = lane / groups, grp = lane - sl * groups;
+    const bool active = sl < a.CV;
+    const int g_first = pf.tile_graph[blk];
+    for (int g = g_first; g < pf.B && (int64_t)pf.gptr[g] < r0 + nrows; ++g) {   // wave-uniform loop
       const int s0 = (int)(max(r0, (int64_t)pf.gptr[g]) - r0), s1 = (int)(min(r0 + nrows, (int64_t)pf.gptr[g + 1]) - r0);
       if (s1 <= s0) continue;                     // an empty graph
-      float acc0[VEC], acc1[VEC];
+      float a0[VEC], a1[VEC];
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc0[v] = acc1[v] = 0.f;
-      if (worker)
-        for (int r = s0 + rl; r < s1; r += lanes_r) {
-          const float w = pf.wts ? pf.wts[r0 + r] : 1.f;
+      for (int v = 0; v < VEC; ++v) a0[v] = a1[v] = 0.f;
+      if (active)
+        for (int r = s0 + grp; r < s1; r += groups) {
+          float xv[VEC];
+          vload<VEC>(s_tile + r * cvv + sl * VEC, xv);
+          const float w = s_wts[r];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float xv = s_tile[r * cvv + chp + v];
-            acc0[v] += xv;
-            acc1[v] = fmaf(w, xv, acc1[v]);
-          }
+          for (int v = 0; v < VEC; ++v) { a0[v] += xv[v]; a1[v] = fmaf(w, xv[v], a1[v]); }
         }
+      for (int off = 32; off >= 1; off >>= 1) {
+        if (off >= groups) continue;              // wave-uniform
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) { s_pred[tid][v] = acc0[v]; s_pred[tid][VEC + v] = acc1[v]; }
-      __syncthreads();
-      const bool second = worker && rl < q_lanes;
-      float t2[2 * VEC];
-#pragma unroll
-      for (int v = 0; v < 2 * VEC; ++v) t2[v] = 0.f;
-      if (second)
-        for (int k = rl; k < lanes_r; k += q_lanes)
-#pragma unroll
-          for (int v = 0; v < 2 * VEC; ++v) t2[v] += s_pred[k * a.CV + cs][v];
-      __syncthreads();                            // every read of the first level is done
-      if (second)
-#pragma unroll
-        for (int v = 0; v < 2 * VEC; ++v) s_pred[tid][v] = t2[v];
-      __syncthreads();
-      if (rl == 0) {
-        float t[2 * VEC];
-#pragma unroll
-        for (int v = 0; v < 2 * VEC; ++v) t[v] = 0.f;
-        for (int k = 0; k < q_lanes; ++k)
-#pragma unroll
-          for (int v = 0; v < 2 * VEC; ++v) t[v] += s_pred[k * a.CV + cs][v];
-        float* dst = pf.partial + (((int64_t)blk + g) * 2) * cvv + chp;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) { dst[v] = t[v]; dst[cvv + v] = t[VEC + v]; }
+        for (int v = 0; v < VEC; ++v) {
+          const float o0 = __shfl_down(a0[v], off), o1 = __shfl_down(a1[v], off);
+          if (grp + off < groups) { a0[v] += o0; a1[v] += o1; }
+        }
       }
-      __syncthreads();                            // s_pred is reused by the next graph of the tile
+      if (active && grp == 0) {
+        float* dst = pf.partial + (((int64_t)blk + g) * 2) * cvv + sl * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { dst[v] = a0[v]; dst[cvv + v] = a1[v]; }
+      }
     }
   }
 }
@@ -537,10 +554,12 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
     grid = dim3((unsigned)eblocks);
   }
   const bool epi = !IS_MAX && (a.z || a.bias || a.act || a.drop_p > 0.f);
-  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr};
+  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr, nullptr};
   if (pool) {     // the pooled form exists for the shape the models launch it with: ELL side table, 16-byte rows, an epilogue
-    if (IS_MAX || !a.ell || vec != 4 || ipt != 2) return MLQEM_ERR_UNSUPPORTED;
+    if (IS_MAX || !a.ell || vec != 4 || ipt != 2 || a.CV * 4 > kWave) return MLQEM_ERR_UNSUPPORTED;      // C <= 64: one wave holds a row of the tile
     if (rows_per_tile) *rows_per_tile = a.R;
+    hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)ceil_div((int64_t)grid.x, kBlock)), dim3(kBlock), 0, stream, pool->gptr, pool->B,
+                       a.R, (int64_t)grid.x, const_cast<int32_t*>(pool->tile_graph));
     if constexpr (!IS_MAX) {
       static const int pool_waves = getenv("MLQEM_AGG_POOL_WAVES") ? atoi(getenv("MLQEM_AGG_POOL_WAVES")) : 7;
       if (pool_waves >= 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<4, false, 2, true, 7, true>), grid, block, 0, stream, a, *pool);
@@ -621,9 +640,9 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
                                const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
-                               float* partial, int* rows_per_tile, hipStream_t stream) {
+                               float* partial, int32_t* tile_graph, int* rows_per_tile, hipStream_t stream) {
   AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, seed_counter, out, ldo, N, C, 0, 0};
-  const PoolFuse pf{pool_weights, graph_ptr, B, partial};
+  const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph};
   return launch_aggregate<false>(a, stream, &pf, rows_per_tile);
 }
 

@@ -291,14 +291,14 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
                                const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
-                               float* partial, int* rows_per_tile, hipStream_t stream);
+                               float* partial, int32_t* tile_graph, int* rows_per_tile, hipStream_t stream);
 int aggregate_pool_rows_per_tile(int C);
 }  // namespace mlqem
 
 extern "C" size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C) {
   if (N < 0 || B < 0 || C <= 0) return 0;
   const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), aggregate_pool_rows_per_tile(C));
-  return (size_t)(tiles + B) * 2 * ((C + 3) / 4 * 4) * sizeof(float);
+  return (size_t)(tiles + B) * 2 * ((C + 3) / 4 * 4) * sizeof(float) + (size_t)tiles * sizeof(int32_t);     // partial sums | tile -> graph
 }
 
 // mlqem_csr_aggregate_f32 and mlqem_segment_pool_f32 of its output in one pass over the rows: the aggregation's workgroups
@@ -320,9 +320,11 @@ extern "C" int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const i
   hipStream_t s = as_stream(stream);
   int rows = 0;
   if (N > 0) {
+    const int64_t tiles = ceil_div(N, aggregate_pool_rows_per_tile(C));
+    float* partial = static_cast<float*>(workspace);
+    int32_t* tile_graph = reinterpret_cast<int32_t*>(partial + (tiles + B) * 2 * ((C + 3) / 4 * 4));
     const int rc = launch_aggregate_with_pool(x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed,
-                                              seed_counter, out, ldo, N, C, pool_weights, graph_ptr, (int)B, static_cast<float*>(workspace),
-                                              &rows, s);
+                                              seed_counter, out, ldo, N, C, pool_weights, graph_ptr, (int)B, partial, tile_graph, &rows, s);
     if (rc != MLQEM_OK) return rc;
     if (rows != aggregate_pool_rows_per_tile(C)) return MLQEM_ERR_LAUNCH;      // the workspace was sized for another tiling
   } else {
