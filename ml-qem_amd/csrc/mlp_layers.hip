@@ -480,6 +480,157 @@ __global__ __launch_bounds__(kLayerThreads) void layer_wgrad_kernel(const WgradL
       for (int r = 0; r < 4; ++r) dst[((t * 4 + s4) * 4 + r) * kWave] = acc[t][s4][r];
 }
 
+// The same product for bf16 [N,128] inputs with the operands brought in by LDS DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes
+// from per-lane global addresses into one contiguous KB of LDS, no registers in between).  The register-prefetch form above
+// holds ONE 32-row slab in flight per workgroup at one workgroup per CU (272 registers): 16 KB per CU against the ~40 KB the
+// memory system needs in flight per CU, 2.8 TB/s.  Here a workgroup keeps kDmaSlabs - 1 slabs (16 KB each: dY 8 KB | X 8 KB)
+// on their way in LDS, registers hold only the slab being multiplied (two workgroups per CU), and every wave reads the dY
+// slab the workgroup fetched ONCE instead of fetching it itself: 47 -> 35 us per launch (134 MB: 3.8 TB/s).
+//   DMA instruction i of a slab, issued by wave i / 2: lane (lq, lr) fetches bytes [16 lr, 16 lr + 16) of row 8 lq + i -> the
+//   consumer's load j = i of lane (lq, lr) is the linear read `region j + 16 lane`: no bank conflicts, no index arithmetic.
+//   One s_barrier per slab: a wave waits for its own DMAs of slab t (vmcnt), the barrier makes everybody's visible, and having
+//   passed it means everybody has finished READING slab t - 1, whose buffer the next DMA may overwrite.  The barrier is the
+//   raw instruction: __syncthreads() carries a release fence that waits for ALL outstanding DMAs (vmcnt(0)) -- the prefetch.
+constexpr int kDmaSlabBytes = 16384;
+
+template <int kDmaSlabs>
+__global__ __launch_bounds__(kLayerThreads, 2) void layer_wgrad_lds_kernel(const WgradLayerArgs a, int cpw) {
+  extern __shared__ __attribute__((aligned(16))) char s_dma[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int col0 = 4 * (cpw * wid + lr);
+  const bool xlane = lr < cpw && col0 <= a.K;
+  const int colc = min(col0, kLW - 4);
+  const bool x_raw[4] = {col0 + 0 < a.K, col0 + 1 < a.K, col0 + 2 < a.K, col0 + 3 < a.K};
+  const float x_fill[4] = {xlane && col0 + 0 == a.K ? 1.f : 0.f, xlane && col0 + 1 == a.K ? 1.f : 0.f,
+                           xlane && col0 + 2 == a.K ? 1.f : 0.f, xlane && col0 + 3 == a.K ? 1.f : 0.f};
+  unsigned x_keep[4], x_or[4];                   // per column: keep the loaded pair of bf16 values, or replace it by 1.0 | 1.0 / by zeros
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    x_keep[c] = x_raw[c] ? 0xFFFFFFFFu : 0u;
+    x_or[c] = x_fill[c] != 0.f ? 0x3F803F80u : 0u;
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[t][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t n_slabs = a.N / 32;
+  const unsigned short* xb = static_cast<const unsigned short*>(a.x);
+  using lds_ptr = __attribute__((address_space(3))) void*;
+  auto issue = [&](int64_t s, int buf) {          // this wave's four DMA instructions of slab s (clamped: the counts stay uniform)
+    const int64_t r0 = 32 * min(s, n_slabs - 1);
+    char* base = s_dma + buf * kDmaSlabBytes;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = 2 * wid + q;
+      const int64_t off = (r0 + 8 * lq + i) * kLW + 8 * lr;
+      __builtin_amdgcn_global_load_lds(a.dy + off, (lds_ptr)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(xb + off, (lds_ptr)(base + 8192 + i * 1024), 16, 0, 0);
+    }
+  };
+  // this lane's 8 bytes of an X row inside the region the DMA wrote: chunk colc / 8 of row-lane lq, half (colc % 8) / 4
+  const int x_off = 8192 + (lq * 16 + (colc >> 3)) * 16 + (colc & 7) * 2;
+  const int64_t G = gridDim.x;
+  if (n_slabs > 0) {
+#pragma unroll
+    for (int s = 0; s < kDmaSlabs - 1; ++s) issue(blockIdx.x + s * G, s);
+    int t = 0;
+    for (int64_t sl = blockIdx.x; sl < n_slabs; sl += G, ++t) {
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * (kDmaSlabs - 2)));      // vmcnt(4 (kDmaSlabs - 2)): this wave's parts of slab t are in LDS
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue(sl + (kDmaSlabs - 1) * G, (t + kDmaSlabs - 1) % kDmaSlabs);
+      // The slab is read with ds_read instructions the compiler does not see as LDS loads: for a load it sees, its wait-count
+      // pass puts s_waitcnt vmcnt(0) in front (any LDS load may alias any pending LDS DMA), i.e. it waits for the slabs that
+      // were only just requested -- the whole prefetch.
+      const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_dma) + (t % kDmaSlabs) * kDmaSlabBytes;
+      const unsigned ad_d = lds0 + lane * 16, ad_x = lds0 + x_off;
+      u32x4 dv[8];
+      uint2 xv[8];
+#define MLQEM_DS_READ(j)                                                                                         \
+      asm volatile("ds_read_b128 %0, %2 offset:" #j "*1024\n\tds_read_b64 %1, %3 offset:" #j "*1024"               \
+                   : "=&v"(dv[j]), "=&v"(xv[j]) : "v"(ad_d), "v"(ad_x));
+      MLQEM_DS_READ(0) MLQEM_DS_READ(1) MLQEM_DS_READ(2) MLQEM_DS_READ(3)
+      MLQEM_DS_READ(4) MLQEM_DS_READ(5) MLQEM_DS_READ(6) MLQEM_DS_READ(7)
+#undef MLQEM_DS_READ
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // B fragments: column c of this lane's four, rows 8 lq .. 8 lq + 7 -- the 16-bit field c of eight registers, gathered two
+      // rows at a time by v_perm, then (raw & keep) | fill: the ones column behind the last input (it makes the bias gradient)
+      // and the zero columns beyond it cost one v_and_or each instead of a round trip through fp32.
+      bf16x8 bx[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned hi = c < 2 ? xv[2 * d + 1].x : xv[2 * d + 1].y, lo = c < 2 ? xv[2 * d].x : xv[2 * d].y;
+          const unsigned raw = __builtin_amdgcn_perm(hi, lo, (c & 1) ? 0x07060302u : 0x05040100u);
+          w[d] = (raw & x_keep[c]) | x_or[c];
+        }
+        const u32x4 v = {w[0], w[1], w[2], w[3]};
+        bx[c] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int c = tt >> 1;
+        unsigned ad[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          ad[d] = (tt & 1) ? __builtin_amdgcn_perm(vget(dv[2 * d + 1], c), vget(dv[2 * d], c), 0x07060302u)
+                           : __builtin_amdgcn_perm(vget(dv[2 * d + 1], c), vget(dv[2 * d], c), 0x05040100u);
+        const u32x4 av = {ad[0], ad[1], ad[2], ad[3]};
+        const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc[tt][s4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bx[s4], acc[tt][s4], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the clamped DMAs of the last iterations land before the LDS is given back
+  }
+  if (blockIdx.x == 0 && (a.N & 31)) {              // the ragged tail: straight from memory, rows beyond N contribute nothing
+    u32x4 dv[8];
+    float xf[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t row = 32 * n_slabs + 8 * lq + j;
+      const int64_t rc = min(row, a.N - 1);
+      const uint2 xq = *reinterpret_cast<const uint2*>(xb + rc * kLW + colc);
+      dv[j] = *reinterpret_cast<const u32x4*>(a.dy + rc * kLW + 8 * lr);
+      if (row >= a.N) dv[j] = u32x4{0u, 0u, 0u, 0u};
+      const float v[4] = {blo(xq.x), bhi(xq.x), blo(xq.y), bhi(xq.y)};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xf[j][c] = x_raw[c] ? v[c] : x_fill[c];
+    }
+    bf16x8 bx[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 v = {lpack(xf[0][c], xf[1][c]), lpack(xf[2][c], xf[3][c]), lpack(xf[4][c], xf[5][c]), lpack(xf[6][c], xf[7][c])};
+      bx[c] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const int c = tt >> 1;
+      unsigned ad[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        ad[d] = (tt & 1) ? __builtin_amdgcn_perm(vget(dv[2 * d + 1], c), vget(dv[2 * d], c), 0x07060302u)
+                         : __builtin_amdgcn_perm(vget(dv[2 * d + 1], c), vget(dv[2 * d], c), 0x05040100u);
+      const u32x4 av = {ad[0], ad[1], ad[2], ad[3]};
+      const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[tt][s4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bx[s4], acc[tt][s4], 0, 0, 0);
+    }
+  }
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kLayerW1Floats + (wid * 32 * 4) * kWave + lane;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[((t * 4 + s4) * 4 + r) * kWave] = acc[t][s4][r];
+}
+
 constexpr int kLayerReduceSlices = 16;      // as mlp_head.hip's second stage: 16 slices of the G range per element
 __global__ __launch_bounds__(kLayerReduceSlices * kWave) void layer_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int K, int U, int cpw,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
@@ -745,7 +896,21 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
   if (N > 0) {
     static const int r0 = layer_resident(layer_wgrad_kernel<false>, kLayerThreads, 0), r1 = layer_resident(layer_wgrad_kernel<true>, kLayerThreads, 0);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(x_is_bf16 ? r1 : r0, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
-    if (x_is_bf16) hipLaunchKernelGGL(layer_wgrad_kernel<true>, dim3(G), dim3(kLayerThreads), 0, s, a, cpw);
+    static const int lds_form = getenv("MLQEM_LAYER_WGRAD_LDS") ? atoi(getenv("MLQEM_LAYER_WGRAD_LDS")) : 1;
+    if (x_is_bf16 && lds_form) {
+      auto go = [&](auto kernel, int slabs) {
+        const size_t lds = (size_t)slabs * kDmaSlabBytes;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        const int rl = layer_resident(kernel, kLayerThreads, lds);
+        G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(rl, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
+        hipLaunchKernelGGL(kernel, dim3(G), dim3(kLayerThreads), lds, s, a, cpw);
+        return true;
+      };
+      // depth 2, 3, 4 and 5 measure the same (34-35 us at 262 144 rows): with the operands in LDS the launch is bound by its
+      // instruction stream (32 MFMAs + ~100 vector instructions per 32 rows and wave: the 8 x 8 transposes of the 16-bit operands
+      // by v_perm), not by latency any more; ds_read_b64_tr_b16 on a swizzled image would remove the transposes
+      if (!go(layer_wgrad_lds_kernel<4>, 4)) return MLQEM_ERR_LAUNCH;
+    } else if (x_is_bf16) hipLaunchKernelGGL(layer_wgrad_kernel<true>, dim3(G), dim3(kLayerThreads), 0, s, a, cpw);
     else hipLaunchKernelGGL(layer_wgrad_kernel<false>, dim3(G), dim3(kLayerThreads), 0, s, a, cpw);
   }
   hipLaunchKernelGGL(layer_wgrad_reduce_kernel, dim3((unsigned)ceil_div(kLayerW1Floats, kWave)), dim3(kLayerReduceSlices * kWave), 0, s, a.partial, G, K, U, cpw, gw, gb);
