@@ -25,6 +25,7 @@ namespace mlqem {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLW = MLQEM_MLP1_HIDDEN_PAD;      // columns of every bf16 activation matrix
@@ -631,6 +632,164 @@ __global__ __launch_bounds__(kLayerThreads, 2) void layer_wgrad_lds_kernel(const
       for (int r = 0; r < 4; ++r) dst[((t * 4 + s4) * 4 + r) * kWave] = acc[t][s4][r];
 }
 
+// ---- the bf16 x bf16 weight gradient without a single transpose instruction: ds_read_b64_tr_b16 ------------------------------
+// Both MFMA operands of gW = dY^T X want, per lane, eight consecutive ROWS of one column -- the operands are row-major, so the
+// kernels above gather them with v_perm (48 per 32 rows and wave: the launch was bound by that instruction stream, not by
+// memory).  gfx950's transposing LDS read does the gather in the LDS crossbar: per 16-lane group it reads a 4-row x 16-column
+// block of 16-bit elements and hands lane i column i.  The slab image in LDS is what the DMA writes (lane-linear: region i = rows
+// {8 lq + i}, 256 B per row), with the 16-byte chunks of row r stored at position chunk ^ 2 g(r), g(r) = (r & 3) | ((r >> 3 & 1) << 2):
+// the eight rows one 32-lane half reads together (4 per 16-lane group) then sit on eight different 32-byte bank ranges and the
+// transposed reads are conflict-free.  Since the image is filled by DMA, the swizzle costs nothing: a lane simply FETCHES the
+// chunk that belongs at its position.
+//   tiles: dY columns 16 t .. 16 t + 15 (t = 0..7, every wave) x X columns 16 u .. 16 u + 15 (u = 2 wave, 2 wave + 1);
+//   D[4 lq + r][lr] = gW[16 t + 4 lq + r][16 u + lr].  The bias gradient is two more MFMAs per wave against a constant operand
+//   that is 1.0 in column 0: D[.][0] = sum over the rows of dY (tiles t = 2 wave, 2 wave + 1).  X needs no fix-up: the pad
+//   columns of a bf16 activation are zeros, and whatever they produced would land in columns the second stage drops.
+// Partial layout per workgroup: [wave][18 tiles: (j, u_local) row-major with t = (j + 2 wave) & 7, then the two bias tiles][register][lane].
+constexpr int kTrTiles = 18;
+constexpr int kLayerTrFloats = 4 * kTrTiles * 4 * kWave;
+constexpr int kTrSlabs = 4;                 // LDS ring (16 KB per slab)
+
+#define MLQEM_TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #imm : "=&v"(dst) : "v"(addr))
+
+__global__ __launch_bounds__(kLayerThreads, 2) void layer_wgrad_tr_kernel(const WgradLayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char s_dma[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lq = lane >> 4, q = lr >> 2, p = lr & 3;
+  const int g = q | ((lq & 1) << 2);              // swizzle key of the rows this lane's reads address (8 lq + q and 8 lq + 4 + q)
+  f32x4 acc[8][2], accb[2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  accb[0] = accb[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned one2 = lr == 0 ? 0x3F803F80u : 0u;     // the constant B operand of the bias tiles: 1.0 in column 0
+  const bf16x4 b_ones = __builtin_bit_cast(bf16x4, (uint2{one2, one2}));
+  const int64_t n_slabs = a.N / 32;
+  const unsigned short* xb = static_cast<const unsigned short*>(a.x);
+  using lds_ptr = __attribute__((address_space(3))) void*;
+  auto issue = [&](int64_t s, int buf) {          // this wave's four DMA instructions of slab s (clamped: the counts stay uniform)
+    const int64_t r0 = 32 * min(s, n_slabs - 1);
+    char* base = s_dma + buf * kDmaSlabBytes;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = 2 * wid + k;                  // region i: rows 8 lq + i; this lane fills position lr with chunk lr ^ 2 g(row)
+      const int gi = (i & 3) | ((lq & 1) << 2);
+      const int64_t off = (r0 + 8 * lq + i) * kLW + 8 * (lr ^ (2 * gi));
+      __builtin_amdgcn_global_load_lds(a.dy + off, (lds_ptr)(base + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(xb + off, (lds_ptr)(base + 8192 + i * 1024), 16, 0, 0);
+    }
+  };
+  // byte addresses of this lane's transposed reads inside a slab (second half of the rows: + 4096).  dY tiles in the order
+  // j -> t = (j + 2 wave) & 7: every wave reads all eight, starting with the two whose column sums (the bias gradient) are its
+  // own -- the bias MFMAs then sit at fixed positions of the instruction stream, no branch, no register indexing.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_dma);
+  const unsigned row_off = q * 1024 + lq * 256 + 8 * p;
+  unsigned ad_a[8], ad_b[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ad_a[j] = lds0 + row_off + 32 * (((j + 2 * wid) & 7) ^ g);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) ad_b[u] = lds0 + 8192 + row_off + 32 * ((2 * wid + u) ^ g);
+  // One slab out of the LDS buffer at byte offset `off`.  A transposed read returns four rows of a column = exactly one operand
+  // of the k = 16 MFMA, so rows 8 lq .. 8 lq + 3 and 8 lq + 4 .. 8 lq + 7 go into two v_mfma_f32_16x16x16_bf16 (the k index is
+  // only a label A and B share) and no register is ever copied or repacked.
+  auto consume = [&](unsigned off) {
+    bf16x4 al[8], ah[8], bl[2], bh[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const unsigned ad = ad_b[u] + off; MLQEM_TR_READ(bl[u], ad, 0); MLQEM_TR_READ(bh[u], ad, 4096); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const unsigned ad = ad_a[j] + off; MLQEM_TR_READ(al[j], ad, 0); MLQEM_TR_READ(ah[j], ad, 4096); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        acc[j][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[j], bl[u], acc[j][u], 0, 0, 0);
+        acc[j][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[j], bh[u], acc[j][u], 0, 0, 0);
+      }
+      if (j < 2) {
+        accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[j], b_ones, accb[j], 0, 0, 0);
+        accb[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[j], b_ones, accb[j], 0, 0, 0);
+      }
+    }
+  };
+  const int64_t G = gridDim.x;
+  if (n_slabs > 0) {
+#pragma unroll
+    for (int s = 0; s < kTrSlabs - 1; ++s) issue(blockIdx.x + s * G, s);
+    int t = 0;
+    for (int64_t sl = blockIdx.x; sl < n_slabs; sl += G, ++t) {
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * (kTrSlabs - 2)));       // vmcnt: this wave's parts of slab t are in LDS
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue(sl + (kTrSlabs - 1) * G, (t + kTrSlabs - 1) % kTrSlabs);
+      consume((unsigned)(t % kTrSlabs) * kDmaSlabBytes);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): the clamped DMAs of the last iterations land before the LDS is given back
+  }
+  if (blockIdx.x == 0 && (a.N & 31)) {              // the ragged tail: its rows go through the same image (rows beyond N as zeros)
+    __builtin_amdgcn_s_barrier();                   // every wave is done with the ring
+    for (int k = threadIdx.x; k < 2 * 32 * 16; k += kLayerThreads) {
+      const int which = k >> 9, row = (k >> 4) & 31, pos = k & 15;
+      const int gr = (row & 3) | (((row >> 3) & 1) << 2);
+      const int64_t r = 32 * n_slabs + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (r < a.N) v = *reinterpret_cast<const u32x4*>((which ? xb : a.dy) + r * kLW + 8 * (pos ^ (2 * gr)));
+      *reinterpret_cast<u32x4*>(s_dma + which * 8192 + (row & 7) * 1024 + ((row >> 3) * 16 + pos) * 16) = v;
+    }
+    __syncthreads();
+    consume(0u);
+  }
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kLayerTrFloats + (wid * kTrTiles * 4) * kWave + lane;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[((j * 2 + u) * 4 + r) * kWave] = acc[j][u][r];
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[((16 + tb) * 4 + r) * kWave] = accb[tb][r];
+}
+
+// second stage of layer_wgrad_tr_kernel: as layer_wgrad_reduce_kernel, decoding the tile layout above
+__global__ __launch_bounds__(16 * kWave) void layer_wgrad_tr_reduce_kernel(const float* __restrict__ partial, int G, int K, int U,
+                                                                          float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float s[16][kWave];
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * kWave + el;
+  const int lane = e & 63, r = (e >> 6) & 3, tile = (e >> 8) % kTrTiles, wid = (e >> 8) / kTrTiles;
+  const int lr = lane & 15, lq = lane >> 4;
+  int o, c;
+  bool live = e < kLayerTrFloats;
+  // tile j of wave w holds dY tile t = (j + 2 w) & 7 (the wave's reading order); the bias tiles are j = 0, 1
+  if (tile < 16) { o = 16 * (((tile >> 1) + 2 * wid) & 7) + 4 * lq + r; c = 16 * (2 * wid + (tile & 1)) + lr; live = live && o < U && c < K; }
+  else { o = 16 * ((tile - 16 + 2 * wid) & 7) + 4 * lq + r; c = K; live = live && lr == 0 && o < U; }
+  float v = 0.f;
+  if (live) {
+    const int per = (G + 15) / 16;
+    const int g1 = min(G, (sl + 1) * per);
+    int g = sl * per;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    for (; g + 3 < g1; g += 4) {
+      v += partial[(int64_t)g * kLayerTrFloats + e];
+      v1 += partial[(int64_t)(g + 1) * kLayerTrFloats + e];
+      v2 += partial[(int64_t)(g + 2) * kLayerTrFloats + e];
+      v3 += partial[(int64_t)(g + 3) * kLayerTrFloats + e];
+    }
+    for (; g < g1; ++g) v += partial[(int64_t)g * kLayerTrFloats + e];
+    v = (v + v1) + (v2 + v3);
+  }
+  s[sl][el] = v;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tot += s[k][el];
+  if (c < K) gw[(int64_t)o * K + c] = tot;
+  else if (gb) gb[o] = tot;
+}
+
 constexpr int kLayerReduceSlices = 16;      // as mlp_head.hip's second stage: 16 slices of the G range per element
 __global__ __launch_bounds__(kLayerReduceSlices * kWave) void layer_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int K, int U, int cpw,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
@@ -896,7 +1055,18 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
   if (N > 0) {
     static const int r0 = layer_resident(layer_wgrad_kernel<false>, kLayerThreads, 0), r1 = layer_resident(layer_wgrad_kernel<true>, kLayerThreads, 0);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(x_is_bf16 ? r1 : r0, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
-    static const int lds_form = getenv("MLQEM_LAYER_WGRAD_LDS") ? atoi(getenv("MLQEM_LAYER_WGRAD_LDS")) : 1;
+    static const int lds_form = getenv("MLQEM_LAYER_WGRAD_LDS") ? atoi(getenv("MLQEM_LAYER_WGRAD_LDS")) : 2;    // 0: register prefetch, 1: LDS DMA + v_perm, 2: LDS DMA + transposing reads
+    if (x_is_bf16 && lds_form == 2) {              // the transposing-read form (default): see layer_wgrad_tr_kernel
+      const size_t lds = (size_t)kTrSlabs * kDmaSlabBytes;
+      static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(layer_wgrad_tr_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
+      if (!once) return MLQEM_ERR_LAUNCH;
+      static const int rl = layer_resident(layer_wgrad_tr_kernel, kLayerThreads, lds);
+      G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(rl, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
+      hipLaunchKernelGGL(layer_wgrad_tr_kernel, dim3(G), dim3(kLayerThreads), lds, s, a);
+      hipLaunchKernelGGL(layer_wgrad_tr_reduce_kernel, dim3((unsigned)ceil_div(kLayerTrFloats, kWave)), dim3(16 * kWave), 0, s, a.partial, G, K, U, gw, gb);
+      return launch_status();
+    }
     if (x_is_bf16 && lds_form) {
       auto go = [&](auto kernel, int slabs) {
         const size_t lds = (size_t)slabs * kDmaSlabBytes;
