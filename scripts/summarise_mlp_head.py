@@ -36,7 +36,7 @@ def model(kind, mode, name):
         return x32 + A16, 2 * N * F * h, "bf16"
     if "layer_fwd_kernel<4, true>" in name or "layer_fwd_kernel<2, true>" in name:     # bf16 in, bf16 out (fc2/fc3, data gradients)
         return 2 * A16, 2 * N * h * h, "bf16"
-    if "layer_wgrad_kernel<true>" in name:
+    if "layer_wgrad_kernel<true>" in name or "layer_wgrad_tr_kernel" in name or "layer_wgrad_lds_kernel" in name:
         return 2 * A16, 2 * N * h * (h + 1), "bf16"
     if "layer_wgrad_kernel<false>" in name:
         return x32 + A16, 2 * N * h * (F + 1), "bf16"
