@@ -851,18 +851,18 @@ class _FamilyAGraph(Function):
         # (mlqem_csr_aggregate_pool_f32: the activation is not read a second time)
         pg = dict(graph_ptr=gptr, num_graphs=nb, weights=tg, mean=False, wmean=True)
         L["g2"] = mk(9, T); hg = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1, pool=pg)
-        wg = pg["out_wmean"]
+        _, wg = ops.pooled_means(hg, pg)
         with torch.cuda.stream(side[0]):
             # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
             pc = dict(graph_ptr=gptr, num_graphs=nb, weights=tc, mean=True, wmean=True)
             L["c1"] = mk(11, Fa); hc = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2,
                                                           pre=pre_c, pool=pc)
-            mc, wc = pc["out_mean"], pc["out_wmean"]
+            mc, wc = ops.pooled_means(hc, pc)
         with torch.cuda.stream(side[1]):
             # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
             ps = dict(graph_ptr=gptr, num_graphs=nb, weights=ts, mean=True, wmean=True)
             L["s1"] = mk(10, Fa); hs = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None, pre=pre_s, pool=ps)
-            ms, ws = ps["out_mean"], ps["out_wmean"]
+            ms, ws = ops.pooled_means(hs, ps)
         for st, ts_ in zip(side, ((mc, wc), (ms, ws))):
             main.wait_stream(st)
             for t in ts_:

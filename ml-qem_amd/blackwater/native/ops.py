@@ -133,7 +133,8 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
 
     ``pool`` = a dict with ``graph_ptr``, ``num_graphs``, optional ``weights`` and the flags ``mean`` / ``wmean``: the pooled
     means of ``out`` come from the same launch (mlqem_csr_aggregate_pool_f32) and are left in ``pool["out_mean"]`` /
-    ``pool["out_wmean"]`` ([B, c] tensors, None for a mean that was not asked for); shapes the fused kernel does not serve fall back to ``segment_pool`` on ``out``."""
+    ``pool["out_wmean"]`` ([B, c] tensors, None for a mean that was not asked for).  When the fused form is switched off or
+    does not serve the shape, ``pool`` is left untouched and the caller pools ``out`` itself (``pooled_means``)."""
     n, c = x.shape
     ldx = _mat(x, "x")
     _vec(ptr, "ptr", n + 1, torch.int32)
@@ -177,10 +178,15 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
                 return out
     code = lib.mlqem_csr_aggregate_f32(*common, _stream())
     _lib.check(code, "mlqem_csr_aggregate_f32")
-    if pool is not None:
-        pool["out_mean"], pool["out_wmean"] = segment_pool(out, pool["graph_ptr"], int(pool["num_graphs"]), weights=pool.get("weights"),
-                                                   mean=bool(pool.get("mean", True)), wmean=bool(pool.get("wmean", True)))
     return out
+
+
+def pooled_means(out, pool):
+    """(mean, wmean) of a ``csr_aggregate(..., pool=pool)`` call: what the launch left in ``pool``, or ``segment_pool`` of ``out``."""
+    if "out_wmean" in pool or "out_mean" in pool:
+        return pool.get("out_mean"), pool.get("out_wmean")
+    return segment_pool(out, pool["graph_ptr"], int(pool["num_graphs"]), weights=pool.get("weights"), mean=bool(pool.get("mean", True)),
+                        wmean=bool(pool.get("wmean", True)))
 
 
 # MLQEM_POOL_FUSED=1: the pooled means from the aggregation launch itself (mlqem_csr_aggregate_pool_f32).  Off by default: on the

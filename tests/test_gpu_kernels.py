@@ -726,7 +726,9 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
     ops._POOL_FUSED = False
     try:
         two = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=True, wmean=True)
-        ops.csr_aggregate(x, in_ptr, in_src, pool=two, **kw)
+        o2 = ops.csr_aggregate(x, in_ptr, in_src, pool=two, **kw)
+        assert "out_mean" not in two                      # switched off: the caller pools
+        two["out_mean"], two["out_wmean"] = ops.pooled_means(o2, two)
     finally:
         ops._POOL_FUSED = True
     one = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=True, wmean=True)

@@ -125,8 +125,11 @@ def test_dropout_masks_are_recomputed_identically_in_the_backward():
 
 
 @pytest.mark.parametrize("n,k,u,bf16_x", [(1, 170, 125, False), (33, 170, 125, False), (4099, 58, 64, False), (1000, 125, 125, True),
-                                           (4099, 128, 41, True), (517, 41, 128, True)])
+                                           (4099, 128, 41, True), (517, 41, 128, True), (7, 125, 125, True), (64, 128, 128, True),
+                                           (131104, 125, 125, True), (262144, 64, 125, True)])
 def test_layer_weight_gradient(n, k, u, bf16_x):
+    """bf16 inputs go through the LDS-DMA / transposing-read kernel: row counts below one 32-row slab (the tail path alone), exact
+    multiples of it (no tail), and enough slabs for the LDS ring to wrap many times."""
     from blackwater.native import ops
 
     g = torch.Generator().manual_seed(n + 7 * k + u)
