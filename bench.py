@@ -36,7 +36,7 @@ import torch
 DEFAULT_BATCH = 1024
 CORPUS_BATCHES = 8          # corpus = CORPUS_BATCHES x batch x world circuits
 STEPS_LIST = list(range(1, 11))
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_aggregate_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_aggregate_pmc.json")
 
 
 _T0 = time.perf_counter()

@@ -18,7 +18,7 @@ timeout 150 rocprofv3 --kernel-trace --output-format csv -d /tmp/pmc_trace -- py
 python3 - "$OUT/aggregate_pmc.json" $REPS <<'PY'
 import csv, glob, json, sys
 out, reps = sys.argv[1], int(sys.argv[2])
-KERNEL = "csr_aggregate_ell_kernel<4, false, 2, false, 8>"
+KERNEL = "csr_aggregate_ell_kernel<4, false, 2, false, 8"     # prefix: the template grew a trailing parameter
 vals = {}
 for path in glob.glob("/tmp/pmc_*/**/*counter_collection.csv", recursive=True):
     with open(path) as fh:
@@ -44,7 +44,7 @@ rec = {
             "forward aggregation (C = 10 in 12-float rows, ELL-assisted kernel, streaming stores) on the benchmark's "
             "representative batch (bench.fixed_ids); plus one --kernel-trace pass of the same command for the duration; "
             "regenerate with scripts/make_pmc.sh",
-    "kernel": "void mlqem::csr_aggregate_ell_kernel<4, false, 2, false, 8>(mlqem::AggArgs)",
+    "kernel": "void mlqem::csr_aggregate_ell_kernel<4, false, 2, false, 8, false>(mlqem::AggArgs, mlqem::PoolFuse)",
     "nodes": n, "edges_with_loops": e, "C": c, "launches_averaged": reps,
     "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
     "TCC_EA0_RDREQ_sum": vals.get("TCC_EA0_RDREQ_sum"), "TCC_EA0_RDREQ_32B_sum": vals.get("TCC_EA0_RDREQ_32B_sum"),

@@ -28,7 +28,7 @@ n = bench["roofline"]["nodes"]
 leg = []
 with open(trace) as fh:
     for r in csv.DictReader(fh):
-        if "csr_aggregate_ell_kernel<4, false, 2, false, 8>" in r["Kernel_Name"]:
+        if "csr_aggregate_ell_kernel<4, false, 2, false, 8" in r["Kernel_Name"]:
             leg.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                         int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)))
 leg.sort()
