@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 18 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 19 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -263,17 +263,21 @@ int mlqem_linear_wgrad_parts_f32(const mlqem_col_parts* gy, const float* x, int6
  * accumulation on v_mfma_f32_16x16x32_bf16, the stash kept in bf16 (the "bf16 MFMA MLP head" of the mixed-corpus
  * configuration); gb2 is summed from the unrounded gout.  workspace (both calls; 16-byte aligned): mlqem_mlp1_workspace_bytes(I, O2) -- the
  * forward keeps the W1 fragment image its workgroups copy into LDS there, the backward its partial sums; a forward and a
- * backward on one stream may share it. */
+ * backward on one stream may share it.
+ *   The training cell's `loss = MSELoss()(out, y); loss.backward()` (docs/tutorials/__ml_models.py:148-160) folded in: with
+ *   `target` [N, O2] the forward also writes gout = 2 (out - target) / (N O2) -- the gradient the backward call takes -- and
+ *   leaves its per-workgroup sums of (out - target)^2 in the workspace; the NEXT backward call on the same workspace then
+ *   writes *loss_out = mean (out - target)^2 (fixed summation order).  target == NULL / loss_out == NULL: neither. */
 #define MLQEM_MLP1_HIDDEN_PAD 128
 #define MLQEM_MLP1_MAX_OUT 4
 #define MLQEM_MLP1_MAX_IN 175
 size_t mlqem_mlp1_workspace_bytes(int I, int O2);
 int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, const float* b2,
-                       void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2, int bf16, void* workspace,
-                       size_t workspace_bytes, mlqem_stream_t stream);
+                       void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2, int bf16, const float* target,
+                       int64_t ldt, float* gout, int64_t ldg, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t ldx, const void* h_stash, const float* w2,
                         float* gw1, float* gb1, float* gw2, float* gb2, int64_t N, int I, int H, int O2, int bf16,
-                        void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+                        float* loss_out, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * MLP2 / MLP3 with bf16 STORAGE (docs/tutorials/mlp.py:33-108 == blackwater/library/learning/mlp.py: fc -> BatchNorm1d -> ReLU ->

@@ -553,9 +553,11 @@ def _mlp1_x(x):
     return x
 
 
-def mlp1_forward(x, w1, b1, w2, b2, bf16=False, stash=True):
-    """(out [N, O2], stash): out = relu(x w1^T + b1) w2^T + b2 in one launch (mlqem_mlp1_forward); ``stash`` = the hidden
-    activation [N, 128] the backward reads, fp32 or -- ``bf16`` -- bfloat16 (None when ``stash`` is False)."""
+def mlp1_forward(x, w1, b1, w2, b2, bf16=False, stash=True, target=None):
+    """(out [N, O2], stash, padded x[, gout]): out = relu(x w1^T + b1) w2^T + b2 in one launch (mlqem_mlp1_forward); ``stash`` =
+    the hidden activation [N, 128] the backward reads, fp32 or -- ``bf16`` -- bfloat16 (None when ``stash`` is False).  With
+    ``target`` [N, O2] the MSE loss is folded in: a fourth result ``gout`` = 2 (out - target) / numel, and the next
+    ``mlp1_backward(..., want_loss=True)`` on this stream returns the loss."""
     x = _mlp1_x(x)
     n, i = x.shape
     h, o2 = w1.shape[0], w2.shape[0]
@@ -568,15 +570,22 @@ def mlp1_forward(x, w1, b1, w2, b2, bf16=False, stash=True):
     lib = _lib.load()
     need = lib.mlqem_mlp1_workspace_bytes(i, o2)
     ws = _wgrad_workspace(x.device, need)
+    gout, ldt = None, 0
+    if target is not None:
+        if tuple(target.shape) != (n, o2) or target.dtype != torch.float32 or not target.is_cuda or n == 0:
+            raise ValueError("mlp1_forward: target must be a non-empty fp32 cuda tensor of the output's shape")
+        ldt = _mat(target, "target") if n > 1 else o2
+        gout = torch.empty((n, o2), dtype=torch.float32, device=x.device)
     code = lib.mlqem_mlp1_forward(_p(x), ldx, _p(w1), _p(b1), _p(w2), _p(b2), _p(hs), _p(out), o2, n, i, h, o2,
-                                  1 if bf16 else 0, _p(ws), need, _stream())
+                                  1 if bf16 else 0, _p(target), ldt, _p(gout), o2, _p(ws), need, _stream())
     _lib.check(code, "mlqem_mlp1_forward")
-    return out, hs, x
+    return (out, hs, x) if target is None else (out, hs, x, gout)
 
 
-def mlp1_backward(gout, x, hs, w2, i, h, bf16=False):
+def mlp1_backward(gout, x, hs, w2, i, h, bf16=False, dst=None, want_loss=False):
     """(gw1 [H, I], gb1, gw2 [O2, H], gb2) from one pass over x and the stash (mlqem_mlp1_backward); ``x`` as returned by
-    :func:`mlp1_forward` (padded rows)."""
+    :func:`mlp1_forward` (padded rows).  ``dst`` = four contiguous fp32 tensors to write the gradients into (a trainer's flat
+    gradient slots); ``want_loss`` appends the MSE loss of the preceding ``mlp1_forward(..., target=)`` (a 0-dim tensor)."""
     n, o2 = gout.shape
     gout = rowmajor(gout)
     if gout.dtype != torch.float32 or hs.shape != (max(n, 1), MLP1_MAX_HIDDEN) or hs.dtype != (torch.bfloat16 if bf16 else torch.float32):
@@ -584,17 +593,24 @@ def mlp1_backward(gout, x, hs, w2, i, h, bf16=False):
     if tuple(x.shape) != (n, i) or tuple(w2.shape) != (o2, h) or not w2.is_contiguous():
         raise ValueError("mlp1_backward: shape mismatch")
     dev = x.device
-    gw1, gb1 = torch.empty((h, i), dtype=torch.float32, device=dev), torch.empty(h, dtype=torch.float32, device=dev)
-    gw2, gb2 = torch.empty((o2, h), dtype=torch.float32, device=dev), torch.empty(o2, dtype=torch.float32, device=dev)
+    if dst is None:
+        gw1, gb1 = torch.empty((h, i), dtype=torch.float32, device=dev), torch.empty(h, dtype=torch.float32, device=dev)
+        gw2, gb2 = torch.empty((o2, h), dtype=torch.float32, device=dev), torch.empty(o2, dtype=torch.float32, device=dev)
+    else:
+        gw1, gb1, gw2, gb2 = dst
+        for t, shape in ((gw1, (h, i)), (gb1, (h,)), (gw2, (o2, h)), (gb2, (o2,))):
+            if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError("mlp1_backward: dst tensors must be contiguous fp32 cuda tensors of the gradients' shapes")
+    loss = torch.empty((), dtype=torch.float32, device=dev) if want_loss else None
     lib = _lib.load()
     need = lib.mlqem_mlp1_workspace_bytes(i, o2)
     ws = _wgrad_workspace(dev, need)
     ldx = _mat(x, "x") if n > 1 else (i + 3) // 4 * 4
     ldg = int(gout.stride(0)) if n > 1 else o2
     code = lib.mlqem_mlp1_backward(_p(gout), ldg, _p(x), ldx, _p(hs), _p(w2), _p(gw1), _p(gb1), _p(gw2), _p(gb2), n, i, h, o2,
-                                   1 if bf16 else 0, _p(ws), need, _stream())
+                                   1 if bf16 else 0, _p(loss), _p(ws), need, _stream())
     _lib.check(code, "mlqem_mlp1_backward")
-    return gw1, gb1, gw2, gb2
+    return (gw1, gb1, gw2, gb2) if not want_loss else (gw1, gb1, gw2, gb2, loss)
 
 
 # ---- bf16-storage layers of MLP2 / MLP3 (csrc/mlp_layers.hip): every activation is a [N, 128] bfloat16 matrix

@@ -350,10 +350,43 @@ class RowsTrainer(Trainer):
             return (self.x,)
 
     def _step_on(self, batch):
+        if self._mlp1_fused(batch):
+            return self._step_mlp1(batch)
         self.counter.add_(1)
         loss = self._forward_backward(batch)
         if self.distributed:
             self.all_reduce_gradients()
+        self.optimizer.step()
+        return loss
+
+    def _mlp1_fused(self, batch) -> bool:
+        """MLP1 with the MSE loss on one rank: the whole step is five launches with nothing of autograd in between."""
+        from .native import functional as F
+        from .nn.mlp import MLP1
+
+        m = self.model
+        return (type(m) is MLP1 and self._fused_loss and not self.distributed and self.flat_grad is not None
+                and type(self.criterion) is nn.MSELoss and self.criterion.reduction == "mean"
+                and os.environ.get("MLQEM_MLP1_FUSED_STEP", "1") != "0"
+                and torch.is_tensor(batch.x) and batch.y.dim() == 2 and batch.y.dtype == torch.float32 and batch.y.shape[0] == batch.x.shape[0]
+                and batch.x.shape[0] > 0 and F.mlp1_fused_ok(batch.x, m.fc1.weight, m.fc2.weight))
+
+    def _step_mlp1(self, batch):
+        """image -> forward (+ loss sums, + d loss / d out) -> backward -> second stage (gradients straight into the flat buffer's
+        slots, the loss) -> Adam: what ``loss = MSELoss()(model(x), y); loss.backward(); optimizer.step()`` computes for
+        MLP1 (docs/tutorials/__ml_models.py:148-160, mlp.py:18-30), same gradients bit for bit as the autograd path."""
+        from .native import ops
+
+        m = self.model
+        if getattr(self, "_mlp1_slots", None) is None:
+            by_id = {id(p): s for p, s in zip(self._params, self._grad_slots)}
+            self._mlp1_slots = tuple(by_id[id(p)] for p in (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias))
+        bf16 = getattr(m, "mfma", "f32") == "bf16"
+        i, h = m.fc1.weight.shape[1], m.fc1.weight.shape[0]
+        _, hs, xp, gout = ops.mlp1_forward(batch.x, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, bf16=bf16, stash=True, target=batch.y)
+        *_, loss = ops.mlp1_backward(gout, xp, hs, m.fc2.weight, i, h, bf16=bf16, dst=self._mlp1_slots, want_loss=True)
+        for p, slot in zip(self._params, self._grad_slots):
+            p.grad = slot
         self.optimizer.step()
         return loss
 

@@ -41,7 +41,12 @@ struct Mlp1Args {
   const float* gout; int64_t ldg;   // backward: d loss / d out, [N,O2]
   float* partial;               // backward: per-workgroup partial sums (kHeadPartialFloats each)
   const void* image;            // forward: the LDS image built by mlp1_image_kernel
+  // forward with the loss folded in (mlqem_mlp1_forward with a target): gout_w = 2 (out - target) / (N O2) is written beside
+  // out, every workgroup leaves its sum of (out - target)^2 in loss_part[blockIdx.x], workgroup 0 the workgroup count behind them
+  const float* target; int64_t ldt; float* gout_w; int64_t ldgw; float* loss_part;
 };
+
+constexpr int kHeadLossSlots = 1024;      // >= the forward's workgroup count (resident workgroups: at most a few per CU)
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -113,7 +118,8 @@ __device__ __forceinline__ void head_fill_lds(const u32x4* __restrict__ image, u
 // bias + ReLU, the stash, fc2: the lane holds 32 hidden units of row `row` (hv[p][e] = unit 32 p + 8 lq + e).
 template <bool BF16>
 __device__ __forceinline__ void head_epilogue(const Mlp1Args& a, const f32x4 (&acc)[8], const float* s_b1, const float* s_w2,
-                                              const float (&b2r)[kHeadMaxOut], int64_t row, int lq) {
+                                              const float (&b2r)[kHeadMaxOut], int64_t row, int lq, float& lsum,
+                                              const float (&tgt)[kHeadMaxOut]) {
   float hv[4][8];
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
@@ -149,7 +155,31 @@ __device__ __forceinline__ void head_epilogue(const Mlp1Args& a, const f32x4 (&a
       for (int e = 0; e < 8; ++e) s = fmaf(hv[p][e], s_w2[q * kHeadH + 32 * p + 8 * lq + e], s);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (lq == 0 && row_ok) a.out[row * a.ldo + q] = s + b2r[q];
+    if (lq == 0 && row_ok) {
+      const float o = s + b2r[q];
+      a.out[row * a.ldo + q] = o;
+      if (a.target) {               // MSE against the target, and the gradient loss.backward() would hand to this output
+        const float d = o - tgt[q];          // fetched before the tile's MFMAs: a load here would queue behind the stash stores
+        a.gout_w[row * a.ldgw + q] = d * (2.0f / (float)(a.N * a.O2));
+        lsum = fmaf(d, d, lsum);
+      }
+    }
+  }
+}
+
+// end of a forward workgroup: its sum of squared errors (fixed order: lanes by a shuffle tree, waves in order)
+__device__ __forceinline__ void head_loss_partial(const Mlp1Args& a, float lsum, float* s_loss) {
+  if (!a.target) return;            // workgroup-uniform
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) s_loss[wid] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kFwdThreads / kWave; ++w) t += s_loss[w];
+    a.loss_part[blockIdx.x] = t;
+    if (blockIdx.x == 0) a.loss_part[kHeadLossSlots] = (float)gridDim.x;
   }
 }
 
@@ -164,6 +194,8 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_f32_kernel(const Mlp1Arg
   float b2r[kHeadMaxOut];       // a global load in the epilogue would sit behind the stash stores (one in-order vmcnt)
 #pragma unroll
   for (int q = 0; q < kHeadMaxOut; ++q) b2r[q] = q < a.O2 ? a.b2[q] : 0.f;
+  __shared__ float s_loss[kFwdThreads / kWave];
+  float lsum = 0.f;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int64_t n_tiles = ceil_div(a.N, 16);
@@ -196,6 +228,10 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_f32_kernel(const Mlp1Arg
   fix_tile(xc);
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
     load_tile(t + n_waves, xn);                // the next tile's operands are in flight while this one multiplies
+    float tgt[kHeadMaxOut];                      // this tile's targets (lanes lq == 0 own a row's outputs), fetched with the prefetch
+#pragma unroll
+    for (int q = 0; q < kHeadMaxOut; ++q)
+      tgt[q] = (a.target && lq == 0 && q < a.O2 && t * 16 + lr < a.N) ? a.target[(t * 16 + lr) * a.ldt + q] : 0.f;
     __builtin_amdgcn_sched_barrier(0);         // ... which they are only if the loads are ISSUED here: left alone, the compiler
                                                // loads xn into xc's registers after xc's last use (the copy below coalesces)
     f32x4 acc[8];
@@ -221,8 +257,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_f32_kernel(const Mlp1Arg
     for (int g = 0; g < G; ++g) xc[g] = xn[g];
     fix_tile(xc);
     __builtin_amdgcn_sched_barrier(0);
-    head_epilogue<false>(a, acc, s_b1, s_w2, b2r, t * 16 + lr, lq);
+    head_epilogue<false>(a, acc, s_b1, s_w2, b2r, t * 16 + lr, lq, lsum, tgt);
   }
+  head_loss_partial(a, lsum, s_loss);
 }
 
 // bf16 matrix cores: G2 = 32-column groups; lane (row lr, quarter lq) loads x[row][32 g + 8 lq .. + 7] (two float4) and
@@ -238,6 +275,8 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_bf16_kernel(const Mlp1Ar
   float b2r[kHeadMaxOut];       // a global load in the epilogue would sit behind the stash stores (one in-order vmcnt)
 #pragma unroll
   for (int q = 0; q < kHeadMaxOut; ++q) b2r[q] = q < a.O2 ? a.b2[q] : 0.f;
+  __shared__ float s_loss[kFwdThreads / kWave];
+  float lsum = 0.f;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int64_t n_tiles = ceil_div(a.N, 16);
@@ -273,6 +312,10 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_bf16_kernel(const Mlp1Ar
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
     float4 xn[2 * G2];
     load_tile(t + n_waves, xn);
+    float tgt[kHeadMaxOut];                      // this tile's targets (lanes lq == 0 own a row's outputs), fetched with the prefetch
+#pragma unroll
+    for (int q = 0; q < kHeadMaxOut; ++q)
+      tgt[q] = (a.target && lq == 0 && q < a.O2 && t * 16 + lr < a.N) ? a.target[(t * 16 + lr) * a.ldt + q] : 0.f;
     __builtin_amdgcn_sched_barrier(0);         // issue the prefetch HERE (see mlp1_fwd_f32_kernel)
     f32x4 acc[8];
 #pragma unroll
@@ -290,8 +333,9 @@ __global__ __launch_bounds__(kFwdThreads) void mlp1_fwd_bf16_kernel(const Mlp1Ar
 #pragma unroll
     for (int g = 0; g < G2; ++g) xc[g] = to_frag(xn, g);
     __builtin_amdgcn_sched_barrier(0);
-    head_epilogue<true>(a, acc, s_b1, s_w2, b2r, t * 16 + lr, lq);
+    head_epilogue<true>(a, acc, s_b1, s_w2, b2r, t * 16 + lr, lq, lsum, tgt);
   }
+  head_loss_partial(a, lsum, s_loss);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -653,8 +697,20 @@ __global__ __launch_bounds__(kBwdThreads) void mlp1_bwd_f32_kernel(const Mlp1Arg
 constexpr int kHeadReduceSlices = 16;
 __global__ __launch_bounds__(kHeadReduceSlices * kWave) void mlp1_bwd_reduce_kernel(const float* __restrict__ partial, int G, int I, int H, int O2,
                                                               int cpw, int bf16, float* __restrict__ gw1, float* __restrict__ gb1,
-                                                              float* __restrict__ gw2, float* __restrict__ gb2) {
+                                                              float* __restrict__ gw2, float* __restrict__ gb2,
+                                                              const float* __restrict__ loss_part, float loss_scale,
+                                                              float* __restrict__ loss_out) {
   __shared__ float s[kHeadReduceSlices][kWave];
+  if (loss_out && blockIdx.x == gridDim.x - 1 && threadIdx.x < kWave) {
+    // the mean squared error the forward left as per-workgroup sums: added in index order by one wave (a block whose elements
+    // mostly stand for nothing has the time)
+    const int n = (int)loss_part[kHeadLossSlots];
+    float t = 0.f;
+    for (int b = threadIdx.x; b < n; b += kWave) t += loss_part[b];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if (threadIdx.x == 0) *loss_out = t * loss_scale;
+  }
   const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int e = blockIdx.x * kWave + el;
   // where the element goes (-1: a lane / row / column that stands for nothing)
@@ -754,23 +810,32 @@ static bool head_shapes_ok(int64_t N, int I, int H, int O2) {
   return N >= 0 && I >= 1 && I <= MLQEM_MLP1_MAX_IN && H >= 1 && H <= kHeadH && O2 >= 1 && O2 <= kHeadMaxOut;
 }
 
-extern "C" size_t mlqem_mlp1_workspace_bytes(int I, int O2) {
-  if (I < 1 || O2 < 1 || O2 > kHeadMaxOut) return 0;
+// the forward's image and the backward's partial sums share the front of the workspace (never alive together); the loss sums
+// of a forward-with-target live behind them, from the forward launch to the backward's second stage
+static size_t head_loss_offset() {
   const size_t bwd = (size_t)kHeadMaxBwdBlocks * (size_t)kHeadPartialFloats * sizeof(float);
   const size_t fwd = (size_t)head_image_u32x4(11) * sizeof(u32x4);      // the widest forward image
-  return bwd > fwd ? bwd : fwd;
+  return ((bwd > fwd ? bwd : fwd) + 255) / 256 * 256;
+}
+
+extern "C" size_t mlqem_mlp1_workspace_bytes(int I, int O2) {
+  if (I < 1 || O2 < 1 || O2 > kHeadMaxOut) return 0;
+  return head_loss_offset() + (size_t)(kHeadLossSlots + 1) * sizeof(float);     // ... | the forward's loss sums (+ their count)
 }
 
 extern "C" int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2,
                                   const float* b2, void* h_stash, float* out, int64_t ldo, int64_t N, int I, int H, int O2,
-                                  int bf16, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+                                  int bf16, const float* target, int64_t ldt, float* gout, int64_t ldg, void* workspace,
+                                  size_t workspace_bytes, mlqem_stream_t stream) {
   begin_launches();
   if (!head_shapes_ok(N, I, H, O2)) return (I > MLQEM_MLP1_MAX_IN || H > kHeadH || O2 > kHeadMaxOut) ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
   if (ldx < (I + 3) / 4 * 4 || ldx % 4 || ldo < O2) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_mlp1_workspace_bytes(I, O2) || !aligned_to(workspace, 16)) return MLQEM_ERR_WORKSPACE;
   if (N == 0) return MLQEM_OK;
   if (!x || !w1 || !b1 || !w2 || !b2 || !out || !aligned_to(x, 16) || (h_stash && !aligned_to(h_stash, 16))) return MLQEM_ERR_BAD_ARG;
-  Mlp1Args a{x, ldx, N, I, H, O2, w1, b1, w2, b2, h_stash, out, ldo, nullptr, 0, nullptr, nullptr};
+  if (target && (!gout || ldt < O2 || ldg < O2)) return MLQEM_ERR_BAD_ARG;
+  Mlp1Args a{x, ldx, N, I, H, O2, w1, b1, w2, b2, h_stash, out, ldo, nullptr, 0, nullptr, nullptr,
+             target, ldt, gout, ldg, reinterpret_cast<float*>(static_cast<char*>(workspace) + head_loss_offset())};
   hipStream_t s = as_stream(stream);
   if (bf16) {
     const int g2 = (I + 31) / 32;
@@ -786,14 +851,16 @@ extern "C" int mlqem_mlp1_forward(const float* x, int64_t ldx, const float* w1, 
 
 extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t ldx, const void* h_stash,
                                    const float* w2, float* gw1, float* gb1, float* gw2, float* gb2, int64_t N, int I, int H,
-                                   int O2, int bf16, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+                                   int O2, int bf16, float* loss_out, void* workspace, size_t workspace_bytes,
+                                   mlqem_stream_t stream) {
   begin_launches();
   if (!head_shapes_ok(N, I, H, O2)) return (I > MLQEM_MLP1_MAX_IN || H > kHeadH || O2 > kHeadMaxOut) ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG;
   if (ldx < (I + 3) / 4 * 4 || ldx % 4 || ldg < O2 || !gw1 || !gb1 || !gw2 || !gb2) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_mlp1_workspace_bytes(I, O2)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && (!gout || !x || !h_stash || !w2 || !aligned_to(x, 16) || !aligned_to(h_stash, 16))) return MLQEM_ERR_BAD_ARG;
+  if (loss_out && N == 0) return MLQEM_ERR_BAD_ARG;       // there is no loss of nothing (and no forward that left its sums)
   Mlp1Args a{x, ldx, N, I, H, O2, nullptr, nullptr, w2, nullptr, const_cast<void*>(h_stash), nullptr, 0, gout, ldg,
-             static_cast<float*>(workspace), nullptr};
+             static_cast<float*>(workspace), nullptr, nullptr, 0, nullptr, 0, nullptr};
   hipStream_t s = as_stream(stream);
   const int chunks = (I + 1 + 3) / 4;             // float4 chunks of [x | 1]
   const int cpw = (chunks + 3) / 4;               // per wave: <= 11 for I <= 175
@@ -830,6 +897,8 @@ extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* 
     }
   }
   hipLaunchKernelGGL(mlp1_bwd_reduce_kernel, dim3((unsigned)ceil_div(kHeadPartialFloats, kWave)), dim3(kHeadReduceSlices * kWave), 0, s, a.partial, G, I, H, O2,
-                     reduce_layout, bf16 ? 1 : 0, gw1, gb1, gw2, gb2);
+                     reduce_layout, bf16 ? 1 : 0, gw1, gb1, gw2, gb2,
+                     reinterpret_cast<const float*>(static_cast<const char*>(workspace) + head_loss_offset()),
+                     N > 0 ? 1.0f / ((float)N * (float)O2) : 0.f, loss_out);
   return launch_status();
 }

@@ -167,3 +167,31 @@ def test_rows_trainer_replays_the_step_from_a_graph_bit_for_bit(kind):
         assert torch.equal(a, b)
     if kind == "mlp3":      # the masks move with the device counter: two consecutive steps on the same rows differ in their dropout
         assert len(set(runs[True][0])) == len(runs[True][0])
+
+
+@pytest.mark.parametrize("mode,shape", [("f32", (170, 128, 1)), ("bf16", (170, 128, 1)), ("f32", (58, 64, 4)), ("bf16", (33, 17, 3))])
+def test_fused_mlp1_step_equals_the_autograd_step(mode, shape, monkeypatch):
+    """train.RowsTrainer's five-launch MLP1 step (forward with the MSE loss folded in -> backward -> second stage writing the
+    gradients into the flat buffer and the loss -> Adam) against the same step through autograd (MLP1.forward, mse_loss_grad,
+    out.backward, gradient filing): the output gradient is formed by the same fp32 expression, so parameters agree BIT FOR
+    BIT after every step; the loss is the same sum in another order (1e-6)."""
+    from blackwater.nn.mlp import MLP1
+    from blackwater.train import RowsTrainer
+
+    i, h, o = shape
+    torch.manual_seed(2)
+    xs = [torch.randn(n, i, device=DEV) for n in (4099, 4099, 33)]
+    ys = [torch.randn(x.shape[0], o, device=DEV) for x in xs]
+    runs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MLQEM_MLP1_FUSED_STEP", fused)
+        torch.manual_seed(3)
+        model = MLP1(i, h, o).to(DEV)
+        model.mfma = mode
+        tr = RowsTrainer(model, lr=1e-3, graphs=False)
+        losses = [float(tr.step_rows(x, y)) for _ in range(2) for x, y in zip(xs, ys)]
+        runs[fused] = (losses, tr.flat_param.detach().clone(), tr.flat_grad.detach().clone())
+    assert torch.equal(runs["1"][1], runs["0"][1]) and torch.equal(runs["1"][2], runs["0"][2])
+    for a, b in zip(runs["1"][0], runs["0"][0]):
+        assert abs(a - b) <= 1e-6 * abs(b)
+    assert runs["1"][0][-1] < runs["1"][0][0]
