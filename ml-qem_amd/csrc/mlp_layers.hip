@@ -1056,7 +1056,8 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
     static const int r0 = layer_resident(layer_wgrad_kernel<false>, kLayerThreads, 0), r1 = layer_resident(layer_wgrad_kernel<true>, kLayerThreads, 0);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(x_is_bf16 ? r1 : r0, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
     static const int lds_form = getenv("MLQEM_LAYER_WGRAD_LDS") ? atoi(getenv("MLQEM_LAYER_WGRAD_LDS")) : 2;    // 0: register prefetch, 1: LDS DMA + v_perm, 2: LDS DMA + transposing reads
-    if (x_is_bf16 && lds_form == 2) {              // the transposing-read form (default): see layer_wgrad_tr_kernel
+    const bool dma_ok = aligned_to(dy, 16) && aligned_to(x, 16);      // the DMA forms move 16 bytes per lane
+    if (x_is_bf16 && lds_form == 2 && dma_ok) {    // the transposing-read form (default): see layer_wgrad_tr_kernel
       const size_t lds = (size_t)kTrSlabs * kDmaSlabBytes;
       static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(layer_wgrad_tr_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
@@ -1067,7 +1068,7 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
       hipLaunchKernelGGL(layer_wgrad_tr_reduce_kernel, dim3((unsigned)ceil_div(kLayerTrFloats, kWave)), dim3(16 * kWave), 0, s, a.partial, G, K, U, gw, gb);
       return launch_status();
     }
-    if (x_is_bf16 && lds_form) {
+    if (x_is_bf16 && lds_form && dma_ok) {
       auto go = [&](auto kernel, int slabs) {
         const size_t lds = (size_t)slabs * kDmaSlabBytes;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
