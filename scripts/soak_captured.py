@@ -39,3 +39,28 @@ for family in ("B", "A"):
         ops.set_seed_counter(None)
         del bt
 print("soak ok", flush=True)
+
+# the feature-matrix models through train.RowsTrainer: the five-launch MLP1 step (fp32 and bf16) and MLP3 on bf16 storage
+from blackwater.nn.mlp import MLP1, MLP3
+from blackwater.train import RowsTrainer
+
+torch.manual_seed(1)
+rows = [ops.padded_copy(torch.randn(65536, 170, device=dev)) for _ in range(3)]
+ys = [torch.randn(65536, 1, device=dev) for _ in range(3)]
+for name, make, mode in (("mlp1", lambda: MLP1(170, 128, 1), "f32"), ("mlp1", lambda: MLP1(170, 128, 1), "bf16"),
+                         ("mlp3", lambda: MLP3(170, 125, 1), "bf16")):
+    model = make().to(dev)
+    model.mfma = mode
+    tr = RowsTrainer(model, lr=1e-3, graphs=True)
+    first = None
+    for k in range(steps):
+        loss = tr.step_rows(rows[k % 3], ys[k % 3])
+        if k % 500 == 499:
+            v = float(loss)
+            assert np.isfinite(v), (name, mode, k, v)
+            first = v if first is None else first
+            print(f"{name} {mode} step {k + 1}: loss {v:.5f}", flush=True)
+    torch.cuda.synchronize()
+    ops.set_seed_counter(None)
+    del tr
+print("soak ok")
