@@ -560,8 +560,10 @@ def mlp_head_leg(dev, rows=262144, steps=50):
     synthetic feature rows, in fp32 (exact, v_mfma_f32_16x16x4_f32) and with `mfma = "bf16"` -- the "bf16 MFMA MLP head" of
     cfg5: v_mfma_f32_16x16x32_bf16, hidden activations kept as a bf16 stash.  The step is replayed from a hipGraph
     (train.RowsTrainer; `eager_ms_per_step` = the same step enqueued launch by launch).  GEMM model: a layer moves
-    4 (rows (in + out) + in out) bytes and does 2 rows in out flops per pass; passes = forward + weight gradient + data
-    gradient, except that the FIRST layer has no data gradient (the feature matrix needs none).  `kernels` times the two
+    rows (in e_in + out e_out) + 4 in out bytes (e = the operand's STORAGE type: fp32 feature rows and outputs, fp32 or bf16
+    hidden activations) and does 2 rows in out flops per pass; passes = forward + weight gradient + data gradient, except
+    that the FIRST layer has no data gradient (the feature matrix needs none); the element-wise passes of MLP3 (BatchNorm,
+    ReLU, dropout) are NOT in the model, so its fractions describe the whole step against its GEMM bytes only.  `kernels` times the two
     launches of the one-launch MLP1 head alone (HIP events on the launch stream) against their own bytes and flops."""
     from blackwater.native import ops as _ops
     from blackwater.nn.mlp import MLP1, MLP3
@@ -606,9 +608,23 @@ def mlp_head_leg(dev, rows=262144, steps=50):
     for name, make, widths in (("mlp1_170_128_1", lambda: MLP1(170, 128, 1), [(170, 128), (128, 1)]),
                                ("mlp3_170_125_1", lambda: MLP3(170, 125, 1), [(170, 125), (125, 125), (125, 41), (41, 1)])):
         passes = [2] + [3] * (len(widths) - 1)       # no data gradient for the first layer
-        gemm_bytes = sum(p * 4 * (rows * (i + o) + i * o) for p, (i, o) in zip(passes, widths))
         gemm_flops = sum(p * 2 * rows * i * o for p, (i, o) in zip(passes, widths))
+
+        def gemm_bytes_of(mode):
+            """Bytes the GEMM passes must move with every tensor in the type it is STORED in: the feature rows and the final
+            output fp32, hidden activations fp32 or -- mode bf16 -- bfloat16, weights fp32.  MLP1 is one launch per direction,
+            so its hidden activation crosses memory twice (stash written, stash read), not once per layer pass."""
+            elem = 2 if mode == "bf16" else 4
+            if name.startswith("mlp1"):
+                return 2 * rows * (4 * 172 + elem * 128 + 4)
+            total = 0
+            for li, (p_, (i, o)) in enumerate(zip(passes, widths)):
+                ei, eo = (4 if li == 0 else elem), (4 if li == len(widths) - 1 else elem)
+                total += p_ * (rows * (i * ei + o * eo) + 4 * i * o)
+            return total
+
         for mode in ("f32", "bf16"):
+            gemm_bytes = gemm_bytes_of(mode)
             rec = {}
             for graphs in (True, False):
                 torch.manual_seed(1)
@@ -627,6 +643,7 @@ def mlp_head_leg(dev, rows=262144, steps=50):
                 dt = (time.perf_counter() - t0) / steps
                 if graphs:
                     rec = {"rows_per_s": round(rows / dt, 0), "ms_per_step": round(dt * 1e3, 3), "step_mode": "hipgraph replay",
+                           "gemm_bytes_per_step": gemm_bytes,
                            "gemm_GBps_algorithmic": round(gemm_bytes / dt / 1e9, 1), "gemm_TFLOPs": round(gemm_flops / dt / 1e12, 3),
                            "frac_of_hbm_peak": round(gemm_bytes / dt / 1e9 / 8000.0, 4),
                            "frac_of_mfma_peak": round(gemm_flops / dt / 1e12 / (157.0 if mode == "f32" else 2500.0), 5),
