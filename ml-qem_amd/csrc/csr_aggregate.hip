@@ -76,7 +76,7 @@ __device__ __forceinline__ void stage_bias(const AggArgs& a, float* s_bias, int 
 template <int VEC, bool IS_MAX, bool EPI = true, bool POOL = false>
 __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
                                            const float (&self)[VEC], float rs, float ds, const float* s_bias,
-                                           float* s_tile = nullptr, int64_t r0 = 0) {
+                                           float* s_tile = nullptr, int64_t r0 = 0, const float* zpre = nullptr) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
@@ -86,7 +86,10 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
     for (int v = 0; v < VEC; ++v) res[v] = a.alpha * fmaf(ds, self[v], rs * acc[v]);
   } else {
     float zz[VEC];
-    if (a.z) vload<VEC>(a.z + row * a.ldz + ch, zz);
+    if (zpre) {                       // fetched with the row's other operands (the ELL kernel's items)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) zz[v] = zpre[v];
+    } else if (a.z) vload<VEC>(a.z + row * a.ldz + ch, zz);
     bool keep[VEC];
     if (a.drop_p > 0.f)
       dropout_keep<VEC>(a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull), (uint64_t)(row * a.C + ch),
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   }
   float acc[kItemsPerThread][VEC], self[kItemsPerThread][VEC];
   float v0[kItemsPerThread][VEC], v1[kItemsPerThread][VEC], w0[kItemsPerThread], w1[kItemsPerThread];
+  float zq[EPI ? kItemsPerThread : 1][VEC];
   bool more[kItemsPerThread];
 #pragma unroll
   for (int k = 0; k < kItemsPerThread; ++k) {
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     vload<VEC>(xc + (int64_t)j0 * a.ldx, v0[k]);
     vload<VEC>(xc + (int64_t)j1 * a.ldx, v1[k]);
     if (use_self) vload<VEC>(xc + (int64_t)row[k] * a.ldx, self[k]);
+    if (EPI && a.z) vload<VEC>(a.z + (int64_t)row[k] * a.ldz + ch[k], zq[k]);      // with the gathers, not behind the arithmetic
   }
 #pragma unroll
   for (int k = 0; k < kItemsPerThread; ++k) {
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
         for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
       }
     }
-    finish_row<VEC, IS_MAX, EPI, POOL>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias, s_tile, r0);
+    finish_row<VEC, IS_MAX, EPI, POOL>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias, s_tile, r0, (EPI && a.z) ? zq[k] : nullptr);
   }
   // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
   // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
