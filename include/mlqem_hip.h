@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 19 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 20 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -100,7 +100,10 @@ int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, con
  * tile order by the pool's finish kernel (deterministic).  Replaces the last hidden layer of a Family A branch followed by
  * global_mean_pool (01_ngem.ipynb cell [9]; DESIGN section 3: the last conv is folded into the pool) without reading the
  * [N, C] activation a second time.  out_mean / out_wmean: [B, C] (either may be NULL).  Needs the ELL side table and rows of
- * round_up(C, 4) floats (MLQEM_ERR_UNSUPPORTED otherwise: call the two entry points).  workspace:
+ * round_up(C, 4) floats (MLQEM_ERR_UNSUPPORTED otherwise: call the two entry points).  gate_bits (optional,
+ * [N * ceil(C / 4)] bytes): bit v of entry (row, slice) = (out[row, 4 slice + v] > 0), the ReLU / dropout gate
+ * mlqem_segment_pool_bwd_f32 applies; with it `out` may be NULL -- a pooled activation whose only other reader is that gate
+ * (the last hidden layer of a Family A branch) is then never written to memory.  workspace:
  * mlqem_csr_aggregate_pool_workspace_bytes(N, B, C). */
 size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C);
 int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
@@ -108,8 +111,8 @@ int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const int32_t* ptr
                                  const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
                                  const uint64_t* seed_counter, float* out, int64_t ldo, int64_t N, int C,
                                  const float* pool_weights, const int32_t* graph_ptr, int64_t B, float* out_mean,
-                                 int64_t ld_mean, float* out_wmean, int64_t ld_wmean, void* workspace, size_t workspace_bytes,
-                                 mlqem_stream_t stream);
+                                 int64_t ld_mean, float* out_wmean, int64_t ld_wmean, uint8_t* gate_bits, void* workspace,
+                                 size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Segment max with the node itself included: out[i,:] = max(x[i,:], max_e x[idx[e],:])
  * (ASAPooling's scatter(..., reduce='max') after add_remaining_self_loops; docs/tutorials/gnn.py:85,92). */
@@ -349,11 +352,13 @@ int mlqem_segment_pool_f32(const float* x, int64_t ldx, const float* weights, co
 /* Backward: gx[r,:] = (g_mean[g,:] + weights[r] * g_wmean[g,:]) / n_g for every row r of graph g (either gradient may be
  * NULL); gate (may be NULL), applied last: gx = gate[r,:] > 0 ? gx * gate_scale : 0 -- the ReLU/dropout mask of the
  * pooled activation, see mlqem_linear_f32.  16-byte accesses when gx, gate AND the [B,C] gradients own round_up(C,4)
- * columns per row. */
+ * columns per row.  gate_bits (instead of gate; needs the 16-byte form): the same mask as sign bits, one byte per (row,
+ * 4-column slice), bit v = (activation[row, 4 slice + v] > 0), as mlqem_csr_aggregate_pool_f32 leaves them -- the gate then
+ * costs one byte per slice instead of sixteen, and the activation need not exist in memory at all. */
 int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const float* g_wmean, int64_t ld_gwmean,
                                const float* weights, const int32_t* graph_ptr, int64_t N, int64_t B, int C,
-                               const float* gate, int64_t ldgate, float gate_scale, float* gx, int64_t ldgx,
-                               mlqem_stream_t stream);
+                               const float* gate, int64_t ldgate, float gate_scale, const uint8_t* gate_bits, float* gx,
+                               int64_t ldgx, mlqem_stream_t stream);
 
 /* What remains of a branch's last conv once it is folded into its pool: out[b, col[t]] (+)= P_t[b, :] . W_t (+ bias[col]),
  * t < n_terms (Family A: GCN one term, Cheb and SAGE two each -> three columns), and its backward:

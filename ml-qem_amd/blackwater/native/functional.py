@@ -849,18 +849,20 @@ class _FamilyAGraph(Function):
         L["g1"] = mk(9, Fa); h = _GCNLayer.forward(L["g1"], x, g1w, g1b, struct, T, p1, seed + 1, T, None, pre=pre_g)
         # the pooled means of each branch's last hidden activation come out of the aggregation launch that writes it
         # (mlqem_csr_aggregate_pool_f32: the activation is not read a second time)
-        pg = dict(graph_ptr=gptr, num_graphs=nb, weights=tg, mean=False, wmean=True)
+        # ... and since the backward reads that activation ONLY as the ReLU / dropout gate of the pool's gradient, the launch leaves
+        # its sign bits (one byte per 16-byte slice) instead of the activation itself: h is never written, never read again
+        pg = dict(graph_ptr=gptr, num_graphs=nb, weights=tg, mean=False, wmean=True, bits=True, store=False)
         L["g2"] = mk(9, T); hg = _GCNLayer.forward(L["g2"], h, g2w, g2b, struct, T, p1, seed + 2, T, k1, pool=pg)
         _, wg = ops.pooled_means(hg, pg)
         with torch.cuda.stream(side[0]):
             # Cheb branch: args (x, bias, struct, relu, drop_p, seed, defer_mask, x_gate_scale, *ws)
-            pc = dict(graph_ptr=gptr, num_graphs=nb, weights=tc, mean=True, wmean=True)
+            pc = dict(graph_ptr=gptr, num_graphs=nb, weights=tc, mean=True, wmean=True, bits=True, store=False)
             L["c1"] = mk(11, Fa); hc = _ChebLayer.forward(L["c1"], x, c1b, struct, T, p2, seed + 3, T, None, c1w0, c1w1, c1w2,
                                                           pre=pre_c, pool=pc)
             mc, wc = ops.pooled_means(hc, pc)
         with torch.cuda.stream(side[1]):
             # SAGE branch: args (x, wl, bl, wr, struct, relu, drop_p, seed, defer_mask, x_gate_scale)
-            ps = dict(graph_ptr=gptr, num_graphs=nb, weights=ts, mean=True, wmean=True)
+            ps = dict(graph_ptr=gptr, num_graphs=nb, weights=ts, mean=True, wmean=True, bits=True, store=False)
             L["s1"] = mk(10, Fa); hs = _SAGELayer.forward(L["s1"], x, s1l, s1b, s1r, struct, T, p2, seed + 4, T, None, pre=pre_s, pool=ps)
             ms, ws = ops.pooled_means(hs, ps)
         for st, ts_ in zip(side, ((mc, wc), (ms, ws))):
@@ -873,13 +875,16 @@ class _FamilyAGraph(Function):
         # the three folded last convs: [wmean_g . W3 + b3 | mean_c . W0 + wmean_c . W1 + b | wmean_s . Wl + bl + mean_s . Wr]
         ctx.head = ([(wg, g3w, 0), (mc, c2w0, 1), (wc, c2w1, 1), (ws, s2l, 2), (ms, s2r, 2)], [g3b, c2b, s2b])
         out = ops.pooled_head(*ctx.head)
+        # the gates of the three pooled activations: the activation itself, or its sign bits when the pooled launch left only those
         ctx.tail = (struct, k1, k2, hg, hc, hs)
+        ctx.gate_bits = (pg.get("out_bits"), pc.get("out_bits"), ps.get("out_bits"))
         return out
 
     @staticmethod
     def backward(ctx, g):
         L = ctx.layers
         struct, k1, k2, hg, hc, hs = ctx.tail
+        bg_, bc_, bs_ = ctx.gate_bits           # sign bits of the pooled activations (then hg / hc / hs are None: never written)
         gptr, n = struct.graph_ptr, struct.num_nodes
         main = torch.cuda.current_stream(g.device)
         side = ctx.side
@@ -890,7 +895,7 @@ class _FamilyAGraph(Function):
         for st in side:
             st.wait_stream(main)
         # GCN branch, last layer first: pooled = wmean(h) W^T + b
-        t = ops.segment_pool_bwd(None, ggw, gptr, n, weights=struct.colsum("gcn"), gate=hg, gate_scale=k1)
+        t = ops.segment_pool_bwd(None, ggw, gptr, n, weights=struct.colsum("gcn"), gate=hg if bg_ is None else None, gate_scale=k1, gate_bits=bg_)
         t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
         fuse = ctx.fuse
         if fuse:
@@ -898,14 +903,14 @@ class _FamilyAGraph(Function):
         else:
             _, g1w, g1b = _GCNLayer.backward(L["g1"], t)[:3]
         with torch.cuda.stream(side[0]):
-            t = ops.segment_pool_bwd(gcm, gcw, gptr, n, weights=struct.colsum("cheb"), gate=hc, gate_scale=k2)
+            t = ops.segment_pool_bwd(gcm, gcw, gptr, n, weights=struct.colsum("cheb"), gate=hc if bc_ is None else None, gate_scale=k2, gate_bits=bc_)
             if fuse:
                 bc = _ChebLayer.backward(L["c1"], t, blocks_only=True)       # [g, g_b1, g_c2]
             else:
                 r = _ChebLayer.backward(L["c1"], t)
                 c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
         with torch.cuda.stream(side[1]):
-            t = ops.segment_pool_bwd(gsm, gsw, gptr, n, weights=struct.colsum("sage"), gate=hs, gate_scale=k2)
+            t = ops.segment_pool_bwd(gsm, gsw, gptr, n, weights=struct.colsum("sage"), gate=hs if bs_ is None else None, gate_scale=k2, gate_bits=bs_)
             if fuse:
                 bs = _SAGELayer.backward(L["s1"], t, blocks_only=True)       # [g_p, g]
             else:

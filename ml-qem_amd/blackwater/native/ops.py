@@ -133,8 +133,10 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
 
     ``pool`` = a dict with ``graph_ptr``, ``num_graphs``, optional ``weights`` and the flags ``mean`` / ``wmean``: the pooled
     means of ``out`` come from the same launch (mlqem_csr_aggregate_pool_f32) and are left in ``pool["out_mean"]`` /
-    ``pool["out_wmean"]`` ([B, c] tensors, None for a mean that was not asked for).  When the fused form is switched off or
-    does not serve the shape, ``pool`` is left untouched and the caller pools ``out`` itself (``pooled_means``)."""
+    ``pool["out_wmean"]`` ([B, c] tensors, None for a mean that was not asked for).  ``bits``: also ``pool["out_bits"]``, the
+    sign bits of ``out`` (uint8 [n * ceil(c / 4)]: what ``segment_pool_bwd(gate_bits=)`` gates with); with ``bits`` and
+    ``store=False`` the activation is not written at all and None is returned.  When the fused form is switched off or does
+    not serve the shape, ``pool`` is left untouched, ``out`` is written and the caller pools it itself (``pooled_means``)."""
     n, c = x.shape
     ldx = _mat(x, "x")
     _vec(ptr, "ptr", n + 1, torch.int32)
@@ -143,39 +145,50 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
     for nm, v in (("cscale", cscale), ("rscale", rscale), ("dself", dself)):
         _vec(v, nm, n)
     _vec(bias, "bias", c)
-    if out is None:
-        out = padded_empty(n, c, x.device)
+    fusable = pool is not None and ell is not None and _POOL_FUSED and n > 0 and int(pool["num_graphs"]) > 0
+    # the pooled form with gate bits and store=False never writes the activation: no buffer for it unless the launch is refused
+    no_store = fusable and bool(pool.get("bits", False)) and not bool(pool.get("store", True))
+    if no_store:
+        out, ldo = None, (c + 3) // 4 * 4
     else:
-        _owns_pad_columns(out, "out")
-    ldo = _mat(out, "out")
+        if out is None:
+            out = padded_empty(n, c, x.device)
+        else:
+            _owns_pad_columns(out, "out")
+        ldo = _mat(out, "out")
     ldz = 0
     if z is not None:
         if z.shape != x.shape:
             raise ValueError("z must have the shape of x")
         ldz = _mat(z, "z")
+    lib = _lib.load()
+    if fusable:
+        gptr, nb, wts = pool["graph_ptr"], int(pool["num_graphs"]), pool.get("weights")
+        want_mean, want_wmean = bool(pool.get("mean", True)), bool(pool.get("wmean", True))
+        want_bits = bool(pool.get("bits", False))
+        store = not no_store
+        _vec(gptr, "graph_ptr", nb + 1, torch.int32)
+        _vec(wts, "weights", n)
+        mean = padded_empty(nb, c, x.device) if want_mean else None
+        wmean = padded_empty(nb, c, x.device) if want_wmean else None
+        bits = torch.empty(n * ((c + 3) // 4), dtype=torch.uint8, device=x.device) if want_bits else None
+        need = lib.mlqem_csr_aggregate_pool_workspace_bytes(n, nb, c)
+        ws = _wgrad_workspace(x.device, need)
+        code = lib.mlqem_csr_aggregate_pool_f32(
+            _p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
+            _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None,
+            _p(out) if store else None, ldo, n, c, _p(wts), _p(gptr), nb, _p(mean), _mat(mean, "mean") if want_mean else 0,
+            _p(wmean), _mat(wmean, "wmean") if want_wmean else 0, _p(bits), _p(ws), need, _stream())
+        if code != _lib.ERR_UNSUPPORTED:
+            _lib.check(code, "mlqem_csr_aggregate_pool_f32")
+            pool["out_mean"], pool["out_wmean"], pool["out_bits"] = mean, wmean, bits
+            return out if store else None
+        if out is None:                # refused (a shape the pooled form does not serve): the plain launch needs the buffer
+            out = padded_empty(n, c, x.device)
+            ldo = _mat(out, "out")
     common = (_p(x), ldx, _p(ptr), _p(idx), _p(ell), _p(cscale), _p(rscale), _p(dself), float(alpha), float(beta), _p(z), ldz,
               _p(bias), 1 if relu else 0, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
               _p(_seed_counter) if drop_p > 0 else None, _p(out), ldo, n, c)
-    lib = _lib.load()
-    if pool is not None:
-        gptr, nb, wts = pool["graph_ptr"], int(pool["num_graphs"]), pool.get("weights")
-        want_mean, want_wmean = bool(pool.get("mean", True)), bool(pool.get("wmean", True))
-        fused = ell is not None and _POOL_FUSED and n > 0 and nb > 0
-        if fused:
-            _vec(gptr, "graph_ptr", nb + 1, torch.int32)
-            _vec(wts, "weights", n)
-            mean = padded_empty(nb, c, x.device) if want_mean else None
-            wmean = padded_empty(nb, c, x.device) if want_wmean else None
-            need = lib.mlqem_csr_aggregate_pool_workspace_bytes(n, nb, c)
-            ws = _wgrad_workspace(x.device, need)
-            code = lib.mlqem_csr_aggregate_pool_f32(*common, _p(wts), _p(gptr), nb, _p(mean), _mat(mean, "mean") if want_mean else 0,
-                                                    _p(wmean), _mat(wmean, "wmean") if want_wmean else 0, _p(ws), need, _stream())
-            if code == _lib.ERR_UNSUPPORTED:
-                fused = False
-            else:
-                _lib.check(code, "mlqem_csr_aggregate_pool_f32")
-                pool["out_mean"], pool["out_wmean"] = mean, wmean
-                return out
     code = lib.mlqem_csr_aggregate_f32(*common, _stream())
     _lib.check(code, "mlqem_csr_aggregate_f32")
     return out
@@ -855,7 +868,7 @@ def segment_pool(x, graph_ptr, num_graphs, weights=None, mean=True, wmean=False)
     return o0, o1
 
 
-def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=None, gate_scale=1.0, out=None):
+def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=None, gate_scale=1.0, out=None, gate_bits=None):
     """gx[r] = (g_mean[g] + weights[r] g_wmean[g]) / n_g (either gradient may be None), optionally gated by gate > 0."""
     ref = g_mean if g_mean is not None else g_wmean
     if ref is None:
@@ -879,10 +892,14 @@ def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=N
     if tuple(gx.shape) != (num_nodes, c):
         raise ValueError("segment_pool_bwd: bad out shape")
     gp, gld = _gate(gate, num_nodes, c, False)
+    if gate_bits is not None:      # the gate as sign bits (csr_aggregate(..., pool=) leaves them): one byte per (row, 4-column slice)
+        if gate is not None or gate_bits.dtype != torch.uint8 or not gate_bits.is_cuda or gate_bits.numel() != num_nodes * ((c + 3) // 4) \
+                or not gate_bits.is_contiguous():
+            raise ValueError("segment_pool_bwd: gate_bits must be a contiguous uint8 cuda tensor of num_nodes * ceil(c / 4) entries (and no gate)")
     ld = lambda t: 0 if t is None else (int(t.stride(0)) if b > 1 else (c + 3) // 4 * 4)
     code = _lib.load().mlqem_segment_pool_bwd_f32(_p(g_mean), ld(g_mean), _p(g_wmean), ld(g_wmean),
                                                   _p(weights) if g_wmean is not None else None, _p(graph_ptr), num_nodes, b, c,
-                                                  gp, gld, float(gate_scale), _p(gx), _mat(gx, "gx"), _stream())
+                                                  gp, gld, float(gate_scale), _p(gate_bits), _p(gx), _mat(gx, "gx"), _stream())
     _lib.check(code, "mlqem_segment_pool_bwd_f32")
     return gx
 

@@ -44,6 +44,9 @@ struct PoolFuse {
   int B;
   float* partial;          // [(tiles + B)][2][CV * VEC]
   const int32_t* tile_graph;   // [tiles]: the graph of each tile's first row (tile_graph_kernel)
+  uint8_t* mask;           // optional [N * CV]: bit v of entry (row, slice) = (out[row, 4 slice + v] > 0) -- what the pooled
+                           // activation's only reader in the backward needs of it (the ReLU / dropout gate); with it the caller
+                           // may pass out == NULL and the activation never reaches memory
 };
 
 // graph of the first row of every tile of `rows` rows: one binary search per tile, outside the kernel that needs it (inside,
@@ -76,7 +79,8 @@ __device__ __forceinline__ void stage_bias(const AggArgs& a, float* s_bias, int 
 template <int VEC, bool IS_MAX, bool EPI = true, bool POOL = false>
 __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
                                            const float (&self)[VEC], float rs, float ds, const float* s_bias,
-                                           float* s_tile = nullptr, int64_t r0 = 0, const float* zpre = nullptr) {
+                                           float* s_tile = nullptr, int64_t r0 = 0, const float* zpre = nullptr,
+                                           uint8_t* mask = nullptr) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
@@ -104,8 +108,16 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
       res[v] = r;
     }
   }
-  if (a.nt) vstore_nt<VEC>(a.out + row * a.ldo + ch, res);
-  else vstore<VEC>(a.out + row * a.ldo + ch, res);
+  if (!POOL || a.out) {
+    if (a.nt) vstore_nt<VEC>(a.out + row * a.ldo + ch, res);
+    else vstore<VEC>(a.out + row * a.ldo + ch, res);
+  }
+  if (POOL && mask) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) bits |= (res[v] > 0.f ? 1u : 0u) << v;
+    mask[row * a.CV + ch / VEC] = (uint8_t)bits;
+  }
   if (POOL) {               // the workgroup's tile of the output, row-major, for the pooled partial sums at the end of the kernel
     float* t = s_tile + (int)(row - r0) * (a.CV * VEC) + ch;
 #pragma unroll
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
         for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
       }
     }
-    finish_row<VEC, IS_MAX, EPI, POOL>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias, s_tile, r0, (EPI && a.z) ? zq[k] : nullptr);
+    finish_row<VEC, IS_MAX, EPI, POOL>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias, s_tile, r0, (EPI && a.z) ? zq[k] : nullptr, pf.mask);
   }
   // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
   // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
             if (!use_self) sf[v] = 0.f;
             if (IS_MAX) part[v] = fmaxf(part[v], sf[v]);
           }
-          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, part, sf, rs_r, ds_r, s_bias, s_tile, r0);
+          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, part, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, pf.mask);
         }
       } else {   // more slices than lanes: every lane walks all edges for its slices
         for (int sl = lane; sl < a.CV; sl += kWave) {
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
 #pragma unroll
             for (int v = 0; v < VEC; ++v) tot[v] = IS_MAX ? fmaxf(tot[v], q[v]) : fmaf(w, q[v], tot[v]);
           }
-          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, tot, sf, rs_r, ds_r, s_bias, s_tile, r0);
+          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, tot, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, pf.mask);
         }
       }
     }
@@ -523,7 +535,8 @@ __global__ __launch_bounds__(kBlock) void ell_from_csr_kernel(const int32_t* __r
 
 template <bool IS_MAX>
 static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool = nullptr, int* rows_per_tile = nullptr) {
-  if (a.N < 0 || a.C <= 0 || !a.x || !a.ptr || !a.out || a.ldx < a.C || a.ldo < a.C) return MLQEM_ERR_BAD_ARG;
+  const bool no_store = pool && pool->mask && !a.out;       // the pooled form with the gate bits: the activation itself is optional
+  if (a.N < 0 || a.C <= 0 || !a.x || !a.ptr || (!a.out && !no_store) || a.ldx < a.C || (a.out && a.ldo < a.C)) return MLQEM_ERR_BAD_ARG;
   if (a.z && a.ldz < a.C) return MLQEM_ERR_BAD_ARG;
   if (a.N == 0) return MLQEM_OK;
   if (!a.idx) return MLQEM_ERR_BAD_ARG;
@@ -534,8 +547,8 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
   int vec = 1;
   auto ok = [&](int v) {
     const int cp = (a.C + v - 1) / v * v;
-    if (a.ldx < cp || a.ldo < cp || a.ldx % v || a.ldo % v) return false;
-    if (!aligned_to(a.x, 4 * v) || !aligned_to(a.out, 4 * v)) return false;
+    if (a.ldx < cp || a.ldx % v || !aligned_to(a.x, 4 * v)) return false;
+    if (a.out && (a.ldo < cp || a.ldo % v || !aligned_to(a.out, 4 * v))) return false;
     if (a.z && (a.ldz < cp || a.ldz % v || !aligned_to(a.z, 4 * v))) return false;
     return true;
   };
@@ -559,7 +572,7 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
     grid = dim3((unsigned)eblocks);
   }
   const bool epi = !IS_MAX && (a.z || a.bias || a.act || a.drop_p > 0.f);
-  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr, nullptr};
+  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr, nullptr, nullptr};
   if (pool) {     // the pooled form exists for the shape the models launch it with: ELL side table, 16-byte rows, an epilogue
     if (IS_MAX || !a.ell || vec != 4 || ipt != 2 || a.CV * 4 > kWave) return MLQEM_ERR_UNSUPPORTED;      // C <= 64: one wave holds a row of the tile
     if (rows_per_tile) *rows_per_tile = a.R;
@@ -645,9 +658,9 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
                                const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
-                               float* partial, int32_t* tile_graph, int* rows_per_tile, hipStream_t stream) {
+                               float* partial, int32_t* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream) {
   AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, seed_counter, out, ldo, N, C, 0, 0};
-  const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph};
+  const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph, gate_bits};
   return launch_aggregate<false>(a, stream, &pf, rows_per_tile);
 }
 

@@ -133,12 +133,14 @@ __global__ __launch_bounds__(kBlock) void pool_finish_kernel(const float* __rest
 constexpr int kPoolBwdItems = 4;
 constexpr int kPoolPtrCache = 64;
 
-template <int VEC, bool GATE>
+// GATE: 0 none, 1 the activation itself (gate > 0), 2 its sign bits (one byte per (row, 16-byte slice), as the pooled
+// aggregation leaves them: the gate then costs 1 byte per item instead of 16)
+template <int VEC, int GATE>
 __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restrict__ g0, int64_t ldg0, const float* __restrict__ g1,
                                                           int64_t ldg1, const float* __restrict__ wts,
                                                           const int32_t* __restrict__ gptr, int64_t N, int B, int CV,
                                                           const float* __restrict__ gate, int64_t ldgate, float gate_scale,
-                                                          float* __restrict__ gx, int64_t ldgx) {
+                                                          const uint8_t* __restrict__ gate_bits, float* __restrict__ gx, int64_t ldgx) {
   __shared__ int s_ptr[kPoolPtrCache + 1];
   __shared__ int s_g0;
   const int tid = threadIdx.x;
@@ -168,11 +170,14 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
     if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
     if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
     const float w = (g1 && wts) ? wts[r] : 1.f;
-    if (GATE) vload<VEC>(gate + r * ldgate + ch, gv);
+    unsigned bits = 0;
+    if (GATE == 1) vload<VEC>(gate + r * ldgate + ch, gv);
+    if (GATE == 2) bits = gate_bits[it];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float u = fmaf(w, a1[v], a0[v]) * inv;
-      if (GATE) u = gv[v] > 0.f ? u * gate_scale : 0.f;
+      if (GATE == 1) u = gv[v] > 0.f ? u * gate_scale : 0.f;
+      if (GATE == 2) u = ((bits >> v) & 1u) ? u * gate_scale : 0.f;
       o[v] = u;
     }
     vstore_nt<VEC>(gx + r * ldgx + ch, o);
@@ -291,7 +296,7 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
                                const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
-                               float* partial, int32_t* tile_graph, int* rows_per_tile, hipStream_t stream);
+                               float* partial, int32_t* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream);
 int aggregate_pool_rows_per_tile(int C);
 }  // namespace mlqem
 
@@ -308,12 +313,13 @@ extern "C" int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const i
                                             const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
                                             const uint64_t* seed_counter, float* out, int64_t ldo, int64_t N, int C,
                                             const float* pool_weights, const int32_t* graph_ptr, int64_t B, float* out_mean,
-                                            int64_t ld_mean, float* out_wmean, int64_t ld_wmean, void* workspace,
-                                            size_t workspace_bytes, mlqem_stream_t stream) {
+                                            int64_t ld_mean, float* out_wmean, int64_t ld_wmean, uint8_t* gate_bits,
+                                            void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || B < 0 || C <= 0 || drop_p < 0.f || drop_p >= 1.f || B > 0x7fffffffLL || N > 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
   if ((!out_mean && !out_wmean) || (out_mean && ld_mean < C) || (out_wmean && ld_wmean < C)) return MLQEM_ERR_BAD_ARG;
   if (!ell) return MLQEM_ERR_UNSUPPORTED;
+  if (!out && !gate_bits) return MLQEM_ERR_BAD_ARG;      // the activation may stay unwritten only when its gate bits are kept
   if (B == 0) return MLQEM_OK;
   if (!graph_ptr) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_csr_aggregate_pool_workspace_bytes(N, B, C)) return MLQEM_ERR_WORKSPACE;
@@ -324,7 +330,7 @@ extern "C" int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const i
     float* partial = static_cast<float*>(workspace);
     int32_t* tile_graph = reinterpret_cast<int32_t*>(partial + (tiles + B) * 2 * ((C + 3) / 4 * 4));
     const int rc = launch_aggregate_with_pool(x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed,
-                                              seed_counter, out, ldo, N, C, pool_weights, graph_ptr, (int)B, partial, tile_graph, &rows, s);
+                                              seed_counter, out, ldo, N, C, pool_weights, graph_ptr, (int)B, partial, tile_graph, gate_bits, &rows, s);
     if (rc != MLQEM_OK) return rc;
     if (rows != aggregate_pool_rows_per_tile(C)) return MLQEM_ERR_LAUNCH;      // the workspace was sized for another tiling
   } else {
@@ -338,8 +344,8 @@ extern "C" int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const i
 
 extern "C" int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const float* g_wmean, int64_t ld_gwmean,
                                           const float* weights, const int32_t* graph_ptr, int64_t N, int64_t B, int C,
-                                          const float* gate, int64_t ldgate, float gate_scale, float* gx, int64_t ldgx,
-                                          mlqem_stream_t stream) {
+                                          const float* gate, int64_t ldgate, float gate_scale, const uint8_t* gate_bits, float* gx,
+                                          int64_t ldgx, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || B < 0 || C <= 0 || ldgx < C || B > 0x7fffffffLL || N > 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
   if ((!g_mean && !g_wmean) || (g_mean && ld_gmean < C) || (g_wmean && ld_gwmean < C) || (gate && ldgate < C)) return MLQEM_ERR_BAD_ARG;
@@ -354,9 +360,12 @@ extern "C" int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean,
   if (blocks > 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
   hipStream_t s = as_stream(stream);
 #define MLQEM_POOL_BWD(V, G) hipLaunchKernelGGL((pool_bwd_kernel<V, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, g_mean, ld_gmean, \
-                                                g_wmean, ld_gwmean, weights, graph_ptr, N, (int)B, cv, gate, ldgate, gate_scale, gx, ldgx)
-  if (wide) { if (gate) MLQEM_POOL_BWD(4, true); else MLQEM_POOL_BWD(4, false); }
-  else { if (gate) MLQEM_POOL_BWD(1, true); else MLQEM_POOL_BWD(1, false); }
+                                                g_wmean, ld_gwmean, weights, graph_ptr, N, (int)B, cv, gate, ldgate, gate_scale, gate_bits, gx, ldgx)
+  if (gate_bits) {      // one byte per (row, 16-byte slice): the layout of the 16-byte form only
+    if (gate || !wide) return MLQEM_ERR_BAD_ARG;
+    MLQEM_POOL_BWD(4, 2);
+  } else if (wide) { if (gate) MLQEM_POOL_BWD(4, 1); else MLQEM_POOL_BWD(4, 0); }
+  else { if (gate) MLQEM_POOL_BWD(1, 1); else MLQEM_POOL_BWD(1, 0); }
 #undef MLQEM_POOL_BWD
   return launch_status();
 }

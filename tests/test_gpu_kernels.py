@@ -722,6 +722,23 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
         again = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=want_mean, wmean=True)
         ops.csr_aggregate(x, in_ptr, in_src, pool=again, **kw)          # a fixed summation order: the same bits every time
         assert torch.equal(again["out_wmean"], req["out_wmean"])
+    # the gate bits, and the form that writes nothing but them: bit v of (row, slice) = (out[row, 4 slice + v] > 0); the pool's
+    # backward gated by the bits equals the one gated by the activation
+    req = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=True, wmean=True, bits=True, store=False)
+    assert ops.csr_aggregate(x, in_ptr, in_src, pool=req, **kw) is None
+    cv = (c + 3) // 4
+    padded = torch.zeros(n, cv * 4, device=DEV)
+    padded[:, :c] = plain
+    want_bits = ((padded.reshape(n, cv, 4) > 0).to(torch.int32) * torch.tensor([1, 2, 4, 8], device=DEV, dtype=torch.int32)).sum(-1)
+    valid = torch.ones(cv, 4, dtype=torch.bool, device=DEV).reshape(-1)
+    valid[c:] = False
+    mask_of_valid = (valid.reshape(cv, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], device=DEV, dtype=torch.int32)).sum(-1)
+    got_bits = req["out_bits"].reshape(n, cv).to(torch.int32) & mask_of_valid          # the pad columns' bits are scratch
+    assert torch.equal(got_bits, want_bits.to(torch.int32))
+    gm, gwm = torch.randn(b, c, device=DEV), torch.randn(b, c, device=DEV)
+    by_act = ops.segment_pool_bwd(gm, gwm, gp, n, weights=wts, gate=plain, gate_scale=1.25)
+    by_bits = ops.segment_pool_bwd(gm, gwm, gp, n, weights=wts, gate_bits=req["out_bits"], gate_scale=1.25)
+    assert torch.equal(by_act, by_bits)
     # the switch restores the two-launch form (results agree to fp32 rounding of another summation order)
     ops._POOL_FUSED = False
     try:
