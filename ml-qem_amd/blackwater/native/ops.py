@@ -202,11 +202,11 @@ def pooled_means(out, pool):
                         wmean=bool(pool.get("wmean", True)))
 
 
-# MLQEM_POOL_FUSED=1: the pooled means from the aggregation launch itself (mlqem_csr_aggregate_pool_f32).  Off by default: on the
-# bench's step it is a wash against the two-launch form (6.91-6.97 vs 6.94-6.98 ms per step on one box; a first version with
-# workgroup barriers at the end of the kernel LOST 0.2-0.6 ms) -- what the pool kernels' second read of the activation costs,
-# the aggregation kernel pays in LDS footprint and in a tail that one wave per workgroup runs alone; see DESIGN.md section 9.
-_POOL_FUSED = __import__("os").environ.get("MLQEM_POOL_FUSED", "0") == "1"
+# MLQEM_POOL_FUSED=0: aggregation, pool and a stored activation as separate steps (A/B).  Default: the pooled means AND the gate
+# bits of a branch's last hidden activation come out of the aggregation launch that computes it (mlqem_csr_aggregate_pool_f32),
+# and the activation itself is never written: 6.75-6.80 against 6.97-7.09 ms per bench step on one box.  (With the activation
+# still stored the fused form was a wash: DESIGN.md section 3.)
+_POOL_FUSED = __import__("os").environ.get("MLQEM_POOL_FUSED", "1") != "0"
 
 
 def _ell(ell, n):

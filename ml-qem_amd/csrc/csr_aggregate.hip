@@ -43,7 +43,7 @@ struct PoolFuse {
   const int32_t* gptr;     // [B+1]
   int B;
   float* partial;          // [(tiles + B)][2][CV * VEC]
-  const int32_t* tile_graph;   // [tiles]: the graph of each tile's first row (tile_graph_kernel)
+  const int2* tile_graph;  // [tiles]: (graph of the tile's first row, first row of the NEXT graph) (tile_graph_kernel)
   uint8_t* mask;           // optional [N * CV]: bit v of entry (row, slice) = (out[row, 4 slice + v] > 0) -- what the pooled
                            // activation's only reader in the backward needs of it (the ReLU / dropout gate); with it the caller
                            // may pass out == NULL and the activation never reaches memory
@@ -52,9 +52,11 @@ struct PoolFuse {
 // graph of the first row of every tile of `rows` rows: one binary search per tile, outside the kernel that needs it (inside,
 // its ten dependent scalar loads sat in front of every later scalar or LDS wait of the workgroup)
 __global__ __launch_bounds__(kBlock) void tile_graph_kernel(const int32_t* __restrict__ gptr, int B, int rows, int64_t tiles,
-                                                            int32_t* __restrict__ out) {
+                                                            int2* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t < tiles) out[t] = graph_at(gptr, B, t * rows);
+  if (t >= tiles) return;
+  const int g = graph_at(gptr, B, t * rows);
+  out[t] = make_int2(g, gptr[g + 1]);       // with the boundary behind it: a tile inside one graph needs nothing else at its end
 }
 
 constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rscale / dself)
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   // POOL: the ticket counter starts at zero (the one barrier, at the start where every wave is anyway and nothing is in
   // flight); the rows' pooling weights are fetched now and parked in LDS just before the ticket is taken
   float wreg[kItemsPerThread];
+  int2 tinfo = make_int2(0, 0);
   if constexpr (POOL) {
     if (tid == 0) s_done = 0;
     __syncthreads();
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
       const int r = k * kBlock + tid;
       wreg[k] = (pf.wts && r < nrows) ? pf.wts[r0 + r] : 1.f;
     }
+    tinfo = pf.tile_graph[blk];                     // needed by the last wave at the very end: fetched now, not waited for then
   }
 
   int row[kItemsPerThread], ch[kItemsPerThread];
@@ -488,10 +492,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     const int groups = kWave / a.CV;              // CV <= 64: checked on the host
     const int sl = lane / groups, grp = lane - sl * groups;
     const bool active = sl < a.CV;
-    const int g_first = pf.tile_graph[blk];
-    for (int g = g_first; g < pf.B && (int64_t)pf.gptr[g] < r0 + nrows; ++g) {   // wave-uniform loop
-      const int s0 = (int)(max(r0, (int64_t)pf.gptr[g]) - r0), s1 = (int)(min(r0 + nrows, (int64_t)pf.gptr[g + 1]) - r0);
-      if (s1 <= s0) continue;                     // an empty graph
+    // the graphs with rows in this tile, in order (wave-uniform loop): the first one and its end came with tinfo; a further
+    // boundary is loaded only by the tiles that contain one
+    int g = tinfo.x;
+    int64_t gbeg = r0, gend = tinfo.y;
+    for (;; ) {
+      const int s0 = (int)(max(r0, gbeg) - r0), s1 = (int)(min(r0 + nrows, gend) - r0);
+      const bool more = gend < r0 + nrows && g + 1 < pf.B;
+      if (s1 <= s0) {                             // an empty graph
+        if (!more) break;
+        ++g; gbeg = gend; gend = pf.gptr[g + 1];
+        continue;
+      }
       float a0[VEC], a1[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) a0[v] = a1[v] = 0.f;
@@ -516,6 +528,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
 #pragma unroll
         for (int v = 0; v < VEC; ++v) { dst[v] = a0[v]; dst[cvv + v] = a1[v]; }
       }
+      if (!more) break;
+      ++g; gbeg = gend; gend = pf.gptr[g + 1];
     }
   }
 }
@@ -577,7 +591,7 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
     if (IS_MAX || !a.ell || vec != 4 || ipt != 2 || a.CV * 4 > kWave) return MLQEM_ERR_UNSUPPORTED;      // C <= 64: one wave holds a row of the tile
     if (rows_per_tile) *rows_per_tile = a.R;
     hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)ceil_div((int64_t)grid.x, kBlock)), dim3(kBlock), 0, stream, pool->gptr, pool->B,
-                       a.R, (int64_t)grid.x, const_cast<int32_t*>(pool->tile_graph));
+                       a.R, (int64_t)grid.x, const_cast<int2*>(pool->tile_graph));
     if constexpr (!IS_MAX) {
       static const int pool_waves = getenv("MLQEM_AGG_POOL_WAVES") ? atoi(getenv("MLQEM_AGG_POOL_WAVES")) : 7;
       if (pool_waves >= 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<4, false, 2, true, 7, true>), grid, block, 0, stream, a, *pool);
@@ -658,7 +672,7 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
                                const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
-                               float* partial, int32_t* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream) {
+                               float* partial, int2* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream) {
   AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, seed_counter, out, ldo, N, C, 0, 0};
   const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph, gate_bits};
   return launch_aggregate<false>(a, stream, &pf, rows_per_tile);

@@ -126,6 +126,32 @@ __global__ __launch_bounds__(kBlock) void pool_finish_kernel(const float* __rest
   if (out_wmean) out_wmean[(int64_t)g * ld1 + c] = s1;
 }
 
+// The same second stage for the pooled aggregation's tiles (170 rows each: a 100-qubit circuit spans ~65 of them, and one thread
+// walking 65 strided partials per (graph, channel) took 59 us): a workgroup per graph, eight tile lanes x 32 value lanes (the
+// 2 x slot_w sums of a partial), every lane adds every eighth tile in order, the eight lanes are added in order.
+__global__ __launch_bounds__(kBlock) void pool_finish_tiles_kernel(const float* __restrict__ partial, const int32_t* __restrict__ gptr,
+                                                                   int C, int slot_w, int rows, float* __restrict__ out_mean,
+                                                                   int64_t ld0, float* __restrict__ out_wmean, int64_t ld1) {
+  __shared__ float s_t[8][32];
+  const int g = blockIdx.x, vl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int beg = gptr[g], end = gptr[g + 1];
+  const int which = vl / slot_w, c = vl - which * slot_w;         // 2 slot_w <= 32: checked on the host
+  float t = 0.f;
+  if (end > beg && vl < 2 * slot_w) {
+    const int64_t t_first = beg / rows, t_last = (end - 1) / rows;
+    for (int64_t tile = t_first + tl; tile <= t_last; tile += 8) t += partial[((tile + g) * 2 + which) * slot_w + c];
+  }
+  s_t[tl][vl] = t;
+  __syncthreads();
+  if (tl != 0 || vl >= 2 * slot_w || c >= C) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tot += s_t[k][vl];
+  tot = end > beg ? tot / (float)(end - beg) : 0.f;
+  if (which == 0) { if (out_mean) out_mean[(int64_t)g * ld0 + c] = tot; }
+  else if (out_wmean) out_wmean[(int64_t)g * ld1 + c] = tot;
+}
+
 // Backward: gx[r,:] = (g_mean[g,:] + wts[r] * g_wmean[g,:]) / n_g, g = graph of row r, optionally gated by the ReLU/dropout
 // mask of the activation that was pooled (gx = gate[r,:] > 0 ? gx * gate_scale : 0 -- the mask hand-over of the layer
 // nodes).  Items = (row, 16-byte channel slice) numbered row-major, kPoolBwdItems per thread; the workgroup finds the
@@ -151,6 +177,17 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
   __syncthreads();
   const int gbase = s_g0;
   if (tid <= kPoolPtrCache) s_ptr[tid] = gptr[min(gbase + tid, B)];
+  // the [B, C] gradient rows of the first two graphs of this workgroup's rows (341 rows: nearly always all of them) in LDS:
+  // read per item from memory they were two more 16-byte requests per item on a kernel whose requests, not bytes, are its limit
+  __shared__ float s_g[2][2][64];
+  const int cw = CV * VEC;
+  if (cw <= 64 && tid < 4 * cw) {
+    const int gg = tid / (2 * cw), which = (tid / cw) & 1, c = tid % cw;
+    const int g = min(gbase + gg, B - 1);
+    const float* src = which ? g1 : g0;
+    const int64_t ld = which ? ldg1 : ldg0;
+    s_g[gg][which][c] = src ? src[(int64_t)g * ld + c] : 0.f;
+  }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kPoolBwdItems; ++k) {
@@ -167,12 +204,18 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
     float a0[VEC], a1[VEC], gv[VEC], o[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) a0[v] = a1[v] = 0.f;
-    if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
-    if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
+    if (j < 2 && cw <= 64) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { a0[v] = s_g[j][0][ch + v]; a1[v] = s_g[j][1][ch + v]; }
+    } else {
+      if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
+      if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
+    }
     const float w = (g1 && wts) ? wts[r] : 1.f;
     unsigned bits = 0;
     if (GATE == 1) vload<VEC>(gate + r * ldgate + ch, gv);
-    if (GATE == 2) bits = gate_bits[it];
+    if (GATE == 2) bits = gate_bits[it];       // (a thread's four items as ONE 4-byte load needs them consecutive, and consecutive
+                                               // items per thread scatter the 16-byte stores: 174 -> 846 us; measured, reverted)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float u = fmaf(w, a1[v], a0[v]) * inv;
@@ -296,14 +339,14 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                const float* rscale, const float* dself, float alpha, float beta, const float* z, int64_t ldz,
                                const float* bias, int act, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* out,
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
-                               float* partial, int32_t* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream);
+                               float* partial, int2* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream);
 int aggregate_pool_rows_per_tile(int C);
 }  // namespace mlqem
 
 extern "C" size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C) {
   if (N < 0 || B < 0 || C <= 0) return 0;
   const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), aggregate_pool_rows_per_tile(C));
-  return (size_t)(tiles + B) * 2 * ((C + 3) / 4 * 4) * sizeof(float) + (size_t)tiles * sizeof(int32_t);     // partial sums | tile -> graph
+  return (size_t)(tiles + B) * 2 * ((C + 3) / 4 * 4) * sizeof(float) + (size_t)tiles * sizeof(int2);     // partial sums | tile -> (graph, next boundary)
 }
 
 // mlqem_csr_aggregate_f32 and mlqem_segment_pool_f32 of its output in one pass over the rows: the aggregation's workgroups
@@ -328,7 +371,7 @@ extern "C" int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const i
   if (N > 0) {
     const int64_t tiles = ceil_div(N, aggregate_pool_rows_per_tile(C));
     float* partial = static_cast<float*>(workspace);
-    int32_t* tile_graph = reinterpret_cast<int32_t*>(partial + (tiles + B) * 2 * ((C + 3) / 4 * 4));
+    int2* tile_graph = reinterpret_cast<int2*>(partial + (tiles + B) * 2 * ((C + 3) / 4 * 4));
     const int rc = launch_aggregate_with_pool(x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed,
                                               seed_counter, out, ldo, N, C, pool_weights, graph_ptr, (int)B, partial, tile_graph, gate_bits, &rows, s);
     if (rc != MLQEM_OK) return rc;
@@ -337,8 +380,12 @@ extern "C" int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const i
     rows = aggregate_pool_rows_per_tile(C);
   }
   const int c4 = (C + 3) / 4 * 4;
-  hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)ceil_div(B * C, kBlock)), dim3(kBlock), 0, s, static_cast<const float*>(workspace),
-                     graph_ptr, (int)B, C, c4, rows, out_mean, ld_mean, out_wmean, ld_wmean);
+  if (2 * c4 <= 32)
+    hipLaunchKernelGGL(pool_finish_tiles_kernel, dim3((unsigned)B), dim3(kBlock), 0, s, static_cast<const float*>(workspace), graph_ptr, C, c4,
+                       rows, out_mean, ld_mean, out_wmean, ld_wmean);
+  else
+    hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)ceil_div(B * C, kBlock)), dim3(kBlock), 0, s, static_cast<const float*>(workspace),
+                       graph_ptr, (int)B, C, c4, rows, out_mean, ld_mean, out_wmean, ld_wmean);
   return launch_status();
 }
 

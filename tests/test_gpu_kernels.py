@@ -701,7 +701,6 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
     gp = torch.from_numpy(gptr.astype(np.int32)).to(DEV)
     kw = dict(ell=ell, rscale=rs, dself=rs, z=z, beta=0.5, bias=bias, relu=True)
     plain = ops.csr_aggregate(x, in_ptr, in_src, **kw)
-    ops._POOL_FUSED = True          # off by default (it loses on the bench's step: ops.py); the entry point is kept correct
     for want_mean in (True, False):
         req = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=want_mean, wmean=True)
         out = ops.csr_aggregate(x, in_ptr, in_src, pool=req, **kw)
@@ -749,9 +748,6 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
     finally:
         ops._POOL_FUSED = True
     one = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=True, wmean=True)
-    try:
-        ops.csr_aggregate(x, in_ptr, in_src, pool=one, **kw)
-    finally:
-        ops._POOL_FUSED = False
+    ops.csr_aggregate(x, in_ptr, in_src, pool=one, **kw)
     assert (one["out_mean"] - two["out_mean"]).abs().max().item() <= 1e-5 * max(plain.abs().max().item(), 1.0)
     assert (one["out_wmean"] - two["out_wmean"]).abs().max().item() <= 1e-5 * max(plain.abs().max().item(), 1.0)
