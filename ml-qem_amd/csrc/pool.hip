@@ -177,17 +177,6 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
   __syncthreads();
   const int gbase = s_g0;
   if (tid <= kPoolPtrCache) s_ptr[tid] = gptr[min(gbase + tid, B)];
-  // the [B, C] gradient rows of the first two graphs of this workgroup's rows (341 rows: nearly always all of them) in LDS:
-  // read per item from memory they were two more 16-byte requests per item on a kernel whose requests, not bytes, are its limit
-  __shared__ float s_g[2][2][64];
-  const int cw = CV * VEC;
-  if (cw <= 64 && tid < 4 * cw) {
-    const int gg = tid / (2 * cw), which = (tid / cw) & 1, c = tid % cw;
-    const int g = min(gbase + gg, B - 1);
-    const float* src = which ? g1 : g0;
-    const int64_t ld = which ? ldg1 : ldg0;
-    s_g[gg][which][c] = src ? src[(int64_t)g * ld + c] : 0.f;
-  }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kPoolBwdItems; ++k) {
@@ -204,13 +193,9 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
     float a0[VEC], a1[VEC], gv[VEC], o[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) a0[v] = a1[v] = 0.f;
-    if (j < 2 && cw <= 64) {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) { a0[v] = s_g[j][0][ch + v]; a1[v] = s_g[j][1][ch + v]; }
-    } else {
-      if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
-      if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
-    }
+    // (the two [B, C] gradient rows staged in LDS per workgroup instead: 174 -> 211 us, measured and reverted)
+    if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
+    if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
     const float w = (g1 && wts) ? wts[r] : 1.f;
     unsigned bits = 0;
     if (GATE == 1) vload<VEC>(gate + r * ldgate + ch, gv);

@@ -739,14 +739,13 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
     by_bits = ops.segment_pool_bwd(gm, gwm, gp, n, weights=wts, gate_bits=req["out_bits"], gate_scale=1.25)
     assert torch.equal(by_act, by_bits)
     # the switch restores the two-launch form (results agree to fp32 rounding of another summation order)
-    ops._POOL_FUSED = False
-    try:
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr(ops, "_POOL_FUSED", False)
         two = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=True, wmean=True)
         o2 = ops.csr_aggregate(x, in_ptr, in_src, pool=two, **kw)
         assert "out_mean" not in two                      # switched off: the caller pools
         two["out_mean"], two["out_wmean"] = ops.pooled_means(o2, two)
-    finally:
-        ops._POOL_FUSED = True
+    assert ops._POOL_FUSED
     one = dict(graph_ptr=gp, num_graphs=b, weights=wts, mean=True, wmean=True)
     ops.csr_aggregate(x, in_ptr, in_src, pool=one, **kw)
     assert (one["out_mean"] - two["out_mean"]).abs().max().item() <= 1e-5 * max(plain.abs().max().item(), 1.0)
