@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 20 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 21 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -324,12 +324,15 @@ int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const void* h, cons
 
 /* Backward of a narrow hidden layer (I, O <= 12) in ONE pass over its operands:
  *   gx[n,:] = (x[n,:] > 0 ? gate_scale : 0) * (gy[n,:] @ W)   (gate != 0; plain gy @ W otherwise)      W: [O, I]
- *   gw2[0:O, :] = gy^T x,   gb2[12:12+O] = sum_n gb_src[n,:]   (gw2: [24, I], gb2: [24] -- the layout of
+ *   gw2[0:O, :] = gy^T x,   gb2[12:12+O] = sum_n gb_src[n,:]   (gw2: [25, I], gb2: [25] -- rows 0..23 in the layout of
  *   mlqem_linear_wgrad_parts_f32 over the two 12-wide blocks [gy | gb_src]; gb_src = NULL means gy)
+ *   gw2[24, 0:I] = sum_n gx[n,:]   (the bias gradient of the layer BELOW when an aggregation sits between the two layers, as
+ *   with GCNConv: conv1's bias gradient is the column sum of what conv2's backward writes, so the first-layer weight-gradient
+ *   pass reads one block less; gb2[24] is written as 0)
  * Replaces the autograd of torch_geometric's GCNConv linear (01_ngem.ipynb cell [9], conv2: gy = the transposed
  * aggregation of the incoming gradient, gb_src = that gradient itself, x = the previous activation whose ReLU/dropout
  * mask is handed over) with one read of gy, x and gb_src instead of two.  Padded 16-byte rows required.
- * workspace: mlqem_linear_wgrad_workspace_bytes(I, 24). */
+ * workspace: mlqem_linear_wgrad_workspace_bytes(I, 25). */
 int mlqem_linear_bwd_fused_f32(const float* gy, int64_t ldgy, const float* gb_src, int64_t ldgbs, const float* x, int64_t ldx,
                                const float* w, int gate, float gate_scale, float* gx, int64_t ldgx, float* gw2, float* gb2,
                                int64_t N, int I, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);

@@ -525,7 +525,7 @@ class _GCNLayer(Function):
         if (_FUSE_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.x_gate_scale is not None
                 and max(w.shape) <= 12 and ops._fused_bwd_ok(gh, g, x)):
             # hidden layer of width <= 12 (conv2): gated data gradient, weight and bias gradient from ONE pass over gh, x, g
-            gx, gw, gb = ops.linear_bwd_fused(gh, x, w.contiguous(), gb_src=g, gate_scale=ctx.x_gate_scale)
+            gx, gw, gb, ctx.gx_colsum = ops.linear_bwd_fused(gh, x, w.contiguous(), gb_src=g, gate_scale=ctx.x_gate_scale)
             return gx, gw, gb, None, None, None, None, None, None
         gx = None
         if ctx.needs_input_grad[0]:
@@ -792,6 +792,10 @@ class _LayerCtx:
         self.saved_tensors = tensors
 
 
+# MLQEM_BIAS_FROM_PRODUCER=0: conv1's bias gradient from a seventh block of the first-layer weight-gradient pass (A/B)
+_BIAS_FROM_PRODUCER = os.environ.get("MLQEM_BIAS_FROM_PRODUCER", "1") != "0"
+
+
 class _FamilyAGraph(Function):
     """pooled [B, 3] = [GCN x3 | Cheb x2 | SAGE x2 branch, each mean-pooled] of the node features (01_ngem.ipynb cell [9]).
 
@@ -897,6 +901,9 @@ class _FamilyAGraph(Function):
         # GCN branch, last layer first: pooled = wmean(h) W^T + b
         t = ops.segment_pool_bwd(None, ggw, gptr, n, weights=struct.colsum("gcn"), gate=hg if bg_ is None else None, gate_scale=k1, gate_bits=bg_)
         t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
+        # conv1's bias gradient is the column sum of the gradient conv2's backward just wrote: taken there, the first-layer
+        # weight-gradient pass below reads six blocks instead of seven
+        g1b_cs = getattr(L["g2"], "gx_colsum", None) if _BIAS_FROM_PRODUCER else None
         fuse = ctx.fuse
         if fuse:
             bg = _GCNLayer.backward(L["g1"], t, blocks_only=True)            # [gh, g]
@@ -925,13 +932,15 @@ class _FamilyAGraph(Function):
             ow = (o + 3) // 4 * 4
             for blk in bc + bs:
                 blk.record_stream(main)
-            gw7 = torch.empty((7 * ow, i), dtype=torch.float32, device=g.device)
-            gb7 = torch.empty(7 * ow, dtype=torch.float32, device=g.device)
-            ops.linear_wgrad_parts(bg + bc + bs, x0, gw7, gb7)
-            gw7 = gw7.reshape(7, ow, i)[:, :o]
-            g1w, g1b = gw7[0], gb7[ow:ow + o]
-            c1w0, c1w1, c1w2, c1b = gw7[2], gw7[3], gw7[4] - gw7[2], gb7[2 * ow:2 * ow + o]
-            s1l, s1r, s1b = gw7[5], gw7[6], gb7[6 * ow:6 * ow + o]
+            blks = ([bg[0]] if g1b_cs is not None else bg) + bc + bs
+            nb, k = len(blks), len(blks) - 5             # k: index of the first Cheb block
+            gwn = torch.empty((nb * ow, i), dtype=torch.float32, device=g.device)
+            gbn = torch.empty(nb * ow, dtype=torch.float32, device=g.device)
+            ops.linear_wgrad_parts(blks, x0, gwn, gbn)
+            gwn = gwn.reshape(nb, ow, i)[:, :o]
+            g1w, g1b = gwn[0], (g1b_cs[:o] if g1b_cs is not None else gbn[ow:ow + o])
+            c1w0, c1w1, c1w2, c1b = gwn[k], gwn[k + 1], gwn[k + 2] - gwn[k], gbn[k * ow:k * ow + o]
+            s1l, s1r, s1b = gwn[k + 3], gwn[k + 4], gbn[(k + 4) * ow:(k + 4) * ow + o]
         for t in (gcm, gcw, gsm, gsw):        # made on the compute stream, consumed by the side streams
             t.record_stream(side[0] if t is gcm or t is gcw else side[1])
         for t in (() if fuse else (c1b, c1w0, c1w1, c1w2, s1l, s1b, s1r)):

@@ -766,17 +766,18 @@ _pool_ws = {}   # (device, stream, bytes) -> partial-sum workspace of the poolin
 
 
 def linear_bwd_fused(gy, x, w, gb_src=None, gate_scale=None):
-    """(gx, gw, gb) of a narrow hidden layer in one pass (mlqem_linear_bwd_fused_f32): gx = gate(x) * (gy @ w),
-    gw = gy.T @ x, gb = gb_src.sum(0) (gb_src defaults to gy).  All row operands in the padded layout, I, O <= 12."""
+    """(gx, gw, gb, gx_colsum) of a narrow hidden layer in one pass (mlqem_linear_bwd_fused_f32): gx = gate(x) * (gy @ w),
+    gw = gy.T @ x, gb = gb_src.sum(0) (gb_src defaults to gy), gx_colsum = gx.sum(0) (the bias gradient of the layer below when
+    an aggregation sits between the two).  All row operands in the padded layout, I, O <= 12."""
     n, o = gy.shape
     i = x.shape[1]
     if tuple(w.shape) != (o, i) or not w.is_contiguous() or x.shape[0] != n or (gb_src is not None and gb_src.shape != gy.shape):
         raise ValueError("linear_bwd_fused: shape mismatch")
     gx = padded_empty(n, i, gy.device)
-    gw2 = torch.empty((24, i), dtype=torch.float32, device=gy.device)
-    gb2 = torch.empty(24, dtype=torch.float32, device=gy.device)
+    gw2 = torch.empty((25, i), dtype=torch.float32, device=gy.device)
+    gb2 = torch.empty(25, dtype=torch.float32, device=gy.device)
     lib = _lib.load()
-    need = lib.mlqem_linear_wgrad_workspace_bytes(i, 24)
+    need = lib.mlqem_linear_wgrad_workspace_bytes(i, 25)
     ws = _wgrad_workspace(gy.device, need)
     if not _fused_bwd_ok(gy, x, *([gb_src] if gb_src is not None else [])):
         raise ValueError("linear_bwd_fused: operands must be 2-D fp32 matrices of <= 12 columns in the padded row layout")
@@ -785,7 +786,7 @@ def linear_bwd_fused(gy, x, w, gb_src=None, gate_scale=None):
                                           0 if gate_scale is None else 1, float(gate_scale or 1.0), _p(gx), ld(gx), _p(gw2),
                                           _p(gb2), n, i, o, _p(ws), need, _stream())
     _lib.check(code, "mlqem_linear_bwd_fused_f32")
-    return gx, gw2[:o], gb2[12:12 + o]
+    return gx, gw2[:o], gb2[12:12 + o], gw2[24]
 
 
 def _fused_bwd_ok(*mats):

@@ -893,6 +893,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_pipe_kernel(const WgradArgs a) {
 // region; the data gradient is one MFMA tile (W^T as the A operand, as in linear_mfma_v4_kernel), the two gradient tiles
 // ([gy | gb_src]^T against [x | 1]) accumulate over the wave's tiles with K = the rows, as in wgrad_mfma_kernel; partials
 // per workgroup, fixed-order second stage (wgrad_reduce_kernel): deterministic.
+constexpr int kBwdFusedRows = 25;   // rows of the fused backward's gradient image: [gy^T x | gb_src^T x | colsum(gx)]
 struct BwdFusedArgs {
   const float* gy; int64_t ldgy; const float* gbs; int64_t ldgbs; const float* x; int64_t ldx; const float* w;
   float gate_scale; int gate;
@@ -914,6 +915,7 @@ __global__ __launch_bounds__(kBlock) void linear_bwd_fused_kernel(const BwdFused
     wf[s4] = (lr < a.I && o < a.O) ? a.w[(int64_t)o * a.I + lr] : 0.f;
   }
   f32x4 acc_w = f32x4{0.f, 0.f, 0.f, 0.f}, acc_b = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};       // this lane's share of sum_n gx[n, 4 lq .. + 3]
   const int tr = lane / 3, tc = (lane - tr * 3) * 4;      // this lane's float4 of a 16 x 12 tile (lanes 0..47)
   const bool loader = lane < 48;
   float (*t_gy)[12] = s_t[wid][0];
@@ -959,6 +961,8 @@ __global__ __launch_bounds__(kBlock) void linear_bwd_fused_kernel(const BwdFused
         v[2] = xv.z > 0.f ? v[2] * a.gate_scale : 0.f; v[3] = xv.w > 0.f ? v[3] * a.gate_scale : 0.f;
       }
       vstore_nt<4>(a.gx + (r0 + lr) * a.ldgx + 4 * lq, v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[r] += v[r];
     }
     // weight / bias gradients: A[m = o][k = row], B[k = row][n = i]; column I of B is the ones column
 #pragma unroll
@@ -974,7 +978,23 @@ __global__ __launch_bounds__(kBlock) void linear_bwd_fused_kernel(const BwdFused
   }
   // partials: [workgroup][(block * 12 + o) * (I + 1) + i], block 0 = gy rows, block 1 = gb_src rows (the layout of
   // mlqem_linear_wgrad_parts_f32 with two 12-wide blocks)
-  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * 24 * I1;
+  float* __restrict__ dst = a.partial + (int64_t)blockIdx.x * kBwdFusedRows * I1;
+  // row 24: the column sums of gx (what the layer BELOW needs as its bias gradient when its own aggregation sits between the two:
+  // the first-layer weight-gradient pass then has one block less to read)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) cs[r] += __shfl_xor(cs[r], o);
+  }
+  float* s_cs = reinterpret_cast<float*>(&s_t[0][0][0][0]);      // [4][12], the tiles are done with
+  __syncthreads();
+  if (lr == 0 && lq < 3) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_cs[wid * 12 + 4 * lq + r] = cs[r];
+  }
+  __syncthreads();
+  if (threadIdx.x < I1)
+    dst[24 * I1 + threadIdx.x] = threadIdx.x < a.I ? (s_cs[threadIdx.x] + s_cs[12 + threadIdx.x]) + (s_cs[24 + threadIdx.x] + s_cs[36 + threadIdx.x]) : 0.f;
 #pragma unroll
   for (int tile = 0; tile < 2; ++tile) {
     s_acc[wid][lane] = tile == 0 ? acc_w : acc_b;
@@ -1070,7 +1090,9 @@ __global__ __launch_bounds__(kBlock) void wgrad_bf16_kernel(const WgradArgs a) {
 constexpr int kReducePairs = 64, kReduceSlices = 16;
 __global__ __launch_bounds__(kReducePairs * kReduceSlices) void wgrad_reduce_kernel(const float* __restrict__ partial, int G, int I, int O,
                                                                                    float* __restrict__ gw, float* __restrict__ gb,
-                                                                                   int accumulate) {
+                                                                                   int accumulate, int pack_w, int pack_c) {
+  // pack_c > 0: the partials hold blocks of pack_c rows back to back (the first stage packed the real columns of pack_w-wide
+  // blocks into fewer MFMA tiles); gw / gb keep pack_w rows per block, the pad rows written as zeros
   __shared__ float s[kReduceSlices][kReducePairs];
   const int I1 = I + 1, pairs = O * I1;
   const int pl = threadIdx.x % kReducePairs, sl = threadIdx.x / kReducePairs;
@@ -1096,7 +1118,16 @@ __global__ __launch_bounds__(kReducePairs * kReduceSlices) void wgrad_reduce_ker
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < kReduceSlices; ++k) tot += s[k][pl];
-    const int o = p / I1, k = p % I1;
+    int o = p / I1;
+    const int k = p % I1;
+    if (pack_c > 0) {
+      const int part = o / pack_c, lc = o - part * pack_c;
+      o = part * pack_w + lc;
+      if (!accumulate && lc < pack_w - pack_c) {          // pack_w - pack_c <= pack_c (checked by the launcher)
+        if (k < I) gw[(o + pack_c) * I + k] = 0.f;
+        else if (gb) gb[o + pack_c] = 0.f;
+      }
+    }
     if (k < I) {
       float* d = gw + o * I + k;
       *d = accumulate ? *d + tot : tot;
@@ -1392,14 +1423,24 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob <= 6 && ib <= 2 && pipe_env && uniform_ld) {
-    // the seven first-layer blocks: software-pipelined form (see wgrad_pipe_kernel)
+    // the first-layer blocks: software-pipelined form (see wgrad_pipe_kernel).  Blocks are 12 floats wide with 10 real columns:
+    // the MFMA rows take the REAL columns back to back (six blocks: 60 rows = four tiles instead of 72 = five; seven: five instead
+    // of six) -- fewer load instructions and a third fewer MFMAs for the same bytes; the second stage spreads them out again.
+    static const int pack_env = getenv("MLQEM_WGRAD_PACK") ? atoi(getenv("MLQEM_WGRAD_PACK")) : 1;
+    const int obp = (a.gn * a.gc + 15) / 16;
+    const bool pack = pack_env && a.gn > 1 && a.gc < a.gw && a.gw - a.gc <= a.gc && obp < ob && obp >= 4 && pipe_env == 2;
+    const int pw = a.gw, pc = a.gc;
+    if (pack) { a.gw = a.gc; a.O = a.gn * a.gc; }
+    static const int res4p = resident_workgroups(wgrad_pipe_kernel<4, 2, 2, 2>), res5p = resident_workgroups(wgrad_pipe_kernel<5, 2, 2, 2>);
     static const int res2 = resident_workgroups(wgrad_pipe_kernel<6, 2, 2, 2>), res4 = resident_workgroups(wgrad_pipe_kernel<6, 2, 4, 2>);
-    const int want = pipe_grid > 0 ? 256 * pipe_grid : (pipe_env == 2 ? res2 : res4);      // one resident round exactly
+    const int want = pipe_grid > 0 ? 256 * pipe_grid : (pack ? (obp == 4 ? res4p : res5p) : pipe_env == 2 ? res2 : res4);      // one resident round exactly
     const int Gp = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(kWgradBlocks, want), ceil_div(ceil_div(a.N, 16), 4)));
-    if (pipe_env == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<6, 2, 2, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
+    if (pack && obp == 4) hipLaunchKernelGGL((wgrad_pipe_kernel<4, 2, 2, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
+    else if (pack) hipLaunchKernelGGL((wgrad_pipe_kernel<5, 2, 2, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
+    else if (pipe_env == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<6, 2, 2, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
     else hipLaunchKernelGGL((wgrad_pipe_kernel<6, 2, 4, 2>), dim3(Gp), dim3(kBlock), 0, s, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial,
-                       Gp, a.I, a.O, gw, gb, accumulate);
+                       Gp, a.I, a.O, gw, gb, accumulate, pack ? pw : 0, pack ? pc : 0);
     return launch_status();
   } else if (ob <= 6 && ib <= 2) {
     if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
@@ -1412,7 +1453,7 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
                        0, s, a);
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial,
-                     G, a.I, a.O, gw, gb, accumulate);
+                     G, a.I, a.O, gw, gb, accumulate, 0, 0);
   return launch_status();
 }
 
@@ -1460,7 +1501,7 @@ extern "C" int mlqem_linear_wgrad_bf16_f32(const float* gy, int64_t ldgy, const 
   const int ob = (O + 15) / 16, ib = (I + 1 + 15) / 16;
   hipLaunchKernelGGL((wgrad_bf16_kernel<2, 2>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 2))), dim3(kBlock), 0, s, a);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(O * (I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial, G, I, O,
-                     gw, gb, accumulate);
+                     gw, gb, accumulate, 0, 0);
   return launch_status();
 }
 
@@ -1471,7 +1512,7 @@ extern "C" int mlqem_linear_bwd_fused_f32(const float* gy, int64_t ldgy, const f
   begin_launches();
   if (N < 0 || I <= 0 || O <= 0 || !gw2 || !gb2) return MLQEM_ERR_BAD_ARG;
   if (I > 12 || O > 12) return MLQEM_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, 24)) return MLQEM_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < mlqem_linear_wgrad_workspace_bytes(I, kBwdFusedRows)) return MLQEM_ERR_WORKSPACE;
   if (N > 0 && (!gy || !x || !w || !gx)) return MLQEM_ERR_BAD_ARG;
   if (!gb_src) { gb_src = gy; ldgbs = ldgy; }
   auto rows_ok = [](const float* p, int64_t ld, int cols) { return ld >= (cols + 3) / 4 * 4 && ld % 4 == 0 && aligned_to(p, 16); };
@@ -1480,10 +1521,10 @@ extern "C" int mlqem_linear_bwd_fused_f32(const float* gy, int64_t ldgy, const f
   const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), 16);
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks * 2, ceil_div(tiles, 4)));
   BwdFusedArgs a{gy, ldgy, gb_src, ldgbs, x, ldx, w, gate_scale, gate, gx, ldgx, static_cast<float*>(workspace), N, I, O};
-  // the partial buffer is sized for kWgradBlocks workgroups of 24 x (I + 1) floats: cap the grid accordingly
+  // the partial buffer is sized for kWgradBlocks workgroups of 25 x (I + 1) floats: cap the grid accordingly
   const int Gc = std::min(G, kWgradBlocks);
   hipLaunchKernelGGL(linear_bwd_fused_kernel, dim3(Gc), dim3(kBlock), 0, s, a);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(24 * (I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial, Gc, I, 24,
-                     gw2, gb2, 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(kBwdFusedRows * (I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial, Gc, I,
+                     kBwdFusedRows, gw2, gb2, 0, 0, 0);
   return launch_status();
 }

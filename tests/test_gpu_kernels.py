@@ -351,15 +351,23 @@ def test_linear_over_many_column_blocks_with_row_scale():
         if j == 1:
             want = want * rs.double()[:, None]
         assert torch.allclose(ys[j].cpu().double(), want, rtol=1e-5, atol=1e-5), j
-    gs = [torch.randn(n, o, generator=g) for _ in range(7)]
-    gw = torch.empty(7 * 12, i, device=DEV)
-    gb = torch.empty(7 * 12, device=DEV)
-    ops.linear_wgrad_parts([_padded(t) for t in gs], xd, gw, gb)
-    gw3 = gw.cpu().double().reshape(7, 12, i)
-    for j in range(7):
-        want = gs[j].double().t() @ x.double()
-        assert (gw3[j, :o] - want).abs().max().item() / want.abs().max().item() < 2e-5
-        assert torch.allclose(gb.cpu().double().reshape(7, 12)[j, :o], gs[j].double().sum(0), rtol=1e-4, atol=1e-4)
+    # six and seven blocks: the first stage packs the 10 real columns of the 12-wide blocks into four / five MFMA tiles, the
+    # second spreads them out again (pad rows zero); "accumulate" adds onto what is there
+    for k in (7, 6):
+        gs = [torch.randn(n, o, generator=g) for _ in range(k)]
+        gw = torch.full((k * 12, i), float("nan"), device=DEV)
+        gb = torch.full((k * 12,), float("nan"), device=DEV)
+        ops.linear_wgrad_parts([_padded(t) for t in gs], xd, gw, gb)
+        gw3 = gw.cpu().double().reshape(k, 12, i)
+        gb3 = gb.cpu().double().reshape(k, 12)
+        for j in range(k):
+            want = gs[j].double().t() @ x.double()
+            assert (gw3[j, :o] - want).abs().max().item() / want.abs().max().item() < 2e-5
+            assert torch.allclose(gb3[j, :o], gs[j].double().sum(0), rtol=1e-4, atol=1e-4)
+        assert torch.equal(gw3[:, o:], torch.zeros_like(gw3[:, o:])) and torch.equal(gb3[:, o:], torch.zeros_like(gb3[:, o:]))
+        first = gw.clone()
+        ops.linear_wgrad_parts([_padded(t) for t in gs], xd, gw, gb, accumulate=True)
+        assert torch.allclose(gw, 2 * first, rtol=1e-6, atol=1e-6)
 
 
 def test_linear_over_column_blocks_rejects_unpadded_operands():
@@ -511,15 +519,20 @@ def test_linear_bwd_fused_equals_separate_kernels(n, i, o):
     gy, gbs, x = torch.randn(n, o, generator=g), torch.randn(n, o, generator=g), torch.randn(n, i, generator=g)
     w = torch.randn(o, i, generator=g)
     gyd, gbd, xd, wd = _padded(gy), _padded(gbs), _padded(x), w.to(DEV)
-    gx, gw, gb = ops.linear_bwd_fused(gyd, xd, wd, gb_src=gbd, gate_scale=1.25)
+    gx, gw, gb, cs = ops.linear_bwd_fused(gyd, xd, wd, gb_src=gbd, gate_scale=1.25)
     want_gx = torch.where(x.double() > 0, (gy.double() @ w.double()) * 1.25, torch.zeros(n, i, dtype=torch.float64))
     assert torch.allclose(gx.cpu().double(), want_gx, rtol=1e-5, atol=1e-5)
     want_gw = gy.double().t() @ x.double()
     assert (gw.cpu().double() - want_gw).abs().max().item() < 2e-5 * max(want_gw.abs().max().item(), 1.0)
     want_gb = gbs.double().sum(0)
     assert (gb.cpu().double() - want_gb).abs().max().item() < 2e-5 * max(want_gb.abs().max().item(), 1.0)
+    # the column sums of the data gradient (the bias gradient of the layer below)
+    want_cs = want_gx.sum(0)
+    assert cs.shape == (i,)
+    assert (cs.cpu().double() - want_cs).abs().max().item() < 2e-5 * max(want_gx.abs().sum(0).max().item(), 1.0)
     # without a gate and with gb_src = gy
-    gx2, _, gb2 = ops.linear_bwd_fused(gyd, xd, wd)
+    gx2, _, gb2, cs2 = ops.linear_bwd_fused(gyd, xd, wd)
+    assert (cs2.cpu().double() - (gy.double() @ w.double()).sum(0)).abs().max().item() < 2e-5 * max((gy.double() @ w.double()).abs().sum(0).max().item(), 1.0)
     assert torch.allclose(gx2.cpu().double(), gy.double() @ w.double(), rtol=1e-5, atol=1e-5)
     assert (gb2.cpu().double() - gy.double().sum(0)).abs().max().item() < 2e-5 * max(gy.double().sum(0).abs().max().item(), 1.0)
     # the two-kernel path it replaces gives the same data gradient to fp32 rounding
@@ -527,7 +540,7 @@ def test_linear_bwd_fused_equals_separate_kernels(n, i, o):
     assert torch.allclose(ref_gx, gx, rtol=1e-5, atol=1e-6)
     # deterministic
     again = ops.linear_bwd_fused(gyd, xd, wd, gb_src=gbd, gate_scale=1.25)
-    assert torch.equal(again[0], gx) and torch.equal(again[1], gw) and torch.equal(again[2], gb)
+    assert torch.equal(again[0], gx) and torch.equal(again[1], gw) and torch.equal(again[2], gb) and torch.equal(again[3], cs)
 
 
 def test_pooled_head_forward_backward():
