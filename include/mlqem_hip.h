@@ -475,12 +475,12 @@ int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t* edge_inde
 /* Coarsened connectivity of LARGE graphs (100-qubit circuits pool to thousands of clusters; their second pooling runs on
  * graphs with hub clusters of hundreds of neighbours, where the two-hop path above sorts ~50 candidate keys per distinct
  * edge).  One wave per cluster p builds the row's reach as bitsets in LDS -- nodes v in N+[N-[c_p]], then clusters
- * q = slot[w], w in N+[v] -- so duplicates collapse without a sort and rows come out in ascending order; the rows and
- * their transpose are kept as bit matrices [K][ceil(kmax / 32)] in the workspace.  Two calls, ONE host read between them:
+ * q = slot[w], w in N+[v] -- and the transposed row the same way from N-[N-[c_p]], so duplicates collapse without a sort or a
+ * global atomic and rows come out in ascending order; both are kept as bit matrices [K][ceil(kmax / 32)] in the workspace.  Two calls, ONE host read between them:
  *   rows_count: slot[N], new_in_ptr[K + 1], new_out_ptr[K + 1]; the caller reads new_out_ptr[K] (the edge total E);
  *   rows_fill:  new_in_src[E], new_out_dst[E], new_out_eid[E] -- the arrays mlqem_csr_build yields from the two-hop path's
  *               edge list -- from the SAME workspace, untouched in between.
- * nmax / kmax: largest graph / largest pooled graph of the batch; nmax + kmax + 64 <= mlqem_asap_coarsen_rows_max_bits()
+ * nmax / kmax: largest graph / largest pooled graph of the batch; nmax + 2 kmax + 96 <= mlqem_asap_coarsen_rows_max_bits()
  * (131 072: 64 KB of LDS for the four waves of a workgroup), else MLQEM_ERR_UNSUPPORTED.  Replaces the same
  * ASAPooling.forward lines as the entry points above (gnn.py:105-107,110-112). */
 size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax);

@@ -684,7 +684,7 @@ class _ASAPool(Function):
                 csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
                 num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
             elif (use_rows and len(keep) > 0
-                  and int(sizes.max()) + int(keep.max()) + 64 <= ops.asap_rows_max_bits()):
+                  and int(sizes.max()) + 2 * int(keep.max()) + 96 <= ops.asap_rows_max_bits()):
                 # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)
                 csr, slot, num_edges = ops.asap_coarsen_rows(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm,
                                                              n, sizes, keep, capacity=getattr(s, "coarse_capacity", None))

@@ -255,21 +255,23 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_fill_kernel(const DenseA
 // 100-qubit circuits pool to thousands of clusters per graph and their second pooling runs on graphs whose hub clusters
 // have hundreds of neighbours: the two-hop path above then enumerates ~50 candidates per distinct pair (147 M hop-1 and
 // 234 M hop-2 keys for eight circuits), sorts them as 64-bit keys (65 GB of buffers at 64 circuits) and reads four sizes
-// back.  Here a wave owns cluster p and keeps two BITSETS in LDS: X (the graph's nodes, n_g bits: v in N+[N-[c_p]]) and
-// Y (the graph's clusters, k_g bits: q = slot[w], w in N+[v], v in X).  Duplicates collapse in the LDS atomicOr, nothing
-// is sorted, and a bitset is enumerated in ascending order -- which is the order the CSR arrays want.  Row p of the
-// pooled adjacency goes to a global bit matrix [K][Wk]; its transpose is filled with one global atomicOr per DISTINCT
-// edge.  Popcounts -> device scans -> the CSR pointers; the host reads ONE number (the edge total) to size the edge
-// arrays; a second kernel lists rows / columns and links them (out_eid).  Graphs up to ~87 k nodes (64 KB of LDS per
-// workgroup of four waves).
+// back.  Here a wave owns cluster p and keeps BITSETS in LDS: X (the graph's nodes, n_g bits) and Y, Z (the graph's
+// clusters, k_g bits each):
+//     X  = N+[N-[c_p]],  Y = { slot[w] : w in N+[X]  }      -- the clusters p points to   (row p of the pooled adjacency)
+//     X' = N-[N-[c_p]],  Z = { slot[w] : w in N+[X'] }      -- the clusters pointing to p (row p of its transpose)
+// Duplicates collapse in the LDS atomicOr, nothing is sorted, and a bitset is enumerated in ascending order -- which is the
+// order the CSR arrays want.  Both rows go to global bit matrices [K][Wk] with plain coalesced stores (the transpose used to
+// be filled with one global atomicOr per distinct edge into a zeroed matrix: 9.7 M random read-modify-writes for 64 circuits,
+// half of the kernel's time, plus the memset and a popcount pass).  Popcounts -> device scans -> the CSR pointers; a second
+// kernel lists rows / columns and links them (out_eid).  Graphs up to ~65 k nodes (64 KB of LDS per workgroup of four waves).
 struct RowsArgs {
   const int32_t* in_ptr; const int32_t* in_src; const int32_t* out_ptr; const int32_t* out_dst;
   const int32_t* gptr; const int32_t* new_gptr; const int32_t* perm; const int32_t* slot;
   int B; int64_t K;
   int Wn, Wk;                    // words of the node / cluster bitsets (batch maxima)
-  uint32_t* bm; uint32_t* bmT;   // [K][Wk]: row p = clusters q (local index) with p -> q; bmT row q = sources p
+  uint32_t* bm;                  // [K][Wk]: row p = clusters q (local index) with p -> q
+  uint64_t* bmT;                 // [K][Wk]: row q = sources p in the low word; high word = set bits of the row before this word
   int32_t* outdeg; int32_t* indeg;   // [K + 1]
-  uint16_t* prefw;               // [K][Wk]: set bits of row p in the words before word j (rank lookups of the fill pass)
 };
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -297,33 +299,53 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int kRowsLight = 16;   // out-degree up to which a lane walks a node's edges alone
+constexpr int kRowsLight = 16;   // degree up to which a lane walks a node's edges alone
 
-// Every lane brings one node (or none); f(w) is called for the node itself and for every w in its out-neighbourhood.
-// Nodes with few edges are walked by their lane; the others one after the other by the whole wave (coalesced reads of
-// their adjacency) -- a hub cluster's reach is a few nodes with hundreds of edges each, which one lane would walk for
+// Every lane brings one node (or none); f(w) is called for the node itself and for every w in its neighbourhood in the CSR
+// (ptr, idx).  Nodes with few edges are walked by their lane; the others one after the other by the whole wave (coalesced reads
+// of their adjacency) -- a hub cluster's reach is a few nodes with hundreds of edges each, which one lane would walk for
 // hundreds of dependent round trips while 63 wait.
 template <typename F>
-__device__ __forceinline__ void visit_closed_out(const RowsArgs& a, bool has, int node, int lane, F f) {
+__device__ __forceinline__ void visit_closed(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, bool has, int node,
+                                             int lane, F f) {
   int eb = 0, ee = 0;
-  if (has) { eb = a.out_ptr[node]; ee = a.out_ptr[node + 1]; f(node); }
+  if (has) { eb = ptr[node]; ee = ptr[node + 1]; f(node); }
   const bool heavy = has && ee - eb > kRowsLight;
   if (has && !heavy)
-    for (int e = eb; e < ee; ++e) f(a.out_dst[e]);
+    for (int e = eb; e < ee; ++e) f(idx[e]);
   unsigned long long todo = __ballot(heavy);
   while (todo) {
     const int owner = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
     const int b = __shfl(eb, owner), e = __shfl(ee, owner);
-    for (int i = b + lane; i < e; i += 64) f(a.out_dst[i]);
+    for (int i = b + lane; i < e; i += 64) f(idx[i]);
+  }
+}
+
+// S = { slot[w] >= 0 : w in N+[v], v in X } without `self` (cluster bits, local to the graph); X: Wn words of node bits
+__device__ __forceinline__ void clusters_reached(const RowsArgs& a, const uint32_t* X, int Wn, uint32_t* S, int n0, int k0, int self,
+                                                 int lane) {
+  for (int w0 = 0; w0 < Wn; w0 += 64) {
+    const int wi = w0 + lane;
+    uint32_t bits = wi < Wn ? X[wi] : 0u;
+    while (__ballot(bits != 0u)) {                   // every lane offers its next node, if it has one left
+      const bool has = bits != 0u;
+      int v = 0;
+      if (has) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; v = n0 + wi * 32 + b; }
+      visit_closed(a.out_ptr, a.out_dst, has, v, lane, [&](int w) {
+        const int q = a.slot[w];
+        if (q >= 0 && q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31));
+      });
+    }
   }
 }
 
 __global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) {
-  extern __shared__ uint32_t s_bits[];              // per wave: X [Wn] then Y [Wk]
+  extern __shared__ uint32_t s_bits[];              // per wave: X [Wn], Y [Wk], Z [Wk]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  uint32_t* X = s_bits + (size_t)wid * (a.Wn + a.Wk);
+  uint32_t* X = s_bits + (size_t)wid * (a.Wn + 2 * a.Wk);
   uint32_t* Y = X + a.Wn;
+  uint32_t* Z = Y + a.Wk;
   const int64_t p = (int64_t)blockIdx.x * 4 + wid;
   if (p >= a.K) return;                              // wave-uniform
   const int c = a.perm[p];
@@ -334,61 +356,45 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_kernel(const RowsArgs a) 
   // graph; a batch mixes 2 k- and 20 k-node circuits, and every loop below runs over words, set or not)
   const int Wn = (a.gptr[lo + 1] - n0 + 31) >> 5, Wk = (a.new_gptr[lo + 1] - k0 + 31) >> 5;
   for (int i = lane; i < Wn; i += 64) X[i] = 0u;
-  for (int i = lane; i < Wk; i += 64) Y[i] = 0u;
+  for (int i = lane; i < Wk; i += 64) { Y[i] = 0u; Z[i] = 0u; }
   wave_lds_sync();
-  // X = N+[N-[c]] (node bits, local to the graph)
   const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
+  // X = N+[N-[c]] (node bits, local to the graph)
   for (int i0 = ib - 1; i0 < ie; i0 += 64) {         // index ib - 1 stands for c itself
     const int i = i0 + lane;
     const bool has = i < ie;
     const int u = has ? (i < ib ? c : a.in_src[i]) : 0;
-    visit_closed_out(a, has, u, lane, [&](int v) { atomicOr(&X[(v - n0) >> 5], 1u << ((v - n0) & 31)); });
+    visit_closed(a.out_ptr, a.out_dst, has, u, lane, [&](int v) { atomicOr(&X[(v - n0) >> 5], 1u << ((v - n0) & 31)); });
   }
   wave_lds_sync();
-  // Y = kept centres among N+[X] (cluster bits, local to the graph), without p itself
-  for (int w0 = 0; w0 < Wn; w0 += 64) {
-    const int wi = w0 + lane;
-    uint32_t bits = wi < Wn ? X[wi] : 0u;
-    while (__ballot(bits != 0u)) {                   // every lane offers its next node, if it has one left
-      const bool has = bits != 0u;
-      int v = 0;
-      if (has) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; v = n0 + wi * 32 + b; }
-      visit_closed_out(a, has, v, lane, [&](int w) {
-        const int q = a.slot[w];
-        if (q >= 0 && q != (int)p) atomicOr(&Y[(q - k0) >> 5], 1u << ((q - k0) & 31));
-      });
-    }
+  clusters_reached(a, X, Wn, Y, n0, k0, (int)p, lane);
+  wave_lds_sync();
+  // X = N-[N-[c]]
+  for (int i = lane; i < Wn; i += 64) X[i] = 0u;
+  wave_lds_sync();
+  for (int i0 = ib - 1; i0 < ie; i0 += 64) {
+    const int i = i0 + lane;
+    const bool has = i < ie;
+    const int u = has ? (i < ib ? c : a.in_src[i]) : 0;
+    visit_closed(a.in_ptr, a.in_src, has, u, lane, [&](int v) { atomicOr(&X[(v - n0) >> 5], 1u << ((v - n0) & 31)); });
   }
   wave_lds_sync();
-  const int pl = (int)(p - k0);
-  int run = 0;                                        // set bits of Y in the words before the current 64
-  for (int w0 = 0; w0 < Wk; w0 += 64) {                // words past Wk of row p of bm / prefw stay unwritten: nobody reads them
+  clusters_reached(a, X, Wn, Z, n0, k0, (int)p, lane);
+  wave_lds_sync();
+  int run_out = 0, run_in = 0;                         // set bits in the words before the current 64
+  for (int w0 = 0; w0 < Wk; w0 += 64) {                // words past Wk of row p stay unwritten: nobody reads them
     const int wi = w0 + lane;
-    uint32_t bits = wi < Wk ? Y[wi] : 0u;
-    const int c = __popc(bits);
-    const int ex = wave_excl_scan(c, lane);
+    const uint32_t yb = wi < Wk ? Y[wi] : 0u, zb = wi < Wk ? Z[wi] : 0u;
+    const int cz = __popc(zb);
+    const int ex = wave_excl_scan(cz, lane);
     if (wi < Wk) {
-      a.bm[p * a.Wk + wi] = bits;
-      a.prefw[p * a.Wk + wi] = (uint16_t)(run + ex);  // rank of the word's first bit inside row p (< k_g <= 65536)
+      a.bm[p * a.Wk + wi] = yb;
+      a.bmT[p * a.Wk + wi] = (uint64_t)zb | ((uint64_t)(uint32_t)(run_in + ex) << 32);   // rank of the word's first bit inside the row
     }
-    run += __shfl(ex + c, 63);
-    while (bits) {                                    // one global atomicOr per distinct edge p -> q
-      const int b = __ffs((int)bits) - 1;
-      bits &= bits - 1;
-      atomicOr(&a.bmT[(int64_t)(k0 + wi * 32 + b) * a.Wk + (pl >> 5)], 1u << (pl & 31));
-    }
+    run_in += __shfl(ex + cz, 63);
+    run_out += wave_sum(__popc(yb));
   }
-  if (lane == 0) a.outdeg[p] = run;
-}
-
-__global__ __launch_bounds__(kBlock) void coarsen_rows_indeg_kernel(const RowsArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= a.K) return;
-  int cnt = 0;
-  for (int wi = lane; wi < a.Wk; wi += 64) cnt += __popc(a.bmT[q * a.Wk + wi]);
-  cnt = wave_sum(cnt);
-  if (lane == 0) a.indeg[q] = cnt;
+  if (lane == 0) { a.outdeg[p] = run_out; a.indeg[p] = run_in; }
 }
 
 __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArgs a, const int32_t* __restrict__ in_ptr_new,
@@ -404,39 +410,41 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArg
   const int k0 = a.new_gptr[lo];
   const int rl = (int)(r - k0);
   const int Wk = (a.new_gptr[lo + 1] - k0 + 31) >> 5;   // words of this graph's rows (the count pass wrote no more)
-  // row r of the out-CSR: destinations ascending
+  // row r of the out-CSR: destinations ascending; each entry also learns where its twin lives in the in-CSR -- the rank of r in
+  // row q of the transpose (bits before word wq: the high half of that word; bits below r inside it).  All stores of this kernel are
+  // consecutive per row; what is random is one 8-byte and one 4-byte read per edge.
+  const int wq = rl >> 5;
+  const uint32_t below = (1u << (rl & 31)) - 1u;
   int base = out_ptr_new[r];
   for (int w0 = 0; w0 < Wk; w0 += 64) {
     const int wi = w0 + lane;
     uint32_t bits = wi < Wk ? a.bm[r * a.Wk + wi] : 0u;
-    const int n = __popc(bits);
-    int pos = base + wave_excl_scan(n, lane);
-    while (bits) {
-      const int b = __ffs((int)bits) - 1;
-      bits &= bits - 1;
-      out_dst_new[pos++] = k0 + wi * 32 + b;
-    }
-    base += __shfl(wave_excl_scan(n, lane) + n, 63);
-  }
-  // row r of the in-CSR: sources ascending; each entry also tells its out-CSR twin where it lives
-  base = in_ptr_new[r];
-  const int wq = rl >> 5;
-  const uint32_t below = (1u << (rl & 31)) - 1u;
-  for (int w0 = 0; w0 < Wk; w0 += 64) {
-    const int wi = w0 + lane;
-    uint32_t bits = wi < Wk ? a.bmT[r * a.Wk + wi] : 0u;
     const int n = __popc(bits);
     const int ex = wave_excl_scan(n, lane);
     int pos = base + ex;
     while (bits) {
       const int b = __ffs((int)bits) - 1;
       bits &= bits - 1;
-      const int64_t src = (int64_t)k0 + wi * 32 + b;
-      in_src_new[pos] = (int32_t)src;
-      // rank of r inside row src of the out-CSR: bits before word wq (count pass) + bits below r in that word
-      const int rank = (int)a.prefw[src * a.Wk + wq] + __popc(a.bm[src * a.Wk + wq] & below);
-      out_eid_new[out_ptr_new[src] + rank] = pos;
+      const int64_t q = (int64_t)k0 + wi * 32 + b;
+      const uint64_t t = a.bmT[q * a.Wk + wq];
+      out_dst_new[pos] = (int32_t)q;
+      out_eid_new[pos] = in_ptr_new[q] + (int)(t >> 32) + __popc((uint32_t)t & below);
       ++pos;
+    }
+    base += __shfl(ex + n, 63);
+  }
+  // row r of the in-CSR: sources ascending
+  base = in_ptr_new[r];
+  for (int w0 = 0; w0 < Wk; w0 += 64) {
+    const int wi = w0 + lane;
+    uint32_t bits = wi < Wk ? (uint32_t)a.bmT[r * a.Wk + wi] : 0u;
+    const int n = __popc(bits);
+    const int ex = wave_excl_scan(n, lane);
+    int pos = base + ex;
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      in_src_new[pos++] = k0 + wi * 32 + b;
     }
     base += __shfl(ex + n, 63);
   }
@@ -627,18 +635,17 @@ extern "C" int mlqem_keys_to_edge_index(const uint64_t* keys, int64_t E, int64_t
   return launch_status();
 }
 
-static void rows_layout(int64_t K, int kmax, size_t& bm, size_t& deg, size_t& pref) {
+static void rows_layout(int64_t K, int kmax, size_t& bm, size_t& deg) {
   const size_t Wk = (size_t)(kmax + 31) / 32;
-  bm = ((size_t)K * Wk * sizeof(uint32_t) + 255) / 256 * 256;
+  bm = ((size_t)K * Wk * sizeof(uint32_t) + 255) / 256 * 256;      // the transpose (bits + ranks, 8 bytes per word) takes 2 * bm
   deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
-  pref = ((size_t)K * Wk * sizeof(uint16_t) + 255) / 256 * 256;
 }
 
 extern "C" size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax) {
   if (K < 0 || kmax < 0) return 0;
-  size_t bm, deg, pref;
-  rows_layout(K, kmax, bm, deg, pref);
-  return 2 * bm + 2 * deg + pref + dense_scan_bytes(K);
+  size_t bm, deg;
+  rows_layout(K, kmax, bm, deg);
+  return 3 * bm + 2 * deg + dense_scan_bytes(K);
 }
 
 extern "C" int mlqem_asap_slot_map(const int32_t* perm, int64_t N, int64_t K, int32_t* slot, mlqem_stream_t stream_) {
@@ -652,18 +659,18 @@ extern "C" int mlqem_asap_slot_map(const int32_t* perm, int64_t N, int64_t K, in
   return launch_status();
 }
 
-extern "C" int mlqem_asap_coarsen_rows_max_bits(void) { return 64 * 1024 * 8 / 4; }   // (n_g + k_g) bits per wave: 64 KB of LDS, four waves
+extern "C" int mlqem_asap_coarsen_rows_max_bits(void) { return 64 * 1024 * 8 / 4; }   // (n_g + 2 k_g) bits per wave: 64 KB of LDS, four waves
 
 static bool rows_args(RowsArgs& a, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                       const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, const int32_t* slot,
                       int64_t K, int64_t B, int nmax, int kmax, void* workspace) {
-  size_t bm, deg, pref;
-  rows_layout(K, kmax, bm, deg, pref);
+  size_t bm, deg;
+  rows_layout(K, kmax, bm, deg);
   char* ws = static_cast<char*>(workspace);
   const int Wk = (kmax + 31) / 32;
   a = RowsArgs{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, K, (nmax + 31) / 32, Wk,
-               reinterpret_cast<uint32_t*>(ws), reinterpret_cast<uint32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + 2 * bm),
-               reinterpret_cast<int32_t*>(ws + 2 * bm + deg), reinterpret_cast<uint16_t*>(ws + 2 * bm + 2 * deg)};
+               reinterpret_cast<uint32_t*>(ws), reinterpret_cast<uint64_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + 3 * bm),
+               reinterpret_cast<int32_t*>(ws + 3 * bm + deg)};
   return true;
 }
 
@@ -677,7 +684,7 @@ extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (N < 0 || K < 0 || K > N || B < 0 || kmax < 0 || nmax < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
-  if (nmax + kmax + 64 > mlqem_asap_coarsen_rows_max_bits() || kmax > 65536) return MLQEM_ERR_UNSUPPORTED;   // ranks are 16-bit
+  if (nmax + 2 * kmax + 96 > mlqem_asap_coarsen_rows_max_bits()) return MLQEM_ERR_UNSUPPORTED;
   if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_asap_coarsen_rows_workspace_bytes(K, kmax)) return MLQEM_ERR_WORKSPACE;
   fill_i32(slot, -1, N, stream);
@@ -689,17 +696,15 @@ extern "C" int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_
   if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm) return MLQEM_ERR_BAD_ARG;
   RowsArgs a;
   rows_args(a, in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, K, B, nmax, kmax, workspace);
-  size_t bm, deg, pref;
-  rows_layout(K, kmax, bm, deg, pref);
-  fill_i32(reinterpret_cast<int32_t*>(a.bmT), 0, (int64_t)(bm / sizeof(int32_t)), stream);
+  size_t bm, deg;
+  rows_layout(K, kmax, bm, deg);
   fill_i32(a.outdeg + K, 0, 1, stream);
   fill_i32(a.indeg + K, 0, 1, stream);
   hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
-  const size_t lds = (size_t)4 * (a.Wn + a.Wk) * sizeof(uint32_t);
+  const size_t lds = (size_t)4 * (a.Wn + 2 * a.Wk) * sizeof(uint32_t);
   const unsigned grid = (unsigned)ceil_div(K, (int64_t)4);
   hipLaunchKernelGGL(coarsen_rows_kernel, dim3(grid), dim3(kBlock), lds, stream, a);
-  hipLaunchKernelGGL(coarsen_rows_indeg_kernel, dim3(grid), dim3(kBlock), 0, stream, a);
-  void* temp = static_cast<char*>(workspace) + 2 * bm + 2 * deg + pref;
+  void* temp = static_cast<char*>(workspace) + 3 * bm + 2 * deg;
   size_t temp_bytes = dense_scan_bytes(K);
   if (rocprim::exclusive_scan(temp, temp_bytes, a.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
                               stream) != hipSuccess)
