@@ -575,7 +575,7 @@ class _TransformerConv(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, struct: GraphStructure, heads, channels, drop_p, seed):
-        x = ops.rowmajor(x)
+        x = ops.rowmajor(x)        # a RowsOf (rows of the device-resident dataset) stays one: the projection reads through its row map
         w = w.contiguous()
         qkvs = ops.linear(x, w, b)
         e = struct.edge_count()
@@ -584,12 +584,20 @@ class _TransformerConv(Function):
         out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
                                                            channels, drop_p, seed)
         ctx.struct, ctx.cfg = struct, (e, heads, channels, drop_p, seed)
-        ctx.save_for_backward(x, w, qkvs, attn, m, den)
+        ctx.x_rows_of = isinstance(x, ops.RowsOf)
+        if ctx.x_rows_of:
+            ctx.save_for_backward(x.base, x.rows, w, qkvs, attn, m, den)
+        else:
+            ctx.save_for_backward(x, w, qkvs, attn, m, den)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w, qkvs, attn, m, den = ctx.saved_tensors
+        if ctx.x_rows_of:
+            base, rows, w, qkvs, attn, m, den = ctx.saved_tensors
+            x = ops.RowsOf(base, rows)
+        else:
+            x, w, qkvs, attn, m, den = ctx.saved_tensors
         e, heads, channels, drop_p, seed = ctx.cfg
         gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed)
         gx = ops.linear(gqkvs, w, transposed=True) if ctx.needs_input_grad[0] else None

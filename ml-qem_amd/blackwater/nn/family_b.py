@@ -85,8 +85,8 @@ class _FamilyB(nn.Module):
         return hidden_channels * h2
 
     def forward(self, exp_value, observable, circuit_depth, nodes, edge_index, batch):
-        if hasattr(nodes, "materialize"):     # a device batch hands over rows-of-the-arena; this family wants the tensor
-            nodes = nodes.materialize()
+        # a device batch hands over rows-of-the-arena (ops.RowsOf): the first projection and its weight gradient read them through
+        # the row map, no per-batch copy of the features is made
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
         self.transformer1.static_dropout_key = self.transformer2.static_dropout_key = getattr(self, "static_dropout_key", False)

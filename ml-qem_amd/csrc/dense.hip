@@ -28,6 +28,7 @@ struct LinArgs {
   int rs_cols;    // rowscale applies to outputs o < rs_cols
   int act_from;   // ReLU / dropout apply to outputs o >= act_from
   const float* gate; int64_t ldgate; float gate_scale;   // last: y = gate[n,o] > 0 ? y * gate_scale : 0
+  const int32_t* xrows;   // optional row map of x (linear_mfma_v4_kernel and the lean column-block kernel): row n of X is row xrows[n] of the buffer
 };
 
 // ---------------------------------------------------------------------------------------------- forward
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
     const int64_t row = t * 16 + lr;          // the row this lane loads AND stores
     const bool row_ok = row < a.N;
-    const float* __restrict__ xr = a.x + row * a.ldx + 4 * lq;
+    const int64_t xrow = (a.xrows && row_ok) ? (int64_t)a.xrows[row] : row;
+    const float* __restrict__ xr = a.x + xrow * a.ldx + 4 * lq;
     float4 av[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1216,7 +1218,6 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
       if (rc != MLQEM_ERR_UNSUPPORTED) return rc;
     }
   }
-  if (x_rows) return MLQEM_ERR_UNSUPPORTED;   // the row map is carried by the lean kernel only
   const int ks = round_ks((I + 3) / 4);
   if (ks > 0) {
     const int ob = (O + 15) / 16;
@@ -1227,6 +1228,8 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
     static const int v4_env = getenv("MLQEM_LINEAR_V4") ? atoi(getenv("MLQEM_LINEAR_V4")) : 1;
     const bool padded = ldx % 4 == 0 && ldx >= c4i && aligned_to(x, 16) && ldy % 4 == 0 && ldy >= c4o && aligned_to(y, 16) &&
                         (!gate || (ldgate % 4 == 0 && ldgate >= c4o && aligned_to(gate, 16)));
+    if (x_rows && !(v4_env && padded)) return MLQEM_ERR_UNSUPPORTED;   // the row map is carried by the lean and the 16-byte kernels only
+    a.xrows = x_rows;
     if (v4_env && padded) {  // padded activation rows on every operand: one 16-byte access path, no scalar tails
       const int g = (I + 15) / 16;
       if (obt == 1) transposed ? launch_linear_v4<1, true>(a, g, grid, s) : launch_linear_v4<1, false>(a, g, grid, s);
@@ -1239,6 +1242,7 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
     else transposed ? launch_linear_mfma<4, true>(a, ks, grid, s) : launch_linear_mfma<4, false>(a, ks, grid, s);
     return launch_status();
   }
+  if (x_rows) return MLQEM_ERR_UNSUPPORTED;
   const int oc = (int)std::min<int64_t>(O, (48 * 1024) / ((I | 1) * sizeof(float)));
   if (oc < 1) return MLQEM_ERR_UNSUPPORTED;
   const size_t lds = (size_t)oc * (I | 1) * sizeof(float);

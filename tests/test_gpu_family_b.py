@@ -509,3 +509,34 @@ def test_family_b_step_on_100_qubit_graphs_is_captured_and_replays_bit_for_bit()
     assert runs[False][0] == runs[True][0]
     assert torch.equal(runs[False][1], runs[True][1])
     assert all(np.isfinite(runs[True][0]))
+
+
+def test_family_b_reads_the_arena_rows_through_the_row_map(g1):
+    """The first TransformerConv takes a device batch's ``RowsOf`` nodes as they are (mlqem_linear_f32 / mlqem_linear_wgrad_f32 with
+    x_rows, 180 output columns: the 16-byte GEMM kernel): outputs and every gradient bit-identical to the materialised copy."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    xs, eis = [], []
+    for i in range(48):
+        x, ei, _ = g1_graph(g1, i)
+        loops = np.arange(x.shape[0])
+        xs.append(x.astype(np.float32))
+        eis.append(np.concatenate([ei, np.stack([loops, loops])], axis=1))
+    arena = GraphArena.from_arrays(xs, eis, g1["ideal"][:48, None, :].astype(np.float32), g1["noisy"][:48, None, :].astype(np.float32),
+                                   g1["depth"][:48, None].astype(np.float32), np.zeros((48, 1, 1), np.float32), device=DEV)
+    batch = arena.batch(np.arange(47, -1, -1))            # reversed: the row map is not the identity
+    args = list(batch.model_args())
+    assert isinstance(args[3], ops.RowsOf)
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel(22, 15, 4).to(DEV).eval()      # eval: no dropout draws, gradients still flow
+    res = []
+    for nodes in (args[3], args[3].materialize()):
+        model.zero_grad(set_to_none=True)
+        out = model(args[0], args[1], args[2], nodes, args[4], args[5])
+        out.square().sum().backward()
+        res.append((out.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    for ga, gb in zip(res[0][1], res[1][1]):
+        assert torch.equal(ga, gb)
