@@ -2,13 +2,17 @@
 // ASAPooling's attention-weighted cluster sum.  Both are "softmax over the in-edges of a row, then a weighted sum
 // of source rows"; the softmax statistics of a row are recomputed by each thread that needs them (rows have a
 // handful of in-edges), which keeps the kernels free of any [E]-sized intermediate.
-#include "attn_fwd.hpp"
+#include "attn_q4.hpp"
 #include "common.hpp"
 
 namespace mlqem {
 
 // TransformerConv (heads=H, concat, root_weight, no edge features), inference form: no dropout, no
 // statistics.  The schedule (short rows from registers, longer ones in one chunked pass) is in attn_fwd.hpp.
+template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_q4_kernel(const AttnFwdArgs a) {
+  attn_forward_q4<false, LPH>(a);
+}
+
 template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const AttnFwdArgs a) {
   attn_forward<false, WIDE>(a);
 }
@@ -200,6 +204,13 @@ extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, co
   if (!qkvs || !in_ptr || !out) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
   const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, 0, H, C, 0.f, 0, nullptr, out, ldo, nullptr, 0, nullptr, nullptr};
+  if (attn_q4_enabled()) {
+    const int lph = C > 16 ? 8 : 4;
+    const dim3 grid4((unsigned)ceil_div(N * H * lph, kBlock));
+    if (lph == 8) hipLaunchKernelGGL(transformer_attn_q4_kernel<8>, grid4, dim3(kBlock), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(transformer_attn_q4_kernel<4>, grid4, dim3(kBlock), 0, as_stream(stream), a);
+    return launch_status();
+  }
   const dim3 grid((unsigned)ceil_div(N * H * kGroup, kBlock));
   if (C > kGroup) hipLaunchKernelGGL(transformer_attn_kernel<true>, grid, dim3(kBlock), 0, as_stream(stream), a);
   else hipLaunchKernelGGL(transformer_attn_kernel<false>, grid, dim3(kBlock), 0, as_stream(stream), a);

@@ -5,7 +5,7 @@
 // out-CSR entry).  No atomics: every gradient row is written once, in a fixed order.
 #include <type_traits>
 
-#include "attn_fwd.hpp"
+#include "attn_q4.hpp"
 #include "common.hpp"
 
 namespace mlqem {
@@ -245,6 +245,141 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
   float* __restrict__ gq = a.gqkvs + (int64_t)row * a.ldq;
   if (c0) { gq[HC + o0] = gk0; gq[2 * HC + o0] = gv0; }
   if (c1) { gq[HC + o1] = gk1; gq[2 * HC + o1] = gv1; }
+}
+
+// The same three kernels with four channels per lane (attn_q4.hpp): LPH = 4 (C <= 16) or 8 lanes per (row, head), 16-byte row
+// segments, entries (in-edges, then the self entry) four at a time with lane u of every quad owning entry u.
+template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_train_q4_kernel(const AttnFwdArgs a) {
+  attn_forward_q4<true, LPH>(a);
+}
+
+template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_q4_kernel(const AttnBwdArgs a) {
+  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LPH;
+  const int lq = threadIdx.x % LPH, lu = lq & 3;
+  const int H = a.H, C = a.C, HC = H * C;
+  if (t >= a.N * H) return;
+  const int row = (int)(t / H);
+  const int h = (int)(t - (int64_t)row * H);
+  const int nv = min(4, max(0, C - 4 * lq));
+  const int off = h * C + 4 * lq;
+  const float scale = 1.0f / sqrtf((float)C);
+  const float keep = 1.f / (1.f - a.drop_p);
+  const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);   // as the forward
+  const float* __restrict__ qkvs = a.qkvs;
+  const int64_t ld = a.ld;
+  const int32_t* __restrict__ idx = a.idx;
+  float* __restrict__ edge_al = a.edge_al;
+  float* __restrict__ edge_gs = a.edge_gs;
+  const f4u q = load_channels(qkvs + (int64_t)row * ld + off, nv, true);
+  const f4u gi = load_channels(a.g + (int64_t)row * a.ldg + off, nv, off + 4 <= a.ldg);
+  const f4u ao = load_channels(a.attn_out + (int64_t)row * a.lda + off, nv, off + 4 <= a.lda);
+  const float delta = head_sum<LPH>(dot4(gi, ao));
+  const float m = a.stat_m[(int64_t)row * H + h];
+  const float inv_den = 1.0f / a.stat_den[(int64_t)row * H + h];     // one division per row, as in the forward
+  const int beg = a.ptr[row];
+  const int deg = a.ptr[row + 1] - beg;
+  const int n_self = a.loops ? a.loops[row] : 0;
+  const int cnt = deg + (n_self > 0 ? 1 : 0);
+  f4u gq = {0.f, 0.f, 0.f, 0.f};
+  for (int x0 = 0; x0 < cnt; x0 += 4) {
+    const int k = min(4, cnt - x0);
+    const int x = x0 + min(lu, k - 1);                   // past the end: the last entry again (gs 0, nothing stored)
+    const bool is_self = x >= deg;
+    const int j = is_self ? row : idx[beg + x];
+    int ju[4];
+    ju[0] = quad_bcast<0>(j); ju[1] = quad_bcast<1>(j); ju[2] = quad_bcast<2>(j); ju[3] = quad_bcast<3>(j);
+    f4u kk[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u < k && nv > 0) {
+        const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HC + off;
+        kk[u] = *reinterpret_cast<const f4u*>(kj);
+        vv[u] = *reinterpret_cast<const f4u*>(kj + HC);
+      } else {
+        kk[u] = f4u{0.f, 0.f, 0.f, 0.f};
+        vv[u] = f4u{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    float mys = 0.f, mygv = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float sd = head_sum<LPH>(dot4(q, kk[u])), gd = head_sum<LPH>(dot4(gi, vv[u]));
+      if (lu == u) { mys = sd; mygv = gd; }
+    }
+    const int64_t pos = is_self ? a.E + row : (int64_t)beg + x;
+    const float alpha = expf(mys * scale - m) * inv_den * (is_self ? (float)n_self : 1.f);
+    float dmask = 1.f;
+    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
+    float gs = alpha * (mygv * dmask - delta) * scale;
+    if (lu >= k) gs = 0.f;
+    if (lq < 4 && lu < k) {                              // LPH = 8: both quads of the head hold the chunk, the first one stores
+      edge_al[pos * H + h] = alpha * dmask;
+      edge_gs[pos * H + h] = gs;
+    }
+    const float gu[4] = {quad_bcast<0>(gs), quad_bcast<1>(gs), quad_bcast<2>(gs), quad_bcast<3>(gs)};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gq += gu[u] * kk[u];
+  }
+  if (n_self == 0 && lq == 0) {
+    edge_al[(a.E + row) * H + h] = 0.f;
+    edge_gs[(a.E + row) * H + h] = 0.f;
+  }
+  float* __restrict__ go = a.gqkvs + (int64_t)row * a.ldq;
+  store_channels(go + off, gq, nv);
+  store_channels(go + 3 * HC + off, gi, nv);
+}
+
+template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_q4_kernel(const AttnBwdArgs a) {
+  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LPH;
+  const int lq = threadIdx.x % LPH, lu = lq & 3;
+  const int H = a.H, C = a.C, HC = H * C;
+  if (t >= a.N * H) return;
+  const int row = (int)(t / H);
+  const int h = (int)(t - (int64_t)row * H);
+  const int nv = min(4, max(0, C - 4 * lq));
+  const int off = h * C + 4 * lq;
+  const float* __restrict__ qkvs = a.qkvs;
+  const float* __restrict__ g = a.g;
+  const float* __restrict__ edge_al = a.edge_al;
+  const float* __restrict__ edge_gs = a.edge_gs;
+  const int64_t ld = a.ld, ldg = a.ldg;
+  const bool g_fits = off + 4 <= ldg;                    // a gradient row is compact [H C] (+ padding to 16 bytes)
+  f4u gk = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+  const int obeg = a.optr[row];
+  const int odeg = a.optr[row + 1] - obeg;
+  const int cnt = odeg + 1;                              // the self entry, last (its weights are zero when the row has no self-loop)
+  for (int x0 = 0; x0 < cnt; x0 += 4) {
+    const int k = min(4, cnt - x0);
+    const int x = x0 + min(lu, k - 1);
+    const bool is_self = x >= odeg;
+    const int i = is_self ? row : a.odst[obeg + x];
+    const int64_t pos = is_self ? a.E + row : (int64_t)a.oeid[obeg + x];
+    const float gs = lu < k ? edge_gs[pos * H + h] : 0.f;    // past the end: the last entry again with weight 0
+    const float al = lu < k ? edge_al[pos * H + h] : 0.f;
+    int iu[4];
+    iu[0] = quad_bcast<0>(i); iu[1] = quad_bcast<1>(i); iu[2] = quad_bcast<2>(i); iu[3] = quad_bcast<3>(i);
+    const float gsu[4] = {quad_bcast<0>(gs), quad_bcast<1>(gs), quad_bcast<2>(gs), quad_bcast<3>(gs)};
+    const float alu[4] = {quad_bcast<0>(al), quad_bcast<1>(al), quad_bcast<2>(al), quad_bcast<3>(al)};
+    f4u qa[4], ga[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u < k && nv > 0) {
+        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + off);       // a query segment runs over into the key part at most
+        ga[u] = g_fits ? *reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off) : load_channels(g + (int64_t)iu[u] * ldg + off, nv, false);
+      } else {
+        qa[u] = f4u{0.f, 0.f, 0.f, 0.f};
+        ga[u] = f4u{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gk += gsu[u] * qa[u];
+      gv += alu[u] * ga[u];
+    }
+  }
+  float* __restrict__ go = a.gqkvs + (int64_t)row * a.ldq;
+  store_channels(go + HC + off, gk, nv);
+  store_channels(go + 2 * HC + off, gv, nv);
 }
 
 // --------------------------------------------------------------------------------------------- ASAPooling
@@ -741,7 +876,10 @@ extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t 
   if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
   const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den};
-  if (C > kGroup) hipLaunchKernelGGL(transformer_attn_train_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
+  if (attn_q4_enabled()) {
+    if (C > 16) hipLaunchKernelGGL(transformer_attn_train_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
+    else hipLaunchKernelGGL(transformer_attn_train_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
+  } else if (C > kGroup) hipLaunchKernelGGL(transformer_attn_train_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
   else hipLaunchKernelGGL(transformer_attn_train_kernel<false>, MLQEM_GRID(N * H * kGroup), a);
   return launch_status();
 }
@@ -765,7 +903,15 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
   const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
                       N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs};
-  if (C > kGroup) {
+  if (attn_q4_enabled()) {
+    if (C > 16) {
+      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
+      hipLaunchKernelGGL(transformer_attn_bwd_src_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
+    } else {
+      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
+      hipLaunchKernelGGL(transformer_attn_bwd_src_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
+    }
+  } else if (C > kGroup) {
     hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
     hipLaunchKernelGGL(transformer_attn_bwd_src_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
   } else {
