@@ -616,6 +616,8 @@ def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
 _ASAP_DENSE = os.environ.get("MLQEM_ASAP_DENSE", "1") != "0"
 # MLQEM_ASAP_ROWS=0 keeps the two-hop path for graphs too large for the dense form (default: the wave-per-cluster form)
 _ASAP_ROWS = os.environ.get("MLQEM_ASAP_ROWS", "1") != "0"
+# MLQEM_ASAP_TIES=0: the segment max's backward counts its ties in a walk of its own (A/B)
+_ASAP_TIES = os.environ.get("MLQEM_ASAP_TIES", "1") != "0"
 # MLQEM_ASAP_LAZY=0 computes the coarsened connectivity inside ASAPooling's forward even when no later layer reads it
 _ASAP_LAZY = os.environ.get("MLQEM_ASAP_LAZY", "1") != "0"
 
@@ -731,7 +733,11 @@ class _ASAPool(Function):
         gb3 = torch.empty(3, dtype=torch.float32, device=dev)
         ops.linear_wgrad(gpqr, x_new, gw3, gb3)
         # x' = sum_e softmax(LeakyReLU(a_i + c_j)) x_j
-        gx, g_a, g_c = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope)
+        # ... its destination-side walk also counts the ties of the segment max below (same x, same entries)
+        if _ASAP_TIES:
+            gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw)
+        else:
+            (gx, g_a, g_c), ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope), None
         att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
         g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
         ops.linear(g_c2, att_x, transposed=True, out=gx, accumulate=True)           # c = x att_x^T
@@ -745,7 +751,7 @@ class _ASAPool(Function):
         g_lin_w = torch.empty_like(lin_w)
         g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
         ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
-        ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s)      # xq_raw = segment max of x
+        ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s, ties=ties)      # xq_raw = segment max of x
         g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],
                 None, None, None, None)

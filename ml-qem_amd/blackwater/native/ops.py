@@ -1219,29 +1219,35 @@ def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channe
     return gqkvs
 
 
-def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope):
+def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope, xmax=None):
+    """(gx, g_a, g_c) -- and, given ``xmax`` (the segment max of x over the same entries, <= 128 channels), a fourth result: the
+    per-channel tie counts ``csr_segment_max_bwd_`` would otherwise walk the in-edges for."""
     n, c = x.shape
     dev = x.device
     gx = padded_empty(n, c, dev)
+    ties = padded_empty(n, c, dev) if (xmax is not None and c <= 128) else None
     g_a = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
     g_c = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
     scratch = torch.empty((2, num_edges + n + 1), dtype=torch.float32, device=dev)
     code = _lib.load().mlqem_csr_softmax_aggregate_bwd_f32(
         _p(x), _mat(x, "x"), _p(xnew), _mat(xnew, "xnew"), _p(gnew), _mat(gnew, "gnew"), _p(s.in_ptr), _p(s.in_src),
         _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(a_dst), _p(c_src), float(negative_slope), n, num_edges, c, 0,
-        _p(gx), _mat(gx, "gx"), _p(g_a), _p(g_c), _p(scratch[0]), _p(scratch[1]), _stream())
+        _p(gx), _mat(gx, "gx"), _p(g_a), _p(g_c), _p(scratch[0]), _p(scratch[1]),
+        _p(xmax) if ties is not None else None, _mat(xmax, "xmax") if ties is not None else 0,
+        _p(ties), _mat(ties, "ties") if ties is not None else 0, _stream())
     _lib.check(code, "mlqem_csr_softmax_aggregate_bwd_f32")
-    return gx, g_a, g_c
+    return (gx, g_a, g_c) if xmax is None else (gx, g_a, g_c, ties)
 
 
-def csr_segment_max_bwd_(gx, x, xmax, gmax, s):
-    """gx += backward of the segment max over structure ``s`` (in place)."""
+def csr_segment_max_bwd_(gx, x, xmax, gmax, s, ties=None):
+    """gx += backward of the segment max over structure ``s`` (in place); ``ties``: the counts ``csr_softmax_aggregate_bwd`` left."""
     n, c = x.shape
     share = padded_empty(n, c, x.device)
     code = _lib.load().mlqem_csr_segment_max_bwd_f32(_p(x), _mat(x, "x"), _p(xmax), _mat(xmax, "xmax"), _p(gmax),
                                                      _mat(gmax, "gmax"), _p(s.in_ptr), _p(s.in_src), _p(s.out_ptr),
                                                      _p(s.out_dst), n, c, _p(gx), _mat(gx, "gx"), _p(share),
-                                                     _mat(share, "share"), _stream())
+                                                     _mat(share, "share"), _p(ties), _mat(ties, "ties") if ties is not None else 0,
+                                                     _stream())
     _lib.check(code, "mlqem_csr_segment_max_bwd_f32")
     return gx
 

@@ -58,29 +58,37 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_ke
     grow(group16_max(s));
     const float p = l < k ? expf(s - m) : 0.f;
     den += group16_sum(p);
-    auto rows = [&](auto first) {                     // eight source rows in flight, then eight multiply-adds in edge order
-      constexpr int U0 = decltype(first)::value;
-      int ju[8];
-      float pu[8], xv[8][NV];
-      ju[0] = group16_bcast<U0 + 0>(j); ju[1] = group16_bcast<U0 + 1>(j); ju[2] = group16_bcast<U0 + 2>(j);
-      ju[3] = group16_bcast<U0 + 3>(j); ju[4] = group16_bcast<U0 + 4>(j); ju[5] = group16_bcast<U0 + 5>(j);
-      ju[6] = group16_bcast<U0 + 6>(j); ju[7] = group16_bcast<U0 + 7>(j);
-      pu[0] = group16_bcast<U0 + 0>(p); pu[1] = group16_bcast<U0 + 1>(p); pu[2] = group16_bcast<U0 + 2>(p);
-      pu[3] = group16_bcast<U0 + 3>(p); pu[4] = group16_bcast<U0 + 4>(p); pu[5] = group16_bcast<U0 + 5>(p);
-      pu[6] = group16_bcast<U0 + 6>(p); pu[7] = group16_bcast<U0 + 7>(p);
+    // CNT source rows in flight, then CNT multiply-adds in edge order.  CNT = 2 serves the rows of a circuit DAG (one or two
+    // in-edges: nine of ten rows of the first pooling) without issuing the other six row loads of an eight-chunk -- these kernels are
+    // bound by instruction issue there, and a skipped slot is a skipped instruction only when the whole chunk form is smaller
+    auto rows = [&](auto first, auto count) {
+      constexpr int U0 = decltype(first)::value, CNT = decltype(count)::value;
+      int ju[CNT];
+      float pu[CNT], xv[CNT][NV];
+      ju[0] = group16_bcast<U0 + 0>(j); ju[1] = group16_bcast<U0 + 1>(j);
+      pu[0] = group16_bcast<U0 + 0>(p); pu[1] = group16_bcast<U0 + 1>(p);
+      if constexpr (CNT == 8) {
+        ju[2] = group16_bcast<U0 + 2>(j); ju[3] = group16_bcast<U0 + 3>(j); ju[4] = group16_bcast<U0 + 4>(j);
+        ju[5] = group16_bcast<U0 + 5>(j); ju[6] = group16_bcast<U0 + 6>(j); ju[7] = group16_bcast<U0 + 7>(j);
+        pu[2] = group16_bcast<U0 + 2>(p); pu[3] = group16_bcast<U0 + 3>(p); pu[4] = group16_bcast<U0 + 4>(p);
+        pu[5] = group16_bcast<U0 + 5>(p); pu[6] = group16_bcast<U0 + 6>(p); pu[7] = group16_bcast<U0 + 7>(p);
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < CNT; ++u) {
         const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
 #pragma unroll
         for (int v = 0; v < NV; ++v) xv[u][v] = has[v] ? xj[v * kGroup] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < CNT; ++u)
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = fmaf(pu[u], xv[u][v], acc[v]);
     };
-    rows(EdgeChunk<0>{});
-    if (k > 8) rows(EdgeChunk<8>{});
+    if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{});
+    else {
+      rows(EdgeChunk<0>{}, EdgeChunk<8>{});
+      if (k > 8) rows(EdgeChunk<8>{}, EdgeChunk<8>{});
+    }
   }
   {  // the self-loop last, as appended by add_remaining_self_loops
     const float s = leaky(ai + c_src[row]);

@@ -390,11 +390,15 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 // softmax weight, its gp -- and writes al / gp for it, so a chunk's results leave as two coalesced 64-byte stores; only the
 // dot product gnew[i] . x[src] of an edge involves the whole group.  Statistics (max, denominator) are recomputed first
 // by the same lane-per-edge walk.
-template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
+// TIES: the walk also counts, per channel, the entries of the row (sources and the row itself) that attain xmax[row, :] -- what
+// the backward of ASAPooling's segment max (same x, same entries) needs from a pass of its own otherwise (segment_max_share_kernel:
+// one more gather of every source row); tie_count[row, c] as a float.
+template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xnew, int64_t ldn,
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
-    float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a) {
+    float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a,
+    const float* __restrict__ xmax, int64_t ldm, float* __restrict__ tie_count, int64_t ldt) {
   const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
@@ -403,12 +407,15 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
   bool has[NV];
   float gi[NV];
+  float mx[TIES ? NV : 1];
+  int ties[TIES ? NV : 1];
   float d = 0.f;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     has[v] = l + v * kGroup < C;
     gi[v] = has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f;
     d = fmaf(gi[v], has[v] ? xnew[row * ldn + l + v * kGroup] : 0.f, d);
+    if (TIES) { mx[v] = has[v] ? xmax[row * ldm + l + v * kGroup] : 0.f; ties[v] = 0; }
   }
   const float delta = group16_sum(d);
   // statistics: running maximum and denominator over the edges, then the self-loop
@@ -430,30 +437,39 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
     const int j = idx[e0 + min(l, k - 1)];
     const float pre = ai + c_src[j];
     float mydot = 0.f;
-    auto dots = [&](auto first) {                      // eight source rows in flight; lane u keeps the dot product of edge u
-      constexpr int U0 = decltype(first)::value;
-      int ju[8];
-      float xv[8][NV];
-      ju[0] = group16_bcast<U0 + 0>(j); ju[1] = group16_bcast<U0 + 1>(j); ju[2] = group16_bcast<U0 + 2>(j);
-      ju[3] = group16_bcast<U0 + 3>(j); ju[4] = group16_bcast<U0 + 4>(j); ju[5] = group16_bcast<U0 + 5>(j);
-      ju[6] = group16_bcast<U0 + 6>(j); ju[7] = group16_bcast<U0 + 7>(j);
+    auto dots = [&](auto first, auto count) {          // CNT source rows in flight; lane u keeps the dot product of edge u
+      constexpr int U0 = decltype(first)::value, CNT = decltype(count)::value;   // CNT = 2: the short rows of a circuit DAG (see attn.hip)
+      int ju[CNT];
+      float xv[CNT][NV];
+      ju[0] = group16_bcast<U0 + 0>(j); ju[1] = group16_bcast<U0 + 1>(j);
+      if constexpr (CNT == 8) {
+        ju[2] = group16_bcast<U0 + 2>(j); ju[3] = group16_bcast<U0 + 3>(j); ju[4] = group16_bcast<U0 + 4>(j);
+        ju[5] = group16_bcast<U0 + 5>(j); ju[6] = group16_bcast<U0 + 6>(j); ju[7] = group16_bcast<U0 + 7>(j);
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < CNT; ++u) {
         const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
 #pragma unroll
         for (int v = 0; v < NV; ++v) xv[u][v] = has[v] ? xj[v * kGroup] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < CNT; ++u) {
         float dd = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) dd = fmaf(gi[v], xv[u][v], dd);
         dd = group16_sum(dd);
         if (l == U0 + u) mydot = dd;
+        if (TIES) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) ties[v] += (U0 + u < k && has[v] && xv[u][v] == mx[v]) ? 1 : 0;
+        }
       }
     };
-    dots(EdgeChunk<0>{});
-    if (k > 8) dots(EdgeChunk<8>{});
+    if (k <= 2) dots(EdgeChunk<0>{}, EdgeChunk<2>{});
+    else {
+      dots(EdgeChunk<0>{}, EdgeChunk<8>{});
+      if (k > 8) dots(EdgeChunk<8>{}, EdgeChunk<8>{});
+    }
     if (l < k) {
       const float al = expf(leaky(pre) - m) * inv;
       const float gp = al * (mydot - delta) * (pre > 0.f ? 1.f : slope);
@@ -468,7 +484,14 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
     const float al = expf(leaky(pre) - m) * inv;
     float dd = 0.f;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) dd = fmaf(gi[v], has[v] ? x[row * ldx + l + v * kGroup] : 0.f, dd);
+    for (int v = 0; v < NV; ++v) {
+      const float xs = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
+      dd = fmaf(gi[v], xs, dd);
+      if (TIES) {
+        ties[v] += (has[v] && xs == mx[v]) ? 1 : 0;
+        if (has[v]) tie_count[row * ldt + l + v * kGroup] = (float)ties[v];
+      }
+    }
     dd = group16_sum(dd);
     const float gp = al * (dd - delta) * (pre > 0.f ? 1.f : slope);
     ga += gp;
@@ -597,25 +620,34 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
     const int i = odst[ee], pos = oeid[ee];
     const float al = l < k ? edge_al[pos] : 0.f;        // lanes past the end: the last edge again with weight 0
     if (l < k) gc += edge_gp[pos];
-    auto rows = [&](auto first) {
-      constexpr int U0 = decltype(first)::value;
-      int iu[8];
-      float au[8], gn[8][NV];
-      group16_bcast8<U0>(i, iu);
-      group16_bcast8<U0>(al, au);
+    auto rows = [&](auto first, auto count) {
+      constexpr int U0 = decltype(first)::value, CNT = decltype(count)::value;   // CNT = 2: the short rows of a circuit DAG (see attn.hip)
+      int iu[CNT];
+      float au[CNT], gn[CNT][NV];
+      iu[0] = group16_bcast<U0 + 0>(i); iu[1] = group16_bcast<U0 + 1>(i);
+      au[0] = group16_bcast<U0 + 0>(al); au[1] = group16_bcast<U0 + 1>(al);
+      if constexpr (CNT == 8) {
+        iu[2] = group16_bcast<U0 + 2>(i); iu[3] = group16_bcast<U0 + 3>(i); iu[4] = group16_bcast<U0 + 4>(i);
+        iu[5] = group16_bcast<U0 + 5>(i); iu[6] = group16_bcast<U0 + 6>(i); iu[7] = group16_bcast<U0 + 7>(i);
+        au[2] = group16_bcast<U0 + 2>(al); au[3] = group16_bcast<U0 + 3>(al); au[4] = group16_bcast<U0 + 4>(al);
+        au[5] = group16_bcast<U0 + 5>(al); au[6] = group16_bcast<U0 + 6>(al); au[7] = group16_bcast<U0 + 7>(al);
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < CNT; ++u) {
         const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg + l;
 #pragma unroll
         for (int v = 0; v < NV; ++v) gn[u][v] = has[v] ? gi[v * kGroup] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < CNT; ++u)
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = fmaf(au[u], gn[u][v], acc[v]);
     };
-    rows(EdgeChunk<0>{});
-    if (k > 8) rows(EdgeChunk<8>{});
+    if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{});
+    else {
+      rows(EdgeChunk<0>{}, EdgeChunk<8>{});
+      if (k > 8) rows(EdgeChunk<8>{}, EdgeChunk<8>{});
+    }
   }
   gc = group16_sum(gc) + edge_gp[E + row];
   float* __restrict__ d = gx + row * ldgx + l;
@@ -673,6 +705,25 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_share_ke
     if (has[v]) gshare[row * lds + l + v * kGroup] = gmax[row * ldg + l + v * kGroup] / (float)(cnt[v] > 0 ? cnt[v] : 1);
 }
 
+// Pass 1 when the tie counts are already known (softmax_aggregate_bwd_dst_kernel<., true>): an elementwise division, a thread per
+// 16-byte slice of a row (VEC = 4: all three matrices in the padded row layout) or per element
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void segment_max_share_from_counts_kernel(const float* __restrict__ gmax, int64_t ldg,
+                                                                               const float* __restrict__ cnt, int64_t ldc, int64_t N, int C,
+                                                                               float* __restrict__ gshare, int64_t lds) {
+  const int cv = (C + VEC - 1) / VEC;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= N * cv) return;
+  const int64_t row = t / cv;
+  const int c = (int)(t - row * cv) * VEC;
+  float g[VEC], n[VEC];
+  vload<VEC>(gmax + row * ldg + c, g);
+  vload<VEC>(cnt + row * ldc + c, n);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) g[v] = g[v] / (n[v] > 0.f ? n[v] : 1.f);       // pad columns: scratch in, scratch out
+  vstore<VEC>(gshare + row * lds + c, g);
+}
+
 // Pass 2 (source side): g_x[j,c] += sum over destinations i of j (and j itself) whose maximum equals x[j,c].
 template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
@@ -693,13 +744,17 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kern
   for (int e0 = beg; e0 < end; e0 += kGroup) {
     const int k = min(kGroup, end - e0);
     const int i = odst[e0 + min(l, k - 1)];
-    auto rows = [&](auto first, int kk) {
-      constexpr int U0 = decltype(first)::value;
-      int iu[8];
-      float xm[8][NV], gm[8][NV];
-      group16_bcast8<U0>(i, iu);
+    auto rows = [&](auto first, auto count, int kk) {
+      constexpr int U0 = decltype(first)::value, CNT = decltype(count)::value;   // CNT = 2: the short rows of a circuit DAG (see attn.hip)
+      int iu[CNT];
+      float xm[CNT][NV], gm[CNT][NV];
+      iu[0] = group16_bcast<U0 + 0>(i); iu[1] = group16_bcast<U0 + 1>(i);
+      if constexpr (CNT == 8) {
+        iu[2] = group16_bcast<U0 + 2>(i); iu[3] = group16_bcast<U0 + 3>(i); iu[4] = group16_bcast<U0 + 4>(i);
+        iu[5] = group16_bcast<U0 + 5>(i); iu[6] = group16_bcast<U0 + 6>(i); iu[7] = group16_bcast<U0 + 7>(i);
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < CNT; ++u) {
         const float* __restrict__ xi = xmax + (int64_t)iu[u] * ldm + l;
         const float* __restrict__ gi = gmax + (int64_t)iu[u] * ldg + l;
 #pragma unroll
@@ -709,12 +764,15 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kern
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < CNT; ++u)
 #pragma unroll
         for (int v = 0; v < NV; ++v) if (u < kk && has[v] && xv[v] == xm[u][v]) acc[v] += gm[u][v];
     };
-    rows(EdgeChunk<0>{}, k);
-    if (k > 8) rows(EdgeChunk<8>{}, k - 8);
+    if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{}, k);
+    else {
+      rows(EdgeChunk<0>{}, EdgeChunk<8>{}, k);
+      if (k > 8) rows(EdgeChunk<8>{}, EdgeChunk<8>{}, k - 8);
+    }
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) if (has[v]) gx[row * ldgx + l + v * kGroup] += acc[v];
@@ -927,15 +985,25 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
                                                    const int32_t* out_dst, const int32_t* out_eid, const float* a_dst,
                                                    const float* c_src, float negative_slope, int64_t N, int64_t E,
                                                    int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
-                                                   float* g_c, float* edge_al, float* edge_gp, mlqem_stream_t stream) {
+                                                   float* g_c, float* edge_al, float* edge_gp, const float* xmax, int64_t ldm,
+                                                   float* tie_count, int64_t ldt, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || C <= 0 || ldx < C || ldn < C || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
+  if (tie_count && (!xmax || ldm < C || ldt < C)) return MLQEM_ERR_BAD_ARG;
+  if (tie_count && C > 128) return MLQEM_ERR_UNSUPPORTED;      // the any-width form does not count
   if (N == 0) return MLQEM_OK;
   if (!x || !xnew || !gnew || !in_ptr || !out_ptr || !a_dst || !c_src || !gx || !g_a || !g_c || !edge_al || !edge_gp)
     return MLQEM_ERR_BAD_ARG;
   if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
-#define MLQEM_SAB(NV) hipLaunchKernelGGL(softmax_aggregate_bwd_dst_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, \
-                                         in_ptr, in_src, a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a)
+#define MLQEM_SAB(NV)                                                                                                                          \
+  do {                                                                                                                                         \
+    if (tie_count)                                                                                                                             \
+      hipLaunchKernelGGL((softmax_aggregate_bwd_dst_kernel<NV, true>), MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,   \
+                         a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a, xmax, ldm, tie_count, ldt);                            \
+    else                                                                                                                                       \
+      hipLaunchKernelGGL((softmax_aggregate_bwd_dst_kernel<NV, false>), MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,  \
+                         a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a, nullptr, 0, nullptr, 0);                               \
+  } while (0)
   if (C <= 16) MLQEM_SAB(1);
   else if (C <= 32) MLQEM_SAB(2);
   else if (C <= 48) MLQEM_SAB(3);
@@ -959,17 +1027,30 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
   return launch_status();
 }
 
+static void launch_share_from_counts(const float* gmax, int64_t ldg, const float* cnt, int64_t ldc, int64_t N, int C, float* gshare,
+                                     int64_t lds, mlqem_stream_t stream) {
+  const int c4 = (C + 3) / 4 * 4;
+  const bool vec = ldg % 4 == 0 && ldc % 4 == 0 && lds % 4 == 0 && ldg >= c4 && ldc >= c4 && lds >= c4 && aligned_to(gmax, 16) &&
+                   aligned_to(cnt, 16) && aligned_to(gshare, 16);
+  if (vec) hipLaunchKernelGGL(segment_max_share_from_counts_kernel<4>, MLQEM_GRID(N * (c4 / 4)), gmax, ldg, cnt, ldc, N, C, gshare, lds);
+  else hipLaunchKernelGGL(segment_max_share_from_counts_kernel<1>, MLQEM_GRID(N * C), gmax, ldg, cnt, ldc, N, C, gshare, lds);
+}
+
 extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm,
                                              const float* gmax, int64_t ldg, const int32_t* in_ptr,
                                              const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                              int64_t N, int C, float* gx, int64_t ldgx, float* gshare, int64_t lds,
-                                             mlqem_stream_t stream) {
+                                             const float* tie_count, int64_t ldt, mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || C <= 0 || ldx < C || ldm < C || ldg < C || ldgx < C || lds < C) return MLQEM_ERR_BAD_ARG;
+  if (N < 0 || C <= 0 || ldx < C || ldm < C || ldg < C || ldgx < C || lds < C || (tie_count && ldt < C)) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!x || !xmax || !gmax || !in_ptr || !out_ptr || !gx || !gshare) return MLQEM_ERR_BAD_ARG;
+  if (tie_count && C > 128) return MLQEM_ERR_UNSUPPORTED;
 #define MLQEM_SMB(NV)                                                                                                        \
   do {                                                                                                                       \
+    if (tie_count)                                                                                                           \
+      launch_share_from_counts(gmax, ldg, tie_count, ldt, N, C, gshare, lds, stream);                                         \
+    else                                                                                                                     \
     hipLaunchKernelGGL(segment_max_share_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, N, \
                        C, gshare, lds);                                                                                      \
     hipLaunchKernelGGL(segment_max_bwd_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xmax, ldm, gshare, lds, out_ptr, out_dst,  \

@@ -540,3 +540,35 @@ def test_family_b_reads_the_arena_rows_through_the_row_map(g1):
     assert torch.equal(res[0][0], res[1][0])
     for ga, gb in zip(res[0][1], res[1][1]):
         assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("c", [30, 45, 7])
+def test_segment_max_backward_takes_its_tie_counts_from_the_softmax_walk(g1, c):
+    """mlqem_csr_softmax_aggregate_bwd_f32 with xmax / tie_count and mlqem_csr_segment_max_bwd_f32 with tie_count: the same gx,
+    bit for bit, as the segment max's own destination-side walk -- on features quantised so that maxima are attained several
+    times (circuit graphs do that: identical gates on one qubit have identical rows)."""
+    from blackwater.native import ops
+    from blackwater.native.structure import GraphStructure
+
+    b = g1_batch(g1, list(range(40)), self_loops=False, first_only=False)
+    n = b["x"].shape[0]
+    s = GraphStructure.from_edge_index(b["edge_index"].to(DEV), n, batch=b["batch"].to(DEV), num_graphs=40)
+    g = torch.Generator().manual_seed(c)
+    x = ops.padded_copy((torch.randint(0, 3, (n, c), generator=g).float() * 0.5).to(DEV))
+    xmax = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
+    a_dst, c_src = torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, 0.2)
+    gnew = ops.padded_copy(torch.randn(n, c, generator=g).to(DEV))
+    gmax = ops.padded_copy(torch.randn(n, c, generator=g).to(DEV))
+    e = s.edge_count()
+    gx0, ga0, gc0 = ops.csr_softmax_aggregate_bwd(x, x_new, gnew, s, e, a_dst, c_src, 0.2)
+    gx1, ga1, gc1, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gnew, s, e, a_dst, c_src, 0.2, xmax=xmax)
+    assert torch.equal(gx0, gx1) and torch.equal(ga0, ga1) and torch.equal(gc0, gc1)
+    # the counts against a direct enumeration
+    src, dst = b["edge_index"][0].to(DEV), b["edge_index"][1].to(DEV)
+    want = (x == xmax).float()
+    want.index_add_(0, dst, (x[src] == xmax[dst]).float())
+    assert torch.equal(ties, want) and ties.max().item() >= 2
+    ops.csr_segment_max_bwd_(gx0, x, xmax, gmax, s)
+    ops.csr_segment_max_bwd_(gx1, x, xmax, gmax, s, ties=ties)
+    assert torch.equal(gx0, gx1)
