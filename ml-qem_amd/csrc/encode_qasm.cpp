@@ -231,6 +231,165 @@ int bits_of(View arg, Registers& regs, std::vector<int>& out) {
   return 1;
 }
 
+// ---- the common statement, fast: `name q[i];`, `name(1.5707963267948966) q[i];`, `name q[i],q[j];` -------------------------
+// A transpiled circuit is tens of thousands of these (20 k statements per 100-qubit Trotter circuit, a run() of a VQE loop hands
+// over a thousand circuits: blackwater/library/ngem/estimator.py:49-84), and the general path spends its time in machinery they
+// do not need: two vectors of argument views, a hash of the gate name, strtod on a 17-digit literal.  Anything else -- angle
+// expressions, whole-register arguments, unknown registers, out-of-range indices, trailing text -- returns false and goes through
+// the general path, which also words the error messages.
+
+// A decimal literal [digits][.digits][e[+-]digits] at p (no sign) -> its correctly rounded double, or nullptr (then the caller
+// uses strtod).  Up to 19 significant digits are an exact 64-bit integer m; m * 10^e is exact in one operation when m < 2^53 and
+// |e| <= 22 (both operands exact doubles: one correctly rounded IEEE operation).  Otherwise, on x86-64, the operation is done in
+// the 80-bit format (m and 10^|e| <= 10^27 are exact there) and rounded to double a second time -- which is the correct rounding
+// unless the 64-bit mantissa sits within two units of a double's rounding boundary (the low 11 bits near 0x400): those literals
+// take strtod.  Checked against strtod on random and adversarial literals (fuzz/fuzz_encode_qasm.cpp, tests/test_native_encoder.py).
+const char* fast_literal(const char* p, const char* end, double& out) {
+  uint64_t m = 0;
+  int sig = 0, frac = 0, digits = 0;
+  bool dropped = false;
+  const char* q = p;
+  for (; q < end && is_digit(*q); ++q, ++digits) {
+    if (sig < 19) { m = m * 10 + (uint64_t)(*q - '0'); if (m) ++sig; } else dropped = true;
+  }
+  if (q < end && *q == '.') {
+    ++q;
+    for (; q < end && is_digit(*q); ++q, ++digits) {
+      if (sig < 19) { m = m * 10 + (uint64_t)(*q - '0'); if (m) ++sig; ++frac; } else dropped = true;
+    }
+  }
+  if (digits == 0 || dropped) return nullptr;
+  int e10 = 0;
+  if (q < end && (*q == 'e' || *q == 'E')) {
+    const char* r = q + 1;
+    bool neg = false;
+    if (r < end && (*r == '+' || *r == '-')) { neg = *r == '-'; ++r; }
+    if (r >= end || !is_digit(*r)) return nullptr;
+    for (; r < end && is_digit(*r); ++r) { e10 = e10 * 10 + (*r - '0'); if (e10 > 400) return nullptr; }
+    if (neg) e10 = -e10;
+    q = r;
+  }
+  e10 -= frac;
+  if (m == 0) { out = 0.0; return q; }
+  static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20,
+                                 1e21, 1e22};
+  if (m < (1ull << 53) && e10 >= -22 && e10 <= 22) {
+    out = e10 < 0 ? (double)m / p10[-e10] : (double)m * p10[e10];
+    return q;
+  }
+#if defined(__x86_64__) && defined(__LDBL_MANT_DIG__) && __LDBL_MANT_DIG__ == 64
+  if (e10 >= -27 && e10 <= 27) {
+    static const long double p10l[28] = {1e0L, 1e1L, 1e2L, 1e3L, 1e4L, 1e5L, 1e6L, 1e7L, 1e8L, 1e9L, 1e10L, 1e11L, 1e12L, 1e13L, 1e14L, 1e15L, 1e16L, 1e17L,
+                                         1e18L, 1e19L, 1e20L, 1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+    const long double r = e10 < 0 ? (long double)m / p10l[-e10] : (long double)m * p10l[e10];
+    uint64_t mant;
+    std::memcpy(&mant, &r, sizeof mant);                  // the explicit 64-bit significand of the x87 format
+    const unsigned low = (unsigned)(mant & 0x7FFu);
+    if (low >= 0x3FEu && low <= 0x402u) return nullptr;   // too close to a double's rounding boundary to round twice
+    out = (double)r;                                      // 19 digits x 10^+-27: far inside the normal range of double
+    return q;
+  }
+#endif
+  return nullptr;
+}
+
+// the last few gate names of a circuit, compared by length and bytes: no hash per statement
+struct NameCache {
+  static constexpr int kSlots = 8;
+  const char* ptr[kSlots]; size_t len[kSlots]; int id[kSlots];
+  int used = 0, next = 0;
+  void reset() { used = next = 0; }
+};
+
+int intern_cached(Circuit& c, NameCache& cache, View name) {
+  for (int k = 0; k < cache.used; ++k)
+    if (cache.len[k] == name.size() && std::memcmp(cache.ptr[k], name.data(), name.size()) == 0) return cache.id[k];
+  const int id = c.intern(name);
+  const std::string& kept = c.names[(size_t)id];        // a deque element: its bytes stay where they are
+  const int slot = cache.used < NameCache::kSlots ? cache.used++ : (cache.next++ % NameCache::kSlots);
+  cache.ptr[slot] = kept.data(); cache.len[slot] = kept.size(); cache.id[slot] = id;
+  return id;
+}
+
+// what the statement loop below recognises by prefix (and `gate` / `opaque` / `if`, which are no applications of a gate)
+inline bool is_keyword(View w) {
+  switch (w[0]) {
+    case 'O': return starts_with(w, "OPENQASM");
+    case 'i': return starts_with(w, "include") || w == "if";
+    case 'q': return starts_with(w, "qreg");
+    case 'c': return starts_with(w, "creg");
+    case 'm': return starts_with(w, "measure");
+    case 'b': return starts_with(w, "barrier");
+    case 'r': return starts_with(w, "reset");
+    case 'g': return w == "gate";
+    case 'o': return w == "opaque";
+    default: return false;
+  }
+}
+
+// `st` (trimmed, non-empty) as one gate on explicit bits; false = not of that form (nothing was appended to c)
+bool fast_gate(View st, Circuit& c, Registers& qregs, NameCache& cache) {
+  const char* p = st.data();
+  const char* const end = p + st.size();
+  const char* w = p;
+  while (w < end && is_word(*w)) ++w;
+  if (w == p || is_digit(*p)) return false;
+  const View name(p, (size_t)(w - p));
+  if (is_keyword(name)) return false;
+  double param = 0.0;
+  int p_cnt = 0;
+  p = w;
+  while (p < end && is_space(*p)) ++p;
+  if (p < end && *p == '(') {
+    ++p;
+    while (p < end && is_space(*p)) ++p;
+    bool neg = false;
+    if (p < end && *p == '-') { neg = true; ++p; while (p < end && is_space(*p)) ++p; }
+    const char* after = fast_literal(p, end, param);
+    if (!after) return false;
+    p = after;
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end || *p != ')') return false;              // an expression, a second parameter: the general path
+    ++p;
+    if (neg) param = -param;
+    p_cnt = 1;
+    while (p < end && is_space(*p)) ++p;
+  }
+  int bits[3], n_bits = 0;
+  for (;;) {
+    const char* r = p;
+    while (r < end && is_word(*r)) ++r;
+    if (r == p || n_bits == 3) return false;
+    const View reg(p, (size_t)(r - p));
+    p = r;
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end || *p != '[') return false;              // a whole-register argument broadcasts: the general path
+    ++p;
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end || !is_digit(*p)) return false;
+    long idx = 0;
+    for (; p < end && is_digit(*p); ++p) { idx = idx * 10 + (*p - '0'); if (idx > kMaxRegisterBits) return false; }
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end || *p != ']') return false;
+    ++p;
+    const Reg* rg = qregs.find(reg);
+    if (!rg || idx >= rg->size) return false;             // the general path words the error
+    bits[n_bits++] = rg->base + (int)idx;
+    while (p < end && is_space(*p)) ++p;
+    if (p == end) break;
+    if (*p != ',') return false;
+    ++p;
+    while (p < end && is_space(*p)) ++p;
+  }
+  const int type = intern_cached(c, cache, name);
+  const int q_off = (int)c.bits.size();
+  for (int k = 0; k < n_bits; ++k) c.bits.push_back(bits[k]);
+  const int p_off = (int)c.params.size();
+  if (p_cnt) c.params.push_back(param);
+  c.ops.push_back(Op{type, q_off, n_bits, q_off, 0, p_off, p_cnt});
+  return true;
+}
+
 // Parses `text` into c (cleared first; its capacity is reused).  `buf_a` / `buf_b` are scratch strings for the stripped text.
 void parse_qasm(const char* text, Circuit& c, std::string& s, std::string& t) {
   const size_t len = std::strlen(text);
@@ -272,6 +431,9 @@ void parse_qasm(const char* text, Circuit& c, std::string& s, std::string& t) {
   c.clear();
   c.barrier = c.intern("barrier"); c.measure = c.intern("measure"); c.reset = c.intern("reset");
   Registers qregs, cregs;
+  NameCache name_cache;
+  name_cache.reset();
+  static const bool fast_path = !(std::getenv("MLQEM_QASM_FAST") && std::atoi(std::getenv("MLQEM_QASM_FAST")) == 0);
   std::vector<View> pieces;
   std::vector<int> arg_off, arg_cnt, scratch;
   size_t pos = 0;
@@ -279,7 +441,9 @@ void parse_qasm(const char* text, Circuit& c, std::string& s, std::string& t) {
     const size_t semi = all.find(';', pos);
     const View st = trim(all.substr(pos, semi == View::npos ? View::npos : semi - pos));
     pos = semi == View::npos ? all.size() : semi + 1;
-    if (st.empty() || starts_with(st, "OPENQASM") || starts_with(st, "include")) continue;
+    if (st.empty()) continue;
+    if (fast_path && fast_gate(st, c, qregs, name_cache)) continue;
+    if (starts_with(st, "OPENQASM") || starts_with(st, "include")) continue;
     if (starts_with(st, "qreg") || starts_with(st, "creg")) {
       const bool q = st[0] == 'q';
       const View rest = trim(st.substr(4));
@@ -435,10 +599,26 @@ Sizes scan(const Circuit& c, const mlqem_backend_props* props, int use_q, const 
 struct GateProps {
   std::unordered_map<std::string, int> by_key;
   std::unordered_map<uint64_t, int> packed;
+  std::vector<int> one_qubit;            // [type][register-local qubit]: -2 = not looked up yet (gates on one qubit: no hash per node)
+  int nq1 = 0;
   std::string key;
   explicit GateProps(const mlqem_backend_props* props) { for (int i = 0; i < props->num_gate_props; ++i) by_key[props->gate_keys[i]] = i; }
+  int slow(const Circuit& c, const Op& op) {
+    const int* qs = c.qubits(op);
+    key = c.names[op.type];
+    for (int s = 0; s < op.q_cnt; ++s) { key += '_'; key += std::to_string(c.reg_index[qs[s]]); }
+    auto it = by_key.find(key);
+    return it == by_key.end() ? -1 : it->second;
+  }
   int find(const Circuit& c, const Op& op) {
     const int* qs = c.qubits(op);
+    if (op.q_cnt == 1) {
+      if (one_qubit.empty()) { nq1 = std::max(c.nq, 1); one_qubit.assign(c.names.size() * (size_t)nq1, -2); }
+      const int qi = c.reg_index[qs[0]];
+      int& slot = one_qubit[(size_t)op.type * nq1 + qi];     // qi < the register's size <= nq
+      if (slot == -2) slot = slow(c, op);
+      return slot;
+    }
     const bool packable = op.q_cnt <= 2 && op.type < (1 << 20);     // 2 x 21 bits of qubit index, 2 of count, 20 of type
     uint64_t pk = 0;
     if (packable) {
@@ -447,10 +627,7 @@ struct GateProps {
       auto hit = packed.find(pk);
       if (hit != packed.end()) return hit->second;
     }
-    key = c.names[op.type];
-    for (int s = 0; s < op.q_cnt; ++s) { key += '_'; key += std::to_string(c.reg_index[qs[s]]); }
-    auto it = by_key.find(key);
-    const int g = it == by_key.end() ? -1 : it->second;
+    const int g = slow(c, op);
     if (packable) packed.emplace(pk, g);
     return g;
   }

@@ -151,3 +151,95 @@ def test_batch_feature_scan_equals_the_per_circuit_scan(g1, lima_props):
     a, _ = encode_data(texts, lima_props, [[0.0]] * len(texts), noisy, 1, meas_bases=bases, native=True)
     b, _ = encode_data(texts, lima_props, [[0.0]] * len(texts), noisy, 1, meas_bases=bases, native=False)
     assert torch.equal(a, b)
+
+
+def _literal_corpus():
+    """Decimal literals that exercise the scanner's own number path: shortest round-trip reprs, the same values cut to 1-19
+    digits, exponent forms, more than 19 digits (-> strtod), and the decimal expansions of points HALFWAY between two adjacent
+    doubles cut to 17-19 digits (where rounding an extended-precision result a second time would go wrong)."""
+    from decimal import Decimal, getcontext
+
+    getcontext().prec = 60
+    rng = np.random.RandomState(7)
+    lits = ["0", "0.0", "1", "3.", ".5", "0.001", "000012.5000", "1e3", "1E-3", "2.5e+2", "6.283185307179586", "1.5707963267948966",
+            "7.853981633974483", "123456789012345678", "1234567890123456789", "12345678901234567890123", "0.30000000000000004",
+            "9007199254740993", "9007199254740992.5", "4.35", "0.1e-10", "1e22", "1e23", "8.5e-27", "1.7976931348623157e308", "5e-324"]
+    vals = np.concatenate([rng.uniform(-10, 10, 3000), rng.lognormal(0, 6, 3000), rng.uniform(0, 2 * np.pi, 3000)])
+    for v in np.abs(vals):
+        r = repr(float(v))
+        lits.append(r)
+        d = Decimal(r)
+        for k in (3, 9, 15, 16, 17, 18, 19):
+            lits.append(format(d, f".{k}f") if d < 1000 else format(d, f".{k}e"))
+        lo = float(v)
+        hi = np.nextafter(lo, np.inf)
+        mid = (Decimal(lo) + Decimal(float(hi))) / 2                  # exact: both are dyadic rationals
+        for k in (17, 18, 19, 20):
+            s = format(mid, "f")
+            digits = 0
+            cut = []
+            for ch in s:                                              # k significant digits of the midpoint's expansion
+                cut.append(ch)
+                if ch.isdigit() and (digits or ch != "0"):
+                    digits += 1
+                if digits == k:
+                    break
+            lits.append("".join(cut))
+    return [l for l in lits if "e" not in l.lower() or "." in l or l[0].isdigit()]
+
+
+def test_scanner_literals_are_correctly_rounded(lima_props):
+    """Every parameter the fast statement path parses itself (csrc/encode_qasm.cpp: fast_literal) equals Python's float() of the
+    same text bit for bit -- i.e. strtod's correctly rounded value, which the general path uses -- also with a sign."""
+    props = dict(lima_props)
+    lits = _literal_corpus()
+    assert len(lits) > 60000
+    text = 'OPENQASM 2.0;\ninclude "qelib1.inc";\nqreg q[5];\n' + "".join(
+        f"rz({'-' if k % 3 == 0 else ''}{l}) q[{k % 5}];\n" for k, l in enumerate(lits))
+    x, _, _, _ = NativeEncoder(props).encode(text, edge_attr=False)
+    want = np.array([(-1.0 if k % 3 == 0 else 1.0) * float(l) for k, l in enumerate(lits)])
+    got = x[:, 0]
+    bad = np.nonzero(got.view(np.int64) != want.view(np.int64))[0]
+    assert bad.size == 0, [(lits[i], got[i], want[i]) for i in bad[:5]]
+
+
+def test_fast_statement_path_equals_the_general_path(g1, lima_props, tmp_path):
+    """MLQEM_QASM_FAST=0 (read once per process: a child interpreter) sends every statement through the general path; rows, edges
+    and depths of the fast path are identical on transpiled circuits, hand-written statement shapes and refused inputs alike."""
+    import subprocess
+    import sys
+
+    texts = [circuit_to_qasm(tfim_circuit(6, s, 0.3 * s + 0.1, two_q="cx")) for s in range(4)]
+    texts.append('OPENQASM 2.0;\ninclude "qelib1.inc";\nqreg q[5];\ncreg c[5];\nrz( -0.5 ) q[ 1 ] ;\nsx q[1];cx q[0] , q[1];\nrz(pi/2) q[2];\n'
+                 'x q;\nbarrier q[0],q[1];\nrz(+1.25) q[3];\nrz(1.5.3e) q[4];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nsx q[7];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nsx r[0];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nrz(0.25) q[1]junk;\nsx q[0];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nmeasurez q[0];\n')
+    (tmp_path / "texts.json").write_text(json.dumps(texts))
+    (tmp_path / "props.json").write_text(json.dumps(lima_props))
+    script = (
+        "import json, sys, numpy as np\n"
+        f"sys.path[:0] = {[p for p in sys.path if p]!r}\n"
+        "from blackwater.data.native_encoder import NativeEncoder\n"
+        f"texts = json.load(open({str(tmp_path / 'texts.json')!r}))\n"
+        f"enc = NativeEncoder(json.load(open({str(tmp_path / 'props.json')!r})))\n"
+        "out = {}\n"
+        "for k, t in enumerate(texts):\n"
+        "    try:\n"
+        "        x, ei, ea, d = enc.encode(t)\n"
+        "        out[f'x{k}'], out[f'e{k}'], out[f'a{k}'], out[f'd{k}'] = x, ei, ea, np.array(d)\n"
+        "    except Exception as err:\n"
+        "        out[f'err{k}'] = np.array(type(err).__name__ + ': ' + str(err))\n"
+        "np.savez(sys.argv[1], **out)\n")
+    res = {}
+    for mode in ("1", "0"):
+        path = tmp_path / f"out{mode}.npz"
+        env = dict(os.environ, MLQEM_QASM_FAST=mode)
+        subprocess.run([sys.executable, "-c", script, str(path)], check=True, env=env, timeout=300)
+        res[mode] = dict(np.load(path))
+    assert sorted(res["1"]) == sorted(res["0"])
+    assert any(k.startswith("err") for k in res["1"]) and any(k.startswith("x") for k in res["1"])
+    for key in res["1"]:
+        a, b = res["1"][key], res["0"][key]
+        assert a.shape == b.shape and (a == b).all(), key
