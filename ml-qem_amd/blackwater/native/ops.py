@@ -341,12 +341,18 @@ def _gate(gate, n, o, padded: bool):
 _MFMA_MAX_IN = 128    # input columns the matrix-core GEMM kernels take in one call (csrc/dense.hip: round_ks)
 
 
+_WIDE_SPLIT_MIN_OUTPUTS = 1 << 16     # (rows x outputs) below which a wide-input product is one scalar-kernel launch
+
+
 def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=None, accumulate=False, drop_p=0.0,
            seed=0, rs_cols=-1, act_from=-1, gate=None, gate_scale=1.0):
     """y = act(x @ w.T + b) (``transposed=False``, w: [O,I]) or y = x @ w (``transposed=True``, w: [I,O]);
     ``gate``: y = gate > 0 ? y * gate_scale : 0 as the last step."""
     i = x.shape[1]
-    if i > _MFMA_MAX_IN and not transposed and torch.is_tensor(x) and w.dim() == 2 and w.shape[1] == i:
+    # ... unless the product is tiny (the observable MLP of Family A: 1024 rows x 401 -> 10): then the split -- four column
+    # slices, four copies, four launches -- costs more than the scalar kernel's one launch (a thread per output, 5 us)
+    if (i > _MFMA_MAX_IN and not transposed and torch.is_tensor(x) and w.dim() == 2 and w.shape[1] == i
+            and x.shape[0] * w.shape[0] > _WIDE_SPLIT_MIN_OUTPUTS):
         # The matrix-core kernels hold a row's inputs in registers (<= 128 columns); wider inputs (MLP rows of 169-170
         # encode_data_v2_ecr features, docs/tutorials/mlp.py:148-194) used to fall to a scalar kernel (1.3 ms for 262 k x 170 -> 125
         # against 0.15 ms here).  Split the k range: y = x[:, :128] W[:, :128]^T + b, then y += x[:, 128:] W[:, 128:]^T with the

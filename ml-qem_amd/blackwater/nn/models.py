@@ -101,7 +101,8 @@ class ExpValCircuitGraphModelA(nn.Module):
         if self._single_node_ok(nodes):
             # the same seven layers and three pools as below, as ONE autograd node (saves ~0.7 ms of host time per step)
             pooled = F.family_a_graph(nodes, s, p1, p2, seed, self._graph_params())
-            obs = torch.mean(self.obs_seq(observable), dim=1)
+            obs = self.obs_seq(observable)
+            obs = obs.squeeze(1) if obs.shape[1] == 1 else torch.mean(obs, dim=1)      # one Pauli term: the mean is the term (a view)
             return self.body_seq(torch.cat((pooled, obs, circuit_depth, exp_value), dim=1))
         g = self.conv1(nodes, s, relu=True, drop_p=p1, seed=seed + 1, defer_mask=True)
         g = self.conv2(g, s, relu=True, drop_p=p1, seed=seed + 2, defer_mask=True, x_gate_scale=k1)
