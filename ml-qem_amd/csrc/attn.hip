@@ -192,8 +192,8 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_kernel(const float* 
                                                                    float* __restrict__ out, int64_t ldo) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= K * C) return;
-  const int64_t p = t / C;
-  const int c = (int)(t - p * C);
+  int c;
+  const int64_t p = split_index(t, C, c);
   const int64_t j = perm[p];
   out[p * ldo + c] = x[j * ldx + c] * (scale ? scale[j] : 1.f);
 }

@@ -172,6 +172,19 @@ template <class F> __device__ __forceinline__ void for_edge_chunks(int beg, int 
   if (e < end) f(e, EdgeChunk<1>{});
 }
 
+// t = row * C + col for 0 <= col < C: a flat thread index split into (row, column).  The 64-bit division the plain expression
+// compiles to is ~80 vector instructions; indices below 2^32 (every launch of this path) take the 32-bit one (~20).
+__device__ __forceinline__ int64_t split_index(int64_t t, int C, int& col) {
+  if (t < (1ll << 32)) {
+    const uint32_t q = (uint32_t)t / (uint32_t)C;
+    col = (int)((uint32_t)t - q * (uint32_t)C);
+    return (int64_t)q;
+  }
+  const int64_t q = t / C;
+  col = (int)(t - q * C);
+  return q;
+}
+
 __device__ __forceinline__ bool aligned_to_dev(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // largest g in [0, B) with gptr[g] <= r (gptr[0] = 0 <= r): the graph of row r, or of the empty graphs just before it

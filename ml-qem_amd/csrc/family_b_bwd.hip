@@ -714,8 +714,9 @@ __global__ __launch_bounds__(kBlock) void segment_max_share_from_counts_kernel(c
   const int cv = (C + VEC - 1) / VEC;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= N * cv) return;
-  const int64_t row = t / cv;
-  const int c = (int)(t - row * cv) * VEC;
+  int cs;
+  const int64_t row = split_index(t, cv, cs);
+  const int c = cs * VEC;
   float g[VEC], n[VEC];
   vload<VEC>(gmax + row * ldg + c, g);
   vload<VEC>(cnt + row * ldc + c, n);
