@@ -572,3 +572,56 @@ def test_segment_max_backward_takes_its_tie_counts_from_the_softmax_walk(g1, c):
     ops.csr_segment_max_bwd_(gx0, x, xmax, gmax, s)
     ops.csr_segment_max_bwd_(gx1, x, xmax, gmax, s, ties=ties)
     assert torch.equal(gx0, gx1)
+
+
+@pytest.mark.parametrize("heads,ch", [(3, 15), (2, 15), (5, 25), (3, 25), (1, 16), (2, 32), (4, 3), (1, 1), (2, 17)])
+def test_attention_kernels_against_a_dense_reference(heads, ch):
+    """mlqem_transformer_attention_train_f32 / _bwd_f32 / the inference entry point (four channels per lane: 4 or 8 lanes per
+    (row, head), the last lane of a head partly filled for C = 15 / 25 / 17 / 3 / 1) against TransformerConv's formulas in
+    fp64 through torch autograd: rows of 0-40 in-edges (one to eleven chunks), repeated edges, rows with and without a
+    self-loop entry, NaN-poisoned row padding."""
+    from blackwater.native import ops
+    from blackwater.native.structure import GraphStructure
+
+    rng = np.random.RandomState(heads * 100 + ch)
+    n = 300
+    deg = rng.choice([0, 1, 2, 3, 4, 5, 8, 9, 17, 40], size=n)
+    dst = np.repeat(np.arange(n), deg)
+    src = rng.randint(0, n, size=dst.shape[0])
+    src = np.where(src == dst, (src + 1) % n, src)                      # self-loops are the structure's own entry
+    loops = rng.randint(0, 3, size=n)                                   # multiplicity 0, 1, 2 of the self entry
+    ei = np.concatenate([np.stack([src, dst]), np.repeat(np.stack([np.arange(n)] * 2), loops, axis=1)], axis=1)
+    s = GraphStructure.from_edge_index(torch.from_numpy(ei).to(DEV), n)
+    assert int(s.loops.sum().item()) == int(loops.sum()) and s.edge_count() == dst.shape[0]
+    hc = heads * ch
+    g = torch.Generator().manual_seed(ch)
+    qkvs_h = torch.randn(n, 4 * hc, generator=g)
+    gout_h = torch.randn(n, hc, generator=g)
+
+    def poisoned(t):
+        buf = torch.full((t.shape[0], (t.shape[1] + 3) // 4 * 4 + 4), float("nan"), device=DEV)     # pads AND slack after the row
+        buf[:, :t.shape[1]] = t.to(DEV)
+        return buf[:, :t.shape[1]]
+
+    qkvs = ops.padded_copy(qkvs_h.to(DEV))            # [N, 4 H C]: no padding inside (4 H C is a multiple of 4)
+    out, attn, m, den = ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, s.edge_count(), heads, ch)
+    gq = ops.transformer_attention_bwd(qkvs, poisoned(gout_h), attn, m, den, s, s.edge_count(), heads, ch)
+    inf = ops.transformer_attention(qkvs, s.in_ptr, s.in_src, s.loops, heads, ch)
+    # reference: softmax over the in-edges and the self entry (multiplicity = repeated entry), fp64
+    x = qkvs_h.double().requires_grad_(True)
+    q, k, v, skip = (x[:, i * hc:(i + 1) * hc].reshape(n, heads, ch) for i in range(4))
+    e_src = torch.from_numpy(ei[0]); e_dst = torch.from_numpy(ei[1])
+    score = (q[e_dst] * k[e_src]).sum(-1) / ch ** 0.5                                   # [E', H]
+    mx = torch.full((n, heads), -float("inf"), dtype=torch.float64).scatter_reduce(0, e_dst[:, None].expand(-1, heads), score.detach(), "amax")
+    p = torch.exp(score - mx[e_dst])
+    denom = torch.zeros(n, heads, dtype=torch.float64).index_add(0, e_dst, p) + 1e-16
+    alpha = p / denom[e_dst]
+    agg = torch.zeros(n, heads, ch, dtype=torch.float64).index_add(0, e_dst, alpha[:, :, None] * v[e_src])
+    want = (agg + skip).reshape(n, hc)
+    want.backward(gout_h.double())
+    scale = max(1.0, want.detach().abs().max().item())
+    assert (out.cpu().double() - want.detach()).abs().max().item() < 2e-5 * scale
+    assert (inf.cpu().double() - want.detach()).abs().max().item() < 2e-5 * scale
+    assert torch.equal(out, inf)
+    gscale = max(1.0, x.grad.abs().max().item())
+    assert (gq.cpu().double() - x.grad).abs().max().item() < 5e-5 * gscale
