@@ -1411,6 +1411,7 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
   const int ob_ = (a.O + 15) / 16, ib_ = (a.I + 1 + 15) / 16;
   const bool wide = ob_ >= 4 && ob_ <= 6 && ib_ <= 2;
   static const int pipe_env = getenv("MLQEM_WGRAD_PIPE") ? atoi(getenv("MLQEM_WGRAD_PIPE")) : 2;    // 0: wgrad_mfma_kernel, 1: KU = 4 (two waves per SIMD), 2: KU = 2 (three)
+  static const int wide6_env = getenv("MLQEM_WGRAD_WIDE6") ? atoi(getenv("MLQEM_WGRAD_WIDE6")) : 1;
   static const int pipe_grid = getenv("MLQEM_WGRAD_GRID") ? atoi(getenv("MLQEM_WGRAD_GRID")) : 0;  // workgroups per CU; 0 = the resident count
   bool uniform_ld = true;
   for (int k = 1; k < a.gn; ++k) uniform_ld = uniform_ld && a.ldgy[k] == a.ldgy[0];
@@ -1452,6 +1453,11 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     else hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
   } else if (ob == 1) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
+  } else if (ob > 6 && ib <= 2 && wide6_env) {
+    // many outputs against a narrow x (Family B's first projection: gy[180]^T x[22]): six output tiles per workgroup -- a row's
+    // gy is read as 384-byte pieces by ceil(ob / 6) workgroup columns instead of 128-byte pieces by ceil(ob / 2), and x is
+    // re-read two times instead of six
+    hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, (unsigned)ceil_div(ob, 6)), dim3(kBlock), 0, s, a);
   } else {
     hipLaunchKernelGGL((wgrad_mfma_kernel<2, 4>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4))), dim3(kBlock),
                        0, s, a);
