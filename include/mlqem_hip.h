@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 22 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 23 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -159,6 +159,24 @@ int mlqem_mse_loss_grad_f32(const float* out, int64_t ldo, const float* y, int64
                             int64_t g_rows, float* loss, void* workspace, size_t workspace_bytes, unsigned* ticket, mlqem_stream_t stream);
 int mlqem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
                         float* step, double beta1, double beta2, double eps, unsigned* ticket, mlqem_stream_t stream);
+
+/* nn.Sequential(Linear(I, H), [Dropout(p)], Linear(H, O)) as ONE launch per direction: y = dropout(x W1^T + b1) W2^T + b2.
+ * Replaces `self.obs_seq(observable)` and `self.body_seq(merged)` of the graph models (01_ngem.ipynb cell [9]; docs/tutorials/
+ * gnn.py:94-98,121): heads that see one row per circuit, where every separate GEMM / bias / dropout / weight-gradient launch is
+ * pure launch latency.  w1: [H, I], w2: [O, H] row-major (torch's Linear.weight); H <= 16, O <= 8 (MLQEM_ERR_UNSUPPORTED beyond).
+ *   forward:  hidden [N, H] = the dropped, rescaled first-layer output (NULL at inference), mask [N] = bit j set when hidden unit
+ *             j of the row was kept (required with drop_p > 0 and hidden), y [N, O]; mask keyed by (seed [+ seed_counter], n H + j).
+ *   backward: gw1 [H, I], gb1 [H], gw2 [O, H], gb2 [O] (gb1 / gb2 may be NULL) and, when gx is given, gx [N, I] = the gradient of
+ *             the input; per-row-chunk partial sums added in chunk order by the workgroup that finishes last (deterministic);
+ *             workspace: mlqem_seq2_backward_workspace_bytes(N, I, H, O); ticket: one zero-initialised unsigned, left at zero. */
+int mlqem_seq2_forward_f32(const float* x, int64_t ldx, int64_t N, int I, const float* w1, const float* b1, int H, const float* w2,
+                           const float* b2, int O, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* hidden,
+                           uint32_t* mask, float* y, int64_t ldy, mlqem_stream_t stream);
+size_t mlqem_seq2_backward_workspace_bytes(int64_t N, int I, int H, int O);
+int mlqem_seq2_backward_f32(const float* gy, int64_t ldgy, const float* x, int64_t ldx, int64_t N, int I, const float* w1, int H,
+                            const float* w2, int O, const float* hidden, const uint32_t* mask, float drop_p, float* gx, int64_t ldgx,
+                            float* gw1, float* gb1, float* gw2, float* gb2, void* workspace, size_t workspace_bytes, unsigned* ticket,
+                            mlqem_stream_t stream);
 
 /* gx[n,c] = (y[n,c] > 0) ? g[n,c] * scale : 0  -- backward of ReLU followed by inverted dropout, recovered from the
  * output y (an element that was clamped OR dropped has y == 0 and no gradient either way). */

@@ -58,6 +58,9 @@ SIGNATURES = {
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
     "mlqem_ell_from_csr": (_I, [_P, _P, _L, _P, _P]),
     "mlqem_mse_loss_workspace_bytes": (_S, []),
+    "mlqem_seq2_forward_f32": (_I, [_P, _L, _L, _I, _P, _P, _I, _P, _P, _I, _F, _U, _P, _P, _P, _P, _L, _P]),
+    "mlqem_seq2_backward_workspace_bytes": (_S, [_L, _I, _I, _I]),
+    "mlqem_seq2_backward_f32": (_I, [_P, _L, _P, _L, _L, _I, _P, _I, _P, _I, _P, _P, _F, _P, _L, _P, _P, _P, _P, _P, _S, _P, _P]),
     "mlqem_mse_loss_grad_f32": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _L, _P, _P, _S, _P, _P]),
     "mlqem_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _P, _P]),
     "mlqem_relu_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _F, _P, _L, _L, _I, _P]),
@@ -131,7 +134,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 22   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 23   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

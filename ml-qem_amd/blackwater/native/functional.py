@@ -90,6 +90,45 @@ def linear(x, w, b=None, relu=False, mfma="f32"):
     return y.reshape(*lead, w.shape[0])
 
 
+class _Seq2(Function):
+    """Linear -> [Dropout] -> Linear as one forward and one backward launch (csrc/seq2.hip): the dense heads of the graph models,
+    which see one row per circuit."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, drop_p, seed):
+        train = any(ctx.needs_input_grad[:5])
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        y, hidden, mask = ops.seq2_forward(x, w1c, None if b1 is None else b1.contiguous(), w2c, None if b2 is None else b2.contiguous(),
+                                           drop_p=drop_p, seed=seed, keep=train)
+        ctx.cfg = (drop_p, b1 is not None, b2 is not None)
+        if train:
+            ctx.save_for_backward(x, w1c, w2c, hidden, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, w2, hidden, mask = ctx.saved_tensors
+        drop_p, has_b1, has_b2 = ctx.cfg
+        gx, gw1, gb1, gw2, gb2 = ops.seq2_backward(gy, x, w1, w2, hidden, mask, drop_p, want_gx=ctx.needs_input_grad[0],
+                                                   want_b1=has_b1, want_b2=has_b2)
+        return gx, gw1, gb1, gw2, gb2, None, None
+
+
+# MLQEM_SEQ2_FUSED=0: the two Linear layers, the dropout and their gradients as separate launches (A/B)
+_SEQ2_FUSED = os.environ.get("MLQEM_SEQ2_FUSED", "1") != "0"
+
+
+def seq2_fused_ok(x, w1, w2) -> bool:
+    return _SEQ2_FUSED and torch.is_tensor(x) and x.dim() in (2, 3) and ops.seq2_fits(x.reshape(-1, x.shape[-1]), w1, w2)
+
+
+def seq2(x, w1, b1, w2, b2, drop_p=0.0, seed=0):
+    """``(dropout(x @ w1.T + b1)) @ w2.T + b2`` over the last axis of a 2-D or 3-D x."""
+    lead = x.shape[:-1]
+    y = _Seq2.apply(x.reshape(-1, x.shape[-1]), w1, b1, w2, b2, float(drop_p), int(seed))
+    return y.reshape(*lead, w2.shape[0])
+
+
 class _MLP1(Function):
     """fc2(relu(fc1(x))) as one forward and one backward launch (csrc/mlp_head.hip); x gets no gradient."""
 

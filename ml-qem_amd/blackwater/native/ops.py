@@ -251,6 +251,56 @@ def _ticket(device):
     return t
 
 
+SEQ2_MAX_HIDDEN, SEQ2_MAX_OUT = 16, 8      # kSeqMaxH / kSeqMaxO of csrc/seq2.hip
+
+
+def seq2_fits(x, w1, w2) -> bool:
+    """Shapes and operands ``seq2_forward`` takes: a 2-D fp32 cuda matrix with contiguous columns, narrow hidden / output layers."""
+    return (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and (x.shape[1] <= 1 or x.stride(1) == 1)
+            and w1.dim() == 2 and w2.dim() == 2 and w1.shape[1] == x.shape[1] and w2.shape[1] == w1.shape[0]
+            and w1.shape[0] <= SEQ2_MAX_HIDDEN and w2.shape[0] <= SEQ2_MAX_OUT)
+
+
+def seq2_forward(x, w1, b1, w2, b2, drop_p=0.0, seed=0, keep=True):
+    """(y [n, o], hidden [n, h] or None, mask [n] int32 or None) of Linear -> [Dropout(drop_p)] -> Linear in one launch
+    (mlqem_seq2_forward_f32); ``keep``: also return what the backward needs."""
+    n, i = x.shape
+    h, o = w1.shape[0], w2.shape[0]
+    dev = x.device
+    y = torch.empty((n, o), dtype=torch.float32, device=dev)
+    hidden = torch.empty((n, h), dtype=torch.float32, device=dev) if keep else None
+    mask = torch.empty(n, dtype=torch.int32, device=dev) if (keep and drop_p > 0) else None
+    code = _lib.load().mlqem_seq2_forward_f32(_p(x), int(x.stride(0)) if n > 1 else i, n, i, _p(w1), _p(b1), h, _p(w2), _p(b2), o, float(drop_p),
+                                              int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, _p(hidden),
+                                              _p(mask), _p(y), o, _stream())
+    _lib.check(code, "mlqem_seq2_forward_f32")
+    return y, hidden, mask
+
+
+def seq2_backward(gy, x, w1, w2, hidden, mask, drop_p, want_gx, want_b1=True, want_b2=True):
+    """(gx or None, gw1, gb1, gw2, gb2) of the same block in one launch (mlqem_seq2_backward_f32)."""
+    n, i = x.shape
+    h, o = w1.shape[0], w2.shape[0]
+    dev = x.device
+    # an expanded gradient (`out.sum().backward()`) has stride 0; the strides of size-1 axes mean nothing (and .contiguous() keeps them)
+    if gy.dim() != 2 or (o > 1 and gy.stride(1) != 1) or (n > 1 and gy.stride(0) < o):
+        gy = gy.clone(memory_format=torch.contiguous_format)
+    ld = lambda t: int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
+    gx = torch.empty((n, i), dtype=torch.float32, device=dev) if want_gx else None
+    gw1 = torch.empty((h, i), dtype=torch.float32, device=dev)
+    gw2 = torch.empty((o, h), dtype=torch.float32, device=dev)
+    gb1 = torch.empty(h, dtype=torch.float32, device=dev) if want_b1 else None
+    gb2 = torch.empty(o, dtype=torch.float32, device=dev) if want_b2 else None
+    lib = _lib.load()
+    need = lib.mlqem_seq2_backward_workspace_bytes(n, i, h, o)
+    ws = _wgrad_workspace(dev, need)
+    code = lib.mlqem_seq2_backward_f32(_p(gy), ld(gy), _p(x), ld(x), n, i, _p(w1), h, _p(w2), o, _p(hidden), _p(mask),
+                                       float(drop_p), _p(gx), i if want_gx else 0, _p(gw1), _p(gb1), _p(gw2), _p(gb2), _p(ws), need,
+                                       _p(_ticket(dev)), _stream())
+    _lib.check(code, "mlqem_seq2_backward_f32")
+    return gx, gw1, gb1, gw2, gb2
+
+
 def mse_loss_grad(out, target, want_grad=True, rows=None):
     """(loss, g): loss = mean((out - target)^2) as a 0-dim device tensor and g = 2 (out - target) / numel -- what
     ``MSELoss()(out, target).backward()`` hands to ``out`` -- from ONE launch (mlqem_mse_loss_grad_f32).  2-D fp32 operands

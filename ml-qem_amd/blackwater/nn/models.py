@@ -50,6 +50,14 @@ class _Seq(nn.Module):
 
     def forward(self, x):
         first, second = getattr(self, "0"), getattr(self, self._second)
+        if F.seq2_fused_ok(x, first.weight, second.weight):
+            # one launch per direction (csrc/seq2.hip); the dropout mask comes from the counter-keyed hash of the native layers:
+            # the module's call count, or the device-resident step counter under hipGraph replay (static_dropout_key)
+            self._calls = getattr(self, "_calls", 0) + 1
+            p = self.p if (self.p and self.training) else 0.0
+            call = 0 if getattr(self, "static_dropout_key", False) else self._calls
+            return F.seq2(x, first.weight, first.bias, second.weight, second.bias, drop_p=p,
+                          seed=dropout_key(call, salt=first.weight.shape[1] * 1009 + first.weight.shape[0]))
         h = F.linear(x, first.weight, first.bias)
         if self.p and self.training:
             h = nn.functional.dropout(h, self.p, True)
@@ -98,6 +106,7 @@ class ExpValCircuitGraphModelA(nn.Module):
         # its backward is applied by that consumer's data-gradient GEMM (native/functional.py, "Mask hand-over").
         p1, p2 = (0.1, 0.2) if train else (0.0, 0.0)
         k1, k2 = 1.0 / (1.0 - p1), 1.0 / (1.0 - p2)
+        self.obs_seq.static_dropout_key = self.body_seq.static_dropout_key = getattr(self, "static_dropout_key", False)
         if self._single_node_ok(nodes):
             # the same seven layers and three pools as below, as ONE autograd node (saves ~0.7 ms of host time per step)
             pooled = F.family_a_graph(nodes, s, p1, p2, seed, self._graph_params())

@@ -87,8 +87,9 @@ def test_single_node_and_per_layer_paths_agree(g1):
     for single in (True, False):
         model.single_node = single
         model.train()
-        model._step = 0                      # same dropout seeds in both runs (the conv layers' counter-based masks ...
-        torch.manual_seed(123)               # ... and torch's generator for the observable MLP's nn.Dropout)
+        model._step = 0                      # same dropout seeds in both runs: the conv layers' counter-based masks, ...
+        model.obs_seq._calls = model.body_seq._calls = 0      # ... the call counters the fused heads key their masks with ...
+        torch.manual_seed(123)               # ... and torch's generator for the unfused nn.Dropout path
         model.zero_grad()
         out = model(*args)
         out.square().mean().backward()

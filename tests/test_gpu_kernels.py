@@ -763,3 +763,46 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
     ops.csr_aggregate(x, in_ptr, in_src, pool=one, **kw)
     assert (one["out_mean"] - two["out_mean"]).abs().max().item() <= 1e-5 * max(plain.abs().max().item(), 1.0)
     assert (one["out_wmean"] - two["out_wmean"]).abs().max().item() <= 1e-5 * max(plain.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("n,i,h,o", [(1024, 401, 10, 1), (32, 6, 10, 1), (1, 6, 10, 1), (1000, 22, 15, 4), (77, 600, 16, 8), (65, 257, 3, 2)])
+@pytest.mark.parametrize("drop_p", [0.0, 0.3])
+def test_two_layer_head_in_one_launch_per_direction(n, i, h, o, drop_p):
+    """mlqem_seq2_forward_f32 / _backward_f32 (Linear -> Dropout -> Linear: obs_seq / body_seq of the graph models) against fp64
+    algebra with the SAME dropout mask (read back from the op): output, input gradient, all four parameter gradients; the mask
+    keeps about 1 - p of the hidden units, differs between seeds and repeats for the same seed; one row, rows that do not fill
+    a 64-row chunk, more than 256 input columns (two column chunks)."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(n + i + h)
+    x = torch.randn(n, i, generator=g)
+    w1, b1 = torch.randn(h, i, generator=g) / i ** 0.5, torch.randn(h, generator=g)
+    w2, b2 = torch.randn(o, h, generator=g) / h ** 0.5, torch.randn(o, generator=g)
+    gy = torch.randn(n, o, generator=g)
+    xd, w1d, b1d, w2d, b2d, gyd = (t.to(DEV) for t in (x, w1, b1, w2, b2, gy))
+    y, hidden, mask = ops.seq2_forward(xd, w1d, b1d, w2d, b2d, drop_p=drop_p, seed=11)
+    if drop_p > 0:
+        bits = ((mask.cpu().to(torch.int64)[:, None] >> torch.arange(h)) & 1).double()
+        if n * h > 2000:
+            assert abs(bits.mean().item() - (1 - drop_p)) < 0.03
+        _, _, mask2 = ops.seq2_forward(xd, w1d, b1d, w2d, b2d, drop_p=drop_p, seed=11)
+        _, _, mask3 = ops.seq2_forward(xd, w1d, b1d, w2d, b2d, drop_p=drop_p, seed=12)
+        assert torch.equal(mask, mask2) and (n * h < 64 or not torch.equal(mask, mask3))
+        scale = 1.0 / (1.0 - drop_p)
+    else:
+        assert mask is None
+        bits, scale = torch.ones(n, h, dtype=torch.float64), 1.0
+    xr, w1r, b1r, w2r, b2r = (t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    hid = (xr @ w1r.t() + b1r) * bits * scale
+    want = hid @ w2r.t() + b2r
+    want.backward(gy.double())
+    tol = lambda ref: 2e-5 * max(1.0, ref.abs().max().item())
+    assert (y.cpu().double() - want.detach()).abs().max().item() < tol(want.detach())
+    assert (hidden.cpu().double() - hid.detach()).abs().max().item() < tol(hid.detach())
+    gx, gw1, gb1, gw2, gb2 = ops.seq2_backward(gyd, xd, w1d, w2d, hidden, mask, drop_p, want_gx=True)
+    for got, ref in ((gx, xr.grad), (gw1, w1r.grad), (gb1, b1r.grad), (gw2, w2r.grad), (gb2, b2r.grad)):
+        assert (got.cpu().double() - ref).abs().max().item() < tol(ref) * (5 if ref is w1r.grad else 1)
+    again = ops.seq2_backward(gyd, xd, w1d, w2d, hidden, mask, drop_p, want_gx=True)
+    assert all(torch.equal(a, b) for a, b in zip(again, (gx, gw1, gb1, gw2, gb2)))            # deterministic, ticket back at zero
+    nogx = ops.seq2_backward(gyd, xd, w1d, w2d, hidden, mask, drop_p, want_gx=False, want_b1=False)
+    assert nogx[0] is None and nogx[2] is None and torch.equal(nogx[1], gw1) and torch.equal(nogx[3], gw2)
