@@ -85,6 +85,7 @@ struct Seq2Bwd {
 
 constexpr int kSeqBlock = 1024, kSeqCols = 32, kSeqSlices = kSeqBlock / kSeqCols;     // 32 columns x 32 row slices per workgroup
 
+template <bool ONE_OUT, bool WANT_GX>
 __global__ __launch_bounds__(kSeqBlock) void seq2_backward_kernel(const Seq2Bwd a) {
   __shared__ float s_acc[kSeqSlices / 2][kSeqMaxH][kSeqCols];    // 32 KB: a wave holds two slices and adds them by a shuffle first
   __shared__ float s_w2[kSeqMaxO][kSeqMaxH];                     // W2, zero-padded: the row loop reads it at constant bounds, and no
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kSeqBlock) void seq2_backward_kernel(const Seq2Bwd 
   const float* __restrict__ gyp = a.gy;
   const float* __restrict__ xp = a.x;
   const uint32_t* __restrict__ maskp = a.mask;
-  float* __restrict__ gxp = a.gx;
+  float* __restrict__ gxp = WANT_GX ? a.gx : nullptr;
   if ((int)blockIdx.x < a.col_blocks) {
     const int cl = tid % kSeqCols, sl = tid / kSeqCols;
     const int c = blockIdx.x * kSeqCols + cl;
@@ -107,8 +108,42 @@ __global__ __launch_bounds__(kSeqBlock) void seq2_backward_kernel(const Seq2Bwd 
 #pragma unroll
     for (int j = 0; j < kSeqMaxH; ++j) {
       acc[j] = 0.f;
-      w1c[j] = (a.gx && col_ok && j < a.H) ? a.w1[(int64_t)j * a.I + c] : 0.f;
+      w1c[j] = (WANT_GX && col_ok && j < a.H) ? a.w1[(int64_t)j * a.I + c] : 0.f;
     }
+    if constexpr (ONE_OUT) {
+      // one output (the heads of Family A): four rows' loads in flight, then the arithmetic -- gh[j] = gy w2[j] mask needs no array
+      constexpr int U = WANT_GX ? 2 : 8;
+      for (int64_t r0 = sl; r0 < a.N; r0 += (int64_t)U * kSeqSlices) {
+        float xv[U], gv[U], gxv[U];
+        uint32_t mv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t r = r0 + (int64_t)u * kSeqSlices;
+          const bool ok = r < a.N;
+          xv[u] = (ok && col_ok) ? xp[r * a.ldx + c] : 0.f;
+          gv[u] = ok ? gyp[r * a.ldgy] * keep_scale : 0.f;
+          mv[u] = (ok && maskp) ? maskp[r] : 0xFFFFFFFFu;
+          gxv[u] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kSeqMaxH; ++j) {
+          const float w2j = s_w2[0][j];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float g = ((mv[u] >> j) & 1u) ? gv[u] * w2j : 0.f;
+            acc[j] = fmaf(g, xv[u], acc[j]);
+            if (WANT_GX) gxv[u] = fmaf(g, w1c[j], gxv[u]);
+          }
+        }
+        if (gxp && col_ok) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + (int64_t)u * kSeqSlices;
+            if (r < a.N) gxp[r * a.ldgx + c] = gxv[u];
+          }
+        }
+      }
+    } else {
 #pragma unroll 2
     for (int64_t r = sl; r < a.N; r += kSeqSlices) {
       const float xv = col_ok ? xp[r * a.ldx + c] : 0.f;
@@ -126,9 +161,10 @@ __global__ __launch_bounds__(kSeqBlock) void seq2_backward_kernel(const Seq2Bwd 
       for (int j = 0; j < kSeqMaxH; ++j) {
         const float g = ((m >> j) & 1u) ? gh[j] * keep_scale : 0.f;
         acc[j] = fmaf(g, xv, acc[j]);
-        gxv = fmaf(g, w1c[j], gxv);
+        if (WANT_GX) gxv = fmaf(g, w1c[j], gxv);
       }
       if (gxp && col_ok) gxp[r * a.ldgx + c] = gxv;
+    }
     }
 #pragma unroll
     for (int j = 0; j < kSeqMaxH; ++j) {
@@ -234,6 +270,10 @@ extern "C" int mlqem_seq2_backward_f32(const float* gy, int64_t ldgy, const floa
   if (drop_p > 0.f && !mask) return MLQEM_ERR_BAD_ARG;
   const int col_blocks = (int)ceil_div((int64_t)I, (int64_t)kSeqCols);
   const Seq2Bwd a{gy, ldgy, x, ldx, N, I, w1, H, w2, O, hidden, drop_p > 0.f ? mask : nullptr, drop_p, gx, ldgx, gw1, gb1, gw2, gb2, col_blocks};
-  hipLaunchKernelGGL(seq2_backward_kernel, dim3((unsigned)(col_blocks + 1)), dim3(kSeqBlock), 0, as_stream(stream), a);
+  const dim3 grid((unsigned)(col_blocks + 1));
+  if (O == 1 && gx) hipLaunchKernelGGL((seq2_backward_kernel<true, true>), grid, dim3(kSeqBlock), 0, as_stream(stream), a);
+  else if (O == 1) hipLaunchKernelGGL((seq2_backward_kernel<true, false>), grid, dim3(kSeqBlock), 0, as_stream(stream), a);
+  else if (gx) hipLaunchKernelGGL((seq2_backward_kernel<false, true>), grid, dim3(kSeqBlock), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((seq2_backward_kernel<false, false>), grid, dim3(kSeqBlock), 0, as_stream(stream), a);
   return launch_status();
 }
