@@ -167,8 +167,8 @@ int mlqem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* 
  *   forward:  hidden [N, H] = the dropped, rescaled first-layer output (NULL at inference), mask [N] = bit j set when hidden unit
  *             j of the row was kept (required with drop_p > 0 and hidden), y [N, O]; mask keyed by (seed [+ seed_counter], n H + j).
  *   backward: gw1 [H, I], gb1 [H], gw2 [O, H], gb2 [O] (gb1 / gb2 may be NULL) and, when gx is given, gx [N, I] = the gradient of
- *             the input; per-row-chunk partial sums added in chunk order by the workgroup that finishes last (deterministic);
- *             workspace: mlqem_seq2_backward_workspace_bytes(N, I, H, O); ticket: one zero-initialised unsigned, left at zero. */
+ *             the input; the row slices of a workgroup meet in LDS and are added in slice order (deterministic, one launch);
+ *             workspace / ticket: reserved for a two-stage form (mlqem_seq2_backward_workspace_bytes returns 0; both may be NULL). */
 int mlqem_seq2_forward_f32(const float* x, int64_t ldx, int64_t N, int I, const float* w1, const float* b1, int H, const float* w2,
                            const float* b2, int O, float drop_p, uint64_t seed, const uint64_t* seed_counter, float* hidden,
                            uint32_t* mask, float* y, int64_t ldy, mlqem_stream_t stream);
