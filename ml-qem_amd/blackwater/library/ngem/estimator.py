@@ -81,7 +81,10 @@ class NgemJob(job_base()):  # type: ignore[misc]
             values.append([float(value)])
             observables.append(encode_pauli_sum_op(obs))   # needs observables of one shape, which a run() over one operator family has
         on_gpu = device is not None and torch.device(device).type == "cuda"
-        x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch(texts, pin=on_gpu)
+        if on_gpu:      # groups of circuits are written and uploaded in turn: the copy of one overlaps the encoding of the next
+            x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch_to_device(texts, device)
+        else:
+            x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch(texts)
         noisy = torch.tensor(values, dtype=torch.float)
         observable = torch.tensor(observables, dtype=torch.float)
         depth = torch.zeros(len(texts), 1)

@@ -119,3 +119,21 @@ def test_learning_process_batch_equals_per_circuit_oracle(g1, lima_backend):
             total += coeff * ref(X.double()).item()
         assert res.values[k] == pytest.approx(total, abs=1e-5)
         assert res.metadata[k]["original_value"] == pytest.approx(value)
+
+
+@pytest.mark.parametrize("count,chunks", [(300, 4), (130, 2), (7, 4), (64, 1)])
+def test_encode_to_device_in_groups_equals_the_one_shot_batch(lima_props, count, chunks):
+    """NativeEncoder.encode_batch_to_device (groups of circuits filled into pinned buffers and copied to their slices of the device
+    tensors while the next group is written; node offsets and graph numbers shifted on the device) returns the arrays of
+    encode_batch bit for bit, for every grouping."""
+    from blackwater.data.circuit import circuit_to_qasm
+    from blackwater.data.native_encoder import NativeEncoder
+    from blackwater.data.synthetic import tfim_circuit
+
+    texts = [circuit_to_qasm(tfim_circuit(5, k % 7, 0.1 + 0.01 * k, two_q="cx")) for k in range(count)]
+    enc = NativeEncoder(lima_props)
+    x, ei, batch, counts, depths = enc.encode_batch(texts)
+    xd, eid, bd, counts_d, depths_d = enc.encode_batch_to_device(texts, DEV, chunks=chunks, group_bytes=4096)
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), x) and torch.equal(eid.cpu(), ei) and torch.equal(bd.cpu(), batch)
+    assert np.array_equal(counts_d, counts) and list(depths_d) == list(depths)
