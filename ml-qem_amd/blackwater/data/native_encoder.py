@@ -137,9 +137,9 @@ class NativeEncoder:
                 code = lib.mlqem_qasm_batch_parse(arr, n_txt, ctypes.byref(self._props), int(use_qubit_features), int(use_gate_features),
                                                   int(threads), ctypes.byref(handle), vp(node_ptr), vp(edge_ptr), vp(depths), ctypes.byref(f),
                                                   ctypes.byref(failed))
-                groups.append([handle, node_ptr, edge_ptr, depths[:n_txt], raw])      # raw: the parsed ops are views into the texts
+                groups.append([handle, node_ptr, edge_ptr, depths[:n_txt], raw])
                 if code != 0:
-                    self._raise(code)
+                    self._raise(code, first=lo)
             n = sum(int(g[1][-1]) for g in groups)
             e = sum(int(g[2][-1]) for g in groups)
             x = torch.empty((n, f.value), dtype=torch.float32, device=device)
@@ -173,8 +173,11 @@ class NativeEncoder:
         depths = [int(d) for g in groups for d in g[3]]
         return x, ei, batch, counts, depths
 
-    def _raise(self, code):
+    def _raise(self, code, first: int = 0):
         msg = self._lib.mlqem_encode_last_error().decode()
+        if first:       # a group of a larger run(): the batch entry points number circuits from the group's first one
+            import re
+            msg = re.sub(r"^circuit (\d+):", lambda m: f"circuit {int(m.group(1)) + first}:", msg)
         if "not in the backend's gates_set" in msg:
             raise KeyError(msg)
         raise Exception(msg or f"mlqem_encode_qasm failed with code {code}")

@@ -137,3 +137,17 @@ def test_encode_to_device_in_groups_equals_the_one_shot_batch(lima_props, count,
     torch.cuda.synchronize()
     assert torch.equal(xd.cpu(), x) and torch.equal(eid.cpu(), ei) and torch.equal(bd.cpu(), batch)
     assert np.array_equal(counts_d, counts) and list(depths_d) == list(depths)
+
+
+def test_encode_to_device_names_a_bad_circuit_by_its_position_in_the_run(lima_props):
+    from blackwater.data.circuit import circuit_to_qasm
+    from blackwater.data.native_encoder import NativeEncoder
+    from blackwater.data.synthetic import tfim_circuit
+
+    texts = [circuit_to_qasm(tfim_circuit(5, k % 5, 0.2, two_q="cx")) for k in range(200)]
+    texts[150] = 'OPENQASM 2.0;\nqreg q[2];\nrz(1 q[0];\n'
+    enc = NativeEncoder(lima_props)
+    with pytest.raises(Exception, match="circuit 150: "):
+        enc.encode_batch_to_device(texts, DEV, chunks=4, group_bytes=4096)
+    x, *_ = enc.encode_batch_to_device(texts[:100], DEV, chunks=4, group_bytes=4096)      # usable after a rejected run
+    assert x.shape[0] > 0
