@@ -240,15 +240,46 @@ def csr_segment_max(x, ptr, idx, ell=None, out=None):
     return out
 
 
-_tickets = {}   # (device, stream) -> zero-initialised unsigned the "last workgroup done" kernels count on (they leave it at zero)
+_TICKET_SLOTS = 256
+_ticket_pools = {}   # device -> (zeroed int32[_TICKET_SLOTS], {stream handle: slot})
+
+
+def prepare_device(device):
+    """Allocates, EAGERLY, the per-device state the launch wrappers hand to kernels: the pool of zero-initialised counters the
+    "last workgroup done" kernels count on (they leave their counter at zero).  Trainers call this before any capture, so that
+    the pool never becomes a node -- or a private-pool allocation -- of whichever hipGraph happened to be captured first; a
+    stream gets its slot of the pool by host bookkeeping alone (kernels on one stream are serialised, streams that run
+    concurrently never share a counter)."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    pool = _ticket_pools.get(device)
+    if pool is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the ticket pool must exist before a capture begins: run a warm-up step or ops.prepare_device(device) first")
+        # a fill, not torch.zeros (which may be recorded as a memset node): the form `loops` uses
+        pool = _ticket_pools[device] = (torch.full((_TICKET_SLOTS,), 0, dtype=torch.int32, device=device), {})
+    return pool
 
 
 def _ticket(device):
-    key = (device, _stream())
-    t = _tickets.get(key)
-    if t is None:
-        t = _tickets[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return t
+    tickets, slots = prepare_device(device)
+    key = _stream()
+    i = slots.get(key)
+    if i is None:
+        i = len(slots)
+        if i >= _TICKET_SLOTS:
+            raise RuntimeError(f"more than {_TICKET_SLOTS} streams have launched ticketed kernels on {device}")
+        slots[key] = i
+    return tickets[i:i + 1]
+
+
+def reset_tickets(device):
+    """Re-zeroes the counters (after a launch that aborted half-way: a non-zero ticket would silently skip every later
+    last-workgroup tail on its stream)."""
+    pool = _ticket_pools.get(torch.device(device))
+    if pool is not None:
+        pool[0].zero_()
 
 
 SEQ2_MAX_HIDDEN, SEQ2_MAX_OUT = 16, 8      # kSeqMaxH / kSeqMaxO of csrc/seq2.hip

@@ -62,6 +62,33 @@ class FlatAdam(torch.optim.Optimizer):
                          "exp_avg_sq": torch.zeros_like(p)}
 
     @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Copies a saved state IN PLACE into this optimizer's device tensors.  ``Optimizer.load_state_dict`` would leave a
+        ``step`` loaded with ``map_location='cpu'`` on the host (this class declares neither ``capturable`` nor ``fused``) and
+        would replace the learning-rate tensor by a deep copy -- captured graphs keep reading the old pointers, so a resumed
+        run would step with stale moments and never see ``ReduceLROnPlateau``.  Hyper-parameters (betas, eps) are taken over."""
+        groups = state_dict["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != 1:
+            raise ValueError("FlatAdam state has one group of one flat parameter")
+        saved = state_dict["state"].get(groups[0]["params"][0], None)
+        group = self.param_groups[0]
+        p = group["params"][0]
+        st = self.state[p]
+        if saved is not None:
+            for key in ("exp_avg", "exp_avg_sq"):
+                src = saved[key]
+                if tuple(src.shape) != tuple(st[key].shape):
+                    raise ValueError(f"FlatAdam.load_state_dict: {key} has {tuple(src.shape)}, this optimizer {tuple(st[key].shape)}")
+                st[key].copy_(src.to(device=p.device, dtype=torch.float32))
+            step = saved["step"]
+            st["step"].fill_(float(step.item() if torch.is_tensor(step) else step))
+        lr = groups[0]["lr"]
+        group["lr"].fill_(float(lr.item() if torch.is_tensor(lr) else lr))
+        for key, val in groups[0].items():
+            if key not in ("params", "lr"):
+                group[key] = tuple(val) if key == "betas" else val
+
+    @torch.no_grad()
     def step(self, closure=None):
         from .native import ops
 
@@ -111,6 +138,10 @@ class Trainer:
             self.flat_param = self.flat_grad = None
             opt_params = list(model.parameters())
         fused = opt_params[0].is_cuda
+        if fused:
+            from .native import ops
+
+            ops.prepare_device(opt_params[0].device)      # per-device launch state exists before anything is captured
         if flat and fused and os.environ.get("MLQEM_TORCH_ADAM", "0") != "1":
             # one native launch over the flat buffer, step count and learning rate on the device (capturable either way)
             self.optimizer = FlatAdam(opt_params, lr=lr)
@@ -134,6 +165,14 @@ class Trainer:
         self.history = {"train_losses": [], "val_losses": []}
         if self.distributed:
             self.broadcast_parameters()
+
+    def _capture_stream(self):
+        """ONE side stream per trainer for the eager warm-up iterations AND every capture: the launch wrappers keep their
+        per-stream state (workspaces, ticket slots) by stream handle, so what the warm-up allocated eagerly is what the
+        captures use -- nothing is allocated, zeroed or first-touched inside a capture."""
+        if getattr(self, "_cap_stream", None) is None:
+            self._cap_stream = torch.cuda.Stream()
+        return self._cap_stream
 
     def broadcast_parameters(self, src: int = 0):
         """Every replica starts from rank ``src``'s parameters and buffers (what DistributedDataParallel does at
@@ -412,7 +451,7 @@ class RowsTrainer(Trainer):
                 keep = (self.flat_param.detach().clone(), self.counter.clone(), torch.cuda.get_rng_state(dev))
                 opt_keep = {id(st): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for st in self.optimizer.state.values()}
                 buf_keep = [b.detach().clone() for b in self.model.buffers()]
-                side = torch.cuda.Stream()
+                side = self._capture_stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(3):
@@ -435,7 +474,7 @@ class RowsTrainer(Trainer):
                 torch.cuda.set_rng_state(keep[2], dev)
                 self._warm = True
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=self._capture_stream()):
                 loss = self._step_on(batch)
             entry = self._entries[key] = {"graph": graph, "x": xs, "y": ys, "loss": loss}
         else:
@@ -588,7 +627,7 @@ class BucketedTrainer(Trainer):
         buf_keep = [b.detach().clone() for b in self.model.buffers()]
         sel, nptr, eptr, nb, eb, real = self.arena.selection(ids, bucket[:2])
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.flat_param.device)
-        side = torch.cuda.Stream()
+        side = self._capture_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
@@ -640,7 +679,9 @@ class BucketedTrainer(Trainer):
                      "graph": torch.cuda.CUDAGraph()}
             self._send(entry, host)
             torch.cuda.synchronize()
-            kw = {} if self._pool is None else {"pool": self._pool}
+            kw = {"stream": self._capture_stream()}
+            if self._pool is not None:
+                kw["pool"] = self._pool
             if not self.split:
                 with torch.cuda.graph(entry["graph"], **kw):
                     entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap)
@@ -653,7 +694,7 @@ class BucketedTrainer(Trainer):
                 # Adam touches the flat buffers only: one graph serves all buckets (its own memory pool: it is replayed after
                 # whichever bucket's graph ran, not in capture order)
                 self._update_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._update_graph):
+                with torch.cuda.graph(self._update_graph, stream=self._capture_stream()):
                     self.optimizer.step()
             self._entries[bucket] = entry
         else:

@@ -718,10 +718,20 @@ class ScratchPool {
 
 ScratchPool& scratch_pool() { static ScratchPool pool; return pool; }
 
+// Worker threads when the caller names none: the host's hardware threads up to 16 (a one-GPU share of this pool's boxes), or
+// MLQEM_ENCODE_THREADS (1..256) when the deployment knows better.
+int default_threads() {
+  if (const char* env = std::getenv("MLQEM_ENCODE_THREADS")) {
+    const long v = std::strtol(env, nullptr, 10);
+    if (v >= 1 && v <= 256) return (int)v;
+  }
+  return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
 // fn(i, scratch) for i in [0, count) on `threads` host threads; the first failure (lowest index wins among those seen) is kept
 template <typename Fn>
 int for_each_parallel(int64_t count, int threads, int64_t* failed, Fn fn) {
-  if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (threads <= 0) threads = default_threads();
   threads = (int)std::min<int64_t>(threads, std::max<int64_t>(count, 1));
   std::atomic<int64_t> next{0};
   std::mutex mu;
@@ -748,8 +758,14 @@ int for_each_parallel(int64_t count, int threads, int64_t* failed, Fn fn) {
   };
   if (threads == 1) worker();
   else {
+    // the caller's thread is one of the workers; if the system refuses a thread the ones that did start (and this one) finish
+    // the job -- a vector of joinable threads must never be destroyed (std::terminate)
     std::vector<std::thread> pool;
-    for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+    pool.reserve((size_t)threads - 1);
+    try {
+      for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    } catch (const std::exception&) {}
+    worker();
     for (auto& t : pool) t.join();
   }
   if (code != MLQEM_OK) { g_last_error = "circuit " + std::to_string(bad) + ": " + message; if (failed) *failed = bad; }
@@ -829,6 +845,7 @@ extern "C" int mlqem_qasm_batch_parse(const char* const* qasm, int64_t count, co
 extern "C" int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_t* edge_src, int64_t* edge_dst, int64_t* batch) {
   Batch* b = static_cast<Batch*>(handle);
   if (!b) { g_last_error = "no batch handle"; return MLQEM_ERR_BAD_ARG; }
+  try {                                                        // no C++ exception may cross the C ABI (bad_alloc, system_error)
   const int64_t count = (int64_t)b->circuits.size();
   std::vector<int64_t> node_ptr((size_t)count + 1, 0), edge_ptr((size_t)count + 1, 0);
   for (int64_t i = 0; i < count; ++i) { node_ptr[i + 1] = node_ptr[i] + b->sizes[i].N; edge_ptr[i + 1] = edge_ptr[i] + b->sizes[i].E; }
@@ -844,6 +861,10 @@ extern "C" int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_
                          edge_dst + edge_ptr[i], node_ptr[i], nullptr);
     if (batch) std::fill(batch + node_ptr[i], batch + node_ptr[i + 1], i);
   });
+  } catch (const std::exception& err) {
+    g_last_error = err.what();
+    return MLQEM_ERR_BAD_ARG;
+  }
 }
 
 extern "C" void mlqem_qasm_batch_free(void* handle) { delete static_cast<Batch*>(handle); }

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kHeadReduceSlices * kWave) void mlp1_bwd_reduce_ker
   if (loss_out && blockIdx.x == gridDim.x - 1 && threadIdx.x < kWave) {
     // the mean squared error the forward left as per-workgroup sums: added in index order by one wave (a block whose elements
     // mostly stand for nothing has the time)
-    const int n = (int)loss_part[kHeadLossSlots];
+    const int n = min((int)loss_part[kHeadLossSlots], kHeadLossSlots);
     float t = 0.f;
     for (int b = threadIdx.x; b < n; b += kWave) t += loss_part[b];
 #pragma unroll
@@ -797,7 +797,9 @@ static int launch_head_fwd(Mlp1Args a, void* workspace, hipStream_t s) {
   hipLaunchKernelGGL(mlp1_image_kernel<BF16>, dim3((unsigned)ceil_div(head_image_u32x4(G) * 4, 256)), dim3(256), 0, s, a, G,
                      static_cast<u32x4*>(workspace));
   const int64_t tiles = ceil_div(a.N, 16);
-  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(res, ceil_div(tiles, kFwdThreads / kWave)));
+  // a workgroup of the loss form files its sum in loss_part[blockIdx.x] (kHeadLossSlots of them, then the count): the grid may
+  // never outgrow the slots, whatever occupancy x CU count says on another compiler or part
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(res, kHeadLossSlots), ceil_div(tiles, kFwdThreads / kWave)));
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(kFwdThreads), lds, s, a);
   return launch_status();
 }
@@ -879,8 +881,12 @@ extern "C" int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* 
     const int ci = I + 1;
     const int ng = ci <= 112 ? 1 : 2, ns = ci <= 64 * ng ? 0 : 3;
     reduce_layout = (ng << 8) | ns;
+    // every instantiation decays to void(*)(Mlp1Args), so a `static` inside the lambda would be ONE value shared by all
+    // eight: the resident-workgroup counts are kept per (O2, ng, ns) instead
+    static int res_of[2][2][2] = {};
     auto launch = [&](auto kernel) {
-      static const int res = head_resident_workgroups(kernel, kBwdThreads, 0);
+      int& res = res_of[O2 == 1 ? 0 : 1][ng - 1][ns ? 1 : 0];
+      if (res == 0) res = head_resident_workgroups(kernel, kBwdThreads, 0);
       G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(res, kHeadMaxBwdBlocks), ceil_div(std::max<int64_t>(N / 4, 1), KU)));
       hipLaunchKernelGGL(kernel, dim3(G), dim3(kBwdThreads), 0, s, a);
     };

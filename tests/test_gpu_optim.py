@@ -77,6 +77,59 @@ def test_reduce_lr_on_plateau_drives_the_device_resident_rate():
     assert torch.allclose(p, torch.full_like(p, -1e-4), rtol=1e-5)   # the first Adam step moves every weight by lr
 
 
+def test_flat_adam_state_round_trips_through_a_cpu_checkpoint(tmp_path):
+    """a state saved with torch.save and loaded with map_location='cpu' (the usual resume) must land IN the
+    optimizer's device tensors -- same addresses (captured graphs read them), same values -- and the resumed run must step like
+    the one that never stopped."""
+    from blackwater.train import FlatAdam
+
+    torch.manual_seed(3)
+    n = 4099
+    p0 = torch.randn(n, device=DEV)
+    grads = [torch.randn(n, device=DEV) for _ in range(12)]
+    ref_p = p0.clone().requires_grad_(True)
+    ref = FlatAdam([ref_p], lr=1e-3)
+    for k, g in enumerate(grads):
+        ref_p.grad = g.clone()
+        ref.step()
+        if k == 5:
+            ref.param_groups[0]["lr"].fill_(3e-4)
+            torch.save({"opt": ref.state_dict(), "p": ref_p.detach().clone()}, tmp_path / "ck.pt")
+    blob = torch.load(tmp_path / "ck.pt", map_location="cpu")
+    p = blob["p"].to(DEV).requires_grad_(True)
+    opt = FlatAdam([p], lr=1e-3)
+    st = opt.state[p]
+    addr = (st["step"].data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), opt.param_groups[0]["lr"].data_ptr())
+    lr_obj = opt.param_groups[0]["lr"]
+    opt.load_state_dict(blob["opt"])
+    st = opt.state[p]
+    assert addr == (st["step"].data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), opt.param_groups[0]["lr"].data_ptr())
+    assert opt.param_groups[0]["lr"] is lr_obj and abs(lr_obj.item() - 3e-4) < 1e-10
+    assert st["step"].is_cuda and st["step"].item() == 6.0
+    for g in grads[6:]:
+        p.grad = g.clone()
+        opt.step()
+    assert torch.equal(p.detach(), ref_p.detach())
+    assert torch.equal(st["exp_avg"], ref.state[ref_p]["exp_avg"]) and torch.equal(st["exp_avg_sq"], ref.state[ref_p]["exp_avg_sq"])
+
+
+def test_ticket_pool_is_allocated_eagerly_and_shared_by_slots():
+    """the counters of the last-workgroup-done kernels come from ONE eagerly allocated per-device pool; a stream
+    gets a slot by host bookkeeping, never by an allocation (which a capture would have swallowed)."""
+    from blackwater.native import ops
+
+    ops.prepare_device(DEV)
+    a = ops._ticket(torch.device(DEV))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        b = ops._ticket(torch.device(DEV))
+        again = ops._ticket(torch.device(DEV))
+    assert a.data_ptr() != b.data_ptr() and b.data_ptr() == again.data_ptr()
+    pool = ops._ticket_pools[torch.device(DEV)][0]
+    assert pool.data_ptr() <= a.data_ptr() < pool.data_ptr() + pool.numel() * 4
+    assert int(pool.abs().sum().item()) == 0
+
+
 def test_fused_mse_on_a_padded_batch_equals_slicing_the_output():
     """A bucket-padded batch: the loss sees the first ``rows`` rows, the gradient has the output's shape with zero rows behind
     them -- what ``mse_loss(out[:rows], y[:rows]).backward()`` leaves in ``out.grad``."""
