@@ -47,9 +47,10 @@ class TorchLearningModelProcessor(LearningMethodEstimatorProcessor):
         results = []
         for term in observables:
             coeff, label = term.coeffs, str(term.paulis[0])
+            # OpenQASM text takes the C++ op scan (mlqem_circuit_features_qasm): same row, no Python circuit objects
             model_input, _ = encode_data(circuits=[circuits], properties=self._properties, ideal_exp_vals=[[0.0]],
                                          noisy_exp_vals=[[expectation_value]], num_qubits=1,
-                                         meas_bases=encode_pauli_sum_op([(label, 1.0)]))
+                                         meas_bases=encode_pauli_sum_op([(label, 1.0)]), native=isinstance(circuits, str))
             if device is not None:
                 model_input = model_input.to(device)
             with torch.no_grad():

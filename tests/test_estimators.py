@@ -65,6 +65,40 @@ def test_ngem_wraps_class_and_postprocesses(lima_backend):
     assert FakeEstimator()._run([QASM], ["x"], [()]).result().values[0] == 0.5  # base class untouched
 
 
+def test_serial_ngem_path_hands_the_model_the_same_tensors_natively_and_from_python(lima_backend, monkeypatch):
+    """the default (serial, reference-shaped) loop encodes OpenQASM text and ``Circuit`` objects with the C++
+    encoder; the six model arguments are equal, bit for bit, to the ones the Python walk (circuit_to_graph_data_json ->
+    ExpValueEntry.to_pyg_data) builds.  Circuits: the boundary text above and three of the reference's G1 circuits."""
+    import json
+    import os
+
+    import blackwater.library.ngem.estimator as mod
+    from blackwater.data.circuit import Circuit
+
+    class Recorder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = []
+
+        def forward(self, *args):
+            self.calls.append([None if a is None else a.clone() for a in args])
+            return args[0] * 2
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g1_circuits.json")))
+    texts = [QASM, gold[0], gold[7], gold[299]]
+    circuits = texts + [Circuit.from_any(QASM)]
+    obs = [PauliObservable("ZIIII")] * len(circuits)
+    native, python = Recorder(), Recorder()
+    monkeypatch.setattr(mod, "_NATIVE_SERIAL", True)
+    a = ngem(FakeEstimator, native, lima_backend)().run(circuits, obs).result()
+    monkeypatch.setattr(mod, "_NATIVE_SERIAL", False)
+    b = ngem(FakeEstimator, python, lima_backend)().run(circuits, obs).result()
+    assert np.array_equal(a.values, b.values) and len(native.calls) == len(python.calls) == len(circuits)
+    for ca, cb in zip(native.calls, python.calls):
+        for ta, tb in zip(ca, cb):
+            assert (ta is None and tb is None) or (ta.dtype == tb.dtype and ta.shape == tb.shape and torch.equal(ta, tb))
+
+
 def test_ngem_rejects_non_pauli_observable(lima_backend):
     job = ngem(FakeEstimator, DummyModel(), lima_backend)().run([QASM], ["not an operator"])
     with pytest.raises(BlackwaterException, match="Only `PauliSumOp` observables are supported by NGEM"):
