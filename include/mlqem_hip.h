@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 23 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 24 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -516,6 +516,31 @@ int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_t* in_src, 
 int mlqem_asap_coarsen_rows_fill(const int32_t* new_graph_ptr, int64_t K, int64_t B, int kmax, const int32_t* new_in_ptr,
                                  const int32_t* new_out_ptr, int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid,
                                  const void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+
+/* The same arrays from SORTED LISTS instead of bit matrices (round 4; the default for large graphs): nothing dense is written
+ * to or read from global memory.  A structural bound per row (two-hop degree sums, clamped to k_g - 1) places every row in
+ * two scratch lists; persistent waves build a cluster's out-row and in-row as LDS bitsets whose second hop is driven by a
+ * node LIST (no scan of n_g bits), read them out in ascending order and clear them on the way; degrees -> scans -> the CSR
+ * pointers; the fill pass copies the lists to their place and finds every out-entry's twin in the in-row by binary search.
+ *   lists_caps:  totals[2] (device int64) = sum of the row bounds of the out- and of the in-side -- what `capacity` must
+ *                cover when the caller has no structural bound of its own (one 16-byte read); workspace for capacity 0;
+ *   lists_count: slot[N], new_in_ptr[K + 1], new_out_ptr[K + 1]; `capacity` = entries per scratch list;
+ *   lists_fill:  new_in_src / new_out_dst / new_out_eid, each holding edge_capacity >= new_out_ptr[K] entries, from the
+ *                SAME workspace; *overflow (device, may be NULL) = 1 if `capacity` was too small (rows were dropped).
+ * nmax + 2 kmax + 96 <= mlqem_asap_coarsen_lists_max_bits(), kmax <= 65535, else MLQEM_ERR_UNSUPPORTED.
+ * Replaces the same ASAPooling.forward lines (gnn.py:105-107,110-112; PyG semantics: SURVEY appendix B.2 step 7). */
+size_t mlqem_asap_coarsen_lists_workspace_bytes(int64_t N, int64_t K, int64_t capacity);
+int mlqem_asap_coarsen_lists_max_bits(void);
+int mlqem_asap_coarsen_lists_caps(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                  const int32_t* new_graph_ptr, const int32_t* perm, int64_t N, int64_t K, int64_t B,
+                                  int64_t* totals, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                   const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N,
+                                   int64_t K, int64_t B, int nmax, int kmax, int64_t capacity, int32_t* slot, int32_t* new_in_ptr,
+                                   int32_t* new_out_ptr, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t capacity, const int32_t* new_in_ptr, const int32_t* new_out_ptr,
+                                  int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid, int64_t edge_capacity,
+                                  int32_t* overflow, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Coarsened connectivity WITHOUT host read-backs, for batches whose graphs all pool to at most
  * mlqem_asap_coarsen_dense_max_k() clusters (512): the pooled adjacency of every graph is built as a k_g x k_g bit

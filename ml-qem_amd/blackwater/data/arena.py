@@ -55,13 +55,18 @@ def _ranges(starts, lengths):
     return np.repeat(np.asarray(starts, dtype=np.int64) - first, lengths) + np.arange(total, dtype=np.int64)
 
 
-def _coarse_capacities(out_ptr, out_dst, gptr, n_total) -> np.ndarray:
+def _coarse_capacities(out_ptr, out_dst, gptr, n_total, in_ptr=None, in_src=None) -> np.ndarray:
     """Per graph, an upper bound on the edges of the graph ASAPooling coarsens it to, from the structure alone (computed once
     per arena, on the device).  Cluster p is its centre and the centre's in-neighbours; (p, q) is a coarsened edge iff some
     member u of p has u -> v or u = v for a member v of q.  A node w belongs to at most
     1 + outdeg(w) clusters (itself, if kept, and its kept out-neighbours), so whatever top-k keeps,
 
         #edges  <=  sum_u (1 + outdeg u) * sum_{v in N+[u] or v = u} (1 + outdeg v).
+
+    This is also the sum over ALL nodes c of the per-row bound the list form of the coarsening places its out-rows by
+    (csrc/asap.hip: cap_o(c) = sum over u in N-[c] of h_out(u)); with ``in_ptr`` / ``in_src`` the same is computed for its
+    in-rows (h_in(u) = sum over v in N-[u] of (1 + outdeg v)) and the larger of the two is returned, so that one number per
+    graph bounds both scratch lists and the edge arrays.
 
     On 100-qubit TFIM circuits this is ~100 per node against ~27 real coarsened edges per node (barrier nodes have 100
     out-edges): memory, not time -- the kernels walk the real rows.  What it buys: the coarsened edge arrays are sized on the
@@ -73,14 +78,22 @@ def _coarse_capacities(out_ptr, out_dst, gptr, n_total) -> np.ndarray:
     outdeg = optr[1:] - optr[:-1]
     od1 = outdeg + 1
     e = int(optr[-1].item())
-    s_u = od1.clone()
-    if e > 0:
-        src = torch.repeat_interleave(torch.arange(n_total, device=optr.device), outdeg)
-        s_u.index_add_(0, src, od1[out_dst[:e].long()])
-    c = torch.zeros(n_total + 1, dtype=torch.int64, device=optr.device)
-    torch.cumsum(od1 * s_u, 0, out=c[1:])
     g = gptr.long()
-    return (c[g[1:]] - c[g[:-1]]).cpu().numpy()
+
+    def per_graph(ptr, idx):
+        deg = ptr[1:] - ptr[:-1]
+        s_u = od1.clone()
+        if e > 0:
+            own = torch.repeat_interleave(torch.arange(n_total, device=optr.device), deg)
+            s_u.index_add_(0, own, od1[idx[:e].long()])
+        c = torch.zeros(n_total + 1, dtype=torch.int64, device=optr.device)
+        torch.cumsum(od1 * s_u, 0, out=c[1:])
+        return c[g[1:]] - c[g[:-1]]
+
+    caps = per_graph(optr, out_dst)
+    if in_ptr is not None and in_src is not None:
+        caps = torch.maximum(caps, per_graph(in_ptr[: n_total + 1].to(torch.int64), in_src))
+    return caps.cpu().numpy()
 
 
 class GraphArena:
@@ -207,7 +220,7 @@ class GraphArena:
         t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
         return GraphArena(x, node_counts, (gptr, in_ptr, in_src, out_ptr, out_dst, loops, csr.out_eid), nscal, t(y), t(noisy),
                           t(depth), t(observable), edge_counts, ell=ell, filler_nodes=filler_nodes,
-                          coarse_caps=_coarse_capacities(out_ptr, out_dst, gptr, n_total))
+                          coarse_caps=_coarse_capacities(out_ptr, out_dst, gptr, n_total, in_ptr, in_src))
 
     @staticmethod
     def from_data_list(graphs, device="cuda") -> "GraphArena":

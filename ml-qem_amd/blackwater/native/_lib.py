@@ -111,6 +111,11 @@ SIGNATURES = {
     "mlqem_batch_norm_train_bwd_f32": (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _L, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_rows_count": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_rows_fill": (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "mlqem_asap_coarsen_lists_workspace_bytes": (_S, [_L, _L, _L]),
+    "mlqem_asap_coarsen_lists_max_bits": (_I, []),
+    "mlqem_asap_coarsen_lists_caps": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _P, _S, _P]),
+    "mlqem_asap_coarsen_lists_count": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _L, _P, _P, _P, _P, _S, _P]),
+    "mlqem_asap_coarsen_lists_fill": (_I, [_L, _L, _L, _P, _P, _P, _P, _P, _L, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_dense_max_k": (_I, []),
     "mlqem_asap_coarsen_dense_workspace_bytes": (_S, [_L, _L, _I]),
     "mlqem_asap_coarsen_dense": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
@@ -134,7 +139,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 23   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 24   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -655,6 +655,11 @@ def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
 _ASAP_DENSE = os.environ.get("MLQEM_ASAP_DENSE", "1") != "0"
 # MLQEM_ASAP_ROWS=0 keeps the two-hop path for graphs too large for the dense form (default: the wave-per-cluster form)
 _ASAP_ROWS = os.environ.get("MLQEM_ASAP_ROWS", "1") != "0"
+# MLQEM_ASAP_LISTS=0: the wave-per-cluster form with dense bit matrices in global memory (round 3) instead of sorted lists (A/B)
+_ASAP_LISTS = os.environ.get("MLQEM_ASAP_LISTS", "1") != "0"
+# MLQEM_ASAP_COMPOSE=0: ASAPooling's query projection lin() as its own [N,D]x[D,D] GEMM (forward and backward) instead of composed
+# into the one-wide score projection that is its only consumer (A/B; the two differ by fp32 rounding order, ~1e-7)
+_ASAP_COMPOSE = os.environ.get("MLQEM_ASAP_COMPOSE", "1") != "0"
 # MLQEM_ASAP_TIES=0: the segment max's backward counts its ties in a walk of its own (A/B)
 _ASAP_TIES = os.environ.get("MLQEM_ASAP_TIES", "1") != "0"
 # MLQEM_ASAP_LAZY=0 computes the coarsened connectivity inside ASAPooling's forward even when no later layer reads it
@@ -707,9 +712,21 @@ class _ASAPool(Function):
         x = ops.rowmajor(x)
         d, n = x.shape[1], s.num_nodes
         xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
-        xq = ops.linear(xq_raw, lin_w.contiguous(), lin_b)
         att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
-        a_dst = ops.linear(xq, att_q, att_b)[:, 0].contiguous()
+        if _ASAP_COMPOSE:
+            # ASAPooling's query x_q = lin(segmax) feeds ONLY the one-wide score a_i = att_q . x_q[i] + att_b (SURVEY appendix
+            # B.2 steps 2-3): a_i = (att_q W) . segmax[i] + (att_q . b + att_b) -- one row dot of the segment max against a composed
+            # 45-vector.  x_q [N, D] is never formed (a [N,D]x[D,D] GEMM forward; a data GEMM and a [D,D] weight-gradient pass
+            # backward), the gradients of lin follow from the composed vector's by the chain rule on D x D host-side tensors.
+            # (element-wise products and sums, not BLAS calls: D x D work, deterministic, capturable)
+            w_comp = (att_q.t() * lin_w).sum(0, keepdim=True)      # [1, D] = att_q W
+            b_comp = (att_q[0] * lin_b).sum().reshape(1) + att_b   # [1]
+            xq = None
+            a_dst = ops.linear(xq_raw, w_comp.contiguous(), b_comp)[:, 0].contiguous()
+        else:
+            w_comp = None
+            xq = ops.linear(xq_raw, lin_w.contiguous(), lin_b)
+            a_dst = ops.linear(xq, att_q, att_b)[:, 0].contiguous()
         c_src = ops.linear(x, att_x)[:, 0].contiguous()
         x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
         w3 = torch.cat([l1_w, l2_w, l3_w], 0).contiguous()
@@ -724,7 +741,7 @@ class _ASAPool(Function):
         new_ptr = _device_ptr(new_ptr_host.astype(np.int32), x.device)
         perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=int(sizes.max()) if len(sizes) else 0)
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
-        use_dense, use_rows = _ASAP_DENSE, _ASAP_ROWS       # the switches as they stand now: build() may run later
+        use_dense, use_rows, use_lists = _ASAP_DENSE, _ASAP_ROWS, _ASAP_LISTS       # the switches as they stand now: build() may run later
 
         def build():
             dense_ok = use_dense and len(keep) > 0 and int(keep.max()) <= ops.asap_dense_max_k()
@@ -732,6 +749,11 @@ class _ASAPool(Function):
                 # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
                 csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
                 num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
+            elif (use_rows and use_lists and len(keep) > 0 and int(keep.max()) <= 65535
+                  and int(sizes.max()) + 2 * int(keep.max()) + 96 <= ops.asap_lists_max_bits()):
+                # large graphs: persistent waves, a cluster's rows as LDS bitsets read out as sorted lists; no host read with a capacity
+                csr, slot, num_edges = ops.asap_coarsen_lists(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm,
+                                                              n, sizes, keep, capacity=getattr(s, "coarse_capacity", None))
             elif (use_rows and len(keep) > 0
                   and int(sizes.max()) + 2 * int(keep.max()) + 96 <= ops.asap_rows_max_bits()):
                 # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)
@@ -754,12 +776,13 @@ class _ASAPool(Function):
                                                  num_edges=csr7[5], graph_sizes=keep, out_eid=csr7[6])
         holder["perm"] = perm
         ctx.struct, ctx.slope, ctx.d = s, slope, d
-        ctx.save_for_backward(x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3)
+        ctx.composed = xq is None
+        ctx.save_for_backward(x, xq_raw, w_comp if xq is None else xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b)
         return x_out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3 = ctx.saved_tensors
+        x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b = ctx.saved_tensors
         s, d = ctx.struct, ctx.d
         e = s.edge_count()
         dev = x.device
@@ -782,14 +805,24 @@ class _ASAPool(Function):
         ops.linear(g_c2, att_x, transposed=True, out=gx, accumulate=True)           # c = x att_x^T
         g_att_x = torch.empty_like(att_x)
         ops.linear_wgrad(g_c2, x, g_att_x, None)
-        g_xq = ops.linear(g_a2, att_q, transposed=True)                              # a = xq att_q^T + b
-        g_att_q = torch.empty_like(att_q)
-        g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
-        ops.linear_wgrad(g_a2, xq, g_att_q, g_att_b)
-        g_xq_raw = ops.linear(g_xq, lin_w.contiguous(), transposed=True)             # xq = xq_raw W^T + b
-        g_lin_w = torch.empty_like(lin_w)
-        g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
-        ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
+        if ctx.composed:
+            w_comp = xq                                                              # a = xq_raw w_comp^T + b_comp, w_comp = att_q W
+            g_xq_raw = ops.linear(g_a2, w_comp.contiguous(), transposed=True)
+            g_w_comp = torch.empty_like(w_comp)
+            g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
+            ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
+            g_att_q = (g_w_comp * lin_w).sum(1).unsqueeze(0) + g_att_b * lin_b.unsqueeze(0)   # w_comp = att_q W, b_comp = att_q . b + att_b
+            g_lin_w = att_q.t() * g_w_comp
+            g_lin_b = g_att_b * att_q[0]
+        else:
+            g_xq = ops.linear(g_a2, att_q, transposed=True)                              # a = xq att_q^T + b
+            g_att_q = torch.empty_like(att_q)
+            g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
+            ops.linear_wgrad(g_a2, xq, g_att_q, g_att_b)
+            g_xq_raw = ops.linear(g_xq, lin_w.contiguous(), transposed=True)             # xq = xq_raw W^T + b
+            g_lin_w = torch.empty_like(lin_w)
+            g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
+            ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
         ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s, ties=ties)      # xq_raw = segment max of x
         g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],

@@ -1223,6 +1223,57 @@ def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_g
     return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], out_eid[:e]), slot, e
 
 
+def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, graph_sizes, keep_sizes,
+                       capacity=None):
+    """The pooled structure arrays of ``asap_coarsen_rows`` from SORTED LISTS (mlqem_asap_coarsen_lists_*, round 4): one
+    walk per cluster by persistent waves, nothing dense in global memory, the twin links by binary search.  ``capacity``: a bound
+    on the row-bound totals of BOTH sides and on the edge total (GraphArena.coarse_capacity); without it the totals are read back
+    (one 16-byte device->host copy) and the edge arrays are sized to the smaller.  Returns (CsrArrays, slot, edge capacity)."""
+    import numpy as np
+
+    keep = np.asarray(keep_sizes, dtype=np.int64)
+    b, k = int(keep.shape[0]), int(keep.sum())
+    kmax = int(keep.max()) if b else 0
+    nmax = int(np.asarray(graph_sizes).max()) if b else 0
+    dev = perm.device
+    lib = _lib.load()
+    mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    slot, in_ptr, out_ptr = mk(num_nodes), mk(k + 1), mk(k + 1)
+    if capacity is None:
+        if k > 0:
+            need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, 0)
+            ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+            totals = torch.empty(2, dtype=torch.int64, device=dev)
+            code = lib.mlqem_asap_coarsen_lists_caps(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(new_graph_ptr), _p(perm),
+                                                     num_nodes, k, b, _p(totals), _p(ws), need, _stream())
+            _lib.check(code, "mlqem_asap_coarsen_lists_caps")
+            t = totals.tolist()
+            cap, e = int(max(t)), int(min(t))
+        else:
+            cap = e = 0
+    else:
+        cap = e = int(capacity) if k > 0 else 0
+    need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, cap)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    code = lib.mlqem_asap_coarsen_lists_count(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(graph_ptr), _p(new_graph_ptr),
+                                              _p(perm), num_nodes, k, b, nmax, kmax, cap, _p(slot), _p(in_ptr), _p(out_ptr), _p(ws), need,
+                                              _stream())
+    _lib.check(code, "mlqem_asap_coarsen_lists_count")
+    if capacity is None and k > 0:
+        e = int(out_ptr[k].item())          # the exact edge total (this path reads the device anyway)
+    in_src, out_dst, out_eid = mk(e), mk(e), mk(e)
+    loops = torch.full((max(k, 1),), 0, dtype=torch.int32, device=dev)      # a fill kernel, not a memset node (the call may be captured)
+    if k > 0:
+        code = lib.mlqem_asap_coarsen_lists_fill(num_nodes, k, cap, _p(in_ptr), _p(out_ptr), _p(in_src), _p(out_dst), _p(out_eid), e,
+                                                 None, _p(ws), need, _stream())
+        _lib.check(code, "mlqem_asap_coarsen_lists_fill")
+    return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], out_eid[:e]), slot, e
+
+
+def asap_lists_max_bits() -> int:
+    return int(_lib.load().mlqem_asap_coarsen_lists_max_bits())
+
+
 def batch_norm_train(x, gamma, beta, eps):
     """y, mean, biased var, invstd of BatchNorm1d in training mode over the rows of x [N, C] (mlqem_batch_norm_train_f32)."""
     n, c = x.shape

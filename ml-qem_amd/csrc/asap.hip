@@ -136,6 +136,10 @@ static inline void fill_i32(int32_t* p, int32_t v, int64_t n, hipStream_t stream
   if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(n, (int64_t)kBlock)), dim3(kBlock), 0, stream, p, v, n);
 }
 
+__global__ void copy_flag_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
+}
+
 __global__ __launch_bounds__(kBlock) void slot_map_kernel(const int32_t* __restrict__ perm, int64_t K,
                                                           int32_t* __restrict__ slot) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -450,6 +454,228 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArg
   }
 }
 
+// ------------------------------------------------------ coarsened connectivity, large graphs: SORTED LISTS, one walk (round 4)
+// The bit-matrix form above writes two dense [K][k_g / 32] matrices (0.93 GB for 64 100-qubit circuits, nearly all zeros) and
+// reads them back (1.36 GB) to list 9.7 M edges, and its waves spend their time on dense scans and on chains of dependent
+// gathers.  This form keeps the LDS bitsets for what they are good at -- collapsing duplicates and handing a row back in
+// ascending order -- and touches nothing dense in global memory:
+//   caps   a structural bound on every row's length, from two-hop degree sums (h_out / h_in per node, then per kept centre),
+//          clamped to k_g - 1; exclusive scans give every row its place in two scratch lists (out-rows, in-rows);
+//   walk   a PERSISTENT wave per cluster p: X = N+[N-[c_p]] as a bitset AND a list (a node enters the list when its bit was
+//          clear), so the third hop takes its nodes 64 at a time from the list instead of scanning n_g bits, and X is cleared
+//          through the list; Y = slot(N+[X]) \ {p}; the same with N-[N-[c_p]] for the transposed row Z; both bitsets are read
+//          out once (a lane owns a run of words: ONE wave scan of packed counts per cluster), written as sorted lists to the
+//          scratch, and cleared on the way; degrees -> device scans -> both CSR pointer arrays;
+//   emit   a 16-lane group per row copies its lists to their final place and links every out-entry p -> q to its twin in q's
+//          in-row by a binary search of p in q's sorted scratch list (out_eid).
+// Same arrays as the bit-matrix form and the two-hop path (tests/test_gpu_family_b.py).
+struct ListsArgs {
+  const int32_t* in_ptr; const int32_t* in_src; const int32_t* out_ptr; const int32_t* out_dst;
+  const int32_t* gptr; const int32_t* new_gptr; const int32_t* perm; const int32_t* slot;
+  int B; int64_t N, K;
+  int Wn, Wk, lcap;              // LDS words of the node / cluster bitsets (batch maxima); entries of the node list
+  const int64_t* off_o; const int64_t* off_i;   // [K + 1]: places of the rows in the scratch lists
+  int32_t* tmp_o; int32_t* tmp_i; int64_t tmp_cap;
+  int32_t* outdeg; int32_t* indeg;   // [K + 1]
+  int32_t* overflow;             // != 0: a row left the scratch (the caller's capacity was no bound)
+};
+
+constexpr int kReachClamp = 1 << 28;   // two-hop degree sums saturate here (a row bound is clamped to k_g - 1 anyway)
+
+// Per lane: g(node) + sum of g over the node's neighbourhood in (ptr, idx); hubs are summed by the whole wave.  Every lane of
+// the wave must call it (has = false for lanes without a node).
+template <typename G>
+__device__ __forceinline__ int64_t sum_closed(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, bool has, int node,
+                                              int lane, G g) {
+  int eb = 0, ee = 0;
+  int64_t acc = 0;
+  if (has) { eb = ptr[node]; ee = ptr[node + 1]; acc = g(node); }
+  const bool heavy = has && ee - eb > kRowsLight;
+  if (has && !heavy)
+    for (int e = eb; e < ee; ++e) acc += g(idx[e]);
+  unsigned long long todo = __ballot(heavy);
+  while (todo) {
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int b = __shfl(eb, owner), e = __shfl(ee, owner);
+    int64_t part = 0;
+    for (int i = b + lane; i < e; i += 64) part += g(idx[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == owner) acc += part;
+  }
+  return acc;
+}
+
+// h_out[u] = sum over v in N+[u] of (1 + outdeg v): how many (v, w) steps leave u's closed out-neighbourhood; h_in likewise
+// over N-[u] -- the third hop is an out-hop on both sides.
+__global__ __launch_bounds__(kBlock) void coarsen_reach_kernel(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src,
+                                                               const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
+                                                               int64_t N, int32_t* __restrict__ h_out, int32_t* __restrict__ h_in) {
+  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool has = u < N;
+  auto od1 = [&](int v) { return (int64_t)(1 + out_ptr[v + 1] - out_ptr[v]); };
+  const int64_t ho = sum_closed(out_ptr, out_dst, has, (int)u, lane, od1);
+  const int64_t hi = sum_closed(in_ptr, in_src, has, (int)u, lane, od1);
+  if (has) {
+    h_out[u] = (int32_t)min(ho, (int64_t)kReachClamp);
+    h_in[u] = (int32_t)min(hi, (int64_t)kReachClamp);
+  }
+}
+
+// cap_o[p] >= |row p|, cap_i[p] >= |row p of the transpose|: sums of h over N-[c_p], clamped to k_g - 1; entry K is 0 (the
+// scans' last element is then the total)
+__global__ __launch_bounds__(kBlock) void coarsen_row_caps_kernel(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src,
+                                                                  const int32_t* __restrict__ perm, const int32_t* __restrict__ new_gptr,
+                                                                  int B, int64_t K, const int32_t* __restrict__ h_out,
+                                                                  const int32_t* __restrict__ h_in, int64_t* __restrict__ cap_o,
+                                                                  int64_t* __restrict__ cap_i) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool has = p < K;
+  const int c = has ? perm[p] : 0;
+  const int64_t so = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return (int64_t)h_out[u]; });
+  const int64_t si = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return (int64_t)h_in[u]; });
+  if (has) {
+    const int g = graph_at(new_gptr, B, p);
+    const int64_t most = (int64_t)(new_gptr[g + 1] - new_gptr[g]) - 1;
+    cap_o[p] = min(so, most);
+    cap_i[p] = min(si, most);
+  } else if (p == K) {
+    cap_o[K] = 0;
+    cap_i[K] = 0;
+  }
+}
+
+// One side of a cluster's reach.  X / L: bitset and list of the closed (ptr2, idx2)-neighbourhood of {c} + N-[c]; S: the clusters
+// (bits local to the graph, without `self`) of the closed out-neighbourhood of X.  Leaves X zero and *cnt zero.
+__device__ __forceinline__ void lists_side(const ListsArgs& a, const int32_t* __restrict__ ptr2, const int32_t* __restrict__ idx2, int c,
+                                           int ib, int ie, int n0, int k0, int Wn, int self, uint32_t* X, int* L, int* cnt, uint32_t* S,
+                                           int lane) {
+  const int lcap = a.lcap;
+  for (int i0 = ib - 1; i0 < ie; i0 += 64) {         // index ib - 1 stands for c itself
+    const int i = i0 + lane;
+    const bool has = i < ie;
+    const int u = has ? (i < ib ? c : a.in_src[i]) : 0;
+    visit_closed(ptr2, idx2, has, u, lane, [&](int v) {
+      const uint32_t bit = 1u << ((v - n0) & 31);
+      const uint32_t old = atomicOr(&X[(v - n0) >> 5], bit);
+      if (!(old & bit)) {
+        const int k = atomicAdd(cnt, 1);
+        if (k < lcap) L[k] = v;
+      }
+    });
+  }
+  wave_lds_sync();
+  const int n = *cnt;
+  auto reach = [&](int w) {
+    const int q = a.slot[w];
+    if (q >= 0 && q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31));
+  };
+  if (n <= lcap) {
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const bool has = i < n;
+      const int v = has ? L[i] : 0;
+      visit_closed(a.out_ptr, a.out_dst, has, v, lane, reach);
+    }
+    for (int i = lane; i < n; i += 64) X[(L[i] - n0) >> 5] = 0u;          // clear X through the list
+  } else {                                                                  // more nodes than the list holds: scan the bitset
+    for (int w0 = 0; w0 < Wn; w0 += 64) {
+      const int wi = w0 + lane;
+      uint32_t bits = wi < Wn ? X[wi] : 0u;
+      while (__ballot(bits != 0u)) {
+        const bool has = bits != 0u;
+        int v = 0;
+        if (has) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; v = n0 + wi * 32 + b; }
+        visit_closed(a.out_ptr, a.out_dst, has, v, lane, reach);
+      }
+    }
+    for (int i = lane; i < Wn; i += 64) X[i] = 0u;
+  }
+  if (lane == 0) *cnt = 0;
+  wave_lds_sync();
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_lists_kernel(const ListsArgs a) {
+  extern __shared__ uint32_t s_bits[];              // per wave: X [Wn], Y [Wk], Z [Wk], L [lcap], count
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int per = a.Wn + 2 * a.Wk + a.lcap + 1;
+  uint32_t* X = s_bits + (size_t)wid * per;
+  uint32_t* Y = X + a.Wn;
+  uint32_t* Z = Y + a.Wk;
+  int* L = reinterpret_cast<int*>(Z + a.Wk);
+  int* cnt = L + a.lcap;
+  for (int i = lane; i < per; i += 64) X[i] = 0u;    // once per wave: every cluster leaves its region as it found it
+  wave_lds_sync();
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + wid; p < a.K; p += stride) {     // wave-uniform; every wave reaches the end
+    const int c = a.perm[p];
+    const int g = graph_at(a.new_gptr, a.B, p);
+    const int n0 = a.gptr[g], k0 = a.new_gptr[g];
+    const int Wn = (a.gptr[g + 1] - n0 + 31) >> 5, Wk = (a.new_gptr[g + 1] - k0 + 31) >> 5;
+    const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
+    lists_side(a, a.out_ptr, a.out_dst, c, ib, ie, n0, k0, Wn, (int)p, X, L, cnt, Y, lane);     // X = N+[N-[c]] -> row p
+    lists_side(a, a.in_ptr, a.in_src, c, ib, ie, n0, k0, Wn, (int)p, X, L, cnt, Z, lane);       // X = N-[N-[c]] -> row p of the transpose
+    // read both bitsets out in ascending order: lane l owns words [l cw, (l + 1) cw); one scan of the packed counts (a row
+    // has fewer than 65 536 entries: Wk <= 2048 words)
+    const int cw = (Wk + 63) >> 6;
+    const int w_lo = lane * cw, w_hi = min(Wk, w_lo + cw);
+    int ny = 0, nz = 0;
+    for (int w = w_lo; w < w_hi; ++w) { ny += __popc(Y[w]); nz += __popc(Z[w]); }
+    const int packed = ny | (nz << 16);
+    const int ex = wave_excl_scan(packed, lane);
+    const int tot = __shfl(ex + packed, 63);
+    const int deg_o = tot & 0xFFFF, deg_i = (int)((unsigned)tot >> 16);
+    const int64_t bo = a.off_o[p], bi = a.off_i[p];
+    int64_t po = bo + (ex & 0xFFFF), pi = bi + (int)((unsigned)ex >> 16);
+    const bool fits = bo + deg_o <= a.tmp_cap && bi + deg_i <= a.tmp_cap;      // wave-uniform
+    for (int w = w_lo; w < w_hi; ++w) {
+      uint32_t yb = Y[w], zb = Z[w];
+      Y[w] = 0u; Z[w] = 0u;
+      const int first = k0 + w * 32;
+      while (yb) { const int b = __ffs((int)yb) - 1; yb &= yb - 1; if (fits) a.tmp_o[po] = first + b; ++po; }
+      while (zb) { const int b = __ffs((int)zb) - 1; zb &= zb - 1; if (fits) a.tmp_i[pi] = first + b; ++pi; }
+    }
+    if (lane == 0) {
+      a.outdeg[p] = fits ? deg_o : 0;
+      a.indeg[p] = fits ? deg_i : 0;
+      if (!fits) atomicOr(a.overflow, 1);
+    }
+    wave_lds_sync();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void coarsen_lists_emit_kernel(const ListsArgs a, const int32_t* __restrict__ in_ptr_new,
+                                                                    const int32_t* __restrict__ out_ptr_new,
+                                                                    int32_t* __restrict__ in_src_new, int32_t* __restrict__ out_dst_new,
+                                                                    int32_t* __restrict__ out_eid_new, int64_t edge_cap) {
+  const int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x & (kGroup - 1);
+  if (r >= a.K) return;
+  const int di = a.indeg[r], dout = a.outdeg[r];
+  const int64_t bi = a.off_i[r], bo = a.off_o[r];
+  const int64_t ip = in_ptr_new[r], op = out_ptr_new[r];
+  for (int i = l; i < di; i += kGroup)
+    if (ip + i < edge_cap) in_src_new[ip + i] = a.tmp_i[bi + i];
+  for (int i = l; i < dout; i += kGroup) {
+    const int q = a.tmp_o[bo + i];
+    // the twin of (r -> q) in q's in-row: the rank of r in q's sorted list of sources (r is in it: the two walks list the same edges)
+    const int32_t* __restrict__ lst = a.tmp_i + a.off_i[q];
+    int lo = 0, hi = a.indeg[q];
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (lst[mid] < (int32_t)r) lo = mid + 1; else hi = mid;
+    }
+    if (op + i < edge_cap) {
+      out_dst_new[op + i] = q;
+      out_eid_new[op + i] = in_ptr_new[q] + lo;
+    }
+  }
+}
+
 static size_t dense_scan_bytes(int64_t K) {
   size_t temp = 0;
   (void)rocprim::exclusive_scan(nullptr, temp, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(K + 1),
@@ -731,6 +957,174 @@ extern "C" int mlqem_asap_coarsen_rows_fill(const int32_t* new_graph_ptr, int64_
             const_cast<void*>(workspace));
   hipLaunchKernelGGL(coarsen_rows_fill_kernel, dim3((unsigned)ceil_div(K, (int64_t)4)), dim3(kBlock), 0, stream, a, new_in_ptr,
                      new_out_ptr, new_in_src, new_out_dst, new_out_eid);
+  return launch_status();
+}
+
+// ---- list form (round 4): workspace = h_out, h_in [N] | cap_o, cap_i, off_o, off_i [K + 1] int64 | outdeg, indeg [K + 1] | flag |
+//      scan temp | tmp_o, tmp_i [capacity]
+namespace {
+struct ListsLayout {
+  size_t h, caps, degs, flag, scan, lists, total;
+};
+size_t lists_scan_bytes(int64_t K) {
+  size_t t64 = 0;
+  (void)rocprim::exclusive_scan(nullptr, t64, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(K + 1), rocprim::plus<int64_t>(),
+                                (hipStream_t)0);
+  return std::max((t64 + 255) / 256 * 256, dense_scan_bytes(K));
+}
+ListsLayout lists_layout(int64_t N, int64_t K, int64_t capacity) {
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  ListsLayout l;
+  l.h = up((size_t)std::max<int64_t>(N, 1) * sizeof(int32_t));
+  l.caps = up((size_t)(K + 1) * sizeof(int64_t));
+  l.degs = up((size_t)(K + 1) * sizeof(int32_t));
+  l.flag = 256;
+  l.scan = lists_scan_bytes(K);
+  l.lists = up((size_t)std::max<int64_t>(capacity, 1) * sizeof(int32_t));
+  l.total = 2 * l.h + 4 * l.caps + 2 * l.degs + l.flag + l.scan + 2 * l.lists;
+  return l;
+}
+constexpr int kListsLcap = 512;                      // nodes the second hop may hold as a list (more: the bitset is scanned)
+constexpr int kListsMaxLds = 160 * 1024;             // one workgroup may take a CU's whole LDS
+int lists_words_per_wave(int nmax, int kmax) { return (nmax + 31) / 32 + 2 * ((kmax + 31) / 32) + kListsLcap + 1; }
+
+struct ListsPointers {
+  int32_t* h_out; int32_t* h_in; int64_t* cap_o; int64_t* cap_i; int64_t* off_o; int64_t* off_i; int32_t* outdeg; int32_t* indeg;
+  int32_t* flag; void* scan; int32_t* tmp_o; int32_t* tmp_i;
+};
+ListsPointers lists_pointers(void* workspace, const ListsLayout& l) {
+  char* w = static_cast<char*>(workspace);
+  ListsPointers q;
+  q.h_out = reinterpret_cast<int32_t*>(w); w += l.h;
+  q.h_in = reinterpret_cast<int32_t*>(w); w += l.h;
+  q.cap_o = reinterpret_cast<int64_t*>(w); w += l.caps;
+  q.cap_i = reinterpret_cast<int64_t*>(w); w += l.caps;
+  q.off_o = reinterpret_cast<int64_t*>(w); w += l.caps;
+  q.off_i = reinterpret_cast<int64_t*>(w); w += l.caps;
+  q.outdeg = reinterpret_cast<int32_t*>(w); w += l.degs;
+  q.indeg = reinterpret_cast<int32_t*>(w); w += l.degs;
+  q.flag = reinterpret_cast<int32_t*>(w); w += l.flag;
+  q.scan = w; w += l.scan;
+  q.tmp_o = reinterpret_cast<int32_t*>(w); w += l.lists;
+  q.tmp_i = reinterpret_cast<int32_t*>(w);
+  return q;
+}
+
+// h, row bounds and their scans: off_o / off_i [K + 1] (entry K = the totals)
+int lists_caps(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* new_graph_ptr,
+               const int32_t* perm, int64_t N, int64_t K, int64_t B, const ListsPointers& q, const ListsLayout& l, hipStream_t stream) {
+  hipLaunchKernelGGL(coarsen_reach_kernel, dim3((unsigned)ceil_div(N, (int64_t)kBlock)), dim3(kBlock), 0, stream, in_ptr, in_src, out_ptr,
+                     out_dst, N, q.h_out, q.h_in);
+  hipLaunchKernelGGL(coarsen_row_caps_kernel, dim3((unsigned)ceil_div(K + 1, (int64_t)kBlock)), dim3(kBlock), 0, stream, in_ptr, in_src, perm,
+                     new_graph_ptr, (int)B, K, q.h_out, q.h_in, q.cap_o, q.cap_i);
+  size_t temp_bytes = l.scan;
+  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.cap_o, q.off_o, (int64_t)0, (size_t)(K + 1), rocprim::plus<int64_t>(), stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.cap_i, q.off_i, (int64_t)0, (size_t)(K + 1), rocprim::plus<int64_t>(), stream) != hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  return MLQEM_OK;
+}
+
+__global__ void lists_totals_kernel(const int64_t* __restrict__ off_o, const int64_t* __restrict__ off_i, int64_t K, int64_t* __restrict__ totals) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { totals[0] = off_o[K]; totals[1] = off_i[K]; }
+}
+}  // namespace
+
+extern "C" size_t mlqem_asap_coarsen_lists_workspace_bytes(int64_t N, int64_t K, int64_t capacity) {
+  if (N < 0 || K < 0 || capacity < 0) return 0;
+  return lists_layout(N, K, capacity).total;
+}
+
+extern "C" int mlqem_asap_coarsen_lists_max_bits(void) { return (kListsMaxLds / 4 / 4 - kListsLcap - 1) * 32; }
+
+extern "C" int mlqem_asap_coarsen_lists_caps(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                             const int32_t* new_graph_ptr, const int32_t* perm, int64_t N, int64_t K, int64_t B,
+                                             int64_t* totals, void* workspace, size_t workspace_bytes, mlqem_stream_t stream_) {
+  begin_launches();
+  hipStream_t stream = as_stream(stream_);
+  if (N < 0 || K < 0 || K > N || B < 0 || N >= 0x7fffffffLL || !totals) return MLQEM_ERR_BAD_ARG;
+  const ListsLayout l = lists_layout(N, K, 0);
+  if (!workspace || workspace_bytes < l.total) return MLQEM_ERR_WORKSPACE;
+  if (K > 0 && (!in_ptr || !out_ptr || !new_graph_ptr || !perm || B == 0)) return MLQEM_ERR_BAD_ARG;
+  const ListsPointers q = lists_pointers(workspace, l);
+  const int rc = lists_caps(in_ptr, in_src, out_ptr, out_dst, new_graph_ptr, perm, N, K, B, q, l, stream);
+  if (rc != MLQEM_OK) return rc;
+  hipLaunchKernelGGL(lists_totals_kernel, dim3(1), dim3(64), 0, stream, q.off_o, q.off_i, K, totals);
+  return launch_status();
+}
+
+// Pass 1: slot[], the rows as sorted lists in the workspace, both CSR pointer arrays.  `capacity`: entries each scratch list
+// holds -- a bound on sum_p cap_o[p] and on sum_p cap_i[p] (mlqem_asap_coarsen_lists_caps reports both; GraphArena knows a
+// structural one); a row that would leave the scratch is dropped and MLQEM never writes past it (the flag is checked by pass 2).
+extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                              const int32_t* out_dst, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
+                                              const int32_t* perm, int64_t N, int64_t K, int64_t B, int nmax, int kmax, int64_t capacity,
+                                              int32_t* slot, int32_t* new_in_ptr, int32_t* new_out_ptr, void* workspace,
+                                              size_t workspace_bytes, mlqem_stream_t stream_) {
+  begin_launches();
+  hipStream_t stream = as_stream(stream_);
+  if (N < 0 || K < 0 || K > N || B < 0 || kmax < 0 || nmax < 0 || capacity < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if (nmax + 2 * kmax + 96 > mlqem_asap_coarsen_lists_max_bits() || kmax > 65535) return MLQEM_ERR_UNSUPPORTED;
+  if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
+  const ListsLayout l = lists_layout(N, K, capacity);
+  if (!workspace || workspace_bytes < l.total) return MLQEM_ERR_WORKSPACE;
+  fill_i32(slot, -1, N, stream);
+  if (K == 0 || B == 0) {
+    fill_i32(new_in_ptr, 0, K + 1, stream);
+    fill_i32(new_out_ptr, 0, K + 1, stream);
+    return launch_status();
+  }
+  if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm) return MLQEM_ERR_BAD_ARG;
+  const ListsPointers q = lists_pointers(workspace, l);
+  hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
+  const int rc = lists_caps(in_ptr, in_src, out_ptr, out_dst, new_graph_ptr, perm, N, K, B, q, l, stream);
+  if (rc != MLQEM_OK) return rc;
+  fill_i32(q.outdeg + K, 0, 1, stream);
+  fill_i32(q.indeg + K, 0, 1, stream);
+  fill_i32(q.flag, 0, 1, stream);
+  ListsArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, N, K, (nmax + 31) / 32, (kmax + 31) / 32,
+              kListsLcap, q.off_o, q.off_i, q.tmp_o, q.tmp_i, capacity, q.outdeg, q.indeg, q.flag};
+  const size_t lds = (size_t)4 * lists_words_per_wave(nmax, kmax) * sizeof(uint32_t);
+  static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(coarsen_lists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              kListsMaxLds) == hipSuccess ? 1 : 0;
+  if (!once) return MLQEM_ERR_LAUNCH;
+  // persistent waves: as many workgroups as the LDS lets a CU hold (at most 8: 32 waves), never more than there are clusters
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kListsMaxLds / std::max<size_t>(lds, 1)));
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(K, (int64_t)4), (int64_t)cus * per_cu));
+  hipLaunchKernelGGL(coarsen_lists_kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+  size_t temp_bytes = l.scan;
+  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(), stream) !=
+      hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.indeg, new_in_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(), stream) !=
+      hipSuccess)
+    return MLQEM_ERR_LAUNCH;
+  return launch_status();
+}
+
+// Pass 2 (same workspace and capacity, untouched in between): the edge arrays, each holding `edge_capacity` entries (>= the edge
+// total new_out_ptr[K]; nothing is written past it).  *overflow (device, optional) = 1 when pass 1 dropped a row.
+extern "C" int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t capacity, const int32_t* new_in_ptr, const int32_t* new_out_ptr,
+                                             int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid, int64_t edge_capacity,
+                                             int32_t* overflow, void* workspace, size_t workspace_bytes, mlqem_stream_t stream_) {
+  begin_launches();
+  hipStream_t stream = as_stream(stream_);
+  if (N < 0 || K < 0 || capacity < 0 || edge_capacity < 0) return MLQEM_ERR_BAD_ARG;
+  if (K == 0) return MLQEM_OK;
+  if (!new_in_ptr || !new_out_ptr || (edge_capacity > 0 && (!new_in_src || !new_out_dst || !new_out_eid))) return MLQEM_ERR_BAD_ARG;
+  const ListsLayout l = lists_layout(N, K, capacity);
+  if (!workspace || workspace_bytes < l.total) return MLQEM_ERR_WORKSPACE;
+  const ListsPointers q = lists_pointers(workspace, l);
+  ListsArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, K, 0, 0, kListsLcap, q.off_o, q.off_i, q.tmp_o,
+              q.tmp_i, capacity, q.outdeg, q.indeg, q.flag};
+  hipLaunchKernelGGL(coarsen_lists_emit_kernel, dim3((unsigned)ceil_div(K * kGroup, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, new_in_ptr,
+                     new_out_ptr, new_in_src, new_out_dst, new_out_eid, edge_capacity);
+  if (overflow) hipLaunchKernelGGL(copy_flag_kernel, dim3(1), dim3(64), 0, stream, q.flag, overflow);
   return launch_status();
 }
 

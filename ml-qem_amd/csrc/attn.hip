@@ -30,7 +30,7 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_ke
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int C,
     float* __restrict__ out, int64_t ldo) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;                              // a whole group leaves together
   const int beg = ptr[row], end = ptr[row + 1];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_any_width_kernel(con
                                                                    const float* __restrict__ c_src, float slope,
                                                                    int64_t N, int C, float* __restrict__ out,
                                                                    int64_t ldo) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = (int64_t)row_block() * kBlock + threadIdx.x;
   if (t >= N * C) return;
   const int64_t row = t / C;
   const int ch = (int)(t - row * C);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void leconv_fitness_kernel(const float* __r
                                                                 const int32_t* __restrict__ ptr,
                                                                 const int32_t* __restrict__ idx, int64_t N,
                                                                 float* __restrict__ fitness) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = (int64_t)row_block() * kBlock + threadIdx.x;
   if (i >= N) return;
   const int beg = ptr[i], end = ptr[i + 1];
   const float qi = pqr[i * 3 + 1];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_kernel(const float* 
                                                                    const int32_t* __restrict__ perm,
                                                                    const float* __restrict__ scale, int64_t K, int C,
                                                                    float* __restrict__ out, int64_t ldo) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = (int64_t)row_block() * kBlock + threadIdx.x;
   if (t >= K * C) return;
   int c;
   const int64_t p = split_index(t, C, c);

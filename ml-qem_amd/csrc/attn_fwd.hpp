@@ -44,7 +44,7 @@ struct AttnFwdArgs {
 };
 
 template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(const AttnFwdArgs& a) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;                             // a whole group leaves together

@@ -70,7 +70,7 @@ __device__ __forceinline__ void store_channels(float* __restrict__ p, const f4u&
 
 // ------------------------------------------------------------------------------------------------------ forward
 template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(const AttnFwdArgs& a) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LPH;
+  const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
   const int lq = threadIdx.x % LPH, lu = lq & 3;
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;                             // a whole (row, head) leaves together

@@ -35,6 +35,21 @@ __device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned nb
   return base + k;
 }
 
+// Block number of a ROW kernel (a block owns a run of consecutive rows): XCD-contiguous, so that the blocks resident on one XCD
+// walk neighbouring rows -- rows of the same graph, whose source rows are then in that XCD's 4 MB L2 (a pooled 100-qubit graph's
+// key + value rows are 1.4 MB; dealt round-robin every XCD sees every graph and the gathers go out to the Infinity Cache).
+// -DMLQEM_XCD_ROWS=0 compiles the plain numbering (A/B builds only).
+#ifndef MLQEM_XCD_ROWS
+#define MLQEM_XCD_ROWS 1
+#endif
+__device__ __forceinline__ unsigned row_block() {
+#if MLQEM_XCD_ROWS
+  return xcd_contiguous_block(blockIdx.x, gridDim.x);
+#else
+  return blockIdx.x;
+#endif
+}
+
 // Counter-based uniform in [0,1): one splitmix64 round over (seed, element index).
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;

@@ -34,7 +34,7 @@ struct AttnBwdArgs {
 };
 
 template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(const AttnBwdArgs a) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;
@@ -161,7 +161,7 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
 
 // Source side: g_k[j] = sum_{e: j->i} gs_e q_i ; g_v[j] = sum_e al_e g_i  (self entry included).
 template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_kernel(const AttnBwdArgs a) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;
@@ -254,7 +254,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_tr
 }
 
 template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_q4_kernel(const AttnBwdArgs a) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LPH;
+  const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
   const int lq = threadIdx.x % LPH, lu = lq & 3;
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;
@@ -330,7 +330,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 }
 
 template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_q4_kernel(const AttnBwdArgs a) {
-  const int64_t t = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LPH;
+  const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
   const int lq = threadIdx.x % LPH, lu = lq & 3;
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;
@@ -399,7 +399,7 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
     float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a,
     const float* __restrict__ xmax, int64_t ldm, float* __restrict__ tie_count, int64_t ldt) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   const int beg = ptr[row], end = ptr[row + 1];
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_any_width_ke
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
     float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   const int beg = ptr[row], end = ptr[row + 1];
@@ -601,7 +601,7 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
     int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   bool has[NV];
@@ -665,7 +665,7 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_share_ke
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ iptr, const int32_t* __restrict__ isrc,
     int64_t N, int C, float* __restrict__ gshare, int64_t lds) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   bool has[NV];
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void segment_max_share_from_counts_kernel(c
                                                                                const float* __restrict__ cnt, int64_t ldc, int64_t N, int C,
                                                                                float* __restrict__ gshare, int64_t lds) {
   const int cv = (C + VEC - 1) / VEC;
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = (int64_t)row_block() * kBlock + threadIdx.x;
   if (t >= N * cv) return;
   int cs;
   const int64_t row = split_index(t, cv, cs);
@@ -730,7 +730,7 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kern
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     int64_t N, int C, float* __restrict__ gx, int64_t ldgx) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   bool has[NV];
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_any_width_ke
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
     int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = (int64_t)row_block() * kBlock + threadIdx.x;
   if (t >= N * C) return;
   const int64_t row = t / C;
   const int ch = (int)(t - row * C);
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void segment_max_share_any_width_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ iptr, const int32_t* __restrict__ isrc,
     int64_t N, int C, float* __restrict__ gshare, int64_t lds) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = (int64_t)row_block() * kBlock + threadIdx.x;
   if (t >= N * C) return;
   const int64_t row = t / C;
   const int ch = (int)(t - row * C);
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void segment_max_bwd_any_width_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     int64_t N, int C, float* __restrict__ gx, int64_t ldgx) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = (int64_t)row_block() * kBlock + threadIdx.x;
   if (t >= N * C) return;
   const int64_t row = t / C;
   const int ch = (int)(t - row * C);
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_kernel(
     const float* __restrict__ gout, int64_t ldgo, const float* __restrict__ xnew, int64_t ldn,
     const float* __restrict__ fitness, const int32_t* __restrict__ slot, int64_t N, int C, float* __restrict__ gxnew,
     int64_t ldgn, float* __restrict__ gfit) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;   // one 16-lane group per row
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;   // one 16-lane group per row
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   const int p = slot[row];
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_kernel(
 __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
     const float* __restrict__ gfit, const float* __restrict__ fitness, const int32_t* __restrict__ iptr,
     const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, int64_t N, float* __restrict__ gpqr) {
-  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t j = (int64_t)row_block() * kBlock + threadIdx.x;
   if (j >= N) return;
   auto graw = [&](int64_t i) { const float f = fitness[i]; return gfit[i] * f * (1.f - f); };
   const float gj = graw(j);

@@ -8,7 +8,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
 import numpy as np, torch
 from blackwater.data.arena import GraphArena
 from blackwater.data.synthetic import TfimCorpus
-from blackwater.native import ops
+from blackwater.native import _lib, ops
+if os.environ.get('MLQEM_LIB'):
+    _lib.LIB_PATH = os.environ['MLQEM_LIB']
 from blackwater.native.structure import GraphStructure
 from blackwater.nn import ExpValCircuitGraphModel
 
@@ -84,11 +86,17 @@ d = indeg.cpu().numpy()
 print("level-1 in-degree quantiles 50/83/90/99/max:", [int(np.quantile(d, q)) for q in (0.5, 0.83, 0.9, 0.99, 1.0)],
       "share of edges in rows >= 32:", float(d[d >= 32].sum()) / float(d.sum()), flush=True)
 run("level 1 as it stands   ", s1, 2, 15)
-run("level 1 by in-degree   ", relabel(s1, indeg), 2, 15)
-run("level 1 by out-degree  ", relabel(s1, outdeg), 2, 15)
-run("level 1 random order   ", relabel(s1, torch.rand(n, device=dev)), 2, 15)
+if os.environ.get("PROBE_ONLY_L1", "0") == "1":
+    sys.exit(0)
+if os.environ.get("PROBE_FULL", "0") == "1":
+    run("level 1 by in-degree   ", relabel(s1, indeg), 2, 15)
+    run("level 1 by out-degree  ", relabel(s1, outdeg), 2, 15)
+    run("level 1 random order   ", relabel(s1, torch.rand(n, device=dev)), 2, 15)
+gid = torch.repeat_interleave(torch.arange(s1.num_graphs, device=dev), (s1.graph_ptr[1:] - s1.graph_ptr[:-1]).long())
+run("level 1 by (graph, in-degree)", relabel(s1, indeg - gid * 4096), 2, 15)
 s0 = b4.structure
 n0 = s0.num_nodes
 indeg0 = (s0.in_ptr[1:n0 + 1] - s0.in_ptr[:n0]).long()
 run("level 0 as it stands   ", s0, 3, 15)
-run("level 0 by in-degree   ", relabel(s0, indeg0), 3, 15)
+if os.environ.get("PROBE_FULL", "0") == "1":
+    run("level 0 by in-degree   ", relabel(s0, indeg0), 3, 15)

@@ -6,6 +6,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
 import numpy as np, torch
 from blackwater.data.arena import GraphArena
 from blackwater.data.synthetic import TfimCorpus
+from blackwater.native import _lib
+if os.environ.get('MLQEM_LIB'):          # A/B builds of the library (scripts/ab_*.sh)
+    _lib.LIB_PATH = os.environ['MLQEM_LIB']
 from blackwater.nn import ExpValCircuitGraphModel
 from blackwater.train import Trainer
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

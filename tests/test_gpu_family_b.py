@@ -372,23 +372,75 @@ def test_wave_per_cluster_coarsening_equals_the_two_hop_path(golden_dir, g1):
                   torch.from_numpy(np.repeat(np.arange(len(counts)), counts)).to(DEV), len(counts)))
     for model, x, ei, bv, b in cases:
         res = {}
-        for rows in (True, False):
-            F._ASAP_DENSE, F._ASAP_ROWS = False, rows
+        # "lists": sorted lists from persistent waves (round 4, the default); "rows": dense bit matrices (round 3); "hop": two-hop
+        for mode, (rows, lists) in {"lists": (True, True), "rows": (True, False), "hop": (False, False)}.items():
+            F._ASAP_DENSE, F._ASAP_ROWS, F._ASAP_LISTS = False, rows, lists
             try:
-                res[rows] = _pooled_levels(model, x, ei, bv, b)
+                res[mode] = _pooled_levels(model, x, ei, bv, b)
+                for lvl in (0, 1):
+                    res[mode][lvl].in_ptr          # the second level is deferred: build it under THIS mode's switches
             finally:
-                F._ASAP_DENSE, F._ASAP_ROWS = True, True
-        for lvl in (0, 1):
-            a, c = res[True][lvl], res[False][lvl]
-            e = int(c.in_ptr[c.num_nodes].item())
-            assert e == c.num_edges == a.num_edges and e > 0
-            assert torch.equal(a.in_ptr[:a.num_nodes + 1], c.in_ptr[:c.num_nodes + 1])
-            assert torch.equal(a.out_ptr[:a.num_nodes + 1], c.out_ptr[:c.num_nodes + 1])
-            assert torch.equal(a.in_src[:e], c.in_src[:e]) and torch.equal(a.out_dst[:e], c.out_dst[:e])
-            assert torch.equal(a.out_eid[:e], c.out_eid[:e])
-            assert not a.loops[:a.num_nodes].any()
-        assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
-        assert torch.equal(res[True][4], res[False][4])
+                F._ASAP_DENSE, F._ASAP_ROWS, F._ASAP_LISTS = True, True, True
+        for mode in ("lists", "rows"):
+            for lvl in (0, 1):
+                a, c = res[mode][lvl], res["hop"][lvl]
+                e = int(c.in_ptr[c.num_nodes].item())
+                assert e == c.num_edges == a.num_edges and e > 0
+                assert torch.equal(a.in_ptr[:a.num_nodes + 1], c.in_ptr[:c.num_nodes + 1])
+                assert torch.equal(a.out_ptr[:a.num_nodes + 1], c.out_ptr[:c.num_nodes + 1])
+                assert torch.equal(a.in_src[:e], c.in_src[:e]) and torch.equal(a.out_dst[:e], c.out_dst[:e])
+                assert torch.equal(a.out_eid[:e], c.out_eid[:e])
+                assert not a.loops[:a.num_nodes].any()
+            assert torch.equal(res[mode][2], res["hop"][2]) and torch.equal(res[mode][3], res["hop"][3])
+            assert torch.equal(res[mode][4], res["hop"][4])
+
+
+def test_list_coarsening_with_a_structural_capacity_equals_the_exact_one(golden_dir):
+    """An arena batch sizes the list form's scratch and edge arrays by GraphArena.coarse_capacity (no device->host copy); the arrays'
+    first in_ptr[K] entries equal the ones built with read-back sizes, the capacity bounds both row-bound totals, and the
+    structure of a batch is the same whichever capacity it was built with -- 100-qubit circuits, both pooling levels."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import TfimCorpus
+    from blackwater.native import _lib
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    corpus = TfimCorpus(100, [1, 3, 6, 10], 2, seed=5, exp_value_size=4)
+    h = corpus.host_graphs()
+    arena = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"], device=DEV)
+    batch = arena.batch(np.arange(len(arena)))
+    s = batch.structure
+    assert s.coarse_capacity is not None and s.coarse_capacity > 0
+    torch.manual_seed(2)
+    model = ExpValCircuitGraphModel(22, 15).to(DEV).eval()
+    with torch.no_grad():
+        g = model.transformer1(batch.nodes.materialize() if hasattr(batch.nodes, "materialize") else batch.nodes, s)
+        cap = s.coarse_capacity
+        _, s1_cap, perm_cap = model.pooling1(g, s)
+        s1_cap.in_ptr
+        s.coarse_capacity = None
+        _, s1_exact, perm_exact = model.pooling1(g, s)
+        s1_exact.in_ptr
+        s.coarse_capacity = cap
+    assert torch.equal(perm_cap, perm_exact)
+    k = s1_exact.num_nodes
+    e = int(s1_exact.in_ptr[k].item())
+    assert e == s1_exact.num_edges and e <= cap and s1_cap.num_edges == cap
+    for name in ("in_ptr", "out_ptr"):
+        assert torch.equal(getattr(s1_cap, name)[:k + 1], getattr(s1_exact, name)[:k + 1])
+    for name in ("in_src", "out_dst", "out_eid"):
+        assert torch.equal(getattr(s1_cap, name)[:e], getattr(s1_exact, name)[:e])
+    # the capacity really bounds the scratch the rows are placed in
+    lib = _lib.load()
+    from blackwater.native import ops
+    need = lib.mlqem_asap_coarsen_lists_workspace_bytes(s.num_nodes, k, 0)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    totals = torch.zeros(2, dtype=torch.int64, device=DEV)
+    code = lib.mlqem_asap_coarsen_lists_caps(s.in_ptr.data_ptr(), s.in_src.data_ptr(), s.out_ptr.data_ptr(), s.out_dst.data_ptr(),
+                                             s1_exact.graph_ptr.data_ptr(), perm_exact.data_ptr(), s.num_nodes, k, s.num_graphs,
+                                             totals.data_ptr(), ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream)
+    assert code == 0
+    t = totals.tolist()
+    assert e <= min(t) and max(t) <= cap
 
 
 def test_family_b_train_step_makes_no_device_to_host_copy(golden_dir, g1):
