@@ -518,29 +518,36 @@ int mlqem_asap_coarsen_rows_fill(const int32_t* new_graph_ptr, int64_t K, int64_
                                  const void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* The same arrays from SORTED LISTS instead of bit matrices (round 4; the default for large graphs): nothing dense is written
- * to or read from global memory.  A structural bound per row (two-hop degree sums, clamped to k_g - 1) places every row in
- * two scratch lists; persistent waves build a cluster's out-row and in-row as LDS bitsets whose second hop is driven by a
- * node LIST (no scan of n_g bits), read them out in ascending order and clear them on the way; degrees -> scans -> the CSR
- * pointers; the fill pass copies the lists to their place and finds every out-entry's twin in the in-row by binary search.
- *   lists_caps:  totals[2] (device int64) = sum of the row bounds of the out- and of the in-side -- what `capacity` must
- *                cover when the caller has no structural bound of its own (one 16-byte read); workspace for capacity 0;
- *   lists_count: slot[N], new_in_ptr[K + 1], new_out_ptr[K + 1]; `capacity` = entries per scratch list;
- *   lists_fill:  new_in_src / new_out_dst / new_out_eid, each holding edge_capacity >= new_out_ptr[K] entries, from the
- *                SAME workspace; *overflow (device, may be NULL) = 1 if `capacity` was too small (rows were dropped).
- * nmax + 2 kmax + 96 <= mlqem_asap_coarsen_lists_max_bits(), kmax <= 65535, else MLQEM_ERR_UNSUPPORTED.
+ * to or read from global memory, and the three hops of a cluster's reach are split into per-NODE lists built once --
+ * C(v): the kept centres among N+[v]; R(u) / R'(u): the C lists of N+[u] / N-[u] one after the other -- so that a hub's list
+ * (a barrier: ~300 entries) is formed once and read, coalesced, by every cluster that contains the hub.  Persistent waves OR a
+ * cluster's few lists into two LDS bitsets (row and transposed row), read them out in ascending order and clear them on the
+ * way; a structural bound per row (sums of two-hop degree sums, clamped to k_g - 1) places every row in a scratch; degrees ->
+ * scans -> the CSR pointers; the fill pass copies the lists to their place and finds every out-entry's twin in the in-row by
+ * binary search, one thread per entry.
+ *   lists_caps:  totals[4] (device int64) = the totals of the row bounds (out, in) and of the per-node list sizes (out, in):
+ *                `capacity` must cover all four when the caller has no structural bound of its own (one 32-byte read);
+ *                workspace of mlqem_asap_coarsen_lists_workspace_bytes(N, K, 0, 0);
+ *   lists_count: slot[N], new_in_ptr[K + 1], new_out_ptr[K + 1]; E = stored edges of the input structure (or a bound);
+ *   lists_fill:  new_in_src / new_out_dst / new_out_eid, each holding edge_capacity entries (new_out_ptr[K] <= edge_capacity
+ *                <= capacity), from the SAME workspace; new_out_eid may be NULL (no link pass: the recomputed backward forms
+ *                need no out_eid); *overflow (device, may be NULL) = 1 if `capacity` was too small.
+ * capacity < 2^32 (places inside the per-node records are 32 bits), else MLQEM_ERR_UNSUPPORTED.
+ * kmax <= mlqem_asap_coarsen_lists_max_k() (65 535 clusters per pooled graph), else MLQEM_ERR_UNSUPPORTED.
  * Replaces the same ASAPooling.forward lines (gnn.py:105-107,110-112; PyG semantics: SURVEY appendix B.2 step 7). */
-size_t mlqem_asap_coarsen_lists_workspace_bytes(int64_t N, int64_t K, int64_t capacity);
-int mlqem_asap_coarsen_lists_max_bits(void);
+size_t mlqem_asap_coarsen_lists_workspace_bytes(int64_t N, int64_t K, int64_t E, int64_t capacity);
+int mlqem_asap_coarsen_lists_max_k(void);
 int mlqem_asap_coarsen_lists_caps(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                   const int32_t* new_graph_ptr, const int32_t* perm, int64_t N, int64_t K, int64_t B,
                                   int64_t* totals, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                    const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N,
-                                   int64_t K, int64_t B, int nmax, int kmax, int64_t capacity, int32_t* slot, int32_t* new_in_ptr,
+                                   int64_t K, int64_t B, int64_t E, int kmax, int64_t capacity, int32_t* slot, int32_t* new_in_ptr,
                                    int32_t* new_out_ptr, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
-int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t capacity, const int32_t* new_in_ptr, const int32_t* new_out_ptr,
-                                  int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid, int64_t edge_capacity,
-                                  int32_t* overflow, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t E, int64_t capacity, const int32_t* new_in_ptr,
+                                  const int32_t* new_out_ptr, int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid,
+                                  int64_t edge_capacity, int32_t* overflow, void* workspace, size_t workspace_bytes,
+                                  mlqem_stream_t stream);
 
 /* Coarsened connectivity WITHOUT host read-backs, for batches whose graphs all pool to at most
  * mlqem_asap_coarsen_dense_max_k() clusters (512): the pooled adjacency of every graph is built as a k_g x k_g bit
@@ -559,32 +566,43 @@ int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const
                              void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Family B backward.  Edge-softmax gradients are split into a destination-side pass that writes per-edge buffers in
- * in-CSR order (E entries, then one self-loop entry per node at E + row) and a source-side pass that reads them
- * through out_eid.  No atomics; every gradient row is written once.
+ * Family B backward.  Edge-softmax gradients are split into a destination-side pass and a source-side pass.  No atomics; every
+ * gradient row is written once.  Two forms of the hand-over between the passes:
+ *   stored      (out_eid given): the destination side writes per-edge buffers in in-CSR order (E entries, then one self-loop
+ *               entry per node at E + row) and the source side reads them through out_eid;
+ *   recomputed  (out_eid == NULL, round 4): nothing is kept per edge; the source side recomputes every weight from the
+ *               per-row statistics of the forward (and one more per-row number the destination side files), the way
+ *               attention backward passes are usually written.  It needs no map from out-entries to in-CSR positions --
+ *               ASAPooling's coarsened graphs come without one (linking their 9.7 M entries cost 0.55 ms of an 8.7 ms step) --
+ *               and reads [N]-sized arrays where the stored form reads [E]-sized ones.
  * ---------------------------------------------------------------------------------------------------- */
 
 /* Training forward of mlqem_transformer_attention_f32: same result, plus attn_out (the sum before the skip term) and
  * the softmax statistics stat_m / stat_den [N,H]; drop_p > 0 drops attention weights (TransformerConv(dropout=0.1),
- * gnn.py:83,90) with a mask keyed by (seed, in-CSR position, head); seed_counter (may be NULL): a device-resident step
- * counter mixed into the seed, so that a launch captured in a hipGraph draws a fresh mask per replay (the backward entry
- * point must be given the same pair). */
+ * gnn.py:83,90) with a mask keyed by (seed, in-CSR position, head) -- or, pair_key != 0, by (seed, destination, head, source):
+ * the same draw from either end of an edge, for graphs WITHOUT parallel edges (they would share a draw); the recomputed
+ * backward needs it.  seed_counter (may be NULL): a device-resident step counter mixed into the seed, so that a launch captured
+ * in a hipGraph draws a fresh mask per replay (the backward entry point must be given the same seed, counter and key form). */
 int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
                                           const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p,
-                                          uint64_t seed, const uint64_t* seed_counter, float* out, int64_t ldo,
+                                          uint64_t seed, const uint64_t* seed_counter, int pair_key, float* out, int64_t ldo,
                                           float* attn_out, int64_t lda, float* stat_m, float* stat_den,
                                           mlqem_stream_t stream);
 
-/* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  edge_al / edge_gs: scratch [(E+N)*H]. */
+/* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  Stored form: edge_al / edge_gs: scratch
+ * [(E+N)*H].  Recomputed form (out_eid == NULL): edge_al: scratch [N*H], edge_gs unused (may be NULL); with drop_p > 0 it needs
+ * pair_key != 0 (MLQEM_ERR_BAD_ARG otherwise). */
 int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg,
                                         const float* attn_out, int64_t lda, const float* stat_m, const float* stat_den,
                                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                         const int32_t* out_dst, const int32_t* out_eid, const int32_t* loops, int64_t N,
                                         int64_t E, int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                        float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs, mlqem_stream_t stream);
+                                        int pair_key, float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
+                                        mlqem_stream_t stream);
 
 /* Backward of mlqem_csr_softmax_aggregate_f32: gx (+)= d/dx, g_a[N] = d/d a_dst, g_c[N] = d/d c_src.
- * xnew = the forward output, gnew its gradient; edge_al / edge_gp: scratch [E+N].
+ * xnew = the forward output, gnew its gradient.  Stored form: edge_al / edge_gp: scratch [E+N].  Recomputed form
+ * (out_eid == NULL; C <= 128): edge_al: scratch [4 N], 16-byte aligned; edge_gp unused (may be NULL).
  * tie_count (may be NULL; C <= 128): with xmax = the segment max of x over the same entries (mlqem_csr_segment_max_f32, what
  * ASAPooling computes from the same x: gnn.py:105-107), tie_count[i, c] = the number of entries of row i (sources and i itself) whose
  * value equals xmax[i, c] -- the destination-side walk holds every source row anyway, and mlqem_csr_segment_max_bwd_f32 then
@@ -666,6 +684,30 @@ int mlqem_qasm_batch_parse(const char* const* qasm, int64_t count, const mlqem_b
                            int* depths, int* num_features, int64_t* failed);
 int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_t* edge_src, int64_t* edge_dst, int64_t* batch);
 void mlqem_qasm_batch_free(void* handle);
+
+/* The parsed batch as a COMPACT OP STREAM for device-side expansion (round 4; mlqem_encode_expand below): 16 bytes per op and two
+ * bytes per qubit argument instead of the 112 bytes per node of rows and indices mlqem_qasm_batch_fill writes -- a 1024-circuit
+ * run() of 100-qubit circuits uploads 0.2 GB instead of 1.3 GB and the host writes a seventh of the bytes.
+ *   mlqem_op_rec:  p0 = the first parameter as float32 (what the row holds); q[] = calibration indices (Qubit.index) of up to
+ *                  three qargs (unused for barriers); slot = one-hot column; meta = q_cnt (bits 0-1, 0 for a barrier) | barrier
+ *                  (bit 2) | p_cnt (bits 4-5); winc = index of the op's first qubit argument in `wires` (the next op's winc, or
+ *                  the circuit's wire_ptr end, closes the range).
+ *   wires:         the circuit-local wire (flat qubit number) of EVERY qubit argument, op after op -- what the op -> op edges
+ *                  are built from (utils.py:334-347: one edge per qubit wire from the previous op on it).
+ *   mlqem_x_patch: x[node, col] = value for what the record has no room for (second / third parameters; the calibration entry
+ *                  of a gate on three qubits); unused slots hold node = 0xFFFFFFFF.
+ * stream_sizes: wire_ptr / patch_ptr [count + 1] = prefix sums of the circuits' wire and patch-slot counts, *max_wires the widest
+ * circuit; stream_fill writes the three arrays (node_ptr as from mlqem_qasm_batch_parse).  MLQEM_ERR_UNSUPPORTED beyond 65 535
+ * wires / calibration qubits or 2^32 ops. */
+typedef struct mlqem_op_rec { float p0; uint16_t q[3]; uint8_t slot; uint8_t meta; uint32_t winc; } mlqem_op_rec;
+typedef struct mlqem_x_patch { uint32_t node; uint32_t col; float value; } mlqem_x_patch;
+int mlqem_qasm_batch_stream_sizes(void* handle, int64_t* wire_ptr, int64_t* patch_ptr, int* max_wires);
+int mlqem_qasm_batch_stream_fill(void* handle, int threads, const int64_t* wire_ptr, const int64_t* patch_ptr, mlqem_op_rec* ops,
+                                 uint16_t* wires, mlqem_x_patch* patches);
+/* g1[(G + 2) * Q], g2[(G + 2) * Q * Q] (G = num_gate_types, Q = num_qubits): index into gate_error / gate_length of the
+ * calibration entry of (one-hot slot, qubit) / (slot, qubit, qubit), -1 where there is none -- the lookups of utils.py:263-269 as
+ * tables the device indexes. */
+int mlqem_props_gate_tables(const mlqem_backend_props* props, int32_t* g1, int32_t* g2);
 
 /* Circuit-level features of the MLP regressors -- the per-circuit part of encode_data / encode_data_v2_ecr
  * (docs/tutorials/mlp.py:111-145 count_gates_by_rotation_angle, :148-252; == blackwater/library/learning/mlp.py) from

@@ -620,9 +620,12 @@ class _TransformerConv(Function):
         e = struct.edge_count()
         if not any(ctx.needs_input_grad) and drop_p == 0.0:  # inference: no statistics kept
             return ops.transformer_attention(qkvs, struct.in_ptr, struct.in_src, struct.loops, heads, channels)
+        # a structure without out_eid (ASAPooling's coarsened graphs: no parallel edges) takes the recomputed backward, whose dropout
+        # draws are keyed by (destination, head, source)
+        pair_key = struct.out_eid is None
         out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
-                                                           channels, drop_p, seed)
-        ctx.struct, ctx.cfg = struct, (e, heads, channels, drop_p, seed)
+                                                           channels, drop_p, seed, pair_key=pair_key)
+        ctx.struct, ctx.cfg = struct, (e, heads, channels, drop_p, seed, pair_key)
         ctx.x_rows_of = isinstance(x, ops.RowsOf)
         if ctx.x_rows_of:
             ctx.save_for_backward(x.base, x.rows, w, qkvs, attn, m, den)
@@ -637,8 +640,8 @@ class _TransformerConv(Function):
             x = ops.RowsOf(base, rows)
         else:
             x, w, qkvs, attn, m, den = ctx.saved_tensors
-        e, heads, channels, drop_p, seed = ctx.cfg
-        gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed)
+        e, heads, channels, drop_p, seed, pair_key = ctx.cfg
+        gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key)
         gx = ops.linear(gqkvs, w, transposed=True) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(w)
         gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
@@ -660,6 +663,9 @@ _ASAP_LISTS = os.environ.get("MLQEM_ASAP_LISTS", "1") != "0"
 # MLQEM_ASAP_COMPOSE=0: ASAPooling's query projection lin() as its own [N,D]x[D,D] GEMM (forward and backward) instead of composed
 # into the one-wide score projection that is its only consumer (A/B; the two differ by fp32 rounding order, ~1e-7)
 _ASAP_COMPOSE = os.environ.get("MLQEM_ASAP_COMPOSE", "1") != "0"
+# MLQEM_ASAP_LINK=1: the list coarsening also links every out-entry to its in-CSR twin (out_eid; 0.55 ms for 64 100-qubit
+# circuits) and the backward kernels on the coarsened graph take the stored form; default: no out_eid, recomputed form
+_ASAP_LINK = os.environ.get("MLQEM_ASAP_LINK", "0") == "1"
 # MLQEM_ASAP_TIES=0: the segment max's backward counts its ties in a walk of its own (A/B)
 _ASAP_TIES = os.environ.get("MLQEM_ASAP_TIES", "1") != "0"
 # MLQEM_ASAP_LAZY=0 computes the coarsened connectivity inside ASAPooling's forward even when no later layer reads it
@@ -741,7 +747,7 @@ class _ASAPool(Function):
         new_ptr = _device_ptr(new_ptr_host.astype(np.int32), x.device)
         perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=int(sizes.max()) if len(sizes) else 0)
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
-        use_dense, use_rows, use_lists = _ASAP_DENSE, _ASAP_ROWS, _ASAP_LISTS       # the switches as they stand now: build() may run later
+        use_dense, use_rows, use_lists, link = _ASAP_DENSE, _ASAP_ROWS, _ASAP_LISTS, _ASAP_LINK   # the switches as they stand now: build() may run later
 
         def build():
             dense_ok = use_dense and len(keep) > 0 and int(keep.max()) <= ops.asap_dense_max_k()
@@ -749,11 +755,12 @@ class _ASAPool(Function):
                 # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
                 csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
                 num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
-            elif (use_rows and use_lists and len(keep) > 0 and int(keep.max()) <= 65535
-                  and int(sizes.max()) + 2 * int(keep.max()) + 96 <= ops.asap_lists_max_bits()):
-                # large graphs: persistent waves, a cluster's rows as LDS bitsets read out as sorted lists; no host read with a capacity
+            elif use_rows and use_lists and len(keep) > 0 and int(keep.max()) <= ops.asap_lists_max_k():
+                # large graphs: per-node cluster lists, persistent waves, a cluster's rows as LDS bitsets read out as sorted lists;
+                # no host read when the structure carries a capacity
                 csr, slot, num_edges = ops.asap_coarsen_lists(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm,
-                                                              n, sizes, keep, capacity=getattr(s, "coarse_capacity", None))
+                                                              n, s.edge_count(), keep, capacity=getattr(s, "coarse_capacity", None),
+                                                              link=link)
             elif (use_rows and len(keep) > 0
                   and int(sizes.max()) + 2 * int(keep.max()) + 96 <= ops.asap_rows_max_bits()):
                 # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)

@@ -1223,55 +1223,57 @@ def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_g
     return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], out_eid[:e]), slot, e
 
 
-def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, graph_sizes, keep_sizes,
-                       capacity=None):
-    """The pooled structure arrays of ``asap_coarsen_rows`` from SORTED LISTS (mlqem_asap_coarsen_lists_*, round 4): one
-    walk per cluster by persistent waves, nothing dense in global memory, the twin links by binary search.  ``capacity``: a bound
-    on the row-bound totals of BOTH sides and on the edge total (GraphArena.coarse_capacity); without it the totals are read back
-    (one 16-byte device->host copy) and the edge arrays are sized to the smaller.  Returns (CsrArrays, slot, edge capacity)."""
+def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, num_edges, keep_sizes,
+                       capacity=None, link=True):
+    """The pooled structure arrays of ``asap_coarsen_rows`` from SORTED LISTS (mlqem_asap_coarsen_lists_*, round 4): per-node
+    cluster lists built once, one walk per cluster by persistent waves, nothing dense in global memory, the twin links by binary
+    search.  ``num_edges``: stored edges of the input structure (or a bound).  ``capacity``: a bound on the four list totals and on
+    the edge total (GraphArena.coarse_capacity); without it the totals are read back (one 32-byte device->host copy, then the
+    4-byte edge total).  Returns (CsrArrays, slot, edge capacity)."""
     import numpy as np
 
     keep = np.asarray(keep_sizes, dtype=np.int64)
     b, k = int(keep.shape[0]), int(keep.sum())
     kmax = int(keep.max()) if b else 0
-    nmax = int(np.asarray(graph_sizes).max()) if b else 0
     dev = perm.device
     lib = _lib.load()
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     slot, in_ptr, out_ptr = mk(num_nodes), mk(k + 1), mk(k + 1)
-    if capacity is None:
+    exact = capacity is None
+    if exact:
         if k > 0:
-            need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, 0)
+            need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, 0, 0)
             ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
-            totals = torch.empty(2, dtype=torch.int64, device=dev)
+            totals = torch.empty(4, dtype=torch.int64, device=dev)
             code = lib.mlqem_asap_coarsen_lists_caps(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(new_graph_ptr), _p(perm),
                                                      num_nodes, k, b, _p(totals), _p(ws), need, _stream())
             _lib.check(code, "mlqem_asap_coarsen_lists_caps")
-            t = totals.tolist()
-            cap, e = int(max(t)), int(min(t))
+            cap = int(max(totals.tolist()))
         else:
-            cap = e = 0
+            cap = 0
     else:
-        cap = e = int(capacity) if k > 0 else 0
-    need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, cap)
+        cap = int(capacity) if k > 0 else 0
+    e = cap
+    need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, int(num_edges), cap)
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     code = lib.mlqem_asap_coarsen_lists_count(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(graph_ptr), _p(new_graph_ptr),
-                                              _p(perm), num_nodes, k, b, nmax, kmax, cap, _p(slot), _p(in_ptr), _p(out_ptr), _p(ws), need,
-                                              _stream())
+                                              _p(perm), num_nodes, k, b, int(num_edges), kmax, cap, _p(slot), _p(in_ptr), _p(out_ptr),
+                                              _p(ws), need, _stream())
     _lib.check(code, "mlqem_asap_coarsen_lists_count")
-    if capacity is None and k > 0:
+    if exact and k > 0:
         e = int(out_ptr[k].item())          # the exact edge total (this path reads the device anyway)
-    in_src, out_dst, out_eid = mk(e), mk(e), mk(e)
+    in_src, out_dst = mk(e), mk(e)
+    out_eid = mk(e) if link else None       # link=False: no out_eid (the recomputed backward forms need none)
     loops = torch.full((max(k, 1),), 0, dtype=torch.int32, device=dev)      # a fill kernel, not a memset node (the call may be captured)
     if k > 0:
-        code = lib.mlqem_asap_coarsen_lists_fill(num_nodes, k, cap, _p(in_ptr), _p(out_ptr), _p(in_src), _p(out_dst), _p(out_eid), e,
-                                                 None, _p(ws), need, _stream())
+        code = lib.mlqem_asap_coarsen_lists_fill(num_nodes, k, int(num_edges), cap, _p(in_ptr), _p(out_ptr), _p(in_src), _p(out_dst),
+                                                 _p(out_eid), e, None, _p(ws), need, _stream())
         _lib.check(code, "mlqem_asap_coarsen_lists_fill")
-    return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], out_eid[:e]), slot, e
+    return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], None if out_eid is None else out_eid[:e]), slot, e
 
 
-def asap_lists_max_bits() -> int:
-    return int(_lib.load().mlqem_asap_coarsen_lists_max_bits())
+def asap_lists_max_k() -> int:
+    return int(_lib.load().mlqem_asap_coarsen_lists_max_k())
 
 
 def batch_norm_train(x, gamma, beta, eps):
@@ -1323,7 +1325,7 @@ def asap_dense_max_k() -> int:
 
 
 # ------------------------------------------------------------------------------------------ Family B backward
-def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0):
+def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False):
     n, hc = qkvs.shape[0], heads * channels
     if qkvs.shape[1] != 4 * hc:
         raise ValueError("qkvs must be [N, 4*H*C]")
@@ -1335,23 +1337,29 @@ def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, c
     den = torch.empty_like(m)
     code = _lib.load().mlqem_transformer_attention_train_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
-        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, _p(out), _mat(out, "out"), _p(attn),
-        _mat(attn, "attn"), _p(m), _p(den), _stream())
+        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(out), _mat(out, "out"),
+        _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
     _lib.check(code, "mlqem_transformer_attention_train_f32")
     return out, attn, m, den
 
 
-def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, drop_p=0.0, seed=0):
+def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False):
+    """Gradient of [query | key | value | skip].  A structure without ``out_eid`` (ASAPooling's coarsened graphs) takes the
+    recomputed form: no per-edge buffers, the source side recomputes its weights from m / den / g . attn_out per (row, head)."""
     n, hc = qkvs.shape[0], heads * channels
     g = rowmajor(g)
     dev = qkvs.device
     gqkvs = padded_empty(n, 4 * hc, dev)
-    scratch = torch.empty((2, (num_edges + n) * heads + 1), dtype=torch.float32, device=dev)
+    if s.out_eid is None:
+        al, gs = torch.empty(max(n, 1) * heads, dtype=torch.float32, device=dev), None
+    else:
+        scratch = torch.empty((2, (num_edges + n) * heads + 1), dtype=torch.float32, device=dev)
+        al, gs = scratch[0], scratch[1]
     code = _lib.load().mlqem_transformer_attention_bwd_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr),
         _p(s.in_src), _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(s.loops), n, num_edges, heads, channels,
-        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, _p(gqkvs),
-        _mat(gqkvs, "gqkvs"), _p(scratch[0]), _p(scratch[1]),
+        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(gqkvs),
+        _mat(gqkvs, "gqkvs"), _p(al), _p(gs),
         _stream())
     _lib.check(code, "mlqem_transformer_attention_bwd_f32")
     return gqkvs
@@ -1366,11 +1374,15 @@ def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negativ
     ties = padded_empty(n, c, dev) if (xmax is not None and c <= 128) else None
     g_a = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
     g_c = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
-    scratch = torch.empty((2, num_edges + n + 1), dtype=torch.float32, device=dev)
+    if s.out_eid is None:          # the recomputed form: one 16-byte record per row instead of two values per edge
+        al, gp = torch.empty(4 * max(n, 1), dtype=torch.float32, device=dev), None
+    else:
+        scratch = torch.empty((2, num_edges + n + 1), dtype=torch.float32, device=dev)
+        al, gp = scratch[0], scratch[1]
     code = _lib.load().mlqem_csr_softmax_aggregate_bwd_f32(
         _p(x), _mat(x, "x"), _p(xnew), _mat(xnew, "xnew"), _p(gnew), _mat(gnew, "gnew"), _p(s.in_ptr), _p(s.in_src),
         _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(a_dst), _p(c_src), float(negative_slope), n, num_edges, c, 0,
-        _p(gx), _mat(gx, "gx"), _p(g_a), _p(g_c), _p(scratch[0]), _p(scratch[1]),
+        _p(gx), _mat(gx, "gx"), _p(g_a), _p(g_c), _p(al), _p(gp),
         _p(xmax) if ties is not None else None, _mat(xmax, "xmax") if ties is not None else 0,
         _p(ties), _mat(ties, "ties") if ties is not None else 0, _stream())
     _lib.check(code, "mlqem_csr_softmax_aggregate_bwd_f32")

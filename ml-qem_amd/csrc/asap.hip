@@ -456,28 +456,33 @@ __global__ __launch_bounds__(kBlock) void coarsen_rows_fill_kernel(const RowsArg
 
 // ------------------------------------------------------ coarsened connectivity, large graphs: SORTED LISTS, one walk (round 4)
 // The bit-matrix form above writes two dense [K][k_g / 32] matrices (0.93 GB for 64 100-qubit circuits, nearly all zeros) and
-// reads them back (1.36 GB) to list 9.7 M edges, and its waves spend their time on dense scans and on chains of dependent
-// gathers.  This form keeps the LDS bitsets for what they are good at -- collapsing duplicates and handing a row back in
-// ascending order -- and touches nothing dense in global memory:
-//   caps   a structural bound on every row's length, from two-hop degree sums (h_out / h_in per node, then per kept centre),
-//          clamped to k_g - 1; exclusive scans give every row its place in two scratch lists (out-rows, in-rows);
-//   walk   a PERSISTENT wave per cluster p: X = N+[N-[c_p]] as a bitset AND a list (a node enters the list when its bit was
-//          clear), so the third hop takes its nodes 64 at a time from the list instead of scanning n_g bits, and X is cleared
-//          through the list; Y = slot(N+[X]) \ {p}; the same with N-[N-[c_p]] for the transposed row Z; both bitsets are read
-//          out once (a lane owns a run of words: ONE wave scan of packed counts per cluster), written as sorted lists to the
-//          scratch, and cleared on the way; degrees -> device scans -> both CSR pointer arrays;
-//   emit   a 16-lane group per row copies its lists to their final place and links every out-entry p -> q to its twin in q's
-//          in-row by a binary search of p in q's sorted scratch list (out_eid).
+// reads them back (1.36 GB) to list 9.7 M edges, and every cluster's wave walks three hops of dependent gathers (in_src ->
+// out_ptr -> out_dst -> slot: 112 M scattered cache accesses per 64 circuits, 72 % of its wave cycles parked on them).
+// This form splits the three hops into per-NODE lists that are built once, so that a cluster only ORs a few contiguous lists
+// into its LDS bitset -- and touches nothing dense in global memory:
+//   C(v)  = { slot[w] >= 0 : w in N+[v] }                    the clusters node v belongs to            (<= 1 + outdeg v entries)
+//   R(u)  = concat of C(v), v in N+[u];  R'(u) likewise over N-[u]  (closed neighbourhoods; duplicates stay: a bitset removes them)
+//   row p       = ( union of R(u),  u in N-[c_p] ) \ {p};   row p of the transpose = ( union of R'(u), u in N-[c_p] ) \ {p}
+// A hub's list (a barrier: ~300 entries) is formed once and read, coalesced, by each of the ~150 clusters that contain the hub,
+// instead of being re-walked by every one of them.  Places: C(v) at out_ptr[v] + v; R / R' by exclusive scans of the structural
+// sizes h_out / h_in; a row's sorted list in a scratch by scans of per-row bounds (sums of h over N-[c_p], clamped to k_g - 1).
+//   walk  a PERSISTENT wave per cluster: two LDS bitsets (k_g bits each), read out in ascending order by lanes that own runs of
+//         words (ONE wave scan of packed counts per cluster) and cleared on the way; degrees -> device scans -> CSR pointers;
+//   copy  a 16-lane group per row moves its lists to their final place and notes every out-entry's row;
+//   link  a thread per out-entry p -> q finds its twin in q's in-row by binary search of p in q's sorted list (out_eid).
 // Same arrays as the bit-matrix form and the two-hop path (tests/test_gpu_family_b.py).
 struct ListsArgs {
   const int32_t* in_ptr; const int32_t* in_src; const int32_t* out_ptr; const int32_t* out_dst;
   const int32_t* gptr; const int32_t* new_gptr; const int32_t* perm; const int32_t* slot;
   int B; int64_t N, K;
-  int Wn, Wk, lcap;              // LDS words of the node / cluster bitsets (batch maxima); entries of the node list
-  const int64_t* off_o; const int64_t* off_i;   // [K + 1]: places of the rows in the scratch lists
+  int Wk;                        // LDS words of a cluster bitset (batch maximum)
+  const uint32_t* rinfo;         // [N][4]: place and length of R(u), place and length of R'(u)
+  const int32_t* r_o; const int32_t* r_i; int64_t r_cap;
+  const int64_t* off_o; const int64_t* off_i;        // [K + 1]: places of the rows in the scratch lists
   int32_t* tmp_o; int32_t* tmp_i; int64_t tmp_cap;
   int32_t* outdeg; int32_t* indeg;   // [K + 1]
-  int32_t* overflow;             // != 0: a row left the scratch (the caller's capacity was no bound)
+  int32_t* overflow;             // != 0: a list left its storage (the caller's capacity was no bound)
+  int skip;                      // measurement switch (MLQEM_LISTS_SKIP; 0 in production): parts of the walk left out
 };
 
 constexpr int kReachClamp = 1 << 28;   // two-hop degree sums saturate here (a row bound is clamped to k_g - 1 anyway)
@@ -507,11 +512,11 @@ __device__ __forceinline__ int64_t sum_closed(const int32_t* __restrict__ ptr, c
   return acc;
 }
 
-// h_out[u] = sum over v in N+[u] of (1 + outdeg v): how many (v, w) steps leave u's closed out-neighbourhood; h_in likewise
-// over N-[u] -- the third hop is an out-hop on both sides.
+// h_out[u] = sum over v in N+[u] of (1 + outdeg v) >= |R(u)|; h_in[u] the same over N-[u] >= |R'(u)| (the last hop is an out-hop on
+// both sides); entry N is 0 (the scans' last element is then the total)
 __global__ __launch_bounds__(kBlock) void coarsen_reach_kernel(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src,
                                                                const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
-                                                               int64_t N, int32_t* __restrict__ h_out, int32_t* __restrict__ h_in) {
+                                                               int64_t N, int64_t* __restrict__ h_out, int64_t* __restrict__ h_in) {
   const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool has = u < N;
@@ -519,24 +524,26 @@ __global__ __launch_bounds__(kBlock) void coarsen_reach_kernel(const int32_t* __
   const int64_t ho = sum_closed(out_ptr, out_dst, has, (int)u, lane, od1);
   const int64_t hi = sum_closed(in_ptr, in_src, has, (int)u, lane, od1);
   if (has) {
-    h_out[u] = (int32_t)min(ho, (int64_t)kReachClamp);
-    h_in[u] = (int32_t)min(hi, (int64_t)kReachClamp);
+    h_out[u] = min(ho, (int64_t)kReachClamp);
+    h_in[u] = min(hi, (int64_t)kReachClamp);
+  } else if (u == N) {
+    h_out[N] = 0;
+    h_in[N] = 0;
   }
 }
 
-// cap_o[p] >= |row p|, cap_i[p] >= |row p of the transpose|: sums of h over N-[c_p], clamped to k_g - 1; entry K is 0 (the
-// scans' last element is then the total)
+// cap_o[p] >= |row p|, cap_i[p] >= |row p of the transpose|: sums of h over N-[c_p], clamped to k_g - 1; entry K is 0
 __global__ __launch_bounds__(kBlock) void coarsen_row_caps_kernel(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src,
                                                                   const int32_t* __restrict__ perm, const int32_t* __restrict__ new_gptr,
-                                                                  int B, int64_t K, const int32_t* __restrict__ h_out,
-                                                                  const int32_t* __restrict__ h_in, int64_t* __restrict__ cap_o,
+                                                                  int B, int64_t K, const int64_t* __restrict__ h_out,
+                                                                  const int64_t* __restrict__ h_in, int64_t* __restrict__ cap_o,
                                                                   int64_t* __restrict__ cap_i) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool has = p < K;
   const int c = has ? perm[p] : 0;
-  const int64_t so = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return (int64_t)h_out[u]; });
-  const int64_t si = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return (int64_t)h_in[u]; });
+  const int64_t so = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return h_out[u]; });
+  const int64_t si = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return h_in[u]; });
   if (has) {
     const int g = graph_at(new_gptr, B, p);
     const int64_t most = (int64_t)(new_gptr[g + 1] - new_gptr[g]) - 1;
@@ -548,90 +555,167 @@ __global__ __launch_bounds__(kBlock) void coarsen_row_caps_kernel(const int32_t*
   }
 }
 
-// One side of a cluster's reach.  X / L: bitset and list of the closed (ptr2, idx2)-neighbourhood of {c} + N-[c]; S: the clusters
-// (bits local to the graph, without `self`) of the closed out-neighbourhood of X.  Leaves X zero and *cnt zero.
-__device__ __forceinline__ void lists_side(const ListsArgs& a, const int32_t* __restrict__ ptr2, const int32_t* __restrict__ idx2, int c,
-                                           int ib, int ie, int n0, int k0, int Wn, int self, uint32_t* X, int* L, int* cnt, uint32_t* S,
-                                           int lane) {
-  const int lcap = a.lcap;
-  for (int i0 = ib - 1; i0 < ie; i0 += 64) {         // index ib - 1 stands for c itself
-    const int i = i0 + lane;
-    const bool has = i < ie;
-    const int u = has ? (i < ib ? c : a.in_src[i]) : 0;
-    visit_closed(ptr2, idx2, has, u, lane, [&](int v) {
-      const uint32_t bit = 1u << ((v - n0) & 31);
-      const uint32_t old = atomicOr(&X[(v - n0) >> 5], bit);
-      if (!(old & bit)) {
-        const int k = atomicAdd(cnt, 1);
-        if (k < lcap) L[k] = v;
-      }
-    });
+// C(v): the kept centres among N+[v] (v itself included), as cluster ids, at clist[out_ptr[v] + v ...]; ccnt[v] of them
+__global__ __launch_bounds__(kBlock) void coarsen_clists_kernel(const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
+                                                                const int32_t* __restrict__ slot, int64_t N, int32_t* __restrict__ clist,
+                                                                int32_t* __restrict__ ccnt) {
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool has = v < N;
+  int eb = 0, ee = 0, n = 0;
+  int64_t base = 0;
+  if (has) {
+    eb = out_ptr[v]; ee = out_ptr[v + 1];
+    base = (int64_t)eb + v;
+    const int q = slot[v];
+    if (q >= 0) clist[base + n++] = q;
   }
-  wave_lds_sync();
-  const int n = *cnt;
-  auto reach = [&](int w) {
-    const int q = a.slot[w];
-    if (q >= 0 && q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31));
-  };
-  if (n <= lcap) {
-    for (int i0 = 0; i0 < n; i0 += 64) {
+  const bool heavy = has && ee - eb > kRowsLight;
+  if (has && !heavy)
+    for (int e = eb; e < ee; ++e) {
+      const int q = slot[out_dst[e]];
+      if (q >= 0) clist[base + n++] = q;
+    }
+  unsigned long long todo = __ballot(heavy);
+  while (todo) {                                       // a hub's out-list: the whole wave, kept entries compacted by ballot
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int b = __shfl(eb, owner), e = __shfl(ee, owner);
+    const int64_t ob = __shfl(base, owner);
+    int on = __shfl(n, owner);
+    for (int i0 = b; i0 < e; i0 += 64) {
       const int i = i0 + lane;
-      const bool has = i < n;
-      const int v = has ? L[i] : 0;
-      visit_closed(a.out_ptr, a.out_dst, has, v, lane, reach);
+      const int q = i < e ? slot[out_dst[i]] : -1;
+      const unsigned long long keep = __ballot(q >= 0);
+      if (q >= 0) clist[ob + on + __popcll(keep & ((1ull << lane) - 1ull))] = q;
+      on += __popcll(keep);
     }
-    for (int i = lane; i < n; i += 64) X[(L[i] - n0) >> 5] = 0u;          // clear X through the list
-  } else {                                                                  // more nodes than the list holds: scan the bitset
-    for (int w0 = 0; w0 < Wn; w0 += 64) {
-      const int wi = w0 + lane;
-      uint32_t bits = wi < Wn ? X[wi] : 0u;
-      while (__ballot(bits != 0u)) {
-        const bool has = bits != 0u;
-        int v = 0;
-        if (has) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; v = n0 + wi * 32 + b; }
-        visit_closed(a.out_ptr, a.out_dst, has, v, lane, reach);
-      }
-    }
-    for (int i = lane; i < Wn; i += 64) X[i] = 0u;
+    if (lane == owner) n = on;
   }
-  if (lane == 0) *cnt = 0;
-  wave_lds_sync();
+  if (has) ccnt[v] = n;
+}
+
+// R(u) (SIDE_IN = false: over N+[u]) or R'(u) (true: over N-[u]): the C lists of the closed neighbourhood, one after the other
+template <bool SIDE_IN>
+__global__ __launch_bounds__(kBlock) void coarsen_rlists_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                                const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ clist,
+                                                                const int32_t* __restrict__ ccnt, int64_t N, const int64_t* __restrict__ roff,
+                                                                int32_t* __restrict__ rlist, int64_t r_cap, uint32_t* __restrict__ rinfo,
+                                                                int32_t* __restrict__ overflow) {
+  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool has = u < N;
+  int eb = 0, ee = 0, n = 0;
+  int64_t base = 0;
+  bool fits = true;
+  auto append = [&](int v, int64_t at) {              // C(v) to rlist[at ...]; returns its length
+    const int m = ccnt[v];
+    const int32_t* __restrict__ src = clist + ((int64_t)out_ptr[v] + v);
+    for (int j = 0; j < m; ++j) rlist[at + j] = src[j];
+    return m;
+  };
+  if (has) {
+    eb = ptr[u]; ee = ptr[u + 1];
+    base = roff[u];
+    fits = roff[u + 1] <= r_cap;                       // the bound h(u) of this list lies inside the storage
+    if (fits) n = append((int)u, base);
+  }
+  const bool heavy = has && fits && ee - eb > kRowsLight;
+  if (has && fits && !heavy)
+    for (int e = eb; e < ee; ++e) n += append(idx[e], base + n);
+  unsigned long long todo = __ballot(heavy);
+  while (todo) {                                       // a hub: a lane per neighbour, places by a wave scan of the lists' lengths
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int b = __shfl(eb, owner), e = __shfl(ee, owner);
+    const int64_t ob = __shfl(base, owner);
+    int on = __shfl(n, owner);
+    for (int i0 = b; i0 < e; i0 += 64) {
+      const int i = i0 + lane;
+      const int v = i < e ? idx[i] : -1;
+      const int m = v >= 0 ? ccnt[v] : 0;
+      const int ex = wave_excl_scan(m, lane);
+      if (v >= 0) append(v, ob + on + ex);
+      on += __shfl(ex + m, 63);
+    }
+    if (lane == owner) n = on;
+  }
+  if (has) {
+    rinfo[u * 4 + (SIDE_IN ? 2 : 0)] = (uint32_t)base;          // r_cap < 2^32 (checked by the host): places fit 32 bits
+    rinfo[u * 4 + (SIDE_IN ? 3 : 1)] = (uint32_t)n;
+    if (!fits) atomicOr(overflow, 1);
+  }
+}
+
+// Y |= the clusters of the lists R(u), Z |= those of R'(u), u in {c} + N-[c], without `self` (bits local to the graph).
+// A lane brings one u and its record {place and length of R(u), of R'(u)}; lists of up to kRowsLight entries are fetched WHOLE
+// before the first bit is set -- a loop that loads an entry, sets its bit and only then loads the next pays a memory round trip per
+// entry, and a persistent wave has nothing else to hide it behind (this was 17 us per cluster) -- longer ones (a hub's) are read
+// by the whole wave, coalesced.
+struct RInfo { uint32_t off_o, cnt_o, off_i, cnt_i; };
+
+__device__ __forceinline__ void lists_or(const int32_t* __restrict__ rlist, int64_t rb, int rn, bool light, int k0, int self, uint32_t* S,
+                                         int lane) {
+  int qs[kRowsLight];
+#pragma unroll
+  for (int j = 0; j < kRowsLight; ++j) qs[j] = (light && j < rn) ? rlist[rb + j] : -1;
+#pragma unroll
+  for (int j = 0; j < kRowsLight; ++j)
+    if (qs[j] >= 0 && qs[j] != self) atomicOr(&S[(qs[j] - k0) >> 5], 1u << ((qs[j] - k0) & 31));
+  unsigned long long todo = __ballot(!light && rn > 0);
+  while (todo) {
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int64_t b = __shfl(rb, owner);
+    const int m = __shfl(rn, owner);
+    for (int j = lane; j < m; j += 64) {
+      const int q = rlist[b + j];
+      if (q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31));
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void coarsen_lists_kernel(const ListsArgs a) {
-  extern __shared__ uint32_t s_bits[];              // per wave: X [Wn], Y [Wk], Z [Wk], L [lcap], count
+  extern __shared__ uint32_t s_bits[];              // per wave: Y [Wk], Z [Wk]
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int per = a.Wn + 2 * a.Wk + a.lcap + 1;
-  uint32_t* X = s_bits + (size_t)wid * per;
-  uint32_t* Y = X + a.Wn;
+  uint32_t* Y = s_bits + (size_t)wid * 2 * a.Wk;
   uint32_t* Z = Y + a.Wk;
-  int* L = reinterpret_cast<int*>(Z + a.Wk);
-  int* cnt = L + a.lcap;
-  for (int i = lane; i < per; i += 64) X[i] = 0u;    // once per wave: every cluster leaves its region as it found it
+  for (int i = lane; i < 2 * a.Wk; i += 64) Y[i] = 0u;     // once per wave: every cluster leaves its region as it found it
   wave_lds_sync();
+  const RInfo* __restrict__ rinfo = reinterpret_cast<const RInfo*>(a.rinfo);
   const int64_t stride = (int64_t)gridDim.x * 4;
   for (int64_t p = (int64_t)blockIdx.x * 4 + wid; p < a.K; p += stride) {     // wave-uniform; every wave reaches the end
     const int c = a.perm[p];
     const int g = graph_at(a.new_gptr, a.B, p);
-    const int n0 = a.gptr[g], k0 = a.new_gptr[g];
-    const int Wn = (a.gptr[g + 1] - n0 + 31) >> 5, Wk = (a.new_gptr[g + 1] - k0 + 31) >> 5;
+    const int k0 = a.new_gptr[g];
+    const int Wk = (a.new_gptr[g + 1] - k0 + 31) >> 5;
     const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
-    lists_side(a, a.out_ptr, a.out_dst, c, ib, ie, n0, k0, Wn, (int)p, X, L, cnt, Y, lane);     // X = N+[N-[c]] -> row p
-    lists_side(a, a.in_ptr, a.in_src, c, ib, ie, n0, k0, Wn, (int)p, X, L, cnt, Z, lane);       // X = N-[N-[c]] -> row p of the transpose
-    // read both bitsets out in ascending order: lane l owns words [l cw, (l + 1) cw); one scan of the packed counts (a row
-    // has fewer than 65 536 entries: Wk <= 2048 words)
-    const int cw = (Wk + 63) >> 6;
-    const int w_lo = lane * cw, w_hi = min(Wk, w_lo + cw);
-    int ny = 0, nz = 0;
-    for (int w = w_lo; w < w_hi; ++w) { ny += __popc(Y[w]); nz += __popc(Z[w]); }
-    const int packed = ny | (nz << 16);
-    const int ex = wave_excl_scan(packed, lane);
-    const int tot = __shfl(ex + packed, 63);
-    const int deg_o = tot & 0xFFFF, deg_i = (int)((unsigned)tot >> 16);
     const int64_t bo = a.off_o[p], bi = a.off_i[p];
-    int64_t po = bo + (ex & 0xFFFF), pi = bi + (int)((unsigned)ex >> 16);
-    const bool fits = bo + deg_o <= a.tmp_cap && bi + deg_i <= a.tmp_cap;      // wave-uniform
+    for (int i0 = ib - 1; i0 < ie; i0 += 64) {        // index ib - 1 stands for c itself
+      const int i = i0 + lane;
+      const bool has = i < ie;
+      const int u = has ? (i < ib ? c : a.in_src[i]) : 0;
+      RInfo r{0u, 0u, 0u, 0u};
+      if (a.skip & 1) continue;
+      if (has) r = rinfo[u];
+      if (a.skip & 2) { if (r.cnt_o == 0xFFFFFFFFu) Y[0] = 1u; continue; }
+      lists_or(a.r_o, (int64_t)r.off_o, (int)r.cnt_o, r.cnt_o <= (uint32_t)kRowsLight, k0, (int)p, Y, lane);     // row p
+      lists_or(a.r_i, (int64_t)r.off_i, (int)r.cnt_i, r.cnt_i <= (uint32_t)kRowsLight, k0, (int)p, Z, lane);     // row p of the transpose
+    }
+    wave_lds_sync();
+    // read both bitsets out in ascending order: lane l owns words [l cw, (l + 1) cw); one scan of the packed counts (a row
+    // has fewer than 65 536 entries: k_g <= 65 535)
+    const int cw = (Wk + 63) >> 6;
+    const int w_lo = min(Wk, lane * cw), w_hi = min(Wk, w_lo + cw);
+    unsigned ny = 0, nz = 0;
+    for (int w = w_lo; w < w_hi; ++w) { ny += __popc(Y[w]); nz += __popc(Z[w]); }
+    const int packed = (int)(ny | (nz << 16));
+    const int ex = wave_excl_scan(packed, lane);
+    const unsigned tot = (unsigned)__shfl(ex + packed, 63);
+    const int deg_o = (int)(tot & 0xFFFFu), deg_i = (int)(tot >> 16);
+    int64_t po = bo + (int)((unsigned)ex & 0xFFFFu), pi = bi + (int)((unsigned)ex >> 16);
+    const bool fits = bo + deg_o <= a.tmp_cap && bi + deg_i <= a.tmp_cap && !(a.skip & 4);      // wave-uniform
     for (int w = w_lo; w < w_hi; ++w) {
       uint32_t yb = Y[w], zb = Z[w];
       Y[w] = 0u; Z[w] = 0u;
@@ -648,10 +732,11 @@ __global__ __launch_bounds__(kBlock) void coarsen_lists_kernel(const ListsArgs a
   }
 }
 
-__global__ __launch_bounds__(kBlock) void coarsen_lists_emit_kernel(const ListsArgs a, const int32_t* __restrict__ in_ptr_new,
+// a row's lists to their final place; out_row[e] = the row of out-entry e (the link pass is a thread per entry)
+__global__ __launch_bounds__(kBlock) void coarsen_lists_copy_kernel(const ListsArgs a, const int32_t* __restrict__ in_ptr_new,
                                                                     const int32_t* __restrict__ out_ptr_new,
                                                                     int32_t* __restrict__ in_src_new, int32_t* __restrict__ out_dst_new,
-                                                                    int32_t* __restrict__ out_eid_new, int64_t edge_cap) {
+                                                                    int32_t* __restrict__ out_row, int64_t edge_cap) {
   const int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x & (kGroup - 1);
   if (r >= a.K) return;
@@ -660,19 +745,28 @@ __global__ __launch_bounds__(kBlock) void coarsen_lists_emit_kernel(const ListsA
   const int64_t ip = in_ptr_new[r], op = out_ptr_new[r];
   for (int i = l; i < di; i += kGroup)
     if (ip + i < edge_cap) in_src_new[ip + i] = a.tmp_i[bi + i];
-  for (int i = l; i < dout; i += kGroup) {
-    const int q = a.tmp_o[bo + i];
-    // the twin of (r -> q) in q's in-row: the rank of r in q's sorted list of sources (r is in it: the two walks list the same edges)
-    const int32_t* __restrict__ lst = a.tmp_i + a.off_i[q];
-    int lo = 0, hi = a.indeg[q];
+  for (int i = l; i < dout; i += kGroup)
+    if (op + i < edge_cap) {
+      out_dst_new[op + i] = a.tmp_o[bo + i];
+      if (out_row) out_row[op + i] = (int32_t)r;
+    }
+}
+
+// the twin of out-entry e = (r -> q) in q's in-row: the rank of r in q's sorted list of sources (r is in it: the two walks list
+// the same edges)
+__global__ __launch_bounds__(kBlock) void coarsen_lists_link_kernel(const int32_t* __restrict__ in_ptr_new, const int32_t* __restrict__ in_src_new,
+                                                                    const int32_t* __restrict__ out_dst_new, const int32_t* __restrict__ out_row,
+                                                                    const int32_t* __restrict__ edge_total, int64_t edge_cap,
+                                                                    int32_t* __restrict__ out_eid_new) {
+  const int64_t total = min(edge_cap, (int64_t)*edge_total);          // the grid is sized for the device, not for the capacity
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    const int q = out_dst_new[e], r = out_row[e];
+    int lo = in_ptr_new[q], hi = in_ptr_new[q + 1];
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (lst[mid] < (int32_t)r) lo = mid + 1; else hi = mid;
+      if (in_src_new[mid] < r) lo = mid + 1; else hi = mid;
     }
-    if (op + i < edge_cap) {
-      out_dst_new[op + i] = q;
-      out_eid_new[op + i] = in_ptr_new[q] + lo;
-    }
+    out_eid_new[e] = lo;
   }
 }
 
@@ -960,82 +1054,107 @@ extern "C" int mlqem_asap_coarsen_rows_fill(const int32_t* new_graph_ptr, int64_
   return launch_status();
 }
 
-// ---- list form (round 4): workspace = h_out, h_in [N] | cap_o, cap_i, off_o, off_i [K + 1] int64 | outdeg, indeg [K + 1] | flag |
-//      scan temp | tmp_o, tmp_i [capacity]
+// ---- list form (round 4).  Workspace: h_out, h_in, roff_o, roff_i [N + 1] int64 | ccnt, rcnt_o, rcnt_i [N] | clist [E + N] |
+//      cap_o, cap_i, off_o, off_i [K + 1] int64 | outdeg, indeg [K + 1] | flag | scan temp | r_o, r_i, tmp_o, tmp_i [capacity]
+//      (rcnt_o + rcnt_i + ... : the per-node records rinfo [N][4] take the place of four count arrays)
+//      (r_o is reused as out_row by the fill pass)
 namespace {
 struct ListsLayout {
-  size_t h, caps, degs, flag, scan, lists, total;
+  size_t h, ncnt, clist, caps, degs, flag, scan, lists, total;
 };
-size_t lists_scan_bytes(int64_t K) {
-  size_t t64 = 0;
-  (void)rocprim::exclusive_scan(nullptr, t64, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(K + 1), rocprim::plus<int64_t>(),
+size_t lists_scan_bytes(int64_t n) {
+  size_t t64 = 0, t32 = 0;
+  (void)rocprim::exclusive_scan(nullptr, t64, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(),
                                 (hipStream_t)0);
-  return std::max((t64 + 255) / 256 * 256, dense_scan_bytes(K));
+  (void)rocprim::exclusive_scan(nullptr, t32, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(n + 1), rocprim::plus<int32_t>(),
+                                (hipStream_t)0);
+  return (std::max(t64, t32) + 255) / 256 * 256;
 }
-ListsLayout lists_layout(int64_t N, int64_t K, int64_t capacity) {
+ListsLayout lists_layout(int64_t N, int64_t K, int64_t E, int64_t capacity) {
   auto up = [](size_t b) { return (b + 255) / 256 * 256; };
   ListsLayout l;
-  l.h = up((size_t)std::max<int64_t>(N, 1) * sizeof(int32_t));
+  l.h = up((size_t)(N + 1) * sizeof(int64_t));
+  l.ncnt = up((size_t)std::max<int64_t>(N, 1) * sizeof(int32_t));
+  l.clist = up((size_t)std::max<int64_t>(E + N, 1) * sizeof(int32_t));
   l.caps = up((size_t)(K + 1) * sizeof(int64_t));
   l.degs = up((size_t)(K + 1) * sizeof(int32_t));
   l.flag = 256;
-  l.scan = lists_scan_bytes(K);
+  l.scan = lists_scan_bytes(std::max(N, K));
   l.lists = up((size_t)std::max<int64_t>(capacity, 1) * sizeof(int32_t));
-  l.total = 2 * l.h + 4 * l.caps + 2 * l.degs + l.flag + l.scan + 2 * l.lists;
+  l.total = 4 * l.h + 5 * l.ncnt + l.clist + 4 * l.caps + 2 * l.degs + l.flag + l.scan + 4 * l.lists;
   return l;
 }
-constexpr int kListsLcap = 512;                      // nodes the second hop may hold as a list (more: the bitset is scanned)
-constexpr int kListsMaxLds = 160 * 1024;             // one workgroup may take a CU's whole LDS
-int lists_words_per_wave(int nmax, int kmax) { return (nmax + 31) / 32 + 2 * ((kmax + 31) / 32) + kListsLcap + 1; }
 
 struct ListsPointers {
-  int32_t* h_out; int32_t* h_in; int64_t* cap_o; int64_t* cap_i; int64_t* off_o; int64_t* off_i; int32_t* outdeg; int32_t* indeg;
-  int32_t* flag; void* scan; int32_t* tmp_o; int32_t* tmp_i;
+  int64_t* h_out; int64_t* h_in; int64_t* roff_o; int64_t* roff_i; int32_t* ccnt; uint32_t* rinfo; int32_t* clist;
+  int64_t* cap_o; int64_t* cap_i; int64_t* off_o; int64_t* off_i; int32_t* outdeg; int32_t* indeg; int32_t* flag; void* scan;
+  int32_t* r_o; int32_t* r_i; int32_t* tmp_o; int32_t* tmp_i;
 };
 ListsPointers lists_pointers(void* workspace, const ListsLayout& l) {
   char* w = static_cast<char*>(workspace);
+  auto take = [&](size_t bytes) { char* at = w; w += bytes; return at; };
   ListsPointers q;
-  q.h_out = reinterpret_cast<int32_t*>(w); w += l.h;
-  q.h_in = reinterpret_cast<int32_t*>(w); w += l.h;
-  q.cap_o = reinterpret_cast<int64_t*>(w); w += l.caps;
-  q.cap_i = reinterpret_cast<int64_t*>(w); w += l.caps;
-  q.off_o = reinterpret_cast<int64_t*>(w); w += l.caps;
-  q.off_i = reinterpret_cast<int64_t*>(w); w += l.caps;
-  q.outdeg = reinterpret_cast<int32_t*>(w); w += l.degs;
-  q.indeg = reinterpret_cast<int32_t*>(w); w += l.degs;
-  q.flag = reinterpret_cast<int32_t*>(w); w += l.flag;
-  q.scan = w; w += l.scan;
-  q.tmp_o = reinterpret_cast<int32_t*>(w); w += l.lists;
-  q.tmp_i = reinterpret_cast<int32_t*>(w);
+  q.h_out = reinterpret_cast<int64_t*>(take(l.h));
+  q.h_in = reinterpret_cast<int64_t*>(take(l.h));
+  q.roff_o = reinterpret_cast<int64_t*>(take(l.h));
+  q.roff_i = reinterpret_cast<int64_t*>(take(l.h));
+  q.ccnt = reinterpret_cast<int32_t*>(take(l.ncnt));
+  q.rinfo = reinterpret_cast<uint32_t*>(take(4 * l.ncnt));
+  q.clist = reinterpret_cast<int32_t*>(take(l.clist));
+  q.cap_o = reinterpret_cast<int64_t*>(take(l.caps));
+  q.cap_i = reinterpret_cast<int64_t*>(take(l.caps));
+  q.off_o = reinterpret_cast<int64_t*>(take(l.caps));
+  q.off_i = reinterpret_cast<int64_t*>(take(l.caps));
+  q.outdeg = reinterpret_cast<int32_t*>(take(l.degs));
+  q.indeg = reinterpret_cast<int32_t*>(take(l.degs));
+  q.flag = reinterpret_cast<int32_t*>(take(l.flag));
+  q.scan = take(l.scan);
+  q.r_o = reinterpret_cast<int32_t*>(take(l.lists));
+  q.r_i = reinterpret_cast<int32_t*>(take(l.lists));
+  q.tmp_o = reinterpret_cast<int32_t*>(take(l.lists));
+  q.tmp_i = reinterpret_cast<int32_t*>(take(l.lists));
   return q;
 }
 
-// h, row bounds and their scans: off_o / off_i [K + 1] (entry K = the totals)
+// structural sizes, row bounds and their scans: roff_o / roff_i [N + 1], off_o / off_i [K + 1] (the last entries = the totals)
 int lists_caps(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* new_graph_ptr,
                const int32_t* perm, int64_t N, int64_t K, int64_t B, const ListsPointers& q, const ListsLayout& l, hipStream_t stream) {
-  hipLaunchKernelGGL(coarsen_reach_kernel, dim3((unsigned)ceil_div(N, (int64_t)kBlock)), dim3(kBlock), 0, stream, in_ptr, in_src, out_ptr,
+  hipLaunchKernelGGL(coarsen_reach_kernel, dim3((unsigned)ceil_div(N + 1, (int64_t)kBlock)), dim3(kBlock), 0, stream, in_ptr, in_src, out_ptr,
                      out_dst, N, q.h_out, q.h_in);
   hipLaunchKernelGGL(coarsen_row_caps_kernel, dim3((unsigned)ceil_div(K + 1, (int64_t)kBlock)), dim3(kBlock), 0, stream, in_ptr, in_src, perm,
                      new_graph_ptr, (int)B, K, q.h_out, q.h_in, q.cap_o, q.cap_i);
   size_t temp_bytes = l.scan;
-  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.cap_o, q.off_o, (int64_t)0, (size_t)(K + 1), rocprim::plus<int64_t>(), stream) != hipSuccess)
-    return MLQEM_ERR_LAUNCH;
-  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.cap_i, q.off_i, (int64_t)0, (size_t)(K + 1), rocprim::plus<int64_t>(), stream) != hipSuccess)
+  auto scan64 = [&](int64_t* src, int64_t* dst, int64_t n) {
+    return rocprim::exclusive_scan(q.scan, temp_bytes, src, dst, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), stream) == hipSuccess;
+  };
+  if (!scan64(q.h_out, q.roff_o, N) || !scan64(q.h_in, q.roff_i, N) || !scan64(q.cap_o, q.off_o, K) || !scan64(q.cap_i, q.off_i, K))
     return MLQEM_ERR_LAUNCH;
   return MLQEM_OK;
 }
 
-__global__ void lists_totals_kernel(const int64_t* __restrict__ off_o, const int64_t* __restrict__ off_i, int64_t K, int64_t* __restrict__ totals) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { totals[0] = off_o[K]; totals[1] = off_i[K]; }
+__global__ void lists_totals_kernel(const int64_t* __restrict__ off_o, const int64_t* __restrict__ off_i, const int64_t* __restrict__ roff_o,
+                                    const int64_t* __restrict__ roff_i, int64_t K, int64_t N, int64_t* __restrict__ totals) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { totals[0] = off_o[K]; totals[1] = off_i[K]; totals[2] = roff_o[N]; totals[3] = roff_i[N]; }
 }
+
+int device_cus() {
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return cus;
+}
+constexpr int kListsMaxLds = 160 * 1024;             // one workgroup may take a CU's whole LDS
+constexpr int kListsMaxK = 65535;                    // a row's two lengths travel as one packed int through the wave scan
 }  // namespace
 
-extern "C" size_t mlqem_asap_coarsen_lists_workspace_bytes(int64_t N, int64_t K, int64_t capacity) {
-  if (N < 0 || K < 0 || capacity < 0) return 0;
-  return lists_layout(N, K, capacity).total;
+extern "C" size_t mlqem_asap_coarsen_lists_workspace_bytes(int64_t N, int64_t K, int64_t E, int64_t capacity) {
+  if (N < 0 || K < 0 || E < 0 || capacity < 0) return 0;
+  return lists_layout(N, K, E, capacity).total;
 }
 
-extern "C" int mlqem_asap_coarsen_lists_max_bits(void) { return (kListsMaxLds / 4 / 4 - kListsLcap - 1) * 32; }
+extern "C" int mlqem_asap_coarsen_lists_max_k(void) { return kListsMaxK; }
 
 extern "C" int mlqem_asap_coarsen_lists_caps(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                              const int32_t* new_graph_ptr, const int32_t* perm, int64_t N, int64_t K, int64_t B,
@@ -1043,30 +1162,32 @@ extern "C" int mlqem_asap_coarsen_lists_caps(const int32_t* in_ptr, const int32_
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (N < 0 || K < 0 || K > N || B < 0 || N >= 0x7fffffffLL || !totals) return MLQEM_ERR_BAD_ARG;
-  const ListsLayout l = lists_layout(N, K, 0);
+  const ListsLayout l = lists_layout(N, K, 0, 0);
   if (!workspace || workspace_bytes < l.total) return MLQEM_ERR_WORKSPACE;
-  if (K > 0 && (!in_ptr || !out_ptr || !new_graph_ptr || !perm || B == 0)) return MLQEM_ERR_BAD_ARG;
+  if (N > 0 && (!in_ptr || !out_ptr)) return MLQEM_ERR_BAD_ARG;
+  if (K > 0 && (!new_graph_ptr || !perm || B == 0)) return MLQEM_ERR_BAD_ARG;
   const ListsPointers q = lists_pointers(workspace, l);
   const int rc = lists_caps(in_ptr, in_src, out_ptr, out_dst, new_graph_ptr, perm, N, K, B, q, l, stream);
   if (rc != MLQEM_OK) return rc;
-  hipLaunchKernelGGL(lists_totals_kernel, dim3(1), dim3(64), 0, stream, q.off_o, q.off_i, K, totals);
+  hipLaunchKernelGGL(lists_totals_kernel, dim3(1), dim3(64), 0, stream, q.off_o, q.off_i, q.roff_o, q.roff_i, K, N, totals);
   return launch_status();
 }
 
-// Pass 1: slot[], the rows as sorted lists in the workspace, both CSR pointer arrays.  `capacity`: entries each scratch list
-// holds -- a bound on sum_p cap_o[p] and on sum_p cap_i[p] (mlqem_asap_coarsen_lists_caps reports both; GraphArena knows a
-// structural one); a row that would leave the scratch is dropped and MLQEM never writes past it (the flag is checked by pass 2).
+// Pass 1: slot[], the per-node lists, the rows as sorted lists in the workspace, both CSR pointer arrays.  E: the number of stored
+// edges of the input structure (out_ptr[N]) or a bound on it.  `capacity`: entries each of the four list buffers holds -- a bound
+// on all four totals mlqem_asap_coarsen_lists_caps reports (GraphArena knows a structural one); a list that would leave its
+// buffer is dropped, nothing is written past one, and pass 2 reports it.
 extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                               const int32_t* out_dst, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
-                                              const int32_t* perm, int64_t N, int64_t K, int64_t B, int nmax, int kmax, int64_t capacity,
+                                              const int32_t* perm, int64_t N, int64_t K, int64_t B, int64_t E, int kmax, int64_t capacity,
                                               int32_t* slot, int32_t* new_in_ptr, int32_t* new_out_ptr, void* workspace,
                                               size_t workspace_bytes, mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
-  if (N < 0 || K < 0 || K > N || B < 0 || kmax < 0 || nmax < 0 || capacity < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
-  if (nmax + 2 * kmax + 96 > mlqem_asap_coarsen_lists_max_bits() || kmax > 65535) return MLQEM_ERR_UNSUPPORTED;
+  if (N < 0 || K < 0 || K > N || B < 0 || E < 0 || kmax < 0 || capacity < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
+  if (kmax > kListsMaxK || capacity >= (1ll << 32)) return MLQEM_ERR_UNSUPPORTED;      // 32-bit places in the per-node records
   if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
-  const ListsLayout l = lists_layout(N, K, capacity);
+  const ListsLayout l = lists_layout(N, K, E, capacity);
   if (!workspace || workspace_bytes < l.total) return MLQEM_ERR_WORKSPACE;
   fill_i32(slot, -1, N, stream);
   if (K == 0 || B == 0) {
@@ -1074,7 +1195,7 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
     fill_i32(new_out_ptr, 0, K + 1, stream);
     return launch_status();
   }
-  if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm) return MLQEM_ERR_BAD_ARG;
+  if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm || (E > 0 && (!in_src || !out_dst))) return MLQEM_ERR_BAD_ARG;
   const ListsPointers q = lists_pointers(workspace, l);
   hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
   const int rc = lists_caps(in_ptr, in_src, out_ptr, out_dst, new_graph_ptr, perm, N, K, B, q, l, stream);
@@ -1082,20 +1203,22 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
   fill_i32(q.outdeg + K, 0, 1, stream);
   fill_i32(q.indeg + K, 0, 1, stream);
   fill_i32(q.flag, 0, 1, stream);
-  ListsArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, N, K, (nmax + 31) / 32, (kmax + 31) / 32,
-              kListsLcap, q.off_o, q.off_i, q.tmp_o, q.tmp_i, capacity, q.outdeg, q.indeg, q.flag};
-  const size_t lds = (size_t)4 * lists_words_per_wave(nmax, kmax) * sizeof(uint32_t);
+  const unsigned node_blocks = (unsigned)ceil_div(N, (int64_t)kBlock);
+  hipLaunchKernelGGL(coarsen_clists_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, out_ptr, out_dst, slot, N, q.clist, q.ccnt);
+  hipLaunchKernelGGL(coarsen_rlists_kernel<false>, dim3(node_blocks), dim3(kBlock), 0, stream, out_ptr, out_dst, out_ptr, q.clist, q.ccnt, N,
+                     q.roff_o, q.r_o, capacity, q.rinfo, q.flag);
+  hipLaunchKernelGGL(coarsen_rlists_kernel<true>, dim3(node_blocks), dim3(kBlock), 0, stream, in_ptr, in_src, out_ptr, q.clist, q.ccnt, N,
+                     q.roff_i, q.r_i, capacity, q.rinfo, q.flag);
+  ListsArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, N, K, (kmax + 31) / 32,
+              q.rinfo, q.r_o, q.r_i, capacity, q.off_o, q.off_i, q.tmp_o, q.tmp_i, capacity, q.outdeg, q.indeg, q.flag,
+              getenv("MLQEM_LISTS_SKIP") ? atoi(getenv("MLQEM_LISTS_SKIP")) : 0};
+  const size_t lds = (size_t)4 * 2 * a.Wk * sizeof(uint32_t);
   static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(coarsen_lists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               kListsMaxLds) == hipSuccess ? 1 : 0;
   if (!once) return MLQEM_ERR_LAUNCH;
   // persistent waves: as many workgroups as the LDS lets a CU hold (at most 8: 32 waves), never more than there are clusters
-  int cus = 256, dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kListsMaxLds / std::max<size_t>(lds, 1)));
-  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(K, (int64_t)4), (int64_t)cus * per_cu));
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(K, (int64_t)4), (int64_t)device_cus() * per_cu));
   hipLaunchKernelGGL(coarsen_lists_kernel, dim3(grid), dim3(kBlock), lds, stream, a);
   size_t temp_bytes = l.scan;
   if (rocprim::exclusive_scan(q.scan, temp_bytes, q.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(), stream) !=
@@ -1107,23 +1230,31 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
   return launch_status();
 }
 
-// Pass 2 (same workspace and capacity, untouched in between): the edge arrays, each holding `edge_capacity` entries (>= the edge
-// total new_out_ptr[K]; nothing is written past it).  *overflow (device, optional) = 1 when pass 1 dropped a row.
-extern "C" int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t capacity, const int32_t* new_in_ptr, const int32_t* new_out_ptr,
-                                             int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid, int64_t edge_capacity,
-                                             int32_t* overflow, void* workspace, size_t workspace_bytes, mlqem_stream_t stream_) {
+// Pass 2 (same workspace, N, K, E and capacity, untouched in between): the edge arrays, each holding `edge_capacity` entries
+// (new_out_ptr[K] <= edge_capacity <= capacity; nothing is written past it).  *overflow (device, optional) = 1 when pass 1
+// dropped a list.
+extern "C" int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t E, int64_t capacity, const int32_t* new_in_ptr,
+                                             const int32_t* new_out_ptr, int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid,
+                                             int64_t edge_capacity, int32_t* overflow, void* workspace, size_t workspace_bytes,
+                                             mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
-  if (N < 0 || K < 0 || capacity < 0 || edge_capacity < 0) return MLQEM_ERR_BAD_ARG;
+  if (N < 0 || K < 0 || E < 0 || capacity < 0 || edge_capacity < 0 || edge_capacity > capacity) return MLQEM_ERR_BAD_ARG;
   if (K == 0) return MLQEM_OK;
-  if (!new_in_ptr || !new_out_ptr || (edge_capacity > 0 && (!new_in_src || !new_out_dst || !new_out_eid))) return MLQEM_ERR_BAD_ARG;
-  const ListsLayout l = lists_layout(N, K, capacity);
+  if (!new_in_ptr || !new_out_ptr || (edge_capacity > 0 && (!new_in_src || !new_out_dst))) return MLQEM_ERR_BAD_ARG;
+  const ListsLayout l = lists_layout(N, K, E, capacity);
   if (!workspace || workspace_bytes < l.total) return MLQEM_ERR_WORKSPACE;
   const ListsPointers q = lists_pointers(workspace, l);
-  ListsArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, N, K, 0, 0, kListsLcap, q.off_o, q.off_i, q.tmp_o,
-              q.tmp_i, capacity, q.outdeg, q.indeg, q.flag};
-  hipLaunchKernelGGL(coarsen_lists_emit_kernel, dim3((unsigned)ceil_div(K * kGroup, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, new_in_ptr,
-                     new_out_ptr, new_in_src, new_out_dst, new_out_eid, edge_capacity);
+  ListsArgs a{};
+  a.N = N; a.K = K;
+  a.off_o = q.off_o; a.off_i = q.off_i; a.tmp_o = q.tmp_o; a.tmp_i = q.tmp_i; a.tmp_cap = capacity;
+  a.outdeg = q.outdeg; a.indeg = q.indeg; a.overflow = q.flag;
+  int32_t* out_row = new_out_eid ? q.r_o : nullptr;  // the R lists are dead after pass 1; no out_eid wanted: no link pass
+  hipLaunchKernelGGL(coarsen_lists_copy_kernel, dim3((unsigned)ceil_div(K * kGroup, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, new_in_ptr,
+                     new_out_ptr, new_in_src, new_out_dst, out_row, edge_capacity);
+  if (edge_capacity > 0 && new_out_eid)
+    hipLaunchKernelGGL(coarsen_lists_link_kernel, dim3((unsigned)(device_cus() * 8)), dim3(kBlock), 0, stream, new_in_ptr, new_in_src,
+                       new_out_dst, out_row, new_out_ptr + K, edge_capacity, new_out_eid);
   if (overflow) hipLaunchKernelGGL(copy_flag_kernel, dim3(1), dim3(64), 0, stream, q.flag, overflow);
   return launch_status();
 }

@@ -41,7 +41,15 @@ struct AttnFwdArgs {
   const uint64_t* seed_counter;             // optional device-resident step counter mixed into the seed (hipGraph replay)
   float* out; int64_t ldo;
   float* attn_out; int64_t lda; float* stat_m; float* stat_den;   // training only
+  int pair_key;                             // dropout draws keyed by (destination, head, source) instead of the in-CSR position
 };
+
+// The key of an attention weight's dropout draw.  By position (the default): (in-CSR position, head), self entries at E + row.
+// By pair: (destination row, head, source row) -- the same number from either end of an edge, so a source-side pass needs no map
+// from its out-entries to in-CSR positions (graphs without parallel edges only: parallel edges would share a draw).
+__device__ __forceinline__ uint64_t attn_drop_key(bool pair_key, int64_t pos, int H, int h, int dst, int src) {
+  return pair_key ? ((uint64_t)((int64_t)dst * H + h) << 32) | (uint32_t)src : (uint64_t)(pos * H + h);
+}
 
 template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(const AttnFwdArgs& a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;

@@ -867,6 +867,168 @@ extern "C" int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_
   }
 }
 
+// ---- the compact op stream of a parsed batch (device-side expansion: csrc/encode_expand.hip) ----------------------------
+// What the GPU needs to rebuild x, edge_index and batch is 16 bytes per op (first parameter, up to three calibration qubit
+// indices, one-hot column, counts) plus two bytes per qubit argument (the wire, for the op -> op edges) -- 0.2 GB for a
+// 1024-circuit run() of 100-qubit circuits instead of the 1.3 GB of float32 rows and int64 indices mlqem_qasm_batch_fill writes.
+// Values the record has no room for (second / third parameters, calibration entries of three-qubit gates) travel as patches.
+namespace {
+
+struct StreamSizes { int64_t wires = 0, patches = 0; };
+
+// does any calibration key start with "<name>_"?  (a slot without one never needs a lookup)
+std::vector<char> slots_with_calibration(const mlqem_backend_props* props) {
+  const int n_slots = props->num_gate_types + 2;
+  std::vector<char> any((size_t)n_slots, 0);
+  auto name_of = [&](int slot) -> std::string {
+    if (slot < props->num_gate_types) return props->gate_names[slot];
+    return slot == props->num_gate_types ? "barrier" : "measure";
+  };
+  for (int slot = 0; slot < n_slots; ++slot) {
+    const std::string pre = name_of(slot) + "_";
+    for (int i = 0; i < props->num_gate_props && !any[slot]; ++i)
+      if (std::strncmp(props->gate_keys[i], pre.c_str(), pre.size()) == 0) any[slot] = 1;
+  }
+  return any;
+}
+
+StreamSizes stream_sizes(const Circuit& c, const std::vector<int>& slot_of, const std::vector<char>& calibrated, int use_g) {
+  StreamSizes sz;
+  for (const Op& op : c.ops) {
+    sz.wires += op.q_cnt;
+    if (op.p_cnt > 1) sz.patches += op.p_cnt - 1;
+    if (use_g && op.q_cnt > 2 && calibrated[(size_t)slot_of[op.type]]) sz.patches += 2;     // at most: error and length, if the key exists
+  }
+  return sz;
+}
+
+}  // namespace
+
+extern "C" int mlqem_qasm_batch_stream_sizes(void* handle, int64_t* wire_ptr, int64_t* patch_ptr, int* max_wires) {
+  Batch* b = static_cast<Batch*>(handle);
+  if (!b || !wire_ptr || !patch_ptr) { g_last_error = "no batch handle or output"; return MLQEM_ERR_BAD_ARG; }
+  try {
+    const std::vector<char> calibrated = slots_with_calibration(b->props);
+    const int64_t count = (int64_t)b->circuits.size();
+    wire_ptr[0] = patch_ptr[0] = 0;
+    int widest = 0;
+    for (int64_t i = 0; i < count; ++i) {
+      const Circuit& c = b->circuits[i];
+      if (c.nq > 65535 || b->props->num_qubits > 65535) { g_last_error = "more than 65535 wires: the op stream holds 16-bit indices"; return MLQEM_ERR_UNSUPPORTED; }
+      const StreamSizes sz = stream_sizes(c, b->slots[i], calibrated, b->use_g);
+      wire_ptr[i + 1] = wire_ptr[i] + sz.wires;
+      patch_ptr[i + 1] = patch_ptr[i] + sz.patches;
+      widest = std::max(widest, c.nq);
+    }
+    if (max_wires) *max_wires = widest;
+    return MLQEM_OK;
+  } catch (const std::exception& err) {
+    g_last_error = err.what();
+    return MLQEM_ERR_BAD_ARG;
+  }
+}
+
+// ops[node_ptr[count]], wires[wire_ptr[count]], patches[patch_ptr[count]] (capacity; *num_patches = how many were written, packed
+// at the front circuit by circuit is NOT guaranteed: unused slots hold node = 0xFFFFFFFF and are skipped by the device)
+extern "C" int mlqem_qasm_batch_stream_fill(void* handle, int threads, const int64_t* wire_ptr, const int64_t* patch_ptr,
+                                            mlqem_op_rec* ops, uint16_t* wires, mlqem_x_patch* patches) {
+  Batch* b = static_cast<Batch*>(handle);
+  if (!b || !wire_ptr || !patch_ptr) { g_last_error = "no batch handle"; return MLQEM_ERR_BAD_ARG; }
+  try {
+    const int64_t count = (int64_t)b->circuits.size();
+    std::vector<int64_t> node_ptr((size_t)count + 1, 0);
+    for (int64_t i = 0; i < count; ++i) node_ptr[i + 1] = node_ptr[i] + b->sizes[i].N;
+    if ((node_ptr[count] > 0 && !ops) || (wire_ptr[count] > 0 && !wires) || (patch_ptr[count] > 0 && !patches)) {
+      g_last_error = "missing output buffer";
+      return MLQEM_ERR_BAD_ARG;
+    }
+    if (wire_ptr[count] >= (1ll << 32) || node_ptr[count] >= (1ll << 32)) { g_last_error = "op stream beyond 2^32 entries"; return MLQEM_ERR_UNSUPPORTED; }
+    const std::vector<char> calibrated = slots_with_calibration(b->props);
+    const int F = feature_width(b->props, b->use_q, b->use_g);
+    return for_each_parallel(count, threads, nullptr, [&](int64_t i, WorkerScratch&) {
+      const Circuit& c = b->circuits[i];
+      const std::vector<int>& slot_of = b->slots[i];
+      mlqem_op_rec* out = ops + node_ptr[i];
+      uint16_t* w = wires + wire_ptr[i];
+      mlqem_x_patch* px = patches + patch_ptr[i];
+      mlqem_x_patch* const px_end = patches + patch_ptr[i + 1];
+      uint32_t winc = (uint32_t)wire_ptr[i];
+      GateProps gate_props(b->props);
+      const int64_t N = (int64_t)c.ops.size();
+      for (int64_t k = 0; k < N; ++k) {
+        const Op& op = c.ops[k];
+        const int* qs = c.qubits(op);
+        const bool is_barrier = op.type == c.barrier;
+        mlqem_op_rec r;
+        r.p0 = op.p_cnt > 0 ? (float)c.params[op.p_off] : 0.f;
+        r.q[0] = r.q[1] = r.q[2] = 0;
+        if (!is_barrier)
+          for (int s2 = 0; s2 < op.q_cnt && s2 < 3; ++s2) r.q[s2] = (uint16_t)std::min(c.reg_index[qs[s2]], 65535);
+        r.slot = (uint8_t)slot_of[op.type];
+        r.meta = (uint8_t)((is_barrier ? 0 : std::min(op.q_cnt, 3)) | (is_barrier ? 4 : 0) | (std::min(op.p_cnt, 3) << 4));
+        r.winc = winc;
+        out[k] = r;
+        for (int s2 = 0; s2 < op.q_cnt; ++s2) w[s2] = (uint16_t)qs[s2];
+        w += op.q_cnt;
+        winc += (uint32_t)op.q_cnt;
+        const uint32_t node = (uint32_t)(node_ptr[i] + k);
+        for (int s2 = 1; s2 < op.p_cnt; ++s2) *px++ = mlqem_x_patch{node, (uint32_t)s2, (float)c.params[op.p_off + s2]};
+        if (b->use_g && op.q_cnt > 2 && calibrated[(size_t)slot_of[op.type]]) {
+          const int g = gate_props.find(c, op);
+          if (g >= 0) {
+            *px++ = mlqem_x_patch{node, (uint32_t)(F - 2), (float)b->props->gate_error[g]};
+            *px++ = mlqem_x_patch{node, (uint32_t)(F - 1), (float)b->props->gate_length[g]};
+          }
+        }
+      }
+      for (; px < px_end; ++px) *px = mlqem_x_patch{0xFFFFFFFFu, 0u, 0.f};
+    });
+  } catch (const std::exception& err) {
+    g_last_error = err.what();
+    return MLQEM_ERR_BAD_ARG;
+  }
+}
+
+// Calibration tables for the device: g1[slot * nq + q] / g2[(slot * nq + q0) * nq + q1] = index of the entry "<name>_<q>" /
+// "<name>_<q0>_<q1>" (-1: none), where <name> is the slot's op name -- the keys the reference builds per node (utils.py:263-269).
+// Every key is matched against every slot name, so a name that itself ends in "_<digits>" is told apart as the string lookup does.
+extern "C" int mlqem_props_gate_tables(const mlqem_backend_props* props, int32_t* g1, int32_t* g2) {
+  if (!props || !g1 || !g2) return MLQEM_ERR_BAD_ARG;
+  try {
+    const int nq = props->num_qubits, n_slots = props->num_gate_types + 2;
+    for (int64_t i = 0; i < (int64_t)n_slots * nq; ++i) g1[i] = -1;
+    for (int64_t i = 0; i < (int64_t)n_slots * nq * nq; ++i) g2[i] = -1;
+    auto number = [](const char* p, const char** end) -> long {     // decimal digits (no sign, no leading zeros but "0"), -1 otherwise
+      if (!is_digit(*p) || (*p == '0' && is_digit(p[1]))) return -1;
+      long v = 0;
+      while (is_digit(*p)) { v = v * 10 + (*p - '0'); if (v > 1000000) return -1; ++p; }
+      *end = p;
+      return v;
+    };
+    for (int i = 0; i < props->num_gate_props; ++i) {           // in order: a later duplicate key replaces an earlier one, as in a dict
+      const char* key = props->gate_keys[i];
+      for (int slot = 0; slot < n_slots; ++slot) {
+        const std::string name = slot < props->num_gate_types ? std::string(props->gate_names[slot]) : (slot == props->num_gate_types ? "barrier" : "measure");
+        if (std::strncmp(key, name.c_str(), name.size()) != 0 || key[name.size()] != '_') continue;
+        const char* p = key + name.size() + 1;
+        const char* e = p;
+        const long q0 = number(p, &e);
+        if (q0 < 0) continue;
+        if (*e == '\0') { if (q0 < nq) g1[(int64_t)slot * nq + q0] = i; continue; }
+        if (*e != '_') continue;
+        const char* e2 = e + 1;
+        const long q1 = number(e + 1, &e2);
+        if (q1 < 0 || *e2 != '\0') continue;
+        if (q0 < nq && q1 < nq) g2[((int64_t)slot * nq + q0) * nq + q1] = i;
+      }
+    }
+    return MLQEM_OK;
+  } catch (const std::exception& err) {
+    g_last_error = err.what();
+    return MLQEM_ERR_BAD_ARG;
+  }
+}
+
 extern "C" void mlqem_qasm_batch_free(void* handle) { delete static_cast<Batch*>(handle); }
 
 // Circuit-level features of the MLP regressors (docs/tutorials/mlp.py:111-145, 148-252): by-products of the same op scan.

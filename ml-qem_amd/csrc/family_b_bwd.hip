@@ -31,7 +31,10 @@ struct AttnBwdArgs {
   const int32_t* ptr; const int32_t* idx; const int32_t* optr; const int32_t* odst; const int32_t* oeid; const int32_t* loops;
   int64_t N, E; int H, C; float drop_p; uint64_t seed; const uint64_t* seed_counter;
   float* gqkvs; int64_t ldq; float* edge_al; float* edge_gs;
+  int pair_key;                   // as the forward's (attn_fwd.hpp)
 };
+// oeid == nullptr selects the RECOMPUTING source side (transformer_attn_bwd_src_rc_q4_kernel): the destination side then files
+// delta[N, H] = g . attn_out per (row, head) in edge_al (its first N H floats) and writes nothing per edge.
 
 template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(const AttnBwdArgs a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
@@ -270,6 +273,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int32_t* __restrict__ idx = a.idx;
   float* __restrict__ edge_al = a.edge_al;
   float* __restrict__ edge_gs = a.edge_gs;
+  const bool recompute = a.oeid == nullptr;              // the source side keeps no per-edge values (see AttnBwdArgs)
   const f4u q = load_channels(qkvs + (int64_t)row * ld + off, nv, true);
   const f4u gi = load_channels(a.g + (int64_t)row * a.ldg + off, nv, off + 4 <= a.ldg);
   const f4u ao = load_channels(a.attn_out + (int64_t)row * a.lda + off, nv, off + 4 <= a.lda);
@@ -309,10 +313,10 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     const int64_t pos = is_self ? a.E + row : (int64_t)beg + x;
     const float alpha = expf(mys * scale - m) * inv_den * (is_self ? (float)n_self : 1.f);
     float dmask = 1.f;
-    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, (uint64_t)(pos * H + h)) < a.drop_p ? 0.f : keep;
+    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, attn_drop_key(a.pair_key != 0, pos, H, h, row, j)) < a.drop_p ? 0.f : keep;
     float gs = alpha * (mygv * dmask - delta) * scale;
     if (lu >= k) gs = 0.f;
-    if (lq < 4 && lu < k) {                              // LPH = 8: both quads of the head hold the chunk, the first one stores
+    if (!recompute && lq < 4 && lu < k) {                // LPH = 8: both quads of the head hold the chunk, the first one stores
       edge_al[pos * H + h] = alpha * dmask;
       edge_gs[pos * H + h] = gs;
     }
@@ -320,13 +324,94 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 #pragma unroll
     for (int u = 0; u < 4; ++u) gq += gu[u] * kk[u];
   }
-  if (n_self == 0 && lq == 0) {
+  if (recompute) {
+    if (lq == 0) edge_al[(int64_t)row * H + h] = delta;   // what the source side needs of this row besides m and den
+  } else if (n_self == 0 && lq == 0) {
     edge_al[(a.E + row) * H + h] = 0.f;
     edge_gs[(a.E + row) * H + h] = 0.f;
   }
   float* __restrict__ go = a.gqkvs + (int64_t)row * a.ldq;
   store_channels(go + off, gq, nv);
   store_channels(go + 3 * HC + off, gi, nv);
+}
+
+// Source side WITHOUT per-edge buffers and without out_eid: every weight is recomputed from what the forward kept per (row, head)
+// -- alpha = exp(q_i . k_j / sqrt(C) - m_i) / den_i, delta_i = g_i . attn_out_i (filed by the destination side) -- the way attention
+// backward passes are usually written:  g_k[j] = sum_i gs_ij q_i,  g_v[j] = sum_i alpha_ij mask_ij g_i,
+// gs_ij = alpha_ij (g_i . v_j mask_ij - delta_i) / sqrt(C).  Per out-entry it gathers the same two rows (query, gradient) as the
+// stored form and three scalars from [N, H] arrays (a few MB: cache-resident) instead of a position and two values from
+// [E, H] arrays; the coarsened graphs of ASAPooling come without out_eid (linking 9.7 M entries cost 0.55 ms per step).
+template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_rc_q4_kernel(const AttnBwdArgs a) {
+  const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
+  const int lq = threadIdx.x % LPH, lu = lq & 3;
+  const int H = a.H, C = a.C, HC = H * C;
+  if (t >= a.N * H) return;
+  const int row = (int)(t / H);
+  const int h = (int)(t - (int64_t)row * H);
+  const int nv = min(4, max(0, C - 4 * lq));
+  const int off = h * C + 4 * lq;
+  const float scale = 1.0f / sqrtf((float)C);
+  const float keep = 1.f / (1.f - a.drop_p);
+  const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);   // as the forward
+  const float* __restrict__ qkvs = a.qkvs;
+  const float* __restrict__ g = a.g;
+  const float* __restrict__ stat_delta = a.edge_al;
+  const int64_t ld = a.ld, ldg = a.ldg;
+  const bool g_fits = off + 4 <= ldg;
+  const float* __restrict__ rj = qkvs + (int64_t)row * ld;
+  const f4u kown = load_channels(rj + HC + off, nv, true);          // runs over into the value part at most
+  const f4u vown = load_channels(rj + 2 * HC + off, nv, true);      // ... into the skip part
+  const int n_self = a.loops ? a.loops[row] : 0;
+  f4u gk = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+  const int obeg = a.optr[row];
+  const int odeg = a.optr[row + 1] - obeg;
+  const int cnt = odeg + (n_self > 0 ? 1 : 0);
+  for (int x0 = 0; x0 < cnt; x0 += 4) {
+    const int k = min(4, cnt - x0);
+    const int x = x0 + min(lu, k - 1);
+    const bool is_self = x >= odeg;
+    const int i = is_self ? row : a.odst[obeg + x];
+    const int64_t sh = (int64_t)i * H + h;
+    const float m_i = a.stat_m[sh], inv_den = 1.0f / a.stat_den[sh], delta_i = stat_delta[sh];
+    int iu[4];
+    iu[0] = quad_bcast<0>(i); iu[1] = quad_bcast<1>(i); iu[2] = quad_bcast<2>(i); iu[3] = quad_bcast<3>(i);
+    f4u qa[4], ga[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u < k && nv > 0) {
+        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + off);
+        ga[u] = g_fits ? *reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off) : load_channels(g + (int64_t)iu[u] * ldg + off, nv, false);
+        if (nv < 4) qa[u].w = 0.f;                       // the lane's fourth component belongs to the next head / part
+        if (nv < 3) qa[u].z = 0.f;
+        if (nv < 2) qa[u].y = 0.f;
+        if (g_fits) { if (nv < 4) ga[u].w = 0.f; if (nv < 3) ga[u].z = 0.f; if (nv < 2) ga[u].y = 0.f; }
+      } else {
+        qa[u] = f4u{0.f, 0.f, 0.f, 0.f};
+        ga[u] = f4u{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    float mys = 0.f, mygv = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float sd = head_sum<LPH>(dot4(qa[u], kown)), gd = head_sum<LPH>(dot4(ga[u], vown));
+      if (lu == u) { mys = sd; mygv = gd; }
+    }
+    const float alpha = expf(mys * scale - m_i) * inv_den * (is_self ? (float)n_self : 1.f);
+    float dmask = 1.f;
+    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, attn_drop_key(true, 0, H, h, i, row)) < a.drop_p ? 0.f : keep;
+    float gs = alpha * (mygv * dmask - delta_i) * scale, al = alpha * dmask;
+    if (lu >= k) { gs = 0.f; al = 0.f; }
+    const float gsu[4] = {quad_bcast<0>(gs), quad_bcast<1>(gs), quad_bcast<2>(gs), quad_bcast<3>(gs)};
+    const float alu[4] = {quad_bcast<0>(al), quad_bcast<1>(al), quad_bcast<2>(al), quad_bcast<3>(al)};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gk += gsu[u] * qa[u];
+      gv += alu[u] * ga[u];
+    }
+  }
+  float* __restrict__ go = a.gqkvs + (int64_t)row * a.ldq;
+  store_channels(go + HC + off, gk, nv);
+  store_channels(go + 2 * HC + off, gv, nv);
 }
 
 template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_q4_kernel(const AttnBwdArgs a) {
@@ -402,6 +487,9 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
+  // edge_gp == nullptr: the source side recomputes its weights (softmax_aggregate_bwd_src_rc_kernel); nothing is written per
+  // edge, and edge_al takes one record {a_i, m_i, 1 / den_i, delta_i} per row
+  const bool recompute = edge_gp == nullptr;
   const int beg = ptr[row], end = ptr[row + 1];
   const float ai = a_dst[row];
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
@@ -473,8 +561,10 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
     if (l < k) {
       const float al = expf(leaky(pre) - m) * inv;
       const float gp = al * (mydot - delta) * (pre > 0.f ? 1.f : slope);
-      edge_al[e0 + l] = al;
-      edge_gp[e0 + l] = gp;
+      if (!recompute) {
+        edge_al[e0 + l] = al;
+        edge_gp[e0 + l] = gp;
+      }
       ga += gp;
     }
   }
@@ -496,8 +586,12 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
     const float gp = al * (dd - delta) * (pre > 0.f ? 1.f : slope);
     ga += gp;
     if (l == 0) {
-      edge_al[E + row] = al;
-      edge_gp[E + row] = gp;
+      if (recompute) {
+        reinterpret_cast<float4*>(edge_al)[row] = make_float4(ai, m, inv, delta);
+      } else {
+        edge_al[E + row] = al;
+        edge_gp[E + row] = gp;
+      }
       g_a[row] = ga;
     }
   }
@@ -650,6 +744,91 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
     }
   }
   gc = group16_sum(gc) + edge_gp[E + row];
+  float* __restrict__ d = gx + row * ldgx + l;
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    if (has[v]) d[v * kGroup] = accumulate ? d[v * kGroup] + acc[v] : acc[v];
+  if (l == 0) g_c[row] = gc;
+}
+
+// Source side WITHOUT per-edge buffers and without out_eid (see transformer_attn_bwd_src_rc_q4_kernel): for every out-entry j -> i
+//   al = exp(LeakyReLU(a_i + c_j) - m_i) / den_i,   gp = al (gnew_i . x_j - delta_i) LeakyReLU'(a_i + c_j)
+// from the row's own x_j, c_j and the destination's record {a_i, m_i, 1 / den_i, delta_i} (one 16-byte gather instead of a
+// position and two values from [E]-sized arrays); the gathered gnew rows are the ones g_x needs anyway.
+template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_rc_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr,
+    const int32_t* __restrict__ odst, const float4* __restrict__ stat, const float* __restrict__ c_src, float slope, int64_t N, int C,
+    int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  const float cj = c_src[row];
+  bool has[NV];
+  float acc[NV], xr[NV];
+  float gc;
+  {  // the self entry
+    const float4 st = stat[row];
+    const float pre = st.x + cj;
+    const float al = expf(leaky(pre) - st.y) * st.z;
+    float dd = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      has[v] = l + v * kGroup < C;
+      xr[v] = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
+      const float gn = has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f;
+      acc[v] = al * gn;
+      dd = fmaf(gn, xr[v], dd);
+    }
+    dd = group16_sum(dd);
+    gc = l == 0 ? al * (dd - st.w) * (pre > 0.f ? 1.f : slope) : 0.f;      // lane u: the gp of its entries (the self entry is lane 0's)
+  }
+  const int beg = optr[row], end = optr[row + 1];
+  for (int e0 = beg; e0 < end; e0 += kGroup) {
+    const int k = min(kGroup, end - e0);
+    const int i = odst[e0 + min(l, k - 1)];
+    const float4 st = stat[i];
+    const float pre = st.x + cj;
+    const float al = l < k ? expf(leaky(pre) - st.y) * st.z : 0.f;        // lanes past the end: the last entry again with weight 0
+    float mydot = 0.f;
+    auto rows = [&](auto first, auto count) {
+      constexpr int U0 = decltype(first)::value, CNT = decltype(count)::value;
+      int iu[CNT];
+      float au[CNT], gn[CNT][NV];
+      iu[0] = group16_bcast<U0 + 0>(i); iu[1] = group16_bcast<U0 + 1>(i);
+      au[0] = group16_bcast<U0 + 0>(al); au[1] = group16_bcast<U0 + 1>(al);
+      if constexpr (CNT == 8) {
+        iu[2] = group16_bcast<U0 + 2>(i); iu[3] = group16_bcast<U0 + 3>(i); iu[4] = group16_bcast<U0 + 4>(i);
+        iu[5] = group16_bcast<U0 + 5>(i); iu[6] = group16_bcast<U0 + 6>(i); iu[7] = group16_bcast<U0 + 7>(i);
+        au[2] = group16_bcast<U0 + 2>(al); au[3] = group16_bcast<U0 + 3>(al); au[4] = group16_bcast<U0 + 4>(al);
+        au[5] = group16_bcast<U0 + 5>(al); au[6] = group16_bcast<U0 + 6>(al); au[7] = group16_bcast<U0 + 7>(al);
+      }
+#pragma unroll
+      for (int u = 0; u < CNT; ++u) {
+        const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg + l;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) gn[u][v] = has[v] ? gi[v * kGroup] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < CNT; ++u) {
+        float dd = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          acc[v] = fmaf(au[u], gn[u][v], acc[v]);
+          dd = fmaf(gn[u][v], xr[v], dd);
+        }
+        dd = group16_sum(dd);
+        if (l == U0 + u) mydot = dd;
+      }
+    };
+    if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{});
+    else {
+      rows(EdgeChunk<0>{}, EdgeChunk<8>{});
+      if (k > 8) rows(EdgeChunk<8>{}, EdgeChunk<8>{});
+    }
+    if (l < k) gc += al * (mydot - st.w) * (pre > 0.f ? 1.f : slope);
+  }
+  gc = group16_sum(gc);
   float* __restrict__ d = gx + row * ldgx + l;
 #pragma unroll
   for (int v = 0; v < NV; ++v)
@@ -925,8 +1104,8 @@ using namespace mlqem;
 extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
                                                      const int32_t* in_src, const int32_t* loops, int64_t N, int64_t E,
                                                      int H, int C, float drop_p, uint64_t seed,
-                                                     const uint64_t* seed_counter, float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m,
-                                                     float* stat_den, mlqem_stream_t stream) {
+                                                     const uint64_t* seed_counter, int pair_key, float* out, int64_t ldo, float* attn_out,
+                                                     int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
     return MLQEM_ERR_BAD_ARG;
@@ -934,7 +1113,9 @@ extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t 
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
-  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den};
+  if (pair_key && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;      // the one-channel-per-lane forms key by position only
+  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den,
+                      pair_key ? 1 : 0};
   if (attn_q4_enabled()) {
     if (C > 16) hipLaunchKernelGGL(transformer_attn_train_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
     else hipLaunchKernelGGL(transformer_attn_train_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
@@ -949,20 +1130,31 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
                                                    const int32_t* out_ptr, const int32_t* out_dst,
                                                    const int32_t* out_eid, const int32_t* loops, int64_t N, int64_t E,
                                                    int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                                   float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
+                                                   int pair_key, float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
                                                    mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldq < 4 * H * C || ldg < H * C || lda < H * C)
     return MLQEM_ERR_BAD_ARG;
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
-  if (!qkvs || !g || !attn_out || !stat_m || !stat_den || !in_ptr || !out_ptr || !gqkvs || !edge_al || !edge_gs)
+  const bool recompute = out_eid == nullptr;             // no out_eid: the source side recomputes its weights (edge_al: [N H] floats)
+  if (!qkvs || !g || !attn_out || !stat_m || !stat_den || !in_ptr || !out_ptr || !gqkvs || !edge_al || (!recompute && !edge_gs))
     return MLQEM_ERR_BAD_ARG;
-  if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
+  if (E > 0 && (!in_src || !out_dst)) return MLQEM_ERR_BAD_ARG;
+  if (recompute && drop_p > 0.f && !pair_key) return MLQEM_ERR_BAD_ARG;   // a position-keyed draw cannot be found from the source side
+  if ((recompute || pair_key) && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
   const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
-                      N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs};
-  if (attn_q4_enabled()) {
+                      N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0};
+  if (recompute) {
+    if (C > 16) {
+      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
+      hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
+    } else {
+      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
+      hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
+    }
+  } else if (attn_q4_enabled()) {
     if (C > 16) {
       hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
       hipLaunchKernelGGL(transformer_attn_bwd_src_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
@@ -993,9 +1185,17 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
   if (tie_count && (!xmax || ldm < C || ldt < C)) return MLQEM_ERR_BAD_ARG;
   if (tie_count && C > 128) return MLQEM_ERR_UNSUPPORTED;      // the any-width form does not count
   if (N == 0) return MLQEM_OK;
-  if (!x || !xnew || !gnew || !in_ptr || !out_ptr || !a_dst || !c_src || !gx || !g_a || !g_c || !edge_al || !edge_gp)
+  // no out_eid: the source side recomputes its weights; edge_al then holds one 16-byte record per row ([4 N] floats, 16-byte
+  // aligned) and edge_gp is not used
+  const bool recompute = out_eid == nullptr;
+  if (!x || !xnew || !gnew || !in_ptr || !out_ptr || !a_dst || !c_src || !gx || !g_a || !g_c || !edge_al || (!recompute && !edge_gp))
     return MLQEM_ERR_BAD_ARG;
-  if (E > 0 && (!in_src || !out_dst || !out_eid)) return MLQEM_ERR_BAD_ARG;
+  if (E > 0 && (!in_src || !out_dst)) return MLQEM_ERR_BAD_ARG;
+  if (recompute) {
+    if (C > 128) return MLQEM_ERR_UNSUPPORTED;
+    if (!aligned_to(edge_al, 16)) return MLQEM_ERR_BAD_ARG;
+    edge_gp = nullptr;
+  }
 #define MLQEM_SAB(NV)                                                                                                                          \
   do {                                                                                                                                         \
     if (tie_count)                                                                                                                             \
@@ -1014,8 +1214,15 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
     hipLaunchKernelGGL(softmax_aggregate_bwd_dst_any_width_kernel, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr,
                        in_src, a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a);
 #undef MLQEM_SAB
-#define MLQEM_SAS(NV) hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel<NV>, MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, \
-                                         out_eid, edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c)
+#define MLQEM_SAS(NV)                                                                                                                    \
+  do {                                                                                                                                   \
+    if (recompute)                                                                                                                       \
+      hipLaunchKernelGGL(softmax_aggregate_bwd_src_rc_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, gnew, ldg, out_ptr, out_dst,           \
+                         reinterpret_cast<const float4*>(edge_al), c_src, negative_slope, N, C, accumulate, gx, ldgx, g_c);              \
+    else                                                                                                                                 \
+      hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel<NV>, MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, out_eid, edge_al,    \
+                         edge_gp, N, E, C, accumulate, gx, ldgx, g_c);                                                                  \
+  } while (0)
   if (C <= 16) MLQEM_SAS(1);
   else if (C <= 32) MLQEM_SAS(2);
   else if (C <= 48) MLQEM_SAS(3);

@@ -8,5 +8,5 @@ for setting in "$@"; do
   ( export $setting; rm -rf /tmp/abf$k
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abf$k -- python3 $R/scripts/profile_family_b.py 64 12 100 > /tmp/abf$k.log 2>&1 )
   echo "== $setting: $(grep 'family B' /tmp/abf$k.log)"
-  python3 $R/scripts/stats_top.py /tmp/abf$k 14 | cut -c1-150
+  python3 $R/scripts/stats_top.py /tmp/abf$k ${TOPN:-14} | cut -c1-150
 done

@@ -312,7 +312,8 @@ def test_dense_sync_free_coarsening_equals_the_two_hop_path(golden_dir, g1):
         n, b = batch["x"].shape[0], batch["noisy"].shape[0]
         results = {}
         for dense in (True, False):
-            F._ASAP_DENSE = dense
+            F._ASAP_DENSE, keep_link = dense, F._ASAP_LINK
+            F._ASAP_LINK = True                    # out_eid is compared below (the list form skips the link pass by default)
             try:
                 with torch.no_grad():
                     s = GraphStructure.from_edge_index(batch["edge_index"].to(DEV), n, batch=batch["batch"].to(DEV), num_graphs=b)
@@ -322,7 +323,7 @@ def test_dense_sync_free_coarsening_equals_the_two_hop_path(golden_dir, g1):
                     out = model(batch["noisy"].to(DEV), None, batch["depth"].to(DEV), batch["x"].to(DEV),
                                 batch["edge_index"].to(DEV), batch["batch"].to(DEV))
             finally:
-                F._ASAP_DENSE = True
+                F._ASAP_DENSE, F._ASAP_LINK = True, keep_link
             results[dense] = (s1, s2, perm1, perm2, out)
         for lvl in (0, 1):
             a, c = results[True][lvl], results[False][lvl]
@@ -374,13 +375,14 @@ def test_wave_per_cluster_coarsening_equals_the_two_hop_path(golden_dir, g1):
         res = {}
         # "lists": sorted lists from persistent waves (round 4, the default); "rows": dense bit matrices (round 3); "hop": two-hop
         for mode, (rows, lists) in {"lists": (True, True), "rows": (True, False), "hop": (False, False)}.items():
-            F._ASAP_DENSE, F._ASAP_ROWS, F._ASAP_LISTS = False, rows, lists
+            F._ASAP_DENSE, F._ASAP_ROWS, F._ASAP_LISTS, keep_link = False, rows, lists, F._ASAP_LINK
+            F._ASAP_LINK = True                    # out_eid is compared below (the default skips the link pass)
             try:
                 res[mode] = _pooled_levels(model, x, ei, bv, b)
                 for lvl in (0, 1):
                     res[mode][lvl].in_ptr          # the second level is deferred: build it under THIS mode's switches
             finally:
-                F._ASAP_DENSE, F._ASAP_ROWS, F._ASAP_LISTS = True, True, True
+                F._ASAP_DENSE, F._ASAP_ROWS, F._ASAP_LISTS, F._ASAP_LINK = True, True, True, keep_link
         for mode in ("lists", "rows"):
             for lvl in (0, 1):
                 a, c = res[mode][lvl], res["hop"][lvl]
@@ -412,6 +414,8 @@ def test_list_coarsening_with_a_structural_capacity_equals_the_exact_one(golden_
     assert s.coarse_capacity is not None and s.coarse_capacity > 0
     torch.manual_seed(2)
     model = ExpValCircuitGraphModel(22, 15).to(DEV).eval()
+    from blackwater.native import functional as F
+    keep_link, F._ASAP_LINK = F._ASAP_LINK, True
     with torch.no_grad():
         g = model.transformer1(batch.nodes.materialize() if hasattr(batch.nodes, "materialize") else batch.nodes, s)
         cap = s.coarse_capacity
@@ -421,6 +425,7 @@ def test_list_coarsening_with_a_structural_capacity_equals_the_exact_one(golden_
         _, s1_exact, perm_exact = model.pooling1(g, s)
         s1_exact.in_ptr
         s.coarse_capacity = cap
+    F._ASAP_LINK = keep_link
     assert torch.equal(perm_cap, perm_exact)
     k = s1_exact.num_nodes
     e = int(s1_exact.in_ptr[k].item())
@@ -432,15 +437,15 @@ def test_list_coarsening_with_a_structural_capacity_equals_the_exact_one(golden_
     # the capacity really bounds the scratch the rows are placed in
     lib = _lib.load()
     from blackwater.native import ops
-    need = lib.mlqem_asap_coarsen_lists_workspace_bytes(s.num_nodes, k, 0)
+    need = lib.mlqem_asap_coarsen_lists_workspace_bytes(s.num_nodes, k, 0, 0)
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
-    totals = torch.zeros(2, dtype=torch.int64, device=DEV)
+    totals = torch.zeros(4, dtype=torch.int64, device=DEV)
     code = lib.mlqem_asap_coarsen_lists_caps(s.in_ptr.data_ptr(), s.in_src.data_ptr(), s.out_ptr.data_ptr(), s.out_dst.data_ptr(),
                                              s1_exact.graph_ptr.data_ptr(), perm_exact.data_ptr(), s.num_nodes, k, s.num_graphs,
                                              totals.data_ptr(), ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream)
     assert code == 0
-    t = totals.tolist()
-    assert e <= min(t) and max(t) <= cap
+    t = totals.tolist()           # row bounds (out, in), per-node list sizes (out, in)
+    assert e <= min(t[:2]) and max(t) <= cap
 
 
 def test_family_b_train_step_makes_no_device_to_host_copy(golden_dir, g1):
@@ -516,7 +521,8 @@ def test_coarsened_edge_capacity_bounds_the_real_count_on_100_qubit_graphs():
     assert c.num_edges == e and a.num_edges == int(arena.coarse_caps[sel].sum()) >= e > 0
     assert torch.equal(a.in_ptr[:a.num_nodes + 1], c.in_ptr[:c.num_nodes + 1])
     assert torch.equal(a.out_ptr[:a.num_nodes + 1], c.out_ptr[:c.num_nodes + 1])
-    assert torch.equal(a.in_src[:e], c.in_src[:e]) and torch.equal(a.out_dst[:e], c.out_dst[:e]) and torch.equal(a.out_eid[:e], c.out_eid[:e])
+    assert torch.equal(a.in_src[:e], c.in_src[:e]) and torch.equal(a.out_dst[:e], c.out_dst[:e])
+    assert a.out_eid is None and c.out_eid is None     # the list form links nothing by default (recomputed backward forms)
     assert torch.equal(res[True][1], res[False][1])
     # per graph: real coarsened edges <= the graph's own bound
     gp = a.graph_ptr.cpu().numpy()
@@ -677,3 +683,80 @@ def test_attention_kernels_against_a_dense_reference(heads, ch):
     assert torch.equal(out, inf)
     gscale = max(1.0, x.grad.abs().max().item())
     assert (gq.cpu().double() - x.grad).abs().max().item() < 5e-5 * gscale
+
+
+@pytest.mark.parametrize("heads,ch", [(2, 15), (3, 15), (3, 25), (1, 16), (2, 17), (4, 3)])
+def test_recomputed_attention_backward_equals_the_stored_form(heads, ch):
+    """A structure without out_eid (ASAPooling's coarsened graphs since round 4) takes the RECOMPUTED source side of
+    mlqem_transformer_attention_bwd_f32: no per-edge buffers, weights recomputed from m / den / g . attn_out per (row, head).  Same
+    gradients as the stored form (through out_eid) within 2e-5 of the gradient scale -- without dropout, and with dropout keyed by
+    (destination, head, source) in both forms (same masks from either end of an edge); the forward under that key drops the
+    stated fraction of the weights.  Graph: no parallel edges, rows of 0-60 in-edges, self entries of multiplicity 0 / 1."""
+    import copy
+
+    from blackwater.native import ops
+    from blackwater.native.structure import GraphStructure
+
+    rng = np.random.RandomState(heads * 100 + ch)
+    n = 400
+    deg = rng.choice([0, 1, 2, 3, 4, 5, 8, 9, 17, 40, 60], size=n)
+    src = np.concatenate([rng.choice(n - 1, size=d, replace=False) for d in deg]) if deg.sum() else np.zeros(0, dtype=np.int64)
+    dst = np.repeat(np.arange(n), deg)
+    src = np.where(src >= dst, src + 1, src)                            # distinct sources per row, never the row itself
+    loops = rng.randint(0, 2, size=n)
+    ei = np.concatenate([np.stack([src, dst]), np.repeat(np.stack([np.arange(n)] * 2), loops, axis=1)], axis=1)
+    s = GraphStructure.from_edge_index(torch.from_numpy(ei).to(DEV), n)
+    s_rc = copy.copy(s)
+    s_rc.out_eid = None
+    hc = heads * ch
+    g = torch.Generator().manual_seed(ch)
+    qkvs = ops.padded_copy(torch.randn(n, 4 * hc, generator=g).to(DEV))
+    gout = ops.padded_copy(torch.randn(n, hc, generator=g).to(DEV))
+    e = s.edge_count()
+    for drop_p in (0.0, 0.3):
+        out, attn, m, den = ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, drop_p, 99, pair_key=True)
+        stored = ops.transformer_attention_bwd(qkvs, gout, attn, m, den, s, e, heads, ch, drop_p, 99, pair_key=True)
+        again = ops.transformer_attention_bwd(qkvs, gout, attn, m, den, s_rc, e, heads, ch, drop_p, 99, pair_key=True)
+        scale = max(1.0, stored[:, :4 * hc].abs().max().item())
+        assert (stored[:, :4 * hc] - again[:, :4 * hc]).abs().max().item() < 2e-5 * scale, drop_p
+        assert torch.isfinite(again[:, :4 * hc]).all()
+        if drop_p == 0.0:
+            by_pos = ops.transformer_attention_bwd(qkvs, gout, attn, m, den, s, e, heads, ch)      # position key: no draws, same numbers
+            assert torch.equal(by_pos[:, :4 * hc], stored[:, :4 * hc])
+            plain = out
+        else:
+            assert not torch.equal(out, plain)                         # weights were dropped
+    with pytest.raises(Exception):                                     # a position-keyed draw cannot be found from the source side
+        ops.transformer_attention_bwd(qkvs, gout, attn, m, den, s_rc, e, heads, ch, 0.3, 99, pair_key=False)
+
+
+@pytest.mark.parametrize("c", [30, 45, 7, 64, 100])
+def test_recomputed_softmax_aggregate_backward_equals_the_stored_form(c):
+    """mlqem_csr_softmax_aggregate_bwd_f32 without out_eid: the source side recomputes al / gp from one record {a_i, m_i, 1 / den_i,
+    delta_i} per destination row.  Same gx, g_a, g_c as the stored form within 2e-5 of their scales; tie counts unchanged."""
+    import copy
+
+    from blackwater.native import ops
+    from blackwater.native.structure import GraphStructure
+
+    rng = np.random.RandomState(c)
+    n = 500
+    deg = rng.choice([0, 1, 2, 3, 5, 8, 16, 17, 33, 70], size=n)
+    src = np.concatenate([rng.choice(n - 1, size=d, replace=False) for d in deg])
+    dst = np.repeat(np.arange(n), deg)
+    src = np.where(src >= dst, src + 1, src)
+    s = GraphStructure.from_edge_index(torch.from_numpy(np.stack([src, dst])).to(DEV), n)
+    s_rc = copy.copy(s)
+    s_rc.out_eid = None
+    g = torch.Generator().manual_seed(c)
+    x = ops.padded_copy(torch.randn(n, c, generator=g).to(DEV))
+    a_dst, c_src = torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, 0.2)
+    xmax = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
+    gnew = ops.padded_copy(torch.randn(n, c, generator=g).to(DEV))
+    e = s.edge_count()
+    gx0, ga0, gc0, t0 = ops.csr_softmax_aggregate_bwd(x, x_new, gnew, s, e, a_dst, c_src, 0.2, xmax=xmax)
+    gx1, ga1, gc1, t1 = ops.csr_softmax_aggregate_bwd(x, x_new, gnew, s_rc, e, a_dst, c_src, 0.2, xmax=xmax)
+    for a, b in ((gx0[:, :c], gx1[:, :c]), (ga0, ga1), (gc0, gc1)):
+        assert (a - b).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
+    assert torch.equal(t0[:, :c], t1[:, :c])
