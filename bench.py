@@ -466,23 +466,27 @@ def family_b_leg(dev, steps=30):
     # rows of 100-500, which the attention / ASAPooling kernels walk in chunks with one lane per edge for the scalar work
     torch.cuda.reset_peak_memory_stats()
     mem_before = torch.cuda.memory_allocated()
-    hb = TfimCorpus(100, list(range(1, 11)), 13, seed=42, exp_value_size=4).host_graphs()
-    big_arena = GraphArena.from_arrays(hb["x"], hb["edge_index"], hb["y"][:, None, :], hb["noisy"][:, None, :], hb["depth"],
-                                       hb["observable"], device=dev, filler_nodes=1024)
-    del hb
+    # 104 J values per Trotter step count: a size-stratified batch of 1024 holds 102-103 circuits of every size.  The arena is built on
+    # the device from one encoded template per step count (TfimCorpus.arena), as the headline workload's
+    big_corpus = TfimCorpus(100, list(range(1, 11)), 104, seed=42, exp_value_size=4)
+    big_arena = big_corpus.arena(dev, filler_nodes=1024)
     nb_graphs = len(big_arena)
-    big_batch, big_steps = 64, max(6, steps // 2)
-    cfg4 = {"nodes_per_circuit": round(big_arena.num_nodes / nb_graphs), "circuits_per_step": big_batch,
-            "coarsened_edge_capacity_per_node": round(float(big_arena.coarse_caps[:nb_graphs].sum()) / big_arena.num_nodes, 1)}
-    # size-stratified batches (6-7 circuits of each Trotter step count) through the bucketed trainer: eager, then captured.  The
-    # coarsened edge arrays are sized by a structural bound (GraphArena.coarse_caps), so the step reads nothing from the device
-    # and the whole of it -- assembly, two TransformerConv + ASAPooling levels, head, backward, Adam -- replays from ONE graph.
-    for graphs in (False, True):
+    cfg4 = {"nodes_per_circuit": round(big_arena.num_nodes / nb_graphs), "circuits_in_the_arena": nb_graphs,
+            "coarsened_edge_capacity_per_node": round(float(big_arena.coarse_caps[:nb_graphs].sum()) / big_arena.num_nodes, 1),
+            "note": "batch 64 is the point every round has reported (circuits_per_s / ms_per_step below); 256 and 1024 separate what the "
+                    "kernels cost per circuit from what a step costs whatever its size (VERDICT r03 item 1c)"}
+    # size-stratified batches (the same number of circuits of each Trotter step count in every batch) through the bucketed trainer:
+    # eager at 64, then captured at 64 / 256 / 1024.  The coarsened edge arrays are sized by a structural bound
+    # (GraphArena.coarse_caps), so the step reads nothing from the device and the whole of it -- assembly, two TransformerConv +
+    # ASAPooling levels, head, backward, Adam -- replays from ONE graph.
+    for big_batch, graphs, big_steps in ((64, False, max(6, steps // 2)), (64, True, max(6, steps // 2)), (256, True, 6), (1024, True, 4)):
         torch.manual_seed(0)
+        torch.cuda.reset_peak_memory_stats()
         sampler = StratifiedBatches(big_arena.node_counts[:nb_graphs], big_arena.edge_counts[:nb_graphs], big_batch, seed=13)
         bt = BucketedTrainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), big_arena, lr=1e-3, graphs=graphs, node_quantum=1024,
                              edge_quantum=4096)
-        for _ in range(4):
+        progress(f"  family B, 100-qubit circuits: {big_batch} per step, {'captured' if graphs else 'eager'}")
+        for _ in range(4 if big_batch == 64 else 2):
             bt.step_ids(sampler.draw())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -490,17 +494,25 @@ def family_b_leg(dev, steps=30):
             last = bt.step_ids(sampler.draw())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        cfg4["hipgraph" if graphs else "eager"] = {"circuits_per_s": round(big_batch * big_steps / dt, 1), "ms_per_step": round(dt / big_steps * 1e3, 2),
-                                                   "steps": big_steps, "final_loss": round(float(last.item()), 6)}
+        rec = {"circuits_per_s": round(big_batch * big_steps / dt, 1), "ms_per_step": round(dt / big_steps * 1e3, 2),
+               "ms_per_64_circuits": round(dt / big_steps * 1e3 * 64 / big_batch, 2), "steps": big_steps,
+               "final_loss": round(float(last.item()), 6), "nodes_per_step": int(sampler.nodes_per_batch),
+               "peak_mem_GB": round((torch.cuda.max_memory_allocated() - mem_before) / 1e9, 2)}
+        cfg4["batch%d_%s" % (big_batch, "hipgraph" if graphs else "eager")] = rec
         _ops.set_seed_counter(None)
         del bt
-    cfg4["circuits_per_s"] = cfg4["hipgraph"]["circuits_per_s"]
-    cfg4["ms_per_step"] = cfg4["hipgraph"]["ms_per_step"]
-    cfg4["peak_mem_GB_above_the_rest_of_the_bench"] = round((torch.cuda.max_memory_allocated() - mem_before) / 1e9, 2)
-    cfg4["attention_roofline"] = attention_roofline(big_arena.batch(np.arange(big_batch) * nb_graphs // big_batch).structure, dev,
+        torch.cuda.empty_cache()
+    cfg4["hipgraph"], cfg4["eager"] = cfg4["batch64_hipgraph"], cfg4["batch64_eager"]
+    cfg4["circuits_per_s"] = cfg4["batch64_hipgraph"]["circuits_per_s"]
+    cfg4["ms_per_step"] = cfg4["batch64_hipgraph"]["ms_per_step"]
+    cfg4["best_circuits_per_s"] = max(cfg4[k]["circuits_per_s"] for k in ("batch64_hipgraph", "batch256_hipgraph", "batch1024_hipgraph"))
+    cfg4["attention_roofline"] = attention_roofline(big_arena.batch(np.arange(64) * nb_graphs // 64).structure, dev,
                                                     "64 100-qubit circuits (the first TransformerConv's graph: the circuit DAGs)")
-    out["cfg4_100q_batch64"] = cfg4
-    del big_arena
+    out["cfg4_100q"] = cfg4
+    out["cfg4_100q_batch64"] = {"renamed": "cfg4_100q (batch points 64 / 256 / 1024)", "circuits_per_s": cfg4["circuits_per_s"],
+                                "ms_per_step": cfg4["ms_per_step"]}
+    del big_arena, big_corpus
+    torch.cuda.empty_cache()
     # the CPU oracle doing the same step at the reference's batch size (bounded: 6 steps, the first one untimed)
     from oracle.models import FamilyB
 

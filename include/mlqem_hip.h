@@ -709,6 +709,24 @@ int mlqem_qasm_batch_stream_fill(void* handle, int threads, const int64_t* wire_
  * tables the device indexes. */
 int mlqem_props_gate_tables(const mlqem_backend_props* props, int32_t* g1, int32_t* g2);
 
+/* Device-side expansion of the op stream (all pointers device memory): x[N, F] (row stride ldx >= F; F = 3 + num_slots + 9 (qubit
+ * features) + 2 (gate features)), edge_src / edge_dst[E] as int64 with node offsets applied (the two rows of edge_index, in the
+ * reference's edge order), batch[N] (optional): the arrays mlqem_qasm_batch_fill writes, bit for bit.  ops / wires / patches as
+ * above; node_ptr[B + 1] as from mlqem_qasm_batch_parse; W = wire_ptr[B]; E = edge_ptr[B]; t1 / t2 / readout: the calibration
+ * table as float32 (the rounding the rows get); g1 / g2: mlqem_props_gate_tables; gate_error / gate_length as float32;
+ * num_slots = num_gate_types + 2.  Edges: a stable radix sort of the qubit arguments by (circuit, wire) puts every wire's ops in
+ * program order; neighbours are the endpoints of an edge; a source's out-edges are listed latest-inserted first, as the
+ * reference's DAG hands them back (blackwater/data/utils.py:334-347).  Asynchronous on `stream`;
+ * replaces circuit_to_graph_data_json + ExpValueEntry.to_pyg_data + Batch.from_data_list for a run() of circuits
+ * (blackwater/library/ngem/estimator.py:49-84). */
+size_t mlqem_encode_expand_workspace_bytes(int64_t N, int64_t W);
+int mlqem_encode_expand(const mlqem_op_rec* ops, const uint16_t* wires, const mlqem_x_patch* patches, int64_t num_patches,
+                        const int64_t* node_ptr, int64_t N, int64_t W, int64_t E, int64_t B, int max_wires, const float* t1,
+                        const float* t2, const float* readout, int num_cal_qubits, const int32_t* g1, const int32_t* g2,
+                        const float* gate_error, const float* gate_length, int num_slots, int use_qubit_features,
+                        int use_gate_features, float* x, int64_t ldx, int64_t* edge_src, int64_t* edge_dst, int64_t* batch,
+                        void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+
 /* Circuit-level features of the MLP regressors -- the per-circuit part of encode_data / encode_data_v2_ecr
  * (docs/tutorials/mlp.py:111-145 count_gates_by_rotation_angle, :148-252; == blackwater/library/learning/mlp.py) from
  * the same op scan as the graph encoder (host CPU):

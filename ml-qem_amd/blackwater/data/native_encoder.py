@@ -87,7 +87,7 @@ class NativeEncoder:
         import torch
 
         lib, count = self._lib, len(texts)
-        raw = [t.encode() for t in texts]
+        raw = [t if isinstance(t, bytes) else t.encode() for t in texts]
         arr = (ctypes.c_char_p * max(count, 1))(*raw)
         node_ptr, edge_ptr = np.zeros(count + 1, dtype=np.int64), np.zeros(count + 1, dtype=np.int64)
         depths = np.zeros(max(count, 1), dtype=np.int32)
@@ -172,6 +172,108 @@ class NativeEncoder:
         counts = np.concatenate([np.diff(g[1]) for g in groups]) if groups else np.zeros(0, dtype=np.int64)
         depths = [int(d) for g in groups for d in g[3]]
         return x, ei, batch, counts, depths
+
+    # ------------------------------------------------------------------------------------------------ device-side expansion
+    def _device_tables(self, device):
+        """The calibration tables the expansion kernel indexes, on ``device`` (built once per encoder and device): t1 / t2 / readout /
+        gate_error / gate_length as float32 (the rounding the rows get), g1 / g2 = mlqem_props_gate_tables."""
+        import torch
+
+        key = str(device)
+        tabs = getattr(self, "_tables", None)
+        if tabs is None:
+            tabs = self._tables = {}
+        if key not in tabs:
+            nq, slots = int(self._props.num_qubits), int(self._props.num_gate_types) + 2
+            g1 = np.empty(max(slots * nq, 1), dtype=np.int32)
+            g2 = np.empty(max(slots * nq * nq, 1), dtype=np.int32)
+            code = self._lib.mlqem_props_gate_tables(ctypes.byref(self._props), g1.ctypes.data_as(ctypes.c_void_p), g2.ctypes.data_as(ctypes.c_void_p))
+            if code != 0:
+                self._raise(code)
+            f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32) if len(a) else np.zeros(1, dtype=np.float32)).to(device)
+            tabs[key] = dict(t1=f32(self._t1), t2=f32(self._t2), ro=f32(self._ro), ge=f32(self._ge), gl=f32(self._gl),
+                             g1=torch.from_numpy(g1).to(device), g2=torch.from_numpy(g2).to(device), nq=nq, slots=slots)
+        return tabs[key]
+
+    @staticmethod
+    def _text_pointers(texts):
+        """char* of every text WITHOUT copying it: a ``str`` hands out its cached UTF-8 buffer (for ASCII text -- OpenQASM -- that is
+        the string's own storage), ``bytes`` its buffer.  The caller keeps ``texts`` alive while the pointers are in use."""
+        api = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
+        api.restype, api.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_void_p]
+        arr = (ctypes.c_void_p * max(len(texts), 1))()
+        keep = []
+        for i, t in enumerate(texts):
+            if isinstance(t, str):
+                ptr = api(t, None)
+                if not ptr:
+                    raise ValueError(f"circuit {i}: text cannot be read as UTF-8")
+                arr[i] = ptr
+            else:
+                b = bytes(t)
+                keep.append(b)
+                arr[i] = ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value
+        return arr, keep
+
+    def encode_batch_expand(self, texts, device, threads: int = 0, use_gate_features: bool = True, use_qubit_features: bool = True):
+        """``encode_batch_to_device`` with the rows, edges and offsets made ON THE DEVICE (round 4): the host scans the texts
+        (``mlqem_qasm_batch_parse``) and writes a compact op stream -- 16 bytes per op, 2 per qubit argument
+        (``mlqem_qasm_batch_stream_fill``) -- into pinned memory; ONE upload (0.2 GB for 1024 100-qubit circuits instead of 1.3 GB
+        of float32 rows and int64 indices); ``mlqem_encode_expand`` builds ``x`` [sum N, F] float32, ``edge_index`` [2, sum E] int64
+        (the reference's edge order) and ``batch`` [sum N] int64.  Same arrays as ``encode_batch``, bit for bit."""
+        import torch
+
+        lib, count = self._lib, len(texts)
+        arr, keep = self._text_pointers(texts)
+        node_ptr, edge_ptr = np.zeros(count + 1, dtype=np.int64), np.zeros(count + 1, dtype=np.int64)
+        wire_ptr, patch_ptr = np.zeros(count + 1, dtype=np.int64), np.zeros(count + 1, dtype=np.int64)
+        depths = np.zeros(max(count, 1), dtype=np.int32)
+        handle, f, failed, widest = ctypes.c_void_p(None), ctypes.c_int(0), ctypes.c_int64(-1), ctypes.c_int(0)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        code = lib.mlqem_qasm_batch_parse(arr, count, ctypes.byref(self._props), int(use_qubit_features), int(use_gate_features),
+                                          int(threads), ctypes.byref(handle), vp(node_ptr), vp(edge_ptr), vp(depths), ctypes.byref(f),
+                                          ctypes.byref(failed))
+        if code != 0:
+            self._raise(code)
+        try:
+            code = lib.mlqem_qasm_batch_stream_sizes(handle, vp(wire_ptr), vp(patch_ptr), ctypes.byref(widest))
+            if code != 0:
+                self._raise(code)
+            n, e, w, p = int(node_ptr[-1]), int(edge_ptr[-1]), int(wire_ptr[-1]), int(patch_ptr[-1])
+            # ONE pinned staging buffer: [ops 16 n | patches 12 p | wires 2 w | node_ptr 8 (count + 1)], every part 16-byte aligned
+            up16 = lambda v: (v + 15) // 16 * 16
+            o_ops, o_pat = 0, up16(16 * n)
+            o_wir = o_pat + up16(12 * p)
+            o_ptr = o_wir + up16(2 * w)
+            total = o_ptr + 8 * (count + 1)
+            stage = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+            base = stage.data_ptr()
+            code = lib.mlqem_qasm_batch_stream_fill(handle, int(threads), vp(wire_ptr), vp(patch_ptr), base + o_ops, base + o_wir, base + o_pat)
+            if code != 0:
+                self._raise(code)
+        finally:
+            lib.mlqem_qasm_batch_free(handle)
+        del keep
+        stage[o_ptr:o_ptr + 8 * (count + 1)].view(torch.int64).copy_(torch.from_numpy(node_ptr))
+        dev_stage = stage.to(device, non_blocking=True)
+        tabs = self._device_tables(device)
+        x = torch.empty((n, f.value), dtype=torch.float32, device=device)
+        ei = torch.empty((2, e), dtype=torch.int64, device=device)
+        batch = torch.empty(n, dtype=torch.int64, device=device)
+        need = lib.mlqem_encode_expand_workspace_bytes(n, w)
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=device)
+        d = dev_stage.data_ptr()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        code = lib.mlqem_encode_expand(d + o_ops, d + o_wir, d + o_pat, p, d + o_ptr, n, w, e, count, int(widest.value),
+                                       tabs["t1"].data_ptr(), tabs["t2"].data_ptr(), tabs["ro"].data_ptr(), tabs["nq"],
+                                       tabs["g1"].data_ptr(), tabs["g2"].data_ptr(), tabs["ge"].data_ptr(), tabs["gl"].data_ptr(),
+                                       tabs["slots"], int(use_qubit_features), int(use_gate_features), x.data_ptr(), f.value,
+                                       ei[0].data_ptr() if e else None, ei[1].data_ptr() if e else None, batch.data_ptr(), ws.data_ptr(), need,
+                                       stream)
+        _lib.check(code, "mlqem_encode_expand")
+        # the staging buffers must outlive the asynchronous copy and kernels: record them on the stream
+        dev_stage.record_stream(torch.cuda.current_stream(device))
+        return x, ei, batch, np.diff(node_ptr), depths[:count].tolist()
 
     def _raise(self, code, first: int = 0):
         msg = self._lib.mlqem_encode_last_error().decode()

@@ -132,6 +132,12 @@ SIGNATURES = {
     "mlqem_qasm_batch_parse": (_I, [_P, _L, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "mlqem_qasm_batch_fill": (_I, [_P, _I, _P, _P, _P, _P]),
     "mlqem_qasm_batch_free": (None, [_P]),
+    "mlqem_qasm_batch_stream_sizes": (_I, [_P, _P, _P, _P]),
+    "mlqem_qasm_batch_stream_fill": (_I, [_P, _I, _P, _P, _P, _P, _P]),
+    "mlqem_props_gate_tables": (_I, [_P, _P, _P]),
+    "mlqem_encode_expand_workspace_bytes": (_S, [_L, _L]),
+    "mlqem_encode_expand": (_I, [_P, _P, _P, _L, _P, _L, _L, _L, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P, _P,
+                                 _P, _S, _P]),
     "mlqem_circuit_features_qasm": (_I, [c_char_p, _P, _I, _P, _I, _P, _P]),
     "mlqem_circuit_features_qasm_batch": (_I, [_P, _L, _P, _I, _P, _I, _I, _P, _P, _P]),
 }

@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -681,13 +683,45 @@ void fill(const Circuit& c, const mlqem_backend_props* props, int use_q, int use
 int report(const ParseError& err) { g_last_error = err.what; return err.unsupported ? MLQEM_ERR_UNSUPPORTED : MLQEM_ERR_BAD_ARG; }
 
 // ---- a batch of circuits: parsed and sized by one call, filled into the caller's collated buffers by another -------------
+struct StreamSizes { int64_t wires = 0, patches = 0; };   // qubit arguments and patch slots of a circuit's op stream (see mlqem_qasm_batch_stream_*)
+
 struct Batch {
   std::vector<Circuit> circuits;
   std::vector<std::vector<int>> slots;
   std::vector<Sizes> sizes;
+  std::vector<StreamSizes> stream;          // filled by the parse workers: a serial pass over 11 M ops cost 20 ms of a 30 ms encode
   const mlqem_backend_props* props = nullptr;
   int use_q = 0, use_g = 0;
+  size_t footprint() const {
+    size_t b = 0;
+    for (const Circuit& c : circuits) b += c.ops.capacity() * sizeof(Op) + c.bits.capacity() * sizeof(int) + c.params.capacity() * sizeof(double);
+    return b;
+  }
 };
+
+// ONE parsed batch is kept between calls with its circuits' storage (vectors keep their capacity): the next run() of the same
+// shape parses straight into it -- no exactly-sized copies, no fresh pages (0.4 GB of them per 1024 100-qubit circuits: their
+// page faults serialise on the process's memory map and were what kept 64 threads from scaling).  Bounded: nothing above 2 GB is kept.
+class BatchPool {
+  std::mutex mu_;
+  Batch* kept_ = nullptr;
+ public:
+  Batch* take() {
+    std::lock_guard<std::mutex> lock(mu_);
+    Batch* b = kept_;
+    kept_ = nullptr;
+    return b ? b : new Batch;
+  }
+  void give(Batch* b) {
+    if (!b) return;
+    if (b->footprint() <= (size_t(2) << 30)) {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (!kept_) { kept_ = b; return; }
+    }
+    delete b;
+  }
+};
+BatchPool& batch_pool() { static BatchPool* pool = new BatchPool; return *pool; }
 
 // What a worker needs while it scans circuit after circuit.  Kept in a process-wide pool between calls, so that a run() of a
 // VQE loop (thousands of calls, blackwater/library/ngem/estimator.py:49-84) does not grow half-megabyte vectors from nothing
@@ -718,15 +752,78 @@ class ScratchPool {
 
 ScratchPool& scratch_pool() { static ScratchPool pool; return pool; }
 
-// Worker threads when the caller names none: the host's hardware threads up to 16 (a one-GPU share of this pool's boxes), or
+// Worker threads when the caller names none: the host's hardware threads up to 64 (a text scan is 60 ns per statement per thread,
+// and a 1024-circuit run() of 100-qubit circuits has 11 M statements: 16 threads took 42 ms of an 88 ms run()), or
 // MLQEM_ENCODE_THREADS (1..256) when the deployment knows better.
 int default_threads() {
   if (const char* env = std::getenv("MLQEM_ENCODE_THREADS")) {
     const long v = std::strtol(env, nullptr, 10);
     if (v >= 1 && v <= 256) return (int)v;
   }
-  return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+  return (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency()));
 }
+
+// A process-wide pool of worker threads for the batch entry points.  A run() of a VQE loop calls them thousands of times
+// (blackwater/library/ngem/estimator.py:49-84): starting 64 threads per call cost 3-4 ms of a 30 ms encode.  Workers are started
+// on demand, wait on a condition variable between jobs and live until the process ends; the pool object is never destroyed (a
+// static's destructor would run while workers still wait on its members).  One job at a time (callers queue on `gate`).
+class WorkerPool {
+  std::mutex mu_, gate_;
+  std::condition_variable wake_, done_;
+  std::function<void()> job_;
+  uint64_t generation_ = 0;
+  int wanted_ = 0, running_ = 0;
+  std::vector<std::thread> threads_;
+
+  void loop(int index) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        wake_.wait(lock, [&] { return generation_ != seen && index < wanted_; });
+        seen = generation_;
+        job = job_;
+      }
+      job();
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (--running_ == 0) done_.notify_all();
+      }
+    }
+  }
+
+ public:
+  // runs job() on `helpers` pool threads AND on the calling thread; returns when all have returned.  Fewer helpers than asked
+  // for (the system refused a thread) is not an error: the job is written so that any number of runners finishes it.
+  void run(int helpers, const std::function<void()>& job) {
+    std::lock_guard<std::mutex> one_job(gate_);
+    int started = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      try {
+        while ((int)threads_.size() < helpers) {
+          const int index = (int)threads_.size();
+          threads_.emplace_back([this, index] { loop(index); });
+          threads_.back().detach();
+        }
+      } catch (const std::exception&) {}
+      started = std::min<int>(helpers, (int)threads_.size());
+      job_ = job;
+      wanted_ = started;
+      running_ = started;
+      ++generation_;
+    }
+    if (started > 0) wake_.notify_all();
+    job();
+    std::unique_lock<std::mutex> lock(mu_);
+    done_.wait(lock, [&] { return running_ == 0; });
+    wanted_ = 0;
+    job_ = nullptr;
+  }
+};
+
+WorkerPool& worker_pool() { static WorkerPool* pool = new WorkerPool; return *pool; }
 
 // fn(i, scratch) for i in [0, count) on `threads` host threads; the first failure (lowest index wins among those seen) is kept
 template <typename Fn>
@@ -757,17 +854,7 @@ int for_each_parallel(int64_t count, int threads, int64_t* failed, Fn fn) {
     }
   };
   if (threads == 1) worker();
-  else {
-    // the caller's thread is one of the workers; if the system refuses a thread the ones that did start (and this one) finish
-    // the job -- a vector of joinable threads must never be destroyed (std::terminate)
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)threads - 1);
-    try {
-      for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
-    } catch (const std::exception&) {}
-    worker();
-    for (auto& t : pool) t.join();
-  }
+  else worker_pool().run(threads - 1, worker);       // the caller's thread is one of the workers
   if (code != MLQEM_OK) { g_last_error = "circuit " + std::to_string(bad) + ": " + message; if (failed) *failed = bad; }
   return code;
 }
@@ -807,6 +894,36 @@ extern "C" int mlqem_encode_qasm(const char* qasm, const mlqem_backend_props* pr
   }
 }
 
+namespace {
+
+// does any calibration key start with "<name>_"?  (a slot without one never needs a lookup)
+std::vector<char> slots_with_calibration(const mlqem_backend_props* props) {
+  const int n_slots = props->num_gate_types + 2;
+  std::vector<char> any((size_t)n_slots, 0);
+  auto name_of = [&](int slot) -> std::string {
+    if (slot < props->num_gate_types) return props->gate_names[slot];
+    return slot == props->num_gate_types ? "barrier" : "measure";
+  };
+  for (int slot = 0; slot < n_slots; ++slot) {
+    const std::string pre = name_of(slot) + "_";
+    for (int i = 0; i < props->num_gate_props && !any[slot]; ++i)
+      if (std::strncmp(props->gate_keys[i], pre.c_str(), pre.size()) == 0) any[slot] = 1;
+  }
+  return any;
+}
+
+StreamSizes stream_sizes(const Circuit& c, const std::vector<int>& slot_of, const std::vector<char>& calibrated, int use_g) {
+  StreamSizes sz;
+  for (const Op& op : c.ops) {
+    sz.wires += op.q_cnt;
+    if (op.p_cnt > 1) sz.patches += op.p_cnt - 1;
+    if (use_g && op.q_cnt > 2 && calibrated[(size_t)slot_of[op.type]]) sz.patches += 2;     // at most: error and length, if the key exists
+  }
+  return sz;
+}
+
+}  // namespace
+
 extern "C" int mlqem_qasm_batch_parse(const char* const* qasm, int64_t count, const mlqem_backend_props* props,
                                       int use_qubit_features, int use_gate_features, int threads, void** handle,
                                       int64_t* node_ptr, int64_t* edge_ptr, int* depths, int* num_features, int64_t* failed) {
@@ -816,16 +933,18 @@ extern "C" int mlqem_qasm_batch_parse(const char* const* qasm, int64_t count, co
   for (int64_t i = 0; i < count; ++i) if (!qasm[i]) return MLQEM_ERR_BAD_ARG;
   Batch* b = nullptr;
   try {
-    b = new Batch;
+    b = batch_pool().take();
     b->circuits.resize((size_t)count); b->slots.resize((size_t)count); b->sizes.resize((size_t)count);
     b->props = props; b->use_q = use_qubit_features; b->use_g = use_gate_features;
+    b->stream.resize((size_t)count);
+    const std::vector<char> calibrated = slots_with_calibration(props);
     const int rc = for_each_parallel(count, threads, failed, [&](int64_t i, WorkerScratch& w) {
-      parse_qasm(qasm[i], w.circuit, w.text_a, w.text_b);
-      b->circuits[i] = w.circuit.compact();
+      parse_qasm(qasm[i], b->circuits[i], w.text_a, w.text_b);       // into the kept circuit: its vectors' capacity is reused
       b->slots[i] = type_slots(b->circuits[i], props);
       b->sizes[i] = scan(b->circuits[i], props, use_qubit_features, b->slots[i], nullptr, w.wires);
+      b->stream[i] = stream_sizes(b->circuits[i], b->slots[i], calibrated, use_gate_features);
     });
-    if (rc != MLQEM_OK) { delete b; return rc; }
+    if (rc != MLQEM_OK) { batch_pool().give(b); return rc; }
     node_ptr[0] = edge_ptr[0] = 0;
     for (int64_t i = 0; i < count; ++i) {
       node_ptr[i + 1] = node_ptr[i] + b->sizes[i].N;
@@ -874,48 +993,19 @@ extern "C" int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_
 // Values the record has no room for (second / third parameters, calibration entries of three-qubit gates) travel as patches.
 namespace {
 
-struct StreamSizes { int64_t wires = 0, patches = 0; };
-
-// does any calibration key start with "<name>_"?  (a slot without one never needs a lookup)
-std::vector<char> slots_with_calibration(const mlqem_backend_props* props) {
-  const int n_slots = props->num_gate_types + 2;
-  std::vector<char> any((size_t)n_slots, 0);
-  auto name_of = [&](int slot) -> std::string {
-    if (slot < props->num_gate_types) return props->gate_names[slot];
-    return slot == props->num_gate_types ? "barrier" : "measure";
-  };
-  for (int slot = 0; slot < n_slots; ++slot) {
-    const std::string pre = name_of(slot) + "_";
-    for (int i = 0; i < props->num_gate_props && !any[slot]; ++i)
-      if (std::strncmp(props->gate_keys[i], pre.c_str(), pre.size()) == 0) any[slot] = 1;
-  }
-  return any;
-}
-
-StreamSizes stream_sizes(const Circuit& c, const std::vector<int>& slot_of, const std::vector<char>& calibrated, int use_g) {
-  StreamSizes sz;
-  for (const Op& op : c.ops) {
-    sz.wires += op.q_cnt;
-    if (op.p_cnt > 1) sz.patches += op.p_cnt - 1;
-    if (use_g && op.q_cnt > 2 && calibrated[(size_t)slot_of[op.type]]) sz.patches += 2;     // at most: error and length, if the key exists
-  }
-  return sz;
-}
-
 }  // namespace
 
 extern "C" int mlqem_qasm_batch_stream_sizes(void* handle, int64_t* wire_ptr, int64_t* patch_ptr, int* max_wires) {
   Batch* b = static_cast<Batch*>(handle);
   if (!b || !wire_ptr || !patch_ptr) { g_last_error = "no batch handle or output"; return MLQEM_ERR_BAD_ARG; }
   try {
-    const std::vector<char> calibrated = slots_with_calibration(b->props);
     const int64_t count = (int64_t)b->circuits.size();
     wire_ptr[0] = patch_ptr[0] = 0;
     int widest = 0;
     for (int64_t i = 0; i < count; ++i) {
       const Circuit& c = b->circuits[i];
       if (c.nq > 65535 || b->props->num_qubits > 65535) { g_last_error = "more than 65535 wires: the op stream holds 16-bit indices"; return MLQEM_ERR_UNSUPPORTED; }
-      const StreamSizes sz = stream_sizes(c, b->slots[i], calibrated, b->use_g);
+      const StreamSizes sz = b->stream[i];
       wire_ptr[i + 1] = wire_ptr[i] + sz.wires;
       patch_ptr[i + 1] = patch_ptr[i] + sz.patches;
       widest = std::max(widest, c.nq);
@@ -1029,7 +1119,7 @@ extern "C" int mlqem_props_gate_tables(const mlqem_backend_props* props, int32_t
   }
 }
 
-extern "C" void mlqem_qasm_batch_free(void* handle) { delete static_cast<Batch*>(handle); }
+extern "C" void mlqem_qasm_batch_free(void* handle) { batch_pool().give(static_cast<Batch*>(handle)); }
 
 // Circuit-level features of the MLP regressors (docs/tutorials/mlp.py:111-145, 148-252): by-products of the same op scan.
 namespace {
