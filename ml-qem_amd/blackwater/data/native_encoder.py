@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Any, Dict, Tuple
 
 import numpy as np
@@ -221,10 +222,16 @@ class NativeEncoder:
         (``mlqem_qasm_batch_stream_fill``) -- into pinned memory; ONE upload (0.2 GB for 1024 100-qubit circuits instead of 1.3 GB
         of float32 rows and int64 indices); ``mlqem_encode_expand`` builds ``x`` [sum N, F] float32, ``edge_index`` [2, sum E] int64
         (the reference's edge order) and ``batch`` [sum N] int64.  Same arrays as ``encode_batch``, bit for bit."""
+        import time
+
         import torch
 
+        trace = [] if os.environ.get("MLQEM_ENCODE_TRACE") else None       # phase times of this call, printed at its end
+        mark = (lambda name: trace.append((name, time.perf_counter()))) if trace is not None else (lambda name: None)
+        mark("start")
         lib, count = self._lib, len(texts)
         arr, keep = self._text_pointers(texts)
+        mark("pointers")
         node_ptr, edge_ptr = np.zeros(count + 1, dtype=np.int64), np.zeros(count + 1, dtype=np.int64)
         wire_ptr, patch_ptr = np.zeros(count + 1, dtype=np.int64), np.zeros(count + 1, dtype=np.int64)
         depths = np.zeros(max(count, 1), dtype=np.int32)
@@ -235,6 +242,7 @@ class NativeEncoder:
                                           ctypes.byref(failed))
         if code != 0:
             self._raise(code)
+        mark("parse")
         try:
             code = lib.mlqem_qasm_batch_stream_sizes(handle, vp(wire_ptr), vp(patch_ptr), ctypes.byref(widest))
             if code != 0:
@@ -246,22 +254,27 @@ class NativeEncoder:
             o_wir = o_pat + up16(12 * p)
             o_ptr = o_wir + up16(2 * w)
             total = o_ptr + 8 * (count + 1)
+            mark("sizes")
             stage = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+            mark("pinned buffer")
             base = stage.data_ptr()
             code = lib.mlqem_qasm_batch_stream_fill(handle, int(threads), vp(wire_ptr), vp(patch_ptr), base + o_ops, base + o_wir, base + o_pat)
             if code != 0:
                 self._raise(code)
         finally:
             lib.mlqem_qasm_batch_free(handle)
+        mark("stream fill")
         del keep
         stage[o_ptr:o_ptr + 8 * (count + 1)].view(torch.int64).copy_(torch.from_numpy(node_ptr))
         dev_stage = stage.to(device, non_blocking=True)
+        mark("upload enqueued")
         tabs = self._device_tables(device)
         x = torch.empty((n, f.value), dtype=torch.float32, device=device)
         ei = torch.empty((2, e), dtype=torch.int64, device=device)
         batch = torch.empty(n, dtype=torch.int64, device=device)
         need = lib.mlqem_encode_expand_workspace_bytes(n, w)
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=device)
+        mark("device buffers")
         d = dev_stage.data_ptr()
         stream = torch.cuda.current_stream(device).cuda_stream
         code = lib.mlqem_encode_expand(d + o_ops, d + o_wir, d + o_pat, p, d + o_ptr, n, w, e, count, int(widest.value),
@@ -273,6 +286,11 @@ class NativeEncoder:
         _lib.check(code, "mlqem_encode_expand")
         # the staging buffers must outlive the asynchronous copy and kernels: record them on the stream
         dev_stage.record_stream(torch.cuda.current_stream(device))
+        if trace is not None:
+            mark("expand enqueued")
+            torch.cuda.synchronize(device)
+            mark("device done")
+            print("encode_batch_expand: " + ", ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.1f} ms" for a, b in zip(trace[:-1], trace[1:])), flush=True)
         return x, ei, batch, np.diff(node_ptr), depths[:count].tolist()
 
     def _raise(self, code, first: int = 0):

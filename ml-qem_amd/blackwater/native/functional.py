@@ -755,12 +755,16 @@ class _ASAPool(Function):
                 # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
                 csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
                 num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
-            elif use_rows and use_lists and len(keep) > 0 and int(keep.max()) <= ops.asap_lists_max_k():
-                # large graphs: per-node cluster lists, persistent waves, a cluster's rows as LDS bitsets read out as sorted lists;
-                # no host read when the structure carries a capacity
-                csr, slot, num_edges = ops.asap_coarsen_lists(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm,
-                                                              n, s.edge_count(), keep, capacity=getattr(s, "coarse_capacity", None),
-                                                              link=link)
+            done = None
+            if not dense_ok and use_rows and use_lists and len(keep) > 0 and int(keep.max()) <= ops.asap_lists_max_k():
+                # large graphs: per-node cluster lists, a thread per cluster gathers its candidates, persistent waves sort them through
+                # LDS bitsets; no host read when the structure carries a capacity.  None: too many candidates for this form
+                done = ops.asap_coarsen_lists(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, s.edge_count(), keep,
+                                              capacity=getattr(s, "coarse_capacity", None), link=link)
+            if dense_ok:
+                pass
+            elif done is not None:
+                csr, slot, num_edges = done
             elif (use_rows and len(keep) > 0
                   and int(sizes.max()) + 2 * int(keep.max()) + 96 <= ops.asap_rows_max_bits()):
                 # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)

@@ -1229,7 +1229,8 @@ def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
     cluster lists built once, one walk per cluster by persistent waves, nothing dense in global memory, the twin links by binary
     search.  ``num_edges``: stored edges of the input structure (or a bound).  ``capacity``: a bound on the four list totals and on
     the edge total (GraphArena.coarse_capacity); without it the totals are read back (one 32-byte device->host copy, then the
-    4-byte edge total).  Returns (CsrArrays, slot, edge capacity)."""
+    4-byte edge total).  Returns (CsrArrays, slot, edge capacity), or None when the candidate lists would exceed
+    ``ASAP_LISTS_MAX_CAPACITY`` entries (the caller then takes another form)."""
     import numpy as np
 
     keep = np.asarray(keep_sizes, dtype=np.int64)
@@ -1253,6 +1254,10 @@ def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
             cap = 0
     else:
         cap = int(capacity) if k > 0 else 0
+    if cap >= ASAP_LISTS_MAX_CAPACITY:
+        # a graph whose clusters have thousands of candidates each (the coarsening of an already coarsened graph: rows of hundreds of
+        # entries, three hops deep): the candidate lists would not fit 32-bit places -- the caller takes the bit-matrix form
+        return None
     e = cap
     need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, int(num_edges), cap)
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
@@ -1270,6 +1275,9 @@ def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
                                                  _p(out_eid), e, None, _p(ws), need, _stream())
         _lib.check(code, "mlqem_asap_coarsen_lists_fill")
     return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], None if out_eid is None else out_eid[:e]), slot, e
+
+
+ASAP_LISTS_MAX_CAPACITY = 1 << 32      # entries per list buffer the list form addresses (32-bit places in its per-node records)
 
 
 def asap_lists_max_k() -> int:

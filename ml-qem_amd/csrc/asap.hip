@@ -303,6 +303,22 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ int64_t wave_excl_scan64(int64_t v, int lane) {
+  int64_t s = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int64_t t = __shfl_up(s, o);
+    if (lane >= o) s += t;
+  }
+  return s - v;
+}
+
+// The same for a wave that has global loads in flight it does not want to wait for (a software pipeline): LDS traffic only.
+__device__ __forceinline__ void wave_lds_only_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 constexpr int kRowsLight = 16;   // degree up to which a lane walks a node's edges alone
 
 // Every lane brings one node (or none); f(w) is called for the node itself and for every w in its neighbourhood in the CSR
@@ -482,7 +498,6 @@ struct ListsArgs {
   int32_t* tmp_o; int32_t* tmp_i; int64_t tmp_cap;
   int32_t* outdeg; int32_t* indeg;   // [K + 1]
   int32_t* overflow;             // != 0: a list left its storage (the caller's capacity was no bound)
-  int skip;                      // measurement switch (MLQEM_LISTS_SKIP; 0 in production): parts of the walk left out
 };
 
 constexpr int kReachClamp = 1 << 28;   // two-hop degree sums saturate here (a row bound is clamped to k_g - 1 anyway)
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void coarsen_reach_kernel(const int32_t* __
   }
 }
 
-// cap_o[p] >= |row p|, cap_i[p] >= |row p of the transpose|: sums of h over N-[c_p], clamped to k_g - 1; entry K is 0
+// cap_o[p] >= the candidates of row p, cap_i[p] >= those of row p of the transpose: sums of h over N-[c_p]; entry K is 0
 __global__ __launch_bounds__(kBlock) void coarsen_row_caps_kernel(const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_src,
                                                                   const int32_t* __restrict__ perm, const int32_t* __restrict__ new_gptr,
                                                                   int B, int64_t K, const int64_t* __restrict__ h_out,
@@ -545,10 +560,8 @@ __global__ __launch_bounds__(kBlock) void coarsen_row_caps_kernel(const int32_t*
   const int64_t so = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return h_out[u]; });
   const int64_t si = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return h_in[u]; });
   if (has) {
-    const int g = graph_at(new_gptr, B, p);
-    const int64_t most = (int64_t)(new_gptr[g + 1] - new_gptr[g]) - 1;
-    cap_o[p] = min(so, most);
-    cap_i[p] = min(si, most);
+    cap_o[p] = so;                 // room for the row's CANDIDATES (duplicates and all): the sorted row is written over them
+    cap_i[p] = si;
   } else if (p == K) {
     cap_o[K] = 0;
     cap_i[K] = 0;
@@ -647,35 +660,97 @@ __global__ __launch_bounds__(kBlock) void coarsen_rlists_kernel(const int32_t* _
   }
 }
 
-// Y |= the clusters of the lists R(u), Z |= those of R'(u), u in {c} + N-[c], without `self` (bits local to the graph).
-// A lane brings one u and its record {place and length of R(u), of R'(u)}; lists of up to kRowsLight entries are fetched WHOLE
-// before the first bit is set -- a loop that loads an entry, sets its bit and only then loads the next pays a memory round trip per
-// entry, and a persistent wave has nothing else to hide it behind (this was 17 us per cluster) -- longer ones (a hub's) are read
-// by the whole wave, coalesced.
+// Per-node record: place and length of R(u), place and length of R'(u)
 struct RInfo { uint32_t off_o, cnt_o, off_i, cnt_i; };
+// Per-cluster record of the gather pass: place and length of the row's candidates, the same for the transposed row
+struct CInfo { uint32_t off_o, cnt_o, off_i, cnt_i; };
 
-__device__ __forceinline__ void lists_or(const int32_t* __restrict__ rlist, int64_t rb, int rn, bool light, int k0, int self, uint32_t* S,
-                                         int lane) {
-  int qs[kRowsLight];
+// GATHER: the candidates of a cluster's two rows -- the lists R(u) / R'(u) of u in {c} + N-[c], one after the other, duplicates and
+// the cluster itself included -- copied to the row's place in the scratch.  A THREAD per cluster: the pass is a chain of dependent
+// gathers (perm -> in_ptr -> in_src -> record -> list), which a wave per cluster paid in full for every cluster (12 us each);
+// here 363 k of them are in flight at once.  Lists longer than kRowsLight (a hub's) and clusters with many members (a hub's own)
+// are copied by the whole wave.
+__device__ __forceinline__ void gather_lists(const int32_t* __restrict__ rlist, uint32_t rb, uint32_t rn, bool has, int32_t* __restrict__ out,
+                                             int64_t at, int64_t cap, int lane) {
+  const bool light = rn <= (uint32_t)kRowsLight;
+  if (has && light && at + rn <= cap) {
+    int qs[kRowsLight];
 #pragma unroll
-  for (int j = 0; j < kRowsLight; ++j) qs[j] = (light && j < rn) ? rlist[rb + j] : -1;
+    for (int j = 0; j < kRowsLight; ++j) qs[j] = j < (int)rn ? rlist[rb + j] : 0;
 #pragma unroll
-  for (int j = 0; j < kRowsLight; ++j)
-    if (qs[j] >= 0 && qs[j] != self) atomicOr(&S[(qs[j] - k0) >> 5], 1u << ((qs[j] - k0) & 31));
-  unsigned long long todo = __ballot(!light && rn > 0);
+    for (int j = 0; j < kRowsLight; ++j) if (j < (int)rn) out[at + j] = qs[j];
+  }
+  // long lists: by all the lanes that are here together (the caller may be inside a loop only some lanes of the wave still run:
+  // a lane's share is its rank among them)
+  const unsigned long long here = __ballot(true);
+  const int rank = __popcll(here & ((1ull << lane) - 1ull)), width = __popcll(here);
+  unsigned long long todo = __ballot(has && !light);
   while (todo) {
     const int owner = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
-    const int64_t b = __shfl(rb, owner);
-    const int m = __shfl(rn, owner);
-    for (int j = lane; j < m; j += 64) {
-      const int q = rlist[b + j];
-      if (q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31));
-    }
+    const uint32_t b = __shfl(rb, owner), m = __shfl(rn, owner);
+    const int64_t o = __shfl(at, owner);
+    if (o + m <= cap)
+      for (uint32_t j = rank; j < m; j += width) out[o + j] = rlist[b + j];
   }
 }
 
-__global__ __launch_bounds__(kBlock) void coarsen_lists_kernel(const ListsArgs a) {
+__global__ __launch_bounds__(kBlock) void coarsen_gather_kernel(const ListsArgs a, uint32_t* __restrict__ cinfo) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool has = p < a.K;
+  const RInfo* __restrict__ rinfo = reinterpret_cast<const RInfo*>(a.rinfo);
+  int c = 0, ib = 0, ie = 0;
+  int64_t bo = 0, bi = 0;
+  if (has) { c = a.perm[p]; ib = a.in_ptr[c]; ie = a.in_ptr[c + 1]; bo = a.off_o[p]; bi = a.off_i[p]; }
+  int64_t no = 0, ni = 0;
+  const bool wide = has && ie - ib > kRowsLight;          // many members (the cluster of a hub): its wave walks them together
+  if (has && !wide)
+    for (int i = ib - 1; i < ie; ++i) {                   // index ib - 1 stands for c itself
+      const int u = i < ib ? c : a.in_src[i];
+      const RInfo r = rinfo[u];
+      gather_lists(a.r_o, r.off_o, r.cnt_o, true, a.tmp_o, bo + no, a.tmp_cap, lane);
+      gather_lists(a.r_i, r.off_i, r.cnt_i, true, a.tmp_i, bi + ni, a.tmp_cap, lane);
+      no += r.cnt_o; ni += r.cnt_i;
+    }
+  unsigned long long todo = __ballot(wide);
+  while (todo) {
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int oc = __shfl(c, owner), ob = __shfl(ib, owner), oe = __shfl(ie, owner);
+    int64_t wo = __shfl(bo, owner), wi = __shfl(bi, owner);
+    int64_t so = 0, si = 0;
+    for (int i0 = ob - 1; i0 < oe; i0 += 64) {
+      const int i = i0 + lane;
+      const bool mine = i < oe;
+      const int u = mine ? (i < ob ? oc : a.in_src[i]) : 0;
+      RInfo r{0u, 0u, 0u, 0u};
+      if (mine) r = rinfo[u];
+      // places of this lane's two lists: wave scans of the lengths
+      const int64_t eo = wave_excl_scan64((int64_t)r.cnt_o, lane), ei2 = wave_excl_scan64((int64_t)r.cnt_i, lane);
+      gather_lists(a.r_o, r.off_o, r.cnt_o, mine, a.tmp_o, wo + so + eo, a.tmp_cap, lane);
+      gather_lists(a.r_i, r.off_i, r.cnt_i, mine, a.tmp_i, wi + si + ei2, a.tmp_cap, lane);
+      so += __shfl(eo + (int64_t)r.cnt_o, 63);
+      si += __shfl(ei2 + (int64_t)r.cnt_i, 63);
+    }
+    if (lane == owner) { no = so; ni = si; }
+  }
+  if (has) {
+    const bool fits = bo + no <= a.tmp_cap && bi + ni <= a.tmp_cap && no < (1ll << 32) && ni < (1ll << 32);
+    cinfo[p * 4 + 0] = (uint32_t)bo; cinfo[p * 4 + 1] = fits ? (uint32_t)no : 0u;
+    cinfo[p * 4 + 2] = (uint32_t)bi; cinfo[p * 4 + 3] = fits ? (uint32_t)ni : 0u;
+    if (!fits) atomicOr(a.overflow, 1);
+  }
+}
+
+// UNIQUE: a persistent wave per cluster turns the two candidate lists into sorted lists without duplicates, IN PLACE: every
+// candidate sets a bit of an LDS bitset (k_g bits), the bitsets are read out in ascending order by lanes that own runs of words
+// (ONE wave scan of packed counts per cluster) and cleared on the way.  The pass streams: a cluster's record and its first 64
+// candidates per side are fetched while the previous cluster is in the LDS (the records two clusters ahead), so the wave never
+// waits on a chain of gathers.
+struct UniqueMeta { CInfo c; int k0, Wk; };
+
+__global__ __launch_bounds__(kBlock) void coarsen_unique_kernel(const ListsArgs a, const uint32_t* __restrict__ cinfo_raw) {
   extern __shared__ uint32_t s_bits[];              // per wave: Y [Wk], Z [Wk]
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -683,27 +758,37 @@ __global__ __launch_bounds__(kBlock) void coarsen_lists_kernel(const ListsArgs a
   uint32_t* Z = Y + a.Wk;
   for (int i = lane; i < 2 * a.Wk; i += 64) Y[i] = 0u;     // once per wave: every cluster leaves its region as it found it
   wave_lds_sync();
-  const RInfo* __restrict__ rinfo = reinterpret_cast<const RInfo*>(a.rinfo);
+  const CInfo* __restrict__ cinfo = reinterpret_cast<const CInfo*>(cinfo_raw);
   const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t p = (int64_t)blockIdx.x * 4 + wid; p < a.K; p += stride) {     // wave-uniform; every wave reaches the end
-    const int c = a.perm[p];
-    const int g = graph_at(a.new_gptr, a.B, p);
-    const int k0 = a.new_gptr[g];
-    const int Wk = (a.new_gptr[g + 1] - k0 + 31) >> 5;
-    const int ib = a.in_ptr[c], ie = a.in_ptr[c + 1];
-    const int64_t bo = a.off_o[p], bi = a.off_i[p];
-    for (int i0 = ib - 1; i0 < ie; i0 += 64) {        // index ib - 1 stands for c itself
-      const int i = i0 + lane;
-      const bool has = i < ie;
-      const int u = has ? (i < ib ? c : a.in_src[i]) : 0;
-      RInfo r{0u, 0u, 0u, 0u};
-      if (a.skip & 1) continue;
-      if (has) r = rinfo[u];
-      if (a.skip & 2) { if (r.cnt_o == 0xFFFFFFFFu) Y[0] = 1u; continue; }
-      lists_or(a.r_o, (int64_t)r.off_o, (int)r.cnt_o, r.cnt_o <= (uint32_t)kRowsLight, k0, (int)p, Y, lane);     // row p
-      lists_or(a.r_i, (int64_t)r.off_i, (int)r.cnt_i, r.cnt_i <= (uint32_t)kRowsLight, k0, (int)p, Z, lane);     // row p of the transpose
+  auto meta_of = [&](int64_t p) {
+    UniqueMeta m{{0u, 0u, 0u, 0u}, 0, 0};
+    if (p < a.K) {
+      m.c = cinfo[p];
+      const int g = graph_at(a.new_gptr, a.B, p);
+      m.k0 = a.new_gptr[g];
+      m.Wk = (a.new_gptr[g + 1] - m.k0 + 31) >> 5;
     }
-    wave_lds_sync();
+    return m;
+  };
+  auto first_of = [&](const UniqueMeta& m, int& qo, int& qi) {       // the first 64 candidates of either side, -1 past the end
+    qo = lane < (int)m.c.cnt_o ? a.tmp_o[(int64_t)m.c.off_o + lane] : -1;
+    qi = lane < (int)m.c.cnt_i ? a.tmp_i[(int64_t)m.c.off_i + lane] : -1;
+  };
+  int64_t p = (int64_t)blockIdx.x * 4 + wid;
+  UniqueMeta m0 = meta_of(p), m1 = meta_of(p + stride);
+  int qo0, qi0;
+  first_of(m0, qo0, qi0);
+  for (; p < a.K; p += stride) {                      // wave-uniform; every wave reaches the end
+    const UniqueMeta m2 = meta_of(p + 2 * stride);    // in flight while this cluster is in the LDS
+    int qo1, qi1;
+    first_of(m1, qo1, qi1);
+    const int k0 = m0.k0, Wk = m0.Wk, self = (int)p;
+    auto mark = [&](uint32_t* S, int q) { if (q >= 0 && q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31)); };
+    mark(Y, qo0);
+    mark(Z, qi0);
+    for (uint32_t j = 64 + lane; j < m0.c.cnt_o; j += 64) mark(Y, a.tmp_o[(int64_t)m0.c.off_o + j]);     // a long row's remaining candidates
+    for (uint32_t j = 64 + lane; j < m0.c.cnt_i; j += 64) mark(Z, a.tmp_i[(int64_t)m0.c.off_i + j]);
+    wave_lds_only_sync();                             // the next cluster's candidates stay in flight
     // read both bitsets out in ascending order: lane l owns words [l cw, (l + 1) cw); one scan of the packed counts (a row
     // has fewer than 65 536 entries: k_g <= 65 535)
     const int cw = (Wk + 63) >> 6;
@@ -713,22 +798,20 @@ __global__ __launch_bounds__(kBlock) void coarsen_lists_kernel(const ListsArgs a
     const int packed = (int)(ny | (nz << 16));
     const int ex = wave_excl_scan(packed, lane);
     const unsigned tot = (unsigned)__shfl(ex + packed, 63);
-    const int deg_o = (int)(tot & 0xFFFFu), deg_i = (int)(tot >> 16);
-    int64_t po = bo + (int)((unsigned)ex & 0xFFFFu), pi = bi + (int)((unsigned)ex >> 16);
-    const bool fits = bo + deg_o <= a.tmp_cap && bi + deg_i <= a.tmp_cap && !(a.skip & 4);      // wave-uniform
-    for (int w = w_lo; w < w_hi; ++w) {
+    int64_t po = (int64_t)m0.c.off_o + (int)((unsigned)ex & 0xFFFFu), pi = (int64_t)m0.c.off_i + (int)((unsigned)ex >> 16);
+    for (int w = w_lo; w < w_hi; ++w) {               // sorted, duplicate-free, over the candidates they came from (never longer)
       uint32_t yb = Y[w], zb = Z[w];
       Y[w] = 0u; Z[w] = 0u;
       const int first = k0 + w * 32;
-      while (yb) { const int b = __ffs((int)yb) - 1; yb &= yb - 1; if (fits) a.tmp_o[po] = first + b; ++po; }
-      while (zb) { const int b = __ffs((int)zb) - 1; zb &= zb - 1; if (fits) a.tmp_i[pi] = first + b; ++pi; }
+      while (yb) { const int b = __ffs((int)yb) - 1; yb &= yb - 1; a.tmp_o[po++] = first + b; }
+      while (zb) { const int b = __ffs((int)zb) - 1; zb &= zb - 1; a.tmp_i[pi++] = first + b; }
     }
     if (lane == 0) {
-      a.outdeg[p] = fits ? deg_o : 0;
-      a.indeg[p] = fits ? deg_i : 0;
-      if (!fits) atomicOr(a.overflow, 1);
+      a.outdeg[p] = (int)(tot & 0xFFFFu);
+      a.indeg[p] = (int)(tot >> 16);
     }
-    wave_lds_sync();
+    wave_lds_only_sync();
+    m0 = m1; m1 = m2; qo0 = qo1; qi0 = qi1;
   }
 }
 
@@ -1081,13 +1164,13 @@ ListsLayout lists_layout(int64_t N, int64_t K, int64_t E, int64_t capacity) {
   l.flag = 256;
   l.scan = lists_scan_bytes(std::max(N, K));
   l.lists = up((size_t)std::max<int64_t>(capacity, 1) * sizeof(int32_t));
-  l.total = 4 * l.h + 5 * l.ncnt + l.clist + 4 * l.caps + 2 * l.degs + l.flag + l.scan + 4 * l.lists;
+  l.total = 4 * l.h + 5 * l.ncnt + l.clist + 4 * l.caps + 6 * l.degs + l.flag + l.scan + 4 * l.lists;
   return l;
 }
 
 struct ListsPointers {
   int64_t* h_out; int64_t* h_in; int64_t* roff_o; int64_t* roff_i; int32_t* ccnt; uint32_t* rinfo; int32_t* clist;
-  int64_t* cap_o; int64_t* cap_i; int64_t* off_o; int64_t* off_i; int32_t* outdeg; int32_t* indeg; int32_t* flag; void* scan;
+  int64_t* cap_o; int64_t* cap_i; int64_t* off_o; int64_t* off_i; int32_t* outdeg; int32_t* indeg; uint32_t* cinfo; int32_t* flag; void* scan;
   int32_t* r_o; int32_t* r_i; int32_t* tmp_o; int32_t* tmp_i;
 };
 ListsPointers lists_pointers(void* workspace, const ListsLayout& l) {
@@ -1107,6 +1190,7 @@ ListsPointers lists_pointers(void* workspace, const ListsLayout& l) {
   q.off_i = reinterpret_cast<int64_t*>(take(l.caps));
   q.outdeg = reinterpret_cast<int32_t*>(take(l.degs));
   q.indeg = reinterpret_cast<int32_t*>(take(l.degs));
+  q.cinfo = reinterpret_cast<uint32_t*>(take(4 * l.degs));          // [K][4]: 16-byte records
   q.flag = reinterpret_cast<int32_t*>(take(l.flag));
   q.scan = take(l.scan);
   q.r_o = reinterpret_cast<int32_t*>(take(l.lists));
@@ -1210,16 +1294,16 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
   hipLaunchKernelGGL(coarsen_rlists_kernel<true>, dim3(node_blocks), dim3(kBlock), 0, stream, in_ptr, in_src, out_ptr, q.clist, q.ccnt, N,
                      q.roff_i, q.r_i, capacity, q.rinfo, q.flag);
   ListsArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, N, K, (kmax + 31) / 32,
-              q.rinfo, q.r_o, q.r_i, capacity, q.off_o, q.off_i, q.tmp_o, q.tmp_i, capacity, q.outdeg, q.indeg, q.flag,
-              getenv("MLQEM_LISTS_SKIP") ? atoi(getenv("MLQEM_LISTS_SKIP")) : 0};
+              q.rinfo, q.r_o, q.r_i, capacity, q.off_o, q.off_i, q.tmp_o, q.tmp_i, capacity, q.outdeg, q.indeg, q.flag};
+  hipLaunchKernelGGL(coarsen_gather_kernel, dim3((unsigned)ceil_div(K, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, q.cinfo);
   const size_t lds = (size_t)4 * 2 * a.Wk * sizeof(uint32_t);
-  static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(coarsen_lists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(coarsen_unique_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               kListsMaxLds) == hipSuccess ? 1 : 0;
   if (!once) return MLQEM_ERR_LAUNCH;
   // persistent waves: as many workgroups as the LDS lets a CU hold (at most 8: 32 waves), never more than there are clusters
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kListsMaxLds / std::max<size_t>(lds, 1)));
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(K, (int64_t)4), (int64_t)device_cus() * per_cu));
-  hipLaunchKernelGGL(coarsen_lists_kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+  hipLaunchKernelGGL(coarsen_unique_kernel, dim3(grid), dim3(kBlock), lds, stream, a, q.cinfo);
   size_t temp_bytes = l.scan;
   if (rocprim::exclusive_scan(q.scan, temp_bytes, q.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(), stream) !=
       hipSuccess)

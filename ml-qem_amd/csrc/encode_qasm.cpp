@@ -13,6 +13,7 @@
 #include <cctype>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
@@ -690,6 +691,12 @@ struct Batch {
   std::vector<std::vector<int>> slots;
   std::vector<Sizes> sizes;
   std::vector<StreamSizes> stream;          // filled by the parse workers: a serial pass over 11 M ops cost 20 ms of a 30 ms encode
+  // circuits / slots / sizes / stream hold ONE entry per DISTINCT text of the run(): entry u_of[i] stands for circuit i.  A run()
+  // often names one circuit many times -- the reference's VQE drivers evaluate every Pauli term of a Hamiltonian as its own
+  // (circuit, observable) pair of the SAME bound circuit (separate_observables=True, docs/tutorials/vqe_rf.py:245) -- and a text
+  // handed over twice as the same buffer is scanned once.  Identity of the pointer, not of the content: no hashing of the texts.
+  std::vector<int64_t> u_of;
+  int64_t count() const { return (int64_t)u_of.size(); }
   const mlqem_backend_props* props = nullptr;
   int use_q = 0, use_g = 0;
   size_t footprint() const {
@@ -934,22 +941,46 @@ extern "C" int mlqem_qasm_batch_parse(const char* const* qasm, int64_t count, co
   Batch* b = nullptr;
   try {
     b = batch_pool().take();
-    b->circuits.resize((size_t)count); b->slots.resize((size_t)count); b->sizes.resize((size_t)count);
+    // distinct texts (by buffer): first[u] = the first circuit that names text u
+    b->u_of.assign((size_t)count, 0);
+    std::vector<int64_t> first;
+    {
+      std::unordered_map<const char*, int64_t> seen;
+      seen.reserve((size_t)count * 2 + 1);
+      for (int64_t i = 0; i < count; ++i) {
+        auto it = seen.find(qasm[i]);
+        if (it == seen.end()) { it = seen.emplace(qasm[i], (int64_t)first.size()).first; first.push_back(i); }
+        b->u_of[(size_t)i] = it->second;
+      }
+    }
+    const int64_t distinct = (int64_t)first.size();
+    b->circuits.resize((size_t)distinct); b->slots.resize((size_t)distinct); b->sizes.resize((size_t)distinct);
     b->props = props; b->use_q = use_qubit_features; b->use_g = use_gate_features;
-    b->stream.resize((size_t)count);
+    b->stream.resize((size_t)distinct);
     const std::vector<char> calibrated = slots_with_calibration(props);
-    const int rc = for_each_parallel(count, threads, failed, [&](int64_t i, WorkerScratch& w) {
-      parse_qasm(qasm[i], b->circuits[i], w.text_a, w.text_b);       // into the kept circuit: its vectors' capacity is reused
-      b->slots[i] = type_slots(b->circuits[i], props);
-      b->sizes[i] = scan(b->circuits[i], props, use_qubit_features, b->slots[i], nullptr, w.wires);
-      b->stream[i] = stream_sizes(b->circuits[i], b->slots[i], calibrated, use_gate_features);
+    int64_t failed_u = -1;
+    const int rc = for_each_parallel(distinct, threads, &failed_u, [&](int64_t u, WorkerScratch& w) {
+      parse_qasm(qasm[first[(size_t)u]], b->circuits[u], w.text_a, w.text_b);       // into the kept circuit: its vectors' capacity is reused
+      b->slots[u] = type_slots(b->circuits[u], props);
+      b->sizes[u] = scan(b->circuits[u], props, use_qubit_features, b->slots[u], nullptr, w.wires);
+      b->stream[u] = stream_sizes(b->circuits[u], b->slots[u], calibrated, use_gate_features);
     });
-    if (rc != MLQEM_OK) { batch_pool().give(b); return rc; }
+    if (rc != MLQEM_OK) {
+      if (failed_u >= 0) {        // name the circuit by its place in the run(), not among the distinct texts
+        const int64_t at = first[(size_t)failed_u];
+        if (failed) *failed = at;
+        const std::string was = "circuit " + std::to_string(failed_u) + ":";
+        if (g_last_error.compare(0, was.size(), was) == 0) g_last_error = "circuit " + std::to_string(at) + ":" + g_last_error.substr(was.size());
+      }
+      batch_pool().give(b);
+      return rc;
+    }
     node_ptr[0] = edge_ptr[0] = 0;
     for (int64_t i = 0; i < count; ++i) {
-      node_ptr[i + 1] = node_ptr[i] + b->sizes[i].N;
-      edge_ptr[i + 1] = edge_ptr[i] + b->sizes[i].E;
-      if (depths) depths[i] = b->sizes[i].depth;
+      const Sizes& sz = b->sizes[(size_t)b->u_of[(size_t)i]];
+      node_ptr[i + 1] = node_ptr[i] + sz.N;
+      edge_ptr[i + 1] = edge_ptr[i] + sz.E;
+      if (depths) depths[i] = sz.depth;
     }
     *num_features = feature_width(props, use_qubit_features, use_gate_features);
     *handle = b;
@@ -965,18 +996,22 @@ extern "C" int mlqem_qasm_batch_fill(void* handle, int threads, float* x, int64_
   Batch* b = static_cast<Batch*>(handle);
   if (!b) { g_last_error = "no batch handle"; return MLQEM_ERR_BAD_ARG; }
   try {                                                        // no C++ exception may cross the C ABI (bad_alloc, system_error)
-  const int64_t count = (int64_t)b->circuits.size();
+  const int64_t count = b->count();
   std::vector<int64_t> node_ptr((size_t)count + 1, 0), edge_ptr((size_t)count + 1, 0);
-  for (int64_t i = 0; i < count; ++i) { node_ptr[i + 1] = node_ptr[i] + b->sizes[i].N; edge_ptr[i + 1] = edge_ptr[i] + b->sizes[i].E; }
+  for (int64_t i = 0; i < count; ++i) {
+    const Sizes& sz = b->sizes[(size_t)b->u_of[(size_t)i]];
+    node_ptr[i + 1] = node_ptr[i] + sz.N; edge_ptr[i + 1] = edge_ptr[i] + sz.E;
+  }
   if ((node_ptr[count] > 0 && !x) || (edge_ptr[count] > 0 && (!edge_src || !edge_dst))) {   // an empty batch needs no buffers
     g_last_error = "missing output buffer";
     return MLQEM_ERR_BAD_ARG;
   }
   const int F = feature_width(b->props, b->use_q, b->use_g);
   return for_each_parallel(count, threads, nullptr, [&](int64_t i, WorkerScratch& w) {
-    const Circuit& c = b->circuits[i];
-    scan(c, b->props, b->use_q, b->slots[i], &w.lists, w.wires);
-    fill<float, int64_t>(c, b->props, b->use_q, b->use_g, b->slots[i], w.lists, x + node_ptr[i] * F, edge_src + edge_ptr[i],
+    const int64_t u = b->u_of[(size_t)i];
+    const Circuit& c = b->circuits[u];
+    scan(c, b->props, b->use_q, b->slots[u], &w.lists, w.wires);
+    fill<float, int64_t>(c, b->props, b->use_q, b->use_g, b->slots[u], w.lists, x + node_ptr[i] * F, edge_src + edge_ptr[i],
                          edge_dst + edge_ptr[i], node_ptr[i], nullptr);
     if (batch) std::fill(batch + node_ptr[i], batch + node_ptr[i + 1], i);
   });
@@ -999,13 +1034,14 @@ extern "C" int mlqem_qasm_batch_stream_sizes(void* handle, int64_t* wire_ptr, in
   Batch* b = static_cast<Batch*>(handle);
   if (!b || !wire_ptr || !patch_ptr) { g_last_error = "no batch handle or output"; return MLQEM_ERR_BAD_ARG; }
   try {
-    const int64_t count = (int64_t)b->circuits.size();
+    const int64_t count = b->count();
     wire_ptr[0] = patch_ptr[0] = 0;
     int widest = 0;
     for (int64_t i = 0; i < count; ++i) {
-      const Circuit& c = b->circuits[i];
+      const int64_t u = b->u_of[(size_t)i];
+      const Circuit& c = b->circuits[u];
       if (c.nq > 65535 || b->props->num_qubits > 65535) { g_last_error = "more than 65535 wires: the op stream holds 16-bit indices"; return MLQEM_ERR_UNSUPPORTED; }
-      const StreamSizes sz = b->stream[i];
+      const StreamSizes sz = b->stream[u];
       wire_ptr[i + 1] = wire_ptr[i] + sz.wires;
       patch_ptr[i + 1] = patch_ptr[i] + sz.patches;
       widest = std::max(widest, c.nq);
@@ -1025,9 +1061,9 @@ extern "C" int mlqem_qasm_batch_stream_fill(void* handle, int threads, const int
   Batch* b = static_cast<Batch*>(handle);
   if (!b || !wire_ptr || !patch_ptr) { g_last_error = "no batch handle"; return MLQEM_ERR_BAD_ARG; }
   try {
-    const int64_t count = (int64_t)b->circuits.size();
+    const int64_t count = b->count();
     std::vector<int64_t> node_ptr((size_t)count + 1, 0);
-    for (int64_t i = 0; i < count; ++i) node_ptr[i + 1] = node_ptr[i] + b->sizes[i].N;
+    for (int64_t i = 0; i < count; ++i) node_ptr[i + 1] = node_ptr[i] + b->sizes[(size_t)b->u_of[(size_t)i]].N;
     if ((node_ptr[count] > 0 && !ops) || (wire_ptr[count] > 0 && !wires) || (patch_ptr[count] > 0 && !patches)) {
       g_last_error = "missing output buffer";
       return MLQEM_ERR_BAD_ARG;
@@ -1036,8 +1072,9 @@ extern "C" int mlqem_qasm_batch_stream_fill(void* handle, int threads, const int
     const std::vector<char> calibrated = slots_with_calibration(b->props);
     const int F = feature_width(b->props, b->use_q, b->use_g);
     return for_each_parallel(count, threads, nullptr, [&](int64_t i, WorkerScratch&) {
-      const Circuit& c = b->circuits[i];
-      const std::vector<int>& slot_of = b->slots[i];
+      const int64_t u = b->u_of[(size_t)i];
+      const Circuit& c = b->circuits[u];
+      const std::vector<int>& slot_of = b->slots[u];
       mlqem_op_rec* out = ops + node_ptr[i];
       uint16_t* w = wires + wire_ptr[i];
       mlqem_x_patch* px = patches + patch_ptr[i];
