@@ -479,7 +479,9 @@ def family_b_leg(dev, steps=30):
     # eager at 64, then captured at 64 / 256 / 1024.  The coarsened edge arrays are sized by a structural bound
     # (GraphArena.coarse_caps), so the step reads nothing from the device and the whole of it -- assembly, two TransformerConv +
     # ASAPooling levels, head, backward, Adam -- replays from ONE graph.
-    for big_batch, graphs, big_steps in ((64, False, max(6, steps // 2)), (64, True, max(6, steps // 2)), (256, True, 6), (1024, True, 4)):
+    # (the 1024-circuit step runs eagerly: its structural edge bound, 2.1e9, is beyond the 2^30 entries a batch may size its edge arrays
+    # to, so its coarsening reads the sizes back -- a captured step may not)
+    for big_batch, graphs, big_steps in ((64, False, max(6, steps // 2)), (64, True, max(6, steps // 2)), (256, True, 6), (1024, False, 4)):
         torch.manual_seed(0)
         torch.cuda.reset_peak_memory_stats()
         sampler = StratifiedBatches(big_arena.node_counts[:nb_graphs], big_arena.edge_counts[:nb_graphs], big_batch, seed=13)
@@ -505,7 +507,7 @@ def family_b_leg(dev, steps=30):
     cfg4["hipgraph"], cfg4["eager"] = cfg4["batch64_hipgraph"], cfg4["batch64_eager"]
     cfg4["circuits_per_s"] = cfg4["batch64_hipgraph"]["circuits_per_s"]
     cfg4["ms_per_step"] = cfg4["batch64_hipgraph"]["ms_per_step"]
-    cfg4["best_circuits_per_s"] = max(cfg4[k]["circuits_per_s"] for k in ("batch64_hipgraph", "batch256_hipgraph", "batch1024_hipgraph"))
+    cfg4["best_circuits_per_s"] = max(cfg4[k]["circuits_per_s"] for k in ("batch64_hipgraph", "batch256_hipgraph", "batch1024_eager"))
     cfg4["attention_roofline"] = attention_roofline(big_arena.batch(np.arange(64) * nb_graphs // 64).structure, dev,
                                                     "64 100-qubit circuits (the first TransformerConv's graph: the circuit DAGs)")
     out["cfg4_100q"] = cfg4

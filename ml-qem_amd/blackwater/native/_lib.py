@@ -177,7 +177,17 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+_SYNC_OPS = os.environ.get("MLQEM_SYNC_OPS", "0") == "1"     # diagnostics: name every native call, then wait for it (a fault then has a name)
+
+
 def check(code: int, what: str) -> None:
+    if _SYNC_OPS:
+        import sys
+
+        import torch
+
+        print(f"[native] {what}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     if code != 0:
         msg = load().mlqem_error_string(code).decode()
         raise NativeLibraryError(f"{what} failed with code {code}: {msg}")

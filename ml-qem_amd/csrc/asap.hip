@@ -50,12 +50,19 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __r
   perm[p] = gptr[lo] + (int32_t)(mask - ((uint32_t)key & mask));
 }
 
+// The device-wide sort of the top-k always takes rocprim's MERGE sort: above 2^20 keys the default configuration switches to
+// Onesweep, which clears its digit counters and look-back states with hipMemsetAsync -- memset nodes of a captured hipGraph, and a
+// captured Family B step on 256 100-qubit circuits (2.8 M keys) died in its second replay inside
+// radix_sort_onesweep_iteration (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION), the same failure hipMemsetAsync gave in this
+// file's own fills (see fill_i32_kernel).  The merge sort launches kernels only.
+using TopkSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t(1) << 40)>;
+
 static size_t topk_temp_bytes(int64_t N, int64_t B) {     // enough for either sort
   size_t seg = 0, whole = 0;
   (void)rocprim::segmented_radix_sort_keys_desc(nullptr, seg, (uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned)N,
                                                 (unsigned)B, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 64,
                                                 (hipStream_t)0);
-  (void)rocprim::radix_sort_keys_desc(nullptr, whole, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)N, 0, 64, (hipStream_t)0);
+  (void)rocprim::radix_sort_keys_desc<TopkSortConfig>(nullptr, whole, (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)N, 0, 64, (hipStream_t)0);
   return (std::max(seg, whole) + 255) / 256 * 256;
 }
 
@@ -896,7 +903,7 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
   hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, fitness,
                      graph_ptr, (int)B, N, idx_bits, whole ? graph_bits : 0, keys);
   if (whole) {
-    if (rocprim::radix_sort_keys_desc(temp, temp_bytes, keys, sorted, (size_t)N, 0, (unsigned)(graph_bits + 32 + idx_bits), stream) != hipSuccess)
+    if (rocprim::radix_sort_keys_desc<TopkSortConfig>(temp, temp_bytes, keys, sorted, (size_t)N, 0, (unsigned)(graph_bits + 32 + idx_bits), stream) != hipSuccess)
       return MLQEM_ERR_LAUNCH;
   } else if (rocprim::segmented_radix_sort_keys_desc(temp, temp_bytes, keys, sorted, (unsigned)N, (unsigned)B, graph_ptr,
                                                      graph_ptr + 1, 0, 32 + idx_bits, stream) != hipSuccess)
