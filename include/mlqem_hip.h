@@ -606,23 +606,27 @@ int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const flo
  * tie_count (may be NULL; C <= 128): with xmax = the segment max of x over the same entries (mlqem_csr_segment_max_f32, what
  * ASAPooling computes from the same x: gnn.py:105-107), tie_count[i, c] = the number of entries of row i (sources and i itself) whose
  * value equals xmax[i, c] -- the destination-side walk holds every source row anyway, and mlqem_csr_segment_max_bwd_f32 then
- * needs no walk of its own to split a maximum's gradient among ties. */
+ * needs no walk of its own to split a maximum's gradient among ties.
+ * gx_rank1 (may be NULL; C <= 128): a [C] vector r; gx additionally receives g_c[j] * r -- the gradient through the source score
+ * c_j = x_j . r (ASAPooling's att on the source half, gnn.py:105-107), which otherwise is a read-modify-write pass over gx. */
 int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn, const float* gnew,
                                         int64_t ldg, const int32_t* in_ptr, const int32_t* in_src,
                                         const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
                                         const float* a_dst, const float* c_src, float negative_slope, int64_t N,
                                         int64_t E, int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
                                         float* g_c, float* edge_al, float* edge_gp, const float* xmax, int64_t ldm,
-                                        float* tie_count, int64_t ldt, mlqem_stream_t stream);
+                                        float* tie_count, int64_t ldt, const float* gx_rank1, mlqem_stream_t stream);
 
 /* Backward of mlqem_csr_segment_max_f32, ACCUMULATING into gx: the gradient of a row's maximum goes to the entries
  * (sources or the row itself) whose value equals it, split evenly among ties (torch scatter_reduce(amax) rule).
+ * gmax_row [N] / gmax_col [C] (may be NULL): gmax = gmax_row (x) gmax_col, never formed (needs tie_count; gmax is then unused).
  * gshare: scratch [N, lds >= C].  tie_count (may be NULL): the counts mlqem_csr_softmax_aggregate_bwd_f32 left; the
  * destination-side pass over the in-edges is then an elementwise division. */
 int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const float* gmax,
                                   int64_t ldg, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                   const int32_t* out_dst, int64_t N, int C, float* gx, int64_t ldgx, float* gshare,
-                                  int64_t lds, const float* tie_count, int64_t ldt, mlqem_stream_t stream);
+                                  int64_t lds, const float* tie_count, int64_t ldt, const float* gmax_row, const float* gmax_col,
+                                  mlqem_stream_t stream);
 
 /* Backward of x_out = x'[perm] * fitness[perm] over all N rows (slot[i] = cluster id or -1 from
  * mlqem_asap_hop1_count): gxnew[i,:] = gout[slot[i],:] * fitness[i] (0 for dropped rows), gfit[i] = gout[slot[i]].x'[i]. */

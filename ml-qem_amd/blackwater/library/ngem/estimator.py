@@ -68,7 +68,8 @@ class NgemJob(job_base()):  # type: ignore[misc]
         mitigated = []
         if self._batched:
             return make_estimator_result(np.array(self._result_batched_native(result, properties, device)), result.metadata)
-        encoder = None      # the C++ encoder (mlqem_encode_qasm), built on first need: same arrays as the Python walk, bit for bit
+        encoder = None      # the C++ encoder, built on first need: same arrays as the Python walk, bit for bit
+        encoded = {}        # an observable OBJECT that appears many times in a run() is encoded once
         for value, circuit, obs, params in zip(result.values, self._circuits, self._observables,
                                                self._parameter_values):
             if not is_pauli_observable(obs):
@@ -83,11 +84,16 @@ class NgemJob(job_base()):  # type: ignore[misc]
                     from ...data.native_encoder import NativeEncoder
 
                     encoder = NativeEncoder(properties)
-                x, edge_index, _, _ = encoder.encode(text, use_gate_features=True, use_qubit_features=True, edge_attr=False)
-                args = [torch.tensor([[value]], dtype=torch.float), torch.tensor([encode_pauli_sum_op(obs)], dtype=torch.float),
-                        torch.zeros(1, 1), torch.from_numpy(x.astype(np.float32)), torch.from_numpy(edge_index), None]
+                # float32 rows and int64 indices straight from the C call (the batch entry points with one circuit: no float64
+                # staging array, no casts), in pinned memory when they are about to be uploaded
+                on_gpu = device is not None and torch.device(device).type == "cuda"
+                x, edge_index, _, _, _ = encoder.encode_batch([text], threads=1, pin=on_gpu)
+                enc = encoded.get(id(obs))
+                if enc is None:
+                    enc = encoded[id(obs)] = torch.tensor([encode_pauli_sum_op(obs)], dtype=torch.float)
+                args = [torch.tensor([[value]], dtype=torch.float), enc, torch.zeros(1, 1), x, edge_index, None]
                 if device is not None:
-                    args = [a if a is None else a.to(device) for a in args]
+                    args = [a if a is None else a.to(device, non_blocking=on_gpu) for a in args]
             else:
                 graph = circuit_to_graph_data_json(circuit=bound, properties=properties, use_qubit_features=True,
                                                    use_gate_features=True)

@@ -123,8 +123,8 @@ SIGNATURES = {
     "mlqem_transformer_attention_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I,
                                                  _F, _U, _P, _I, _P, _L, _P, _P, _P]),
     "mlqem_csr_softmax_aggregate_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _L, _L, _I, _I,
-                                                 _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
-    "mlqem_csr_segment_max_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _P]),
+                                                 _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P]),
+    "mlqem_csr_segment_max_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P]),
     "mlqem_gather_scale_rows_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _P, _L, _P, _P]),
     "mlqem_leconv_fitness_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
     "mlqem_encode_qasm": (_I, [c_char_p, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -807,18 +807,19 @@ class _ASAPool(Function):
         ops.linear_wgrad(gpqr, x_new, gw3, gb3)
         # x' = sum_e softmax(LeakyReLU(a_i + c_j)) x_j
         # ... its destination-side walk also counts the ties of the segment max below (same x, same entries)
-        if _ASAP_TIES:
-            gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw)
-        else:
-            (gx, g_a, g_c), ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope), None
         att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
+        # c = x att_x^T: its gradient g_c (x) att_x rides in the source-side kernel's store of gx (it computes g_c itself) instead of
+        # being a read-modify-write pass over gx
+        if _ASAP_TIES:
+            gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0])
+        else:
+            (gx, g_a, g_c), ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, gx_rank1=att_x[0]), None
         g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
-        ops.linear(g_c2, att_x, transposed=True, out=gx, accumulate=True)           # c = x att_x^T
         g_att_x = torch.empty_like(att_x)
         ops.linear_wgrad(g_c2, x, g_att_x, None)
         if ctx.composed:
             w_comp = xq                                                              # a = xq_raw w_comp^T + b_comp, w_comp = att_q W
-            g_xq_raw = ops.linear(g_a2, w_comp.contiguous(), transposed=True)
+            g_xq_raw = None                                                          # = g_a (x) w_comp: formed inside the segment max's backward
             g_w_comp = torch.empty_like(w_comp)
             g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
             ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
@@ -834,7 +835,10 @@ class _ASAPool(Function):
             g_lin_w = torch.empty_like(lin_w)
             g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
             ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
-        ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s, ties=ties)      # xq_raw = segment max of x
+        if g_xq_raw is None:
+            ops.csr_segment_max_bwd_(gx, x, xq_raw, None, s, ties=ties, gmax_rank1=(g_a, w_comp[0].contiguous()))
+        else:
+            ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s, ties=ties)      # xq_raw = segment max of x
         g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],
                 None, None, None, None)

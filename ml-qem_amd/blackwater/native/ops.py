@@ -1373,7 +1373,7 @@ def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channe
     return gqkvs
 
 
-def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope, xmax=None):
+def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope, xmax=None, gx_rank1=None):
     """(gx, g_a, g_c) -- and, given ``xmax`` (the segment max of x over the same entries, <= 128 channels), a fourth result: the
     per-channel tie counts ``csr_segment_max_bwd_`` would otherwise walk the in-edges for."""
     n, c = x.shape
@@ -1392,20 +1392,26 @@ def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negativ
         _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(a_dst), _p(c_src), float(negative_slope), n, num_edges, c, 0,
         _p(gx), _mat(gx, "gx"), _p(g_a), _p(g_c), _p(al), _p(gp),
         _p(xmax) if ties is not None else None, _mat(xmax, "xmax") if ties is not None else 0,
-        _p(ties), _mat(ties, "ties") if ties is not None else 0, _stream())
+        _p(ties), _mat(ties, "ties") if ties is not None else 0, _p(gx_rank1) if c <= 128 else None, _stream())
+    if gx_rank1 is not None and c > 128:         # wider than the kernels that fold it in: as its own pass
+        linear(g_c.unsqueeze(1), gx_rank1.reshape(1, -1).contiguous(), transposed=True, out=gx, accumulate=True)
     _lib.check(code, "mlqem_csr_softmax_aggregate_bwd_f32")
     return (gx, g_a, g_c) if xmax is None else (gx, g_a, g_c, ties)
 
 
-def csr_segment_max_bwd_(gx, x, xmax, gmax, s, ties=None):
-    """gx += backward of the segment max over structure ``s`` (in place); ``ties``: the counts ``csr_softmax_aggregate_bwd`` left."""
+def csr_segment_max_bwd_(gx, x, xmax, gmax, s, ties=None, gmax_rank1=None):
+    """gx += backward of the segment max over structure ``s`` (in place); ``ties``: the counts ``csr_softmax_aggregate_bwd`` left.
+    ``gmax_rank1 = (row [N], col [C])``: the maximum's gradient is row (x) col and is never formed (needs ``ties``; ``gmax`` unused)."""
     n, c = x.shape
     share = padded_empty(n, c, x.device)
-    code = _lib.load().mlqem_csr_segment_max_bwd_f32(_p(x), _mat(x, "x"), _p(xmax), _mat(xmax, "xmax"), _p(gmax),
-                                                     _mat(gmax, "gmax"), _p(s.in_ptr), _p(s.in_src), _p(s.out_ptr),
+    row, col = gmax_rank1 if (gmax_rank1 is not None and ties is not None) else (None, None)
+    if gmax_rank1 is not None and row is None:
+        gmax = gmax_rank1[0].unsqueeze(1) * gmax_rank1[1].unsqueeze(0)
+    code = _lib.load().mlqem_csr_segment_max_bwd_f32(_p(x), _mat(x, "x"), _p(xmax), _mat(xmax, "xmax"), _p(gmax) if row is None else None,
+                                                     _mat(gmax, "gmax") if row is None else 0, _p(s.in_ptr), _p(s.in_src), _p(s.out_ptr),
                                                      _p(s.out_dst), n, c, _p(gx), _mat(gx, "gx"), _p(share),
                                                      _mat(share, "share"), _p(ties), _mat(ties, "ties") if ties is not None else 0,
-                                                     _stream())
+                                                     _p(row), _p(col), _stream())
     _lib.check(code, "mlqem_csr_segment_max_bwd_f32")
     return gx
 

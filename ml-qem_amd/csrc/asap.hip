@@ -702,7 +702,7 @@ __device__ __forceinline__ void gather_lists(const int32_t* __restrict__ rlist, 
   }
 }
 
-__global__ __launch_bounds__(kBlock) void coarsen_gather_kernel(const ListsArgs a, uint32_t* __restrict__ cinfo) {
+__global__ __launch_bounds__(kBlock) void coarsen_gather_kernel(const ListsArgs a, uint32_t* __restrict__ cinfo, int2* __restrict__ cgraph) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool has = p < a.K;
@@ -746,6 +746,9 @@ __global__ __launch_bounds__(kBlock) void coarsen_gather_kernel(const ListsArgs 
     const bool fits = bo + no <= a.tmp_cap && bi + ni <= a.tmp_cap && no < (1ll << 32) && ni < (1ll << 32);
     cinfo[p * 4 + 0] = (uint32_t)bo; cinfo[p * 4 + 1] = fits ? (uint32_t)no : 0u;
     cinfo[p * 4 + 2] = (uint32_t)bi; cinfo[p * 4 + 3] = fits ? (uint32_t)ni : 0u;
+    const int g = graph_at(a.new_gptr, a.B, p);       // the cluster's graph: its first cluster and the words of its bitsets
+    const int k0 = a.new_gptr[g];
+    cgraph[p] = make_int2(k0, (a.new_gptr[g + 1] - k0 + 31) >> 5);
     if (!fits) atomicOr(a.overflow, 1);
   }
 }
@@ -757,7 +760,8 @@ __global__ __launch_bounds__(kBlock) void coarsen_gather_kernel(const ListsArgs 
 // waits on a chain of gathers.
 struct UniqueMeta { CInfo c; int k0, Wk; };
 
-__global__ __launch_bounds__(kBlock) void coarsen_unique_kernel(const ListsArgs a, const uint32_t* __restrict__ cinfo_raw) {
+__global__ __launch_bounds__(kBlock) void coarsen_unique_kernel(const ListsArgs a, const uint32_t* __restrict__ cinfo_raw,
+                                                                const int2* __restrict__ cgraph) {
   extern __shared__ uint32_t s_bits[];              // per wave: Y [Wk], Z [Wk]
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -766,59 +770,108 @@ __global__ __launch_bounds__(kBlock) void coarsen_unique_kernel(const ListsArgs 
   for (int i = lane; i < 2 * a.Wk; i += 64) Y[i] = 0u;     // once per wave: every cluster leaves its region as it found it
   wave_lds_sync();
   const CInfo* __restrict__ cinfo = reinterpret_cast<const CInfo*>(cinfo_raw);
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  auto meta_of = [&](int64_t p) {
-    UniqueMeta m{{0u, 0u, 0u, 0u}, 0, 0};
-    if (p < a.K) {
-      m.c = cinfo[p];
-      const int g = graph_at(a.new_gptr, a.B, p);
-      m.k0 = a.new_gptr[g];
-      m.Wk = (a.new_gptr[g + 1] - m.k0 + 31) >> 5;
-    }
-    return m;
-  };
+  const int64_t stride = (int64_t)gridDim.x * 4, lim = a.K;
   auto first_of = [&](const UniqueMeta& m, int& qo, int& qi) {       // the first 64 candidates of either side, -1 past the end
     qo = lane < (int)m.c.cnt_o ? a.tmp_o[(int64_t)m.c.off_o + lane] : -1;
     qi = lane < (int)m.c.cnt_i ? a.tmp_i[(int64_t)m.c.off_i + lane] : -1;
   };
-  int64_t p = (int64_t)blockIdx.x * 4 + wid;
-  UniqueMeta m0 = meta_of(p), m1 = meta_of(p + stride);
-  int qo0, qi0;
-  first_of(m0, qo0, qi0);
-  for (; p < a.K; p += stride) {                      // wave-uniform; every wave reaches the end
-    const UniqueMeta m2 = meta_of(p + 2 * stride);    // in flight while this cluster is in the LDS
-    int qo1, qi1;
-    first_of(m1, qo1, qi1);
-    const int k0 = m0.k0, Wk = m0.Wk, self = (int)p;
-    auto mark = [&](uint32_t* S, int q) { if (q >= 0 && q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31)); };
-    mark(Y, qo0);
-    mark(Z, qi0);
-    for (uint32_t j = 64 + lane; j < m0.c.cnt_o; j += 64) mark(Y, a.tmp_o[(int64_t)m0.c.off_o + j]);     // a long row's remaining candidates
-    for (uint32_t j = 64 + lane; j < m0.c.cnt_i; j += 64) mark(Z, a.tmp_i[(int64_t)m0.c.off_i + j]);
-    wave_lds_only_sync();                             // the next cluster's candidates stay in flight
-    // read both bitsets out in ascending order: lane l owns words [l cw, (l + 1) cw); one scan of the packed counts (a row
-    // has fewer than 65 536 entries: k_g <= 65 535)
-    const int cw = (Wk + 63) >> 6;
-    const int w_lo = min(Wk, lane * cw), w_hi = min(Wk, w_lo + cw);
-    unsigned ny = 0, nz = 0;
-    for (int w = w_lo; w < w_hi; ++w) { ny += __popc(Y[w]); nz += __popc(Z[w]); }
-    const int packed = (int)(ny | (nz << 16));
-    const int ex = wave_excl_scan(packed, lane);
-    const unsigned tot = (unsigned)__shfl(ex + packed, 63);
-    int64_t po = (int64_t)m0.c.off_o + (int)((unsigned)ex & 0xFFFFu), pi = (int64_t)m0.c.off_i + (int)((unsigned)ex >> 16);
-    for (int w = w_lo; w < w_hi; ++w) {               // sorted, duplicate-free, over the candidates they came from (never longer)
-      uint32_t yb = Y[w], zb = Z[w];
-      Y[w] = 0u; Z[w] = 0u;
-      const int first = k0 + w * 32;
-      while (yb) { const int b = __ffs((int)yb) - 1; yb &= yb - 1; a.tmp_o[po++] = first + b; }
-      while (zb) { const int b = __ffs((int)zb) - 1; zb &= zb - 1; a.tmp_i[pi++] = first + b; }
+  // The wave's clusters are first + j stride.  Their records come 64 at a time, ONE per lane (a vector load: a scalar load per
+  // cluster -- and a search for its graph -- stood in every iteration's way: scalar loads return out of order, so every use waits
+  // for all of them; measured 190 of 438 us for the search), and reach the scalar side by readlane when their turn comes.
+  // What is left (330 us on 64 100-qubit circuits: 170 for the five light clusters of six, 45 for the marks and 115 for the
+  // read-out of the heavy ones) is instruction issue, not latency: static chunks, deeper prefetch and batched loads moved nothing.
+  for (int64_t first = (int64_t)blockIdx.x * 4 + wid; first < lim; first += stride * 64) {
+    const int64_t mine = first + (int64_t)lane * stride;
+    CInfo rc{0u, 0u, 0u, 0u};
+    int2 kg = make_int2(0, 0);
+    if (mine < lim) { rc = cinfo[mine]; kg = cgraph[mine]; }
+    const int nb = (int)min((int64_t)64, (lim - first + stride - 1) / stride);      // clusters of this batch (wave-uniform)
+    auto meta_of = [&](int j) {
+      UniqueMeta m;
+      m.c.off_o = (uint32_t)__builtin_amdgcn_readlane((int)rc.off_o, j); m.c.cnt_o = (uint32_t)__builtin_amdgcn_readlane((int)rc.cnt_o, j);
+      m.c.off_i = (uint32_t)__builtin_amdgcn_readlane((int)rc.off_i, j); m.c.cnt_i = (uint32_t)__builtin_amdgcn_readlane((int)rc.cnt_i, j);
+      m.k0 = __builtin_amdgcn_readlane(kg.x, j); m.Wk = __builtin_amdgcn_readlane(kg.y, j);
+      return m;
+    };
+    UniqueMeta m0 = meta_of(0);
+    int qo0, qi0;
+    first_of(m0, qo0, qi0);
+    for (int j = 0; j < nb; ++j) {
+      const int64_t p = first + (int64_t)j * stride;
+      UniqueMeta m1{{0u, 0u, 0u, 0u}, 0, 0};
+      if (j + 1 < nb) m1 = meta_of(j + 1);
+      int qo1, qi1;
+      first_of(m1, qo1, qi1);                           // in flight while this cluster is sorted
+      const int k0 = m0.k0, Wk = m0.Wk, self = (int)p;
+      if (m0.c.cnt_o <= 64u && m0.c.cnt_i <= 64u) {
+        // A LIGHT cluster (five of six): its candidates are already in registers, one per lane and side.  Sorted by a bitonic
+        // network across the wave (21 exchange steps, both sides interleaved), duplicates dropped by a look at the left
+        // neighbour, ranks from a ballot -- no LDS, no scan of k_g bits to find two dozen of them.
+        int vo = (qo0 >= 0 && qo0 != self) ? qo0 : INT32_MAX, vi = (qi0 >= 0 && qi0 != self) ? qi0 : INT32_MAX;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+          for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            const int po2 = __shfl_xor(vo, jj), pi2 = __shfl_xor(vi, jj);
+            const bool take_min = ((lane & k) == 0) == ((lane & jj) == 0);
+            vo = take_min ? min(vo, po2) : max(vo, po2);
+            vi = take_min ? min(vi, pi2) : max(vi, pi2);
+          }
+        }
+        const int lo = __shfl_up(vo, 1), li = __shfl_up(vi, 1);
+        const bool ko = vo != INT32_MAX && (lane == 0 || vo != lo), ki = vi != INT32_MAX && (lane == 0 || vi != li);
+        const unsigned long long mo = __ballot(ko), mi = __ballot(ki), below = (1ull << lane) - 1ull;
+        if (ko) a.tmp_o[(int64_t)m0.c.off_o + __popcll(mo & below)] = vo;       // over the candidates they came from (all in registers)
+        if (ki) a.tmp_i[(int64_t)m0.c.off_i + __popcll(mi & below)] = vi;
+        if (lane == 0) {
+          a.outdeg[p] = __popcll(mo);
+          a.indeg[p] = __popcll(mi);
+        }
+      } else {
+        // A cluster with more than 64 candidates on a side (a hub's neighbourhood): every candidate sets a bit of an LDS bitset
+        // (k_g bits), the bitsets are read out in ascending order by lanes that own runs of words (ONE wave scan of packed counts)
+        // and cleared on the way.
+        auto mark = [&](uint32_t* S, int q) { if (q >= 0 && q != self) atomicOr(&S[(q - k0) >> 5], 1u << ((q - k0) & 31)); };
+        mark(Y, qo0);
+        mark(Z, qi0);
+        // the rest eight loads a side at a time, all issued before the first of them is marked (an LDS atomic behind every
+        // load had the rounds wait for one another: ~2.5 us each)
+        const uint32_t most = max(m0.c.cnt_o, m0.c.cnt_i);
+        for (uint32_t t0 = 64; t0 < most; t0 += 512) {
+          int ro[8], ri[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const uint32_t t = t0 + r * 64 + lane;
+            ro[r] = t < m0.c.cnt_o ? a.tmp_o[(int64_t)m0.c.off_o + t] : -1;
+            ri[r] = t < m0.c.cnt_i ? a.tmp_i[(int64_t)m0.c.off_i + t] : -1;
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { mark(Y, ro[r]); mark(Z, ri[r]); }
+        }
+        wave_lds_only_sync();                             // the next cluster's candidates stay in flight
+        const int cw = (Wk + 63) >> 6;                    // lane l owns words [l cw, (l + 1) cw); a row has fewer than 65 536 entries
+        const int w_lo = min(Wk, lane * cw), w_hi = min(Wk, w_lo + cw);
+        unsigned ny = 0, nz = 0;
+        for (int w = w_lo; w < w_hi; ++w) { ny += __popc(Y[w]); nz += __popc(Z[w]); }
+        const int packed = (int)(ny | (nz << 16));
+        const int ex = wave_excl_scan(packed, lane);
+        const unsigned tot = (unsigned)__shfl(ex + packed, 63);
+        int64_t po = (int64_t)m0.c.off_o + (int)((unsigned)ex & 0xFFFFu), pi = (int64_t)m0.c.off_i + (int)((unsigned)ex >> 16);
+        for (int w = w_lo; w < w_hi; ++w) {               // sorted, duplicate-free, over the candidates they came from (never longer)
+          uint32_t yb = Y[w], zb = Z[w];
+          Y[w] = 0u; Z[w] = 0u;
+          const int first_q = k0 + w * 32;
+          while (yb) { const int b = __ffs((int)yb) - 1; yb &= yb - 1; a.tmp_o[po++] = first_q + b; }
+          while (zb) { const int b = __ffs((int)zb) - 1; zb &= zb - 1; a.tmp_i[pi++] = first_q + b; }
+        }
+        if (lane == 0) {
+          a.outdeg[p] = (int)(tot & 0xFFFFu);
+          a.indeg[p] = (int)(tot >> 16);
+        }
+        wave_lds_only_sync();
+      }
+      m0 = m1; qo0 = qo1; qi0 = qi1;
     }
-    if (lane == 0) {
-      a.outdeg[p] = (int)(tot & 0xFFFFu);
-      a.indeg[p] = (int)(tot >> 16);
-    }
-    wave_lds_only_sync();
-    m0 = m1; m1 = m2; qo0 = qo1; qi0 = qi1;
   }
 }
 
@@ -1171,13 +1224,13 @@ ListsLayout lists_layout(int64_t N, int64_t K, int64_t E, int64_t capacity) {
   l.flag = 256;
   l.scan = lists_scan_bytes(std::max(N, K));
   l.lists = up((size_t)std::max<int64_t>(capacity, 1) * sizeof(int32_t));
-  l.total = 4 * l.h + 5 * l.ncnt + l.clist + 4 * l.caps + 6 * l.degs + l.flag + l.scan + 4 * l.lists;
+  l.total = 4 * l.h + 5 * l.ncnt + l.clist + 4 * l.caps + 8 * l.degs + l.flag + l.scan + 4 * l.lists;
   return l;
 }
 
 struct ListsPointers {
   int64_t* h_out; int64_t* h_in; int64_t* roff_o; int64_t* roff_i; int32_t* ccnt; uint32_t* rinfo; int32_t* clist;
-  int64_t* cap_o; int64_t* cap_i; int64_t* off_o; int64_t* off_i; int32_t* outdeg; int32_t* indeg; uint32_t* cinfo; int32_t* flag; void* scan;
+  int64_t* cap_o; int64_t* cap_i; int64_t* off_o; int64_t* off_i; int32_t* outdeg; int32_t* indeg; uint32_t* cinfo; int2* cgraph; int32_t* flag; void* scan;
   int32_t* r_o; int32_t* r_i; int32_t* tmp_o; int32_t* tmp_i;
 };
 ListsPointers lists_pointers(void* workspace, const ListsLayout& l) {
@@ -1198,6 +1251,7 @@ ListsPointers lists_pointers(void* workspace, const ListsLayout& l) {
   q.outdeg = reinterpret_cast<int32_t*>(take(l.degs));
   q.indeg = reinterpret_cast<int32_t*>(take(l.degs));
   q.cinfo = reinterpret_cast<uint32_t*>(take(4 * l.degs));          // [K][4]: 16-byte records
+  q.cgraph = reinterpret_cast<int2*>(take(2 * l.degs));             // [K]: first cluster and bitset words of the cluster's graph
   q.flag = reinterpret_cast<int32_t*>(take(l.flag));
   q.scan = take(l.scan);
   q.r_o = reinterpret_cast<int32_t*>(take(l.lists));
@@ -1302,7 +1356,7 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
                      q.roff_i, q.r_i, capacity, q.rinfo, q.flag);
   ListsArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, perm, slot, (int)B, N, K, (kmax + 31) / 32,
               q.rinfo, q.r_o, q.r_i, capacity, q.off_o, q.off_i, q.tmp_o, q.tmp_i, capacity, q.outdeg, q.indeg, q.flag};
-  hipLaunchKernelGGL(coarsen_gather_kernel, dim3((unsigned)ceil_div(K, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, q.cinfo);
+  hipLaunchKernelGGL(coarsen_gather_kernel, dim3((unsigned)ceil_div(K, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, q.cinfo, q.cgraph);
   const size_t lds = (size_t)4 * 2 * a.Wk * sizeof(uint32_t);
   static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(coarsen_unique_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               kListsMaxLds) == hipSuccess ? 1 : 0;
@@ -1310,7 +1364,7 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
   // persistent waves: as many workgroups as the LDS lets a CU hold (at most 8: 32 waves), never more than there are clusters
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kListsMaxLds / std::max<size_t>(lds, 1)));
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(K, (int64_t)4), (int64_t)device_cus() * per_cu));
-  hipLaunchKernelGGL(coarsen_unique_kernel, dim3(grid), dim3(kBlock), lds, stream, a, q.cinfo);
+  hipLaunchKernelGGL(coarsen_unique_kernel, dim3(grid), dim3(kBlock), lds, stream, a, q.cinfo, q.cgraph);
   size_t temp_bytes = l.scan;
   if (rocprim::exclusive_scan(q.scan, temp_bytes, q.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(), stream) !=
       hipSuccess)

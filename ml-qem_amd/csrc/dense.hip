@@ -234,6 +234,89 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
   }
 }
 
+// WIDE outputs from narrow inputs with NOTHING in the epilogue but the bias: the q / k / v / skip projection of a TransformerConv
+// (22 -> 180 on the circuit DAGs, 45 -> 120 on the pooled graph; docs/tutorials/gnn.py:80-91).  The kernel above gives a wave
+// OBT = 4 output tiles, so three workgroups write three 256-byte pieces of every 720-byte row at different times, each store
+// instruction 64 bytes of 16 different rows: 1.7 TB/s at 11 M rows.  Here a wave owns 16 WHOLE rows: all NT tiles of the product
+// (W fragments in registers: NT x G x 4), the result transposed through LDS into the rows' memory order -- a tile of 16 padded rows
+// IS one contiguous block when ldy = round_up(O, 4) -- and written as full 1 KB wave stores; the bias is added on the way out.
+template <int NT, int G>
+__global__ __launch_bounds__(kBlock) void linear_rows_lds_kernel(const LinArgs a, int LS) {
+  extern __shared__ float s_rows_lds[];                  // [4 waves][16 rows][LS] | bias [NT * 16]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kBlock) >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int c4o = (a.O + 3) / 4 * 4, q4 = c4o / 4;
+  float* __restrict__ tile = s_rows_lds + (size_t)wid * 16 * LS;
+  float* __restrict__ s_bias = s_rows_lds + (size_t)4 * 16 * LS;
+  for (int i = threadIdx.x; i < NT * 16; i += kBlock) s_bias[i] = (a.b && i < a.O) ? a.b[i] : 0.f;
+  __syncthreads();
+  float wf[NT][G][4];
+#pragma unroll
+  for (int ob = 0; ob < NT; ++ob) {
+    const int o = ob * 16 + lr;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 16 * g + 4 * lq + s4;
+        wf[ob][g][s4] = (o < a.O && k < a.I) ? a.w[(int64_t)o * a.I + k] : 0.f;
+      }
+  }
+  // a lane's places in the copy-out: float4 number i = lane + 64 j of the tile (row i / q4, column group i % q4)
+  const int r_first = lane / q4, c_first = lane - r_first * q4, r_step = 64 / q4, c_step = 64 - r_step * q4;
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    const int64_t row = t * 16 + lr;
+    const bool row_ok = row < a.N;
+    const int64_t xrow = (a.xrows && row_ok) ? (int64_t)a.xrows[row] : row;
+    const float* __restrict__ xr = a.x + xrow * a.ldx + 4 * lq;
+    float4 av[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 16 * g + 4 * lq;
+      av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row_ok && k0 < a.I) av[g] = *reinterpret_cast<const float4*>(xr + 16 * g);     // padded rows: the float4 lies inside the row
+      if (k0 + 1 >= a.I) av[g].y = 0.f;
+      if (k0 + 2 >= a.I) av[g].z = 0.f;
+      if (k0 + 3 >= a.I) av[g].w = 0.f;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int ob = 0; ob < NT; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float comp[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int ob = 0; ob < NT; ++ob) acc[ob] = mfma16x16x4(wf[ob][g][s4], comp[s4], acc[ob]);
+    }
+    // lane (lr, lq) holds outputs ob 16 + 4 lq .. + 3 of row lr: one 16-byte LDS store per tile
+#pragma unroll
+    for (int ob = 0; ob < NT; ++ob) {
+      const int c0 = ob * 16 + 4 * lq;
+      if (c0 < c4o) *reinterpret_cast<float4*>(tile + lr * LS + c0) = make_float4(acc[ob][0], acc[ob][1], acc[ob][2], acc[ob][3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int nrows = (int)min((int64_t)16, a.N - t * 16);
+    float* __restrict__ dst = a.y + t * 16 * a.ldy;      // ldy == c4o: the tile's rows are one contiguous block
+    int r = r_first, c = c_first;
+    for (int i = lane; i < nrows * q4; i += 64) {
+      const float4 v = *reinterpret_cast<const float4*>(tile + r * LS + 4 * c);
+      const float4 bb = *reinterpret_cast<const float4*>(s_bias + 4 * c);
+      const float out[4] = {v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w};
+      vstore_nt<4>(dst + (int64_t)i * 4, out);
+      c += c_step; r += r_step;
+      if (c >= q4) { c -= q4; ++r; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile is read before the next product overwrites it
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------- bf16 matrix cores
 // Y = act(X W^T + b) with the operands ROUNDED TO BF16 IN REGISTERS (round-to-nearest-even) and fp32 accumulation on
 // v_mfma_f32_16x16x32_bf16 -- the "bf16 MFMA MLP head" of BASELINE.json's mixed-corpus configuration.  X, W, Y stay
@@ -1193,6 +1276,29 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
   LinArgs a{x, ldx, w, b, rowscale, y, ldy, N, I, O, act | (plain ? 256 : 0), accumulate, drop_p, seed, rs_cols, act_from,
             gate, ldgate, gate_scale};
   hipStream_t s = as_stream(stream);
+  {
+    // wide rows from narrow inputs, bias only (TransformerConv's q / k / v / skip projection): whole rows per wave through LDS
+    const int c4 = (O + 3) / 4 * 4;
+    static const int rows_env = getenv("MLQEM_LINEAR_ROWS") ? atoi(getenv("MLQEM_LINEAR_ROWS")) : 1;
+    if (rows_env && !transposed && !accumulate && !gate && !rowscale && act == 0 && drop_p == 0.f && O >= 96 && O <= 192 && I <= 48 &&
+        ldy == c4 && ldx % 4 == 0 && ldx >= (I + 3) / 4 * 4 && aligned_to(x, 16) && aligned_to(y, 16) && N >= 4096) {
+      a.xrows = x_rows;
+      const int nt = O <= 128 ? 8 : 12, g = I <= 32 ? 2 : 3;
+      const int LS = c4 + (((c4 / 4) & 1) ? 0 : 4);          // an odd number of float4 per LDS row: 16-byte stores of 16 rows spread over the banks
+      const size_t lds = ((size_t)4 * 16 * LS + (size_t)nt * 16) * sizeof(float);
+      int cus = 256, dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+      }
+      const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * 3, ceil_div(ceil_div(N, 16), 4)));
+      if (nt == 8 && g == 2) hipLaunchKernelGGL((linear_rows_lds_kernel<8, 2>), dim3(grid), dim3(kBlock), lds, s, a, LS);
+      else if (nt == 8) hipLaunchKernelGGL((linear_rows_lds_kernel<8, 3>), dim3(grid), dim3(kBlock), lds, s, a, LS);
+      else if (g == 2) hipLaunchKernelGGL((linear_rows_lds_kernel<12, 2>), dim3(grid), dim3(kBlock), lds, s, a, LS);
+      else hipLaunchKernelGGL((linear_rows_lds_kernel<12, 3>), dim3(grid), dim3(kBlock), lds, s, a, LS);
+      return launch_status();
+    }
+  }
   // The column-block kernel with one block on each side is the lean form of this GEMM (bias, row scale, ReLU/dropout,
   // gate; no accumulate, no column ranges) and runs 1.4-1.6x faster than the general kernel below on the tall-skinny
   // shapes of this path (2.8M x 22 -> 10: 69 vs 108 us): use it whenever it can express the call (one output tile

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_any_width_ke
 template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
-    int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
+    int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c, const float* __restrict__ rank1) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
@@ -747,7 +747,10 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
   float* __restrict__ d = gx + row * ldgx + l;
 #pragma unroll
   for (int v = 0; v < NV; ++v)
-    if (has[v]) d[v * kGroup] = accumulate ? d[v * kGroup] + acc[v] : acc[v];
+    if (has[v]) {
+      const float r = acc[v] + (rank1 ? gc * rank1[l + v * kGroup] : 0.f);      // + g_c[row] * att_x: the gradient through c = x . att_x
+      d[v * kGroup] = accumulate ? d[v * kGroup] + r : r;
+    }
   if (l == 0) g_c[row] = gc;
 }
 
@@ -758,7 +761,7 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
 template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_rc_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr,
     const int32_t* __restrict__ odst, const float4* __restrict__ stat, const float* __restrict__ c_src, float slope, int64_t N, int C,
-    int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c) {
+    int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c, const float* __restrict__ rank1) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
@@ -832,7 +835,10 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
   float* __restrict__ d = gx + row * ldgx + l;
 #pragma unroll
   for (int v = 0; v < NV; ++v)
-    if (has[v]) d[v * kGroup] = accumulate ? d[v * kGroup] + acc[v] : acc[v];
+    if (has[v]) {
+      const float r = acc[v] + (rank1 ? gc * rank1[l + v * kGroup] : 0.f);      // + g_c[row] * att_x: the gradient through c = x . att_x
+      d[v * kGroup] = accumulate ? d[v * kGroup] + r : r;
+    }
   if (l == 0) g_c[row] = gc;
 }
 
@@ -889,7 +895,8 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_share_ke
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void segment_max_share_from_counts_kernel(const float* __restrict__ gmax, int64_t ldg,
                                                                                const float* __restrict__ cnt, int64_t ldc, int64_t N, int C,
-                                                                               float* __restrict__ gshare, int64_t lds) {
+                                                                               float* __restrict__ gshare, int64_t lds,
+                                                                               const float* __restrict__ g_row, const float* __restrict__ g_col) {
   const int cv = (C + VEC - 1) / VEC;
   const int64_t t = (int64_t)row_block() * kBlock + threadIdx.x;
   if (t >= N * cv) return;
@@ -897,7 +904,11 @@ __global__ __launch_bounds__(kBlock) void segment_max_share_from_counts_kernel(c
   const int64_t row = split_index(t, cv, cs);
   const int c = cs * VEC;
   float g[VEC], n[VEC];
-  vload<VEC>(gmax + row * ldg + c, g);
+  if (g_row) {                       // gmax = g_row (x) g_col, never formed (ASAPooling's composed score projection: one-wide gradient)
+    const float gr = g_row[row];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) g[v] = c + v < C ? gr * g_col[c + v] : 0.f;
+  } else vload<VEC>(gmax + row * ldg + c, g);
   vload<VEC>(cnt + row * ldc + c, n);
 #pragma unroll
   for (int v = 0; v < VEC; ++v) g[v] = g[v] / (n[v] > 0.f ? n[v] : 1.f);       // pad columns: scratch in, scratch out
@@ -1179,7 +1190,7 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
                                                    const float* c_src, float negative_slope, int64_t N, int64_t E,
                                                    int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
                                                    float* g_c, float* edge_al, float* edge_gp, const float* xmax, int64_t ldm,
-                                                   float* tie_count, int64_t ldt, mlqem_stream_t stream) {
+                                                   float* tie_count, int64_t ldt, const float* gx_rank1, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || C <= 0 || ldx < C || ldn < C || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
   if (tie_count && (!xmax || ldm < C || ldt < C)) return MLQEM_ERR_BAD_ARG;
@@ -1196,6 +1207,7 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
     if (!aligned_to(edge_al, 16)) return MLQEM_ERR_BAD_ARG;
     edge_gp = nullptr;
   }
+  if (gx_rank1 && C > 128) return MLQEM_ERR_UNSUPPORTED;      // the any-width source side does not add it
 #define MLQEM_SAB(NV)                                                                                                                          \
   do {                                                                                                                                         \
     if (tie_count)                                                                                                                             \
@@ -1218,10 +1230,10 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
   do {                                                                                                                                   \
     if (recompute)                                                                                                                       \
       hipLaunchKernelGGL(softmax_aggregate_bwd_src_rc_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, gnew, ldg, out_ptr, out_dst,           \
-                         reinterpret_cast<const float4*>(edge_al), c_src, negative_slope, N, C, accumulate, gx, ldgx, g_c);              \
+                         reinterpret_cast<const float4*>(edge_al), c_src, negative_slope, N, C, accumulate, gx, ldgx, g_c, gx_rank1);    \
     else                                                                                                                                 \
       hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel<NV>, MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, out_eid, edge_al,    \
-                         edge_gp, N, E, C, accumulate, gx, ldgx, g_c);                                                                  \
+                         edge_gp, N, E, C, accumulate, gx, ldgx, g_c, gx_rank1);                                                        \
   } while (0)
   if (C <= 16) MLQEM_SAS(1);
   else if (C <= 32) MLQEM_SAS(2);
@@ -1236,28 +1248,31 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
 }
 
 static void launch_share_from_counts(const float* gmax, int64_t ldg, const float* cnt, int64_t ldc, int64_t N, int C, float* gshare,
-                                     int64_t lds, mlqem_stream_t stream) {
+                                     int64_t lds, mlqem_stream_t stream, const float* g_row = nullptr, const float* g_col = nullptr) {
   const int c4 = (C + 3) / 4 * 4;
-  const bool vec = ldg % 4 == 0 && ldc % 4 == 0 && lds % 4 == 0 && ldg >= c4 && ldc >= c4 && lds >= c4 && aligned_to(gmax, 16) &&
+  const bool vec = (g_row || (ldg % 4 == 0 && ldg >= c4 && aligned_to(gmax, 16))) && ldc % 4 == 0 && lds % 4 == 0 && ldc >= c4 && lds >= c4 &&
                    aligned_to(cnt, 16) && aligned_to(gshare, 16);
-  if (vec) hipLaunchKernelGGL(segment_max_share_from_counts_kernel<4>, MLQEM_GRID(N * (c4 / 4)), gmax, ldg, cnt, ldc, N, C, gshare, lds);
-  else hipLaunchKernelGGL(segment_max_share_from_counts_kernel<1>, MLQEM_GRID(N * C), gmax, ldg, cnt, ldc, N, C, gshare, lds);
+  if (vec) hipLaunchKernelGGL(segment_max_share_from_counts_kernel<4>, MLQEM_GRID(N * (c4 / 4)), gmax, ldg, cnt, ldc, N, C, gshare, lds, g_row, g_col);
+  else hipLaunchKernelGGL(segment_max_share_from_counts_kernel<1>, MLQEM_GRID(N * C), gmax, ldg, cnt, ldc, N, C, gshare, lds, g_row, g_col);
 }
 
 extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm,
                                              const float* gmax, int64_t ldg, const int32_t* in_ptr,
                                              const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                              int64_t N, int C, float* gx, int64_t ldgx, float* gshare, int64_t lds,
-                                             const float* tie_count, int64_t ldt, mlqem_stream_t stream) {
+                                             const float* tie_count, int64_t ldt, const float* gmax_row, const float* gmax_col,
+                                             mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || C <= 0 || ldx < C || ldm < C || ldg < C || ldgx < C || lds < C || (tie_count && ldt < C)) return MLQEM_ERR_BAD_ARG;
+  const bool rank1 = gmax_row != nullptr;             // gmax = gmax_row (x) gmax_col (needs tie_count: the counted form); gmax unused
+  if (N < 0 || C <= 0 || ldx < C || ldm < C || (!rank1 && ldg < C) || ldgx < C || lds < C || (tie_count && ldt < C)) return MLQEM_ERR_BAD_ARG;
+  if (rank1 && (!gmax_col || !tie_count)) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
-  if (!x || !xmax || !gmax || !in_ptr || !out_ptr || !gx || !gshare) return MLQEM_ERR_BAD_ARG;
+  if (!x || !xmax || (!rank1 && !gmax) || !in_ptr || !out_ptr || !gx || !gshare) return MLQEM_ERR_BAD_ARG;
   if (tie_count && C > 128) return MLQEM_ERR_UNSUPPORTED;
 #define MLQEM_SMB(NV)                                                                                                        \
   do {                                                                                                                       \
     if (tie_count)                                                                                                           \
-      launch_share_from_counts(gmax, ldg, tie_count, ldt, N, C, gshare, lds, stream);                                         \
+      launch_share_from_counts(gmax, ldg, tie_count, ldt, N, C, gshare, lds, stream, gmax_row, gmax_col);                     \
     else                                                                                                                     \
     hipLaunchKernelGGL(segment_max_share_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, N, \
                        C, gshare, lds);                                                                                      \

@@ -151,6 +151,36 @@ def test_heavy_rows_barrier_like(c):
         assert torch.equal(mx.cpu(), ref)
 
 
+@pytest.mark.parametrize("n,i,o", [(4096, 22, 180), (70001, 22, 180), (5003, 45, 120), (8192, 45, 180), (4100, 30, 100), (9999, 22, 96), (6000, 48, 192)])
+def test_wide_projection_through_lds_writes_whole_rows(n, i, o):
+    """The q / k / v / skip projection of a TransformerConv (22 -> 180, 45 -> 120; gnn.py:80-91) takes linear_rows_lds_kernel: a
+    wave owns 16 whole rows, the product is transposed through LDS and written as contiguous 1 KB stores, bias added on the way.
+    Against fp64 within 1e-5 of the output scale -- with and without a row map of x, row counts that are no multiple of 16, NaN in the
+    input's pad columns -- and bit-equal to the general kernel it replaces for these shapes (MLQEM_LINEAR_ROWS=0 in a second process is
+    not needed: the same products in the same order)."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(n + i + o)
+    x = torch.randn(n, i, generator=g)
+    w = (torch.randn(o, i, generator=g) / i ** 0.5).to(DEV)
+    b = torch.randn(o, generator=g).to(DEV)
+    xd = ops.padded_copy(x.to(DEV))
+    if xd.stride(0) > i:
+        torch.as_strided(xd, (n, xd.stride(0)), (xd.stride(0), 1))[:, i:] = float("nan")
+    want = x.double() @ w.cpu().double().t() + b.cpu().double()
+    scale = want.abs().max().item()
+    y = ops.linear(xd, w, b)
+    assert y.stride(0) == (o + 3) // 4 * 4
+    assert (y.cpu().double() - want).abs().max().item() < 1e-5 * scale
+    # through a row map (the batch's rows of the device-resident dataset)
+    rows = torch.randperm(n, generator=g).to(torch.int32).to(DEV)
+    y2 = ops.linear(ops.RowsOf(xd, rows), w, b)
+    assert (y2.cpu().double() - want[rows.cpu().long()]).abs().max().item() < 1e-5 * scale
+    # no bias
+    y3 = ops.linear(xd, w, None)
+    assert (y3.cpu().double() - (want - b.cpu().double())).abs().max().item() < 1e-5 * scale
+
+
 @pytest.mark.parametrize("n,i,o", [(1, 22, 10), (1000, 22, 45), (777, 45, 30), (64, 35, 15), (5000, 10, 1), (333, 125, 125)])
 def test_linear_forward_backward(n, i, o):
     from blackwater.native import functional as F
@@ -678,6 +708,41 @@ def test_segment_topk_lists_each_graph_by_descending_fitness_ties_to_the_lower_i
     for bound in (int(sizes.max()), 0):
         perm = ops.segment_topk(f, gp, np_, n, len(sizes), int(keep.sum()), max_graph_nodes=bound)
         assert np.array_equal(perm.cpu().numpy().astype(np.int64), want), bound
+
+
+def test_topk_of_more_than_a_million_nodes_replays_from_a_captured_graph():
+    """Round 4: above 2^20 keys rocprim's default radix sort switches to Onesweep, whose hipMemsetAsync calls become memset nodes
+    of a captured hipGraph -- the second replay of a captured Family B step on 256 100-qubit circuits (2.8 M keys) died inside it.
+    mlqem_segment_topk now always takes the merge sort; here 70 graphs of 20 000 nodes (1.4 M keys) are ranked from a captured
+    graph, replayed four times on fresh fitness values, and must equal the eager result every time."""
+    import numpy as np
+
+    from blackwater.native import ops
+
+    sizes = np.full(70, 20000, dtype=np.int64)
+    n = int(sizes.sum())
+    keep = (sizes + 1) // 2
+    gptr = np.zeros(len(sizes) + 1, dtype=np.int32); gptr[1:] = np.cumsum(sizes)
+    nptr = np.zeros(len(sizes) + 1, dtype=np.int32); nptr[1:] = np.cumsum(keep)
+    gp, np_ = torch.from_numpy(gptr).to(DEV), torch.from_numpy(nptr).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    f = torch.rand(n, device=DEV, generator=g)
+    run = lambda: ops.segment_topk(f, gp, np_, n, len(sizes), int(keep.sum()), max_graph_nodes=20000)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        perm = run()
+    for _ in range(4):
+        f.copy_(torch.rand(n, device=DEV, generator=g))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(perm, run())
 
 
 @pytest.mark.parametrize("c", [1, 3, 10, 22, 45])
