@@ -473,15 +473,15 @@ def family_b_leg(dev, steps=30):
     nb_graphs = len(big_arena)
     cfg4 = {"nodes_per_circuit": round(big_arena.num_nodes / nb_graphs), "circuits_in_the_arena": nb_graphs,
             "coarsened_edge_capacity_per_node": round(float(big_arena.coarse_caps[:nb_graphs].sum()) / big_arena.num_nodes, 1),
-            "note": "batch 64 is the point every round has reported (circuits_per_s / ms_per_step below); 256 and 1024 separate what the "
+            "note": "batch 64 is the point every round has reported (circuits_per_s / ms_per_step below); 256, 512 and 1024 separate what the "
                     "kernels cost per circuit from what a step costs whatever its size (VERDICT r03 item 1c)"}
     # size-stratified batches (the same number of circuits of each Trotter step count in every batch) through the bucketed trainer:
-    # eager at 64, then captured at 64 / 256 / 1024.  The coarsened edge arrays are sized by a structural bound
+    # eager at 64, then captured at 64 / 256 / 512.  The coarsened edge arrays are sized by a structural bound
     # (GraphArena.coarse_caps), so the step reads nothing from the device and the whole of it -- assembly, two TransformerConv +
     # ASAPooling levels, head, backward, Adam -- replays from ONE graph.
     # (the 1024-circuit step runs eagerly: its structural edge bound, 2.1e9, is beyond the 2^30 entries a batch may size its edge arrays
     # to, so its coarsening reads the sizes back -- a captured step may not)
-    for big_batch, graphs, big_steps in ((64, False, max(6, steps // 2)), (64, True, max(6, steps // 2)), (256, True, 6), (1024, False, 4)):
+    for big_batch, graphs, big_steps in ((64, False, max(6, steps // 2)), (64, True, max(6, steps // 2)), (256, True, 6), (512, True, 4), (1024, False, 4)):
         torch.manual_seed(0)
         torch.cuda.reset_peak_memory_stats()
         sampler = StratifiedBatches(big_arena.node_counts[:nb_graphs], big_arena.edge_counts[:nb_graphs], big_batch, seed=13)
@@ -507,11 +507,11 @@ def family_b_leg(dev, steps=30):
     cfg4["hipgraph"], cfg4["eager"] = cfg4["batch64_hipgraph"], cfg4["batch64_eager"]
     cfg4["circuits_per_s"] = cfg4["batch64_hipgraph"]["circuits_per_s"]
     cfg4["ms_per_step"] = cfg4["batch64_hipgraph"]["ms_per_step"]
-    cfg4["best_circuits_per_s"] = max(cfg4[k]["circuits_per_s"] for k in ("batch64_hipgraph", "batch256_hipgraph", "batch1024_eager"))
+    cfg4["best_circuits_per_s"] = max(cfg4[k]["circuits_per_s"] for k in ("batch64_hipgraph", "batch256_hipgraph", "batch512_hipgraph", "batch1024_eager"))
     cfg4["attention_roofline"] = attention_roofline(big_arena.batch(np.arange(64) * nb_graphs // 64).structure, dev,
                                                     "64 100-qubit circuits (the first TransformerConv's graph: the circuit DAGs)")
     out["cfg4_100q"] = cfg4
-    out["cfg4_100q_batch64"] = {"renamed": "cfg4_100q (batch points 64 / 256 / 1024)", "circuits_per_s": cfg4["circuits_per_s"],
+    out["cfg4_100q_batch64"] = {"renamed": "cfg4_100q (batch points 64 / 256 / 512 / 1024)", "circuits_per_s": cfg4["circuits_per_s"],
                                 "ms_per_step": cfg4["ms_per_step"]}
     del big_arena, big_corpus
     torch.cuda.empty_cache()

@@ -41,9 +41,10 @@ def run(tag, s, heads, ch):
     torch.manual_seed(1)
     qkvs = ops.padded_empty(n, 4 * hc, dev).normal_()
     g = ops.padded_empty(n, hc, dev).normal_()
-    fwd = lambda: ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 1234)
+    pk = s.out_eid is None          # the recomputed backward forms (what the step runs on coarsened graphs)
+    fwd = lambda: ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 1234, pair_key=pk)
     out, attn, m, den = fwd()
-    bwd = lambda: ops.transformer_attention_bwd(qkvs, g, attn, m, den, s, e, heads, ch, 0.1, 1234)
+    bwd = lambda: ops.transformer_attention_bwd(qkvs, g, attn, m, den, s, e, heads, ch, 0.1, 1234, pair_key=pk)
     x = ops.padded_empty(n, hc, dev).normal_()
     smax = lambda: ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
     a_dst = torch.randn(n, device=dev)
@@ -68,7 +69,10 @@ def relabel(s, key):
     new_id = torch.empty(n, dtype=torch.long, device=dev)
     new_id[order] = torch.arange(n, device=dev)
     ei = torch.stack([new_id[src], new_id[dst]])
-    return GraphStructure.from_edge_index(ei, n)
+    r = GraphStructure.from_edge_index(ei, n)
+    if s.out_eid is None:
+        r.out_eid = None
+    return r
 
 
 rng = np.random.RandomState(0)
@@ -78,7 +82,7 @@ a4 = arena_of(TfimCorpus(100, list(range(1, 11)), 7, seed=42, exp_value_size=4))
 b4 = a4.batch(rng.randint(0, len(a4), size=64))
 with torch.no_grad():
     g = model.transformer1(b4.nodes.materialize() if hasattr(b4.nodes, "materialize") else b4.nodes, b4.structure)
-    g, s1, _ = model.pooling1(g, b4.structure)
+    g, s1, perm1 = model.pooling1(g, b4.structure)
 n = s1.num_nodes
 indeg = (s1.in_ptr[1:n + 1] - s1.in_ptr[:n]).long()
 outdeg = (s1.out_ptr[1:n + 1] - s1.out_ptr[:n]).long()
@@ -94,6 +98,8 @@ if os.environ.get("PROBE_FULL", "0") == "1":
     run("level 1 random order   ", relabel(s1, torch.rand(n, device=dev)), 2, 15)
 gid = torch.repeat_interleave(torch.arange(s1.num_graphs, device=dev), (s1.graph_ptr[1:] - s1.graph_ptr[:-1]).long())
 run("level 1 by (graph, in-degree)", relabel(s1, indeg - gid * 4096), 2, 15)
+# the kept nodes in the order of the circuit (their level-0 index: program order of the ops) instead of the order of their scores
+run("level 1 by level-0 position  ", relabel(s1, -perm1.long()), 2, 15)
 s0 = b4.structure
 n0 = s0.num_nodes
 indeg0 = (s0.in_ptr[1:n0 + 1] - s0.in_ptr[:n0]).long()
