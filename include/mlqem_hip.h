@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 24 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 25 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -101,11 +101,16 @@ int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, con
  * global_mean_pool (01_ngem.ipynb cell [9]; DESIGN section 3: the last conv is folded into the pool) without reading the
  * [N, C] activation a second time.  out_mean / out_wmean: [B, C] (either may be NULL).  Needs the ELL side table and rows of
  * round_up(C, 4) floats (MLQEM_ERR_UNSUPPORTED otherwise: call the two entry points).  gate_bits (optional,
- * [N * ceil(C / 4)] bytes): bit v of entry (row, slice) = (out[row, 4 slice + v] > 0), the ReLU / dropout gate
- * mlqem_segment_pool_bwd_f32 applies; with it `out` may be NULL -- a pooled activation whose only other reader is that gate
+ * mlqem_csr_aggregate_pool_gate_bytes(N, C) bytes, 16-byte aligned): the signs of `out` -- the ReLU / dropout gate
+ * mlqem_segment_pool_bwd_f32 applies -- in the launch's own tiling: with R = the rows of a workgroup's tile (512 / ceil(C / 4))
+ * and T = ceil(N / R) tiles, first T 16-byte records int32 (graph of the tile's first row, that graph's first row, the next
+ * graph's first row, 0), then T x 32 uint64 words: the items (row, 16-byte column slice) of a tile are numbered row-major,
+ * item i = 256 k + 64 w + l sets bit l of word (4 k + w) 4 + v of its tile iff out[row, 4 slice + v] > 0 (per-wave ballots: ABI
+ * 25; a byte per item until 24).  With gate_bits `out` may be NULL -- a pooled activation whose only other reader is that gate
  * (the last hidden layer of a Family A branch) is then never written to memory.  workspace:
  * mlqem_csr_aggregate_pool_workspace_bytes(N, B, C). */
 size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C);
+size_t mlqem_csr_aggregate_pool_gate_bytes(int64_t N, int C);
 int mlqem_csr_aggregate_pool_f32(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell,
                                  const float* cscale, const float* rscale, const float* dself, float alpha, float beta,
                                  const float* z, int64_t ldz, const float* bias, int act, float drop_p, uint64_t seed,
@@ -373,9 +378,9 @@ int mlqem_segment_pool_f32(const float* x, int64_t ldx, const float* weights, co
 /* Backward: gx[r,:] = (g_mean[g,:] + weights[r] * g_wmean[g,:]) / n_g for every row r of graph g (either gradient may be
  * NULL); gate (may be NULL), applied last: gx = gate[r,:] > 0 ? gx * gate_scale : 0 -- the ReLU/dropout mask of the
  * pooled activation, see mlqem_linear_f32.  16-byte accesses when gx, gate AND the [B,C] gradients own round_up(C,4)
- * columns per row.  gate_bits (instead of gate; needs the 16-byte form): the same mask as sign bits, one byte per (row,
- * 4-column slice), bit v = (activation[row, 4 slice + v] > 0), as mlqem_csr_aggregate_pool_f32 leaves them -- the gate then
- * costs one byte per slice instead of sixteen, and the activation need not exist in memory at all. */
+ * columns per row.  gate_bits (instead of gate; needs the 16-byte form and C <= 64): the same mask as the sign bits
+ * mlqem_csr_aggregate_pool_f32 leaves for the same N and C (tile records + per-wave ballots, see there) -- the gate then costs
+ * half a byte per slice instead of sixteen, read at wave-uniform addresses, and the activation need not exist in memory at all. */
 int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const float* g_wmean, int64_t ld_gwmean,
                                const float* weights, const int32_t* graph_ptr, int64_t N, int64_t B, int C,
                                const float* gate, int64_t ldgate, float gate_scale, const uint8_t* gate_bits, float* gx,

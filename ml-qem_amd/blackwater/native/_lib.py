@@ -11,7 +11,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmlqem_hip.so"))
+# MLQEM_LIB: another build of the same library (A/B measurements of one kernel on one box: scripts/ab_*.sh)
+LIB_PATH = os.environ.get("MLQEM_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmlqem_hip.so"))
 
 
 class NativeLibraryError(RuntimeError):
@@ -53,6 +54,7 @@ SIGNATURES = {
                                   _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mlqem_csr_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _P, _L, _L, _I, _P]),
     "mlqem_csr_aggregate_pool_workspace_bytes": (_S, [_L, _L, _I]),
+    "mlqem_csr_aggregate_pool_gate_bytes": (_S, [_L, _I]),
     "mlqem_csr_aggregate_pool_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _P, _L, _P, _I, _F, _U, _P, _P, _L, _L, _I,
                                           _P, _P, _L, _P, _L, _P, _L, _P, _P, _S, _P]),
     "mlqem_csr_segment_max_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _L, _I, _P]),
@@ -145,7 +147,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 24   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 25   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

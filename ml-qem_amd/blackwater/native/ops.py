@@ -134,7 +134,8 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
     ``pool`` = a dict with ``graph_ptr``, ``num_graphs``, optional ``weights`` and the flags ``mean`` / ``wmean``: the pooled
     means of ``out`` come from the same launch (mlqem_csr_aggregate_pool_f32) and are left in ``pool["out_mean"]`` /
     ``pool["out_wmean"]`` ([B, c] tensors, None for a mean that was not asked for).  ``bits``: also ``pool["out_bits"]``, the
-    sign bits of ``out`` (uint8 [n * ceil(c / 4)]: what ``segment_pool_bwd(gate_bits=)`` gates with); with ``bits`` and
+    sign bits of ``out`` (an opaque uint8 buffer in the launch's tiling -- ``pool_gate_unpack`` decodes it -- that
+    ``segment_pool_bwd(gate_bits=)`` gates with); with ``bits`` and
     ``store=False`` the activation is not written at all and None is returned.  When the fused form is switched off or does
     not serve the shape, ``pool`` is left untouched, ``out`` is written and the caller pools it itself (``pooled_means``)."""
     n, c = x.shape
@@ -171,7 +172,7 @@ def csr_aggregate(x, ptr, idx, *, ell=None, cscale=None, rscale=None, dself=None
         _vec(wts, "weights", n)
         mean = padded_empty(nb, c, x.device) if want_mean else None
         wmean = padded_empty(nb, c, x.device) if want_wmean else None
-        bits = torch.empty(n * ((c + 3) // 4), dtype=torch.uint8, device=x.device) if want_bits else None
+        bits = torch.empty(lib.mlqem_csr_aggregate_pool_gate_bytes(n, c), dtype=torch.uint8, device=x.device) if want_bits else None
         need = lib.mlqem_csr_aggregate_pool_workspace_bytes(n, nb, c)
         ws = _wgrad_workspace(x.device, need)
         code = lib.mlqem_csr_aggregate_pool_f32(
@@ -956,6 +957,26 @@ def segment_pool(x, graph_ptr, num_graphs, weights=None, mean=True, wmean=False)
     return o0, o1
 
 
+def pool_gate_unpack(bits, n, c):
+    """[n, ceil(c / 4)] int32 on the host: bit v of entry (row, slice) = (activation[row, 4 slice + v] > 0), decoded from the gate
+    buffer a pooled aggregation leaves (include/mlqem_hip.h, mlqem_csr_aggregate_pool_f32: tile records, then 32 ballot words per
+    tile).  For tests and debugging; the backward kernel reads the buffer as it is."""
+    import numpy as np
+
+    cv = (c + 3) // 4
+    rows = max(1, 512 // cv)
+    tiles = (max(n, 1) + rows - 1) // rows
+    raw = bits.cpu().numpy()
+    words = raw[16 * tiles:].view(np.uint64).reshape(tiles, 2, 4, 4)              # [tile][k][wave][v]
+    item = np.arange(n * cv, dtype=np.int64)
+    tile, local = item // (rows * cv), item % (rows * cv)
+    k, wave, lane = local >> 8, (local >> 6) & 3, (local & 63).astype(np.uint64)
+    out = np.zeros(n * cv, dtype=np.int32)
+    for v in range(4):
+        out |= ((words[tile, k, wave, v] >> lane) & np.uint64(1)).astype(np.int32) << v
+    return out.reshape(n, cv)
+
+
 def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=None, gate_scale=1.0, out=None, gate_bits=None):
     """gx[r] = (g_mean[g] + weights[r] g_wmean[g]) / n_g (either gradient may be None), optionally gated by gate > 0."""
     ref = g_mean if g_mean is not None else g_wmean
@@ -980,10 +1001,12 @@ def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=N
     if tuple(gx.shape) != (num_nodes, c):
         raise ValueError("segment_pool_bwd: bad out shape")
     gp, gld = _gate(gate, num_nodes, c, False)
-    if gate_bits is not None:      # the gate as sign bits (csr_aggregate(..., pool=) leaves them): one byte per (row, 4-column slice)
-        if gate is not None or gate_bits.dtype != torch.uint8 or not gate_bits.is_cuda or gate_bits.numel() != num_nodes * ((c + 3) // 4) \
+    if gate_bits is not None:      # the gate as sign bits (csr_aggregate(..., pool=) leaves them: tile records + per-wave ballots)
+        want = _lib.load().mlqem_csr_aggregate_pool_gate_bytes(num_nodes, c)
+        if gate is not None or gate_bits.dtype != torch.uint8 or not gate_bits.is_cuda or gate_bits.numel() != want \
                 or not gate_bits.is_contiguous():
-            raise ValueError("segment_pool_bwd: gate_bits must be a contiguous uint8 cuda tensor of num_nodes * ceil(c / 4) entries (and no gate)")
+            raise ValueError(f"segment_pool_bwd: gate_bits must be the contiguous uint8 cuda tensor of {want} bytes the pooled "
+                             "aggregation of the same rows and columns left (and no gate)")
     ld = lambda t: 0 if t is None else (int(t.stride(0)) if b > 1 else (c + 3) // 4 * 4)
     code = _lib.load().mlqem_segment_pool_bwd_f32(_p(g_mean), ld(g_mean), _p(g_wmean), ld(g_wmean),
                                                   _p(weights) if g_wmean is not None else None, _p(graph_ptr), num_nodes, b, c,

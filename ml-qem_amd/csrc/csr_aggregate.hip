@@ -44,21 +44,28 @@ struct PoolFuse {
   int B;
   float* partial;          // [(tiles + B)][2][CV * VEC]
   const int2* tile_graph;  // [tiles]: (graph of the tile's first row, first row of the NEXT graph) (tile_graph_kernel)
-  uint8_t* mask;           // optional [N * CV]: bit v of entry (row, slice) = (out[row, 4 slice + v] > 0) -- what the pooled
-                           // activation's only reader in the backward needs of it (the ReLU / dropout gate); with it the caller
-                           // may pass out == NULL and the activation never reaches memory
+  unsigned long long* mask;  // optional [tiles][kPoolMaskWords]: the sign bits of the tile's items as per-wave BALLOTS -- word
+                             // ((k 4 + wave) 4 + v) of a tile, bit `lane`: out[item k 256 + 64 wave + lane][channel v of its slice] > 0
+                             // (items = (row, 16-byte slice) pairs of the tile, row-major).  What the pooled activation's only
+                             // reader in the backward needs of it (the ReLU / dropout gate); with it the caller may pass
+                             // out == NULL and the activation never reaches memory.  r03 stored a byte per item from every lane
+                             // (24 us of a 381 us launch); the ballots go through LDS and leave as ONE 256-byte store per tile
+  int4* tile_info;           // with mask: [tiles] (graph of the tile's first row, that graph's first row, the next graph's, 0) for
+                             // the backward pass that reads the ballots (pool.hip pool_bwd_tiles_kernel)
 };
 
 // graph of the first row of every tile of `rows` rows: one binary search per tile, outside the kernel that needs it (inside,
 // its ten dependent scalar loads sat in front of every later scalar or LDS wait of the workgroup)
 __global__ __launch_bounds__(kBlock) void tile_graph_kernel(const int32_t* __restrict__ gptr, int B, int rows, int64_t tiles,
-                                                            int2* __restrict__ out) {
+                                                            int2* __restrict__ out, int4* __restrict__ info) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= tiles) return;
   const int g = graph_at(gptr, B, t * rows);
   out[t] = make_int2(g, gptr[g + 1]);       // with the boundary behind it: a tile inside one graph needs nothing else at its end
+  if (info) info[t] = make_int4(g, gptr[g], gptr[g + 1], 0);
 }
 
+constexpr int kPoolMaskWords = 2 * 4 * 4;     // items per thread x waves x channels of a slice (the pooled instantiation: 2, 4, 4)
 constexpr int kRowsMax = 512;        // rows per block (LDS slices of ptr / rscale / dself)
 constexpr int kHeavyDegree = 32;     // rows above this are reduced by the whole block
 constexpr int kHeavyCap = 64;
@@ -79,10 +86,10 @@ __device__ __forceinline__ void stage_bias(const AggArgs& a, float* s_bias, int 
 // per SIMD and the epilogue's operands (about a dozen more SGPRs, 64-bit hash temporaries) tipped the hot path into
 // scratch: +20 % write traffic and +15 % time on the plain launches, measured with the PMC passes of round 2.
 template <int VEC, bool IS_MAX, bool EPI = true, bool POOL = false>
-__device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
+__device__ __forceinline__ unsigned finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
                                            const float (&self)[VEC], float rs, float ds, const float* s_bias,
                                            float* s_tile = nullptr, int64_t r0 = 0, const float* zpre = nullptr,
-                                           uint8_t* mask = nullptr) {
+                                           unsigned long long* s_mask = nullptr, int item = 0) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
@@ -114,17 +121,26 @@ __device__ __forceinline__ void finish_row(const AggArgs& a, int64_t row, int ch
     if (a.nt) vstore_nt<VEC>(a.out + row * a.ldo + ch, res);
     else vstore<VEC>(a.out + row * a.ldo + ch, res);
   }
-  if (POOL && mask) {
-    unsigned bits = 0;
+  unsigned signs = 0;       // POOL: returned -- a lane finishing its OWN item keeps them in a register and the kernel ballots them after
+                            // its item loop (ballots in here kept the compiler from interleaving the items: 384 -> 449 us; handed
+                            // back through a pointer to an array element they went through scratch memory: 413 us)
+  if (POOL) {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) bits |= (res[v] > 0.f ? 1u : 0u) << v;
-    mask[row * a.CV + ch / VEC] = (uint8_t)bits;
+    for (int v = 0; v < VEC; ++v) signs |= (res[v] > 0.f ? 1u : 0u) << v;
+  }
+  if (POOL && s_mask) {
+    // a hub row's items are finished by the lanes of the wave that walked the row: item `item` of the tile (k 256 + 64 wave +
+    // lane) is bit `lane` of word (k 4 + wave) VEC + v -- OR-ed in bit by bit (rare), into the words the ballots are OR-ed into
+    unsigned long long* w = s_mask + ((item >> 8) * 4 + ((item >> 6) & 3)) * VEC;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) if (res[v] > 0.f) atomicOr(w + v, 1ull << (item & 63));
   }
   if (POOL) {               // the workgroup's tile of the output, row-major, for the pooled partial sums at the end of the kernel
     float* t = s_tile + (int)(row - r0) * (a.CV * VEC) + ch;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) t[v] = res[v];
   }
+  return signs;
 }
 
 template <int VEC, bool IS_MAX, int kItemsPerThread>
@@ -289,6 +305,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   __shared__ float s_tile[POOL ? kBlock * kItemsPerThread * VEC : 1];       // POOL: this workgroup's rows of the output
   __shared__ float s_wts[POOL ? kBlock * kItemsPerThread : 1];               // ... the rows' pooling weights
   __shared__ int s_done;                                                     // ... tickets of the waves that are done
+  __shared__ unsigned long long s_mask[POOL ? kPoolMaskWords : 1];           // ... the sign bits of its items (PoolFuse::mask)
+  static_assert(!POOL || (kItemsPerThread == 2 && VEC == 4 && kBlock == 256), "the ballot layout of the pooled form");
   if (EPI) stage_bias(a, s_bias, a.CV * VEC);
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int64_t r0 = (int64_t)blk * a.R;
@@ -305,6 +323,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   int2 tinfo = make_int2(0, 0);
   if constexpr (POOL) {
     if (tid == 0) s_done = 0;
+    if (tid < kPoolMaskWords) s_mask[tid] = 0ull;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kItemsPerThread; ++k) {
@@ -366,8 +385,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     }
   }
   bool heavy[kItemsPerThread];
+  unsigned sign_bits[kItemsPerThread];      // POOL with PoolFuse::mask: signs of the items this lane finishes itself
 #pragma unroll
-  for (int k = 0; k < kItemsPerThread; ++k) heavy[k] = false;
+  for (int k = 0; k < kItemsPerThread; ++k) { heavy[k] = false; sign_bits[k] = 0u; }
 #pragma unroll
   for (int k = 0; k < kItemsPerThread; ++k) {
     if (!live[k]) continue;
@@ -387,7 +407,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
         for (int v = 0; v < VEC; ++v) acc[k][v] = IS_MAX ? fmaxf(acc[k][v], r[v]) : fmaf(w, r[v], acc[k][v]);
       }
     }
-    finish_row<VEC, IS_MAX, EPI, POOL>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias, s_tile, r0, (EPI && a.z) ? zq[k] : nullptr, pf.mask);
+    const unsigned sg = finish_row<VEC, IS_MAX, EPI, POOL>(a, row[k], ch[k], acc[k], self[k], rs[k], ds[k], s_bias, s_tile, r0,
+                                                           (EPI && a.z) ? zq[k] : nullptr);
+    if (POOL) sign_bits[k] = sg;
+  }
+  if constexpr (POOL) {
+    if (pf.mask) {          // the items' signs as per-wave ballots into the tile's words (PoolFuse::mask), one LDS atomic per word
+      const int wv = tid >> 6;
+#pragma unroll
+      for (int k = 0; k < kItemsPerThread; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const unsigned long long b = __ballot((sign_bits[k] >> v) & 1u);
+          if ((tid & 63) == 0 && b) atomicOr(&s_mask[(k * 4 + wv) * VEC + v], b);
+        }
+    }
   }
   // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
   // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
@@ -443,7 +477,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
             if (!use_self) sf[v] = 0.f;
             if (IS_MAX) part[v] = fmaxf(part[v], sf[v]);
           }
-          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, part, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, pf.mask);
+          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, part, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, (POOL && pf.mask) ? s_mask : nullptr,
+                                             (int)(r - r0) * a.CV + hch / VEC);
         }
       } else {   // more slices than lanes: every lane walks all edges for its slices
         for (int sl = lane; sl < a.CV; sl += kWave) {
@@ -463,7 +498,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
 #pragma unroll
             for (int v = 0; v < VEC; ++v) tot[v] = IS_MAX ? fmaxf(tot[v], q[v]) : fmaf(w, q[v], tot[v]);
           }
-          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, tot, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, pf.mask);
+          finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, tot, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, (POOL && pf.mask) ? s_mask : nullptr,
+                                             (int)(r - r0) * a.CV + hch / VEC);
         }
       }
     }
@@ -486,6 +522,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     last = __shfl(last, 0);
     if (!last) return;
     __threadfence_block();
+    if (pf.mask && lane < kPoolMaskWords) pf.mask[(int64_t)blk * kPoolMaskWords + lane] = s_mask[lane];
     // lane = slice * groups + group: a lane adds every groups-th row of its 16-byte channel slice, then the groups of a slice
     // (consecutive lanes) are added by a fixed shuffle tree
     const int cvv = a.CV * VEC;
@@ -586,12 +623,12 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
     grid = dim3((unsigned)eblocks);
   }
   const bool epi = !IS_MAX && (a.z || a.bias || a.act || a.drop_p > 0.f);
-  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
   if (pool) {     // the pooled form exists for the shape the models launch it with: ELL side table, 16-byte rows, an epilogue
     if (IS_MAX || !a.ell || vec != 4 || ipt != 2 || a.CV * 4 > kWave) return MLQEM_ERR_UNSUPPORTED;      // C <= 64: one wave holds a row of the tile
     if (rows_per_tile) *rows_per_tile = a.R;
     hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)ceil_div((int64_t)grid.x, kBlock)), dim3(kBlock), 0, stream, pool->gptr, pool->B,
-                       a.R, (int64_t)grid.x, const_cast<int2*>(pool->tile_graph));
+                       a.R, (int64_t)grid.x, const_cast<int2*>(pool->tile_graph), pool->mask ? pool->tile_info : nullptr);
     if constexpr (!IS_MAX) {
       static const int pool_waves = getenv("MLQEM_AGG_POOL_WAVES") ? atoi(getenv("MLQEM_AGG_POOL_WAVES")) : 7;
       if (pool_waves >= 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<4, false, 2, true, 7, true>), grid, block, 0, stream, a, *pool);
@@ -666,6 +703,8 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_kernel(const float* __res
   if (sum) vstore<VEC>(sum + r * lds + c, sv);
 }
 
+int aggregate_pool_rows_per_tile(int C);
+
 // The aggregation launch of mlqem_csr_aggregate_pool_f32 (pool.hip owns the entry point and the finish kernel): the epilogue
 // form writing per-(tile, graph) pooled partial sums; *rows_per_tile = the rows a workgroup owns.
 int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, const int32_t* idx, const int32_t* ell, const float* cscale,
@@ -674,12 +713,17 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
                                float* partial, int2* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream) {
   AggArgs a{x, ldx, ptr, idx, ell, cscale, rscale, dself, alpha, beta, z, ldz, bias, act, drop_p, seed, seed_counter, out, ldo, N, C, 0, 0};
-  const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph, gate_bits};
+  // gate_bits: [tiles] 16-byte tile records, then [tiles][kPoolMaskWords] ballot words (mlqem_csr_aggregate_pool_gate_bytes)
+  const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), (int64_t)aggregate_pool_rows_per_tile(C));
+  int4* info = reinterpret_cast<int4*>(gate_bits);
+  const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph, gate_bits ? reinterpret_cast<unsigned long long*>(info + tiles) : nullptr,
+                    info};
   return launch_aggregate<false>(a, stream, &pf, rows_per_tile);
 }
 
-// rows a workgroup of the pooled form owns for C channels (what sizes the partial-sum workspace)
+// rows a workgroup of the pooled form owns for C channels (what sizes the partial-sum workspace and the gate buffer)
 int aggregate_pool_rows_per_tile(int C) { return std::max(1, kBlock * 2 / ((C + 3) / 4)); }
+int aggregate_pool_mask_words() { return kPoolMaskWords; }
 
 }  // namespace mlqem
 

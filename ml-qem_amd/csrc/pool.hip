@@ -159,14 +159,13 @@ __global__ __launch_bounds__(kBlock) void pool_finish_tiles_kernel(const float* 
 constexpr int kPoolBwdItems = 4;
 constexpr int kPoolPtrCache = 64;
 
-// GATE: 0 none, 1 the activation itself (gate > 0), 2 its sign bits (one byte per (row, 16-byte slice), as the pooled
-// aggregation leaves them: the gate then costs 1 byte per item instead of 16)
+// GATE: 0 none, 1 the activation itself (gate > 0).  (The sign-bit gate the pooled aggregation leaves has its own kernel below.)
 template <int VEC, int GATE>
 __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restrict__ g0, int64_t ldg0, const float* __restrict__ g1,
                                                           int64_t ldg1, const float* __restrict__ wts,
                                                           const int32_t* __restrict__ gptr, int64_t N, int B, int CV,
                                                           const float* __restrict__ gate, int64_t ldgate, float gate_scale,
-                                                          const uint8_t* __restrict__ gate_bits, float* __restrict__ gx, int64_t ldgx) {
+                                                          float* __restrict__ gx, int64_t ldgx) {
   __shared__ int s_ptr[kPoolPtrCache + 1];
   __shared__ int s_g0;
   const int tid = threadIdx.x;
@@ -197,16 +196,70 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
     if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
     if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
     const float w = (g1 && wts) ? wts[r] : 1.f;
-    unsigned bits = 0;
     if (GATE == 1) vload<VEC>(gate + r * ldgate + ch, gv);
-    if (GATE == 2) bits = gate_bits[it];       // (a thread's four items as ONE 4-byte load needs them consecutive, and consecutive
-                                               // items per thread scatter the 16-byte stores: 174 -> 846 us; measured, reverted)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       float u = fmaf(w, a1[v], a0[v]) * inv;
       if (GATE == 1) u = gv[v] > 0.f ? u * gate_scale : 0.f;
-      if (GATE == 2) u = ((bits >> v) & 1u) ? u * gate_scale : 0.f;
       o[v] = u;
+    }
+    vstore_nt<VEC>(gx + r * ldgx + ch, o);
+  }
+}
+
+// The same gradient gated by the SIGN BITS the pooled aggregation leaves (csr_aggregate.hip PoolFuse::mask): a workgroup takes the
+// tile of rows a workgroup of that launch produced, thread t the items k 256 + t as there, so a wave's gate is four 8-byte words
+// per k at a wave-uniform address (scalar loads) instead of a byte per lane, the item -> (row, slice) split is the tile-local
+// multiply-shift instead of a 64-bit division per item, and the tile's graph comes from the 16-byte record the forward launch left
+// next to the bits (r03: 178 us for 0.59 GB, bound by its request rate: five memory instructions per 16 bytes written).
+// A tile inside ONE graph (all but one in 65 at 100 qubits) reads the graph's two gradient rows at uniform addresses as well.
+template <int CVT>
+__global__ __launch_bounds__(kBlock) void pool_bwd_tiles_kernel(const float* __restrict__ g0, int64_t ldg0, const float* __restrict__ g1,
+                                                                int64_t ldg1, const float* __restrict__ wts,
+                                                                const int32_t* __restrict__ gptr, int64_t N, int B, int CV, int R,
+                                                                float gate_scale, const int4* __restrict__ tile_info,
+                                                                const unsigned long long* __restrict__ words, int words_per_tile,
+                                                                float* __restrict__ gx, int64_t ldgx) {
+  constexpr int VEC = 4;
+  // (several tiles per workgroup with every load issued up front: 167 -> 185 us at one tile, 190 at two, 244 at four -- measured, dropped)
+  const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int64_t r0 = (int64_t)blk * R;
+  const int nrows = (int)min((int64_t)R, N - r0);
+  const int cv = CVT ? CVT : CV;
+  const int n_local = nrows * cv;
+  const unsigned magic = ((1u << 20) + cv - 1) / cv;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int4 ti = tile_info[blk];                      // (graph, its first row, the next graph's first row, -)
+  const bool one_graph = r0 + nrows <= (int64_t)ti.z;  // workgroup-uniform
+  const float inv0 = 1.f / (float)max(ti.z - ti.y, 1);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int li = k * kBlock + tid;
+    if (li >= n_local) continue;
+    const int lrow = (int)(((unsigned)li * magic) >> 20);
+    const int sl = li - lrow * cv, ch = sl * VEC;
+    const int64_t r = r0 + lrow;
+    const unsigned long long* __restrict__ w4 = words + ((int64_t)blk * words_per_tile + (k * 4 + wid) * VEC);
+    float a0[VEC], a1[VEC], o[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) a0[v] = a1[v] = 0.f;
+    float inv = inv0;
+    if (one_graph) {
+      if (g0) vload<VEC>(g0 + (int64_t)ti.x * ldg0 + ch, a0);
+      if (g1) vload<VEC>(g1 + (int64_t)ti.x * ldg1 + ch, a1);
+    } else {
+      int g = ti.x, beg = ti.y, end = ti.z;
+      if (r >= (int64_t)end) { g = graph_at(gptr, B, r); beg = gptr[g]; end = gptr[g + 1]; }
+      inv = 1.f / (float)(end - beg);
+      if (g0) vload<VEC>(g0 + (int64_t)g * ldg0 + ch, a0);
+      if (g1) vload<VEC>(g1 + (int64_t)g * ldg1 + ch, a1);
+    }
+    const float w = (g1 && wts) ? wts[r] : 1.f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float u = fmaf(w, a1[v], a0[v]) * inv;
+      o[v] = ((w4[v] >> lane) & 1ull) ? u * gate_scale : 0.f;
     }
     vstore_nt<VEC>(gx + r * ldgx + ch, o);
   }
@@ -326,7 +379,16 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
                                int64_t ldo, int64_t N, int C, const float* pool_weights, const int32_t* graph_ptr, int B,
                                float* partial, int2* tile_graph, uint8_t* gate_bits, int* rows_per_tile, hipStream_t stream);
 int aggregate_pool_rows_per_tile(int C);
+int aggregate_pool_mask_words();
 }  // namespace mlqem
+
+// Bytes of the gate buffer the pooled aggregation leaves for mlqem_segment_pool_bwd_f32: per tile of rows a 16-byte record
+// (graph, its boundaries) and the sign bits of the tile's items as per-wave ballots (csr_aggregate.hip PoolFuse::mask).
+extern "C" size_t mlqem_csr_aggregate_pool_gate_bytes(int64_t N, int C) {
+  if (N < 0 || C <= 0) return 0;
+  const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), aggregate_pool_rows_per_tile(C));
+  return (size_t)tiles * (sizeof(int4) + (size_t)aggregate_pool_mask_words() * sizeof(unsigned long long));
+}
 
 extern "C" size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C) {
   if (N < 0 || B < 0 || C <= 0) return 0;
@@ -392,10 +454,18 @@ extern "C" int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean,
   if (blocks > 0x7fffffffLL) return MLQEM_ERR_UNSUPPORTED;
   hipStream_t s = as_stream(stream);
 #define MLQEM_POOL_BWD(V, G) hipLaunchKernelGGL((pool_bwd_kernel<V, G>), dim3((unsigned)blocks), dim3(kBlock), 0, s, g_mean, ld_gmean, \
-                                                g_wmean, ld_gwmean, weights, graph_ptr, N, (int)B, cv, gate, ldgate, gate_scale, gate_bits, gx, ldgx)
-  if (gate_bits) {      // one byte per (row, 16-byte slice): the layout of the 16-byte form only
-    if (gate || !wide) return MLQEM_ERR_BAD_ARG;
-    MLQEM_POOL_BWD(4, 2);
+                                                g_wmean, ld_gwmean, weights, graph_ptr, N, (int)B, cv, gate, ldgate, gate_scale, gx, ldgx)
+  if (gate_bits) {      // the pooled aggregation's tile records + ballots: the layout of the 16-byte form only
+    if (gate || !wide || cv * 4 > kWave || !aligned_to(gate_bits, 16)) return MLQEM_ERR_BAD_ARG;
+    const int R = aggregate_pool_rows_per_tile(C);
+    const int64_t tiles = ceil_div(N, (int64_t)R);
+    const int4* info = reinterpret_cast<const int4*>(gate_bits);
+    const unsigned long long* words = reinterpret_cast<const unsigned long long*>(info + tiles);
+#define MLQEM_POOL_BWD_TILES(T) hipLaunchKernelGGL((pool_bwd_tiles_kernel<T>), dim3((unsigned)tiles), dim3(kBlock), 0, s, g_mean, ld_gmean, \
+                                                   g_wmean, ld_gwmean, weights, graph_ptr, N, (int)B, cv, R, gate_scale, info, words,        \
+                                                   aggregate_pool_mask_words(), gx, ldgx)
+    if (cv == 3) MLQEM_POOL_BWD_TILES(3); else MLQEM_POOL_BWD_TILES(0);
+#undef MLQEM_POOL_BWD_TILES
   } else if (wide) { if (gate) MLQEM_POOL_BWD(4, 1); else MLQEM_POOL_BWD(4, 0); }
   else { if (gate) MLQEM_POOL_BWD(1, 1); else MLQEM_POOL_BWD(1, 0); }
 #undef MLQEM_POOL_BWD

@@ -810,7 +810,7 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
     valid = torch.ones(cv, 4, dtype=torch.bool, device=DEV).reshape(-1)
     valid[c:] = False
     mask_of_valid = (valid.reshape(cv, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], device=DEV, dtype=torch.int32)).sum(-1)
-    got_bits = req["out_bits"].reshape(n, cv).to(torch.int32) & mask_of_valid          # the pad columns' bits are scratch
+    got_bits = torch.from_numpy(ops.pool_gate_unpack(req["out_bits"], n, c)).to(DEV) & mask_of_valid    # the pad columns' bits are scratch
     assert torch.equal(got_bits, want_bits.to(torch.int32))
     gm, gwm = torch.randn(b, c, device=DEV), torch.randn(b, c, device=DEV)
     by_act = ops.segment_pool_bwd(gm, gwm, gp, n, weights=wts, gate=plain, gate_scale=1.25)
