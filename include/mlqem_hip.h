@@ -323,7 +323,9 @@ int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t 
  *               k1 = dbeta / N, k2 = dgamma / N  (g: bf16 [N,128], or fp32 [N,ldg32] when g32 != NULL).
  *   pointwise 0: out = dropout(relu?(y scale + shift)) (+ res);   1: out = gs (gu - k1 - xhat k2)   (BatchNorm backward).
  *   wgrad     : gw [U,K] = dY^T X, gb [U] = sum dY  (X fp32 [N,K <= 175] or bf16 [N,128], K <= 128).
- *   rowdot    : the final O <= 4 outputs, out = h w^T + b; rowdot_bwd: gh = g w (bf16), gw = g^T h, gb = sum g. */
+ *   rowdot    : the final O <= 4 outputs, out = h w^T + b; rowdot_bwd: gh = g w (bf16), gw = g^T h, gb = sum g; with gate_scale > 0
+ *               gh = (h > 0 ? gate_scale : 0) g w -- h = dropout(relu(u)) of a block without BatchNorm is its own gate, gh is then
+ *               the gradient at u (ABI 25). */
 size_t mlqem_layer_workspace_bytes(void);
 int mlqem_layer_gemm_bf16(const void* x, int x_is_bf16, int64_t ldx, const float* w, int transposed, const float* b,
                           const void* add_bf16, void* y, int y_is_f32, int64_t ldy, int64_t N, int K, int U, void* workspace,
@@ -342,8 +344,39 @@ int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf16, int64_t
                            void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_layer_rowdot_bf16(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O,
                             mlqem_stream_t stream);
-int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float* gw, float* gb,
-                                int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float gate_scale, float* gw,
+                                float* gb, int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+
+/* The same pipeline with fp32 STORAGE (`mfma = "f32"`: the reference's own arithmetic, docs/tutorials/mlp.py:33-108 in torch's
+ * default dtype): every activation matrix is [N, MLQEM_MLP1_HIDDEN_PAD] fp32 (512-byte rows, 16-byte aligned, columns beyond the
+ * layer's width zero), GEMM operands are NOT rounded (v_mfma_f32_16x16x4_f32).  colstats / pointwise / rowdot / rowdot_bwd:
+ * the bf16 entry points' signatures and meaning with fp32 activation matrices for y, g, res, out, h, gh (g32 stays the narrow
+ * [N, ldg32] form of the incoming gradient).  Same workspace, same counter-based dropout (keyed by the first of every four columns
+ * a lane owns: masks differ from the bf16 pipeline's, forward and backward of one pipeline agree).
+ *   gemm_f32  : Y = X W^T + b (transposed = 0, W [U,K]) or Y = X W (+ add [N,128]) (transposed = 1, W [K,U]); X fp32 [N, ldx],
+ *               K <= 192 columns used (ldx % 4 == 0; an activation matrix: ldx = 128); Y an activation matrix (y_is_act, ldy = 128,
+ *               every column written) or the first U columns of [N, ldy]; U <= 128.  relu / drop_p: the epilogue of a block
+ *               without BatchNorm, Y = dropout(relu(.)) (counter-based mask; its backward gates by Y > 0: rowdot_bwd's gate_scale).
+ *   wgrad_f32 : gw [U,K] = dY^T X, gb [U] = sum dY; dY an activation matrix, X fp32 [N, ldx], K <= 191. */
+int mlqem_layer_gemm_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, const float* add, float* y,
+                         int y_is_act, int64_t ldy, int relu, float drop_p, uint64_t seed, const uint64_t* seed_counter, int64_t N,
+                         int K, int U, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_layer_colstats_f32(int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale,
+                             const float* shift, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float eps, int relu, float drop_p, uint64_t seed, const uint64_t* seed_counter, int64_t N, int C,
+                             float* o1, float* o2, float* o3, float* o4, float* o5, float* running_mean, float* running_var,
+                             float momentum, int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
+                             mlqem_stream_t stream);
+int mlqem_layer_pointwise_f32(int op, const void* y, const void* g, const float* g32, int64_t ldg32, const void* res,
+                              const float* scale, const float* shift, const float* mean, const float* invstd, const float* gs,
+                              const float* k1, const float* k2, int relu, float drop_p, uint64_t seed,
+                              const uint64_t* seed_counter, void* out, int64_t N, int C, mlqem_stream_t stream);
+int mlqem_layer_wgrad_f32(const float* dy, const float* x, int64_t ldx, float* gw, float* gb, int64_t N, int K, int U,
+                          void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+int mlqem_layer_rowdot_f32(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O,
+                           mlqem_stream_t stream);
+int mlqem_layer_rowdot_bwd_f32(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float gate_scale, float* gw,
+                               float* gb, int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Backward of a narrow hidden layer (I, O <= 12) in ONE pass over its operands:
  *   gx[n,:] = (x[n,:] > 0 ? gate_scale : 0) * (gy[n,:] @ W)   (gate != 0; plain gy @ W otherwise)      W: [O, I]

@@ -84,7 +84,14 @@ SIGNATURES = {
     "mlqem_layer_pointwise_bf16": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U, _P, _P, _L, _I, _P]),
     "mlqem_layer_wgrad_bf16": (_I, [_P, _P, _I, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_layer_rowdot_bf16": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P]),
-    "mlqem_layer_rowdot_bwd_bf16": (_I, [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _P, _S, _P]),
+    "mlqem_layer_rowdot_bwd_bf16": (_I, [_P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _P, _S, _P]),
+    "mlqem_layer_gemm_f32": (_I, [_P, _L, _P, _I, _P, _P, _P, _I, _L, _I, _F, _U, _P, _L, _I, _I, _P, _S, _P]),
+    "mlqem_layer_colstats_f32": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _F, _I, _F, _U, _P, _L, _I, _P, _P, _P, _P, _P,
+                                       _P, _P, _F, _P, _P, _S, _P]),
+    "mlqem_layer_pointwise_f32": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U, _P, _P, _L, _I, _P]),
+    "mlqem_layer_wgrad_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
+    "mlqem_layer_rowdot_f32": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P]),
+    "mlqem_layer_rowdot_bwd_f32": (_I, [_P, _L, _P, _P, _P, _F, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_linear_bwd_fused_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _F, _P, _L, _P, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_pooled_head_f32": (_I, [_P, _L, _I, _P, _L, _P]),
     "mlqem_pooled_head_bwd_f32": (_I, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _P]),

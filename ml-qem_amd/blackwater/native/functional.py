@@ -168,14 +168,16 @@ class _MLPTrunkBf16(Function):
 
     @staticmethod
     def forward(ctx, x, cfg, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, w4, b4, run1=None, run2=None):
-        eps1, eps2, p_trunk, p_tail, seeds = cfg
+        eps1, eps2, p_trunk, p_tail, seeds = cfg[:5]
+        f32 = ctx.f32 = len(cfg) > 5 and bool(cfg[5])      # fp32 storage (mfma = "f32"): the same graph on the _f32 entry points
+        gemm = ctx.gemm = (ops.layer_gemm_f32 if f32 else ops.layer_gemm_bf16)
         n, i = x.shape
         h = w1.shape[0]
         xin = x if x.dtype == torch.bfloat16 else ops._mlp1_x(x)
-        y1 = ops.layer_gemm_bf16(xin, w1.contiguous(), b1)
+        y1 = gemm(xin, w1.contiguous(), b1)
         m1, v1, is1, sc1, sh1 = ops.layer_colstats_fwd(y1, g1, be1, eps1, n, h, running=run1)
         x1 = ops.layer_act_bf16(y1, sc1, sh1, n, h, True, p_trunk, seeds[0])
-        y2 = ops.layer_gemm_bf16(x1, w2.contiguous(), b2)
+        y2 = gemm(x1, w2.contiguous(), b2)
         m2, v2, is2, sc2, sh2 = ops.layer_colstats_fwd(y2, g2, be2, eps2, n, h, running=run2)
         s = ops.layer_act_bf16(y2, sc2, sh2, n, h, True, p_trunk, seeds[1], res=x1)
         if w4 is None:                      # MLP2: out = fc3(s)
@@ -183,9 +185,12 @@ class _MLPTrunkBf16(Function):
             y3 = h3 = None
         else:                               # MLP3: out = fc4(drop(relu(fc3(s))))
             h3w = w3.shape[0]
-            y3 = ops.layer_gemm_bf16(s, w3.contiguous(), b3)
             ctx.one, ctx.zero = ops.layer_identity_vectors(x.device)
-            h3 = ops.layer_act_bf16(y3, ctx.one, ctx.zero, n, h3w, True, p_tail, seeds[2])
+            if f32:      # no BatchNorm between fc3 and its ReLU: the GEMM's epilogue applies ReLU + dropout, y3 is never stored
+                y3, h3 = None, gemm(s, w3.contiguous(), b3, relu=True, drop_p=p_tail, seed=seeds[2])
+            else:
+                y3 = gemm(s, w3.contiguous(), b3)
+                h3 = ops.layer_act_bf16(y3, ctx.one, ctx.zero, n, h3w, True, p_tail, seeds[2])
             out = ops.layer_rowdot_bf16(h3, w4.contiguous(), b4, n)
         ctx.cfg, ctx.dims = cfg, (n, i, h)
         ctx.x_needs_grad = ctx.needs_input_grad[0]
@@ -196,34 +201,44 @@ class _MLPTrunkBf16(Function):
     @staticmethod
     def backward(ctx, gout, *_):
         xin, y1, x1, y2, s, y3, h3, w1, w2, w3, w4, g1, g2, m1, is1, sc1, sh1, m2, is2, sc2, sh2 = ctx.saved_tensors
-        eps1, eps2, p_trunk, p_tail, seeds = ctx.cfg
+        eps1, eps2, p_trunk, p_tail, seeds = ctx.cfg[:5]
         n, i, h = ctx.dims
+        gemm, wgrad = ctx.gemm, (ops.layer_wgrad_f32 if ctx.f32 else ops.layer_wgrad_bf16)
         gout = ops.rowmajor(gout)
         if w4 is None:
             gs, gw3, gb3 = ops.layer_rowdot_bwd_bf16(gout, s, w3.contiguous(), n)
             gw4 = gb4 = None
         else:
             h3w = w3.shape[0]
-            gh3, gw4, gb4 = ops.layer_rowdot_bwd_bf16(gout, h3, w4.contiguous(), n)
-            dy3 = ops.layer_bwd_apply_bf16(gh3, y3, ctx.one, ctx.zero, ctx.zero, ctx.one, ctx.one, ctx.zero, ctx.zero, n, h3w, True,
-                                           p_tail, seeds[2])
-            gw3, gb3 = ops.layer_wgrad_bf16(dy3, s, h3w, h)
-            gs = ops.layer_gemm_bf16(dy3, w3.contiguous(), transposed=True)
+            if y3 is None:    # h3 = dropout(relu(u)) is its own gate: the gradient at u in the launch that forms g w4
+                dy3, gw4, gb4 = ops.layer_rowdot_bwd_bf16(gout, h3, w4.contiguous(), n, gate_scale=1.0 / (1.0 - p_tail))
+            else:
+                gh3, gw4, gb4 = ops.layer_rowdot_bwd_bf16(gout, h3, w4.contiguous(), n)
+                dy3 = ops.layer_bwd_apply_bf16(gh3, y3, ctx.one, ctx.zero, ctx.zero, ctx.one, ctx.one, ctx.zero, ctx.zero, n, h3w, True,
+                                               p_tail, seeds[2])
+            gw3, gb3 = wgrad(dy3, s, h3w, h)
+            gs = gemm(dy3, w3.contiguous(), transposed=True)
         # block 2: s = x1 + drop(relu(bn2(fc2 x1)))
         db2, dg2, gs2, k1, k2 = ops.layer_colstats_bwd(gs, y2, sc2, sh2, m2, is2, g2, True, p_trunk, seeds[1], n, h)
         dy2 = ops.layer_bwd_apply_bf16(gs, y2, sc2, sh2, m2, is2, gs2, k1, k2, n, h, True, p_trunk, seeds[1])
-        gw2, gb2 = ops.layer_wgrad_bf16(dy2, x1, h, h)
-        gx1 = ops.layer_gemm_bf16(dy2, w2.contiguous(), transposed=True, add=gs)       # + the residual path
+        gw2, gb2 = wgrad(dy2, x1, h, h)
+        gx1 = gemm(dy2, w2.contiguous(), transposed=True, add=gs)       # + the residual path
         # block 1: x1 = drop(relu(bn1(fc1 x)))
         db1, dg1, gs1, k1, k2 = ops.layer_colstats_bwd(gx1, y1, sc1, sh1, m1, is1, g1, True, p_trunk, seeds[0], n, h)
         dy1 = ops.layer_bwd_apply_bf16(gx1, y1, sc1, sh1, m1, is1, gs1, k1, k2, n, h, True, p_trunk, seeds[0])
-        gw1, gb1 = ops.layer_wgrad_bf16(dy1, xin, h, i)
-        gx = ops.layer_gemm_bf16(dy1, w1.contiguous(), transposed=True, out_f32=True) if ctx.x_needs_grad else None
+        gw1, gb1 = wgrad(dy1, xin, h, i)
+        if not ctx.x_needs_grad:
+            gx = None
+        elif ctx.f32:
+            gx = gemm(dy1, w1.contiguous(), transposed=True, narrow_out=True)
+        else:
+            gx = gemm(dy1, w1.contiguous(), transposed=True, out_f32=True)
         return (gx, None, gw1, gb1, dg1[:h], db1[:h], gw2, gb2, dg2[:h], db2[:h], gw3, gb3, gw4, gb4, None, None)
 
 
 def mlp_trunk_bf16_ok(x, fc1, fc2, fc3, fc4, bn1, bn2) -> bool:
-    """Whether the bf16-storage pipeline takes this call: widths inside the kernels' limits, affine BatchNorm with a momentum."""
+    """Whether the layer pipeline (csrc/mlp_layers.hip, either storage) takes this call: widths inside the kernels' limits, affine
+    BatchNorm with a momentum."""
     if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 2):
         return False
     i, h = fc1.weight.shape[1], fc1.weight.shape[0]
@@ -238,9 +253,14 @@ def mlp_trunk_bf16_ok(x, fc1, fc2, fc3, fc4, bn1, bn2) -> bool:
     return os.environ.get("MLQEM_MLP_BF16_STORAGE", "1") != "0"
 
 
-def mlp_trunk_bf16(x, fc1, bn1, fc2, bn2, fc3, fc4, p_trunk, p_tail, seeds):
-    """Runs the block and updates the BatchNorm running statistics like torch (momentum, unbiased variance, batch counter)."""
-    cfg = (float(bn1.eps), float(bn2.eps), float(p_trunk), float(p_tail), tuple(int(v) for v in seeds))
+# MLQEM_MLP_F32_LAYERS=0: the fp32 models' training step on the general kernels again (linear + bn.hip + relu_dropout; A/B)
+_MLP_F32_LAYERS = os.environ.get("MLQEM_MLP_F32_LAYERS", "1") != "0"
+
+
+def mlp_trunk_bf16(x, fc1, bn1, fc2, bn2, fc3, fc4, p_trunk, p_tail, seeds, f32=False):
+    """Runs the block and updates the BatchNorm running statistics like torch (momentum, unbiased variance, batch counter).
+    ``f32``: fp32 storage and unrounded operands (mfma = "f32") instead of bfloat16."""
+    cfg = (float(bn1.eps), float(bn2.eps), float(p_trunk), float(p_tail), tuple(int(v) for v in seeds), bool(f32))
     w4, b4 = (None, None) if fc4 is None else (fc4.weight, fc4.bias)
     # BatchNorm1d's buffer update rides in the statistics launches (running mean / unbiased variance / batch counter)
     runs = [((bn.running_mean, bn.running_var, float(bn.momentum), bn.num_batches_tracked)

@@ -714,7 +714,9 @@ def mlp1_backward(gout, x, hs, w2, i, h, bf16=False, dst=None, want_loss=False):
     return (gw1, gb1, gw2, gb2) if not want_loss else (gw1, gb1, gw2, gb2, loss)
 
 
-# ---- bf16-storage layers of MLP2 / MLP3 (csrc/mlp_layers.hip): every activation is a [N, 128] bfloat16 matrix
+# ---- the layers of MLP2 / MLP3 in training mode (csrc/mlp_layers.hip): every activation is a [N, 128] matrix, bfloat16 (mfma = "bf16":
+# half the bytes of every pass) or float32 (mfma = "f32": the reference's own arithmetic).  The wrappers below take either -- the
+# storage is the dtype of the activation they are handed -- and call the _bf16 / _f32 entry point of the same name.
 LAYER_W = 128
 
 
@@ -733,8 +735,16 @@ def layer_identity_vectors(device):
     return c
 
 
-def _act(n, device):
-    return torch.empty((max(n, 1), LAYER_W), dtype=torch.bfloat16, device=device)
+def _act(n, device, f32=False):
+    return torch.empty((max(n, 1), LAYER_W), dtype=torch.float32 if f32 else torch.bfloat16, device=device)
+
+
+def _is_act(t):
+    return t.dim() == 2 and t.shape[1] == LAYER_W and t.is_contiguous()
+
+
+def _sfx(f32):
+    return "f32" if f32 else "bf16"
 
 
 def _seed_args(drop_p, seed):
@@ -766,8 +776,31 @@ def layer_gemm_bf16(x, w, b=None, *, transposed=False, add=None, out_f32=False):
     return y
 
 
+def layer_gemm_f32(x, w, b=None, *, transposed=False, add=None, narrow_out=False, relu=False, drop_p=0.0, seed=0):
+    """The fp32-storage twin: X fp32 -- [N, K] in padded rows (the block's input) or an fp32 activation [N, 128] -- to an fp32
+    activation [N, 128] or, ``narrow_out``, fp32 [N, U]; operands are not rounded.  ``relu`` / ``drop_p``: the result is
+    dropout(relu(.)) -- a block without BatchNorm in one launch (its backward gates by result > 0)."""
+    n = x.shape[0]
+    k, u = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] < k:
+        raise ValueError(f"layer_gemm_f32: x must be fp32 [N, >= {k}]")
+    x = _mlp1_x(x)
+    ldx = _mat(x, "x") if n > 1 else (x.shape[1] + 3) // 4 * 4
+    if not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
+        raise ValueError("layer_gemm_f32: w must be a contiguous fp32 cuda tensor")
+    if add is not None and not (add.dtype == torch.float32 and _is_act(add)):
+        raise ValueError("layer_gemm_f32: add must be an fp32 activation [N, 128]")
+    y = torch.empty((n, u), dtype=torch.float32, device=w.device) if narrow_out else _act(n, w.device, True)
+    ws, need = _layer_ws(w.device)
+    code = _lib.load().mlqem_layer_gemm_f32(_p(x), ldx, _p(w), 1 if transposed else 0, _p(b), _p(add), _p(y), 0 if narrow_out else 1,
+                                            u if narrow_out else LAYER_W, 1 if relu else 0, *_seed_args(drop_p, seed), n, k, u, _p(ws), need,
+                                            _stream())
+    _lib.check(code, "mlqem_layer_gemm_f32")
+    return y
+
+
 def layer_colstats_fwd(y, gamma, beta, eps, n, c, running=None):
-    """(mean, var, invstd, scale, shift) of the first ``c`` columns of the bf16 activation ``y`` over ``n`` rows (each [128], zeros
+    """(mean, var, invstd, scale, shift) of the first ``c`` columns of the activation ``y`` over ``n`` rows (each [128], zeros
     beyond ``c``).  ``running`` = (running_mean, running_var, momentum, num_batches_tracked | None): BatchNorm1d's buffer update,
     applied by the same launch."""
     dev = y.device
@@ -777,41 +810,56 @@ def layer_colstats_fwd(y, gamma, beta, eps, n, c, running=None):
     if rm is not None and not (rm.is_cuda and rv.is_cuda and rm.dtype == rv.dtype == torch.float32 and rm.numel() == rv.numel() == c
                                and rm.is_contiguous() and rv.is_contiguous() and (nbt is None or (nbt.is_cuda and nbt.dtype == torch.int64))):
         raise ValueError("layer_colstats_fwd: running statistics must be contiguous fp32 [c] device tensors (counter: int64)")
-    code = _lib.load().mlqem_layer_colstats_bf16(0, _p(y), None, None, 0, None, None, None, None, _p(gamma), _p(beta), float(eps), 0, 0.0, 0,
-                                                 None, n, c, *[_p(t) for t in o], _p(rm), _p(rv), float(mo), _p(nbt), _p(ws), need, _stream())
-    _lib.check(code, "mlqem_layer_colstats_bf16")
+    name = "mlqem_layer_colstats_" + _sfx(y.dtype == torch.float32)
+    code = getattr(_lib.load(), name)(0, _p(y), None, None, 0, None, None, None, None, _p(gamma), _p(beta), float(eps), 0, 0.0, 0,
+                                      None, n, c, *[_p(t) for t in o], _p(rm), _p(rv), float(mo), _p(nbt), _p(ws), need, _stream())
+    _lib.check(code, name)
     return o
 
 
+def _grad_operand(g, y, n, c):
+    """The incoming gradient as (activation in y's storage | None, narrow fp32 | None, its row pitch)."""
+    if g.dtype == y.dtype and _is_act(g):
+        return g, None, 0
+    if g.dtype != torch.float32:
+        raise ValueError("the incoming gradient must be an activation in the pipeline's storage or fp32 [N, c]")
+    return None, g, (_mat(g, "g") if n > 1 else c)
+
+
 def layer_colstats_bwd(g, y, scale, shift, mean, invstd, gamma, relu, drop_p, seed, n, c):
-    """(dbeta, dgamma, gs, k1, k2) of a BatchNorm block from the incoming gradient ``g`` (bf16 activation or fp32 [N, c]) and ``y``."""
+    """(dbeta, dgamma, gs, k1, k2) of a BatchNorm block from the incoming gradient ``g`` (an activation or fp32 [N, c]) and ``y``."""
     dev = y.device
     o = list(torch.empty((5, LAYER_W), dtype=torch.float32, device=dev).unbind(0))      # the launch writes every entry
     ws, need = _layer_ws(dev)
-    g16, g32, ld = (g, None, 0) if g.dtype == torch.bfloat16 else (None, g, _mat(g, "g") if n > 1 else c)
-    code = _lib.load().mlqem_layer_colstats_bf16(1, _p(y), _p(g16), _p(g32), ld, _p(scale), _p(shift), _p(mean), _p(invstd), _p(gamma), None,
-                                                 0.0, 1 if relu else 0, *_seed_args(drop_p, seed), n, c, *[_p(t) for t in o], None, None, 0.0,
-                                                 None, _p(ws), need, _stream())
-    _lib.check(code, "mlqem_layer_colstats_bf16")
+    ga, g32, ld = _grad_operand(g, y, n, c)
+    name = "mlqem_layer_colstats_" + _sfx(y.dtype == torch.float32)
+    code = getattr(_lib.load(), name)(1, _p(y), _p(ga), _p(g32), ld, _p(scale), _p(shift), _p(mean), _p(invstd), _p(gamma), None,
+                                      0.0, 1 if relu else 0, *_seed_args(drop_p, seed), n, c, *[_p(t) for t in o], None, None, 0.0,
+                                      None, _p(ws), need, _stream())
+    _lib.check(code, name)
     return o
 
 
 def layer_act_bf16(y, scale, shift, n, c, relu=True, drop_p=0.0, seed=0, res=None):
-    """drop(relu(y scale + shift)) (+ res) as a new bf16 activation."""
-    out = _act(n, y.device)
-    code = _lib.load().mlqem_layer_pointwise_bf16(0, _p(y), None, None, 0, _p(res), _p(scale), _p(shift), None, None, None, None, None,
-                                                  1 if relu else 0, *_seed_args(drop_p, seed), _p(out), n, c, _stream())
-    _lib.check(code, "mlqem_layer_pointwise_bf16")
+    """drop(relu(y scale + shift)) (+ res) as a new activation in y's storage."""
+    f32 = y.dtype == torch.float32
+    out = _act(n, y.device, f32)
+    name = "mlqem_layer_pointwise_" + _sfx(f32)
+    code = getattr(_lib.load(), name)(0, _p(y), None, None, 0, _p(res), _p(scale), _p(shift), None, None, None, None, None,
+                                      1 if relu else 0, *_seed_args(drop_p, seed), _p(out), n, c, _stream())
+    _lib.check(code, name)
     return out
 
 
 def layer_bwd_apply_bf16(g, y, scale, shift, mean, invstd, gs, k1, k2, n, c, relu=True, drop_p=0.0, seed=0):
-    """dy = gs (gu - k1 - xhat k2) as a bf16 activation (gs = 1, k1 = k2 = 0: dy = gu, a block without BatchNorm)."""
-    out = _act(n, y.device)
-    g16, g32, ld = (g, None, 0) if g.dtype == torch.bfloat16 else (None, g, _mat(g, "g") if n > 1 else c)
-    code = _lib.load().mlqem_layer_pointwise_bf16(1, _p(y), _p(g16), _p(g32), ld, None, _p(scale), _p(shift), _p(mean), _p(invstd), _p(gs),
-                                                  _p(k1), _p(k2), 1 if relu else 0, *_seed_args(drop_p, seed), _p(out), n, c, _stream())
-    _lib.check(code, "mlqem_layer_pointwise_bf16")
+    """dy = gs (gu - k1 - xhat k2) as an activation in y's storage (gs = 1, k1 = k2 = 0: dy = gu, a block without BatchNorm)."""
+    f32 = y.dtype == torch.float32
+    out = _act(n, y.device, f32)
+    ga, g32, ld = _grad_operand(g, y, n, c)
+    name = "mlqem_layer_pointwise_" + _sfx(f32)
+    code = getattr(_lib.load(), name)(1, _p(y), _p(ga), _p(g32), ld, None, _p(scale), _p(shift), _p(mean), _p(invstd), _p(gs),
+                                      _p(k1), _p(k2), 1 if relu else 0, *_seed_args(drop_p, seed), _p(out), n, c, _stream())
+    _lib.check(code, name)
     return out
 
 
@@ -828,25 +876,41 @@ def layer_wgrad_bf16(dy, x, u, k):
     return gw, gb
 
 
+def layer_wgrad_f32(dy, x, u, k):
+    """The fp32-storage twin: dy an fp32 activation, x fp32 [N, >= k] (padded rows or an activation)."""
+    n = x.shape[0]
+    ldx = _mat(x, "x") if n > 1 else (x.shape[1] + 3) // 4 * 4
+    gw = torch.empty((u, k), dtype=torch.float32, device=dy.device)
+    gb = torch.empty(u, dtype=torch.float32, device=dy.device)
+    ws, need = _layer_ws(dy.device)
+    code = _lib.load().mlqem_layer_wgrad_f32(_p(dy), _p(x), ldx, _p(gw), _p(gb), n, k, u, _p(ws), need, _stream())
+    _lib.check(code, "mlqem_layer_wgrad_f32")
+    return gw, gb
+
+
 def layer_rowdot_bf16(h, w, b, n):
     o, c = w.shape
     out = torch.empty((n, o), dtype=torch.float32, device=h.device)
-    code = _lib.load().mlqem_layer_rowdot_bf16(_p(h), _p(w), _p(b), _p(out), o, n, c, o, _stream())
-    _lib.check(code, "mlqem_layer_rowdot_bf16")
+    name = "mlqem_layer_rowdot_" + _sfx(h.dtype == torch.float32)
+    code = getattr(_lib.load(), name)(_p(h), _p(w), _p(b), _p(out), o, n, c, o, _stream())
+    _lib.check(code, name)
     return out
 
 
-def layer_rowdot_bwd_bf16(g, h, w, n):
-    """(gh bf16 activation, gw [O, C], gb [O]) of out = h w^T + b."""
+def layer_rowdot_bwd_bf16(g, h, w, n, gate_scale=0.0):
+    """(gh activation in h's storage, gw [O, C], gb [O]) of out = h w^T + b.  ``gate_scale`` > 0: gh comes out gated by h > 0 and
+    scaled -- with h = dropout(relu(u)) that is the gradient at u (gate_scale = 1 / (1 - p))."""
     o, c = w.shape
     g = rowmajor(g)
-    gh = _act(n, h.device)
+    f32 = h.dtype == torch.float32
+    gh = _act(n, h.device, f32)
     gw = torch.empty((o, c), dtype=torch.float32, device=h.device)
     gb = torch.empty(o, dtype=torch.float32, device=h.device)
     ws, need = _layer_ws(h.device)
-    code = _lib.load().mlqem_layer_rowdot_bwd_bf16(_p(g), int(g.stride(0)) if n > 1 else o, _p(h), _p(w), _p(gh), _p(gw), _p(gb), n, c, o,
-                                                   _p(ws), need, _stream())
-    _lib.check(code, "mlqem_layer_rowdot_bwd_bf16")
+    name = "mlqem_layer_rowdot_bwd_" + _sfx(f32)
+    code = getattr(_lib.load(), name)(_p(g), int(g.stride(0)) if n > 1 else o, _p(h), _p(w), _p(gh), float(gate_scale), _p(gw), _p(gb), n, c, o,
+                                      _p(ws), need, _stream())
+    _lib.check(code, name)
     return gh, gw, gb
 
 

@@ -88,18 +88,20 @@ class MLP2(nn.Module):
         return self._layer(x1, self.fc2, self.bn2, residual=x1)
 
     def _bf16_storage(self, x, fc4=None, p_tail=0.0):
-        """``mfma == "bf16"`` in training mode: the whole block on the bf16-storage kernels (csrc/mlp_layers.hip) -- layer outputs
-        and everything kept for the backward as bfloat16, half the bytes of every pass.  None when the shapes are not theirs."""
+        """Training mode: the whole block as ONE autograd node on the layer kernels (csrc/mlp_layers.hip) -- ``mfma == "bf16"``: layer
+        outputs and everything kept for the backward as bfloat16, half the bytes of every pass; ``mfma == "f32"`` (the default, the
+        reference's arithmetic): the same kernels with fp32 storage and unrounded operands.  None when the shapes are not theirs."""
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        if not (self.training and self.mfma == "bf16" and F.mlp_trunk_bf16_ok(x2, self.fc1, self.fc2, self.fc3, fc4, self.bn1, self.bn2)):
+        f32 = self.mfma == "f32" and F._MLP_F32_LAYERS
+        if not (self.training and (self.mfma == "bf16" or f32) and F.mlp_trunk_bf16_ok(x2, self.fc1, self.fc2, self.fc3, fc4, self.bn1, self.bn2)):
             return None
         from .models import dropout_key
 
         self._calls = getattr(self, "_calls", 0) + 1
         static = getattr(self, "static_dropout_key", False)
         seeds = [dropout_key((k + 1) if static else 3 * self._calls + k, salt=0x4D4C50) for k in range(3)]
-        out = F.mlp_trunk_bf16(x2, self.fc1, self.bn1, self.fc2, self.bn2, self.fc3, fc4, self.p, p_tail, seeds)
+        out = F.mlp_trunk_bf16(x2, self.fc1, self.bn1, self.fc2, self.bn2, self.fc3, fc4, self.p, p_tail, seeds, f32=f32)
         return out.reshape(*lead, out.shape[-1])
 
     def forward(self, x):

@@ -185,13 +185,41 @@ __global__ __launch_bounds__(kLayerThreads) void layer_fwd_kernel(const LayerArg
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise and column sums
-// A thread owns the 8 columns c0 = 8 (tid & 15) of rows (tid >> 4) + 16 k: one 16-byte access per matrix and row.
+// A thread owns 8 columns of rows (tid >> 4) + 16 k.  bf16 storage: the columns 8 t .. 8 t + 7, t = tid & 15 (one 16-byte access
+// per matrix and row).  fp32 storage: 4 t .. 4 t + 3 and 64 + 4 t .. 64 + 4 t + 3 -- two 16-byte accesses, each of them contiguous
+// across the 16 lanes of a row (eight adjacent floats per lane would make every load instruction touch every other 16 bytes).
+template <typename ST> __device__ __forceinline__ int col_of(int t, int e) {
+  if constexpr (std::is_same_v<ST, float>) return e < 4 ? 4 * t + e : 60 + 4 * t + e; else return 8 * t + e;
+}
+template <typename ST>
+__device__ __forceinline__ void load8(const ST* __restrict__ row, int t, float (&f)[8]) {
+  if constexpr (std::is_same_v<ST, float>) {
+    const float4 lo = *reinterpret_cast<const float4*>(row + 4 * t), hi = *reinterpret_cast<const float4*>(row + 64 + 4 * t);
+    f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+  } else {
+    unpack8(*reinterpret_cast<const u32x4*>(row + 8 * t), f);
+  }
+}
+template <typename ST>
+__device__ __forceinline__ void store8(ST* __restrict__ row, int t, const float (&f)[8]) {
+  if constexpr (std::is_same_v<ST, float>) {
+    *reinterpret_cast<float4*>(row + 4 * t) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(row + 64 + 4 * t) = make_float4(f[4], f[5], f[6], f[7]);
+  } else {
+    *reinterpret_cast<u32x4*>(row + 8 * t) = pack8(f);
+  }
+}
+// a value as the storage holds it (what the next reader sees)
+template <typename ST> __device__ __forceinline__ float stored(float v) {
+  if constexpr (std::is_same_v<ST, float>) return v; else return (float)(__bf16)v;
+}
+
 struct ActArgs {
-  const unsigned short* y; const unsigned short* g; const unsigned short* res;   // [N,128] bf16
+  const void* y; const void* g; const void* res;                                   // [N,128] in the pipeline's storage (bf16 or fp32)
   const float* g32; int64_t ldg32;                                                  // the incoming gradient as fp32 [N, ldg32] instead of g
   const float* scale; const float* shift; const float* mean; const float* invstd;  // per column [128]
   const float* gs; const float* k1; const float* k2;                                // backward apply
-  unsigned short* out;
+  void* out;
   float* partial;                                                                   // column sums: [blocks][2][128]
   int64_t N; int C; int relu;
   float drop_p; uint64_t seed; const uint64_t* seed_counter;
@@ -200,21 +228,24 @@ struct ActArgs {
 
 // the 8 per-column constants of this thread: two 16-byte loads (every per-column vector of this file is [128] floats with zeros
 // beyond the layer's width).  Eight predicated scalar loads per vector cost more than the rows the thread then processes.
-__device__ __forceinline__ void col8(const float* __restrict__ v, int c0, float (&f)[8]) {
-  const float4 lo = *reinterpret_cast<const float4*>(v + c0), hi = *reinterpret_cast<const float4*>(v + c0 + 4);
+template <typename ST>
+__device__ __forceinline__ void col8(const float* __restrict__ v, int t, float (&f)[8]) {
+  const float4 lo = *reinterpret_cast<const float4*>(v + col_of<ST>(t, 0)), hi = *reinterpret_cast<const float4*>(v + col_of<ST>(t, 4));
   f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
 }
 
-// keep / drop decisions of the 8 columns c0 .. c0 + 7 of a row as a bit mask: two splitmix64 rounds, four 16-bit uniforms each
-// (the scheme of common.hpp's dropout_keep; a mask in a register -- bool arrays handed through references went to scratch
-// memory, byte by byte, and made every element-wise kernel of this file six times slower than its bytes)
-__device__ __forceinline__ unsigned keep_mask8(const ActArgs& a, uint64_t seed, int64_t row, int c0) {
+// keep / drop decisions of the thread's 8 columns of a row as a bit mask: two splitmix64 rounds, four 16-bit uniforms each, keyed
+// by the first column of each group of four (the scheme of common.hpp's dropout_keep; a mask in a register -- bool arrays handed
+// through references went to scratch memory, byte by byte, and made every element-wise kernel of this file six times slower than
+// its bytes)
+template <typename ST>
+__device__ __forceinline__ unsigned keep_mask8(const ActArgs& a, uint64_t seed, int64_t row, int t) {
   if (!(a.drop_p > 0.f)) return 0xFFu;
   const unsigned thr = (unsigned)(a.drop_p * 65536.f);
   unsigned m = 0;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    uint64_t z = seed + ((uint64_t)(row * kLW + c0 + 4 * half) + 1) * 0x9E3779B97F4A7C15ull;
+    uint64_t z = seed + ((uint64_t)(row * kLW + col_of<ST>(t, 4 * half)) + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
@@ -225,78 +256,80 @@ __device__ __forceinline__ unsigned keep_mask8(const ActArgs& a, uint64_t seed, 
 }
 
 // z = drop(relu(y s + t)) (+ res); columns >= C stay zero
+template <typename ST>
 __global__ __launch_bounds__(256) void layer_act_kernel(const ActArgs a) {
-  const int c0 = 8 * (threadIdx.x & 15);
+  const int t = threadIdx.x & 15;
   float sc[8], sh[8];
-  col8(a.scale, c0, sc);
-  col8(a.shift, c0, sh);
+  col8<ST>(a.scale, t, sc);
+  col8<ST>(a.shift, t, sh);
   const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
   const float inv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < a.N; row += (int64_t)gridDim.x * 16) {
     float y[8], r[8];
-    unpack8(*reinterpret_cast<const u32x4*>(a.y + row * kLW + c0), y);
-    if (a.res) unpack8(*reinterpret_cast<const u32x4*>(a.res + row * kLW + c0), r);
-    const unsigned keep = keep_mask8(a, seed, row, c0);
+    load8(static_cast<const ST*>(a.y) + row * kLW, t, y);
+    if (a.res) load8(static_cast<const ST*>(a.res) + row * kLW, t, r);
+    const unsigned keep = keep_mask8<ST>(a, seed, row, t);
     float z[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float u = fmaf(y[e], sc[e], sh[e]);
       if (a.relu) u = fmaxf(u, 0.f);
       u = ((keep >> e) & 1u) ? u * inv : 0.f;
-      if (a.res) u = (float)(__bf16)u + r[e];        // the residual adds to the STORED activation (what the next layer and the backward see)
-      z[e] = (c0 + e < a.C) ? u : 0.f;
+      if (a.res) u = stored<ST>(u) + r[e];           // the residual adds to the STORED activation (what the next layer and the backward see)
+      z[e] = (col_of<ST>(t, e) < a.C) ? u : 0.f;
     }
-    *reinterpret_cast<u32x4*>(a.out + row * kLW + c0) = pack8(z);
+    store8(static_cast<ST*>(a.out) + row * kLW, t, z);
   }
 }
 
-// The gradient at a block's pre-activation u = y s + t: gu = g o (u > 0) o keep / (1 - p), from g (bf16 or fp32) and y.
+// The gradient at a block's pre-activation u = y s + t: gu = g o (u > 0) o keep / (1 - p), from g (storage type or fp32) and y.
+template <typename ST>
 __device__ __forceinline__ void load_gu(const ActArgs& a, uint64_t seed, float inv, const float (&sc)[8], const float (&sh)[8], int64_t row,
-                                        int c0, float (&gu)[8], float (&y)[8]) {
+                                        int t, float (&gu)[8], float (&y)[8]) {
   float g[8];
-  unpack8(*reinterpret_cast<const u32x4*>(a.y + row * kLW + c0), y);
+  load8(static_cast<const ST*>(a.y) + row * kLW, t, y);
   if (a.g32) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = (c0 + e < a.C) ? a.g32[row * a.ldg32 + c0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) g[e] = (col_of<ST>(t, e) < a.C) ? a.g32[row * a.ldg32 + col_of<ST>(t, e)] : 0.f;
   } else {
-    unpack8(*reinterpret_cast<const u32x4*>(a.g + row * kLW + c0), g);
+    load8(static_cast<const ST*>(a.g) + row * kLW, t, g);
   }
-  const unsigned keep = keep_mask8(a, seed, row, c0);
+  const unsigned keep = keep_mask8<ST>(a, seed, row, t);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float u = fmaf(y[e], sc[e], sh[e]);
-    const bool on = (!a.relu || u > 0.f) && ((keep >> e) & 1u) && c0 + e < a.C;
+    const bool on = (!a.relu || u > 0.f) && ((keep >> e) & 1u) && col_of<ST>(t, e) < a.C;
     gu[e] = on ? g[e] * inv : 0.f;
   }
 }
 
 // MODE 0: s1 = sum y, s2 = sum y^2.  MODE 1: s1 = sum gu, s2 = sum gu xhat, xhat = (y - mean) invstd.
-template <int MODE>
+template <int MODE, typename ST>
 __global__ __launch_bounds__(256) void layer_colsum_kernel(const ActArgs a) {
   __shared__ float s_red[2][16][kLW];
-  const int c0 = 8 * (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  const int t = threadIdx.x & 15, rl = threadIdx.x >> 4;
   float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = sh[e] = mu[e] = is[e] = s1[e] = s2[e] = 0.f;
-  if (MODE == 1) { col8(a.scale, c0, sc); col8(a.shift, c0, sh); col8(a.mean, c0, mu); col8(a.invstd, c0, is); }
+  if (MODE == 1) { col8<ST>(a.scale, t, sc); col8<ST>(a.shift, t, sh); col8<ST>(a.mean, t, mu); col8<ST>(a.invstd, t, is); }
   const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
   const float inv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block, r1 = min(r0 + a.rows_per_block, a.N);
   for (int64_t row = r0 + rl; row < r1; row += 16) {
     if (MODE == 0) {
       float y[8];
-      unpack8(*reinterpret_cast<const u32x4*>(a.y + row * kLW + c0), y);
+      load8(static_cast<const ST*>(a.y) + row * kLW, t, y);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] += y[e]; s2[e] = fmaf(y[e], y[e], s2[e]); }
     } else {
       float gu[8], y[8];
-      load_gu(a, seed, inv, sc, sh, row, c0, gu, y);
+      load_gu<ST>(a, seed, inv, sc, sh, row, t, gu, y);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] += gu[e]; s2[e] = fmaf(gu[e], (y[e] - mu[e]) * is[e], s2[e]); }
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { s_red[0][rl][c0 + e] = s1[e]; s_red[1][rl][c0 + e] = s2[e]; }
+  for (int e = 0; e < 8; ++e) { s_red[0][rl][col_of<ST>(t, e)] = s1[e]; s_red[1][rl][col_of<ST>(t, e)] = s2[e]; }
   __syncthreads();
   if (threadIdx.x < kLW) {
     float t1 = 0.f, t2 = 0.f;
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(256) void layer_colsum_kernel(const ActArgs a) {
 // MODE 1 -> dbeta (s1), dgamma (s2), gs = gamma invstd, k1 = s1 / N, k2 = s2 / N.
 // One workgroup per column of the 128-wide layout (columns >= C get zeros: the element-wise kernels load the vectors eight
 // columns at a time).  256 threads walk the partials (with 64 a thread summed 32 partials one load after the other: 15 us a
-// launch, four launches a step); the 256 thread sums are added in thread order, in double.  MODE 0 also applies the
+// launch, four launches a step); the 256 thread sums are added by a fixed tree, in double.  MODE 0 also applies the
 // BatchNorm running-statistics update (torch: running = (1 - momentum) running + momentum batch, the variance unbiased;
 // num_batches_tracked += 1) when the buffers are given -- five element-wise launches of the host side otherwise.
 constexpr int kFinishThreads = 256;
@@ -337,9 +370,14 @@ __global__ __launch_bounds__(kFinishThreads) void layer_finish_kernel(const floa
   }
   s_t[0][j] = t1; s_t[1][j] = t2;
   __syncthreads();
+  // a fixed tree over the 256 thread sums (thread 0 adding them one after the other was most of the launch's 11 us)
+#pragma unroll
+  for (int half = kFinishThreads / 2; half >= 1; half >>= 1) {
+    if (j < half) { s_t[0][j] += s_t[0][j + half]; s_t[1][j] += s_t[1][j + half]; }
+    __syncthreads();
+  }
   if (j != 0) return;
-  t1 = t2 = 0.0;
-  for (int k = 0; k < kFinishThreads; ++k) { t1 += s_t[0][k]; t2 += s_t[1][k]; }
+  t1 = s_t[0][0]; t2 = s_t[1][0];
   if (MODE == 0) {
     const double m = t1 / (double)N;
     double var = t2 / (double)N - m * m;
@@ -358,22 +396,23 @@ __global__ __launch_bounds__(kFinishThreads) void layer_finish_kernel(const floa
   }
 }
 
-// dy = gs (gu - k1 - xhat k2) in bf16; with gs = 1, k1 = k2 = 0 (a block without BatchNorm) dy = gu
+// dy = gs (gu - k1 - xhat k2) in the pipeline's storage; with gs = 1, k1 = k2 = 0 (a block without BatchNorm) dy = gu
+template <typename ST>
 __global__ __launch_bounds__(256) void layer_bwd_apply_kernel(const ActArgs a) {
-  const int c0 = 8 * (threadIdx.x & 15);
+  const int t = threadIdx.x & 15;
   float sc[8], sh[8], mu[8], is[8], gs[8], k1[8], k2[8];
-  col8(a.scale, c0, sc); col8(a.shift, c0, sh); col8(a.mean, c0, mu); col8(a.invstd, c0, is);
-  col8(a.gs, c0, gs); col8(a.k1, c0, k1); col8(a.k2, c0, k2);
+  col8<ST>(a.scale, t, sc); col8<ST>(a.shift, t, sh); col8<ST>(a.mean, t, mu); col8<ST>(a.invstd, t, is);
+  col8<ST>(a.gs, t, gs); col8<ST>(a.k1, t, k1); col8<ST>(a.k2, t, k2);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) if (c0 + e >= a.C) gs[e] = 0.f;          // dy of the pad columns is zero whatever the vectors hold there
+  for (int e = 0; e < 8; ++e) if (col_of<ST>(t, e) >= a.C) gs[e] = 0.f;  // dy of the pad columns is zero whatever the vectors hold there
   const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
   const float inv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < a.N; row += (int64_t)gridDim.x * 16) {
     float gu[8], y[8], d[8];
-    load_gu(a, seed, inv, sc, sh, row, c0, gu, y);
+    load_gu<ST>(a, seed, inv, sc, sh, row, t, gu, y);
 #pragma unroll
     for (int e = 0; e < 8; ++e) d[e] = gs[e] * (gu[e] - k1[e] - (y[e] - mu[e]) * is[e] * k2[e]);
-    *reinterpret_cast<u32x4*>(a.out + row * kLW + c0) = pack8(d);
+    store8(static_cast<ST*>(a.out) + row * kLW, t, d);
   }
 }
 
@@ -828,24 +867,26 @@ __global__ __launch_bounds__(kLayerReduceSlices * kWave) void layer_wgrad_reduce
 // ------------------------------------------------------------------------------------------------ the final O <= 4 outputs
 // forward: out[n,q] = sum_c h[n,c] w[q,c] + b[q] (operands rounded to bf16 like every GEMM of the mode); 16 lanes per row.
 struct DotArgs {
-  const unsigned short* h; const float* w; const float* b; float* out; int64_t ldo;     // forward
-  const float* g; int64_t ldg; unsigned short* gh; float* partial;                         // backward
+  const void* h; const float* w; const float* b; float* out; int64_t ldo;               // forward (h in the pipeline's storage)
+  const float* g; int64_t ldg; void* gh; float* partial;                                   // backward
+  float gate_scale;                 // backward, > 0: gh = (h > 0 ? gate_scale : 0) g w -- h = drop(relu(u)) of a block without BatchNorm, gh = du
   int64_t N; int C; int O; int64_t rows_per_block;
 };
 
+template <typename ST>
 __global__ __launch_bounds__(256) void layer_rowdot_fwd_kernel(const DotArgs a) {
-  const int c0 = 8 * (threadIdx.x & 15);
+  const int t = threadIdx.x & 15;
   float w[MLQEM_MLP1_MAX_OUT][8];
 #pragma unroll
   for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) w[q][e] = (q < a.O && c0 + e < a.C) ? (float)(__bf16)a.w[(int64_t)q * a.C + c0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) w[q][e] = (q < a.O && col_of<ST>(t, e) < a.C) ? stored<ST>(a.w[(int64_t)q * a.C + col_of<ST>(t, e)]) : 0.f;
   const int64_t n_iter = ceil_div(a.N, (int64_t)gridDim.x * 16);
   for (int64_t it = 0; it < n_iter; ++it) {                    // every lane of a 16-lane group stays in the loop (DPP sums)
     const int64_t row = it * gridDim.x * 16 + (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool ok = row < a.N;
     float h[8];
-    unpack8(*reinterpret_cast<const u32x4*>(a.h + min(row, a.N - 1) * kLW + c0), h);
+    load8(static_cast<const ST*>(a.h) + min(row, a.N - 1) * kLW, t, h);
 #pragma unroll
     for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
       if (q >= a.O) break;
@@ -853,52 +894,60 @@ __global__ __launch_bounds__(256) void layer_rowdot_fwd_kernel(const DotArgs a) 
 #pragma unroll
       for (int e = 0; e < 8; ++e) s = fmaf(h[e], w[q][e], s);
       s = group16_sum(s);
-      if (ok && (threadIdx.x & 15) == 0) a.out[row * a.ldo + q] = s + a.b[q];
+      if (ok && t == 0) a.out[row * a.ldo + q] = s + a.b[q];
     }
   }
 }
 
-// backward: gh[n,c] = sum_q g[n,q] w[q,c] (bf16), and per-workgroup partials of gw[q,c] = sum_n g[n,q] h[n,c], gb[q] = sum_n g[n,q]:
+// backward: gh[n,c] = sum_q g[n,q] w[q,c] (storage type), and per-workgroup partials of gw[q,c] = sum_n g[n,q] h[n,c], gb[q] = sum_n g[n,q]:
 // partial[block][q][c] for c < 128, partial[block][q][128] = gb.
+template <typename ST>
 __global__ __launch_bounds__(256) void layer_rowdot_bwd_kernel(const DotArgs a) {
   __shared__ float s_red[16][MLQEM_MLP1_MAX_OUT][kLW + 1];
-  const int c0 = 8 * (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  const int t = threadIdx.x & 15, rl = threadIdx.x >> 4;
   float w[MLQEM_MLP1_MAX_OUT][8], gw[MLQEM_MLP1_MAX_OUT][8], gb[MLQEM_MLP1_MAX_OUT];
 #pragma unroll
   for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
     gb[q] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { w[q][e] = (q < a.O && c0 + e < a.C) ? (float)(__bf16)a.w[(int64_t)q * a.C + c0 + e] : 0.f; gw[q][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) {
+      w[q][e] = (q < a.O && col_of<ST>(t, e) < a.C) ? stored<ST>(a.w[(int64_t)q * a.C + col_of<ST>(t, e)]) : 0.f;
+      gw[q][e] = 0.f;
+    }
   }
   const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block, r1 = min(r0 + a.rows_per_block, a.N);
   for (int64_t row = r0 + rl; row < r1; row += 16) {
     float h[8], gh[8];
-    unpack8(*reinterpret_cast<const u32x4*>(a.h + row * kLW + c0), h);
+    load8(static_cast<const ST*>(a.h) + row * kLW, t, h);
 #pragma unroll
     for (int e = 0; e < 8; ++e) gh[e] = 0.f;
 #pragma unroll
     for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
       if (q >= a.O) break;
-      const float g = a.g[row * a.ldg + q], gr = (float)(__bf16)g;
-      if (c0 == 0) gb[q] += g;
+      const float g = a.g[row * a.ldg + q], gr = stored<ST>(g);
+      if (t == 0) gb[q] += g;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { gh[e] = fmaf(gr, w[q][e], gh[e]); gw[q][e] = fmaf(gr, h[e], gw[q][e]); }
     }
-    *reinterpret_cast<u32x4*>(a.gh + row * kLW + c0) = pack8(gh);
+    if (a.gate_scale > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gh[e] = h[e] > 0.f ? gh[e] * a.gate_scale : 0.f;
+    }
+    store8(static_cast<ST*>(a.gh) + row * kLW, t, gh);
   }
 #pragma unroll
   for (int q = 0; q < MLQEM_MLP1_MAX_OUT; ++q) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s_red[rl][q][c0 + e] = gw[q][e];
-    if (c0 == 0) s_red[rl][q][kLW] = gb[q];
+    for (int e = 0; e < 8; ++e) s_red[rl][q][col_of<ST>(t, e)] = gw[q][e];
+    if (t == 0) s_red[rl][q][kLW] = gb[q];
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < MLQEM_MLP1_MAX_OUT * (kLW + 1); idx += 256) {
     const int q = idx / (kLW + 1), c = idx % (kLW + 1);
-    float t = 0.f;
+    float tt = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t += s_red[j][q][c];
-    a.partial[((int64_t)blockIdx.x * MLQEM_MLP1_MAX_OUT + q) * (kLW + 1) + c] = t;
+    for (int j = 0; j < 16; ++j) tt += s_red[j][q][c];
+    a.partial[((int64_t)blockIdx.x * MLQEM_MLP1_MAX_OUT + q) * (kLW + 1) + c] = tt;
   }
 }
 
@@ -916,6 +965,272 @@ __global__ __launch_bounds__(kFinishThreads) void layer_rowdot_finish_kernel(con
   for (int k = 0; k < kFinishThreads; ++k) t += s_t[k];
   if (c < C) gw[(int64_t)q * C + c] = (float)t;
   else if (c == kLW) gb[q] = (float)t;
+}
+
+// ================================================================================================ fp32 storage: the two GEMMs
+// mfma = "f32" (the reference's own arithmetic): activations [N,128] fp32, products on v_mfma_f32_16x16x4_f32 (no rounding of
+// the operands).  At 262 144 rows a 128 x 128 layer is 8.6 GFLOP against 157 TFLOP/s of fp32 matrix rate (55 us) and 268 MB
+// against ~5 TB/s (50 us): both GEMMs are written to keep the matrix pipes fed, the general kernels of dense.hip ran them at a third.
+//
+// Forward / data gradient: Y^T tile = W (A operand, from an LDS image) x X^T (B operand, from the rows as they lie in memory).
+//   A 16-row tile of X: lane (lr, lq) loads X[row lr][16 j + 4 lq .. + 3] for j < NJ (16-byte loads, 64 contiguous bytes per row
+//   and instruction); component c of load j is the B operand of k-step 4 j + c with k = 16 j + 4 lq + c -- k is only a label A
+//   and B share, so the image holds W[16 ob + lr][16 j + 4 lq + c] as float4 over c at [(ob NJ + j) 64 + lane]: one conflict-free
+//   ds_read_b128 feeds four MFMAs.  D[4 lq + i][lr] = Y[row lr][16 ob + 4 lq + i]: a lane stores 16 bytes per output tile.
+//   512 threads: two waves per SIMD share one image (at 64-96 KB only one workgroup fits a CU), one wave's loads and stores
+//   hide behind the other's 32-cycle MFMAs.
+struct LayerF32Args {
+  const float* x; int64_t ldx; const float* w; const float* b; int transposed;
+  const float* add;              // optional [N,128] added to the result
+  float* y; int64_t ldy; int y_act;   // y_act: an activation matrix [N,128], every tile stored; else the first U columns of [N, ldy]
+  int64_t N; int K, U; const void* image;
+  int relu; float drop_p; uint64_t seed; const uint64_t* seed_counter;   // epilogue of a block WITHOUT BatchNorm: y = drop(relu(.))
+};
+constexpr int kF32Threads = 512;
+__host__ __device__ inline int layer_f32_image_float4(int NJ, int NOB) { return NOB * NJ * kWave + kLW / 4; }
+
+__global__ __launch_bounds__(256) void layer_f32_image_kernel(const LayerF32Args a, int NJ, int NOB, float4* __restrict__ image) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int n_frag = NOB * NJ * kWave;
+  if (idx < n_frag) {
+    const int l = idx & 63, j = (idx >> 6) % NJ, ob = idx / (64 * NJ);
+    const int u = 16 * ob + (l & 15), lq = l >> 4;
+    float w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = 16 * j + 4 * lq + c;
+      w[c] = (u < a.U && k < a.K) ? (a.transposed ? a.w[(int64_t)k * a.U + u] : a.w[(int64_t)u * a.K + k]) : 0.f;
+    }
+    image[idx] = make_float4(w[0], w[1], w[2], w[3]);
+    return;
+  }
+  const int t = idx - n_frag;
+  if (t < kLW) reinterpret_cast<float*>(image + n_frag)[t] = (a.b && t < a.U) ? a.b[t] : 0.f;
+}
+
+template <int NJ, int NOB>
+__global__ __launch_bounds__(kF32Threads) void layer_fwd_f32_kernel(const LayerF32Args a) {
+  extern __shared__ float4 s_img[];
+  for (int idx = threadIdx.x; idx < layer_f32_image_float4(NJ, NOB); idx += kF32Threads) s_img[idx] = static_cast<const float4*>(a.image)[idx];
+  __syncthreads();
+  const float* s_b = reinterpret_cast<const float*>(s_img + NOB * NJ * kWave);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int64_t n_tiles = ceil_div(a.N, 16);
+  const int64_t n_waves = (int64_t)gridDim.x * (kF32Threads / kWave), wave = (int64_t)blockIdx.x * (kF32Threads / kWave) + wid;
+  const int kpad = (a.K + 3) / 4 * 4;
+  const uint64_t dseed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
+  const unsigned dthr = (unsigned)(a.drop_p * 65536.f);
+  const float dinv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  struct Raw { float4 v[NJ]; };
+  auto load_tile = [&](int64_t t, Raw& r) {       // unconditional, clamped loads; the fix-up where the values are consumed
+    const float* xr = a.x + min(t * 16 + lr, a.N - 1) * a.ldx;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) r.v[j] = *reinterpret_cast<const float4*>(xr + min(16 * j + 4 * lq, kpad - 4));
+  };
+  auto fix = [&](Raw& r) {                        // columns >= K must not reach the MFMA (x's pad columns are scratch: 0 x NaN)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (16 * j + 16 <= a.K) continue;           // uniform
+      const int k0 = 16 * j + 4 * lq;
+      if (k0 + 0 >= a.K) r.v[j].x = 0.f;
+      if (k0 + 1 >= a.K) r.v[j].y = 0.f;
+      if (k0 + 2 >= a.K) r.v[j].z = 0.f;
+      if (k0 + 3 >= a.K) r.v[j].w = 0.f;
+    }
+  };
+  Raw cur;
+  load_tile(wave, cur);
+  fix(cur);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    Raw nxt;
+    load_tile(t + n_waves, nxt);
+    __builtin_amdgcn_sched_barrier(0);            // the prefetch is issued HERE
+    f32x4 acc[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      // consecutive MFMAs go to DIFFERENT accumulators: four k-steps in a row on one output tile would each wait for the one before
+      float4 wv[NOB];
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) wv[ob] = s_img[(ob * NJ + j) * kWave + lane];
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].x, cur.v[j].x, acc[ob], 0, 0, 0);
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].y, cur.v[j].y, acc[ob], 0, 0, 0);
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].z, cur.v[j].z, acc[ob], 0, 0, 0);
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ob].w, cur.v[j].w, acc[ob], 0, 0, 0);
+    }
+    const int64_t row = t * 16 + lr;
+    float4 addv[NOB];
+    if (a.add) {
+      const float* ar = a.add + min(row, a.N - 1) * kLW;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) addv[ob] = *reinterpret_cast<const float4*>(ar + 16 * ob + 4 * lq);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+    fix(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (row < a.N) {
+      float* yr = a.y + row * a.ldy;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const int u0 = 16 * ob + 4 * lq;
+        float4 v = make_float4(acc[ob][0] + s_b[u0], acc[ob][1] + s_b[u0 + 1], acc[ob][2] + s_b[u0 + 2], acc[ob][3] + s_b[u0 + 3]);
+        if (a.add) { v.x += addv[ob].x; v.y += addv[ob].y; v.z += addv[ob].z; v.w += addv[ob].w; }
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.drop_p > 0.f) {       // one splitmix64 round per four units, keyed by (row, first unit); the backward gates by y > 0
+          uint64_t z = dseed + ((uint64_t)(row * kLW + u0) + 1) * 0x9E3779B97F4A7C15ull;
+          z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+          z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+          z = z ^ (z >> 31);
+          v.x = (unsigned)(z & 0xFFFFu) >= dthr ? v.x * dinv : 0.f;
+          v.y = (unsigned)((z >> 16) & 0xFFFFu) >= dthr ? v.y * dinv : 0.f;
+          v.z = (unsigned)((z >> 32) & 0xFFFFu) >= dthr ? v.z * dinv : 0.f;
+          v.w = (unsigned)((z >> 48) & 0xFFFFu) >= dthr ? v.w * dinv : 0.f;
+        }
+        if (a.y_act) {
+          *reinterpret_cast<float4*>(yr + u0) = v;          // units >= U: zero image rows, zero bias -> zeros
+        } else {
+          if (u0 + 0 < a.U) yr[u0 + 0] = v.x;
+          if (u0 + 1 < a.U) yr[u0 + 1] = v.y;
+          if (u0 + 2 < a.U) yr[u0 + 2] = v.z;
+          if (u0 + 3 < a.U) yr[u0 + 3] = v.w;
+        }
+      }
+      if (a.y_act && NOB < 8) {                             // a narrow layer: the rest of the 128 columns are zeros
+#pragma unroll
+        for (int ob = NOB; ob < 8; ++ob) *reinterpret_cast<float4*>(yr + 16 * ob + 4 * lq) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+}
+
+// Weight gradient gW[U, K] = dY^T X, gb = sum dY (the ones column of X at index K), fp32 operands.  k of the MFMA = 4 ROWS:
+//   lane (lr, lq) loads dY[r + lq][64 wu + 4 lr .. + 3] and X[r + lq][64 wc + 4 lr .. + 3] (16 bytes each, 256 contiguous bytes
+//   per row and instruction); component cu of the first is the A operand of "unit tile cu" (m = lr <-> unit 64 wu + 4 lr + cu),
+//   component cx of the second the B operand of "column tile cx" (n = lr <-> column 64 wc + 4 lr + cx): 16 MFMAs per two loads,
+//   no transposes, no LDS.  D[4 lq + i][lr] of tile (cu, cx) = gW[64 wu + 4 (4 lq + i) + cu][64 wc + 4 lr + cx].
+//   A wave owns a 64 x 64 block of gW (wu, wc): 64 accumulator registers; a workgroup = NU x NC waves covers [U <= 128] x [K + 1 <= 192].
+//   Rows in slabs of 32 dealt to the workgroups round-robin, one slab prefetched in registers; per-workgroup partial sums, added in
+//   a fixed order by layer_wgrad_f32_reduce_kernel.
+struct WgradF32Args {
+  const float* dy; const float* x; int64_t ldx; int64_t N; int K; int NC; float* partial;
+};
+constexpr int kWgF32WaveFloats = 16 * 4 * kWave;       // a wave's 16 tiles
+
+__global__ __launch_bounds__(384) void layer_wgrad_f32_kernel(const WgradF32Args a) {
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wu = wid / a.NC, wc = wid - wu * a.NC;
+  const int kpad = (a.K + 3) / 4 * 4;
+  const int col0 = 64 * wc + 4 * lr;                       // this lane's four X columns
+  const int colc = min(col0, kpad - 4);
+  // per column: the loaded value, 1.0 (the ones column, index K) or 0.0 (beyond)
+  const bool x_raw[4] = {col0 + 0 < a.K, col0 + 1 < a.K, col0 + 2 < a.K, col0 + 3 < a.K};
+  const float x_fill[4] = {col0 + 0 == a.K ? 1.f : 0.f, col0 + 1 == a.K ? 1.f : 0.f, col0 + 2 == a.K ? 1.f : 0.f, col0 + 3 == a.K ? 1.f : 0.f};
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int cu = 0; cu < 4; ++cu)
+#pragma unroll
+    for (int cx = 0; cx < 4; ++cx) acc[cu][cx] = f32x4{0.f, 0.f, 0.f, 0.f};
+  struct Slab { float4 d[8], x[8]; };
+  const int64_t n_slabs = a.N / 32;
+  const float* dyl = a.dy + (int64_t)lq * kLW + 64 * wu + 4 * lr;
+  const float* xl = a.x + (int64_t)lq * a.ldx + colc;
+  auto issue = [&](Slab& s, int64_t sl) {
+    const int64_t r0 = 32 * min(sl, n_slabs - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      s.d[q] = *reinterpret_cast<const float4*>(dyl + (r0 + 4 * q) * kLW);
+      s.x[q] = *reinterpret_cast<const float4*>(xl + (r0 + 4 * q) * a.ldx);
+    }
+  };
+  auto consume = [&](const Slab& s, int64_t first_row) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool ok = first_row + 4 * q + lq < a.N;         // the ragged tail: a clamped row contributes nothing
+      const float dv[4] = {ok ? s.d[q].x : 0.f, ok ? s.d[q].y : 0.f, ok ? s.d[q].z : 0.f, ok ? s.d[q].w : 0.f};
+      const float xr[4] = {s.x[q].x, s.x[q].y, s.x[q].z, s.x[q].w};
+      float xv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[c] = x_raw[c] ? xr[c] : x_fill[c];
+#pragma unroll
+      for (int cu = 0; cu < 4; ++cu)
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) acc[cu][cx] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[cu], xv[cx], acc[cu][cx], 0, 0, 0);
+    }
+  };
+  Slab cur, nxt;
+  const int64_t G = gridDim.x;
+  if (n_slabs > 0) {
+    issue(cur, blockIdx.x);
+    for (int64_t sl = blockIdx.x; sl < n_slabs; sl += G) {
+      issue(nxt, sl + G);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(cur, 32 * sl);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+  }
+  if (blockIdx.x == 0 && (a.N & 31)) {
+    Slab t;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t row = min(32 * n_slabs + 4 * q + lq, a.N - 1);
+      t.d[q] = *reinterpret_cast<const float4*>(a.dy + row * kLW + 64 * wu + 4 * lr);
+      t.x[q] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + colc);
+    }
+    consume(t, 32 * n_slabs);
+  }
+  float* __restrict__ dst = a.partial + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wid) * kWgF32WaveFloats + lane;
+#pragma unroll
+  for (int cu = 0; cu < 4; ++cu)
+#pragma unroll
+    for (int cx = 0; cx < 4; ++cx)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[((cu * 4 + cx) * 4 + i) * kWave] = acc[cu][cx][i];
+}
+
+// second stage: element e of a workgroup's partial = (wave, tile (cu, cx), register i, lane) -> (unit, column); 16 slices of the G range
+__global__ __launch_bounds__(16 * kWave) void layer_wgrad_f32_reduce_kernel(const float* __restrict__ partial, int G, int K, int U, int NC, int n_waves,
+                                                                           float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float s[16][kWave];
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * kWave + el;
+  const int per_wg = n_waves * kWgF32WaveFloats;
+  const int lane = e & 63, i = (e >> 6) & 3, cx = (e >> 8) & 3, cu = (e >> 10) & 3, wid = e >> 12;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int wu = wid / NC, wc = wid - wu * NC;
+  const int o = 64 * wu + 4 * (4 * lq + i) + cu, c = 64 * wc + 4 * lr + cx;
+  const bool live = e < per_wg && o < U && c <= K;
+  float v = 0.f;
+  if (live) {
+    const int per = (G + 15) / 16;
+    const int g1 = min(G, (sl + 1) * per);
+    int g = sl * per;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    for (; g + 3 < g1; g += 4) {
+      v += partial[(int64_t)g * per_wg + e];
+      v1 += partial[(int64_t)(g + 1) * per_wg + e];
+      v2 += partial[(int64_t)(g + 2) * per_wg + e];
+      v3 += partial[(int64_t)(g + 3) * per_wg + e];
+    }
+    for (; g < g1; ++g) v += partial[(int64_t)g * per_wg + e];
+    v = (v + v1) + (v2 + v3);
+  }
+  s[sl][el] = v;
+  __syncthreads();
+  if (sl != 0 || !live) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tot += s[k][el];
+  if (c < K) gw[(int64_t)o * K + c] = tot;
+  else if (gb) gb[o] = tot;
 }
 
 template <typename K>
@@ -989,12 +1304,13 @@ extern "C" int mlqem_layer_gemm_bf16(const void* x, int x_is_bf16, int64_t ldx, 
 
 // mode 0: batch statistics of y -> mean, var, invstd, scale, shift (each [128]; gamma / beta [C]).
 // mode 1: backward sums from (g, y) -> dbeta, dgamma, gs, k1, k2.  g: bf16 [N,128], or fp32 [N, ldg32] when g32 != NULL.
-extern "C" int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale,
-                                         const float* shift, const float* mean, const float* invstd, const float* gamma,
-                                         const float* beta, float eps, int relu, float drop_p, uint64_t seed,
-                                         const uint64_t* seed_counter, int64_t N, int C, float* o1, float* o2, float* o3, float* o4,
-                                         float* o5, float* running_mean, float* running_var, float momentum,
-                                         int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+template <typename ST>
+static int layer_colstats(int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, float eps, int relu, float drop_p, uint64_t seed,
+                          const uint64_t* seed_counter, int64_t N, int C, float* o1, float* o2, float* o3, float* o4,
+                          float* o5, float* running_mean, float* running_var, float momentum,
+                          int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
   begin_launches();
   if (N <= 0 || C < 1 || C > kLW || !y || !gamma || !o1 || !o2 || !o3 || !o4 || !o5 || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
   if (mode == 0 ? !beta : (!scale || !shift || !mean || !invstd || (!g && !g32))) return MLQEM_ERR_BAD_ARG;
@@ -1002,43 +1318,66 @@ extern "C" int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g,
   hipStream_t s = as_stream(stream);
   const int nb = colsum_blocks(N);
   ActArgs a{};
-  a.y = static_cast<const unsigned short*>(y); a.g = static_cast<const unsigned short*>(g); a.g32 = g32; a.ldg32 = ldg32;
+  a.y = y; a.g = g; a.g32 = g32; a.ldg32 = ldg32;
   a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.partial = static_cast<float*>(workspace);
   a.N = N; a.C = C; a.relu = relu; a.drop_p = drop_p; a.seed = seed; a.seed_counter = seed_counter;
   a.rows_per_block = ceil_div(N, (int64_t)nb);
   if (mode == 0) {
-    hipLaunchKernelGGL(layer_colsum_kernel<0>, dim3(nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((layer_colsum_kernel<0, ST>), dim3(nb), dim3(256), 0, s, a);
     if ((running_mean == nullptr) != (running_var == nullptr) || (running_mean && N < 2)) return MLQEM_ERR_BAD_ARG;
     hipLaunchKernelGGL(layer_finish_kernel<0>, dim3(kLW), dim3(kFinishThreads), 0, s, a.partial, nb, N, C, gamma, beta, (const float*)nullptr, eps,
                        o1, o2, o3, o4, o5, running_mean, running_var, momentum, reinterpret_cast<long long*>(num_batches_tracked));
   } else {
-    hipLaunchKernelGGL(layer_colsum_kernel<1>, dim3(nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((layer_colsum_kernel<1, ST>), dim3(nb), dim3(256), 0, s, a);
     hipLaunchKernelGGL(layer_finish_kernel<1>, dim3(kLW), dim3(kFinishThreads), 0, s, a.partial, nb, N, C, gamma, (const float*)nullptr, invstd, 0.f,
                        o1, o2, o3, o4, o5, (float*)nullptr, (float*)nullptr, 0.f, (long long*)nullptr);
   }
   return launch_status();
 }
 
+#define MLQEM_COLSTATS_ARGS                                                                                                       \
+  int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale, const float* shift, const float* mean, \
+      const float* invstd, const float* gamma, const float* beta, float eps, int relu, float drop_p, uint64_t seed,                   \
+      const uint64_t* seed_counter, int64_t N, int C, float* o1, float* o2, float* o3, float* o4, float* o5, float* running_mean,     \
+      float* running_var, float momentum, int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, mlqem_stream_t stream
+#define MLQEM_COLSTATS_PASS                                                                                                        \
+  mode, y, g, g32, ldg32, scale, shift, mean, invstd, gamma, beta, eps, relu, drop_p, seed, seed_counter, N, C, o1, o2, o3, o4, o5,  \
+      running_mean, running_var, momentum, num_batches_tracked, workspace, workspace_bytes, stream
+extern "C" int mlqem_layer_colstats_bf16(MLQEM_COLSTATS_ARGS) { return layer_colstats<unsigned short>(MLQEM_COLSTATS_PASS); }
+extern "C" int mlqem_layer_colstats_f32(MLQEM_COLSTATS_ARGS) { return layer_colstats<float>(MLQEM_COLSTATS_PASS); }
+#undef MLQEM_COLSTATS_ARGS
+#undef MLQEM_COLSTATS_PASS
+
 // op 0: out = drop(relu?(y scale + shift)) (+ res).   op 1: out = gs (gu - k1 - xhat k2), gu from (g | g32, y).
-extern "C" int mlqem_layer_pointwise_bf16(int op, const void* y, const void* g, const float* g32, int64_t ldg32, const void* res,
-                                          const float* scale, const float* shift, const float* mean, const float* invstd,
-                                          const float* gs, const float* k1, const float* k2, int relu, float drop_p, uint64_t seed,
-                                          const uint64_t* seed_counter, void* out, int64_t N, int C, mlqem_stream_t stream) {
+template <typename ST>
+static int layer_pointwise(int op, const void* y, const void* g, const float* g32, int64_t ldg32, const void* res,
+                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                           const float* gs, const float* k1, const float* k2, int relu, float drop_p, uint64_t seed,
+                           const uint64_t* seed_counter, void* out, int64_t N, int C, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || C < 1 || C > kLW || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!y || !out || !scale || !shift) return MLQEM_ERR_BAD_ARG;
   if (op == 1 && (!mean || !invstd || !gs || !k1 || !k2 || (!g && !g32))) return MLQEM_ERR_BAD_ARG;
   ActArgs a{};
-  a.y = static_cast<const unsigned short*>(y); a.g = static_cast<const unsigned short*>(g); a.g32 = g32; a.ldg32 = ldg32;
-  a.res = static_cast<const unsigned short*>(res); a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
-  a.gs = gs; a.k1 = k1; a.k2 = k2; a.out = static_cast<unsigned short*>(out);
+  a.y = y; a.g = g; a.g32 = g32; a.ldg32 = ldg32;
+  a.res = res; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+  a.gs = gs; a.k1 = k1; a.k2 = k2; a.out = out;
   a.N = N; a.C = C; a.relu = relu; a.drop_p = drop_p; a.seed = seed; a.seed_counter = seed_counter;
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(N, 16), 256 * 8);
-  if (op == 0) hipLaunchKernelGGL(layer_act_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
-  else hipLaunchKernelGGL(layer_bwd_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  if (op == 0) hipLaunchKernelGGL(layer_act_kernel<ST>, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(layer_bwd_apply_kernel<ST>, dim3(grid), dim3(256), 0, as_stream(stream), a);
   return launch_status();
 }
+#define MLQEM_POINTWISE_ARGS                                                                                                          \
+  int op, const void* y, const void* g, const float* g32, int64_t ldg32, const void* res, const float* scale, const float* shift,       \
+      const float* mean, const float* invstd, const float* gs, const float* k1, const float* k2, int relu, float drop_p, uint64_t seed, \
+      const uint64_t* seed_counter, void* out, int64_t N, int C, mlqem_stream_t stream
+#define MLQEM_POINTWISE_PASS op, y, g, g32, ldg32, res, scale, shift, mean, invstd, gs, k1, k2, relu, drop_p, seed, seed_counter, out, N, C, stream
+extern "C" int mlqem_layer_pointwise_bf16(MLQEM_POINTWISE_ARGS) { return layer_pointwise<unsigned short>(MLQEM_POINTWISE_PASS); }
+extern "C" int mlqem_layer_pointwise_f32(MLQEM_POINTWISE_ARGS) { return layer_pointwise<float>(MLQEM_POINTWISE_PASS); }
+#undef MLQEM_POINTWISE_ARGS
+#undef MLQEM_POINTWISE_PASS
 
 extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf16, int64_t ldx, float* gw, float* gb, int64_t N,
                                       int K, int U, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
@@ -1088,29 +1427,117 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
   return launch_status();
 }
 
-extern "C" int mlqem_layer_rowdot_bf16(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O,
-                                       mlqem_stream_t stream) {
+template <typename ST>
+static int layer_rowdot(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || C < 1 || C > kLW || O < 1 || O > MLQEM_MLP1_MAX_OUT || ldo < O) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!h || !w || !b || !out) return MLQEM_ERR_BAD_ARG;
   DotArgs a{};
-  a.h = static_cast<const unsigned short*>(h); a.w = w; a.b = b; a.out = out; a.ldo = ldo; a.N = N; a.C = C; a.O = O;
-  hipLaunchKernelGGL(layer_rowdot_fwd_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(N, 16), 256 * 16)), dim3(256), 0, as_stream(stream), a);
+  a.h = h; a.w = w; a.b = b; a.out = out; a.ldo = ldo; a.N = N; a.C = C; a.O = O;
+  hipLaunchKernelGGL(layer_rowdot_fwd_kernel<ST>, dim3((unsigned)std::min<int64_t>(ceil_div(N, 16), 256 * 16)), dim3(256), 0, as_stream(stream), a);
   return launch_status();
 }
 
-extern "C" int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float* gw, float* gb,
-                                           int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+extern "C" int mlqem_layer_rowdot_bf16(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O,
+                                       mlqem_stream_t stream) {
+  return layer_rowdot<unsigned short>(h, w, b, out, ldo, N, C, O, stream);
+}
+extern "C" int mlqem_layer_rowdot_f32(const void* h, const float* w, const float* b, float* out, int64_t ldo, int64_t N, int C, int O,
+                                      mlqem_stream_t stream) {
+  return layer_rowdot<float>(h, w, b, out, ldo, N, C, O, stream);
+}
+
+template <typename ST>
+static int layer_rowdot_bwd(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float gate_scale, float* gw, float* gb,
+                            int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
   begin_launches();
   if (N <= 0 || C < 1 || C > kLW || O < 1 || O > MLQEM_MLP1_MAX_OUT || ldg < O || !g || !h || !w || !gh || !gw || !gb) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes()) return MLQEM_ERR_WORKSPACE;
   hipStream_t s = as_stream(stream);
   const int nb = colsum_blocks(N);
   DotArgs a{};
-  a.h = static_cast<const unsigned short*>(h); a.w = w; a.g = g; a.ldg = ldg; a.gh = static_cast<unsigned short*>(gh);
+  a.h = h; a.w = w; a.g = g; a.ldg = ldg; a.gh = gh; a.gate_scale = gate_scale;
   a.partial = static_cast<float*>(workspace); a.N = N; a.C = C; a.O = O; a.rows_per_block = ceil_div(N, (int64_t)nb);
-  hipLaunchKernelGGL(layer_rowdot_bwd_kernel, dim3(nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(layer_rowdot_bwd_kernel<ST>, dim3(nb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(layer_rowdot_finish_kernel, dim3(MLQEM_MLP1_MAX_OUT * (kLW + 1)), dim3(kFinishThreads), 0, s, a.partial, nb, C, O, gw, gb);
+  return launch_status();
+}
+extern "C" int mlqem_layer_rowdot_bwd_bf16(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float gate_scale, float* gw,
+                                           float* gb, int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  return layer_rowdot_bwd<unsigned short>(g, ldg, h, w, gh, gate_scale, gw, gb, N, C, O, workspace, workspace_bytes, stream);
+}
+extern "C" int mlqem_layer_rowdot_bwd_f32(const float* g, int64_t ldg, const void* h, const float* w, void* gh, float gate_scale, float* gw,
+                                          float* gb, int64_t N, int C, int O, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  return layer_rowdot_bwd<float>(g, ldg, h, w, gh, gate_scale, gw, gb, N, C, O, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 storage: entry points
+template <int NJ, int NOB>
+static int launch_layer_fwd_f32(LayerF32Args a, void* workspace, hipStream_t s) {
+  const size_t lds = (size_t)layer_f32_image_float4(NJ, NOB) * sizeof(float4);
+  auto kernel = layer_fwd_f32_kernel<NJ, NOB>;
+  static const int once = [&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
+  }();
+  if (!once) return MLQEM_ERR_LAUNCH;
+  static const int res = layer_resident(kernel, kF32Threads, lds);
+  a.image = workspace;
+  hipLaunchKernelGGL(layer_f32_image_kernel, dim3((unsigned)ceil_div(layer_f32_image_float4(NJ, NOB) * 4, 256)), dim3(256), 0, s, a, NJ, NOB,
+                     static_cast<float4*>(workspace));
+  const int64_t tiles = ceil_div(a.N, 16);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(res, ceil_div(tiles, kF32Threads / kWave)));
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kF32Threads), lds, s, a);
+  return launch_status();
+}
+
+// Y = X W^T + b (or, transposed, X W) with fp32 rows in and out: x [N, ldx] (K columns used; an activation matrix has ldx = 128),
+// y an activation matrix [N,128] (y_is_act; every column written, zeros beyond U) or the first U columns of [N, ldy].
+extern "C" int mlqem_layer_gemm_f32(const float* x, int64_t ldx, const float* w, int transposed, const float* b, const float* add,
+                                    float* y, int y_is_act, int64_t ldy, int relu, float drop_p, uint64_t seed, const uint64_t* seed_counter,
+                                    int64_t N, int K, int U, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || K < 1 || U < 1 || !w || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
+  if (U > kLW || K > 192) return MLQEM_ERR_UNSUPPORTED;
+  if (ldx < (K + 3) / 4 * 4 || ldx % 4 || (y_is_act ? ldy != kLW : ldy < U)) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes() || !aligned_to(workspace, 16)) return MLQEM_ERR_WORKSPACE;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !y || !aligned_to(x, 16) || (y_is_act && !aligned_to(y, 16)) || (add && !aligned_to(add, 16))) return MLQEM_ERR_BAD_ARG;
+  LayerF32Args a{x, ldx, w, b, transposed, add, y, ldy, y_is_act, N, K, U, nullptr, relu, drop_p, seed, seed_counter};
+  hipStream_t s = as_stream(stream);
+  const int nj = (K + 15) / 16, narrow = U <= 64;
+  if (nj <= 4) return narrow ? launch_layer_fwd_f32<4, 4>(a, workspace, s) : launch_layer_fwd_f32<4, 8>(a, workspace, s);
+  if (nj <= 8) return narrow ? launch_layer_fwd_f32<8, 4>(a, workspace, s) : launch_layer_fwd_f32<8, 8>(a, workspace, s);
+  return narrow ? launch_layer_fwd_f32<12, 4>(a, workspace, s) : launch_layer_fwd_f32<12, 8>(a, workspace, s);
+}
+
+// gw [U, K] = dy^T x, gb [U] = column sums of dy: dy an fp32 activation matrix [N,128], x fp32 [N, ldx] (K <= 191 columns).
+extern "C" int mlqem_layer_wgrad_f32(const float* dy, const float* x, int64_t ldx, float* gw, float* gb, int64_t N, int K, int U,
+                                     void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || K < 1 || U < 1 || !gw) return MLQEM_ERR_BAD_ARG;
+  if (U > kLW || K > 191) return MLQEM_ERR_UNSUPPORTED;
+  if (ldx < (K + 3) / 4 * 4 || ldx % 4) return MLQEM_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes()) return MLQEM_ERR_WORKSPACE;
+  if (N > 0 && (!dy || !x || !aligned_to(dy, 16) || !aligned_to(x, 16))) return MLQEM_ERR_BAD_ARG;
+  hipStream_t s = as_stream(stream);
+  const int NU = (U + 63) / 64, NC = (K + 1 + 63) / 64, n_waves = NU * NC;       // <= 2 x 3 waves
+  WgradF32Args a{dy, x, ldx, N, K, NC, static_cast<float*>(workspace)};
+  int G = 0;
+  if (N > 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    // the partial sums of a workgroup are n_waves x 16 KB
+    const int64_t cap = (int64_t)(mlqem_layer_workspace_bytes() / ((size_t)n_waves * kWgF32WaveFloats * sizeof(float)));
+    // ~12 waves per CU whatever the workgroup's size (a 41-unit layer's workgroup is two waves)
+    const int64_t want = (int64_t)cus * std::max(2, 12 / n_waves);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cap), std::max<int64_t>(N / 32, 1)));
+    hipLaunchKernelGGL(layer_wgrad_f32_kernel, dim3(G), dim3(n_waves * kWave), 0, s, a);
+  }
+  hipLaunchKernelGGL(layer_wgrad_f32_reduce_kernel, dim3((unsigned)ceil_div(n_waves * kWgF32WaveFloats, kWave)), dim3(16 * kWave), 0, s,
+                     a.partial, G, K, U, NC, n_waves, gw, gb);
   return launch_status();
 }

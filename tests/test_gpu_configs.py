@@ -162,6 +162,22 @@ def test_cfg1_mlp_on_v2_features():
         for (name, p), (_, q) in zip(gpu.named_parameters(), ref.named_parameters()):
             scale = max(q.grad.abs().max().item(), 1e-9)
             assert (p.grad.cpu().double() - q.grad).abs().max().item() / scale < 2e-4, (cls, name)
+    # TRAINING mode: MLP3's step on the fp32 layer kernels (csrc/mlp_layers.hip: batch statistics, one autograd
+    # node) against the oracle in fp64, dropout off so that both evaluate the same function: 1e-5 of each result's scale
+    torch.manual_seed(4)
+    gpu = bnn.MLP3(169, 128, 4, dropout_rate=0.0)
+    ref = om.MLP3(169, 128, 4, dropout_rate=0.0).double().train()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in gpu.state_dict().items()})
+    gpu = gpu.to(DEV).train()
+    out, want = gpu(X.to(DEV)), ref(X.double())
+    assert (out.detach().cpu().double() - want.detach()).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1.0)
+    out.square().mean().backward()
+    want.square().mean().backward()
+    top = max(q.grad.abs().max().item() for q in ref.parameters())
+    for (name, p), (_, q) in zip(gpu.named_parameters(), ref.named_parameters()):
+        # (a Linear's bias in front of a BatchNorm has an analytically zero gradient: rounding noise, measured against the largest one)
+        assert (p.grad.cpu().double() - q.grad).abs().max().item() <= 1e-5 * max(q.grad.abs().max().item(), 1e-2 * top), name
+    assert (gpu.bn1.running_var.cpu().double() - ref.bn1.running_var).abs().max().item() <= 1e-5 * ref.bn1.running_var.abs().max().item()
 
 
 def test_cfg5_bf16_mfma_mlp_head():
