@@ -615,16 +615,20 @@ int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const
  *               and reads [N]-sized arrays where the stored form reads [E]-sized ones.
  * ---------------------------------------------------------------------------------------------------- */
 
-/* Training forward of mlqem_transformer_attention_f32: same result, plus attn_out (the sum before the skip term) and
- * the softmax statistics stat_m / stat_den [N,H]; drop_p > 0 drops attention weights (TransformerConv(dropout=0.1),
+/* Training forward of mlqem_transformer_attention_f32: same result, plus attn_out (the sum before the skip term; since ABI 25
+ * written only for rows of MORE THAN FOUR entries, in-edges + self entry: the backward forms what it needs of a shorter row --
+ * g . attn_out -- from the row's own entries, so on circuit DAGs attn_out is neither written nor read but for barrier rows;
+ * the buffer is opaque to callers, hand it to the backward as it is) and the softmax statistics stat_m / stat_den [N,H]; drop_p > 0 drops attention weights (TransformerConv(dropout=0.1),
  * gnn.py:83,90) with a mask keyed by (seed, in-CSR position, head) -- or, pair_key != 0, by (seed, destination, head, source):
  * the same draw from either end of an edge, for graphs WITHOUT parallel edges (they would share a draw); the recomputed
  * backward needs it.  seed_counter (may be NULL): a device-resident step counter mixed into the seed, so that a launch captured
- * in a hipGraph draws a fresh mask per replay (the backward entry point must be given the same seed, counter and key form). */
+ * in a hipGraph draws a fresh mask per replay (the backward entry point must be given the same seed, counter and key form).
+ * in_ell (optional, ABI 25): the [N,2] side table of mlqem_ell_from_csr over the same in-CSR -- rows of at most two in-edges then
+ * reach their key / value rows without the ptr -> idx round trip (same result bit for bit). */
 int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
                                           const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p,
-                                          uint64_t seed, const uint64_t* seed_counter, int pair_key, float* out, int64_t ldo,
-                                          float* attn_out, int64_t lda, float* stat_m, float* stat_den,
+                                          uint64_t seed, const uint64_t* seed_counter, int pair_key, const int32_t* in_ell,
+                                          float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m, float* stat_den,
                                           mlqem_stream_t stream);
 
 /* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  Stored form: edge_al / edge_gs: scratch

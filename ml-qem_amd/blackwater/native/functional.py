@@ -643,8 +643,10 @@ class _TransformerConv(Function):
         # a structure without out_eid (ASAPooling's coarsened graphs: no parallel edges) takes the recomputed backward, whose dropout
         # draws are keyed by (destination, head, source)
         pair_key = struct.out_eid is None
+        # the side table of a graph of short rows (circuit DAGs: the arena builds it with the batch); a coarsened graph's rows are long
+        ell = struct.in_ell if struct.out_eid is not None else None
         out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
-                                                           channels, drop_p, seed, pair_key=pair_key)
+                                                           channels, drop_p, seed, pair_key=pair_key, ell=ell)
         ctx.struct, ctx.cfg = struct, (e, heads, channels, drop_p, seed, pair_key)
         ctx.x_rows_of = isinstance(x, ops.RowsOf)
         if ctx.x_rows_of:

@@ -1420,8 +1420,12 @@ def asap_dense_max_k() -> int:
 
 
 # ------------------------------------------------------------------------------------------ Family B backward
-def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False):
+def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False, ell=None):
+    """(out, attn_out, m, den).  ``ell``: the structure's in-edge side table (``GraphStructure.in_ell``) where most rows have at
+    most two in-edges (circuit DAGs): those rows skip the ptr -> idx round trip.  ``attn_out`` is for the backward only (rows of at
+    most four entries are not written)."""
     n, hc = qkvs.shape[0], heads * channels
+    _ell(ell, n)
     if qkvs.shape[1] != 4 * hc:
         raise ValueError("qkvs must be [N, 4*H*C]")
     _vec(in_ptr, "in_ptr", n + 1, torch.int32)
@@ -1432,7 +1436,7 @@ def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, c
     den = torch.empty_like(m)
     code = _lib.load().mlqem_transformer_attention_train_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
-        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(out), _mat(out, "out"),
+        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(ell), _p(out), _mat(out, "out"),
         _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
     _lib.check(code, "mlqem_transformer_attention_train_f32")
     return out, attn, m, den

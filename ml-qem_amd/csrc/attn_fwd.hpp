@@ -42,6 +42,9 @@ struct AttnFwdArgs {
   float* out; int64_t ldo;
   float* attn_out; int64_t lda; float* stat_m; float* stat_den;   // training only
   int pair_key;                             // dropout draws keyed by (destination, head, source) instead of the in-CSR position
+  const int32_t* ell;                       // optional [N,2] side table (mlqem_ell_from_csr): the first two in-edges of every row, so
+                                            // that a row of at most two (a circuit DAG's, but for barriers) goes ell -> key / value
+                                            // rows instead of ptr -> idx -> key / value rows (four-channels-per-lane kernels only)
 };
 
 // The key of an attention weight's dropout draw.  By position (the default): (in-CSR position, head), self entries at E + row.

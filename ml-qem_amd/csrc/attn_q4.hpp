@@ -61,7 +61,18 @@ __device__ __forceinline__ f4u load_channels(const float* __restrict__ p, int nv
   }
   return v;
 }
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+// MLQEM_ATTN_VSTORE=0 (compile time): one dword store per channel (A/B builds)
+#ifndef MLQEM_ATTN_VSTORE
+#define MLQEM_ATTN_VSTORE 1
+#endif
+// A lane's channels as ONE store: 16 bytes, or 12 from the last lane of a 15-channel head (the fourth float is the next head's
+// first channel, another lane's) -- two store instructions per wave and matrix instead of four that each touch every line.
 __device__ __forceinline__ void store_channels(float* __restrict__ p, const f4u& v, int nv) {
+#if MLQEM_ATTN_VSTORE
+  if (nv == 4) { *reinterpret_cast<f4u*>(p) = v; return; }
+  if (nv == 3) { *reinterpret_cast<f3u*>(p) = f3u{v.x, v.y, v.z}; return; }
+#endif
   if (nv > 0) p[0] = v.x;
   if (nv > 1) p[1] = v.y;
   if (nv > 2) p[2] = v.z;
@@ -88,8 +99,16 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
   const float* __restrict__ ri = qkvs + (int64_t)row * ld;
   const f4u q = load_channels(ri + off, nv, true);                            // runs over into the key part at most
   const f4u skip = load_channels(ri + 3 * HC + off, nv, 3 * HC + off + 4 <= 4 * HC);
-  const int beg = a.ptr[row];
-  const int deg = a.ptr[row + 1] - beg;
+  // the row's in-edges: from the ELL side table when the row has at most two (one dependent round trip less), else from the CSR arrays
+  int s0 = -1, s1 = -1;
+  bool fast = false;
+  if (a.ell) {
+    const int2 e2 = reinterpret_cast<const int2*>(a.ell)[row];
+    fast = e2.x == -1 || (e2.x & kEllMore) == 0;
+    s0 = e2.x; s1 = e2.y;
+  }
+  const int beg = a.ptr[row];                           // fast rows: only the dropout key by position reads it
+  const int deg = fast ? (s0 >= 0 ? 1 : 0) + (s1 >= 0 ? 1 : 0) : a.ptr[row + 1] - beg;
   const int n_self = a.loops ? a.loops[row] : 0;
   const int cnt = deg + (n_self > 0 ? 1 : 0);           // the self-loop entry comes last (PyG appends it after the edges)
 
@@ -99,7 +118,7 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
     const int k = min(4, cnt - x0);
     const int x = x0 + min(lu, k - 1);                   // past the end: the last entry again (weight 0)
     const bool is_self = x >= deg;
-    const int j = is_self ? row : idx[beg + x];
+    const int j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : idx[beg + x]);
     int ju[4];
     ju[0] = quad_bcast<0>(j); ju[1] = quad_bcast<1>(j); ju[2] = quad_bcast<2>(j); ju[3] = quad_bcast<3>(j);
     f4u kk[4], vv[4];
@@ -143,7 +162,9 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
   acc *= 1.0f / denom;
   store_channels(a.out + (int64_t)row * a.ldo + off, acc + skip, nv);
   if (TRAIN) {
-    store_channels(a.attn_out + (int64_t)row * a.lda + off, acc, nv);
+    // the backward needs attn_out only as delta = g . attn_out, and a row of at most four entries (one chunk: every row of a
+    // circuit DAG but the barriers') yields delta from what its destination-side pass holds anyway: such rows store nothing
+    if (cnt > 4) store_channels(a.attn_out + (int64_t)row * a.lda + off, acc, nv);
     if (lq == 0) {
       a.stat_m[(int64_t)row * H + h] = m;
       a.stat_den[(int64_t)row * H + h] = denom;

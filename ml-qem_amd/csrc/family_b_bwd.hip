@@ -252,6 +252,8 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
 
 // The same three kernels with four channels per lane (attn_q4.hpp): LPH = 4 (C <= 16) or 8 lanes per (row, head), 16-byte row
 // segments, entries (in-edges, then the self entry) four at a time with lane u of every quad owning entry u.
+// (76 registers: six waves per SIMD.  Compiled for seven -- 72 registers, 20 bytes of scratch -- the circuit-DAG forward took 224 us
+// instead of 200, for eight -- 64 registers, 56 bytes -- 343: measured, left to the compiler)
 template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_train_q4_kernel(const AttnFwdArgs a) {
   attn_forward_q4<true, LPH>(a);
 }
@@ -276,14 +278,16 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const bool recompute = a.oeid == nullptr;              // the source side keeps no per-edge values (see AttnBwdArgs)
   const f4u q = load_channels(qkvs + (int64_t)row * ld + off, nv, true);
   const f4u gi = load_channels(a.g + (int64_t)row * a.ldg + off, nv, off + 4 <= a.ldg);
-  const f4u ao = load_channels(a.attn_out + (int64_t)row * a.lda + off, nv, off + 4 <= a.lda);
-  const float delta = head_sum<LPH>(dot4(gi, ao));
   const float m = a.stat_m[(int64_t)row * H + h];
   const float inv_den = 1.0f / a.stat_den[(int64_t)row * H + h];     // one division per row, as in the forward
   const int beg = a.ptr[row];
   const int deg = a.ptr[row + 1] - beg;
   const int n_self = a.loops ? a.loops[row] : 0;
   const int cnt = deg + (n_self > 0 ? 1 : 0);
+  // delta = g . attn_out.  A row of more than four entries reads the attn_out the forward stored; a shorter one (ONE chunk) forms
+  // it below as sum_u alpha_u mask_u (g . v_u) -- the forward stores nothing for it (attn_q4.hpp)
+  float delta = 0.f;
+  if (cnt > 4) delta = head_sum<LPH>(dot4(gi, load_channels(a.attn_out + (int64_t)row * a.lda + off, nv, off + 4 <= a.lda)));
   f4u gq = {0.f, 0.f, 0.f, 0.f};
   for (int x0 = 0; x0 < cnt; x0 += 4) {
     const int k = min(4, cnt - x0);
@@ -314,6 +318,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     const float alpha = expf(mys * scale - m) * inv_den * (is_self ? (float)n_self : 1.f);
     float dmask = 1.f;
     if (a.drop_p > 0.f) dmask = uniform01_edge(seed, attn_drop_key(a.pair_key != 0, pos, H, h, row, j)) < a.drop_p ? 0.f : keep;
+    if (cnt <= 4) delta = quad_sum(lu < k ? alpha * dmask * mygv : 0.f);
     float gs = alpha * (mygv * dmask - delta) * scale;
     if (lu >= k) gs = 0.f;
     if (!recompute && lq < 4 && lu < k) {                // LPH = 8: both quads of the head hold the chunk, the first one stores
@@ -1115,8 +1120,8 @@ using namespace mlqem;
 extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
                                                      const int32_t* in_src, const int32_t* loops, int64_t N, int64_t E,
                                                      int H, int C, float drop_p, uint64_t seed,
-                                                     const uint64_t* seed_counter, int pair_key, float* out, int64_t ldo, float* attn_out,
-                                                     int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream) {
+                                                     const uint64_t* seed_counter, int pair_key, const int32_t* in_ell, float* out, int64_t ldo,
+                                                     float* attn_out, int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream) {
   begin_launches();
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
     return MLQEM_ERR_BAD_ARG;
@@ -1125,8 +1130,9 @@ extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t 
   if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
   if (pair_key && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;      // the one-channel-per-lane forms key by position only
+  if (in_ell && !aligned_to(in_ell, 8)) return MLQEM_ERR_BAD_ARG;
   const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den,
-                      pair_key ? 1 : 0};
+                      pair_key ? 1 : 0, in_ell};
   if (attn_q4_enabled()) {
     if (C > 16) hipLaunchKernelGGL(transformer_attn_train_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
     else hipLaunchKernelGGL(transformer_attn_train_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);

@@ -42,7 +42,7 @@ def run(tag, s, heads, ch):
     qkvs = ops.padded_empty(n, 4 * hc, dev).normal_()
     g = ops.padded_empty(n, hc, dev).normal_()
     pk = s.out_eid is None          # the recomputed backward forms (what the step runs on coarsened graphs)
-    fwd = lambda: ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 1234, pair_key=pk)
+    fwd = lambda: ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 1234, pair_key=pk, ell=None if pk else s.in_ell)
     out, attn, m, den = fwd()
     bwd = lambda: ops.transformer_attention_bwd(qkvs, g, attn, m, den, s, e, heads, ch, 0.1, 1234, pair_key=pk)
     x = ops.padded_empty(n, hc, dev).normal_()
