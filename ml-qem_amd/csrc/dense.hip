@@ -9,6 +9,9 @@
 // C/D: lane l, register r holds D[(l >> 4) * 4 + r][l & 15].
 #include <cstdlib>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.hpp"
 
 namespace mlqem {
@@ -267,21 +270,36 @@ __global__ __launch_bounds__(kBlock) void linear_rows_lds_kernel(const LinArgs a
   // a lane's places in the copy-out: float4 number i = lane + 64 j of the tile (row i / q4, column group i % q4)
   const int r_first = lane / q4, c_first = lane - r_first * q4, r_step = 64 / q4, c_step = 64 - r_step * q4;
   const int64_t n_tiles = ceil_div(a.N, 16);
-  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+  // the rows of a tile as this lane's B operands (zeros beyond I and beyond N); the NEXT tile's are requested before this tile's
+  // products are formed: at 125 + 72 registers only two waves share a SIMD, and a wave that loads, multiplies, transposes and stores
+  // one thing after the other left the launch at 3.1 TB/s of stores
+  auto load_rows = [&](int64_t t, float4 (&v)[G]) {
     const int64_t row = t * 16 + lr;
-    const bool row_ok = row < a.N;
+    const bool row_ok = t < n_tiles && row < a.N;
     const int64_t xrow = (a.xrows && row_ok) ? (int64_t)a.xrows[row] : row;
     const float* __restrict__ xr = a.x + xrow * a.ldx + 4 * lq;
-    float4 av[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int k0 = 16 * g + 4 * lq;
-      av[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_ok && k0 < a.I) av[g] = *reinterpret_cast<const float4*>(xr + 16 * g);     // padded rows: the float4 lies inside the row
-      if (k0 + 1 >= a.I) av[g].y = 0.f;
-      if (k0 + 2 >= a.I) av[g].z = 0.f;
-      if (k0 + 3 >= a.I) av[g].w = 0.f;
+      v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row_ok && k0 < a.I) v[g] = *reinterpret_cast<const float4*>(xr + 16 * g);     // padded rows: the float4 lies inside the row
     }
+  };
+  auto mask_cols = [&](float4 (&v)[G]) {             // where the values are taken over, not behind the load (that would wait for it)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 16 * g + 4 * lq;
+      if (k0 + 1 >= a.I) v[g].y = 0.f;
+      if (k0 + 2 >= a.I) v[g].z = 0.f;
+      if (k0 + 3 >= a.I) v[g].w = 0.f;
+    }
+  };
+  float4 av[G], an[G];
+  load_rows(wave, av);
+  mask_cols(av);
+  for (int64_t t = wave; t < n_tiles; t += n_waves) {
+    load_rows(t + n_waves, an);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[NT];
 #pragma unroll
     for (int ob = 0; ob < NT; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -314,6 +332,9 @@ __global__ __launch_bounds__(kBlock) void linear_rows_lds_kernel(const LinArgs a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile is read before the next product overwrites it
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < G; ++g) av[g] = an[g];
+    mask_cols(av);
   }
 }
 
@@ -1226,10 +1247,37 @@ __global__ __launch_bounds__(kReducePairs * kReduceSlices) void wgrad_reduce_ker
 // 2.8M-row shapes (x[22]^T g[10]: 103 us at 512, 81 us at 1024, 94 us at 2048).
 constexpr int kWgradBlocks = 1024;
 
+// The grid of a kernel whose workgroups walk the row tiles with stride gridDim.x, cut to a WHOLE number of resident rounds (occupancy x
+// compute units): 2048 workgroups of a kernel that fits 6 per CU ran as one full round and a second one at a third of the
+// occupancy -- a third of the launch's time for a sixth of its work (the Family A launchers below have sized their grids this way
+// since round 2; the general kernels behind Family B's dense layers did not until round 4).
+static int resident_of(const void* kernel) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(kernel);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return cache[kernel] = per_cu * cus;
+}
+template <typename K>
+static dim3 whole_rounds(K kernel, dim3 grid) {
+  static const int off = getenv("MLQEM_WHOLE_ROUNDS") && atoi(getenv("MLQEM_WHOLE_ROUNDS")) == 0;     // A/B
+  if (off) return grid;
+  const int64_t per_round = std::max<int64_t>(1, resident_of(reinterpret_cast<const void*>(kernel)) / std::max(1u, grid.y));
+  if ((int64_t)grid.x > per_round) grid.x = (unsigned)((int64_t)grid.x / per_round * per_round);
+  return grid;
+}
+
 template <int OBT, bool TRANSPOSED>
 static void launch_linear_mfma(const LinArgs& a, int ks, dim3 grid, hipStream_t s) {
   switch (ks) {
-#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_mfma_kernel<OBT, K, TRANSPOSED>), grid, dim3(kBlock), 0, s, a); break;
+#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_mfma_kernel<OBT, K, TRANSPOSED>), whole_rounds(linear_mfma_kernel<OBT, K, TRANSPOSED>, grid), dim3(kBlock), 0, s, a); break;
     MLQEM_CASE(1) MLQEM_CASE(2) MLQEM_CASE(3) MLQEM_CASE(4) MLQEM_CASE(6) MLQEM_CASE(8) MLQEM_CASE(12) MLQEM_CASE(16)
     MLQEM_CASE(20) MLQEM_CASE(24) MLQEM_CASE(32)
 #undef MLQEM_CASE
@@ -1239,7 +1287,7 @@ static void launch_linear_mfma(const LinArgs& a, int ks, dim3 grid, hipStream_t 
 template <int OBT, bool TRANSPOSED>
 static void launch_linear_v4(const LinArgs& a, int g, dim3 grid, hipStream_t s) {
   switch (g) {
-#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_mfma_v4_kernel<OBT, K, TRANSPOSED>), grid, dim3(kBlock), 0, s, a); break;
+#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_mfma_v4_kernel<OBT, K, TRANSPOSED>), whole_rounds(linear_mfma_v4_kernel<OBT, K, TRANSPOSED>, grid), dim3(kBlock), 0, s, a); break;
     MLQEM_CASE(1) MLQEM_CASE(2) MLQEM_CASE(3) MLQEM_CASE(4) MLQEM_CASE(5) MLQEM_CASE(6) MLQEM_CASE(7) MLQEM_CASE(8)
 #undef MLQEM_CASE
   }
@@ -1291,11 +1339,18 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
       }
-      const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * 3, ceil_div(ceil_div(N, 16), 4)));
-      if (nt == 8 && g == 2) hipLaunchKernelGGL((linear_rows_lds_kernel<8, 2>), dim3(grid), dim3(kBlock), lds, s, a, LS);
-      else if (nt == 8) hipLaunchKernelGGL((linear_rows_lds_kernel<8, 3>), dim3(grid), dim3(kBlock), lds, s, a, LS);
-      else if (g == 2) hipLaunchKernelGGL((linear_rows_lds_kernel<12, 2>), dim3(grid), dim3(kBlock), lds, s, a, LS);
-      else hipLaunchKernelGGL((linear_rows_lds_kernel<12, 3>), dim3(grid), dim3(kBlock), lds, s, a, LS);
+      // persistent waves: exactly the workgroups that are resident at once (registers allow two per CU at twelve output tiles; three
+      // were launched until round 4 -- the third ran alone after the others had finished: 166 us where 125 were due)
+      auto go = [&](auto kernel) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * per_cu, ceil_div(ceil_div(N, 16), 4)));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, s, a, LS);
+      };
+      if (nt == 8 && g == 2) go(linear_rows_lds_kernel<8, 2>);
+      else if (nt == 8) go(linear_rows_lds_kernel<8, 3>);
+      else if (g == 2) go(linear_rows_lds_kernel<12, 2>);
+      else go(linear_rows_lds_kernel<12, 3>);
       return launch_status();
     }
   }
@@ -1363,7 +1418,7 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
 
 template <bool TRANSPOSED, bool ACT, bool GATE>
 static bool launch_linear_parts(const PartsArgs& a, int g, int obt, dim3 grid, hipStream_t s) {
-#define MLQEM_PARTS(OB, K) hipLaunchKernelGGL((linear_parts_kernel<OB, K, TRANSPOSED, ACT, GATE>), grid, dim3(kBlock), 0, s, a); return true;
+#define MLQEM_PARTS(OB, K) hipLaunchKernelGGL((linear_parts_kernel<OB, K, TRANSPOSED, ACT, GATE>), whole_rounds(linear_parts_kernel<OB, K, TRANSPOSED, ACT, GATE>, grid), dim3(kBlock), 0, s, a); return true;
 #define MLQEM_PARTS_G(OB) switch (g) { case 1: MLQEM_PARTS(OB, 1) case 2: MLQEM_PARTS(OB, 2) case 3: MLQEM_PARTS(OB, 3) case 4: MLQEM_PARTS(OB, 4) default: return false; }
   if (obt == 1) MLQEM_PARTS_G(1)
   if (obt == 2) MLQEM_PARTS_G(2)
@@ -1522,17 +1577,19 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
   bool uniform_ld = true;
   for (int k = 1; k < a.gn; ++k) uniform_ld = uniform_ld && a.ldgy[k] == a.ldgy[0];
   const int64_t iters = ceil_div(std::max<int64_t>(a.N, 1), 4 * (wide && wide_u == 2 ? 2 : kWgradUnroll));
-  const int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
+  int G = (int)std::max<int64_t>(1, std::min<int64_t>(kWgradBlocks, ceil_div(iters, 4)));
+  // the workgroups walk the rows with stride gridDim.x and leave one partial each: a whole number of resident rounds (whole_rounds)
+#define MLQEM_WG(KERNEL, GY) { const dim3 gr = whole_rounds(KERNEL, dim3((unsigned)G, (unsigned)(GY))); G = (int)gr.x; hipLaunchKernelGGL(KERNEL, gr, dim3(kBlock), 0, s, a); }
   const int ob = (a.O + 15) / 16, ib = (a.I + 1 + 15) / 16;
   if (ob == 1 && ib <= 2) {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    MLQEM_WG((wgrad_mfma_kernel<1, 2>), 1)
   } else if (ob == 2 && ib <= 2) {   // two or three column blocks of gy against a narrow x: still ONE pass over x
-    hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    MLQEM_WG((wgrad_mfma_kernel<2, 2>), 1)
   } else if (ob == 3 && ib <= 2) {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<3, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    MLQEM_WG((wgrad_mfma_kernel<3, 2>), 1)
   } else if (ob == 4 && ib <= 2) {   // up to eight blocks (the three first layers of Family A share x): one pass
-    if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_mfma_kernel<4, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    if (wide_u == 2) MLQEM_WG((wgrad_mfma_kernel<4, 2, 2>), 1)
+    else MLQEM_WG((wgrad_mfma_kernel<4, 2>), 1)
   } else if (ob <= 6 && ib <= 2 && pipe_env && uniform_ld) {
     // the first-layer blocks: software-pipelined form (see wgrad_pipe_kernel).  Blocks are 12 floats wide with 10 real columns:
     // the MFMA rows take the REAL columns back to back (six blocks: 60 rows = four tiles instead of 72 = five; seven: five instead
@@ -1554,20 +1611,20 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
                        Gp, a.I, a.O, gw, gb, accumulate, pack ? pw : 0, pack ? pc : 0);
     return launch_status();
   } else if (ob <= 6 && ib <= 2) {
-    if (wide_u == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
-    else if (wide_pf) hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2, kWgradUnroll, true>), dim3(G, 1), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, 1), dim3(kBlock), 0, s, a);
+    if (wide_u == 2) MLQEM_WG((wgrad_mfma_kernel<6, 2, 2>), 1)
+    else if (wide_pf) MLQEM_WG((wgrad_mfma_kernel<6, 2, kWgradUnroll, true>), 1)
+    else MLQEM_WG((wgrad_mfma_kernel<6, 2>), 1)
   } else if (ob == 1) {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), dim3(G, (unsigned)ceil_div(ib, 4)), dim3(kBlock), 0, s, a);
+    MLQEM_WG((wgrad_mfma_kernel<1, 4>), (unsigned)ceil_div(ib, 4))
   } else if (ob > 6 && ib <= 2 && wide6_env) {
     // many outputs against a narrow x (Family B's first projection: gy[180]^T x[22]): six output tiles per workgroup -- a row's
     // gy is read as 384-byte pieces by ceil(ob / 6) workgroup columns instead of 128-byte pieces by ceil(ob / 2), and x is
     // re-read two times instead of six
-    hipLaunchKernelGGL((wgrad_mfma_kernel<6, 2>), dim3(G, (unsigned)ceil_div(ob, 6)), dim3(kBlock), 0, s, a);
+    MLQEM_WG((wgrad_mfma_kernel<6, 2>), (unsigned)ceil_div(ob, 6))
   } else {
-    hipLaunchKernelGGL((wgrad_mfma_kernel<2, 4>), dim3(G, (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4))), dim3(kBlock),
-                       0, s, a);
+    MLQEM_WG((wgrad_mfma_kernel<2, 4>), (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4)))
   }
+#undef MLQEM_WG
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(a.O * (a.I + 1), kReducePairs)), dim3(kReducePairs * kReduceSlices), 0, s, a.partial,
                      G, a.I, a.O, gw, gb, accumulate, 0, 0);
   return launch_status();

@@ -1532,8 +1532,10 @@ extern "C" int mlqem_layer_wgrad_f32(const float* dy, const float* x, int64_t ld
     }
     // the partial sums of a workgroup are n_waves x 16 KB
     const int64_t cap = (int64_t)(mlqem_layer_workspace_bytes() / ((size_t)n_waves * kWgF32WaveFloats * sizeof(float)));
-    // ~12 waves per CU whatever the workgroup's size (a 41-unit layer's workgroup is two waves)
-    const int64_t want = (int64_t)cus * std::max(2, 12 / n_waves);
+    // persistent workgroups: exactly as many as are resident at once (at 210 registers two waves share a SIMD: eight waves per CU)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel, n_waves * kWave, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int64_t want = (int64_t)cus * per_cu;
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cap), std::max<int64_t>(N / 32, 1)));
     hipLaunchKernelGGL(layer_wgrad_f32_kernel, dim3(G), dim3(n_waves * kWave), 0, s, a);
   }

@@ -1,5 +1,5 @@
 """Merges the four rocprofv3 kernel-stats files scripts/profile_mlp_head.sh leaves under gpurun_out/ into ONE table with a
-roofline row per kernel of the MLP steps: python scripts/summarise_mlp_head.py [gpurun_out] [profiles/r03_mlp_head_kernel_stats.csv]
+roofline row per kernel of the MLP steps: python scripts/summarise_mlp_head.py [gpurun_out] [profiles/r04_mlp_head_kernel_stats.csv]
 
 Per kernel: launches per step, average duration inside the eagerly enqueued train step (every kernel its own trace record),
 ALGORITHMIC bytes per launch (operands at their unpadded widths... except the 128-wide bf16 activations, which ARE the storage
@@ -12,7 +12,7 @@ import sys
 
 ROWS, F, FP = 262144, 170, 172
 SRC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
-OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_mlp_head_kernel_stats.csv"
+OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04_mlp_head_kernel_stats.csv"
 STEPS = 24
 HBM, MFMA = 8000.0, {"f32": 157.0, "bf16": 2500.0}
 
@@ -32,6 +32,20 @@ def model(kind, mode, name):
         return x32 + A16 + N * 4, 2 * N * (F * h + h), "bf16"
     if "mlp1_bwd_bf16" in name:
         return x32 + A16 + N * 4, 2 * N * (h * (F + 1)) + 4 * N * h, "bf16"
+    # fp32 storage (round 4): activations are [N, 128] fp32 matrices
+    A32 = 2 * A16
+    f32s = "<float>" in name or ", float>" in name
+    A = A32 if f32s else A16
+    if "layer_fwd_f32_kernel<12, 8>" in name:                   # fc1: fp32 rows in, fp32 activation out
+        return x32 + A32, 2 * N * F * h, "f32"
+    if "layer_fwd_f32_kernel<8, 8>" in name:                    # fc2, and the data gradient of fc2 (+ the residual's gradient: one more read)
+        return 2.5 * A32, 2 * N * h * h, "f32"
+    if "layer_fwd_f32_kernel<8, 4>" in name:                    # fc3 (41 units) with ReLU + dropout in the epilogue
+        return 2 * A32, 2 * N * h * (h // 3), "f32"
+    if "layer_fwd_f32_kernel<4, 8>" in name:                    # the data gradient of fc3
+        return 2 * A32, 2 * N * h * (h // 3), "f32"
+    if "layer_wgrad_f32_kernel" in name:                        # three launches a step (fc1, fc2, fc3): their average
+        return (x32 + A32 + 2 * A32 + 2 * A32) / 3, 2 * N * (h * (F + 1) + h * (h + 1) + (h // 3) * (h + 1)) / 3, "f32"
     if "layer_fwd_kernel<6, false>" in name:                   # fc1: fp32 rows in, bf16 activation out
         return x32 + A16, 2 * N * F * h, "bf16"
     if "layer_fwd_kernel<4, true>" in name or "layer_fwd_kernel<2, true>" in name:     # bf16 in, bf16 out (fc2/fc3, data gradients)
@@ -41,17 +55,17 @@ def model(kind, mode, name):
     if "layer_wgrad_kernel<false>" in name:
         return x32 + A16, 2 * N * h * (F + 1), "bf16"
     if "layer_act_kernel" in name:
-        return 2 * A16, 0, None
+        return 2 * A, 0, None
     if "layer_bwd_apply_kernel" in name:
-        return 3 * A16, 0, None
-    if "layer_colsum_kernel<0>" in name:
-        return A16, 0, None
-    if "layer_colsum_kernel<1>" in name:
-        return 2 * A16, 0, None
+        return 3 * A, 0, None
+    if "layer_colsum_kernel<0" in name:
+        return A, 0, None
+    if "layer_colsum_kernel<1" in name:
+        return 2 * A, 0, None
     if "layer_rowdot_fwd" in name:
-        return A16 + N * 4, 2 * N * h, None
+        return A + N * 4, 2 * N * h, None
     if "layer_rowdot_bwd" in name:
-        return 2 * A16 + N * 4, 4 * N * h, None
+        return 2 * A + N * 4, 4 * N * h, None
     if "linear_mfma_v4_kernel" in name or "linear_mfma_kernel" in name:
         return None
     return None
