@@ -507,7 +507,9 @@ def family_b_leg(dev, steps=30):
     cfg4["hipgraph"], cfg4["eager"] = cfg4["batch64_hipgraph"], cfg4["batch64_eager"]
     cfg4["circuits_per_s"] = cfg4["batch64_hipgraph"]["circuits_per_s"]
     cfg4["ms_per_step"] = cfg4["batch64_hipgraph"]["ms_per_step"]
-    cfg4["best_circuits_per_s"] = max(cfg4[k]["circuits_per_s"] for k in ("batch64_hipgraph", "batch256_hipgraph", "batch512_hipgraph", "batch1024_eager"))
+    points = ("batch64_hipgraph", "batch256_hipgraph", "batch512_hipgraph", "batch1024_eager")
+    cfg4["best_point"] = max(points, key=lambda k: cfg4[k]["circuits_per_s"])
+    cfg4["best_circuits_per_s"] = cfg4[cfg4["best_point"]]["circuits_per_s"]
     cfg4["attention_roofline"] = attention_roofline(big_arena.batch(np.arange(64) * nb_graphs // 64).structure, dev,
                                                     "64 100-qubit circuits (the first TransformerConv's graph: the circuit DAGs)")
     out["cfg4_100q"] = cfg4
