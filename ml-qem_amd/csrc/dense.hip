@@ -587,8 +587,12 @@ __global__ __launch_bounds__(kBlock) void linear_parts_kernel(const PartsArgs a)
 // one accumulator tile at a time (~48 VGPRs, eight waves per SIMD), reads a tile's fragments with one ds_read_b128 per
 // 16 input columns, and a tile's store is 16 rows x (block width) contiguous bytes of ONE buffer.  Same MFMA step order
 // per output as linear_parts_kernel: bit-identical results.
-template <int G>
+// K24 (G = 2, 17-24 input columns: the 22 node features of the headline model): the second k-group holds EIGHT columns, two per
+// lane quarter (k = 16 + 2 lq + s, s < 2, an 8-byte load) instead of sixteen of which the upper eight are padding -- six MFMAs per
+// output block and 16-row tile instead of eight (the launch's MFMA time at 11.3 M rows: 441 -> 331 us of a 945 us launch).
+template <int G, bool K24 = false>
 __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsArgs a) {
+  static_assert(!K24 || G == 2, "the 24-column form has two k-groups");
   __shared__ float4 s_w[kMaxParts][G][kWave];
   __shared__ float s_b[kMaxParts][16];
   const int tid = threadIdx.x;
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
     float v[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      const int k = 16 * g + 4 * lq + s4;
+      const int k = (K24 && g == 1) ? (s4 < 2 ? 16 + 2 * lq + s4 : a.xc) : 16 * g + 4 * lq + s4;
       float w = 0.f;
       if (o < a.yc && k < a.xc) {
         w = a.wk[blk][(int64_t)o * a.xc + k];
@@ -620,8 +624,8 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
   const float* xcol[G]; int xlive[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const int k0 = 16 * g + 4 * lq;
-    xlive[g] = k0 < a.xc ? min(4, a.xc - k0) : 0;
+    const int k0 = (K24 && g == 1) ? 16 + 2 * lq : 16 * g + 4 * lq;
+    xlive[g] = k0 < a.xc ? min((K24 && g == 1) ? 2 : 4, a.xc - k0) : 0;
     xcol[g] = xlive[g] ? a.xp[0] + k0 : nullptr;
   }
   const bool store_lane = 4 * lq < a.yw;       // the block's padded width: lanes beyond it own no output columns
@@ -634,7 +638,14 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
     const int64_t r = min(t * 16 + lr, a.N - 1);
     const int64_t xr = a.xrows ? (int64_t)xmap : r;
 #pragma unroll
-    for (int g = 0; g < G; ++g) v[g] = xcol[g] ? *reinterpret_cast<const float4*>(xcol[g] + xr * a.ldx[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < G; ++g) {
+      if (K24 && g == 1) {
+        const float2 h = xcol[g] ? *reinterpret_cast<const float2*>(xcol[g] + xr * a.ldx[0]) : make_float2(0.f, 0.f);
+        v[g] = make_float4(h.x, h.y, 0.f, 0.f);
+      } else {
+        v[g] = xcol[g] ? *reinterpret_cast<const float4*>(xcol[g] + xr * a.ldx[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
   };
   auto map_at = [&](int64_t t) {
     const int64_t r = min(t * 16 + lr, a.N - 1);
@@ -674,6 +685,7 @@ __global__ __launch_bounds__(kBlock) void linear_fanout_lds_kernel(const PartsAr
         const float4 w4 = s_w[blk][g][lane];
         acc = mfma16x16x4(w4.x, av[g].x, acc);
         acc = mfma16x16x4(w4.y, av[g].y, acc);
+        if (K24 && g == 1) continue;       // the group's eight columns are done
         acc = mfma16x16x4(w4.z, av[g].z, acc);
         acc = mfma16x16x4(w4.w, av[g].w, acc);
       }
@@ -1460,17 +1472,23 @@ static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
     static const int grid_env = getenv("MLQEM_FANOUT_GRID") ? atoi(getenv("MLQEM_FANOUT_GRID")) : 0;    // workgroups per CU; 0 = whole resident rounds
     static const int rounds_env = getenv("MLQEM_FANOUT_ROUNDS") ? atoi(getenv("MLQEM_FANOUT_ROUNDS")) : 1;
     a.plain_stores = plain_env;
+    static const int k24_env = getenv("MLQEM_FANOUT_K24") ? atoi(getenv("MLQEM_FANOUT_K24")) : 1;
+    const bool k24 = k24_env && g == 2 && a.xc <= 24 && a.ldx[0] % 2 == 0 && aligned_to(a.xp[0], 8);
     int res = 0;
     switch (g) {
       case 1: { static const int r = resident_workgroups(linear_fanout_lds_kernel<1>); res = r; break; }
-      case 2: { static const int r = resident_workgroups(linear_fanout_lds_kernel<2>); res = r; break; }
+      case 2: { static const int r = resident_workgroups(linear_fanout_lds_kernel<2>), r24 = resident_workgroups(linear_fanout_lds_kernel<2, true>);
+                res = k24 ? r24 : r; break; }
       case 3: { static const int r = resident_workgroups(linear_fanout_lds_kernel<3>); res = r; break; }
       default: { static const int r = resident_workgroups(linear_fanout_lds_kernel<4>); res = r; break; }
     }
     dim3 grid((unsigned)std::min<int64_t>(ceil_div(tiles, 4), grid_env > 0 ? 256 * grid_env : res * rounds_env));
     switch (g) {
       case 1: hipLaunchKernelGGL(linear_fanout_lds_kernel<1>, grid, dim3(kBlock), 0, s, a); break;
-      case 2: hipLaunchKernelGGL(linear_fanout_lds_kernel<2>, grid, dim3(kBlock), 0, s, a); break;
+      case 2:
+        if (k24) hipLaunchKernelGGL((linear_fanout_lds_kernel<2, true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL(linear_fanout_lds_kernel<2>, grid, dim3(kBlock), 0, s, a);
+        break;
       case 3: hipLaunchKernelGGL(linear_fanout_lds_kernel<3>, grid, dim3(kBlock), 0, s, a); break;
       default: hipLaunchKernelGGL(linear_fanout_lds_kernel<4>, grid, dim3(kBlock), 0, s, a); break;
     }
