@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
 // instruction 64 bytes of 16 different rows: 1.7 TB/s at 11 M rows.  Here a wave owns 16 WHOLE rows: all NT tiles of the product
 // (W fragments in registers: NT x G x 4), the result transposed through LDS into the rows' memory order -- a tile of 16 padded rows
 // IS one contiguous block when ldy = round_up(O, 4) -- and written as full 1 KB wave stores; the bias is added on the way out.
-template <int NT, int G>
+template <int NT, int G, bool K24 = false>     // K24: 17-24 input columns as 16 + 8 (see linear_fanout_lds_kernel)
 __global__ __launch_bounds__(kBlock) void linear_rows_lds_kernel(const LinArgs a, int LS) {
   extern __shared__ float s_rows_lds[];                  // [4 waves][16 rows][LS] | bias [NT * 16]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void linear_rows_lds_kernel(const LinArgs a
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const int k = 16 * g + 4 * lq + s4;
+        const int k = (K24 && g == 1) ? (s4 < 2 ? 16 + 2 * lq + s4 : a.I) : 16 * g + 4 * lq + s4;
         wf[ob][g][s4] = (o < a.O && k < a.I) ? a.w[(int64_t)o * a.I + k] : 0.f;
       }
   }
@@ -280,14 +280,25 @@ __global__ __launch_bounds__(kBlock) void linear_rows_lds_kernel(const LinArgs a
     const float* __restrict__ xr = a.x + xrow * a.ldx + 4 * lq;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int k0 = 16 * g + 4 * lq;
       v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_ok && k0 < a.I) v[g] = *reinterpret_cast<const float4*>(xr + 16 * g);     // padded rows: the float4 lies inside the row
+      if (K24 && g == 1) {
+        if (row_ok && 16 + 2 * lq < a.I) {
+          const float2 h = *reinterpret_cast<const float2*>(a.x + xrow * a.ldx + 16 + 2 * lq);
+          v[g].x = h.x; v[g].y = h.y;
+        }
+      } else {
+        const int k0 = 16 * g + 4 * lq;
+        if (row_ok && k0 < a.I) v[g] = *reinterpret_cast<const float4*>(xr + 16 * g);   // padded rows: the float4 lies inside the row
+      }
     }
   };
   auto mask_cols = [&](float4 (&v)[G]) {             // where the values are taken over, not behind the load (that would wait for it)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+      if (K24 && g == 1) {
+        if (16 + 2 * lq + 1 >= a.I) v[g].y = 0.f;
+        continue;
+      }
       const int k0 = 16 * g + 4 * lq;
       if (k0 + 1 >= a.I) v[g].y = 0.f;
       if (k0 + 2 >= a.I) v[g].z = 0.f;
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void linear_rows_lds_kernel(const LinArgs a
     for (int g = 0; g < G; ++g) {
       const float comp[4] = {av[g].x, av[g].y, av[g].z, av[g].w};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
+      for (int s4 = 0; s4 < ((K24 && g == 1) ? 2 : 4); ++s4)
 #pragma unroll
         for (int ob = 0; ob < NT; ++ob) acc[ob] = mfma16x16x4(wf[ob][g][s4], comp[s4], acc[ob]);
     }
@@ -1359,9 +1370,10 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * per_cu, ceil_div(ceil_div(N, 16), 4)));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, s, a, LS);
       };
-      if (nt == 8 && g == 2) go(linear_rows_lds_kernel<8, 2>);
+      const bool k24 = g == 2 && I > 16 && I <= 24 && ldx % 2 == 0;
+      if (nt == 8 && g == 2) { if (k24) go(linear_rows_lds_kernel<8, 2, true>); else go(linear_rows_lds_kernel<8, 2>); }
       else if (nt == 8) go(linear_rows_lds_kernel<8, 3>);
-      else if (g == 2) go(linear_rows_lds_kernel<12, 2>);
+      else if (g == 2) { if (k24) go(linear_rows_lds_kernel<12, 2, true>); else go(linear_rows_lds_kernel<12, 2>); }
       else go(linear_rows_lds_kernel<12, 3>);
       return launch_status();
     }
