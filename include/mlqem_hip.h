@@ -632,7 +632,7 @@ int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const i
                                           mlqem_stream_t stream);
 
 /* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  Stored form: edge_al / edge_gs: scratch
- * [(E+N)*H].  Recomputed form (out_eid == NULL): edge_al: scratch [N*H], edge_gs unused (may be NULL); with drop_p > 0 it needs
+ * [(E+N)*H].  Recomputed form (out_eid == NULL): edge_al: scratch [4*N*H] (16-byte aligned), edge_gs unused (may be NULL); with drop_p > 0 it needs
  * pair_key != 0 (MLQEM_ERR_BAD_ARG otherwise). */
 int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg,
                                         const float* attn_out, int64_t lda, const float* stat_m, const float* stat_den,

@@ -1449,8 +1449,8 @@ def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channe
     g = rowmajor(g)
     dev = qkvs.device
     gqkvs = padded_empty(n, 4 * hc, dev)
-    if s.out_eid is None:
-        al, gs = torch.empty(max(n, 1) * heads, dtype=torch.float32, device=dev), None
+    if s.out_eid is None:          # the recomputed form: one 16-byte record {m, 1 / den, g . attn_out} per (row, head)
+        al, gs = torch.empty(4 * max(n, 1) * heads, dtype=torch.float32, device=dev), None
     else:
         scratch = torch.empty((2, (num_edges + n) * heads + 1), dtype=torch.float32, device=dev)
         al, gs = scratch[0], scratch[1]

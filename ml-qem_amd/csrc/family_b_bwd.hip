@@ -330,7 +330,9 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     for (int u = 0; u < 4; ++u) gq += gu[u] * kk[u];
   }
   if (recompute) {
-    if (lq == 0) edge_al[(int64_t)row * H + h] = delta;   // what the source side needs of this row besides m and den
+    // what the source side needs of this row, as ONE 16-byte record per (row, head): three 4-byte gathers from three arrays per
+    // out-entry were three of its seven cache-line requests
+    if (lq == 0) reinterpret_cast<float4*>(edge_al)[(int64_t)row * H + h] = make_float4(m, inv_den, delta, 0.f);
   } else if (n_self == 0 && lq == 0) {
     edge_al[(a.E + row) * H + h] = 0.f;
     edge_gs[(a.E + row) * H + h] = 0.f;
@@ -377,7 +379,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     const bool is_self = x >= odeg;
     const int i = is_self ? row : a.odst[obeg + x];
     const int64_t sh = (int64_t)i * H + h;
-    const float m_i = a.stat_m[sh], inv_den = 1.0f / a.stat_den[sh], delta_i = stat_delta[sh];
+    const float4 rec = reinterpret_cast<const float4*>(stat_delta)[sh];     // {m, 1 / den, delta} filed by the destination side
+    const float m_i = rec.x, inv_den = rec.y, delta_i = rec.z;
     int iu[4];
     iu[0] = quad_bcast<0>(i); iu[1] = quad_bcast<1>(i); iu[2] = quad_bcast<2>(i); iu[3] = quad_bcast<3>(i);
     f4u qa[4], ga[4];
@@ -1155,6 +1158,7 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
   const bool recompute = out_eid == nullptr;             // no out_eid: the source side recomputes its weights (edge_al: [N H] floats)
+  if (recompute && !aligned_to(edge_al, 16)) return MLQEM_ERR_BAD_ARG;       // the per-(row, head) records are 16-byte stores
   if (!qkvs || !g || !attn_out || !stat_m || !stat_den || !in_ptr || !out_ptr || !gqkvs || !edge_al || (!recompute && !edge_gs))
     return MLQEM_ERR_BAD_ARG;
   if (E > 0 && (!in_src || !out_dst)) return MLQEM_ERR_BAD_ARG;
