@@ -1123,6 +1123,7 @@ struct WgradF32Args {
 };
 constexpr int kWgF32WaveFloats = 16 * 4 * kWave;       // a wave's 16 tiles
 
+template <int Q>      // 4-row steps per slab (a slab in flight, one being multiplied: 2 x 2 Q float4 registers)
 __global__ __launch_bounds__(384) void layer_wgrad_f32_kernel(const WgradF32Args a) {
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -1138,21 +1139,22 @@ __global__ __launch_bounds__(384) void layer_wgrad_f32_kernel(const WgradF32Args
   for (int cu = 0; cu < 4; ++cu)
 #pragma unroll
     for (int cx = 0; cx < 4; ++cx) acc[cu][cx] = f32x4{0.f, 0.f, 0.f, 0.f};
-  struct Slab { float4 d[8], x[8]; };
-  const int64_t n_slabs = a.N / 32;
+  struct Slab { float4 d[Q], x[Q]; };
+  constexpr int SR = 4 * Q;                                  // rows of a slab
+  const int64_t n_slabs = a.N / SR;
   const float* dyl = a.dy + (int64_t)lq * kLW + 64 * wu + 4 * lr;
   const float* xl = a.x + (int64_t)lq * a.ldx + colc;
   auto issue = [&](Slab& s, int64_t sl) {
-    const int64_t r0 = 32 * min(sl, n_slabs - 1);
+    const int64_t r0 = SR * min(sl, n_slabs - 1);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < Q; ++q) {
       s.d[q] = *reinterpret_cast<const float4*>(dyl + (r0 + 4 * q) * kLW);
       s.x[q] = *reinterpret_cast<const float4*>(xl + (r0 + 4 * q) * a.ldx);
     }
   };
   auto consume = [&](const Slab& s, int64_t first_row) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < Q; ++q) {
       const bool ok = first_row + 4 * q + lq < a.N;         // the ragged tail: a clamped row contributes nothing
       const float dv[4] = {ok ? s.d[q].x : 0.f, ok ? s.d[q].y : 0.f, ok ? s.d[q].z : 0.f, ok ? s.d[q].w : 0.f};
       const float xr[4] = {s.x[q].x, s.x[q].y, s.x[q].z, s.x[q].w};
@@ -1172,20 +1174,20 @@ __global__ __launch_bounds__(384) void layer_wgrad_f32_kernel(const WgradF32Args
     for (int64_t sl = blockIdx.x; sl < n_slabs; sl += G) {
       issue(nxt, sl + G);
       __builtin_amdgcn_sched_barrier(0);
-      consume(cur, 32 * sl);
+      consume(cur, SR * sl);
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
     }
   }
-  if (blockIdx.x == 0 && (a.N & 31)) {
+  if (blockIdx.x == 0 && (a.N % SR)) {
     Slab t;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int64_t row = min(32 * n_slabs + 4 * q + lq, a.N - 1);
+    for (int q = 0; q < Q; ++q) {
+      const int64_t row = min(SR * n_slabs + 4 * q + lq, a.N - 1);
       t.d[q] = *reinterpret_cast<const float4*>(a.dy + row * kLW + 64 * wu + 4 * lr);
       t.x[q] = *reinterpret_cast<const float4*>(a.x + row * a.ldx + colc);
     }
-    consume(t, 32 * n_slabs);
+    consume(t, SR * n_slabs);
   }
   float* __restrict__ dst = a.partial + ((int64_t)blockIdx.x * (blockDim.x / kWave) + wid) * kWgF32WaveFloats + lane;
 #pragma unroll
@@ -1533,11 +1535,16 @@ extern "C" int mlqem_layer_wgrad_f32(const float* dy, const float* x, int64_t ld
     // the partial sums of a workgroup are n_waves x 16 KB
     const int64_t cap = (int64_t)(mlqem_layer_workspace_bytes() / ((size_t)n_waves * kWgF32WaveFloats * sizeof(float)));
     // persistent workgroups: exactly as many as are resident at once (at 210 registers two waves share a SIMD: eight waves per CU)
+    static const int q_env = getenv("MLQEM_LAYER_WGRAD_Q") ? atoi(getenv("MLQEM_LAYER_WGRAD_Q")) : 8;
+    const bool q4 = q_env == 4;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel, n_waves * kWave, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if ((q4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel<4>, n_waves * kWave, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel<8>, n_waves * kWave, 0)) != hipSuccess || per_cu < 1)
+      per_cu = 1;
     const int64_t want = (int64_t)cus * per_cu;
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cap), std::max<int64_t>(N / 32, 1)));
-    hipLaunchKernelGGL(layer_wgrad_f32_kernel, dim3(G), dim3(n_waves * kWave), 0, s, a);
+    if (q4) hipLaunchKernelGGL(layer_wgrad_f32_kernel<4>, dim3(G), dim3(n_waves * kWave), 0, s, a);
+    else hipLaunchKernelGGL(layer_wgrad_f32_kernel<8>, dim3(G), dim3(n_waves * kWave), 0, s, a);
   }
   hipLaunchKernelGGL(layer_wgrad_f32_reduce_kernel, dim3((unsigned)ceil_div(n_waves * kWgF32WaveFloats, kWave)), dim3(16 * kWave), 0, s,
                      a.partial, G, K, U, NC, n_waves, gw, gb);
