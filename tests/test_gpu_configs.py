@@ -175,8 +175,8 @@ def test_cfg1_mlp_on_v2_features():
     want.square().mean().backward()
     top = max(q.grad.abs().max().item() for q in ref.parameters())
     for (name, p), (_, q) in zip(gpu.named_parameters(), ref.named_parameters()):
-        # (a Linear's bias in front of a BatchNorm has an analytically zero gradient: rounding noise, measured against the largest one)
-        assert (p.grad.cpu().double() - q.grad).abs().max().item() <= 1e-5 * max(q.grad.abs().max().item(), 1e-2 * top), name
+        # (a Linear's bias in front of a BatchNorm has an analytically zero gradient: rounding noise of a few fp32 ulps of the LARGEST gradient -- 1.2e-7 of it measured -- so the floor is 5e-7 of that)
+        assert (p.grad.cpu().double() - q.grad).abs().max().item() <= 1e-5 * max(q.grad.abs().max().item(), 5e-2 * top), name
     assert (gpu.bn1.running_var.cpu().double() - ref.bn1.running_var).abs().max().item() <= 1e-5 * ref.bn1.running_var.abs().max().item()
 
 

@@ -230,9 +230,9 @@ def test_train_step_on_the_layer_kernels_equals_the_oracle_in_fp64(cls, args):
     assert abs(loss.item() - wl.item()) <= 1e-5 * max(abs(wl.item()), 1.0)
     top = max(q.grad.abs().max().item() for q in ref.parameters())
     for (name, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        # the bias of a Linear in front of a BatchNorm has an analytically ZERO gradient: rounding noise on both sides
+        # the bias of a Linear in front of a BatchNorm has an analytically ZERO gradient: rounding noise of a few fp32 ulps of the largest gradient, hence the floor of 5e-7 of it
         err = (p.grad.cpu().double() - q.grad).abs().max().item()
-        assert err <= 1e-5 * max(q.grad.abs().max().item(), 1e-2 * top), (name, err)
+        assert err <= 1e-5 * max(q.grad.abs().max().item(), 5e-2 * top), (name, err)
     if needs:
         _close(xin.grad, xr.grad, "input gradient")
     for bn, rbn in ((model.bn1, ref.bn1), (model.bn2, ref.bn2)):
