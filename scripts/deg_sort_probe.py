@@ -90,6 +90,9 @@ d = indeg.cpu().numpy()
 print("level-1 in-degree quantiles 50/83/90/99/max:", [int(np.quantile(d, q)) for q in (0.5, 0.83, 0.9, 0.99, 1.0)],
       "share of edges in rows >= 32:", float(d[d >= 32].sum()) / float(d.sum()), flush=True)
 run("level 1 as it stands   ", s1, 2, 15)
+if os.environ.get("PROBE_ALIGNED", "0") == "1":      # what 128-byte-aligned q / k / v parts would buy: the same graph with 16 channels per head
+    run("level 1, 16 channels   ", s1, 2, 16)
+    run("level 0, 16 channels   ", b4.structure, 3, 16)
 if os.environ.get("PROBE_ONLY_L1", "0") == "1":
     sys.exit(0)
 if os.environ.get("PROBE_FULL", "0") == "1":
