@@ -315,12 +315,25 @@ __global__ __launch_bounds__(256) void layer_colsum_kernel(const ActArgs a) {
   const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
   const float inv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block, r1 = min(r0 + a.rows_per_block, a.N);
+  // MODE 0: the sums are taken of y - s with s = row 0 of the matrix (as bn.hip does): E[y^2] - E[y]^2 of columns whose mean is large
+  // against their spread loses the variance to cancellation in fp32; the shifted sums do not.  Workgroup 0 files s behind the partials.
+  float sh0[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh0[e] = 0.f;
+  if (MODE == 0) {
+    load8(static_cast<const ST*>(a.y), t, sh0);
+    if (blockIdx.x == 0 && rl == 0) {
+      float* __restrict__ shift = a.partial + (int64_t)gridDim.x * 2 * kLW;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) shift[col_of<ST>(t, e)] = sh0[e];
+    }
+  }
   for (int64_t row = r0 + rl; row < r1; row += 16) {
     if (MODE == 0) {
       float y[8];
       load8(static_cast<const ST*>(a.y) + row * kLW, t, y);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s1[e] += y[e]; s2[e] = fmaf(y[e], y[e], s2[e]); }
+      for (int e = 0; e < 8; ++e) { const float d = y[e] - sh0[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
     } else {
       float gu[8], y[8];
       load_gu<ST>(a, seed, inv, sc, sh, row, t, gu, y);
@@ -379,8 +392,9 @@ __global__ __launch_bounds__(kFinishThreads) void layer_finish_kernel(const floa
   if (j != 0) return;
   t1 = s_t[0][0]; t2 = s_t[1][0];
   if (MODE == 0) {
-    const double m = t1 / (double)N;
-    double var = t2 / (double)N - m * m;
+    const double ms = t1 / (double)N;                   // mean of the shifted values (shift = row 0, filed behind the partials)
+    const double m = (double)partial[(int64_t)nblocks * 2 * kLW + c] + ms;
+    double var = t2 / (double)N - ms * ms;
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * is;
@@ -1276,7 +1290,7 @@ using namespace mlqem;
 extern "C" size_t mlqem_layer_workspace_bytes(void) {
   const size_t image = (size_t)layer_image_u32x4(6) * sizeof(u32x4);
   const size_t wgrad = (size_t)kLayerMaxBlocks * kLayerW1Floats * sizeof(float);
-  const size_t colsum = (size_t)kColsumMaxBlocks * 2 * kLW * sizeof(float);
+  const size_t colsum = ((size_t)kColsumMaxBlocks * 2 + 1) * kLW * sizeof(float);      // per-workgroup partial sums | the shift (row 0)
   const size_t dot = (size_t)kColsumMaxBlocks * MLQEM_MLP1_MAX_OUT * (kLW + 1) * sizeof(float);
   return std::max(std::max(image, wgrad), std::max(colsum, dot));
 }

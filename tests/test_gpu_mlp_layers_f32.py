@@ -103,6 +103,21 @@ def test_batch_statistics_activation_and_backward_blocks(n, c):
         assert rel(d2[0], gu.sum(0)) < 1e-5
 
 
+def test_batch_statistics_of_columns_far_from_zero():
+    """Columns whose mean is a thousand times their spread: the sums are taken of y - y[0] (as csrc/bn.hip does), so the variance
+    does not drown in E[y^2] - E[y]^2 (unshifted fp32 sums lose every digit of it here)."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(3)
+    n, c = 100000, 125
+    ya, yv = _act_matrix(n, c, g, scale=0.1, shift=100.0)
+    gamma, beta = torch.ones(c), torch.zeros(c)
+    mean, var, invstd, scale, shift = ops.layer_colstats_fwd(ya, gamma.to(DEV), beta.to(DEV), 1e-5, n, c)
+    m64, v64 = yv.mean(0), yv.var(0, unbiased=False)
+    assert (mean.cpu().double()[:c] - m64).abs().max().item() <= 1e-6 * 100.0
+    assert ((var.cpu().double()[:c] - v64).abs() / v64).max().item() < 1e-4
+
+
 def test_dropout_masks_are_recomputed_identically_in_the_backward():
     from blackwater.native import ops
 
