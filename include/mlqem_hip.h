@@ -624,12 +624,17 @@ int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const
  * backward needs it.  seed_counter (may be NULL): a device-resident step counter mixed into the seed, so that a launch captured
  * in a hipGraph draws a fresh mask per replay (the backward entry point must be given the same seed, counter and key form).
  * in_ell (optional, ABI 25): the [N,2] side table of mlqem_ell_from_csr over the same in-CSR -- rows of at most two in-edges then
- * reach their key / value rows without the ptr -> idx round trip (same result bit for bit). */
+ * reach their key / value rows without the ptr -> idx round trip (same result bit for bit).
+ * head_pitch (ABI 25; 0 = C): the channel pitch of a head inside the four parts of qkvs -- and of gqkvs in the backward --
+ * i.e. qkvs is [N, 4 H head_pitch] with part p of head h at column (p H + h) head_pitch and zeros in the head_pitch - C pad
+ * channels (a projection whose weight and bias rows are padded the same way produces exactly that).  16 for the reference's
+ * 15 channels makes every gathered key / value / query segment an aligned 64-byte piece (forward -8 %, backward -7..-17 % on
+ * the 100-qubit graphs for 7 % more bytes); out, attn_out and g stay compact [N, H C]; the backward writes zeros into gqkvs' pads. */
 int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
                                           const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p,
                                           uint64_t seed, const uint64_t* seed_counter, int pair_key, const int32_t* in_ell,
-                                          float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m, float* stat_den,
-                                          mlqem_stream_t stream);
+                                          int head_pitch, float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m,
+                                          float* stat_den, mlqem_stream_t stream);
 
 /* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  Stored form: edge_al / edge_gs: scratch
  * [(E+N)*H].  Recomputed form (out_eid == NULL): edge_al: scratch [4*N*H] (16-byte aligned), edge_gs unused (may be NULL); with drop_p > 0 it needs
@@ -639,7 +644,7 @@ int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const flo
                                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                         const int32_t* out_dst, const int32_t* out_eid, const int32_t* loops, int64_t N,
                                         int64_t E, int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                        int pair_key, float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
+                                        int pair_key, int head_pitch, float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
                                         mlqem_stream_t stream);
 
 /* Backward of mlqem_csr_softmax_aggregate_f32: gx (+)= d/dx, g_a[N] = d/d a_dst, g_c[N] = d/d c_src.

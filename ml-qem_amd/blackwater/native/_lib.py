@@ -128,9 +128,9 @@ SIGNATURES = {
     "mlqem_asap_coarsen_dense_max_k": (_I, []),
     "mlqem_asap_coarsen_dense_workspace_bytes": (_S, [_L, _L, _I]),
     "mlqem_asap_coarsen_dense": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
-    "mlqem_transformer_attention_train_f32": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _F, _U, _P, _I, _P, _P, _L, _P, _L, _P, _P, _P]),
+    "mlqem_transformer_attention_train_f32": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _F, _U, _P, _I, _P, _I, _P, _L, _P, _L, _P, _P, _P]),
     "mlqem_transformer_attention_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I,
-                                                 _F, _U, _P, _I, _P, _L, _P, _P, _P]),
+                                                 _F, _U, _P, _I, _I, _P, _L, _P, _P, _P]),
     "mlqem_csr_softmax_aggregate_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _L, _L, _I, _I,
                                                  _P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P]),
     "mlqem_csr_segment_max_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P]),

@@ -636,23 +636,39 @@ class _TransformerConv(Function):
     def forward(ctx, x, w, b, struct: GraphStructure, heads, channels, drop_p, seed):
         x = ops.rowmajor(x)        # a RowsOf (rows of the device-resident dataset) stays one: the projection reads through its row map
         w = w.contiguous()
-        qkvs = ops.linear(x, w, b)
         e = struct.edge_count()
         if not any(ctx.needs_input_grad) and drop_p == 0.0:  # inference: no statistics kept
-            return ops.transformer_attention(qkvs, struct.in_ptr, struct.in_src, struct.loops, heads, channels)
+            return ops.transformer_attention(ops.linear(x, w, b), struct.in_ptr, struct.in_src, struct.loops, heads, channels)
+        # Training: a head's channels at a pitch of 16 inside q / k / v / skip (the reference's 15: every gathered segment becomes an
+        # aligned 64-byte piece).  The projection writes that layout by itself when its weight and bias rows are padded the same way
+        # (zero rows: the pads of qkvs are zeros, the gradient of a pad row is exactly zero); w itself stays [4 H C, in].
+        cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and w.is_cuda) else 0
+        ctx.cp = cp
+        if cp:
+            groups = 4 * heads
+            wp = w.new_zeros((groups * cp, w.shape[1]))
+            wp.view(groups, cp, -1)[:, :channels].copy_(w.view(groups, channels, -1))
+            bp = None
+            if b is not None:
+                bp = b.new_zeros(groups * cp)
+                bp.view(groups, cp)[:, :channels].copy_(b.view(groups, channels))
+            w_used, b_used = wp, bp
+        else:
+            w_used, b_used = w, b
+        qkvs = ops.linear(x, w_used, b_used)
         # a structure without out_eid (ASAPooling's coarsened graphs: no parallel edges) takes the recomputed backward, whose dropout
         # draws are keyed by (destination, head, source)
         pair_key = struct.out_eid is None
         # the side table of a graph of short rows (circuit DAGs: the arena builds it with the batch); a coarsened graph's rows are long
         ell = struct.in_ell if struct.out_eid is not None else None
         out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
-                                                           channels, drop_p, seed, pair_key=pair_key, ell=ell)
+                                                           channels, drop_p, seed, pair_key=pair_key, ell=ell, head_pitch=cp)
         ctx.struct, ctx.cfg = struct, (e, heads, channels, drop_p, seed, pair_key)
         ctx.x_rows_of = isinstance(x, ops.RowsOf)
         if ctx.x_rows_of:
-            ctx.save_for_backward(x.base, x.rows, w, qkvs, attn, m, den)
+            ctx.save_for_backward(x.base, x.rows, w_used, qkvs, attn, m, den)
         else:
-            ctx.save_for_backward(x, w, qkvs, attn, m, den)
+            ctx.save_for_backward(x, w_used, qkvs, attn, m, den)
         return out
 
     @staticmethod
@@ -663,12 +679,22 @@ class _TransformerConv(Function):
         else:
             x, w, qkvs, attn, m, den = ctx.saved_tensors
         e, heads, channels, drop_p, seed, pair_key = ctx.cfg
-        gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key)
-        gx = ops.linear(gqkvs, w, transposed=True) if ctx.needs_input_grad[0] else None
+        cp = ctx.cp
+        gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key,
+                                              head_pitch=cp)
+        gx = ops.linear(gqkvs, w, transposed=True) if ctx.needs_input_grad[0] else None       # w: the (padded) weight the forward used
         gw = torch.empty_like(w)
         gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
         ops.linear_wgrad(gqkvs, x, gw, gb)
+        if cp:                     # the real rows of the padded gradients
+            groups = 4 * heads
+            gw = gw.view(groups, cp, -1)[:, :channels].reshape(groups * channels, -1)
+            gb = gb.view(groups, cp)[:, :channels].reshape(groups * channels)
         return gx, gw, gb, None, None, None, None, None
+
+
+# MLQEM_ATTN_PITCH=0: compact heads inside q / k / v / skip (the layout of rounds 1-3; A/B)
+_ATTN_PITCH = int(os.environ.get("MLQEM_ATTN_PITCH", "16"))
 
 
 def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):

@@ -1420,14 +1420,16 @@ def asap_dense_max_k() -> int:
 
 
 # ------------------------------------------------------------------------------------------ Family B backward
-def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False, ell=None):
+def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False, ell=None,
+                                head_pitch=0):
     """(out, attn_out, m, den).  ``ell``: the structure's in-edge side table (``GraphStructure.in_ell``) where most rows have at
     most two in-edges (circuit DAGs): those rows skip the ptr -> idx round trip.  ``attn_out`` is for the backward only (rows of at
     most four entries are not written)."""
     n, hc = qkvs.shape[0], heads * channels
     _ell(ell, n)
-    if qkvs.shape[1] != 4 * hc:
-        raise ValueError("qkvs must be [N, 4*H*C]")
+    cp = head_pitch or channels      # ``head_pitch``: channel pitch of a head inside qkvs' parts (pads zero; out stays compact)
+    if qkvs.shape[1] != 4 * heads * cp:
+        raise ValueError("qkvs must be [N, 4*H*head_pitch]")
     _vec(in_ptr, "in_ptr", n + 1, torch.int32)
     _vec(loops, "loops", n, torch.int32)
     dev = qkvs.device
@@ -1436,19 +1438,19 @@ def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, c
     den = torch.empty_like(m)
     code = _lib.load().mlqem_transformer_attention_train_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
-        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(ell), _p(out), _mat(out, "out"),
+        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(ell), int(head_pitch), _p(out), _mat(out, "out"),
         _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
     _lib.check(code, "mlqem_transformer_attention_train_f32")
     return out, attn, m, den
 
 
-def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False):
+def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False, head_pitch=0):
     """Gradient of [query | key | value | skip].  A structure without ``out_eid`` (ASAPooling's coarsened graphs) takes the
     recomputed form: no per-edge buffers, the source side recomputes its weights from m / den / g . attn_out per (row, head)."""
-    n, hc = qkvs.shape[0], heads * channels
+    n = qkvs.shape[0]
     g = rowmajor(g)
     dev = qkvs.device
-    gqkvs = padded_empty(n, 4 * hc, dev)
+    gqkvs = padded_empty(n, 4 * heads * (head_pitch or channels), dev)      # the layout of qkvs (``head_pitch``: pads come out zero)
     if s.out_eid is None:          # the recomputed form: one 16-byte record {m, 1 / den, g . attn_out} per (row, head)
         al, gs = torch.empty(4 * max(n, 1) * heads, dtype=torch.float32, device=dev), None
     else:
@@ -1457,8 +1459,8 @@ def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channe
     code = _lib.load().mlqem_transformer_attention_bwd_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr),
         _p(s.in_src), _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(s.loops), n, num_edges, heads, channels,
-        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(gqkvs),
-        _mat(gqkvs, "gqkvs"), _p(al), _p(gs),
+        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, int(head_pitch),
+        _p(gqkvs), _mat(gqkvs, "gqkvs"), _p(al), _p(gs),
         _stream())
     _lib.check(code, "mlqem_transformer_attention_bwd_f32")
     return gqkvs

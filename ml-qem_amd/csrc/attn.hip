@@ -211,7 +211,7 @@ extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, co
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out) return MLQEM_ERR_BAD_ARG;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
-  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, 0, H, C, 0.f, 0, nullptr, out, ldo, nullptr, 0, nullptr, nullptr, 0, nullptr};
+  const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, 0, H, C, 0.f, 0, nullptr, out, ldo, nullptr, 0, nullptr, nullptr, 0, nullptr, 0};
   if (attn_q4_enabled()) {
     const int lph = C > 16 ? 8 : 4;
     const dim3 grid4((unsigned)ceil_div(N * H * lph, kBlock));

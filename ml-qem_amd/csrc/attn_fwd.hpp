@@ -45,6 +45,10 @@ struct AttnFwdArgs {
   const int32_t* ell;                       // optional [N,2] side table (mlqem_ell_from_csr): the first two in-edges of every row, so
                                             // that a row of at most two (a circuit DAG's, but for barriers) goes ell -> key / value
                                             // rows instead of ptr -> idx -> key / value rows (four-channels-per-lane kernels only)
+  int CP;                                   // channel pitch of a head inside the parts of qkvs (0 = C: compact).  16 for the 15
+                                            // channels of the reference's models: every key / value / query segment is then an aligned
+                                            // 16-byte-per-lane, 64-byte-per-head piece (pads are zeros the projection's padded weights
+                                            // produce); out / attn_out stay compact [N, H C] (four-channels-per-lane kernels only)
 };
 
 // The key of an attention weight's dropout draw.  By position (the default): (in-CSR position, head), self entries at E + row.

@@ -88,7 +88,10 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
   const int row = (int)(t / H);
   const int h = (int)(t - (int64_t)row * H);
   const int nv = min(4, max(0, C - 4 * lq));            // real channels of this lane
-  const int off = h * C + 4 * lq;                       // the lane's first channel inside a part
+  const int off = h * C + 4 * lq;                       // the lane's first channel inside a compact [H C] row (out, attn_out)
+  const int CP = a.CP > 0 ? a.CP : C, HP = H * CP;      // head pitch and part stride inside a qkvs row
+  const int offp = h * CP + 4 * lq;                     // the lane's first channel inside a part of qkvs
+  const bool roomy = CP - 4 * lq >= 4;                  // the lane's 16 bytes lie inside its head's slot (pads are zeros)
   const float scale = 1.0f / sqrtf((float)C);
   const float keep = 1.f / (1.f - a.drop_p);
   const uint64_t seed = a.seed + ((TRAIN && a.seed_counter) ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
@@ -97,8 +100,8 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
   const int32_t* __restrict__ idx = a.idx;
 
   const float* __restrict__ ri = qkvs + (int64_t)row * ld;
-  const f4u q = load_channels(ri + off, nv, true);                            // runs over into the key part at most
-  const f4u skip = load_channels(ri + 3 * HC + off, nv, 3 * HC + off + 4 <= 4 * HC);
+  const f4u q = load_channels(ri + offp, nv, true);                           // runs over into the key part at most
+  const f4u skip = load_channels(ri + 3 * HP + offp, nv, roomy || 3 * HP + offp + 4 <= 4 * HP);
   // the row's in-edges: from the ELL side table when the row has at most two (one dependent round trip less), else from the CSR arrays
   int s0 = -1, s1 = -1;
   bool fast = false;
@@ -125,9 +128,9 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u < k && nv > 0) {                             // uniform over the (row, head)'s lanes but for the channel-less ones
-        const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HC + off;
+        const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HP + offp;
         kk[u] = *reinterpret_cast<const f4u*>(kj);       // inside the row: a key segment runs over into the value part at most,
-        vv[u] = *reinterpret_cast<const f4u*>(kj + HC);  // a value segment into the skip part
+        vv[u] = *reinterpret_cast<const f4u*>(kj + HP);  // a value segment into the skip part
       } else {
         kk[u] = f4u{0.f, 0.f, 0.f, 0.f};
         vv[u] = f4u{0.f, 0.f, 0.f, 0.f};

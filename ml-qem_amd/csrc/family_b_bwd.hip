@@ -32,6 +32,7 @@ struct AttnBwdArgs {
   int64_t N, E; int H, C; float drop_p; uint64_t seed; const uint64_t* seed_counter;
   float* gqkvs; int64_t ldq; float* edge_al; float* edge_gs;
   int pair_key;                   // as the forward's (attn_fwd.hpp)
+  int CP;                         // as the forward's: channel pitch of a head inside the parts of qkvs AND gqkvs (0 = C)
 };
 // oeid == nullptr selects the RECOMPUTING source side (transformer_attn_bwd_src_rc_q4_kernel): the destination side then files
 // delta[N, H] = g . attn_out per (row, head) in edge_al (its first N H floats) and writes nothing per edge.
@@ -267,6 +268,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int h = (int)(t - (int64_t)row * H);
   const int nv = min(4, max(0, C - 4 * lq));
   const int off = h * C + 4 * lq;
+  const int CP = a.CP > 0 ? a.CP : C, HP = H * CP, offp = h * CP + 4 * lq;      // head pitch / part stride / lane offset inside qkvs, gqkvs
+  const int nvs = min(4, max(0, CP - 4 * lq));           // floats of the lane's slot: what it stores (pads come out zero)
   const float scale = 1.0f / sqrtf((float)C);
   const float keep = 1.f / (1.f - a.drop_p);
   const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);   // as the forward
@@ -276,7 +279,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   float* __restrict__ edge_al = a.edge_al;
   float* __restrict__ edge_gs = a.edge_gs;
   const bool recompute = a.oeid == nullptr;              // the source side keeps no per-edge values (see AttnBwdArgs)
-  const f4u q = load_channels(qkvs + (int64_t)row * ld + off, nv, true);
+  const f4u q = load_channels(qkvs + (int64_t)row * ld + offp, nv, true);
   const f4u gi = load_channels(a.g + (int64_t)row * a.ldg + off, nv, off + 4 <= a.ldg);
   const float m = a.stat_m[(int64_t)row * H + h];
   const float inv_den = 1.0f / a.stat_den[(int64_t)row * H + h];     // one division per row, as in the forward
@@ -300,9 +303,9 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u < k && nv > 0) {
-        const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HC + off;
+        const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HP + offp;
         kk[u] = *reinterpret_cast<const f4u*>(kj);
-        vv[u] = *reinterpret_cast<const f4u*>(kj + HC);
+        vv[u] = *reinterpret_cast<const f4u*>(kj + HP);
       } else {
         kk[u] = f4u{0.f, 0.f, 0.f, 0.f};
         vv[u] = f4u{0.f, 0.f, 0.f, 0.f};
@@ -338,8 +341,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     edge_gs[(a.E + row) * H + h] = 0.f;
   }
   float* __restrict__ go = a.gqkvs + (int64_t)row * a.ldq;
-  store_channels(go + off, gq, nv);
-  store_channels(go + 3 * HC + off, gi, nv);
+  store_channels(go + offp, gq, nvs);
+  store_channels(go + 3 * HP + offp, gi, nvs);
 }
 
 // Source side WITHOUT per-edge buffers and without out_eid: every weight is recomputed from what the forward kept per (row, head)
@@ -357,6 +360,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int h = (int)(t - (int64_t)row * H);
   const int nv = min(4, max(0, C - 4 * lq));
   const int off = h * C + 4 * lq;
+  const int CP = a.CP > 0 ? a.CP : C, HP = H * CP, offp = h * CP + 4 * lq;      // head pitch / part stride / lane offset inside qkvs, gqkvs
+  const int nvs = min(4, max(0, CP - 4 * lq));           // floats of the lane's slot: what it stores (pads come out zero)
   const float scale = 1.0f / sqrtf((float)C);
   const float keep = 1.f / (1.f - a.drop_p);
   const uint64_t seed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);   // as the forward
@@ -366,8 +371,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int64_t ld = a.ld, ldg = a.ldg;
   const bool g_fits = off + 4 <= ldg;
   const float* __restrict__ rj = qkvs + (int64_t)row * ld;
-  const f4u kown = load_channels(rj + HC + off, nv, true);          // runs over into the value part at most
-  const f4u vown = load_channels(rj + 2 * HC + off, nv, true);      // ... into the skip part
+  const f4u kown = load_channels(rj + HP + offp, nv, true);         // runs over into the value part at most
+  const f4u vown = load_channels(rj + 2 * HP + offp, nv, true);     // ... into the skip part
   const int n_self = a.loops ? a.loops[row] : 0;
   f4u gk = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
   const int obeg = a.optr[row];
@@ -387,7 +392,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u < k && nv > 0) {
-        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + off);
+        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + offp);
         ga[u] = g_fits ? *reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off) : load_channels(g + (int64_t)iu[u] * ldg + off, nv, false);
         if (nv < 4) qa[u].w = 0.f;                       // the lane's fourth component belongs to the next head / part
         if (nv < 3) qa[u].z = 0.f;
@@ -418,8 +423,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     }
   }
   float* __restrict__ go = a.gqkvs + (int64_t)row * a.ldq;
-  store_channels(go + HC + off, gk, nv);
-  store_channels(go + 2 * HC + off, gv, nv);
+  store_channels(go + HP + offp, gk, nvs);
+  store_channels(go + 2 * HP + offp, gv, nvs);
 }
 
 template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_q4_kernel(const AttnBwdArgs a) {
@@ -431,6 +436,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int h = (int)(t - (int64_t)row * H);
   const int nv = min(4, max(0, C - 4 * lq));
   const int off = h * C + 4 * lq;
+  const int CP = a.CP > 0 ? a.CP : C, HP = H * CP, offp = h * CP + 4 * lq;      // head pitch / part stride / lane offset inside qkvs, gqkvs
+  const int nvs = min(4, max(0, CP - 4 * lq));           // floats of the lane's slot: what it stores (pads come out zero)
   const float* __restrict__ qkvs = a.qkvs;
   const float* __restrict__ g = a.g;
   const float* __restrict__ edge_al = a.edge_al;
@@ -457,8 +464,13 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u < k && nv > 0) {
-        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + off);       // a query segment runs over into the key part at most
+        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + offp);      // a query segment runs over into the key part at most
         ga[u] = g_fits ? *reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off) : load_channels(g + (int64_t)iu[u] * ldg + off, nv, false);
+        if (nvs > nv && g_fits) {                        // a padded slot is stored whole: its pads must come out zero, not the next head's
+          if (nv < 4) ga[u].w = 0.f;
+          if (nv < 3) ga[u].z = 0.f;
+          if (nv < 2) ga[u].y = 0.f;
+        }
       } else {
         qa[u] = f4u{0.f, 0.f, 0.f, 0.f};
         ga[u] = f4u{0.f, 0.f, 0.f, 0.f};
@@ -471,8 +483,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     }
   }
   float* __restrict__ go = a.gqkvs + (int64_t)row * a.ldq;
-  store_channels(go + HC + off, gk, nv);
-  store_channels(go + 2 * HC + off, gv, nv);
+  store_channels(go + HP + offp, gk, nvs);
+  store_channels(go + 2 * HP + offp, gv, nvs);
 }
 
 // --------------------------------------------------------------------------------------------- ASAPooling
@@ -1123,11 +1135,14 @@ using namespace mlqem;
 extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
                                                      const int32_t* in_src, const int32_t* loops, int64_t N, int64_t E,
                                                      int H, int C, float drop_p, uint64_t seed,
-                                                     const uint64_t* seed_counter, int pair_key, const int32_t* in_ell, float* out, int64_t ldo,
-                                                     float* attn_out, int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream) {
+                                                     const uint64_t* seed_counter, int pair_key, const int32_t* in_ell, int head_pitch,
+                                                     float* out, int64_t ldo, float* attn_out, int64_t lda, float* stat_m, float* stat_den,
+                                                     mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
+  const int CP = head_pitch > 0 ? head_pitch : C;
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || CP < C || ld < 4 * H * CP || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
     return MLQEM_ERR_BAD_ARG;
+  if (CP != C && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;         // the one-channel-per-lane forms read compact parts only
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
   if (!qkvs || !in_ptr || !out || !attn_out || !stat_m || !stat_den) return MLQEM_ERR_BAD_ARG;
@@ -1135,7 +1150,7 @@ extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t 
   if (pair_key && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;      // the one-channel-per-lane forms key by position only
   if (in_ell && !aligned_to(in_ell, 8)) return MLQEM_ERR_BAD_ARG;
   const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den,
-                      pair_key ? 1 : 0, in_ell};
+                      pair_key ? 1 : 0, in_ell, CP};
   if (attn_q4_enabled()) {
     if (C > 16) hipLaunchKernelGGL(transformer_attn_train_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
     else hipLaunchKernelGGL(transformer_attn_train_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
@@ -1150,11 +1165,13 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
                                                    const int32_t* out_ptr, const int32_t* out_dst,
                                                    const int32_t* out_eid, const int32_t* loops, int64_t N, int64_t E,
                                                    int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                                   int pair_key, float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
-                                                   mlqem_stream_t stream) {
+                                                   int pair_key, int head_pitch, float* gqkvs, int64_t ldq, float* edge_al,
+                                                   float* edge_gs, mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || E < 0 || H <= 0 || C <= 0 || ld < 4 * H * C || ldq < 4 * H * C || ldg < H * C || lda < H * C)
+  const int CP = head_pitch > 0 ? head_pitch : C;
+  if (N < 0 || E < 0 || H <= 0 || C <= 0 || CP < C || ld < 4 * H * CP || ldq < 4 * H * CP || ldg < H * C || lda < H * C)
     return MLQEM_ERR_BAD_ARG;
+  if (CP != C && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;
   if (C > kAttnMaxC) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
   const bool recompute = out_eid == nullptr;             // no out_eid: the source side recomputes its weights (edge_al: [N H] floats)
@@ -1166,7 +1183,7 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if ((recompute || pair_key) && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
   const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
-                      N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0};
+                      N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0, CP};
   if (recompute) {
     if (C > 16) {
       hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);

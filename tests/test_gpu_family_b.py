@@ -685,6 +685,43 @@ def test_attention_kernels_against_a_dense_reference(heads, ch):
     assert (gq.cpu().double() - x.grad).abs().max().item() < 5e-5 * gscale
 
 
+@pytest.mark.parametrize("heads,ch,linked", [(3, 15, True), (2, 15, False), (2, 13, True)])
+def test_attention_with_a_head_pitch_of_16_equals_the_compact_layout(heads, ch, linked):
+    """``head_pitch = 16``: q / k / v / skip as [N, 4 H 16] with zero pads (what a projection with padded weight rows writes) -- the same
+    output bit for bit, the same gradient in the real channels, zeros in the pads; stored and recomputed backward forms, with dropout."""
+    from blackwater.native import ops
+    from blackwater.native.structure import GraphStructure
+
+    rng = np.random.RandomState(heads * 10 + ch)
+    n, hc, cp = 700, heads * ch, 16
+    pairs = set()
+    for i in range(n):
+        for j in rng.choice(n, size=rng.randint(0, 40 if i % 7 == 0 else 3), replace=False):
+            if i != j:
+                pairs.add((int(j), i))
+    ei = np.array(sorted(pairs)).T
+    s = GraphStructure.from_edge_index(torch.from_numpy(ei).to(DEV), n)
+    if not linked:
+        s.out_eid = None
+    pk = not linked
+    g = torch.Generator().manual_seed(ch)
+    qkvs_h, gout_h = torch.randn(n, 4 * hc, generator=g), torch.randn(n, hc, generator=g)
+    qkvs = ops.padded_copy(qkvs_h.to(DEV))
+    qp_h = torch.zeros(n, 4 * heads, cp)
+    qp_h[:, :, :ch] = qkvs_h.view(n, 4 * heads, ch)
+    qkvs_p = ops.padded_copy(qp_h.view(n, 4 * heads * cp).to(DEV))
+    e = s.edge_count()
+    for drop_p in (0.0, 0.2):
+        a = ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, drop_p, 7, pair_key=pk, ell=s.in_ell)
+        b = ops.transformer_attention_train(qkvs_p, s.in_ptr, s.in_src, s.loops, e, heads, ch, drop_p, 7, pair_key=pk, ell=s.in_ell, head_pitch=cp)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        ga = ops.transformer_attention_bwd(qkvs, gout_h.to(DEV), a[1], a[2], a[3], s, e, heads, ch, drop_p, 7, pair_key=pk)
+        gb = ops.transformer_attention_bwd(qkvs_p, gout_h.to(DEV), b[1], b[2], b[3], s, e, heads, ch, drop_p, 7, pair_key=pk, head_pitch=cp)
+        gb3 = gb.view(n, 4 * heads, cp)
+        assert torch.equal(gb3[:, :, :ch].reshape(n, 4 * hc), ga)
+        assert (gb3[:, :, ch:] == 0).all()
+
+
 @pytest.mark.parametrize("heads,ch", [(2, 15), (3, 15), (3, 25), (1, 16), (2, 17), (4, 3)])
 def test_recomputed_attention_backward_equals_the_stored_form(heads, ch):
     """A structure without out_eid (ASAPooling's coarsened graphs since round 4) takes the RECOMPUTED source side of
