@@ -555,11 +555,21 @@ def attention_roofline(s, dev, what, heads=3, ch=15):
     statistics: ``frac_r02_model`` keeps that figure for comparison.)"""
     from blackwater.native import ops
 
+    import blackwater.native.functional as Fn
+
     n, e = s.num_nodes, s.num_edges
     hc = heads * ch
-    qk = [ops.padded_empty(n, 4 * hc, dev).normal_() for _ in range(4)]
-    ell = s.in_ell                                   # as the model's step hands it over (functional._TransformerConv)
-    run = lambda k: ops.transformer_attention_train(qk[k % 4], s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 1234 + k, ell=ell)
+    # the layout the model's step hands over (functional._TransformerConv): a head's channels at a pitch of 16 floats, pads zero
+    cp = Fn._ATTN_PITCH if (Fn._ATTN_PITCH > ch and Fn._ATTN_PITCH - ch < 4) else 0
+    pitch = cp or ch
+    qk = []
+    for _ in range(4):
+        t = ops.padded_empty(n, 4 * heads * pitch, dev).normal_()
+        if cp:
+            t.view(n, 4 * heads, pitch)[:, :, ch:] = 0.0
+        qk.append(t)
+    ell = s.in_ell
+    run = lambda k: ops.transformer_attention_train(qk[k % 4], s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 1234 + k, ell=ell, head_pitch=cp)
     for k in range(4):
         run(k)
     stream = torch.cuda.current_stream()
@@ -575,8 +585,9 @@ def attention_roofline(s, dev, what, heads=3, ch=15):
     # attn_out is written for rows of more than four entries only (round 4: the backward forms g . attn_out of a shorter row itself)
     deg = (s.in_ptr[1:n + 1] - s.in_ptr[:n]).long() + (s.loops[:n] > 0).long()
     n_long = int((deg > 4).sum().item())
-    by = 4 * (n + 1) + 8 * n + 4 * e1 + 4 * hc * (3 * n + n_long + 2 * e1) + 8 * n * heads
-    return {"bound": "hbm", "kernel": f"transformer_attn_train_q4_kernel<4> (H={heads}, C={ch}, attention dropout 0.1)", "workload": what,
+    hp = heads * pitch                               # columns of a part as stored (pads included: they are moved)
+    by = 4 * (n + 1) + 8 * n + 4 * e1 + 4 * hp * (2 * n + 2 * e1) + 4 * hc * (n + n_long) + 8 * n * heads
+    return {"bound": "hbm", "kernel": f"transformer_attn_train_q4_kernel<4> (H={heads}, C={ch}, head pitch {pitch}, attention dropout 0.1)", "workload": what,
             "achieved": round(by / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / sec / 1e9 / 8000.0, 4),
             "frac_r02_model": round(by_r02 / sec / 1e9 / 8000.0, 4),
             "traffic": None, "bytes_per_launch": int(by), "us_per_launch": round(sec * 1e6, 2), "nodes": n, "edges_with_loops": e1,
