@@ -213,6 +213,9 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
 // multiply-shift instead of a 64-bit division per item, and the tile's graph comes from the 16-byte record the forward launch left
 // next to the bits (r03: 178 us for 0.59 GB, bound by its request rate: five memory instructions per 16 bytes written).
 // A tile inside ONE graph (all but one in 65 at 100 qubits) reads the graph's two gradient rows at uniform addresses as well.
+#ifndef MLQEM_POOL_BWD_PLAIN
+#define MLQEM_POOL_BWD_PLAIN 0     // 1: plain instead of non-temporal stores (A/B builds)
+#endif
 template <int CVT>
 __global__ __launch_bounds__(kBlock) void pool_bwd_tiles_kernel(const float* __restrict__ g0, int64_t ldg0, const float* __restrict__ g1,
                                                                 int64_t ldg1, const float* __restrict__ wts,
@@ -261,7 +264,11 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_tiles_kernel(const float* __r
       const float u = fmaf(w, a1[v], a0[v]) * inv;
       o[v] = ((w4[v] >> lane) & 1ull) ? u * gate_scale : 0.f;
     }
+#if MLQEM_POOL_BWD_PLAIN
+    vstore<VEC>(gx + r * ldgx + ch, o);
+#else
     vstore_nt<VEC>(gx + r * ldgx + ch, o);
+#endif
   }
 }
 
