@@ -643,6 +643,8 @@ class _TransformerConv(Function):
         # aligned 64-byte piece).  The projection writes that layout by itself when its weight and bias rows are padded the same way
         # (zero rows: the pads of qkvs are zeros, the gradient of a pad row is exactly zero); w itself stays [4 H C, in].
         cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and w.is_cuda) else 0
+        if cp and struct.out_eid is not None and not _ATTN_PITCH_LINKED:       # (A/B: the pitch on coarsened graphs only)
+            cp = 0
         ctx.cp = cp
         if cp:
             groups = 4 * heads
@@ -695,6 +697,8 @@ class _TransformerConv(Function):
 
 # MLQEM_ATTN_PITCH=0: compact heads inside q / k / v / skip (the layout of rounds 1-3; A/B)
 _ATTN_PITCH = int(os.environ.get("MLQEM_ATTN_PITCH", "16"))
+# MLQEM_ATTN_PITCH_LINKED=0: graphs that come with edge links (the circuit DAGs: stored source-side backward) keep compact heads
+_ATTN_PITCH_LINKED = os.environ.get("MLQEM_ATTN_PITCH_LINKED", "1") != "0"
 
 
 def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
