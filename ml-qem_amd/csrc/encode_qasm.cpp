@@ -762,12 +762,38 @@ ScratchPool& scratch_pool() { static ScratchPool pool; return pool; }
 // Worker threads when the caller names none: the host's hardware threads up to 64 (a text scan is 60 ns per statement per thread,
 // and a 1024-circuit run() of 100-qubit circuits has 11 M statements: 16 threads took 42 ms of an 88 ms run()), or
 // MLQEM_ENCODE_THREADS (1..256) when the deployment knows better.
+// CPUs this process may use at a time by its control group's bandwidth limit (cgroup v2 cpu.max, v1 cfs quota / period), 0 = no
+// limit found.  A container that shows 256 cores and grants 16 of them THROTTLES a burst of 64 threads: on such a box a run()'s scan
+// took 29 ms and the next one 70 ms, alternately (nr_throttled in cpu.stat counted every second call); at 24 threads every call takes
+// 35-40 ms -- a better sustained rate, and the same one every time.
+int cgroup_cpu_limit() {
+  auto ratio = [](long long quota, long long period) { return (quota > 0 && period > 0) ? (int)((quota + period - 1) / period) : 0; };
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    long long period = 0;
+    const int got = std::fscanf(f, "%31s %lld", q, &period);
+    std::fclose(f);
+    if (got == 2 && std::strcmp(q, "max") != 0) return ratio(std::atoll(q), period);
+    if (got >= 1) return 0;
+  }
+  long long quota = 0, period = 0;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(f, "%lld", &quota) != 1) quota = 0; std::fclose(f); }
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(f, "%lld", &period) != 1) period = 0; std::fclose(f); }
+  return ratio(quota, period);
+}
+
 int default_threads() {
   if (const char* env = std::getenv("MLQEM_ENCODE_THREADS")) {
     const long v = std::strtol(env, nullptr, 10);
     if (v >= 1 && v <= 256) return (int)v;
   }
-  return (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency()));
+  static const int chosen = [] {
+    int n = (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency()));
+    const int limit = cgroup_cpu_limit();
+    if (limit > 0) n = std::min(n, std::max(2, limit + limit / 2));      // one and a half threads per granted CPU (measured: 16 / 24 / 32 / 64)
+    return n;
+  }();
+  return chosen;
 }
 
 // A process-wide pool of worker threads for the batch entry points.  A run() of a VQE loop calls them thousands of times
