@@ -1332,7 +1332,13 @@ static int layer_colstats(int mode, const void* y, const void* g, const float* g
   if (mode == 0 ? !beta : (!scale || !shift || !mean || !invstd || (!g && !g32))) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes()) return MLQEM_ERR_WORKSPACE;
   hipStream_t s = as_stream(stream);
-  const int nb = colsum_blocks(N);
+  int nb = colsum_blocks(N);
+  {   // a fixed partition of the rows over the workgroups: a whole number of resident rounds (the backward sums fit five workgroups
+      // per CU: 2048 of them ran as one round and a second one at 60 % of the occupancy)
+    static const int r0 = layer_resident(layer_colsum_kernel<0, ST>, 256, 0), r1 = layer_resident(layer_colsum_kernel<1, ST>, 256, 0);
+    const int res = mode == 0 ? r0 : r1;
+    if (nb > res) nb = nb / res * res;
+  }
   ActArgs a{};
   a.y = y; a.g = g; a.g32 = g32; a.ldg32 = ldg32;
   a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.partial = static_cast<float*>(workspace);
