@@ -637,7 +637,14 @@ class _TransformerConv(Function):
         x = ops.rowmajor(x)        # a RowsOf (rows of the device-resident dataset) stays one: the projection reads through its row map
         w = w.contiguous()
         e = struct.edge_count()
+        # a structure whose rows share their sources (ASAPooling's coarsened graphs of large circuits) takes the tiled kernels
+        tiled = (_TILES and struct.tiled and w.is_cuda and struct.out_eid is None
+                 and ops.tile_attention_fits(heads, channels, 16 if 13 <= channels <= 16 else 0))
         if not any(ctx.needs_input_grad) and drop_p == 0.0:  # inference: no statistics kept
+            if tiled:
+                wp, bp = _pad_heads(w, b, 4 * heads, channels, 16)
+                return ops.tile_attention(ops.linear(x, wp, bp), struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
+                                          struct.tile_plan("in"), head_pitch=16, train=False)
             return ops.transformer_attention(ops.linear(x, w, b), struct.in_ptr, struct.in_src, struct.loops, heads, channels)
         # Training: a head's channels at a pitch of 16 inside q / k / v / skip (the reference's 15: every gathered segment becomes an
         # aligned 64-byte piece).  The projection writes that layout by itself when its weight and bias rows are padded the same way
@@ -645,26 +652,23 @@ class _TransformerConv(Function):
         cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and w.is_cuda) else 0
         if cp and struct.out_eid is not None and not _ATTN_PITCH_LINKED:       # (A/B: the pitch on coarsened graphs only)
             cp = 0
+        if tiled:
+            cp = 16 if channels < 16 else 0
         ctx.cp = cp
-        if cp:
-            groups = 4 * heads
-            wp = w.new_zeros((groups * cp, w.shape[1]))
-            wp.view(groups, cp, -1)[:, :channels].copy_(w.view(groups, channels, -1))
-            bp = None
-            if b is not None:
-                bp = b.new_zeros(groups * cp)
-                bp.view(groups, cp)[:, :channels].copy_(b.view(groups, channels))
-            w_used, b_used = wp, bp
-        else:
-            w_used, b_used = w, b
+        ctx.tiled = tiled
+        w_used, b_used = _pad_heads(w, b, 4 * heads, channels, cp) if cp else (w, b)
         qkvs = ops.linear(x, w_used, b_used)
         # a structure without out_eid (ASAPooling's coarsened graphs: no parallel edges) takes the recomputed backward, whose dropout
         # draws are keyed by (destination, head, source)
         pair_key = struct.out_eid is None
         # the side table of a graph of short rows (circuit DAGs: the arena builds it with the batch); a coarsened graph's rows are long
         ell = struct.in_ell if struct.out_eid is not None else None
-        out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
-                                                           channels, drop_p, seed, pair_key=pair_key, ell=ell, head_pitch=cp)
+        if tiled:
+            out, attn, m, den = ops.tile_attention(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
+                                                   struct.tile_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp or channels)
+        else:
+            out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
+                                                               channels, drop_p, seed, pair_key=pair_key, ell=ell, head_pitch=cp)
         ctx.struct, ctx.cfg = struct, (e, heads, channels, drop_p, seed, pair_key)
         ctx.x_rows_of = isinstance(x, ops.RowsOf)
         if ctx.x_rows_of:
@@ -682,8 +686,13 @@ class _TransformerConv(Function):
             x, w, qkvs, attn, m, den = ctx.saved_tensors
         e, heads, channels, drop_p, seed, pair_key = ctx.cfg
         cp = ctx.cp
-        gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key,
-                                              head_pitch=cp)
+        if ctx.tiled:
+            st = ctx.struct
+            gqkvs = ops.tile_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, st.tile_plan("in"), st.tile_plan("out"),
+                                           drop_p=drop_p, seed=seed, head_pitch=cp or channels)
+        else:
+            gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key,
+                                                  head_pitch=cp)
         gx = ops.linear(gqkvs, w, transposed=True) if ctx.needs_input_grad[0] else None       # w: the (padded) weight the forward used
         gw = torch.empty_like(w)
         gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
@@ -695,6 +704,22 @@ class _TransformerConv(Function):
         return gx, gw, gb, None, None, None, None, None
 
 
+def _pad_heads(w, b, groups, channels, cp):
+    """Weight and bias of a projection whose ``groups`` blocks of ``channels`` rows each are spread to a pitch of ``cp`` rows (zero
+    rows between: the projection then writes its output at that pitch, pads zero; the gradient of a pad row is exactly zero)."""
+    if cp <= channels:
+        return w, b
+    wp = w.new_zeros((groups * cp, w.shape[1]))
+    wp.view(groups, cp, -1)[:, :channels].copy_(w.view(groups, channels, -1))
+    bp = None
+    if b is not None:
+        bp = b.new_zeros(groups * cp)
+        bp.view(groups, cp)[:, :channels].copy_(b.view(groups, channels))
+    return wp, bp
+
+
+# MLQEM_TILES=0: the per-edge kernels on ASAPooling's coarsened graphs too (the round-4 path; A/B and the parity tests' second arm)
+_TILES = os.environ.get("MLQEM_TILES", "1") != "0"
 # MLQEM_ATTN_PITCH=0: compact heads inside q / k / v / skip (the layout of rounds 1-3; A/B)
 _ATTN_PITCH = int(os.environ.get("MLQEM_ATTN_PITCH", "16"))
 # MLQEM_ATTN_PITCH_LINKED=0: graphs that come with edge links (the circuit DAGs: stored source-side backward) keep compact heads
@@ -769,9 +794,27 @@ class _ASAPool(Function):
         s = struct
         x = ops.rowmajor(x)
         d, n = x.shape[1], s.num_nodes
-        xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
         att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
-        if _ASAP_COMPOSE:
+        w3 = torch.cat([l1_w, l2_w, l3_w], 0).contiguous()
+        b3 = torch.cat([l1_b, l1_b * 0.0, l3_b], 0)      # lin2 has no bias (a multiply, not a memset: the step may be captured)
+        # the input graph's rows share their sources (it is itself a coarsened graph): segment max, composed score, softmax-sum and
+        # LEConv's projections in ONE tiled pass (csrc/tile_pool.hip)
+        tiled = _TILES and _ASAP_COMPOSE and s.tiled and x.is_cuda and ops.tile_pool_fits(d)
+        ctx.tiled = tiled
+        stat = None
+        if tiled:
+            w_comp = (att_q.t() * lin_w).sum(0, keepdim=True)
+            b_comp = (att_q[0] * lin_b).sum().reshape(1) + att_b
+            xq = a_dst = None
+            c_src = ops.linear(x, att_x)[:, 0].contiguous()
+            x_new, xq_raw, stat, pqr = ops.tile_asap_scores(x, s.in_ptr, s.in_src, c_src, w_comp[0].contiguous(), b_comp, w3, b3, slope,
+                                                            s.tile_plan("in"))
+            fitness = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
+        else:
+            xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
+        if tiled:
+            pass
+        elif _ASAP_COMPOSE:
             # ASAPooling's query x_q = lin(segmax) feeds ONLY the one-wide score a_i = att_q . x_q[i] + att_b (SURVEY appendix
             # B.2 steps 2-3): a_i = (att_q W) . segmax[i] + (att_q . b + att_b) -- one row dot of the segment max against a composed
             # 45-vector.  x_q [N, D] is never formed (a [N,D]x[D,D] GEMM forward; a data GEMM and a [D,D] weight-gradient pass
@@ -785,11 +828,10 @@ class _ASAPool(Function):
             w_comp = None
             xq = ops.linear(xq_raw, lin_w.contiguous(), lin_b)
             a_dst = ops.linear(xq, att_q, att_b)[:, 0].contiguous()
-        c_src = ops.linear(x, att_x)[:, 0].contiguous()
-        x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
-        w3 = torch.cat([l1_w, l2_w, l3_w], 0).contiguous()
-        b3 = torch.cat([l1_b, l1_b * 0.0, l3_b], 0)      # lin2 has no bias (a multiply, not a memset: the step may be captured)
-        fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
+        if not tiled:
+            c_src = ops.linear(x, att_x)[:, 0].contiguous()
+            x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
+            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
         # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk (float32 tensor times a python scalar)
         sizes = np.asarray(s.graph_sizes, dtype=np.int64)
         keep = np.ceil(sizes.astype(np.float32) * np.float32(ratio)).astype(np.int64)
@@ -837,10 +879,19 @@ class _ASAPool(Function):
             csr7, slot = build()
             holder["structure"] = GraphStructure(k_total, csr7[0], csr7[1], csr7[2], csr7[3], csr7[4], new_ptr, s.num_graphs,
                                                  num_edges=csr7[5], graph_sizes=keep, out_eid=csr7[6])
+        if (_TILES and use_rows and use_lists and not link and len(keep) > 0 and ops.asap_dense_max_k() < int(keep.max())):
+            # large graphs (the list coarsening's): clusters whose centres are close in program order share their neighbours, so
+            # the layers that read this graph walk it in tiles of rows ordered by their centres' node index
+            def tile_spec(slot=slot, gptr=s.graph_ptr, b=s.num_graphs):
+                # a tile may straddle a graph boundary: its entries' ids then span (parts of) two graphs' ranges
+                return ops.tile_order_by_position(slot, gptr, new_ptr, b, k_total), 2 * int(keep.max()) + ops.TILE_ROWS
+
+            holder["structure"].set_tile_spec(tile_spec)
         holder["perm"] = perm
         ctx.struct, ctx.slope, ctx.d = s, slope, d
         ctx.composed = xq is None
-        ctx.save_for_backward(x, xq_raw, w_comp if xq is None else xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b)
+        ctx.save_for_backward(x, xq_raw, w_comp if xq is None else xq, stat if tiled else a_dst, c_src, x_new, fitness, slot, lin_w, att_w,
+                              w3, lin_b)
         return x_out
 
     @staticmethod
@@ -862,7 +913,11 @@ class _ASAPool(Function):
         att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
         # c = x att_x^T: its gradient g_c (x) att_x rides in the source-side kernel's store of gx (it computes g_c itself) instead of
         # being a read-modify-write pass over gx
-        if _ASAP_TIES:
+        ties = None
+        if ctx.tiled:        # a_dst holds the forward's per-row record; the segment max's backward is part of the call
+            gx, g_a, g_c = ops.tile_asap_scores_bwd(x, x_new, gxnew, xq_raw, s, c_src, xq[0].contiguous(), att_x[0].contiguous(), ctx.slope,
+                                                    s.tile_plan("in"), s.tile_plan("out"), a_dst)
+        elif _ASAP_TIES:
             gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0])
         else:
             (gx, g_a, g_c), ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, gx_rank1=att_x[0]), None
@@ -887,7 +942,9 @@ class _ASAPool(Function):
             g_lin_w = torch.empty_like(lin_w)
             g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
             ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
-        if g_xq_raw is None:
+        if ctx.tiled:
+            pass
+        elif g_xq_raw is None:
             ops.csr_segment_max_bwd_(gx, x, xq_raw, None, s, ties=ties, gmax_rank1=(g_a, w_comp[0].contiguous()))
         else:
             ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s, ties=ties)      # xq_raw = segment max of x

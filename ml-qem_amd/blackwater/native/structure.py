@@ -48,12 +48,40 @@ class GraphStructure:
             return self.__dict__[name]
         raise AttributeError(name)
 
+    # ------------------------------------------------------------------------------------------------
+    def set_tile_spec(self, make):
+        """Marks the structure as one whose rows share their sources when taken in a certain order (ASAPooling's coarsened graphs
+        of large circuits, rows by the program position of their centres): the edge walks over it then run tiled
+        (csrc/tile_common.hpp).  ``make()`` -> (order, max_span) runs when the first plan is built (a structure no layer reads
+        never pays for it); ``max_span``: a bound on the id range of one tile's entries."""
+        self._tile_spec = make
+        self._tile_plans = {}
+
+    @property
+    def tiled(self) -> bool:
+        return self._tile_spec is not None
+
+    def tile_plan(self, direction: str):
+        """The plan of the in-CSR ("in": forward and destination-side passes) or of the out-CSR ("out": source-side passes),
+        built on first use; None for a structure without a tile spec."""
+        if self._tile_spec is None:
+            return None
+        if direction not in self._tile_plans:
+            if callable(self._tile_spec):
+                self._tile_spec = self._tile_spec()
+            order, max_span = self._tile_spec
+            ptr, idx = (self.in_ptr, self.in_src) if direction == "in" else (self.out_ptr, self.out_dst)
+            self._tile_plans[direction] = ops.tile_plan_build(ptr, idx, self.num_nodes, int(idx.shape[0]), order, max_span)
+        return self._tile_plans[direction]
+
     @property
     def connectivity_built(self) -> bool:
         return "_build" not in self.__dict__
 
     def _init_rest(self, norms, graph_sizes, ell, colsums, derived):
         self.coarse_capacity = None   # host-side upper bound on the edges of this structure's ASAPooling coarsening (data/arena.py)
+        self._tile_spec = None        # (order, tiles, num_tiles, max_span): what a tiled row walk's plan is built from (set_tile_spec)
+        self._tile_plans = {}
         self._norms = norms
         self._derived = {} if derived is None else dict(derived)
         self._colsum = {} if colsums is None else dict(zip(("gcn", "sage", "cheb"), colsums))

@@ -51,6 +51,19 @@ struct AttnFwdArgs {
                                             // produce); out / attn_out stay compact [N, H C] (four-channels-per-lane kernels only)
 };
 
+// Arguments of the backward kernels (family_b_bwd.hip, tile_attn.hip).
+struct AttnBwdArgs {
+  const float* qkvs; int64_t ld; const float* g; int64_t ldg; const float* attn_out; int64_t lda;
+  const float* stat_m; const float* stat_den;
+  const int32_t* ptr; const int32_t* idx; const int32_t* optr; const int32_t* odst; const int32_t* oeid; const int32_t* loops;
+  int64_t N, E; int H, C; float drop_p; uint64_t seed; const uint64_t* seed_counter;
+  float* gqkvs; int64_t ldq; float* edge_al; float* edge_gs;
+  int pair_key;                   // as the forward's (attn_fwd.hpp)
+  int CP;                         // as the forward's: channel pitch of a head inside the parts of qkvs AND gqkvs (0 = C)
+};
+// oeid == nullptr selects the RECOMPUTING source side (transformer_attn_bwd_src_rc_q4_kernel): the destination side then files
+// delta[N, H] = g . attn_out per (row, head) in edge_al (its first N H floats) and writes nothing per edge.
+
 // The key of an attention weight's dropout draw.  By position (the default): (in-CSR position, head), self entries at E + row.
 // By pair: (destination row, head, source row) -- the same number from either end of an edge, so a source-side pass needs no map
 // from its out-entries to in-CSR positions (graphs without parallel edges only: parallel edges would share a draw).

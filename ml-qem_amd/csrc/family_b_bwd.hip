@@ -25,17 +25,7 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
 // Destination side: g_q, g_skip, and per edge (in-CSR order; self entries at E + row): al = effective attention weight
 // (after dropout), gs = d loss / d score * (1/sqrt(C)).  WIDE = channels 16..31 present (C > 16); rows are walked in
 // chunks of edges whose key and value rows are fetched together (for_edge_chunks, common.hpp).
-struct AttnBwdArgs {
-  const float* qkvs; int64_t ld; const float* g; int64_t ldg; const float* attn_out; int64_t lda;
-  const float* stat_m; const float* stat_den;
-  const int32_t* ptr; const int32_t* idx; const int32_t* optr; const int32_t* odst; const int32_t* oeid; const int32_t* loops;
-  int64_t N, E; int H, C; float drop_p; uint64_t seed; const uint64_t* seed_counter;
-  float* gqkvs; int64_t ldq; float* edge_al; float* edge_gs;
-  int pair_key;                   // as the forward's (attn_fwd.hpp)
-  int CP;                         // as the forward's: channel pitch of a head inside the parts of qkvs AND gqkvs (0 = C)
-};
-// oeid == nullptr selects the RECOMPUTING source side (transformer_attn_bwd_src_rc_q4_kernel): the destination side then files
-// delta[N, H] = g . attn_out per (row, head) in edge_al (its first N H floats) and writes nothing per edge.
+// (AttnBwdArgs: attn_fwd.hpp)
 
 template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_kernel(const AttnBwdArgs a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
