@@ -71,6 +71,22 @@ __device__ __forceinline__ uint64_t attn_drop_key(bool pair_key, int64_t pos, in
   return pair_key ? ((uint64_t)((int64_t)dst * H + h) << 32) | (uint32_t)src : (uint64_t)(pos * H + h);
 }
 
+// Draws under the pair key: ONE 32-bit hash per (destination, source) serves two heads (its 16-bit halves; heads 2k and 2k + 1 share
+// hash k), so a kernel that handles an entry for all heads draws once -- the draw had been a quarter of the per-entry vector
+// instructions (five quarter-rate 32-bit multiplies per head).  A weight is dropped when its 16-bit field is below floor(p * 65536)
+// (|P(drop) - p| < 1.6e-5, as common.hpp's dropout_keep).
+__device__ __forceinline__ uint32_t attn_pair_hash(uint64_t seed, int dst, int src, int hpair) {
+  uint32_t x = avalanche32((uint32_t)src ^ (uint32_t)seed);
+  return avalanche32(x ^ (uint32_t)(seed >> 32) ^ ((uint32_t)dst * 0x9E3779B1u) ^ ((uint32_t)hpair * 0x85EBCA6Bu));
+}
+__device__ __forceinline__ bool attn_pair_dropped(uint32_t hash, int h, uint32_t thr16) { return ((hash >> (16 * (h & 1))) & 0xFFFFu) < thr16; }
+__device__ __forceinline__ uint32_t attn_drop_threshold(float p) { return (uint32_t)(p * 65536.f); }
+// whether the weight of (destination dst, head h, source src) -- in-CSR position pos -- is dropped, under either key
+__device__ __forceinline__ bool attn_dropped(uint64_t seed, bool pair_key, int64_t pos, int H, int h, int dst, int src, float p) {
+  if (pair_key) return attn_pair_dropped(attn_pair_hash(seed, dst, src, h >> 1), h, attn_drop_threshold(p));
+  return uniform01_edge(seed, (uint64_t)(pos * H + h)) < p;
+}
+
 template <bool TRAIN, bool WIDE> __device__ __forceinline__ void attn_forward(const AttnFwdArgs& a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;

@@ -155,7 +155,7 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
     float w = p;
     if (TRAIN && a.drop_p > 0.f) {
       const int64_t pos = is_self ? a.E + row : (int64_t)beg + x;
-      w = uniform01_edge(seed, attn_drop_key(a.pair_key != 0, pos, H, h, row, j)) < a.drop_p ? 0.f : p * keep;
+      w = attn_dropped(seed, a.pair_key != 0, pos, H, h, row, j, a.drop_p) ? 0.f : p * keep;
     }
     const float wu[4] = {quad_bcast<0>(w), quad_bcast<1>(w), quad_bcast<2>(w), quad_bcast<3>(w)};
 #pragma unroll

@@ -310,7 +310,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     const int64_t pos = is_self ? a.E + row : (int64_t)beg + x;
     const float alpha = expf(mys * scale - m) * inv_den * (is_self ? (float)n_self : 1.f);
     float dmask = 1.f;
-    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, attn_drop_key(a.pair_key != 0, pos, H, h, row, j)) < a.drop_p ? 0.f : keep;
+    if (a.drop_p > 0.f) dmask = attn_dropped(seed, a.pair_key != 0, pos, H, h, row, j, a.drop_p) ? 0.f : keep;
     if (cnt <= 4) delta = quad_sum(lu < k ? alpha * dmask * mygv : 0.f);
     float gs = alpha * (mygv * dmask - delta) * scale;
     if (lu >= k) gs = 0.f;
@@ -401,7 +401,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     }
     const float alpha = expf(mys * scale - m_i) * inv_den * (is_self ? (float)n_self : 1.f);
     float dmask = 1.f;
-    if (a.drop_p > 0.f) dmask = uniform01_edge(seed, attn_drop_key(true, 0, H, h, i, row)) < a.drop_p ? 0.f : keep;
+    if (a.drop_p > 0.f) dmask = attn_dropped(seed, true, 0, H, h, i, row, a.drop_p) ? 0.f : keep;
     float gs = alpha * (mygv * dmask - delta_i) * scale, al = alpha * dmask;
     if (lu >= k) { gs = 0.f; al = 0.f; }
     const float gsu[4] = {quad_bcast<0>(gs), quad_bcast<1>(gs), quad_bcast<2>(gs), quad_bcast<3>(gs)};

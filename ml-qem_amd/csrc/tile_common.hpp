@@ -21,6 +21,8 @@
 // SIMD -- the tiled kernels took 1.3-2.6x the time of the per-edge ones.)
 #pragma once
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mlqem {
@@ -30,6 +32,8 @@ constexpr uint32_t kTileNoSlot = 0xFFFFu;
 constexpr int kTileMaxRows = 128;           // rows per tile
 constexpr int kTileLocEntries = 4096;       // entries of a tile whose slots are staged in LDS (rows past that read `loc` from global memory)
 
+typedef float f4a __attribute__((ext_vector_type(4)));   // a 16-byte aligned access (LDS: ds_read_b128 / ds_write_b128)
+
 struct TilePlan {
   const int4* tinfo;
   const int4* rinfo;
@@ -37,7 +41,9 @@ struct TilePlan {
   const uint16_t* loc;
   int64_t nt;
   int cap, tile_rows;
+  int dbg;           // MLQEM_TILE_DEBUG (bisecting a kernel's time: 1 = stop after the prologue, 2 = after the staging, 3 = no long rows, 4 = no short rows)
 };
+inline int tile_debug_mode() { static const int m = getenv("MLQEM_TILE_DEBUG") ? atoi(getenv("MLQEM_TILE_DEBUG")) : 0; return m; }
 
 // what every tiled kernel keeps in LDS besides its staged rows
 struct TileLds {
@@ -66,14 +72,141 @@ __device__ __forceinline__ int4 tile_prologue(const TilePlan& p, int t, const Ti
   __syncthreads();
   return ti;
 }
-// Part of the second round trip: the tile's slots, row after row (a row's entries are contiguous in `loc`).  Call between
-// tile_prologue and the barrier that ends the staging.
+// The second round trip of a tile, ALL of it in flight at once: the tile's slots (`loc`), up to two operand blocks of the tile's own
+// rows, and the union's rows -- every global load is issued before the first LDS store.  (Three helpers that each loaded and then
+// stored were three round trips one after the other: 130 us of a 430 us kernel; and a loop over the rows with one row's `loc` loads per
+// iteration before that was a round trip per row and wave.)
+//   loc:   a thread takes entries q = tid, tid + 256, ... of the tile's entry list and finds each one's row by bisection over the row
+//          records' offsets (a row's entries are contiguous in `loc`, the tile's rows are not);
+//   own:   `pieces` 16-byte pieces from row rinfo[i].x of `src` (+ off floats) to own[i * pitch + at ..]; at most 4 pieces per thread
+//          and block (tile_rows * pieces <= 1024);
+//   union: `pieces` 16-byte pieces per slot from row uid[slot] of `src`; a slot belongs to a power-of-two group of lanes (no division
+//          per piece), eight loads per thread in flight; unions past 8 * 256 / group slots take further rounds.
+struct TileOwn { const float* src; int64_t ld; int off, pieces, at; };
+__device__ __forceinline__ void tile_stage(const TilePlan& p, const int4& ti, const TileLds& l, const float* __restrict__ usrc, int64_t uld,
+                                           int uoff, int upieces, float* __restrict__ rows, int upitch, const TileOwn& o0, const TileOwn& o1,
+                                           float* __restrict__ own, int opitch) {
+  const int cnt = ti.x, ucnt = ti.z, tid = threadIdx.x;
+  // own-row operands
+  f4a ov[2][4];
+  const TileOwn* os[2] = {&o0, &o1};
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const TileOwn& o = *os[b];
+    if (o.src) {
+      const int total = cnt * o.pieces;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = tid + u * kBlock;
+        if (i < total) {
+          const int r = i / o.pieces, pc = i - r * o.pieces;
+          ov[b][u] = *reinterpret_cast<const f4a*>(o.src + (int64_t)l.rinfo[r].x * o.ld + o.off + 4 * pc);
+        }
+      }
+    }
+  }
+  // slots of the tile's entries (first round)
+  const int ltotal = min(ti.w, kTileLocEntries);
+  uint16_t lv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int q = u * kBlock + tid;
+    if (q < ltotal) {
+      int lo = 0, hi = cnt;                                 // the last row whose offset is <= q (offsets ascend; empty rows share one)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (l.rinfo[mid].w <= q) lo = mid; else hi = mid;
+      }
+      const int4 ri = l.rinfo[lo];
+      lv[u] = p.loc[ri.y + (q - ri.w)];
+    }
+  }
+  // the union's rows (first round)
+  const int shift = upieces <= 8 ? 3 : upieces <= 16 ? 4 : upieces <= 32 ? 5 : 6;
+  const int pc = tid & ((1 << shift) - 1), s_in = tid >> shift, per = kBlock >> shift;
+  f4a uv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int sl = u * per + s_in;
+    if (pc < upieces && sl < ucnt) uv[u] = *reinterpret_cast<const f4a*>(usrc + (int64_t)l.uid[sl] * uld + uoff + 4 * pc);
+  }
+  // ... and only now the stores
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const TileOwn& o = *os[b];
+    if (o.src) {
+      const int total = cnt * o.pieces;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = tid + u * kBlock;
+        if (i < total) {
+          const int r = i / o.pieces, pc2 = i - r * o.pieces;
+          *reinterpret_cast<f4a*>(own + r * opitch + o.at + 4 * pc2) = ov[b][u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int q = u * kBlock + tid;
+    if (q < ltotal) l.loc[q] = lv[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int sl = u * per + s_in;
+    if (pc < upieces && sl < ucnt) *reinterpret_cast<f4a*>(rows + sl * upitch + 4 * pc) = uv[u];
+  }
+  // further rounds (large tiles: more than 2048 entries / 8 * 256 / group slots)
+  for (int q0 = 8 * kBlock; q0 < ltotal; q0 += kBlock) {
+    const int q = q0 + tid;
+    if (q < ltotal) {
+      int lo = 0, hi = cnt;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (l.rinfo[mid].w <= q) lo = mid; else hi = mid;
+      }
+      const int4 ri = l.rinfo[lo];
+      l.loc[q] = p.loc[ri.y + (q - ri.w)];
+    }
+  }
+  if (pc < upieces)
+    for (int s0 = 8 * per; s0 < ucnt; s0 += 8 * per) {
+      f4a v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s0 + u * per + s_in;
+        if (sl < ucnt) v[u] = *reinterpret_cast<const f4a*>(usrc + (int64_t)l.uid[sl] * uld + uoff + 4 * pc);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sl = s0 + u * per + s_in;
+        if (sl < ucnt) *reinterpret_cast<f4a*>(rows + sl * upitch + 4 * pc) = v[u];
+      }
+    }
+}
+// the slots alone (kernels whose other staging has its own shape)
 __device__ __forceinline__ void tile_stage_loc(const TilePlan& p, const int4& ti, const TileLds& l) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = wave; i < ti.x; i += kBlock / kWave) {
-    const int4 ri = l.rinfo[i];
-    if (ri.w + ri.z <= kTileLocEntries)
-      for (int x = lane; x < ri.z; x += kWave) l.loc[ri.w + x] = p.loc[ri.y + x];
+  const int cnt = ti.x, total = min(ti.w, kTileLocEntries);
+  for (int q0 = 0; q0 < total; q0 += 8 * kBlock) {
+    uint16_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * kBlock + (int)threadIdx.x;
+      if (q < total) {
+        int lo = 0, hi = cnt;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (l.rinfo[mid].w <= q) lo = mid; else hi = mid;
+        }
+        const int4 ri = l.rinfo[lo];
+        v[u] = p.loc[ri.y + (q - ri.w)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * kBlock + (int)threadIdx.x;
+      if (q < total) l.loc[q] = v[u];
+    }
   }
 }
 // the slot of entry x of a row (ri: its record)
@@ -89,7 +222,40 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-typedef float f4a __attribute__((ext_vector_type(4)));   // a 16-byte aligned access (LDS: ds_read_b128 / ds_write_b128)
+// ---- whole-wave reductions for the rows a wave walks with ONE LANE PER ENTRY (all 64 lanes active) ----
+__device__ __forceinline__ float wave_max_all(float v) {
+  v = fmaxf(v, dpp_row<0xB1>(v));
+  v = fmaxf(v, dpp_row<0x4E>(v));
+  v = fmaxf(v, dpp_row<0x141>(v));
+  v = fmaxf(v, dpp_row<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+  v += dpp_row<0xB1>(v);
+  v += dpp_row<0x4E>(v);
+  v += dpp_row<0x141>(v);
+  v += dpp_row<0x140>(v);
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+// Sixteen per-lane partial sums -> their totals over the wave, one channel per lane: lane l ends with the total of channel
+// wave_channel16(l).  A reduce-scatter: at every step a lane keeps half of its channels and hands the other half to its partner
+// (lane ^ 1, ^ 2: DPP quad permutes; ^ 4, ^ 8, ^ 16, ^ 32: the LDS crossbar), 8 + 4 + 2 + 1 + 1 + 1 adds instead of 16 x 6.
+__device__ __forceinline__ int wave_channel16(int lane) { return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3); }
+__device__ __forceinline__ float wave_reduce16(const float (&v)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float w[8], u[4], t[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = (b0 ? v[i + 8] : v[i]) + dpp_row<0xB1>(b0 ? v[i] : v[i + 8]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (b1 ? w[i + 4] : w[i]) + dpp_row<0x4E>(b1 ? w[i] : w[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) t[i] = (b2 ? u[i + 2] : u[i]) + __shfl_xor(b2 ? u[i] : u[i + 2], 4, 64);
+  float r = (b3 ? t[1] : t[0]) + __shfl_xor(b3 ? t[0] : t[1], 8, 64);
+  r += __shfl_xor(r, 16, 64);
+  return r + __shfl_xor(r, 32, 64);
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: remembered per (device, kernel) so that a process
 // that drives several GPUs raises the limit on each of them and a launch path pays one table lookup
