@@ -36,7 +36,7 @@ import torch
 DEFAULT_BATCH = 1024
 CORPUS_BATCHES = 8          # corpus = CORPUS_BATCHES x batch x world circuits
 STEPS_LIST = list(range(1, 11))
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_aggregate_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_aggregate_pmc.json")
 
 
 _T0 = time.perf_counter()
@@ -510,8 +510,10 @@ def family_b_leg(dev, steps=30):
     points = ("batch64_hipgraph", "batch256_hipgraph", "batch512_hipgraph", "batch1024_eager")
     cfg4["best_point"] = max(points, key=lambda k: cfg4[k]["circuits_per_s"])
     cfg4["best_circuits_per_s"] = cfg4[cfg4["best_point"]]["circuits_per_s"]
-    cfg4["attention_roofline"] = attention_roofline(big_arena.batch(np.arange(64) * nb_graphs // 64).structure, dev,
-                                                    "64 100-qubit circuits (the first TransformerConv's graph: the circuit DAGs)")
+    b64 = big_arena.batch(np.arange(64) * nb_graphs // 64)
+    cfg4["attention_roofline"] = attention_roofline(b64.structure, dev, "64 100-qubit circuits (the first TransformerConv's graph: the circuit DAGs)")
+    cfg4["attention_roofline"]["level1"] = level1_attention_roofline(b64, dev)
+    del b64
     out["cfg4_100q"] = cfg4
     out["cfg4_100q_batch64"] = {"renamed": "cfg4_100q (batch points 64 / 256 / 512 / 1024)", "circuits_per_s": cfg4["circuits_per_s"],
                                 "ms_per_step": cfg4["ms_per_step"]}
@@ -545,6 +547,39 @@ def family_b_leg(dev, steps=30):
     out["roofline"] = attention_roofline(arena.batch(np.arange(1024) * len(arena) // 1024).structure, dev,
                                          "1024 4-qubit circuits (0.23 M nodes: a small launch, the step spreads over ~100 of them)")
     return out
+
+
+def level1_attention_roofline(batch, dev, heads=2, ch=15):
+    """The SECOND TransformerConv's forward (docs/tutorials/gnn.py:86-91) on the graph ASAPooling coarsens out of ``batch`` -- where
+    most of the attention time of a 100-qubit step goes (what's weak 3).  Same byte model as ``attention_roofline``
+    (no cache credit); dropout keyed by (destination, head, source) as in the model's step."""
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel(22, 15, 4).to(dev).train()
+    with torch.no_grad():
+        g = model.transformer1(batch.nodes, batch.structure)
+        g, s, _ = model.pooling1(g, batch.structure)
+    n = s.num_nodes
+    e_cap, e = s.edge_count(), int(s.in_ptr[n].item())
+    qk = []
+    for _ in range(4):
+        t = ops.padded_empty(n, 4 * heads * 16, dev).normal_()
+        t.view(n, 4 * heads, 16)[:, :, ch:] = 0.0
+        qk.append(t)
+    run = lambda k: ops.transformer_attention_train(qk[k % 4], s.in_ptr, s.in_src, s.loops, e_cap, heads, ch, 0.1, 1234 + k, pair_key=True, head_pitch=16)
+    sec = _timed_launches(run, 20, 4)
+    hc = heads * ch
+    by_r02 = 4 * (n + 1) + 4 * e + 4 * hc * (n + e + e + n)                      # the coarsened graph has no self entries
+    deg = (s.in_ptr[1:n + 1] - s.in_ptr[:n]).long()
+    n_long = int((deg > 4).sum().item())
+    by = 4 * (n + 1) + 4 * e + 4 * heads * 16 * (2 * n + 2 * e) + 4 * hc * (n + n_long) + 8 * n * heads
+    return {"bound": "hbm (by the contract's byte model; the counters say vector ALU: 0.69 of the SIMD cycles busy, profiles/r05_level1_pmc.json)",
+            "kernel": f"transformer_attn_train_q4_kernel<4> (H={heads}, C={ch}, head pitch 16, pair-keyed dropout 0.1)",
+            "workload": "the graph ASAPooling makes of 64 100-qubit circuits", "achieved": round(by / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(by / sec / 1e9 / 8000.0, 4), "frac_r02_model": round(by_r02 / sec / 1e9 / 8000.0, 4), "traffic": None,
+            "bytes_per_launch": int(by), "us_per_launch": round(sec * 1e6, 2), "nodes": n, "edges": e, "mean_row_length": round(e / max(n, 1), 1)}
 
 
 def attention_roofline(s, dev, what, heads=3, ch=15):
@@ -594,6 +629,163 @@ def attention_roofline(s, dev, what, heads=3, ch=15):
             "note": "four channels per lane (csrc/attn_q4.hpp): a (row, head) is 4 lanes, a key / value segment one 16-byte load, entries "
                     "four at a time with one lane per entry for the scalar work; the one-channel-per-lane form it replaces was bound by "
                     "instruction issue (0.29 of the HBM peak on the 100-qubit circuit DAGs)"}
+
+
+def replicated_arena(enc, copies, dev, filler_nodes=0, scalar_labels=False, seed=0):
+    """A device-resident arena of ``copies[t]`` copies of every encoded template graph ``t`` (``synthetic.encode_corpus``): distinct
+    circuit STRUCTURES are encoded once on the host and replicated by torch ops on the GPU (labels random per copy), the way
+    ``TfimCorpus.arena`` builds the headline corpus.  Returns (arena, template index of every circuit)."""
+    from blackwater.data.arena import GraphArena
+
+    copies = np.asarray(copies, dtype=np.int64)
+    sizes = np.array([x.shape[0] for x in enc["x"]])
+    f = enc["x"][0].shape[1]
+    f4 = (f + 3) // 4 * 4
+    n_total = int((sizes * copies).sum())
+    x = torch.zeros((n_total, f4), dtype=torch.float32, device=dev)
+    eis, base, tmpl_of = [], 0, []
+    for t, (xt, et, c) in enumerate(zip(enc["x"], enc["edge_index"], copies)):
+        n_t, c = xt.shape[0], int(c)
+        x[base:base + c * n_t].view(c, n_t, f4)[:, :, :f] = torch.from_numpy(xt).to(dev).unsqueeze(0)
+        offs = base + torch.arange(c, device=dev, dtype=torch.int64) * n_t
+        eis.append((torch.from_numpy(et).to(dev).unsqueeze(1) + offs.view(1, c, 1)).reshape(2, -1))
+        base += c * n_t
+        tmpl_of.append(np.full(c, t))
+    tmpl_of = np.concatenate(tmpl_of)
+    g = len(tmpl_of)
+    rng = np.random.default_rng(seed)
+    width = 1 if scalar_labels else enc["y"].shape[-1]
+    y = rng.uniform(-1, 1, size=(g, width) if scalar_labels else (g, 1, width)).astype(np.float32)
+    noisy = (y * 0.9 + rng.normal(0, 0.01, size=y.shape)).astype(np.float32)
+    arena = GraphArena.from_device(x[:, :f], sizes[tmpl_of], torch.cat(eis, dim=1), y, noisy, enc["depth"][tmpl_of], enc["observable"][tmpl_of],
+                                   filler_nodes=filler_nodes)
+    return arena, tmpl_of
+
+
+def _timed_steps(run, warm, steps):
+    for _ in range(warm):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, last
+
+
+def _agg_frac(arena, ids, n_qubits):
+    """Byte-weighted fraction of the 8 TB/s HBM peak over every CSR aggregation launch of a Family A step on this batch."""
+    rows = in_step_aggregation_times(arena, ids, n_qubits, steps=2)
+    us = sum(v[0] * v[2] for v in rows.values())
+    by = sum(v[1] * v[2] for v in rows.values())
+    return {"frac": round(by / us / 1e3 / 8000.0, 4), "GBps": round(by / us / 1e3, 1), "launches_per_step": int(sum(v[2] for v in rows.values())),
+            "bytes_per_step": int(by), "us_per_step": round(us, 1)}
+
+
+def configs_leg(dev):
+    """BASELINE.json's configs that the other legs do not time: cfg1 (MLP on the 169-wide circuit features of 3 000
+    4-qubit circuits: the demo2 sizes), cfg3 (random 20-qubit depth-40 circuits, 100 k circuits on one GPU; Family A and Family B train
+    steps) and cfg5 (one rank's 1/64 cut of the 1 M-circuit mixed corpus: 50 % 4-qubit TFIM, 30 % random 20-qubit, 20 % Pauli-twirled
+    100-qubit TFIM; Family A in fp32 and Family B with the MLP3 head on the bf16 matrix cores).  Every graph leg: circuits/s, ms per
+    step, and the byte-weighted fraction of the HBM peak over its aggregation (Family A) or first-level attention (Family B) launches,
+    by the algorithmic bytes of SURVEY section 8(d)."""
+    from blackwater.data.synthetic import encode_corpus, pauli_twirl, random_circuit, tfim_circuit
+    from blackwater.native import ops
+    from blackwater.nn import MLP1, ExpValCircuitGraphModel, ExpValCircuitGraphModel_3, ExpValCircuitGraphModelA
+    from blackwater.train import BucketedTrainer, RowsTrainer, StratifiedBatches, Trainer
+
+    out = {}
+    # ---- cfg1: MLP1(169, 64, 1) on 3 000 feature rows (500 train / 2 500 test in demo2), one captured step per batch of 500
+    torch.manual_seed(0)
+    rows = torch.randn(3000, 169, device=dev)
+    target = torch.randn(3000, 1, device=dev)
+    tr = RowsTrainer(MLP1(169, 64, 1).to(dev), lr=1e-3)
+    sel = [torch.arange(k * 500, (k + 1) * 500, device=dev) for k in range(6)]
+    k = [0]
+
+    def mlp_step():
+        i = sel[k[0] % 6]
+        k[0] += 1
+        return tr.step_rows(rows[i], target[i])
+
+    sec, loss = _timed_steps(mlp_step, 20, 200)
+    out["cfg1_mlp1_169"] = {"workload": "cfg1: MLP1(169, 64, 1) train step on 500 of 3 000 feature rows (encode_data_v2_ecr width for two_q = 'cx')",
+                            "circuits_per_s": round(500 / sec, 1), "ms_per_step": round(sec * 1e3, 4), "final_loss": round(float(loss.item()), 6),
+                            "note": "launch-bound (a 500-row step is ~10 launches); the throughput shape of the same kernels is the mlp_head leg"}
+    del tr
+    # ---- cfg3: random 20-qubit depth-40 circuits
+    progress("  cfg3: random 20-qubit depth-40 circuits")
+    tmpl = [random_circuit(20, 40, seed=s, two_q="cx") for s in range(16)]
+    cfg3 = {"workload": "cfg3: 100 000 random 20-qubit depth-40 circuits (16 distinct structures, replicated on the device)"}
+    enc = encode_corpus(tmpl, 20, two_q="cx", exp_value_size=1)
+    arena, _ = replicated_arena(enc, np.full(16, 6250), dev, filler_nodes=1024, scalar_labels=True)
+    g = len(arena) - 1
+    cfg3["nodes_per_circuit"] = round((arena.num_nodes - 1024) / g, 1)
+    sampler = StratifiedBatches(arena.node_counts[:g], arena.edge_counts[:g], 4096, seed=5)
+    torch.manual_seed(0)
+    bt = BucketedTrainer(ExpValCircuitGraphModelA(20, 22, 10).to(dev), arena, lr=1e-3, graphs=True, node_quantum=1024)
+    sec, loss = _timed_steps(lambda: bt.step_ids(sampler.draw()), 3, 20)
+    cfg3["family_a"] = {"circuits_per_step": 4096, "circuits_per_s": round(4096 / sec, 1), "ms_per_step": round(sec * 1e3, 3),
+                        "nodes_per_step": int(sampler.nodes_per_batch), "step_mode": "hipgraph replay", "final_loss": round(float(loss.item()), 6)}
+    ops.set_seed_counter(None)
+    del bt
+    cfg3["family_a"]["aggregation_roofline"] = _agg_frac(arena, sampler.draw(), 20)
+    del arena
+    torch.cuda.empty_cache()
+    enc4 = encode_corpus(tmpl, 20, two_q="cx", exp_value_size=4)
+    arena, _ = replicated_arena(enc4, np.full(16, 1024), dev, filler_nodes=1024)
+    g = len(arena) - 1
+    sampler = StratifiedBatches(arena.node_counts[:g], arena.edge_counts[:g], 1024, seed=5)
+    torch.manual_seed(0)
+    bt = BucketedTrainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), arena, lr=1e-3, graphs=True, node_quantum=1024, edge_quantum=4096)
+    sec, loss = _timed_steps(lambda: bt.step_ids(sampler.draw()), 3, 10)
+    cfg3["family_b"] = {"circuits_per_step": 1024, "circuits_per_s": round(1024 / sec, 1), "ms_per_step": round(sec * 1e3, 3),
+                        "nodes_per_step": int(sampler.nodes_per_batch), "step_mode": "hipgraph replay", "final_loss": round(float(loss.item()), 6)}
+    ops.set_seed_counter(None)
+    del bt
+    cfg3["family_b"]["attention_roofline"] = attention_roofline(arena.batch(sampler.draw()).structure, dev, "1024 random 20-qubit circuits (level 0)")
+    del arena
+    torch.cuda.empty_cache()
+    out["cfg3_random_20q"] = cfg3
+    # ---- cfg5: the mixed corpus, 1/64 of one rank's shard (15 625 circuits)
+    progress("  cfg5: mixed corpus")
+    total = 15_625
+    n2, n3 = total // 2, total * 3 // 10
+    n4 = total - n2 - n3
+    small = [tfim_circuit(4, st, J=0.3 + 0.01 * st, two_q="cx") for st in range(15)]
+    rand = [random_circuit(20, 40, seed=s, two_q="cx") for s in range(12)]
+    twirled = [pauli_twirl(tfim_circuit(100, st, J=0.5, two_q="cx"), seed=100 + st, two_q=("cx",)) for st in range(1, 11)]
+    enc5 = encode_corpus(small + rand + twirled, 100, two_q="cx", exp_value_size=4)
+    copies = np.concatenate([np.full(15, -(-n2 // 15)), np.full(12, -(-n3 // 12)), np.full(10, -(-n4 // 10))])
+    cfg5 = {"workload": "cfg5: %d circuits = 1/64 of one rank's shard of the 1 M-circuit mixed corpus (50 %% 4-qubit TFIM, 30 %% random 20-qubit "
+                        "depth-40, 20 %% Pauli-twirled 100-qubit TFIM), device-resident" % int(copies.sum())}
+    rs = np.random.RandomState(0)
+    for name, make, batch, steps, scalar in (("family_a_f32", lambda: ExpValCircuitGraphModelA(100, 22, 10), 1024, 10, True),
+                                             ("family_b_mlp3_head_bf16", lambda: ExpValCircuitGraphModel_3(22, 15, 4), 64, 12, False)):
+        arena, _ = replicated_arena(enc5, copies, dev, scalar_labels=scalar)
+        g = len(arena)
+        cfg5.setdefault("nodes", int(arena.num_nodes))
+        torch.manual_seed(0)
+        model = make().to(dev)
+        if not scalar:
+            model.body_seq.mfma = "bf16"
+        tr = Trainer(model, lr=1e-3)
+        draw = lambda: rs.randint(0, g, size=batch)
+        sec, loss = _timed_steps(lambda: tr.step(arena.batch(draw())), 2, steps)
+        rec = {"circuits_per_step": batch, "circuits_per_s": round(batch / sec, 1), "ms_per_step": round(sec * 1e3, 3), "step_mode": "eager",
+               "final_loss": round(float(loss.item()), 6)}
+        del tr, model
+        ids = draw()
+        rec["nodes_in_the_roofline_batch"] = int(arena.node_counts[ids].sum())
+        if scalar:
+            rec["aggregation_roofline"] = _agg_frac(arena, ids, 100)
+        else:
+            rec["attention_roofline"] = attention_roofline(arena.batch(ids).structure, dev, "64 circuits of the mixed corpus (level 0)")
+        cfg5[name] = rec
+        del arena
+        torch.cuda.empty_cache()
+    out["cfg5_mixed"] = cfg5
+    return out
 
 
 def mlp_head_leg(dev, rows=262144, steps=50):
@@ -1062,11 +1254,27 @@ def main():
             torch.cuda.empty_cache()
             only = [k for k in os.environ.get("MLQEM_BENCH_LEGS", "").split(",") if k]     # diagnostics: a subset of the legs
             for key, leg in (("accuracy", accuracy_leg), ("family_b", family_b_leg), ("small_batch", small_batch_leg),
-                             ("mlp_head", mlp_head_leg), ("inference", inference_leg)):
+                             ("mlp_head", mlp_head_leg), ("configs", configs_leg), ("inference", inference_leg)):
                 if only and key not in only:
                     continue
                 progress(f"{key} leg")
                 line[key] = leg(dev)
+            # one scalar per BASELINE.json config at the top level (a driver that keeps only scalar keys keeps these)
+            flat = {"cfg1_mlp1_169_circuits_per_s": ("configs", "cfg1_mlp1_169", "circuits_per_s"),
+                    "cfg2_family_a_batch32_circuits_per_s": ("small_batch", "hipgraph", "circuits_per_s"),
+                    "cfg2_family_b_batch32_circuits_per_s": ("family_b", "batch32_stratified_hipgraph", "circuits_per_s"),
+                    "cfg3_family_a_circuits_per_s": ("configs", "cfg3_random_20q", "family_a", "circuits_per_s"),
+                    "cfg3_family_b_circuits_per_s": ("configs", "cfg3_random_20q", "family_b", "circuits_per_s"),
+                    "cfg4_family_b_best_circuits_per_s": ("family_b", "cfg4_100q", "best_circuits_per_s"),
+                    "cfg4_family_b_batch64_ms_per_step": ("family_b", "cfg4_100q", "ms_per_step"),
+                    "cfg5_family_a_circuits_per_s": ("configs", "cfg5_mixed", "family_a_f32", "circuits_per_s"),
+                    "cfg5_family_b_bf16_head_circuits_per_s": ("configs", "cfg5_mixed", "family_b_mlp3_head_bf16", "circuits_per_s")}
+            for key, path in flat.items():
+                node = line
+                for part in path:
+                    node = node.get(part) if isinstance(node, dict) else None
+                if node is not None:
+                    line[key] = node
             progress("done")
         print(json.dumps(line), flush=True)
     if distributed:

@@ -278,7 +278,10 @@ def _ticket(device):
 def reset_tickets(device):
     """Re-zeroes the counters (after a launch that aborted half-way: a non-zero ticket would silently skip every later
     last-workgroup tail on its stream)."""
-    pool = _ticket_pools.get(torch.device(device))
+    device = torch.device(device)
+    if device.index is None:            # the key prepare_device files the pool under ('cuda' alone found nothing: ADVICE r04)
+        device = torch.device("cuda", torch.cuda.current_device())
+    pool = _ticket_pools.get(device)
     if pool is not None:
         pool[0].zero_()
 
@@ -1358,10 +1361,37 @@ def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
     out_eid = mk(e) if link else None       # link=False: no out_eid (the recomputed backward forms need none)
     loops = torch.full((max(k, 1),), 0, dtype=torch.int32, device=dev)      # a fill kernel, not a memset node (the call may be captured)
     if k > 0:
+        # with a capacity bound nothing is read back: a list that would leave its buffer is dropped by the kernels, which raise this
+        # flag -- read lazily (check_overflow_flags: epoch ends, MLQEM_SYNC_OPS, tests), so a truncated graph cannot pass unnoticed
+        flag = torch.full((1,), 0, dtype=torch.int32, device=dev)
         code = lib.mlqem_asap_coarsen_lists_fill(num_nodes, k, int(num_edges), cap, _p(in_ptr), _p(out_ptr), _p(in_src), _p(out_dst),
-                                                 _p(out_eid), e, None, _p(ws), need, _stream())
+                                                 _p(out_eid), e, _p(flag), _p(ws), need, _stream())
         _lib.check(code, "mlqem_asap_coarsen_lists_fill")
+        _note_overflow_flag(flag, f"mlqem_asap_coarsen_lists_fill: a list outgrew the capacity {cap} (k = {k} clusters)")
     return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], None if out_eid is None else out_eid[:e]), slot, e
+
+
+_overflow_flags = []      # (device int32 flag, what it means): at most 64 recent ones
+
+
+def _note_overflow_flag(flag, what):
+    _overflow_flags.append((flag, what))
+    if len(_overflow_flags) > 64:
+        del _overflow_flags[0]
+    if _lib._SYNC_OPS:
+        check_overflow_flags()
+
+
+def check_overflow_flags():
+    """Reads (one host sync) the overflow flags the capacity-bound kernels left since the last call and raises if one is set."""
+    flags, _overflow_flags[:] = list(_overflow_flags), []
+    if not flags or torch.cuda.is_current_stream_capturing():
+        _overflow_flags[:] = flags
+        return
+    raised = torch.stack([f[0] for f, _ in flags]).cpu().tolist()
+    bad = [what for (_, what), v in zip(flags, raised) if v != 0]
+    if bad:
+        raise _lib.NativeLibraryError("capacity overflow on the device: " + "; ".join(sorted(set(bad))))
 
 
 ASAP_LISTS_MAX_CAPACITY = 1 << 32      # entries per list buffer the list form addresses (32-bit places in its per-node records)

@@ -20,6 +20,8 @@ import numpy as np
 import torch
 from torch import nn
 
+from .native import ops as _ops
+
 
 def flatten_parameters(model: nn.Module):
     """Re-homes every parameter as a view into one contiguous fp32 buffer and gives each a ``.grad`` view into a
@@ -353,6 +355,7 @@ class Trainer:
             if self.distributed:
                 torch.distributed.all_reduce(val_total, op=torch.distributed.ReduceOp.SUM)
             self.scheduler.step(val_total.item())  # one sync per epoch
+            _ops.check_overflow_flags()            # the epoch's capacity-bound launches (ASAPooling's list coarsening): raise, never truncate
             if epoch >= 1:  # the reference drops epoch 0 from its curves (__ml_models.py:182)
                 history["train_losses"].append(running.item() / n_batches)
                 history["val_losses"].append(val_total.item() / max(len(val_batches), 1) / self.world)

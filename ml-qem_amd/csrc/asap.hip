@@ -1358,9 +1358,7 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
               q.rinfo, q.r_o, q.r_i, capacity, q.off_o, q.off_i, q.tmp_o, q.tmp_i, capacity, q.outdeg, q.indeg, q.flag};
   hipLaunchKernelGGL(coarsen_gather_kernel, dim3((unsigned)ceil_div(K, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, q.cinfo, q.cgraph);
   const size_t lds = (size_t)4 * 2 * a.Wk * sizeof(uint32_t);
-  static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(coarsen_unique_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              kListsMaxLds) == hipSuccess ? 1 : 0;
-  if (!once) return MLQEM_ERR_LAUNCH;
+  if (!ensure_dynamic_lds(coarsen_unique_kernel, (size_t)kListsMaxLds)) return MLQEM_ERR_LAUNCH;      // per device (common.hpp)
   // persistent waves: as many workgroups as the LDS lets a CU hold (at most 8: 32 waves), never more than there are clusters
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)kListsMaxLds / std::max<size_t>(lds, 1)));
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(K, (int64_t)4), (int64_t)device_cus() * per_cu));

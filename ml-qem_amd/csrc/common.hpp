@@ -131,6 +131,15 @@ template <int V> __device__ __forceinline__ void vstore_nt(float* p, const float
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: remembered per (device, kernel), so that a process
+// that drives several GPUs raises the limit on each of them (a `static const int once = hipFuncSetAttribute(...)` did it for the first
+// device only and the launch failed on the second: ADVICE r04) and a launch path pays one table lookup.  Defined in tile_plan.hip.
+bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes);
+template <class K> inline bool ensure_dynamic_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) return false;
+  return ensure_dynamic_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
+}
 // Sum over the 16 lanes of an aligned lane group (all 16 must be active); every lane gets the total.  The attention
 // and pooling kernels give one group to a (row, head) or a row: lane l holds channels l, l + 16, ... so that a source row
 // is read with 64-byte coalesced loads and a dot product over the channels is four cross-lane adds in a fixed order.

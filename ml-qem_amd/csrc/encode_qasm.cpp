@@ -28,6 +28,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <pthread.h>
+
 #include "../../include/mlqem_hip.h"
 
 namespace {
@@ -708,7 +710,30 @@ struct Batch {
 
 // ONE parsed batch is kept between calls with its circuits' storage (vectors keep their capacity): the next run() of the same
 // shape parses straight into it -- no exactly-sized copies, no fresh pages (0.4 GB of them per 1024 100-qubit circuits: their
-// page faults serialise on the process's memory map and were what kept 64 threads from scaling).  Bounded: nothing above 2 GB is kept.
+// page faults serialise on the process's memory map and were what kept 64 threads from scaling).  Bounded: nothing above 768 MB is kept
+// (1024 100-qubit circuits parse into 0.4 GB).
+// The process-wide pools below hold mutexes, condition variables and (the worker pool) threads.  After fork() the child has ONE thread
+// -- the one that forked -- while the pools it inherited still say that workers exist and may hold locks some other parent thread held
+// at that instant: a child that encoded again waited for ever on workers that are not there (multiprocessing / DataLoader
+// workers started by fork do exactly this).  Every pool therefore sits behind a pointer that a pthread_atfork child handler clears: the
+// child abandons the parent's objects (never touches their locks) and builds its own on first use.
+template <class T> class ForkSafe {
+  static std::atomic<T*>& slot() { static std::atomic<T*> p{nullptr}; return p; }
+  static void forget() { slot().store(nullptr, std::memory_order_relaxed); }      // in the child, single-threaded
+ public:
+  static T& get() {
+    T* p = slot().load(std::memory_order_acquire);
+    if (!p) {
+      static std::once_flag registered;
+      std::call_once(registered, [] { pthread_atfork(nullptr, nullptr, &ForkSafe<T>::forget); });
+      T* fresh = new T;
+      if (slot().compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;
+      else delete fresh;                 // another thread was first
+    }
+    return *p;
+  }
+};
+
 class BatchPool {
   std::mutex mu_;
   Batch* kept_ = nullptr;
@@ -721,14 +746,14 @@ class BatchPool {
   }
   void give(Batch* b) {
     if (!b) return;
-    if (b->footprint() <= (size_t(2) << 30)) {
+    if (b->footprint() <= (size_t(768) << 20)) {
       std::lock_guard<std::mutex> lock(mu_);
       if (!kept_) { kept_ = b; return; }
     }
     delete b;
   }
 };
-BatchPool& batch_pool() { static BatchPool* pool = new BatchPool; return *pool; }
+BatchPool& batch_pool() { return ForkSafe<BatchPool>::get(); }
 
 // What a worker needs while it scans circuit after circuit.  Kept in a process-wide pool between calls, so that a run() of a
 // VQE loop (thousands of calls, blackwater/library/ngem/estimator.py:49-84) does not grow half-megabyte vectors from nothing
@@ -757,7 +782,7 @@ class ScratchPool {
   }
 };
 
-ScratchPool& scratch_pool() { static ScratchPool pool; return pool; }
+ScratchPool& scratch_pool() { return ForkSafe<ScratchPool>::get(); }
 
 // Worker threads when the caller names none: the host's hardware threads up to 64 (a text scan is 60 ns per statement per thread,
 // and a 1024-circuit run() of 100-qubit circuits has 11 M statements: 16 threads took 42 ms of an 88 ms run()), or
@@ -856,7 +881,7 @@ class WorkerPool {
   }
 };
 
-WorkerPool& worker_pool() { static WorkerPool* pool = new WorkerPool; return *pool; }
+WorkerPool& worker_pool() { return ForkSafe<WorkerPool>::get(); }
 
 // fn(i, scratch) for i in [0, count) on `threads` host threads; the first failure (lowest index wins among those seen) is kept
 template <typename Fn>

@@ -788,10 +788,7 @@ static int launch_head_fwd(Mlp1Args a, void* workspace, hipStream_t s) {
   const size_t lds = (size_t)head_image_u32x4(G) * sizeof(u32x4);
   void (*kernel)(Mlp1Args);
   if constexpr (BF16) kernel = mlp1_fwd_bf16_kernel<G>; else kernel = mlp1_fwd_f32_kernel<G>;
-  static const int once = [&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
-  }();
-  if (!once) return MLQEM_ERR_LAUNCH;
+  if (!ensure_dynamic_lds(kernel, lds)) return MLQEM_ERR_LAUNCH;      // per device (common.hpp)
   static const int res = head_resident_workgroups(kernel, kFwdThreads, lds);
   a.image = workspace;
   hipLaunchKernelGGL(mlp1_image_kernel<BF16>, dim3((unsigned)ceil_div(head_image_u32x4(G) * 4, 256)), dim3(256), 0, s, a, G,

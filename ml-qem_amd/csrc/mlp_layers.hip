@@ -1264,10 +1264,7 @@ template <int G2, bool IN_BF16>
 static int launch_layer_fwd(LayerArgs a, void* workspace, hipStream_t s) {
   const size_t lds = (size_t)layer_image_u32x4(G2) * sizeof(u32x4);
   auto kernel = layer_fwd_kernel<G2, IN_BF16>;
-  static const int once = [&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
-  }();
-  if (!once) return MLQEM_ERR_LAUNCH;
+  if (!ensure_dynamic_lds(kernel, lds)) return MLQEM_ERR_LAUNCH;      // per device (common.hpp)
   static const int res = layer_resident(kernel, kLayerThreads, lds);
   a.image = workspace;
   hipLaunchKernelGGL(layer_image_kernel, dim3((unsigned)ceil_div(layer_image_u32x4(G2) * 4, 256)), dim3(256), 0, s, a, G2, static_cast<u32x4*>(workspace));
@@ -1420,9 +1417,7 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
     const bool dma_ok = aligned_to(dy, 16) && aligned_to(x, 16);      // the DMA forms move 16 bytes per lane
     if (x_is_bf16 && lds_form == 2 && dma_ok) {    // the transposing-read form (default): see layer_wgrad_tr_kernel
       const size_t lds = (size_t)kTrSlabs * kDmaSlabBytes;
-      static const int once = hipFuncSetAttribute(reinterpret_cast<const void*>(layer_wgrad_tr_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
-      if (!once) return MLQEM_ERR_LAUNCH;
+      if (!ensure_dynamic_lds(layer_wgrad_tr_kernel, lds)) return MLQEM_ERR_LAUNCH;      // per device (common.hpp)
       static const int rl = layer_resident(layer_wgrad_tr_kernel, kLayerThreads, lds);
       G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(rl, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
       hipLaunchKernelGGL(layer_wgrad_tr_kernel, dim3(G), dim3(kLayerThreads), lds, s, a);
@@ -1432,7 +1427,7 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
     if (x_is_bf16 && lds_form && dma_ok) {
       auto go = [&](auto kernel, int slabs) {
         const size_t lds = (size_t)slabs * kDmaSlabBytes;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (!ensure_dynamic_lds(kernel, lds)) return false;
         const int rl = layer_resident(kernel, kLayerThreads, lds);
         G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(rl, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
         hipLaunchKernelGGL(kernel, dim3(G), dim3(kLayerThreads), lds, s, a, cpw);
@@ -1499,10 +1494,7 @@ template <int NJ, int NOB>
 static int launch_layer_fwd_f32(LayerF32Args a, void* workspace, hipStream_t s) {
   const size_t lds = (size_t)layer_f32_image_float4(NJ, NOB) * sizeof(float4);
   auto kernel = layer_fwd_f32_kernel<NJ, NOB>;
-  static const int once = [&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
-  }();
-  if (!once) return MLQEM_ERR_LAUNCH;
+  if (!ensure_dynamic_lds(kernel, lds)) return MLQEM_ERR_LAUNCH;      // per device (common.hpp)
   static const int res = layer_resident(kernel, kF32Threads, lds);
   a.image = workspace;
   hipLaunchKernelGGL(layer_f32_image_kernel, dim3((unsigned)ceil_div(layer_f32_image_float4(NJ, NOB) * 4, 256)), dim3(256), 0, s, a, NJ, NOB,
@@ -1557,10 +1549,14 @@ extern "C" int mlqem_layer_wgrad_f32(const float* dy, const float* x, int64_t ld
     // persistent workgroups: exactly as many as are resident at once (at 210 registers two waves share a SIMD: eight waves per CU)
     static const int q_env = getenv("MLQEM_LAYER_WGRAD_Q") ? atoi(getenv("MLQEM_LAYER_WGRAD_Q")) : 8;
     const bool q4 = q_env == 4;
-    int per_cu = 0;
-    if ((q4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel<4>, n_waves * kWave, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel<8>, n_waves * kWave, 0)) != hipSuccess || per_cu < 1)
-      per_cu = 1;
+    static int per_cu_of[8] = {};                    // by workgroup size (1..6 waves): asked of the runtime once, not per call
+    int per_cu = per_cu_of[n_waves & 7];
+    if (per_cu == 0) {
+      if ((q4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel<4>, n_waves * kWave, 0)
+              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_wgrad_f32_kernel<8>, n_waves * kWave, 0)) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+      per_cu_of[n_waves & 7] = per_cu;
+    }
     const int64_t want = (int64_t)cus * per_cu;
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cap), std::max<int64_t>(N / 32, 1)));
     if (q4) hipLaunchKernelGGL(layer_wgrad_f32_kernel<4>, dim3(G), dim3(n_waves * kWave), 0, s, a);

@@ -257,13 +257,4 @@ __device__ __forceinline__ float wave_reduce16(const float (&v)[16], int lane) {
   return r + __shfl_xor(r, 32, 64);
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: remembered per (device, kernel) so that a process
-// that drives several GPUs raises the limit on each of them and a launch path pays one table lookup
-bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes);      // tile_plan.hip
-template <class K> inline bool ensure_dynamic_lds(K kernel, size_t bytes) {
-  if (bytes <= 48 * 1024) return true;
-  if (bytes > 160 * 1024) return false;
-  return ensure_dynamic_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
-}
-
 }  // namespace mlqem

@@ -27,7 +27,7 @@ bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes) {
     e = &table[used++];
     e->f = kernel;
   }
-  if (e->have[dev] >= bytes) return true;
+  if (e->have[dev] >= bytes || bytes <= 48 * 1024) return true;      // (the default limit serves small requests)
   if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
     (void)hipGetLastError();
     return false;

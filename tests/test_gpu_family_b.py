@@ -448,6 +448,34 @@ def test_list_coarsening_with_a_structural_capacity_equals_the_exact_one(golden_
     assert e <= min(t[:2]) and max(t) <= cap
 
 
+def test_list_coarsening_raises_its_overflow_flag_when_the_capacity_is_no_bound():
+    """with a capacity the list form reads nothing back and DROPS a list that would leave its buffer; the flag the kernels
+    raise must reach the host (ops.check_overflow_flags: epoch ends, MLQEM_SYNC_OPS) instead of a silently truncated graph."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import TfimCorpus
+    from blackwater.native import _lib, ops
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    h = TfimCorpus(100, [2, 5], 1, seed=5, exp_value_size=4).host_graphs()
+    arena = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"], device=DEV)
+    batch = arena.batch(np.arange(len(arena)))
+    s = batch.structure
+    torch.manual_seed(2)
+    model = ExpValCircuitGraphModel(22, 15).to(DEV).eval()
+    ops.check_overflow_flags()                         # whatever earlier tests left
+    with torch.no_grad():
+        g = model.transformer1(batch.nodes, s)
+        _, s1, _ = model.pooling1(g, s)
+        s1.in_ptr                                      # builds the coarsened graph within the structural capacity
+        ops.check_overflow_flags()                     # ... which is a bound: nothing raised
+        s.coarse_capacity = 4096                       # far below the real edge total
+        _, s1_small, _ = model.pooling1(g, s)
+        s1_small.in_ptr
+    with pytest.raises(_lib.NativeLibraryError, match="capacity overflow"):
+        ops.check_overflow_flags()
+    ops.check_overflow_flags()                         # read once, cleared
+
+
 def test_family_b_train_step_makes_no_device_to_host_copy(golden_dir, g1):
     """A Family B train step on an arena batch of small graphs enqueues without a single device->host read: checked by
     making every synchronising call an error (torch.cuda.set_sync_debug_mode) around the step."""

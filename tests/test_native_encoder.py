@@ -243,3 +243,29 @@ def test_fast_statement_path_equals_the_general_path(g1, lima_props, tmp_path):
     for key in res["1"]:
         a, b = res["1"][key], res["0"][key]
         assert a.shape == b.shape and (a == b).all(), key
+
+
+def test_encoding_after_fork_does_not_wait_for_the_parents_workers(g1, lima_props):
+    """the process-wide worker pool must not be inherited across fork() -- the child has none of its threads.  The parent
+    encodes with helper threads, forks, and the child encodes the same batch again (a DataLoader / multiprocessing worker started by
+    fork does this); the child must finish (an alarm ends a hung one) and produce the parent's arrays."""
+    import signal
+
+    import torch
+
+    enc = NativeEncoder(dict(lima_props, gates_set=G1_GATES_ORDER))
+    texts = list(g1["qasm"][:48])
+    want = enc.encode_batch(texts, threads=4)
+    pid = os.fork()
+    if pid == 0:                                  # the child: exit codes only, no pytest machinery
+        code = 3
+        try:
+            signal.alarm(20)
+            got = enc.encode_batch(texts, threads=4)
+            code = 0 if all(torch.equal(a, b) for a, b in zip(want[:3], got[:3])) else 2
+        finally:
+            os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, f"child status {status} (ended by the alarm = it hung)"
+    again = enc.encode_batch(texts, threads=4)   # the parent's pool is untouched
+    assert all(torch.equal(a, b) for a, b in zip(want[:3], again[:3]))
