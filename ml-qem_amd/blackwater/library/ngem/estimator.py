@@ -22,11 +22,11 @@ from ...exception import BlackwaterException
 from ..primitives import job_base, make_estimator_result, model_device, transpile_and_bind
 
 
-# MLQEM_NGEM_NATIVE=0: the serial path encodes with the Python walk (circuit_to_graph_data_json) whatever the circuit's type
-_NATIVE_SERIAL = os.environ.get("MLQEM_NGEM_NATIVE", "1") != "0"
-# MLQEM_ENCODE_EXPAND=0: the batched path fills float32 rows and int64 indices on the host (1.3 GB per 1024 100-qubit circuits)
-# instead of uploading the compact op stream and expanding it on the device
-_EXPAND_ON_DEVICE = os.environ.get("MLQEM_ENCODE_EXPAND", "1") != "0"
+
+
+# False: the serial path encodes with the Python walk (circuit_to_graph_data_json) whatever the circuit's type -- the form the native
+# encoder is compared with (tests/test_estimators.py sets it)
+_NATIVE_SERIAL = True
 
 
 def _qasm_text(bound):
@@ -118,7 +118,7 @@ class NgemJob(job_base()):  # type: ignore[misc]
         for value, circuit, obs, params in zip(result.values, self._circuits, self._observables, self._parameter_values):
             if not is_pauli_observable(obs):
                 raise BlackwaterException("Only `PauliSumOp` observables are supported by NGEM.")
-            bound = transpile_and_bind(circuit, self._backend, params, _options_dict(self._options), keep_text=True)
+            bound = transpile_and_bind(circuit, self._backend, params, _options_dict(self._options), keep_text=_NATIVE_SERIAL)
             texts.append(bound if isinstance(bound, str) else circuit_to_qasm(Circuit.from_any(bound)))
             values.append([float(value)])
             # needs observables of one shape, which a run() over one operator family has; an operator OBJECT that appears many times
@@ -129,7 +129,7 @@ class NgemJob(job_base()):  # type: ignore[misc]
                 enc = encoded[id(obs)] = np.asarray(encode_pauli_sum_op(obs), dtype=np.float32)
             observables.append(enc)
         on_gpu = device is not None and torch.device(device).type == "cuda"
-        if on_gpu and _EXPAND_ON_DEVICE:
+        if on_gpu:
             # the host scans the texts into a compact op stream (16 bytes per op); rows, edges and offsets are made on the device
             x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch_expand(texts, device)
         elif on_gpu:    # groups of circuits are written and uploaded in turn: the copy of one overlaps the encoding of the next

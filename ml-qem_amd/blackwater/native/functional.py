@@ -114,12 +114,8 @@ class _Seq2(Function):
         return gx, gw1, gb1, gw2, gb2, None, None
 
 
-# MLQEM_SEQ2_FUSED=0: the two Linear layers, the dropout and their gradients as separate launches (A/B)
-_SEQ2_FUSED = os.environ.get("MLQEM_SEQ2_FUSED", "1") != "0"
-
-
 def seq2_fused_ok(x, w1, w2) -> bool:
-    return _SEQ2_FUSED and torch.is_tensor(x) and x.dim() in (2, 3) and ops.seq2_fits(x.reshape(-1, x.shape[-1]), w1, w2)
+    return torch.is_tensor(x) and x.dim() in (2, 3) and ops.seq2_fits(x.reshape(-1, x.shape[-1]), w1, w2)
 
 
 def seq2(x, w1, b1, w2, b2, drop_p=0.0, seed=0):
@@ -151,7 +147,7 @@ class _MLP1(Function):
 def mlp1_fused_ok(x, w1, w2) -> bool:
     """Whether ``mlp1`` can take this call: a GPU feature matrix that needs no gradient, widths inside the kernel's limits."""
     return (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and not x.requires_grad
-            and ops.mlp1_fits(w1.shape[1], w1.shape[0], w2.shape[0]) and os.environ.get("MLQEM_MLP1_FUSED", "1") != "0")
+            and ops.mlp1_fits(w1.shape[1], w1.shape[0], w2.shape[0]))
 
 
 def mlp1(x, w1, b1, w2, b2, mfma="f32"):
@@ -250,11 +246,7 @@ def mlp_trunk_bf16_ok(x, fc1, fc2, fc3, fc4, bn1, bn2) -> bool:
     for bn in (bn1, bn2):
         if bn.weight is None or bn.momentum is None:
             return False
-    return os.environ.get("MLQEM_MLP_BF16_STORAGE", "1") != "0"
-
-
-# MLQEM_MLP_F32_LAYERS=0: the fp32 models' training step on the general kernels again (linear + bn.hip + relu_dropout; A/B)
-_MLP_F32_LAYERS = os.environ.get("MLQEM_MLP_F32_LAYERS", "1") != "0"
+    return True
 
 
 def mlp_trunk_bf16(x, fc1, bn1, fc2, bn2, fc3, fc4, p_trunk, p_tail, seeds, f32=False):
@@ -581,7 +573,7 @@ class _GCNLayer(Function):
                                dself=s.derived("gcn_dself"))
         if blocks_only:
             return [gh, _padded_rows(g)]
-        if (_FUSE_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.x_gate_scale is not None
+        if (ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.x_gate_scale is not None
                 and max(w.shape) <= 12 and ops._fused_bwd_ok(gh, g, x)):
             # hidden layer of width <= 12 (conv2): gated data gradient, weight and bias gradient from ONE pass over gh, x, g
             gx, gw, gb, ctx.gx_colsum = ops.linear_bwd_fused(gh, x, w.contiguous(), gb_src=g, gate_scale=ctx.x_gate_scale)
@@ -650,8 +642,6 @@ class _TransformerConv(Function):
         # aligned 64-byte piece).  The projection writes that layout by itself when its weight and bias rows are padded the same way
         # (zero rows: the pads of qkvs are zeros, the gradient of a pad row is exactly zero); w itself stays [4 H C, in].
         cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and w.is_cuda) else 0
-        if cp and struct.out_eid is not None and not _ATTN_PITCH_LINKED:       # (A/B: the pitch on coarsened graphs only)
-            cp = 0
         if tiled:
             cp = 16 if channels < 16 else 0
         ctx.cp = cp
@@ -723,33 +713,25 @@ def _pad_heads(w, b, groups, channels, cp):
 # gathers, and a tile's prologue + staging round trips cost what a whole per-edge launch does); tests/test_gpu_tiles.py keeps the path
 # correct against the per-edge kernels and the oracle.
 _TILES = os.environ.get("MLQEM_TILES", "0") == "1"
-# MLQEM_ATTN_PITCH=0: compact heads inside q / k / v / skip (the layout of rounds 1-3; A/B)
-_ATTN_PITCH = int(os.environ.get("MLQEM_ATTN_PITCH", "16"))
-# MLQEM_ATTN_PITCH_LINKED=0: graphs that come with edge links (the circuit DAGs: stored source-side backward) keep compact heads
-_ATTN_PITCH_LINKED = os.environ.get("MLQEM_ATTN_PITCH_LINKED", "1") != "0"
+# channel pitch of a head inside q / k / v / skip in training (0: compact heads, the layout of rounds 1-3; the parity test of the two
+# layouts sets it)
+_ATTN_PITCH = 16
 
 
 def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
     return _TransformerConv.apply(x, w, b, struct, heads, channels, drop_p, seed)
 
 
-# MLQEM_ASAP_DENSE=0 forces the general two-hop coarsening (four device->host size reads per pooling) for every batch; the
-# default uses the sync-free dense form whenever every graph of the batch pools to <= 512 clusters.
-_ASAP_DENSE = os.environ.get("MLQEM_ASAP_DENSE", "1") != "0"
-# MLQEM_ASAP_ROWS=0 keeps the two-hop path for graphs too large for the dense form (default: the wave-per-cluster form)
-_ASAP_ROWS = os.environ.get("MLQEM_ASAP_ROWS", "1") != "0"
-# MLQEM_ASAP_LISTS=0: the wave-per-cluster form with dense bit matrices in global memory (round 3) instead of sorted lists (A/B)
-_ASAP_LISTS = os.environ.get("MLQEM_ASAP_LISTS", "1") != "0"
-# MLQEM_ASAP_COMPOSE=0: ASAPooling's query projection lin() as its own [N,D]x[D,D] GEMM (forward and backward) instead of composed
-# into the one-wide score projection that is its only consumer (A/B; the two differ by fp32 rounding order, ~1e-7)
-_ASAP_COMPOSE = os.environ.get("MLQEM_ASAP_COMPOSE", "1") != "0"
-# MLQEM_ASAP_LINK=1: the list coarsening also links every out-entry to its in-CSR twin (out_eid; 0.55 ms for 64 100-qubit
-# circuits) and the backward kernels on the coarsened graph take the stored form; default: no out_eid, recomputed form
-_ASAP_LINK = os.environ.get("MLQEM_ASAP_LINK", "0") == "1"
-# MLQEM_ASAP_TIES=0: the segment max's backward counts its ties in a walk of its own (A/B)
-_ASAP_TIES = os.environ.get("MLQEM_ASAP_TIES", "1") != "0"
-# MLQEM_ASAP_LAZY=0 computes the coarsened connectivity inside ASAPooling's forward even when no later layer reads it
-_ASAP_LAZY = os.environ.get("MLQEM_ASAP_LAZY", "1") != "0"
+# Which form of the coarsening S^T (A S) a pooling takes, by the batch's graph sizes: the sync-free dense form when every graph pools to
+# <= 512 clusters, the sorted-list form for larger graphs, the wave-per-cluster bit-matrix form when the lists would not fit 32-bit
+# places, the general two-hop path (four device->host size reads) otherwise.  All forms yield identical arrays; these module
+# attributes exist so that the tests can force one form and compare it with another (tests/test_gpu_family_b.py).
+_ASAP_DENSE = True
+_ASAP_ROWS = True
+_ASAP_LISTS = True
+# True: the list coarsening also links every out-entry to its in-CSR twin (out_eid; 0.55 ms for 64 100-qubit circuits) and the
+# backward kernels on the coarsened graph take the stored form; default: no out_eid, recomputed form
+_ASAP_LINK = False
 
 
 # Graph boundaries of pooled batches on the device, by content.  Batches of a training run repeat their size patterns (the
@@ -802,22 +784,20 @@ class _ASAPool(Function):
         b3 = torch.cat([l1_b, l1_b * 0.0, l3_b], 0)      # lin2 has no bias (a multiply, not a memset: the step may be captured)
         # the input graph's rows share their sources (it is itself a coarsened graph): segment max, composed score, softmax-sum and
         # LEConv's projections in ONE tiled pass (csrc/tile_pool.hip)
-        tiled = _TILES and _ASAP_COMPOSE and s.tiled and x.is_cuda and ops.tile_pool_fits(d)
+        tiled = _TILES and s.tiled and x.is_cuda and ops.tile_pool_fits(d)
         ctx.tiled = tiled
         stat = None
         if tiled:
             w_comp = (att_q.t() * lin_w).sum(0, keepdim=True)
             b_comp = (att_q[0] * lin_b).sum().reshape(1) + att_b
-            xq = a_dst = None
+            a_dst = None
             c_src = ops.linear(x, att_x)[:, 0].contiguous()
             x_new, xq_raw, stat, pqr = ops.tile_asap_scores(x, s.in_ptr, s.in_src, c_src, w_comp[0].contiguous(), b_comp, w3, b3, slope,
                                                             s.tile_plan("in"))
             fitness = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
         else:
             xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
-        if tiled:
-            pass
-        elif _ASAP_COMPOSE:
+        if not tiled:
             # ASAPooling's query x_q = lin(segmax) feeds ONLY the one-wide score a_i = att_q . x_q[i] + att_b (SURVEY appendix
             # B.2 steps 2-3): a_i = (att_q W) . segmax[i] + (att_q . b + att_b) -- one row dot of the segment max against a composed
             # 45-vector.  x_q [N, D] is never formed (a [N,D]x[D,D] GEMM forward; a data GEMM and a [D,D] weight-gradient pass
@@ -825,12 +805,7 @@ class _ASAPool(Function):
             # (element-wise products and sums, not BLAS calls: D x D work, deterministic, capturable)
             w_comp = (att_q.t() * lin_w).sum(0, keepdim=True)      # [1, D] = att_q W
             b_comp = (att_q[0] * lin_b).sum().reshape(1) + att_b   # [1]
-            xq = None
             a_dst = ops.linear(xq_raw, w_comp.contiguous(), b_comp)[:, 0].contiguous()
-        else:
-            w_comp = None
-            xq = ops.linear(xq_raw, lin_w.contiguous(), lin_b)
-            a_dst = ops.linear(xq, att_q, att_b)[:, 0].contiguous()
         if not tiled:
             c_src = ops.linear(x, att_x)[:, 0].contiguous()
             x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
@@ -873,15 +848,10 @@ class _ASAPool(Function):
                 num_edges = int(ei.shape[1])
             return (csr[0], csr[1], csr[2], csr[3], csr[4], num_edges, csr.out_eid), slot
 
-        if _ASAP_LAZY:
-            # the coarsened connectivity S^T A S waits until a layer reads it (GraphStructure.deferred); the backward's
-            # slot[] (cluster id of every kept centre, -1 elsewhere) does not depend on it
-            slot = ops.asap_slot_map(perm, n)
-            holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=keep)
-        else:
-            csr7, slot = build()
-            holder["structure"] = GraphStructure(k_total, csr7[0], csr7[1], csr7[2], csr7[3], csr7[4], new_ptr, s.num_graphs,
-                                                 num_edges=csr7[5], graph_sizes=keep, out_eid=csr7[6])
+        # the coarsened connectivity S^T A S waits until a layer reads it (GraphStructure.deferred); the backward's slot[] (cluster id of
+        # every kept centre, -1 elsewhere) does not depend on it
+        slot = ops.asap_slot_map(perm, n)
+        holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=keep)
         if (_TILES and use_rows and use_lists and not link and len(keep) > 0 and ops.asap_dense_max_k() < int(keep.max())):
             # large graphs (the list coarsening's): clusters whose centres are close in program order share their neighbours, so
             # the layers that read this graph walk it in tiles of rows ordered by their centres' node index
@@ -892,14 +862,13 @@ class _ASAPool(Function):
             holder["structure"].set_tile_spec(tile_spec)
         holder["perm"] = perm
         ctx.struct, ctx.slope, ctx.d = s, slope, d
-        ctx.composed = xq is None
-        ctx.save_for_backward(x, xq_raw, w_comp if xq is None else xq, stat if tiled else a_dst, c_src, x_new, fitness, slot, lin_w, att_w,
+        ctx.save_for_backward(x, xq_raw, w_comp, stat if tiled else a_dst, c_src, x_new, fitness, slot, lin_w, att_w,
                               w3, lin_b)
         return x_out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, xq_raw, xq, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b = ctx.saved_tensors
+        x, xq_raw, w_comp, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b = ctx.saved_tensors
         s, d = ctx.struct, ctx.d
         e = s.edge_count()
         dev = x.device
@@ -916,41 +885,24 @@ class _ASAPool(Function):
         att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
         # c = x att_x^T: its gradient g_c (x) att_x rides in the source-side kernel's store of gx (it computes g_c itself) instead of
         # being a read-modify-write pass over gx
-        ties = None
         if ctx.tiled:        # a_dst holds the forward's per-row record; the segment max's backward is part of the call
-            gx, g_a, g_c = ops.tile_asap_scores_bwd(x, x_new, gxnew, xq_raw, s, c_src, xq[0].contiguous(), att_x[0].contiguous(), ctx.slope,
+            gx, g_a, g_c = ops.tile_asap_scores_bwd(x, x_new, gxnew, xq_raw, s, c_src, w_comp[0].contiguous(), att_x[0].contiguous(), ctx.slope,
                                                     s.tile_plan("in"), s.tile_plan("out"), a_dst)
-        elif _ASAP_TIES:
-            gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0])
         else:
-            (gx, g_a, g_c), ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, gx_rank1=att_x[0]), None
+            gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0])
         g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
         g_att_x = torch.empty_like(att_x)
         ops.linear_wgrad(g_c2, x, g_att_x, None)
-        if ctx.composed:
-            w_comp = xq                                                              # a = xq_raw w_comp^T + b_comp, w_comp = att_q W
-            g_xq_raw = None                                                          # = g_a (x) w_comp: formed inside the segment max's backward
-            g_w_comp = torch.empty_like(w_comp)
-            g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
-            ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
-            g_att_q = (g_w_comp * lin_w).sum(1).unsqueeze(0) + g_att_b * lin_b.unsqueeze(0)   # w_comp = att_q W, b_comp = att_q . b + att_b
-            g_lin_w = att_q.t() * g_w_comp
-            g_lin_b = g_att_b * att_q[0]
-        else:
-            g_xq = ops.linear(g_a2, att_q, transposed=True)                              # a = xq att_q^T + b
-            g_att_q = torch.empty_like(att_q)
-            g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
-            ops.linear_wgrad(g_a2, xq, g_att_q, g_att_b)
-            g_xq_raw = ops.linear(g_xq, lin_w.contiguous(), transposed=True)             # xq = xq_raw W^T + b
-            g_lin_w = torch.empty_like(lin_w)
-            g_lin_b = torch.empty(lin_w.shape[0], dtype=torch.float32, device=dev)
-            ops.linear_wgrad(g_xq, xq_raw, g_lin_w, g_lin_b)
-        if ctx.tiled:
-            pass
-        elif g_xq_raw is None:
+        # a = xq_raw w_comp^T + b_comp with w_comp = att_q W, b_comp = att_q . b + att_b: the gradients of lin and of att's query half
+        # by the chain rule on D x D tensors; the segment max's gradient g_a (x) w_comp is formed inside its backward kernel
+        g_w_comp = torch.empty_like(w_comp)
+        g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
+        g_att_q = (g_w_comp * lin_w).sum(1).unsqueeze(0) + g_att_b * lin_b.unsqueeze(0)
+        g_lin_w = att_q.t() * g_w_comp
+        g_lin_b = g_att_b * att_q[0]
+        if not ctx.tiled:
             ops.csr_segment_max_bwd_(gx, x, xq_raw, None, s, ties=ties, gmax_rank1=(g_a, w_comp[0].contiguous()))
-        else:
-            ops.csr_segment_max_bwd_(gx, x, xq_raw, g_xq_raw, s, ties=ties)      # xq_raw = segment max of x
         g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],
                 None, None, None, None)
@@ -971,12 +923,6 @@ def asap_pool(x, mod, struct):
 # small graphs is host-bound).  This node runs the very same layer code -- each layer's forward/backward static methods
 # are called with a private context object -- so the arithmetic and the launch sequence do not change.
 _side_streams = {}
-# MLQEM_FUSE_FIRST=0: every branch projects x with its own GEMM and runs its own weight-gradient pass (three reads of the
-# feature rows per direction instead of one); kept for measurements.
-_FUSE_FIRST = os.environ.get("MLQEM_FUSE_FIRST", "1") != "0"
-# MLQEM_FUSE_NARROW_BWD=0: data gradient and weight gradient of GCN layer 2 as two kernels (each reading gh and x) instead of
-# the one-pass mlqem_linear_bwd_fused_f32
-_FUSE_NARROW_BWD = os.environ.get("MLQEM_FUSE_NARROW_BWD", "1") != "0"
 
 
 def _branch_streams(device):
@@ -1003,10 +949,6 @@ class _LayerCtx:
 
     def save_for_backward(self, *tensors):
         self.saved_tensors = tensors
-
-
-# MLQEM_BIAS_FROM_PRODUCER=0: conv1's bias gradient from a seventh block of the first-layer weight-gradient pass (A/B)
-_BIAS_FROM_PRODUCER = os.environ.get("MLQEM_BIAS_FROM_PRODUCER", "1") != "0"
 
 
 class _FamilyAGraph(Function):
@@ -1049,7 +991,7 @@ class _FamilyAGraph(Function):
         # The first layer of every branch projects the SAME x: one GEMM over six output blocks reads x once instead of
         # three times (GCN: dinv * x W^T | Cheb: x (W_0 - W_2)^T + b, x W_1^T, x W_2^T | SAGE: x W_l^T, x W_r^T + b), and in the
         # backward ONE weight-gradient pass over x serves all seven gradient blocks (see backward).
-        fuse = ctx.fuse = _FUSE_FIRST and x.shape[1] <= _PARTS_MAX_COLS and 6 * ((g1w.shape[0] + 3) // 4 * 4) <= 96
+        fuse = ctx.fuse = x.shape[1] <= _PARTS_MAX_COLS and 6 * ((g1w.shape[0] + 3) // 4 * 4) <= 96
         pre_g = pre_c = pre_s = None
         if fuse:
             xr = _padded_rows(ops.rowmajor(x))
@@ -1116,7 +1058,7 @@ class _FamilyAGraph(Function):
         t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
         # conv1's bias gradient is the column sum of the gradient conv2's backward just wrote: taken there, the first-layer
         # weight-gradient pass below reads six blocks instead of seven
-        g1b_cs = getattr(L["g2"], "gx_colsum", None) if _BIAS_FROM_PRODUCER else None
+        g1b_cs = getattr(L["g2"], "gx_colsum", None)
         fuse = ctx.fuse
         if fuse:
             bg = _GCNLayer.backward(L["g1"], t, blocks_only=True)            # [gh, g]

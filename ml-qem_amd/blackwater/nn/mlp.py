@@ -93,7 +93,7 @@ class MLP2(nn.Module):
         reference's arithmetic): the same kernels with fp32 storage and unrounded operands.  None when the shapes are not theirs."""
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        f32 = self.mfma == "f32" and F._MLP_F32_LAYERS
+        f32 = self.mfma == "f32"
         if not (self.training and (self.mfma == "bf16" or f32) and F.mlp_trunk_bf16_ok(x2, self.fc1, self.fc2, self.fc3, fc4, self.bn1, self.bn2)):
             return None
         from .models import dropout_key

@@ -144,7 +144,7 @@ class Trainer:
             from .native import ops
 
             ops.prepare_device(opt_params[0].device)      # per-device launch state exists before anything is captured
-        if flat and fused and os.environ.get("MLQEM_TORCH_ADAM", "0") != "1":
+        if flat and fused:
             # one native launch over the flat buffer, step count and learning rate on the device (capturable either way)
             self.optimizer = FlatAdam(opt_params, lr=lr)
         elif capturable:   # step count and learning rate live on the device: the update can sit inside a captured hipGraph
@@ -155,7 +155,7 @@ class Trainer:
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", factor=0.1, patience=15,
                                                                     min_lr=1e-5)
         self.criterion = nn.MSELoss()
-        self._fused_loss = os.environ.get("MLQEM_TORCH_MSE", "0") != "1"      # A/B switch: torch's MSELoss kernels instead of optim.hip's
+        self._fused_loss = True                # optim.hip's one-launch MSE loss + gradient (a subclass with another criterion clears it)
         # The host enqueues a step several times faster than the device runs it.  Unbounded run-ahead makes torch's caching
         # allocator grow without end on the multi-stream path: blocks handed between the branch streams can only be reused
         # after their recorded events have completed, so every step queued ahead needs its own copy of the activations and
@@ -378,6 +378,7 @@ class RowsTrainer(Trainer):
         from .native import ops
 
         self.graphs = graphs
+        self.fused_mlp1_step = True        # MLP1: image -> forward -> backward -> second stage -> Adam, nothing of autograd (False: the autograd path; tests compare the two)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.flat_param.device)
         ops.set_seed_counter(self.counter)
         model.static_dropout_key = True
@@ -409,7 +410,7 @@ class RowsTrainer(Trainer):
         m = self.model
         return (type(m) is MLP1 and self._fused_loss and not self.distributed and self.flat_grad is not None
                 and type(self.criterion) is nn.MSELoss and self.criterion.reduction == "mean"
-                and os.environ.get("MLQEM_MLP1_FUSED_STEP", "1") != "0"
+                and self.fused_mlp1_step
                 and torch.is_tensor(batch.x) and batch.y.dim() == 2 and batch.y.dtype == torch.float32 and batch.y.shape[0] == batch.x.shape[0]
                 and batch.x.shape[0] > 0 and F.mlp1_fused_ok(batch.x, m.fc1.weight, m.fc2.weight))
 

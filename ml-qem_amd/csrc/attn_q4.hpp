@@ -175,10 +175,8 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
   }
 }
 
-// MLQEM_ATTN_Q4=0: the 16-lane (one channel per lane) kernels (A/B)
-inline bool attn_q4_enabled() {
-  static const bool on = !(getenv("MLQEM_ATTN_Q4") && atoi(getenv("MLQEM_ATTN_Q4")) == 0);
-  return on;
-}
+// the four-channels-per-lane kernels serve every shape the one-channel-per-lane forms do (C <= 32); the latter stay as the reference the
+// q4 forms were first checked against (attn_fwd.hpp, family_b_bwd.hip) and are no longer launched
+inline bool attn_q4_enabled() { return true; }
 
 }  // namespace mlqem

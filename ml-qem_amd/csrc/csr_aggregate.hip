@@ -608,9 +608,9 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
   if (a.CV > kBlock) return MLQEM_ERR_UNSUPPORTED;
   // items per thread: measured best on MI355X (C = 10 and 22, 2.8M-node batch): 4 for the CSR walk (more loads in
   // flight per thread outweigh 6 waves/SIMD), 2 for the ELL-assisted kernel (8 waves/SIMD).  MLQEM_AGG_IPT overrides.
-  static const int nt_env = getenv("MLQEM_AGG_NT") ? atoi(getenv("MLQEM_AGG_NT")) : 1;  // streaming stores (-8 % measured)
+  constexpr int nt_env = 1;      // (was the A/B switch MLQEM_AGG_NT: settled)  // streaming stores (-8 % measured)
   a.nt = nt_env;
-  static const int ipt_env = getenv("MLQEM_AGG_IPT") ? atoi(getenv("MLQEM_AGG_IPT")) : 0;
+  constexpr int ipt_env = 0;      // (was the A/B switch MLQEM_AGG_IPT: settled)
   const int ipt = ipt_env > 0 ? ipt_env : (a.ell ? 2 : 4);
   a.R = std::min(kRowsMax, kBlock * ipt / a.CV);
   const int64_t blocks = ceil_div(a.N, a.R);
@@ -630,13 +630,13 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
     hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)ceil_div((int64_t)grid.x, kBlock)), dim3(kBlock), 0, stream, pool->gptr, pool->B,
                        a.R, (int64_t)grid.x, const_cast<int2*>(pool->tile_graph), pool->mask ? pool->tile_info : nullptr);
     if constexpr (!IS_MAX) {
-      static const int pool_waves = getenv("MLQEM_AGG_POOL_WAVES") ? atoi(getenv("MLQEM_AGG_POOL_WAVES")) : 7;
+      constexpr int pool_waves = 7;      // (was the A/B switch MLQEM_AGG_POOL_WAVES: settled)
       if (pool_waves >= 7) hipLaunchKernelGGL((csr_aggregate_ell_kernel<4, false, 2, true, 7, true>), grid, block, 0, stream, a, *pool);
       else hipLaunchKernelGGL((csr_aggregate_ell_kernel<4, false, 2, true, 6, true>), grid, block, 0, stream, a, *pool);
     }
     return launch_status();
   }
-  static const int epi_waves = getenv("MLQEM_AGG_EPI_WAVES") ? atoi(getenv("MLQEM_AGG_EPI_WAVES")) : 7;   // measured: 7 -> 304/351 us, 6 -> 341/385, 8 (spilling) -> 356/385 (GCN / Cheb forward)
+  constexpr int epi_waves = 7;      // (was the A/B switch MLQEM_AGG_EPI_WAVES: settled)   // measured: 7 -> 304/351 us, 6 -> 341/385, 8 (spilling) -> 356/385 (GCN / Cheb forward)
 #define MLQEM_LAUNCH(V, P)                                                                                  \
   do {                                                                                                      \
     if (a.ell && epi && epi_waves == 8) hipLaunchKernelGGL((csr_aggregate_ell_kernel<V, IS_MAX, P, true, 8>), grid, block, 0, stream, a, no_pool);   \

@@ -1290,7 +1290,7 @@ static int resident_of(const void* kernel) {
 }
 template <typename K>
 static dim3 whole_rounds(K kernel, dim3 grid) {
-  static const int off = getenv("MLQEM_WHOLE_ROUNDS") && atoi(getenv("MLQEM_WHOLE_ROUNDS")) == 0;     // A/B
+  constexpr int off = 0;      // (was the A/B switch MLQEM_WHOLE_ROUNDS: settled)
   if (off) return grid;
   const int64_t per_round = std::max<int64_t>(1, resident_of(reinterpret_cast<const void*>(kernel)) / std::max(1u, grid.y));
   if ((int64_t)grid.x > per_round) grid.x = (unsigned)((int64_t)grid.x / per_round * per_round);
@@ -1350,7 +1350,7 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
   {
     // wide rows from narrow inputs, bias only (TransformerConv's q / k / v / skip projection): whole rows per wave through LDS
     const int c4 = (O + 3) / 4 * 4;
-    static const int rows_env = getenv("MLQEM_LINEAR_ROWS") ? atoi(getenv("MLQEM_LINEAR_ROWS")) : 1;
+    constexpr int rows_env = 1;      // (was the A/B switch MLQEM_LINEAR_ROWS: settled)
     if (rows_env && !transposed && !accumulate && !gate && !rowscale && act == 0 && drop_p == 0.f && O >= 96 && O <= 192 && I <= 48 &&
         ldy == c4 && ldx % 4 == 0 && ldx >= (I + 3) / 4 * 4 && aligned_to(x, 16) && aligned_to(y, 16) && N >= 4096) {
       a.xrows = x_rows;
@@ -1387,7 +1387,7 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
                     ldy >= c4o && aligned_to(x, 16) && aligned_to(y, 16) && !(transposed && (act || drop_p > 0.f)) &&
                     (!gate || (ldgate % 4 == 0 && ldgate >= c4o && aligned_to(gate, 16))) && !(transposed && rowscale) &&
                     !(act & ~1);
-  static const int lean_env = getenv("MLQEM_LINEAR_LEAN") ? atoi(getenv("MLQEM_LINEAR_LEAN")) : 1;
+  constexpr int lean_env = 1;      // (was the A/B switch MLQEM_LINEAR_LEAN: settled)
   if (lean && lean_env) {
     PartsArgs p{};
     p.xp[0] = x; p.ldx[0] = ldx; p.xn = 1; p.xw = c4i; p.xc = I;
@@ -1410,7 +1410,7 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
     const int64_t tiles = ceil_div(N, 16);
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8);  // 4 waves per block
     dim3 grid(gx, (unsigned)ceil_div(ob, obt));
-    static const int v4_env = getenv("MLQEM_LINEAR_V4") ? atoi(getenv("MLQEM_LINEAR_V4")) : 1;
+    constexpr int v4_env = 1;      // (was the A/B switch MLQEM_LINEAR_V4: settled)
     const bool padded = ldx % 4 == 0 && ldx >= c4i && aligned_to(x, 16) && ldy % 4 == 0 && ldy >= c4o && aligned_to(y, 16) &&
                         (!gate || (ldgate % 4 == 0 && ldgate >= c4o && aligned_to(gate, 16)));
     if (x_rows && !(v4_env && padded)) return MLQEM_ERR_UNSUPPORTED;   // the row map is carried by the lean and the 16-byte kernels only
@@ -1476,15 +1476,15 @@ static int resident_workgroups(K kernel) {
 static int run_linear_parts(PartsArgs& a, int transposed, hipStream_t s) {
   const int g = (a.I + 15) / 16, ob = (a.O + 15) / 16;
   if (g > 4 || ob > 16) return MLQEM_ERR_UNSUPPORTED;
-  static const int lds_env = getenv("MLQEM_FANOUT_LDS") ? atoi(getenv("MLQEM_FANOUT_LDS")) : 1;
+  constexpr int lds_env = 1;      // (was the A/B switch MLQEM_FANOUT_LDS: settled)
   if (lds_env && !transposed && a.xn == 1 && a.yn >= 2 && a.yw <= 16 && !a.act && a.drop_p == 0.f && !a.gate) {
     // several narrow output blocks from one read of x: weight fragments in LDS, one MFMA tile per block
     const int64_t tiles = ceil_div(a.N, 16);
-    static const int plain_env = getenv("MLQEM_FANOUT_PLAIN") ? atoi(getenv("MLQEM_FANOUT_PLAIN")) : 0;
-    static const int grid_env = getenv("MLQEM_FANOUT_GRID") ? atoi(getenv("MLQEM_FANOUT_GRID")) : 0;    // workgroups per CU; 0 = whole resident rounds
-    static const int rounds_env = getenv("MLQEM_FANOUT_ROUNDS") ? atoi(getenv("MLQEM_FANOUT_ROUNDS")) : 1;
+    constexpr int plain_env = 0;      // (was the A/B switch MLQEM_FANOUT_PLAIN: settled)
+    constexpr int grid_env = 0;      // (was the A/B switch MLQEM_FANOUT_GRID: settled)    // workgroups per CU; 0 = whole resident rounds
+    constexpr int rounds_env = 1;      // (was the A/B switch MLQEM_FANOUT_ROUNDS: settled)
     a.plain_stores = plain_env;
-    static const int k24_env = getenv("MLQEM_FANOUT_K24") ? atoi(getenv("MLQEM_FANOUT_K24")) : 1;
+    constexpr int k24_env = 1;      // (was the A/B switch MLQEM_FANOUT_K24: settled)
     const bool k24 = k24_env && g == 2 && a.xc <= 24 && a.ldx[0] % 2 == 0 && aligned_to(a.xp[0], 8);
     int res = 0;
     switch (g) {
@@ -1597,13 +1597,13 @@ extern "C" size_t mlqem_linear_wgrad_workspace_bytes(int I, int O) {
 }
 
 static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipStream_t s) {
-  static const int wide_u = getenv("MLQEM_WGRAD_WIDE_U") ? atoi(getenv("MLQEM_WGRAD_WIDE_U")) : 4;   // measured on the 7-block pass: 4 -> 1201 us (180 VGPRs, 2 waves/SIMD), 2 -> 1680 us (136 VGPRs, 3 waves): loads in flight per wave matter more than occupancy
-  static const int wide_pf = getenv("MLQEM_WGRAD_PF") ? atoi(getenv("MLQEM_WGRAD_PF")) : 1;
+  constexpr int wide_u = 4;      // (was the A/B switch MLQEM_WGRAD_WIDE_U: settled)   // measured on the 7-block pass: 4 -> 1201 us (180 VGPRs, 2 waves/SIMD), 2 -> 1680 us (136 VGPRs, 3 waves): loads in flight per wave matter more than occupancy
+  constexpr int wide_pf = 1;      // (was the A/B switch MLQEM_WGRAD_PF: settled)
   const int ob_ = (a.O + 15) / 16, ib_ = (a.I + 1 + 15) / 16;
   const bool wide = ob_ >= 4 && ob_ <= 6 && ib_ <= 2;
-  static const int pipe_env = getenv("MLQEM_WGRAD_PIPE") ? atoi(getenv("MLQEM_WGRAD_PIPE")) : 2;    // 0: wgrad_mfma_kernel, 1: KU = 4 (two waves per SIMD), 2: KU = 2 (three)
-  static const int wide6_env = getenv("MLQEM_WGRAD_WIDE6") ? atoi(getenv("MLQEM_WGRAD_WIDE6")) : 1;
-  static const int pipe_grid = getenv("MLQEM_WGRAD_GRID") ? atoi(getenv("MLQEM_WGRAD_GRID")) : 0;  // workgroups per CU; 0 = the resident count
+  constexpr int pipe_env = 2;      // (was the A/B switch MLQEM_WGRAD_PIPE: settled)    // 0: wgrad_mfma_kernel, 1: KU = 4 (two waves per SIMD), 2: KU = 2 (three)
+  constexpr int wide6_env = 1;      // (was the A/B switch MLQEM_WGRAD_WIDE6: settled)
+  constexpr int pipe_grid = 0;      // (was the A/B switch MLQEM_WGRAD_GRID: settled)  // workgroups per CU; 0 = the resident count
   bool uniform_ld = true;
   for (int k = 1; k < a.gn; ++k) uniform_ld = uniform_ld && a.ldgy[k] == a.ldgy[0];
   const int64_t iters = ceil_div(std::max<int64_t>(a.N, 1), 4 * (wide && wide_u == 2 ? 2 : kWgradUnroll));
@@ -1624,7 +1624,7 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     // the first-layer blocks: software-pipelined form (see wgrad_pipe_kernel).  Blocks are 12 floats wide with 10 real columns:
     // the MFMA rows take the REAL columns back to back (six blocks: 60 rows = four tiles instead of 72 = five; seven: five instead
     // of six) -- fewer load instructions and a third fewer MFMAs for the same bytes; the second stage spreads them out again.
-    static const int pack_env = getenv("MLQEM_WGRAD_PACK") ? atoi(getenv("MLQEM_WGRAD_PACK")) : 1;
+    constexpr int pack_env = 1;      // (was the A/B switch MLQEM_WGRAD_PACK: settled)
     const int obp = (a.gn * a.gc + 15) / 16;
     const bool pack = pack_env && a.gn > 1 && a.gc < a.gw && a.gw - a.gc <= a.gc && obp < ob && obp >= 4 && pipe_env == 2;
     const int pw = a.gw, pc = a.gc;

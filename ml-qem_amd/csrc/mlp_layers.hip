@@ -1413,7 +1413,7 @@ extern "C" int mlqem_layer_wgrad_bf16(const void* dy, const void* x, int x_is_bf
   if (N > 0) {
     static const int r0 = layer_resident(layer_wgrad_kernel<false>, kLayerThreads, 0), r1 = layer_resident(layer_wgrad_kernel<true>, kLayerThreads, 0);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(x_is_bf16 ? r1 : r0, kLayerMaxBlocks), std::max<int64_t>(N / 32, 1)));
-    static const int lds_form = getenv("MLQEM_LAYER_WGRAD_LDS") ? atoi(getenv("MLQEM_LAYER_WGRAD_LDS")) : 2;    // 0: register prefetch, 1: LDS DMA + v_perm, 2: LDS DMA + transposing reads
+    constexpr int lds_form = 2;      // (was the A/B switch MLQEM_LAYER_WGRAD_LDS: settled)    // 0: register prefetch, 1: LDS DMA + v_perm, 2: LDS DMA + transposing reads
     const bool dma_ok = aligned_to(dy, 16) && aligned_to(x, 16);      // the DMA forms move 16 bytes per lane
     if (x_is_bf16 && lds_form == 2 && dma_ok) {    // the transposing-read form (default): see layer_wgrad_tr_kernel
       const size_t lds = (size_t)kTrSlabs * kDmaSlabBytes;
@@ -1547,7 +1547,7 @@ extern "C" int mlqem_layer_wgrad_f32(const float* dy, const float* x, int64_t ld
     // the partial sums of a workgroup are n_waves x 16 KB
     const int64_t cap = (int64_t)(mlqem_layer_workspace_bytes() / ((size_t)n_waves * kWgF32WaveFloats * sizeof(float)));
     // persistent workgroups: exactly as many as are resident at once (at 210 registers two waves share a SIMD: eight waves per CU)
-    static const int q_env = getenv("MLQEM_LAYER_WGRAD_Q") ? atoi(getenv("MLQEM_LAYER_WGRAD_Q")) : 8;
+    constexpr int q_env = 8;      // (was the A/B switch MLQEM_LAYER_WGRAD_Q: settled)
     const bool q4 = q_env == 4;
     static int per_cu_of[8] = {};                    // by workgroup size (1..6 waves): asked of the runtime once, not per call
     int per_cu = per_cu_of[n_waves & 7];

@@ -75,13 +75,11 @@ template <bool TRAIN> __global__ __launch_bounds__(kBlock) void tile_attn_fwd_ke
   const int4 ti = tile_prologue(p, t, L.c);
   const int cnt = ti.x, ucnt = ti.z;
   int nlong = ti.y;
-  if (p.dbg == 1) return;
   const float* __restrict__ qkvs = a.qkvs;
   const int64_t ld = a.ld;
   tile_stage(p, ti, L.c, qkvs, ld, HP, 2 * H * 4, L.rows, pitch, TileOwn{qkvs, ld, 0, H * 4, 0}, TileOwn{qkvs, ld, 3 * HP, H * 4, HP}, L.own, 2 * HP);
   __syncthreads();
-  if (p.dbg == 2) return;
-  const int nlong_run = p.dbg == 3 ? 0 : nlong;
+  const int nlong_run = nlong;
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, quad = lane >> 2, lq = lane & 3;
   const int nv = min(4, max(0, C - 4 * lq));
@@ -307,7 +305,7 @@ template <bool TRAIN> __global__ __launch_bounds__(kBlock) void tile_attn_fwd_ke
     }
   }
   // short rows: a quad per (row, head)
-  const int npairs = p.dbg == 4 ? 0 : (cnt - nlong) * H;
+  const int npairs = (cnt - nlong) * H;
   for (int p0 = wave * 16; p0 < npairs; p0 += 64) {
     const int pr = p0 + quad;
     if (pr < npairs) {
@@ -671,7 +669,7 @@ extern "C" int mlqem_tile_attention_train_f32(const float* qkvs, int64_t ld, con
   if (N > INT32_MAX || !aligned_to(qkvs, 16) || ld % 4 != 0) return MLQEM_ERR_UNSUPPORTED;
   const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den,
                       pair_key ? 1 : 0, nullptr, 16};
-  const TilePlan p{reinterpret_cast<const int4*>(tinfo), reinterpret_cast<const int4*>(rinfo), uni, loc, num_tiles, cap, tile_rows, tile_debug_mode()};
+  const TilePlan p{reinterpret_cast<const int4*>(tinfo), reinterpret_cast<const int4*>(rinfo), uni, loc, num_tiles, cap, tile_rows};
   const size_t lds = tile_attn_lds_bytes(cap, 2 * H * 16 + 4, tile_rows, 2 * H * 16, false);
   if (train) {
     if (!ensure_dynamic_lds(tile_attn_fwd_kernel<true>, lds)) return MLQEM_ERR_UNSUPPORTED;
@@ -705,9 +703,9 @@ extern "C" int mlqem_tile_attention_bwd_f32(const float* qkvs, int64_t ld, const
   if (N > INT32_MAX || !aligned_to(qkvs, 16) || ld % 4 != 0) return MLQEM_ERR_UNSUPPORTED;
   const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, nullptr, loops,
                       N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, rec, nullptr, 1, 16};
-  const TilePlan pin{reinterpret_cast<const int4*>(in_tinfo), reinterpret_cast<const int4*>(in_rinfo), in_uni, in_loc, in_tiles, in_cap, in_tile_rows, tile_debug_mode()};
+  const TilePlan pin{reinterpret_cast<const int4*>(in_tinfo), reinterpret_cast<const int4*>(in_rinfo), in_uni, in_loc, in_tiles, in_cap, in_tile_rows};
   const TilePlan pout{reinterpret_cast<const int4*>(out_tinfo), reinterpret_cast<const int4*>(out_rinfo), out_uni, out_loc, out_tiles, out_cap,
-                      out_tile_rows, tile_debug_mode()};
+                      out_tile_rows};
   const size_t lds_d = tile_attn_lds_bytes(in_cap, 2 * H * 16 + 4, in_tile_rows, 0, true), lds_s = tile_attn_lds_bytes(out_cap, H * kSrcHead, out_tile_rows, 0, true);
   if (!ensure_dynamic_lds(tile_attn_bwd_dst_kernel, lds_d) || !ensure_dynamic_lds(tile_attn_bwd_src_kernel, lds_s)) return MLQEM_ERR_UNSUPPORTED;
   if (in_tiles > 0) hipLaunchKernelGGL(tile_attn_bwd_dst_kernel, dim3((unsigned)in_tiles), dim3(kBlock), lds_d, as_stream(stream), a, pin);

@@ -41,9 +41,7 @@ struct TilePlan {
   const uint16_t* loc;
   int64_t nt;
   int cap, tile_rows;
-  int dbg;           // MLQEM_TILE_DEBUG (bisecting a kernel's time: 1 = stop after the prologue, 2 = after the staging, 3 = no long rows, 4 = no short rows)
 };
-inline int tile_debug_mode() { static const int m = getenv("MLQEM_TILE_DEBUG") ? atoi(getenv("MLQEM_TILE_DEBUG")) : 0; return m; }
 
 // what every tiled kernel keeps in LDS besides its staged rows
 struct TileLds {

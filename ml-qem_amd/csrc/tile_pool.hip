@@ -832,7 +832,7 @@ extern "C" int mlqem_tile_asap_scores_f32(const float* x, int64_t ldx, const int
   a.x = x; a.ldx = ldx; a.ptr = in_ptr; a.idx = in_src; a.c_src = c_src; a.slope = negative_slope; a.N = N; a.D = D;
   a.w_comp = w_comp; a.b_comp = b_comp; a.w3 = w3; a.b3 = b3;
   a.xnew = xnew; a.ldn = ldn; a.xmax = xmax; a.ldm = ldm; a.stat = reinterpret_cast<float4*>(stat); a.pqr = pqr;
-  const TilePlan p{reinterpret_cast<const int4*>(tinfo), reinterpret_cast<const int4*>(rinfo), uni, loc, num_tiles, cap, tile_rows, tile_debug_mode()};
+  const TilePlan p{reinterpret_cast<const int4*>(tinfo), reinterpret_cast<const int4*>(rinfo), uni, loc, num_tiles, cap, tile_rows};
   MLQEM_TILE_POOL(tile_pool_fwd_kernel, 16 * NV + 4, p, num_tiles, cap);
   return launch_status();
 }
@@ -860,9 +860,9 @@ extern "C" int mlqem_tile_asap_scores_bwd_f32(const float* x, int64_t ldx, const
   a.x = x; a.ldx = ldx; a.c_src = c_src; a.slope = negative_slope; a.N = N; a.D = D; a.w_comp = w_comp;
   a.xnew = const_cast<float*>(xnew); a.ldn = ldn; a.xmax = const_cast<float*>(xmax); a.ldm = ldm; a.stat = reinterpret_cast<float4*>(stat);
   a.gnew = gnew; a.ldg = ldg; a.g_a = g_a; a.share = share; a.lds = lds_; a.gx = gx; a.ldgx = ldgx; a.g_c = g_c; a.rank1 = rank1;
-  const TilePlan pin{reinterpret_cast<const int4*>(in_tinfo), reinterpret_cast<const int4*>(in_rinfo), in_uni, in_loc, in_tiles, in_cap, in_tile_rows, tile_debug_mode()};
+  const TilePlan pin{reinterpret_cast<const int4*>(in_tinfo), reinterpret_cast<const int4*>(in_rinfo), in_uni, in_loc, in_tiles, in_cap, in_tile_rows};
   const TilePlan pout{reinterpret_cast<const int4*>(out_tinfo), reinterpret_cast<const int4*>(out_rinfo), out_uni, out_loc, out_tiles, out_cap,
-                      out_tile_rows, tile_debug_mode()};
+                      out_tile_rows};
   a.ptr = in_ptr; a.idx = in_src;
   if (in_tiles > 0) MLQEM_TILE_POOL(tile_pool_bwd_dst_kernel, 16 * NV + 4, pin, in_tiles, in_cap);
   a.ptr = out_ptr; a.idx = out_dst;

@@ -96,7 +96,8 @@ def _check_family_b(corpus, sel, out_size, tag=None):
                       "max_abs_gpu_minus_fp32_cpu": err32, "bound_asserted": max(1e-5, 2 * fp32_gap), "north_star": 1e-5,
                       "prediction_scale": float(want.detach().abs().max()), "nodes": int(hb["x"].shape[0]), "graphs": int(len(sel))})
     assert err < max(1e-5, 2 * fp32_gap), (err, fp32_gap)
-    assert err32 < max(1e-5, 2 * fp32_gap)
+    # the north_star's literal bar: 1e-5 against the fp32 CPU path (realised: ~3e-8 on cfg3)
+    assert err32 < 1e-5, err32
     torch.nn.functional.mse_loss(out, hb["y"].to(DEV)).backward()
     torch.nn.functional.mse_loss(want, hb["y"].double()).backward()
     grads = {k: p.grad for k, p in ref.named_parameters()}

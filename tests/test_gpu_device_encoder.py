@@ -13,7 +13,7 @@ from blackwater.data.circuit import circuit_to_qasm
 from blackwater.data.native_encoder import NativeEncoder
 from blackwater.data.synthetic import synthetic_backend, tfim_circuit
 from blackwater.data.utils import get_backend_properties_v1
-from helpers import G1_GATES_ORDER
+from helpers import G1_GATES_ORDER, g1_graph, infer_gates_order
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -42,6 +42,38 @@ def test_the_references_circuits_bit_for_bit(g1, golden_dir, lima_props):
         for texts in (list(g1["qasm"]), ising, goldens):
             for gate_f, qubit_f in ((True, True), (False, False), (True, False)):
                 _same(enc, texts, use_gate_features=gate_f, use_qubit_features=qubit_f)
+
+
+def test_device_encoder_against_the_references_stored_graphs(g1, golden_dir, lima_props):
+    """The pin without a hop through the host fill: what the device expansion writes for the reference's own circuits
+    equals the graphs the REFERENCE stored next to them -- the 30 JSON input/output pairs of encoder_goldens.json (the op -> op wire
+    edges in the reference's order, exactly; the feature rows exactly but for the three angle columns, which the stored QASM prints
+    rounded: 1e-6, as float32) and the 300 G1 graphs (x, edge_index as stored, exactly)."""
+    from blackwater.data.circuit import Circuit
+
+    for e in json.load(open(os.path.join(golden_dir, "encoder_goldens.json"))):
+        want = e["circuit_graph"]
+        rows = np.array(want["nodes"]["DAGOpNode"])
+        props = dict(lima_props, gates_set=infer_gates_order(Circuit.from_qasm_str(e["circuit"]), want["nodes"]["DAGOpNode"], lima_props["gates_set"]))
+        x, ei, _, counts, depths = NativeEncoder(props).encode_batch_expand([e["circuit"]], DEV)
+        torch.cuda.synchronize()
+        x = x.cpu().numpy()
+        assert x.shape == rows.shape and counts[0] == rows.shape[0] and depths[0] == e["circuit_depth"]
+        assert np.array_equal(x[:, 3:], rows[:, 3:].astype(np.float32))
+        assert np.abs(x[:, :3] - rows[:, :3]).max() < 1e-6
+        assert np.array_equal(ei.cpu().numpy(), np.array(want["edges"]["DAGOpNode_wire_DAGOpNode"]["edge_index"], dtype=np.int64).reshape(2, -1))
+    enc = NativeEncoder(dict(lima_props, gates_set=G1_GATES_ORDER))
+    x, ei, batch, counts, _ = enc.encode_batch_expand(list(g1["qasm"]), DEV)
+    torch.cuda.synchronize()
+    x, ei = x.cpu().numpy(), ei.cpu().numpy()
+    node0 = np.concatenate([[0], np.cumsum(counts)])
+    e0 = 0
+    for i in range(len(g1["qasm"])):
+        xs, eis, _ = g1_graph(g1, i)
+        assert np.array_equal(x[node0[i]:node0[i + 1]], np.asarray(xs, dtype=np.float32))
+        assert np.array_equal(ei[:, e0:e0 + eis.shape[1]] - node0[i], eis)
+        e0 += eis.shape[1]
+    assert e0 == ei.shape[1]
 
 
 @pytest.mark.parametrize("nq,two_q,count", [(100, "ecr", 48), (20, "cx", 100), (4, "cx", 700)])

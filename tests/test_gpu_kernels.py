@@ -156,7 +156,7 @@ def test_wide_projection_through_lds_writes_whole_rows(n, i, o):
     """The q / k / v / skip projection of a TransformerConv (22 -> 180, 45 -> 120; gnn.py:80-91) takes linear_rows_lds_kernel: a
     wave owns 16 whole rows, the product is transposed through LDS and written as contiguous 1 KB stores, bias added on the way.
     Against fp64 within 1e-5 of the output scale -- with and without a row map of x, row counts that are no multiple of 16, NaN in the
-    input's pad columns -- and bit-equal to the general kernel it replaces for these shapes (MLQEM_LINEAR_ROWS=0 in a second process is
+    input's pad columns -- and bit-equal to the general kernel it replaces for these shapes (the general kernel, in a second process, was
     not needed: the same products in the same order)."""
     from blackwater.native import ops
 

@@ -184,11 +184,11 @@ def test_fused_mlp1_step_equals_the_autograd_step(mode, shape, monkeypatch):
     ys = [torch.randn(x.shape[0], o, device=DEV) for x in xs]
     runs = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("MLQEM_MLP1_FUSED_STEP", fused)
         torch.manual_seed(3)
         model = MLP1(i, h, o).to(DEV)
         model.mfma = mode
         tr = RowsTrainer(model, lr=1e-3, graphs=False)
+        tr.fused_mlp1_step = fused == "1"
         losses = [float(tr.step_rows(x, y)) for _ in range(2) for x, y in zip(xs, ys)]
         runs[fused] = (losses, tr.flat_param.detach().clone(), tr.flat_grad.detach().clone())
     assert torch.equal(runs["1"][1], runs["0"][1]) and torch.equal(runs["1"][2], runs["0"][2])
