@@ -974,7 +974,8 @@ def inference_leg(dev):
                 ob = [obs1] * count
                 est_b.run(qs, ob).result()        # warm-up at the same size: pinned staging buffers, encoder scratch, allocator
                 dt, vals = wall(lambda: est_b.run(qs, ob).result().values)
-                r[f"batched_{count}"] = {"circuits_per_s": round(count / dt, 1), "ms_per_run": round(dt * 1e3, 2)}
+                r[f"batched_{count}_texts_repeated_as_buffers"] = {"circuits_per_s": round(count / dt, 1), "ms_per_run": round(dt * 1e3, 2),
+                                                                   "distinct_buffers_scanned": min(count, n_distinct)}
                 if count == 1024:
                     # the run() above names each of the distinct texts many times AS THE SAME BUFFER (what the reference's VQE drivers do:
                     # one bound circuit, one pair per Pauli term) and such a text is scanned once; the same run() with every text its
@@ -982,7 +983,9 @@ def inference_leg(dev):
                     qs_own = [(t + " ")[:-1] for t in qs]
                     est_b.run(qs_own, ob).result()
                     dt, _ = wall(lambda: est_b.run(qs_own, ob).result().values)
-                    r["batched_1024_every_text_its_own_buffer"] = {"circuits_per_s": round(count / dt, 1), "ms_per_run": round(dt * 1e3, 2)}
+                    # THE figure of this leg: every circuit of the run() scanned
+                    r["batched_1024"] = {"circuits_per_s": round(count / dt, 1), "ms_per_run": round(dt * 1e3, 2),
+                                         "note": "every text its own buffer: 1024 texts scanned in full"}
                     del qs_own
             n_serial = 32 if nq == 4 else 16      # the serial loop encodes natively since round 4: a 100-qubit circuit is milliseconds
             est_s = ngem(Est, model, backend)()
@@ -1108,6 +1111,9 @@ def main():
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="circuits per step per GPU")
     ap.add_argument("--n-j", type=int, default=0, help="J values per Trotter step count; 0 = 8 x batch x gpus / 10")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline, parity, accuracy, family_b)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the GLOBAL number of circuits per step (each rank takes batch / gpus) and the corpus does "
+                         "not grow with the number of GPUs; default: weak scaling (--batch circuits per step PER GPU)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -1137,7 +1143,12 @@ def main():
     from blackwater.nn import ExpValCircuitGraphModelA
     from blackwater.train import BucketedTrainer, DataParallelShard, StratifiedBatches
 
-    n_j = args.n_j if args.n_j > 0 else -(-CORPUS_BATCHES * args.batch * world // len(STEPS_LIST))
+    global_batch = args.batch if args.strong else args.batch * world
+    if args.strong:
+        if args.batch % world:
+            sys.exit(f"bench.py --strong: --batch {args.batch} is not a multiple of --gpus {world}")
+        args.batch //= world               # circuits per step on THIS rank from here on
+    n_j = args.n_j if args.n_j > 0 else -(-CORPUS_BATCHES * global_batch // len(STEPS_LIST))
     progress("building the corpus")
     corpus = build_corpus(n_j)
     # the data-parallel split by circuit: balanced by node count, every shard the same length
@@ -1156,7 +1167,12 @@ def main():
     # time on a quiet box, 6 ms on a loaded one -- the step takes 6.8 ms on the device).
     sampler = StratifiedBatches(arena.node_counts[:n_local], arena.edge_counts[:n_local], args.batch, seed=1000 + rank)
     use_graphs = os.environ.get("MLQEM_BENCH_GRAPHS", "1") != "0"
-    trainer = BucketedTrainer(model, arena, lr=1e-3, graphs=use_graphs, node_quantum=node_quantum, distributed=distributed)
+    # MLQEM_BENCH_CAPTURE_COLLECTIVE=1: the gradient all-reduce captured inside the step's graph (one replay per step instead of two
+    # replays around an eager collective).  Off by default: the step is device-bound either way (0.2 ms of host time against 6.2 ms), and
+    # a capture that hangs on a multi-GPU node this session cannot rehearse would cost the scaling run; tests cover it at world size 1.
+    capture_coll = distributed and backend == "nccl" and os.environ.get("MLQEM_BENCH_CAPTURE_COLLECTIVE", "0") == "1"
+    trainer = BucketedTrainer(model, arena, lr=1e-3, graphs=use_graphs, node_quantum=node_quantum, distributed=distributed,
+                              capture_collective=capture_coll)
     step_mode = "hipgraph replay (one capture: size-stratified batches share one bucket)" if use_graphs else "eager (bucketed)"
 
     def step():
@@ -1222,7 +1238,7 @@ def main():
             "metric": "circuits/sec (GNN train step), 100q TFIM Trotter",
             "value": round(total / elapsed, 2), "unit": "circuits/s", "n_gpus": joined, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg4: 100-qubit TFIM Trotter steps 1-10 x %d J values, GNN family A "
                                    "(GCNx3 || Chebx2 || SAGEx2, hidden 10, F=22), full train step" % n_j,
                        "circuits_per_step_per_gpu": args.batch, "corpus_circuits": len(corpus),
@@ -1232,6 +1248,10 @@ def main():
                        "sampling": "size-stratified: %s circuits of the 10 Trotter step counts per batch" % "/".join(map(str, sampler.quota)),
                        "backend": backend, "ranks_joined": joined, "host_ms_between_graph_replays_per_rank": dp_host_ms,
                        "gradient_floats_all_reduced": int(trainer.flat_grad.numel()),
+                       "global_circuits_per_step": args.batch * joined,
+                       "collective": (None if not distributed else "captured inside the step's hipGraph" if trainer.collective_in_graph
+                                      else "eager all-reduce between two graph replays"
+                                      + (" (capture refused: %s)" % trainer.collective_capture_error if trainer.collective_capture_error else "")),
                        "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if backend == "nccl" else None},
             "ms_per_step_percentiles": {"p10": round(float(np.percentile(per_step, 10)), 3), "p50": round(float(np.percentile(per_step, 50)), 3),
                                         "p90": round(float(np.percentile(per_step, 90)), 3), "min": round(float(per_step.min()), 3),

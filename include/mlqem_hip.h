@@ -833,7 +833,9 @@ int mlqem_qasm_batch_stream_fill(void* handle, int threads, const int64_t* wire_
                                  uint16_t* wires, mlqem_x_patch* patches);
 /* g1[(G + 2) * Q], g2[(G + 2) * Q * Q] (G = num_gate_types, Q = num_qubits): index into gate_error / gate_length of the
  * calibration entry of (one-hot slot, qubit) / (slot, qubit, qubit), -1 where there is none -- the lookups of utils.py:263-269 as
- * tables the device indexes. */
+ * tables the device indexes.  Keys naming a qubit >= num_qubits have no place in the tables and are left out: the host string lookup
+ * would still find such a key, but no circuit the encoder accepts addresses that qubit (ops on qubits >= num_qubits are refused),
+ * so the two lookups agree on every op that can occur. */
 int mlqem_props_gate_tables(const mlqem_backend_props* props, int32_t* g1, int32_t* g2);
 
 /* Device-side expansion of the op stream (all pointers device memory): x[N, F] (row stride ldx >= F; F = 3 + num_slots + 9 (qubit

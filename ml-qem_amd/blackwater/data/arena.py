@@ -234,6 +234,51 @@ class GraphArena:
         return GraphArena.from_arrays(xs, eis, y, noisy, depth, obs, device=device)
 
     # ------------------------------------------------------------------------------------------------
+    _DEVICE_ARRAYS = ("x", "nscal", "gptr", "in_ptr", "in_src", "out_ptr", "out_dst", "out_eid", "loops", "in_ell", "out_ell",
+                      "y", "noisy", "depth", "observable")
+
+    def with_capacity(self, factor: float = 2.0) -> "GraphArena":
+        """A copy of this arena whose device arrays are the leading parts of allocations ``factor`` times their size: ``refill_from``
+        then puts ANOTHER arena's content at the same addresses, which is what a hipGraph captured over ``assemble`` needs to be
+        replayed for the circuits of a later run() (train.BucketedPredictor)."""
+        import copy
+
+        grown = copy.copy(self)
+        grown._base = {}
+        for name in self._DEVICE_ARRAYS:
+            t = getattr(self, name)
+            rows = max(int(t.shape[0] * factor), t.shape[0] + 1)
+            if name == "x":
+                f4 = t.stride(0) if t.shape[0] > 1 else (t.shape[1] + 3) // 4 * 4
+                base = torch.zeros((rows, f4), dtype=t.dtype, device=t.device)
+                base[:t.shape[0], :t.shape[1]].copy_(t)
+            else:
+                base = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                base[:t.shape[0]].copy_(t)
+            grown._base[name] = base
+            setattr(grown, name, base[:t.shape[0], :t.shape[1]] if name == "x" else base[:t.shape[0]])
+        return grown
+
+    def refill_from(self, other: "GraphArena") -> bool:
+        """Takes over ``other``'s graphs in place (an arena made by ``with_capacity``): False -- and nothing changed -- when an array
+        of ``other`` is longer than its allocation here or of another row shape / type."""
+        base = getattr(self, "_base", None)
+        if base is None or other.filler_nodes != self.filler_nodes:
+            return False
+        for name in self._DEVICE_ARRAYS:
+            t, b = getattr(other, name), base[name]
+            trailing = (t.shape[1],) if name == "x" else tuple(t.shape[1:])
+            mine = (getattr(self, name).shape[1],) if name == "x" else tuple(b.shape[1:])
+            if t.shape[0] > b.shape[0] or trailing != mine or t.dtype != b.dtype:
+                return False
+        for name in self._DEVICE_ARRAYS:
+            t, b = getattr(other, name), base[name]
+            view = b[:t.shape[0], :t.shape[1]] if name == "x" else b[:t.shape[0]]
+            view.copy_(t)
+            setattr(self, name, view)
+        self.node_counts, self.edge_counts, self.coarse_caps = other.node_counts, other.edge_counts, other.coarse_caps
+        return True
+
     def selection(self, graph_ids, bucket=None):
         """Host side of a batch: (sel, nptr, eptr, Nb, Eb, number of real graphs).  With ``bucket = (n_pad, e_pad)`` the
         batch is padded to exactly n_pad nodes by a slice of the filler graph (appended as one more, edgeless, graph) and

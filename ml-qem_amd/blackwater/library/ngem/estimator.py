@@ -7,7 +7,7 @@ and call ``model(noisy_0, observable, circuit_depth, x, edge_index, batch)``; te
 """
 from __future__ import annotations
 
-import os
+import weakref
 from functools import wraps
 from typing import Any, Callable, Optional, Type
 
@@ -27,6 +27,28 @@ from ..primitives import job_base, make_estimator_result, model_device, transpil
 # False: the serial path encodes with the Python walk (circuit_to_graph_data_json) whatever the circuit's type -- the form the native
 # encoder is compared with (tests/test_estimators.py sets it)
 _NATIVE_SERIAL = True
+
+
+_predictors = weakref.WeakKeyDictionary()      # model -> train.BucketedPredictor: captured forwards outlive a result() call
+_encoders = {}          # content of a backend-properties dict -> NativeEncoder (at most 8, oldest dropped first)
+
+
+def _encoder_for(properties):
+    """The native encoder of these backend properties, kept between result() calls: the reference re-reads the backend's calibration
+    on every result() (:46) and so does this path, but an encoder -- its calibration tables on the host and, for the device
+    expansion, on the GPU -- is rebuilt only when the CONTENT of the properties changed (a VQE loop calls result() thousands of
+    times against one calibration)."""
+    import json
+
+    from ...data.native_encoder import NativeEncoder
+
+    key = hash(json.dumps(properties, sort_keys=True, default=str))
+    enc = _encoders.get(key)
+    if enc is None:
+        while len(_encoders) >= 8:
+            _encoders.pop(next(iter(_encoders)))
+        enc = _encoders[key] = NativeEncoder(properties)
+    return enc
 
 
 def _qasm_text(bound):
@@ -68,6 +90,11 @@ class NgemJob(job_base()):  # type: ignore[misc]
         mitigated = []
         if self._batched:
             return make_estimator_result(np.array(self._result_batched_native(result, properties, device)), result.metadata)
+        if (_NATIVE_SERIAL and device is not None and torch.device(device).type == "cuda" and len(self._circuits) > 1
+                and getattr(self._model, "accepts_device_batches", False) and not getattr(self._model, "needs_size_pattern", False)):
+            replayed = self._result_serial_replayed(result, properties, device)
+            if replayed is not None:
+                return make_estimator_result(np.array(replayed), result.metadata)
         encoder = None      # the C++ encoder, built on first need: same arrays as the Python walk, bit for bit
         encoded = {}        # an observable OBJECT that appears many times in a run() is encoded once
         for value, circuit, obs, params in zip(result.values, self._circuits, self._observables,
@@ -83,7 +110,7 @@ class NgemJob(job_base()):  # type: ignore[misc]
                 if encoder is None:
                     from ...data.native_encoder import NativeEncoder
 
-                    encoder = NativeEncoder(properties)
+                    encoder = _encoder_for(properties)
                 # float32 rows and int64 indices straight from the C call (the batch entry points with one circuit: no float64
                 # staging array, no casts), in pinned memory when they are about to be uploaded
                 on_gpu = device is not None and torch.device(device).type == "cuda"
@@ -107,6 +134,44 @@ class NgemJob(job_base()):  # type: ignore[misc]
             mitigated.append(out.item())
         return make_estimator_result(np.array(mitigated), result.metadata)
 
+    def _result_serial_replayed(self, result, properties, device):
+        """The serial loop of the reference -- one model call per circuit, values read back one by one -- for this package's own
+        models on the GPU: the run()'s circuits are scanned natively into a device-resident arena once, and every per-circuit model
+        call is the replay of a forward captured per size bucket (train.BucketedPredictor) instead of ~45 launches enqueued from
+        Python.  None when a circuit is not OpenQASM text / a ``Circuit`` (the caller then walks the loop as before)."""
+        from ...data.arena import GraphArena
+        from ...train import BucketedPredictor
+
+        texts, values, observables, encoded = [], [], [], {}
+        for value, circuit, obs, params in zip(result.values, self._circuits, self._observables, self._parameter_values):
+            if not is_pauli_observable(obs):
+                raise BlackwaterException("Only `PauliSumOp` observables are supported by NGEM.")
+            bound = transpile_and_bind(circuit, self._backend, params, _options_dict(self._options), keep_text=True)
+            text = _qasm_text(bound)
+            if text is None:
+                return None
+            texts.append(text)
+            values.append([float(value)])
+            enc = encoded.get(id(obs))
+            if enc is None:
+                enc = encoded[id(obs)] = np.asarray(encode_pauli_sum_op(obs), dtype=np.float32)
+            observables.append(enc)
+        if len({o.shape for o in observables}) != 1:
+            return None                       # observables of several shapes cannot share one arena: the plain loop takes them
+        x, edge_index, _, counts, _ = _encoder_for(properties).encode_batch_expand(texts, device)
+        n = len(texts)
+        arena = GraphArena.from_device(x, counts, edge_index, np.zeros((n, 1), np.float32), np.asarray(values, np.float32),
+                                       np.zeros((n, 1), np.float32), np.stack(observables), filler_nodes=256)
+        predictor = _predictors.get(self._model)
+        if predictor is None:
+            predictor = _predictors[self._model] = BucketedPredictor(self._model, arena)
+        else:
+            predictor.load(arena)           # the captures of earlier run()s, over this run()'s circuits
+        mitigated = []
+        for i in range(n):
+            mitigated.append(predictor.predict_ids([i]).reshape(-1)[0].item())      # one model call, one value read back, per circuit
+        return mitigated
+
     def _result_batched_native(self, result, properties, device):
         """``batched=True``: every circuit of this run() encoded by the C++ encoder on a pool of host threads straight into ONE
         collated batch (pinned when the model is on the GPU), ONE upload, ONE model call.  The reference's loop
@@ -129,13 +194,12 @@ class NgemJob(job_base()):  # type: ignore[misc]
                 enc = encoded[id(obs)] = np.asarray(encode_pauli_sum_op(obs), dtype=np.float32)
             observables.append(enc)
         on_gpu = device is not None and torch.device(device).type == "cuda"
+        encoder = _encoder_for(properties)
         if on_gpu:
             # the host scans the texts into a compact op stream (16 bytes per op); rows, edges and offsets are made on the device
-            x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch_expand(texts, device)
-        elif on_gpu:    # groups of circuits are written and uploaded in turn: the copy of one overlaps the encoding of the next
-            x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch_to_device(texts, device)
+            x, edge_index, batch, counts, _ = encoder.encode_batch_expand(texts, device)
         else:
-            x, edge_index, batch, counts, _ = NativeEncoder(properties).encode_batch(texts)
+            x, edge_index, batch, counts, _ = encoder.encode_batch(texts)
         noisy = torch.tensor(values, dtype=torch.float)
         observable = torch.from_numpy(np.stack(observables)) if observables else torch.zeros((0, 0, 0))
         depth = torch.zeros(len(texts), 1)

@@ -75,6 +75,7 @@ class _FamilyB(nn.Module):
     # ASAPooling sizes its outputs from the per-graph node counts (k_g = ceil(n_g / 2), the capacity of the coarsened edge
     # list): a captured step (train.BucketedTrainer) is only valid for batches with the SAME sequence of graph sizes
     needs_size_pattern = True
+    accepts_device_batches = True
 
     def _build(self, num_node_features, hidden_channels):
         h1, h2 = self.heads

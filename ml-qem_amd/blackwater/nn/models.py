@@ -68,6 +68,10 @@ class ExpValCircuitGraphModelA(nn.Module):
     """Family A: GCNx3 || Chebx2 || SAGEx2 -> mean pools; observable MLP; 6-wide body
     (reference: docs/tutorials/01_ngem.ipynb cell [9], constructed with n_qubits=5, 22 features, hidden 10)."""
 
+    # ``nodes`` may be rows of a device-resident arena (ops.RowsOf) and ``edge_index`` a GraphStructure: the estimators' serial path
+    # then replays one captured forward per size bucket (train.BucketedPredictor) instead of enqueueing every launch per circuit
+    accepts_device_batches = True
+
     def __init__(self, n_qubits: int, num_node_features: int, hidden_channels: int):
         super().__init__()
         hc = hidden_channels

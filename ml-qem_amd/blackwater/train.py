@@ -565,12 +565,17 @@ class BucketedTrainer(Trainer):
     matters whether the box's host enqueues a 70-launch step in 2 ms or in 6."""
 
     def __init__(self, model: nn.Module, arena, lr: float = 1e-3, graphs: bool = True, node_quantum: int = 1024,
-                 edge_quantum: int = 2048, distributed: bool = False, split_update: bool = False):
+                 edge_quantum: int = 2048, distributed: bool = False, split_update: bool = False, capture_collective: bool = False):
         super().__init__(model, lr=lr, distributed=distributed, flat=True, capturable=True)
         # Under data parallelism the gradient all-reduce sits between two captured halves -- (assembly, forward, backward)
         # and (Adam) -- and is enqueued eagerly: one collective call per step on the host instead of ~70 launches.
         # ``split_update`` forces the two-graph form without a process group (tests).
+        # ``capture_collective``: try to capture the all-reduce INSIDE the step's graph (RCCL collectives are stream-ordered kernels
+        # and can be captured; backend "nccl" only): the step is then ONE replay under data parallelism too.  A capture that raises
+        # falls back to the two-graph form for the rest of the run; ``collective_in_graph`` says which form runs (None: not tried yet).
         self.split = bool(split_update) or self.distributed
+        self.capture_collective = bool(capture_collective) and self.distributed and torch.distributed.get_backend() == "nccl"
+        self.collective_in_graph, self.collective_capture_error = None, None
         if not arena.filler_nodes:
             raise ValueError("BucketedTrainer needs an arena built with filler_nodes > 0")
         if node_quantum > arena.filler_nodes:
@@ -686,15 +691,27 @@ class BucketedTrainer(Trainer):
             kw = {"stream": self._capture_stream()}
             if self._pool is not None:
                 kw["pool"] = self._pool
-            if not self.split:
-                with torch.cuda.graph(entry["graph"], **kw):
-                    entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap)
+            whole = not self.split
+            if self.split and self.capture_collective and self.collective_in_graph is not False:
+                try:        # assembly, forward, backward, all-reduce, Adam as ONE graph
+                    with torch.cuda.graph(entry["graph"], **kw):
+                        entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap)
+                    whole, self.collective_in_graph = True, True
+                except Exception as exc:          # this RCCL / runtime does not capture it: the two-graph form from here on
+                    self.collective_in_graph, self.collective_capture_error = False, f"{type(exc).__name__}: {exc}"
+                    torch.cuda.synchronize()
+                    entry["graph"] = torch.cuda.CUDAGraph()
+            if whole:
+                if "loss" not in entry:
+                    with torch.cuda.graph(entry["graph"], **kw):
+                        entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap)
             else:
                 with torch.cuda.graph(entry["graph"], **kw):
                     entry["loss"] = self._local_half(entry["packed"], len(sel), nb, eb, sizes, real, cap)
+            entry["whole"] = whole
             if self._pool is None:
                 self._pool = entry["graph"].pool()
-            if self.split and self._update_graph is None:
+            if self.split and not whole and self._update_graph is None:
                 # Adam touches the flat buffers only: one graph serves all buckets (its own memory pool: it is replayed after
                 # whichever bucket's graph ran, not in capture order)
                 self._update_graph = torch.cuda.CUDAGraph()
@@ -704,7 +721,7 @@ class BucketedTrainer(Trainer):
         else:
             self._send(entry, host)
         entry["graph"].replay()
-        if self.split:
+        if self.split and not entry["whole"]:
             if self.distributed:
                 self._prescaled = True      # the replayed half scaled the flat buffer by 1/world (its capture ran _forward_backward)
                 t0 = time.perf_counter()
@@ -724,3 +741,93 @@ class BucketedTrainer(Trainer):
         entry["packed"].copy_(slot[0], non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
+
+
+class BucketedPredictor:
+    """Inference analogue of :class:`BucketedTrainer`: model outputs for selections of a device-resident arena, with the WHOLE forward
+    -- device batch assembly and the model -- captured once per size bucket in a hipGraph and replayed.  The serial decorator path
+    (blackwater/library/ngem/estimator.py:49-84: one model call per circuit) runs on it: a 4-qubit circuit is ~270 graph nodes, its
+    ~45 launches take the host 0.6-0.8 ms to enqueue one by one and 0.1 ms to replay (the per-circuit device path was slower than
+    the CPU oracle's loop: 1.2 k against 1.7 k circuits/s).  Models whose launch shapes follow every graph's size
+    (``needs_size_pattern``: Family B) are run eagerly -- a per-circuit pattern never repeats.  The model is used in eval mode under
+    ``torch.no_grad()``; outputs of a replayed bucket are overwritten by the next replay of the same bucket."""
+
+    def __init__(self, model: nn.Module, arena, node_quantum: int = 256, edge_quantum: int = 512, graphs: bool = True):
+        if not arena.filler_nodes:
+            raise ValueError("BucketedPredictor needs an arena built with filler_nodes > 0")
+        self.model, self.nq, self.eq = model, int(min(node_quantum, arena.filler_nodes)), int(edge_quantum)
+        self.graphs = graphs and not getattr(model, "needs_size_pattern", False)
+        self._entries, self._pool, self._stream, self._warm = {}, None, None, False
+        self.captures = 0
+        self.arena = arena.with_capacity(2.0) if self.graphs else arena
+        self._weights = self._weight_addresses()
+
+    def _weight_addresses(self):
+        return tuple(p.data_ptr() for p in self.model.parameters())
+
+    def load(self, arena) -> None:
+        """Another arena's graphs under the SAME captured forwards: its arrays are copied to the addresses the captures read (the
+        circuits of the next run(); data/arena.py refill_from).  An arena that outgrew the allocation, or a model whose parameters
+        moved (``.to()``, a replaced layer), drops the captures and starts again."""
+        if not self.graphs:
+            self.arena = arena
+            return
+        moved = self._weight_addresses() != self._weights
+        if moved or not self.arena.refill_from(arena):
+            self._entries.clear()
+            self._pool = None               # the graphs' memory pool went with the last of them
+            self.arena = arena.with_capacity(2.0)
+            self._weights = self._weight_addresses()
+
+    def _forward(self, packed, b, n_pad, e_pad, sizes, num_real):
+        batch = self.arena.assemble(packed, b, n_pad, e_pad, sizes, None, num_real)
+        return self.model(*batch.model_args())
+
+    def predict_ids(self, graph_ids) -> torch.Tensor:
+        """Outputs [len(graph_ids), out] of the model for these graphs (the filler row of a padded batch is cut off)."""
+        sel0 = np.asarray(graph_ids, dtype=np.int64)
+        nb, eb = int(self.arena.node_counts[sel0].sum()), int(self.arena.edge_counts[sel0].sum())
+        bucket = (-(-nb // self.nq) * self.nq, -(-max(eb, 1) // self.eq) * self.eq, len(sel0))
+        sel, nptr, eptr, n_pad, e_pad, real = self.arena.selection(sel0, bucket[:2])
+        host = np.concatenate([sel, nptr, eptr]).astype(np.int32)
+        sizes = nptr[1:] - nptr[:-1]
+        dev = self.arena.device
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            with torch.no_grad():
+                if not self.graphs:
+                    packed = torch.from_numpy(host).to(dev, non_blocking=True)
+                    return self._forward(packed, len(sel), n_pad, e_pad, sizes, real)[:real]
+                entry = self._entries.get(bucket)
+                if entry is None:
+                    if self._stream is None:
+                        self._stream = torch.cuda.Stream()
+                    entry = {"ring": [[torch.empty(len(host), dtype=torch.int32).pin_memory(), None] for _ in range(4)], "turn": 0,
+                             "packed": torch.empty(len(host), dtype=torch.int32, device=dev), "graph": torch.cuda.CUDAGraph()}
+                    BucketedTrainer._send(entry, host)
+                    if not self._warm:          # torch asks for eager iterations on the capture stream before the first capture
+                        self._stream.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(self._stream):
+                            for _ in range(3):
+                                self._forward(entry["packed"], len(sel), n_pad, e_pad, sizes, real)
+                        torch.cuda.current_stream().wait_stream(self._stream)
+                        self._warm = True
+                    torch.cuda.synchronize()
+                    kw = {"stream": self._stream}
+                    if self._pool is not None:
+                        kw["pool"] = self._pool
+                    with torch.cuda.graph(entry["graph"], **kw):
+                        entry["out"] = self._forward(entry["packed"], len(sel), n_pad, e_pad, sizes, real)
+                    if self._pool is None:
+                        self._pool = entry["graph"].pool()
+                    self._entries[bucket] = entry
+                    self.captures += 1
+                else:
+                    BucketedTrainer._send(entry, host)
+                entry["graph"].replay()
+                return entry["out"][:real]
+        finally:
+            if was_training:
+                self.model.train()
+

@@ -151,3 +151,49 @@ def test_encode_to_device_names_a_bad_circuit_by_its_position_in_the_run(lima_pr
         enc.encode_batch_to_device(texts, DEV, chunks=4, group_bytes=4096)
     x, *_ = enc.encode_batch_to_device(texts[:100], DEV, chunks=4, group_bytes=4096)      # usable after a rejected run
     assert x.shape[0] > 0
+
+
+def test_serial_decorator_replays_one_captured_forward_per_size_bucket(g1, lima_backend):
+    """the serial ``ngem`` loop with this package's Family A on the GPU makes every per-circuit model call by
+    replaying a forward captured per size bucket (train.BucketedPredictor).  The values equal the eager per-circuit loop's; the
+    captures are kept with the model and reused by later run()s over OTHER circuits (their arrays are copied to the addresses the
+    captures read), including a run() that outgrows the allocation, and by one after the model's parameters moved (captures dropped)."""
+    import blackwater.library.ngem.estimator as mod
+    from blackwater.data.backends import PauliObservable
+    from blackwater.library.ngem.estimator import ngem
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from test_estimators import FakeEstimator
+
+    torch.manual_seed(11)
+    model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV).eval()
+    eager = ExpValCircuitGraphModelA(5, 22, 10).to(DEV).eval()
+    eager.load_state_dict(model.state_dict())
+    eager.accepts_device_batches = False          # the plain loop: one encode, one upload, ~45 launches per circuit
+    obs = PauliObservable([("ZIIIZ", 1.0), ("IXIII", -0.5)])
+
+    def both(ids):
+        circuits = [g1["qasm"][i] for i in ids]
+        a = ngem(FakeEstimator, model, lima_backend)().run(circuits, [obs] * len(ids)).result().values
+        b = ngem(FakeEstimator, eager, lima_backend)().run(circuits, [obs] * len(ids)).result().values
+        assert np.abs(a - b).max() < 1e-6, (ids, np.abs(a - b).max())
+        return a
+
+    both(IDX)
+    predictor = mod._predictors[model]
+    first = predictor.captures
+    assert 1 <= first <= len(IDX) and eager not in mod._predictors
+    both(IDX[::-1])                                # the same circuits in another order: no new capture
+    assert predictor.captures == first
+    both([1, 5, 9, 33, 64, 128, 256, 290])         # other circuits, same allocation
+    assert mod._predictors[model] is predictor
+    seen = predictor.captures
+    both(list(range(0, 300, 2)))                   # 150 circuits: outgrows the first allocation (2 x 12 circuits)
+    assert mod._predictors[model] is predictor and predictor.captures > seen
+    keep = [p.data for p in model.parameters()]    # (held, so that the allocator cannot hand the same addresses back)
+    model.to(torch.float64).to(torch.float32)      # parameters at new addresses: the captures of the old ones are dropped
+    again = predictor.captures
+    both(IDX)
+    assert predictor.captures > again and len(keep) > 0
+    # a single circuit keeps the plain call (nothing to amortise a capture over)
+    one = ngem(FakeEstimator, model, lima_backend)().run([g1["qasm"][3]], [obs]).result().values
+    assert np.abs(one - both([3, 3])[:1]).max() < 1e-6

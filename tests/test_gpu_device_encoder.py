@@ -118,11 +118,12 @@ def test_patches_registers_and_odd_circuits(lima_props):
     _same(enc, texts[:2])                                # usable after a rejected run
 
 
-def test_batched_decorator_on_the_device_expansion_equals_the_host_fill(g1, lima_backend, monkeypatch):
-    """ngem(..., batched=True): the values of a run() are the same whether the batch was expanded on the device or filled on the
-    host (same arrays, same model call)."""
-    import blackwater.library.ngem.estimator as mod
+def test_batched_decorator_on_the_device_expansion_equals_the_host_fill(g1, lima_backend):
+    """ngem(..., batched=True) expands the batch on the device: the values of a run() are those of the same model call on the batch
+    the host encoder fills (same arrays, same model call)."""
     from blackwater.data.backends import PauliObservable
+    from blackwater.data.native_encoder import NativeEncoder
+    from blackwater.data.utils import encode_pauli_sum_op, get_backend_properties_v1
     from blackwater.library.ngem.estimator import ngem
     from blackwater.nn import ExpValCircuitGraphModelA
 
@@ -132,8 +133,12 @@ def test_batched_decorator_on_the_device_expansion_equals_the_host_fill(g1, lima
     model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV).eval()
     circuits = [g1["qasm"][i] for i in range(0, 300, 7)]
     obs = PauliObservable("ZIIII")
-    vals = {}
-    for on_device in (True, False):
-        monkeypatch.setattr(mod, "_EXPAND_ON_DEVICE", on_device)
-        vals[on_device] = ngem(FakeEstimator, model, lima_backend, batched=True)().run(circuits, [obs] * len(circuits)).result().values
-    assert np.array_equal(vals[True], vals[False])
+    job = ngem(FakeEstimator, model, lima_backend, batched=True)().run(circuits, [obs] * len(circuits))
+    base = job._base_job.result().values
+    got = job.result().values
+    x, edge_index, batch, _, _ = NativeEncoder(get_backend_properties_v1(lima_backend)).encode_batch(circuits)
+    noisy = torch.tensor([[float(v)] for v in base], dtype=torch.float)
+    observable = torch.tensor([encode_pauli_sum_op(obs)] * len(circuits), dtype=torch.float)
+    with torch.no_grad():
+        want = model(*[a.to(DEV) for a in (noisy, observable, torch.zeros(len(circuits), 1), x, edge_index, batch)])
+    assert np.array_equal(np.asarray(got), want.reshape(len(circuits), -1)[:, 0].cpu().numpy().astype(np.asarray(got).dtype))

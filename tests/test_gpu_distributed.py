@@ -52,6 +52,55 @@ def test_trainer_step_over_rccl_world1(g1):
         torch.distributed.destroy_process_group()
 
 
+def test_all_reduce_captured_inside_the_step_graph_equals_the_eager_step(g1):
+    """``BucketedTrainer(capture_collective=True)`` captures assembly, forward, backward, the flat-gradient all-reduce
+    and Adam as ONE hipGraph (a world-size-1 ``nccl`` group exercises RCCL's capture path on the one GPU); replays of it equal the eager
+    bucketed step and the two-graph form (eager collective between two replays) bit for bit, dropout on.  Should this RCCL refuse the
+    capture, the trainer must say so and still produce the same numbers from the two-graph form."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from blackwater.train import BucketedTrainer
+    from helpers import g1_batch
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        xs, eis = [], []
+        for i in range(64):
+            x, ei, _ = g1_graph(g1, i)
+            loops = np.arange(x.shape[0])
+            xs.append(x.astype(np.float32))
+            eis.append(np.concatenate([ei, np.stack([loops, loops])], axis=1))
+        host = g1_batch(g1, range(64))
+        arena = GraphArena.from_arrays(xs, eis, host["y"].numpy(), host["noisy"].numpy(), host["depth"].numpy(), host["observable"].numpy(),
+                                       device=DEV, filler_nodes=1024)
+        plans = [list(range(k, k + 32)) for k in (0, 8, 16, 24, 32, 0, 8, 16)]
+        runs = {}
+        for mode in ("eager", "two_graphs", "one_graph"):
+            torch.manual_seed(0)
+            model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV)
+            tr = BucketedTrainer(model, arena, lr=1e-3, graphs=mode != "eager", node_quantum=1024, distributed=True,
+                                 capture_collective=mode == "one_graph")
+            assert tr.distributed
+            losses = [float(tr.step_ids(ids).item()) for ids in plans]
+            runs[mode] = (losses, tr.flat_param.detach().clone())
+            if mode == "one_graph":
+                assert tr.collective_in_graph is not None
+                assert tr.collective_in_graph or tr.collective_capture_error        # the form that ran is on record
+                one_graph_form = tr.collective_in_graph
+            ops.set_seed_counter(None)
+        for mode in ("two_graphs", "one_graph"):
+            assert runs[mode][0] == runs["eager"][0], mode
+            assert torch.equal(runs[mode][1], runs["eager"][1]), mode
+        print("collective captured inside the step graph:", one_graph_form)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
 def test_bench_two_ranks_on_one_gpu_rehearsal():
     """Plain ``python bench.py --gpus 2`` (the shape of the driver's command): bench.py starts the two ranks itself before
     touching the GPU, each rank builds ITS shard of the corpus, and rank 0 prints the one line.  The two ranks share this
