@@ -168,9 +168,9 @@ class NgemJob(job_base()):  # type: ignore[misc]
         else:
             predictor.load(arena)           # the captures of earlier run()s, over this run()'s circuits
         mitigated = []
-        for i in range(n):
-            mitigated.append(predictor.predict_ids([i]).reshape(-1)[0].item())      # one model call, one value read back, per circuit
-        return mitigated
+        for i in range(n):              # one model call per circuit; a bucket's output is overwritten by its next replay, so each is kept
+            mitigated.append(predictor.predict_ids([i]).reshape(-1)[:1].clone())
+        return torch.cat(mitigated).tolist()        # ... and the values are read back together
 
     def _result_batched_native(self, result, properties, device):
         """``batched=True``: every circuit of this run() encoded by the C++ encoder on a pool of host threads straight into ONE
