@@ -632,6 +632,9 @@ class _TransformerConv(Function):
         # a structure whose rows share their sources (ASAPooling's coarsened graphs of large circuits) takes the tiled kernels
         tiled = (_TILES and struct.tiled and w.is_cuda and struct.out_eid is None
                  and ops.tile_attention_fits(heads, channels, 16 if 13 <= channels <= 16 else 0))
+        # ... or, its long rows as dense blocks, the edge softmax on the matrix cores (csrc/dense_block.hip)
+        dense = (_DENSE_BLOCKS and not tiled and struct.tiled and w.is_cuda and struct.out_eid is None and channels < 16
+                 and ops.dense_attention_supported(heads, channels, 16))
         if not any(ctx.needs_input_grad) and drop_p == 0.0:  # inference: no statistics kept
             if tiled:
                 wp, bp = _pad_heads(w, b, 4 * heads, channels, 16)
@@ -642,10 +645,11 @@ class _TransformerConv(Function):
         # aligned 64-byte piece).  The projection writes that layout by itself when its weight and bias rows are padded the same way
         # (zero rows: the pads of qkvs are zeros, the gradient of a pad row is exactly zero); w itself stays [4 H C, in].
         cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and w.is_cuda) else 0
-        if tiled:
+        if tiled or dense:
             cp = 16 if channels < 16 else 0
         ctx.cp = cp
         ctx.tiled = tiled
+        ctx.dense = dense
         w_used, b_used = _pad_heads(w, b, 4 * heads, channels, cp) if cp else (w, b)
         qkvs = ops.linear(x, w_used, b_used)
         # a structure without out_eid (ASAPooling's coarsened graphs: no parallel edges) takes the recomputed backward, whose dropout
@@ -656,6 +660,9 @@ class _TransformerConv(Function):
         if tiled:
             out, attn, m, den = ops.tile_attention(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
                                                    struct.tile_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp or channels)
+        elif dense:
+            out, attn, m, den = ops.dense_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
+                                                         struct.dense_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp)
         else:
             out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
                                                                channels, drop_p, seed, pair_key=pair_key, ell=ell, head_pitch=cp)
@@ -680,6 +687,10 @@ class _TransformerConv(Function):
             st = ctx.struct
             gqkvs = ops.tile_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, st.tile_plan("in"), st.tile_plan("out"),
                                            drop_p=drop_p, seed=seed, head_pitch=cp or channels)
+        elif ctx.dense:
+            st = ctx.struct
+            gqkvs = ops.dense_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, st.dense_plan("in"), st.dense_plan("out"),
+                                            drop_p=drop_p, seed=seed, head_pitch=cp)
         else:
             gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key,
                                                   head_pitch=cp)
@@ -713,6 +724,9 @@ def _pad_heads(w, b, groups, channels, cp):
 # gathers, and a tile's prologue + staging round trips cost what a whole per-edge launch does); tests/test_gpu_tiles.py keeps the path
 # correct against the per-edge kernels and the oracle.
 _TILES = os.environ.get("MLQEM_TILES", "0") == "1"
+# the long rows of ASAPooling's coarsened graphs as dense blocks: TransformerConv's edge softmax over them on the f32 matrix cores
+# (csrc/dense_block.hip); MLQEM_DENSE_BLOCKS=0: the per-edge kernels for every row (A/B runs, tests/test_gpu_dense_blocks.py)
+_DENSE_BLOCKS = os.environ.get("MLQEM_DENSE_BLOCKS", "1") == "1"
 # channel pitch of a head inside q / k / v / skip in training (0: compact heads, the layout of rounds 1-3; the parity test of the two
 # layouts sets it)
 _ATTN_PITCH = 16
@@ -852,7 +866,7 @@ class _ASAPool(Function):
         # every kept centre, -1 elsewhere) does not depend on it
         slot = ops.asap_slot_map(perm, n)
         holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=keep)
-        if (_TILES and use_rows and use_lists and not link and len(keep) > 0 and ops.asap_dense_max_k() < int(keep.max())):
+        if ((_TILES or _DENSE_BLOCKS) and use_rows and use_lists and not link and len(keep) > 0 and ops.asap_dense_max_k() < int(keep.max())):
             # large graphs (the list coarsening's): clusters whose centres are close in program order share their neighbours, so
             # the layers that read this graph walk it in tiles of rows ordered by their centres' node index
             def tile_spec(slot=slot, gptr=s.graph_ptr, b=s.num_graphs):

@@ -1608,6 +1608,69 @@ def tile_plan_build(ptr, idx, num_rows, num_entries, order, max_span, tile_rows=
     return TilePlan(tinfo, rinfo, uni, loc, num_tiles, cap, tile_rows)
 
 
+class DensePlan:
+    """A structure's long rows as dense blocks (csrc/dense_block.hpp): what the matrix-core forms of the edge walks read."""
+
+    def __init__(self, records, counter, row_flag, lrows, max_blocks):
+        self.records, self.counter, self.row_flag, self.lrows, self.max_blocks = records, counter, row_flag, lrows, int(max_blocks)
+
+    def args(self):
+        return _p(self.records), _p(self.counter), _p(self.row_flag), self.max_blocks
+
+
+def dense_plan_build(ptr, idx, loops, num_rows, graph_ptr, num_graphs, order, max_span) -> DensePlan:
+    """The dense blocks of the CSR (ptr, idx): rows of 32+ entries, 16 at a time in ``order`` (program position; None = row order)
+    inside each graph (``graph_ptr``: the graphs' position ranges)."""
+    lib = _lib.load()
+    dev = ptr.device
+    _vec(ptr, "ptr", num_rows + 1, torch.int32)
+    max_blocks = max(int(lib.mlqem_dense_plan_max_blocks(num_rows, num_graphs)), 1)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    row_flag = torch.zeros(max(num_rows, 1), dtype=torch.uint8, device=dev)
+    lrows = torch.empty(max_blocks * 16, dtype=torch.int32, device=dev)
+    records = torch.empty(max_blocks * lib.mlqem_dense_plan_record_ints(), dtype=torch.int32, device=dev)
+    code = lib.mlqem_dense_plan_build(_p(ptr), _p(idx), _p(loops), _p(order), _p(graph_ptr), num_graphs, num_rows, int(max_span),
+                                      _p(counter), _p(lrows), _p(records), _p(row_flag), _stream())
+    _lib.check(code, "mlqem_dense_plan_build")
+    return DensePlan(records, counter, row_flag, lrows, max_blocks)
+
+
+def dense_attention_supported(heads, channels, head_pitch) -> bool:
+    return bool(_lib.load().mlqem_dense_attention_supported(heads, channels, head_pitch or channels))
+
+
+def dense_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, plan: DensePlan, drop_p=0.0, seed=0, head_pitch=16):
+    """``transformer_attention_train`` (pair-keyed draws) with the plan's rows on the matrix cores: (out, attn_out, m, den)."""
+    n, hc = qkvs.shape[0], heads * channels
+    dev = qkvs.device
+    out, attn = padded_empty(n, hc, dev), padded_empty(n, hc, dev)
+    m = torch.empty((max(n, 1), heads), dtype=torch.float32, device=dev)
+    den = torch.empty_like(m)
+    code = _lib.load().mlqem_dense_attention_train_f32(
+        _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
+        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, int(head_pitch), *plan.args(),
+        _p(out), _mat(out, "out"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
+    _lib.check(code, "mlqem_dense_attention_train_f32")
+    return out, attn, m, den
+
+
+def dense_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, plan_in: DensePlan, plan_out: DensePlan, drop_p=0.0, seed=0,
+                        head_pitch=16):
+    """``transformer_attention_bwd`` (recomputing form) with the plans' rows on the matrix cores: the gradient of qkvs."""
+    n = qkvs.shape[0]
+    g = rowmajor(g)
+    dev = qkvs.device
+    gqkvs = padded_empty(n, 4 * heads * head_pitch, dev)
+    al = torch.empty(4 * max(n, 1) * heads, dtype=torch.float32, device=dev)
+    code = _lib.load().mlqem_dense_attention_bwd_f32(
+        _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr), _p(s.in_src),
+        _p(s.out_ptr), _p(s.out_dst), _p(s.loops), n, num_edges, heads, channels, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+        _p(_seed_counter) if drop_p > 0 else None, int(head_pitch), *plan_in.args(), *plan_out.args(), _p(gqkvs), _mat(gqkvs, "gqkvs"),
+        _p(al), _stream())
+    _lib.check(code, "mlqem_dense_attention_bwd_f32")
+    return gqkvs
+
+
 _LDS_BUDGET = 80 * 1024      # per workgroup: two workgroups of a tiled kernel per CU (160 KB)
 
 

@@ -56,10 +56,25 @@ class GraphStructure:
         never pays for it); ``max_span``: a bound on the id range of one tile's entries."""
         self._tile_spec = make
         self._tile_plans = {}
+        self._dense_plans = {}
 
     @property
     def tiled(self) -> bool:
         return self._tile_spec is not None
+
+    def dense_plan(self, direction: str):
+        """The dense blocks of the in- ("in") or out-structure ("out") (csrc/dense_block.hpp), built on first use; None for a
+        structure without a tile spec (its rows are short, or nothing is known about their order)."""
+        if self._tile_spec is None:
+            return None
+        if direction not in self._dense_plans:
+            if callable(self._tile_spec):
+                self._tile_spec = self._tile_spec()
+            order, max_span = self._tile_spec
+            ptr, idx = (self.in_ptr, self.in_src) if direction == "in" else (self.out_ptr, self.out_dst)
+            self._dense_plans[direction] = ops.dense_plan_build(ptr, idx, self.loops, self.num_nodes, self.graph_ptr, self.num_graphs,
+                                                                order, max_span)
+        return self._dense_plans[direction]
 
     def tile_plan(self, direction: str):
         """The plan of the in-CSR ("in": forward and destination-side passes) or of the out-CSR ("out": source-side passes),
@@ -82,6 +97,7 @@ class GraphStructure:
         self.coarse_capacity = None   # host-side upper bound on the edges of this structure's ASAPooling coarsening (data/arena.py)
         self._tile_spec = None        # (order, tiles, num_tiles, max_span): what a tiled row walk's plan is built from (set_tile_spec)
         self._tile_plans = {}
+        self._dense_plans = {}
         self._norms = norms
         self._derived = {} if derived is None else dict(derived)
         self._colsum = {} if colsums is None else dict(zip(("gcn", "sage", "cheb"), colsums))

@@ -49,6 +49,7 @@ struct AttnFwdArgs {
                                             // channels of the reference's models: every key / value / query segment is then an aligned
                                             // 16-byte-per-lane, 64-byte-per-head piece (pads are zeros the projection's padded weights
                                             // produce); out / attn_out stay compact [N, H C] (four-channels-per-lane kernels only)
+  const uint8_t* skip = nullptr;            // optional [N]: rows served by a dense block (dense_block.hpp) are left alone
 };
 
 // Arguments of the backward kernels (family_b_bwd.hip, tile_attn.hip).
@@ -60,6 +61,8 @@ struct AttnBwdArgs {
   float* gqkvs; int64_t ldq; float* edge_al; float* edge_gs;
   int pair_key;                   // as the forward's (attn_fwd.hpp)
   int CP;                         // as the forward's: channel pitch of a head inside the parts of qkvs AND gqkvs (0 = C)
+  const uint8_t* skip_dst = nullptr;   // optional [N]: rows whose destination side / source side a dense block serves (dense_block.hpp)
+  const uint8_t* skip_src = nullptr;
 };
 // oeid == nullptr selects the RECOMPUTING source side (transformer_attn_bwd_src_rc_q4_kernel): the destination side then files
 // delta[N, H] = g . attn_out per (row, head) in edge_al (its first N H floats) and writes nothing per edge.

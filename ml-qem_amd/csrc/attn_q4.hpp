@@ -86,6 +86,7 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;                             // a whole (row, head) leaves together
   const int row = (int)(t / H);
+  if (a.skip && a.skip[row]) return;
   const int h = (int)(t - (int64_t)row * H);
   const int nv = min(4, max(0, C - 4 * lq));            // real channels of this lane
   const int off = h * C + 4 * lq;                       // the lane's first channel inside a compact [H C] row (out, attn_out)

@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "attn_q4.hpp"
+#include "dense_block.hpp"
 #include "common.hpp"
 
 namespace mlqem {
@@ -255,6 +256,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;
   const int row = (int)(t / H);
+  if (a.skip_dst && a.skip_dst[row]) return;
   const int h = (int)(t - (int64_t)row * H);
   const int nv = min(4, max(0, C - 4 * lq));
   const int off = h * C + 4 * lq;
@@ -347,6 +349,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int H = a.H, C = a.C, HC = H * C;
   if (t >= a.N * H) return;
   const int row = (int)(t / H);
+  if (a.skip_src && a.skip_src[row]) return;
   const int h = (int)(t - (int64_t)row * H);
   const int nv = min(4, max(0, C - 4 * lq));
   const int off = h * C + 4 * lq;
@@ -1121,6 +1124,22 @@ __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
 using namespace mlqem;
 
 #define MLQEM_GRID(n) dim3((unsigned)ceil_div((n), kBlock)), dim3(kBlock), 0, as_stream(stream)
+
+namespace mlqem {
+// the four-channels-per-lane kernels for callers in other translation units (dense_block.hip: the rows its blocks do not serve)
+void launch_attn_train_q4(const AttnFwdArgs& a, hipStream_t stream) {
+  if (a.C > 16) hipLaunchKernelGGL(transformer_attn_train_q4_kernel<8>, dim3((unsigned)ceil_div(a.N * a.H * 8, kBlock)), dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL(transformer_attn_train_q4_kernel<4>, dim3((unsigned)ceil_div(a.N * a.H * 4, kBlock)), dim3(kBlock), 0, stream, a);
+}
+void launch_attn_bwd_dst_q4(const AttnBwdArgs& a, hipStream_t stream) {
+  if (a.C > 16) hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, dim3((unsigned)ceil_div(a.N * a.H * 8, kBlock)), dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<4>, dim3((unsigned)ceil_div(a.N * a.H * 4, kBlock)), dim3(kBlock), 0, stream, a);
+}
+void launch_attn_bwd_src_rc_q4(const AttnBwdArgs& a, hipStream_t stream) {
+  if (a.C > 16) hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<8>, dim3((unsigned)ceil_div(a.N * a.H * 8, kBlock)), dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<4>, dim3((unsigned)ceil_div(a.N * a.H * 4, kBlock)), dim3(kBlock), 0, stream, a);
+}
+}  // namespace mlqem
 
 extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
                                                      const int32_t* in_src, const int32_t* loops, int64_t N, int64_t E,

@@ -43,6 +43,20 @@ with torch.no_grad():
 n, e = s.num_nodes, s.edge_count()
 real_e = int(s.in_ptr[n].item())
 print(f"level 1: N = {n}, E = {real_e} (capacity {e}), tiled = {s.tiled}, tile rows {ops.TILE_ROWS}, cap {ops.TILE_CAP}", flush=True)
+for name, ptr in (("in", s.in_ptr), ("out", s.out_ptr)):
+    # how the quad walk of the per-edge kernels (4 lanes per (row, head), 8 rows per wave, 4 entries per trip) fills its waves:
+    # a wave makes as many trips as its LONGEST row needs
+    deg = np.diff(ptr[: n + 1].cpu().numpy().astype(np.int64)) + 1
+    trips = -(-deg // 4)
+    pad = (-len(trips)) % 8
+    per_wave = np.concatenate([trips, np.zeros(pad, np.int64)]).reshape(-1, 8)
+    long_rows = deg >= 32
+    short_trips = np.where(long_rows, 0, trips)
+    coop = np.concatenate([short_trips, np.zeros(pad, np.int64)]).reshape(-1, 8).max(1).sum() + 2 * (-(-deg[long_rows] // 64)).sum()
+    print(f"rows {name}: degree median {int(np.median(deg))}, p90 {int(np.percentile(deg, 90))}, p99 {int(np.percentile(deg, 99))}, max {deg.max()}; "
+          f"rows of 32+ entries: {100.0 * long_rows.mean():.2f} % of the rows, {100.0 * deg[long_rows].sum() / deg.sum():.1f} % of the entries; "
+          f"wave trips: {per_wave.max(1).sum()} as walked, {int(np.ceil(trips.sum() / 8))} if every quad were busy, {coop} with long rows shared by the wave",
+          flush=True)
 pin, pout = s.tile_plan("in"), s.tile_plan("out")
 for name, p in (("in", pin), ("out", pout)):
     ti = p.tinfo.cpu().numpy()

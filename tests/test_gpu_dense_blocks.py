@@ -1,0 +1,149 @@
+"""Dense blocks (csrc/dense_block.hip; round 5): TransformerConv's edge softmax over the long rows of ASAPooling's coarsened graphs on
+the f32 matrix cores (docs/tutorials/gnn.py:80-91: the second TransformerConv of every reference GNN), against the per-edge kernels.
+
+The per-edge kernels are pinned to dense fp64 algebra and to the oracle (test_gpu_family_b.py); here the block forms must reproduce
+them on graphs shaped like the coarsened ones -- long rows that share their sources, short rows between them, graphs of every size,
+with and without self entries, with dropout (keyed by (destination, head, source): the same draws in both forms) -- and the plan
+itself must list exactly the structure's entries.  Tolerance: 2e-5 of each result's scale (another fp32 summation order, exp2 on the
+hardware's transcendental unit); the plan exactly."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_tiles import _blocky_graphs, _structure
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SIZES = [700, 1, 333, 64, 2, 1500]
+CAP = 512            # kDbCap of csrc/dense_block.hpp: union slots of a block
+
+
+def _make(seed, loops_p, sizes=SIZES, permute=True):
+    rng = np.random.RandomState(seed)
+    ei, loops, n = _blocky_graphs(rng, sizes, loops_p)
+    s = _structure(ei, loops, n, sizes)
+    # "program order": a graph's rows sorted by where their sources sit (rows around one hub follow each other, as the clusters
+    # around one barrier of a circuit do), ties and source-less rows shuffled -- blocks that straddle two hubs outgrow the capacity
+    # and stay with the per-edge kernels
+    centre = np.full(n, -1.0)
+    sums, cnts = np.bincount(ei[1], weights=ei[0], minlength=n), np.bincount(ei[1], minlength=n)
+    centre[cnts > 0] = np.floor(sums[cnts > 0] / cnts[cnts > 0] / 40.0)
+    centre += rng.rand(n) * (0.5 if permute else 0.0)
+    offs = np.cumsum([0] + sizes[:-1])
+    centre[offs[-1]:] = rng.rand(sizes[-1])            # ... and the last graph's rows in NO order: its blocks outgrow the capacity
+    order = torch.cat([torch.from_numpy(np.argsort(centre[o:o + k], kind="stable") + o) for k, o in zip(sizes, offs)])
+    order = order.to(torch.int32).to(DEV)
+    s.set_tile_spec(lambda: (order, max(sizes) + 8))
+    return s, order, rng
+
+
+@pytest.mark.parametrize("direction", ["in", "out"])
+@pytest.mark.parametrize("loops_p", [0.0, 0.6])
+def test_plan_lists_exactly_the_entries_of_the_long_rows(direction, loops_p):
+    """Every row of 32+ entries sits in exactly one block, in program order inside its graph; a block's union is the sorted set of its
+    rows' sources and the rows themselves; a cell's bit is set exactly when the cell is an entry (or the row's own self-loop)."""
+    from blackwater.native import _lib
+
+    s, order, _ = _make(3, loops_p)
+    plan = s.dense_plan(direction)
+    ptr, idx = (s.in_ptr, s.in_src) if direction == "in" else (s.out_ptr, s.out_dst)
+    ptr, idx, loops = ptr.cpu().numpy(), idx.cpu().numpy(), s.loops.cpu().numpy()
+    stride = _lib.load().mlqem_dense_plan_record_ints()
+    nblocks = int(plan.counter.item()) // 16
+    rec = plan.records.cpu().numpy()[: nblocks * stride].reshape(nblocks, stride)
+    flag = plan.row_flag.cpu().numpy()
+    deg = np.diff(ptr[: s.num_nodes + 1])
+    gid = np.repeat(np.arange(len(SIZES)), SIZES)
+    order_h = order.cpu().numpy()
+    rank = np.empty(s.num_nodes, np.int64)
+    rank[order_h] = np.arange(s.num_nodes)
+    seen = np.zeros(s.num_nodes, bool)
+    assert nblocks > 10
+    usable = 0
+    for b in range(nblocks):
+        nrows, nu, ok, entries = rec[b, :4]
+        rows = rec[b, 4:4 + nrows]
+        assert 1 <= nrows <= 16 and (rec[b, 4 + nrows:20] == -1).all()
+        assert (deg[rows] >= 32).all() and len(set(gid[rows])) == 1 and (np.diff(rank[rows]) > 0).all()
+        assert not seen[rows].any()
+        seen[rows] = True
+        assert entries == deg[rows].sum()
+        union = np.unique(np.concatenate([idx[ptr[r]:ptr[r + 1]] for r in rows] + [rows]))
+        assert ok == (len(union) <= CAP) and (flag[rows] == ok).all()
+        usable += int(ok)
+        if not ok:
+            continue
+        assert nu == len(union) and (rec[b, 36:36 + nu] == union).all() and (rec[b, 36 + nu:36 + CAP] == rows[0]).all()
+        mask = rec[b, 36 + CAP:36 + CAP + CAP // 2].view(np.uint32).reshape(16, CAP // 32)
+        bits = ((mask[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(16, CAP).astype(bool)
+        for i, r in enumerate(rows):
+            want = np.isin(union, idx[ptr[r]:ptr[r + 1]])
+            selfs = np.searchsorted(union, r)
+            assert rec[b, 20 + i] == selfs
+            if loops[r] > 0:
+                want[selfs] = True
+            assert (bits[i, :nu] == want).all() and not bits[i, nu:].any()
+        assert not bits[nrows:].any()
+    assert (seen == (deg >= 32)).all() and not flag[deg < 32].any()
+    # both kinds of block occur (the out-structure's unions -- the long rows of a few hubs -- are small in every order)
+    assert 0 < usable and (usable < nblocks or direction == "out")
+
+
+def _qkvs(rng, n, heads, ch):
+    from blackwater.native import ops
+
+    q = torch.zeros(n, 4 * heads, 16)
+    q[:, :, :ch] = torch.from_numpy(rng.standard_normal((n, 4 * heads, ch)).astype(np.float32))
+    return ops.padded_copy(q.view(n, -1).to(DEV))
+
+
+def _close(a, b, what, tol=2e-5):
+    scale = max(1.0, b.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err < tol * scale, (what, err, scale)
+
+
+@pytest.mark.parametrize("heads,ch,drop_p,loops_p", [(2, 15, 0.1, 0.0), (2, 15, 0.0, 0.7), (1, 16, 0.25, 0.5), (2, 13, 0.1, 1.0)])
+def test_attention_on_the_blocks_equals_the_per_edge_kernels(heads, ch, drop_p, loops_p):
+    """Forward (out, attn_out, both statistics) and backward (the gradient of [query | key | value | skip]) of the edge softmax."""
+    from blackwater.native import ops
+
+    s, _, rng = _make(11 + heads, loops_p)
+    n, e = s.num_nodes, s.edge_count()
+    assert ops.dense_attention_supported(heads, ch, 16)
+    qkvs = _qkvs(rng, n, heads, ch)
+    pin, pout = s.dense_plan("in"), s.dense_plan("out")
+    assert int(pin.row_flag.sum().item()) > 100 and int(pout.row_flag.sum().item()) > 100
+    ref = ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, drop_p, 7, pair_key=True, head_pitch=16)
+    got = ops.dense_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, pin, drop_p=drop_p, seed=7)
+    deg = (s.in_ptr[1:n + 1] - s.in_ptr[:n]).cpu() + (s.loops.cpu() > 0).int()
+    stored = (deg > 4).to(DEV)                                   # rows of at most four entries leave attn_out unwritten
+    _close(got[0], ref[0], "out")
+    _close(got[1][stored], ref[1][stored], "attn_out")
+    fin = torch.isfinite(ref[2])
+    _close(got[2][fin], ref[2][fin], "m")
+    _close(got[3], ref[3], "den")
+    gout = ops.padded_copy(torch.from_numpy(rng.standard_normal((n, heads * ch)).astype(np.float32)).to(DEV))
+    gref = ops.transformer_attention_bwd(qkvs, gout, ref[1], ref[2], ref[3], s, e, heads, ch, drop_p, 7, pair_key=True, head_pitch=16)
+    ggot = ops.dense_attention_bwd(qkvs, gout, got[1], got[2], got[3], s, e, heads, ch, pin, pout, drop_p=drop_p, seed=7)
+    for part, name in enumerate(("query", "key", "value", "skip")):
+        w = heads * 16
+        _close(ggot[:, part * w:(part + 1) * w], gref[:, part * w:(part + 1) * w], "gradient of " + name)
+
+
+def test_a_structure_without_long_rows_has_no_blocks_and_the_same_results():
+    from blackwater.native import ops
+
+    rng = np.random.RandomState(2)
+    sizes = [40, 9]
+    ei = np.stack([rng.randint(0, 40, 90), rng.randint(0, 40, 90)])
+    ei = np.unique(ei[:, ei[0] != ei[1]], axis=1)
+    s = _structure(ei, np.zeros(49, np.int64), 49, sizes)
+    s.set_tile_spec(lambda: (None, 64))
+    pin = s.dense_plan("in")
+    assert int(pin.counter.item()) == 0 and int(pin.row_flag.sum().item()) == 0
+    qkvs = _qkvs(rng, 49, 2, 15)
+    e = s.edge_count()
+    ref = ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, 2, 15, 0.1, 3, pair_key=True, head_pitch=16)
+    got = ops.dense_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, 2, 15, pin, drop_p=0.1, seed=3)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[3], ref[3])
