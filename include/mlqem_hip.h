@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 27 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 28 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -768,10 +768,10 @@ int mlqem_tile_asap_scores_bwd_f32(const float* x, int64_t ldx, const float* xne
  * are flagged in row_flag and left alone by the per-edge kernels, which serve every other row in the same call.
  *
  * mlqem_dense_plan_build, once per structure and direction (in-CSR: forward and destination-side backward; out-CSR: source-side
- * backward):  counter[1] (zero on entry) receives 16 x the number of blocks; lrows[16 * max_blocks] the blocks' rows;
+ * backward):  counter[1] (zero on entry) receives 16 x the number of blocks; lrows[17 * max_blocks] the blocks' rows, then their graphs;
  * records[max_blocks * mlqem_dense_plan_record_ints()] (16-byte aligned) the blocks; row_flag[num_rows] (zero on entry) the flags.
  * max_blocks = mlqem_dense_plan_max_blocks(num_rows, num_graphs).  graph_ptr[num_graphs + 1]: the graphs' ranges of positions in
- * `order` (null: the rows themselves); max_span: a bound on the id range of one graph's rows (<= mlqem_tile_plan_max_span()).
+ * `order` AND of row ids (null order: the rows themselves); max_span: a bound on the rows of one graph (<= mlqem_tile_plan_max_span()).
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_dense_plan_record_ints(void);
 int mlqem_dense_plan_min_degree(void);
@@ -782,21 +782,25 @@ int mlqem_dense_plan_build(const int32_t* ptr, const int32_t* idx, const int32_t
 /* 1 when the dense kernels serve this shape: one or two heads of at most 16 channels at a head pitch of 16 */
 int mlqem_dense_attention_supported(int H, int C, int head_pitch);
 /* mlqem_transformer_attention_train_f32 (pair-keyed dropout draws, no side table) with the rows of the plan's blocks on the matrix
- * cores: same arguments, outputs and statistics. */
+ * cores: same arguments, outputs and statistics.  `parts` selects the launches of this call -- 1: the per-edge kernel over the rows
+ * outside the blocks, 2: the block kernel (3: both) -- so that a caller may put the two, which touch disjoint rows, on two streams. */
 int mlqem_dense_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
                                     const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
                                     const uint64_t* seed_counter, int head_pitch, const int32_t* records, const int32_t* counter,
-                                    const uint8_t* row_flag, int64_t max_blocks, float* out, int64_t ldo, float* attn_out,
-                                    int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream);
+                                    const uint8_t* row_flag, int64_t max_blocks, int parts, float* out, int64_t ldo,
+                                    float* attn_out, int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream);
 /* mlqem_transformer_attention_bwd_f32 in its recomputing form (no out_eid, no per-edge buffers; edge_al: [4 N H] floats, 16-byte
- * aligned) with a plan of the in-CSR for the destination side and one of the out-CSR for the source side. */
+ * aligned) with a plan of the in-CSR for the destination side and one of the out-CSR for the source side.  `parts`: 1 / 2 =
+ * destination side per-edge rows / blocks, 4 / 8 = source side per-edge rows / blocks (15: all four, in that order).  The source
+ * side reads what BOTH destination-side launches file in edge_al. */
 int mlqem_dense_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg, const float* attn_out, int64_t lda,
                                   const float* stat_m, const float* stat_den, const int32_t* in_ptr, const int32_t* in_src,
                                   const int32_t* out_ptr, const int32_t* out_dst, const int32_t* loops, int64_t N, int64_t E, int H,
                                   int C, float drop_p, uint64_t seed, const uint64_t* seed_counter, int head_pitch,
                                   const int32_t* in_records, const int32_t* in_counter, const uint8_t* in_flag, int64_t in_max_blocks,
                                   const int32_t* out_records, const int32_t* out_counter, const uint8_t* out_flag,
-                                  int64_t out_max_blocks, float* gqkvs, int64_t ldq, float* edge_al, mlqem_stream_t stream);
+                                  int64_t out_max_blocks, int parts, float* gqkvs, int64_t ldq, float* edge_al,
+                                  mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Host-side native encoder (no GPU needed).  Replaces the Python loops of circuit_to_graph_data_json

@@ -662,7 +662,8 @@ class _TransformerConv(Function):
                                                    struct.tile_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp or channels)
         elif dense:
             out, attn, m, den = ops.dense_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
-                                                         struct.dense_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp)
+                                                         struct.dense_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp,
+                                                         side=_dense_side(w.device))
         else:
             out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
                                                                channels, drop_p, seed, pair_key=pair_key, ell=ell, head_pitch=cp)
@@ -690,7 +691,7 @@ class _TransformerConv(Function):
         elif ctx.dense:
             st = ctx.struct
             gqkvs = ops.dense_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, st.dense_plan("in"), st.dense_plan("out"),
-                                            drop_p=drop_p, seed=seed, head_pitch=cp)
+                                            drop_p=drop_p, seed=seed, head_pitch=cp, side=_dense_side(w.device))
         else:
             gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key,
                                                   head_pitch=cp)
@@ -727,6 +728,14 @@ _TILES = os.environ.get("MLQEM_TILES", "0") == "1"
 # the long rows of ASAPooling's coarsened graphs as dense blocks: TransformerConv's edge softmax over them on the f32 matrix cores
 # (csrc/dense_block.hip); MLQEM_DENSE_BLOCKS=0: the per-edge kernels for every row (A/B runs, tests/test_gpu_dense_blocks.py)
 _DENSE_BLOCKS = os.environ.get("MLQEM_DENSE_BLOCKS", "1") == "1"
+# True: the per-edge kernel over the rows outside the blocks on a side stream, beside the block kernel (disjoint rows).  Measured on
+# 64 100-qubit circuits: 117.7 us against 109.4 on one stream (forward), 305.5 against 290.7 (backward) -- the first kernel fills
+# the chip, the fork and join cost more than the overlap gains
+_DENSE_TWO_STREAMS = False
+
+
+def _dense_side(device):
+    return _branch_streams(device)[0] if _DENSE_TWO_STREAMS else None
 # channel pitch of a head inside q / k / v / skip in training (0: compact heads, the layout of rounds 1-3; the parity test of the two
 # layouts sets it)
 _ATTN_PITCH = 16

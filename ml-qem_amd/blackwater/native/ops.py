@@ -1627,7 +1627,7 @@ def dense_plan_build(ptr, idx, loops, num_rows, graph_ptr, num_graphs, order, ma
     max_blocks = max(int(lib.mlqem_dense_plan_max_blocks(num_rows, num_graphs)), 1)
     counter = torch.zeros(1, dtype=torch.int32, device=dev)
     row_flag = torch.zeros(max(num_rows, 1), dtype=torch.uint8, device=dev)
-    lrows = torch.empty(max_blocks * 16, dtype=torch.int32, device=dev)
+    lrows = torch.empty(max_blocks * 17, dtype=torch.int32, device=dev)      # the blocks' rows, then one graph id per block
     records = torch.empty(max_blocks * lib.mlqem_dense_plan_record_ints(), dtype=torch.int32, device=dev)
     code = lib.mlqem_dense_plan_build(_p(ptr), _p(idx), _p(loops), _p(order), _p(graph_ptr), num_graphs, num_rows, int(max_span),
                                       _p(counter), _p(lrows), _p(records), _p(row_flag), _stream())
@@ -1639,35 +1639,62 @@ def dense_attention_supported(heads, channels, head_pitch) -> bool:
     return bool(_lib.load().mlqem_dense_attention_supported(heads, channels, head_pitch or channels))
 
 
-def dense_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, plan: DensePlan, drop_p=0.0, seed=0, head_pitch=16):
-    """``transformer_attention_train`` (pair-keyed draws) with the plan's rows on the matrix cores: (out, attn_out, m, den)."""
+def _two_streams(first, second, side):
+    """``first()`` on a side stream while ``second()`` runs on the caller's: two launches that touch disjoint rows.  Joined before
+    returning (the caller's stream then holds both)."""
+    if side is None:
+        first()
+        second()
+        return
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        first()
+    second()
+    main.wait_stream(side)
+
+
+def dense_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, plan: DensePlan, drop_p=0.0, seed=0, head_pitch=16,
+                          side=None):
+    """``transformer_attention_train`` (pair-keyed draws) with the plan's rows on the matrix cores: (out, attn_out, m, den).
+    ``side``: a stream for the per-edge kernel over the rows outside the blocks, which then runs beside the block kernel."""
     n, hc = qkvs.shape[0], heads * channels
     dev = qkvs.device
     out, attn = padded_empty(n, hc, dev), padded_empty(n, hc, dev)
     m = torch.empty((max(n, 1), heads), dtype=torch.float32, device=dev)
     den = torch.empty_like(m)
-    code = _lib.load().mlqem_dense_attention_train_f32(
-        _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
-        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, int(head_pitch), *plan.args(),
-        _p(out), _mat(out, "out"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
-    _lib.check(code, "mlqem_dense_attention_train_f32")
+
+    def call(parts):
+        code = _lib.load().mlqem_dense_attention_train_f32(
+            _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, int(head_pitch), *plan.args(), parts,
+            _p(out), _mat(out, "out"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _stream())
+        _lib.check(code, "mlqem_dense_attention_train_f32")
+
+    _two_streams(lambda: call(1), lambda: call(2), side)
     return out, attn, m, den
 
 
 def dense_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, plan_in: DensePlan, plan_out: DensePlan, drop_p=0.0, seed=0,
-                        head_pitch=16):
+                        head_pitch=16, side=None):
     """``transformer_attention_bwd`` (recomputing form) with the plans' rows on the matrix cores: the gradient of qkvs."""
     n = qkvs.shape[0]
     g = rowmajor(g)
     dev = qkvs.device
     gqkvs = padded_empty(n, 4 * heads * head_pitch, dev)
     al = torch.empty(4 * max(n, 1) * heads, dtype=torch.float32, device=dev)
-    code = _lib.load().mlqem_dense_attention_bwd_f32(
-        _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr), _p(s.in_src),
-        _p(s.out_ptr), _p(s.out_dst), _p(s.loops), n, num_edges, heads, channels, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
-        _p(_seed_counter) if drop_p > 0 else None, int(head_pitch), *plan_in.args(), *plan_out.args(), _p(gqkvs), _mat(gqkvs, "gqkvs"),
-        _p(al), _stream())
-    _lib.check(code, "mlqem_dense_attention_bwd_f32")
+
+    def call(parts):
+        code = _lib.load().mlqem_dense_attention_bwd_f32(
+            _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr), _p(s.in_src),
+            _p(s.out_ptr), _p(s.out_dst), _p(s.loops), n, num_edges, heads, channels, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            _p(_seed_counter) if drop_p > 0 else None, int(head_pitch), *plan_in.args(), *plan_out.args(), parts, _p(gqkvs),
+            _mat(gqkvs, "gqkvs"), _p(al), _stream())
+        _lib.check(code, "mlqem_dense_attention_bwd_f32")
+
+    # the source side reads the records BOTH destination-side launches file: joined in between
+    _two_streams(lambda: call(1), lambda: call(2), side)
+    _two_streams(lambda: call(4), lambda: call(8), side)
     return gqkvs
 
 

@@ -70,44 +70,67 @@ __device__ __forceinline__ int block_scan(int v, int* tmp, int& tot) {      // e
 }
 
 // One workgroup per graph: the graph's rows of at least min_deg entries, in the order of `order` (program position; null = row
-// order), as whole blocks of 16 -- a graph's last block is padded with -1 -- at a place of lrows reserved with one atomic add.
+// order), as whole blocks of 16 -- a graph's last block is padded with -1 -- at a place of lrows reserved with one atomic add;
+// bgraph[b] = the graph of block b.  Four rows per thread and trip.
 __global__ __launch_bounds__(kBlock) void dense_rows_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ order,
                                                             const int32_t* __restrict__ gptr, int min_deg, int32_t* __restrict__ lrows,
-                                                            int32_t* __restrict__ counter) {
+                                                            int32_t* __restrict__ bgraph, int32_t* __restrict__ counter) {
   __shared__ int tmp[8];
+  constexpr int kPer = 4;
   const int g = blockIdx.x, tid = threadIdx.x;
   const int p0 = gptr[g], p1 = gptr[g + 1];
   int mine = 0;
-  for (int p = p0 + tid; p < p1; p += kBlock) {
-    const int r = order ? order[p] : p;
-    mine += (ptr[r + 1] - ptr[r] >= min_deg) ? 1 : 0;
+  for (int q0 = p0; q0 < p1; q0 += kBlock * 8) {             // eight independent rows per thread and trip: their loads fly together
+    int r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int p = q0 + k * kBlock + tid;
+      r[k] = p < p1 ? (order ? order[p] : p) : -1;
+    }
+    int d0[8], d1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      d0[k] = r[k] >= 0 ? ptr[r[k]] : 0;
+      d1[k] = r[k] >= 0 ? ptr[r[k] + 1] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mine += (r[k] >= 0 && d1[k] - d0[k] >= min_deg) ? 1 : 0;
   }
   const int cnt = block_sum(mine, tmp);
   const int padded = (cnt + kDbRows - 1) / kDbRows * kDbRows;
   if (tid == 0) tmp[4] = padded ? atomicAdd(counter, padded) : 0;
   __syncthreads();
   const int start = tmp[4];
+  for (int k = tid; k < padded / kDbRows; k += kBlock) bgraph[start / kDbRows + k] = g;
   int run = 0;
-  for (int q0 = p0; q0 < p1; q0 += kBlock) {
-    const int p = q0 + tid;
-    int r = -1;
-    bool is_long = false;
-    if (p < p1) {
-      r = order ? order[p] : p;
-      is_long = ptr[r + 1] - ptr[r] >= min_deg;
+  for (int q0 = p0; q0 < p1; q0 += kBlock * kPer) {
+    int rows[kPer], n_long = 0;
+    unsigned is_long = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {                         // a thread's rows are neighbours in the order: the scan keeps it
+      const int p = q0 + tid * kPer + k;
+      rows[k] = -1;
+      if (p < p1) {
+        rows[k] = order ? order[p] : p;
+        if (ptr[rows[k] + 1] - ptr[rows[k]] >= min_deg) { is_long |= 1u << k; ++n_long; }
+      }
     }
     int tot;
-    const int pos = block_scan(is_long ? 1 : 0, tmp, tot);
-    if (is_long) lrows[start + run + pos] = r;
+    int pos = start + run + block_scan(n_long, tmp, tot);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (is_long >> k & 1u) lrows[pos++] = rows[k];
     run += tot;
   }
   for (int k = cnt + tid; k < padded; k += kBlock) lrows[start + k] = -1;
 }
 
 // One workgroup per block: the union of the 16 rows' sources (and the rows themselves), every entry's slot in it, the cell mask.
-// LDS: bits[max_words] | pre[max_words] | mask[16 * 8] | rows, beg, deg [16 each] | tmp[16].
+// The union's bitset covers the ids of the block's graph (gptr: a graph's rows are a contiguous range of ids).
+// LDS: bits[max_words] | pre[max_words] | mask[16 * kDbMaskWords] | rows, beg, deg [16 each] | tmp[16].
 __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                                            const int32_t* __restrict__ loops, const int32_t* __restrict__ lrows,
+                                                            const int32_t* __restrict__ loops, const int32_t* __restrict__ gptr,
+                                                            const int32_t* __restrict__ lrows, const int32_t* __restrict__ bgraph,
                                                             const int32_t* __restrict__ counter, int max_words, int32_t* __restrict__ records,
                                                             uint8_t* __restrict__ row_flag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,7 +144,13 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
   int* rdeg = rbeg + kDbRows;
   int* tmp = rdeg + kDbRows;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid == 0) { tmp[8] = INT32_MAX; tmp[9] = -1; tmp[10] = 0; tmp[11] = 0; }
+  const int gr = bgraph[b];
+  const int lo = gptr[gr];
+  const int64_t width = (int64_t)gptr[gr + 1] - lo;
+  const bool clamped = width > (int64_t)max_words * 32;
+  const int span = clamped ? max_words * 32 : (int)width;
+  const int words = (span + 31) >> 5;
+  if (tid == 0) { tmp[10] = 0; tmp[11] = 0; }
   if (tid < kDbRows) {
     const int r = lrows[b * kDbRows + tid];
     rid[tid] = r;
@@ -129,41 +158,27 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
     rdeg[tid] = r >= 0 ? ptr[r + 1] - ptr[r] : 0;
   }
   for (int w = tid; w < kDbRows * kDbMaskWords; w += kBlock) mask[w] = 0u;
+  for (int w = tid; w < words; w += kBlock) bits[w] = 0u;
   __syncthreads();
   int nrows = 0;
   for (int i = 0; i < kDbRows; ++i) nrows += rid[i] >= 0 ? 1 : 0;        // (pads sit at the end)
-  {                                                          // the id range: the entries' sources and the rows themselves
-    int lo_t = INT32_MAX, hi_t = -1, bad = 0;
-    for (int i = wave; i < nrows; i += 4) {
+  {
+    int bad = 0;
+    for (int i = wave; i < nrows; i += 4) {                  // mark the sources of the block's rows, and the rows themselves
       const int bg = rbeg[i], d = rdeg[i], r = rid[i];
-      if (lane == 0) { lo_t = min(lo_t, r); hi_t = max(hi_t, r); }
+      if (lane == 0) {
+        const int j = r - lo;
+        if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
+        else bad = 1;
+      }
       for (int x = lane; x < d; x += kWave) {
-        const int j = idx[bg + x];
-        lo_t = min(lo_t, j); hi_t = max(hi_t, j);
-        bad |= (j == r) ? 1 : 0;                             // a self-loop among the entries: its cell would be two entries
+        const int jr = idx[bg + x], j = jr - lo;
+        if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
+        else bad = 1;                                        // an id outside the graph's range (or past the bitset)
+        bad |= (jr == r) ? 1 : 0;                            // a self-loop among the entries: its cell would be two entries
       }
     }
-    if (hi_t >= 0) { atomicMin(&tmp[8], lo_t); atomicMax(&tmp[9], hi_t); }
     if (bad) atomicOr(&tmp[10], 1);
-  }
-  __syncthreads();
-  const int lo = tmp[8];
-  const int64_t width = (int64_t)tmp[9] - lo + 1;
-  const bool clamped = width > (int64_t)max_words * 32;
-  const int span = clamped ? max_words * 32 : (int)width;
-  const int words = (span + 31) >> 5;
-  for (int w = tid; w < words; w += kBlock) bits[w] = 0u;
-  __syncthreads();
-  for (int i = wave; i < nrows; i += 4) {
-    const int bg = rbeg[i], d = rdeg[i];
-    if (lane == 0) {
-      const int j = rid[i] - lo;
-      if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
-    }
-    for (int x = lane; x < d; x += kWave) {
-      const int j = idx[bg + x] - lo;
-      if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
-    }
   }
   __syncthreads();
   const int wpt = (words + kBlock - 1) / kBlock;             // words per thread, contiguous: slots ascend with the id
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
     }
   }
   for (int s = total + tid; s < kDbCap; s += kBlock) un[s] = rid[0];     // pads: a valid row (its cells are masked out)
-  const bool ok = !clamped && total <= kDbCap && tmp[10] == 0;
+  const bool ok = total <= kDbCap && tmp[10] == 0;
   __syncthreads();
   if (ok) {
     for (int i = wave; i < nrows; i += 4) {
@@ -646,11 +661,12 @@ extern "C" int mlqem_dense_plan_build(const int32_t* ptr, const int32_t* idx, co
   const int max_words = (int)std::max<int64_t>(1, (std::min<int64_t>(max_span, 8192 * 32) + 31) / 32);
   const size_t lds = (size_t)max_words * 8 + (size_t)kDbRows * kDbMaskWords * 4 + (size_t)kDbRows * 12 + 64;
   if (!ensure_dynamic_lds(dense_plan_kernel, lds)) return MLQEM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)num_graphs), dim3(kBlock), 0, as_stream(stream), ptr, order, graph_ptr, kDbMinDeg,
-                     lrows, counter);
   const int64_t max_blocks = mlqem_dense_plan_max_blocks(num_rows, num_graphs);
-  hipLaunchKernelGGL(dense_plan_kernel, dim3((unsigned)max_blocks), dim3(kBlock), lds, as_stream(stream), ptr, idx, loops, lrows, counter,
-                     max_words, records, row_flag);
+  int32_t* bgraph = lrows + max_blocks * kDbRows;            // (the second part of lrows: one graph id per block)
+  hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)num_graphs), dim3(kBlock), 0, as_stream(stream), ptr, order, graph_ptr, kDbMinDeg,
+                     lrows, bgraph, counter);
+  hipLaunchKernelGGL(dense_plan_kernel, dim3((unsigned)max_blocks), dim3(kBlock), lds, as_stream(stream), ptr, idx, loops, graph_ptr, lrows,
+                     bgraph, counter, max_words, records, row_flag);
   return launch_status();
 }
 
@@ -659,8 +675,8 @@ extern "C" int mlqem_dense_attention_supported(int H, int C, int head_pitch) { r
 extern "C" int mlqem_dense_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
                                                const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
                                                const uint64_t* seed_counter, int head_pitch, const int32_t* records, const int32_t* counter,
-                                               const uint8_t* row_flag, int64_t max_blocks, float* out, int64_t ldo, float* attn_out,
-                                               int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream) {
+                                               const uint8_t* row_flag, int64_t max_blocks, int parts, float* out, int64_t ldo,
+                                               float* attn_out, int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream) {
   begin_launches();
   if (!mlqem_dense_attention_supported(H, C, head_pitch)) return MLQEM_ERR_UNSUPPORTED;
   if (N < 0 || E < 0 || C <= 0 || ld < 4 * H * head_pitch || ldo < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
@@ -672,10 +688,12 @@ extern "C" int mlqem_dense_attention_train_f32(const float* qkvs, int64_t ld, co
                 1, nullptr, head_pitch};
   a.skip = row_flag;
   const DensePlan p{records, counter, row_flag, max_blocks};
-  launch_attn_train_q4(a, as_stream(stream));
+  if (parts & 1) launch_attn_train_q4(a, as_stream(stream));
   const dim3 grid((unsigned)dense_grid(max_blocks));
-  if (H == 2) hipLaunchKernelGGL((dense_attn_fwd_kernel<2, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
-  else hipLaunchKernelGGL((dense_attn_fwd_kernel<1, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
+  if (parts & 2) {
+    if (H == 2) hipLaunchKernelGGL((dense_attn_fwd_kernel<2, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
+    else hipLaunchKernelGGL((dense_attn_fwd_kernel<1, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
+  }
   return launch_status();
 }
 
@@ -685,7 +703,8 @@ extern "C" int mlqem_dense_attention_bwd_f32(const float* qkvs, int64_t ld, cons
                                              int C, float drop_p, uint64_t seed, const uint64_t* seed_counter, int head_pitch,
                                              const int32_t* in_records, const int32_t* in_counter, const uint8_t* in_flag, int64_t in_max_blocks,
                                              const int32_t* out_records, const int32_t* out_counter, const uint8_t* out_flag,
-                                             int64_t out_max_blocks, float* gqkvs, int64_t ldq, float* edge_al, mlqem_stream_t stream) {
+                                             int64_t out_max_blocks, int parts, float* gqkvs, int64_t ldq, float* edge_al,
+                                             mlqem_stream_t stream) {
   begin_launches();
   if (!mlqem_dense_attention_supported(H, C, head_pitch)) return MLQEM_ERR_UNSUPPORTED;
   if (N < 0 || E < 0 || C <= 0 || ld < 4 * H * head_pitch || ldq < 4 * H * head_pitch || ldg < H * C || lda < H * C || drop_p < 0.f || drop_p >= 1.f)
@@ -702,12 +721,18 @@ extern "C" int mlqem_dense_attention_bwd_f32(const float* qkvs, int64_t ld, cons
   a.skip_src = out_flag;
   const DensePlan pin{in_records, in_counter, in_flag, in_max_blocks}, pout{out_records, out_counter, out_flag, out_max_blocks};
   const hipStream_t s = as_stream(stream);
-  launch_attn_bwd_dst_q4(a, s);
+  // parts: 1 = destination side, per-edge rows; 2 = destination side, blocks; 4 = source side, per-edge rows; 8 = source side, blocks.
+  // The source side reads the records BOTH destination-side kernels file: a caller that spreads the parts over streams joins between.
+  if (parts & 1) launch_attn_bwd_dst_q4(a, s);
   const dim3 gin((unsigned)dense_grid(in_max_blocks)), gout((unsigned)dense_grid(out_max_blocks));
-  if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<2>, gin, dim3(kBlock), 0, s, a, pin);
-  else hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<1>, gin, dim3(kBlock), 0, s, a, pin);
-  launch_attn_bwd_src_rc_q4(a, s);                  // (after BOTH destination-side kernels: it reads the records they file)
-  if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_src_kernel<2>, gout, dim3(kBlock), 0, s, a, pout);
-  else hipLaunchKernelGGL(dense_attn_bwd_src_kernel<1>, gout, dim3(kBlock), 0, s, a, pout);
+  if (parts & 2) {
+    if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<2>, gin, dim3(kBlock), 0, s, a, pin);
+    else hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<1>, gin, dim3(kBlock), 0, s, a, pin);
+  }
+  if (parts & 4) launch_attn_bwd_src_rc_q4(a, s);
+  if (parts & 8) {
+    if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_src_kernel<2>, gout, dim3(kBlock), 0, s, a, pout);
+    else hipLaunchKernelGGL(dense_attn_bwd_src_kernel<1>, gout, dim3(kBlock), 0, s, a, pout);
+  }
   return launch_status();
 }

@@ -66,11 +66,12 @@ qkvs = ops.padded_copy(qh.view(n, -1).to(dev))
 gout = ops.padded_copy(torch.randn(n, heads * ch).to(dev))
 pin, pout = plans["in"], plans["out"]
 edge_f = lambda: ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, 0.1, 7, pair_key=True, head_pitch=cp)
-dense_f = lambda: ops.dense_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, pin, drop_p=0.1, seed=7)
+side = torch.cuda.Stream()
+dense_f = lambda side=None: ops.dense_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, pin, drop_p=0.1, seed=7, side=side)
 ref, got = edge_f(), dense_f()
-print("attention forward: per-edge %.1f us, with dense blocks %.1f us (max diff %.2e)" % (timed(edge_f), timed(dense_f),
-                                                                                          (ref[0] - got[0]).abs().max().item()), flush=True)
+print("attention forward: per-edge %.1f us, with dense blocks %.1f us, the two kernels on two streams %.1f us (max diff %.2e)" % (
+    timed(edge_f), timed(dense_f), timed(lambda: dense_f(side)), (ref[0] - dense_f(side)[0]).abs().max().item()), flush=True)
 edge_b = lambda: ops.transformer_attention_bwd(qkvs, gout, ref[1], ref[2], ref[3], s, e, heads, ch, 0.1, 7, pair_key=True, head_pitch=cp)
-dense_b = lambda: ops.dense_attention_bwd(qkvs, gout, got[1], got[2], got[3], s, e, heads, ch, pin, pout, drop_p=0.1, seed=7)
-print("attention backward (both sides): per-edge %.1f us, with dense blocks %.1f us (max diff %.2e)" % (
-    timed(edge_b), timed(dense_b), (edge_b() - dense_b()).abs().max().item()), flush=True)
+dense_b = lambda side=None: ops.dense_attention_bwd(qkvs, gout, got[1], got[2], got[3], s, e, heads, ch, pin, pout, drop_p=0.1, seed=7, side=side)
+print("attention backward (both sides): per-edge %.1f us, with dense blocks %.1f us, on two streams %.1f us (max diff %.2e)" % (
+    timed(edge_b), timed(dense_b), timed(lambda: dense_b(side)), (edge_b() - dense_b(side)).abs().max().item()), flush=True)
