@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 28 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 29 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -801,6 +801,15 @@ int mlqem_dense_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g,
                                   const int32_t* out_records, const int32_t* out_counter, const uint8_t* out_flag,
                                   int64_t out_max_blocks, int parts, float* gqkvs, int64_t ldq, float* edge_al,
                                   mlqem_stream_t stream);
+
+/* ASAPooling's cluster sums over the same plans (csrc/dense_pool.hip; rows of at most 32 channels: mlqem_dense_pool_supported).
+ * mlqem_csr_softmax_aggregate_f32 with the rows of the plan's blocks on the matrix cores; stat (optional, [N, 2] floats, 8-byte
+ * aligned) receives {maximum, 1 / denominator} of the block rows for the backward kernels below. */
+int mlqem_dense_pool_supported(int D);
+int mlqem_dense_softmax_aggregate_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* a_dst,
+                                      const float* c_src, float negative_slope, int64_t N, int D, const int32_t* records,
+                                      const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks, float* out, int64_t ldo,
+                                      float* stat, mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Host-side native encoder (no GPU needed).  Replaces the Python loops of circuit_to_graph_data_json

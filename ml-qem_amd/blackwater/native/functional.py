@@ -729,8 +729,9 @@ _TILES = os.environ.get("MLQEM_TILES", "0") == "1"
 # (csrc/dense_block.hip); MLQEM_DENSE_BLOCKS=0: the per-edge kernels for every row (A/B runs, tests/test_gpu_dense_blocks.py)
 _DENSE_BLOCKS = os.environ.get("MLQEM_DENSE_BLOCKS", "1") == "1"
 # True: the per-edge kernel over the rows outside the blocks on a side stream, beside the block kernel (disjoint rows).  Measured on
-# 64 100-qubit circuits: 117.7 us against 109.4 on one stream (forward), 305.5 against 290.7 (backward) -- the first kernel fills
-# the chip, the fork and join cost more than the overlap gains
+# 64 100-qubit circuits: slower -- eagerly 117.7 us against 109.4 on one stream (forward), 305.5 against 290.7 (backward); inside the
+# captured step 7.12 ms against 7.00 (scripts/family_b_step.py): the per-edge kernel's 11 k workgroups fill the chip either way, the
+# fork and the join cost more than the overlap returns.  Kept as a switch of the ops (tests/test_gpu_dense_blocks.py runs both).
 _DENSE_TWO_STREAMS = False
 
 

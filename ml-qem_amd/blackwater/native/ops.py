@@ -1698,6 +1698,25 @@ def dense_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, pl
     return gqkvs
 
 
+def dense_pool_supported(d) -> bool:
+    return bool(_lib.load().mlqem_dense_pool_supported(int(d)))
+
+
+def dense_softmax_aggregate(x, in_ptr, in_src, a_dst, c_src, negative_slope, plan: DensePlan, want_stat=True):
+    """``csr_softmax_aggregate`` with the plan's rows on the matrix cores: (x', stat) -- stat [N, 2] = {maximum, 1 / denominator} of the
+    block rows (other rows: not written), what ``dense_softmax_aggregate_bwd`` reads."""
+    n, c = x.shape
+    _vec(a_dst, "a_dst", n)
+    _vec(c_src, "c_src", n)
+    out = padded_empty(n, c, x.device)
+    stat = torch.empty((max(n, 1), 2), dtype=torch.float32, device=x.device) if want_stat else None
+    code = _lib.load().mlqem_dense_softmax_aggregate_f32(_p(x), _mat(x, "x"), _p(in_ptr), _p(in_src), _p(a_dst), _p(c_src),
+                                                         float(negative_slope), n, c, *plan.args(), _p(out), _mat(out, "out"), _p(stat),
+                                                         _stream())
+    _lib.check(code, "mlqem_dense_softmax_aggregate_f32")
+    return out, stat
+
+
 _LDS_BUDGET = 80 * 1024      # per workgroup: two workgroups of a tiled kernel per CU (160 KB)
 
 

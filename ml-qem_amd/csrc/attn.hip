@@ -29,10 +29,11 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
 template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_kernel(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int C,
-    float* __restrict__ out, int64_t ldo) {
+    float* __restrict__ out, int64_t ldo, const uint8_t* __restrict__ skip) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;                              // a whole group leaves together
+  if (skip && skip[row]) return;                     // a row a dense block serves (dense_pool.hip)
   const int beg = ptr[row], end = ptr[row + 1];
   const float ai = a_dst[row];
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
@@ -225,6 +226,25 @@ extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, co
   return launch_status();
 }
 
+namespace mlqem {
+// (also for dense_pool.hip: the rows its blocks do not serve)
+void launch_softmax_aggregate(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* a_dst, const float* c_src,
+                              float negative_slope, int64_t N, int C, float* out, int64_t ldo, const uint8_t* skip, hipStream_t stream) {
+  const dim3 grid((unsigned)ceil_div(N * kGroup, kBlock));
+#define MLQEM_SA(NV) hipLaunchKernelGGL(softmax_aggregate_kernel<NV>, grid, dim3(kBlock), 0, stream, x, ldx, in_ptr, in_src, a_dst, c_src, \
+                                        negative_slope, N, C, out, ldo, skip)
+  if (C <= 16) MLQEM_SA(1);
+  else if (C <= 32) MLQEM_SA(2);
+  else if (C <= 48) MLQEM_SA(3);
+  else if (C <= 64) MLQEM_SA(4);
+  else if (C <= 128) MLQEM_SA(8);
+  else
+    hipLaunchKernelGGL(softmax_aggregate_any_width_kernel, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0, stream, x, ldx, in_ptr,
+                       in_src, a_dst, c_src, negative_slope, N, C, out, ldo);
+#undef MLQEM_SA
+}
+}  // namespace mlqem
+
 extern "C" int mlqem_csr_softmax_aggregate_f32(const float* x, int64_t ldx, const int32_t* in_ptr,
                                                const int32_t* in_src, const float* a_dst, const float* c_src,
                                                float negative_slope, int64_t N, int C, float* out, int64_t ldo,
@@ -233,18 +253,7 @@ extern "C" int mlqem_csr_softmax_aggregate_f32(const float* x, int64_t ldx, cons
   if (N < 0 || C <= 0 || ldx < C || ldo < C) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!x || !in_ptr || !a_dst || !c_src || !out) return MLQEM_ERR_BAD_ARG;
-  const dim3 grid((unsigned)ceil_div(N * kGroup, kBlock));
-#define MLQEM_SA(NV) hipLaunchKernelGGL(softmax_aggregate_kernel<NV>, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, in_ptr, \
-                                        in_src, a_dst, c_src, negative_slope, N, C, out, ldo)
-  if (C <= 16) MLQEM_SA(1);
-  else if (C <= 32) MLQEM_SA(2);
-  else if (C <= 48) MLQEM_SA(3);
-  else if (C <= 64) MLQEM_SA(4);
-  else if (C <= 128) MLQEM_SA(8);
-  else
-    hipLaunchKernelGGL(softmax_aggregate_any_width_kernel, dim3((unsigned)ceil_div(N * C, kBlock)), dim3(kBlock), 0,
-                       as_stream(stream), x, ldx, in_ptr, in_src, a_dst, c_src, negative_slope, N, C, out, ldo);
-#undef MLQEM_SA
+  launch_softmax_aggregate(x, ldx, in_ptr, in_src, a_dst, c_src, negative_slope, N, C, out, ldo, nullptr, as_stream(stream));
   return launch_status();
 }
 

@@ -20,7 +20,8 @@
 //                         mask bit (i, s): source slot s is an entry of row i -- or s is the row itself and it has a self-loop
 #pragma once
 
-#include "attn_fwd.hpp"
+#include "attn_q4.hpp"
+#include "tile_common.hpp"
 
 namespace mlqem {
 
@@ -39,9 +40,68 @@ struct DensePlan {
   int64_t max_blocks;
 };
 
+// ---- device helpers of the block kernels (dense_block.hip: attention; dense_pool.hip: ASAPooling's cluster sums)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// D += A(16 x 16, a lane's four k-values in `a`) x B(16 x 16, in `b`)
+__device__ __forceinline__ f32x4 mfma16(const f4u& a, const f4u& b, f32x4 c) {
+  c = mfma4(a.x, b.x, c);
+  c = mfma4(a.y, b.y, c);
+  c = mfma4(a.z, b.z, c);
+  c = mfma4(a.w, b.w, c);
+  return c;
+}
+// over the four lanes that hold a block row's cells (l, l ^ 16, l ^ 32, l ^ 48)
+__device__ __forceinline__ float rows_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// ---- what every kernel keeps in LDS: the block's union ids and its cell mask (one coalesced round trip at the block's start; the loop
+// then reads ids and bits at LDS latency and only row segments from global memory), and the four waves' partial results.
+// A WORKGROUP owns a block; its four waves take the column blocks w, w + 4, ... : a structure has a few thousand blocks of 4-30
+// column blocks each, and with one wave per block the longest block's chain of dependent loads was the kernel's duration.
+constexpr int kDbWaves = kBlock / kWave;
+constexpr int kDbLdsInts = kDbCap + kDbRows * kDbMaskWords;
+static_assert(kDbMaskOff == kDbUniOff + kDbCap && kDbLdsInts % 4 == 0 && kDbLdsInts <= 4 * kBlock, "one int4 per thread stages a block");
+struct BlockLds { const int* uni; const uint32_t* mask; };
+__device__ __forceinline__ BlockLds block_stage(const int32_t* __restrict__ rec, int* base) {
+  const int k = threadIdx.x * 4;
+  int4 v = make_int4(0, 0, 0, 0);
+  if (k < kDbLdsInts) v = *reinterpret_cast<const int4*>(rec + kDbUniOff + k);
+  __syncthreads();                                         // the previous block's reads are done
+  if (k < kDbLdsInts) *reinterpret_cast<int4*>(base + k) = v;
+  __syncthreads();
+  return BlockLds{base, reinterpret_cast<const uint32_t*>(base + kDbCap)};
+}
+// the cell bits of column block cb for this lane's four cells (u = 16 cb + 4 g + i, row r)
+__device__ __forceinline__ uint32_t cell_bits(const uint32_t* maskrow, int cb, int g) {
+  return (maskrow[cb >> 1] >> ((cb & 1) * 16 + 4 * g)) & 0xFu;
+}
+constexpr float kNoMax = -1e30f;                           // "no entry yet" (finite: differences of it stay numbers)
+// sum over the four waves of one accumulator tile per lane: red[w][lane] (16 bytes each); the caller syncs before and reads after
+__device__ __forceinline__ f32x4 waves_sum(const f32x4* red, int lane) {
+  f32x4 t = red[lane];
+#pragma unroll
+  for (int w = 1; w < kDbWaves; ++w) t += red[w * kWave + lane];
+  return t;
+}
+
+
 // launches of the per-edge kernels (family_b_bwd.hip) for the rows a plan leaves to them
 void launch_attn_train_q4(const AttnFwdArgs& a, hipStream_t stream);
 void launch_attn_bwd_dst_q4(const AttnBwdArgs& a, hipStream_t stream);
 void launch_attn_bwd_src_rc_q4(const AttnBwdArgs& a, hipStream_t stream);
+// ... and of ASAPooling's per-edge kernels (attn.hip, family_b_bwd.hip); skip: the plan's row flags
+void launch_softmax_aggregate(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* a_dst, const float* c_src,
+                              float negative_slope, int64_t N, int C, float* out, int64_t ldo, const uint8_t* skip, hipStream_t stream);
 
 }  // namespace mlqem

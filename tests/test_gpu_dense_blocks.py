@@ -129,6 +129,12 @@ def test_attention_on_the_blocks_equals_the_per_edge_kernels(heads, ch, drop_p, 
     for part, name in enumerate(("query", "key", "value", "skip")):
         w = heads * 16
         _close(ggot[:, part * w:(part + 1) * w], gref[:, part * w:(part + 1) * w], "gradient of " + name)
+    # the two launches of a call touch disjoint rows: on two streams (the `parts` of the entry points) they give the same arrays
+    side = torch.cuda.Stream()
+    two = ops.dense_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, heads, ch, pin, drop_p=drop_p, seed=7, side=side)
+    assert all(torch.equal(a[stored] if k == 1 else a, b[stored] if k == 1 else b) for k, (a, b) in enumerate(zip(two, got)))
+    gtwo = ops.dense_attention_bwd(qkvs, gout, got[1], got[2], got[3], s, e, heads, ch, pin, pout, drop_p=drop_p, seed=7, side=side)
+    assert torch.equal(gtwo, ggot)
 
 
 def test_a_structure_without_long_rows_has_no_blocks_and_the_same_results():
@@ -147,3 +153,24 @@ def test_a_structure_without_long_rows_has_no_blocks_and_the_same_results():
     ref = ops.transformer_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, 2, 15, 0.1, 3, pair_key=True, head_pitch=16)
     got = ops.dense_attention_train(qkvs, s.in_ptr, s.in_src, s.loops, e, 2, 15, pin, drop_p=0.1, seed=3)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[3], ref[3])
+
+
+@pytest.mark.parametrize("d,loops_p", [(30, 0.0), (30, 0.8), (16, 0.3), (7, 0.0), (32, 0.5)])
+def test_pooling_cluster_sums_on_the_blocks_equal_the_per_edge_kernels(d, loops_p):
+    """ASAPooling's softmax-weighted cluster sum x' (the row itself is ALWAYS an entry there, whatever ``loops`` says)."""
+    from blackwater.native import ops
+
+    s, _, rng = _make(29 + d, loops_p)
+    n = s.num_nodes
+    assert ops.dense_pool_supported(d)
+    x = ops.padded_copy(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV))
+    a_dst = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+    c_src = torch.from_numpy(rng.standard_normal(n).astype(np.float32) * 2).to(DEV)
+    pin = s.dense_plan("in")
+    ref = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, 0.2)
+    got, stat = ops.dense_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, 0.2, pin)
+    _close(got, ref, "x'")
+    flag = pin.row_flag.bool()
+    assert int(flag.sum().item()) > 100 and torch.equal(got[~flag], ref[~flag])          # the other rows: the same kernel, bit for bit
+    assert torch.isfinite(stat[flag]).all() and (stat[flag][:, 1] > 0).all()
+
