@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 29 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 30 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -806,6 +806,28 @@ int mlqem_dense_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g,
  * mlqem_csr_softmax_aggregate_f32 with the rows of the plan's blocks on the matrix cores; stat (optional, [N, 2] floats, 8-byte
  * aligned) receives {maximum, 1 / denominator} of the block rows for the backward kernels below. */
 int mlqem_dense_pool_supported(int D);
+/* The pooling's other walks over the plans, for matrices whose rows are exactly 32 floats (29-32 channels, 16-byte aligned; anything
+ * else: MLQEM_ERR_UNSUPPORTED / BAD_ARG, the caller keeps the per-edge entry points):
+ *   mlqem_dense_segment_max_f32           = mlqem_csr_segment_max_f32 (the row itself included)
+ *   mlqem_dense_softmax_aggregate_bwd_f32 = mlqem_csr_softmax_aggregate_bwd_f32 in its recomputing form with tie counts (edge_al: [4 N]
+ *                                           floats, 16-byte aligned); stat: what mlqem_dense_softmax_aggregate_f32 left
+ *   mlqem_dense_segment_max_bwd_f32       = mlqem_csr_segment_max_bwd_f32 with tie counts and a rank-one gradient of the maximum */
+int mlqem_dense_segment_max_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, int64_t N, int D,
+                                const int32_t* records, const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks, float* out,
+                                int64_t ldo, mlqem_stream_t stream);
+int mlqem_dense_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn, const float* gnew, int64_t ldg,
+                                          const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                          const float* a_dst, const float* c_src, float negative_slope, int64_t N, int64_t E, int D,
+                                          const float* stat, const int32_t* in_records, const int32_t* in_counter, const uint8_t* in_flag,
+                                          int64_t in_max_blocks, const int32_t* out_records, const int32_t* out_counter,
+                                          const uint8_t* out_flag, int64_t out_max_blocks, float* gx, int64_t ldgx, float* g_a, float* g_c,
+                                          float* edge_al, const float* xmax, int64_t ldm, float* tie_count, int64_t ldt,
+                                          const float* gx_rank1, mlqem_stream_t stream);
+int mlqem_dense_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const int32_t* in_ptr,
+                                    const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, int64_t N, int D, float* gx,
+                                    int64_t ldgx, float* gshare, int64_t lds, const float* tie_count, int64_t ldt, const float* gmax_row,
+                                    const float* gmax_col, const int32_t* out_records, const int32_t* out_counter, const uint8_t* out_flag,
+                                    int64_t out_max_blocks, mlqem_stream_t stream);
 int mlqem_dense_softmax_aggregate_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* a_dst,
                                       const float* c_src, float negative_slope, int64_t N, int D, const int32_t* records,
                                       const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks, float* out, int64_t ldo,

@@ -1717,6 +1717,52 @@ def dense_softmax_aggregate(x, in_ptr, in_src, a_dst, c_src, negative_slope, pla
     return out, stat
 
 
+def dense_pool_fits(*mats) -> bool:
+    """The pooling's block kernels take matrices of 29-32 channels whose rows are exactly 32 floats (the padded row layout)."""
+    return all(m.is_cuda and m.dtype == torch.float32 and 29 <= m.shape[1] <= 32 and (m.shape[0] <= 1 or m.stride(0) == 32) and m.stride(1) == 1
+               and m.data_ptr() % 16 == 0 for m in mats)
+
+
+def dense_segment_max(x, in_ptr, in_src, plan: DensePlan):
+    """``csr_segment_max`` (the row itself included) with the plan's rows walked as dense blocks."""
+    n, c = x.shape
+    out = padded_empty(n, c, x.device)
+    code = _lib.load().mlqem_dense_segment_max_f32(_p(x), _mat(x, "x"), _p(in_ptr), _p(in_src), n, c, *plan.args(), _p(out), _mat(out, "out"),
+                                                   _stream())
+    _lib.check(code, "mlqem_dense_segment_max_f32")
+    return out
+
+
+def dense_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope, stat, plan_in: DensePlan, plan_out: DensePlan,
+                                xmax, gx_rank1=None):
+    """``csr_softmax_aggregate_bwd`` (recomputing form, with the tie counts of the segment max): (gx, g_a, g_c, ties)."""
+    n, c = x.shape
+    dev = x.device
+    gx, ties = padded_empty(n, c, dev), padded_empty(n, c, dev)
+    g_a = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
+    g_c = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
+    al = torch.empty(4 * max(n, 1), dtype=torch.float32, device=dev)
+    code = _lib.load().mlqem_dense_softmax_aggregate_bwd_f32(
+        _p(x), _mat(x, "x"), _p(xnew), _mat(xnew, "xnew"), _p(gnew), _mat(gnew, "gnew"), _p(s.in_ptr), _p(s.in_src), _p(s.out_ptr),
+        _p(s.out_dst), _p(a_dst), _p(c_src), float(negative_slope), n, num_edges, c, _p(stat), *plan_in.args(), *plan_out.args(), _p(gx),
+        _mat(gx, "gx"), _p(g_a), _p(g_c), _p(al), _p(xmax), _mat(xmax, "xmax"), _p(ties), _mat(ties, "ties"), _p(gx_rank1), _stream())
+    _lib.check(code, "mlqem_dense_softmax_aggregate_bwd_f32")
+    return gx, g_a, g_c, ties
+
+
+def dense_segment_max_bwd_(gx, x, xmax, s, ties, gmax_rank1, plan_out: DensePlan):
+    """``csr_segment_max_bwd_`` with tie counts and the maximum's gradient as row (x) col: gx += (in place)."""
+    n, c = x.shape
+    share = padded_empty(n, c, x.device)
+    row, col = gmax_rank1
+    code = _lib.load().mlqem_dense_segment_max_bwd_f32(_p(x), _mat(x, "x"), _p(xmax), _mat(xmax, "xmax"), _p(s.in_ptr), _p(s.in_src),
+                                                       _p(s.out_ptr), _p(s.out_dst), n, c, _p(gx), _mat(gx, "gx"), _p(share),
+                                                       _mat(share, "share"), _p(ties), _mat(ties, "ties"), _p(row), _p(col),
+                                                       *plan_out.args(), _stream())
+    _lib.check(code, "mlqem_dense_segment_max_bwd_f32")
+    return gx
+
+
 _LDS_BUDGET = 80 * 1024      # per workgroup: two workgroups of a tiled kernel per CU (160 KB)
 
 

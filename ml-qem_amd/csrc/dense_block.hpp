@@ -101,6 +101,16 @@ void launch_attn_train_q4(const AttnFwdArgs& a, hipStream_t stream);
 void launch_attn_bwd_dst_q4(const AttnBwdArgs& a, hipStream_t stream);
 void launch_attn_bwd_src_rc_q4(const AttnBwdArgs& a, hipStream_t stream);
 // ... and of ASAPooling's per-edge kernels (attn.hip, family_b_bwd.hip); skip: the plan's row flags
+int softmax_aggregate_bwd_launches(const float* x, int64_t ldx, const float* xnew, int64_t ldn, const float* gnew, int64_t ldg,
+                                   const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                   const int32_t* out_eid, const float* a_dst, const float* c_src, float negative_slope, int64_t N, int64_t E,
+                                   int C, int accumulate, float* gx, int64_t ldgx, float* g_a, float* g_c, float* edge_al, float* edge_gp,
+                                   const float* xmax, int64_t ldm, float* tie_count, int64_t ldt, const float* gx_rank1,
+                                   const uint8_t* skip_in, const uint8_t* skip_out, int parts, mlqem_stream_t stream);
+int segment_max_bwd_launches(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const float* gmax, int64_t ldg, const int32_t* in_ptr,
+                             const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, int64_t N, int C, float* gx, int64_t ldgx,
+                             float* gshare, int64_t lds, const float* tie_count, int64_t ldt, const float* gmax_row, const float* gmax_col,
+                             const uint8_t* skip_out, mlqem_stream_t stream);
 void launch_softmax_aggregate(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* a_dst, const float* c_src,
                               float negative_slope, int64_t N, int C, float* out, int64_t ldo, const uint8_t* skip, hipStream_t stream);
 

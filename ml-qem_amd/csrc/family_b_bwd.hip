@@ -496,10 +496,11 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ a_dst, const float* __restrict__ c_src, float slope, int64_t N, int64_t E, int C,
     float* __restrict__ edge_al, float* __restrict__ edge_gp, float* __restrict__ g_a,
-    const float* __restrict__ xmax, int64_t ldm, float* __restrict__ tie_count, int64_t ldt) {
+    const float* __restrict__ xmax, int64_t ldm, float* __restrict__ tie_count, int64_t ldt, const uint8_t* __restrict__ skip) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
+  if (skip && skip[row]) return;                       // a row a dense block serves (dense_pool.hip)
   // edge_gp == nullptr: the source side recomputes its weights (softmax_aggregate_bwd_src_rc_kernel); nothing is written per
   // edge, and edge_al takes one record {a_i, m_i, 1 / den_i, delta_i} per row
   const bool recompute = edge_gp == nullptr;
@@ -774,10 +775,12 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
 template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_rc_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr,
     const int32_t* __restrict__ odst, const float4* __restrict__ stat, const float* __restrict__ c_src, float slope, int64_t N, int C,
-    int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c, const float* __restrict__ rank1) {
+    int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c, const float* __restrict__ rank1,
+    const uint8_t* __restrict__ skip) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
+  if (skip && skip[row]) return;
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
   const float cj = c_src[row];
   bool has[NV];
@@ -932,10 +935,11 @@ __global__ __launch_bounds__(kBlock) void segment_max_share_from_counts_kernel(c
 template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xmax, int64_t ldm,
     const float* __restrict__ gmax, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
-    int64_t N, int C, float* __restrict__ gx, int64_t ldgx) {
+    int64_t N, int C, float* __restrict__ gx, int64_t ldgx, const uint8_t* __restrict__ skip) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
+  if (skip && skip[row]) return;
   bool has[NV];
   float xv[NV], acc[NV];
 #pragma unroll
@@ -1219,15 +1223,15 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   return launch_status();
 }
 
-extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn,
-                                                   const float* gnew, int64_t ldg, const int32_t* in_ptr,
-                                                   const int32_t* in_src, const int32_t* out_ptr,
-                                                   const int32_t* out_dst, const int32_t* out_eid, const float* a_dst,
-                                                   const float* c_src, float negative_slope, int64_t N, int64_t E,
-                                                   int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
-                                                   float* g_c, float* edge_al, float* edge_gp, const float* xmax, int64_t ldm,
-                                                   float* tie_count, int64_t ldt, const float* gx_rank1, mlqem_stream_t stream) {
-  begin_launches();
+namespace mlqem {
+// mlqem_csr_softmax_aggregate_bwd_f32 for callers that serve some rows themselves (dense_pool.hip): skip_in / skip_out flag the rows
+// the destination-side / source-side launch leaves alone; parts: 1 = the destination-side launch, 2 = the source-side launch
+int softmax_aggregate_bwd_launches(const float* x, int64_t ldx, const float* xnew, int64_t ldn, const float* gnew, int64_t ldg,
+                                   const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                   const int32_t* out_eid, const float* a_dst, const float* c_src, float negative_slope, int64_t N, int64_t E,
+                                   int C, int accumulate, float* gx, int64_t ldgx, float* g_a, float* g_c, float* edge_al, float* edge_gp,
+                                   const float* xmax, int64_t ldm, float* tie_count, int64_t ldt, const float* gx_rank1,
+                                   const uint8_t* skip_in, const uint8_t* skip_out, int parts, mlqem_stream_t stream) {
   if (N < 0 || E < 0 || C <= 0 || ldx < C || ldn < C || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
   if (tie_count && (!xmax || ldm < C || ldt < C)) return MLQEM_ERR_BAD_ARG;
   if (tie_count && C > 128) return MLQEM_ERR_UNSUPPORTED;      // the any-width form does not count
@@ -1244,14 +1248,16 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
     edge_gp = nullptr;
   }
   if (gx_rank1 && C > 128) return MLQEM_ERR_UNSUPPORTED;      // the any-width source side does not add it
+  if ((skip_in || skip_out) && C > 128) return MLQEM_ERR_UNSUPPORTED;
+  if (parts & 1) {
 #define MLQEM_SAB(NV)                                                                                                                          \
   do {                                                                                                                                         \
     if (tie_count)                                                                                                                             \
       hipLaunchKernelGGL((softmax_aggregate_bwd_dst_kernel<NV, true>), MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,   \
-                         a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a, xmax, ldm, tie_count, ldt);                            \
+                         a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a, xmax, ldm, tie_count, ldt, skip_in);                   \
     else                                                                                                                                       \
       hipLaunchKernelGGL((softmax_aggregate_bwd_dst_kernel<NV, false>), MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src,  \
-                         a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a, nullptr, 0, nullptr, 0);                               \
+                         a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a, nullptr, 0, nullptr, 0, skip_in);                      \
   } while (0)
   if (C <= 16) MLQEM_SAB(1);
   else if (C <= 32) MLQEM_SAB(2);
@@ -1262,11 +1268,14 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
     hipLaunchKernelGGL(softmax_aggregate_bwd_dst_any_width_kernel, MLQEM_GRID(N * kGroup), x, ldx, xnew, ldn, gnew, ldg, in_ptr,
                        in_src, a_dst, c_src, negative_slope, N, E, C, edge_al, edge_gp, g_a);
 #undef MLQEM_SAB
+  }
+  if (!(parts & 2)) return launch_status();
 #define MLQEM_SAS(NV)                                                                                                                    \
   do {                                                                                                                                   \
     if (recompute)                                                                                                                       \
       hipLaunchKernelGGL(softmax_aggregate_bwd_src_rc_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, gnew, ldg, out_ptr, out_dst,           \
-                         reinterpret_cast<const float4*>(edge_al), c_src, negative_slope, N, C, accumulate, gx, ldgx, g_c, gx_rank1);    \
+                         reinterpret_cast<const float4*>(edge_al), c_src, negative_slope, N, C, accumulate, gx, ldgx, g_c, gx_rank1,     \
+                         skip_out);                                                                                                       \
     else                                                                                                                                 \
       hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel<NV>, MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, out_eid, edge_al,    \
                          edge_gp, N, E, C, accumulate, gx, ldgx, g_c, gx_rank1);                                                        \
@@ -1282,6 +1291,21 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
 #undef MLQEM_SAS
   return launch_status();
 }
+}  // namespace mlqem
+
+extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn,
+                                                   const float* gnew, int64_t ldg, const int32_t* in_ptr,
+                                                   const int32_t* in_src, const int32_t* out_ptr,
+                                                   const int32_t* out_dst, const int32_t* out_eid, const float* a_dst,
+                                                   const float* c_src, float negative_slope, int64_t N, int64_t E,
+                                                   int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
+                                                   float* g_c, float* edge_al, float* edge_gp, const float* xmax, int64_t ldm,
+                                                   float* tie_count, int64_t ldt, const float* gx_rank1, mlqem_stream_t stream) {
+  begin_launches();
+  return softmax_aggregate_bwd_launches(x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src, out_ptr, out_dst, out_eid, a_dst, c_src, negative_slope,
+                                        N, E, C, accumulate, gx, ldgx, g_a, g_c, edge_al, edge_gp, xmax, ldm, tie_count, ldt, gx_rank1,
+                                        nullptr, nullptr, 3, stream);
+}
 
 static void launch_share_from_counts(const float* gmax, int64_t ldg, const float* cnt, int64_t ldc, int64_t N, int C, float* gshare,
                                      int64_t lds, mlqem_stream_t stream, const float* g_row = nullptr, const float* g_col = nullptr) {
@@ -1292,6 +1316,12 @@ static void launch_share_from_counts(const float* gmax, int64_t ldg, const float
   else hipLaunchKernelGGL(segment_max_share_from_counts_kernel<1>, MLQEM_GRID(N * C), gmax, ldg, cnt, ldc, N, C, gshare, lds, g_row, g_col);
 }
 
+namespace mlqem {
+int segment_max_bwd_launches(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const float* gmax, int64_t ldg, const int32_t* in_ptr,
+                             const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, int64_t N, int C, float* gx, int64_t ldgx,
+                             float* gshare, int64_t lds, const float* tie_count, int64_t ldt, const float* gmax_row, const float* gmax_col,
+                             const uint8_t* skip_out, mlqem_stream_t stream);
+}
 extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax, int64_t ldm,
                                              const float* gmax, int64_t ldg, const int32_t* in_ptr,
                                              const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
@@ -1299,6 +1329,13 @@ extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const 
                                              const float* tie_count, int64_t ldt, const float* gmax_row, const float* gmax_col,
                                              mlqem_stream_t stream) {
   begin_launches();
+  return segment_max_bwd_launches(x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, out_ptr, out_dst, N, C, gx, ldgx, gshare, lds, tie_count, ldt,
+                                  gmax_row, gmax_col, nullptr, stream);
+}
+int mlqem::segment_max_bwd_launches(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const float* gmax, int64_t ldg,
+                                    const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, int64_t N,
+                                    int C, float* gx, int64_t ldgx, float* gshare, int64_t lds, const float* tie_count, int64_t ldt,
+                                    const float* gmax_row, const float* gmax_col, const uint8_t* skip_out, mlqem_stream_t stream) {
   const bool rank1 = gmax_row != nullptr;             // gmax = gmax_row (x) gmax_col (needs tie_count: the counted form); gmax unused
   if (N < 0 || C <= 0 || ldx < C || ldm < C || (!rank1 && ldg < C) || ldgx < C || lds < C || (tie_count && ldt < C)) return MLQEM_ERR_BAD_ARG;
   if (rank1 && (!gmax_col || !tie_count)) return MLQEM_ERR_BAD_ARG;
@@ -1313,7 +1350,7 @@ extern "C" int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const 
     hipLaunchKernelGGL(segment_max_share_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xmax, ldm, gmax, ldg, in_ptr, in_src, N, \
                        C, gshare, lds);                                                                                      \
     hipLaunchKernelGGL(segment_max_bwd_kernel<NV>, MLQEM_GRID(N * kGroup), x, ldx, xmax, ldm, gshare, lds, out_ptr, out_dst,  \
-                       N, C, gx, ldgx);                                                                                      \
+                       N, C, gx, ldgx, skip_out);                                                                            \
   } while (0)
   if (C <= 16) MLQEM_SMB(1);
   else if (C <= 32) MLQEM_SMB(2);

@@ -174,3 +174,37 @@ def test_pooling_cluster_sums_on_the_blocks_equal_the_per_edge_kernels(d, loops_
     assert int(flag.sum().item()) > 100 and torch.equal(got[~flag], ref[~flag])          # the other rows: the same kernel, bit for bit
     assert torch.isfinite(stat[flag]).all() and (stat[flag][:, 1] > 0).all()
 
+
+@pytest.mark.parametrize("d,loops_p,ties", [(30, 0.0, False), (30, 0.8, True), (32, 0.5, True), (29, 0.2, False)])
+def test_pooling_walks_on_the_blocks_equal_the_per_edge_kernels(d, loops_p, ties):
+    """ASAPooling's other walks over a coarsened graph: the segment max (the row itself included), the backward of the cluster sum
+    (g_x, g_a, g_c, the tie counts of the maximum) and the backward of the maximum.  ``ties``: x drawn from five values, so that maxima
+    are attained many times (identical gates on one qubit have identical feature rows: the gradient is split evenly)."""
+    from blackwater.native import ops
+
+    s, _, rng = _make(41 + d, loops_p)
+    n, e = s.num_nodes, s.edge_count()
+    xh = rng.randint(0, 5, size=(n, d)).astype(np.float32) if ties else rng.standard_normal((n, d)).astype(np.float32)
+    x = ops.padded_copy(torch.from_numpy(xh).to(DEV))
+    assert ops.dense_pool_fits(x)
+    pin, pout = s.dense_plan("in"), s.dense_plan("out")
+    xmax_ref = ops.csr_segment_max(x, s.in_ptr, s.in_src)
+    xmax = ops.dense_segment_max(x, s.in_ptr, s.in_src, pin)
+    assert torch.equal(xmax[:, :d], xmax_ref[:, :d])
+    a_dst = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+    c_src = torch.from_numpy(rng.standard_normal(n).astype(np.float32) * 2).to(DEV)
+    w_comp = torch.from_numpy(rng.standard_normal(d).astype(np.float32)).to(DEV)
+    att_x = torch.from_numpy(rng.standard_normal(d).astype(np.float32)).to(DEV)
+    xnew_ref = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, 0.2)
+    xnew, stat = ops.dense_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, 0.2, pin)
+    gnew = ops.padded_copy(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV))
+    gx_r, ga_r, gc_r, ties_r = ops.csr_softmax_aggregate_bwd(x, xnew_ref, gnew, s, e, a_dst, c_src, 0.2, xmax=xmax_ref, gx_rank1=att_x)
+    gx, ga, gc, ties_d = ops.dense_softmax_aggregate_bwd(x, xnew, gnew, s, e, a_dst, c_src, 0.2, stat, pin, pout, xmax, gx_rank1=att_x)
+    assert torch.equal(ties_d[:, :d], ties_r[:, :d])
+    _close(ga, ga_r, "g_a")
+    _close(gc, gc_r, "g_c")
+    _close(gx[:, :d], gx_r[:, :d], "g_x of the cluster sum")
+    ops.csr_segment_max_bwd_(gx_r, x, xmax_ref, None, s, ties=ties_r, gmax_rank1=(ga_r, w_comp))
+    ops.dense_segment_max_bwd_(gx, x, xmax, s, ties_d, (ga, w_comp), pout)
+    _close(gx[:, :d], gx_r[:, :d], "g_x with the maximum's part")
+
