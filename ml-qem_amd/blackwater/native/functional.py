@@ -810,6 +810,9 @@ class _ASAPool(Function):
         # LEConv's projections in ONE tiled pass (csrc/tile_pool.hip)
         tiled = _TILES and s.tiled and x.is_cuda and ops.tile_pool_fits(d)
         ctx.tiled = tiled
+        # ... or its long rows as dense blocks (csrc/dense_pool.hip): the same plans TransformerConv's edge softmax built on this graph
+        dense = _DENSE_BLOCKS and not tiled and s.tiled and s.out_eid is None and ops.dense_pool_fits(x)
+        ctx.dense = dense
         stat = None
         if tiled:
             w_comp = (att_q.t() * lin_w).sum(0, keepdim=True)
@@ -819,6 +822,8 @@ class _ASAPool(Function):
             x_new, xq_raw, stat, pqr = ops.tile_asap_scores(x, s.in_ptr, s.in_src, c_src, w_comp[0].contiguous(), b_comp, w3, b3, slope,
                                                             s.tile_plan("in"))
             fitness = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
+        elif dense:
+            xq_raw = ops.dense_segment_max(x, s.in_ptr, s.in_src, s.dense_plan("in"))
         else:
             xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
         if not tiled:
@@ -832,7 +837,10 @@ class _ASAPool(Function):
             a_dst = ops.linear(xq_raw, w_comp.contiguous(), b_comp)[:, 0].contiguous()
         if not tiled:
             c_src = ops.linear(x, att_x)[:, 0].contiguous()
-            x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
+            if dense:
+                x_new, stat = ops.dense_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope, s.dense_plan("in"))
+            else:
+                x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
             fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
         # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk (float32 tensor times a python scalar)
         sizes = np.asarray(s.graph_sizes, dtype=np.int64)
@@ -887,12 +895,12 @@ class _ASAPool(Function):
         holder["perm"] = perm
         ctx.struct, ctx.slope, ctx.d = s, slope, d
         ctx.save_for_backward(x, xq_raw, w_comp, stat if tiled else a_dst, c_src, x_new, fitness, slot, lin_w, att_w,
-                              w3, lin_b)
+                              w3, lin_b, stat if dense else None)
         return x_out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, xq_raw, w_comp, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b = ctx.saved_tensors
+        x, xq_raw, w_comp, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b, dense_stat = ctx.saved_tensors
         s, d = ctx.struct, ctx.d
         e = s.edge_count()
         dev = x.device
@@ -912,7 +920,11 @@ class _ASAPool(Function):
         if ctx.tiled:        # a_dst holds the forward's per-row record; the segment max's backward is part of the call
             gx, g_a, g_c = ops.tile_asap_scores_bwd(x, x_new, gxnew, xq_raw, s, c_src, w_comp[0].contiguous(), att_x[0].contiguous(), ctx.slope,
                                                     s.tile_plan("in"), s.tile_plan("out"), a_dst)
-        else:
+        dense = ctx.dense and ops.dense_pool_fits(gxnew, x_new, xq_raw)
+        if dense:
+            gx, g_a, g_c, ties = ops.dense_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, dense_stat, s.dense_plan("in"),
+                                                                 s.dense_plan("out"), xq_raw, gx_rank1=att_x[0].contiguous())
+        elif not ctx.tiled:
             gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0])
         g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
         g_att_x = torch.empty_like(att_x)
@@ -925,7 +937,9 @@ class _ASAPool(Function):
         g_att_q = (g_w_comp * lin_w).sum(1).unsqueeze(0) + g_att_b * lin_b.unsqueeze(0)
         g_lin_w = att_q.t() * g_w_comp
         g_lin_b = g_att_b * att_q[0]
-        if not ctx.tiled:
+        if dense:
+            ops.dense_segment_max_bwd_(gx, x, xq_raw, s, ties, (g_a, w_comp[0].contiguous()), s.dense_plan("out"))
+        elif not ctx.tiled:
             ops.csr_segment_max_bwd_(gx, x, xq_raw, None, s, ties=ties, gmax_rank1=(g_a, w_comp[0].contiguous()))
         g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],
