@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void dense_rows_kernel(const int32_t* __res
 
 // One workgroup per block: the union of the 16 rows' sources (and the rows themselves), every entry's slot in it, the cell mask.
 // The union's bitset covers the ids of the block's graph (gptr: a graph's rows are a contiguous range of ids).
-// LDS: bits[max_words] | pre[max_words] | mask[16 * kDbMaskWords] | rows, beg, deg [16 each] | tmp[16].
+// LDS: bits[max_words] | pre[max_words] | mask[16 * kDbMaskWords] | rows, beg, deg [16 each] | offsets [20] | tmp[16].
 __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                             const int32_t* __restrict__ loops, const int32_t* __restrict__ gptr,
                                                             const int32_t* __restrict__ lrows, const int32_t* __restrict__ bgraph,
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
   int* rid = reinterpret_cast<int*>(mask + kDbRows * kDbMaskWords);
   int* rbeg = rid + kDbRows;
   int* rdeg = rbeg + kDbRows;
-  int* tmp = rdeg + kDbRows;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int* roff = rdeg + kDbRows;                                // [17]: the rows' offsets in the block's entry list
+  int* tmp = roff + kDbRows + 4;
+  const int tid = threadIdx.x;
   const int gr = bgraph[b];
   const int lo = gptr[gr];
   const int64_t width = (int64_t)gptr[gr + 1] - lo;
@@ -136,22 +137,49 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
   __syncthreads();
   int nrows = 0;
   for (int i = 0; i < kDbRows; ++i) nrows += rid[i] >= 0 ? 1 : 0;        // (pads sit at the end)
+  if (tid == 0) {
+    int o = 0;
+    for (int i = 0; i < kDbRows; ++i) { roff[i] = o; o += rdeg[i]; }
+    roff[kDbRows] = o;
+  }
+  __syncthreads();
+  const int total_entries = roff[kDbRows];
+  // The block's entries as ONE list, a thread taking entries tid, tid + 256, ...: four loads in flight per thread (a loop over the
+  // rows with a wave per row was a chain of dependent round trips: 91 us for 4 000 blocks).  f(row index in the block, source id).
+  auto for_entries = [&](auto f) {
+    for (int q0 = tid; q0 < total_entries; q0 += 4 * kBlock) {
+      int ri[4], jv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = q0 + k * kBlock;
+        ri[k] = -1;
+        if (q < total_entries) {
+          int i = 0;                                         // the row of entry q: the last i with roff[i] <= q
+#pragma unroll
+          for (int step = 8; step > 0; step >>= 1)
+            if (i + step < kDbRows && roff[i + step] <= q) i += step;
+          ri[k] = i;
+          jv[k] = idx[rbeg[i] + (q - roff[i])];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ri[k] >= 0) f(ri[k], jv[k]);
+    }
+  };
   {
     int bad = 0;
-    for (int i = wave; i < nrows; i += 4) {                  // mark the sources of the block's rows, and the rows themselves
-      const int bg = rbeg[i], d = rdeg[i], r = rid[i];
-      if (lane == 0) {
-        const int j = r - lo;
-        if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
-        else bad = 1;
-      }
-      for (int x = lane; x < d; x += kWave) {
-        const int jr = idx[bg + x], j = jr - lo;
-        if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
-        else bad = 1;                                        // an id outside the graph's range (or past the bitset)
-        bad |= (jr == r) ? 1 : 0;                            // a self-loop among the entries: its cell would be two entries
-      }
+    if (tid < nrows) {                                       // the rows themselves
+      const int j = rid[tid] - lo;
+      if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
+      else bad = 1;
     }
+    for_entries([&](int i, int jr) {                         // mark the sources of the block's rows
+      const int j = jr - lo;
+      if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
+      else bad = 1;                                          // an id outside the graph's range (or past the bitset)
+      bad |= (jr == rid[i]) ? 1 : 0;                         // a self-loop among the entries: its cell would be two entries
+    });
     if (bad) atomicOr(&tmp[10], 1);
   }
   __syncthreads();
@@ -177,14 +205,11 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
   const bool ok = total <= kDbCap && tmp[10] == 0;
   __syncthreads();
   if (ok) {
-    for (int i = wave; i < nrows; i += 4) {
-      const int bg = rbeg[i], d = rdeg[i];
-      for (int x = lane; x < d; x += kWave) {
-        const int j = idx[bg + x] - lo;
-        const uint32_t s = pre[j >> 5] + (uint32_t)__popc(bits[j >> 5] & ((1u << (j & 31)) - 1u));
-        atomicOr(&mask[i * kDbMaskWords + (s >> 5)], 1u << (s & 31));
-      }
-    }
+    for_entries([&](int i, int jr) {
+      const int j = jr - lo;
+      const uint32_t s = pre[j >> 5] + (uint32_t)__popc(bits[j >> 5] & ((1u << (j & 31)) - 1u));
+      atomicOr(&mask[i * kDbMaskWords + (s >> 5)], 1u << (s & 31));
+    });
   }
   int selfs = 0;
   if (tid < nrows) {
@@ -603,7 +628,7 @@ extern "C" int mlqem_dense_plan_build(const int32_t* ptr, const int32_t* idx, co
   if (num_graphs == 0 || num_rows == 0) return MLQEM_OK;
   if (!ptr || !idx || !graph_ptr || !counter || !lrows || !records || !row_flag || !aligned_to(records, 16)) return MLQEM_ERR_BAD_ARG;
   const int max_words = (int)std::max<int64_t>(1, (std::min<int64_t>(max_span, 8192 * 32) + 31) / 32);
-  const size_t lds = (size_t)max_words * 8 + (size_t)kDbRows * kDbMaskWords * 4 + (size_t)kDbRows * 12 + 64;
+  const size_t lds = (size_t)max_words * 8 + (size_t)kDbRows * kDbMaskWords * 4 + (size_t)kDbRows * 16 + 16 + 64;
   if (!ensure_dynamic_lds(dense_plan_kernel, lds)) return MLQEM_ERR_UNSUPPORTED;
   const int64_t max_blocks = mlqem_dense_plan_max_blocks(num_rows, num_graphs);
   int32_t* bgraph = lrows + max_blocks * kDbRows;            // (the second part of lrows: one graph id per block)

@@ -168,14 +168,19 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void dense_pool_scan_ke
     for (int k = 0; k < 8; ++k) acc[k] = MODE == kMax ? -INFINITY : 0.f;
     const BlockLds l = block_stage(rec, lds);
     const uint32_t* maskrow = l.mask + r * kDbMaskWords;
-    for (int cb = wave; cb < ncb; cb += kDbWaves) {
+    // the union rows of the wave's NEXT column block are in flight while this one is walked
+    f4a a0, a1, b0, b1;
+    auto fetch = [&](int cb) {
       const int uid = l.uni[16 * cb + r];                  // (as a stager the lane is (union row r, channels 8 g ..))
-      const f4a a0 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g), a1 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g + 4);
-      f4a b0, b1;
+      a0 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g);
+      a1 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g + 4);
       if (MODE == kShare) {
         b0 = *reinterpret_cast<const f4a*>(B + (int64_t)uid * LD + 8 * g);
         b1 = *reinterpret_cast<const f4a*>(B + (int64_t)uid * LD + 8 * g + 4);
       }
+    };
+    if (wave < ncb) fetch(wave);
+    for (int cb = wave; cb < ncb; cb += kDbWaves) {
       wave_sync();                                         // the previous column block's reads are done
       *reinterpret_cast<f4a*>(&tile[wave][0][r * LD + 8 * g]) = a0;
       *reinterpret_cast<f4a*>(&tile[wave][0][r * LD + 8 * g + 4]) = a1;
@@ -184,17 +189,18 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void dense_pool_scan_ke
         *reinterpret_cast<f4a*>(&tile[wave][NT - 1][r * LD + 8 * g + 4]) = b1;
       }
       wave_sync();
+      if (cb + kDbWaves < ncb) fetch(cb + kDbWaves);
       uint32_t bits = (maskrow[cb >> 1] >> ((cb & 1) * 16)) & 0xFFFFu;       // the row's cells of this column block
       const int d = selfs - 16 * cb;
       if ((unsigned)d < 16u) bits |= 1u << d;              // the row itself: always an entry here
-#pragma unroll
+#pragma unroll 4
       for (int u = 0; u < 16; ++u) {
         const f4a t0 = *reinterpret_cast<const f4a*>(&tile[wave][0][u * LD + 8 * g]), t1 = *reinterpret_cast<const f4a*>(&tile[wave][0][u * LD + 8 * g + 4]);
         const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         const bool on = bits >> u & 1u;
         if (MODE == kMax) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) acc[k] = on ? fmaxf(acc[k], tv[k]) : acc[k];
+          for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], on ? tv[k] : -INFINITY);
         } else if (MODE == kTies) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) acc[k] += (on && tv[k] == mine[k]) ? 1.f : 0.f;

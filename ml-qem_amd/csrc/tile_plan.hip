@@ -63,16 +63,27 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* tmp, int& tot) {
 __global__ __launch_bounds__(kBlock) void tile_order_kernel(const int32_t* __restrict__ slot, const int32_t* __restrict__ gptr,
                                                             const int32_t* __restrict__ new_gptr, int32_t* __restrict__ order) {
   __shared__ int tmp[8];
+  constexpr int kPer = 8;                                   // nodes per thread and trip: neighbours, so that the scan keeps their order
   const int g = blockIdx.x;
   const int n0 = gptr[g], n1 = gptr[g + 1];
   const int base = new_gptr[g], lim = new_gptr[g + 1];
   int run = 0;
-  for (int v0 = n0; v0 < n1; v0 += kBlock) {
-    const int v = v0 + (int)threadIdx.x;
-    const int s = v < n1 ? slot[v] : -1;
+  for (int v0 = n0; v0 < n1; v0 += kBlock * kPer) {
+    int s[kPer], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int v = v0 + (int)threadIdx.x * kPer + k;
+      s[k] = v < n1 ? slot[v] : -1;
+      mine += s[k] >= 0 ? 1 : 0;
+    }
     int tot;
-    const int pos = block_exclusive_scan(s >= 0 ? 1 : 0, tmp, tot);
-    if (s >= 0 && base + run + pos < lim) order[base + run + pos] = s;
+    int pos = base + run + block_exclusive_scan(mine, tmp, tot);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (s[k] >= 0) {
+        if (pos < lim) order[pos] = s[k];
+        ++pos;
+      }
     run += tot;
   }
 }
