@@ -549,6 +549,12 @@ def family_b_leg(dev, steps=30):
     return out
 
 
+def _lib_mod():
+    from blackwater.native import _lib
+
+    return _lib
+
+
 def level1_attention_roofline(batch, dev, heads=2, ch=15):
     """The SECOND TransformerConv's forward (docs/tutorials/gnn.py:86-91) on the graph ASAPooling coarsens out of ``batch`` -- where
     most of the attention time of a 100-qubit step goes (what's weak 3).  Same byte model as ``attention_roofline``
@@ -568,18 +574,43 @@ def level1_attention_roofline(batch, dev, heads=2, ch=15):
         t = ops.padded_empty(n, 4 * heads * 16, dev).normal_()
         t.view(n, 4 * heads, 16)[:, :, ch:] = 0.0
         qk.append(t)
-    run = lambda k: ops.transformer_attention_train(qk[k % 4], s.in_ptr, s.in_src, s.loops, e_cap, heads, ch, 0.1, 1234 + k, pair_key=True, head_pitch=16)
+    run_edge = lambda k: ops.transformer_attention_train(qk[k % 4], s.in_ptr, s.in_src, s.loops, e_cap, heads, ch, 0.1, 1234 + k, pair_key=True, head_pitch=16)
+    sec_edge = _timed_launches(run_edge, 20, 4)
+    # what the step runs since round 5: the rows of 32+ entries as dense blocks on the f32 matrix cores (csrc/dense_block.hip), the other
+    # rows in the per-edge kernel, one call; the plan is built once per structure and direction and shared with ASAPooling's walks
+    plan = s.dense_plan("in")
+    run = lambda k: ops.dense_attention_train(qk[k % 4], s.in_ptr, s.in_src, s.loops, e_cap, heads, ch, plan, drop_p=0.1, seed=1234 + k)
     sec = _timed_launches(run, 20, 4)
+    stride = _lib_mod().load().mlqem_dense_plan_record_ints()
+    nb = int(plan.counter.item()) // 16
+    rec = plan.records[: nb * stride].view(nb, stride)[:, :4].cpu().numpy()
+    usable = rec[:, 2] == 1
+    cells = int((16 * ((rec[usable, 1] + 15) // 16 * 16)).sum())
+    flag = plan.row_flag.bool()
     hc = heads * ch
     by_r02 = 4 * (n + 1) + 4 * e + 4 * hc * (n + e + e + n)                      # the coarsened graph has no self entries
     deg = (s.in_ptr[1:n + 1] - s.in_ptr[:n]).long()
     n_long = int((deg > 4).sum().item())
     by = 4 * (n + 1) + 4 * e + 4 * heads * 16 * (2 * n + 2 * e) + 4 * hc * (n + n_long) + 8 * n * heads
-    return {"bound": "hbm (by the contract's byte model; the counters say vector ALU: 0.69 of the SIMD cycles busy, profiles/r05_level1_pmc.json)",
-            "kernel": f"transformer_attn_train_q4_kernel<4> (H={heads}, C={ch}, head pitch 16, pair-keyed dropout 0.1)",
+    deg_h = deg.cpu().numpy()
+    flag_h = flag.cpu().numpy()
+    flops = cells * heads * (2 * 16 + 2 * 16) * 1.0                               # scores and weighted values of every cell, 16 channels each
+    return {"bound": "hbm by the contract's byte model (no cache credit: a key / value row is counted once per ENTRY, the block kernel reads it "
+                     "once per 16 rows, so the figure exceeds 1); the per-edge kernel alone is bound by vector instructions (0.69 of the SIMD "
+                     "cycles busy, profiles/r05_level1_pmc.json), the block kernel by the latency of its gathers",
+            "kernel": f"dense_attn_fwd_kernel<2> + transformer_attn_train_q4_kernel<4> over the rows outside the blocks (H={heads}, C={ch}, head "
+                      "pitch 16, pair-keyed dropout 0.1)",
             "workload": "the graph ASAPooling makes of 64 100-qubit circuits", "achieved": round(by / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(by / sec / 1e9 / 8000.0, 4), "frac_r02_model": round(by_r02 / sec / 1e9 / 8000.0, 4), "traffic": None,
-            "bytes_per_launch": int(by), "us_per_launch": round(sec * 1e6, 2), "nodes": n, "edges": e, "mean_row_length": round(e / max(n, 1), 1)}
+            "bytes_per_launch": int(by), "us_per_launch": round(sec * 1e6, 2), "nodes": n, "edges": e, "mean_row_length": round(e / max(n, 1), 1),
+            "per_edge_kernel_alone": {"us_per_launch": round(sec_edge * 1e6, 2), "frac": round(by / sec_edge / 1e9 / 8000.0, 4),
+                                      "note": "every row in transformer_attn_train_q4_kernel<4>: the r04 form of this launch"},
+            "dense_blocks": {"blocks": nb, "usable": int(usable.sum()), "rows_in_blocks": int(flag_h.sum()),
+                             "share_of_the_entries": round(float(deg_h[flag_h].sum()) / max(float(deg_h.sum()), 1.0), 4),
+                             "cells": cells, "cells_per_entry": round(cells / max(float(deg_h[flag_h].sum()), 1.0), 3),
+                             "mfma_flops_per_launch": int(flops),
+                             "note": "16 rows x the union of their sources per block; scores and weighted values on v_mfma_f32_16x16x4_f32 "
+                                     "(157.3 TFLOP/s dense f32 peak: the products are a few percent of it, the kernel waits on its gathers)"}}
 
 
 def attention_roofline(s, dev, what, heads=3, ch=15):

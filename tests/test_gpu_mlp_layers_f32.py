@@ -215,7 +215,6 @@ def test_train_step_on_the_layer_kernels_equals_the_oracle_in_fp64(cls, args):
     import blackwater.native.functional as F
     import oracle.models as om
 
-    assert F._MLP_F32_LAYERS
     torch.manual_seed(1)
     n = 3000
     x, y = torch.randn(n, args[0]), torch.randn(n, args[2])
