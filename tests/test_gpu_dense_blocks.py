@@ -208,3 +208,29 @@ def test_pooling_walks_on_the_blocks_equal_the_per_edge_kernels(d, loops_p, ties
     ops.dense_segment_max_bwd_(gx, x, xmax, s, ties_d, (ga, w_comp), pout)
     _close(gx[:, :d], gx_r[:, :d], "g_x with the maximum's part")
 
+
+def test_family_b_on_100_qubit_graphs_with_dense_blocks_equals_per_edge():
+    """The switch that stays (functional._DENSE_BLOCKS / MLQEM_DENSE_BLOCKS): the whole model (docs/tutorials/gnn.py:70-122) on four
+    100-qubit circuits, eval mode and train mode with dropout (the same draws in both forms), level 1 on the dense blocks against the
+    per-edge kernels on every row -- predictions within 2e-5 of their scale, every parameter gradient within 2e-4 of the largest
+    gradient (the forms sum a row's 200 entries in different orders); and blocks were really used."""
+    from blackwater.native import ops
+    from test_gpu_tiles import _family_b_on_100q
+
+    calls = []
+    real = ops.dense_attention_train
+    ops.dense_attention_train = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        out_d, _ = _family_b_on_100q(False, train=False, dense_on=True)
+        out_e, _ = _family_b_on_100q(False, train=False, dense_on=False)
+        assert (out_d - out_e).abs().max().item() < 1e-5 * max(1.0, out_e.abs().max().item())
+        out_d, g_d = _family_b_on_100q(False, train=True, dense_on=True)
+        out_e, g_e = _family_b_on_100q(False, train=True, dense_on=False)
+    finally:
+        ops.dense_attention_train = real
+    assert len(calls) == 2                        # the second TransformerConv's forward of both dense runs (parameters want gradients in both)
+    assert (out_d - out_e).abs().max().item() < 2e-5 * max(1.0, out_e.abs().max().item())
+    gmax = max(v.abs().max().item() for v in g_e.values())
+    for k in g_e:
+        assert (g_d[k] - g_e[k]).abs().max().item() < 2e-4 * gmax, k
+

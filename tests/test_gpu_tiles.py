@@ -204,7 +204,7 @@ def test_tiled_pooling_scores_equal_the_per_edge_kernels(d, cap):
     assert torch.isfinite(gx[:, :d]).all()
 
 
-def _family_b_on_100q(tiles_on, train):
+def _family_b_on_100q(tiles_on, train, dense_on=False):
     from blackwater.data.arena import GraphArena
     from blackwater.data.synthetic import tfim_corpus
     from blackwater.native import functional as F
@@ -216,8 +216,8 @@ def _family_b_on_100q(tiles_on, train):
     torch.manual_seed(0)
     model = ExpValCircuitGraphModel(22, 15).to(DEV)
     model.train(train)
-    was = F._TILES
-    F._TILES = tiles_on
+    was = F._TILES, F._DENSE_BLOCKS
+    F._TILES, F._DENSE_BLOCKS = tiles_on, dense_on       # both off: the per-edge kernels on every row
     try:
         batch = arena.batch(np.arange(len(arena)))
         out = model(*batch.model_args())
@@ -228,7 +228,7 @@ def _family_b_on_100q(tiles_on, train):
             grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
         return out.detach().clone(), grads
     finally:
-        F._TILES = was
+        F._TILES, F._DENSE_BLOCKS = was
 
 
 def test_family_b_on_100_qubit_graphs_tiled_equals_per_edge():
