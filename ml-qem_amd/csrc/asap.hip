@@ -50,6 +50,99 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __r
   perm[p] = gptr[lo] + (int32_t)(mask - ((uint32_t)key & mask));
 }
 
+// Top-k of LARGE graphs (thousands of nodes: 100-qubit circuits) in two launches (round 5; was one device-wide merge sort: 19-22
+// launches of 5-7 us per pooling, 0.26 ms of a 64-circuit step).
+//   topk_chunk_sort_kernel: a workgroup sorts one CHUNK of kTopkChunk consecutive nodes of one graph in LDS (bitonic, descending; the
+//     key = ordered fitness bits above (2^32 - 1 - local index): unique inside a graph, equal fitness -> lower index first, the order
+//     of the keys above) and writes it back in place of the chunk.  Workgroup w -> (graph, chunk) by cstart[g] = gptr[g] / chunk + g.
+//   topk_rank_select_kernel: a thread per node: its rank in its graph = its place in its chunk + for every other chunk of the graph the
+//     number of keys above it (a binary search in a sorted chunk); rank < k_g -> perm[new_gptr[g] + rank] = the node.  A thread
+//     stops as soon as its rank reaches k_g.
+constexpr int kTopkChunk = 4096;
+constexpr int kTopkPer = kTopkChunk / kBlock;
+
+__device__ __forceinline__ int topk_graph_of_chunk(const int32_t* __restrict__ gptr, int B, int w) {
+  int lo = 0, hi = B;                                    // largest g with cstart[g] <= w
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (gptr[mid] / kTopkChunk + mid <= w) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void topk_chunk_sort_kernel(const float* __restrict__ fitness, const int32_t* __restrict__ gptr, int B,
+                                                                 uint64_t* __restrict__ sorted) {
+  __shared__ uint64_t key[kTopkChunk];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int g = topk_graph_of_chunk(gptr, B, w);
+  const int g0 = gptr[g], n = gptr[g + 1] - g0;
+  const int c = w - (g0 / kTopkChunk + g);
+  const int first = c * kTopkChunk;
+  if (first >= n) return;                                // (the whole workgroup)
+  const int cnt = min(kTopkChunk, n - first);
+#pragma unroll
+  for (int k = 0; k < kTopkPer; ++k) {
+    const int i = k * kBlock + tid;
+    uint64_t v = 0;                                      // pads: below every key
+    if (i < cnt) {
+      const uint32_t bits = __float_as_uint(fitness[g0 + first + i]);
+      const uint32_t ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+      v = ((uint64_t)ord << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(first + i));
+    }
+    key[i] = v;
+  }
+  __syncthreads();
+  for (int size = 2; size <= kTopkChunk; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int k = 0; k < kTopkPer / 2; ++k) {
+        const int t = k * kBlock + tid;                  // compare-exchange number t of this pass
+        const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);            // descending overall: the blocks with this bit clear sort downwards
+        const uint64_t a = key[lo], b = key[hi];
+        if ((a < b) == desc) { key[lo] = b; key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kTopkPer; ++k) {
+    const int i = k * kBlock + tid;
+    if (i < cnt) sorted[g0 + first + i] = key[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void topk_rank_select_kernel(const uint64_t* __restrict__ sorted, const int32_t* __restrict__ gptr,
+                                                                  const int32_t* __restrict__ new_gptr, int B, int64_t N,
+                                                                  int32_t* __restrict__ perm) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= N) return;
+  int lo = 0, hi = B;                                    // graph of element e
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (gptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  const int g = lo, g0 = gptr[g], n = gptr[g + 1] - g0;
+  const int keep = new_gptr[g + 1] - new_gptr[g];
+  const int local = (int)(e - g0), c = local / kTopkChunk;
+  int rank = local - c * kTopkChunk;                     // its place in its own (sorted) chunk
+  if (rank >= keep) return;
+  const uint64_t mine = sorted[e];
+  const int nch = (n + kTopkChunk - 1) / kTopkChunk;
+  for (int o = 0; o < nch; ++o) {
+    if (o == c) continue;
+    const uint64_t* __restrict__ ch = sorted + g0 + (int64_t)o * kTopkChunk;
+    int a = 0, b = min(kTopkChunk, n - o * kTopkChunk);  // the number of keys of chunk o above `mine` (the chunk descends)
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if (ch[mid] > mine) a = mid + 1; else b = mid;
+    }
+    rank += a;
+    if (rank >= keep) return;
+  }
+  perm[new_gptr[g] + rank] = g0 + (int32_t)(0xFFFFFFFFu - (uint32_t)mine);
+}
+
 // The device-wide sort of the top-k always takes rocprim's MERGE sort: above 2^20 keys the default configuration switches to
 // Onesweep, which clears its digit counters and look-back states with hipMemsetAsync -- memset nodes of a captured hipGraph, and a
 // captured Family B step on 256 100-qubit circuits (2.8 M keys) died in its second replay inside
@@ -953,6 +1046,15 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
   // does the same job with every CU.  Same keys below the graph bits, so the same permutation.
   const int graph_bits = bits_for(B);
   const bool whole = N / B >= 1024 && graph_bits + 32 + idx_bits <= 64;
+  if (N / B >= 1024) {
+    // ... and since round 5 two launches of this file instead of the ~20 of a device-wide merge sort: chunks of a graph sorted in LDS,
+    // then every node's rank among its graph's chunks.  Same order (fitness descending, equal fitness by index), so the same perm.
+    const int64_t chunks = N / kTopkChunk + B + 1;
+    hipLaunchKernelGGL(topk_chunk_sort_kernel, dim3((unsigned)chunks), dim3(kBlock), 0, stream, fitness, graph_ptr, (int)B, sorted);
+    hipLaunchKernelGGL(topk_rank_select_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, sorted, graph_ptr,
+                       new_graph_ptr, (int)B, N, perm);
+    return launch_status();
+  }
   hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, fitness,
                      graph_ptr, (int)B, N, idx_bits, whole ? graph_bits : 0, keys);
   if (whole) {

@@ -679,10 +679,13 @@ def test_linear_with_more_than_128_inputs_runs_on_the_matrix_cores_in_two_pieces
     assert (got2.double() - (want + x.double() @ w.double().t())).abs().max().item() < 1e-4 * want.abs().max().item() * 2
 
 
-@pytest.mark.parametrize("sizes", [[5, 1, 0, 17, 300], [3000, 9000, 1500, 4096, 2048, 7777], [20000] * 3 + [2089] * 5])
+@pytest.mark.parametrize("sizes", [[5, 1, 0, 17, 300], [3000, 9000, 1500, 4096, 2048, 7777], [20000] * 3 + [2089] * 5,
+                                   [4097, 1, 8192, 4095, 12288, 0, 5000, 16385]])
 def test_segment_topk_lists_each_graph_by_descending_fitness_ties_to_the_lower_index(sizes):
     """mlqem_segment_topk (PyG ``topk(fitness, ratio, batch)`` of ASAPooling): small graphs go through the segmented sort,
-    batches of large graphs through ONE device-wide sort with the graph index in the key -- both must list, for every graph,
+    batches of large graphs (a thousand nodes per graph on average) through the two launches of round 5 -- chunks of 4 096 nodes
+    sorted in LDS, then every node ranked among its graph's chunks (sizes around the chunk boundaries, an empty graph and a graph
+    of one node among them) -- both must list, for every graph,
     its ceil(n/2) nodes of largest fitness in descending order with ties broken by the lower index; with and without the
     caller's bound on the graph size.  Fitness values are quantised so that ties are frequent; integers: exact."""
     import numpy as np
