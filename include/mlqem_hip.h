@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 30 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 31 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -760,6 +760,19 @@ int mlqem_tile_asap_scores_bwd_f32(const float* x, int64_t ldx, const float* xne
                                    const int32_t* out_tinfo, const int32_t* out_rinfo, const int32_t* out_uni, const uint16_t* out_loc,
                                    int64_t out_tiles, int out_cap, int out_tile_rows, float* stat, float* g_a, float* share, int64_t lds,
                                    float* gx, int64_t ldgx, float* g_c, mlqem_stream_t stream);
+
+/* The small-tensor algebra around ASAPooling's score and fitness projections (docs/tutorials/gnn.py:85,92: ASAPooling.lin, .att,
+ * .gnn_score.lin1/2/3; D = the pooling's channels), one launch per direction instead of ten element-wise launches each:
+ *   forward : w_comp[D] = att_q W_lin, b_comp[1] = att_q . b_lin + att_b (the query projection composed into the one-wide score
+ *             projection that is its only consumer), att_q[D] / att_x[D] = the halves of att_w[2 D], w3[3 D] = (l1_w; l2_w; l3_w),
+ *             b3[3] = (l1_b, 0, l3_b)
+ *   backward: g_lin_w[D D], g_lin_b[D], g_att_w[2 D] from g_w_comp[D], g_att_b[1], g_att_x[D] by the chain rule. */
+int mlqem_asap_compose_f32(const float* lin_w, const float* lin_b, const float* att_w, const float* att_b, const float* l1_w,
+                           const float* l1_b, const float* l2_w, const float* l3_w, const float* l3_b, int D, float* w_comp,
+                           float* b_comp, float* att_q, float* att_x, float* w3, float* b3, mlqem_stream_t stream);
+int mlqem_asap_compose_bwd_f32(const float* g_w_comp, const float* g_att_b, const float* lin_w, const float* lin_b,
+                               const float* att_w, const float* g_att_x, int D, float* g_lin_w, float* g_lin_b, float* g_att_w,
+                               mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Dense blocks (csrc/dense_block.hpp): TransformerConv's edge softmax (docs/tutorials/gnn.py:80-91) over the LONG rows of a

@@ -803,9 +803,9 @@ class _ASAPool(Function):
         s = struct
         x = ops.rowmajor(x)
         d, n = x.shape[1], s.num_nodes
-        att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
-        w3 = torch.cat([l1_w, l2_w, l3_w], 0).contiguous()
-        b3 = torch.cat([l1_b, l1_b * 0.0, l3_b], 0)      # lin2 has no bias (a multiply, not a memset: the step may be captured)
+        # the parameters' small-tensor algebra in one launch (csrc/asap.hip asap_compose_kernel): the halves of att_w, LEConv's three
+        # one-wide projections as one [3, D] matrix (lin2 has no bias), and the query projection composed into the score projection
+        w_comp, b_comp, att_q, att_x, w3, b3 = ops.asap_compose(lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w, l3_b)
         # the input graph's rows share their sources (it is itself a coarsened graph): segment max, composed score, softmax-sum and
         # LEConv's projections in ONE tiled pass (csrc/tile_pool.hip)
         tiled = _TILES and s.tiled and x.is_cuda and ops.tile_pool_fits(d)
@@ -815,8 +815,6 @@ class _ASAPool(Function):
         ctx.dense = dense
         stat = None
         if tiled:
-            w_comp = (att_q.t() * lin_w).sum(0, keepdim=True)
-            b_comp = (att_q[0] * lin_b).sum().reshape(1) + att_b
             a_dst = None
             c_src = ops.linear(x, att_x)[:, 0].contiguous()
             x_new, xq_raw, stat, pqr = ops.tile_asap_scores(x, s.in_ptr, s.in_src, c_src, w_comp[0].contiguous(), b_comp, w3, b3, slope,
@@ -830,11 +828,9 @@ class _ASAPool(Function):
             # ASAPooling's query x_q = lin(segmax) feeds ONLY the one-wide score a_i = att_q . x_q[i] + att_b (SURVEY appendix
             # B.2 steps 2-3): a_i = (att_q W) . segmax[i] + (att_q . b + att_b) -- one row dot of the segment max against a composed
             # 45-vector.  x_q [N, D] is never formed (a [N,D]x[D,D] GEMM forward; a data GEMM and a [D,D] weight-gradient pass
-            # backward), the gradients of lin follow from the composed vector's by the chain rule on D x D host-side tensors.
-            # (element-wise products and sums, not BLAS calls: D x D work, deterministic, capturable)
-            w_comp = (att_q.t() * lin_w).sum(0, keepdim=True)      # [1, D] = att_q W
-            b_comp = (att_q[0] * lin_b).sum().reshape(1) + att_b   # [1]
-            a_dst = ops.linear(xq_raw, w_comp.contiguous(), b_comp)[:, 0].contiguous()
+            # backward), the gradients of lin follow from the composed vector's by the chain rule on D x D tensors
+            # (asap_compose above, asap_compose_bwd in the backward: deterministic, capturable).
+            a_dst = ops.linear(xq_raw, w_comp, b_comp)[:, 0].contiguous()
         if not tiled:
             c_src = ops.linear(x, att_x)[:, 0].contiguous()
             if dense:
@@ -914,7 +910,7 @@ class _ASAPool(Function):
         ops.linear_wgrad(gpqr, x_new, gw3, gb3)
         # x' = sum_e softmax(LeakyReLU(a_i + c_j)) x_j
         # ... its destination-side walk also counts the ties of the segment max below (same x, same entries)
-        att_q, att_x = att_w[:, :d].contiguous(), att_w[:, d:].contiguous()
+        att_x = att_w[:, d:]                 # (a view: its one row is contiguous)
         # c = x att_x^T: its gradient g_c (x) att_x rides in the source-side kernel's store of gx (it computes g_c itself) instead of
         # being a read-modify-write pass over gx
         if ctx.tiled:        # a_dst holds the forward's per-row record; the segment max's backward is part of the call
@@ -923,25 +919,22 @@ class _ASAPool(Function):
         dense = ctx.dense and ops.dense_pool_fits(gxnew, x_new, xq_raw)
         if dense:
             gx, g_a, g_c, ties = ops.dense_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, dense_stat, s.dense_plan("in"),
-                                                                 s.dense_plan("out"), xq_raw, gx_rank1=att_x[0].contiguous())
+                                                                 s.dense_plan("out"), xq_raw, gx_rank1=att_x[0])
         elif not ctx.tiled:
             gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0])
         g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
-        g_att_x = torch.empty_like(att_x)
+        g_att_x = torch.empty((1, d), dtype=torch.float32, device=dev)
         ops.linear_wgrad(g_c2, x, g_att_x, None)
         # a = xq_raw w_comp^T + b_comp with w_comp = att_q W, b_comp = att_q . b + att_b: the gradients of lin and of att's query half
         # by the chain rule on D x D tensors; the segment max's gradient g_a (x) w_comp is formed inside its backward kernel
         g_w_comp = torch.empty_like(w_comp)
         g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
         ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
-        g_att_q = (g_w_comp * lin_w).sum(1).unsqueeze(0) + g_att_b * lin_b.unsqueeze(0)
-        g_lin_w = att_q.t() * g_w_comp
-        g_lin_b = g_att_b * att_q[0]
         if dense:
             ops.dense_segment_max_bwd_(gx, x, xq_raw, s, ties, (g_a, w_comp[0].contiguous()), s.dense_plan("out"))
         elif not ctx.tiled:
             ops.csr_segment_max_bwd_(gx, x, xq_raw, None, s, ties=ties, gmax_rank1=(g_a, w_comp[0].contiguous()))
-        g_att_w = torch.cat([g_att_q, g_att_x], dim=1)
+        g_lin_w, g_lin_b, g_att_w = ops.asap_compose_bwd(g_w_comp, g_att_b, lin_w, lin_b, att_w, g_att_x)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],
                 None, None, None, None)
 

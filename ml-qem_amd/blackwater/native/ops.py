@@ -1180,6 +1180,32 @@ def gather_scale_rows(x, perm, scale=None):
     return out
 
 
+def asap_compose(lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w, l3_b):
+    """(w_comp [1, D], b_comp [1], att_q [1, D], att_x [1, D], w3 [3, D], b3 [3]) of ASAPooling's parameters in one launch."""
+    d = lin_w.shape[0]
+    dev = lin_w.device
+    ts = [t.contiguous() for t in (lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w, l3_b)]
+    buf = torch.empty(6 * d + 4, dtype=torch.float32, device=dev)
+    w_comp, att_q, att_x, w3 = buf[:d].view(1, d), buf[d:2 * d].view(1, d), buf[2 * d:3 * d].view(1, d), buf[3 * d:6 * d].view(3, d)
+    b_comp, b3 = buf[6 * d:6 * d + 1], buf[6 * d + 1:6 * d + 4]
+    code = _lib.load().mlqem_asap_compose_f32(*[_p(t) for t in ts], d, _p(w_comp), _p(b_comp), _p(att_q), _p(att_x), _p(w3), _p(b3), _stream())
+    _lib.check(code, "mlqem_asap_compose_f32")
+    return w_comp, b_comp, att_q, att_x, w3, b3
+
+
+def asap_compose_bwd(g_w_comp, g_att_b, lin_w, lin_b, att_w, g_att_x):
+    """(g_lin_w [D, D], g_lin_b [D], g_att_w [1, 2 D]): the chain rule of ``asap_compose`` in one launch."""
+    d = lin_w.shape[0]
+    dev = lin_w.device
+    buf = torch.empty(d * d + 3 * d, dtype=torch.float32, device=dev)
+    g_lin_w, g_lin_b, g_att_w = buf[:d * d].view(d, d), buf[d * d:d * d + d], buf[d * d + d:].view(1, 2 * d)
+    code = _lib.load().mlqem_asap_compose_bwd_f32(_p(g_w_comp.contiguous()), _p(g_att_b), _p(lin_w.contiguous()), _p(lin_b.contiguous()),
+                                                  _p(att_w.contiguous()), _p(g_att_x.contiguous()), d, _p(g_lin_w), _p(g_lin_b), _p(g_att_w),
+                                                  _stream())
+    _lib.check(code, "mlqem_asap_compose_bwd_f32")
+    return g_lin_w, g_lin_b, g_att_w
+
+
 def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_total, max_graph_nodes=0):
     _vec(fitness, "fitness", num_nodes)
     _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)

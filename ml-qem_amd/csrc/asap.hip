@@ -50,6 +50,56 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __r
   perm[p] = gptr[lo] + (int32_t)(mask - ((uint32_t)key & mask));
 }
 
+// The small-tensor algebra around ASAPooling's composed score (native/functional.py: a_i = (att_q W) . segmax_i + (att_q . b + att_b),
+// LEConv's three one-wide projections as one [3, D] matrix) as ONE launch per direction instead of ten element-wise / reduce / cat
+// launches of the host framework each (a 5 us launch each: a fifth of a 32-circuit step of the reference's batch size).
+//   forward:  w_comp[j] = sum_i att_q[i] lin_w[i, j];  b_comp = att_q . lin_b + att_b;  att_q, att_x = the halves of att_w;
+//             w3 = [l1_w; l2_w; l3_w];  b3 = (l1_b, 0, l3_b)
+//   backward: g_att_q[i] = sum_j g_w_comp[j] lin_w[i, j] + g_att_b lin_b[i];  g_lin_w[i, j] = att_q[i] g_w_comp[j];
+//             g_lin_b[i] = g_att_b att_q[i];  g_att_w = (g_att_q | g_att_x)
+__global__ __launch_bounds__(kBlock) void asap_compose_kernel(const float* __restrict__ lin_w, const float* __restrict__ lin_b,
+                                                              const float* __restrict__ att_w, const float* __restrict__ att_b,
+                                                              const float* __restrict__ l1_w, const float* __restrict__ l1_b,
+                                                              const float* __restrict__ l2_w, const float* __restrict__ l3_w,
+                                                              const float* __restrict__ l3_b, int D, float* __restrict__ w_comp,
+                                                              float* __restrict__ b_comp, float* __restrict__ att_q, float* __restrict__ att_x,
+                                                              float* __restrict__ w3, float* __restrict__ b3) {
+  for (int j = threadIdx.x; j < D; j += kBlock) {
+    float acc = 0.f;
+    for (int i = 0; i < D; ++i) acc = fmaf(att_w[i], lin_w[(int64_t)i * D + j], acc);
+    w_comp[j] = acc;
+    att_q[j] = att_w[j];
+    att_x[j] = att_w[D + j];
+    w3[j] = l1_w[j];
+    w3[D + j] = l2_w[j];
+    w3[2 * D + j] = l3_w[j];
+  }
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < D; ++i) acc = fmaf(att_w[i], lin_b[i], acc);
+    b_comp[0] = acc + att_b[0];
+    b3[0] = l1_b[0];
+    b3[1] = 0.f;
+    b3[2] = l3_b[0];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void asap_compose_bwd_kernel(const float* __restrict__ g_w_comp, const float* __restrict__ g_att_b,
+                                                                  const float* __restrict__ lin_w, const float* __restrict__ lin_b,
+                                                                  const float* __restrict__ att_w, const float* __restrict__ g_att_x, int D,
+                                                                  float* __restrict__ g_lin_w, float* __restrict__ g_lin_b,
+                                                                  float* __restrict__ g_att_w) {
+  const float gb = g_att_b[0];
+  for (int i = threadIdx.x; i < D; i += kBlock) {
+    float acc = 0.f;
+    for (int j = 0; j < D; ++j) acc = fmaf(g_w_comp[j], lin_w[(int64_t)i * D + j], acc);
+    g_att_w[i] = acc + gb * lin_b[i];
+    g_att_w[D + i] = g_att_x[i];
+    g_lin_b[i] = gb * att_w[i];
+  }
+  for (int t = threadIdx.x; t < D * D; t += kBlock) g_lin_w[t] = att_w[t / D] * g_w_comp[t % D];
+}
+
 // Top-k of LARGE graphs (thousands of nodes: 100-qubit circuits) in two launches (round 5; was one device-wide merge sort: 19-22
 // launches of 5-7 us per pooling, 0.26 ms of a 64-circuit step).
 //   topk_chunk_sort_kernel: a workgroup sorts one CHUNK of kTopkChunk consecutive nodes of one graph in LDS (bitonic, descending; the
@@ -1016,6 +1066,29 @@ static size_t dense_scan_bytes(int64_t K) {
 }  // namespace mlqem
 
 using namespace mlqem;
+
+extern "C" int mlqem_asap_compose_f32(const float* lin_w, const float* lin_b, const float* att_w, const float* att_b, const float* l1_w,
+                                      const float* l1_b, const float* l2_w, const float* l3_w, const float* l3_b, int D, float* w_comp,
+                                      float* b_comp, float* att_q, float* att_x, float* w3, float* b3, mlqem_stream_t stream) {
+  begin_launches();
+  if (D <= 0 || D > 4096) return MLQEM_ERR_BAD_ARG;
+  if (!lin_w || !lin_b || !att_w || !att_b || !l1_w || !l1_b || !l2_w || !l3_w || !l3_b || !w_comp || !b_comp || !att_q || !att_x || !w3 || !b3)
+    return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(asap_compose_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w,
+                     l3_b, D, w_comp, b_comp, att_q, att_x, w3, b3);
+  return launch_status();
+}
+
+extern "C" int mlqem_asap_compose_bwd_f32(const float* g_w_comp, const float* g_att_b, const float* lin_w, const float* lin_b,
+                                          const float* att_w, const float* g_att_x, int D, float* g_lin_w, float* g_lin_b, float* g_att_w,
+                                          mlqem_stream_t stream) {
+  begin_launches();
+  if (D <= 0 || D > 4096) return MLQEM_ERR_BAD_ARG;
+  if (!g_w_comp || !g_att_b || !lin_w || !lin_b || !att_w || !g_att_x || !g_lin_w || !g_lin_b || !g_att_w) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(asap_compose_bwd_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), g_w_comp, g_att_b, lin_w, lin_b, att_w, g_att_x, D,
+                     g_lin_w, g_lin_b, g_att_w);
+  return launch_status();
+}
 
 extern "C" size_t mlqem_segment_topk_workspace_bytes(int64_t N, int64_t B) {
   if (N <= 0 || B <= 0) return 256;

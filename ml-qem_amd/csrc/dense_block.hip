@@ -13,8 +13,6 @@
 
 namespace mlqem {
 
-namespace {
-
 // ---------------------------------------------------------------------------------------------------------------- plan
 __device__ __forceinline__ int block_sum(int v, int* tmp) {     // tmp: 4 ints of LDS
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -602,13 +600,12 @@ template <int H> __global__ __launch_bounds__(kBlock) void dense_attn_bwd_src_ke
   }
 }
 
-int dense_grid(int64_t max_blocks) { return (int)std::max<int64_t>(1, std::min<int64_t>(max_blocks, 16384)); }
+static int dense_grid(int64_t max_blocks) { return (int)std::max<int64_t>(1, std::min<int64_t>(max_blocks, 16384)); }
 
-bool plan_ok(const int32_t* records, const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks) {
+static bool plan_ok(const int32_t* records, const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks) {
   return records && counter && row_flag && max_blocks > 0 && aligned_to(records, 16);
 }
 
-}  // namespace
 }  // namespace mlqem
 
 using namespace mlqem;

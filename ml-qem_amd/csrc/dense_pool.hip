@@ -11,8 +11,6 @@
 
 namespace mlqem {
 
-namespace {
-
 constexpr int kPoolTiles = 2;                               // channel tiles of 16: D <= 32
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -413,13 +411,12 @@ __global__ __launch_bounds__(kBlock) void dense_softmax_aggregate_bwd_src_kernel
   }
 }
 
-int pool_grid(int64_t max_blocks) { return (int)std::max<int64_t>(1, std::min<int64_t>(max_blocks, 16384)); }
+static int pool_grid(int64_t max_blocks) { return (int)std::max<int64_t>(1, std::min<int64_t>(max_blocks, 16384)); }
 
-bool plan_ok(const int32_t* records, const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks) {
+static bool plan_ok(const int32_t* records, const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks) {
   return records && counter && row_flag && max_blocks > 0 && aligned_to(records, 16);
 }
 
-}  // namespace
 }  // namespace mlqem
 
 using namespace mlqem;
