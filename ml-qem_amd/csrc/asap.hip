@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const uint64_t* __r
 //             w3 = [l1_w; l2_w; l3_w];  b3 = (l1_b, 0, l3_b)
 //   backward: g_att_q[i] = sum_j g_w_comp[j] lin_w[i, j] + g_att_b lin_b[i];  g_lin_w[i, j] = att_q[i] g_w_comp[j];
 //             g_lin_b[i] = g_att_b att_q[i];  g_att_w = (g_att_q | g_att_x)
+constexpr int kComposeLds = 64;                            // lin_w of up to 64 x 64 is staged in LDS (the reference's poolings: 45, 30)
 __global__ __launch_bounds__(kBlock) void asap_compose_kernel(const float* __restrict__ lin_w, const float* __restrict__ lin_b,
                                                               const float* __restrict__ att_w, const float* __restrict__ att_b,
                                                               const float* __restrict__ l1_w, const float* __restrict__ l1_b,
@@ -64,9 +65,20 @@ __global__ __launch_bounds__(kBlock) void asap_compose_kernel(const float* __res
                                                               const float* __restrict__ l3_b, int D, float* __restrict__ w_comp,
                                                               float* __restrict__ b_comp, float* __restrict__ att_q, float* __restrict__ att_x,
                                                               float* __restrict__ w3, float* __restrict__ b3) {
+  __shared__ float lw[kComposeLds * kComposeLds], aq[kComposeLds], lb[kComposeLds];
+  const bool staged = D <= kComposeLds;                  // one coalesced round trip instead of D dependent ones per thread
+  if (staged) {
+    for (int t = threadIdx.x; t < D * D; t += kBlock) lw[t] = lin_w[t];
+    for (int t = threadIdx.x; t < D; t += kBlock) { aq[t] = att_w[t]; lb[t] = lin_b[t]; }
+    __syncthreads();
+  }
   for (int j = threadIdx.x; j < D; j += kBlock) {
     float acc = 0.f;
-    for (int i = 0; i < D; ++i) acc = fmaf(att_w[i], lin_w[(int64_t)i * D + j], acc);
+    if (staged) {
+      for (int i = 0; i < D; ++i) acc = fmaf(aq[i], lw[i * D + j], acc);
+    } else {
+      for (int i = 0; i < D; ++i) acc = fmaf(att_w[i], lin_w[(int64_t)i * D + j], acc);
+    }
     w_comp[j] = acc;
     att_q[j] = att_w[j];
     att_x[j] = att_w[D + j];
@@ -74,9 +86,13 @@ __global__ __launch_bounds__(kBlock) void asap_compose_kernel(const float* __res
     w3[D + j] = l2_w[j];
     w3[2 * D + j] = l3_w[j];
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == kBlock - 1) {                       // (a lane of the last wave: the first ones hold the columns)
     float acc = 0.f;
-    for (int i = 0; i < D; ++i) acc = fmaf(att_w[i], lin_b[i], acc);
+    if (staged) {
+      for (int i = 0; i < D; ++i) acc = fmaf(aq[i], lb[i], acc);
+    } else {
+      for (int i = 0; i < D; ++i) acc = fmaf(att_w[i], lin_b[i], acc);
+    }
     b_comp[0] = acc + att_b[0];
     b3[0] = l1_b[0];
     b3[1] = 0.f;
@@ -89,15 +105,30 @@ __global__ __launch_bounds__(kBlock) void asap_compose_bwd_kernel(const float* _
                                                                   const float* __restrict__ att_w, const float* __restrict__ g_att_x, int D,
                                                                   float* __restrict__ g_lin_w, float* __restrict__ g_lin_b,
                                                                   float* __restrict__ g_att_w) {
+  __shared__ float lw[kComposeLds * kComposeLds], gw[kComposeLds], aq[kComposeLds];
+  const bool staged = D <= kComposeLds;
+  if (staged) {
+    for (int t = threadIdx.x; t < D * D; t += kBlock) lw[t] = lin_w[t];
+    for (int t = threadIdx.x; t < D; t += kBlock) { gw[t] = g_w_comp[t]; aq[t] = att_w[t]; }
+    __syncthreads();
+  }
   const float gb = g_att_b[0];
   for (int i = threadIdx.x; i < D; i += kBlock) {
     float acc = 0.f;
-    for (int j = 0; j < D; ++j) acc = fmaf(g_w_comp[j], lin_w[(int64_t)i * D + j], acc);
+    if (staged) {
+      for (int j = 0; j < D; ++j) acc = fmaf(gw[j], lw[i * D + j], acc);
+    } else {
+      for (int j = 0; j < D; ++j) acc = fmaf(g_w_comp[j], lin_w[(int64_t)i * D + j], acc);
+    }
     g_att_w[i] = acc + gb * lin_b[i];
     g_att_w[D + i] = g_att_x[i];
     g_lin_b[i] = gb * att_w[i];
   }
-  for (int t = threadIdx.x; t < D * D; t += kBlock) g_lin_w[t] = att_w[t / D] * g_w_comp[t % D];
+  if (staged) {
+    for (int t = threadIdx.x; t < D * D; t += kBlock) g_lin_w[t] = aq[t / D] * gw[t % D];
+  } else {
+    for (int t = threadIdx.x; t < D * D; t += kBlock) g_lin_w[t] = att_w[t / D] * g_w_comp[t % D];
+  }
 }
 
 // Top-k of LARGE graphs (thousands of nodes: 100-qubit circuits) in two launches (round 5; was one device-wide merge sort: 19-22
@@ -143,11 +174,12 @@ __global__ __launch_bounds__(kBlock) void topk_chunk_sort_kernel(const float* __
   }
   __syncthreads();
   for (int size = 2; size <= kTopkChunk; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    for (int ls = 31 - __clz(size) - 1; ls >= 0; --ls) {  // stride = 1 << ls (shifts and masks: a variable division costs ~40 instructions)
+      const int stride = 1 << ls;
 #pragma unroll
       for (int k = 0; k < kTopkPer / 2; ++k) {
         const int t = k * kBlock + tid;                  // compare-exchange number t of this pass
-        const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+        const int lo = ((t >> ls) << (ls + 1)) | (t & (stride - 1)), hi = lo + stride;
         const bool desc = ((lo & size) == 0);            // descending overall: the blocks with this bit clear sort downwards
         const uint64_t a = key[lo], b = key[hi];
         if ((a < b) == desc) { key[lo] = b; key[hi] = a; }
