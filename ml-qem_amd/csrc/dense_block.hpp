@@ -46,7 +46,9 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-// D += A(16 x 16, a lane's four k-values in `a`) x B(16 x 16, in `b`)
+// D += A(16 x 16, a lane's four k-values in `a`) x B(16 x 16, in `b`).  (ONE accumulator: the counters have 31 % of the block kernels'
+// wave cycles stalled on issue behind this chain of dependent MFMAs, but two accumulators and an add ran the backward 10 % slower --
+// 290 -> 318 us -- and the forward no faster: registers.)
 __device__ __forceinline__ f32x4 mfma16(const f4u& a, const f4u& b, f32x4 c) {
   c = mfma4(a.x, b.x, c);
   c = mfma4(a.y, b.y, c);
