@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 31 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 32 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -760,6 +760,15 @@ int mlqem_tile_asap_scores_bwd_f32(const float* x, int64_t ldx, const float* xne
                                    const int32_t* out_tinfo, const int32_t* out_rinfo, const int32_t* out_uni, const uint16_t* out_loc,
                                    int64_t out_tiles, int out_cap, int out_tile_rows, float* stat, float* g_a, float* share, int64_t lds,
                                    float* gx, int64_t ldgx, float* g_c, mlqem_stream_t stream);
+
+/* The q / k / v / skip projection of a TransformerConv (docs/tutorials/gnn.py:80-91) writes a head's C channels at a pitch of
+ * `pitch` floats when its weight [groups * channels, cols] and bias [groups * channels] have every group of rows spread to that pitch
+ * with zero rows between (groups = 4 heads); mlqem_unpad_head_rows_f32 takes the real rows of the padded gradients back.  b, b_padded,
+ * gb_padded, gb may be NULL. */
+int mlqem_pad_head_rows_f32(const float* w, const float* b, int groups, int channels, int pitch, int cols, float* w_padded,
+                            float* b_padded, mlqem_stream_t stream);
+int mlqem_unpad_head_rows_f32(const float* gw_padded, const float* gb_padded, int groups, int channels, int pitch, int cols,
+                              float* gw, float* gb, mlqem_stream_t stream);
 
 /* The small-tensor algebra around ASAPooling's score and fitness projections (docs/tutorials/gnn.py:85,92: ASAPooling.lin, .att,
  * .gnn_score.lin1/2/3; D = the pooling's channels), one launch per direction instead of ten element-wise launches each:

@@ -700,9 +700,7 @@ class _TransformerConv(Function):
         gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device)
         ops.linear_wgrad(gqkvs, x, gw, gb)
         if cp:                     # the real rows of the padded gradients
-            groups = 4 * heads
-            gw = gw.view(groups, cp, -1)[:, :channels].reshape(groups * channels, -1)
-            gb = gb.view(groups, cp)[:, :channels].reshape(groups * channels)
+            gw, gb = ops.unpad_head_rows(gw, gb, 4 * heads, channels, cp)
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -711,6 +709,8 @@ def _pad_heads(w, b, groups, channels, cp):
     rows between: the projection then writes its output at that pitch, pads zero; the gradient of a pad row is exactly zero)."""
     if cp <= channels:
         return w, b
+    if w.is_cuda:
+        return ops.pad_head_rows(w, b, groups, channels, cp)
     wp = w.new_zeros((groups * cp, w.shape[1]))
     wp.view(groups, cp, -1)[:, :channels].copy_(w.view(groups, channels, -1))
     bp = None
@@ -830,14 +830,16 @@ class _ASAPool(Function):
             # 45-vector.  x_q [N, D] is never formed (a [N,D]x[D,D] GEMM forward; a data GEMM and a [D,D] weight-gradient pass
             # backward), the gradients of lin follow from the composed vector's by the chain rule on D x D tensors
             # (asap_compose above, asap_compose_bwd in the backward: deterministic, capturable).
-            a_dst = ops.linear(xq_raw, w_comp, b_comp)[:, 0].contiguous()
+            # (one-wide and three-wide projections into COMPACT outputs: a [N, 1] matrix with a row pitch of one float is the vector the
+            # edge kernels take -- the padded default cost a strided copy per projection)
+            a_dst = ops.linear(xq_raw, w_comp, b_comp, out=torch.empty((n, 1), dtype=torch.float32, device=x.device))[:, 0]
         if not tiled:
-            c_src = ops.linear(x, att_x)[:, 0].contiguous()
+            c_src = ops.linear(x, att_x, out=torch.empty((n, 1), dtype=torch.float32, device=x.device))[:, 0]
             if dense:
                 x_new, stat = ops.dense_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope, s.dense_plan("in"))
             else:
                 x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
-            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3).contiguous(), s.in_ptr, s.in_src)
+            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3, out=torch.empty((n, 3), dtype=torch.float32, device=x.device)), s.in_ptr, s.in_src)
         # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk (float32 tensor times a python scalar)
         sizes = np.asarray(s.graph_sizes, dtype=np.int64)
         keep = np.ceil(sizes.astype(np.float32) * np.float32(ratio)).astype(np.int64)

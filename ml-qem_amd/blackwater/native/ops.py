@@ -1180,6 +1180,26 @@ def gather_scale_rows(x, perm, scale=None):
     return out
 
 
+def pad_head_rows(w, b, groups, channels, pitch):
+    """(w, b) with every group of ``channels`` rows spread to ``pitch`` rows (zero rows between), in one launch."""
+    cols = w.shape[1]
+    wp = torch.empty((groups * pitch, cols), dtype=torch.float32, device=w.device)
+    bp = torch.empty(groups * pitch, dtype=torch.float32, device=w.device) if b is not None else None
+    code = _lib.load().mlqem_pad_head_rows_f32(_p(w.contiguous()), _p(b), groups, channels, pitch, cols, _p(wp), _p(bp), _stream())
+    _lib.check(code, "mlqem_pad_head_rows_f32")
+    return wp, bp
+
+
+def unpad_head_rows(gwp, gbp, groups, channels, pitch):
+    """The real rows of gradients in the padded layout of ``pad_head_rows``: (gw [groups * channels, cols], gb), one launch."""
+    cols = gwp.shape[1]
+    gw = torch.empty((groups * channels, cols), dtype=torch.float32, device=gwp.device)
+    gb = torch.empty(groups * channels, dtype=torch.float32, device=gwp.device) if gbp is not None else None
+    code = _lib.load().mlqem_unpad_head_rows_f32(_p(gwp.contiguous()), _p(gbp), groups, channels, pitch, cols, _p(gw), _p(gb), _stream())
+    _lib.check(code, "mlqem_unpad_head_rows_f32")
+    return gw, gb
+
+
 def asap_compose(lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w, l3_b):
     """(w_comp [1, D], b_comp [1], att_q [1, D], att_x [1, D], w3 [3, D], b3 [3]) of ASAPooling's parameters in one launch."""
     d = lin_w.shape[0]

@@ -199,9 +199,60 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_kernel(const float* 
   out[p * ldo + c] = x[j * ldx + c] * (scale ? scale[j] : 1.f);
 }
 
+// A projection's weight [G C, I] and bias [G C] with every group of C rows spread to a pitch of CP rows (zero rows between), and back
+// (the gradients' real rows): what gives q / k / v / skip a head pitch of 16 floats.  One launch each way (was four / two
+// element-wise launches of the host framework per TransformerConv and step).
+__global__ __launch_bounds__(kBlock) void pad_head_rows_kernel(const float* __restrict__ w, const float* __restrict__ b, int G, int C, int CP,
+                                                               int I, float* __restrict__ wp, float* __restrict__ bp) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t total = (int64_t)G * CP * (I + 1);       // column I of a row: its bias
+  if (t >= total) return;
+  const int col = (int)(t % (I + 1));
+  const int64_t row = t / (I + 1);
+  const int g = (int)(row / CP), c = (int)(row % CP);
+  const bool real = c < C;
+  const int64_t src = (int64_t)g * C + c;
+  if (col < I) wp[row * I + col] = real ? w[src * I + col] : 0.f;
+  else if (bp) bp[row] = (real && b) ? b[src] : 0.f;
+}
+__global__ __launch_bounds__(kBlock) void unpad_head_rows_kernel(const float* __restrict__ gwp, const float* __restrict__ gbp, int G, int C,
+                                                                 int CP, int I, float* __restrict__ gw, float* __restrict__ gb) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t total = (int64_t)G * C * (I + 1);
+  if (t >= total) return;
+  const int col = (int)(t % (I + 1));
+  const int64_t row = t / (I + 1);
+  const int g = (int)(row / C), c = (int)(row % C);
+  const int64_t src = (int64_t)g * CP + c;
+  if (col < I) gw[row * I + col] = gwp[src * I + col];
+  else if (gb && gbp) gb[row] = gbp[src];
+}
+
 }  // namespace mlqem
 
 using namespace mlqem;
+
+extern "C" int mlqem_pad_head_rows_f32(const float* w, const float* b, int groups, int channels, int pitch, int cols, float* w_padded,
+                                       float* b_padded, mlqem_stream_t stream) {
+  begin_launches();
+  if (groups <= 0 || channels <= 0 || pitch < channels || cols <= 0) return MLQEM_ERR_BAD_ARG;
+  if (!w || !w_padded) return MLQEM_ERR_BAD_ARG;
+  const int64_t total = (int64_t)groups * pitch * (cols + 1);
+  hipLaunchKernelGGL(pad_head_rows_kernel, dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0, as_stream(stream), w, b, groups, channels,
+                     pitch, cols, w_padded, b_padded);
+  return launch_status();
+}
+
+extern "C" int mlqem_unpad_head_rows_f32(const float* gw_padded, const float* gb_padded, int groups, int channels, int pitch, int cols,
+                                         float* gw, float* gb, mlqem_stream_t stream) {
+  begin_launches();
+  if (groups <= 0 || channels <= 0 || pitch < channels || cols <= 0) return MLQEM_ERR_BAD_ARG;
+  if (!gw_padded || !gw) return MLQEM_ERR_BAD_ARG;
+  const int64_t total = (int64_t)groups * channels * (cols + 1);
+  hipLaunchKernelGGL(unpad_head_rows_kernel, dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0, as_stream(stream), gw_padded, gb_padded,
+                     groups, channels, pitch, cols, gw, gb);
+  return launch_status();
+}
 
 extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr,
                                                const int32_t* in_src, const int32_t* loops, int64_t N, int H, int C,
