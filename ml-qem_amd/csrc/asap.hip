@@ -360,28 +360,60 @@ struct DenseArgs {
   int32_t* outdeg; int32_t* indeg;   // [K + 1]
 };
 
+// Small graphs are STAGED: the graph's out-CSR and its nodes' cluster ids in LDS (a 4-qubit circuit: 230 nodes, 300 edges), so that
+// the three nested walks below run at LDS latency (from global memory each level was a dependent round trip: 41 us for 32 graphs).
+constexpr int kDenseStageNodes = 2 * kDenseMaxK + 2, kDenseStageEdges = 6144;
 __global__ __launch_bounds__(kBlock) void coarsen_dense_bitmap_kernel(const DenseArgs a) {
   extern __shared__ uint32_t s_bm[];   // [kg][W]
+  __shared__ int s_ptr[kDenseStageNodes + 1], s_slot[kDenseStageNodes], s_dst[kDenseStageEdges];
   const int g = blockIdx.x, tid = threadIdx.x;
   const int n0 = a.gptr[g], n1 = a.gptr[g + 1];
   const int k0 = a.new_gptr[g], kg = a.new_gptr[g + 1] - k0;
   const int W = a.W;
   for (int i = tid; i < kg * W; i += kBlock) s_bm[i] = 0u;
+  const int ng = n1 - n0, e0 = a.out_ptr[n0], eg = a.out_ptr[n1] - e0;
+  const bool staged = ng <= kDenseStageNodes && eg <= kDenseStageEdges;
+  if (staged) {
+    for (int i = tid; i <= ng; i += kBlock) s_ptr[i] = a.out_ptr[n0 + i] - e0;
+    for (int i = tid; i < ng; i += kBlock) s_slot[i] = a.slot[n0 + i];
+    for (int i = tid; i < eg; i += kBlock) s_dst[i] = a.out_dst[e0 + i] - n0;      // (a graph's edges stay inside the graph)
+  }
   __syncthreads();
-  for (int u = n0 + tid; u < n1; u += kBlock) {
-    const int ub = a.out_ptr[u], ue = a.out_ptr[u + 1];
-    for (int ci = ub - 1; ci < ue; ++ci) {                 // c over {u} + out(u)
-      const int c = ci < ub ? u : a.out_dst[ci];
-      const int p = a.slot[c];
-      if (p < 0) continue;
-      uint32_t* row = s_bm + (p - k0) * W;
-      for (int vi = ub - 1; vi < ue; ++vi) {               // v over {u} + out(u)
-        const int v = vi < ub ? u : a.out_dst[vi];
-        const int vb = a.out_ptr[v], ve = a.out_ptr[v + 1];
-        for (int di = vb - 1; di < ve; ++di) {             // d over {v} + out(v)
-          const int d = di < vb ? v : a.out_dst[di];
-          const int q = a.slot[d];
-          if (q >= 0 && q != p) atomicOr(row + ((q - k0) >> 5), 1u << ((q - k0) & 31));
+  if (staged) {
+    for (int u = tid; u < ng; u += kBlock) {
+      const int ub = s_ptr[u], ue = s_ptr[u + 1];
+      for (int ci = ub - 1; ci < ue; ++ci) {               // c over {u} + out(u)
+        const int c = ci < ub ? u : s_dst[ci];
+        const int p = s_slot[c];
+        if (p < 0) continue;
+        uint32_t* row = s_bm + (p - k0) * W;
+        for (int vi = ub - 1; vi < ue; ++vi) {             // v over {u} + out(u)
+          const int v = vi < ub ? u : s_dst[vi];
+          const int vb = s_ptr[v], ve = s_ptr[v + 1];
+          for (int di = vb - 1; di < ve; ++di) {           // d over {v} + out(v)
+            const int d = di < vb ? v : s_dst[di];
+            const int q = s_slot[d];
+            if (q >= 0 && q != p) atomicOr(row + ((q - k0) >> 5), 1u << ((q - k0) & 31));
+          }
+        }
+      }
+    }
+  } else {
+    for (int u = n0 + tid; u < n1; u += kBlock) {
+      const int ub = a.out_ptr[u], ue = a.out_ptr[u + 1];
+      for (int ci = ub - 1; ci < ue; ++ci) {               // c over {u} + out(u)
+        const int c = ci < ub ? u : a.out_dst[ci];
+        const int p = a.slot[c];
+        if (p < 0) continue;
+        uint32_t* row = s_bm + (p - k0) * W;
+        for (int vi = ub - 1; vi < ue; ++vi) {             // v over {u} + out(u)
+          const int v = vi < ub ? u : a.out_dst[vi];
+          const int vb = a.out_ptr[v], ve = a.out_ptr[v + 1];
+          for (int di = vb - 1; di < ve; ++di) {           // d over {v} + out(v)
+            const int d = di < vb ? v : a.out_dst[di];
+            const int q = a.slot[d];
+            if (q >= 0 && q != p) atomicOr(row + ((q - k0) >> 5), 1u << ((q - k0) & 31));
+          }
         }
       }
     }
@@ -410,10 +442,12 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_fill_kernel(const DenseA
   const int k0 = a.new_gptr[g], kg = a.new_gptr[g + 1] - k0;
   const int W = a.W;
   const uint32_t* gb = a.bitmaps + (int64_t)g * a.kmax * W;
+  __shared__ int s_optr[kDenseMaxK];                     // the rows' places in the out-CSR (read once per EDGE below)
   for (int i = tid; i < kg * W; i += kBlock) s_bm[i] = gb[i];
+  for (int i = tid; i < kg; i += kBlock) s_optr[i] = out_ptr_new[k0 + i];
   __syncthreads();
   for (int r = tid; r < kg; r += kBlock) {
-    int pos = out_ptr_new[k0 + r];                         // row r: destinations in ascending order
+    int pos = s_optr[r];                                   // row r: destinations in ascending order
     for (int w = 0; w < W; ++w) {
       uint32_t bits = s_bm[r * W + w];
       while (bits) {
@@ -431,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_fill_kernel(const DenseA
       in_src_new[ipos] = k0 + rr;
       int rank = __popc(row[wq] & below);                  // position of (rr -> r) inside row rr of the out-CSR
       for (int w = 0; w < wq; ++w) rank += __popc(row[w]);
-      out_eid_new[out_ptr_new[k0 + rr] + rank] = ipos;
+      out_eid_new[s_optr[rr] + rank] = ipos;
       ++ipos;
     }
   }
