@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 32 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 33 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -760,6 +760,15 @@ int mlqem_tile_asap_scores_bwd_f32(const float* x, int64_t ldx, const float* xne
                                    const int32_t* out_tinfo, const int32_t* out_rinfo, const int32_t* out_uni, const uint16_t* out_loc,
                                    int64_t out_tiles, int out_cap, int out_tile_rows, float* stat, float* g_a, float* share, int64_t lds,
                                    float* gx, int64_t ldgx, float* g_c, mlqem_stream_t stream);
+
+/* ASAPooling's forward up to the fitness projections in one pass, for graphs of short rows (C <= 64): per row the segment max over
+ * its in-entries and itself (xmax), the composed score a_dst = w_comp . xmax + b_comp, c_src = att_x . x, the score softmax + cluster
+ * sum (xnew) and pqr[N, 3] = xnew W3^T + b3.  Stands for mlqem_csr_segment_max_f32 + mlqem_linear_f32 x 3 +
+ * mlqem_csr_softmax_aggregate_f32 of ASAPooling.forward (docs/tutorials/gnn.py:85,92); same outputs. */
+int mlqem_asap_scores_fused_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* w_comp,
+                                const float* b_comp, const float* att_x, const float* w3, const float* b3, float negative_slope,
+                                int64_t N, int C, float* xmax, int64_t ldm, float* a_dst, float* c_src, float* xnew, int64_t ldn,
+                                float* pqr, mlqem_stream_t stream);
 
 /* The q / k / v / skip projection of a TransformerConv (docs/tutorials/gnn.py:80-91) writes a head's C channels at a pitch of
  * `pitch` floats when its weight [groups * channels, cols] and bias [groups * channels] have every group of rows spread to that pitch

@@ -751,6 +751,8 @@ def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
 # places, the general two-hop path (four device->host size reads) otherwise.  All forms yield identical arrays; these module
 # attributes exist so that the tests can force one form and compare it with another (tests/test_gpu_family_b.py).
 _ASAP_DENSE = True
+# ASAPooling's forward on a graph of short rows as one fused pass (tests/test_gpu_family_b.py flips it: both forms, same results)
+_ASAP_FUSED = True
 _ASAP_ROWS = True
 _ASAP_LISTS = True
 # True: the list coarsening also links every out-entry to its in-CSR twin (out_eid; 0.55 ms for 64 100-qubit circuits) and the
@@ -813,8 +815,14 @@ class _ASAPool(Function):
         # ... or its long rows as dense blocks (csrc/dense_pool.hip): the same plans TransformerConv's edge softmax built on this graph
         dense = _DENSE_BLOCKS and not tiled and s.tiled and s.out_eid is None and ops.dense_pool_fits(x)
         ctx.dense = dense
+        # ... or, a graph of short rows (the circuit DAGs: the arena hands their side table along): everything up to the fitness
+        # projections in one pass over the rows (csrc/attn.hip asap_scores_fused_kernel)
+        fused = _ASAP_FUSED and not tiled and not dense and x.is_cuda and d <= 64 and s.in_ell is not None
         stat = None
-        if tiled:
+        if fused:
+            xq_raw, a_dst, c_src, x_new, pqr = ops.asap_scores_fused(x, s.in_ptr, s.in_src, w_comp, b_comp, att_x, w3, b3, slope)
+            fitness = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
+        elif tiled:
             a_dst = None
             c_src = ops.linear(x, att_x)[:, 0].contiguous()
             x_new, xq_raw, stat, pqr = ops.tile_asap_scores(x, s.in_ptr, s.in_src, c_src, w_comp[0].contiguous(), b_comp, w3, b3, slope,
@@ -824,7 +832,7 @@ class _ASAPool(Function):
             xq_raw = ops.dense_segment_max(x, s.in_ptr, s.in_src, s.dense_plan("in"))
         else:
             xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
-        if not tiled:
+        if not tiled and not fused:
             # ASAPooling's query x_q = lin(segmax) feeds ONLY the one-wide score a_i = att_q . x_q[i] + att_b (SURVEY appendix
             # B.2 steps 2-3): a_i = (att_q W) . segmax[i] + (att_q . b + att_b) -- one row dot of the segment max against a composed
             # 45-vector.  x_q [N, D] is never formed (a [N,D]x[D,D] GEMM forward; a data GEMM and a [D,D] weight-gradient pass
@@ -833,7 +841,7 @@ class _ASAPool(Function):
             # (one-wide and three-wide projections into COMPACT outputs: a [N, 1] matrix with a row pitch of one float is the vector the
             # edge kernels take -- the padded default cost a strided copy per projection)
             a_dst = ops.linear(xq_raw, w_comp, b_comp, out=torch.empty((n, 1), dtype=torch.float32, device=x.device))[:, 0]
-        if not tiled:
+        if not tiled and not fused:
             c_src = ops.linear(x, att_x, out=torch.empty((n, 1), dtype=torch.float32, device=x.device))[:, 0]
             if dense:
                 x_new, stat = ops.dense_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope, s.dense_plan("in"))

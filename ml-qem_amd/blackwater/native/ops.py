@@ -1180,6 +1180,22 @@ def gather_scale_rows(x, perm, scale=None):
     return out
 
 
+def asap_scores_fused(x, in_ptr, in_src, w_comp, b_comp, att_x, w3, b3, negative_slope):
+    """(xmax, a_dst, c_src, x_new, pqr) of ASAPooling's forward in one pass over a graph of short rows (<= 64 channels)."""
+    n, c = x.shape
+    dev = x.device
+    xmax, xnew = padded_empty(n, c, dev), padded_empty(n, c, dev)
+    a_dst = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
+    c_src = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
+    pqr = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    code = _lib.load().mlqem_asap_scores_fused_f32(_p(x), _mat(x, "x"), _p(in_ptr), _p(in_src), _p(w_comp.contiguous()), _p(b_comp),
+                                                   _p(att_x.contiguous()), _p(w3.contiguous()), _p(b3), float(negative_slope), n, c,
+                                                   _p(xmax), _mat(xmax, "xmax"), _p(a_dst), _p(c_src), _p(xnew), _mat(xnew, "xnew"), _p(pqr),
+                                                   _stream())
+    _lib.check(code, "mlqem_asap_scores_fused_f32")
+    return xmax, a_dst, c_src, xnew, pqr
+
+
 def pad_head_rows(w, b, groups, channels, pitch):
     """(w, b) with every group of ``channels`` rows spread to ``pitch`` rows (zero rows between), in one launch."""
     cols = w.shape[1]

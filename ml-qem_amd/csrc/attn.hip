@@ -199,6 +199,152 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_kernel(const float* 
   out[p * ldo + c] = x[j * ldx + c] * (scale ? scale[j] : 1.f);
 }
 
+// ASAPooling's forward up to the fitness projections in ONE pass over the rows (round 5), for graphs of SHORT rows (circuit DAGs: one
+// or two in-edges per node but for barriers): per row i the segment max over N(i) + {i}, the composed score a_i = w_comp . max + b_comp,
+// c_j = att_x . x_j of every entry (and c_i, stored for the backward), the softmax of LeakyReLU(a_i + c_j) over the entries, the
+// cluster sum x'_i and pqr_i = W3 x'_i + b3.  Was: csr_aggregate<IS_MAX>, a [N,D]x[D,1] GEMM, another, softmax_aggregate_kernel, a
+// [N,D]x[D,3] GEMM -- five passes that read x, the maxima or x' from memory (294 us on the circuit DAGs of 64 100-qubit circuits).
+// A 16-lane group per row, lane l channels l, l + 16, ... (NV per lane); rows of at most two in-edges keep the gathered rows in
+// registers between the maximum and the sum, longer rows gather twice (the second time from cache).
+template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_kernel(
+    const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+    const float* __restrict__ w_comp, const float* __restrict__ b_comp, const float* __restrict__ att_x, const float* __restrict__ w3,
+    const float* __restrict__ b3, float slope, int64_t N, int C, float* __restrict__ xmax, int64_t ldm, float* __restrict__ a_dst,
+    float* __restrict__ c_src, float* __restrict__ xnew, int64_t ldn, float* __restrict__ pqr) {
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  bool has[NV];
+  float wc[NV], ax[NV], own[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    has[v] = l + v * kGroup < C;
+    wc[v] = has[v] ? w_comp[l + v * kGroup] : 0.f;
+    ax[v] = has[v] ? att_x[l + v * kGroup] : 0.f;
+    own[v] = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
+  }
+  auto dot = [&](const float (&a)[NV], const float (&b)[NV]) {
+    float d = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) d = fmaf(a[v], b[v], d);
+    return group16_sum(d);
+  };
+  const float c_own = dot(ax, own);
+  const int beg = ptr[row], deg = ptr[row + 1] - beg;
+  float mx[NV], acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) mx[v] = own[v];
+  float a_i, m, den;
+  if (deg <= 2) {                                          // (group-uniform) the gathered rows stay in registers
+    float xs[2][NV], cs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = u < deg ? idx[beg + u] : (int)row;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        xs[u][v] = has[v] ? x[(int64_t)j * ldx + l + v * kGroup] : 0.f;
+        if (u < deg) mx[v] = fmaxf(mx[v], xs[u][v]);
+      }
+      cs[u] = dot(ax, xs[u]);
+    }
+    a_i = dot(wc, mx) + b_comp[0];
+    const float s_own = leaky(a_i + c_own), s0 = deg > 0 ? leaky(a_i + cs[0]) : -INFINITY, s1 = deg > 1 ? leaky(a_i + cs[1]) : -INFINITY;
+    m = fmaxf(s_own, fmaxf(s0, s1));
+    const float p_own = expf(s_own - m), p0 = deg > 0 ? expf(s0 - m) : 0.f, p1 = deg > 1 ? expf(s1 - m) : 0.f;
+    den = p0 + p1 + p_own;                                 // entries first, the self-loop last (add_remaining_self_loops)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = fmaf(p_own, own[v], fmaf(p1, xs[1][v], p0 * xs[0][v]));
+  } else {
+    const int end = beg + deg;
+    // eight gathered rows in flight at a time (one row per trip was a dependent round trip per entry: a barrier's 100 entries took
+    // 300 us, the whole launch's duration)
+    for (int e0 = beg; e0 < end; e0 += kGroup) {           // the maximum
+      const int k = min(kGroup, end - e0);
+      const int j = idx[e0 + min(l, k - 1)];
+      for (int u0 = 0; u0 < k; u0 += 8) {
+        float xj[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ju = __shfl(j, min(u0 + u, k - 1), kGroup);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) xj[u][v] = has[v] ? x[(int64_t)ju * ldx + l + v * kGroup] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) mx[v] = fmaxf(mx[v], xj[u][v]);       // (past the end: the last entry again)
+      }
+    }
+    a_i = dot(wc, mx) + b_comp[0];
+    m = -INFINITY; den = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    auto grow = [&](float cm) {
+      if (cm > m) {
+        const float r = expf(m - cm);
+        den *= r;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] *= r;
+        m = cm;
+      }
+    };
+    for (int e0 = beg; e0 < end; e0 += kGroup) {           // scores, weights, the sum (rows from cache), in entry order
+      const int k = min(kGroup, end - e0);
+      const int j = idx[e0 + min(l, k - 1)];
+      for (int u0 = 0; u0 < k; u0 += 8) {
+        float xj[8][NV];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ju = __shfl(j, min(u0 + u, k - 1), kGroup);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) xj[u][v] = has[v] ? x[(int64_t)ju * ldx + l + v * kGroup] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u0 + u < k) {                                // (group-uniform)
+            const float sj = leaky(a_i + dot(ax, xj[u]));
+            grow(sj);
+            const float pj = expf(sj - m);
+            den += pj;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = fmaf(pj, xj[u][v], acc[v]);
+          }
+        }
+      }
+    }
+    const float s_own = leaky(a_i + c_own);
+    grow(s_own);
+    const float p_own = expf(s_own - m);
+    den += p_own;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = fmaf(p_own, own[v], acc[v]);
+  }
+  const float inv = 1.0f / (den + 1e-16f);
+  float xn[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    xn[v] = acc[v] * inv;
+    if (has[v]) {
+      xmax[row * ldm + l + v * kGroup] = mx[v];
+      xnew[row * ldn + l + v * kGroup] = xn[v];
+    }
+  }
+  float out3[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float wv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) wv[v] = has[v] ? w3[t * C + l + v * kGroup] : 0.f;
+    out3[t] = dot(wv, xn) + b3[t];
+  }
+  if (l == 0) {
+    a_dst[row] = a_i;
+    c_src[row] = c_own;
+    pqr[row * 3 + 0] = out3[0]; pqr[row * 3 + 1] = out3[1]; pqr[row * 3 + 2] = out3[2];
+  }
+}
+
 // A projection's weight [G C, I] and bias [G C] with every group of C rows spread to a pitch of CP rows (zero rows between), and back
 // (the gradients' real rows): what gives q / k / v / skip a head pitch of 16 floats.  One launch each way (was four / two
 // element-wise launches of the host framework per TransformerConv and step).
@@ -231,6 +377,26 @@ __global__ __launch_bounds__(kBlock) void unpad_head_rows_kernel(const float* __
 }  // namespace mlqem
 
 using namespace mlqem;
+
+extern "C" int mlqem_asap_scores_fused_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* w_comp,
+                                           const float* b_comp, const float* att_x, const float* w3, const float* b3, float negative_slope,
+                                           int64_t N, int C, float* xmax, int64_t ldm, float* a_dst, float* c_src, float* xnew, int64_t ldn,
+                                           float* pqr, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C <= 0 || ldx < C || ldm < C || ldn < C) return MLQEM_ERR_BAD_ARG;
+  if (C > 64) return MLQEM_ERR_UNSUPPORTED;
+  if (N == 0) return MLQEM_OK;
+  if (!x || !in_ptr || !w_comp || !b_comp || !att_x || !w3 || !b3 || !xmax || !a_dst || !c_src || !xnew || !pqr) return MLQEM_ERR_BAD_ARG;
+  const dim3 grid((unsigned)ceil_div(N * kGroup, kBlock));
+#define MLQEM_AF(NV) hipLaunchKernelGGL(asap_scores_fused_kernel<NV>, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, in_ptr, in_src, w_comp, \
+                                        b_comp, att_x, w3, b3, negative_slope, N, C, xmax, ldm, a_dst, c_src, xnew, ldn, pqr)
+  if (C <= 16) MLQEM_AF(1);
+  else if (C <= 32) MLQEM_AF(2);
+  else if (C <= 48) MLQEM_AF(3);
+  else MLQEM_AF(4);
+#undef MLQEM_AF
+  return launch_status();
+}
 
 extern "C" int mlqem_pad_head_rows_f32(const float* w, const float* b, int groups, int channels, int pitch, int cols, float* w_padded,
                                        float* b_padded, mlqem_stream_t stream) {

@@ -825,3 +825,69 @@ def test_recomputed_softmax_aggregate_backward_equals_the_stored_form(c):
     for a, b in ((gx0[:, :c], gx1[:, :c]), (ga0, ga1), (gc0, gc1)):
         assert (a - b).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
     assert torch.equal(t0[:, :c], t1[:, :c])
+
+
+@pytest.mark.parametrize("d", [45, 30, 7, 64])
+def test_fused_pooling_forward_equals_the_chain_of_kernels_it_stands_for(d):
+    """Round 5: on graphs of short rows ASAPooling's forward up to the fitness projections is one pass (mlqem_asap_scores_fused_f32) --
+    against the chain it replaces (segment max, the composed score projection, c = x att_x, score softmax + cluster sum, LEConv's three
+    projections) on a graph of rows with 0-2 entries and a few rows of up to 150: the maxima exactly, everything else to 1e-5 of
+    its scale; and the model-level results agree with the switch off (functional._ASAP_FUSED)."""
+    import numpy as np
+
+    from blackwater.native import ops
+    from blackwater.native.structure import GraphStructure
+
+    rng = np.random.RandomState(d)
+    n = 4000
+    deg = rng.choice([0, 1, 2, 2, 2, 1], size=n)
+    deg[rng.choice(n, 12, replace=False)] = rng.randint(3, 150, size=12)
+    dst = np.repeat(np.arange(n), deg)
+    src = np.concatenate([rng.choice(n, k, replace=False) for k in deg]) if deg.sum() else np.zeros(0, np.int64)
+    keep = src != dst
+    ei = torch.from_numpy(np.stack([src[keep], dst[keep]]).astype(np.int64)).to(DEV)
+    s = GraphStructure.from_edge_index(ei, n)
+    x = ops.padded_copy(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV))
+    w_comp = torch.from_numpy(rng.standard_normal((1, d)).astype(np.float32)).to(DEV)
+    b_comp = torch.from_numpy(rng.standard_normal(1).astype(np.float32)).to(DEV)
+    att_x = torch.from_numpy(rng.standard_normal((1, d)).astype(np.float32)).to(DEV)
+    w3 = torch.from_numpy(rng.standard_normal((3, d)).astype(np.float32)).to(DEV)
+    b3 = torch.from_numpy(rng.standard_normal(3).astype(np.float32)).to(DEV)
+    xmax_r = ops.csr_segment_max(x, s.in_ptr, s.in_src)
+    a_r = ops.linear(xmax_r, w_comp, b_comp)[:, 0].contiguous()
+    c_r = ops.linear(x, att_x)[:, 0].contiguous()
+    xnew_r = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_r, c_r, 0.2)
+    pqr_r = ops.linear(xnew_r, w3, b3)[:, :3]
+    xmax, a_dst, c_src, xnew, pqr = ops.asap_scores_fused(x, s.in_ptr, s.in_src, w_comp, b_comp, att_x, w3, b3, 0.2)
+    assert torch.equal(xmax[:, :d], xmax_r[:, :d])
+    tol = lambda t: 1e-5 * max(1.0, t.abs().max().item())
+    assert (a_dst - a_r).abs().max().item() < tol(a_r) and (c_src - c_r).abs().max().item() < tol(c_r)
+    assert (xnew[:, :d] - xnew_r[:, :d]).abs().max().item() < tol(xnew_r) and (pqr - pqr_r).abs().max().item() < tol(pqr_r)
+
+
+def test_family_b_with_and_without_the_fused_pooling_forward(g1):
+    import blackwater.native.functional as F
+    from blackwater.data.arena import GraphArena
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    xs, eis = zip(*[g1_graph(g1, i)[:2] for i in range(40)])
+    noisy = np.asarray([g1["noisy"][i] for i in range(40)], dtype=np.float32)[:, None, :]
+    arena = GraphArena.from_arrays([np.asarray(a, np.float32) for a in xs], [np.asarray(e) for e in eis], noisy, noisy, np.zeros((40, 1), np.float32),
+                                   np.zeros((40, 1, 1), np.float32), device=DEV)
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(3)
+        model = ExpValCircuitGraphModel(22, 15, noisy.shape[2]).to(DEV).train()
+        was = F._ASAP_FUSED
+        F._ASAP_FUSED = fused
+        try:
+            out = model(*arena.batch(np.arange(40)).model_args())
+            out.square().sum().backward()
+        finally:
+            F._ASAP_FUSED = was
+        res[fused] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    (oa, ga), (ob, gb) = res[True], res[False]
+    assert (oa - ob).abs().max().item() < 2e-5 * max(1.0, ob.abs().max().item())
+    gmax = max(v.abs().max().item() for v in gb.values())
+    for k in gb:
+        assert (ga[k] - gb[k]).abs().max().item() < 2e-4 * gmax, k
