@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 33 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 34 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -655,14 +655,18 @@ int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const flo
  * value equals xmax[i, c] -- the destination-side walk holds every source row anyway, and mlqem_csr_segment_max_bwd_f32 then
  * needs no walk of its own to split a maximum's gradient among ties.
  * gx_rank1 (may be NULL; C <= 128): a [C] vector r; gx additionally receives g_c[j] * r -- the gradient through the source score
- * c_j = x_j . r (ASAPooling's att on the source half, gnn.py:105-107), which otherwise is a read-modify-write pass over gx. */
+ * c_j = x_j . r (ASAPooling's att on the source half, gnn.py:105-107), which otherwise is a read-modify-write pass over gx.
+ * fuse_max_col (may be NULL; stored form with tie_count only; ABI 34): a [C] vector w; the source-side walk then also adds the
+ * backward of the segment max whose gradient is g_a (x) w -- gx[j, c] += sum over the destinations i of j, and j itself, with
+ * x[j, c] == xmax[i, c] of g_a[i] w[c] / max(tie_count[i, c], 1) -- and mlqem_csr_segment_max_bwd_f32 is not called at all. */
 int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn, const float* gnew,
                                         int64_t ldg, const int32_t* in_ptr, const int32_t* in_src,
                                         const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
                                         const float* a_dst, const float* c_src, float negative_slope, int64_t N,
                                         int64_t E, int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
                                         float* g_c, float* edge_al, float* edge_gp, const float* xmax, int64_t ldm,
-                                        float* tie_count, int64_t ldt, const float* gx_rank1, mlqem_stream_t stream);
+                                        float* tie_count, int64_t ldt, const float* gx_rank1, const float* fuse_max_col,
+                                        mlqem_stream_t stream);
 
 /* Backward of mlqem_csr_segment_max_f32, ACCUMULATING into gx: the gradient of a row's maximum goes to the entries
  * (sources or the row itself) whose value equals it, split evenly among ties (torch scatter_reduce(amax) rule).

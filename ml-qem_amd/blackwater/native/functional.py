@@ -927,11 +927,15 @@ class _ASAPool(Function):
             gx, g_a, g_c = ops.tile_asap_scores_bwd(x, x_new, gxnew, xq_raw, s, c_src, w_comp[0].contiguous(), att_x[0].contiguous(), ctx.slope,
                                                     s.tile_plan("in"), s.tile_plan("out"), a_dst)
         dense = ctx.dense and ops.dense_pool_fits(gxnew, x_new, xq_raw)
+        fuse_max = False
         if dense:
             gx, g_a, g_c, ties = ops.dense_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, dense_stat, s.dense_plan("in"),
                                                                  s.dense_plan("out"), xq_raw, gx_rank1=att_x[0])
         elif not ctx.tiled:
-            gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0])
+            # the stored form (a graph with out_eid: the circuit DAGs) carries the segment max's backward in its source-side walk
+            fuse_max = _ASAP_FUSED and s.out_eid is not None and d <= 128
+            gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0],
+                                                               fuse_max_col=w_comp[0].contiguous() if fuse_max else None)
         g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
         g_att_x = torch.empty((1, d), dtype=torch.float32, device=dev)
         ops.linear_wgrad(g_c2, x, g_att_x, None)
@@ -942,7 +946,7 @@ class _ASAPool(Function):
         ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
         if dense:
             ops.dense_segment_max_bwd_(gx, x, xq_raw, s, ties, (g_a, w_comp[0].contiguous()), s.dense_plan("out"))
-        elif not ctx.tiled:
+        elif not ctx.tiled and not fuse_max:
             ops.csr_segment_max_bwd_(gx, x, xq_raw, None, s, ties=ties, gmax_rank1=(g_a, w_comp[0].contiguous()))
         g_lin_w, g_lin_b, g_att_w = ops.asap_compose_bwd(g_w_comp, g_att_b, lin_w, lin_b, att_w, g_att_x)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],

@@ -1558,9 +1558,11 @@ def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channe
     return gqkvs
 
 
-def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope, xmax=None, gx_rank1=None):
+def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negative_slope, xmax=None, gx_rank1=None, fuse_max_col=None):
     """(gx, g_a, g_c) -- and, given ``xmax`` (the segment max of x over the same entries, <= 128 channels), a fourth result: the
-    per-channel tie counts ``csr_segment_max_bwd_`` would otherwise walk the in-edges for."""
+    per-channel tie counts ``csr_segment_max_bwd_`` would otherwise walk the in-edges for.  ``fuse_max_col`` (a [C] vector w; stored
+    form, with ``xmax``): gx also receives the backward of that segment max for a gradient g_a (x) w, and ``csr_segment_max_bwd_``
+    is not to be called."""
     n, c = x.shape
     dev = x.device
     gx = padded_empty(n, c, dev)
@@ -1577,7 +1579,7 @@ def csr_softmax_aggregate_bwd(x, xnew, gnew, s, num_edges, a_dst, c_src, negativ
         _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(a_dst), _p(c_src), float(negative_slope), n, num_edges, c, 0,
         _p(gx), _mat(gx, "gx"), _p(g_a), _p(g_c), _p(al), _p(gp),
         _p(xmax) if ties is not None else None, _mat(xmax, "xmax") if ties is not None else 0,
-        _p(ties), _mat(ties, "ties") if ties is not None else 0, _p(gx_rank1) if c <= 128 else None, _stream())
+        _p(ties), _mat(ties, "ties") if ties is not None else 0, _p(gx_rank1) if c <= 128 else None, _p(fuse_max_col), _stream())
     if gx_rank1 is not None and c > 128:         # wider than the kernels that fold it in: as its own pass
         linear(g_c.unsqueeze(1), gx_rank1.reshape(1, -1).contiguous(), transposed=True, out=gx, accumulate=True)
     _lib.check(code, "mlqem_csr_softmax_aggregate_bwd_f32")

@@ -108,7 +108,8 @@ int softmax_aggregate_bwd_launches(const float* x, int64_t ldx, const float* xne
                                    const int32_t* out_eid, const float* a_dst, const float* c_src, float negative_slope, int64_t N, int64_t E,
                                    int C, int accumulate, float* gx, int64_t ldgx, float* g_a, float* g_c, float* edge_al, float* edge_gp,
                                    const float* xmax, int64_t ldm, float* tie_count, int64_t ldt, const float* gx_rank1,
-                                   const uint8_t* skip_in, const uint8_t* skip_out, int parts, mlqem_stream_t stream);
+                                   const uint8_t* skip_in, const uint8_t* skip_out, int parts, mlqem_stream_t stream,
+                                   const float* fuse_max_col = nullptr);
 int segment_max_bwd_launches(const float* x, int64_t ldx, const float* xmax, int64_t ldm, const float* gmax, int64_t ldg, const int32_t* in_ptr,
                              const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, int64_t N, int C, float* gx, int64_t ldgx,
                              float* gshare, int64_t lds, const float* tie_count, int64_t ldt, const float* gmax_row, const float* gmax_col,

@@ -705,20 +705,37 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_any_width_ke
 // The *_any_width kernels after them are the thread-per-(row, channel) forms, kept for rows wider than 128 channels.
 
 // Source side: g_x[j,:] (+)= sum_{e: j->i} al_e gnew[i,:] (self included); g_c[j] = sum_e gp_e.
-template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
+// FUSE_MAX (round 5): the walk also carries the backward of ASAPooling's segment max over the same entries -- g_x[j, c] += sum over
+// the destinations i of j (and j itself) with x[j, c] == xmax[i, c] of g_a[i] w_comp[c] / ties[i, c] -- which was a share pass over
+// [N, C] (segment_max_share_from_counts_kernel) and a second walk that re-read g_x (segment_max_bwd_kernel): 0.28 ms of the level-0
+// backward of a 64-circuit step.  MaxFuse: x, xmax, the tie counts, g_a and w_comp.
+struct MaxFuse {
+  const float* x; int64_t ldx; const float* xmax; int64_t ldm; const float* ties; int64_t ldt; const float* g_row; const float* g_col;
+};
+template <int NV, bool FUSE_MAX> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
-    int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c, const float* __restrict__ rank1) {
+    int64_t E, int C, int accumulate, float* __restrict__ gx, int64_t ldgx, float* __restrict__ g_c, const float* __restrict__ rank1,
+    const MaxFuse mf) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   bool has[NV];
-  float acc[NV];
+  float acc[NV], xv[FUSE_MAX ? NV : 1], wc[FUSE_MAX ? NV : 1];
   const float al_self = edge_al[E + row];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     has[v] = l + v * kGroup < C;
     acc[v] = al_self * (has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f);
+    if (FUSE_MAX) {
+      const int c = l + v * kGroup;
+      xv[v] = has[v] ? mf.x[row * mf.ldx + c] : 0.f;
+      wc[v] = has[v] ? mf.g_col[c] : 0.f;
+      if (has[v] && xv[v] == mf.xmax[row * mf.ldm + c]) {          // the row itself is an entry of its own maximum
+        const float n = mf.ties[row * mf.ldt + c];
+        acc[v] += mf.g_row[row] * wc[v] / (n > 0.f ? n : 1.f);
+      }
+    }
   }
   float gc = 0.f;                                      // lane u: the gp of its edges
   const int beg = optr[row], end = optr[row + 1];
@@ -740,21 +757,63 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
         au[2] = group16_bcast<U0 + 2>(al); au[3] = group16_bcast<U0 + 3>(al); au[4] = group16_bcast<U0 + 4>(al);
         au[5] = group16_bcast<U0 + 5>(al); au[6] = group16_bcast<U0 + 6>(al); au[7] = group16_bcast<U0 + 7>(al);
       }
+      // the maximum's part rides in the two-entry form (the rows of a circuit DAG); longer rows take it four entries at a time
+      // below -- with eight rows of three matrices in flight the kernel needed 130 registers (three waves per SIMD: 520 us)
+      constexpr bool MAX_HERE = FUSE_MAX && CNT == 2;
+      float xm[MAX_HERE ? CNT : 1][MAX_HERE ? NV : 1], tc[MAX_HERE ? CNT : 1][MAX_HERE ? NV : 1], gr[MAX_HERE ? CNT : 1];
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
         const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg + l;
 #pragma unroll
         for (int v = 0; v < NV; ++v) gn[u][v] = has[v] ? gi[v * kGroup] : 0.f;
+        if (MAX_HERE) {
+          gr[u] = mf.g_row[iu[u]];
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            xm[u][v] = has[v] ? mf.xmax[(int64_t)iu[u] * mf.ldm + l + v * kGroup] : 0.f;
+            tc[u][v] = has[v] ? mf.ties[(int64_t)iu[u] * mf.ldt + l + v * kGroup] : 1.f;
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = fmaf(au[u], gn[u][v], acc[v]);
+        for (int v = 0; v < NV; ++v) {
+          acc[v] = fmaf(au[u], gn[u][v], acc[v]);
+          if (MAX_HERE) {                                  // (U0 + u < k: lanes past the end repeat the last entry)
+            if (U0 + u < k && has[v] && xv[v] == xm[u][v]) acc[v] += gr[u] * wc[v] / (tc[u][v] > 0.f ? tc[u][v] : 1.f);
+          }
+        }
+    };
+    auto max_rows = [&](auto first) {                      // four destinations' maxima, tie counts and g_a in flight
+      constexpr int U0 = decltype(first)::value;
+      const int iu[4] = {group16_bcast<U0 + 0>(i), group16_bcast<U0 + 1>(i), group16_bcast<U0 + 2>(i), group16_bcast<U0 + 3>(i)};
+      float xm[4][NV], tc[4][NV], gr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gr[u] = mf.g_row[iu[u]];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          xm[u][v] = has[v] ? mf.xmax[(int64_t)iu[u] * mf.ldm + l + v * kGroup] : 0.f;
+          tc[u][v] = has[v] ? mf.ties[(int64_t)iu[u] * mf.ldt + l + v * kGroup] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+          if (U0 + u < k && has[v] && xv[FUSE_MAX ? v : 0] == xm[u][v]) acc[v] += gr[u] * wc[FUSE_MAX ? v : 0] / (tc[u][v] > 0.f ? tc[u][v] : 1.f);
     };
     if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{});
     else {
       rows(EdgeChunk<0>{}, EdgeChunk<8>{});
       if (k > 8) rows(EdgeChunk<8>{}, EdgeChunk<8>{});
+      if (FUSE_MAX) {
+        max_rows(EdgeChunk<0>{});
+        if (k > 4) max_rows(EdgeChunk<4>{});
+        if (k > 8) max_rows(EdgeChunk<8>{});
+        if (k > 12) max_rows(EdgeChunk<12>{});
+      }
     }
   }
   gc = group16_sum(gc) + edge_gp[E + row];
@@ -1231,7 +1290,8 @@ int softmax_aggregate_bwd_launches(const float* x, int64_t ldx, const float* xne
                                    const int32_t* out_eid, const float* a_dst, const float* c_src, float negative_slope, int64_t N, int64_t E,
                                    int C, int accumulate, float* gx, int64_t ldgx, float* g_a, float* g_c, float* edge_al, float* edge_gp,
                                    const float* xmax, int64_t ldm, float* tie_count, int64_t ldt, const float* gx_rank1,
-                                   const uint8_t* skip_in, const uint8_t* skip_out, int parts, mlqem_stream_t stream) {
+                                   const uint8_t* skip_in, const uint8_t* skip_out, int parts, mlqem_stream_t stream,
+                                   const float* fuse_max_col) {
   if (N < 0 || E < 0 || C <= 0 || ldx < C || ldn < C || ldg < C || ldgx < C) return MLQEM_ERR_BAD_ARG;
   if (tie_count && (!xmax || ldm < C || ldt < C)) return MLQEM_ERR_BAD_ARG;
   if (tie_count && C > 128) return MLQEM_ERR_UNSUPPORTED;      // the any-width form does not count
@@ -1249,6 +1309,8 @@ int softmax_aggregate_bwd_launches(const float* x, int64_t ldx, const float* xne
   }
   if (gx_rank1 && C > 128) return MLQEM_ERR_UNSUPPORTED;      // the any-width source side does not add it
   if ((skip_in || skip_out) && C > 128) return MLQEM_ERR_UNSUPPORTED;
+  // the segment max's backward inside the source-side walk: the stored form only, with the tie counts of this call's destination side
+  if (fuse_max_col && (recompute || !tie_count || !xmax || C > 128)) return MLQEM_ERR_BAD_ARG;
   if (parts & 1) {
 #define MLQEM_SAB(NV)                                                                                                                          \
   do {                                                                                                                                         \
@@ -1277,8 +1339,13 @@ int softmax_aggregate_bwd_launches(const float* x, int64_t ldx, const float* xne
                          reinterpret_cast<const float4*>(edge_al), c_src, negative_slope, N, C, accumulate, gx, ldgx, g_c, gx_rank1,     \
                          skip_out);                                                                                                       \
     else                                                                                                                                 \
-      hipLaunchKernelGGL(softmax_aggregate_bwd_src_kernel<NV>, MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, out_eid, edge_al,    \
-                         edge_gp, N, E, C, accumulate, gx, ldgx, g_c, gx_rank1);                                                        \
+      if (fuse_max_col)                                                                                                                  \
+        hipLaunchKernelGGL((softmax_aggregate_bwd_src_kernel<NV, true>), MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, out_eid,   \
+                           edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c, gx_rank1,                                               \
+                           MaxFuse{x, ldx, xmax, ldm, tie_count, ldt, g_a, fuse_max_col});                                               \
+      else                                                                                                                               \
+        hipLaunchKernelGGL((softmax_aggregate_bwd_src_kernel<NV, false>), MLQEM_GRID(N * kGroup), gnew, ldg, out_ptr, out_dst, out_eid,  \
+                           edge_al, edge_gp, N, E, C, accumulate, gx, ldgx, g_c, gx_rank1, MaxFuse{});                                   \
   } while (0)
   if (C <= 16) MLQEM_SAS(1);
   else if (C <= 32) MLQEM_SAS(2);
@@ -1300,11 +1367,12 @@ extern "C" int mlqem_csr_softmax_aggregate_bwd_f32(const float* x, int64_t ldx, 
                                                    const float* c_src, float negative_slope, int64_t N, int64_t E,
                                                    int C, int accumulate, float* gx, int64_t ldgx, float* g_a,
                                                    float* g_c, float* edge_al, float* edge_gp, const float* xmax, int64_t ldm,
-                                                   float* tie_count, int64_t ldt, const float* gx_rank1, mlqem_stream_t stream) {
+                                                   float* tie_count, int64_t ldt, const float* gx_rank1, const float* fuse_max_col,
+                                                   mlqem_stream_t stream) {
   begin_launches();
   return softmax_aggregate_bwd_launches(x, ldx, xnew, ldn, gnew, ldg, in_ptr, in_src, out_ptr, out_dst, out_eid, a_dst, c_src, negative_slope,
                                         N, E, C, accumulate, gx, ldgx, g_a, g_c, edge_al, edge_gp, xmax, ldm, tie_count, ldt, gx_rank1,
-                                        nullptr, nullptr, 3, stream);
+                                        nullptr, nullptr, 3, stream, fuse_max_col);
 }
 
 static void launch_share_from_counts(const float* gmax, int64_t ldg, const float* cnt, int64_t ldc, int64_t N, int C, float* gshare,

@@ -863,6 +863,19 @@ def test_fused_pooling_forward_equals_the_chain_of_kernels_it_stands_for(d):
     tol = lambda t: 1e-5 * max(1.0, t.abs().max().item())
     assert (a_dst - a_r).abs().max().item() < tol(a_r) and (c_src - c_r).abs().max().item() < tol(c_r)
     assert (xnew[:, :d] - xnew_r[:, :d]).abs().max().item() < tol(xnew_r) and (pqr - pqr_r).abs().max().item() < tol(pqr_r)
+    # ... and the backward: the segment max's gradient carried by the source-side walk of the cluster sum's backward (fuse_max_col)
+    # against the two walks it stands for; x quantised so that maxima tie (the gradient is split evenly)
+    xq = ops.padded_copy(torch.from_numpy(rng.randint(0, 4, size=(n, d)).astype(np.float32)).to(DEV))
+    xmax_q = ops.csr_segment_max(xq, s.in_ptr, s.in_src)
+    xnew_q = ops.csr_softmax_aggregate(xq, s.in_ptr, s.in_src, a_r, c_r, 0.2)
+    gnew = ops.padded_copy(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(DEV))
+    e = s.edge_count()
+    gx_r, ga_r, gc_r, ties_r = ops.csr_softmax_aggregate_bwd(xq, xnew_q, gnew, s, e, a_r, c_r, 0.2, xmax=xmax_q, gx_rank1=att_x[0])
+    ops.csr_segment_max_bwd_(gx_r, xq, xmax_q, None, s, ties=ties_r, gmax_rank1=(ga_r, w_comp[0].contiguous()))
+    gx, ga, gc, ties = ops.csr_softmax_aggregate_bwd(xq, xnew_q, gnew, s, e, a_r, c_r, 0.2, xmax=xmax_q, gx_rank1=att_x[0],
+                                                     fuse_max_col=w_comp[0].contiguous())
+    assert torch.equal(ties[:, :d], ties_r[:, :d]) and torch.equal(ga, ga_r) and torch.equal(gc, gc_r)
+    assert (gx[:, :d] - gx_r[:, :d]).abs().max().item() < tol(gx_r[:, :d])
 
 
 def test_family_b_with_and_without_the_fused_pooling_forward(g1):
