@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 34 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 35 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -847,6 +847,11 @@ int mlqem_dense_pool_supported(int D);
  *   mlqem_dense_softmax_aggregate_bwd_f32 = mlqem_csr_softmax_aggregate_bwd_f32 in its recomputing form with tie counts (edge_al: [4 N]
  *                                           floats, 16-byte aligned); stat: what mlqem_dense_softmax_aggregate_f32 left
  *   mlqem_dense_segment_max_bwd_f32       = mlqem_csr_segment_max_bwd_f32 with tie counts and a rank-one gradient of the maximum */
+/* mlqem_leconv_fitness_bwd_f32 with the rows of the OUT structure's plan (lrows / counter / row_flag of mlqem_dense_plan_build) summed
+ * by a wave each instead of a thread. */
+int mlqem_dense_leconv_fitness_bwd_f32(const float* gfit, const float* fitness, const int32_t* in_ptr, const int32_t* out_ptr,
+                                       const int32_t* out_dst, int64_t N, const int32_t* lrows, const int32_t* counter,
+                                       const uint8_t* row_flag, int64_t max_blocks, float* gpqr, mlqem_stream_t stream);
 int mlqem_dense_segment_max_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, int64_t N, int D,
                                 const int32_t* records, const int32_t* counter, const uint8_t* row_flag, int64_t max_blocks, float* out,
                                 int64_t ldo, mlqem_stream_t stream);

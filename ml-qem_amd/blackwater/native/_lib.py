@@ -160,6 +160,7 @@ SIGNATURES = {
                                            _P, _P, _P, _L, _P, _P, _P, _L, _I, _P, _L, _P, _P]),
     "mlqem_dense_pool_supported": (_I, [_I]),
     "mlqem_dense_softmax_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _F, _L, _I, _P, _P, _P, _L, _P, _L, _P, _P]),
+    "mlqem_dense_leconv_fitness_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P]),
     "mlqem_dense_segment_max_f32": (_I, [_P, _L, _P, _P, _L, _I, _P, _P, _P, _L, _P, _L, _P]),
     "mlqem_dense_softmax_aggregate_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _F, _L, _L, _I, _P, _P, _P, _P, _L,
                                                    _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _P]),
@@ -187,7 +188,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 34   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 35   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

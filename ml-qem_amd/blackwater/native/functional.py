@@ -913,7 +913,10 @@ class _ASAPool(Function):
         # x_out = x'[perm] * f[perm]
         gxnew, gfit = ops.gather_scale_rows_bwd(g_out, x_new, fitness, slot)
         # f = sigmoid(LEConv(x')) on scalars pqr = x' W3^T + b3
-        gpqr = ops.leconv_fitness_bwd(gfit, fitness, s.in_ptr, s.out_ptr, s.out_dst)
+        if ctx.dense:        # the long rows of the coarsened graph: a wave each (the plan of the out-structure lists them)
+            gpqr = ops.dense_leconv_fitness_bwd(gfit, fitness, s.in_ptr, s.out_ptr, s.out_dst, s.dense_plan("out"))
+        else:
+            gpqr = ops.leconv_fitness_bwd(gfit, fitness, s.in_ptr, s.out_ptr, s.out_dst)
         ops.linear(gpqr, w3, transposed=True, out=gxnew, accumulate=True)
         gw3 = torch.empty_like(w3)
         gb3 = torch.empty(3, dtype=torch.float32, device=dev)

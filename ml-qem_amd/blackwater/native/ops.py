@@ -1787,6 +1787,16 @@ def dense_pool_fits(*mats) -> bool:
                and m.data_ptr() % 16 == 0 for m in mats)
 
 
+def dense_leconv_fitness_bwd(gfit, fitness, in_ptr, out_ptr, out_dst, plan_out: DensePlan):
+    """``leconv_fitness_bwd`` with the long rows of the out-structure's plan summed by a wave each."""
+    n = fitness.shape[0]
+    gpqr = torch.empty((max(n, 1), 3), dtype=torch.float32, device=fitness.device)[:n]
+    code = _lib.load().mlqem_dense_leconv_fitness_bwd_f32(_p(gfit), _p(fitness), _p(in_ptr), _p(out_ptr), _p(out_dst), n, _p(plan_out.lrows),
+                                                          _p(plan_out.counter), _p(plan_out.row_flag), plan_out.max_blocks, _p(gpqr), _stream())
+    _lib.check(code, "mlqem_dense_leconv_fitness_bwd_f32")
+    return gpqr
+
+
 def dense_segment_max(x, in_ptr, in_src, plan: DensePlan):
     """``csr_segment_max`` (the row itself included) with the plan's rows walked as dense blocks."""
     n, c = x.shape

@@ -1163,9 +1163,11 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_kernel(
 //   g_raw = g_f f (1 - f);  g_p[j] = g_raw[j] + sum_{e: j->i} g_raw[i];  g_q[i] = -(indeg_i + 1) g_raw[i];  g_r = g_raw.
 __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
     const float* __restrict__ gfit, const float* __restrict__ fitness, const int32_t* __restrict__ iptr,
-    const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, int64_t N, float* __restrict__ gpqr) {
+    const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, int64_t N, float* __restrict__ gpqr,
+    const uint8_t* __restrict__ skip) {
   const int64_t j = (int64_t)row_block() * kBlock + threadIdx.x;
   if (j >= N) return;
+  if (skip && skip[j]) return;                         // a long row: leconv_fitness_bwd_long_kernel
   auto graw = [&](int64_t i) { const float f = fitness[i]; return gfit[i] * f * (1.f - f); };
   const float gj = graw(j);
   float gp = gj;
@@ -1180,6 +1182,32 @@ __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
   gpqr[j * 3] = gp;
   gpqr[j * 3 + 1] = -(float)(iptr[j + 1] - iptr[j] + 1) * gj;
   gpqr[j * 3 + 2] = gj;
+}
+
+// The same for the LONG rows of a coarsened graph (a thread per row walked a row of 150 out-entries alone: 100 us on the level-1
+// graph of 64 100-qubit circuits): a wave per row of the OUT structure's dense-block plan (lrows: its rows of 32+ entries; row_flag:
+// those a usable block holds -- exactly the rows the kernel above skips), lanes over the entries, one wave sum.
+__global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_long_kernel(
+    const float* __restrict__ gfit, const float* __restrict__ fitness, const int32_t* __restrict__ iptr,
+    const int32_t* __restrict__ optr, const int32_t* __restrict__ odst, const int32_t* __restrict__ lrows,
+    const int32_t* __restrict__ counter, const uint8_t* __restrict__ row_flag, float* __restrict__ gpqr) {
+  const int lane = threadIdx.x & 63;
+  const int total = *counter, nwaves = gridDim.x * (kBlock / kWave);
+  auto graw = [&](int64_t i) { const float f = fitness[i]; return gfit[i] * f * (1.f - f); };
+  for (int k = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6); k < total; k += nwaves) {
+    const int j = lrows[k];
+    if (j < 0 || !row_flag[j]) continue;                 // (wave-uniform)
+    const int beg = optr[j], end = optr[j + 1];
+    float gp = 0.f;
+    for (int e = beg + lane; e < end; e += kWave) gp += graw(odst[e]);
+    for (int d = 32; d > 0; d >>= 1) gp += __shfl_xor(gp, d, 64);
+    if (lane == 0) {
+      const float gj = graw(j);
+      gpqr[(int64_t)j * 3] = gp + gj;
+      gpqr[(int64_t)j * 3 + 1] = -(float)(iptr[j + 1] - iptr[j] + 1) * gj;
+      gpqr[(int64_t)j * 3 + 2] = gj;
+    }
+  }
 }
 
 }  // namespace mlqem
@@ -1454,6 +1482,20 @@ extern "C" int mlqem_leconv_fitness_bwd_f32(const float* gfit, const float* fitn
   if (N < 0) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!gfit || !fitness || !in_ptr || !out_ptr || !gpqr) return MLQEM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(leconv_fitness_bwd_kernel, MLQEM_GRID(N), gfit, fitness, in_ptr, out_ptr, out_dst, N, gpqr);
+  hipLaunchKernelGGL(leconv_fitness_bwd_kernel, MLQEM_GRID(N), gfit, fitness, in_ptr, out_ptr, out_dst, N, gpqr, nullptr);
+  return launch_status();
+}
+
+extern "C" int mlqem_dense_leconv_fitness_bwd_f32(const float* gfit, const float* fitness, const int32_t* in_ptr, const int32_t* out_ptr,
+                                                  const int32_t* out_dst, int64_t N, const int32_t* lrows, const int32_t* counter,
+                                                  const uint8_t* row_flag, int64_t max_blocks, float* gpqr, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || max_blocks <= 0) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!gfit || !fitness || !in_ptr || !out_ptr || !out_dst || !lrows || !counter || !row_flag || !gpqr) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(leconv_fitness_bwd_kernel, MLQEM_GRID(N), gfit, fitness, in_ptr, out_ptr, out_dst, N, gpqr, row_flag);
+  const int64_t waves = max_blocks * 16;                 // an upper bound on the plan's rows
+  hipLaunchKernelGGL(leconv_fitness_bwd_long_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(waves, kBlock / kWave), 8192))),
+                     dim3(kBlock), 0, as_stream(stream), gfit, fitness, in_ptr, out_ptr, out_dst, lrows, counter, row_flag, gpqr);
   return launch_status();
 }

@@ -234,3 +234,16 @@ def test_family_b_on_100_qubit_graphs_with_dense_blocks_equals_per_edge():
     for k in g_e:
         assert (g_d[k] - g_e[k]).abs().max().item() < 2e-4 * gmax, k
 
+
+def test_fitness_backward_with_a_wave_per_long_row_equals_the_thread_per_row_kernel():
+    from blackwater.native import ops
+
+    s, _, rng = _make(77, 0.3)
+    n = s.num_nodes
+    gfit = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+    fit = torch.from_numpy(rng.rand(n).astype(np.float32)).to(DEV)
+    ref = ops.leconv_fitness_bwd(gfit, fit, s.in_ptr, s.out_ptr, s.out_dst)
+    got = ops.dense_leconv_fitness_bwd(gfit, fit, s.in_ptr, s.out_ptr, s.out_dst, s.dense_plan("out"))
+    assert torch.equal(got[:, 1:], ref[:, 1:])
+    _close(got[:, 0], ref[:, 0], "g_p")
+
