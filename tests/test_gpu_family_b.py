@@ -904,3 +904,35 @@ def test_family_b_with_and_without_the_fused_pooling_forward(g1):
     gmax = max(v.abs().max().item() for v in gb.values())
     for k in gb:
         assert (ga[k] - gb[k]).abs().max().item() < 2e-4 * gmax, k
+
+
+def test_list_coarsening_equals_the_bit_matrix_form_on_a_64_circuit_batch():
+    """Scale matters to the persistent kernels of the list coarsening (batches of 64 clusters per wave, partial last batches, several
+    batches per wave): the first pooling of 64 100-qubit circuits (363 k clusters, ~20 M coarsened edges) must give the arrays of the
+    round-3 bit-matrix form exactly.  (A variant of coarsen_unique_kernel passed every smaller comparison and failed this one.)"""
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import TfimCorpus
+    from blackwater.native import functional as F
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    h = TfimCorpus(100, list(range(1, 11)), 7, seed=42, exp_value_size=4).host_graphs()
+    arena = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"], device=DEV)
+    b = arena.batch(np.random.RandomState(0).randint(0, len(arena), size=64))
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel(22, 15, 4).to(DEV).eval()
+    res = {}
+    keep = F._ASAP_LISTS
+    try:
+        with torch.no_grad():
+            g = model.transformer1(b.nodes, b.structure)
+            for lists in (True, False):
+                F._ASAP_LISTS = lists
+                _, s, perm = model.pooling1(g, b.structure)
+                k = s.num_nodes
+                e = int(s.in_ptr[k].item())
+                res[lists] = (s.in_ptr[:k + 1].clone(), s.in_src[:e].clone(), s.out_ptr[:k + 1].clone(), s.out_dst[:e].clone(), perm.clone())
+                del s
+    finally:
+        F._ASAP_LISTS = keep
+    for a, c in zip(res[True], res[False]):
+        assert a.shape == c.shape and torch.equal(a, c)
