@@ -1004,55 +1004,69 @@ __global__ __launch_bounds__(kBlock) void coarsen_unique_kernel(const ListsArgs 
     };
     // Clusters of at most 16 candidates on either side (most of the coarsened graph's rows: median degree 3) go FOUR at a time, one
     // per 16-lane row: a 16-wide bitonic network (10 exchange steps, 7 of them quad permutes) instead of the 64-wide one (21 steps of
-    // ds_bpermute per side) that a wave ran for each of them alone -- 170 of this kernel's 410 us were those clusters.
-    const unsigned long long tiny = __ballot(mine < lim && rc.cnt_o <= 16u && rc.cnt_i <= 16u);
+    // ds_bpermute per side) that a wave ran for each of them alone -- 170 of this kernel's 410 us were those clusters.  Any four of
+    // the batch's tiny clusters share a pass (their bits of `tiny`, lowest first); the others follow one by one.
+    const unsigned long long valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+    const unsigned long long tiny = __ballot(mine < lim && rc.cnt_o <= 16u && rc.cnt_i <= 16u) & valid;
+    for (unsigned long long t = tiny; t;) {
+      int take[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        take[r] = t ? __ffsll((long long)t) - 1 : -1;
+        if (t) t &= t - 1;
+      }
+      const int row = lane >> 4, sub = lane & 15;
+      const int src = row == 0 ? take[0] : (row == 1 ? take[1] : (row == 2 ? take[2] : take[3]));
+      const bool on = src >= 0;
+      const int from = on ? src : 0;
+      // (every shuffle OUTSIDE a condition on `on`: a ds_bpermute under a divergent branch reads nothing from the lanes the branch
+      // switched off -- the first form of this pass had them inside one and emptied the clusters of rows whose source lane idled)
+      const uint32_t co = (uint32_t)__shfl((int)rc.cnt_o, from), ci = (uint32_t)__shfl((int)rc.cnt_i, from);
+      const uint32_t off_o = (uint32_t)__shfl((int)rc.off_o, from), cnt_o = on ? co : 0u;
+      const uint32_t off_i = (uint32_t)__shfl((int)rc.off_i, from), cnt_i = on ? ci : 0u;
+      const int64_t pr = first + (int64_t)from * stride;
+      const int self = (int)pr;
+      int vo = sub < (int)cnt_o ? a.tmp_o[(int64_t)off_o + sub] : -1, vi = sub < (int)cnt_i ? a.tmp_i[(int64_t)off_i + sub] : -1;
+      vo = (vo >= 0 && vo != self) ? vo : INT32_MAX;
+      vi = (vi >= 0 && vi != self) ? vi : INT32_MAX;
+#pragma unroll
+      for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+          int po2, pi2;
+          if (jj == 1) { po2 = __builtin_amdgcn_update_dpp(0, vo, 0xB1, 0xF, 0xF, true); pi2 = __builtin_amdgcn_update_dpp(0, vi, 0xB1, 0xF, 0xF, true); }
+          else if (jj == 2) { po2 = __builtin_amdgcn_update_dpp(0, vo, 0x4E, 0xF, 0xF, true); pi2 = __builtin_amdgcn_update_dpp(0, vi, 0x4E, 0xF, 0xF, true); }
+          else { po2 = __shfl_xor(vo, jj); pi2 = __shfl_xor(vi, jj); }
+          const bool take_min = ((sub & k) == 0) == ((sub & jj) == 0);
+          vo = take_min ? min(vo, po2) : max(vo, po2);
+          vi = take_min ? min(vi, pi2) : max(vi, pi2);
+        }
+      }
+      const int lo = __shfl_up(vo, 1), li = __shfl_up(vi, 1);
+      const bool ko = vo != INT32_MAX && (sub == 0 || vo != lo), ki = vi != INT32_MAX && (sub == 0 || vi != li);
+      const unsigned mo = (unsigned)(__ballot(ko) >> (16 * row)) & 0xFFFFu, mi = (unsigned)(__ballot(ki) >> (16 * row)) & 0xFFFFu;
+      const unsigned below = (1u << sub) - 1u;
+      if (ko) a.tmp_o[(int64_t)off_o + __popc(mo & below)] = vo;
+      if (ki) a.tmp_i[(int64_t)off_i + __popc(mi & below)] = vi;
+      if (on && sub == 0) {
+        a.outdeg[pr] = __popc(mo);
+        a.indeg[pr] = __popc(mi);
+      }
+    }
+    unsigned long long rest = valid & ~tiny;               // the other clusters, one per pass, the next one's candidates in flight
     UniqueMeta m0{{0u, 0u, 0u, 0u}, 0, 0};
     int qo0 = -1, qi0 = -1;
-    bool primed = false;
-    for (int j = 0; j < nb;) {
-      if (j + 4 <= nb && ((tiny >> j) & 0xFull) == 0xFull) {
-        const int row = lane >> 4, sub = lane & 15, src = j + row;
-        const uint32_t off_o = (uint32_t)__shfl((int)rc.off_o, src), cnt_o = (uint32_t)__shfl((int)rc.cnt_o, src);
-        const uint32_t off_i = (uint32_t)__shfl((int)rc.off_i, src), cnt_i = (uint32_t)__shfl((int)rc.cnt_i, src);
-        const int64_t pr = first + (int64_t)src * stride;
-        const int self = (int)pr;
-        int vo = sub < (int)cnt_o ? a.tmp_o[(int64_t)off_o + sub] : -1, vi = sub < (int)cnt_i ? a.tmp_i[(int64_t)off_i + sub] : -1;
-        vo = (vo >= 0 && vo != self) ? vo : INT32_MAX;
-        vi = (vi >= 0 && vi != self) ? vi : INT32_MAX;
-#pragma unroll
-        for (int k = 2; k <= 16; k <<= 1) {
-#pragma unroll
-          for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            int po2, pi2;
-            if (jj == 1) { po2 = __builtin_amdgcn_update_dpp(0, vo, 0xB1, 0xF, 0xF, true); pi2 = __builtin_amdgcn_update_dpp(0, vi, 0xB1, 0xF, 0xF, true); }
-            else if (jj == 2) { po2 = __builtin_amdgcn_update_dpp(0, vo, 0x4E, 0xF, 0xF, true); pi2 = __builtin_amdgcn_update_dpp(0, vi, 0x4E, 0xF, 0xF, true); }
-            else { po2 = __shfl_xor(vo, jj); pi2 = __shfl_xor(vi, jj); }
-            const bool take_min = ((sub & k) == 0) == ((sub & jj) == 0);
-            vo = take_min ? min(vo, po2) : max(vo, po2);
-            vi = take_min ? min(vi, pi2) : max(vi, pi2);
-          }
-        }
-        const int lo = __shfl_up(vo, 1), li = __shfl_up(vi, 1);
-        const bool ko = vo != INT32_MAX && (sub == 0 || vo != lo), ki = vi != INT32_MAX && (sub == 0 || vi != li);
-        const unsigned mo = (unsigned)(__ballot(ko) >> (16 * row)) & 0xFFFFu, mi = (unsigned)(__ballot(ki) >> (16 * row)) & 0xFFFFu;
-        const unsigned below = (1u << sub) - 1u;
-        if (ko) a.tmp_o[(int64_t)off_o + __popc(mo & below)] = vo;
-        if (ki) a.tmp_i[(int64_t)off_i + __popc(mi & below)] = vi;
-        if (sub == 0) {
-          a.outdeg[pr] = __popc(mo);
-          a.indeg[pr] = __popc(mi);
-        }
-        j += 4;
-        primed = false;
-        continue;
-      }
-      if (!primed) {
-        m0 = meta_of(j);
-        first_of(m0, qo0, qi0);
-      }
+    if (rest) {
+      m0 = meta_of(__ffsll((long long)rest) - 1);
+      first_of(m0, qo0, qi0);
+    }
+    while (rest) {
+      const int j = __ffsll((long long)rest) - 1;
+      rest &= rest - 1;
+      const int jn = rest ? __ffsll((long long)rest) - 1 : -1;
       const int64_t p = first + (int64_t)j * stride;
       UniqueMeta m1{{0u, 0u, 0u, 0u}, 0, 0};
-      if (j + 1 < nb) m1 = meta_of(j + 1);
+      if (jn >= 0) m1 = meta_of(jn);
       int qo1, qi1;
       first_of(m1, qo1, qi1);                           // in flight while this cluster is sorted
       const int k0 = m0.k0, Wk = m0.Wk, self = (int)p;
@@ -1124,8 +1138,6 @@ __global__ __launch_bounds__(kBlock) void coarsen_unique_kernel(const ListsArgs 
         wave_lds_only_sync();
       }
       m0 = m1; qo0 = qo1; qi0 = qi1;
-      primed = true;
-      ++j;
     }
   }
 }
