@@ -7,6 +7,8 @@
 // The score of a cell is one add of two per-node scalars; the weighted sum of the source rows is x'^T = X_U^T W on the f32 matrix
 // cores, one accumulator tile per 16 channels (rows of at most 32 channels: the reference's 30).  Rows outside the blocks stay with the
 // per-edge kernels (attn.hip, family_b_bwd.hip), which skip the rows a plan flags.
+#include <utility>
+
 #include "dense_block.hpp"
 
 namespace mlqem {
@@ -118,9 +120,9 @@ __global__ __launch_bounds__(kBlock) void dense_softmax_aggregate_kernel(const f
 
 // ------------------------------------------------------------------------------------------- segment max, its ties, its backward
 // Per-channel work over a block's cells: no matrix product.  Lane (r, g) owns channels 8 g .. 8 g + 7 of block row r (rows of exactly
-// 32 floats: 29-32 channels); a wave stages the 16 union rows of a column block in LDS -- lane (u, g) brings channels 8 g .. 8 g + 7 of
-// union row u, two 16-byte loads -- and every lane then walks the 16 rows against its row's cell bits with two ds_read_b128 each
-// (the 16 lanes of one g read the same address: a broadcast).
+// 32 floats: 29-32 channels) and, as a stager, brings the same channels of union row r of the column block (two 16-byte loads); every
+// lane then walks the 16 union rows against its row's cell bits, each row's values handed over by a DPP broadcast inside the 16-lane
+// row of its g (scan_step).
 //   kMax   out[row, c]  = max over the row's cells of A[u, c]                                  (ASAPooling's query: the segment max of x)
 //   kTies  out[row, c]  = number of the row's cells with A[u, c] == own[row, c]                (A = x, own = xmax: the ties of that max)
 //   kShare out[row, c] += sum over the row's cells with own[row, c] == A[u, c] of B[u, c]      (the OUT structure: own = x, A = xmax of the
@@ -139,13 +141,34 @@ __device__ __forceinline__ void store8(float* __restrict__ p, const float* v, in
   }
 }
 
+// One union row of the column block against the lane's row: the stager lanes of the same 16-lane row (same g) hold that union row's
+// eight channels in registers, and a DPP row broadcast hands them over -- no LDS tile (the first form staged the 16 union rows in LDS
+// and read them back with 32-64 ds_read_b128 per lane and column block: the three scans were bound by LDS bandwidth, 57 / 84 / 113 us).
+template <int MODE, int U> __device__ __forceinline__ void scan_step(const float (&a)[8], const float (&bsh)[8], const float (&mine)[8],
+                                                                     uint32_t bits, float (&acc)[8]) {
+  const bool on = bits >> U & 1u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float tv = group16_bcast<U>(a[k]);
+    if (MODE == kMax) acc[k] = fmaxf(acc[k], on ? tv : -INFINITY);
+    else if (MODE == kTies) acc[k] += (on && tv == mine[k]) ? 1.f : 0.f;
+    else {
+      const float sv = group16_bcast<U>(bsh[k]);
+      acc[k] += (on && tv == mine[k]) ? sv : 0.f;
+    }
+  }
+}
+template <int MODE, int... U> __device__ __forceinline__ void scan_steps(std::integer_sequence<int, U...>, const float (&a)[8],
+                                                                         const float (&bsh)[8], const float (&mine)[8], uint32_t bits,
+                                                                         float (&acc)[8]) {
+  (scan_step<MODE, U>(a, bsh, mine, bits, acc), ...);
+}
+
 template <int MODE> __global__ __launch_bounds__(kBlock) void dense_pool_scan_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                                     const float* __restrict__ own, int D,
                                                                                     float* __restrict__ out, const DensePlan p) {
   constexpr int LD = 32;                                   // every matrix here: rows of 32 floats
-  constexpr int NT = MODE == kShare ? 2 : 1;
   __shared__ __attribute__((aligned(16))) int lds[kDbLdsInts];
-  __shared__ __attribute__((aligned(16))) float tile[kDbWaves][NT][kDbRows * LD];
   __shared__ __attribute__((aligned(16))) float red[kDbWaves][kWave][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int nblocks = *p.counter / kDbRows;
@@ -157,7 +180,7 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void dense_pool_scan_ke
     const bool valid = r < nrows;
     const int row = valid ? rec[kDbRowsOff + r] : rec[kDbRowsOff];
     const int selfs = valid ? rec[kDbSelfOff + r] : -1;
-    float mine[8], acc[8];
+    float mine[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc[8];
     if (MODE != kMax) {
       const f4a o0 = *reinterpret_cast<const f4a*>(own + (int64_t)row * LD + 8 * g), o1 = *reinterpret_cast<const f4a*>(own + (int64_t)row * LD + 8 * g + 4);
       mine[0] = o0.x; mine[1] = o0.y; mine[2] = o0.z; mine[3] = o0.w; mine[4] = o1.x; mine[5] = o1.y; mine[6] = o1.z; mine[7] = o1.w;
@@ -166,49 +189,28 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void dense_pool_scan_ke
     for (int k = 0; k < 8; ++k) acc[k] = MODE == kMax ? -INFINITY : 0.f;
     const BlockLds l = block_stage(rec, lds);
     const uint32_t* maskrow = l.mask + r * kDbMaskWords;
-    // the union rows of the wave's NEXT column block are in flight while this one is walked
-    f4a a0, a1, b0, b1;
+    // as a stager the lane is (union row r of the column block, channels 8 g .. 8 g + 7); the rows of the wave's NEXT column block are
+    // in flight while this one is walked
+    f4a n0, n1, m0, m1;
     auto fetch = [&](int cb) {
-      const int uid = l.uni[16 * cb + r];                  // (as a stager the lane is (union row r, channels 8 g ..))
-      a0 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g);
-      a1 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g + 4);
+      const int uid = l.uni[16 * cb + r];
+      n0 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g);
+      n1 = *reinterpret_cast<const f4a*>(A + (int64_t)uid * LD + 8 * g + 4);
       if (MODE == kShare) {
-        b0 = *reinterpret_cast<const f4a*>(B + (int64_t)uid * LD + 8 * g);
-        b1 = *reinterpret_cast<const f4a*>(B + (int64_t)uid * LD + 8 * g + 4);
+        m0 = *reinterpret_cast<const f4a*>(B + (int64_t)uid * LD + 8 * g);
+        m1 = *reinterpret_cast<const f4a*>(B + (int64_t)uid * LD + 8 * g + 4);
       }
     };
     if (wave < ncb) fetch(wave);
     for (int cb = wave; cb < ncb; cb += kDbWaves) {
-      wave_sync();                                         // the previous column block's reads are done
-      *reinterpret_cast<f4a*>(&tile[wave][0][r * LD + 8 * g]) = a0;
-      *reinterpret_cast<f4a*>(&tile[wave][0][r * LD + 8 * g + 4]) = a1;
-      if (MODE == kShare) {
-        *reinterpret_cast<f4a*>(&tile[wave][NT - 1][r * LD + 8 * g]) = b0;
-        *reinterpret_cast<f4a*>(&tile[wave][NT - 1][r * LD + 8 * g + 4]) = b1;
-      }
-      wave_sync();
+      const float a[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+      float bsh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (MODE == kShare) { bsh[0] = m0.x; bsh[1] = m0.y; bsh[2] = m0.z; bsh[3] = m0.w; bsh[4] = m1.x; bsh[5] = m1.y; bsh[6] = m1.z; bsh[7] = m1.w; }
       if (cb + kDbWaves < ncb) fetch(cb + kDbWaves);
       uint32_t bits = (maskrow[cb >> 1] >> ((cb & 1) * 16)) & 0xFFFFu;       // the row's cells of this column block
       const int d = selfs - 16 * cb;
       if ((unsigned)d < 16u) bits |= 1u << d;              // the row itself: always an entry here
-#pragma unroll 4
-      for (int u = 0; u < 16; ++u) {
-        const f4a t0 = *reinterpret_cast<const f4a*>(&tile[wave][0][u * LD + 8 * g]), t1 = *reinterpret_cast<const f4a*>(&tile[wave][0][u * LD + 8 * g + 4]);
-        const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        const bool on = bits >> u & 1u;
-        if (MODE == kMax) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], on ? tv[k] : -INFINITY);
-        } else if (MODE == kTies) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) acc[k] += (on && tv[k] == mine[k]) ? 1.f : 0.f;
-        } else {
-          const f4a s0 = *reinterpret_cast<const f4a*>(&tile[wave][NT - 1][u * LD + 8 * g]), s1 = *reinterpret_cast<const f4a*>(&tile[wave][NT - 1][u * LD + 8 * g + 4]);
-          const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-          for (int k = 0; k < 8; ++k) acc[k] += (on && tv[k] == mine[k]) ? sv[k] : 0.f;
-        }
-      }
+      scan_steps<MODE>(std::make_integer_sequence<int, 16>{}, a, bsh, mine, bits, acc);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[wave][lane][k] = acc[k];
