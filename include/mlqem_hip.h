@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 35 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 36 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -106,7 +106,8 @@ int mlqem_csr_aggregate_f32(const float* x, int64_t ldx, const int32_t* ptr, con
  * and T = ceil(N / R) tiles, first T 16-byte records int32 (graph of the tile's first row, that graph's first row, the next
  * graph's first row, 0), then T x 32 uint64 words: the items (row, 16-byte column slice) of a tile are numbered row-major,
  * item i = 256 k + 64 w + l sets bit l of word (4 k + w) 4 + v of its tile iff out[row, 4 slice + v] > 0 (per-wave ballots: ABI
- * 25; a byte per item until 24).  With gate_bits `out` may be NULL -- a pooled activation whose only other reader is that gate
+ * 25; a byte per item until 24); then, for C <= 16 (ABI 36), ceil(N / 2) uint32 words holding the same signs PER NODE, 16 bits each:
+ * bit 4 slice + v of node i = out[i, 4 slice + v] > 0 -- what mlqem_pooled_grad_aggregate_f32 gathers.  With gate_bits `out` may be NULL -- a pooled activation whose only other reader is that gate
  * (the last hidden layer of a Family A branch) is then never written to memory.  workspace:
  * mlqem_csr_aggregate_pool_workspace_bytes(N, B, C). */
 size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C);
@@ -418,6 +419,29 @@ int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const floa
                                const float* weights, const int32_t* graph_ptr, int64_t N, int64_t B, int C,
                                const float* gate, int64_t ldgate, float gate_scale, const uint8_t* gate_bits, float* gx,
                                int64_t ldgx, mlqem_stream_t stream);
+
+/* mlqem_segment_pool_bwd_f32(gate_bits=) followed by mlqem_csr_aggregate_f32 of its result over the transposed structure, in ONE
+ * launch that never gathers the [N, C] gradient: the first backward aggregation of a Family A branch (01_ngem.ipynb cell [9]; the
+ * reference's autograd through global_mean_pool and the branch's last conv).  A source's row is computed from what defines it -- the
+ * 16 gate bits the pooled forward left for the node, its pool weight t_j = weights[j], the aggregation's column scale cscale[j], and the two
+ * gradient rows of the row's own graph (edges stay inside a graph):
+ *     g[j, :]   = gate(j, :) ? ((g_mean[b, :] + t_j g_wmean[b, :]) / n_b) * gate_scale : 0
+ *     out[i, :] = alpha * (rscale[i] * sum_e cscale[idx[e]] * g[idx[e], :] + dself[i] * g[i, :])
+ * Both are written (g, optional, for the dense consumers: weight and bias gradients); results equal the two-launch form bit for bit.
+ * mlqem_pooled_grad_colsum_f32: sum_j g[j, :] without g -- partial[mlqem_pooled_grad_colsum_groups()][round_up(C, 4)], added over the
+ * groups by the caller (the bias gradient of a layer whose aggregation did not write g).
+ * gate_bits: the buffer mlqem_csr_aggregate_pool_f32 filled for the same N and C.  Needs C <= 16 (mlqem_pooled_grad_aggregate_supported),
+ * the ELL side table of (ptr, idx), and 16-byte rows everywhere (ld % 4 == 0, ld >= round_up(C, 4)). */
+int mlqem_pooled_grad_aggregate_supported(int C);
+int mlqem_pooled_grad_colsum_groups(void);
+int mlqem_pooled_grad_colsum_f32(const uint8_t* gate_bits, const float* weights, const float* g_mean, int64_t ld_gmean, const float* g_wmean,
+                                 int64_t ld_gwmean, const int32_t* graph_ptr, int64_t B, float gate_scale, int64_t N, int C, float* partial,
+                                 mlqem_stream_t stream);
+int mlqem_pooled_grad_aggregate_f32(const uint8_t* gate_bits, const float* weights, const float* cscale, const float* g_mean, int64_t ld_gmean,
+                                    const float* g_wmean, int64_t ld_gwmean, const int32_t* graph_ptr, int64_t B, float gate_scale,
+                                    const int32_t* ptr, const int32_t* idx, const int32_t* ell, const float* rscale,
+                                    const float* dself, float alpha, float* out, int64_t ldo, float* g, int64_t ldg, int64_t N, int C,
+                                    mlqem_stream_t stream);
 
 /* What remains of a branch's last conv once it is folded into its pool: out[b, col[t]] (+)= P_t[b, :] . W_t (+ bias[col]),
  * t < n_terms (Family A: GCN one term, Cheb and SAGE two each -> three columns), and its backward:

@@ -97,6 +97,10 @@ SIGNATURES = {
     "mlqem_pooled_head_bwd_f32": (_I, [_P, _P, _L, _L, _I, _P, _P, _P, _P, _P]),
     "mlqem_segment_pool_workspace_bytes": (_S, [_L, _L, _I]),
     "mlqem_segment_pool_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P, _L, _P, _L, _P, _S, _P]),
+    "mlqem_pooled_grad_aggregate_supported": (_I, [_I]),
+    "mlqem_pooled_grad_colsum_groups": (_I, []),
+    "mlqem_pooled_grad_colsum_f32": (_I, [_P, _P, _P, _L, _P, _L, _P, _L, _F, _L, _I, _P, _P]),
+    "mlqem_pooled_grad_aggregate_f32": (_I, [_P, _P, _P, _P, _L, _P, _L, _P, _L, _F, _P, _P, _P, _P, _P, _F, _P, _L, _P, _L, _L, _I, _P]),
     "mlqem_segment_pool_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _L, _F, _P, _P, _L, _P]),
     "mlqem_transformer_attention_f32": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
     "mlqem_csr_softmax_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _F, _L, _I, _P, _L, _P]),
@@ -188,7 +192,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 35   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 36   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

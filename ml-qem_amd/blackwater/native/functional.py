@@ -336,6 +336,10 @@ def _mask_grad(g, y, drop_p):
     return ops.relu_dropout_bwd(g, y, 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0)
 
 
+# MLQEM_POOLED_GRAD=0: the pooled gradient of a Family A branch written out by ops.segment_pool_bwd and gathered by the transposed
+# aggregation (A/B).  Default: computed inside that aggregation (ops.PooledGrad, csrc/pooled_grad.hip).
+_POOLED_GRAD = os.environ.get("MLQEM_POOLED_GRAD", "1") != "0"
+
 _PARTS_MAX_COLS = 64   # mlqem_linear_parts_f32 keeps the weight fragments of I <= 64 concatenated columns in registers
 
 
@@ -417,11 +421,17 @@ class _ChebLayer(Function):
         k, s, (o, ow) = ctx.k, ctx.struct, ctx.dims
         x, y, *ws = ctx.saved_tensors
         n, i = x.shape
-        g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
         lap_t = dict(ell=s.out_ell, cscale=s.derived("cheb_neg"), rscale=s.cheb_dinv)
-        gs = [g]
-        if k >= 2:
-            gs.append(ops.csr_aggregate(g, s.out_ptr, s.out_dst, **lap_t))
+        if isinstance(g, ops.PooledGrad) and k >= 2 and y is None:      # the pooled gradient, computed inside its first aggregation
+            g1, g = g.aggregate(s.out_ptr, s.out_dst, s.out_ell, s.derived("cheb_neg"), rscale=s.cheb_dinv)
+            gs = [g, g1]
+        else:
+            if isinstance(g, ops.PooledGrad):
+                g = g.materialise()
+            g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
+            gs = [g]
+            if k >= 2:
+                gs.append(ops.csr_aggregate(g, s.out_ptr, s.out_dst, **lap_t))
         if k == 3:
             gs.append(ops.csr_aggregate(gs[1], s.out_ptr, s.out_dst, alpha=2.0, **lap_t))
         if blocks_only:     # the caller runs ONE weight-gradient pass over x for several layers (see cheb_grads_from_blocks)
@@ -528,8 +538,13 @@ class _SAGELayer(Function):
         x, wl, wr, y = ctx.saved_tensors
         s, (o, ow) = ctx.struct, ctx.dims
         n, i = x.shape
-        g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
-        gp = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.sage_rinv, dself=s.derived("sage_dself"))
+        if isinstance(g, ops.PooledGrad) and y is None:
+            gp, g = g.aggregate(s.out_ptr, s.out_dst, s.out_ell, s.sage_rinv, dself=s.derived("sage_dself"))
+        else:
+            if isinstance(g, ops.PooledGrad):
+                g = g.materialise()
+            g = _padded_rows(_mask_grad(g, y, ctx.drop_p))
+            gp = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.sage_rinv, dself=s.derived("sage_dself"))
         if blocks_only:
             return [gp, g]
         gw = torch.empty((2 * ow, i), dtype=torch.float32, device=x.device)
@@ -568,9 +583,23 @@ class _GCNLayer(Function):
     def backward(ctx, g, blocks_only=False):
         x, w, y = ctx.saved_tensors
         s = ctx.struct
-        g = _mask_grad(g, y, ctx.drop_p)
-        gh = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.gcn_dinv, rscale=s.gcn_dinv,
-                               dself=s.derived("gcn_dself"))
+        fused = (not blocks_only and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.x_gate_scale is not None
+                 and max(w.shape) <= 12)
+        if isinstance(g, ops.PooledGrad) and y is None:
+            # the fused backward below reads g only for the bias gradient: its column sums come from the bits, g is never written
+            pooled = g
+            gh, g = pooled.aggregate(s.out_ptr, s.out_dst, s.out_ell, s.gcn_dinv, rscale=s.gcn_dinv, dself=s.derived("gcn_dself"), want_g=not fused)
+            if fused and ops._fused_bwd_ok(gh, x):
+                gx, gw, _, ctx.gx_colsum = ops.linear_bwd_fused(gh, x, w.contiguous(), gate_scale=ctx.x_gate_scale)
+                return gx, gw, pooled.colsum(), None, None, None, None, None, None
+            if g is None:
+                g = pooled.materialise()
+        else:
+            if isinstance(g, ops.PooledGrad):
+                g = g.materialise()
+            g = _mask_grad(g, y, ctx.drop_p)
+            gh = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=s.gcn_dinv, rscale=s.gcn_dinv,
+                                   dself=s.derived("gcn_dself"))
         if blocks_only:
             return [gh, _padded_rows(g)]
         if (ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.x_gate_scale is not None
@@ -1099,10 +1128,19 @@ class _FamilyAGraph(Function):
         (ggw, gcm, gcw, gsw, gsm), gw5, gb3 = ops.pooled_head_bwd(ctx.head[0], ctx.head[1], g)
         g3wg, c2w0g, c2w1g, s2lg, s2rg = gw5[0:1], gw5[1:2], gw5[2:3], gw5[3:4], gw5[4:5]
         g3bg, c2bg, s2bg = gb3[0:1], gb3[1:2], gb3[2:3]
+        c_ = ggw.shape[1]
+        synth = _POOLED_GRAD and ops.pooled_grad_supported(c_) and struct.out_ell is not None      # per branch: its gate bits exist
         for st in side:
             st.wait_stream(main)
         # GCN branch, last layer first: pooled = wmean(h) W^T + b
-        t = ops.segment_pool_bwd(None, ggw, gptr, n, weights=struct.colsum("gcn"), gate=hg if bg_ is None else None, gate_scale=k1, gate_bits=bg_)
+
+        def pooled_grad(gm, gw, kind, gate, scale, bits):
+            if synth and bits is not None:
+                return ops.PooledGrad(gm, gw, gptr, n, struct.colsum(kind), scale, bits)
+            return ops.segment_pool_bwd(gm, gw, gptr, n, weights=struct.colsum(kind), gate=gate if bits is None else None, gate_scale=scale,
+                                        gate_bits=bits)
+
+        t = pooled_grad(None, ggw, "gcn", hg, k1, bg_)
         t, g2w, g2b = _GCNLayer.backward(L["g2"], t)[:3]
         # conv1's bias gradient is the column sum of the gradient conv2's backward just wrote: taken there, the first-layer
         # weight-gradient pass below reads six blocks instead of seven
@@ -1113,14 +1151,14 @@ class _FamilyAGraph(Function):
         else:
             _, g1w, g1b = _GCNLayer.backward(L["g1"], t)[:3]
         with torch.cuda.stream(side[0]):
-            t = ops.segment_pool_bwd(gcm, gcw, gptr, n, weights=struct.colsum("cheb"), gate=hc if bc_ is None else None, gate_scale=k2, gate_bits=bc_)
+            t = pooled_grad(gcm, gcw, "cheb", hc, k2, bc_)
             if fuse:
                 bc = _ChebLayer.backward(L["c1"], t, blocks_only=True)       # [g, g_b1, g_c2]
             else:
                 r = _ChebLayer.backward(L["c1"], t)
                 c1b, c1w0, c1w1, c1w2 = r[1], r[8], r[9], r[10]
         with torch.cuda.stream(side[1]):
-            t = ops.segment_pool_bwd(gsm, gsw, gptr, n, weights=struct.colsum("sage"), gate=hs if bs_ is None else None, gate_scale=k2, gate_bits=bs_)
+            t = pooled_grad(gsm, gsw, "sage", hs, k2, bs_)
             if fuse:
                 bs = _SAGELayer.backward(L["s1"], t, blocks_only=True)       # [g_p, g]
             else:

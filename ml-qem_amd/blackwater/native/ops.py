@@ -1034,7 +1034,7 @@ def pool_gate_unpack(bits, n, c):
     rows = max(1, 512 // cv)
     tiles = (max(n, 1) + rows - 1) // rows
     raw = bits.cpu().numpy()
-    words = raw[16 * tiles:].view(np.uint64).reshape(tiles, 2, 4, 4)              # [tile][k][wave][v]
+    words = raw[16 * tiles:16 * tiles + 256 * tiles].view(np.uint64).reshape(tiles, 2, 4, 4)              # [tile][k][wave][v]
     item = np.arange(n * cv, dtype=np.int64)
     tile, local = item // (rows * cv), item % (rows * cv)
     k, wave, lane = local >> 8, (local >> 6) & 3, (local & 63).astype(np.uint64)
@@ -1042,6 +1042,18 @@ def pool_gate_unpack(bits, n, c):
     for v in range(4):
         out |= ((words[tile, k, wave, v] >> lane) & np.uint64(1)).astype(np.int32) << v
     return out.reshape(n, cv)
+
+
+def pool_node_gates(bits, n, c):
+    """[n, ceil(c / 4)] int32 like ``pool_gate_unpack``, decoded from the per-node section of the gate buffer (c <= 16: 16 bits a node
+    after the tile records and the ballots; what ``PooledGrad.aggregate`` gathers)."""
+    import numpy as np
+
+    cv = (c + 3) // 4
+    rows = max(1, 512 // cv)
+    tiles = (max(n, 1) + rows - 1) // rows
+    per = bits.cpu().numpy()[(16 + 256) * tiles:].view(np.uint16)[:n].astype(np.int32)
+    return np.stack([(per >> (4 * sl)) & 15 for sl in range(cv)], axis=1)
 
 
 def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=None, gate_scale=1.0, out=None, gate_bits=None):
@@ -1080,6 +1092,77 @@ def segment_pool_bwd(g_mean, g_wmean, graph_ptr, num_nodes, weights=None, gate=N
                                                   gp, gld, float(gate_scale), _p(gate_bits), _p(gx), _mat(gx, "gx"), _stream())
     _lib.check(code, "mlqem_segment_pool_bwd_f32")
     return gx
+
+
+def pooled_grad_supported(c):
+    """Does ``pooled_grad_aggregate`` serve rows of ``c`` channels (the per-node gate of the pooled forward: c <= 16)?"""
+    return bool(_lib.load().mlqem_pooled_grad_aggregate_supported(int(c)))
+
+
+class PooledGrad:
+    """The gradient of a Family A branch's last hidden activation, NOT written out: what ``segment_pool_bwd(gate_bits=)`` would
+    compute it from.  A conv layer's backward hands it to ``aggregate`` -- its first transposed aggregation, which computes every
+    source row from (gate bits, pool weight, the graph's two gradient rows) instead of gathering it, and leaves the matrix itself
+    for the layer's dense consumers (csrc/pooled_grad.hip)."""
+
+    def __init__(self, g_mean, g_wmean, graph_ptr, num_nodes, weights, gate_scale, gate_bits):
+        self.g_mean, self.g_wmean, self.graph_ptr, self.num_nodes = g_mean, g_wmean, graph_ptr, num_nodes
+        self.weights, self.gate_scale, self.gate_bits = weights, gate_scale, gate_bits
+
+    def materialise(self):
+        return segment_pool_bwd(self.g_mean, self.g_wmean, self.graph_ptr, self.num_nodes, weights=self.weights,
+                                gate_scale=self.gate_scale, gate_bits=self.gate_bits)
+
+    def _operands(self):
+        ref = self.g_wmean if self.g_wmean is not None else self.g_mean
+        b, c = ref.shape
+        n = self.num_nodes
+
+        def padded(t):
+            if t is None:
+                return None
+            ok = t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and \
+                t.stride(0) >= (c + 3) // 4 * 4 and t.data_ptr() % 16 == 0
+            return t if ok else padded_copy(t)
+
+        gm, gw = padded(self.g_mean), padded(self.g_wmean)
+        _vec(self.graph_ptr, "graph_ptr", b + 1, torch.int32)
+        _vec(self.weights, "weights", n)
+        want = _lib.load().mlqem_csr_aggregate_pool_gate_bytes(n, c)
+        bits = self.gate_bits
+        if bits.dtype != torch.uint8 or not bits.is_cuda or bits.numel() != want or not bits.is_contiguous():
+            raise ValueError(f"PooledGrad: gate_bits must be the {want}-byte buffer the pooled aggregation left")
+        ld = lambda t: 0 if t is None else (int(t.stride(0)) if b > 1 else (c + 3) // 4 * 4)
+        return ref, b, c, n, gm, ld(gm), gw, ld(gw)
+
+    def colsum(self):
+        """sum_j g[j, :] -> [C], from the same operands (six bytes a node): the bias gradient of a layer whose ``aggregate`` did not
+        write g."""
+        ref, b, c, n, gm, ldm, gw, ldw = self._operands()
+        lib = _lib.load()
+        part = torch.empty((lib.mlqem_pooled_grad_colsum_groups(), (c + 3) // 4 * 4), dtype=torch.float32, device=ref.device)
+        code = lib.mlqem_pooled_grad_colsum_f32(_p(self.gate_bits), _p(self.weights), _p(gm), ldm, _p(gw), ldw, _p(self.graph_ptr), b,
+                                                float(self.gate_scale), n, c, _p(part), _stream())
+        _lib.check(code, "mlqem_pooled_grad_colsum_f32")
+        return part.sum(0)[:c]
+
+    def aggregate(self, ptr, idx, ell, cscale, rscale=None, dself=None, alpha=1.0, want_g=True):
+        """(alpha (rscale * sum_e cscale[idx[e]] g[idx[e]] + dself g), g or None)."""
+        ref, b, c, n, gm, ldm, gw, ldw = self._operands()
+        _vec(ptr, "ptr", n + 1, torch.int32)
+        _vec(idx, "idx", 0, torch.int32)
+        _ell(ell, n)
+        for nm, v in (("cscale", cscale), ("rscale", rscale), ("dself", dself)):
+            _vec(v, nm, n)
+        if cscale is None:
+            raise ValueError("PooledGrad.aggregate: cscale is required")
+        out, g = padded_empty(n, c, ref.device), (padded_empty(n, c, ref.device) if want_g else None)
+        code = _lib.load().mlqem_pooled_grad_aggregate_f32(_p(self.gate_bits), _p(self.weights), _p(cscale), _p(gm), ldm, _p(gw), ldw, _p(self.graph_ptr), b,
+                                                           float(self.gate_scale), _p(ptr), _p(idx), _p(ell), _p(rscale), _p(dself),
+                                                           float(alpha), _p(out), _mat(out, "out"), _p(g), _mat(g, "g") if want_g else 0,
+                                                           n, c, _stream())
+        _lib.check(code, "mlqem_pooled_grad_aggregate_f32")
+        return out, g
 
 
 def segment_mean(x, graph_ptr, num_graphs):

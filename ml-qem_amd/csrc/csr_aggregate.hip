@@ -52,6 +52,9 @@ struct PoolFuse {
                              // (24 us of a 381 us launch); the ballots go through LDS and leave as ONE 256-byte store per tile
   int4* tile_info;           // with mask: [tiles] (graph of the tile's first row, that graph's first row, the next graph's, 0) for
                              // the backward pass that reads the ballots (pool.hip pool_bwd_tiles_kernel)
+  unsigned* node_gate;       // optional (CV <= 4), [ceil(N / 2)] words: the same sign bits PER NODE, 16 bits each -- bit 4 slice + v of
+                             // node i = out[i, 4 slice + v] > 0.  A gather can read a SOURCE's gate (2 bytes) where the ballots only
+                             // serve a launch that walks the tiles themselves (pooled_grad.hip)
 };
 
 // graph of the first row of every tile of `rows` rows: one binary search per tile, outside the kernel that needs it (inside,
@@ -89,7 +92,7 @@ template <int VEC, bool IS_MAX, bool EPI = true, bool POOL = false>
 __device__ __forceinline__ unsigned finish_row(const AggArgs& a, int64_t row, int ch, const float (&acc)[VEC],
                                            const float (&self)[VEC], float rs, float ds, const float* s_bias,
                                            float* s_tile = nullptr, int64_t r0 = 0, const float* zpre = nullptr,
-                                           unsigned long long* s_mask = nullptr, int item = 0) {
+                                           unsigned long long* s_mask = nullptr, int item = 0, unsigned* s_gate = nullptr) {
   float res[VEC];
   if (IS_MAX) {
 #pragma unroll
@@ -134,6 +137,7 @@ __device__ __forceinline__ unsigned finish_row(const AggArgs& a, int64_t row, in
     unsigned long long* w = s_mask + ((item >> 8) * 4 + ((item >> 6) & 3)) * VEC;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) if (res[v] > 0.f) atomicOr(w + v, 1ull << (item & 63));
+    if (s_gate && signs) atomicOr(s_gate + ((int)(row - r0) >> 1), signs << ((((int)(row - r0) & 1) << 4) + ch));      // ch = 4 slice
   }
   if (POOL) {               // the workgroup's tile of the output, row-major, for the pooled partial sums at the end of the kernel
     float* t = s_tile + (int)(row - r0) * (a.CV * VEC) + ch;
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   __shared__ float s_wts[POOL ? kBlock * kItemsPerThread : 1];               // ... the rows' pooling weights
   __shared__ int s_done;                                                     // ... tickets of the waves that are done
   __shared__ unsigned long long s_mask[POOL ? kPoolMaskWords : 1];           // ... the sign bits of its items (PoolFuse::mask)
+  __shared__ unsigned s_gate[POOL ? kBlock : 1];                             // ... and per node (PoolFuse::node_gate): two rows a word
   static_assert(!POOL || (kItemsPerThread == 2 && VEC == 4 && kBlock == 256), "the ballot layout of the pooled form");
   if (EPI) stage_bias(a, s_bias, a.CV * VEC);
   const unsigned blk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -324,6 +329,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
   if constexpr (POOL) {
     if (tid == 0) s_done = 0;
     if (tid < kPoolMaskWords) s_mask[tid] = 0ull;
+    s_gate[tid] = 0u;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kItemsPerThread; ++k) {
@@ -422,6 +428,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
           if ((tid & 63) == 0 && b) atomicOr(&s_mask[(k * 4 + wv) * VEC + v], b);
         }
     }
+    if (pf.node_gate) {
+#pragma unroll
+      for (int k = 0; k < kItemsPerThread; ++k) {
+        const int lr = row[k] - (int)r0;
+        if (sign_bits[k]) atomicOr(&s_gate[lr >> 1], sign_bits[k] << (((lr & 1) << 4) + ch[k]));
+      }
+    }
   }
   // Hub rows (barrier nodes: one in-edge per qubit), one at a time, by the WAVE that owns the row's slice-0 item: its 64
   // lanes split the row's edges (a lane = one edge slot x one channel slice), then the slots are added up by a shuffle
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
             if (IS_MAX) part[v] = fmaxf(part[v], sf[v]);
           }
           finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, part, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, (POOL && pf.mask) ? s_mask : nullptr,
-                                             (int)(r - r0) * a.CV + hch / VEC);
+                                             (int)(r - r0) * a.CV + hch / VEC, (POOL && pf.node_gate) ? s_gate : nullptr);
         }
       } else {   // more slices than lanes: every lane walks all edges for its slices
         for (int sl = lane; sl < a.CV; sl += kWave) {
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
             for (int v = 0; v < VEC; ++v) tot[v] = IS_MAX ? fmaxf(tot[v], q[v]) : fmaf(w, q[v], tot[v]);
           }
           finish_row<VEC, IS_MAX, EPI, POOL>(a, r, hch, tot, sf, rs_r, ds_r, s_bias, s_tile, r0, nullptr, (POOL && pf.mask) ? s_mask : nullptr,
-                                             (int)(r - r0) * a.CV + hch / VEC);
+                                             (int)(r - r0) * a.CV + hch / VEC, (POOL && pf.node_gate) ? s_gate : nullptr);
         }
       }
     }
@@ -523,6 +536,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     if (!last) return;
     __threadfence_block();
     if (pf.mask && lane < kPoolMaskWords) pf.mask[(int64_t)blk * kPoolMaskWords + lane] = s_mask[lane];
+    if (pf.node_gate)         // R is even: a tile's rows start at a word
+      for (int i = lane; i < (nrows + 1) / 2; i += kWave) pf.node_gate[(r0 >> 1) + i] = s_gate[i];
     // lane = slice * groups + group: a lane adds every groups-th row of its 16-byte channel slice, then the groups of a slice
     // (consecutive lanes) are added by a fixed shuffle tree
     const int cvv = a.CV * VEC;
@@ -623,7 +638,7 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
     grid = dim3((unsigned)eblocks);
   }
   const bool epi = !IS_MAX && (a.z || a.bias || a.act || a.drop_p > 0.f);
-  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+  const PoolFuse no_pool{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (pool) {     // the pooled form exists for the shape the models launch it with: ELL side table, 16-byte rows, an epilogue
     if (IS_MAX || !a.ell || vec != 4 || ipt != 2 || a.CV * 4 > kWave) return MLQEM_ERR_UNSUPPORTED;      // C <= 64: one wave holds a row of the tile
     if (rows_per_tile) *rows_per_tile = a.R;
@@ -716,8 +731,10 @@ int launch_aggregate_with_pool(const float* x, int64_t ldx, const int32_t* ptr, 
   // gate_bits: [tiles] 16-byte tile records, then [tiles][kPoolMaskWords] ballot words (mlqem_csr_aggregate_pool_gate_bytes)
   const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), (int64_t)aggregate_pool_rows_per_tile(C));
   int4* info = reinterpret_cast<int4*>(gate_bits);
-  const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph, gate_bits ? reinterpret_cast<unsigned long long*>(info + tiles) : nullptr,
-                    info};
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(info + tiles);
+  const bool per_node = gate_bits && (C + 3) / 4 <= 4 && aggregate_pool_rows_per_tile(C) % 2 == 0;
+  const PoolFuse pf{pool_weights, graph_ptr, B, partial, tile_graph, gate_bits ? words : nullptr, info,
+                    per_node ? reinterpret_cast<unsigned*>(words + tiles * kPoolMaskWords) : nullptr};
   return launch_aggregate<false>(a, stream, &pf, rows_per_tile);
 }
 

@@ -394,7 +394,9 @@ int aggregate_pool_mask_words();
 extern "C" size_t mlqem_csr_aggregate_pool_gate_bytes(int64_t N, int C) {
   if (N < 0 || C <= 0) return 0;
   const int64_t tiles = ceil_div(std::max<int64_t>(N, 1), aggregate_pool_rows_per_tile(C));
-  return (size_t)tiles * (sizeof(int4) + (size_t)aggregate_pool_mask_words() * sizeof(unsigned long long));
+  // ... and, for rows of at most four 16-byte slices, the same bits per node (16 each; csr_aggregate.hip PoolFuse::node_gate)
+  const size_t per_node = (C + 3) / 4 <= 4 ? ((size_t)(N + 1) / 2 * 4 + 15) / 16 * 16 : 0;
+  return (size_t)tiles * (sizeof(int4) + (size_t)aggregate_pool_mask_words() * sizeof(unsigned long long)) + per_node;
 }
 
 extern "C" size_t mlqem_csr_aggregate_pool_workspace_bytes(int64_t N, int64_t B, int C) {

@@ -115,3 +115,38 @@ def test_train_mode_dropout_runs_and_is_seeded(g1):
         outs.append(out.detach().clone())
     assert torch.equal(outs[0], outs[1])
     assert not torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("hidden", [10, 16])
+def test_pooled_gradient_computed_in_its_aggregation_equals_the_written_one(g1, hidden, monkeypatch):
+    """native/functional.py _POOLED_GRAD: the gradient of every branch's last hidden activation computed inside its first transposed
+    aggregation (ops.PooledGrad, csrc/pooled_grad.hip) instead of written by ops.segment_pool_bwd and gathered: same arithmetic in
+    the same order, so every parameter gradient is bit-equal -- but the bias of the GCN branch's second conv, whose gradient is a
+    column sum taken from the gate bits in another order (the gradient matrix is not written at all there).  Train mode (dropout
+    gates in the bits), batch of 64 graphs."""
+    from blackwater.native import functional as F, ops
+
+    model, _ = _models(seed=5, hidden=hidden)
+    batch = g1_batch(g1, range(10, 74))
+    args = [batch[k].to(DEV) for k in ARGS]
+    calls = []
+    real = ops.PooledGrad.aggregate
+    monkeypatch.setattr(ops.PooledGrad, "aggregate", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+    results = []
+    for on in (True, False):
+        monkeypatch.setattr(F, "_POOLED_GRAD", on)
+        model.train()
+        model._step = 0
+        model.obs_seq._calls = model.body_seq._calls = 0
+        torch.manual_seed(7)
+        model.zero_grad()
+        out = model(*args)
+        out.square().mean().backward()
+        results.append([p.grad.clone() for p in model.parameters()])
+    assert len(calls) == 3                      # the three branches, in the first run only
+    inexact = 0
+    for (name, _), a, b in zip(model.named_parameters(), results[0], results[1]):
+        if not torch.equal(a, b):
+            inexact += 1
+            assert name.endswith("bias") and (a - b).abs().max().item() <= 1e-6 * (b.abs().max().item() + 1e-12), name
+    assert inexact <= 1

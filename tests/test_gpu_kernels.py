@@ -819,6 +819,28 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
     by_act = ops.segment_pool_bwd(gm, gwm, gp, n, weights=wts, gate=plain, gate_scale=1.25)
     by_bits = ops.segment_pool_bwd(gm, gwm, gp, n, weights=wts, gate_bits=req["out_bits"], gate_scale=1.25)
     assert torch.equal(by_act, by_bits)
+    if ops.pooled_grad_supported(c):
+        # ... the same bits per node, and the transposed aggregation that computes its source from them (csrc/pooled_grad.hip) against
+        # the pool's backward written out and gathered: bit-equal, with / without a mean gradient, row scale and self term -- rows of
+        # 0, 1, 2, 3-32 and more entries, tiles of many graphs
+        got_nodes = torch.from_numpy(ops.pool_node_gates(req["out_bits"], n, c)).to(DEV) & mask_of_valid
+        assert torch.equal(got_nodes, want_bits.to(torch.int32))
+        _, _, out_ptr, out_dst, _ = ops.csr_build(ei.to(DEV), n)
+        oell = ops.ell_from_csr(out_ptr, out_dst, n)
+        cs = (torch.rand(n, device=DEV) - 0.5)
+        for g0, rs_, ds_, alpha in ((gm, rs, rs * rs, 1.0), (None, None, cs, 1.0), (gm, rs, None, 2.0)):
+            written = ops.segment_pool_bwd(g0, gwm, gp, n, weights=wts, gate_bits=req["out_bits"], gate_scale=1.25)
+            want = ops.csr_aggregate(written, out_ptr, out_dst, ell=oell, cscale=cs, rscale=rs_, dself=ds_, alpha=alpha)
+            pgr = ops.PooledGrad(g0, gwm, gp, n, wts, 1.25, req["out_bits"])
+            got, g_rows = pgr.aggregate(out_ptr, out_dst, oell, cs, rscale=rs_, dself=ds_, alpha=alpha)
+            assert torch.equal(g_rows[:, :c], written[:, :c])
+            assert torch.equal(got[:, :c], want[:, :c])
+            assert torch.equal(pgr.materialise(), written)
+            # ... without writing the rows at all, and their column sums (a bias gradient) from the bits alone
+            got2, none = pgr.aggregate(out_ptr, out_dst, oell, cs, rscale=rs_, dself=ds_, alpha=alpha, want_g=False)
+            assert none is None and torch.equal(got2, got)
+            sums, want_sums = pgr.colsum().double().cpu(), written[:, :c].double().sum(0).cpu()
+            assert (sums - want_sums).abs().max().item() <= 1e-5 * max(written.abs().sum(0).max().item(), 1.0)
     # the switch restores the two-launch form (results agree to fp32 rounding of another summation order)
     with pytest.MonkeyPatch.context() as mp:
         mp.setattr(ops, "_POOL_FUSED", False)
