@@ -395,6 +395,167 @@ bool fast_gate(View st, Circuit& c, Registers& qregs, NameCache& cache) {
   return true;
 }
 
+// ---- the same statements scanned a machine word at a time (round 5) ------------------------------------------------------------
+// fast_gate above still walks views, calls memchr / memcmp per token and parses every literal: 40 ns per statement of ~20 bytes,
+// 11 M statements per run() of 1024 100-qubit circuits.  The scanner below reads the text where it lies, from the first byte of a
+// statement to its ';':
+//   * names (gate, register) of up to 8 bytes are ONE unaligned 64-bit load masked to their length: a keyword test is a masked
+//     compare, the gate-name and register caches compare integers, not bytes;
+//   * the parenthesised parameter is looked up by its bytes -- length, first and last 8 bytes, the 8 in the middle -- in a small
+//     table before anything is parsed: a transpiled circuit repeats a handful of angles thousands of times (six distinct literals
+//     among 9 930 in a 10-step Trotter circuit); a miss parses with fast_literal as before and remembers the value;
+//   * nothing is appended to the circuit before the ';' is reached, so any other shape (expressions, whole registers, unknown
+//     names, out-of-range indices, names longer than 8 bytes, the last 8 bytes of the text) returns false and the statement goes
+//     through fast_gate / the general path unchanged, which also word the errors.
+// Same circuits as the general path, op for op (tests/test_native_encoder.py runs all three against each other; the fuzz driver
+// feeds malformed text through this entry first).
+inline uint64_t load8(const char* p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+inline uint64_t low_bytes(int n) { return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1); }
+constexpr uint64_t word8(const char* s) {      // the bytes of a short literal as load8 sees them (little endian)
+  uint64_t v = 0;
+  for (int i = 0; i < 8 && s[i]; ++i) v |= (uint64_t)(unsigned char)s[i] << (8 * i);
+  return v;
+}
+// is_keyword() on the word: prefixes of OPENQASM / include / qreg / creg / measure / barrier / reset, exactly if / gate / opaque
+inline bool keyword_word(uint64_t w, int n) {
+  switch ((char)(w & 0xFF)) {
+    case 'O': return w == word8("OPENQASM");
+    case 'i': return (w & low_bytes(7)) == word8("include") || (n == 2 && w == word8("if"));
+    case 'q': return (w & low_bytes(4)) == word8("qreg");
+    case 'c': return (w & low_bytes(4)) == word8("creg");
+    case 'm': return (w & low_bytes(7)) == word8("measure");
+    case 'b': return (w & low_bytes(7)) == word8("barrier");
+    case 'r': return (w & low_bytes(5)) == word8("reset");
+    case 'g': return n == 4 && w == word8("gate");
+    case 'o': return n == 6 && w == word8("opaque");
+    default: return false;
+  }
+}
+
+struct WordCache {      // per circuit: gate names and the register last named, as words; parameters by their bytes
+  static constexpr int kNames = 8, kParams = 64;
+  uint64_t name[kNames]; int name_id[kNames]; int names = 0, next_name = 0;
+  uint64_t reg_word = 0; int reg_len = -1; Reg reg{0, 0};
+  struct Param { uint64_t head, mid, tail; int len; double value; };
+  Param param[kParams];
+  void reset() { names = next_name = 0; reg_len = -1; for (auto& q : param) q.len = -1; }
+};
+
+// a word of at most 8 word-characters at p (p + 8 <= end): its length, 0 when it does not start one or is longer
+inline int word_at(const char* p, uint64_t& w) {
+  if (!(is_alpha(*p) || *p == '_')) return 0;
+  int n = 1;
+  while (n < 8 && is_word(p[n])) ++n;
+  if (n == 8 && is_word(p[8])) return 0;      // longer than a machine word (p[8] is readable: the caller keeps 9 bytes)
+  w = load8(p) & low_bytes(n);
+  return n;
+}
+
+// One statement starting at p (first non-space byte) -> appended to c, p behind its ';'.  false: nothing appended, p unchanged.
+bool fast_statement(const char*& pos, const char* const end, Circuit& c, Registers& qregs, WordCache& wc) {
+  const char* p = pos;
+  if (end - p < 16) return false;                       // the loads below read up to 9 bytes ahead of a token's start
+  uint64_t w;
+  const int n = word_at(p, w);
+  if (n == 0 || keyword_word(w, n)) return false;
+  const char* const name_at = p;
+  p += n;
+  while (p < end && is_space(*p)) ++p;
+  double param = 0.0;
+  int p_cnt = 0;
+  if (p < end && *p == '(') {
+    const char* const lp = p + 1;
+    // the closing parenthesis, eight bytes at a time, within 64 bytes (a hit below means the bytes in between ARE a literal seen
+    // before; a miss parses them, and anything but a literal fails there)
+    const char* rp = nullptr;
+    for (const char* q = lp; q + 8 <= end && q < lp + 64; q += 8) {
+      const uint64_t x = load8(q) ^ 0x2929292929292929ull;              // ')' = 0x29: a zero byte where one is
+      const uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+      if (z) { rp = q + (__builtin_ctzll(z) >> 3); break; }
+    }
+    if (!rp) return false;                              // unbalanced, or far away: the general path
+    const int len = (int)(rp - lp);
+    if (len < 1) return false;
+    // the bytes between the parentheses as (length, first 8, middle 8, last 8): exact for up to 24 bytes
+    uint64_t head = 0, mid = 0, tail = 0;
+    const bool keyed = len <= 24 && end - lp >= 8;
+    if (keyed) {
+      if (len >= 8) { head = load8(lp); tail = load8(rp - 8); if (len > 16) mid = load8(lp + 8); }
+      else { head = load8(lp) & low_bytes(len); tail = head; }
+    }
+    WordCache::Param* slot = nullptr;
+    if (keyed) {
+      slot = &wc.param[((head * 0x9E3779B97F4A7C15ull) ^ (tail * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)len) >> 58];
+      if (slot->len == len && slot->head == head && slot->tail == tail && slot->mid == mid) { param = slot->value; p_cnt = 1; }
+    }
+    if (!p_cnt) {
+      const char* q = lp;
+      while (q < rp && is_space(*q)) ++q;
+      bool neg = false;
+      if (q < rp && *q == '-') { neg = true; ++q; while (q < rp && is_space(*q)) ++q; }
+      const char* after = fast_literal(q, rp, param);
+      if (!after) return false;
+      while (after < rp && is_space(*after)) ++after;
+      if (after != rp) return false;                    // an expression, a second parameter: the general path
+      if (neg) param = -param;
+      p_cnt = 1;
+      if (slot) *slot = WordCache::Param{head, mid, tail, len, param};
+    }
+    p = rp + 1;
+    while (p < end && is_space(*p)) ++p;
+  }
+  int bits[3], n_bits = 0;
+  for (;;) {
+    if (end - p < 16 || n_bits == 3) return false;
+    uint64_t rw;
+    const int rn = word_at(p, rw);
+    if (rn == 0) return false;
+    const Reg* rg;
+    if (rn == wc.reg_len && rw == wc.reg_word) rg = &wc.reg;
+    else {
+      rg = qregs.find(View(p, (size_t)rn));
+      if (!rg) return false;
+      wc.reg = *rg; wc.reg_word = rw; wc.reg_len = rn;
+      rg = &wc.reg;
+    }
+    p += rn;
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end || *p != '[') return false;            // a whole-register argument broadcasts: the general path
+    ++p;
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end || !is_digit(*p)) return false;
+    long idx = 0;
+    for (; p < end && is_digit(*p); ++p) { idx = idx * 10 + (*p - '0'); if (idx > kMaxRegisterBits) return false; }
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end || *p != ']') return false;
+    ++p;
+    if (idx >= rg->size) return false;                  // the general path words the error
+    bits[n_bits++] = rg->base + (int)idx;
+    while (p < end && is_space(*p)) ++p;
+    if (p >= end) return false;                         // no ';': the last statement of a text goes the general way
+    if (*p == ';') break;
+    if (*p != ',') return false;
+    ++p;
+    while (p < end && is_space(*p)) ++p;
+  }
+  // the gate name -> its id (after the arguments: an unknown register must not intern a name)
+  int type = -1;
+  for (int k = 0; k < wc.names; ++k)
+    if (wc.name[k] == w) { type = wc.name_id[k]; break; }
+  if (type < 0) {
+    type = c.intern(View(name_at, (size_t)n));
+    const int slot = wc.names < WordCache::kNames ? wc.names++ : (wc.next_name++ % WordCache::kNames);
+    wc.name[slot] = w; wc.name_id[slot] = type;
+  }
+  const int q_off = (int)c.bits.size();
+  for (int k = 0; k < n_bits; ++k) c.bits.push_back(bits[k]);
+  const int p_off = (int)c.params.size();
+  if (p_cnt) c.params.push_back(param);
+  c.ops.push_back(Op{type, q_off, n_bits, q_off, 0, p_off, p_cnt});
+  pos = p + 1;
+  return true;
+}
+
 // Parses `text` into c (cleared first; its capacity is reused).  `buf_a` / `buf_b` are scratch strings for the stripped text.
 void parse_qasm(const char* text, Circuit& c, std::string& s, std::string& t) {
   const size_t len = std::strlen(text);
@@ -438,11 +599,24 @@ void parse_qasm(const char* text, Circuit& c, std::string& s, std::string& t) {
   Registers qregs, cregs;
   NameCache name_cache;
   name_cache.reset();
-  static const bool fast_path = !(std::getenv("MLQEM_QASM_FAST") && std::atoi(std::getenv("MLQEM_QASM_FAST")) == 0);
+  // MLQEM_QASM_FAST: 0 = the general path only, 1 = fast_gate (round 4), default 2 = the word scanner in front of it
+  static const int fast_level = std::getenv("MLQEM_QASM_FAST") ? std::atoi(std::getenv("MLQEM_QASM_FAST")) : 2;
+  static const bool fast_path = fast_level != 0;
+  WordCache words;
+  words.reset();
   std::vector<View> pieces;
   std::vector<int> arg_off, arg_cnt, scratch;
   size_t pos = 0;
+  const char* const text_end = all.data() + all.size();
   while (pos < all.size()) {
+    if (fast_level >= 2) {
+      const char* q = all.data() + pos;
+      while (q < text_end && is_space(*q)) ++q;
+      const char* const from = q;
+      while (fast_statement(q, text_end, c, qregs, words))
+        while (q < text_end && is_space(*q)) ++q;
+      if (q != from) { pos = (size_t)(q - all.data()); if (pos >= all.size()) break; }
+    }
     const size_t semi = all.find(';', pos);
     const View st = trim(all.substr(pos, semi == View::npos ? View::npos : semi - pos));
     pos = semi == View::npos ? all.size() : semi + 1;

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void pooled_grad_colsum_kernel(const uint16
     float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, inv = 1.f / (float)max(gend - gptr[g], 1);
     if (g0) vload<4>(g0 + (int64_t)g * ldg0 + ch, a0);
     if (g1) vload<4>(g1 + (int64_t)g * ldg1 + ch, a1);
-    constexpr int kAhead = 4;                                // rows in flight per thread: the loop is a chain of dependent loads otherwise
+    constexpr int kAhead = 8;                                // rows in flight per thread: the loop is a chain of dependent loads otherwise
     for (int64_t r = beg + rl; r < end; r += (int64_t)kAhead * lanes) {
       unsigned gt[kAhead]; float tw[kAhead];
 #pragma unroll
@@ -242,12 +242,17 @@ __global__ __launch_bounds__(kBlock) void pooled_grad_colsum_kernel(const uint16
 #pragma unroll
   for (int v = 0; v < 4; ++v) s_sum[tid][v] = acc[v];
   __syncthreads();
-  if (tid < CV * 4) {
-    const int sl = tid >> 2, v = tid & 3;
-    float t = 0.f;
-    for (int l = 0; l < lanes; ++l) t += s_sum[l * CV + sl][v];
-    partial[(int64_t)blockIdx.x * (CV * 4) + tid] = t;
+  // the row lanes of a slice, halved until one is left: a fixed tree
+  for (int n = lanes; n > 1;) {
+    const int h = (n + 1) >> 1;
+    if (rl < n - h) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) s_sum[tid][v] += s_sum[tid + h * CV][v];
+    }
+    __syncthreads();
+    n = h;
   }
+  if (tid < CV * 4) partial[(int64_t)blockIdx.x * (CV * 4) + tid] = s_sum[tid >> 2][tid & 3];
 }
 
 int aggregate_pool_rows_per_tile(int C);

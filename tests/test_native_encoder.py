@@ -204,8 +204,9 @@ def test_scanner_literals_are_correctly_rounded(lima_props):
 
 
 def test_fast_statement_path_equals_the_general_path(g1, lima_props, tmp_path):
-    """MLQEM_QASM_FAST=0 (read once per process: a child interpreter) sends every statement through the general path; rows, edges
-    and depths of the fast path are identical on transpiled circuits, hand-written statement shapes and refused inputs alike."""
+    """MLQEM_QASM_FAST=0 (read once per process: a child interpreter) sends every statement through the general path, 1 through
+    round 4's fast_gate first, 2 (the default) through the word scanner in front of that; rows, edges and depths are identical on
+    transpiled circuits, hand-written statement shapes and refused inputs alike."""
     import subprocess
     import sys
 
@@ -216,6 +217,21 @@ def test_fast_statement_path_equals_the_general_path(g1, lima_props, tmp_path):
     texts.append('OPENQASM 2.0;\nqreg q[5];\nsx r[0];\n')
     texts.append('OPENQASM 2.0;\nqreg q[5];\nrz(0.25) q[1]junk;\nsx q[0];\n')
     texts.append('OPENQASM 2.0;\nqreg q[5];\nmeasurez q[0];\n')
+    # the word scanner (MLQEM_QASM_FAST=2, the default): parameters of 1 .. 25 bytes seen once and again (its table is keyed by
+    # their bytes), spaces and signs inside the parentheses, two registers taking turns, a last statement without ';', names of
+    # 8 and 9 bytes, keyword prefixes, unbalanced parentheses, a text shorter than its look-ahead
+    texts.append('OPENQASM 2.0;\nqreg q[3];\nqreg r[2];\nrz(1) q[0];rz(1.5) r[1];rz(1.5) q[1];rz(0.12345678) q[0];rz(0.123456789) q[0];'
+                 'rz(0.1234567890123456) q[2];rz(0.12345678901234567) q[2];rz(0.12345678901234567) q[1];rz(1.234567890123456789e-3) q[0];'
+                 'rz(1.2345678901234567890123) q[1];rz(1.2345678901234567890123) q[1];rz(1.23456789012345678901234) q[1];rz( 0.5 ) q[0];'
+                 'rz(-0.5) q[0];rz(- 0.5) q[0];rz(0.5 ) q[0];rz(0.5) q[0];cx q[0],r[1];cx r[0],q[2];cx q[10],q[0];sx q[2]')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nsx q[0];\nabcdefgh q[0];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nsx q[0];\nabcdefghi q[0];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nresetx q[0];\nsx q[1];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nrz(0.5 q[0];sx q[1];\nsx q[2];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nrz(0.5)) q[0];sx q[1];\n')
+    texts.append('OPENQASM 2.0;\nqreg q[5];\nrz(0.5)(0.25) q[0];sx q[1];\n')
+    texts.append('OPENQASM 2.0;qreg q[1];x q[0];')
+    texts.append('OPENQASM 2.0;\nqreg verylongregister[4];\nsx verylongregister[3];\nx verylongregister[0];\nrz(0.5) verylongregister[1];\n')
     (tmp_path / "texts.json").write_text(json.dumps(texts))
     (tmp_path / "props.json").write_text(json.dumps(lima_props))
     script = (
@@ -233,16 +249,17 @@ def test_fast_statement_path_equals_the_general_path(g1, lima_props, tmp_path):
         "        out[f'err{k}'] = np.array(type(err).__name__ + ': ' + str(err))\n"
         "np.savez(sys.argv[1], **out)\n")
     res = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):
         path = tmp_path / f"out{mode}.npz"
         env = dict(os.environ, MLQEM_QASM_FAST=mode)
         subprocess.run([sys.executable, "-c", script, str(path)], check=True, env=env, timeout=300)
         res[mode] = dict(np.load(path))
-    assert sorted(res["1"]) == sorted(res["0"])
+    assert sorted(res["1"]) == sorted(res["0"]) == sorted(res["2"])
     assert any(k.startswith("err") for k in res["1"]) and any(k.startswith("x") for k in res["1"])
     for key in res["1"]:
-        a, b = res["1"][key], res["0"][key]
-        assert a.shape == b.shape and (a == b).all(), key
+        for mode in ("1", "2"):
+            a, b = res[mode][key], res["0"][key]
+            assert a.shape == b.shape and (a == b).all(), (mode, key)
 
 
 def test_encoding_after_fork_does_not_wait_for_the_parents_workers(g1, lima_props):
