@@ -428,12 +428,12 @@ int mlqem_segment_pool_bwd_f32(const float* g_mean, int64_t ld_gmean, const floa
  *     g[j, :]   = gate(j, :) ? ((g_mean[b, :] + t_j g_wmean[b, :]) / n_b) * gate_scale : 0
  *     out[i, :] = alpha * (rscale[i] * sum_e cscale[idx[e]] * g[idx[e], :] + dself[i] * g[i, :])
  * Both are written (g, optional, for the dense consumers: weight and bias gradients); results equal the two-launch form bit for bit.
- * mlqem_pooled_grad_colsum_f32: sum_j g[j, :] without g -- partial[mlqem_pooled_grad_colsum_groups()][round_up(C, 4)], added over the
+ * mlqem_pooled_grad_colsum_f32: sum_j g[j, :] without g -- partial[mlqem_pooled_grad_colsum_groups(N)][round_up(C, 4)], added over the
  * groups by the caller (the bias gradient of a layer whose aggregation did not write g).
  * gate_bits: the buffer mlqem_csr_aggregate_pool_f32 filled for the same N and C.  Needs C <= 16 (mlqem_pooled_grad_aggregate_supported),
  * the ELL side table of (ptr, idx), and 16-byte rows everywhere (ld % 4 == 0, ld >= round_up(C, 4)). */
 int mlqem_pooled_grad_aggregate_supported(int C);
-int mlqem_pooled_grad_colsum_groups(void);
+int mlqem_pooled_grad_colsum_groups(int64_t N);
 int mlqem_pooled_grad_colsum_f32(const uint8_t* gate_bits, const float* weights, const float* g_mean, int64_t ld_gmean, const float* g_wmean,
                                  int64_t ld_gwmean, const int32_t* graph_ptr, int64_t B, float gate_scale, int64_t N, int C, float* partial,
                                  mlqem_stream_t stream);

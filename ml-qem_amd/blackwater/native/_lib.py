@@ -98,7 +98,7 @@ SIGNATURES = {
     "mlqem_segment_pool_workspace_bytes": (_S, [_L, _L, _I]),
     "mlqem_segment_pool_f32": (_I, [_P, _L, _P, _P, _L, _L, _I, _P, _L, _P, _L, _P, _S, _P]),
     "mlqem_pooled_grad_aggregate_supported": (_I, [_I]),
-    "mlqem_pooled_grad_colsum_groups": (_I, []),
+    "mlqem_pooled_grad_colsum_groups": (_I, [_L]),
     "mlqem_pooled_grad_colsum_f32": (_I, [_P, _P, _P, _L, _P, _L, _P, _L, _F, _L, _I, _P, _P]),
     "mlqem_pooled_grad_aggregate_f32": (_I, [_P, _P, _P, _P, _L, _P, _L, _P, _L, _F, _P, _P, _P, _P, _P, _F, _P, _L, _P, _L, _L, _I, _P]),
     "mlqem_segment_pool_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _L, _F, _P, _P, _L, _P]),

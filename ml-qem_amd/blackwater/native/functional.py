@@ -339,6 +339,9 @@ def _mask_grad(g, y, drop_p):
 # MLQEM_POOLED_GRAD=0: the pooled gradient of a Family A branch written out by ops.segment_pool_bwd and gathered by the transposed
 # aggregation (A/B).  Default: computed inside that aggregation (ops.PooledGrad, csrc/pooled_grad.hip).
 _POOLED_GRAD = os.environ.get("MLQEM_POOLED_GRAD", "1") != "0"
+# ... for batches of at least this many nodes: below, a step is a chain of launches of a few microseconds each and the computed form
+# has one more of them per branch than the written one (the reference's 32 four-qubit circuits per step: 0.222 -> 0.244 ms captured)
+_POOLED_GRAD_MIN_NODES = 1 << 16
 
 _PARTS_MAX_COLS = 64   # mlqem_linear_parts_f32 keeps the weight fragments of I <= 64 concatenated columns in registers
 
@@ -1129,7 +1132,8 @@ class _FamilyAGraph(Function):
         g3wg, c2w0g, c2w1g, s2lg, s2rg = gw5[0:1], gw5[1:2], gw5[2:3], gw5[3:4], gw5[4:5]
         g3bg, c2bg, s2bg = gb3[0:1], gb3[1:2], gb3[2:3]
         c_ = ggw.shape[1]
-        synth = _POOLED_GRAD and ops.pooled_grad_supported(c_) and struct.out_ell is not None      # per branch: its gate bits exist
+        synth = (_POOLED_GRAD and n >= _POOLED_GRAD_MIN_NODES and ops.pooled_grad_supported(c_)
+                 and struct.out_ell is not None)      # per branch: its gate bits exist
         for st in side:
             st.wait_stream(main)
         # GCN branch, last layer first: pooled = wmean(h) W^T + b

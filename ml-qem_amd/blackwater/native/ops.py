@@ -1140,7 +1140,7 @@ class PooledGrad:
         write g."""
         ref, b, c, n, gm, ldm, gw, ldw = self._operands()
         lib = _lib.load()
-        part = torch.empty((lib.mlqem_pooled_grad_colsum_groups(), (c + 3) // 4 * 4), dtype=torch.float32, device=ref.device)
+        part = torch.empty((lib.mlqem_pooled_grad_colsum_groups(n), (c + 3) // 4 * 4), dtype=torch.float32, device=ref.device)
         code = lib.mlqem_pooled_grad_colsum_f32(_p(self.gate_bits), _p(self.weights), _p(gm), ldm, _p(gw), ldw, _p(self.graph_ptr), b,
                                                 float(self.gate_scale), n, c, _p(part), _stream())
         _lib.check(code, "mlqem_pooled_grad_colsum_f32")

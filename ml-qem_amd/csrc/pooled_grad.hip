@@ -224,9 +224,10 @@ __global__ __launch_bounds__(kBlock) void pooled_grad_colsum_kernel(const uint16
       for (int u = 0; u < kAhead; ++u) {
         const int64_t ru = r + (int64_t)u * lanes;
         if (ru >= end) break;
-        if (ru >= gend) {
-          g = graph_at(gptr, B, ru); gend = gptr[g + 1];
-          inv = 1.f / (float)max(gend - gptr[g], 1);
+        if (ru >= gend) {                                    // the next graphs in turn: a thread's rows are `lanes` apart, a search from
+          int gbeg = gend;                                   // scratch (ten dependent loads) per row was the kernel's time on small graphs
+          do { ++g; gbeg = gend; gend = gptr[g + 1]; } while (ru >= gend && g + 1 < B);
+          inv = 1.f / (float)max(gend - gbeg, 1);
           if (g0) vload<4>(g0 + (int64_t)g * ldg0 + ch, a0);
           if (g1) vload<4>(g1 + (int64_t)g * ldg1 + ch, a1);
         }
@@ -289,8 +290,10 @@ extern "C" int mlqem_pooled_grad_aggregate_f32(const uint8_t* gate_bits, const f
   return launch_status();
 }
 
-// partial: [mlqem_pooled_grad_colsum_groups()][round_up(C, 4)] floats, to be added over the groups by the caller -> sum_j g[j, :]
-extern "C" int mlqem_pooled_grad_colsum_groups(void) { return kColsumGroups; }
+// partial: [mlqem_pooled_grad_colsum_groups(N)][round_up(C, 4)] floats, to be added over the groups by the caller -> sum_j g[j, :]
+extern "C" int mlqem_pooled_grad_colsum_groups(int64_t N) {      // a trip or more of eight rows per thread, at most kColsumGroups workgroups
+  return (int)std::min<int64_t>(kColsumGroups, std::max<int64_t>(1, ceil_div(std::max<int64_t>(N, 1), (int64_t)512)));
+}
 extern "C" int mlqem_pooled_grad_colsum_f32(const uint8_t* gate_bits, const float* weights, const float* g_mean, int64_t ld_gmean,
                                             const float* g_wmean, int64_t ld_gwmean, const int32_t* graph_ptr, int64_t B, float gate_scale,
                                             int64_t N, int C, float* partial, mlqem_stream_t stream) {
@@ -307,6 +310,6 @@ extern "C" int mlqem_pooled_grad_colsum_f32(const uint8_t* gate_bits, const floa
   const int4* info = reinterpret_cast<const int4*>(gate_bits);
   const unsigned long long* words = reinterpret_cast<const unsigned long long*>(info + tiles);
   const uint16_t* node_gate = reinterpret_cast<const uint16_t*>(words + tiles * aggregate_pool_mask_words());
-  hipLaunchKernelGGL(pooled_grad_colsum_kernel, dim3(kColsumGroups), dim3(kBlock), 0, as_stream(stream), node_gate, weights, g_mean, ld_gmean, g_wmean, ld_gwmean, graph_ptr, (int)B, gate_scale, N, cv, partial);
+  hipLaunchKernelGGL(pooled_grad_colsum_kernel, dim3((unsigned)mlqem_pooled_grad_colsum_groups(N)), dim3(kBlock), 0, as_stream(stream), node_gate, weights, g_mean, ld_gmean, g_wmean, ld_gwmean, graph_ptr, (int)B, gate_scale, N, cv, partial);
   return launch_status();
 }

@@ -133,6 +133,7 @@ def test_pooled_gradient_computed_in_its_aggregation_equals_the_written_one(g1, 
     real = ops.PooledGrad.aggregate
     monkeypatch.setattr(ops.PooledGrad, "aggregate", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
     results = []
+    monkeypatch.setattr(F, "_POOLED_GRAD_MIN_NODES", 0)      # small batches keep the written form by default (launch counts)
     for on in (True, False):
         monkeypatch.setattr(F, "_POOLED_GRAD", on)
         model.train()
