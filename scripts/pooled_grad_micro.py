@@ -41,14 +41,21 @@ for kind, kw in kinds.items():
     gm = ops.padded_empty(nb, c, dev).normal_() if kw["mean"] else None
     gw = ops.padded_empty(nb, c, dev).normal_()
     pg = ops.PooledGrad(gm, gw, gptr, n, wts, 1.25, bits)
+    form = os.environ.get("PG_FORM", "")      # one form only (counter passes: scripts/pmc_tiles.sh averages a kernel's launches)
+    agg = lambda **k: pg.aggregate(s.out_ptr, s.out_dst, s.out_ell, kw["cscale"], rscale=kw["rscale"], dself=kw["dself"], **k)
+    if form == "computed":
+        timed(lambda: agg()); continue
+    if form == "computed_not_written":
+        timed(lambda: agg(want_g=False)); timed(lambda: pg.colsum()); continue
     t_w = timed(lambda: ops.segment_pool_bwd(gm, gw, gptr, n, weights=wts, gate_scale=1.25, gate_bits=bits))
     g = ops.segment_pool_bwd(gm, gw, gptr, n, weights=wts, gate_scale=1.25, gate_bits=bits)
     t_a = timed(lambda: ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=kw["cscale"], rscale=kw["rscale"], dself=kw["dself"]))
-    t_p = timed(lambda: pg.aggregate(s.out_ptr, s.out_dst, s.out_ell, kw["cscale"], rscale=kw["rscale"], dself=kw["dself"]))
-    want = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=kw["cscale"], rscale=kw["rscale"], dself=kw["dself"])
-    got, rows = pg.aggregate(s.out_ptr, s.out_dst, s.out_ell, kw["cscale"], rscale=kw["rscale"], dself=kw["dself"])
-    t_n = timed(lambda: pg.aggregate(s.out_ptr, s.out_dst, s.out_ell, kw["cscale"], rscale=kw["rscale"], dself=kw["dself"], want_g=False))
+    if form == "written":
+        continue
+    t_p = timed(lambda: agg())
+    t_n = timed(lambda: agg(want_g=False))
     t_c = timed(lambda: pg.colsum())
-    print(f"{kind}: not written {t_n:.1f} us, column sums {t_c:.1f} us")
-    print(f"{kind}: written {t_w:.1f} + gathered {t_a:.1f} = {t_w + t_a:.1f} us; computed in the aggregation {t_p:.1f} us; "
-          f"equal {torch.equal(got, want) and torch.equal(rows, g)}  variant {os.environ.get('MLQEM_PG_VARIANT', '0')}", flush=True)
+    want = ops.csr_aggregate(g, s.out_ptr, s.out_dst, ell=s.out_ell, cscale=kw["cscale"], rscale=kw["rscale"], dself=kw["dself"])
+    got, rows = agg()
+    print(f"{kind}: written {t_w:.1f} + gathered {t_a:.1f} = {t_w + t_a:.1f} us; computed in the aggregation: and written {t_p:.1f} us, "
+          f"not written {t_n:.1f} us + column sums {t_c:.1f} us; equal {torch.equal(got, want) and torch.equal(rows, g)}", flush=True)
