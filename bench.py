@@ -111,17 +111,37 @@ def in_step_aggregation_times(arena, ids, n_qubits, steps=3):
         records.append((name, c, by, b, e))
         return out
 
+    orig_pg = ops.PooledGrad.aggregate
+
+    def wrapped_pg(self, ptr, idx, ell, cscale, rscale=None, dself=None, alpha=1.0, want_g=True):
+        # the first backward aggregation of a branch with its source COMPUTED (csrc/pooled_grad.hip): per entry (and the row itself)
+        # two scalars and 2 bytes of gate bits instead of a 4 C-byte row; g written or not
+        n = self.num_nodes
+        c = (self.g_wmean if self.g_wmean is not None else self.g_mean).shape[1]
+        e = e_real + n
+        by = 4 * (n + 1) + 4 * e + 4 * n + 10 * (e + n) + 4 * c * n * (2 if want_g else 1)
+        name = "plain, source computed from the pooled gradient" + (" +g written" if want_g else "") + \
+               (" +self" if dself is not None else "") + " transposed CSR"
+        b, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b.record()
+        out = orig_pg(self, ptr, idx, ell, cscale, rscale=rscale, dself=dself, alpha=alpha, want_g=want_g)
+        e_.record()
+        records.append((name, c, by, b, e_))
+        return out
+
     try:
         torch.manual_seed(0)
         tr = Trainer(ExpValCircuitGraphModelA(n_qubits, 22, 10).to(st.in_ptr.device), lr=1e-3)
         tr.step(batch)                              # allocator warm-up, untimed
         torch.cuda.synchronize()
         ops.csr_aggregate = wrapped
+        ops.PooledGrad.aggregate = wrapped_pg
         for _ in range(steps):
             tr.step(batch)
         torch.cuda.synchronize()
     finally:
         ops.csr_aggregate = orig
+        ops.PooledGrad.aggregate = orig_pg
         ops.set_seed_counter(keep_counter)
         if prev is None:
             os.environ.pop("MLQEM_SINGLE_STREAM", None)

@@ -426,7 +426,7 @@ class _ChebLayer(Function):
         n, i = x.shape
         lap_t = dict(ell=s.out_ell, cscale=s.derived("cheb_neg"), rscale=s.cheb_dinv)
         if isinstance(g, ops.PooledGrad) and k >= 2 and y is None:      # the pooled gradient, computed inside its first aggregation
-            g1, g = g.aggregate(s.out_ptr, s.out_dst, s.out_ell, s.derived("cheb_neg"), rscale=s.cheb_dinv)
+            g1, g = ops.pooled_grad_aggregate(g, s.out_ptr, s.out_dst, s.out_ell, s.derived("cheb_neg"), rscale=s.cheb_dinv)
             gs = [g, g1]
         else:
             if isinstance(g, ops.PooledGrad):
@@ -542,7 +542,7 @@ class _SAGELayer(Function):
         s, (o, ow) = ctx.struct, ctx.dims
         n, i = x.shape
         if isinstance(g, ops.PooledGrad) and y is None:
-            gp, g = g.aggregate(s.out_ptr, s.out_dst, s.out_ell, s.sage_rinv, dself=s.derived("sage_dself"))
+            gp, g = ops.pooled_grad_aggregate(g, s.out_ptr, s.out_dst, s.out_ell, s.sage_rinv, dself=s.derived("sage_dself"))
         else:
             if isinstance(g, ops.PooledGrad):
                 g = g.materialise()
@@ -591,10 +591,10 @@ class _GCNLayer(Function):
         if isinstance(g, ops.PooledGrad) and y is None:
             # the fused backward below reads g only for the bias gradient: its column sums come from the bits, g is never written
             pooled = g
-            gh, g = pooled.aggregate(s.out_ptr, s.out_dst, s.out_ell, s.gcn_dinv, rscale=s.gcn_dinv, dself=s.derived("gcn_dself"), want_g=not fused)
+            gh, g = ops.pooled_grad_aggregate(pooled, s.out_ptr, s.out_dst, s.out_ell, s.gcn_dinv, rscale=s.gcn_dinv, dself=s.derived("gcn_dself"), want_g=not fused)
             if fused and ops._fused_bwd_ok(gh, x):
                 gx, gw, _, ctx.gx_colsum = ops.linear_bwd_fused(gh, x, w.contiguous(), gate_scale=ctx.x_gate_scale)
-                return gx, gw, pooled.colsum(), None, None, None, None, None, None
+                return gx, gw, ops.pooled_grad_colsum(pooled), None, None, None, None, None, None
             if g is None:
                 g = pooled.materialise()
         else:

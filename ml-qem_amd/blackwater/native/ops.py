@@ -1165,6 +1165,16 @@ class PooledGrad:
         return out, g
 
 
+def pooled_grad_aggregate(pooled, ptr, idx, ell, cscale, **kw):
+    """``pooled.aggregate(...)`` as a module-level call (what the layers use: tools that wrap the entry points of this module by name --
+    scripts/kernel_roofline.py -- see it)."""
+    return pooled.aggregate(ptr, idx, ell, cscale, **kw)
+
+
+def pooled_grad_colsum(pooled):
+    return pooled.colsum()
+
+
 def segment_mean(x, graph_ptr, num_graphs):
     return segment_pool(x, graph_ptr, num_graphs)[0]
 

@@ -43,7 +43,7 @@ class Recorder:
 
     NAMES = ("csr_aggregate", "linear", "linear_parts", "linear_wgrad", "linear_wgrad_parts", "segment_mean",
              "segment_mean_bwd", "relu_dropout_bwd", "segment_pool", "segment_pool_bwd", "linear_bwd_fused", "pooled_head",
-             "pooled_head_bwd")
+             "pooled_head_bwd", "pooled_grad_aggregate", "pooled_grad_colsum")
 
     def __init__(self):
         self.calls, self.orig = [], {}
@@ -81,6 +81,18 @@ def describe(name, a, k, struct):
                                      "self" if k.get("dself") is not None else "",
                                      "T" if a[1].data_ptr() == struct.out_ptr.data_ptr() else "") if f)
         return f"csr_aggregate N={n} C={c} [{flags}]", by
+    if name == "pooled_grad_aggregate":      # a branch's first backward aggregation, its source computed (csrc/pooled_grad.hip)
+        pg = a[0]
+        n = pg.num_nodes
+        c = (pg.g_wmean if pg.g_wmean is not None else pg.g_mean).shape[1]
+        e_eff = e + n                             # the row itself is always computed (its g, or its self term)
+        want_g = k.get("want_g", True)
+        by = 4 * (n + 1) + 4 * e_eff + 4 * n + 10 * (e_eff + n) + 4 * c * n * (2 if want_g else 1)
+        flags = "+".join(f for f in ("self" if k.get("dself") is not None else "", "g" if want_g else "", "T") if f)
+        return f"pooled_grad_aggregate N={n} C={c} [{flags}]", by
+    if name == "pooled_grad_colsum":
+        pg = a[0]
+        return f"pooled_grad_colsum N={pg.num_nodes}", 6 * pg.num_nodes
     if name == "segment_pool":
         x = a[0]
         n, c = x.shape
