@@ -221,12 +221,18 @@ class NativeEncoder:
         (``mlqem_qasm_batch_parse``) and writes a compact op stream -- 16 bytes per op, 2 per qubit argument
         (``mlqem_qasm_batch_stream_fill``) -- into pinned memory; ONE upload (0.2 GB for 1024 100-qubit circuits instead of 1.3 GB
         of float32 rows and int64 indices); ``mlqem_encode_expand`` builds ``x`` [sum N, F] float32, ``edge_index`` [2, sum E] int64
-        (the reference's edge order) and ``batch`` [sum N] int64.  Same arrays as ``encode_batch``, bit for bit."""
+        (the reference's edge order) and ``batch`` [sum N] int64.  Same arrays as ``encode_batch``, bit for bit.  The two halves are
+        callable on their own -- ``scan_to_stream`` (host only) and ``expand_stream`` (device only) -- so that a caller can scan the
+        next slice of a run() on another thread while this one is expanded and evaluated (library/ngem/estimator.py)."""
+        return self.expand_stream(self.scan_to_stream(texts, threads, use_gate_features, use_qubit_features), device)
+
+    def scan_to_stream(self, texts, threads: int = 0, use_gate_features: bool = True, use_qubit_features: bool = True):
+        """The host half of ``encode_batch_expand``: the op stream of ``texts`` in one pinned staging buffer (no device call)."""
         import time
 
         import torch
 
-        trace = [] if os.environ.get("MLQEM_ENCODE_TRACE") else None       # phase times of this call, printed at its end
+        trace = [] if os.environ.get("MLQEM_ENCODE_TRACE") else None       # phase times of this call, printed by expand_stream
         mark = (lambda name: trace.append((name, time.perf_counter()))) if trace is not None else (lambda name: None)
         mark("start")
         lib, count = self._lib, len(texts)
@@ -266,10 +272,23 @@ class NativeEncoder:
         mark("stream fill")
         del keep
         stage[o_ptr:o_ptr + 8 * (count + 1)].view(torch.int64).copy_(torch.from_numpy(node_ptr))
+        return dict(stage=stage, offsets=(o_ops, o_pat, o_wir, o_ptr), sizes=(n, e, w, p), count=count, f=f.value, widest=int(widest.value),
+                    node_ptr=node_ptr, depths=depths, use=(int(use_qubit_features), int(use_gate_features)), trace=trace)
+
+    def expand_stream(self, scan, device):
+        """The device half: one upload of the staging buffer, ``mlqem_encode_expand`` -> (x, edge_index, batch, node counts, depths)."""
+        import time
+
+        import torch
+
+        lib = self._lib
+        stage, (o_ops, o_pat, o_wir, o_ptr), (n, e, w, p), count = scan["stage"], scan["offsets"], scan["sizes"], scan["count"]
+        trace = scan["trace"]
+        mark = (lambda name: trace.append((name, time.perf_counter()))) if trace is not None else (lambda name: None)
         dev_stage = stage.to(device, non_blocking=True)
         mark("upload enqueued")
         tabs = self._device_tables(device)
-        x = torch.empty((n, f.value), dtype=torch.float32, device=device)
+        x = torch.empty((n, scan["f"]), dtype=torch.float32, device=device)
         ei = torch.empty((2, e), dtype=torch.int64, device=device)
         batch = torch.empty(n, dtype=torch.int64, device=device)
         need = lib.mlqem_encode_expand_workspace_bytes(n, w)
@@ -277,10 +296,10 @@ class NativeEncoder:
         mark("device buffers")
         d = dev_stage.data_ptr()
         stream = torch.cuda.current_stream(device).cuda_stream
-        code = lib.mlqem_encode_expand(d + o_ops, d + o_wir, d + o_pat, p, d + o_ptr, n, w, e, count, int(widest.value),
+        code = lib.mlqem_encode_expand(d + o_ops, d + o_wir, d + o_pat, p, d + o_ptr, n, w, e, count, scan["widest"],
                                        tabs["t1"].data_ptr(), tabs["t2"].data_ptr(), tabs["ro"].data_ptr(), tabs["nq"],
                                        tabs["g1"].data_ptr(), tabs["g2"].data_ptr(), tabs["ge"].data_ptr(), tabs["gl"].data_ptr(),
-                                       tabs["slots"], int(use_qubit_features), int(use_gate_features), x.data_ptr(), f.value,
+                                       tabs["slots"], scan["use"][0], scan["use"][1], x.data_ptr(), scan["f"],
                                        ei[0].data_ptr() if e else None, ei[1].data_ptr() if e else None, batch.data_ptr(), ws.data_ptr(), need,
                                        stream)
         _lib.check(code, "mlqem_encode_expand")
@@ -291,7 +310,7 @@ class NativeEncoder:
             torch.cuda.synchronize(device)
             mark("device done")
             print("encode_batch_expand: " + ", ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.1f} ms" for a, b in zip(trace[:-1], trace[1:])), flush=True)
-        return x, ei, batch, np.diff(node_ptr), depths[:count].tolist()
+        return x, ei, batch, np.diff(scan["node_ptr"]), scan["depths"][:count].tolist()
 
     def _raise(self, code, first: int = 0):
         msg = self._lib.mlqem_encode_last_error().decode()

@@ -197,3 +197,48 @@ def test_serial_decorator_replays_one_captured_forward_per_size_bucket(g1, lima_
     # a single circuit keeps the plain call (nothing to amortise a capture over)
     one = ngem(FakeEstimator, model, lima_backend)().run([g1["qasm"][3]], [obs]).result().values
     assert np.abs(one - both([3, 3])[:1]).max() < 1e-6
+
+
+def test_a_large_batched_run_in_slices_equals_the_one_batch_form(g1, lima_backend, monkeypatch):
+    """library/ngem/estimator.py ``_batched_in_slices``: a run() of at least two slices is scanned, expanded and evaluated slice by
+    slice (host and device overlap) -- the values are those of the one-batch form (a circuit's value does not depend on the batch it
+    is in; fp32 summation order of the pooled means: 1e-6), for a slice size that does not divide the run, and nothing in the slice
+    loop waits for the device (torch's sync-debug mode raises on a blocking call)."""
+    from blackwater.data.backends import PauliObservable
+    from blackwater.library.ngem.estimator import ngem
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from test_estimators import FakeEstimator, _Job
+    import blackwater.library.ngem.estimator as mod
+
+    torch.manual_seed(9)
+    model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV).eval()
+    idx = list(range(0, 150, 3))                     # 50 circuits
+    obs = PauliObservable([("IIZIZ", 0.75)])
+
+    class Est(FakeEstimator):
+        def _run(self, circuits, observables, parameter_values, **opts):
+            return _Job([g1["noisy"][i][0] for i in idx])
+
+    orig = mod.get_backend_properties_v1
+    monkeypatch.setattr(mod, "get_backend_properties_v1", lambda b: orig(b, gates_order=G1_GATES_ORDER))
+    circuits = [g1["qasm"][i] for i in idx]
+    monkeypatch.setattr(mod, "_SLICE", 10 ** 6)
+    whole = ngem(Est, model, lima_backend, batched=True)().run(circuits, [obs] * len(idx)).result().values
+    calls = []
+    real = mod.NgemJob._batched_in_slices
+
+    def watched(self, *a, **k):
+        calls.append(1)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")      # a blocking call inside the slice loop raises
+        try:
+            return real(self, *a, **k)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+
+    monkeypatch.setattr(mod.NgemJob, "_batched_in_slices", watched)
+    monkeypatch.setattr(mod, "_SLICE", 16)           # 50 circuits: slices of 16, 16, 16, 2
+    sliced = ngem(Est, model, lima_backend, batched=True)().run(circuits, [obs] * len(idx)).result().values
+    assert calls == [1]
+    assert whole.shape == sliced.shape == (len(idx),)
+    assert np.abs(whole - sliced).max() <= 1e-6 * max(1.0, np.abs(whole).max())
