@@ -768,8 +768,10 @@ def test_aggregation_with_pooled_means_equals_aggregation_then_pool(c, sizes):
             continue
         m = int(2 * sz)
         src.append(lo + rng.randint(0, sz, m)); dst.append(lo + rng.randint(0, sz, m))
-        if sz >= 100:                                  # a hub row
+        if sz >= 100:                                  # a hub row ...
             src.append(lo + np.arange(1, sz)); dst.append(np.full(sz - 1, lo))
+            # ... and a hub of the TRANSPOSED structure (a source with an edge to each of the graph's nodes: a barrier has both)
+            src.append(np.full(sz - 2, lo + 1)); dst.append(lo + np.arange(2, sz))
     ei = torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)])) if src else torch.zeros((2, 0), dtype=torch.long)
     in_ptr, in_src, *_ = ops.csr_build(ei.to(DEV), n)
     ell = ops.ell_from_csr(in_ptr, in_src, n)
