@@ -37,6 +37,23 @@ DEFAULT_BATCH = 1024
 CORPUS_BATCHES = 8          # corpus = CORPUS_BATCHES x batch x world circuits
 STEPS_LIST = list(range(1, 11))
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_aggregate_pmc.json")
+# per-kernel-name HBM traffic of one replayed Family A step (scripts/make_pmc_step.sh): the newest committed summary
+STEP_PMC = [os.path.join(ROOT, "profiles", f"r{r:02d}_step_pmc.json") for r in (6, 5)]
+
+
+def step_pmc_traffic(kernel_tag):
+    """(bytes per launch, source file) of the kernel whose name contains ``kernel_tag`` in the newest committed step PMC summary
+    (rocprofv3 --pmc passes cannot run inside this process), or (None, None)."""
+    for path in STEP_PMC:
+        try:
+            with open(path) as fh:
+                rows = json.load(fh)["rows"]
+        except (OSError, KeyError, ValueError):
+            continue
+        for r in rows:
+            if kernel_tag in r["kernel"].replace(" ", ""):
+                return int(r["traffic_GB"] * 1e9), os.path.relpath(path, ROOT)
+    return None, None
 
 
 _T0 = time.perf_counter()
@@ -100,7 +117,8 @@ def in_step_aggregation_times(arena, ids, n_qubits, steps=3):
 
     def wrapped(x, ptr, idx, **kw):
         epi = kw.get("bias") is not None or kw.get("relu") or kw.get("drop_p", 0.0) > 0
-        name = ("epilogue (bias+ReLU+dropout)" if epi else "plain") + (" +z" if kw.get("z") is not None else "") + \
+        pooled = kw.get("pool") is not None and kw.get("ell") is not None and ops._POOL_FUSED
+        name = ("pooled " if pooled else "") + ("epilogue (bias+ReLU+dropout)" if epi else "plain") + (" +z" if kw.get("z") is not None else "") + \
                (" +self" if kw.get("dself") is not None else "") + (" forward CSR" if ptr.data_ptr() == in_ptr else " transposed CSR")
         n, c = x.shape
         by = agg_bytes(n, e_real + (n if kw.get("dself") is not None else 0), c) + (4 * n * c if kw.get("z") is not None else 0)
@@ -263,6 +281,19 @@ def roofline_leg(batch, arena=None, ids=None, n_qubits=100, reps=20):
         out["in_step"] = in_step
         out["in_step_all_aggregations"] = {"bytes_per_step": int(tot_b), "us_per_step": round(tot_t * 1e6, 1),
                                            "frac": round(tot_b / tot_t / 1e9 / peak, 4)}
+        # The step's dominant kernel by rocprof (profiles/*_bench_kernel_stats.csv) is the POOLED epilogue instantiation
+        # csr_aggregate_ell_kernel<4,false,2,true,7,true>: the last hidden aggregation of each of the three branches, whose
+        # launch also reduces the per-graph means and the gate bits.  The headline record quotes THIS launch, in the step.
+        dom = [v for k, v in rec.items() if " pooled " in " " + k]
+        if dom:
+            d_n = sum(v[2] for v in dom)
+            d_b = sum(v[1] * v[2] for v in dom) / d_n
+            d_t = sum(v[0] * v[2] for v in dom) / d_n * 1e-6
+            out["step_dominant"] = {"kernel": "csr_aggregate_ell_kernel<4,false,2,true,7,true>", "launches_per_step": int(d_n),
+                                    "bytes_per_launch": int(d_b), "us_per_launch": round(d_t * 1e6, 2),
+                                    "achieved": round(d_b / d_t / 1e9, 1), "frac": round(d_b / d_t / 1e9 / peak, 4)}
+            tr, tr_src = step_pmc_traffic("csr_aggregate_ell_kernel<4,false,2,true,7,true>")
+            out["step_dominant"].update(traffic=tr, traffic_source=(tr_src + " (FETCH_SIZE x2 + WRITE_SIZE, mean over its launches)") if tr_src else None)
     if traffic:
         out["hbm_GBps"] = round(traffic / sec / 1e9, 1)
         out["hbm_frac"] = round(traffic / sec / 1e9 / peak, 4)
@@ -298,8 +329,10 @@ def parity_leg(model, arena, corpus, local_ids, n_qubits, n_check=10):
                 want.append(ref(t("noisy"), t("observable"), t("depth"), x, torch.from_numpy(host["edge_index"][g]),
                                 torch.zeros(x.shape[0], dtype=torch.long)).double())
         err = (got - torch.cat(want)).abs()
-        out[name] = {"mae": float(err.mean()), "max": float(err.max())}
-    return {"circuits": int(n_check), "tolerance": 1e-5, "exp_val_mae_vs_cpu_f64": out["f64"]["mae"],
+        out[name] = {"mae": float(err.mean()), "max": float(err.max()), "want": torch.cat(want)}
+    cpu_gap = float((out["f32"]["want"] - out["f64"]["want"]).abs().max())     # the fp32 CPU path's own distance from exact
+    return {"circuits": int(n_check), "tolerance": 1e-5, "criterion": "1e-5 vs fp64-exact",
+            "cpu_f32_max_abs_err_vs_cpu_f64": cpu_gap, "exp_val_mae_vs_cpu_f64": out["f64"]["mae"],
             "max_abs_err_vs_cpu_f64": out["f64"]["max"], "within_tolerance_of_exact": out["f64"]["max"] < 1e-5,
             "exp_val_mae_vs_cpu_f32": out["f32"]["mae"], "max_abs_err_vs_cpu_f32": out["f32"]["max"],
             "prediction_scale": float(got.abs().mean()),
@@ -1136,6 +1169,126 @@ def small_batch_leg(dev, steps=300):
     return out
 
 
+HEADLINE_MAX_BYTES = 8192     # the driver keeps ~11 KB of stdout tail; the r05 line (22.8 KB) came back unparsed
+FULL_RECORD = os.path.join("gpurun_out", "bench_full.json")
+
+# one scalar per BASELINE.json config: (key in the headline record, path into the full record)
+FLAT_KEYS = {"cfg1_mlp1_169_circuits_per_s": ("configs", "cfg1_mlp1_169", "circuits_per_s"),
+             "cfg2_family_a_batch32_circuits_per_s": ("small_batch", "hipgraph", "circuits_per_s"),
+             "cfg2_family_b_batch32_circuits_per_s": ("family_b", "batch32_stratified_hipgraph", "circuits_per_s"),
+             "cfg2_family_b_batch32_shuffled_circuits_per_s": ("family_b", "batch32_shuffled_hipgraph", "circuits_per_s"),
+             "cfg3_family_a_circuits_per_s": ("configs", "cfg3_random_20q", "family_a", "circuits_per_s"),
+             "cfg3_family_b_circuits_per_s": ("configs", "cfg3_random_20q", "family_b", "circuits_per_s"),
+             "cfg4_family_b_best_circuits_per_s": ("family_b", "cfg4_100q", "best_circuits_per_s"),
+             "cfg4_family_b_batch64_ms_per_step": ("family_b", "cfg4_100q", "ms_per_step"),
+             "cfg5_family_a_circuits_per_s": ("configs", "cfg5_mixed", "family_a_f32", "circuits_per_s"),
+             "cfg5_family_b_bf16_head_circuits_per_s": ("configs", "cfg5_mixed", "family_b_mlp3_head_bf16", "circuits_per_s"),
+             "mlp3_head_f32_ms_per_step": ("mlp_head", "mlp3_170_125_1_f32", "ms_per_step"),
+             "mlp3_head_bf16_ms_per_step": ("mlp_head", "mlp3_170_125_1_bf16", "ms_per_step")}
+
+
+def _dig(node, path):
+    for part in path:
+        node = node.get(part) if isinstance(node, dict) else None
+    return node
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 1] + "~"
+
+
+def headline_record(full):
+    """The compact record the driver parses (the LAST stdout line): the contract keys, ``roofline`` re-based on the step's
+    dominant kernel IN the step, ``cpu_baseline``, the parity scalars with the criterion spelt out, and one scalar per
+    BASELINE.json config.  Scalars and short strings only; every leg's full output goes to FULL_RECORD and to an earlier
+    stdout line.  Pure function of the full record (tests/test_bench_cli.py builds one from canned legs)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    rec = {k: full[k] for k in keep if k in full}
+    cfg = full.get("config", {})
+    host = cfg.get("host_ms_between_graph_replays_per_rank")
+    rec["config"] = {
+        "workload": _short(cfg.get("workload", ""), 160),
+        "circuits_per_step_per_gpu": cfg.get("circuits_per_step_per_gpu"), "global_circuits_per_step": cfg.get("global_circuits_per_step"),
+        "corpus_circuits": cfg.get("corpus_circuits"), "corpus_circuits_per_gpu": cfg.get("corpus_circuits_per_gpu"),
+        "nodes_per_step_per_gpu": cfg.get("nodes_per_step_per_gpu"),
+        "parallelism": cfg.get("parallelism"), "step_mode": _short(cfg.get("step_mode", ""), 80), "backend": cfg.get("backend"),
+        "ranks_joined": cfg.get("ranks_joined"), "collective": _short(cfg.get("collective"), 120) if cfg.get("collective") else None,
+        "host_ms_between_graph_replays_per_rank": (round(max(host), 4) if isinstance(host, (list, tuple)) and host else host),
+        "gradient_floats_all_reduced": cfg.get("gradient_floats_all_reduced"), "rccl_version": cfg.get("rccl_version")}
+    for k in ("ms_per_step_p10", "ms_per_step_p50", "ms_per_step_p90", "final_loss", "host_enqueue_ms_per_step"):
+        if k in full:
+            rec[k] = full[k]
+    rf = full.get("roofline")
+    if rf:
+        dom = rf.get("step_dominant")
+        out = {"bound": rf.get("bound"), "peak": rf.get("peak"), "unit": rf.get("unit")}
+        if dom:
+            out.update({"kernel": dom["kernel"], "achieved": dom["achieved"], "frac": dom["frac"],
+                        "bytes_per_launch": dom["bytes_per_launch"], "us_per_launch": dom["us_per_launch"],
+                        "launches_per_step": dom["launches_per_step"],
+                        "basis": "the step-dominant instantiation (pooled epilogue form) timed IN an eager single-stream train "
+                                 "step with HIP events on its stream; ALGORITHMIC bytes (SURVEY 8d B_agg), mean of its launches",
+                        "traffic": dom.get("traffic"), "traffic_source": dom.get("traffic_source")})
+        else:           # N > 1 (no arena leg): the plain instantiation alone, labelled as such
+            out.update({"kernel": _short(rf.get("kernel", ""), 60), "achieved": rf.get("achieved"), "frac": rf.get("frac"),
+                        "bytes_per_launch": rf.get("bytes_per_launch"), "us_per_launch": rf.get("us_per_launch"),
+                        "basis": "plain instantiation timed alone with rotated buffers (no in-step leg at N > 1)",
+                        "traffic": rf.get("traffic")})
+        out["nodes"], out["edges_with_loops"] = rf.get("nodes"), rf.get("edges_with_loops")
+        out["frac_isolated_plain"] = rf.get("frac")
+        out["us_isolated_plain"] = rf.get("us_per_launch")
+        out["traffic_isolated_plain"] = rf.get("traffic")
+        out["hbm_frac_isolated_plain"] = rf.get("hbm_frac")
+        out["in_step_all_aggregations_frac"] = _dig(rf, ("in_step_all_aggregations", "frac"))
+        out["measured_copy_GBps"] = rf.get("measured_copy_GBps")
+        out["measured_add_GBps"] = rf.get("measured_add_GBps")
+        rec["roofline"] = out
+    cb = full.get("cpu_baseline")
+    if cb:
+        rec["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": _short(cb.get("sample", ""), 200), "batch32_ms_per_step": cb.get("batch32_ms_per_step")}
+    pr = full.get("parity")
+    if pr:
+        rec["parity"] = {"criterion": "max |device - fp64 oracle| < 1e-5 (fp64 = the exact value of the reference's expression); "
+                                      "the reference's own fp32 CPU arithmetic is reported beside it",
+                         "oracle_pin": "Family A (this workload): no reference-held artefact exists, oracle pinned by dense algebra "
+                                       "only; Family B / MLP oracles pinned by the reference's goldens 0.117838 / 0.032910",
+                         "circuits": pr.get("circuits"), "tolerance": pr.get("tolerance"),
+                         "max_abs_err_vs_cpu_f64": pr.get("max_abs_err_vs_cpu_f64"), "exp_val_mae_vs_cpu_f64": pr.get("exp_val_mae_vs_cpu_f64"),
+                         "max_abs_err_vs_cpu_f32": pr.get("max_abs_err_vs_cpu_f32"),
+                         "cpu_f32_own_gap_vs_f64": pr.get("cpu_f32_max_abs_err_vs_cpu_f64"),
+                         "within_tolerance_of_exact": pr.get("within_tolerance_of_exact")}
+    for key, path in FLAT_KEYS.items():
+        v = _dig(full, path)
+        if isinstance(v, (int, float)):
+            rec[key] = v
+    rec["full_record"] = FULL_RECORD
+    return rec
+
+
+def emit(full):
+    """stdout: ONE JSON line, the headline record (the task's contract: "rank 0 prints ONE JSON line").  The full record of
+    every leg lands in gpurun_out/bench_full.json (best effort: the directory may not be writable where the driver runs);
+    MLQEM_BENCH_FULL_STDOUT=1 also prints it as an EARLIER stdout line (scripts/refresh_profiles.sh reads it from there)."""
+    try:
+        os.makedirs(os.path.join(ROOT, os.path.dirname(FULL_RECORD)), exist_ok=True)
+        with open(os.path.join(ROOT, FULL_RECORD), "w") as fh:
+            json.dump(full, fh, indent=1)
+    except OSError as exc:
+        progress(f"could not write {FULL_RECORD}: {exc}")
+    head = headline_record(full)
+    text = json.dumps(head)
+    if len(text) > HEADLINE_MAX_BYTES:          # never again a line the driver cannot parse: drop the optional scalars
+        for k in list(FLAT_KEYS) + ["parity"]:
+            head.pop(k, None)
+        text = json.dumps(head)
+    if os.environ.get("MLQEM_BENCH_FULL_STDOUT", "0") == "1":
+        print(json.dumps(dict(full, record="full (every leg); the headline record is the next and last line")), flush=True)
+    print(text, flush=True)
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run.  Nothing in
     this process has touched the GPU (torch.cuda.device_count() does not initialise it on this image); the parent only
@@ -1330,24 +1483,8 @@ def main():
                     continue
                 progress(f"{key} leg")
                 line[key] = leg(dev)
-            # one scalar per BASELINE.json config at the top level (a driver that keeps only scalar keys keeps these)
-            flat = {"cfg1_mlp1_169_circuits_per_s": ("configs", "cfg1_mlp1_169", "circuits_per_s"),
-                    "cfg2_family_a_batch32_circuits_per_s": ("small_batch", "hipgraph", "circuits_per_s"),
-                    "cfg2_family_b_batch32_circuits_per_s": ("family_b", "batch32_stratified_hipgraph", "circuits_per_s"),
-                    "cfg3_family_a_circuits_per_s": ("configs", "cfg3_random_20q", "family_a", "circuits_per_s"),
-                    "cfg3_family_b_circuits_per_s": ("configs", "cfg3_random_20q", "family_b", "circuits_per_s"),
-                    "cfg4_family_b_best_circuits_per_s": ("family_b", "cfg4_100q", "best_circuits_per_s"),
-                    "cfg4_family_b_batch64_ms_per_step": ("family_b", "cfg4_100q", "ms_per_step"),
-                    "cfg5_family_a_circuits_per_s": ("configs", "cfg5_mixed", "family_a_f32", "circuits_per_s"),
-                    "cfg5_family_b_bf16_head_circuits_per_s": ("configs", "cfg5_mixed", "family_b_mlp3_head_bf16", "circuits_per_s")}
-            for key, path in flat.items():
-                node = line
-                for part in path:
-                    node = node.get(part) if isinstance(node, dict) else None
-                if node is not None:
-                    line[key] = node
             progress("done")
-        print(json.dumps(line), flush=True)
+        emit(line)
     if distributed:
         torch.distributed.barrier()  # rank 0 is still in its roofline leg: leave together
         torch.distributed.destroy_process_group()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/bench_line.json                     one default `python bench.py` run
+#   gpurun_out/bench_line.json, bench_full.json    one default `python bench.py` run: the headline line and every leg's record
 #   gpurun_out/bench_kernel_stats.csv              rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline`, SINGLE STREAM
 #                                                  (MLQEM_SINGLE_STREAM=1: kernels run one after the other, so a kernel's average
 #                                                  duration is its own) + the roofline leg's launches broken out of the trace
@@ -13,6 +13,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# the headline record (bench.py's one stdout line); the full record of every leg is written by bench.py to gpurun_out/bench_full.json
 timeout 900 python3 "$ROOT/bench.py" 2>/dev/null | grep '{"metric"' > "$OUT/bench_line.json"
 
 summarise() {  # $1 = rocprof output dir, $2 = log, $3 = output csv, $4 = label

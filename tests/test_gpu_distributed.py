@@ -120,6 +120,8 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1                                    # rank 0 only
+    # the headline record is the LAST stdout line, parses, and is small enough for the driver's stdout window
+    assert out.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 8192
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["value"] > 0
     cfg = rec["config"]
