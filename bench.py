@@ -1170,7 +1170,7 @@ def small_batch_leg(dev, steps=300):
 
 
 HEADLINE_MAX_BYTES = 8192     # the driver keeps ~11 KB of stdout tail; the r05 line (22.8 KB) came back unparsed
-FULL_RECORD = os.path.join("gpurun_out", "bench_full.json")
+FULL_RECORD = os.environ.get("MLQEM_BENCH_FULL_RECORD", os.path.join("gpurun_out", "bench_full.json"))
 
 # one scalar per BASELINE.json config: (key in the headline record, path into the full record)
 FLAT_KEYS = {"cfg1_mlp1_169_circuits_per_s": ("configs", "cfg1_mlp1_169", "circuits_per_s"),

@@ -260,6 +260,7 @@ def prepare_device(device):
             raise RuntimeError("the ticket pool must exist before a capture begins: run a warm-up step or ops.prepare_device(device) first")
         # a fill, not torch.zeros (which may be recorded as a memset node): the form `loops` uses
         pool = _ticket_pools[device] = (torch.full((_TICKET_SLOTS,), 0, dtype=torch.int32, device=device), {})
+        _overflow_flag(device)               # the sticky capacity-overflow flag: same rule, it must exist before any capture
     return pool
 
 
@@ -1516,35 +1517,50 @@ def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
     out_eid = mk(e) if link else None       # link=False: no out_eid (the recomputed backward forms need none)
     loops = torch.full((max(k, 1),), 0, dtype=torch.int32, device=dev)      # a fill kernel, not a memset node (the call may be captured)
     if k > 0:
-        # with a capacity bound nothing is read back: a list that would leave its buffer is dropped by the kernels, which raise this
-        # flag -- read lazily (check_overflow_flags: epoch ends, MLQEM_SYNC_OPS, tests), so a truncated graph cannot pass unnoticed
-        flag = torch.full((1,), 0, dtype=torch.int32, device=dev)
+        # with a capacity bound nothing is read back: a list that would leave its buffer is dropped by the kernels, which OR this
+        # device's STICKY flag -- read (and reset) lazily (check_overflow_flags: epoch ends, every 256 steps of step_ids,
+        # MLQEM_SYNC_OPS, tests), so a truncated graph cannot pass unnoticed, in an eager step or in any replay of a captured one
+        flag = _overflow_flag(dev)
         code = lib.mlqem_asap_coarsen_lists_fill(num_nodes, k, int(num_edges), cap, _p(in_ptr), _p(out_ptr), _p(in_src), _p(out_dst),
                                                  _p(out_eid), e, _p(flag), _p(ws), need, _stream())
         _lib.check(code, "mlqem_asap_coarsen_lists_fill")
-        _note_overflow_flag(flag, f"mlqem_asap_coarsen_lists_fill: a list outgrew the capacity {cap} (k = {k} clusters)")
+        _overflow_what[flag.device] = f"mlqem_asap_coarsen_lists_fill: a list outgrew its capacity (last launch: capacity {cap}, k = {k} clusters)"
+        if _lib._SYNC_OPS:
+            check_overflow_flags()
     return CsrArrays(in_ptr, in_src[:e], out_ptr, out_dst[:e], loops[:k], None if out_eid is None else out_eid[:e]), slot, e
 
 
-_overflow_flags = []      # (device int32 flag, what it means): at most 64 recent ones
+# One persistent int32 flag per device that the capacity-bound kernels atomicOr into.  It is allocated (zero) OUTSIDE any capture and
+# never re-zeroed inside one: a flag raised by the 500th replay of a captured step is still set when the host looks (the
+# per-launch flags of rounds 4-5 were registered at capture time only and capped at the 64 most recent launches).
+_overflow_sticky = {}     # device -> int32[1]
+_overflow_what = {}       # device -> what the last launch that could raise it was
 
 
-def _note_overflow_flag(flag, what):
-    _overflow_flags.append((flag, what))
-    if len(_overflow_flags) > 64:
-        del _overflow_flags[0]
-    if _lib._SYNC_OPS:
-        check_overflow_flags()
+def _overflow_flag(device):
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    flag = _overflow_sticky.get(device)
+    if flag is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the overflow flag must exist before a capture begins: run the step eagerly once (or ops.prepare_device) first")
+        flag = _overflow_sticky[device] = torch.full((1,), 0, dtype=torch.int32, device=device)
+    return flag
 
 
 def check_overflow_flags():
-    """Reads (one host sync) the overflow flags the capacity-bound kernels left since the last call and raises if one is set."""
-    flags, _overflow_flags[:] = list(_overflow_flags), []
-    if not flags or torch.cuda.is_current_stream_capturing():
-        _overflow_flags[:] = flags
+    """Reads (one host sync per device that launched a capacity-bound kernel) the sticky overflow flags, resets them and raises if one
+    was set since the last call.  A no-op while a capture is in progress."""
+    if not _overflow_sticky or torch.cuda.is_current_stream_capturing():
         return
-    raised = torch.stack([f[0] for f, _ in flags]).cpu().tolist()
-    bad = [what for (_, what), v in zip(flags, raised) if v != 0]
+    bad = []
+    for device, flag in _overflow_sticky.items():
+        if device not in _overflow_what:
+            continue                                  # no capacity-bound launch was ever enqueued (or captured) on this device
+        if int(flag.item()) != 0:                     # (the entry stays: replays of a captured step raise the flag without the host)
+            flag.zero_()
+            bad.append(_overflow_what[device])
     if bad:
         raise _lib.NativeLibraryError("capacity overflow on the device: " + "; ".join(sorted(set(bad))))
 

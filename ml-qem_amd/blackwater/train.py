@@ -600,6 +600,7 @@ class BucketedTrainer(Trainer):
         self._pattern_model = bool(getattr(model, "needs_size_pattern", False))
         self.max_pattern_captures = int(os.environ.get("MLQEM_MAX_PATTERN_CAPTURES", "64"))
         self._seen = {}
+        self.overflow_check_every = 256
 
     def bucket_of(self, graph_ids):
         sel = np.asarray(graph_ids, dtype=np.int64)
@@ -662,6 +663,13 @@ class BucketedTrainer(Trainer):
     def step_ids(self, graph_ids) -> torch.Tensor:
         """One optimisation step on the graphs ``graph_ids`` of the arena; returns the loss (a device tensor that the
         NEXT step of the same bucket overwrites in graph mode: read or clone it before stepping again)."""
+        self._steps_taken = getattr(self, "_steps_taken", 0) + 1
+        if self._steps_taken % self.overflow_check_every == 0:
+            # loops that call step_ids directly never reach fit()'s epoch-end check: the device's sticky capacity-overflow flag is read
+            # here every so often (one 4-byte read; nothing at all unless a capacity-bound kernel was ever launched on this device)
+            from .native import ops as _ops
+
+            _ops.check_overflow_flags()
         bucket = self.bucket_of(graph_ids)
         sel, nptr, eptr, nb, eb, real = self.arena.selection(graph_ids, bucket[:2])
         host = np.concatenate([sel, nptr, eptr]).astype(np.int32)

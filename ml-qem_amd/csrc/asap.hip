@@ -318,8 +318,10 @@ static inline void fill_i32(int32_t* p, int32_t v, int64_t n, hipStream_t stream
   if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(n, (int64_t)kBlock)), dim3(kBlock), 0, stream, p, v, n);
 }
 
-__global__ void copy_flag_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
+// The caller's overflow flag is STICKY: a launch ORs its own flag into it and never clears it, so a flag raised by any replay of a
+// captured step is still there when the host reads it (and resets it) at the end of an epoch.
+__global__ void or_flag_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *src != 0) atomicOr(dst, *src);
 }
 
 __global__ __launch_bounds__(kBlock) void slot_map_kernel(const int32_t* __restrict__ perm, int64_t K,
@@ -1697,7 +1699,7 @@ extern "C" int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t E, in
   if (edge_capacity > 0 && new_out_eid)
     hipLaunchKernelGGL(coarsen_lists_link_kernel, dim3((unsigned)(device_cus() * 8)), dim3(kBlock), 0, stream, new_in_ptr, new_in_src,
                        new_out_dst, out_row, new_out_ptr + K, edge_capacity, new_out_eid);
-  if (overflow) hipLaunchKernelGGL(copy_flag_kernel, dim3(1), dim3(64), 0, stream, q.flag, overflow);
+  if (overflow) hipLaunchKernelGGL(or_flag_kernel, dim3(1), dim3(64), 0, stream, q.flag, overflow);
   return launch_status();
 }
 

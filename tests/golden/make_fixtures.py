@@ -20,6 +20,8 @@ Outputs (all data, no source):
                                  (docs/tutorials/model/ising_init_from_qasm_no_readout/{gnn1,mlp1_smaller_2}.pk)
   ckpt/*.pth                     reference state-dicts (one per architecture used by the parity tests)
   ckpt_manifest.json             key -> shape for all 63 reference checkpoints (strict-load test)
+  g4_digest.json                 tally + digests of ALL 1 100 QASM -> graph pairs of
+                                 docs/tutorials/data/mbd_datasets2/theta_0.05pi/ run through the Python and the C++ encoder
 """
 import datetime
 import glob
@@ -35,6 +37,7 @@ import torch
 REF = "/root/reference"
 TUT = os.path.join(REF, "docs/tutorials")
 OUT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(OUT))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -205,6 +208,96 @@ def make_encoder_goldens():
     print("encoder goldens:", len(out))
 
 
+G4_FILES = ["train/step_0.json", "val/step_0.json", "val/step_1.json", "val/step_2.json"]
+
+
+def g4_pair_check(entry, lima_props, native_by_order):
+    """One QASM -> graph pair of golden G4 through BOTH encoders of the build.  Returns (python_ok, native_ok, digest, pair name): the Python
+    encoder against the stored graph (edges, edge_attr and every non-angle column exactly; angles within 1e-9: the stored QASM prints
+    angles near k pi / n symbolically), the C++ encoder against the Python one bit for bit, and the sha256 of the native arrays."""
+    import hashlib
+
+    import numpy as np
+
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd"), os.path.join(ROOT, "tests")]
+    from blackwater.data.circuit import Circuit
+    from blackwater.data.native_encoder import NativeEncoder
+    from blackwater.data.utils import circuit_to_graph_data_json
+    from helpers import infer_gates_order
+
+    circ = Circuit.from_qasm_str(entry["circuit"])
+    want = entry["circuit_graph"]
+    props = dict(lima_props)
+    props["gates_set"] = infer_gates_order(circ, want["nodes"]["DAGOpNode"], lima_props["gates_set"])
+    got = circuit_to_graph_data_json(circ, props, use_gate_features=True, use_qubit_features=True)
+    a, b = np.array(got["nodes"]["DAGOpNode"]), np.array(want["nodes"]["DAGOpNode"])
+    py_ok = (got["edges"] == want["edges"] and got["nodes"]["DAGInNode"] == want["nodes"]["DAGInNode"]
+             and got["nodes"]["DAGOutNode"] == want["nodes"]["DAGOutNode"] and a.shape == b.shape
+             and bool(np.array_equal(a[:, 3:], b[:, 3:])) and float(np.abs(a[:, :3] - b[:, :3]).max()) < 1e-9
+             and circ.depth() == entry["circuit_depth"])
+    key = tuple(props["gates_set"])
+    enc = native_by_order.get(key)
+    if enc is None:
+        enc = native_by_order[key] = NativeEncoder(props)
+    x, ei, ea, depth = enc.encode(entry["circuit"])
+    wires = got["edges"]["DAGOpNode_wire_DAGOpNode"]
+    nat_ok = (bool(np.array_equal(x, a)) and bool(np.array_equal(ei, np.array(wires["edge_index"])))
+              and bool(np.array_equal(ea, np.array(wires["edge_attr"]))) and depth == entry["circuit_depth"])
+    h = hashlib.sha256()
+    h.update(entry["circuit"].encode())
+    h.update(",".join(props["gates_set"]).encode())
+    for arr, dt in ((x, np.float64), (ei, np.int64), (ea, np.float64)):
+        h.update(np.ascontiguousarray(arr, dtype=dt).tobytes())
+    # the pair's name: the text AND the one-hot column order of its stored graph (hash-random per generation run in the reference:
+    # the same circuit text occurs with different orders)
+    name = hashlib.sha256((entry["circuit"] + "|" + ",".join(props["gates_set"])).encode()).hexdigest()
+    return py_ok, nat_ok, h.hexdigest(), name
+
+
+def compute_g4_digest():
+    """ALL 1 100 QASM -> graph pairs the reference holds through the Python and the C++ encoder, here in the
+    build container; what is committed is the tally and one digest per file (and per pair for the 30 committed pairs), which
+    tests/test_encoder_goldens.py compares against -- the pairs themselves (13 MB of JSON) stay in the reference."""
+    import hashlib
+
+    base = os.path.join(TUT, "data/mbd_datasets2/theta_0.05pi")
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
+    from blackwater.data.backends import StaticBackend
+    from blackwater.data.utils import get_backend_properties_v1
+
+    lima = get_backend_properties_v1(StaticBackend.from_json(os.path.join(OUT, "fake_lima_backend_props.json")))
+    with open(os.path.join(OUT, "encoder_goldens.json")) as fh:
+        committed = {e["circuit"] for e in json.load(fh)}
+    native, files, committed_digests = {}, {}, {}
+    tot = py = nat = 0
+    for rel in G4_FILES:
+        data = json.load(open(os.path.join(base, rel)))
+        fh_ = hashlib.sha256()
+        n_py = n_nat = 0
+        for e in data:
+            p_ok, n_ok, dig, name = g4_pair_check(e, lima, native)
+            n_py += p_ok
+            n_nat += n_ok
+            fh_.update(bytes.fromhex(dig))
+            if e["circuit"] in committed:
+                committed_digests[name] = dig
+        files["docs/tutorials/data/mbd_datasets2/theta_0.05pi/" + rel] = {"pairs": len(data), "python_encoder_matches": n_py,
+                                                                          "native_encoder_matches": n_nat, "sha256_of_pair_digests": fh_.hexdigest()}
+        tot, py, nat = tot + len(data), py + n_py, nat + n_nat
+    out = {"what": "golden G4: every QASM -> circuit_graph pair the reference stores, through the build's Python encoder (vs the stored "
+                   "graph) and C++ encoder (vs the Python one), run by tests/golden/make_fixtures.py make_g4_digest() in the build container",
+           "pairs": tot, "python_encoder_matches": py, "native_encoder_matches": nat, "files": files,
+           "committed_pair_digests": committed_digests}
+    return out
+
+
+def make_g4_digest():
+    out = compute_g4_digest()
+    with open(os.path.join(OUT, "g4_digest.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("G4:", out["pairs"], "pairs; python", out["python_encoder_matches"], "native", out["native_encoder_matches"])
+
+
 def make_ckpts():
     keep = {
         "model/ising_init_from_qasm_no_readout/gnn1.pth": "gnn1.pth",
@@ -233,4 +326,5 @@ if __name__ == "__main__":
     make_g1()
     make_trainval()
     make_encoder_goldens()
+    make_g4_digest()
     make_ckpts()

@@ -30,6 +30,33 @@ def test_json_goldens_bit_exact(golden_dir, lima_props):
         assert circ.depth() == e["circuit_depth"]
 
 
+def test_g4_all_1100_reference_pairs_digest(golden_dir, lima_props):
+    """the reference stores 1 100 QASM -> circuit_graph pairs; 30 are committed in full
+    (test_json_goldens_bit_exact), ALL of them were run through the Python and the C++ encoder in the build container and the tally
+    and digests committed (tests/golden/g4_digest.json, written by make_fixtures.make_g4_digest).  Here: the tally is complete, the
+    committed pairs still hash to their digests through both encoders, and -- where the reference checkout is present (the build
+    container; never the GPU box) -- the whole run is repeated and must reproduce the committed digests."""
+    import sys
+
+    sys.path.insert(0, golden_dir)
+    import make_fixtures as mf
+
+    with open(os.path.join(golden_dir, "g4_digest.json")) as fh:
+        dig = json.load(fh)
+    assert dig["pairs"] == dig["python_encoder_matches"] == dig["native_encoder_matches"] == 1100
+    assert [f["pairs"] for f in dig["files"].values()] == [500, 200, 200, 200]
+    assert all(f["python_encoder_matches"] == f["native_encoder_matches"] == f["pairs"] for f in dig["files"].values())
+    entries = json.load(open(os.path.join(golden_dir, "encoder_goldens.json")))
+    native = {}
+    for e in entries:
+        py_ok, nat_ok, d, name = mf.g4_pair_check(e, lima_props, native)
+        assert py_ok and nat_ok
+        assert dig["committed_pair_digests"][name] == d
+    if os.path.isdir(os.path.join(mf.TUT, "data/mbd_datasets2/theta_0.05pi")):
+        again = mf.compute_g4_digest()
+        assert again["files"] == dig["files"] and again["committed_pair_digests"] == dig["committed_pair_digests"]
+
+
 def test_g1_circuits_bit_exact(g1, lima_props):
     props = dict(lima_props)
     props["gates_set"] = G1_GATES_ORDER

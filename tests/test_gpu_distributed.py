@@ -112,7 +112,8 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MLQEM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MLQEM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               MLQEM_BENCH_FULL_RECORD=os.path.join("gpurun_out", "bench_full_rehearsal.json"))     # not over a real run's record
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32"]

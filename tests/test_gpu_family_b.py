@@ -72,6 +72,47 @@ def test_other_reference_architectures(golden_dir, g1, name):
     assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
+def _widen_features(x, width):
+    """The G1 graphs (F = 22: FakeLima's six gates) as graphs of a backend with more gates: zero one-hot columns inserted after the
+    existing gate columns, the way `circuit_to_graph_data_json` lays a wider gates_set out (blackwater/data/utils.py:214-222)."""
+    out = np.zeros((x.shape[0], width), dtype=x.dtype)
+    out[:, :11] = x[:, :11]
+    out[:, width - 11:] = x[:, 11:]
+    return out
+
+
+def test_iskandar_checkpoint_f28_hidden20_on_gpu(golden_dir, g1):
+    """The reference's lima-backend checkpoint (docs/tutorials/model/finetuning/iskandar.pth: F = 28, hidden 20, heads 3/2 ->
+    60 / 40 channels, one output; 03_experiments_on_lima_backend.ipynb): a 28 -> 60 -> 40 model on the device against the fp64
+    oracle, per circuit (inference convention) and batched with self-loops (training convention), outputs and every gradient."""
+    from blackwater.nn import family_b_from_state_dict
+    from oracle.models import family_b_from_state_dict as oracle_from_sd
+
+    sd = _ckpt(golden_dir, "iskandar.pth")
+    assert sd["transformer1.lin_key.weight"].shape == (60, 28) and sd["body_seq.0.weight"].shape == (20, 42)
+    wide = dict(g1)
+    wide["x"] = _widen_features(g1["x"], 28)
+    wide["noisy"] = g1["noisy"][:, :1]
+    wide["ideal"] = g1["ideal"][:, :1]
+    model = family_b_from_state_dict(sd).to(DEV).eval()
+    idx = range(0, 300, 5)
+    got, want = _gpu_outputs(model, wide, idx), _oracle_outputs(sd, wide, idx)
+    assert got.shape == (60, 1) and np.abs(got - want).max() < 1e-5
+    ref = oracle_from_sd(sd).double().eval()
+    batch = g1_batch(wide, range(40, 72), self_loops=True, first_only=False)
+    out = model(batch["noisy"].to(DEV), None, batch["depth"].to(DEV), batch["x"].to(DEV), batch["edge_index"].to(DEV), batch["batch"].to(DEV))
+    torch.nn.functional.mse_loss(out, batch["y"].to(DEV)).backward()
+    ref_out = ref(batch["noisy"].double(), None, batch["depth"].double(), batch["x"].double(), batch["edge_index"], batch["batch"])
+    assert (out.detach().cpu().double() - ref_out.detach()).abs().max().item() < 1e-5
+    torch.nn.functional.mse_loss(ref_out, batch["y"].double()).backward()
+    ref_grads = {k: p.grad for k, p in ref.named_parameters()}
+    overall = max(g.abs().max().item() for g in ref_grads.values())
+    for name, p in model.named_parameters():
+        scale = max(ref_grads[name].abs().max().item(), 1e-3 * overall)
+        err = (p.grad.cpu().double() - ref_grads[name]).abs().max().item() / scale
+        assert err < 2e-4, f"{name}: relative gradient error {err}"
+
+
 def test_batched_with_self_loops_matches_oracle(golden_dir, g1):
     """The training-time convention: AddSelfLoops + collate (the attention then includes the self-loop)."""
     from blackwater.nn import family_b_from_state_dict
@@ -474,6 +515,45 @@ def test_list_coarsening_raises_its_overflow_flag_when_the_capacity_is_no_bound(
     with pytest.raises(_lib.NativeLibraryError, match="capacity overflow"):
         ops.check_overflow_flags()
     ops.check_overflow_flags()                         # read once, cleared
+
+
+def test_overflow_flag_is_sticky_across_replays_of_a_captured_launch():
+    """a captured step registers nothing on the host when it is replayed, so the flag its kernels raise must be ONE
+    persistent per-device word that launches OR into and only the host's check resets: every replay that overflows is seen, not
+    only the launch that was enqueued (or captured) by the Python wrapper."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import TfimCorpus
+    from blackwater.native import _lib, ops
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    h = TfimCorpus(100, [2, 5], 1, seed=5, exp_value_size=4).host_graphs()
+    arena = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"], device=DEV)
+    batch = arena.batch(np.arange(len(arena)))
+    s = batch.structure
+    torch.manual_seed(2)
+    model = ExpValCircuitGraphModel(22, 15).to(DEV).eval()
+    ops.check_overflow_flags()
+    with torch.no_grad():
+        g = model.transformer1(batch.nodes, s)
+        s.coarse_capacity = 4096                       # far below the real edge total
+        _, s1, _ = model.pooling1(g, s)
+        s1.in_ptr                                      # the eager pass (it also leaves the pooled graph boundaries on the device)
+    with pytest.raises(_lib.NativeLibraryError, match="capacity overflow"):
+        ops.check_overflow_flags()
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(graph, stream=side):
+        with torch.no_grad():
+            _, s1, _ = model.pooling1(g, s)
+            s1.in_ptr
+    ops.check_overflow_flags()                         # a capture runs nothing: the flag is still clear
+    for _ in range(3):                                 # every replay raises it again, with no host-side registration in between
+        graph.replay()
+        graph.replay()
+        with pytest.raises(_lib.NativeLibraryError, match="capacity overflow"):
+            ops.check_overflow_flags()
+        ops.check_overflow_flags()                     # read once, reset
 
 
 def test_family_b_train_step_makes_no_device_to_host_copy(golden_dir, g1):
