@@ -43,7 +43,7 @@ def _host_batch(corpus, sel, exp_3d=False):
                 edge_index=torch.cat(eis, 1), batch=torch.cat(bs), y=y)
 
 
-def _check_family_a(corpus, nq, sel):
+def _check_family_a(corpus, nq, sel, tag=None):
     from blackwater.nn import ExpValCircuitGraphModelA
     from oracle.models import FamilyA
 
@@ -56,7 +56,21 @@ def _check_family_a(corpus, nq, sel):
     keys = ("noisy", "observable", "depth", "x", "edge_index", "batch")
     out = model(*[hb[k].to(DEV) for k in keys])
     want = ref(*[hb[k].double() if hb[k].is_floating_point() else hb[k] for k in keys])
-    assert (out.detach().cpu().double() - want.detach()).abs().max().item() < 1e-5
+    err = (out.detach().cpu().double() - want.detach()).abs().max().item()
+    # north_star's literal bar: 1e-5 against the reference's fp32 CPU arithmetic (the same oracle module in fp32), next to the
+    # criterion the repo states (1e-5 against the exact, fp64, value) and the CPU path's own distance from exact
+    ref32 = FamilyA(nq, 22, 10).eval()
+    ref32.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        want32 = ref32(*[hb[k] for k in keys])
+    err32 = (out.detach().cpu() - want32).abs().max().item()
+    fp32_gap = (want32.double() - want.detach()).abs().max().item()
+    if tag:
+        _record(tag, {"max_abs_gpu_minus_fp64_oracle": err, "max_abs_fp32_cpu_minus_fp64_oracle": fp32_gap,
+                      "max_abs_gpu_minus_fp32_cpu": err32, "bound_asserted": 1e-5, "north_star": 1e-5,
+                      "prediction_scale": float(want.detach().abs().max()), "nodes": int(hb["x"].shape[0]), "graphs": int(len(sel))})
+    assert err < 1e-5, (err, fp32_gap)
+    assert err32 < 1e-5, (err32, fp32_gap)         # holds on every small config (cfg4's 100-qubit graphs: tests/test_gpu_cfg4_parity.py)
     torch.nn.functional.mse_loss(out, hb["y"].to(DEV)).backward()
     torch.nn.functional.mse_loss(want, hb["y"].double()).backward()
     grads = {k: p.grad for k, p in ref.named_parameters()}
@@ -112,7 +126,7 @@ def test_cfg2_tfim_4q_gnn_batch32():
 
     corpus = tfim_corpus(4, list(range(0, 15)), 3, two_q="cx", exp_value_size=1)
     sel = np.arange(0, 45)[:32]
-    _check_family_a(corpus, 4, sel)
+    _check_family_a(corpus, 4, sel, tag="cfg2_family_a")
     corpus4 = tfim_corpus(4, list(range(0, 15)), 3, two_q="cx", exp_value_size=4)
     _check_family_b(corpus4, sel, 4, tag="cfg2_family_b_gnn1")
 
@@ -123,7 +137,7 @@ def test_cfg3_random_20q_depth40():
     circs = [random_circuit(20, 40, seed=s) for s in range(12)]
     corpus = encode_corpus(circs, 20, exp_value_size=1)
     assert 400 < corpus["x"][0].shape[0] < 900
-    _check_family_a(corpus, 20, np.arange(12))
+    _check_family_a(corpus, 20, np.arange(12), tag="cfg3_family_a")
     corpus4 = encode_corpus(circs, 20, exp_value_size=4)
     _check_family_b(corpus4, np.arange(12), 4, tag="cfg3_family_b_gnn1")
 
@@ -135,7 +149,7 @@ def test_cfg5_mixed_corpus_with_pauli_twirl():
     circs += [random_circuit(12, 20, seed=s) for s in range(3)]
     circs += [pauli_twirl(tfim_circuit(12, s, J=0.7, two_q="cx"), seed=s) for s in (2, 4)]
     corpus = encode_corpus(circs, 12, exp_value_size=1)
-    _check_family_a(corpus, 12, np.arange(len(circs)))
+    _check_family_a(corpus, 12, np.arange(len(circs)), tag="cfg5_family_a")
 
 
 def test_cfg1_mlp_on_v2_features():
