@@ -512,6 +512,40 @@ def family_b_leg(dev, steps=30):
                 "final_loss": round(float(last.item()), 6), "captures": len(bt._entries)}
             _ops.set_seed_counter(None)
             del bt
+    # ... and with the reference's loader ITSELF: DataLoader(batch_size=32, shuffle=True) (docs/tutorials/__ml_models.py:105) --
+    # uniformly shuffled epochs, the last short batch of an epoch dropped.  No size sequence repeats, but the size-stable buckets do
+    # (train.stable_padding: a few dozen for this corpus), each captured at first sight; the timed region starts after ten epochs.
+    for graphs in (False, True):
+        torch.manual_seed(0)
+        bt = BucketedTrainer(ExpValCircuitGraphModel(22, 15, 4).to(dev), arena_f, lr=1e-3, graphs=graphs, node_quantum=1024, edge_quantum=4096)
+        rng_s = np.random.RandomState(5)
+
+        def shuffled(n_batches):
+            done = 0
+            while done < n_batches:
+                order = rng_s.permutation(n_f)
+                for i in range(0, n_f - 31, 32):
+                    if done == n_batches:
+                        return
+                    done += 1
+                    yield order[i:i + 32]
+
+        for ids in shuffled(320 if graphs else 10):
+            bt.step_ids(ids)
+        torch.cuda.synchronize()
+        before = len(bt._entries)
+        n_steps = 12 * steps
+        t0 = time.perf_counter()
+        for ids in shuffled(n_steps):
+            last = bt.step_ids(ids)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["batch32_shuffled_%s" % ("hipgraph" if graphs else "eager")] = {
+            "circuits_per_s": round(32 * n_steps / dt, 1), "ms_per_step": round(dt / n_steps * 1e3, 3), "steps": n_steps,
+            "final_loss": round(float(last.item()), 6), "size_stable_buckets": bool(bt.stable), "captures": len(bt._entries),
+            "captures_made_inside_the_timed_region": len(bt._entries) - before, "capture_budget": bt.max_pattern_captures}
+        _ops.set_seed_counter(None)
+        del bt
     del arena_f
     # the same model on the headline workload's graphs (100-qubit circuits, 2-20 k nodes each): ASAPooling's coarsening takes the
     # wave-per-cluster form there (mlqem_asap_coarsen_rows_*: no sort, one host read per pooling) and is computed for the first

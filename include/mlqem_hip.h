@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 36 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 37 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -517,6 +517,13 @@ int mlqem_leconv_fitness_f32(const float* pqr, const int32_t* in_ptr, const int3
 /* out[p,:] = x[perm[p],:] * scale[perm[p]]  (x_out = x'[perm] * fitness[perm]; scale may be NULL). */
 int mlqem_gather_scale_rows_f32(const float* x, int64_t ldx, const int32_t* perm, const float* scale, int64_t K, int C,
                                 float* out, int64_t ldo, mlqem_stream_t stream);
+
+/* Boundaries of the pooled batch on the device (ABI 37): new_graph_ptr[0] = 0, new_graph_ptr[g + 1] = new_graph_ptr[g] +
+ * ceil((float)(graph_ptr[g + 1] - graph_ptr[g]) * ratio) -- the k of PyG's topk(x, ratio, batch) (torch_geometric
+ * nn/pool/topk_pool.py, called from ASAPooling, reference docs/tutorials/gnn.py:85,92), evaluated in float32 as there.  Replaces
+ * the host-side cumsum over per-graph sizes for batches whose sizes the host does not look at (size-stable captured steps).
+ * graph_ptr [B + 1], new_graph_ptr [B + 1] int32; 0 < ratio <= 1.  One small launch, no workspace, asynchronous on `stream`. */
+int mlqem_pool_keep_ptr(const int32_t* graph_ptr, int64_t B, float ratio, int32_t* new_graph_ptr, mlqem_stream_t stream);
 
 /* ASAPooling step 6 (PyG topk(fitness, ratio, batch)): for graph g keep its new_graph_ptr[g+1]-new_graph_ptr[g]
  * nodes of largest fitness, listed by descending fitness (ties: lower index first), graphs in order.

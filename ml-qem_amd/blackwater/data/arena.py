@@ -279,11 +279,13 @@ class GraphArena:
         self.node_counts, self.edge_counts, self.coarse_caps = other.node_counts, other.edge_counts, other.coarse_caps
         return True
 
-    def selection(self, graph_ids, bucket=None):
+    def selection(self, graph_ids, bucket=None, filler_sizes=None):
         """Host side of a batch: (sel, nptr, eptr, Nb, Eb, number of real graphs).  With ``bucket = (n_pad, e_pad)`` the
         batch is padded to exactly n_pad nodes by a slice of the filler graph (appended as one more, edgeless, graph) and
         Eb = e_pad is a capacity: every kernel of a step then launches with the same shapes for all selections that fit the
-        bucket -- what a captured hipGraph needs."""
+        bucket -- what a captured hipGraph needs.  ``filler_sizes``: pad with SEVERAL edgeless graphs of these sizes (slices of
+        the same filler; they must add up to n_pad minus the selection's nodes) instead of one: train.stable_padding sizes them
+        so that the node totals after each ASAPooling are functions of the bucket too."""
         sel = np.asarray(graph_ids, dtype=np.int64)
         b = int(sel.shape[0])
         if b == 0:
@@ -298,8 +300,11 @@ class GraphArena:
                 raise ValueError("bucketed batches need an arena built with filler_nodes > 0")
             if nb > n_pad or eb > e_pad or n_pad - nb > self.filler_nodes:
                 raise ValueError(f"selection ({nb} nodes, {eb} edges) does not fit bucket {bucket} (filler {self.filler_nodes})")
-            sel = np.concatenate([sel, [len(self)]])
-            n_of, e_of = np.concatenate([n_of, [n_pad - nb]]), np.concatenate([e_of, [0]])
+            fill = np.asarray([n_pad - nb] if filler_sizes is None else filler_sizes, dtype=np.int64)
+            if int(fill.sum()) != n_pad - nb or (filler_sizes is not None and (fill.min() < 1 or fill.max() > self.filler_nodes)):
+                raise ValueError(f"filler sizes {fill.tolist()} do not pad {nb} nodes to {n_pad}")
+            sel = np.concatenate([sel, np.full(len(fill), len(self), dtype=np.int64)])
+            n_of, e_of = np.concatenate([n_of, fill]), np.concatenate([e_of, np.zeros(len(fill), dtype=np.int64)])
         nptr = np.zeros(len(sel) + 1, dtype=np.int64)
         eptr = np.zeros(len(sel) + 1, dtype=np.int64)
         np.cumsum(n_of, out=nptr[1:])
@@ -324,7 +329,7 @@ class GraphArena:
                              sel, b_real, coarse_capacity=self.coarse_capacity(sel))
 
     def assemble(self, packed: torch.Tensor, b: int, nb: int, eb: int, graph_sizes, sel_host=None, num_real=None,
-                 coarse_capacity=None) -> DeviceBatch:
+                 coarse_capacity=None, pool_plan=None) -> DeviceBatch:
         """Device side of a batch: ``packed`` = [sel (b) | nptr (b + 1) | eptr (b + 1)] int32 on the device.  Nothing
         here reads a host value other than the shapes, so with a persistent ``packed`` buffer the whole call can sit
         inside a captured hipGraph and be replayed for another selection of the same bucket."""
@@ -352,6 +357,8 @@ class GraphArena:
                            colsums=(nscal_b[3, :nb], nscal_b[4, :nb], nscal_b[5, :nb]),
                            derived={"gcn_dself": derived_b[0, :nb], "sage_dself": derived_b[1, :nb], "cheb_neg": derived_b[2, :nb]})
         s.coarse_capacity = coarse_capacity
+        s.pool_plan = pool_plan           # size-stable batch: graph_sizes is None and the poolings go by this plan
+        s.num_real = num_real
         idx = sel_d.to(torch.int64)
         nodes = ops.RowsOf(self.x, src_node[:nb])     # the feature rows stay in the arena
         return DeviceBatch(nodes, s, self.y[idx], self.noisy[idx], self.depth[idx], self.observable[idx], sel_host, num_real)

@@ -106,6 +106,7 @@ SIGNATURES = {
     "mlqem_csr_softmax_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _F, _L, _I, _P, _L, _P]),
     "mlqem_leconv_fitness_f32": (_I, [_P, _P, _P, _L, _P, _P]),
     "mlqem_gather_scale_rows_f32": (_I, [_P, _L, _P, _P, _L, _I, _P, _L, _P]),
+    "mlqem_pool_keep_ptr": (_I, [_P, _L, _F, _P, _P]),
     "mlqem_segment_topk_workspace_bytes": (_S, [_L, _L]),
     "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_workspace_bytes": (_S, [_L]),
@@ -192,7 +193,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 36   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 37   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

@@ -880,25 +880,38 @@ class _ASAPool(Function):
             else:
                 x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
             fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3, out=torch.empty((n, 3), dtype=torch.float32, device=x.device)), s.in_ptr, s.in_src)
-        # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk (float32 tensor times a python scalar)
-        sizes = np.asarray(s.graph_sizes, dtype=np.int64)
-        keep = np.ceil(sizes.astype(np.float32) * np.float32(ratio)).astype(np.int64)
-        new_ptr_host = np.zeros(len(keep) + 1, dtype=np.int64)
-        np.cumsum(keep, out=new_ptr_host[1:])
-        k_total = int(new_ptr_host[-1])
-        new_ptr = _device_ptr(new_ptr_host.astype(np.int32), x.device)
-        perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=int(sizes.max()) if len(sizes) else 0)
+        plan = getattr(s, "pool_plan", None)
+        if plan:
+            # a size-stable batch (train.BucketedTrainer): the per-graph sizes stay on the device.  The pooled boundaries come from a
+            # launch, the number of kept nodes is a function of the bucket (the batch's filler graphs are sized for that), and the
+            # largest graph before / after pooling is known by a bound -- nothing here depends on the size SEQUENCE of the batch
+            k_total, nmax, kmax = (int(v) for v in plan[0])
+            new_ptr = ops.pool_keep_ptr(s.graph_ptr, s.num_graphs, ratio)
+            keep = {"b": s.num_graphs, "k": k_total, "kmax": kmax, "nmax": nmax}
+            sizes = None
+            have = s.num_graphs > 0
+        else:
+            # k_g = ceil(ratio * n_g) evaluated in float32 like PyG's topk (float32 tensor times a python scalar)
+            sizes = np.asarray(s.graph_sizes, dtype=np.int64)
+            keep = np.ceil(sizes.astype(np.float32) * np.float32(ratio)).astype(np.int64)
+            new_ptr_host = np.zeros(len(keep) + 1, dtype=np.int64)
+            np.cumsum(keep, out=new_ptr_host[1:])
+            k_total = int(new_ptr_host[-1])
+            new_ptr = _device_ptr(new_ptr_host.astype(np.int32), x.device)
+            have = len(keep) > 0
+            nmax, kmax = (int(sizes.max()), int(keep.max())) if have else (0, 0)
+        perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=min(nmax, n))
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
         use_dense, use_rows, use_lists, link = _ASAP_DENSE, _ASAP_ROWS, _ASAP_LISTS, _ASAP_LINK   # the switches as they stand now: build() may run later
 
         def build():
-            dense_ok = use_dense and len(keep) > 0 and int(keep.max()) <= ops.asap_dense_max_k()
+            dense_ok = use_dense and have and kmax <= ops.asap_dense_max_k()
             if dense_ok:
                 # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
                 csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
                 num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
             done = None
-            if not dense_ok and use_rows and use_lists and len(keep) > 0 and int(keep.max()) <= ops.asap_lists_max_k():
+            if not dense_ok and use_rows and use_lists and have and kmax <= ops.asap_lists_max_k():
                 # large graphs: per-node cluster lists, a thread per cluster gathers its candidates, persistent waves sort them through
                 # LDS bitsets; no host read when the structure carries a capacity.  None: too many candidates for this form
                 done = ops.asap_coarsen_lists(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, s.edge_count(), keep,
@@ -907,8 +920,7 @@ class _ASAPool(Function):
                 pass
             elif done is not None:
                 csr, slot, num_edges = done
-            elif (use_rows and len(keep) > 0
-                  and int(sizes.max()) + 2 * int(keep.max()) + 96 <= ops.asap_rows_max_bits()):
+            elif (use_rows and have and nmax + 2 * kmax + 96 <= ops.asap_rows_max_bits()):
                 # large graphs: one wave per cluster, bitsets in LDS, no sort; one 4-byte read (the edge total)
                 csr, slot, num_edges = ops.asap_coarsen_rows(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm,
                                                              n, sizes, keep, capacity=getattr(s, "coarse_capacity", None))
@@ -921,13 +933,16 @@ class _ASAPool(Function):
         # the coarsened connectivity S^T A S waits until a layer reads it (GraphStructure.deferred); the backward's slot[] (cluster id of
         # every kept centre, -1 elsewhere) does not depend on it
         slot = ops.asap_slot_map(perm, n)
-        holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=keep)
-        if ((_TILES or _DENSE_BLOCKS) and use_rows and use_lists and not link and len(keep) > 0 and ops.asap_dense_max_k() < int(keep.max())):
+        holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=None if plan else keep)
+        if plan:
+            holder["structure"].pool_plan = plan[1:]             # the next pooling's level
+            holder["structure"].num_real = s.num_real
+        if ((_TILES or _DENSE_BLOCKS) and use_rows and use_lists and not link and have and ops.asap_dense_max_k() < kmax):
             # large graphs (the list coarsening's): clusters whose centres are close in program order share their neighbours, so
             # the layers that read this graph walk it in tiles of rows ordered by their centres' node index
             def tile_spec(slot=slot, gptr=s.graph_ptr, b=s.num_graphs):
                 # a tile may straddle a graph boundary: its entries' ids then span (parts of) two graphs' ranges
-                return ops.tile_order_by_position(slot, gptr, new_ptr, b, k_total), 2 * int(keep.max()) + ops.TILE_ROWS
+                return ops.tile_order_by_position(slot, gptr, new_ptr, b, k_total), 2 * kmax + ops.TILE_ROWS
 
             holder["structure"].set_tile_spec(tile_spec)
         holder["perm"] = perm

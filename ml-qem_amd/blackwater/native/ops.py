@@ -1336,6 +1336,16 @@ def asap_compose_bwd(g_w_comp, g_att_b, lin_w, lin_b, att_w, g_att_x):
     return g_lin_w, g_lin_b, g_att_w
 
 
+def pool_keep_ptr(graph_ptr, num_graphs, ratio):
+    """Boundaries [B + 1] int32 of the pooled batch, computed ON THE DEVICE from the batch's boundaries: k_g = ceil(float32(n_g) * ratio)
+    per graph (mlqem_pool_keep_ptr).  No host value but B enters: the call can be captured and replayed for other size sequences."""
+    _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
+    out = torch.empty(num_graphs + 1, dtype=torch.int32, device=graph_ptr.device)
+    code = _lib.load().mlqem_pool_keep_ptr(_p(graph_ptr), num_graphs, float(ratio), _p(out), _stream())
+    _lib.check(code, "mlqem_pool_keep_ptr")
+    return out
+
+
 def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_total, max_graph_nodes=0):
     _vec(fitness, "fitness", num_nodes)
     _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
@@ -1410,15 +1420,24 @@ def asap_coarsen(in_ptr, in_src, out_ptr, out_dst, perm, num_nodes, return_slot=
     return (ei, slot) if return_slot else ei
 
 
+def _keep_info(keep_sizes):
+    """(B, k_total, kmax, dense edge capacity) of a pooled batch from the host array of its k_g -- or from BOUNDS, a dict with
+    ``b``, ``k`` (exact) and ``kmax`` (an upper bound on the largest k_g), when the per-graph sizes stay on the device (size-stable
+    captured steps): sum k_g (k_g - 1) <= k (kmax - 1)."""
+    import numpy as np
+
+    if isinstance(keep_sizes, dict):
+        b, k, kmax = int(keep_sizes["b"]), int(keep_sizes["k"]), int(keep_sizes["kmax"])
+        return b, k, kmax, k * max(kmax - 1, 0)
+    keep = np.asarray(keep_sizes, dtype=np.int64)
+    b, k = int(keep.shape[0]), int(keep.sum())
+    return b, k, (int(keep.max()) if b else 0), int((keep * (keep - 1)).sum())
+
+
 def asap_coarsen_dense(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, keep_sizes):
     """Pooled structure arrays (in_ptr, in_src, out_ptr, out_dst, out_eid, loops, slot) and the capacity of the edge
     arrays, with NO device->host copy (mlqem_asap_coarsen_dense).  ``keep_sizes``: host array of k_g per graph."""
-    import numpy as np
-
-    keep = np.asarray(keep_sizes, dtype=np.int64)
-    b, k = int(keep.shape[0]), int(keep.sum())
-    kmax = int(keep.max()) if b else 0
-    cap = int((keep * (keep - 1)).sum())
+    b, k, kmax, cap = _keep_info(keep_sizes)
     dev = perm.device
     lib = _lib.load()
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
@@ -1442,10 +1461,8 @@ def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_g
     number of edges or the capacity)."""
     import numpy as np
 
-    keep = np.asarray(keep_sizes, dtype=np.int64)
-    b, k = int(keep.shape[0]), int(keep.sum())
-    kmax = int(keep.max()) if b else 0
-    nmax = int(np.asarray(graph_sizes).max()) if b else 0
+    b, k, kmax, _ = _keep_info(keep_sizes)
+    nmax = (int(keep_sizes["nmax"]) if isinstance(keep_sizes, dict) else int(np.asarray(graph_sizes).max())) if b else 0
     dev = perm.device
     lib = _lib.load()
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
@@ -1477,11 +1494,7 @@ def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
     the edge total (GraphArena.coarse_capacity); without it the totals are read back (one 32-byte device->host copy, then the
     4-byte edge total).  Returns (CsrArrays, slot, edge capacity), or None when the candidate lists would exceed
     ``ASAP_LISTS_MAX_CAPACITY`` entries (the caller then takes another form)."""
-    import numpy as np
-
-    keep = np.asarray(keep_sizes, dtype=np.int64)
-    b, k = int(keep.shape[0]), int(keep.sum())
-    kmax = int(keep.max()) if b else 0
+    b, k, kmax, _ = _keep_info(keep_sizes)
     dev = perm.device
     lib = _lib.load()
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)

@@ -95,6 +95,11 @@ class GraphStructure:
 
     def _init_rest(self, norms, graph_sizes, ell, colsums, derived):
         self.coarse_capacity = None   # host-side upper bound on the edges of this structure's ASAPooling coarsening (data/arena.py)
+        # Size-stable batches (train.BucketedTrainer): what the poolings that follow may know of the batch WITHOUT its per-graph sizes
+        # -- one (k_total, nmax, kmax) per pooling level: the exact number of kept nodes (the batch's filler graphs are sized to
+        # make it a function of the bucket) and bounds on the largest graph before / after.  None: sizes come from graph_sizes.
+        self.pool_plan = None
+        self.num_real = None          # graphs of the batch that are circuits (the rest: edgeless fillers at the end)
         self._tile_spec = None        # (order, tiles, num_tiles, max_span): what a tiled row walk's plan is built from (set_tile_spec)
         self._tile_plans = {}
         self._dense_plans = {}

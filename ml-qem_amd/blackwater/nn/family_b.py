@@ -90,6 +90,7 @@ class _FamilyB(nn.Module):
         # the row map, no per-batch copy of the features is made
         b = exp_value.shape[0]
         s = as_structure(edge_index, nodes.shape[0], batch, b)
+        real = getattr(s, "num_real", None)
         self.transformer1.static_dropout_key = self.transformer2.static_dropout_key = getattr(self, "static_dropout_key", False)
         self.body_seq.static_dropout_key = getattr(self, "static_dropout_key", False)      # an MLP2 / MLP3 head draws masks too
         g = self.transformer1(nodes, s)
@@ -98,6 +99,11 @@ class _FamilyB(nn.Module):
         g, s, _ = self.pooling2(g, s)
         g = F.segment_mean(g, s)
         merged = torch.cat((g, torch.squeeze(exp_value, 1), circuit_depth), dim=1)
+        if real is not None and real < b and isinstance(self.body_seq, (MLP2, MLP3)):
+            # a bucket-padded batch ends in edgeless filler graphs: a head with BatchNorm must not see their rows (its batch
+            # statistics are over the circuits: docs/tutorials/gnn.py:150-170); the other heads are row-wise and the trainer cuts the
+            # filler rows off before the loss
+            merged = merged[:real]
         return self.body_seq(merged)
 
 

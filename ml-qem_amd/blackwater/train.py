@@ -541,6 +541,40 @@ class StratifiedBatches:
         return np.concatenate(out)
 
 
+def stable_padding(node_counts, node_quantum: int, n_fill: int):
+    """Filler graphs that make a batch's node totals after EVERY ASAPooling level (ratio 0.5: k_g = ceil(n_g / 2), then
+    ceil(k_g / 2) = ceil(n_g / 4)) functions of a bucket instead of the batch's size sequence.
+
+    With N = sum n_g, sum ceil(n_g / 2) = (N + #odd) / 2 and sum ceil(n_g / 4) = (N + sum (-n_g mod 4)) / 4.  The batch is padded
+    with exactly ``n_fill`` edgeless graphs (slices of the arena's filler) whose sizes bring the node total to a multiple of
+    ``node_quantum``, the number of odd-sized graphs to a multiple of n_fill and sum (-n mod 4) to a multiple of 2 n_fill: the
+    bucket is (n_pad, c1, c2) and K1 = (n_pad + c1) / 2, K2 = (n_pad + c2) / 4 whatever graphs were drawn.  A uniformly shuffled
+    loader (the reference's: docs/tutorials/__ml_models.py:105, shuffle=True) then revisits a few dozen buckets, each captured once.
+    Returns (n_pad, c1, c2, filler sizes [n_fill])."""
+    n_of = np.asarray(node_counts, dtype=np.int64)
+    f = int(n_fill)
+    if f < 2 or f % 2 or node_quantum % 4:
+        raise ValueError("stable_padding: an even number of fillers and a node quantum that is a multiple of 4")
+    total, odd, pad4 = int(n_of.sum()), int((n_of & 1).sum()), int(((-n_of) % 4).sum())
+    n_pad = -(-(total + 4 * f) // node_quantum) * node_quantum
+    c1 = -(-odd // f) * f
+    o = c1 - odd                                   # fillers of odd size: 0 .. f - 1
+    c2 = -(-(pad4 + o) // (2 * f)) * (2 * f)
+    m = (c2 - pad4 - o) // 2                       # 0 .. f - 1; (c2 - pad4 - o) is even: pad4 = odd (mod 2), c1 and c2 are even
+    c_1 = min(o, m)                                # fillers of size 1 (mod 4), then 2, 3, 0: c_1 + c_3 = o, c_1 + c_2 = m
+    c_2 = m - c_1
+    c_3 = o - c_1
+    c_0 = f - c_1 - c_2 - c_3
+    assert c_0 >= 0 and (c2 - pad4 - o) % 2 == 0
+    sizes = np.array([1] * c_1 + [2] * c_2 + [3] * c_3 + [4] * c_0, dtype=np.int64)
+    extra = n_pad - total - int(sizes.sum())       # a non-negative multiple of 4 (n_pad >= total + 4 f)
+    assert extra >= 0 and extra % 4 == 0
+    units = extra // 4
+    sizes += 4 * (units // f)
+    sizes[: units % f] += 4
+    return n_pad, c1, c2, sizes
+
+
 class BucketedTrainer(Trainer):
     """The small-batch path (the reference's regime: batches of 32, docs/tutorials/__ml_models.py:105,148).
 
@@ -601,10 +635,26 @@ class BucketedTrainer(Trainer):
         self.max_pattern_captures = int(os.environ.get("MLQEM_MAX_PATTERN_CAPTURES", "64"))
         self._seen = {}
         self.overflow_check_every = 256
+        # SIZE-STABLE buckets for such models (default; MLQEM_STABLE_SHAPES=0: the size-pattern keys of rounds 3-5): every batch is
+        # padded with a fixed number of small edgeless filler graphs sized so that the node totals after both poolings depend on
+        # the bucket only (stable_padding), the pooled boundaries are computed on the device and the kernels that wanted the largest
+        # graph get a bound -- a capture then serves every batch of its bucket, whatever the order or mix of graph sizes, and the
+        # reference's shuffled loader replays captures instead of staying eager.  Needs every pooling at ratio 0.5 (the reference's).
+        ratios = [float(getattr(m, "ratio")) for m in model.modules() if type(m).__name__ == "ASAPooling"]
+        self.stable = (self._pattern_model and os.environ.get("MLQEM_STABLE_SHAPES", "1") != "0" and len(ratios) == 2
+                       and all(r == 0.5 for r in ratios) and self.nq % 4 == 0)
+        if self.stable:
+            real_max = int(arena.node_counts[:len(arena)].max()) if len(arena) else 1
+            self._nmax0 = max(real_max, 8 + 4 * (-(-self.nq // 16)))       # the largest filler (>= 4 of them share <= nq + 4 f nodes)
+            self._kmax1, self._kmax2 = -(-self._nmax0 // 2), -(-(-(-self._nmax0 // 2)) // 2)
+            # the structural capacity of the coarsened edge arrays matters to the list coarsening (large graphs) only
+            self._cap_in_key = self._kmax1 > ops.asap_dense_max_k()
 
     def bucket_of(self, graph_ids):
         sel = np.asarray(graph_ids, dtype=np.int64)
         nb, eb = int(self.arena.node_counts[sel].sum()), int(self.arena.edge_counts[sel].sum())
+        if self.stable:
+            return self._stable_bucket(sel)[0]
         key = (-(-nb // self.nq) * self.nq, -(-max(eb, 1) // self.eq) * self.eq, len(sel))
         if getattr(self.model, "needs_size_pattern", False):
             # models whose launch shapes depend on every graph's size (Family B: ASAPooling keeps ceil(n_g / 2) clusters per
@@ -613,16 +663,36 @@ class BucketedTrainer(Trainer):
             key += (self.arena.node_counts[sel].tobytes(), self.arena.coarse_capacity(sel))
         return key
 
-    def _step_on(self, packed, b, n_pad, e_pad, sizes, num_real, cap=None):
-        loss = self._local_half(packed, b, n_pad, e_pad, sizes, num_real, cap)
+    @staticmethod
+    def fillers_for(batch: int) -> int:
+        """Filler graphs of a size-stable batch: about half as many as circuits (even, 4 .. 64)."""
+        return int(min(64, max(4, 2 * (-(-int(batch) // 4)))))
+
+    def _stable_bucket(self, sel):
+        """(bucket key, filler sizes, pooling plan, capacity) of a size-stable batch of the graphs ``sel``."""
+        n_of, e_of = self.arena.node_counts[sel], self.arena.edge_counts[sel]
+        f = self.fillers_for(len(sel))
+        n_pad, c1, c2, fill = stable_padding(n_of, self.nq, f)
+        e_pad = -(-max(int(e_of.sum()), 1) // self.eq) * self.eq
+        cap = None
+        if self._cap_in_key:
+            cap = self.arena.coarse_capacity(np.concatenate([sel, np.full(f, len(self.arena), dtype=np.int64)]))
+            if cap is not None:            # a bound: rounded up on a grid of 3 mantissa bits (<= 12.5 % over) so that batches share it
+                e = max(int(cap).bit_length() - 4, 0)
+                cap = -(-cap >> e) << e
+        plan = (((n_pad + c1) // 2, self._nmax0, self._kmax1), ((n_pad + c2) // 4, self._kmax1, self._kmax2))
+        return (n_pad, e_pad, len(sel) + f, "stable", c1, c2, cap), fill, plan, cap
+
+    def _step_on(self, packed, b, n_pad, e_pad, sizes, num_real, cap=None, plan=None):
+        loss = self._local_half(packed, b, n_pad, e_pad, sizes, num_real, cap, plan)
         if self.distributed:
             self.all_reduce_gradients()
         self.optimizer.step()
         return loss
 
-    def _local_half(self, packed, b, n_pad, e_pad, sizes, num_real, cap=None):
+    def _local_half(self, packed, b, n_pad, e_pad, sizes, num_real, cap=None, plan=None):
         self.counter.add_(1)
-        batch = self.arena.assemble(packed, b, n_pad, e_pad, sizes, None, num_real, coarse_capacity=cap)
+        batch = self.arena.assemble(packed, b, n_pad, e_pad, None if plan else sizes, None, num_real, coarse_capacity=cap, pool_plan=plan)
         return self._forward_backward(batch)
 
     def _warm_up(self, ids, bucket):
@@ -635,13 +705,16 @@ class BucketedTrainer(Trainer):
         # running statistics of an MLP2/3 head) are saved and put back: the three warm-up steps must leave no trace
         opt_keep = {id(st): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for st in self.optimizer.state.values()}
         buf_keep = [b.detach().clone() for b in self.model.buffers()]
-        sel, nptr, eptr, nb, eb, real = self.arena.selection(ids, bucket[:2])
+        fill, plan, cap = None, None, bucket[4] if len(bucket) > 4 else None
+        if self.stable:
+            _, fill, plan, cap = self._stable_bucket(np.asarray(ids, dtype=np.int64))
+        sel, nptr, eptr, nb, eb, real = self.arena.selection(ids, bucket[:2], filler_sizes=fill)
         packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(self.flat_param.device)
         side = self._capture_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                self._step_on(packed, len(sel), nb, eb, nptr[1:] - nptr[:-1], real, bucket[4] if len(bucket) > 4 else None)
+                self._step_on(packed, len(sel), nb, eb, nptr[1:] - nptr[:-1], real, cap, plan)
         torch.cuda.current_stream().wait_stream(side)
         with torch.no_grad():
             self.flat_param.copy_(keep[0])
@@ -670,22 +743,28 @@ class BucketedTrainer(Trainer):
             from .native import ops as _ops
 
             _ops.check_overflow_flags()
-        bucket = self.bucket_of(graph_ids)
-        sel, nptr, eptr, nb, eb, real = self.arena.selection(graph_ids, bucket[:2])
+        fill, plan = None, None
+        if self.stable:
+            bucket, fill, plan, cap = self._stable_bucket(np.asarray(graph_ids, dtype=np.int64))
+        else:
+            bucket = self.bucket_of(graph_ids)
+            cap = bucket[4] if len(bucket) > 4 else None
+        sel, nptr, eptr, nb, eb, real = self.arena.selection(graph_ids, bucket[:2], filler_sizes=fill)
         host = np.concatenate([sel, nptr, eptr]).astype(np.int32)
         sizes = nptr[1:] - nptr[:-1]
-        cap = bucket[4] if len(bucket) > 4 else None
         entry = self._entries.get(bucket) if self.graphs else None
         eager = not self.graphs
-        if self.graphs and entry is None and self._pattern_model:
+        if self.graphs and entry is None and self._pattern_model and not self.stable:
             first_sight = bucket not in self._seen
             if first_sight and len(self._seen) >= 4096:
                 self._seen.pop(next(iter(self._seen)))       # forget the oldest pattern: it gets its eager pass again
             self._seen[bucket] = True
             eager = first_sight or len(self._entries) >= self.max_pattern_captures
+        if self.graphs and entry is None and self.stable and len(self._entries) >= self.max_pattern_captures:
+            eager = True                 # a rare bucket beyond the capture budget (each capture holds a graph and a pinned ring)
         if eager:
             packed = torch.from_numpy(host).to(self.flat_param.device, non_blocking=True)
-            return self._step_on(packed, len(sel), nb, eb, sizes, real, cap)
+            return self._step_on(packed, len(sel), nb, eb, sizes, real, cap, plan)
         if entry is None:
             if not self._warm:
                 self._warm_up(graph_ids, bucket)
@@ -703,7 +782,7 @@ class BucketedTrainer(Trainer):
             if self.split and self.capture_collective and self.collective_in_graph is not False:
                 try:        # assembly, forward, backward, all-reduce, Adam as ONE graph
                     with torch.cuda.graph(entry["graph"], **kw):
-                        entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap)
+                        entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap, plan)
                     whole, self.collective_in_graph = True, True
                 except Exception as exc:          # this RCCL / runtime does not capture it: the two-graph form from here on
                     self.collective_in_graph, self.collective_capture_error = False, f"{type(exc).__name__}: {exc}"
@@ -712,10 +791,10 @@ class BucketedTrainer(Trainer):
             if whole:
                 if "loss" not in entry:
                     with torch.cuda.graph(entry["graph"], **kw):
-                        entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap)
+                        entry["loss"] = self._step_on(entry["packed"], len(sel), nb, eb, sizes, real, cap, plan)
             else:
                 with torch.cuda.graph(entry["graph"], **kw):
-                    entry["loss"] = self._local_half(entry["packed"], len(sel), nb, eb, sizes, real, cap)
+                    entry["loss"] = self._local_half(entry["packed"], len(sel), nb, eb, sizes, real, cap, plan)
             entry["whole"] = whole
             if self._pool is None:
                 self._pool = entry["graph"].pool()

@@ -1216,6 +1216,44 @@ extern "C" int mlqem_asap_compose_bwd_f32(const float* g_w_comp, const float* g_
   return launch_status();
 }
 
+// new_graph_ptr[g] = sum over h < g of ceil(float(n_h) * ratio), n_h = graph_ptr[h + 1] - graph_ptr[h]: the boundaries of the pooled
+// batch (PyG topk keeps ceil(ratio * n) nodes per graph, evaluated in float32) from the DEVICE-resident boundaries of the batch.
+// A captured step whose launch shapes do not depend on the per-graph sizes (train.BucketedTrainer's size-stable buckets) pools
+// without a host-made boundary array.  One workgroup, B values in chunks of 1024 with a running carry.
+__global__ __launch_bounds__(1024) void keep_ptr_kernel(const int32_t* __restrict__ graph_ptr, int64_t B, float ratio,
+                                                        int32_t* __restrict__ new_ptr) {
+  __shared__ int32_t part[1024];
+  __shared__ int32_t carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry = 0; new_ptr[0] = 0; }
+  __syncthreads();
+  for (int64_t base = 0; base < B; base += 1024) {
+    const int64_t g = base + tid;
+    int32_t v = 0;
+    if (g < B) v = (int32_t)ceilf((float)(graph_ptr[g + 1] - graph_ptr[g]) * ratio);
+    part[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int32_t t = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    if (g < B) new_ptr[g + 1] = carry + part[tid];
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+}
+
+extern "C" int mlqem_pool_keep_ptr(const int32_t* graph_ptr, int64_t B, float ratio, int32_t* new_graph_ptr, mlqem_stream_t stream_) {
+  begin_launches();
+  if (B < 0 || !(ratio > 0.0f) || ratio > 1.0f) return MLQEM_ERR_BAD_ARG;
+  if (!graph_ptr || !new_graph_ptr) return MLQEM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(keep_ptr_kernel, dim3(1), dim3(1024), 0, as_stream(stream_), graph_ptr, B, ratio, new_graph_ptr);
+  return launch_status();
+}
+
 extern "C" size_t mlqem_segment_topk_workspace_bytes(int64_t N, int64_t B) {
   if (N <= 0 || B <= 0) return 256;
   const size_t keys = ((size_t)N * sizeof(uint64_t) + 255) / 256 * 256;

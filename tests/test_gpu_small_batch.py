@@ -176,3 +176,118 @@ def test_bucketed_trainer_follows_the_plain_trainer(g1):
     t2 = Trainer(m2)
     l2 = [t2.step(arena.batch(ids)).item() for ids in plans]
     assert np.allclose(l1, l2, rtol=2e-5, atol=1e-7)
+
+
+def _cfg2_arena(n_j=12, filler=2048):
+    """4-qubit TFIM-Trotter circuits of 15 different sizes (Trotter steps 0-14): the reference's training set shape (cfg2)."""
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import TfimCorpus
+
+    h = TfimCorpus(4, list(range(15)), n_j, seed=3, two_q="cx", exp_value_size=4).host_graphs()
+    return GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"],
+                                  device=DEV, filler_nodes=filler)
+
+
+def test_size_stable_batch_pools_to_the_buckets_totals_and_leaves_the_circuits_alone():
+    """A size-stable batch (train.stable_padding): the fillers bring the node totals after BOTH poolings to the bucket's values, the
+    pooled boundaries computed on the device equal the host formula, and the circuits' predictions equal the unpadded batch's."""
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModel
+    from blackwater.train import BucketedTrainer
+
+    arena = _cfg2_arena()
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel(22, 15, 4).to(DEV)
+    tr = BucketedTrainer(model, arena, graphs=False, node_quantum=1024, edge_quantum=4096)
+    assert tr.stable
+    rng = np.random.RandomState(1)
+    model.eval()
+    for _ in range(3):
+        ids = rng.permutation(len(arena))[:32]
+        bucket, fill, plan, cap = tr._stable_bucket(ids)
+        assert len(fill) == 16 and bucket[2] == 48 and bucket[0] % 1024 == 0
+        sel, nptr, eptr, nb, eb, real = arena.selection(ids, bucket[:2], filler_sizes=fill)
+        packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(DEV)
+        batch = arena.assemble(packed, len(sel), nb, eb, None, None, real, coarse_capacity=cap, pool_plan=plan)
+        s0 = batch.structure
+        sizes = nptr[1:] - nptr[:-1]
+        keep1 = np.ceil(sizes.astype(np.float32) * np.float32(0.5)).astype(np.int64)
+        keep2 = np.ceil(keep1.astype(np.float32) * np.float32(0.5)).astype(np.int64)
+        assert plan[0][0] == keep1.sum() and plan[1][0] == keep2.sum()
+        assert sizes.max() <= plan[0][1] and keep1.max() <= plan[0][2] and keep2.max() <= plan[1][2]
+        got_ptr = ops.pool_keep_ptr(s0.graph_ptr, s0.num_graphs, 0.5).cpu().numpy()
+        assert np.array_equal(got_ptr, np.concatenate([[0], np.cumsum(keep1)]))
+        with torch.no_grad():
+            g = model.transformer1(batch.nodes, s0)
+            g, s1, _ = model.pooling1(g, s0)
+            assert s1.num_nodes == plan[0][0] and int(s1.graph_ptr[-1].item()) == plan[0][0]
+            g = model.transformer2(g, s1)
+            g, s2, _ = model.pooling2(g, s1)
+            assert s2.num_nodes == plan[1][0] and int(s2.graph_ptr[-1].item()) == plan[1][0]
+            out_padded = model(*batch.model_args())[:32]
+            out_plain = model(*arena.batch(ids).model_args())
+        assert (out_padded - out_plain).abs().max().item() < 1e-6
+    ops.set_seed_counter(None)
+
+
+def test_family_b_shuffled_batches_replay_from_size_stable_captures():
+    """The reference's loader (DataLoader(batch_size=32, shuffle=True), docs/tutorials/__ml_models.py:105): uniformly shuffled
+    batches never repeat a size sequence, but they do repeat size-stable BUCKETS.  Captured (graphs=True) and eager (graphs=False)
+    bucketed steps -- attention and head dropout ON, Adam, 30 steps -- give the same losses and parameters bit for bit; the captured
+    run replays (fewer captures than steps), stays inside its capture budget and never runs a step eagerly."""
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModel
+    from blackwater.train import BucketedTrainer
+
+    arena = _cfg2_arena()
+    n = len(arena)
+    finals = []
+    for graphs in (True, False):
+        rng = np.random.RandomState(11)
+        torch.manual_seed(0)
+        model = ExpValCircuitGraphModel(22, 15, 4).to(DEV)
+        tr = BucketedTrainer(model, arena, lr=1e-3, graphs=graphs, node_quantum=1024, edge_quantum=4096)
+        assert tr.stable
+        torch.manual_seed(5)
+        losses, keys = [], []
+        for epoch in range(6):
+            order = rng.permutation(n)
+            for i in range(0, 32 * 5, 32):
+                ids = order[i:i + 32]
+                keys.append(tr.bucket_of(ids))
+                losses.append(tr.step_ids(ids).item())
+        finals.append((losses, tr.flat_param.detach().clone(), len(tr._entries), len(set(keys))))
+        ops.check_overflow_flags()
+        ops.set_seed_counter(None)
+    assert len(finals[0][0]) == 30 and all(np.isfinite(finals[0][0]))
+    assert finals[0][0] == finals[1][0]
+    assert torch.equal(finals[0][1], finals[1][1])
+    captures, buckets = finals[0][2], finals[0][3]
+    assert captures == buckets < 30          # every bucket captured at first sight, and buckets come back
+    assert captures < int(__import__("os").environ.get("MLQEM_MAX_PATTERN_CAPTURES", "64"))
+    assert len(set(finals[0][0])) > 25
+
+
+def test_bn_head_does_not_see_filler_rows():
+    """ExpValCircuitGraphModel_2 (MLP2 head: BatchNorm over the batch): a bucket-padded batch must give the circuits the outputs of
+    the unpadded batch in TRAIN mode too -- the filler graphs' rows are cut off before the head (dropout off for the comparison)."""
+    from blackwater.native import ops
+    from blackwater.nn.family_b import ExpValCircuitGraphModel_2
+    from blackwater.train import BucketedTrainer
+
+    arena = _cfg2_arena()
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel_2(22, 15, 4, dropout=0.0).to(DEV).train()
+    model.transformer1.dropout = model.transformer2.dropout = 0.0
+    tr = BucketedTrainer(model, arena, graphs=False, node_quantum=1024, edge_quantum=4096)
+    ids = np.arange(0, 160, 5)
+    bucket, fill, plan, cap = tr._stable_bucket(ids)
+    sel, nptr, eptr, nb, eb, real = arena.selection(ids, bucket[:2], filler_sizes=fill)
+    packed = torch.from_numpy(np.concatenate([sel, nptr, eptr]).astype(np.int32)).to(DEV)
+    batch = arena.assemble(packed, len(sel), nb, eb, None, None, real, coarse_capacity=cap, pool_plan=plan)
+    with torch.no_grad():
+        out_padded = model(*batch.model_args())
+        out_plain = model(*arena.batch(ids).model_args())
+    assert out_padded.shape == out_plain.shape == (32, 4)
+    assert (out_padded - out_plain).abs().max().item() < 1e-5
+    ops.set_seed_counter(None)
