@@ -284,7 +284,7 @@ def roofline_leg(batch, arena=None, ids=None, n_qubits=100, reps=20):
         # The step's dominant kernel by rocprof (profiles/*_bench_kernel_stats.csv) is the POOLED epilogue instantiation
         # csr_aggregate_ell_kernel<4,false,2,true,7,true>: the last hidden aggregation of each of the three branches, whose
         # launch also reduces the per-graph means and the gate bits.  The headline record quotes THIS launch, in the step.
-        dom = [v for k, v in rec.items() if " pooled " in " " + k]
+        dom = [v for k, v in rec.items() if k.split(" ", 1)[1].startswith("pooled ")]        # keys read "C=10 pooled epilogue ..."
         if dom:
             d_n = sum(v[2] for v in dom)
             d_b = sum(v[1] * v[2] for v in dom) / d_n

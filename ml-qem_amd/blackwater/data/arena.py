@@ -298,7 +298,7 @@ class GraphArena:
             nb, eb = int(n_of.sum()), int(e_of.sum())
             if not self.filler_nodes:
                 raise ValueError("bucketed batches need an arena built with filler_nodes > 0")
-            if nb > n_pad or eb > e_pad or n_pad - nb > self.filler_nodes:
+            if nb > n_pad or eb > e_pad or (filler_sizes is None and n_pad - nb > self.filler_nodes):
                 raise ValueError(f"selection ({nb} nodes, {eb} edges) does not fit bucket {bucket} (filler {self.filler_nodes})")
             fill = np.asarray([n_pad - nb] if filler_sizes is None else filler_sizes, dtype=np.int64)
             if int(fill.sum()) != n_pad - nb or (filler_sizes is not None and (fill.min() < 1 or fill.max() > self.filler_nodes)):
