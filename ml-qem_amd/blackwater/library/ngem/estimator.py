@@ -33,7 +33,9 @@ _NATIVE_SERIAL = True
 _SLICE = int(os.environ.get("MLQEM_NGEM_SLICE", "512"))      # measured on 1024 100-qubit circuits: one batch 32.9 ms, 512: 29.5, 256: 33.6, 128: 37.4
 
 
-_predictors = weakref.WeakKeyDictionary()      # model -> train.BucketedPredictor: captured forwards outlive a result() call
+# model -> train.BucketedPredictor: captured forwards outlive a result() call, not the model -- the predictor holds its model through a
+# weak reference (train.BucketedPredictor.model), so the entry, its hipGraphs, their memory pool and its arena go with the model
+_predictors = weakref.WeakKeyDictionary()
 _encoders = {}          # content of a backend-properties dict -> NativeEncoder (at most 8, oldest dropped first)
 
 
@@ -42,11 +44,12 @@ def _encoder_for(properties):
     on every result() (:46) and so does this path, but an encoder -- its calibration tables on the host and, for the device
     expansion, on the GPU -- is rebuilt only when the CONTENT of the properties changed (a VQE loop calls result() thousands of
     times against one calibration)."""
+    import hashlib
     import json
 
     from ...data.native_encoder import NativeEncoder
 
-    key = hash(json.dumps(properties, sort_keys=True, default=str))
+    key = hashlib.sha256(json.dumps(properties, sort_keys=True, default=str).encode()).hexdigest()      # the content, not hash() of it
     enc = _encoders.get(key)
     if enc is None:
         while len(_encoders) >= 8:
@@ -94,7 +97,10 @@ class NgemJob(job_base()):  # type: ignore[misc]
         mitigated = []
         if self._batched:
             return make_estimator_result(np.array(self._result_batched_native(result, properties, device)), result.metadata)
+        # (a model left in train() mode is called in train() mode by the reference's loop -- dropout on -- whatever the number of
+        # circuits; the replayed path evaluates in eval mode, so it serves eval-mode models only and the plain loop takes the rest)
         if (_NATIVE_SERIAL and device is not None and torch.device(device).type == "cuda" and len(self._circuits) > 1
+                and not getattr(self._model, "training", False)
                 and getattr(self._model, "accepts_device_batches", False) and not getattr(self._model, "needs_size_pattern", False)):
             replayed = self._result_serial_replayed(result, properties, device)
             if replayed is not None:

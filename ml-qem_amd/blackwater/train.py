@@ -842,12 +842,24 @@ class BucketedPredictor:
     def __init__(self, model: nn.Module, arena, node_quantum: int = 256, edge_quantum: int = 512, graphs: bool = True):
         if not arena.filler_nodes:
             raise ValueError("BucketedPredictor needs an arena built with filler_nodes > 0")
-        self.model, self.nq, self.eq = model, int(min(node_quantum, arena.filler_nodes)), int(edge_quantum)
+        import weakref
+
+        # the model through a WEAK reference: a predictor kept per model (library/ngem/estimator._predictors is keyed weakly by the
+        # model) must not be what keeps the model -- and with it the captures, their pool and the arena -- alive
+        self._model_ref = weakref.ref(model)
+        self.nq, self.eq = int(min(node_quantum, arena.filler_nodes)), int(edge_quantum)
         self.graphs = graphs and not getattr(model, "needs_size_pattern", False)
         self._entries, self._pool, self._stream, self._warm = {}, None, None, False
         self.captures = 0
         self.arena = arena.with_capacity(2.0) if self.graphs else arena
         self._weights = self._weight_addresses()
+
+    @property
+    def model(self):
+        model = self._model_ref()
+        if model is None:
+            raise RuntimeError("BucketedPredictor: its model has been garbage-collected")
+        return model
 
     def _weight_addresses(self):
         return tuple(p.data_ptr() for p in self.model.parameters())

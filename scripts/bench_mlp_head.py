@@ -1,5 +1,5 @@
 """Times the one-launch MLP head kernels (csrc/mlp_head.hip) alone, with HIP events on the launch stream, and the whole MLP1
-train step, fp32 and bf16, against the per-layer path (MLQEM_MLP1_FUSED=0).
+train step, fp32 and bf16, against the per-layer path (a model whose input requires grad takes it).
 
     python scripts/bench_mlp_head.py [rows] [in] [hidden] [out]
 """

@@ -199,6 +199,38 @@ def test_serial_decorator_replays_one_captured_forward_per_size_bucket(g1, lima_
     assert np.abs(one - both([3, 3])[:1]).max() < 1e-6
 
 
+def test_serial_decorator_keeps_a_train_mode_model_in_train_mode_and_lets_go_of_dead_models(g1, lima_backend):
+    """(1) a model left in train() mode (dropout on) is called in train() mode by the reference's loop
+    (blackwater/library/ngem/estimator.py:75-82) whatever the number of circuits -- the replayed path, which evaluates in eval
+    mode, must leave such a model to the plain loop: two runs over the same circuits then differ (fresh masks) for one circuit AND
+    for several; (2) the predictor kept per model holds it weakly: when the model goes, so do its captures and arena."""
+    import gc
+    import weakref
+
+    import blackwater.library.ngem.estimator as mod
+    from blackwater.data.backends import PauliObservable
+    from blackwater.library.ngem.estimator import ngem
+    from blackwater.nn import ExpValCircuitGraphModelA
+    from test_estimators import FakeEstimator
+
+    torch.manual_seed(3)
+    model = ExpValCircuitGraphModelA(5, 22, 10).to(DEV).train()
+    obs = PauliObservable([("ZIIIZ", 1.0)])
+    for ids in ([4], [4, 7, 19]):
+        circuits = [g1["qasm"][i] for i in ids]
+        a = ngem(FakeEstimator, model, lima_backend)().run(circuits, [obs] * len(ids)).result().values
+        b = ngem(FakeEstimator, model, lima_backend)().run(circuits, [obs] * len(ids)).result().values
+        assert model.training and np.abs(a - b).max() > 0, ids          # dropout drew twice: train-mode semantics on both paths
+    assert model not in mod._predictors                                 # the replayed path never took it
+    model.eval()
+    ngem(FakeEstimator, model, lima_backend)().run([g1["qasm"][i] for i in (4, 7, 19)], [obs] * 3).result()
+    assert model in mod._predictors
+    alive = weakref.ref(mod._predictors[model])
+    del model
+    gc.collect()
+    assert alive() is None                                              # predictor, captures, pool and arena went with the model
+
+
 def test_a_large_batched_run_in_slices_equals_the_one_batch_form(g1, lima_backend, monkeypatch):
     """library/ngem/estimator.py ``_batched_in_slices``: a run() of at least two slices is scanned, expanded and evaluated slice by
     slice (host and device overlap) -- the values are those of the one-batch form (a circuit's value does not depend on the batch it
