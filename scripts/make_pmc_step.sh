@@ -16,9 +16,9 @@ for grp in FETCH_SIZE WRITE_SIZE; do
 done
 rm -rf /tmp/spmc_trace
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/spmc_trace -- python3 $ROOT/$PMC_SCRIPT > /tmp/spmc_trace.log 2>&1 || echo "trace rc=$?"
-python3 - "$OUT/$PMC_OUT" <<'PY'
+python3 - "$OUT/$PMC_OUT" "$PMC_SCRIPT" <<'PY'
 import csv, glob, json, sys, collections
-out = sys.argv[1]
+out, workload = sys.argv[1], sys.argv[2]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob("/tmp/spmc_*/**/*counter_collection.csv", recursive=True):
     with open(path) as fh:
@@ -45,7 +45,7 @@ for name, c in vals.items():
                  "traffic_GB": round((rd + wr) / 1e9, 3), "avg_us_under_trace": round(us, 1),
                  "hbm_TBps": round((rd + wr) / us / 1e6, 2) if us else None})
 rows.sort(key=lambda r: -r["traffic_GB"])
-json.dump({"what": "PMC-counted HBM traffic per kernel name over the large launches of the profiled workload (default: one replayed Family A step; see PMC_SCRIPT) "
+json.dump({"what": "PMC-counted HBM traffic per kernel name over the large launches of the profiled workload: python3 " + workload + " "
                    "(scripts/make_pmc_step.sh); read = FETCH_SIZE*1024*2 (gfx950), write = WRITE_SIZE*1024; kernels that run at several "
                    "shapes (aggregation variants, linear_parts) are averaged over their large launches", "rows": rows}, open(out, "w"), indent=1)
 for r in rows[:14]:
