@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 37 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 39 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -721,80 +721,17 @@ int mlqem_leconv_fitness_bwd_f32(const float* gfit, const float* fitness, const 
                                  const int32_t* out_dst, int64_t N, float* gpqr, mlqem_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Tiled row walks (round 5; csrc/tile_common.hpp).  The graph ASAPooling coarsens out of a large circuit
- * (docs/tutorials/gnn.py:85,92,104-112: TransformerConv 2 and ASAPooling 2 of every reference GNN run on it) is a union
- * of dense blocks: rows whose centres are close in program order share nearly all their sources.  A PLAN groups the rows
- * of one CSR direction into tiles of `tile_rows` rows and lists, per tile, the union of its rows' column ids (at most
- * `cap` slots) and, per CSR entry, the entry's slot in its row's tile -- built once per structure and direction, read by
- * every tiled pass: a workgroup stages its tile's union in LDS once and walks its rows out of LDS.  An entry whose id did
- * not fit the union carries slot 0xFFFF and is read from global memory (results never depend on `cap`).
- *
- * Tile t holds the rows at positions [t * tile_rows, (t + 1) * tile_rows) of `order` (order == NULL: the rows in index order).
- * Plan arrays (caller-allocated), num_tiles = ceil(num_rows / tile_rows):
- *   tinfo[num_tiles][4] int32 {rows, long rows, union slots, entries}, 16-byte aligned (long = at least 32 entries; listed first);
- *   rinfo[num_tiles * tile_rows][4] int32 {row, first CSR entry, entries, offset inside the tile's entry list}, 16-byte aligned;
- *   uni[num_tiles * cap] int32;  loc[E] uint16. */
-
+ * Row order of a coarsened graph (csrc/row_order.hip).  The graph ASAPooling coarsens out of a large circuit
+ * (docs/tutorials/gnn.py:85,92,104-112: TransformerConv 2 and ASAPooling 2 of every reference GNN run on it) is a union of dense
+ * blocks: rows whose centres are close in program order share nearly all their sources.  The dense-block plans below take their
+ * rows in that order.  (ABI <= 38 also exported LDS-staged "tile" kernels built on the same order -- mlqem_tile_plan_build,
+ * mlqem_tile_attention_*, mlqem_tile_asap_scores_*: measured slower than the per-edge kernels, superseded by the dense blocks,
+ * removed with ABI 39.)
+ * ---------------------------------------------------------------------------------------------------- */
 /* order[new_graph_ptr[g] + r] = the cluster of graph g whose centre is the r-th kept node of the graph in node order
  * (= program order of a circuit); slot[] from mlqem_asap_slot_map.  One workgroup per graph. */
 int mlqem_tile_order_by_position(const int32_t* slot, const int32_t* graph_ptr, const int32_t* new_graph_ptr, int64_t num_graphs,
                                  int32_t* order, mlqem_stream_t stream);
-
-/* Largest id range of a tile's entries the plan builder's LDS bitset covers (ids beyond it get slot 0xFFFF). */
-int64_t mlqem_tile_plan_max_span(void);
-
-/* Builds a plan for the CSR (ptr, idx) of num_rows rows; tile_rows <= 128; max_span: a bound on (largest - smallest id + 1) over
- * the entries of one tile (sizes the bitset; clamped to mlqem_tile_plan_max_span()). */
-int mlqem_tile_plan_build(const int32_t* ptr, const int32_t* idx, const int32_t* order, int64_t num_rows, int tile_rows, int cap,
-                          int64_t max_span, int32_t* rinfo, int32_t* tinfo, int32_t* uni, uint16_t* loc, mlqem_stream_t stream);
-
-/* Largest `cap` whose attention / pooling kernels fit lds_bytes of LDS per workgroup (H heads / D channels). */
-int mlqem_tile_attention_cap(int H, int tile_rows, int lds_bytes);
-int mlqem_tile_pool_cap(int D, int tile_rows, int lds_bytes);
-
-/* mlqem_transformer_attention_train_f32 on a plan of the in-CSR (13 <= C <= 16 at head_pitch 16 only; attn_out == NULL:
- * inference form, no statistics, drop_p must be 0).  attn_out is written for EVERY row (the tiled backward reads it). */
-int mlqem_tile_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src, const int32_t* loops,
-                                   int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                   int pair_key, int head_pitch, const int32_t* tinfo, const int32_t* rinfo, const int32_t* uni,
-                                   const uint16_t* loc, int64_t num_tiles, int cap, int tile_rows, float* out, int64_t ldo,
-                                   float* attn_out, int64_t lda, float* stat_m, float* stat_den, mlqem_stream_t stream);
-
-/* mlqem_transformer_attention_bwd_f32 in its recomputing form (no out_eid, dropout keyed by pair) on plans of both CSR
- * directions; rec: [4 N H] floats of scratch (16-byte aligned): {m, 1/den, g.attn_out, -} per (row, head). */
-int mlqem_tile_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg, const float* attn_out, int64_t lda,
-                                 const float* stat_m, const float* stat_den, const int32_t* in_ptr, const int32_t* in_src,
-                                 const int32_t* out_ptr, const int32_t* out_dst, const int32_t* loops, int64_t N, int64_t E, int H, int C,
-                                 float drop_p, uint64_t seed, const uint64_t* seed_counter, int pair_key, int head_pitch,
-                                 const int32_t* in_tinfo, const int32_t* in_rinfo, const int32_t* in_uni, const uint16_t* in_loc,
-                                 int64_t in_tiles, int in_cap, int in_tile_rows, const int32_t* out_tinfo, const int32_t* out_rinfo,
-                                 const int32_t* out_uni, const uint16_t* out_loc, int64_t out_tiles, int out_cap, int out_tile_rows,
-                                 float* gqkvs, int64_t ldq, float* rec, mlqem_stream_t stream);
-
-/* ASAPooling steps 2-4 + LEConv's projections in ONE pass (D <= 48; x, its rows 16-byte aligned):
- *   xmax[i] = max over row i's entries and i itself of x;  a_i = w_comp . xmax[i] + b_comp[0];
- *   xnew[i] = sum_j softmax_j(LeakyReLU(a_i + c_src[j])) x[j] (self entry included);  pqr[i, k] = w3[k] . xnew[i] + b3[k];
- *   stat[i] = {a_i, m_i, 1 / den_i, 0} (float4 per row) for the backward.
- * Replaces mlqem_csr_segment_max_f32 + two one-wide GEMMs + mlqem_csr_softmax_aggregate_f32 + a three-wide GEMM. */
-int mlqem_tile_asap_scores_f32(const float* x, int64_t ldx, const int32_t* in_ptr, const int32_t* in_src, const float* c_src,
-                               const float* w_comp, const float* b_comp, const float* w3, const float* b3, float negative_slope,
-                               int64_t N, int D, const int32_t* tinfo, const int32_t* rinfo, const int32_t* uni, const uint16_t* loc,
-                               int64_t num_tiles, int cap, int tile_rows, float* xnew, int64_t ldn, float* xmax, int64_t ldm, float* stat,
-                               float* pqr, mlqem_stream_t stream);
-
-/* Its backward given gnew = d loss / d xnew (the LEConv projections' gradient already added):
- *   g_a[i] (gradient of a_i), stat[i].w = gnew_i . xnew_i, share[i, c] = g_a[i] w_comp[c] / #{entries attaining xmax[i, c]},
- *   gx = gradient of x through the weighted sum, through c_src (g_c[j] * rank1, rank1 = att_x or NULL) and through the
- *   segment max; g_c[j] = gradient of c_src[j].
- * Replaces mlqem_csr_softmax_aggregate_bwd_f32 + mlqem_csr_segment_max_bwd_f32. */
-int mlqem_tile_asap_scores_bwd_f32(const float* x, int64_t ldx, const float* xnew, int64_t ldn, const float* gnew, int64_t ldg,
-                                   const float* xmax, int64_t ldm, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
-                                   const int32_t* out_dst, const float* c_src, const float* w_comp, const float* rank1,
-                                   float negative_slope, int64_t N, int D, const int32_t* in_tinfo, const int32_t* in_rinfo,
-                                   const int32_t* in_uni, const uint16_t* in_loc, int64_t in_tiles, int in_cap, int in_tile_rows,
-                                   const int32_t* out_tinfo, const int32_t* out_rinfo, const int32_t* out_uni, const uint16_t* out_loc,
-                                   int64_t out_tiles, int out_cap, int out_tile_rows, float* stat, float* g_a, float* share, int64_t lds,
-                                   float* gx, int64_t ldgx, float* g_c, mlqem_stream_t stream);
 
 /* ASAPooling's forward up to the fitness projections in one pass, for graphs of short rows (C <= 64): per row the segment max over
  * its in-entries and itself (xmax), the composed score a_dst = w_comp . xmax + b_comp, c_src = att_x . x, the score softmax + cluster
@@ -837,7 +774,7 @@ int mlqem_asap_compose_bwd_f32(const float* g_w_comp, const float* g_att_b, cons
  * backward):  counter[1] (zero on entry) receives 16 x the number of blocks; lrows[17 * max_blocks] the blocks' rows, then their graphs;
  * records[max_blocks * mlqem_dense_plan_record_ints()] (16-byte aligned) the blocks; row_flag[num_rows] (zero on entry) the flags.
  * max_blocks = mlqem_dense_plan_max_blocks(num_rows, num_graphs).  graph_ptr[num_graphs + 1]: the graphs' ranges of positions in
- * `order` AND of row ids (null order: the rows themselves); max_span: a bound on the rows of one graph (<= mlqem_tile_plan_max_span()).
+ * `order` AND of row ids (null order: the rows themselves); max_span: a bound on the rows of one graph (ids beyond 262 144 from a block's first are left to the per-edge kernels).
  * ---------------------------------------------------------------------------------------------------- */
 int mlqem_dense_plan_record_ints(void);
 int mlqem_dense_plan_min_degree(void);

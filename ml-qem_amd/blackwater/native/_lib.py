@@ -142,18 +142,6 @@ SIGNATURES = {
     "mlqem_gather_scale_rows_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _P, _L, _P, _P]),
     "mlqem_leconv_fitness_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _P, _P]),
     "mlqem_tile_order_by_position": (_I, [_P, _P, _P, _L, _P, _P]),
-    "mlqem_tile_plan_max_span": (_L, []),
-    "mlqem_tile_plan_build": (_I, [_P, _P, _P, _L, _I, _I, _L, _P, _P, _P, _P, _P]),
-    "mlqem_tile_attention_cap": (_I, [_I, _I, _I]),
-    "mlqem_tile_pool_cap": (_I, [_I, _I, _I]),
-    "mlqem_tile_attention_train_f32": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _F, _U, _P, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _L,
-                                            _P, _L, _P, _P, _P]),
-    "mlqem_tile_attention_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _F, _U, _P, _I, _I,
-                                          _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _L, _P, _P]),
-    "mlqem_tile_asap_scores_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _L, _I, _P, _P, _P, _P, _L, _I, _I, _P, _L, _P, _L, _P,
-                                        _P, _P]),
-    "mlqem_tile_asap_scores_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _L, _I, _P, _P, _P, _P, _L,
-                                            _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _L, _P, _L, _P, _P]),
     "mlqem_dense_plan_record_ints": (_I, []),
     "mlqem_dense_plan_min_degree": (_I, []),
     "mlqem_dense_plan_max_blocks": (_L, [_L, _L]),
@@ -193,7 +181,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 37   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 39   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

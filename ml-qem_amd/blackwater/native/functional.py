@@ -661,26 +661,19 @@ class _TransformerConv(Function):
         x = ops.rowmajor(x)        # a RowsOf (rows of the device-resident dataset) stays one: the projection reads through its row map
         w = w.contiguous()
         e = struct.edge_count()
-        # a structure whose rows share their sources (ASAPooling's coarsened graphs of large circuits) takes the tiled kernels
-        tiled = (_TILES and struct.tiled and w.is_cuda and struct.out_eid is None
-                 and ops.tile_attention_fits(heads, channels, 16 if 13 <= channels <= 16 else 0))
-        # ... or, its long rows as dense blocks, the edge softmax on the matrix cores (csrc/dense_block.hip)
-        dense = (_DENSE_BLOCKS and not tiled and struct.tiled and w.is_cuda and struct.out_eid is None and channels < 16
+        # a structure whose rows share their sources (ASAPooling's coarsened graphs of large circuits): its long rows as dense blocks,
+        # the edge softmax on the matrix cores (csrc/dense_block.hip)
+        dense = (_DENSE_BLOCKS and struct.blocked and w.is_cuda and struct.out_eid is None and channels < 16
                  and ops.dense_attention_supported(heads, channels, 16))
         if not any(ctx.needs_input_grad) and drop_p == 0.0:  # inference: no statistics kept
-            if tiled:
-                wp, bp = _pad_heads(w, b, 4 * heads, channels, 16)
-                return ops.tile_attention(ops.linear(x, wp, bp), struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
-                                          struct.tile_plan("in"), head_pitch=16, train=False)
             return ops.transformer_attention(ops.linear(x, w, b), struct.in_ptr, struct.in_src, struct.loops, heads, channels)
         # Training: a head's channels at a pitch of 16 inside q / k / v / skip (the reference's 15: every gathered segment becomes an
         # aligned 64-byte piece).  The projection writes that layout by itself when its weight and bias rows are padded the same way
         # (zero rows: the pads of qkvs are zeros, the gradient of a pad row is exactly zero); w itself stays [4 H C, in].
         cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and w.is_cuda) else 0
-        if tiled or dense:
+        if dense:
             cp = 16 if channels < 16 else 0
         ctx.cp = cp
-        ctx.tiled = tiled
         ctx.dense = dense
         w_used, b_used = _pad_heads(w, b, 4 * heads, channels, cp) if cp else (w, b)
         qkvs = ops.linear(x, w_used, b_used)
@@ -689,10 +682,7 @@ class _TransformerConv(Function):
         pair_key = struct.out_eid is None
         # the side table of a graph of short rows (circuit DAGs: the arena builds it with the batch); a coarsened graph's rows are long
         ell = struct.in_ell if struct.out_eid is not None else None
-        if tiled:
-            out, attn, m, den = ops.tile_attention(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
-                                                   struct.tile_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp or channels)
-        elif dense:
+        if dense:
             out, attn, m, den = ops.dense_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
                                                          struct.dense_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp,
                                                          side=_dense_side(w.device))
@@ -716,11 +706,7 @@ class _TransformerConv(Function):
             x, w, qkvs, attn, m, den = ctx.saved_tensors
         e, heads, channels, drop_p, seed, pair_key = ctx.cfg
         cp = ctx.cp
-        if ctx.tiled:
-            st = ctx.struct
-            gqkvs = ops.tile_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, st.tile_plan("in"), st.tile_plan("out"),
-                                           drop_p=drop_p, seed=seed, head_pitch=cp or channels)
-        elif ctx.dense:
+        if ctx.dense:
             st = ctx.struct
             gqkvs = ops.dense_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, st.dense_plan("in"), st.dense_plan("out"),
                                             drop_p=drop_p, seed=seed, head_pitch=cp, side=_dense_side(w.device))
@@ -752,11 +738,6 @@ def _pad_heads(w, b, groups, channels, cp):
     return wp, bp
 
 
-# MLQEM_TILES=1: the LDS-staged tiled kernels (csrc/tile_*.hip) on ASAPooling's coarsened graphs.  OFF by default: measured slower than
-# the per-edge kernels on the 100-qubit graphs (the per-edge kernels are bound by vector instructions, not by
-# gathers, and a tile's prologue + staging round trips cost what a whole per-edge launch does); tests/test_gpu_tiles.py keeps the path
-# correct against the per-edge kernels and the oracle.
-_TILES = os.environ.get("MLQEM_TILES", "0") == "1"
 # the long rows of ASAPooling's coarsened graphs as dense blocks: TransformerConv's edge softmax over them on the f32 matrix cores
 # (csrc/dense_block.hip); MLQEM_DENSE_BLOCKS=0: the per-edge kernels for every row (A/B runs, tests/test_gpu_dense_blocks.py)
 _DENSE_BLOCKS = os.environ.get("MLQEM_DENSE_BLOCKS", "1") == "1"
@@ -840,31 +821,22 @@ class _ASAPool(Function):
         # the parameters' small-tensor algebra in one launch (csrc/asap.hip asap_compose_kernel): the halves of att_w, LEConv's three
         # one-wide projections as one [3, D] matrix (lin2 has no bias), and the query projection composed into the score projection
         w_comp, b_comp, att_q, att_x, w3, b3 = ops.asap_compose(lin_w, lin_b, att_w, att_b, l1_w, l1_b, l2_w, l3_w, l3_b)
-        # the input graph's rows share their sources (it is itself a coarsened graph): segment max, composed score, softmax-sum and
-        # LEConv's projections in ONE tiled pass (csrc/tile_pool.hip)
-        tiled = _TILES and s.tiled and x.is_cuda and ops.tile_pool_fits(d)
-        ctx.tiled = tiled
-        # ... or its long rows as dense blocks (csrc/dense_pool.hip): the same plans TransformerConv's edge softmax built on this graph
-        dense = _DENSE_BLOCKS and not tiled and s.tiled and s.out_eid is None and ops.dense_pool_fits(x)
+        # the input graph's rows share their sources (it is itself a coarsened graph): its long rows as dense blocks
+        # (csrc/dense_pool.hip), on the same plans TransformerConv's edge softmax built on this graph
+        dense = _DENSE_BLOCKS and s.blocked and s.out_eid is None and ops.dense_pool_fits(x)
         ctx.dense = dense
         # ... or, a graph of short rows (the circuit DAGs: the arena hands their side table along): everything up to the fitness
         # projections in one pass over the rows (csrc/attn.hip asap_scores_fused_kernel)
-        fused = _ASAP_FUSED and not tiled and not dense and x.is_cuda and d <= 64 and s.in_ell is not None
+        fused = _ASAP_FUSED and not dense and x.is_cuda and d <= 64 and s.in_ell is not None
         stat = None
         if fused:
             xq_raw, a_dst, c_src, x_new, pqr = ops.asap_scores_fused(x, s.in_ptr, s.in_src, w_comp, b_comp, att_x, w3, b3, slope)
-            fitness = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
-        elif tiled:
-            a_dst = None
-            c_src = ops.linear(x, att_x)[:, 0].contiguous()
-            x_new, xq_raw, stat, pqr = ops.tile_asap_scores(x, s.in_ptr, s.in_src, c_src, w_comp[0].contiguous(), b_comp, w3, b3, slope,
-                                                            s.tile_plan("in"))
             fitness = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
         elif dense:
             xq_raw = ops.dense_segment_max(x, s.in_ptr, s.in_src, s.dense_plan("in"))
         else:
             xq_raw = ops.csr_segment_max(x, s.in_ptr, s.in_src, ell=s.in_ell)
-        if not tiled and not fused:
+        if not fused:
             # ASAPooling's query x_q = lin(segmax) feeds ONLY the one-wide score a_i = att_q . x_q[i] + att_b (SURVEY appendix
             # B.2 steps 2-3): a_i = (att_q W) . segmax[i] + (att_q . b + att_b) -- one row dot of the segment max against a composed
             # 45-vector.  x_q [N, D] is never formed (a [N,D]x[D,D] GEMM forward; a data GEMM and a [D,D] weight-gradient pass
@@ -873,7 +845,7 @@ class _ASAPool(Function):
             # (one-wide and three-wide projections into COMPACT outputs: a [N, 1] matrix with a row pitch of one float is the vector the
             # edge kernels take -- the padded default cost a strided copy per projection)
             a_dst = ops.linear(xq_raw, w_comp, b_comp, out=torch.empty((n, 1), dtype=torch.float32, device=x.device))[:, 0]
-        if not tiled and not fused:
+        if not fused:
             c_src = ops.linear(x, att_x, out=torch.empty((n, 1), dtype=torch.float32, device=x.device))[:, 0]
             if dense:
                 x_new, stat = ops.dense_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope, s.dense_plan("in"))
@@ -937,18 +909,17 @@ class _ASAPool(Function):
         if plan:
             holder["structure"].pool_plan = plan[1:]             # the next pooling's level
             holder["structure"].num_real = s.num_real
-        if ((_TILES or _DENSE_BLOCKS) and use_rows and use_lists and not link and have and ops.asap_dense_max_k() < kmax):
+        if (_DENSE_BLOCKS and use_rows and use_lists and not link and have and ops.asap_dense_max_k() < kmax):
             # large graphs (the list coarsening's): clusters whose centres are close in program order share their neighbours, so
-            # the layers that read this graph walk it in tiles of rows ordered by their centres' node index
-            def tile_spec(slot=slot, gptr=s.graph_ptr, b=s.num_graphs):
-                # a tile may straddle a graph boundary: its entries' ids then span (parts of) two graphs' ranges
-                return ops.tile_order_by_position(slot, gptr, new_ptr, b, k_total), 2 * kmax + ops.TILE_ROWS
+            # the layers that read this graph take its long rows 16 at a time in the order of their centres' node index
+            def block_order(slot=slot, gptr=s.graph_ptr, b=s.num_graphs):
+                # (a bound on the id range of one block's entries: its rows may straddle two graphs)
+                return ops.tile_order_by_position(slot, gptr, new_ptr, b, k_total), 2 * kmax + ops.ORDER_SPAN_SLACK
 
-            holder["structure"].set_tile_spec(tile_spec)
+            holder["structure"].set_block_order(block_order)
         holder["perm"] = perm
         ctx.struct, ctx.slope, ctx.d = s, slope, d
-        ctx.save_for_backward(x, xq_raw, w_comp, stat if tiled else a_dst, c_src, x_new, fitness, slot, lin_w, att_w,
-                              w3, lin_b, stat if dense else None)
+        ctx.save_for_backward(x, xq_raw, w_comp, a_dst, c_src, x_new, fitness, slot, lin_w, att_w, w3, lin_b, stat if dense else None)
         return x_out
 
     @staticmethod
@@ -973,15 +944,12 @@ class _ASAPool(Function):
         att_x = att_w[:, d:]                 # (a view: its one row is contiguous)
         # c = x att_x^T: its gradient g_c (x) att_x rides in the source-side kernel's store of gx (it computes g_c itself) instead of
         # being a read-modify-write pass over gx
-        if ctx.tiled:        # a_dst holds the forward's per-row record; the segment max's backward is part of the call
-            gx, g_a, g_c = ops.tile_asap_scores_bwd(x, x_new, gxnew, xq_raw, s, c_src, w_comp[0].contiguous(), att_x[0].contiguous(), ctx.slope,
-                                                    s.tile_plan("in"), s.tile_plan("out"), a_dst)
         dense = ctx.dense and ops.dense_pool_fits(gxnew, x_new, xq_raw)
         fuse_max = False
         if dense:
             gx, g_a, g_c, ties = ops.dense_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, dense_stat, s.dense_plan("in"),
                                                                  s.dense_plan("out"), xq_raw, gx_rank1=att_x[0])
-        elif not ctx.tiled:
+        else:
             # the stored form (a graph with out_eid: the circuit DAGs) carries the segment max's backward in its source-side walk
             fuse_max = _ASAP_FUSED and s.out_eid is not None and d <= 128
             gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0],
@@ -996,7 +964,7 @@ class _ASAPool(Function):
         ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
         if dense:
             ops.dense_segment_max_bwd_(gx, x, xq_raw, s, ties, (g_a, w_comp[0].contiguous()), s.dense_plan("out"))
-        elif not ctx.tiled and not fuse_max:
+        elif not fuse_max:
             ops.csr_segment_max_bwd_(gx, x, xq_raw, None, s, ties=ties, gmax_rank1=(g_a, w_comp[0].contiguous()))
         g_lin_w, g_lin_b, g_att_w = ops.asap_compose_bwd(g_w_comp, g_att_b, lin_w, lin_b, att_w, g_att_x)
         return (gx, g_lin_w, g_lin_b, g_att_w, g_att_b, gw3[0:1], gb3[0:1], gw3[1:2], gw3[2:3], gb3[2:3],

@@ -1746,26 +1746,10 @@ def leconv_fitness_bwd(gfit, fitness, in_ptr, out_ptr, out_dst):
     return gpqr
 
 
-# ------------------------------------------------------------------------------------------ tiled row walks (round 5)
-# The coarsened graphs ASAPooling makes of large circuits are unions of dense blocks: a tile of rows whose centres are close in
-# program order shares its sources (csrc/tile_common.hpp).  A TilePlan is built once per structure and direction.
-TILE_ROWS = int(os.environ.get("MLQEM_TILE_ROWS", "32"))      # rows per tile (<= 128)
-TILE_CAP = int(os.environ.get("MLQEM_TILE_CAP", "224"))       # slots of a tile's source union staged in LDS
-
-
-class TilePlan:
-    __slots__ = ("tinfo", "rinfo", "uni", "loc", "num_tiles", "cap", "tile_rows")
-
-    def __init__(self, tinfo, rinfo, uni, loc, num_tiles, cap, tile_rows):
-        self.tinfo, self.rinfo, self.uni, self.loc = tinfo, rinfo, uni, loc
-        self.num_tiles, self.cap, self.tile_rows = int(num_tiles), int(cap), int(tile_rows)
-
-    def args(self):
-        return _p(self.tinfo), _p(self.rinfo), _p(self.uni), _p(self.loc), self.num_tiles, self.cap, self.tile_rows
-
-
-def tile_plan_max_span() -> int:
-    return int(_lib.load().mlqem_tile_plan_max_span())
+# ------------------------------------------------------------------------------------------ row order of a coarsened graph
+# The coarsened graphs ASAPooling makes of large circuits are unions of dense blocks: rows whose centres are close in program order
+# share their sources.  The dense-block plans (DensePlan below) take a structure's long rows 16 at a time in that order.
+ORDER_SPAN_SLACK = 32      # added to twice the largest pooled graph: a bound on the id range of one block's entries
 
 
 def tile_order_by_position(slot, graph_ptr, new_graph_ptr, num_graphs, k_total):
@@ -1773,25 +1757,6 @@ def tile_order_by_position(slot, graph_ptr, new_graph_ptr, num_graphs, k_total):
     code = _lib.load().mlqem_tile_order_by_position(_p(slot), _p(graph_ptr), _p(new_graph_ptr), num_graphs, _p(order), _stream())
     _lib.check(code, "mlqem_tile_order_by_position")
     return order
-
-
-def tile_plan_build(ptr, idx, num_rows, num_entries, order, max_span, tile_rows=None, cap=None) -> TilePlan:
-    """A plan of the CSR (ptr, idx): tiles of ``tile_rows`` rows taken in ``order`` (None: index order).  ``num_entries``: size of
-    ``idx`` (or a bound on it); ``max_span``: a bound on the id range of one tile's entries (two graphs' worth of ids when the
-    graphs' ids are contiguous ranges and a tile may straddle a boundary)."""
-    tile_rows = TILE_ROWS if tile_rows is None else tile_rows
-    cap = TILE_CAP if cap is None else cap
-    dev = ptr.device
-    _vec(ptr, "ptr", num_rows + 1, torch.int32)
-    num_tiles = (num_rows + tile_rows - 1) // tile_rows
-    rinfo = torch.empty((max(num_tiles * tile_rows, 1), 4), dtype=torch.int32, device=dev)
-    tinfo = torch.empty((max(num_tiles, 1), 4), dtype=torch.int32, device=dev)
-    uni = torch.empty(max(num_tiles * cap, 1), dtype=torch.int32, device=dev)
-    loc = torch.empty(max(int(num_entries), 1), dtype=torch.int16, device=dev)
-    code = _lib.load().mlqem_tile_plan_build(_p(ptr), _p(idx), _p(order), num_rows, tile_rows, cap, int(max_span), _p(rinfo), _p(tinfo),
-                                             _p(uni), _p(loc), _stream())
-    _lib.check(code, "mlqem_tile_plan_build")
-    return TilePlan(tinfo, rinfo, uni, loc, num_tiles, cap, tile_rows)
 
 
 class DensePlan:
@@ -1958,79 +1923,3 @@ def dense_segment_max_bwd_(gx, x, xmax, s, ties, gmax_rank1, plan_out: DensePlan
     _lib.check(code, "mlqem_dense_segment_max_bwd_f32")
     return gx
 
-
-_LDS_BUDGET = 80 * 1024      # per workgroup: two workgroups of a tiled kernel per CU (160 KB)
-
-
-def tile_attention_fits(heads, channels, head_pitch, cap=None) -> bool:
-    cap = TILE_CAP if cap is None else cap
-    return (13 <= channels <= 16 and (head_pitch or channels) == 16 and heads <= 16
-            and _lib.load().mlqem_tile_attention_cap(heads, TILE_ROWS, 2 * _LDS_BUDGET) >= cap)
-
-
-def tile_pool_fits(d, cap=None) -> bool:
-    cap = TILE_CAP if cap is None else cap
-    return 0 < d <= 48 and _lib.load().mlqem_tile_pool_cap(d, TILE_ROWS, 2 * _LDS_BUDGET) >= cap
-
-
-def tile_attention(qkvs, in_ptr, in_src, loops, num_edges, heads, channels, plan: TilePlan, drop_p=0.0, seed=0, head_pitch=0, train=True):
-    """``transformer_attention_train`` on a plan of the in-CSR: (out, attn_out, m, den); ``train=False``: out alone."""
-    n, hc = qkvs.shape[0], heads * channels
-    dev = qkvs.device
-    out = padded_empty(n, hc, dev)
-    attn = padded_empty(n, hc, dev) if train else None
-    m = torch.empty((max(n, 1), heads), dtype=torch.float32, device=dev) if train else None
-    den = torch.empty_like(m) if train else None
-    code = _lib.load().mlqem_tile_attention_train_f32(
-        _p(qkvs), _mat(qkvs, "qkvs"), _p(in_ptr), _p(in_src), _p(loops), n, num_edges, heads, channels, float(drop_p),
-        int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1, int(head_pitch), *plan.args(),
-        _p(out), _mat(out, "out"), _p(attn), _mat(attn, "attn") if train else 0, _p(m), _p(den), _stream())
-    _lib.check(code, "mlqem_tile_attention_train_f32")
-    return (out, attn, m, den) if train else out
-
-
-def tile_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, plan_in: TilePlan, plan_out: TilePlan, drop_p=0.0, seed=0,
-                       head_pitch=0):
-    n = qkvs.shape[0]
-    g = rowmajor(g)
-    dev = qkvs.device
-    gqkvs = padded_empty(n, 4 * heads * (head_pitch or channels), dev)
-    rec = torch.empty(4 * max(n, 1) * heads, dtype=torch.float32, device=dev)
-    code = _lib.load().mlqem_tile_attention_bwd_f32(
-        _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr), _p(s.in_src),
-        _p(s.out_ptr), _p(s.out_dst), _p(s.loops), n, num_edges, heads, channels, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
-        _p(_seed_counter) if drop_p > 0 else None, 1, int(head_pitch), *plan_in.args(), *plan_out.args(), _p(gqkvs), _mat(gqkvs, "gqkvs"),
-        _p(rec), _stream())
-    _lib.check(code, "mlqem_tile_attention_bwd_f32")
-    return gqkvs
-
-
-def tile_asap_scores(x, in_ptr, in_src, c_src, w_comp, b_comp, w3, b3, negative_slope, plan: TilePlan):
-    """(xnew, xmax, stat [N,4], pqr [N,3]) -- ASAPooling's segment max, composed score, softmax-sum and LEConv projections in one pass."""
-    n, d = x.shape
-    dev = x.device
-    xnew, xmax = padded_empty(n, d, dev), padded_empty(n, d, dev)
-    stat = torch.empty((max(n, 1), 4), dtype=torch.float32, device=dev)
-    pqr = torch.empty((max(n, 1), 3), dtype=torch.float32, device=dev)[:n]
-    _vec(c_src, "c_src", n)
-    _vec(w_comp, "w_comp", d)
-    code = _lib.load().mlqem_tile_asap_scores_f32(_p(x), _mat(x, "x"), _p(in_ptr), _p(in_src), _p(c_src), _p(w_comp), _p(b_comp), _p(w3),
-                                                  _p(b3), float(negative_slope), n, d, *plan.args(), _p(xnew), _mat(xnew, "xnew"),
-                                                  _p(xmax), _mat(xmax, "xmax"), _p(stat), _p(pqr), _stream())
-    _lib.check(code, "mlqem_tile_asap_scores_f32")
-    return xnew, xmax, stat, pqr
-
-
-def tile_asap_scores_bwd(x, xnew, gnew, xmax, s, c_src, w_comp, rank1, negative_slope, plan_in: TilePlan, plan_out: TilePlan, stat):
-    """(gx, g_a, g_c): gradients of x (through the sum, c_src and the segment max), of the destination score and of c_src."""
-    n, d = x.shape
-    dev = x.device
-    gx, share = padded_empty(n, d, dev), padded_empty(n, d, dev)
-    g_a = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
-    g_c = torch.empty(max(n, 1), dtype=torch.float32, device=dev)[:n]
-    code = _lib.load().mlqem_tile_asap_scores_bwd_f32(
-        _p(x), _mat(x, "x"), _p(xnew), _mat(xnew, "xnew"), _p(gnew), _mat(gnew, "gnew"), _p(xmax), _mat(xmax, "xmax"), _p(s.in_ptr),
-        _p(s.in_src), _p(s.out_ptr), _p(s.out_dst), _p(c_src), _p(w_comp), _p(rank1), float(negative_slope), n, d, *plan_in.args(),
-        *plan_out.args(), _p(stat), _p(g_a), _p(share), _mat(share, "share"), _p(gx), _mat(gx, "gx"), _p(g_c), _stream())
-    _lib.check(code, "mlqem_tile_asap_scores_bwd_f32")
-    return gx, g_a, g_c

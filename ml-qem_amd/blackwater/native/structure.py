@@ -49,45 +49,31 @@ class GraphStructure:
         raise AttributeError(name)
 
     # ------------------------------------------------------------------------------------------------
-    def set_tile_spec(self, make):
+    def set_block_order(self, make):
         """Marks the structure as one whose rows share their sources when taken in a certain order (ASAPooling's coarsened graphs
-        of large circuits, rows by the program position of their centres): the edge walks over it then run tiled
-        (csrc/tile_common.hpp).  ``make()`` -> (order, max_span) runs when the first plan is built (a structure no layer reads
-        never pays for it); ``max_span``: a bound on the id range of one tile's entries."""
-        self._tile_spec = make
-        self._tile_plans = {}
+        of large circuits, rows by the program position of their centres): the edge walks over it then take its long rows as
+        dense blocks (csrc/dense_block.hpp).  ``make()`` -> (order, max_span) runs when the first plan is built (a structure no
+        layer reads never pays for it); ``max_span``: a bound on the id range of one block's entries."""
+        self._block_order = make
         self._dense_plans = {}
 
     @property
-    def tiled(self) -> bool:
-        return self._tile_spec is not None
+    def blocked(self) -> bool:
+        return self._block_order is not None
 
     def dense_plan(self, direction: str):
         """The dense blocks of the in- ("in") or out-structure ("out") (csrc/dense_block.hpp), built on first use; None for a
-        structure without a tile spec (its rows are short, or nothing is known about their order)."""
-        if self._tile_spec is None:
+        structure without a block order (its rows are short, or nothing is known about their order)."""
+        if self._block_order is None:
             return None
         if direction not in self._dense_plans:
-            if callable(self._tile_spec):
-                self._tile_spec = self._tile_spec()
-            order, max_span = self._tile_spec
+            if callable(self._block_order):
+                self._block_order = self._block_order()
+            order, max_span = self._block_order
             ptr, idx = (self.in_ptr, self.in_src) if direction == "in" else (self.out_ptr, self.out_dst)
             self._dense_plans[direction] = ops.dense_plan_build(ptr, idx, self.loops, self.num_nodes, self.graph_ptr, self.num_graphs,
                                                                 order, max_span)
         return self._dense_plans[direction]
-
-    def tile_plan(self, direction: str):
-        """The plan of the in-CSR ("in": forward and destination-side passes) or of the out-CSR ("out": source-side passes),
-        built on first use; None for a structure without a tile spec."""
-        if self._tile_spec is None:
-            return None
-        if direction not in self._tile_plans:
-            if callable(self._tile_spec):
-                self._tile_spec = self._tile_spec()
-            order, max_span = self._tile_spec
-            ptr, idx = (self.in_ptr, self.in_src) if direction == "in" else (self.out_ptr, self.out_dst)
-            self._tile_plans[direction] = ops.tile_plan_build(ptr, idx, self.num_nodes, int(idx.shape[0]), order, max_span)
-        return self._tile_plans[direction]
 
     @property
     def connectivity_built(self) -> bool:
@@ -100,8 +86,7 @@ class GraphStructure:
         # make it a function of the bucket) and bounds on the largest graph before / after.  None: sizes come from graph_sizes.
         self.pool_plan = None
         self.num_real = None          # graphs of the batch that are circuits (the rest: edgeless fillers at the end)
-        self._tile_spec = None        # (order, tiles, num_tiles, max_span): what a tiled row walk's plan is built from (set_tile_spec)
-        self._tile_plans = {}
+        self._block_order = None      # (order, max_span): what the dense-block plans are built from (set_block_order)
         self._dense_plans = {}
         self._norms = norms
         self._derived = {} if derived is None else dict(derived)

@@ -134,7 +134,7 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device and per kernel: remembered per (device, kernel), so that a process
 // that drives several GPUs raises the limit on each of them (a `static const int once = hipFuncSetAttribute(...)` did it for the first
-// device only and the launch failed on the second: ADVICE r04) and a launch path pays one table lookup.  Defined in tile_plan.hip.
+// device only and the launch failed on the second: ADVICE r04) and a launch path pays one table lookup.  Defined in row_order.hip.
 bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes);
 template <class K> inline bool ensure_dynamic_lds(K kernel, size_t bytes) {
   if (bytes > 160 * 1024) return false;

@@ -21,9 +21,11 @@
 #pragma once
 
 #include "attn_q4.hpp"
-#include "tile_common.hpp"
+#include "common.hpp"
 
 namespace mlqem {
+
+typedef float f4a __attribute__((ext_vector_type(4)));   // a 16-byte aligned access (LDS: ds_read_b128 / ds_write_b128)
 
 constexpr int kDbRows = 16;
 constexpr int kDbCap = 512;                                  // union slots of a block (32 column blocks of 16)

@@ -55,7 +55,7 @@ for name in ("in", "out"):
     print(f"plan {name}: {nb} blocks ({100.0 * ok.mean():.1f} % usable), union mean {rec[ok, 1].mean():.0f} max {rec[:, 1].max()}, "
           f"rows in blocks {flag.sum()} ({100.0 * flag.mean():.1f} %) holding {100.0 * deg[flag].sum() / deg.sum():.1f} % of the entries, "
           f"cells {cells} = {cells / max(deg[flag].sum(), 1):.2f} per entry", flush=True)
-spec = s._tile_spec
+spec = s._block_order
 t_build = timed(lambda: ops.dense_plan_build(s.in_ptr, s.in_src, s.loops, n, s.graph_ptr, s.num_graphs, spec[0], spec[1]))
 print(f"plan build (one direction): {t_build:.1f} us")
 

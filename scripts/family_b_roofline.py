@@ -68,8 +68,8 @@ STRUCTURAL = {"segment_topk", "asap_coarsen_lists", "asap_coarsen_dense", "asap_
               "tile_order_by_position", "pool_keep_ptr", "asap_slot_map", "csr_build", "ell_from_csr"}
 SKIP = {"padded_empty", "padded_copy", "rowmajor", "set_seed_counter", "prepare_device", "reset_tickets", "check_overflow_flags",
         "pool_gate_unpack", "pool_node_gates", "layer_identity_vectors", "pooled_means", "dense_attention_supported",
-        "dense_pool_supported", "dense_pool_fits", "tile_attention_fits", "tile_pool_fits", "seq2_fits", "mlp1_fits",
-        "pooled_grad_supported", "asap_lists_max_k", "asap_rows_max_bits", "asap_dense_max_k", "tile_plan_max_span"}
+        "dense_pool_supported", "dense_pool_fits", "seq2_fits", "mlp1_fits",
+        "pooled_grad_supported", "asap_lists_max_k", "asap_rows_max_bits", "asap_dense_max_k"}
 
 
 def tensors_in(obj, seen):

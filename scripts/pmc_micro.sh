@@ -1,7 +1,7 @@
 #!/bin/bash
-# Diagnostic counters per kernel over a level-1 micro benchmark -- scripts/tile_micro.py (the tiled and per-edge kernels) or, with
-# PMC_SCRIPT=dense_micro.py, the dense-block kernels: one rocprofv3 --pmc pass per counter group, no tracing domains.
-#   bash scripts/pmc_tiles.sh "CNT_A CNT_B" "CNT_C ..."  -> gpurun_out/pmc_tiles.json (PMC_OUT names another file)
+# Diagnostic counters per kernel over a level-1 micro benchmark -- a micro benchmark script (PMC_SCRIPT, default dense_micro.py: the dense-block and per-edge level-1 kernels;
+# pooled_grad_micro.py: the pooled-gradient aggregation): one rocprofv3 --pmc pass per counter group, no tracing domains.
+#   bash scripts/pmc_micro.sh "CNT_A CNT_B" "CNT_C ..."  -> gpurun_out/pmc_micro.json (PMC_OUT names another file)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -10,10 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1)); rm -rf /tmp/tpmc_$i
-  timeout 300 rocprofv3 --pmc $grp --output-format csv -d /tmp/tpmc_$i -- python3 "$ROOT/scripts/${PMC_SCRIPT:-tile_micro.py}" 2 > /tmp/tpmc_$i.log 2>&1 || { echo "pass $i ($grp) rc=$?"; tail -5 /tmp/tpmc_$i.log; }
+  timeout 300 rocprofv3 --pmc $grp --output-format csv -d /tmp/tpmc_$i -- python3 "$ROOT/scripts/${PMC_SCRIPT:-dense_micro.py}" 2 > /tmp/tpmc_$i.log 2>&1 || { echo "pass $i ($grp) rc=$?"; tail -5 /tmp/tpmc_$i.log; }
   echo "pass $i done: $grp"
 done
-python3 - "$OUT/${PMC_OUT:-pmc_tiles.json}" <<'PY'
+python3 - "$OUT/${PMC_OUT:-pmc_micro.json}" <<'PY'
 import csv, glob, json, sys, collections
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob("/tmp/tpmc_*/**/*counter_collection.csv", recursive=True):
@@ -31,6 +31,6 @@ for name, c in vals.items():
     out[name[:90]] = row
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 for k, v in out.items():
-    if "tile_" in k or "attn" in k or "softmax" in k or "dense_" in k:
+    if "attn" in k or "softmax" in k or "dense_" in k:
         print(k[:70], v)
 PY

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 for form in written computed computed_not_written; do
-  PG_FORM=$form PMC_SCRIPT=pooled_grad_micro.py PMC_OUT=pg_pmc_$form.json bash scripts/pmc_tiles.sh "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/pg_pmc_$form.log 2>&1
+  PG_FORM=$form PMC_SCRIPT=pooled_grad_micro.py PMC_OUT=pg_pmc_$form.json bash scripts/pmc_micro.sh "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/pg_pmc_$form.log 2>&1
   echo "$form done"
 done
 python3 - <<'PY'

@@ -41,7 +41,7 @@ for kind, kw in kinds.items():
     gm = ops.padded_empty(nb, c, dev).normal_() if kw["mean"] else None
     gw = ops.padded_empty(nb, c, dev).normal_()
     pg = ops.PooledGrad(gm, gw, gptr, n, wts, 1.25, bits)
-    form = os.environ.get("PG_FORM", "")      # one form only (counter passes: scripts/pmc_tiles.sh averages a kernel's launches)
+    form = os.environ.get("PG_FORM", "")      # one form only (counter passes: scripts/pmc_micro.sh averages a kernel's launches)
     agg = lambda **k: pg.aggregate(s.out_ptr, s.out_dst, s.out_ell, kw["cscale"], rscale=kw["rscale"], dself=kw["dself"], **k)
     if form == "computed":
         timed(lambda: agg()); continue

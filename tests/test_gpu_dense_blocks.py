@@ -10,10 +10,91 @@ import numpy as np
 import pytest
 import torch
 
-from test_gpu_tiles import _blocky_graphs, _structure
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+def _blocky_graphs(rng, sizes, loops_p=0.0):
+    """Graphs whose rows share sources in blocks, like S^T A S of a circuit with barriers: per graph a few hubs, each with a window of
+    ids; a row is short (0-3 sources anywhere near) or long (60-200 sources of one hub's window).  No parallel edges, no stored self
+    entries (``loops`` carries those).  Returns (edge_index [2, E], loops [N], sizes)."""
+    src, dst, off = [], [], 0
+    for n in sizes:
+        hubs = max(1, n // 150)
+        for i in range(n):
+            hub = rng.randint(hubs)
+            lo = hub * n // hubs
+            win = np.arange(lo, min(n, lo + max(40, min(320, n // hubs + 60))))
+            win = win[win != i]
+            if rng.rand() < 0.3 and len(win) >= 60:
+                d = rng.randint(60, min(200, len(win)) + 1)
+            else:
+                d = rng.randint(0, 4)
+            picks = rng.choice(win, size=min(d, len(win)), replace=False) if len(win) and d else np.zeros(0, np.int64)
+            src.append(picks + off)
+            dst.append(np.full(len(picks), i + off))
+        off += n
+    ei = np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64)
+    n_total = int(sum(sizes))
+    loops = (rng.rand(n_total) < loops_p).astype(np.int64)
+    return ei, loops, n_total
+
+
+def _structure(ei, loops, n, sizes):
+    from blackwater.native.structure import GraphStructure
+
+    full = np.concatenate([ei, np.repeat(np.stack([np.arange(n)] * 2), loops, axis=1)], axis=1)
+    ptr = np.zeros(len(sizes) + 1, np.int32)
+    ptr[1:] = np.cumsum(sizes)
+    s = GraphStructure.from_edge_index(torch.from_numpy(full).to(DEV), n, graph_ptr=torch.from_numpy(ptr))
+    s.out_eid = None                         # the recomputing backward forms, as on the coarsened graphs
+    return s
+
+
+def _family_b_on_100q(train, dense_on=False):
+    from blackwater.data.arena import GraphArena
+    from blackwater.data.synthetic import tfim_corpus
+    from blackwater.native import functional as F
+    from blackwater.nn import ExpValCircuitGraphModel
+
+    corpus = tfim_corpus(100, [2, 4], 2, seed=42, two_q="ecr", exp_value_size=4)
+    arena = GraphArena.from_arrays(corpus["x"], corpus["edge_index"], corpus["y"][:, None, :], corpus["noisy"][:, None, :], corpus["depth"],
+                                   corpus["observable"], device=DEV)
+    torch.manual_seed(0)
+    model = ExpValCircuitGraphModel(22, 15).to(DEV)
+    model.train(train)
+    was = F._DENSE_BLOCKS
+    F._DENSE_BLOCKS = dense_on       # off: the per-edge kernels on every row
+    try:
+        batch = arena.batch(np.arange(len(arena)))
+        out = model(*batch.model_args())
+        grads = None
+        if train:
+            model.zero_grad()
+            (out * torch.linspace(1.0, 2.0, out.numel(), device=DEV).view_as(out)).sum().backward()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        return out.detach().clone(), grads
+    finally:
+        F._DENSE_BLOCKS = was
+
+
+def test_order_by_position_is_the_argsort_of_the_kept_nodes():
+    from blackwater.native import ops
+
+    rng = np.random.RandomState(5)
+    sizes = [1000, 3, 0, 517]
+    keep = [(k + 1) // 2 for k in sizes]
+    gptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    nptr = np.concatenate([[0], np.cumsum(keep)]).astype(np.int32)
+    perm = np.concatenate([np.sort(rng.choice(k, size=kk, replace=False))[rng.permutation(kk)] + o for k, kk, o in zip(sizes, keep, gptr[:-1])])
+    perm_d = torch.from_numpy(perm.astype(np.int32)).to(DEV)
+    slot = ops.asap_slot_map(perm_d, int(gptr[-1]))
+    order = ops.tile_order_by_position(slot, torch.from_numpy(gptr).to(DEV), torch.from_numpy(nptr).to(DEV), len(sizes), int(nptr[-1]))
+    want = np.concatenate([np.argsort(perm[a:b], kind="stable") + a for a, b in zip(nptr[:-1], nptr[1:])])
+    assert (order.cpu().numpy() == want).all()
+
+
 SIZES = [700, 1, 333, 64, 2, 1500]
 CAP = 512            # kDbCap of csrc/dense_block.hpp: union slots of a block
 
@@ -33,7 +114,7 @@ def _make(seed, loops_p, sizes=SIZES, permute=True):
     centre[offs[-1]:] = rng.rand(sizes[-1])            # ... and the last graph's rows in NO order: its blocks outgrow the capacity
     order = torch.cat([torch.from_numpy(np.argsort(centre[o:o + k], kind="stable") + o) for k, o in zip(sizes, offs)])
     order = order.to(torch.int32).to(DEV)
-    s.set_tile_spec(lambda: (order, max(sizes) + 8))
+    s.set_block_order(lambda: (order, max(sizes) + 8))
     return s, order, rng
 
 
@@ -145,7 +226,7 @@ def test_a_structure_without_long_rows_has_no_blocks_and_the_same_results():
     ei = np.stack([rng.randint(0, 40, 90), rng.randint(0, 40, 90)])
     ei = np.unique(ei[:, ei[0] != ei[1]], axis=1)
     s = _structure(ei, np.zeros(49, np.int64), 49, sizes)
-    s.set_tile_spec(lambda: (None, 64))
+    s.set_block_order(lambda: (None, 64))
     pin = s.dense_plan("in")
     assert int(pin.counter.item()) == 0 and int(pin.row_flag.sum().item()) == 0
     qkvs = _qkvs(rng, 49, 2, 15)
@@ -215,17 +296,16 @@ def test_family_b_on_100_qubit_graphs_with_dense_blocks_equals_per_edge():
     per-edge kernels on every row -- predictions within 2e-5 of their scale, every parameter gradient within 2e-4 of the largest
     gradient (the forms sum a row's 200 entries in different orders); and blocks were really used."""
     from blackwater.native import ops
-    from test_gpu_tiles import _family_b_on_100q
 
     calls = []
     real = ops.dense_attention_train
     ops.dense_attention_train = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     try:
-        out_d, _ = _family_b_on_100q(False, train=False, dense_on=True)
-        out_e, _ = _family_b_on_100q(False, train=False, dense_on=False)
+        out_d, _ = _family_b_on_100q(train=False, dense_on=True)
+        out_e, _ = _family_b_on_100q(train=False, dense_on=False)
         assert (out_d - out_e).abs().max().item() < 1e-5 * max(1.0, out_e.abs().max().item())
-        out_d, g_d = _family_b_on_100q(False, train=True, dense_on=True)
-        out_e, g_e = _family_b_on_100q(False, train=True, dense_on=False)
+        out_d, g_d = _family_b_on_100q(train=True, dense_on=True)
+        out_e, g_e = _family_b_on_100q(train=True, dense_on=False)
     finally:
         ops.dense_attention_train = real
     assert len(calls) == 2                        # the second TransformerConv's forward of both dense runs (parameters want gradients in both)
