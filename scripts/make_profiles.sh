@@ -15,6 +15,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the headline record (bench.py's one stdout line); the full record of every leg is written by bench.py to gpurun_out/bench_full.json
 timeout 900 python3 "$ROOT/bench.py" 2>/dev/null | grep '{"metric"' > "$OUT/bench_line.json"
+# (the profiled --no-cpu-baseline runs below write their own, shorter, full records elsewhere)
+export MLQEM_BENCH_FULL_RECORD=gpurun_out/bench_full_profiled.json
 
 summarise() {  # $1 = rocprof output dir, $2 = log, $3 = output csv, $4 = label
 python3 - "$1" "$2" "$3" "$4" <<'PY'
