@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 39 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 40 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -491,6 +491,13 @@ int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const float* nscal,
                          int32_t* out_dst_b, int32_t* out_eid_b, int32_t* loops_b, int32_t* in_ell_b, int32_t* out_ell_b,
                          mlqem_stream_t stream);
 
+/* The per-graph inputs of a batch in ONE launch (ABI 40): dst[k][b, :] = src[k][sel[b], :] for up to four fp32 row-major matrices
+ * src[k] [G, width[k]] (the dataset's labels y, noisy values, circuit depths and observables; reference collate:
+ * torch_geometric DataLoader at docs/tutorials/__ml_models.py:105-119 concatenates them per batch on the host) -- five torch gather
+ * launches per step before, which a captured step of 32 four-qubit circuits (~80 launches of ~5 us) feels. */
+int mlqem_gather_rows_f32(int count, const float* const* src, const int64_t* width, const int32_t* sel, int64_t B, float* const* dst,
+                          mlqem_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Family B (docs/tutorials/gnn.py:70-276): TransformerConv attention and ASAPooling.  Forward kernels.
  * ---------------------------------------------------------------------------------------------------- */
@@ -624,13 +631,15 @@ int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t E, int64_t capac
  * popcounts give new_in_ptr / new_out_ptr directly, and a second kernel lists rows and columns in ascending order --
  * the same arrays mlqem_csr_build yields from the two-hop path's sorted edge list.  graph_ptr / new_graph_ptr: node
  * ranges of the graphs before / after pooling; perm: the kept centres, graph by graph (mlqem_segment_topk); kmax >= the
- * largest k_g (host knows it: k_g = ceil(ratio * n_g)).  new_in_src / new_out_dst / new_out_eid must hold
- * sum_g k_g (k_g - 1) entries; only the first new_in_ptr[K] are written.  new_loops[K] = 0 (no diagonal). */
+ * largest k_g (host knows it: k_g = ceil(ratio * n_g); a bound will do).  new_in_src / new_out_dst / new_out_eid must hold
+ * sum_g k_g (k_g - 1) entries; only the first new_in_ptr[K] are written.  new_loops[K] = 0 (no diagonal).
+ * slot_ready (ABI 40): `slot` already holds mlqem_asap_slot_map(perm) -- the call then makes three launches (bit matrices, one
+ * scan of both degree vectors, the fill) where ABI <= 39 made eleven. */
 int mlqem_asap_coarsen_dense_max_k(void);
 size_t mlqem_asap_coarsen_dense_workspace_bytes(int64_t B, int64_t K, int kmax);
 int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                              const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N, int64_t K,
-                             int64_t B, int kmax, int32_t* slot, int32_t* new_in_ptr, int32_t* new_in_src,
+                             int64_t B, int kmax, int32_t* slot, int slot_ready, int32_t* new_in_ptr, int32_t* new_in_src,
                              int32_t* new_out_ptr, int32_t* new_out_dst, int32_t* new_out_eid, int32_t* new_loops,
                              void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
@@ -715,6 +724,16 @@ int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax
 int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, const float* xnew, int64_t ldn,
                                     const float* fitness, const int32_t* slot, int64_t N, int C, float* gxnew,
                                     int64_t ldgn, float* gfit, mlqem_stream_t stream);
+
+/* The three tiny weight gradients at the end of ASAPooling's backward in ONE pass (ABI 40): up to three weighted column sums over the
+ * same N rows.  Term t: weight columns g[t] [N, ldg[t]] (k[t] <= 3 of them), matrix x[t] [N, ldx[t]] with D columns in 16-byte rows;
+ * out [sum k, D] row-major in term order = g[t]^T x[t], bias [sum k] = the column sums of the weights.  Replaces the autograd of
+ * ASAPooling's `lin` / `att` / `gnn_score` projections (torch_geometric ASAPooling.forward, called at docs/tutorials/gnn.py:105-112):
+ * three [N, k] x [N, D] weight-gradient GEMMs.  Deterministic (fixed-order partial sums).  workspace:
+ * mlqem_rank_grad_workspace_bytes(D); D <= 256. */
+size_t mlqem_rank_grad_workspace_bytes(int D);
+int mlqem_rank_grad_f32(int terms, const float* const* x, const int64_t* ldx, const float* const* g, const int64_t* ldg, const int* k,
+                        int64_t N, int D, float* out, float* bias, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 
 /* Backward of mlqem_leconv_fitness_f32 onto pqr[N,3]. */
 int mlqem_leconv_fitness_bwd_f32(const float* gfit, const float* fitness, const int32_t* in_ptr, const int32_t* out_ptr,

@@ -107,6 +107,8 @@ SIGNATURES = {
     "mlqem_leconv_fitness_f32": (_I, [_P, _P, _P, _L, _P, _P]),
     "mlqem_gather_scale_rows_f32": (_I, [_P, _L, _P, _P, _L, _I, _P, _L, _P]),
     "mlqem_pool_keep_ptr": (_I, [_P, _L, _F, _P, _P]),
+    "mlqem_rank_grad_workspace_bytes": (_S, [_I]),
+    "mlqem_rank_grad_f32": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _S, _P]),
     "mlqem_segment_topk_workspace_bytes": (_S, [_L, _L]),
     "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_workspace_bytes": (_S, [_L]),
@@ -132,7 +134,8 @@ SIGNATURES = {
     "mlqem_asap_coarsen_lists_fill": (_I, [_L, _L, _L, _L, _P, _P, _P, _P, _P, _L, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_dense_max_k": (_I, []),
     "mlqem_asap_coarsen_dense_workspace_bytes": (_S, [_L, _L, _I]),
-    "mlqem_asap_coarsen_dense": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "mlqem_asap_coarsen_dense": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "mlqem_gather_rows_f32": (_I, [_I, _P, _P, _P, _L, _P, _P]),
     "mlqem_transformer_attention_train_f32": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _F, _U, _P, _I, _P, _I, _P, _L, _P, _L, _P, _P, _P]),
     "mlqem_transformer_attention_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I,
                                                  _F, _U, _P, _I, _I, _P, _L, _P, _P, _P]),
@@ -181,7 +184,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 39   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 40   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

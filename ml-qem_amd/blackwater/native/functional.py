@@ -874,13 +874,16 @@ class _ASAPool(Function):
             nmax, kmax = (int(sizes.max()), int(keep.max())) if have else (0, 0)
         perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=min(nmax, n))
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
+        # the backward's slot[] (cluster id of every kept centre, -1 elsewhere); the dense coarsening reads the same map
+        slot_fwd = ops.asap_slot_map(perm, n)
         use_dense, use_rows, use_lists, link = _ASAP_DENSE, _ASAP_ROWS, _ASAP_LISTS, _ASAP_LINK   # the switches as they stand now: build() may run later
 
         def build():
             dense_ok = use_dense and have and kmax <= ops.asap_dense_max_k()
             if dense_ok:
                 # small graphs: the pooled adjacency as per-graph bit matrices in LDS -- no device->host copy anywhere
-                csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep)
+                csr, slot, cap = ops.asap_coarsen_dense(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, keep,
+                                                        slot=slot_fwd)
                 num_edges = cap     # an upper bound: the true count stays on the device (in_ptr[k_total])
             done = None
             if not dense_ok and use_rows and use_lists and have and kmax <= ops.asap_lists_max_k():
@@ -902,9 +905,9 @@ class _ASAPool(Function):
                 num_edges = int(ei.shape[1])
             return (csr[0], csr[1], csr[2], csr[3], csr[4], num_edges, csr.out_eid), slot
 
-        # the coarsened connectivity S^T A S waits until a layer reads it (GraphStructure.deferred); the backward's slot[] (cluster id of
-        # every kept centre, -1 elsewhere) does not depend on it
-        slot = ops.asap_slot_map(perm, n)
+        # the coarsened connectivity S^T A S waits until a layer reads it (GraphStructure.deferred); the backward's slot[] does not
+        # depend on it
+        slot = slot_fwd
         holder["structure"] = GraphStructure.deferred(k_total, new_ptr, s.num_graphs, lambda: build()[0], graph_sizes=None if plan else keep)
         if plan:
             holder["structure"].pool_plan = plan[1:]             # the next pooling's level
@@ -936,9 +939,6 @@ class _ASAPool(Function):
         else:
             gpqr = ops.leconv_fitness_bwd(gfit, fitness, s.in_ptr, s.out_ptr, s.out_dst)
         ops.linear(gpqr, w3, transposed=True, out=gxnew, accumulate=True)
-        gw3 = torch.empty_like(w3)
-        gb3 = torch.empty(3, dtype=torch.float32, device=dev)
-        ops.linear_wgrad(gpqr, x_new, gw3, gb3)
         # x' = sum_e softmax(LeakyReLU(a_i + c_j)) x_j
         # ... its destination-side walk also counts the ties of the segment max below (same x, same entries)
         att_x = att_w[:, d:]                 # (a view: its one row is contiguous)
@@ -954,14 +954,20 @@ class _ASAPool(Function):
             fuse_max = _ASAP_FUSED and s.out_eid is not None and d <= 128
             gx, g_a, g_c, ties = ops.csr_softmax_aggregate_bwd(x, x_new, gxnew, s, e, a_dst, c_src, ctx.slope, xmax=xq_raw, gx_rank1=att_x[0],
                                                                fuse_max_col=w_comp[0].contiguous() if fuse_max else None)
-        g_c2, g_a2 = g_c.unsqueeze(1), g_a.unsqueeze(1)
-        g_att_x = torch.empty((1, d), dtype=torch.float32, device=dev)
-        ops.linear_wgrad(g_c2, x, g_att_x, None)
-        # a = xq_raw w_comp^T + b_comp with w_comp = att_q W, b_comp = att_q . b + att_b: the gradients of lin and of att's query half
-        # by the chain rule on D x D tensors; the segment max's gradient g_a (x) w_comp is formed inside its backward kernel
-        g_w_comp = torch.empty_like(w_comp)
-        g_att_b = torch.empty(1, dtype=torch.float32, device=dev)
-        ops.linear_wgrad(g_a2, xq_raw, g_w_comp, g_att_b)                        # [1, D] = sum_n g_a[n] segmax[n], and sum_n g_a[n]
+        # The three tiny weight gradients of the pooling in ONE pass over their operands (csrc/family_b_bwd.hip rank_grad_*: two
+        # launches where three linear_wgrad calls were six): gw3 [3, D] = gpqr^T x' and gb3 = its column sums (LEConv's projections);
+        # g_att_x [1, D] = g_c^T x (c = x att_x^T); g_w_comp [1, D] = g_a^T segmax and g_att_b = sum g_a -- a = xq_raw w_comp^T + b_comp
+        # with w_comp = att_q W, b_comp = att_q . b + att_b: the gradients of lin and of att's query half follow by the chain rule on
+        # D x D tensors (asap_compose_bwd); the segment max's gradient g_a (x) w_comp is formed inside its backward kernel
+        if x.is_cuda:
+            (gw3, gb3), (g_att_x, _), (g_w_comp, g_att_b) = ops.rank_grad([(gpqr, x_new), (g_c, x), (g_a, xq_raw)])
+        else:
+            gw3, gb3 = torch.empty_like(w3), torch.empty(3, dtype=torch.float32, device=dev)
+            ops.linear_wgrad(gpqr, x_new, gw3, gb3)
+            g_att_x = torch.empty((1, d), dtype=torch.float32, device=dev)
+            ops.linear_wgrad(g_c.unsqueeze(1), x, g_att_x, None)
+            g_w_comp, g_att_b = torch.empty_like(w_comp), torch.empty(1, dtype=torch.float32, device=dev)
+            ops.linear_wgrad(g_a.unsqueeze(1), xq_raw, g_w_comp, g_att_b)
         if dense:
             ops.dense_segment_max_bwd_(gx, x, xq_raw, s, ties, (g_a, w_comp[0].contiguous()), s.dense_plan("out"))
         elif not fuse_max:

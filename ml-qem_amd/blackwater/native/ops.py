@@ -1336,6 +1336,31 @@ def asap_compose_bwd(g_w_comp, g_att_b, lin_w, lin_b, att_w, g_att_x):
     return g_lin_w, g_lin_b, g_att_w
 
 
+def gather_rows(mats, sel):
+    """[m[sel] for m in mats] for up to four contiguous fp32 matrices with one leading dimension G, in ONE launch
+    (mlqem_gather_rows_f32): the per-graph inputs of a batch (labels, noisy values, depths, observables).  ``sel``: int32 [B]."""
+    import ctypes as _ct
+
+    if not 1 <= len(mats) <= 4:
+        raise ValueError("gather_rows: one to four matrices")
+    b = int(sel.shape[0])
+    _vec(sel, "sel", b, torch.int32)
+    outs, widths = [], []
+    for m in mats:
+        if not m.is_cuda or m.dtype != torch.float32 or not m.is_contiguous():
+            raise ValueError("gather_rows: contiguous fp32 cuda tensors")
+        w = int(m[0].numel()) if m.shape[0] else int(torch.Size(m.shape[1:]).numel())
+        widths.append(w)
+        outs.append(torch.empty((b,) + tuple(m.shape[1:]), dtype=torch.float32, device=m.device))
+    n = len(mats)
+    src = (_ct.c_void_p * 4)(*[mats[i].data_ptr() if i < n else None for i in range(4)])
+    dst = (_ct.c_void_p * 4)(*[outs[i].data_ptr() if i < n else None for i in range(4)])
+    wid = (_ct.c_int64 * 4)(*[widths[i] if i < n else 0 for i in range(4)])
+    code = _lib.load().mlqem_gather_rows_f32(n, src, wid, _p(sel), b, dst, _stream())
+    _lib.check(code, "mlqem_gather_rows_f32")
+    return outs
+
+
 def pool_keep_ptr(graph_ptr, num_graphs, ratio):
     """Boundaries [B + 1] int32 of the pooled batch, computed ON THE DEVICE from the batch's boundaries: k_g = ceil(float32(n_g) * ratio)
     per graph (mlqem_pool_keep_ptr).  No host value but B enters: the call can be captured and replayed for other size sequences."""
@@ -1434,19 +1459,24 @@ def _keep_info(keep_sizes):
     return b, k, (int(keep.max()) if b else 0), int((keep * (keep - 1)).sum())
 
 
-def asap_coarsen_dense(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, keep_sizes):
+def asap_coarsen_dense(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, keep_sizes, slot=None):
     """Pooled structure arrays (in_ptr, in_src, out_ptr, out_dst, out_eid, loops, slot) and the capacity of the edge
-    arrays, with NO device->host copy (mlqem_asap_coarsen_dense).  ``keep_sizes``: host array of k_g per graph."""
+    arrays, with NO device->host copy (mlqem_asap_coarsen_dense).  ``keep_sizes``: host array of k_g per graph (or bounds:
+    ``_keep_info``).  ``slot``: ``asap_slot_map(perm, num_nodes)`` when the caller has it already (two launches less)."""
     b, k, kmax, cap = _keep_info(keep_sizes)
     dev = perm.device
     lib = _lib.load()
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    slot, in_ptr, out_ptr, loops = mk(num_nodes), mk(k + 1), mk(k + 1), mk(k)
+    ready = slot is not None
+    if ready:
+        _vec(slot, "slot", num_nodes, torch.int32)
+    in_ptr, out_ptr, loops = mk(k + 1), mk(k + 1), mk(k)
+    slot = slot if ready else mk(num_nodes)
     in_src, out_dst, out_eid = mk(cap), mk(cap), mk(cap)
     need = lib.mlqem_asap_coarsen_dense_workspace_bytes(b, k, kmax)
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     code = lib.mlqem_asap_coarsen_dense(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(graph_ptr), _p(new_graph_ptr),
-                                        _p(perm), num_nodes, k, b, kmax, _p(slot), _p(in_ptr), _p(in_src), _p(out_ptr),
+                                        _p(perm), num_nodes, k, b, kmax, _p(slot), 1 if ready else 0, _p(in_ptr), _p(in_src), _p(out_ptr),
                                         _p(out_dst), _p(out_eid), _p(loops), _p(ws), need, _stream())
     _lib.check(code, "mlqem_asap_coarsen_dense")
     return CsrArrays(in_ptr, in_src, out_ptr, out_dst, loops, out_eid), slot, cap
@@ -1723,6 +1753,57 @@ def csr_segment_max_bwd_(gx, x, xmax, gmax, s, ties=None, gmax_rank1=None):
                                                      _p(row), _p(col), _stream())
     _lib.check(code, "mlqem_csr_segment_max_bwd_f32")
     return gx
+
+
+def rank_grad(terms):
+    """Up to three weighted column sums over the same rows in ONE pass (mlqem_rank_grad_f32): ``terms`` = [(g, x), ...] with g [N]
+    or [N, k <= 3] weights and x [N, D] in the padded row layout.  Returns [(g^T x [k, D], column sums of g [k]), ...] -- the
+    weight and bias gradients of ASAPooling's one- and three-wide projections (what three ``linear_wgrad`` calls computed in six
+    launches)."""
+    import ctypes as _ct
+
+    if not 1 <= len(terms) <= 3:
+        raise ValueError("rank_grad: one to three terms")
+    n, d = terms[0][1].shape
+    gs, xs, ks = [], [], []
+    for g, x in terms:
+        if tuple(x.shape) != (n, d):
+            raise ValueError("rank_grad: the matrices must share one shape")
+        g2 = g.unsqueeze(1) if g.dim() == 1 else g
+        if g2.shape[0] != n or g2.shape[1] > 3 or g2.dtype != torch.float32 or not g2.is_cuda or g2.stride(1) != 1:
+            raise ValueError("rank_grad: weights must be fp32 [N] or [N, <= 3] on the device")
+        x = rowmajor(x)
+        _mat(x, "x")
+        if n > 0 and (x.stride(0) < (d + 3) // 4 * 4 or x.stride(0) % 4 or x.data_ptr() % 16):
+            x = padded_copy(x)
+        gs.append(g2); xs.append(x); ks.append(int(g2.shape[1]))
+    t = len(terms)
+    dev = xs[0].device
+    arr_p = lambda ts: (_ct.c_void_p * 3)(*[ts[i].data_ptr() if i < t else None for i in range(3)])
+    arr_l = lambda vs: (_ct.c_int64 * 3)(*[int(vs[i]) if i < t else 0 for i in range(3)])
+    ldx = [int(x.stride(0)) if n > 1 else (d + 3) // 4 * 4 for x in xs]
+    ldg = [int(g.stride(0)) if n > 1 else int(g.shape[1]) for g in gs]
+    k_arr = (_ct.c_int * 3)(*[ks[i] if i < t else 0 for i in range(3)])
+    total = sum(ks)
+    out = torch.empty((total, d), dtype=torch.float32, device=dev)
+    bias = torch.empty(total, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    need = lib.mlqem_rank_grad_workspace_bytes(d)
+    ws = _wgrad_workspace(dev, need)
+    code = lib.mlqem_rank_grad_f32(t, arr_p(xs), arr_l(ldx), arr_p(gs), arr_l(ldg), k_arr, n, d, _p(out), _p(bias), _p(ws), need, _stream())
+    if code == _lib.ERR_UNSUPPORTED:           # wider than the kernel's 64 column groups: the general weight-gradient kernel, term by term
+        res, at = [], 0
+        for g, x, k in zip(gs, xs, ks):
+            gw, gb = torch.empty((k, d), dtype=torch.float32, device=dev), torch.empty(k, dtype=torch.float32, device=dev)
+            linear_wgrad(g.contiguous(), x, gw, gb)
+            res.append((gw, gb))
+        return res
+    _lib.check(code, "mlqem_rank_grad_f32")
+    res, at = [], 0
+    for k in ks:
+        res.append((out[at:at + k], bias[at:at + k]))
+        at += k
+    return res
 
 
 def gather_scale_rows_bwd(gout, xnew, fitness, slot):

@@ -356,6 +356,7 @@ constexpr int kDenseMaxK = 512;
 struct DenseArgs {
   const int32_t* in_ptr; const int32_t* in_src; const int32_t* out_ptr; const int32_t* out_dst;
   const int32_t* gptr; const int32_t* new_gptr; const int32_t* slot;
+  int32_t* loops; int64_t K;     // new_loops [K] (zeroed by the bitmap kernel, a graph's range per workgroup); K: the scans' last element
   int W;                         // 32-bit words per bitmap row (uniform over the batch)
   uint32_t* bitmaps;             // [B][kmax][W]
   int kmax;
@@ -373,6 +374,10 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_bitmap_kernel(const Dens
   const int k0 = a.new_gptr[g], kg = a.new_gptr[g + 1] - k0;
   const int W = a.W;
   for (int i = tid; i < kg * W; i += kBlock) s_bm[i] = 0u;
+  // (what used to be three fill launches in front of this kernel: a pooled graph has no self-loops, and the degree arrays end in a
+  // zero so that their exclusive scans end in the totals)
+  for (int i = tid; i < kg; i += kBlock) a.loops[k0 + i] = 0;
+  if (g == 0 && tid == 0) { a.outdeg[a.K] = 0; a.indeg[a.K] = 0; }
   const int ng = n1 - n0, e0 = a.out_ptr[n0], eg = a.out_ptr[n1] - e0;
   const bool staged = ng <= kDenseStageNodes && eg <= kDenseStageEdges;
   if (staged) {
@@ -1182,6 +1187,37 @@ __global__ __launch_bounds__(kBlock) void coarsen_lists_link_kernel(const int32_
   }
 }
 
+// Exclusive scans of TWO short int32 arrays (the degree vectors of a dense coarsening: K + 1 <= kDualScanMax entries) by ONE
+// workgroup in ONE launch -- rocprim's device scan is two launches per array, four of the eleven this coarsening made for a batch
+// of 32 four-qubit circuits, where a launch costs what the whole kernel does.  Thread t scans its own run of ceil(n / 1024)
+// consecutive entries, the runs' totals are scanned through LDS (wave scans, then the 16 wave totals).
+constexpr int kDualScanThreads = 1024, kDualScanMax = 16 * kDualScanThreads;
+__global__ __launch_bounds__(kDualScanThreads) void dual_scan_small_kernel(const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+                                                                           int n, int32_t* __restrict__ o0, int32_t* __restrict__ o1) {
+  __shared__ int s_w[2][kDualScanThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + kDualScanThreads - 1) / kDualScanThreads;        // <= 16
+  const int lo = min(n, tid * per), hi = min(n, lo + per);
+  int t0 = 0, t1 = 0;
+  for (int i = lo; i < hi; ++i) { t0 += a0[i]; t1 += a1[i]; }
+  int i0 = t0, i1 = t1;                                                   // inclusive scans inside the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u0 = __shfl_up(i0, d), u1 = __shfl_up(i1, d);
+    if (lane >= d) { i0 += u0; i1 += u1; }
+  }
+  if (lane == 63) { s_w[0][wave] = i0; s_w[1][wave] = i1; }
+  __syncthreads();
+  int b0 = 0, b1 = 0;
+  for (int w = 0; w < wave; ++w) { b0 += s_w[0][w]; b1 += s_w[1][w]; }
+  int r0 = b0 + i0 - t0, r1 = b1 + i1 - t1;                              // exclusive prefix of this thread's run
+  for (int i = lo; i < hi; ++i) {
+    const int v0 = a0[i], v1 = a1[i];
+    o0[i] = r0; o1[i] = r1;
+    r0 += v0; r1 += v1;
+  }
+}
+
 static size_t dense_scan_bytes(int64_t K) {
   size_t temp = 0;
   (void)rocprim::exclusive_scan(nullptr, temp, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(K + 1),
@@ -1753,7 +1789,7 @@ extern "C" size_t mlqem_asap_coarsen_dense_workspace_bytes(int64_t B, int64_t K,
 
 extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                         const int32_t* out_dst, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
-                                        const int32_t* perm, int64_t N, int64_t K, int64_t B, int kmax, int32_t* slot,
+                                        const int32_t* perm, int64_t N, int64_t K, int64_t B, int kmax, int32_t* slot, int slot_ready,
                                         int32_t* new_in_ptr, int32_t* new_in_src, int32_t* new_out_ptr, int32_t* new_out_dst,
                                         int32_t* new_out_eid, int32_t* new_loops, void* workspace, size_t workspace_bytes,
                                         mlqem_stream_t stream_) {
@@ -1763,7 +1799,8 @@ extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in
   if (kmax > kDenseMaxK) return MLQEM_ERR_UNSUPPORTED;
   if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_asap_coarsen_dense_workspace_bytes(B, K, kmax)) return MLQEM_ERR_WORKSPACE;
-  fill_i32(slot, -1, N, stream);
+  // slot_ready: `slot` already holds mlqem_asap_slot_map(perm) (the pooling's forward made it for its backward): two launches less
+  if (!slot_ready) fill_i32(slot, -1, N, stream);
   if (K == 0 || B == 0) {
     fill_i32(new_in_ptr, 0, K + 1, stream);
     fill_i32(new_out_ptr, 0, K + 1, stream);
@@ -1775,22 +1812,23 @@ extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in
   const size_t bm = ((size_t)B * kmax * W * sizeof(uint32_t) + 255) / 256 * 256;
   const size_t deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
   char* ws = static_cast<char*>(workspace);
-  DenseArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, slot, W, reinterpret_cast<uint32_t*>(ws), kmax,
+  DenseArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, slot, new_loops, K, W, reinterpret_cast<uint32_t*>(ws), kmax,
               reinterpret_cast<int32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + bm + deg)};
   void* temp = ws + bm + 2 * deg;
   size_t temp_bytes = dense_scan_bytes(K);
-  fill_i32(a.outdeg + K, 0, 1, stream);
-  fill_i32(a.indeg + K, 0, 1, stream);
-  fill_i32(new_loops, 0, K, stream);
-  hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
+  if (!slot_ready) hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
   const size_t lds = (size_t)kmax * W * sizeof(uint32_t);
   hipLaunchKernelGGL(coarsen_dense_bitmap_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, a);
-  if (rocprim::exclusive_scan(temp, temp_bytes, a.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
-                              stream) != hipSuccess)
-    return MLQEM_ERR_LAUNCH;
-  if (rocprim::exclusive_scan(temp, temp_bytes, a.indeg, new_in_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
-                              stream) != hipSuccess)
-    return MLQEM_ERR_LAUNCH;
+  if (K + 1 <= kDualScanMax) {
+    hipLaunchKernelGGL(dual_scan_small_kernel, dim3(1), dim3(kDualScanThreads), 0, stream, a.outdeg, a.indeg, (int)(K + 1), new_out_ptr, new_in_ptr);
+  } else {
+    if (rocprim::exclusive_scan(temp, temp_bytes, a.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
+                                stream) != hipSuccess)
+      return MLQEM_ERR_LAUNCH;
+    if (rocprim::exclusive_scan(temp, temp_bytes, a.indeg, new_in_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(),
+                                stream) != hipSuccess)
+      return MLQEM_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(coarsen_dense_fill_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, a, new_in_ptr, new_out_ptr,
                      new_in_src, new_out_dst, new_out_eid);
   return launch_status();

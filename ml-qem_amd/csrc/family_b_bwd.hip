@@ -1210,6 +1210,117 @@ __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_long_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------- rank-k weight gradients of a pooling
+// ASAPooling's backward ends in three tiny weight gradients over the SAME rows: gw3 [3, D] = gpqr^T x', g_att_x [1, D] = g_c^T x and
+// g_w_comp [1, D] = g_a^T segmax(x) (+ their bias sums) -- weighted column sums of three [N, D] matrices.  As three calls of the
+// general MFMA weight-gradient kernel they were six launches per pooling (a first stage and a fixed-order second stage each, 12 of
+// a Family B step's 134) at a few per cent of the matrix rate.  Here ONE pass reads the three matrices once: thread (row group,
+// 16-byte column group) adds its rows' products in registers, the row groups of a workgroup meet through LDS in a fixed order, one
+// partial per workgroup; a second launch adds the partials in workgroup order (deterministic).
+constexpr int kRankTermsMax = 3, kRankAccMax = 5, kRankGroupsMax = 1024;
+struct RankGradArgs {
+  const float* x[kRankTermsMax]; int64_t ldx[kRankTermsMax];
+  const float* g[kRankTermsMax]; int64_t ldg[kRankTermsMax]; int k[kRankTermsMax];
+  int terms; int64_t N; int CV;
+  float* partial;            // [groups][acc][4 CV + 4]: the sums, then (in the first of the last four floats) the sum of the weights
+};
+
+__global__ __launch_bounds__(kBlock) void rank_grad_partial_kernel(const RankGradArgs a) {
+  __shared__ float4 s_acc[kRankAccMax][kBlock];
+  __shared__ float s_gsum[kRankAccMax][kBlock];
+  const int tid = threadIdx.x;
+  const int R = kBlock / a.CV;                        // rows of a trip
+  const int rg = tid / a.CV, cg = tid - rg * a.CV;
+  const bool on = rg < R;
+  // (accumulators indexed by COMPILE-TIME (term, weight column): a running index that depends on k[] put the array in scratch memory
+  // and the kernel at 0.9 ms; the running index is used where it addresses LDS)
+  float4 acc[kRankTermsMax][3];
+  float gs[kRankTermsMax][3];
+#pragma unroll
+  for (int t = 0; t < kRankTermsMax; ++t)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { acc[t][c] = make_float4(0.f, 0.f, 0.f, 0.f); gs[t][c] = 0.f; }
+  for (int64_t base = (int64_t)blockIdx.x * R; base < a.N; base += (int64_t)gridDim.x * R) {
+    const int64_t row = base + rg;
+    if (!on || row >= a.N) continue;
+#pragma unroll
+    for (int t = 0; t < kRankTermsMax; ++t) {
+      if (t < a.terms) {
+        const float4 xv = *reinterpret_cast<const float4*>(a.x[t] + row * a.ldx[t] + 4 * cg);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (c < a.k[t]) {
+            const float w = a.g[t][row * a.ldg[t] + c];
+            acc[t][c].x = fmaf(w, xv.x, acc[t][c].x); acc[t][c].y = fmaf(w, xv.y, acc[t][c].y);
+            acc[t][c].z = fmaf(w, xv.z, acc[t][c].z); acc[t][c].w = fmaf(w, xv.w, acc[t][c].w);
+            if (cg == 0) gs[t][c] += w;
+          }
+        }
+      }
+    }
+  }
+  {
+    int j = 0;
+#pragma unroll
+    for (int t = 0; t < kRankTermsMax; ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (t < a.terms && c < a.k[t]) { s_acc[j][tid] = acc[t][c]; s_gsum[j][tid] = gs[t][c]; ++j; }
+  }
+  __syncthreads();
+  int n_acc = 0;
+  for (int t = 0; t < a.terms; ++t) n_acc += a.k[t];
+  const int pitch = 4 * a.CV + 4;
+  for (int o = tid; o < n_acc * (a.CV + 1); o += kBlock) {       // (accumulator, column group | the weight sum): the row groups in order
+    const int j = o / (a.CV + 1), c = o - j * (a.CV + 1);
+    float* dst = a.partial + ((int64_t)blockIdx.x * n_acc + j) * pitch;
+    if (c < a.CV) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < R; ++r) {
+        const float4 v = s_acc[j][r * a.CV + c];
+        tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+      }
+      *reinterpret_cast<float4*>(dst + 4 * c) = tot;
+    } else {
+      float tot = 0.f;
+      for (int r = 0; r < R; ++r) tot += s_gsum[j][r * a.CV];
+      dst[4 * a.CV] = tot;
+    }
+  }
+}
+
+// out[j, 0 .. D) = the sum over the groups of the partials; bias[j] = the summed weights.  A workgroup per (accumulator j, chunk of 16
+// partial columns): thread (slice of 16, column) adds the groups slice, slice + 16, ... on four independent chains (a thread per
+// output walking all 1024 groups alone took 235 us), then the sixteen slices are added in order: deterministic.
+__global__ __launch_bounds__(kBlock) void rank_grad_finish_kernel(const float* __restrict__ partial, int groups, int n_acc, int CV, int D,
+                                                                  float* __restrict__ out, float* __restrict__ bias) {
+  __shared__ float s_part[16][16];
+  const int j = blockIdx.x, chunk = blockIdx.y;
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int pitch = 4 * CV + 4;
+  const int col = chunk * 16 + c;                     // of a partial row: [0, 4 CV) the sums, 4 CV the weight sum
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (col < pitch) {
+    const float* __restrict__ p = partial + (int64_t)j * pitch + col;
+    const int64_t stride = (int64_t)n_acc * pitch;
+    int g = sl;
+    for (; g + 48 < groups; g += 64) {
+      t0 += p[(int64_t)g * stride]; t1 += p[(int64_t)(g + 16) * stride];
+      t2 += p[(int64_t)(g + 32) * stride]; t3 += p[(int64_t)(g + 48) * stride];
+    }
+    for (; g < groups; g += 16) t0 += p[(int64_t)g * stride];
+  }
+  s_part[sl][c] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (sl == 0 && col < pitch) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += s_part[q][c];
+    if (col < D) out[j * D + col] = tot;
+    else if (col == 4 * CV) bias[j] = tot;
+  }
+}
+
 }  // namespace mlqem
 
 using namespace mlqem;
@@ -1497,5 +1608,38 @@ extern "C" int mlqem_dense_leconv_fitness_bwd_f32(const float* gfit, const float
   const int64_t waves = max_blocks * 16;                 // an upper bound on the plan's rows
   hipLaunchKernelGGL(leconv_fitness_bwd_long_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(waves, kBlock / kWave), 8192))),
                      dim3(kBlock), 0, as_stream(stream), gfit, fitness, in_ptr, out_ptr, out_dst, lrows, counter, row_flag, gpqr);
+  return launch_status();
+}
+
+// Up to three weighted column sums over the same N rows in one pass (see rank_grad_partial_kernel): term t has k[t] <= 3 weight columns
+// g[t] [N, ldg[t]] and a matrix x[t] [N, ldx[t]] of D columns in 16-byte rows; out [sum k, D] row-major in term order, bias [sum k] the
+// sums of the weight columns.  workspace: mlqem_rank_grad_workspace_bytes(D) bytes.
+extern "C" size_t mlqem_rank_grad_workspace_bytes(int D) {
+  if (D <= 0) return 0;
+  return (size_t)kRankGroupsMax * kRankAccMax * (size_t)(((D + 3) / 4) * 4 + 4) * sizeof(float);
+}
+
+extern "C" int mlqem_rank_grad_f32(int terms, const float* const* x, const int64_t* ldx, const float* const* g, const int64_t* ldg, const int* k,
+                                   int64_t N, int D, float* out, float* bias, void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+  begin_launches();
+  if (terms < 1 || terms > kRankTermsMax || N < 0 || D <= 0 || !x || !ldx || !g || !ldg || !k || !out || !bias) return MLQEM_ERR_BAD_ARG;
+  const int cv = (D + 3) / 4;
+  if (cv > 64) return MLQEM_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < mlqem_rank_grad_workspace_bytes(D)) return MLQEM_ERR_WORKSPACE;
+  RankGradArgs a{};
+  int n_acc = 0;
+  for (int t = 0; t < terms; ++t) {
+    if (k[t] < 1 || k[t] > 3 || ldx[t] < 4 * cv || ldx[t] % 4 || ldg[t] < k[t] || (N > 0 && (!x[t] || !g[t] || !aligned_to(x[t], 16)))) return MLQEM_ERR_BAD_ARG;
+    a.x[t] = x[t]; a.ldx[t] = ldx[t]; a.g[t] = g[t]; a.ldg[t] = ldg[t]; a.k[t] = k[t];
+    n_acc += k[t];
+  }
+  if (n_acc > kRankAccMax) return MLQEM_ERR_UNSUPPORTED;
+  a.terms = terms; a.N = N; a.CV = cv; a.partial = static_cast<float*>(workspace);
+  const int rows = kBlock / cv;
+  const int groups = (int)std::max<int64_t>(1, std::min<int64_t>(kRankGroupsMax, ceil_div(std::max<int64_t>(N, 1), (int64_t)rows * 8)));
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(rank_grad_partial_kernel, dim3((unsigned)groups), dim3(kBlock), 0, s, a);
+  hipLaunchKernelGGL(rank_grad_finish_kernel, dim3((unsigned)n_acc, (unsigned)ceil_div((int64_t)(4 * cv + 4), (int64_t)16)), dim3(kBlock), 0, s,
+                     a.partial, groups, n_acc, cv, D, out, bias);
   return launch_status();
 }

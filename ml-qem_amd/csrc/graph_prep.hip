@@ -428,3 +428,38 @@ extern "C" int mlqem_batch_assemble(const float* x, int64_t ldx, int F, const fl
     hipLaunchKernelGGL(assemble_edges_kernel, dim3((unsigned)ceil_div(Eb, (int64_t)kChunk)), dim3(kBlock), 0, stream, a);
   return launch_status();
 }
+
+namespace mlqem {
+struct GatherRowsArgs { const float* src[4]; float* dst[4]; int64_t width[4]; int64_t end[4]; int count; const int32_t* sel; int64_t B; };
+// element e of the concatenation [B x width[0] | B x width[1] | ...]: which matrix, which row of the batch, which column
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const GatherRowsArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= a.end[a.count - 1]) return;
+  int k = 0;
+  while (e >= a.end[k]) ++k;                 // <= 3 steps
+  const int64_t local = e - (k ? a.end[k - 1] : 0);
+  const int64_t row = local / a.width[k], col = local - row * a.width[k];
+  a.dst[k][local] = a.src[k][(int64_t)a.sel[row] * a.width[k] + col];
+}
+}  // namespace mlqem
+
+extern "C" int mlqem_gather_rows_f32(int count, const float* const* src, const int64_t* width, const int32_t* sel, int64_t B,
+                                     float* const* dst, mlqem_stream_t stream) {
+  begin_launches();
+  if (count < 1 || count > 4 || B < 0 || !src || !width || !dst) return MLQEM_ERR_BAD_ARG;
+  if (B == 0) return MLQEM_OK;
+  if (!sel) return MLQEM_ERR_BAD_ARG;
+  mlqem::GatherRowsArgs a{};
+  int64_t total = 0;
+  for (int k = 0; k < count; ++k) {
+    if (width[k] < 0 || (width[k] > 0 && (!src[k] || !dst[k]))) return MLQEM_ERR_BAD_ARG;
+    a.src[k] = src[k]; a.dst[k] = dst[k]; a.width[k] = std::max<int64_t>(width[k], 1);
+    total += B * width[k];
+    a.end[k] = total;
+  }
+  if (total == 0) return MLQEM_OK;
+  a.count = count; a.sel = sel; a.B = B;
+  hipLaunchKernelGGL(mlqem::gather_rows_kernel, dim3((unsigned)mlqem::ceil_div(total, (int64_t)mlqem::kBlock)), dim3(mlqem::kBlock), 0,
+                     mlqem::as_stream(stream), a);
+  return mlqem::launch_status();
+}

@@ -1,5 +1,6 @@
 """The Family B train step on 100-qubit circuits the way bench.py's cfg4 leg times it (size-stratified batches through the bucketed
-trainer, the whole step replayed from one hipGraph): python scripts/family_b_step.py [batch] [steps] [captured 0/1]"""
+trainer, the whole step replayed from one hipGraph): python scripts/family_b_step.py [batch] [steps] [captured 0/1]
+NQ=4: the same on 4-qubit circuits (cfg2; use batch 32: the reference's regime)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ml-qem_amd")]
@@ -13,8 +14,14 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 graphs = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
 dev = "cuda:0"
-corpus = TfimCorpus(100, list(range(1, 11)), 104, seed=42, exp_value_size=4)
-arena = corpus.arena(dev, filler_nodes=1024)
+if os.environ.get("NQ", "100") == "4":      # the reference's regime: 4-qubit circuits (cfg2), batches of 32 (bench.py's family_b leg)
+    from blackwater.data.arena import GraphArena
+    h = TfimCorpus(4, list(range(15)), 70, seed=42, two_q="cx", exp_value_size=4).host_graphs()
+    arena = GraphArena.from_arrays(h["x"], h["edge_index"], h["y"][:, None, :], h["noisy"][:, None, :], h["depth"], h["observable"],
+                                   device=dev, filler_nodes=1024)
+else:
+    corpus = TfimCorpus(100, list(range(1, 11)), 104, seed=42, exp_value_size=4)
+    arena = corpus.arena(dev, filler_nodes=1024)
 n = len(arena)
 torch.manual_seed(0)
 sampler = StratifiedBatches(arena.node_counts[:n], arena.edge_counts[:n], batch, seed=13)

@@ -898,3 +898,27 @@ def test_two_layer_head_in_one_launch_per_direction(n, i, h, o, drop_p):
     assert all(torch.equal(a, b) for a, b in zip(again, (gx, gw1, gb1, gw2, gb2)))            # deterministic, ticket back at zero
     nogx = ops.seq2_backward(gyd, xd, w1d, w2d, hidden, mask, drop_p, want_gx=False, want_b1=False)
     assert nogx[0] is None and nogx[2] is None and torch.equal(nogx[1], gw1) and torch.equal(nogx[3], gw2)
+
+
+@pytest.mark.parametrize("n,d", [(1, 45), (257, 45), (5000, 30), (3333, 125), (40000, 7), (0, 16)])
+def test_rank_grad_equals_fp64_weighted_column_sums(n, d):
+    """mlqem_rank_grad_f32: ASAPooling's three tiny weight gradients (gpqr^T x' [3, D], g_c^T x, g_a^T segmax, and the weights'
+    column sums) from one pass, against fp64; padded rows with NaN in the pad columns of a row-sliced operand; the same bits on a
+    second call (fixed-order partial sums)."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(n + d)
+    xs = [ops.padded_copy(torch.randn(n, d, generator=g).to(DEV)) for _ in range(3)]
+    ws = [torch.randn(n, 3, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)]
+    got = ops.rank_grad(list(zip(ws, xs)))
+    again = ops.rank_grad(list(zip(ws, xs)))
+    assert [tuple(a.shape) for a, _ in got] == [(3, d), (1, d), (1, d)] and [tuple(b.shape) for _, b in got] == [(3,), (1,), (1,)]
+    for (gw, gb), (gw2, gb2), w, x in zip(got, again, ws, xs):
+        w2 = (w if w.dim() == 2 else w.unsqueeze(1)).double().cpu()
+        want = w2.t() @ x.double().cpu()
+        scale = max(1.0, float(want.abs().max())) if n else 1.0
+        assert (gw.double().cpu() - want).abs().max().item() <= 2e-5 * scale if n else float(gw.abs().max()) == 0.0
+        assert (gb.double().cpu() - w2.sum(0)).abs().max().item() <= 2e-5 * max(1.0, float(w2.sum(0).abs().max())) if n else True
+        assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    one, = ops.rank_grad([(ws[1], xs[0])])                     # a single term
+    assert torch.equal(one[0], ops.rank_grad([(ws[1], xs[0]), (ws[2], xs[1])])[0][0])
