@@ -359,6 +359,7 @@ struct DenseArgs {
   int32_t* loops; int64_t K;     // new_loops [K] (zeroed by the bitmap kernel, a graph's range per workgroup); K: the scans' last element
   int W;                         // 32-bit words per bitmap row (uniform over the batch)
   uint32_t* bitmaps;             // [B][kmax][W]
+  uint32_t* bitmaps_t;           // [B][kmax][W]: the transposes (row q = the sources p with p -> q)
   int kmax;
   int32_t* outdeg; int32_t* indeg;   // [K + 1]
 };
@@ -426,14 +427,28 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_bitmap_kernel(const Dens
     }
   }
   __syncthreads();
+  // The TRANSPOSE, in LDS behind the matrix: every row's owner sets bit p of the columns q it points to (a row has a few bits).  In-
+  // degrees are then popcounts of its rows, and the fill kernel lists a column's sources by walking set bits -- both used to test
+  // bit r of ALL k_g rows, a loop of k_g LDS reads per thread (36 + 50 us for 32 four-qubit circuits: a fifth of their train step).
+  uint32_t* s_t = s_bm + kg * W;
+  for (int i = tid; i < kg * W; i += kBlock) s_t[i] = 0u;
+  __syncthreads();
+  for (int r = tid; r < kg; r += kBlock)
+    for (int w = 0; w < W; ++w) {
+      uint32_t bits = s_bm[r * W + w];
+      while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        atomicOr(s_t + (w * 32 + b) * W + (r >> 5), 1u << (r & 31));
+      }
+    }
+  __syncthreads();
   uint32_t* gb = a.bitmaps + (int64_t)g * a.kmax * W;
-  for (int i = tid; i < kg * W; i += kBlock) gb[i] = s_bm[i];
+  uint32_t* gt = a.bitmaps_t + (int64_t)g * a.kmax * W;
+  for (int i = tid; i < kg * W; i += kBlock) { gb[i] = s_bm[i]; gt[i] = s_t[i]; }
   for (int r = tid; r < kg; r += kBlock) {
     int od = 0, id = 0;
-    for (int w = 0; w < W; ++w) od += __popc(s_bm[r * W + w]);
-    const int wq = r >> 5;
-    const uint32_t mq = 1u << (r & 31);
-    for (int rr = 0; rr < kg; ++rr) id += (s_bm[rr * W + wq] & mq) ? 1 : 0;   // column r
+    for (int w = 0; w < W; ++w) { od += __popc(s_bm[r * W + w]); id += __popc(s_t[r * W + w]); }
     a.outdeg[k0 + r] = od;
     a.indeg[k0 + r] = id;
   }
@@ -444,14 +459,22 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_fill_kernel(const DenseA
                                                                     int32_t* __restrict__ in_src_new,
                                                                     int32_t* __restrict__ out_dst_new,
                                                                     int32_t* __restrict__ out_eid_new) {
-  extern __shared__ uint32_t s_bm[];
+  extern __shared__ uint32_t s_bm[];                       // the matrix [kg][W], its transpose [kg][W], prefix popcounts [kg][W]
   const int g = blockIdx.x, tid = threadIdx.x;
   const int k0 = a.new_gptr[g], kg = a.new_gptr[g + 1] - k0;
   const int W = a.W;
   const uint32_t* gb = a.bitmaps + (int64_t)g * a.kmax * W;
-  __shared__ int s_optr[kDenseMaxK];                     // the rows' places in the out-CSR (read once per EDGE below)
-  for (int i = tid; i < kg * W; i += kBlock) s_bm[i] = gb[i];
+  const uint32_t* gt = a.bitmaps_t + (int64_t)g * a.kmax * W;
+  uint32_t* s_t = s_bm + kg * W;
+  uint32_t* s_pre = s_t + kg * W;                          // s_pre[r][w] = set bits of row r in the words before w
+  __shared__ int s_optr[kDenseMaxK];                       // the rows' places in the out-CSR (read once per EDGE below)
+  for (int i = tid; i < kg * W; i += kBlock) { s_bm[i] = gb[i]; s_t[i] = gt[i]; }
   for (int i = tid; i < kg; i += kBlock) s_optr[i] = out_ptr_new[k0 + i];
+  __syncthreads();
+  for (int r = tid; r < kg; r += kBlock) {
+    uint32_t run = 0;
+    for (int w = 0; w < W; ++w) { s_pre[r * W + w] = run; run += (uint32_t)__popc(s_bm[r * W + w]); }
+  }
   __syncthreads();
   for (int r = tid; r < kg; r += kBlock) {
     int pos = s_optr[r];                                   // row r: destinations in ascending order
@@ -463,17 +486,21 @@ __global__ __launch_bounds__(kBlock) void coarsen_dense_fill_kernel(const DenseA
         out_dst_new[pos++] = k0 + w * 32 + b;
       }
     }
-    int ipos = in_ptr_new[k0 + r];                         // column r: sources in ascending order
+    int ipos = in_ptr_new[k0 + r];                         // column r: sources in ascending order = the set bits of row r of the transpose
     const int wq = r >> 5;
-    const uint32_t mq = 1u << (r & 31), below = mq - 1u;
-    for (int rr = 0; rr < kg; ++rr) {
-      const uint32_t* row = s_bm + rr * W;
-      if (!(row[wq] & mq)) continue;
-      in_src_new[ipos] = k0 + rr;
-      int rank = __popc(row[wq] & below);                  // position of (rr -> r) inside row rr of the out-CSR
-      for (int w = 0; w < wq; ++w) rank += __popc(row[w]);
-      out_eid_new[s_optr[rr] + rank] = ipos;
-      ++ipos;
+    const uint32_t below = (1u << (r & 31)) - 1u;
+    for (int w = 0; w < W; ++w) {
+      uint32_t bits = s_t[r * W + w];
+      while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const int rr = w * 32 + b;
+        in_src_new[ipos] = k0 + rr;
+        // position of (rr -> r) inside row rr of the out-CSR
+        const int rank = (int)s_pre[rr * W + wq] + __popc(s_bm[rr * W + wq] & below);
+        out_eid_new[s_optr[rr] + rank] = ipos;
+        ++ipos;
+      }
     }
   }
 }
@@ -1784,7 +1811,7 @@ extern "C" size_t mlqem_asap_coarsen_dense_workspace_bytes(int64_t B, int64_t K,
   const size_t W = (size_t)(kmax + 31) / 32;
   const size_t bm = ((size_t)B * kmax * W * sizeof(uint32_t) + 255) / 256 * 256;
   const size_t deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
-  return bm + 2 * deg + dense_scan_bytes(K);
+  return 2 * bm + 2 * deg + dense_scan_bytes(K);      // the bit matrices and their transposes | both degree vectors | scan temp
 }
 
 extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
@@ -1812,13 +1839,14 @@ extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in
   const size_t bm = ((size_t)B * kmax * W * sizeof(uint32_t) + 255) / 256 * 256;
   const size_t deg = ((size_t)(K + 1) * sizeof(int32_t) + 255) / 256 * 256;
   char* ws = static_cast<char*>(workspace);
-  DenseArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, slot, new_loops, K, W, reinterpret_cast<uint32_t*>(ws), kmax,
-              reinterpret_cast<int32_t*>(ws + bm), reinterpret_cast<int32_t*>(ws + bm + deg)};
-  void* temp = ws + bm + 2 * deg;
+  DenseArgs a{in_ptr, in_src, out_ptr, out_dst, graph_ptr, new_graph_ptr, slot, new_loops, K, W, reinterpret_cast<uint32_t*>(ws),
+              reinterpret_cast<uint32_t*>(ws + bm), kmax, reinterpret_cast<int32_t*>(ws + 2 * bm), reinterpret_cast<int32_t*>(ws + 2 * bm + deg)};
+  void* temp = ws + 2 * bm + 2 * deg;
   size_t temp_bytes = dense_scan_bytes(K);
   if (!slot_ready) hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
-  const size_t lds = (size_t)kmax * W * sizeof(uint32_t);
-  hipLaunchKernelGGL(coarsen_dense_bitmap_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, a);
+  const size_t lds = (size_t)kmax * W * sizeof(uint32_t);      // one k x k bit matrix; the kernels hold two and three of them
+  if (!ensure_dynamic_lds(coarsen_dense_bitmap_kernel, 2 * lds) || !ensure_dynamic_lds(coarsen_dense_fill_kernel, 3 * lds)) return MLQEM_ERR_LAUNCH;
+  hipLaunchKernelGGL(coarsen_dense_bitmap_kernel, dim3((unsigned)B), dim3(kBlock), 2 * lds, stream, a);
   if (K + 1 <= kDualScanMax) {
     hipLaunchKernelGGL(dual_scan_small_kernel, dim3(1), dim3(kDualScanThreads), 0, stream, a.outdeg, a.indeg, (int)(K + 1), new_out_ptr, new_in_ptr);
   } else {
@@ -1829,7 +1857,7 @@ extern "C" int mlqem_asap_coarsen_dense(const int32_t* in_ptr, const int32_t* in
                                 stream) != hipSuccess)
       return MLQEM_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(coarsen_dense_fill_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, a, new_in_ptr, new_out_ptr,
+  hipLaunchKernelGGL(coarsen_dense_fill_kernel, dim3((unsigned)B), dim3(kBlock), 3 * lds, stream, a, new_in_ptr, new_out_ptr,
                      new_in_src, new_out_dst, new_out_eid);
   return launch_status();
 }
