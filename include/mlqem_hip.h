@@ -767,6 +767,11 @@ int mlqem_asap_scores_fused_f32(const float* x, int64_t ldx, const int32_t* in_p
  * gb_padded, gb may be NULL. */
 int mlqem_pad_head_rows_f32(const float* w, const float* b, int groups, int channels, int pitch, int cols, float* w_padded,
                             float* b_padded, mlqem_stream_t stream);
+/* The same from up to four separate [groups_per_part * channels, cols] matrices (and biases; b or b[k] may be NULL) laid one after the
+ * other: the query / key / value / skip projections of a TransformerConv (reference construction docs/tutorials/gnn.py:80-91) as ONE
+ * padded weight without a torch.cat in front (ABI 40); pitch == channels gives the plain concatenation. */
+int mlqem_pad_head_rows_parts_f32(const float* const* w, const float* const* b, int parts, int groups_per_part, int channels, int pitch,
+                                  int cols, float* w_padded, float* b_padded, mlqem_stream_t stream);
 int mlqem_unpad_head_rows_f32(const float* gw_padded, const float* gb_padded, int groups, int channels, int pitch, int cols,
                               float* gw, float* gb, mlqem_stream_t stream);
 

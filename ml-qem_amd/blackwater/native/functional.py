@@ -657,25 +657,44 @@ class _TransformerConv(Function):
     gradient kernels followed by the projection's data and weight gradients."""
 
     @staticmethod
-    def forward(ctx, x, w, b, struct: GraphStructure, heads, channels, drop_p, seed):
+    def forward(ctx, x, struct: GraphStructure, heads, channels, drop_p, seed, *wb):
+        # wb = (w, b): the fused [4 H C, in] projection, or the reference's eight parameters (query, key, value, skip: weight, bias
+        # each) as they are -- their concatenation and the per-head padding then come from ONE launch (ops.pad_head_rows_parts)
+        # instead of two torch.cat and a padding launch
         x = ops.rowmajor(x)        # a RowsOf (rows of the device-resident dataset) stays one: the projection reads through its row map
-        w = w.contiguous()
+        parts = len(wb) == 8
+        ctx.parts = parts
+        if parts:
+            ws_, bs_ = list(wb[0::2]), list(wb[1::2])
+            on_gpu = ws_[0].is_cuda
+            fused = lambda pitch: (ops.pad_head_rows_parts(ws_, bs_, heads, channels, pitch) if on_gpu
+                                   else _pad_heads(torch.cat(ws_, 0), torch.cat(bs_, 0), 4 * heads, channels, pitch))
+            w = None
+        else:
+            w, b = wb
+            w = w.contiguous()
+            on_gpu = w.is_cuda
         e = struct.edge_count()
         # a structure whose rows share their sources (ASAPooling's coarsened graphs of large circuits): its long rows as dense blocks,
         # the edge softmax on the matrix cores (csrc/dense_block.hip)
-        dense = (_DENSE_BLOCKS and struct.blocked and w.is_cuda and struct.out_eid is None and channels < 16
+        dense = (_DENSE_BLOCKS and struct.blocked and on_gpu and struct.out_eid is None and channels < 16
                  and ops.dense_attention_supported(heads, channels, 16))
         if not any(ctx.needs_input_grad) and drop_p == 0.0:  # inference: no statistics kept
+            if parts:
+                w, b = fused(channels)
             return ops.transformer_attention(ops.linear(x, w, b), struct.in_ptr, struct.in_src, struct.loops, heads, channels)
         # Training: a head's channels at a pitch of 16 inside q / k / v / skip (the reference's 15: every gathered segment becomes an
         # aligned 64-byte piece).  The projection writes that layout by itself when its weight and bias rows are padded the same way
         # (zero rows: the pads of qkvs are zeros, the gradient of a pad row is exactly zero); w itself stays [4 H C, in].
-        cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and w.is_cuda) else 0
+        cp = _ATTN_PITCH if (_ATTN_PITCH > channels and _ATTN_PITCH - channels < 4 and on_gpu) else 0
         if dense:
             cp = 16 if channels < 16 else 0
         ctx.cp = cp
         ctx.dense = dense
-        w_used, b_used = _pad_heads(w, b, 4 * heads, channels, cp) if cp else (w, b)
+        if parts:
+            w_used, b_used = fused(cp if cp else channels)
+        else:
+            w_used, b_used = _pad_heads(w, b, 4 * heads, channels, cp) if cp else (w, b)
         qkvs = ops.linear(x, w_used, b_used)
         # a structure without out_eid (ASAPooling's coarsened graphs: no parallel edges) takes the recomputed backward, whose dropout
         # draws are keyed by (destination, head, source)
@@ -685,7 +704,7 @@ class _TransformerConv(Function):
         if dense:
             out, attn, m, den = ops.dense_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads, channels,
                                                          struct.dense_plan("in"), drop_p=drop_p, seed=seed, head_pitch=cp,
-                                                         side=_dense_side(w.device))
+                                                         side=_dense_side(w_used.device))
         else:
             out, attn, m, den = ops.transformer_attention_train(qkvs, struct.in_ptr, struct.in_src, struct.loops, e, heads,
                                                                channels, drop_p, seed, pair_key=pair_key, ell=ell, head_pitch=cp)
@@ -719,7 +738,13 @@ class _TransformerConv(Function):
         ops.linear_wgrad(gqkvs, x, gw, gb)
         if cp:                     # the real rows of the padded gradients
             gw, gb = ops.unpad_head_rows(gw, gb, 4 * heads, channels, cp)
-        return gx, gw, gb, None, None, None, None, None
+        if ctx.parts:              # the four parameters' gradients: row blocks of the fused one
+            hc = heads * channels
+            grads = []
+            for k in range(4):
+                grads += [gw[k * hc:(k + 1) * hc], gb[k * hc:(k + 1) * hc]]
+            return (gx, None, None, None, None, None, *grads)
+        return gx, None, None, None, None, None, gw, gb
 
 
 def _pad_heads(w, b, groups, channels, cp):
@@ -756,7 +781,11 @@ _ATTN_PITCH = 16
 
 
 def transformer_conv(x, w, b, struct, heads, channels, drop_p=0.0, seed=0):
-    return _TransformerConv.apply(x, w, b, struct, heads, channels, drop_p, seed)
+    """``w`` / ``b``: the fused [4 H C, in] projection and its bias, or lists of the four parts (query, key, value, skip)."""
+    if isinstance(w, (list, tuple)):
+        wb = [t for pair in zip(w, b) for t in pair]
+        return _TransformerConv.apply(x, struct, heads, channels, drop_p, seed, *wb)
+    return _TransformerConv.apply(x, struct, heads, channels, drop_p, seed, w, b)
 
 
 # Which form of the coarsening S^T (A S) a pooling takes, by the batch's graph sizes: the sync-free dense form when every graph pools to

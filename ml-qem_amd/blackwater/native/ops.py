@@ -1300,6 +1300,27 @@ def pad_head_rows(w, b, groups, channels, pitch):
     return wp, bp
 
 
+def pad_head_rows_parts(ws, bs, groups_per_part, channels, pitch):
+    """(w, b) of ``pad_head_rows(torch.cat(ws), torch.cat(bs), len(ws) * groups_per_part, channels, pitch)`` in ONE launch, from the
+    separate matrices (``pitch == channels``: the concatenation itself)."""
+    import ctypes as _ct
+
+    parts, cols = len(ws), ws[0].shape[1]
+    if not 1 <= parts <= 4 or any(tuple(w.shape) != (groups_per_part * channels, cols) or w.dtype != torch.float32 or not w.is_cuda for w in ws):
+        raise ValueError("pad_head_rows_parts: one to four fp32 cuda matrices of one shape [groups_per_part * channels, cols]")
+    ws = [w.contiguous() for w in ws]
+    bs = [None if b is None else b.contiguous() for b in bs]
+    dev = ws[0].device
+    wp = torch.empty((parts * groups_per_part * pitch, cols), dtype=torch.float32, device=dev)
+    has_b = any(b is not None for b in bs)
+    bp = torch.empty(parts * groups_per_part * pitch, dtype=torch.float32, device=dev) if has_b else None
+    w_arr = (_ct.c_void_p * 4)(*[ws[k].data_ptr() if k < parts else None for k in range(4)])
+    b_arr = (_ct.c_void_p * 4)(*[(bs[k].data_ptr() if bs[k] is not None else None) if k < parts else None for k in range(4)])
+    code = _lib.load().mlqem_pad_head_rows_parts_f32(w_arr, b_arr, parts, groups_per_part, channels, pitch, cols, _p(wp), _p(bp), _stream())
+    _lib.check(code, "mlqem_pad_head_rows_parts_f32")
+    return wp, bp
+
+
 def unpad_head_rows(gwp, gbp, groups, channels, pitch):
     """The real rows of gradients in the padded layout of ``pad_head_rows``: (gw [groups * channels, cols], gb), one launch."""
     cols = gwp.shape[1]

@@ -38,9 +38,10 @@ class TransformerConv(nn.Module):
         self.lin_value, self.lin_skip = _lin(in_channels, hc), _lin(in_channels, hc)
 
     def forward(self, x, struct: GraphStructure):
-        # one projection for query | key | value | skip: x is read once
-        w = torch.cat([self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight], 0)
-        b = torch.cat([self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias], 0)
+        # one projection for query | key | value | skip: x is read once; the four parameters are fused (and padded per head) by one
+        # launch inside the autograd node
+        w = [self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight]
+        b = [self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias]
         self._calls = getattr(self, "_calls", 0) + 1
         drop = self.dropout if self.training else 0.0
         # static_dropout_key: a device-resident step counter varies the masks instead (train.BucketedTrainer, hipGraph replay)

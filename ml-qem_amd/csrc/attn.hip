@@ -361,6 +361,26 @@ __global__ __launch_bounds__(kBlock) void pad_head_rows_kernel(const float* __re
   if (col < I) wp[row * I + col] = real ? w[src * I + col] : 0.f;
   else if (bp) bp[row] = (real && b) ? b[src] : 0.f;
 }
+// The same from up to four SEPARATE weight matrices (query, key, value, skip: the parameters of a TransformerConv as the reference's
+// state dict keeps them), part k covering the groups [k GP, (k + 1) GP): the two torch.cat launches in front of the padding go, and
+// with CP == C this is the concatenation itself.
+struct PadParts { const float* w[4]; const float* b[4]; };
+__global__ __launch_bounds__(kBlock) void pad_head_rows_parts_kernel(const PadParts q, int parts, int GP, int C, int CP, int I,
+                                                                     float* __restrict__ wp, float* __restrict__ bp) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t total = (int64_t)parts * GP * CP * (I + 1);       // column I of a row: its bias
+  if (t >= total) return;
+  const int col = (int)(t % (I + 1));
+  const int64_t row = t / (I + 1);
+  const int g = (int)(row / CP), c = (int)(row % CP);
+  const int part = g / GP, gl = g - part * GP;
+  const bool real = c < C;
+  const int64_t src = (int64_t)gl * C + c;
+  const float* __restrict__ w = part == 0 ? q.w[0] : part == 1 ? q.w[1] : part == 2 ? q.w[2] : q.w[3];
+  const float* __restrict__ b = part == 0 ? q.b[0] : part == 1 ? q.b[1] : part == 2 ? q.b[2] : q.b[3];
+  if (col < I) wp[row * I + col] = real ? w[src * I + col] : 0.f;
+  else if (bp) bp[row] = (real && b) ? b[src] : 0.f;
+}
 __global__ __launch_bounds__(kBlock) void unpad_head_rows_kernel(const float* __restrict__ gwp, const float* __restrict__ gbp, int G, int C,
                                                                  int CP, int I, float* __restrict__ gw, float* __restrict__ gb) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -406,6 +426,22 @@ extern "C" int mlqem_pad_head_rows_f32(const float* w, const float* b, int group
   const int64_t total = (int64_t)groups * pitch * (cols + 1);
   hipLaunchKernelGGL(pad_head_rows_kernel, dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0, as_stream(stream), w, b, groups, channels,
                      pitch, cols, w_padded, b_padded);
+  return launch_status();
+}
+
+extern "C" int mlqem_pad_head_rows_parts_f32(const float* const* w, const float* const* b, int parts, int groups_per_part, int channels,
+                                             int pitch, int cols, float* w_padded, float* b_padded, mlqem_stream_t stream) {
+  begin_launches();
+  if (parts < 1 || parts > 4 || groups_per_part <= 0 || channels <= 0 || pitch < channels || cols <= 0 || !w || !w_padded) return MLQEM_ERR_BAD_ARG;
+  PadParts q{};
+  for (int k = 0; k < parts; ++k) {
+    if (!w[k]) return MLQEM_ERR_BAD_ARG;
+    q.w[k] = w[k];
+    q.b[k] = b ? b[k] : nullptr;
+  }
+  const int64_t total = (int64_t)parts * groups_per_part * pitch * (cols + 1);
+  hipLaunchKernelGGL(pad_head_rows_parts_kernel, dim3((unsigned)ceil_div(total, kBlock)), dim3(kBlock), 0, as_stream(stream), q, parts,
+                     groups_per_part, channels, pitch, cols, w_padded, b_padded);
   return launch_status();
 }
 
