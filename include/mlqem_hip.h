@@ -584,6 +584,9 @@ size_t mlqem_asap_coarsen_rows_workspace_bytes(int64_t K, int kmax);
  * coarsened connectivity -- the second pooling of every reference model is followed by global_mean_pool (gnn.py:112-114)
  * -- so the host can skip the coarsening and call only this. */
 int mlqem_asap_slot_map(const int32_t* perm, int64_t N, int64_t K, int32_t* slot, mlqem_stream_t stream);
+/* The same in ONE launch given the graphs' node ranges before / after pooling (ABI 40; graph g's centres are its own nodes). */
+int mlqem_asap_slot_map_graphs(const int32_t* perm, const int32_t* graph_ptr, const int32_t* new_graph_ptr, int64_t B, int64_t N,
+                               int64_t K, int32_t* slot, mlqem_stream_t stream);
 int mlqem_asap_coarsen_rows_max_bits(void);
 int mlqem_asap_coarsen_rows_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                   const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N,

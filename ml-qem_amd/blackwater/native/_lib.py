@@ -136,6 +136,7 @@ SIGNATURES = {
     "mlqem_asap_coarsen_dense_workspace_bytes": (_S, [_L, _L, _I]),
     "mlqem_asap_coarsen_dense": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "mlqem_gather_rows_f32": (_I, [_I, _P, _P, _P, _L, _P, _P]),
+    "mlqem_asap_slot_map_graphs": (_I, [_P, _P, _P, _L, _L, _L, _P, _P]),
     "mlqem_pad_head_rows_parts_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mlqem_transformer_attention_train_f32": (_I, [_P, _L, _P, _P, _P, _L, _L, _I, _I, _F, _U, _P, _I, _P, _I, _P, _L, _P, _L, _P, _P, _P]),
     "mlqem_transformer_attention_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I,

@@ -904,7 +904,7 @@ class _ASAPool(Function):
         perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=min(nmax, n))
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
         # the backward's slot[] (cluster id of every kept centre, -1 elsewhere); the dense coarsening reads the same map
-        slot_fwd = ops.asap_slot_map(perm, n)
+        slot_fwd = ops.asap_slot_map(perm, n, s.graph_ptr, new_ptr, s.num_graphs)
         use_dense, use_rows, use_lists, link = _ASAP_DENSE, _ASAP_ROWS, _ASAP_LISTS, _ASAP_LINK   # the switches as they stand now: build() may run later
 
         def build():

@@ -1667,10 +1667,15 @@ def batch_norm_train_bwd(dy, x, gamma, mean, invstd):
     return dx, dgamma, dbeta
 
 
-def asap_slot_map(perm, num_nodes):
-    """slot[N]: cluster id of every kept centre (slot[perm[p]] = p), -1 elsewhere."""
+def asap_slot_map(perm, num_nodes, graph_ptr=None, new_graph_ptr=None, num_graphs=0):
+    """slot[N]: cluster id of every kept centre (slot[perm[p]] = p), -1 elsewhere.  With the graphs' node ranges before / after the
+    pooling: one launch (a workgroup per graph) instead of a fill and a scatter."""
     k = int(perm.shape[0])
     slot = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=perm.device)
+    if graph_ptr is not None and new_graph_ptr is not None and num_graphs > 0:
+        code = _lib.load().mlqem_asap_slot_map_graphs(_p(perm), _p(graph_ptr), _p(new_graph_ptr), int(num_graphs), num_nodes, k, _p(slot), _stream())
+        _lib.check(code, "mlqem_asap_slot_map_graphs")
+        return slot
     code = _lib.load().mlqem_asap_slot_map(_p(perm), num_nodes, k, _p(slot), _stream())
     _lib.check(code, "mlqem_asap_slot_map")
     return slot
