@@ -332,6 +332,10 @@ class Trainer:
                 self.history = pickle.load(handle)
         return self.history
 
+    def _fit_step(self, arena, ids) -> torch.Tensor:
+        """One training step of ``fit`` on the graphs ``ids`` of ``arena`` (BucketedTrainer replays a captured step here)."""
+        return self.step(arena.batch(ids))
+
     def fit(self, arena, train_ids, val_ids, epochs: int, batch_size: int = 32, seed: int = 0, log: Callable = None):
         """Epoch loop with per-epoch shuffling (seed + epoch) and the reference's LR schedule.
 
@@ -347,8 +351,8 @@ class Trainer:
             order = rng.permutation(train_ids)
             running, n_batches = None, 0
             for i in range(0, steps_per_epoch * batch_size, batch_size):
-                loss = self.step(arena.batch(order[i:i + batch_size]))
-                running = loss if running is None else running + loss
+                loss = self._fit_step(arena, order[i:i + batch_size])
+                running = loss.clone() if running is None else running + loss     # (a captured step's loss tensor is rewritten by the next replay)
                 n_batches += 1
             val_batches = [arena.batch(val_ids[i:i + batch_size]) for i in range(0, len(val_ids), batch_size)]
             val_total = self.evaluate(val_batches)
@@ -732,6 +736,13 @@ class BucketedTrainer(Trainer):
         torch.cuda.synchronize()
         torch.cuda.set_rng_state(keep[2], dev)
         self._warm = True
+
+    def _fit_step(self, arena, ids) -> torch.Tensor:
+        # the reference's loop (shuffled epochs of 32, docs/tutorials/__ml_models.py:100-187) on this trainer's arena: every step is
+        # the replay of a captured bucket -- size-stable buckets make that true for shuffled batches of Family B too
+        if arena is self.arena:
+            return self.step_ids(ids)
+        return super()._fit_step(arena, ids)
 
     def step_ids(self, graph_ids) -> torch.Tensor:
         """One optimisation step on the graphs ``graph_ids`` of the arena; returns the loss (a device tensor that the

@@ -291,3 +291,38 @@ def test_bn_head_does_not_see_filler_rows():
     assert out_padded.shape == out_plain.shape == (32, 4)
     assert (out_padded - out_plain).abs().max().item() < 1e-5
     ops.set_seed_counter(None)
+
+
+def test_fit_with_the_references_loader_replays_captured_steps():
+    """``BucketedTrainer.fit`` -- the reference's loop (shuffled epochs of 32, summed validation loss into ReduceLROnPlateau,
+    docs/tutorials/__ml_models.py:100-187) -- on Family B: every training step is the replay of a size-stable bucket's capture; the
+    loss curves equal the eagerly enqueued bucketed fit's bit for bit (dropout on), and a scheduler step that lowers the rate
+    reaches the captured Adam (the rate is a device tensor the graphs read)."""
+    from blackwater.native import ops
+    from blackwater.nn import ExpValCircuitGraphModel
+    from blackwater.train import BucketedTrainer
+
+    arena = _cfg2_arena(n_j=14)
+    n = len(arena)
+    train_ids, val_ids = np.arange(0, n - 30), np.arange(n - 30, n)
+    curves = []
+    for graphs in (True, False):
+        torch.manual_seed(0)
+        model = ExpValCircuitGraphModel(22, 15, 4).to(DEV)
+        tr = BucketedTrainer(model, arena, lr=1e-3, graphs=graphs, node_quantum=1024, edge_quantum=4096)
+        torch.manual_seed(7)
+        hist = tr.fit(arena, train_ids, val_ids, epochs=4, batch_size=32, seed=3)
+        curves.append((hist["train_losses"], hist["val_losses"], tr.flat_param.detach().clone(), len(tr._entries)))
+        if graphs:
+            steps = 4 * (-(-len(train_ids) // 32))
+            assert 0 < len(tr._entries) < steps            # buckets come back: replays, not one capture per step
+            lr = tr.optimizer.param_groups[0]["lr"]
+            before = tr.flat_param.detach().clone()
+            lr.fill_(0.0)                                   # what ReduceLROnPlateau does, in place -- taken to the extreme
+            tr.step_ids(train_ids[:32])
+            assert torch.equal(tr.flat_param.detach(), before)      # the replayed Adam read the new rate: no movement
+            lr.fill_(1e-3)
+        ops.set_seed_counter(None)
+    assert len(curves[0][0]) == 3 and all(np.isfinite(curves[0][0])) and all(np.isfinite(curves[0][1]))
+    assert curves[0][0] == curves[1][0] and curves[0][1] == curves[1][1]
+    assert curves[0][0][-1] < curves[0][0][0]
