@@ -139,9 +139,7 @@ __global__ __launch_bounds__(kBlock) void asap_compose_bwd_kernel(const float* _
 //   topk_rank_select_kernel: a thread per node: its rank in its graph = its place in its chunk + for every other chunk of the graph the
 //     number of keys above it (a binary search in a sorted chunk); rank < k_g -> perm[new_gptr[g] + rank] = the node.  A thread
 //     stops as soon as its rank reaches k_g.
-constexpr int kTopkChunk = 4096;
-constexpr int kTopkPer = kTopkChunk / kBlock;
-
+template <int kTopkChunk>
 __device__ __forceinline__ int topk_graph_of_chunk(const int32_t* __restrict__ gptr, int B, int w) {
   int lo = 0, hi = B;                                    // largest g with cstart[g] <= w
   while (hi - lo > 1) {
@@ -151,11 +149,13 @@ __device__ __forceinline__ int topk_graph_of_chunk(const int32_t* __restrict__ g
   return lo;
 }
 
+template <int kTopkChunk>
 __global__ __launch_bounds__(kBlock) void topk_chunk_sort_kernel(const float* __restrict__ fitness, const int32_t* __restrict__ gptr, int B,
                                                                  uint64_t* __restrict__ sorted) {
+  constexpr int kTopkPer = kTopkChunk / kBlock;
   __shared__ uint64_t key[kTopkChunk];
   const int w = blockIdx.x, tid = threadIdx.x;
-  const int g = topk_graph_of_chunk(gptr, B, w);
+  const int g = topk_graph_of_chunk<kTopkChunk>(gptr, B, w);
   const int g0 = gptr[g], n = gptr[g + 1] - g0;
   const int c = w - (g0 / kTopkChunk + g);
   const int first = c * kTopkChunk;
@@ -230,6 +230,10 @@ __global__ __launch_bounds__(kBlock) void topk_small_kernel(const float* __restr
   for (int r = tid; r < keep; r += kBlock) perm[k0 + r] = g0 + (int32_t)(0xFFFFFFFFu - (uint32_t)key[r]);
 }
 
+// (Round 6 tried two other forms of this pass on the step's graphs of 2 000-20 000 nodes: a workgroup per chunk with the other chunks
+// staged in LDS -- 107-115 us at chunks of 1 024, too few workgroups -- and this form with the searches of four chunks interleaved,
+// branch-free: 103 against 101 us, the pass is bound by the number of loads, not by their latency.)
+template <int kTopkChunk>
 __global__ __launch_bounds__(kBlock) void topk_rank_select_kernel(const uint64_t* __restrict__ sorted, const int32_t* __restrict__ gptr,
                                                                   const int32_t* __restrict__ new_gptr, int B, int64_t N,
                                                                   int32_t* __restrict__ perm) {
@@ -1392,9 +1396,13 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
   if (N / B >= 1024) {
     // ... and since round 5 two launches of this file instead of the ~20 of a device-wide merge sort: chunks of a graph sorted in LDS,
     // then every node's rank among its graph's chunks.  Same order (fitness descending, equal fitness by index), so the same perm.
+    // (chunk size, round 6 on a 64-circuit step, both poolings, sort + rank: 4 096 keys 117 + 35 us -- 64 graphs of 3 680 nodes are 64
+    // workgroups on 256 CUs, 78 passes of 8 compare-exchanges per thread; 2 048: 64 + 57; 1 024: 42 + 101; 512: 28 + 182 -- the rank
+    // pass searches every other chunk of the graph)
+    constexpr int kTopkChunk = 2048;
     const int64_t chunks = N / kTopkChunk + B + 1;
-    hipLaunchKernelGGL(topk_chunk_sort_kernel, dim3((unsigned)chunks), dim3(kBlock), 0, stream, fitness, graph_ptr, (int)B, sorted);
-    hipLaunchKernelGGL(topk_rank_select_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, sorted, graph_ptr,
+    hipLaunchKernelGGL(topk_chunk_sort_kernel<kTopkChunk>, dim3((unsigned)chunks), dim3(kBlock), 0, stream, fitness, graph_ptr, (int)B, sorted);
+    hipLaunchKernelGGL(topk_rank_select_kernel<kTopkChunk>, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, sorted, graph_ptr,
                        new_graph_ptr, (int)B, N, perm);
     return launch_status();
   }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -24,6 +25,12 @@ inline int launch_status() {
 }
 
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// A/B switch of an experiment in flight (scripts/ab_env.sh): read once per call site.  Settled switches become constants.
+inline int ab_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Kernels that walk a
 // row range want each XCD to own one CONTIGUOUS slice of it, so that the window of source rows a tile

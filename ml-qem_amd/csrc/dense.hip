@@ -237,6 +237,51 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
   }
 }
 
+// NARROW outputs (O <= 4) of padded rows with nothing in the epilogue but the bias: ASAPooling's one-wide score projections a = w . segmax
+// and c = att_x . x, and LEConv's three one-wide projections as one [3, D] matrix (docs/tutorials/gnn.py:93-101 through PyG's ASAPooling).
+// A 16-row MFMA tile uses one to three of its sixteen output columns and loads a row as 64-byte pieces; here LPR lanes own a row
+// (a float4 each: the row is one contiguous read), multiply against the weights in registers and add up across the lanes; R rows per
+// thread keep R loads in flight.  45 MB of rows at N = 353 k: 23 -> ~9 us.
+template <int LPR, int OC, int R>
+__global__ __launch_bounds__(kBlock) void linear_rowdot_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y, int64_t ldy, int64_t N,
+                                                               int I) {
+  constexpr int kRows = kBlock / LPR;                 // rows per block and pass
+  const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int k0 = 4 * sub;
+  float wv[OC][4];
+#pragma unroll
+  for (int o = 0; o < OC; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[o][j] = k0 + j < I ? w[o * I + k0 + j] : 0.f;
+  const int64_t row0 = (int64_t)blockIdx.x * (kRows * R) + rl;
+  float4 v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + (int64_t)r * kRows;
+    v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < N && k0 < I) v[r] = *reinterpret_cast<const float4*>(x + row * ldx + k0);
+    if (k0 + 1 >= I) v[r].y = 0.f;       // the pad columns of a row are scratch
+    if (k0 + 2 >= I) v[r].z = 0.f;
+    if (k0 + 3 >= I) v[r].w = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + (int64_t)r * kRows;
+    float acc[OC];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+      acc[o] = fmaf(v[r].w, wv[o][3], fmaf(v[r].z, wv[o][2], fmaf(v[r].y, wv[o][1], v[r].x * wv[o][0])));
+#pragma unroll
+      for (int m = LPR / 2; m >= 1; m >>= 1) acc[o] += __shfl_xor(acc[o], m, LPR);
+    }
+    if (sub == 0 && row < N) {
+#pragma unroll
+      for (int o = 0; o < OC; ++o) y[row * ldy + o] = acc[o] + (b ? b[o] : 0.f);
+    }
+  }
+}
+
 // WIDE outputs from narrow inputs with NOTHING in the epilogue but the bias: the q / k / v / skip projection of a TransformerConv
 // (22 -> 180 on the circuit DAGs, 45 -> 120 on the pooled graph; docs/tutorials/gnn.py:80-91).  The kernel above gives a wave
 // OBT = 4 output tiles, so three workgroups write three 256-byte pieces of every 720-byte row at different times, each store
@@ -1309,8 +1354,14 @@ static void launch_linear_mfma(const LinArgs& a, int ks, dim3 grid, hipStream_t 
 
 template <int OBT, bool TRANSPOSED>
 static void launch_linear_v4(const LinArgs& a, int g, dim3 grid, hipStream_t s) {
+  // a wave's prologue loads OBT x G x 4 weight registers by 4-byte gathers: with many of them (128 at I = 128, O = 45: the weights ARE the
+  // kernel when a wave then serves three row tiles) the grid is ONE resident round of persistent waves
+  const bool one_round = OBT * g >= 16;      // (101 -> 81 us at N = 353 k)
   switch (g) {
-#define MLQEM_CASE(K) case K: hipLaunchKernelGGL((linear_mfma_v4_kernel<OBT, K, TRANSPOSED>), whole_rounds(linear_mfma_v4_kernel<OBT, K, TRANSPOSED>, grid), dim3(kBlock), 0, s, a); break;
+#define MLQEM_CASE(K) case K: { \
+      dim3 gr = whole_rounds(linear_mfma_v4_kernel<OBT, K, TRANSPOSED>, grid); \
+      if (one_round) gr.x = (unsigned)std::min<int64_t>(gr.x, std::max<int64_t>(1, resident_of(reinterpret_cast<const void*>(linear_mfma_v4_kernel<OBT, K, TRANSPOSED>)) / std::max(1u, grid.y))); \
+      hipLaunchKernelGGL((linear_mfma_v4_kernel<OBT, K, TRANSPOSED>), gr, dim3(kBlock), 0, s, a); } break;
     MLQEM_CASE(1) MLQEM_CASE(2) MLQEM_CASE(3) MLQEM_CASE(4) MLQEM_CASE(5) MLQEM_CASE(6) MLQEM_CASE(7) MLQEM_CASE(8)
 #undef MLQEM_CASE
   }
@@ -1375,6 +1426,25 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
       else if (nt == 8) go(linear_rows_lds_kernel<8, 3>);
       else if (g == 2) { if (k24) go(linear_rows_lds_kernel<12, 2, true>); else go(linear_rows_lds_kernel<12, 2>); }
       else go(linear_rows_lds_kernel<12, 3>);
+      return launch_status();
+    }
+  }
+  {
+    // one to four outputs, bias only: lanes along the row (linear_rowdot_kernel)
+    if (!transposed && !accumulate && !gate && !rowscale && act == 0 && drop_p == 0.f && !x_rows && O <= 4 && I <= 64 &&
+        ldx % 4 == 0 && ldx >= (I + 3) / 4 * 4 && aligned_to(x, 16) && N >= 4096) {
+      const bool narrow = I <= 32;
+      const int lpr = narrow ? 8 : 16;
+      constexpr int R = 4;
+      const unsigned grid = (unsigned)ceil_div(N, (kBlock / lpr) * R);
+#define MLQEM_ROWDOT(L, OC) hipLaunchKernelGGL((linear_rowdot_kernel<L, OC, R>), dim3(grid), dim3(kBlock), 0, s, x, ldx, w, b, y, ldy, N, I)
+      switch (O) {
+        case 1: if (narrow) MLQEM_ROWDOT(8, 1); else MLQEM_ROWDOT(16, 1); break;
+        case 2: if (narrow) MLQEM_ROWDOT(8, 2); else MLQEM_ROWDOT(16, 2); break;
+        case 3: if (narrow) MLQEM_ROWDOT(8, 3); else MLQEM_ROWDOT(16, 3); break;
+        default: if (narrow) MLQEM_ROWDOT(8, 4); else MLQEM_ROWDOT(16, 4); break;
+      }
+#undef MLQEM_ROWDOT
       return launch_status();
     }
   }
@@ -1650,7 +1720,13 @@ static int launch_wgrad(WgradArgs a, float* gw, float* gb, int accumulate, hipSt
     // many outputs against a narrow x (Family B's first projection: gy[180]^T x[22]): six output tiles per workgroup -- a row's
     // gy is read as 384-byte pieces by ceil(ob / 6) workgroup columns instead of 128-byte pieces by ceil(ob / 2), and x is
     // re-read two times instead of six
+    // (the software-pipelined form of this shape, wgrad_mfma_kernel<6, 2, 4, true>: 186 against 180 us at N = 706 k, round 6)
     MLQEM_WG((wgrad_mfma_kernel<6, 2>), (unsigned)ceil_div(ob, 6))
+  } else if (ob > 2 && ib == 3) {
+    // a few output tiles against three input tiles (Family B's second projection: gy[128]^T x[45]): x is re-read once per workgroup
+    // column, so fewer, taller columns than the general form below: 4 x 3 tiles, 79 us at N = 353 k (2 x 4: 100 us, x read four times;
+    // 8 x 3, x read once: 109 us at 170 registers)
+    MLQEM_WG((wgrad_mfma_kernel<4, 3>), (unsigned)ceil_div(ob, 4))
   } else {
     MLQEM_WG((wgrad_mfma_kernel<2, 4>), (unsigned)(ceil_div(ob, 2) * ceil_div(ib, 4)))
   }

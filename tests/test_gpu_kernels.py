@@ -680,11 +680,11 @@ def test_linear_with_more_than_128_inputs_runs_on_the_matrix_cores_in_two_pieces
 
 
 @pytest.mark.parametrize("sizes", [[5, 1, 0, 17, 300], [3000, 9000, 1500, 4096, 2048, 7777], [20000] * 3 + [2089] * 5,
-                                   [4097, 1, 8192, 4095, 12288, 0, 5000, 16385]])
+                                   [4097, 1, 8192, 4095, 12288, 0, 5000, 16385], [1025, 1023, 2047, 2049, 1024, 3073, 6000, 1, 513, 511, 512]])
 def test_segment_topk_lists_each_graph_by_descending_fitness_ties_to_the_lower_index(sizes):
     """mlqem_segment_topk (PyG ``topk(fitness, ratio, batch)`` of ASAPooling): small graphs go through the segmented sort,
-    batches of large graphs (a thousand nodes per graph on average) through the two launches of round 5 -- chunks of 4 096 nodes
-    sorted in LDS, then every node ranked among its graph's chunks (sizes around the chunk boundaries, an empty graph and a graph
+    batches of large graphs (a thousand nodes per graph on average) through the two launches of round 5 -- chunks of 2 048 nodes
+    (4 096 until round 6) sorted in LDS, then every node ranked among its graph's chunks (sizes around the chunk boundaries, an empty graph and a graph
     of one node among them) -- both must list, for every graph,
     its ceil(n/2) nodes of largest fitness in descending order with ties broken by the lower index; with and without the
     caller's bound on the graph size.  Fitness values are quantised so that ties are frequent; integers: exact."""
