@@ -206,6 +206,8 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_kernel(const float* 
 // [N,D]x[D,3] GEMM -- five passes that read x, the maxima or x' from memory (294 us on the circuit DAGs of 64 100-qubit circuits).
 // A 16-lane group per row, lane l channels l, l + 16, ... (NV per lane); rows of at most two in-edges keep the gathered rows in
 // registers between the maximum and the sum, longer rows gather twice (the second time from cache).
+// (Round 6: every load unconditional -- a lane without a channel in slice v reads the row's last channel and masks the value:
+// `has[v] ? p[..] : 0` compiles to a branch around each load; see softmax_aggregate_bwd_src_kernel, family_b_bwd.hip.)
 template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_kernel(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
     const float* __restrict__ w_comp, const float* __restrict__ b_comp, const float* __restrict__ att_x, const float* __restrict__ w3,
@@ -215,14 +217,24 @@ template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_ke
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  constexpr int kFull = NV - 1;                            // slices every lane has a channel of: 16 (NV - 1) < C <= 16 NV
   bool has[NV];
-  float wc[NV], ax[NV], own[NV];
+  int col[NV];                                             // the lane's channel of slice v, or the last channel (loaded, then masked)
+  float wc[NV], ax[NV], own[NV], w3v[3][NV];
+  const int beg = ptr[row], deg = ptr[row + 1] - beg;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    has[v] = l + v * kGroup < C;
-    wc[v] = has[v] ? w_comp[l + v * kGroup] : 0.f;
-    ax[v] = has[v] ? att_x[l + v * kGroup] : 0.f;
-    own[v] = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
+    has[v] = v < kFull || l + v * kGroup < C;
+    col[v] = v < kFull ? l + v * kGroup : min(l + v * kGroup, C - 1);
+  }
+  auto masked = [&](float t, int v) { return has[v] ? t : 0.f; };
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    wc[v] = masked(w_comp[col[v]], v);
+    ax[v] = masked(att_x[col[v]], v);
+    own[v] = masked(x[row * ldx + col[v]], v);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) w3v[t][v] = masked(w3[t * C + col[v]], v);
   }
   auto dot = [&](const float (&a)[NV], const float (&b)[NV]) {
     float d = 0.f;
@@ -231,21 +243,24 @@ template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_ke
     return group16_sum(d);
   };
   const float c_own = dot(ax, own);
-  const int beg = ptr[row], deg = ptr[row + 1] - beg;
   float mx[NV], acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) mx[v] = own[v];
   float a_i, m, den;
   if (deg <= 2) {                                          // (group-uniform) the gathered rows stay in registers
     float xs[2][NV], cs[2] = {0.f, 0.f};
+    const int j0 = idx[deg > 0 ? beg : 0], j1 = idx[deg > 1 ? beg + 1 : 0];      // (entry 0 exists in every index array: allocated with >= 1)
+    const int jj[2] = {deg > 0 ? j0 : (int)row, deg > 1 ? j1 : (int)row};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = u < deg ? idx[beg + u] : (int)row;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        xs[u][v] = has[v] ? x[(int64_t)j * ldx + l + v * kGroup] : 0.f;
+      for (int v = 0; v < NV; ++v) xs[u][v] = masked(x[(int64_t)jj[u] * ldx + col[v]], v);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
         if (u < deg) mx[v] = fmaxf(mx[v], xs[u][v]);
-      }
       cs[u] = dot(ax, xs[u]);
     }
     a_i = dot(wc, mx) + b_comp[0];
@@ -257,21 +272,22 @@ template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_ke
     for (int v = 0; v < NV; ++v) acc[v] = fmaf(p_own, own[v], fmaf(p1, xs[1][v], p0 * xs[0][v]));
   } else {
     const int end = beg + deg;
-    // eight gathered rows in flight at a time (one row per trip was a dependent round trip per entry: a barrier's 100 entries took
-    // 300 us, the whole launch's duration)
+    // eight (four: wide rows) gathered rows in flight at a time (one row per trip was a dependent round trip per entry: a barrier's
+    // 100 entries took 300 us, the whole launch's duration)
+    constexpr int kFly = NV >= 3 ? 4 : 8;
     for (int e0 = beg; e0 < end; e0 += kGroup) {           // the maximum
       const int k = min(kGroup, end - e0);
       const int j = idx[e0 + min(l, k - 1)];
-      for (int u0 = 0; u0 < k; u0 += 8) {
-        float xj[8][NV];
+      for (int u0 = 0; u0 < k; u0 += kFly) {
+        float xj[kFly][NV];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kFly; ++u) {
           const int ju = __shfl(j, min(u0 + u, k - 1), kGroup);
 #pragma unroll
-          for (int v = 0; v < NV; ++v) xj[u][v] = has[v] ? x[(int64_t)ju * ldx + l + v * kGroup] : 0.f;
+          for (int v = 0; v < NV; ++v) xj[u][v] = masked(x[(int64_t)ju * ldx + col[v]], v);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < kFly; ++u)
 #pragma unroll
           for (int v = 0; v < NV; ++v) mx[v] = fmaxf(mx[v], xj[u][v]);       // (past the end: the last entry again)
       }
@@ -292,16 +308,16 @@ template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_ke
     for (int e0 = beg; e0 < end; e0 += kGroup) {           // scores, weights, the sum (rows from cache), in entry order
       const int k = min(kGroup, end - e0);
       const int j = idx[e0 + min(l, k - 1)];
-      for (int u0 = 0; u0 < k; u0 += 8) {
-        float xj[8][NV];
+      for (int u0 = 0; u0 < k; u0 += kFly) {
+        float xj[kFly][NV];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kFly; ++u) {
           const int ju = __shfl(j, min(u0 + u, k - 1), kGroup);
 #pragma unroll
-          for (int v = 0; v < NV; ++v) xj[u][v] = has[v] ? x[(int64_t)ju * ldx + l + v * kGroup] : 0.f;
+          for (int v = 0; v < NV; ++v) xj[u][v] = masked(x[(int64_t)ju * ldx + col[v]], v);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kFly; ++u) {
           if (u0 + u < k) {                                // (group-uniform)
             const float sj = leaky(a_i + dot(ax, xj[u]));
             grow(sj);
@@ -332,12 +348,7 @@ template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_ke
   }
   float out3[3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    float wv[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) wv[v] = has[v] ? w3[t * C + l + v * kGroup] : 0.f;
-    out3[t] = dot(wv, xn) + b3[t];
-  }
+  for (int t = 0; t < 3; ++t) out3[t] = dot(w3v[t], xn) + b3[t];
   if (l == 0) {
     a_dst[row] = a_i;
     c_src[row] = c_own;
@@ -406,7 +417,7 @@ extern "C" int mlqem_asap_scores_fused_f32(const float* x, int64_t ldx, const in
   if (N < 0 || C <= 0 || ldx < C || ldm < C || ldn < C) return MLQEM_ERR_BAD_ARG;
   if (C > 64) return MLQEM_ERR_UNSUPPORTED;
   if (N == 0) return MLQEM_OK;
-  if (!x || !in_ptr || !w_comp || !b_comp || !att_x || !w3 || !b3 || !xmax || !a_dst || !c_src || !xnew || !pqr) return MLQEM_ERR_BAD_ARG;
+  if (!x || !in_ptr || !in_src || !w_comp || !b_comp || !att_x || !w3 || !b3 || !xmax || !a_dst || !c_src || !xnew || !pqr) return MLQEM_ERR_BAD_ARG;
   const dim3 grid((unsigned)ceil_div(N * kGroup, kBlock));
 #define MLQEM_AF(NV) hipLaunchKernelGGL(asap_scores_fused_kernel<NV>, grid, dim3(kBlock), 0, as_stream(stream), x, ldx, in_ptr, in_src, w_comp, \
                                         b_comp, att_x, w3, b3, negative_slope, N, C, xmax, ldm, a_dst, c_src, xnew, ldn, pqr)

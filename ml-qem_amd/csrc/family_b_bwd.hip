@@ -491,6 +491,8 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 // TIES: the walk also counts, per channel, the entries of the row (sources and the row itself) that attain xmax[row, :] -- what
 // the backward of ASAPooling's segment max (same x, same entries) needs from a pass of its own otherwise (segment_max_share_kernel:
 // one more gather of every source row); tie_count[row, c] as a float.
+// (Round 6: every load unconditional -- a lane without a channel in slice v reads the row's last channel and masks the value; see
+// softmax_aggregate_bwd_src_kernel.  `has[v] ? p[..] : 0` compiles to a branch around each load: ~100 branches per row here.)
 template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ xnew, int64_t ldn,
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
@@ -505,27 +507,40 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
   // edge, and edge_al takes one record {a_i, m_i, 1 / den_i, delta_i} per row
   const bool recompute = edge_gp == nullptr;
   const int beg = ptr[row], end = ptr[row + 1];
-  const float ai = a_dst[row];
+  const float ai = a_dst[row], c_own = c_src[row];
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
+  constexpr int kFull = NV <= 4 ? NV - 1 : 4;          // slices every lane has a channel of: 16 (NV - 1) < C <= 16 NV, NV = 8: 64 < C
   bool has[NV];
-  float gi[NV];
+  int col[NV];                                         // the lane's channel of slice v, or the last channel (loaded, then masked)
+  float gi[NV], xs[NV];
   float mx[TIES ? NV : 1];
   int ties[TIES ? NV : 1];
   float d = 0.f;
+  {
+    float g0[NV], xn[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    has[v] = l + v * kGroup < C;
-    gi[v] = has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f;
-    d = fmaf(gi[v], has[v] ? xnew[row * ldn + l + v * kGroup] : 0.f, d);
-    if (TIES) { mx[v] = has[v] ? xmax[row * ldm + l + v * kGroup] : 0.f; ties[v] = 0; }
+    for (int v = 0; v < NV; ++v) {
+      has[v] = v < kFull || l + v * kGroup < C;
+      col[v] = v < kFull ? l + v * kGroup : min(l + v * kGroup, C - 1);
+      g0[v] = gnew[row * ldg + col[v]];
+      xn[v] = xnew[row * ldn + col[v]];
+      xs[v] = x[row * ldx + col[v]];
+      if (TIES) { mx[v] = xmax[row * ldm + col[v]]; ties[v] = 0; }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      gi[v] = has[v] ? g0[v] : 0.f;
+      d = fmaf(gi[v], xn[v], d);
+    }
   }
   const float delta = group16_sum(d);
   // statistics: running maximum and denominator over the edges, then the self-loop
-  const float s_self = leaky(ai + c_src[row]);
+  const float s_self = leaky(ai + c_own);
   float m = -INFINITY, den = 0.f;
   for (int e0 = beg; e0 < end; e0 += kGroup) {
     const int k = min(kGroup, end - e0);
-    const float s = l < k ? leaky(ai + c_src[idx[e0 + min(l, k - 1)]]) : -INFINITY;
+    const float cj = c_src[idx[e0 + min(l, k - 1)]];
+    const float s = l < k ? leaky(ai + cj) : -INFINITY;
     const float cm = group16_max(s);
     if (cm > m) { den *= expf(m - cm); m = cm; }
     den += group16_sum(l < k ? expf(s - m) : 0.f);
@@ -550,9 +565,9 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
-        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
+        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) xv[u][v] = has[v] ? xj[v * kGroup] : 0.f;
+        for (int v = 0; v < NV; ++v) xv[u][v] = xj[col[v]];
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
@@ -584,15 +599,14 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
   }
   ga = group16_sum(ga);
   {  // the self-loop entry (position E + row)
-    const float pre = ai + c_src[row];
+    const float pre = ai + c_own;
     const float al = expf(leaky(pre) - m) * inv;
     float dd = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const float xs = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
-      dd = fmaf(gi[v], xs, dd);
+      dd = fmaf(gi[v], xs[v], dd);
       if (TIES) {
-        ties[v] += (has[v] && xs == mx[v]) ? 1 : 0;
+        ties[v] += (has[v] && xs[v] == mx[v]) ? 1 : 0;
         if (has[v]) tie_count[row * ldt + l + v * kGroup] = (float)ties[v];
       }
     }
@@ -712,6 +726,13 @@ __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_dst_any_width_ke
 struct MaxFuse {
   const float* x; int64_t ldx; const float* xmax; int64_t ldm; const float* ties; int64_t ldt; const float* g_row; const float* g_col;
 };
+// (Round 6: every load of this kernel is UNCONDITIONAL -- a lane without a channel in slice v reads the row's last channel and masks
+// the value -- and every load the maximum's part needs is issued in front of the comparison `x == xmax`.  `has[v] ? p[..] : 0` compiles to
+// a branch around the load and a load whose only use sits inside `if (x == xmax)` is sunk into that branch: the first form of this
+// kernel waited for memory six times at the top of every row, one slice after the other, where one round trip was due.)
+// 1 / (the number of entries that attain a maximum): v_rcp_f32 (1 ulp; exact for 1, 2, 4, ...).  A division here is a dozen
+// instructions, and -- worse -- the compiler turns `cond ? a / b : 0` into a branch and sinks the loads behind it into that branch.
+__device__ __forceinline__ float share_of(float ties) { return __builtin_amdgcn_rcpf(ties > 0.f ? ties : 1.f); }
 template <int NV, bool FUSE_MAX> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bwd_src_kernel(
     const float* __restrict__ gnew, int64_t ldg, const int32_t* __restrict__ optr, const int32_t* __restrict__ odst,
     const int32_t* __restrict__ oeid, const float* __restrict__ edge_al, const float* __restrict__ edge_gp, int64_t N,
@@ -720,42 +741,60 @@ template <int NV, bool FUSE_MAX> __global__ __launch_bounds__(kBlock) void softm
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
+  constexpr int kFull = NV <= 4 ? NV - 1 : 4;          // slices every lane has a channel of: 16 (NV - 1) < C <= 16 NV, NV = 8: 64 < C
   bool has[NV];
+  int col[NV];                                         // the lane's channel of slice v, or the last channel (loaded, then masked)
   float acc[NV], xv[FUSE_MAX ? NV : 1], wc[FUSE_MAX ? NV : 1];
-  const float al_self = edge_al[E + row];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    has[v] = l + v * kGroup < C;
-    acc[v] = al_self * (has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f);
-    if (FUSE_MAX) {
-      const int c = l + v * kGroup;
-      xv[v] = has[v] ? mf.x[row * mf.ldx + c] : 0.f;
-      wc[v] = has[v] ? mf.g_col[c] : 0.f;
-      if (has[v] && xv[v] == mf.xmax[row * mf.ldm + c]) {          // the row itself is an entry of its own maximum
-        const float n = mf.ties[row * mf.ldt + c];
-        acc[v] += mf.g_row[row] * wc[v] / (n > 0.f ? n : 1.f);
+    has[v] = v < kFull || l + v * kGroup < C;
+    col[v] = v < kFull ? l + v * kGroup : min(l + v * kGroup, C - 1);
+  }
+  const float al_self = edge_al[E + row];
+  const int beg = optr[row], end = optr[row + 1];
+  {
+    float g0[NV], xm[FUSE_MAX ? NV : 1], n[FUSE_MAX ? NV : 1];
+    const float g_own = FUSE_MAX ? mf.g_row[row] : 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      g0[v] = gnew[row * ldg + col[v]];
+      if (FUSE_MAX) {
+        xv[v] = mf.x[row * mf.ldx + col[v]];
+        wc[v] = mf.g_col[col[v]];
+        xm[v] = mf.xmax[row * mf.ldm + col[v]];
+        n[v] = mf.ties[row * mf.ldt + col[v]];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      acc[v] = has[v] ? al_self * g0[v] : 0.f;
+      if (FUSE_MAX) {                                  // the row itself is an entry of its own maximum
+        const float share = g_own * wc[v] * share_of(n[v]);
+        acc[v] += (has[v] && xv[v] == xm[v]) ? share : 0.f;
       }
     }
   }
   float gc = 0.f;                                      // lane u: the gp of its edges
-  const int beg = optr[row], end = optr[row + 1];
   for (int e0 = beg; e0 < end; e0 += kGroup) {
     const int k = min(kGroup, end - e0);
     const int ee = e0 + min(l, k - 1);
     const int i = odst[ee], pos = oeid[ee];
-    const float al = l < k ? edge_al[pos] : 0.f;        // lanes past the end: the last edge again with weight 0
-    if (l < k) gc += edge_gp[pos];
+    const float alv = edge_al[pos], gpv = edge_gp[pos];
+    const float al = l < k ? alv : 0.f;                  // lanes past the end: the last edge again with weight 0
+    gc += l < k ? gpv : 0.f;
     auto rows = [&](auto first, auto count) {
       constexpr int U0 = decltype(first)::value, CNT = decltype(count)::value;   // CNT = 2: the short rows of a circuit DAG (see attn.hip)
       int iu[CNT];
       float au[CNT], gn[CNT][NV];
       iu[0] = group16_bcast<U0 + 0>(i); iu[1] = group16_bcast<U0 + 1>(i);
       au[0] = group16_bcast<U0 + 0>(al); au[1] = group16_bcast<U0 + 1>(al);
+      if constexpr (CNT >= 4) {
+        iu[2] = group16_bcast<U0 + 2>(i); iu[3] = group16_bcast<U0 + 3>(i);
+        au[2] = group16_bcast<U0 + 2>(al); au[3] = group16_bcast<U0 + 3>(al);
+      }
       if constexpr (CNT == 8) {
-        iu[2] = group16_bcast<U0 + 2>(i); iu[3] = group16_bcast<U0 + 3>(i); iu[4] = group16_bcast<U0 + 4>(i);
-        iu[5] = group16_bcast<U0 + 5>(i); iu[6] = group16_bcast<U0 + 6>(i); iu[7] = group16_bcast<U0 + 7>(i);
-        au[2] = group16_bcast<U0 + 2>(al); au[3] = group16_bcast<U0 + 3>(al); au[4] = group16_bcast<U0 + 4>(al);
-        au[5] = group16_bcast<U0 + 5>(al); au[6] = group16_bcast<U0 + 6>(al); au[7] = group16_bcast<U0 + 7>(al);
+        iu[4] = group16_bcast<U0 + 4>(i); iu[5] = group16_bcast<U0 + 5>(i); iu[6] = group16_bcast<U0 + 6>(i); iu[7] = group16_bcast<U0 + 7>(i);
+        au[4] = group16_bcast<U0 + 4>(al); au[5] = group16_bcast<U0 + 5>(al); au[6] = group16_bcast<U0 + 6>(al); au[7] = group16_bcast<U0 + 7>(al);
       }
       // the maximum's part rides in the two-entry form (the rows of a circuit DAG); longer rows take it four entries at a time
       // below -- with eight rows of three matrices in flight the kernel needed 130 registers (three waves per SIMD: 520 us)
@@ -763,15 +802,15 @@ template <int NV, bool FUSE_MAX> __global__ __launch_bounds__(kBlock) void softm
       float xm[MAX_HERE ? CNT : 1][MAX_HERE ? NV : 1], tc[MAX_HERE ? CNT : 1][MAX_HERE ? NV : 1], gr[MAX_HERE ? CNT : 1];
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
-        const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg + l;
+        const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) gn[u][v] = has[v] ? gi[v * kGroup] : 0.f;
+        for (int v = 0; v < NV; ++v) gn[u][v] = gi[col[v]];
         if (MAX_HERE) {
           gr[u] = mf.g_row[iu[u]];
 #pragma unroll
           for (int v = 0; v < NV; ++v) {
-            xm[u][v] = has[v] ? mf.xmax[(int64_t)iu[u] * mf.ldm + l + v * kGroup] : 0.f;
-            tc[u][v] = has[v] ? mf.ties[(int64_t)iu[u] * mf.ldt + l + v * kGroup] : 1.f;
+            xm[u][v] = mf.xmax[(int64_t)iu[u] * mf.ldm + col[v]];
+            tc[u][v] = mf.ties[(int64_t)iu[u] * mf.ldt + col[v]];
           }
         }
       }
@@ -779,9 +818,10 @@ template <int NV, bool FUSE_MAX> __global__ __launch_bounds__(kBlock) void softm
       for (int u = 0; u < CNT; ++u)
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          acc[v] = fmaf(au[u], gn[u][v], acc[v]);
+          acc[v] = fmaf(au[u], has[v] ? gn[u][v] : 0.f, acc[v]);
           if (MAX_HERE) {                                  // (U0 + u < k: lanes past the end repeat the last entry)
-            if (U0 + u < k && has[v] && xv[v] == xm[u][v]) acc[v] += gr[u] * wc[v] / (tc[u][v] > 0.f ? tc[u][v] : 1.f);
+            const float share = gr[u] * wc[v] * share_of(tc[u][v]);
+            acc[v] += (U0 + u < k && has[v] && xv[v] == xm[u][v]) ? share : 0.f;
           }
         }
     };
@@ -794,36 +834,40 @@ template <int NV, bool FUSE_MAX> __global__ __launch_bounds__(kBlock) void softm
         gr[u] = mf.g_row[iu[u]];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          xm[u][v] = has[v] ? mf.xmax[(int64_t)iu[u] * mf.ldm + l + v * kGroup] : 0.f;
-          tc[u][v] = has[v] ? mf.ties[(int64_t)iu[u] * mf.ldt + l + v * kGroup] : 1.f;
+          xm[u][v] = mf.xmax[(int64_t)iu[u] * mf.ldm + col[v]];
+          tc[u][v] = mf.ties[(int64_t)iu[u] * mf.ldt + col[v]];
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
-          if (U0 + u < k && has[v] && xv[FUSE_MAX ? v : 0] == xm[u][v]) acc[v] += gr[u] * wc[FUSE_MAX ? v : 0] / (tc[u][v] > 0.f ? tc[u][v] : 1.f);
+        for (int v = 0; v < NV; ++v) {
+          const float share = gr[u] * wc[FUSE_MAX ? v : 0] * share_of(tc[u][v]);
+          acc[v] += (U0 + u < k && has[v] && xv[FUSE_MAX ? v : 0] == xm[u][v]) ? share : 0.f;
+        }
     };
     if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{});
-    else {
+    else if (FUSE_MAX) {                                   // (four rows of one matrix in flight: the registers of the two-entry form)
+      rows(EdgeChunk<0>{}, EdgeChunk<4>{}); max_rows(EdgeChunk<0>{});
+      if (k > 4) { rows(EdgeChunk<4>{}, EdgeChunk<4>{}); max_rows(EdgeChunk<4>{}); }
+      if (k > 8) { rows(EdgeChunk<8>{}, EdgeChunk<4>{}); max_rows(EdgeChunk<8>{}); }
+      if (k > 12) { rows(EdgeChunk<12>{}, EdgeChunk<4>{}); max_rows(EdgeChunk<12>{}); }
+    } else {
       rows(EdgeChunk<0>{}, EdgeChunk<8>{});
       if (k > 8) rows(EdgeChunk<8>{}, EdgeChunk<8>{});
-      if (FUSE_MAX) {
-        max_rows(EdgeChunk<0>{});
-        if (k > 4) max_rows(EdgeChunk<4>{});
-        if (k > 8) max_rows(EdgeChunk<8>{});
-        if (k > 12) max_rows(EdgeChunk<12>{});
-      }
     }
   }
   gc = group16_sum(gc) + edge_gp[E + row];
-  float* __restrict__ d = gx + row * ldgx + l;
+  float* __restrict__ d = gx + row * ldgx;
+  float r1[NV], prev[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    r1[v] = rank1 ? rank1[col[v]] : 0.f;                  // + g_c[row] * att_x: the gradient through c = x . att_x
+    prev[v] = accumulate ? d[col[v]] : 0.f;
+  }
 #pragma unroll
   for (int v = 0; v < NV; ++v)
-    if (has[v]) {
-      const float r = acc[v] + (rank1 ? gc * rank1[l + v * kGroup] : 0.f);      // + g_c[row] * att_x: the gradient through c = x . att_x
-      d[v * kGroup] = accumulate ? d[v * kGroup] + r : r;
-    }
+    if (has[v]) d[l + v * kGroup] = prev[v] + (acc[v] + gc * r1[v]);
   if (l == 0) g_c[row] = gc;
 }
 
