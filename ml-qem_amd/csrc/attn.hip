@@ -9,8 +9,8 @@ namespace mlqem {
 
 // TransformerConv (heads=H, concat, root_weight, no edge features), inference form: no dropout, no
 // statistics.  The schedule (short rows from registers, longer ones in one chunked pass) is in attn_fwd.hpp.
-template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_q4_kernel(const AttnFwdArgs a) {
-  attn_forward_q4<false, LPH>(a);
+template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transformer_attn_q4_kernel(const AttnFwdArgs a) {
+  attn_forward_q4<false, LPH, FAST>(a);
 }
 
 template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_kernel(const AttnFwdArgs a) {
@@ -38,8 +38,12 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_ke
   const float ai = a_dst[row];
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
   bool has[NV];
+  int col[NV];                                       // (every load unconditional: common.hpp slice_columns)
+  slice_columns<NV>(l, C, has, col);
+  float own[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) has[v] = l + v * kGroup < C;
+  for (int v = 0; v < NV; ++v) own[v] = x[row * ldx + col[v]];
+  const float c_own = c_src[row];
   float m = -INFINITY, den = 0.f, acc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = 0.f;
@@ -55,7 +59,8 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_ke
   for (int e0 = beg; e0 < end; e0 += kGroup) {
     const int k = min(kGroup, end - e0);              // group-uniform
     const int j = idx[e0 + min(l, k - 1)];            // lane u: edge e0 + u (lanes past k repeat the last edge, weight 0)
-    const float s = l < k ? leaky(ai + c_src[j]) : -INFINITY;
+    const float cj = c_src[j];
+    const float s = l < k ? leaky(ai + cj) : -INFINITY;
     grow(group16_max(s));
     const float p = l < k ? expf(s - m) : 0.f;
     den += group16_sum(p);
@@ -76,14 +81,14 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_ke
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
-        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
+        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) xv[u][v] = has[v] ? xj[v * kGroup] : 0.f;
+        for (int v = 0; v < NV; ++v) xv[u][v] = xj[col[v]];
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = fmaf(pu[u], xv[u][v], acc[v]);
+        for (int v = 0; v < NV; ++v) acc[v] = fmaf(pu[u], xv[u][v], acc[v]);      // (a lane without the channel: never stored)
     };
     if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{});
     else {
@@ -92,13 +97,12 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_ke
     }
   }
   {  // the self-loop last, as appended by add_remaining_self_loops
-    const float s = leaky(ai + c_src[row]);
+    const float s = leaky(ai + c_own);
     grow(s);
     const float p = expf(s - m);
     den += p;
-    const float* __restrict__ xr = x + row * ldx + l;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = fmaf(p, has[v] ? xr[v * kGroup] : 0.f, acc[v]);
+    for (int v = 0; v < NV; ++v) acc[v] = fmaf(p, own[v], acc[v]);
   }
   // PyG normalises every edge score first (p / (denom + 1e-16)) and then sums the messages: the same value, one division
   const float inv = 1.0f / (den + 1e-16f);
@@ -217,16 +221,11 @@ template <int NV> __global__ __launch_bounds__(kBlock) void asap_scores_fused_ke
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
-  constexpr int kFull = NV - 1;                            // slices every lane has a channel of: 16 (NV - 1) < C <= 16 NV
   bool has[NV];
   int col[NV];                                             // the lane's channel of slice v, or the last channel (loaded, then masked)
+  slice_columns<NV>(l, C, has, col);
   float wc[NV], ax[NV], own[NV], w3v[3][NV];
   const int beg = ptr[row], deg = ptr[row + 1] - beg;
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    has[v] = v < kFull || l + v * kGroup < C;
-    col[v] = v < kFull ? l + v * kGroup : min(l + v * kGroup, C - 1);
-  }
   auto masked = [&](float t, int v) { return has[v] ? t : 0.f; };
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
@@ -480,8 +479,11 @@ extern "C" int mlqem_transformer_attention_f32(const float* qkvs, int64_t ld, co
   if (attn_q4_enabled()) {
     const int lph = C > 16 ? 8 : 4;
     const dim3 grid4((unsigned)ceil_div(N * H * lph, kBlock));
-    if (lph == 8) hipLaunchKernelGGL(transformer_attn_q4_kernel<8>, grid4, dim3(kBlock), 0, as_stream(stream), a);
-    else hipLaunchKernelGGL(transformer_attn_q4_kernel<4>, grid4, dim3(kBlock), 0, as_stream(stream), a);
+    const bool fast = attn_q4_fast(a.H, a.C, a.CP > 0 ? a.CP : a.C, INT64_MAX, a.idx);
+    if (lph == 8 && fast) hipLaunchKernelGGL((transformer_attn_q4_kernel<8, true>), grid4, dim3(kBlock), 0, as_stream(stream), a);
+    else if (lph == 8) hipLaunchKernelGGL((transformer_attn_q4_kernel<8, false>), grid4, dim3(kBlock), 0, as_stream(stream), a);
+    else if (fast) hipLaunchKernelGGL((transformer_attn_q4_kernel<4, true>), grid4, dim3(kBlock), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((transformer_attn_q4_kernel<4, false>), grid4, dim3(kBlock), 0, as_stream(stream), a);
     return launch_status();
   }
   const dim3 grid((unsigned)ceil_div(N * H * kGroup, kBlock));

@@ -50,10 +50,10 @@ __device__ __forceinline__ float dot4(const f4u& a, const f4u& b) { return fmaf(
 __device__ __forceinline__ f4u load_channels(const float* __restrict__ p, int nv, bool fits) {
   f4u v = {0.f, 0.f, 0.f, 0.f};
   if (nv == 4 || (fits && nv > 0)) {
-    v = *reinterpret_cast<const f4u*>(p);
-    if (nv < 4) v.w = 0.f;
-    if (nv < 3) v.z = 0.f;
-    if (nv < 2) v.y = 0.f;
+    // (masked by selects on a COPY: `if (nv < 4) v.w = 0` writes a register the load is still filling, and the wave waits for the load
+    // right there, in front of every load that could have been in flight beside it)
+    const f4u t = *reinterpret_cast<const f4u*>(p);
+    v = f4u{t.x, nv > 1 ? t.y : 0.f, nv > 2 ? t.z : 0.f, nv > 3 ? t.w : 0.f};
   } else {
     if (nv > 0) v.x = p[0];
     if (nv > 1) v.y = p[1];
@@ -80,7 +80,19 @@ __device__ __forceinline__ void store_channels(float* __restrict__ p, const f4u&
 }
 
 // ------------------------------------------------------------------------------------------------------ forward
-template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(const AttnFwdArgs& a) {
+// FAST (host: attn_q4_fast): every lane of a (row, head) group has a channel, every head sits in a slot of 4 LPH floats whose pads are
+// zeros, every 16-byte access lies inside its row and there is an index array -- no load of the kernel then needs a LANE-VARYING
+// condition.  A conditional load compiles to a branch; masking a loaded vector in place (`if (nv < 4) v.w = 0`) writes a register the
+// load is still filling and waits for it on the spot; a load under `u < k` waits for k.  The general forms waited for memory six to
+// eight times per (row, head) where three round trips are due (round 6).  Entries past the end of a chunk repeat its last entry (their
+// weights are zero): FAST loads their rows again instead of branching around them.
+__device__ __forceinline__ f4u mask4(const f4u& t, int nv) { return f4u{t.x, nv > 1 ? t.y : 0.f, nv > 2 ? t.z : 0.f, nv > 3 ? t.w : 0.f}; }
+inline bool attn_q4_fast(int H, int C, int CP, int64_t ld_compact, const void* idx) {
+  const int lph = C > 16 ? 8 : 4;
+  return 4 * (lph - 1) < C && CP >= 4 * lph && (int64_t)(H - 1) * C + 4 * lph <= ld_compact && idx != nullptr;
+}
+
+template <bool TRAIN, int LPH, bool FAST = false> __device__ __forceinline__ void attn_forward_q4(const AttnFwdArgs& a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
   const int lq = threadIdx.x % LPH, lu = lq & 3;
   const int H = a.H, C = a.C, HC = H * C;
@@ -101,8 +113,14 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
   const int32_t* __restrict__ idx = a.idx;
 
   const float* __restrict__ ri = qkvs + (int64_t)row * ld;
-  const f4u q = load_channels(ri + offp, nv, true);                           // runs over into the key part at most
-  const f4u skip = load_channels(ri + 3 * HP + offp, nv, roomy || 3 * HP + offp + 4 <= 4 * HP);
+  f4u q, skip;
+  if constexpr (FAST) {
+    q = *reinterpret_cast<const f4u*>(ri + offp);
+    skip = *reinterpret_cast<const f4u*>(ri + 3 * HP + offp);
+  } else {
+    q = load_channels(ri + offp, nv, true);                                   // runs over into the key part at most
+    skip = load_channels(ri + 3 * HP + offp, nv, roomy || 3 * HP + offp + 4 <= 4 * HP);
+  }
   // the row's in-edges: from the ELL side table when the row has at most two (one dependent round trip less), else from the CSR arrays
   int s0 = -1, s1 = -1;
   bool fast = false;
@@ -122,13 +140,19 @@ template <bool TRAIN, int LPH> __device__ __forceinline__ void attn_forward_q4(c
     const int k = min(4, cnt - x0);
     const int x = x0 + min(lu, k - 1);                   // past the end: the last entry again (weight 0)
     const bool is_self = x >= deg;
-    const int j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : idx[beg + x]);
+    int j;
+    if constexpr (FAST) {
+      const int jx = idx[max(beg + min(x, deg - 1), 0)];   // (unconditional: entry 0 exists in every index array)
+      j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : jx);
+    } else {
+      j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : idx[beg + x]);
+    }
     int ju[4];
     ju[0] = quad_bcast<0>(j); ju[1] = quad_bcast<1>(j); ju[2] = quad_bcast<2>(j); ju[3] = quad_bcast<3>(j);
     f4u kk[4], vv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (u < k && nv > 0) {                             // uniform over the (row, head)'s lanes but for the channel-less ones
+      if (FAST || (u < k && nv > 0)) {                   // uniform over the (row, head)'s lanes but for the channel-less ones
         const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HP + offp;
         kk[u] = *reinterpret_cast<const f4u*>(kj);       // inside the row: a key segment runs over into the value part at most,
         vv[u] = *reinterpret_cast<const f4u*>(kj + HP);  // a value segment into the skip part

@@ -185,6 +185,21 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// The channel slices of a row group (lane l holds channels l, l + 16, ...; NV = 1, 2, 3, 4 slices for C <= 16 NV and 8 for 64 < C <= 128,
+// as every launcher of these kernels picks it): col[v] = the lane's channel of slice v, or -- a lane past the end of a partly filled
+// slice -- the row's LAST channel, so that every load of a kernel is unconditional and the value is masked by has[v] afterwards.
+// `has[v] ? p[l + 16 v] : 0` compiles to a branch around the load (~100 branches per row in the pooling kernels), and a load whose only
+// use sits inside a data-dependent `if` is sunk into it, where it waits for the condition's operands first (round 6: ASAPooling's
+// source-side backward waited six times at the top of every row; 325 -> 234 us once its loads were unconditional and up front).
+template <int NV> __device__ __forceinline__ void slice_columns(int l, int C, bool (&has)[NV], int (&col)[NV]) {
+  constexpr int kFull = NV <= 4 ? NV - 1 : 4;          // slices every lane has a channel of: 16 (NV - 1) < C <= 16 NV; NV = 8: 64 < C
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    has[v] = v < kFull || l + v * kGroup < C;
+    col[v] = v < kFull ? l + v * kGroup : min(l + v * kGroup, C - 1);
+  }
+}
+
 // ELL side table of a CSR structure (mlqem_ell_from_csr): ell[row] = (s0, s1), the first two col[] entries of the row, -1 for
 // a missing one; the sign bit of s0 says that the row has more than two entries.
 constexpr int kEllMore = (int)0x80000000;

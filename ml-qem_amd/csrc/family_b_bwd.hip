@@ -246,11 +246,12 @@ template <bool WIDE> __global__ __launch_bounds__(kBlock) void transformer_attn_
 // segments, entries (in-edges, then the self entry) four at a time with lane u of every quad owning entry u.
 // (76 registers: six waves per SIMD.  Compiled for seven -- 72 registers, 20 bytes of scratch -- the circuit-DAG forward took 224 us
 // instead of 200, for eight -- 64 registers, 56 bytes -- 343: measured, left to the compiler)
-template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_train_q4_kernel(const AttnFwdArgs a) {
-  attn_forward_q4<true, LPH>(a);
+template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transformer_attn_train_q4_kernel(const AttnFwdArgs a) {
+  attn_forward_q4<true, LPH, FAST>(a);
 }
 
-template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_q4_kernel(const AttnBwdArgs a) {
+// (FAST: attn_q4.hpp -- no load under a lane-varying condition)
+template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_dst_q4_kernel(const AttnBwdArgs a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
   const int lq = threadIdx.x % LPH, lu = lq & 3;
   const int H = a.H, C = a.C, HC = H * C;
@@ -271,8 +272,14 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   float* __restrict__ edge_al = a.edge_al;
   float* __restrict__ edge_gs = a.edge_gs;
   const bool recompute = a.oeid == nullptr;              // the source side keeps no per-edge values (see AttnBwdArgs)
-  const f4u q = load_channels(qkvs + (int64_t)row * ld + offp, nv, true);
-  const f4u gi = load_channels(a.g + (int64_t)row * a.ldg + off, nv, off + 4 <= a.ldg);
+  f4u q, gi;
+  if constexpr (FAST) {
+    q = *reinterpret_cast<const f4u*>(qkvs + (int64_t)row * ld + offp);
+    gi = mask4(*reinterpret_cast<const f4u*>(a.g + (int64_t)row * a.ldg + off), nv);
+  } else {
+    q = load_channels(qkvs + (int64_t)row * ld + offp, nv, true);
+    gi = load_channels(a.g + (int64_t)row * a.ldg + off, nv, off + 4 <= a.ldg);
+  }
   const float m = a.stat_m[(int64_t)row * H + h];
   const float inv_den = 1.0f / a.stat_den[(int64_t)row * H + h];     // one division per row, as in the forward
   const int beg = a.ptr[row];
@@ -282,19 +289,28 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   // delta = g . attn_out.  A row of more than four entries reads the attn_out the forward stored; a shorter one (ONE chunk) forms
   // it below as sum_u alpha_u mask_u (g . v_u) -- the forward stores nothing for it (attn_q4.hpp)
   float delta = 0.f;
-  if (cnt > 4) delta = head_sum<LPH>(dot4(gi, load_channels(a.attn_out + (int64_t)row * a.lda + off, nv, off + 4 <= a.lda)));
+  if (cnt > 4) {                                         // ((row, head)-uniform; rare on the circuit DAGs)
+    const float* __restrict__ ao = a.attn_out + (int64_t)row * a.lda + off;
+    delta = head_sum<LPH>(dot4(gi, FAST ? mask4(*reinterpret_cast<const f4u*>(ao), nv) : load_channels(ao, nv, off + 4 <= a.lda)));
+  }
   f4u gq = {0.f, 0.f, 0.f, 0.f};
   for (int x0 = 0; x0 < cnt; x0 += 4) {
     const int k = min(4, cnt - x0);
     const int x = x0 + min(lu, k - 1);                   // past the end: the last entry again (gs 0, nothing stored)
     const bool is_self = x >= deg;
-    const int j = is_self ? row : idx[beg + x];
+    int j;
+    if constexpr (FAST) {
+      const int jx = idx[max(beg + min(x, deg - 1), 0)];   // (unconditional: entry 0 exists in every index array)
+      j = is_self ? row : jx;
+    } else {
+      j = is_self ? row : idx[beg + x];
+    }
     int ju[4];
     ju[0] = quad_bcast<0>(j); ju[1] = quad_bcast<1>(j); ju[2] = quad_bcast<2>(j); ju[3] = quad_bcast<3>(j);
     f4u kk[4], vv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (u < k && nv > 0) {
+      if (FAST || (u < k && nv > 0)) {
         const float* __restrict__ kj = qkvs + (int64_t)ju[u] * ld + HP + offp;
         kk[u] = *reinterpret_cast<const f4u*>(kj);
         vv[u] = *reinterpret_cast<const f4u*>(kj + HP);
@@ -343,7 +359,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
 // gs_ij = alpha_ij (g_i . v_j mask_ij - delta_i) / sqrt(C).  Per out-entry it gathers the same two rows (query, gradient) as the
 // stored form and three scalars from [N, H] arrays (a few MB: cache-resident) instead of a position and two values from
 // [E, H] arrays; the coarsened graphs of ASAPooling come without out_eid (linking 9.7 M entries cost 0.55 ms per step).
-template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_rc_q4_kernel(const AttnBwdArgs a) {
+template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_rc_q4_kernel(const AttnBwdArgs a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
   const int lq = threadIdx.x % LPH, lu = lq & 3;
   const int H = a.H, C = a.C, HC = H * C;
@@ -364,8 +380,14 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   const int64_t ld = a.ld, ldg = a.ldg;
   const bool g_fits = off + 4 <= ldg;
   const float* __restrict__ rj = qkvs + (int64_t)row * ld;
-  const f4u kown = load_channels(rj + HP + offp, nv, true);         // runs over into the value part at most
-  const f4u vown = load_channels(rj + 2 * HP + offp, nv, true);     // ... into the skip part
+  f4u kown, vown;
+  if constexpr (FAST) {
+    kown = *reinterpret_cast<const f4u*>(rj + HP + offp);
+    vown = *reinterpret_cast<const f4u*>(rj + 2 * HP + offp);
+  } else {
+    kown = load_channels(rj + HP + offp, nv, true);                  // runs over into the value part at most
+    vown = load_channels(rj + 2 * HP + offp, nv, true);              // ... into the skip part
+  }
   const int n_self = a.loops ? a.loops[row] : 0;
   f4u gk = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
   const int obeg = a.optr[row];
@@ -375,7 +397,13 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     const int k = min(4, cnt - x0);
     const int x = x0 + min(lu, k - 1);
     const bool is_self = x >= odeg;
-    const int i = is_self ? row : a.odst[obeg + x];
+    int i;
+    if constexpr (FAST) {
+      const int ix = a.odst[max(obeg + min(x, odeg - 1), 0)];
+      i = is_self ? row : ix;
+    } else {
+      i = is_self ? row : a.odst[obeg + x];
+    }
     const int64_t sh = (int64_t)i * H + h;
     const float4 rec = reinterpret_cast<const float4*>(stat_delta)[sh];     // {m, 1 / den, delta} filed by the destination side
     const float m_i = rec.x, inv_den = rec.y, delta_i = rec.z;
@@ -384,7 +412,10 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     f4u qa[4], ga[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (u < k && nv > 0) {
+      if constexpr (FAST) {                              // (a padded slot's pads are zeros: only the compact gradient row is masked)
+        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + offp);
+        ga[u] = mask4(*reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off), nv);
+      } else if (u < k && nv > 0) {
         qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + offp);
         ga[u] = g_fits ? *reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off) : load_channels(g + (int64_t)iu[u] * ldg + off, nv, false);
         if (nv < 4) qa[u].w = 0.f;                       // the lane's fourth component belongs to the next head / part
@@ -420,7 +451,7 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
   store_channels(go + 2 * HP + offp, gv, nvs);
 }
 
-template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_q4_kernel(const AttnBwdArgs a) {
+template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transformer_attn_bwd_src_q4_kernel(const AttnBwdArgs a) {
   const int64_t t = ((int64_t)row_block() * kBlock + threadIdx.x) / LPH;
   const int lq = threadIdx.x % LPH, lu = lq & 3;
   const int H = a.H, C = a.C, HC = H * C;
@@ -445,10 +476,23 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     const int k = min(4, cnt - x0);
     const int x = x0 + min(lu, k - 1);
     const bool is_self = x >= odeg;
-    const int i = is_self ? row : a.odst[obeg + x];
-    const int64_t pos = is_self ? a.E + row : (int64_t)a.oeid[obeg + x];
-    const float gs = lu < k ? edge_gs[pos * H + h] : 0.f;    // past the end: the last entry again with weight 0
-    const float al = lu < k ? edge_al[pos * H + h] : 0.f;
+    int i;
+    int64_t pos;
+    float gs, al;
+    if constexpr (FAST) {
+      const int ex = max(obeg + min(x, odeg - 1), 0);
+      const int ix = a.odst[ex], px = a.oeid[ex];
+      i = is_self ? row : ix;
+      pos = is_self ? a.E + row : (int64_t)px;
+      const float gsv = edge_gs[pos * H + h], alv = edge_al[pos * H + h];
+      gs = lu < k ? gsv : 0.f;                               // past the end: the last entry again with weight 0
+      al = lu < k ? alv : 0.f;
+    } else {
+      i = is_self ? row : a.odst[obeg + x];
+      pos = is_self ? a.E + row : (int64_t)a.oeid[obeg + x];
+      gs = lu < k ? edge_gs[pos * H + h] : 0.f;              // past the end: the last entry again with weight 0
+      al = lu < k ? edge_al[pos * H + h] : 0.f;
+    }
     int iu[4];
     iu[0] = quad_bcast<0>(i); iu[1] = quad_bcast<1>(i); iu[2] = quad_bcast<2>(i); iu[3] = quad_bcast<3>(i);
     const float gsu[4] = {quad_bcast<0>(gs), quad_bcast<1>(gs), quad_bcast<2>(gs), quad_bcast<3>(gs)};
@@ -456,7 +500,10 @@ template <int LPH> __global__ __launch_bounds__(kBlock) void transformer_attn_bw
     f4u qa[4], ga[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (u < k && nv > 0) {
+      if constexpr (FAST) {                              // (gs = al = 0 past the end; a padded slot's pads are zeros)
+        qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + offp);
+        ga[u] = mask4(*reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off), nv);
+      } else if (u < k && nv > 0) {
         qa[u] = *reinterpret_cast<const f4u*>(qkvs + (int64_t)iu[u] * ld + offp);      // a query segment runs over into the key part at most
         ga[u] = g_fits ? *reinterpret_cast<const f4u*>(g + (int64_t)iu[u] * ldg + off) : load_channels(g + (int64_t)iu[u] * ldg + off, nv, false);
         if (nvs > nv && g_fits) {                        // a padded slot is stored whole: its pads must come out zero, not the next head's
@@ -509,9 +556,9 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
   const int beg = ptr[row], end = ptr[row + 1];
   const float ai = a_dst[row], c_own = c_src[row];
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
-  constexpr int kFull = NV <= 4 ? NV - 1 : 4;          // slices every lane has a channel of: 16 (NV - 1) < C <= 16 NV, NV = 8: 64 < C
   bool has[NV];
   int col[NV];                                         // the lane's channel of slice v, or the last channel (loaded, then masked)
+  slice_columns<NV>(l, C, has, col);
   float gi[NV], xs[NV];
   float mx[TIES ? NV : 1];
   int ties[TIES ? NV : 1];
@@ -520,8 +567,6 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
     float g0[NV], xn[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      has[v] = v < kFull || l + v * kGroup < C;
-      col[v] = v < kFull ? l + v * kGroup : min(l + v * kGroup, C - 1);
       g0[v] = gnew[row * ldg + col[v]];
       xn[v] = xnew[row * ldn + col[v]];
       xs[v] = x[row * ldx + col[v]];
@@ -741,15 +786,10 @@ template <int NV, bool FUSE_MAX> __global__ __launch_bounds__(kBlock) void softm
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
-  constexpr int kFull = NV <= 4 ? NV - 1 : 4;          // slices every lane has a channel of: 16 (NV - 1) < C <= 16 NV, NV = 8: 64 < C
   bool has[NV];
   int col[NV];                                         // the lane's channel of slice v, or the last channel (loaded, then masked)
+  slice_columns<NV>(l, C, has, col);
   float acc[NV], xv[FUSE_MAX ? NV : 1], wc[FUSE_MAX ? NV : 1];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    has[v] = v < kFull || l + v * kGroup < C;
-    col[v] = v < kFull ? l + v * kGroup : min(l + v * kGroup, C - 1);
-  }
   const float al_self = edge_al[E + row];
   const int beg = optr[row], end = optr[row + 1];
   {
@@ -887,18 +927,24 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
   auto leaky = [&](float v) { return v > 0.f ? v : v * slope; };
   const float cj = c_src[row];
   bool has[NV];
+  int col[NV];
+  slice_columns<NV>(l, C, has, col);
   float acc[NV], xr[NV];
   float gc;
   {  // the self entry
     const float4 st = stat[row];
     const float pre = st.x + cj;
     const float al = expf(leaky(pre) - st.y) * st.z;
-    float dd = 0.f;
+    float dd = 0.f, g0[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      has[v] = l + v * kGroup < C;
-      xr[v] = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
-      const float gn = has[v] ? gnew[row * ldg + l + v * kGroup] : 0.f;
+      xr[v] = x[row * ldx + col[v]];
+      g0[v] = gnew[row * ldg + col[v]];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xr[v] = has[v] ? xr[v] : 0.f;
+      const float gn = has[v] ? g0[v] : 0.f;
       acc[v] = al * gn;
       dd = fmaf(gn, xr[v], dd);
     }
@@ -927,17 +973,18 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
-        const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg + l;
+        const float* __restrict__ gi = gnew + (int64_t)iu[u] * ldg;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) gn[u][v] = has[v] ? gi[v * kGroup] : 0.f;
+        for (int v = 0; v < NV; ++v) gn[u][v] = gi[col[v]];
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
         float dd = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          acc[v] = fmaf(au[u], gn[u][v], acc[v]);
-          dd = fmaf(gn[u][v], xr[v], dd);
+          const float g = has[v] ? gn[u][v] : 0.f;
+          acc[v] = fmaf(au[u], g, acc[v]);
+          dd = fmaf(g, xr[v], dd);
         }
         dd = group16_sum(dd);
         if (l == U0 + u) mydot = dd;
@@ -951,12 +998,18 @@ template <int NV> __global__ __launch_bounds__(kBlock) void softmax_aggregate_bw
     if (l < k) gc += al * (mydot - st.w) * (pre > 0.f ? 1.f : slope);
   }
   gc = group16_sum(gc);
-  float* __restrict__ d = gx + row * ldgx + l;
+  float* __restrict__ d = gx + row * ldgx;
+  float r1[NV], prev[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    r1[v] = rank1 ? rank1[col[v]] : 0.f;                  // + g_c[row] * att_x: the gradient through c = x . att_x
+    prev[v] = accumulate ? d[col[v]] : 0.f;
+  }
 #pragma unroll
   for (int v = 0; v < NV; ++v)
     if (has[v]) {
-      const float r = acc[v] + (rank1 ? gc * rank1[l + v * kGroup] : 0.f);      // + g_c[row] * att_x: the gradient through c = x . att_x
-      d[v * kGroup] = accumulate ? d[v * kGroup] + r : r;
+      const float r = acc[v] + (rank1 ? gc * r1[v] : 0.f);
+      d[l + v * kGroup] = accumulate ? prev[v] + r : r;
     }
   if (l == 0) g_c[row] = gc;
 }
@@ -973,13 +1026,15 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_share_ke
   const int l = threadIdx.x % kGroup;
   if (row >= N) return;
   bool has[NV];
-  float m[NV];
+  int col[NV];
+  slice_columns<NV>(l, C, has, col);
+  float m[NV], gm[NV];
   int cnt[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    has[v] = l + v * kGroup < C;
-    m[v] = has[v] ? xmax[row * ldm + l + v * kGroup] : 0.f;
-    cnt[v] = (has[v] && x[row * ldx + l + v * kGroup] == m[v]) ? 1 : 0;
+    m[v] = xmax[row * ldm + col[v]];
+    gm[v] = gmax[row * ldg + col[v]];
+    cnt[v] = (has[v] && x[row * ldx + col[v]] == m[v]) ? 1 : 0;
   }
   const int beg = iptr[row], end = iptr[row + 1];
   for (int e0 = beg; e0 < end; e0 += kGroup) {
@@ -992,21 +1047,21 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_share_ke
       group16_bcast8<U0>(j, ju);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx + l;
+        const float* __restrict__ xj = x + (int64_t)ju[u] * ldx;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) xs[u][v] = has[v] ? xj[v * kGroup] : 0.f;
+        for (int v = 0; v < NV; ++v) xs[u][v] = xj[col[v]];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) cnt[v] += (u < kk && xs[u][v] == m[v]) ? 1 : 0;
+        for (int v = 0; v < NV; ++v) cnt[v] += (u < kk && has[v] && xs[u][v] == m[v]) ? 1 : 0;
     };
     rows(EdgeChunk<0>{}, k);
     if (k > 8) rows(EdgeChunk<8>{}, k - 8);
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v)
-    if (has[v]) gshare[row * lds + l + v * kGroup] = gmax[row * ldg + l + v * kGroup] / (float)(cnt[v] > 0 ? cnt[v] : 1);
+    if (has[v]) gshare[row * lds + l + v * kGroup] = gm[v] / (float)(cnt[v] > 0 ? cnt[v] : 1);
 }
 
 // Pass 1 when the tie counts are already known (softmax_aggregate_bwd_dst_kernel<., true>): an elementwise division, a thread per
@@ -1044,12 +1099,20 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kern
   if (row >= N) return;
   if (skip && skip[row]) return;
   bool has[NV];
-  float xv[NV], acc[NV];
+  int col[NV];
+  slice_columns<NV>(l, C, has, col);
+  float xv[NV], acc[NV], prev[NV];
+  {
+    float xm0[NV], gm0[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    has[v] = l + v * kGroup < C;
-    xv[v] = has[v] ? x[row * ldx + l + v * kGroup] : 0.f;
-    acc[v] = (has[v] && xv[v] == xmax[row * ldm + l + v * kGroup]) ? gmax[row * ldg + l + v * kGroup] : 0.f;
+    for (int v = 0; v < NV; ++v) {
+      xv[v] = x[row * ldx + col[v]];
+      xm0[v] = xmax[row * ldm + col[v]];
+      gm0[v] = gmax[row * ldg + col[v]];
+      prev[v] = gx[row * ldgx + col[v]];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = (has[v] && xv[v] == xm0[v]) ? gm0[v] : 0.f;
   }
   const int beg = optr[row], end = optr[row + 1];
   for (int e0 = beg; e0 < end; e0 += kGroup) {
@@ -1066,18 +1129,18 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kern
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u) {
-        const float* __restrict__ xi = xmax + (int64_t)iu[u] * ldm + l;
-        const float* __restrict__ gi = gmax + (int64_t)iu[u] * ldg + l;
+        const float* __restrict__ xi = xmax + (int64_t)iu[u] * ldm;
+        const float* __restrict__ gi = gmax + (int64_t)iu[u] * ldg;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          xm[u][v] = has[v] ? xi[v * kGroup] : 0.f;
-          gm[u][v] = has[v] ? gi[v * kGroup] : 0.f;
+          xm[u][v] = xi[col[v]];
+          gm[u][v] = gi[col[v]];
         }
       }
 #pragma unroll
       for (int u = 0; u < CNT; ++u)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) if (u < kk && has[v] && xv[v] == xm[u][v]) acc[v] += gm[u][v];
+        for (int v = 0; v < NV; ++v) acc[v] += (u < kk && has[v] && xv[v] == xm[u][v]) ? gm[u][v] : 0.f;
     };
     if (k <= 2) rows(EdgeChunk<0>{}, EdgeChunk<2>{}, k);
     else {
@@ -1086,7 +1149,7 @@ template <int NV> __global__ __launch_bounds__(kBlock) void segment_max_bwd_kern
     }
   }
 #pragma unroll
-  for (int v = 0; v < NV; ++v) if (has[v]) gx[row * ldgx + l + v * kGroup] += acc[v];
+  for (int v = 0; v < NV; ++v) if (has[v]) gx[row * ldgx + l + v * kGroup] = prev[v] + acc[v];
 }
 
 // Source side: g_x[j,:] (+)= sum_{e: j->i} al_e gnew[i,:] (self included); g_c[j] = sum_e gp_e.
@@ -1373,17 +1436,27 @@ using namespace mlqem;
 
 namespace mlqem {
 // the four-channels-per-lane kernels for callers in other translation units (dense_block.hip: the rows its blocks do not serve)
+// (FAST forms whenever the layout allows: attn_q4_fast)
+#define MLQEM_Q4(KERNEL, FASTCOND)                                                                                                     \
+  do {                                                                                                                                 \
+    const bool fast_ = (FASTCOND);                                                                                                     \
+    const dim3 grid_((unsigned)ceil_div(a.N * a.H * (a.C > 16 ? 8 : 4), kBlock));                                                      \
+    if (a.C > 16 && fast_) hipLaunchKernelGGL((KERNEL<8, true>), grid_, dim3(kBlock), 0, stream, a);                                   \
+    else if (a.C > 16) hipLaunchKernelGGL((KERNEL<8, false>), grid_, dim3(kBlock), 0, stream, a);                                      \
+    else if (fast_) hipLaunchKernelGGL((KERNEL<4, true>), grid_, dim3(kBlock), 0, stream, a);                                          \
+    else hipLaunchKernelGGL((KERNEL<4, false>), grid_, dim3(kBlock), 0, stream, a);                                                    \
+  } while (0)
 void launch_attn_train_q4(const AttnFwdArgs& a, hipStream_t stream) {
-  if (a.C > 16) hipLaunchKernelGGL(transformer_attn_train_q4_kernel<8>, dim3((unsigned)ceil_div(a.N * a.H * 8, kBlock)), dim3(kBlock), 0, stream, a);
-  else hipLaunchKernelGGL(transformer_attn_train_q4_kernel<4>, dim3((unsigned)ceil_div(a.N * a.H * 4, kBlock)), dim3(kBlock), 0, stream, a);
+  MLQEM_Q4(transformer_attn_train_q4_kernel, attn_q4_fast(a.H, a.C, a.CP > 0 ? a.CP : a.C, INT64_MAX, a.idx));
 }
 void launch_attn_bwd_dst_q4(const AttnBwdArgs& a, hipStream_t stream) {
-  if (a.C > 16) hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, dim3((unsigned)ceil_div(a.N * a.H * 8, kBlock)), dim3(kBlock), 0, stream, a);
-  else hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<4>, dim3((unsigned)ceil_div(a.N * a.H * 4, kBlock)), dim3(kBlock), 0, stream, a);
+  MLQEM_Q4(transformer_attn_bwd_dst_q4_kernel, attn_q4_fast(a.H, a.C, a.CP > 0 ? a.CP : a.C, std::min(a.ldg, a.lda), a.idx));
 }
 void launch_attn_bwd_src_rc_q4(const AttnBwdArgs& a, hipStream_t stream) {
-  if (a.C > 16) hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<8>, dim3((unsigned)ceil_div(a.N * a.H * 8, kBlock)), dim3(kBlock), 0, stream, a);
-  else hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<4>, dim3((unsigned)ceil_div(a.N * a.H * 4, kBlock)), dim3(kBlock), 0, stream, a);
+  MLQEM_Q4(transformer_attn_bwd_src_rc_q4_kernel, attn_q4_fast(a.H, a.C, a.CP > 0 ? a.CP : a.C, a.ldg, a.odst));
+}
+void launch_attn_bwd_src_q4(const AttnBwdArgs& a, hipStream_t stream) {
+  MLQEM_Q4(transformer_attn_bwd_src_q4_kernel, attn_q4_fast(a.H, a.C, a.CP > 0 ? a.CP : a.C, a.ldg, a.odst) && a.oeid != nullptr);
 }
 }  // namespace mlqem
 
@@ -1406,10 +1479,8 @@ extern "C" int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t 
   if (in_ell && !aligned_to(in_ell, 8)) return MLQEM_ERR_BAD_ARG;
   const AttnFwdArgs a{qkvs, ld, in_ptr, in_src, loops, N, E, H, C, drop_p, seed, seed_counter, out, ldo, attn_out, lda, stat_m, stat_den,
                       pair_key ? 1 : 0, in_ell, CP};
-  if (attn_q4_enabled()) {
-    if (C > 16) hipLaunchKernelGGL(transformer_attn_train_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
-    else hipLaunchKernelGGL(transformer_attn_train_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
-  } else if (C > kGroup) hipLaunchKernelGGL(transformer_attn_train_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
+  if (attn_q4_enabled()) launch_attn_train_q4(a, as_stream(stream));
+  else if (C > kGroup) hipLaunchKernelGGL(transformer_attn_train_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
   else hipLaunchKernelGGL(transformer_attn_train_kernel<false>, MLQEM_GRID(N * H * kGroup), a);
   return launch_status();
 }
@@ -1440,21 +1511,11 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
                       N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0, CP};
   if (recompute) {
-    if (C > 16) {
-      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
-      hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
-    } else {
-      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
-      hipLaunchKernelGGL(transformer_attn_bwd_src_rc_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
-    }
+    launch_attn_bwd_dst_q4(a, as_stream(stream));
+    launch_attn_bwd_src_rc_q4(a, as_stream(stream));
   } else if (attn_q4_enabled()) {
-    if (C > 16) {
-      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
-      hipLaunchKernelGGL(transformer_attn_bwd_src_q4_kernel<8>, MLQEM_GRID(N * H * 8), a);
-    } else {
-      hipLaunchKernelGGL(transformer_attn_bwd_dst_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
-      hipLaunchKernelGGL(transformer_attn_bwd_src_q4_kernel<4>, MLQEM_GRID(N * H * 4), a);
-    }
+    launch_attn_bwd_dst_q4(a, as_stream(stream));
+    launch_attn_bwd_src_q4(a, as_stream(stream));
   } else if (C > kGroup) {
     hipLaunchKernelGGL(transformer_attn_bwd_dst_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
     hipLaunchKernelGGL(transformer_attn_bwd_src_kernel<true>, MLQEM_GRID(N * H * kGroup), a);
