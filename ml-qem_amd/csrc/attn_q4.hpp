@@ -87,6 +87,14 @@ __device__ __forceinline__ void store_channels(float* __restrict__ p, const f4u&
 // eight times per (row, head) where three round trips are due (round 6).  Entries past the end of a chunk repeat its last entry (their
 // weights are zero): FAST loads their rows again instead of branching around them.
 __device__ __forceinline__ f4u mask4(const f4u& t, int nv) { return f4u{t.x, nv > 1 ? t.y : 0.f, nv > 2 ? t.z : 0.f, nv > 3 ? t.w : 0.f}; }
+// a lane's four channels 4 l .. 4 l + 3 of a row in the PADDED layout (16-byte aligned rows of at least round_up(C, 4) floats, pads are
+// scratch), UNCONDITIONALLY: a lane past the row's last slice reads that slice and masks everything
+__device__ __forceinline__ f4u row4(const float* __restrict__ row, int l, int C) {
+  const int last = (C - 1) >> 2;
+  const int nv = min(4, max(0, C - 4 * l));
+  const f4u t = *reinterpret_cast<const f4u*>(row + 4 * min(l, last));
+  return f4u{nv > 0 ? t.x : 0.f, nv > 1 ? t.y : 0.f, nv > 2 ? t.z : 0.f, nv > 3 ? t.w : 0.f};
+}
 inline bool attn_q4_fast(int H, int C, int CP, int64_t ld_compact, const void* idx) {
   const int lph = C > 16 ? 8 : 4;
   return 4 * (lph - 1) < C && CP >= 4 * lph && (int64_t)(H - 1) * C + 4 * lph <= ld_compact && idx != nullptr;

@@ -282,8 +282,16 @@ template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transfor
   }
   const float m = a.stat_m[(int64_t)row * H + h];
   const float inv_den = 1.0f / a.stat_den[(int64_t)row * H + h];     // one division per row, as in the forward
-  const int beg = a.ptr[row];
-  const int deg = a.ptr[row + 1] - beg;
+  // the row's in-edges: from the ELL side table when the row has at most two (one dependent round trip less), else from the CSR arrays
+  int s0 = -1, s1 = -1;
+  bool fast = false;
+  if (a.ell) {
+    const int2 e2 = reinterpret_cast<const int2*>(a.ell)[row];
+    fast = e2.x == -1 || (e2.x & kEllMore) == 0;
+    s0 = e2.x; s1 = e2.y;
+  }
+  const int beg = a.ptr[row];                            // fast rows: the entries' positions ([E]-sized outputs, dropout keys) only
+  const int deg = fast ? (s0 >= 0 ? 1 : 0) + (s1 >= 0 ? 1 : 0) : a.ptr[row + 1] - beg;
   const int n_self = a.loops ? a.loops[row] : 0;
   const int cnt = deg + (n_self > 0 ? 1 : 0);
   // delta = g . attn_out.  A row of more than four entries reads the attn_out the forward stored; a shorter one (ONE chunk) forms
@@ -301,9 +309,9 @@ template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transfor
     int j;
     if constexpr (FAST) {
       const int jx = idx[max(beg + min(x, deg - 1), 0)];   // (unconditional: entry 0 exists in every index array)
-      j = is_self ? row : jx;
+      j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : jx);
     } else {
-      j = is_self ? row : idx[beg + x];
+      j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : idx[beg + x]);
     }
     int ju[4];
     ju[0] = quad_bcast<0>(j); ju[1] = quad_bcast<1>(j); ju[2] = quad_bcast<2>(j); ju[3] = quad_bcast<3>(j);
@@ -582,6 +590,46 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
   // statistics: running maximum and denominator over the edges, then the self-loop
   const float s_self = leaky(ai + c_own);
   float m = -INFINITY, den = 0.f;
+  float ga = 0.f;                                      // lane u: the sum of its edges' gp
+  const int deg = end - beg;
+  const bool short_row = deg <= 2;                     // (group-uniform) nine of ten rows of a circuit DAG
+  if (short_row) {
+    // ONE round trip for the entries' ids and one for their scores and rows: the general walk below reads the index list twice
+    // (statistics, then weights) and waits for each -- four dependent round trips
+    const int j0 = idx[deg > 0 ? beg : 0], j1 = idx[deg > 1 ? beg + 1 : 0];      // (entry 0 exists in every index array)
+    const float cj0 = c_src[j0], cj1 = c_src[j1];
+    float x0[NV], x1[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      x0[v] = x[(int64_t)j0 * ldx + col[v]];
+      x1[v] = x[(int64_t)j1 * ldx + col[v]];
+    }
+    const float pre0 = ai + cj0, pre1 = ai + cj1;
+    const float s0 = deg > 0 ? leaky(pre0) : -INFINITY, s1 = deg > 1 ? leaky(pre1) : -INFINITY;
+    if (deg > 0) {                                     // the general walk's sequence: the entries' chunk, then the self-loop
+      m = fmaxf(s0, s1);
+      den = expf(s0 - m) + (deg > 1 ? expf(s1 - m) : 0.f);
+    }
+    if (s_self > m) { den *= expf(m - s_self); m = s_self; }
+    den += expf(s_self - m);
+    const float inv = 1.0f / (den + 1e-16f);
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      d0 = fmaf(gi[v], x0[v], d0);
+      d1 = fmaf(gi[v], x1[v], d1);
+      if (TIES) ties[v] += ((deg > 0 && has[v] && x0[v] == mx[v]) ? 1 : 0) + ((deg > 1 && has[v] && x1[v] == mx[v]) ? 1 : 0);
+    }
+    d0 = group16_sum(d0); d1 = group16_sum(d1);
+    const float al0 = expf(s0 - m) * inv, al1 = expf(s1 - m) * inv;
+    const float gp0 = deg > 0 ? al0 * (d0 - delta) * (pre0 > 0.f ? 1.f : slope) : 0.f;
+    const float gp1 = deg > 1 ? al1 * (d1 - delta) * (pre1 > 0.f ? 1.f : slope) : 0.f;
+    if (!recompute && l < deg) {
+      edge_al[beg + l] = l == 0 ? al0 : al1;
+      edge_gp[beg + l] = l == 0 ? gp0 : gp1;
+    }
+    ga = gp0 + gp1;
+  } else {
   for (int e0 = beg; e0 < end; e0 += kGroup) {
     const int k = min(kGroup, end - e0);
     const float cj = c_src[idx[e0 + min(l, k - 1)]];
@@ -592,8 +640,9 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
   }
   if (s_self > m) { den *= expf(m - s_self); m = s_self; }
   den += expf(s_self - m);
+  }
   const float inv = 1.0f / (den + 1e-16f);
-  float ga = 0.f;                                      // lane u: the sum of its edges' gp
+  if (!short_row)
   for (int e0 = beg; e0 < end; e0 += kGroup) {
     const int k = min(kGroup, end - e0);
     const int j = idx[e0 + min(l, k - 1)];
@@ -642,7 +691,7 @@ template <int NV, bool TIES> __global__ __launch_bounds__(kBlock) void softmax_a
       ga += gp;
     }
   }
-  ga = group16_sum(ga);
+  if (!short_row) ga = group16_sum(ga);
   {  // the self-loop entry (position E + row)
     const float pre = ai + c_own;
     const float al = expf(leaky(pre) - m) * inv;
@@ -1266,6 +1315,24 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_kernel(
   if (l == 0) gfit[row] = dot;
 }
 
+// ... rows of at most 64 channels in the padded layout: a lane's four channels as one 16-byte access, no loop over the channels and no
+// load under `if (kept)` (the form above waits for slot[row] before it issues the row loads, one channel slice after the other)
+__global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_v4_kernel(
+    const float* __restrict__ gout, int64_t ldgo, const float* __restrict__ xnew, int64_t ldn, const float* __restrict__ fitness,
+    const int32_t* __restrict__ slot, int64_t N, int C, float* __restrict__ gxnew, int64_t ldgn, float* __restrict__ gfit) {
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;   // one 16-lane group per row
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  const int p = slot[row];
+  const float f = fitness[row];
+  const f4u xn = row4(xnew + row * ldn, l, C);
+  const f4u go = row4(gout + (int64_t)max(p, 0) * ldgo, l, C);
+  const bool kept = p >= 0;
+  const float dot = group16_sum(dot4(go, xn));
+  if (4 * l < ldgn) *reinterpret_cast<f4u*>(gxnew + row * ldgn + 4 * l) = kept ? go * f : f4u{0.f, 0.f, 0.f, 0.f};      // (pads: zeros)
+  if (l == 0) gfit[row] = kept ? dot : 0.f;
+}
+
 // LEConv + sigmoid backward on scalars: from g_f and f build the gradient of pqr[N,3] = (p, q, r):
 //   g_raw = g_f f (1 - f);  g_p[j] = g_raw[j] + sum_{e: j->i} g_raw[i];  g_q[i] = -(indeg_i + 1) g_raw[i];  g_r = g_raw.
 __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
@@ -1347,6 +1414,7 @@ __global__ __launch_bounds__(kBlock) void rank_grad_partial_kernel(const RankGra
   for (int t = 0; t < kRankTermsMax; ++t)
 #pragma unroll
     for (int c = 0; c < 3; ++c) { acc[t][c] = make_float4(0.f, 0.f, 0.f, 0.f); gs[t][c] = 0.f; }
+  // (round 6: two rows per thread and trip, all loads before the first product -- 140 against 132 us: 114 registers instead of 60)
   for (int64_t base = (int64_t)blockIdx.x * R; base < a.N; base += (int64_t)gridDim.x * R) {
     const int64_t row = base + rg;
     if (!on || row >= a.N) continue;
@@ -1491,8 +1559,8 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
                                                    const int32_t* out_ptr, const int32_t* out_dst,
                                                    const int32_t* out_eid, const int32_t* loops, int64_t N, int64_t E,
                                                    int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                                   int pair_key, int head_pitch, float* gqkvs, int64_t ldq, float* edge_al,
-                                                   float* edge_gs, mlqem_stream_t stream) {
+                                                   int pair_key, const int32_t* in_ell, int head_pitch, float* gqkvs, int64_t ldq,
+                                                   float* edge_al, float* edge_gs, mlqem_stream_t stream) {
   begin_launches();
   const int CP = head_pitch > 0 ? head_pitch : C;
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || CP < C || ld < 4 * H * CP || ldq < 4 * H * CP || ldg < H * C || lda < H * C)
@@ -1508,8 +1576,10 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if (recompute && drop_p > 0.f && !pair_key) return MLQEM_ERR_BAD_ARG;   // a position-keyed draw cannot be found from the source side
   if ((recompute || pair_key) && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
-  const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
-                      N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0, CP};
+  if (in_ell && !aligned_to(in_ell, 8)) return MLQEM_ERR_BAD_ARG;
+  AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
+                N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0, CP};
+  a.ell = attn_q4_enabled() ? in_ell : nullptr;            // (the four-channels-per-lane destination side only)
   if (recompute) {
     launch_attn_bwd_dst_q4(a, as_stream(stream));
     launch_attn_bwd_src_rc_q4(a, as_stream(stream));
@@ -1686,6 +1756,12 @@ extern "C" int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, 
   if (N < 0 || C <= 0 || ldgo < C || ldn < C || ldgn < C) return MLQEM_ERR_BAD_ARG;
   if (N == 0) return MLQEM_OK;
   if (!xnew || !fitness || !slot || !gxnew || !gfit) return MLQEM_ERR_BAD_ARG;
+  const int c4 = (C + 3) / 4 * 4;
+  auto padded = [&](const float* q, int64_t ld) { return q && ld % 4 == 0 && ld >= c4 && aligned_to(q, 16); };
+  if (C <= 64 && padded(gout, ldgo) && padded(xnew, ldn) && padded(gxnew, ldgn)) {
+    hipLaunchKernelGGL(gather_scale_rows_bwd_v4_kernel, MLQEM_GRID(N * kGroup), gout, ldgo, xnew, ldn, fitness, slot, N, C, gxnew, ldgn, gfit);
+    return launch_status();
+  }
   hipLaunchKernelGGL(gather_scale_rows_bwd_kernel, MLQEM_GRID(N * kGroup), gout, ldgo, xnew, ldn, fitness, slot, N, C, gxnew,
                      ldgn, gfit);
   return launch_status();

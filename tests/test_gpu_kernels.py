@@ -922,3 +922,49 @@ def test_rank_grad_equals_fp64_weighted_column_sums(n, d):
         assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
     one, = ops.rank_grad([(ws[1], xs[0])])                     # a single term
     assert torch.equal(one[0], ops.rank_grad([(ws[1], xs[0]), (ws[2], xs[1])])[0][0])
+
+
+def test_leconv_fitness_and_the_kept_rows_gather_on_short_and_long_rows():
+    """mlqem_leconv_fitness_f32 (a thread per row, entries in order), mlqem_gather_scale_rows_f32 and its backward (16-byte slices of padded rows since round 6; compact rows take the per-element forms)
+    against their formulas in fp64: f = sigmoid(sum_e (p[src_e] - q_i) + p_i - q_i + r_i); out[k] = x[perm[k]] f[perm[k]];
+    g_x[perm[k]] = g_out[k] f, zero rows elsewhere, g_f[perm[k]] = g_out[k] . x[perm[k]]."""
+    import numpy as np
+
+    from blackwater.native import ops
+    from blackwater.native.structure import GraphStructure
+
+    rng = np.random.RandomState(11)
+    n = 3000
+    deg = rng.choice([0, 1, 2, 3, 15, 16, 17, 40, 64, 65, 129, 300], size=n)
+    src = np.concatenate([rng.choice(n, size=d, replace=False) for d in deg])
+    dst = np.repeat(np.arange(n), deg)
+    s = GraphStructure.from_edge_index(torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV), n)
+    pqr = torch.from_numpy((rng.standard_normal((n, 3)) * 0.2).astype(np.float32)).to(DEV)
+    f = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
+    ptr, idx = s.in_ptr.cpu().numpy(), s.in_src.cpu().numpy()
+    p64 = pqr.double().cpu().numpy()
+    want = np.empty(n)
+    for i in range(n):
+        e = idx[ptr[i]:ptr[i + 1]]
+        want[i] = p64[e, 0].sum() - len(e) * p64[i, 1] + p64[i, 0] - p64[i, 1] + p64[i, 2]
+    want = 1.0 / (1.0 + np.exp(-want))
+    assert np.abs(f.cpu().numpy() - want).max() < 2e-6
+    for c, padded in ((45, True), (30, True), (7, True), (45, False)):
+        x_h = rng.standard_normal((n, c)).astype(np.float32)
+        x = torch.from_numpy(x_h).to(DEV)
+        if padded:
+            base = torch.full((n, (c + 3) // 4 * 4), float("nan"), device=DEV); base[:, :c] = x; x = base[:, :c]      # poisoned pads
+        perm_h = rng.permutation(n)[: n // 2].astype(np.int32)
+        perm = torch.from_numpy(perm_h).to(DEV)
+        out = ops.gather_scale_rows(x, perm, f)
+        want_out = x_h[perm_h].astype(np.float64) * want[perm_h][:, None]
+        assert np.abs(out[:, :c].cpu().numpy() - want_out).max() < 1e-5
+        slot_h = np.full(n, -1, dtype=np.int32); slot_h[perm_h] = np.arange(len(perm_h), dtype=np.int32)
+        g_h = rng.standard_normal((len(perm_h), c)).astype(np.float32)
+        g = torch.from_numpy(g_h).to(DEV)
+        if padded:
+            gb = torch.full((len(perm_h), (c + 3) // 4 * 4), float("nan"), device=DEV); gb[:, :c] = g; g = gb[:, :c]
+        gx, gf = ops.gather_scale_rows_bwd(g, x, f, torch.from_numpy(slot_h).to(DEV))
+        want_gx = np.zeros((n, c)); want_gx[perm_h] = g_h.astype(np.float64) * f.double().cpu().numpy()[perm_h][:, None]
+        want_gf = np.zeros(n); want_gf[perm_h] = (g_h.astype(np.float64) * x_h[perm_h]).sum(1)
+        assert np.abs(gx[:, :c].cpu().numpy() - want_gx).max() < 1e-5 and np.abs(gf.cpu().numpy() - want_gf).max() < 1e-4
