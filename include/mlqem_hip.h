@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 41 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 40 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -681,16 +681,14 @@ int mlqem_transformer_attention_train_f32(const float* qkvs, int64_t ld, const i
 
 /* gqkvs[N, 4HC] = gradient of [query | key | value | skip] given g = dL/d out.  Stored form: edge_al / edge_gs: scratch
  * [(E+N)*H].  Recomputed form (out_eid == NULL): edge_al: scratch [4*N*H] (16-byte aligned), edge_gs unused (may be NULL); with drop_p > 0 it needs
- * pair_key != 0 (MLQEM_ERR_BAD_ARG otherwise).
- * in_ell (ABI 41; may be NULL): the IN-edge side table the forward takes (mlqem_ell_from_csr of in_ptr / in_src): the destination side
- * of a row of at most two in-edges reaches its key / value rows without the ptr -> idx round trip (same result bit for bit). */
+ * pair_key != 0 (MLQEM_ERR_BAD_ARG otherwise). */
 int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g, int64_t ldg,
                                         const float* attn_out, int64_t lda, const float* stat_m, const float* stat_den,
                                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                         const int32_t* out_dst, const int32_t* out_eid, const int32_t* loops, int64_t N,
                                         int64_t E, int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                        int pair_key, const int32_t* in_ell, int head_pitch, float* gqkvs, int64_t ldq, float* edge_al,
-                                        float* edge_gs, mlqem_stream_t stream);
+                                        int pair_key, int head_pitch, float* gqkvs, int64_t ldq, float* edge_al, float* edge_gs,
+                                        mlqem_stream_t stream);
 
 /* Backward of mlqem_csr_softmax_aggregate_f32: gx (+)= d/dx, g_a[N] = d/d a_dst, g_c[N] = d/d c_src.
  * xnew = the forward output, gnew its gradient.  Stored form: edge_al / edge_gp: scratch [E+N].  Recomputed form

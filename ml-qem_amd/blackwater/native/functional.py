@@ -730,9 +730,8 @@ class _TransformerConv(Function):
             gqkvs = ops.dense_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, st.dense_plan("in"), st.dense_plan("out"),
                                             drop_p=drop_p, seed=seed, head_pitch=cp, side=_dense_side(w.device))
         else:
-            st = ctx.struct
-            gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, st, e, heads, channels, drop_p, seed, pair_key=pair_key,
-                                                  head_pitch=cp, ell=st.in_ell if st.out_eid is not None else None)      # (as the forward)
+            gqkvs = ops.transformer_attention_bwd(qkvs, g, attn, m, den, ctx.struct, e, heads, channels, drop_p, seed, pair_key=pair_key,
+                                                  head_pitch=cp)
         gx = ops.linear(gqkvs, w, transposed=True) if ctx.needs_input_grad[0] else None       # w: the (padded) weight the forward used
         gw = torch.empty_like(w)
         gb = torch.empty(w.shape[0], dtype=w.dtype, device=w.device)

@@ -1714,8 +1714,7 @@ def transformer_attention_train(qkvs, in_ptr, in_src, loops, num_edges, heads, c
     return out, attn, m, den
 
 
-def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False, head_pitch=0,
-                              ell=None):
+def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channels, drop_p=0.0, seed=0, pair_key=False, head_pitch=0):
     """Gradient of [query | key | value | skip].  A structure without ``out_eid`` (ASAPooling's coarsened graphs) takes the
     recomputed form: no per-edge buffers, the source side recomputes its weights from m / den / g . attn_out per (row, head)."""
     n = qkvs.shape[0]
@@ -1730,8 +1729,8 @@ def transformer_attention_bwd(qkvs, g, attn, m, den, s, num_edges, heads, channe
     code = _lib.load().mlqem_transformer_attention_bwd_f32(
         _p(qkvs), _mat(qkvs, "qkvs"), _p(g), _mat(g, "g"), _p(attn), _mat(attn, "attn"), _p(m), _p(den), _p(s.in_ptr),
         _p(s.in_src), _p(s.out_ptr), _p(s.out_dst), _p(s.out_eid), _p(s.loops), n, num_edges, heads, channels,
-        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, _p(ell),
-        int(head_pitch), _p(gqkvs), _mat(gqkvs, "gqkvs"), _p(al), _p(gs),
+        float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(_seed_counter) if drop_p > 0 else None, 1 if pair_key else 0, int(head_pitch),
+        _p(gqkvs), _mat(gqkvs, "gqkvs"), _p(al), _p(gs),
         _stream())
     _lib.check(code, "mlqem_transformer_attention_bwd_f32")
     return gqkvs

@@ -63,8 +63,6 @@ struct AttnBwdArgs {
   int CP;                         // as the forward's: channel pitch of a head inside the parts of qkvs AND gqkvs (0 = C)
   const uint8_t* skip_dst = nullptr;   // optional [N]: rows whose destination side / source side a dense block serves (dense_block.hpp)
   const uint8_t* skip_src = nullptr;
-  const int32_t* ell = nullptr;        // optional [N,2] IN-edge side table (as the forward's): the destination side of a row of at most two
-                                       // in-edges then reaches its key / value rows without the ptr -> idx round trip
 };
 // oeid == nullptr selects the RECOMPUTING source side (transformer_attn_bwd_src_rc_q4_kernel): the destination side then files
 // delta[N, H] = g . attn_out per (row, head) in edge_al (its first N H floats) and writes nothing per edge.

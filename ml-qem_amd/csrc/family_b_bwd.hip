@@ -282,16 +282,10 @@ template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transfor
   }
   const float m = a.stat_m[(int64_t)row * H + h];
   const float inv_den = 1.0f / a.stat_den[(int64_t)row * H + h];     // one division per row, as in the forward
-  // the row's in-edges: from the ELL side table when the row has at most two (one dependent round trip less), else from the CSR arrays
-  int s0 = -1, s1 = -1;
-  bool fast = false;
-  if (a.ell) {
-    const int2 e2 = reinterpret_cast<const int2*>(a.ell)[row];
-    fast = e2.x == -1 || (e2.x & kEllMore) == 0;
-    s0 = e2.x; s1 = e2.y;
-  }
-  const int beg = a.ptr[row];                            // fast rows: the entries' positions ([E]-sized outputs, dropout keys) only
-  const int deg = fast ? (s0 >= 0 ? 1 : 0) + (s1 >= 0 ? 1 : 0) : a.ptr[row + 1] - beg;
+  // (round 6: the in-edge side table of the forward here as well -- one dependent round trip less for rows of at most two in-edges --
+  // left the kernel where it was, 268 against 262 us: it is not bound by that latency)
+  const int beg = a.ptr[row];
+  const int deg = a.ptr[row + 1] - beg;
   const int n_self = a.loops ? a.loops[row] : 0;
   const int cnt = deg + (n_self > 0 ? 1 : 0);
   // delta = g . attn_out.  A row of more than four entries reads the attn_out the forward stored; a shorter one (ONE chunk) forms
@@ -309,9 +303,9 @@ template <int LPH, bool FAST> __global__ __launch_bounds__(kBlock) void transfor
     int j;
     if constexpr (FAST) {
       const int jx = idx[max(beg + min(x, deg - 1), 0)];   // (unconditional: entry 0 exists in every index array)
-      j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : jx);
+      j = is_self ? row : jx;
     } else {
-      j = is_self ? row : (fast ? (x == 0 ? s0 : s1) : idx[beg + x]);
+      j = is_self ? row : idx[beg + x];
     }
     int ju[4];
     ju[0] = quad_bcast<0>(j); ju[1] = quad_bcast<1>(j); ju[2] = quad_bcast<2>(j); ju[3] = quad_bcast<3>(j);
@@ -1559,8 +1553,8 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
                                                    const int32_t* out_ptr, const int32_t* out_dst,
                                                    const int32_t* out_eid, const int32_t* loops, int64_t N, int64_t E,
                                                    int H, int C, float drop_p, uint64_t seed, const uint64_t* seed_counter,
-                                                   int pair_key, const int32_t* in_ell, int head_pitch, float* gqkvs, int64_t ldq,
-                                                   float* edge_al, float* edge_gs, mlqem_stream_t stream) {
+                                                   int pair_key, int head_pitch, float* gqkvs, int64_t ldq, float* edge_al,
+                                                   float* edge_gs, mlqem_stream_t stream) {
   begin_launches();
   const int CP = head_pitch > 0 ? head_pitch : C;
   if (N < 0 || E < 0 || H <= 0 || C <= 0 || CP < C || ld < 4 * H * CP || ldq < 4 * H * CP || ldg < H * C || lda < H * C)
@@ -1576,10 +1570,8 @@ extern "C" int mlqem_transformer_attention_bwd_f32(const float* qkvs, int64_t ld
   if (recompute && drop_p > 0.f && !pair_key) return MLQEM_ERR_BAD_ARG;   // a position-keyed draw cannot be found from the source side
   if ((recompute || pair_key) && !attn_q4_enabled()) return MLQEM_ERR_UNSUPPORTED;
   if (N > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
-  if (in_ell && !aligned_to(in_ell, 8)) return MLQEM_ERR_BAD_ARG;
-  AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
-                N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0, CP};
-  a.ell = attn_q4_enabled() ? in_ell : nullptr;            // (the four-channels-per-lane destination side only)
+  const AttnBwdArgs a{qkvs, ld, g, ldg, attn_out, lda, stat_m, stat_den, in_ptr, in_src, out_ptr, out_dst, out_eid, loops,
+                      N, E, H, C, drop_p, seed, seed_counter, gqkvs, ldq, edge_al, edge_gs, pair_key ? 1 : 0, CP};
   if (recompute) {
     launch_attn_bwd_dst_q4(a, as_stream(stream));
     launch_attn_bwd_src_rc_q4(a, as_stream(stream));
