@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 40 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 41 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -727,6 +727,16 @@ int mlqem_csr_segment_max_bwd_f32(const float* x, int64_t ldx, const float* xmax
 int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, const float* xnew, int64_t ldn,
                                     const float* fitness, const int32_t* slot, int64_t N, int C, float* gxnew,
                                     int64_t ldgn, float* gfit, mlqem_stream_t stream);
+
+/* ABI 41: mlqem_gather_scale_rows_bwd_f32 as two launches around the fitness backward (ASAPooling.backward, gnn.py:85,92): the first
+ * stores gfit[row] = g_out[slot[row]] . x'[row] (0 for rows that were not kept) only; the second forms
+ * gxnew[row] = (kept ? g_out[slot[row]] fitness[row] : 0) + sum_{t < K} g3[row, t] w3[t, :]  (K <= 3; w3 compact [K, C]) in ONE store --
+ * the gradient through x_out = x'[perm] f[perm] plus the gradient g_pqr W3 through pqr = x' W3^T + b3, which was a read-modify-write
+ * GEMM over gxnew.  Rows of at most 64 channels in the padded layout (16-byte rows); MLQEM_ERR_UNSUPPORTED otherwise. */
+int mlqem_gather_rows_dot_f32(const float* gout, int64_t ldgo, const float* xnew, int64_t ldn, const int32_t* slot, int64_t N, int C,
+                              float* gfit, mlqem_stream_t stream);
+int mlqem_scatter_scale_rank_f32(const float* gout, int64_t ldgo, const float* fitness, const int32_t* slot, const float* g3, int64_t ldg3,
+                                 const float* w3, int K, int64_t N, int C, float* gxnew, int64_t ldgn, mlqem_stream_t stream);
 
 /* The three tiny weight gradients at the end of ASAPooling's backward in ONE pass (ABI 40): up to three weighted column sums over the
  * same N rows.  Term t: weight columns g[t] [N, ldg[t]] (k[t] <= 3 of them), matrix x[t] [N, ldx[t]] with D columns in 16-byte rows;

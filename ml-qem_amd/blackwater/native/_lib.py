@@ -163,6 +163,8 @@ SIGNATURES = {
     "mlqem_dense_softmax_aggregate_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _F, _L, _L, _I, _P, _P, _P, _P, _L,
                                                    _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _P]),
     "mlqem_dense_segment_max_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _P]),
+    "mlqem_gather_rows_dot_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _P, _P]),
+    "mlqem_scatter_scale_rank_f32": (_I, [_P, _L, _P, _P, _P, _L, _P, _I, _L, _I, _P, _L, _P]),
     "mlqem_asap_scores_fused_f32": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _P, _F, _L, _I, _P, _L, _P, _P, _P, _L, _P, _P]),
     "mlqem_pad_head_rows_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "mlqem_unpad_head_rows_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -186,7 +188,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 40   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 41   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

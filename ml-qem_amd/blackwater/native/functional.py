@@ -960,14 +960,21 @@ class _ASAPool(Function):
         s, d = ctx.struct, ctx.d
         e = s.edge_count()
         dev = x.device
-        # x_out = x'[perm] * f[perm]
-        gxnew, gfit = ops.gather_scale_rows_bwd(g_out, x_new, fitness, slot)
+        # x_out = x'[perm] * f[perm]: g_f = g_out . x' first (the fitness backward needs it), g_x' = g_out f + g_pqr W3 in one store after it
+        # (padded rows of at most 64 channels; otherwise g_x' = g_out f is stored with g_f and a [N,3]x[3,D] GEMM adds g_pqr W3 to it)
+        gfit = ops.gather_rows_dot(g_out, x_new, slot) if (x.is_cuda and _ASAP_FUSED) else None
+        split = gfit is not None
+        if not split:
+            gxnew, gfit = ops.gather_scale_rows_bwd(g_out, x_new, fitness, slot)
         # f = sigmoid(LEConv(x')) on scalars pqr = x' W3^T + b3
         if ctx.dense:        # the long rows of the coarsened graph: a wave each (the plan of the out-structure lists them)
             gpqr = ops.dense_leconv_fitness_bwd(gfit, fitness, s.in_ptr, s.out_ptr, s.out_dst, s.dense_plan("out"))
         else:
             gpqr = ops.leconv_fitness_bwd(gfit, fitness, s.in_ptr, s.out_ptr, s.out_dst)
-        ops.linear(gpqr, w3, transposed=True, out=gxnew, accumulate=True)
+        if split:
+            gxnew = ops.scatter_scale_rank(g_out, fitness, slot, gpqr, w3, x_new.shape[0], x_new.shape[1])
+        else:
+            ops.linear(gpqr, w3, transposed=True, out=gxnew, accumulate=True)
         # x' = sum_e softmax(LeakyReLU(a_i + c_j)) x_j
         # ... its destination-side walk also counts the ties of the segment max below (same x, same entries)
         att_x = att_w[:, d:]                 # (a view: its one row is contiguous)

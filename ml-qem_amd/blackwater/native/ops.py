@@ -1844,6 +1844,33 @@ def gather_scale_rows_bwd(gout, xnew, fitness, slot):
     return gxnew, gfit
 
 
+def gather_rows_dot(gout, xnew, slot):
+    """g_f[row] = g_out[slot[row]] . x'[row] (0 where slot < 0): the first half of ``gather_scale_rows_bwd``.  None when the layout is
+    not the padded one (the caller then takes ``gather_scale_rows_bwd``)."""
+    n, c = xnew.shape
+    gout = rowmajor(gout)
+    if gout.shape[0] == 0:
+        return None
+    gfit = torch.empty(max(n, 1), dtype=torch.float32, device=xnew.device)[:n]
+    code = _lib.load().mlqem_gather_rows_dot_f32(_p(gout), _mat(gout, "gout"), _p(xnew), _mat(xnew, "xnew"), _p(slot), n, c, _p(gfit), _stream())
+    if code == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(code, "mlqem_gather_rows_dot_f32")
+    return gfit
+
+
+def scatter_scale_rank(gout, fitness, slot, g3, w3, n, c):
+    """g_x'[row] = (slot[row] >= 0 ? g_out[slot[row]] f[row] : 0) + g3[row] @ w3 in one store (g3 [N, K <= 3], w3 [K, C]): the second half
+    of ``gather_scale_rows_bwd`` with the rank-K update that followed it.  Layout as ``gather_rows_dot`` (which the caller tried first)."""
+    gout = rowmajor(gout)
+    gxnew = padded_empty(n, c, fitness.device)
+    w3 = w3.contiguous()
+    code = _lib.load().mlqem_scatter_scale_rank_f32(_p(gout), _mat(gout, "gout"), _p(fitness), _p(slot), _p(g3), _mat(g3, "g3"), _p(w3),
+                                                    int(g3.shape[1]), n, c, _p(gxnew), _mat(gxnew, "gxnew"), _stream())
+    _lib.check(code, "mlqem_scatter_scale_rank_f32")
+    return gxnew
+
+
 def leconv_fitness_bwd(gfit, fitness, in_ptr, out_ptr, out_dst):
     n = fitness.shape[0]
     gpqr = torch.empty((max(n, 1), 3), dtype=torch.float32, device=fitness.device)[:n]

@@ -1327,6 +1327,72 @@ __global__ __launch_bounds__(kBlock) void gather_scale_rows_bwd_v4_kernel(
   if (l == 0) gfit[row] = kept ? dot : 0.f;
 }
 
+// The two halves of gather_scale_rows_bwd_v4_kernel as two launches AROUND the fitness backward (round 6).  x_out = x'[perm] f[perm] gives
+// g_f = g_out . x' (needed first: LEConv's backward turns it into g_pqr) and g_x' = g_out f, to which g_pqr W3 is then ADDED
+// (pqr = x' W3^T + b3).  Written by the first launch and updated by a [N,3]x[3,D] GEMM, g_x' was stored, read and stored again:
+// 0.61 GB per pooling of 706 k rows; here the first launch stores g_f only and the second forms g_x' once: 0.41 GB.
+__global__ __launch_bounds__(kBlock) void gather_rows_dot_kernel(const float* __restrict__ gout, int64_t ldgo, const float* __restrict__ xnew,
+                                                                 int64_t ldn, const int32_t* __restrict__ slot, int64_t N, int C,
+                                                                 float* __restrict__ gfit) {
+  const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x % kGroup;
+  if (row >= N) return;
+  const int p = slot[row];
+  const f4u xn = row4(xnew + row * ldn, l, C);
+  const f4u go = row4(gout + (int64_t)max(p, 0) * ldgo, l, C);
+  const float dot = group16_sum(dot4(go, xn));
+  if (l == 0) gfit[row] = p >= 0 ? dot : 0.f;
+}
+// g_x'[row] = (kept ? g_out[slot[row]] f[row] : 0) + sum_t g3[row, t] w3[t, :]   (K <= 3 terms).  Persistent groups: a 16-lane group
+// keeps its slice of w3 in registers and walks rows group, group + G, ... two at a time (a group per row loaded the twelve weights
+// again for every row: 164 us for the two poolings of 64 100-qubit circuits where the bytes take 60).
+__global__ __launch_bounds__(kBlock) void scatter_scale_rank_kernel(const float* __restrict__ gout, int64_t ldgo, const float* __restrict__ fitness,
+                                                                    const int32_t* __restrict__ slot, const float* __restrict__ g3, int64_t ldg3,
+                                                                    const float* __restrict__ w3, int K, int64_t N, int C,
+                                                                    float* __restrict__ gxnew, int64_t ldgn) {
+  const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup, groups = (int64_t)gridDim.x * (kBlock / kGroup);
+  const int l = threadIdx.x % kGroup;
+  const int last = (C - 1) >> 2, lc = min(l, last);
+  const int nv = min(4, max(0, C - 4 * l));
+  const bool writes = 4 * l < ldgn;
+  f4u wt[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    wt[t] = f4u{0.f, 0.f, 0.f, 0.f};
+    if (t < K) {                                         // (uniform) compact [K, C]: a slice one channel at a time
+      const float* __restrict__ wr = w3 + (int64_t)t * C;
+      const int c0 = 4 * lc;
+      wt[t] = f4u{nv > 0 ? wr[min(c0, C - 1)] : 0.f, nv > 1 ? wr[min(c0 + 1, C - 1)] : 0.f, nv > 2 ? wr[min(c0 + 2, C - 1)] : 0.f,
+                  nv > 3 ? wr[min(c0 + 3, C - 1)] : 0.f};
+    }
+  }
+  for (int64_t r0 = group; r0 < N; r0 += 2 * groups) {
+    int p[2];
+    float f[2], gt[2][3];
+    f4u go[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = r0 + u * groups;
+      live[u] = row < N;
+      const int64_t rc = min(row, N - 1);
+      p[u] = slot[rc];
+      f[u] = fitness[rc];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) gt[u][t] = t < K ? g3[rc * ldg3 + t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) go[u] = row4(gout + (int64_t)max(p[u], 0) * ldgo, l, C);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f4u v = p[u] >= 0 ? go[u] * f[u] : f4u{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) v += gt[u][t] * wt[t];      // (wt is zero past the row's channels: the pads come out zero)
+      if (live[u] && writes) *reinterpret_cast<f4u*>(gxnew + (r0 + u * groups) * ldgn + 4 * l) = v;
+    }
+  }
+}
+
 // LEConv + sigmoid backward on scalars: from g_f and f build the gradient of pqr[N,3] = (p, q, r):
 //   g_raw = g_f f (1 - f);  g_p[j] = g_raw[j] + sum_{e: j->i} g_raw[i];  g_q[i] = -(indeg_i + 1) g_raw[i];  g_r = g_raw.
 __global__ __launch_bounds__(kBlock) void leconv_fitness_bwd_kernel(
@@ -1756,6 +1822,35 @@ extern "C" int mlqem_gather_scale_rows_bwd_f32(const float* gout, int64_t ldgo, 
   }
   hipLaunchKernelGGL(gather_scale_rows_bwd_kernel, MLQEM_GRID(N * kGroup), gout, ldgo, xnew, ldn, fitness, slot, N, C, gxnew,
                      ldgn, gfit);
+  return launch_status();
+}
+
+extern "C" int mlqem_gather_rows_dot_f32(const float* gout, int64_t ldgo, const float* xnew, int64_t ldn, const int32_t* slot, int64_t N, int C,
+                                         float* gfit, mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C <= 0 || ldgo < C || ldn < C) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!gout || !xnew || !slot || !gfit) return MLQEM_ERR_BAD_ARG;
+  const int c4 = (C + 3) / 4 * 4;
+  auto padded = [&](const float* q, int64_t ld) { return ld % 4 == 0 && ld >= c4 && aligned_to(q, 16); };
+  if (C > 64 || !padded(gout, ldgo) || !padded(xnew, ldn)) return MLQEM_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gather_rows_dot_kernel, MLQEM_GRID(N * kGroup), gout, ldgo, xnew, ldn, slot, N, C, gfit);
+  return launch_status();
+}
+
+extern "C" int mlqem_scatter_scale_rank_f32(const float* gout, int64_t ldgo, const float* fitness, const int32_t* slot, const float* g3,
+                                            int64_t ldg3, const float* w3, int K, int64_t N, int C, float* gxnew, int64_t ldgn,
+                                            mlqem_stream_t stream) {
+  begin_launches();
+  if (N < 0 || C <= 0 || K < 0 || K > 3 || ldgo < C || ldgn < C || ldg3 < K) return MLQEM_ERR_BAD_ARG;
+  if (N == 0) return MLQEM_OK;
+  if (!gout || !fitness || !slot || !gxnew || (K > 0 && (!g3 || !w3))) return MLQEM_ERR_BAD_ARG;
+  const int c4 = (C + 3) / 4 * 4;
+  auto padded = [&](const float* q, int64_t ld) { return ld % 4 == 0 && ld >= c4 && aligned_to(q, 16); };
+  if (C > 64 || !padded(gout, ldgo) || !padded(gxnew, ldgn)) return MLQEM_ERR_UNSUPPORTED;
+  const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(N * kGroup, kBlock), 256 * 16);      // persistent 16-lane groups
+  hipLaunchKernelGGL(scatter_scale_rank_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), gout, ldgo, fitness, slot, g3, ldg3, w3, K, N,
+                     C, gxnew, ldgn);
   return launch_status();
 }
 

@@ -968,3 +968,14 @@ def test_leconv_fitness_and_the_kept_rows_gather_on_short_and_long_rows():
         want_gx = np.zeros((n, c)); want_gx[perm_h] = g_h.astype(np.float64) * f.double().cpu().numpy()[perm_h][:, None]
         want_gf = np.zeros(n); want_gf[perm_h] = (g_h.astype(np.float64) * x_h[perm_h]).sum(1)
         assert np.abs(gx[:, :c].cpu().numpy() - want_gx).max() < 1e-5 and np.abs(gf.cpu().numpy() - want_gf).max() < 1e-4
+        # ... and the same backward as two launches around the fitness backward (round 6): g_f alone, then g_x' with a rank-3 update
+        gf2 = ops.gather_rows_dot(g, x, torch.from_numpy(slot_h).to(DEV))
+        assert (gf2 is not None) == padded
+        if padded:
+            assert torch.equal(gf2, gf)
+            g3_h, w3_h = rng.standard_normal((n, 3)).astype(np.float32), rng.standard_normal((3, c)).astype(np.float32)
+            gx2 = ops.scatter_scale_rank(g, f, torch.from_numpy(slot_h).to(DEV), torch.from_numpy(g3_h).to(DEV), torch.from_numpy(w3_h).to(DEV), n, c)
+            want2 = want_gx + g3_h.astype(np.float64) @ w3_h.astype(np.float64)
+            assert np.abs(gx2[:, :c].cpu().numpy() - want2).max() < 2e-5
+            base2 = gx2._base if gx2._base is not None else gx2
+            assert torch.isfinite(base2).all()                       # the pads of the padded rows: zeros, not the poisoned inputs'
