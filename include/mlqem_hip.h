@@ -536,10 +536,12 @@ int mlqem_pool_keep_ptr(const int32_t* graph_ptr, int64_t B, float ratio, int32_
  * nodes of largest fitness, listed by descending fitness (ties: lower index first), graphs in order.
  * max_graph_nodes: an upper bound on a graph's node count when the caller has one (0: none, N is used) -- it sizes the
  * index field of the sort key, and lets batches of large graphs (>= 1024 nodes on average) go through ONE device-wide radix
- * sort with the graph index in the key's top bits instead of a segmented sort that gives each graph to one workgroup. */
+ * sort with the graph index in the key's top bits instead of a segmented sort that gives each graph to one workgroup.
+ * slot (ABI 41; may be NULL): [N], mlqem_asap_slot_map's result for perm (slot[perm[p]] = p, -1 elsewhere) written by the same
+ * launches -- every node is one of the sorted keys -- where the caller made it with a launch of its own. */
 size_t mlqem_segment_topk_workspace_bytes(int64_t N, int64_t B);
 int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr, const int32_t* new_graph_ptr, int64_t N,
-                       int64_t B, int64_t K, int64_t max_graph_nodes, int32_t* perm, void* workspace,
+                       int64_t B, int64_t K, int64_t max_graph_nodes, int32_t* perm, int32_t* slot, void* workspace,
                        size_t workspace_bytes, mlqem_stream_t stream);
 
 /* ASAPooling step 7 (torch-sparse S^T A S, remove_diag, coo): only the PATTERN is consumed by the models.
@@ -613,6 +615,8 @@ int mlqem_asap_coarsen_rows_fill(const int32_t* new_graph_ptr, int64_t K, int64_
  *                need no out_eid); *overflow (device, may be NULL) = 1 if `capacity` was too small.
  * capacity < 2^32 (places inside the per-node records are 32 bits), else MLQEM_ERR_UNSUPPORTED.
  * kmax <= mlqem_asap_coarsen_lists_max_k() (65 535 clusters per pooled graph), else MLQEM_ERR_UNSUPPORTED.
+ * ABI 41: slot_ready != 0: slot[] already holds mlqem_asap_slot_map's result (the caller made it for the backward: no fill, no map
+ * launch here); new_loops (may be NULL): [K], zeroed (the coarsened graph lists no self-loops).
  * Replaces the same ASAPooling.forward lines (gnn.py:105-107,110-112; PyG semantics: SURVEY appendix B.2 step 7). */
 size_t mlqem_asap_coarsen_lists_workspace_bytes(int64_t N, int64_t K, int64_t E, int64_t capacity);
 int mlqem_asap_coarsen_lists_max_k(void);
@@ -621,8 +625,9 @@ int mlqem_asap_coarsen_lists_caps(const int32_t* in_ptr, const int32_t* in_src, 
                                   int64_t* totals, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
 int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                    const int32_t* graph_ptr, const int32_t* new_graph_ptr, const int32_t* perm, int64_t N,
-                                   int64_t K, int64_t B, int64_t E, int kmax, int64_t capacity, int32_t* slot, int32_t* new_in_ptr,
-                                   int32_t* new_out_ptr, void* workspace, size_t workspace_bytes, mlqem_stream_t stream);
+                                   int64_t K, int64_t B, int64_t E, int kmax, int64_t capacity, int32_t* slot, int slot_ready,
+                                   int32_t* new_in_ptr, int32_t* new_out_ptr, int32_t* new_loops, void* workspace, size_t workspace_bytes,
+                                   mlqem_stream_t stream);
 int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t E, int64_t capacity, const int32_t* new_in_ptr,
                                   const int32_t* new_out_ptr, int32_t* new_in_src, int32_t* new_out_dst, int32_t* new_out_eid,
                                   int64_t edge_capacity, int32_t* overflow, void* workspace, size_t workspace_bytes,

@@ -110,7 +110,7 @@ SIGNATURES = {
     "mlqem_rank_grad_workspace_bytes": (_S, [_I]),
     "mlqem_rank_grad_f32": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _S, _P]),
     "mlqem_segment_topk_workspace_bytes": (_S, [_L, _L]),
-    "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _S, _P]),
+    "mlqem_segment_topk": (_I, [_P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_workspace_bytes": (_S, [_L]),
     "mlqem_asap_hop1_count": (_I, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _S, _P]),
     "mlqem_asap_hop1_fill": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P]),
@@ -130,7 +130,7 @@ SIGNATURES = {
     "mlqem_asap_coarsen_lists_workspace_bytes": (_S, [_L, _L, _L, _L]),
     "mlqem_asap_coarsen_lists_max_k": (_I, []),
     "mlqem_asap_coarsen_lists_caps": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _P, _S, _P]),
-    "mlqem_asap_coarsen_lists_count": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _L, _P, _P, _P, _P, _S, _P]),
+    "mlqem_asap_coarsen_lists_count": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _L, _P, _I, _P, _P, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_lists_fill": (_I, [_L, _L, _L, _L, _P, _P, _P, _P, _P, _L, _P, _P, _S, _P]),
     "mlqem_asap_coarsen_dense_max_k": (_I, []),
     "mlqem_asap_coarsen_dense_workspace_bytes": (_S, [_L, _L, _I]),

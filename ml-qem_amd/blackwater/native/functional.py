@@ -901,10 +901,9 @@ class _ASAPool(Function):
             new_ptr = _device_ptr(new_ptr_host.astype(np.int32), x.device)
             have = len(keep) > 0
             nmax, kmax = (int(sizes.max()), int(keep.max())) if have else (0, 0)
-        perm = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=min(nmax, n))
+        # ... with the backward's slot[] (cluster id of every kept centre, -1 elsewhere; the coarsenings read the same map) from the same launches
+        perm, slot_fwd = ops.segment_topk(fitness, s.graph_ptr, new_ptr, n, s.num_graphs, k_total, max_graph_nodes=min(nmax, n), with_slot=True)
         x_out = ops.gather_scale_rows(x_new, perm, fitness)
-        # the backward's slot[] (cluster id of every kept centre, -1 elsewhere); the dense coarsening reads the same map
-        slot_fwd = ops.asap_slot_map(perm, n, s.graph_ptr, new_ptr, s.num_graphs)
         use_dense, use_rows, use_lists, link = _ASAP_DENSE, _ASAP_ROWS, _ASAP_LISTS, _ASAP_LINK   # the switches as they stand now: build() may run later
 
         def build():
@@ -919,7 +918,7 @@ class _ASAPool(Function):
                 # large graphs: per-node cluster lists, a thread per cluster gathers its candidates, persistent waves sort them through
                 # LDS bitsets; no host read when the structure carries a capacity.  None: too many candidates for this form
                 done = ops.asap_coarsen_lists(s.in_ptr, s.in_src, s.out_ptr, s.out_dst, s.graph_ptr, new_ptr, perm, n, s.edge_count(), keep,
-                                              capacity=getattr(s, "coarse_capacity", None), link=link)
+                                              capacity=getattr(s, "coarse_capacity", None), link=link, slot=slot_fwd)
             if dense_ok:
                 pass
             elif done is not None:

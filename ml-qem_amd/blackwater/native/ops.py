@@ -1392,7 +1392,8 @@ def pool_keep_ptr(graph_ptr, num_graphs, ratio):
     return out
 
 
-def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_total, max_graph_nodes=0):
+def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_total, max_graph_nodes=0, with_slot=False):
+    """perm [k_total] -- and, ``with_slot``, (perm, slot) with ``asap_slot_map``'s slot[N] from the same launches."""
     _vec(fitness, "fitness", num_nodes)
     _vec(graph_ptr, "graph_ptr", num_graphs + 1, torch.int32)
     _vec(new_graph_ptr, "new_graph_ptr", num_graphs + 1, torch.int32)
@@ -1400,10 +1401,11 @@ def segment_topk(fitness, graph_ptr, new_graph_ptr, num_nodes, num_graphs, k_tot
     need = lib.mlqem_segment_topk_workspace_bytes(num_nodes, num_graphs)
     ws = torch.empty(need, dtype=torch.uint8, device=fitness.device)
     perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=fitness.device)[:k_total]
+    slot = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=fitness.device) if with_slot else None
     code = lib.mlqem_segment_topk(_p(fitness), _p(graph_ptr), _p(new_graph_ptr), num_nodes, num_graphs, k_total, int(max_graph_nodes),
-                                  _p(perm), _p(ws), need, _stream())
+                                  _p(perm), _p(slot), _p(ws), need, _stream())
     _lib.check(code, "mlqem_segment_topk")
-    return perm
+    return (perm, slot) if with_slot else perm
 
 
 def _sort_unique(keys, total):
@@ -1538,18 +1540,22 @@ def asap_coarsen_rows(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_g
 
 
 def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_graph_ptr, perm, num_nodes, num_edges, keep_sizes,
-                       capacity=None, link=True):
+                       capacity=None, link=True, slot=None):
     """The pooled structure arrays of ``asap_coarsen_rows`` from SORTED LISTS (mlqem_asap_coarsen_lists_*, round 4): per-node
     cluster lists built once, one walk per cluster by persistent waves, nothing dense in global memory, the twin links by binary
     search.  ``num_edges``: stored edges of the input structure (or a bound).  ``capacity``: a bound on the four list totals and on
     the edge total (GraphArena.coarse_capacity); without it the totals are read back (one 32-byte device->host copy, then the
     4-byte edge total).  Returns (CsrArrays, slot, edge capacity), or None when the candidate lists would exceed
-    ``ASAP_LISTS_MAX_CAPACITY`` entries (the caller then takes another form)."""
+    ``ASAP_LISTS_MAX_CAPACITY`` entries (the caller then takes another form).  ``slot``: ``asap_slot_map``'s result when the caller has
+    it (ASAPooling's autograd node makes it for its backward)."""
     b, k, kmax, _ = _keep_info(keep_sizes)
     dev = perm.device
     lib = _lib.load()
     mk = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    slot, in_ptr, out_ptr = mk(num_nodes), mk(k + 1), mk(k + 1)
+    slot_ready = slot is not None
+    if not slot_ready:
+        slot = mk(num_nodes)
+    in_ptr, out_ptr = mk(k + 1), mk(k + 1)
     exact = capacity is None
     if exact:
         if k > 0:
@@ -1571,15 +1577,15 @@ def asap_coarsen_lists(s_in_ptr, s_in_src, s_out_ptr, s_out_dst, graph_ptr, new_
     e = cap
     need = lib.mlqem_asap_coarsen_lists_workspace_bytes(num_nodes, k, int(num_edges), cap)
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    loops = mk(k)                           # zeroed by the count pass (a kernel, not a memset node: the call may be captured)
     code = lib.mlqem_asap_coarsen_lists_count(_p(s_in_ptr), _p(s_in_src), _p(s_out_ptr), _p(s_out_dst), _p(graph_ptr), _p(new_graph_ptr),
-                                              _p(perm), num_nodes, k, b, int(num_edges), kmax, cap, _p(slot), _p(in_ptr), _p(out_ptr),
-                                              _p(ws), need, _stream())
+                                              _p(perm), num_nodes, k, b, int(num_edges), kmax, cap, _p(slot), 1 if slot_ready else 0,
+                                              _p(in_ptr), _p(out_ptr), _p(loops), _p(ws), need, _stream())
     _lib.check(code, "mlqem_asap_coarsen_lists_count")
     if exact and k > 0:
         e = int(out_ptr[k].item())          # the exact edge total (this path reads the device anyway)
     in_src, out_dst = mk(e), mk(e)
     out_eid = mk(e) if link else None       # link=False: no out_eid (the recomputed backward forms need none)
-    loops = torch.full((max(k, 1),), 0, dtype=torch.int32, device=dev)      # a fill kernel, not a memset node (the call may be captured)
     if k > 0:
         # with a capacity bound nothing is read back: a list that would leave its buffer is dropped by the kernels, which OR this
         # device's STICKY flag -- read (and reset) lazily (check_overflow_flags: epoch ends, every 256 steps of step_ids,
@@ -1910,8 +1916,9 @@ def dense_plan_build(ptr, idx, loops, num_rows, graph_ptr, num_graphs, order, ma
     dev = ptr.device
     _vec(ptr, "ptr", num_rows + 1, torch.int32)
     max_blocks = max(int(lib.mlqem_dense_plan_max_blocks(num_rows, num_graphs)), 1)
-    counter = torch.zeros(1, dtype=torch.int32, device=dev)
-    row_flag = torch.zeros(max(num_rows, 1), dtype=torch.uint8, device=dev)
+    # the block counter and the row flags in ONE zeroed buffer (one fill launch instead of two: twice per pooled graph and step)
+    zeroed = torch.zeros(16 + max(num_rows, 1), dtype=torch.uint8, device=dev)
+    counter, row_flag = zeroed[:4].view(torch.int32), zeroed[16:]
     lrows = torch.empty(max_blocks * 17, dtype=torch.int32, device=dev)      # the blocks' rows, then one graph id per block
     records = torch.empty(max_blocks * lib.mlqem_dense_plan_record_ints(), dtype=torch.int32, device=dev)
     code = lib.mlqem_dense_plan_build(_p(ptr), _p(idx), _p(loops), _p(order), _p(graph_ptr), num_graphs, num_rows, int(max_span),

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kBlock) void topk_chunk_sort_kernel(const float* __
 // launch, rocprim's segmented radix sort and a select launch -- 25-30 us of a 0.4 ms train step on 32 four-qubit circuits, twice.
 template <int SIZE>
 __global__ __launch_bounds__(kBlock) void topk_small_kernel(const float* __restrict__ fitness, const int32_t* __restrict__ gptr,
-                                                            const int32_t* __restrict__ new_gptr, int32_t* __restrict__ perm) {
+                                                            const int32_t* __restrict__ new_gptr, int32_t* __restrict__ perm,
+                                                            int32_t* __restrict__ slot) {
   __shared__ uint64_t key[SIZE];
   const int g = blockIdx.x, tid = threadIdx.x;
   const int g0 = gptr[g], n = min(SIZE, gptr[g + 1] - g0);
@@ -228,6 +229,9 @@ __global__ __launch_bounds__(kBlock) void topk_small_kernel(const float* __restr
     }
   }
   for (int r = tid; r < keep; r += kBlock) perm[k0 + r] = g0 + (int32_t)(0xFFFFFFFFu - (uint32_t)key[r]);
+  // slot[] (mlqem_asap_slot_map: the cluster of every kept centre, -1 elsewhere) from the same sorted keys: no launch of its own
+  if (slot)
+    for (int r = tid; r < n; r += kBlock) slot[g0 + (int32_t)(0xFFFFFFFFu - (uint32_t)key[r])] = r < keep ? k0 + r : -1;
 }
 
 // (Round 6 tried two other forms of this pass on the step's graphs of 2 000-20 000 nodes: a workgroup per chunk with the other chunks
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void topk_small_kernel(const float* __restr
 template <int kTopkChunk>
 __global__ __launch_bounds__(kBlock) void topk_rank_select_kernel(const uint64_t* __restrict__ sorted, const int32_t* __restrict__ gptr,
                                                                   const int32_t* __restrict__ new_gptr, int B, int64_t N,
-                                                                  int32_t* __restrict__ perm) {
+                                                                  int32_t* __restrict__ perm, int32_t* __restrict__ slot) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (e >= N) return;
   int lo = 0, hi = B;                                    // graph of element e
@@ -248,10 +252,11 @@ __global__ __launch_bounds__(kBlock) void topk_rank_select_kernel(const uint64_t
   const int keep = new_gptr[g + 1] - new_gptr[g];
   const int local = (int)(e - g0), c = local / kTopkChunk;
   int rank = local - c * kTopkChunk;                     // its place in its own (sorted) chunk
-  if (rank >= keep) return;
+  if (rank >= keep && !slot) return;
   const uint64_t mine = sorted[e];
+  const int node = g0 + (int32_t)(0xFFFFFFFFu - (uint32_t)mine);
   const int nch = (n + kTopkChunk - 1) / kTopkChunk;
-  for (int o = 0; o < nch; ++o) {
+  for (int o = 0; o < nch && rank < keep; ++o) {
     if (o == c) continue;
     const uint64_t* __restrict__ ch = sorted + g0 + (int64_t)o * kTopkChunk;
     int a = 0, b = min(kTopkChunk, n - o * kTopkChunk);  // the number of keys of chunk o above `mine` (the chunk descends)
@@ -260,9 +265,11 @@ __global__ __launch_bounds__(kBlock) void topk_rank_select_kernel(const uint64_t
       if (ch[mid] > mine) a = mid + 1; else b = mid;
     }
     rank += a;
-    if (rank >= keep) return;
   }
-  perm[new_gptr[g] + rank] = g0 + (int32_t)(0xFFFFFFFFu - (uint32_t)mine);
+  const bool kept = rank < keep;
+  if (kept) perm[new_gptr[g] + rank] = node;
+  // slot[] (mlqem_asap_slot_map: the cluster of every kept centre, -1 elsewhere): every node is one sorted key -- no launch of its own
+  if (slot) slot[node] = kept ? new_gptr[g] + rank : -1;
 }
 
 // The device-wide sort of the top-k always takes rocprim's MERGE sort: above 2^20 keys the default configuration switches to
@@ -358,11 +365,8 @@ static inline void fill_i32(int32_t* p, int32_t v, int64_t n, hipStream_t stream
   if (n > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(n, (int64_t)kBlock)), dim3(kBlock), 0, stream, p, v, n);
 }
 
-// The caller's overflow flag is STICKY: a launch ORs its own flag into it and never clears it, so a flag raised by any replay of a
-// captured step is still there when the host reads it (and resets it) at the end of an epoch.
-__global__ void or_flag_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && *src != 0) atomicOr(dst, *src);
-}
+// (The caller's overflow flag is STICKY: a launch ORs its own flag into it and never clears it, so a flag raised by any replay of a
+// captured step is still there when the host reads it -- and resets it -- at the end of an epoch: coarsen_lists_copy_kernel.)
 
 __global__ __launch_bounds__(kBlock) void slot_map_kernel(const int32_t* __restrict__ perm, int64_t K,
                                                           int32_t* __restrict__ slot) {
@@ -842,10 +846,11 @@ __global__ __launch_bounds__(kBlock) void coarsen_row_caps_kernel(const int32_t*
                                                                   const int32_t* __restrict__ perm, const int32_t* __restrict__ new_gptr,
                                                                   int B, int64_t K, const int64_t* __restrict__ h_out,
                                                                   const int64_t* __restrict__ h_in, int64_t* __restrict__ cap_o,
-                                                                  int64_t* __restrict__ cap_i) {
+                                                                  int64_t* __restrict__ cap_i, int32_t* __restrict__ zero_rows) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool has = p < K;
+  if (has && zero_rows) zero_rows[p] = 0;            // (the coarsened structure's self-loop counts: none -- a fill launch of its own before)
   const int c = has ? perm[p] : 0;
   const int64_t so = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return h_out[u]; });
   const int64_t si = sum_closed(in_ptr, in_src, has, c, lane, [&](int u) { return h_in[u]; });
@@ -861,10 +866,12 @@ __global__ __launch_bounds__(kBlock) void coarsen_row_caps_kernel(const int32_t*
 // C(v): the kept centres among N+[v] (v itself included), as cluster ids, at clist[out_ptr[v] + v ...]; ccnt[v] of them
 __global__ __launch_bounds__(kBlock) void coarsen_clists_kernel(const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
                                                                 const int32_t* __restrict__ slot, int64_t N, int32_t* __restrict__ clist,
-                                                                int32_t* __restrict__ ccnt) {
+                                                                int32_t* __restrict__ ccnt, int32_t* __restrict__ zero_a,
+                                                                int32_t* __restrict__ zero_b, int32_t* __restrict__ zero_c) {
   const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool has = v < N;
+  if (v == 0) { *zero_a = 0; *zero_b = 0; *zero_c = 0; }      // three words the LATER launches of the coarsening count into
   int eb = 0, ee = 0, n = 0;
   int64_t base = 0;
   if (has) {
@@ -1220,10 +1227,13 @@ __global__ __launch_bounds__(kBlock) void coarsen_unique_kernel(const ListsArgs 
 __global__ __launch_bounds__(kBlock) void coarsen_lists_copy_kernel(const ListsArgs a, const int32_t* __restrict__ in_ptr_new,
                                                                     const int32_t* __restrict__ out_ptr_new,
                                                                     int32_t* __restrict__ in_src_new, int32_t* __restrict__ out_dst_new,
-                                                                    int32_t* __restrict__ out_row, int64_t edge_cap) {
+                                                                    int32_t* __restrict__ out_row, int64_t edge_cap,
+                                                                    int32_t* __restrict__ sticky) {
   const int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x & (kGroup - 1);
   if (r >= a.K) return;
+  // the caller's STICKY overflow flag takes pass 1's flag here (or_flag_kernel's job: a launch of its own before)
+  if (r == 0 && l == 0 && sticky && *a.overflow != 0) atomicOr(sticky, *a.overflow);
   const int di = a.indeg[r], dout = a.outdeg[r];
   const int64_t bi = a.off_i[r], bo = a.off_o[r];
   const int64_t ip = in_ptr_new[r], op = out_ptr_new[r];
@@ -1364,12 +1374,16 @@ extern "C" size_t mlqem_segment_topk_workspace_bytes(int64_t N, int64_t B) {
 }
 
 extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
-                                  int64_t N, int64_t B, int64_t K, int64_t max_graph_nodes, int32_t* perm, void* workspace,
+                                  int64_t N, int64_t B, int64_t K, int64_t max_graph_nodes, int32_t* perm, int32_t* slot, void* workspace,
                                   size_t workspace_bytes, mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (N < 0 || B <= 0 || K < 0 || K > N || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
-  if (N == 0 || K == 0) return MLQEM_OK;
+  if (N == 0) return MLQEM_OK;
+  if (K == 0) {
+    if (slot) fill_i32(slot, -1, N, stream);
+    return launch_status();
+  }
   if (!fitness || !graph_ptr || !new_graph_ptr || !perm) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_segment_topk_workspace_bytes(N, B)) return MLQEM_ERR_WORKSPACE;
   const size_t kb = ((size_t)N * sizeof(uint64_t) + 255) / 256 * 256;
@@ -1386,9 +1400,9 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
   // does the same job with every CU.  Same keys below the graph bits, so the same permutation.
   if (max_graph_nodes > 0 && max_graph_nodes <= 1024 && B <= 0x7fffffffLL) {      // small graphs, and the caller vouches for the bound
     const dim3 grid((unsigned)B), block(kBlock);
-    if (max_graph_nodes <= 64) hipLaunchKernelGGL(topk_small_kernel<64>, grid, block, 0, stream, fitness, graph_ptr, new_graph_ptr, perm);
-    else if (max_graph_nodes <= 256) hipLaunchKernelGGL(topk_small_kernel<256>, grid, block, 0, stream, fitness, graph_ptr, new_graph_ptr, perm);
-    else hipLaunchKernelGGL(topk_small_kernel<1024>, grid, block, 0, stream, fitness, graph_ptr, new_graph_ptr, perm);
+    if (max_graph_nodes <= 64) hipLaunchKernelGGL(topk_small_kernel<64>, grid, block, 0, stream, fitness, graph_ptr, new_graph_ptr, perm, slot);
+    else if (max_graph_nodes <= 256) hipLaunchKernelGGL(topk_small_kernel<256>, grid, block, 0, stream, fitness, graph_ptr, new_graph_ptr, perm, slot);
+    else hipLaunchKernelGGL(topk_small_kernel<1024>, grid, block, 0, stream, fitness, graph_ptr, new_graph_ptr, perm, slot);
     return launch_status();
   }
   const int graph_bits = bits_for(B);
@@ -1403,7 +1417,7 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
     const int64_t chunks = N / kTopkChunk + B + 1;
     hipLaunchKernelGGL(topk_chunk_sort_kernel<kTopkChunk>, dim3((unsigned)chunks), dim3(kBlock), 0, stream, fitness, graph_ptr, (int)B, sorted);
     hipLaunchKernelGGL(topk_rank_select_kernel<kTopkChunk>, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, sorted, graph_ptr,
-                       new_graph_ptr, (int)B, N, perm);
+                       new_graph_ptr, (int)B, N, perm, slot);
     return launch_status();
   }
   hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)ceil_div(N, kBlock)), dim3(kBlock), 0, stream, fitness,
@@ -1416,6 +1430,10 @@ extern "C" int mlqem_segment_topk(const float* fitness, const int32_t* graph_ptr
     return MLQEM_ERR_LAUNCH;
   hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, sorted,
                      graph_ptr, new_graph_ptr, (int)B, K, idx_bits, perm);
+  if (slot) {                                          // (this form does not see every node: the map as launches of its own)
+    fill_i32(slot, -1, N, stream);
+    hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
+  }
   return launch_status();
 }
 
@@ -1685,12 +1703,22 @@ namespace {
 struct ListsLayout {
   size_t h, ncnt, clist, caps, degs, flag, scan, lists, total;
 };
+// TWO arrays of one length scanned by ONE call (a zip of the two, added component-wise): rocprim's device scan is two launches per call,
+// and the six scans of a list coarsening were twelve of a 64-circuit step's 115 launches
+template <class T> struct PairPlus {
+  __host__ __device__ rocprim::tuple<T, T> operator()(const rocprim::tuple<T, T>& a, const rocprim::tuple<T, T>& b) const {
+    return rocprim::make_tuple(rocprim::get<0>(a) + rocprim::get<0>(b), rocprim::get<1>(a) + rocprim::get<1>(b));
+  }
+};
+template <class T> hipError_t pair_scan(void* temp, size_t& bytes, T* a, T* b, T* oa, T* ob, size_t n, hipStream_t stream) {
+  auto in = rocprim::make_zip_iterator(rocprim::make_tuple(a, b));
+  auto out = rocprim::make_zip_iterator(rocprim::make_tuple(oa, ob));
+  return rocprim::exclusive_scan(temp, bytes, in, out, rocprim::make_tuple(T(0), T(0)), n, PairPlus<T>(), stream);
+}
 size_t lists_scan_bytes(int64_t n) {
   size_t t64 = 0, t32 = 0;
-  (void)rocprim::exclusive_scan(nullptr, t64, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(),
-                                (hipStream_t)0);
-  (void)rocprim::exclusive_scan(nullptr, t32, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(n + 1), rocprim::plus<int32_t>(),
-                                (hipStream_t)0);
+  (void)pair_scan<int64_t>(nullptr, t64, nullptr, nullptr, nullptr, nullptr, (size_t)(n + 1), (hipStream_t)0);
+  (void)pair_scan<int32_t>(nullptr, t32, nullptr, nullptr, nullptr, nullptr, (size_t)(n + 1), (hipStream_t)0);
   return (std::max(t64, t32) + 255) / 256 * 256;
 }
 ListsLayout lists_layout(int64_t N, int64_t K, int64_t E, int64_t capacity) {
@@ -1743,17 +1771,16 @@ ListsPointers lists_pointers(void* workspace, const ListsLayout& l) {
 
 // structural sizes, row bounds and their scans: roff_o / roff_i [N + 1], off_o / off_i [K + 1] (the last entries = the totals)
 int lists_caps(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst, const int32_t* new_graph_ptr,
-               const int32_t* perm, int64_t N, int64_t K, int64_t B, const ListsPointers& q, const ListsLayout& l, hipStream_t stream) {
+               const int32_t* perm, int64_t N, int64_t K, int64_t B, const ListsPointers& q, const ListsLayout& l, hipStream_t stream,
+               int32_t* zero_rows = nullptr) {
   hipLaunchKernelGGL(coarsen_reach_kernel, dim3((unsigned)ceil_div(N + 1, (int64_t)kBlock)), dim3(kBlock), 0, stream, in_ptr, in_src, out_ptr,
                      out_dst, N, q.h_out, q.h_in);
   hipLaunchKernelGGL(coarsen_row_caps_kernel, dim3((unsigned)ceil_div(K + 1, (int64_t)kBlock)), dim3(kBlock), 0, stream, in_ptr, in_src, perm,
-                     new_graph_ptr, (int)B, K, q.h_out, q.h_in, q.cap_o, q.cap_i);
+                     new_graph_ptr, (int)B, K, q.h_out, q.h_in, q.cap_o, q.cap_i, zero_rows);
   size_t temp_bytes = l.scan;
-  auto scan64 = [&](int64_t* src, int64_t* dst, int64_t n) {
-    return rocprim::exclusive_scan(q.scan, temp_bytes, src, dst, (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), stream) == hipSuccess;
-  };
-  if (!scan64(q.h_out, q.roff_o, N) || !scan64(q.h_in, q.roff_i, N) || !scan64(q.cap_o, q.off_o, K) || !scan64(q.cap_i, q.off_i, K))
-    return MLQEM_ERR_LAUNCH;
+  if (pair_scan<int64_t>(q.scan, temp_bytes, q.h_out, q.h_in, q.roff_o, q.roff_i, (size_t)(N + 1), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
+  temp_bytes = l.scan;
+  if (pair_scan<int64_t>(q.scan, temp_bytes, q.cap_o, q.cap_i, q.off_o, q.off_i, (size_t)(K + 1), stream) != hipSuccess) return MLQEM_ERR_LAUNCH;
   return MLQEM_OK;
 }
 
@@ -1805,8 +1832,8 @@ extern "C" int mlqem_asap_coarsen_lists_caps(const int32_t* in_ptr, const int32_
 extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
                                               const int32_t* out_dst, const int32_t* graph_ptr, const int32_t* new_graph_ptr,
                                               const int32_t* perm, int64_t N, int64_t K, int64_t B, int64_t E, int kmax, int64_t capacity,
-                                              int32_t* slot, int32_t* new_in_ptr, int32_t* new_out_ptr, void* workspace,
-                                              size_t workspace_bytes, mlqem_stream_t stream_) {
+                                              int32_t* slot, int slot_ready, int32_t* new_in_ptr, int32_t* new_out_ptr, int32_t* new_loops,
+                                              void* workspace, size_t workspace_bytes, mlqem_stream_t stream_) {
   begin_launches();
   hipStream_t stream = as_stream(stream_);
   if (N < 0 || K < 0 || K > N || B < 0 || E < 0 || kmax < 0 || capacity < 0 || N >= 0x7fffffffLL) return MLQEM_ERR_BAD_ARG;
@@ -1814,7 +1841,7 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
   if (!slot || !new_in_ptr || !new_out_ptr) return MLQEM_ERR_BAD_ARG;
   const ListsLayout l = lists_layout(N, K, E, capacity);
   if (!workspace || workspace_bytes < l.total) return MLQEM_ERR_WORKSPACE;
-  fill_i32(slot, -1, N, stream);
+  if (!slot_ready) fill_i32(slot, -1, N, stream);
   if (K == 0 || B == 0) {
     fill_i32(new_in_ptr, 0, K + 1, stream);
     fill_i32(new_out_ptr, 0, K + 1, stream);
@@ -1822,14 +1849,14 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
   }
   if (!in_ptr || !out_ptr || !graph_ptr || !new_graph_ptr || !perm || (E > 0 && (!in_src || !out_dst))) return MLQEM_ERR_BAD_ARG;
   const ListsPointers q = lists_pointers(workspace, l);
-  hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
-  const int rc = lists_caps(in_ptr, in_src, out_ptr, out_dst, new_graph_ptr, perm, N, K, B, q, l, stream);
+  if (!slot_ready) hipLaunchKernelGGL(slot_map_kernel, dim3((unsigned)ceil_div(K, kBlock)), dim3(kBlock), 0, stream, perm, K, slot);
+  const int rc = lists_caps(in_ptr, in_src, out_ptr, out_dst, new_graph_ptr, perm, N, K, B, q, l, stream, new_loops);
   if (rc != MLQEM_OK) return rc;
-  fill_i32(q.outdeg + K, 0, 1, stream);
-  fill_i32(q.indeg + K, 0, 1, stream);
-  fill_i32(q.flag, 0, 1, stream);
   const unsigned node_blocks = (unsigned)ceil_div(N, (int64_t)kBlock);
-  hipLaunchKernelGGL(coarsen_clists_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, out_ptr, out_dst, slot, N, q.clist, q.ccnt);
+  // (the three words the later passes count into -- the scanned degree arrays' last entries and the overflow flag -- are zeroed by the
+  // first thread of this launch: three one-word fill launches)
+  hipLaunchKernelGGL(coarsen_clists_kernel, dim3(node_blocks), dim3(kBlock), 0, stream, out_ptr, out_dst, slot, N, q.clist, q.ccnt, q.outdeg + K,
+                     q.indeg + K, q.flag);
   hipLaunchKernelGGL(coarsen_rlists_kernel<false>, dim3(node_blocks), dim3(kBlock), 0, stream, out_ptr, out_dst, out_ptr, q.clist, q.ccnt, N,
                      q.roff_o, q.r_o, capacity, q.rinfo, q.flag);
   hipLaunchKernelGGL(coarsen_rlists_kernel<true>, dim3(node_blocks), dim3(kBlock), 0, stream, in_ptr, in_src, out_ptr, q.clist, q.ccnt, N,
@@ -1844,11 +1871,7 @@ extern "C" int mlqem_asap_coarsen_lists_count(const int32_t* in_ptr, const int32
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(K, (int64_t)4), (int64_t)device_cus() * per_cu));
   hipLaunchKernelGGL(coarsen_unique_kernel, dim3(grid), dim3(kBlock), lds, stream, a, q.cinfo, q.cgraph);
   size_t temp_bytes = l.scan;
-  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.outdeg, new_out_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(), stream) !=
-      hipSuccess)
-    return MLQEM_ERR_LAUNCH;
-  if (rocprim::exclusive_scan(q.scan, temp_bytes, q.indeg, new_in_ptr, (int32_t)0, (size_t)(K + 1), rocprim::plus<int32_t>(), stream) !=
-      hipSuccess)
+  if (pair_scan<int32_t>(q.scan, temp_bytes, q.outdeg, q.indeg, new_out_ptr, new_in_ptr, (size_t)(K + 1), stream) != hipSuccess)
     return MLQEM_ERR_LAUNCH;
   return launch_status();
 }
@@ -1874,11 +1897,10 @@ extern "C" int mlqem_asap_coarsen_lists_fill(int64_t N, int64_t K, int64_t E, in
   a.outdeg = q.outdeg; a.indeg = q.indeg; a.overflow = q.flag;
   int32_t* out_row = new_out_eid ? q.r_o : nullptr;  // the R lists are dead after pass 1; no out_eid wanted: no link pass
   hipLaunchKernelGGL(coarsen_lists_copy_kernel, dim3((unsigned)ceil_div(K * kGroup, (int64_t)kBlock)), dim3(kBlock), 0, stream, a, new_in_ptr,
-                     new_out_ptr, new_in_src, new_out_dst, out_row, edge_capacity);
+                     new_out_ptr, new_in_src, new_out_dst, out_row, edge_capacity, overflow);
   if (edge_capacity > 0 && new_out_eid)
     hipLaunchKernelGGL(coarsen_lists_link_kernel, dim3((unsigned)(device_cus() * 8)), dim3(kBlock), 0, stream, new_in_ptr, new_in_src,
                        new_out_dst, out_row, new_out_ptr + K, edge_capacity, new_out_eid);
-  if (overflow) hipLaunchKernelGGL(or_flag_kernel, dim3(1), dim3(64), 0, stream, q.flag, overflow);
   return launch_status();
 }
 

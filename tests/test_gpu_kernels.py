@@ -711,6 +711,10 @@ def test_segment_topk_lists_each_graph_by_descending_fitness_ties_to_the_lower_i
     for bound in (int(sizes.max()), 0):
         perm = ops.segment_topk(f, gp, np_, n, len(sizes), int(keep.sum()), max_graph_nodes=bound)
         assert np.array_equal(perm.cpu().numpy().astype(np.int64), want), bound
+        # ... and with the slot map of the kept nodes from the same launches (round 6): slot[perm[p]] = p, -1 elsewhere
+        perm2, slot = ops.segment_topk(f, gp, np_, n, len(sizes), int(keep.sum()), max_graph_nodes=bound, with_slot=True)
+        want_slot = np.full(n, -1, dtype=np.int64); want_slot[want] = np.arange(len(want))
+        assert torch.equal(perm2, perm) and np.array_equal(slot[:n].cpu().numpy().astype(np.int64), want_slot), bound
 
 
 def test_topk_of_more_than_a_million_nodes_replays_from_a_captured_graph():
