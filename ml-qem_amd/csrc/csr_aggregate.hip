@@ -368,8 +368,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kMinWave
     const int j0 = s0 >= 0 ? s0 : row[k];  // a missing edge reads the row itself with weight 0 / as a no-op for max
     const int j1 = s1 >= 0 ? s1 : row[k];
     const float* __restrict__ xc = a.x + ch[k];
-    w0[k] = s0 >= 0 ? ((IS_MAX || !a.cscale) ? 1.f : a.cscale[j0]) : 0.f;
-    w1[k] = s1 >= 0 ? ((IS_MAX || !a.cscale) ? 1.f : a.cscale[j1]) : 0.f;
+    // (the column scales loaded UNCONDITIONALLY -- j0 / j1 are valid rows either way -- and masked afterwards: `s0 >= 0 ? cscale[j0] : 0`
+    // compiles to a branch around the load, and the path of the lanes without that edge waited there for every load in flight
+    // (a register written on both paths) BEFORE the row loads below were issued: a round trip per batch of items for most waves)
+    float c0 = 1.f, c1 = 1.f;
+    if (!IS_MAX && a.cscale) { c0 = a.cscale[j0]; c1 = a.cscale[j1]; }      // (uniform condition)
+    w0[k] = s0 >= 0 ? c0 : 0.f;
+    w1[k] = s1 >= 0 ? c1 : 0.f;
     vload<VEC>(xc + (int64_t)j0 * a.ldx, v0[k]);
     vload<VEC>(xc + (int64_t)j1 * a.ldx, v1[k]);
     if (use_self) vload<VEC>(xc + (int64_t)row[k] * a.ldx, self[k]);
