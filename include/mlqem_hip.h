@@ -517,9 +517,11 @@ int mlqem_csr_softmax_aggregate_f32(const float* x, int64_t ldx, const int32_t* 
                                     float* out, int64_t ldo, mlqem_stream_t stream);
 
 /* ASAPooling step 5, LEConv(D->1) + sigmoid on per-node scalars pqr[N,3] = (lin1 x', lin2 x', lin3 x'):
- * fitness[i] = sigmoid( sum_{e in in(i) + self} (p[src_e] - q[i]) + r[i] ). */
+ * fitness[i] = sigmoid( sum_{e in in(i) + self} (p[src_e] - q[i]) + r[i] ).
+ * long_rows (ABI 41) != 0: the graph's rows are long (a coarsened graph): a 16-lane group per row instead of a thread (the sum of a
+ * row's p values is then a tree sum, not the entries in order). */
 int mlqem_leconv_fitness_f32(const float* pqr, const int32_t* in_ptr, const int32_t* in_src, int64_t N,
-                             float* fitness, mlqem_stream_t stream);
+                             float* fitness, int long_rows, mlqem_stream_t stream);
 
 /* out[p,:] = x[perm[p],:] * scale[perm[p]]  (x_out = x'[perm] * fitness[perm]; scale may be NULL). */
 int mlqem_gather_scale_rows_f32(const float* x, int64_t ldx, const int32_t* perm, const float* scale, int64_t K, int C,

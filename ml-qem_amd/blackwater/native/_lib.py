@@ -104,7 +104,7 @@ SIGNATURES = {
     "mlqem_segment_pool_bwd_f32": (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _L, _F, _P, _P, _L, _P]),
     "mlqem_transformer_attention_f32": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
     "mlqem_csr_softmax_aggregate_f32": (_I, [_P, _L, _P, _P, _P, _P, _F, _L, _I, _P, _L, _P]),
-    "mlqem_leconv_fitness_f32": (_I, [_P, _P, _P, _L, _P, _P]),
+    "mlqem_leconv_fitness_f32": (_I, [_P, _P, _P, _L, _P, _I, _P]),
     "mlqem_gather_scale_rows_f32": (_I, [_P, _L, _P, _P, _L, _I, _P, _L, _P]),
     "mlqem_pool_keep_ptr": (_I, [_P, _L, _F, _P, _P]),
     "mlqem_rank_grad_workspace_bytes": (_S, [_I]),

@@ -880,7 +880,8 @@ class _ASAPool(Function):
                 x_new, stat = ops.dense_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope, s.dense_plan("in"))
             else:
                 x_new = ops.csr_softmax_aggregate(x, s.in_ptr, s.in_src, a_dst, c_src, slope)
-            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3, out=torch.empty((n, 3), dtype=torch.float32, device=x.device)), s.in_ptr, s.in_src)
+            fitness = ops.leconv_fitness(ops.linear(x_new, w3, b3, out=torch.empty((n, 3), dtype=torch.float32, device=x.device)), s.in_ptr, s.in_src,
+                                         long_rows=dense)      # (the coarsened graph: a 16-lane group per row)
         plan = getattr(s, "pool_plan", None)
         if plan:
             # a size-stable batch (train.BucketedTrainer): the per-graph sizes stay on the device.  The pooled boundaries come from a

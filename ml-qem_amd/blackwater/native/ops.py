@@ -1252,13 +1252,14 @@ def csr_softmax_aggregate(x, in_ptr, in_src, a_dst, c_src, negative_slope):
     return out
 
 
-def leconv_fitness(pqr, in_ptr, in_src):
+def leconv_fitness(pqr, in_ptr, in_src, long_rows=False):
+    """``long_rows``: a graph of long rows (a coarsened graph): a 16-lane group per row instead of a thread."""
     n = pqr.shape[0]
     if pqr.shape[1] != 3 or not pqr.is_contiguous() or pqr.dtype != torch.float32 or not pqr.is_cuda:
         raise ValueError("pqr must be a contiguous [N,3] fp32 cuda tensor")
     _vec(in_ptr, "in_ptr", n + 1, torch.int32)
     f = torch.empty(max(n, 1), dtype=torch.float32, device=pqr.device)[:n]
-    code = _lib.load().mlqem_leconv_fitness_f32(_p(pqr), _p(in_ptr), _p(in_src), n, _p(f), _stream())
+    code = _lib.load().mlqem_leconv_fitness_f32(_p(pqr), _p(in_ptr), _p(in_src), n, _p(f), 1 if long_rows else 0, _stream())
     _lib.check(code, "mlqem_leconv_fitness_f32")
     return f
 

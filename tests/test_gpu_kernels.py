@@ -929,7 +929,7 @@ def test_rank_grad_equals_fp64_weighted_column_sums(n, d):
 
 
 def test_leconv_fitness_and_the_kept_rows_gather_on_short_and_long_rows():
-    """mlqem_leconv_fitness_f32 (a thread per row, entries in order), mlqem_gather_scale_rows_f32 and its backward (16-byte slices of padded rows since round 6; compact rows take the per-element forms)
+    """mlqem_leconv_fitness_f32 (a thread per row, entries in order; ``long_rows``: a 16-lane group per row), mlqem_gather_scale_rows_f32 and its backward (16-byte slices of padded rows since round 6; compact rows take the per-element forms)
     against their formulas in fp64: f = sigmoid(sum_e (p[src_e] - q_i) + p_i - q_i + r_i); out[k] = x[perm[k]] f[perm[k]];
     g_x[perm[k]] = g_out[k] f, zero rows elsewhere, g_f[perm[k]] = g_out[k] . x[perm[k]]."""
     import numpy as np
@@ -945,6 +945,7 @@ def test_leconv_fitness_and_the_kept_rows_gather_on_short_and_long_rows():
     s = GraphStructure.from_edge_index(torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(DEV), n)
     pqr = torch.from_numpy((rng.standard_normal((n, 3)) * 0.2).astype(np.float32)).to(DEV)
     f = ops.leconv_fitness(pqr, s.in_ptr, s.in_src)
+    f_rows = ops.leconv_fitness(pqr, s.in_ptr, s.in_src, long_rows=True)      # the 16-lane-group form of a coarsened graph's rows
     ptr, idx = s.in_ptr.cpu().numpy(), s.in_src.cpu().numpy()
     p64 = pqr.double().cpu().numpy()
     want = np.empty(n)
@@ -952,7 +953,7 @@ def test_leconv_fitness_and_the_kept_rows_gather_on_short_and_long_rows():
         e = idx[ptr[i]:ptr[i + 1]]
         want[i] = p64[e, 0].sum() - len(e) * p64[i, 1] + p64[i, 0] - p64[i, 1] + p64[i, 2]
     want = 1.0 / (1.0 + np.exp(-want))
-    assert np.abs(f.cpu().numpy() - want).max() < 2e-6
+    assert np.abs(f.cpu().numpy() - want).max() < 2e-6 and np.abs(f_rows.cpu().numpy() - want).max() < 2e-6
     for c, padded in ((45, True), (30, True), (7, True), (45, False)):
         x_h = rng.standard_normal((n, c)).astype(np.float32)
         x = torch.from_numpy(x_h).to(DEV)
