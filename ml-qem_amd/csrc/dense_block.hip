@@ -8,6 +8,8 @@
 // The k index of a product may be permuted as long as A and B agree: a lane's FOUR channels 4 g .. 4 g + 3 (one 16-byte load of a
 // row segment) serve the four k-steps of a 16-channel dot product, and its four cells serve the four k-steps of a product that sums
 // over the column block.
+#include <type_traits>
+
 #include "dense_block.hpp"
 
 
@@ -144,22 +146,39 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
   const int total_entries = roff[kDbRows];
   // The block's entries as ONE list, a thread taking entries tid, tid + 256, ...: four loads in flight per thread (a loop over the
   // rows with a wave per row was a chain of dependent round trips: 91 us for 4 000 blocks).  f(row index in the block, source id).
-  auto for_entries = [&](auto f) {
-    for (int q0 = tid; q0 < total_entries; q0 += 4 * kBlock) {
-      int ri[4], jv[4];
+  // (The first kKeep trips' entries -- 3 072: most blocks' whole list -- stay in registers between the two passes over the list: the
+  // second pass read every index again and searched its row again, three of a block's six dependent global round trips.)
+  constexpr int kKeep = 3;
+  int cj[kKeep][4], ci[kKeep][4];
+  auto fetch4 = [&](int q0, int (&ri)[4], int (&jv)[4]) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int q = q0 + k * kBlock;
-        ri[k] = -1;
-        if (q < total_entries) {
-          int i = 0;                                         // the row of entry q: the last i with roff[i] <= q
+    for (int k = 0; k < 4; ++k) {
+      const int q = q0 + k * kBlock;
+      ri[k] = -1;
+      jv[k] = 0;
+      if (q < total_entries) {
+        int i = 0;                                           // the row of entry q: the last i with roff[i] <= q
 #pragma unroll
-          for (int step = 8; step > 0; step >>= 1)
-            if (i + step < kDbRows && roff[i + step] <= q) i += step;
-          ri[k] = i;
-          jv[k] = idx[rbeg[i] + (q - roff[i])];
-        }
+        for (int step = 8; step > 0; step >>= 1)
+          if (i + step < kDbRows && roff[i + step] <= q) i += step;
+        ri[k] = i;
+        jv[k] = idx[rbeg[i] + (q - roff[i])];
       }
+    }
+  };
+  auto for_entries = [&](auto f, auto first_pass) {
+    constexpr bool FIRST = decltype(first_pass)::value;
+#pragma unroll
+    for (int trip = 0; trip < kKeep; ++trip) {
+      const int q0 = tid + trip * 4 * kBlock;
+      if (FIRST) fetch4(q0, ci[trip], cj[trip]);             // (past the end: ri = -1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ci[trip][k] >= 0) f(ci[trip][k], cj[trip][k]);
+    }
+    for (int q0 = tid + kKeep * 4 * kBlock; q0 < total_entries; q0 += 4 * kBlock) {
+      int ri[4], jv[4];
+      fetch4(q0, ri, jv);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (ri[k] >= 0) f(ri[k], jv[k]);
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
       if ((unsigned)j < (unsigned)span) atomicOr(&bits[j >> 5], 1u << (j & 31));
       else bad = 1;                                          // an id outside the graph's range (or past the bitset)
       bad |= (jr == rid[i]) ? 1 : 0;                         // a self-loop among the entries: its cell would be two entries
-    });
+    }, std::true_type{});
     if (bad) atomicOr(&tmp[10], 1);
   }
   __syncthreads();
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
       const int j = jr - lo;
       const uint32_t s = pre[j >> 5] + (uint32_t)__popc(bits[j >> 5] & ((1u << (j & 31)) - 1u));
       atomicOr(&mask[i * kDbMaskWords + (s >> 5)], 1u << (s & 31));
-    });
+    }, std::false_type{});
   }
   int selfs = 0;
   if (tid < nrows) {
