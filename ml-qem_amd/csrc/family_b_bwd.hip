@@ -1904,7 +1904,9 @@ extern "C" int mlqem_rank_grad_f32(int terms, const float* const* x, const int64
   if (n_acc > kRankAccMax) return MLQEM_ERR_UNSUPPORTED;
   a.terms = terms; a.N = N; a.CV = cv; a.partial = static_cast<float*>(workspace);
   const int rows = kBlock / cv;
-  const int groups = (int)std::max<int64_t>(1, std::min<int64_t>(kRankGroupsMax, ceil_div(std::max<int64_t>(N, 1), (int64_t)rows * 8)));
+  // a workgroup per `rows` rows up to the cap: a small batch's rows (32 four-qubit circuits: 2-3 k) in ONE trip per workgroup -- eight
+  // trips each, a dependent round trip apiece, were 12.6 us of a 0.4 ms step, twice
+  const int groups = (int)std::max<int64_t>(1, std::min<int64_t>(kRankGroupsMax, ceil_div(std::max<int64_t>(N, 1), (int64_t)rows)));
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(rank_grad_partial_kernel, dim3((unsigned)groups), dim3(kBlock), 0, s, a);
   hipLaunchKernelGGL(rank_grad_finish_kernel, dim3((unsigned)n_acc, (unsigned)ceil_div((int64_t)(4 * cv + 4), (int64_t)16)), dim3(kBlock), 0, s,
