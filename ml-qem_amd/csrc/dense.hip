@@ -160,12 +160,36 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
   const int gate_cols = (a.O + 3) / 4 * 4;
 
   const int64_t n_tiles = ceil_div(a.N, 16);
+  // PREFETCH (the three-tile persistent forms): the NEXT tile's operand rows are loaded -- unconditionally,
+  // from a clamped row, masked when they are consumed -- before this tile's MFMAs, so a wave's loads fly under its own matrix work (two
+  // waves per SIMD at 200 registers: nothing else hides them; 79 us for 249 MB at I = 128, O = 45)
+  constexpr bool PREFETCH = OBT == 3 && G >= 6;   // (the four-tile forms at G >= 7 would drop to one wave per SIMD)
+  const int kq = (a.I + 3) / 4 * 4;
+  float4 nx[PREFETCH ? G : 1];
+  auto load_raw = [&](int64_t t, float4 (&r)[PREFETCH ? G : 1]) {
+    const int64_t rw = min(t * 16 + lr, a.N - 1);
+    const int64_t xrw = a.xrows ? (int64_t)a.xrows[rw] : rw;
+    const float* __restrict__ p = a.x + xrw * a.ldx;
+#pragma unroll
+    for (int g = 0; g < (PREFETCH ? G : 1); ++g) r[g] = *reinterpret_cast<const float4*>(p + min(16 * g + 4 * lq, kq - 4));
+  };
+  if (PREFETCH && wave < n_tiles) load_raw(wave, nx);
   for (int64_t t = wave; t < n_tiles; t += n_waves) {
     const int64_t row = t * 16 + lr;          // the row this lane loads AND stores
     const bool row_ok = row < a.N;
+    float4 av[G];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int k0 = 16 * g + 4 * lq;
+        const bool on = row_ok && k0 < a.I;
+        av[g] = make_float4(on ? nx[g].x : 0.f, (on && k0 + 1 < a.I) ? nx[g].y : 0.f, (on && k0 + 2 < a.I) ? nx[g].z : 0.f,
+                            (on && k0 + 3 < a.I) ? nx[g].w : 0.f);
+      }
+      if (t + n_waves < n_tiles) load_raw(t + n_waves, nx);
+    } else {
     const int64_t xrow = (a.xrows && row_ok) ? (int64_t)a.xrows[row] : row;
     const float* __restrict__ xr = a.x + xrow * a.ldx + 4 * lq;
-    float4 av[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int k0 = 16 * g + 4 * lq;
@@ -176,6 +200,7 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_v4_kernel(const LinArgs a)
       if (k0 + 1 >= a.I) av[g].y = 0.f;
       if (k0 + 2 >= a.I) av[g].z = 0.f;
       if (k0 + 3 >= a.I) av[g].w = 0.f;
+    }
     }
     // the gate rows are independent of the product: fetch them with the operands, not after the MFMAs
     float4 gv[OBT];
@@ -1476,19 +1501,23 @@ extern "C" int mlqem_linear_f32(const float* x, int64_t ldx, const float* w, int
   const int ks = round_ks((I + 3) / 4);
   if (ks > 0) {
     const int ob = (O + 15) / 16;
-    const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : 4);
+    const bool v4_form = ldx % 4 == 0 && ldx >= c4i && aligned_to(x, 16) && ldy % 4 == 0 && ldy >= c4o && aligned_to(y, 16) &&
+                         (!gate || (ldgate % 4 == 0 && ldgate >= c4o && aligned_to(gate, 16)));
+    // three output tiles (O = 33..48: the 45-wide pooled rows) are their own form on the 16-byte path: a quarter fewer weight registers
+    // and MFMAs than the four-tile form, which is what leaves room for the operand prefetch at two waves per SIMD
+    const int obt = ob == 1 ? 1 : (ob == 2 ? 2 : (ob == 3 && v4_form ? 3 : 4));
     const int64_t tiles = ceil_div(N, 16);
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(tiles, 4), 256 * 8);  // 4 waves per block
     dim3 grid(gx, (unsigned)ceil_div(ob, obt));
     constexpr int v4_env = 1;      // (was the A/B switch MLQEM_LINEAR_V4: settled)
-    const bool padded = ldx % 4 == 0 && ldx >= c4i && aligned_to(x, 16) && ldy % 4 == 0 && ldy >= c4o && aligned_to(y, 16) &&
-                        (!gate || (ldgate % 4 == 0 && ldgate >= c4o && aligned_to(gate, 16)));
+    const bool padded = v4_form;
     if (x_rows && !(v4_env && padded)) return MLQEM_ERR_UNSUPPORTED;   // the row map is carried by the lean and the 16-byte kernels only
     a.xrows = x_rows;
     if (v4_env && padded) {  // padded activation rows on every operand: one 16-byte access path, no scalar tails
       const int g = (I + 15) / 16;
       if (obt == 1) transposed ? launch_linear_v4<1, true>(a, g, grid, s) : launch_linear_v4<1, false>(a, g, grid, s);
       else if (obt == 2) transposed ? launch_linear_v4<2, true>(a, g, grid, s) : launch_linear_v4<2, false>(a, g, grid, s);
+      else if (obt == 3) transposed ? launch_linear_v4<3, true>(a, g, grid, s) : launch_linear_v4<3, false>(a, g, grid, s);
       else transposed ? launch_linear_v4<4, true>(a, g, grid, s) : launch_linear_v4<4, false>(a, g, grid, s);
       return launch_status();
     }
