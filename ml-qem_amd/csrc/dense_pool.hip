@@ -234,27 +234,32 @@ template <int MODE> __global__ __launch_bounds__(kBlock) void dense_pool_scan_ke
   }
 }
 
-// the segment max of the rows OUTSIDE the blocks (the per-edge form: a 16-lane group per row, lane l channels l and l + 16)
+// the segment max of the rows OUTSIDE the blocks (the per-edge form: a 16-lane group per row, lane l channels 2 l and 2 l + 1 -- rows of exactly
+// 32 floats: every load is in bounds whatever D is, and a maximum does not mind an entry read twice, so four source rows fly together from
+// clamped places with no mask at all)
 __global__ __launch_bounds__(kBlock) void pool_segment_max_rest_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ ptr,
                                                                        const int32_t* __restrict__ idx, int64_t N, int D,
                                                                        float* __restrict__ out, int64_t ldo, const uint8_t* __restrict__ skip) {
   const int64_t row = ((int64_t)row_block() * kBlock + threadIdx.x) / kGroup;
   const int l = threadIdx.x % kGroup;
   if (row >= N || skip[row]) return;
-  const bool h0 = l < D, h1 = l + 16 < D;
-  float m0 = h0 ? x[row * ldx + l] : 0.f, m1 = h1 ? x[row * ldx + l + 16] : 0.f;      // the row itself
+  const float2* __restrict__ xr = reinterpret_cast<const float2*>(x) + l;       // ldx == 32 (the host checks): 16 pairs a row
+  float2 m = xr[row * 16];                                                       // the row itself
   const int beg = ptr[row], end = ptr[row + 1];
   for (int e0 = beg; e0 < end; e0 += kGroup) {
     const int k = min(kGroup, end - e0);
     const int j = idx[e0 + min(l, k - 1)];
-    for (int u = 0; u < k; ++u) {
-      const int ju = __shfl(j, u, kGroup);
-      if (h0) m0 = fmaxf(m0, x[(int64_t)ju * ldx + l]);
-      if (h1) m1 = fmaxf(m1, x[(int64_t)ju * ldx + l + 16]);
+    for (int u = 0; u < k; u += 4) {
+      const int j0 = __shfl(j, u, kGroup), j1 = __shfl(j, min(u + 1, k - 1), kGroup), j2 = __shfl(j, min(u + 2, k - 1), kGroup),
+                j3 = __shfl(j, min(u + 3, k - 1), kGroup);
+      const float2 v0 = xr[(int64_t)j0 * 16], v1 = xr[(int64_t)j1 * 16], v2 = xr[(int64_t)j2 * 16], v3 = xr[(int64_t)j3 * 16];
+      m.x = fmaxf(fmaxf(m.x, v0.x), fmaxf(fmaxf(v1.x, v2.x), v3.x));
+      m.y = fmaxf(fmaxf(m.y, v0.y), fmaxf(fmaxf(v1.y, v2.y), v3.y));
     }
   }
-  if (h0) out[row * ldo + l] = m0;
-  if (h1) out[row * ldo + l + 16] = m1;
+  float* __restrict__ o = out + row * ldo + 2 * l;
+  if (2 * l + 1 < D) *reinterpret_cast<float2*>(o) = m;
+  else if (2 * l < D) o[0] = m.x;
 }
 
 // ------------------------------------------------------------------------------------------------- destination-side backward
