@@ -16,14 +16,19 @@
 namespace mlqem {
 
 // ---------------------------------------------------------------------------------------------------------------- plan
-__device__ __forceinline__ int block_sum(int v, int* tmp) {     // tmp: 4 ints of LDS
+constexpr int kRowsThreads = 1024;       // dense_rows_kernel's workgroup (16 waves)
+__device__ __forceinline__ int block_sum(int v, int* tmp) {     // tmp: 16 ints of LDS
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
   __syncthreads();
-  return tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  int t = 0;
+#pragma unroll
+  for (int w = 0; w < kRowsThreads / 64; ++w) t += tmp[w];
+  return t;
 }
-__device__ __forceinline__ int block_scan(int v, int* tmp, int& tot) {      // exclusive; tmp: 4 ints of LDS
+template <int WAVES>
+__device__ __forceinline__ int block_scan(int v, int* tmp, int& tot) {      // exclusive, over a workgroup of WAVES waves; tmp: WAVES ints of LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
 #pragma unroll
@@ -34,69 +39,70 @@ __device__ __forceinline__ int block_scan(int v, int* tmp, int& tot) {      // e
   __syncthreads();
   if (lane == 63) tmp[wave] = inc;
   __syncthreads();
-  int base = 0;
+  int base = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    if (w < wave) base += tmp[w];
+  for (int w = 0; w < WAVES; ++w) {
+    const int t = tmp[w];
+    if (w < wave) base += t;
+    all += t;
   }
-  tot = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  tot = all;
   return base + inc - v;
 }
 
 // One workgroup per graph: the graph's rows of at least min_deg entries, in the order of `order` (program position; null = row
 // order), as whole blocks of 16 -- a graph's last block is padded with -1 -- at a place of lrows reserved with one atomic add;
-// bgraph[b] = the graph of block b.  Four rows per thread and trip.
-__global__ __launch_bounds__(kBlock) void dense_rows_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ order,
-                                                            const int32_t* __restrict__ gptr, int min_deg, int32_t* __restrict__ lrows,
-                                                            int32_t* __restrict__ bgraph, int32_t* __restrict__ counter) {
-  __shared__ int tmp[8];
-  constexpr int kPer = 4;
+// bgraph[b] = the graph of block b.  1024 threads, six rows each: the 5.5 k rows of a 100-qubit circuit's coarsened graph are ONE trip of
+// either pass, and the second pass keeps the degrees of the first (at 256 threads and four rows a trip the nine trips -- dependent loads
+// order -> ptr, a scan's two barriers -- were 27 us a launch whatever the batch).
+__global__ __launch_bounds__(kRowsThreads) void dense_rows_kernel(const int32_t* __restrict__ ptr, const int32_t* __restrict__ order,
+                                                                  const int32_t* __restrict__ gptr, int min_deg, int32_t* __restrict__ lrows,
+                                                                  int32_t* __restrict__ bgraph, int32_t* __restrict__ counter) {
+  __shared__ int tmp[kRowsThreads / 64 + 1];
+  constexpr int kPer = 6;
   const int g = blockIdx.x, tid = threadIdx.x;
   const int p0 = gptr[g], p1 = gptr[g + 1];
-  int mine = 0;
-  for (int q0 = p0; q0 < p1; q0 += kBlock * 8) {             // eight independent rows per thread and trip: their loads fly together
-    int r[8];
+  const bool one_trip = p1 - p0 <= kRowsThreads * kPer;
+  int rows[kPer];
+  unsigned is_long = 0;
+  auto fetch = [&](int q0) {                                 // a thread's rows are neighbours in the order: the scan keeps it
+    int d0[kPer], d1[kPer];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int p = q0 + k * kBlock + tid;
-      r[k] = p < p1 ? (order ? order[p] : p) : -1;
-    }
-    int d0[8], d1[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      d0[k] = r[k] >= 0 ? ptr[r[k]] : 0;
-      d1[k] = r[k] >= 0 ? ptr[r[k] + 1] : 0;
+    for (int k = 0; k < kPer; ++k) {
+      const int p = min(q0 + tid * kPer + k, p1 - 1);
+      rows[k] = order ? order[p] : p;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) mine += (r[k] >= 0 && d1[k] - d0[k] >= min_deg) ? 1 : 0;
-  }
-  const int cnt = block_sum(mine, tmp);
-  const int padded = (cnt + kDbRows - 1) / kDbRows * kDbRows;
-  if (tid == 0) tmp[4] = padded ? atomicAdd(counter, padded) : 0;
-  __syncthreads();
-  const int start = tmp[4];
-  for (int k = tid; k < padded / kDbRows; k += kBlock) bgraph[start / kDbRows + k] = g;
-  int run = 0;
-  for (int q0 = p0; q0 < p1; q0 += kBlock * kPer) {
-    int rows[kPer], n_long = 0;
-    unsigned is_long = 0;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {                         // a thread's rows are neighbours in the order: the scan keeps it
-      const int p = q0 + tid * kPer + k;
-      rows[k] = -1;
-      if (p < p1) {
-        rows[k] = order ? order[p] : p;
-        if (ptr[rows[k] + 1] - ptr[rows[k]] >= min_deg) { is_long |= 1u << k; ++n_long; }
-      }
-    }
-    int tot;
-    int pos = start + run + block_scan(n_long, tmp, tot);
+    for (int k = 0; k < kPer; ++k) { d0[k] = ptr[rows[k]]; d1[k] = ptr[rows[k] + 1]; }
+    is_long = 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k)
-      if (is_long >> k & 1u) lrows[pos++] = rows[k];
-    run += tot;
-  }
-  for (int k = cnt + tid; k < padded; k += kBlock) lrows[start + k] = -1;
+      if (q0 + tid * kPer + k < p1 && d1[k] - d0[k] >= min_deg) is_long |= 1u << k;
+  };
+  int mine = 0;
+  if (p1 > p0)
+    for (int q0 = p0; q0 < p1; q0 += kRowsThreads * kPer) {
+      fetch(q0);
+      mine += __popc(is_long);
+    }
+  const int cnt = block_sum(mine, tmp);
+  const int padded = (cnt + kDbRows - 1) / kDbRows * kDbRows;
+  if (tid == 0) tmp[kRowsThreads / 64] = padded ? atomicAdd(counter, padded) : 0;
+  __syncthreads();
+  const int start = tmp[kRowsThreads / 64];
+  for (int k = tid; k < padded / kDbRows; k += kRowsThreads) bgraph[start / kDbRows + k] = g;
+  int run = 0;
+  if (p1 > p0)
+    for (int q0 = p0; q0 < p1; q0 += kRowsThreads * kPer) {
+      if (!one_trip) fetch(q0);                              // (one trip: what the counting pass fetched is still here)
+      int tot;
+      int pos = start + run + block_scan<kRowsThreads / 64>(__popc(is_long), tmp, tot);
+#pragma unroll
+      for (int k = 0; k < kPer; ++k)
+        if (is_long >> k & 1u) lrows[pos++] = rows[k];
+      run += tot;
+    }
+  for (int k = cnt + tid; k < padded; k += kRowsThreads) lrows[start + k] = -1;
 }
 
 // One workgroup per block: the union of the 16 rows' sources (and the rows themselves), every entry's slot in it, the cell mask.
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void dense_plan_kernel(const int32_t* __res
   int mine = 0;
   for (int w = w0; w < w1; ++w) mine += __popc(bits[w]);
   int total;
-  int run = block_scan(mine, tmp, total);
+  int run = block_scan<4>(mine, tmp, total);
   int32_t* __restrict__ rec = records + (int64_t)b * kDbStride;
   int32_t* __restrict__ un = rec + kDbUniOff;
   for (int w = w0; w < w1; ++w) {
@@ -648,7 +654,7 @@ extern "C" int mlqem_dense_plan_build(const int32_t* ptr, const int32_t* idx, co
   if (!ensure_dynamic_lds(dense_plan_kernel, lds)) return MLQEM_ERR_UNSUPPORTED;
   const int64_t max_blocks = mlqem_dense_plan_max_blocks(num_rows, num_graphs);
   int32_t* bgraph = lrows + max_blocks * kDbRows;            // (the second part of lrows: one graph id per block)
-  hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)num_graphs), dim3(kBlock), 0, as_stream(stream), ptr, order, graph_ptr, kDbMinDeg,
+  hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)num_graphs), dim3(kRowsThreads), 0, as_stream(stream), ptr, order, graph_ptr, kDbMinDeg,
                      lrows, bgraph, counter);
   hipLaunchKernelGGL(dense_plan_kernel, dim3((unsigned)max_blocks), dim3(kBlock), lds, as_stream(stream), ptr, idx, loops, graph_ptr, lrows,
                      bgraph, counter, max_words, records, row_flag);

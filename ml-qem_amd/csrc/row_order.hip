@@ -37,7 +37,8 @@ bool ensure_dynamic_lds_impl(const void* kernel, size_t bytes) {
   return true;
 }
 
-// exclusive prefix of one int per thread over a 256-thread workgroup; `tot` receives the total.  `tmp`: 8 ints of LDS.
+// exclusive prefix of one int per thread over a workgroup of WAVES waves; `tot` receives the total.  `tmp`: WAVES ints of LDS.
+template <int WAVES>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* tmp, int& tot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
@@ -49,36 +50,42 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* tmp, int& tot) {
   __syncthreads();                       // tmp may still be read from an earlier call
   if (lane == 63) tmp[wave] = inc;
   __syncthreads();
-  int base = 0;
+  int base = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    if (w < wave) base += tmp[w];
+  for (int w = 0; w < WAVES; ++w) {
+    const int t = tmp[w];
+    if (w < wave) base += t;
+    all += t;
   }
-  tot = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  tot = all;
   return base + inc - v;
 }
 
 // order[new_ptr[g] + r] = the cluster whose centre is the r-th kept node of graph g in NODE order (= program order: the encoder
 // numbers a circuit's operations in instruction order, blackwater/data/utils.py:198-389).  slot[v] = cluster id of a kept centre v,
-// -1 elsewhere (mlqem_asap_slot_map).  One workgroup per graph.
-__global__ __launch_bounds__(kBlock) void tile_order_kernel(const int32_t* __restrict__ slot, const int32_t* __restrict__ gptr,
-                                                            const int32_t* __restrict__ new_gptr, int32_t* __restrict__ order) {
-  __shared__ int tmp[8];
-  constexpr int kPer = 8;                                   // nodes per thread and trip: neighbours, so that the scan keeps their order
+// -1 elsewhere (mlqem_asap_slot_map).  One workgroup per graph -- of 1024 threads, twelve nodes each: a 100-qubit circuit's 11 k nodes
+// are ONE trip (load, scan, store); at 256 threads and eight nodes a trip the six trips, each waiting for its loads and two barriers,
+// were 22 us whatever the batch (64 workgroups on 256 compute units).
+constexpr int kOrderThreads = 1024;
+__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(const int32_t* __restrict__ slot, const int32_t* __restrict__ gptr,
+                                                                   const int32_t* __restrict__ new_gptr, int32_t* __restrict__ order) {
+  __shared__ int tmp[kOrderThreads / 64];
+  constexpr int kPer = 12;                                  // nodes per thread and trip: neighbours, so that the scan keeps their order
   const int g = blockIdx.x;
   const int n0 = gptr[g], n1 = gptr[g + 1];
   const int base = new_gptr[g], lim = new_gptr[g + 1];
   int run = 0;
-  for (int v0 = n0; v0 < n1; v0 += kBlock * kPer) {
+  for (int v0 = n0; v0 < n1; v0 += kOrderThreads * kPer) {
     int s[kPer], mine = 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int v = v0 + (int)threadIdx.x * kPer + k;
-      s[k] = v < n1 ? slot[v] : -1;
+      s[k] = slot[min(v, n1 - 1)];
+      s[k] = v < n1 ? s[k] : -1;
       mine += s[k] >= 0 ? 1 : 0;
     }
     int tot;
-    int pos = base + run + block_exclusive_scan(mine, tmp, tot);
+    int pos = base + run + block_exclusive_scan<kOrderThreads / 64>(mine, tmp, tot);
 #pragma unroll
     for (int k = 0; k < kPer; ++k)
       if (s[k] >= 0) {
@@ -100,7 +107,7 @@ extern "C" int mlqem_tile_order_by_position(const int32_t* slot, const int32_t* 
   if (num_graphs == 0) return MLQEM_OK;
   if (!slot || !graph_ptr || !new_graph_ptr || !order) return MLQEM_ERR_BAD_ARG;
   if (num_graphs > INT32_MAX) return MLQEM_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)num_graphs), dim3(kBlock), 0, as_stream(stream), slot, graph_ptr, new_graph_ptr,
+  hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)num_graphs), dim3(kOrderThreads), 0, as_stream(stream), slot, graph_ptr, new_graph_ptr,
                      order);
   return launch_status();
 }
