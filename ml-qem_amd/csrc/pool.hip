@@ -29,6 +29,12 @@ struct PoolArgs {
   int rows;                  // rows per tile: kPoolRows or kPoolRowsSmall
 };
 
+// LDS traffic of ONE wave on its own region (asap.hip's wave_lds_sync): the LDS pipeline serves a wave's instructions in order
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void pool_partial_kernel(const PoolArgs a) {
   __shared__ float s_red[kBlock][2 * VEC];
@@ -41,7 +47,66 @@ __global__ __launch_bounds__(kBlock) void pool_partial_kernel(const PoolArgs a) 
   const int ch = cs * VEC;
   const int q_lanes = min(16, lanes_r);         // second-level width of the LDS tree
   const int slot_w = a.CV * VEC;
-  for (int g = graph_at(a.gptr, a.B, r0); g < a.B && (int64_t)a.gptr[g] < r1; ++g) {   // workgroup-uniform loop
+  const int g_first = graph_at(a.gptr, a.B, r0);
+  int g_end = g_first;
+  while (g_end < a.B && (int64_t)a.gptr[g_end] < r1) ++g_end;      // graphs [g_first, g_end) touch the tile (workgroup-uniform)
+  if (g_end - g_first > 4 && a.CV <= kWave) {
+    // A tile of MANY short segments (the filler graphs behind a size-stable batch, batches of small circuits): a WAVE per segment, the
+    // four waves side by side, each on its own quarter of the LDS with wave-level fences -- the workgroup-wide tree below pays three
+    // barriers a segment, one segment after the other (55 us for the tile that holds the 32 fillers of a 64-circuit batch; the
+    // whole pool takes 11 us without them).
+    const int lane = tid & (kWave - 1), wv = tid / kWave;
+    const int lanes_w = kWave / a.CV, cs_w = lane % a.CV, rl_w = lane / a.CV, ch_w = cs_w * VEC;
+    const bool worker_w = rl_w < lanes_w;
+    float (*red)[2 * VEC] = s_red + wv * kWave;
+    for (int g = g_first + wv; g < g_end; g += kBlock / kWave) {
+      const int64_t s0 = max(r0, (int64_t)a.gptr[g]), s1 = min(r1, (int64_t)a.gptr[g + 1]);
+      if (s1 <= s0) continue;                   // an empty graph (wave-uniform)
+      float acc0[VEC], acc1[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc0[v] = acc1[v] = 0.f;
+      if (worker_w)
+        for (int64_t r = s0 + rl_w; r < s1; r += (int64_t)lanes_w * kPoolUnroll) {
+          float xv[kPoolUnroll][VEC], w[kPoolUnroll];
+#pragma unroll
+          for (int u = 0; u < kPoolUnroll; ++u) {
+            const int64_t ru = r + (int64_t)u * lanes_w;
+            const bool ok = ru < s1;
+            const int64_t rr = ok ? ru : s0;
+            float raw[VEC];
+            vload<VEC>(a.x + rr * a.ldx + ch_w, raw);
+            const float wr = a.wts ? a.wts[rr] : 1.f;
+            w[u] = ok ? wr : 0.f;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xv[u][v] = ok ? raw[v] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < kPoolUnroll; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              acc0[v] += xv[u][v];
+              acc1[v] = fmaf(w[u], xv[u][v], acc1[v]);
+            }
+        }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { red[lane][v] = acc0[v]; red[lane][VEC + v] = acc1[v]; }
+      wave_lds_fence();
+      if (worker_w && rl_w == 0) {              // the row lanes in order
+        float t[2 * VEC];
+#pragma unroll
+        for (int v = 0; v < 2 * VEC; ++v) t[v] = 0.f;
+        for (int k = 0; k < lanes_w; ++k)
+#pragma unroll
+          for (int v = 0; v < 2 * VEC; ++v) t[v] += red[k * a.CV + cs_w][v];
+        float* dst = a.partial + ((tile + g) * 2) * slot_w + ch_w;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { dst[v] = t[v]; dst[slot_w + v] = t[VEC + v]; }
+      }
+      wave_lds_fence();                         // the region is reused by the wave's next segment
+    }
+    return;
+  }
+  for (int g = g_first; g < g_end; ++g) {   // workgroup-uniform loop
     const int64_t s0 = max(r0, (int64_t)a.gptr[g]), s1 = min(r1, (int64_t)a.gptr[g + 1]);
     if (s1 <= s0) continue;                     // an empty graph
     float acc0[VEC], acc1[VEC];
