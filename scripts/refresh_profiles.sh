@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every measurement artefact of the round on ONE GPU box (run through gpurun from the repo root, ~12 minutes):
 #   scripts/make_profiles.sh                bench line, kernel stats (single stream / three streams), kernel roofline table
-#   Family B train step, 100-qubit / 4-qubit rocprofv3 --kernel-trace --stats summaries (top 60 kernels) + one step's timeline
+#   Family B train step, 100-qubit / 4-qubit rocprofv3 --kernel-trace --stats summaries (top 60 kernels) + one step's timeline (eager and captured)
 #   scripts/cfg5_scale.py                   one rank's shard of the mixed 1 M-circuit corpus
 # Everything lands in gpurun_out/; copy into profiles/rNN_* afterwards (scripts/copy_profiles.sh NN).
 set -u
@@ -33,5 +33,10 @@ python3 $R/scripts/step_timeline.py /tmp/pfb adam_step_kernel 2 1 > "$OUT/family
 tail -1 "$OUT/family_b_100q_step_timeline.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfc -- python3 $R/scripts/profile_family_b.py 1024 30 > /tmp/pfc.log 2>&1 || { tail -5 /tmp/pfc.log; exit 1; }
 top60 /tmp/pfc /tmp/pfc.log "$OUT/family_b_kernel_stats.csv" "python3 scripts/profile_family_b.py 1024 30"
+# the CAPTURED 100-qubit step (what bench.py's cfg4 leg times): one replay's timeline
+bash $R/scripts/profile_family_b_captured.sh 64 12 > "$OUT/family_b_captured.log" 2>&1 || { tail -5 "$OUT/family_b_captured.log"; exit 1; }
+python3 $R/scripts/step_timeline.py /tmp/pfc2 adam_step_kernel 4 1 > "$OUT/family_b_100q_captured_timeline.txt"
+tail -1 "$OUT/family_b_100q_captured_timeline.txt"
+cd /tmp
 timeout -k 10 400 python3 $R/scripts/cfg5_scale.py > "$OUT/cfg5_scale.log" 2>&1 || { tail -5 "$OUT/cfg5_scale.log"; exit 1; }
 tail -3 "$OUT/cfg5_scale.log"
