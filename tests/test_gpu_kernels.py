@@ -181,6 +181,35 @@ def test_wide_projection_through_lds_writes_whole_rows(n, i, o):
     assert (y3.cpu().double() - (want - b.cpu().double())).abs().max().item() < 1e-5 * scale
 
 
+@pytest.mark.parametrize("n,i,o", [(5003, 128, 45), (70001, 128, 45), (4100, 96, 33), (999, 100, 48), (17, 81, 40), (8192, 112, 36)])
+def test_linear_three_output_tiles_with_prefetched_rows(n, i, o):
+    """33..48 outputs from 81..128 inputs on padded rows (the pooled rows' projection and its data gradient, gnn.py:85-92) take the
+    three-tile form of linear_mfma_v4_kernel, which loads the NEXT tile's operand rows -- unconditionally, from clamped places -- before
+    this tile's MFMAs.  Both orientations against fp64 within 1e-5 of the output scale: row counts that are no multiple of 16 (the
+    prefetch past the last tile must read nothing it uses), a row map, NaN in the operand's pad columns."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(3 * n + i + o)
+    x = torch.randn(n, i, generator=g)
+    w = (torch.randn(o, i, generator=g) / i ** 0.5).to(DEV)
+    b = torch.randn(o, generator=g).to(DEV)
+    xd = ops.padded_copy(x.to(DEV))
+    if xd.stride(0) > i:
+        torch.as_strided(xd, (n, xd.stride(0)), (xd.stride(0), 1))[:, i:] = float("nan")
+    want = x.double() @ w.cpu().double().t() + b.cpu().double()
+    scale = want.abs().max().item()
+    assert (ops.linear(xd, w, b).cpu().double() - want).abs().max().item() < 1e-5 * scale
+    rows = torch.randperm(n, generator=g).to(torch.int32).to(DEV)
+    y2 = ops.linear(ops.RowsOf(xd, rows), w, b)
+    assert (y2.cpu().double() - want[rows.cpu().long()]).abs().max().item() < 1e-5 * scale
+    # the data-gradient orientation: gx [n, i] = gy [n, o] W, o on the operand side (o = 33..48 inputs is NOT this form; i = 81..128
+    # inputs to 33..48 outputs is: W^T of a 45 -> 128 layer)
+    wt = (torch.randn(i, o, generator=g) / i ** 0.5).to(DEV)            # the weight of an o -> i layer
+    want_t = x.double() @ wt.cpu().double()
+    yt = ops.linear(xd, wt, None, transposed=True)
+    assert (yt.cpu().double() - want_t).abs().max().item() < 1e-5 * want_t.abs().max().item()
+
+
 @pytest.mark.parametrize("n,i,o", [(1, 22, 10), (1000, 22, 45), (777, 45, 30), (64, 35, 15), (5000, 10, 1), (333, 125, 125)])
 def test_linear_forward_backward(n, i, o):
     from blackwater.native import functional as F
