@@ -38,7 +38,7 @@ extern "C" {
 
 typedef void* mlqem_stream_t; /* hipStream_t */
 
-#define MLQEM_ABI_VERSION 41 /* bumped whenever a signature below changes; bindings compare it at load time */
+#define MLQEM_ABI_VERSION 42 /* bumped whenever a signature below changes; bindings compare it at load time */
 int mlqem_abi_version(void);
 const char* mlqem_error_string(int code);
 
@@ -315,7 +315,9 @@ int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t 
  * are counter-based, keyed by (seed + *seed_counter, row * 128 + column), and recomputed in the backward.  All entry points
  * take workspace = mlqem_layer_workspace_bytes() (16-byte aligned); partial sums per workgroup, fixed-order second stages.
  *   gemm      : Y = X W^T + b (transposed = 0, W [U,K]) or Y = X W (+ add) (transposed = 1, W [K,U]: the data gradient);
- *               X fp32 [N,K <= 192] (ldx floats, ldx % 4 == 0) or bf16 [N,128] (K <= 128); Y bf16 [N,128] or fp32 [N,ldy].
+ *               X fp32 [N,K <= 192] (ldx floats, ldx % 4 == 0) or bf16 [N,128] (K <= 128); Y bf16 [N,128] or fp32 [N,ldy];
+ *               relu / drop_p (ABI 42): Y = dropout(relu(.)) in the epilogue, mlqem_layer_gemm_f32's mask -- a block without
+ *               BatchNorm (MLP3's fc3, mlp.py:96-104) in one launch; its backward gates by Y > 0 (rowdot_bwd's gate_scale).
  *   colstats 0: batch statistics of y -> mean, biased var, invstd, scale = gamma invstd, shift = beta - mean scale (outputs
  *               are [128]; columns >= C come out 0), and, when running_mean / running_var [C] are given, BatchNorm1d's
  *               update of them in the same launch (running = (1 - momentum) running + momentum batch, variance unbiased,
@@ -329,8 +331,9 @@ int mlqem_mlp1_backward(const float* gout, int64_t ldg, const float* x, int64_t 
  *               the gradient at u (ABI 25). */
 size_t mlqem_layer_workspace_bytes(void);
 int mlqem_layer_gemm_bf16(const void* x, int x_is_bf16, int64_t ldx, const float* w, int transposed, const float* b,
-                          const void* add_bf16, void* y, int y_is_f32, int64_t ldy, int64_t N, int K, int U, void* workspace,
-                          size_t workspace_bytes, mlqem_stream_t stream);
+                          const void* add_bf16, void* y, int y_is_f32, int64_t ldy, int relu, float drop_p, uint64_t seed,
+                          const uint64_t* seed_counter, int64_t N, int K, int U, void* workspace, size_t workspace_bytes,
+                          mlqem_stream_t stream);
 int mlqem_layer_colstats_bf16(int mode, const void* y, const void* g, const float* g32, int64_t ldg32, const float* scale,
                               const float* shift, const float* mean, const float* invstd, const float* gamma, const float* beta,
                               float eps, int relu, float drop_p, uint64_t seed, const uint64_t* seed_counter, int64_t N, int C,

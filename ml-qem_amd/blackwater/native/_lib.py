@@ -78,7 +78,7 @@ SIGNATURES = {
     "mlqem_mlp1_forward": (_I, [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P, _S, _P]),
     "mlqem_mlp1_backward": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _S, _P]),
     "mlqem_layer_workspace_bytes": (_S, []),
-    "mlqem_layer_gemm_bf16": (_I, [_P, _I, _L, _P, _I, _P, _P, _P, _I, _L, _L, _I, _I, _P, _S, _P]),
+    "mlqem_layer_gemm_bf16": (_I, [_P, _I, _L, _P, _I, _P, _P, _P, _I, _L, _I, _F, _U, _P, _L, _I, _I, _P, _S, _P]),
     "mlqem_layer_colstats_bf16": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _F, _I, _F, _U, _P, _L, _I, _P, _P, _P, _P, _P,
                                        _P, _P, _F, _P, _P, _S, _P]),
     "mlqem_layer_pointwise_bf16": (_I, [_I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _U, _P, _P, _L, _I, _P]),
@@ -188,7 +188,7 @@ SIGNATURES = {
 _lib = None
 ERR_UNSUPPORTED = -2   # MLQEM_ERR_UNSUPPORTED: a shape this kernel does not serve
 ERR_WORKSPACE = -4   # MLQEM_ERR_WORKSPACE: a caller-provided buffer is too small (the encoder then says what it needs)
-ABI_VERSION = 41   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
+ABI_VERSION = 42   # MLQEM_ABI_VERSION of include/mlqem_hip.h; bumped whenever a signature changes
 
 
 def load() -> ctypes.CDLL:

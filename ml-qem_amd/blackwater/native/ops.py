@@ -755,9 +755,10 @@ def _seed_args(drop_p, seed):
     return float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, (_p(_seed_counter) if drop_p > 0 else None)
 
 
-def layer_gemm_bf16(x, w, b=None, *, transposed=False, add=None, out_f32=False):
+def layer_gemm_bf16(x, w, b=None, *, transposed=False, add=None, out_f32=False, relu=False, drop_p=0.0, seed=0):
     """Y = X W^T + b (W [U, K]) or, ``transposed``, Y = X W (+ add) (W [K, U]: the data gradient).  X: fp32 [N, K] (padded rows)
-    or a bf16 activation [N, 128]; returns a bf16 activation [N, 128] or, ``out_f32``, fp32 [N, U]."""
+    or a bf16 activation [N, 128]; returns a bf16 activation [N, 128] or, ``out_f32``, fp32 [N, U].  ``relu`` / ``drop_p``: the
+    result is dropout(relu(.)) -- a block without BatchNorm in one launch (its backward gates by result > 0), as layer_gemm_f32."""
     x_bf16 = x.dtype == torch.bfloat16
     n = x.shape[0]
     k, u = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
@@ -775,7 +776,8 @@ def layer_gemm_bf16(x, w, b=None, *, transposed=False, add=None, out_f32=False):
     y = torch.empty((n, u), dtype=torch.float32, device=w.device) if out_f32 else _act(n, w.device)
     ws, need = _layer_ws(w.device)
     code = _lib.load().mlqem_layer_gemm_bf16(_p(x), 1 if x_bf16 else 0, ldx, _p(w), 1 if transposed else 0, _p(b), _p(add), _p(y),
-                                             1 if out_f32 else 0, u, n, k, u, _p(ws), need, _stream())
+                                             1 if out_f32 else 0, u, 1 if relu else 0, *_seed_args(drop_p, seed), n, k, u, _p(ws), need,
+                                             _stream())
     _lib.check(code, "mlqem_layer_gemm_bf16")
     return y
 

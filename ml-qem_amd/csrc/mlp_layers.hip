@@ -57,6 +57,7 @@ struct LayerArgs {
   void* y; int y_f32; int64_t ldy;              // output: bf16 [N,128], or fp32 [N, ldy] (the first U columns)
   int64_t N; int K, U;                          // K input columns, U output units (<= 128)
   const void* image;
+  int relu; float drop_p; uint64_t seed; const uint64_t* seed_counter;   // epilogue of a block WITHOUT BatchNorm: y = drop(relu(.))
 };
 
 __host__ __device__ inline int layer_image_u32x4(int G2) { return 8 * G2 * kWave + kLW / 4; }
@@ -95,6 +96,9 @@ __global__ __launch_bounds__(kLayerThreads) void layer_fwd_kernel(const LayerArg
   const int64_t n_tiles = ceil_div(a.N, 16);
   const int64_t n_waves = (int64_t)gridDim.x * (kLayerThreads / kWave), wave = (int64_t)blockIdx.x * (kLayerThreads / kWave) + wid;
   const int kpad = (a.K + 3) / 4 * 4;
+  const uint64_t dseed = a.seed + (a.seed_counter ? *a.seed_counter * 0xD1B54A32D192ED03ull : 0ull);
+  const unsigned dthr = (unsigned)(a.drop_p * 65536.f);
+  const float dinv = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   // unconditional, clamped loads; fix-ups where the values are consumed (see mlp_head.hip)
   // fp32 rows are loaded as float4 (HIP's struct of floats), bf16 rows as 4 dwords: a 16-byte load of float memory through an
   // unsigned-int vector type came out of the compiler as ONE global_load_dword with the other three components undefined
@@ -171,6 +175,21 @@ __global__ __launch_bounds__(kLayerThreads) void layer_fwd_kernel(const LayerArg
           unpack8(addv[p], r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (a.drop_p > 0.f) {       // layer_fwd_f32_kernel's mask: one splitmix64 round per four units, keyed by (row, first unit)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint64_t z = dseed + ((uint64_t)(row * kLW + 32 * p + 8 * lq + 4 * h) + 1) * 0x9E3779B97F4A7C15ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z = z ^ (z >> 31);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * h + e] = (unsigned)((z >> (16 * e)) & 0xFFFFu) >= dthr ? v[4 * h + e] * dinv : 0.f;
+          }
         }
         if (a.y_f32) {
           float* dst = static_cast<float*>(a.y) + row * a.ldy;
@@ -1293,17 +1312,19 @@ extern "C" size_t mlqem_layer_workspace_bytes(void) {
 }
 
 extern "C" int mlqem_layer_gemm_bf16(const void* x, int x_is_bf16, int64_t ldx, const float* w, int transposed, const float* b,
-                                     const void* add_bf16, void* y, int y_is_f32, int64_t ldy, int64_t N, int K, int U,
-                                     void* workspace, size_t workspace_bytes, mlqem_stream_t stream) {
+                                     const void* add_bf16, void* y, int y_is_f32, int64_t ldy, int relu, float drop_p, uint64_t seed,
+                                     const uint64_t* seed_counter, int64_t N, int K, int U, void* workspace, size_t workspace_bytes,
+                                     mlqem_stream_t stream) {
   begin_launches();
-  if (N < 0 || K < 1 || U < 1 || !w) return MLQEM_ERR_BAD_ARG;
+  if (N < 0 || K < 1 || U < 1 || !w || drop_p < 0.f || drop_p >= 1.f) return MLQEM_ERR_BAD_ARG;
   if (U > kLW || K > (x_is_bf16 ? kLW : 192)) return MLQEM_ERR_UNSUPPORTED;
   if (!x_is_bf16 && (ldx < (K + 3) / 4 * 4 || ldx % 4)) return MLQEM_ERR_BAD_ARG;
   if (y_is_f32 && ldy < U) return MLQEM_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < mlqem_layer_workspace_bytes() || !aligned_to(workspace, 16)) return MLQEM_ERR_WORKSPACE;
   if (N == 0) return MLQEM_OK;
   if (!x || !y || !aligned_to(x, 16) || (!y_is_f32 && !aligned_to(y, 16)) || (add_bf16 && !aligned_to(add_bf16, 16))) return MLQEM_ERR_BAD_ARG;
-  LayerArgs a{x, ldx, x_is_bf16, w, b, transposed, static_cast<const unsigned short*>(add_bf16), y, y_is_f32, ldy, N, K, U, nullptr};
+  LayerArgs a{x, ldx, x_is_bf16, w, b, transposed, static_cast<const unsigned short*>(add_bf16), y, y_is_f32, ldy, N, K, U, nullptr,
+              relu, drop_p, seed, seed_counter};
   hipStream_t s = as_stream(stream);
   const int g2 = (K + 31) / 32;
   if (x_is_bf16) {
