@@ -157,14 +157,16 @@ int mlqem_batch_norm_train_bwd_f32(const float* dy, int64_t ldg, const float* x,
  *   p <- p - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)  (betas arrive as doubles: 1 - beta and the bias
  *   corrections are formed in double, as torch forms them, the update itself in fp32).  `lr` and `step` (a float, as torch keeps
  *   it) live on the device, so the launch can sit in a captured hipGraph and a scheduler can change the rate between
- *   replays; ticket as above.  Replaces torch's multi-tensor kernel, which runs a buffer of this path's size (1.8 k-180 k
+ *   replays; ticket as above; bump_counter (optional, ABI 42): a device counter the launch's last workgroup increments -- the
+ *   trainers' dropout step counter, so that a step needs no launch of its own for it.  Replaces torch's multi-tensor kernel, which runs a buffer of this path's size (1.8 k-180 k
  *   floats) on one workgroup.
  * ---------------------------------------------------------------------------------------------------- */
 size_t mlqem_mse_loss_workspace_bytes(void);
 int mlqem_mse_loss_grad_f32(const float* out, int64_t ldo, const float* y, int64_t ldy, float* g, int64_t ldg, int64_t N, int C,
                             int64_t g_rows, float* loss, void* workspace, size_t workspace_bytes, unsigned* ticket, mlqem_stream_t stream);
 int mlqem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
-                        float* step, double beta1, double beta2, double eps, unsigned* ticket, mlqem_stream_t stream);
+                        float* step, double beta1, double beta2, double eps, unsigned* ticket, uint64_t* bump_counter,
+                        mlqem_stream_t stream);
 
 /* nn.Sequential(Linear(I, H), [Dropout(p)], Linear(H, O)) as ONE launch per direction: y = dropout(x W1^T + b1) W2^T + b2.
  * Replaces `self.obs_seq(observable)` and `self.body_seq(merged)` of the graph models (01_ngem.ipynb cell [9]; docs/tutorials/

@@ -64,7 +64,7 @@ SIGNATURES = {
     "mlqem_seq2_backward_workspace_bytes": (_S, [_L, _I, _I, _I]),
     "mlqem_seq2_backward_f32": (_I, [_P, _L, _P, _L, _L, _I, _P, _I, _P, _I, _P, _P, _F, _P, _L, _P, _P, _P, _P, _P, _S, _P, _P]),
     "mlqem_mse_loss_grad_f32": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _L, _P, _P, _S, _P, _P]),
-    "mlqem_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _P, _P]),
+    "mlqem_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _P, _P, _P]),
     "mlqem_relu_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _F, _P, _L, _L, _I, _P]),
     "mlqem_relu_dropout_f32": (_I, [_P, _L, _F, _U, _P, _P, _L, _P, _L, _P, _L, _L, _I, _P]),
     "mlqem_linear_f32": (_I, [_P, _L, _P, _I, _P, _P, _P, _L, _L, _I, _I, _I, _I, _F, _U, _I, _I, _P, _L, _F, _P, _P]),

@@ -361,18 +361,21 @@ def mse_loss_grad(out, target, want_grad=True, rows=None):
     return loss, g
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, bump=None):
     """One Adam update of the flat fp32 buffer ``param`` in place (mlqem_adam_step_f32); ``step`` (0-dim fp32) and ``lr`` (0-dim
-    fp32) live on the device: ``step`` is incremented by the launch."""
+    fp32) live on the device: ``step`` is incremented by the launch, and so is ``bump`` (a one-element int64 device tensor: the
+    trainers' dropout step counter) when given."""
     for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         if not t.is_cuda:
             raise _lib.NativeLibraryError(f"adam_step: {name} must live on the GPU; there is no CPU path")
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != param.numel():
             raise ValueError(f"adam_step: {name} must be contiguous fp32 of the parameters' size")
+    if bump is not None and not (bump.is_cuda and bump.dtype == torch.int64 and bump.numel() == 1):
+        raise ValueError("adam_step: bump must be a one-element int64 device tensor")
     if step.dtype != torch.float32 or lr.dtype != torch.float32 or step.numel() != 1 or lr.numel() != 1 or not (step.is_cuda and lr.is_cuda):
         raise ValueError("adam_step: step and lr must be one-element fp32 device tensors")
     code = _lib.load().mlqem_adam_step_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(lr), _p(step), float(beta1),
-                                           float(beta2), float(eps), _p(_ticket(param.device)), _stream())
+                                           float(beta2), float(eps), _p(_ticket(param.device)), _p(bump), _stream())
     _lib.check(code, "mlqem_adam_step_f32")
 
 

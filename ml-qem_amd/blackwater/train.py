@@ -99,7 +99,8 @@ class FlatAdam(torch.optim.Optimizer):
         st = self.state[p]
         if p.grad is None:
             return None
-        ops.adam_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], group["betas"][0], group["betas"][1], group["eps"])
+        ops.adam_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"], group["betas"][0], group["betas"][1], group["eps"],
+                      bump=getattr(self, "bump_counter", None))
         return None
 
 
@@ -215,6 +216,20 @@ class Trainer:
             ev.record()
             self._inflight.append(ev)
         return loss
+
+    def _step_counter(self, dev) -> torch.Tensor:
+        """The device-resident step counter the dropout keys are derived from.  Every step sees the next value.  With FlatAdam the
+        optimizer's launch increments it when the step is done (``mlqem_adam_step_f32`` ``bump_counter``: no launch of its own, which
+        is 1.5-2.5 % of a launch-bound step); otherwise ``_tick`` does, before the step.  Either way the steps see 1, 2, 3, ..."""
+        self._bumped_by_optimizer = isinstance(self.optimizer, FlatAdam)
+        counter = torch.full((1,), 1 if self._bumped_by_optimizer else 0, dtype=torch.int64, device=dev)
+        if self._bumped_by_optimizer:
+            self.optimizer.bump_counter = counter
+        return counter
+
+    def _tick(self):
+        if not self._bumped_by_optimizer:
+            self.counter.add_(1)
 
     def _forward_backward(self, batch) -> torch.Tensor:
         """The local half of a step: forward, loss, backward, gradients filed into the flat buffer.  Returns the loss."""
@@ -383,7 +398,7 @@ class RowsTrainer(Trainer):
 
         self.graphs = graphs
         self.fused_mlp1_step = True        # MLP1: image -> forward -> backward -> second stage -> Adam, nothing of autograd (False: the autograd path; tests compare the two)
-        self.counter = torch.zeros(1, dtype=torch.int64, device=self.flat_param.device)
+        self.counter = self._step_counter(self.flat_param.device)
         ops.set_seed_counter(self.counter)
         model.static_dropout_key = True
         self._entries = {}
@@ -399,7 +414,7 @@ class RowsTrainer(Trainer):
     def _step_on(self, batch):
         if self._mlp1_fused(batch):
             return self._step_mlp1(batch)
-        self.counter.add_(1)
+        self._tick()
         loss = self._forward_backward(batch)
         if self.distributed:
             self.all_reduce_gradients()
@@ -622,7 +637,7 @@ class BucketedTrainer(Trainer):
 
         self.arena, self.graphs, self.nq, self.eq = arena, graphs, int(node_quantum), int(edge_quantum)
         dev = self.flat_param.device
-        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.counter = self._step_counter(dev)
         ops.set_seed_counter(self.counter)
         model.static_dropout_key = True          # seeds = key(seed, rank) + device counter instead of a host call counter
         self._entries = {}
@@ -695,7 +710,7 @@ class BucketedTrainer(Trainer):
         return loss
 
     def _local_half(self, packed, b, n_pad, e_pad, sizes, num_real, cap=None, plan=None):
-        self.counter.add_(1)
+        self._tick()
         batch = self.arena.assemble(packed, b, n_pad, e_pad, None if plan else sizes, None, num_real, coarse_capacity=cap, pool_plan=plan)
         return self._forward_backward(batch)
 

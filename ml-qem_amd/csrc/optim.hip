@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void mse_loss_grad_kernel(const float* __re
 __global__ __launch_bounds__(kBlock) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, int64_t n, const float* __restrict__ lr_ptr,
                                                            float* __restrict__ step_ptr, double beta1_d, double beta2_d, float eps,
-                                                           unsigned* __restrict__ ticket) {
+                                                           unsigned* __restrict__ ticket, unsigned long long* __restrict__ bump) {
   const float s = *step_ptr + 1.0f;
   const float lr = *lr_ptr;
   // torch.optim.Adam: bias corrections in double from the double betas (fused_adam_utils.cuh), the update in fp32
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void adam_step_kernel(float* __restrict__ p
   if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
     *step_ptr = s;
     *ticket = 0u;
+    if (bump) *bump += 1ull;                           // the caller's step counter (dropout keys): one torch launch a step less
   }
 }
 
@@ -132,12 +133,13 @@ extern "C" int mlqem_mse_loss_grad_f32(const float* out, int64_t ldo, const floa
 }
 
 extern "C" int mlqem_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
-                                   float* step, double beta1, double beta2, double eps, unsigned* ticket, mlqem_stream_t stream) {
+                                   float* step, double beta1, double beta2, double eps, unsigned* ticket, uint64_t* bump_counter,
+                                   mlqem_stream_t stream) {
   begin_launches();
   if (n < 0 || !lr || !step || !ticket || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return MLQEM_ERR_BAD_ARG;
   if (!aligned_to(param, 16) || !aligned_to(grad, 16) || !aligned_to(exp_avg, 16) || !aligned_to(exp_avg_sq, 16)) return MLQEM_ERR_BAD_ARG;
   const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(n, 4 * kBlock));
   hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n, lr, step,
-                     beta1, beta2, (float)eps, ticket);
+                     beta1, beta2, (float)eps, ticket, reinterpret_cast<unsigned long long*>(bump_counter));
   return launch_status();
 }
