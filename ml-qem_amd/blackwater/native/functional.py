@@ -1027,13 +1027,17 @@ def asap_pool(x, mod, struct):
 _side_streams = {}
 
 
-def _branch_streams(device):
+_BRANCH_STREAMS_MIN_NODES = int(os.environ.get("MLQEM_BRANCH_STREAMS_MIN_NODES", "200000"))
+
+
+def _branch_streams(device, num_nodes=None):
     """Two side streams per device for the Cheb and SAGE branches (created once).  ``MLQEM_SINGLE_STREAM=1`` keeps all
     three branches on the caller's stream: kernels then run one after the other, which is what a per-kernel profile
-    needs (durations of overlapping kernels stretch each other; scripts/make_profiles.sh uses it for attribution)."""
-    import os
-
-    if os.environ.get("MLQEM_SINGLE_STREAM", "0") == "1":
+    needs (durations of overlapping kernels stretch each other; scripts/make_profiles.sh uses it for attribution).
+    A SMALL batch stays on one stream too: its kernels are launch latency, and the forks and joins of a three-stream graph cost
+    more than the branches' overlap returns (32 four-qubit circuits, captured: 0.245-0.279 ms on three streams, 0.199 on one;
+    2.4 M nodes: 1.48 against 1.75 ms the other way round; 11.3 M nodes: 5.86-6.0 against 6.03-6.13)."""
+    if os.environ.get("MLQEM_SINGLE_STREAM", "0") == "1" or (num_nodes is not None and num_nodes < _BRANCH_STREAMS_MIN_NODES):
         cur = torch.cuda.current_stream(device)
         return (cur, cur)
     key = torch.device(device).index
@@ -1084,7 +1088,7 @@ class _FamilyAGraph(Function):
         # The three branches are independent until the concatenation: each runs on its own HIP stream, so the tail of one
         # branch's kernels (hub-row waves keep a launch's last workgroups alive) is filled by the others' workgroups.
         main = torch.cuda.current_stream(x.device)
-        side = ctx.side = _branch_streams(x.device)
+        side = ctx.side = _branch_streams(x.device, n)
         # everything the branches share must exist before they fork: the structure builds its side tables and derived
         # scalars on first use, and a table built by one branch's stream would be read by another's without an edge
         _ = (struct.in_ell, struct.out_ell, struct.gcn_dinv, struct.derived("gcn_dself"), struct.derived("sage_dself"),
