@@ -886,11 +886,20 @@ __global__ __launch_bounds__(kBlock) void coarsen_clists_kernel(const int32_t* _
     if (q >= 0) clist[base + n++] = q;
   }
   const bool heavy = has && ee - eb > kRowsLight;
-  if (has && !heavy)
+  // PARALLEL EDGES are walked once (here and in the two passes below: the coarsened graph is a set of edges, and the lists are sorted by
+  // the structure's build, so a repeated neighbour is the one before it).  A hundred parallel edges between two consecutive barriers
+  // of a 100-qubit circuit otherwise make |C| = 101, |R| = 10 201 and 1 020 201 candidates for ONE cluster, walked by one wave: 2 ms
+  // in either list pass whenever the scores keep such a barrier (scripts/coarse_degree_probe.py).
+  if (has && !heavy) {
+    int prev = -1;
     for (int e = eb; e < ee; ++e) {
-      const int q = slot[out_dst[e]];
+      const int d = out_dst[e];
+      if (d == prev) continue;
+      prev = d;
+      const int q = slot[d];
       if (q >= 0) clist[base + n++] = q;
     }
+  }
   unsigned long long todo = __ballot(heavy);
   while (todo) {                                       // a hub's out-list: the whole wave, kept entries compacted by ballot
     const int owner = __ffsll((long long)todo) - 1;
@@ -900,7 +909,9 @@ __global__ __launch_bounds__(kBlock) void coarsen_clists_kernel(const int32_t* _
     int on = __shfl(n, owner);
     for (int i0 = b; i0 < e; i0 += 64) {
       const int i = i0 + lane;
-      const int q = i < e ? slot[out_dst[i]] : -1;
+      const int d = i < e ? out_dst[i] : -1;
+      const bool again = i < e && i > b && out_dst[i - 1] == d;
+      const int q = (i < e && !again) ? slot[d] : -1;
       const unsigned long long keep = __ballot(q >= 0);
       if (q >= 0) clist[ob + on + __popcll(keep & ((1ull << lane) - 1ull))] = q;
       on += __popcll(keep);
@@ -936,8 +947,15 @@ __global__ __launch_bounds__(kBlock) void coarsen_rlists_kernel(const int32_t* _
     if (fits) n = append((int)u, base);
   }
   const bool heavy = has && fits && ee - eb > kRowsLight;
-  if (has && fits && !heavy)
-    for (int e = eb; e < ee; ++e) n += append(idx[e], base + n);
+  if (has && fits && !heavy) {
+    int prev = -1;
+    for (int e = eb; e < ee; ++e) {
+      const int v = idx[e];
+      if (v == prev) continue;                         // a parallel edge
+      prev = v;
+      n += append(v, base + n);
+    }
+  }
   unsigned long long todo = __ballot(heavy);
   while (todo) {                                       // a hub: a lane per neighbour, places by a wave scan of the lists' lengths
     const int owner = __ffsll((long long)todo) - 1;
@@ -947,7 +965,8 @@ __global__ __launch_bounds__(kBlock) void coarsen_rlists_kernel(const int32_t* _
     int on = __shfl(n, owner);
     for (int i0 = b; i0 < e; i0 += 64) {
       const int i = i0 + lane;
-      const int v = i < e ? idx[i] : -1;
+      int v = i < e ? idx[i] : -1;
+      if (i < e && i > b && idx[i - 1] == v) v = -1;    // a parallel edge
       const int m = v >= 0 ? ccnt[v] : 0;
       const int ex = wave_excl_scan(m, lane);
       if (v >= 0) append(v, ob + on + ex);
@@ -1015,8 +1034,10 @@ __global__ __launch_bounds__(kBlock) void coarsen_gather_kernel(const ListsArgs 
   int64_t no = 0, ni = 0;
   const bool wide = has && ie - ib > kRowsLight;          // many members (the cluster of a hub): its wave walks them together
   if (has && !wide)
-    for (int i = ib - 1; i < ie; ++i) {                   // index ib - 1 stands for c itself
+    for (int i = ib - 1, prev = -1; i < ie; ++i) {        // index ib - 1 stands for c itself
       const int u = i < ib ? c : a.in_src[i];
+      if (i >= ib && u == prev) continue;                 // a parallel edge: the member is in the cluster once
+      prev = i < ib ? -1 : u;
       const RInfo r = rinfo[u];
       gather_lists(a.r_o, r.off_o, r.cnt_o, true, a.tmp_o, bo + no, a.tmp_cap, lane);
       gather_lists(a.r_i, r.off_i, r.cnt_i, true, a.tmp_i, bi + ni, a.tmp_cap, lane);
@@ -1031,8 +1052,8 @@ __global__ __launch_bounds__(kBlock) void coarsen_gather_kernel(const ListsArgs 
     int64_t so = 0, si = 0;
     for (int i0 = ob - 1; i0 < oe; i0 += 64) {
       const int i = i0 + lane;
-      const bool mine = i < oe;
-      const int u = mine ? (i < ob ? oc : a.in_src[i]) : 0;
+      const int u = i < oe ? (i < ob ? oc : a.in_src[i]) : 0;
+      const bool mine = i < oe && !(i > ob && a.in_src[i - 1] == u);      // (not a parallel edge)
       RInfo r{0u, 0u, 0u, 0u};
       if (mine) r = rinfo[u];
       // places of this lane's two lists: wave scans of the lengths

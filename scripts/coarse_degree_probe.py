@@ -55,6 +55,22 @@ for name, circs in fams.items():
         lib.mlqem_asap_coarsen_lists_caps(ops._p(s.in_ptr), ops._p(s.in_src), ops._p(s.out_ptr), ops._p(s.out_dst), ops._p(s1.graph_ptr), ops._p(perm.to(torch.int32)),
                                           s.num_nodes, k, s.num_graphs, ops._p(totals), ops._p(ws), need, ops._stream())
         tot = totals.tolist()
+        # what the list passes walk: |C(v)| = [v kept] + kept out-neighbours of v; |R(u)| = sum of |C(v)| over v in N+[u] and u itself;
+        # candidates of cluster c = sum of |R(u)| over u in N-[c] and c itself
+        n0 = s.num_nodes
+        kept = torch.zeros(n0, dtype=torch.int64, device=dev); kept[perm.long()] = 1
+        optr, iptr = s.out_ptr[:n0 + 1].long(), s.in_ptr[:n0 + 1].long()
+        rows_o = torch.repeat_interleave(torch.arange(n0, device=dev), optr[1:] - optr[:-1])
+        rows_i = torch.repeat_interleave(torch.arange(n0, device=dev), iptr[1:] - iptr[:-1])
+        odst, isrc = s.out_dst[:rows_o.numel()].long(), s.in_src[:rows_i.numel()].long()
+        csz = kept.clone().index_add_(0, rows_o, kept[odst])
+        rsz = csz.clone().index_add_(0, rows_o, csz[odst])
+        cand_all = rsz.clone().index_add_(0, rows_i, rsz[isrc])
+        cand = cand_all[perm.long()].float()
+        members = (iptr[1:] - iptr[:-1])[perm.long()] + 1
+        q = lambda t, f: float(torch.quantile(t.float()[:: max(1, t.numel() // 1000000)], f))
+        print(f"    |C| max {int(csz.max())}  |R| mean {float(rsz.float().mean()):.1f} p99 {q(rsz, 0.99):.0f} max {int(rsz.max())}   members max {int(members.max())}   candidates per cluster: "
+              f"sum {int(cand.sum())} mean {float(cand.mean()):.0f} p50 {q(cand, 0.5):.0f} p99 {q(cand, 0.99):.0f} max {int(cand.max())}  clusters > 64: {int((cand > 64).sum())} > 4096: {int((cand > 4096).sum())} > 65536: {int((cand > 65536).sum())}", flush=True)
         cap_ = getattr(s, 'coarse_capacity', None)
     d0 = (s.in_ptr[1:] - s.in_ptr[:-1]).cpu().numpy()
     print(f"{name:16s} circuits {len(arena):3d}  level 0: nodes {len(d0):7d} max in-degree {d0.max():4d}   level 1: rows {len(deg):7d} entries {deg.sum():9d} "
