@@ -440,20 +440,22 @@ def linear(x, w, b=None, *, transposed=False, relu=False, rowscale=None, out=Non
     i = x.shape[1]
     # ... unless the product is tiny (the observable MLP of Family A: 1024 rows x 401 -> 10): then the split -- four column
     # slices, four copies, four launches -- costs more than the scalar kernel's one launch (a thread per output, 5 us)
-    if (i > _MFMA_MAX_IN and not transposed and torch.is_tensor(x) and w.dim() == 2 and w.shape[1] == i
-            and x.shape[0] * w.shape[0] > _WIDE_SPLIT_MIN_OUTPUTS):
+    if (i > _MFMA_MAX_IN and torch.is_tensor(x) and w.dim() == 2 and w.shape[0 if transposed else 1] == i
+            and x.shape[0] * w.shape[1 if transposed else 0] > _WIDE_SPLIT_MIN_OUTPUTS):
         # The matrix-core kernels hold a row's inputs in registers (<= 128 columns); wider inputs (MLP rows of 169-170
         # encode_data_v2_ecr features, docs/tutorials/mlp.py:148-194) used to fall to a scalar kernel (1.3 ms for 262 k x 170 -> 125
         # against 0.15 ms here).  Split the k range: y = x[:, :128] W[:, :128]^T + b, then y += x[:, 128:] W[:, 128:]^T with the
-        # epilogue (row scale, ReLU, dropout, gate) on the last piece.
+        # epilogue (row scale, ReLU, dropout, gate) on the last piece.  The data-gradient orientation (w: [I, O]) splits the same way,
+        # over ROWS of w: the 192 padded head slots of a three-head TransformerConv's q | k | v | skip gradient (gnn.py:178-276: heads
+        # 5 / 3) ran the scalar kernel, 245 us a step of the mixed corpus.
         if out is None:
             if accumulate:
                 raise ValueError("linear: accumulate needs an existing out")
-            out = padded_empty(x.shape[0], w.shape[0], x.device)
+            out = padded_empty(x.shape[0], w.shape[1 if transposed else 0], x.device)
         for k0 in range(0, i, _MFMA_MAX_IN):
             k1 = min(k0 + _MFMA_MAX_IN, i)
             first, last = k0 == 0, k1 == i
-            linear(x[:, k0:k1], w[:, k0:k1].contiguous(), b if first else None, relu=relu and last,
+            linear(x[:, k0:k1], w[k0:k1] if transposed else w[:, k0:k1].contiguous(), b if first else None, transposed=transposed, relu=relu and last,
                    rowscale=rowscale if last else None, out=out, accumulate=accumulate or not first,
                    drop_p=drop_p if last else 0.0, seed=seed, rs_cols=rs_cols if last else -1, act_from=act_from if last else -1,
                    gate=gate if last else None, gate_scale=gate_scale)

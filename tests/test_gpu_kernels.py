@@ -210,6 +210,29 @@ def test_linear_three_output_tiles_with_prefetched_rows(n, i, o):
     assert (yt.cpu().double() - want_t).abs().max().item() < 1e-5 * want_t.abs().max().item()
 
 
+@pytest.mark.parametrize("n,i,o", [(5003, 192, 75), (4100, 300, 22), (3000, 180, 45), (2049, 130, 128)])
+def test_linear_data_gradient_splits_wide_operands(n, i, o):
+    """gx = gy W with more than 128 operand columns (the 192 padded head slots of a three-head TransformerConv's q | k | v | skip gradient,
+    gnn.py:178-276) is the sum of matrix-core products over 128-column slices of gy and row slices of W -- not the scalar kernel.  Against
+    fp64 within 1e-5 of the output scale, with a gate on the last piece and NaN in the operand's pad columns."""
+    from blackwater.native import ops
+
+    g = torch.Generator().manual_seed(n + 5 * i + o)
+    gy = torch.randn(n, i, generator=g)
+    w = (torch.randn(i, o, generator=g) / i ** 0.5).to(DEV)
+    gate = torch.randn(n, o, generator=g)
+    gyd = ops.padded_copy(gy.to(DEV))
+    if gyd.stride(0) > i:
+        torch.as_strided(gyd, (n, gyd.stride(0)), (gyd.stride(0), 1))[:, i:] = float("nan")
+    want = gy.double() @ w.cpu().double()
+    scale = want.abs().max().item()
+    got = ops.linear(gyd, w, None, transposed=True)
+    assert (got.cpu().double() - want).abs().max().item() < 1e-5 * scale
+    gated = ops.linear(gyd, w, None, transposed=True, gate=ops.padded_copy(gate.to(DEV)), gate_scale=1.25)
+    want_g = torch.where(gate.double() > 0, want * 1.25, torch.zeros_like(want))
+    assert (gated.cpu().double() - want_g).abs().max().item() < 1e-5 * scale
+
+
 @pytest.mark.parametrize("n,i,o", [(1, 22, 10), (1000, 22, 45), (777, 45, 30), (64, 35, 15), (5000, 10, 1), (333, 125, 125)])
 def test_linear_forward_backward(n, i, o):
     from blackwater.native import functional as F
