@@ -317,10 +317,13 @@ template <int H, bool TRAIN> __global__ __launch_bounds__(kBlock) void dense_att
         for (int h = 0; h < H; ++h) vv[h][i] = vr[h * CP];
       }
       const uint32_t nib = cell_bits(maskrow, cb, g);
-      uint32_t hash[4] = {0u, 0u, 0u, 0u};
+      constexpr int HP2 = (H + 1) / 2;                     // one 32-bit hash serves a PAIR of heads (attn_fwd.hpp)
+      uint32_t hash[HP2][4] = {};
       if (drop) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hash[i] = attn_pair_hash(seed, row, ids[i], 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int hp = 0; hp < HP2; ++hp) hash[hp][i] = attn_pair_hash(seed, row, ids[i], hp);
       }
       const int u0 = 16 * cb + 4 * g;
       f32x4 s[H];
@@ -348,7 +351,7 @@ template <int H, bool TRAIN> __global__ __launch_bounds__(kBlock) void dense_att
           float pr = (nib >> i & 1u) ? __builtin_amdgcn_exp2f(s[h][i] - mn) : 0.f;
           if (u0 + i == selfs) pr *= nself;
           den[h] += pr;
-          w[i] = (drop && attn_pair_dropped(hash[i], h, thr)) ? 0.f : (drop ? pr * keep : pr);
+          w[i] = (drop && attn_pair_dropped(hash[h >> 1][i], h, thr)) ? 0.f : (drop ? pr * keep : pr);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[h] = mfma4(vv[h][i], w[i], o[h]);
@@ -470,10 +473,13 @@ template <int H> __global__ __launch_bounds__(kBlock) void dense_attn_bwd_dst_ke
         for (int h = 0; h < H; ++h) kc[h][i] = kp[h * CP];
       }
       const uint32_t nib = cell_bits(maskrow, cb, g);
-      uint32_t hash[4] = {0u, 0u, 0u, 0u};
+      constexpr int HP2 = (H + 1) / 2;                     // one 32-bit hash serves a PAIR of heads (attn_fwd.hpp)
+      uint32_t hash[HP2][4] = {};
       if (drop) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hash[i] = attn_pair_hash(seed, row, ids[i], 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int hp = 0; hp < HP2; ++hp) hash[hp][i] = attn_pair_hash(seed, row, ids[i], hp);
       }
       const int u0 = 16 * cb + 4 * g;
 #pragma unroll
@@ -485,7 +491,7 @@ template <int H> __global__ __launch_bounds__(kBlock) void dense_attn_bwd_dst_ke
         for (int i = 0; i < 4; ++i) {
           float alpha = (nib >> i & 1u) ? __builtin_amdgcn_exp2f(s[i] - m2[h]) * inv_den[h] : 0.f;
           if (u0 + i == selfs) alpha *= nself;
-          const float dmask = drop ? (attn_pair_dropped(hash[i], h, thr) ? 0.f : keep) : 1.f;
+          const float dmask = drop ? (attn_pair_dropped(hash[h >> 1][i], h, thr) ? 0.f : keep) : 1.f;
           gs[i] = alpha * (gv[i] * dmask - delta[h]) * scale;
         }
 #pragma unroll
@@ -585,10 +591,13 @@ template <int H> __global__ __launch_bounds__(kBlock) void dense_attn_bwd_src_ke
         }
       }
       const uint32_t nib = cell_bits(maskrow, cb, g);
-      uint32_t hash[4] = {0u, 0u, 0u, 0u};
+      constexpr int HP2 = (H + 1) / 2;                     // one 32-bit hash serves a PAIR of heads (attn_fwd.hpp)
+      uint32_t hash[HP2][4] = {};
       if (drop) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hash[i] = attn_pair_hash(seed, ids[i], row, 0);      // (destination, source)
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int hp = 0; hp < HP2; ++hp) hash[hp][i] = attn_pair_hash(seed, ids[i], row, hp);      // (destination, source)
       }
       const int u0 = 16 * cb + 4 * g;
 #pragma unroll
@@ -600,7 +609,7 @@ template <int H> __global__ __launch_bounds__(kBlock) void dense_attn_bwd_src_ke
         for (int i = 0; i < 4; ++i) {
           float alpha = (nib >> i & 1u) ? __builtin_amdgcn_exp2f(s[i] - st[h][i].x * kLog2e) * st[h][i].y : 0.f;
           if (u0 + i == selfs) alpha *= nself;
-          const float dmask = drop ? (attn_pair_dropped(hash[i], h, thr) ? 0.f : keep) : 1.f;
+          const float dmask = drop ? (attn_pair_dropped(hash[h >> 1][i], h, thr) ? 0.f : keep) : 1.f;
           gs[i] = alpha * (gv[i] * dmask - st[h][i].z) * scale;
           al[i] = alpha * dmask;
         }
@@ -617,9 +626,10 @@ template <int H> __global__ __launch_bounds__(kBlock) void dense_attn_bwd_src_ke
       red_o[2 * h + 1][wave * kWave + lane] = gvv[h];
     }
     __syncthreads();
-    if (wave < 2 * H && valid) {                           // wave 2 h finishes g_k of head h, wave 2 h + 1 its g_v
-      const int h = wave >> 1, part = 1 + (wave & 1);
-      const f32x4 t = waves_sum(red_o[wave], lane);
+    for (int w = wave; w < 2 * H; w += kDbWaves) {         // sum 2 h finishes g_k of head h, sum 2 h + 1 its g_v (three heads: six sums, four waves)
+      if (!valid) break;
+      const int h = w >> 1, part = 1 + (w & 1);
+      const f32x4 t = waves_sum(red_o[w], lane);
       *reinterpret_cast<f4u*>(a.gqkvs + (int64_t)row * a.ldq + part * HP + h * CP + 4 * g) = f4u{t[0], t[1], t[2], t[3]};
     }
   }
@@ -661,7 +671,7 @@ extern "C" int mlqem_dense_plan_build(const int32_t* ptr, const int32_t* idx, co
   return launch_status();
 }
 
-extern "C" int mlqem_dense_attention_supported(int H, int C, int head_pitch) { return (H == 1 || H == 2) && C <= 16 && head_pitch == 16; }
+extern "C" int mlqem_dense_attention_supported(int H, int C, int head_pitch) { return H >= 1 && H <= 3 && C <= 16 && head_pitch == 16; }
 
 extern "C" int mlqem_dense_attention_train_f32(const float* qkvs, int64_t ld, const int32_t* in_ptr, const int32_t* in_src,
                                                const int32_t* loops, int64_t N, int64_t E, int H, int C, float drop_p, uint64_t seed,
@@ -682,7 +692,8 @@ extern "C" int mlqem_dense_attention_train_f32(const float* qkvs, int64_t ld, co
   if (parts & 1) launch_attn_train_q4(a, as_stream(stream));
   const dim3 grid((unsigned)dense_grid(max_blocks));
   if (parts & 2) {
-    if (H == 2) hipLaunchKernelGGL((dense_attn_fwd_kernel<2, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
+    if (H == 3) hipLaunchKernelGGL((dense_attn_fwd_kernel<3, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
+    else if (H == 2) hipLaunchKernelGGL((dense_attn_fwd_kernel<2, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
     else hipLaunchKernelGGL((dense_attn_fwd_kernel<1, true>), grid, dim3(kBlock), 0, as_stream(stream), a, p);
   }
   return launch_status();
@@ -717,12 +728,14 @@ extern "C" int mlqem_dense_attention_bwd_f32(const float* qkvs, int64_t ld, cons
   if (parts & 1) launch_attn_bwd_dst_q4(a, s);
   const dim3 gin((unsigned)dense_grid(in_max_blocks)), gout((unsigned)dense_grid(out_max_blocks));
   if (parts & 2) {
-    if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<2>, gin, dim3(kBlock), 0, s, a, pin);
+    if (H == 3) hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<3>, gin, dim3(kBlock), 0, s, a, pin);
+    else if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<2>, gin, dim3(kBlock), 0, s, a, pin);
     else hipLaunchKernelGGL(dense_attn_bwd_dst_kernel<1>, gin, dim3(kBlock), 0, s, a, pin);
   }
   if (parts & 4) launch_attn_bwd_src_rc_q4(a, s);
   if (parts & 8) {
-    if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_src_kernel<2>, gout, dim3(kBlock), 0, s, a, pout);
+    if (H == 3) hipLaunchKernelGGL(dense_attn_bwd_src_kernel<3>, gout, dim3(kBlock), 0, s, a, pout);
+    else if (H == 2) hipLaunchKernelGGL(dense_attn_bwd_src_kernel<2>, gout, dim3(kBlock), 0, s, a, pout);
     else hipLaunchKernelGGL(dense_attn_bwd_src_kernel<1>, gout, dim3(kBlock), 0, s, a, pout);
   }
   return launch_status();

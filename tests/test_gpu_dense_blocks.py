@@ -184,7 +184,7 @@ def _close(a, b, what, tol=2e-5):
     assert err < tol * scale, (what, err, scale)
 
 
-@pytest.mark.parametrize("heads,ch,drop_p,loops_p", [(2, 15, 0.1, 0.0), (2, 15, 0.0, 0.7), (1, 16, 0.25, 0.5), (2, 13, 0.1, 1.0)])
+@pytest.mark.parametrize("heads,ch,drop_p,loops_p", [(2, 15, 0.1, 0.0), (2, 15, 0.0, 0.7), (1, 16, 0.25, 0.5), (2, 13, 0.1, 1.0), (3, 15, 0.1, 0.3), (3, 16, 0.0, 0.0)])
 def test_attention_on_the_blocks_equals_the_per_edge_kernels(heads, ch, drop_p, loops_p):
     """Forward (out, attn_out, both statistics) and backward (the gradient of [query | key | value | skip]) of the edge softmax."""
     from blackwater.native import ops
