@@ -878,8 +878,9 @@ def configs_leg(dev):
     cfg5 = {"workload": "cfg5: %d circuits = 1/64 of one rank's shard of the 1 M-circuit mixed corpus (50 %% 4-qubit TFIM, 30 %% random 20-qubit "
                         "depth-40, 20 %% Pauli-twirled 100-qubit TFIM), device-resident" % int(copies.sum())}
     rs = np.random.RandomState(0)
-    for name, make, batch, steps, scalar in (("family_a_f32", lambda: ExpValCircuitGraphModelA(100, 22, 10), 1024, 10, True),
-                                             ("family_b_mlp3_head_bf16", lambda: ExpValCircuitGraphModel_3(22, 15, 4), 64, 12, False)):
+    # (eager steps on random draws of the mix: host-bound, so 30 timed steps after 4 -- ten after two swung 440-720 k box to box)
+    for name, make, batch, steps, scalar in (("family_a_f32", lambda: ExpValCircuitGraphModelA(100, 22, 10), 1024, 30, True),
+                                             ("family_b_mlp3_head_bf16", lambda: ExpValCircuitGraphModel_3(22, 15, 4), 64, 30, False)):
         arena, _ = replicated_arena(enc5, copies, dev, scalar_labels=scalar)
         g = len(arena)
         cfg5.setdefault("nodes", int(arena.num_nodes))
@@ -889,7 +890,7 @@ def configs_leg(dev):
             model.body_seq.mfma = "bf16"
         tr = Trainer(model, lr=1e-3)
         draw = lambda: rs.randint(0, g, size=batch)
-        sec, loss = _timed_steps(lambda: tr.step(arena.batch(draw())), 2, steps)
+        sec, loss = _timed_steps(lambda: tr.step(arena.batch(draw())), 4, steps)
         rec = {"circuits_per_step": batch, "circuits_per_s": round(batch / sec, 1), "ms_per_step": round(sec * 1e3, 3), "step_mode": "eager",
                "final_loss": round(float(loss.item()), 6)}
         del tr, model
