@@ -568,7 +568,7 @@ def family_b_leg(dev, steps=30):
     # ASAPooling levels, head, backward, Adam -- replays from ONE graph.
     # (the 1024-circuit step runs eagerly: its structural edge bound, 2.1e9, is beyond the 2^30 entries a batch may size its edge arrays
     # to, so its coarsening reads the sizes back -- a captured step may not)
-    for big_batch, graphs, big_steps in ((64, False, max(6, steps // 2)), (64, True, max(6, steps // 2)), (256, True, 6), (512, True, 4), (1024, False, 4)):
+    for big_batch, graphs, big_steps in ((64, False, max(6, steps // 2)), (64, True, max(6, steps // 2)), (256, True, 10), (512, True, 8), (1024, False, 6)):
         torch.manual_seed(0)
         torch.cuda.reset_peak_memory_stats()
         sampler = StratifiedBatches(big_arena.node_counts[:nb_graphs], big_arena.edge_counts[:nb_graphs], big_batch, seed=13)
