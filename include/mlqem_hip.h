@@ -854,7 +854,10 @@ int mlqem_dense_attention_bwd_f32(const float* qkvs, int64_t ld, const float* g,
                                   int64_t out_max_blocks, int parts, float* gqkvs, int64_t ldq, float* edge_al,
                                   mlqem_stream_t stream);
 
-/* ASAPooling's cluster sums over the same plans (csrc/dense_pool.hip; rows of at most 32 channels: mlqem_dense_pool_supported).
+/* ASAPooling's cluster sums over the same plans (csrc/dense_pool.hip; rows of at most 48 channels: mlqem_dense_pool_supported -- two or
+ * three channel tiles of 16; the scans and the backward entry points take D = 29..32 in rows of exactly 32 floats or D = 45..48 in rows of
+ * exactly 48, the second pooling of the heads-3/2 and of the heads-5/3 variants, gnn.py:70-276).  The dense attention entry points above
+ * take one to three heads.
  * mlqem_csr_softmax_aggregate_f32 with the rows of the plan's blocks on the matrix cores; stat (optional, [N, 2] floats, 8-byte
  * aligned) receives {maximum, 1 / denominator} of the block rows for the backward kernels below. */
 int mlqem_dense_pool_supported(int D);

@@ -2018,9 +2018,14 @@ def dense_softmax_aggregate(x, in_ptr, in_src, a_dst, c_src, negative_slope, pla
 
 
 def dense_pool_fits(*mats) -> bool:
-    """The pooling's block kernels take matrices of 29-32 channels whose rows are exactly 32 floats (the padded row layout)."""
-    return all(m.is_cuda and m.dtype == torch.float32 and 29 <= m.shape[1] <= 32 and (m.shape[0] <= 1 or m.stride(0) == 32) and m.stride(1) == 1
-               and m.data_ptr() % 16 == 0 for m in mats)
+    """The pooling's block kernels take matrices of 29-32 channels whose rows are exactly 32 floats, or of 45-48 channels in rows of 48 (the
+    padded row layout of either: two or three channel tiles of 16; 45 = the heads-5/3 variants' second pooling, gnn.py:178-276)."""
+    def ok(m):
+        c = m.shape[1]
+        ld = 32 if 29 <= c <= 32 else (48 if 45 <= c <= 48 else 0)
+        return (ld and m.is_cuda and m.dtype == torch.float32 and (m.shape[0] <= 1 or m.stride(0) == ld) and m.stride(1) == 1
+                and m.data_ptr() % 16 == 0)
+    return all(ok(m) for m in mats)
 
 
 def dense_leconv_fitness_bwd(gfit, fitness, in_ptr, out_ptr, out_dst, plan_out: DensePlan):

@@ -236,7 +236,7 @@ def test_a_structure_without_long_rows_has_no_blocks_and_the_same_results():
     assert torch.equal(got[0], ref[0]) and torch.equal(got[3], ref[3])
 
 
-@pytest.mark.parametrize("d,loops_p", [(30, 0.0), (30, 0.8), (16, 0.3), (7, 0.0), (32, 0.5)])
+@pytest.mark.parametrize("d,loops_p", [(30, 0.0), (30, 0.8), (16, 0.3), (7, 0.0), (32, 0.5), (45, 0.3), (48, 0.0), (40, 0.5)])
 def test_pooling_cluster_sums_on_the_blocks_equal_the_per_edge_kernels(d, loops_p):
     """ASAPooling's softmax-weighted cluster sum x' (the row itself is ALWAYS an entry there, whatever ``loops`` says)."""
     from blackwater.native import ops
@@ -256,7 +256,7 @@ def test_pooling_cluster_sums_on_the_blocks_equal_the_per_edge_kernels(d, loops_
     assert torch.isfinite(stat[flag]).all() and (stat[flag][:, 1] > 0).all()
 
 
-@pytest.mark.parametrize("d,loops_p,ties", [(30, 0.0, False), (30, 0.8, True), (32, 0.5, True), (29, 0.2, False)])
+@pytest.mark.parametrize("d,loops_p,ties", [(30, 0.0, False), (30, 0.8, True), (32, 0.5, True), (29, 0.2, False), (45, 0.3, True), (48, 0.0, False), (46, 0.6, True)])
 def test_pooling_walks_on_the_blocks_equal_the_per_edge_kernels(d, loops_p, ties):
     """ASAPooling's other walks over a coarsened graph: the segment max (the row itself included), the backward of the cluster sum
     (g_x, g_a, g_c, the tie counts of the maximum) and the backward of the maximum.  ``ties``: x drawn from five values, so that maxima
