@@ -59,13 +59,19 @@ struct PoolFuse {
 
 // graph of the first row of every tile of `rows` rows: one binary search per tile, outside the kernel that needs it (inside,
 // its ten dependent scalar loads sat in front of every later scalar or LDS wait of the workgroup)
+// (a 16-lane group per GRAPH files the tiles whose first row lies in it: two loads and a handful of stores -- a thread per tile searched
+// the boundaries, ten dependent loads each: 24 us on every branch's stream for the 66 k tiles of the headline batch)
 __global__ __launch_bounds__(kBlock) void tile_graph_kernel(const int32_t* __restrict__ gptr, int B, int rows, int64_t tiles,
                                                             int2* __restrict__ out, int4* __restrict__ info) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= tiles) return;
-  const int g = graph_at(gptr, B, t * rows);
-  out[t] = make_int2(g, gptr[g + 1]);       // with the boundary behind it: a tile inside one graph needs nothing else at its end
-  if (info) info[t] = make_int4(g, gptr[g], gptr[g + 1], 0);
+  const int64_t g = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int l = threadIdx.x & (kGroup - 1);
+  if (g >= B) return;
+  const int64_t beg = gptr[g], end = gptr[g + 1];
+  const int64_t t0 = (beg + rows - 1) / rows, t1 = min(tiles, (end + rows - 1) / rows);      // tiles t with beg <= t rows < end
+  for (int64_t t = t0 + l; t < t1; t += kGroup) {
+    out[t] = make_int2((int)g, (int)end);   // with the boundary behind it: a tile inside one graph needs nothing else at its end
+    if (info) info[t] = make_int4((int)g, (int)beg, (int)end, 0);
+  }
 }
 
 constexpr int kPoolMaskWords = 2 * 4 * 4;     // items per thread x waves x channels of a slice (the pooled instantiation: 2, 4, 4)
@@ -647,7 +653,7 @@ static int launch_aggregate(AggArgs a, hipStream_t stream, const PoolFuse* pool 
   if (pool) {     // the pooled form exists for the shape the models launch it with: ELL side table, 16-byte rows, an epilogue
     if (IS_MAX || !a.ell || vec != 4 || ipt != 2 || a.CV * 4 > kWave) return MLQEM_ERR_UNSUPPORTED;      // C <= 64: one wave holds a row of the tile
     if (rows_per_tile) *rows_per_tile = a.R;
-    hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)ceil_div((int64_t)grid.x, kBlock)), dim3(kBlock), 0, stream, pool->gptr, pool->B,
+    hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)ceil_div((int64_t)std::max(pool->B, 1) * kGroup, kBlock)), dim3(kBlock), 0, stream, pool->gptr, pool->B,
                        a.R, (int64_t)grid.x, const_cast<int2*>(pool->tile_graph), pool->mask ? pool->tile_info : nullptr);
     if constexpr (!IS_MAX) {
       constexpr int pool_waves = 7;      // (was the A/B switch MLQEM_AGG_POOL_WAVES: settled)
